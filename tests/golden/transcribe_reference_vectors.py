@@ -1,0 +1,283 @@
+#!/usr/bin/env python3
+"""Hand transcription of the golden vectors the reference's OWN tests hold for the
+rolling-window path.  This script is the transcription: it does not
+read /root/reference; every block cites the reference test file:line it was copied from.
+Go untyped constant expressions (e.g. `100*0.1 + 200*0.9`) are exact rationals in Go, so
+they are written with Fraction here and rounded to float64 once, as the Go compiler does.
+
+Run:  python3 tests/golden/transcribe_reference_vectors.py   -> reference_vectors.json
+"""
+import json
+import os
+from fractions import Fraction as F
+
+N = None  # nil
+
+
+def c(x):
+    """Go constant expression -> float64"""
+    return float(x)
+
+
+bows = {
+    # rolling/aggregation/core_test.go:25-28
+    "emptyBow": {"time": [], "value": [], "value_type": "float64"},
+    # core_test.go:29-36
+    "nilBow": {"time": [10, 11, 20], "value": [N, N, N], "value_type": "float64"},
+    # core_test.go:37-53
+    "sparseFloatBow": {
+        "time": [10, 11, 20, 40, 41, 50, 51, 61, 69],
+        "value": [10.0, N, N, N, 10.0, 10.0, 20.0, 10.0, 20.0],
+        "value_type": "float64",
+    },
+    # core_test.go:54-70
+    "sparseBoolBow": {
+        "time": [10, 11, 20, 40, 41, 50, 51, 61, 69],
+        "value": [True, N, N, N, False, True, False, True, False],
+        "value_type": "bool",
+    },
+}
+
+WIN = [10, 20, 30, 40, 50, 60]
+
+
+def red(reducer, name, bow, values, src, out_type="float64", factors=None):
+    return {
+        "reducer": reducer, "name": name, "bow": bow, "interval": 10, "offset": 0,
+        "factors": factors or [], "expect_time": [] if bow == "emptyBow" else (WIN if bow != "nilBow" else [10, 20]),
+        "expect_value": values, "expect_type": out_type, "src": src,
+    }
+
+
+factor = 0.1  # integral_test.go:86 (a float64 VARIABLE: products below are float64 ops)
+
+reducers = [
+    # sum_test.go:10-42 (+ sparse bool :44-61)
+    red("Sum", "empty", "emptyBow", [], "rolling/aggregation/sum_test.go:13-23"),
+    red("Sum", "sparse float", "sparseFloatBow", [10.0, 0.0, 0.0, 10.0, 30.0, 30.0], "sum_test.go:25-42"),
+    red("Sum", "sparse bool", "sparseBoolBow", [1.0, 0.0, 0.0, 0.0, 1.0, 1.0], "sum_test.go:44-61"),
+    # arithmeticmean_test.go
+    red("ArithmeticMean", "empty", "emptyBow", [], "arithmeticmean_test.go:13-23"),
+    red("ArithmeticMean", "sparse", "sparseFloatBow", [10.0, N, N, 10.0, 15.0, 15.0], "arithmeticmean_test.go:24-42"),
+    red("ArithmeticMean", "sparse bool", "sparseBoolBow", [1.0, N, N, 0.0, 0.5, 0.5], "arithmeticmean_test.go:44-61"),
+    # minmax_test.go
+    red("Min", "empty", "emptyBow", [], "minmax_test.go:13-23"),
+    red("Min", "sparse float", "sparseFloatBow", [10.0, N, N, 10.0, 10.0, 10.0], "minmax_test.go:25-42"),
+    red("Min", "sparse bool", "sparseBoolBow", [1.0, N, N, 0.0, 0.0, 0.0], "minmax_test.go:44-61"),
+    red("Max", "empty", "emptyBow", [], "minmax_test.go:87-97"),
+    red("Max", "sparse float", "sparseFloatBow", [10.0, N, N, 10.0, 20.0, 20.0], "minmax_test.go:99-116"),
+    red("Max", "sparse bool", "sparseBoolBow", [1.0, N, N, 0.0, 1.0, 1.0], "minmax_test.go:118-135"),
+    # count_test.go
+    red("Count", "empty", "emptyBow", [], "count_test.go:13-23", out_type="int64"),
+    red("Count", "sparse", "sparseFloatBow", [1, 0, 0, 1, 2, 2], "count_test.go:24-42", out_type="int64"),
+    # firstlast_test.go
+    red("First", "empty", "emptyBow", [], "firstlast_test.go:13-23"),
+    red("First", "sparse", "sparseFloatBow", [10.0, N, N, 10.0, 10.0, 10.0], "firstlast_test.go:25-42"),
+    red("First", "sparse bool", "sparseBoolBow", [True, N, N, False, True, True], "firstlast_test.go:44-61", out_type="bool"),
+    red("Last", "empty", "emptyBow", [], "firstlast_test.go:87-97"),
+    red("Last", "sparse float", "sparseFloatBow", [10.0, N, N, 10.0, 20.0, 20.0], "firstlast_test.go:99-116"),
+    red("Last", "sparse bool", "sparseBoolBow", [True, N, N, False, False, False], "firstlast_test.go:118-135", out_type="bool"),
+    # integral_test.go
+    red("IntegralStep", "empty", "emptyBow", [], "integral_test.go:13-24"),
+    red("IntegralStep", "sparse float", "sparseFloatBow",
+        [100.0, N, N, c(100 * F(9, 10)), c(100 * F(1, 10) + 200 * F(9, 10)), c(100 * F(8, 10) + 200 * F(1, 10))],
+        "integral_test.go:26-43"),
+    red("IntegralStep", "sparse bool", "sparseBoolBow", [10.0, N, N, 0.0, 1.0, 8.0], "integral_test.go:45-62"),
+    red("IntegralStep", "scaled sparse", "sparseFloatBow",
+        [factor * 100.0, N, N, factor * c(100 * F(9, 10)), factor * c(100 * F(1, 10) + 200 * F(9, 10)),
+         factor * c(100 * F(8, 10) + 200 * F(1, 10))],
+        "integral_test.go:85-128", factors=[0.1]),
+    red("IntegralTrapezoid", "empty", "emptyBow", [], "integral_test.go:133-143"),
+    red("IntegralTrapezoid", "sparse float", "sparseFloatBow", [N, N, N, 9 * 10.0, 15.0, 8 * 15.0], "integral_test.go:145-162"),
+    red("IntegralTrapezoid", "sparse bool", "sparseBoolBow", [N, N, N, 4.5, 0.5, 4.0], "integral_test.go:164-181"),
+    # weightedmean_test.go
+    red("WeightedAverageStep", "empty", "emptyBow", [], "weightedmean_test.go:12-23"),
+    red("WeightedAverageStep", "sparse float", "sparseFloatBow",
+        [10.0, N, N, c(10 * F(9, 10)), c(10 * F(1, 10) + 20 * F(9, 10)), c(10 * F(8, 10) + 20 * F(1, 10))],
+        "weightedmean_test.go:24-42"),
+    red("WeightedAverageStep", "float only nil", "nilBow", [N, N], "weightedmean_test.go:43-57"),
+    red("WeightedAverageStep", "sparse bool", "sparseBoolBow", [1.0, N, N, 0.0, 0.1, 0.8], "weightedmean_test.go:59-76"),
+    red("WeightedAverageLinear", "sparse float", "sparseFloatBow",
+        [N, N, N, c(10 * F(9, 10)), c(15 * F(1, 10)), c(15 * F(8, 10))], "weightedmean_test.go:113-131"),
+    red("WeightedAverageLinear", "sparse bool", "sparseBoolBow", [N, N, N, 0.45, 0.05, 0.4], "weightedmean_test.go:133-150"),
+]
+
+# rolling/rolling_test.go:20-68
+num_windows = [
+    {"name": "empty bow", "time": [], "interval": 1, "offset": 0, "W": 0, "src": "rolling_test.go:21-27"},
+    {"name": "one liner bow", "time": [0], "interval": 1, "offset": 0, "W": 1, "src": "rolling_test.go:29-37"},
+    {"name": "points in same window", "time": [0, 9], "interval": 10, "offset": 0, "W": 1, "src": "rolling_test.go:39-47"},
+    {"name": "excluded point goes in next window", "time": [0, 10], "interval": 10, "offset": 0, "W": 2, "src": "rolling_test.go:49-57"},
+    {"name": "offset puts first value in preceding window", "time": [0, 9], "interval": 10, "offset": 1, "W": 2, "src": "rolling_test.go:59-67"},
+]
+
+# rolling/rolling_test.go:111-297
+IT_TIME = [12, 15, 16, 25, 25, 29]
+IT_VAL = [1.2, 1.5, 1.6, 2.5, 3.5, 2.9]
+_w3 = [(0, 8, 13, 0, [12], [1.2]), (1, 13, 18, 1, [15, 16], [1.5, 1.6]), (2, 18, 23, 3, [], []),
+       (3, 23, 28, 3, [25, 25], [2.5, 3.5]), (4, 28, 33, 5, [29], [2.9])]
+_w0 = [(0, 10, 15, 0, [12], [1.2]), (1, 15, 20, 1, [15, 16], [1.5, 1.6]), (2, 20, 25, 3, [], []),
+       (3, 25, 30, 3, [25, 25, 29], [2.5, 3.5, 2.9])]
+iterate = [
+    {"name": "no option", "offset": 0, "inclusive": False, "windows": _w0, "src": "rolling_test.go:119-139"},
+    {"name": "with inclusive windows", "offset": 0, "inclusive": True, "windows": [
+        (0, 10, 15, 0, [12, 15], [1.2, 1.5]), (1, 15, 20, 1, [15, 16], [1.5, 1.6]), (2, 20, 25, 3, [25], [2.5]),
+        (3, 25, 30, 3, [25, 25, 29], [2.5, 3.5, 2.9])], "src": "rolling_test.go:141-161"},
+    {"name": "with offset falling before first point", "offset": 1, "inclusive": False, "windows": [
+        (0, 11, 16, 0, [12, 15], [1.2, 1.5]), (1, 16, 21, 2, [16], [1.6]), (2, 21, 26, 3, [25, 25], [2.5, 3.5]),
+        (3, 26, 31, 5, [29], [2.9])], "src": "rolling_test.go:163-183"},
+    {"name": "with offset falling at first point", "offset": 2, "inclusive": False, "windows": [
+        (0, 12, 17, 0, [12, 15, 16], [1.2, 1.5, 1.6]), (1, 17, 22, 3, [], []), (2, 22, 27, 3, [25, 25], [2.5, 3.5]),
+        (3, 27, 32, 5, [29], [2.9])], "src": "rolling_test.go:185-205"},
+    {"name": "with offset falling after first point", "offset": 3, "inclusive": False, "windows": _w3, "src": "rolling_test.go:207-228"},
+    {"name": "offset > interval", "offset": 8, "inclusive": False, "windows": _w3, "src": "rolling_test.go:230-251"},
+    {"name": "offset == interval", "offset": 5, "inclusive": False, "windows": _w0, "src": "rolling_test.go:253-273"},
+    {"name": "offset < 0", "offset": -2, "inclusive": False, "windows": _w3, "src": "rolling_test.go:275-296"},
+]
+for it in iterate:
+    it.update({"time": IT_TIME, "value": IT_VAL, "interval": 5})
+    it["windows"] = [
+        {"index": w[0], "start": w[1], "end": w[2], "first_index": w[3], "time_rows": w[4], "value_rows": w[5]}
+        for w in it["windows"]
+    ]
+
+# rolling/rolling_test.go:70-109 and the other exact error strings tests assert
+ctor_errors = [
+    {"name": "interval == 0", "time": [0], "time_type": "int64", "interval": 0, "col": "time",
+     "error": "enforceIntervalAndOffset: strictly positive interval required", "src": "rolling_test.go:71-83"},
+    {"name": "non existing index", "time": [0], "time_type": "int64", "interval": 1, "col": "badcol",
+     "error": "no column 'badcol'", "src": "rolling_test.go:85-89"},
+    {"name": "invalid interval type", "time": [0.0], "time_type": "float64", "interval": 1, "col": "time",
+     "error": "impossible to create a new intervalRolling on column of type float64", "src": "rolling_test.go:91-98"},
+]
+
+# rolling/aggregation_test.go:12-123 — custom closures: timeAggr = w.FirstValue,
+# valueAggr = float64(w.Bow.NumRows()), doubleAggr = 2*float64(w.Bow.NumRows())
+DRV = {"time": [10, 15, 16, 25, 29], "value": [1.0, 1.5, 1.6, 2.5, 2.9], "interval": 10}
+driver = [
+    {"name": "keep columns", "aggs": [["time", "FirstValue", ""], ["value", "NumRows", ""]],
+     "expect_names": ["time", "value"], "expect_types": ["int64", "float64"], "expect": [[10, 20], [3.0, 2.0]],
+     "src": "aggregation_test.go:37-51"},
+    {"name": "swap columns", "aggs": [["value", "NumRows", ""], ["time", "FirstValue", ""]],
+     "expect_names": ["value", "time"], "expect_types": ["float64", "int64"], "expect": [[3.0, 2.0], [10, 20]],
+     "src": "aggregation_test.go:53-67"},
+    {"name": "rename columns", "aggs": [["time", "FirstValue", "a"], ["value", "NumRows", "b"]],
+     "expect_names": ["a", "b"], "expect_types": ["int64", "float64"], "expect": [[10, 20], [3.0, 2.0]],
+     "src": "aggregation_test.go:69-81"},
+    {"name": "less than in original", "aggs": [["time", "FirstValue", ""]],
+     "expect_names": ["time"], "expect_types": ["int64"], "expect": [[10, 20]], "src": "aggregation_test.go:83-94"},
+    {"name": "more than in original", "aggs": [["time", "FirstValue", ""], ["value", "NumRows2x", "double"], ["value", "NumRows", ""]],
+     "expect_names": ["time", "double", "value"], "expect_types": ["int64", "float64", "float64"],
+     "expect": [[10, 20], [6.0, 4.0], [3.0, 2.0]], "src": "aggregation_test.go:96-109"},
+    {"name": "missing interval colIndex", "aggs": [["value", "NumRows", ""]],
+     "error": "intervalRolling.indexedAggregations: must keep interval column 'time'", "src": "aggregation_test.go:111-115"},
+    {"name": "invalid colIndex", "aggs": [["time", "FirstValue", ""], ["-", "Nil", ""]],
+     "error": "intervalRolling.indexedAggregations: no column '-'", "src": "aggregation_test.go:117-122"},
+]
+for d in driver:
+    d.update(DRV)
+
+# rolling/aggregation/whole_test.go (next tier)
+whole = [
+    {"name": "empty bow", "time": [], "value": [], "aggs": ["WindowStart:time", "ArithmeticMean:value"],
+     "expect": [[], []], "src": "whole_test.go:12-28"},
+    {"name": "keep columns", "time": [10, 20, 30], "value": [1.0, 2.0, 3.0],
+     "aggs": ["WindowStart:time", "ArithmeticMean:value"], "expect": [[10], [2.0]], "src": "whole_test.go:30-53"},
+    {"name": "swap columns", "time": [10, 20, 30], "value": [1.0, 2.0, 3.0],
+     "aggs": ["ArithmeticMean:value", "WindowStart:time"], "expect": [[2.0], [10]], "src": "whole_test.go:55-78"},
+]
+
+# rolling/interpolation_test.go:64-100 (custom interps: time -> w.FirstValue, value -> 9.9)
+interpolate = [
+    {"name": "driver no options", "time": [10, 13], "value": [1.0, 1.3], "interval": 2, "offset": 0,
+     "interps": ["WindowStart", "Const:9.9"], "expect_time": [10, 12, 13], "expect_value": [1.0, 9.9, 1.3],
+     "src": "rolling/interpolation_test.go:64-81"},
+    {"name": "driver with offset", "time": [10, 13], "value": [1.0, 1.3], "interval": 2, "offset": 1,
+     "interps": ["WindowStart", "Const:9.9"], "expect_time": [9, 10, 11, 13], "expect_value": [9.9, 1.0, 9.9, 1.3],
+     "src": "rolling/interpolation_test.go:83-100"},
+    {"name": "driver empty bow", "time": [], "value": [], "interval": 2, "offset": 0,
+     "interps": ["WindowStart", "Const:9.9"], "expect_time": [], "expect_value": [],
+     "src": "rolling/interpolation_test.go:49-62"},
+    # rolling/interpolation/linear_test.go
+    {"name": "linear asc no options", "time": [10, 15, 17], "value": [10.0, 15.0, 17.0], "interval": 2, "offset": 0,
+     "interps": ["WindowStart", "Linear"], "expect_time": [10, 12, 14, 15, 16, 17],
+     "expect_value": [10.0, 12.0, 14.0, 15.0, 16.0, 17.0], "src": "linear_test.go:26-47"},
+    {"name": "linear asc with offset", "time": [10, 15, 17], "value": [10.0, 15.0, 17.0], "interval": 2, "offset": 3,
+     "interps": ["WindowStart", "Linear"], "expect_time": [9, 10, 11, 13, 15, 17],
+     "expect_value": [N, 10.0, 11.0, 13.0, 15.0, 17.0], "src": "linear_test.go:49-70"},
+    {"name": "linear desc no options", "time": [10, 15, 17], "value": [30.0, 25.0, 24.0], "interval": 2, "offset": 0,
+     "interps": ["WindowStart", "Linear"], "expect_time": [10, 12, 14, 15, 16, 17],
+     "expect_value": [30.0, 28.0, 26.0, 25.0, 24.5, 24.0], "src": "linear_test.go:82-103"},
+    {"name": "linear desc with offset", "time": [10, 15, 17], "value": [30.0, 25.0, 24.0], "interval": 2, "offset": 3,
+     "interps": ["WindowStart", "Linear"], "expect_time": [9, 10, 11, 13, 15, 17],
+     "expect_value": [N, 30.0, 29.0, 27.0, 25.0, 24.0], "src": "linear_test.go:105-126"},
+    # rolling/interpolation/stepprevious_test.go
+    {"name": "stepprevious no options", "time": [10, 13], "value": [1.0, 1.3], "interval": 2, "offset": 0,
+     "interps": ["WindowStart", "StepPrevious"], "expect_time": [10, 12, 13], "expect_value": [1.0, 1.0, 1.3],
+     "src": "stepprevious_test.go:19-46"},
+    {"name": "stepprevious with offset", "time": [10, 13], "value": [1.0, 1.3], "interval": 2, "offset": 1,
+     "interps": ["WindowStart", "StepPrevious"], "expect_time": [9, 10, 11, 13], "expect_value": [N, 1.0, 1.0, 1.3],
+     "src": "stepprevious_test.go:106-134"},
+    {"name": "stepprevious with nils", "time": [10, 11, 13, 15], "value": [1.0, N, N, 1.5], "interval": 2, "offset": 0,
+     "interps": ["WindowStart", "StepPrevious"], "expect_time": [10, 11, 12, 13, 14, 15],
+     "expect_value": [1.0, N, 1.0, N, 1.0, 1.5], "src": "stepprevious_test.go:136-165"},
+    # rolling/interpolation/none_test.go
+    {"name": "none no options", "time": [10, 13], "value": [1.0, 1.3], "interval": 2, "offset": 0,
+     "interps": ["WindowStart", "None"], "expect_time": [10, 12, 13], "expect_value": [1.0, N, 1.3],
+     "src": "none_test.go:25-43"},
+    {"name": "none with offset", "time": [10, 13], "value": [1.0, 1.3], "interval": 2, "offset": 1,
+     "interps": ["WindowStart", "None"], "expect_time": [9, 10, 11, 13], "expect_value": [N, 1.0, N, 1.3],
+     "src": "none_test.go:45-64"},
+]
+interp_errors = [
+    {"name": "invalid input type", "value_type": "float64", "interps": ["WindowStart", "CustomTypes:int64,bool"],
+     "error": "intervalRolling.validateInterpolation: accepts types [int64 bool], got type float64",
+     "src": "rolling/interpolation_test.go:21-35"},
+    {"name": "missing interval column", "value_type": "float64", "interps": ["-", "Const:9.9"],
+     "error": "must keep interval column 'time'", "src": "rolling/interpolation_test.go:37-47"},
+    {"name": "linear bool error", "value_type": "bool", "interps": ["WindowStart", "Linear"],
+     "error": "intervalRolling.validateInterpolation: accepts types [int64 float64], got type bool",
+     "src": "linear_test.go:146-162"},
+]
+
+# bowfill_test.go:11-26 newFreshBow: columns a..e, rows top to bottom
+FILL = {"a": [20, 13, 10, 0, N, -2], "b": [6, N, 4, N, N, 1], "c": [30, N, 10, 3, N, N],
+        "d": [400, N, 10, 4, N, N], "e": [-10, N, -5, 0, N, -8]}
+fill_linear = [
+    {"name": "int64 ref a fill b (desc)", "type": "int64", "ref": "a", "fill": "b", "expect": [6, 5, 4, 2, N, 1],
+     "src": "bowfill_test.go:156-174"},
+    {"name": "int64 ref a fill e (asc)", "type": "int64", "ref": "a", "fill": "e", "expect": [-10, -7, -5, 0, N, -8],
+     "src": "bowfill_test.go:176-195"},
+    {"name": "int64 ref not sorted", "type": "int64", "ref": "e", "fill": "b", "error": True, "src": "bowfill_test.go:197-203"},
+    {"name": "float64 ref a fill b (desc)", "type": "float64", "ref": "a", "fill": "b", "expect": [6.0, 4.6, 4.0, 1.5, N, 1.0],
+     "src": "bowfill_test.go:332-351"},
+    {"name": "float64 ref a fill e (asc)", "type": "float64", "ref": "a", "fill": "e", "expect": [-10.0, -6.5, -5.0, 0.0, N, -8.0],
+     "src": "bowfill_test.go:353-372"},
+    {"name": "float64 ref not sorted", "type": "float64", "ref": "e", "fill": "b", "error": True, "src": "bowfill_test.go:374-380"},
+]
+# bowfill_test.go:533-546: ref column itself null at the row => stays null
+fill_linear_meta = {"name": "with metadata: ref null at row", "ref_type": "int64", "ref": [1, N, 3],
+                    "fill_type": "float64", "fill": [1.0, N, 3.0], "expect": [1.0, N, 3.0], "src": "bowfill_test.go:533-546"}
+
+# rolling/transformation/factor_test.go:10-34 (Factor(0.1))
+factor_vectors = [
+    {"in": None, "out": None}, {"in": {"int64": 11}, "out": {"int64": 1}}, {"in": {"float64": 11.0}, "out": {"float64": 1.1}},
+]
+
+# rolling/rolling_test.go:230-296 offsets equivalence via enforceIntervalAndOffset (interval 5)
+offsets = [{"interval": 5, "offset": 8, "norm": 3}, {"interval": 5, "offset": -2, "norm": 3},
+           {"interval": 5, "offset": 5, "norm": 0}, {"interval": 5, "offset": 3, "norm": 3}]
+
+out = {
+    "_comment": "Golden vectors transcribed from the reference's own tests; see transcribe_reference_vectors.py",
+    "bows": bows, "reducers": reducers, "num_windows": num_windows, "iterate": iterate,
+    "ctor_errors": ctor_errors, "driver": driver, "whole": whole, "interpolate": interpolate,
+    "interp_errors": interp_errors, "fill_bow": FILL, "fill_linear": fill_linear,
+    "fill_linear_meta": fill_linear_meta, "factor": factor_vectors, "offsets": offsets,
+}
+
+if __name__ == "__main__":
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_vectors.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote", path)
