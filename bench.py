@@ -1,0 +1,153 @@
+#!/usr/bin/env python3
+"""bench.py — rows/s of rolling ArithmeticMean (+WindowStart key) on dense int64-ts / float64-value
+columns resident in HBM (BASELINE.json metric; SURVEY.md §8d cfg-dense: ts=i, value=u01, interval 10).
+
+One "step" = one full Rolling.Aggregate(WindowStart(time), ArithmeticMean(value)) over the rank's
+rows through the C ABI (bitmap init + bucketing/reduction kernel + status readback + null counts).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--rows R]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: rows are range-partitioned (rank r owns rows [r*R, (r+1)*R): weak scaling); the only
+exchange is the boundary-window carry (one fixed-size record per rank, all_gather over RCCL).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+BYTES_PER_ROW = 16.0   # algorithmic read bytes/row: 8 (ts) + 8 (value); null_count == 0 => no bitmap
+INTERVAL = 10
+# an interval that does not divide the shard size is used for N > 1 so that windows straddle shard boundaries
+INTERVAL_MULTI = 7
+
+
+def cpu_baseline(capi, rows_sample):
+    """The oracle (C restatement of the reference's algorithm, 1 thread — the reference is
+    single-goroutine on this path) timed on a bounded sample of the same workload."""
+    import numpy as np
+    from oracle import pyoracle as orc
+    ts_d, val_d = capi.gen_dense(0, rows_sample, seed=42)
+    ts = ts_d.values.to_numpy(np.int64, rows_sample)
+    val = val_d.values.to_numpy(np.float64, rows_sample)
+    del ts_d, val_d
+    cols = [orc.Column(ts, None, orc.INT64), orc.Column(val, None, orc.FLOAT64)]
+    t0 = time.perf_counter()
+    orc.aggregate(cols, 0, INTERVAL, [("WindowStart", 0), ("ArithmeticMean", 1)])
+    dt = time.perf_counter() - t0
+    return {"value": rows_sample / dt, "unit": "rows/s", "cores": 1, "kind": "port",
+            "sample": "%d rows of the same dense workload (ts=i, value=u01, interval %d), oracle/bow_oracle.c "
+                      "literal scan, %.1f s" % (rows_sample, INTERVAL, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=1_000_000_000, help="rows per GPU")
+    ap.add_argument("--cpu-sample", type=int, default=100_000_000)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    import torch
+    from bow_amd import capi
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the bowgpu path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    capi.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    rows = args.rows
+    aggs = [("WindowStart", 0), ("ArithmeticMean", 1)]
+    if world == 1:
+        ts, val = capi.gen_dense(0, rows, seed=42)
+        cols = [ts, val]
+        s0, W = capi.plan_windows(ts, INTERVAL, 0)
+        outs = [capi.OutColumn(W, capi.DEVICE) for _ in aggs]
+
+        def step():
+            return capi.rolling_aggregate(cols, 0, INTERVAL, aggs, outs=outs)[1]
+        interval = INTERVAL
+    else:
+        from bow_amd import sharded
+        runner = sharded.ShardedRolling(rank, world, rows, INTERVAL_MULTI, aggs, dist, torch)
+        step = runner.step
+        interval = INTERVAL_MULTI
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        capi.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms = []
+    for _ in range(args.steps):
+        info = step()
+        kernel_ms.append(info.kernel_ms)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        total_rows = rows * world * args.steps
+        value = total_rows / dt
+        k_ms = sum(kernel_ms) / len(kernel_ms)
+        achieved = rows * BYTES_PER_ROW / (k_ms * 1e-3) / 1e9
+        line = {
+            "metric": "rows/sec rolling-mean on 1B-row float64",
+            "value": value,
+            "unit": "rows/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "IntervalRolling(interval=%d)+Aggregate(WindowStart,ArithmeticMean), dense int64 ts=i + "
+                                   "float64 u01 values, %d rows/GPU resident in HBM, null_count=0" % (interval, rows),
+                       "rows_per_gpu": rows, "windows_per_gpu": rows // interval, "parallelism": "rows range-partitioned x%d" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "rolling_agg_kernel", "kernel_ms": k_ms,
+                         "algorithmic_bytes_per_launch": rows * BYTES_PER_ROW},
+            "device": capi.device_name(),
+        }
+        if not args.no_cpu and world == 1:
+            try:
+                line["cpu_baseline"] = cpu_baseline(capi, min(args.cpu_sample, rows))
+            except Exception as e:  # the baseline is a reported aside; never lose the GPU number over it
+                line["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,449 @@
+"""ctypes binding of libbowgpu.so (include/bowgpu.h) — plumbing for the tests and bench.py.
+
+This module is NOT a CPU implementation of anything: every function forwards to the HIP
+library.  If the library is missing or no GPU is present the call raises (BowGpuError /
+OSError); there is no fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbowgpu.so")
+
+FLOAT64, INT64, BOOLEAN, STRING = 1, 2, 3, 4
+HOST, DEVICE = 0, 1
+TYPE_NAMES = {"float64": FLOAT64, "int64": INT64, "bool": BOOLEAN, "utf8": STRING}
+
+AGG = {
+    "WindowStart": 0, "Sum": 1, "ArithmeticMean": 2, "Min": 3, "Max": 4, "Count": 5, "First": 6,
+    "Last": 7, "IntegralStep": 8, "IntegralTrapezoid": 9, "WeightedAverageStep": 10,
+    "WeightedAverageLinear": 11, "NumRows": 12,
+}
+INTERP = {"WindowStart": 0, "Linear": 1, "StepPrevious": 2, "None": 3, "Const": 4}
+
+MAX_FACTORS = 4
+CARRY_MAX_AGGS = 16
+
+ERR_NAMES = {
+    -1: "INTERVAL", -2: "TS_TYPE", -3: "FIRST_TS_NULL", -4: "NO_AGG", -5: "KEEP_INTERVAL", -6: "BAD_COL",
+    -7: "TYPE", -8: "NOT_SORTED", -9: "UNSUPPORTED", -10: "ARG", -11: "NO_DEVICE", -12: "HIP",
+    -13: "TS_NULLS", -14: "TS_UNSORTED", -15: "OOM",
+}
+
+
+class BowGpuError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("bowgpu error %d (%s): %s" % (code, ERR_NAMES.get(code, "?"), msg))
+        self.code = code
+        self.message = msg
+
+
+class Col(C.Structure):
+    _fields_ = [("values", C.c_void_p), ("validity", C.c_void_p), ("offset", C.c_int64), ("length", C.c_int64),
+                ("null_count", C.c_int64), ("type", C.c_int32), ("residency", C.c_int32)]
+
+
+class Out(C.Structure):
+    _fields_ = [("values", C.c_void_p), ("validity", C.c_void_p), ("length", C.c_int64), ("null_count", C.c_int64),
+                ("type", C.c_int32), ("residency", C.c_int32)]
+
+
+class Agg(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("col", C.c_int32), ("n_factors", C.c_int32), ("_pad", C.c_int32),
+                ("factors", C.c_double * MAX_FACTORS)]
+
+
+class Options(C.Structure):
+    _fields_ = [("offset", C.c_int64), ("inclusive", C.c_int32), ("_pad", C.c_int32)]
+
+
+class AggInfo(C.Structure):
+    _fields_ = [("s0", C.c_int64), ("num_windows", C.c_int64), ("new_interval_col", C.c_int32),
+                ("inclusive", C.c_int32), ("long_windows", C.c_int64), ("kernel_ms", C.c_double)]
+
+
+class Interp(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("col", C.c_int32), ("const_value", C.c_double), ("has_prev_row", C.c_int32),
+                ("prev_t_valid", C.c_int32), ("prev_v_valid", C.c_int32), ("_pad", C.c_int32),
+                ("prev_t", C.c_double), ("prev_v", C.c_double), ("prev_v_i64", C.c_int64)]
+
+
+class CarryState(C.Structure):
+    _fields_ = [("sum", C.c_double), ("vmin", C.c_double), ("vmax", C.c_double), ("last_t", C.c_double),
+                ("last_v", C.c_double), ("integ", C.c_double), ("count", C.c_int64), ("nrows", C.c_int64),
+                ("first_bits", C.c_int64), ("last_bits", C.c_int64), ("has_value", C.c_int32),
+                ("has_point", C.c_int32), ("has_pair", C.c_int32), ("_pad", C.c_int32)]
+
+
+class ShardCarry(C.Structure):
+    _fields_ = [("window_id", C.c_int64), ("first_window_id", C.c_int64), ("first_ts", C.c_int64),
+                ("last_ts", C.c_int64), ("nrows", C.c_int64), ("naggs", C.c_int32), ("_pad", C.c_int32),
+                ("agg", CarryState * CARRY_MAX_AGGS)]
+
+
+# every symbol include/bowgpu.h declares (checked by tests/test_abi_symbols.py)
+SYMBOLS = [
+    "bowgpu_abi_version", "bowgpu_last_error", "bowgpu_device_count", "bowgpu_set_device", "bowgpu_device_name",
+    "bowgpu_set_stream", "bowgpu_synchronize", "bowgpu_malloc", "bowgpu_free", "bowgpu_memcpy_h2d",
+    "bowgpu_memcpy_d2h", "bowgpu_memset", "bowgpu_timer_create", "bowgpu_timer_start", "bowgpu_timer_stop",
+    "bowgpu_timer_elapsed_ms", "bowgpu_timer_destroy", "bowgpu_enforce_interval_and_offset", "bowgpu_plan_windows",
+    "bowgpu_rolling_aggregate", "bowgpu_window_bounds", "bowgpu_aggregate_whole",
+    "bowgpu_rolling_interpolate_count", "bowgpu_rolling_interpolate_fill", "bowgpu_fill_linear",
+    "bowgpu_is_col_sorted", "bowgpu_shard_aggregate", "bowgpu_shard_stitch", "bowgpu_gen_dense",
+    "bowgpu_gen_sparse", "bowgpu_checksum64",
+]
+
+_lib = None
+
+
+def lib():
+    """Loads libbowgpu.so; raises OSError if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OSError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(make -C bow_amd/csrc). The bowgpu path has no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.bowgpu_last_error.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise BowGpuError(rc, lib().bowgpu_last_error().decode("utf-8", "replace"))
+
+
+# ------------------------------------------------------------------ device buffers
+class DeviceBuffer:
+    """A hipMalloc'd buffer owned by Python."""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        check(lib().bowgpu_malloc(C.byref(p), C.c_int64(self.nbytes)))
+        self.ptr = p.value
+
+    @classmethod
+    def from_numpy(cls, arr):
+        arr = np.ascontiguousarray(arr)
+        b = cls(max(arr.nbytes, 8))
+        if arr.nbytes:
+            check(lib().bowgpu_memcpy_h2d(C.c_void_p(b.ptr), arr.ctypes.data_as(C.c_void_p), C.c_int64(arr.nbytes)))
+        return b
+
+    def to_numpy(self, dtype, count):
+        out = np.empty(count, dtype=dtype)
+        if out.nbytes:
+            check(lib().bowgpu_memcpy_d2h(out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr), C.c_int64(out.nbytes)))
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib().bowgpu_free(C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Column:
+    """One Arrow array handed to the C ABI: numpy buffers (HOST) or DeviceBuffers (DEVICE)."""
+
+    def __init__(self, values, validity=None, typ=None, offset=0, length=None, null_count=-1):
+        if isinstance(values, DeviceBuffer):
+            self.residency = DEVICE
+            assert typ is not None and length is not None
+            self.values, self.validity = values, validity
+        else:
+            self.residency = HOST
+            if typ is None:
+                typ = INT64 if np.asarray(values).dtype == np.int64 else FLOAT64
+            dt = {INT64: np.int64, FLOAT64: np.float64}.get(typ, np.uint8)
+            self.values = np.ascontiguousarray(values, dtype=dt)
+            self.validity = None if validity is None else np.ascontiguousarray(validity, dtype=np.uint8)
+            if length is None:
+                length = len(self.values) - offset
+        self.type, self.offset, self.length = typ, offset, length
+        self.null_count = 0 if validity is None else null_count
+
+    @classmethod
+    def from_list(cls, data, typ):
+        """python list with None for nulls (bow.NewBowFromColBasedInterfaces)."""
+        if isinstance(typ, str):
+            typ = TYPE_NAMES[typ]
+        n = len(data)
+        valid = np.array([x is not None for x in data], dtype=bool)
+        validity = np.packbits(valid, bitorder="little") if n else np.zeros(0, np.uint8)
+        if typ == BOOLEAN:
+            vals = np.packbits(np.array([bool(x) for x in data], dtype=bool), bitorder="little") if n else np.zeros(0, np.uint8)
+            return cls(vals, validity, BOOLEAN, 0, n, int(n - valid.sum()))
+        dt = np.int64 if typ == INT64 else np.float64
+        vals = np.array([x if x is not None else 0 for x in data], dtype=dt)
+        return cls(vals, validity, typ, 0, n, int(n - valid.sum()))
+
+    def to_device(self):
+        if self.residency == DEVICE:
+            return self
+        v = DeviceBuffer.from_numpy(self.values.view(np.uint8) if self.values.size else np.zeros(8, np.uint8))
+        b = None if self.validity is None else DeviceBuffer.from_numpy(
+            np.concatenate([self.validity, np.zeros(8, np.uint8)]))
+        return Column(v, b, self.type, self.offset, self.length, self.null_count)
+
+    def c(self):
+        s = Col()
+        if self.residency == DEVICE:
+            s.values = self.values.ptr
+            s.validity = None if self.validity is None else self.validity.ptr
+        else:
+            s.values = self.values.ctypes.data if self.values.size else None
+            s.validity = None if self.validity is None else (self.validity.ctypes.data if self.validity.size else None)
+        s.offset, s.length, s.null_count = self.offset, self.length, self.null_count
+        s.type, s.residency = self.type, self.residency
+        return s
+
+
+class OutColumn:
+    """Caller-owned output storage (what bow.NewBuffer(W, typ) allocates)."""
+
+    def __init__(self, slots, residency=HOST):
+        self.slots = slots
+        self.residency = residency
+        nb = (slots + 7) // 8
+        if residency == HOST:
+            self.values = np.full(max(slots, 1), 0x5A5A5A5A5A5A5A5A, dtype=np.uint64)  # poisoned
+            self.validity = np.full(max(nb, 1), 0xA5, dtype=np.uint8)
+        else:
+            self.values = DeviceBuffer(max(slots, 1) * 8)
+            self.validity = DeviceBuffer(max(nb, 1))
+        self.type = 0
+        self.null_count = -1
+        self.length = slots
+
+    def c(self):
+        o = Out()
+        if self.residency == HOST:
+            o.values, o.validity = self.values.ctypes.data, self.validity.ctypes.data
+        else:
+            o.values, o.validity = self.values.ptr, self.validity.ptr
+        o.length, o.residency = self.slots, self.residency
+        return o
+
+    def absorb(self, o):
+        self.type, self.null_count, self.length = o.type, o.null_count, o.length
+
+    def host_arrays(self):
+        n = self.length
+        nb = (n + 7) // 8
+        if self.residency == HOST:
+            vals, bm = self.values[:n], self.validity[:nb]
+        else:
+            vals, bm = self.values.to_numpy(np.uint64, n), self.validity.to_numpy(np.uint8, nb)
+        dt = np.int64 if self.type == INT64 else np.float64
+        return vals.view(dt), bm
+
+    def valid_mask(self):
+        _, bm = self.host_arrays()
+        n = self.length
+        if n == 0:
+            return np.zeros(0, bool)
+        return np.unpackbits(bm, bitorder="little")[:n].astype(bool)
+
+    def to_list(self):
+        vals, _ = self.host_arrays()
+        m = self.valid_mask()
+        conv = int if self.type == INT64 else float
+        return [conv(v) if ok else None for v, ok in zip(vals, m)]
+
+
+def _cols(cols):
+    arr = (Col * max(len(cols), 1))()
+    for i, c in enumerate(cols):
+        arr[i] = c.c()
+    return arr
+
+
+def _aggs(aggs):
+    arr = (Agg * max(len(aggs), 1))()
+    for i, a in enumerate(aggs):
+        arr[i].kind = AGG[a[0]] if isinstance(a[0], str) else a[0]
+        arr[i].col = a[1]
+        factors = list(a[2]) if len(a) > 2 and a[2] else []
+        arr[i].n_factors = len(factors)
+        for k, f in enumerate(factors[:MAX_FACTORS]):
+            arr[i].factors[k] = f
+    return arr
+
+
+# ------------------------------------------------------------------ entry points
+def device_count():
+    n = C.c_int(0)
+    check(lib().bowgpu_device_count(C.byref(n)))
+    return n.value
+
+
+def set_device(d):
+    check(lib().bowgpu_set_device(int(d)))
+
+
+def device_name():
+    buf = C.create_string_buffer(256)
+    check(lib().bowgpu_device_name(buf, 256))
+    return buf.value.decode()
+
+
+def set_stream(ptr):
+    check(lib().bowgpu_set_stream(C.c_void_p(ptr)))
+
+
+def synchronize():
+    check(lib().bowgpu_synchronize())
+
+
+def enforce_interval_and_offset(interval, offset):
+    out = C.c_int64()
+    check(lib().bowgpu_enforce_interval_and_offset(C.c_int64(interval), C.c_int64(offset), C.byref(out)))
+    return out.value
+
+
+def plan_windows(ts, interval, offset=0):
+    s0, W = C.c_int64(), C.c_int64()
+    c = ts.c()
+    check(lib().bowgpu_plan_windows(C.byref(c), C.c_int64(interval), C.c_int64(offset), C.byref(s0), C.byref(W)))
+    return s0.value, W.value
+
+
+def rolling_aggregate(cols, ts_col, interval, aggs, offset=0, inclusive=False, out_residency=HOST, outs=None):
+    """Returns (list[OutColumn], AggInfo).  aggs: [(kind, col[, factors])]."""
+    s0, W = plan_windows(cols[ts_col], interval, offset)
+    if outs is None:
+        outs = [OutColumn(W, out_residency) for _ in aggs]
+    oarr = (Out * max(len(aggs), 1))()
+    for i, o in enumerate(outs):
+        oarr[i] = o.c()
+    opts = Options(offset, int(bool(inclusive)), 0)
+    info = AggInfo()
+    check(lib().bowgpu_rolling_aggregate(_cols(cols), len(cols), ts_col, C.c_int64(interval), C.byref(opts),
+                                         _aggs(aggs), len(aggs), oarr, C.byref(info)))
+    for i, o in enumerate(outs):
+        o.absorb(oarr[i])
+    return outs, info
+
+
+def window_bounds(ts, interval, offset=0, inclusive=False):
+    s0, W = plan_windows(ts, interval, offset)
+    arrs = [np.zeros(max(W, 1), dtype=np.int64) for _ in range(3)]
+    inc = np.zeros(max(W, 1), dtype=np.uint8)
+    opts = Options(offset, int(bool(inclusive)), 0)
+    c = ts.c()
+    check(lib().bowgpu_window_bounds(C.byref(c), C.c_int64(interval), C.byref(opts),
+                                     *[a.ctypes.data_as(C.c_void_p) for a in arrs], inc.ctypes.data_as(C.c_void_p), HOST))
+    return s0, W, arrs[0][:W], arrs[1][:W], arrs[2][:W], inc[:W].astype(bool)
+
+
+def aggregate_whole(cols, ts_col, aggs):
+    outs = [OutColumn(1) for _ in aggs]
+    oarr = (Out * max(len(aggs), 1))()
+    for i, o in enumerate(outs):
+        oarr[i] = o.c()
+    check(lib().bowgpu_aggregate_whole(_cols(cols), len(cols), ts_col, _aggs(aggs), len(aggs), oarr))
+    for i, o in enumerate(outs):
+        o.absorb(oarr[i])
+    return outs
+
+
+def _interps(interps):
+    arr = (Interp * max(len(interps), 1))()
+    for i, ip in enumerate(interps):
+        arr[i].kind, arr[i].col = INTERP[ip["kind"]], ip["col"]
+        arr[i].const_value = ip.get("const", 0.0)
+        prev = ip.get("prev")
+        if prev is not None:
+            arr[i].has_prev_row = 1
+            arr[i].prev_t, arr[i].prev_t_valid = prev[0], int(prev[1])
+            arr[i].prev_v, arr[i].prev_v_valid = prev[2], int(prev[3])
+            arr[i].prev_v_i64 = prev[4] if len(prev) > 4 else 0
+    return arr
+
+
+def rolling_interpolate(cols, ts_col, interval, interps, offset=0, inclusive=False, out_residency=HOST):
+    opts = Options(offset, int(bool(inclusive)), 0)
+    n_out = C.c_int64(0)
+    carr, iarr = _cols(cols), _interps(interps)
+    check(lib().bowgpu_rolling_interpolate_count(carr, len(cols), ts_col, C.c_int64(interval), C.byref(opts),
+                                                 iarr, len(interps), C.byref(n_out)))
+    outs = [OutColumn(n_out.value, out_residency) for _ in interps]
+    oarr = (Out * max(len(interps), 1))()
+    for i, o in enumerate(outs):
+        oarr[i] = o.c()
+    check(lib().bowgpu_rolling_interpolate_fill(carr, len(cols), ts_col, C.c_int64(interval), C.byref(opts),
+                                                iarr, len(interps), oarr))
+    for i, o in enumerate(outs):
+        o.absorb(oarr[i])
+    return outs
+
+
+def fill_linear(cols, ref_col, fill_col, out_residency=HOST):
+    out = OutColumn(cols[fill_col].length, out_residency)
+    o = out.c()
+    unchanged = C.c_int32(0)
+    check(lib().bowgpu_fill_linear(_cols(cols), len(cols), ref_col, fill_col, C.byref(o), C.byref(unchanged)))
+    out.absorb(o)
+    return out, bool(unchanged.value)
+
+
+def is_col_sorted(col):
+    c = col.c()
+    s = C.c_int32(0)
+    check(lib().bowgpu_is_col_sorted(C.byref(c), C.byref(s)))
+    return bool(s.value)
+
+
+def gen_dense(row0, n, seed=42):
+    ts, val = DeviceBuffer(max(n, 1) * 8), DeviceBuffer(max(n, 1) * 8)
+    check(lib().bowgpu_gen_dense(C.c_int64(row0), C.c_int64(n), C.c_uint64(seed), C.c_void_p(ts.ptr), C.c_void_p(val.ptr)))
+    return Column(ts, None, INT64, 0, n, 0), Column(val, None, FLOAT64, 0, n, 0)
+
+
+def gen_sparse(row0, n, seed=42):
+    ts, val = DeviceBuffer(max(n, 1) * 8), DeviceBuffer(max(n, 1) * 8)
+    bm = DeviceBuffer((n + 7) // 8 + 8)
+    check(lib().bowgpu_memset(C.c_void_p(bm.ptr), 0, C.c_int64(bm.nbytes)))
+    check(lib().bowgpu_gen_sparse(C.c_int64(row0), C.c_int64(n), C.c_uint64(seed), C.c_void_p(ts.ptr),
+                                  C.c_void_p(val.ptr), C.c_void_p(bm.ptr)))
+    return Column(ts, None, INT64, 0, n, 0), Column(val, bm, FLOAT64, 0, n, -1)
+
+
+def checksum64(devbuf, n_words):
+    x, s = C.c_uint64(0), C.c_uint64(0)
+    check(lib().bowgpu_checksum64(C.c_void_p(devbuf.ptr), C.c_int64(n_words), C.byref(x), C.byref(s)))
+    return x.value, s.value
+
+
+class Timer:
+    def __init__(self):
+        p = C.c_void_p()
+        check(lib().bowgpu_timer_create(C.byref(p)))
+        self.p = p
+
+    def start(self):
+        check(lib().bowgpu_timer_start(self.p))
+
+    def stop(self):
+        check(lib().bowgpu_timer_stop(self.p))
+
+    def elapsed_ms(self):
+        ms = C.c_double(0)
+        check(lib().bowgpu_timer_elapsed_ms(self.p, C.byref(ms)))
+        return ms.value
+
+    def __del__(self):
+        try:
+            lib().bowgpu_timer_destroy(self.p)
+        except Exception:
+            pass

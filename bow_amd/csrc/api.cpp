@@ -1,0 +1,711 @@
+// api.cpp — the C ABI of libbowgpu.so (include/bowgpu.h): argument validation mirroring the
+// reference's drivers, residency handling, window planning, and kernel orchestration.
+// No CPU implementation of any reducer lives here: everything that touches column data runs
+// in the HIP kernels; without a GPU every entry point fails with BOWGPU_ERR_NO_DEVICE.
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "common.h"
+
+namespace bowgpu {
+
+// ---------------------------------------------------------------- errors
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int hip_fail(hipError_t e, const char *what) {
+    snprintf(g_err, sizeof g_err, "HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
+    if (e == hipErrorOutOfMemory) return BOWGPU_ERR_OOM;
+    if (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorInsufficientDriver) return BOWGPU_ERR_NO_DEVICE;
+    return BOWGPU_ERR_HIP;
+}
+
+// ---------------------------------------------------------------- context
+static thread_local Ctx g_ctx;
+
+int ctx_get(Ctx **out) {
+    Ctx *c = &g_ctx;
+    if (!c->inited) {
+        int n = 0;
+        hipError_t e = hipGetDeviceCount(&n);
+        if (e != hipSuccess || n <= 0)
+            return fail(BOWGPU_ERR_NO_DEVICE, "no HIP device available (hipGetDeviceCount: %s); the bowgpu path has no CPU fallback",
+                        e == hipSuccess ? "0 devices" : hipGetErrorString(e));
+        if (c->device >= n) return fail(BOWGPU_ERR_NO_DEVICE, "device %d out of range (%d devices)", c->device, n);
+        BG_HIP(hipSetDevice(c->device));
+        BG_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+        BG_HIP(hipEventCreate(&c->ev0));
+        BG_HIP(hipEventCreate(&c->ev1));
+        if (!c->stream) c->stream = c->own_stream;
+        c->inited = true;
+    } else {
+        BG_HIP(hipSetDevice(c->device));  // cgo calls may hop OS threads: no thread-affine HIP state assumed
+    }
+    *out = c;
+    return 0;
+}
+
+int ctx_scratch(Ctx *c, size_t bytes, void **dptr) {
+    if (c->d_scratch_bytes < bytes) {
+        if (c->d_scratch) (void)hipFree(c->d_scratch);
+        c->d_scratch = nullptr;
+        c->d_scratch_bytes = 0;
+        BG_HIP(hipMalloc(&c->d_scratch, bytes));
+        c->d_scratch_bytes = bytes;
+    }
+    *dptr = c->d_scratch;
+    return 0;
+}
+
+int ctx_pinned(Ctx *c, size_t bytes, void **hptr) {
+    if (c->h_pinned_bytes < bytes) {
+        if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+        c->h_pinned = nullptr;
+        c->h_pinned_bytes = 0;
+        BG_HIP(hipHostMalloc(&c->h_pinned, bytes, hipHostMallocDefault));
+        c->h_pinned_bytes = bytes;
+    }
+    *hptr = c->h_pinned;
+    return 0;
+}
+
+int DevBuf::alloc(size_t n) {
+    if (p) { (void)hipFree(p); p = nullptr; }
+    bytes = n;
+    if (n == 0) return 0;
+    BG_HIP(hipMalloc(&p, n));
+    return 0;
+}
+
+// ---------------------------------------------------------------- magic division
+MagicDiv magic_make(uint64_t d) {
+    // Granlund & Montgomery, "Division by invariant integers using multiplication", fig. 4.1, N = 64
+    MagicDiv r;
+    int l = 0;
+    while (l < 64 && ((unsigned __int128)1 << l) < d) l++;
+    const unsigned __int128 two_l = (unsigned __int128)1 << l;
+    const unsigned __int128 num = ((two_l - d) << 64);
+    r.m = (uint64_t)(num / d) + 1;
+    r.sh1 = l < 1 ? (uint32_t)l : 1u;
+    r.sh2 = l > 1 ? (uint32_t)(l - 1) : 0u;
+    return r;
+}
+
+// ---------------------------------------------------------------- columns on the device
+static int fetch_i64(Ctx *c, const bowgpu_col *col, int64_t row, int64_t *out) {
+    const int64_t *p = reinterpret_cast<const int64_t *>(col->values) + col->offset + row;
+    if (col->residency == BOWGPU_DEVICE) {
+        if (!c) BG_TRY(ctx_get(&c));
+        BG_HIP(hipMemcpyAsync(out, p, 8, hipMemcpyDeviceToHost, c->stream));
+        BG_HIP(hipStreamSynchronize(c->stream));
+    } else {
+        *out = *p;
+    }
+    return 0;
+}
+
+static int fetch_valid(Ctx *c, const bowgpu_col *col, int64_t row, int *valid) {
+    if (!col->validity) { *valid = 1; return 0; }
+    const int64_t bit = col->offset + row;
+    uint8_t byte = 0;
+    if (col->residency == BOWGPU_DEVICE) {
+        if (!c) BG_TRY(ctx_get(&c));
+        BG_HIP(hipMemcpyAsync(&byte, col->validity + (bit >> 3), 1, hipMemcpyDeviceToHost, c->stream));
+        BG_HIP(hipStreamSynchronize(c->stream));
+    } else {
+        byte = col->validity[bit >> 3];
+    }
+    *valid = (byte >> (bit & 7)) & 1;
+    return 0;
+}
+
+int count_nulls_device(Ctx *c, DevCol *dc) {
+    if (!dc->vbits || dc->length == 0) { dc->null_count = 0; return 0; }
+    void *d;
+    BG_TRY(ctx_scratch(c, 4096, &d));
+    uint64_t *dcount = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(d) + 2048);
+    BG_TRY(launch_popcount(c, dc->vbits, dc->vbit0, dc->length, dcount));
+    uint64_t set = 0;
+    BG_HIP(hipMemcpyAsync(&set, dcount, 8, hipMemcpyDeviceToHost, c->stream));
+    BG_HIP(hipStreamSynchronize(c->stream));
+    dc->null_count = dc->length - (int64_t)set;
+    return 0;
+}
+
+int devcol_prepare(Ctx *c, const bowgpu_col *col, DevCol *out, bool need_values, bool need_validity) {
+    if (col->length < 0 || col->offset < 0) return fail(BOWGPU_ERR_ARG, "negative column length/offset");
+    if (col->length > 0 && !col->values) return fail(BOWGPU_ERR_ARG, "column has no values buffer");
+    out->length = col->length;
+    out->type = col->type;
+    out->null_count = col->null_count;
+    const int64_t n = col->length;
+    if (n == 0) { out->null_count = 0; return 0; }
+    const bool has_bitmap = col->validity != nullptr && col->null_count != 0;
+    if (col->residency == BOWGPU_DEVICE) {
+        if (reinterpret_cast<uintptr_t>(col->values) & 7) return fail(BOWGPU_ERR_ARG, "values buffer must be 8-byte aligned");
+        out->values = reinterpret_cast<const char *>(col->values) + 8 * col->offset;
+        if (has_bitmap) {
+            const uintptr_t a = reinterpret_cast<uintptr_t>(col->validity);
+            out->vbits = reinterpret_cast<const uint32_t *>(a & ~(uintptr_t)3);
+            out->vbit0 = (int64_t)(a & 3) * 8 + col->offset;
+            out->vwords = (out->vbit0 + n + 31) >> 5;
+        }
+    } else if (col->residency == BOWGPU_HOST) {
+        if (need_values) {
+            BG_TRY(out->own_values.alloc((size_t)n * 8 + 16));
+            BG_HIP(hipMemcpyAsync(out->own_values.p, reinterpret_cast<const char *>(col->values) + 8 * col->offset,
+                                  (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+            out->values = out->own_values.p;
+        }
+        if (has_bitmap && need_validity) {
+            const int64_t b0 = col->offset >> 3, b1 = (col->offset + n + 7) >> 3;
+            const size_t nb = (size_t)(b1 - b0);
+            BG_TRY(out->own_validity.alloc(((nb + 3) & ~(size_t)3) + 8));
+            BG_HIP(hipMemsetAsync(out->own_validity.p, 0, out->own_validity.bytes, c->stream));
+            BG_HIP(hipMemcpyAsync(out->own_validity.p, col->validity + b0, nb, hipMemcpyHostToDevice, c->stream));
+            out->vbits = reinterpret_cast<const uint32_t *>(out->own_validity.p);
+            out->vbit0 = col->offset & 7;
+            out->vwords = (out->vbit0 + n + 31) >> 5;
+        }
+    } else {
+        return fail(BOWGPU_ERR_ARG, "unknown residency %d", col->residency);
+    }
+    if (has_bitmap && out->vbits && col->null_count < 0) BG_TRY(count_nulls_device(c, out));
+    if (!has_bitmap) out->null_count = 0;
+    if (out->null_count == 0) { out->vbits = nullptr; }
+    return 0;
+}
+
+int devout_prepare(Ctx *c, bowgpu_out *out, int64_t slots, DevOut *d) {
+    d->user = out;
+    d->capacity = slots;
+    if (out->length < slots) return fail(BOWGPU_ERR_ARG, "output column has %lld slots, %lld needed", (long long)out->length, (long long)slots);
+    if (slots == 0) return 0;
+    if (!out->values || !out->validity) return fail(BOWGPU_ERR_ARG, "output column lacks a values or validity buffer");
+    const size_t vb = (size_t)((slots + 7) >> 3);
+    if (out->residency == BOWGPU_DEVICE) {
+        if (reinterpret_cast<uintptr_t>(out->values) & 7) return fail(BOWGPU_ERR_ARG, "output values must be 8-byte aligned");
+        d->values = out->values;
+        // The kernels update validity as 32-bit words; a caller buffer of exactly ceil(W/8) bytes may end
+        // mid-word, so always assemble in an aligned temporary and copy the exact byte count back.
+        BG_TRY(d->own_validity.alloc(((vb + 3) & ~(size_t)3) + 4));
+        d->validity = reinterpret_cast<uint8_t *>(d->own_validity.p);
+    } else {
+        BG_TRY(d->own_values.alloc((size_t)slots * 8));
+        BG_TRY(d->own_validity.alloc(((vb + 3) & ~(size_t)3) + 4));
+        d->values = d->own_values.p;
+        d->validity = reinterpret_cast<uint8_t *>(d->own_validity.p);
+    }
+    return 0;
+}
+
+int devout_finish(Ctx *c, DevOut *d, int64_t slots, int32_t type, int64_t null_count) {
+    bowgpu_out *out = d->user;
+    out->length = slots;
+    out->type = type;
+    out->null_count = null_count;
+    if (slots == 0) return 0;
+    const size_t vb = (size_t)((slots + 7) >> 3);
+    if (out->residency == BOWGPU_DEVICE) {
+        BG_HIP(hipMemcpyAsync(out->validity, d->validity, vb, hipMemcpyDeviceToDevice, c->stream));
+    } else {
+        BG_HIP(hipMemcpyAsync(out->values, d->values, (size_t)slots * 8, hipMemcpyDeviceToHost, c->stream));
+        BG_HIP(hipMemcpyAsync(out->validity, d->validity, vb, hipMemcpyDeviceToHost, c->stream));
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------- plan
+static int enforce_interval_and_offset(int64_t interval, int64_t offset, int64_t *out) {
+    // reference rolling/rolling.go:114-128
+    if (interval <= 0) return fail(BOWGPU_ERR_INTERVAL, "strictly positive interval required");
+    if (offset >= interval || offset <= -interval) offset = offset % interval;
+    if (offset < 0) offset += interval;
+    *out = offset;
+    return 0;
+}
+
+int plan_make(Ctx *c, const bowgpu_col *ts, int64_t interval, int64_t raw_offset, Plan *p) {
+    // reference rolling/rolling.go:69-112 and :143-154
+    if (ts->type != BOWGPU_INT64)
+        return fail(BOWGPU_ERR_TS_TYPE, "impossible to create a new intervalRolling on column of type %s",
+                    ts->type == BOWGPU_FLOAT64 ? "float64" : ts->type == BOWGPU_BOOLEAN ? "bool" : ts->type == BOWGPU_STRING ? "utf8" : "undefined");
+    BG_TRY(enforce_interval_and_offset(interval, raw_offset, &p->offset));
+    p->interval = interval;
+    p->magic = magic_make((uint64_t)interval);
+    p->s0 = 0;
+    p->W = 0;
+    const int64_t n = ts->length;
+    if (n == 0) return 0;
+    int valid = 1;
+    BG_TRY(fetch_valid(c, ts, 0, &valid));
+    if (!valid) return fail(BOWGPU_ERR_FIRST_TS_NULL, "the first value of the column should be convertible to int64, got <nil>");
+    int64_t first = 0;
+    BG_TRY(fetch_i64(c, ts, 0, &first));
+    p->first_ts = first;
+    // Go: (first/interval)*interval + offset with wrapping int64 arithmetic
+    int64_t s0 = (int64_t)((uint64_t)((first / interval) * interval) + (uint64_t)p->offset);
+    if (s0 > first) s0 = (int64_t)((uint64_t)s0 - (uint64_t)interval);
+    p->s0 = s0;
+    // countWindows: last VALID ts scanning backwards (GetPrevInt64, bowgetters.go:189-199)
+    int64_t row = n - 1;
+    int lv = 1;
+    while (row >= 0) {
+        BG_TRY(fetch_valid(c, ts, row, &lv));
+        if (lv) break;
+        row--;
+    }
+    if (row < 0) { p->W = 0; return 0; }
+    int64_t last = 0;
+    BG_TRY(fetch_i64(c, ts, row, &last));
+    p->last_ts = last;
+    if (s0 > last) { p->W = 0; return 0; }
+    p->W = (int64_t)(((uint64_t)last - (uint64_t)s0) / (uint64_t)interval) + 1;
+    // the reference computes (last - s0)/interval in int64: decline ranges where that wraps
+    if ((last > 0 && s0 < 0 && (uint64_t)last - (uint64_t)s0 > (uint64_t)INT64_MAX))
+        return fail(BOWGPU_ERR_UNSUPPORTED, "interval column spans more than 2^63: int64 overflow in the reference's countWindows");
+    return 0;
+}
+
+// ---------------------------------------------------------------- aggregate
+static bool kind_needs_inclusive(int kind) {
+    // NewColAggregation(col, true, ...) only at integral.go:9 and weightedmean.go:24
+    return kind == BOWGPU_AGG_INTEGRAL_TRAPEZOID || kind == BOWGPU_AGG_WAVG_LINEAR;
+}
+
+static int kind_type(int kind) {
+    switch (kind) {
+    case BOWGPU_AGG_WINDOW_START: return BOWGPU_ITERATOR_DEPENDENT;  // windowstart.go:9
+    case BOWGPU_AGG_COUNT: return BOWGPU_INT64;                      // count.go:9
+    case BOWGPU_AGG_FIRST:
+    case BOWGPU_AGG_LAST: return BOWGPU_INPUT_DEPENDENT;             // firstlast.go:9,:24
+    default: return BOWGPU_FLOAT64;
+    }
+}
+
+static bool kind_never_nil(int kind) {
+    return kind == BOWGPU_AGG_WINDOW_START || kind == BOWGPU_AGG_SUM || kind == BOWGPU_AGG_COUNT || kind == BOWGPU_AGG_NUM_ROWS;
+}
+
+static bool kind_reads_values(int kind) { return !(kind == BOWGPU_AGG_WINDOW_START || kind == BOWGPU_AGG_NUM_ROWS); }
+
+struct AggRun {
+    Plan plan;
+    std::vector<DevCol> dcols;   // indexed by user column
+    std::vector<DevOut> douts;
+    AggParams params;
+    int inclusive = 0;
+    int new_interval_col = -1;
+};
+
+// validation shared by the single-GPU and the sharded entry points
+// (indexedAggregations + validateAggregation: reference rolling/aggregation.go:147-188)
+static int validate_aggs(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, const bowgpu_agg *aggs, int32_t naggs,
+                         int *inclusive, int *new_interval_col) {
+    if (naggs <= 0) return fail(BOWGPU_ERR_NO_AGG, "at least one column aggregation is required");
+    if (naggs > kMaxAggs) return fail(BOWGPU_ERR_UNSUPPORTED, "at most %d aggregations per call", kMaxAggs);
+    int nic = -1;
+    for (int i = 0; i < naggs; i++) {
+        if (aggs[i].col < 0 || aggs[i].col >= ncols) return fail(BOWGPU_ERR_BAD_COL, "aggregation %d: no column with index %d", i, aggs[i].col);
+        if (aggs[i].kind < 0 || aggs[i].kind >= BOWGPU_AGG__COUNT) return fail(BOWGPU_ERR_ARG, "aggregation %d: unknown kind %d", i, aggs[i].kind);
+        if (aggs[i].n_factors < 0 || aggs[i].n_factors > BOWGPU_MAX_FACTORS) return fail(BOWGPU_ERR_ARG, "aggregation %d: bad factor count", i);
+        const int t = cols[aggs[i].col].type;
+        if (t != BOWGPU_FLOAT64 && t != BOWGPU_INT64)
+            return fail(BOWGPU_ERR_UNSUPPORTED, "aggregation %d: column type %d is outside the device path (Float64/Int64 only)", i, t);
+        if (kind_needs_inclusive(aggs[i].kind)) *inclusive = 1;  // aggregation.go:183-185
+        if (aggs[i].col == ts_col) nic = i;                      // aggregation.go:158-160 (last one wins)
+    }
+    if (nic == -1) return fail(BOWGPU_ERR_KEEP_INTERVAL, "must keep interval column");
+    *new_interval_col = nic;
+    return 0;
+}
+
+// Builds AggParams for the rows of `cols` (already planned) and runs the kernels.
+static int run_aggregate(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t ts_col, const Plan &plan,
+                         int inclusive, const bowgpu_agg *aggs, int32_t naggs, bowgpu_out *outs,
+                         int64_t wid_base, int64_t W, int64_t *long_windows, double *kernel_ms) {
+    const bowgpu_col *tsc = &cols[ts_col];
+    const int64_t n = tsc->length;
+    for (int i = 0; i < ncols; i++)
+        if (cols[i].length != n) return fail(BOWGPU_ERR_ARG, "column %d has %lld rows, interval column has %lld", i, (long long)cols[i].length, (long long)n);
+
+    // device path contract: no null timestamps
+    if (tsc->validity && tsc->null_count != 0) {
+        DevCol probe;
+        BG_TRY(devcol_prepare(c, tsc, &probe, false, true));
+        if (probe.null_count > 0)
+            return fail(BOWGPU_ERR_TS_NULLS, "interval column has %lld nulls: outside the device path", (long long)probe.null_count);
+    }
+
+    // column slots: each distinct input column whose values some reducer reads
+    std::vector<DevCol> dcols(ncols);
+    std::vector<int> slot_of(ncols, -1);
+    AggParams P;
+    memset(&P, 0, sizeof P);
+    DevCol dts;
+    {
+        bowgpu_col t = *tsc;
+        t.validity = nullptr;
+        t.null_count = 0;
+        BG_TRY(devcol_prepare(c, &t, &dts, true, false));
+    }
+    P.ts = reinterpret_cast<const int64_t *>(dts.values);
+    P.n = n;
+    P.row_base = 0;
+    P.s0 = plan.s0;
+    P.interval = plan.interval;
+    P.W = W;
+    P.wid_base = wid_base;
+    P.magic = plan.magic;
+    P.inclusive = inclusive;
+    P.naggs = naggs;
+    P.pre_rows = (n > 0 && wid_base == 0 && plan.s0 > plan.first_ts) ? 1 : 0;
+
+    std::vector<int> nullable_in_slot;
+    for (int i = 0; i < naggs; i++) {
+        if (!kind_reads_values(aggs[i].kind)) continue;
+        const int col = aggs[i].col;
+        int s = slot_of[col];
+        const bool nullable = !kind_never_nil(aggs[i].kind);
+        if (s >= 0 && nullable && nullable_in_slot[s] >= 8) s = -1;  // at most 8 nullable reducers per pass: open another slot
+        if (s < 0) {
+            if (P.ncols >= kMaxCols) return fail(BOWGPU_ERR_UNSUPPORTED, "at most %d value columns per call", kMaxCols);
+            s = P.ncols++;
+            slot_of[col] = s;
+            nullable_in_slot.push_back(0);
+            DevCol &dc = dcols[col];
+            if (dc.values == nullptr && n > 0) {
+                if (col == ts_col) {
+                    dc.values = dts.values; dc.length = n; dc.type = BOWGPU_INT64; dc.null_count = 0;
+                } else {
+                    BG_TRY(devcol_prepare(c, &cols[col], &dc, true, true));
+                }
+            }
+            ColDesc &cd = P.cols[s];
+            cd.values = dc.values;
+            cd.vbits = dc.vbits;
+            cd.vbit0 = dc.vbit0;
+            cd.vwords = dc.vwords;
+            cd.type = cols[col].type;
+        }
+        if (nullable) nullable_in_slot[s]++;
+        P.aggs[i].slot = s;
+    }
+
+    std::vector<DevOut> douts(naggs);
+    for (int i = 0; i < naggs; i++) {
+        AggDesc &a = P.aggs[i];
+        a.kind = aggs[i].kind;
+        if (!kind_reads_values(aggs[i].kind)) a.slot = P.ncols > 0 ? 0 : -1;  // rides along with the first column pass
+        int t = kind_type(aggs[i].kind);
+        if (t == BOWGPU_INPUT_DEPENDENT) t = cols[aggs[i].col].type;      // aggregation.go:114-115
+        if (t == BOWGPU_ITERATOR_DEPENDENT) t = tsc->type;                // aggregation.go:116-117
+        a.out_type = t;
+        a.n_factors = aggs[i].n_factors;
+        for (int f = 0; f < a.n_factors; f++) a.factors[f] = aggs[i].factors[f];
+        BG_TRY(devout_prepare(c, &outs[i], W, &douts[i]));
+        a.out_values = douts[i].values;
+        a.out_valid = kind_never_nil(aggs[i].kind) ? nullptr : reinterpret_cast<uint32_t *>(douts[i].validity);
+    }
+
+    // status words + long-window list
+    const int64_t ntiles = (n + 2047) / 2048;
+    const size_t scratch_bytes = 4096 + (size_t)(ntiles + 1) * 16;
+    void *dscr;
+    BG_TRY(ctx_scratch(c, scratch_bytes, &dscr));
+    P.status = reinterpret_cast<uint32_t *>(dscr);
+    P.long_list = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(dscr) + 4096);
+    P.long_cap = ntiles + 1;
+    BG_HIP(hipMemsetAsync(P.status, 0, 64, c->stream));
+
+    if (W > 0) {
+        for (int i = 0; i < naggs; i++) {
+            const size_t vb = (size_t)((W + 7) >> 3);
+            // never-nil reducers: all-ones bitmap (tail bits cleared); nullable ones start all-null (bowbuffer.go:25)
+            BG_HIP(hipMemsetAsync(douts[i].validity, kind_never_nil(aggs[i].kind) ? 0xFF : 0x00, ((vb + 3) & ~(size_t)3), c->stream));
+            if (kind_never_nil(aggs[i].kind)) BG_TRY(launch_fix_tail_bits(c, douts[i].validity, W));
+        }
+        // kernel_ms brackets the dominant kernel only (rolling_agg_kernel), on the stream it runs on
+        BG_HIP(hipEventRecord(c->ev0, c->stream));
+        BG_TRY(launch_rolling_aggregate(c, P));
+        BG_HIP(hipEventRecord(c->ev1, c->stream));
+    }
+    // status -> host (pinned) ; decides whether the long-window kernel is needed
+    uint32_t *hstat;
+    BG_TRY(ctx_pinned(c, 64, reinterpret_cast<void **>(&hstat)));
+    BG_HIP(hipMemcpyAsync(hstat, P.status, 16, hipMemcpyDeviceToHost, c->stream));
+    BG_HIP(hipStreamSynchronize(c->stream));
+    if (hstat[0]) return fail(BOWGPU_ERR_TS_UNSORTED, "interval column is not ascending: outside the device path");
+    if (hstat[2]) return fail(BOWGPU_ERR_HIP, "internal: long-window list overflow");
+    const int64_t n_long = hstat[1];
+    if (n_long > 0) BG_TRY(launch_long_windows(c, P, n_long));
+
+    // null counts of the nullable outputs
+    std::vector<int64_t> nulls(naggs, 0);
+    if (W > 0) {
+        void *d;
+        BG_TRY(ctx_scratch(c, scratch_bytes, &d));
+        uint64_t *dcnt = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(d) + 1024);
+        uint64_t *hcnt;
+        BG_TRY(ctx_pinned(c, 64 + 8 * kMaxAggs, reinterpret_cast<void **>(&hcnt)));
+        hcnt += 8;
+        for (int i = 0; i < naggs; i++) {
+            if (kind_never_nil(aggs[i].kind)) continue;
+            BG_TRY(launch_popcount(c, reinterpret_cast<const uint32_t *>(douts[i].validity), 0, W, dcnt + i));
+            BG_HIP(hipMemcpyAsync(hcnt + i, dcnt + i, 8, hipMemcpyDeviceToHost, c->stream));
+        }
+        BG_HIP(hipStreamSynchronize(c->stream));
+        for (int i = 0; i < naggs; i++)
+            if (!kind_never_nil(aggs[i].kind)) nulls[i] = W - (int64_t)hcnt[i];
+    }
+    for (int i = 0; i < naggs; i++) BG_TRY(devout_finish(c, &douts[i], W, P.aggs[i].out_type, nulls[i]));
+    BG_HIP(hipStreamSynchronize(c->stream));
+    if (long_windows) *long_windows = n_long;
+    if (kernel_ms) {
+        float ms = 0;
+        if (W > 0) BG_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        *kernel_ms = ms;
+    }
+    return 0;
+}
+
+}  // namespace bowgpu
+
+using namespace bowgpu;
+
+// ====================================================================================== C ABI
+extern "C" {
+
+int bowgpu_abi_version(void) { return BOWGPU_ABI_VERSION; }
+
+const char *bowgpu_last_error(void) { return g_err; }
+
+int bowgpu_device_count(int *count) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return hip_fail(e, "hipGetDeviceCount"); }
+    *count = n;
+    return 0;
+}
+
+int bowgpu_set_device(int device) {
+    Ctx *c = &g_ctx;
+    if (c->inited && c->device != device) {
+        // drop per-device state of the old device
+        (void)hipSetDevice(c->device);
+        if (c->d_scratch) (void)hipFree(c->d_scratch);
+        if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+        if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+        if (c->ev0) (void)hipEventDestroy(c->ev0);
+        if (c->ev1) (void)hipEventDestroy(c->ev1);
+        *c = Ctx();
+    }
+    c->device = device;
+    Ctx *cc;
+    return ctx_get(&cc);
+}
+
+int bowgpu_device_name(char *buf, int cap) {
+    Ctx *c;
+    BG_TRY(ctx_get(&c));
+    hipDeviceProp_t prop;
+    BG_HIP(hipGetDeviceProperties(&prop, c->device));
+    snprintf(buf, (size_t)cap, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return 0;
+}
+
+int bowgpu_set_stream(void *hip_stream) {
+    Ctx *c;
+    BG_TRY(ctx_get(&c));
+    c->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->own_stream;
+    return 0;
+}
+
+int bowgpu_synchronize(void) {
+    Ctx *c;
+    BG_TRY(ctx_get(&c));
+    BG_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int bowgpu_malloc(void **ptr, int64_t bytes) {
+    Ctx *c;
+    BG_TRY(ctx_get(&c));
+    if (bytes < 0) return fail(BOWGPU_ERR_ARG, "negative size");
+    *ptr = nullptr;
+    BG_HIP(hipMalloc(ptr, (size_t)(bytes > 0 ? bytes : 1)));
+    return 0;
+}
+
+int bowgpu_free(void *ptr) {
+    Ctx *c;
+    BG_TRY(ctx_get(&c));
+    if (ptr) BG_HIP(hipFree(ptr));
+    return 0;
+}
+
+int bowgpu_memcpy_h2d(void *dst, const void *src, int64_t bytes) {
+    Ctx *c;
+    BG_TRY(ctx_get(&c));
+    if (bytes > 0) {
+        BG_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
+        BG_HIP(hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
+int bowgpu_memcpy_d2h(void *dst, const void *src, int64_t bytes) {
+    Ctx *c;
+    BG_TRY(ctx_get(&c));
+    if (bytes > 0) {
+        BG_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
+        BG_HIP(hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
+int bowgpu_memset(void *dst, int value, int64_t bytes) {
+    Ctx *c;
+    BG_TRY(ctx_get(&c));
+    if (bytes > 0) BG_HIP(hipMemsetAsync(dst, value, (size_t)bytes, c->stream));
+    return 0;
+}
+
+struct Timer {
+    hipEvent_t a, b;
+};
+
+int bowgpu_timer_create(void **timer) {
+    Ctx *c;
+    BG_TRY(ctx_get(&c));
+    Timer *t = new Timer();
+    BG_HIP(hipEventCreate(&t->a));
+    BG_HIP(hipEventCreate(&t->b));
+    *timer = t;
+    return 0;
+}
+int bowgpu_timer_start(void *timer) {
+    Ctx *c;
+    BG_TRY(ctx_get(&c));
+    BG_HIP(hipEventRecord(reinterpret_cast<Timer *>(timer)->a, c->stream));
+    return 0;
+}
+int bowgpu_timer_stop(void *timer) {
+    Ctx *c;
+    BG_TRY(ctx_get(&c));
+    BG_HIP(hipEventRecord(reinterpret_cast<Timer *>(timer)->b, c->stream));
+    return 0;
+}
+int bowgpu_timer_elapsed_ms(void *timer, double *ms) {
+    Timer *t = reinterpret_cast<Timer *>(timer);
+    BG_HIP(hipEventSynchronize(t->b));
+    float f = 0;
+    BG_HIP(hipEventElapsedTime(&f, t->a, t->b));
+    *ms = f;
+    return 0;
+}
+int bowgpu_timer_destroy(void *timer) {
+    Timer *t = reinterpret_cast<Timer *>(timer);
+    if (!t) return 0;
+    (void)hipEventDestroy(t->a);
+    (void)hipEventDestroy(t->b);
+    delete t;
+    return 0;
+}
+
+int bowgpu_enforce_interval_and_offset(int64_t interval, int64_t offset, int64_t *offset_out) {
+    return enforce_interval_and_offset(interval, offset, offset_out);
+}
+
+int bowgpu_plan_windows(const bowgpu_col *ts, int64_t interval, int64_t offset, int64_t *s0, int64_t *num_windows) {
+    if (!ts || !s0 || !num_windows) return fail(BOWGPU_ERR_ARG, "null argument");
+    // O(1) host arithmetic on ts[0] and the last valid ts; the GPU is touched only to fetch
+    // those scalars when the column lives in HBM (plan_make acquires the context lazily).
+    Plan p;
+    BG_TRY(plan_make(nullptr, ts, interval, offset, &p));
+    *s0 = p.s0;
+    *num_windows = p.W;
+    return 0;
+}
+
+int bowgpu_rolling_aggregate(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval,
+                             const bowgpu_options *opts, const bowgpu_agg *aggs, int32_t naggs,
+                             bowgpu_out *outs, bowgpu_agg_info *info) {
+    if (!cols || ncols <= 0) return fail(BOWGPU_ERR_ARG, "no columns");
+    if (ts_col < 0 || ts_col >= ncols) return fail(BOWGPU_ERR_BAD_COL, "no interval column with index %d", ts_col);
+    bowgpu_options o = {0, 0, 0};
+    if (opts) o = *opts;
+    // reference order: the Rolling exists first (newIntervalRolling errors), then Aggregate validates
+    Plan plan;
+    int64_t s0 = 0, W = 0;
+    BG_TRY(bowgpu_plan_windows(&cols[ts_col], interval, o.offset, &s0, &W));
+    int inclusive = o.inclusive ? 1 : 0, nic = -1;
+    BG_TRY(validate_aggs(cols, ncols, ts_col, aggs, naggs, &inclusive, &nic));
+    if (!outs) return fail(BOWGPU_ERR_ARG, "no output columns");
+    Ctx *c;
+    BG_TRY(ctx_get(&c));
+    BG_TRY(plan_make(c, &cols[ts_col], interval, o.offset, &plan));
+    int64_t n_long = 0;
+    double ms = 0;
+    BG_TRY(run_aggregate(c, cols, ncols, ts_col, plan, inclusive, aggs, naggs, outs, 0, plan.W, &n_long, &ms));
+    if (info) {
+        info->s0 = plan.s0;
+        info->num_windows = plan.W;
+        info->new_interval_col = nic;
+        info->inclusive = inclusive;
+        info->long_windows = n_long;
+        info->kernel_ms = ms;
+    }
+    return 0;
+}
+
+// ---- entry points implemented in extras.cpp: window_bounds, aggregate_whole, interpolate,
+// fill_linear, is_col_sorted, shard_* ----
+
+int bowgpu_gen_dense(int64_t row0, int64_t n, uint64_t seed, int64_t *ts_dev, double *val_dev) {
+    Ctx *c;
+    BG_TRY(ctx_get(&c));
+    return launch_gen_dense(c, row0, n, seed, ts_dev, val_dev);
+}
+
+int bowgpu_gen_sparse(int64_t row0, int64_t n, uint64_t seed, int64_t *ts_dev, double *val_dev, uint8_t *validity_dev) {
+    Ctx *c;
+    BG_TRY(ctx_get(&c));
+    if (row0 & 7) return fail(BOWGPU_ERR_ARG, "row0 must be a multiple of 8");
+    return launch_gen_sparse(c, row0, n, seed, ts_dev, val_dev, validity_dev);
+}
+
+int bowgpu_checksum64(const void *dev, int64_t n_words, uint64_t *xor_out, uint64_t *sum_out) {
+    Ctx *c;
+    BG_TRY(ctx_get(&c));
+    void *d;
+    BG_TRY(ctx_scratch(c, 4096, &d));
+    uint64_t *dout = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(d) + 3072);
+    BG_TRY(launch_checksum64(c, dev, n_words, dout));
+    uint64_t h[2] = {0, 0};
+    BG_HIP(hipMemcpyAsync(h, dout, 16, hipMemcpyDeviceToHost, c->stream));
+    BG_HIP(hipStreamSynchronize(c->stream));
+    *xor_out = h[0];
+    *sum_out = h[1];
+    return 0;
+}
+
+}  // extern "C"

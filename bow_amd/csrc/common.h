@@ -1,0 +1,161 @@
+// Internal declarations shared by the HIP translation units of libbowgpu.so.
+// gfx950 (MI355X / CDNA4) only: 64-wide wavefronts, 160 KB LDS per CU, 256 CUs in 8 XCDs.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/bowgpu.h"
+
+namespace bowgpu {
+
+// ---------------------------------------------------------------- errors
+void set_error(const char *fmt, ...);
+int fail(int code, const char *fmt, ...);
+int hip_fail(hipError_t e, const char *what);
+
+#define BG_HIP(expr)                                         \
+    do {                                                     \
+        hipError_t _e = (expr);                              \
+        if (_e != hipSuccess) return hip_fail(_e, #expr);    \
+    } while (0)
+
+#define BG_TRY(expr)              \
+    do {                          \
+        int _rc = (expr);         \
+        if (_rc != 0) return _rc; \
+    } while (0)
+
+// ---------------------------------------------------------------- per-thread context
+struct Ctx {
+    int device = 0;
+    bool inited = false;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;  // stream in use (own or external)
+    // small persistent device scratch (status words, long-window list) + pinned host mirror
+    void *d_scratch = nullptr;
+    size_t d_scratch_bytes = 0;
+    void *h_pinned = nullptr;
+    size_t h_pinned_bytes = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+int ctx_get(Ctx **out);                       // initialises HIP on first use; fails loudly without a GPU
+int ctx_scratch(Ctx *c, size_t bytes, void **dptr);
+int ctx_pinned(Ctx *c, size_t bytes, void **hptr);
+
+// ---------------------------------------------------------------- temp device buffers
+// RAII device allocation (stream-ordered free at scope exit after a sync by the caller).
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t n);
+};
+
+// A column made device-resident: aliases the caller's pointers (BOWGPU_DEVICE) or owns an
+// uploaded copy (BOWGPU_HOST).  values_dev points at element `offset` already; validity is
+// kept as (aligned dword pointer, bit offset).
+struct DevCol {
+    const void *values = nullptr;      // element 0 of the logical array
+    const uint32_t *vbits = nullptr;   // 4-byte aligned word containing bit `vbit0`
+    int64_t vbit0 = 0;                 // bit index (from vbits) of logical row 0
+    int64_t vwords = 0;                // number of readable 32-bit words at vbits
+    int64_t length = 0;
+    int64_t null_count = 0;            // exact (counted on device if the caller said -1)
+    int32_t type = 0;
+    DevBuf own_values, own_validity;
+};
+int devcol_prepare(Ctx *c, const bowgpu_col *col, DevCol *out, bool need_values, bool need_validity);
+int count_nulls_device(Ctx *c, DevCol *dc);
+
+// An output column on the device: aliases the caller's buffers or owns temporaries that are
+// copied back by finish().
+struct DevOut {
+    void *values = nullptr;
+    uint8_t *validity = nullptr;
+    int64_t capacity = 0;
+    DevBuf own_values, own_validity;
+    bowgpu_out *user = nullptr;
+};
+int devout_prepare(Ctx *c, bowgpu_out *out, int64_t slots, DevOut *d);
+int devout_finish(Ctx *c, DevOut *d, int64_t slots, int32_t type, int64_t null_count);
+
+// ---------------------------------------------------------------- division by the interval
+// Granlund–Montgomery round-up method (N = 64): exact floor(n / d) for every 0 <= n < 2^64.
+struct MagicDiv {
+    uint64_t m;
+    uint32_t sh1, sh2;
+};
+MagicDiv magic_make(uint64_t d);
+
+// ---------------------------------------------------------------- window plan (host side)
+struct Plan {
+    int64_t interval = 0;
+    int64_t offset = 0;    // normalised
+    int64_t s0 = 0;
+    int64_t W = 0;
+    int64_t first_ts = 0, last_ts = 0;
+    MagicDiv magic{};
+};
+int plan_make(Ctx *c, const bowgpu_col *ts, int64_t interval, int64_t raw_offset, Plan *p);
+
+// ---------------------------------------------------------------- kernels (rolling_agg.hip)
+constexpr int kMaxCols = 8;    // value columns reduced per launch
+constexpr int kMaxAggs = 16;   // output columns per launch
+
+struct AggDesc {
+    int32_t kind;
+    int32_t slot;        // index into AggParams::cols (value column), -1 for ts-only reducers
+    int32_t out_type;    // BOWGPU_FLOAT64 / BOWGPU_INT64
+    int32_t n_factors;
+    double factors[BOWGPU_MAX_FACTORS];
+    void *out_values;
+    uint32_t *out_valid; // nullptr when the reducer never yields nil (WindowStart/Sum/Count/NumRows)
+};
+
+struct ColDesc {
+    const void *values;
+    const uint32_t *vbits;  // nullptr => no nulls
+    int64_t vbit0;
+    int64_t vwords;
+    int32_t type;
+    int32_t need_ts;        // some reducer of this column integrates over time
+};
+
+struct AggParams {
+    const int64_t *ts;
+    int64_t n;              // rows in this launch's column slice
+    int64_t row_base;       // global row index of ts[0] (sharding); 0 otherwise
+    int64_t s0;
+    int64_t interval;
+    int64_t W;              // windows addressable in the outputs
+    int64_t wid_base;       // global window id of output slot 0 (sharding); 0 otherwise
+    MagicDiv magic;
+    int32_t inclusive;      // effective Options.Inclusive
+    int32_t ncols;
+    int32_t naggs;
+    int32_t pre_rows;       // s0 > ts[0] (negative ts + truncating division): rows below s0 ride in window 0
+    ColDesc cols[kMaxCols];
+    AggDesc aggs[kMaxAggs];
+    // status block in device memory
+    uint32_t *status;       // [0]=unsorted flag, [1]=long-window count, [2]=overflow flag
+    int64_t *long_list;     // pairs (global window id, first row)
+    int64_t long_cap;
+};
+
+int launch_rolling_aggregate(Ctx *c, const AggParams &p);
+int launch_long_windows(Ctx *c, const AggParams &p, int64_t n_long);
+int launch_fix_tail_bits(Ctx *c, uint8_t *bitmap, int64_t nbits);
+int launch_popcount(Ctx *c, const uint32_t *words, int64_t bit0, int64_t nbits, uint64_t *d_count);
+
+// generate.hip
+int launch_gen_dense(Ctx *c, int64_t row0, int64_t n, uint64_t seed, int64_t *ts, double *val);
+int launch_gen_sparse(Ctx *c, int64_t row0, int64_t n, uint64_t seed, int64_t *ts, double *val, uint8_t *validity);
+int launch_checksum64(Ctx *c, const void *dev, int64_t n, uint64_t *d_out2);
+
+}  // namespace bowgpu

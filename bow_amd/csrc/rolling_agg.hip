@@ -1,0 +1,807 @@
+// rolling_agg.hip — the hot path: Rolling.Aggregate over an int64 interval column.
+//
+// Replaces, in one pass, reference rolling/rolling.go:177-239 (intervalRolling.Next: the
+// sequential interval-bucketing scan), rolling/aggregation.go:190-238 (aggregateWindows: one
+// full scan per aggregator) and the reducer closures of rolling/aggregation/*.go.
+//
+// Data-parallel restatement: for an ascending, non-null interval column the
+// scan is  wid(i) = (ts[i] - s0) div interval ; window k = the run of rows with wid == k.
+// Row i is a *head* when wid(i) != wid(i-1).  A workgroup owns the windows whose head lies in
+// its TILE of rows and walks each of them with ONE lane, in row order, so Sum / Mean /
+// Integral are accumulated in exactly the reference's left-to-right order (bit-exact).
+//
+// Per workgroup (256 threads = 4 wavefronts of 64):
+//   1. coalesced 16-B/lane loads of ts (+ the first value column) for TILE+HALO rows,
+//   2. wid by an exact multiply-high division (no 64-bit divide in the loop),
+//      head flags via ballot / mbcnt, compaction of the heads into an LDS segment list,
+//   3. per value column: values (+ validity words) staged in LDS, lane q walks segment q,
+//   4. outputs: 8-B coalesced stores (lane q -> window slot wid(q)); validity bits are
+//      assembled in an LDS bitmap and flushed as whole words (atomicOr only on the two
+//      boundary words shared with the neighbouring tiles).
+// Windows whose rows run past TILE+HALO are queued for long_window_kernel (cooperative,
+// fixed-shape tree order: Sum/Mean/Integral within 1e-12 relative; the rest bit-exact).
+//
+// HBM-bound: algorithmic bytes = 8 (ts) + 8 per value column (+1/8 per nullable column) per row.
+// Nothing here is a contraction, so no MFMA.
+
+#include "common.h"
+
+namespace bowgpu {
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kTile = 2048;                // rows owned by a workgroup
+constexpr int kHalo = 128;                 // look-ahead rows (one 16-B/lane load of wave 0)
+constexpr int kRows = kTile + kHalo;
+constexpr int kChunks = kTile / (2 * kBlock);  // 4 chunks of 512 rows, 2 rows per lane each
+constexpr int kCnt = kChunks * 4 + 1;      // (chunk, wave) head counters + halo
+constexpr int kSpanBits = 2048 + 64;       // output-validity bits assembled in LDS per tile
+constexpr int kSpanWords = kSpanBits / 32;
+constexpr int kMaxNullable = 8;            // nullable reducers per column pass
+constexpr int kGapInline = 4;
+constexpr int kGapList = 64;
+constexpr uint32_t kSat = 0xFFFFFFFFu;
+
+__device__ __forceinline__ uint64_t magic_div(uint64_t n, const MagicDiv &d) {
+    uint64_t t = __umul64hi(d.m, n);
+    return (t + ((n - t) >> d.sh1)) >> d.sh2;
+}
+
+// Go's float64 -> int64 conversion on amd64 (CVTTSD2SI): NaN / out of range => INT64_MIN.
+__device__ __forceinline__ int64_t go_f64_to_i64(double x) {
+    if (!(x >= -9223372036854775808.0 && x < 9223372036854775808.0)) return INT64_MIN;
+    return (int64_t)x;
+}
+
+__device__ __forceinline__ double bits_to_f64(uint64_t b, int type) {
+    // Bow.GetFloat64: bowgetters.go:224-229 (Int64 columns convert per element)
+    return type == BOWGPU_FLOAT64 ? __longlong_as_double((long long)b) : (double)(int64_t)b;
+}
+
+// ---------------------------------------------------------------- running state of a window
+struct Stats {
+    double sum;          // sum.go:16-22 / arithmeticmean.go:17-24
+    double vmin, vmax;   // minmax.go:16-28 / :41-53 (seeded by the first valid value)
+    double nn_min, nn_max;  // NaN-ignoring extrema, only used when partial states are merged
+    uint64_t first_bits, last_bits;  // firstlast.go
+    int64_t count;       // count.go / mean
+    // integrals (integral.go): previous both-valid point and running sums
+    double pt, pv, first_pt, first_pv;
+    double integ_step, integ_trap;
+    int has_value;
+    int has_nn;
+    int has_point;
+    int has_pair;
+};
+
+__device__ __forceinline__ void stats_init(Stats &s) {
+    s.sum = 0.0; s.vmin = 0.0; s.vmax = 0.0; s.nn_min = 0.0; s.nn_max = 0.0;
+    s.first_bits = 0; s.last_bits = 0; s.count = 0;
+    s.pt = 0.0; s.pv = 0.0; s.first_pt = 0.0; s.first_pv = 0.0; s.integ_step = 0.0; s.integ_trap = 0.0;
+    s.has_value = 0; s.has_nn = 0; s.has_point = 0; s.has_pair = 0;
+}
+
+// one valid value, in row order
+template <bool kMerge>
+__device__ __forceinline__ void stats_value(Stats &s, double x, uint64_t raw) {
+    s.sum += x;
+    s.count++;
+    if (s.has_value) {
+        if (x < s.vmin) s.vmin = x;
+        if (x > s.vmax) s.vmax = x;
+    } else {
+        s.vmin = x; s.vmax = x; s.first_bits = raw; s.has_value = 1;
+    }
+    s.last_bits = raw;
+    if (kMerge) {
+        if (x == x) {
+            if (!s.has_nn) { s.nn_min = x; s.nn_max = x; s.has_nn = 1; }
+            else { if (x < s.nn_min) s.nn_min = x; if (x > s.nn_max) s.nn_max = x; }
+        }
+    }
+}
+
+// one both-valid (t, v) point, in row order (integral.go:14-31, :46-62)
+__device__ __forceinline__ void stats_point(Stats &s, double t, double v) {
+    if (s.has_point) {
+        s.integ_trap += (s.pv + v) / 2 * (t - s.pt);
+        s.integ_step += s.pv * (t - s.pt);
+        s.has_pair = 1;
+    } else {
+        s.first_pt = t; s.first_pv = v; s.has_point = 1;
+    }
+    s.pt = t; s.pv = v;
+}
+
+// merge R (later rows) into L (earlier rows): used by the cooperative long-window path only
+__device__ __forceinline__ void stats_merge(Stats &L, const Stats &R) {
+    if (R.has_point) {
+        if (L.has_point) {
+            L.integ_trap = L.integ_trap + (L.pv + R.first_pv) / 2 * (R.first_pt - L.pt) + R.integ_trap;
+            L.integ_step = L.integ_step + L.pv * (R.first_pt - L.pt) + R.integ_step;
+            L.has_pair = 1;
+        } else {
+            L.first_pt = R.first_pt; L.first_pv = R.first_pv; L.integ_trap = R.integ_trap;
+            L.integ_step = R.integ_step; L.has_pair = R.has_pair; L.has_point = 1;
+        }
+        L.pt = R.pt; L.pv = R.pv;
+    }
+    if (!R.has_value) return;
+    if (!L.has_value) {
+        double isum = L.integ_step, itrap = L.integ_trap;  // keep merged integral fields
+        double pt = L.pt, pv = L.pv, fpt = L.first_pt, fpv = L.first_pv;
+        int hp = L.has_point, hpair = L.has_pair;
+        L = R;
+        L.integ_step = isum; L.integ_trap = itrap; L.pt = pt; L.pv = pv; L.first_pt = fpt; L.first_pv = fpv;
+        L.has_point = hp; L.has_pair = hpair;
+        return;
+    }
+    L.sum += R.sum;
+    L.count += R.count;
+    // minmax.go semantics on the concatenation: only R's non-NaN values can replace the seed
+    if (R.has_nn) {
+        if (R.nn_min < L.vmin) L.vmin = R.nn_min;
+        if (R.nn_max > L.vmax) L.vmax = R.nn_max;
+        if (!L.has_nn) { L.nn_min = R.nn_min; L.nn_max = R.nn_max; L.has_nn = 1; }
+        else { if (R.nn_min < L.nn_min) L.nn_min = R.nn_min; if (R.nn_max > L.nn_max) L.nn_max = R.nn_max; }
+    }
+    L.last_bits = R.last_bits;
+}
+
+// ---------------------------------------------------------------- result of one reducer
+struct Val {
+    uint64_t bits;  // float64 or int64 payload
+    int valid;      // 0 => nil
+    int is_int;
+};
+
+// transformation.Factor chain (factor.go:7-20), then Buffer.SetOrDrop into a column of
+// out_type (bowbuffer.go:60-80; bowconvert.go:24-29,:59-60)
+__device__ __forceinline__ Val finish_val(Val v, const AggDesc &a) {
+    if (!v.valid) { v.bits = 0; return v; }
+    for (int f = 0; f < a.n_factors; f++) {
+        if (v.is_int) v.bits = (uint64_t)go_f64_to_i64((double)(int64_t)v.bits * a.factors[f]);
+        else v.bits = (uint64_t)__double_as_longlong(__longlong_as_double((long long)v.bits) * a.factors[f]);
+    }
+    if (a.out_type == BOWGPU_INT64 && !v.is_int) {
+        v.bits = (uint64_t)go_f64_to_i64(__longlong_as_double((long long)v.bits));
+        v.is_int = 1;
+    } else if (a.out_type == BOWGPU_FLOAT64 && v.is_int) {
+        v.bits = (uint64_t)__double_as_longlong((double)(int64_t)v.bits);
+        v.is_int = 0;
+    }
+    return v;
+}
+
+__device__ __forceinline__ Val make_f64(double x) { Val v; v.bits = (uint64_t)__double_as_longlong(x); v.valid = 1; v.is_int = 0; return v; }
+__device__ __forceinline__ Val make_i64(int64_t x) { Val v; v.bits = (uint64_t)x; v.valid = 1; v.is_int = 1; return v; }
+__device__ __forceinline__ Val make_nil() { Val v; v.bits = 0; v.valid = 0; v.is_int = 0; return v; }
+
+__device__ __forceinline__ bool kind_needs_inclusive(int kind) {
+    return kind == BOWGPU_AGG_INTEGRAL_TRAPEZOID || kind == BOWGPU_AGG_WAVG_LINEAR;
+}
+
+// The value a reducer returns for a window, from the running state over its rows.
+//   nrows      = w.Bow.NumRows() as THIS reducer sees it (after UnsetInclusive, aggregation.go:207-208)
+//   s          = state over those rows
+//   col_is_int = input column type (First/Last return the input type)
+__device__ __forceinline__ Val reduce_val(int kind, const Stats &s, int64_t nrows, int64_t win_start,
+                                          int64_t interval, int col_is_int) {
+    switch (kind) {
+    case BOWGPU_AGG_WINDOW_START: return make_i64(win_start);                       // windowstart.go:11
+    case BOWGPU_AGG_NUM_ROWS: return make_f64((double)nrows);
+    case BOWGPU_AGG_SUM: return make_f64(nrows == 0 ? 0.0 : s.sum);                 // sum.go:11-24
+    case BOWGPU_AGG_MEAN:                                                          // arithmeticmean.go:11-29
+        if (nrows == 0 || s.count == 0) return make_nil();
+        return make_f64(s.sum / (double)s.count);
+    case BOWGPU_AGG_MIN: return s.has_value ? make_f64(s.vmin) : make_nil();        // minmax.go:11-30
+    case BOWGPU_AGG_MAX: return s.has_value ? make_f64(s.vmax) : make_nil();
+    case BOWGPU_AGG_COUNT: return make_i64(s.count);                                // count.go:11-19
+    case BOWGPU_AGG_FIRST:                                                         // firstlast.go:11-20
+        if (!s.has_value) return make_nil();
+        { Val v; v.bits = s.first_bits; v.valid = 1; v.is_int = col_is_int; return v; }
+    case BOWGPU_AGG_LAST:
+        if (!s.has_value) return make_nil();
+        { Val v; v.bits = s.last_bits; v.valid = 1; v.is_int = col_is_int; return v; }
+    case BOWGPU_AGG_INTEGRAL_STEP:                                                 // integral.go:43-68
+    case BOWGPU_AGG_WAVG_STEP: {                                                   // weightedmean.go:11-19
+        if (!s.has_point) return make_nil();
+        int64_t last_value = win_start + interval;
+        double r = s.integ_step + s.pv * ((double)last_value - s.pt);
+        if (kind == BOWGPU_AGG_WAVG_STEP) r = r / (double)(last_value - win_start);
+        return make_f64(r);
+    }
+    case BOWGPU_AGG_INTEGRAL_TRAPEZOID:                                            // integral.go:11-37
+    case BOWGPU_AGG_WAVG_LINEAR: {                                                 // weightedmean.go:25-33
+        if (!s.has_pair) return make_nil();
+        double r = s.integ_trap;
+        if (kind == BOWGPU_AGG_WAVG_LINEAR) r = r / (double)((win_start + interval) - win_start);
+        return make_f64(r);
+    }
+    default: return make_nil();
+    }
+}
+
+__device__ __forceinline__ bool kind_is_integral(int kind) {
+    return kind >= BOWGPU_AGG_INTEGRAL_STEP && kind <= BOWGPU_AGG_WAVG_LINEAR;
+}
+
+// ---------------------------------------------------------------- loads
+__device__ __forceinline__ void load_pair(const uint64_t *__restrict__ p, int64_t g, int64_t n, bool vec,
+                                          uint64_t &a, uint64_t &b) {
+    if (vec && g + 1 < n) {
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(p + g);
+        a = v.x; b = v.y;
+    } else {
+        a = g < n ? p[g] : 0;
+        b = g + 1 < n ? p[g + 1] : 0;
+    }
+}
+
+// 32 validity bits starting at logical row `row` of a column
+__device__ __forceinline__ uint32_t load_vbits32(const ColDesc &c, int64_t row) {
+    int64_t bit = c.vbit0 + row;
+    int64_t wi = bit >> 5;
+    int sh = (int)(bit & 31);
+    uint32_t lo = wi < c.vwords ? c.vbits[wi] : 0u;
+    if (sh == 0) return lo;
+    uint32_t hi = wi + 1 < c.vwords ? c.vbits[wi + 1] : 0u;
+    return (lo >> sh) | (hi << (32 - sh));
+}
+
+struct TileShared {
+    uint64_t val[kRows];
+    uint32_t seg_wid[kRows + 2];   // window id - wid0 (kSat => recompute from ts)
+    uint16_t seg_row[kRows + 2];   // local head row | (at-window-start << 15)
+    uint32_t vbits[kRows / 32 + 2];
+    uint32_t obits[kMaxNullable][kSpanWords];
+    int cnt[kCnt + 1];
+    int gap_q[kGapList];
+    int gap_n;
+    unsigned long long wid0;
+};
+
+template <bool kWithTs>
+struct TileSharedTs : TileShared {
+    double tsf[kWithTs ? kRows : 1];
+};
+
+}  // namespace
+
+// ---------------------------------------------------------------- the tile kernel
+template <bool kWithTs>
+__global__ __launch_bounds__(kBlock) void rolling_agg_kernel(const AggParams p, const int64_t ntiles,
+                                                             const int64_t tiles_per_xcd) {
+    __shared__ TileSharedTs<kWithTs> sh;
+
+    // XCD-aware tile mapping: workgroups are dealt round-robin over the 8 XCDs, so give every
+    // XCD a contiguous run of tiles (a tile's halo is its right neighbour's first rows: same L2).
+    const int64_t b = blockIdx.x;
+    const int64_t tile = (b & 7) * tiles_per_xcd + (b >> 3);
+    if (tile >= ntiles) return;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int64_t base = tile * kTile;
+    const int64_t n = p.n;
+    const uint64_t *__restrict__ ts = reinterpret_cast<const uint64_t *>(p.ts);
+    const bool ts_vec = (reinterpret_cast<uintptr_t>(ts) & 15) == 0;
+
+    // ---- 1. loads: ts for 4 chunks (+halo), first value column right behind them
+    uint64_t ta[kChunks + 1], tb[kChunks + 1];
+#pragma unroll
+    for (int j = 0; j < kChunks; j++) load_pair(ts, base + j * 512 + 2 * tid, n, ts_vec, ta[j], tb[j]);
+    ta[kChunks] = 0; tb[kChunks] = 0;
+    if (wave == 0) load_pair(ts, base + kTile + 2 * tid, n, ts_vec, ta[kChunks], tb[kChunks]);
+
+    uint64_t va[kChunks + 1], vb[kChunks + 1];
+    int staged_slot = -1;
+    if (p.ncols > 0 && p.cols[0].values != nullptr) {
+        const uint64_t *vp = reinterpret_cast<const uint64_t *>(p.cols[0].values);
+        const bool vvec = (reinterpret_cast<uintptr_t>(vp) & 15) == 0;
+#pragma unroll
+        for (int j = 0; j < kChunks; j++) load_pair(vp, base + j * 512 + 2 * tid, n, vvec, va[j], vb[j]);
+        va[kChunks] = 0; vb[kChunks] = 0;
+        if (wave == 0) load_pair(vp, base + kTile + 2 * tid, n, vvec, va[kChunks], vb[kChunks]);
+        staged_slot = 0;
+    }
+
+    // previous row's ts for lane 0 of each wave (one extra 8-B load per wave per chunk; L2/L1 hit)
+    // ---- 2. window ids, head flags, compaction
+    unsigned long long mask_a[kChunks + 1], mask_b[kChunks + 1];
+    uint64_t wid_a[kChunks + 1], wid_b[kChunks + 1];
+    int flag_a[kChunks + 1], flag_b[kChunks + 1];  // at-window-start
+    bool unsorted = false;
+#pragma unroll
+    for (int j = 0; j <= kChunks; j++) {
+        const bool active = (j < kChunks) || (wave == 0);
+        const int64_t l = (j < kChunks) ? (j * 512 + 2 * tid) : (kTile + 2 * tid);
+        const int64_t g = base + l;
+        const bool pa = active && g < n, pb = active && g + 1 < n;
+        const int64_t tsa = (int64_t)ta[j], tsb = (int64_t)tb[j];
+        // previous row
+        int64_t prev = (int64_t)__shfl_up((unsigned long long)tb[j], 1);
+        if (lane == 0 && pa && g > 0) prev = (int64_t)ts[g - 1];
+        // Rows below s0 exist only when Go's truncating division put s0 above a negative ts[0]
+        // (rolling.go:96-99); the reference's scan skips-but-spans them (rolling.go:194-196), so
+        // they ride in window 0.
+        const uint64_t wa = tsa < p.s0 ? 0 : magic_div((uint64_t)tsa - (uint64_t)p.s0, p.magic);
+        const uint64_t wb = tsb < p.s0 ? 0 : magic_div((uint64_t)tsb - (uint64_t)p.s0, p.magic);
+        const int64_t wsa = p.s0 + (int64_t)(wa * (uint64_t)p.interval);
+        const int64_t wsb = p.s0 + (int64_t)(wb * (uint64_t)p.interval);
+        const bool ha = pa && (g == 0 || (prev < wsa && (prev >= p.s0 || wa != 0)));
+        const bool hb = pb && (tsa < wsb && (tsa >= p.s0 || wb != 0));
+        if (pa && g > 0 && prev > tsa) unsorted = true;
+        if (pb && tsa > tsb) unsorted = true;
+        wid_a[j] = wa; wid_b[j] = wb;
+        flag_a[j] = (tsa == wsa); flag_b[j] = (tsb == wsb);
+        mask_a[j] = __ballot(ha);
+        mask_b[j] = __ballot(hb);
+        if (kWithTs) {
+            if (pa) sh.tsf[l] = (double)tsa;        // float64(ts): lossy above 2^53, as in the reference
+            if (pb) sh.tsf[l + 1] = (double)tsb;
+        }
+        if (lane == 0 && active) {
+            const int slot = (j < kChunks) ? (j * 4 + wave) : (kChunks * 4);
+            sh.cnt[slot] = __popcll(mask_a[j]) + __popcll(mask_b[j]);
+        }
+    }
+    if (tid == 0) { sh.wid0 = wid_a[0]; sh.gap_n = 0; }
+    if (unsorted) atomicOr(&p.status[0], 1u);
+    __syncthreads();
+
+    const uint64_t wid0 = sh.wid0;
+    int nseg_owned = 0, nseg_total = 0;
+    {
+        int run = 0;
+#pragma unroll
+        for (int k = 0; k < kCnt; k++) {
+            if (k == kChunks * 4) nseg_owned = run;
+            run += sh.cnt[k];
+        }
+        nseg_total = run;
+    }
+#pragma unroll
+    for (int j = 0; j <= kChunks; j++) {
+        const bool active = (j < kChunks) || (wave == 0);
+        if (!active) continue;
+        const int slot = (j < kChunks) ? (j * 4 + wave) : (kChunks * 4);
+        int pos = 0;
+        for (int k = 0; k < slot; k++) pos += sh.cnt[k];
+        const unsigned lo_a = (unsigned)mask_a[j], hi_a = (unsigned)(mask_a[j] >> 32);
+        const unsigned lo_b = (unsigned)mask_b[j], hi_b = (unsigned)(mask_b[j] >> 32);
+        pos += __builtin_amdgcn_mbcnt_hi(hi_a, __builtin_amdgcn_mbcnt_lo(lo_a, 0));
+        pos += __builtin_amdgcn_mbcnt_hi(hi_b, __builtin_amdgcn_mbcnt_lo(lo_b, 0));
+        const int l = (j < kChunks) ? (j * 512 + 2 * tid) : (kTile + 2 * tid);
+        const bool ha = (mask_a[j] >> lane) & 1, hb = (mask_b[j] >> lane) & 1;
+        if (ha) {
+            const uint64_t d = wid_a[j] - wid0;
+            sh.seg_row[pos] = (uint16_t)(l | (flag_a[j] << 15));
+            sh.seg_wid[pos] = d >= kSat ? kSat : (uint32_t)d;
+            pos++;
+        }
+        if (hb) {
+            const uint64_t d = wid_b[j] - wid0;
+            sh.seg_row[pos] = (uint16_t)((l + 1) | (flag_b[j] << 15));
+            sh.seg_wid[pos] = d >= kSat ? kSat : (uint32_t)d;
+        }
+    }
+    // (seg arrays are read after the staging barrier below)
+
+    const int64_t rows_here = (n - base) < kRows ? (n - base) : kRows;  // local rows that exist
+    const bool reaches_end = base + kRows >= n;
+    const int64_t wid_end = p.wid_base + p.W;  // one past the last addressable window
+
+    auto seg_wid_of = [&](int q) -> uint64_t {
+        const uint32_t d = sh.seg_wid[q];
+        if (d != kSat) return wid0 + d;
+        const int64_t t = p.ts[base + (sh.seg_row[q] & 0x7FFF)];
+        return magic_div((uint64_t)t - (uint64_t)p.s0, p.magic);
+    };
+
+    // ---- 3./4. one pass per column slot (-1 = reducers that read no column values)
+    bool first_pass = true;
+    for (int slot = -1; slot < p.ncols; slot++) {
+        // which aggregators belong to this pass? (bitmask over p.aggs: no private arrays)
+        unsigned my_mask = 0;
+        bool any_nullable = false, any_incl = false, need_vals = false;
+        for (int a = 0; a < p.naggs; a++) {
+            if (p.aggs[a].slot != slot) continue;
+            my_mask |= 1u << a;
+            any_nullable |= (p.aggs[a].out_valid != nullptr);
+            any_incl |= kind_needs_inclusive(p.aggs[a].kind);
+            const int k = p.aggs[a].kind;
+            need_vals |= !(k == BOWGPU_AGG_WINDOW_START || k == BOWGPU_AGG_NUM_ROWS);
+        }
+        if (my_mask == 0) continue;
+
+        const ColDesc *cd = slot >= 0 ? &p.cols[slot] : nullptr;
+        const bool has_nulls = cd && cd->vbits != nullptr;
+        const int col_type = cd ? cd->type : BOWGPU_INT64;
+
+        __syncthreads();  // previous pass finished reading sh.val / sh.vbits / sh.obits / sh.gap_*
+        if (tid == 0) sh.gap_n = 0;
+        if (cd && need_vals) {
+            if (staged_slot != slot) {
+                const uint64_t *vp = reinterpret_cast<const uint64_t *>(cd->values);
+                const bool vvec = (reinterpret_cast<uintptr_t>(vp) & 15) == 0;
+#pragma unroll
+                for (int j = 0; j < kChunks; j++) load_pair(vp, base + j * 512 + 2 * tid, n, vvec, va[j], vb[j]);
+                if (wave == 0) load_pair(vp, base + kTile + 2 * tid, n, vvec, va[kChunks], vb[kChunks]);
+            }
+#pragma unroll
+            for (int j = 0; j < kChunks; j++) {
+                sh.val[j * 512 + 2 * tid] = va[j];
+                sh.val[j * 512 + 2 * tid + 1] = vb[j];
+            }
+            if (wave == 0) { sh.val[kTile + 2 * tid] = va[kChunks]; sh.val[kTile + 2 * tid + 1] = vb[kChunks]; }
+            staged_slot = -2;
+            if (has_nulls && tid < kRows / 32) sh.vbits[tid] = load_vbits32(*cd, base + 32 * (int64_t)tid);
+        }
+        if (any_nullable)
+            for (int i = tid; i < kMaxNullable * kSpanWords; i += kBlock) (&sh.obits[0][0])[i] = 0u;
+        __syncthreads();
+
+        // window slot range this tile flushes through LDS: [span0, span0 + kSpanBits)
+        const uint64_t wid_first = nseg_owned > 0 ? seg_wid_of(0) : 0;
+        const int64_t slot_first = (int64_t)(wid_first - (uint64_t)p.wid_base);
+        const int64_t span0 = slot_first & ~(int64_t)31;
+
+        for (int q = tid; q < nseg_owned; q += kBlock) {
+            const int r0 = sh.seg_row[q] & 0x7FFF;
+            const uint64_t wid = seg_wid_of(q);
+            int r1;
+            uint64_t next_wid;
+            bool next_at_start = false;
+            bool complete = true;
+            if (q + 1 < nseg_total) {
+                r1 = sh.seg_row[q + 1] & 0x7FFF;
+                next_at_start = (sh.seg_row[q + 1] >> 15) & 1;
+                next_wid = seg_wid_of(q + 1);
+            } else if (reaches_end) {
+                r1 = (int)rows_here;
+                next_wid = (uint64_t)wid_end;
+            } else {
+                complete = false; r1 = r0; next_wid = wid + 1;
+            }
+            if (!complete) {
+                // rows run past the halo: hand the window (all its column passes) to the cooperative path
+                if (!first_pass) continue;
+                const unsigned idx = atomicAdd(&p.status[1], 1u);
+                if ((int64_t)idx < p.long_cap) {
+                    p.long_list[2 * idx] = (int64_t)wid;
+                    p.long_list[2 * idx + 1] = base + r0;
+                } else {
+                    atomicOr(&p.status[2], 1u);
+                }
+                continue;
+            }
+            const bool incl_row = p.inclusive && (q + 1 < nseg_total) && next_at_start && next_wid == wid + 1;
+            // window 0 made only of rows below s0 is an empty slice in the reference (lastRowIndex stays -1)
+            const bool dead = p.pre_rows && tile == 0 && q == 0 && !(p.ts[base + r1 - 1] >= p.s0 || incl_row);
+
+            // ---- sequential walk of rows [r0, r1) (+ the inclusive row)
+            Stats st;
+            stats_init(st);
+            Stats st_incl;  // state including the inclusive row, for reducers that need it
+            if (need_vals && !dead) {
+                for (int r = r0; r < r1; r++) {
+                    const bool ok = !has_nulls || ((sh.vbits[r >> 5] >> (r & 31)) & 1u);
+                    if (!ok) continue;
+                    const uint64_t raw = sh.val[r];
+                    const double x = bits_to_f64(raw, col_type);
+                    stats_value<false>(st, x, raw);
+                    if (kWithTs) stats_point(st, sh.tsf[r], x);
+                }
+                st_incl = st;
+                if (any_incl && incl_row) {
+                    const int r = r1;
+                    const bool ok = !has_nulls || ((sh.vbits[r >> 5] >> (r & 31)) & 1u);
+                    if (ok) {
+                        const uint64_t raw = sh.val[r];
+                        const double x = bits_to_f64(raw, col_type);
+                        stats_value<false>(st_incl, x, raw);
+                        if (kWithTs) stats_point(st_incl, sh.tsf[r], x);
+                    }
+                }
+            } else {
+                st_incl = st;
+            }
+            const int64_t win_start = p.s0 + (int64_t)(wid * (uint64_t)p.interval);
+            const int64_t oslot = (int64_t)(wid - (uint64_t)p.wid_base);
+            const int64_t nrows = dead ? 0 : r1 - r0;
+            const int64_t gap = (int64_t)(next_wid - wid) - 1;
+            const bool big_gap = gap > kGapInline;
+            if (big_gap) {
+                const int gi = atomicAdd(&sh.gap_n, 1);
+                if (gi < kGapList) sh.gap_q[gi] = q;
+            }
+            if (oslot >= 0 && oslot < p.W) {
+                int nb = 0;
+                for (unsigned m = my_mask; m; m &= m - 1) {
+                    const AggDesc &a = p.aggs[__ffs(m) - 1];
+                    const bool inc = kind_needs_inclusive(a.kind);
+                    Val v = reduce_val(a.kind, inc ? st_incl : st, inc ? nrows + (incl_row ? 1 : 0) : nrows,
+                                       win_start, p.interval, col_type == BOWGPU_INT64);
+                    v = finish_val(v, a);
+                    reinterpret_cast<uint64_t *>(a.out_values)[oslot] = v.bits;
+                    if (a.out_valid) {
+                        if (v.valid) {
+                            const int64_t lb = oslot - span0;
+                            if (lb >= 0 && lb < kSpanBits) atomicOr(&sh.obits[nb][lb >> 5], 1u << (lb & 31));
+                            else atomicOr(&a.out_valid[oslot >> 5], 1u << (oslot & 31));
+                        }
+                        nb++;
+                    }
+                }
+                // small gaps: the empty windows right after this one (A.9 "Empty slice" column)
+                if (gap > 0 && (!big_gap)) {
+                    Stats e;
+                    stats_init(e);
+                    for (int64_t gk = 1; gk <= gap; gk++) {
+                        const int64_t gs = oslot + gk;
+                        if (gs >= p.W) break;
+                        const int64_t gstart = win_start + gk * p.interval;
+                        for (unsigned m = my_mask; m; m &= m - 1) {
+                            const AggDesc &a = p.aggs[__ffs(m) - 1];
+                            Val v = finish_val(reduce_val(a.kind, e, 0, gstart, p.interval, col_type == BOWGPU_INT64), a);
+                            reinterpret_cast<uint64_t *>(a.out_values)[gs] = v.bits;
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- big gaps (sparse data): the whole workgroup writes the empty windows, coalesced
+        const int n_gaps = sh.gap_n;
+        if (n_gaps > 0) {
+            const bool overflow = n_gaps > kGapList;
+            const int n_iter = overflow ? nseg_owned : n_gaps;
+            for (int gi = 0; gi < n_iter; gi++) {
+                const int q = overflow ? gi : sh.gap_q[gi];
+                if (q + 1 >= nseg_total && !reaches_end) continue;
+                const uint64_t wid = seg_wid_of(q);
+                const uint64_t next_wid = (q + 1 < nseg_total) ? seg_wid_of(q + 1) : (uint64_t)wid_end;
+                const int64_t gap = (int64_t)(next_wid - wid) - 1;
+                if (gap <= kGapInline) continue;
+                const int64_t oslot = (int64_t)(wid - (uint64_t)p.wid_base);
+                const int64_t win_start = p.s0 + (int64_t)(wid * (uint64_t)p.interval);
+                Stats e;
+                stats_init(e);
+                for (int64_t gk = 1 + tid; gk <= gap; gk += kBlock) {
+                    const int64_t gs = oslot + gk;
+                    if (gs < 0 || gs >= p.W) break;
+                    const int64_t gstart = win_start + gk * p.interval;
+                    for (unsigned m = my_mask; m; m &= m - 1) {
+                        const AggDesc &a = p.aggs[__ffs(m) - 1];
+                        Val v = finish_val(reduce_val(a.kind, e, 0, gstart, p.interval, col_type == BOWGPU_INT64), a);
+                        reinterpret_cast<uint64_t *>(a.out_values)[gs] = v.bits;
+                    }
+                }
+            }
+        }
+
+        // ---- flush the validity bits assembled in LDS
+        if (any_nullable && nseg_owned > 0) {
+            // bits [slot_first, slot_end) are this tile's to define (later ones belong to other
+            // tiles or to the long-window path); whole words inside are stored, the rest OR-ed.
+            int64_t slot_end;
+            {
+                const int ql = nseg_owned - 1;
+                if (ql + 1 < nseg_total) slot_end = (int64_t)(seg_wid_of(ql + 1) - (uint64_t)p.wid_base);
+                else if (reaches_end) slot_end = p.W;
+                else slot_end = (int64_t)(seg_wid_of(ql) - (uint64_t)p.wid_base);  // long window: not ours
+            }
+            if (slot_end > p.W) slot_end = p.W;
+            int64_t lim = slot_end - span0;
+            if (lim > kSpanBits) lim = kSpanBits;
+            const int nwords = (int)((lim + 31) >> 5);
+            int nb = 0;
+            for (unsigned m = my_mask; m; m &= m - 1) {
+                const AggDesc &a = p.aggs[__ffs(m) - 1];
+                if (!a.out_valid) continue;
+                for (int w = tid; w < nwords; w += kBlock) {
+                    const uint32_t bits = sh.obits[nb][w];
+                    const int64_t gw = (span0 >> 5) + w;
+                    const int64_t wlo = gw << 5, whi = wlo + 32;
+                    if (gw < 0 || wlo >= p.W) continue;  // only reachable on unsorted input
+                    const bool whole = wlo >= slot_first && whi <= slot_end;
+                    if (whole) a.out_valid[gw] = bits;
+                    else if (bits) atomicOr(&a.out_valid[gw], bits);
+                }
+                nb++;
+            }
+        }
+        first_pass = false;
+    }
+}
+
+// ---------------------------------------------------------------- cooperative long windows
+// One workgroup per queued window: thread t walks a contiguous 1/256th of the rows in row
+// order, the 256 partial states are merged in thread order.  Deterministic, but Sum / Mean /
+// Integral are no longer accumulated strictly left to right (|err| <= 1e-12 relative).
+__global__ __launch_bounds__(kBlock) void long_window_kernel(const AggParams p, const int64_t n_long) {
+    __shared__ Stats part[kBlock];
+    __shared__ int64_t s_end;
+    const int tid = threadIdx.x;
+    const int64_t wid_end = p.wid_base + p.W;
+
+    for (int64_t e = blockIdx.x; e < n_long; e += gridDim.x) {
+        const uint64_t wid = (uint64_t)p.long_list[2 * e];
+        const int64_t r0 = p.long_list[2 * e + 1];
+        const int64_t win_start = p.s0 + (int64_t)(wid * (uint64_t)p.interval);
+        if (tid == 0) {
+            // first row >= r0 with ts >= win_start + interval (rolling.go:197-209), by bisection
+            int64_t lo = r0 + 1, hi = p.n;
+            const int64_t lim = win_start + p.interval;
+            const bool ovf = lim < win_start;  // int64 overflow: no row can reach it
+            while (lo < hi && !ovf) {
+                const int64_t mid = lo + ((hi - lo) >> 1);
+                if (p.ts[mid] >= lim) hi = mid; else lo = mid + 1;
+            }
+            s_end = ovf ? p.n : lo;
+        }
+        __syncthreads();
+        const int64_t r1 = s_end;
+        uint64_t next_wid = (uint64_t)wid_end;
+        bool next_at_start = false;
+        if (r1 < p.n) {
+            const int64_t t = p.ts[r1];
+            next_wid = magic_div((uint64_t)t - (uint64_t)p.s0, p.magic);
+            next_at_start = (t == p.s0 + (int64_t)(next_wid * (uint64_t)p.interval));
+        }
+        const bool incl_row = p.inclusive && r1 < p.n && next_at_start && next_wid == wid + 1;
+        const int64_t oslot = (int64_t)(wid - (uint64_t)p.wid_base);
+        const bool dead = p.pre_rows && r0 == 0 && !(p.ts[r1 - 1] >= p.s0 || incl_row);
+        const int64_t len = dead ? 0 : r1 - r0;
+        const int64_t lo_r = r0 + (len * tid) / kBlock, hi_r = r0 + (len * (tid + 1)) / kBlock;
+
+        for (int slot = -1; slot < p.ncols; slot++) {
+            unsigned my_mask = 0;
+            bool need_vals = false, need_ts = false;
+            for (int a = 0; a < p.naggs; a++) {
+                if (p.aggs[a].slot != slot) continue;
+                my_mask |= 1u << a;
+                const int k = p.aggs[a].kind;
+                need_vals |= !(k == BOWGPU_AGG_WINDOW_START || k == BOWGPU_AGG_NUM_ROWS);
+                need_ts |= kind_is_integral(k);
+            }
+            if (my_mask == 0) continue;
+            const ColDesc *cd = slot >= 0 ? &p.cols[slot] : nullptr;
+            const int col_type = cd ? cd->type : BOWGPU_INT64;
+            Stats st;
+            stats_init(st);
+            if (cd && need_vals) {
+                const uint64_t *vp = reinterpret_cast<const uint64_t *>(cd->values);
+                for (int64_t r = lo_r; r < hi_r; r++) {
+                    if (cd->vbits) {
+                        const int64_t bit = cd->vbit0 + r;
+                        if (!((cd->vbits[bit >> 5] >> (bit & 31)) & 1u)) continue;
+                    }
+                    const uint64_t raw = vp[r];
+                    const double x = bits_to_f64(raw, col_type);
+                    stats_value<true>(st, x, raw);
+                    if (need_ts) stats_point(st, (double)p.ts[r], x);
+                }
+            }
+            __syncthreads();
+            part[tid] = st;
+            __syncthreads();
+            if (tid == 0) {
+                Stats acc = part[0];
+                for (int t = 1; t < kBlock; t++) stats_merge(acc, part[t]);
+                Stats acc_incl = acc;
+                if (incl_row && cd && need_vals) {
+                    bool ok = true;
+                    if (cd->vbits) {
+                        const int64_t bit = cd->vbit0 + r1;
+                        ok = (cd->vbits[bit >> 5] >> (bit & 31)) & 1u;
+                    }
+                    if (ok) {
+                        const uint64_t raw = reinterpret_cast<const uint64_t *>(cd->values)[r1];
+                        const double x = bits_to_f64(raw, col_type);
+                        Stats one;
+                        stats_init(one);
+                        stats_value<true>(one, x, raw);
+                        stats_point(one, (double)p.ts[r1], x);
+                        stats_merge(acc_incl, one);
+                    }
+                }
+                if (oslot >= 0 && oslot < p.W) {
+                    for (unsigned m = my_mask; m; m &= m - 1) {
+                        const AggDesc &a = p.aggs[__ffs(m) - 1];
+                        const bool inc = kind_needs_inclusive(a.kind);
+                        Val v = reduce_val(a.kind, inc ? acc_incl : acc, inc ? len + (incl_row ? 1 : 0) : len,
+                                           win_start, p.interval, col_type == BOWGPU_INT64);
+                        v = finish_val(v, a);
+                        reinterpret_cast<uint64_t *>(a.out_values)[oslot] = v.bits;
+                        if (a.out_valid && v.valid) atomicOr(&a.out_valid[oslot >> 5], 1u << (oslot & 31));
+                    }
+                }
+            }
+            // empty windows after this one
+            const int64_t gap = (int64_t)(next_wid - wid) - 1;
+            Stats em;
+            stats_init(em);
+            for (int64_t gk = 1 + tid; gk <= gap; gk += kBlock) {
+                const int64_t gs = oslot + gk;
+                if (gs < 0 || gs >= p.W) break;
+                const int64_t gstart = win_start + gk * p.interval;
+                for (unsigned m = my_mask; m; m &= m - 1) {
+                    const AggDesc &a = p.aggs[__ffs(m) - 1];
+                    Val v = finish_val(reduce_val(a.kind, em, 0, gstart, p.interval, col_type == BOWGPU_INT64), a);
+                    reinterpret_cast<uint64_t *>(a.out_values)[gs] = v.bits;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------- small helpers
+__global__ void fix_tail_bits_kernel(uint8_t *bitmap, int64_t nbits) {
+    // Arrow/bow leave the padding bits of the last byte clear (bowbuffer.go:25, bitutil.SetBit)
+    if (threadIdx.x == 0 && blockIdx.x == 0 && (nbits & 7)) bitmap[nbits >> 3] &= (uint8_t)((1u << (nbits & 7)) - 1u);
+}
+
+__global__ __launch_bounds__(256) void popcount_kernel(const uint32_t *words, int64_t bit0, int64_t nbits,
+                                                       unsigned long long *out) {
+    // counts set bits in [bit0, bit0+nbits)
+    const int64_t w0 = bit0 >> 5, w1 = (bit0 + nbits + 31) >> 5;
+    unsigned long long acc = 0;
+    for (int64_t w = w0 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; w < w1; w += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t x = words[w];
+        const int64_t lo = w << 5;
+        if (lo < bit0) x &= ~0u << (bit0 - lo);
+        if (lo + 32 > bit0 + nbits) { const int keep = (int)(bit0 + nbits - lo); x &= keep >= 32 ? ~0u : ((1u << keep) - 1u); }
+        acc += __popc(x);
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
+}
+
+int launch_rolling_aggregate(Ctx *c, const AggParams &p) {
+    if (p.n <= 0) return 0;
+    const int64_t ntiles = (p.n + kTile - 1) / kTile;
+    const int64_t per_xcd = (ntiles + 7) / 8;
+    const int64_t grid = per_xcd * 8;
+    if (grid > 0x7FFFFFFFll) return fail(BOWGPU_ERR_UNSUPPORTED, "too many rows for one launch: %lld", (long long)p.n);
+    bool with_ts = false;
+    for (int a = 0; a < p.naggs; a++) with_ts |= (p.aggs[a].kind >= BOWGPU_AGG_INTEGRAL_STEP && p.aggs[a].kind <= BOWGPU_AGG_WAVG_LINEAR);
+    if (with_ts) hipLaunchKernelGGL(rolling_agg_kernel<true>, dim3((unsigned)grid), dim3(kBlock), 0, c->stream, p, ntiles, per_xcd);
+    else hipLaunchKernelGGL(rolling_agg_kernel<false>, dim3((unsigned)grid), dim3(kBlock), 0, c->stream, p, ntiles, per_xcd);
+    BG_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_long_windows(Ctx *c, const AggParams &p, int64_t n_long) {
+    if (n_long <= 0) return 0;
+    const unsigned grid = (unsigned)(n_long < 4096 ? n_long : 4096);
+    hipLaunchKernelGGL(long_window_kernel, dim3(grid), dim3(kBlock), 0, c->stream, p, n_long);
+    BG_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_fix_tail_bits(Ctx *c, uint8_t *bitmap, int64_t nbits) {
+    if ((nbits & 7) == 0) return 0;
+    hipLaunchKernelGGL(fix_tail_bits_kernel, dim3(1), dim3(64), 0, c->stream, bitmap, nbits);
+    BG_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_popcount(Ctx *c, const uint32_t *words, int64_t bit0, int64_t nbits, uint64_t *d_count) {
+    BG_HIP(hipMemsetAsync(d_count, 0, 8, c->stream));
+    if (nbits <= 0) return 0;
+    const int64_t nwords = (nbits + 63) / 32;
+    int64_t grid = (nwords + 255) / 256;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(popcount_kernel, dim3((unsigned)grid), dim3(256), 0, c->stream, words, bit0, nbits,
+                       reinterpret_cast<unsigned long long *>(d_count));
+    BG_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace bowgpu

@@ -1,0 +1,309 @@
+/*
+ * bowgpu.h — C ABI of the MI355X-native rolling-window aggregation path for Metronlab/bow.
+ *
+ * This is the drop-in boundary: the entry points a cgo shim inside the
+ * reference's `rolling` package would bind (INTEGRATION.md shows that shim).  Plain C99,
+ * plain pointers and sizes, no exceptions, no torch / HIP types.  Every function returns
+ * 0 on success or a negative BOWGPU_ERR_* code; bowgpu_last_error() gives the message
+ * (thread-local).  Nothing here ever falls back to a CPU implementation: if the HIP
+ * runtime or a GPU is missing the call fails with BOWGPU_ERR_NO_DEVICE.
+ *
+ * Column layout is Arrow's, exactly as bow holds it (reference bowseries.go:59-83,
+ * bowgetters.go:46-63): values = Data().Buffers()[1], validity = Data().Buffers()[0]
+ * (LSB-first bits, bit i <-> buf[i>>3] & (1<<(i&7)); NULL => all valid), both indexed
+ * from Data().Offset().  Buffers are borrowed for the duration of the call only.
+ */
+#ifndef BOWGPU_H
+#define BOWGPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BOWGPU_ABI_VERSION 1
+
+/* bow.Type (reference bowtypes.go:17-32) */
+enum {
+    BOWGPU_UNKNOWN = 0,
+    BOWGPU_FLOAT64 = 1,
+    BOWGPU_INT64 = 2,
+    BOWGPU_BOOLEAN = 3,            /* not accepted by the device path */
+    BOWGPU_STRING = 4,             /* not accepted by the device path */
+    BOWGPU_INPUT_DEPENDENT = 5,
+    BOWGPU_ITERATOR_DEPENDENT = 6
+};
+
+/* where a buffer lives */
+enum {
+    BOWGPU_HOST = 0,   /* ordinary host memory (Go heap / malloc): staged through HBM by the call */
+    BOWGPU_DEVICE = 1  /* HBM of the current device (bowgpu_malloc or any hipMalloc'd pointer) */
+};
+
+/* error codes; the Go shim maps them back to the reference's error strings */
+enum {
+    BOWGPU_OK = 0,
+    BOWGPU_ERR_INTERVAL = -1,        /* "strictly positive interval required"            rolling/rolling.go:115-117 */
+    BOWGPU_ERR_TS_TYPE = -2,         /* "impossible to create a new intervalRolling ..."  rolling/rolling.go:70-73 */
+    BOWGPU_ERR_FIRST_TS_NULL = -3,   /* "the first value of the column should be ..."     rolling/rolling.go:89-93 */
+    BOWGPU_ERR_NO_AGG = -4,          /* "at least one column aggregation is required"    rolling/aggregation.go:148-150 */
+    BOWGPU_ERR_KEEP_INTERVAL = -5,   /* "must keep interval column '%s'"                 rolling/aggregation.go:163-166 */
+    BOWGPU_ERR_BAD_COL = -6,         /* "no column '%s'"                                 bowgetters.go:323 */
+    BOWGPU_ERR_TYPE = -7,            /* type whitelist                                   rolling/interpolation.go:82-93 */
+    BOWGPU_ERR_NOT_SORTED = -8,      /* FillLinear: "refColIndex '%d' is empty or not sorted" bowfill.go:39-42 */
+    BOWGPU_ERR_UNSUPPORTED = -9,     /* input outside the device path's contract (see each function) */
+    BOWGPU_ERR_ARG = -10,
+    BOWGPU_ERR_NO_DEVICE = -11,      /* no HIP device / runtime: the product path has no CPU fallback */
+    BOWGPU_ERR_HIP = -12,            /* a HIP call failed; message has the hipError string */
+    BOWGPU_ERR_TS_NULLS = -13,       /* interval column has nulls: device path declines (caller keeps the reference path) */
+    BOWGPU_ERR_TS_UNSORTED = -14,    /* interval column not ascending: device path declines */
+    BOWGPU_ERR_OOM = -15
+};
+
+/* One Arrow array as bow holds it.  Replaces per-element Bow.GetInt64/GetFloat64/GetValue
+ * (reference bowgetters.go:155-247) with bulk buffer access. */
+typedef struct bowgpu_col {
+    const void *values;       /* int64 / float64 little-endian, 8-byte aligned */
+    const uint8_t *validity;  /* may be NULL (all valid) */
+    int64_t offset;           /* arrow Data.Offset(): slices share buffers (bow.go:279-283) */
+    int64_t length;           /* Data.Len() */
+    int64_t null_count;       /* Data.NullN(); -1 = unknown (the library counts) */
+    int32_t type;             /* BOWGPU_FLOAT64 | BOWGPU_INT64 */
+    int32_t residency;        /* BOWGPU_HOST | BOWGPU_DEVICE */
+} bowgpu_col;
+
+/* Output column: caller-owned storage for `length` slots — what bow.NewBuffer(W, typ)
+ * (bowbuffer.go:22-40) would allocate: 8*length value bytes and ceil(length/8) validity
+ * bytes.  The call fills both (null slots hold 0, as in the reference) and sets
+ * null_count so the shim can wrap them with bow.NewSeries(name, typ, data, validity)
+ * (bowseries.go:27-29). */
+typedef struct bowgpu_out {
+    void *values;
+    uint8_t *validity;
+    int64_t length;           /* in: capacity in slots (>= W); out: slots produced */
+    int64_t null_count;       /* out */
+    int32_t type;             /* out: resolved return type (rolling/aggregation.go:110-121) */
+    int32_t residency;        /* in */
+} bowgpu_out;
+
+/* Built-in reducers: one per constructor of reference rolling/aggregation/<name>.go */
+enum {
+    BOWGPU_AGG_WINDOW_START = 0,       /* windowstart.go:8-13 */
+    BOWGPU_AGG_SUM = 1,                /* sum.go:8-25 */
+    BOWGPU_AGG_MEAN = 2,               /* arithmeticmean.go:8-30 */
+    BOWGPU_AGG_MIN = 3,                /* minmax.go:8-31 */
+    BOWGPU_AGG_MAX = 4,                /* minmax.go:33-56 */
+    BOWGPU_AGG_COUNT = 5,              /* count.go:8-20 */
+    BOWGPU_AGG_FIRST = 6,              /* firstlast.go:8-21 */
+    BOWGPU_AGG_LAST = 7,               /* firstlast.go:23-36 */
+    BOWGPU_AGG_INTEGRAL_STEP = 8,      /* integral.go:40-69 */
+    BOWGPU_AGG_INTEGRAL_TRAPEZOID = 9, /* integral.go:8-38, NeedInclusiveWindow */
+    BOWGPU_AGG_WAVG_STEP = 10,         /* weightedmean.go:8-20 */
+    BOWGPU_AGG_WAVG_LINEAR = 11,       /* weightedmean.go:22-34, NeedInclusiveWindow */
+    BOWGPU_AGG_NUM_ROWS = 12,          /* float64(w.Bow.NumRows()): the closure of aggregation_test.go:28-31 */
+    BOWGPU_AGG__COUNT = 13
+};
+
+#define BOWGPU_MAX_FACTORS 4
+
+/* One rolling.ColAggregation (rolling/aggregation.go:40-50) restricted to the built-in
+ * kinds, with its transformation.Factor chain (rolling/transformation/factor.go:7-20). */
+typedef struct bowgpu_agg {
+    int32_t kind;
+    int32_t col;                         /* input column index: what SetInputIndex receives (aggregation.go:181) */
+    int32_t n_factors;                   /* 0..BOWGPU_MAX_FACTORS */
+    int32_t _pad;
+    double factors[BOWGPU_MAX_FACTORS];  /* applied in order to the reducer's result (aggregation.go:216-221) */
+} bowgpu_agg;
+
+/* rolling.Options (rolling/rolling.go:49-53); PrevRow travels with the interpolators. */
+typedef struct bowgpu_options {
+    int64_t offset;
+    int32_t inclusive;
+    int32_t _pad;
+} bowgpu_options;
+
+/* Diagnostics of one aggregate call */
+typedef struct bowgpu_agg_info {
+    int64_t s0;                 /* first window start (rolling.go:95-99) */
+    int64_t num_windows;        /* W (rolling.go:143-154) */
+    int32_t new_interval_col;   /* index of the LAST aggregator reading the interval column (aggregation.go:152-161) */
+    int32_t inclusive;          /* effective Options.Inclusive after validateAggregation (aggregation.go:183-185) */
+    int64_t long_windows;       /* windows reduced by the cooperative (non-sequential-order) path: Sum/Mean/Integral
+                                   of those are within 1e-12 relative, everything else is bit-exact */
+    double kernel_ms;           /* device time of the kernels of this call (HIP events on the library stream) */
+} bowgpu_agg_info;
+
+/* ---- library / device ------------------------------------------------------------- */
+int bowgpu_abi_version(void);
+const char *bowgpu_last_error(void);
+int bowgpu_device_count(int *count);
+int bowgpu_set_device(int device);          /* per calling thread; default device 0 */
+int bowgpu_device_name(char *buf, int cap);
+/* Use an externally owned hipStream_t (e.g. torch's current stream) for all work of this
+ * thread; NULL restores the library's own stream. */
+int bowgpu_set_stream(void *hip_stream);
+int bowgpu_synchronize(void);
+
+/* ---- HBM buffers (so callers can keep columns resident between calls) ------------- */
+int bowgpu_malloc(void **ptr, int64_t bytes);
+int bowgpu_free(void *ptr);
+int bowgpu_memcpy_h2d(void *dst, const void *src, int64_t bytes);
+int bowgpu_memcpy_d2h(void *dst, const void *src, int64_t bytes);
+int bowgpu_memset(void *dst, int value, int64_t bytes);
+
+/* ---- stream timers (HIP events on the stream the kernels are launched on) --------- */
+int bowgpu_timer_create(void **timer);
+int bowgpu_timer_start(void *timer);
+int bowgpu_timer_stop(void *timer);
+int bowgpu_timer_elapsed_ms(void *timer, double *ms); /* synchronises on the stop event */
+int bowgpu_timer_destroy(void *timer);
+
+/* ---- rolling.IntervalRolling ------------------------------------------------------- */
+
+/* enforceIntervalAndOffset — reference rolling/rolling.go:114-128 */
+int bowgpu_enforce_interval_and_offset(int64_t interval, int64_t offset, int64_t *offset_out);
+
+/* newIntervalRolling + countWindows — reference rolling/rolling.go:69-112, :143-154.
+ * `offset` is the raw Options.Offset.  Outputs the first window start and numWindows. */
+int bowgpu_plan_windows(const bowgpu_col *ts, int64_t interval, int64_t offset, int64_t *s0,
+                        int64_t *num_windows);
+
+/* Rolling.Aggregate — reference rolling/aggregation.go:123-238 (indexedAggregations,
+ * validateAggregation, aggregateWindows) fused with the reducers of rolling/aggregation/.
+ * One pass over the interval column buckets rows into windows; every aggregator of every
+ * value column is reduced in that same pass.
+ *   cols[ncols]   the Bow's columns (only those referenced by ts_col / aggs are touched)
+ *   outs[naggs]   one output column per aggregator, in aggregator order (A.7)
+ * Device-path contract: interval column Int64, no nulls, ascending (else BOWGPU_ERR_TS_NULLS /
+ * BOWGPU_ERR_TS_UNSORTED: the caller keeps the reference's own path); value columns
+ * Float64 or Int64. */
+int bowgpu_rolling_aggregate(const bowgpu_col *cols, int32_t ncols, int32_t ts_col,
+                             int64_t interval, const bowgpu_options *opts,
+                             const bowgpu_agg *aggs, int32_t naggs, bowgpu_out *outs,
+                             bowgpu_agg_info *info);
+
+/* intervalRolling.Next for every window at once — reference rolling/rolling.go:177-239.
+ * For window k: first_index[k] = Window.FirstIndex, [slice_begin[k], slice_end[k]) = the rows
+ * of Window.Bow (0,0 when empty), is_inclusive[k] = Window.IsInclusive.  Arrays hold W
+ * entries and may be NULL; residency applies to all of them. */
+int bowgpu_window_bounds(const bowgpu_col *ts, int64_t interval, const bowgpu_options *opts,
+                         int64_t *first_index, int64_t *slice_begin, int64_t *slice_end,
+                         uint8_t *is_inclusive, int32_t residency);
+
+/* aggregation.Aggregate (whole frame) — reference rolling/aggregation/whole.go:12-93.
+ * outs[i].length is 1 (0 for an empty Bow). */
+int bowgpu_aggregate_whole(const bowgpu_col *cols, int32_t ncols, int32_t ts_col,
+                           const bowgpu_agg *aggs, int32_t naggs, bowgpu_out *outs);
+
+/* ---- Rolling.Interpolate ----------------------------------------------------------- */
+enum {
+    BOWGPU_INTERP_WINDOW_START = 0,  /* interpolation/windowstart.go:8-14 */
+    BOWGPU_INTERP_LINEAR = 1,        /* interpolation/linear.go:8-38 */
+    BOWGPU_INTERP_STEP_PREVIOUS = 2, /* interpolation/stepprevious.go:8-26 */
+    BOWGPU_INTERP_NONE = 3,          /* interpolation/none.go:7-13 */
+    BOWGPU_INTERP_CONST = 4          /* constant-valued closure (interpolation_test.go:16-19) */
+};
+
+/* One rolling.ColInterpolation (rolling/interpolation.go:10-28) of a built-in kind plus what
+ * it reads from Options.PrevRow (linear.go:14-18, stepprevious.go:13-15). */
+typedef struct bowgpu_interp {
+    int32_t kind;
+    int32_t col;
+    double const_value;
+    int32_t has_prev_row;
+    int32_t prev_t_valid;
+    int32_t prev_v_valid;
+    int32_t _pad;
+    double prev_t;      /* prevRow.GetFloat64(intervalCol, last) */
+    double prev_v;      /* prevRow.GetFloat64(col, last) */
+    int64_t prev_v_i64; /* prevRow.GetValue(col, last) for Int64 columns (StepPrevious) */
+} bowgpu_interp;
+
+/* Rolling.Interpolate — reference rolling/interpolation.go:30-161.  Two calls: _count gives
+ * the number of output rows (N + windows missing their start), _fill writes them.
+ * interps must list the Bow's columns in order (bowappend.go:11-13 needs equal schemas). */
+int bowgpu_rolling_interpolate_count(const bowgpu_col *cols, int32_t ncols, int32_t ts_col,
+                                     int64_t interval, const bowgpu_options *opts,
+                                     const bowgpu_interp *interps, int32_t ninterps,
+                                     int64_t *n_out);
+int bowgpu_rolling_interpolate_fill(const bowgpu_col *cols, int32_t ncols, int32_t ts_col,
+                                    int64_t interval, const bowgpu_options *opts,
+                                    const bowgpu_interp *interps, int32_t ninterps,
+                                    bowgpu_out *outs);
+
+/* ---- Bow.FillLinear / IsColSorted -------------------------------------------------- */
+
+/* Bow.FillLinear — reference bowfill.go:14-103.  out receives the filled copy of
+ * cols[fill_col]; *unchanged = 1 where the reference returns the receiver itself
+ * (bowfill.go:35-37, :53-55). */
+int bowgpu_fill_linear(const bowgpu_col *cols, int32_t ncols, int32_t ref_col, int32_t fill_col,
+                       bowgpu_out *out, int32_t *unchanged);
+
+/* Bow.IsColSorted — reference bowassertion.go:15-81 (ascending OR descending, nulls skipped,
+ * empty => false). */
+int bowgpu_is_col_sorted(const bowgpu_col *col, int32_t *sorted);
+
+/* ---- row-range sharding across GPUs ----------------------------------- */
+
+/* What one rank tells its right neighbour about the window that straddles the shard
+ * boundary: the running state of every aggregator over the rows the left rank holds.
+ * Fixed size so it can travel through one RCCL all_gather. */
+#define BOWGPU_CARRY_MAX_AGGS 16
+typedef struct bowgpu_carry_state {
+    double sum;
+    double vmin, vmax;
+    double last_t, last_v;      /* last both-valid point (integrals) */
+    double integ;               /* running integral */
+    int64_t count;
+    int64_t nrows;
+    int64_t first_bits, last_bits; /* First/Last raw 64-bit values */
+    int32_t has_value;          /* any valid value so far */
+    int32_t has_point;          /* any both-valid point so far */
+    int32_t has_pair;           /* trapezoid: at least one pair integrated */
+    int32_t _pad;
+} bowgpu_carry_state;
+
+typedef struct bowgpu_shard_carry {
+    int64_t window_id;          /* global id of the rank's LAST window; -1 when the shard is empty */
+    int64_t first_window_id;    /* global id of the rank's FIRST window */
+    int64_t first_ts, last_ts;
+    int64_t nrows;
+    int32_t naggs;
+    int32_t _pad;
+    bowgpu_carry_state agg[BOWGPU_CARRY_MAX_AGGS];
+} bowgpu_shard_carry;
+
+/* Sharded Rolling.Aggregate: this rank holds rows [row0, row0+len) of every column.
+ * global_s0 comes from rank 0's bowgpu_plan_windows.  Phase 1 reduces every window whose
+ * first row is in the shard and fills *carry with the state of the last (possibly
+ * unfinished) window.  After the ranks exchange carries (RCCL all_gather; the payload is
+ * bytes), phase 2 re-walks the rows of the shard's first window seeded with the left
+ * neighbours' state, so the straddling window is reduced in the reference's row order. */
+int bowgpu_shard_aggregate(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval,
+                           const bowgpu_options *opts, int64_t global_s0,
+                           const bowgpu_agg *aggs, int32_t naggs, bowgpu_out *outs,
+                           int64_t *first_window_id, int64_t *n_windows_local,
+                           bowgpu_shard_carry *carry);
+int bowgpu_shard_stitch(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval,
+                        const bowgpu_options *opts, int64_t global_s0,
+                        const bowgpu_agg *aggs, int32_t naggs, bowgpu_out *outs,
+                        int64_t first_window_id, const bowgpu_shard_carry *all_carries,
+                        int32_t rank, int32_t world, int32_t *drop_last_window);
+
+/* ---- synthetic inputs generated in HBM -------------------------------- */
+
+/* cfg-dense: ts[i] = row0+i, val[i] = u01(mix64(seed, row0+i)); device pointers. */
+int bowgpu_gen_dense(int64_t row0, int64_t n, uint64_t seed, int64_t *ts_dev, double *val_dev);
+/* cfg-sparse: ts = 10*i + U{0..9}, val = U{0..9}+0.5, P(valid) = 0.7; validity_dev holds
+ * ceil(n/8) bytes, bit i = row row0+i (row0 must be a multiple of 8). */
+int bowgpu_gen_sparse(int64_t row0, int64_t n, uint64_t seed, int64_t *ts_dev, double *val_dev,
+                      uint8_t *validity_dev);
+/* order-independent 64-bit checksum of a device buffer of n 8-byte words (xor / sum of mix) */
+int bowgpu_checksum64(const void *dev, int64_t n_words, uint64_t *xor_out, uint64_t *sum_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

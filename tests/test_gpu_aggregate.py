@@ -1,0 +1,320 @@
+"""GPU parity tests for Rolling.Aggregate: the HIP path (through the C ABI) against
+(1) the reference's own golden vectors and (2) the CPU oracle on seeded inputs.
+Bar: bit-exact for every output (values of valid slots, validity bitmaps, null slots == 0);
+Sum/Mean/Integral of windows that take the cooperative long-window path: 1e-12 relative."""
+import numpy as np
+import pytest
+
+from bow_amd import capi
+from oracle import pyoracle as orc
+
+pytestmark = pytest.mark.gpu
+
+T = {"float64": capi.FLOAT64, "int64": capi.INT64}
+ALL_AGGS = ["WindowStart", "Sum", "ArithmeticMean", "Min", "Max", "Count", "First", "Last", "NumRows"]
+TIME_AGGS = ["IntegralStep", "IntegralTrapezoid", "WeightedAverageStep", "WeightedAverageLinear"]
+ORDER_SENSITIVE = {"Sum", "ArithmeticMean", "IntegralStep", "IntegralTrapezoid", "WeightedAverageStep",
+                   "WeightedAverageLinear"}
+
+
+def same_list(a, b):
+    assert len(a) == len(b), (a, b)
+    for x, y in zip(a, b):
+        assert (x is None) == (y is None) and (x is None or x == y), (a, b)
+
+
+def compare(name, got, want, exact=True, rtol=1e-12):
+    """got: capi.OutColumn, want: orc.Column"""
+    assert got.length == want.length, (name, got.length, want.length)
+    assert got.type == want.type, (name, got.type, want.type)
+    gv, gb = got.host_arrays()
+    gm, wm = got.valid_mask(), want.valid_mask()
+    assert np.array_equal(gm, wm), (name, np.flatnonzero(gm != wm)[:10])
+    assert got.null_count == int((~wm).sum()), name
+    wv = want.values[:want.length]
+    gbits, wbits = gv.view(np.uint64), wv.view(np.uint64)
+    # null slots hold 0 (bow.NewBuffer zero-init; never written)
+    assert not gbits[~gm].any(), name
+    if exact:
+        bad = np.flatnonzero(gbits[gm] != wbits[wm])
+        assert bad.size == 0, (name, bad[:10], gv[gm][bad[:5]], wv[wm][bad[:5]])
+    else:
+        g, w = gv[gm].astype(np.float64), wv[wm].astype(np.float64)
+        both_nan = np.isnan(g) & np.isnan(w)
+        err = np.abs(g - w) / np.maximum(np.abs(w), 1e-300)
+        err[both_nan] = 0
+        err[(g == w)] = 0
+        assert np.nanmax(err, initial=0) <= rtol, (name, np.nanmax(err))
+    # padding bits of the last validity byte stay clear
+    n = got.length
+    if n % 8:
+        assert (gb[-1] >> (n % 8)) == 0, name
+
+
+def run_both(ts, cols_np, interval, aggs, offset=0, inclusive=False, device=False):
+    """cols_np: list of (values ndarray, valid bool ndarray or None).  Column 0 is ts."""
+    ccols = [capi.Column(ts, None, capi.INT64)]
+    ocols = [orc.Column(ts, None, orc.INT64)]
+    for vals, valid in cols_np:
+        bm = None if valid is None else np.packbits(valid, bitorder="little")
+        typ = capi.INT64 if vals.dtype == np.int64 else capi.FLOAT64
+        ccols.append(capi.Column(vals, bm, typ, 0, len(vals), -1))
+        ocols.append(orc.Column(vals, bm, typ))
+    if device:
+        ccols = [c.to_device() for c in ccols]
+    outs, info = capi.rolling_aggregate(ccols, 0, interval, aggs, offset=offset, inclusive=inclusive,
+                                        out_residency=capi.DEVICE if device else capi.HOST)
+    exp, nic = orc.aggregate(ocols, 0, interval, aggs, offset=offset, inclusive=inclusive)
+    assert info.new_interval_col == nic
+    return outs, exp, info
+
+
+# ------------------------------------------------------------------ golden vectors through the HIP path
+def test_golden_reducers(golden):
+    n = 0
+    for v in golden["reducers"]:
+        b = golden["bows"][v["bow"]]
+        if b["value_type"] != "float64":
+            continue  # Boolean columns are outside the device path (north_star: int64/float64)
+        cols = [capi.Column.from_list(b["time"], "int64"), capi.Column.from_list(b["value"], "float64")]
+        outs, info = capi.rolling_aggregate(cols, 0, v["interval"], [("WindowStart", 0), (v["reducer"], 1, v["factors"])],
+                                            offset=v["offset"])
+        assert outs[0].type == capi.INT64
+        same_list(outs[0].to_list(), v["expect_time"])
+        assert outs[1].type == T[v["expect_type"]], (v["reducer"], v["name"])
+        same_list(outs[1].to_list(), v["expect_value"])
+        n += 1
+    assert n >= 20
+
+
+def test_golden_driver(golden):
+    kind = {"FirstValue": ("WindowStart", None), "NumRows": ("NumRows", None), "NumRows2x": ("NumRows", [2.0])}
+    names = {"time": 0, "value": 1}
+    for v in golden["driver"]:
+        cols = [capi.Column.from_list(v["time"], "int64"), capi.Column.from_list(v["value"], "float64")]
+        if "error" in v:
+            aggs = [(kind.get(k, ("WindowStart", None))[0], names.get(n, 7)) for n, k, _ in v["aggs"]]
+            with pytest.raises(capi.BowGpuError) as e:
+                capi.rolling_aggregate(cols, 0, v["interval"], aggs)
+            assert e.value.code == (-5 if "must keep" in v["error"] else -6)
+            continue
+        aggs = [(kind[k][0], names[n], kind[k][1]) for n, k, _ in v["aggs"]]
+        outs, info = capi.rolling_aggregate(cols, 0, v["interval"], aggs)
+        for o, typ, exp in zip(outs, v["expect_types"], v["expect"]):
+            assert o.type == T[typ]
+            same_list(o.to_list(), exp)
+        assert info.new_interval_col == max(i for i, a in enumerate(v["aggs"]) if a[0] == "time")
+
+
+def test_golden_iterate_rows_via_numrows(golden):
+    # window membership of rolling_test.go:111-297 observed through NumRows/First/Last/Sum
+    for v in golden["iterate"]:
+        if v["inclusive"]:
+            continue
+        cols = [capi.Column.from_list(v["time"], "int64"), capi.Column.from_list(v["value"], "float64")]
+        outs, _ = capi.rolling_aggregate(cols, 0, v["interval"],
+                                         [("WindowStart", 0), ("NumRows", 1), ("First", 1), ("Last", 1)], offset=v["offset"])
+        same_list(outs[0].to_list(), [w["start"] for w in v["windows"]])
+        same_list(outs[1].to_list(), [float(len(w["time_rows"])) for w in v["windows"]])
+        same_list(outs[2].to_list(), [w["value_rows"][0] if w["value_rows"] else None for w in v["windows"]])
+        same_list(outs[3].to_list(), [w["value_rows"][-1] if w["value_rows"] else None for w in v["windows"]])
+
+
+def test_empty_bow():
+    cols = [capi.Column.from_list([], "int64"), capi.Column.from_list([], "float64")]
+    outs, info = capi.rolling_aggregate(cols, 0, 10, [("WindowStart", 0), ("ArithmeticMean", 1)])
+    assert info.num_windows == 0 and outs[0].length == 0 and outs[1].length == 0
+    assert outs[0].type == capi.INT64 and outs[1].type == capi.FLOAT64
+
+
+# ------------------------------------------------------------------ randomized parity vs the oracle
+def make_ts(rng, n, mode):
+    if mode == "dense":
+        return np.arange(n, dtype=np.int64) + int(rng.integers(-50, 50))
+    if mode == "irregular":  # steps in [1,19] like bowgenerator.go:97-106
+        return np.cumsum(rng.integers(1, 20, n)).astype(np.int64) + int(rng.integers(-1000, 1000))
+    if mode == "dups":  # duplicates and runs
+        return np.cumsum(rng.integers(0, 3, n)).astype(np.int64) - 77
+    if mode == "gappy":  # occasional big jumps => runs of empty windows
+        step = rng.integers(1, 5, n)
+        step[rng.random(n) < 0.01] = rng.integers(100, 5000)
+        return np.cumsum(step).astype(np.int64) - 12345
+    if mode == "negative":
+        return np.cumsum(rng.integers(1, 7, n)).astype(np.int64) - 3 * n
+    raise ValueError(mode)
+
+
+def make_vals(rng, n, kind, null_frac):
+    if kind == "f64":
+        v = rng.standard_normal(n) * 10.0 ** rng.integers(-3, 6, n)
+    elif kind == "i64":
+        v = rng.integers(-(2 ** 40), 2 ** 40, n).astype(np.int64)
+    else:
+        raise ValueError(kind)
+    valid = None if null_frac == 0 else rng.random(n) >= null_frac
+    return v, valid
+
+
+@pytest.mark.parametrize("mode", ["dense", "irregular", "dups", "gappy", "negative"])
+@pytest.mark.parametrize("vkind,null_frac", [("f64", 0.0), ("f64", 0.3), ("i64", 0.3)])
+def test_random_parity_exact(mode, vkind, null_frac):
+    rng = np.random.default_rng(hash((mode, vkind, null_frac)) % (2 ** 32))
+    for n, interval, offset in [(1, 10, 0), (7, 3, 1), (2047, 10, 0), (2048, 10, 3), (2049, 10, -4), (6000, 7, 8),
+                                (50_000, 10, 0), (50_000, 13, 5), (200_003, 25, 11)]:
+        ts = make_ts(rng, n, mode)
+        vals, valid = make_vals(rng, n, vkind, null_frac)
+        aggs = [(k, 0 if k == "WindowStart" else 1) for k in ALL_AGGS]
+        outs, exp, info = run_both(ts, [(vals, valid)], interval, aggs, offset=offset)
+        for (k, _), g, w in zip(aggs, outs, exp):
+            exact = info.long_windows == 0 or k not in ORDER_SENSITIVE
+            compare("%s/%s n=%d I=%d" % (mode, k, n, interval), g, w, exact=exact)
+
+
+@pytest.mark.parametrize("inclusive", [False, True])
+def test_time_weighted_reducers(inclusive):
+    rng = np.random.default_rng(99)
+    for mode in ["irregular", "dups", "gappy", "dense"]:
+        for n, interval, offset in [(5, 10, 0), (3000, 10, 0), (40_000, 16, 5)]:
+            ts = make_ts(rng, n, mode)
+            vals, valid = make_vals(rng, n, "f64", 0.3)
+            aggs = [("WindowStart", 0)] + [(k, 1) for k in TIME_AGGS] + [("Sum", 1), ("Count", 1)]
+            outs, exp, info = run_both(ts, [(vals, valid)], interval, aggs, offset=offset, inclusive=inclusive)
+            assert info.inclusive == 1  # trapezoid / linear force inclusive windows (aggregation.go:183-185)
+            for (k, _), g, w in zip(aggs, outs, exp):
+                exact = info.long_windows == 0 or k not in ORDER_SENSITIVE
+                compare("%s/%s n=%d" % (mode, k, n), g, w, exact=exact)
+
+
+def test_inclusive_option_does_not_change_plain_reducers():
+    # A.6: reducers that don't need the inclusive point get UnsetInclusive windows
+    rng = np.random.default_rng(5)
+    ts = make_ts(rng, 30_000, "dups") * 2
+    vals, valid = make_vals(rng, 30_000, "f64", 0.2)
+    aggs = [("WindowStart", 0), ("Sum", 1), ("Count", 1), ("Last", 1), ("NumRows", 1)]
+    outs, exp, _ = run_both(ts, [(vals, valid)], 4, aggs, inclusive=True)
+    for (k, _), g, w in zip(aggs, outs, exp):
+        compare(k, g, w)
+
+
+def test_multi_column_and_factors():
+    rng = np.random.default_rng(11)
+    n = 120_000
+    ts = make_ts(rng, n, "irregular")
+    cols = [make_vals(rng, n, "f64", 0.0), make_vals(rng, n, "f64", 0.3), make_vals(rng, n, "i64", 0.1),
+            make_vals(rng, n, "i64", 0.0)]
+    aggs = [("ArithmeticMean", 1), ("WindowStart", 0, [0.5]), ("Sum", 2, [-1.0]), ("Max", 3), ("First", 3, [0.1]),
+            ("Count", 4, [3.0]), ("Min", 4), ("Last", 2), ("WindowStart", 0), ("ArithmeticMean", 0), ("Sum", 1, [0.1, 10.0])]
+    outs, exp, info = run_both(ts, cols, 100, aggs, offset=7)
+    for (k, *_), g, w in zip(aggs, outs, exp):
+        compare(k, g, w)
+    assert info.new_interval_col == 9
+
+
+def test_nan_inf_signed_zero_semantics():
+    # minmax.go: NaN result iff the FIRST valid value is NaN; -0.0/+0.0 ties keep the earlier one
+    ts = np.array([0, 1, 2, 10, 11, 12, 20, 21, 30, 31, 40, 41, 42], dtype=np.int64)
+    v = np.array([np.nan, 1.0, -1.0, 2.0, np.nan, 3.0, -0.0, 0.0, 0.0, -0.0, np.inf, -np.inf, 5.0])
+    valid = np.ones(len(v), bool)
+    aggs = [("WindowStart", 0), ("Min", 1), ("Max", 1), ("Sum", 1), ("ArithmeticMean", 1), ("First", 1), ("Last", 1)]
+    outs, exp, _ = run_both(ts, [(v, valid)], 10, aggs)
+    for (k, _), g, w in zip(aggs, outs, exp):
+        compare(k, g, w)
+    gmin = outs[1].host_arrays()[0]
+    assert np.isnan(gmin[0]) and gmin[1] == 2.0
+    assert np.signbit(gmin[2]) and not np.signbit(gmin[3])
+    # all(-0.0) window sums to +0.0 because the accumulator starts at +0.0 (sum.go:15)
+    outs, exp, _ = run_both(np.array([0, 1], dtype=np.int64), [(np.array([-0.0, -0.0]), None)], 10, [("WindowStart", 0), ("Sum", 1)])
+    compare("Sum", outs[1], exp[1])
+    assert not np.signbit(outs[1].host_arrays()[0][0])
+
+
+def test_device_resident_columns_and_arrow_offsets():
+    rng = np.random.default_rng(21)
+    n, off = 70_000, 13  # a sliced Arrow array: offset 13 into shared buffers (bow.go:279-283)
+    ts_full = make_ts(rng, n + off, "irregular")
+    v_full, valid_full = make_vals(rng, n + off, "f64", 0.3)
+    bm = np.packbits(valid_full, bitorder="little")
+    aggs = [("WindowStart", 0), ("ArithmeticMean", 1), ("Count", 1), ("Min", 1)]
+    ocols = [orc.Column(ts_full, None, orc.INT64, offset=off, length=n), orc.Column(v_full, bm, orc.FLOAT64, offset=off, length=n)]
+    exp, _ = orc.aggregate(ocols, 0, 50, aggs)
+    for dev in (False, True):
+        ccols = [capi.Column(ts_full, None, capi.INT64, off, n, 0), capi.Column(v_full, bm, capi.FLOAT64, off, n, -1)]
+        if dev:
+            ccols = [c.to_device() for c in ccols]
+        outs, _ = capi.rolling_aggregate(ccols, 0, 50, aggs, out_residency=capi.DEVICE if dev else capi.HOST)
+        for (k, _), g, w in zip(aggs, outs, exp):
+            compare("%s dev=%s" % (k, dev), g, w)
+
+
+def test_long_windows_cooperative_path():
+    rng = np.random.default_rng(31)
+    n = 300_000
+    ts = make_ts(rng, n, "dense")
+    vals, valid = make_vals(rng, n, "f64", 0.2)
+    aggs = [(k, 0 if k == "WindowStart" else 1) for k in ALL_AGGS] + [(k, 1) for k in TIME_AGGS]
+    for interval in (1000, 50_000, 10 ** 9):
+        outs, exp, info = run_both(ts, [(vals, valid)], interval, aggs)
+        assert info.long_windows > 0
+        for (k, _), g, w in zip(aggs, outs, exp):
+            compare("%s I=%d" % (k, interval), g, w, exact=k not in ORDER_SENSITIVE, rtol=1e-11)
+
+
+def test_declines_unsorted_and_null_timestamps():
+    ts = np.array([1, 5, 3, 9, 12, 20], dtype=np.int64)
+    v = np.arange(6, dtype=np.float64)
+    with pytest.raises(capi.BowGpuError) as e:
+        capi.rolling_aggregate([capi.Column(ts), capi.Column(v)], 0, 4, [("WindowStart", 0), ("Sum", 1)])
+    assert e.value.code == -14
+    tsn = capi.Column.from_list([1, None, 3, 9], "int64")
+    with pytest.raises(capi.BowGpuError) as e:
+        capi.rolling_aggregate([tsn, capi.Column(v[:4])], 0, 4, [("WindowStart", 0), ("Sum", 1)])
+    assert e.value.code == -13
+    with pytest.raises(capi.BowGpuError) as e:  # first ts null is the reference's own ctor error (rolling.go:89-93)
+        capi.rolling_aggregate([capi.Column.from_list([None, 2, 3, 9], "int64"), capi.Column(v[:4])], 0, 4,
+                               [("WindowStart", 0), ("Sum", 1)])
+    assert e.value.code == -3
+
+
+def test_deterministic_and_generator_parity():
+    n = 1_000_000
+    ts_d, val_d = capi.gen_dense(0, n, seed=42)
+    ts_o, val_o = orc.gen_dense(0, n, seed=42)
+    assert np.array_equal(ts_d.values.to_numpy(np.int64, n), ts_o)
+    assert np.array_equal(val_d.values.to_numpy(np.float64, n), val_o)
+    aggs = [("WindowStart", 0), ("ArithmeticMean", 1), ("Sum", 1), ("Min", 1), ("Max", 1)]
+    a, _ = capi.rolling_aggregate([ts_d, val_d], 0, 10, aggs)
+    b, _ = capi.rolling_aggregate([ts_d, val_d], 0, 10, aggs)
+    exp, _ = orc.aggregate([orc.Column(ts_o, None, orc.INT64), orc.Column(val_o, None, orc.FLOAT64)], 0, 10, aggs)
+    for (k, _), x, y, w in zip(aggs, a, b, exp):
+        assert np.array_equal(x.host_arrays()[0].view(np.uint64), y.host_arrays()[0].view(np.uint64))
+        compare(k, x, w)
+    # sparse generator
+    ts_s, val_s = capi.gen_sparse(0, n, seed=3)
+    ts_so, val_so, bm_so = orc.gen_sparse(0, n, seed=3)
+    assert np.array_equal(ts_s.values.to_numpy(np.int64, n), ts_so)
+    assert np.array_equal(val_s.values.to_numpy(np.float64, n), val_so)
+    assert np.array_equal(val_s.validity.to_numpy(np.uint8, (n + 7) // 8), bm_so)
+    outs, _ = capi.rolling_aggregate([ts_s, val_s], 0, 100, aggs, offset=7)
+    exp, _ = orc.aggregate([orc.Column(ts_so, None, orc.INT64), orc.Column(val_so, bm_so, orc.FLOAT64)], 0, 100, aggs, offset=7)
+    for (k, _), g, w in zip(aggs, outs, exp):
+        compare(k, g, w)
+
+
+def test_rows_below_first_window_start():
+    # Negative ts: Go's truncating division can leave s0 ABOVE ts[0] (rolling.go:96-99); the rows
+    # below s0 are skipped-but-spanned by the scan (rolling.go:194-196) and ride in window 0 -
+    # unless window 0 has no row of its own, in which case it is an empty slice.
+    for ts_list, interval, offset, inclusive in [
+        ([-37, -36, -35, -30, -20, -5, 3], 10, -4, False),   # s0 = -34 > -37, window 0 has own rows
+        ([-37, -36, -35, -20, -5, 3], 10, -4, False),        # window 0 = only rows below s0 => empty
+        ([-37, -36, -24, -5, 3], 10, -4, True),              # only an inclusive row at s0+I
+        ([-19, -19, -18, -3, 0, 4, 8], 10, 9, True),
+    ]:
+        ts = np.array(ts_list, dtype=np.int64)
+        v = np.arange(len(ts), dtype=np.float64) + 0.5
+        aggs = [("WindowStart", 0), ("Sum", 1), ("NumRows", 1), ("First", 1), ("ArithmeticMean", 1),
+                ("IntegralTrapezoid", 1), ("IntegralStep", 1)]
+        outs, exp, info = run_both(ts, [(v, None)], interval, aggs, offset=offset, inclusive=inclusive)
+        assert info.s0 > ts[0]
+        for (k, _), g, w in zip(aggs, outs, exp):
+            compare("%s %s" % (k, ts_list), g, w)
