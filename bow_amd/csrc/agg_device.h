@@ -1,0 +1,221 @@
+// agg_device.h — device-side helpers shared by the tile kernels: exact division by the interval,
+// Go numeric conversions, the running state of a window and the reducers' result rules
+// (reference rolling/aggregation/*.go; see each function).
+#pragma once
+
+#include "common.h"
+
+namespace bowgpu {
+
+constexpr uint32_t kSat = 0xFFFFFFFFu;
+
+__device__ __forceinline__ uint64_t magic_div(uint64_t n, const MagicDiv &d) {
+    uint64_t t = __umul64hi(d.m, n);
+    return (t + ((n - t) >> d.sh1)) >> d.sh2;
+}
+
+// Go's float64 -> int64 conversion on amd64 (CVTTSD2SI): NaN / out of range => INT64_MIN.
+__device__ __forceinline__ int64_t go_f64_to_i64(double x) {
+    if (!(x >= -9223372036854775808.0 && x < 9223372036854775808.0)) return INT64_MIN;
+    return (int64_t)x;
+}
+
+__device__ __forceinline__ double bits_to_f64(uint64_t b, int type) {
+    // Bow.GetFloat64: bowgetters.go:224-229 (Int64 columns convert per element)
+    return type == BOWGPU_FLOAT64 ? __longlong_as_double((long long)b) : (double)(int64_t)b;
+}
+
+// ---------------------------------------------------------------- running state of a window
+struct Stats {
+    double sum;          // sum.go:16-22 / arithmeticmean.go:17-24
+    double vmin, vmax;   // minmax.go:16-28 / :41-53 (seeded by the first valid value)
+    double nn_min, nn_max;  // NaN-ignoring extrema, only used when partial states are merged
+    uint64_t first_bits, last_bits;  // firstlast.go
+    int64_t count;       // count.go / mean
+    // integrals (integral.go): previous both-valid point and running sums
+    double pt, pv, first_pt, first_pv;
+    double integ_step, integ_trap;
+    int has_value;
+    int has_nn;
+    int has_point;
+    int has_pair;
+};
+
+__device__ __forceinline__ void stats_init(Stats &s) {
+    s.sum = 0.0; s.vmin = 0.0; s.vmax = 0.0; s.nn_min = 0.0; s.nn_max = 0.0;
+    s.first_bits = 0; s.last_bits = 0; s.count = 0;
+    s.pt = 0.0; s.pv = 0.0; s.first_pt = 0.0; s.first_pv = 0.0; s.integ_step = 0.0; s.integ_trap = 0.0;
+    s.has_value = 0; s.has_nn = 0; s.has_point = 0; s.has_pair = 0;
+}
+
+// one valid value, in row order
+template <bool kMerge>
+__device__ __forceinline__ void stats_value(Stats &s, double x, uint64_t raw) {
+    s.sum += x;
+    s.count++;
+    if (s.has_value) {
+        if (x < s.vmin) s.vmin = x;
+        if (x > s.vmax) s.vmax = x;
+    } else {
+        s.vmin = x; s.vmax = x; s.first_bits = raw; s.has_value = 1;
+    }
+    s.last_bits = raw;
+    if (kMerge) {
+        if (x == x) {
+            if (!s.has_nn) { s.nn_min = x; s.nn_max = x; s.has_nn = 1; }
+            else { if (x < s.nn_min) s.nn_min = x; if (x > s.nn_max) s.nn_max = x; }
+        }
+    }
+}
+
+// one both-valid (t, v) point, in row order (integral.go:14-31, :46-62)
+__device__ __forceinline__ void stats_point(Stats &s, double t, double v) {
+    if (s.has_point) {
+        s.integ_trap += (s.pv + v) / 2 * (t - s.pt);
+        s.integ_step += s.pv * (t - s.pt);
+        s.has_pair = 1;
+    } else {
+        s.first_pt = t; s.first_pv = v; s.has_point = 1;
+    }
+    s.pt = t; s.pv = v;
+}
+
+// merge R (later rows) into L (earlier rows): used by the cooperative long-window path only
+__device__ __forceinline__ void stats_merge(Stats &L, const Stats &R) {
+    if (R.has_point) {
+        if (L.has_point) {
+            L.integ_trap = L.integ_trap + (L.pv + R.first_pv) / 2 * (R.first_pt - L.pt) + R.integ_trap;
+            L.integ_step = L.integ_step + L.pv * (R.first_pt - L.pt) + R.integ_step;
+            L.has_pair = 1;
+        } else {
+            L.first_pt = R.first_pt; L.first_pv = R.first_pv; L.integ_trap = R.integ_trap;
+            L.integ_step = R.integ_step; L.has_pair = R.has_pair; L.has_point = 1;
+        }
+        L.pt = R.pt; L.pv = R.pv;
+    }
+    if (!R.has_value) return;
+    if (!L.has_value) {
+        double isum = L.integ_step, itrap = L.integ_trap;  // keep merged integral fields
+        double pt = L.pt, pv = L.pv, fpt = L.first_pt, fpv = L.first_pv;
+        int hp = L.has_point, hpair = L.has_pair;
+        L = R;
+        L.integ_step = isum; L.integ_trap = itrap; L.pt = pt; L.pv = pv; L.first_pt = fpt; L.first_pv = fpv;
+        L.has_point = hp; L.has_pair = hpair;
+        return;
+    }
+    L.sum += R.sum;
+    L.count += R.count;
+    // minmax.go semantics on the concatenation: only R's non-NaN values can replace the seed
+    if (R.has_nn) {
+        if (R.nn_min < L.vmin) L.vmin = R.nn_min;
+        if (R.nn_max > L.vmax) L.vmax = R.nn_max;
+        if (!L.has_nn) { L.nn_min = R.nn_min; L.nn_max = R.nn_max; L.has_nn = 1; }
+        else { if (R.nn_min < L.nn_min) L.nn_min = R.nn_min; if (R.nn_max > L.nn_max) L.nn_max = R.nn_max; }
+    }
+    L.last_bits = R.last_bits;
+}
+
+// ---------------------------------------------------------------- result of one reducer
+struct Val {
+    uint64_t bits;  // float64 or int64 payload
+    int valid;      // 0 => nil
+    int is_int;
+};
+
+// transformation.Factor chain (factor.go:7-20), then Buffer.SetOrDrop into a column of
+// out_type (bowbuffer.go:60-80; bowconvert.go:24-29,:59-60)
+__device__ __forceinline__ Val finish_val(Val v, const AggDesc &a) {
+    if (!v.valid) { v.bits = 0; return v; }
+    for (int f = 0; f < a.n_factors; f++) {
+        if (v.is_int) v.bits = (uint64_t)go_f64_to_i64((double)(int64_t)v.bits * a.factors[f]);
+        else v.bits = (uint64_t)__double_as_longlong(__longlong_as_double((long long)v.bits) * a.factors[f]);
+    }
+    if (a.out_type == BOWGPU_INT64 && !v.is_int) {
+        v.bits = (uint64_t)go_f64_to_i64(__longlong_as_double((long long)v.bits));
+        v.is_int = 1;
+    } else if (a.out_type == BOWGPU_FLOAT64 && v.is_int) {
+        v.bits = (uint64_t)__double_as_longlong((double)(int64_t)v.bits);
+        v.is_int = 0;
+    }
+    return v;
+}
+
+__device__ __forceinline__ Val make_f64(double x) { Val v; v.bits = (uint64_t)__double_as_longlong(x); v.valid = 1; v.is_int = 0; return v; }
+__device__ __forceinline__ Val make_i64(int64_t x) { Val v; v.bits = (uint64_t)x; v.valid = 1; v.is_int = 1; return v; }
+__device__ __forceinline__ Val make_nil() { Val v; v.bits = 0; v.valid = 0; v.is_int = 0; return v; }
+
+__device__ __forceinline__ bool kind_needs_inclusive(int kind) {
+    return kind == BOWGPU_AGG_INTEGRAL_TRAPEZOID || kind == BOWGPU_AGG_WAVG_LINEAR;
+}
+
+// The value a reducer returns for a window, from the running state over its rows.
+//   nrows      = w.Bow.NumRows() as THIS reducer sees it (after UnsetInclusive, aggregation.go:207-208)
+//   s          = state over those rows
+//   col_is_int = input column type (First/Last return the input type)
+__device__ __forceinline__ Val reduce_val(int kind, const Stats &s, int64_t nrows, int64_t win_start,
+                                          int64_t interval, int col_is_int) {
+    switch (kind) {
+    case BOWGPU_AGG_WINDOW_START: return make_i64(win_start);                       // windowstart.go:11
+    case BOWGPU_AGG_NUM_ROWS: return make_f64((double)nrows);
+    case BOWGPU_AGG_SUM: return make_f64(nrows == 0 ? 0.0 : s.sum);                 // sum.go:11-24
+    case BOWGPU_AGG_MEAN:                                                          // arithmeticmean.go:11-29
+        if (nrows == 0 || s.count == 0) return make_nil();
+        return make_f64(s.sum / (double)s.count);
+    case BOWGPU_AGG_MIN: return s.has_value ? make_f64(s.vmin) : make_nil();        // minmax.go:11-30
+    case BOWGPU_AGG_MAX: return s.has_value ? make_f64(s.vmax) : make_nil();
+    case BOWGPU_AGG_COUNT: return make_i64(s.count);                                // count.go:11-19
+    case BOWGPU_AGG_FIRST:                                                         // firstlast.go:11-20
+        if (!s.has_value) return make_nil();
+        { Val v; v.bits = s.first_bits; v.valid = 1; v.is_int = col_is_int; return v; }
+    case BOWGPU_AGG_LAST:
+        if (!s.has_value) return make_nil();
+        { Val v; v.bits = s.last_bits; v.valid = 1; v.is_int = col_is_int; return v; }
+    case BOWGPU_AGG_INTEGRAL_STEP:                                                 // integral.go:43-68
+    case BOWGPU_AGG_WAVG_STEP: {                                                   // weightedmean.go:11-19
+        if (!s.has_point) return make_nil();
+        int64_t last_value = win_start + interval;
+        double r = s.integ_step + s.pv * ((double)last_value - s.pt);
+        if (kind == BOWGPU_AGG_WAVG_STEP) r = r / (double)(last_value - win_start);
+        return make_f64(r);
+    }
+    case BOWGPU_AGG_INTEGRAL_TRAPEZOID:                                            // integral.go:11-37
+    case BOWGPU_AGG_WAVG_LINEAR: {                                                 // weightedmean.go:25-33
+        if (!s.has_pair) return make_nil();
+        double r = s.integ_trap;
+        if (kind == BOWGPU_AGG_WAVG_LINEAR) r = r / (double)((win_start + interval) - win_start);
+        return make_f64(r);
+    }
+    default: return make_nil();
+    }
+}
+
+__device__ __forceinline__ bool kind_is_integral(int kind) {
+    return kind >= BOWGPU_AGG_INTEGRAL_STEP && kind <= BOWGPU_AGG_WAVG_LINEAR;
+}
+
+
+// ---------------------------------------------------------------- loads
+__device__ __forceinline__ void load_pair(const uint64_t *__restrict__ p, int64_t g, int64_t n, bool vec,
+                                          uint64_t &a, uint64_t &b) {
+    if (vec && g + 1 < n) {
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(p + g);
+        a = v.x; b = v.y;
+    } else {
+        a = g < n ? p[g] : 0;
+        b = g + 1 < n ? p[g + 1] : 0;
+    }
+}
+
+// 32 validity bits starting at logical row `row` of a column
+__device__ __forceinline__ uint32_t load_vbits32(const ColDesc &c, int64_t row) {
+    int64_t bit = c.vbit0 + row;
+    int64_t wi = bit >> 5;
+    int sh = (int)(bit & 31);
+    uint32_t lo = wi < c.vwords ? c.vbits[wi] : 0u;
+    if (sh == 0) return lo;
+    uint32_t hi = wi + 1 < c.vwords ? c.vbits[wi + 1] : 0u;
+    return (lo >> sh) | (hi << (32 - sh));
+}
+
+
+}  // namespace bowgpu

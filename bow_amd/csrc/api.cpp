@@ -5,6 +5,7 @@
 
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -375,6 +376,16 @@ static int run_aggregate(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t 
     P.W = W;
     P.wid_base = wid_base;
     P.magic = plan.magic;
+    P.fits32 = ((uint64_t)plan.interval >> 32) == 0;
+    if (P.fits32) {
+        // Granlund & Montgomery fig. 4.1 with N = 32
+        const uint64_t d = (uint64_t)plan.interval;
+        int l = 0;
+        while (l < 32 && (1ull << l) < d) l++;
+        P.m32 = (uint32_t)((((1ull << l) - d) << 32) / d) + 1;
+        P.sh1_32 = l < 1 ? (uint32_t)l : 1u;
+        P.sh2_32 = l > 1 ? (uint32_t)(l - 1) : 0u;
+    }
     P.inclusive = inclusive;
     P.naggs = naggs;
     P.pre_rows = (n > 0 && wid_base == 0 && plan.s0 > plan.first_ts) ? 1 : 0;
@@ -444,8 +455,17 @@ static int run_aggregate(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t 
             if (kind_never_nil(aggs[i].kind)) BG_TRY(launch_fix_tail_bits(c, douts[i].validity, W));
         }
         // kernel_ms brackets the dominant kernel only (rolling_agg_kernel), on the stream it runs on
+        // The lean kernel covers exclusive windows without time-weighted reducers and without rows below
+        // s0; everything else (and BOWGPU_FORCE_GENERAL=1, used by the tests to cover both) takes the
+        // general kernel.  Both are HIP; results are identical where both apply.
+        bool lean = !inclusive && !P.pre_rows;
+        for (int i = 0; i < naggs; i++)
+            if (aggs[i].kind >= BOWGPU_AGG_INTEGRAL_STEP && aggs[i].kind <= BOWGPU_AGG_WAVG_LINEAR) lean = false;
+        const char *force = getenv("BOWGPU_FORCE_GENERAL");
+        if (force && force[0] == '1') lean = false;
         BG_HIP(hipEventRecord(c->ev0, c->stream));
-        BG_TRY(launch_rolling_aggregate(c, P));
+        if (lean) BG_TRY(launch_rolling_fast(c, P));
+        else BG_TRY(launch_rolling_aggregate(c, P));
         BG_HIP(hipEventRecord(c->ev1, c->stream));
     }
     // status -> host (pinned) ; decides whether the long-window kernel is needed

@@ -136,6 +136,8 @@ struct AggParams {
     int64_t W;              // windows addressable in the outputs
     int64_t wid_base;       // global window id of output slot 0 (sharding); 0 otherwise
     MagicDiv magic;
+    uint32_t m32, sh1_32, sh2_32;  // 32-bit form of the same division (valid when fits32)
+    int32_t fits32;         // interval < 2^32: tiles whose ts span fits 32 bits use 32-bit window arithmetic
     int32_t inclusive;      // effective Options.Inclusive
     int32_t ncols;
     int32_t naggs;
@@ -148,7 +150,8 @@ struct AggParams {
     int64_t long_cap;
 };
 
-int launch_rolling_aggregate(Ctx *c, const AggParams &p);
+int launch_rolling_aggregate(Ctx *c, const AggParams &p);   // general kernel (rolling_agg.hip)
+int launch_rolling_fast(Ctx *c, const AggParams &p);        // lean kernel for exclusive windows without time-weighted reducers (rolling_fast.hip)
 int launch_long_windows(Ctx *c, const AggParams &p, int64_t n_long);
 int launch_fix_tail_bits(Ctx *c, uint8_t *bitmap, int64_t nbits);
 int launch_popcount(Ctx *c, const uint32_t *words, int64_t bit0, int64_t nbits, uint64_t *d_count);

@@ -51,8 +51,15 @@ def compare(name, got, want, exact=True, rtol=1e-12):
         assert (gb[-1] >> (n % 8)) == 0, name
 
 
+def _names(aggs):
+    return [a[0] for a in aggs]
+
+
 def run_both(ts, cols_np, interval, aggs, offset=0, inclusive=False, device=False):
-    """cols_np: list of (values ndarray, valid bool ndarray or None).  Column 0 is ts."""
+    """cols_np: list of (values ndarray, valid bool ndarray or None).  Column 0 is ts.
+    Runs the HIP path twice - lean kernel (where it applies) and general kernel
+    (BOWGPU_FORCE_GENERAL=1) - checks both against the oracle, returns the first run."""
+    import os
     ccols = [capi.Column(ts, None, capi.INT64)]
     ocols = [orc.Column(ts, None, orc.INT64)]
     for vals, valid in cols_np:
@@ -62,11 +69,22 @@ def run_both(ts, cols_np, interval, aggs, offset=0, inclusive=False, device=Fals
         ocols.append(orc.Column(vals, bm, typ))
     if device:
         ccols = [c.to_device() for c in ccols]
-    outs, info = capi.rolling_aggregate(ccols, 0, interval, aggs, offset=offset, inclusive=inclusive,
-                                        out_residency=capi.DEVICE if device else capi.HOST)
     exp, nic = orc.aggregate(ocols, 0, interval, aggs, offset=offset, inclusive=inclusive)
-    assert info.new_interval_col == nic
-    return outs, exp, info
+    first = None
+    for force in ("0", "1"):
+        os.environ["BOWGPU_FORCE_GENERAL"] = force
+        try:
+            outs, info = capi.rolling_aggregate(ccols, 0, interval, aggs, offset=offset, inclusive=inclusive,
+                                                out_residency=capi.DEVICE if device else capi.HOST)
+        finally:
+            os.environ["BOWGPU_FORCE_GENERAL"] = "0"
+        assert info.new_interval_col == nic
+        for k, g, w in zip(_names(aggs), outs, exp):
+            exact = info.long_windows == 0 or k not in ORDER_SENSITIVE
+            compare("%s general=%s n=%d I=%d off=%d" % (k, force, len(ts), interval, offset), g, w, exact=exact, rtol=1e-11)
+        if first is None:
+            first = (outs, exp, info)
+    return first
 
 
 # ------------------------------------------------------------------ golden vectors through the HIP path
