@@ -88,6 +88,12 @@ int ctx_pinned(Ctx *c, size_t bytes, void **hptr) {
     return 0;
 }
 
+int ctx_params(Ctx *c, void **dptr) {
+    if (!c->d_params) BG_HIP(hipMalloc(&c->d_params, 4096));
+    *dptr = c->d_params;
+    return 0;
+}
+
 int DevBuf::alloc(size_t n) {
     if (p) { (void)hipFree(p); p = nullptr; }
     bytes = n;
@@ -396,7 +402,7 @@ static int run_aggregate(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t 
         const int col = aggs[i].col;
         int s = slot_of[col];
         const bool nullable = !kind_never_nil(aggs[i].kind);
-        if (s >= 0 && nullable && nullable_in_slot[s] >= 8) s = -1;  // at most 8 nullable reducers per pass: open another slot
+        if (s >= 0 && nullable && nullable_in_slot[s] >= 4) s = -1;  // at most 4 nullable reducers per pass: open another slot
         if (s < 0) {
             if (P.ncols >= kMaxCols) return fail(BOWGPU_ERR_UNSUPPORTED, "at most %d value columns per call", kMaxCols);
             s = P.ncols++;
@@ -438,7 +444,7 @@ static int run_aggregate(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t 
     }
 
     // status words + long-window list
-    const int64_t ntiles = (n + 2047) / 2048;
+    const int64_t ntiles = (n + 511) / 512;  // the lean kernel's tile (one wavefront); at most one long window per tile
     const size_t scratch_bytes = 4096 + (size_t)(ntiles + 1) * 16;
     void *dscr;
     BG_TRY(ctx_scratch(c, scratch_bytes, &dscr));
@@ -532,6 +538,7 @@ int bowgpu_set_device(int device) {
         // drop per-device state of the old device
         (void)hipSetDevice(c->device);
         if (c->d_scratch) (void)hipFree(c->d_scratch);
+        if (c->d_params) (void)hipFree(c->d_params);
         if (c->h_pinned) (void)hipHostFree(c->h_pinned);
         if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
         if (c->ev0) (void)hipEventDestroy(c->ev0);

@@ -40,10 +40,12 @@ struct Ctx {
     void *h_pinned = nullptr;
     size_t h_pinned_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    void *d_params = nullptr;      // 4 KB device block holding the kernels' descriptor struct
 };
 int ctx_get(Ctx **out);                       // initialises HIP on first use; fails loudly without a GPU
 int ctx_scratch(Ctx *c, size_t bytes, void **dptr);
 int ctx_pinned(Ctx *c, size_t bytes, void **hptr);
+int ctx_params(Ctx *c, void **dptr);
 
 // ---------------------------------------------------------------- temp device buffers
 // RAII device allocation (stream-ordered free at scope exit after a sync by the caller).

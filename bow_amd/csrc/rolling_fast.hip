@@ -1,20 +1,27 @@
-// rolling_fast.hip — the lean tile kernel for the headline family of Rolling.Aggregate:
+// rolling_fast.hip — the lean kernel for the headline family of Rolling.Aggregate:
 // WindowStart / Sum / ArithmeticMean / Min / Max / Count / First / Last / NumRows over
 // exclusive windows (reference rolling/rolling.go:177-239 + rolling/aggregation.go:190-238 +
 // rolling/aggregation/{windowstart,sum,arithmeticmean,minmax,count,firstlast}.go).
 // Inclusive windows, the time-weighted reducers and inputs with rows below s0 take the general
 // kernel in rolling_agg.hip; results are identical where both apply.
 //
-// Same data-parallel restatement as rolling_agg.hip (heads -> LDS segment list -> one lane walks
-// one window in row order => reference summation order, bit-exact), but the per-row work is cut
-// to the bone, because at 16 B/row the HBM roofline leaves ~1.7 wave-instructions per row:
-//   * the window id is computed RELATIVE to the tile's first window, in 32-bit arithmetic
-//     (one v_mul_hi_u32) whenever the tile's ts span and the interval fit 32 bits — decided per
-//     tile from two scalar loads; otherwise the exact 64-bit multiply-high path is used;
-//   * the per-tile base window is derived on the scalar unit (s_load + SALU), not per lane;
-//   * neighbour rows come from DPP wave shifts, not LDS; lane 0 takes its neighbour from a
-//     scalar load;
-//   * the walk is specialised at compile time on {has nulls, int64 values, min/max, first/last}.
+// Same data-parallel restatement as rolling_agg.hip (row i is a head when its window id differs
+// from row i-1's; heads -> LDS segment list -> ONE lane walks one window in row order, i.e. the
+// reference's summation order, bit-exact) organised for the machine:
+//   * one WAVEFRONT (64 lanes) owns a tile of 512 rows + 128 look-ahead rows and never meets
+//     another wave: no s_barrier, no cross-wave prefix.  ~20 such waves are resident per CU at
+//     different phases, which is what keeps HBM reads in flight while others reduce;
+//   * coalesced 16-B/lane loads (2 rows per lane, 5 chunks of 128 rows);
+//   * the window id is computed RELATIVE to the tile's first window in 32-bit arithmetic (one
+//     v_mul_hi_u32 per row) whenever the tile's ts span and the interval fit 32 bits — decided per
+//     tile on the scalar unit; otherwise the exact 64-bit multiply-high division is used;
+//   * neighbour rows come from DPP wave shifts / v_readlane, not memory;
+//   * heads are compacted with ballot + mbcnt and a running scalar count (chunks are consecutive);
+//   * the walk is specialised at compile time on {has nulls, int64 values, min/max, first/last};
+//   * outputs: lane q stores window slot wid(q) (8-B coalesced stores); validity bits are assembled in
+//     LDS and flushed as whole words, atomicOr only for the boundary words shared with neighbours.
+//
+// HBM-bound: algorithmic bytes = 8 (ts) + 8 per value column (+1/8 per nullable column) per row.
 
 #include "agg_device.h"
 
@@ -22,28 +29,23 @@ namespace bowgpu {
 
 namespace {
 
-constexpr int kBlock = 256;
-constexpr int kTile = 2048;
-constexpr int kHalo = 128;
-constexpr int kRows = kTile + kHalo;
-constexpr int kChunks = 4;
-constexpr int kCnt = kChunks * 4 + 1;
-constexpr int kSpanBits = 2048 + 64;
-constexpr int kSpanWords = kSpanBits / 32;
-constexpr int kMaxNullable = 8;
-constexpr int kGapInline = 4;
-constexpr int kGapList = 64;
+constexpr int kWave = 64;
+constexpr int kTileW = 512;               // rows owned by a wavefront
+constexpr int kHaloW = 128;               // look-ahead rows
+constexpr int kRowsW = kTileW + kHaloW;   // 640
+constexpr int kChunksW = kRowsW / 128;    // 5 (the last one is the halo)
+constexpr int kSpanBitsW = kTileW + 64;
+constexpr int kSpanWordsW = kSpanBitsW / 32;
+constexpr int kMaxNullableW = 4;
+constexpr int kGapInlineW = 8;
+constexpr uint32_t kSat16 = 0xFFFFu;
 
-struct FastShared {
-    uint64_t val[kRows];
-    uint32_t seg_lw[kRows + 2];    // window id - w0 (kSat => recompute from ts)
-    uint16_t seg_row[kRows + 2];   // local head row
-    uint32_t vbits[kRows / 32 + 2];
-    uint32_t obits[kMaxNullable][kSpanWords];
-    int cnt[kCnt + 3];
-    int pre[kCnt + 3];
-    int gap_q[kGapList];
-    int gap_n;
+struct WaveShared {
+    uint64_t val[kRowsW];
+    uint16_t seg_row[kRowsW + 2];   // local head rows, in row order
+    uint16_t seg_lw[kRowsW + 2];    // window id - w0 (kSat16 => recompute from ts)
+    uint32_t vbits[kRowsW / 32 + 2];
+    uint32_t obits[kMaxNullableW][kSpanWordsW + 1];
 };
 
 __device__ __forceinline__ uint32_t magic_div32(uint32_t n, uint32_t m, uint32_t sh1, uint32_t sh2) {
@@ -60,10 +62,19 @@ __device__ __forceinline__ uint64_t from_left64(uint64_t x, uint64_t lane0) {
     const uint32_t hi = from_left32((uint32_t)(x >> 32), (uint32_t)(lane0 >> 32));
     return ((uint64_t)hi << 32) | lo;
 }
+__device__ __forceinline__ uint64_t readlane64(uint64_t x, int l) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, l);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), l);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// One wave only: LDS operations of a wave retire in order, so a write phase followed by reads from
+// other lanes needs no s_barrier - only that the compiler keeps the order (workgroup == this wave).
+__device__ __forceinline__ void wave_lds_fence() { __syncthreads(); }
 
 // ---- the walk of one window, specialised at compile time
 template <bool kNulls, bool kInt, bool kMinMax, bool kFirstLast>
-__device__ __forceinline__ void walk(const FastShared &sh, int r0, int r1, Stats &s) {
+__device__ __forceinline__ void walk(const WaveShared &sh, int r0, int r1, Stats &s) {
     double sum = 0.0;
     if (!kNulls) {
         const uint64_t raw0 = sh.val[r0];
@@ -107,8 +118,8 @@ __device__ __forceinline__ void walk(const FastShared &sh, int r0, int r1, Stats
     }
 }
 
-__device__ __forceinline__ void walk_dispatch(int variant, const FastShared &sh, int r0, int r1, Stats &s) {
-    // variant: bit0 nulls, bit1 int64 values, bit2 min/max, bit3 first/last  (workgroup-uniform)
+__device__ __forceinline__ void walk_dispatch(int variant, const WaveShared &sh, int r0, int r1, Stats &s) {
+    // variant: bit0 nulls, bit1 int64 values, bit2 min/max, bit3 first/last  (wave-uniform)
     switch (variant) {
 #define BG_CASE(v) case v: walk<((v) & 1) != 0, ((v) & 2) != 0, ((v) & 4) != 0, ((v) & 8) != 0>(sh, r0, r1, s); break;
         BG_CASE(0) BG_CASE(1) BG_CASE(2) BG_CASE(3) BG_CASE(4) BG_CASE(5) BG_CASE(6) BG_CASE(7)
@@ -119,129 +130,100 @@ __device__ __forceinline__ void walk_dispatch(int variant, const FastShared &sh,
 
 }  // namespace
 
-__global__ __launch_bounds__(kBlock) void rolling_fast_kernel(const AggParams p, const int64_t ntiles,
-                                                              const int64_t tiles_per_xcd) {
-    __shared__ FastShared sh;
+__global__ __launch_bounds__(kWave, 5) void rolling_wave_kernel(const AggParams p, const int64_t ntiles,
+                                                                const int64_t tiles_per_xcd) {
+    __shared__ WaveShared sh;
 
+    // XCD-aware tile mapping: workgroups are dealt round-robin over the 8 XCDs, so give every XCD a
+    // contiguous run of tiles (a tile's look-ahead rows are its right neighbour's first rows: same L2).
     const int64_t b = blockIdx.x;
-    const int64_t tile = (b & 7) * tiles_per_xcd + (b >> 3);  // XCD-contiguous tile runs
+    const int64_t tile = (b & 7) * tiles_per_xcd + (b >> 3);
     if (tile >= ntiles) return;
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t base = tile * kTile;
+    const int lane = threadIdx.x;
+    const int64_t base = tile * kTileW;
     const int64_t n = p.n;
-    const int nloc = (int)((n - base) < kRows ? (n - base) : kRows);  // rows of this tile(+halo) that exist
+    const int nloc = (int)((n - base) < kRowsW ? (n - base) : kRowsW);  // rows of this tile(+halo) that exist
     const uint64_t *__restrict__ ts = reinterpret_cast<const uint64_t *>(p.ts);
     const bool ts_vec = (reinterpret_cast<uintptr_t>(ts) & 15) == 0;
 
-    // ---- 1. vector loads first (latency), scalar prologue underneath them
-    uint64_t ta[kChunks + 1], tb[kChunks + 1];
+    // ---- 1. loads: ts, then the first value column right behind it
+    uint64_t ta[kChunksW], tb[kChunksW];
 #pragma unroll
-    for (int j = 0; j < kChunks; j++) load_pair(ts, base + j * 512 + 2 * tid, n, ts_vec, ta[j], tb[j]);
-    ta[kChunks] = 0; tb[kChunks] = 0;
-    if (wave == 0) load_pair(ts, base + kTile + 2 * tid, n, ts_vec, ta[kChunks], tb[kChunks]);
-
-    uint64_t va[kChunks + 1], vb[kChunks + 1];
+    for (int j = 0; j < kChunksW; j++) load_pair(ts, base + j * 128 + 2 * lane, n, ts_vec, ta[j], tb[j]);
+    uint64_t va[kChunksW], vb[kChunksW];
     int staged_slot = -1;
     if (p.ncols > 0 && p.cols[0].values != nullptr) {
         const uint64_t *vp = reinterpret_cast<const uint64_t *>(p.cols[0].values);
         const bool vvec = (reinterpret_cast<uintptr_t>(vp) & 15) == 0;
 #pragma unroll
-        for (int j = 0; j < kChunks; j++) load_pair(vp, base + j * 512 + 2 * tid, n, vvec, va[j], vb[j]);
-        va[kChunks] = 0; vb[kChunks] = 0;
-        if (wave == 0) load_pair(vp, base + kTile + 2 * tid, n, vvec, va[kChunks], vb[kChunks]);
+        for (int j = 0; j < kChunksW; j++) load_pair(vp, base + j * 128 + 2 * lane, n, vvec, va[j], vb[j]);
         staged_slot = 0;
     }
-
-    // scalar: the tile's first window (one exact 64-bit division on the SALU) and its ts span
-    const int64_t ts_first = p.ts[base];
+    // the row left of the tile and the tile's last row (scalar loads): first head flag, order check, ts span
+    const int64_t left0 = base > 0 ? p.ts[base - 1] : INT64_MIN;
     const int64_t ts_last = p.ts[base + nloc - 1];
+
+    // scalar: the tile's first window (one exact 64-bit division on the SALU)
+    const int64_t ts_first = (int64_t)readlane64(ta[0], 0);
     const uint64_t w0 = magic_div((uint64_t)ts_first - (uint64_t)p.s0, p.magic);
     const int64_t ws0 = p.s0 + (int64_t)(w0 * (uint64_t)p.interval);
     const bool fast32 = p.fits32 && ts_last >= ts_first && (uint64_t)(ts_last - ws0) < 0xFFFFFFF0ull;
 
-    // ---- 2. local window ids, head flags, compaction
-    unsigned long long mask_a[kChunks + 1], mask_b[kChunks + 1];
-    uint32_t lwa[kChunks + 1], lwb[kChunks + 1];
+    // ---- 2. local window ids, head flags, compaction (chunks are consecutive: running scalar count)
     bool unsorted = false;
+    int nseg_total = 0, nseg_owned = 0;
+    int64_t left_ts = left0;
 #pragma unroll
-    for (int j = 0; j <= kChunks; j++) {
-        if (j == kChunks && wave != 0) { mask_a[j] = 0; mask_b[j] = 0; lwa[j] = 0; lwb[j] = 0; continue; }
-        const int l = (j < kChunks) ? (j * 512 + 2 * tid) : (kTile + 2 * tid);
+    for (int j = 0; j < kChunksW; j++) {
+        const int l = j * 128 + 2 * lane;
         const bool pa = l < nloc, pb = l + 1 < nloc;
         const int64_t tsa = (int64_t)ta[j], tsb = (int64_t)tb[j];
-        // the row left of this wave's first row, from the scalar unit
-        const int l0 = (j < kChunks) ? (j * 512 + 128 * wave) : kTile;  // wave-uniform
-        const int64_t g0 = base + l0;
-        const bool has_left = g0 > 0 && l0 < nloc;
-        const int64_t left_ts = has_left ? p.ts[g0 - 1] : INT64_MIN;
         const int64_t prev_ts = (int64_t)from_left64((uint64_t)tb[j], (uint64_t)left_ts);
         if (pa && prev_ts > tsa) unsorted = true;
         if (pb && tsa > tsb) unsorted = true;
         bool ha, hb;
+        uint32_t la, lb;
         if (fast32) {
             const uint32_t base_lo = (uint32_t)ws0;
-            const uint32_t la = magic_div32((uint32_t)tsa - base_lo, p.m32, p.sh1_32, p.sh2_32);
-            const uint32_t lb = magic_div32((uint32_t)tsb - base_lo, p.m32, p.sh1_32, p.sh2_32);
-            // left neighbour's local window; rows left of the tile's first window wrap to a huge id (!= any la)
-            const uint32_t left_lw = (has_left && left_ts >= ws0) ? magic_div32((uint32_t)left_ts - base_lo, p.m32, p.sh1_32, p.sh2_32)
-                                                                   : 0xFFFFFFFEu;
+            la = magic_div32((uint32_t)tsa - base_lo, p.m32, p.sh1_32, p.sh2_32);
+            lb = magic_div32((uint32_t)tsb - base_lo, p.m32, p.sh1_32, p.sh2_32);
+            // left neighbour's local window; a row left of the tile's first window gets an id no row of the tile has
+            const uint32_t left_lw = (left_ts != INT64_MIN && left_ts >= ws0)
+                                         ? magic_div32((uint32_t)left_ts - base_lo, p.m32, p.sh1_32, p.sh2_32)
+                                         : 0xFFFFFFFEu;
             const uint32_t lprev = from_left32(lb, left_lw);
             ha = pa && (la != lprev);
             hb = pb && (lb != la);
-            lwa[j] = la; lwb[j] = lb;
         } else {
             const uint64_t wa = magic_div((uint64_t)tsa - (uint64_t)p.s0, p.magic);
             const uint64_t wb = magic_div((uint64_t)tsb - (uint64_t)p.s0, p.magic);
-            const uint64_t left_w = has_left ? magic_div((uint64_t)left_ts - (uint64_t)p.s0, p.magic) : ~0ull;
+            const uint64_t left_w = left_ts != INT64_MIN ? magic_div((uint64_t)left_ts - (uint64_t)p.s0, p.magic) : ~0ull;
             const uint64_t wprev = from_left64(wb, left_w);
             ha = pa && (wa != wprev);
             hb = pb && (wb != wa);
             const uint64_t da = wa - w0, db = wb - w0;
-            lwa[j] = da >= kSat ? kSat : (uint32_t)da;
-            lwb[j] = db >= kSat ? kSat : (uint32_t)db;
+            la = da >= kSat16 ? kSat16 : (uint32_t)da;
+            lb = db >= kSat16 ? kSat16 : (uint32_t)db;
         }
-        mask_a[j] = __ballot(ha);
-        mask_b[j] = __ballot(hb);
-        if (lane == 0) sh.cnt[(j < kChunks) ? (j * 4 + wave) : (kChunks * 4)] = __popcll(mask_a[j]) + __popcll(mask_b[j]);
+        const unsigned long long ma = __ballot(ha), mb = __ballot(hb);
+        int pos = nseg_total;
+        pos += __builtin_amdgcn_mbcnt_hi((unsigned)(ma >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ma, 0));
+        pos += __builtin_amdgcn_mbcnt_hi((unsigned)(mb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb, 0));
+        if (ha) { sh.seg_row[pos] = (uint16_t)l; sh.seg_lw[pos] = (uint16_t)(la >= kSat16 ? kSat16 : la); pos++; }
+        if (hb) { sh.seg_row[pos] = (uint16_t)(l + 1); sh.seg_lw[pos] = (uint16_t)(lb >= kSat16 ? kSat16 : lb); }
+        nseg_total += __popcll(ma) + __popcll(mb);
+        if (j == kChunksW - 2) nseg_owned = nseg_total;  // heads inside the 512 owned rows
+        left_ts = (int64_t)readlane64(tb[j], 63);         // last row of this chunk = left neighbour of the next
     }
-    if (tid == 0) sh.gap_n = 0;
     if (unsorted) atomicOr(&p.status[0], 1u);
-    __syncthreads();
-    // exclusive prefix of the 17 counters, once
-    if (tid < 32) {
-        int v = tid < kCnt ? sh.cnt[tid] : 0;
-        int incl = v;
-#pragma unroll
-        for (int o = 1; o < 32; o <<= 1) {
-            const int up = __shfl_up(incl, o);
-            if (tid >= o) incl += up;
-        }
-        sh.pre[tid < kCnt + 2 ? tid : kCnt + 2] = incl - v;  // pre[k] = heads before counter k ; pre[kCnt] = total
-    }
-    __syncthreads();
-    const int nseg_owned = sh.pre[kChunks * 4];
-    const int nseg_total = sh.pre[kCnt];
-#pragma unroll
-    for (int j = 0; j <= kChunks; j++) {
-        if (j == kChunks && wave != 0) continue;
-        int pos = sh.pre[(j < kChunks) ? (j * 4 + wave) : (kChunks * 4)];
-        pos += __builtin_amdgcn_mbcnt_hi((unsigned)(mask_a[j] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask_a[j], 0));
-        pos += __builtin_amdgcn_mbcnt_hi((unsigned)(mask_b[j] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask_b[j], 0));
-        const int l = (j < kChunks) ? (j * 512 + 2 * tid) : (kTile + 2 * tid);
-        const bool ha = (mask_a[j] >> lane) & 1, hb = (mask_b[j] >> lane) & 1;
-        if (ha) { sh.seg_row[pos] = (uint16_t)l; sh.seg_lw[pos] = lwa[j]; pos++; }
-        if (hb) { sh.seg_row[pos] = (uint16_t)(l + 1); sh.seg_lw[pos] = lwb[j]; }
-    }
 
-    const bool reaches_end = base + kRows >= n;
+    const bool reaches_end = base + kRowsW >= n;
     const int64_t wid_end = p.wid_base + p.W;
 
-    auto seg_wid_of = [&](int q) -> uint64_t {
+    auto wid_at = [&](int q) -> uint64_t {
         const uint32_t d = sh.seg_lw[q];
-        if (d != kSat) return w0 + d;
+        if (d != kSat16) return w0 + d;
         const int64_t t = p.ts[base + sh.seg_row[q]];
         return magic_div((uint64_t)t - (uint64_t)p.s0, p.magic);
     };
@@ -267,44 +249,42 @@ __global__ __launch_bounds__(kBlock) void rolling_fast_kernel(const AggParams p,
         const int col_type = cd ? cd->type : BOWGPU_INT64;
         const int variant = (has_nulls ? 1 : 0) | (col_type == BOWGPU_INT64 ? 2 : 0) | (need_mm ? 4 : 0) | (need_fl ? 8 : 0);
 
-        __syncthreads();  // previous pass finished with sh.val / sh.vbits / sh.obits / sh.gap_*
-        if (tid == 0) sh.gap_n = 0;
+        wave_lds_fence();  // previous pass finished with sh.val / sh.vbits / sh.obits
         if (cd && need_vals) {
             if (staged_slot != slot) {
                 const uint64_t *vp = reinterpret_cast<const uint64_t *>(cd->values);
                 const bool vvec = (reinterpret_cast<uintptr_t>(vp) & 15) == 0;
 #pragma unroll
-                for (int j = 0; j < kChunks; j++) load_pair(vp, base + j * 512 + 2 * tid, n, vvec, va[j], vb[j]);
-                if (wave == 0) load_pair(vp, base + kTile + 2 * tid, n, vvec, va[kChunks], vb[kChunks]);
+                for (int j = 0; j < kChunksW; j++) load_pair(vp, base + j * 128 + 2 * lane, n, vvec, va[j], vb[j]);
             }
 #pragma unroll
-            for (int j = 0; j < kChunks; j++)
-                *reinterpret_cast<ulonglong2 *>(&sh.val[j * 512 + 2 * tid]) = make_ulonglong2(va[j], vb[j]);
-            if (wave == 0) *reinterpret_cast<ulonglong2 *>(&sh.val[kTile + 2 * tid]) = make_ulonglong2(va[kChunks], vb[kChunks]);
+            for (int j = 0; j < kChunksW; j++)
+                *reinterpret_cast<ulonglong2 *>(&sh.val[j * 128 + 2 * lane]) = make_ulonglong2(va[j], vb[j]);
             staged_slot = -2;
-            if (has_nulls && tid < kRows / 32) sh.vbits[tid] = load_vbits32(*cd, base + 32 * (int64_t)tid);
+            if (has_nulls && lane < kRowsW / 32) sh.vbits[lane] = load_vbits32(*cd, base + 32 * (int64_t)lane);
         }
         if (any_nullable)
-            for (int i = tid; i < kMaxNullable * kSpanWords; i += kBlock) (&sh.obits[0][0])[i] = 0u;
-        __syncthreads();
+            for (int i = lane; i < kMaxNullableW * (kSpanWordsW + 1); i += kWave) (&sh.obits[0][0])[i] = 0u;
+        wave_lds_fence();
 
-        const uint64_t wid_first = nseg_owned > 0 ? seg_wid_of(0) : 0;
+        const uint64_t wid_first = nseg_owned > 0 ? wid_at(0) : 0;
         const int64_t slot_first = (int64_t)(wid_first - (uint64_t)p.wid_base);
         const int64_t span0 = slot_first & ~(int64_t)31;
+        bool any_big_gap = false;
 
-        for (int q = tid; q < nseg_owned; q += kBlock) {
+        for (int q = lane; q < nseg_owned; q += kWave) {
             const int r0 = sh.seg_row[q];
-            const uint64_t wid = seg_wid_of(q);
+            const uint64_t wid = wid_at(q);
             int r1;
             uint64_t next_wid;
             if (q + 1 < nseg_total) {
                 r1 = sh.seg_row[q + 1];
-                next_wid = seg_wid_of(q + 1);
+                next_wid = wid_at(q + 1);
             } else if (reaches_end) {
                 r1 = nloc;
                 next_wid = (uint64_t)wid_end;
             } else {
-                // rows run past the halo: hand the window (all its column passes) to the cooperative path
+                // rows run past the look-ahead: hand the window (all its column passes) to the cooperative path
                 if (first_pass) {
                     const unsigned idx = atomicAdd(&p.status[1], 1u);
                     if ((int64_t)idx < p.long_cap) {
@@ -323,11 +303,8 @@ __global__ __launch_bounds__(kBlock) void rolling_fast_kernel(const AggParams p,
             const int64_t oslot = (int64_t)(wid - (uint64_t)p.wid_base);
             const int64_t nrows = r1 - r0;
             const int64_t gap = (int64_t)(next_wid - wid) - 1;
-            const bool big_gap = gap > kGapInline;
-            if (big_gap) {
-                const int gi = atomicAdd(&sh.gap_n, 1);
-                if (gi < kGapList) sh.gap_q[gi] = q;
-            }
+            const bool big_gap = gap > kGapInlineW;
+            any_big_gap |= big_gap;
             if ((uint64_t)oslot < (uint64_t)p.W) {
                 int nb = 0;
                 for (unsigned m = my_mask; m; m &= m - 1) {
@@ -337,7 +314,7 @@ __global__ __launch_bounds__(kBlock) void rolling_fast_kernel(const AggParams p,
                     if (a.out_valid) {
                         if (v.valid) {
                             const int64_t lb = oslot - span0;
-                            if (lb >= 0 && lb < kSpanBits) atomicOr(&sh.obits[nb][lb >> 5], 1u << (lb & 31));
+                            if (lb >= 0 && lb < kSpanBitsW) atomicOr(&sh.obits[nb][lb >> 5], 1u << (lb & 31));
                             else atomicOr(&a.out_valid[oslot >> 5], 1u << (oslot & 31));
                         }
                         nb++;
@@ -359,25 +336,21 @@ __global__ __launch_bounds__(kBlock) void rolling_fast_kernel(const AggParams p,
                 }
             }
         }
-        __syncthreads();
+        wave_lds_fence();
 
-        // ---- big gaps (sparse data): the whole workgroup writes the empty windows, coalesced
-        const int n_gaps = sh.gap_n;
-        if (n_gaps > 0) {
-            const bool overflow = n_gaps > kGapList;
-            const int n_iter = overflow ? nseg_owned : n_gaps;
-            for (int gi = 0; gi < n_iter; gi++) {
-                const int q = overflow ? gi : sh.gap_q[gi];
+        // ---- big gaps (sparse data): the whole wave writes the empty windows, coalesced
+        if (__ballot(any_big_gap)) {
+            for (int q = 0; q < nseg_owned; q++) {
                 if (q + 1 >= nseg_total && !reaches_end) continue;
-                const uint64_t wid = seg_wid_of(q);
-                const uint64_t next_wid = (q + 1 < nseg_total) ? seg_wid_of(q + 1) : (uint64_t)wid_end;
+                const uint64_t wid = wid_at(q);
+                const uint64_t next_wid = (q + 1 < nseg_total) ? wid_at(q + 1) : (uint64_t)wid_end;
                 const int64_t gap = (int64_t)(next_wid - wid) - 1;
-                if (gap <= kGapInline) continue;
+                if (gap <= kGapInlineW) continue;
                 const int64_t oslot = (int64_t)(wid - (uint64_t)p.wid_base);
                 const int64_t win_start = p.s0 + (int64_t)(wid * (uint64_t)p.interval);
                 Stats e;
                 stats_init(e);
-                for (int64_t gk = 1 + tid; gk <= gap; gk += kBlock) {
+                for (int64_t gk = 1 + lane; gk <= gap; gk += kWave) {
                     const int64_t gs = oslot + gk;
                     if (gs < 0 || gs >= p.W) break;
                     const int64_t gstart = win_start + gk * p.interval;
@@ -395,19 +368,19 @@ __global__ __launch_bounds__(kBlock) void rolling_fast_kernel(const AggParams p,
             int64_t slot_end;
             {
                 const int ql = nseg_owned - 1;
-                if (ql + 1 < nseg_total) slot_end = (int64_t)(seg_wid_of(ql + 1) - (uint64_t)p.wid_base);
+                if (ql + 1 < nseg_total) slot_end = (int64_t)(wid_at(ql + 1) - (uint64_t)p.wid_base);
                 else if (reaches_end) slot_end = p.W;
-                else slot_end = (int64_t)(seg_wid_of(ql) - (uint64_t)p.wid_base);  // long window: not ours
+                else slot_end = (int64_t)(wid_at(ql) - (uint64_t)p.wid_base);  // long window: not ours
             }
             if (slot_end > p.W) slot_end = p.W;
             int64_t lim = slot_end - span0;
-            if (lim > kSpanBits) lim = kSpanBits;
+            if (lim > kSpanBitsW) lim = kSpanBitsW;
             const int nwords = (int)((lim + 31) >> 5);
             int nb = 0;
             for (unsigned m = my_mask; m; m &= m - 1) {
                 const AggDesc &a = p.aggs[__ffs(m) - 1];
                 if (!a.out_valid) continue;
-                for (int w = tid; w < nwords; w += kBlock) {
+                for (int w = lane; w < nwords; w += kWave) {
                     const uint32_t bits = sh.obits[nb][w];
                     const int64_t gw = (span0 >> 5) + w;
                     const int64_t wlo = gw << 5, whi = wlo + 32;
@@ -425,11 +398,11 @@ __global__ __launch_bounds__(kBlock) void rolling_fast_kernel(const AggParams p,
 
 int launch_rolling_fast(Ctx *c, const AggParams &p) {
     if (p.n <= 0) return 0;
-    const int64_t ntiles = (p.n + kTile - 1) / kTile;
+    const int64_t ntiles = (p.n + kTileW - 1) / kTileW;
     const int64_t per_xcd = (ntiles + 7) / 8;
     const int64_t grid = per_xcd * 8;
     if (grid > 0x7FFFFFFFll) return fail(BOWGPU_ERR_UNSUPPORTED, "too many rows for one launch: %lld", (long long)p.n);
-    hipLaunchKernelGGL(rolling_fast_kernel, dim3((unsigned)grid), dim3(kBlock), 0, c->stream, p, ntiles, per_xcd);
+    hipLaunchKernelGGL(rolling_wave_kernel, dim3((unsigned)grid), dim3(kWave), 0, c->stream, p, ntiles, per_xcd);
     BG_HIP(hipGetLastError());
     return 0;
 }

@@ -6,7 +6,7 @@ for f in glob.glob(root + '/p*/**/*counter_collection.csv', recursive=True):
         k = r['Kernel_Name'][:48]
         acc[k][r['Counter_Name']].append(float(r['Counter_Value']))
 for k, d in acc.items():
-    if 'rolling' not in k and 'long' not in k: continue
+    if "rolling" not in k and "long" not in k: continue
     print(k)
     for c, v in sorted(d.items()):
         print('   %-24s n=%d avg=%.4g' % (c, len(v), sum(v)/len(v)))
