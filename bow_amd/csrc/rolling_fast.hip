@@ -147,18 +147,32 @@ __global__ __launch_bounds__(kWave, 5) void rolling_wave_kernel(const AggParams 
     const uint64_t *__restrict__ ts = reinterpret_cast<const uint64_t *>(p.ts);
     const bool ts_vec = (reinterpret_cast<uintptr_t>(ts) & 15) == 0;
 
-    // ---- 1. loads: ts, then the first value column right behind it
+    // ---- 1. loads: ts, then the first value column right behind it.  Interior tiles (all rows exist,
+    // 16-B aligned columns) take straight-line 16-B/lane loads; only the last tile / odd offsets are guarded.
     uint64_t ta[kChunksW], tb[kChunksW];
-#pragma unroll
-    for (int j = 0; j < kChunksW; j++) load_pair(ts, base + j * 128 + 2 * lane, n, ts_vec, ta[j], tb[j]);
     uint64_t va[kChunksW], vb[kChunksW];
+    const uint64_t *__restrict__ vp0 = p.ncols > 0 ? reinterpret_cast<const uint64_t *>(p.cols[0].values) : nullptr;
+    const bool v0_vec = (reinterpret_cast<uintptr_t>(vp0) & 15) == 0;
+    const bool interior = (base + kRowsW <= n) && ts_vec && v0_vec;  // wave-uniform
     int staged_slot = -1;
-    if (p.ncols > 0 && p.cols[0].values != nullptr) {
-        const uint64_t *vp = reinterpret_cast<const uint64_t *>(p.cols[0].values);
-        const bool vvec = (reinterpret_cast<uintptr_t>(vp) & 15) == 0;
+    if (interior) {
+        const ulonglong2 *tp = reinterpret_cast<const ulonglong2 *>(ts + base) + lane;
 #pragma unroll
-        for (int j = 0; j < kChunksW; j++) load_pair(vp, base + j * 128 + 2 * lane, n, vvec, va[j], vb[j]);
-        staged_slot = 0;
+        for (int j = 0; j < kChunksW; j++) { const ulonglong2 t = tp[j * 64]; ta[j] = t.x; tb[j] = t.y; }
+        if (vp0 != nullptr) {
+            const ulonglong2 *vq = reinterpret_cast<const ulonglong2 *>(vp0 + base) + lane;
+#pragma unroll
+            for (int j = 0; j < kChunksW; j++) { const ulonglong2 t = vq[j * 64]; va[j] = t.x; vb[j] = t.y; }
+            staged_slot = 0;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < kChunksW; j++) load_pair(ts, base + j * 128 + 2 * lane, n, ts_vec, ta[j], tb[j]);
+        if (vp0 != nullptr) {
+#pragma unroll
+            for (int j = 0; j < kChunksW; j++) load_pair(vp0, base + j * 128 + 2 * lane, n, v0_vec, va[j], vb[j]);
+            staged_slot = 0;
+        }
     }
     // the row left of the tile and the tile's last row (scalar loads): first head flag, order check, ts span
     const int64_t left0 = base > 0 ? p.ts[base - 1] : INT64_MIN;
@@ -254,8 +268,14 @@ __global__ __launch_bounds__(kWave, 5) void rolling_wave_kernel(const AggParams 
             if (staged_slot != slot) {
                 const uint64_t *vp = reinterpret_cast<const uint64_t *>(cd->values);
                 const bool vvec = (reinterpret_cast<uintptr_t>(vp) & 15) == 0;
+                if (interior && vvec) {
+                    const ulonglong2 *vq = reinterpret_cast<const ulonglong2 *>(vp + base) + lane;
 #pragma unroll
-                for (int j = 0; j < kChunksW; j++) load_pair(vp, base + j * 128 + 2 * lane, n, vvec, va[j], vb[j]);
+                    for (int j = 0; j < kChunksW; j++) { const ulonglong2 t = vq[j * 64]; va[j] = t.x; vb[j] = t.y; }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < kChunksW; j++) load_pair(vp, base + j * 128 + 2 * lane, n, vvec, va[j], vb[j]);
+                }
             }
 #pragma unroll
             for (int j = 0; j < kChunksW; j++)
