@@ -71,27 +71,26 @@ class Interp(C.Structure):
 
 
 class CarryState(C.Structure):
-    _fields_ = [("sum", C.c_double), ("vmin", C.c_double), ("vmax", C.c_double), ("last_t", C.c_double),
-                ("last_v", C.c_double), ("integ", C.c_double), ("count", C.c_int64), ("nrows", C.c_int64),
-                ("first_bits", C.c_int64), ("last_bits", C.c_int64), ("has_value", C.c_int32),
-                ("has_point", C.c_int32), ("has_pair", C.c_int32), ("_pad", C.c_int32)]
+    _fields_ = [("sum", C.c_double), ("vmin", C.c_double), ("vmax", C.c_double), ("nn_min", C.c_double),
+                ("nn_max", C.c_double), ("first_bits", C.c_uint64), ("last_bits", C.c_uint64),
+                ("count", C.c_int64), ("nrows", C.c_int64), ("has_value", C.c_int32), ("has_nn", C.c_int32)]
 
 
 class ShardCarry(C.Structure):
-    _fields_ = [("window_id", C.c_int64), ("first_window_id", C.c_int64), ("first_ts", C.c_int64),
+    _fields_ = [("first_window_id", C.c_int64), ("last_window_id", C.c_int64), ("first_ts", C.c_int64),
                 ("last_ts", C.c_int64), ("nrows", C.c_int64), ("naggs", C.c_int32), ("_pad", C.c_int32),
-                ("agg", CarryState * CARRY_MAX_AGGS)]
+                ("last", CarryState * CARRY_MAX_AGGS)]
 
 
 # every symbol include/bowgpu.h declares (checked by tests/test_abi_symbols.py)
 SYMBOLS = [
     "bowgpu_abi_version", "bowgpu_last_error", "bowgpu_device_count", "bowgpu_set_device", "bowgpu_device_name",
-    "bowgpu_set_stream", "bowgpu_synchronize", "bowgpu_malloc", "bowgpu_free", "bowgpu_memcpy_h2d",
+    "bowgpu_set_stream", "bowgpu_synchronize", "bowgpu_last_kernel_ms", "bowgpu_malloc", "bowgpu_free", "bowgpu_memcpy_h2d",
     "bowgpu_memcpy_d2h", "bowgpu_memset", "bowgpu_timer_create", "bowgpu_timer_start", "bowgpu_timer_stop",
     "bowgpu_timer_elapsed_ms", "bowgpu_timer_destroy", "bowgpu_enforce_interval_and_offset", "bowgpu_plan_windows",
     "bowgpu_rolling_aggregate", "bowgpu_window_bounds", "bowgpu_aggregate_whole",
     "bowgpu_rolling_interpolate_count", "bowgpu_rolling_interpolate_fill", "bowgpu_fill_linear",
-    "bowgpu_is_col_sorted", "bowgpu_shard_aggregate", "bowgpu_shard_stitch", "bowgpu_gen_dense",
+    "bowgpu_is_col_sorted", "bowgpu_shard_aggregate", "bowgpu_shard_fix_first", "bowgpu_carry_merge", "bowgpu_gen_dense",
     "bowgpu_gen_sparse", "bowgpu_checksum64",
 ]
 
@@ -303,6 +302,12 @@ def set_stream(ptr):
 
 def synchronize():
     check(lib().bowgpu_synchronize())
+
+
+def last_kernel_ms():
+    ms = C.c_double(0)
+    check(lib().bowgpu_last_kernel_ms(C.byref(ms)))
+    return ms.value
 
 
 def enforce_interval_and_offset(interval, offset):

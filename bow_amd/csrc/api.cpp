@@ -345,10 +345,23 @@ static int validate_aggs(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, 
     return 0;
 }
 
-// Builds AggParams for the rows of `cols` (already planned) and runs the kernels.
-static int run_aggregate(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t ts_col, const Plan &plan,
-                         int inclusive, const bowgpu_agg *aggs, int32_t naggs, bowgpu_out *outs,
-                         int64_t wid_base, int64_t W, int64_t *long_windows, double *kernel_ms) {
+// One aggregate call in three stages so that the sharded entry points can reuse them:
+//   job_build  - device residency of columns / outputs + the kernels' descriptor block
+//   job_run    - bitmap initialisation, tile kernel, long-window kernel
+//   job_finish - null counts of the nullable outputs, copy-back of host-resident outputs
+struct AggJob {
+    std::vector<DevCol> dcols;
+    std::vector<DevOut> douts;
+    DevCol dts;
+    AggParams P;
+    int64_t W = 0;
+    size_t scratch_bytes = 0;
+    int inclusive = 0;
+};
+
+static int job_build(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t ts_col, const Plan &plan, int inclusive,
+                     const bowgpu_agg *aggs, int32_t naggs, bowgpu_out *outs, int64_t wid_base, int64_t W,
+                     bool holds_row0, AggJob *job) {
     const bowgpu_col *tsc = &cols[ts_col];
     const int64_t n = tsc->length;
     for (int i = 0; i < ncols; i++)
@@ -362,19 +375,23 @@ static int run_aggregate(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t 
             return fail(BOWGPU_ERR_TS_NULLS, "interval column has %lld nulls: outside the device path", (long long)probe.null_count);
     }
 
-    // column slots: each distinct input column whose values some reducer reads
-    std::vector<DevCol> dcols(ncols);
+    job->dcols.clear();
+    job->dcols.resize(ncols);
+    job->douts.clear();
+    job->douts.resize(naggs);
+    job->W = W;
+    job->inclusive = inclusive;
+    std::vector<DevCol> &dcols = job->dcols;
     std::vector<int> slot_of(ncols, -1);
-    AggParams P;
+    AggParams &P = job->P;
     memset(&P, 0, sizeof P);
-    DevCol dts;
     {
         bowgpu_col t = *tsc;
         t.validity = nullptr;
         t.null_count = 0;
-        BG_TRY(devcol_prepare(c, &t, &dts, true, false));
+        BG_TRY(devcol_prepare(c, &t, &job->dts, true, false));
     }
-    P.ts = reinterpret_cast<const int64_t *>(dts.values);
+    P.ts = reinterpret_cast<const int64_t *>(job->dts.values);
     P.n = n;
     P.row_base = 0;
     P.s0 = plan.s0;
@@ -394,8 +411,9 @@ static int run_aggregate(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t 
     }
     P.inclusive = inclusive;
     P.naggs = naggs;
-    P.pre_rows = (n > 0 && wid_base == 0 && plan.s0 > plan.first_ts) ? 1 : 0;
+    P.pre_rows = (n > 0 && holds_row0 && plan.s0 > plan.first_ts) ? 1 : 0;
 
+    // column slots: each distinct input column whose values some reducer reads
     std::vector<int> nullable_in_slot;
     for (int i = 0; i < naggs; i++) {
         if (!kind_reads_values(aggs[i].kind)) continue;
@@ -411,7 +429,7 @@ static int run_aggregate(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t 
             DevCol &dc = dcols[col];
             if (dc.values == nullptr && n > 0) {
                 if (col == ts_col) {
-                    dc.values = dts.values; dc.length = n; dc.type = BOWGPU_INT64; dc.null_count = 0;
+                    dc.values = job->dts.values; dc.length = n; dc.type = BOWGPU_INT64; dc.null_count = 0;
                 } else {
                     BG_TRY(devcol_prepare(c, &cols[col], &dc, true, true));
                 }
@@ -427,7 +445,6 @@ static int run_aggregate(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t 
         P.aggs[i].slot = s;
     }
 
-    std::vector<DevOut> douts(naggs);
     for (int i = 0; i < naggs; i++) {
         AggDesc &a = P.aggs[i];
         a.kind = aggs[i].kind;
@@ -438,37 +455,42 @@ static int run_aggregate(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t 
         a.out_type = t;
         a.n_factors = aggs[i].n_factors;
         for (int f = 0; f < a.n_factors; f++) a.factors[f] = aggs[i].factors[f];
-        BG_TRY(devout_prepare(c, &outs[i], W, &douts[i]));
-        a.out_values = douts[i].values;
-        a.out_valid = kind_never_nil(aggs[i].kind) ? nullptr : reinterpret_cast<uint32_t *>(douts[i].validity);
+        BG_TRY(devout_prepare(c, &outs[i], W, &job->douts[i]));
+        a.out_values = job->douts[i].values;
+        a.out_valid = kind_never_nil(aggs[i].kind) ? nullptr : reinterpret_cast<uint32_t *>(job->douts[i].validity);
     }
 
     // status words + long-window list
     const int64_t ntiles = (n + 511) / 512;  // the lean kernel's tile (one wavefront); at most one long window per tile
-    const size_t scratch_bytes = 4096 + (size_t)(ntiles + 1) * 16;
+    job->scratch_bytes = 8192 + (size_t)(ntiles + 1) * 16;
     void *dscr;
-    BG_TRY(ctx_scratch(c, scratch_bytes, &dscr));
+    BG_TRY(ctx_scratch(c, job->scratch_bytes, &dscr));
     P.status = reinterpret_cast<uint32_t *>(dscr);
-    P.long_list = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(dscr) + 4096);
+    P.long_list = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(dscr) + 8192);
     P.long_cap = ntiles + 1;
-    BG_HIP(hipMemsetAsync(P.status, 0, 64, c->stream));
+    return 0;
+}
 
+static int job_run(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, int64_t *long_windows, double *kernel_ms) {
+    AggParams &P = job->P;
+    const int64_t W = job->W;
+    BG_HIP(hipMemsetAsync(P.status, 0, 64, c->stream));
     if (W > 0) {
         for (int i = 0; i < naggs; i++) {
             const size_t vb = (size_t)((W + 7) >> 3);
             // never-nil reducers: all-ones bitmap (tail bits cleared); nullable ones start all-null (bowbuffer.go:25)
-            BG_HIP(hipMemsetAsync(douts[i].validity, kind_never_nil(aggs[i].kind) ? 0xFF : 0x00, ((vb + 3) & ~(size_t)3), c->stream));
-            if (kind_never_nil(aggs[i].kind)) BG_TRY(launch_fix_tail_bits(c, douts[i].validity, W));
+            BG_HIP(hipMemsetAsync(job->douts[i].validity, kind_never_nil(aggs[i].kind) ? 0xFF : 0x00, ((vb + 3) & ~(size_t)3), c->stream));
+            if (kind_never_nil(aggs[i].kind)) BG_TRY(launch_fix_tail_bits(c, job->douts[i].validity, W));
         }
-        // kernel_ms brackets the dominant kernel only (rolling_agg_kernel), on the stream it runs on
         // The lean kernel covers exclusive windows without time-weighted reducers and without rows below
         // s0; everything else (and BOWGPU_FORCE_GENERAL=1, used by the tests to cover both) takes the
         // general kernel.  Both are HIP; results are identical where both apply.
-        bool lean = !inclusive && !P.pre_rows;
+        bool lean = !job->inclusive && !P.pre_rows;
         for (int i = 0; i < naggs; i++)
             if (aggs[i].kind >= BOWGPU_AGG_INTEGRAL_STEP && aggs[i].kind <= BOWGPU_AGG_WAVG_LINEAR) lean = false;
         const char *force = getenv("BOWGPU_FORCE_GENERAL");
         if (force && force[0] == '1') lean = false;
+        // kernel_ms brackets the dominant kernel only, on the stream it runs on
         BG_HIP(hipEventRecord(c->ev0, c->stream));
         if (lean) BG_TRY(launch_rolling_fast(c, P));
         else BG_TRY(launch_rolling_aggregate(c, P));
@@ -476,40 +498,59 @@ static int run_aggregate(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t 
     }
     // status -> host (pinned) ; decides whether the long-window kernel is needed
     uint32_t *hstat;
-    BG_TRY(ctx_pinned(c, 64, reinterpret_cast<void **>(&hstat)));
+    BG_TRY(ctx_pinned(c, 4096, reinterpret_cast<void **>(&hstat)));
     BG_HIP(hipMemcpyAsync(hstat, P.status, 16, hipMemcpyDeviceToHost, c->stream));
     BG_HIP(hipStreamSynchronize(c->stream));
     if (hstat[0]) return fail(BOWGPU_ERR_TS_UNSORTED, "interval column is not ascending: outside the device path");
     if (hstat[2]) return fail(BOWGPU_ERR_HIP, "internal: long-window list overflow");
     const int64_t n_long = hstat[1];
     if (n_long > 0) BG_TRY(launch_long_windows(c, P, n_long));
+    if (long_windows) *long_windows = n_long;
+    {
+        float ms = 0;
+        if (W > 0) {
+            BG_HIP(hipEventSynchronize(c->ev1));
+            BG_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        }
+        c->last_kernel_ms = ms;
+        if (kernel_ms) *kernel_ms = ms;
+    }
+    return 0;
+}
 
-    // null counts of the nullable outputs
+static int job_finish(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs) {
+    const int64_t W = job->W;
     std::vector<int64_t> nulls(naggs, 0);
     if (W > 0) {
         void *d;
-        BG_TRY(ctx_scratch(c, scratch_bytes, &d));
+        BG_TRY(ctx_scratch(c, job->scratch_bytes, &d));
         uint64_t *dcnt = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(d) + 1024);
         uint64_t *hcnt;
-        BG_TRY(ctx_pinned(c, 64 + 8 * kMaxAggs, reinterpret_cast<void **>(&hcnt)));
+        BG_TRY(ctx_pinned(c, 4096, reinterpret_cast<void **>(&hcnt)));
         hcnt += 8;
+        bool any = false;
         for (int i = 0; i < naggs; i++) {
             if (kind_never_nil(aggs[i].kind)) continue;
-            BG_TRY(launch_popcount(c, reinterpret_cast<const uint32_t *>(douts[i].validity), 0, W, dcnt + i));
+            BG_TRY(launch_popcount(c, reinterpret_cast<const uint32_t *>(job->douts[i].validity), 0, W, dcnt + i));
             BG_HIP(hipMemcpyAsync(hcnt + i, dcnt + i, 8, hipMemcpyDeviceToHost, c->stream));
+            any = true;
         }
-        BG_HIP(hipStreamSynchronize(c->stream));
+        if (any) BG_HIP(hipStreamSynchronize(c->stream));
         for (int i = 0; i < naggs; i++)
             if (!kind_never_nil(aggs[i].kind)) nulls[i] = W - (int64_t)hcnt[i];
     }
-    for (int i = 0; i < naggs; i++) BG_TRY(devout_finish(c, &douts[i], W, P.aggs[i].out_type, nulls[i]));
+    for (int i = 0; i < naggs; i++) BG_TRY(devout_finish(c, &job->douts[i], W, job->P.aggs[i].out_type, nulls[i]));
     BG_HIP(hipStreamSynchronize(c->stream));
-    if (long_windows) *long_windows = n_long;
-    if (kernel_ms) {
-        float ms = 0;
-        if (W > 0) BG_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
-        *kernel_ms = ms;
-    }
+    return 0;
+}
+
+static int run_aggregate(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t ts_col, const Plan &plan,
+                         int inclusive, const bowgpu_agg *aggs, int32_t naggs, bowgpu_out *outs,
+                         int64_t wid_base, int64_t W, int64_t *long_windows, double *kernel_ms) {
+    AggJob job;
+    BG_TRY(job_build(c, cols, ncols, ts_col, plan, inclusive, aggs, naggs, outs, wid_base, W, wid_base == 0, &job));
+    BG_TRY(job_run(c, &job, aggs, naggs, long_windows, kernel_ms));
+    BG_TRY(job_finish(c, &job, aggs, naggs));
     return 0;
 }
 
@@ -570,6 +611,13 @@ int bowgpu_synchronize(void) {
     Ctx *c;
     BG_TRY(ctx_get(&c));
     BG_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int bowgpu_last_kernel_ms(double *ms) {
+    Ctx *c;
+    BG_TRY(ctx_get(&c));
+    *ms = c->last_kernel_ms;
     return 0;
 }
 
@@ -706,6 +754,143 @@ int bowgpu_rolling_aggregate(const bowgpu_col *cols, int32_t ncols, int32_t ts_c
 
 // ---- entry points implemented in extras.cpp: window_bounds, aggregate_whole, interpolate,
 // fill_linear, is_col_sorted, shard_* ----
+
+
+// ---- row-range sharding -------------------------------------------------------------------
+
+static int shard_check(const bowgpu_col *cols, int32_t ncols, const bowgpu_agg *aggs, int32_t naggs, bowgpu_out *outs,
+                       const bowgpu_options *o) {
+    if (o && o->inclusive) return fail(BOWGPU_ERR_UNSUPPORTED, "sharded aggregate: inclusive windows are not supported yet");
+    for (int i = 0; i < naggs; i++) {
+        const int k = aggs[i].kind;
+        if (k >= BOWGPU_AGG_INTEGRAL_STEP && k <= BOWGPU_AGG_WAVG_LINEAR)
+            return fail(BOWGPU_ERR_UNSUPPORTED, "sharded aggregate: time-weighted reducers are not supported yet");
+        if (outs[i].residency != BOWGPU_DEVICE) return fail(BOWGPU_ERR_UNSUPPORTED, "sharded aggregate: outputs must be device-resident");
+    }
+    for (int i = 0; i < ncols; i++)
+        if (cols[i].residency != BOWGPU_DEVICE) return fail(BOWGPU_ERR_UNSUPPORTED, "sharded aggregate: columns must be device-resident");
+    if (naggs > BOWGPU_CARRY_MAX_AGGS) return fail(BOWGPU_ERR_UNSUPPORTED, "sharded aggregate: too many aggregations");
+    return 0;
+}
+
+// the plan of a shard: global s0, local first/last ts -> local window range
+static int shard_plan(Ctx *c, const bowgpu_col *ts, int64_t interval, int64_t raw_offset, int64_t global_s0, Plan *p,
+                      int64_t *wid_first, int64_t *wid_last) {
+    BG_TRY(plan_make(c, ts, interval, raw_offset, p));  // validates type / interval / first ts; local s0, W are replaced below
+    p->s0 = global_s0;
+    *wid_first = -1;
+    *wid_last = -1;
+    p->W = 0;
+    if (ts->length == 0) return 0;
+    if (p->last_ts < global_s0) return 0;
+    const int64_t f = p->first_ts < global_s0 ? global_s0 : p->first_ts;
+    *wid_first = (int64_t)(((uint64_t)f - (uint64_t)global_s0) / (uint64_t)interval);
+    *wid_last = (int64_t)(((uint64_t)p->last_ts - (uint64_t)global_s0) / (uint64_t)interval);
+    p->W = *wid_last - *wid_first + 1;
+    return 0;
+}
+
+int bowgpu_shard_aggregate(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval,
+                           const bowgpu_options *opts, int64_t global_s0, int32_t holds_global_row0,
+                           int64_t lead, const bowgpu_agg *aggs, int32_t naggs, bowgpu_out *outs,
+                           bowgpu_shard_carry *carry) {
+    if (!cols || ncols <= 0 || !carry || !outs) return fail(BOWGPU_ERR_ARG, "null argument");
+    if (ts_col < 0 || ts_col >= ncols) return fail(BOWGPU_ERR_BAD_COL, "no interval column with index %d", ts_col);
+    bowgpu_options o = {0, 0, 0};
+    if (opts) o = *opts;
+    int inclusive = 0, nic = -1;
+    BG_TRY(validate_aggs(cols, ncols, ts_col, aggs, naggs, &inclusive, &nic));
+    BG_TRY(shard_check(cols, ncols, aggs, naggs, outs, &o));
+    Ctx *c;
+    BG_TRY(ctx_get(&c));
+    Plan plan;
+    int64_t wf, wl;
+    BG_TRY(shard_plan(c, &cols[ts_col], interval, o.offset, global_s0, &plan, &wf, &wl));
+    memset(carry, 0, sizeof *carry);
+    carry->first_window_id = wf;
+    carry->last_window_id = wl;
+    carry->first_ts = plan.first_ts;
+    carry->last_ts = plan.last_ts;
+    carry->nrows = cols[ts_col].length;
+    carry->naggs = naggs;
+    AggJob job;
+    if (lead < 0 || (wf < 0 && lead != 0) || (wf >= 0 && lead > wf)) return fail(BOWGPU_ERR_ARG, "bad lead_empty_windows %lld", (long long)lead);
+    const int64_t Wtot = plan.W + lead;
+    BG_TRY(job_build(c, cols, ncols, ts_col, plan, 0, aggs, naggs, outs, wf < 0 ? 0 : wf - lead, Wtot, holds_global_row0 != 0, &job));
+    BG_TRY(job_run(c, &job, aggs, naggs, nullptr, nullptr));
+    if (lead > 0) BG_TRY(launch_fill_empty(c, job.P, 0, lead));
+    if (plan.W > 0) {
+        // running state of the last window over this shard's rows
+        bowgpu_carry_state *dst = reinterpret_cast<bowgpu_carry_state *>(reinterpret_cast<char *>(job.P.status) + 4096);
+        BG_TRY(launch_range_state(c, job.P, 0, (uint64_t)wl, nullptr, dst));
+        BG_HIP(hipMemcpyAsync(carry->last, dst, sizeof(bowgpu_carry_state) * naggs, hipMemcpyDeviceToHost, c->stream));
+        BG_HIP(hipStreamSynchronize(c->stream));
+    }
+    BG_TRY(job_finish(c, &job, aggs, naggs));
+    return 0;
+}
+
+int bowgpu_shard_fix_first(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval,
+                           const bowgpu_options *opts, int64_t global_s0, int64_t lead, const bowgpu_agg *aggs,
+                           int32_t naggs, bowgpu_out *outs, int64_t first_window_id, const bowgpu_carry_state *seeds,
+                           bowgpu_carry_state *merged_out) {
+    if (!cols || ncols <= 0 || !seeds || !outs) return fail(BOWGPU_ERR_ARG, "null argument");
+    bowgpu_options o = {0, 0, 0};
+    if (opts) o = *opts;
+    int inclusive = 0, nic = -1;
+    BG_TRY(validate_aggs(cols, ncols, ts_col, aggs, naggs, &inclusive, &nic));
+    BG_TRY(shard_check(cols, ncols, aggs, naggs, outs, &o));
+    Ctx *c;
+    BG_TRY(ctx_get(&c));
+    Plan plan;
+    int64_t wf, wl;
+    BG_TRY(shard_plan(c, &cols[ts_col], interval, o.offset, global_s0, &plan, &wf, &wl));
+    if (wf != first_window_id) return fail(BOWGPU_ERR_ARG, "first_window_id %lld does not match the shard (%lld)", (long long)first_window_id, (long long)wf);
+    AggJob job;
+    if (lead < 0 || lead > wf) return fail(BOWGPU_ERR_ARG, "bad lead_empty_windows %lld", (long long)lead);
+    const int64_t Wtot = plan.W + lead;
+    BG_TRY(job_build(c, cols, ncols, ts_col, plan, 0, aggs, naggs, outs, wf - lead, Wtot, false, &job));
+    // the caller's validity bytes are the truth for this second phase: bring them into the word-aligned working copy
+    for (int i = 0; i < naggs; i++)
+        BG_HIP(hipMemcpyAsync(job.douts[i].validity, outs[i].validity, (size_t)((Wtot + 7) >> 3), hipMemcpyDeviceToDevice, c->stream));
+    char *scr = reinterpret_cast<char *>(job.P.status);
+    bowgpu_carry_state *dseed = reinterpret_cast<bowgpu_carry_state *>(scr + 4096);
+    bowgpu_carry_state *dout = reinterpret_cast<bowgpu_carry_state *>(scr + 4096 + 2048);
+    BG_HIP(hipMemcpyAsync(dseed, seeds, sizeof(bowgpu_carry_state) * naggs, hipMemcpyHostToDevice, c->stream));
+    BG_TRY(launch_range_state(c, job.P, 1, (uint64_t)wf, dseed, dout));
+    if (merged_out) {
+        BG_HIP(hipMemcpyAsync(merged_out, dout, sizeof(bowgpu_carry_state) * naggs, hipMemcpyDeviceToHost, c->stream));
+        BG_HIP(hipStreamSynchronize(c->stream));
+    }
+    BG_TRY(job_finish(c, &job, aggs, naggs));
+    return 0;
+}
+
+int bowgpu_carry_merge(const bowgpu_carry_state *L, const bowgpu_carry_state *R, bowgpu_carry_state *out) {
+    // concatenation of two row ranges of one window, left then right (same rules as the device stats_merge)
+    if (!L || !R || !out) return fail(BOWGPU_ERR_ARG, "null argument");
+    bowgpu_carry_state m = *L;
+    m.nrows = L->nrows + R->nrows;
+    if (R->has_value) {
+        if (!L->has_value) {
+            const int64_t nrows = m.nrows;
+            m = *R;
+            m.nrows = nrows;
+        } else {
+            m.sum = L->sum + R->sum;
+            m.count = L->count + R->count;
+            if (R->has_nn) {
+                if (R->nn_min < m.vmin) m.vmin = R->nn_min;
+                if (R->nn_max > m.vmax) m.vmax = R->nn_max;
+                if (!m.has_nn) { m.nn_min = R->nn_min; m.nn_max = R->nn_max; m.has_nn = 1; }
+                else { if (R->nn_min < m.nn_min) m.nn_min = R->nn_min; if (R->nn_max > m.nn_max) m.nn_max = R->nn_max; }
+            }
+            m.last_bits = R->last_bits;
+        }
+    }
+    *out = m;
+    return 0;
+}
 
 int bowgpu_gen_dense(int64_t row0, int64_t n, uint64_t seed, int64_t *ts_dev, double *val_dev) {
     Ctx *c;

@@ -40,6 +40,7 @@ struct Ctx {
     void *h_pinned = nullptr;
     size_t h_pinned_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double last_kernel_ms = 0.0;
     void *d_params = nullptr;      // 4 KB device block holding the kernels' descriptor struct
 };
 int ctx_get(Ctx **out);                       // initialises HIP on first use; fails loudly without a GPU
@@ -55,6 +56,11 @@ struct DevBuf {
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
+    DevBuf(DevBuf &&o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+    DevBuf &operator=(DevBuf &&o) noexcept {
+        if (this != &o) { if (p) (void)hipFree(p); p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0; }
+        return *this;
+    }
     ~DevBuf() { if (p) (void)hipFree(p); }
     int alloc(size_t n);
 };
@@ -157,6 +163,12 @@ int launch_rolling_fast(Ctx *c, const AggParams &p);        // lean kernel for e
 int launch_long_windows(Ctx *c, const AggParams &p, int64_t n_long);
 int launch_fix_tail_bits(Ctx *c, uint8_t *bitmap, int64_t nbits);
 int launch_popcount(Ctx *c, const uint32_t *words, int64_t bit0, int64_t nbits, uint64_t *d_count);
+
+// shard.hip
+int launch_range_state(Ctx *c, const AggParams &p, int mode, uint64_t wid, const bowgpu_carry_state *d_seeds,
+                       bowgpu_carry_state *d_states_out);
+
+int launch_fill_empty(Ctx *c, const AggParams &p, int64_t slot0, int64_t slot1);
 
 // generate.hip
 int launch_gen_dense(Ctx *c, int64_t row0, int64_t n, uint64_t seed, int64_t *ts, double *val);

@@ -23,12 +23,4 @@ int bowgpu_fill_linear(const bowgpu_col *, int32_t, int32_t, int32_t, bowgpu_out
 int bowgpu_is_col_sorted(const bowgpu_col *, int32_t *) {
     return fail(BOWGPU_ERR_UNSUPPORTED, "bowgpu_is_col_sorted: not implemented yet");
 }
-int bowgpu_shard_aggregate(const bowgpu_col *, int32_t, int32_t, int64_t, const bowgpu_options *, int64_t, const bowgpu_agg *, int32_t,
-                           bowgpu_out *, int64_t *, int64_t *, bowgpu_shard_carry *) {
-    return fail(BOWGPU_ERR_UNSUPPORTED, "bowgpu_shard_aggregate: not implemented yet");
-}
-int bowgpu_shard_stitch(const bowgpu_col *, int32_t, int32_t, int64_t, const bowgpu_options *, int64_t, const bowgpu_agg *, int32_t,
-                        bowgpu_out *, int64_t, const bowgpu_shard_carry *, int32_t, int32_t, int32_t *) {
-    return fail(BOWGPU_ERR_UNSUPPORTED, "bowgpu_shard_stitch: not implemented yet");
-}
 }

@@ -1,0 +1,140 @@
+// shard.hip — the boundary-window stitch of the row-range sharded Rolling.Aggregate.
+//
+// A rank reduces its own rows with the ordinary tile kernels.  Only the window that straddles a
+// shard boundary needs more: the left rank exports the RUNNING STATE of its last window
+// (range_state_kernel, mode 0), the ranks exchange those fixed-size records (one RCCL all_gather of
+// bytes, done by the caller), and the right rank re-walks its own rows of that window seeded with
+// the left state (mode 1) - i.e. the straddling window is folded in the reference's row order
+// (sum.go:16-22, arithmeticmean.go:17-24, minmax.go:16-28), bit-exact, with no collective on the data.
+#include "agg_device.h"
+
+namespace bowgpu {
+
+namespace {
+
+__device__ __forceinline__ void carry_to_stats(const bowgpu_carry_state &c, Stats &s) {
+    stats_init(s);
+    s.sum = c.sum; s.vmin = c.vmin; s.vmax = c.vmax; s.nn_min = c.nn_min; s.nn_max = c.nn_max;
+    s.first_bits = c.first_bits; s.last_bits = c.last_bits; s.count = c.count;
+    s.has_value = c.has_value; s.has_nn = c.has_nn;
+}
+__device__ __forceinline__ void stats_to_carry(const Stats &s, int64_t nrows, bowgpu_carry_state &c) {
+    c.sum = s.sum; c.vmin = s.vmin; c.vmax = s.vmax; c.nn_min = s.nn_min; c.nn_max = s.nn_max;
+    c.first_bits = s.first_bits; c.last_bits = s.last_bits; c.count = s.count; c.nrows = nrows;
+    c.has_value = s.has_value; c.has_nn = s.has_nn;
+}
+
+constexpr int kSeqLimit = 8192;  // longer ranges are merged from 256 contiguous partials (order-changing for Sum)
+
+}  // namespace
+
+// mode 0: state of window `wid` over rows [lower_bound(ts, start(wid)), n)        -> states_out
+// mode 1: seeds + rows [0, lower_bound(ts, start(wid+1))) of window `wid` -> outputs slot + states_out
+__global__ __launch_bounds__(256) void range_state_kernel(const AggParams p, const int mode, const uint64_t wid,
+                                                          const bowgpu_carry_state *seeds,
+                                                          bowgpu_carry_state *states_out) {
+    __shared__ Stats part[256];
+    __shared__ int64_t s_r0, s_r1;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        const int64_t win_start = p.s0 + (int64_t)(wid * (uint64_t)p.interval);
+        const int64_t lim = mode == 0 ? win_start : win_start + p.interval;
+        const bool ovf = mode == 1 && lim < win_start;
+        int64_t lo = 0, hi = p.n;
+        while (lo < hi && !ovf) {  // first row with ts >= lim
+            const int64_t mid = lo + ((hi - lo) >> 1);
+            if (p.ts[mid] >= lim) hi = mid; else lo = mid + 1;
+        }
+        const int64_t b = ovf ? p.n : lo;
+        s_r0 = mode == 0 ? b : 0;
+        s_r1 = mode == 0 ? p.n : b;
+    }
+    __syncthreads();
+    const int64_t r0 = s_r0, r1 = s_r1;
+    const int64_t len = r1 - r0;
+    const int64_t win_start = p.s0 + (int64_t)(wid * (uint64_t)p.interval);
+    const int64_t oslot = (int64_t)(wid - (uint64_t)p.wid_base);
+
+    for (int a = 0; a < p.naggs; a++) {
+        const AggDesc &ad = p.aggs[a];
+        const bool reads = !(ad.kind == BOWGPU_AGG_WINDOW_START || ad.kind == BOWGPU_AGG_NUM_ROWS);
+        const ColDesc *cd = (reads && ad.slot >= 0) ? &p.cols[ad.slot] : nullptr;
+        const int col_type = cd ? cd->type : BOWGPU_INT64;
+        Stats acc;
+        stats_init(acc);
+        int64_t seed_rows = 0;
+        if (seeds) { carry_to_stats(seeds[a], acc); seed_rows = seeds[a].nrows; }
+        if (cd) {
+            const uint64_t *vp = reinterpret_cast<const uint64_t *>(cd->values);
+            auto valid_at = [&](int64_t r) -> bool {
+                if (!cd->vbits) return true;
+                const int64_t bit = cd->vbit0 + r;
+                return (cd->vbits[bit >> 5] >> (bit & 31)) & 1u;
+            };
+            if (len <= kSeqLimit) {
+                if (tid == 0)
+                    for (int64_t r = r0; r < r1; r++)
+                        if (valid_at(r)) { const uint64_t raw = vp[r]; stats_value<true>(acc, bits_to_f64(raw, col_type), raw); }
+            } else {
+                Stats st;
+                stats_init(st);
+                const int64_t lo_r = r0 + (len * tid) / 256, hi_r = r0 + (len * (tid + 1)) / 256;
+                for (int64_t r = lo_r; r < hi_r; r++)
+                    if (valid_at(r)) { const uint64_t raw = vp[r]; stats_value<true>(st, bits_to_f64(raw, col_type), raw); }
+                __syncthreads();
+                part[tid] = st;
+                __syncthreads();
+                if (tid == 0)
+                    for (int t = 0; t < 256; t++) stats_merge(acc, part[t]);
+            }
+        }
+        if (tid == 0) {
+            const int64_t nrows = seed_rows + len;
+            if (states_out) stats_to_carry(acc, nrows, states_out[a]);
+            if (mode == 1 && (uint64_t)oslot < (uint64_t)p.W) {
+                Val v = finish_val(reduce_val(ad.kind, acc, nrows, win_start, p.interval, col_type == BOWGPU_INT64), ad);
+                reinterpret_cast<uint64_t *>(ad.out_values)[oslot] = v.bits;
+                if (ad.out_valid) {
+                    const uint32_t bit = 1u << (oslot & 31);
+                    if (v.valid) atomicOr(&ad.out_valid[oslot >> 5], bit);
+                    else atomicAnd(&ad.out_valid[oslot >> 5], ~bit);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// the empty windows [slot0, slot1) of every reducer (A.9 "Empty slice"); nullable bits stay 0
+__global__ __launch_bounds__(256) void fill_empty_kernel(const AggParams p, const int64_t slot0, const int64_t slot1) {
+    Stats e;
+    stats_init(e);
+    for (int64_t s = slot0 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < slot1; s += (int64_t)gridDim.x * blockDim.x) {
+        if (s < 0 || s >= p.W) continue;
+        const int64_t win_start = p.s0 + (int64_t)(((uint64_t)p.wid_base + (uint64_t)s) * (uint64_t)p.interval);
+        for (int a = 0; a < p.naggs; a++) {
+            const AggDesc &ad = p.aggs[a];
+            const int ct = ad.slot >= 0 ? p.cols[ad.slot].type : BOWGPU_INT64;
+            Val v = finish_val(reduce_val(ad.kind, e, 0, win_start, p.interval, ct == BOWGPU_INT64), ad);
+            reinterpret_cast<uint64_t *>(ad.out_values)[s] = v.bits;
+        }
+    }
+}
+
+int launch_fill_empty(Ctx *c, const AggParams &p, int64_t slot0, int64_t slot1) {
+    if (slot1 <= slot0) return 0;
+    int64_t grid = (slot1 - slot0 + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(fill_empty_kernel, dim3((unsigned)grid), dim3(256), 0, c->stream, p, slot0, slot1);
+    BG_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_range_state(Ctx *c, const AggParams &p, int mode, uint64_t wid, const bowgpu_carry_state *d_seeds,
+                       bowgpu_carry_state *d_states_out) {
+    hipLaunchKernelGGL(range_state_kernel, dim3(1), dim3(256), 0, c->stream, p, mode, wid, d_seeds, d_states_out);
+    BG_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace bowgpu

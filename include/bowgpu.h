@@ -145,6 +145,8 @@ int bowgpu_device_name(char *buf, int cap);
  * thread; NULL restores the library's own stream. */
 int bowgpu_set_stream(void *hip_stream);
 int bowgpu_synchronize(void);
+/* device time (HIP events on the stream) of the tile kernel of this thread's last aggregate call */
+int bowgpu_last_kernel_ms(double *ms);
 
 /* ---- HBM buffers (so callers can keep columns resident between calls) ------------- */
 int bowgpu_malloc(void **ptr, int64_t bytes);
@@ -247,50 +249,64 @@ int bowgpu_is_col_sorted(const bowgpu_col *col, int32_t *sorted);
 
 /* ---- row-range sharding across GPUs ----------------------------------- */
 
-/* What one rank tells its right neighbour about the window that straddles the shard
- * boundary: the running state of every aggregator over the rows the left rank holds.
- * Fixed size so it can travel through one RCCL all_gather. */
-#define BOWGPU_CARRY_MAX_AGGS 16
+/* Running state of one reducer over the rows a rank holds of a window that straddles a shard
+ * boundary: what the reference's loops carry from one row to the next (sum.go:15-22,
+ * arithmeticmean.go:15-24, minmax.go:14-28, count.go:12-18, firstlast.go).  Fixed size so a
+ * rank's record travels through one RCCL all_gather; nn_min / nn_max (NaN-ignoring extrema) are
+ * only consulted when more than two ranks share one window. */
 typedef struct bowgpu_carry_state {
     double sum;
     double vmin, vmax;
-    double last_t, last_v;      /* last both-valid point (integrals) */
-    double integ;               /* running integral */
-    int64_t count;
-    int64_t nrows;
-    int64_t first_bits, last_bits; /* First/Last raw 64-bit values */
-    int32_t has_value;          /* any valid value so far */
-    int32_t has_point;          /* any both-valid point so far */
-    int32_t has_pair;           /* trapezoid: at least one pair integrated */
-    int32_t _pad;
+    double nn_min, nn_max;
+    uint64_t first_bits, last_bits;   /* First / Last raw 64-bit payloads */
+    int64_t count;                    /* valid values */
+    int64_t nrows;                    /* rows (w.Bow.NumRows() contribution) */
+    int32_t has_value;
+    int32_t has_nn;
 } bowgpu_carry_state;
 
+#define BOWGPU_CARRY_MAX_AGGS 16
 typedef struct bowgpu_shard_carry {
-    int64_t window_id;          /* global id of the rank's LAST window; -1 when the shard is empty */
-    int64_t first_window_id;    /* global id of the rank's FIRST window */
+    int64_t first_window_id;   /* global id of the FIRST window with a row in this shard; -1: empty shard */
+    int64_t last_window_id;    /* global id of the LAST one */
     int64_t first_ts, last_ts;
     int64_t nrows;
     int32_t naggs;
     int32_t _pad;
-    bowgpu_carry_state agg[BOWGPU_CARRY_MAX_AGGS];
+    bowgpu_carry_state last[BOWGPU_CARRY_MAX_AGGS];  /* per aggregator: state of the LAST window over this shard's rows */
 } bowgpu_shard_carry;
 
-/* Sharded Rolling.Aggregate: this rank holds rows [row0, row0+len) of every column.
- * global_s0 comes from rank 0's bowgpu_plan_windows.  Phase 1 reduces every window whose
- * first row is in the shard and fills *carry with the state of the last (possibly
- * unfinished) window.  After the ranks exchange carries (RCCL all_gather; the payload is
- * bytes), phase 2 re-walks the rows of the shard's first window seeded with the left
- * neighbours' state, so the straddling window is reduced in the reference's row order. */
+/* Sharded Rolling.Aggregate, phase 1.  This rank holds rows [row0, row0+len) of every column
+ * (device-resident; outs device-resident).  global_s0 comes from bowgpu_plan_windows on the rank
+ * that holds global row 0.  Reduces every window that has a row in the shard - output slot k is
+ * global window first_window_id + k - treating the shard's first row as a window start, and
+ * exports in *carry the running state of its last window.  Supported: exclusive windows and the
+ * reducers WindowStart/Sum/ArithmeticMean/Min/Max/Count/First/Last/NumRows.
+ * lead_empty_windows: number of EMPTY windows between the left neighbour's last window and this
+ * shard's first one that this rank also outputs (known after the ranks exchanged first/last ts):
+ * output slot k is then global window first_window_id - lead_empty_windows + k. */
 int bowgpu_shard_aggregate(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval,
-                           const bowgpu_options *opts, int64_t global_s0,
+                           const bowgpu_options *opts, int64_t global_s0, int32_t holds_global_row0,
+                           int64_t lead_empty_windows,
                            const bowgpu_agg *aggs, int32_t naggs, bowgpu_out *outs,
-                           int64_t *first_window_id, int64_t *n_windows_local,
                            bowgpu_shard_carry *carry);
-int bowgpu_shard_stitch(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval,
-                        const bowgpu_options *opts, int64_t global_s0,
-                        const bowgpu_agg *aggs, int32_t naggs, bowgpu_out *outs,
-                        int64_t first_window_id, const bowgpu_shard_carry *all_carries,
-                        int32_t rank, int32_t world, int32_t *drop_last_window);
+
+/* Phase 2, after the ranks exchanged their carries.  seeds[i] is the state of this shard's first
+ * window accumulated over the rows the LEFT ranks hold (one rank: its carry as is; several:
+ * bowgpu_carry_merge in rank order).  Re-walks the shard's rows of that window seeded with it - so
+ * the straddling window is reduced in the reference's row order - and rewrites output slot 0. */
+int bowgpu_shard_fix_first(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval,
+                           const bowgpu_options *opts, int64_t global_s0,
+                           int64_t lead_empty_windows,
+                           const bowgpu_agg *aggs, int32_t naggs, bowgpu_out *outs,
+                           int64_t first_window_id, const bowgpu_carry_state *seeds,
+                           bowgpu_carry_state *merged_out /* nullable: state after this shard's rows */);
+
+/* left (earlier rows) then right: the state of the concatenation.  Pure bookkeeping on two
+ * records (no column data); Sum is left.sum + right.sum, i.e. NOT the row-order association -
+ * only used when one window spans three or more ranks. */
+int bowgpu_carry_merge(const bowgpu_carry_state *left, const bowgpu_carry_state *right,
+                       bowgpu_carry_state *out);
 
 /* ---- synthetic inputs generated in HBM -------------------------------- */
 

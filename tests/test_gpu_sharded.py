@@ -1,0 +1,100 @@
+"""Row-range sharding on ONE GPU: K simulated ranks each hold a row range in HBM and
+run the real protocol of bow_amd/sharded.py (ShardSession: plan exchange -> phase 1 -> carry exchange
+-> phase 2) with the HIP provider; the stitched windows must equal the oracle on the whole frame."""
+import numpy as np
+import pytest
+
+from bow_amd import capi, sharded
+from oracle import pyoracle as orc
+
+pytestmark = pytest.mark.gpu
+
+AGGS = [("WindowStart", 0), ("Sum", 1), ("ArithmeticMean", 1), ("Min", 1), ("Max", 1), ("Count", 1), ("First", 1),
+        ("Last", 1), ("NumRows", 1)]
+ORDER = {"Sum", "ArithmeticMean"}
+
+
+def run_sharded(ts, vals, valid, bounds, interval, offset=0):
+    """bounds: row boundaries [0, b1, ..., n] of the simulated ranks"""
+    world = len(bounds) - 1
+    provs, sess = [], []
+    for r in range(world):
+        a, b = bounds[r], bounds[r + 1]
+        bm = None if valid is None else np.packbits(valid[a:b], bitorder="little")
+        cols = [capi.Column(ts[a:b].copy(), None, capi.INT64).to_device(),
+                capi.Column(vals[a:b].copy(), bm, capi.FLOAT64 if vals.dtype == np.float64 else capi.INT64, 0, b - a, -1).to_device()]
+        p = sharded.GpuProvider(cols, 0, interval, AGGS, offset=offset)
+        provs.append(p)
+        sess.append(sharded.ShardSession(p, r, world, interval))
+    s0 = provs[0].plan_s0()
+    info = [s.local_info() for s in sess]
+    carries = [s.phase1(s0, info) for s in sess]
+    owned = [s.phase2(carries) for s in sess]
+    # assemble the global result from what each rank owns
+    W = max(fs + n for fs, n in owned if fs >= 0)
+    res = []
+    for i, (k, _) in enumerate(AGGS):
+        vals_g = np.zeros(W, dtype=np.uint64)
+        valid_g = np.zeros(W, dtype=bool)
+        seen = np.zeros(W, dtype=int)
+        for r, (fs, n) in enumerate(owned):
+            if fs < 0 or n <= 0:
+                continue
+            v, _ = provs[r].outs[i].host_arrays()
+            m = provs[r].outs[i].valid_mask()
+            vals_g[fs:fs + n] = v.view(np.uint64)[:n]
+            valid_g[fs:fs + n] = m[:n]
+            seen[fs:fs + n] += 1
+        assert (seen == 1).all(), (k, np.flatnonzero(seen != 1)[:10])
+        res.append((vals_g, valid_g, provs[0].outs[i].type))
+    return res, sess[0].plan
+
+
+@pytest.mark.parametrize("mode", ["dense", "irregular", "gappy"])
+def test_sharded_equals_whole(mode):
+    rng = np.random.default_rng(77)
+    n = 40_000
+    if mode == "dense":
+        ts = np.arange(n, dtype=np.int64)
+    elif mode == "irregular":
+        ts = np.cumsum(rng.integers(1, 20, n)).astype(np.int64)
+    else:
+        step = rng.integers(1, 5, n)
+        step[rng.random(n) < 0.002] = rng.integers(100, 3000)
+        ts = np.cumsum(step).astype(np.int64)
+    vals = rng.standard_normal(n) * 100
+    valid = rng.random(n) >= 0.2
+    for interval, bounds in [(7, [0, 10_000, 20_000, 30_000, n]),          # windows straddle every boundary
+                             (10, [0, 9_999, 20_001, 20_002, n]),          # a 1-row shard
+                             (64, [0, 13, 40, 41, 20_000, n]),             # shards smaller than a window: 3+ ranks per window
+                             (1000, [0, 5_000, 5_000, 25_000, n])]:        # an EMPTY shard in the middle
+        res, plan = run_sharded(ts, vals, valid, bounds, interval)
+        bm = np.packbits(valid, bitorder="little")
+        exp, _ = orc.aggregate([orc.Column(ts, None, orc.INT64), orc.Column(vals, bm, orc.FLOAT64)], 0, interval, AGGS)
+        multi = any(len(plan.seed_ranks(r)) > 1 for r in range(plan.world))
+        for (k, _), (gv, gm, typ), w in zip(AGGS, res, exp):
+            assert len(gv) == w.length, (k, len(gv), w.length)
+            wm = w.valid_mask()
+            assert np.array_equal(gm, wm), (mode, interval, k)
+            wv = w.values[:w.length].view(np.uint64)
+            if k in ORDER and (multi or interval >= 129):
+                g = gv.view(np.float64)[gm]
+                e = wv.view(np.float64)[wm]
+                assert np.allclose(g, e, rtol=1e-11, atol=0), (mode, interval, k)
+            else:
+                bad = np.flatnonzero(gv[gm] != wv[wm])
+                assert bad.size == 0, (mode, interval, k, bad[:5])
+
+
+def test_sharded_gaps_between_shards():
+    # the first row of a shard is many empty windows after the last row of the previous one
+    ts = np.concatenate([np.arange(0, 1000), np.arange(50_000, 51_000), np.arange(200_000, 200_500)]).astype(np.int64)
+    vals = np.arange(len(ts), dtype=np.float64)
+    res, plan = run_sharded(ts, vals, None, [0, 1000, 2000, len(ts)], 10)
+    exp, _ = orc.aggregate([orc.Column(ts, None, orc.INT64), orc.Column(vals, None, orc.FLOAT64)], 0, 10, AGGS)
+    assert plan.lead_empty(1) > 0 and plan.lead_empty(2) > 0
+    for (k, _), (gv, gm, typ), w in zip(AGGS, res, exp):
+        wm = w.valid_mask()
+        assert len(gv) == w.length and np.array_equal(gm, wm), k
+        assert np.array_equal(gv[gm], w.values[:w.length].view(np.uint64)[wm]), k
+        assert not gv[~gm].any(), k
