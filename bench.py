@@ -66,13 +66,20 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the bowgpu path has no CPU fallback")
+    # BOW_BENCH_SINGLE_DEVICE=1 + BOW_BENCH_BACKEND=gloo: exercise the N>1 code path on a 1-GPU box (testing aid)
+    if os.environ.get("BOW_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("BOW_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     capi.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     rows = args.rows
     aggs = [("WindowStart", 0), ("ArithmeticMean", 1)]
@@ -87,7 +94,8 @@ def main():
         interval = INTERVAL
     else:
         from bow_amd import sharded
-        runner = sharded.ShardedRolling(rank, world, rows, INTERVAL_MULTI, aggs, dist, torch)
+        runner = sharded.ShardedRolling(rank, world, rows, INTERVAL_MULTI, aggs, dist, torch,
+                                        exchange_device="cuda" if backend == "nccl" else "cpu")
         step = runner.step
         interval = INTERVAL_MULTI
 
@@ -108,7 +116,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

@@ -293,12 +293,12 @@ int plan_make(Ctx *c, const bowgpu_col *ts, int64_t interval, int64_t raw_offset
 }
 
 // ---------------------------------------------------------------- aggregate
-static bool kind_needs_inclusive(int kind) {
+bool kind_needs_inclusive(int kind) {
     // NewColAggregation(col, true, ...) only at integral.go:9 and weightedmean.go:24
     return kind == BOWGPU_AGG_INTEGRAL_TRAPEZOID || kind == BOWGPU_AGG_WAVG_LINEAR;
 }
 
-static int kind_type(int kind) {
+int kind_type(int kind) {
     switch (kind) {
     case BOWGPU_AGG_WINDOW_START: return BOWGPU_ITERATOR_DEPENDENT;  // windowstart.go:9
     case BOWGPU_AGG_COUNT: return BOWGPU_INT64;                      // count.go:9
@@ -308,11 +308,11 @@ static int kind_type(int kind) {
     }
 }
 
-static bool kind_never_nil(int kind) {
+bool kind_never_nil(int kind) {
     return kind == BOWGPU_AGG_WINDOW_START || kind == BOWGPU_AGG_SUM || kind == BOWGPU_AGG_COUNT || kind == BOWGPU_AGG_NUM_ROWS;
 }
 
-static bool kind_reads_values(int kind) { return !(kind == BOWGPU_AGG_WINDOW_START || kind == BOWGPU_AGG_NUM_ROWS); }
+bool kind_reads_values(int kind) { return !(kind == BOWGPU_AGG_WINDOW_START || kind == BOWGPU_AGG_NUM_ROWS); }
 
 struct AggRun {
     Plan plan;

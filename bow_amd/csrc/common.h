@@ -111,6 +111,10 @@ struct Plan {
     MagicDiv magic{};
 };
 int plan_make(Ctx *c, const bowgpu_col *ts, int64_t interval, int64_t raw_offset, Plan *p);
+bool kind_needs_inclusive(int kind);
+int kind_type(int kind);
+bool kind_never_nil(int kind);
+bool kind_reads_values(int kind);
 
 // ---------------------------------------------------------------- kernels (rolling_agg.hip)
 constexpr int kMaxCols = 8;    // value columns reduced per launch
@@ -169,6 +173,69 @@ int launch_range_state(Ctx *c, const AggParams &p, int mode, uint64_t wid, const
                        bowgpu_carry_state *d_states_out);
 
 int launch_fill_empty(Ctx *c, const AggParams &p, int64_t slot0, int64_t slot1);
+
+// interp_fill.hip
+int launch_window_first_rows(Ctx *c, const int64_t *ts, int64_t n, const Plan &plan, int64_t *first_idx, uint32_t *status);
+int launch_window_missing(Ctx *c, const int64_t *ts, const Plan &plan, const int64_t *first_idx, int32_t *missing);
+int launch_exclusive_scan(Ctx *c, const int32_t *in, int64_t n, int64_t *out, int64_t *block_sums, int64_t *d_total);
+int launch_pack_validity(Ctx *c, const uint8_t *bytes, int64_t n, uint32_t *words, uint64_t *d_set_count);
+int launch_col_order(Ctx *c, const uint64_t *values, const uint32_t *vbits, int64_t vbit0, int64_t n, int32_t type, uint32_t *d_flags);
+int launch_window_bounds(Ctx *c, const int64_t *ts, int64_t n, const Plan &plan, int inclusive, int pre_rows,
+                         const int64_t *first_idx, int64_t *first_index, int64_t *slice_begin, int64_t *slice_end, uint8_t *is_incl);
+int interp_run(Ctx *c, const void *params_blob);
+int fill_linear_run(Ctx *c, const void *params_blob);
+int whole_run(Ctx *c, const void *params_blob, int64_t nblocks);
+int whole_final_run(Ctx *c, const void *partials, int64_t nblocks, int64_t nrows, int64_t first_value, int64_t last_value,
+                    const void *final_blob);
+size_t stats_size();
+
+// host-side mirrors of the kernel parameter blocks of interp_fill.hip (same layout; see the .hip)
+struct InterpColH {
+    const uint64_t *values;
+    const uint32_t *vbits;
+    int64_t vbit0;
+    int32_t type;
+    int32_t kind;
+    double const_value;
+    int32_t has_prev, prev_t_valid, prev_v_valid, _pad;
+    double prev_t, prev_v;
+    int64_t prev_v_i64;
+    uint64_t *out_values;
+    uint8_t *out_valid_bytes;
+};
+struct InterpParamsH {
+    const int64_t *ts;
+    int64_t n, s0, interval, W;
+    MagicDiv magic;
+    const int64_t *first_idx;
+    const int32_t *missing;
+    const int64_t *pos;
+    int32_t ncols, ts_col;
+    InterpColH cols[kMaxCols];
+};
+struct FillParamsH {
+    const uint64_t *ref_values; const uint32_t *ref_vbits; int64_t ref_vbit0; int32_t ref_type;
+    const uint64_t *fill_values; const uint32_t *fill_vbits; int64_t fill_vbit0; int32_t fill_type;
+    int64_t n;
+    uint64_t *out_values; uint8_t *out_valid_bytes;
+};
+struct WholeParamsH {
+    const int64_t *ts;
+    const uint64_t *values;
+    const uint32_t *vbits;
+    int64_t vbit0;
+    int64_t n;
+    int32_t type;
+    int32_t need_ts;
+    void *partials;
+    int64_t chunk;
+};
+struct WholeFinalH {
+    int32_t kind, out_type, col_is_int, n_factors;
+    double factors[BOWGPU_MAX_FACTORS];
+    uint64_t *out_value;
+    uint8_t *out_valid_byte;
+};
 
 // generate.hip
 int launch_gen_dense(Ctx *c, int64_t row0, int64_t n, uint64_t seed, int64_t *ts, double *val);

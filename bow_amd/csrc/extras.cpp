@@ -1,26 +1,429 @@
-// extras.cpp — C-ABI entry points beyond Rolling.Aggregate (placeholders until their kernels land).
+// extras.cpp — C-ABI entry points either side of Rolling.Aggregate: window bounds (the iterator),
+// Rolling.Interpolate, Bow.FillLinear / IsColSorted and the whole-frame aggregation.Aggregate.
+// Host code here only validates (mirroring the reference's drivers), prepares residency and
+// orchestrates the HIP kernels of interp_fill.hip; no column data is reduced on the CPU.
+#include <string.h>
+
+#include <vector>
+
 #include "common.h"
 
 using namespace bowgpu;
 
+namespace {
+
+// a device-resident output of `slots` rows whose validity is produced as one byte per row and packed
+struct ByteOut {
+    DevOut out;
+    DevBuf bytes;
+};
+
+int copy_or_alias(Ctx *c, void *user, int residency, const void *dev, size_t nbytes) {
+    if (nbytes == 0 || !user) return 0;
+    BG_HIP(hipMemcpyAsync(user, dev, nbytes, residency == BOWGPU_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+    return 0;
+}
+
+int ts_contract(Ctx *c, const bowgpu_col *tsc) {
+    if (tsc->validity && tsc->null_count != 0) {
+        DevCol probe;
+        BG_TRY(devcol_prepare(c, tsc, &probe, false, true));
+        if (probe.null_count > 0) return fail(BOWGPU_ERR_TS_NULLS, "interval column has %lld nulls: outside the device path", (long long)probe.null_count);
+    }
+    return 0;
+}
+
+int ts_device(Ctx *c, const bowgpu_col *tsc, DevCol *dts) {
+    bowgpu_col t = *tsc;
+    t.validity = nullptr;
+    t.null_count = 0;
+    return devcol_prepare(c, &t, dts, true, false);
+}
+
+}  // namespace
+
 extern "C" {
 
-int bowgpu_window_bounds(const bowgpu_col *, int64_t, const bowgpu_options *, int64_t *, int64_t *, int64_t *, uint8_t *, int32_t) {
-    return fail(BOWGPU_ERR_UNSUPPORTED, "bowgpu_window_bounds: not implemented yet");
+// ---------------------------------------------------------------------------- window bounds
+int bowgpu_window_bounds(const bowgpu_col *ts, int64_t interval, const bowgpu_options *opts, int64_t *first_index,
+                         int64_t *slice_begin, int64_t *slice_end, uint8_t *is_inclusive, int32_t residency) {
+    if (!ts) return fail(BOWGPU_ERR_ARG, "null argument");
+    bowgpu_options o = {0, 0, 0};
+    if (opts) o = *opts;
+    Plan plan;
+    BG_TRY(plan_make(nullptr, ts, interval, o.offset, &plan));
+    if (plan.W == 0) return 0;
+    Ctx *c;
+    BG_TRY(ctx_get(&c));
+    BG_TRY(ts_contract(c, ts));
+    DevCol dts;
+    BG_TRY(ts_device(c, ts, &dts));
+    const int64_t n = ts->length, W = plan.W;
+    DevBuf first_idx, d_fi, d_sb, d_se, d_in;
+    BG_TRY(first_idx.alloc((size_t)(W + 1) * 8));
+    void *dscr;
+    BG_TRY(ctx_scratch(c, 8192, &dscr));
+    uint32_t *status = reinterpret_cast<uint32_t *>(dscr);
+    BG_HIP(hipMemsetAsync(status, 0, 64, c->stream));
+    BG_TRY(launch_window_first_rows(c, reinterpret_cast<const int64_t *>(dts.values), n, plan, reinterpret_cast<int64_t *>(first_idx.p), status));
+    const bool dev = residency == BOWGPU_DEVICE;
+    int64_t *pfi = first_index, *psb = slice_begin, *pse = slice_end;
+    uint8_t *pin = is_inclusive;
+    if (!dev) {
+        if (first_index) { BG_TRY(d_fi.alloc((size_t)W * 8)); pfi = reinterpret_cast<int64_t *>(d_fi.p); }
+        if (slice_begin) { BG_TRY(d_sb.alloc((size_t)W * 8)); psb = reinterpret_cast<int64_t *>(d_sb.p); }
+        if (slice_end) { BG_TRY(d_se.alloc((size_t)W * 8)); pse = reinterpret_cast<int64_t *>(d_se.p); }
+        if (is_inclusive) { BG_TRY(d_in.alloc((size_t)W)); pin = reinterpret_cast<uint8_t *>(d_in.p); }
+    }
+    BG_TRY(launch_window_bounds(c, reinterpret_cast<const int64_t *>(dts.values), n, plan, o.inclusive ? 1 : 0,
+                                plan.s0 > plan.first_ts ? 1 : 0, reinterpret_cast<const int64_t *>(first_idx.p), pfi, psb, pse, pin));
+    uint32_t hstat[4] = {0, 0, 0, 0};
+    BG_HIP(hipMemcpyAsync(hstat, status, 16, hipMemcpyDeviceToHost, c->stream));
+    if (!dev) {
+        if (first_index) BG_HIP(hipMemcpyAsync(first_index, pfi, (size_t)W * 8, hipMemcpyDeviceToHost, c->stream));
+        if (slice_begin) BG_HIP(hipMemcpyAsync(slice_begin, psb, (size_t)W * 8, hipMemcpyDeviceToHost, c->stream));
+        if (slice_end) BG_HIP(hipMemcpyAsync(slice_end, pse, (size_t)W * 8, hipMemcpyDeviceToHost, c->stream));
+        if (is_inclusive) BG_HIP(hipMemcpyAsync(is_inclusive, pin, (size_t)W, hipMemcpyDeviceToHost, c->stream));
+    }
+    BG_HIP(hipStreamSynchronize(c->stream));
+    if (hstat[0]) return fail(BOWGPU_ERR_TS_UNSORTED, "interval column is not ascending: outside the device path");
+    return 0;
 }
-int bowgpu_aggregate_whole(const bowgpu_col *, int32_t, int32_t, const bowgpu_agg *, int32_t, bowgpu_out *) {
-    return fail(BOWGPU_ERR_UNSUPPORTED, "bowgpu_aggregate_whole: not implemented yet");
+
+// ---------------------------------------------------------------------------- Interpolate
+static bool interp_type_ok(int kind, int t) {
+    switch (kind) {
+    case BOWGPU_INTERP_WINDOW_START: return t == BOWGPU_INT64;                         // interpolation/windowstart.go:9
+    case BOWGPU_INTERP_LINEAR: return t == BOWGPU_INT64 || t == BOWGPU_FLOAT64;        // interpolation/linear.go:11
+    case BOWGPU_INTERP_STEP_PREVIOUS:                                                  // stepprevious.go:10 (+ Boolean, String)
+    case BOWGPU_INTERP_NONE: return t == BOWGPU_INT64 || t == BOWGPU_FLOAT64 || t == BOWGPU_BOOLEAN || (kind == BOWGPU_INTERP_STEP_PREVIOUS && t == BOWGPU_STRING);
+    case BOWGPU_INTERP_CONST: return t == BOWGPU_INT64 || t == BOWGPU_FLOAT64;
+    default: return false;
+    }
 }
-int bowgpu_rolling_interpolate_count(const bowgpu_col *, int32_t, int32_t, int64_t, const bowgpu_options *, const bowgpu_interp *, int32_t, int64_t *) {
-    return fail(BOWGPU_ERR_UNSUPPORTED, "bowgpu_rolling_interpolate_count: not implemented yet");
+
+static const char *type_name(int t) {
+    return t == BOWGPU_FLOAT64 ? "float64" : t == BOWGPU_INT64 ? "int64" : t == BOWGPU_BOOLEAN ? "bool" : t == BOWGPU_STRING ? "utf8" : "undefined";
 }
-int bowgpu_rolling_interpolate_fill(const bowgpu_col *, int32_t, int32_t, int64_t, const bowgpu_options *, const bowgpu_interp *, int32_t, bowgpu_out *) {
-    return fail(BOWGPU_ERR_UNSUPPORTED, "bowgpu_rolling_interpolate_fill: not implemented yet");
+
+static int interp_validate(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, const bowgpu_options *o,
+                           const bowgpu_interp *interps, int32_t ninterps) {
+    // Interpolate + validateInterpolation: reference rolling/interpolation.go:30-96
+    if (ninterps <= 0) return fail(BOWGPU_ERR_ARG, "at least one column interpolation is required");
+    int nic = -1;
+    for (int i = 0; i < ninterps; i++) {
+        if (interps[i].col < 0 || interps[i].col >= ncols) return fail(BOWGPU_ERR_BAD_COL, "interpolation %d: no column with index %d", i, interps[i].col);
+        const int t = cols[interps[i].col].type;
+        if (!interp_type_ok(interps[i].kind, t)) {
+            const char *acc = interps[i].kind == BOWGPU_INTERP_WINDOW_START ? "[int64]"
+                              : interps[i].kind == BOWGPU_INTERP_LINEAR ? "[int64 float64]"
+                              : interps[i].kind == BOWGPU_INTERP_STEP_PREVIOUS ? "[int64 float64 bool utf8]"
+                              : interps[i].kind == BOWGPU_INTERP_NONE ? "[int64 float64 bool]" : "[int64 float64]";
+            return fail(BOWGPU_ERR_TYPE, "accepts types %s, got type %s", acc, type_name(t));
+        }
+        if (interps[i].col == ts_col) nic = i;
+    }
+    if (nic == -1) return fail(BOWGPU_ERR_KEEP_INTERVAL, "must keep interval column");
+    // AppendBows(startBow, window.Bow) needs one schema (bowappend.go:11-13): the interpolators must list the columns in order
+    if (ninterps != ncols) return fail(BOWGPU_ERR_UNSUPPORTED, "interpolators must cover every column of the Bow, in order (bowappend.go:11-13)");
+    for (int i = 0; i < ninterps; i++) {
+        if (interps[i].col != i) return fail(BOWGPU_ERR_UNSUPPORTED, "interpolators must cover every column of the Bow, in order (bowappend.go:11-13)");
+        const int t = cols[i].type;
+        if (t != BOWGPU_INT64 && t != BOWGPU_FLOAT64) return fail(BOWGPU_ERR_UNSUPPORTED, "column type %s is outside the device path", type_name(t));
+    }
+    if (o->inclusive) return fail(BOWGPU_ERR_UNSUPPORTED, "Interpolate on inclusive windows duplicates rows in the reference; not on the device path");
+    if (ncols > kMaxCols) return fail(BOWGPU_ERR_UNSUPPORTED, "at most %d columns", kMaxCols);
+    return 0;
 }
-int bowgpu_fill_linear(const bowgpu_col *, int32_t, int32_t, int32_t, bowgpu_out *, int32_t *) {
-    return fail(BOWGPU_ERR_UNSUPPORTED, "bowgpu_fill_linear: not implemented yet");
+
+struct InterpJob {
+    Plan plan;
+    DevCol dts;
+    std::vector<DevCol> dcols;
+    DevBuf first_idx, missing, pos, block_sums;
+    int64_t M = 0;
+};
+
+static int interp_prepare(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval,
+                          const bowgpu_options *o, InterpJob *job) {
+    BG_TRY(plan_make(c, &cols[ts_col], interval, o->offset, &job->plan));
+    const int64_t n = cols[ts_col].length, W = job->plan.W;
+    for (int i = 0; i < ncols; i++)
+        if (cols[i].length != n) return fail(BOWGPU_ERR_ARG, "column %d has a different length", i);
+    job->M = 0;
+    if (n == 0) return 0;
+    BG_TRY(ts_contract(c, &cols[ts_col]));
+    BG_TRY(ts_device(c, &cols[ts_col], &job->dts));
+    if (W == 0) return 0;
+    BG_TRY(job->first_idx.alloc((size_t)(W + 1) * 8));
+    BG_TRY(job->missing.alloc((size_t)W * 4 + 16));
+    BG_TRY(job->pos.alloc((size_t)(W + 1) * 8));
+    BG_TRY(job->block_sums.alloc((size_t)((W + 2047) / 2048 + 1) * 8));
+    void *dscr;
+    BG_TRY(ctx_scratch(c, 8192, &dscr));
+    uint32_t *status = reinterpret_cast<uint32_t *>(dscr);
+    int64_t *d_total = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(dscr) + 512);
+    BG_HIP(hipMemsetAsync(status, 0, 64, c->stream));
+    const int64_t *ts = reinterpret_cast<const int64_t *>(job->dts.values);
+    BG_TRY(launch_window_first_rows(c, ts, n, job->plan, reinterpret_cast<int64_t *>(job->first_idx.p), status));
+    BG_TRY(launch_window_missing(c, ts, job->plan, reinterpret_cast<const int64_t *>(job->first_idx.p), reinterpret_cast<int32_t *>(job->missing.p)));
+    BG_TRY(launch_exclusive_scan(c, reinterpret_cast<const int32_t *>(job->missing.p), W, reinterpret_cast<int64_t *>(job->pos.p),
+                                 reinterpret_cast<int64_t *>(job->block_sums.p), d_total));
+    uint32_t hstat[4];
+    int64_t total = 0;
+    BG_HIP(hipMemcpyAsync(hstat, status, 16, hipMemcpyDeviceToHost, c->stream));
+    BG_HIP(hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, c->stream));
+    BG_HIP(hipStreamSynchronize(c->stream));
+    if (hstat[0]) return fail(BOWGPU_ERR_TS_UNSORTED, "interval column is not ascending: outside the device path");
+    job->M = total;
+    return 0;
 }
-int bowgpu_is_col_sorted(const bowgpu_col *, int32_t *) {
-    return fail(BOWGPU_ERR_UNSUPPORTED, "bowgpu_is_col_sorted: not implemented yet");
+
+int bowgpu_rolling_interpolate_count(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval,
+                                     const bowgpu_options *opts, const bowgpu_interp *interps, int32_t ninterps, int64_t *n_out) {
+    if (!cols || ncols <= 0 || !n_out) return fail(BOWGPU_ERR_ARG, "null argument");
+    if (ts_col < 0 || ts_col >= ncols) return fail(BOWGPU_ERR_BAD_COL, "no interval column with index %d", ts_col);
+    bowgpu_options o = {0, 0, 0};
+    if (opts) o = *opts;
+    Plan probe;
+    BG_TRY(plan_make(nullptr, &cols[ts_col], interval, o.offset, &probe));  // ctor errors first (rolling.go:69-112)
+    BG_TRY(interp_validate(cols, ncols, ts_col, &o, interps, ninterps));
+    if (cols[ts_col].length == 0) { *n_out = 0; return 0; }
+    Ctx *c;
+    BG_TRY(ctx_get(&c));
+    InterpJob job;
+    BG_TRY(interp_prepare(c, cols, ncols, ts_col, interval, &o, &job));
+    *n_out = cols[ts_col].length + job.M;
+    return 0;
 }
+
+int bowgpu_rolling_interpolate_fill(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval,
+                                    const bowgpu_options *opts, const bowgpu_interp *interps, int32_t ninterps, bowgpu_out *outs) {
+    if (!cols || ncols <= 0 || !outs) return fail(BOWGPU_ERR_ARG, "null argument");
+    if (ts_col < 0 || ts_col >= ncols) return fail(BOWGPU_ERR_BAD_COL, "no interval column with index %d", ts_col);
+    bowgpu_options o = {0, 0, 0};
+    if (opts) o = *opts;
+    Plan probe;
+    BG_TRY(plan_make(nullptr, &cols[ts_col], interval, o.offset, &probe));
+    BG_TRY(interp_validate(cols, ncols, ts_col, &o, interps, ninterps));
+    const int64_t n = cols[ts_col].length;
+    if (n == 0) {
+        for (int i = 0; i < ninterps; i++) { outs[i].length = 0; outs[i].null_count = 0; outs[i].type = cols[i].type; }
+        return 0;
+    }
+    Ctx *c;
+    BG_TRY(ctx_get(&c));
+    InterpJob job;
+    BG_TRY(interp_prepare(c, cols, ncols, ts_col, interval, &o, &job));
+    const int64_t n_out = n + job.M;
+    job.dcols.resize(ncols);
+    std::vector<DevOut> douts(ninterps);
+    std::vector<DevBuf> vbytes(ninterps);
+    InterpParamsH P;
+    memset(&P, 0, sizeof P);
+    P.ts = reinterpret_cast<const int64_t *>(job.dts.values);
+    P.n = n; P.s0 = job.plan.s0; P.interval = job.plan.interval; P.W = job.plan.W; P.magic = job.plan.magic;
+    P.first_idx = reinterpret_cast<const int64_t *>(job.first_idx.p);
+    P.missing = reinterpret_cast<const int32_t *>(job.missing.p);
+    P.pos = reinterpret_cast<const int64_t *>(job.pos.p);
+    P.ncols = ncols; P.ts_col = ts_col;
+    for (int i = 0; i < ncols; i++) {
+        DevCol &dc = job.dcols[i];
+        if (i == ts_col) { dc.values = job.dts.values; dc.length = n; dc.type = BOWGPU_INT64; }
+        else BG_TRY(devcol_prepare(c, &cols[i], &dc, true, true));
+        BG_TRY(devout_prepare(c, &outs[i], n_out, &douts[i]));
+        BG_TRY(vbytes[i].alloc((size_t)n_out + 64));
+        InterpColH &ic = P.cols[i];
+        ic.values = reinterpret_cast<const uint64_t *>(dc.values);
+        ic.vbits = dc.vbits; ic.vbit0 = dc.vbit0; ic.type = cols[i].type; ic.kind = interps[i].kind;
+        ic.const_value = interps[i].const_value;
+        ic.has_prev = interps[i].has_prev_row; ic.prev_t_valid = interps[i].prev_t_valid; ic.prev_v_valid = interps[i].prev_v_valid;
+        ic.prev_t = interps[i].prev_t; ic.prev_v = interps[i].prev_v; ic.prev_v_i64 = interps[i].prev_v_i64;
+        ic.out_values = reinterpret_cast<uint64_t *>(douts[i].values);
+        ic.out_valid_bytes = reinterpret_cast<uint8_t *>(vbytes[i].p);
+    }
+    BG_TRY(interp_run(c, &P));
+    void *dscr;
+    BG_TRY(ctx_scratch(c, 8192, &dscr));
+    uint64_t *dcnt = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(dscr) + 1024);
+    std::vector<uint64_t> hcnt(ninterps, 0);
+    for (int i = 0; i < ninterps; i++) {
+        BG_TRY(launch_pack_validity(c, reinterpret_cast<const uint8_t *>(vbytes[i].p), n_out, reinterpret_cast<uint32_t *>(douts[i].validity), dcnt + i));
+        BG_HIP(hipMemcpyAsync(&hcnt[i], dcnt + i, 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    BG_HIP(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < ninterps; i++) BG_TRY(devout_finish(c, &douts[i], n_out, cols[i].type, n_out - (int64_t)hcnt[i]));
+    BG_HIP(hipStreamSynchronize(c->stream));
+    return 0;
 }
+
+// ---------------------------------------------------------------------------- IsColSorted / FillLinear
+static int col_order_flags(Ctx *c, const DevCol &dc, int32_t type, uint32_t *flags) {
+    void *dscr;
+    BG_TRY(ctx_scratch(c, 8192, &dscr));
+    uint32_t *dflags = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(dscr) + 256);
+    BG_TRY(launch_col_order(c, reinterpret_cast<const uint64_t *>(dc.values), dc.vbits, dc.vbit0, dc.length, type, dflags));
+    BG_HIP(hipMemcpyAsync(flags, dflags, 4, hipMemcpyDeviceToHost, c->stream));
+    BG_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int bowgpu_is_col_sorted(const bowgpu_col *col, int32_t *sorted) {
+    // reference bowassertion.go:15-81: empty column or unsupported type => false
+    if (!col || !sorted) return fail(BOWGPU_ERR_ARG, "null argument");
+    *sorted = 0;
+    if (col->type != BOWGPU_INT64 && col->type != BOWGPU_FLOAT64) return 0;
+    if (col->length == 0) return 0;
+    Ctx *c;
+    BG_TRY(ctx_get(&c));
+    DevCol dc;
+    BG_TRY(devcol_prepare(c, col, &dc, true, true));
+    uint32_t f = 0;
+    BG_TRY(col_order_flags(c, dc, col->type, &f));
+    *sorted = (f & 4) && !((f & 1) && (f & 2));
+    return 0;
+}
+
+int bowgpu_fill_linear(const bowgpu_col *cols, int32_t ncols, int32_t ref_col, int32_t fill_col, bowgpu_out *out, int32_t *unchanged) {
+    // reference bowfill.go:14-103
+    if (!cols || !out || !unchanged) return fail(BOWGPU_ERR_ARG, "null argument");
+    if (ref_col < 0 || ref_col > ncols - 1) return fail(BOWGPU_ERR_BAD_COL, "refColIndex is out of range");
+    if (fill_col < 0 || fill_col > ncols - 1) return fail(BOWGPU_ERR_BAD_COL, "toFillColIndex is out of range");
+    if (ref_col == fill_col) return fail(BOWGPU_ERR_ARG, "refColIndex and toFillColIndex are equal");
+    const int rt = cols[ref_col].type, ft = cols[fill_col].type;
+    if (rt != BOWGPU_INT64 && rt != BOWGPU_FLOAT64) return fail(BOWGPU_ERR_TYPE, "refColIndex '%d' is of type '%s'", ref_col, type_name(rt));
+    const int64_t n = cols[fill_col].length;
+    if (cols[ref_col].length != n) return fail(BOWGPU_ERR_ARG, "columns differ in length");
+    *unchanged = 0;
+    if (ft != BOWGPU_INT64 && ft != BOWGPU_FLOAT64) {
+        // the reference checks the fill column's type after the ref column's emptiness / order (bowfill.go:35-51)
+        return fail(BOWGPU_ERR_UNSUPPORTED, "toFillColIndex '%d' is of unsupported type '%s'", fill_col, type_name(ft));
+    }
+    Ctx *c;
+    BG_TRY(ctx_get(&c));
+    DevCol dref, dfill;
+    BG_TRY(devcol_prepare(c, &cols[ref_col], &dref, true, true));
+    BG_TRY(devcol_prepare(c, &cols[fill_col], &dfill, true, true));
+    DevOut dout;
+    BG_TRY(devout_prepare(c, out, n, &dout));
+    DevBuf vbytes;
+    BG_TRY(vbytes.alloc((size_t)n + 64));
+    uint32_t f = 0;
+    if (n > 0) BG_TRY(col_order_flags(c, dref, rt, &f));
+    const bool ref_empty = !(f & 4);                                  // IsColEmpty: bowassertion.go:84-86
+    const bool ref_sorted = (f & 4) && !((f & 1) && (f & 2));
+    if (!ref_empty && !ref_sorted) return fail(BOWGPU_ERR_NOT_SORTED, "refColIndex '%d' is empty or not sorted", ref_col);
+    const bool nothing = ref_empty || dfill.null_count == 0;          // bowfill.go:35-37, :53-55 return the receiver
+    *unchanged = nothing ? 1 : 0;
+    FillParamsH P;
+    memset(&P, 0, sizeof P);
+    P.ref_values = reinterpret_cast<const uint64_t *>(dref.values); P.ref_vbits = dref.vbits; P.ref_vbit0 = dref.vbit0; P.ref_type = rt;
+    P.fill_values = reinterpret_cast<const uint64_t *>(dfill.values); P.fill_vbits = dfill.vbits; P.fill_vbit0 = dfill.vbit0; P.fill_type = ft;
+    P.n = n;
+    P.out_values = reinterpret_cast<uint64_t *>(dout.values);
+    P.out_valid_bytes = reinterpret_cast<uint8_t *>(vbytes.p);
+    // (no special casing is needed for the two "return the receiver" cases: without nulls every row is copied,
+    //  and with an all-null reference column no null row passes the valid1 test of bowfill.go:74)
+    BG_TRY(fill_linear_run(c, &P));
+    void *dscr;
+    BG_TRY(ctx_scratch(c, 8192, &dscr));
+    uint64_t *dcnt = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(dscr) + 1024);
+    uint64_t hcnt = 0;
+    BG_TRY(launch_pack_validity(c, reinterpret_cast<const uint8_t *>(vbytes.p), n, reinterpret_cast<uint32_t *>(dout.validity), dcnt));
+    BG_HIP(hipMemcpyAsync(&hcnt, dcnt, 8, hipMemcpyDeviceToHost, c->stream));
+    BG_HIP(hipStreamSynchronize(c->stream));
+    BG_TRY(devout_finish(c, &dout, n, ft, n - (int64_t)hcnt));
+    BG_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------- whole-frame Aggregate
+int bowgpu_aggregate_whole(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, const bowgpu_agg *aggs, int32_t naggs, bowgpu_out *outs) {
+    // reference rolling/aggregation/whole.go:12-93
+    if (!cols || ncols <= 0) return fail(BOWGPU_ERR_ARG, "nil bow");
+    if (naggs <= 0) return fail(BOWGPU_ERR_NO_AGG, "at least one column aggregation is required");
+    if (ts_col < 0 || ts_col >= ncols) return fail(BOWGPU_ERR_BAD_COL, "no interval column with index %d", ts_col);
+    if (!outs) return fail(BOWGPU_ERR_ARG, "no output columns");
+    for (int i = 0; i < naggs; i++) {
+        if (aggs[i].col < 0 || aggs[i].col >= ncols) return fail(BOWGPU_ERR_BAD_COL, "column aggregation %d: no column with index %d", i, aggs[i].col);
+        if (aggs[i].kind < 0 || aggs[i].kind >= BOWGPU_AGG__COUNT) return fail(BOWGPU_ERR_ARG, "column aggregation %d: unknown kind", i);
+        const int t = cols[aggs[i].col].type;
+        if (t != BOWGPU_INT64 && t != BOWGPU_FLOAT64) return fail(BOWGPU_ERR_UNSUPPORTED, "column aggregation %d: column type outside the device path", i);
+    }
+    const int64_t n = cols[ts_col].length;
+    auto out_type_of = [&](int i) {
+        int t = kind_type(aggs[i].kind);
+        // both InputDependent and IteratorDependent resolve to the INPUT column's type here (whole.go:44-46)
+        if (t == BOWGPU_INPUT_DEPENDENT || t == BOWGPU_ITERATOR_DEPENDENT) t = cols[aggs[i].col].type;
+        return t;
+    };
+    if (n == 0) {  // whole.go:49-50
+        for (int i = 0; i < naggs; i++) { outs[i].length = 0; outs[i].null_count = 0; outs[i].type = out_type_of(i); }
+        return 0;
+    }
+    if (cols[ts_col].type != BOWGPU_INT64 && cols[ts_col].type != BOWGPU_FLOAT64) return fail(BOWGPU_ERR_UNSUPPORTED, "interval column type outside the device path");
+    Ctx *c;
+    BG_TRY(ctx_get(&c));
+    BG_TRY(ts_contract(c, &cols[ts_col]));  // (the reference tolerates null ts here; the device path declines them)
+    if (cols[ts_col].type != BOWGPU_INT64) return fail(BOWGPU_ERR_UNSUPPORTED, "whole-frame aggregation on the device path needs an Int64 interval column");
+    DevCol dts;
+    BG_TRY(ts_device(c, &cols[ts_col], &dts));
+    // FirstValue / LastValue: int64(float64(first / last valid ts)) (whole.go:54-71)
+    int64_t tfirst = 0, tlast = 0;
+    BG_HIP(hipMemcpyAsync(&tfirst, dts.values, 8, hipMemcpyDeviceToHost, c->stream));
+    BG_HIP(hipMemcpyAsync(&tlast, reinterpret_cast<const char *>(dts.values) + 8 * (n - 1), 8, hipMemcpyDeviceToHost, c->stream));
+    BG_HIP(hipStreamSynchronize(c->stream));
+    auto go_i64 = [](double x) -> int64_t { return (!(x >= -9223372036854775808.0 && x < 9223372036854775808.0)) ? INT64_MIN : (int64_t)x; };
+    const int64_t first_value = go_i64((double)tfirst), last_value = go_i64((double)tlast);
+
+    int64_t nblocks = (n + 65535) / 65536;
+    if (nblocks > 2048) nblocks = 2048;
+    const int64_t chunk = (n + nblocks - 1) / nblocks;
+    DevBuf partials, onev, oneb;
+    BG_TRY(partials.alloc((size_t)nblocks * stats_size()));
+    BG_TRY(onev.alloc(8 * (size_t)naggs));
+    BG_TRY(oneb.alloc(64 + (size_t)naggs));
+    std::vector<DevCol> dcols(ncols);
+    for (int i = 0; i < naggs; i++) {
+        const int col = aggs[i].col;
+        DevCol &dc = dcols[col];
+        if (dc.values == nullptr) {
+            if (col == ts_col) { dc.values = dts.values; dc.length = n; dc.type = BOWGPU_INT64; }
+            else BG_TRY(devcol_prepare(c, &cols[col], &dc, true, true));
+        }
+        WholeParamsH P;
+        memset(&P, 0, sizeof P);
+        P.ts = reinterpret_cast<const int64_t *>(dts.values);
+        P.values = reinterpret_cast<const uint64_t *>(dc.values);
+        P.vbits = dc.vbits; P.vbit0 = dc.vbit0; P.n = n; P.type = cols[col].type;
+        P.need_ts = aggs[i].kind >= BOWGPU_AGG_INTEGRAL_STEP && aggs[i].kind <= BOWGPU_AGG_WAVG_LINEAR;
+        P.partials = partials.p; P.chunk = chunk;
+        BG_TRY(whole_run(c, &P, nblocks));
+        WholeFinalH F;
+        memset(&F, 0, sizeof F);
+        F.kind = aggs[i].kind; F.out_type = out_type_of(i); F.col_is_int = cols[col].type == BOWGPU_INT64;
+        F.n_factors = aggs[i].n_factors;
+        for (int k = 0; k < F.n_factors && k < BOWGPU_MAX_FACTORS; k++) F.factors[k] = aggs[i].factors[k];
+        F.out_value = reinterpret_cast<uint64_t *>(onev.p) + i;
+        F.out_valid_byte = reinterpret_cast<uint8_t *>(oneb.p) + i;
+        BG_TRY(whole_final_run(c, partials.p, nblocks, n, first_value, last_value, &F));
+    }
+    std::vector<uint64_t> hv(naggs);
+    std::vector<uint8_t> hb(naggs);
+    BG_HIP(hipMemcpyAsync(hv.data(), onev.p, 8 * (size_t)naggs, hipMemcpyDeviceToHost, c->stream));
+    BG_HIP(hipMemcpyAsync(hb.data(), oneb.p, (size_t)naggs, hipMemcpyDeviceToHost, c->stream));
+    BG_HIP(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < naggs; i++) {
+        if (outs[i].length < 1 || !outs[i].values || !outs[i].validity) return fail(BOWGPU_ERR_ARG, "output column %d needs one slot", i);
+        const uint8_t vb = hb[i] ? 1 : 0;
+        BG_HIP(hipMemcpyAsync(outs[i].values, &hv[i], 8, outs[i].residency == BOWGPU_DEVICE ? hipMemcpyHostToDevice : hipMemcpyHostToHost, c->stream));
+        BG_HIP(hipMemcpyAsync(outs[i].validity, &vb, 1, outs[i].residency == BOWGPU_DEVICE ? hipMemcpyHostToDevice : hipMemcpyHostToHost, c->stream));
+        BG_HIP(hipStreamSynchronize(c->stream));
+        outs[i].length = 1;
+        outs[i].null_count = vb ? 0 : 1;
+        outs[i].type = out_type_of(i);
+    }
+    return 0;
+}
+
+}  // extern "C"

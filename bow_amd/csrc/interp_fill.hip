@@ -1,0 +1,489 @@
+// interp_fill.hip — the callers either side of Rolling.Aggregate:
+//   * Rolling.Interpolate with the built-in interpolators (reference rolling/interpolation.go:30-161,
+//     rolling/interpolation/{windowstart,linear,stepprevious,none}.go),
+//   * Bow.FillLinear (reference bowfill.go:14-103) and Bow.IsColSorted (bowassertion.go:15-81),
+//   * the whole-frame aggregation.Aggregate (reference rolling/aggregation/whole.go:12-93).
+// All are streaming, HBM-bound passes over Arrow value / validity buffers; none is a contraction.
+#include "agg_device.h"
+
+namespace bowgpu {
+
+namespace {
+
+__device__ __forceinline__ bool bit_at(const uint32_t *bits, int64_t bit0, int64_t row) {
+    if (!bits) return true;
+    const int64_t b = bit0 + row;
+    return (bits[b >> 5] >> (b & 31)) & 1u;
+}
+
+// previous / next valid row of a column (Bow.GetPrevFloat64 / GetNextFloat64 index semantics,
+// bowgetters.go:252-277), skipping 32 rows at a time over all-null words
+__device__ int64_t prev_valid(const uint32_t *bits, int64_t bit0, int64_t n, int64_t row) {
+    if (row < 0 || row >= n) return -1;
+    if (!bits) return row;
+    int64_t b = bit0 + row;
+    while (b >= bit0) {
+        const int64_t w = b >> 5;
+        const int sh = (int)(b & 31);
+        uint32_t x = bits[w];
+        x = sh == 31 ? x : (x & ((2u << sh) - 1u));  // bits <= sh
+        if (w == (bit0 >> 5)) x &= ~0u << (bit0 & 31);  // not before the column's first bit
+        if (x) return (w << 5) + (31 - __clz((int)x)) - bit0;
+        b = (w << 5) - 1;
+    }
+    return -1;
+}
+__device__ int64_t next_valid(const uint32_t *bits, int64_t bit0, int64_t n, int64_t row) {
+    if (row < 0 || row >= n) return -1;
+    if (!bits) return row;
+    int64_t b = bit0 + row;
+    const int64_t bend = bit0 + n;
+    while (b < bend) {
+        const int64_t w = b >> 5;
+        uint32_t x = bits[w] & (~0u << (b & 31));
+        if (x) {
+            const int64_t r = (w << 5) + (__ffs((int)x) - 1) - bit0;
+            return r < n ? r : -1;
+        }
+        b = (w + 1) << 5;
+    }
+    return -1;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ Interpolate
+// first row of every window: first_idx[k] = lower_bound(ts, s_k) for k in [0, W], first_idx[W] = n
+__global__ __launch_bounds__(256) void window_first_rows_kernel(const int64_t *ts, int64_t n, int64_t s0, int64_t interval,
+                                                                MagicDiv magic, int64_t W, int64_t *first_idx,
+                                                                uint32_t *status) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += stride) {
+        if (i == n) {  // windows after the last row's window do not exist (W = wid(last)+1); terminator
+            first_idx[W] = n;
+            continue;
+        }
+        const int64_t t = ts[i];
+        const uint64_t w = t < s0 ? 0 : magic_div((uint64_t)t - (uint64_t)s0, magic);
+        uint64_t wp;
+        if (i == 0) {
+            first_idx[0] = 0;
+            wp = 0;
+        } else {
+            const int64_t tp = ts[i - 1];
+            if (tp > t) atomicOr(&status[0], 1u);
+            wp = tp < s0 ? 0 : magic_div((uint64_t)tp - (uint64_t)s0, magic);
+        }
+        for (uint64_t k = wp + 1; k <= w && (int64_t)k < W; k++) first_idx[k] = i;  // k's first row (and every empty window before it)
+    }
+}
+
+// missing[k] = 1 when window k gets a synthetic start row (interpolation.go:118-137)
+__global__ __launch_bounds__(256) void window_missing_kernel(const int64_t *ts, int64_t s0, int64_t interval, int64_t W,
+                                                             const int64_t *first_idx, int32_t *missing) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < W; k += stride) {
+        const int64_t a = first_idx[k], b = first_idx[k + 1];
+        const int64_t sk = s0 + k * interval;
+        // Window 0 also spans rows below s0; its first valid ts is then ts[0] != s_0
+        int64_t first_col_value = -1;                                   // interpolation.go:119
+        if (k == 0 ? (b > 0 && ts[b - 1] >= s0) : (b > a))
+            first_col_value = go_f64_to_i64((double)ts[k == 0 ? 0 : a]);  // int64(float64(ts)) :121-123
+        missing[k] = first_col_value != sk;
+    }
+}
+
+// three-kernel exclusive scan of int32 flags into int64 positions
+__global__ __launch_bounds__(256) void scan_block_sums_kernel(const int32_t *in, int64_t n, int64_t *block_sums) {
+    __shared__ long long sh[4];
+    const int64_t base = (int64_t)blockIdx.x * 2048;
+    long long acc = 0;
+    for (int j = 0; j < 8; j++) {
+        const int64_t i = base + j * 256 + threadIdx.x;
+        if (i < n) acc += in[i];
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+__global__ void scan_sums_kernel(int64_t *block_sums, int64_t nblocks, int64_t *total) {
+    // single thread: nblocks = W/2048 (<= ~50 k for W = 1e8)
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int64_t run = 0;
+        for (int64_t i = 0; i < nblocks; i++) { const int64_t v = block_sums[i]; block_sums[i] = run; run += v; }
+        *total = run;
+    }
+}
+__global__ __launch_bounds__(256) void scan_apply_kernel(const int32_t *in, int64_t n, const int64_t *block_sums, int64_t *out) {
+    __shared__ long long sh[256];
+    const int64_t base = (int64_t)blockIdx.x * 2048 + (int64_t)threadIdx.x * 8;
+    long long loc[8], acc = 0;
+    for (int j = 0; j < 8; j++) { loc[j] = acc; if (base + j < n) acc += in[base + j]; }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) { long long run = block_sums[blockIdx.x]; for (int t = 0; t < 256; t++) { const long long v = sh[t]; sh[t] = run; run += v; } }
+    __syncthreads();
+    const long long off = sh[threadIdx.x];
+    for (int j = 0; j < 8; j++) if (base + j < n) out[base + j] = off + loc[j];
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) out[n] = off + acc;  // out has n+1 entries
+}
+
+struct InterpCol {
+    const uint64_t *values;
+    const uint32_t *vbits;
+    int64_t vbit0;
+    int32_t type;
+    int32_t kind;
+    double const_value;
+    int32_t has_prev, prev_t_valid, prev_v_valid, _pad;
+    double prev_t, prev_v;
+    int64_t prev_v_i64;
+    uint64_t *out_values;
+    uint8_t *out_valid_bytes;  // one byte per output row, packed afterwards
+};
+struct InterpParams {
+    const int64_t *ts;
+    int64_t n, s0, interval, W;
+    MagicDiv magic;
+    const int64_t *first_idx;
+    const int32_t *missing;
+    const int64_t *pos;  // exclusive scan of missing, W+1 entries
+    int32_t ncols, ts_col;
+    InterpCol cols[kMaxCols];
+};
+
+// real rows: output position = i + (synthetic rows of windows <= wid(i))
+__global__ __launch_bounds__(256) void interp_scatter_rows_kernel(const InterpParams p) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < p.n; i += stride) {
+        const int64_t t = p.ts[i];
+        const uint64_t w = t < p.s0 ? 0 : magic_div((uint64_t)t - (uint64_t)p.s0, p.magic);
+        const int64_t o = i + p.pos[w + 1];
+        for (int c = 0; c < p.ncols; c++) {
+            const InterpCol &ic = p.cols[c];
+            ic.out_values[o] = ic.values[i];
+            ic.out_valid_bytes[o] = bit_at(ic.vbits, ic.vbit0, i) ? 1 : 0;
+        }
+    }
+}
+
+// synthetic rows: one per window that misses its start
+__global__ __launch_bounds__(256) void interp_synth_rows_kernel(const InterpParams p) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < p.W; k += stride) {
+        if (!p.missing[k]) continue;
+        const int64_t a = k == 0 ? 0 : p.first_idx[k];  // Window.FirstIndex
+        const int64_t o = a + p.pos[k];
+        const int64_t sk = p.s0 + k * p.interval;
+        for (int c = 0; c < p.ncols; c++) {
+            const InterpCol &ic = p.cols[c];
+            const bool is_int = ic.type == BOWGPU_INT64;
+            uint64_t bits = 0;
+            int valid = 0;
+            switch (ic.kind) {
+            case BOWGPU_INTERP_WINDOW_START:  // interpolation/windowstart.go:10-12
+                bits = is_int ? (uint64_t)sk : (uint64_t)__double_as_longlong((double)sk);
+                valid = 1;
+                break;
+            case BOWGPU_INTERP_CONST:
+                bits = is_int ? (uint64_t)go_f64_to_i64(ic.const_value) : (uint64_t)__double_as_longlong(ic.const_value);
+                valid = 1;
+                break;
+            case BOWGPU_INTERP_LINEAR: {  // interpolation/linear.go:12-37 (ts has no nulls: both-valid == value valid)
+                double t0, v0;
+                const int64_t pi = prev_valid(ic.vbits, ic.vbit0, p.n, a - 1);
+                if (pi >= 0) { t0 = (double)p.ts[pi]; v0 = bits_to_f64(ic.values[pi], ic.type); }
+                else if (ic.has_prev && ic.prev_t_valid && ic.prev_v_valid) { t0 = ic.prev_t; v0 = ic.prev_v; }
+                else break;
+                const int64_t ni = next_valid(ic.vbits, ic.vbit0, p.n, a);
+                if (ni < 0) break;
+                const double t2 = (double)p.ts[ni], v2 = bits_to_f64(ic.values[ni], ic.type);
+                const double coef = ((double)sk - t0) / (t2 - t0);
+                const double r = ((v2 - v0) * coef) + v0;
+                bits = is_int ? (uint64_t)go_f64_to_i64(r) : (uint64_t)__double_as_longlong(r);  // SetOrDrop: bowconvert.go:28-29
+                valid = 1;
+                break;
+            }
+            case BOWGPU_INTERP_STEP_PREVIOUS: {  // interpolation/stepprevious.go:11-24
+                const int64_t pi = prev_valid(ic.vbits, ic.vbit0, p.n, a - 1);
+                if (pi >= 0) { bits = ic.values[pi]; valid = 1; }
+                else if (ic.has_prev && ic.prev_v_valid) {
+                    bits = is_int ? (uint64_t)ic.prev_v_i64 : (uint64_t)__double_as_longlong(ic.prev_v);
+                    valid = 1;
+                }
+                break;
+            }
+            default: break;  // None: nil
+            }
+            ic.out_values[o] = valid ? bits : 0;
+            ic.out_valid_bytes[o] = (uint8_t)valid;
+        }
+    }
+}
+
+// bytes (0/1) -> Arrow validity bits, 32 rows per lane-word; also counts the set bits
+__global__ __launch_bounds__(256) void pack_validity_kernel(const uint8_t *bytes, int64_t n, uint32_t *words,
+                                                            unsigned long long *set_count) {
+    const int64_t nwords = (n + 31) >> 5;
+    unsigned long long acc = 0;
+    for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t x = 0;
+        const int64_t base = w << 5;
+        for (int j = 0; j < 32; j++) if (base + j < n && bytes[base + j]) x |= 1u << j;
+        words[w] = x;
+        acc += __popc(x);
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(set_count, acc);
+}
+
+// ------------------------------------------------------------------ IsColSorted / FillLinear
+// flags[0] |= 1 if some consecutive valid pair increases, |= 2 if some decreases, |= 4 if any valid value exists
+__global__ __launch_bounds__(256) void col_order_kernel(const uint64_t *values, const uint32_t *vbits, int64_t vbit0, int64_t n,
+                                                        int32_t type, uint32_t *flags) {
+    uint32_t f = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (!bit_at(vbits, vbit0, i)) continue;
+        f |= 4;
+        const int64_t pi = prev_valid(vbits, vbit0, n, i - 1);
+        if (pi < 0) continue;
+        if (type == BOWGPU_INT64) {
+            const int64_t c = (int64_t)values[pi], x = (int64_t)values[i];
+            if (c < x) f |= 1; else if (c > x) f |= 2;
+        } else {
+            const double c = __longlong_as_double((long long)values[pi]), x = __longlong_as_double((long long)values[i]);
+            if (c < x) f |= 1; else if (c > x) f |= 2;  // NaN compares false both ways (bowassertion.go:64-74)
+        }
+    }
+    if (f) atomicOr(flags, f);
+}
+
+struct FillParams {
+    const uint64_t *ref_values; const uint32_t *ref_vbits; int64_t ref_vbit0; int32_t ref_type;
+    const uint64_t *fill_values; const uint32_t *fill_vbits; int64_t fill_vbit0; int32_t fill_type;
+    int64_t n;
+    uint64_t *out_values; uint8_t *out_valid_bytes;
+};
+
+__global__ __launch_bounds__(256) void fill_linear_kernel(const FillParams p) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < p.n; i += (int64_t)gridDim.x * blockDim.x) {
+        uint64_t bits = p.fill_values[i];
+        int valid = bit_at(p.fill_vbits, p.fill_vbit0, i) ? 1 : 0;
+        if (!valid) {  // bowfill.go:65-97
+            const int64_t rp = prev_valid(p.fill_vbits, p.fill_vbit0, p.n, i - 1);
+            const int64_t rn = next_valid(p.fill_vbits, p.fill_vbit0, p.n, i + 1);
+            const bool v1 = bit_at(p.ref_vbits, p.ref_vbit0, i);
+            const bool v2 = rp >= 0 && bit_at(p.ref_vbits, p.ref_vbit0, rp);   // GetFloat64(ref, -1) => (0,false) :72
+            const bool v3 = rn >= 0 && bit_at(p.ref_vbits, p.ref_vbit0, rn);
+            if (v1 && v2 && v3) {
+                const double prev_fill = bits_to_f64(p.fill_values[rp], p.fill_type);
+                const double next_fill = bits_to_f64(p.fill_values[rn], p.fill_type);
+                const double row_ref = bits_to_f64(p.ref_values[i], p.ref_type);
+                const double prev_ref = bits_to_f64(p.ref_values[rp], p.ref_type);
+                const double next_ref = bits_to_f64(p.ref_values[rn], p.ref_type);
+                // (the nextRef-prevRef == 0 branch of :78-85 is overwritten by the fall-through below)
+                double tmp = row_ref - prev_ref;   // :87-90, four separate statements
+                tmp /= next_ref - prev_ref;
+                tmp *= next_fill - prev_fill;
+                tmp += prev_fill;
+                if (p.fill_type == BOWGPU_INT64) bits = (uint64_t)go_f64_to_i64(round(tmp));  // math.Round: half away from zero :93
+                else bits = (uint64_t)__double_as_longlong(tmp);
+                valid = 1;
+            }
+        }
+        p.out_values[i] = bits;
+        p.out_valid_bytes[i] = (uint8_t)valid;
+    }
+}
+
+// ------------------------------------------------------------------ whole-frame aggregation
+// Level 1: block b reduces rows [b*chunk, (b+1)*chunk) of one column into a partial state (thread t walks a
+// contiguous sub-range in row order; 256 partials merged in order).  Level 2: one thread merges the block
+// partials in order.  Fixed shape => deterministic; Sum/Mean/Integral are not in strict row order (1e-12 rel).
+struct WholeParams {
+    const int64_t *ts;
+    const uint64_t *values;
+    const uint32_t *vbits;
+    int64_t vbit0;
+    int64_t n;
+    int32_t type;
+    int32_t need_ts;
+    Stats *partials;
+    int64_t chunk;
+};
+
+__global__ __launch_bounds__(256) void whole_partial_kernel(const WholeParams p) {
+    __shared__ Stats part[256];
+    const int tid = threadIdx.x;
+    const int64_t lo = (int64_t)blockIdx.x * p.chunk;
+    int64_t hi = lo + p.chunk;
+    if (hi > p.n) hi = p.n;
+    const int64_t len = hi > lo ? hi - lo : 0;
+    const int64_t a = lo + (len * tid) / 256, b = lo + (len * (tid + 1)) / 256;
+    Stats st;
+    stats_init(st);
+    for (int64_t r = a; r < b; r++) {
+        if (!bit_at(p.vbits, p.vbit0, r)) continue;
+        const uint64_t raw = p.values[r];
+        const double x = bits_to_f64(raw, p.type);
+        stats_value<true>(st, x, raw);
+        if (p.need_ts) stats_point(st, (double)p.ts[r], x);
+    }
+    part[tid] = st;
+    __syncthreads();
+    if (tid == 0) {
+        Stats acc = part[0];
+        for (int t = 1; t < 256; t++) stats_merge(acc, part[t]);
+        p.partials[blockIdx.x] = acc;
+    }
+}
+
+struct WholeFinal {
+    int32_t kind, out_type, col_is_int, n_factors;
+    double factors[BOWGPU_MAX_FACTORS];
+    uint64_t *out_value;
+    uint8_t *out_valid_byte;
+};
+
+__global__ void whole_final_kernel(const Stats *partials, int64_t nblocks, int64_t nrows, int64_t first_value,
+                                   int64_t last_value, WholeFinal f) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    Stats acc;
+    stats_init(acc);
+    for (int64_t i = 0; i < nblocks; i++) stats_merge(acc, partials[i]);
+    // reduce_val expects (win_start, interval) with LastValue = win_start + interval (whole.go:64-71)
+    Val v = reduce_val(f.kind, acc, nrows, first_value, last_value - first_value, f.col_is_int);
+    if (v.valid) {
+        for (int k = 0; k < f.n_factors; k++) {
+            if (v.is_int) v.bits = (uint64_t)go_f64_to_i64((double)(int64_t)v.bits * f.factors[k]);
+            else v.bits = (uint64_t)__double_as_longlong(__longlong_as_double((long long)v.bits) * f.factors[k]);
+        }
+        // SetOrDropStrict (bowbuffer.go:84-104): a type assertion, no conversion
+        if ((f.out_type == BOWGPU_INT64) != (v.is_int != 0)) v.valid = 0;
+    }
+    *f.out_value = v.valid ? v.bits : 0;
+    *f.out_valid_byte = (uint8_t)(v.valid ? 1 : 0);
+}
+
+// Window.FirstIndex / Window.Bow row range / Window.IsInclusive of every window (rolling.go:177-239)
+__global__ __launch_bounds__(256) void window_bounds_kernel(const int64_t *ts, int64_t n, int64_t s0, int64_t interval, int64_t W,
+                                                            int inclusive, int pre_rows, const int64_t *first_idx,
+                                                            int64_t *first_index, int64_t *slice_begin, int64_t *slice_end,
+                                                            uint8_t *is_incl) {
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < W; k += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t a = first_idx[k], b = first_idx[k + 1];
+        const bool incl = inclusive && b < n && ts[b] == s0 + (k + 1) * interval;       // rolling.go:201-209
+        bool real = b > a;
+        if (k == 0 && pre_rows) real = b > 0 && ts[b - 1] >= s0;                        // rows below s0 alone do not make a window
+        const int64_t end = b + (incl ? 1 : 0);
+        const bool empty = !(real || incl);
+        if (first_index) first_index[k] = a;
+        if (slice_begin) slice_begin[k] = empty ? 0 : a;                                // NewEmptySlice :225-226
+        if (slice_end) slice_end[k] = empty ? 0 : end;
+        if (is_incl) is_incl[k] = incl ? 1 : 0;
+    }
+}
+
+// ------------------------------------------------------------------ launchers
+static inline unsigned grid_for(int64_t n, int per_block = 256, int64_t cap = 256 * 16) {
+    int64_t g = (n + per_block - 1) / per_block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+int launch_window_first_rows(Ctx *c, const int64_t *ts, int64_t n, const Plan &plan, int64_t *first_idx, uint32_t *status) {
+    hipLaunchKernelGGL(window_first_rows_kernel, dim3(grid_for(n + 1)), dim3(256), 0, c->stream, ts, n, plan.s0, plan.interval,
+                       plan.magic, plan.W, first_idx, status);
+    BG_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_window_missing(Ctx *c, const int64_t *ts, const Plan &plan, const int64_t *first_idx, int32_t *missing) {
+    hipLaunchKernelGGL(window_missing_kernel, dim3(grid_for(plan.W)), dim3(256), 0, c->stream, ts, plan.s0, plan.interval, plan.W,
+                       first_idx, missing);
+    BG_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_exclusive_scan(Ctx *c, const int32_t *in, int64_t n, int64_t *out /* n+1 */, int64_t *block_sums, int64_t *d_total) {
+    const int64_t nblocks = (n + 2047) / 2048;
+    if (n == 0) { BG_HIP(hipMemsetAsync(out, 0, 8, c->stream)); BG_HIP(hipMemsetAsync(d_total, 0, 8, c->stream)); return 0; }
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3((unsigned)nblocks), dim3(256), 0, c->stream, in, n, block_sums);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(64), 0, c->stream, block_sums, nblocks, d_total);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nblocks), dim3(256), 0, c->stream, in, n, block_sums, out);
+    BG_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_pack_validity(Ctx *c, const uint8_t *bytes, int64_t n, uint32_t *words, uint64_t *d_set_count) {
+    BG_HIP(hipMemsetAsync(d_set_count, 0, 8, c->stream));
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(pack_validity_kernel, dim3(grid_for((n + 31) / 32)), dim3(256), 0, c->stream, bytes, n, words,
+                       reinterpret_cast<unsigned long long *>(d_set_count));
+    BG_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_col_order(Ctx *c, const uint64_t *values, const uint32_t *vbits, int64_t vbit0, int64_t n, int32_t type, uint32_t *d_flags) {
+    BG_HIP(hipMemsetAsync(d_flags, 0, 4, c->stream));
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(col_order_kernel, dim3(grid_for(n)), dim3(256), 0, c->stream, values, vbits, vbit0, n, type, d_flags);
+    BG_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_window_bounds(Ctx *c, const int64_t *ts, int64_t n, const Plan &plan, int inclusive, int pre_rows,
+                         const int64_t *first_idx, int64_t *first_index, int64_t *slice_begin, int64_t *slice_end, uint8_t *is_incl) {
+    if (plan.W <= 0) return 0;
+    hipLaunchKernelGGL(window_bounds_kernel, dim3(grid_for(plan.W)), dim3(256), 0, c->stream, ts, n, plan.s0, plan.interval, plan.W,
+                       inclusive, pre_rows, first_idx, first_index, slice_begin, slice_end, is_incl);
+    BG_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace bowgpu
+
+// launchers that take the kernel-parameter structs live here with them
+namespace bowgpu {
+
+static_assert(sizeof(InterpParams) == sizeof(InterpParamsH), "InterpParams layout");
+static_assert(sizeof(FillParams) == sizeof(FillParamsH), "FillParams layout");
+static_assert(sizeof(WholeParams) == sizeof(WholeParamsH), "WholeParams layout");
+static_assert(sizeof(WholeFinal) == sizeof(WholeFinalH), "WholeFinal layout");
+
+int interp_run(Ctx *c, const void *params_blob) {
+    const InterpParams &p = *reinterpret_cast<const InterpParams *>(params_blob);
+    if (p.n > 0) hipLaunchKernelGGL(interp_scatter_rows_kernel, dim3(grid_for(p.n)), dim3(256), 0, c->stream, p);
+    if (p.W > 0) hipLaunchKernelGGL(interp_synth_rows_kernel, dim3(grid_for(p.W)), dim3(256), 0, c->stream, p);
+    BG_HIP(hipGetLastError());
+    return 0;
+}
+
+int fill_linear_run(Ctx *c, const void *params_blob) {
+    const FillParams &p = *reinterpret_cast<const FillParams *>(params_blob);
+    if (p.n > 0) hipLaunchKernelGGL(fill_linear_kernel, dim3(grid_for(p.n)), dim3(256), 0, c->stream, p);
+    BG_HIP(hipGetLastError());
+    return 0;
+}
+
+int whole_run(Ctx *c, const void *params_blob, int64_t nblocks) {
+    const WholeParams &p = *reinterpret_cast<const WholeParams *>(params_blob);
+    hipLaunchKernelGGL(whole_partial_kernel, dim3((unsigned)nblocks), dim3(256), 0, c->stream, p);
+    BG_HIP(hipGetLastError());
+    return 0;
+}
+
+int whole_final_run(Ctx *c, const void *partials, int64_t nblocks, int64_t nrows, int64_t first_value, int64_t last_value,
+                    const void *final_blob) {
+    const WholeFinal &f = *reinterpret_cast<const WholeFinal *>(final_blob);
+    hipLaunchKernelGGL(whole_final_kernel, dim3(1), dim3(64), 0, c->stream, reinterpret_cast<const Stats *>(partials), nblocks, nrows,
+                       first_value, last_value, f);
+    BG_HIP(hipGetLastError());
+    return 0;
+}
+
+size_t stats_size() { return sizeof(Stats); }
+
+}  // namespace bowgpu

@@ -1,0 +1,213 @@
+"""GPU parity for the callers either side of Rolling.Aggregate (SURVEY §8 a16-a18 + f2):
+Rolling.Interpolate, Bow.FillLinear / IsColSorted, window bounds (the iterator), whole-frame
+Aggregate — golden vectors of the reference's tests plus seeded comparisons with the oracle."""
+import numpy as np
+import pytest
+
+from bow_amd import capi
+from oracle import pyoracle as orc
+
+pytestmark = pytest.mark.gpu
+
+T = {"float64": capi.FLOAT64, "int64": capi.INT64}
+
+
+def same_list(a, b):
+    assert len(a) == len(b), (a, b)
+    for x, y in zip(a, b):
+        assert (x is None) == (y is None) and (x is None or x == y), (a, b)
+
+
+def _interps(spec):
+    out = []
+    for i, s in enumerate(spec):
+        if s.startswith("Const:"):
+            out.append({"kind": "Const", "col": i, "const": float(s.split(":")[1])})
+        else:
+            out.append({"kind": s, "col": i})
+    return out
+
+
+def cmp_out(name, got, want):
+    assert got.length == want.length, (name, got.length, want.length)
+    gm, wm = got.valid_mask(), want.valid_mask()
+    assert np.array_equal(gm, wm), (name, np.flatnonzero(gm != wm)[:10])
+    gv, _ = got.host_arrays()
+    wv = want.values[:want.length]
+    assert np.array_equal(gv.view(np.uint64)[gm], wv.view(np.uint64)[wm]), name
+    assert got.null_count == int((~wm).sum()), name
+
+
+# ------------------------------------------------------------------ Interpolate
+def test_golden_interpolate(golden):
+    for v in golden["interpolate"]:
+        cols = [capi.Column.from_list(v["time"], "int64"), capi.Column.from_list(v["value"], "float64")]
+        outs = capi.rolling_interpolate(cols, 0, v["interval"], _interps(v["interps"]), offset=v["offset"])
+        same_list(outs[0].to_list(), v["expect_time"])
+        same_list(outs[1].to_list(), v["expect_value"])
+
+
+def test_interpolate_errors():
+    cols = [capi.Column.from_list([10, 13], "int64"), capi.Column.from_list([1.0, 1.3], "float64")]
+    with pytest.raises(capi.BowGpuError) as e:  # rolling/interpolation_test.go:37-47
+        capi.rolling_interpolate(cols, 0, 2, [{"kind": "Const", "col": 1, "const": 9.9}])
+    assert e.value.code == -5
+    with pytest.raises(capi.BowGpuError) as e:  # WindowStart accepts Int64 only (windowstart.go:9)
+        capi.rolling_interpolate(cols, 0, 2, [{"kind": "WindowStart", "col": 0}, {"kind": "WindowStart", "col": 1}])
+    assert e.value.code == -7 and e.value.message == "accepts types [int64], got type float64"
+
+
+@pytest.mark.parametrize("vtype", ["f64", "i64"])
+def test_interpolate_random_vs_oracle(vtype):
+    rng = np.random.default_rng(3)
+    for n, interval, offset in [(1, 5, 0), (50, 3, 1), (5000, 10, 0), (60_000, 100, 7), (60_000, 7, 0)]:
+        ts = np.cumsum(rng.integers(1, 20, n)).astype(np.int64) - 500
+        if vtype == "f64":
+            vals = np.round(rng.standard_normal(n) * 100, 2)
+        else:
+            vals = rng.integers(-1000, 1000, n).astype(np.int64)
+        valid = rng.random(n) >= 0.3
+        bm = np.packbits(valid, bitorder="little")
+        typ = capi.FLOAT64 if vtype == "f64" else capi.INT64
+        for kind in ["Linear", "StepPrevious", "None"]:
+            for prev in [None, (float(ts[0] - 3), True, 42.5, True, 42)]:
+                ip = [{"kind": "WindowStart", "col": 0}, {"kind": kind, "col": 1}]
+                if prev is not None:
+                    ip[1]["prev"] = prev
+                got = capi.rolling_interpolate([capi.Column(ts), capi.Column(vals, bm, typ, 0, n, -1)], 0, interval, ip, offset=offset)
+                want = orc.interpolate([orc.Column(ts, None, orc.INT64), orc.Column(vals, bm, typ)], 0, interval, ip, offset=offset)
+                cmp_out("ts %s" % kind, got[0], want[0])
+                cmp_out("val %s n=%d prev=%s" % (kind, n, prev is not None), got[1], want[1])
+
+
+def test_interpolate_then_mean_sparse_generator():
+    # configs[2]: irregular ts, 30 % nulls, Linear fill then rolling mean - both stages on the device
+    n = 300_000
+    ts_d, val_d = capi.gen_sparse(0, n, seed=11)
+    ip = [{"kind": "WindowStart", "col": 0}, {"kind": "Linear", "col": 1}]
+    filled = capi.rolling_interpolate([ts_d, val_d], 0, 100, ip, out_residency=capi.DEVICE)
+    ts_o, val_o, bm_o = orc.gen_sparse(0, n, seed=11)
+    want = orc.interpolate([orc.Column(ts_o, None, orc.INT64), orc.Column(val_o, bm_o, orc.FLOAT64)], 0, 100, ip)
+    cmp_out("ts", filled[0], want[0])
+    cmp_out("val", filled[1], want[1])
+    m = filled[0].length
+    cols2 = [capi.Column(filled[0].values, None, capi.INT64, 0, m, 0), capi.Column(filled[1].values, filled[1].validity, capi.FLOAT64, 0, m, -1)]
+    aggs = [("WindowStart", 0), ("ArithmeticMean", 1), ("Count", 1)]
+    outs, _ = capi.rolling_aggregate(cols2, 0, 100, aggs)
+    exp, _ = orc.aggregate([want[0], want[1]], 0, 100, aggs)
+    for (k, _), g, w in zip(aggs, outs, exp):
+        cmp_out(k, g, w)
+
+
+# ------------------------------------------------------------------ FillLinear / IsColSorted
+def test_golden_fill_linear(golden):
+    names = ["a", "b", "c", "d", "e"]
+    for v in golden["fill_linear"]:
+        cols = [capi.Column.from_list([None if x is None else (float(x) if v["type"] == "float64" else x)
+                                       for x in golden["fill_bow"][n]], v["type"]) for n in names]
+        ref, fill = names.index(v["ref"]), names.index(v["fill"])
+        if v.get("error"):
+            with pytest.raises(capi.BowGpuError) as e:
+                capi.fill_linear(cols, ref, fill)
+            assert e.value.code == -8
+            continue
+        out, unchanged = capi.fill_linear(cols, ref, fill)
+        assert not unchanged and out.type == T[v["type"]]
+        same_list(out.to_list(), v["expect"])
+    m = golden["fill_linear_meta"]
+    cols = [capi.Column.from_list(m["ref"], m["ref_type"]), capi.Column.from_list(m["fill"], m["fill_type"])]
+    out, _ = capi.fill_linear(cols, 0, 1)
+    same_list(out.to_list(), m["expect"])
+
+
+@pytest.mark.parametrize("ftype", ["f64", "i64"])
+@pytest.mark.parametrize("desc", [False, True])
+def test_fill_linear_random_vs_oracle(ftype, desc):
+    rng = np.random.default_rng(17)
+    n = 100_000
+    ref = np.cumsum(rng.integers(0, 5, n)).astype(np.float64) * 0.5
+    if desc:
+        ref = ref[::-1].copy()
+    ref_valid = rng.random(n) >= 0.1
+    fill = np.round(rng.standard_normal(n) * 1000, 1) if ftype == "f64" else rng.integers(-10**6, 10**6, n).astype(np.int64)
+    fill_valid = rng.random(n) >= 0.4
+    fill_valid[:3] = False  # leading nulls have no previous value
+    rb, fb = np.packbits(ref_valid, bitorder="little"), np.packbits(fill_valid, bitorder="little")
+    ftyp = capi.FLOAT64 if ftype == "f64" else capi.INT64
+    got, unchanged = capi.fill_linear([capi.Column(ref, rb, capi.FLOAT64, 0, n, -1), capi.Column(fill, fb, ftyp, 0, n, -1)], 0, 1)
+    want, wu = orc.fill_linear([orc.Column(ref, rb, orc.FLOAT64), orc.Column(fill, fb, ftyp)], 0, 1)
+    assert unchanged == wu
+    cmp_out("fill", got, want)
+    # no nulls => the reference returns the receiver
+    got, unchanged = capi.fill_linear([capi.Column(ref, rb, capi.FLOAT64, 0, n, -1), capi.Column(fill, None, ftyp)], 0, 1)
+    assert unchanged and got.null_count == 0
+
+
+def test_is_col_sorted():
+    cases = [([1, 2, 2, 5], True), ([5, 4, 4, 1], True), ([1, 3, 2], False), ([None, None], False), ([], False),
+             ([None, 1, None, 2, 3], True), ([3, None, 3, 3], True), ([1.0, float("nan"), 2.0], True)]
+    for data, want in cases:
+        typ = "float64" if any(isinstance(x, float) for x in data) else "int64"
+        col = capi.Column.from_list(data, typ)
+        assert capi.is_col_sorted(col) == want, data
+        assert orc.is_col_sorted(orc.Column.from_list(data, typ)) == want, data
+
+
+# ------------------------------------------------------------------ window bounds (the iterator)
+def test_golden_window_bounds(golden):
+    for v in golden["iterate"]:
+        ts = capi.Column.from_list(v["time"], "int64")
+        s0, W, fi, sb, se, inc = capi.window_bounds(ts, v["interval"], v["offset"], v["inclusive"])
+        assert W == len(v["windows"])
+        for k, w in enumerate(v["windows"]):
+            assert s0 + k * v["interval"] == w["start"]
+            assert fi[k] == w["first_index"], (v["name"], k)
+            assert [v["time"][r] for r in range(sb[k], se[k])] == w["time_rows"], (v["name"], k)
+
+
+@pytest.mark.parametrize("inclusive", [False, True])
+def test_window_bounds_random_vs_oracle(inclusive):
+    rng = np.random.default_rng(8)
+    for n, interval, offset in [(1, 3, 0), (5000, 4, 1), (80_000, 25, -3)]:
+        ts = np.cumsum(rng.integers(0, 6, n)).astype(np.int64) - 40
+        s0, W, fi, sb, se, inc = capi.window_bounds(capi.Column(ts), interval, offset, inclusive)
+        wins = orc.iterate_windows(orc.Column(ts, None, orc.INT64), interval, offset, inclusive)
+        assert W == len(wins)
+        assert np.array_equal(fi, [w["first_index"] for w in wins])
+        assert np.array_equal(sb, [w["slice_begin"] for w in wins])
+        assert np.array_equal(se, [w["slice_end"] for w in wins])
+        assert np.array_equal(inc, [w["is_inclusive"] for w in wins])
+
+
+# ------------------------------------------------------------------ whole-frame Aggregate
+def test_golden_whole(golden):
+    for v in golden["whole"]:
+        cols = [capi.Column.from_list(v["time"], "int64"), capi.Column.from_list(v["value"], "float64")]
+        aggs = []
+        for a in v["aggs"]:
+            k, cname = a.split(":")
+            aggs.append((k, 0 if cname == "time" else 1))
+        outs = capi.aggregate_whole(cols, 0, aggs)
+        for o, exp in zip(outs, v["expect"]):
+            same_list(o.to_list(), exp)
+
+
+def test_whole_random_vs_oracle():
+    rng = np.random.default_rng(23)
+    n = 500_000
+    ts = np.cumsum(rng.integers(1, 9, n)).astype(np.int64)
+    vals = rng.standard_normal(n)
+    valid = rng.random(n) >= 0.25
+    bm = np.packbits(valid, bitorder="little")
+    kinds = ["WindowStart", "Sum", "ArithmeticMean", "Min", "Max", "Count", "First", "Last", "IntegralStep",
+             "IntegralTrapezoid", "WeightedAverageStep", "WeightedAverageLinear"]
+    aggs = [(k, 0 if k == "WindowStart" else 1) for k in kinds]
+    got = capi.aggregate_whole([capi.Column(ts), capi.Column(vals, bm, capi.FLOAT64, 0, n, -1)], 0, aggs)
+    want = orc.aggregate_whole([orc.Column(ts, None, orc.INT64), orc.Column(vals, bm, orc.FLOAT64)], 0, aggs)
+    for k, g, w in zip(kinds, got, want):
+        gl, wl = g.to_list(), w.to_list()
+        assert len(gl) == len(wl) == 1 and (gl[0] is None) == (wl[0] is None), k
+        if k in ("WindowStart", "Min", "Max", "Count", "First", "Last"):
+            assert gl[0] == wl[0], k
+        else:
+            assert abs(gl[0] - wl[0]) <= 1e-10 * max(1.0, abs(wl[0])), (k, gl[0], wl[0])
