@@ -325,8 +325,8 @@ def plan_windows(ts, interval, offset=0):
 
 def rolling_aggregate(cols, ts_col, interval, aggs, offset=0, inclusive=False, out_residency=HOST, outs=None):
     """Returns (list[OutColumn], AggInfo).  aggs: [(kind, col[, factors])]."""
-    s0, W = plan_windows(cols[ts_col], interval, offset)
     if outs is None:
+        s0, W = plan_windows(cols[ts_col], interval, offset)
         outs = [OutColumn(W, out_residency) for _ in aggs]
     oarr = (Out * max(len(aggs), 1))()
     for i, o in enumerate(outs):

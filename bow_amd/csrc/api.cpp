@@ -262,27 +262,45 @@ int plan_make(Ctx *c, const bowgpu_col *ts, int64_t interval, int64_t raw_offset
     p->W = 0;
     const int64_t n = ts->length;
     if (n == 0) return 0;
-    int valid = 1;
-    BG_TRY(fetch_valid(c, ts, 0, &valid));
-    if (!valid) return fail(BOWGPU_ERR_FIRST_TS_NULL, "the first value of the column should be convertible to int64, got <nil>");
-    int64_t first = 0;
-    BG_TRY(fetch_i64(c, ts, 0, &first));
+    int64_t first = 0, last = 0;
+    int64_t row = n - 1;
+    if (!ts->validity) {
+        // common case (no validity buffer): both scalars with one round trip
+        const int64_t *base = reinterpret_cast<const int64_t *>(ts->values) + ts->offset;
+        if (ts->residency == BOWGPU_DEVICE) {
+            if (!c) BG_TRY(ctx_get(&c));
+            int64_t *hp;
+            BG_TRY(ctx_pinned(c, 4096, reinterpret_cast<void **>(&hp)));
+            hp += 256;  // bytes 2048.. of the pinned block
+            BG_HIP(hipMemcpyAsync(hp, base, 8, hipMemcpyDeviceToHost, c->stream));
+            BG_HIP(hipMemcpyAsync(hp + 1, base + (n - 1), 8, hipMemcpyDeviceToHost, c->stream));
+            BG_HIP(hipStreamSynchronize(c->stream));
+            first = hp[0]; last = hp[1];
+        } else {
+            first = base[0]; last = base[n - 1];
+        }
+    } else {
+        int valid = 1;
+        BG_TRY(fetch_valid(c, ts, 0, &valid));
+        if (!valid) return fail(BOWGPU_ERR_FIRST_TS_NULL, "the first value of the column should be convertible to int64, got <nil>");
+        BG_TRY(fetch_i64(c, ts, 0, &first));
+    }
     p->first_ts = first;
     // Go: (first/interval)*interval + offset with wrapping int64 arithmetic
     int64_t s0 = (int64_t)((uint64_t)((first / interval) * interval) + (uint64_t)p->offset);
     if (s0 > first) s0 = (int64_t)((uint64_t)s0 - (uint64_t)interval);
     p->s0 = s0;
-    // countWindows: last VALID ts scanning backwards (GetPrevInt64, bowgetters.go:189-199)
-    int64_t row = n - 1;
-    int lv = 1;
-    while (row >= 0) {
-        BG_TRY(fetch_valid(c, ts, row, &lv));
-        if (lv) break;
-        row--;
+    if (ts->validity) {
+        // countWindows: last VALID ts scanning backwards (GetPrevInt64, bowgetters.go:189-199)
+        int lv = 1;
+        while (row >= 0) {
+            BG_TRY(fetch_valid(c, ts, row, &lv));
+            if (lv) break;
+            row--;
+        }
+        if (row < 0) { p->W = 0; return 0; }
+        BG_TRY(fetch_i64(c, ts, row, &last));
     }
-    if (row < 0) { p->W = 0; return 0; }
-    int64_t last = 0;
-    BG_TRY(fetch_i64(c, ts, row, &last));
     p->last_ts = last;
     if (s0 > last) { p->W = 0; return 0; }
     p->W = (int64_t)(((uint64_t)last - (uint64_t)s0) / (uint64_t)interval) + 1;
@@ -471,7 +489,28 @@ static int job_build(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t ts_c
     return 0;
 }
 
-static int job_run(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, int64_t *long_windows, double *kernel_ms) {
+// null counts of the nullable outputs + copy-back, enqueued only (no sync)
+static int job_enqueue_tail(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, uint64_t **hcnt_out) {
+    const int64_t W = job->W;
+    void *d;
+    BG_TRY(ctx_scratch(c, job->scratch_bytes, &d));
+    uint64_t *dcnt = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(d) + 1024);
+    uint64_t *hcnt;
+    BG_TRY(ctx_pinned(c, 4096, reinterpret_cast<void **>(&hcnt)));
+    hcnt += 8;
+    *hcnt_out = hcnt;
+    if (W > 0)
+        for (int i = 0; i < naggs; i++) {
+            if (kind_never_nil(aggs[i].kind)) continue;
+            BG_TRY(launch_popcount(c, reinterpret_cast<const uint32_t *>(job->douts[i].validity), 0, W, dcnt + i));
+            BG_HIP(hipMemcpyAsync(hcnt + i, dcnt + i, 8, hipMemcpyDeviceToHost, c->stream));
+        }
+    for (int i = 0; i < naggs; i++) BG_TRY(devout_finish(c, &job->douts[i], W, job->P.aggs[i].out_type, 0));
+    return 0;
+}
+
+static int job_run(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, int64_t *long_windows, double *kernel_ms,
+                   bool finish) {
     AggParams &P = job->P;
     const int64_t W = job->W;
     BG_HIP(hipMemsetAsync(P.status, 0, 64, c->stream));
@@ -496,22 +535,31 @@ static int job_run(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, i
         else BG_TRY(launch_rolling_aggregate(c, P));
         BG_HIP(hipEventRecord(c->ev1, c->stream));
     }
-    // status -> host (pinned) ; decides whether the long-window kernel is needed
+    // status -> host (pinned).  Optimistically enqueue the tail (null counts, copy-back) behind the tile kernel so
+    // the common case needs ONE synchronisation; if windows were queued for the cooperative path, run it and redo the tail.
     uint32_t *hstat;
     BG_TRY(ctx_pinned(c, 4096, reinterpret_cast<void **>(&hstat)));
     BG_HIP(hipMemcpyAsync(hstat, P.status, 16, hipMemcpyDeviceToHost, c->stream));
+    uint64_t *hcnt = nullptr;
+    if (finish) BG_TRY(job_enqueue_tail(c, job, aggs, naggs, &hcnt));
     BG_HIP(hipStreamSynchronize(c->stream));
     if (hstat[0]) return fail(BOWGPU_ERR_TS_UNSORTED, "interval column is not ascending: outside the device path");
     if (hstat[2]) return fail(BOWGPU_ERR_HIP, "internal: long-window list overflow");
     const int64_t n_long = hstat[1];
-    if (n_long > 0) BG_TRY(launch_long_windows(c, P, n_long));
+    if (n_long > 0) {
+        BG_TRY(launch_long_windows(c, P, n_long));
+        if (finish) {
+            BG_TRY(job_enqueue_tail(c, job, aggs, naggs, &hcnt));
+            BG_HIP(hipStreamSynchronize(c->stream));
+        }
+    }
+    if (finish)
+        for (int i = 0; i < naggs; i++)
+            job->douts[i].user->null_count = (W > 0 && !kind_never_nil(aggs[i].kind)) ? W - (int64_t)hcnt[i] : 0;
     if (long_windows) *long_windows = n_long;
     {
         float ms = 0;
-        if (W > 0) {
-            BG_HIP(hipEventSynchronize(c->ev1));
-            BG_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
-        }
+        if (W > 0) BG_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
         c->last_kernel_ms = ms;
         if (kernel_ms) *kernel_ms = ms;
     }
@@ -519,28 +567,11 @@ static int job_run(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, i
 }
 
 static int job_finish(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs) {
-    const int64_t W = job->W;
-    std::vector<int64_t> nulls(naggs, 0);
-    if (W > 0) {
-        void *d;
-        BG_TRY(ctx_scratch(c, job->scratch_bytes, &d));
-        uint64_t *dcnt = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(d) + 1024);
-        uint64_t *hcnt;
-        BG_TRY(ctx_pinned(c, 4096, reinterpret_cast<void **>(&hcnt)));
-        hcnt += 8;
-        bool any = false;
-        for (int i = 0; i < naggs; i++) {
-            if (kind_never_nil(aggs[i].kind)) continue;
-            BG_TRY(launch_popcount(c, reinterpret_cast<const uint32_t *>(job->douts[i].validity), 0, W, dcnt + i));
-            BG_HIP(hipMemcpyAsync(hcnt + i, dcnt + i, 8, hipMemcpyDeviceToHost, c->stream));
-            any = true;
-        }
-        if (any) BG_HIP(hipStreamSynchronize(c->stream));
-        for (int i = 0; i < naggs; i++)
-            if (!kind_never_nil(aggs[i].kind)) nulls[i] = W - (int64_t)hcnt[i];
-    }
-    for (int i = 0; i < naggs; i++) BG_TRY(devout_finish(c, &job->douts[i], W, job->P.aggs[i].out_type, nulls[i]));
+    uint64_t *hcnt = nullptr;
+    BG_TRY(job_enqueue_tail(c, job, aggs, naggs, &hcnt));
     BG_HIP(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < naggs; i++)
+        job->douts[i].user->null_count = (job->W > 0 && !kind_never_nil(aggs[i].kind)) ? job->W - (int64_t)hcnt[i] : 0;
     return 0;
 }
 
@@ -549,8 +580,7 @@ static int run_aggregate(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t 
                          int64_t wid_base, int64_t W, int64_t *long_windows, double *kernel_ms) {
     AggJob job;
     BG_TRY(job_build(c, cols, ncols, ts_col, plan, inclusive, aggs, naggs, outs, wid_base, W, wid_base == 0, &job));
-    BG_TRY(job_run(c, &job, aggs, naggs, long_windows, kernel_ms));
-    BG_TRY(job_finish(c, &job, aggs, naggs));
+    BG_TRY(job_run(c, &job, aggs, naggs, long_windows, kernel_ms, true));
     return 0;
 }
 
@@ -730,14 +760,12 @@ int bowgpu_rolling_aggregate(const bowgpu_col *cols, int32_t ncols, int32_t ts_c
     if (opts) o = *opts;
     // reference order: the Rolling exists first (newIntervalRolling errors), then Aggregate validates
     Plan plan;
-    int64_t s0 = 0, W = 0;
-    BG_TRY(bowgpu_plan_windows(&cols[ts_col], interval, o.offset, &s0, &W));
+    BG_TRY(plan_make(nullptr, &cols[ts_col], interval, o.offset, &plan));
     int inclusive = o.inclusive ? 1 : 0, nic = -1;
     BG_TRY(validate_aggs(cols, ncols, ts_col, aggs, naggs, &inclusive, &nic));
     if (!outs) return fail(BOWGPU_ERR_ARG, "no output columns");
     Ctx *c;
     BG_TRY(ctx_get(&c));
-    BG_TRY(plan_make(c, &cols[ts_col], interval, o.offset, &plan));
     int64_t n_long = 0;
     double ms = 0;
     BG_TRY(run_aggregate(c, cols, ncols, ts_col, plan, inclusive, aggs, naggs, outs, 0, plan.W, &n_long, &ms));
@@ -817,7 +845,7 @@ int bowgpu_shard_aggregate(const bowgpu_col *cols, int32_t ncols, int32_t ts_col
     if (lead < 0 || (wf < 0 && lead != 0) || (wf >= 0 && lead > wf)) return fail(BOWGPU_ERR_ARG, "bad lead_empty_windows %lld", (long long)lead);
     const int64_t Wtot = plan.W + lead;
     BG_TRY(job_build(c, cols, ncols, ts_col, plan, 0, aggs, naggs, outs, wf < 0 ? 0 : wf - lead, Wtot, holds_global_row0 != 0, &job));
-    BG_TRY(job_run(c, &job, aggs, naggs, nullptr, nullptr));
+    BG_TRY(job_run(c, &job, aggs, naggs, nullptr, nullptr, false));
     if (lead > 0) BG_TRY(launch_fill_empty(c, job.P, 0, lead));
     if (plan.W > 0) {
         // running state of the last window over this shard's rows

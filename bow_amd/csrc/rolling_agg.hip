@@ -552,7 +552,13 @@ __global__ __launch_bounds__(256) void popcount_kernel(const uint32_t *words, in
         acc += __popc(x);
     }
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
-    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
+    __shared__ unsigned long long part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long t = part[0] + part[1] + part[2] + part[3];
+        if (t) atomicAdd(out, t);
+    }
 }
 
 int launch_rolling_aggregate(Ctx *c, const AggParams &p) {
@@ -589,7 +595,7 @@ int launch_popcount(Ctx *c, const uint32_t *words, int64_t bit0, int64_t nbits, 
     if (nbits <= 0) return 0;
     const int64_t nwords = (nbits + 63) / 32;
     int64_t grid = (nwords + 255) / 256;
-    if (grid > 2048) grid = 2048;
+    if (grid > 512) grid = 512;
     hipLaunchKernelGGL(popcount_kernel, dim3((unsigned)grid), dim3(256), 0, c->stream, words, bit0, nbits,
                        reinterpret_cast<unsigned long long *>(d_count));
     BG_HIP(hipGetLastError());

@@ -233,14 +233,14 @@ class GpuProvider:
 class ShardedRolling:
     """bench.py's multi-GPU step: dense synthetic rows generated in this rank's HBM."""
 
-    def __init__(self, rank, world, rows, interval, aggs, dist, torch, seed=42, exchange_device="cuda"):
+    def __init__(self, rank, world, rows, interval, aggs, dist, torch, seed=42, offset=0, exchange_device="cuda"):
         from . import capi
         self.rank, self.world, self.interval, self.aggs = rank, world, interval, aggs
         self.dist, self.torch = dist, torch
         ts, val = capi.gen_dense(rank * rows, rows, seed=seed)
         self.cols = [ts, val]
         cap = rows // interval + 3
-        self.provider = GpuProvider(self.cols, 0, interval, aggs, out_capacity=cap)
+        self.provider = GpuProvider(self.cols, 0, interval, aggs, offset=offset, out_capacity=cap)
         self.device = torch.device("cuda", torch.cuda.current_device()) if (world > 1 and exchange_device == "cuda") else "cpu"
         self.kernel_timer = capi.Timer()
 
