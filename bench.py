@@ -53,6 +53,25 @@ def cpu_baseline(capi, rows_sample):
                       "reference's time), %.1f s" % (reps, rows_sample, INTERVAL, dt)}
 
 
+def measured_traffic(rows):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r*_pmc_hbm_traffic_bench_1e9.csv: FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, in KB), when they were
+    collected for this row count; None otherwise (PMC cannot be collected from inside the timed run)."""
+    import csv
+    import glob
+    if rows != 1_000_000_000:
+        return None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic_bench_1e9.csv")))
+    if not files:
+        return None
+    f, w = [], []
+    for r in csv.DictReader(open(files[-1])):
+        (f if r["counter"] == "FETCH_SIZE" else w).append(float(r["value_KB"]))
+    if not f or not w:
+        return None
+    return (2.0 * sum(f) / len(f) + sum(w) / len(w)) * 1024.0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -154,6 +173,7 @@ def main():
                          "algorithmic_bytes_per_launch": rows * BYTES_PER_ROW},
             "device": capi.device_name(),
         }
+        line["roofline"]["traffic"] = measured_traffic(rows)
         if not args.no_cpu and world == 1:
             try:
                 line["cpu_baseline"] = cpu_baseline(capi, min(args.cpu_sample, rows))

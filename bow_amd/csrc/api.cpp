@@ -94,6 +94,19 @@ int ctx_params(Ctx *c, void **dptr) {
     return 0;
 }
 
+int ctx_pool(Ctx *c, int slot, size_t bytes, void **dptr) {
+    if (slot < 0 || slot >= Ctx::kPoolSlots) return fail(BOWGPU_ERR_ARG, "bad pool slot");
+    if (c->pool_bytes[slot] < bytes) {
+        if (c->pool[slot]) (void)hipFree(c->pool[slot]);
+        c->pool[slot] = nullptr;
+        c->pool_bytes[slot] = 0;
+        BG_HIP(hipMalloc(&c->pool[slot], bytes));
+        c->pool_bytes[slot] = bytes;
+    }
+    *dptr = c->pool[slot];
+    return 0;
+}
+
 int DevBuf::alloc(size_t n) {
     if (p) { (void)hipFree(p); p = nullptr; }
     bytes = n;
@@ -201,7 +214,7 @@ int devcol_prepare(Ctx *c, const bowgpu_col *col, DevCol *out, bool need_values,
     return 0;
 }
 
-int devout_prepare(Ctx *c, bowgpu_out *out, int64_t slots, DevOut *d) {
+int devout_prepare(Ctx *c, bowgpu_out *out, int64_t slots, DevOut *d, int pool_slot) {
     d->user = out;
     d->capacity = slots;
     if (out->length < slots) return fail(BOWGPU_ERR_ARG, "output column has %lld slots, %lld needed", (long long)out->length, (long long)slots);
@@ -213,8 +226,15 @@ int devout_prepare(Ctx *c, bowgpu_out *out, int64_t slots, DevOut *d) {
         d->values = out->values;
         // The kernels update validity as 32-bit words; a caller buffer of exactly ceil(W/8) bytes may end
         // mid-word, so always assemble in an aligned temporary and copy the exact byte count back.
-        BG_TRY(d->own_validity.alloc(((vb + 3) & ~(size_t)3) + 4));
-        d->validity = reinterpret_cast<uint8_t *>(d->own_validity.p);
+        if (pool_slot >= 0) {
+            void *pp;
+            BG_TRY(ctx_pool(c, pool_slot, ((vb + 3) & ~(size_t)3) + 4, &pp));
+            d->validity = reinterpret_cast<uint8_t *>(pp);
+            d->pool_slot = pool_slot;
+        } else {
+            BG_TRY(d->own_validity.alloc(((vb + 3) & ~(size_t)3) + 4));
+            d->validity = reinterpret_cast<uint8_t *>(d->own_validity.p);
+        }
     } else {
         BG_TRY(d->own_values.alloc((size_t)slots * 8));
         BG_TRY(d->own_validity.alloc(((vb + 3) & ~(size_t)3) + 4));
@@ -473,7 +493,7 @@ static int job_build(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t ts_c
         a.out_type = t;
         a.n_factors = aggs[i].n_factors;
         for (int f = 0; f < a.n_factors; f++) a.factors[f] = aggs[i].factors[f];
-        BG_TRY(devout_prepare(c, &outs[i], W, &job->douts[i]));
+        BG_TRY(devout_prepare(c, &outs[i], W, &job->douts[i], i));
         a.out_values = job->douts[i].values;
         a.out_valid = kind_never_nil(aggs[i].kind) ? nullptr : reinterpret_cast<uint32_t *>(job->douts[i].validity);
     }
@@ -610,6 +630,7 @@ int bowgpu_set_device(int device) {
         (void)hipSetDevice(c->device);
         if (c->d_scratch) (void)hipFree(c->d_scratch);
         if (c->d_params) (void)hipFree(c->d_params);
+        for (int i = 0; i < Ctx::kPoolSlots; i++) if (c->pool[i]) (void)hipFree(c->pool[i]);
         if (c->h_pinned) (void)hipHostFree(c->h_pinned);
         if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
         if (c->ev0) (void)hipEventDestroy(c->ev0);

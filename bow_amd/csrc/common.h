@@ -41,12 +41,18 @@ struct Ctx {
     size_t h_pinned_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double last_kernel_ms = 0.0;
+    // grow-only pool of temporaries reused across calls (word-aligned validity working copies, ...):
+    // hipMalloc / hipFree per call cost more than the kernels' fixed overhead
+    static constexpr int kPoolSlots = 40;
+    void *pool[kPoolSlots] = {};
+    size_t pool_bytes[kPoolSlots] = {};
     void *d_params = nullptr;      // 4 KB device block holding the kernels' descriptor struct
 };
 int ctx_get(Ctx **out);                       // initialises HIP on first use; fails loudly without a GPU
 int ctx_scratch(Ctx *c, size_t bytes, void **dptr);
 int ctx_pinned(Ctx *c, size_t bytes, void **hptr);
 int ctx_params(Ctx *c, void **dptr);
+int ctx_pool(Ctx *c, int slot, size_t bytes, void **dptr);
 
 // ---------------------------------------------------------------- temp device buffers
 // RAII device allocation (stream-ordered free at scope exit after a sync by the caller).
@@ -87,10 +93,11 @@ struct DevOut {
     void *values = nullptr;
     uint8_t *validity = nullptr;
     int64_t capacity = 0;
+    int pool_slot = -1;   // >= 0: the validity working copy comes from the context pool
     DevBuf own_values, own_validity;
     bowgpu_out *user = nullptr;
 };
-int devout_prepare(Ctx *c, bowgpu_out *out, int64_t slots, DevOut *d);
+int devout_prepare(Ctx *c, bowgpu_out *out, int64_t slots, DevOut *d, int pool_slot = -1);
 int devout_finish(Ctx *c, DevOut *d, int64_t slots, int32_t type, int64_t null_count);
 
 // ---------------------------------------------------------------- division by the interval
