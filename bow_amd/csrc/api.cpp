@@ -450,6 +450,7 @@ static int job_build(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t ts_c
     P.inclusive = inclusive;
     P.naggs = naggs;
     P.pre_rows = (n > 0 && holds_row0 && plan.s0 > plan.first_ts) ? 1 : 0;
+    if (const char *e = getenv("BOWGPU_DBG_STOP")) P.dbg_stop = atoi(e);
 
     // column slots: each distinct input column whose values some reducer reads
     std::vector<int> nullable_in_slot;
@@ -498,6 +499,29 @@ static int job_build(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t ts_c
         a.out_valid = kind_never_nil(aggs[i].kind) ? nullptr : reinterpret_cast<uint32_t *>(job->douts[i].validity);
     }
 
+    // per-pass summaries
+    P.first_pass_slot = kMaxCols;
+    P.last_val_slot = -1;
+    for (int i = 0; i < naggs; i++) {
+        const AggDesc &d = P.aggs[i];
+        const int k = d.kind;
+        const int idx = d.slot + 1;
+        P.pass_mask[idx] |= 1u << i;
+        uint32_t fl = 0;
+        if (kind_reads_values(k)) fl |= kPassNeedVals;
+        if (k == BOWGPU_AGG_MIN || k == BOWGPU_AGG_MAX) fl |= kPassMinMax;
+        if (k == BOWGPU_AGG_FIRST || k == BOWGPU_AGG_LAST) fl |= kPassFirstLast;
+        if (d.out_valid) fl |= kPassNullable;
+        P.pass_flags[idx] |= fl;
+        if (d.slot < P.first_pass_slot) P.first_pass_slot = d.slot;
+        if (kind_reads_values(k) && d.slot > P.last_val_slot) P.last_val_slot = d.slot;
+    }
+    for (int s = 0; s <= kMaxCols; s++) {
+        int nn = 0;
+        for (int i = 0; i < naggs; i++) if ((P.pass_mask[s] >> i) & 1u) nn += P.aggs[i].out_valid != nullptr;
+        if (nn > P.n_nullable_max) P.n_nullable_max = nn;
+    }
+
     // status words + long-window list
     const int64_t ntiles = (n + 511) / 512;  // the lean kernel's tile (one wavefront); at most one long window per tile
     job->scratch_bytes = 8192 + (size_t)(ntiles + 1) * 16;
@@ -529,41 +553,111 @@ static int job_enqueue_tail(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t
     return 0;
 }
 
-static int job_run(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, int64_t *long_windows, double *kernel_ms,
-                   bool finish) {
+// Can the stripped-down kernel of rolling_simple.hip take this call?  (one null-free, 16-B aligned value column, at most
+// 4 factor-free outputs, exclusive windows, the whole interval column within 2^32 of s0, not a shard)
+static bool simple_applies(const AggJob *job, const bowgpu_agg *aggs, int32_t naggs, const Plan &plan, int *need, bool *is_int) {
+    const AggParams &P = job->P;
+    if (job->inclusive || P.pre_rows || P.wid_base != 0 || !P.fits32 || naggs > 4 || P.ncols > 1) return false;
+    if (P.W <= 0 || P.W >= 0xFFFFFFF0ll) return false;
+    if ((uint64_t)plan.last_ts - (uint64_t)plan.s0 >= 0xFFFFFFF0ull) return false;
+    if (reinterpret_cast<uintptr_t>(P.ts) & 15) return false;
+    *need = 0;
+    *is_int = false;
+    const void *vals = P.ts;
+    if (P.ncols == 1) {
+        if (P.cols[0].vbits != nullptr || (reinterpret_cast<uintptr_t>(P.cols[0].values) & 15)) return false;
+        vals = P.cols[0].values;
+        *is_int = P.cols[0].type == BOWGPU_INT64;
+    }
+    (void)vals;
+    for (int i = 0; i < naggs; i++) {
+        const int k = aggs[i].kind;
+        if (aggs[i].n_factors != 0) return false;
+        if (k >= BOWGPU_AGG_INTEGRAL_STEP && k <= BOWGPU_AGG_WAVG_LINEAR) return false;
+        if (k == BOWGPU_AGG_MIN || k == BOWGPU_AGG_MAX) *need |= 1;
+        if (k == BOWGPU_AGG_FIRST || k == BOWGPU_AGG_LAST) *need |= 2;
+    }
+    const char *off = getenv("BOWGPU_NO_SIMPLE");
+    if (off && off[0] == '1') return false;
+    return true;
+}
+
+static int job_launch_tiles(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, const Plan *plan, bool allow_simple,
+                            bool *used_simple) {
     AggParams &P = job->P;
     const int64_t W = job->W;
+    *used_simple = false;
     BG_HIP(hipMemsetAsync(P.status, 0, 64, c->stream));
-    if (W > 0) {
-        for (int i = 0; i < naggs; i++) {
-            const size_t vb = (size_t)((W + 7) >> 3);
-            // never-nil reducers: all-ones bitmap (tail bits cleared); nullable ones start all-null (bowbuffer.go:25)
-            BG_HIP(hipMemsetAsync(job->douts[i].validity, kind_never_nil(aggs[i].kind) ? 0xFF : 0x00, ((vb + 3) & ~(size_t)3), c->stream));
-            if (kind_never_nil(aggs[i].kind)) BG_TRY(launch_fix_tail_bits(c, job->douts[i].validity, W));
-        }
-        // The lean kernel covers exclusive windows without time-weighted reducers and without rows below
-        // s0; everything else (and BOWGPU_FORCE_GENERAL=1, used by the tests to cover both) takes the
-        // general kernel.  Both are HIP; results are identical where both apply.
-        bool lean = !job->inclusive && !P.pre_rows;
-        for (int i = 0; i < naggs; i++)
-            if (aggs[i].kind >= BOWGPU_AGG_INTEGRAL_STEP && aggs[i].kind <= BOWGPU_AGG_WAVG_LINEAR) lean = false;
-        const char *force = getenv("BOWGPU_FORCE_GENERAL");
-        if (force && force[0] == '1') lean = false;
-        // kernel_ms brackets the dominant kernel only, on the stream it runs on
-        BG_HIP(hipEventRecord(c->ev0, c->stream));
-        if (lean) BG_TRY(launch_rolling_fast(c, P));
-        else BG_TRY(launch_rolling_aggregate(c, P));
-        BG_HIP(hipEventRecord(c->ev1, c->stream));
+    if (W <= 0) return 0;
+    // The lean kernels cover exclusive windows without time-weighted reducers and without rows below s0; everything
+    // else (and BOWGPU_FORCE_GENERAL=1, used by the tests to cover all of them) takes the general kernel.
+    bool lean = !job->inclusive && !P.pre_rows;
+    for (int i = 0; i < naggs; i++)
+        if (aggs[i].kind >= BOWGPU_AGG_INTEGRAL_STEP && aggs[i].kind <= BOWGPU_AGG_WAVG_LINEAR) lean = false;
+    const char *force = getenv("BOWGPU_FORCE_GENERAL");
+    if (force && force[0] == '1') lean = false;
+    int need = 0;
+    bool is_int = false;
+    const bool simple = lean && allow_simple && plan && simple_applies(job, aggs, naggs, *plan, &need, &is_int);
+    P.bits_preset = simple ? 1 : 0;
+    for (int i = 0; i < naggs; i++) {
+        const size_t vb = (size_t)((W + 7) >> 3);
+        // never-nil reducers: all-ones bitmap (tail bits cleared); nullable ones start all-null (bowbuffer.go:25) - except
+        // under the simple kernel, where every bitmap starts as ones and only empty windows are cleared
+        const bool ones = simple || kind_never_nil(aggs[i].kind);
+        BG_HIP(hipMemsetAsync(job->douts[i].validity, ones ? 0xFF : 0x00, ((vb + 3) & ~(size_t)3), c->stream));
+        if (ones) BG_TRY(launch_fix_tail_bits(c, job->douts[i].validity, W));
     }
+    // kernel_ms brackets the dominant kernel only, on the stream it runs on
+    BG_HIP(hipEventRecord(c->ev0, c->stream));
+    if (simple) {
+        SimpleParams S;
+        memset(&S, 0, sizeof S);
+        S.ts = P.ts;
+        S.values = P.ncols == 1 ? P.cols[0].values : P.ts;
+        S.n = P.n; S.s0 = P.s0; S.interval = P.interval; S.W = P.W;
+        S.m32 = P.m32; S.sh1 = P.sh1_32; S.sh2 = P.sh2_32;
+        S.naggs = naggs;
+        for (int i = 0; i < naggs; i++) {
+            S.kind[i] = aggs[i].kind;
+            S.out_values[i] = reinterpret_cast<uint64_t *>(P.aggs[i].out_values);
+            S.out_valid[i] = P.aggs[i].out_valid;
+        }
+        S.status = P.status; S.long_list = P.long_list; S.long_cap = P.long_cap;
+        BG_TRY(launch_rolling_simple(c, S, need, is_int));
+        *used_simple = true;
+    } else if (lean) {
+        BG_TRY(launch_rolling_fast(c, P));
+    } else {
+        BG_TRY(launch_rolling_aggregate(c, P));
+    }
+    BG_HIP(hipEventRecord(c->ev1, c->stream));
+    return 0;
+}
+
+static int job_run(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, int64_t *long_windows, double *kernel_ms,
+                   bool finish, const Plan *plan = nullptr) {
+    AggParams &P = job->P;
+    const int64_t W = job->W;
+    bool used_simple = false;
+    BG_TRY(job_launch_tiles(c, job, aggs, naggs, plan, true, &used_simple));
     // status -> host (pinned).  Optimistically enqueue the tail (null counts, copy-back) behind the tile kernel so
     // the common case needs ONE synchronisation; if windows were queued for the cooperative path, run it and redo the tail.
     uint32_t *hstat;
     BG_TRY(ctx_pinned(c, 4096, reinterpret_cast<void **>(&hstat)));
-    BG_HIP(hipMemcpyAsync(hstat, P.status, 16, hipMemcpyDeviceToHost, c->stream));
+    BG_HIP(hipMemcpyAsync(hstat, P.status, 32, hipMemcpyDeviceToHost, c->stream));
     uint64_t *hcnt = nullptr;
     if (finish) BG_TRY(job_enqueue_tail(c, job, aggs, naggs, &hcnt));
     BG_HIP(hipStreamSynchronize(c->stream));
     if (hstat[0]) return fail(BOWGPU_ERR_TS_UNSORTED, "interval column is not ascending: outside the device path");
+    if (used_simple && hstat[4]) {
+        // some tile needs window ids the simple kernel cannot encode: redo the call with the general lean kernel
+        BG_TRY(job_launch_tiles(c, job, aggs, naggs, plan, false, &used_simple));
+        BG_HIP(hipMemcpyAsync(hstat, P.status, 32, hipMemcpyDeviceToHost, c->stream));
+        if (finish) BG_TRY(job_enqueue_tail(c, job, aggs, naggs, &hcnt));
+        BG_HIP(hipStreamSynchronize(c->stream));
+        if (hstat[0]) return fail(BOWGPU_ERR_TS_UNSORTED, "interval column is not ascending: outside the device path");
+    }
     if (hstat[2]) return fail(BOWGPU_ERR_HIP, "internal: long-window list overflow");
     const int64_t n_long = hstat[1];
     if (n_long > 0) {
@@ -600,7 +694,7 @@ static int run_aggregate(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t 
                          int64_t wid_base, int64_t W, int64_t *long_windows, double *kernel_ms) {
     AggJob job;
     BG_TRY(job_build(c, cols, ncols, ts_col, plan, inclusive, aggs, naggs, outs, wid_base, W, wid_base == 0, &job));
-    BG_TRY(job_run(c, &job, aggs, naggs, long_windows, kernel_ms, true));
+    BG_TRY(job_run(c, &job, aggs, naggs, long_windows, kernel_ms, true, &plan));
     return 0;
 }
 

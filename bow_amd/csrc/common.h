@@ -146,6 +146,8 @@ struct ColDesc {
     int32_t need_ts;        // some reducer of this column integrates over time
 };
 
+enum : uint32_t { kPassNeedVals = 1, kPassMinMax = 2, kPassFirstLast = 4, kPassNullable = 8 };
+
 struct AggParams {
     const int64_t *ts;
     int64_t n;              // rows in this launch's column slice
@@ -160,14 +162,37 @@ struct AggParams {
     int32_t inclusive;      // effective Options.Inclusive
     int32_t ncols;
     int32_t naggs;
+    int32_t dbg_stop;       // profiling aid: leave the tile kernel after phase k (0 = off)
     int32_t pre_rows;       // s0 > ts[0] (negative ts + truncating division): rows below s0 ride in window 0
     ColDesc cols[kMaxCols];
     AggDesc aggs[kMaxAggs];
+    // per column-slot pass summary (index = slot + 1; index 0 is the "no column" pass), precomputed on the host so
+    // the kernels do not scan the aggregator list per tile
+    uint32_t pass_mask[kMaxCols + 1];   // bit a set: aggregator a belongs to this pass
+    uint32_t pass_flags[kMaxCols + 1];  // kPass* bits
+    int32_t first_pass_slot, last_val_slot, n_nullable_max;
+    int32_t bits_preset;    // output bitmaps start as all-ones (rolling_simple.hip): the long-window path clears empties instead of setting valids
     // status block in device memory
     uint32_t *status;       // [0]=unsorted flag, [1]=long-window count, [2]=overflow flag
     int64_t *long_list;     // pairs (global window id, first row)
     int64_t long_cap;
 };
+
+// descriptor of rolling_simple.hip's kernel: one null-free value column, <= 4 factor-free outputs, 32-bit window ids
+struct SimpleParams {
+    const int64_t *ts;
+    const void *values;
+    int64_t n, s0, interval, W;
+    uint32_t m32, sh1, sh2;
+    int32_t naggs;
+    int32_t kind[4];
+    uint64_t *out_values[4];
+    uint32_t *out_valid[4];   // nullptr for never-nil reducers; all bitmaps are preset to ones by the host
+    uint32_t *status;         // [0] unsorted, [1] long-window count, [2] list overflow, [4] redo with the general lean kernel
+    int64_t *long_list;
+    int64_t long_cap;
+};
+int launch_rolling_simple(Ctx *c, const SimpleParams &p, int need, bool is_int);
 
 int launch_rolling_aggregate(Ctx *c, const AggParams &p);   // general kernel (rolling_agg.hip)
 int launch_rolling_fast(Ctx *c, const AggParams &p);        // lean kernel for exclusive windows without time-weighted reducers (rolling_fast.hip)

@@ -510,7 +510,10 @@ __global__ __launch_bounds__(kBlock) void long_window_kernel(const AggParams p, 
                                            win_start, p.interval, col_type == BOWGPU_INT64);
                         v = finish_val(v, a);
                         reinterpret_cast<uint64_t *>(a.out_values)[oslot] = v.bits;
-                        if (a.out_valid && v.valid) atomicOr(&a.out_valid[oslot >> 5], 1u << (oslot & 31));
+                        if (a.out_valid) {
+                            if (v.valid) atomicOr(&a.out_valid[oslot >> 5], 1u << (oslot & 31));
+                            else if (p.bits_preset) atomicAnd(&a.out_valid[oslot >> 5], ~(1u << (oslot & 31)));
+                        }
                     }
                 }
             }
@@ -526,6 +529,7 @@ __global__ __launch_bounds__(kBlock) void long_window_kernel(const AggParams p, 
                     const AggDesc &a = p.aggs[__ffs(m) - 1];
                     Val v = finish_val(reduce_val(a.kind, em, 0, gstart, p.interval, col_type == BOWGPU_INT64), a);
                     reinterpret_cast<uint64_t *>(a.out_values)[gs] = v.bits;
+                    if (p.bits_preset && a.out_valid && !v.valid) atomicAnd(&a.out_valid[gs >> 5], ~(1u << (gs & 31)));
                 }
             }
         }

@@ -23,6 +23,8 @@
 //
 // HBM-bound: algorithmic bytes = 8 (ts) + 8 per value column (+1/8 per nullable column) per row.
 
+#include <stdlib.h>
+
 #include "agg_device.h"
 
 namespace bowgpu {
@@ -42,8 +44,7 @@ constexpr uint32_t kSat16 = 0xFFFFu;
 
 struct WaveShared {
     uint64_t val[kRowsW];
-    uint16_t seg_row[kRowsW + 2];   // local head rows, in row order
-    uint16_t seg_lw[kRowsW + 2];    // window id - w0 (kSat16 => recompute from ts)
+    uint32_t seg[kRowsW + 2];       // heads in row order: local row | (window id - w0) << 16 (0xFFFF => recompute from ts)
     uint32_t vbits[kRowsW / 32 + 2];
     uint32_t obits[kMaxNullableW][kSpanWordsW + 1];
 };
@@ -68,9 +69,14 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t x, int l) {
     return ((uint64_t)hi << 32) | lo;
 }
 
-// One wave only: LDS operations of a wave retire in order, so a write phase followed by reads from
-// other lanes needs no s_barrier - only that the compiler keeps the order (workgroup == this wave).
-__device__ __forceinline__ void wave_lds_fence() { __syncthreads(); }
+// One wave only: LDS operations of a wave execute in order, so a write phase followed by reads from
+// other lanes needs neither s_barrier nor a wait - only that the compiler keeps the program order.
+// (__syncthreads() would also drain vmcnt(0), i.e. the next tile's prefetch.)
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // ---- the walk of one window, specialised at compile time
 template <bool kNulls, bool kInt, bool kMinMax, bool kFirstLast>
@@ -80,7 +86,21 @@ __device__ __forceinline__ void walk(const WaveShared &sh, int r0, int r1, Stats
         const uint64_t raw0 = sh.val[r0];
         double mn = kInt ? (double)(int64_t)raw0 : __longlong_as_double((long long)raw0);
         double mx = mn;
-        for (int r = r0; r < r1; r++) {
+        int r = r0;
+        for (; r + 1 < r1; r += 2) {  // two LDS values per round trip; the two adds keep the row order
+            const uint64_t rawa = sh.val[r], rawb = sh.val[r + 1];
+            const double xa = kInt ? (double)(int64_t)rawa : __longlong_as_double((long long)rawa);
+            const double xb = kInt ? (double)(int64_t)rawb : __longlong_as_double((long long)rawb);
+            sum += xa;
+            sum += xb;
+            if (kMinMax) {
+                if (xa < mn) mn = xa;
+                if (xa > mx) mx = xa;
+                if (xb < mn) mn = xb;
+                if (xb > mx) mx = xb;
+            }
+        }
+        if (r < r1) {
             const uint64_t raw = sh.val[r];
             const double x = kInt ? (double)(int64_t)raw : __longlong_as_double((long long)raw);
             sum += x;
@@ -130,50 +150,78 @@ __device__ __forceinline__ void walk_dispatch(int variant, const WaveShared &sh,
 
 }  // namespace
 
-__global__ __launch_bounds__(kWave, 5) void rolling_wave_kernel(const AggParams p, const int64_t ntiles,
-                                                                const int64_t tiles_per_xcd) {
+// kPersist: the wave walks tiles t0, t0 + stride, ... and keeps the NEXT tile's global loads in flight while it
+// reduces the current one (the registers of the current tile's ts / values are dead by then), so it never sits
+// idle on HBM latency while holding its LDS.
+template <bool kPersist>
+__global__ __launch_bounds__(kWave, kPersist ? 4 : 5) void rolling_wave_kernel(const AggParams p, const int64_t ntiles,
+                                                                               const int64_t tiles_per_xcd) {
     __shared__ WaveShared sh;
 
     // XCD-aware tile mapping: workgroups are dealt round-robin over the 8 XCDs, so give every XCD a
     // contiguous run of tiles (a tile's look-ahead rows are its right neighbour's first rows: same L2).
     const int64_t b = blockIdx.x;
-    const int64_t tile = (b & 7) * tiles_per_xcd + (b >> 3);
-    if (tile >= ntiles) return;
+    const int64_t xcd_lo = (b & 7) * tiles_per_xcd;
+    int64_t xcd_hi = xcd_lo + tiles_per_xcd;
+    if (xcd_hi > ntiles) xcd_hi = ntiles;
+    const int64_t t_step = kPersist ? (int64_t)(gridDim.x >> 3) : tiles_per_xcd;
+    int64_t tile = xcd_lo + (b >> 3);
+    if (tile >= xcd_hi) return;
 
     const int lane = threadIdx.x;
-    const int64_t base = tile * kTileW;
     const int64_t n = p.n;
-    const int nloc = (int)((n - base) < kRowsW ? (n - base) : kRowsW);  // rows of this tile(+halo) that exist
     const uint64_t *__restrict__ ts = reinterpret_cast<const uint64_t *>(p.ts);
     const bool ts_vec = (reinterpret_cast<uintptr_t>(ts) & 15) == 0;
+    const uint64_t *__restrict__ vp0 = p.ncols > 0 ? reinterpret_cast<const uint64_t *>(p.cols[0].values) : nullptr;
+    const bool v0_vec = (reinterpret_cast<uintptr_t>(vp0) & 15) == 0;
+    const int last_val_slot = p.last_val_slot;  // the last column slot whose values get staged (the next tile's value prefetch follows it)
+
+    uint64_t ta[kChunksW], tb[kChunksW];
+    uint64_t va[kChunksW], vb[kChunksW];
+    auto is_interior = [&](int64_t t) { return (t * kTileW + kRowsW <= n) && ts_vec && v0_vec; };
+    auto load_ts = [&](int64_t t, bool inter) {
+        const int64_t b0 = t * kTileW;
+        if (inter) {
+            const ulonglong2 *tp = reinterpret_cast<const ulonglong2 *>(ts + b0) + lane;
+#pragma unroll
+            for (int j = 0; j < kChunksW; j++) { const ulonglong2 x = tp[j * 64]; ta[j] = x.x; tb[j] = x.y; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < kChunksW; j++) load_pair(ts, b0 + j * 128 + 2 * lane, n, ts_vec, ta[j], tb[j]);
+        }
+    };
+    auto load_v0 = [&](int64_t t, bool inter) {
+        if (vp0 == nullptr) return;
+        const int64_t b0 = t * kTileW;
+        if (inter) {
+            const ulonglong2 *vq = reinterpret_cast<const ulonglong2 *>(vp0 + b0) + lane;
+#pragma unroll
+            for (int j = 0; j < kChunksW; j++) { const ulonglong2 x = vq[j * 64]; va[j] = x.x; vb[j] = x.y; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < kChunksW; j++) load_pair(vp0, b0 + j * 128 + 2 * lane, n, v0_vec, va[j], vb[j]);
+        }
+    };
 
     // ---- 1. loads: ts, then the first value column right behind it.  Interior tiles (all rows exist,
     // 16-B aligned columns) take straight-line 16-B/lane loads; only the last tile / odd offsets are guarded.
-    uint64_t ta[kChunksW], tb[kChunksW];
-    uint64_t va[kChunksW], vb[kChunksW];
-    const uint64_t *__restrict__ vp0 = p.ncols > 0 ? reinterpret_cast<const uint64_t *>(p.cols[0].values) : nullptr;
-    const bool v0_vec = (reinterpret_cast<uintptr_t>(vp0) & 15) == 0;
-    const bool interior = (base + kRowsW <= n) && ts_vec && v0_vec;  // wave-uniform
-    int staged_slot = -1;
-    if (interior) {
-        const ulonglong2 *tp = reinterpret_cast<const ulonglong2 *>(ts + base) + lane;
-#pragma unroll
-        for (int j = 0; j < kChunksW; j++) { const ulonglong2 t = tp[j * 64]; ta[j] = t.x; tb[j] = t.y; }
-        if (vp0 != nullptr) {
-            const ulonglong2 *vq = reinterpret_cast<const ulonglong2 *>(vp0 + base) + lane;
-#pragma unroll
-            for (int j = 0; j < kChunksW; j++) { const ulonglong2 t = vq[j * 64]; va[j] = t.x; vb[j] = t.y; }
-            staged_slot = 0;
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < kChunksW; j++) load_pair(ts, base + j * 128 + 2 * lane, n, ts_vec, ta[j], tb[j]);
-        if (vp0 != nullptr) {
-#pragma unroll
-            for (int j = 0; j < kChunksW; j++) load_pair(vp0, base + j * 128 + 2 * lane, n, v0_vec, va[j], vb[j]);
-            staged_slot = 0;
-        }
-    }
+    bool interior = is_interior(tile);
+    load_ts(tile, interior);
+    load_v0(tile, interior);
+    bool ts_prefetched = true, v0_prefetched = true;
+
+  for (; tile < xcd_hi; tile += t_step) {
+    const int64_t base = tile * kTileW;
+    const int nloc = (int)((n - base) < kRowsW ? (n - base) : kRowsW);  // rows of this tile(+halo) that exist
+    interior = is_interior(tile);
+    if (!ts_prefetched) load_ts(tile, interior);
+    if (!v0_prefetched) load_v0(tile, interior);
+    int staged_slot = vp0 != nullptr ? 0 : -1;
+    // the next tile of this wave (persistent variant): prefetched only through the straight-line path
+    const int64_t next_tile = tile + t_step;
+    const bool prefetch_next = kPersist && next_tile < xcd_hi && is_interior(next_tile);
+    ts_prefetched = prefetch_next;
+    v0_prefetched = prefetch_next;
     // the row left of the tile and the tile's last row (scalar loads): first head flag, order check, ts span
     const int64_t left0 = base > 0 ? p.ts[base - 1] : INT64_MIN;
     const int64_t ts_last = p.ts[base + nloc - 1];
@@ -184,10 +232,30 @@ __global__ __launch_bounds__(kWave, 5) void rolling_wave_kernel(const AggParams 
     const int64_t ws0 = p.s0 + (int64_t)(w0 * (uint64_t)p.interval);
     const bool fast32 = p.fits32 && ts_last >= ts_first && (uint64_t)(ts_last - ws0) < 0xFFFFFFF0ull;
 
+    if (p.dbg_stop == 1) { if (lane == 0 && fast32) atomicOr(&p.status[3], (unsigned)ta[0] & 1u); return; }
+    if (p.dbg_stop == 6) {  // streaming floor of this launch geometry: consume the loads, nothing else
+        uint64_t x = 0;
+#pragma unroll
+        for (int j = 0; j < kChunksW; j++) x ^= ta[j] ^ tb[j] ^ va[j] ^ vb[j];
+        if (x == 0x1234567887654321ull) atomicOr(&p.status[3], 1u);
+        if (!kPersist) return;
+        if (prefetch_next) { load_ts(next_tile, true); load_v0(next_tile, true); }
+        continue;
+    }
     // ---- 2. local window ids, head flags, compaction (chunks are consecutive: running scalar count)
     bool unsorted = false;
     int nseg_total = 0, nseg_owned = 0;
     int64_t left_ts = left0;
+    // window of the row left of the current chunk: from the scalar unit for chunk 0, then lane 63 of the previous chunk
+    const uint32_t base_lo = (uint32_t)ws0;
+    uint32_t left_lw = 0xFFFFFFFEu;  // an id no row of the tile has: the first row of the frame, or a left row in an earlier window
+    uint64_t left_w = ~0ull;
+    if (left0 != INT64_MIN) {
+        if (fast32) { if (left0 >= ws0) left_lw = magic_div32((uint32_t)left0 - base_lo, p.m32, p.sh1_32, p.sh2_32); }
+        else left_w = magic_div((uint64_t)left0 - (uint64_t)p.s0, p.magic);
+    }
+    // no local window id saturates its 16-bit slot => wid = w0 + id without a per-lane fallback test
+    const bool no_sat = fast32 && magic_div32((uint32_t)ts_last - base_lo, p.m32, p.sh1_32, p.sh2_32) < kSat16;
 #pragma unroll
     for (int j = 0; j < kChunksW; j++) {
         const int l = j * 128 + 2 * lane;
@@ -199,23 +267,19 @@ __global__ __launch_bounds__(kWave, 5) void rolling_wave_kernel(const AggParams 
         bool ha, hb;
         uint32_t la, lb;
         if (fast32) {
-            const uint32_t base_lo = (uint32_t)ws0;
             la = magic_div32((uint32_t)tsa - base_lo, p.m32, p.sh1_32, p.sh2_32);
             lb = magic_div32((uint32_t)tsb - base_lo, p.m32, p.sh1_32, p.sh2_32);
-            // left neighbour's local window; a row left of the tile's first window gets an id no row of the tile has
-            const uint32_t left_lw = (left_ts != INT64_MIN && left_ts >= ws0)
-                                         ? magic_div32((uint32_t)left_ts - base_lo, p.m32, p.sh1_32, p.sh2_32)
-                                         : 0xFFFFFFFEu;
             const uint32_t lprev = from_left32(lb, left_lw);
             ha = pa && (la != lprev);
             hb = pb && (lb != la);
+            left_lw = (uint32_t)__builtin_amdgcn_readlane((int)lb, 63);
         } else {
             const uint64_t wa = magic_div((uint64_t)tsa - (uint64_t)p.s0, p.magic);
             const uint64_t wb = magic_div((uint64_t)tsb - (uint64_t)p.s0, p.magic);
-            const uint64_t left_w = left_ts != INT64_MIN ? magic_div((uint64_t)left_ts - (uint64_t)p.s0, p.magic) : ~0ull;
             const uint64_t wprev = from_left64(wb, left_w);
             ha = pa && (wa != wprev);
             hb = pb && (wb != wa);
+            left_w = readlane64(wb, 63);
             const uint64_t da = wa - w0, db = wb - w0;
             la = da >= kSat16 ? kSat16 : (uint32_t)da;
             lb = db >= kSat16 ? kSat16 : (uint32_t)db;
@@ -224,39 +288,35 @@ __global__ __launch_bounds__(kWave, 5) void rolling_wave_kernel(const AggParams 
         int pos = nseg_total;
         pos += __builtin_amdgcn_mbcnt_hi((unsigned)(ma >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ma, 0));
         pos += __builtin_amdgcn_mbcnt_hi((unsigned)(mb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb, 0));
-        if (ha) { sh.seg_row[pos] = (uint16_t)l; sh.seg_lw[pos] = (uint16_t)(la >= kSat16 ? kSat16 : la); pos++; }
-        if (hb) { sh.seg_row[pos] = (uint16_t)(l + 1); sh.seg_lw[pos] = (uint16_t)(lb >= kSat16 ? kSat16 : lb); }
+        if (ha) { sh.seg[pos] = (uint32_t)l | ((la >= kSat16 ? kSat16 : la) << 16); pos++; }
+        if (hb) { sh.seg[pos] = (uint32_t)(l + 1) | ((lb >= kSat16 ? kSat16 : lb) << 16); }
         nseg_total += __popcll(ma) + __popcll(mb);
         if (j == kChunksW - 2) nseg_owned = nseg_total;  // heads inside the 512 owned rows
         left_ts = (int64_t)readlane64(tb[j], 63);         // last row of this chunk = left neighbour of the next
     }
     if (unsorted) atomicOr(&p.status[0], 1u);
+    if (p.dbg_stop == 2) { if (lane == 0) atomicOr(&p.status[3], (unsigned)nseg_total & 1u); return; }
+    if (prefetch_next) load_ts(next_tile, true);  // this tile's ts registers are dead
 
     const bool reaches_end = base + kRowsW >= n;
     const int64_t wid_end = p.wid_base + p.W;
 
-    auto wid_at = [&](int q) -> uint64_t {
-        const uint32_t d = sh.seg_lw[q];
-        if (d != kSat16) return w0 + d;
-        const int64_t t = p.ts[base + sh.seg_row[q]];
+    auto wid_of = [&](uint32_t e) -> uint64_t {
+        const uint32_t d = e >> 16;
+        if (no_sat || d != kSat16) return w0 + d;
+        const int64_t t = p.ts[base + (e & 0xFFFFu)];
         return magic_div((uint64_t)t - (uint64_t)p.s0, p.magic);
     };
+    auto wid_at = [&](int q) -> uint64_t { return wid_of(sh.seg[q]); };
 
     // ---- 3./4. one pass per column slot
     bool first_pass = true;
-    for (int slot = -1; slot < p.ncols; slot++) {
-        unsigned my_mask = 0;
-        bool any_nullable = false, need_vals = false, need_mm = false, need_fl = false;
-        for (int a = 0; a < p.naggs; a++) {
-            if (p.aggs[a].slot != slot) continue;
-            my_mask |= 1u << a;
-            any_nullable |= (p.aggs[a].out_valid != nullptr);
-            const int k = p.aggs[a].kind;
-            need_vals |= !(k == BOWGPU_AGG_WINDOW_START || k == BOWGPU_AGG_NUM_ROWS);
-            need_mm |= (k == BOWGPU_AGG_MIN || k == BOWGPU_AGG_MAX);
-            need_fl |= (k == BOWGPU_AGG_FIRST || k == BOWGPU_AGG_LAST);
-        }
+    for (int slot = p.first_pass_slot; slot < p.ncols; slot++) {
+        const unsigned my_mask = p.pass_mask[slot + 1];
         if (my_mask == 0) continue;
+        const unsigned pfl = p.pass_flags[slot + 1];
+        const bool any_nullable = pfl & kPassNullable, need_vals = pfl & kPassNeedVals;
+        const bool need_mm = pfl & kPassMinMax, need_fl = pfl & kPassFirstLast;
 
         const ColDesc *cd = slot >= 0 ? &p.cols[slot] : nullptr;
         const bool has_nulls = cd && cd->vbits != nullptr;
@@ -282,24 +342,29 @@ __global__ __launch_bounds__(kWave, 5) void rolling_wave_kernel(const AggParams 
                 *reinterpret_cast<ulonglong2 *>(&sh.val[j * 128 + 2 * lane]) = make_ulonglong2(va[j], vb[j]);
             staged_slot = -2;
             if (has_nulls && lane < kRowsW / 32) sh.vbits[lane] = load_vbits32(*cd, base + 32 * (int64_t)lane);
+            if (prefetch_next && slot == last_val_slot) load_v0(next_tile, true);  // the value registers are dead
         }
-        if (any_nullable)
-            for (int i = lane; i < kMaxNullableW * (kSpanWordsW + 1); i += kWave) (&sh.obits[0][0])[i] = 0u;
+        if (any_nullable) {
+            (&sh.obits[0][0])[lane] = 0u;  // 4 x 19 words: two stores per lane at most
+            if (lane < kMaxNullableW * (kSpanWordsW + 1) - kWave) (&sh.obits[0][0])[kWave + lane] = 0u;
+        }
         wave_lds_fence();
 
+        if (p.dbg_stop == 3) return;
         const uint64_t wid_first = nseg_owned > 0 ? wid_at(0) : 0;
         const int64_t slot_first = (int64_t)(wid_first - (uint64_t)p.wid_base);
         const int64_t span0 = slot_first & ~(int64_t)31;
         bool any_big_gap = false;
 
         for (int q = lane; q < nseg_owned; q += kWave) {
-            const int r0 = sh.seg_row[q];
-            const uint64_t wid = wid_at(q);
+            const uint32_t e0 = sh.seg[q], e1 = sh.seg[q + 1];  // (one ds_read2_b32; entry q+1 is only used when it exists)
+            const int r0 = (int)(e0 & 0xFFFFu);
+            const uint64_t wid = wid_of(e0);
             int r1;
             uint64_t next_wid;
             if (q + 1 < nseg_total) {
-                r1 = sh.seg_row[q + 1];
-                next_wid = wid_at(q + 1);
+                r1 = (int)(e1 & 0xFFFFu);
+                next_wid = wid_of(e1);
             } else if (reaches_end) {
                 r1 = nloc;
                 next_wid = (uint64_t)wid_end;
@@ -319,6 +384,7 @@ __global__ __launch_bounds__(kWave, 5) void rolling_wave_kernel(const AggParams 
             Stats st;
             stats_init(st);
             if (need_vals) walk_dispatch(variant, sh, r0, r1, st);
+            if (p.dbg_stop == 4) { if (st.sum == 12345.678) atomicOr(&p.status[3], 1u); continue; }
             const int64_t win_start = p.s0 + (int64_t)(wid * (uint64_t)p.interval);
             const int64_t oslot = (int64_t)(wid - (uint64_t)p.wid_base);
             const int64_t nrows = r1 - r0;
@@ -358,6 +424,7 @@ __global__ __launch_bounds__(kWave, 5) void rolling_wave_kernel(const AggParams 
         }
         wave_lds_fence();
 
+        if (p.dbg_stop == 5) return;
         // ---- big gaps (sparse data): the whole wave writes the empty windows, coalesced
         if (__ballot(any_big_gap)) {
             for (int q = 0; q < nseg_owned; q++) {
@@ -414,15 +481,29 @@ __global__ __launch_bounds__(kWave, 5) void rolling_wave_kernel(const AggParams 
         }
         first_pass = false;
     }
+    if (prefetch_next && last_val_slot < 0) load_v0(next_tile, true);
+    wave_lds_fence();
+    if (!kPersist) break;  // one tile per wave: no loop for the compiler to carry registers around
+  }  // tiles of this wave
 }
 
 int launch_rolling_fast(Ctx *c, const AggParams &p) {
     if (p.n <= 0) return 0;
     const int64_t ntiles = (p.n + kTileW - 1) / kTileW;
     const int64_t per_xcd = (ntiles + 7) / 8;
-    const int64_t grid = per_xcd * 8;
-    if (grid > 0x7FFFFFFFll) return fail(BOWGPU_ERR_UNSUPPORTED, "too many rows for one launch: %lld", (long long)p.n);
-    hipLaunchKernelGGL(rolling_wave_kernel, dim3((unsigned)grid), dim3(kWave), 0, c->stream, p, ntiles, per_xcd);
+    int persist = 1;
+    if (const char *e = getenv("BOWGPU_FAST_PERSIST")) persist = atoi(e);
+    if (persist && ntiles >= 256 * 16 * 4) {
+        // 16 resident waves per CU, each walking its tiles with the next one prefetched
+        int waves = 16;
+        if (const char *e = getenv("BOWGPU_FAST_WAVES")) waves = atoi(e);
+        const int64_t grid = 256 * (int64_t)waves;
+        hipLaunchKernelGGL(rolling_wave_kernel<true>, dim3((unsigned)grid), dim3(kWave), 0, c->stream, p, ntiles, per_xcd);
+    } else {
+        const int64_t grid = per_xcd * 8;
+        if (grid > 0x7FFFFFFFll) return fail(BOWGPU_ERR_UNSUPPORTED, "too many rows for one launch: %lld", (long long)p.n);
+        hipLaunchKernelGGL(rolling_wave_kernel<false>, dim3((unsigned)grid), dim3(kWave), 0, c->stream, p, ntiles, per_xcd);
+    }
     BG_HIP(hipGetLastError());
     return 0;
 }

@@ -1,0 +1,228 @@
+// rolling_simple.hip — the tile kernel for the most common shape of Rolling.Aggregate, stripped of every
+// descriptor-driven branch:
+//   * ONE value column WITHOUT nulls (null_count == 0), Float64 or Int64, plus the interval column;
+//   * up to 4 outputs among WindowStart / Sum / ArithmeticMean / Min / Max / Count / First / Last / NumRows,
+//     no transformation factors, exclusive windows;
+//   * the whole interval column spans less than 2^32 and interval < 2^32, so window ids are 32-bit:
+//     wid = magic32((uint32)(ts - s0)) with no per-tile base.
+// (reference rolling/rolling.go:177-239 + rolling/aggregation.go:190-238 + the reducer closures of
+// rolling/aggregation/{windowstart,sum,arithmeticmean,minmax,count,firstlast}.go.)  Anything else takes
+// rolling_fast.hip / rolling_agg.hip; results are identical where several apply (tests run all of them).
+//
+// Because the value column has no nulls, every non-empty window yields a value: the host presets all output
+// validity bitmaps to ones and this kernel only CLEARS the bits of empty windows (gaps), which removes the
+// LDS bitmap assembly from the hot path.  Structure otherwise as rolling_fast.hip: one wavefront per tile of
+// 512 rows + 128 look-ahead rows, no barriers, heads -> LDS segment list -> one lane walks one window in
+// row order (reference summation order, bit-exact).
+#include "agg_device.h"
+
+namespace bowgpu {
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kTileS = 512;
+constexpr int kHaloS = 128;
+constexpr int kRowsS = kTileS + kHaloS;
+constexpr int kChunksS = kRowsS / 128;
+constexpr uint32_t kSatS = 0xFFFFu;
+
+struct SimpleShared {
+    uint64_t val[kRowsS];
+    uint32_t seg[kRowsS + 2];  // heads in row order: local row | (wid - wid of the tile's first row) << 16
+};
+
+__device__ __forceinline__ uint32_t mdiv32(uint32_t n, uint32_t m, uint32_t sh1, uint32_t sh2) {
+    const uint32_t t = __umulhi(m, n);
+    return (t + ((n - t) >> sh1)) >> sh2;
+}
+__device__ __forceinline__ uint32_t left32(uint32_t x, uint32_t lane0) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)lane0, (int)x, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+__device__ __forceinline__ void lds_order() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+}  // namespace
+
+// kNeed: bit0 min/max wanted, bit1 first/last wanted; kInt: Int64 value column
+template <int kNeed, bool kInt>
+__global__ __launch_bounds__(kWave, 5) void rolling_simple_kernel(const SimpleParams p, const int64_t ntiles,
+                                                                  const int64_t tiles_per_xcd) {
+    __shared__ SimpleShared sh;
+    const int64_t b = blockIdx.x;
+    const int64_t tile = (b & 7) * tiles_per_xcd + (b >> 3);  // XCD-contiguous tile runs (look-ahead rows hit the same L2)
+    if (tile >= ntiles) return;
+    const int lane = threadIdx.x;
+    const int64_t base = tile * kTileS;
+    const int64_t n = p.n;
+    const bool interior = base + kRowsS <= n;
+    const int nloc = interior ? kRowsS : (int)(n - base);
+
+    // ---- loads
+    uint64_t ta[kChunksS], tb[kChunksS], va[kChunksS], vb[kChunksS];
+    const uint64_t *__restrict__ ts = reinterpret_cast<const uint64_t *>(p.ts);
+    const uint64_t *__restrict__ vp = reinterpret_cast<const uint64_t *>(p.values);
+    if (interior) {
+        const ulonglong2 *tp = reinterpret_cast<const ulonglong2 *>(ts + base) + lane;
+        const ulonglong2 *vq = reinterpret_cast<const ulonglong2 *>(vp + base) + lane;
+#pragma unroll
+        for (int j = 0; j < kChunksS; j++) { const ulonglong2 x = tp[j * 64]; ta[j] = x.x; tb[j] = x.y; }
+#pragma unroll
+        for (int j = 0; j < kChunksS; j++) { const ulonglong2 x = vq[j * 64]; va[j] = x.x; vb[j] = x.y; }
+    } else {
+#pragma unroll
+        for (int j = 0; j < kChunksS; j++) load_pair(ts, base + j * 128 + 2 * lane, n, true, ta[j], tb[j]);
+#pragma unroll
+        for (int j = 0; j < kChunksS; j++) load_pair(vp, base + j * 128 + 2 * lane, n, true, va[j], vb[j]);
+    }
+    // the row left of the tile (scalar load): first head flag + order check
+    const int64_t left0 = base > 0 ? p.ts[base - 1] : INT64_MIN;
+    const uint32_t s0_lo = (uint32_t)p.s0;
+
+    // ---- window ids (32-bit, global), head flags, compaction with a running scalar count
+    const uint32_t w_first = mdiv32((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ta[0]) - s0_lo, p.m32, p.sh1, p.sh2);
+    uint32_t left_w = base > 0 ? mdiv32((uint32_t)left0 - s0_lo, p.m32, p.sh1, p.sh2) : 0xFFFFFFFEu;
+    int64_t left_ts = left0;
+    bool unsorted = false, sat = false;  // rows out of order ; a local window id that does not fit 16 bits
+    int nseg_total = 0, nseg_owned = 0;
+#pragma unroll
+    for (int j = 0; j < kChunksS; j++) {
+        const int l = j * 128 + 2 * lane;
+        const bool pa = l < nloc, pb = l + 1 < nloc;
+        const int64_t tsa = (int64_t)ta[j], tsb = (int64_t)tb[j];
+        const uint32_t plo = left32((uint32_t)tb[j], (uint32_t)left_ts);
+        const uint32_t phi = left32((uint32_t)(tb[j] >> 32), (uint32_t)((uint64_t)left_ts >> 32));
+        const int64_t prev_ts = (int64_t)(((uint64_t)phi << 32) | plo);
+        unsorted |= (pa && prev_ts > tsa) || (pb && tsa > tsb);
+        const uint32_t wa = mdiv32((uint32_t)tsa - s0_lo, p.m32, p.sh1, p.sh2);
+        const uint32_t wb = mdiv32((uint32_t)tsb - s0_lo, p.m32, p.sh1, p.sh2);
+        const uint32_t wprev = left32(wb, left_w);
+        const bool ha = pa && (wa != wprev);
+        const bool hb = pb && (wb != wa);
+        const uint32_t la = wa - w_first, lb = wb - w_first;
+        sat |= (ha && la >= kSatS) || (hb && lb >= kSatS);
+        const unsigned long long ma = __ballot(ha), mb = __ballot(hb);
+        int pos = nseg_total;
+        pos += __builtin_amdgcn_mbcnt_hi((unsigned)(ma >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ma, 0));
+        pos += __builtin_amdgcn_mbcnt_hi((unsigned)(mb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb, 0));
+        if (ha) { sh.seg[pos] = (uint32_t)l | (la << 16); pos++; }
+        if (hb) sh.seg[pos] = (uint32_t)(l + 1) | (lb << 16);
+        nseg_total += __popcll(ma) + __popcll(mb);
+        if (j == kChunksS - 2) nseg_owned = nseg_total;
+        left_w = (uint32_t)__builtin_amdgcn_readlane((int)wb, 63);
+        left_ts = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(tb[j] >> 32), 63) << 32) |
+                            (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)tb[j], 63));
+        // values of this chunk go to LDS now (their registers die here)
+        *reinterpret_cast<ulonglong2 *>(&sh.val[l]) = make_ulonglong2(va[j], vb[j]);
+    }
+    if (__ballot(unsorted)) {  // the call fails with BOWGPU_ERR_TS_UNSORTED
+        if (lane == 0) atomicOr(&p.status[0], 1u);
+        return;
+    }
+    if (__ballot(sat)) {  // a tile the 16-bit local ids cannot describe: the host redoes the call with the general lean kernel
+        if (lane == 0) atomicOr(&p.status[4], 1u);
+        return;
+    }
+    lds_order();
+
+    const bool reaches_end = base + kRowsS >= n;
+    const uint32_t W32 = (uint32_t)p.W;
+    for (int q = lane; q < nseg_owned; q += kWave) {
+        const uint32_t e0 = sh.seg[q], e1 = sh.seg[q + 1];
+        const int r0 = (int)(e0 & 0xFFFFu);
+        const uint32_t wid = w_first + (e0 >> 16);
+        int r1;
+        uint32_t next_wid;
+        if (q + 1 < nseg_total) {
+            r1 = (int)(e1 & 0xFFFFu);
+            next_wid = w_first + (e1 >> 16);
+        } else if (reaches_end) {
+            r1 = nloc;
+            next_wid = W32;
+        } else {
+            // rows run past the look-ahead: hand the window to the cooperative path
+            const unsigned idx = atomicAdd(&p.status[1], 1u);
+            if ((int64_t)idx < p.long_cap) {
+                p.long_list[2 * idx] = (int64_t)wid;
+                p.long_list[2 * idx + 1] = base + r0;
+            } else {
+                atomicOr(&p.status[2], 1u);
+            }
+            continue;
+        }
+        // ---- the walk: rows r0 .. r1-1 in order (sum.go:16-22, arithmeticmean.go:17-24, minmax.go:16-28)
+        const uint64_t raw0 = sh.val[r0];
+        double sum = 0.0;
+        double mn = kInt ? (double)(int64_t)raw0 : __longlong_as_double((long long)raw0);
+        double mx = mn;
+        for (int r = r0; r < r1; r++) {
+            const uint64_t raw = sh.val[r];
+            const double x = kInt ? (double)(int64_t)raw : __longlong_as_double((long long)raw);
+            sum += x;
+            if (kNeed & 1) {
+                if (x < mn) mn = x;
+                if (x > mx) mx = x;
+            }
+        }
+        const int nrows = r1 - r0;
+        const uint64_t last_raw = (kNeed & 2) ? sh.val[r1 - 1] : 0;
+        const int64_t win_start = p.s0 + (int64_t)((uint64_t)wid * (uint64_t)(uint32_t)p.interval);
+        if (wid >= W32) continue;  // (only on corrupt input)
+        // ---- outputs: lane q -> slot wid
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+            if (a >= p.naggs) break;
+            uint64_t bits;
+            switch (p.kind[a]) {
+            case BOWGPU_AGG_WINDOW_START: bits = (uint64_t)win_start; break;
+            case BOWGPU_AGG_SUM: bits = (uint64_t)__double_as_longlong(sum); break;
+            case BOWGPU_AGG_MEAN: bits = (uint64_t)__double_as_longlong(sum / (double)(int64_t)nrows); break;
+            case BOWGPU_AGG_MIN: bits = (uint64_t)__double_as_longlong(mn); break;
+            case BOWGPU_AGG_MAX: bits = (uint64_t)__double_as_longlong(mx); break;
+            case BOWGPU_AGG_COUNT: bits = (uint64_t)(int64_t)nrows; break;
+            case BOWGPU_AGG_FIRST: bits = raw0; break;
+            case BOWGPU_AGG_LAST: bits = last_raw; break;
+            default: bits = (uint64_t)__double_as_longlong((double)nrows); break;  // NumRows
+            }
+            p.out_values[a][wid] = bits;
+        }
+        // ---- the empty windows right after this one (rare): values of an empty slice + cleared validity bits
+        const uint32_t gap = next_wid - wid - 1;
+        if (gap != 0) {
+            for (uint32_t g = 1; g <= gap; g++) {
+                const uint32_t gw = wid + g;
+                if (gw >= W32) break;
+                const int64_t gstart = p.s0 + (int64_t)((uint64_t)gw * (uint64_t)(uint32_t)p.interval);
+                for (int a = 0; a < p.naggs; a++) {
+                    const int k = p.kind[a];
+                    // A.9 "Empty slice": WindowStart s_k ; Sum 0.0 ; Count 0 ; NumRows 0.0 ; the rest nil (slot 0, bit cleared)
+                    p.out_values[a][gw] = k == BOWGPU_AGG_WINDOW_START ? (uint64_t)gstart : 0ull;
+                    if (p.out_valid[a]) atomicAnd(&p.out_valid[a][gw >> 5], ~(1u << (gw & 31)));
+                }
+            }
+        }
+    }
+}
+
+int launch_rolling_simple(Ctx *c, const SimpleParams &p, int need, bool is_int) {
+    if (p.n <= 0) return 0;
+    const int64_t ntiles = (p.n + kTileS - 1) / kTileS;
+    const int64_t per_xcd = (ntiles + 7) / 8;
+    const int64_t grid = per_xcd * 8;
+    if (grid > 0x7FFFFFFFll) return fail(BOWGPU_ERR_UNSUPPORTED, "too many rows for one launch: %lld", (long long)p.n);
+    const dim3 g((unsigned)grid), blk(kWave);
+#define BG_LAUNCH(N, I) hipLaunchKernelGGL((rolling_simple_kernel<N, I>), g, blk, 0, c->stream, p, ntiles, per_xcd)
+    if (is_int) {
+        switch (need) { case 0: BG_LAUNCH(0, true); break; case 1: BG_LAUNCH(1, true); break; case 2: BG_LAUNCH(2, true); break; default: BG_LAUNCH(3, true); break; }
+    } else {
+        switch (need) { case 0: BG_LAUNCH(0, false); break; case 1: BG_LAUNCH(1, false); break; case 2: BG_LAUNCH(2, false); break; default: BG_LAUNCH(3, false); break; }
+    }
+#undef BG_LAUNCH
+    BG_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace bowgpu

@@ -1,7 +1,7 @@
 import csv, glob, sys, collections
 root = sys.argv[1]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(root + '/p*/**/*counter_collection.csv', recursive=True):
+for f in glob.glob(root + '/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name'][:48]
         acc[k][r['Counter_Name']].append(float(r['Counter_Value']))

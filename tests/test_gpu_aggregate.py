@@ -71,17 +71,20 @@ def run_both(ts, cols_np, interval, aggs, offset=0, inclusive=False, device=Fals
         ccols = [c.to_device() for c in ccols]
     exp, nic = orc.aggregate(ocols, 0, interval, aggs, offset=offset, inclusive=inclusive)
     first = None
-    for force in ("0", "1"):
-        os.environ["BOWGPU_FORCE_GENERAL"] = force
+    # three HIP code paths over the same inputs: simple kernel where it applies (else lean), lean kernel, general kernel
+    for label, env in (("auto", {}), ("lean", {"BOWGPU_NO_SIMPLE": "1"}), ("general", {"BOWGPU_FORCE_GENERAL": "1"})):
+        for k in ("BOWGPU_NO_SIMPLE", "BOWGPU_FORCE_GENERAL"):
+            os.environ[k] = env.get(k, "0")
         try:
             outs, info = capi.rolling_aggregate(ccols, 0, interval, aggs, offset=offset, inclusive=inclusive,
                                                 out_residency=capi.DEVICE if device else capi.HOST)
         finally:
+            os.environ["BOWGPU_NO_SIMPLE"] = "0"
             os.environ["BOWGPU_FORCE_GENERAL"] = "0"
         assert info.new_interval_col == nic
         for k, g, w in zip(_names(aggs), outs, exp):
             exact = info.long_windows == 0 or k not in ORDER_SENSITIVE
-            compare("%s general=%s n=%d I=%d off=%d" % (k, force, len(ts), interval, offset), g, w, exact=exact, rtol=1e-11)
+            compare("%s path=%s n=%d I=%d off=%d" % (k, label, len(ts), interval, offset), g, w, exact=exact, rtol=1e-11)
         if first is None:
             first = (outs, exp, info)
     return first
@@ -336,3 +339,26 @@ def test_rows_below_first_window_start():
         assert info.s0 > ts[0]
         for (k, _), g, w in zip(aggs, outs, exp):
             compare("%s %s" % (k, ts_list), g, w)
+
+
+@pytest.mark.parametrize("vkind", ["f64", "i64"])
+def test_simple_kernel_shapes(vkind):
+    # the shapes rolling_simple.hip takes: one null-free column, <= 4 factor-free outputs, 32-bit span
+    rng = np.random.default_rng(41)
+    for mode in ["dense", "irregular", "dups", "gappy"]:
+        for n, interval, offset in [(1, 10, 0), (513, 10, 0), (640, 7, 3), (641, 10, 0), (100_000, 10, 0), (100_000, 3, 2), (100_001, 100, 7)]:
+            ts = make_ts(rng, n, mode)
+            vals, _ = make_vals(rng, n, vkind, 0.0)
+            for aggs in ([("WindowStart", 0), ("ArithmeticMean", 1)],
+                         [("WindowStart", 0), ("Sum", 1), ("Min", 1), ("Max", 1)],
+                         [("Count", 1), ("WindowStart", 0), ("First", 1), ("Last", 1)],
+                         [("WindowStart", 0), ("NumRows", 1), ("ArithmeticMean", 1)],
+                         [("WindowStart", 0), ("Sum", 0), ("Max", 0)]):
+                run_both(ts, [(vals, None)], interval, aggs, offset=offset)
+
+
+def test_simple_kernel_redo_when_ids_overflow():
+    # > 65535 windows inside one 640-row tile: the simple kernel flags the call, the lean kernel redoes it
+    ts = np.concatenate([np.arange(0, 300), np.arange(300, 600) * 1000]).astype(np.int64)
+    vals = np.arange(len(ts), dtype=np.float64)
+    run_both(ts, [(vals, None)], 2, [("WindowStart", 0), ("ArithmeticMean", 1), ("Count", 1)])
