@@ -169,7 +169,7 @@ def main():
                        "rows_per_gpu": rows, "windows_per_gpu": rows // interval, "parallelism": "rows range-partitioned x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "rolling_wave_kernel", "kernel_ms": k_ms,
+                         "kernel": "rolling_simple_kernel" if world == 1 else "rolling_wave_kernel", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": rows * BYTES_PER_ROW},
             "device": capi.device_name(),
         }

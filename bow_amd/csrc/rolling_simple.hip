@@ -26,10 +26,13 @@ constexpr int kHaloS = 128;
 constexpr int kRowsS = kTileS + kHaloS;
 constexpr int kChunksS = kRowsS / 128;
 constexpr uint32_t kSatS = 0xFFFFu;
+// At most kSegCapS windows may start inside one tile (+ look-ahead); denser tiles (windows of < 1.6 rows on average)
+// send the call to the general lean kernel.  The cap keeps a wave's LDS at 6.6 KB => 24 resident waves per CU.
+constexpr int kSegCapS = 400;
 
 struct SimpleShared {
     uint64_t val[kRowsS];
-    uint32_t seg[kRowsS + 2];  // heads in row order: local row | (wid - wid of the tile's first row) << 16
+    uint32_t seg[kSegCapS + 2];  // heads in row order: local row | (wid - wid of the tile's first row) << 16
 };
 
 __device__ __forceinline__ uint32_t mdiv32(uint32_t n, uint32_t m, uint32_t sh1, uint32_t sh2) {
@@ -49,7 +52,7 @@ __device__ __forceinline__ void lds_order() {
 
 // kNeed: bit0 min/max wanted, bit1 first/last wanted; kInt: Int64 value column
 template <int kNeed, bool kInt>
-__global__ __launch_bounds__(kWave, 5) void rolling_simple_kernel(const SimpleParams p, const int64_t ntiles,
+__global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimpleParams p, const int64_t ntiles,
                                                                   const int64_t tiles_per_xcd) {
     __shared__ SimpleShared sh;
     const int64_t b = blockIdx.x;
@@ -108,8 +111,9 @@ __global__ __launch_bounds__(kWave, 5) void rolling_simple_kernel(const SimplePa
         int pos = nseg_total;
         pos += __builtin_amdgcn_mbcnt_hi((unsigned)(ma >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ma, 0));
         pos += __builtin_amdgcn_mbcnt_hi((unsigned)(mb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb, 0));
-        if (ha) { sh.seg[pos] = (uint32_t)l | (la << 16); pos++; }
-        if (hb) sh.seg[pos] = (uint32_t)(l + 1) | (lb << 16);
+        if (ha && pos < kSegCapS) sh.seg[pos] = (uint32_t)l | (la << 16);
+        pos += ha ? 1 : 0;
+        if (hb && pos < kSegCapS) sh.seg[pos] = (uint32_t)(l + 1) | (lb << 16);
         nseg_total += __popcll(ma) + __popcll(mb);
         if (j == kChunksS - 2) nseg_owned = nseg_total;
         left_w = (uint32_t)__builtin_amdgcn_readlane((int)wb, 63);
@@ -122,7 +126,8 @@ __global__ __launch_bounds__(kWave, 5) void rolling_simple_kernel(const SimplePa
         if (lane == 0) atomicOr(&p.status[0], 1u);
         return;
     }
-    if (__ballot(sat)) {  // a tile the 16-bit local ids cannot describe: the host redoes the call with the general lean kernel
+    if (nseg_total > kSegCapS) sat = true;
+    if (__ballot(sat)) {  // a tile the 16-bit local ids / the segment list cannot describe: the host redoes the call with the general lean kernel
         if (lane == 0) atomicOr(&p.status[4], 1u);
         return;
     }

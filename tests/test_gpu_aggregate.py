@@ -357,6 +357,13 @@ def test_simple_kernel_shapes(vkind):
                 run_both(ts, [(vals, None)], interval, aggs, offset=offset)
 
 
+def test_simple_kernel_redo_when_tile_too_dense():
+    # one window per row: more heads than the simple kernel's segment list holds => redone by the lean kernel
+    ts = np.arange(5000, dtype=np.int64) * 3
+    vals = np.arange(5000, dtype=np.float64)
+    run_both(ts, [(vals, None)], 2, [("WindowStart", 0), ("Sum", 1), ("Count", 1)])
+
+
 def test_simple_kernel_redo_when_ids_overflow():
     # > 65535 windows inside one 640-row tile: the simple kernel flags the call, the lean kernel redoes it
     ts = np.concatenate([np.arange(0, 300), np.arange(300, 600) * 1000]).astype(np.int64)
