@@ -555,21 +555,21 @@ static int job_enqueue_tail(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t
 
 // Can the stripped-down kernel of rolling_simple.hip take this call?  (one null-free, 16-B aligned value column, at most
 // 4 factor-free outputs, exclusive windows, the whole interval column within 2^32 of s0, not a shard)
-static bool simple_applies(const AggJob *job, const bowgpu_agg *aggs, int32_t naggs, const Plan &plan, int *need, bool *is_int) {
+static bool simple_applies(const AggJob *job, const bowgpu_agg *aggs, int32_t naggs, const Plan &plan, int *need, bool *is_int,
+                           bool *has_nulls) {
     const AggParams &P = job->P;
-    if (job->inclusive || P.pre_rows || P.wid_base != 0 || !P.fits32 || naggs > 4 || P.ncols > 1) return false;
+    if (job->inclusive || P.pre_rows || P.wid_base != 0 || !P.fits32 || naggs > kSimpleMaxAggs || P.ncols > 1) return false;
     if (P.W <= 0 || P.W >= 0xFFFFFFF0ll) return false;
     if ((uint64_t)plan.last_ts - (uint64_t)plan.s0 >= 0xFFFFFFF0ull) return false;
     if (reinterpret_cast<uintptr_t>(P.ts) & 15) return false;
     *need = 0;
-    *is_int = false;
-    const void *vals = P.ts;
+    *is_int = true;  // (reducers over the interval column itself)
+    *has_nulls = false;
     if (P.ncols == 1) {
-        if (P.cols[0].vbits != nullptr || (reinterpret_cast<uintptr_t>(P.cols[0].values) & 15)) return false;
-        vals = P.cols[0].values;
+        if (reinterpret_cast<uintptr_t>(P.cols[0].values) & 15) return false;
+        *has_nulls = P.cols[0].vbits != nullptr;
         *is_int = P.cols[0].type == BOWGPU_INT64;
     }
-    (void)vals;
     for (int i = 0; i < naggs; i++) {
         const int k = aggs[i].kind;
         if (aggs[i].n_factors != 0) return false;
@@ -597,8 +597,8 @@ static int job_launch_tiles(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t
     const char *force = getenv("BOWGPU_FORCE_GENERAL");
     if (force && force[0] == '1') lean = false;
     int need = 0;
-    bool is_int = false;
-    const bool simple = lean && allow_simple && plan && simple_applies(job, aggs, naggs, *plan, &need, &is_int);
+    bool is_int = false, has_nulls = false;
+    const bool simple = lean && allow_simple && plan && simple_applies(job, aggs, naggs, *plan, &need, &is_int, &has_nulls);
     P.bits_preset = simple ? 1 : 0;
     for (int i = 0; i < naggs; i++) {
         const size_t vb = (size_t)((W + 7) >> 3);
@@ -624,7 +624,8 @@ static int job_launch_tiles(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t
             S.out_valid[i] = P.aggs[i].out_valid;
         }
         S.status = P.status; S.long_list = P.long_list; S.long_cap = P.long_cap;
-        BG_TRY(launch_rolling_simple(c, S, need, is_int));
+        if (has_nulls) { S.vbits = P.cols[0].vbits; S.vbit0 = P.cols[0].vbit0; S.vwords = P.cols[0].vwords; }
+        BG_TRY(launch_rolling_simple(c, S, need, is_int, has_nulls));
         *used_simple = true;
     } else if (lean) {
         BG_TRY(launch_rolling_fast(c, P));

@@ -178,6 +178,7 @@ struct AggParams {
     int64_t long_cap;
 };
 
+constexpr int kSimpleMaxAggs = 8;
 // descriptor of rolling_simple.hip's kernel: one null-free value column, <= 4 factor-free outputs, 32-bit window ids
 struct SimpleParams {
     const int64_t *ts;
@@ -185,14 +186,16 @@ struct SimpleParams {
     int64_t n, s0, interval, W;
     uint32_t m32, sh1, sh2;
     int32_t naggs;
-    int32_t kind[4];
-    uint64_t *out_values[4];
-    uint32_t *out_valid[4];   // nullptr for never-nil reducers; all bitmaps are preset to ones by the host
+    int32_t kind[kSimpleMaxAggs];
+    uint64_t *out_values[kSimpleMaxAggs];
+    uint32_t *out_valid[kSimpleMaxAggs];   // nullptr for never-nil reducers; all bitmaps are preset to ones by the host
+    const uint32_t *vbits;    // validity words of the value column (nullptr: no nulls), bit `vbit0` = row 0
+    int64_t vbit0, vwords;
     uint32_t *status;         // [0] unsorted, [1] long-window count, [2] list overflow, [4] redo with the general lean kernel
     int64_t *long_list;
     int64_t long_cap;
 };
-int launch_rolling_simple(Ctx *c, const SimpleParams &p, int need, bool is_int);
+int launch_rolling_simple(Ctx *c, const SimpleParams &p, int need, bool is_int, bool has_nulls);
 
 int launch_rolling_aggregate(Ctx *c, const AggParams &p);   // general kernel (rolling_agg.hip)
 int launch_rolling_fast(Ctx *c, const AggParams &p);        // lean kernel for exclusive windows without time-weighted reducers (rolling_fast.hip)

@@ -1,7 +1,7 @@
 // rolling_simple.hip — the tile kernel for the most common shape of Rolling.Aggregate, stripped of every
 // descriptor-driven branch:
-//   * ONE value column WITHOUT nulls (null_count == 0), Float64 or Int64, plus the interval column;
-//   * up to 4 outputs among WindowStart / Sum / ArithmeticMean / Min / Max / Count / First / Last / NumRows,
+//   * ONE value column (Float64 or Int64, with or without nulls) plus the interval column;
+//   * up to 8 outputs among WindowStart / Sum / ArithmeticMean / Min / Max / Count / First / Last / NumRows,
 //     no transformation factors, exclusive windows;
 //   * the whole interval column spans less than 2^32 and interval < 2^32, so window ids are 32-bit:
 //     wid = magic32((uint32)(ts - s0)) with no per-tile base.
@@ -9,9 +9,9 @@
 // rolling/aggregation/{windowstart,sum,arithmeticmean,minmax,count,firstlast}.go.)  Anything else takes
 // rolling_fast.hip / rolling_agg.hip; results are identical where several apply (tests run all of them).
 //
-// Because the value column has no nulls, every non-empty window yields a value: the host presets all output
-// validity bitmaps to ones and this kernel only CLEARS the bits of empty windows (gaps), which removes the
-// LDS bitmap assembly from the hot path.  Structure otherwise as rolling_fast.hip: one wavefront per tile of
+// Nil results are the exception (empty windows; windows whose values are all null), so the host presets all
+// output validity bitmaps to ones and this kernel only CLEARS the bits of nil results, which removes the LDS
+// bitmap assembly from the hot path.  Structure otherwise as rolling_fast.hip: one wavefront per tile of
 // 512 rows + 128 look-ahead rows, no barriers, heads -> LDS segment list -> one lane walks one window in
 // row order (reference summation order, bit-exact).
 #include "agg_device.h"
@@ -32,6 +32,7 @@ constexpr int kSegCapS = 400;
 
 struct SimpleShared {
     uint64_t val[kRowsS];
+    uint32_t vbits[kRowsS / 32 + 2];  // validity words of the value column for this tile (kNulls only)
     uint32_t seg[kSegCapS + 2];  // heads in row order: local row | (wid - wid of the tile's first row) << 16
 };
 
@@ -50,8 +51,8 @@ __device__ __forceinline__ void lds_order() {
 
 }  // namespace
 
-// kNeed: bit0 min/max wanted, bit1 first/last wanted; kInt: Int64 value column
-template <int kNeed, bool kInt>
+// kNeed: bit0 min/max wanted, bit1 first/last wanted; kInt: Int64 value column; kNulls: the column has nulls
+template <int kNeed, bool kInt, bool kNulls>
 __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimpleParams p, const int64_t ntiles,
                                                                   const int64_t tiles_per_xcd) {
     __shared__ SimpleShared sh;
@@ -80,6 +81,14 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
         for (int j = 0; j < kChunksS; j++) load_pair(ts, base + j * 128 + 2 * lane, n, true, ta[j], tb[j]);
 #pragma unroll
         for (int j = 0; j < kChunksS; j++) load_pair(vp, base + j * 128 + 2 * lane, n, true, va[j], vb[j]);
+    }
+    if (kNulls && lane < kRowsS / 32) {  // 32 validity bits per lane, any bit offset (Arrow slices)
+        const int64_t bit = p.vbit0 + base + 32 * (int64_t)lane;
+        const int64_t wi = bit >> 5;
+        const int shb = (int)(bit & 31);
+        const uint32_t lo = wi < p.vwords ? p.vbits[wi] : 0u;
+        const uint32_t hi = (shb != 0 && wi + 1 < p.vwords) ? p.vbits[wi + 1] : 0u;
+        sh.vbits[lane] = shb ? ((lo >> shb) | (hi << (32 - shb))) : lo;
     }
     // the row left of the tile (scalar load): first head flag + order check
     const int64_t left0 = base > 0 ? p.ts[base - 1] : INT64_MIN;
@@ -158,39 +167,62 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
             }
             continue;
         }
-        // ---- the walk: rows r0 .. r1-1 in order (sum.go:16-22, arithmeticmean.go:17-24, minmax.go:16-28)
-        const uint64_t raw0 = sh.val[r0];
-        double sum = 0.0;
-        double mn = kInt ? (double)(int64_t)raw0 : __longlong_as_double((long long)raw0);
-        double mx = mn;
-        for (int r = r0; r < r1; r++) {
-            const uint64_t raw = sh.val[r];
-            const double x = kInt ? (double)(int64_t)raw : __longlong_as_double((long long)raw);
-            sum += x;
-            if (kNeed & 1) {
-                if (x < mn) mn = x;
-                if (x > mx) mx = x;
+        // ---- the walk: rows r0 .. r1-1 in order (sum.go:16-22, arithmeticmean.go:17-24, minmax.go:16-28, count.go:12-18)
+        double sum = 0.0, mn = 0.0, mx = 0.0;
+        uint64_t first_raw = 0, last_raw = 0;
+        int count;
+        if (!kNulls) {
+            first_raw = sh.val[r0];
+            mn = kInt ? (double)(int64_t)first_raw : __longlong_as_double((long long)first_raw);
+            mx = mn;
+            for (int r = r0; r < r1; r++) {
+                const uint64_t raw = sh.val[r];
+                const double x = kInt ? (double)(int64_t)raw : __longlong_as_double((long long)raw);
+                sum += x;
+                if (kNeed & 1) {
+                    if (x < mn) mn = x;
+                    if (x > mx) mx = x;
+                }
+            }
+            count = r1 - r0;
+            if (kNeed & 2) last_raw = sh.val[r1 - 1];
+        } else {
+            count = 0;
+            for (int r = r0; r < r1; r++) {
+                if (!((sh.vbits[r >> 5] >> (r & 31)) & 1u)) continue;
+                const uint64_t raw = sh.val[r];
+                const double x = kInt ? (double)(int64_t)raw : __longlong_as_double((long long)raw);
+                sum += x;
+                if (count == 0) { mn = x; mx = x; first_raw = raw; }
+                else if (kNeed & 1) { if (x < mn) mn = x; if (x > mx) mx = x; }
+                last_raw = raw;
+                count++;
             }
         }
         const int nrows = r1 - r0;
-        const uint64_t last_raw = (kNeed & 2) ? sh.val[r1 - 1] : 0;
+        const bool has_value = count > 0;  // (always true without nulls)
         const int64_t win_start = p.s0 + (int64_t)((uint64_t)wid * (uint64_t)(uint32_t)p.interval);
         if (wid >= W32) continue;  // (only on corrupt input)
         // ---- outputs: lane q -> slot wid
 #pragma unroll
-        for (int a = 0; a < 4; a++) {
+        for (int a = 0; a < kSimpleMaxAggs; a++) {
             if (a >= p.naggs) break;
             uint64_t bits;
+            bool nil = false;
             switch (p.kind[a]) {
             case BOWGPU_AGG_WINDOW_START: bits = (uint64_t)win_start; break;
             case BOWGPU_AGG_SUM: bits = (uint64_t)__double_as_longlong(sum); break;
-            case BOWGPU_AGG_MEAN: bits = (uint64_t)__double_as_longlong(sum / (double)(int64_t)nrows); break;
-            case BOWGPU_AGG_MIN: bits = (uint64_t)__double_as_longlong(mn); break;
-            case BOWGPU_AGG_MAX: bits = (uint64_t)__double_as_longlong(mx); break;
-            case BOWGPU_AGG_COUNT: bits = (uint64_t)(int64_t)nrows; break;
-            case BOWGPU_AGG_FIRST: bits = raw0; break;
-            case BOWGPU_AGG_LAST: bits = last_raw; break;
+            case BOWGPU_AGG_MEAN: bits = (uint64_t)__double_as_longlong(sum / (double)(int64_t)count); nil = !has_value; break;
+            case BOWGPU_AGG_MIN: bits = (uint64_t)__double_as_longlong(mn); nil = !has_value; break;
+            case BOWGPU_AGG_MAX: bits = (uint64_t)__double_as_longlong(mx); nil = !has_value; break;
+            case BOWGPU_AGG_COUNT: bits = (uint64_t)(int64_t)count; break;
+            case BOWGPU_AGG_FIRST: bits = first_raw; nil = !has_value; break;
+            case BOWGPU_AGG_LAST: bits = last_raw; nil = !has_value; break;
             default: bits = (uint64_t)__double_as_longlong((double)nrows); break;  // NumRows
+            }
+            if (kNulls && nil) {  // a window whose values are all null (rare): nil => slot 0, bit cleared
+                bits = 0;
+                atomicAnd(&p.out_valid[a][wid >> 5], ~(1u << (wid & 31)));
             }
             p.out_values[a][wid] = bits;
         }
@@ -212,19 +244,20 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
     }
 }
 
-int launch_rolling_simple(Ctx *c, const SimpleParams &p, int need, bool is_int) {
+int launch_rolling_simple(Ctx *c, const SimpleParams &p, int need, bool is_int, bool has_nulls) {
     if (p.n <= 0) return 0;
     const int64_t ntiles = (p.n + kTileS - 1) / kTileS;
     const int64_t per_xcd = (ntiles + 7) / 8;
     const int64_t grid = per_xcd * 8;
     if (grid > 0x7FFFFFFFll) return fail(BOWGPU_ERR_UNSUPPORTED, "too many rows for one launch: %lld", (long long)p.n);
     const dim3 g((unsigned)grid), blk(kWave);
-#define BG_LAUNCH(N, I) hipLaunchKernelGGL((rolling_simple_kernel<N, I>), g, blk, 0, c->stream, p, ntiles, per_xcd)
-    if (is_int) {
-        switch (need) { case 0: BG_LAUNCH(0, true); break; case 1: BG_LAUNCH(1, true); break; case 2: BG_LAUNCH(2, true); break; default: BG_LAUNCH(3, true); break; }
-    } else {
-        switch (need) { case 0: BG_LAUNCH(0, false); break; case 1: BG_LAUNCH(1, false); break; case 2: BG_LAUNCH(2, false); break; default: BG_LAUNCH(3, false); break; }
-    }
+#define BG_LAUNCH(N, I, U) hipLaunchKernelGGL((rolling_simple_kernel<N, I, U>), g, blk, 0, c->stream, p, ntiles, per_xcd)
+#define BG_NEED(I, U)                                                                                   \
+    switch (need) { case 0: BG_LAUNCH(0, I, U); break; case 1: BG_LAUNCH(1, I, U); break;              \
+                    case 2: BG_LAUNCH(2, I, U); break; default: BG_LAUNCH(3, I, U); break; }
+    if (is_int) { if (has_nulls) { BG_NEED(true, true) } else { BG_NEED(true, false) } }
+    else { if (has_nulls) { BG_NEED(false, true) } else { BG_NEED(false, false) } }
+#undef BG_NEED
 #undef BG_LAUNCH
     BG_HIP(hipGetLastError());
     return 0;

@@ -1,0 +1,39 @@
+"""Quick timing of BASELINE.json configs 1-3 on one GPU (parity cases, not the bench line)."""
+import sys, time
+sys.path.insert(0, '.')
+import numpy as np
+from bow_amd import capi
+n = 100_000_000
+def run(label, cols, interval, aggs, bytes_per_row, offset=0, reps=5):
+    s0, W = capi.plan_windows(cols[0], interval, offset)
+    outs = [capi.OutColumn(W, capi.DEVICE) for _ in aggs]
+    ms = []
+    for i in range(reps + 1):
+        _, info = capi.rolling_aggregate(cols, 0, interval, aggs, offset=offset, outs=outs)
+        ms.append(info.kernel_ms)
+    k = sum(ms[1:]) / reps
+    print("%-58s W=%-9d kernel %.3f ms  %.1f Grows/s  %.0f GB/s (%.1f%% of 8 TB/s) long=%d" % (
+        label, W, k, n / k / 1e6, n * bytes_per_row / k / 1e6, n * bytes_per_row / k / 1e6 / 80, info.long_windows))
+ts, val = capi.gen_dense(0, n, seed=42)
+run("cfg1 dense Sum/Mean/Min/Max (+WindowStart), interval 10", [ts, val], 10,
+    [("WindowStart", 0), ("Sum", 1), ("ArithmeticMean", 1), ("Min", 1), ("Max", 1)], 16)
+run("cfg1 dense WindowStart+Mean, interval 10", [ts, val], 10, [("WindowStart", 0), ("ArithmeticMean", 1)], 16)
+run("cfg1 dense WindowStart+Mean, interval 1000 (long windows)", [ts, val], 1000, [("WindowStart", 0), ("ArithmeticMean", 1)], 16)
+ts2, val2 = capi.gen_sparse(0, n, seed=42)
+run("cfg2 sparse 30% nulls WindowStart+Mean, interval 100", [ts2, val2], 100, [("WindowStart", 0), ("ArithmeticMean", 1)], 16.125)
+t0 = time.perf_counter()
+ip = [{"kind": "WindowStart", "col": 0}, {"kind": "Linear", "col": 1}]
+filled = capi.rolling_interpolate([ts2, val2], 0, 100, ip, out_residency=capi.DEVICE)
+capi.synchronize()
+t1 = time.perf_counter()
+filled = capi.rolling_interpolate([ts2, val2], 0, 100, ip, out_residency=capi.DEVICE)
+capi.synchronize()
+t2 = time.perf_counter()
+print("cfg2 Interpolate(WindowStart, Linear) interval 100: %d -> %d rows, %.1f ms wall (2nd call)  %.1f Grows/s" % (n, filled[0].length, (t2 - t1) * 1e3, n / (t2 - t1) / 1e9))
+m = filled[0].length
+cols2 = [capi.Column(filled[0].values, None, capi.INT64, 0, m, 0), capi.Column(filled[1].values, filled[1].validity, capi.FLOAT64, 0, m, -1)]
+run("cfg2 Mean after Linear fill, interval 100", cols2, 100, [("WindowStart", 0), ("ArithmeticMean", 1)], 16.125)
+del filled, cols2
+cols8 = [ts] + [capi.gen_dense(0, n, seed=42 + k)[1] for k in range(8)]
+run("cfg3 8 float64 columns Mean each (+WindowStart), interval 10", cols8, 10,
+    [("WindowStart", 0)] + [("ArithmeticMean", 1 + k) for k in range(8)], 72)

@@ -349,6 +349,9 @@ def test_simple_kernel_shapes(vkind):
         for n, interval, offset in [(1, 10, 0), (513, 10, 0), (640, 7, 3), (641, 10, 0), (100_000, 10, 0), (100_000, 3, 2), (100_001, 100, 7)]:
             ts = make_ts(rng, n, mode)
             vals, _ = make_vals(rng, n, vkind, 0.0)
+            valid = rng.random(n) >= 0.5  # heavy nulls: some windows have no valid value at all
+            run_both(ts, [(vals, valid)], interval, [("WindowStart", 0), ("Sum", 1), ("ArithmeticMean", 1), ("Min", 1), ("Max", 1),
+                                                      ("Count", 1), ("First", 1), ("Last", 1)], offset=offset)
             for aggs in ([("WindowStart", 0), ("ArithmeticMean", 1)],
                          [("WindowStart", 0), ("Sum", 1), ("Min", 1), ("Max", 1)],
                          [("Count", 1), ("WindowStart", 0), ("First", 1), ("Last", 1)],
