@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbowgpu.so")
+LIB_PATH = os.environ.get("BOWGPU_LIB") or os.path.join(_HERE, "libbowgpu.so")
 
 FLOAT64, INT64, BOOLEAN, STRING = 1, 2, 3, 4
 HOST, DEVICE = 0, 1

@@ -558,16 +558,17 @@ static int job_enqueue_tail(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t
 static bool simple_applies(const AggJob *job, const bowgpu_agg *aggs, int32_t naggs, const Plan &plan, int *need, bool *is_int,
                            bool *has_nulls) {
     const AggParams &P = job->P;
-    if (job->inclusive || P.pre_rows || P.wid_base != 0 || !P.fits32 || naggs > kSimpleMaxAggs || P.ncols > 1) return false;
+    if (job->inclusive || P.pre_rows || P.wid_base != 0 || !P.fits32 || naggs > kSimpleMaxAggs) return false;
     if (P.W <= 0 || P.W >= 0xFFFFFFF0ll) return false;
     if ((uint64_t)plan.last_ts - (uint64_t)plan.s0 >= 0xFFFFFFF0ull) return false;
     if (reinterpret_cast<uintptr_t>(P.ts) & 15) return false;
     *need = 0;
     *is_int = true;  // (reducers over the interval column itself)
     *has_nulls = false;
-    if (P.ncols == 1) {
-        if (reinterpret_cast<uintptr_t>(P.cols[0].values) & 15) return false;
-        *has_nulls = P.cols[0].vbits != nullptr;
+    for (int s = 0; s < P.ncols; s++) {
+        if (reinterpret_cast<uintptr_t>(P.cols[s].values) & 15) return false;
+        if (P.cols[s].type != P.cols[0].type) return false;  // one walk specialisation per launch
+        *has_nulls = *has_nulls || P.cols[s].vbits != nullptr;
         *is_int = P.cols[0].type == BOWGPU_INT64;
     }
     for (int i = 0; i < naggs; i++) {
@@ -614,17 +615,22 @@ static int job_launch_tiles(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t
         SimpleParams S;
         memset(&S, 0, sizeof S);
         S.ts = P.ts;
-        S.values = P.ncols == 1 ? P.cols[0].values : P.ts;
         S.n = P.n; S.s0 = P.s0; S.interval = P.interval; S.W = P.W;
         S.m32 = P.m32; S.sh1 = P.sh1_32; S.sh2 = P.sh2_32;
         S.naggs = naggs;
+        S.ncols = P.ncols > 0 ? P.ncols : 1;
+        S.values[0] = P.ts;  // only WindowStart / NumRows: any column serves as "the" column
+        for (int s = 0; s < P.ncols; s++) {
+            S.values[s] = P.cols[s].values;
+            S.vbits[s] = P.cols[s].vbits; S.vbit0[s] = P.cols[s].vbit0; S.vwords[s] = P.cols[s].vwords;
+        }
         for (int i = 0; i < naggs; i++) {
             S.kind[i] = aggs[i].kind;
+            S.col[i] = P.aggs[i].slot < 0 ? 0 : P.aggs[i].slot;
             S.out_values[i] = reinterpret_cast<uint64_t *>(P.aggs[i].out_values);
             S.out_valid[i] = P.aggs[i].out_valid;
         }
         S.status = P.status; S.long_list = P.long_list; S.long_cap = P.long_cap;
-        if (has_nulls) { S.vbits = P.cols[0].vbits; S.vbit0 = P.cols[0].vbit0; S.vwords = P.cols[0].vwords; }
         BG_TRY(launch_rolling_simple(c, S, need, is_int, has_nulls));
         *used_simple = true;
     } else if (lean) {

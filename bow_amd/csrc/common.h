@@ -178,19 +178,22 @@ struct AggParams {
     int64_t long_cap;
 };
 
-constexpr int kSimpleMaxAggs = 8;
-// descriptor of rolling_simple.hip's kernel: one null-free value column, <= 4 factor-free outputs, 32-bit window ids
+constexpr int kSimpleMaxAggs = 12;
+// descriptor of rolling_simple.hip's kernel: value columns of one type, factor-free outputs, 32-bit window ids
 struct SimpleParams {
     const int64_t *ts;
-    const void *values;
     int64_t n, s0, interval, W;
     uint32_t m32, sh1, sh2;
     int32_t naggs;
+    int32_t ncols;                         // value columns (>= 1; reducers over the interval column use it as a column)
+    int32_t _pad;
+    const void *values[kMaxCols];
+    const uint32_t *vbits[kMaxCols];       // nullptr: this column has no nulls
+    int64_t vbit0[kMaxCols], vwords[kMaxCols];
     int32_t kind[kSimpleMaxAggs];
+    int32_t col[kSimpleMaxAggs];           // column slot each output reads (WindowStart / NumRows ride with slot 0)
     uint64_t *out_values[kSimpleMaxAggs];
     uint32_t *out_valid[kSimpleMaxAggs];   // nullptr for never-nil reducers; all bitmaps are preset to ones by the host
-    const uint32_t *vbits;    // validity words of the value column (nullptr: no nulls), bit `vbit0` = row 0
-    int64_t vbit0, vwords;
     uint32_t *status;         // [0] unsorted, [1] long-window count, [2] list overflow, [4] redo with the general lean kernel
     int64_t *long_list;
     int64_t long_cap;

@@ -1,7 +1,7 @@
 // rolling_simple.hip — the tile kernel for the most common shape of Rolling.Aggregate, stripped of every
 // descriptor-driven branch:
-//   * ONE value column (Float64 or Int64, with or without nulls) plus the interval column;
-//   * up to 8 outputs among WindowStart / Sum / ArithmeticMean / Min / Max / Count / First / Last / NumRows,
+//   * up to 8 value columns of ONE type (all Float64 or all Int64, with or without nulls) plus the interval column;
+//   * up to 12 outputs among WindowStart / Sum / ArithmeticMean / Min / Max / Count / First / Last / NumRows,
 //     no transformation factors, exclusive windows;
 //   * the whole interval column spans less than 2^32 and interval < 2^32, so window ids are 32-bit:
 //     wid = magic32((uint32)(ts - s0)) with no per-tile base.
@@ -51,8 +51,9 @@ __device__ __forceinline__ void lds_order() {
 
 }  // namespace
 
-// kNeed: bit0 min/max wanted, bit1 first/last wanted; kInt: Int64 value column; kNulls: the column has nulls
-template <int kNeed, bool kInt, bool kNulls>
+// kNeed: bit0 min/max wanted, bit1 first/last wanted; kInt: Int64 value columns; kNulls: some column has nulls;
+// kMulti: more than one value column (the single-column shape keeps its straight-line form)
+template <int kNeed, bool kInt, bool kNulls, bool kMulti>
 __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimpleParams p, const int64_t ntiles,
                                                                   const int64_t tiles_per_xcd) {
     __shared__ SimpleShared sh;
@@ -65,31 +66,21 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
     const bool interior = base + kRowsS <= n;
     const int nloc = interior ? kRowsS : (int)(n - base);
 
-    // ---- loads
+    // ---- loads: ts, then the first value column right behind it
     uint64_t ta[kChunksS], tb[kChunksS], va[kChunksS], vb[kChunksS];
     const uint64_t *__restrict__ ts = reinterpret_cast<const uint64_t *>(p.ts);
-    const uint64_t *__restrict__ vp = reinterpret_cast<const uint64_t *>(p.values);
-    if (interior) {
-        const ulonglong2 *tp = reinterpret_cast<const ulonglong2 *>(ts + base) + lane;
-        const ulonglong2 *vq = reinterpret_cast<const ulonglong2 *>(vp + base) + lane;
+    auto load_col = [&](const uint64_t *__restrict__ src, uint64_t (&a)[kChunksS], uint64_t (&bb)[kChunksS]) {
+        if (interior) {
+            const ulonglong2 *q = reinterpret_cast<const ulonglong2 *>(src + base) + lane;
 #pragma unroll
-        for (int j = 0; j < kChunksS; j++) { const ulonglong2 x = tp[j * 64]; ta[j] = x.x; tb[j] = x.y; }
+            for (int j = 0; j < kChunksS; j++) { const ulonglong2 x = q[j * 64]; a[j] = x.x; bb[j] = x.y; }
+        } else {
 #pragma unroll
-        for (int j = 0; j < kChunksS; j++) { const ulonglong2 x = vq[j * 64]; va[j] = x.x; vb[j] = x.y; }
-    } else {
-#pragma unroll
-        for (int j = 0; j < kChunksS; j++) load_pair(ts, base + j * 128 + 2 * lane, n, true, ta[j], tb[j]);
-#pragma unroll
-        for (int j = 0; j < kChunksS; j++) load_pair(vp, base + j * 128 + 2 * lane, n, true, va[j], vb[j]);
-    }
-    if (kNulls && lane < kRowsS / 32) {  // 32 validity bits per lane, any bit offset (Arrow slices)
-        const int64_t bit = p.vbit0 + base + 32 * (int64_t)lane;
-        const int64_t wi = bit >> 5;
-        const int shb = (int)(bit & 31);
-        const uint32_t lo = wi < p.vwords ? p.vbits[wi] : 0u;
-        const uint32_t hi = (shb != 0 && wi + 1 < p.vwords) ? p.vbits[wi + 1] : 0u;
-        sh.vbits[lane] = shb ? ((lo >> shb) | (hi << (32 - shb))) : lo;
-    }
+            for (int j = 0; j < kChunksS; j++) load_pair(src, base + j * 128 + 2 * lane, n, true, a[j], bb[j]);
+        }
+    };
+    load_col(ts, ta, tb);
+    load_col(reinterpret_cast<const uint64_t *>(p.values[0]), va, vb);
     // the row left of the tile (scalar load): first head flag + order check
     const int64_t left0 = base > 0 ? p.ts[base - 1] : INT64_MIN;
     const uint32_t s0_lo = (uint32_t)p.s0;
@@ -128,8 +119,8 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
         left_w = (uint32_t)__builtin_amdgcn_readlane((int)wb, 63);
         left_ts = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(tb[j] >> 32), 63) << 32) |
                             (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)tb[j], 63));
-        // values of this chunk go to LDS now (their registers die here)
-        *reinterpret_cast<ulonglong2 *>(&sh.val[l]) = make_ulonglong2(va[j], vb[j]);
+        // single column: its values go to LDS now (their registers die here)
+        if (!kMulti) *reinterpret_cast<ulonglong2 *>(&sh.val[l]) = make_ulonglong2(va[j], vb[j]);
     }
     if (__ballot(unsorted)) {  // the call fails with BOWGPU_ERR_TS_UNSORTED
         if (lane == 0) atomicOr(&p.status[0], 1u);
@@ -140,10 +131,33 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
         if (lane == 0) atomicOr(&p.status[4], 1u);
         return;
     }
-    lds_order();
 
     const bool reaches_end = base + kRowsS >= n;
     const uint32_t W32 = (uint32_t)p.W;
+    // ---- one pass per value column: stage its values in LDS (the next column's loads go out first), walk, store
+    const int ncols = kMulti ? p.ncols : 1;
+    for (int c = 0; c < ncols; c++) {
+        if (kMulti) {
+            lds_order();  // the previous pass is done with sh.val / sh.vbits
+#pragma unroll
+            for (int j = 0; j < kChunksS; j++)
+                *reinterpret_cast<ulonglong2 *>(&sh.val[j * 128 + 2 * lane]) = make_ulonglong2(va[j], vb[j]);
+            if (c + 1 < ncols) load_col(reinterpret_cast<const uint64_t *>(p.values[c + 1]), va, vb);
+        }
+        if (kNulls && lane < kRowsS / 32) {  // 32 validity bits per lane, any bit offset (Arrow slices)
+            uint32_t word = 0xFFFFFFFFu;
+            if (p.vbits[c] != nullptr) {
+                const int64_t bit = p.vbit0[c] + base + 32 * (int64_t)lane;
+                const int64_t wi = bit >> 5;
+                const int shb = (int)(bit & 31);
+                const uint32_t lo = wi < p.vwords[c] ? p.vbits[c][wi] : 0u;
+                const uint32_t hi = (shb != 0 && wi + 1 < p.vwords[c]) ? p.vbits[c][wi + 1] : 0u;
+                word = shb ? ((lo >> shb) | (hi << (32 - shb))) : lo;
+            }
+            sh.vbits[lane] = word;
+        }
+        lds_order();
+
     for (int q = lane; q < nseg_owned; q += kWave) {
         const uint32_t e0 = sh.seg[q], e1 = sh.seg[q + 1];
         const int r0 = (int)(e0 & 0xFFFFu);
@@ -157,13 +171,15 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
             r1 = nloc;
             next_wid = W32;
         } else {
-            // rows run past the look-ahead: hand the window to the cooperative path
-            const unsigned idx = atomicAdd(&p.status[1], 1u);
-            if ((int64_t)idx < p.long_cap) {
-                p.long_list[2 * idx] = (int64_t)wid;
-                p.long_list[2 * idx + 1] = base + r0;
-            } else {
-                atomicOr(&p.status[2], 1u);
+            // rows run past the look-ahead: hand the window (all its columns) to the cooperative path
+            if (c == 0) {
+                const unsigned idx = atomicAdd(&p.status[1], 1u);
+                if ((int64_t)idx < p.long_cap) {
+                    p.long_list[2 * idx] = (int64_t)wid;
+                    p.long_list[2 * idx + 1] = base + r0;
+                } else {
+                    atomicOr(&p.status[2], 1u);
+                }
             }
             continue;
         }
@@ -203,13 +219,16 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
         const bool has_value = count > 0;  // (always true without nulls)
         const int64_t win_start = p.s0 + (int64_t)((uint64_t)wid * (uint64_t)(uint32_t)p.interval);
         if (wid >= W32) continue;  // (only on corrupt input)
-        // ---- outputs: lane q -> slot wid
+        const uint32_t gap = next_wid - wid - 1;
+        // ---- outputs of this column: lane q -> slot wid
 #pragma unroll
         for (int a = 0; a < kSimpleMaxAggs; a++) {
             if (a >= p.naggs) break;
+            if (kMulti && p.col[a] != c) continue;
             uint64_t bits;
             bool nil = false;
-            switch (p.kind[a]) {
+            const int k = p.kind[a];
+            switch (k) {
             case BOWGPU_AGG_WINDOW_START: bits = (uint64_t)win_start; break;
             case BOWGPU_AGG_SUM: bits = (uint64_t)__double_as_longlong(sum); break;
             case BOWGPU_AGG_MEAN: bits = (uint64_t)__double_as_longlong(sum / (double)(int64_t)count); nil = !has_value; break;
@@ -225,23 +244,18 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
                 atomicAnd(&p.out_valid[a][wid >> 5], ~(1u << (wid & 31)));
             }
             p.out_values[a][wid] = bits;
-        }
-        // ---- the empty windows right after this one (rare): values of an empty slice + cleared validity bits
-        const uint32_t gap = next_wid - wid - 1;
-        if (gap != 0) {
+            // the empty windows right after this one (rare): values of an empty slice + cleared validity bits
+            // (A.9 "Empty slice": WindowStart s_k ; Sum 0.0 ; Count 0 ; NumRows 0.0 ; the rest nil)
             for (uint32_t g = 1; g <= gap; g++) {
                 const uint32_t gw = wid + g;
                 if (gw >= W32) break;
                 const int64_t gstart = p.s0 + (int64_t)((uint64_t)gw * (uint64_t)(uint32_t)p.interval);
-                for (int a = 0; a < p.naggs; a++) {
-                    const int k = p.kind[a];
-                    // A.9 "Empty slice": WindowStart s_k ; Sum 0.0 ; Count 0 ; NumRows 0.0 ; the rest nil (slot 0, bit cleared)
-                    p.out_values[a][gw] = k == BOWGPU_AGG_WINDOW_START ? (uint64_t)gstart : 0ull;
-                    if (p.out_valid[a]) atomicAnd(&p.out_valid[a][gw >> 5], ~(1u << (gw & 31)));
-                }
+                p.out_values[a][gw] = k == BOWGPU_AGG_WINDOW_START ? (uint64_t)gstart : 0ull;
+                if (p.out_valid[a]) atomicAnd(&p.out_valid[a][gw >> 5], ~(1u << (gw & 31)));
             }
         }
     }
+    }  // columns
 }
 
 int launch_rolling_simple(Ctx *c, const SimpleParams &p, int need, bool is_int, bool has_nulls) {
@@ -251,7 +265,11 @@ int launch_rolling_simple(Ctx *c, const SimpleParams &p, int need, bool is_int, 
     const int64_t grid = per_xcd * 8;
     if (grid > 0x7FFFFFFFll) return fail(BOWGPU_ERR_UNSUPPORTED, "too many rows for one launch: %lld", (long long)p.n);
     const dim3 g((unsigned)grid), blk(kWave);
-#define BG_LAUNCH(N, I, U) hipLaunchKernelGGL((rolling_simple_kernel<N, I, U>), g, blk, 0, c->stream, p, ntiles, per_xcd)
+#define BG_LAUNCH(N, I, U)                                                                                                  \
+    do {                                                                                                                    \
+        if (p.ncols > 1) hipLaunchKernelGGL((rolling_simple_kernel<N, I, U, true>), g, blk, 0, c->stream, p, ntiles, per_xcd);  \
+        else hipLaunchKernelGGL((rolling_simple_kernel<N, I, U, false>), g, blk, 0, c->stream, p, ntiles, per_xcd);          \
+    } while (0)
 #define BG_NEED(I, U)                                                                                   \
     switch (need) { case 0: BG_LAUNCH(0, I, U); break; case 1: BG_LAUNCH(1, I, U); break;              \
                     case 2: BG_LAUNCH(2, I, U); break; default: BG_LAUNCH(3, I, U); break; }
