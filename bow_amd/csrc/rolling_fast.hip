@@ -491,7 +491,9 @@ int launch_rolling_fast(Ctx *c, const AggParams &p) {
     if (p.n <= 0) return 0;
     const int64_t ntiles = (p.n + kTileW - 1) / kTileW;
     const int64_t per_xcd = (ntiles + 7) / 8;
-    int persist = 1;
+    // The persistent variant (each wave prefetches its next tile) measured SLOWER than one tile per wave on MI355X
+    // (4.24 vs 3.78 ms at 1e9 rows: fewer resident waves at 127 VGPRs); kept behind BOWGPU_FAST_PERSIST=1 for experiments.
+    int persist = 0;
     if (const char *e = getenv("BOWGPU_FAST_PERSIST")) persist = atoi(e);
     if (persist && ntiles >= 256 * 16 * 4) {
         // 16 resident waves per CU, each walking its tiles with the next one prefetched
