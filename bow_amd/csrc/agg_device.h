@@ -194,6 +194,22 @@ __device__ __forceinline__ bool kind_is_integral(int kind) {
 }
 
 
+// ---------------------------------------------------------------- the queue of long windows
+// A tile queues at most one window (the one still open at the end of its look-ahead).  kLongLists sub-lists with their
+// own counters (status[16 + s]) keep the appends off a single contended address: 1e5 appends to ONE counter cost ~1 ms.
+__device__ __forceinline__ void push_long_window(uint32_t *status, int64_t *long_list, int64_t sub_cap, int64_t tile,
+                                                 uint64_t wid, int64_t row) {
+    const int64_t s = tile & (kLongLists - 1);
+    const unsigned idx = atomicAdd(&status[kLongCountWord + s], 1u);
+    if ((int64_t)idx < sub_cap) {
+        int64_t *e = long_list + 2 * (s * sub_cap + (int64_t)idx);
+        e[0] = (int64_t)wid;
+        e[1] = row;
+    } else {
+        atomicOr(&status[2], 1u);
+    }
+}
+
 // ---------------------------------------------------------------- loads
 __device__ __forceinline__ void load_pair(const uint64_t *__restrict__ p, int64_t g, int64_t n, bool vec,
                                           uint64_t &a, uint64_t &b) {

@@ -523,13 +523,15 @@ static int job_build(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t ts_c
     }
 
     // status words + long-window list
-    const int64_t ntiles = (n + 511) / 512;  // the lean kernel's tile (one wavefront); at most one long window per tile
-    job->scratch_bytes = 8192 + (size_t)(ntiles + 1) * 16;
+    // at most one long window per tile (the lean kernels' tile = 512 rows), spread over kLongLists sub-lists
+    const int64_t ntiles = (n + 511) / 512;
+    const int64_t sub_cap = ntiles / kLongLists + 2;
+    job->scratch_bytes = 8192 + (size_t)sub_cap * kLongLists * 16;
     void *dscr;
     BG_TRY(ctx_scratch(c, job->scratch_bytes, &dscr));
     P.status = reinterpret_cast<uint32_t *>(dscr);
     P.long_list = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(dscr) + 8192);
-    P.long_cap = ntiles + 1;
+    P.long_cap = sub_cap;
     return 0;
 }
 
@@ -541,7 +543,7 @@ static int job_enqueue_tail(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t
     uint64_t *dcnt = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(d) + 1024);
     uint64_t *hcnt;
     BG_TRY(ctx_pinned(c, 4096, reinterpret_cast<void **>(&hcnt)));
-    hcnt += 8;
+    hcnt += 64;  // behind the status words, which share the pinned block
     *hcnt_out = hcnt;
     if (W > 0)
         for (int i = 0; i < naggs; i++) {
@@ -588,7 +590,7 @@ static int job_launch_tiles(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t
     AggParams &P = job->P;
     const int64_t W = job->W;
     *used_simple = false;
-    BG_HIP(hipMemsetAsync(P.status, 0, 64, c->stream));
+    BG_HIP(hipMemsetAsync(P.status, 0, kStatusWords * 4, c->stream));
     if (W <= 0) return 0;
     // The lean kernels cover exclusive windows without time-weighted reducers and without rows below s0; everything
     // else (and BOWGPU_FORCE_GENERAL=1, used by the tests to cover all of them) takes the general kernel.
@@ -642,6 +644,35 @@ static int job_launch_tiles(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t
     return 0;
 }
 
+// Windows longer than a tile's look-ahead: workspace from the context pool, then long_windows.hip
+static int run_long_windows(Ctx *c, const AggParams &P, const uint32_t *hstat, int64_t *n_long_out) {
+    LongListStarts starts;
+    starts.start[0] = 0;
+    for (int s = 0; s < kLongLists; s++) starts.start[s + 1] = starts.start[s] + hstat[kLongCountWord + s];
+    const int64_t n_long = starts.start[kLongLists];
+    *n_long_out = n_long;
+    if (n_long == 0) return 0;
+    const int64_t max_work = n_long + (P.n + kLongChunkRows - 1) / kLongChunkRows;
+    const int64_t scan_blocks = (n_long + 2047) / 2048;
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t b_entries = up((size_t)n_long * long_entry_size());
+    const size_t b_nchunks = up((size_t)n_long * 4);
+    const size_t b_offsets = up((size_t)(n_long + 1) * 8);
+    const size_t b_sums = up((size_t)(scan_blocks + 1) * 8);
+    const size_t b_parts = up((size_t)max_work * (size_t)(P.ncols > 0 ? P.ncols : 1) * long_part_size());
+    void *w;
+    const size_t b_map = up((size_t)max_work * 4);
+    BG_TRY(ctx_pool(c, Ctx::kPoolSlots - 1, b_entries + b_nchunks + b_offsets + b_sums + 256 + b_map + b_parts, &w));
+    char *q = reinterpret_cast<char *>(w);
+    void *entries = q; q += b_entries;
+    int32_t *nchunks = reinterpret_cast<int32_t *>(q); q += b_nchunks;
+    int64_t *offsets = reinterpret_cast<int64_t *>(q); q += b_offsets;
+    int64_t *sums = reinterpret_cast<int64_t *>(q); q += b_sums;
+    int64_t *total = reinterpret_cast<int64_t *>(q); q += 256;
+    int32_t *work_entry = reinterpret_cast<int32_t *>(q); q += b_map;
+    return launch_long_windows_v2(c, P, starts, entries, nchunks, offsets, sums, total, work_entry, q, max_work);
+}
+
 static int job_run(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, int64_t *long_windows, double *kernel_ms,
                    bool finish, const Plan *plan = nullptr) {
     AggParams &P = job->P;
@@ -652,7 +683,7 @@ static int job_run(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, i
     // the common case needs ONE synchronisation; if windows were queued for the cooperative path, run it and redo the tail.
     uint32_t *hstat;
     BG_TRY(ctx_pinned(c, 4096, reinterpret_cast<void **>(&hstat)));
-    BG_HIP(hipMemcpyAsync(hstat, P.status, 32, hipMemcpyDeviceToHost, c->stream));
+    BG_HIP(hipMemcpyAsync(hstat, P.status, kStatusWords * 4, hipMemcpyDeviceToHost, c->stream));
     uint64_t *hcnt = nullptr;
     if (finish) BG_TRY(job_enqueue_tail(c, job, aggs, naggs, &hcnt));
     BG_HIP(hipStreamSynchronize(c->stream));
@@ -660,15 +691,15 @@ static int job_run(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, i
     if (used_simple && hstat[4]) {
         // some tile needs window ids the simple kernel cannot encode: redo the call with the general lean kernel
         BG_TRY(job_launch_tiles(c, job, aggs, naggs, plan, false, &used_simple));
-        BG_HIP(hipMemcpyAsync(hstat, P.status, 32, hipMemcpyDeviceToHost, c->stream));
+        BG_HIP(hipMemcpyAsync(hstat, P.status, kStatusWords * 4, hipMemcpyDeviceToHost, c->stream));
         if (finish) BG_TRY(job_enqueue_tail(c, job, aggs, naggs, &hcnt));
         BG_HIP(hipStreamSynchronize(c->stream));
         if (hstat[0]) return fail(BOWGPU_ERR_TS_UNSORTED, "interval column is not ascending: outside the device path");
     }
     if (hstat[2]) return fail(BOWGPU_ERR_HIP, "internal: long-window list overflow");
-    const int64_t n_long = hstat[1];
+    int64_t n_long = 0;
+    BG_TRY(run_long_windows(c, P, hstat, &n_long));
     if (n_long > 0) {
-        BG_TRY(launch_long_windows(c, P, n_long));
         if (finish) {
             BG_TRY(job_enqueue_tail(c, job, aggs, naggs, &hcnt));
             BG_HIP(hipStreamSynchronize(c->stream));

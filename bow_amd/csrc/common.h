@@ -174,7 +174,7 @@ struct AggParams {
     int32_t bits_preset;    // output bitmaps start as all-ones (rolling_simple.hip): the long-window path clears empties instead of setting valids
     // status block in device memory
     uint32_t *status;       // [0]=unsorted flag, [1]=long-window count, [2]=overflow flag
-    int64_t *long_list;     // pairs (global window id, first row)
+    int64_t *long_list;     // kLongLists sub-lists of pairs (global window id, first row), long_cap pairs each
     int64_t long_cap;
 };
 
@@ -202,7 +202,15 @@ int launch_rolling_simple(Ctx *c, const SimpleParams &p, int need, bool is_int, 
 
 int launch_rolling_aggregate(Ctx *c, const AggParams &p);   // general kernel (rolling_agg.hip)
 int launch_rolling_fast(Ctx *c, const AggParams &p);        // lean kernel for exclusive windows without time-weighted reducers (rolling_fast.hip)
-int launch_long_windows(Ctx *c, const AggParams &p, int64_t n_long);
+constexpr int kLongChunkRows = 8192;
+constexpr int kLongLists = 64;      // sub-lists of the long-window queue (agg_device.h push_long_window)
+constexpr int kLongCountWord = 16;  // status[kLongCountWord + s] = entries in sub-list s
+constexpr int kStatusWords = kLongCountWord + kLongLists;
+struct LongListStarts { int64_t start[kLongLists + 1]; };  // prefix sums of the sub-list counts (host side)
+size_t long_entry_size();
+size_t long_part_size();
+int launch_long_windows_v2(Ctx *c, const AggParams &p, const LongListStarts &starts, void *entries, int32_t *nchunks, int64_t *offsets,
+                           int64_t *block_sums, int64_t *d_total, int32_t *work_entry, void *partials, int64_t max_work);
 int launch_fix_tail_bits(Ctx *c, uint8_t *bitmap, int64_t nbits);
 int launch_popcount(Ctx *c, const uint32_t *words, int64_t bit0, int64_t nbits, uint64_t *d_count);
 

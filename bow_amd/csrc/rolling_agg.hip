@@ -18,7 +18,7 @@
 //   4. outputs: 8-B coalesced stores (lane q -> window slot wid(q)); validity bits are
 //      assembled in an LDS bitmap and flushed as whole words (atomicOr only on the two
 //      boundary words shared with the neighbouring tiles).
-// Windows whose rows run past TILE+HALO are queued for long_window_kernel (cooperative,
+// Windows whose rows run past TILE+HALO are queued for long_windows.hip (cooperative,
 // fixed-shape tree order: Sum/Mean/Integral within 1e-12 relative; the rest bit-exact).
 //
 // HBM-bound: algorithmic bytes = 8 (ts) + 8 per value column (+1/8 per nullable column) per row.
@@ -261,13 +261,7 @@ __global__ __launch_bounds__(kBlock) void rolling_agg_kernel(const AggParams p, 
             if (!complete) {
                 // rows run past the halo: hand the window (all its column passes) to the cooperative path
                 if (!first_pass) continue;
-                const unsigned idx = atomicAdd(&p.status[1], 1u);
-                if ((int64_t)idx < p.long_cap) {
-                    p.long_list[2 * idx] = (int64_t)wid;
-                    p.long_list[2 * idx + 1] = base + r0;
-                } else {
-                    atomicOr(&p.status[2], 1u);
-                }
+                push_long_window(p.status, p.long_list, p.long_cap, tile, wid, base + r0);
                 continue;
             }
             const bool incl_row = p.inclusive && (q + 1 < nseg_total) && next_at_start && next_wid == wid + 1;
@@ -411,132 +405,6 @@ __global__ __launch_bounds__(kBlock) void rolling_agg_kernel(const AggParams p, 
     }
 }
 
-// ---------------------------------------------------------------- cooperative long windows
-// One workgroup per queued window: thread t walks a contiguous 1/256th of the rows in row
-// order, the 256 partial states are merged in thread order.  Deterministic, but Sum / Mean /
-// Integral are no longer accumulated strictly left to right (|err| <= 1e-12 relative).
-__global__ __launch_bounds__(kBlock) void long_window_kernel(const AggParams p, const int64_t n_long) {
-    __shared__ Stats part[kBlock];
-    __shared__ int64_t s_end;
-    const int tid = threadIdx.x;
-    const int64_t wid_end = p.wid_base + p.W;
-
-    for (int64_t e = blockIdx.x; e < n_long; e += gridDim.x) {
-        const uint64_t wid = (uint64_t)p.long_list[2 * e];
-        const int64_t r0 = p.long_list[2 * e + 1];
-        const int64_t win_start = p.s0 + (int64_t)(wid * (uint64_t)p.interval);
-        if (tid == 0) {
-            // first row >= r0 with ts >= win_start + interval (rolling.go:197-209), by bisection
-            int64_t lo = r0 + 1, hi = p.n;
-            const int64_t lim = win_start + p.interval;
-            const bool ovf = lim < win_start;  // int64 overflow: no row can reach it
-            while (lo < hi && !ovf) {
-                const int64_t mid = lo + ((hi - lo) >> 1);
-                if (p.ts[mid] >= lim) hi = mid; else lo = mid + 1;
-            }
-            s_end = ovf ? p.n : lo;
-        }
-        __syncthreads();
-        const int64_t r1 = s_end;
-        uint64_t next_wid = (uint64_t)wid_end;
-        bool next_at_start = false;
-        if (r1 < p.n) {
-            const int64_t t = p.ts[r1];
-            next_wid = magic_div((uint64_t)t - (uint64_t)p.s0, p.magic);
-            next_at_start = (t == p.s0 + (int64_t)(next_wid * (uint64_t)p.interval));
-        }
-        const bool incl_row = p.inclusive && r1 < p.n && next_at_start && next_wid == wid + 1;
-        const int64_t oslot = (int64_t)(wid - (uint64_t)p.wid_base);
-        const bool dead = p.pre_rows && r0 == 0 && !(p.ts[r1 - 1] >= p.s0 || incl_row);
-        const int64_t len = dead ? 0 : r1 - r0;
-        const int64_t lo_r = r0 + (len * tid) / kBlock, hi_r = r0 + (len * (tid + 1)) / kBlock;
-
-        for (int slot = -1; slot < p.ncols; slot++) {
-            unsigned my_mask = 0;
-            bool need_vals = false, need_ts = false;
-            for (int a = 0; a < p.naggs; a++) {
-                if (p.aggs[a].slot != slot) continue;
-                my_mask |= 1u << a;
-                const int k = p.aggs[a].kind;
-                need_vals |= !(k == BOWGPU_AGG_WINDOW_START || k == BOWGPU_AGG_NUM_ROWS);
-                need_ts |= kind_is_integral(k);
-            }
-            if (my_mask == 0) continue;
-            const ColDesc *cd = slot >= 0 ? &p.cols[slot] : nullptr;
-            const int col_type = cd ? cd->type : BOWGPU_INT64;
-            Stats st;
-            stats_init(st);
-            if (cd && need_vals) {
-                const uint64_t *vp = reinterpret_cast<const uint64_t *>(cd->values);
-                for (int64_t r = lo_r; r < hi_r; r++) {
-                    if (cd->vbits) {
-                        const int64_t bit = cd->vbit0 + r;
-                        if (!((cd->vbits[bit >> 5] >> (bit & 31)) & 1u)) continue;
-                    }
-                    const uint64_t raw = vp[r];
-                    const double x = bits_to_f64(raw, col_type);
-                    stats_value<true>(st, x, raw);
-                    if (need_ts) stats_point(st, (double)p.ts[r], x);
-                }
-            }
-            __syncthreads();
-            part[tid] = st;
-            __syncthreads();
-            if (tid == 0) {
-                Stats acc = part[0];
-                for (int t = 1; t < kBlock; t++) stats_merge(acc, part[t]);
-                Stats acc_incl = acc;
-                if (incl_row && cd && need_vals) {
-                    bool ok = true;
-                    if (cd->vbits) {
-                        const int64_t bit = cd->vbit0 + r1;
-                        ok = (cd->vbits[bit >> 5] >> (bit & 31)) & 1u;
-                    }
-                    if (ok) {
-                        const uint64_t raw = reinterpret_cast<const uint64_t *>(cd->values)[r1];
-                        const double x = bits_to_f64(raw, col_type);
-                        Stats one;
-                        stats_init(one);
-                        stats_value<true>(one, x, raw);
-                        stats_point(one, (double)p.ts[r1], x);
-                        stats_merge(acc_incl, one);
-                    }
-                }
-                if (oslot >= 0 && oslot < p.W) {
-                    for (unsigned m = my_mask; m; m &= m - 1) {
-                        const AggDesc &a = p.aggs[__ffs(m) - 1];
-                        const bool inc = kind_needs_inclusive(a.kind);
-                        Val v = reduce_val(a.kind, inc ? acc_incl : acc, inc ? len + (incl_row ? 1 : 0) : len,
-                                           win_start, p.interval, col_type == BOWGPU_INT64);
-                        v = finish_val(v, a);
-                        reinterpret_cast<uint64_t *>(a.out_values)[oslot] = v.bits;
-                        if (a.out_valid) {
-                            if (v.valid) atomicOr(&a.out_valid[oslot >> 5], 1u << (oslot & 31));
-                            else if (p.bits_preset) atomicAnd(&a.out_valid[oslot >> 5], ~(1u << (oslot & 31)));
-                        }
-                    }
-                }
-            }
-            // empty windows after this one
-            const int64_t gap = (int64_t)(next_wid - wid) - 1;
-            Stats em;
-            stats_init(em);
-            for (int64_t gk = 1 + tid; gk <= gap; gk += kBlock) {
-                const int64_t gs = oslot + gk;
-                if (gs < 0 || gs >= p.W) break;
-                const int64_t gstart = win_start + gk * p.interval;
-                for (unsigned m = my_mask; m; m &= m - 1) {
-                    const AggDesc &a = p.aggs[__ffs(m) - 1];
-                    Val v = finish_val(reduce_val(a.kind, em, 0, gstart, p.interval, col_type == BOWGPU_INT64), a);
-                    reinterpret_cast<uint64_t *>(a.out_values)[gs] = v.bits;
-                    if (p.bits_preset && a.out_valid && !v.valid) atomicAnd(&a.out_valid[gs >> 5], ~(1u << (gs & 31)));
-                }
-            }
-        }
-        __syncthreads();
-    }
-}
-
 // ---------------------------------------------------------------- small helpers
 __global__ void fix_tail_bits_kernel(uint8_t *bitmap, int64_t nbits) {
     // Arrow/bow leave the padding bits of the last byte clear (bowbuffer.go:25, bitutil.SetBit)
@@ -575,14 +443,6 @@ int launch_rolling_aggregate(Ctx *c, const AggParams &p) {
     for (int a = 0; a < p.naggs; a++) with_ts |= (p.aggs[a].kind >= BOWGPU_AGG_INTEGRAL_STEP && p.aggs[a].kind <= BOWGPU_AGG_WAVG_LINEAR);
     if (with_ts) hipLaunchKernelGGL(rolling_agg_kernel<true>, dim3((unsigned)grid), dim3(kBlock), 0, c->stream, p, ntiles, per_xcd);
     else hipLaunchKernelGGL(rolling_agg_kernel<false>, dim3((unsigned)grid), dim3(kBlock), 0, c->stream, p, ntiles, per_xcd);
-    BG_HIP(hipGetLastError());
-    return 0;
-}
-
-int launch_long_windows(Ctx *c, const AggParams &p, int64_t n_long) {
-    if (n_long <= 0) return 0;
-    const unsigned grid = (unsigned)(n_long < 4096 ? n_long : 4096);
-    hipLaunchKernelGGL(long_window_kernel, dim3(grid), dim3(kBlock), 0, c->stream, p, n_long);
     BG_HIP(hipGetLastError());
     return 0;
 }

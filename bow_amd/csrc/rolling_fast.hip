@@ -371,13 +371,7 @@ __global__ __launch_bounds__(kWave, kPersist ? 4 : 5) void rolling_wave_kernel(c
             } else {
                 // rows run past the look-ahead: hand the window (all its column passes) to the cooperative path
                 if (first_pass) {
-                    const unsigned idx = atomicAdd(&p.status[1], 1u);
-                    if ((int64_t)idx < p.long_cap) {
-                        p.long_list[2 * idx] = (int64_t)wid;
-                        p.long_list[2 * idx + 1] = base + r0;
-                    } else {
-                        atomicOr(&p.status[2], 1u);
-                    }
+                    push_long_window(p.status, p.long_list, p.long_cap, tile, wid, base + r0);
                 }
                 continue;
             }

@@ -173,13 +173,7 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
         } else {
             // rows run past the look-ahead: hand the window (all its columns) to the cooperative path
             if (c == 0) {
-                const unsigned idx = atomicAdd(&p.status[1], 1u);
-                if ((int64_t)idx < p.long_cap) {
-                    p.long_list[2 * idx] = (int64_t)wid;
-                    p.long_list[2 * idx + 1] = base + r0;
-                } else {
-                    atomicOr(&p.status[2], 1u);
-                }
+                push_long_window(p.status, p.long_list, p.long_cap, tile, wid, base + r0);
             }
             continue;
         }
@@ -191,15 +185,20 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
             first_raw = sh.val[r0];
             mn = kInt ? (double)(int64_t)first_raw : __longlong_as_double((long long)first_raw);
             mx = mn;
-            for (int r = r0; r < r1; r++) {
-                const uint64_t raw = sh.val[r];
+            auto step = [&](uint64_t raw) {
                 const double x = kInt ? (double)(int64_t)raw : __longlong_as_double((long long)raw);
                 sum += x;
                 if (kNeed & 1) {
                     if (x < mn) mn = x;
                     if (x > mx) mx = x;
                 }
+            };
+            int r = r0;
+            for (; r + 4 <= r1; r += 4) {  // four LDS reads in flight; the additions stay in row order
+                const uint64_t q0 = sh.val[r], q1 = sh.val[r + 1], q2 = sh.val[r + 2], q3 = sh.val[r + 3];
+                step(q0); step(q1); step(q2); step(q3);
             }
+            for (; r < r1; r++) step(sh.val[r]);
             count = r1 - r0;
             if (kNeed & 2) last_raw = sh.val[r1 - 1];
         } else {

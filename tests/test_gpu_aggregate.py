@@ -280,6 +280,46 @@ def test_long_windows_cooperative_path():
             compare("%s I=%d" % (k, interval), g, w, exact=k not in ORDER_SENSITIVE, rtol=1e-11)
 
 
+@pytest.mark.parametrize("inclusive", [False, True])
+def test_long_windows_mixed_shapes(inclusive):
+    """Windows of 1 .. 60k rows side by side (several 8192-row chunks, chunk boundaries inside null runs), runs of empty
+    windows after long ones, an all-null long window, NaN seeds and -0.0/+0.0 ties for Min/Max, an Int64 column, two
+    value columns - through the multi-workgroup long-window path of every tile kernel."""
+    rng = np.random.default_rng(77 + inclusive)
+    interval = 1000
+    pieces, t = [], -5000
+    for rows in (3, 700, 1, 9000, 60_000, 12, 2500, 8192, 8193, 40, 20_000, 641, 5):
+        # `rows` rows spread inside one window, then skip 0..3 windows
+        offs = np.sort(rng.integers(0, interval, rows))
+        if inclusive and rows > 1:
+            offs[0] = 0  # a row exactly on the window start => the previous window is inclusive
+        pieces.append(t + offs)
+        t += interval * int(rng.integers(1, 5))
+    ts = np.concatenate(pieces).astype(np.int64)
+    n = len(ts)
+    f, fvalid = make_vals(rng, n, "f64", 0.25)
+    f[rng.random(n) < 0.001] = np.nan
+    f[rng.random(n) < 0.01] = 0.0
+    f[rng.random(n) < 0.01] = -0.0
+    i, ivalid = make_vals(rng, n, "i64", 0.1)
+    # the 20_000-row window: all null in the float column; the 9000-row one: first valid value NaN
+    starts = np.cumsum([0] + [len(p) for p in pieces])
+    fvalid[starts[10]:starts[11]] = False
+    fvalid[starts[3]] = True
+    f[starts[3]] = np.nan
+    # a null run across a chunk boundary of the 60k window
+    fvalid[starts[4] + 8192 - 40:starts[4] + 8192 + 40] = False
+    aggs = ([(k, 0 if k == "WindowStart" else 1) for k in ALL_AGGS] + [(k, 1) for k in TIME_AGGS] +
+            [(k, 2) for k in ("Sum", "Min", "IntegralTrapezoid")])
+    outs, exp, info = run_both(ts, [(f, fvalid), (i, ivalid)], interval, aggs, inclusive=inclusive)
+    assert info.long_windows >= 5
+    # the simple / lean kernels only take exclusive windows without time-weighted reducers: cover them too
+    if not inclusive:
+        aggs2 = [(k, 0 if k == "WindowStart" else 1) for k in ALL_AGGS] + [(k, 2) for k in ("Sum", "Min", "Max", "Last")]
+        outs, exp, info = run_both(ts, [(f, fvalid), (i, ivalid)], interval, aggs2)
+        assert info.long_windows >= 5
+
+
 def test_declines_unsorted_and_null_timestamps():
     ts = np.array([1, 5, 3, 9, 12, 20], dtype=np.int64)
     v = np.arange(6, dtype=np.float64)
