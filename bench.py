@@ -53,7 +53,7 @@ def cpu_baseline(capi, rows_sample):
                       "reference's time), %.1f s" % (reps, rows_sample, INTERVAL, dt)}
 
 
-def measured_traffic(rows):
+def measured_traffic(rows, kernel=None):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/r*_pmc_hbm_traffic_bench_1e9.csv: FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, in KB), when they were
     collected for this row count; None otherwise (PMC cannot be collected from inside the timed run)."""
@@ -66,6 +66,8 @@ def measured_traffic(rows):
         return None
     f, w = [], []
     for r in csv.DictReader(open(files[-1])):
+        if kernel and r["kernel"] != kernel:
+            continue  # counters of another kernel (an older build): not this run's traffic
         (f if r["counter"] == "FETCH_SIZE" else w).append(float(r["value_KB"]))
     if not f or not w:
         return None
@@ -149,6 +151,7 @@ def main():
         total_rows = rows * world * args.steps
         value = total_rows / dt
         k_ms = sum(kernel_ms) / len(kernel_ms)
+        kernel_name = capi.last_kernel_name()
         achieved = rows * BYTES_PER_ROW / (k_ms * 1e-3) / 1e9
         line = {
             "metric": "rows/sec rolling-mean on 1B-row float64",
@@ -169,11 +172,11 @@ def main():
                        "rows_per_gpu": rows, "windows_per_gpu": rows // interval, "parallelism": "rows range-partitioned x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "rolling_simple_kernel" if world == 1 else "rolling_wave_kernel", "kernel_ms": k_ms,
+                         "kernel": kernel_name, "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": rows * BYTES_PER_ROW},
             "device": capi.device_name(),
         }
-        line["roofline"]["traffic"] = measured_traffic(rows)
+        line["roofline"]["traffic"] = measured_traffic(rows, kernel_name)
         if not args.no_cpu and world == 1:
             try:
                 line["cpu_baseline"] = cpu_baseline(capi, min(args.cpu_sample, rows))

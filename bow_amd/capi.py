@@ -85,7 +85,7 @@ class ShardCarry(C.Structure):
 # every symbol include/bowgpu.h declares (checked by tests/test_abi_symbols.py)
 SYMBOLS = [
     "bowgpu_abi_version", "bowgpu_last_error", "bowgpu_device_count", "bowgpu_set_device", "bowgpu_device_name",
-    "bowgpu_set_stream", "bowgpu_synchronize", "bowgpu_last_kernel_ms", "bowgpu_malloc", "bowgpu_free", "bowgpu_memcpy_h2d",
+    "bowgpu_set_stream", "bowgpu_synchronize", "bowgpu_last_kernel_ms", "bowgpu_last_kernel_name", "bowgpu_malloc", "bowgpu_free", "bowgpu_memcpy_h2d",
     "bowgpu_memcpy_d2h", "bowgpu_memset", "bowgpu_timer_create", "bowgpu_timer_start", "bowgpu_timer_stop",
     "bowgpu_timer_elapsed_ms", "bowgpu_timer_destroy", "bowgpu_enforce_interval_and_offset", "bowgpu_plan_windows",
     "bowgpu_rolling_aggregate", "bowgpu_window_bounds", "bowgpu_aggregate_whole",
@@ -106,6 +106,7 @@ def lib():
                           "(make -C bow_amd/csrc). The bowgpu path has no CPU fallback." % LIB_PATH)
         L = C.CDLL(LIB_PATH)
         L.bowgpu_last_error.restype = C.c_char_p
+        L.bowgpu_last_kernel_name.restype = C.c_char_p
         _lib = L
     return _lib
 
@@ -302,6 +303,10 @@ def set_stream(ptr):
 
 def synchronize():
     check(lib().bowgpu_synchronize())
+
+
+def last_kernel_name():
+    return lib().bowgpu_last_kernel_name().decode()
 
 
 def last_kernel_ms():

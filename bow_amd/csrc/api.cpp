@@ -560,9 +560,11 @@ static int job_enqueue_tail(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t
 static bool simple_applies(const AggJob *job, const bowgpu_agg *aggs, int32_t naggs, const Plan &plan, int *need, bool *is_int,
                            bool *has_nulls) {
     const AggParams &P = job->P;
-    if (job->inclusive || P.pre_rows || P.wid_base != 0 || !P.fits32 || naggs > kSimpleMaxAggs) return false;
+    if (job->inclusive || P.pre_rows || !P.fits32 || naggs > kSimpleMaxAggs) return false;
     if (P.W <= 0 || P.W >= 0xFFFFFFF0ll) return false;
-    if ((uint64_t)plan.last_ts - (uint64_t)plan.s0 >= 0xFFFFFFF0ull) return false;
+    // output slot 0 starts at s0 + wid_base * interval (wid_base != 0: a shard; it never lies above the shard's first row)
+    const int64_t slot0_start = P.s0 + (int64_t)((uint64_t)P.wid_base * (uint64_t)P.interval);
+    if (plan.first_ts < slot0_start || (uint64_t)plan.last_ts - (uint64_t)slot0_start >= 0xFFFFFFF0ull) return false;
     if (reinterpret_cast<uintptr_t>(P.ts) & 15) return false;
     *need = 0;
     *is_int = true;  // (reducers over the interval column itself)
@@ -617,7 +619,9 @@ static int job_launch_tiles(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t
         SimpleParams S;
         memset(&S, 0, sizeof S);
         S.ts = P.ts;
-        S.n = P.n; S.s0 = P.s0; S.interval = P.interval; S.W = P.W;
+        S.n = P.n; S.interval = P.interval; S.W = P.W;
+        S.wid_base = P.wid_base;
+        S.s0 = P.s0 + (int64_t)((uint64_t)P.wid_base * (uint64_t)P.interval);
         S.m32 = P.m32; S.sh1 = P.sh1_32; S.sh2 = P.sh2_32;
         S.naggs = naggs;
         S.ncols = P.ncols > 0 ? P.ncols : 1;
@@ -635,10 +639,13 @@ static int job_launch_tiles(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t
         S.status = P.status; S.long_list = P.long_list; S.long_cap = P.long_cap;
         BG_TRY(launch_rolling_simple(c, S, need, is_int, has_nulls));
         *used_simple = true;
+        c->last_kernel_name = "rolling_simple_kernel";
     } else if (lean) {
         BG_TRY(launch_rolling_fast(c, P));
+        c->last_kernel_name = "rolling_wave_kernel";
     } else {
         BG_TRY(launch_rolling_aggregate(c, P));
+        c->last_kernel_name = "rolling_agg_kernel";
     }
     BG_HIP(hipEventRecord(c->ev1, c->stream));
     return 0;
@@ -795,6 +802,12 @@ int bowgpu_synchronize(void) {
     BG_TRY(ctx_get(&c));
     BG_HIP(hipStreamSynchronize(c->stream));
     return 0;
+}
+
+const char *bowgpu_last_kernel_name(void) {
+    Ctx *c;
+    if (ctx_get(&c) != 0) return "";
+    return c->last_kernel_name;
 }
 
 int bowgpu_last_kernel_ms(double *ms) {
@@ -998,7 +1011,7 @@ int bowgpu_shard_aggregate(const bowgpu_col *cols, int32_t ncols, int32_t ts_col
     if (lead < 0 || (wf < 0 && lead != 0) || (wf >= 0 && lead > wf)) return fail(BOWGPU_ERR_ARG, "bad lead_empty_windows %lld", (long long)lead);
     const int64_t Wtot = plan.W + lead;
     BG_TRY(job_build(c, cols, ncols, ts_col, plan, 0, aggs, naggs, outs, wf < 0 ? 0 : wf - lead, Wtot, holds_global_row0 != 0, &job));
-    BG_TRY(job_run(c, &job, aggs, naggs, nullptr, nullptr, false));
+    BG_TRY(job_run(c, &job, aggs, naggs, nullptr, nullptr, false, &plan));
     if (lead > 0) BG_TRY(launch_fill_empty(c, job.P, 0, lead));
     if (plan.W > 0) {
         // running state of the last window over this shard's rows

@@ -41,6 +41,7 @@ struct Ctx {
     size_t h_pinned_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double last_kernel_ms = 0.0;
+    const char *last_kernel_name = "";  // the tile kernel last_kernel_ms brackets
     // grow-only pool of temporaries reused across calls (word-aligned validity working copies, ...):
     // hipMalloc / hipFree per call cost more than the kernels' fixed overhead
     static constexpr int kPoolSlots = 40;
@@ -182,7 +183,8 @@ constexpr int kSimpleMaxAggs = 12;
 // descriptor of rolling_simple.hip's kernel: value columns of one type, factor-free outputs, 32-bit window ids
 struct SimpleParams {
     const int64_t *ts;
-    int64_t n, s0, interval, W;
+    int64_t n, s0, interval, W;            // s0 = start of output slot 0 (a shard: global s0 + wid_base * interval)
+    int64_t wid_base;                      // global id of output slot 0 (only for the long-window queue)
     uint32_t m32, sh1, sh2;
     int32_t naggs;
     int32_t ncols;                         // value columns (>= 1; reducers over the interval column use it as a column)
@@ -194,7 +196,7 @@ struct SimpleParams {
     int32_t col[kSimpleMaxAggs];           // column slot each output reads (WindowStart / NumRows ride with slot 0)
     uint64_t *out_values[kSimpleMaxAggs];
     uint32_t *out_valid[kSimpleMaxAggs];   // nullptr for never-nil reducers; all bitmaps are preset to ones by the host
-    uint32_t *status;         // [0] unsorted, [1] long-window count, [2] list overflow, [4] redo with the general lean kernel
+    uint32_t *status;         // [0] unsorted, [2] list overflow, [4] redo with the general lean kernel, [16..79] long-window counts
     int64_t *long_list;
     int64_t long_cap;
 };

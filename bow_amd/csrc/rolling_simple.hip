@@ -3,8 +3,8 @@
 //   * up to 8 value columns of ONE type (all Float64 or all Int64, with or without nulls) plus the interval column;
 //   * up to 12 outputs among WindowStart / Sum / ArithmeticMean / Min / Max / Count / First / Last / NumRows,
 //     no transformation factors, exclusive windows;
-//   * the whole interval column spans less than 2^32 and interval < 2^32, so window ids are 32-bit:
-//     wid = magic32((uint32)(ts - s0)) with no per-tile base.
+//   * the rows of this call (the whole frame, or one rank's shard of it) span less than 2^32 from the start of output
+//     slot 0 and interval < 2^32, so window ids are 32-bit: wid = magic32((uint32)(ts - s0)) with no per-tile base.
 // (reference rolling/rolling.go:177-239 + rolling/aggregation.go:190-238 + the reducer closures of
 // rolling/aggregation/{windowstart,sum,arithmeticmean,minmax,count,firstlast}.go.)  Anything else takes
 // rolling_fast.hip / rolling_agg.hip; results are identical where several apply (tests run all of them).
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
         } else {
             // rows run past the look-ahead: hand the window (all its columns) to the cooperative path
             if (c == 0) {
-                push_long_window(p.status, p.long_list, p.long_cap, tile, wid, base + r0);
+                push_long_window(p.status, p.long_list, p.long_cap, tile, (uint64_t)p.wid_base + wid, base + r0);
             }
             continue;
         }

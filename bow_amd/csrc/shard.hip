@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void range_state_kernel(const AggParams p, con
     }
 }
 
-// the empty windows [slot0, slot1) of every reducer (A.9 "Empty slice"); nullable bits stay 0
+// the empty windows [slot0, slot1) of every reducer (A.9 "Empty slice"); nullable bits end up 0
 __global__ __launch_bounds__(256) void fill_empty_kernel(const AggParams p, const int64_t slot0, const int64_t slot1) {
     Stats e;
     stats_init(e);
@@ -117,6 +117,7 @@ __global__ __launch_bounds__(256) void fill_empty_kernel(const AggParams p, cons
             const int ct = ad.slot >= 0 ? p.cols[ad.slot].type : BOWGPU_INT64;
             Val v = finish_val(reduce_val(ad.kind, e, 0, win_start, p.interval, ct == BOWGPU_INT64), ad);
             reinterpret_cast<uint64_t *>(ad.out_values)[s] = v.bits;
+            if (p.bits_preset && ad.out_valid && !v.valid) atomicAnd(&ad.out_valid[s >> 5], ~(1u << (s & 31)));
         }
     }
 }

@@ -147,6 +147,8 @@ int bowgpu_set_stream(void *hip_stream);
 int bowgpu_synchronize(void);
 /* device time (HIP events on the stream) of the tile kernel of this thread's last aggregate call */
 int bowgpu_last_kernel_ms(double *ms);
+/* ... and which tile kernel that was ("rolling_simple_kernel", "rolling_wave_kernel", "rolling_agg_kernel"; "" before any call) */
+const char *bowgpu_last_kernel_name(void);
 
 /* ---- HBM buffers (so callers can keep columns resident between calls) ------------- */
 int bowgpu_malloc(void **ptr, int64_t bytes);
