@@ -53,6 +53,40 @@ def cpu_baseline(capi, rows_sample):
                       "reference's time), %.1f s" % (reps, rows_sample, INTERVAL, dt)}
 
 
+def cpu_baseline_parallel(capi, rows_sample):
+    """The same oracle on ALL host cores (SURVEY §8d "parallel mode"): the sample is cut into row ranges on window
+    boundaries, one range per core, each range scanned by the single-threaded oracle (ctypes releases the GIL).  The
+    reference itself is single-goroutine on this path: this is what a multi-core restatement of it could reach."""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import pyoracle as orc
+    cores = os.cpu_count() or 1
+    ts_d, val_d = capi.gen_dense(0, rows_sample, seed=42)
+    ts = ts_d.values.to_numpy(np.int64, rows_sample)
+    val = val_d.values.to_numpy(np.float64, rows_sample)
+    del ts_d, val_d
+    per = -(-rows_sample // cores)
+    per += (-per) % INTERVAL  # ts = i: a multiple of the interval is a window boundary
+    ranges = [(a, min(a + per, rows_sample)) for a in range(0, rows_sample, per)]
+
+    def one(r):
+        a, b = r
+        cols = [orc.Column(ts[a:b], None, orc.INT64), orc.Column(val[a:b], None, orc.FLOAT64)]
+        orc.aggregate(cols, 0, INTERVAL, [("WindowStart", 0), ("ArithmeticMean", 1)])
+
+    reps, dt = 0, 0.0
+    with ThreadPoolExecutor(max_workers=cores) as ex:
+        list(ex.map(one, ranges))  # warm-up (page faults of the output buffers)
+        while dt < 5.0 and reps < 200:
+            t0 = time.perf_counter()
+            list(ex.map(one, ranges))
+            dt += time.perf_counter() - t0
+            reps += 1
+    return {"value": rows_sample * reps / dt, "unit": "rows/s", "cores": min(cores, len(ranges)), "kind": "port",
+            "sample": "%d passes over %d rows, %d row ranges cut on window boundaries, one oracle scan per range on a "
+                      "thread pool, %.1f s" % (reps, rows_sample, len(ranges), dt)}
+
+
 def measured_traffic(rows, kernel=None):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/r*_pmc_hbm_traffic_bench_1e9.csv: FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, in KB), when they were
@@ -182,6 +216,10 @@ def main():
                 line["cpu_baseline"] = cpu_baseline(capi, min(args.cpu_sample, rows))
             except Exception as e:  # the baseline is a reported aside; never lose the GPU number over it
                 line["cpu_baseline"] = {"error": repr(e)}
+            try:
+                line["cpu_baseline_all_cores"] = cpu_baseline_parallel(capi, min(args.cpu_sample, rows))
+            except Exception as e:
+                line["cpu_baseline_all_cores"] = {"error": repr(e)}
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()

@@ -89,7 +89,7 @@ SYMBOLS = [
     "bowgpu_memcpy_d2h", "bowgpu_memset", "bowgpu_timer_create", "bowgpu_timer_start", "bowgpu_timer_stop",
     "bowgpu_timer_elapsed_ms", "bowgpu_timer_destroy", "bowgpu_enforce_interval_and_offset", "bowgpu_plan_windows",
     "bowgpu_rolling_aggregate", "bowgpu_window_bounds", "bowgpu_aggregate_whole",
-    "bowgpu_rolling_interpolate_count", "bowgpu_rolling_interpolate_fill", "bowgpu_fill_linear",
+    "bowgpu_rolling_interpolate_count", "bowgpu_rolling_interpolate_fill", "bowgpu_fill_linear", "bowgpu_fill",
     "bowgpu_is_col_sorted", "bowgpu_shard_aggregate", "bowgpu_shard_fix_first", "bowgpu_carry_merge", "bowgpu_gen_dense",
     "bowgpu_gen_sparse", "bowgpu_checksum64",
 ]
@@ -403,6 +403,20 @@ def fill_linear(cols, ref_col, fill_col, out_residency=HOST):
     o = out.c()
     unchanged = C.c_int32(0)
     check(lib().bowgpu_fill_linear(_cols(cols), len(cols), ref_col, fill_col, C.byref(o), C.byref(unchanged)))
+    out.absorb(o)
+    return out, bool(unchanged.value)
+
+
+FILL = {"Previous": 0, "Next": 1, "Mean": 2}
+
+
+def fill(col, method, out_residency=HOST):
+    """Bow.FillPrevious / FillNext / FillMean of one column -> (OutColumn, unchanged)"""
+    out = OutColumn(col.length, out_residency)
+    o = out.c()
+    c = col.c()
+    unchanged = C.c_int32(0)
+    check(lib().bowgpu_fill(C.byref(c), FILL[method], C.byref(o), C.byref(unchanged)))
     out.absorb(o)
     return out, bool(unchanged.value)
 

@@ -231,7 +231,6 @@ int launch_col_order(Ctx *c, const uint64_t *values, const uint32_t *vbits, int6
 int launch_window_bounds(Ctx *c, const int64_t *ts, int64_t n, const Plan &plan, int inclusive, int pre_rows,
                          const int64_t *first_idx, int64_t *first_index, int64_t *slice_begin, int64_t *slice_end, uint8_t *is_incl);
 int interp_run(Ctx *c, const void *params_blob);
-int fill_linear_run(Ctx *c, const void *params_blob);
 int whole_run(Ctx *c, const void *params_blob, int64_t nblocks);
 int whole_final_run(Ctx *c, const void *partials, int64_t nblocks, int64_t nrows, int64_t first_value, int64_t last_value,
                     const void *final_blob);
@@ -261,12 +260,28 @@ struct InterpParamsH {
     int32_t ncols, ts_col;
     InterpColH cols[kMaxCols];
 };
-struct FillParamsH {
-    const uint64_t *ref_values; const uint32_t *ref_vbits; int64_t ref_vbit0; int32_t ref_type;
+// Neighbour index of one validity bitmap: for every block of kNbrBlockBits bits (absolute bit positions, so blocks are
+// word-aligned whatever the Arrow offset) the nearest valid ROW before the block and after it.  Bounds every
+// previous/next-valid lookup to one block of words + one table read, however long the runs of nulls are.
+constexpr int kNbrBlockBits = 4096;
+struct NbrIndex {
+    const int64_t *prev_before;  // [nblocks] last valid row in any earlier block, -1 if none
+    const int64_t *next_after;   // [nblocks] first valid row in any later block, -1 if none
+    int64_t g0;                  // absolute block number of the column's first bit
+};
+enum { kFillLinear = -1 };  // FillParams::method; >= 0: BOWGPU_FILL_PREVIOUS / NEXT / MEAN
+struct FillParams {
+    const uint64_t *ref_values; const uint32_t *ref_vbits; int64_t ref_vbit0; int32_t ref_type;  // FillLinear only
     const uint64_t *fill_values; const uint32_t *fill_vbits; int64_t fill_vbit0; int32_t fill_type;
+    int32_t method;
     int64_t n;
     uint64_t *out_values; uint8_t *out_valid_bytes;
+    NbrIndex nbr;                // of the fill column's bitmap
 };
+// builds the index of (vbits, vbit0, n) into `work` (nbr_index_bytes(n, vbit0) bytes of device memory)
+size_t nbr_index_bytes(int64_t n, int64_t vbit0);
+int nbr_index_build(Ctx *c, const uint32_t *vbits, int64_t vbit0, int64_t n, void *work, NbrIndex *out);
+int fill_run(Ctx *c, const FillParams &p);
 struct WholeParamsH {
     const int64_t *ts;
     const uint64_t *values;

@@ -284,6 +284,8 @@ int bowgpu_is_col_sorted(const bowgpu_col *col, int32_t *sorted) {
     return 0;
 }
 
+static int fill_finish(Ctx *c, FillParams &P, int64_t n, const DevCol &dfill, DevOut *dout, int type);
+
 int bowgpu_fill_linear(const bowgpu_col *cols, int32_t ncols, int32_t ref_col, int32_t fill_col, bowgpu_out *out, int32_t *unchanged) {
     // reference bowfill.go:14-103
     if (!cols || !out || !unchanged) return fail(BOWGPU_ERR_ARG, "null argument");
@@ -306,8 +308,6 @@ int bowgpu_fill_linear(const bowgpu_col *cols, int32_t ncols, int32_t ref_col, i
     BG_TRY(devcol_prepare(c, &cols[fill_col], &dfill, true, true));
     DevOut dout;
     BG_TRY(devout_prepare(c, out, n, &dout));
-    DevBuf vbytes;
-    BG_TRY(vbytes.alloc((size_t)n + 64));
     uint32_t f = 0;
     if (n > 0) BG_TRY(col_order_flags(c, dref, rt, &f));
     const bool ref_empty = !(f & 4);                                  // IsColEmpty: bowassertion.go:84-86
@@ -315,26 +315,58 @@ int bowgpu_fill_linear(const bowgpu_col *cols, int32_t ncols, int32_t ref_col, i
     if (!ref_empty && !ref_sorted) return fail(BOWGPU_ERR_NOT_SORTED, "refColIndex '%d' is empty or not sorted", ref_col);
     const bool nothing = ref_empty || dfill.null_count == 0;          // bowfill.go:35-37, :53-55 return the receiver
     *unchanged = nothing ? 1 : 0;
-    FillParamsH P;
+    FillParams P;
     memset(&P, 0, sizeof P);
     P.ref_values = reinterpret_cast<const uint64_t *>(dref.values); P.ref_vbits = dref.vbits; P.ref_vbit0 = dref.vbit0; P.ref_type = rt;
     P.fill_values = reinterpret_cast<const uint64_t *>(dfill.values); P.fill_vbits = dfill.vbits; P.fill_vbit0 = dfill.vbit0; P.fill_type = ft;
-    P.n = n;
-    P.out_values = reinterpret_cast<uint64_t *>(dout.values);
-    P.out_valid_bytes = reinterpret_cast<uint8_t *>(vbytes.p);
+    P.method = kFillLinear;
     // (no special casing is needed for the two "return the receiver" cases: without nulls every row is copied,
     //  and with an all-null reference column no null row passes the valid1 test of bowfill.go:74)
-    BG_TRY(fill_linear_run(c, &P));
+    return fill_finish(c, P, n, dfill, &dout, ft);
+}
+
+// shared tail of the fill entry points: neighbour index of the fill column, the kernel, validity bytes -> bits, copy-back
+static int fill_finish(Ctx *c, FillParams &P, int64_t n, const DevCol &dfill, DevOut *dout, int type) {
+    DevBuf vbytes, ixbuf;
+    BG_TRY(vbytes.alloc((size_t)n + 64));
+    BG_TRY(ixbuf.alloc(nbr_index_bytes(n, dfill.vbit0)));
+    BG_TRY(nbr_index_build(c, dfill.vbits, dfill.vbit0, n, ixbuf.p, &P.nbr));
+    P.n = n;
+    P.out_values = reinterpret_cast<uint64_t *>(dout->values);
+    P.out_valid_bytes = reinterpret_cast<uint8_t *>(vbytes.p);
+    BG_TRY(fill_run(c, P));
     void *dscr;
     BG_TRY(ctx_scratch(c, 8192, &dscr));
     uint64_t *dcnt = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(dscr) + 1024);
     uint64_t hcnt = 0;
-    BG_TRY(launch_pack_validity(c, reinterpret_cast<const uint8_t *>(vbytes.p), n, reinterpret_cast<uint32_t *>(dout.validity), dcnt));
+    BG_TRY(launch_pack_validity(c, reinterpret_cast<const uint8_t *>(vbytes.p), n, reinterpret_cast<uint32_t *>(dout->validity), dcnt));
     BG_HIP(hipMemcpyAsync(&hcnt, dcnt, 8, hipMemcpyDeviceToHost, c->stream));
     BG_HIP(hipStreamSynchronize(c->stream));
-    BG_TRY(devout_finish(c, &dout, n, ft, n - (int64_t)hcnt));
+    BG_TRY(devout_finish(c, dout, n, type, n - (int64_t)hcnt));
     BG_HIP(hipStreamSynchronize(c->stream));
     return 0;
+}
+
+int bowgpu_fill(const bowgpu_col *col, int32_t method, bowgpu_out *out, int32_t *unchanged) {
+    // reference bowfill.go:105-160 (FillMean), :162-253 (FillNext / FillPrevious)
+    if (!col || !out || !unchanged) return fail(BOWGPU_ERR_ARG, "null argument");
+    if (method != BOWGPU_FILL_PREVIOUS && method != BOWGPU_FILL_NEXT && method != BOWGPU_FILL_MEAN) return fail(BOWGPU_ERR_ARG, "unknown fill method %d", method);
+    const int ft = col->type;
+    if (ft != BOWGPU_INT64 && ft != BOWGPU_FLOAT64)  // FillMean's own error (bowfill.go:119-122); Previous/Next on Boolean/String: declined
+        return fail(BOWGPU_ERR_UNSUPPORTED, "column is of unsupported type '%s'", type_name(ft));
+    const int64_t n = col->length;
+    Ctx *c;
+    BG_TRY(ctx_get(&c));
+    DevCol dfill;
+    BG_TRY(devcol_prepare(c, col, &dfill, true, true));
+    DevOut dout;
+    BG_TRY(devout_prepare(c, out, n, &dout));
+    *unchanged = dfill.null_count == 0 ? 1 : 0;
+    FillParams P;
+    memset(&P, 0, sizeof P);
+    P.fill_values = reinterpret_cast<const uint64_t *>(dfill.values); P.fill_vbits = dfill.vbits; P.fill_vbit0 = dfill.vbit0; P.fill_type = ft;
+    P.method = method;
+    return fill_finish(c, P, n, dfill, &dout, ft);
 }
 
 // ---------------------------------------------------------------------------- whole-frame Aggregate

@@ -259,37 +259,135 @@ __global__ __launch_bounds__(256) void col_order_kernel(const uint64_t *values, 
     if (f) atomicOr(flags, f);
 }
 
-struct FillParams {
-    const uint64_t *ref_values; const uint32_t *ref_vbits; int64_t ref_vbit0; int32_t ref_type;
-    const uint64_t *fill_values; const uint32_t *fill_vbits; int64_t fill_vbit0; int32_t fill_type;
-    int64_t n;
-    uint64_t *out_values; uint8_t *out_valid_bytes;
-};
+// ---- neighbour index (common.h NbrIndex)
+// one wavefront per block of 4096 bits = 128 words: last / first valid row inside the block
+__global__ __launch_bounds__(256) void nbr_block_kernel(const uint32_t *vbits, int64_t vbit0, int64_t n, int64_t g0, int64_t nblocks,
+                                                        int64_t *last_in, int64_t *first_in) {
+    const int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= nblocks) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t wbase = (g0 + g) * (kNbrBlockBits / 32);
+    const int64_t bit_lo = vbit0, bit_hi = vbit0 + n;  // the column's bits
+    int64_t hi = -1, lo = INT64_MAX;
+    for (int k = 0; k < 2; k++) {
+        const int64_t w = wbase + lane + 64 * k;
+        const int64_t b0 = w << 5;
+        if (b0 + 32 <= bit_lo || b0 >= bit_hi) continue;
+        uint32_t x = vbits[w];
+        if (b0 < bit_lo) x &= ~0u << (bit_lo - b0);
+        if (b0 + 32 > bit_hi) x &= (1u << (bit_hi - b0)) - 1u;
+        if (!x) continue;
+        const int64_t h = b0 + (31 - __clz((int)x)) - vbit0, l = b0 + (__ffs((int)x) - 1) - vbit0;
+        if (h > hi) hi = h;
+        if (l < lo) lo = l;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const int64_t h2 = __shfl_down((long long)hi, o), l2 = __shfl_down((long long)lo, o);
+        if (h2 > hi) hi = h2;
+        if (l2 < lo) lo = l2;
+    }
+    if (lane == 0) { last_in[g] = hi; first_in[g] = lo; }
+}
 
-__global__ __launch_bounds__(256) void fill_linear_kernel(const FillParams p) {
+// exclusive running max of last_in (-> prev_before) and exclusive reverse running min of first_in (-> next_after):
+// one workgroup, each thread owns a contiguous run of blocks
+__global__ __launch_bounds__(1024) void nbr_scan_kernel(const int64_t *last_in, const int64_t *first_in, int64_t nblocks,
+                                                        int64_t *prev_before, int64_t *next_after) {
+    __shared__ int64_t s_hi[1024], s_lo[1024];
+    const int t = threadIdx.x;
+    const int64_t per = (nblocks + 1023) / 1024;
+    const int64_t a = t * per, b = a + per < nblocks ? a + per : nblocks;
+    int64_t hi = -1, lo = INT64_MAX;
+    for (int64_t g = a; g < b; g++) { if (last_in[g] > hi) hi = last_in[g]; if (first_in[g] < lo) lo = first_in[g]; }
+    s_hi[t] = hi; s_lo[t] = lo;
+    __syncthreads();
+    if (t == 0) {  // 1024 entries: serial is cheap
+        int64_t run = -1;
+        for (int i = 0; i < 1024; i++) { const int64_t x = s_hi[i]; s_hi[i] = run; if (x > run) run = x; }
+        run = INT64_MAX;
+        for (int i = 1023; i >= 0; i--) { const int64_t x = s_lo[i]; s_lo[i] = run; if (x < run) run = x; }
+    }
+    __syncthreads();
+    int64_t run = s_hi[t];
+    for (int64_t g = a; g < b; g++) { prev_before[g] = run; if (last_in[g] > run) run = last_in[g]; }
+    run = s_lo[t];
+    for (int64_t g = b - 1; g >= a; g--) { next_after[g] = run == INT64_MAX ? -1 : run; if (first_in[g] < run) run = first_in[g]; }
+}
+
+namespace {
+// previous / next valid row at or before / after `row`, looking at most one block of words, then the index
+__device__ __forceinline__ int64_t prev_valid_ix(const uint32_t *bits, int64_t bit0, int64_t n, int64_t row, const NbrIndex &ix) {
+    if (row < 0 || row >= n) return -1;
+    if (!bits) return row;
+    int64_t b = bit0 + row;
+    const int64_t g = b / kNbrBlockBits;
+    const int64_t stop = g * kNbrBlockBits > bit0 ? g * kNbrBlockBits : bit0;  // first bit of the block that belongs to the column
+    while (b >= stop) {
+        const int64_t w = b >> 5;
+        const int sh = (int)(b & 31);
+        uint32_t x = bits[w];
+        x = sh == 31 ? x : (x & ((2u << sh) - 1u));
+        if ((w << 5) < stop) x &= ~0u << (stop - (w << 5));
+        if (x) return (w << 5) + (31 - __clz((int)x)) - bit0;
+        b = (w << 5) - 1;
+    }
+    return ix.prev_before[g - ix.g0];
+}
+__device__ __forceinline__ int64_t next_valid_ix(const uint32_t *bits, int64_t bit0, int64_t n, int64_t row, const NbrIndex &ix) {
+    if (row < 0 || row >= n) return -1;
+    if (!bits) return row;
+    int64_t b = bit0 + row;
+    const int64_t g = b / kNbrBlockBits;
+    const int64_t bend = (g + 1) * kNbrBlockBits < bit0 + n ? (g + 1) * kNbrBlockBits : bit0 + n;
+    while (b < bend) {
+        const int64_t w = b >> 5;
+        uint32_t x = bits[w] & (~0u << (b & 31));
+        if (((w + 1) << 5) > bend) x &= (1u << (bend - (w << 5))) - 1u;
+        if (x) return (w << 5) + (__ffs((int)x) - 1) - bit0;
+        b = (w + 1) << 5;
+    }
+    return ix.next_after[g - ix.g0];
+}
+}  // namespace
+
+// Bow.FillLinear (bowfill.go:14-103), FillPrevious / FillNext (:162-253), FillMean (:105-160): one thread per row, null
+// rows look their neighbours up through the index
+__global__ __launch_bounds__(256) void fill_kernel(const FillParams p) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < p.n; i += (int64_t)gridDim.x * blockDim.x) {
         uint64_t bits = p.fill_values[i];
         int valid = bit_at(p.fill_vbits, p.fill_vbit0, i) ? 1 : 0;
-        if (!valid) {  // bowfill.go:65-97
-            const int64_t rp = prev_valid(p.fill_vbits, p.fill_vbit0, p.n, i - 1);
-            const int64_t rn = next_valid(p.fill_vbits, p.fill_vbit0, p.n, i + 1);
-            const bool v1 = bit_at(p.ref_vbits, p.ref_vbit0, i);
-            const bool v2 = rp >= 0 && bit_at(p.ref_vbits, p.ref_vbit0, rp);   // GetFloat64(ref, -1) => (0,false) :72
-            const bool v3 = rn >= 0 && bit_at(p.ref_vbits, p.ref_vbit0, rn);
-            if (v1 && v2 && v3) {
-                const double prev_fill = bits_to_f64(p.fill_values[rp], p.fill_type);
-                const double next_fill = bits_to_f64(p.fill_values[rn], p.fill_type);
-                const double row_ref = bits_to_f64(p.ref_values[i], p.ref_type);
-                const double prev_ref = bits_to_f64(p.ref_values[rp], p.ref_type);
-                const double next_ref = bits_to_f64(p.ref_values[rn], p.ref_type);
-                // (the nextRef-prevRef == 0 branch of :78-85 is overwritten by the fall-through below)
-                double tmp = row_ref - prev_ref;   // :87-90, four separate statements
-                tmp /= next_ref - prev_ref;
-                tmp *= next_fill - prev_fill;
-                tmp += prev_fill;
-                if (p.fill_type == BOWGPU_INT64) bits = (uint64_t)go_f64_to_i64(round(tmp));  // math.Round: half away from zero :93
-                else bits = (uint64_t)__double_as_longlong(tmp);
-                valid = 1;
+        if (!valid) {
+            const int64_t rp = p.method == BOWGPU_FILL_NEXT ? -1 : prev_valid_ix(p.fill_vbits, p.fill_vbit0, p.n, i - 1, p.nbr);
+            const int64_t rn = p.method == BOWGPU_FILL_PREVIOUS ? -1 : next_valid_ix(p.fill_vbits, p.fill_vbit0, p.n, i + 1, p.nbr);
+            if (p.method == BOWGPU_FILL_PREVIOUS) {
+                if (rp >= 0) { bits = p.fill_values[rp]; valid = 1; }          // arr.Value(fillRowIndex): bowfill.go:196-199
+            } else if (p.method == BOWGPU_FILL_NEXT) {
+                if (rn >= 0) { bits = p.fill_values[rn]; valid = 1; }
+            } else if (p.method == BOWGPU_FILL_MEAN) {
+                if (rp >= 0 && rn >= 0) {                                       // bowfill.go:145-154
+                    const double m = (bits_to_f64(p.fill_values[rp], p.fill_type) + bits_to_f64(p.fill_values[rn], p.fill_type)) / 2;
+                    bits = p.fill_type == BOWGPU_INT64 ? (uint64_t)go_f64_to_i64(round(m)) : (uint64_t)__double_as_longlong(m);
+                    valid = 1;
+                }
+            } else {                                                            // FillLinear: bowfill.go:65-97
+                const bool v1 = bit_at(p.ref_vbits, p.ref_vbit0, i);
+                const bool v2 = rp >= 0 && bit_at(p.ref_vbits, p.ref_vbit0, rp);   // GetFloat64(ref, -1) => (0,false) :72
+                const bool v3 = rn >= 0 && bit_at(p.ref_vbits, p.ref_vbit0, rn);
+                if (v1 && v2 && v3) {
+                    const double prev_fill = bits_to_f64(p.fill_values[rp], p.fill_type);
+                    const double next_fill = bits_to_f64(p.fill_values[rn], p.fill_type);
+                    const double row_ref = bits_to_f64(p.ref_values[i], p.ref_type);
+                    const double prev_ref = bits_to_f64(p.ref_values[rp], p.ref_type);
+                    const double next_ref = bits_to_f64(p.ref_values[rn], p.ref_type);
+                    // (the nextRef-prevRef == 0 branch of :78-85 is overwritten by the fall-through below)
+                    double tmp = row_ref - prev_ref;   // :87-90, four separate statements
+                    tmp /= next_ref - prev_ref;
+                    tmp *= next_fill - prev_fill;
+                    tmp += prev_fill;
+                    if (p.fill_type == BOWGPU_INT64) bits = (uint64_t)go_f64_to_i64(round(tmp));  // math.Round: half away from zero :93
+                    else bits = (uint64_t)__double_as_longlong(tmp);
+                    valid = 1;
+                }
             }
         }
         p.out_values[i] = bits;
@@ -449,7 +547,6 @@ int launch_window_bounds(Ctx *c, const int64_t *ts, int64_t n, const Plan &plan,
 namespace bowgpu {
 
 static_assert(sizeof(InterpParams) == sizeof(InterpParamsH), "InterpParams layout");
-static_assert(sizeof(FillParams) == sizeof(FillParamsH), "FillParams layout");
 static_assert(sizeof(WholeParams) == sizeof(WholeParamsH), "WholeParams layout");
 static_assert(sizeof(WholeFinal) == sizeof(WholeFinalH), "WholeFinal layout");
 
@@ -461,9 +558,27 @@ int interp_run(Ctx *c, const void *params_blob) {
     return 0;
 }
 
-int fill_linear_run(Ctx *c, const void *params_blob) {
-    const FillParams &p = *reinterpret_cast<const FillParams *>(params_blob);
-    if (p.n > 0) hipLaunchKernelGGL(fill_linear_kernel, dim3(grid_for(p.n)), dim3(256), 0, c->stream, p);
+size_t nbr_index_bytes(int64_t n, int64_t vbit0) {
+    const int64_t nblocks = (vbit0 + (n > 0 ? n : 1) - 1) / kNbrBlockBits - vbit0 / kNbrBlockBits + 1;
+    return (size_t)nblocks * 8 * 4;
+}
+
+int nbr_index_build(Ctx *c, const uint32_t *vbits, int64_t vbit0, int64_t n, void *work, NbrIndex *out) {
+    out->prev_before = nullptr; out->next_after = nullptr; out->g0 = vbit0 / kNbrBlockBits;
+    if (!vbits || n <= 0) return 0;  // no bitmap: every lookup answers without the index
+    const int64_t nblocks = (vbit0 + n - 1) / kNbrBlockBits - out->g0 + 1;
+    int64_t *w = reinterpret_cast<int64_t *>(work);
+    int64_t *last_in = w, *first_in = w + nblocks, *prev_before = w + 2 * nblocks, *next_after = w + 3 * nblocks;
+    hipLaunchKernelGGL(nbr_block_kernel, dim3((unsigned)((nblocks + 3) / 4)), dim3(256), 0, c->stream, vbits, vbit0, n, out->g0, nblocks,
+                       last_in, first_in);
+    hipLaunchKernelGGL(nbr_scan_kernel, dim3(1), dim3(1024), 0, c->stream, last_in, first_in, nblocks, prev_before, next_after);
+    BG_HIP(hipGetLastError());
+    out->prev_before = prev_before; out->next_after = next_after;
+    return 0;
+}
+
+int fill_run(Ctx *c, const FillParams &p) {
+    if (p.n > 0) hipLaunchKernelGGL(fill_kernel, dim3(grid_for(p.n)), dim3(256), 0, c->stream, p);
     BG_HIP(hipGetLastError());
     return 0;
 }

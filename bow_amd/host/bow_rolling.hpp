@@ -210,6 +210,13 @@ class Bow {
     // FillLinear: bowfill.go:14-103 (device) ; IsColSorted: bowassertion.go:15-81 (device)
     std::pair<BowPtr, Error> FillLinear(int refColIndex, int toFillColIndex) const;
     bool IsColSorted(int colIndex) const;
+    // FillPrevious / FillNext: bowfill.go:162-253 ; FillMean: bowfill.go:105-160 (device; colIndices defaults to all columns)
+    std::pair<BowPtr, Error> FillPrevious(std::vector<int> colIndices = {}) const { return fill(BOWGPU_FILL_PREVIOUS, colIndices); }
+    std::pair<BowPtr, Error> FillNext(std::vector<int> colIndices = {}) const { return fill(BOWGPU_FILL_NEXT, colIndices); }
+    std::pair<BowPtr, Error> FillMean(std::vector<int> colIndices = {}) const { return fill(BOWGPU_FILL_MEAN, colIndices); }
+
+private:
+    std::pair<BowPtr, Error> fill(int method, const std::vector<int> &colIndices) const;
 };
 
 // NewBow: bow.go:109-116 (all series must have the same length)
@@ -293,6 +300,29 @@ inline std::pair<BowPtr, Error> Bow::FillLinear(int refColIndex, int toFillColIn
     if (rc) return {nullptr, detail::AbiError(rc)};
     auto out = std::make_shared<Bow>(*this);
     if (!unchanged) out->cols[toFillColIndex] = st.ToSeries(cols[toFillColIndex].Name, o);
+    return {out, Error()};
+}
+
+inline std::pair<BowPtr, Error> Bow::fill(int method, const std::vector<int> &colIndices) const {
+    std::vector<bool> selected(NumCols(), colIndices.empty());  // selectCols: bowfill.go:268-288
+    for (int ci : colIndices) {
+        if (ci < 0 || ci > NumCols() - 1) return {nullptr, Errorf("selectCols: colIndex '" + std::to_string(ci) + "' out of range")};
+        selected[ci] = true;
+    }
+    for (int ci = 0; ci < NumCols(); ci++)  // FillMean checks types first (bowfill.go:114-125); this mirror holds Int64 / Float64 only
+        if (selected[ci] && cols[ci].typ != Type::Int64 && cols[ci].typ != Type::Float64)
+            return {nullptr, Errorf("column '" + cols[ci].Name + "' is of unsupported type '" + TypeString(cols[ci].typ) + "'")};
+    auto out = std::make_shared<Bow>(*this);
+    for (int ci = 0; ci < NumCols(); ci++) {
+        if (!selected[ci] || cols[ci].NullN() == 0) continue;  // passed through: bowfill.go:130-133, :186-189
+        bowgpu_col c = ArrowCol(ci);
+        detail::OutStore st;
+        bowgpu_out o = st.Make(NumRows());
+        int32_t unchanged = 0;
+        int rc = bowgpu_fill(&c, method, &o, &unchanged);
+        if (rc) return {nullptr, detail::AbiError(rc)};
+        out->cols[ci] = st.ToSeries(cols[ci].Name, o);
+    }
     return {out, Error()};
 }
 

@@ -245,6 +245,15 @@ int bowgpu_rolling_interpolate_fill(const bowgpu_col *cols, int32_t ncols, int32
 int bowgpu_fill_linear(const bowgpu_col *cols, int32_t ncols, int32_t ref_col, int32_t fill_col,
                        bowgpu_out *out, int32_t *unchanged);
 
+/* Bow.FillPrevious / Bow.FillNext (LOCF / NOCB) — reference bowfill.go:162-253 — and Bow.FillMean — reference
+ * bowfill.go:105-160 — of ONE Int64 / Float64 column (the reference loops over the selected columns, one goroutine each;
+ * call once per column).  out receives the filled copy; *unchanged = 1 when the column has no nulls (the reference
+ * passes such a column through, bowfill.go:130-133, :176-179).  Boolean / String columns: BOWGPU_ERR_UNSUPPORTED. */
+#define BOWGPU_FILL_PREVIOUS 0
+#define BOWGPU_FILL_NEXT 1
+#define BOWGPU_FILL_MEAN 2
+int bowgpu_fill(const bowgpu_col *col, int32_t method, bowgpu_out *out, int32_t *unchanged);
+
 /* Bow.IsColSorted — reference bowassertion.go:15-81 (ascending OR descending, nulls skipped,
  * empty => false). */
 int bowgpu_is_col_sorted(const bowgpu_col *col, int32_t *sorted);

@@ -821,6 +821,37 @@ int orc_fill_linear(const orc_col_t *cols, int ncols, int ref_col, int fill_col,
     return ORC_OK;
 }
 
+int orc_fill(const orc_col_t *col, int method, orc_out_t *out, int *unchanged) {
+    /* FillPrevious / FillNext: bowfill.go:166-253 (fill + getFillRowIndex); FillMean: bowfill.go:108-160.
+     * One column per call (the reference runs one goroutine per selected column). */
+    if (method != ORC_FILL_PREVIOUS && method != ORC_FILL_NEXT && method != ORC_FILL_MEAN) return ORC_ERR_ARG;
+    if (col->type != ORC_INT64 && col->type != ORC_FLOAT64) return ORC_ERR_TYPE; /* :115-123 (Mean); Bool/String: not restated */
+    int64_t n = col->length;
+    view_t b = {col, 0, n};
+    out_init(out, n, col->type);
+    for (int64_t i = 0; i < n; i++) out_copy_row(out, i, col, i); /* NewBufferFromCol */
+    int64_t nulls = 0;
+    for (int64_t i = 0; i < n; i++) nulls += !col_is_valid(col, i);
+    *unchanged = nulls == 0; /* NullN() == 0: the column is passed through (:130-133, :176-179) */
+    if (nulls == 0) return ORC_OK;
+    for (int64_t row = 0; row < n; row++) {
+        if (col_is_valid(col, row)) continue;
+        if (method == ORC_FILL_MEAN) {
+            int64_t prev_row, next_row;
+            double prev_val = view_prev_f64(&b, 0, row - 1, &prev_row); /* :145 */
+            double next_val = view_next_f64(&b, 0, row + 1, &next_row); /* :146 */
+            if (prev_row > -1 && next_row > -1) {
+                if (col->type == ORC_INT64) out_set_or_drop_strict(out, row, val_i64(go_f64_to_i64(round((prev_val + next_val) / 2)))); /* :150 */
+                else out_set_or_drop_strict(out, row, val_f64((prev_val + next_val) / 2)); /* :152 */
+            }
+        } else {
+            int64_t src = method == ORC_FILL_PREVIOUS ? view_prev_valid(&b, 0, row - 1) : view_next_valid(&b, 0, row + 1); /* :247-253 */
+            if (src > -1) out_copy_row(out, row, col, src); /* arr.Value(fillRowIndex), valid (:196-199, :207-210) */
+        }
+    }
+    return ORC_OK;
+}
+
 /* ---------------------------------------------------------------- synthetic generators */
 
 uint64_t orc_mix64(uint64_t seed, uint64_t i) {

@@ -158,6 +158,11 @@ int orc_interpolate(const orc_col_t *cols, int ncols, int ts_col, int64_t interv
 int orc_fill_linear(const orc_col_t *cols, int ncols, int ref_col, int fill_col, orc_out_t *out,
                     int *unchanged);
 
+/* Bow.FillPrevious / FillNext (bowfill.go:162-253) and Bow.FillMean (bowfill.go:105-160) of ONE Int64 / Float64
+ * column: out gets the filled copy; *unchanged = 1 when the column has no nulls (passed through). */
+enum { ORC_FILL_PREVIOUS = 0, ORC_FILL_NEXT = 1, ORC_FILL_MEAN = 2 };
+int orc_fill(const orc_col_t *col, int method, orc_out_t *out, int *unchanged);
+
 /* bowassertion.go:15-86 */
 int orc_is_col_sorted(const orc_col_t *col);
 int orc_is_col_empty(const orc_col_t *col);

@@ -293,6 +293,21 @@ def fill_linear(cols, ref_col, fill_col):
     return out.column(o.type), bool(unchanged.value)
 
 
+FILL = {"Previous": 0, "Next": 1, "Mean": 2}
+
+
+def fill(col, method):
+    """Bow.FillPrevious / FillNext / FillMean of one column -> (Column, unchanged)"""
+    c = col.c()
+    out = OutBuf(col.length)
+    o = out.c()
+    unchanged = C.c_int(0)
+    rc = lib().orc_fill(C.byref(c), FILL[method], C.byref(o), C.byref(unchanged))
+    if rc:
+        raise OracleError(rc)
+    return out.column(o.type), bool(unchanged.value)
+
+
 def is_col_sorted(col):
     c = col.c()
     return bool(lib().orc_is_col_sorted(C.byref(c)))

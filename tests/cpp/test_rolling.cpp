@@ -329,6 +329,38 @@ static void TestFillLinear() {
       auto [res, e] = b->FillLinear(0, 1); CHECK(!e); CHECK(eq(col(res, 1), {F(1.), N, F(3.)})); }
     TEST("IsColSorted");
     { auto b = fresh(Int64); CHECK(b->IsColSorted(0)); CHECK(!b->IsColSorted(4)); }
+    // bowfill_test.go:29-154 (int64), :204-330 (float64): Mean / Next / Previous, one column then all columns
+    auto all = [&](const BowPtr &b, std::vector<std::vector<Value>> want) {
+        bool ok = true;
+        for (int c = 0; c < 5; c++) ok = ok && eq(col(b, c), want[c]);
+        return ok;
+    };
+    TEST("Fill/int64 Mean one column");
+    { auto [res, e] = fresh(Int64)->FillMean({1}); CHECK(!e); CHECK(eq(col(res, 1), {I(6), I(5), I(4), I(3), I(3), I(1)})); CHECK(eq(col(res, 4), {I(-10), N, I(-5), I(0), N, I(-8)})); }
+    TEST("Fill/int64 Mean all columns");
+    { auto [res, e] = fresh(Int64)->FillMean(); CHECK(!e);
+      CHECK(all(res, {{I(20), I(13), I(10), I(0), I(-1), I(-2)}, {I(6), I(5), I(4), I(3), I(3), I(1)}, {I(30), I(20), I(10), I(3), N, N},
+                      {I(400), I(205), I(10), I(4), N, N}, {I(-10), I(-8), I(-5), I(0), I(-4), I(-8)}})); }
+    TEST("Fill/int64 Next all columns");
+    { auto [res, e] = fresh(Int64)->FillNext(); CHECK(!e);
+      CHECK(all(res, {{I(20), I(13), I(10), I(0), I(-2), I(-2)}, {I(6), I(4), I(4), I(1), I(1), I(1)}, {I(30), I(10), I(10), I(3), N, N},
+                      {I(400), I(10), I(10), I(4), N, N}, {I(-10), I(-5), I(-5), I(0), I(-8), I(-8)}})); }
+    TEST("Fill/int64 Previous all columns");
+    { auto [res, e] = fresh(Int64)->FillPrevious(); CHECK(!e);
+      CHECK(all(res, {{I(20), I(13), I(10), I(0), I(0), I(-2)}, {I(6), I(6), I(4), I(4), I(4), I(1)}, {I(30), I(30), I(10), I(3), I(3), I(3)},
+                      {I(400), I(400), I(10), I(4), I(4), I(4)}, {I(-10), I(-10), I(-5), I(0), I(0), I(-8)}})); }
+    TEST("Fill/float64 Mean all columns");
+    { auto [res, e] = fresh(Float64)->FillMean(); CHECK(!e);
+      CHECK(all(res, {{F(20), F(13), F(10), F(0), F(-1), F(-2)}, {F(6), F(5), F(4), F(2.5), F(2.5), F(1)}, {F(30), F(20), F(10), F(3), N, N},
+                      {F(400), F(205), F(10), F(4), N, N}, {F(-10), F(-7.5), F(-5), F(0), F(-4), F(-8)}})); }
+    TEST("Fill/float64 Next one column");
+    { auto [res, e] = fresh(Float64)->FillNext({1}); CHECK(!e); CHECK(eq(col(res, 1), {F(6), F(4), F(4), F(1), F(1), F(1)})); CHECK(eq(col(res, 0), {F(20), F(13), F(10), F(0), N, F(-2)})); }
+    TEST("Fill/float64 Previous all columns");
+    { auto [res, e] = fresh(Float64)->FillPrevious(); CHECK(!e);
+      CHECK(all(res, {{F(20), F(13), F(10), F(0), F(0), F(-2)}, {F(6), F(6), F(4), F(4), F(4), F(1)}, {F(30), F(30), F(10), F(3), F(3), F(3)},
+                      {F(400), F(400), F(10), F(4), F(4), F(4)}, {F(-10), F(-10), F(-5), F(0), F(0), F(-8)}})); }
+    TEST("Fill/selectCols out of range");
+    { auto [res, e] = fresh(Int64)->FillNext({7}); CHECK((bool)e); CHECK(e.msg == "selectCols: colIndex '7' out of range"); }
 }
 
 // ---- rolling/aggregation/XXXbenchmarks_test.go:125-138 shape, small: IntervalRolling + Aggregate(WindowStart, ArithmeticMean)

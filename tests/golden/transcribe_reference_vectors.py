@@ -259,6 +259,27 @@ fill_linear = [
 fill_linear_meta = {"name": "with metadata: ref null at row", "ref_type": "int64", "ref": [1, N, 3],
                     "fill_type": "float64", "fill": [1.0, N, 3.0], "expect": [1.0, N, 3.0], "src": "bowfill_test.go:533-546"}
 
+# bowfill_test.go:29-154 (int64) and :204-330 (float64): FillMean / FillNext / FillPrevious on newFreshBow; the
+# "all columns" cases give every column's expectation, the "one column" cases repeat column b
+fill_methods = {
+    "int64": {
+        "Mean": {"a": [20, 13, 10, 0, -1, -2], "b": [6, 5, 4, 3, 3, 1], "c": [30, 20, 10, 3, N, N],
+                 "d": [400, 205, 10, 4, N, N], "e": [-10, -8, -5, 0, -4, -8], "src": "bowfill_test.go:31-71"},
+        "Next": {"a": [20, 13, 10, 0, -2, -2], "b": [6, 4, 4, 1, 1, 1], "c": [30, 10, 10, 3, N, N],
+                 "d": [400, 10, 10, 4, N, N], "e": [-10, -5, -5, 0, -8, -8], "src": "bowfill_test.go:73-113"},
+        "Previous": {"a": [20, 13, 10, 0, 0, -2], "b": [6, 6, 4, 4, 4, 1], "c": [30, 30, 10, 3, 3, 3],
+                     "d": [400, 400, 10, 4, 4, 4], "e": [-10, -10, -5, 0, 0, -8], "src": "bowfill_test.go:115-155"},
+    },
+    "float64": {
+        "Mean": {"a": [20.0, 13.0, 10.0, 0.0, -1.0, -2.0], "b": [6.0, 5.0, 4.0, 2.5, 2.5, 1.0], "c": [30.0, 20.0, 10.0, 3.0, N, N],
+                 "d": [400.0, 205.0, 10.0, 4.0, N, N], "e": [-10.0, -7.5, -5.0, 0.0, -4.0, -8.0], "src": "bowfill_test.go:205-245"},
+        "Next": {"a": [20.0, 13.0, 10.0, 0.0, -2.0, -2.0], "b": [6.0, 4.0, 4.0, 1.0, 1.0, 1.0], "c": [30.0, 10.0, 10.0, 3.0, N, N],
+                 "d": [400.0, 10.0, 10.0, 4.0, N, N], "e": [-10.0, -5.0, -5.0, 0.0, -8.0, -8.0], "src": "bowfill_test.go:247-287"},
+        "Previous": {"a": [20.0, 13.0, 10.0, 0.0, 0.0, -2.0], "b": [6.0, 6.0, 4.0, 4.0, 4.0, 1.0], "c": [30.0, 30.0, 10.0, 3.0, 3.0, 3.0],
+                     "d": [400.0, 400.0, 10.0, 4.0, 4.0, 4.0], "e": [-10.0, -10.0, -5.0, 0.0, 0.0, -8.0], "src": "bowfill_test.go:289-330"},
+    },
+}
+
 # rolling/transformation/factor_test.go:10-34 (Factor(0.1))
 factor_vectors = [
     {"in": None, "out": None}, {"in": {"int64": 11}, "out": {"int64": 1}}, {"in": {"float64": 11.0}, "out": {"float64": 1.1}},
@@ -273,7 +294,7 @@ out = {
     "bows": bows, "reducers": reducers, "num_windows": num_windows, "iterate": iterate,
     "ctor_errors": ctor_errors, "driver": driver, "whole": whole, "interpolate": interpolate,
     "interp_errors": interp_errors, "fill_bow": FILL, "fill_linear": fill_linear,
-    "fill_linear_meta": fill_linear_meta, "factor": factor_vectors, "offsets": offsets,
+    "fill_linear_meta": fill_linear_meta, "fill_methods": fill_methods, "factor": factor_vectors, "offsets": offsets,
 }
 
 if __name__ == "__main__":

@@ -143,6 +143,79 @@ def test_fill_linear_random_vs_oracle(ftype, desc):
     assert unchanged and got.null_count == 0
 
 
+# ------------------------------------------------------------------ FillPrevious / FillNext / FillMean
+def test_golden_fill_previous_next_mean(golden):
+    # bowfill_test.go:29-154, :204-330
+    for typ, methods in golden["fill_methods"].items():
+        for method, expect in methods.items():
+            for name in ["a", "b", "c", "d", "e"]:
+                data = [None if x is None else (float(x) if typ == "float64" else x) for x in golden["fill_bow"][name]]
+                out, unchanged = capi.fill(capi.Column.from_list(data, typ), method)
+                assert not unchanged and out.type == T[typ]
+                same_list(out.to_list(), expect[name])
+    out, unchanged = capi.fill(capi.Column.from_list([1, 2, 3], "int64"), "Mean")
+    assert unchanged and out.to_list() == [1, 2, 3]
+
+
+@pytest.mark.parametrize("ftype", ["f64", "i64"])
+@pytest.mark.parametrize("method", ["Previous", "Next", "Mean"])
+def test_fill_random_vs_oracle(ftype, method):
+    rng = np.random.default_rng(41)
+    for n, null_frac, off in [(1, 1.0, 0), (7, 0.5, 0), (100_000, 0.4, 0), (100_000, 0.4, 13), (300_000, 0.999, 5)]:
+        tot = n + off + 9
+        vals = np.round(rng.standard_normal(tot) * 1000, 1) if ftype == "f64" else rng.integers(-10**12, 10**12, tot).astype(np.int64)
+        valid = rng.random(tot) >= null_frac
+        bm = np.packbits(valid, bitorder="little")
+        typ = capi.FLOAT64 if ftype == "f64" else capi.INT64
+        got, gu = capi.fill(capi.Column(vals, bm, typ, off, n, -1), method)
+        want, wu = orc.fill(orc.Column(vals, bm, typ, offset=off, length=n), method)
+        assert gu == wu
+        cmp_out("%s n=%d off=%d" % (method, n, off), got, want)
+
+
+def test_fill_long_null_runs_use_the_block_index():
+    # runs of nulls far longer than a 4096-bit block of the neighbour index, starting / ending anywhere, plus leading and
+    # trailing nulls (no previous / no next value).  The oracle (like the reference) walks row by row from every null row -
+    # quadratic on such input - so the expectation here is numpy's forward / backward fill.
+    n = 3_000_000
+    valid = np.zeros(n, dtype=bool)
+    valid[[5, 6, 4095, 4096, 4097, 1_000_000, 1_000_001, 2_500_123]] = True
+    vals = np.arange(n, dtype=np.float64) * 0.5
+    bm = np.packbits(valid, bitorder="little")
+    for off in (0, 3):
+        m = n - off
+        v, ok = vals[off:], valid[off:]
+        idx = np.arange(m)
+        prev = np.maximum.accumulate(np.where(ok, idx, -1))
+        nxt = np.minimum.accumulate(np.where(ok, idx, m)[::-1])[::-1]
+        exp = {"Previous": (np.where(prev >= 0, v[np.maximum(prev, 0)], 0.0), prev >= 0),
+               "Next": (np.where(nxt < m, v[np.minimum(nxt, m - 1)], 0.0), nxt < m)}
+        both = (prev >= 0) & (nxt < m)
+        exp["Mean"] = (np.where(both, (v[np.maximum(prev, 0)] + v[np.minimum(nxt, m - 1)]) / 2, 0.0), both)
+        for method in ("Previous", "Next", "Mean"):
+            got, _ = capi.fill(capi.Column(vals, bm, capi.FLOAT64, off, m, -1), method, out_residency=capi.DEVICE)
+            gv, gm = got.host_arrays()[0], got.valid_mask()
+            wv, wm = exp[method]
+            assert np.array_equal(gm, wm), (method, off)
+            assert np.array_equal(gv[gm], wv[wm]), (method, off)
+            assert got.null_count == int((~wm).sum())
+    # FillLinear through the same index: ref = row number => linear in the row between the two valid neighbours
+    ref = np.arange(n, dtype=np.int64)
+    got, _ = capi.fill_linear([capi.Column(ref), capi.Column(vals, bm, capi.FLOAT64, 0, n, -1)], 0, 1)
+    gv, gm = got.host_arrays()[0], got.valid_mask()
+    idx = np.arange(n)
+    prev = np.maximum.accumulate(np.where(valid, idx, -1))
+    nxt = np.minimum.accumulate(np.where(valid, idx, n)[::-1])[::-1]
+    both = (prev >= 0) & (nxt < n)
+    assert np.array_equal(gm, both)
+    p, q = np.maximum(prev, 0), np.minimum(nxt, n - 1)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        lin = (idx - p).astype(np.float64) / (q - p).astype(np.float64) * (vals[q] - vals[p]) + vals[p]  # bowfill.go:87-90
+    sel = both & ~valid
+    assert np.array_equal(gv[sel], lin[sel])
+    assert np.array_equal(gv[valid], vals[valid])
+
+
 def test_is_col_sorted():
     cases = [([1, 2, 2, 5], True), ([5, 4, 4, 1], True), ([1, 3, 2], False), ([None, None], False), ([], False),
              ([None, 1, None, 2, 3], True), ([3, None, 3, 3], True), ([1.0, float("nan"), 2.0], True)]

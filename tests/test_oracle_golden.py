@@ -160,6 +160,22 @@ def test_fill_linear(golden):
     same(out.to_list(), m["expect"])
 
 
+def test_fill_previous_next_mean(golden):
+    # bowfill_test.go:29-154, :204-330 - every column of newFreshBow under each method
+    n = 0
+    for typ, methods in golden["fill_methods"].items():
+        for method, expect in methods.items():
+            for name in ["a", "b", "c", "d", "e"]:
+                data = [None if x is None else (float(x) if typ == "float64" else x) for x in golden["fill_bow"][name]]
+                out, unchanged = orc.fill(orc.Column.from_list(data, T[typ]), method)
+                assert not unchanged and out.type == T[typ]
+                same(out.to_list(), expect[name])
+                n += 1
+    assert n == 30
+    out, unchanged = orc.fill(orc.Column.from_list([1, 2, 3], orc.INT64), "Mean")
+    assert unchanged and out.to_list() == [1, 2, 3]
+
+
 def test_factor(golden):
     # Factor(0.1): int64 11 -> 1, float64 11. -> 1.1 (factor_test.go:24-34), via a 1-window Last aggregation
     cols = [orc.Column.from_list([0], orc.INT64), orc.Column.from_list([11], orc.INT64)]

@@ -128,6 +128,10 @@ def test_hip_fill_and_sorted_on_the_file(bow1):
     want, wu = orc.fill_linear(ocols, 0, 1)
     assert unchanged == wu is False
     cmp_out("FillLinear", got, want)
+    for method in ("Previous", "Next", "Mean"):               # data.FillPrevious(3) / FillNext(3) / FillMean(3)
+        got, _ = capi.fill(ccols[1], method)
+        want, _ = orc.fill(ocols[1], method)
+        cmp_out("Fill" + method, got, want)
     assert capi.is_col_sorted(ccols[0]) is True               # data.IsColSorted(0)
     unsorted = capi.Column(bow1["Int64_no_nils_bow1"])
     assert capi.is_col_sorted(unsorted) is False              # data.IsColSorted(1)
