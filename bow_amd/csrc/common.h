@@ -236,8 +236,17 @@ int whole_final_run(Ctx *c, const void *partials, int64_t nblocks, int64_t nrows
                     const void *final_blob);
 size_t stats_size();
 
-// host-side mirrors of the kernel parameter blocks of interp_fill.hip (same layout; see the .hip)
-struct InterpColH {
+// Neighbour index of one validity bitmap: for every block of kNbrBlockBits bits (absolute bit positions, so blocks are
+// word-aligned whatever the Arrow offset) the nearest valid ROW before the block and after it.  Bounds every
+// previous/next-valid lookup to one block of words + one table read, however long the runs of nulls are.
+constexpr int kNbrBlockBits = 4096;
+struct NbrIndex {
+    const int64_t *prev_before;  // [nblocks] last valid row in any earlier block, -1 if none
+    const int64_t *next_after;   // [nblocks] first valid row in any later block, -1 if none
+    int64_t g0;                  // absolute block number of the column's first bit
+};
+// kernel parameter blocks of interp_fill.hip (filled by extras.cpp, passed by value)
+struct InterpCol {
     const uint64_t *values;
     const uint32_t *vbits;
     int64_t vbit0;
@@ -248,26 +257,18 @@ struct InterpColH {
     double prev_t, prev_v;
     int64_t prev_v_i64;
     uint64_t *out_values;
-    uint8_t *out_valid_bytes;
+    uint8_t *out_valid_bytes;  // one byte per output row, packed afterwards
+    NbrIndex nbr;              // of this column's bitmap (Linear / StepPrevious look their neighbours up through it)
 };
-struct InterpParamsH {
+struct InterpParams {
     const int64_t *ts;
     int64_t n, s0, interval, W;
     MagicDiv magic;
     const int64_t *first_idx;
     const int32_t *missing;
-    const int64_t *pos;
+    const int64_t *pos;  // exclusive scan of missing, W+1 entries
     int32_t ncols, ts_col;
-    InterpColH cols[kMaxCols];
-};
-// Neighbour index of one validity bitmap: for every block of kNbrBlockBits bits (absolute bit positions, so blocks are
-// word-aligned whatever the Arrow offset) the nearest valid ROW before the block and after it.  Bounds every
-// previous/next-valid lookup to one block of words + one table read, however long the runs of nulls are.
-constexpr int kNbrBlockBits = 4096;
-struct NbrIndex {
-    const int64_t *prev_before;  // [nblocks] last valid row in any earlier block, -1 if none
-    const int64_t *next_after;   // [nblocks] first valid row in any later block, -1 if none
-    int64_t g0;                  // absolute block number of the column's first bit
+    InterpCol cols[kMaxCols];
 };
 enum { kFillLinear = -1 };  // FillParams::method; >= 0: BOWGPU_FILL_PREVIOUS / NEXT / MEAN
 struct FillParams {

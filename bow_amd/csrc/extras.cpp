@@ -218,8 +218,8 @@ int bowgpu_rolling_interpolate_fill(const bowgpu_col *cols, int32_t ncols, int32
     const int64_t n_out = n + job.M;
     job.dcols.resize(ncols);
     std::vector<DevOut> douts(ninterps);
-    std::vector<DevBuf> vbytes(ninterps);
-    InterpParamsH P;
+    std::vector<DevBuf> vbytes(ninterps), ixbufs(ninterps);
+    InterpParams P;
     memset(&P, 0, sizeof P);
     P.ts = reinterpret_cast<const int64_t *>(job.dts.values);
     P.n = n; P.s0 = job.plan.s0; P.interval = job.plan.interval; P.W = job.plan.W; P.magic = job.plan.magic;
@@ -233,7 +233,7 @@ int bowgpu_rolling_interpolate_fill(const bowgpu_col *cols, int32_t ncols, int32
         else BG_TRY(devcol_prepare(c, &cols[i], &dc, true, true));
         BG_TRY(devout_prepare(c, &outs[i], n_out, &douts[i]));
         BG_TRY(vbytes[i].alloc((size_t)n_out + 64));
-        InterpColH &ic = P.cols[i];
+        InterpCol &ic = P.cols[i];
         ic.values = reinterpret_cast<const uint64_t *>(dc.values);
         ic.vbits = dc.vbits; ic.vbit0 = dc.vbit0; ic.type = cols[i].type; ic.kind = interps[i].kind;
         ic.const_value = interps[i].const_value;
@@ -241,6 +241,10 @@ int bowgpu_rolling_interpolate_fill(const bowgpu_col *cols, int32_t ncols, int32
         ic.prev_t = interps[i].prev_t; ic.prev_v = interps[i].prev_v; ic.prev_v_i64 = interps[i].prev_v_i64;
         ic.out_values = reinterpret_cast<uint64_t *>(douts[i].values);
         ic.out_valid_bytes = reinterpret_cast<uint8_t *>(vbytes[i].p);
+        if (dc.vbits && (ic.kind == BOWGPU_INTERP_LINEAR || ic.kind == BOWGPU_INTERP_STEP_PREVIOUS)) {
+            BG_TRY(ixbufs[i].alloc(nbr_index_bytes(n, dc.vbit0)));
+            BG_TRY(nbr_index_build(c, dc.vbits, dc.vbit0, n, ixbufs[i].p, &ic.nbr));
+        }
     }
     BG_TRY(interp_run(c, &P));
     void *dscr;

@@ -52,213 +52,6 @@ __device__ int64_t next_valid(const uint32_t *bits, int64_t bit0, int64_t n, int
 
 }  // namespace
 
-// ------------------------------------------------------------------ Interpolate
-// first row of every window: first_idx[k] = lower_bound(ts, s_k) for k in [0, W], first_idx[W] = n
-__global__ __launch_bounds__(256) void window_first_rows_kernel(const int64_t *ts, int64_t n, int64_t s0, int64_t interval,
-                                                                MagicDiv magic, int64_t W, int64_t *first_idx,
-                                                                uint32_t *status) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += stride) {
-        if (i == n) {  // windows after the last row's window do not exist (W = wid(last)+1); terminator
-            first_idx[W] = n;
-            continue;
-        }
-        const int64_t t = ts[i];
-        const uint64_t w = t < s0 ? 0 : magic_div((uint64_t)t - (uint64_t)s0, magic);
-        uint64_t wp;
-        if (i == 0) {
-            first_idx[0] = 0;
-            wp = 0;
-        } else {
-            const int64_t tp = ts[i - 1];
-            if (tp > t) atomicOr(&status[0], 1u);
-            wp = tp < s0 ? 0 : magic_div((uint64_t)tp - (uint64_t)s0, magic);
-        }
-        for (uint64_t k = wp + 1; k <= w && (int64_t)k < W; k++) first_idx[k] = i;  // k's first row (and every empty window before it)
-    }
-}
-
-// missing[k] = 1 when window k gets a synthetic start row (interpolation.go:118-137)
-__global__ __launch_bounds__(256) void window_missing_kernel(const int64_t *ts, int64_t s0, int64_t interval, int64_t W,
-                                                             const int64_t *first_idx, int32_t *missing) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < W; k += stride) {
-        const int64_t a = first_idx[k], b = first_idx[k + 1];
-        const int64_t sk = s0 + k * interval;
-        // Window 0 also spans rows below s0 (SURVEY A.5); its first valid ts is then ts[0] != s_0
-        int64_t first_col_value = -1;                                   // interpolation.go:119
-        if (k == 0 ? (b > 0 && ts[b - 1] >= s0) : (b > a))
-            first_col_value = go_f64_to_i64((double)ts[k == 0 ? 0 : a]);  // int64(float64(ts)) :121-123
-        missing[k] = first_col_value != sk;
-    }
-}
-
-// three-kernel exclusive scan of int32 flags into int64 positions
-__global__ __launch_bounds__(256) void scan_block_sums_kernel(const int32_t *in, int64_t n, int64_t *block_sums) {
-    __shared__ long long sh[4];
-    const int64_t base = (int64_t)blockIdx.x * 2048;
-    long long acc = 0;
-    for (int j = 0; j < 8; j++) {
-        const int64_t i = base + j * 256 + threadIdx.x;
-        if (i < n) acc += in[i];
-    }
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
-}
-__global__ void scan_sums_kernel(int64_t *block_sums, int64_t nblocks, int64_t *total) {
-    // single thread: nblocks = W/2048 (<= ~50 k for W = 1e8)
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        int64_t run = 0;
-        for (int64_t i = 0; i < nblocks; i++) { const int64_t v = block_sums[i]; block_sums[i] = run; run += v; }
-        *total = run;
-    }
-}
-__global__ __launch_bounds__(256) void scan_apply_kernel(const int32_t *in, int64_t n, const int64_t *block_sums, int64_t *out) {
-    __shared__ long long sh[256];
-    const int64_t base = (int64_t)blockIdx.x * 2048 + (int64_t)threadIdx.x * 8;
-    long long loc[8], acc = 0;
-    for (int j = 0; j < 8; j++) { loc[j] = acc; if (base + j < n) acc += in[base + j]; }
-    sh[threadIdx.x] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) { long long run = block_sums[blockIdx.x]; for (int t = 0; t < 256; t++) { const long long v = sh[t]; sh[t] = run; run += v; } }
-    __syncthreads();
-    const long long off = sh[threadIdx.x];
-    for (int j = 0; j < 8; j++) if (base + j < n) out[base + j] = off + loc[j];
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) out[n] = off + acc;  // out has n+1 entries
-}
-
-struct InterpCol {
-    const uint64_t *values;
-    const uint32_t *vbits;
-    int64_t vbit0;
-    int32_t type;
-    int32_t kind;
-    double const_value;
-    int32_t has_prev, prev_t_valid, prev_v_valid, _pad;
-    double prev_t, prev_v;
-    int64_t prev_v_i64;
-    uint64_t *out_values;
-    uint8_t *out_valid_bytes;  // one byte per output row, packed afterwards
-};
-struct InterpParams {
-    const int64_t *ts;
-    int64_t n, s0, interval, W;
-    MagicDiv magic;
-    const int64_t *first_idx;
-    const int32_t *missing;
-    const int64_t *pos;  // exclusive scan of missing, W+1 entries
-    int32_t ncols, ts_col;
-    InterpCol cols[kMaxCols];
-};
-
-// real rows: output position = i + (synthetic rows of windows <= wid(i))
-__global__ __launch_bounds__(256) void interp_scatter_rows_kernel(const InterpParams p) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < p.n; i += stride) {
-        const int64_t t = p.ts[i];
-        const uint64_t w = t < p.s0 ? 0 : magic_div((uint64_t)t - (uint64_t)p.s0, p.magic);
-        const int64_t o = i + p.pos[w + 1];
-        for (int c = 0; c < p.ncols; c++) {
-            const InterpCol &ic = p.cols[c];
-            ic.out_values[o] = ic.values[i];
-            ic.out_valid_bytes[o] = bit_at(ic.vbits, ic.vbit0, i) ? 1 : 0;
-        }
-    }
-}
-
-// synthetic rows: one per window that misses its start
-__global__ __launch_bounds__(256) void interp_synth_rows_kernel(const InterpParams p) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < p.W; k += stride) {
-        if (!p.missing[k]) continue;
-        const int64_t a = k == 0 ? 0 : p.first_idx[k];  // Window.FirstIndex
-        const int64_t o = a + p.pos[k];
-        const int64_t sk = p.s0 + k * p.interval;
-        for (int c = 0; c < p.ncols; c++) {
-            const InterpCol &ic = p.cols[c];
-            const bool is_int = ic.type == BOWGPU_INT64;
-            uint64_t bits = 0;
-            int valid = 0;
-            switch (ic.kind) {
-            case BOWGPU_INTERP_WINDOW_START:  // interpolation/windowstart.go:10-12
-                bits = is_int ? (uint64_t)sk : (uint64_t)__double_as_longlong((double)sk);
-                valid = 1;
-                break;
-            case BOWGPU_INTERP_CONST:
-                bits = is_int ? (uint64_t)go_f64_to_i64(ic.const_value) : (uint64_t)__double_as_longlong(ic.const_value);
-                valid = 1;
-                break;
-            case BOWGPU_INTERP_LINEAR: {  // interpolation/linear.go:12-37 (ts has no nulls: both-valid == value valid)
-                double t0, v0;
-                const int64_t pi = prev_valid(ic.vbits, ic.vbit0, p.n, a - 1);
-                if (pi >= 0) { t0 = (double)p.ts[pi]; v0 = bits_to_f64(ic.values[pi], ic.type); }
-                else if (ic.has_prev && ic.prev_t_valid && ic.prev_v_valid) { t0 = ic.prev_t; v0 = ic.prev_v; }
-                else break;
-                const int64_t ni = next_valid(ic.vbits, ic.vbit0, p.n, a);
-                if (ni < 0) break;
-                const double t2 = (double)p.ts[ni], v2 = bits_to_f64(ic.values[ni], ic.type);
-                const double coef = ((double)sk - t0) / (t2 - t0);
-                const double r = ((v2 - v0) * coef) + v0;
-                bits = is_int ? (uint64_t)go_f64_to_i64(r) : (uint64_t)__double_as_longlong(r);  // SetOrDrop: bowconvert.go:28-29
-                valid = 1;
-                break;
-            }
-            case BOWGPU_INTERP_STEP_PREVIOUS: {  // interpolation/stepprevious.go:11-24
-                const int64_t pi = prev_valid(ic.vbits, ic.vbit0, p.n, a - 1);
-                if (pi >= 0) { bits = ic.values[pi]; valid = 1; }
-                else if (ic.has_prev && ic.prev_v_valid) {
-                    bits = is_int ? (uint64_t)ic.prev_v_i64 : (uint64_t)__double_as_longlong(ic.prev_v);
-                    valid = 1;
-                }
-                break;
-            }
-            default: break;  // None: nil
-            }
-            ic.out_values[o] = valid ? bits : 0;
-            ic.out_valid_bytes[o] = (uint8_t)valid;
-        }
-    }
-}
-
-// bytes (0/1) -> Arrow validity bits, 32 rows per lane-word; also counts the set bits
-__global__ __launch_bounds__(256) void pack_validity_kernel(const uint8_t *bytes, int64_t n, uint32_t *words,
-                                                            unsigned long long *set_count) {
-    const int64_t nwords = (n + 31) >> 5;
-    unsigned long long acc = 0;
-    for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += (int64_t)gridDim.x * blockDim.x) {
-        uint32_t x = 0;
-        const int64_t base = w << 5;
-        for (int j = 0; j < 32; j++) if (base + j < n && bytes[base + j]) x |= 1u << j;
-        words[w] = x;
-        acc += __popc(x);
-    }
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
-    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(set_count, acc);
-}
-
-// ------------------------------------------------------------------ IsColSorted / FillLinear
-// flags[0] |= 1 if some consecutive valid pair increases, |= 2 if some decreases, |= 4 if any valid value exists
-__global__ __launch_bounds__(256) void col_order_kernel(const uint64_t *values, const uint32_t *vbits, int64_t vbit0, int64_t n,
-                                                        int32_t type, uint32_t *flags) {
-    uint32_t f = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        if (!bit_at(vbits, vbit0, i)) continue;
-        f |= 4;
-        const int64_t pi = prev_valid(vbits, vbit0, n, i - 1);
-        if (pi < 0) continue;
-        if (type == BOWGPU_INT64) {
-            const int64_t c = (int64_t)values[pi], x = (int64_t)values[i];
-            if (c < x) f |= 1; else if (c > x) f |= 2;
-        } else {
-            const double c = __longlong_as_double((long long)values[pi]), x = __longlong_as_double((long long)values[i]);
-            if (c < x) f |= 1; else if (c > x) f |= 2;  // NaN compares false both ways (bowassertion.go:64-74)
-        }
-    }
-    if (f) atomicOr(flags, f);
-}
-
 // ---- neighbour index (common.h NbrIndex)
 // one wavefront per block of 4096 bits = 128 words: last / first valid row inside the block
 __global__ __launch_bounds__(256) void nbr_block_kernel(const uint32_t *vbits, int64_t vbit0, int64_t n, int64_t g0, int64_t nblocks,
@@ -349,6 +142,189 @@ __device__ __forceinline__ int64_t next_valid_ix(const uint32_t *bits, int64_t b
     return ix.next_after[g - ix.g0];
 }
 }  // namespace
+
+// ------------------------------------------------------------------ Interpolate
+// first row of every window: first_idx[k] = lower_bound(ts, s_k) for k in [0, W], first_idx[W] = n
+__global__ __launch_bounds__(256) void window_first_rows_kernel(const int64_t *ts, int64_t n, int64_t s0, int64_t interval,
+                                                                MagicDiv magic, int64_t W, int64_t *first_idx,
+                                                                uint32_t *status) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += stride) {
+        if (i == n) {  // windows after the last row's window do not exist (W = wid(last)+1); terminator
+            first_idx[W] = n;
+            continue;
+        }
+        const int64_t t = ts[i];
+        const uint64_t w = t < s0 ? 0 : magic_div((uint64_t)t - (uint64_t)s0, magic);
+        uint64_t wp;
+        if (i == 0) {
+            first_idx[0] = 0;
+            wp = 0;
+        } else {
+            const int64_t tp = ts[i - 1];
+            if (tp > t) atomicOr(&status[0], 1u);
+            wp = tp < s0 ? 0 : magic_div((uint64_t)tp - (uint64_t)s0, magic);
+        }
+        for (uint64_t k = wp + 1; k <= w && (int64_t)k < W; k++) first_idx[k] = i;  // k's first row (and every empty window before it)
+    }
+}
+
+// missing[k] = 1 when window k gets a synthetic start row (interpolation.go:118-137)
+__global__ __launch_bounds__(256) void window_missing_kernel(const int64_t *ts, int64_t s0, int64_t interval, int64_t W,
+                                                             const int64_t *first_idx, int32_t *missing) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < W; k += stride) {
+        const int64_t a = first_idx[k], b = first_idx[k + 1];
+        const int64_t sk = s0 + k * interval;
+        // Window 0 also spans rows below s0 (SURVEY A.5); its first valid ts is then ts[0] != s_0
+        int64_t first_col_value = -1;                                   // interpolation.go:119
+        if (k == 0 ? (b > 0 && ts[b - 1] >= s0) : (b > a))
+            first_col_value = go_f64_to_i64((double)ts[k == 0 ? 0 : a]);  // int64(float64(ts)) :121-123
+        missing[k] = first_col_value != sk;
+    }
+}
+
+// three-kernel exclusive scan of int32 flags into int64 positions
+__global__ __launch_bounds__(256) void scan_block_sums_kernel(const int32_t *in, int64_t n, int64_t *block_sums) {
+    __shared__ long long sh[4];
+    const int64_t base = (int64_t)blockIdx.x * 2048;
+    long long acc = 0;
+    for (int j = 0; j < 8; j++) {
+        const int64_t i = base + j * 256 + threadIdx.x;
+        if (i < n) acc += in[i];
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+__global__ void scan_sums_kernel(int64_t *block_sums, int64_t nblocks, int64_t *total) {
+    // single thread: nblocks = W/2048 (<= ~50 k for W = 1e8)
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int64_t run = 0;
+        for (int64_t i = 0; i < nblocks; i++) { const int64_t v = block_sums[i]; block_sums[i] = run; run += v; }
+        *total = run;
+    }
+}
+__global__ __launch_bounds__(256) void scan_apply_kernel(const int32_t *in, int64_t n, const int64_t *block_sums, int64_t *out) {
+    __shared__ long long sh[256];
+    const int64_t base = (int64_t)blockIdx.x * 2048 + (int64_t)threadIdx.x * 8;
+    long long loc[8], acc = 0;
+    for (int j = 0; j < 8; j++) { loc[j] = acc; if (base + j < n) acc += in[base + j]; }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) { long long run = block_sums[blockIdx.x]; for (int t = 0; t < 256; t++) { const long long v = sh[t]; sh[t] = run; run += v; } }
+    __syncthreads();
+    const long long off = sh[threadIdx.x];
+    for (int j = 0; j < 8; j++) if (base + j < n) out[base + j] = off + loc[j];
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) out[n] = off + acc;  // out has n+1 entries
+}
+
+// real rows: output position = i + (synthetic rows of windows <= wid(i))
+__global__ __launch_bounds__(256) void interp_scatter_rows_kernel(const InterpParams p) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < p.n; i += stride) {
+        const int64_t t = p.ts[i];
+        const uint64_t w = t < p.s0 ? 0 : magic_div((uint64_t)t - (uint64_t)p.s0, p.magic);
+        const int64_t o = i + p.pos[w + 1];
+        for (int c = 0; c < p.ncols; c++) {
+            const InterpCol &ic = p.cols[c];
+            ic.out_values[o] = ic.values[i];
+            ic.out_valid_bytes[o] = bit_at(ic.vbits, ic.vbit0, i) ? 1 : 0;
+        }
+    }
+}
+
+// synthetic rows: one per window that misses its start
+__global__ __launch_bounds__(256) void interp_synth_rows_kernel(const InterpParams p) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < p.W; k += stride) {
+        if (!p.missing[k]) continue;
+        const int64_t a = k == 0 ? 0 : p.first_idx[k];  // Window.FirstIndex
+        const int64_t o = a + p.pos[k];
+        const int64_t sk = p.s0 + k * p.interval;
+        for (int c = 0; c < p.ncols; c++) {
+            const InterpCol &ic = p.cols[c];
+            const bool is_int = ic.type == BOWGPU_INT64;
+            uint64_t bits = 0;
+            int valid = 0;
+            switch (ic.kind) {
+            case BOWGPU_INTERP_WINDOW_START:  // interpolation/windowstart.go:10-12
+                bits = is_int ? (uint64_t)sk : (uint64_t)__double_as_longlong((double)sk);
+                valid = 1;
+                break;
+            case BOWGPU_INTERP_CONST:
+                bits = is_int ? (uint64_t)go_f64_to_i64(ic.const_value) : (uint64_t)__double_as_longlong(ic.const_value);
+                valid = 1;
+                break;
+            case BOWGPU_INTERP_LINEAR: {  // interpolation/linear.go:12-37 (ts has no nulls: both-valid == value valid)
+                double t0, v0;
+                const int64_t pi = prev_valid_ix(ic.vbits, ic.vbit0, p.n, a - 1, ic.nbr);
+                if (pi >= 0) { t0 = (double)p.ts[pi]; v0 = bits_to_f64(ic.values[pi], ic.type); }
+                else if (ic.has_prev && ic.prev_t_valid && ic.prev_v_valid) { t0 = ic.prev_t; v0 = ic.prev_v; }
+                else break;
+                const int64_t ni = next_valid_ix(ic.vbits, ic.vbit0, p.n, a, ic.nbr);
+                if (ni < 0) break;
+                const double t2 = (double)p.ts[ni], v2 = bits_to_f64(ic.values[ni], ic.type);
+                const double coef = ((double)sk - t0) / (t2 - t0);
+                const double r = ((v2 - v0) * coef) + v0;
+                bits = is_int ? (uint64_t)go_f64_to_i64(r) : (uint64_t)__double_as_longlong(r);  // SetOrDrop: bowconvert.go:28-29
+                valid = 1;
+                break;
+            }
+            case BOWGPU_INTERP_STEP_PREVIOUS: {  // interpolation/stepprevious.go:11-24
+                const int64_t pi = prev_valid_ix(ic.vbits, ic.vbit0, p.n, a - 1, ic.nbr);
+                if (pi >= 0) { bits = ic.values[pi]; valid = 1; }
+                else if (ic.has_prev && ic.prev_v_valid) {
+                    bits = is_int ? (uint64_t)ic.prev_v_i64 : (uint64_t)__double_as_longlong(ic.prev_v);
+                    valid = 1;
+                }
+                break;
+            }
+            default: break;  // None: nil
+            }
+            ic.out_values[o] = valid ? bits : 0;
+            ic.out_valid_bytes[o] = (uint8_t)valid;
+        }
+    }
+}
+
+// bytes (0/1) -> Arrow validity bits, 32 rows per lane-word; also counts the set bits
+__global__ __launch_bounds__(256) void pack_validity_kernel(const uint8_t *bytes, int64_t n, uint32_t *words,
+                                                            unsigned long long *set_count) {
+    const int64_t nwords = (n + 31) >> 5;
+    unsigned long long acc = 0;
+    for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t x = 0;
+        const int64_t base = w << 5;
+        for (int j = 0; j < 32; j++) if (base + j < n && bytes[base + j]) x |= 1u << j;
+        words[w] = x;
+        acc += __popc(x);
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(set_count, acc);
+}
+
+// ------------------------------------------------------------------ IsColSorted / FillLinear
+// flags[0] |= 1 if some consecutive valid pair increases, |= 2 if some decreases, |= 4 if any valid value exists
+__global__ __launch_bounds__(256) void col_order_kernel(const uint64_t *values, const uint32_t *vbits, int64_t vbit0, int64_t n,
+                                                        int32_t type, uint32_t *flags) {
+    uint32_t f = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (!bit_at(vbits, vbit0, i)) continue;
+        f |= 4;
+        const int64_t pi = prev_valid(vbits, vbit0, n, i - 1);
+        if (pi < 0) continue;
+        if (type == BOWGPU_INT64) {
+            const int64_t c = (int64_t)values[pi], x = (int64_t)values[i];
+            if (c < x) f |= 1; else if (c > x) f |= 2;
+        } else {
+            const double c = __longlong_as_double((long long)values[pi]), x = __longlong_as_double((long long)values[i]);
+            if (c < x) f |= 1; else if (c > x) f |= 2;  // NaN compares false both ways (bowassertion.go:64-74)
+        }
+    }
+    if (f) atomicOr(flags, f);
+}
 
 // Bow.FillLinear (bowfill.go:14-103), FillPrevious / FillNext (:162-253), FillMean (:105-160): one thread per row, null
 // rows look their neighbours up through the index
@@ -546,7 +522,6 @@ int launch_window_bounds(Ctx *c, const int64_t *ts, int64_t n, const Plan &plan,
 // launchers that take the kernel-parameter structs live here with them
 namespace bowgpu {
 
-static_assert(sizeof(InterpParams) == sizeof(InterpParamsH), "InterpParams layout");
 static_assert(sizeof(WholeParams) == sizeof(WholeParamsH), "WholeParams layout");
 static_assert(sizeof(WholeFinal) == sizeof(WholeFinalH), "WholeFinal layout");
 

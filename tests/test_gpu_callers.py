@@ -80,6 +80,32 @@ def test_interpolate_random_vs_oracle(vtype):
                 cmp_out("val %s n=%d prev=%s" % (kind, n, prev is not None), got[1], want[1])
 
 
+def test_interpolate_across_long_null_runs():
+    # runs of nulls longer than a 4096-bit block of the neighbour index, with irregular ts: Linear / StepPrevious at every
+    # window start inside a run reach the same two far-away neighbours.  (Sizes are bounded by the ORACLE: like the reference's
+    # GetPrevFloat64s it is quadratic in the run length per window.)
+    rng = np.random.default_rng(5)
+    n = 40_000
+    ts = np.cumsum(rng.integers(1, 20, n)).astype(np.int64)
+    vals = np.round(rng.standard_normal(n) * 100, 2)
+    valid = rng.random(n) >= 0.3
+    valid[2_000:7_000] = False      # crosses the block boundaries at bits 4096 (and 8192 with the Arrow offset below)
+    valid[20_470:24_600] = False    # starts just before bit 20480 = 5 * 4096
+    valid[:7] = False
+    valid[-9:] = False
+    bm = np.packbits(valid, bitorder="little")
+    for off in (0, 1500):
+        m = n - off
+        for kind in ("Linear", "StepPrevious"):
+            ip = [{"kind": "WindowStart", "col": 0}, {"kind": kind, "col": 1}]
+            got = capi.rolling_interpolate([capi.Column(ts, None, capi.INT64, off, m, 0), capi.Column(vals, bm, capi.FLOAT64, off, m, -1)],
+                                           0, 1000, ip, offset=3)
+            want = orc.interpolate([orc.Column(ts, None, orc.INT64, offset=off, length=m),
+                                    orc.Column(vals, bm, orc.FLOAT64, offset=off, length=m)], 0, 1000, ip, offset=3)
+            cmp_out("ts " + kind, got[0], want[0])
+            cmp_out("val " + kind, got[1], want[1])
+
+
 def test_interpolate_then_mean_sparse_generator():
     # configs[2]: irregular ts, 30 % nulls, Linear fill then rolling mean - both stages on the device
     n = 300_000
