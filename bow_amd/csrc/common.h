@@ -224,13 +224,11 @@ int launch_fill_empty(Ctx *c, const AggParams &p, int64_t slot0, int64_t slot1);
 
 // interp_fill.hip
 int launch_window_first_rows(Ctx *c, const int64_t *ts, int64_t n, const Plan &plan, int64_t *first_idx, uint32_t *status);
-int launch_window_missing(Ctx *c, const int64_t *ts, const Plan &plan, const int64_t *first_idx, int32_t *missing);
 int launch_exclusive_scan(Ctx *c, const int32_t *in, int64_t n, int64_t *out, int64_t *block_sums, int64_t *d_total);
 int launch_pack_validity(Ctx *c, const uint8_t *bytes, int64_t n, uint32_t *words, uint64_t *d_set_count);
 int launch_col_order(Ctx *c, const uint64_t *values, const uint32_t *vbits, int64_t vbit0, int64_t n, int32_t type, uint32_t *d_flags);
 int launch_window_bounds(Ctx *c, const int64_t *ts, int64_t n, const Plan &plan, int inclusive, int pre_rows,
                          const int64_t *first_idx, int64_t *first_index, int64_t *slice_begin, int64_t *slice_end, uint8_t *is_incl);
-int interp_run(Ctx *c, const void *params_blob);
 int whole_run(Ctx *c, const void *params_blob, int64_t nblocks);
 int whole_final_run(Ctx *c, const void *partials, int64_t nblocks, int64_t nrows, int64_t first_value, int64_t last_value,
                     const void *final_blob);
@@ -257,19 +255,23 @@ struct InterpCol {
     double prev_t, prev_v;
     int64_t prev_v_i64;
     uint64_t *out_values;
-    uint8_t *out_valid_bytes;  // one byte per output row, packed afterwards
+    uint32_t *out_valid_words; // output validity bitmap (zeroed by the host before the launch)
     NbrIndex nbr;              // of this column's bitmap (Linear / StepPrevious look their neighbours up through it)
 };
 struct InterpParams {
     const int64_t *ts;
     int64_t n, s0, interval, W;
     MagicDiv magic;
-    const int64_t *first_idx;
-    const int32_t *missing;
-    const int64_t *pos;  // exclusive scan of missing, W+1 entries
+    const int64_t *tile_exact_before;  // per tile of interpolate.hip: exact heads in all earlier tiles
+    uint32_t *status;                  // [0] |= 1: interval column not ascending; [1]: window kq has no row of its own
+    int64_t kq;                        // index of the window that starts at -1 (the reference's "no first value" sentinel), else -1
+    int64_t drop;                      // leading rows that belong to no window (interp_quirk_kernel), normally 0
     int32_t ncols, ts_col;
     InterpCol cols[kMaxCols];
 };
+int64_t interp_tiles(int64_t n);
+int launch_interp_count(Ctx *c, const int64_t *ts, int64_t n, const Plan &plan, int64_t kq, int32_t *tile_exact, uint32_t *status);
+int launch_interp_tiles(Ctx *c, const InterpParams &p);
 enum { kFillLinear = -1 };  // FillParams::method; >= 0: BOWGPU_FILL_PREVIOUS / NEXT / MEAN
 struct FillParams {
     const uint64_t *ref_values; const uint32_t *ref_vbits; int64_t ref_vbit0; int32_t ref_type;  // FillLinear only

@@ -140,10 +140,13 @@ struct InterpJob {
     Plan plan;
     DevCol dts;
     std::vector<DevCol> dcols;
-    DevBuf first_idx, missing, pos, block_sums;
-    int64_t M = 0;
+    DevBuf tile_exact, tile_before, block_sums;
+    int64_t kq = -1;  // window whose start is -1 (InterpParams::kq)
+    int64_t drop = 0; // leading rows that belong to no window (InterpParams::drop)
+    int64_t M = 0;    // output rows - input rows
 };
 
+// pass 1 of interpolate.hip: exact heads per tile, their exclusive scan, M = synthetic rows
 static int interp_prepare(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval,
                           const bowgpu_options *o, InterpJob *job) {
     BG_TRY(plan_make(c, &cols[ts_col], interval, o->offset, &job->plan));
@@ -154,20 +157,25 @@ static int interp_prepare(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t
     if (n == 0) return 0;
     BG_TRY(ts_contract(c, &cols[ts_col]));
     BG_TRY(ts_device(c, &cols[ts_col], &job->dts));
-    if (W == 0) return 0;
-    BG_TRY(job->first_idx.alloc((size_t)(W + 1) * 8));
-    BG_TRY(job->missing.alloc((size_t)W * 4 + 16));
-    BG_TRY(job->pos.alloc((size_t)(W + 1) * 8));
-    BG_TRY(job->block_sums.alloc((size_t)((W + 2047) / 2048 + 1) * 8));
+    if (W == 0) { job->M = -n; return 0; }  // no window at all (every row lies below s0): the concatenation of zero window bows is empty
+    const Plan &pl = job->plan;
+    job->kq = -1;
+    if (pl.s0 <= -1 && (uint64_t)(-1 - pl.s0) % (uint64_t)pl.interval == 0) {
+        const int64_t k = (int64_t)((uint64_t)(-1 - pl.s0) / (uint64_t)pl.interval);
+        if (k < W) job->kq = k;
+    }
+    const int64_t ntiles = interp_tiles(n);
+    BG_TRY(job->tile_exact.alloc((size_t)ntiles * 4 + 16));
+    BG_TRY(job->tile_before.alloc((size_t)(ntiles + 1) * 8));
+    BG_TRY(job->block_sums.alloc((size_t)((ntiles + 2047) / 2048 + 1) * 8));
     void *dscr;
     BG_TRY(ctx_scratch(c, 8192, &dscr));
     uint32_t *status = reinterpret_cast<uint32_t *>(dscr);
     int64_t *d_total = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(dscr) + 512);
     BG_HIP(hipMemsetAsync(status, 0, 64, c->stream));
     const int64_t *ts = reinterpret_cast<const int64_t *>(job->dts.values);
-    BG_TRY(launch_window_first_rows(c, ts, n, job->plan, reinterpret_cast<int64_t *>(job->first_idx.p), status));
-    BG_TRY(launch_window_missing(c, ts, job->plan, reinterpret_cast<const int64_t *>(job->first_idx.p), reinterpret_cast<int32_t *>(job->missing.p)));
-    BG_TRY(launch_exclusive_scan(c, reinterpret_cast<const int32_t *>(job->missing.p), W, reinterpret_cast<int64_t *>(job->pos.p),
+    BG_TRY(launch_interp_count(c, ts, n, pl, job->kq, reinterpret_cast<int32_t *>(job->tile_exact.p), status));
+    BG_TRY(launch_exclusive_scan(c, reinterpret_cast<const int32_t *>(job->tile_exact.p), ntiles, reinterpret_cast<int64_t *>(job->tile_before.p),
                                  reinterpret_cast<int64_t *>(job->block_sums.p), d_total));
     uint32_t hstat[4];
     int64_t total = 0;
@@ -175,7 +183,8 @@ static int interp_prepare(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t
     BG_HIP(hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, c->stream));
     BG_HIP(hipStreamSynchronize(c->stream));
     if (hstat[0]) return fail(BOWGPU_ERR_TS_UNSORTED, "interval column is not ascending: outside the device path");
-    job->M = total;
+    job->drop = (int64_t)(((uint64_t)hstat[3] << 32) | hstat[2]);
+    job->M = W - total - ((job->kq >= 0 && hstat[1]) ? 1 : 0) - job->drop;  // rows added (synthetic) minus rows dropped
     return 0;
 }
 
@@ -216,23 +225,30 @@ int bowgpu_rolling_interpolate_fill(const bowgpu_col *cols, int32_t ncols, int32
     InterpJob job;
     BG_TRY(interp_prepare(c, cols, ncols, ts_col, interval, &o, &job));
     const int64_t n_out = n + job.M;
+    if (n_out == 0) {
+        for (int i = 0; i < ninterps; i++) { outs[i].length = 0; outs[i].null_count = 0; outs[i].type = cols[i].type; }
+        return 0;
+    }
     job.dcols.resize(ncols);
     std::vector<DevOut> douts(ninterps);
-    std::vector<DevBuf> vbytes(ninterps), ixbufs(ninterps);
+    std::vector<DevBuf> ixbufs(ninterps);
     InterpParams P;
     memset(&P, 0, sizeof P);
+    void *dscr;
+    BG_TRY(ctx_scratch(c, 8192, &dscr));
     P.ts = reinterpret_cast<const int64_t *>(job.dts.values);
     P.n = n; P.s0 = job.plan.s0; P.interval = job.plan.interval; P.W = job.plan.W; P.magic = job.plan.magic;
-    P.first_idx = reinterpret_cast<const int64_t *>(job.first_idx.p);
-    P.missing = reinterpret_cast<const int32_t *>(job.missing.p);
-    P.pos = reinterpret_cast<const int64_t *>(job.pos.p);
+    P.tile_exact_before = reinterpret_cast<const int64_t *>(job.tile_before.p);
+    P.status = reinterpret_cast<uint32_t *>(dscr);  // (status[1] still holds pass 1's answer about window kq)
+    P.kq = job.kq;
+    P.drop = job.drop;
     P.ncols = ncols; P.ts_col = ts_col;
     for (int i = 0; i < ncols; i++) {
         DevCol &dc = job.dcols[i];
         if (i == ts_col) { dc.values = job.dts.values; dc.length = n; dc.type = BOWGPU_INT64; }
         else BG_TRY(devcol_prepare(c, &cols[i], &dc, true, true));
         BG_TRY(devout_prepare(c, &outs[i], n_out, &douts[i]));
-        BG_TRY(vbytes[i].alloc((size_t)n_out + 64));
+        BG_HIP(hipMemsetAsync(douts[i].validity, 0, (size_t)(((n_out + 7) >> 3) + 3) & ~(size_t)3, c->stream));
         InterpCol &ic = P.cols[i];
         ic.values = reinterpret_cast<const uint64_t *>(dc.values);
         ic.vbits = dc.vbits; ic.vbit0 = dc.vbit0; ic.type = cols[i].type; ic.kind = interps[i].kind;
@@ -240,19 +256,17 @@ int bowgpu_rolling_interpolate_fill(const bowgpu_col *cols, int32_t ncols, int32
         ic.has_prev = interps[i].has_prev_row; ic.prev_t_valid = interps[i].prev_t_valid; ic.prev_v_valid = interps[i].prev_v_valid;
         ic.prev_t = interps[i].prev_t; ic.prev_v = interps[i].prev_v; ic.prev_v_i64 = interps[i].prev_v_i64;
         ic.out_values = reinterpret_cast<uint64_t *>(douts[i].values);
-        ic.out_valid_bytes = reinterpret_cast<uint8_t *>(vbytes[i].p);
+        ic.out_valid_words = reinterpret_cast<uint32_t *>(douts[i].validity);
         if (dc.vbits && (ic.kind == BOWGPU_INTERP_LINEAR || ic.kind == BOWGPU_INTERP_STEP_PREVIOUS)) {
             BG_TRY(ixbufs[i].alloc(nbr_index_bytes(n, dc.vbit0)));
             BG_TRY(nbr_index_build(c, dc.vbits, dc.vbit0, n, ixbufs[i].p, &ic.nbr));
         }
     }
-    BG_TRY(interp_run(c, &P));
-    void *dscr;
-    BG_TRY(ctx_scratch(c, 8192, &dscr));
+    BG_TRY(launch_interp_tiles(c, P));
     uint64_t *dcnt = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(dscr) + 1024);
     std::vector<uint64_t> hcnt(ninterps, 0);
     for (int i = 0; i < ninterps; i++) {
-        BG_TRY(launch_pack_validity(c, reinterpret_cast<const uint8_t *>(vbytes[i].p), n_out, reinterpret_cast<uint32_t *>(douts[i].validity), dcnt + i));
+        BG_TRY(launch_popcount(c, reinterpret_cast<const uint32_t *>(douts[i].validity), 0, n_out, dcnt + i));
         BG_HIP(hipMemcpyAsync(&hcnt[i], dcnt + i, 8, hipMemcpyDeviceToHost, c->stream));
     }
     BG_HIP(hipStreamSynchronize(c->stream));

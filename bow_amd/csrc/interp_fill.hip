@@ -4,53 +4,10 @@
 //   * Bow.FillLinear (reference bowfill.go:14-103) and Bow.IsColSorted (bowassertion.go:15-81),
 //   * the whole-frame aggregation.Aggregate (reference rolling/aggregation/whole.go:12-93).
 // All are streaming, HBM-bound passes over Arrow value / validity buffers; none is a contraction.
-#include "agg_device.h"
+#include "bitmap_device.h"
 
 namespace bowgpu {
 
-namespace {
-
-__device__ __forceinline__ bool bit_at(const uint32_t *bits, int64_t bit0, int64_t row) {
-    if (!bits) return true;
-    const int64_t b = bit0 + row;
-    return (bits[b >> 5] >> (b & 31)) & 1u;
-}
-
-// previous / next valid row of a column (Bow.GetPrevFloat64 / GetNextFloat64 index semantics,
-// bowgetters.go:252-277), skipping 32 rows at a time over all-null words
-__device__ int64_t prev_valid(const uint32_t *bits, int64_t bit0, int64_t n, int64_t row) {
-    if (row < 0 || row >= n) return -1;
-    if (!bits) return row;
-    int64_t b = bit0 + row;
-    while (b >= bit0) {
-        const int64_t w = b >> 5;
-        const int sh = (int)(b & 31);
-        uint32_t x = bits[w];
-        x = sh == 31 ? x : (x & ((2u << sh) - 1u));  // bits <= sh
-        if (w == (bit0 >> 5)) x &= ~0u << (bit0 & 31);  // not before the column's first bit
-        if (x) return (w << 5) + (31 - __clz((int)x)) - bit0;
-        b = (w << 5) - 1;
-    }
-    return -1;
-}
-__device__ int64_t next_valid(const uint32_t *bits, int64_t bit0, int64_t n, int64_t row) {
-    if (row < 0 || row >= n) return -1;
-    if (!bits) return row;
-    int64_t b = bit0 + row;
-    const int64_t bend = bit0 + n;
-    while (b < bend) {
-        const int64_t w = b >> 5;
-        uint32_t x = bits[w] & (~0u << (b & 31));
-        if (x) {
-            const int64_t r = (w << 5) + (__ffs((int)x) - 1) - bit0;
-            return r < n ? r : -1;
-        }
-        b = (w + 1) << 5;
-    }
-    return -1;
-}
-
-}  // namespace
 
 // ---- neighbour index (common.h NbrIndex)
 // one wavefront per block of 4096 bits = 128 words: last / first valid row inside the block
@@ -107,41 +64,6 @@ __global__ __launch_bounds__(1024) void nbr_scan_kernel(const int64_t *last_in, 
     for (int64_t g = b - 1; g >= a; g--) { next_after[g] = run == INT64_MAX ? -1 : run; if (first_in[g] < run) run = first_in[g]; }
 }
 
-namespace {
-// previous / next valid row at or before / after `row`, looking at most one block of words, then the index
-__device__ __forceinline__ int64_t prev_valid_ix(const uint32_t *bits, int64_t bit0, int64_t n, int64_t row, const NbrIndex &ix) {
-    if (row < 0 || row >= n) return -1;
-    if (!bits) return row;
-    int64_t b = bit0 + row;
-    const int64_t g = b / kNbrBlockBits;
-    const int64_t stop = g * kNbrBlockBits > bit0 ? g * kNbrBlockBits : bit0;  // first bit of the block that belongs to the column
-    while (b >= stop) {
-        const int64_t w = b >> 5;
-        const int sh = (int)(b & 31);
-        uint32_t x = bits[w];
-        x = sh == 31 ? x : (x & ((2u << sh) - 1u));
-        if ((w << 5) < stop) x &= ~0u << (stop - (w << 5));
-        if (x) return (w << 5) + (31 - __clz((int)x)) - bit0;
-        b = (w << 5) - 1;
-    }
-    return ix.prev_before[g - ix.g0];
-}
-__device__ __forceinline__ int64_t next_valid_ix(const uint32_t *bits, int64_t bit0, int64_t n, int64_t row, const NbrIndex &ix) {
-    if (row < 0 || row >= n) return -1;
-    if (!bits) return row;
-    int64_t b = bit0 + row;
-    const int64_t g = b / kNbrBlockBits;
-    const int64_t bend = (g + 1) * kNbrBlockBits < bit0 + n ? (g + 1) * kNbrBlockBits : bit0 + n;
-    while (b < bend) {
-        const int64_t w = b >> 5;
-        uint32_t x = bits[w] & (~0u << (b & 31));
-        if (((w + 1) << 5) > bend) x &= (1u << (bend - (w << 5))) - 1u;
-        if (x) return (w << 5) + (__ffs((int)x) - 1) - bit0;
-        b = (w + 1) << 5;
-    }
-    return ix.next_after[g - ix.g0];
-}
-}  // namespace
 
 // ------------------------------------------------------------------ Interpolate
 // first row of every window: first_idx[k] = lower_bound(ts, s_k) for k in [0, W], first_idx[W] = n
@@ -166,21 +88,6 @@ __global__ __launch_bounds__(256) void window_first_rows_kernel(const int64_t *t
             wp = tp < s0 ? 0 : magic_div((uint64_t)tp - (uint64_t)s0, magic);
         }
         for (uint64_t k = wp + 1; k <= w && (int64_t)k < W; k++) first_idx[k] = i;  // k's first row (and every empty window before it)
-    }
-}
-
-// missing[k] = 1 when window k gets a synthetic start row (interpolation.go:118-137)
-__global__ __launch_bounds__(256) void window_missing_kernel(const int64_t *ts, int64_t s0, int64_t interval, int64_t W,
-                                                             const int64_t *first_idx, int32_t *missing) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < W; k += stride) {
-        const int64_t a = first_idx[k], b = first_idx[k + 1];
-        const int64_t sk = s0 + k * interval;
-        // Window 0 also spans rows below s0; its first valid ts is then ts[0] != s_0
-        int64_t first_col_value = -1;                                   // interpolation.go:119
-        if (k == 0 ? (b > 0 && ts[b - 1] >= s0) : (b > a))
-            first_col_value = go_f64_to_i64((double)ts[k == 0 ? 0 : a]);  // int64(float64(ts)) :121-123
-        missing[k] = first_col_value != sk;
     }
 }
 
@@ -218,75 +125,6 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const int32_t *in, int6
     const long long off = sh[threadIdx.x];
     for (int j = 0; j < 8; j++) if (base + j < n) out[base + j] = off + loc[j];
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) out[n] = off + acc;  // out has n+1 entries
-}
-
-// real rows: output position = i + (synthetic rows of windows <= wid(i))
-__global__ __launch_bounds__(256) void interp_scatter_rows_kernel(const InterpParams p) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < p.n; i += stride) {
-        const int64_t t = p.ts[i];
-        const uint64_t w = t < p.s0 ? 0 : magic_div((uint64_t)t - (uint64_t)p.s0, p.magic);
-        const int64_t o = i + p.pos[w + 1];
-        for (int c = 0; c < p.ncols; c++) {
-            const InterpCol &ic = p.cols[c];
-            ic.out_values[o] = ic.values[i];
-            ic.out_valid_bytes[o] = bit_at(ic.vbits, ic.vbit0, i) ? 1 : 0;
-        }
-    }
-}
-
-// synthetic rows: one per window that misses its start
-__global__ __launch_bounds__(256) void interp_synth_rows_kernel(const InterpParams p) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < p.W; k += stride) {
-        if (!p.missing[k]) continue;
-        const int64_t a = k == 0 ? 0 : p.first_idx[k];  // Window.FirstIndex
-        const int64_t o = a + p.pos[k];
-        const int64_t sk = p.s0 + k * p.interval;
-        for (int c = 0; c < p.ncols; c++) {
-            const InterpCol &ic = p.cols[c];
-            const bool is_int = ic.type == BOWGPU_INT64;
-            uint64_t bits = 0;
-            int valid = 0;
-            switch (ic.kind) {
-            case BOWGPU_INTERP_WINDOW_START:  // interpolation/windowstart.go:10-12
-                bits = is_int ? (uint64_t)sk : (uint64_t)__double_as_longlong((double)sk);
-                valid = 1;
-                break;
-            case BOWGPU_INTERP_CONST:
-                bits = is_int ? (uint64_t)go_f64_to_i64(ic.const_value) : (uint64_t)__double_as_longlong(ic.const_value);
-                valid = 1;
-                break;
-            case BOWGPU_INTERP_LINEAR: {  // interpolation/linear.go:12-37 (ts has no nulls: both-valid == value valid)
-                double t0, v0;
-                const int64_t pi = prev_valid_ix(ic.vbits, ic.vbit0, p.n, a - 1, ic.nbr);
-                if (pi >= 0) { t0 = (double)p.ts[pi]; v0 = bits_to_f64(ic.values[pi], ic.type); }
-                else if (ic.has_prev && ic.prev_t_valid && ic.prev_v_valid) { t0 = ic.prev_t; v0 = ic.prev_v; }
-                else break;
-                const int64_t ni = next_valid_ix(ic.vbits, ic.vbit0, p.n, a, ic.nbr);
-                if (ni < 0) break;
-                const double t2 = (double)p.ts[ni], v2 = bits_to_f64(ic.values[ni], ic.type);
-                const double coef = ((double)sk - t0) / (t2 - t0);
-                const double r = ((v2 - v0) * coef) + v0;
-                bits = is_int ? (uint64_t)go_f64_to_i64(r) : (uint64_t)__double_as_longlong(r);  // SetOrDrop: bowconvert.go:28-29
-                valid = 1;
-                break;
-            }
-            case BOWGPU_INTERP_STEP_PREVIOUS: {  // interpolation/stepprevious.go:11-24
-                const int64_t pi = prev_valid_ix(ic.vbits, ic.vbit0, p.n, a - 1, ic.nbr);
-                if (pi >= 0) { bits = ic.values[pi]; valid = 1; }
-                else if (ic.has_prev && ic.prev_v_valid) {
-                    bits = is_int ? (uint64_t)ic.prev_v_i64 : (uint64_t)__double_as_longlong(ic.prev_v);
-                    valid = 1;
-                }
-                break;
-            }
-            default: break;  // None: nil
-            }
-            ic.out_values[o] = valid ? bits : 0;
-            ic.out_valid_bytes[o] = (uint8_t)valid;
-        }
-    }
 }
 
 // bytes (0/1) -> Arrow validity bits, 32 rows per lane-word; also counts the set bits
@@ -474,13 +312,6 @@ int launch_window_first_rows(Ctx *c, const int64_t *ts, int64_t n, const Plan &p
     return 0;
 }
 
-int launch_window_missing(Ctx *c, const int64_t *ts, const Plan &plan, const int64_t *first_idx, int32_t *missing) {
-    hipLaunchKernelGGL(window_missing_kernel, dim3(grid_for(plan.W)), dim3(256), 0, c->stream, ts, plan.s0, plan.interval, plan.W,
-                       first_idx, missing);
-    BG_HIP(hipGetLastError());
-    return 0;
-}
-
 int launch_exclusive_scan(Ctx *c, const int32_t *in, int64_t n, int64_t *out /* n+1 */, int64_t *block_sums, int64_t *d_total) {
     const int64_t nblocks = (n + 2047) / 2048;
     if (n == 0) { BG_HIP(hipMemsetAsync(out, 0, 8, c->stream)); BG_HIP(hipMemsetAsync(d_total, 0, 8, c->stream)); return 0; }
@@ -524,14 +355,6 @@ namespace bowgpu {
 
 static_assert(sizeof(WholeParams) == sizeof(WholeParamsH), "WholeParams layout");
 static_assert(sizeof(WholeFinal) == sizeof(WholeFinalH), "WholeFinal layout");
-
-int interp_run(Ctx *c, const void *params_blob) {
-    const InterpParams &p = *reinterpret_cast<const InterpParams *>(params_blob);
-    if (p.n > 0) hipLaunchKernelGGL(interp_scatter_rows_kernel, dim3(grid_for(p.n)), dim3(256), 0, c->stream, p);
-    if (p.W > 0) hipLaunchKernelGGL(interp_synth_rows_kernel, dim3(grid_for(p.W)), dim3(256), 0, c->stream, p);
-    BG_HIP(hipGetLastError());
-    return 0;
-}
 
 size_t nbr_index_bytes(int64_t n, int64_t vbit0) {
     const int64_t nblocks = (vbit0 + (n > 0 ? n : 1) - 1) / kNbrBlockBits - vbit0 / kNbrBlockBits + 1;

@@ -80,6 +80,46 @@ def test_interpolate_random_vs_oracle(vtype):
                 cmp_out("val %s n=%d prev=%s" % (kind, n, prev is not None), got[1], want[1])
 
 
+def test_interpolate_empty_window_runs_and_the_minus_one_sentinel():
+    # (1) long runs of empty windows (thousands of synthetic rows in front of one row, more than a tile stages in LDS);
+    # (2) the reference's sentinel: an EMPTY window whose start is -1 gets no synthetic row, because "no first value" is
+    #     encoded as -1 and compares equal to the window start (interpolation.go:119-125)
+    rng = np.random.default_rng(12)
+    ip = [{"kind": "WindowStart", "col": 0}, {"kind": "Linear", "col": 1}, {"kind": "StepPrevious", "col": 2}]
+
+    def check(ts, interval, offset):
+        n = len(ts)
+        v1 = np.round(rng.standard_normal(n) * 10, 1)
+        v2 = rng.integers(-50, 50, n).astype(np.int64)
+        m1, m2 = rng.random(n) >= 0.3, rng.random(n) >= 0.3
+        b1, b2 = np.packbits(m1, bitorder="little"), np.packbits(m2, bitorder="little")
+        got = capi.rolling_interpolate([capi.Column(ts), capi.Column(v1, b1, capi.FLOAT64, 0, n, -1), capi.Column(v2, b2, capi.INT64, 0, n, -1)],
+                                       0, interval, ip, offset=offset)
+        want = orc.interpolate([orc.Column(ts, None, orc.INT64), orc.Column(v1, b1, orc.FLOAT64), orc.Column(v2, b2, orc.INT64)],
+                               0, interval, ip, offset=offset)
+        for c in range(3):
+            cmp_out("col %d I=%d off=%d" % (c, interval, offset), got[c], want[c])
+        return got[0].length - n
+
+    step = rng.integers(1, 4, 30_000)
+    step[rng.random(30_000) < 0.003] = rng.integers(5_000, 60_000)
+    added = check(np.cumsum(step).astype(np.int64) - 1_000_000, 7, 2)
+    assert added > 100_000
+    # window starts = 4 (mod 5): ..., -6, -1, 4, ...; the window [-1, 4) is empty in the first two, not in the third
+    assert check(np.array([-11, -9, 6, 7], dtype=np.int64), 5, 4) == 2      # windows -11, -6 (exact / synthetic), NOT -1, then 4
+    # s0 = -1 above ts[0] = -3 (Go's truncating division) and window 0 = [-1, 4) has no row of its own: the row
+    # below s0 belongs to no window and is dropped; window 0 gets no synthetic row either (sentinel); window 1 gets one (4)
+    assert check(np.array([-3, 6, 7], dtype=np.int64), 5, 4) == 0
+    assert check(np.array([-8, -7, 4, 9], dtype=np.int64), 5, 4) == -1      # -8, -7 dropped; synthetic -6; none for -1; 4 exact
+    assert check(np.array([-8, -7, -3, 4, 9], dtype=np.int64), 5, 4) == 1   # window 0 has -3: nothing dropped
+    assert check(np.array([-3, -2], dtype=np.int64), 5, 4) == -2            # no window at all => empty result
+    check(np.array([-11, -9, 0, 6, 7], dtype=np.int64), 5, 4)
+    check(np.array([-1, 3, 4, 9, 30], dtype=np.int64), 5, 4)                # -1 is an exact head
+    # rows below s0 (Go's truncating division) with s0 = -1
+    check(np.array([-3, -2, 8, 9], dtype=np.int64), 5, 4)
+    check(np.array([-3, -2, 0, 8, 9], dtype=np.int64), 5, 4)
+
+
 def test_interpolate_across_long_null_runs():
     # runs of nulls longer than a 4096-bit block of the neighbour index, with irregular ts: Linear / StepPrevious at every
     # window start inside a run reach the same two far-away neighbours.  (Sizes are bounded by the ORACLE: like the reference's
