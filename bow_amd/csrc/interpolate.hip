@@ -19,42 +19,12 @@ namespace bowgpu {
 
 namespace {
 
-constexpr int kITile = 1024;        // rows per workgroup
+constexpr int kIR = 2;              // consecutive rows per thread (one 16-B load per lane and column)
+constexpr int kITile = 512;         // rows per workgroup
 constexpr int kIThreads = 256;
-constexpr int kIRounds = kITile / kIThreads;
+constexpr int kIStage = 1024;       // outputs of one column staged in LDS per tile (rows + synthetic rows)
 constexpr int kISpanWords = 128;    // output validity bits staged in LDS per column: 4096 bits (rows + synthetic rows of a tile)
 constexpr int kSmallRun = 4;        // synthetic rows a lane writes itself; longer runs of empty windows go to the whole workgroup
-
-struct RowFlags {
-    uint64_t wid;
-    int64_t synth;   // synthetic rows right in front of this row
-    bool exact;
-};
-
-// wid / head / exact-head / synthetic rows in front of row i (i > 0 reads ts[i-1] too)
-// kq >= 0: the window whose start is -1 has no row of its own; the reference then takes its "first value" -1
-// (interpolation.go:119) for a timestamp equal to the window start and adds NO synthetic row for it.
-__device__ __forceinline__ RowFlags row_flags(const int64_t *ts, int64_t i, int64_t s0, int64_t interval, const MagicDiv &magic,
-                                              int64_t kq, bool *unsorted) {
-    RowFlags f;
-    const int64_t t = ts[i];
-    f.wid = t < s0 ? 0 : magic_div((uint64_t)t - (uint64_t)s0, magic);   // rows below s0 ride in window 0
-    bool head = true;
-    uint64_t wprev = 0;
-    int64_t before = 0;  // windows that end before this row's window and have no row: wid - wprev - 1
-    if (i > 0) {
-        const int64_t tp = ts[i - 1];
-        if (tp > t) *unsorted = true;
-        wprev = tp < s0 ? 0 : magic_div((uint64_t)tp - (uint64_t)s0, magic);
-        head = f.wid != wprev;
-        before = head ? (int64_t)(f.wid - wprev) - 1 : 0;
-    }
-    // first valid ts of the window, through float64 as the reference does (interpolation.go:121-123)
-    f.exact = head && go_f64_to_i64((double)t) == s0 + (int64_t)(f.wid * (uint64_t)interval);
-    f.synth = head ? before + (f.exact ? 0 : 1) : 0;
-    if (head && kq >= 0 && (uint64_t)kq <= f.wid && (i == 0 || (uint64_t)kq > wprev) && !(f.exact && (uint64_t)kq == f.wid)) f.synth -= 1;
-    return f;
-}
 
 // the value an interpolator gives the synthetic row of a window starting at sk whose FirstIndex is row a
 // (interpolation/windowstart.go:10-12, linear.go:12-37, stepprevious.go:11-24, none.go); pi / ni = previous valid row
@@ -101,16 +71,75 @@ __device__ __forceinline__ void synth_value(const InterpCol &ic, const int64_t *
 
 }  // namespace
 
+// ---- kIR consecutive rows per thread: ts (and each column) arrive as one 16-B load per lane
+struct RowsR {
+    uint64_t wid[kIR];
+    int64_t synth[kIR];   // synthetic rows right in front of row k
+    bool exact[kIR];
+};
+
+__device__ __forceinline__ void loadR(const uint64_t *__restrict__ src, int64_t i, int64_t n, bool vec, uint64_t (&v)[kIR]) {
+    if (vec && i + 1 < n) {
+        const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(src + i);
+        v[0] = a.x; v[1] = a.y;
+    } else {
+        v[0] = i < n ? src[i] : 0;
+        v[1] = i + 1 < n ? src[i + 1] : 0;
+    }
+}
+
+// flags of rows i..i+kIR-1 from their timestamps and the timestamp left of row i (t_left; ignored for i == 0)
+__device__ __forceinline__ RowsR rows_flags(const uint64_t (&t)[kIR], int64_t t_left, int64_t i, int64_t n, int64_t s0, int64_t interval,
+                                             const MagicDiv &magic, int64_t kq, bool *unsorted) {
+    RowsR f;
+    uint64_t wprev = 0;
+    int64_t tprev = t_left;
+    if (i > 0) wprev = t_left < s0 ? 0 : magic_div((uint64_t)t_left - (uint64_t)s0, magic);
+#pragma unroll
+    for (int k = 0; k < kIR; k++) {
+        f.wid[k] = 0; f.synth[k] = 0; f.exact[k] = false;
+        if (i + k >= n) continue;
+        const int64_t tk = (int64_t)t[k];
+        const bool first = i + k == 0;
+        if (!first && tprev > tk) *unsorted = true;
+        const uint64_t w = tk < s0 ? 0 : magic_div((uint64_t)tk - (uint64_t)s0, magic);  // rows below s0 ride in window 0
+        const bool head = first || w != wprev;
+        const int64_t before = (head && !first) ? (int64_t)(w - wprev) - 1 : 0;            // empty windows in front of this row's window
+        // first valid ts of the window, through float64 as the reference does (interpolation.go:121-123)
+        const bool exact = head && go_f64_to_i64((double)tk) == s0 + (int64_t)(w * (uint64_t)interval);
+        int64_t synth = head ? before + (exact ? 0 : 1) : 0;
+        // kq >= 0: the window that starts at -1 has no row of its own; the reference then takes its "first value" -1
+        // (interpolation.go:119) for a timestamp equal to the window start and adds NO synthetic row for it
+        if (head && kq >= 0 && (uint64_t)kq <= w && (first || (uint64_t)kq > wprev) && !(exact && (uint64_t)kq == w)) synth -= 1;
+        f.wid[k] = w; f.synth[k] = synth; f.exact[k] = exact;
+        wprev = w; tprev = tk;
+    }
+    return f;
+}
+
+// timestamp left of a thread's first row: the neighbouring lane's last row, LDS across waves, global across tiles
+__device__ __forceinline__ int64_t left_ts(const uint64_t (&t)[kIR], const int64_t *ts, int64_t i, int64_t n, long long *wave_last, int tid) {
+    const int lane = tid & 63, wv = tid >> 6;
+    const long long mine = (long long)t[kIR - 1];
+    long long l = __shfl_up(mine, 1);
+    if (lane == 63) wave_last[wv] = mine;
+    __syncthreads();
+    if (lane == 0) l = wv > 0 ? wave_last[wv - 1] : ((i > 0 && i < n) ? ts[i - 1] : 0);
+    return (int64_t)l;
+}
+
 __global__ __launch_bounds__(kIThreads) void interp_count_kernel(const int64_t *ts, int64_t n, int64_t s0, int64_t interval,
                                                                  MagicDiv magic, int32_t *tile_exact, uint32_t *status) {
     __shared__ int part[kIThreads / 64];
-    const int64_t r0 = (int64_t)blockIdx.x * kITile;
-    int cnt = 0;
+    __shared__ long long wave_last[kIThreads / 64];
+    const int64_t i = (int64_t)blockIdx.x * kITile + kIR * (int64_t)threadIdx.x;
+    const bool vec = (reinterpret_cast<uintptr_t>(ts) & 15) == 0;
+    uint64_t t[kIR];
+    loadR(reinterpret_cast<const uint64_t *>(ts), i, n, vec, t);
+    const int64_t tl = left_ts(t, ts, i, n, wave_last, threadIdx.x);
     bool unsorted = false;
-    for (int k = 0; k < kIRounds; k++) {
-        const int64_t i = r0 + k * kIThreads + threadIdx.x;
-        if (i < n) cnt += row_flags(ts, i, s0, interval, magic, -1, &unsorted).exact ? 1 : 0;
-    }
+    const RowsR f = rows_flags(t, tl, i, n, s0, interval, magic, -1, &unsorted);
+    int cnt = (int)f.exact[0] + (int)f.exact[1];
     if (unsorted) atomicOr(&status[0], 1u);
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = cnt;
@@ -122,13 +151,22 @@ __global__ __launch_bounds__(kIThreads) void interp_tile_kernel(const InterpPara
     struct LongRun { long long a, o_row, synth; unsigned long long k0; };
     __shared__ uint32_t lbits[kMaxCols][kISpanWords];
     __shared__ long long wave_tot[kIThreads / 64];
-    __shared__ long long s_running;
+    __shared__ long long wave_last[kIThreads / 64];
     __shared__ int s_nlong;
     __shared__ LongRun runs[kIThreads];
+    __shared__ uint64_t sval[kIStage];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t r0 = (int64_t)blockIdx.x * kITile;
+    const int64_t i = r0 + kIR * (int64_t)tid;
     for (int w = tid; w < kMaxCols * kISpanWords; w += kIThreads) (&lbits[0][0])[w] = 0;
-    const int64_t kq = (p.kq >= 0 && p.status[1]) ? p.kq : -1;  // see row_flags
+    const int64_t kq = (p.kq >= 0 && p.status[1]) ? p.kq : -1;  // see rows_flags
+    if (tid == 0) s_nlong = 0;
+
+    // ---- loads: ts, then the first column right behind it
+    const bool vec_ts = (reinterpret_cast<uintptr_t>(p.ts) & 15) == 0;
+    uint64_t t[kIR], v[kIR];
+    loadR(reinterpret_cast<const uint64_t *>(p.ts), i, p.n, vec_ts, t);
+    loadR(p.cols[0].values, i, p.n, (reinterpret_cast<uintptr_t>(p.cols[0].values) & 15) == 0, v);
 
     // first output position of this tile: one past the position of row r0 - 1
     int64_t o_base = 0;
@@ -139,81 +177,121 @@ __global__ __launch_bounds__(kIThreads) void interp_tile_kernel(const InterpPara
         if (kq >= 0 && (uint64_t)kq <= wp) o_base -= 1;
     }
     const int64_t lbase = o_base & ~(int64_t)31;  // LDS bit 0
-    if (tid == 0) s_running = 0;
+
+    const int64_t tl = left_ts(t, p.ts, i, p.n, wave_last, tid);  // (one __syncthreads inside: the LDS clears above are visible after it)
+    bool unsorted = false;
+    const RowsR f = rows_flags(t, tl, i, p.n, p.s0, p.interval, p.magic, kq, &unsorted);
+    if (unsorted) atomicOr(&p.status[0], 1u);
+
+    // ---- output positions: thread totals -> wave scan -> workgroup
+    int emitted[kIR];
+    long long mine = 0;
+#pragma unroll
+    for (int k = 0; k < kIR; k++) {
+        emitted[k] = (i + k < p.n && i + k >= p.drop) ? 1 : 0;  // (rows of a window 0 without own rows are dropped: interp_quirk_kernel)
+        mine += emitted[k] + f.synth[k];
+    }
+    long long inc = mine;
+    for (int o = 1; o < 64; o <<= 1) { const long long y = __shfl_up(inc, o); if (lane >= o) inc += y; }
+    if (lane == 63) wave_tot[wv] = inc;
     __syncthreads();
-
-    auto set_bit = [&](int c, int64_t o) {
-        const int64_t rel = o - lbase;
-        if (rel < (int64_t)kISpanWords * 32) atomicOr(&lbits[c][rel >> 5], 1u << (rel & 31));
-        else atomicOr(&p.cols[c].out_valid_words[o >> 5], 1u << (o & 31));  // a tile with very many synthetic rows
-    };
-    // synthetic rows j = first, first + step, ... < count in front of row a (j = 0 is the one next to the row; its window is
-    // k0 = the row's own window when the row is not an exact head, else the window before; then the empty windows, latest first)
-    auto emit_synth = [&](int64_t a, int64_t o_row, uint64_t k0, int64_t count, int64_t first, int64_t step) {
-        for (int c = 0; c < p.ncols; c++) {
-            const InterpCol &ic = p.cols[c];
-            int64_t pi = -1, ni = -1;  // the same two neighbours for the whole run: FirstIndex of all these windows is row a
-            if (ic.kind == BOWGPU_INTERP_LINEAR || ic.kind == BOWGPU_INTERP_STEP_PREVIOUS) pi = prev_valid_ix(ic.vbits, ic.vbit0, p.n, a - 1, ic.nbr);
-            if (ic.kind == BOWGPU_INTERP_LINEAR) ni = next_valid_ix(ic.vbits, ic.vbit0, p.n, a, ic.nbr);
-            for (int64_t j = first; j < count; j += step) {
-                uint64_t k = k0 - (uint64_t)j;
-                if (kq >= 0 && (uint64_t)kq <= k0 && (uint64_t)kq >= k) k -= 1;  // the run skips window kq
-                const int64_t sk = p.s0 + (int64_t)(k * (uint64_t)p.interval);
-                uint64_t bits;
-                int valid;
-                synth_value(ic, p.ts, sk, pi, ni, &bits, &valid);
-                ic.out_values[o_row - 1 - j] = bits;
-                if (valid) set_bit(c, o_row - 1 - j);
-            }
-        }
-    };
-
-    for (int round = 0; round < kIRounds; round++) {
-        const int64_t i = r0 + round * kIThreads + tid;
-        RowFlags f;
-        f.wid = 0; f.synth = 0; f.exact = false;
-        bool unsorted = false;
-        const bool live = i < p.n;
-        if (live) f = row_flags(p.ts, i, p.s0, p.interval, p.magic, kq, &unsorted);
-        if (unsorted) atomicOr(&p.status[0], 1u);
-        // workgroup inclusive scan of (1 + synthetic rows in front of the row)
-        const int emitted = (live && i >= p.drop) ? 1 : 0;  // (rows of a window 0 without own rows are dropped: interp_quirk_kernel)
-        long long inc = live ? emitted + f.synth : 0;
-        for (int o = 1; o < 64; o <<= 1) { const long long y = __shfl_up(inc, o); if (lane >= o) inc += y; }
-        if (lane == 63) wave_tot[wv] = inc;
-        if (tid == 0) s_nlong = 0;
-        __syncthreads();
-        long long woff = 0;
-        for (int k = 0; k < wv; k++) woff += wave_tot[k];
-        const long long round_total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
-        const int64_t o_row = o_base + s_running + woff + inc - emitted;  // output position of the real row; synthetic rows end right before it
-        if (live) {
-            if (emitted)
-                for (int c = 0; c < p.ncols; c++) {
-                    const InterpCol &ic = p.cols[c];
-                    ic.out_values[o_row] = ic.values[i];
-                    if (bit_at(ic.vbits, ic.vbit0, i)) set_bit(c, o_row);
-                }
-            if (f.synth > 0) {
-                const uint64_t k0 = f.exact ? f.wid - 1 : f.wid;
-                if (f.synth <= kSmallRun) {
-                    emit_synth(i, o_row, k0, f.synth, 0, 1);
-                } else {  // a long run of empty windows: shared by the whole workgroup below
-                    const int q = atomicAdd(&s_nlong, 1);
-                    runs[q].a = i; runs[q].o_row = o_row; runs[q].synth = f.synth; runs[q].k0 = k0;
-                }
-            }
-        }
-        __syncthreads();
-        const int nlong = s_nlong;
-        for (int q = 0; q < nlong; q++) emit_synth(runs[q].a, runs[q].o_row, runs[q].k0, runs[q].synth, tid, kIThreads);
-        __syncthreads();
-        if (tid == 0) s_running += round_total;
-        __syncthreads();
+    long long woff = 0;
+    for (int k = 0; k < wv; k++) woff += wave_tot[k];
+    const long long tile_total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+    int64_t o_row[kIR];  // output position of real row k; its synthetic rows end right before it
+    {
+        int64_t o = o_base + woff + inc - mine;
+#pragma unroll
+        for (int k = 0; k < kIR; k++) { o += f.synth[k]; o_row[k] = o; o += emitted[k]; }
     }
 
-    // flush the staged validity bits: whole words; the first and last word may be shared with the neighbouring tiles
-    const int64_t span_bits = (o_base - lbase) + s_running;
+    auto set_bits = [&](int c, int64_t o, uint32_t mask) {  // mask: up to 4 consecutive bits from output position o
+        const int64_t rel = o - lbase;
+        if (rel + 4 <= (int64_t)kISpanWords * 32) {
+            const int sh = (int)(rel & 31);
+            atomicOr(&lbits[c][rel >> 5], mask << sh);
+            if (sh > 28 && (mask >> (32 - sh))) atomicOr(&lbits[c][(rel >> 5) + 1], mask >> (32 - sh));
+        } else {  // a tile with very many synthetic rows
+            for (int b = 0; b < 4; b++)
+                if ((mask >> b) & 1u) atomicOr(&p.cols[c].out_valid_words[(o + b) >> 5], 1u << ((o + b) & 31));
+        }
+    };
+    // Outputs are staged in LDS in output order and leave as contiguous 8-B-per-lane stores: written straight from the rows'
+    // own lanes they would be 8-B pieces ~36 B apart, which the memory system turns into 2.4x the write traffic plus
+    // read-modify-write fills (measured).  A tile with more outputs than the stage holds (long runs of empty windows)
+    // writes directly.
+    const bool staged = tile_total <= kIStage;
+    auto put = [&](const InterpCol &ic, int64_t o, uint64_t bits) {
+        if (staged) sval[o - o_base] = bits;
+        else ic.out_values[o] = bits;
+    };
+    // synthetic rows j = first, first + step, ... < count of column c in front of row a (j = 0 is the one next to the row; its
+    // window is k0 = the row's own window when the row is not an exact head, else the window before; then the empty windows,
+    // latest first)
+    auto emit_synth = [&](int c, int64_t a, int64_t o_a, uint64_t k0, int64_t count, int64_t first, int64_t step) {
+        const InterpCol &ic = p.cols[c];
+        int64_t pi = -1, ni = -1;  // the same two neighbours for the whole run: FirstIndex of all these windows is row a
+        if (ic.kind == BOWGPU_INTERP_LINEAR || ic.kind == BOWGPU_INTERP_STEP_PREVIOUS) pi = prev_valid_ix(ic.vbits, ic.vbit0, p.n, a - 1, ic.nbr);
+        if (ic.kind == BOWGPU_INTERP_LINEAR) ni = next_valid_ix(ic.vbits, ic.vbit0, p.n, a, ic.nbr);
+        for (int64_t j = first; j < count; j += step) {
+            uint64_t k = k0 - (uint64_t)j;
+            if (kq >= 0 && (uint64_t)kq <= k0 && (uint64_t)kq >= k) k -= 1;  // the run skips window kq
+            const int64_t sk = p.s0 + (int64_t)(k * (uint64_t)p.interval);
+            uint64_t bits;
+            int valid;
+            synth_value(ic, p.ts, sk, pi, ni, &bits, &valid);
+            put(ic, o_a - 1 - j, bits);
+            if (valid) set_bits(c, o_a - 1 - j, 1u);
+        }
+    };
+
+    // long runs of empty windows are shared by the whole workgroup; the short ones stay with their row's lane
+    bool own_run[kIR];
+#pragma unroll
+    for (int k = 0; k < kIR; k++) {
+        own_run[k] = f.synth[k] > 0;
+        if (f.synth[k] > kSmallRun) {
+            const int q = atomicAdd(&s_nlong, 1);
+            if (q < kIThreads) {
+                runs[q].a = i + k; runs[q].o_row = o_row[k]; runs[q].synth = f.synth[k];
+                runs[q].k0 = f.exact[k] ? f.wid[k] - 1 : f.wid[k];
+                own_run[k] = false;
+            }  // (list full: the owner writes the run itself)
+        }
+    }
+    __syncthreads();
+    const int nlong = s_nlong < kIThreads ? s_nlong : kIThreads;
+
+    // ---- one column at a time (the next column's loads go out before this one's stores)
+    const bool contiguous = f.synth[1] == 0 && emitted[0] && i + 1 < p.n;
+    for (int c = 0; c < p.ncols; c++) {
+        const InterpCol &ic = p.cols[c];
+        uint64_t cur[kIR] = {v[0], v[1]};
+        if (c + 1 < p.ncols) loadR(p.cols[c + 1].values, i, p.n, (reinterpret_cast<uintptr_t>(p.cols[c + 1].values) & 15) == 0, v);
+        uint32_t m = 0;
+#pragma unroll
+        for (int k = 0; k < kIR; k++)
+            if (emitted[k]) {
+                put(ic, o_row[k], cur[k]);
+                if (bit_at(ic.vbits, ic.vbit0, i + k)) m |= 1u << k;
+            }
+        if (contiguous) { if (m) set_bits(c, o_row[0], m); }
+        else
+            for (int k = 0; k < kIR; k++) if ((m >> k) & 1u) set_bits(c, o_row[k], 1u);
+#pragma unroll
+        for (int k = 0; k < kIR; k++)
+            if (own_run[k]) emit_synth(c, i + k, o_row[k], f.exact[k] ? f.wid[k] - 1 : f.wid[k], f.synth[k], 0, 1);
+        for (int q = 0; q < nlong; q++) emit_synth(c, runs[q].a, runs[q].o_row, runs[q].k0, runs[q].synth, tid, kIThreads);
+        if (staged) {
+            __syncthreads();
+            for (int64_t rel = tid; rel < tile_total; rel += kIThreads) ic.out_values[o_base + rel] = sval[rel];
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+
+    // ---- flush the staged validity bits: whole words; the first and last word may be shared with the neighbouring tiles
+    const int64_t span_bits = (o_base - lbase) + tile_total;
     int64_t nwords = (span_bits + 31) >> 5;
     if (nwords > kISpanWords) nwords = kISpanWords;
     for (int c = 0; c < p.ncols; c++) {

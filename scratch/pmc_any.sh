@@ -1,0 +1,21 @@
+#!/bin/bash
+# usage: scratch/pmc_any.sh <tag> <kernel substring> <python script...> : FETCH_SIZE / WRITE_SIZE / busy counters of one kernel
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+TAG=$1; KSUB=$2; shift; shift
+OUT=gpurun_out/pmc_$TAG
+rm -rf $OUT && mkdir -p $OUT
+i=0
+for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum TCC_EA_WRREQ_sum TCC_EA_WRREQ_64B_sum"; do
+  i=$((i+1))
+  timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/p$i -- python3 "$@" > $OUT/p$i.log 2>&1
+done
+python3 - <<PY
+import csv, glob, collections
+acc = collections.defaultdict(list)
+for f in glob.glob("$OUT/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "$KSUB" in r["Kernel_Name"]:
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, v in sorted(acc.items()):
+    print("%-26s n=%d avg=%.5g" % (k, len(v), sum(v) / len(v)))
+PY
