@@ -5,9 +5,9 @@ ranges, so every rank reduces its own rows with no data-path collective.  The on
 bookkeeping, as bytes through torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box,
 "gloo" in the CPU tests):
 
-  1. broadcast of s0 (first window start) from the rank holding global row 0          (8 B)
-  2. all_gather of (first_ts, last_ts, nrows) so every rank knows all window ranges   (24 B/rank)
-  3. all_gather of each rank's carry: the running state of its LAST window            (~1.5 KB/rank)
+  1. all_gather of (first_ts, last_ts, nrows) so every rank knows all window ranges   (24 B/rank); the first window
+     start s0 is host arithmetic on the first timestamp of the rank holding global row 0 (first_window_start)
+  2. all_gather of each rank's carry: the running state of its LAST window            (~1.5 KB/rank)
 
 A window that straddles a shard boundary is finished by the right rank: it re-walks its own rows
 of that window seeded with the left rank's carry, i.e. in the reference's row order (bit-exact for
@@ -81,6 +81,25 @@ class ShardPlan:
         return q >= 0 and self.wf[q] == self.wl[r]
 
 
+def first_window_start(first_ts, interval, offset=0):
+    """s0 of rolling.IntervalRolling from the first timestamp alone (rolling.go:96-99 + enforceIntervalAndOffset :114-128),
+    with Go's integer semantics (division and % truncate toward zero).  Host arithmetic on three scalars: every rank derives
+    it from the gathered first timestamp of the rank that holds global row 0, so no separate broadcast is needed."""
+    if interval <= 0:
+        raise ValueError("strictly positive interval required")
+    if offset >= interval or offset <= -interval:
+        offset = offset - int(offset / interval) * interval   # Go's %: sign of the dividend
+    if offset < 0:
+        offset += interval
+    q = abs(first_ts) // interval
+    if first_ts < 0:
+        q = -q
+    s0 = q * interval + offset
+    if s0 > first_ts:
+        s0 -= interval
+    return s0
+
+
 def _gather_bytes(dist, torch, payload, world, device):
     t = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(device)
     outs = [torch.empty_like(t) for _ in range(world)]
@@ -128,24 +147,23 @@ def sharded_aggregate(provider, dist, torch, rank, world, interval, device="cpu"
     """Runs the protocol over torch.distributed.  Returns (first_slot_window_id, n_windows_owned, plan).
     provider:
        first_last_nrows() -> (first_ts, last_ts, nrows)
-       plan_s0() -> s0                                   (only called on the rank holding row 0)
+       offset (attribute, optional)                      Options.Offset as given by the caller
        shard_aggregate(s0, holds_row0, lead) -> carry bytes (ShardCarry layout)
        fix_first(s0, lead, first_window_id, seed_bytes) -> merged carry-state bytes
        merge(a_bytes, b_bytes) -> bytes                  (array of CarryState, one per aggregator)
     """
     sess = ShardSession(provider, rank, world, interval)
-    # 1. s0 from the rank holding global row 0 (rank 0)
-    s0_t = torch.zeros(1, dtype=torch.int64, device=device)
-    if rank == 0:
-        s0_t[0] = provider.plan_s0()
-    if world > 1:
-        dist.broadcast(s0_t, src=0)
-    s0 = int(s0_t.item())
-    # 2. every rank's (first_ts, last_ts, nrows)
+    # 1. every rank's (first_ts, last_ts, nrows); s0 follows from the first timestamp of the rank holding global row 0
     mine = sess.local_info()
     all_info = _gather_bytes(dist, torch, mine, world, device) if world > 1 else [mine]
+    s0 = 0
+    for b in all_info:
+        f, _, n = np.frombuffer(b, dtype=np.int64)
+        if n > 0:
+            s0 = first_window_start(int(f), interval, getattr(provider, "offset", 0))
+            break
     carry = sess.phase1(s0, all_info)
-    # 3. carries
+    # 2. carries
     carries = _gather_bytes(dist, torch, carry, world, device) if world > 1 else [carry]
     first_slot, owned = sess.phase2(carries)
     return first_slot, owned, sess.plan
