@@ -225,7 +225,6 @@ int launch_fill_empty(Ctx *c, const AggParams &p, int64_t slot0, int64_t slot1);
 // interp_fill.hip
 int launch_window_first_rows(Ctx *c, const int64_t *ts, int64_t n, const Plan &plan, int64_t *first_idx, uint32_t *status);
 int launch_exclusive_scan(Ctx *c, const int32_t *in, int64_t n, int64_t *out, int64_t *block_sums, int64_t *d_total);
-int launch_pack_validity(Ctx *c, const uint8_t *bytes, int64_t n, uint32_t *words, uint64_t *d_set_count);
 int launch_col_order(Ctx *c, const uint64_t *values, const uint32_t *vbits, int64_t vbit0, int64_t n, int32_t type, uint32_t *d_flags);
 int launch_window_bounds(Ctx *c, const int64_t *ts, int64_t n, const Plan &plan, int inclusive, int pre_rows,
                          const int64_t *first_idx, int64_t *first_index, int64_t *slice_begin, int64_t *slice_end, uint8_t *is_incl);
@@ -278,7 +277,9 @@ struct FillParams {
     const uint64_t *fill_values; const uint32_t *fill_vbits; int64_t fill_vbit0; int32_t fill_type;
     int32_t method;
     int64_t n;
-    uint64_t *out_values; uint8_t *out_valid_bytes;
+    uint64_t *out_values;
+    uint32_t *out_valid_words;   // 8-byte aligned, a multiple of 64 bits long
+    unsigned long long *valid_count;  // += valid output rows
     NbrIndex nbr;                // of the fill column's bitmap
 };
 // builds the index of (vbits, vbit0, n) into `work` (nbr_index_bytes(n, vbit0) bytes of device memory)

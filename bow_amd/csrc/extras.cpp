@@ -345,19 +345,21 @@ int bowgpu_fill_linear(const bowgpu_col *cols, int32_t ncols, int32_t ref_col, i
 
 // shared tail of the fill entry points: neighbour index of the fill column, the kernel, validity bytes -> bits, copy-back
 static int fill_finish(Ctx *c, FillParams &P, int64_t n, const DevCol &dfill, DevOut *dout, int type) {
-    DevBuf vbytes, ixbuf;
-    BG_TRY(vbytes.alloc((size_t)n + 64));
+    DevBuf ixbuf;
     BG_TRY(ixbuf.alloc(nbr_index_bytes(n, dfill.vbit0)));
     BG_TRY(nbr_index_build(c, dfill.vbits, dfill.vbit0, n, ixbuf.p, &P.nbr));
-    P.n = n;
-    P.out_values = reinterpret_cast<uint64_t *>(dout->values);
-    P.out_valid_bytes = reinterpret_cast<uint8_t *>(vbytes.p);
-    BG_TRY(fill_run(c, P));
     void *dscr;
     BG_TRY(ctx_scratch(c, 8192, &dscr));
     uint64_t *dcnt = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(dscr) + 1024);
+    BG_HIP(hipMemsetAsync(dcnt, 0, 8, c->stream));
+    P.n = n;
+    P.out_values = reinterpret_cast<uint64_t *>(dout->values);
+    // the kernel stores one whole 64-bit validity word per wavefront trip: ceil(n/64)*8 bytes, which the word-aligned working
+    // copy of devout_prepare (((ceil(n/8)+3)&~3)+4 bytes) always holds
+    P.out_valid_words = reinterpret_cast<uint32_t *>(dout->validity);
+    P.valid_count = reinterpret_cast<unsigned long long *>(dcnt);
+    BG_TRY(fill_run(c, P));
     uint64_t hcnt = 0;
-    BG_TRY(launch_pack_validity(c, reinterpret_cast<const uint8_t *>(vbytes.p), n, reinterpret_cast<uint32_t *>(dout->validity), dcnt));
     BG_HIP(hipMemcpyAsync(&hcnt, dcnt, 8, hipMemcpyDeviceToHost, c->stream));
     BG_HIP(hipStreamSynchronize(c->stream));
     BG_TRY(devout_finish(c, dout, n, type, n - (int64_t)hcnt));

@@ -127,22 +127,6 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const int32_t *in, int6
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) out[n] = off + acc;  // out has n+1 entries
 }
 
-// bytes (0/1) -> Arrow validity bits, 32 rows per lane-word; also counts the set bits
-__global__ __launch_bounds__(256) void pack_validity_kernel(const uint8_t *bytes, int64_t n, uint32_t *words,
-                                                            unsigned long long *set_count) {
-    const int64_t nwords = (n + 31) >> 5;
-    unsigned long long acc = 0;
-    for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += (int64_t)gridDim.x * blockDim.x) {
-        uint32_t x = 0;
-        const int64_t base = w << 5;
-        for (int j = 0; j < 32; j++) if (base + j < n && bytes[base + j]) x |= 1u << j;
-        words[w] = x;
-        acc += __popc(x);
-    }
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
-    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(set_count, acc);
-}
-
 // ------------------------------------------------------------------ IsColSorted / FillLinear
 // flags[0] |= 1 if some consecutive valid pair increases, |= 2 if some decreases, |= 4 if any valid value exists
 __global__ __launch_bounds__(256) void col_order_kernel(const uint64_t *values, const uint32_t *vbits, int64_t vbit0, int64_t n,
@@ -167,10 +151,14 @@ __global__ __launch_bounds__(256) void col_order_kernel(const uint64_t *values, 
 // Bow.FillLinear (bowfill.go:14-103), FillPrevious / FillNext (:162-253), FillMean (:105-160): one thread per row, null
 // rows look their neighbours up through the index
 __global__ __launch_bounds__(256) void fill_kernel(const FillParams p) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < p.n; i += (int64_t)gridDim.x * blockDim.x) {
-        uint64_t bits = p.fill_values[i];
-        int valid = bit_at(p.fill_vbits, p.fill_vbit0, i) ? 1 : 0;
-        if (!valid) {
+    unsigned long long nvalid = 0;
+    // a wavefront covers 64 consecutive rows per trip: its validity bits leave as one aligned 64-bit word (ballot)
+    for (int64_t base = ((int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63)); base < p.n; base += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = base + (threadIdx.x & 63);
+        const bool live = i < p.n;
+        uint64_t bits = live ? p.fill_values[i] : 0;
+        int valid = (live && bit_at(p.fill_vbits, p.fill_vbit0, i)) ? 1 : 0;
+        if (live && !valid) {
             const int64_t rp = p.method == BOWGPU_FILL_NEXT ? -1 : prev_valid_ix(p.fill_vbits, p.fill_vbit0, p.n, i - 1, p.nbr);
             const int64_t rn = p.method == BOWGPU_FILL_PREVIOUS ? -1 : next_valid_ix(p.fill_vbits, p.fill_vbit0, p.n, i + 1, p.nbr);
             if (p.method == BOWGPU_FILL_PREVIOUS) {
@@ -204,9 +192,14 @@ __global__ __launch_bounds__(256) void fill_kernel(const FillParams p) {
                 }
             }
         }
-        p.out_values[i] = bits;
-        p.out_valid_bytes[i] = (uint8_t)valid;
+        if (live) p.out_values[i] = bits;
+        const unsigned long long word = __ballot(valid);
+        if ((threadIdx.x & 63) == 0) {
+            *reinterpret_cast<unsigned long long *>(p.out_valid_words + (base >> 5)) = word;  // base is a multiple of 64
+            nvalid += __popcll(word);
+        }
     }
+    if ((threadIdx.x & 63) == 0 && nvalid) atomicAdd(p.valid_count, nvalid);
 }
 
 // ------------------------------------------------------------------ whole-frame aggregation
@@ -318,15 +311,6 @@ int launch_exclusive_scan(Ctx *c, const int32_t *in, int64_t n, int64_t *out /* 
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3((unsigned)nblocks), dim3(256), 0, c->stream, in, n, block_sums);
     hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(64), 0, c->stream, block_sums, nblocks, d_total);
     hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nblocks), dim3(256), 0, c->stream, in, n, block_sums, out);
-    BG_HIP(hipGetLastError());
-    return 0;
-}
-
-int launch_pack_validity(Ctx *c, const uint8_t *bytes, int64_t n, uint32_t *words, uint64_t *d_set_count) {
-    BG_HIP(hipMemsetAsync(d_set_count, 0, 8, c->stream));
-    if (n == 0) return 0;
-    hipLaunchKernelGGL(pack_validity_kernel, dim3(grid_for((n + 31) / 32)), dim3(256), 0, c->stream, bytes, n, words,
-                       reinterpret_cast<unsigned long long *>(d_set_count));
     BG_HIP(hipGetLastError());
     return 0;
 }
