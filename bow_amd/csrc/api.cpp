@@ -450,7 +450,6 @@ static int job_build(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t ts_c
     P.inclusive = inclusive;
     P.naggs = naggs;
     P.pre_rows = (n > 0 && holds_row0 && plan.s0 > plan.first_ts) ? 1 : 0;
-    if (const char *e = getenv("BOWGPU_DBG_STOP")) P.dbg_stop = atoi(e);
 
     // column slots: each distinct input column whose values some reducer reads
     std::vector<int> nullable_in_slot;

@@ -163,7 +163,7 @@ struct AggParams {
     int32_t inclusive;      // effective Options.Inclusive
     int32_t ncols;
     int32_t naggs;
-    int32_t dbg_stop;       // profiling aid: leave the tile kernel after phase k (0 = off)
+    int32_t _pad0;
     int32_t pre_rows;       // s0 > ts[0] (negative ts + truncating division): rows below s0 ride in window 0
     ColDesc cols[kMaxCols];
     AggDesc aggs[kMaxAggs];

@@ -232,16 +232,6 @@ __global__ __launch_bounds__(kWave, kPersist ? 4 : 5) void rolling_wave_kernel(c
     const int64_t ws0 = p.s0 + (int64_t)(w0 * (uint64_t)p.interval);
     const bool fast32 = p.fits32 && ts_last >= ts_first && (uint64_t)(ts_last - ws0) < 0xFFFFFFF0ull;
 
-    if (p.dbg_stop == 1) { if (lane == 0 && fast32) atomicOr(&p.status[3], (unsigned)ta[0] & 1u); return; }
-    if (p.dbg_stop == 6) {  // streaming floor of this launch geometry: consume the loads, nothing else
-        uint64_t x = 0;
-#pragma unroll
-        for (int j = 0; j < kChunksW; j++) x ^= ta[j] ^ tb[j] ^ va[j] ^ vb[j];
-        if (x == 0x1234567887654321ull) atomicOr(&p.status[3], 1u);
-        if (!kPersist) return;
-        if (prefetch_next) { load_ts(next_tile, true); load_v0(next_tile, true); }
-        continue;
-    }
     // ---- 2. local window ids, head flags, compaction (chunks are consecutive: running scalar count)
     bool unsorted = false;
     int nseg_total = 0, nseg_owned = 0;
@@ -295,7 +285,6 @@ __global__ __launch_bounds__(kWave, kPersist ? 4 : 5) void rolling_wave_kernel(c
         left_ts = (int64_t)readlane64(tb[j], 63);         // last row of this chunk = left neighbour of the next
     }
     if (unsorted) atomicOr(&p.status[0], 1u);
-    if (p.dbg_stop == 2) { if (lane == 0) atomicOr(&p.status[3], (unsigned)nseg_total & 1u); return; }
     if (prefetch_next) load_ts(next_tile, true);  // this tile's ts registers are dead
 
     const bool reaches_end = base + kRowsW >= n;
@@ -350,7 +339,6 @@ __global__ __launch_bounds__(kWave, kPersist ? 4 : 5) void rolling_wave_kernel(c
         }
         wave_lds_fence();
 
-        if (p.dbg_stop == 3) return;
         const uint64_t wid_first = nseg_owned > 0 ? wid_at(0) : 0;
         const int64_t slot_first = (int64_t)(wid_first - (uint64_t)p.wid_base);
         const int64_t span0 = slot_first & ~(int64_t)31;
@@ -378,7 +366,6 @@ __global__ __launch_bounds__(kWave, kPersist ? 4 : 5) void rolling_wave_kernel(c
             Stats st;
             stats_init(st);
             if (need_vals) walk_dispatch(variant, sh, r0, r1, st);
-            if (p.dbg_stop == 4) { if (st.sum == 12345.678) atomicOr(&p.status[3], 1u); continue; }
             const int64_t win_start = p.s0 + (int64_t)(wid * (uint64_t)p.interval);
             const int64_t oslot = (int64_t)(wid - (uint64_t)p.wid_base);
             const int64_t nrows = r1 - r0;
@@ -418,7 +405,6 @@ __global__ __launch_bounds__(kWave, kPersist ? 4 : 5) void rolling_wave_kernel(c
         }
         wave_lds_fence();
 
-        if (p.dbg_stop == 5) return;
         // ---- big gaps (sparse data): the whole wave writes the empty windows, coalesced
         if (__ballot(any_big_gap)) {
             for (int q = 0; q < nseg_owned; q++) {
