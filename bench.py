@@ -211,6 +211,13 @@ def main():
             "device": capi.device_name(),
         }
         line["roofline"]["traffic"] = measured_traffic(rows, kernel_name)
+        if world == 1:
+            # the achievable line: a trivial streaming sum over the same two columns, measured in this run
+            try:
+                ceil = capi.stream_read_ceiling(cols[0].values, cols[1].values, rows * 8)
+                line["roofline"]["stream_read_ceiling"] = {"value": ceil, "unit": "GB/s", "frac_of_ceiling": achieved / ceil}
+            except Exception as e:
+                line["roofline"]["stream_read_ceiling"] = {"error": repr(e)}
         if not args.no_cpu and world == 1:
             try:
                 line["cpu_baseline"] = cpu_baseline(capi, min(args.cpu_sample, rows))

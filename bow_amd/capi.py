@@ -91,7 +91,7 @@ SYMBOLS = [
     "bowgpu_rolling_aggregate", "bowgpu_window_bounds", "bowgpu_aggregate_whole",
     "bowgpu_rolling_interpolate_count", "bowgpu_rolling_interpolate_fill", "bowgpu_fill_linear", "bowgpu_fill",
     "bowgpu_is_col_sorted", "bowgpu_shard_aggregate", "bowgpu_shard_fix_first", "bowgpu_carry_merge", "bowgpu_gen_dense",
-    "bowgpu_gen_sparse", "bowgpu_checksum64",
+    "bowgpu_gen_sparse", "bowgpu_stream_read_ceiling", "bowgpu_checksum64",
 ]
 
 _lib = None
@@ -441,6 +441,13 @@ def gen_sparse(row0, n, seed=42):
     check(lib().bowgpu_gen_sparse(C.c_int64(row0), C.c_int64(n), C.c_uint64(seed), C.c_void_p(ts.ptr),
                                   C.c_void_p(val.ptr), C.c_void_p(bm.ptr)))
     return Column(ts, None, INT64, 0, n, 0), Column(val, bm, FLOAT64, 0, n, -1)
+
+
+def stream_read_ceiling(buf_a, buf_b, bytes_each):
+    """best GB/s of a trivial streaming sum over two device buffers (the achievable line of the roofline)"""
+    g = C.c_double(0)
+    check(lib().bowgpu_stream_read_ceiling(C.c_void_p(buf_a.ptr), C.c_void_p(buf_b.ptr), C.c_int64(bytes_each), C.byref(g)))
+    return g.value
 
 
 def checksum64(devbuf, n_words):

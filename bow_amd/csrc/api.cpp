@@ -1098,6 +1098,26 @@ int bowgpu_gen_sparse(int64_t row0, int64_t n, uint64_t seed, int64_t *ts_dev, d
     return launch_gen_sparse(c, row0, n, seed, ts_dev, val_dev, validity_dev);
 }
 
+int bowgpu_stream_read_ceiling(const void *dev_a, const void *dev_b, int64_t bytes_each, double *gb_per_s) {
+    if (!dev_a || !dev_b || !gb_per_s || bytes_each < (1 << 20)) return fail(BOWGPU_ERR_ARG, "two device buffers of at least 1 MiB each are needed");
+    if ((reinterpret_cast<uintptr_t>(dev_a) | reinterpret_cast<uintptr_t>(dev_b)) & 15) return fail(BOWGPU_ERR_ARG, "buffers must be 16-byte aligned");
+    Ctx *c;
+    BG_TRY(ctx_get(&c));
+    void *d;
+    BG_TRY(ctx_scratch(c, 4096, &d));
+    uint64_t *dout = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(d) + 3072);
+    double best = 0.0;
+    const int shapes[][2] = {{0, 8}, {0, 16}, {0, 32}, {1, 0}};  // {mode, workgroups per CU}
+    for (const auto &sh : shapes) {
+        float ms = 0;
+        BG_TRY(stream_sum_run(c, dev_a, dev_b, bytes_each, sh[0], sh[1], 5, dout, &ms));
+        const double gbs = 2.0 * (double)(bytes_each / 16 * 16) / (ms * 1e-3) / 1e9;
+        if (gbs > best) best = gbs;
+    }
+    *gb_per_s = best;
+    return 0;
+}
+
 int bowgpu_checksum64(const void *dev, int64_t n_words, uint64_t *xor_out, uint64_t *sum_out) {
     Ctx *c;
     BG_TRY(ctx_get(&c));

@@ -211,6 +211,7 @@ constexpr int kStatusWords = kLongCountWord + kLongLists;
 struct LongListStarts { int64_t start[kLongLists + 1]; };  // prefix sums of the sub-list counts (host side)
 size_t long_entry_size();
 size_t long_part_size();
+int stream_sum_run(Ctx *c, const void *a, const void *b, int64_t bytes_each, int mode, int blocks_per_cu, int reps, uint64_t *d_out, float *ms);
 int launch_long_windows_v2(Ctx *c, const AggParams &p, const LongListStarts &starts, void *entries, int32_t *nchunks, int64_t *offsets,
                            int64_t *block_sums, int64_t *d_total, int32_t *work_entry, void *partials, int64_t max_work);
 int launch_fix_tail_bits(Ctx *c, uint8_t *bitmap, int64_t nbits);

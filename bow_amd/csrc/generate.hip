@@ -83,6 +83,69 @@ __global__ __launch_bounds__(256) void checksum64_kernel(const uint64_t *__restr
     }
 }
 
+// The "achievable" line of the roofline: a trivial streaming sum over two device buffers, nothing else.
+// kMode 0: grid-stride over 16-B words, 4 independent loads per trip; kMode 1: one wavefront per 10 KB + 10 KB tile in the
+// launch shape of the rolling kernels (two streams, 16 B per lane, XCD-contiguous tiles).
+template <int kMode>
+__global__ __launch_bounds__(256) void stream_sum_kernel(const ulonglong2 *__restrict__ a, const ulonglong2 *__restrict__ b, int64_t n16,
+                                                         unsigned long long *out) {
+    unsigned long long x = 0;
+    if (kMode == 0) {
+        const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+        int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        for (; i + 3 * stride < n16; i += 4 * stride) {
+            const ulonglong2 a0 = a[i], a1 = a[i + stride], a2 = a[i + 2 * stride], a3 = a[i + 3 * stride];
+            const ulonglong2 b0 = b[i], b1 = b[i + stride], b2 = b[i + 2 * stride], b3 = b[i + 3 * stride];
+            x ^= a0.x ^ a0.y ^ a1.x ^ a1.y ^ a2.x ^ a2.y ^ a3.x ^ a3.y ^ b0.x ^ b0.y ^ b1.x ^ b1.y ^ b2.x ^ b2.y ^ b3.x ^ b3.y;
+        }
+        for (; i < n16; i += stride) { const ulonglong2 a0 = a[i], b0 = b[i]; x ^= a0.x ^ a0.y ^ b0.x ^ b0.y; }
+    } else {
+        // 256 threads = 4 wavefronts, each its own tile of 256 16-B words per stream (4 loads per lane and stream)
+        const int64_t ntiles = n16 / 256;
+        const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+        const int64_t per_xcd = (ntiles + 7) / 8;
+        const int64_t tile = (wave & 7) * per_xcd + (wave >> 3);
+        if (tile < ntiles && (wave >> 3) < per_xcd) {
+            const ulonglong2 *pa = a + tile * 256 + (threadIdx.x & 63), *pb = b + tile * 256 + (threadIdx.x & 63);
+            const ulonglong2 a0 = pa[0], a1 = pa[64], a2 = pa[128], a3 = pa[192];
+            const ulonglong2 b0 = pb[0], b1 = pb[64], b2 = pb[128], b3 = pb[192];
+            x ^= a0.x ^ a0.y ^ a1.x ^ a1.y ^ a2.x ^ a2.y ^ a3.x ^ a3.y ^ b0.x ^ b0.y ^ b1.x ^ b1.y ^ b2.x ^ b2.y ^ b3.x ^ b3.y;
+        }
+    }
+    if (x == 0x0123456789abcdefull) atomicXor(out, x);  // keeps the loads alive; practically never taken
+}
+
+}  // namespace
+
+// average duration (ms) of `reps` launches of the streaming sum over 2 x bytes_each
+int stream_sum_run(Ctx *c, const void *a, const void *b, int64_t bytes_each, int mode, int blocks_per_cu, int reps, uint64_t *d_out, float *ms) {
+    const int64_t n16 = bytes_each / 16;
+    hipEvent_t e0, e1;
+    BG_HIP(hipEventCreate(&e0));
+    BG_HIP(hipEventCreate(&e1));
+    auto launch = [&]() {
+        if (mode == 0)
+            hipLaunchKernelGGL(stream_sum_kernel<0>, dim3(256 * blocks_per_cu), dim3(256), 0, c->stream, reinterpret_cast<const ulonglong2 *>(a),
+                               reinterpret_cast<const ulonglong2 *>(b), n16, reinterpret_cast<unsigned long long *>(d_out));
+        else
+            hipLaunchKernelGGL(stream_sum_kernel<1>, dim3((unsigned)(((n16 / 256 + 7) / 8 * 8 + 3) / 4)), dim3(256), 0, c->stream,
+                               reinterpret_cast<const ulonglong2 *>(a), reinterpret_cast<const ulonglong2 *>(b), n16,
+                               reinterpret_cast<unsigned long long *>(d_out));
+    };
+    launch();  // warm-up
+    BG_HIP(hipEventRecord(e0, c->stream));
+    for (int r = 0; r < reps; r++) launch();
+    BG_HIP(hipEventRecord(e1, c->stream));
+    BG_HIP(hipEventSynchronize(e1));
+    BG_HIP(hipGetLastError());
+    BG_HIP(hipEventElapsedTime(ms, e0, e1));
+    *ms /= reps;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return 0;
+}
+
+namespace {
 }  // namespace
 
 int launch_gen_dense(Ctx *c, int64_t row0, int64_t n, uint64_t seed, int64_t *ts, double *val) {

@@ -327,6 +327,9 @@ int bowgpu_gen_dense(int64_t row0, int64_t n, uint64_t seed, int64_t *ts_dev, do
  * ceil(n/8) bytes, bit i = row row0+i (row0 must be a multiple of 8). */
 int bowgpu_gen_sparse(int64_t row0, int64_t n, uint64_t seed, int64_t *ts_dev, double *val_dev,
                       uint8_t *validity_dev);
+/* The "achievable" line next to the 8 TB/s peak: best rate (GB/s) of a trivial streaming sum over two device
+ * buffers of bytes_each bytes (16-byte aligned), tried in a few launch shapes.  Measurement aid for bench.py. */
+int bowgpu_stream_read_ceiling(const void *dev_a, const void *dev_b, int64_t bytes_each, double *gb_per_s);
 /* order-independent 64-bit checksum of a device buffer of n 8-byte words (xor / sum of mix) */
 int bowgpu_checksum64(const void *dev, int64_t n_words, uint64_t *xor_out, uint64_t *sum_out);
 
