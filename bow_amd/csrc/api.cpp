@@ -556,10 +556,10 @@ static int job_enqueue_tail(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t
 
 // Can the stripped-down kernel of rolling_simple.hip take this call?  (one null-free, 16-B aligned value column, at most
 // 4 factor-free outputs, exclusive windows, the whole interval column within 2^32 of s0, not a shard)
-static bool simple_applies(const AggJob *job, const bowgpu_agg *aggs, int32_t naggs, const Plan &plan, int *need, bool *is_int,
-                           bool *has_nulls) {
+static bool simple_applies(const AggJob *job, const bowgpu_agg *aggs, int32_t naggs, const Plan &plan, bool time_weighted, int *need,
+                           bool *is_int, bool *has_nulls) {
     const AggParams &P = job->P;
-    if (job->inclusive || P.pre_rows || !P.fits32 || naggs > kSimpleMaxAggs) return false;
+    if ((job->inclusive && !time_weighted) || P.pre_rows || !P.fits32 || naggs > kSimpleMaxAggs) return false;
     if (P.W <= 0 || P.W >= 0xFFFFFFF0ll) return false;
     // output slot 0 starts at s0 + wid_base * interval (wid_base != 0: a shard; it never lies above the shard's first row)
     const int64_t slot0_start = P.s0 + (int64_t)((uint64_t)P.wid_base * (uint64_t)P.interval);
@@ -577,7 +577,7 @@ static bool simple_applies(const AggJob *job, const bowgpu_agg *aggs, int32_t na
     for (int i = 0; i < naggs; i++) {
         const int k = aggs[i].kind;
         if (aggs[i].n_factors != 0) return false;
-        if (k >= BOWGPU_AGG_INTEGRAL_STEP && k <= BOWGPU_AGG_WAVG_LINEAR) return false;
+        if (k >= BOWGPU_AGG_INTEGRAL_STEP && k <= BOWGPU_AGG_WAVG_LINEAR && !time_weighted) return false;
         if (k == BOWGPU_AGG_MIN || k == BOWGPU_AGG_MAX) *need |= 1;
         if (k == BOWGPU_AGG_FIRST || k == BOWGPU_AGG_LAST) *need |= 2;
     }
@@ -602,7 +602,11 @@ static int job_launch_tiles(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t
     if (force && force[0] == '1') lean = false;
     int need = 0;
     bool is_int = false, has_nulls = false;
-    const bool simple = lean && allow_simple && plan && simple_applies(job, aggs, naggs, *plan, &need, &is_int, &has_nulls);
+    bool simple = lean && allow_simple && plan && simple_applies(job, aggs, naggs, *plan, false, &need, &is_int, &has_nulls);
+    // time-weighted reducers / inclusive windows: the same wave-tile structure with ts staged as float64 (rolling_tw.hip)
+    const bool tw = !lean && !(force && force[0] == '1') && allow_simple && plan &&
+                    simple_applies(job, aggs, naggs, *plan, true, &need, &is_int, &has_nulls);
+    simple = simple || tw;
     P.bits_preset = simple ? 1 : 0;
     for (int i = 0; i < naggs; i++) {
         const size_t vb = (size_t)((W + 7) >> 3);
@@ -636,9 +640,15 @@ static int job_launch_tiles(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t
             S.out_valid[i] = P.aggs[i].out_valid;
         }
         S.status = P.status; S.long_list = P.long_list; S.long_cap = P.long_cap;
-        BG_TRY(launch_rolling_simple(c, S, need, is_int, has_nulls));
+        S.inclusive = job->inclusive ? 1 : 0;
+        if (tw) {
+            BG_TRY(launch_rolling_tw(c, S, is_int, has_nulls));
+            c->last_kernel_name = "rolling_tw_kernel";
+        } else {
+            BG_TRY(launch_rolling_simple(c, S, need, is_int, has_nulls));
+            c->last_kernel_name = "rolling_simple_kernel";
+        }
         *used_simple = true;
-        c->last_kernel_name = "rolling_simple_kernel";
     } else if (lean) {
         BG_TRY(launch_rolling_fast(c, P));
         c->last_kernel_name = "rolling_wave_kernel";

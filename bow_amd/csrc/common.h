@@ -188,7 +188,7 @@ struct SimpleParams {
     uint32_t m32, sh1, sh2;
     int32_t naggs;
     int32_t ncols;                         // value columns (>= 1; reducers over the interval column use it as a column)
-    int32_t _pad;
+    int32_t inclusive;                     // rolling_tw.hip: windows are built inclusive (some reducer needs it)
     const void *values[kMaxCols];
     const uint32_t *vbits[kMaxCols];       // nullptr: this column has no nulls
     int64_t vbit0[kMaxCols], vwords[kMaxCols];
@@ -201,6 +201,7 @@ struct SimpleParams {
     int64_t long_cap;
 };
 int launch_rolling_simple(Ctx *c, const SimpleParams &p, int need, bool is_int, bool has_nulls);
+int launch_rolling_tw(Ctx *c, const SimpleParams &p, bool is_int, bool has_nulls);  // time-weighted reducers / inclusive windows (rolling_tw.hip)
 
 int launch_rolling_aggregate(Ctx *c, const AggParams &p);   // general kernel (rolling_agg.hip)
 int launch_rolling_fast(Ctx *c, const AggParams &p);        // lean kernel for exclusive windows without time-weighted reducers (rolling_fast.hip)

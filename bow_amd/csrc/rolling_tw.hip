@@ -1,0 +1,289 @@
+// rolling_tw.hip — the wave-tile kernel for the TIME-WEIGHTED reducers and INCLUSIVE windows: IntegralStep,
+// IntegralTrapezoid, WeightedAverageStep, WeightedAverageLinear (reference rolling/aggregation/integral.go:8-69,
+// weightedmean.go:8-34) next to WindowStart / Sum / ArithmeticMean / Min / Max / Count / First / Last / NumRows, with the
+// windows built inclusive when a reducer asks for it (rolling/aggregation.go:183-185, :207-211; rolling.go:201-209).
+// Same structure and limits as rolling_simple.hip (one wavefront per tile of 512 + 128 rows, 32-bit global window ids,
+// preset validity bitmaps, one lane walks one window in row order => bit-exact sums and integrals); in addition the
+// interval column is staged in LDS as float64 (the reducers read float64(ts): integral.go:17,:49) and a window whose
+// successor starts exactly at its end also folds that first row of the successor in for the reducers that declared
+// NeedInclusiveWindow, while the others see the window without it (Window.UnsetInclusive, window.go:23-31).
+// What this kernel does not take goes to rolling_agg.hip (transformation factors, rows below s0, 64-bit window ids).
+#include "agg_device.h"
+
+namespace bowgpu {
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kTileT = 512;
+constexpr int kHaloT = 128;
+constexpr int kRowsT = kTileT + kHaloT;
+constexpr int kChunksT = kRowsT / 128;
+constexpr uint32_t kSatT = 0xFFFFu;
+// At most kSegCapT windows may start inside one tile (+ look-ahead); denser tiles (windows of < 1.6 rows on average)
+// send the call to the general kernel.  A wave's LDS: 11.8 KB => 13 resident waves per CU.
+constexpr int kSegCapT = 400;
+
+struct TwShared {
+    uint64_t val[kRowsT];
+    double tsf[kRowsT];          // float64(ts) of every row of the tile (integral.go:17)
+    uint32_t vbits[kRowsT / 32 + 2];  // validity words of the value column for this tile (kNulls only)
+    uint32_t seg[kSegCapT + 2];  // heads in row order: local row | on-window-start flag << 15 | (wid - wid of the tile's first row) << 16
+};
+
+__device__ __forceinline__ uint32_t mdiv32(uint32_t n, uint32_t m, uint32_t sh1, uint32_t sh2) {
+    const uint32_t t = __umulhi(m, n);
+    return (t + ((n - t) >> sh1)) >> sh2;
+}
+__device__ __forceinline__ uint32_t left32(uint32_t x, uint32_t lane0) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)lane0, (int)x, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+__device__ __forceinline__ void lds_order() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+}  // namespace
+
+// kInt: Int64 value columns; kNulls: some column has nulls
+template <bool kInt, bool kNulls>
+__global__ __launch_bounds__(kWave, 3) void rolling_tw_kernel(const SimpleParams p, const int64_t ntiles, const int64_t tiles_per_xcd) {
+    constexpr bool kMulti = true;  // one pass per value column, always in loop form
+    __shared__ TwShared sh;
+    const int64_t b = blockIdx.x;
+    const int64_t tile = (b & 7) * tiles_per_xcd + (b >> 3);  // XCD-contiguous tile runs (look-ahead rows hit the same L2)
+    if (tile >= ntiles) return;
+    const int lane = threadIdx.x;
+    const int64_t base = tile * kTileT;
+    const int64_t n = p.n;
+    const bool interior = base + kRowsT <= n;
+    const int nloc = interior ? kRowsT : (int)(n - base);
+
+    // ---- loads: ts, then the first value column right behind it
+    uint64_t ta[kChunksT], tb[kChunksT], va[kChunksT], vb[kChunksT];
+    const uint64_t *__restrict__ ts = reinterpret_cast<const uint64_t *>(p.ts);
+    auto load_col = [&](const uint64_t *__restrict__ src, uint64_t (&a)[kChunksT], uint64_t (&bb)[kChunksT]) {
+        if (interior) {
+            const ulonglong2 *q = reinterpret_cast<const ulonglong2 *>(src + base) + lane;
+#pragma unroll
+            for (int j = 0; j < kChunksT; j++) { const ulonglong2 x = q[j * 64]; a[j] = x.x; bb[j] = x.y; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < kChunksT; j++) load_pair(src, base + j * 128 + 2 * lane, n, true, a[j], bb[j]);
+        }
+    };
+    load_col(ts, ta, tb);
+    load_col(reinterpret_cast<const uint64_t *>(p.values[0]), va, vb);
+    // the row left of the tile (scalar load): first head flag + order check
+    const int64_t left0 = base > 0 ? p.ts[base - 1] : INT64_MIN;
+    const uint32_t s0_lo = (uint32_t)p.s0;
+
+    // ---- window ids (32-bit, global), head flags, compaction with a running scalar count
+    const uint32_t w_first = mdiv32((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ta[0]) - s0_lo, p.m32, p.sh1, p.sh2);
+    uint32_t left_w = base > 0 ? mdiv32((uint32_t)left0 - s0_lo, p.m32, p.sh1, p.sh2) : 0xFFFFFFFEu;
+    int64_t left_ts = left0;
+    bool unsorted = false, sat = false;  // rows out of order ; a local window id that does not fit 16 bits
+    int nseg_total = 0, nseg_owned = 0;
+#pragma unroll
+    for (int j = 0; j < kChunksT; j++) {
+        const int l = j * 128 + 2 * lane;
+        const bool pa = l < nloc, pb = l + 1 < nloc;
+        const int64_t tsa = (int64_t)ta[j], tsb = (int64_t)tb[j];
+        const uint32_t plo = left32((uint32_t)tb[j], (uint32_t)left_ts);
+        const uint32_t phi = left32((uint32_t)(tb[j] >> 32), (uint32_t)((uint64_t)left_ts >> 32));
+        const int64_t prev_ts = (int64_t)(((uint64_t)phi << 32) | plo);
+        unsorted |= (pa && prev_ts > tsa) || (pb && tsa > tsb);
+        const uint32_t wa = mdiv32((uint32_t)tsa - s0_lo, p.m32, p.sh1, p.sh2);
+        const uint32_t wb = mdiv32((uint32_t)tsb - s0_lo, p.m32, p.sh1, p.sh2);
+        const uint32_t wprev = left32(wb, left_w);
+        const bool ha = pa && (wa != wprev);
+        const bool hb = pb && (wb != wa);
+        const uint32_t la = wa - w_first, lb = wb - w_first;
+        sat |= (ha && la >= kSatT) || (hb && lb >= kSatT);
+        const unsigned long long ma = __ballot(ha), mb = __ballot(hb);
+        int pos = nseg_total;
+        pos += __builtin_amdgcn_mbcnt_hi((unsigned)(ma >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ma, 0));
+        pos += __builtin_amdgcn_mbcnt_hi((unsigned)(mb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb, 0));
+        // bit 15: the row sits exactly on its window's start (what makes it the inclusive row of the window before)
+        const uint32_t sa = (((uint32_t)tsa - s0_lo) == wa * (uint32_t)p.interval) ? 0x8000u : 0u;
+        const uint32_t sb = (((uint32_t)tsb - s0_lo) == wb * (uint32_t)p.interval) ? 0x8000u : 0u;
+        if (ha && pos < kSegCapT) sh.seg[pos] = (uint32_t)l | sa | (la << 16);
+        pos += ha ? 1 : 0;
+        if (hb && pos < kSegCapT) sh.seg[pos] = (uint32_t)(l + 1) | sb | (lb << 16);
+        nseg_total += __popcll(ma) + __popcll(mb);
+        if (j == kChunksT - 2) nseg_owned = nseg_total;
+        left_w = (uint32_t)__builtin_amdgcn_readlane((int)wb, 63);
+        left_ts = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(tb[j] >> 32), 63) << 32) |
+                            (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)tb[j], 63));
+        sh.tsf[l] = (double)tsa;
+        sh.tsf[l + 1] = (double)tsb;
+    }
+    if (__ballot(unsorted)) {  // the call fails with BOWGPU_ERR_TS_UNSORTED
+        if (lane == 0) atomicOr(&p.status[0], 1u);
+        return;
+    }
+    if (nseg_total > kSegCapT) sat = true;
+    if (__ballot(sat)) {  // a tile the 16-bit local ids / the segment list cannot describe: the host redoes the call with the general lean kernel
+        if (lane == 0) atomicOr(&p.status[4], 1u);
+        return;
+    }
+
+    const bool reaches_end = base + kRowsT >= n;
+    const uint32_t W32 = (uint32_t)p.W;
+    // ---- one pass per value column: stage its values in LDS (the next column's loads go out first), walk, store
+    const int ncols = kMulti ? p.ncols : 1;
+    for (int c = 0; c < ncols; c++) {
+        if (kMulti) {
+            lds_order();  // the previous pass is done with sh.val / sh.vbits
+#pragma unroll
+            for (int j = 0; j < kChunksT; j++)
+                *reinterpret_cast<ulonglong2 *>(&sh.val[j * 128 + 2 * lane]) = make_ulonglong2(va[j], vb[j]);
+            if (c + 1 < ncols) load_col(reinterpret_cast<const uint64_t *>(p.values[c + 1]), va, vb);
+        }
+        if (kNulls && lane < kRowsT / 32) {  // 32 validity bits per lane, any bit offset (Arrow slices)
+            uint32_t word = 0xFFFFFFFFu;
+            if (p.vbits[c] != nullptr) {
+                const int64_t bit = p.vbit0[c] + base + 32 * (int64_t)lane;
+                const int64_t wi = bit >> 5;
+                const int shb = (int)(bit & 31);
+                const uint32_t lo = wi < p.vwords[c] ? p.vbits[c][wi] : 0u;
+                const uint32_t hi = (shb != 0 && wi + 1 < p.vwords[c]) ? p.vbits[c][wi + 1] : 0u;
+                word = shb ? ((lo >> shb) | (hi << (32 - shb))) : lo;
+            }
+            sh.vbits[lane] = word;
+        }
+        lds_order();
+
+    for (int q = lane; q < nseg_owned; q += kWave) {
+        const uint32_t e0 = sh.seg[q], e1 = sh.seg[q + 1];
+        const int r0 = (int)(e0 & 0x7FFFu);
+        const uint32_t wid = w_first + (e0 >> 16);
+        int r1;
+        uint32_t next_wid;
+        if (q + 1 < nseg_total) {
+            r1 = (int)(e1 & 0x7FFFu);
+            next_wid = w_first + (e1 >> 16);
+        } else if (reaches_end) {
+            r1 = nloc;
+            next_wid = W32;
+        } else {
+            // rows run past the look-ahead: hand the window (all its columns) to the cooperative path
+            if (c == 0) {
+                push_long_window(p.status, p.long_list, p.long_cap, tile, (uint64_t)p.wid_base + wid, base + r0);
+            }
+            continue;
+        }
+        // does the successor's first row sit exactly on this window's end?  (rolling.go:201-209; only looked at for inclusive calls)
+        const bool incl_row = p.inclusive && q + 1 < nseg_total && next_wid == wid + 1 && (e1 & 0x8000u);
+        // ---- the walk: rows r0 .. r1-1 in order (sum.go:16-22, arithmeticmean.go:17-24, minmax.go:16-28, count.go:12-18,
+        // firstlast.go, integral.go:14-31 / :46-62), then the inclusive row for the reducers that want it
+        double sum = 0.0, mn = 0.0, mx = 0.0;
+        uint64_t first_raw = 0, last_raw = 0;
+        int count = 0;
+        double pt = 0.0, pv = 0.0, integ_step = 0.0, integ_trap = 0.0;
+        for (int r = r0; r < r1; r++) {
+            if (kNulls && !((sh.vbits[r >> 5] >> (r & 31)) & 1u)) continue;
+            const uint64_t raw = sh.val[r];
+            const double x = kInt ? (double)(int64_t)raw : __longlong_as_double((long long)raw);
+            const double t = sh.tsf[r];
+            sum += x;
+            if (count == 0) { mn = x; mx = x; first_raw = raw; }
+            else {
+                if (x < mn) mn = x;
+                if (x > mx) mx = x;
+                integ_trap += (pv + x) / 2 * (t - pt);
+                integ_step += pv * (t - pt);
+            }
+            pt = t; pv = x;
+            last_raw = raw;
+            count++;
+        }
+        // the same state with the inclusive row folded in (only the trapezoid integral and its point count are read)
+        double integ_trap_incl = integ_trap;
+        int count_incl = count;
+        if (incl_row && (!kNulls || ((sh.vbits[r1 >> 5] >> (r1 & 31)) & 1u))) {
+            const uint64_t raw = sh.val[r1];
+            const double x = kInt ? (double)(int64_t)raw : __longlong_as_double((long long)raw);
+            if (count > 0) integ_trap_incl += (pv + x) / 2 * (sh.tsf[r1] - pt);
+            count_incl++;
+        }
+        const int nrows = r1 - r0;
+        const bool has_value = count > 0;
+        const int64_t win_start = p.s0 + (int64_t)((uint64_t)wid * (uint64_t)(uint32_t)p.interval);
+        if (wid >= W32) continue;  // (only on corrupt input)
+        const uint32_t gap = next_wid - wid - 1;
+        // ---- outputs of this column: lane q -> slot wid
+#pragma unroll
+        for (int a = 0; a < kSimpleMaxAggs; a++) {
+            if (a >= p.naggs) break;
+            if (kMulti && p.col[a] != c) continue;
+            uint64_t bits;
+            bool nil = false;
+            const int k = p.kind[a];
+            switch (k) {
+            case BOWGPU_AGG_WINDOW_START: bits = (uint64_t)win_start; break;
+            case BOWGPU_AGG_SUM: bits = (uint64_t)__double_as_longlong(sum); break;
+            case BOWGPU_AGG_MEAN: bits = (uint64_t)__double_as_longlong(sum / (double)(int64_t)count); nil = !has_value; break;
+            case BOWGPU_AGG_MIN: bits = (uint64_t)__double_as_longlong(mn); nil = !has_value; break;
+            case BOWGPU_AGG_MAX: bits = (uint64_t)__double_as_longlong(mx); nil = !has_value; break;
+            case BOWGPU_AGG_COUNT: bits = (uint64_t)(int64_t)count; break;
+            case BOWGPU_AGG_FIRST: bits = first_raw; nil = !has_value; break;
+            case BOWGPU_AGG_LAST: bits = last_raw; nil = !has_value; break;
+            case BOWGPU_AGG_INTEGRAL_STEP:                                                  // integral.go:43-68
+            case BOWGPU_AGG_WAVG_STEP: {                                                    // weightedmean.go:11-19
+                const int64_t last_value = win_start + p.interval;
+                double r = integ_step + pv * ((double)last_value - pt);
+                if (k == BOWGPU_AGG_WAVG_STEP) r = r / (double)(last_value - win_start);
+                bits = (uint64_t)__double_as_longlong(r);
+                nil = !has_value;
+                break;
+            }
+            case BOWGPU_AGG_INTEGRAL_TRAPEZOID:                                             // integral.go:11-37 (inclusive window)
+            case BOWGPU_AGG_WAVG_LINEAR: {                                                  // weightedmean.go:25-33
+                double r = integ_trap_incl;
+                if (k == BOWGPU_AGG_WAVG_LINEAR) r = r / (double)((win_start + p.interval) - win_start);
+                bits = (uint64_t)__double_as_longlong(r);
+                nil = count_incl < 2;
+                break;
+            }
+            default: bits = (uint64_t)__double_as_longlong((double)nrows); break;  // NumRows
+            }
+            if (nil) {  // no value (all null; fewer than two points for the trapezoid): nil => slot 0, bit cleared
+                bits = 0;
+                atomicAnd(&p.out_valid[a][wid >> 5], ~(1u << (wid & 31)));
+            }
+            p.out_values[a][wid] = bits;
+            // the empty windows right after this one (rare): values of an empty slice + cleared validity bits
+            // (A.9 "Empty slice": WindowStart s_k ; Sum 0.0 ; Count 0 ; NumRows 0.0 ; the rest nil)
+            for (uint32_t g = 1; g <= gap; g++) {
+                const uint32_t gw = wid + g;
+                if (gw >= W32) break;
+                const int64_t gstart = p.s0 + (int64_t)((uint64_t)gw * (uint64_t)(uint32_t)p.interval);
+                p.out_values[a][gw] = k == BOWGPU_AGG_WINDOW_START ? (uint64_t)gstart : 0ull;
+                if (p.out_valid[a]) atomicAnd(&p.out_valid[a][gw >> 5], ~(1u << (gw & 31)));
+            }
+        }
+    }
+    }  // columns
+}
+
+int launch_rolling_tw(Ctx *c, const SimpleParams &p, bool is_int, bool has_nulls) {
+    if (p.n <= 0) return 0;
+    const int64_t ntiles = (p.n + kTileT - 1) / kTileT;
+    const int64_t per_xcd = (ntiles + 7) / 8;
+    const int64_t grid = per_xcd * 8;
+    if (grid > 0x7FFFFFFFll) return fail(BOWGPU_ERR_UNSUPPORTED, "too many rows for one launch: %lld", (long long)p.n);
+    const dim3 g((unsigned)grid), blk(kWave);
+    if (is_int) {
+        if (has_nulls) hipLaunchKernelGGL((rolling_tw_kernel<true, true>), g, blk, 0, c->stream, p, ntiles, per_xcd);
+        else hipLaunchKernelGGL((rolling_tw_kernel<true, false>), g, blk, 0, c->stream, p, ntiles, per_xcd);
+    } else {
+        if (has_nulls) hipLaunchKernelGGL((rolling_tw_kernel<false, true>), g, blk, 0, c->stream, p, ntiles, per_xcd);
+        else hipLaunchKernelGGL((rolling_tw_kernel<false, false>), g, blk, 0, c->stream, p, ntiles, per_xcd);
+    }
+    BG_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace bowgpu
