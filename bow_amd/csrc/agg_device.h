@@ -140,6 +140,15 @@ __device__ __forceinline__ Val finish_val(Val v, const AggDesc &a) {
     return v;
 }
 
+// the same chain on a raw 8-byte result of the lean kernels (is_int: the result is an Int64)
+__device__ __forceinline__ uint64_t apply_factors(uint64_t bits, bool is_int, int n, const double *f) {
+    for (int k = 0; k < n; k++) {
+        if (is_int) bits = (uint64_t)go_f64_to_i64((double)(int64_t)bits * f[k]);
+        else bits = (uint64_t)__double_as_longlong(__longlong_as_double((long long)bits) * f[k]);
+    }
+    return bits;
+}
+
 __device__ __forceinline__ Val make_f64(double x) { Val v; v.bits = (uint64_t)__double_as_longlong(x); v.valid = 1; v.is_int = 0; return v; }
 __device__ __forceinline__ Val make_i64(int64_t x) { Val v; v.bits = (uint64_t)x; v.valid = 1; v.is_int = 1; return v; }
 __device__ __forceinline__ Val make_nil() { Val v; v.bits = 0; v.valid = 0; v.is_int = 0; return v; }

@@ -576,7 +576,6 @@ static bool simple_applies(const AggJob *job, const bowgpu_agg *aggs, int32_t na
     }
     for (int i = 0; i < naggs; i++) {
         const int k = aggs[i].kind;
-        if (aggs[i].n_factors != 0) return false;
         if (k >= BOWGPU_AGG_INTEGRAL_STEP && k <= BOWGPU_AGG_WAVG_LINEAR && !time_weighted) return false;
         if (k == BOWGPU_AGG_MIN || k == BOWGPU_AGG_MAX) *need |= 1;
         if (k == BOWGPU_AGG_FIRST || k == BOWGPU_AGG_LAST) *need |= 2;
@@ -635,6 +634,8 @@ static int job_launch_tiles(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t
         }
         for (int i = 0; i < naggs; i++) {
             S.kind[i] = aggs[i].kind;
+            S.nfac[i] = aggs[i].n_factors;
+            for (int f = 0; f < aggs[i].n_factors && f < BOWGPU_MAX_FACTORS; f++) S.fac[i][f] = aggs[i].factors[f];
             S.col[i] = P.aggs[i].slot < 0 ? 0 : P.aggs[i].slot;
             S.out_values[i] = reinterpret_cast<uint64_t *>(P.aggs[i].out_values);
             S.out_valid[i] = P.aggs[i].out_valid;

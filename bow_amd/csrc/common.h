@@ -194,6 +194,8 @@ struct SimpleParams {
     int64_t vbit0[kMaxCols], vwords[kMaxCols];
     int32_t kind[kSimpleMaxAggs];
     int32_t col[kSimpleMaxAggs];           // column slot each output reads (WindowStart / NumRows ride with slot 0)
+    int32_t nfac[kSimpleMaxAggs];          // transformation.Factor chain of each output (factor.go:7-20), usually empty
+    double fac[kSimpleMaxAggs][BOWGPU_MAX_FACTORS];
     uint64_t *out_values[kSimpleMaxAggs];
     uint32_t *out_valid[kSimpleMaxAggs];   // nullptr for never-nil reducers; all bitmaps are preset to ones by the host
     uint32_t *status;         // [0] unsorted, [2] list overflow, [4] redo with the general lean kernel, [16..79] long-window counts

@@ -249,6 +249,9 @@ __global__ __launch_bounds__(kWave, 3) void rolling_tw_kernel(const SimpleParams
             }
             default: bits = (uint64_t)__double_as_longlong((double)nrows); break;  // NumRows
             }
+            const bool int_result = k == BOWGPU_AGG_WINDOW_START || k == BOWGPU_AGG_COUNT || (kInt && (k == BOWGPU_AGG_FIRST || k == BOWGPU_AGG_LAST));
+            const int nf = p.nfac[a];
+            if (nf) bits = apply_factors(bits, int_result, nf, p.fac[a]);
             if (nil) {  // no value (all null; fewer than two points for the trapezoid): nil => slot 0, bit cleared
                 bits = 0;
                 atomicAnd(&p.out_valid[a][wid >> 5], ~(1u << (wid & 31)));
@@ -260,7 +263,11 @@ __global__ __launch_bounds__(kWave, 3) void rolling_tw_kernel(const SimpleParams
                 const uint32_t gw = wid + g;
                 if (gw >= W32) break;
                 const int64_t gstart = p.s0 + (int64_t)((uint64_t)gw * (uint64_t)(uint32_t)p.interval);
-                p.out_values[a][gw] = k == BOWGPU_AGG_WINDOW_START ? (uint64_t)gstart : 0ull;
+                uint64_t gbits = k == BOWGPU_AGG_WINDOW_START ? (uint64_t)gstart : 0ull;
+                // (Sum / NumRows of an empty slice are +0.0 and Count is 0: a negative factor still turns the floats into -0.0)
+                if (nf && (k == BOWGPU_AGG_WINDOW_START || k == BOWGPU_AGG_SUM || k == BOWGPU_AGG_NUM_ROWS || k == BOWGPU_AGG_COUNT))
+                    gbits = apply_factors(gbits, int_result, nf, p.fac[a]);
+                p.out_values[a][gw] = gbits;
                 if (p.out_valid[a]) atomicAnd(&p.out_valid[a][gw >> 5], ~(1u << (gw & 31)));
             }
         }

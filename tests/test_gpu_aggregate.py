@@ -2,6 +2,8 @@
 (1) the reference's own golden vectors and (2) the CPU oracle on seeded inputs.
 Bar: bit-exact for every output (values of valid slots, validity bitmaps, null slots == 0);
 Sum/Mean/Integral of windows that take the cooperative long-window path: 1e-12 relative."""
+import os
+
 import numpy as np
 import pytest
 
@@ -229,6 +231,34 @@ def test_multi_column_and_factors():
     for (k, *_), g, w in zip(aggs, outs, exp):
         compare(k, g, w)
     assert info.new_interval_col == 9
+
+
+@pytest.mark.parametrize("vkind", ["f64", "i64"])
+def test_factors_on_the_simple_and_time_weighted_kernels(vkind):
+    # transformation.Factor chains (factor.go:7-20) on every reducer, one column type per call so the simple / time-weighted
+    # wave kernels take it; gappy ts => empty windows, where a negative factor turns Sum / NumRows (+0.0) into -0.0
+    rng = np.random.default_rng(21)
+    n = 90_000
+    ts = make_ts(rng, n, "gappy")
+    cols = [make_vals(rng, n, vkind, 0.25), make_vals(rng, n, vkind, 0.0)]
+    aggs = [("WindowStart", 0, [0.5]), ("Sum", 1, [-1.0]), ("ArithmeticMean", 1, [0.1, 10.0]), ("Min", 2, [3.0]), ("Max", 1, [-2.5]),
+            ("Count", 1, [3.0]), ("First", 2, [0.1]), ("Last", 1, [7.0]), ("NumRows", 1, [-2.0]), ("WindowStart", 0)]
+    outs, exp, info = run_both(ts, cols, 10, aggs, offset=3)
+    assert capi.last_kernel_name() == "rolling_agg_kernel"  # (run_both ends with the general kernel; "auto" was the simple one)
+    tw = [("WindowStart", 0), ("IntegralStep", 1, [0.5]), ("IntegralTrapezoid", 1, [-1.0]), ("WeightedAverageStep", 2, [2.0]),
+          ("WeightedAverageLinear", 1, [0.25, 4.0]), ("Sum", 1, [-1.0]), ("Count", 2, [2.0])]
+    for inclusive in (False, True):
+        run_both(ts, cols, 10, tw, offset=3, inclusive=inclusive)
+    os.environ["BOWGPU_NO_SIMPLE"] = "0"
+    os.environ["BOWGPU_FORCE_GENERAL"] = "0"
+    capi.rolling_aggregate([capi.Column(ts)] + [capi.Column(v, np.packbits(m, bitorder="little") if m is not None else None,
+                                                             capi.INT64 if vkind == "i64" else capi.FLOAT64, 0, n, -1) for v, m in cols],
+                           0, 10, tw, offset=3)
+    assert capi.last_kernel_name() == "rolling_tw_kernel"
+    capi.rolling_aggregate([capi.Column(ts)] + [capi.Column(v, np.packbits(m, bitorder="little") if m is not None else None,
+                                                             capi.INT64 if vkind == "i64" else capi.FLOAT64, 0, n, -1) for v, m in cols],
+                           0, 10, aggs, offset=3)
+    assert capi.last_kernel_name() == "rolling_simple_kernel"
 
 
 def test_nan_inf_signed_zero_semantics():
