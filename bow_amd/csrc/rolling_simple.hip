@@ -2,7 +2,7 @@
 // descriptor-driven branch:
 //   * up to 8 value columns of ONE type (all Float64 or all Int64, with or without nulls) plus the interval column;
 //   * up to 12 outputs among WindowStart / Sum / ArithmeticMean / Min / Max / Count / First / Last / NumRows,
-//     no transformation factors, exclusive windows;
+//     transformation.Factor chains applied to the result, exclusive windows;
 //   * the rows of this call (the whole frame, or one rank's shard of it) span less than 2^32 from the start of output
 //     slot 0 and interval < 2^32, so window ids are 32-bit: wid = magic32((uint32)(ts - s0)) with no per-tile base.
 // (reference rolling/rolling.go:177-239 + rolling/aggregation.go:190-238 + the reducer closures of

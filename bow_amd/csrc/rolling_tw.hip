@@ -7,7 +7,7 @@
 // interval column is staged in LDS as float64 (the reducers read float64(ts): integral.go:17,:49) and a window whose
 // successor starts exactly at its end also folds that first row of the successor in for the reducers that declared
 // NeedInclusiveWindow, while the others see the window without it (Window.UnsetInclusive, window.go:23-31).
-// What this kernel does not take goes to rolling_agg.hip (transformation factors, rows below s0, 64-bit window ids).
+// What this kernel does not take goes to rolling_agg.hip (rows below s0, mixed column types, 64-bit window ids).
 #include "agg_device.h"
 
 namespace bowgpu {
