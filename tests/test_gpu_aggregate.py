@@ -350,6 +350,23 @@ def test_long_windows_mixed_shapes(inclusive):
         assert info.long_windows >= 5
 
 
+def test_nanosecond_timestamps_beyond_2_53():
+    # nanosecond timestamps far above 2^53, where float64(ts) is lossy - and that lossy value is what the time-weighted
+    # reducers read (integral.go:17,:49) - positive and negative; 1 s windows (tile kernels) and 1 day windows (long-window path).
+    # (Rows within one interval of INT64_MAX / INT64_MIN make s_k + interval wrap in the reference itself: not a defined input.)
+    rng = np.random.default_rng(3)
+    aggs = [(k, 0 if k == "WindowStart" else 1) for k in ALL_AGGS]
+    tw = [("WindowStart", 0)] + [(k, 1) for k in TIME_AGGS]
+    for base, interval, offset in [(1_700_000_000_000_000_000, 1_000_000_000, 0), (1_700_000_000_000_000_000, 86_400_000_000_000, 5),
+                                   (-1_700_000_000_000_000_000, 1_000_000_007, -3)]:
+        n = 60_000
+        ts = np.sort(rng.integers(0, 200_000_000_000_000, n)).astype(np.int64) + np.int64(base)
+        vals, valid = make_vals(rng, n, "f64", 0.2)
+        run_both(ts, [(vals, valid)], interval, aggs, offset=offset)
+        for inclusive in (False, True):
+            run_both(ts, [(vals, valid)], interval, tw, offset=offset, inclusive=inclusive)
+
+
 def test_declines_unsorted_and_null_timestamps():
     ts = np.array([1, 5, 3, 9, 12, 20], dtype=np.int64)
     v = np.arange(6, dtype=np.float64)
