@@ -269,10 +269,14 @@ struct InterpParams {
     uint32_t *status;                  // [0] |= 1: interval column not ascending; [1]: window kq has no row of its own
     int64_t kq;                        // index of the window that starts at -1 (the reference's "no first value" sentinel), else -1
     int64_t drop;                      // leading rows that belong to no window (interp_quirk_kernel), normally 0
+    uint32_t m32, sh1_32, sh2_32;      // 32-bit magic of the interval (fast32 only)
+    int32_t fast32;                    // interp_fast32(plan, kq): 32-bit window ids, integer exact-head test
     int32_t ncols, ts_col;
     InterpCol cols[kMaxCols];
 };
 int64_t interp_tiles(int64_t n);
+bool interp_fast32(const Plan &plan, int64_t kq);
+void interp_magic32(int64_t interval, uint32_t *m, uint32_t *sh1, uint32_t *sh2);
 int launch_interp_count(Ctx *c, const int64_t *ts, int64_t n, const Plan &plan, int64_t kq, int32_t *tile_exact, uint32_t *status);
 int launch_interp_tiles(Ctx *c, const InterpParams &p);
 enum { kFillLinear = -1 };  // FillParams::method; >= 0: BOWGPU_FILL_PREVIOUS / NEXT / MEAN

@@ -242,6 +242,8 @@ int bowgpu_rolling_interpolate_fill(const bowgpu_col *cols, int32_t ncols, int32
     P.status = reinterpret_cast<uint32_t *>(dscr);  // (status[1] still holds pass 1's answer about window kq)
     P.kq = job.kq;
     P.drop = job.drop;
+    P.fast32 = interp_fast32(job.plan, job.kq) ? 1 : 0;
+    if (P.fast32) interp_magic32(job.plan.interval, &P.m32, &P.sh1_32, &P.sh2_32);
     P.ncols = ncols; P.ts_col = ts_col;
     for (int i = 0; i < ncols; i++) {
         DevCol &dc = job.dcols[i];

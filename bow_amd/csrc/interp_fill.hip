@@ -148,58 +148,83 @@ __global__ __launch_bounds__(256) void col_order_kernel(const uint64_t *values, 
     if (f) atomicOr(flags, f);
 }
 
-// Bow.FillLinear (bowfill.go:14-103), FillPrevious / FillNext (:162-253), FillMean (:105-160): one thread per row, null
-// rows look their neighbours up through the index
-__global__ __launch_bounds__(256) void fill_kernel(const FillParams p) {
-    unsigned long long nvalid = 0;
-    // a wavefront covers 64 consecutive rows per trip: its validity bits leave as one aligned 64-bit word (ballot)
-    for (int64_t base = ((int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63)); base < p.n; base += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t i = base + (threadIdx.x & 63);
-        const bool live = i < p.n;
-        uint64_t bits = live ? p.fill_values[i] : 0;
-        int valid = (live && bit_at(p.fill_vbits, p.fill_vbit0, i)) ? 1 : 0;
-        if (live && !valid) {
-            const int64_t rp = p.method == BOWGPU_FILL_NEXT ? -1 : prev_valid_ix(p.fill_vbits, p.fill_vbit0, p.n, i - 1, p.nbr);
-            const int64_t rn = p.method == BOWGPU_FILL_PREVIOUS ? -1 : next_valid_ix(p.fill_vbits, p.fill_vbit0, p.n, i + 1, p.nbr);
-            if (p.method == BOWGPU_FILL_PREVIOUS) {
-                if (rp >= 0) { bits = p.fill_values[rp]; valid = 1; }          // arr.Value(fillRowIndex): bowfill.go:196-199
-            } else if (p.method == BOWGPU_FILL_NEXT) {
-                if (rn >= 0) { bits = p.fill_values[rn]; valid = 1; }
-            } else if (p.method == BOWGPU_FILL_MEAN) {
-                if (rp >= 0 && rn >= 0) {                                       // bowfill.go:145-154
-                    const double m = (bits_to_f64(p.fill_values[rp], p.fill_type) + bits_to_f64(p.fill_values[rn], p.fill_type)) / 2;
-                    bits = p.fill_type == BOWGPU_INT64 ? (uint64_t)go_f64_to_i64(round(m)) : (uint64_t)__double_as_longlong(m);
-                    valid = 1;
-                }
-            } else {                                                            // FillLinear: bowfill.go:65-97
-                const bool v1 = bit_at(p.ref_vbits, p.ref_vbit0, i);
-                const bool v2 = rp >= 0 && bit_at(p.ref_vbits, p.ref_vbit0, rp);   // GetFloat64(ref, -1) => (0,false) :72
-                const bool v3 = rn >= 0 && bit_at(p.ref_vbits, p.ref_vbit0, rn);
-                if (v1 && v2 && v3) {
-                    const double prev_fill = bits_to_f64(p.fill_values[rp], p.fill_type);
-                    const double next_fill = bits_to_f64(p.fill_values[rn], p.fill_type);
-                    const double row_ref = bits_to_f64(p.ref_values[i], p.ref_type);
-                    const double prev_ref = bits_to_f64(p.ref_values[rp], p.ref_type);
-                    const double next_ref = bits_to_f64(p.ref_values[rn], p.ref_type);
-                    // (the nextRef-prevRef == 0 branch of :78-85 is overwritten by the fall-through below)
-                    double tmp = row_ref - prev_ref;   // :87-90, four separate statements
-                    tmp /= next_ref - prev_ref;
-                    tmp *= next_fill - prev_fill;
-                    tmp += prev_fill;
-                    if (p.fill_type == BOWGPU_INT64) bits = (uint64_t)go_f64_to_i64(round(tmp));  // math.Round: half away from zero :93
-                    else bits = (uint64_t)__double_as_longlong(tmp);
-                    valid = 1;
-                }
-            }
+// the value a null row i receives (bits, valid) under p.method
+__device__ __forceinline__ void fill_one(const FillParams &p, int64_t i, uint64_t *bits_io, int *valid_io) {
+    uint64_t bits = *bits_io;
+    int valid = 0;
+    const int64_t rp = p.method == BOWGPU_FILL_NEXT ? -1 : prev_valid_ix(p.fill_vbits, p.fill_vbit0, p.n, i - 1, p.nbr);
+    const int64_t rn = p.method == BOWGPU_FILL_PREVIOUS ? -1 : next_valid_ix(p.fill_vbits, p.fill_vbit0, p.n, i + 1, p.nbr);
+    if (p.method == BOWGPU_FILL_PREVIOUS) {
+        if (rp >= 0) { bits = p.fill_values[rp]; valid = 1; }          // arr.Value(fillRowIndex): bowfill.go:196-199
+    } else if (p.method == BOWGPU_FILL_NEXT) {
+        if (rn >= 0) { bits = p.fill_values[rn]; valid = 1; }
+    } else if (p.method == BOWGPU_FILL_MEAN) {
+        if (rp >= 0 && rn >= 0) {                                       // bowfill.go:145-154
+            const double m = (bits_to_f64(p.fill_values[rp], p.fill_type) + bits_to_f64(p.fill_values[rn], p.fill_type)) / 2;
+            bits = p.fill_type == BOWGPU_INT64 ? (uint64_t)go_f64_to_i64(round(m)) : (uint64_t)__double_as_longlong(m);
+            valid = 1;
         }
-        if (live) p.out_values[i] = bits;
-        const unsigned long long word = __ballot(valid);
-        if ((threadIdx.x & 63) == 0) {
-            *reinterpret_cast<unsigned long long *>(p.out_valid_words + (base >> 5)) = word;  // base is a multiple of 64
-            nvalid += __popcll(word);
+    } else {                                                            // FillLinear: bowfill.go:65-97
+        const bool v1 = bit_at(p.ref_vbits, p.ref_vbit0, i);
+        const bool v2 = rp >= 0 && bit_at(p.ref_vbits, p.ref_vbit0, rp);   // GetFloat64(ref, -1) => (0,false) :72
+        const bool v3 = rn >= 0 && bit_at(p.ref_vbits, p.ref_vbit0, rn);
+        if (v1 && v2 && v3) {
+            const double prev_fill = bits_to_f64(p.fill_values[rp], p.fill_type);
+            const double next_fill = bits_to_f64(p.fill_values[rn], p.fill_type);
+            const double row_ref = bits_to_f64(p.ref_values[i], p.ref_type);
+            const double prev_ref = bits_to_f64(p.ref_values[rp], p.ref_type);
+            const double next_ref = bits_to_f64(p.ref_values[rn], p.ref_type);
+            // (the nextRef-prevRef == 0 branch of :78-85 is overwritten by the fall-through below)
+            double tmp = row_ref - prev_ref;   // :87-90, four separate statements
+            tmp /= next_ref - prev_ref;
+            tmp *= next_fill - prev_fill;
+            tmp += prev_fill;
+            if (p.fill_type == BOWGPU_INT64) bits = (uint64_t)go_f64_to_i64(round(tmp));  // math.Round: half away from zero :93
+            else bits = (uint64_t)__double_as_longlong(tmp);
+            valid = 1;
         }
     }
-    if ((threadIdx.x & 63) == 0 && nvalid) atomicAdd(p.valid_count, nvalid);
+    *bits_io = bits;
+    *valid_io = valid;
+}
+
+// Bow.FillLinear (bowfill.go:14-103), FillPrevious / FillNext (:162-253), FillMean (:105-160).  A wavefront owns 512 consecutive
+// rows per trip as four chunks of 128: lane l holds rows 2l, 2l+1 of each chunk (one 16-B load and one 16-B store per chunk,
+// all four loads in flight at once); null rows look their neighbours up through the index; the validity bits of a chunk
+// leave as two aligned 64-bit words (the flags hop to the lane whose number is the row number, then one ballot per word).
+__global__ __launch_bounds__(256) void fill_kernel(const FillParams p) {
+    unsigned long long nvalid = 0;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    const bool vec = ((reinterpret_cast<uintptr_t>(p.fill_values) | reinterpret_cast<uintptr_t>(p.out_values)) & 15) == 0;
+    for (int64_t base = wave * 512; base < p.n; base += nwaves * 512) {
+        uint64_t a[4], b[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) load_pair(p.fill_values, base + 128 * k + 2 * lane, p.n, vec, a[k], b[k]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int64_t i = base + 128 * k + 2 * lane;
+            int va = (i < p.n && bit_at(p.fill_vbits, p.fill_vbit0, i)) ? 1 : 0;
+            int vb = (i + 1 < p.n && bit_at(p.fill_vbits, p.fill_vbit0, i + 1)) ? 1 : 0;
+            if (i < p.n && !va) fill_one(p, i, &a[k], &va);
+            if (i + 1 < p.n && !vb) fill_one(p, i + 1, &b[k], &vb);
+            if (vec && i + 1 < p.n) *reinterpret_cast<ulonglong2 *>(p.out_values + i) = make_ulonglong2(a[k], b[k]);
+            else {
+                if (i < p.n) p.out_values[i] = a[k];
+                if (i + 1 < p.n) p.out_values[i + 1] = b[k];
+            }
+            const int f = va | (vb << 1);
+            const int lo = __shfl(f, lane >> 1), hi = __shfl(f, 32 + (lane >> 1));   // rows lane and 64 + lane of the chunk
+            const unsigned long long w0 = __ballot((lo >> (lane & 1)) & 1), w1 = __ballot((hi >> (lane & 1)) & 1);
+            if (lane == 0 && base + 128 * k < p.n) {
+                unsigned long long *dst = reinterpret_cast<unsigned long long *>(p.out_valid_words + ((base + 128 * k) >> 5));
+                dst[0] = w0;
+                if (base + 128 * k + 64 < p.n) dst[1] = w1;
+                nvalid += __popcll(w0) + __popcll(w1);
+            }
+        }
+    }
+    if (lane == 0 && nvalid) atomicAdd(p.valid_count, nvalid);
 }
 
 // ------------------------------------------------------------------ whole-frame aggregation

@@ -88,13 +88,26 @@ __device__ __forceinline__ void loadR(const uint64_t *__restrict__ src, int64_t 
     }
 }
 
-// flags of rows i..i+kIR-1 from their timestamps and the timestamp left of row i (t_left; ignored for i == 0)
+// flags of rows i..i+kIR-1 from their timestamps and the timestamp left of row i (t_left; ignored for i == 0).
+// kFast: every row lies in [s0, s0 + 2^31), |ts| < 2^53 and no window starts at -1 - the usual case, established by the host:
+// window ids come from one 32-bit multiply-high per row and "exact head" is an integer comparison (the float64 round trip
+// of interpolation.go:121-123 is the identity below 2^53).
+struct Magic32 { uint32_t m, sh1, sh2; };
+__device__ __forceinline__ uint32_t mdiv32(uint32_t x, const Magic32 &d) {
+    const uint32_t t = __umulhi(d.m, x);
+    return (t + ((x - t) >> d.sh1)) >> d.sh2;
+}
+
+template <bool kFast>
 __device__ __forceinline__ RowsR rows_flags(const uint64_t (&t)[kIR], int64_t t_left, int64_t i, int64_t n, int64_t s0, int64_t interval,
-                                             const MagicDiv &magic, int64_t kq, bool *unsorted) {
+                                            const MagicDiv &magic, const Magic32 &m32, int64_t kq, bool *unsorted) {
     RowsR f;
     uint64_t wprev = 0;
     int64_t tprev = t_left;
-    if (i > 0) wprev = t_left < s0 ? 0 : magic_div((uint64_t)t_left - (uint64_t)s0, magic);
+    if (i > 0) {
+        if (kFast) wprev = mdiv32((uint32_t)((uint64_t)t_left - (uint64_t)s0), m32);
+        else wprev = t_left < s0 ? 0 : magic_div((uint64_t)t_left - (uint64_t)s0, magic);
+    }
 #pragma unroll
     for (int k = 0; k < kIR; k++) {
         f.wid[k] = 0; f.synth[k] = 0; f.exact[k] = false;
@@ -102,15 +115,28 @@ __device__ __forceinline__ RowsR rows_flags(const uint64_t (&t)[kIR], int64_t t_
         const int64_t tk = (int64_t)t[k];
         const bool first = i + k == 0;
         if (!first && tprev > tk) *unsorted = true;
-        const uint64_t w = tk < s0 ? 0 : magic_div((uint64_t)tk - (uint64_t)s0, magic);  // rows below s0 ride in window 0
-        const bool head = first || w != wprev;
-        const int64_t before = (head && !first) ? (int64_t)(w - wprev) - 1 : 0;            // empty windows in front of this row's window
-        // first valid ts of the window, through float64 as the reference does (interpolation.go:121-123)
-        const bool exact = head && go_f64_to_i64((double)tk) == s0 + (int64_t)(w * (uint64_t)interval);
-        int64_t synth = head ? before + (exact ? 0 : 1) : 0;
-        // kq >= 0: the window that starts at -1 has no row of its own; the reference then takes its "first value" -1
-        // (interpolation.go:119) for a timestamp equal to the window start and adds NO synthetic row for it
-        if (head && kq >= 0 && (uint64_t)kq <= w && (first || (uint64_t)kq > wprev) && !(exact && (uint64_t)kq == w)) synth -= 1;
+        uint64_t w;
+        bool head, exact;
+        int64_t synth;
+        if (kFast) {
+            const uint32_t rel = (uint32_t)((uint64_t)tk - (uint64_t)s0);
+            const uint32_t w32 = mdiv32(rel, m32);
+            head = first || w32 != (uint32_t)wprev;
+            exact = head && rel == w32 * (uint32_t)interval;
+            const uint32_t before = (head && !first) ? w32 - (uint32_t)wprev - 1u : 0u;
+            synth = head ? (int64_t)(before + (exact ? 0u : 1u)) : 0;
+            w = w32;
+        } else {
+            w = tk < s0 ? 0 : magic_div((uint64_t)tk - (uint64_t)s0, magic);  // rows below s0 ride in window 0
+            head = first || w != wprev;
+            const int64_t before = (head && !first) ? (int64_t)(w - wprev) - 1 : 0;        // empty windows in front of this row's window
+            // first valid ts of the window, through float64 as the reference does (interpolation.go:121-123)
+            exact = head && go_f64_to_i64((double)tk) == s0 + (int64_t)(w * (uint64_t)interval);
+            synth = head ? before + (exact ? 0 : 1) : 0;
+            // kq >= 0: the window that starts at -1 has no row of its own; the reference then takes its "first value" -1
+            // (interpolation.go:119) for a timestamp equal to the window start and adds NO synthetic row for it
+            if (head && kq >= 0 && (uint64_t)kq <= w && (first || (uint64_t)kq > wprev) && !(exact && (uint64_t)kq == w)) synth -= 1;
+        }
         f.wid[k] = w; f.synth[k] = synth; f.exact[k] = exact;
         wprev = w; tprev = tk;
     }
@@ -128,8 +154,9 @@ __device__ __forceinline__ int64_t left_ts(const uint64_t (&t)[kIR], const int64
     return (int64_t)l;
 }
 
+template <bool kFast>
 __global__ __launch_bounds__(kIThreads) void interp_count_kernel(const int64_t *ts, int64_t n, int64_t s0, int64_t interval,
-                                                                 MagicDiv magic, int32_t *tile_exact, uint32_t *status) {
+                                                                 MagicDiv magic, Magic32 m32, int32_t *tile_exact, uint32_t *status) {
     __shared__ int part[kIThreads / 64];
     __shared__ long long wave_last[kIThreads / 64];
     const int64_t i = (int64_t)blockIdx.x * kITile + kIR * (int64_t)threadIdx.x;
@@ -138,7 +165,7 @@ __global__ __launch_bounds__(kIThreads) void interp_count_kernel(const int64_t *
     loadR(reinterpret_cast<const uint64_t *>(ts), i, n, vec, t);
     const int64_t tl = left_ts(t, ts, i, n, wave_last, threadIdx.x);
     bool unsorted = false;
-    const RowsR f = rows_flags(t, tl, i, n, s0, interval, magic, -1, &unsorted);
+    const RowsR f = rows_flags<kFast>(t, tl, i, n, s0, interval, magic, m32, -1, &unsorted);
     int cnt = (int)f.exact[0] + (int)f.exact[1];
     if (unsorted) atomicOr(&status[0], 1u);
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
@@ -147,6 +174,7 @@ __global__ __launch_bounds__(kIThreads) void interp_count_kernel(const int64_t *
     if (threadIdx.x == 0) tile_exact[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
 }
 
+template <bool kFast>
 __global__ __launch_bounds__(kIThreads) void interp_tile_kernel(const InterpParams p) {
     struct LongRun { long long a, o_row, synth; unsigned long long k0; };
     __shared__ uint32_t lbits[kMaxCols][kISpanWords];
@@ -159,7 +187,8 @@ __global__ __launch_bounds__(kIThreads) void interp_tile_kernel(const InterpPara
     const int64_t r0 = (int64_t)blockIdx.x * kITile;
     const int64_t i = r0 + kIR * (int64_t)tid;
     for (int w = tid; w < kMaxCols * kISpanWords; w += kIThreads) (&lbits[0][0])[w] = 0;
-    const int64_t kq = (p.kq >= 0 && p.status[1]) ? p.kq : -1;  // see rows_flags
+    const int64_t kq = (!kFast && p.kq >= 0 && p.status[1]) ? p.kq : -1;  // see rows_flags
+    const Magic32 m32 = {p.m32, p.sh1_32, p.sh2_32};
     if (tid == 0) s_nlong = 0;
 
     // ---- loads: ts, then the first column right behind it
@@ -172,7 +201,8 @@ __global__ __launch_bounds__(kIThreads) void interp_tile_kernel(const InterpPara
     int64_t o_base = 0;
     if (r0 > 0) {
         const int64_t tp = p.ts[r0 - 1];
-        const uint64_t wp = tp < p.s0 ? 0 : magic_div((uint64_t)tp - (uint64_t)p.s0, p.magic);
+        const uint64_t wp = kFast ? (uint64_t)mdiv32((uint32_t)((uint64_t)tp - (uint64_t)p.s0), m32)
+                                  : (tp < p.s0 ? 0 : magic_div((uint64_t)tp - (uint64_t)p.s0, p.magic));
         o_base = (r0 - (p.drop < r0 ? p.drop : r0)) + (int64_t)wp + 1 - p.tile_exact_before[blockIdx.x];
         if (kq >= 0 && (uint64_t)kq <= wp) o_base -= 1;
     }
@@ -180,7 +210,7 @@ __global__ __launch_bounds__(kIThreads) void interp_tile_kernel(const InterpPara
 
     const int64_t tl = left_ts(t, p.ts, i, p.n, wave_last, tid);  // (one __syncthreads inside: the LDS clears above are visible after it)
     bool unsorted = false;
-    const RowsR f = rows_flags(t, tl, i, p.n, p.s0, p.interval, p.magic, kq, &unsorted);
+    const RowsR f = rows_flags<kFast>(t, tl, i, p.n, p.s0, p.interval, p.magic, m32, kq, &unsorted);
     if (unsorted) atomicOr(&p.status[0], 1u);
 
     // ---- output positions: thread totals -> wave scan -> workgroup
@@ -328,23 +358,50 @@ __global__ void interp_quirk_kernel(const int64_t *ts, int64_t n, int64_t s0, in
     }
 }
 
+static Magic32 magic32_make(int64_t interval) {  // Granlund & Montgomery fig. 4.1 with N = 32 (interval < 2^31)
+    const uint64_t d = (uint64_t)interval;
+    int l = 0;
+    while (l < 32 && (1ull << l) < d) l++;
+    Magic32 m;
+    m.m = (uint32_t)((((1ull << l) - d) << 32) / d) + 1;
+    m.sh1 = l < 1 ? (uint32_t)l : 1u;
+    m.sh2 = l > 1 ? (uint32_t)(l - 1) : 0u;
+    return m;
+}
+
+// the fast 32-bit form applies when every row lies in [s0, s0 + 2^31), timestamps are exact in float64 and no window starts at -1
+bool interp_fast32(const Plan &plan, int64_t kq) {
+    const int64_t lim53 = 1ll << 53;
+    return kq < 0 && plan.first_ts >= plan.s0 && plan.interval < (1ll << 31) && (uint64_t)plan.last_ts - (uint64_t)plan.s0 < (1ull << 31) &&
+           plan.first_ts > -lim53 && plan.last_ts < lim53;
+}
+
 int launch_interp_count(Ctx *c, const int64_t *ts, int64_t n, const Plan &plan, int64_t kq, int32_t *tile_exact, uint32_t *status) {
     const int64_t ntiles = (n + kITile - 1) / kITile;
     if (ntiles <= 0) return 0;
     if (kq >= 0 || plan.first_ts < plan.s0)
         hipLaunchKernelGGL(interp_quirk_kernel, dim3(1), dim3(64), 0, c->stream, ts, n, plan.s0, plan.interval, kq, status);
-    hipLaunchKernelGGL(interp_count_kernel, dim3((unsigned)ntiles), dim3(kIThreads), 0, c->stream, ts, n, plan.s0, plan.interval, plan.magic,
-                       tile_exact, status);
+    if (interp_fast32(plan, kq))
+        hipLaunchKernelGGL(interp_count_kernel<true>, dim3((unsigned)ntiles), dim3(kIThreads), 0, c->stream, ts, n, plan.s0, plan.interval,
+                           plan.magic, magic32_make(plan.interval), tile_exact, status);
+    else
+        hipLaunchKernelGGL(interp_count_kernel<false>, dim3((unsigned)ntiles), dim3(kIThreads), 0, c->stream, ts, n, plan.s0, plan.interval,
+                           plan.magic, Magic32{0, 0, 0}, tile_exact, status);
     BG_HIP(hipGetLastError());
     return 0;
 }
 
 int64_t interp_tiles(int64_t n) { return (n + kITile - 1) / kITile; }
+void interp_magic32(int64_t interval, uint32_t *m, uint32_t *sh1, uint32_t *sh2) {
+    const Magic32 x = magic32_make(interval);
+    *m = x.m; *sh1 = x.sh1; *sh2 = x.sh2;
+}
 
 int launch_interp_tiles(Ctx *c, const InterpParams &p) {
     const int64_t ntiles = (p.n + kITile - 1) / kITile;
     if (ntiles <= 0) return 0;
-    hipLaunchKernelGGL(interp_tile_kernel, dim3((unsigned)ntiles), dim3(kIThreads), 0, c->stream, p);
+    if (p.fast32) hipLaunchKernelGGL(interp_tile_kernel<true>, dim3((unsigned)ntiles), dim3(kIThreads), 0, c->stream, p);
+    else hipLaunchKernelGGL(interp_tile_kernel<false>, dim3((unsigned)ntiles), dim3(kIThreads), 0, c->stream, p);
     BG_HIP(hipGetLastError());
     return 0;
 }
