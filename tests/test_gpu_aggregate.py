@@ -38,7 +38,13 @@ def compare(name, got, want, exact=True, rtol=1e-12):
     # null slots hold 0 (bow.NewBuffer zero-init; never written)
     assert not gbits[~gm].any(), name
     if exact:
-        bad = np.flatnonzero(gbits[gm] != wbits[wm])
+        diff = gbits[gm] != wbits[wm]
+        if diff.any() and got.type == capi.FLOAT64:
+            # A NaN that the arithmetic GENERATES (inf - inf, 0 * inf) carries the hardware's default payload: x86 (the oracle,
+            # and Go on amd64) gives the negative "real indefinite" 0xFFF8..., gfx950 the positive 0x7FF8...; Go prints both as
+            # NaN and no operation on this path tells them apart.  NaNs that come from the input keep their bits on both.
+            diff &= ~(np.isnan(gv[gm].view(np.float64)) & np.isnan(wv[wm].view(np.float64)))
+        bad = np.flatnonzero(diff)
         assert bad.size == 0, (name, bad[:10], gv[gm][bad[:5]], wv[wm][bad[:5]])
     else:
         g, w = gv[gm].astype(np.float64), wv[wm].astype(np.float64)

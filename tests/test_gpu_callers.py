@@ -34,7 +34,11 @@ def cmp_out(name, got, want):
     assert np.array_equal(gm, wm), (name, np.flatnonzero(gm != wm)[:10])
     gv, _ = got.host_arrays()
     wv = want.values[:want.length]
-    assert np.array_equal(gv.view(np.uint64)[gm], wv.view(np.uint64)[wm]), name
+    gb_, wb_ = gv.view(np.uint64)[gm], wv.view(np.uint64)[wm]
+    diff = gb_ != wb_
+    if diff.any() and gv.dtype == np.float64:  # generated NaNs: hardware-default payload (see test_gpu_aggregate.compare)
+        diff &= ~(np.isnan(gv[gm]) & np.isnan(wv[wm].view(np.float64)))
+    assert not diff.any(), (name, np.flatnonzero(diff)[:10])
     assert got.null_count == int((~wm).sum()), name
 
 

@@ -1,0 +1,165 @@
+"""Differential fuzzing of the HIP path against the oracle: seeded random shapes of everything the C ABI accepts - row
+counts around the tile sizes, timestamp patterns (dense, irregular, duplicates, gaps, negative / rows below s0), intervals
+and raw offsets, Arrow offsets into longer buffers, null densities from 0 to 100 %, NaN / +-0 / Inf values, mixed column
+types, random reducer lists with Factor chains, inclusive windows, host / device residency - each case through every tile
+kernel that covers it (BOW_FUZZ_SEEDS=N runs N seeds instead of 8).  Bit-exact except Sum / Mean / integrals of windows on the long-window path (1e-11 relative)."""
+import os
+
+import numpy as np
+import pytest
+
+from bow_amd import capi
+from oracle import pyoracle as orc
+from test_gpu_aggregate import ALL_AGGS, TIME_AGGS, ORDER_SENSITIVE, compare
+from test_gpu_callers import cmp_out
+
+pytestmark = pytest.mark.gpu
+
+
+def rand_ts(rng, n):
+    mode = rng.integers(0, 7)
+    if n == 0:
+        return np.zeros(0, np.int64)
+    if mode == 0:
+        ts = np.arange(n, dtype=np.int64)
+    elif mode == 1:
+        ts = np.cumsum(rng.integers(1, 20, n))
+    elif mode == 2:
+        ts = np.cumsum(rng.integers(0, 3, n))
+    elif mode == 3:
+        step = rng.integers(1, 5, n)
+        step[rng.random(n) < 0.02] = rng.integers(50, 20_000)
+        ts = np.cumsum(step)
+    elif mode == 4:
+        ts = np.cumsum(rng.integers(1, 7, n)) - 3 * n
+    elif mode == 5:
+        ts = np.cumsum(rng.integers(0, 2, n)) * int(rng.integers(1, 1000))
+    else:
+        ts = np.sort(rng.integers(-5000, 5000, n))
+    return ts.astype(np.int64) + int(rng.integers(-2000, 2000))
+
+
+def rand_col(rng, n, pad):
+    """(values, validity bytes or None, type, arrow offset): a column of n rows living at `pad` rows into longer buffers"""
+    tot = n + pad + int(rng.integers(0, 9))
+    if rng.random() < 0.5:
+        v = rng.standard_normal(tot) * 10.0 ** rng.integers(-3, 6, tot)
+        sp = rng.random(tot)
+        v[sp < 0.01] = np.nan
+        v[(sp >= 0.01) & (sp < 0.02)] = 0.0
+        v[(sp >= 0.02) & (sp < 0.03)] = -0.0
+        v[(sp >= 0.03) & (sp < 0.035)] = np.inf
+        v[(sp >= 0.035) & (sp < 0.04)] = -np.inf
+        typ = capi.FLOAT64
+    else:
+        v = rng.integers(-(2 ** 50), 2 ** 50, tot).astype(np.int64)
+        typ = capi.INT64
+    frac = [0.0, 0.0, 0.05, 0.3, 0.9, 1.0][int(rng.integers(0, 6))]
+    if frac == 0.0 and rng.random() < 0.5:
+        return v, None, typ, pad
+    valid = rng.random(tot) >= frac
+    return v, np.packbits(valid, bitorder="little"), typ, pad
+
+
+def run_paths(ccols, ocols, interval, aggs, offset, inclusive, label):
+    exp, nic = orc.aggregate(ocols, 0, interval, aggs, offset=offset, inclusive=inclusive)
+    for path, env in (("auto", {}), ("lean", {"BOWGPU_NO_SIMPLE": "1"}), ("general", {"BOWGPU_FORCE_GENERAL": "1"})):
+        for k in ("BOWGPU_NO_SIMPLE", "BOWGPU_FORCE_GENERAL"):
+            os.environ[k] = env.get(k, "0")
+        try:
+            outs, info = capi.rolling_aggregate(ccols, 0, interval, aggs, offset=offset, inclusive=inclusive)
+        finally:
+            os.environ["BOWGPU_NO_SIMPLE"] = "0"
+            os.environ["BOWGPU_FORCE_GENERAL"] = "0"
+        assert info.new_interval_col == nic, label
+        for a, g, w in zip(aggs, outs, exp):
+            exact = info.long_windows == 0 or a[0] not in ORDER_SENSITIVE
+            compare("%s %s path=%s" % (label, a[0], path), g, w, exact=exact, rtol=1e-11)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BOW_FUZZ_SEEDS", "8"))))
+def test_fuzz_aggregate(seed):
+    rng = np.random.default_rng(1000 + seed)
+    sizes = [0, 1, 2, 63, 64, 65, 511, 512, 513, 639, 640, 641, 1023, 1025, 2047, 2049, 5000, 40_000]
+    for case in range(45):
+        n = int(sizes[int(rng.integers(0, len(sizes)))]) if rng.random() < 0.8 else int(rng.integers(0, 3000))
+        ts = rand_ts(rng, n)
+        interval = int([1, 2, 3, 7, 10, 64, 100, 1000, 12345, 10 ** 6][int(rng.integers(0, 10))])
+        while n and (int(ts[-1]) - int(ts[0])) // interval > 1_500_000:
+            interval *= 10  # keep the number of windows (output slots) reasonable
+        offset = int(rng.integers(-3 * interval, 3 * interval + 1))
+        ncols = int(rng.integers(1, 4))
+        pad = int(rng.integers(0, 70)) if rng.random() < 0.5 else 0
+        raw = [rand_col(rng, n, pad) for _ in range(ncols)]
+        ts_buf = np.concatenate([np.zeros(pad, np.int64), ts, np.zeros(3, np.int64)])
+        ccols = [capi.Column(ts_buf, None, capi.INT64, pad, n, 0)]
+        ocols = [orc.Column(ts_buf, None, orc.INT64, offset=pad, length=n)]
+        for v, bm, typ, off in raw:
+            ccols.append(capi.Column(v, bm, typ, off, n, -1 if bm is not None else 0))
+            ocols.append(orc.Column(v, bm, typ, offset=off, length=n))
+        if rng.random() < 0.3:
+            ccols = [c.to_device() for c in ccols]
+        inclusive = bool(rng.random() < 0.35)
+        kinds = list(ALL_AGGS) + (TIME_AGGS if (inclusive or rng.random() < 0.3) else [])
+        na = int(rng.integers(1, 9))
+        aggs = [("WindowStart", 0)]
+        for _ in range(na):
+            k = kinds[int(rng.integers(0, len(kinds)))]
+            col = 0 if k == "WindowStart" else int(rng.integers(0 if rng.random() < 0.1 else 1, ncols + 1))
+            if rng.random() < 0.25:
+                aggs.append((k, col, [float(rng.choice([0.5, -1.0, 2.0, 0.1, 1e3])) for _ in range(int(rng.integers(1, 3)))]))
+            else:
+                aggs.append((k, col))
+        if inclusive and not any(a[0] in ("IntegralTrapezoid", "WeightedAverageLinear") for a in aggs):
+            aggs.append(("IntegralTrapezoid", 1))
+        inclusive_call = any(a[0] in ("IntegralTrapezoid", "WeightedAverageLinear") for a in aggs)
+        label = "seed=%d case=%d n=%d I=%d off=%d pad=%d" % (seed, case, n, interval, offset, pad)
+        if n == 0:
+            outs, info = capi.rolling_aggregate(ccols, 0, interval, aggs, offset=offset)
+            assert all(o.length == 0 for o in outs), label
+            continue
+        run_paths(ccols, ocols, interval, aggs, offset, inclusive_call, label)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BOW_FUZZ_SEEDS", "8")) // 2))
+def test_fuzz_interpolate_and_fills(seed):
+    rng = np.random.default_rng(2000 + seed)
+    for case in range(40):
+        # (sizes are bounded by the ORACLE: like the reference's GetPrevFloat64s walks it is cubic on all-null columns)
+        n = int(rng.integers(1, 500)) if rng.random() < 0.7 else int([511, 512, 513, 700][int(rng.integers(0, 4))])
+        ts = rand_ts(rng, n)
+        interval = int([1, 2, 5, 10, 64, 100, 1000][int(rng.integers(0, 7))])
+        offset = int(rng.integers(-2 * interval, 2 * interval + 1))
+        pad = int(rng.integers(0, 40)) if rng.random() < 0.5 else 0
+        v, bm, typ, off = rand_col(rng, n, pad)
+        ts_buf = np.concatenate([np.zeros(pad, np.int64), ts, np.zeros(3, np.int64)])
+        ccols = [capi.Column(ts_buf, None, capi.INT64, pad, n, 0), capi.Column(v, bm, typ, off, n, -1 if bm is not None else 0)]
+        ocols = [orc.Column(ts_buf, None, orc.INT64, offset=pad, length=n), orc.Column(v, bm, typ, offset=off, length=n)]
+        label = "seed=%d case=%d n=%d I=%d off=%d pad=%d" % (seed, case, n, interval, offset, pad)
+        kind = ["Linear", "StepPrevious", "None"][int(rng.integers(0, 3))]
+        ip = [{"kind": "WindowStart", "col": 0}, {"kind": kind, "col": 1}]
+        if rng.random() < 0.3:
+            ip[1]["prev"] = (float(ts[0] - 3), True, 42.5, True, 42)
+        got = capi.rolling_interpolate(ccols, 0, interval, ip, offset=offset)
+        want = orc.interpolate(ocols, 0, interval, ip, offset=offset)
+        cmp_out(label + " interp ts", got[0], want[0])
+        cmp_out(label + " interp " + kind, got[1], want[1])
+        for method in ("Previous", "Next", "Mean"):
+            g, gu = capi.fill(ccols[1], method)
+            w, wu = orc.fill(ocols[1], method)
+            assert gu == wu, label
+            cmp_out(label + " fill " + method, g, w)
+        # FillLinear against a sorted reference column (the interval column)
+        if n > 0 and (np.diff(ts) >= 0).all():
+            g, gu = capi.fill_linear(ccols, 0, 1)
+            w, wu = orc.fill_linear(ocols, 0, 1)
+            assert gu == wu, label
+            cmp_out(label + " fill_linear", g, w)
+        # window bounds
+        for inclusive in (False, True):
+            s0, W, fi, sb, se, inc = capi.window_bounds(ccols[0], interval, offset, inclusive)
+            wins = orc.iterate_windows(ocols[0], interval, offset, inclusive)
+            assert W == len(wins), label
+            assert np.array_equal(fi, [w_["first_index"] for w_ in wins]), label
+            assert np.array_equal(sb, [w_["slice_begin"] for w_ in wins]), label
+            assert np.array_equal(se, [w_["slice_end"] for w_ in wins]), label
