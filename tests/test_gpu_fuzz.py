@@ -163,3 +163,45 @@ def test_fuzz_interpolate_and_fills(seed):
             assert np.array_equal(fi, [w_["first_index"] for w_ in wins]), label
             assert np.array_equal(sb, [w_["slice_begin"] for w_ in wins]), label
             assert np.array_equal(se, [w_["slice_end"] for w_ in wins]), label
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BOW_FUZZ_SEEDS", "8")) // 2))
+def test_fuzz_sharded(seed):
+    """random row-range splits (empty shards, one-row shards, shards smaller than a window) through the real protocol of
+    bow_amd/sharded.py on simulated ranks; the stitched result must equal the oracle on the whole frame"""
+    from test_gpu_sharded import run_sharded, AGGS, ORDER
+    rng = np.random.default_rng(3000 + seed)
+    for case in range(12):
+        n = int(rng.integers(2, 6000))
+        ts = rand_ts(rng, n)
+        if ts[0] < 0 and rng.random() < 0.5:
+            ts = ts - ts[0]  # (rows below s0 are the unsharded call's business: the sharded entry declines them)
+        interval = int([1, 3, 7, 10, 64, 100, 1000, 5000][int(rng.integers(0, 8))])
+        while (int(ts[-1]) - int(ts[0])) // interval > 1_000_000:
+            interval *= 10
+        offset = int(rng.integers(-2 * interval, 2 * interval + 1))
+        vals = rng.standard_normal(n) * 100
+        valid = rng.random(n) >= [0.0, 0.2, 0.9][int(rng.integers(0, 3))]
+        world = int(rng.integers(2, 7))
+        cuts = np.sort(rng.integers(0, n + 1, world - 1))
+        bounds = [0] + [int(c) for c in cuts] + [n]
+        label = "seed=%d case=%d n=%d I=%d off=%d bounds=%s" % (seed, case, n, interval, offset, bounds)
+        bm = np.packbits(valid, bitorder="little")
+        try:
+            exp, _ = orc.aggregate([orc.Column(ts, None, orc.INT64), orc.Column(vals, bm, orc.FLOAT64)], 0, interval, AGGS, offset=offset)
+        except orc.OracleError:
+            continue
+        s0, _W = orc.plan_windows(orc.Column(ts, None, orc.INT64), interval, offset)
+        if s0 > ts[0]:
+            continue  # rows below s0: not a sharded-mode input
+        res, plan = run_sharded(ts, vals, valid, bounds, interval, offset=offset)
+        for (k, _), (gv, gm, typ), w in zip(AGGS, res, exp):
+            assert len(gv) == w.length, (label, k, len(gv), w.length)
+            wm = w.valid_mask()
+            assert np.array_equal(gm, wm), (label, k)
+            wv = w.values[:w.length].view(np.uint64)
+            if k in ORDER:
+                g, e = gv.view(np.float64)[gm], wv.view(np.float64)[wm]
+                assert np.allclose(g, e, rtol=1e-11, atol=0), (label, k)
+            else:
+                assert np.array_equal(gv[gm], wv[wm]), (label, k)

@@ -26,8 +26,14 @@ def run_sharded(ts, vals, valid, bounds, interval, offset=0):
         p = sharded.GpuProvider(cols, 0, interval, AGGS, offset=offset)
         provs.append(p)
         sess.append(sharded.ShardSession(p, r, world, interval))
-    s0 = provs[0].plan_s0()
     info = [s.local_info() for s in sess]
+    # s0 as sharded_aggregate derives it: from the first timestamp of the first rank that holds rows
+    s0 = 0
+    for b in info:
+        f, _, nr = np.frombuffer(b, dtype=np.int64)
+        if nr > 0:
+            s0 = sharded.first_window_start(int(f), interval, offset)
+            break
     carries = [s.phase1(s0, info) for s in sess]
     owned = [s.phase2(carries) for s in sess]
     # assemble the global result from what each rank owns
