@@ -662,11 +662,13 @@ static int job_launch_tiles(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t
 }
 
 // Windows longer than a tile's look-ahead: workspace from the context pool, then long_windows.hip
+// hstat == nullptr: the long-only pipeline (every window of the call)
 static int run_long_windows(Ctx *c, const AggParams &P, const uint32_t *hstat, int64_t *n_long_out) {
     LongListStarts starts;
     starts.start[0] = 0;
-    for (int s = 0; s < kLongLists; s++) starts.start[s + 1] = starts.start[s] + hstat[kLongCountWord + s];
-    const int64_t n_long = starts.start[kLongLists];
+    if (hstat)
+        for (int s = 0; s < kLongLists; s++) starts.start[s + 1] = starts.start[s] + hstat[kLongCountWord + s];
+    const int64_t n_long = hstat ? starts.start[kLongLists] : P.W;
     *n_long_out = n_long;
     if (n_long == 0) return 0;
     const int64_t max_work = n_long + (P.n + kLongChunkRows - 1) / kLongChunkRows;
@@ -687,14 +689,49 @@ static int run_long_windows(Ctx *c, const AggParams &P, const uint32_t *hstat, i
     int64_t *sums = reinterpret_cast<int64_t *>(q); q += b_sums;
     int64_t *total = reinterpret_cast<int64_t *>(q); q += 256;
     int32_t *work_entry = reinterpret_cast<int32_t *>(q); q += b_map;
-    return launch_long_windows_v2(c, P, starts, entries, nchunks, offsets, sums, total, work_entry, q, max_work);
+    return launch_long_windows_v2(c, P, hstat ? &starts : nullptr, entries, nchunks, offsets, sums, total, work_entry, q, max_work);
 }
 
 static int job_run(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, int64_t *long_windows, double *kernel_ms,
-                   bool finish, const Plan *plan = nullptr) {
+                   bool finish, const Plan *plan = nullptr, bool allow_long_only = false) {
     AggParams &P = job->P;
     const int64_t W = job->W;
     bool used_simple = false;
+    // Long-only pipeline: when the windows of an unsharded call average thousands of rows, nearly all of them would be queued
+    // for long_windows.hip by a tile kernel that reads every row just to find that out.  Skip it: order check of the interval
+    // column + every window as an entry of the multi-workgroup reduction.  (BOWGPU_NO_LONG_ONLY=1: test switch.)
+    const char *nlo = getenv("BOWGPU_NO_LONG_ONLY");
+    if (allow_long_only && plan && W > 0 && P.wid_base == 0 && P.n / W >= kLongOnlyAvgRows && !(nlo && nlo[0] == '1')) {
+        BG_HIP(hipMemsetAsync(P.status, 0, kStatusWords * 4, c->stream));
+        P.bits_preset = 0;
+        for (int i = 0; i < naggs; i++) {
+            const size_t vb = (size_t)((W + 7) >> 3);
+            const bool ones = kind_never_nil(aggs[i].kind);
+            BG_HIP(hipMemsetAsync(job->douts[i].validity, ones ? 0xFF : 0x00, ((vb + 3) & ~(size_t)3), c->stream));
+            if (ones) BG_TRY(launch_fix_tail_bits(c, job->douts[i].validity, W));
+        }
+        BG_HIP(hipEventRecord(c->ev0, c->stream));
+        int64_t n_all = 0;
+        BG_TRY(run_long_windows(c, P, nullptr, &n_all));
+        BG_HIP(hipEventRecord(c->ev1, c->stream));
+        c->last_kernel_name = "long_partial_kernel";
+        uint32_t *hs;
+        BG_TRY(ctx_pinned(c, 4096, reinterpret_cast<void **>(&hs)));
+        BG_HIP(hipMemcpyAsync(hs, P.status, kStatusWords * 4, hipMemcpyDeviceToHost, c->stream));
+        uint64_t *hc = nullptr;
+        if (finish) BG_TRY(job_enqueue_tail(c, job, aggs, naggs, &hc));
+        BG_HIP(hipStreamSynchronize(c->stream));
+        if (hs[0]) return fail(BOWGPU_ERR_TS_UNSORTED, "interval column is not ascending: outside the device path");
+        if (finish)
+            for (int i = 0; i < naggs; i++)
+                job->douts[i].user->null_count = !kind_never_nil(aggs[i].kind) ? W - (int64_t)hc[i] : 0;
+        if (long_windows) *long_windows = n_all;
+        float ms = 0;
+        BG_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        c->last_kernel_ms = ms;
+        if (kernel_ms) *kernel_ms = ms;
+        return 0;
+    }
     BG_TRY(job_launch_tiles(c, job, aggs, naggs, plan, true, &used_simple));
     // status -> host (pinned).  Optimistically enqueue the tail (null counts, copy-back) behind the tile kernel so
     // the common case needs ONE synchronisation; if windows were queued for the cooperative path, run it and redo the tail.
@@ -749,7 +786,7 @@ static int run_aggregate(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t 
                          int64_t wid_base, int64_t W, int64_t *long_windows, double *kernel_ms) {
     AggJob job;
     BG_TRY(job_build(c, cols, ncols, ts_col, plan, inclusive, aggs, naggs, outs, wid_base, W, wid_base == 0, &job));
-    BG_TRY(job_run(c, &job, aggs, naggs, long_windows, kernel_ms, true, &plan));
+    BG_TRY(job_run(c, &job, aggs, naggs, long_windows, kernel_ms, true, &plan, true));
     return 0;
 }
 

@@ -207,7 +207,8 @@ int launch_rolling_tw(Ctx *c, const SimpleParams &p, bool is_int, bool has_nulls
 
 int launch_rolling_aggregate(Ctx *c, const AggParams &p);   // general kernel (rolling_agg.hip)
 int launch_rolling_fast(Ctx *c, const AggParams &p);        // lean kernel for exclusive windows without time-weighted reducers (rolling_fast.hip)
-constexpr int kLongChunkRows = 8192;
+constexpr int kLongChunkRows = 4096;
+constexpr int64_t kLongOnlyAvgRows = 512;   // windows averaging at least this many rows skip the tile kernels (api.cpp job_run)
 constexpr int kLongLists = 64;      // sub-lists of the long-window queue (agg_device.h push_long_window)
 constexpr int kLongCountWord = 16;  // status[kLongCountWord + s] = entries in sub-list s
 constexpr int kStatusWords = kLongCountWord + kLongLists;
@@ -215,7 +216,7 @@ struct LongListStarts { int64_t start[kLongLists + 1]; };  // prefix sums of the
 size_t long_entry_size();
 size_t long_part_size();
 int stream_sum_run(Ctx *c, const void *a, const void *b, int64_t bytes_each, int mode, int blocks_per_cu, int reps, uint64_t *d_out, float *ms);
-int launch_long_windows_v2(Ctx *c, const AggParams &p, const LongListStarts &starts, void *entries, int32_t *nchunks, int64_t *offsets,
+int launch_long_windows_v2(Ctx *c, const AggParams &p, const LongListStarts *starts, void *entries, int32_t *nchunks, int64_t *offsets,
                            int64_t *block_sums, int64_t *d_total, int32_t *work_entry, void *partials, int64_t max_work);
 int launch_fix_tail_bits(Ctx *c, uint8_t *bitmap, int64_t nbits);
 int launch_popcount(Ctx *c, const uint32_t *words, int64_t bit0, int64_t nbits, uint64_t *d_count);

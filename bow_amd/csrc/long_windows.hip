@@ -12,7 +12,7 @@
 //                   valid row (looked up forward, across chunk boundaries), so the terms sum in any order
 //
 // Launches: long_bounds (end row of each window by bisection + chunk counts) -> exclusive scan -> long_map ->
-// long_partial (one workgroup per 8192-row chunk, 16-B/lane loads) -> long_final (merge in chunk order, outputs,
+// long_partial (one wavefront per 4096-row chunk) -> long_final (merge in chunk order, outputs,
 // empty windows after it).
 #include "agg_device.h"
 
@@ -141,6 +141,41 @@ __global__ __launch_bounds__(256) void long_bounds_kernel(const AggParams p, con
     nchunks[e] = (int32_t)((r1 - r0 + kChunkRows - 1) / kChunkRows);
 }
 
+// Every window of the call as an entry (the "long-only" pipeline: when windows average thousands of rows the tile kernels
+// would read every row just to queue almost every window here, so the host skips them): r0 / r1 by bisection.
+__global__ __launch_bounds__(256) void long_bounds_all_kernel(const AggParams p, LongEntry *entries, int32_t *nchunks) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= p.W) return;
+    const uint64_t wid = (uint64_t)(p.wid_base + k);
+    const int64_t win_start = p.s0 + (int64_t)(wid * (uint64_t)p.interval);
+    auto lower_bound = [&](int64_t v) {
+        int64_t lo = 0, hi = p.n;
+        while (lo < hi) { const int64_t mid = lo + ((hi - lo) >> 1); if (p.ts[mid] >= v) hi = mid; else lo = mid + 1; }
+        return lo;
+    };
+    const int64_t lim = win_start + p.interval;
+    const int64_t r0 = wid == 0 ? 0 : lower_bound(win_start);  // rows below s0 ride in window 0
+    const int64_t r1 = lim < win_start ? p.n : lower_bound(lim);
+    LongEntry le;
+    le.wid = wid; le.r0 = r0; le.r1 = r1; le.next_wid = wid + 1;  // (empty windows are entries of their own: no run to fill behind)
+    le.incl_row = (p.inclusive && r1 < p.n && p.ts[r1] == lim && lim > win_start) ? 1 : 0;
+    le.dead = (p.pre_rows && wid == 0 && !((r1 > 0 && p.ts[r1 - 1] >= p.s0) || le.incl_row)) ? 1 : 0;
+    entries[k] = le;
+    nchunks[k] = (int32_t)((r1 - r0 + kChunkRows - 1) / kChunkRows);
+}
+
+// status[0] |= 1 when the interval column is not ascending (the tile kernels check this on their way; the long-only pipeline
+// has no tile kernel)
+__global__ __launch_bounds__(256) void ts_sorted_kernel(const int64_t *__restrict__ ts, int64_t n, uint32_t *status) {
+    bool bad = false;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 2;
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2; i < n; i += stride) {
+        const int64_t a = ts[i], b = i + 1 < n ? ts[i + 1] : a, l = i > 0 ? ts[i - 1] : a;
+        bad |= l > a || a > b;
+    }
+    if (bad) atomicOr(&status[0], 1u);
+}
+
 // chunk -> window map: work_entry[w] = e for the chunks [offsets[e], offsets[e+1]) of queued window e
 __global__ __launch_bounds__(256) void long_map_kernel(const int64_t n_long, const int64_t *offsets, int32_t *work_entry) {
     const int64_t e = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // one wavefront per window
@@ -149,17 +184,18 @@ __global__ __launch_bounds__(256) void long_map_kernel(const int64_t n_long, con
 }
 
 // one workgroup per chunk of one long window; partials[(work * ncols) + slot]
+// one WAVEFRONT per chunk of one window (four independent wavefronts per workgroup, no barrier): lanes stride the chunk's rows,
+// four rows per lane in flight per trip; partials[(work * ncols) + slot]
 __global__ __launch_bounds__(256) void long_partial_kernel(const AggParams p, const int64_t n_long, const LongEntry *entries,
                                                            const int64_t *offsets /* n_long + 1 */, const int32_t *work_entry,
                                                            Part *partials) {
-    __shared__ Part red[4];
-    const int64_t work = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int64_t work = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (work >= offsets[n_long]) return;
     const int64_t s_e = work_entry[work];
     const LongEntry le = entries[s_e];
     const int64_t c0 = le.r0 + (work - offsets[s_e]) * kChunkRows;
     const int64_t c1 = (c0 + kChunkRows < le.r1) ? c0 + kChunkRows : le.r1;
-    const int tid = threadIdx.x;
 
     for (int slot = 0; slot < p.ncols; slot++) {
         bool need_ts;
@@ -169,9 +205,7 @@ __global__ __launch_bounds__(256) void long_partial_kernel(const AggParams p, co
         if (need_vals && !le.dead) {
             const ColDesc &cd = p.cols[slot];
             const uint64_t *vp = reinterpret_cast<const uint64_t *>(cd.values);
-            for (int64_t r = c0 + tid; r < c1; r += 256) {
-                if (!col_valid(cd, r)) continue;
-                const uint64_t raw = vp[r];
+            auto one = [&](int64_t r, uint64_t raw) {
                 const double x = bits_to_f64(raw, cd.type);
                 acc.sum += x;
                 acc.count++;
@@ -190,10 +224,28 @@ __global__ __launch_bounds__(256) void long_partial_kernel(const AggParams p, co
                         acc.step += x * (t1 - t0);              // integral.go:55
                     }
                 }
+            };
+            int64_t r = c0 + lane;
+            for (; r + 192 < c1; r += 256) {  // four independent loads per lane before any of them is consumed
+                const uint64_t q0 = vp[r], q1 = vp[r + 64], q2 = vp[r + 128], q3 = vp[r + 192];
+                if (col_valid(cd, r)) one(r, q0);
+                if (col_valid(cd, r + 64)) one(r + 64, q1);
+                if (col_valid(cd, r + 128)) one(r + 128, q2);
+                if (col_valid(cd, r + 192)) one(r + 192, q3);
             }
+            for (; r < c1; r += 64)
+                if (col_valid(cd, r)) one(r, vp[r]);
         }
-        block_reduce(acc, red, tid);
-        if (tid == 0) partials[work * p.ncols + slot] = acc;
+        for (int o = 32; o > 0; o >>= 1) {  // wavefront reduction in a fixed shape
+            Part other;
+            other.sum = __shfl_down(acc.sum, o); other.trap = __shfl_down(acc.trap, o); other.step = __shfl_down(acc.step, o);
+            other.vmin = __shfl_down(acc.vmin, o); other.vmax = __shfl_down(acc.vmax, o);
+            other.count = __shfl_down((long long)acc.count, o);
+            other.min_idx = __shfl_down((long long)acc.min_idx, o); other.max_idx = __shfl_down((long long)acc.max_idx, o);
+            other.first_idx = __shfl_down((long long)acc.first_idx, o); other.last_idx = __shfl_down((long long)acc.last_idx, o);
+            if (lane + o < 64) part_merge(acc, other);
+        }
+        if (lane == 0) partials[work * p.ncols + slot] = acc;
     }
 }
 
@@ -286,16 +338,26 @@ __global__ __launch_bounds__(256) void long_final_kernel(const AggParams p, cons
 size_t long_entry_size() { return sizeof(LongEntry); }
 size_t long_part_size() { return sizeof(Part); }
 
-int launch_long_windows_v2(Ctx *c, const AggParams &p, const LongListStarts &starts, void *entries, int32_t *nchunks,
+// starts == nullptr: every window of the call is an entry (long-only pipeline), preceded by the order check of the interval column
+int launch_long_windows_v2(Ctx *c, const AggParams &p, const LongListStarts *starts, void *entries, int32_t *nchunks,
                            int64_t *offsets, int64_t *block_sums, int64_t *d_total, int32_t *work_entry, void *partials,
                            int64_t max_work) {
-    const int64_t n_long = starts.start[kLongLists];
+    const int64_t n_long = starts ? starts->start[kLongLists] : p.W;
     if (n_long <= 0) return 0;
-    hipLaunchKernelGGL(long_bounds_kernel, dim3((unsigned)((n_long + 255) / 256)), dim3(256), 0, c->stream, p, starts,
-                       reinterpret_cast<LongEntry *>(entries), nchunks);
+    if (starts) {
+        hipLaunchKernelGGL(long_bounds_kernel, dim3((unsigned)((n_long + 255) / 256)), dim3(256), 0, c->stream, p, *starts,
+                           reinterpret_cast<LongEntry *>(entries), nchunks);
+    } else {
+        int64_t g = (p.n / 2 + 255) / 256;
+        if (g > 256 * 32) g = 256 * 32;
+        if (g < 1) g = 1;
+        hipLaunchKernelGGL(ts_sorted_kernel, dim3((unsigned)g), dim3(256), 0, c->stream, p.ts, p.n, p.status);
+        hipLaunchKernelGGL(long_bounds_all_kernel, dim3((unsigned)((n_long + 255) / 256)), dim3(256), 0, c->stream, p,
+                           reinterpret_cast<LongEntry *>(entries), nchunks);
+    }
     BG_TRY(launch_exclusive_scan(c, nchunks, n_long, offsets, block_sums, d_total));
     hipLaunchKernelGGL(long_map_kernel, dim3((unsigned)((n_long + 3) / 4)), dim3(256), 0, c->stream, n_long, offsets, work_entry);
-    hipLaunchKernelGGL(long_partial_kernel, dim3((unsigned)max_work), dim3(256), 0, c->stream, p, n_long,
+    hipLaunchKernelGGL(long_partial_kernel, dim3((unsigned)((max_work + 3) / 4)), dim3(256), 0, c->stream, p, n_long,
                        reinterpret_cast<const LongEntry *>(entries), offsets, work_entry, reinterpret_cast<Part *>(partials));
     hipLaunchKernelGGL(long_final_kernel, dim3((unsigned)n_long), dim3(256), 0, c->stream, p, n_long,
                        reinterpret_cast<const LongEntry *>(entries), offsets, reinterpret_cast<const Part *>(partials));

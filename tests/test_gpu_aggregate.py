@@ -80,8 +80,10 @@ def run_both(ts, cols_np, interval, aggs, offset=0, inclusive=False, device=Fals
     exp, nic = orc.aggregate(ocols, 0, interval, aggs, offset=offset, inclusive=inclusive)
     first = None
     # three HIP code paths over the same inputs: simple kernel where it applies (else lean), lean kernel, general kernel
-    for label, env in (("auto", {}), ("lean", {"BOWGPU_NO_SIMPLE": "1"}), ("general", {"BOWGPU_FORCE_GENERAL": "1"})):
-        for k in ("BOWGPU_NO_SIMPLE", "BOWGPU_FORCE_GENERAL"):
+    # (the lean / general runs also switch the long-only shortcut off, so windows of thousands of rows take both long paths)
+    for label, env in (("auto", {}), ("lean", {"BOWGPU_NO_SIMPLE": "1", "BOWGPU_NO_LONG_ONLY": "1"}),
+                       ("general", {"BOWGPU_FORCE_GENERAL": "1", "BOWGPU_NO_LONG_ONLY": "1"})):
+        for k in ("BOWGPU_NO_SIMPLE", "BOWGPU_FORCE_GENERAL", "BOWGPU_NO_LONG_ONLY"):
             os.environ[k] = env.get(k, "0")
         try:
             outs, info = capi.rolling_aggregate(ccols, 0, interval, aggs, offset=offset, inclusive=inclusive,
@@ -89,6 +91,7 @@ def run_both(ts, cols_np, interval, aggs, offset=0, inclusive=False, device=Fals
         finally:
             os.environ["BOWGPU_NO_SIMPLE"] = "0"
             os.environ["BOWGPU_FORCE_GENERAL"] = "0"
+            os.environ["BOWGPU_NO_LONG_ONLY"] = "0"
         assert info.new_interval_col == nic
         for k, g, w in zip(_names(aggs), outs, exp):
             exact = info.long_windows == 0 or k not in ORDER_SENSITIVE

@@ -25,14 +25,17 @@ BIG_HOST = psutil.virtual_memory().total > 200e9
 
 def _paths():
     """the three tile kernels over the same call (auto = simple kernel where it applies)"""
-    for label, env in (("auto", {}), ("lean", {"BOWGPU_NO_SIMPLE": "1"}), ("general", {"BOWGPU_FORCE_GENERAL": "1"})):
-        for k in ("BOWGPU_NO_SIMPLE", "BOWGPU_FORCE_GENERAL"):
+    # (the lean / general runs also switch the long-only shortcut off, so windows of thousands of rows take both long paths)
+    for label, env in (("auto", {}), ("lean", {"BOWGPU_NO_SIMPLE": "1", "BOWGPU_NO_LONG_ONLY": "1"}),
+                       ("general", {"BOWGPU_FORCE_GENERAL": "1", "BOWGPU_NO_LONG_ONLY": "1"})):
+        for k in ("BOWGPU_NO_SIMPLE", "BOWGPU_FORCE_GENERAL", "BOWGPU_NO_LONG_ONLY"):
             os.environ[k] = env.get(k, "0")
         try:
             yield label
         finally:
             os.environ["BOWGPU_NO_SIMPLE"] = "0"
             os.environ["BOWGPU_FORCE_GENERAL"] = "0"
+            os.environ["BOWGPU_NO_LONG_ONLY"] = "0"
 
 
 def test_config1_dense_1e8_sum_mean_min_max():
