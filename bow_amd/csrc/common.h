@@ -44,7 +44,7 @@ struct Ctx {
     const char *last_kernel_name = "";  // the tile kernel last_kernel_ms brackets
     // grow-only pool of temporaries reused across calls (word-aligned validity working copies, ...):
     // hipMalloc / hipFree per call cost more than the kernels' fixed overhead
-    static constexpr int kPoolSlots = 40;
+    static constexpr int kPoolSlots = 40;   // 0..15 output validity working copies, kPoolInterp.. Interpolate / fill scratch, last: long windows
     void *pool[kPoolSlots] = {};
     size_t pool_bytes[kPoolSlots] = {};
     void *d_params = nullptr;      // 4 KB device block holding the kernels' descriptor struct
@@ -242,6 +242,7 @@ size_t stats_size();
 // word-aligned whatever the Arrow offset) the nearest valid ROW before the block and after it.  Bounds every
 // previous/next-valid lookup to one block of words + one table read, however long the runs of nulls are.
 constexpr int kNbrBlockBits = 4096;
+constexpr int kPoolInterp = 20;  // context pool slots 20..30: tile counts, their scan, scan sums, one neighbour index per column
 struct NbrIndex {
     const int64_t *prev_before;  // [nblocks] last valid row in any earlier block, -1 if none
     const int64_t *next_after;   // [nblocks] first valid row in any later block, -1 if none

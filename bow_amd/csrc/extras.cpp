@@ -140,7 +140,7 @@ struct InterpJob {
     Plan plan;
     DevCol dts;
     std::vector<DevCol> dcols;
-    DevBuf tile_exact, tile_before, block_sums;
+    void *tile_exact = nullptr, *tile_before = nullptr, *block_sums = nullptr;  // context pool (no hipMalloc / hipFree per call)
     int64_t kq = -1;  // window whose start is -1 (InterpParams::kq)
     int64_t drop = 0; // leading rows that belong to no window (InterpParams::drop)
     int64_t M = 0;    // output rows - input rows
@@ -165,18 +165,18 @@ static int interp_prepare(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t
         if (k < W) job->kq = k;
     }
     const int64_t ntiles = interp_tiles(n);
-    BG_TRY(job->tile_exact.alloc((size_t)ntiles * 4 + 16));
-    BG_TRY(job->tile_before.alloc((size_t)(ntiles + 1) * 8));
-    BG_TRY(job->block_sums.alloc((size_t)((ntiles + 2047) / 2048 + 1) * 8));
+    BG_TRY(ctx_pool(c, kPoolInterp + 0, (size_t)ntiles * 4 + 16, &job->tile_exact));
+    BG_TRY(ctx_pool(c, kPoolInterp + 1, (size_t)(ntiles + 1) * 8, &job->tile_before));
+    BG_TRY(ctx_pool(c, kPoolInterp + 2, (size_t)((ntiles + 2047) / 2048 + 1) * 8, &job->block_sums));
     void *dscr;
     BG_TRY(ctx_scratch(c, 8192, &dscr));
     uint32_t *status = reinterpret_cast<uint32_t *>(dscr);
     int64_t *d_total = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(dscr) + 512);
     BG_HIP(hipMemsetAsync(status, 0, 64, c->stream));
     const int64_t *ts = reinterpret_cast<const int64_t *>(job->dts.values);
-    BG_TRY(launch_interp_count(c, ts, n, pl, job->kq, reinterpret_cast<int32_t *>(job->tile_exact.p), status));
-    BG_TRY(launch_exclusive_scan(c, reinterpret_cast<const int32_t *>(job->tile_exact.p), ntiles, reinterpret_cast<int64_t *>(job->tile_before.p),
-                                 reinterpret_cast<int64_t *>(job->block_sums.p), d_total));
+    BG_TRY(launch_interp_count(c, ts, n, pl, job->kq, reinterpret_cast<int32_t *>(job->tile_exact), status));
+    BG_TRY(launch_exclusive_scan(c, reinterpret_cast<const int32_t *>(job->tile_exact), ntiles, reinterpret_cast<int64_t *>(job->tile_before),
+                                 reinterpret_cast<int64_t *>(job->block_sums), d_total));
     uint32_t hstat[4];
     int64_t total = 0;
     BG_HIP(hipMemcpyAsync(hstat, status, 16, hipMemcpyDeviceToHost, c->stream));
@@ -231,14 +231,13 @@ int bowgpu_rolling_interpolate_fill(const bowgpu_col *cols, int32_t ncols, int32
     }
     job.dcols.resize(ncols);
     std::vector<DevOut> douts(ninterps);
-    std::vector<DevBuf> ixbufs(ninterps);
     InterpParams P;
     memset(&P, 0, sizeof P);
     void *dscr;
     BG_TRY(ctx_scratch(c, 8192, &dscr));
     P.ts = reinterpret_cast<const int64_t *>(job.dts.values);
     P.n = n; P.s0 = job.plan.s0; P.interval = job.plan.interval; P.W = job.plan.W; P.magic = job.plan.magic;
-    P.tile_exact_before = reinterpret_cast<const int64_t *>(job.tile_before.p);
+    P.tile_exact_before = reinterpret_cast<const int64_t *>(job.tile_before);
     P.status = reinterpret_cast<uint32_t *>(dscr);  // (status[1] still holds pass 1's answer about window kq)
     P.kq = job.kq;
     P.drop = job.drop;
@@ -249,7 +248,7 @@ int bowgpu_rolling_interpolate_fill(const bowgpu_col *cols, int32_t ncols, int32
         DevCol &dc = job.dcols[i];
         if (i == ts_col) { dc.values = job.dts.values; dc.length = n; dc.type = BOWGPU_INT64; }
         else BG_TRY(devcol_prepare(c, &cols[i], &dc, true, true));
-        BG_TRY(devout_prepare(c, &outs[i], n_out, &douts[i]));
+        BG_TRY(devout_prepare(c, &outs[i], n_out, &douts[i], i));  // validity working copy from the context pool
         BG_HIP(hipMemsetAsync(douts[i].validity, 0, (size_t)(((n_out + 7) >> 3) + 3) & ~(size_t)3, c->stream));
         InterpCol &ic = P.cols[i];
         ic.values = reinterpret_cast<const uint64_t *>(dc.values);
@@ -260,8 +259,9 @@ int bowgpu_rolling_interpolate_fill(const bowgpu_col *cols, int32_t ncols, int32
         ic.out_values = reinterpret_cast<uint64_t *>(douts[i].values);
         ic.out_valid_words = reinterpret_cast<uint32_t *>(douts[i].validity);
         if (dc.vbits && (ic.kind == BOWGPU_INTERP_LINEAR || ic.kind == BOWGPU_INTERP_STEP_PREVIOUS)) {
-            BG_TRY(ixbufs[i].alloc(nbr_index_bytes(n, dc.vbit0)));
-            BG_TRY(nbr_index_build(c, dc.vbits, dc.vbit0, n, ixbufs[i].p, &ic.nbr));
+            void *ix;
+            BG_TRY(ctx_pool(c, kPoolInterp + 3 + i, nbr_index_bytes(n, dc.vbit0), &ix));
+            BG_TRY(nbr_index_build(c, dc.vbits, dc.vbit0, n, ix, &ic.nbr));
         }
     }
     BG_TRY(launch_interp_tiles(c, P));
@@ -327,7 +327,7 @@ int bowgpu_fill_linear(const bowgpu_col *cols, int32_t ncols, int32_t ref_col, i
     BG_TRY(devcol_prepare(c, &cols[ref_col], &dref, true, true));
     BG_TRY(devcol_prepare(c, &cols[fill_col], &dfill, true, true));
     DevOut dout;
-    BG_TRY(devout_prepare(c, out, n, &dout));
+    BG_TRY(devout_prepare(c, out, n, &dout, 0));
     uint32_t f = 0;
     if (n > 0) BG_TRY(col_order_flags(c, dref, rt, &f));
     const bool ref_empty = !(f & 4);                                  // IsColEmpty: bowassertion.go:84-86
@@ -347,9 +347,9 @@ int bowgpu_fill_linear(const bowgpu_col *cols, int32_t ncols, int32_t ref_col, i
 
 // shared tail of the fill entry points: neighbour index of the fill column, the kernel, validity bytes -> bits, copy-back
 static int fill_finish(Ctx *c, FillParams &P, int64_t n, const DevCol &dfill, DevOut *dout, int type) {
-    DevBuf ixbuf;
-    BG_TRY(ixbuf.alloc(nbr_index_bytes(n, dfill.vbit0)));
-    BG_TRY(nbr_index_build(c, dfill.vbits, dfill.vbit0, n, ixbuf.p, &P.nbr));
+    void *ix;
+    BG_TRY(ctx_pool(c, kPoolInterp + 3, nbr_index_bytes(n, dfill.vbit0), &ix));
+    BG_TRY(nbr_index_build(c, dfill.vbits, dfill.vbit0, n, ix, &P.nbr));
     void *dscr;
     BG_TRY(ctx_scratch(c, 8192, &dscr));
     uint64_t *dcnt = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(dscr) + 1024);
@@ -382,7 +382,7 @@ int bowgpu_fill(const bowgpu_col *col, int32_t method, bowgpu_out *out, int32_t 
     DevCol dfill;
     BG_TRY(devcol_prepare(c, col, &dfill, true, true));
     DevOut dout;
-    BG_TRY(devout_prepare(c, out, n, &dout));
+    BG_TRY(devout_prepare(c, out, n, &dout, 0));
     *unchanged = dfill.null_count == 0 ? 1 : 0;
     FillParams P;
     memset(&P, 0, sizeof P);
