@@ -91,7 +91,8 @@ SYMBOLS = [
     "bowgpu_rolling_aggregate", "bowgpu_window_bounds", "bowgpu_aggregate_whole",
     "bowgpu_rolling_interpolate_count", "bowgpu_rolling_interpolate_fill", "bowgpu_fill_linear", "bowgpu_fill",
     "bowgpu_is_col_sorted", "bowgpu_shard_aggregate", "bowgpu_shard_fix_first", "bowgpu_carry_merge", "bowgpu_gen_dense",
-    "bowgpu_gen_sparse", "bowgpu_stream_read_ceiling", "bowgpu_checksum64",
+    "bowgpu_gen_sparse", "bowgpu_stream_read_ceiling", "bowgpu_checksum64", "bowgpu_parquet_open", "bowgpu_parquet_close",
+    "bowgpu_parquet_info", "bowgpu_parquet_column", "bowgpu_parquet_read_column",
 ]
 
 _lib = None
@@ -448,6 +449,38 @@ def stream_read_ceiling(buf_a, buf_b, bytes_each):
     g = C.c_double(0)
     check(lib().bowgpu_stream_read_ceiling(C.c_void_p(buf_a.ptr), C.c_void_p(buf_b.ptr), C.c_int64(bytes_each), C.byref(g)))
     return g.value
+
+
+class ParquetFile:
+    """Parquet column chunks decoded on the device (bowgpu_parquet_*): the reference's NewBowFromParquet for INT64 / DOUBLE columns"""
+
+    def __init__(self, path):
+        self.h = C.c_void_p()
+        check(lib().bowgpu_parquet_open(path.encode(), C.byref(self.h)))
+        n, k = C.c_int64(0), C.c_int32(0)
+        check(lib().bowgpu_parquet_info(self.h, C.byref(n), C.byref(k)))
+        self.num_rows, self.num_columns = n.value, k.value
+        self.columns = []
+        for i in range(k.value):
+            name = C.create_string_buffer(256)
+            t, opt = C.c_int32(0), C.c_int32(0)
+            check(lib().bowgpu_parquet_column(self.h, i, name, 256, C.byref(t), C.byref(opt)))
+            self.columns.append((name.value.decode(), t.value, bool(opt.value)))
+
+    def read_column(self, i, out_residency=HOST):
+        out = OutColumn(self.num_rows, out_residency)
+        o = out.c()
+        check(lib().bowgpu_parquet_read_column(self.h, i, C.byref(o)))
+        out.absorb(o)
+        return out
+
+    def close(self):
+        if self.h:
+            lib().bowgpu_parquet_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
 
 
 def checksum64(devbuf, n_words):

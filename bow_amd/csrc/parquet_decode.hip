@@ -1,0 +1,228 @@
+// parquet_decode.hip — device side of the Parquet column-chunk loader (reference bowparquet.go:44-153 reads
+// the file with parquet-go into []interface{} rows and SetOrDrop's every value, bowparquet.go:101-105).  Here the compressed
+// pages of one column travel to HBM as they lie in the file and are decoded there, one wavefront per page:
+//
+//   snappy_pages_kernel   raw Snappy block -> the page's uncompressed bytes.  All 64 lanes parse the same element header (uniform
+//                         control flow), then copy cooperatively: a literal is a plain strided copy; a back-reference of
+//                         `len` bytes at distance `off` is periodic with period `off` when it overlaps itself, so
+//                         dst[i] = base[off >= len ? i : i % off] is parallel in every case.
+//   page_scatter_kernel   data page v1 of a flat OPTIONAL / REQUIRED INT64 / DOUBLE column, PLAIN values: definition levels
+//                         (RLE / bit-packed hybrid, bit width 1) -> Arrow validity bits; dense PLAIN values -> row slots
+//                         (null slots = 0, as bow.NewBuffer leaves them: bowbuffer.go:22-40).  Lane l owns rows 32k + l ... of the
+//                         page in words of 32: level word, popcount, wave scan = index of its first value.
+#include "agg_device.h"
+
+namespace bowgpu {
+
+struct PqPage {
+    int64_t src_off;        // payload offset inside the uploaded column chunk bytes
+    int64_t raw_off;        // offset of the page's uncompressed bytes inside the scratch buffer (or the chunk, if stored raw)
+    int64_t row0;           // first output row of the page
+    int32_t comp_size, raw_size;
+    int32_t num_values;     // rows of the page (levels); non-null values = what the levels say
+    int32_t compressed;     // 1: Snappy
+};
+
+namespace {
+
+__device__ __forceinline__ uint32_t rd_varint(const uint8_t *p, int64_t *pos, int64_t end) {
+    uint32_t r = 0;
+    int sh = 0;
+    while (*pos < end) {
+        const uint8_t c = p[(*pos)++];
+        r |= (uint32_t)(c & 0x7f) << sh;
+        if (!(c & 0x80)) break;
+        sh += 7;
+        if (sh > 28) break;
+    }
+    return r;
+}
+
+}  // namespace
+
+// status[0] |= 1: malformed Snappy stream / size mismatch
+__global__ __launch_bounds__(256) void snappy_pages_kernel(const uint8_t *__restrict__ chunk, const PqPage *__restrict__ pages, int64_t npages,
+                                                           uint8_t *raw, uint32_t *status) {
+    const int lane = threadIdx.x & 63;
+    const int64_t pg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pg >= npages) return;
+    const PqPage P = pages[pg];
+    if (!P.compressed) return;
+    const uint8_t *src = chunk + P.src_off;
+    uint8_t *dst = raw + P.raw_off;
+    int64_t ip = 0;
+    const int64_t iend = P.comp_size;
+    const uint32_t ulen = rd_varint(src, &ip, iend);
+    bool bad = ulen != (uint32_t)P.raw_size;
+    int64_t op = 0;
+    while (ip < iend && !bad) {
+        const uint32_t tag = src[ip++];
+        uint32_t len, off = 0;
+        if ((tag & 3) == 0) {  // literal
+            len = (tag >> 2) + 1;
+            if (len > 60) {
+                const int nb = (int)len - 60;
+                if (ip + nb > iend) { bad = true; break; }
+                uint32_t v = 0;
+                for (int k = 0; k < nb; k++) v |= (uint32_t)src[ip + k] << (8 * k);
+                ip += nb;
+                len = v + 1;
+            }
+            if (ip + len > iend || op + len > P.raw_size) { bad = true; break; }
+            for (uint32_t i = lane; i < len; i += 64) dst[op + i] = src[ip + i];
+            ip += len;
+        } else {
+            if ((tag & 3) == 1) {
+                if (ip + 1 > iend) { bad = true; break; }
+                len = 4 + ((tag >> 2) & 7);
+                off = ((tag >> 5) << 8) | src[ip];
+                ip += 1;
+            } else if ((tag & 3) == 2) {
+                if (ip + 2 > iend) { bad = true; break; }
+                len = (tag >> 2) + 1;
+                off = (uint32_t)src[ip] | ((uint32_t)src[ip + 1] << 8);
+                ip += 2;
+            } else {
+                if (ip + 4 > iend) { bad = true; break; }
+                len = (tag >> 2) + 1;
+                off = (uint32_t)src[ip] | ((uint32_t)src[ip + 1] << 8) | ((uint32_t)src[ip + 2] << 16) | ((uint32_t)src[ip + 3] << 24);
+                ip += 4;
+            }
+            if (off == 0 || off > op || op + len > P.raw_size) { bad = true; break; }
+            // earlier stores of this wavefront must be visible to the loads below
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const uint8_t *base = dst + op - off;
+            for (uint32_t i = lane; i < len; i += 64) {
+                const uint32_t j = off >= len ? i : i % off;
+                dst[op + i] = __builtin_nontemporal_load(base + j);
+            }
+        }
+        op += len;
+    }
+    if (!bad && op != P.raw_size) bad = true;
+    if (bad && lane == 0) atomicOr(&status[0], 1u);
+}
+
+// optional: column has definition levels (max level 1); out_valid must be zeroed; valid_count += non-null rows
+__global__ __launch_bounds__(256) void page_scatter_kernel(const uint8_t *__restrict__ raw, const PqPage *__restrict__ pages, int64_t npages,
+                                                           int optional, uint64_t *out_values, uint32_t *out_valid,
+                                                           unsigned long long *valid_count, uint32_t *status) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t pg = (int64_t)blockIdx.x * 4 + wv;
+    if (pg >= npages) return;
+    const PqPage P = pages[pg];
+    const uint8_t *src = raw + P.raw_off;
+    const int nv = P.num_values;
+    int64_t vpos = 0;  // offset of the PLAIN values inside the page
+    const uint8_t *lv = nullptr;
+    int64_t lv_end = 0;
+    if (optional) {
+        const uint32_t lbytes = (uint32_t)src[0] | ((uint32_t)src[1] << 8) | ((uint32_t)src[2] << 16) | ((uint32_t)src[3] << 24);
+        if ((int64_t)lbytes + 4 > P.raw_size) { if (lane == 0) atomicOr(&status[0], 2u); return; }
+        lv = src + 4;
+        lv_end = lbytes;
+        vpos = 4 + (int64_t)lbytes;
+    }
+    const uint8_t *vals = src + vpos;
+    const int64_t val_bytes = P.raw_size - vpos;
+    unsigned long long page_valid = 0;
+
+    // the levels arrive as runs; rows are handled 2048 at a time (64 lanes x one 32-row word)
+    int64_t lpos = 0;        // read position in the level bytes
+    int run_left = 0;        // levels left in the current run
+    int run_kind = 0;        // 0: RLE, 1: bit-packed
+    int run_val = 0;         // RLE value
+    int64_t run_bits = 0;    // bit-packed: BIT position (from lv) of the run's next unread level
+    int64_t vidx_base = 0;   // values consumed so far
+    for (int row = 0; row < nv; row += 2048) {
+        uint32_t word = 0;
+        const int my0 = row + 32 * lane;
+        if (!optional) {
+            const int cnt = nv - my0;
+            word = cnt >= 32 ? 0xFFFFFFFFu : (cnt > 0 ? ((1u << cnt) - 1u) : 0u);
+        } else {
+            // every lane walks the same runs (uniform), keeping the bits of its own word
+            int pos = row;               // level index the walk has reached
+            const int stop = row + 2048 < nv ? row + 2048 : nv;
+            while (pos < stop) {
+                if (run_left == 0) {
+                    if (lpos >= lv_end) break;
+                    const uint32_t h = rd_varint(lv, &lpos, lv_end);
+                    if (h & 1) { run_kind = 1; run_left = (int)(h >> 1) * 8; run_bits = lpos * 8; lpos += (h >> 1); }  // bit width 1: one byte per group of 8
+                    else { run_kind = 0; run_left = (int)(h >> 1); run_val = lpos < lv_end ? (lv[lpos] & 1) : 0; lpos += 1; }
+                    if (run_left == 0) continue;
+                }
+                const int take = run_left < stop - pos ? run_left : stop - pos;
+                // levels [pos, pos + take) come from this run; intersect with my word [my0, my0 + 32)
+                const int a = pos > my0 ? pos : my0, b = (pos + take) < (my0 + 32) ? (pos + take) : (my0 + 32);
+                if (a < b) {
+                    if (run_kind == 0) {
+                        if (run_val) word |= (b - a >= 32 ? 0xFFFFFFFFu : ((1u << (b - a)) - 1u)) << (a - my0);
+                    } else {
+                        for (int r = a; r < b; r++) {  // (at most 32 single-bit reads; LSB first, like Arrow validity)
+                            const int64_t bit = run_bits + (r - pos);
+                            const uint8_t byte = (bit >> 3) < lv_end ? lv[bit >> 3] : 0;
+                            word |= (uint32_t)((byte >> (bit & 7)) & 1u) << (r - my0);
+                        }
+                    }
+                }
+                pos += take;
+                run_left -= take;
+                if (run_kind == 1) run_bits += take;
+            }
+            if (my0 < nv) { const int cnt = nv - my0; if (cnt < 32) word &= (1u << cnt) - 1u; }
+            else word = 0;
+        }
+        // value index of my word's first value: scan of the popcounts
+        const int pc = __popc(word);
+        int inc = pc;
+        for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(inc, o); if (lane >= o) inc += y; }
+        const int total = __shfl(inc, 63);
+        int64_t vi = vidx_base + inc - pc;
+        if (my0 < nv) {
+            const int64_t orow = P.row0 + my0;
+            const int cnt = nv - my0 < 32 ? nv - my0 : 32;
+            for (int k = 0; k < cnt; k++) {
+                uint64_t v = 0;
+                if ((word >> k) & 1u) {
+                    if ((vi + 1) * 8 <= val_bytes) {
+                        // PLAIN: 8 little-endian bytes at any byte offset inside the page: two aligned loads + funnel shift
+                        // (the buffers are padded by 16 bytes, so the second load never leaves them)
+                        const uintptr_t addr = reinterpret_cast<uintptr_t>(vals + vi * 8);
+                        const uint64_t *al = reinterpret_cast<const uint64_t *>(addr & ~(uintptr_t)7);
+                        const int shb = (int)(addr & 7) * 8;
+                        v = shb ? ((al[0] >> shb) | (al[1] << (64 - shb))) : al[0];
+                    } else {
+                        atomicOr(&status[0], 4u);
+                    }
+                    vi++;
+                }
+                out_values[orow + k] = v;
+            }
+            // validity bits of rows [orow, orow + cnt): the page's first row is anywhere inside a word
+            const int sh = (int)(orow & 31);
+            const int64_t w = orow >> 5;
+            if (word) {
+                atomicOr(&out_valid[w], word << sh);
+                if (sh && (word >> (32 - sh))) atomicOr(&out_valid[w + 1], word >> (32 - sh));
+            }
+        }
+        vidx_base += total;
+        page_valid += total;
+    }
+    if (lane == 0 && page_valid) atomicAdd(valid_count, page_valid);
+}
+
+int launch_parquet_decode(Ctx *c, const uint8_t *chunk, const PqPage *pages, int64_t npages, bool any_compressed, uint8_t *raw,
+                          int optional, uint64_t *out_values, uint32_t *out_valid, unsigned long long *valid_count, uint32_t *status) {
+    if (npages <= 0) return 0;
+    const unsigned grid = (unsigned)((npages + 3) / 4);
+    if (any_compressed) hipLaunchKernelGGL(snappy_pages_kernel, dim3(grid), dim3(256), 0, c->stream, chunk, pages, npages, raw, status);
+    hipLaunchKernelGGL(page_scatter_kernel, dim3(grid), dim3(256), 0, c->stream, any_compressed ? raw : chunk, pages, npages, optional,
+                       out_values, out_valid, valid_count, status);
+    BG_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace bowgpu

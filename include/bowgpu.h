@@ -258,6 +258,23 @@ int bowgpu_fill(const bowgpu_col *col, int32_t method, bowgpu_out *out, int32_t 
  * empty => false). */
 int bowgpu_is_col_sorted(const bowgpu_col *col, int32_t *sorted);
 
+/* ---- Parquet column chunk -> device column --------------------------- */
+
+/* Reads INT64 / DOUBLE columns of a Parquet file the way the reference's NewBowFromParquet does (bowparquet.go:44-153), but
+ * decodes on the device: the column's compressed pages are uploaded as they lie in the file and decompressed (Snappy), their
+ * definition levels turned into an Arrow validity bitmap and their PLAIN values scattered to row slots by HIP kernels.
+ * Read: flat schemas, OPTIONAL / REQUIRED columns, UNCOMPRESSED / SNAPPY, PLAIN values, RLE definition levels, data page v1 -
+ * what the reference writes (bowparquet.go:326-338).  Anything else: BOWGPU_ERR_UNSUPPORTED. */
+typedef struct bowgpu_parquet bowgpu_parquet;
+int bowgpu_parquet_open(const char *path, bowgpu_parquet **handle);
+int bowgpu_parquet_close(bowgpu_parquet *handle);
+int bowgpu_parquet_info(const bowgpu_parquet *handle, int64_t *num_rows, int32_t *num_columns);
+/* name (NUL-terminated, truncated to name_cap), type (BOWGPU_INT64 / BOWGPU_FLOAT64 / BOWGPU_BOOLEAN / BOWGPU_STRING / -1) and
+ * whether the column is OPTIONAL (may hold nulls) */
+int bowgpu_parquet_column(const bowgpu_parquet *handle, int32_t i, char *name, int32_t name_cap, int32_t *type, int32_t *optional);
+/* out: num_rows slots (HOST or DEVICE residency); values, validity, null_count and type are filled in */
+int bowgpu_parquet_read_column(bowgpu_parquet *handle, int32_t i, bowgpu_out *out);
+
 /* ---- row-range sharding across GPUs ----------------------------------- */
 
 /* Running state of one reducer over the rows a rank holds of a window that straddles a shard

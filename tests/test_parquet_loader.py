@@ -1,0 +1,117 @@
+"""Parquet column chunk -> device column (bowgpu_parquet_*; reference bowparquet.go:44-153).  The expectation is
+pyarrow's own decode of the same file - an independent implementation.  Files: the reference's benchmark inputs (data files its
+tests hold: benchmarks/bow1-{100,1000,10000}-rows.parquet, written by parquet-go with SNAPPY / PLAIN / 8 KB pages, copied to
+tests/golden/) and files pyarrow writes here with the same options over the shapes that matter (null patterns, many small pages,
+several row groups, REQUIRED columns, compressible data that makes Snappy emit overlapping back-references)."""
+import os
+
+import numpy as np
+import pyarrow as pa
+import pyarrow.parquet as pq
+import pytest
+
+from bow_amd import capi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF_FILES = [os.path.join(HERE, "golden", "bow1-%d-rows.parquet" % n) for n in (100, 1000, 10000)]
+
+
+def expect(table, name):
+    c = table.column(name).combine_chunks()
+    valid = ~np.asarray(c.is_null())
+    return np.asarray(c.fill_null(0)), valid
+
+
+def check_file(path, table=None):
+    table = table if table is not None else pq.read_table(path)
+    f = capi.ParquetFile(path)
+    assert f.num_rows == table.num_rows
+    assert [c[0] for c in f.columns] == table.schema.names
+    n = 0
+    for i, (name, typ, optional) in enumerate(f.columns):
+        if typ not in (capi.INT64, capi.FLOAT64):
+            with pytest.raises(capi.BowGpuError) as e:
+                f.read_column(i)
+            assert e.value.code == -9
+            continue
+        for res in (capi.HOST, capi.DEVICE):
+            out = f.read_column(i, out_residency=res)
+            vals, valid = expect(table, name)
+            assert out.type == typ and out.length == len(vals), name
+            gm = out.valid_mask()
+            assert np.array_equal(gm, valid), (name, np.flatnonzero(gm != valid)[:10])
+            gv = out.host_arrays()[0]
+            assert np.array_equal(gv.view(np.uint64)[gm], vals.view(np.uint64)[valid]), name
+            assert not gv.view(np.uint64)[~gm].any(), name          # null slots hold 0 (bow.NewBuffer)
+            assert out.null_count == int((~valid).sum()), name
+        n += 1
+    f.close()
+    return n
+
+
+def test_footer_of_the_reference_files_without_a_gpu():
+    for path in REF_FILES:
+        f = capi.ParquetFile(path)
+        md = pq.ParquetFile(path)
+        assert f.num_rows == md.metadata.num_rows
+        assert [c[0] for c in f.columns] == md.schema_arrow.names
+        kinds = {"int64": capi.INT64, "double": capi.FLOAT64}
+        for (name, typ, optional), field in zip(f.columns, md.schema_arrow):
+            if str(field.type) in kinds:
+                assert typ == kinds[str(field.type)] and optional
+        f.close()
+    with pytest.raises(capi.BowGpuError):
+        capi.ParquetFile(os.path.join(HERE, "golden", "reference_vectors.json"))  # not a parquet file
+    with pytest.raises(capi.BowGpuError):
+        capi.ParquetFile("/nonexistent/file.parquet")
+
+
+@pytest.mark.gpu
+def test_reference_benchmark_files_decode_like_pyarrow():
+    for path in REF_FILES:
+        assert check_file(path) == 4  # Int64_ref, Int64_no_nils_bow1, Int64_bow1, Float64_bow1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("compression", ["snappy", "none"])
+def test_files_written_here(tmp_path, compression):
+    rng = np.random.default_rng(5)
+    for case, (n, null_frac, page, rg) in enumerate([(1, 0.0, 8192, None), (1000, 0.3, 8192, None), (100_000, 0.3, 8192, None),
+                                                     (100_000, 0.0, 1024, 30_000), (250_000, 0.9, 4096, 100_000), (70_000, 1.0, 8192, None),
+                                                     (1_000_000, 0.05, 65536, 300_000)]):
+        def mask():
+            if null_frac == 0.0:
+                return None
+            m = rng.random(n) < null_frac
+            runs = rng.random(n) < 0.001   # long runs of nulls / of valid rows => RLE runs next to bit-packed ones
+            m[np.repeat(runs[::64], 64)[:n]] = True
+            return m
+        cols = {
+            "ts": pa.array(np.cumsum(rng.integers(1, 20, n)).astype(np.int64)),                        # ascending: compressible
+            "f_rand": pa.array(rng.standard_normal(n), mask=mask()),                                    # incompressible
+            "i_small": pa.array(rng.integers(0, 10, n).astype(np.int64), mask=mask()),                 # many back-references
+            "f_const": pa.array(np.full(n, 2.5), mask=mask()),                                         # overlapping copies
+            "i_req": pa.array(np.arange(n, dtype=np.int64) * 3),
+        }
+        schema = pa.schema([pa.field(k, v.type, nullable=(k != "i_req")) for k, v in cols.items()])
+        table = pa.table(cols, schema=schema)
+        path = str(tmp_path / ("case%d_%s.parquet" % (case, compression)))
+        pq.write_table(table, path, compression=compression, use_dictionary=False, data_page_size=page, data_page_version="1.0",
+                       row_group_size=rg, write_statistics=bool(case % 2))
+        assert check_file(path, table) == 5
+
+
+@pytest.mark.gpu
+def test_declines_what_it_does_not_read(tmp_path):
+    t = pa.table({"a": pa.array(np.arange(1000, dtype=np.int64) % 7)})
+    p1 = str(tmp_path / "dict.parquet")
+    pq.write_table(t, p1, use_dictionary=True, compression="snappy")
+    f = capi.ParquetFile(p1)
+    with pytest.raises(capi.BowGpuError) as e:
+        f.read_column(0)
+    assert e.value.code == -9
+    p2 = str(tmp_path / "zstd.parquet")
+    pq.write_table(t, p2, use_dictionary=False, compression="zstd")
+    with pytest.raises(capi.BowGpuError) as e:
+        capi.ParquetFile(p2).read_column(0)
+    assert e.value.code == -9
