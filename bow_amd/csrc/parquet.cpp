@@ -6,6 +6,11 @@
 // Scope: what the reference writes (bowparquet.go:326-338: SNAPPY, PLAIN, data page v1, RLE definition levels, flat schema
 // of OPTIONAL columns) and what pyarrow writes with the same options; INT64 and DOUBLE columns (the device path's types).
 // Dictionary pages, data page v2, other codecs / encodings and nested schemas are declined with BOWGPU_ERR_UNSUPPORTED.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -95,25 +100,22 @@ struct PqSchemaCol { std::string name; int32_t type = -1, repetition = 0; };
 
 struct ParquetFile {
     std::string path;
-    FILE *f = nullptr;
-    int64_t size = 0, num_rows = 0;
+    int fd = -1;
+    const uint8_t *map = nullptr;       // the whole file, mapped read-only: page headers are parsed in place and the column
+    int64_t size = 0, num_rows = 0;     // chunks go to the device straight from the page cache
     std::vector<PqSchemaCol> cols;      // leaf columns of a flat schema, in order
     std::vector<PqRowGroup> groups;
     bool flat = true;
-    ~ParquetFile() { if (f) fclose(f); }
+    ~ParquetFile() {
+        if (map) munmap(const_cast<uint8_t *>(map), (size_t)size);
+        if (fd >= 0) close(fd);
+    }
 };
 
 namespace {
 
-int read_at(ParquetFile *pf, int64_t off, size_t len, std::vector<uint8_t> *out) {
-    out->resize(len);
-    if (fseeko(pf->f, (off_t)off, SEEK_SET) != 0 || fread(out->data(), 1, len, pf->f) != len)
-        return fail(BOWGPU_ERR_ARG, "parquet: short read at offset %lld of '%s'", (long long)off, pf->path.c_str());
-    return 0;
-}
-
-int parse_footer(ParquetFile *pf, const std::vector<uint8_t> &buf) {
-    TReader r{buf.data(), buf.size()};
+int parse_footer(ParquetFile *pf, const uint8_t *buf, size_t len) {
+    TReader r{buf, len};
     int16_t fid = 0;
     int t;
     while (r.field(&fid, &t)) {
@@ -227,19 +229,23 @@ int bowgpu_parquet_open(const char *path, bowgpu_parquet **handle) {
     *handle = nullptr;
     ParquetFile *pf = new ParquetFile();
     pf->path = path;
-    pf->f = fopen(path, "rb");
-    if (!pf->f) { delete pf; return fail(BOWGPU_ERR_ARG, "parquet: cannot open '%s'", path); }
-    fseeko(pf->f, 0, SEEK_END);
-    pf->size = (int64_t)ftello(pf->f);
-    std::vector<uint8_t> tail;
-    int rc = pf->size >= 12 ? read_at(pf, pf->size - 8, 8, &tail) : fail(BOWGPU_ERR_ARG, "parquet: '%s' is too short", path);
-    if (!rc && memcmp(tail.data() + 4, "PAR1", 4) != 0) rc = fail(BOWGPU_ERR_ARG, "parquet: '%s' lacks the PAR1 magic", path);
+    pf->fd = open(path, O_RDONLY);
+    if (pf->fd < 0) { delete pf; return fail(BOWGPU_ERR_ARG, "parquet: cannot open '%s'", path); }
+    struct stat st;
+    int rc = 0;
+    if (fstat(pf->fd, &st) != 0 || st.st_size < 12) rc = fail(BOWGPU_ERR_ARG, "parquet: '%s' is too short", path);
     if (!rc) {
+        pf->size = (int64_t)st.st_size;
+        void *m = mmap(nullptr, (size_t)pf->size, PROT_READ, MAP_PRIVATE, pf->fd, 0);
+        if (m == MAP_FAILED) rc = fail(BOWGPU_ERR_ARG, "parquet: cannot map '%s'", path);
+        else pf->map = reinterpret_cast<const uint8_t *>(m);
+    }
+    if (!rc && (memcmp(pf->map + pf->size - 4, "PAR1", 4) != 0 || memcmp(pf->map, "PAR1", 4) != 0)) rc = fail(BOWGPU_ERR_ARG, "parquet: '%s' lacks the PAR1 magic", path);
+    if (!rc) {
+        const uint8_t *tail = pf->map + pf->size - 8;
         const uint32_t flen = (uint32_t)tail[0] | ((uint32_t)tail[1] << 8) | ((uint32_t)tail[2] << 16) | ((uint32_t)tail[3] << 24);
         if ((int64_t)flen + 12 > pf->size) rc = fail(BOWGPU_ERR_ARG, "parquet: bad footer length in '%s'", path);
-        std::vector<uint8_t> footer;
-        if (!rc) rc = read_at(pf, pf->size - 8 - flen, flen, &footer);
-        if (!rc) rc = parse_footer(pf, footer);
+        if (!rc) rc = parse_footer(pf, pf->map + pf->size - 8 - flen, flen);
     }
     if (!rc)
         for (const PqRowGroup &g : pf->groups)
@@ -289,31 +295,34 @@ int bowgpu_parquet_read_column(bowgpu_parquet *handle, int32_t i, bowgpu_out *ou
     const int32_t otype = sc.type == 2 ? BOWGPU_INT64 : BOWGPU_FLOAT64;
     if (n == 0) { BG_TRY(devout_finish(c, &dout, 0, otype, 0)); return 0; }
 
-    // ---- page table: walk the page headers of this column in every row group; the bytes of all its chunks are concatenated
-    std::vector<uint8_t> bytes;
+    // ---- page table: walk the page headers of this column in every row group (in place, on the mapped file); the chunks are
+    // laid out back to back in the device buffer
+    struct Span { int64_t file_off, len, dev_off; };
+    std::vector<Span> spans;
     std::vector<PqPage> pages;
-    int64_t row0 = 0, raw_total = 0;
+    int64_t row0 = 0, raw_total = 0, dev_total = 0;
     bool any_comp = false;
     for (const PqRowGroup &g : pf->groups) {
         const PqColumnChunk &cc = g.cols[i];
         if (cc.codec != 0 && cc.codec != 1) return fail(BOWGPU_ERR_UNSUPPORTED, "parquet: codec %d of column '%s' (UNCOMPRESSED and SNAPPY are read)", cc.codec, sc.name.c_str());
         if (cc.dictionary_page_offset > 0) return fail(BOWGPU_ERR_UNSUPPORTED, "parquet: column '%s' is dictionary-encoded (PLAIN is read)", sc.name.c_str());
-        std::vector<uint8_t> chunk;
-        if (cc.data_page_offset < 4 || cc.data_page_offset + cc.total_compressed > pf->size) return fail(BOWGPU_ERR_ARG, "parquet: column chunk of '%s' lies outside the file", sc.name.c_str());
-        BG_TRY(read_at(pf, cc.data_page_offset, (size_t)cc.total_compressed, &chunk));
-        const size_t base = bytes.size();
+        if (cc.data_page_offset < 4 || cc.total_compressed < 0 || cc.data_page_offset + cc.total_compressed > pf->size)
+            return fail(BOWGPU_ERR_ARG, "parquet: column chunk of '%s' lies outside the file", sc.name.c_str());
+        const uint8_t *chunk = pf->map + cc.data_page_offset;
+        const size_t chunk_len = (size_t)cc.total_compressed;
+        const int64_t base = dev_total;
         size_t p = 0;
         int64_t vals = 0;
-        while (p < chunk.size() && vals < cc.num_values) {
+        while (p < chunk_len && vals < cc.num_values) {
             PageHdr h;
-            if (!parse_page_header(chunk.data() + p, chunk.size() - p, &h)) return fail(BOWGPU_ERR_ARG, "parquet: malformed page header in column '%s'", sc.name.c_str());
+            if (!parse_page_header(chunk + p, chunk_len - p, &h)) return fail(BOWGPU_ERR_ARG, "parquet: malformed page header in column '%s'", sc.name.c_str());
             p += h.hdr_len;
-            if (h.comp_size < 0 || p + (size_t)h.comp_size > chunk.size()) return fail(BOWGPU_ERR_ARG, "parquet: page of column '%s' runs past its chunk", sc.name.c_str());
+            if (h.comp_size < 0 || p + (size_t)h.comp_size > chunk_len) return fail(BOWGPU_ERR_ARG, "parquet: page of column '%s' runs past its chunk", sc.name.c_str());
             if (h.type == 0) {
                 if (h.encoding != 0) return fail(BOWGPU_ERR_UNSUPPORTED, "parquet: value encoding %d in column '%s' (PLAIN is read)", h.encoding, sc.name.c_str());
                 if (optional && h.def_encoding != 3) return fail(BOWGPU_ERR_UNSUPPORTED, "parquet: definition-level encoding %d in column '%s' (RLE is read)", h.def_encoding, sc.name.c_str());
                 PqPage pg;
-                pg.src_off = (int64_t)(base + p);
+                pg.src_off = base + (int64_t)p;
                 pg.comp_size = h.comp_size;
                 pg.raw_size = h.raw_size;
                 pg.num_values = h.num_values;
@@ -329,7 +338,8 @@ int bowgpu_parquet_read_column(bowgpu_parquet *handle, int32_t i, bowgpu_out *ou
             p += (size_t)h.comp_size;
         }
         if (vals != cc.num_values || vals != g.num_rows) return fail(BOWGPU_ERR_ARG, "parquet: column '%s' holds %lld values for %lld rows", sc.name.c_str(), (long long)vals, (long long)g.num_rows);
-        bytes.insert(bytes.end(), chunk.begin(), chunk.end());
+        spans.push_back({cc.data_page_offset, (int64_t)chunk_len, base});
+        dev_total += (int64_t)chunk_len;
         row0 += g.num_rows;
     }
     if (row0 != n) return fail(BOWGPU_ERR_ARG, "parquet: row groups hold %lld rows, the footer says %lld", (long long)row0, (long long)n);
@@ -338,10 +348,11 @@ int bowgpu_parquet_read_column(bowgpu_parquet *handle, int32_t i, bowgpu_out *ou
 
     // ---- upload + decode
     void *d_bytes, *d_pages, *d_raw = nullptr;
-    BG_TRY(ctx_pool(c, kPoolInterp + 0, bytes.size() + 32, &d_bytes));
+    BG_TRY(ctx_pool(c, kPoolInterp + 0, (size_t)dev_total + 32, &d_bytes));
     BG_TRY(ctx_pool(c, kPoolInterp + 1, pages.size() * sizeof(PqPage) + 32, &d_pages));
     if (any_comp) BG_TRY(ctx_pool(c, kPoolInterp + 2, (size_t)raw_total + 32, &d_raw));
-    BG_HIP(hipMemcpyAsync(d_bytes, bytes.data(), bytes.size(), hipMemcpyHostToDevice, c->stream));
+    for (const Span &sp : spans)
+        BG_HIP(hipMemcpyAsync(reinterpret_cast<char *>(d_bytes) + sp.dev_off, pf->map + sp.file_off, (size_t)sp.len, hipMemcpyHostToDevice, c->stream));
     BG_HIP(hipMemcpyAsync(d_pages, pages.data(), pages.size() * sizeof(PqPage), hipMemcpyHostToDevice, c->stream));
     void *dscr;
     BG_TRY(ctx_scratch(c, 8192, &dscr));
