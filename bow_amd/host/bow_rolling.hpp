@@ -303,6 +303,32 @@ inline std::pair<BowPtr, Error> Bow::FillLinear(int refColIndex, int toFillColIn
     return {out, Error()};
 }
 
+// NewBowFromParquet: bowparquet.go:44-153, with the columns decoded on the device (bowgpu_parquet_*).  This mirror holds
+// Int64 / Float64 columns; the reference's Boolean / String columns are outside the device path and are skipped.
+inline std::pair<BowPtr, Error> NewBowFromParquet(const std::string &path) {
+    bowgpu_parquet *h = nullptr;
+    int rc = bowgpu_parquet_open(path.c_str(), &h);
+    if (rc) return {nullptr, Wrap("bow.NewBowFromParquet", detail::AbiError(rc))};
+    int64_t rows = 0;
+    int32_t ncols = 0;
+    bowgpu_parquet_info(h, &rows, &ncols);
+    std::vector<Series> series;
+    for (int32_t i = 0; i < ncols && !rc; i++) {
+        char name[256];
+        int32_t type = -1, optional = 0;
+        bowgpu_parquet_column(h, i, name, (int32_t)sizeof name, &type, &optional);
+        if (type != BOWGPU_INT64 && type != BOWGPU_FLOAT64) continue;
+        detail::OutStore st;
+        bowgpu_out o = st.Make(rows);
+        rc = bowgpu_parquet_read_column(h, i, &o);
+        if (!rc) series.push_back(st.ToSeries(name, o));
+    }
+    const Error err = rc ? Wrap("bow.NewBowFromParquet", detail::AbiError(rc)) : Error();
+    bowgpu_parquet_close(h);
+    if (rc) return {nullptr, err};
+    return NewBow(std::move(series));
+}
+
 inline std::pair<BowPtr, Error> Bow::fill(int method, const std::vector<int> &colIndices) const {
     std::vector<bool> selected(NumCols(), colIndices.empty());  // selectCols: bowfill.go:268-288
     for (int ci : colIndices) {

@@ -363,6 +363,36 @@ static void TestFillLinear() {
     { auto [res, e] = fresh(Int64)->FillNext({7}); CHECK((bool)e); CHECK(e.msg == "selectCols: colIndex '7' out of range"); }
 }
 
+// ---- bowparquet.go:44 NewBowFromParquet on the reference's own benchmark input (benchmarks/bow1-100-rows.parquet, a data file of its
+// tests, copied to tests/golden/), then the calls its benchmarks make on it (bowfill_test.go:550-585, bowassertion_test.go:93-111)
+static void TestParquet(const std::string &dir) {
+    TEST("NewBowFromParquet/bow1-100-rows");
+    auto [b, e] = NewBowFromParquet(dir + "/bow1-100-rows.parquet");
+    CHECK(!e);
+    if (e) { printf("   %s\n", e.msg.c_str()); return; }
+    CHECK(b->NumRows() == 100);
+    CHECK(b->NumCols() == 4);  // Int64_ref, Int64_no_nils_bow1, Int64_bow1, Float64_bow1 (Boolean / String columns are skipped)
+    CHECK(b->ColumnName(0) == "Int64_ref" && b->ColumnName(3) == "Float64_bow1");
+    CHECK(b->ColumnType(0) == Int64 && b->ColumnType(3) == Float64);
+    CHECK(b->IsColSorted(0));
+    CHECK(!b->IsColSorted(1));
+    int nulls = 0;
+    for (int r = 0; r < 100; r++) nulls += !b->GetValue(3, r).has_value();
+    CHECK(nulls > 0 && nulls < 100);
+    { auto [f, e2] = b->FillLinear(0, 3); CHECK(!e2); }
+    { auto [f, e2] = b->FillPrevious({3}); CHECK(!e2);
+      bool ok = true, seen = false;
+      for (int r = 0; r < 100; r++) { if (b->GetValue(3, r).has_value()) seen = true; if (seen && !f->GetValue(3, r).has_value()) ok = false; }
+      CHECK(ok); }
+    auto [r, e3] = rl::IntervalRolling(b, "Int64_ref", 100, {});
+    CHECK(!e3);
+    auto [a, e4] = r->Aggregate({ag::WindowStart("Int64_ref"), ag::ArithmeticMean("Float64_bow1")})->Bow();
+    CHECK(!e4);
+    CHECK(a->NumRows() > 0);
+    TEST("NewBowFromParquet/missing file");
+    { auto [x, e5] = NewBowFromParquet(dir + "/nope.parquet"); CHECK((bool)e5); }
+}
+
 // ---- rolling/aggregation/XXXbenchmarks_test.go:125-138 shape, small: IntervalRolling + Aggregate(WindowStart, ArithmeticMean)
 static void TestBenchShape() {
     TEST("bench shape 1e5 rows");
@@ -385,7 +415,7 @@ static void TestBenchShape() {
     CHECK(ok);
 }
 
-int main() {
+int main(int argc, char **argv) {
     int ndev = 0;
     if (bowgpu_device_count(&ndev) != 0 || ndev == 0) {
         printf("no GPU: %s\n", bowgpu_last_error());
@@ -401,6 +431,7 @@ int main() {
     TestWhole();
     TestInterpolate();
     TestFillLinear();
+    TestParquet(argc > 1 ? argv[1] : "tests/golden");
     TestBenchShape();
     printf("%d checks, %d failures\n", g_checks, g_fail);
     return g_fail ? 1 : 0;

@@ -13,7 +13,7 @@ def test_cpp_mirror_replays_reference_tests():
     exe = os.path.join(ROOT, "tests", "cpp", "test_rolling")
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "bow_amd", "host")])
-    p = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    p = subprocess.run([exe, os.path.join(ROOT, "tests", "golden")], capture_output=True, text=True, timeout=600)
     print(p.stdout[-4000:])
     print(p.stderr[-2000:])
     assert p.returncode == 0, p.stdout[-4000:]
