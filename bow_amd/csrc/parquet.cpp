@@ -318,6 +318,8 @@ int bowgpu_parquet_read_column(bowgpu_parquet *handle, int32_t i, bowgpu_out *ou
             if (!parse_page_header(chunk + p, chunk_len - p, &h)) return fail(BOWGPU_ERR_ARG, "parquet: malformed page header in column '%s'", sc.name.c_str());
             p += h.hdr_len;
             if (h.comp_size < 0 || p + (size_t)h.comp_size > chunk_len) return fail(BOWGPU_ERR_ARG, "parquet: page of column '%s' runs past its chunk", sc.name.c_str());
+            if (h.raw_size < 0 || h.num_values < 0 || (int64_t)h.raw_size > (int64_t)16 * h.num_values + (1 << 20))
+                return fail(BOWGPU_ERR_ARG, "parquet: implausible page header in column '%s'", sc.name.c_str());
             if (h.type == 0) {
                 if (h.encoding != 0) return fail(BOWGPU_ERR_UNSUPPORTED, "parquet: value encoding %d in column '%s' (PLAIN is read)", h.encoding, sc.name.c_str());
                 if (optional && h.def_encoding != 3) return fail(BOWGPU_ERR_UNSUPPORTED, "parquet: definition-level encoding %d in column '%s' (RLE is read)", h.def_encoding, sc.name.c_str());

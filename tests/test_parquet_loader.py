@@ -115,3 +115,32 @@ def test_declines_what_it_does_not_read(tmp_path):
     with pytest.raises(capi.BowGpuError) as e:
         capi.ParquetFile(p2).read_column(0)
     assert e.value.code == -9
+
+
+@pytest.mark.gpu
+def test_corrupted_files_fail_cleanly(tmp_path):
+    # flipped bytes anywhere in the file (page payloads, page headers, footer): every call returns - with an error or with
+    # some decode of the damaged data - and the library keeps working afterwards
+    rng = np.random.default_rng(9)
+    good = open(REF_FILES[1], "rb").read()
+    for k in range(40):
+        b = bytearray(good)
+        for _ in range(int(rng.integers(1, 6))):
+            pos = int(rng.integers(4, len(b) - 4))
+            b[pos] = int(rng.integers(0, 256))
+        if rng.random() < 0.2:
+            b = b[:int(rng.integers(12, len(b)))] + b[-8:]  # truncated in the middle, tail kept
+        path = str(tmp_path / ("bad%d.parquet" % k))
+        open(path, "wb").write(bytes(b))
+        try:
+            f = capi.ParquetFile(path)
+        except capi.BowGpuError:
+            continue
+        for i, (name, typ, opt) in enumerate(f.columns):
+            if typ in (capi.INT64, capi.FLOAT64) and f.num_rows < 10_000_000:
+                try:
+                    f.read_column(i)
+                except capi.BowGpuError:
+                    pass
+        f.close()
+    assert check_file(REF_FILES[1]) == 4
