@@ -144,3 +144,29 @@ def test_corrupted_files_fail_cleanly(tmp_path):
                     pass
         f.close()
     assert check_file(REF_FILES[1]) == 4
+
+
+@pytest.mark.gpu
+def test_config0_parquet_to_rolling_mean_without_leaving_the_device():
+    """BASELINE.json configs[0]: benchmarks/bow1-*-rows.parquet -> IntervalRolling + ArithmeticMean.  Columns are decoded into HBM
+    and aggregated there; the expectation is the oracle over pyarrow's decode of the same file."""
+    from oracle import pyoracle as orc
+    from test_gpu_aggregate import compare
+    path = REF_FILES[2]
+    f = capi.ParquetFile(path)
+    names = [c[0] for c in f.columns]
+    ts = f.read_column(names.index("Int64_ref"), out_residency=capi.DEVICE)
+    val = f.read_column(names.index("Float64_bow1"), out_residency=capi.DEVICE)
+    n = f.num_rows
+    assert ts.null_count == 0
+    cols = [capi.Column(ts.values, None, capi.INT64, 0, n, 0), capi.Column(val.values, val.validity, capi.FLOAT64, 0, n, val.null_count)]
+    aggs = [("WindowStart", 0), ("ArithmeticMean", 1), ("Count", 1), ("Min", 1), ("Max", 1)]
+    table = pq.read_table(path)
+    tv, _ = expect(table, "Int64_ref")
+    vv, vm = expect(table, "Float64_bow1")
+    ocols = [orc.Column(tv, None, orc.INT64), orc.Column(vv, np.packbits(vm, bitorder="little"), orc.FLOAT64)]
+    for interval, offset in [(10, 0), (100, 7), (1000, 0)]:
+        got, info = capi.rolling_aggregate(cols, 0, interval, aggs, offset=offset, out_residency=capi.DEVICE)
+        want, _ = orc.aggregate(ocols, 0, interval, aggs, offset=offset)
+        for (k, _), g, w in zip(aggs, got, want):
+            compare("config0 %s I=%d" % (k, interval), g, w)
