@@ -73,7 +73,15 @@ class Interp(C.Structure):
 class CarryState(C.Structure):
     _fields_ = [("sum", C.c_double), ("vmin", C.c_double), ("vmax", C.c_double), ("nn_min", C.c_double),
                 ("nn_max", C.c_double), ("first_bits", C.c_uint64), ("last_bits", C.c_uint64),
-                ("count", C.c_int64), ("nrows", C.c_int64), ("has_value", C.c_int32), ("has_nn", C.c_int32)]
+                ("count", C.c_int64), ("nrows", C.c_int64),
+                ("pt", C.c_double), ("pv", C.c_double), ("first_pt", C.c_double), ("first_pv", C.c_double),
+                ("integ_step", C.c_double), ("integ_trap", C.c_double),
+                ("has_value", C.c_int32), ("has_nn", C.c_int32), ("has_point", C.c_int32), ("has_pair", C.c_int32)]
+
+
+class NextRow(C.Structure):
+    """bowgpu_next_row: the first row of a shard, as its left neighbour needs it for inclusive windows"""
+    _fields_ = [("present", C.c_int32), ("_pad", C.c_int32), ("ts", C.c_int64), ("bits", C.c_uint64 * 16), ("valid", C.c_int32 * 16)]
 
 
 class ShardCarry(C.Structure):
@@ -90,7 +98,7 @@ SYMBOLS = [
     "bowgpu_timer_elapsed_ms", "bowgpu_timer_destroy", "bowgpu_enforce_interval_and_offset", "bowgpu_plan_windows",
     "bowgpu_rolling_aggregate", "bowgpu_window_bounds", "bowgpu_aggregate_whole",
     "bowgpu_rolling_interpolate_count", "bowgpu_rolling_interpolate_fill", "bowgpu_fill_linear", "bowgpu_fill",
-    "bowgpu_is_col_sorted", "bowgpu_shard_aggregate", "bowgpu_shard_fix_first", "bowgpu_carry_merge", "bowgpu_gen_dense",
+    "bowgpu_is_col_sorted", "bowgpu_shard_aggregate", "bowgpu_shard_first_row", "bowgpu_shard_fix_first", "bowgpu_carry_merge", "bowgpu_gen_dense",
     "bowgpu_gen_sparse", "bowgpu_stream_read_ceiling", "bowgpu_checksum64", "bowgpu_parquet_open", "bowgpu_parquet_close",
     "bowgpu_parquet_info", "bowgpu_parquet_column", "bowgpu_parquet_read_column",
 ]

@@ -1001,11 +1001,8 @@ int bowgpu_rolling_aggregate(const bowgpu_col *cols, int32_t ncols, int32_t ts_c
 
 static int shard_check(const bowgpu_col *cols, int32_t ncols, const bowgpu_agg *aggs, int32_t naggs, bowgpu_out *outs,
                        const bowgpu_options *o) {
-    if (o && o->inclusive) return fail(BOWGPU_ERR_UNSUPPORTED, "sharded aggregate: inclusive windows are not supported yet");
+    (void)o;
     for (int i = 0; i < naggs; i++) {
-        const int k = aggs[i].kind;
-        if (k >= BOWGPU_AGG_INTEGRAL_STEP && k <= BOWGPU_AGG_WAVG_LINEAR)
-            return fail(BOWGPU_ERR_UNSUPPORTED, "sharded aggregate: time-weighted reducers are not supported yet");
         if (outs[i].residency != BOWGPU_DEVICE) return fail(BOWGPU_ERR_UNSUPPORTED, "sharded aggregate: outputs must be device-resident");
     }
     for (int i = 0; i < ncols; i++)
@@ -1034,7 +1031,7 @@ static int shard_plan(Ctx *c, const bowgpu_col *ts, int64_t interval, int64_t ra
 int bowgpu_shard_aggregate(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval,
                            const bowgpu_options *opts, int64_t global_s0, int32_t holds_global_row0,
                            int64_t lead, const bowgpu_agg *aggs, int32_t naggs, bowgpu_out *outs,
-                           bowgpu_shard_carry *carry) {
+                           bowgpu_shard_carry *carry, const bowgpu_next_row *next_row, int32_t finish_last) {
     if (!cols || ncols <= 0 || !carry || !outs) return fail(BOWGPU_ERR_ARG, "null argument");
     if (ts_col < 0 || ts_col >= ncols) return fail(BOWGPU_ERR_BAD_COL, "no interval column with index %d", ts_col);
     bowgpu_options o = {0, 0, 0};
@@ -1057,13 +1054,22 @@ int bowgpu_shard_aggregate(const bowgpu_col *cols, int32_t ncols, int32_t ts_col
     AggJob job;
     if (lead < 0 || (wf < 0 && lead != 0) || (wf >= 0 && lead > wf)) return fail(BOWGPU_ERR_ARG, "bad lead_empty_windows %lld", (long long)lead);
     const int64_t Wtot = plan.W + lead;
-    BG_TRY(job_build(c, cols, ncols, ts_col, plan, 0, aggs, naggs, outs, wf < 0 ? 0 : wf - lead, Wtot, holds_global_row0 != 0, &job));
+    BG_TRY(job_build(c, cols, ncols, ts_col, plan, inclusive, aggs, naggs, outs, wf < 0 ? 0 : wf - lead, Wtot, holds_global_row0 != 0, &job));
     BG_TRY(job_run(c, &job, aggs, naggs, nullptr, nullptr, false, &plan));
     if (lead > 0) BG_TRY(launch_fill_empty(c, job.P, 0, lead));
     if (plan.W > 0) {
-        // running state of the last window over this shard's rows
-        bowgpu_carry_state *dst = reinterpret_cast<bowgpu_carry_state *>(reinterpret_cast<char *>(job.P.status) + 4096);
-        BG_TRY(launch_range_state(c, job.P, 0, (uint64_t)wl, nullptr, dst));
+        // running state of the last window over this shard's rows; when the shard owns that window and the windows are
+        // inclusive, its outputs are rewritten with the next shard's first row folded in where it is the inclusive row
+        void *pool;
+        BG_TRY(ctx_pool(c, kPoolShard, 16384, &pool));
+        bowgpu_carry_state *dst = reinterpret_cast<bowgpu_carry_state *>(pool);
+        bowgpu_next_row *dnext = nullptr;
+        const bool finish = inclusive && finish_last && next_row && next_row->present;
+        if (finish) {
+            dnext = reinterpret_cast<bowgpu_next_row *>(reinterpret_cast<char *>(pool) + 8192);
+            BG_HIP(hipMemcpyAsync(dnext, next_row, sizeof *next_row, hipMemcpyHostToDevice, c->stream));
+        }
+        BG_TRY(launch_range_state(c, job.P, finish ? 2 : 0, (uint64_t)wl, nullptr, dst, dnext));
         BG_HIP(hipMemcpyAsync(carry->last, dst, sizeof(bowgpu_carry_state) * naggs, hipMemcpyDeviceToHost, c->stream));
         BG_HIP(hipStreamSynchronize(c->stream));
     }
@@ -1074,7 +1080,7 @@ int bowgpu_shard_aggregate(const bowgpu_col *cols, int32_t ncols, int32_t ts_col
 int bowgpu_shard_fix_first(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval,
                            const bowgpu_options *opts, int64_t global_s0, int64_t lead, const bowgpu_agg *aggs,
                            int32_t naggs, bowgpu_out *outs, int64_t first_window_id, const bowgpu_carry_state *seeds,
-                           bowgpu_carry_state *merged_out) {
+                           bowgpu_carry_state *merged_out, const bowgpu_next_row *next_row) {
     if (!cols || ncols <= 0 || !seeds || !outs) return fail(BOWGPU_ERR_ARG, "null argument");
     bowgpu_options o = {0, 0, 0};
     if (opts) o = *opts;
@@ -1090,15 +1096,21 @@ int bowgpu_shard_fix_first(const bowgpu_col *cols, int32_t ncols, int32_t ts_col
     AggJob job;
     if (lead < 0 || lead > wf) return fail(BOWGPU_ERR_ARG, "bad lead_empty_windows %lld", (long long)lead);
     const int64_t Wtot = plan.W + lead;
-    BG_TRY(job_build(c, cols, ncols, ts_col, plan, 0, aggs, naggs, outs, wf - lead, Wtot, false, &job));
+    BG_TRY(job_build(c, cols, ncols, ts_col, plan, inclusive, aggs, naggs, outs, wf - lead, Wtot, false, &job));
     // the caller's validity bytes are the truth for this second phase: bring them into the word-aligned working copy
     for (int i = 0; i < naggs; i++)
         BG_HIP(hipMemcpyAsync(job.douts[i].validity, outs[i].validity, (size_t)((Wtot + 7) >> 3), hipMemcpyDeviceToDevice, c->stream));
-    char *scr = reinterpret_cast<char *>(job.P.status);
-    bowgpu_carry_state *dseed = reinterpret_cast<bowgpu_carry_state *>(scr + 4096);
-    bowgpu_carry_state *dout = reinterpret_cast<bowgpu_carry_state *>(scr + 4096 + 2048);
+    void *pool;
+    BG_TRY(ctx_pool(c, kPoolShard, 16384, &pool));
+    bowgpu_carry_state *dseed = reinterpret_cast<bowgpu_carry_state *>(pool);
+    bowgpu_carry_state *dout = reinterpret_cast<bowgpu_carry_state *>(reinterpret_cast<char *>(pool) + 4096);
+    bowgpu_next_row *dnext = nullptr;
+    if (inclusive && next_row && next_row->present) {
+        dnext = reinterpret_cast<bowgpu_next_row *>(reinterpret_cast<char *>(pool) + 8192);
+        BG_HIP(hipMemcpyAsync(dnext, next_row, sizeof *next_row, hipMemcpyHostToDevice, c->stream));
+    }
     BG_HIP(hipMemcpyAsync(dseed, seeds, sizeof(bowgpu_carry_state) * naggs, hipMemcpyHostToDevice, c->stream));
-    BG_TRY(launch_range_state(c, job.P, 1, (uint64_t)wf, dseed, dout));
+    BG_TRY(launch_range_state(c, job.P, 1, (uint64_t)wf, dseed, dout, dnext));
     if (merged_out) {
         BG_HIP(hipMemcpyAsync(merged_out, dout, sizeof(bowgpu_carry_state) * naggs, hipMemcpyDeviceToHost, c->stream));
         BG_HIP(hipStreamSynchronize(c->stream));
@@ -1129,7 +1141,55 @@ int bowgpu_carry_merge(const bowgpu_carry_state *L, const bowgpu_carry_state *R,
             m.last_bits = R->last_bits;
         }
     }
+    // the both-valid points of the time-weighted reducers (device stats_merge)
+    m.pt = L->pt; m.pv = L->pv; m.first_pt = L->first_pt; m.first_pv = L->first_pv;
+    m.integ_step = L->integ_step; m.integ_trap = L->integ_trap; m.has_point = L->has_point; m.has_pair = L->has_pair;
+    if (R->has_point) {
+        if (L->has_point) {
+            m.integ_trap = L->integ_trap + (L->pv + R->first_pv) / 2 * (R->first_pt - L->pt) + R->integ_trap;
+            m.integ_step = L->integ_step + L->pv * (R->first_pt - L->pt) + R->integ_step;
+            m.has_pair = 1;
+        } else {
+            m.first_pt = R->first_pt; m.first_pv = R->first_pv; m.integ_trap = R->integ_trap; m.integ_step = R->integ_step;
+            m.has_pair = R->has_pair; m.has_point = 1;
+        }
+        m.pt = R->pt; m.pv = R->pv;
+    }
     *out = m;
+    return 0;
+}
+
+int bowgpu_shard_first_row(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, const bowgpu_agg *aggs, int32_t naggs,
+                           bowgpu_next_row *out) {
+    if (!cols || !aggs || !out || ncols <= 0) return fail(BOWGPU_ERR_ARG, "null argument");
+    if (ts_col < 0 || ts_col >= ncols) return fail(BOWGPU_ERR_BAD_COL, "no interval column with index %d", ts_col);
+    if (naggs > BOWGPU_CARRY_MAX_AGGS) return fail(BOWGPU_ERR_UNSUPPORTED, "sharded aggregate: too many aggregations");
+    memset(out, 0, sizeof *out);
+    if (cols[ts_col].length == 0) return 0;
+    Ctx *c;
+    BG_TRY(ctx_get(&c));
+    auto fetch = [&](const bowgpu_col &col, uint64_t *bits, int32_t *valid) -> int {
+        if (col.residency != BOWGPU_DEVICE) return fail(BOWGPU_ERR_UNSUPPORTED, "sharded aggregate: columns must be device-resident");
+        BG_HIP(hipMemcpyAsync(bits, reinterpret_cast<const char *>(col.values) + 8 * col.offset, 8, hipMemcpyDeviceToHost, c->stream));
+        *valid = 1;
+        if (col.validity && col.null_count != 0) {
+            uint8_t byte = 0;
+            BG_HIP(hipMemcpyAsync(&byte, col.validity + (col.offset >> 3), 1, hipMemcpyDeviceToHost, c->stream));
+            BG_HIP(hipStreamSynchronize(c->stream));
+            *valid = (byte >> (col.offset & 7)) & 1;
+        }
+        return 0;
+    };
+    uint64_t tsb = 0;
+    int32_t tv = 0;
+    BG_TRY(fetch(cols[ts_col], &tsb, &tv));
+    for (int i = 0; i < naggs; i++) {
+        if (aggs[i].col < 0 || aggs[i].col >= ncols) return fail(BOWGPU_ERR_BAD_COL, "aggregation %d: no column with index %d", i, aggs[i].col);
+        BG_TRY(fetch(cols[aggs[i].col], &out->bits[i], &out->valid[i]));
+    }
+    BG_HIP(hipStreamSynchronize(c->stream));
+    out->ts = (int64_t)tsb;
+    out->present = 1;
     return 0;
 }
 

@@ -223,7 +223,7 @@ int launch_popcount(Ctx *c, const uint32_t *words, int64_t bit0, int64_t nbits, 
 
 // shard.hip
 int launch_range_state(Ctx *c, const AggParams &p, int mode, uint64_t wid, const bowgpu_carry_state *d_seeds,
-                       bowgpu_carry_state *d_states_out);
+                       bowgpu_carry_state *d_states_out, const bowgpu_next_row *d_next = nullptr);
 
 int launch_fill_empty(Ctx *c, const AggParams &p, int64_t slot0, int64_t slot1);
 
@@ -242,6 +242,7 @@ size_t stats_size();
 // word-aligned whatever the Arrow offset) the nearest valid ROW before the block and after it.  Bounds every
 // previous/next-valid lookup to one block of words + one table read, however long the runs of nulls are.
 constexpr int kNbrBlockBits = 4096;
+constexpr int kPoolShard = 19;   // shard stitch: seed / merged states and the next shard's first row
 constexpr int kPoolInterp = 20;  // context pool slots 20..30: tile counts, their scan, scan sums, one neighbour index per column
 struct NbrIndex {
     const int64_t *prev_before;  // [nblocks] last valid row in any earlier block, -1 if none

@@ -5,8 +5,9 @@ ranges, so every rank reduces its own rows with no data-path collective.  The on
 bookkeeping, as bytes through torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box,
 "gloo" in the CPU tests):
 
-  1. all_gather of (first_ts, last_ts, nrows) so every rank knows all window ranges   (24 B/rank); the first window
-     start s0 is host arithmetic on the first timestamp of the rank holding global row 0 (first_window_start)
+  1. all_gather of (first_ts, last_ts, nrows) + each shard's first row (232 B/rank) so every rank knows all window
+     ranges and, for inclusive windows, the row its last window may still need from the right; the first window start s0
+     is host arithmetic on the first timestamp of the rank holding global row 0 (first_window_start)
   2. all_gather of each rank's carry: the running state of its LAST window            (~1.5 KB/rank)
 
 A window that straddles a shard boundary is finished by the right rank: it re-walks its own rows
@@ -116,15 +117,34 @@ class ShardSession:
         self.plan = None
 
     def local_info(self):
+        """(first_ts, last_ts, nrows) + this shard's first row (for the inclusive windows of the rank to the left), as bytes"""
         f, l, n = self.provider.first_last_nrows()
-        return np.array([f, l, n], dtype=np.int64).tobytes()
+        rec = np.array([f, l, n], dtype=np.int64).tobytes()
+        if hasattr(self.provider, "first_row_record"):
+            rec += self.provider.first_row_record()
+        return rec
+
+    def _next_row(self, all_info):
+        """first-row record of the next non-empty rank to the right (None: there is none / the provider has no such records)"""
+        q = self.plan.right_nonempty(self.rank)
+        if q < 0 or len(all_info[q]) <= 24:
+            return None
+        return all_info[q][24:]
 
     def phase1(self, s0, all_info):
-        arr = [np.frombuffer(b, dtype=np.int64) for b in all_info]
+        arr = [np.frombuffer(b[:24], dtype=np.int64) for b in all_info]
         self.s0 = s0
         self.plan = ShardPlan(s0, self.interval, [int(a[0]) for a in arr], [int(a[1]) for a in arr], [int(a[2]) for a in arr])
         self.lead = self.plan.lead_empty(self.rank)
-        return self.provider.shard_aggregate(s0, self.rank == 0, self.lead)  # carry bytes
+        self.next_row = self._next_row(all_info)
+        plan, rank = self.plan, self.rank
+        # the shard folds the next shard's first row into its last window itself when it owns that window and the window is
+        # not also its first one shared with ranks to the left (then phase 2 does it, after the seeds)
+        owns_last = plan.wf[rank] >= 0 and not plan.drops_last(rank)
+        seeded_single = plan.wf[rank] == plan.wl[rank] and bool(plan.seed_ranks(rank))
+        if self.next_row is not None:
+            return self.provider.shard_aggregate(s0, rank == 0, self.lead, self.next_row, owns_last and not seeded_single)
+        return self.provider.shard_aggregate(s0, rank == 0, self.lead)  # carry bytes
 
     def phase2(self, all_carries):
         from . import capi
@@ -136,7 +156,10 @@ class ShardSession:
             state = all_carries[seeds[0]][off:off + sz]
             for q in seeds[1:]:
                 state = self.provider.merge(state, all_carries[q][off:off + sz])
-            self.provider.fix_first(self.s0, self.lead, plan.wf[rank], state)
+            if self.next_row is not None and plan.wf[rank] == plan.wl[rank] and not plan.drops_last(rank):
+                self.provider.fix_first(self.s0, self.lead, plan.wf[rank], state, self.next_row)
+            else:
+                self.provider.fix_first(self.s0, self.lead, plan.wf[rank], state)
         W_local = 0 if plan.wf[rank] < 0 else plan.wl[rank] - plan.wf[rank] + 1 + self.lead
         owned = W_local - (1 if plan.drops_last(rank) else 0)
         first_slot = -1 if plan.wf[rank] < 0 else plan.wf[rank] - self.lead
@@ -158,7 +181,7 @@ def sharded_aggregate(provider, dist, torch, rank, world, interval, device="cpu"
     all_info = _gather_bytes(dist, torch, mine, world, device) if world > 1 else [mine]
     s0 = 0
     for b in all_info:
-        f, _, n = np.frombuffer(b, dtype=np.int64)
+        f, _, n = np.frombuffer(b[:24], dtype=np.int64)
         if n > 0:
             s0 = first_window_start(int(f), interval, getattr(provider, "offset", 0))
             break
@@ -213,19 +236,28 @@ class GpuProvider:
             oarr[i] = o.c()
         return oarr
 
-    def shard_aggregate(self, s0, holds_row0, lead):
+    def first_row_record(self):
+        capi = self.capi
+        rec = capi.NextRow()
+        capi.check(capi.lib().bowgpu_shard_first_row(self._carr, len(self.cols), self.ts_col, self._aarr, len(self.aggs), C.byref(rec)))
+        return bytes(rec)
+
+    def shard_aggregate(self, s0, holds_row0, lead, next_row=None, finish_last=False):
         capi = self.capi
         oarr = self._ensure_outs(s0, lead)
         carry = capi.ShardCarry()
+        nr = capi.NextRow.from_buffer_copy(next_row) if next_row is not None else None
         capi.check(capi.lib().bowgpu_shard_aggregate(self._carr, len(self.cols), self.ts_col, C.c_int64(self.interval),
                                                      C.byref(self._opts), C.c_int64(s0), int(holds_row0), C.c_int64(lead),
-                                                     self._aarr, len(self.aggs), oarr, C.byref(carry)))
+                                                     self._aarr, len(self.aggs), oarr, C.byref(carry),
+                                                     C.byref(nr) if nr is not None else None, int(bool(finish_last))))
         for i, o in enumerate(self.outs):
             o.absorb(oarr[i])
         return bytes(carry)
 
-    def fix_first(self, s0, lead, first_window_id, seed_bytes):
+    def fix_first(self, s0, lead, first_window_id, seed_bytes, next_row=None):
         capi = self.capi
+        nr = capi.NextRow.from_buffer_copy(next_row) if next_row is not None else None
         oarr = self._ensure_outs(s0, lead)
         for i, o in enumerate(self.outs):
             oarr[i].length = o.slots
@@ -233,7 +265,8 @@ class GpuProvider:
         merged = (capi.CarryState * capi.CARRY_MAX_AGGS)()
         capi.check(capi.lib().bowgpu_shard_fix_first(self._carr, len(self.cols), self.ts_col, C.c_int64(self.interval),
                                                      C.byref(self._opts), C.c_int64(s0), C.c_int64(lead), self._aarr,
-                                                     len(self.aggs), oarr, C.c_int64(first_window_id), seeds, merged))
+                                                     len(self.aggs), oarr, C.c_int64(first_window_id), seeds, merged,
+                                                     C.byref(nr) if nr is not None else None))
         for i, o in enumerate(self.outs):
             o.absorb(oarr[i])
         return bytes(merged)

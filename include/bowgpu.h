@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define BOWGPU_ABI_VERSION 1
+#define BOWGPU_ABI_VERSION 2
 
 /* bow.Type (reference bowtypes.go:17-32) */
 enum {
@@ -289,9 +289,25 @@ typedef struct bowgpu_carry_state {
     uint64_t first_bits, last_bits;   /* First / Last raw 64-bit payloads */
     int64_t count;                    /* valid values */
     int64_t nrows;                    /* rows (w.Bow.NumRows() contribution) */
+    /* time-weighted reducers (integral.go:14-31, :46-62): last and first both-valid point, running sums */
+    double pt, pv, first_pt, first_pv;
+    double integ_step, integ_trap;
     int32_t has_value;
     int32_t has_nn;
+    int32_t has_point;
+    int32_t has_pair;
 } bowgpu_carry_state;
+
+/* The first row of the next non-empty shard to the right, per aggregator: what an INCLUSIVE window that ends exactly where
+ * this shard's rows end needs from its successor (rolling.go:201-209).  Fixed size: it rides in the same all_gather as
+ * (first_ts, last_ts, nrows). */
+typedef struct bowgpu_next_row {
+    int32_t present;                  /* 0: there is no row to the right */
+    int32_t _pad;
+    int64_t ts;
+    uint64_t bits[16];                /* value of each aggregator's input column at that row */
+    int32_t valid[16];
+} bowgpu_next_row;
 
 #define BOWGPU_CARRY_MAX_AGGS 16
 typedef struct bowgpu_shard_carry {
@@ -308,8 +324,10 @@ typedef struct bowgpu_shard_carry {
  * (device-resident; outs device-resident).  global_s0 comes from bowgpu_plan_windows on the rank
  * that holds global row 0.  Reduces every window that has a row in the shard - output slot k is
  * global window first_window_id + k - treating the shard's first row as a window start, and
- * exports in *carry the running state of its last window.  Supported: exclusive windows and the
- * reducers WindowStart/Sum/ArithmeticMean/Min/Max/Count/First/Last/NumRows.
+ * exports in *carry the running state of its last window.  All reducers; when some reducer needs inclusive windows
+ * (IntegralTrapezoid, WeightedAverageLinear) pass next_row = the first row of the next non-empty shard to the right
+ * (bowgpu_shard_first_row there), and finish_last = 1 when this shard owns its last window and that window is not
+ * also its first one shared with ranks to the left (then bowgpu_shard_fix_first folds the row in).
  * lead_empty_windows: number of EMPTY windows between the left neighbour's last window and this
  * shard's first one that this rank also outputs (known after the ranks exchanged first/last ts):
  * output slot k is then global window first_window_id - lead_empty_windows + k. */
@@ -317,7 +335,12 @@ int bowgpu_shard_aggregate(const bowgpu_col *cols, int32_t ncols, int32_t ts_col
                            const bowgpu_options *opts, int64_t global_s0, int32_t holds_global_row0,
                            int64_t lead_empty_windows,
                            const bowgpu_agg *aggs, int32_t naggs, bowgpu_out *outs,
-                           bowgpu_shard_carry *carry);
+                           bowgpu_shard_carry *carry,
+                           const bowgpu_next_row *next_row /* nullable */, int32_t finish_last);
+
+/* This shard's first row in the layout bowgpu_shard_aggregate / _fix_first of the LEFT neighbour expect. */
+int bowgpu_shard_first_row(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, const bowgpu_agg *aggs, int32_t naggs,
+                           bowgpu_next_row *out);
 
 /* Phase 2, after the ranks exchanged their carries.  seeds[i] is the state of this shard's first
  * window accumulated over the rows the LEFT ranks hold (one rank: its carry as is; several:
@@ -328,7 +351,8 @@ int bowgpu_shard_fix_first(const bowgpu_col *cols, int32_t ncols, int32_t ts_col
                            int64_t lead_empty_windows,
                            const bowgpu_agg *aggs, int32_t naggs, bowgpu_out *outs,
                            int64_t first_window_id, const bowgpu_carry_state *seeds,
-                           bowgpu_carry_state *merged_out /* nullable: state after this shard's rows */);
+                           bowgpu_carry_state *merged_out /* nullable: state after this shard's rows */,
+                           const bowgpu_next_row *next_row /* nullable: used when the window is also the shard's last */);
 
 /* left (earlier rows) then right: the state of the concatenation.  Pure bookkeeping on two
  * records (no column data); Sum is left.sum + right.sum, i.e. NOT the row-order association -

@@ -171,9 +171,13 @@ def test_fuzz_interpolate_and_fills(seed):
 def test_fuzz_sharded(seed):
     """random row-range splits (empty shards, one-row shards, shards smaller than a window) through the real protocol of
     bow_amd/sharded.py on simulated ranks; the stitched result must equal the oracle on the whole frame"""
-    from test_gpu_sharded import run_sharded, AGGS, ORDER
+    from test_gpu_sharded import run_sharded, AGGS as PLAIN_AGGS, TW_AGGS, ORDER as PLAIN_ORDER
     rng = np.random.default_rng(3000 + seed)
     for case in range(12):
+        # plain reducers on exclusive windows, or the time-weighted ones (which make every window inclusive)
+        tw = bool(rng.random() < 0.5)
+        AGGS = TW_AGGS if tw else PLAIN_AGGS
+        ORDER = {"IntegralStep", "WeightedAverageStep", "IntegralTrapezoid", "WeightedAverageLinear", "ArithmeticMean"} if tw else PLAIN_ORDER
         n = int(rng.integers(2, 6000))
         ts = rand_ts(rng, n)
         if ts[0] < 0 and rng.random() < 0.5:
@@ -190,13 +194,14 @@ def test_fuzz_sharded(seed):
         label = "seed=%d case=%d n=%d I=%d off=%d bounds=%s" % (seed, case, n, interval, offset, bounds)
         bm = np.packbits(valid, bitorder="little")
         try:
-            exp, _ = orc.aggregate([orc.Column(ts, None, orc.INT64), orc.Column(vals, bm, orc.FLOAT64)], 0, interval, AGGS, offset=offset)
+            exp, _ = orc.aggregate([orc.Column(ts, None, orc.INT64), orc.Column(vals, bm, orc.FLOAT64)], 0, interval, AGGS, offset=offset,
+                                   inclusive=tw)
         except orc.OracleError:
             continue
         s0, _W = orc.plan_windows(orc.Column(ts, None, orc.INT64), interval, offset)
         if s0 > ts[0]:
             continue  # rows below s0: not a sharded-mode input
-        res, plan = run_sharded(ts, vals, valid, bounds, interval, offset=offset)
+        res, plan = run_sharded(ts, vals, valid, bounds, interval, offset=offset, aggs=AGGS)
         for (k, _), (gv, gm, typ), w in zip(AGGS, res, exp):
             assert len(gv) == w.length, (label, k, len(gv), w.length)
             wm = w.valid_mask()
@@ -204,6 +209,6 @@ def test_fuzz_sharded(seed):
             wv = w.values[:w.length].view(np.uint64)
             if k in ORDER:
                 g, e = gv.view(np.float64)[gm], wv.view(np.float64)[wm]
-                assert np.allclose(g, e, rtol=1e-11, atol=0), (label, k)
+                assert np.allclose(g, e, rtol=1e-10, atol=1e-9 if tw else 0), (label, k)
             else:
                 assert np.array_equal(gv[gm], wv[wm]), (label, k)

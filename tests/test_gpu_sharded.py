@@ -14,8 +14,13 @@ AGGS = [("WindowStart", 0), ("Sum", 1), ("ArithmeticMean", 1), ("Min", 1), ("Max
 ORDER = {"Sum", "ArithmeticMean"}
 
 
-def run_sharded(ts, vals, valid, bounds, interval, offset=0):
+TW_AGGS = [("WindowStart", 0), ("IntegralStep", 1), ("WeightedAverageStep", 1), ("IntegralTrapezoid", 1), ("WeightedAverageLinear", 1),
+           ("ArithmeticMean", 1), ("Count", 1), ("Last", 1), ("NumRows", 1)]
+
+
+def run_sharded(ts, vals, valid, bounds, interval, offset=0, aggs=None):
     """bounds: row boundaries [0, b1, ..., n] of the simulated ranks"""
+    AGGS = aggs if aggs is not None else globals()["AGGS"]
     world = len(bounds) - 1
     provs, sess = [], []
     for r in range(world):
@@ -30,7 +35,7 @@ def run_sharded(ts, vals, valid, bounds, interval, offset=0):
     # s0 as sharded_aggregate derives it: from the first timestamp of the first rank that holds rows
     s0 = 0
     for b in info:
-        f, _, nr = np.frombuffer(b, dtype=np.int64)
+        f, _, nr = np.frombuffer(b[:24], dtype=np.int64)
         if nr > 0:
             s0 = sharded.first_window_start(int(f), interval, offset)
             break
@@ -104,3 +109,43 @@ def test_sharded_gaps_between_shards():
         assert len(gv) == w.length and np.array_equal(gm, wm), k
         assert np.array_equal(gv[gm], w.values[:w.length].view(np.uint64)[wm]), k
         assert not gv[~gm].any(), k
+
+
+@pytest.mark.parametrize("mode", ["dense", "irregular", "gappy"])
+def test_sharded_time_weighted_and_inclusive_windows(mode):
+    """IntegralStep / WeightedAverageStep carry their last point across the boundary; IntegralTrapezoid / WeightedAverageLinear make
+    every window inclusive, so a window that ends exactly where a shard ends takes the NEXT shard's first row (shipped with the plan
+    exchange), and a straddling one takes it from wherever its successor starts"""
+    rng = np.random.default_rng(91)
+    n = 30_000
+    if mode == "dense":
+        ts = np.arange(n, dtype=np.int64)
+    elif mode == "irregular":
+        ts = np.cumsum(rng.integers(1, 20, n)).astype(np.int64)
+    else:
+        step = rng.integers(1, 5, n)
+        step[rng.random(n) < 0.003] = rng.integers(100, 3000)
+        ts = np.cumsum(step).astype(np.int64)
+    vals = np.round(rng.standard_normal(n) * 100, 3)
+    valid = rng.random(n) >= 0.2
+    cases = [(10, [0, 10_000, 20_000, n]),             # dense: shard ends ARE window ends => next shard's first row is the inclusive row
+             (7, [0, 9_999, 20_001, 20_002, n]),       # straddling windows, a one-row shard
+             (64, [0, 13, 40, 41, 15_000, n]),         # three and more ranks per window
+             (1000, [0, 5_000, 5_000, 25_000, n])]     # an empty shard in the middle
+    for interval, bounds in cases:
+        res, plan = run_sharded(ts, vals, valid, bounds, interval, aggs=TW_AGGS)
+        bm = np.packbits(valid, bitorder="little")
+        exp, _ = orc.aggregate([orc.Column(ts, None, orc.INT64), orc.Column(vals, bm, orc.FLOAT64)], 0, interval, TW_AGGS, inclusive=True)
+        multi = any(len(plan.seed_ranks(r)) > 1 for r in range(plan.world))
+        for (k, _), (gv, gm, typ), w in zip(TW_AGGS, res, exp):
+            assert len(gv) == w.length, (mode, interval, k, len(gv), w.length)
+            wm = w.valid_mask()
+            assert np.array_equal(gm, wm), (mode, interval, k, np.flatnonzero(gm != wm)[:8])
+            wv = w.values[:w.length].view(np.uint64)
+            if k in ("WindowStart", "Count", "Last", "NumRows"):
+                assert np.array_equal(gv[gm], wv[wm]), (mode, interval, k)
+            elif multi or interval >= 129:
+                assert np.allclose(gv.view(np.float64)[gm], wv.view(np.float64)[wm], rtol=1e-10, atol=1e-9), (mode, interval, k)
+            else:
+                bad = np.flatnonzero(gv[gm] != wv[wm])
+                assert bad.size == 0, (mode, interval, k, bad[:5], gv.view(np.float64)[gm][bad[:3]], wv.view(np.float64)[wm][bad[:3]])
