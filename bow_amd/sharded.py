@@ -239,6 +239,8 @@ class GpuProvider:
     def first_row_record(self):
         capi = self.capi
         rec = capi.NextRow()
+        if not any(a[0] in ("IntegralTrapezoid", "WeightedAverageLinear") for a in self.aggs):
+            return bytes(rec)  # exclusive windows: nobody needs this shard's first row (present = 0, no device access)
         capi.check(capi.lib().bowgpu_shard_first_row(self._carr, len(self.cols), self.ts_col, self._aarr, len(self.aggs), C.byref(rec)))
         return bytes(rec)
 
