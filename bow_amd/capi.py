@@ -70,6 +70,17 @@ class Interp(C.Structure):
                 ("prev_t", C.c_double), ("prev_v", C.c_double), ("prev_v_i64", C.c_int64)]
 
 
+class InterpEdge(C.Structure):
+    _fields_ = [("has_left", C.c_int32), ("_pad", C.c_int32), ("left_last_ts", C.c_int64), ("next_valid", C.c_int32 * 8),
+                ("next_t", C.c_double * 8), ("next_v", C.c_double * 8)]
+
+
+class InterpPoints(C.Structure):
+    _fields_ = [("nrows", C.c_int64), ("first_ts", C.c_int64), ("last_ts", C.c_int64), ("first_valid", C.c_int32 * 8),
+                ("last_valid", C.c_int32 * 8), ("first_t", C.c_double * 8), ("first_v", C.c_double * 8), ("last_t", C.c_double * 8),
+                ("last_v", C.c_double * 8), ("last_v_i64", C.c_int64 * 8)]
+
+
 class CarryState(C.Structure):
     _fields_ = [("sum", C.c_double), ("vmin", C.c_double), ("vmax", C.c_double), ("nn_min", C.c_double),
                 ("nn_max", C.c_double), ("first_bits", C.c_uint64), ("last_bits", C.c_uint64),
@@ -97,7 +108,8 @@ SYMBOLS = [
     "bowgpu_memcpy_d2h", "bowgpu_memset", "bowgpu_timer_create", "bowgpu_timer_start", "bowgpu_timer_stop",
     "bowgpu_timer_elapsed_ms", "bowgpu_timer_destroy", "bowgpu_enforce_interval_and_offset", "bowgpu_plan_windows",
     "bowgpu_rolling_aggregate", "bowgpu_window_bounds", "bowgpu_aggregate_whole",
-    "bowgpu_rolling_interpolate_count", "bowgpu_rolling_interpolate_fill", "bowgpu_fill_linear", "bowgpu_fill",
+    "bowgpu_rolling_interpolate_count", "bowgpu_rolling_interpolate_fill", "bowgpu_shard_interp_points",
+    "bowgpu_shard_interpolate_count", "bowgpu_shard_interpolate_fill", "bowgpu_fill_linear", "bowgpu_fill",
     "bowgpu_is_col_sorted", "bowgpu_shard_aggregate", "bowgpu_shard_first_row", "bowgpu_shard_fix_first", "bowgpu_carry_merge", "bowgpu_gen_dense",
     "bowgpu_gen_sparse", "bowgpu_stream_read_ceiling", "bowgpu_checksum64", "bowgpu_parquet_open", "bowgpu_parquet_close",
     "bowgpu_parquet_info", "bowgpu_parquet_column", "bowgpu_parquet_read_column",
@@ -402,6 +414,47 @@ def rolling_interpolate(cols, ts_col, interval, interps, offset=0, inclusive=Fal
         oarr[i] = o.c()
     check(lib().bowgpu_rolling_interpolate_fill(carr, len(cols), ts_col, C.c_int64(interval), C.byref(opts),
                                                 iarr, len(interps), oarr))
+    for i, o in enumerate(outs):
+        o.absorb(oarr[i])
+    return outs
+
+
+def shard_interp_points(cols, ts_col):
+    """this shard's first / last valid point per column (bytes of bowgpu_interp_points: travels through an all_gather)"""
+    pts = InterpPoints()
+    check(lib().bowgpu_shard_interp_points(_cols(cols), len(cols), ts_col, C.byref(pts)))
+    return bytes(pts)
+
+
+def shard_interpolate(cols, ts_col, interval, interps, global_s0, rank, all_points, offset=0, out_residency=HOST):
+    """Rolling.Interpolate of one row-range shard.  all_points: every rank's shard_interp_points bytes, in rank order.  The
+    shards' outputs concatenated in rank order equal the unsharded result."""
+    pts = [InterpPoints.from_buffer_copy(b) for b in all_points]
+    edge = InterpEdge()
+    left = [q for q in range(rank) if pts[q].nrows > 0]
+    if left:
+        edge.has_left, edge.left_last_ts = 1, pts[left[-1]].last_ts
+    ips = [dict(ip) for ip in interps]
+    for i in range(len(cols)):
+        for q in reversed(left):              # nearest valid point on the left: the reference's PrevRow mechanism carries it
+            if pts[q].last_valid[i]:
+                ips[i]["prev"] = (pts[q].last_t[i], True, pts[q].last_v[i], True, pts[q].last_v_i64[i])
+                break
+        for q in range(rank + 1, len(pts)):   # nearest valid point on the right
+            if pts[q].nrows > 0 and pts[q].first_valid[i]:
+                edge.next_valid[i], edge.next_t[i], edge.next_v[i] = 1, pts[q].first_t[i], pts[q].first_v[i]
+                break
+    opts = Options(offset, 0, 0)
+    carr, iarr = _cols(cols), _interps(ips)
+    n_out = C.c_int64(0)
+    check(lib().bowgpu_shard_interpolate_count(carr, len(cols), ts_col, C.c_int64(interval), C.byref(opts), C.c_int64(global_s0),
+                                               iarr, len(ips), C.byref(edge), C.byref(n_out)))
+    outs = [OutColumn(n_out.value, out_residency) for _ in ips]
+    oarr = (Out * max(len(ips), 1))()
+    for i, o in enumerate(outs):
+        oarr[i] = o.c()
+    check(lib().bowgpu_shard_interpolate_fill(carr, len(cols), ts_col, C.c_int64(interval), C.byref(opts), C.c_int64(global_s0),
+                                              iarr, len(ips), C.byref(edge), oarr))
     for i, o in enumerate(outs):
         o.absorb(oarr[i])
     return outs

@@ -263,6 +263,8 @@ struct InterpCol {
     uint64_t *out_values;
     uint32_t *out_valid_words; // output validity bitmap (zeroed by the host before the launch)
     NbrIndex nbr;              // of this column's bitmap (Linear / StepPrevious look their neighbours up through it)
+    int32_t next_valid, _pad2; // sharded Interpolate: the nearest valid point on the shards to the right (Linear)
+    double next_t, next_v;
 };
 struct InterpParams {
     const int64_t *ts;
@@ -274,13 +276,16 @@ struct InterpParams {
     int64_t drop;                      // leading rows that belong to no window (interp_quirk_kernel), normally 0
     uint32_t m32, sh1_32, sh2_32;      // 32-bit magic of the interval (fast32 only)
     int32_t fast32;                    // interp_fast32(plan, kq): 32-bit window ids, integer exact-head test
+    int32_t has_left, _pad3;           // sharded Interpolate: rows exist on shards to the left, the last of them at left_ts;
+    int64_t left_ts, wbase;            // the windows up to theirs (wbase = its id + 1) are not this shard's to account for
     int32_t ncols, ts_col;
     InterpCol cols[kMaxCols];
 };
 int64_t interp_tiles(int64_t n);
 bool interp_fast32(const Plan &plan, int64_t kq);
 void interp_magic32(int64_t interval, uint32_t *m, uint32_t *sh1, uint32_t *sh2);
-int launch_interp_count(Ctx *c, const int64_t *ts, int64_t n, const Plan &plan, int64_t kq, int32_t *tile_exact, uint32_t *status);
+int launch_interp_count(Ctx *c, const int64_t *ts, int64_t n, const Plan &plan, int64_t kq, int has_left, int64_t left_ts,
+                        int32_t *tile_exact, uint32_t *status);
 int launch_interp_tiles(Ctx *c, const InterpParams &p);
 enum { kFillLinear = -1 };  // FillParams::method; >= 0: BOWGPU_FILL_PREVIOUS / NEXT / MEAN
 struct FillParams {
@@ -294,6 +299,7 @@ struct FillParams {
     NbrIndex nbr;                // of the fill column's bitmap
 };
 // builds the index of (vbits, vbit0, n) into `work` (nbr_index_bytes(n, vbit0) bytes of device memory)
+int launch_first_last_valid(Ctx *c, const uint32_t *vbits, int64_t vbit0, int64_t n, int64_t *d_rows);
 size_t nbr_index_bytes(int64_t n, int64_t vbit0);
 int nbr_index_build(Ctx *c, const uint32_t *vbits, int64_t vbit0, int64_t n, void *work, NbrIndex *out);
 int fill_run(Ctx *c, const FillParams &p);

@@ -144,12 +144,32 @@ struct InterpJob {
     int64_t kq = -1;  // window whose start is -1 (InterpParams::kq)
     int64_t drop = 0; // leading rows that belong to no window (InterpParams::drop)
     int64_t M = 0;    // output rows - input rows
+    int has_left = 0; // sharded Interpolate: rows exist to the left, the last of them at left_ts, in window wbase - 1
+    int64_t left_ts = 0, wbase = 0;
 };
 
 // pass 1 of interpolate.hip: exact heads per tile, their exclusive scan, M = synthetic rows
+// shard: global_s0 + edge of a row-range shard (nullptr: the whole frame)
 static int interp_prepare(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval,
-                          const bowgpu_options *o, InterpJob *job) {
+                          const bowgpu_options *o, InterpJob *job, const int64_t *global_s0 = nullptr, const bowgpu_interp_edge *edge = nullptr) {
     BG_TRY(plan_make(c, &cols[ts_col], interval, o->offset, &job->plan));
+    if (global_s0) {
+        // a shard: windows are counted from the frame's s0; the shard accounts for the windows after its left neighbours' last one
+        Plan &pl = job->plan;
+        pl.s0 = *global_s0;
+        if (cols[ts_col].length > 0) {
+            if (pl.first_ts < pl.s0) return fail(BOWGPU_ERR_UNSUPPORTED, "sharded interpolate: rows below the first window start are outside the sharded path");
+            const int64_t wl = (int64_t)(((uint64_t)pl.last_ts - (uint64_t)pl.s0) / (uint64_t)interval);
+            job->has_left = edge && edge->has_left ? 1 : 0;
+            if (job->has_left) {
+                if (edge->left_last_ts < pl.s0 || edge->left_last_ts > pl.first_ts) return fail(BOWGPU_ERR_ARG, "sharded interpolate: the left neighbour's last timestamp does not precede this shard");
+                job->left_ts = edge->left_last_ts;
+                job->wbase = (int64_t)(((uint64_t)edge->left_last_ts - (uint64_t)pl.s0) / (uint64_t)interval) + 1;
+            }
+            pl.W = wl + 1 - job->wbase;  // windows this shard accounts for
+            if (pl.s0 <= -1) return fail(BOWGPU_ERR_UNSUPPORTED, "sharded interpolate: negative window starts are outside the sharded path");
+        }
+    }
     const int64_t n = cols[ts_col].length, W = job->plan.W;
     for (int i = 0; i < ncols; i++)
         if (cols[i].length != n) return fail(BOWGPU_ERR_ARG, "column %d has a different length", i);
@@ -157,7 +177,7 @@ static int interp_prepare(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t
     if (n == 0) return 0;
     BG_TRY(ts_contract(c, &cols[ts_col]));
     BG_TRY(ts_device(c, &cols[ts_col], &job->dts));
-    if (W == 0) { job->M = -n; return 0; }  // no window at all (every row lies below s0): the concatenation of zero window bows is empty
+    if (W == 0 && !global_s0) { job->M = -n; return 0; }  // no window at all (every row lies below s0): the concatenation of zero window bows is empty
     const Plan &pl = job->plan;
     job->kq = -1;
     if (pl.s0 <= -1 && (uint64_t)(-1 - pl.s0) % (uint64_t)pl.interval == 0) {
@@ -174,7 +194,7 @@ static int interp_prepare(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t
     int64_t *d_total = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(dscr) + 512);
     BG_HIP(hipMemsetAsync(status, 0, 64, c->stream));
     const int64_t *ts = reinterpret_cast<const int64_t *>(job->dts.values);
-    BG_TRY(launch_interp_count(c, ts, n, pl, job->kq, reinterpret_cast<int32_t *>(job->tile_exact), status));
+    BG_TRY(launch_interp_count(c, ts, n, pl, job->kq, job->has_left, job->left_ts, reinterpret_cast<int32_t *>(job->tile_exact), status));
     BG_TRY(launch_exclusive_scan(c, reinterpret_cast<const int32_t *>(job->tile_exact), ntiles, reinterpret_cast<int64_t *>(job->tile_before),
                                  reinterpret_cast<int64_t *>(job->block_sums), d_total));
     uint32_t hstat[4];
@@ -188,8 +208,9 @@ static int interp_prepare(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t
     return 0;
 }
 
-int bowgpu_rolling_interpolate_count(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval,
-                                     const bowgpu_options *opts, const bowgpu_interp *interps, int32_t ninterps, int64_t *n_out) {
+static int interp_count_impl(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval, const bowgpu_options *opts,
+                             const bowgpu_interp *interps, int32_t ninterps, int64_t *n_out, const int64_t *global_s0,
+                             const bowgpu_interp_edge *edge) {
     if (!cols || ncols <= 0 || !n_out) return fail(BOWGPU_ERR_ARG, "null argument");
     if (ts_col < 0 || ts_col >= ncols) return fail(BOWGPU_ERR_BAD_COL, "no interval column with index %d", ts_col);
     bowgpu_options o = {0, 0, 0};
@@ -201,13 +222,14 @@ int bowgpu_rolling_interpolate_count(const bowgpu_col *cols, int32_t ncols, int3
     Ctx *c;
     BG_TRY(ctx_get(&c));
     InterpJob job;
-    BG_TRY(interp_prepare(c, cols, ncols, ts_col, interval, &o, &job));
+    BG_TRY(interp_prepare(c, cols, ncols, ts_col, interval, &o, &job, global_s0, edge));
     *n_out = cols[ts_col].length + job.M;
     return 0;
 }
 
-int bowgpu_rolling_interpolate_fill(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval,
-                                    const bowgpu_options *opts, const bowgpu_interp *interps, int32_t ninterps, bowgpu_out *outs) {
+static int interp_fill_impl(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval, const bowgpu_options *opts,
+                            const bowgpu_interp *interps, int32_t ninterps, bowgpu_out *outs, const int64_t *global_s0,
+                            const bowgpu_interp_edge *edge) {
     if (!cols || ncols <= 0 || !outs) return fail(BOWGPU_ERR_ARG, "null argument");
     if (ts_col < 0 || ts_col >= ncols) return fail(BOWGPU_ERR_BAD_COL, "no interval column with index %d", ts_col);
     bowgpu_options o = {0, 0, 0};
@@ -223,7 +245,7 @@ int bowgpu_rolling_interpolate_fill(const bowgpu_col *cols, int32_t ncols, int32
     Ctx *c;
     BG_TRY(ctx_get(&c));
     InterpJob job;
-    BG_TRY(interp_prepare(c, cols, ncols, ts_col, interval, &o, &job));
+    BG_TRY(interp_prepare(c, cols, ncols, ts_col, interval, &o, &job, global_s0, edge));
     const int64_t n_out = n + job.M;
     if (n_out == 0) {
         for (int i = 0; i < ninterps; i++) { outs[i].length = 0; outs[i].null_count = 0; outs[i].type = cols[i].type; }
@@ -241,6 +263,7 @@ int bowgpu_rolling_interpolate_fill(const bowgpu_col *cols, int32_t ncols, int32
     P.status = reinterpret_cast<uint32_t *>(dscr);  // (status[1] still holds pass 1's answer about window kq)
     P.kq = job.kq;
     P.drop = job.drop;
+    P.has_left = job.has_left; P.left_ts = job.left_ts; P.wbase = job.wbase;
     P.fast32 = interp_fast32(job.plan, job.kq) ? 1 : 0;
     if (P.fast32) interp_magic32(job.plan.interval, &P.m32, &P.sh1_32, &P.sh2_32);
     P.ncols = ncols; P.ts_col = ts_col;
@@ -258,6 +281,7 @@ int bowgpu_rolling_interpolate_fill(const bowgpu_col *cols, int32_t ncols, int32
         ic.prev_t = interps[i].prev_t; ic.prev_v = interps[i].prev_v; ic.prev_v_i64 = interps[i].prev_v_i64;
         ic.out_values = reinterpret_cast<uint64_t *>(douts[i].values);
         ic.out_valid_words = reinterpret_cast<uint32_t *>(douts[i].validity);
+        if (edge && edge->next_valid[i]) { ic.next_valid = 1; ic.next_t = edge->next_t[i]; ic.next_v = edge->next_v[i]; }
         if (dc.vbits && (ic.kind == BOWGPU_INTERP_LINEAR || ic.kind == BOWGPU_INTERP_STEP_PREVIOUS)) {
             void *ix;
             BG_TRY(ctx_pool(c, kPoolInterp + 3 + i, nbr_index_bytes(n, dc.vbit0), &ix));
@@ -274,6 +298,79 @@ int bowgpu_rolling_interpolate_fill(const bowgpu_col *cols, int32_t ncols, int32
     BG_HIP(hipStreamSynchronize(c->stream));
     for (int i = 0; i < ninterps; i++) BG_TRY(devout_finish(c, &douts[i], n_out, cols[i].type, n_out - (int64_t)hcnt[i]));
     BG_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int bowgpu_rolling_interpolate_count(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval,
+                                     const bowgpu_options *opts, const bowgpu_interp *interps, int32_t ninterps, int64_t *n_out) {
+    return interp_count_impl(cols, ncols, ts_col, interval, opts, interps, ninterps, n_out, nullptr, nullptr);
+}
+
+int bowgpu_rolling_interpolate_fill(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval,
+                                    const bowgpu_options *opts, const bowgpu_interp *interps, int32_t ninterps, bowgpu_out *outs) {
+    return interp_fill_impl(cols, ncols, ts_col, interval, opts, interps, ninterps, outs, nullptr, nullptr);
+}
+
+// ---- row-range sharded Interpolate: a shard + what lies beyond its two ends
+int bowgpu_shard_interpolate_count(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval, const bowgpu_options *opts,
+                                   int64_t global_s0, const bowgpu_interp *interps, int32_t ninterps, const bowgpu_interp_edge *edge,
+                                   int64_t *n_out) {
+    return interp_count_impl(cols, ncols, ts_col, interval, opts, interps, ninterps, n_out, &global_s0, edge);
+}
+
+int bowgpu_shard_interpolate_fill(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval, const bowgpu_options *opts,
+                                  int64_t global_s0, const bowgpu_interp *interps, int32_t ninterps, const bowgpu_interp_edge *edge,
+                                  bowgpu_out *outs) {
+    return interp_fill_impl(cols, ncols, ts_col, interval, opts, interps, ninterps, outs, &global_s0, edge);
+}
+
+// first / last valid point of every column of a shard: what its neighbours' Linear / StepPrevious interpolators may need
+int bowgpu_shard_interp_points(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, bowgpu_interp_points *out) {
+    if (!cols || !out || ncols <= 0 || ncols > kMaxCols) return fail(BOWGPU_ERR_ARG, "bad argument");
+    if (ts_col < 0 || ts_col >= ncols) return fail(BOWGPU_ERR_BAD_COL, "no interval column with index %d", ts_col);
+    memset(out, 0, sizeof *out);
+    const int64_t n = cols[ts_col].length;
+    out->nrows = n;
+    if (n == 0) return 0;
+    Ctx *c;
+    BG_TRY(ctx_get(&c));
+    DevCol dts;
+    BG_TRY(ts_contract(c, &cols[ts_col]));
+    BG_TRY(ts_device(c, &cols[ts_col], &dts));
+    void *pool;
+    BG_TRY(ctx_pool(c, kPoolShard, 16384, &pool));
+    int64_t *drows = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(pool) + 12288);  // [col][first, last]
+    std::vector<DevCol> dcs(ncols);
+    for (int i = 0; i < ncols; i++) {
+        if (cols[i].type != BOWGPU_INT64 && cols[i].type != BOWGPU_FLOAT64) return fail(BOWGPU_ERR_UNSUPPORTED, "column type outside the device path");
+        BG_TRY(devcol_prepare(c, &cols[i], &dcs[i], true, true));
+        BG_TRY(launch_first_last_valid(c, dcs[i].vbits, dcs[i].vbit0, n, drows + 2 * i));
+    }
+    int64_t hrows[2 * kMaxCols];
+    BG_HIP(hipMemcpyAsync(hrows, drows, sizeof(int64_t) * 2 * ncols, hipMemcpyDeviceToHost, c->stream));
+    BG_HIP(hipStreamSynchronize(c->stream));
+    auto at = [&](const void *base, int64_t row, uint64_t *v) -> int {
+        BG_HIP(hipMemcpyAsync(v, reinterpret_cast<const char *>(base) + 8 * row, 8, hipMemcpyDeviceToHost, c->stream));
+        return 0;
+    };
+    uint64_t tf = 0, tl = 0;
+    BG_TRY(at(dts.values, 0, &tf));
+    BG_TRY(at(dts.values, n - 1, &tl));
+    uint64_t tv[4 * kMaxCols] = {0};
+    for (int i = 0; i < ncols; i++) {
+        const int64_t fr = hrows[2 * i], lr = hrows[2 * i + 1];
+        out->first_valid[i] = fr >= 0; out->last_valid[i] = lr >= 0;
+        if (fr >= 0) { BG_TRY(at(dts.values, fr, &tv[4 * i])); BG_TRY(at(dcs[i].values, fr, &tv[4 * i + 1])); }
+        if (lr >= 0) { BG_TRY(at(dts.values, lr, &tv[4 * i + 2])); BG_TRY(at(dcs[i].values, lr, &tv[4 * i + 3])); }
+    }
+    BG_HIP(hipStreamSynchronize(c->stream));
+    out->first_ts = (int64_t)tf; out->last_ts = (int64_t)tl;
+    for (int i = 0; i < ncols; i++) {
+        auto as_f64 = [&](uint64_t b) { double d; if (cols[i].type == BOWGPU_FLOAT64) memcpy(&d, &b, 8); else d = (double)(int64_t)b; return d; };
+        out->first_t[i] = (double)(int64_t)tv[4 * i]; out->first_v[i] = as_f64(tv[4 * i + 1]);
+        out->last_t[i] = (double)(int64_t)tv[4 * i + 2]; out->last_v[i] = as_f64(tv[4 * i + 3]);
+        out->last_v_i64[i] = (int64_t)tv[4 * i + 3];
+    }
     return 0;
 }
 

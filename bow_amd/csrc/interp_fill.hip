@@ -365,6 +365,20 @@ namespace bowgpu {
 static_assert(sizeof(WholeParams) == sizeof(WholeParamsH), "WholeParams layout");
 static_assert(sizeof(WholeFinal) == sizeof(WholeFinalH), "WholeFinal layout");
 
+// rows[0] = first valid row of the column (-1: none), rows[1] = last valid row; word walks by one thread (a handful of words
+// unless the column starts / ends with a long run of nulls)
+__global__ void first_last_valid_kernel(const uint32_t *vbits, int64_t vbit0, int64_t n, int64_t *rows) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    rows[0] = next_valid(vbits, vbit0, n, 0);
+    rows[1] = prev_valid(vbits, vbit0, n, n - 1);
+}
+
+int launch_first_last_valid(Ctx *c, const uint32_t *vbits, int64_t vbit0, int64_t n, int64_t *d_rows) {
+    hipLaunchKernelGGL(first_last_valid_kernel, dim3(1), dim3(64), 0, c->stream, vbits, vbit0, n, d_rows);
+    BG_HIP(hipGetLastError());
+    return 0;
+}
+
 size_t nbr_index_bytes(int64_t n, int64_t vbit0) {
     const int64_t nblocks = (vbit0 + (n > 0 ? n : 1) - 1) / kNbrBlockBits - vbit0 / kNbrBlockBits + 1;
     return (size_t)nblocks * 8 * 4;

@@ -48,8 +48,10 @@ __device__ __forceinline__ void synth_value(const InterpCol &ic, const int64_t *
         if (pi >= 0) { t0 = (double)ts[pi]; v0 = bits_to_f64(ic.values[pi], ic.type); }
         else if (ic.has_prev && ic.prev_t_valid && ic.prev_v_valid) { t0 = ic.prev_t; v0 = ic.prev_v; }
         else break;
-        if (ni < 0) break;
-        const double t2 = (double)ts[ni], v2 = bits_to_f64(ic.values[ni], ic.type);
+        double t2, v2;
+        if (ni >= 0) { t2 = (double)ts[ni]; v2 = bits_to_f64(ic.values[ni], ic.type); }
+        else if (ic.next_valid) { t2 = ic.next_t; v2 = ic.next_v; }  // the nearest valid point lies on a shard to the right
+        else break;
         const double coef = ((double)sk - t0) / (t2 - t0);
         const double r = ((v2 - v0) * coef) + v0;
         bits = is_int ? (uint64_t)go_f64_to_i64(r) : (uint64_t)__double_as_longlong(r);  // SetOrDrop: bowconvert.go:28-29
@@ -98,13 +100,14 @@ __device__ __forceinline__ uint32_t mdiv32(uint32_t x, const Magic32 &d) {
     return (t + ((x - t) >> d.sh1)) >> d.sh2;
 }
 
+// has_left: the shard has rows to its left (sharded Interpolate): row 0 then has a left neighbour too, t_left = their last ts
 template <bool kFast>
 __device__ __forceinline__ RowsR rows_flags(const uint64_t (&t)[kIR], int64_t t_left, int64_t i, int64_t n, int64_t s0, int64_t interval,
-                                            const MagicDiv &magic, const Magic32 &m32, int64_t kq, bool *unsorted) {
+                                            const MagicDiv &magic, const Magic32 &m32, int64_t kq, bool has_left, bool *unsorted) {
     RowsR f;
     uint64_t wprev = 0;
     int64_t tprev = t_left;
-    if (i > 0) {
+    if (i > 0 || has_left) {
         if (kFast) wprev = mdiv32((uint32_t)((uint64_t)t_left - (uint64_t)s0), m32);
         else wprev = t_left < s0 ? 0 : magic_div((uint64_t)t_left - (uint64_t)s0, magic);
     }
@@ -113,7 +116,7 @@ __device__ __forceinline__ RowsR rows_flags(const uint64_t (&t)[kIR], int64_t t_
         f.wid[k] = 0; f.synth[k] = 0; f.exact[k] = false;
         if (i + k >= n) continue;
         const int64_t tk = (int64_t)t[k];
-        const bool first = i + k == 0;
+        const bool first = i + k == 0 && !has_left;
         if (!first && tprev > tk) *unsorted = true;
         uint64_t w;
         bool head, exact;
@@ -144,28 +147,30 @@ __device__ __forceinline__ RowsR rows_flags(const uint64_t (&t)[kIR], int64_t t_
 }
 
 // timestamp left of a thread's first row: the neighbouring lane's last row, LDS across waves, global across tiles
-__device__ __forceinline__ int64_t left_ts(const uint64_t (&t)[kIR], const int64_t *ts, int64_t i, int64_t n, long long *wave_last, int tid) {
+__device__ __forceinline__ int64_t left_ts(const uint64_t (&t)[kIR], const int64_t *ts, int64_t i, int64_t n, long long *wave_last, int tid,
+                                           int64_t shard_left_ts) {
     const int lane = tid & 63, wv = tid >> 6;
     const long long mine = (long long)t[kIR - 1];
     long long l = __shfl_up(mine, 1);
     if (lane == 63) wave_last[wv] = mine;
     __syncthreads();
-    if (lane == 0) l = wv > 0 ? wave_last[wv - 1] : ((i > 0 && i < n) ? ts[i - 1] : 0);
+    if (lane == 0) l = wv > 0 ? wave_last[wv - 1] : ((i > 0 && i < n) ? ts[i - 1] : shard_left_ts);
     return (int64_t)l;
 }
 
 template <bool kFast>
 __global__ __launch_bounds__(kIThreads) void interp_count_kernel(const int64_t *ts, int64_t n, int64_t s0, int64_t interval,
-                                                                 MagicDiv magic, Magic32 m32, int32_t *tile_exact, uint32_t *status) {
+                                                                 MagicDiv magic, Magic32 m32, int has_left, int64_t shard_left_ts,
+                                                                 int32_t *tile_exact, uint32_t *status) {
     __shared__ int part[kIThreads / 64];
     __shared__ long long wave_last[kIThreads / 64];
     const int64_t i = (int64_t)blockIdx.x * kITile + kIR * (int64_t)threadIdx.x;
     const bool vec = (reinterpret_cast<uintptr_t>(ts) & 15) == 0;
     uint64_t t[kIR];
     loadR(reinterpret_cast<const uint64_t *>(ts), i, n, vec, t);
-    const int64_t tl = left_ts(t, ts, i, n, wave_last, threadIdx.x);
+    const int64_t tl = left_ts(t, ts, i, n, wave_last, threadIdx.x, shard_left_ts);
     bool unsorted = false;
-    const RowsR f = rows_flags<kFast>(t, tl, i, n, s0, interval, magic, m32, -1, &unsorted);
+    const RowsR f = rows_flags<kFast>(t, tl, i, n, s0, interval, magic, m32, -1, has_left != 0, &unsorted);
     int cnt = (int)f.exact[0] + (int)f.exact[1];
     if (unsorted) atomicOr(&status[0], 1u);
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
@@ -203,14 +208,15 @@ __global__ __launch_bounds__(kIThreads) void interp_tile_kernel(const InterpPara
         const int64_t tp = p.ts[r0 - 1];
         const uint64_t wp = kFast ? (uint64_t)mdiv32((uint32_t)((uint64_t)tp - (uint64_t)p.s0), m32)
                                   : (tp < p.s0 ? 0 : magic_div((uint64_t)tp - (uint64_t)p.s0, p.magic));
-        o_base = (r0 - (p.drop < r0 ? p.drop : r0)) + (int64_t)wp + 1 - p.tile_exact_before[blockIdx.x];
+        // (a shard with rows to its left only accounts for the windows after their last one: wbase = that window + 1)
+        o_base = (r0 - (p.drop < r0 ? p.drop : r0)) + (int64_t)wp + 1 - p.wbase - p.tile_exact_before[blockIdx.x];
         if (kq >= 0 && (uint64_t)kq <= wp) o_base -= 1;
     }
     const int64_t lbase = o_base & ~(int64_t)31;  // LDS bit 0
 
-    const int64_t tl = left_ts(t, p.ts, i, p.n, wave_last, tid);  // (one __syncthreads inside: the LDS clears above are visible after it)
+    const int64_t tl = left_ts(t, p.ts, i, p.n, wave_last, tid, p.left_ts);  // (one __syncthreads inside: the LDS clears above are visible after it)
     bool unsorted = false;
-    const RowsR f = rows_flags<kFast>(t, tl, i, p.n, p.s0, p.interval, p.magic, m32, kq, &unsorted);
+    const RowsR f = rows_flags<kFast>(t, tl, i, p.n, p.s0, p.interval, p.magic, m32, kq, p.has_left != 0, &unsorted);
     if (unsorted) atomicOr(&p.status[0], 1u);
 
     // ---- output positions: thread totals -> wave scan -> workgroup
@@ -376,17 +382,18 @@ bool interp_fast32(const Plan &plan, int64_t kq) {
            plan.first_ts > -lim53 && plan.last_ts < lim53;
 }
 
-int launch_interp_count(Ctx *c, const int64_t *ts, int64_t n, const Plan &plan, int64_t kq, int32_t *tile_exact, uint32_t *status) {
+int launch_interp_count(Ctx *c, const int64_t *ts, int64_t n, const Plan &plan, int64_t kq, int has_left, int64_t left_ts,
+                        int32_t *tile_exact, uint32_t *status) {
     const int64_t ntiles = (n + kITile - 1) / kITile;
     if (ntiles <= 0) return 0;
     if (kq >= 0 || plan.first_ts < plan.s0)
         hipLaunchKernelGGL(interp_quirk_kernel, dim3(1), dim3(64), 0, c->stream, ts, n, plan.s0, plan.interval, kq, status);
     if (interp_fast32(plan, kq))
         hipLaunchKernelGGL(interp_count_kernel<true>, dim3((unsigned)ntiles), dim3(kIThreads), 0, c->stream, ts, n, plan.s0, plan.interval,
-                           plan.magic, magic32_make(plan.interval), tile_exact, status);
+                           plan.magic, magic32_make(plan.interval), has_left, left_ts, tile_exact, status);
     else
         hipLaunchKernelGGL(interp_count_kernel<false>, dim3((unsigned)ntiles), dim3(kIThreads), 0, c->stream, ts, n, plan.s0, plan.interval,
-                           plan.magic, Magic32{0, 0, 0}, tile_exact, status);
+                           plan.magic, Magic32{0, 0, 0}, has_left, left_ts, tile_exact, status);
     BG_HIP(hipGetLastError());
     return 0;
 }

@@ -237,6 +237,34 @@ int bowgpu_rolling_interpolate_fill(const bowgpu_col *cols, int32_t ncols, int32
                                     const bowgpu_interp *interps, int32_t ninterps,
                                     bowgpu_out *outs);
 
+/* Row-range sharded Rolling.Interpolate: a shard of the frame plus what lies beyond its two ends.
+ * Synthetic rows sit in front of a window's first row, so the shard holding that row emits them - including the empty windows
+ * since the last row on the shards to its left (has_left / left_last_ts).  A Linear / StepPrevious interpolator whose nearest
+ * valid point lies on another shard gets it from the caller: the point to the LEFT through bowgpu_interp.prev_* (the reference's
+ * own Options.PrevRow mechanism), the point to the RIGHT through next_*.  Shards concatenated in rank order = the unsharded
+ * result.  Frames with rows below the first window start or negative window starts are outside the sharded path. */
+typedef struct bowgpu_interp_edge {
+    int32_t has_left;         /* a shard to the left holds rows */
+    int32_t _pad;
+    int64_t left_last_ts;     /* the last of them */
+    int32_t next_valid[8];    /* per column of the Bow: nearest valid point on the shards to the right (Linear) */
+    double next_t[8], next_v[8];
+} bowgpu_interp_edge;
+/* a shard's own first / last valid point per column: what its neighbours fill their edges from (all_gather'ed as bytes) */
+typedef struct bowgpu_interp_points {
+    int64_t nrows, first_ts, last_ts;
+    int32_t first_valid[8], last_valid[8];
+    double first_t[8], first_v[8], last_t[8], last_v[8];
+    int64_t last_v_i64[8];    /* raw payload of the last valid value of an Int64 column (StepPrevious keeps the integer) */
+} bowgpu_interp_points;
+int bowgpu_shard_interp_points(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, bowgpu_interp_points *out);
+int bowgpu_shard_interpolate_count(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval,
+                                   const bowgpu_options *opts, int64_t global_s0, const bowgpu_interp *interps, int32_t ninterps,
+                                   const bowgpu_interp_edge *edge, int64_t *n_out);
+int bowgpu_shard_interpolate_fill(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval,
+                                  const bowgpu_options *opts, int64_t global_s0, const bowgpu_interp *interps, int32_t ninterps,
+                                  const bowgpu_interp_edge *edge, bowgpu_out *outs);
+
 /* ---- Bow.FillLinear / IsColSorted -------------------------------------------------- */
 
 /* Bow.FillLinear — reference bowfill.go:14-103.  out receives the filled copy of

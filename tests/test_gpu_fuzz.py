@@ -212,3 +212,47 @@ def test_fuzz_sharded(seed):
                 assert np.allclose(g, e, rtol=1e-10, atol=1e-9 if tw else 0), (label, k)
             else:
                 assert np.array_equal(gv[gm], wv[wm]), (label, k)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BOW_FUZZ_SEEDS", "8")) // 2))
+def test_fuzz_sharded_interpolate(seed):
+    """Rolling.Interpolate over random row-range splits (empty shards, one-row shards): concatenated shard outputs == the oracle on
+    the whole frame"""
+    from bow_amd import sharded
+    rng = np.random.default_rng(4000 + seed)
+    for case in range(15):
+        n = int(rng.integers(2, 500))
+        ts = rand_ts(rng, n)
+        ts = ts - min(int(ts[0]), 0) + int(rng.integers(0, 50))      # non-negative frame: the sharded path's domain
+        interval = int([1, 2, 5, 10, 64, 100, 1000][int(rng.integers(0, 7))])
+        offset = int(rng.integers(0, interval))
+        s0 = sharded.first_window_start(int(ts[0]), interval, offset)
+        if s0 < 0 or s0 > ts[0]:
+            continue
+        v, bm, typ, _ = rand_col(rng, n, 0)
+        kind = ["Linear", "StepPrevious", "None"][int(rng.integers(0, 3))]
+        ip = [{"kind": "WindowStart", "col": 0}, {"kind": kind, "col": 1}]
+        world = int(rng.integers(2, 6))
+        bounds = [0] + [int(c) for c in np.sort(rng.integers(0, n + 1, world - 1))] + [n]
+        label = "seed=%d case=%d n=%d I=%d off=%d %s bounds=%s" % (seed, case, n, interval, offset, kind, bounds)
+        valid = np.ones(n, bool) if bm is None else np.unpackbits(bm, bitorder="little")[:n].astype(bool)
+        want = orc.interpolate([orc.Column(ts, None, orc.INT64), orc.Column(v[:n], None if bm is None else np.packbits(valid, bitorder="little"), typ)],
+                               0, interval, ip, offset=offset)
+        shards = []
+        for r in range(world):
+            a, b = bounds[r], bounds[r + 1]
+            shards.append([capi.Column(ts[a:b].copy(), None, capi.INT64).to_device(),
+                           capi.Column(v[a:b].copy(), np.packbits(valid[a:b], bitorder="little"), typ, 0, b - a, -1).to_device()])
+        points = [capi.shard_interp_points(cols, 0) for cols in shards]
+        outs = [capi.shard_interpolate(cols, 0, interval, ip, s0, r, points, offset=offset) for r, cols in enumerate(shards)]
+        for c in range(2):
+            gv = np.concatenate([o[c].host_arrays()[0].view(np.uint64) for o in outs])
+            gm = np.concatenate([o[c].valid_mask() for o in outs])
+            wm = want[c].valid_mask()
+            assert len(gv) == want[c].length, (label, c, len(gv), want[c].length)
+            assert np.array_equal(gm, wm), (label, c, np.flatnonzero(gm != wm)[:10])
+            wv = want[c].values[:want[c].length].view(np.uint64)
+            diff = gv[gm] != wv[wm]
+            if diff.any() and typ == capi.FLOAT64 and c == 1:
+                diff &= ~(np.isnan(gv[gm].view(np.float64)) & np.isnan(wv[wm].view(np.float64)))
+            assert not diff.any(), (label, c, np.flatnonzero(diff)[:10])

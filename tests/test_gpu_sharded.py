@@ -149,3 +149,50 @@ def test_sharded_time_weighted_and_inclusive_windows(mode):
             else:
                 bad = np.flatnonzero(gv[gm] != wv[wm])
                 assert bad.size == 0, (mode, interval, k, bad[:5], gv.view(np.float64)[gm][bad[:3]], wv.view(np.float64)[wm][bad[:3]])
+
+
+@pytest.mark.parametrize("kind", ["Linear", "StepPrevious", "None"])
+def test_sharded_interpolate_equals_whole(kind):
+    """Rolling.Interpolate over row-range shards: every shard emits the synthetic rows in front of ITS rows (including the
+    empty windows since the last row to its left) and finds the nearest valid neighbours of a window start on other shards
+    through the exchanged first / last valid points; the outputs concatenated in rank order are the unsharded result."""
+    rng = np.random.default_rng(17)
+    ip = [{"kind": "WindowStart", "col": 0}, {"kind": kind, "col": 1}, {"kind": "Linear" if kind != "Linear" else "StepPrevious", "col": 2}]
+    for mode, n, interval, offset, bounds in [
+            ("irregular", 20_000, 100, 7, [0, 5_000, 5_001, 12_000, 20_000]),
+            ("dense", 9_000, 10, 0, [0, 3_000, 6_000, 9_000]),               # shard ends are window ends: exact heads on the boundary
+            ("gappy", 15_000, 50, 3, [0, 4_000, 4_000, 9_000, 15_000]),      # an empty shard; long runs of empty windows
+            ("irregular", 6_000, 1000, 0, [0, 10, 20, 30, 6_000])]:          # shards smaller than a window
+        if mode == "dense":
+            ts = np.arange(n, dtype=np.int64) * 2
+        elif mode == "irregular":
+            ts = np.cumsum(rng.integers(1, 20, n)).astype(np.int64)
+        else:
+            step = rng.integers(1, 5, n)
+            step[rng.random(n) < 0.004] = rng.integers(100, 3000)
+            ts = np.cumsum(step).astype(np.int64)
+        v1 = np.round(rng.standard_normal(n) * 100, 2)
+        v2 = rng.integers(-1000, 1000, n).astype(np.int64)
+        m1, m2 = rng.random(n) >= 0.4, rng.random(n) >= 0.4
+        m1[bounds[1] - 40:bounds[1] + 60] = False       # the nearest valid points of the boundary windows lie deep inside the neighbours
+        m2[:bounds[1]] = rng.random(bounds[1]) >= 0.97
+        b1, b2 = np.packbits(m1, bitorder="little"), np.packbits(m2, bitorder="little")
+        want = orc.interpolate([orc.Column(ts, None, orc.INT64), orc.Column(v1, b1, orc.FLOAT64), orc.Column(v2, b2, orc.INT64)],
+                               0, interval, ip, offset=offset)
+        s0 = sharded.first_window_start(int(ts[0]), interval, offset)
+        shards = []
+        for r in range(len(bounds) - 1):
+            a, b = bounds[r], bounds[r + 1]
+            shards.append([capi.Column(ts[a:b].copy(), None, capi.INT64).to_device(),
+                           capi.Column(v1[a:b].copy(), np.packbits(m1[a:b], bitorder="little"), capi.FLOAT64, 0, b - a, -1).to_device(),
+                           capi.Column(v2[a:b].copy(), np.packbits(m2[a:b], bitorder="little"), capi.INT64, 0, b - a, -1).to_device()])
+        points = [capi.shard_interp_points(cols, 0) for cols in shards]
+        outs = [capi.shard_interpolate(cols, 0, interval, ip, s0, r, points, offset=offset) for r, cols in enumerate(shards)]
+        for c in range(3):
+            gv = np.concatenate([o[c].host_arrays()[0].view(np.uint64) for o in outs])
+            gm = np.concatenate([o[c].valid_mask() for o in outs])
+            wm = want[c].valid_mask()
+            assert len(gv) == want[c].length, (mode, c, len(gv), want[c].length)
+            assert np.array_equal(gm, wm), (mode, c, np.flatnonzero(gm != wm)[:10])
+            wv = want[c].values[:want[c].length].view(np.uint64)
+            assert np.array_equal(gv[gm], wv[wm]), (mode, c, np.flatnonzero(gv[gm] != wv[wm])[:10])
