@@ -531,11 +531,14 @@ int bowgpu_aggregate_whole(const bowgpu_col *cols, int32_t ncols, int32_t ts_col
     if (nblocks > 2048) nblocks = 2048;
     const int64_t chunk = (n + nblocks - 1) / nblocks;
     DevBuf partials, onev, oneb;
-    BG_TRY(partials.alloc((size_t)nblocks * stats_size()));
+    BG_TRY(partials.alloc((size_t)(nblocks + 1) * stats_size()));  // + the merged state of the column (whole_run)
     BG_TRY(onev.alloc(8 * (size_t)naggs));
     BG_TRY(oneb.alloc(64 + (size_t)naggs));
     std::vector<DevCol> dcols(ncols);
+    std::vector<char> done(naggs, 0);
     for (int i = 0; i < naggs; i++) {
+        if (done[i]) continue;
+        // one pass per distinct input column: the partial state holds what every reducer needs
         const int col = aggs[i].col;
         DevCol &dc = dcols[col];
         if (dc.values == nullptr) {
@@ -547,17 +550,23 @@ int bowgpu_aggregate_whole(const bowgpu_col *cols, int32_t ncols, int32_t ts_col
         P.ts = reinterpret_cast<const int64_t *>(dts.values);
         P.values = reinterpret_cast<const uint64_t *>(dc.values);
         P.vbits = dc.vbits; P.vbit0 = dc.vbit0; P.n = n; P.type = cols[col].type;
-        P.need_ts = aggs[i].kind >= BOWGPU_AGG_INTEGRAL_STEP && aggs[i].kind <= BOWGPU_AGG_WAVG_LINEAR;
+        P.need_ts = 0;
+        for (int j = i; j < naggs; j++)
+            if (aggs[j].col == col && aggs[j].kind >= BOWGPU_AGG_INTEGRAL_STEP && aggs[j].kind <= BOWGPU_AGG_WAVG_LINEAR) P.need_ts = 1;
         P.partials = partials.p; P.chunk = chunk;
         BG_TRY(whole_run(c, &P, nblocks));
-        WholeFinalH F;
-        memset(&F, 0, sizeof F);
-        F.kind = aggs[i].kind; F.out_type = out_type_of(i); F.col_is_int = cols[col].type == BOWGPU_INT64;
-        F.n_factors = aggs[i].n_factors;
-        for (int k = 0; k < F.n_factors && k < BOWGPU_MAX_FACTORS; k++) F.factors[k] = aggs[i].factors[k];
-        F.out_value = reinterpret_cast<uint64_t *>(onev.p) + i;
-        F.out_valid_byte = reinterpret_cast<uint8_t *>(oneb.p) + i;
-        BG_TRY(whole_final_run(c, partials.p, nblocks, n, first_value, last_value, &F));
+        for (int j = i; j < naggs; j++) {
+            if (aggs[j].col != col) continue;
+            done[j] = 1;
+            WholeFinalH F;
+            memset(&F, 0, sizeof F);
+            F.kind = aggs[j].kind; F.out_type = out_type_of(j); F.col_is_int = cols[col].type == BOWGPU_INT64;
+            F.n_factors = aggs[j].n_factors;
+            for (int k = 0; k < F.n_factors && k < BOWGPU_MAX_FACTORS; k++) F.factors[k] = aggs[j].factors[k];
+            F.out_value = reinterpret_cast<uint64_t *>(onev.p) + j;
+            F.out_valid_byte = reinterpret_cast<uint8_t *>(oneb.p) + j;
+            BG_TRY(whole_final_run(c, reinterpret_cast<const char *>(partials.p) + (size_t)nblocks * stats_size(), 1, n, first_value, last_value, &F));
+        }
     }
     std::vector<uint64_t> hv(naggs);
     std::vector<uint8_t> hb(naggs);

@@ -228,9 +228,12 @@ __global__ __launch_bounds__(256) void fill_kernel(const FillParams p) {
 }
 
 // ------------------------------------------------------------------ whole-frame aggregation
-// Level 1: block b reduces rows [b*chunk, (b+1)*chunk) of one column into a partial state (thread t walks a
-// contiguous sub-range in row order; 256 partials merged in order).  Level 2: one thread merges the block
-// partials in order.  Fixed shape => deterministic; Sum/Mean/Integral are not in strict row order (1e-12 rel).
+// Level 1: workgroup b reduces rows [b*chunk, (b+1)*chunk) of one column into a partial state; each of its four wavefronts
+// owns a contiguous quarter and steps through it 512 rows at a time - lane l holds rows 8l..8l+7 of the step (four 16-B loads) -
+// merging the lanes' states with an ORDER-PRESERVING shuffle tree (stats_merge is concatenation: First / Last, the NaN-seed
+// rule of Min / Max and the integrals' adjacency survive), then the step into the wavefront's running state.  Level 2: one
+// thread merges the workgroup partials in order.  Fixed shape => deterministic; Sum / Mean / Integral are not in strict
+// row order (1e-12 rel).
 struct WholeParams {
     const int64_t *ts;
     const uint64_t *values;
@@ -243,29 +246,90 @@ struct WholeParams {
     int64_t chunk;
 };
 
+__device__ __forceinline__ Stats stats_shfl_down(const Stats &s, int o) {
+    Stats r;
+    r.sum = __shfl_down(s.sum, o); r.vmin = __shfl_down(s.vmin, o); r.vmax = __shfl_down(s.vmax, o);
+    r.nn_min = __shfl_down(s.nn_min, o); r.nn_max = __shfl_down(s.nn_max, o);
+    r.first_bits = __shfl_down((unsigned long long)s.first_bits, o); r.last_bits = __shfl_down((unsigned long long)s.last_bits, o);
+    r.count = __shfl_down((long long)s.count, o);
+    r.pt = __shfl_down(s.pt, o); r.pv = __shfl_down(s.pv, o); r.first_pt = __shfl_down(s.first_pt, o); r.first_pv = __shfl_down(s.first_pv, o);
+    r.integ_step = __shfl_down(s.integ_step, o); r.integ_trap = __shfl_down(s.integ_trap, o);
+    r.has_value = __shfl_down(s.has_value, o); r.has_nn = __shfl_down(s.has_nn, o);
+    r.has_point = __shfl_down(s.has_point, o); r.has_pair = __shfl_down(s.has_pair, o);
+    return r;
+}
+
 __global__ __launch_bounds__(256) void whole_partial_kernel(const WholeParams p) {
-    __shared__ Stats part[256];
-    const int tid = threadIdx.x;
+    __shared__ Stats part[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t lo = (int64_t)blockIdx.x * p.chunk;
     int64_t hi = lo + p.chunk;
     if (hi > p.n) hi = p.n;
-    const int64_t len = hi > lo ? hi - lo : 0;
-    const int64_t a = lo + (len * tid) / 256, b = lo + (len * (tid + 1)) / 256;
+    // the wavefront's quarter, in whole steps of 512 rows
+    const int64_t steps = hi > lo ? (hi - lo + 511) / 512 : 0;
+    const int64_t s_per = (steps + 3) / 4;
+    const int64_t q_lo = lo + (int64_t)wv * s_per * 512;
+    int64_t q_hi = q_lo + s_per * 512;
+    if (q_hi > hi) q_hi = hi;
+    const bool vec = (reinterpret_cast<uintptr_t>(p.values) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.ts) & 15) == 0;
+    Stats running;
+    stats_init(running);
+    for (int64_t base = q_lo; base < q_hi; base += 512) {
+        const int64_t r0 = base + 8 * lane;
+        uint64_t v[8], t[8];
+#pragma unroll
+        for (int k = 0; k < 4; k++) load_pair(p.values, r0 + 2 * k, q_hi, vec && (r0 & 1) == 0, v[2 * k], v[2 * k + 1]);
+        if (p.need_ts) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) load_pair(reinterpret_cast<const uint64_t *>(p.ts), r0 + 2 * k, q_hi, vec && (r0 & 1) == 0, t[2 * k], t[2 * k + 1]);
+        }
+        Stats st;
+        stats_init(st);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int64_t r = r0 + k;
+            if (r >= q_hi || !bit_at(p.vbits, p.vbit0, r)) continue;
+            const double x = bits_to_f64(v[k], p.type);
+            stats_value<true>(st, x, v[k]);
+            if (p.need_ts) stats_point(st, (double)(int64_t)t[k], x);
+        }
+        for (int o = 1; o < 64; o <<= 1) {  // lane i <- merge(lane i, lane i + o): contiguous row ranges, left then right
+            const Stats other = stats_shfl_down(st, o);
+            if ((lane & (2 * o - 1)) == 0) stats_merge(st, other);
+        }
+        if (lane == 0) stats_merge(running, st);
+    }
+    if (lane == 0) part[wv] = running;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        Stats acc = part[0];
+        stats_merge(acc, part[1]); stats_merge(acc, part[2]); stats_merge(acc, part[3]);
+        p.partials[blockIdx.x] = acc;
+    }
+}
+
+// Level 2: the workgroup partials of one column -> one state, in order: thread t merges a contiguous run of them, then the
+// same order-preserving tree across lanes and the four wavefronts.  merged[0] receives the result.
+__global__ __launch_bounds__(256) void whole_merge_kernel(const Stats *partials, int64_t nblocks, Stats *merged) {
+    __shared__ Stats part[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t per = (nblocks + 255) / 256;
+    const int64_t a = (int64_t)threadIdx.x * per;
+    int64_t b = a + per;
+    if (b > nblocks) b = nblocks;
     Stats st;
     stats_init(st);
-    for (int64_t r = a; r < b; r++) {
-        if (!bit_at(p.vbits, p.vbit0, r)) continue;
-        const uint64_t raw = p.values[r];
-        const double x = bits_to_f64(raw, p.type);
-        stats_value<true>(st, x, raw);
-        if (p.need_ts) stats_point(st, (double)p.ts[r], x);
+    for (int64_t i = a; i < b; i++) stats_merge(st, partials[i]);
+    for (int o = 1; o < 64; o <<= 1) {
+        const Stats other = stats_shfl_down(st, o);
+        if ((lane & (2 * o - 1)) == 0) stats_merge(st, other);
     }
-    part[tid] = st;
+    if (lane == 0) part[wv] = st;
     __syncthreads();
-    if (tid == 0) {
+    if (threadIdx.x == 0) {
         Stats acc = part[0];
-        for (int t = 1; t < 256; t++) stats_merge(acc, part[t]);
-        p.partials[blockIdx.x] = acc;
+        stats_merge(acc, part[1]); stats_merge(acc, part[2]); stats_merge(acc, part[3]);
+        merged[0] = acc;
     }
 }
 
@@ -404,9 +468,11 @@ int fill_run(Ctx *c, const FillParams &p) {
     return 0;
 }
 
+// partial states of the column's row chunks, then their ordered merge into partials[nblocks] (one extra slot)
 int whole_run(Ctx *c, const void *params_blob, int64_t nblocks) {
     const WholeParams &p = *reinterpret_cast<const WholeParams *>(params_blob);
     hipLaunchKernelGGL(whole_partial_kernel, dim3((unsigned)nblocks), dim3(256), 0, c->stream, p);
+    hipLaunchKernelGGL(whole_merge_kernel, dim3(1), dim3(256), 0, c->stream, p.partials, nblocks, p.partials + nblocks);
     BG_HIP(hipGetLastError());
     return 0;
 }

@@ -29,3 +29,7 @@ print("FillLinear: %.2f ms  %.1f Grows/s" % ((t1 - t0) * 1e3, n / (t1 - t0) / 1e
 t0 = time.perf_counter(); s = capi.is_col_sorted(ts); capi.synchronize(); t1 = time.perf_counter()
 t0 = time.perf_counter(); s = capi.is_col_sorted(ts); capi.synchronize(); t1 = time.perf_counter()
 print("IsColSorted: %.2f ms" % ((t1 - t0) * 1e3))
+aggs = [("WindowStart", 0), ("Sum", 1), ("ArithmeticMean", 1), ("Min", 1), ("Max", 1), ("Count", 1), ("WeightedAverageLinear", 1)]
+for rep in range(2):
+    t0 = time.perf_counter(); outs = capi.aggregate_whole([ts, val], 0, aggs); capi.synchronize(); t1 = time.perf_counter()
+print("aggregation.Aggregate (whole frame, 7 reducers over 2 columns): %.2f ms  %.1f Grows/s" % ((t1 - t0) * 1e3, n / (t1 - t0) / 1e9))
