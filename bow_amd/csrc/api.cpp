@@ -557,13 +557,15 @@ static int job_enqueue_tail(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t
 // Can the stripped-down kernel of rolling_simple.hip take this call?  (one null-free, 16-B aligned value column, at most
 // 4 factor-free outputs, exclusive windows, the whole interval column within 2^32 of s0, not a shard)
 static bool simple_applies(const AggJob *job, const bowgpu_agg *aggs, int32_t naggs, const Plan &plan, bool time_weighted, int *need,
-                           bool *is_int, bool *has_nulls) {
+                           bool *is_int, bool *has_nulls, bool *wide) {
     const AggParams &P = job->P;
     if ((job->inclusive && !time_weighted) || P.pre_rows || !P.fits32 || naggs > kSimpleMaxAggs) return false;
-    if (P.W <= 0 || P.W >= 0xFFFFFFF0ll) return false;
+    if (P.W <= 0) return false;
     // output slot 0 starts at s0 + wid_base * interval (wid_base != 0: a shard; it never lies above the shard's first row)
     const int64_t slot0_start = P.s0 + (int64_t)((uint64_t)P.wid_base * (uint64_t)P.interval);
-    if (plan.first_ts < slot0_start || (uint64_t)plan.last_ts - (uint64_t)slot0_start >= 0xFFFFFFF0ull) return false;
+    if (plan.first_ts < slot0_start) return false;
+    // rows within 2^32 of slot 0: global 32-bit window ids; else (nanosecond timestamps) ids relative to each tile's first window
+    *wide = (uint64_t)plan.last_ts - (uint64_t)slot0_start >= 0xFFFFFFF0ull || P.W >= 0xFFFFFFF0ll;
     if (reinterpret_cast<uintptr_t>(P.ts) & 15) return false;
     *need = 0;
     *is_int = true;  // (reducers over the interval column itself)
@@ -600,11 +602,11 @@ static int job_launch_tiles(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t
     const char *force = getenv("BOWGPU_FORCE_GENERAL");
     if (force && force[0] == '1') lean = false;
     int need = 0;
-    bool is_int = false, has_nulls = false;
-    bool simple = lean && allow_simple && plan && simple_applies(job, aggs, naggs, *plan, false, &need, &is_int, &has_nulls);
+    bool is_int = false, has_nulls = false, wide = false;
+    bool simple = lean && allow_simple && plan && simple_applies(job, aggs, naggs, *plan, false, &need, &is_int, &has_nulls, &wide);
     // time-weighted reducers / inclusive windows: the same wave-tile structure with ts staged as float64 (rolling_tw.hip)
     const bool tw = !lean && !(force && force[0] == '1') && allow_simple && plan &&
-                    simple_applies(job, aggs, naggs, *plan, true, &need, &is_int, &has_nulls);
+                    simple_applies(job, aggs, naggs, *plan, true, &need, &is_int, &has_nulls, &wide);
     simple = simple || tw;
     P.bits_preset = simple ? 1 : 0;
     for (int i = 0; i < naggs; i++) {
@@ -623,8 +625,21 @@ static int job_launch_tiles(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t
         S.ts = P.ts;
         S.n = P.n; S.interval = P.interval; S.W = P.W;
         S.wid_base = P.wid_base;
+        S.magic = P.magic;
         S.s0 = P.s0 + (int64_t)((uint64_t)P.wid_base * (uint64_t)P.interval);
         S.m32 = P.m32; S.sh1 = P.sh1_32; S.sh2 = P.sh2_32;
+        S.shift_k = 0;
+        if (wide) {  // ids from (ts - tile base) >> k divided by interval >> k, k = trailing zero bits of the interval
+            int k = 0;
+            while (k < 31 && !(((uint64_t)P.interval >> k) & 1ull)) k++;
+            S.shift_k = k;
+            const uint64_t d = (uint64_t)P.interval >> k;
+            int l = 0;
+            while (l < 32 && (1ull << l) < d) l++;
+            S.m32 = (uint32_t)((((1ull << l) - d) << 32) / d) + 1;
+            S.sh1 = l < 1 ? (uint32_t)l : 1u;
+            S.sh2 = l > 1 ? (uint32_t)(l - 1) : 0u;
+        }
         S.naggs = naggs;
         S.ncols = P.ncols > 0 ? P.ncols : 1;
         S.values[0] = P.ts;  // only WindowStart / NumRows: any column serves as "the" column
@@ -643,10 +658,10 @@ static int job_launch_tiles(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t
         S.status = P.status; S.long_list = P.long_list; S.long_cap = P.long_cap;
         S.inclusive = job->inclusive ? 1 : 0;
         if (tw) {
-            BG_TRY(launch_rolling_tw(c, S, is_int, has_nulls));
+            BG_TRY(launch_rolling_tw(c, S, is_int, has_nulls, wide));
             c->last_kernel_name = "rolling_tw_kernel";
         } else {
-            BG_TRY(launch_rolling_simple(c, S, need, is_int, has_nulls));
+            BG_TRY(launch_rolling_simple(c, S, need, is_int, has_nulls, wide));
             c->last_kernel_name = "rolling_simple_kernel";
         }
         *used_simple = true;

@@ -185,6 +185,8 @@ struct SimpleParams {
     const int64_t *ts;
     int64_t n, s0, interval, W;            // s0 = start of output slot 0 (a shard: global s0 + wid_base * interval)
     int64_t wid_base;                      // global id of output slot 0 (only for the long-window queue)
+    MagicDiv magic;                        // 64-bit magic of the interval: the per-tile base window of the kWide variants
+    int32_t shift_k, _pad4;                // kWide: trailing zero bits of the interval; m32 / sh1 / sh2 then divide by interval >> shift_k
     uint32_t m32, sh1, sh2;
     int32_t naggs;
     int32_t ncols;                         // value columns (>= 1; reducers over the interval column use it as a column)
@@ -202,8 +204,8 @@ struct SimpleParams {
     int64_t *long_list;
     int64_t long_cap;
 };
-int launch_rolling_simple(Ctx *c, const SimpleParams &p, int need, bool is_int, bool has_nulls);
-int launch_rolling_tw(Ctx *c, const SimpleParams &p, bool is_int, bool has_nulls);  // time-weighted reducers / inclusive windows (rolling_tw.hip)
+int launch_rolling_simple(Ctx *c, const SimpleParams &p, int need, bool is_int, bool has_nulls, bool wide);
+int launch_rolling_tw(Ctx *c, const SimpleParams &p, bool is_int, bool has_nulls, bool wide);  // time-weighted reducers / inclusive windows (rolling_tw.hip)
 
 int launch_rolling_aggregate(Ctx *c, const AggParams &p);   // general kernel (rolling_agg.hip)
 int launch_rolling_fast(Ctx *c, const AggParams &p);        // lean kernel for exclusive windows without time-weighted reducers (rolling_fast.hip)

@@ -53,7 +53,9 @@ __device__ __forceinline__ void lds_order() {
 
 // kNeed: bit0 min/max wanted, bit1 first/last wanted; kInt: Int64 value columns; kNulls: some column has nulls;
 // kMulti: more than one value column (the single-column shape keeps its straight-line form)
-template <int kNeed, bool kInt, bool kNulls, bool kMulti>
+// kWide: the rows of the call span 2^32 or more from slot 0 (nanosecond timestamps): window ids are taken relative to the
+// tile's first window (one exact 64-bit division on the scalar unit per tile), which only needs each TILE's rows within 2^32
+template <int kNeed, bool kInt, bool kNulls, bool kMulti, bool kWide>
 __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimpleParams p, const int64_t ntiles,
                                                                   const int64_t tiles_per_xcd) {
     __shared__ SimpleShared sh;
@@ -83,13 +85,29 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
     load_col(reinterpret_cast<const uint64_t *>(p.values[0]), va, vb);
     // the row left of the tile (scalar load): first head flag + order check
     const int64_t left0 = base > 0 ? p.ts[base - 1] : INT64_MIN;
-    const uint32_t s0_lo = (uint32_t)p.s0;
+    // ids are 32-bit and relative to window w0, which starts at ws0: slot 0 of the call, or (kWide) the tile's first window
+    uint64_t w0 = 0;
+    int64_t ws0 = p.s0;
+    bool unsorted = false, sat = false;  // rows out of order ; ids the 16-bit local fields / 32-bit arithmetic cannot hold
+    if (kWide) {
+        const int64_t ts_first = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ta[0] >> 32)) << 32) |
+                                           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ta[0]));
+        w0 = magic_div((uint64_t)ts_first - (uint64_t)p.s0, p.magic);
+        ws0 = p.s0 + (int64_t)(w0 * (uint64_t)p.interval);
+        const int64_t ts_last = p.ts[base + nloc - 1];
+        // ids come from (ts - ws0) >> k with k = trailing zero bits of the interval (floor(a / b) == floor((a >> k) / (b >> k)) when
+        // 2^k divides b): the tile's rows must lie within 2^(32+k) of ws0 - 2199 s for 1 s windows of nanosecond timestamps
+        sat = ts_last < ts_first || (((uint64_t)ts_last - (uint64_t)ws0) >> p.shift_k) >= 0xFFFFFFF0ull;  // (unsorted rows are caught below too)
+    }
+    const uint32_t s0_lo = (uint32_t)ws0;
+    auto rel32 = [&](int64_t t) -> uint32_t {  // timestamp -> 32-bit numerator of the window id
+        return kWide ? (uint32_t)(((uint64_t)t - (uint64_t)ws0) >> p.shift_k) : (uint32_t)t - s0_lo;
+    };
 
-    // ---- window ids (32-bit, global), head flags, compaction with a running scalar count
-    const uint32_t w_first = mdiv32((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ta[0]) - s0_lo, p.m32, p.sh1, p.sh2);
-    uint32_t left_w = base > 0 ? mdiv32((uint32_t)left0 - s0_lo, p.m32, p.sh1, p.sh2) : 0xFFFFFFFEu;
+    // ---- window ids (32-bit), head flags, compaction with a running scalar count
+    const uint32_t w_first = kWide ? 0u : mdiv32((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ta[0]) - s0_lo, p.m32, p.sh1, p.sh2);
+    uint32_t left_w = (base > 0 && (!kWide || left0 >= ws0)) ? mdiv32(rel32(left0), p.m32, p.sh1, p.sh2) : 0xFFFFFFFEu;
     int64_t left_ts = left0;
-    bool unsorted = false, sat = false;  // rows out of order ; a local window id that does not fit 16 bits
     int nseg_total = 0, nseg_owned = 0;
 #pragma unroll
     for (int j = 0; j < kChunksS; j++) {
@@ -100,8 +118,9 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
         const uint32_t phi = left32((uint32_t)(tb[j] >> 32), (uint32_t)((uint64_t)left_ts >> 32));
         const int64_t prev_ts = (int64_t)(((uint64_t)phi << 32) | plo);
         unsorted |= (pa && prev_ts > tsa) || (pb && tsa > tsb);
-        const uint32_t wa = mdiv32((uint32_t)tsa - s0_lo, p.m32, p.sh1, p.sh2);
-        const uint32_t wb = mdiv32((uint32_t)tsb - s0_lo, p.m32, p.sh1, p.sh2);
+        const uint32_t ra = rel32(tsa), rb = rel32(tsb);
+        const uint32_t wa = mdiv32(ra, p.m32, p.sh1, p.sh2);
+        const uint32_t wb = mdiv32(rb, p.m32, p.sh1, p.sh2);
         const uint32_t wprev = left32(wb, left_w);
         const bool ha = pa && (wa != wprev);
         const bool hb = pb && (wb != wa);
@@ -133,7 +152,9 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
     }
 
     const bool reaches_end = base + kRowsS >= n;
-    const uint32_t W32 = (uint32_t)p.W;
+    // windows of the call, as an id relative to w0 (the last tile's successor id when the data ends in it)
+    const uint64_t Wrel = (uint64_t)p.W - w0;
+    const uint32_t W32 = Wrel > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)Wrel;
     // ---- one pass per value column: stage its values in LDS (the next column's loads go out first), walk, store
     const int ncols = kMulti ? p.ncols : 1;
     for (int c = 0; c < ncols; c++) {
@@ -173,7 +194,7 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
         } else {
             // rows run past the look-ahead: hand the window (all its columns) to the cooperative path
             if (c == 0) {
-                push_long_window(p.status, p.long_list, p.long_cap, tile, (uint64_t)p.wid_base + wid, base + r0);
+                push_long_window(p.status, p.long_list, p.long_cap, tile, (uint64_t)p.wid_base + w0 + wid, base + r0);
             }
             continue;
         }
@@ -216,7 +237,8 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
         }
         const int nrows = r1 - r0;
         const bool has_value = count > 0;  // (always true without nulls)
-        const int64_t win_start = p.s0 + (int64_t)((uint64_t)wid * (uint64_t)(uint32_t)p.interval);
+        const int64_t win_start = ws0 + (int64_t)((uint64_t)wid * (uint64_t)(uint32_t)p.interval);
+        const int64_t slot = (int64_t)(w0 + wid);  // output slot
         if (wid >= W32) continue;  // (only on corrupt input)
         const uint32_t gap = next_wid - wid - 1;
         // ---- outputs of this column: lane q -> slot wid
@@ -243,15 +265,15 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
             if (nf) bits = apply_factors(bits, int_result, nf, p.fac[a]);
             if (kNulls && nil) {  // a window whose values are all null (rare): nil => slot 0, bit cleared
                 bits = 0;
-                atomicAnd(&p.out_valid[a][wid >> 5], ~(1u << (wid & 31)));
+                atomicAnd(&p.out_valid[a][slot >> 5], ~(1u << (slot & 31)));
             }
-            p.out_values[a][wid] = bits;
+            p.out_values[a][slot] = bits;
             // the empty windows right after this one (rare): values of an empty slice + cleared validity bits
             // (A.9 "Empty slice": WindowStart s_k ; Sum 0.0 ; Count 0 ; NumRows 0.0 ; the rest nil)
             for (uint32_t g = 1; g <= gap; g++) {
-                const uint32_t gw = wid + g;
-                if (gw >= W32) break;
-                const int64_t gstart = p.s0 + (int64_t)((uint64_t)gw * (uint64_t)(uint32_t)p.interval);
+                if (wid + g >= W32) break;
+                const int64_t gw = slot + g;
+                const int64_t gstart = win_start + (int64_t)((uint64_t)g * (uint64_t)(uint32_t)p.interval);
                 uint64_t gbits = k == BOWGPU_AGG_WINDOW_START ? (uint64_t)gstart : 0ull;
                 // (Sum / NumRows of an empty slice are +0.0 and Count is 0: a negative factor still turns the floats into -0.0)
                 if (nf && (k == BOWGPU_AGG_WINDOW_START || k == BOWGPU_AGG_SUM || k == BOWGPU_AGG_NUM_ROWS || k == BOWGPU_AGG_COUNT))
@@ -264,17 +286,22 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
     }  // columns
 }
 
-int launch_rolling_simple(Ctx *c, const SimpleParams &p, int need, bool is_int, bool has_nulls) {
+int launch_rolling_simple(Ctx *c, const SimpleParams &p, int need, bool is_int, bool has_nulls, bool wide) {
     if (p.n <= 0) return 0;
     const int64_t ntiles = (p.n + kTileS - 1) / kTileS;
     const int64_t per_xcd = (ntiles + 7) / 8;
     const int64_t grid = per_xcd * 8;
     if (grid > 0x7FFFFFFFll) return fail(BOWGPU_ERR_UNSUPPORTED, "too many rows for one launch: %lld", (long long)p.n);
     const dim3 g((unsigned)grid), blk(kWave);
-#define BG_LAUNCH(N, I, U)                                                                                                  \
-    do {                                                                                                                    \
-        if (p.ncols > 1) hipLaunchKernelGGL((rolling_simple_kernel<N, I, U, true>), g, blk, 0, c->stream, p, ntiles, per_xcd);  \
-        else hipLaunchKernelGGL((rolling_simple_kernel<N, I, U, false>), g, blk, 0, c->stream, p, ntiles, per_xcd);          \
+#define BG_LAUNCH2(N, I, U, M)                                                                                               \
+    do {                                                                                                                     \
+        if (wide) hipLaunchKernelGGL((rolling_simple_kernel<N, I, U, M, true>), g, blk, 0, c->stream, p, ntiles, per_xcd);   \
+        else hipLaunchKernelGGL((rolling_simple_kernel<N, I, U, M, false>), g, blk, 0, c->stream, p, ntiles, per_xcd);       \
+    } while (0)
+#define BG_LAUNCH(N, I, U)                                                \
+    do {                                                                  \
+        if (p.ncols > 1) BG_LAUNCH2(N, I, U, true);                       \
+        else BG_LAUNCH2(N, I, U, false);                                  \
     } while (0)
 #define BG_NEED(I, U)                                                                                   \
     switch (need) { case 0: BG_LAUNCH(0, I, U); break; case 1: BG_LAUNCH(1, I, U); break;              \
@@ -283,6 +310,7 @@ int launch_rolling_simple(Ctx *c, const SimpleParams &p, int need, bool is_int, 
     else { if (has_nulls) { BG_NEED(false, true) } else { BG_NEED(false, false) } }
 #undef BG_NEED
 #undef BG_LAUNCH
+#undef BG_LAUNCH2
     BG_HIP(hipGetLastError());
     return 0;
 }

@@ -47,7 +47,8 @@ __device__ __forceinline__ void lds_order() {
 }  // namespace
 
 // kInt: Int64 value columns; kNulls: some column has nulls
-template <bool kInt, bool kNulls>
+// kWide: see rolling_simple.hip (window ids relative to the tile's first window: rows may span more than 2^32 from slot 0)
+template <bool kInt, bool kNulls, bool kWide>
 __global__ __launch_bounds__(kWave, 3) void rolling_tw_kernel(const SimpleParams p, const int64_t ntiles, const int64_t tiles_per_xcd) {
     constexpr bool kMulti = true;  // one pass per value column, always in loop form
     __shared__ TwShared sh;
@@ -77,13 +78,29 @@ __global__ __launch_bounds__(kWave, 3) void rolling_tw_kernel(const SimpleParams
     load_col(reinterpret_cast<const uint64_t *>(p.values[0]), va, vb);
     // the row left of the tile (scalar load): first head flag + order check
     const int64_t left0 = base > 0 ? p.ts[base - 1] : INT64_MIN;
-    const uint32_t s0_lo = (uint32_t)p.s0;
+    // ids are 32-bit and relative to window w0, which starts at ws0: slot 0 of the call, or (kWide) the tile's first window
+    uint64_t w0 = 0;
+    int64_t ws0 = p.s0;
+    bool unsorted = false, sat = false;  // rows out of order ; ids the 16-bit local fields / 32-bit arithmetic cannot hold
+    if (kWide) {
+        const int64_t ts_first = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ta[0] >> 32)) << 32) |
+                                           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ta[0]));
+        w0 = magic_div((uint64_t)ts_first - (uint64_t)p.s0, p.magic);
+        ws0 = p.s0 + (int64_t)(w0 * (uint64_t)p.interval);
+        const int64_t ts_last = p.ts[base + nloc - 1];
+        // ids come from (ts - ws0) >> k with k = trailing zero bits of the interval (floor(a / b) == floor((a >> k) / (b >> k)) when
+        // 2^k divides b): the tile's rows must lie within 2^(32+k) of ws0 - 2199 s for 1 s windows of nanosecond timestamps
+        sat = ts_last < ts_first || (((uint64_t)ts_last - (uint64_t)ws0) >> p.shift_k) >= 0xFFFFFFF0ull;  // (unsorted rows are caught below too)
+    }
+    const uint32_t s0_lo = (uint32_t)ws0;
+    auto rel32 = [&](int64_t t) -> uint32_t {  // timestamp -> 32-bit numerator of the window id
+        return kWide ? (uint32_t)(((uint64_t)t - (uint64_t)ws0) >> p.shift_k) : (uint32_t)t - s0_lo;
+    };
 
-    // ---- window ids (32-bit, global), head flags, compaction with a running scalar count
-    const uint32_t w_first = mdiv32((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ta[0]) - s0_lo, p.m32, p.sh1, p.sh2);
-    uint32_t left_w = base > 0 ? mdiv32((uint32_t)left0 - s0_lo, p.m32, p.sh1, p.sh2) : 0xFFFFFFFEu;
+    // ---- window ids (32-bit), head flags, compaction with a running scalar count
+    const uint32_t w_first = kWide ? 0u : mdiv32((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ta[0]) - s0_lo, p.m32, p.sh1, p.sh2);
+    uint32_t left_w = (base > 0 && (!kWide || left0 >= ws0)) ? mdiv32(rel32(left0), p.m32, p.sh1, p.sh2) : 0xFFFFFFFEu;
     int64_t left_ts = left0;
-    bool unsorted = false, sat = false;  // rows out of order ; a local window id that does not fit 16 bits
     int nseg_total = 0, nseg_owned = 0;
 #pragma unroll
     for (int j = 0; j < kChunksT; j++) {
@@ -94,8 +111,9 @@ __global__ __launch_bounds__(kWave, 3) void rolling_tw_kernel(const SimpleParams
         const uint32_t phi = left32((uint32_t)(tb[j] >> 32), (uint32_t)((uint64_t)left_ts >> 32));
         const int64_t prev_ts = (int64_t)(((uint64_t)phi << 32) | plo);
         unsorted |= (pa && prev_ts > tsa) || (pb && tsa > tsb);
-        const uint32_t wa = mdiv32((uint32_t)tsa - s0_lo, p.m32, p.sh1, p.sh2);
-        const uint32_t wb = mdiv32((uint32_t)tsb - s0_lo, p.m32, p.sh1, p.sh2);
+        const uint32_t ra = rel32(tsa), rb = rel32(tsb);
+        const uint32_t wa = mdiv32(ra, p.m32, p.sh1, p.sh2);
+        const uint32_t wb = mdiv32(rb, p.m32, p.sh1, p.sh2);
         const uint32_t wprev = left32(wb, left_w);
         const bool ha = pa && (wa != wprev);
         const bool hb = pb && (wb != wa);
@@ -106,8 +124,10 @@ __global__ __launch_bounds__(kWave, 3) void rolling_tw_kernel(const SimpleParams
         pos += __builtin_amdgcn_mbcnt_hi((unsigned)(ma >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ma, 0));
         pos += __builtin_amdgcn_mbcnt_hi((unsigned)(mb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb, 0));
         // bit 15: the row sits exactly on its window's start (what makes it the inclusive row of the window before)
-        const uint32_t sa = (((uint32_t)tsa - s0_lo) == wa * (uint32_t)p.interval) ? 0x8000u : 0u;
-        const uint32_t sb = (((uint32_t)tsb - s0_lo) == wb * (uint32_t)p.interval) ? 0x8000u : 0u;
+        const uint32_t ik = (uint32_t)((uint64_t)p.interval >> (kWide ? p.shift_k : 0));
+        const uint64_t lowmask = kWide ? ((1ull << p.shift_k) - 1ull) : 0ull;
+        const uint32_t sa = (ra == wa * ik && (((uint64_t)tsa - (uint64_t)ws0) & lowmask) == 0) ? 0x8000u : 0u;
+        const uint32_t sb = (rb == wb * ik && (((uint64_t)tsb - (uint64_t)ws0) & lowmask) == 0) ? 0x8000u : 0u;
         if (ha && pos < kSegCapT) sh.seg[pos] = (uint32_t)l | sa | (la << 16);
         pos += ha ? 1 : 0;
         if (hb && pos < kSegCapT) sh.seg[pos] = (uint32_t)(l + 1) | sb | (lb << 16);
@@ -130,7 +150,9 @@ __global__ __launch_bounds__(kWave, 3) void rolling_tw_kernel(const SimpleParams
     }
 
     const bool reaches_end = base + kRowsT >= n;
-    const uint32_t W32 = (uint32_t)p.W;
+    // windows of the call, as an id relative to w0 (the last tile's successor id when the data ends in it)
+    const uint64_t Wrel = (uint64_t)p.W - w0;
+    const uint32_t W32 = Wrel > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)Wrel;
     // ---- one pass per value column: stage its values in LDS (the next column's loads go out first), walk, store
     const int ncols = kMulti ? p.ncols : 1;
     for (int c = 0; c < ncols; c++) {
@@ -170,7 +192,7 @@ __global__ __launch_bounds__(kWave, 3) void rolling_tw_kernel(const SimpleParams
         } else {
             // rows run past the look-ahead: hand the window (all its columns) to the cooperative path
             if (c == 0) {
-                push_long_window(p.status, p.long_list, p.long_cap, tile, (uint64_t)p.wid_base + wid, base + r0);
+                push_long_window(p.status, p.long_list, p.long_cap, tile, (uint64_t)p.wid_base + w0 + wid, base + r0);
             }
             continue;
         }
@@ -210,7 +232,8 @@ __global__ __launch_bounds__(kWave, 3) void rolling_tw_kernel(const SimpleParams
         }
         const int nrows = r1 - r0;
         const bool has_value = count > 0;
-        const int64_t win_start = p.s0 + (int64_t)((uint64_t)wid * (uint64_t)(uint32_t)p.interval);
+        const int64_t win_start = ws0 + (int64_t)((uint64_t)wid * (uint64_t)(uint32_t)p.interval);
+        const int64_t slot = (int64_t)(w0 + wid);  // output slot
         if (wid >= W32) continue;  // (only on corrupt input)
         const uint32_t gap = next_wid - wid - 1;
         // ---- outputs of this column: lane q -> slot wid
@@ -254,15 +277,15 @@ __global__ __launch_bounds__(kWave, 3) void rolling_tw_kernel(const SimpleParams
             if (nf) bits = apply_factors(bits, int_result, nf, p.fac[a]);
             if (nil) {  // no value (all null; fewer than two points for the trapezoid): nil => slot 0, bit cleared
                 bits = 0;
-                atomicAnd(&p.out_valid[a][wid >> 5], ~(1u << (wid & 31)));
+                atomicAnd(&p.out_valid[a][slot >> 5], ~(1u << (slot & 31)));
             }
-            p.out_values[a][wid] = bits;
+            p.out_values[a][slot] = bits;
             // the empty windows right after this one (rare): values of an empty slice + cleared validity bits
             // (A.9 "Empty slice": WindowStart s_k ; Sum 0.0 ; Count 0 ; NumRows 0.0 ; the rest nil)
             for (uint32_t g = 1; g <= gap; g++) {
-                const uint32_t gw = wid + g;
-                if (gw >= W32) break;
-                const int64_t gstart = p.s0 + (int64_t)((uint64_t)gw * (uint64_t)(uint32_t)p.interval);
+                if (wid + g >= W32) break;
+                const int64_t gw = slot + g;
+                const int64_t gstart = win_start + (int64_t)((uint64_t)g * (uint64_t)(uint32_t)p.interval);
                 uint64_t gbits = k == BOWGPU_AGG_WINDOW_START ? (uint64_t)gstart : 0ull;
                 // (Sum / NumRows of an empty slice are +0.0 and Count is 0: a negative factor still turns the floats into -0.0)
                 if (nf && (k == BOWGPU_AGG_WINDOW_START || k == BOWGPU_AGG_SUM || k == BOWGPU_AGG_NUM_ROWS || k == BOWGPU_AGG_COUNT))
@@ -275,20 +298,21 @@ __global__ __launch_bounds__(kWave, 3) void rolling_tw_kernel(const SimpleParams
     }  // columns
 }
 
-int launch_rolling_tw(Ctx *c, const SimpleParams &p, bool is_int, bool has_nulls) {
+int launch_rolling_tw(Ctx *c, const SimpleParams &p, bool is_int, bool has_nulls, bool wide) {
     if (p.n <= 0) return 0;
     const int64_t ntiles = (p.n + kTileT - 1) / kTileT;
     const int64_t per_xcd = (ntiles + 7) / 8;
     const int64_t grid = per_xcd * 8;
     if (grid > 0x7FFFFFFFll) return fail(BOWGPU_ERR_UNSUPPORTED, "too many rows for one launch: %lld", (long long)p.n);
     const dim3 g((unsigned)grid), blk(kWave);
-    if (is_int) {
-        if (has_nulls) hipLaunchKernelGGL((rolling_tw_kernel<true, true>), g, blk, 0, c->stream, p, ntiles, per_xcd);
-        else hipLaunchKernelGGL((rolling_tw_kernel<true, false>), g, blk, 0, c->stream, p, ntiles, per_xcd);
-    } else {
-        if (has_nulls) hipLaunchKernelGGL((rolling_tw_kernel<false, true>), g, blk, 0, c->stream, p, ntiles, per_xcd);
-        else hipLaunchKernelGGL((rolling_tw_kernel<false, false>), g, blk, 0, c->stream, p, ntiles, per_xcd);
-    }
+#define BG_TW(I, U)                                                                                             \
+    do {                                                                                                        \
+        if (wide) hipLaunchKernelGGL((rolling_tw_kernel<I, U, true>), g, blk, 0, c->stream, p, ntiles, per_xcd);  \
+        else hipLaunchKernelGGL((rolling_tw_kernel<I, U, false>), g, blk, 0, c->stream, p, ntiles, per_xcd);      \
+    } while (0)
+    if (is_int) { if (has_nulls) BG_TW(true, true); else BG_TW(true, false); }
+    else { if (has_nulls) BG_TW(false, true); else BG_TW(false, false); }
+#undef BG_TW
     BG_HIP(hipGetLastError());
     return 0;
 }

@@ -25,3 +25,9 @@ run("WeightedAverageLinear (inclusive)", [ts, val], 10, [W0, ("WeightedAverageLi
 run("IntegralStep + IntegralTrapezoid + Mean", [ts, val], 10, [W0, ("IntegralStep", 1), ("IntegralTrapezoid", 1), ("ArithmeticMean", 1)], 16)
 run("sparse 30% nulls: WeightedAverageStep I=100", [ts2, val2], 100, [W0, ("WeightedAverageStep", 1)], 16.125)
 run("Mean x Factor(0.5) (wave kernel: factors)", [ts, val], 10, [W0, ("ArithmeticMean", 1, [0.5])], 16)
+# nanosecond timestamps (rows span far more than 2^32 from the first window): the kWide variants
+import numpy as np
+tsn = capi.Column((np.arange(n, dtype=np.int64) * 100_000_000 + 1_700_000_000_000_000_000)).to_device()
+run("ns timestamps, 1 s windows: Mean", [tsn, val], 1_000_000_000, [W0, ("ArithmeticMean", 1)], 16)
+run("ns timestamps, 1 s windows: WeightedAverageLinear", [tsn, val], 1_000_000_000, [W0, ("WeightedAverageLinear", 1)], 16)
+run("ns timestamps: Mean (wave kernel)", [tsn, val], 1_000_000_000, [W0, ("ArithmeticMean", 1)], 16, {"BOWGPU_NO_SIMPLE": "1"})

@@ -89,6 +89,15 @@ def test_fuzz_aggregate(seed):
         interval = int([1, 2, 3, 7, 10, 64, 100, 1000, 12345, 10 ** 6][int(rng.integers(0, 10))])
         while n and (int(ts[-1]) - int(ts[0])) // interval > 1_500_000:
             interval *= 10  # keep the number of windows (output slots) reasonable
+        if n and rng.random() < 0.3:
+            # the same shape at nanosecond scale: rows span far more than 2^32 from the first window (per-tile window ids)
+            scale = int(10 ** rng.integers(5, 10)) + int(rng.integers(0, 3))
+            ts = ts * scale + int(rng.integers(-2, 3)) * 1_500_000_000_000_000_000 // 2
+            interval *= scale
+            if interval >= 2 ** 32 and rng.random() < 0.7:
+                interval = int(rng.integers(1, 2 ** 32 - 1))
+                while (int(ts[-1]) - int(ts[0])) // interval > 1_500_000:
+                    interval = min(interval * 10, 2 ** 62)
         offset = int(rng.integers(-3 * interval, 3 * interval + 1))
         ncols = int(rng.integers(1, 4))
         pad = int(rng.integers(0, 70)) if rng.random() < 0.5 else 0
