@@ -375,14 +375,18 @@ def test_nanosecond_timestamps_beyond_2_53():
         run_both(ts, [(vals, valid)], interval, aggs, offset=offset)
         for inclusive in (False, True):
             run_both(ts, [(vals, valid)], interval, tw, offset=offset, inclusive=inclusive)
-        if interval == 1_000_000_000:
-            # 1 s = 2^9 * 5^9 ns: the wave-tile kernels take this call with window ids relative to each tile's first window
-            # ((ts - base) >> 9 fits 32 bits), although the rows span 2e14 ns from the first window
-            cols = [capi.Column(ts), capi.Column(vals, np.packbits(valid, bitorder="little"), capi.FLOAT64, 0, n, -1)]
-            capi.rolling_aggregate(cols, 0, interval, aggs, offset=offset)
-            assert capi.last_kernel_name() == "rolling_simple_kernel"
-            capi.rolling_aggregate(cols, 0, interval, tw, offset=offset)
-            assert capi.last_kernel_name() == "rolling_tw_kernel"
+    # dense nanosecond data (rows ~0.1 ms apart, 1.024 ms = 2^13 * 125 ns windows): the wave-tile kernels take it with window ids
+    # relative to each tile's first window ((ts - tile base) >> 13 fits 32 bits) although the rows span 6e9 ns from the first window
+    n = 60_000
+    ts = np.cumsum(rng.integers(50_000, 150_000, n)).astype(np.int64) + np.int64(1_700_000_000_000_000_000)
+    vals, valid = make_vals(rng, n, "f64", 0.2)
+    run_both(ts, [(vals, valid)], 1_024_000, aggs, offset=77)
+    run_both(ts, [(vals, valid)], 1_024_000, tw, offset=77, inclusive=True)
+    cols = [capi.Column(ts), capi.Column(vals, np.packbits(valid, bitorder="little"), capi.FLOAT64, 0, n, -1)]
+    capi.rolling_aggregate(cols, 0, 1_024_000, aggs, offset=77)
+    assert capi.last_kernel_name() == "rolling_simple_kernel"
+    capi.rolling_aggregate(cols, 0, 1_024_000, tw, offset=77)
+    assert capi.last_kernel_name() == "rolling_tw_kernel"
 
 
 def test_declines_unsorted_and_null_timestamps():
