@@ -572,7 +572,6 @@ static bool simple_applies(const AggJob *job, const bowgpu_agg *aggs, int32_t na
     *has_nulls = false;
     for (int s = 0; s < P.ncols; s++) {
         if (reinterpret_cast<uintptr_t>(P.cols[s].values) & 15) return false;
-        if (P.cols[s].type != P.cols[0].type) return false;  // one walk specialisation per launch
         *has_nulls = *has_nulls || P.cols[s].vbits != nullptr;
         *is_int = P.cols[0].type == BOWGPU_INT64;
     }
@@ -646,6 +645,7 @@ static int job_launch_tiles(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t
         for (int s = 0; s < P.ncols; s++) {
             S.values[s] = P.cols[s].values;
             S.vbits[s] = P.cols[s].vbits; S.vbit0[s] = P.cols[s].vbit0; S.vwords[s] = P.cols[s].vwords;
+            S.col_is_int[s] = P.cols[s].type == BOWGPU_INT64;
         }
         for (int i = 0; i < naggs; i++) {
             S.kind[i] = aggs[i].kind;

@@ -194,6 +194,7 @@ struct SimpleParams {
     const void *values[kMaxCols];
     const uint32_t *vbits[kMaxCols];       // nullptr: this column has no nulls
     int64_t vbit0[kMaxCols], vwords[kMaxCols];
+    int32_t col_is_int[kMaxCols];          // Int64 column (read as float64(v), First / Last return Int64)
     int32_t kind[kSimpleMaxAggs];
     int32_t col[kSimpleMaxAggs];           // column slot each output reads (WindowStart / NumRows ride with slot 0)
     int32_t nfac[kSimpleMaxAggs];          // transformation.Factor chain of each output (factor.go:7-20), usually empty

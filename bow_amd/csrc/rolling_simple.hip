@@ -1,6 +1,6 @@
 // rolling_simple.hip — the tile kernel for the most common shape of Rolling.Aggregate, stripped of every
 // descriptor-driven branch:
-//   * up to 8 value columns of ONE type (all Float64 or all Int64, with or without nulls) plus the interval column;
+//   * up to 8 value columns (Float64 / Int64, with or without nulls) plus the interval column;
 //   * up to 12 outputs among WindowStart / Sum / ArithmeticMean / Min / Max / Count / First / Last / NumRows,
 //     transformation.Factor chains applied to the result, exclusive windows;
 //   * the rows of this call (the whole frame, or one rank's shard of it) span less than 2^32 from the start of output
@@ -51,7 +51,8 @@ __device__ __forceinline__ void lds_order() {
 
 }  // namespace
 
-// kNeed: bit0 min/max wanted, bit1 first/last wanted; kInt: Int64 value columns; kNulls: some column has nulls;
+// kNeed: bit0 min/max wanted, bit1 first/last wanted; kInt: Int64 value column (several columns carry their types in
+// p.col_is_int); kNulls: some column has nulls;
 // kMulti: more than one value column (the single-column shape keeps its straight-line form)
 // kWide: the rows of the call span 2^32 or more from slot 0 (nanosecond timestamps): window ids are taken relative to the
 // tile's first window (one exact 64-bit division on the scalar unit per tile), which only needs each TILE's rows within 2^32
@@ -158,6 +159,7 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
     // ---- one pass per value column: stage its values in LDS (the next column's loads go out first), walk, store
     const int ncols = kMulti ? p.ncols : 1;
     for (int c = 0; c < ncols; c++) {
+        const bool cint = kMulti ? (p.col_is_int[c] != 0) : kInt;  // mixed column types: per pass (uniform)
         if (kMulti) {
             lds_order();  // the previous pass is done with sh.val / sh.vbits
 #pragma unroll
@@ -204,10 +206,10 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
         int count;
         if (!kNulls) {
             first_raw = sh.val[r0];
-            mn = kInt ? (double)(int64_t)first_raw : __longlong_as_double((long long)first_raw);
+            mn = cint ? (double)(int64_t)first_raw : __longlong_as_double((long long)first_raw);
             mx = mn;
             auto step = [&](uint64_t raw) {
-                const double x = kInt ? (double)(int64_t)raw : __longlong_as_double((long long)raw);
+                const double x = cint ? (double)(int64_t)raw : __longlong_as_double((long long)raw);
                 sum += x;
                 if (kNeed & 1) {
                     if (x < mn) mn = x;
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
             for (int r = r0; r < r1; r++) {
                 if (!((sh.vbits[r >> 5] >> (r & 31)) & 1u)) continue;
                 const uint64_t raw = sh.val[r];
-                const double x = kInt ? (double)(int64_t)raw : __longlong_as_double((long long)raw);
+                const double x = cint ? (double)(int64_t)raw : __longlong_as_double((long long)raw);
                 sum += x;
                 if (count == 0) { mn = x; mx = x; first_raw = raw; }
                 else if (kNeed & 1) { if (x < mn) mn = x; if (x > mx) mx = x; }
@@ -260,7 +262,7 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
             case BOWGPU_AGG_LAST: bits = last_raw; nil = !has_value; break;
             default: bits = (uint64_t)__double_as_longlong((double)nrows); break;  // NumRows
             }
-            const bool int_result = k == BOWGPU_AGG_WINDOW_START || k == BOWGPU_AGG_COUNT || (kInt && (k == BOWGPU_AGG_FIRST || k == BOWGPU_AGG_LAST));
+            const bool int_result = k == BOWGPU_AGG_WINDOW_START || k == BOWGPU_AGG_COUNT || (cint && (k == BOWGPU_AGG_FIRST || k == BOWGPU_AGG_LAST));
             const int nf = p.nfac[a];
             if (nf) bits = apply_factors(bits, int_result, nf, p.fac[a]);
             if (kNulls && nil) {  // a window whose values are all null (rare): nil => slot 0, bit cleared

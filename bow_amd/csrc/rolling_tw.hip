@@ -156,6 +156,7 @@ __global__ __launch_bounds__(kWave, 3) void rolling_tw_kernel(const SimpleParams
     // ---- one pass per value column: stage its values in LDS (the next column's loads go out first), walk, store
     const int ncols = kMulti ? p.ncols : 1;
     for (int c = 0; c < ncols; c++) {
+        const bool cint = kMulti ? (p.col_is_int[c] != 0) : kInt;  // mixed column types: per pass (uniform)
         if (kMulti) {
             lds_order();  // the previous pass is done with sh.val / sh.vbits
 #pragma unroll
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(kWave, 3) void rolling_tw_kernel(const SimpleParams
         for (int r = r0; r < r1; r++) {
             if (kNulls && !((sh.vbits[r >> 5] >> (r & 31)) & 1u)) continue;
             const uint64_t raw = sh.val[r];
-            const double x = kInt ? (double)(int64_t)raw : __longlong_as_double((long long)raw);
+            const double x = cint ? (double)(int64_t)raw : __longlong_as_double((long long)raw);
             const double t = sh.tsf[r];
             sum += x;
             if (count == 0) { mn = x; mx = x; first_raw = raw; }
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(kWave, 3) void rolling_tw_kernel(const SimpleParams
         int count_incl = count;
         if (incl_row && (!kNulls || ((sh.vbits[r1 >> 5] >> (r1 & 31)) & 1u))) {
             const uint64_t raw = sh.val[r1];
-            const double x = kInt ? (double)(int64_t)raw : __longlong_as_double((long long)raw);
+            const double x = cint ? (double)(int64_t)raw : __longlong_as_double((long long)raw);
             if (count > 0) integ_trap_incl += (pv + x) / 2 * (sh.tsf[r1] - pt);
             count_incl++;
         }
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(kWave, 3) void rolling_tw_kernel(const SimpleParams
             }
             default: bits = (uint64_t)__double_as_longlong((double)nrows); break;  // NumRows
             }
-            const bool int_result = k == BOWGPU_AGG_WINDOW_START || k == BOWGPU_AGG_COUNT || (kInt && (k == BOWGPU_AGG_FIRST || k == BOWGPU_AGG_LAST));
+            const bool int_result = k == BOWGPU_AGG_WINDOW_START || k == BOWGPU_AGG_COUNT || (cint && (k == BOWGPU_AGG_FIRST || k == BOWGPU_AGG_LAST));
             const int nf = p.nfac[a];
             if (nf) bits = apply_factors(bits, int_result, nf, p.fac[a]);
             if (nil) {  // no value (all null; fewer than two points for the trapezoid): nil => slot 0, bit cleared
