@@ -179,7 +179,7 @@ struct AggParams {
     int64_t long_cap;
 };
 
-constexpr int kSimpleMaxAggs = 12;
+constexpr int kSimpleMaxAggs = 16;
 // descriptor of rolling_simple.hip's kernel: value columns of one type, factor-free outputs, 32-bit window ids
 struct SimpleParams {
     const int64_t *ts;

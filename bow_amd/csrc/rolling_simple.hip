@@ -1,7 +1,7 @@
 // rolling_simple.hip — the tile kernel for the most common shape of Rolling.Aggregate, stripped of every
 // descriptor-driven branch:
 //   * up to 8 value columns (Float64 / Int64, with or without nulls) plus the interval column;
-//   * up to 12 outputs among WindowStart / Sum / ArithmeticMean / Min / Max / Count / First / Last / NumRows,
+//   * up to 16 outputs among WindowStart / Sum / ArithmeticMean / Min / Max / Count / First / Last / NumRows,
 //     transformation.Factor chains applied to the result, exclusive windows;
 //   * the rows of this call (the whole frame, or one rank's shard of it) span less than 2^32 from the start of output
 //     slot 0 and interval < 2^32, so window ids are 32-bit: wid = magic32((uint32)(ts - s0)) with no per-tile base.

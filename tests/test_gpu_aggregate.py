@@ -271,6 +271,22 @@ def test_factors_on_the_simple_and_time_weighted_kernels(vkind):
     assert capi.last_kernel_name() == "rolling_simple_kernel"
 
 
+def test_sixteen_outputs_in_one_call():
+    # the ABI's maximum (16 reducers) over three columns of both types, through every kernel
+    rng = np.random.default_rng(2)
+    n = 50_000
+    ts = make_ts(rng, n, "irregular")
+    cols = [make_vals(rng, n, "f64", 0.2), make_vals(rng, n, "i64", 0.0), make_vals(rng, n, "f64", 0.0)]
+    aggs = [("WindowStart", 0)] + [(k, 1 + (i % 3)) for i, k in enumerate(["Sum", "ArithmeticMean", "Min", "Max", "Count", "First", "Last", "NumRows",
+                                                                           "Sum", "ArithmeticMean", "Min", "Max", "Count", "First", "Last"])]
+    assert len(aggs) == 16
+    run_both(ts, cols, 25, aggs, offset=4)
+    cc = [capi.Column(ts)] + [capi.Column(v, None if m is None else np.packbits(m, bitorder="little"),
+                                          capi.INT64 if v.dtype == np.int64 else capi.FLOAT64, 0, n, -1) for v, m in cols]
+    capi.rolling_aggregate(cc, 0, 25, aggs, offset=4)
+    assert capi.last_kernel_name() == "rolling_simple_kernel"
+
+
 def test_nan_inf_signed_zero_semantics():
     # minmax.go: NaN result iff the FIRST valid value is NaN; -0.0/+0.0 ties keep the earlier one
     ts = np.array([0, 1, 2, 10, 11, 12, 20, 21, 30, 31, 40, 41, 42], dtype=np.int64)
