@@ -187,7 +187,7 @@ __global__ __launch_bounds__(kIThreads) void interp_tile_kernel(const InterpPara
     __shared__ long long wave_last[kIThreads / 64];
     __shared__ int s_nlong;
     __shared__ LongRun runs[kIThreads];
-    __shared__ uint64_t sval[kIStage];
+    __shared__ uint64_t sval2[2][kIStage];  // double-buffered by column parity: a column is staged while the previous one drains
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t r0 = (int64_t)blockIdx.x * kITile;
     const int64_t i = r0 + kIR * (int64_t)tid;
@@ -257,8 +257,9 @@ __global__ __launch_bounds__(kIThreads) void interp_tile_kernel(const InterpPara
     // read-modify-write fills (measured).  A tile with more outputs than the stage holds (long runs of empty windows)
     // writes directly.
     const bool staged = tile_total <= kIStage;
+    uint64_t *sval = sval2[0];
     auto put = [&](const InterpCol &ic, int64_t o, uint64_t bits) {
-        if (staged) sval[o - o_base] = bits;
+        if (staged) sval[o - o_base] = bits;  // (sval: the buffer of the column being staged)
         else ic.out_values[o] = bits;
     };
     // synthetic rows j = first, first + step, ... < count of column c in front of row a (j = 0 is the one next to the row; its
@@ -302,6 +303,7 @@ __global__ __launch_bounds__(kIThreads) void interp_tile_kernel(const InterpPara
     const bool contiguous = f.synth[1] == 0 && emitted[0] && i + 1 < p.n;
     for (int c = 0; c < p.ncols; c++) {
         const InterpCol &ic = p.cols[c];
+        sval = sval2[c & 1];
         uint64_t cur[kIR] = {v[0], v[1]};
         if (c + 1 < p.ncols) loadR(p.cols[c + 1].values, i, p.n, (reinterpret_cast<uintptr_t>(p.cols[c + 1].values) & 15) == 0, v);
         uint32_t m = 0;
@@ -319,9 +321,8 @@ __global__ __launch_bounds__(kIThreads) void interp_tile_kernel(const InterpPara
             if (own_run[k]) emit_synth(c, i + k, o_row[k], f.exact[k] ? f.wid[k] - 1 : f.wid[k], f.synth[k], 0, 1);
         for (int q = 0; q < nlong; q++) emit_synth(c, runs[q].a, runs[q].o_row, runs[q].k0, runs[q].synth, tid, kIThreads);
         if (staged) {
-            __syncthreads();
+            __syncthreads();  // staged -> flush; the next column stages into the other buffer, so no barrier after the flush
             for (int64_t rel = tid; rel < tile_total; rel += kIThreads) ic.out_values[o_base + rel] = sval[rel];
-            __syncthreads();
         }
     }
     __syncthreads();
