@@ -107,12 +107,67 @@ int ctx_pool(Ctx *c, int slot, size_t bytes, void **dptr) {
     return 0;
 }
 
+// ---------------------------------------------------------------- per-thread cache of device scratch blocks
+namespace {
+struct BufCache {
+    struct E { void *p; size_t cap; };
+    std::vector<E> v;
+    size_t total = 0;
+    void drop_all() {
+        for (const E &e : v) (void)hipFree(e.p);
+        v.clear();
+        total = 0;
+    }
+    ~BufCache() { /* process exit: the runtime may already be gone; leave the blocks to it */ }
+};
+thread_local BufCache g_bufs;
+constexpr size_t kCacheEntries = 24;
+constexpr size_t kCacheBytes = (size_t)48 << 30;
+}  // namespace
+
+void devbuf_cache_drop() { g_bufs.drop_all(); }
+
+int devbuf_acquire(size_t n, void **p, size_t *cap) {
+    // smallest cached block that holds n without wasting more than half of itself (or 1 MiB)
+    int best = -1;
+    for (size_t i = 0; i < g_bufs.v.size(); i++) {
+        const size_t c = g_bufs.v[i].cap;
+        if (c >= n && (c <= 2 * n || c <= n + (1u << 20)) && (best < 0 || c < g_bufs.v[best].cap)) best = (int)i;
+    }
+    if (best >= 0) {
+        *p = g_bufs.v[best].p;
+        *cap = g_bufs.v[best].cap;
+        g_bufs.total -= *cap;
+        g_bufs.v.erase(g_bufs.v.begin() + best);
+        return 0;
+    }
+    hipError_t e = hipMalloc(p, n);
+    if (e == hipErrorOutOfMemory && !g_bufs.v.empty()) {  // give the cached blocks back and try once more
+        g_bufs.drop_all();
+        e = hipMalloc(p, n);
+    }
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc");
+    *cap = n;
+    return 0;
+}
+
+void devbuf_release(void *p, size_t cap) {
+    g_bufs.v.push_back({p, cap});
+    g_bufs.total += cap;
+    while (g_bufs.v.size() > kCacheEntries || g_bufs.total > kCacheBytes) {  // evict the largest
+        size_t big = 0;
+        for (size_t i = 1; i < g_bufs.v.size(); i++) if (g_bufs.v[i].cap > g_bufs.v[big].cap) big = i;
+        (void)hipFree(g_bufs.v[big].p);
+        g_bufs.total -= g_bufs.v[big].cap;
+        g_bufs.v.erase(g_bufs.v.begin() + big);
+    }
+}
+
 int DevBuf::alloc(size_t n) {
-    if (p) { (void)hipFree(p); p = nullptr; }
+    if (p) { devbuf_release(p, cap); p = nullptr; cap = 0; }
     bytes = n;
     if (n == 0) return 0;
-    BG_HIP(hipMalloc(&p, n));
-    return 0;
+    return devbuf_acquire(n, &p, &cap);
 }
 
 // ---------------------------------------------------------------- magic division
@@ -829,6 +884,7 @@ int bowgpu_set_device(int device) {
     if (c->inited && c->device != device) {
         // drop per-device state of the old device
         (void)hipSetDevice(c->device);
+        devbuf_cache_drop();
         if (c->d_scratch) (void)hipFree(c->d_scratch);
         if (c->d_params) (void)hipFree(c->d_params);
         for (int i = 0; i < Ctx::kPoolSlots; i++) if (c->pool[i]) (void)hipFree(c->pool[i]);

@@ -57,18 +57,25 @@ int ctx_pool(Ctx *c, int slot, size_t bytes, void **dptr);
 
 // ---------------------------------------------------------------- temp device buffers
 // RAII device allocation (stream-ordered free at scope exit after a sync by the caller).
+// Device scratch of one call.  Blocks come from / go back to a small per-thread cache (api.cpp devbuf_*), so a call pays
+// neither hipMalloc nor hipFree (which also synchronises the device) once the sizes have been seen; every entry point
+// synchronises its stream before its DevBufs go out of scope.
+void devbuf_release(void *p, size_t cap);
+void devbuf_cache_drop();
+int devbuf_acquire(size_t n, void **p, size_t *cap);
 struct DevBuf {
     void *p = nullptr;
-    size_t bytes = 0;
+    size_t bytes = 0;  // requested
+    size_t cap = 0;    // size of the underlying block
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
-    DevBuf(DevBuf &&o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+    DevBuf(DevBuf &&o) noexcept : p(o.p), bytes(o.bytes), cap(o.cap) { o.p = nullptr; o.bytes = 0; o.cap = 0; }
     DevBuf &operator=(DevBuf &&o) noexcept {
-        if (this != &o) { if (p) (void)hipFree(p); p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0; }
+        if (this != &o) { if (p) devbuf_release(p, cap); p = o.p; bytes = o.bytes; cap = o.cap; o.p = nullptr; o.bytes = 0; o.cap = 0; }
         return *this;
     }
-    ~DevBuf() { if (p) (void)hipFree(p); }
+    ~DevBuf() { if (p) devbuf_release(p, cap); }
     int alloc(size_t n);
 };
 
