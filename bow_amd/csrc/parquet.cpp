@@ -4,8 +4,9 @@
 // the file, launch of the decode kernels (parquet_decode.hip).
 //
 // Scope: what the reference writes (bowparquet.go:326-338: SNAPPY, PLAIN, data page v1, RLE definition levels, flat schema
-// of OPTIONAL columns) and what pyarrow writes with the same options; INT64 and DOUBLE columns (the device path's types).
-// Dictionary pages, data page v2, other codecs / encodings and nested schemas are declined with BOWGPU_ERR_UNSUPPORTED.
+// of OPTIONAL columns) and what pyarrow / pandas write by default (a dictionary page per column chunk, RLE_DICTIONARY data
+// pages, PLAIN fall-back pages); INT64 and DOUBLE columns (the device path's types).  Data page v2, other codecs /
+// encodings and nested schemas are declined with BOWGPU_ERR_UNSUPPORTED.
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -23,9 +24,12 @@ namespace bowgpu {
 struct PqPage {  // must match parquet_decode.hip
     int64_t src_off, raw_off, row0;
     int32_t comp_size, raw_size, num_values, compressed;
+    int32_t kind, dict_count;
+    int64_t dict_off, idx_off;
 };
 int launch_parquet_decode(Ctx *c, const uint8_t *chunk, const PqPage *pages, int64_t npages, bool any_compressed, uint8_t *raw,
-                          int optional, uint64_t *out_values, uint32_t *out_valid, unsigned long long *valid_count, uint32_t *status);
+                          int optional, bool any_dict, uint32_t *indices, uint64_t *out_values, uint32_t *out_valid,
+                          unsigned long long *valid_count, uint32_t *status);
 
 namespace {
 
@@ -191,7 +195,7 @@ int parse_footer(ParquetFile *pf, const uint8_t *buf, size_t len) {
     return 0;
 }
 
-struct PageHdr { int32_t type = -1, raw_size = 0, comp_size = 0, num_values = 0, encoding = -1, def_encoding = -1; size_t hdr_len = 0; bool v2 = false; };
+struct PageHdr { int32_t type = -1, raw_size = 0, comp_size = 0, num_values = 0, encoding = -1, def_encoding = -1, dict_values = 0, dict_encoding = -1; size_t hdr_len = 0; bool v2 = false; };
 
 bool parse_page_header(const uint8_t *b, size_t n, PageHdr *h) {
     TReader r{b, n};
@@ -208,6 +212,14 @@ bool parse_page_header(const uint8_t *b, size_t n, PageHdr *h) {
                 if (f2 == 1) h->num_values = (int32_t)r.zigzag();
                 else if (f2 == 2) h->encoding = (int32_t)r.zigzag();
                 else if (f2 == 3) h->def_encoding = (int32_t)r.zigzag();
+                else r.skip(t2);
+            }
+        } else if (fid == 7 && t == 12) {  // dictionary_page_header
+            int16_t f2 = 0;
+            int t2;
+            while (r.field(&f2, &t2)) {
+                if (f2 == 1) h->dict_values = (int32_t)r.zigzag();
+                else if (f2 == 2) h->dict_encoding = (int32_t)r.zigzag();
                 else r.skip(t2);
             }
         } else if (fid == 8) { h->v2 = true; r.skip(t); }
@@ -301,14 +313,19 @@ int bowgpu_parquet_read_column(bowgpu_parquet *handle, int32_t i, bowgpu_out *ou
     std::vector<Span> spans;
     std::vector<PqPage> pages;
     int64_t row0 = 0, raw_total = 0, dev_total = 0;
-    bool any_comp = false;
+    bool any_comp = false, any_dict = false;
     for (const PqRowGroup &g : pf->groups) {
         const PqColumnChunk &cc = g.cols[i];
         if (cc.codec != 0 && cc.codec != 1) return fail(BOWGPU_ERR_UNSUPPORTED, "parquet: codec %d of column '%s' (UNCOMPRESSED and SNAPPY are read)", cc.codec, sc.name.c_str());
-        if (cc.dictionary_page_offset > 0) return fail(BOWGPU_ERR_UNSUPPORTED, "parquet: column '%s' is dictionary-encoded (PLAIN is read)", sc.name.c_str());
-        if (cc.data_page_offset < 4 || cc.total_compressed < 0 || cc.data_page_offset + cc.total_compressed > pf->size)
+        // the chunk starts at its dictionary page when it has one (some writers leave dictionary_page_offset unset: the first
+        // page header tells)
+        const int64_t chunk_off = (cc.dictionary_page_offset >= 4 && cc.dictionary_page_offset < cc.data_page_offset) ? cc.dictionary_page_offset
+                                                                                                                     : cc.data_page_offset;
+        if (chunk_off < 4 || cc.total_compressed < 0 || chunk_off + cc.total_compressed > pf->size)
             return fail(BOWGPU_ERR_ARG, "parquet: column chunk of '%s' lies outside the file", sc.name.c_str());
-        const uint8_t *chunk = pf->map + cc.data_page_offset;
+        const uint8_t *chunk = pf->map + chunk_off;
+        int64_t dict_off = -1;   // raw offset of this chunk's dictionary values
+        int32_t dict_count = 0;
         const size_t chunk_len = (size_t)cc.total_compressed;
         const int64_t base = dev_total;
         size_t p = 0;
@@ -320,10 +337,38 @@ int bowgpu_parquet_read_column(bowgpu_parquet *handle, int32_t i, bowgpu_out *ou
             if (h.comp_size < 0 || p + (size_t)h.comp_size > chunk_len) return fail(BOWGPU_ERR_ARG, "parquet: page of column '%s' runs past its chunk", sc.name.c_str());
             if (h.raw_size < 0 || h.num_values < 0 || (int64_t)h.raw_size > (int64_t)16 * h.num_values + (1 << 20))
                 return fail(BOWGPU_ERR_ARG, "parquet: implausible page header in column '%s'", sc.name.c_str());
-            if (h.type == 0) {
-                if (h.encoding != 0) return fail(BOWGPU_ERR_UNSUPPORTED, "parquet: value encoding %d in column '%s' (PLAIN is read)", h.encoding, sc.name.c_str());
+            if (h.type == 2) {  // the chunk's dictionary: PLAIN values, decompressed like a page
+                if ((h.dict_encoding != 0 && h.dict_encoding != 2) || dict_off >= 0 || (int64_t)h.raw_size != (int64_t)h.dict_values * 8)
+                    return fail(BOWGPU_ERR_UNSUPPORTED, "parquet: dictionary page of column '%s' is not PLAIN 8-byte values", sc.name.c_str());
+                PqPage pg;
+                memset(&pg, 0, sizeof pg);
+                pg.src_off = base + (int64_t)p;
+                pg.comp_size = h.comp_size;
+                pg.raw_size = h.raw_size;
+                pg.compressed = cc.codec == 1 ? 1 : 0;
+                pg.kind = 2;
+                if (pg.compressed) {
+                    pg.raw_off = raw_total;
+                    raw_total += ((int64_t)h.raw_size + 15) & ~(int64_t)15;
+                    any_comp = true;
+                } else {
+                    pg.raw_off = pg.src_off;  // a stored dictionary is read in place
+                }
+                dict_off = pg.raw_off;
+                dict_count = h.dict_values;
+                pages.push_back(pg);
+            } else if (h.type == 0) {
+                const bool dict_page = h.encoding == 2 || h.encoding == 8;
+                if (h.encoding != 0 && !dict_page) return fail(BOWGPU_ERR_UNSUPPORTED, "parquet: value encoding %d in column '%s' (PLAIN and dictionary are read)", h.encoding, sc.name.c_str());
+                if (dict_page && dict_off < 0) return fail(BOWGPU_ERR_ARG, "parquet: column '%s' has dictionary-encoded pages but no dictionary", sc.name.c_str());
                 if (optional && h.def_encoding != 3) return fail(BOWGPU_ERR_UNSUPPORTED, "parquet: definition-level encoding %d in column '%s' (RLE is read)", h.def_encoding, sc.name.c_str());
                 PqPage pg;
+                memset(&pg, 0, sizeof pg);
+                pg.kind = dict_page ? 1 : 0;
+                pg.dict_off = dict_off;
+                pg.dict_count = dict_count;
+                pg.idx_off = row0 + vals;  // (one slot per row is always enough)
+                any_dict = any_dict || dict_page;
                 pg.src_off = base + (int64_t)p;
                 pg.comp_size = h.comp_size;
                 pg.raw_size = h.raw_size;
@@ -334,13 +379,13 @@ int bowgpu_parquet_read_column(bowgpu_parquet *handle, int32_t i, bowgpu_out *ou
                 if (pg.compressed) { raw_total += ((int64_t)h.raw_size + 15) & ~(int64_t)15; any_comp = true; }
                 pages.push_back(pg);
                 vals += h.num_values;
-            } else if (h.type == 2 || h.v2 || h.type == 3) {
+            } else if (h.v2 || h.type == 3) {
                 return fail(BOWGPU_ERR_UNSUPPORTED, "parquet: page type %d in column '%s' (data page v1 is read)", h.type, sc.name.c_str());
             }  // (index pages are skipped)
             p += (size_t)h.comp_size;
         }
         if (vals != cc.num_values || vals != g.num_rows) return fail(BOWGPU_ERR_ARG, "parquet: column '%s' holds %lld values for %lld rows", sc.name.c_str(), (long long)vals, (long long)g.num_rows);
-        spans.push_back({cc.data_page_offset, (int64_t)chunk_len, base});
+        spans.push_back({chunk_off, (int64_t)chunk_len, base});
         dev_total += (int64_t)chunk_len;
         row0 += g.num_rows;
     }
@@ -363,8 +408,11 @@ int bowgpu_parquet_read_column(bowgpu_parquet *handle, int32_t i, bowgpu_out *ou
     BG_HIP(hipMemsetAsync(status, 0, 64, c->stream));
     BG_HIP(hipMemsetAsync(dcnt, 0, 8, c->stream));
     BG_HIP(hipMemsetAsync(dout.validity, 0, (size_t)(((n + 7) >> 3) + 3) & ~(size_t)3, c->stream));
+    void *d_idx = nullptr;
+    if (any_dict) BG_TRY(ctx_pool(c, kPoolInterp + 3, (size_t)n * 4 + 32, &d_idx));
     BG_TRY(launch_parquet_decode(c, reinterpret_cast<const uint8_t *>(d_bytes), reinterpret_cast<const PqPage *>(d_pages), (int64_t)pages.size(),
-                                 any_comp, reinterpret_cast<uint8_t *>(d_raw), optional, reinterpret_cast<uint64_t *>(dout.values),
+                                 any_comp, reinterpret_cast<uint8_t *>(d_raw), optional, any_dict, reinterpret_cast<uint32_t *>(d_idx),
+                                 reinterpret_cast<uint64_t *>(dout.values),
                                  reinterpret_cast<uint32_t *>(dout.validity), dcnt, status));
     uint32_t hstat = 0;
     uint64_t hcnt = 0;

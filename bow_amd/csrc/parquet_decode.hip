@@ -6,7 +6,8 @@
 //                         control flow), then copy cooperatively: a literal is a plain strided copy; a back-reference of
 //                         `len` bytes at distance `off` is periodic with period `off` when it overlaps itself, so
 //                         dst[i] = base[off >= len ? i : i % off] is parallel in every case.
-//   page_scatter_kernel   data page v1 of a flat OPTIONAL / REQUIRED INT64 / DOUBLE column, PLAIN values: definition levels
+//   dict_indices_kernel   dictionary-encoded data pages: bit width byte + RLE / bit-packed hybrid of indices -> dense uint32 array
+//   page_scatter_kernel   data page v1 of a flat OPTIONAL / REQUIRED INT64 / DOUBLE column, PLAIN or dictionary values: definition levels
 //                         (RLE / bit-packed hybrid, bit width 1) -> Arrow validity bits; dense PLAIN values -> row slots
 //                         (null slots = 0, as bow.NewBuffer leaves them: bowbuffer.go:22-40).  Lane l owns rows 32k + l ... of the
 //                         page in words of 32: level word, popcount, wave scan = index of its first value.
@@ -21,6 +22,10 @@ struct PqPage {
     int32_t comp_size, raw_size;
     int32_t num_values;     // rows of the page (levels); non-null values = what the levels say
     int32_t compressed;     // 1: Snappy
+    int32_t kind;           // 0: data page, PLAIN values; 1: data page, dictionary indices; 2: the chunk's dictionary page (PLAIN values)
+    int32_t dict_count;     // kind 1: entries of the chunk's dictionary
+    int64_t dict_off;       // kind 1: offset of the dictionary's values (same buffer as raw_off)
+    int64_t idx_off;        // kind 1: first slot of this page in the expanded index array
 };
 
 namespace {
@@ -106,14 +111,67 @@ __global__ __launch_bounds__(256) void snappy_pages_kernel(const uint8_t *__rest
     if (bad && lane == 0) atomicOr(&status[0], 1u);
 }
 
+// Dictionary-encoded data pages (PLAIN_DICTIONARY / RLE_DICTIONARY): after the definition levels comes one byte = bit width, then
+// the RLE / bit-packed hybrid of dictionary indices, one per non-null value.  One wavefront per page expands it into a dense
+// uint32 array (the lanes share every run: an RLE run is a fill, a bit-packed run one bit-field extraction per value).
+__global__ __launch_bounds__(256) void dict_indices_kernel(const uint8_t *__restrict__ raw, const PqPage *__restrict__ pages, int64_t npages,
+                                                           int optional, uint32_t *indices, uint32_t *status) {
+    const int lane = threadIdx.x & 63;
+    const int64_t pg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pg >= npages) return;
+    const PqPage P = pages[pg];
+    if (P.kind != 1) return;
+    const uint8_t *src = raw + P.raw_off;
+    int64_t pos = 0;
+    if (optional) {
+        const uint32_t lbytes = (uint32_t)src[0] | ((uint32_t)src[1] << 8) | ((uint32_t)src[2] << 16) | ((uint32_t)src[3] << 24);
+        pos = 4 + (int64_t)lbytes;
+    }
+    if (pos >= P.raw_size) return;  // a page of nulls only carries no index stream
+    const int bw = src[pos++];
+    if (bw > 32) { if (lane == 0) atomicOr(&status[0], 16u); return; }
+    const int vbytes = (bw + 7) >> 3;
+    uint32_t *dst = indices + P.idx_off;
+    int64_t outp = 0;
+    const int64_t cap = P.num_values;  // at most one index per row
+    while (pos < P.raw_size && outp < cap) {
+        const uint32_t h = rd_varint(src, &pos, P.raw_size);
+        if (h & 1) {  // bit-packed: (h >> 1) groups of 8 values, bw bits each, LSB first
+            const int64_t count = (int64_t)(h >> 1) * 8;
+            const int64_t nbytes = (int64_t)(h >> 1) * bw;
+            if (pos + nbytes > P.raw_size + 8) { if (lane == 0) atomicOr(&status[0], 16u); return; }
+            const int64_t take = count < cap - outp ? count : cap - outp;
+            for (int64_t j = lane; j < take; j += 64) {
+                const int64_t bit = j * bw;
+                const uint8_t *q = src + pos + (bit >> 3);
+                uint64_t w = 0;
+                for (int b = 0; b < 5; b++) w |= (pos + (bit >> 3) + b < P.raw_size ? (uint64_t)q[b] : 0ull) << (8 * b);
+                dst[outp + j] = bw == 32 ? (uint32_t)(w >> (bit & 7)) : (uint32_t)((w >> (bit & 7)) & ((1ull << bw) - 1ull));
+            }
+            pos += nbytes;
+            outp += take;
+        } else {  // RLE: (h >> 1) copies of one value stored in ceil(bw / 8) bytes
+            const int64_t count = h >> 1;
+            uint32_t val = 0;
+            for (int b = 0; b < vbytes; b++) val |= (pos + b < P.raw_size ? (uint32_t)src[pos + b] : 0u) << (8 * b);
+            pos += vbytes;
+            const int64_t take = count < cap - outp ? count : cap - outp;
+            for (int64_t j = lane; j < take; j += 64) dst[outp + j] = val;
+            outp += take;
+            if (count == 0) break;  // malformed: no progress
+        }
+    }
+}
+
 // optional: column has definition levels (max level 1); out_valid must be zeroed; valid_count += non-null rows
 __global__ __launch_bounds__(256) void page_scatter_kernel(const uint8_t *__restrict__ raw, const PqPage *__restrict__ pages, int64_t npages,
-                                                           int optional, uint64_t *out_values, uint32_t *out_valid,
-                                                           unsigned long long *valid_count, uint32_t *status) {
+                                                           int optional, const uint32_t *__restrict__ indices, uint64_t *out_values,
+                                                           uint32_t *out_valid, unsigned long long *valid_count, uint32_t *status) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t pg = (int64_t)blockIdx.x * 4 + wv;
     if (pg >= npages) return;
     const PqPage P = pages[pg];
+    if (P.kind == 2) return;  // the dictionary page itself holds no rows
     const uint8_t *src = raw + P.raw_off;
     const int nv = P.num_values;
     int64_t vpos = 0;  // offset of the PLAIN values inside the page
@@ -188,7 +246,17 @@ __global__ __launch_bounds__(256) void page_scatter_kernel(const uint8_t *__rest
             for (int k = 0; k < cnt; k++) {
                 uint64_t v = 0;
                 if ((word >> k) & 1u) {
-                    if ((vi + 1) * 8 <= val_bytes) {
+                    if (P.kind == 1) {  // the vi-th index of the page (expanded by dict_indices_kernel) -> the chunk's dictionary
+                        const uint32_t ix = indices[P.idx_off + vi];
+                        if (ix < (uint32_t)P.dict_count) {
+                            const uintptr_t addr = reinterpret_cast<uintptr_t>(raw + P.dict_off + (int64_t)ix * 8);  // (a stored dictionary sits at any byte offset)
+                            const uint64_t *al = reinterpret_cast<const uint64_t *>(addr & ~(uintptr_t)7);
+                            const int shb = (int)(addr & 7) * 8;
+                            v = shb ? ((al[0] >> shb) | (al[1] << (64 - shb))) : al[0];
+                        } else {
+                            atomicOr(&status[0], 8u);
+                        }
+                    } else if ((vi + 1) * 8 <= val_bytes) {
                         // PLAIN: 8 little-endian bytes at any byte offset inside the page: two aligned loads + funnel shift
                         // (the buffers are padded by 16 bytes, so the second load never leaves them)
                         const uintptr_t addr = reinterpret_cast<uintptr_t>(vals + vi * 8);
@@ -217,12 +285,15 @@ __global__ __launch_bounds__(256) void page_scatter_kernel(const uint8_t *__rest
 }
 
 int launch_parquet_decode(Ctx *c, const uint8_t *chunk, const PqPage *pages, int64_t npages, bool any_compressed, uint8_t *raw,
-                          int optional, uint64_t *out_values, uint32_t *out_valid, unsigned long long *valid_count, uint32_t *status) {
+                          int optional, bool any_dict, uint32_t *indices, uint64_t *out_values, uint32_t *out_valid,
+                          unsigned long long *valid_count, uint32_t *status) {
     if (npages <= 0) return 0;
     const unsigned grid = (unsigned)((npages + 3) / 4);
+    const uint8_t *src = any_compressed ? raw : chunk;
     if (any_compressed) hipLaunchKernelGGL(snappy_pages_kernel, dim3(grid), dim3(256), 0, c->stream, chunk, pages, npages, raw, status);
-    hipLaunchKernelGGL(page_scatter_kernel, dim3(grid), dim3(256), 0, c->stream, any_compressed ? raw : chunk, pages, npages, optional,
-                       out_values, out_valid, valid_count, status);
+    if (any_dict) hipLaunchKernelGGL(dict_indices_kernel, dim3(grid), dim3(256), 0, c->stream, src, pages, npages, optional, indices, status);
+    hipLaunchKernelGGL(page_scatter_kernel, dim3(grid), dim3(256), 0, c->stream, src, pages, npages, optional, indices, out_values, out_valid,
+                       valid_count, status);
     BG_HIP(hipGetLastError());
     return 0;
 }

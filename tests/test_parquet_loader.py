@@ -102,18 +102,40 @@ def test_files_written_here(tmp_path, compression):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("compression", ["snappy", "none"])
+def test_dictionary_encoded_files(tmp_path, compression):
+    """what pyarrow / pandas write by default: a dictionary page per column chunk, data pages of RLE / bit-packed indices (bit widths
+    1 .. 17 here), and PLAIN fall-back pages once a dictionary has grown too large"""
+    rng = np.random.default_rng(8)
+    for case, (n, card, null_frac, page, rg) in enumerate([(1000, 3, 0.0, 8192, None), (100_000, 7, 0.3, 8192, None), (100_000, 1000, 0.3, 4096, 30_000),
+                                                           (300_000, 100_000, 0.1, 65536, None), (50_000, 1, 0.5, 8192, None),
+                                                           (200_000, 2, 1.0, 8192, 50_000), (400_000, 300_000, 0.0, 1 << 20, None)]):
+        def mask():
+            return None if null_frac == 0.0 else rng.random(n) < null_frac
+        pool_f = rng.standard_normal(card)
+        pool_i = rng.integers(-2 ** 40, 2 ** 40, card).astype(np.int64)
+        cols = {"f": pa.array(pool_f[rng.integers(0, card, n)], mask=mask()),
+                "i": pa.array(pool_i[rng.integers(0, card, n)], mask=mask()),
+                "runs": pa.array(np.repeat(pool_i[:max(card // 2, 1)], -(-n // max(card // 2, 1)))[:n], mask=mask())}   # long RLE runs
+        table = pa.table(cols)
+        path = str(tmp_path / ("dict%d_%s.parquet" % (case, compression)))
+        pq.write_table(table, path, compression=compression, use_dictionary=True, data_page_size=page, data_page_version="1.0",
+                       row_group_size=rg, dictionary_pagesize_limit=64 * 1024 if case in (3, 6) else 1 << 20)
+        assert check_file(path, table) == 3
+
+
+@pytest.mark.gpu
 def test_declines_what_it_does_not_read(tmp_path):
     t = pa.table({"a": pa.array(np.arange(1000, dtype=np.int64) % 7)})
-    p1 = str(tmp_path / "dict.parquet")
-    pq.write_table(t, p1, use_dictionary=True, compression="snappy")
-    f = capi.ParquetFile(p1)
-    with pytest.raises(capi.BowGpuError) as e:
-        f.read_column(0)
-    assert e.value.code == -9
     p2 = str(tmp_path / "zstd.parquet")
     pq.write_table(t, p2, use_dictionary=False, compression="zstd")
     with pytest.raises(capi.BowGpuError) as e:
         capi.ParquetFile(p2).read_column(0)
+    assert e.value.code == -9
+    p3 = str(tmp_path / "v2.parquet")
+    pq.write_table(t, p3, use_dictionary=False, compression="snappy", data_page_version="2.0")
+    with pytest.raises(capi.BowGpuError) as e:
+        capi.ParquetFile(p3).read_column(0)
     assert e.value.code == -9
 
 
