@@ -1230,6 +1230,17 @@ int bowgpu_carry_merge(const bowgpu_carry_state *L, const bowgpu_carry_state *R,
     return 0;
 }
 
+int bowgpu_shard_span(const bowgpu_col *ts, int64_t *first_ts, int64_t *last_ts, int64_t *nrows) {
+    if (!ts || !first_ts || !last_ts || !nrows) return fail(BOWGPU_ERR_ARG, "null argument");
+    *first_ts = 0; *last_ts = 0; *nrows = ts->length;
+    if (ts->length == 0) return 0;
+    Plan p;
+    BG_TRY(plan_make(nullptr, ts, 1, 0, &p));  // (interval 1: only the two scalars matter; one synchronisation)
+    *first_ts = p.first_ts;
+    *last_ts = p.last_ts;
+    return 0;
+}
+
 int bowgpu_shard_first_row(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, const bowgpu_agg *aggs, int32_t naggs,
                            bowgpu_next_row *out) {
     if (!cols || !aggs || !out || ncols <= 0) return fail(BOWGPU_ERR_ARG, "null argument");

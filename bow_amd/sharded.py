@@ -213,12 +213,10 @@ class GpuProvider:
         ts = self.cols[self.ts_col]
         if self.n == 0:
             return 0, 0, 0
-        f = np.empty(1, np.int64)
-        l = np.empty(1, np.int64)
-        base = ts.values.ptr + 8 * ts.offset
-        capi.check(capi.lib().bowgpu_memcpy_d2h(f.ctypes.data_as(C.c_void_p), C.c_void_p(base), C.c_int64(8)))
-        capi.check(capi.lib().bowgpu_memcpy_d2h(l.ctypes.data_as(C.c_void_p), C.c_void_p(base + 8 * (self.n - 1)), C.c_int64(8)))
-        self._f, self._l = int(f[0]), int(l[0])
+        f, l, n = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        c = ts.c()
+        capi.check(capi.lib().bowgpu_shard_span(C.byref(c), C.byref(f), C.byref(l), C.byref(n)))
+        self._f, self._l = f.value, l.value
         return self._f, self._l, self.n
 
     def plan_s0(self):

@@ -349,6 +349,9 @@ typedef struct bowgpu_shard_carry {
     bowgpu_carry_state last[BOWGPU_CARRY_MAX_AGGS];  /* per aggregator: state of the LAST window over this shard's rows */
 } bowgpu_shard_carry;
 
+/* first / last timestamp and row count of a shard's interval column: what the ranks exchange first (one round trip to the device) */
+int bowgpu_shard_span(const bowgpu_col *ts, int64_t *first_ts, int64_t *last_ts, int64_t *nrows);
+
 /* Sharded Rolling.Aggregate, phase 1.  This rank holds rows [row0, row0+len) of every column
  * (device-resident; outs device-resident).  global_s0 comes from bowgpu_plan_windows on the rank
  * that holds global row 0.  Reduces every window that has a row in the shard - output slot k is
