@@ -5,7 +5,7 @@
 //
 // Scope: what the reference writes (bowparquet.go:326-338: SNAPPY, PLAIN, data page v1, RLE definition levels, flat schema
 // of OPTIONAL columns) and what pyarrow / pandas write by default (a dictionary page per column chunk, RLE_DICTIONARY data
-// pages, PLAIN fall-back pages); INT64 and DOUBLE columns (the device path's types).  Data page v2, other codecs /
+// pages, PLAIN fall-back pages, data page v2 when asked for); INT64 and DOUBLE columns (the device path's types).  Other codecs /
 // encodings and nested schemas are declined with BOWGPU_ERR_UNSUPPORTED.
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -26,6 +26,9 @@ struct PqPage {  // must match parquet_decode.hip
     int32_t comp_size, raw_size, num_values, compressed;
     int32_t kind, dict_count;
     int64_t dict_off, idx_off;
+    int64_t lv_off;
+    int32_t lv_len, v2;
+    int32_t dict_in_raw, _pad;
 };
 int launch_parquet_decode(Ctx *c, const uint8_t *chunk, const PqPage *pages, int64_t npages, bool any_compressed, uint8_t *raw,
                           int optional, bool any_dict, uint32_t *indices, uint64_t *out_values, uint32_t *out_valid,
@@ -195,7 +198,12 @@ int parse_footer(ParquetFile *pf, const uint8_t *buf, size_t len) {
     return 0;
 }
 
-struct PageHdr { int32_t type = -1, raw_size = 0, comp_size = 0, num_values = 0, encoding = -1, def_encoding = -1, dict_values = 0, dict_encoding = -1; size_t hdr_len = 0; bool v2 = false; };
+struct PageHdr {
+    int32_t type = -1, raw_size = 0, comp_size = 0, num_values = 0, encoding = -1, def_encoding = -1, dict_values = 0, dict_encoding = -1;
+    int32_t def_len = 0, rep_len = 0, v2_compressed = 1;  // data page v2
+    size_t hdr_len = 0;
+    bool v2 = false;
+};
 
 bool parse_page_header(const uint8_t *b, size_t n, PageHdr *h) {
     TReader r{b, n};
@@ -222,7 +230,19 @@ bool parse_page_header(const uint8_t *b, size_t n, PageHdr *h) {
                 else if (f2 == 2) h->dict_encoding = (int32_t)r.zigzag();
                 else r.skip(t2);
             }
-        } else if (fid == 8) { h->v2 = true; r.skip(t); }
+        } else if (fid == 8 && t == 12) {  // data_page_header_v2
+            h->v2 = true;
+            int16_t f2 = 0;
+            int t2;
+            while (r.field(&f2, &t2)) {
+                if (f2 == 1) h->num_values = (int32_t)r.zigzag();
+                else if (f2 == 4) h->encoding = (int32_t)r.zigzag();
+                else if (f2 == 5) h->def_len = (int32_t)r.zigzag();
+                else if (f2 == 6) h->rep_len = (int32_t)r.zigzag();
+                else if (f2 == 7) h->v2_compressed = t2 == 1 ? 1 : 0;  // bool lives in the field header
+                else r.skip(t2);
+            }
+        }
         else r.skip(t);
     }
     h->hdr_len = r.p;
@@ -324,8 +344,8 @@ int bowgpu_parquet_read_column(bowgpu_parquet *handle, int32_t i, bowgpu_out *ou
         if (chunk_off < 4 || cc.total_compressed < 0 || chunk_off + cc.total_compressed > pf->size)
             return fail(BOWGPU_ERR_ARG, "parquet: column chunk of '%s' lies outside the file", sc.name.c_str());
         const uint8_t *chunk = pf->map + chunk_off;
-        int64_t dict_off = -1;   // raw offset of this chunk's dictionary values
-        int32_t dict_count = 0;
+        int64_t dict_off = -1;   // offset of this chunk's dictionary values (scratch buffer if it was compressed, else the chunk bytes)
+        int32_t dict_count = 0, dict_in_raw = 0;
         const size_t chunk_len = (size_t)cc.total_compressed;
         const int64_t base = dev_total;
         size_t p = 0;
@@ -355,32 +375,40 @@ int bowgpu_parquet_read_column(bowgpu_parquet *handle, int32_t i, bowgpu_out *ou
                     pg.raw_off = pg.src_off;  // a stored dictionary is read in place
                 }
                 dict_off = pg.raw_off;
+                dict_in_raw = pg.compressed;
                 dict_count = h.dict_values;
                 pages.push_back(pg);
-            } else if (h.type == 0) {
+            } else if (h.type == 0 || (h.type == 3 && h.v2)) {
                 const bool dict_page = h.encoding == 2 || h.encoding == 8;
                 if (h.encoding != 0 && !dict_page) return fail(BOWGPU_ERR_UNSUPPORTED, "parquet: value encoding %d in column '%s' (PLAIN and dictionary are read)", h.encoding, sc.name.c_str());
                 if (dict_page && dict_off < 0) return fail(BOWGPU_ERR_ARG, "parquet: column '%s' has dictionary-encoded pages but no dictionary", sc.name.c_str());
-                if (optional && h.def_encoding != 3) return fail(BOWGPU_ERR_UNSUPPORTED, "parquet: definition-level encoding %d in column '%s' (RLE is read)", h.def_encoding, sc.name.c_str());
+                if (optional && !h.v2 && h.def_encoding != 3) return fail(BOWGPU_ERR_UNSUPPORTED, "parquet: definition-level encoding %d in column '%s' (RLE is read)", h.def_encoding, sc.name.c_str());
+                const int32_t lv_bytes = h.v2 ? h.def_len + h.rep_len : 0;
+                if (h.v2 && (h.def_len < 0 || h.rep_len != 0 || lv_bytes > h.comp_size || lv_bytes > h.raw_size))
+                    return fail(BOWGPU_ERR_ARG, "parquet: implausible level sizes in a v2 page of column '%s'", sc.name.c_str());
                 PqPage pg;
                 memset(&pg, 0, sizeof pg);
                 pg.kind = dict_page ? 1 : 0;
+                pg.v2 = h.v2 ? 1 : 0;
+                pg.lv_off = base + (int64_t)p + h.rep_len;
+                pg.lv_len = h.def_len;
                 pg.dict_off = dict_off;
+                pg.dict_in_raw = dict_in_raw;
                 pg.dict_count = dict_count;
                 pg.idx_off = row0 + vals;  // (one slot per row is always enough)
                 any_dict = any_dict || dict_page;
-                pg.src_off = base + (int64_t)p;
-                pg.comp_size = h.comp_size;
-                pg.raw_size = h.raw_size;
+                pg.src_off = base + (int64_t)p + lv_bytes;
+                pg.comp_size = h.comp_size - lv_bytes;
+                pg.raw_size = h.raw_size - lv_bytes;
                 pg.num_values = h.num_values;
-                pg.compressed = cc.codec == 1 ? 1 : 0;
+                pg.compressed = (cc.codec == 1 && (!h.v2 || h.v2_compressed)) ? 1 : 0;
                 pg.row0 = row0 + vals;
                 pg.raw_off = pg.compressed ? raw_total : pg.src_off;
                 if (pg.compressed) { raw_total += ((int64_t)h.raw_size + 15) & ~(int64_t)15; any_comp = true; }
                 pages.push_back(pg);
                 vals += h.num_values;
-            } else if (h.v2 || h.type == 3) {
-                return fail(BOWGPU_ERR_UNSUPPORTED, "parquet: page type %d in column '%s' (data page v1 is read)", h.type, sc.name.c_str());
+            } else if (h.type == 3) {
+                return fail(BOWGPU_ERR_UNSUPPORTED, "parquet: page type %d in column '%s' (data pages v1 / v2 are read)", h.type, sc.name.c_str());
             }  // (index pages are skipped)
             p += (size_t)h.comp_size;
         }
@@ -390,8 +418,6 @@ int bowgpu_parquet_read_column(bowgpu_parquet *handle, int32_t i, bowgpu_out *ou
         row0 += g.num_rows;
     }
     if (row0 != n) return fail(BOWGPU_ERR_ARG, "parquet: row groups hold %lld rows, the footer says %lld", (long long)row0, (long long)n);
-    for (const PqPage &pg : pages)
-        if (!pg.compressed && any_comp) return fail(BOWGPU_ERR_UNSUPPORTED, "parquet: column '%s' mixes compressed and stored chunks", sc.name.c_str());
 
     // ---- upload + decode
     void *d_bytes, *d_pages, *d_raw = nullptr;

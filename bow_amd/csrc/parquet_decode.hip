@@ -7,7 +7,7 @@
 //                         `len` bytes at distance `off` is periodic with period `off` when it overlaps itself, so
 //                         dst[i] = base[off >= len ? i : i % off] is parallel in every case.
 //   dict_indices_kernel   dictionary-encoded data pages: bit width byte + RLE / bit-packed hybrid of indices -> dense uint32 array
-//   page_scatter_kernel   data page v1 of a flat OPTIONAL / REQUIRED INT64 / DOUBLE column, PLAIN or dictionary values: definition levels
+//   page_scatter_kernel   data page (v1 / v2) of a flat OPTIONAL / REQUIRED INT64 / DOUBLE column, PLAIN or dictionary values: definition levels
 //                         (RLE / bit-packed hybrid, bit width 1) -> Arrow validity bits; dense PLAIN values -> row slots
 //                         (null slots = 0, as bow.NewBuffer leaves them: bowbuffer.go:22-40).  Lane l owns rows 32k + l ... of the
 //                         page in words of 32: level word, popcount, wave scan = index of its first value.
@@ -26,6 +26,11 @@ struct PqPage {
     int32_t dict_count;     // kind 1: entries of the chunk's dictionary
     int64_t dict_off;       // kind 1: offset of the dictionary's values (same buffer as raw_off)
     int64_t idx_off;        // kind 1: first slot of this page in the expanded index array
+    int64_t lv_off;         // data page v2: offset of the definition-level bytes inside the chunk bytes (never compressed there)
+    int32_t lv_len;         // data page v2: their length (v1 pages carry a 4-byte length in front of the levels instead)
+    int32_t v2;             // data page v2: src / raw describe the VALUES section only
+    int32_t dict_in_raw;    // kind 1: the dictionary was decompressed (it lives in the scratch buffer, else in the chunk bytes)
+    int32_t _pad;
 };
 
 namespace {
@@ -114,16 +119,17 @@ __global__ __launch_bounds__(256) void snappy_pages_kernel(const uint8_t *__rest
 // Dictionary-encoded data pages (PLAIN_DICTIONARY / RLE_DICTIONARY): after the definition levels comes one byte = bit width, then
 // the RLE / bit-packed hybrid of dictionary indices, one per non-null value.  One wavefront per page expands it into a dense
 // uint32 array (the lanes share every run: an RLE run is a fill, a bit-packed run one bit-field extraction per value).
-__global__ __launch_bounds__(256) void dict_indices_kernel(const uint8_t *__restrict__ raw, const PqPage *__restrict__ pages, int64_t npages,
+__global__ __launch_bounds__(256) void dict_indices_kernel(const uint8_t *__restrict__ raw, const uint8_t *__restrict__ chunk,
+                                                           const PqPage *__restrict__ pages, int64_t npages,
                                                            int optional, uint32_t *indices, uint32_t *status) {
     const int lane = threadIdx.x & 63;
     const int64_t pg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (pg >= npages) return;
     const PqPage P = pages[pg];
     if (P.kind != 1) return;
-    const uint8_t *src = raw + P.raw_off;
+    const uint8_t *src = (P.compressed ? raw : chunk) + P.raw_off;  // a page's values: decompressed into the scratch buffer, or stored
     int64_t pos = 0;
-    if (optional) {
+    if (optional && !P.v2) {
         const uint32_t lbytes = (uint32_t)src[0] | ((uint32_t)src[1] << 8) | ((uint32_t)src[2] << 16) | ((uint32_t)src[3] << 24);
         pos = 4 + (int64_t)lbytes;
     }
@@ -164,7 +170,8 @@ __global__ __launch_bounds__(256) void dict_indices_kernel(const uint8_t *__rest
 }
 
 // optional: column has definition levels (max level 1); out_valid must be zeroed; valid_count += non-null rows
-__global__ __launch_bounds__(256) void page_scatter_kernel(const uint8_t *__restrict__ raw, const PqPage *__restrict__ pages, int64_t npages,
+__global__ __launch_bounds__(256) void page_scatter_kernel(const uint8_t *__restrict__ raw, const uint8_t *__restrict__ chunk,
+                                                           const PqPage *__restrict__ pages, int64_t npages,
                                                            int optional, const uint32_t *__restrict__ indices, uint64_t *out_values,
                                                            uint32_t *out_valid, unsigned long long *valid_count, uint32_t *status) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -172,12 +179,15 @@ __global__ __launch_bounds__(256) void page_scatter_kernel(const uint8_t *__rest
     if (pg >= npages) return;
     const PqPage P = pages[pg];
     if (P.kind == 2) return;  // the dictionary page itself holds no rows
-    const uint8_t *src = raw + P.raw_off;
+    const uint8_t *src = (P.compressed ? raw : chunk) + P.raw_off;
     const int nv = P.num_values;
     int64_t vpos = 0;  // offset of the PLAIN values inside the page
     const uint8_t *lv = nullptr;
     int64_t lv_end = 0;
-    if (optional) {
+    if (optional && P.v2) {  // levels sit uncompressed in the chunk, without a length prefix
+        lv = chunk + P.lv_off;
+        lv_end = P.lv_len;
+    } else if (optional) {
         const uint32_t lbytes = (uint32_t)src[0] | ((uint32_t)src[1] << 8) | ((uint32_t)src[2] << 16) | ((uint32_t)src[3] << 24);
         if ((int64_t)lbytes + 4 > P.raw_size) { if (lane == 0) atomicOr(&status[0], 2u); return; }
         lv = src + 4;
@@ -249,7 +259,7 @@ __global__ __launch_bounds__(256) void page_scatter_kernel(const uint8_t *__rest
                     if (P.kind == 1) {  // the vi-th index of the page (expanded by dict_indices_kernel) -> the chunk's dictionary
                         const uint32_t ix = indices[P.idx_off + vi];
                         if (ix < (uint32_t)P.dict_count) {
-                            const uintptr_t addr = reinterpret_cast<uintptr_t>(raw + P.dict_off + (int64_t)ix * 8);  // (a stored dictionary sits at any byte offset)
+                            const uintptr_t addr = reinterpret_cast<uintptr_t>((P.dict_in_raw ? raw : chunk) + P.dict_off + (int64_t)ix * 8);  // (a stored dictionary sits at any byte offset)
                             const uint64_t *al = reinterpret_cast<const uint64_t *>(addr & ~(uintptr_t)7);
                             const int shb = (int)(addr & 7) * 8;
                             v = shb ? ((al[0] >> shb) | (al[1] << (64 - shb))) : al[0];
@@ -289,11 +299,10 @@ int launch_parquet_decode(Ctx *c, const uint8_t *chunk, const PqPage *pages, int
                           unsigned long long *valid_count, uint32_t *status) {
     if (npages <= 0) return 0;
     const unsigned grid = (unsigned)((npages + 3) / 4);
-    const uint8_t *src = any_compressed ? raw : chunk;
     if (any_compressed) hipLaunchKernelGGL(snappy_pages_kernel, dim3(grid), dim3(256), 0, c->stream, chunk, pages, npages, raw, status);
-    if (any_dict) hipLaunchKernelGGL(dict_indices_kernel, dim3(grid), dim3(256), 0, c->stream, src, pages, npages, optional, indices, status);
-    hipLaunchKernelGGL(page_scatter_kernel, dim3(grid), dim3(256), 0, c->stream, src, pages, npages, optional, indices, out_values, out_valid,
-                       valid_count, status);
+    if (any_dict) hipLaunchKernelGGL(dict_indices_kernel, dim3(grid), dim3(256), 0, c->stream, raw, chunk, pages, npages, optional, indices, status);
+    hipLaunchKernelGGL(page_scatter_kernel, dim3(grid), dim3(256), 0, c->stream, raw, chunk, pages, npages, optional, indices, out_values,
+                       out_valid, valid_count, status);
     BG_HIP(hipGetLastError());
     return 0;
 }

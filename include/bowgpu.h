@@ -292,7 +292,7 @@ int bowgpu_is_col_sorted(const bowgpu_col *col, int32_t *sorted);
  * decodes on the device: the column's compressed pages are uploaded as they lie in the file and decompressed (Snappy), their
  * definition levels turned into an Arrow validity bitmap and their PLAIN values scattered to row slots by HIP kernels.
  * Read: flat schemas, OPTIONAL / REQUIRED columns, UNCOMPRESSED / SNAPPY, PLAIN and dictionary-encoded values (PLAIN_DICTIONARY /
- * RLE_DICTIONARY, with PLAIN fall-back pages), RLE definition levels, data page v1 - what the reference writes
+ * RLE_DICTIONARY, with PLAIN fall-back pages), RLE definition levels, data page v1 and v2 - what the reference writes
  * (bowparquet.go:326-338) and what pyarrow / pandas write by default.  Anything else: BOWGPU_ERR_UNSUPPORTED. */
 typedef struct bowgpu_parquet bowgpu_parquet;
 int bowgpu_parquet_open(const char *path, bowgpu_parquet **handle);
