@@ -19,7 +19,7 @@ TYPE_NAMES = {"float64": FLOAT64, "int64": INT64, "bool": BOOLEAN, "utf8": STRIN
 AGG = {
     "WindowStart": 0, "Sum": 1, "ArithmeticMean": 2, "Min": 3, "Max": 4, "Count": 5, "First": 6,
     "Last": 7, "IntegralStep": 8, "IntegralTrapezoid": 9, "WeightedAverageStep": 10,
-    "WeightedAverageLinear": 11, "NumRows": 12,
+    "WeightedAverageLinear": 11, "NumRows": 12, "Mode": 13,
 }
 INTERP = {"WindowStart": 0, "Linear": 1, "StepPrevious": 2, "None": 3, "Const": 4}
 

@@ -397,6 +397,7 @@ int kind_type(int kind) {
     case BOWGPU_AGG_COUNT: return BOWGPU_INT64;                      // count.go:9
     case BOWGPU_AGG_FIRST:
     case BOWGPU_AGG_LAST: return BOWGPU_INPUT_DEPENDENT;             // firstlast.go:9,:24
+    case BOWGPU_AGG_MODE: return BOWGPU_INPUT_DEPENDENT;             // mode.go:9
     default: return BOWGPU_FLOAT64;
     }
 }
@@ -851,9 +852,98 @@ static int job_finish(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs
     return 0;
 }
 
+// aggregation.Mode outputs (mode.go:8-32): not a streaming reducer, so they run apart from the tile kernels, over the
+// windows' row ranges (an inclusive window reaches them without its extra row: window.go:23-31, aggregation.go:207-211)
+static int run_modes(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t ts_col, const Plan &plan, const bowgpu_agg *aggs,
+                     int32_t naggs, bowgpu_out *outs, int inclusive, int64_t *long_windows) {
+    const bowgpu_col *tsc = &cols[ts_col];
+    const int64_t n = tsc->length, W = plan.W;
+    for (int i = 0; i < ncols; i++)
+        if (cols[i].length != n) return fail(BOWGPU_ERR_ARG, "column %d has %lld rows, interval column has %lld", i, (long long)cols[i].length, (long long)n);
+    if (tsc->validity && tsc->null_count != 0) {
+        DevCol probe;
+        BG_TRY(devcol_prepare(c, tsc, &probe, false, true));
+        if (probe.null_count > 0)
+            return fail(BOWGPU_ERR_TS_NULLS, "interval column has %lld nulls: outside the device path", (long long)probe.null_count);
+    }
+    DevCol dts;
+    DevBuf first_idx;
+    if (W > 0) {
+        bowgpu_col t = *tsc;
+        t.validity = nullptr;
+        t.null_count = 0;
+        BG_TRY(devcol_prepare(c, &t, &dts, true, false));
+        BG_TRY(first_idx.alloc((size_t)(W + 1) * 8));
+        void *dscr;
+        BG_TRY(ctx_scratch(c, 8192, &dscr));
+        uint32_t *status = reinterpret_cast<uint32_t *>(dscr);
+        BG_HIP(hipMemsetAsync(status, 0, 64, c->stream));
+        BG_TRY(launch_window_first_rows(c, reinterpret_cast<const int64_t *>(dts.values), n, plan, reinterpret_cast<int64_t *>(first_idx.p), status));
+        uint32_t hstat[4] = {0, 0, 0, 0};
+        BG_HIP(hipMemcpyAsync(hstat, status, 16, hipMemcpyDeviceToHost, c->stream));
+        BG_HIP(hipStreamSynchronize(c->stream));
+        if (hstat[0]) return fail(BOWGPU_ERR_TS_UNSORTED, "interval column is not ascending: outside the device path");
+    }
+    for (int i = 0; i < naggs; i++) {
+        if (aggs[i].kind != BOWGPU_AGG_MODE) continue;
+        const int col = aggs[i].col;
+        DevCol dc;
+        const void *values = dts.values;
+        const uint32_t *vbits = nullptr;
+        int64_t vbit0 = 0;
+        if (col != ts_col && W > 0) {
+            BG_TRY(devcol_prepare(c, &cols[col], &dc, true, true));
+            values = dc.values; vbits = dc.vbits; vbit0 = dc.vbit0;
+        }
+        DevOut d;
+        BG_TRY(devout_prepare(c, &outs[i], W, &d, kPoolMode));
+        int64_t nulls = 0;
+        if (W > 0) {
+            const size_t vb = (size_t)((W + 7) >> 3);
+            BG_HIP(hipMemsetAsync(d.validity, 0, ((vb + 3) & ~(size_t)3) + 4, c->stream));
+            int64_t n_mid = 0, n_long = 0;
+            BG_TRY(launch_mode(c, reinterpret_cast<const int64_t *>(dts.values), reinterpret_cast<const int64_t *>(first_idx.p), n, plan.s0, plan.interval, W,
+                               plan.s0 > plan.first_ts ? 1 : 0, inclusive, values, vbits, vbit0, cols[col].type == BOWGPU_INT64, &aggs[i], d.values,
+                               reinterpret_cast<uint32_t *>(d.validity), &n_mid, &n_long));
+            if (long_windows) *long_windows += n_mid + n_long;
+            void *dscr;
+            BG_TRY(ctx_scratch(c, 8192, &dscr));
+            uint64_t *dcnt = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(dscr) + 1024);
+            uint64_t hcnt = 0;
+            BG_TRY(launch_popcount(c, reinterpret_cast<const uint32_t *>(d.validity), 0, W, dcnt));
+            BG_HIP(hipMemcpyAsync(&hcnt, dcnt, 8, hipMemcpyDeviceToHost, c->stream));
+            BG_HIP(hipStreamSynchronize(c->stream));
+            nulls = W - (int64_t)hcnt;
+        }
+        BG_TRY(devout_finish(c, &d, W, cols[col].type, nulls));
+        BG_HIP(hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
 static int run_aggregate(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t ts_col, const Plan &plan,
                          int inclusive, const bowgpu_agg *aggs, int32_t naggs, bowgpu_out *outs,
                          int64_t wid_base, int64_t W, int64_t *long_windows, double *kernel_ms) {
+    int n_mode = 0;
+    for (int i = 0; i < naggs; i++) n_mode += aggs[i].kind == BOWGPU_AGG_MODE;
+    if (n_mode > 0) {
+        if (wid_base != 0 || W != plan.W) return fail(BOWGPU_ERR_UNSUPPORTED, "Mode runs on unsharded calls only");
+        // the streaming reducers first, as a call of their own; then each Mode output
+        std::vector<bowgpu_agg> rest;
+        std::vector<bowgpu_out> rest_outs;
+        std::vector<int> at;
+        for (int i = 0; i < naggs; i++)
+            if (aggs[i].kind != BOWGPU_AGG_MODE) { rest.push_back(aggs[i]); rest_outs.push_back(outs[i]); at.push_back(i); }
+        if (long_windows) *long_windows = 0;
+        if (kernel_ms) *kernel_ms = 0;
+        if (!rest.empty()) {
+            AggJob job;
+            BG_TRY(job_build(c, cols, ncols, ts_col, plan, inclusive, rest.data(), (int32_t)rest.size(), rest_outs.data(), 0, W, true, &job));
+            BG_TRY(job_run(c, &job, rest.data(), (int32_t)rest.size(), long_windows, kernel_ms, true, &plan, true));
+            for (size_t j = 0; j < at.size(); j++) outs[at[j]] = rest_outs[j];
+        }
+        return run_modes(c, cols, ncols, ts_col, plan, aggs, naggs, outs, inclusive, long_windows);
+    }
     AggJob job;
     BG_TRY(job_build(c, cols, ncols, ts_col, plan, inclusive, aggs, naggs, outs, wid_base, W, wid_base == 0, &job));
     BG_TRY(job_run(c, &job, aggs, naggs, long_windows, kernel_ms, true, &plan, true));
@@ -1074,6 +1164,8 @@ static int shard_check(const bowgpu_col *cols, int32_t ncols, const bowgpu_agg *
                        const bowgpu_options *o) {
     (void)o;
     for (int i = 0; i < naggs; i++) {
+        // a window cut by a shard boundary needs all its rows in one place: Mode has no constant-size partial state
+        if (aggs[i].kind == BOWGPU_AGG_MODE) return fail(BOWGPU_ERR_UNSUPPORTED, "sharded aggregate: Mode is not a mergeable reducer");
         if (outs[i].residency != BOWGPU_DEVICE) return fail(BOWGPU_ERR_UNSUPPORTED, "sharded aggregate: outputs must be device-resident");
     }
     for (int i = 0; i < ncols; i++)

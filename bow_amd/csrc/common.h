@@ -231,6 +231,12 @@ int launch_long_windows_v2(Ctx *c, const AggParams &p, const LongListStarts *sta
 int launch_fix_tail_bits(Ctx *c, uint8_t *bitmap, int64_t nbits);
 int launch_popcount(Ctx *c, const uint32_t *words, int64_t bit0, int64_t nbits, uint64_t *d_count);
 
+// mode.hip: one aggregation.Mode output over the windows whose first rows are first_idx[0 .. W]
+int launch_mode(Ctx *c, const int64_t *ts, const int64_t *first_idx, int64_t n, int64_t s0, int64_t interval, int64_t W, int pre_rows,
+                int inclusive, const void *values,
+                const uint32_t *vbits, int64_t vbit0, int is_int, const bowgpu_agg *agg, void *out_values, uint32_t *out_valid,
+                int64_t *n_mid, int64_t *n_long);
+
 // shard.hip
 int launch_range_state(Ctx *c, const AggParams &p, int mode, uint64_t wid, const bowgpu_carry_state *d_seeds,
                        bowgpu_carry_state *d_states_out, const bowgpu_next_row *d_next = nullptr);
@@ -252,6 +258,7 @@ size_t stats_size();
 // word-aligned whatever the Arrow offset) the nearest valid ROW before the block and after it.  Bounds every
 // previous/next-valid lookup to one block of words + one table read, however long the runs of nulls are.
 constexpr int kNbrBlockBits = 4096;
+constexpr int kPoolMode = 17;    // aggregation.Mode: its output's validity working copy
 constexpr int kPoolShard = 19;   // shard stitch: seed / merged states and the next shard's first row
 constexpr int kPoolInterp = 20;  // context pool slots 20..30: tile counts, their scan, scan sums, one neighbour index per column
 struct NbrIndex {

@@ -536,6 +536,28 @@ int bowgpu_aggregate_whole(const bowgpu_col *cols, int32_t ncols, int32_t ts_col
     BG_TRY(oneb.alloc(64 + (size_t)naggs));
     std::vector<DevCol> dcols(ncols);
     std::vector<char> done(naggs, 0);
+    // Mode (mode.go:8-32) over the one window [0, n): mode.hip, not the streaming partial states
+    for (int i = 0; i < naggs; i++) {
+        if (aggs[i].kind != BOWGPU_AGG_MODE) continue;
+        done[i] = 1;
+        const int col = aggs[i].col;
+        DevCol &dc = dcols[col];
+        if (dc.values == nullptr) {
+            if (col == ts_col) { dc.values = dts.values; dc.length = n; dc.type = BOWGPU_INT64; }
+            else BG_TRY(devcol_prepare(c, &cols[col], &dc, true, true));
+        }
+        DevBuf fi;
+        BG_TRY(fi.alloc(64));
+        const int64_t bounds[2] = {0, n};
+        BG_HIP(hipMemcpyAsync(fi.p, bounds, 16, hipMemcpyHostToDevice, c->stream));
+        BG_HIP(hipMemsetAsync(reinterpret_cast<char *>(fi.p) + 16, 0, 8, c->stream));
+        uint32_t *word = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(fi.p) + 16);
+        int64_t n_mid = 0, n_long = 0;
+        BG_TRY(launch_mode(c, reinterpret_cast<const int64_t *>(dts.values), reinterpret_cast<const int64_t *>(fi.p), n, 0, 1, 1, 0, 0, dc.values, dc.vbits,
+                           dc.vbit0, cols[col].type == BOWGPU_INT64, &aggs[i], reinterpret_cast<uint64_t *>(onev.p) + i, word, &n_mid, &n_long));
+        BG_HIP(hipMemcpyAsync(reinterpret_cast<uint8_t *>(oneb.p) + i, word, 1, hipMemcpyDeviceToDevice, c->stream));
+        BG_HIP(hipStreamSynchronize(c->stream));
+    }
     for (int i = 0; i < naggs; i++) {
         if (done[i]) continue;
         // one pass per distinct input column: the partial state holds what every reducer needs
@@ -556,7 +578,7 @@ int bowgpu_aggregate_whole(const bowgpu_col *cols, int32_t ncols, int32_t ts_col
         P.partials = partials.p; P.chunk = chunk;
         BG_TRY(whole_run(c, &P, nblocks));
         for (int j = i; j < naggs; j++) {
-            if (aggs[j].col != col) continue;
+            if (aggs[j].col != col || done[j]) continue;
             done[j] = 1;
             WholeFinalH F;
             memset(&F, 0, sizeof F);

@@ -1,0 +1,318 @@
+// mode.hip — aggregation.Mode on the device (reference rolling/aggregation/mode.go:8-32).
+//
+// The reference walks a window's rows in order, counts each non-nil value in a map[interface{}]int and keeps the value
+// whose count first exceeds every count seen so far.  Restated without the map: with nb(i) = #{valid j <= i : v_j == v_i}
+// (1 for a NaN: a NaN map key never matches) and M = max nb, the result is the value of the FIRST row with nb(i) == M -
+// counts grow by one, so the running maximum reaches M exactly there.  Key equality is Go's == on the dynamic type:
+// Int64 compares bits, Float64 compares numerically (-0 == +0; the value returned is the row's own).
+//
+// Mode is not a streaming reducer (no constant-size state), so it does not ride in the tile kernels; it runs over the
+// window row ranges (first row of every window: interp_fill.hip window_first_rows_kernel) in three size classes:
+//   <= 32 rows     mode_small_kernel : one lane per window, validity as a 32-bit mask, O(n^2) compares from L1/L2
+//   <= kModeMid    mode_mid_kernel   : one workgroup per window, valid values compacted in row order into LDS,
+//                                      nb(i) by a broadcast scan of LDS, (count, first row) reduced across the workgroup
+//   longer         mode_long_*       : valid rows selected, keyed (canonical bits; NaNs get unique keys), radix-sorted
+//                                      stably with their row number (hipCUB), run lengths by binary search from each run head,
+//                                      (length, row of the run's M-th element) reduced with a 64-bit atomic max
+// HBM-bound / latency-bound integer work: no MFMA anywhere.
+#include <hipcub/hipcub.hpp>
+
+#include "agg_device.h"
+#include "bitmap_device.h"
+
+namespace bowgpu {
+
+namespace {
+
+constexpr int kModeSmall = 32;
+constexpr int kModeMid = 7680;  // 60 KB of LDS values
+
+struct ModeParams {
+    const uint64_t *values;
+    const uint32_t *vbits;  // nullptr: no nulls
+    int64_t vbit0;
+    const int64_t *ts;
+    const int64_t *first_idx;  // [W + 1] first row of every window
+    int64_t s0, W, n, interval;
+    int32_t pre_rows, is_int;
+    int32_t nfac, inclusive;
+    double fac[BOWGPU_MAX_FACTORS];
+    uint64_t *out_values;
+    uint32_t *out_valid;
+    uint32_t *counters;  // [0] = mid-size windows queued, [1] = long windows queued
+    int64_t *mid_queue, *long_queue;
+};
+
+__device__ __forceinline__ bool mode_eq(uint64_t a, uint64_t b, bool is_int) {
+    return is_int ? a == b : __longlong_as_double((long long)a) == __longlong_as_double((long long)b);
+}
+
+__device__ __forceinline__ void window_rows(const ModeParams &p, int64_t k, int64_t *a, int64_t *b) {
+    int64_t lo = p.first_idx[k], hi = p.first_idx[k + 1];
+    // rows below s0 ride in window 0, but alone they do not make a window (rolling.go:177-239) - unless the call is inclusive
+    // and the next window's first row sits exactly on its start: that row makes window 0 exist, and once it is dropped again
+    // (Window.UnsetInclusive, window.go:23-31) the rows below s0 are what Mode sees
+    if (k == 0 && p.pre_rows && !(hi > 0 && p.ts[hi - 1] >= p.s0) && !(p.inclusive && hi < p.n && p.ts[hi] == p.s0 + p.interval)) hi = lo;
+    *a = lo;
+    *b = hi;
+}
+
+__device__ __forceinline__ bool row_valid(const ModeParams &p, int64_t row) { return !p.vbits || bit_at(p.vbits, p.vbit0, row); }
+
+__device__ __forceinline__ void store_result(const ModeParams &p, int64_t k, uint64_t v) {
+    p.out_values[k] = apply_factors(v, p.is_int != 0, p.nfac, p.fac);
+    atomicOr(&p.out_valid[k >> 5], 1u << (k & 31));
+}
+
+__global__ __launch_bounds__(256) void mode_small_kernel(ModeParams p) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    bool have = false;
+    uint64_t res = 0;
+    if (k < p.W) {
+        int64_t a, b;
+        window_rows(p, k, &a, &b);
+        const int64_t n = b - a;
+        if (n > kModeSmall) {
+            if (n <= kModeMid) p.mid_queue[atomicAdd(&p.counters[0], 1u)] = k;
+            else p.long_queue[atomicAdd(&p.counters[1], 1u)] = k;
+        } else if (n > 0) {
+            uint32_t mask = 0;
+            for (int i = 0; i < (int)n; i++) mask |= row_valid(p, a + i) ? (1u << i) : 0u;
+            int best = 0;
+            const bool is_int = p.is_int != 0;
+            for (int i = 0; i < (int)n; i++) {
+                if (!((mask >> i) & 1u)) continue;
+                const uint64_t v = p.values[a + i];
+                int nb = 0;
+                for (int j = 0; j < i; j++) nb += (((mask >> j) & 1u) && mode_eq(p.values[a + j], v, is_int)) ? 1 : 0;
+                nb += 1;  // this row (a NaN: its own fresh key)
+                if (nb > best) { best = nb; res = v; }
+            }
+            have = best > 0;
+        }
+        if (n <= kModeSmall) p.out_values[k] = have ? apply_factors(res, p.is_int != 0, p.nfac, p.fac) : 0ull;  // nil slots hold 0 (bowbuffer.go:22-40)
+    }
+    // validity words of this wavefront's 64 windows (queued windows set their bit later, atomically)
+    const uint64_t m = __ballot(have);
+    const int lane = threadIdx.x & 63;
+    const int64_t k0 = k - lane;
+    if (lane == 0 && k0 < p.W) p.out_valid[k0 >> 5] = (uint32_t)m;
+    if (lane == 32 && k0 + 32 < p.W) p.out_valid[(k0 >> 5) + 1] = (uint32_t)(m >> 32);
+}
+
+__global__ __launch_bounds__(256) void mode_mid_kernel(ModeParams p) {
+    __shared__ uint64_t sv[kModeMid];
+    __shared__ uint32_t wtot[4];
+    __shared__ unsigned long long sbest[4];
+    const int64_t k = p.mid_queue[blockIdx.x];
+    int64_t a, b;
+    window_rows(p, k, &a, &b);
+    const int n = (int)(b - a);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool is_int = p.is_int != 0;
+    // valid values, compacted in row order
+    int m = 0;
+    for (int c0 = 0; c0 < n; c0 += 256) {
+        const int r = c0 + tid;
+        const bool ok = r < n && row_valid(p, a + r);
+        const uint64_t v = ok ? p.values[a + r] : 0ull;
+        const uint64_t bal = __ballot(ok);
+        if (lane == 0) wtot[wave] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        int off = m;
+        for (int w = 0; w < wave; w++) off += (int)wtot[w];
+        if (ok) sv[off + __popcll(bal & ((1ull << lane) - 1ull))] = v;
+        m += (int)(wtot[0] + wtot[1] + wtot[2] + wtot[3]);
+        __syncthreads();
+    }
+    // (count, earliest row): counts first, then the smaller row wins
+    unsigned long long best = 0;
+    for (int i = tid; i < m; i += 256) {
+        const uint64_t v = sv[i];
+        uint32_t nb = 1;
+        for (int j = 0; j < i; j++) nb += mode_eq(sv[j], v, is_int) ? 1u : 0u;
+        const unsigned long long cand = ((unsigned long long)nb << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)i);
+        best = cand > best ? cand : best;
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned long long o = __shfl_down(best, d, 64);
+        best = o > best ? o : best;
+    }
+    if (lane == 0) sbest[wave] = best;
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; w++) best = sbest[w] > best ? sbest[w] : best;
+        if (m > 0) store_result(p, k, sv[0xFFFFFFFFu - (uint32_t)best]);
+        else p.out_values[k] = 0ull;
+    }
+}
+
+// ---- long windows: sort path -----------------------------------------------------------------------------------------
+struct RowValid {
+    const uint32_t *vbits;
+    int64_t bit0;  // bit of the window's first row
+    __host__ __device__ __forceinline__ bool operator()(uint32_t r) const { return (vbits[(bit0 + r) >> 5] >> ((bit0 + r) & 31)) & 1u; }
+};
+
+// keys[q] of the q-th valid row of the window: equal keys <=> equal map keys
+__global__ __launch_bounds__(256) void mode_long_keys_kernel(const uint64_t *values, int64_t a, const uint32_t *rows, int64_t m, int is_int,
+                                                             uint64_t *keys, uint32_t *rows_out) {
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < m; q += (int64_t)gridDim.x * 256) {
+        const uint32_t r = rows ? rows[q] : (uint32_t)q;
+        uint64_t v = values[a + r];
+        if (!is_int) {
+            const double x = __longlong_as_double((long long)v);
+            if (x != x) v = 0xFFF8000000000000ull | (uint64_t)q;  // every NaN is its own key (q < 2^32)
+            else if (x == 0.0) v = 0ull;                           // -0 == +0
+        }
+        keys[q] = v;
+        rows_out[q] = r;
+    }
+}
+
+// from every run head: the run's length (binary search for its end) and the row that completes it
+__global__ __launch_bounds__(256) void mode_long_runs_kernel(const uint64_t *keys, const uint32_t *rows, int64_t m, unsigned long long *best) {
+    unsigned long long mine = 0;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < m; q += (int64_t)gridDim.x * 256) {
+        const uint64_t key = keys[q];
+        if (q > 0 && keys[q - 1] == key) continue;
+        int64_t lo = q + 1, hi = m;  // first index in (q, m] whose key differs
+        while (lo < hi) {
+            const int64_t mid = lo + ((hi - lo) >> 1);
+            if (keys[mid] == key) lo = mid + 1;
+            else hi = mid;
+        }
+        const unsigned long long cand = ((unsigned long long)(lo - q) << 32) | (unsigned long long)(0xFFFFFFFFu - rows[lo - 1]);
+        mine = cand > mine ? cand : mine;
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned long long o = __shfl_down(mine, d, 64);
+        mine = o > mine ? o : mine;
+    }
+    if ((threadIdx.x & 63) == 0 && mine) atomicMax(best, mine);
+}
+
+__global__ void mode_long_store_kernel(ModeParams p, int64_t k, int64_t a, const unsigned long long *best) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const unsigned long long bv = *best;
+    if (bv) store_result(p, k, p.values[a + (int64_t)(0xFFFFFFFFu - (uint32_t)bv)]);
+    else p.out_values[k] = 0ull;
+}
+
+__global__ void mode_fetch_bounds_kernel(ModeParams p, int64_t nq, int64_t *bounds) {
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t k = p.long_queue[q];
+        int64_t a, b;
+        window_rows(p, k, &a, &b);
+        bounds[3 * q] = k; bounds[3 * q + 1] = a; bounds[3 * q + 2] = b;
+    }
+}
+
+int mode_long_window(Ctx *c, const ModeParams &P, int64_t k, int64_t a, int64_t b) {
+    const int64_t n = b - a;
+    if (n >= 0xFFFFFFF0ll) return fail(BOWGPU_ERR_UNSUPPORTED, "Mode over a window of %lld rows (at most 2^32 rows per window on the device)", (long long)n);
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    DevBuf d_small;
+    BG_TRY(d_small.alloc(512));
+    int64_t *d_m = reinterpret_cast<int64_t *>(d_small.p);
+    unsigned long long *d_best = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(d_small.p) + 256);
+    BG_HIP(hipMemsetAsync(d_small.p, 0, 512, c->stream));
+    int64_t m = n;
+    DevBuf d_rows;
+    if (P.vbits) {  // the window's valid rows, ascending
+        BG_TRY(d_rows.alloc(up((size_t)n * 4)));
+        hipcub::CountingInputIterator<uint32_t> rows_in(0u);
+        RowValid pred{P.vbits, P.vbit0 + a};
+        size_t tmp_bytes = 0;
+        BG_HIP(hipcub::DeviceSelect::If(nullptr, tmp_bytes, rows_in, reinterpret_cast<uint32_t *>(d_rows.p), d_m, n, pred, c->stream));
+        DevBuf tmp;
+        BG_TRY(tmp.alloc(tmp_bytes + 256));
+        BG_HIP(hipcub::DeviceSelect::If(tmp.p, tmp_bytes, rows_in, reinterpret_cast<uint32_t *>(d_rows.p), d_m, n, pred, c->stream));
+        BG_HIP(hipMemcpyAsync(&m, d_m, 8, hipMemcpyDeviceToHost, c->stream));
+        BG_HIP(hipStreamSynchronize(c->stream));
+    }
+    if (m > 0) {
+        DevBuf d_keys, d_keys2, d_r1, d_r2, tmp;
+        BG_TRY(d_keys.alloc(up((size_t)m * 8)));
+        BG_TRY(d_keys2.alloc(up((size_t)m * 8)));
+        BG_TRY(d_r1.alloc(up((size_t)m * 4)));
+        BG_TRY(d_r2.alloc(up((size_t)m * 4)));
+        int64_t g = (m + 255) / 256;
+        if (g > 256 * 32) g = 256 * 32;
+        hipLaunchKernelGGL(mode_long_keys_kernel, dim3((unsigned)g), dim3(256), 0, c->stream, P.values, a,
+                           P.vbits ? reinterpret_cast<const uint32_t *>(d_rows.p) : nullptr, m, P.is_int,
+                           reinterpret_cast<uint64_t *>(d_keys.p), reinterpret_cast<uint32_t *>(d_r1.p));
+        size_t tmp_bytes = 0;
+        BG_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, reinterpret_cast<const uint64_t *>(d_keys.p), reinterpret_cast<uint64_t *>(d_keys2.p),
+                                                  reinterpret_cast<const uint32_t *>(d_r1.p), reinterpret_cast<uint32_t *>(d_r2.p), m, 0, 64, c->stream));
+        BG_TRY(tmp.alloc(tmp_bytes + 256));
+        BG_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, reinterpret_cast<const uint64_t *>(d_keys.p), reinterpret_cast<uint64_t *>(d_keys2.p),
+                                                  reinterpret_cast<const uint32_t *>(d_r1.p), reinterpret_cast<uint32_t *>(d_r2.p), m, 0, 64, c->stream));
+        hipLaunchKernelGGL(mode_long_runs_kernel, dim3((unsigned)g), dim3(256), 0, c->stream, reinterpret_cast<const uint64_t *>(d_keys2.p),
+                           reinterpret_cast<const uint32_t *>(d_r2.p), m, d_best);
+        hipLaunchKernelGGL(mode_long_store_kernel, dim3(1), dim3(64), 0, c->stream, P, k, a, d_best);
+        BG_HIP(hipGetLastError());
+        BG_HIP(hipStreamSynchronize(c->stream));  // the DevBufs above go back to the cache here
+    } else {
+        hipLaunchKernelGGL(mode_long_store_kernel, dim3(1), dim3(64), 0, c->stream, P, k, a, d_best);
+        BG_HIP(hipGetLastError());
+        BG_HIP(hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
+}  // namespace
+
+// One Mode output over the windows whose first rows are first_idx[0 .. W] (device).  out_valid must be zeroed words.
+int launch_mode(Ctx *c, const int64_t *ts, const int64_t *first_idx, int64_t n, int64_t s0, int64_t interval, int64_t W, int pre_rows,
+                int inclusive, const void *values,
+                const uint32_t *vbits, int64_t vbit0, int is_int, const bowgpu_agg *agg, void *out_values, uint32_t *out_valid,
+                int64_t *n_mid, int64_t *n_long) {
+    *n_mid = 0;
+    *n_long = 0;
+    if (W <= 0) return 0;
+    ModeParams P;
+    memset(&P, 0, sizeof P);
+    P.values = reinterpret_cast<const uint64_t *>(values);
+    P.vbits = vbits; P.vbit0 = vbit0;
+    P.ts = ts; P.first_idx = first_idx; P.s0 = s0; P.W = W; P.n = n; P.interval = interval;
+    P.pre_rows = pre_rows; P.is_int = is_int; P.inclusive = inclusive;
+    P.nfac = agg->n_factors;
+    for (int f = 0; f < agg->n_factors && f < BOWGPU_MAX_FACTORS; f++) P.fac[f] = agg->factors[f];
+    P.out_values = reinterpret_cast<uint64_t *>(out_values);
+    P.out_valid = out_valid;
+    // queues: a queued window has > kModeSmall rows
+    const int64_t qcap = n / (kModeSmall + 1) + 2;
+    DevBuf dq;
+    BG_TRY(dq.alloc(256 + (size_t)qcap * 16));
+    P.counters = reinterpret_cast<uint32_t *>(dq.p);
+    P.mid_queue = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(dq.p) + 256);
+    P.long_queue = P.mid_queue + qcap;
+    BG_HIP(hipMemsetAsync(P.counters, 0, 256, c->stream));
+    hipLaunchKernelGGL(mode_small_kernel, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, c->stream, P);
+    BG_HIP(hipGetLastError());
+    uint32_t hcount[2] = {0, 0};
+    BG_HIP(hipMemcpyAsync(hcount, P.counters, 8, hipMemcpyDeviceToHost, c->stream));
+    BG_HIP(hipStreamSynchronize(c->stream));
+    *n_mid = hcount[0];
+    *n_long = hcount[1];
+    if (hcount[0] > 0) {
+        hipLaunchKernelGGL(mode_mid_kernel, dim3(hcount[0]), dim3(256), 0, c->stream, P);
+        BG_HIP(hipGetLastError());
+    }
+    if (hcount[1] > 0) {
+        DevBuf db;
+        BG_TRY(db.alloc((size_t)hcount[1] * 24));
+        hipLaunchKernelGGL(mode_fetch_bounds_kernel, dim3(64), dim3(256), 0, c->stream, P, (int64_t)hcount[1], reinterpret_cast<int64_t *>(db.p));
+        BG_HIP(hipGetLastError());
+        std::string hb((size_t)hcount[1] * 24, '\0');
+        BG_HIP(hipMemcpyAsync(&hb[0], db.p, hb.size(), hipMemcpyDeviceToHost, c->stream));
+        BG_HIP(hipStreamSynchronize(c->stream));
+        const int64_t *bounds = reinterpret_cast<const int64_t *>(hb.data());
+        for (uint32_t q = 0; q < hcount[1]; q++) BG_TRY(mode_long_window(c, P, bounds[3 * q], bounds[3 * q + 1], bounds[3 * q + 2]));
+    }
+    BG_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+}  // namespace bowgpu

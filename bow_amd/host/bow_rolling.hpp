@@ -5,7 +5,7 @@
 //   bow::Bow / Series / Type                   <- bow.go, bowseries.go, bowtypes.go
 //   bow::rolling::IntervalRolling, Rolling, Options, Window, ColAggregation, NewColAggregation,
 //        ColInterpolation, NewColInterpolation  <- rolling/rolling.go, window.go, aggregation.go, interpolation.go
-//   bow::rolling::aggregation::{WindowStart,Sum,ArithmeticMean,Min,Max,Count,First,Last,IntegralStep,
+//   bow::rolling::aggregation::{WindowStart,Sum,ArithmeticMean,Min,Max,Count,First,Last,Mode,IntegralStep,
 //        IntegralTrapezoid,WeightedAverageStep,WeightedAverageLinear}   <- rolling/aggregation/*.go
 //   bow::rolling::interpolation::{WindowStart,Linear,StepPrevious,None} <- rolling/interpolation/*.go
 //   bow::rolling::transformation::Factor                                 <- rolling/transformation/factor.go
@@ -802,6 +802,7 @@ inline ColAggregation Max(const std::string &col) { return detail2::builtin(col,
 inline ColAggregation Count(const std::string &col) { return detail2::builtin(col, false, Int64, BOWGPU_AGG_COUNT); }
 inline ColAggregation First(const std::string &col) { return detail2::builtin(col, false, InputDependent, BOWGPU_AGG_FIRST); }
 inline ColAggregation Last(const std::string &col) { return detail2::builtin(col, false, InputDependent, BOWGPU_AGG_LAST); }
+inline ColAggregation Mode(const std::string &col) { return detail2::builtin(col, false, InputDependent, BOWGPU_AGG_MODE); }  // mode.go:8-32
 inline ColAggregation IntegralStep(const std::string &col) { return detail2::builtin(col, false, Float64, BOWGPU_AGG_INTEGRAL_STEP); }
 inline ColAggregation IntegralTrapezoid(const std::string &col) { return detail2::builtin(col, true, Float64, BOWGPU_AGG_INTEGRAL_TRAPEZOID); }
 inline ColAggregation WeightedAverageStep(const std::string &col) { return detail2::builtin(col, false, Float64, BOWGPU_AGG_WAVG_STEP); }

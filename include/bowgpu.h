@@ -102,7 +102,8 @@ enum {
     BOWGPU_AGG_WAVG_STEP = 10,         /* weightedmean.go:8-20 */
     BOWGPU_AGG_WAVG_LINEAR = 11,       /* weightedmean.go:22-34, NeedInclusiveWindow */
     BOWGPU_AGG_NUM_ROWS = 12,          /* float64(w.Bow.NumRows()): the closure of aggregation_test.go:28-31 */
-    BOWGPU_AGG__COUNT = 13
+    BOWGPU_AGG_MODE = 13,              /* mode.go:8-32 (not mergeable: unsharded calls only) */
+    BOWGPU_AGG__COUNT = 14
 };
 
 #define BOWGPU_MAX_FACTORS 4

@@ -298,6 +298,7 @@ static int agg_type(int kind) {
     case ORC_AGG_COUNT: return ORC_INT64;                     /* count.go:9 */
     case ORC_AGG_FIRST:
     case ORC_AGG_LAST: return ORC_INPUT_DEPENDENT;            /* firstlast.go:9,24 */
+    case ORC_AGG_MODE: return ORC_INPUT_DEPENDENT;            /* mode.go:9 */
     default: return ORC_FLOAT64;
     }
 }
@@ -420,6 +421,26 @@ static val_t apply_agg(int kind, const orc_col_t *cols, int ts_col, int col, con
         int64_t r = view_prev_valid(&wv, col, n - 1);
         if (r == -1) return val_nil();
         return view_get_value(&wv, col, r);
+    }
+    case ORC_AGG_MODE: { /* mode.go:8-32: occurrences[v]++ per non-nil value in row order; the result is the value whose count first
+                          * exceeds every earlier count.  Map keys are interface{} values: == of the dynamic type, so for float64
+                          * NaN never equals anything (each NaN counts once) and -0 == +0; the value kept is the row's own. */
+        if (n == 0) return val_nil();
+        int64_t max = 0;
+        val_t res = val_nil();
+        for (int64_t i = 0; i < n; i++) {
+            val_t v = view_get_value(&wv, col, i);
+            if (v.tag == VAL_NIL) continue;
+            int64_t nb = 0;
+            for (int64_t j = 0; j <= i; j++) { /* occurrences[v] after this row's increment */
+                val_t u = view_get_value(&wv, col, j);
+                if (u.tag == VAL_NIL) continue;
+                if (u.tag == VAL_F64 ? (u.f == v.f) : (u.i == v.i)) nb++;
+            }
+            if (v.tag == VAL_F64 && v.f != v.f) nb = 1; /* a NaN key never matches an earlier one (nor itself above) */
+            if (nb > max) { max = nb; res = v; }
+        }
+        return res;
     }
     case ORC_AGG_INTEGRAL_TRAPEZOID: return integral_trapezoid(&wv, ts_col, col);
     case ORC_AGG_INTEGRAL_STEP: return integral_step(&wv, ts_col, col, w->last_value);

@@ -71,7 +71,8 @@ enum {
     ORC_AGG_INTEGRAL_TRAPEZOID = 9, /* integral.go:8-38 (needs inclusive window) */
     ORC_AGG_WAVG_STEP = 10,      /* weightedmean.go:8-20 */
     ORC_AGG_WAVG_LINEAR = 11,    /* weightedmean.go:22-34 (needs inclusive window) */
-    ORC_AGG_NUM_ROWS = 12        /* test-only closure float64(w.Bow.NumRows()): aggregation_test.go:28-31 */
+    ORC_AGG_NUM_ROWS = 12,       /* test-only closure float64(w.Bow.NumRows()): aggregation_test.go:28-31 */
+    ORC_AGG_MODE = 13            /* mode.go:8-32 */
 };
 
 typedef struct {

@@ -17,7 +17,7 @@ TYPE_NAMES = {"float64": FLOAT64, "int64": INT64, "bool": BOOLEAN}
 AGG = {
     "WindowStart": 0, "Sum": 1, "ArithmeticMean": 2, "Min": 3, "Max": 4, "Count": 5, "First": 6,
     "Last": 7, "IntegralStep": 8, "IntegralTrapezoid": 9, "WeightedAverageStep": 10,
-    "WeightedAverageLinear": 11, "NumRows": 12,
+    "WeightedAverageLinear": 11, "NumRows": 12, "Mode": 13,
 }
 INTERP = {"WindowStart": 0, "Linear": 1, "StepPrevious": 2, "None": 3, "Const": 4}
 
@@ -239,8 +239,13 @@ def aggregate(cols, ts_col, interval, aggs, offset=0, inclusive=False):
 def aggregate_whole(cols, ts_col, aggs):
     carr = _cols_array(cols)
     aarr = (_Agg * max(len(aggs), 1))()
+    keep = []
     for i, a in enumerate(aggs):
-        aarr[i].kind, aarr[i].col, aarr[i].n_factors = AGG[a[0]], a[1], 0
+        factors = list(a[2]) if len(a) > 2 and a[2] else []
+        fa = (C.c_double * max(len(factors), 1))(*factors)
+        keep.append(fa)
+        aarr[i].kind, aarr[i].col, aarr[i].n_factors = AGG[a[0]], a[1], len(factors)
+        aarr[i].factors = C.cast(fa, C.POINTER(C.c_double))
     outs = [OutBuf(1) for _ in aggs]
     oarr = (_Out * max(len(aggs), 1))()
     for i, o in enumerate(outs):

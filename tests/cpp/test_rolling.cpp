@@ -204,6 +204,10 @@ static void TestReducers() {
     runTestCase("Count/sparse", ag::Count, {}, sparseFloatBow(), win6({I(1), I(0), I(0), I(1), I(2), I(2)}, Int64));    // :24-42
     runTestCase("First/sparse", ag::First, {}, sparseFloatBow(), win6({F(10.), N, N, F(10.), F(10.), F(10.)}));         // firstlast_test.go:25-42
     runTestCase("Last/sparse float", ag::Last, {}, sparseFloatBow(), win6({F(10.), N, N, F(10.), F(20.), F(20.)}));     // :99-116
+    runTestCase("Mode/empty", ag::Mode, {}, emptyBow(), emptyBow());                                                    // mode_test.go:33-44
+    runTestCase("Mode/mode float", ag::Mode, {},                                                                        // mode_test.go:11-31, :45-62
+                tv({I(10), I(11), I(20), I(21), I(22), I(30), I(31), I(32), I(50), I(51)}, {F(10.), F(10.), F(42.), F(42.), F(10.), N, N, F(10.), N, N}),
+                tv({I(10), I(20), I(30), I(40), I(50)}, {F(10.), F(42.), F(10.), N, N}));
     runTestCase("IntegralStep/sparse float", ag::IntegralStep, {}, sparseFloatBow(), win6({F(100.), N, N, F(90.), F(190.), F(100.)}));  // integral_test.go:26-43
     runTestCase("IntegralStep_scaled/sparse (custom transform func)", ag::IntegralStep,                                  // integral_test.go:85-128
                 {tr::Func{[factor](Value x) -> std::pair<Value, Error> { if (!x) return {Nil(), Error()}; return {F(std::get<double>(*x) * factor), Error()}; }}},

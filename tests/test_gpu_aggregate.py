@@ -497,3 +497,86 @@ def test_simple_kernel_redo_when_ids_overflow():
     ts = np.concatenate([np.arange(0, 300), np.arange(300, 600) * 1000]).astype(np.int64)
     vals = np.arange(len(ts), dtype=np.float64)
     run_both(ts, [(vals, None)], 2, [("WindowStart", 0), ("ArithmeticMean", 1), ("Count", 1)])
+
+
+# ------------------------------------------------------------------ aggregation.Mode (mode.go:8-32)
+def _mode_values(rng, n, kind):
+    if kind == "int":
+        v = rng.integers(-3, 4, n).astype(np.int64)
+        v[rng.random(n) < 0.02] = np.iinfo(np.int64).min
+        return v
+    v = rng.integers(-2, 3, n).astype(np.float64) / 2
+    r = rng.random(n)
+    v[r < 0.05] = np.nan          # every NaN is a map key of its own
+    v[(r >= 0.05) & (r < 0.10)] = -0.0   # -0 == +0 as keys; the row's own value comes back
+    v[(r >= 0.10) & (r < 0.12)] = np.inf
+    return v
+
+
+@pytest.mark.parametrize("kind", ["float", "int"])
+@pytest.mark.parametrize("interval", [3, 10, 40, 400, 9000])
+def test_mode_against_oracle(kind, interval):
+    """ties (few distinct values), nulls, NaN / -0 keys; intervals that put windows in the lane-per-window class (<= 32 rows),
+    the workgroup class (<= 7680 rows) and mixes of both"""
+    rng = np.random.default_rng(interval * 7 + (kind == "int"))
+    n = 30_000 if interval <= 400 else 60_000
+    ts = np.cumsum(rng.integers(0, 3, n)).astype(np.int64) - 50
+    vals = _mode_values(rng, n, kind)
+    valid = rng.random(n) > 0.3
+    valid[100:300] = False         # all-null windows
+    aggs = [("WindowStart", 0), ("Mode", 1), ("Count", 1), ("Mode", 0), ("Mode", 2, [2.5]), ("ArithmeticMean", 2)]
+    outs, exp, info = run_both(ts, [(vals, valid), (vals, None)], interval, aggs, offset=1)
+    assert outs[1].type == (capi.INT64 if kind == "int" else capi.FLOAT64)
+    assert outs[3].type == capi.INT64
+
+
+def test_mode_long_windows_sort_path():
+    """windows of more than 7680 rows: select valid rows -> key -> stable radix sort -> run lengths"""
+    rng = np.random.default_rng(5)
+    n = 50_000
+    ts = np.arange(n, dtype=np.int64)
+    for kind in ("float", "int"):
+        vals = _mode_values(rng, n, kind)
+        valid = rng.random(n) > 0.2
+        valid[20_000:40_000] = rng.random(20_000) > 0.999     # a long window with a handful of valid rows
+        outs, exp, info = run_both(ts, [(vals, valid), (vals, None)], 10_000, [("WindowStart", 0), ("Mode", 1), ("Mode", 2)])
+        assert info.long_windows >= 5
+    # all values distinct: every count is 1, the first valid row wins
+    vals = rng.permutation(n).astype(np.float64)
+    valid = np.ones(n, dtype=bool)
+    valid[:7] = False
+    outs, exp, info = run_both(ts, [(vals, valid)], 25_000, [("WindowStart", 0), ("Mode", 1)])
+    assert outs[1].to_list()[0] == vals[7]
+    # no valid row at all in a long window
+    valid[:] = False
+    run_both(ts, [(vals, valid)], 25_000, [("WindowStart", 0), ("Mode", 1)])
+
+
+def test_mode_pre_rows_inclusive_and_alone():
+    """rows below s0 ride in window 0; an inclusive call (IntegralTrapezoid) hands Mode the window without its extra row;
+    Mode as the only kind of reducer of a call"""
+    rng = np.random.default_rng(11)
+    n = 5000
+    ts = (np.cumsum(rng.integers(1, 4, n)) - 3000).astype(np.int64)
+    vals = _mode_values(rng, n, "float")
+    valid = rng.random(n) > 0.25
+    run_both(ts, [(vals, valid)], 7, [("WindowStart", 0), ("Mode", 1), ("IntegralTrapezoid", 1)], offset=3)
+    run_both(ts, [(vals, valid)], 7, [("Mode", 0), ("Mode", 1)], offset=3)
+    run_both(ts, [(vals, valid)], 7, [("Mode", 0), ("Mode", 1)], offset=3, device=True)
+    run_both(ts[:0], [(vals[:0], valid[:0])], 7, [("Mode", 0), ("Mode", 1)])
+
+
+def test_mode_whole_frame():
+    rng = np.random.default_rng(3)
+    for n in (1, 20, 3000, 20_000):
+        ts = np.arange(n, dtype=np.int64)
+        vals = _mode_values(rng, n, "float")
+        valid = rng.random(n) > 0.3
+        bm = np.packbits(valid, bitorder="little")
+        ccols = [capi.Column(ts, None, capi.INT64), capi.Column(vals, bm, capi.FLOAT64, 0, n, -1)]
+        ocols = [orc.Column(ts, None, orc.INT64), orc.Column(vals, bm, orc.FLOAT64)]
+        aggs = [("Mode", 1), ("Sum", 1), ("Mode", 0), ("Mode", 1, [3.0])]
+        got = capi.aggregate_whole(ccols, 0, aggs)
+        want = orc.aggregate_whole(ocols, 0, aggs)
+        for k, g, w in zip(_names(aggs), got, want):
+            compare("whole %s n=%d" % (k, n), g, w, exact=k != "Sum", rtol=1e-11)

@@ -54,6 +54,9 @@ def rand_col(rng, n, pad):
     else:
         v = rng.integers(-(2 ** 50), 2 ** 50, tot).astype(np.int64)
         typ = capi.INT64
+    if rng.random() < 0.3:   # few distinct values: ties for Mode, equal neighbours for Min / Max / First / Last
+        small = rng.integers(-2, 3, tot)
+        v = np.where(rng.random(tot) < 0.85, small.astype(v.dtype), v)
     frac = [0.0, 0.0, 0.05, 0.3, 0.9, 1.0][int(rng.integers(0, 6))]
     if frac == 0.0 and rng.random() < 0.5:
         return v, None, typ, pad
@@ -121,6 +124,9 @@ def test_fuzz_aggregate(seed):
                 aggs.append((k, col, [float(rng.choice([0.5, -1.0, 2.0, 0.1, 1e3])) for _ in range(int(rng.integers(1, 3)))]))
             else:
                 aggs.append((k, col))
+        if n <= 5000 and rng.random() < 0.4:   # (the oracle's Mode is quadratic in the window's rows)
+            aggs.append(("Mode", int(rng.integers(0, ncols + 1))) if rng.random() < 0.7 else
+                        ("Mode", int(rng.integers(1, ncols + 1)), [float(rng.choice([0.5, -1.0, 1e3]))]))
         if inclusive and not any(a[0] in ("IntegralTrapezoid", "WeightedAverageLinear") for a in aggs):
             aggs.append(("IntegralTrapezoid", 1))
         inclusive_call = any(a[0] in ("IntegralTrapezoid", "WeightedAverageLinear") for a in aggs)
