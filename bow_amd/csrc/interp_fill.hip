@@ -148,20 +148,22 @@ __global__ __launch_bounds__(256) void col_order_kernel(const uint64_t *values, 
     if (f) atomicOr(flags, f);
 }
 
-// the value a null row i receives (bits, valid) under p.method
-__device__ __forceinline__ void fill_one(const FillParams &p, int64_t i, uint64_t *bits_io, int *valid_io) {
+// The value a null row i receives (bits, valid) under p.method.  rp / rn: its nearest valid rows (-1: none), with their
+// values pbits / nbits (and, FillLinear, the reference column's values there: pref / nref; own_ref: at row i itself).
+// kFillInt / kRefInt: the filled / the reference column is Int64 (else Float64)
+template <int kMethod, bool kFillInt, bool kRefInt>
+__device__ __forceinline__ void fill_row(const FillParams &p, int64_t i, int64_t rp, int64_t rn, uint64_t pbits, uint64_t nbits,
+                                         uint64_t pref, uint64_t nref, uint64_t own_ref, uint64_t *bits_io, int *valid_io) {
     uint64_t bits = *bits_io;
     int valid = 0;
-    const int64_t rp = p.method == BOWGPU_FILL_NEXT ? -1 : prev_valid_ix(p.fill_vbits, p.fill_vbit0, p.n, i - 1, p.nbr);
-    const int64_t rn = p.method == BOWGPU_FILL_PREVIOUS ? -1 : next_valid_ix(p.fill_vbits, p.fill_vbit0, p.n, i + 1, p.nbr);
-    if (p.method == BOWGPU_FILL_PREVIOUS) {
-        if (rp >= 0) { bits = p.fill_values[rp]; valid = 1; }          // arr.Value(fillRowIndex): bowfill.go:196-199
-    } else if (p.method == BOWGPU_FILL_NEXT) {
-        if (rn >= 0) { bits = p.fill_values[rn]; valid = 1; }
-    } else if (p.method == BOWGPU_FILL_MEAN) {
+    if (kMethod == BOWGPU_FILL_PREVIOUS) {
+        if (rp >= 0) { bits = pbits; valid = 1; }                      // arr.Value(fillRowIndex): bowfill.go:196-199
+    } else if (kMethod == BOWGPU_FILL_NEXT) {
+        if (rn >= 0) { bits = nbits; valid = 1; }
+    } else if (kMethod == BOWGPU_FILL_MEAN) {
         if (rp >= 0 && rn >= 0) {                                       // bowfill.go:145-154
-            const double m = (bits_to_f64(p.fill_values[rp], p.fill_type) + bits_to_f64(p.fill_values[rn], p.fill_type)) / 2;
-            bits = p.fill_type == BOWGPU_INT64 ? (uint64_t)go_f64_to_i64(round(m)) : (uint64_t)__double_as_longlong(m);
+            const double m = (bits_to_f64(pbits, kFillInt ? BOWGPU_INT64 : BOWGPU_FLOAT64) + bits_to_f64(nbits, kFillInt ? BOWGPU_INT64 : BOWGPU_FLOAT64)) / 2;
+            bits = kFillInt ? (uint64_t)go_f64_to_i64(round(m)) : (uint64_t)__double_as_longlong(m);
             valid = 1;
         }
     } else {                                                            // FillLinear: bowfill.go:65-97
@@ -169,17 +171,17 @@ __device__ __forceinline__ void fill_one(const FillParams &p, int64_t i, uint64_
         const bool v2 = rp >= 0 && bit_at(p.ref_vbits, p.ref_vbit0, rp);   // GetFloat64(ref, -1) => (0,false) :72
         const bool v3 = rn >= 0 && bit_at(p.ref_vbits, p.ref_vbit0, rn);
         if (v1 && v2 && v3) {
-            const double prev_fill = bits_to_f64(p.fill_values[rp], p.fill_type);
-            const double next_fill = bits_to_f64(p.fill_values[rn], p.fill_type);
-            const double row_ref = bits_to_f64(p.ref_values[i], p.ref_type);
-            const double prev_ref = bits_to_f64(p.ref_values[rp], p.ref_type);
-            const double next_ref = bits_to_f64(p.ref_values[rn], p.ref_type);
+            const double prev_fill = bits_to_f64(pbits, kFillInt ? BOWGPU_INT64 : BOWGPU_FLOAT64);
+            const double next_fill = bits_to_f64(nbits, kFillInt ? BOWGPU_INT64 : BOWGPU_FLOAT64);
+            const double row_ref = bits_to_f64(own_ref, kRefInt ? BOWGPU_INT64 : BOWGPU_FLOAT64);
+            const double prev_ref = bits_to_f64(pref, kRefInt ? BOWGPU_INT64 : BOWGPU_FLOAT64);
+            const double next_ref = bits_to_f64(nref, kRefInt ? BOWGPU_INT64 : BOWGPU_FLOAT64);
             // (the nextRef-prevRef == 0 branch of :78-85 is overwritten by the fall-through below)
             double tmp = row_ref - prev_ref;   // :87-90, four separate statements
             tmp /= next_ref - prev_ref;
             tmp *= next_fill - prev_fill;
             tmp += prev_fill;
-            if (p.fill_type == BOWGPU_INT64) bits = (uint64_t)go_f64_to_i64(round(tmp));  // math.Round: half away from zero :93
+            if (kFillInt) bits = (uint64_t)go_f64_to_i64(round(tmp));  // math.Round: half away from zero :93
             else bits = (uint64_t)__double_as_longlong(tmp);
             valid = 1;
         }
@@ -188,43 +190,257 @@ __device__ __forceinline__ void fill_one(const FillParams &p, int64_t i, uint64_
     *valid_io = valid;
 }
 
+// 128 validity bits of rows [row0, row0 + 128) in row order (w0 = rows 0..63); rows at or beyond n read as 0 (kFull: the
+// caller knows row0 + 128 <= n).  Every lane passes the same arguments and the bitmap is an input nobody writes during the
+// kernel, so it is read through the constant address space: scalar loads, scalar arithmetic.
+template <bool kFull>
+__device__ __forceinline__ void load_bits128(const uint32_t *vbits, int64_t vbit0, int64_t row0, int64_t n, uint64_t *w0, uint64_t *w1) {
+    uint64_t x0 = ~0ull, x1 = ~0ull;
+    const int64_t left = n - row0;  // >= 1
+    if (vbits) {
+        typedef const uint32_t __attribute__((address_space(4))) *const_words;
+        const_words q = (const_words)(uintptr_t)vbits;
+        const int64_t bit = vbit0 + row0;
+        const int64_t wi = bit >> 5;
+        const int sh = (int)(bit & 31);
+        uint32_t d0, d1, d2, d3, d4;
+        if (kFull) {
+            d0 = q[wi]; d1 = q[wi + 1]; d2 = q[wi + 2]; d3 = q[wi + 3];
+            d4 = sh ? q[wi + 4] : 0u;  // (the chunk ends inside word wi + 3 when it starts on a word boundary)
+        } else {
+            const int64_t wl = (vbit0 + (left < 128 ? n : row0 + 128) - 1) >> 5;  // last word that holds a row of the chunk
+            d0 = q[wi];
+            d1 = wi + 1 <= wl ? q[wi + 1] : 0u; d2 = wi + 2 <= wl ? q[wi + 2] : 0u;
+            d3 = wi + 3 <= wl ? q[wi + 3] : 0u; d4 = wi + 4 <= wl ? q[wi + 4] : 0u;
+        }
+        const uint64_t lo = (uint64_t)d0 | ((uint64_t)d1 << 32), mid = (uint64_t)d2 | ((uint64_t)d3 << 32);
+        x0 = sh ? (lo >> sh) | (mid << (64 - sh)) : lo;
+        x1 = sh ? (mid >> sh) | ((uint64_t)d4 << (64 - sh)) : mid;
+    }
+    if (!kFull && left < 128) {
+        if (left <= 64) { x1 = 0; x0 = left == 64 ? x0 : (x0 & ((1ull << left) - 1ull)); }
+        else x1 &= (1ull << (left - 64)) - 1ull;
+    }
+    *w0 = x0;
+    *w1 = x1;
+}
+
+// bits of e on the even positions, bits of o on the odd ones
+__device__ __forceinline__ uint64_t spread32(uint32_t x) {
+    uint64_t v = x;
+    v = (v | (v << 16)) & 0x0000FFFF0000FFFFull;
+    v = (v | (v << 8)) & 0x00FF00FF00FF00FFull;
+    v = (v | (v << 4)) & 0x0F0F0F0F0F0F0F0Full;
+    v = (v | (v << 2)) & 0x3333333333333333ull;
+    v = (v | (v << 1)) & 0x5555555555555555ull;
+    return v;
+}
+__device__ __forceinline__ uint64_t interleave32(uint32_t e, uint32_t o) { return spread32(e) | (spread32(o) << 1); }
+
+__device__ __forceinline__ uint64_t lane_value(uint64_t v, int src_lane) {  // src_lane is the same in every lane
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src_lane);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src_lane);
+    return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+
+// a neighbour of a null row: its row (-1: none), its value and (FillLinear) the reference column's value there
+struct FillNb { int64_t row; uint64_t bits, ref; };
+
 // Bow.FillLinear (bowfill.go:14-103), FillPrevious / FillNext (:162-253), FillMean (:105-160).  A wavefront owns 512 consecutive
-// rows per trip as four chunks of 128: lane l holds rows 2l, 2l+1 of each chunk (one 16-B load and one 16-B store per chunk,
-// all four loads in flight at once); null rows look their neighbours up through the index; the validity bits of a chunk
-// leave as two aligned 64-bit words (the flags hop to the lane whose number is the row number, then one ballot per word).
-__global__ __launch_bounds__(256) void fill_kernel(const FillParams p) {
-    unsigned long long nvalid = 0;
-    const int lane = threadIdx.x & 63;
-    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
-    const bool vec = ((reinterpret_cast<uintptr_t>(p.fill_values) | reinterpret_cast<uintptr_t>(p.out_values)) & 15) == 0;
-    for (int64_t base = wave * 512; base < p.n; base += nwaves * 512) {
-        uint64_t a[4], b[4];
+// rows per trip as four chunks of 128 (FillLinear: 256 rows, two chunks): lane l holds rows 2l, 2l+1 of each chunk (one 16-B load and one 16-B store per chunk,
+// all loads of the trip in flight at once).  The kernel is bound by instruction issue unless the per-row work is a handful of
+// operations, so everything that is the same for the whole wavefront stays scalar: a chunk's validity comes as two 64-bit
+// words (scalar loads) and is split into an even-row and an odd-row lane mask by two ballots; a null row finds its nearest
+// valid rows with two count-leading / trailing-zeros on those masks and takes their values from the lanes that hold them
+// (shuffles); a run of nulls that reaches past its chunk gets the chunk's carry - the nearest valid row before / after the
+// chunk, handed from chunk to chunk in scalar registers, and looked up in the bitmap + neighbour index once per trip, only
+// when the trip starts / ends with a null.  The output's validity words are the two result ballots, bit-interleaved.
+// kFull: all rows of the trip exist (every trip but the last): no range checks.
+// chunks of 128 rows a wavefront takes per trip: FillLinear holds two columns in registers, so half as many
+__host__ __device__ constexpr int fill_chunks(int method) { return method == kFillLinear ? 2 : 4; }
+
+template <int kMethod, bool kFillInt, bool kRefInt, bool kFull>
+__device__ __forceinline__ void fill_trip(const FillParams &p, const int64_t base, const int lane, const uint64_t lt, const uint64_t gt,
+                                          const bool vec, const bool rvec, unsigned long long *nvalid_io) {
+    constexpr bool linear = kMethod == kFillLinear;
+    constexpr int kC = fill_chunks(kMethod), kTrip = 128 * kC;
+    constexpr bool want_prev = kMethod != BOWGPU_FILL_NEXT, want_next = kMethod != BOWGPU_FILL_PREVIOUS;
+    unsigned long long nvalid = *nvalid_io;
+    const uint64_t *src = p.fill_values + base, *rsrc = linear ? p.ref_values + base : nullptr;
+    uint64_t *dst = p.out_values + base;
+    const int64_t left_trip = p.n - base;  // rows of the trip that exist (>= 1; >= kTrip when kFull)
+    uint64_t a[kC], b[kC], ra[kC], rb[kC];
 #pragma unroll
-        for (int k = 0; k < 4; k++) load_pair(p.fill_values, base + 128 * k + 2 * lane, p.n, vec, a[k], b[k]);
+    for (int k = 0; k < kC; k++) {
+        const int r = 128 * k + 2 * lane;
+        if (kFull && vec) { const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(src + r); a[k] = v.x; b[k] = v.y; }
+        else { a[k] = r < left_trip ? src[r] : 0; b[k] = r + 1 < left_trip ? src[r + 1] : 0; }
+    }
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int64_t i = base + 128 * k + 2 * lane;
-            int va = (i < p.n && bit_at(p.fill_vbits, p.fill_vbit0, i)) ? 1 : 0;
-            int vb = (i + 1 < p.n && bit_at(p.fill_vbits, p.fill_vbit0, i + 1)) ? 1 : 0;
-            if (i < p.n && !va) fill_one(p, i, &a[k], &va);
-            if (i + 1 < p.n && !vb) fill_one(p, i + 1, &b[k], &vb);
-            if (vec && i + 1 < p.n) *reinterpret_cast<ulonglong2 *>(p.out_values + i) = make_ulonglong2(a[k], b[k]);
-            else {
-                if (i < p.n) p.out_values[i] = a[k];
-                if (i + 1 < p.n) p.out_values[i + 1] = b[k];
+    for (int k = 0; k < kC; k++) { ra[k] = 0; rb[k] = 0; }
+    if (linear) {
+#pragma unroll
+        for (int k = 0; k < kC; k++) {
+            const int r = 128 * k + 2 * lane;
+            if (kFull && rvec) { const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(rsrc + r); ra[k] = v.x; rb[k] = v.y; }
+            else { ra[k] = r < left_trip ? rsrc[r] : 0; rb[k] = r + 1 < left_trip ? rsrc[r + 1] : 0; }
+        }
+    }
+    // validity of the trip: per chunk the even-row / odd-row lane masks
+    uint64_t me[kC], mo[kC];
+    int fl[kC];
+    bool any_null = false;
+    const int sh = (2 * lane) & 63;
+#pragma unroll
+    for (int k = 0; k < kC; k++) {
+        const int64_t cb = base + 128 * k;
+        me[k] = 0; mo[k] = 0; fl[k] = 0;
+        if (kFull || cb < p.n) {
+            uint64_t w0, w1;
+            load_bits128<kFull>(p.fill_vbits, p.fill_vbit0, cb, p.n, &w0, &w1);
+            const uint64_t w = lane < 32 ? w0 : w1;
+            fl[k] = (int)((w >> sh) & 3ull);
+            me[k] = __ballot(fl[k] & 1);
+            mo[k] = __ballot(fl[k] & 2);
+            uint64_t full_e = ~0ull, full_o = ~0ull;
+            if (!kFull) {
+                const int64_t left = p.n - cb;
+                if (left < 128) {
+                    full_e = (left + 1) / 2 >= 64 ? ~0ull : ((1ull << ((left + 1) / 2)) - 1ull);
+                    full_o = left / 2 >= 64 ? ~0ull : ((1ull << (left / 2)) - 1ull);
+                }
             }
-            const int f = va | (vb << 1);
-            const int lo = __shfl(f, lane >> 1), hi = __shfl(f, 32 + (lane >> 1));   // rows lane and 64 + lane of the chunk
-            const unsigned long long w0 = __ballot((lo >> (lane & 1)) & 1), w1 = __ballot((hi >> (lane & 1)) & 1);
-            if (lane == 0 && base + 128 * k < p.n) {
-                unsigned long long *dst = reinterpret_cast<unsigned long long *>(p.out_valid_words + ((base + 128 * k) >> 5));
-                dst[0] = w0;
-                if (base + 128 * k + 64 < p.n) dst[1] = w1;
-                nvalid += __popcll(w0) + __popcll(w1);
+            any_null = any_null || me[k] != full_e || mo[k] != full_o;
+        }
+    }
+    // carries: the nearest valid row before / after every chunk (the same for all lanes)
+    FillNb cp[kC], cn[kC];
+#pragma unroll
+    for (int k = 0; k < kC; k++) { cp[k].row = -1; cp[k].bits = 0; cp[k].ref = 0; cn[k] = cp[k]; }
+    if (any_null) {
+        if (want_prev) {
+            FillNb cur; cur.row = -1; cur.bits = 0; cur.ref = 0;
+            if (!(me[0] & 1ull)) {  // the trip starts with a null: what lies before it
+                cur.row = prev_valid_ix(p.fill_vbits, p.fill_vbit0, p.n, base - 1, p.nbr);
+                if (cur.row >= 0) { cur.bits = p.fill_values[cur.row]; if (linear) cur.ref = p.ref_values[cur.row]; }
+            }
+#pragma unroll
+            for (int k = 0; k < kC; k++) {
+                cp[k] = cur;
+                if (me[k] | mo[k]) {
+                    const int le = me[k] ? 63 - __clzll((long long)me[k]) : -1, lo = mo[k] ? 63 - __clzll((long long)mo[k]) : -1;
+                    const bool odd = lo >= le;
+                    const int sl = odd ? lo : le;
+                    cur.row = base + 128 * k + 2 * sl + (odd ? 1 : 0);
+                    cur.bits = odd ? lane_value(b[k], sl) : lane_value(a[k], sl);
+                    if (linear) cur.ref = odd ? lane_value(rb[k], sl) : lane_value(ra[k], sl);
+                }
+            }
+        }
+        if (want_next) {
+            FillNb cur; cur.row = -1; cur.bits = 0; cur.ref = 0;
+            const int last = (int)(kFull ? kTrip - 1 : (left_trip < kTrip ? left_trip : kTrip) - 1);  // last row of the trip, relative
+            const int kl = last >> 7, rl = last & 127;
+            uint64_t mlast = 0;
+#pragma unroll
+            for (int k = 0; k < kC; k++) if (k == kl) mlast = (rl & 1) ? mo[k] : me[k];
+            if (!((mlast >> (rl >> 1)) & 1ull)) {  // the trip ends with a null: what lies after it
+                cur.row = next_valid_ix(p.fill_vbits, p.fill_vbit0, p.n, base + kTrip, p.nbr);
+                if (cur.row >= 0) { cur.bits = p.fill_values[cur.row]; if (linear) cur.ref = p.ref_values[cur.row]; }
+            }
+#pragma unroll
+            for (int k = kC - 1; k >= 0; k--) {
+                cn[k] = cur;
+                if (me[k] | mo[k]) {
+                    const int fe = me[k] ? __ffsll((long long)me[k]) - 1 : 64, fo = mo[k] ? __ffsll((long long)mo[k]) - 1 : 64;
+                    const bool even = fe <= fo;
+                    const int sl = even ? fe : fo;
+                    cur.row = base + 128 * k + 2 * sl + (even ? 0 : 1);
+                    cur.bits = even ? lane_value(a[k], sl) : lane_value(b[k], sl);
+                    if (linear) cur.ref = even ? lane_value(ra[k], sl) : lane_value(rb[k], sl);
+                }
             }
         }
     }
-    if (lane == 0 && nvalid) atomicAdd(p.valid_count, nvalid);
+#pragma unroll
+    for (int k = 0; k < kC; k++) {
+        const int64_t cb = base + 128 * k;
+        const int r = 128 * k + 2 * lane;   // relative to the trip
+        const int64_t i = base + r;
+        int va = fl[k] & 1, vb = (fl[k] >> 1) & 1;
+        uint64_t oa = a[k], ob = b[k];
+        const bool in_a = kFull || r < left_trip, in_b = kFull || r + 1 < left_trip;
+        const bool need_a = in_a && !va, need_b = in_b && !vb;
+        if (any_null && __ballot(need_a || need_b)) {
+            FillNb pa, nb2;  // previous of the lane's even row, next of its odd row
+            pa = cp[k]; nb2 = cn[k];
+            if (want_prev) {
+                const uint64_t xe = me[k] & lt, xo = mo[k] & lt;
+                const int le = xe ? 63 - __clzll((long long)xe) : -1, lo = xo ? 63 - __clzll((long long)xo) : -1;
+                const bool odd = lo >= le;
+                const int sl = (xe | xo) ? (odd ? lo : le) : lane;
+                const uint64_t sa = __shfl((unsigned long long)a[k], sl), sb = __shfl((unsigned long long)b[k], sl);
+                uint64_t sr = 0;
+                if (linear) { const uint64_t x = __shfl((unsigned long long)ra[k], sl), y = __shfl((unsigned long long)rb[k], sl); sr = odd ? y : x; }
+                if (xe | xo) { pa.row = cb + 2 * sl + (odd ? 1 : 0); pa.bits = odd ? sb : sa; pa.ref = sr; }
+            }
+            if (want_next) {
+                const uint64_t xe = me[k] & gt, xo = mo[k] & gt;
+                const int fe = xe ? __ffsll((long long)xe) - 1 : 64, fo = xo ? __ffsll((long long)xo) - 1 : 64;
+                const bool even = fe <= fo;
+                const int sl = (xe | xo) ? (even ? fe : fo) : lane;
+                const uint64_t sa = __shfl((unsigned long long)a[k], sl), sb = __shfl((unsigned long long)b[k], sl);
+                uint64_t sr = 0;
+                if (linear) { const uint64_t x = __shfl((unsigned long long)ra[k], sl), y = __shfl((unsigned long long)rb[k], sl); sr = even ? x : y; }
+                if (xe | xo) { nb2.row = cb + 2 * sl + (even ? 0 : 1); nb2.bits = even ? sa : sb; nb2.ref = sr; }
+            }
+            // the even row's next: its odd partner when that is valid; the odd row's previous: its even partner
+            FillNb na = nb2, pb = pa;
+            if (vb) { na.row = i + 1; na.bits = b[k]; na.ref = rb[k]; }
+            if (va) { pb.row = i; pb.bits = a[k]; pb.ref = ra[k]; }
+            if (need_a) fill_row<kMethod, kFillInt, kRefInt>(p, i, pa.row, na.row, pa.bits, na.bits, pa.ref, na.ref, ra[k], &oa, &va);
+            if (need_b) fill_row<kMethod, kFillInt, kRefInt>(p, i + 1, pb.row, nb2.row, pb.bits, nb2.bits, pb.ref, nb2.ref, rb[k], &ob, &vb);
+        }
+        if (kFull && vec) *reinterpret_cast<ulonglong2 *>(dst + r) = make_ulonglong2(oa, ob);
+        else {
+            if (in_a) dst[r] = oa;
+            if (in_b) dst[r + 1] = ob;
+        }
+        if (kFull || cb < p.n) {
+            const uint64_t oe = __ballot(va), oo = __ballot(vb);
+            const uint64_t w0 = interleave32((uint32_t)oe, (uint32_t)oo), w1 = interleave32((uint32_t)(oe >> 32), (uint32_t)(oo >> 32));
+            if (lane == 0) {
+                unsigned long long *wdst = reinterpret_cast<unsigned long long *>(p.out_valid_words + (cb >> 5));
+                wdst[0] = w0;
+                if (kFull || cb + 64 < p.n) wdst[1] = w1;
+            }
+            nvalid += __popcll(oe) + __popcll(oo);
+        }
+    }
+    *nvalid_io = nvalid;
+}
+
+template <int kMethod, bool kFillInt, bool kRefInt>
+__global__ __launch_bounds__(256) void fill_kernel(const FillParams p) {
+    __shared__ unsigned long long block_valid[4];
+    unsigned long long nvalid = 0;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t wave = (int64_t)blockIdx.x * 4 + wv, nwaves = (int64_t)gridDim.x * 4;
+    const bool vec = ((reinterpret_cast<uintptr_t>(p.fill_values) | reinterpret_cast<uintptr_t>(p.out_values)) & 15) == 0;
+    const bool rvec = kMethod == kFillLinear && (reinterpret_cast<uintptr_t>(p.ref_values) & 15) == 0;
+    const uint64_t lt = (1ull << lane) - 1ull, gt = lane == 63 ? 0ull : (~0ull << (lane + 1));
+    constexpr int kTrip = 128 * fill_chunks(kMethod);
+    for (int64_t base = wave * kTrip; base < p.n; base += nwaves * kTrip) {
+        if (base + kTrip <= p.n) fill_trip<kMethod, kFillInt, kRefInt, true>(p, base, lane, lt, gt, vec, rvec, &nvalid);
+        else fill_trip<kMethod, kFillInt, kRefInt, false>(p, base, lane, lt, gt, vec, rvec, &nvalid);
+    }
+    if (lane == 0) block_valid[wv] = nvalid;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long t = block_valid[0] + block_valid[1] + block_valid[2] + block_valid[3];
+        if (t) atomicAdd(p.valid_count, t);
+    }
 }
 
 // ------------------------------------------------------------------ whole-frame aggregation
@@ -463,7 +679,23 @@ int nbr_index_build(Ctx *c, const uint32_t *vbits, int64_t vbit0, int64_t n, voi
 }
 
 int fill_run(Ctx *c, const FillParams &p) {
-    if (p.n > 0) hipLaunchKernelGGL(fill_kernel, dim3(grid_for(p.n)), dim3(256), 0, c->stream, p);
+    if (p.n > 0) {
+        const dim3 grid(grid_for(p.n, 256, 2048)), block(256);
+        const bool fi = p.fill_type == BOWGPU_INT64, ri = p.ref_type == BOWGPU_INT64;
+        // (FillPrevious / FillNext copy bits: one instantiation serves both column types)
+        if (p.method == BOWGPU_FILL_PREVIOUS) hipLaunchKernelGGL((fill_kernel<BOWGPU_FILL_PREVIOUS, false, false>), grid, block, 0, c->stream, p);
+        else if (p.method == BOWGPU_FILL_NEXT) hipLaunchKernelGGL((fill_kernel<BOWGPU_FILL_NEXT, false, false>), grid, block, 0, c->stream, p);
+        else if (p.method == BOWGPU_FILL_MEAN) {
+            if (fi) hipLaunchKernelGGL((fill_kernel<BOWGPU_FILL_MEAN, true, false>), grid, block, 0, c->stream, p);
+            else hipLaunchKernelGGL((fill_kernel<BOWGPU_FILL_MEAN, false, false>), grid, block, 0, c->stream, p);
+        } else if (fi) {
+            if (ri) hipLaunchKernelGGL((fill_kernel<kFillLinear, true, true>), grid, block, 0, c->stream, p);
+            else hipLaunchKernelGGL((fill_kernel<kFillLinear, true, false>), grid, block, 0, c->stream, p);
+        } else {
+            if (ri) hipLaunchKernelGGL((fill_kernel<kFillLinear, false, true>), grid, block, 0, c->stream, p);
+            else hipLaunchKernelGGL((fill_kernel<kFillLinear, false, false>), grid, block, 0, c->stream, p);
+        }
+    }
     BG_HIP(hipGetLastError());
     return 0;
 }
