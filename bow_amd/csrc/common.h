@@ -259,6 +259,7 @@ size_t stats_size();
 // previous/next-valid lookup to one block of words + one table read, however long the runs of nulls are.
 constexpr int kNbrBlockBits = 4096;
 constexpr int kPoolMode = 17;    // aggregation.Mode: its output's validity working copy
+constexpr int kPoolColOrder = 18; // IsColSorted: one (first valid, last valid) record per 512-row trip
 constexpr int kPoolShard = 19;   // shard stitch: seed / merged states and the next shard's first row
 constexpr int kPoolInterp = 20;  // context pool slots 20..30: tile counts, their scan, scan sums, one neighbour index per column
 struct NbrIndex {

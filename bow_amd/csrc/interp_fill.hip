@@ -127,27 +127,7 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const int32_t *in, int6
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) out[n] = off + acc;  // out has n+1 entries
 }
 
-// ------------------------------------------------------------------ IsColSorted / FillLinear
-// flags[0] |= 1 if some consecutive valid pair increases, |= 2 if some decreases, |= 4 if any valid value exists
-__global__ __launch_bounds__(256) void col_order_kernel(const uint64_t *values, const uint32_t *vbits, int64_t vbit0, int64_t n,
-                                                        int32_t type, uint32_t *flags) {
-    uint32_t f = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        if (!bit_at(vbits, vbit0, i)) continue;
-        f |= 4;
-        const int64_t pi = prev_valid(vbits, vbit0, n, i - 1);
-        if (pi < 0) continue;
-        if (type == BOWGPU_INT64) {
-            const int64_t c = (int64_t)values[pi], x = (int64_t)values[i];
-            if (c < x) f |= 1; else if (c > x) f |= 2;
-        } else {
-            const double c = __longlong_as_double((long long)values[pi]), x = __longlong_as_double((long long)values[i]);
-            if (c < x) f |= 1; else if (c > x) f |= 2;  // NaN compares false both ways (bowassertion.go:64-74)
-        }
-    }
-    if (f) atomicOr(flags, f);
-}
-
+// ------------------------------------------------------------------ FillLinear / FillMean / FillPrevious / FillNext
 // The value a null row i receives (bits, valid) under p.method.  rp / rn: its nearest valid rows (-1: none), with their
 // values pbits / nbits (and, FillLinear, the reference column's values there: pref / nref; own_ref: at row i itself).
 // kFillInt / kRefInt: the filled / the reference column is Int64 (else Float64)
@@ -443,6 +423,114 @@ __global__ __launch_bounds__(256) void fill_kernel(const FillParams p) {
     }
 }
 
+// ------------------------------------------------------------------ IsColSorted (bowassertion.go:15-86)
+// flags[0] |= 1 if some consecutive valid pair increases, |= 2 if some decreases, |= 4 if any valid value exists.
+// Same wave-trip shape as fill_kernel: 512 rows per trip, lane l holds rows 2l, 2l+1 of each 128-row chunk; a valid row finds
+// the valid row before it through the chunk's even / odd lane masks and a shuffle, across chunks through a scalar carry.
+// Pairs that straddle two trips are settled afterwards from one (first valid, last valid) record per trip
+// (col_order_edges_kernel), so no lookup ever walks back through a long run of nulls.
+struct TripEdge { uint64_t first, last; int32_t has, _pad; };
+
+template <bool kInt>
+__device__ __forceinline__ uint32_t order_cmp(uint64_t prev, uint64_t cur) {
+    if (kInt) {
+        const int64_t c = (int64_t)prev, x = (int64_t)cur;
+        return c < x ? 1u : (c > x ? 2u : 0u);
+    }
+    const double c = __longlong_as_double((long long)prev), x = __longlong_as_double((long long)cur);
+    return c < x ? 1u : (c > x ? 2u : 0u);  // NaN compares false both ways (bowassertion.go:64-74)
+}
+
+template <bool kInt>
+__global__ __launch_bounds__(256) void col_order_kernel(const uint64_t *values, const uint32_t *vbits, int64_t vbit0, int64_t n,
+                                                        TripEdge *edges, uint32_t *flags) {
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t wave = (int64_t)blockIdx.x * 4 + wv, nwaves = (int64_t)gridDim.x * 4;
+    const bool vec = (reinterpret_cast<uintptr_t>(values) & 15) == 0;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    const int sh = (2 * lane) & 63;
+    uint32_t f = 0;
+    bool any_valid = false;
+    for (int64_t trip = wave; trip * 512 < n; trip += nwaves) {
+        const int64_t base = trip * 512;
+        const int64_t left_trip = n - base;
+        const bool full = left_trip >= 512;
+        const uint64_t *src = values + base;
+        uint64_t a[4], b[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int r = 128 * k + 2 * lane;
+            if (full && vec) { const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(src + r); a[k] = v.x; b[k] = v.y; }
+            else { a[k] = r < left_trip ? src[r] : 0; b[k] = r + 1 < left_trip ? src[r + 1] : 0; }
+        }
+        bool chas = false, fhas = false;  // carry = the last valid value so far in this trip; the trip's first valid value
+        uint64_t cbits = 0, first = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int64_t cb = base + 128 * k;
+            if (cb >= n) break;
+            uint64_t w0, w1;
+            if (full) load_bits128<true>(vbits, vbit0, cb, n, &w0, &w1);
+            else load_bits128<false>(vbits, vbit0, cb, n, &w0, &w1);
+            const uint64_t w = lane < 32 ? w0 : w1;
+            const int fl = (int)((w >> sh) & 3ull);
+            const uint64_t me = __ballot(fl & 1), mo = __ballot(fl & 2);
+            if (!(me | mo)) continue;
+            const uint64_t xe = me & lt, xo = mo & lt;
+            const int le = xe ? 63 - __clzll((long long)xe) : -1, lo = xo ? 63 - __clzll((long long)xo) : -1;
+            const bool odd = lo >= le, inch = (xe | xo) != 0;
+            const int sl = inch ? (odd ? lo : le) : lane;
+            const uint64_t sa = __shfl((unsigned long long)a[k], sl), sb = __shfl((unsigned long long)b[k], sl);
+            const uint64_t pbits = inch ? (odd ? sb : sa) : cbits;
+            const bool phas = inch || chas;
+            if ((fl & 1) && phas) f |= order_cmp<kInt>(pbits, a[k]);
+            if (fl & 2) {
+                const bool h2 = (fl & 1) || phas;
+                if (h2) f |= order_cmp<kInt>((fl & 1) ? a[k] : pbits, b[k]);
+            }
+            if (!fhas) {
+                const int fe = me ? __ffsll((long long)me) - 1 : 64, fo = mo ? __ffsll((long long)mo) - 1 : 64;
+                first = fe <= fo ? lane_value(a[k], fe) : lane_value(b[k], fo);
+                fhas = true;
+            }
+            {
+                const int ge = me ? 63 - __clzll((long long)me) : -1, go = mo ? 63 - __clzll((long long)mo) : -1;
+                cbits = go >= ge ? lane_value(b[k], go) : lane_value(a[k], ge);
+                chas = true;
+            }
+        }
+        any_valid = any_valid || fhas;
+        if (lane == 0) { TripEdge e; e.first = first; e.last = cbits; e.has = fhas ? 1 : 0; e._pad = 0; edges[trip] = e; }
+    }
+    const uint32_t F = (__ballot(f & 1) ? 1u : 0u) | (__ballot(f & 2) ? 2u : 0u) | (any_valid ? 4u : 0u);
+    if (lane == 0 && F) atomicOr(flags, F);
+}
+
+// pairs whose rows lie in different trips: 256 consecutive records per workgroup, joined in order by one thread out of LDS;
+// the workgroup's own (first valid, last valid) record goes to the next level (the host repeats until one record is left)
+template <bool kInt>
+__global__ __launch_bounds__(256) void col_order_join_kernel(const TripEdge *in, int64_t n_in, TripEdge *out, uint32_t *flags) {
+    __shared__ TripEdge seg[256];
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    TripEdge e; e.first = 0; e.last = 0; e.has = 0; e._pad = 0;
+    if (q < n_in) e = in[q];
+    seg[threadIdx.x] = e;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t f = 0;
+        TripEdge c; c.has = 0; c.last = 0; c.first = 0; c._pad = 0;
+        for (int j = 0; j < 256; j++) {
+            if (!seg[j].has) continue;
+            if (c.has) f |= order_cmp<kInt>(c.last, seg[j].first);
+            else c.first = seg[j].first;
+            c.last = seg[j].last; c.has = 1;
+        }
+        out[blockIdx.x] = c;
+        if (f) atomicOr(flags, f);
+    }
+}
+
 // ------------------------------------------------------------------ whole-frame aggregation
 // Level 1: workgroup b reduces rows [b*chunk, (b+1)*chunk) of one column into a partial state; each of its four wavefronts
 // owns a contiguous quarter and steps through it 512 rows at a time - lane l holds rows 8l..8l+7 of the step (four 16-B loads) -
@@ -623,7 +711,23 @@ int launch_exclusive_scan(Ctx *c, const int32_t *in, int64_t n, int64_t *out /* 
 int launch_col_order(Ctx *c, const uint64_t *values, const uint32_t *vbits, int64_t vbit0, int64_t n, int32_t type, uint32_t *d_flags) {
     BG_HIP(hipMemsetAsync(d_flags, 0, 4, c->stream));
     if (n == 0) return 0;
-    hipLaunchKernelGGL(col_order_kernel, dim3(grid_for(n)), dim3(256), 0, c->stream, values, vbits, vbit0, n, type, d_flags);
+    const int64_t ntrips = (n + 511) / 512;
+    void *w;
+    BG_TRY(ctx_pool(c, kPoolColOrder, (size_t)(ntrips + ntrips / 128 + 8) * sizeof(TripEdge), &w));  // every level of the join
+    TripEdge *edges = reinterpret_cast<TripEdge *>(w);
+    const dim3 grid(grid_for(ntrips, 4, 2048)), block(256);
+    const bool is_int = type == BOWGPU_INT64;
+    if (is_int) hipLaunchKernelGGL(col_order_kernel<true>, grid, block, 0, c->stream, values, vbits, vbit0, n, edges, d_flags);
+    else hipLaunchKernelGGL(col_order_kernel<false>, grid, block, 0, c->stream, values, vbits, vbit0, n, edges, d_flags);
+    int64_t n_in = ntrips;
+    while (n_in > 1) {
+        const int64_t n_out = (n_in + 255) / 256;
+        TripEdge *out = edges + n_in;
+        if (is_int) hipLaunchKernelGGL(col_order_join_kernel<true>, dim3((unsigned)n_out), block, 0, c->stream, edges, n_in, out, d_flags);
+        else hipLaunchKernelGGL(col_order_join_kernel<false>, dim3((unsigned)n_out), block, 0, c->stream, edges, n_in, out, d_flags);
+        edges = out;
+        n_in = n_out;
+    }
     BG_HIP(hipGetLastError());
     return 0;
 }

@@ -296,6 +296,36 @@ def test_is_col_sorted():
         assert orc.is_col_sorted(orc.Column.from_list(data, typ)) == want, data
 
 
+def test_is_col_sorted_across_trips():
+    """the kernel works in 512-row trips joined afterwards: violations whose two rows lie in different trips (behind runs of
+    nulls of any length), all-null stretches, Arrow offsets, both types"""
+    rng = np.random.default_rng(17)
+    for case in range(60):
+        n = int(rng.choice([511, 512, 513, 1024, 5000, 140_000]))
+        as_int = bool(rng.random() < 0.5)
+        vals = np.cumsum(rng.integers(0, 3, n)).astype(np.int64)
+        if rng.random() < 0.3:
+            vals = vals[::-1].copy()            # descending is sorted too (bowassertion.go:40-58)
+        valid = rng.random(n) < [1.0, 0.7, 0.05][int(rng.integers(0, 3))]
+        for _ in range(int(rng.integers(0, 3))):   # long runs of nulls over trip boundaries
+            a = int(rng.integers(0, n)); valid[a:a + int(rng.integers(1, 3000))] = False
+        if rng.random() < 0.6 and valid.sum() >= 3:  # one pair of consecutive valid rows out of order
+            rows = np.flatnonzero(valid)
+            j = int(rng.integers(1, len(rows)))
+            vals[rows[j]:] += int(rng.choice([-1000, 1000]))
+        if rng.random() < 0.1:
+            valid[:] = False
+        pad = int(rng.integers(0, 40))
+        buf = np.concatenate([np.zeros(pad, np.int64), vals, np.zeros(5, np.int64)])
+        vb = np.concatenate([np.ones(pad, bool), valid, np.ones(5, bool)])
+        data = buf if as_int else buf.astype(np.float64)
+        bm = None if valid.all() and rng.random() < 0.5 else np.packbits(vb, bitorder="little")
+        typ = capi.INT64 if as_int else capi.FLOAT64
+        got = capi.is_col_sorted(capi.Column(data, bm, typ, pad, n, -1 if bm is not None else 0))
+        want = orc.is_col_sorted(orc.Column(data, bm, typ, offset=pad, length=n))
+        assert got == want, (case, n, as_int, pad)
+
+
 # ------------------------------------------------------------------ window bounds (the iterator)
 def test_golden_window_bounds(golden):
     for v in golden["iterate"]:
