@@ -82,4 +82,58 @@ __device__ __forceinline__ int64_t next_valid_ix(const uint32_t *bits, int64_t b
     return ix.next_after[g - ix.g0];
 }
 
+// ---------------------------------------------------------------- wave-uniform bitmap access (fills, IsColSorted, Interpolate)
+// 128 validity bits of rows [row0, row0 + 128) in row order (w0 = rows 0..63); rows at or beyond n read as 0 (kFull: the
+// caller knows row0 + 128 <= n).  Every lane passes the same arguments and the bitmap is an input nobody writes during the
+// kernel, so it is read through the constant address space: scalar loads, scalar arithmetic.
+template <bool kFull>
+__device__ __forceinline__ void load_bits128(const uint32_t *vbits, int64_t vbit0, int64_t row0, int64_t n, uint64_t *w0, uint64_t *w1) {
+    uint64_t x0 = ~0ull, x1 = ~0ull;
+    const int64_t left = n - row0;  // >= 1
+    if (vbits) {
+        typedef const uint32_t __attribute__((address_space(4))) *const_words;
+        const_words q = (const_words)(uintptr_t)vbits;
+        const int64_t bit = vbit0 + row0;
+        const int64_t wi = bit >> 5;
+        const int sh = (int)(bit & 31);
+        uint32_t d0, d1, d2, d3, d4;
+        if (kFull) {
+            d0 = q[wi]; d1 = q[wi + 1]; d2 = q[wi + 2]; d3 = q[wi + 3];
+            d4 = sh ? q[wi + 4] : 0u;  // (the chunk ends inside word wi + 3 when it starts on a word boundary)
+        } else {
+            const int64_t wl = (vbit0 + (left < 128 ? n : row0 + 128) - 1) >> 5;  // last word that holds a row of the chunk
+            d0 = q[wi];
+            d1 = wi + 1 <= wl ? q[wi + 1] : 0u; d2 = wi + 2 <= wl ? q[wi + 2] : 0u;
+            d3 = wi + 3 <= wl ? q[wi + 3] : 0u; d4 = wi + 4 <= wl ? q[wi + 4] : 0u;
+        }
+        const uint64_t lo = (uint64_t)d0 | ((uint64_t)d1 << 32), mid = (uint64_t)d2 | ((uint64_t)d3 << 32);
+        x0 = sh ? (lo >> sh) | (mid << (64 - sh)) : lo;
+        x1 = sh ? (mid >> sh) | ((uint64_t)d4 << (64 - sh)) : mid;
+    }
+    if (!kFull && left < 128) {
+        if (left <= 64) { x1 = 0; x0 = left == 64 ? x0 : (x0 & ((1ull << left) - 1ull)); }
+        else x1 &= (1ull << (left - 64)) - 1ull;
+    }
+    *w0 = x0;
+    *w1 = x1;
+}
+
+// bits of e on the even positions, bits of o on the odd ones
+__device__ __forceinline__ uint64_t spread32(uint32_t x) {
+    uint64_t v = x;
+    v = (v | (v << 16)) & 0x0000FFFF0000FFFFull;
+    v = (v | (v << 8)) & 0x00FF00FF00FF00FFull;
+    v = (v | (v << 4)) & 0x0F0F0F0F0F0F0F0Full;
+    v = (v | (v << 2)) & 0x3333333333333333ull;
+    v = (v | (v << 1)) & 0x5555555555555555ull;
+    return v;
+}
+__device__ __forceinline__ uint64_t interleave32(uint32_t e, uint32_t o) { return spread32(e) | (spread32(o) << 1); }
+
+__device__ __forceinline__ uint64_t lane_value(uint64_t v, int src_lane) {  // src_lane is the same in every lane
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src_lane);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src_lane);
+    return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+
 }  // namespace bowgpu
