@@ -51,16 +51,18 @@ __global__ __launch_bounds__(1024) void nbr_scan_kernel(const int64_t *last_in, 
     for (int64_t g = a; g < b; g++) { if (last_in[g] > hi) hi = last_in[g]; if (first_in[g] < lo) lo = first_in[g]; }
     s_hi[t] = hi; s_lo[t] = lo;
     __syncthreads();
-    if (t == 0) {  // 1024 entries: serial is cheap
-        int64_t run = -1;
-        for (int i = 0; i < 1024; i++) { const int64_t x = s_hi[i]; s_hi[i] = run; if (x > run) run = x; }
-        run = INT64_MAX;
-        for (int i = 1023; i >= 0; i--) { const int64_t x = s_lo[i]; s_lo[i] = run; if (x < run) run = x; }
+    // inclusive running max (forward) / running min (backward) over the 1024 thread totals, ten doubling steps
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int64_t h = t >= o ? s_hi[t - o] : -1, l = t + o < 1024 ? s_lo[t + o] : INT64_MAX;
+        __syncthreads();
+        if (h > s_hi[t]) s_hi[t] = h;
+        if (l < s_lo[t]) s_lo[t] = l;
+        __syncthreads();
     }
-    __syncthreads();
-    int64_t run = s_hi[t];
+    const int64_t before = t > 0 ? s_hi[t - 1] : -1, after = t < 1023 ? s_lo[t + 1] : INT64_MAX;  // exclusive
+    int64_t run = before;
     for (int64_t g = a; g < b; g++) { prev_before[g] = run; if (last_in[g] > run) run = last_in[g]; }
-    run = s_lo[t];
+    run = after;
     for (int64_t g = b - 1; g >= a; g--) { next_after[g] = run == INT64_MAX ? -1 : run; if (first_in[g] < run) run = first_in[g]; }
 }
 
