@@ -610,8 +610,9 @@ static int job_enqueue_tail(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t
     return 0;
 }
 
-// Can the stripped-down kernel of rolling_simple.hip take this call?  (one null-free, 16-B aligned value column, at most
-// 4 factor-free outputs, exclusive windows, the whole interval column within 2^32 of s0, not a shard)
+// Can the wave-tile kernels (rolling_simple.hip; time_weighted: rolling_tw.hip) take this call?  16-B aligned columns, no rows
+// below s0, interval < 2^32, at most kSimpleMaxAggs outputs; rolling_simple.hip: exclusive windows without time-weighted
+// reducers.  *wide: the rows reach 2^32 or more past output slot 0 (nanosecond timestamps): ids relative to each tile's window.
 static bool simple_applies(const AggJob *job, const bowgpu_agg *aggs, int32_t naggs, const Plan &plan, bool time_weighted, int *need,
                            bool *is_int, bool *has_nulls, bool *wide) {
     const AggParams &P = job->P;
