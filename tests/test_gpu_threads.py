@@ -1,0 +1,77 @@
+"""SURVEY §8(b) "Threading": cgo calls arrive on arbitrary OS threads, several at once.  The ABI keeps its state per thread
+(context, stream, scratch, error string): concurrent calls from many threads give the same results as the oracle, an error in
+one thread is reported there and nowhere else, and a column uploaded by one thread serves calls made by another."""
+import threading
+
+import numpy as np
+import pytest
+
+from bow_amd import capi
+from oracle import pyoracle as orc
+from test_gpu_aggregate import compare
+from test_gpu_fuzz import cmp_out
+
+pytestmark = pytest.mark.gpu
+
+AGGS = [("WindowStart", 0), ("Sum", 1), ("ArithmeticMean", 1), ("Min", 1), ("Max", 1), ("Count", 1), ("First", 1), ("Last", 1),
+        ("WeightedAverageStep", 1), ("Mode", 1)]
+
+
+def _case(seed):
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(2000, 60_000))
+    ts = np.cumsum(rng.integers(0, 4, n)).astype(np.int64) - int(rng.integers(0, 500))
+    vals = np.round(np.abs(rng.standard_normal(n)), 1)   # (one sign: the long-window path's tree sums are compared relatively)
+    valid = rng.random(n) > 0.3
+    interval = int(rng.choice([3, 10, 64, 1000]))
+    return ts, vals, valid, interval
+
+
+def test_concurrent_calls_from_many_threads():
+    n_threads, per_thread = 8, 12
+    cases = {(t, j): _case(100 * t + j) for t in range(n_threads) for j in range(per_thread)}
+    want = {}
+    for key, (ts, vals, valid, interval) in cases.items():
+        bm = np.packbits(valid, bitorder="little")
+        ocols = [orc.Column(ts, None, orc.INT64), orc.Column(vals, bm, orc.FLOAT64)]
+        want[key] = (orc.aggregate(ocols, 0, interval, AGGS, offset=1)[0], orc.fill(ocols[1], "Previous")[0])
+    shared_ts, shared_vals, _, _ = _case(7)
+    shared = [capi.Column(shared_ts, None, capi.INT64).to_device(), capi.Column(shared_vals, None, capi.FLOAT64).to_device()]  # uploaded HERE
+    shared_want = orc.aggregate([orc.Column(shared_ts, None, orc.INT64), orc.Column(shared_vals, None, orc.FLOAT64)], 0, 10, AGGS[:8])[0]
+    errors = []
+    start = threading.Barrier(n_threads)
+
+    def worker(t):
+        try:
+            start.wait()
+            for j in range(per_thread):
+                ts, vals, valid, interval = cases[(t, j)]
+                bm = np.packbits(valid, bitorder="little")
+                cols = [capi.Column(ts, None, capi.INT64), capi.Column(vals, bm, capi.FLOAT64, 0, len(vals), -1)]
+                if (t + j) % 2:
+                    cols = [c.to_device() for c in cols]
+                outs, info = capi.rolling_aggregate(cols, 0, interval, AGGS, offset=1)
+                exp, exp_fill = want[(t, j)]
+                for (k, _), g, w in zip(AGGS, outs, exp):
+                    exact = k not in ("Sum", "ArithmeticMean", "WeightedAverageStep") or info.long_windows == 0
+                    compare("thread %d case %d %s" % (t, j, k), g, w, exact=exact, rtol=1e-11)
+                g, _ = capi.fill(cols[1], "Previous")
+                cmp_out("thread %d case %d FillPrevious" % (t, j), g, exp_fill)
+                if j % 4 == t % 4:   # an error of this thread's own, between good calls: message and code stay here
+                    bad = ts.copy(); bad[len(bad) // 2] -= 10_000
+                    with pytest.raises(capi.BowGpuError) as e:
+                        capi.rolling_aggregate([capi.Column(bad, None, capi.INT64), cols[1]], 0, interval, AGGS[:3])
+                    assert "TS_UNSORTED" in str(e.value) and "ascending" in str(e.value)
+                outs, _ = capi.rolling_aggregate(shared, 0, 10, AGGS[:8])   # columns another thread put on the device
+                for (k, _), g, w in zip(AGGS[:8], outs, shared_want):
+                    compare("thread %d shared %s" % (t, k), g, w)
+        except BaseException as ex:   # noqa: BLE001 - reported by the main thread
+            errors.append((t, repr(ex)[:600]))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(n_threads)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=500)
+    assert not any(th.is_alive() for th in threads), "a worker hangs"
+    assert not errors, errors[:3]
