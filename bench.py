@@ -221,6 +221,12 @@ def main():
         if not args.no_cpu and world == 1:
             try:
                 line["cpu_baseline"] = cpu_baseline(capi, min(args.cpu_sample, rows))
+                # the Go reference itself would be the baseline of choice; it needs a Go toolchain plus the module's
+                # un-vendored dependencies (arrow/go/v8, parquet-go), neither of which exists on these boxes
+                import shutil
+                line["cpu_baseline"]["go_reference"] = ("go toolchain found at %s, but github.com/metronlab/bow and its modules are not "
+                                                        "available offline: not run" % shutil.which("go")) if shutil.which("go") \
+                    else "not runnable on this box (no go toolchain)"
             except Exception as e:  # the baseline is a reported aside; never lose the GPU number over it
                 line["cpu_baseline"] = {"error": repr(e)}
             try:

@@ -158,25 +158,36 @@ __device__ __forceinline__ int64_t left_ts(const uint64_t (&t)[kIR], const int64
     return (int64_t)l;
 }
 
+// exact heads per tile of kITile rows.  One wavefront per tile, no barrier: lane l holds rows 2l, 2l+1 of each of the tile's four
+// 128-row chunks (16-B loads, all in flight at once); the timestamp left of a lane's rows comes from its neighbour lane, from
+// the previous chunk's last lane, or (first chunk) from the row before the tile; the count is two ballots per chunk.
 template <bool kFast>
 __global__ __launch_bounds__(kIThreads) void interp_count_kernel(const int64_t *ts, int64_t n, int64_t s0, int64_t interval,
                                                                  MagicDiv magic, Magic32 m32, int has_left, int64_t shard_left_ts,
                                                                  int32_t *tile_exact, uint32_t *status) {
-    __shared__ int part[kIThreads / 64];
-    __shared__ long long wave_last[kIThreads / 64];
-    const int64_t i = (int64_t)blockIdx.x * kITile + kIR * (int64_t)threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t tile = (int64_t)blockIdx.x * (kIThreads / 64) + wv;
+    const int64_t base = tile * kITile;
+    if (base >= n) return;
     const bool vec = (reinterpret_cast<uintptr_t>(ts) & 15) == 0;
-    uint64_t t[kIR];
-    loadR(reinterpret_cast<const uint64_t *>(ts), i, n, vec, t);
-    const int64_t tl = left_ts(t, ts, i, n, wave_last, threadIdx.x, shard_left_ts);
+    uint64_t t[kITile / 128][kIR];
+#pragma unroll
+    for (int k = 0; k < kITile / 128; k++) loadR(reinterpret_cast<const uint64_t *>(ts), base + 128 * k + kIR * lane, n, vec, t[k]);
+    int64_t t_before = base > 0 ? ts[base - 1] : shard_left_ts;
     bool unsorted = false;
-    const RowsR f = rows_flags<kFast>(t, tl, i, n, s0, interval, magic, m32, -1, has_left != 0, &unsorted);
-    int cnt = (int)f.exact[0] + (int)f.exact[1];
-    if (unsorted) atomicOr(&status[0], 1u);
-    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = cnt;
-    __syncthreads();
-    if (threadIdx.x == 0) tile_exact[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < kITile / 128; k++) {
+        const int64_t i = base + 128 * k + kIR * lane;
+        long long tl = __shfl_up((long long)t[k][kIR - 1], 1);
+        if (lane == 0) tl = (long long)t_before;
+        const RowsR f = rows_flags<kFast>(t[k], (int64_t)tl, i, n, s0, interval, magic, m32, -1, has_left != 0, &unsorted);
+        cnt += __popcll(__ballot(f.exact[0])) + __popcll(__ballot(f.exact[1]));
+        t_before = (int64_t)lane_value(t[k][kIR - 1], 63);
+    }
+    if (__ballot(unsorted) && lane == 0) atomicOr(&status[0], 1u);
+    if (lane == 0) tile_exact[tile] = cnt;
 }
 
 template <bool kFast>
@@ -390,10 +401,10 @@ int launch_interp_count(Ctx *c, const int64_t *ts, int64_t n, const Plan &plan, 
     if (kq >= 0 || plan.first_ts < plan.s0)
         hipLaunchKernelGGL(interp_quirk_kernel, dim3(1), dim3(64), 0, c->stream, ts, n, plan.s0, plan.interval, kq, status);
     if (interp_fast32(plan, kq))
-        hipLaunchKernelGGL(interp_count_kernel<true>, dim3((unsigned)ntiles), dim3(kIThreads), 0, c->stream, ts, n, plan.s0, plan.interval,
+        hipLaunchKernelGGL(interp_count_kernel<true>, dim3((unsigned)((ntiles + 3) / 4)), dim3(kIThreads), 0, c->stream, ts, n, plan.s0, plan.interval,
                            plan.magic, magic32_make(plan.interval), has_left, left_ts, tile_exact, status);
     else
-        hipLaunchKernelGGL(interp_count_kernel<false>, dim3((unsigned)ntiles), dim3(kIThreads), 0, c->stream, ts, n, plan.s0, plan.interval,
+        hipLaunchKernelGGL(interp_count_kernel<false>, dim3((unsigned)((ntiles + 3) / 4)), dim3(kIThreads), 0, c->stream, ts, n, plan.s0, plan.interval,
                            plan.magic, Magic32{0, 0, 0}, has_left, left_ts, tile_exact, status);
     BG_HIP(hipGetLastError());
     return 0;
