@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "common.h"
@@ -422,7 +423,6 @@ struct AggRun {
 static int validate_aggs(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, const bowgpu_agg *aggs, int32_t naggs,
                          int *inclusive, int *new_interval_col) {
     if (naggs <= 0) return fail(BOWGPU_ERR_NO_AGG, "at least one column aggregation is required");
-    if (naggs > kMaxAggs) return fail(BOWGPU_ERR_UNSUPPORTED, "at most %d aggregations per call", kMaxAggs);
     int nic = -1;
     for (int i = 0; i < naggs; i++) {
         if (aggs[i].col < 0 || aggs[i].col >= ncols) return fail(BOWGPU_ERR_BAD_COL, "aggregation %d: no column with index %d", i, aggs[i].col);
@@ -922,32 +922,69 @@ static int run_modes(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t ts_c
     return 0;
 }
 
+// An unsharded Aggregate call: the streaming reducers in batches that one launch of the tile kernels takes (at most kMaxAggs
+// outputs over at most kMaxCols column passes - the reference has no such limits, aggregation.go:190-238 simply loops), then the
+// Mode outputs.
 static int run_aggregate(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t ts_col, const Plan &plan,
                          int inclusive, const bowgpu_agg *aggs, int32_t naggs, bowgpu_out *outs,
                          int64_t wid_base, int64_t W, int64_t *long_windows, double *kernel_ms) {
     int n_mode = 0;
     for (int i = 0; i < naggs; i++) n_mode += aggs[i].kind == BOWGPU_AGG_MODE;
-    if (n_mode > 0) {
-        if (wid_base != 0 || W != plan.W) return fail(BOWGPU_ERR_UNSUPPORTED, "Mode runs on unsharded calls only");
-        // the streaming reducers first, as a call of their own; then each Mode output
-        std::vector<bowgpu_agg> rest;
-        std::vector<bowgpu_out> rest_outs;
-        std::vector<int> at;
-        for (int i = 0; i < naggs; i++)
-            if (aggs[i].kind != BOWGPU_AGG_MODE) { rest.push_back(aggs[i]); rest_outs.push_back(outs[i]); at.push_back(i); }
-        if (long_windows) *long_windows = 0;
-        if (kernel_ms) *kernel_ms = 0;
-        if (!rest.empty()) {
-            AggJob job;
-            BG_TRY(job_build(c, cols, ncols, ts_col, plan, inclusive, rest.data(), (int32_t)rest.size(), rest_outs.data(), 0, W, true, &job));
-            BG_TRY(job_run(c, &job, rest.data(), (int32_t)rest.size(), long_windows, kernel_ms, true, &plan, true));
-            for (size_t j = 0; j < at.size(); j++) outs[at[j]] = rest_outs[j];
+    if (n_mode > 0 && (wid_base != 0 || W != plan.W)) return fail(BOWGPU_ERR_UNSUPPORTED, "Mode runs on unsharded calls only");
+    if (long_windows) *long_windows = 0;
+    if (kernel_ms) *kernel_ms = 0;
+    // greedy batches in output order; the column-pass count follows job_build's rule (a pass serves at most 4 nullable reducers)
+    std::vector<std::vector<int>> batches;
+    {
+        std::vector<int> cur, slot_of(ncols, -1), nullable_in_slot;
+        auto flush = [&]() {
+            if (!cur.empty()) batches.push_back(cur);
+            cur.clear(); nullable_in_slot.clear();
+            std::fill(slot_of.begin(), slot_of.end(), -1);
+        };
+        for (int i = 0; i < naggs; i++) {
+            if (aggs[i].kind == BOWGPU_AGG_MODE) continue;
+            for (int attempt = 0; attempt < 2; attempt++) {
+                bool fits = (int)cur.size() < kMaxAggs;
+                int s = -1;
+                bool new_slot = false;
+                const bool reads = kind_reads_values(aggs[i].kind), nullable = !kind_never_nil(aggs[i].kind);
+                if (fits && reads) {
+                    s = slot_of[aggs[i].col];
+                    if (s >= 0 && nullable && nullable_in_slot[s] >= 4) s = -1;
+                    if (s < 0) { new_slot = true; fits = (int)nullable_in_slot.size() < kMaxCols; }
+                }
+                if (!fits) { flush(); continue; }  // (an empty batch always takes one reducer)
+                if (reads) {
+                    if (new_slot) { s = (int)nullable_in_slot.size(); nullable_in_slot.push_back(0); slot_of[aggs[i].col] = s; }
+                    if (nullable) nullable_in_slot[s]++;
+                }
+                cur.push_back(i);
+                break;
+            }
         }
-        return run_modes(c, cols, ncols, ts_col, plan, aggs, naggs, outs, inclusive, long_windows);
+        flush();
     }
-    AggJob job;
-    BG_TRY(job_build(c, cols, ncols, ts_col, plan, inclusive, aggs, naggs, outs, wid_base, W, wid_base == 0, &job));
-    BG_TRY(job_run(c, &job, aggs, naggs, long_windows, kernel_ms, true, &plan, true));
+    for (const std::vector<int> &at : batches) {
+        if ((int)at.size() == naggs) {  // the usual case: the whole call in one launch
+            AggJob job;
+            BG_TRY(job_build(c, cols, ncols, ts_col, plan, inclusive, aggs, naggs, outs, wid_base, W, wid_base == 0, &job));
+            BG_TRY(job_run(c, &job, aggs, naggs, long_windows, kernel_ms, true, &plan, true));
+            continue;
+        }
+        std::vector<bowgpu_agg> part;
+        std::vector<bowgpu_out> part_outs;
+        for (int i : at) { part.push_back(aggs[i]); part_outs.push_back(outs[i]); }
+        int64_t lw = 0;
+        double ms = 0;
+        AggJob job;
+        BG_TRY(job_build(c, cols, ncols, ts_col, plan, inclusive, part.data(), (int32_t)part.size(), part_outs.data(), wid_base, W, wid_base == 0, &job));
+        BG_TRY(job_run(c, &job, part.data(), (int32_t)part.size(), &lw, &ms, true, &plan, true));
+        for (size_t j = 0; j < at.size(); j++) outs[at[j]] = part_outs[j];
+        if (long_windows && lw > *long_windows) *long_windows = lw;   // (the same windows in every batch)
+        if (kernel_ms) *kernel_ms += ms;
+    }
+    if (n_mode > 0) return run_modes(c, cols, ncols, ts_col, plan, aggs, naggs, outs, inclusive, long_windows);
     return 0;
 }
 

@@ -132,7 +132,6 @@ static int interp_validate(const bowgpu_col *cols, int32_t ncols, int32_t ts_col
         if (t != BOWGPU_INT64 && t != BOWGPU_FLOAT64) return fail(BOWGPU_ERR_UNSUPPORTED, "column type %s is outside the device path", type_name(t));
     }
     if (o->inclusive) return fail(BOWGPU_ERR_UNSUPPORTED, "Interpolate on inclusive windows duplicates rows in the reference; not on the device path");
-    if (ncols > kMaxCols) return fail(BOWGPU_ERR_UNSUPPORTED, "at most %d columns", kMaxCols);
     return 0;
 }
 
@@ -213,6 +212,7 @@ static int interp_count_impl(const bowgpu_col *cols, int32_t ncols, int32_t ts_c
                              const bowgpu_interp_edge *edge) {
     if (!cols || ncols <= 0 || !n_out) return fail(BOWGPU_ERR_ARG, "null argument");
     if (ts_col < 0 || ts_col >= ncols) return fail(BOWGPU_ERR_BAD_COL, "no interval column with index %d", ts_col);
+    if (edge && ncols > kMaxCols) return fail(BOWGPU_ERR_UNSUPPORTED, "sharded Interpolate: at most %d columns (bowgpu_interp_edge)", kMaxCols);
     bowgpu_options o = {0, 0, 0};
     if (opts) o = *opts;
     Plan probe;
@@ -232,6 +232,7 @@ static int interp_fill_impl(const bowgpu_col *cols, int32_t ncols, int32_t ts_co
                             const bowgpu_interp_edge *edge) {
     if (!cols || ncols <= 0 || !outs) return fail(BOWGPU_ERR_ARG, "null argument");
     if (ts_col < 0 || ts_col >= ncols) return fail(BOWGPU_ERR_BAD_COL, "no interval column with index %d", ts_col);
+    if (edge && ncols > kMaxCols) return fail(BOWGPU_ERR_UNSUPPORTED, "sharded Interpolate: at most %d columns (bowgpu_interp_edge)", kMaxCols);
     bowgpu_options o = {0, 0, 0};
     if (opts) o = *opts;
     Plan probe;
@@ -266,29 +267,40 @@ static int interp_fill_impl(const bowgpu_col *cols, int32_t ncols, int32_t ts_co
     P.has_left = job.has_left; P.left_ts = job.left_ts; P.wbase = job.wbase;
     P.fast32 = interp_fast32(job.plan, job.kq) ? 1 : 0;
     if (P.fast32) interp_magic32(job.plan.interval, &P.m32, &P.sh1_32, &P.sh2_32);
-    P.ncols = ncols; P.ts_col = ts_col;
+    P.ts_col = ts_col;
     for (int i = 0; i < ncols; i++) {
         DevCol &dc = job.dcols[i];
         if (i == ts_col) { dc.values = job.dts.values; dc.length = n; dc.type = BOWGPU_INT64; }
         else BG_TRY(devcol_prepare(c, &cols[i], &dc, true, true));
-        BG_TRY(devout_prepare(c, &outs[i], n_out, &douts[i], i));  // validity working copy from the context pool
+        BG_TRY(devout_prepare(c, &outs[i], n_out, &douts[i], i < 16 ? i : -1));  // validity working copy from the context pool
         BG_HIP(hipMemsetAsync(douts[i].validity, 0, (size_t)(((n_out + 7) >> 3) + 3) & ~(size_t)3, c->stream));
-        InterpCol &ic = P.cols[i];
-        ic.values = reinterpret_cast<const uint64_t *>(dc.values);
-        ic.vbits = dc.vbits; ic.vbit0 = dc.vbit0; ic.type = cols[i].type; ic.kind = interps[i].kind;
-        ic.const_value = interps[i].const_value;
-        ic.has_prev = interps[i].has_prev_row; ic.prev_t_valid = interps[i].prev_t_valid; ic.prev_v_valid = interps[i].prev_v_valid;
-        ic.prev_t = interps[i].prev_t; ic.prev_v = interps[i].prev_v; ic.prev_v_i64 = interps[i].prev_v_i64;
-        ic.out_values = reinterpret_cast<uint64_t *>(douts[i].values);
-        ic.out_valid_words = reinterpret_cast<uint32_t *>(douts[i].validity);
-        if (edge && edge->next_valid[i]) { ic.next_valid = 1; ic.next_t = edge->next_t[i]; ic.next_v = edge->next_v[i]; }
-        if (dc.vbits && (ic.kind == BOWGPU_INTERP_LINEAR || ic.kind == BOWGPU_INTERP_STEP_PREVIOUS)) {
-            void *ix;
-            BG_TRY(ctx_pool(c, kPoolInterp + 3 + i, nbr_index_bytes(n, dc.vbit0), &ix));
-            BG_TRY(nbr_index_build(c, dc.vbits, dc.vbit0, n, ix, &ic.nbr));
-        }
     }
-    BG_TRY(launch_interp_tiles(c, P));
+    // the output positions depend on the interval column alone, so the columns go through the tile kernel kMaxCols at a time
+    // (a Bow of any width: interpolation.go:98-161 loops over the interpolators)
+    for (int b0 = 0; b0 < ncols; b0 += kMaxCols) {
+        const int nb = ncols - b0 < kMaxCols ? ncols - b0 : kMaxCols;
+        P.ncols = nb;
+        for (int j = 0; j < nb; j++) {
+            const int i = b0 + j;
+            const DevCol &dc = job.dcols[i];
+            InterpCol &ic = P.cols[j];
+            memset(&ic, 0, sizeof ic);
+            ic.values = reinterpret_cast<const uint64_t *>(dc.values);
+            ic.vbits = dc.vbits; ic.vbit0 = dc.vbit0; ic.type = cols[i].type; ic.kind = interps[i].kind;
+            ic.const_value = interps[i].const_value;
+            ic.has_prev = interps[i].has_prev_row; ic.prev_t_valid = interps[i].prev_t_valid; ic.prev_v_valid = interps[i].prev_v_valid;
+            ic.prev_t = interps[i].prev_t; ic.prev_v = interps[i].prev_v; ic.prev_v_i64 = interps[i].prev_v_i64;
+            ic.out_values = reinterpret_cast<uint64_t *>(douts[i].values);
+            ic.out_valid_words = reinterpret_cast<uint32_t *>(douts[i].validity);
+            if (edge && edge->next_valid[i]) { ic.next_valid = 1; ic.next_t = edge->next_t[i]; ic.next_v = edge->next_v[i]; }
+            if (dc.vbits && (ic.kind == BOWGPU_INTERP_LINEAR || ic.kind == BOWGPU_INTERP_STEP_PREVIOUS)) {
+                void *ix;
+                BG_TRY(ctx_pool(c, kPoolInterp + 3 + j, nbr_index_bytes(n, dc.vbit0), &ix));  // (reused by the next batch: stream order)
+                BG_TRY(nbr_index_build(c, dc.vbits, dc.vbit0, n, ix, &ic.nbr));
+            }
+        }
+        BG_TRY(launch_interp_tiles(c, P));
+    }
     uint64_t *dcnt = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(dscr) + 1024);
     std::vector<uint64_t> hcnt(ninterps, 0);
     for (int i = 0; i < ninterps; i++) {

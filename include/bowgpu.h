@@ -178,7 +178,8 @@ int bowgpu_plan_windows(const bowgpu_col *ts, int64_t interval, int64_t offset, 
 /* Rolling.Aggregate — reference rolling/aggregation.go:123-238 (indexedAggregations,
  * validateAggregation, aggregateWindows) fused with the reducers of rolling/aggregation/.
  * One pass over the interval column buckets rows into windows; every aggregator of every
- * value column is reduced in that same pass.
+ * value column is reduced in that same pass (any number of aggregators and columns: beyond 16 outputs /
+ * 8 column passes the call is cut into launches internally; aggregation.Mode runs as a pass of its own).
  *   cols[ncols]   the Bow's columns (only those referenced by ts_col / aggs are touched)
  *   outs[naggs]   one output column per aggregator, in aggregator order (A.7)
  * Device-path contract: interval column Int64, no nulls, ascending (else BOWGPU_ERR_TS_NULLS /

@@ -287,6 +287,27 @@ def test_sixteen_outputs_in_one_call():
     assert capi.last_kernel_name() == "rolling_simple_kernel"
 
 
+def test_more_outputs_and_columns_than_one_launch_takes():
+    """the reference loops over any number of aggregators (aggregation.go:190-238): calls beyond one launch's 16 outputs / 8
+    column passes are cut into batches behind the ABI - 40 reducers over 12 columns, Mode and inclusive reducers among them"""
+    rng = np.random.default_rng(8)
+    n = 20_000
+    ts = make_ts(rng, n, "irregular")
+    cols = [make_vals(rng, n, "f64" if j % 3 else "i64", [0.0, 0.2, 0.6][j % 3]) for j in range(12)]
+    kinds = ["Sum", "ArithmeticMean", "Min", "Max", "Count", "First", "Last", "NumRows", "IntegralStep", "WeightedAverageLinear", "Mode"]
+    aggs = [("WindowStart", 0)]
+    for i in range(39):
+        k = kinds[int(rng.integers(0, len(kinds)))]
+        a = (k, 1 + int(rng.integers(0, 12)))
+        aggs.append(a + ([2.0],) if rng.random() < 0.2 and k != "Mode" else a)
+    aggs.append(("Sum", 0))           # the interval column as a value column, last in the list (new interval column = this one)
+    outs, exp, info = run_both(ts, cols, 25, aggs, offset=4)
+    assert len(outs) == 41
+    # all twelve columns with five nullable reducers each: more column passes than a launch has
+    aggs = [("WindowStart", 0)] + [(k, 1 + j) for j in range(12) for k in ("ArithmeticMean", "Min", "Max", "First", "Last")]
+    run_both(ts, cols, 7, aggs)
+
+
 def test_nan_inf_signed_zero_semantics():
     # minmax.go: NaN result iff the FIRST valid value is NaN; -0.0/+0.0 ties keep the earlier one
     ts = np.array([0, 1, 2, 10, 11, 12, 20, 21, 30, 31, 40, 41, 42], dtype=np.int64)

@@ -124,6 +124,27 @@ def test_interpolate_empty_window_runs_and_the_minus_one_sentinel():
     check(np.array([-3, -2, 0, 8, 9], dtype=np.int64), 5, 4)
 
 
+def test_interpolate_a_wide_bow():
+    """a Bow of 21 columns (the tile kernel takes 8 per launch; interpolation.go:98-161 loops over any number)"""
+    rng = np.random.default_rng(23)
+    n = 3000
+    ts = np.cumsum(rng.integers(1, 9, n)).astype(np.int64)
+    ccols, ocols, ip = [capi.Column(ts, None, capi.INT64)], [orc.Column(ts, None, orc.INT64)], [{"kind": "WindowStart", "col": 0}]
+    for j in range(1, 21):
+        as_int = j % 4 == 0
+        v = rng.integers(-50, 50, n).astype(np.int64) if as_int else np.round(rng.standard_normal(n), 2)
+        bm = None if j % 5 == 0 else np.packbits(rng.random(n) > 0.3, bitorder="little")
+        typ = capi.INT64 if as_int else capi.FLOAT64
+        ccols.append(capi.Column(v, bm, typ, 0, n, -1 if bm is not None else 0))
+        ocols.append(orc.Column(v, bm, typ))
+        ip.append({"kind": ["Linear", "StepPrevious", "None"][j % 3], "col": j})
+    got = capi.rolling_interpolate(ccols, 0, 10, ip, offset=3)
+    want = orc.interpolate(ocols, 0, 10, ip, offset=3)
+    assert len(got) == 21
+    for j, (g, w) in enumerate(zip(got, want)):
+        cmp_out("wide bow column %d" % j, g, w)
+
+
 def test_interpolate_across_long_null_runs():
     # runs of nulls longer than a 4096-bit block of the neighbour index, with irregular ts: Linear / StepPrevious at every
     # window start inside a run reach the same two far-away neighbours.  (Sizes are bounded by the ORACLE: like the reference's
