@@ -25,6 +25,7 @@ constexpr int kIThreads = 256;
 constexpr int kCountThreads = 256;  // interp_count_kernel: four tiles (wavefronts) per workgroup
 constexpr int kIStage = 1024;       // outputs of one column staged in LDS per tile (rows + synthetic rows)
 constexpr int kISpanWords = 128;    // output validity bits staged in LDS per column: 4096 bits (rows + synthetic rows of a tile)
+constexpr int kLongRuns = 32;       // long runs of empty windows a tile shares among its threads (more: their owners write them)
 constexpr int kSmallRun = 4;        // synthetic rows a lane writes itself; longer runs of empty windows go to the whole workgroup
 
 // the value an interpolator gives the synthetic row of a window starting at sk whose FirstIndex is row a
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(kIThreads) void interp_tile_kernel(const InterpPara
     __shared__ long long wave_tot[kIThreads / 64];
     __shared__ long long wave_last[kIThreads / 64];
     __shared__ int s_nlong;
-    __shared__ LongRun runs[kIThreads];
+    __shared__ LongRun runs[kLongRuns];
     __shared__ uint64_t sval2[2][kIStage];  // double-buffered by column parity: a column is staged while the previous one drains
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t r0 = (int64_t)blockIdx.x * kITile;
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(kIThreads) void interp_tile_kernel(const InterpPara
         own_run[k] = f.synth[k] > 0;
         if (f.synth[k] > kSmallRun) {
             const int q = atomicAdd(&s_nlong, 1);
-            if (q < kIThreads) {
+            if (q < kLongRuns) {
                 runs[q].a = i + k; runs[q].o_row = o_row[k]; runs[q].synth = f.synth[k];
                 runs[q].k0 = f.exact[k] ? f.wid[k] - 1 : f.wid[k];
                 own_run[k] = false;
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(kIThreads) void interp_tile_kernel(const InterpPara
         }
     }
     __syncthreads();
-    const int nlong = s_nlong < kIThreads ? s_nlong : kIThreads;
+    const int nlong = s_nlong < kLongRuns ? s_nlong : kLongRuns;
 
     // ---- one column at a time (the next column's loads go out before this one's stores)
     const bool contiguous = f.synth[1] == 0 && emitted[0] && i + 1 < p.n;
