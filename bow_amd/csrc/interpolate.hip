@@ -13,6 +13,8 @@
 //   interp_tile_kernel    per tile: flags, workgroup scan, copy the rows of every column to their positions, synthesise
 //                         the start rows, assemble the output validity bits in LDS (flushed as whole words)
 // Algorithmic traffic: 8 B (ts, twice) + 8 B per column read, 8 B per column written, per row.
+#include <stdlib.h>
+
 #include "bitmap_device.h"
 
 namespace bowgpu {
@@ -355,6 +357,310 @@ __global__ __launch_bounds__(kIThreads) void interp_tile_kernel(const InterpPara
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// interp_wave_kernel: the same pass for the usual shape (fast32: every row in [s0, s0 + 2^31), no dropped rows, no -1 sentinel
+// window) with ONE WAVEFRONT per 512 rows and no barrier.  interp_tile_kernel is bound by waiting (six workgroup barriers per
+// tile; every synthetic row walks bitmap -> neighbour index -> value through dependent global loads).  Here:
+//   phase 1  flags and output positions of the trip's four 128-row chunks (lane l = rows 2l, 2l+1): a wave scan per chunk and a
+//            running scalar total; per-lane results parked in the wavefront's LDS slice;
+//   phase 2  column by column, chunk by chunk (rolled loops: one copy of the code, few registers): the column's validity as
+//            two 64-bit words (scalar loads) split into even-row / odd-row lane masks; the neighbours of a window start from
+//            those masks (count-leading / trailing-zeros) with values and timestamps by shuffle, the previous chunk's last
+//            valid point carried in scalar registers, the bitmap + index consulted once per trip (before its first row) and
+//            by the rare lane whose next valid row lies beyond its chunk; outputs staged in LDS in output order and written
+//            as contiguous stores; output validity = the ballot of the staged flags, streamed through a scalar bit
+//            accumulator into whole words (atomic only where a word is shared with another trip).
+constexpr int kWStage = 256;  // outputs of one chunk staged in LDS (128 rows + up to 128 synthetic rows; more: written directly)
+
+struct NbPoint { int64_t t; uint64_t bits; int has; };
+
+// synth_value with the neighbours given as points (the valid row before FirstIndex / from it on) instead of row numbers
+__device__ __forceinline__ void synth_value_pt(const InterpCol &ic, int64_t sk, const NbPoint &pp, const NbPoint &np, uint64_t *bits_out,
+                                               int *valid_out) {
+    const bool is_int = ic.type == BOWGPU_INT64;
+    uint64_t bits = 0;
+    int valid = 0;
+    switch (ic.kind) {
+    case BOWGPU_INTERP_WINDOW_START:
+        bits = is_int ? (uint64_t)sk : (uint64_t)__double_as_longlong((double)sk);
+        valid = 1;
+        break;
+    case BOWGPU_INTERP_CONST:
+        bits = is_int ? (uint64_t)go_f64_to_i64(ic.const_value) : (uint64_t)__double_as_longlong(ic.const_value);
+        valid = 1;
+        break;
+    case BOWGPU_INTERP_LINEAR: {
+        double t0, v0;
+        if (pp.has) { t0 = (double)pp.t; v0 = bits_to_f64(pp.bits, ic.type); }
+        else if (ic.has_prev && ic.prev_t_valid && ic.prev_v_valid) { t0 = ic.prev_t; v0 = ic.prev_v; }
+        else break;
+        double t2, v2;
+        if (np.has) { t2 = (double)np.t; v2 = bits_to_f64(np.bits, ic.type); }
+        else if (ic.next_valid) { t2 = ic.next_t; v2 = ic.next_v; }
+        else break;
+        const double coef = ((double)sk - t0) / (t2 - t0);
+        const double r = ((v2 - v0) * coef) + v0;
+        bits = is_int ? (uint64_t)go_f64_to_i64(r) : (uint64_t)__double_as_longlong(r);
+        valid = 1;
+        break;
+    }
+    case BOWGPU_INTERP_STEP_PREVIOUS:
+        if (pp.has) { bits = pp.bits; valid = 1; }
+        else if (ic.has_prev && ic.prev_v_valid) {
+            bits = is_int ? (uint64_t)ic.prev_v_i64 : (uint64_t)__double_as_longlong(ic.prev_v);
+            valid = 1;
+        }
+        break;
+    default: break;
+    }
+    *bits_out = valid ? bits : 0;
+    *valid_out = valid;
+}
+
+struct WaveLds {
+    uint64_t val[kWStage];
+    uint8_t flag[kWStage];
+    uint32_t synth[4][2][64], k0[4][2][64], orel[4][2][64];  // [chunk][row of the lane][lane]
+    uint32_t o0[4], tot[4];
+};
+
+__device__ __forceinline__ void wave_lds_order() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// output validity bits of one column, appended in output order; whole words leave with plain stores, a word that another trip
+// (or a directly written chunk) may also touch with an atomic OR.  All state is wave-uniform.
+struct BitStream {
+    uint32_t *words;
+    uint64_t acc;      // pending bits (fewer than 32 between appends)
+    int nacc;
+    int64_t wpos;      // word index of acc's bit 0
+    bool shared;       // the next word to leave may hold bits of somebody else
+    __device__ __forceinline__ void start(uint32_t *w, int64_t bitpos) { words = w; acc = 0; nacc = (int)(bitpos & 31); wpos = bitpos >> 5; shared = true; }
+    __device__ __forceinline__ void append(uint64_t b, int r, int lane) {  // r <= 64 bits of b
+        uint64_t lo = acc | (b << nacc), hi = nacc ? (b >> (64 - nacc)) : 0ull;
+        int total = nacc + r;
+        while (total >= 32) {
+            const uint32_t w = (uint32_t)lo;
+            if (lane == 0) { if (shared) { if (w) atomicOr(&words[wpos], w); } else words[wpos] = w; }
+            shared = false;
+            lo = (lo >> 32) | (hi << 32); hi >>= 32;
+            total -= 32; wpos++;
+        }
+        acc = lo; nacc = total;
+    }
+    __device__ __forceinline__ void finish(int lane) {
+        if (nacc > 0 && lane == 0 && (uint32_t)acc) atomicOr(&words[wpos], (uint32_t)acc);
+        acc = 0; nacc = 0;
+    }
+};
+
+__global__ __launch_bounds__(64) void interp_wave_kernel(const InterpParams p) {
+    __shared__ WaveLds L;
+    const int lane = threadIdx.x;
+    const int64_t trip = blockIdx.x;
+    const int64_t base = trip * 512;
+    if (base >= p.n) return;
+    const int64_t left_trip = p.n - base;
+    const bool full = left_trip >= 512;
+    const Magic32 m32 = {p.m32, p.sh1_32, p.sh2_32};
+    const uint64_t lt = (1ull << lane) - 1ull, gt = lane == 63 ? 0ull : (~0ull << (lane + 1));
+    const int sh2l = (2 * lane) & 63;
+
+    // a pair of one column's rows of chunk k (16-B load when the trip is whole and the column aligned)
+    auto load2 = [&](const uint64_t *col, int k, uint64_t *a, uint64_t *b) {
+        const int r = 128 * k + 2 * lane;
+        const uint64_t *src = col + base;
+        if (full && (reinterpret_cast<uintptr_t>(col) & 15) == 0) { const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(src + r); *a = v.x; *b = v.y; }
+        else { *a = r < left_trip ? src[r] : 0; *b = r + 1 < left_trip ? src[r + 1] : 0; }
+    };
+
+    // ---- phase 1: where the trip's outputs start; flags and output positions (relative to o_trip) of every row
+    int64_t o_trip = 0, t_before = p.left_ts;
+    {
+        uint64_t ta[4], tb[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) load2(reinterpret_cast<const uint64_t *>(p.ts), k, &ta[k], &tb[k]);
+        if (base > 0) {
+            t_before = p.ts[base - 1];
+            const uint32_t wp = mdiv32((uint32_t)((uint64_t)t_before - (uint64_t)p.s0), m32);
+            o_trip = base + (int64_t)wp + 1 - p.wbase - p.tile_exact_before[trip];
+        }
+        uint32_t run = 0;
+        bool unsorted = false;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int64_t i = base + 128 * k + 2 * lane;
+            long long tl = __shfl_up((long long)tb[k], 1);
+            if (lane == 0) tl = k == 0 ? (long long)t_before : (long long)lane_value(tb[k > 0 ? k - 1 : 0], 63);
+            const uint64_t tt[kIR] = {ta[k], tb[k]};
+            const RowsR f = rows_flags<true>(tt, (int64_t)tl, i, p.n, p.s0, p.interval, p.magic, m32, -1, p.has_left != 0, &unsorted);
+            const uint32_t e0 = i < p.n ? 1u : 0u, e1 = i + 1 < p.n ? 1u : 0u;
+            const uint32_t sy0 = (uint32_t)f.synth[0], sy1 = (uint32_t)f.synth[1];
+            const uint32_t mine = e0 + e1 + sy0 + sy1;
+            uint32_t inc = mine;
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(inc, o); if (lane >= o) inc += y; }
+            const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+            uint32_t o = run + inc - mine;
+            o += sy0; L.orel[k][0][lane] = o; o += e0;
+            o += sy1; L.orel[k][1][lane] = o;
+            L.synth[k][0][lane] = sy0; L.synth[k][1][lane] = sy1;
+            L.k0[k][0][lane] = (uint32_t)(f.exact[0] ? f.wid[0] - 1 : f.wid[0]);
+            L.k0[k][1][lane] = (uint32_t)(f.exact[1] ? f.wid[1] - 1 : f.wid[1]);
+            if (lane == 0) { L.o0[k] = run; L.tot[k] = tot; }
+            run += tot;
+        }
+        (void)unsorted;  // (interp_count_kernel has already checked the order)
+    }
+    wave_lds_order();
+
+    // ---- phase 2: one column at a time, one chunk at a time
+#pragma unroll 1
+    for (int c = 0; c < p.ncols; c++) {
+        const InterpCol &ic = p.cols[c];
+        const bool want_p = ic.kind == BOWGPU_INTERP_LINEAR || ic.kind == BOWGPU_INTERP_STEP_PREVIOUS, want_n = ic.kind == BOWGPU_INTERP_LINEAR;
+        const uint64_t *tsu = reinterpret_cast<const uint64_t *>(p.ts);
+        NbPoint carry; carry.has = 0; carry.t = 0; carry.bits = 0;  // the last valid point before the current chunk (wave-uniform)
+        if (want_p && base > 0) {
+            const int64_t pi = prev_valid_ix(ic.vbits, ic.vbit0, p.n, base - 1, ic.nbr);
+            if (pi >= 0) { carry.has = 1; carry.t = p.ts[pi]; carry.bits = ic.values[pi]; }
+        }
+        BitStream bs;
+        bs.start(ic.out_valid_words, o_trip);
+        // (the next chunk's rows are requested before this chunk is worked on)
+        uint64_t na, nb, nta = 0, ntb = 0;
+        load2(ic.values, 0, &na, &nb);
+        if (want_n) load2(tsu, 0, &nta, &ntb);
+#pragma unroll 1
+        for (int k = 0; k < 4; k++) {
+            const int64_t cb = base + 128 * k;
+            if (cb >= p.n) break;
+            const uint64_t a = na, b = nb, ta = nta, tb = ntb;
+            if (k + 1 < 4 && cb + 128 < p.n) {
+                load2(ic.values, k + 1, &na, &nb);
+                if (want_n) load2(tsu, k + 1, &nta, &ntb);
+            }
+            uint64_t w0, w1;
+            load_bits128<false>(ic.vbits, ic.vbit0, cb, p.n, &w0, &w1);
+            const int fl = (int)(((lane < 32 ? w0 : w1) >> sh2l) & 3ull);
+            const uint32_t tot = L.tot[k], o0 = L.o0[k];
+            const uint32_t sy0 = L.synth[k][0][lane], sy1 = L.synth[k][1][lane];
+            const uint32_t or0 = L.orel[k][0][lane] - o0, or1 = L.orel[k][1][lane] - o0;   // relative to the chunk's first output
+            const bool staged = tot <= (uint32_t)kWStage;
+            uint64_t *out = ic.out_values + o_trip + o0;
+            const int64_t obit0 = o_trip + o0;
+            auto put = [&](uint32_t pos, uint64_t bits, int valid) {
+                if (staged) { L.val[pos] = bits; L.flag[pos] = (uint8_t)valid; }
+                else {
+                    out[pos] = bits;
+                    if (valid) atomicOr(&ic.out_valid_words[(obit0 + pos) >> 5], 1u << ((obit0 + pos) & 31));
+                }
+            };
+            const int64_t i = cb + 2 * lane;
+            if (i < p.n) put(or0, a, fl & 1);
+            if (i + 1 < p.n) put(or1, b, (fl >> 1) & 1);
+            uint64_t me = 0, mo = 0;
+            if (want_p) { me = __ballot(fl & 1); mo = __ballot(fl & 2); }
+            if (__ballot(sy0 > 0 || sy1 > 0)) {
+                // pp = the valid point before the lane's even row, np = the valid point from its odd row on
+                NbPoint pp = carry, np; np.has = 0; np.t = 0; np.bits = 0;
+                if (want_p) {
+                    const uint64_t xe = me & lt, xo = mo & lt;
+                    const int le = xe ? 63 - __clzll((long long)xe) : -1, lo = xo ? 63 - __clzll((long long)xo) : -1;
+                    const bool odd = lo >= le, found = (xe | xo) != 0;
+                    const int sl = found ? (odd ? lo : le) : lane;
+                    const uint64_t x0 = __shfl((unsigned long long)a, sl), x1 = __shfl((unsigned long long)b, sl);
+                    if (found) { pp.has = 1; pp.bits = odd ? x1 : x0; }
+                    if (want_n) {
+                        const uint64_t y0 = __shfl((unsigned long long)ta, sl), y1 = __shfl((unsigned long long)tb, sl);
+                        if (found) pp.t = (int64_t)(odd ? y1 : y0);
+                    }
+                }
+                if (want_n) {
+                    const uint64_t xe = me & gt, xo = mo & gt;
+                    const int fe = xe ? __ffsll((long long)xe) - 1 : 64, fo = xo ? __ffsll((long long)xo) - 1 : 64;
+                    const bool even = fe <= fo, found = (xe | xo) != 0;
+                    const int sl = found ? (even ? fe : fo) : lane;
+                    const uint64_t x0 = __shfl((unsigned long long)a, sl), x1 = __shfl((unsigned long long)b, sl);
+                    const uint64_t y0 = __shfl((unsigned long long)ta, sl), y1 = __shfl((unsigned long long)tb, sl);
+                    if (found) { np.has = 1; np.bits = even ? x0 : x1; np.t = (int64_t)(even ? y0 : y1); }
+                }
+                // a lane's first synthetic run sits before its even row when that row starts a window, else before its odd row;
+                // both rows starting windows (one-row windows) takes a second turn
+#pragma unroll 1
+                for (int turn = 0; turn < 2; turn++) {
+                    const bool odd_row = turn == 1 || sy0 == 0;
+                    const bool active = turn == 0 ? (sy0 > 0 || sy1 > 0) : (sy0 > 0 && sy1 > 0);
+                    if (!__ballot(active)) break;
+                    const uint32_t cnt = active ? (odd_row ? sy1 : sy0) : 0u;
+                    const uint32_t kk0 = odd_row ? L.k0[k][1][lane] : L.k0[k][0][lane];
+                    const uint32_t orow = odd_row ? or1 : or0;
+                    // neighbours of that row: before it / from it on
+                    NbPoint qp = pp, qn = np;
+                    if (odd_row) { if (fl & 1) { qp.has = 1; qp.bits = a; qp.t = (int64_t)ta; } }
+                    if (fl & 2) { qn.has = 1; qn.bits = b; qn.t = (int64_t)tb; }
+                    if (!odd_row && (fl & 1)) { qn.has = 1; qn.bits = a; qn.t = (int64_t)ta; }
+                    if (want_n && cnt > 0 && !qn.has) {  // no valid row from here to the end of the chunk: bitmap + index (rare)
+                        const int64_t ni = next_valid_ix(ic.vbits, ic.vbit0, p.n, cb + 128, ic.nbr);
+                        if (ni >= 0) { qn.has = 1; qn.t = p.ts[ni]; qn.bits = ic.values[ni]; }
+                    }
+                    const bool is_long = cnt > (uint32_t)kSmallRun;
+                    if (cnt > 0 && !is_long) {
+                        for (uint32_t j = 0; j < cnt; j++) {
+                            const int64_t sk = p.s0 + (int64_t)((uint64_t)(kk0 - j) * (uint64_t)p.interval);
+                            uint64_t bits; int valid;
+                            synth_value_pt(ic, sk, qp, qn, &bits, &valid);
+                            put(orow - 1 - j, bits, valid);
+                        }
+                    }
+                    uint64_t lm = __ballot(is_long);  // long runs of empty windows: the whole wavefront, one run at a time
+                    while (lm) {
+                        const int src = __ffsll((long long)lm) - 1;
+                        lm &= lm - 1;
+                        const uint32_t rcnt = (uint32_t)__builtin_amdgcn_readlane((int)cnt, src);
+                        const uint32_t rk0 = (uint32_t)__builtin_amdgcn_readlane((int)kk0, src);
+                        const uint32_t ro = (uint32_t)__builtin_amdgcn_readlane((int)orow, src);
+                        NbPoint rp, rn;
+                        rp.has = __builtin_amdgcn_readlane(qp.has, src); rp.bits = lane_value(qp.bits, src); rp.t = (int64_t)lane_value((uint64_t)qp.t, src);
+                        rn.has = __builtin_amdgcn_readlane(qn.has, src); rn.bits = lane_value(qn.bits, src); rn.t = (int64_t)lane_value((uint64_t)qn.t, src);
+                        for (uint32_t j = (uint32_t)lane; j < rcnt; j += 64) {
+                            const int64_t sk = p.s0 + (int64_t)((uint64_t)(rk0 - j) * (uint64_t)p.interval);
+                            uint64_t bits; int valid;
+                            synth_value_pt(ic, sk, rp, rn, &bits, &valid);
+                            put(ro - 1 - j, bits, valid);
+                        }
+                    }
+                }
+            }
+            if (staged) {
+                wave_lds_order();
+                for (uint32_t g = 0; g < tot; g += 64) {
+                    const uint32_t j = g + (uint32_t)lane;
+                    int fv = 0;
+                    if (j < tot) { out[j] = L.val[j]; fv = L.flag[j]; }
+                    const uint64_t bb = __ballot(fv != 0);
+                    bs.append(bb, (int)(tot - g < 64u ? tot - g : 64u), lane);
+                }
+                wave_lds_order();
+            } else {  // written directly (values + atomic bits): restart the bit stream behind this chunk
+                bs.finish(lane);
+                bs.start(ic.out_valid_words, obit0 + (int64_t)tot);
+            }
+            if (want_p && (me | mo)) {  // the chunk's last valid point, for the chunks after it
+                const int le = me ? 63 - __clzll((long long)me) : -1, lo = mo ? 63 - __clzll((long long)mo) : -1;
+                const bool odd = lo >= le;
+                const int sl = odd ? lo : le;
+                carry.has = 1;
+                carry.bits = odd ? lane_value(b, sl) : lane_value(a, sl);
+                if (want_n) carry.t = (int64_t)(odd ? lane_value(tb, sl) : lane_value(ta, sl));
+            }
+        }
+        bs.finish(lane);
+    }
+}
+
 // The two corner cases of the reference's window walk that are not statements about single rows:
 //   status[1] = 1 when window kq (the one that starts at -1, if any) has no row of its own;
 //   status[2..3] = number of leading rows below s0 when window 0 has no row of its own: Go's truncating division can put
@@ -422,7 +728,12 @@ void interp_magic32(int64_t interval, uint32_t *m, uint32_t *sh1, uint32_t *sh2)
 int launch_interp_tiles(Ctx *c, const InterpParams &p) {
     const int64_t ntiles = (p.n + kITile - 1) / kITile;
     if (ntiles <= 0) return 0;
-    if (p.fast32) hipLaunchKernelGGL(interp_tile_kernel<true>, dim3((unsigned)ntiles), dim3(kIThreads), 0, c->stream, p);
+    // the usual shape takes the barrier-free wave kernel (BOWGPU_INTERP_TILE=1: test switch that keeps it on the tile kernel)
+    const char *force_tile = getenv("BOWGPU_INTERP_TILE");
+    static_assert(kITile == 512, "interp_wave_kernel's trips are the count kernel's tiles");
+    if (p.fast32 && p.drop == 0 && p.kq < 0 && !(force_tile && force_tile[0] == '1'))
+        hipLaunchKernelGGL(interp_wave_kernel, dim3((unsigned)ntiles), dim3(64), 0, c->stream, p);
+    else if (p.fast32) hipLaunchKernelGGL(interp_tile_kernel<true>, dim3((unsigned)ntiles), dim3(kIThreads), 0, c->stream, p);
     else hipLaunchKernelGGL(interp_tile_kernel<false>, dim3((unsigned)ntiles), dim3(kIThreads), 0, c->stream, p);
     BG_HIP(hipGetLastError());
     return 0;

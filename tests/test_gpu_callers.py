@@ -28,6 +28,31 @@ def _interps(spec):
     return out
 
 
+def both_interp_kernels(fn):
+    """runs fn() under both Interpolate tile kernels (the barrier-free wave kernel takes the usual shapes; BOWGPU_INTERP_TILE=1
+    keeps them on the workgroup kernel that serves the rest), checks that they agree bit for bit, returns the first result"""
+    import os
+    res = []
+    for flag in ("0", "1"):
+        os.environ["BOWGPU_INTERP_TILE"] = flag
+        try:
+            res.append(fn())
+        finally:
+            os.environ["BOWGPU_INTERP_TILE"] = "0"
+    a, b = res
+    if isinstance(a, list) and a and isinstance(a[0], list):   # one list of columns per shard
+        a_cols, b_cols = [c for sh in a for c in sh], [c for sh in b for c in sh]
+    else:
+        a_cols, b_cols = list(a), list(b)
+    assert len(a_cols) == len(b_cols)
+    for x, y in zip(a_cols, b_cols):
+        assert x.length == y.length and x.null_count == y.null_count
+        xv, xb = x.host_arrays()
+        yv, yb = y.host_arrays()
+        assert np.array_equal(xv.view(np.uint64), yv.view(np.uint64)) and np.array_equal(xb, yb)
+    return a
+
+
 def cmp_out(name, got, want):
     assert got.length == want.length, (name, got.length, want.length)
     gm, wm = got.valid_mask(), want.valid_mask()
@@ -78,7 +103,8 @@ def test_interpolate_random_vs_oracle(vtype):
                 ip = [{"kind": "WindowStart", "col": 0}, {"kind": kind, "col": 1}]
                 if prev is not None:
                     ip[1]["prev"] = prev
-                got = capi.rolling_interpolate([capi.Column(ts), capi.Column(vals, bm, typ, 0, n, -1)], 0, interval, ip, offset=offset)
+                got = both_interp_kernels(lambda: capi.rolling_interpolate([capi.Column(ts), capi.Column(vals, bm, typ, 0, n, -1)], 0, interval, ip,
+                                                                           offset=offset))
                 want = orc.interpolate([orc.Column(ts, None, orc.INT64), orc.Column(vals, bm, typ)], 0, interval, ip, offset=offset)
                 cmp_out("ts %s" % kind, got[0], want[0])
                 cmp_out("val %s n=%d prev=%s" % (kind, n, prev is not None), got[1], want[1])
@@ -97,8 +123,8 @@ def test_interpolate_empty_window_runs_and_the_minus_one_sentinel():
         v2 = rng.integers(-50, 50, n).astype(np.int64)
         m1, m2 = rng.random(n) >= 0.3, rng.random(n) >= 0.3
         b1, b2 = np.packbits(m1, bitorder="little"), np.packbits(m2, bitorder="little")
-        got = capi.rolling_interpolate([capi.Column(ts), capi.Column(v1, b1, capi.FLOAT64, 0, n, -1), capi.Column(v2, b2, capi.INT64, 0, n, -1)],
-                                       0, interval, ip, offset=offset)
+        got = both_interp_kernels(lambda: capi.rolling_interpolate(
+            [capi.Column(ts), capi.Column(v1, b1, capi.FLOAT64, 0, n, -1), capi.Column(v2, b2, capi.INT64, 0, n, -1)], 0, interval, ip, offset=offset))
         want = orc.interpolate([orc.Column(ts, None, orc.INT64), orc.Column(v1, b1, orc.FLOAT64), orc.Column(v2, b2, orc.INT64)],
                                0, interval, ip, offset=offset)
         for c in range(3):
@@ -138,7 +164,7 @@ def test_interpolate_a_wide_bow():
         ccols.append(capi.Column(v, bm, typ, 0, n, -1 if bm is not None else 0))
         ocols.append(orc.Column(v, bm, typ))
         ip.append({"kind": ["Linear", "StepPrevious", "None"][j % 3], "col": j})
-    got = capi.rolling_interpolate(ccols, 0, 10, ip, offset=3)
+    got = both_interp_kernels(lambda: capi.rolling_interpolate(ccols, 0, 10, ip, offset=3))
     want = orc.interpolate(ocols, 0, 10, ip, offset=3)
     assert len(got) == 21
     for j, (g, w) in enumerate(zip(got, want)):
@@ -163,8 +189,8 @@ def test_interpolate_across_long_null_runs():
         m = n - off
         for kind in ("Linear", "StepPrevious"):
             ip = [{"kind": "WindowStart", "col": 0}, {"kind": kind, "col": 1}]
-            got = capi.rolling_interpolate([capi.Column(ts, None, capi.INT64, off, m, 0), capi.Column(vals, bm, capi.FLOAT64, off, m, -1)],
-                                           0, 1000, ip, offset=3)
+            got = both_interp_kernels(lambda: capi.rolling_interpolate(
+                [capi.Column(ts, None, capi.INT64, off, m, 0), capi.Column(vals, bm, capi.FLOAT64, off, m, -1)], 0, 1000, ip, offset=3))
             want = orc.interpolate([orc.Column(ts, None, orc.INT64, offset=off, length=m),
                                     orc.Column(vals, bm, orc.FLOAT64, offset=off, length=m)], 0, 1000, ip, offset=3)
             cmp_out("ts " + kind, got[0], want[0])

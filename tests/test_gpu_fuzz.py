@@ -11,6 +11,7 @@ import pytest
 from bow_amd import capi
 from oracle import pyoracle as orc
 from test_gpu_aggregate import ALL_AGGS, TIME_AGGS, ORDER_SENSITIVE, compare
+from test_gpu_callers import both_interp_kernels
 from test_gpu_callers import cmp_out
 
 pytestmark = pytest.mark.gpu
@@ -157,7 +158,7 @@ def test_fuzz_interpolate_and_fills(seed):
         ip = [{"kind": "WindowStart", "col": 0}, {"kind": kind, "col": 1}]
         if rng.random() < 0.3:
             ip[1]["prev"] = (float(ts[0] - 3), True, 42.5, True, 42)
-        got = capi.rolling_interpolate(ccols, 0, interval, ip, offset=offset)
+        got = both_interp_kernels(lambda: capi.rolling_interpolate(ccols, 0, interval, ip, offset=offset))
         want = orc.interpolate(ocols, 0, interval, ip, offset=offset)
         cmp_out(label + " interp ts", got[0], want[0])
         cmp_out(label + " interp " + kind, got[1], want[1])
@@ -259,7 +260,7 @@ def test_fuzz_sharded_interpolate(seed):
             shards.append([capi.Column(ts[a:b].copy(), None, capi.INT64).to_device(),
                            capi.Column(v[a:b].copy(), np.packbits(valid[a:b], bitorder="little"), typ, 0, b - a, -1).to_device()])
         points = [capi.shard_interp_points(cols, 0) for cols in shards]
-        outs = [capi.shard_interpolate(cols, 0, interval, ip, s0, r, points, offset=offset) for r, cols in enumerate(shards)]
+        outs = both_interp_kernels(lambda: [capi.shard_interpolate(cols, 0, interval, ip, s0, r, points, offset=offset) for r, cols in enumerate(shards)])
         for c in range(2):
             gv = np.concatenate([o[c].host_arrays()[0].view(np.uint64) for o in outs])
             gm = np.concatenate([o[c].valid_mask() for o in outs])

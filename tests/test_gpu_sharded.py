@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 from bow_amd import capi, sharded
+from test_gpu_callers import both_interp_kernels
 from oracle import pyoracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -187,7 +188,7 @@ def test_sharded_interpolate_equals_whole(kind):
                            capi.Column(v1[a:b].copy(), np.packbits(m1[a:b], bitorder="little"), capi.FLOAT64, 0, b - a, -1).to_device(),
                            capi.Column(v2[a:b].copy(), np.packbits(m2[a:b], bitorder="little"), capi.INT64, 0, b - a, -1).to_device()])
         points = [capi.shard_interp_points(cols, 0) for cols in shards]
-        outs = [capi.shard_interpolate(cols, 0, interval, ip, s0, r, points, offset=offset) for r, cols in enumerate(shards)]
+        outs = both_interp_kernels(lambda: [capi.shard_interpolate(cols, 0, interval, ip, s0, r, points, offset=offset) for r, cols in enumerate(shards)])
         for c in range(3):
             gv = np.concatenate([o[c].host_arrays()[0].view(np.uint64) for o in outs])
             gm = np.concatenate([o[c].valid_mask() for o in outs])
