@@ -489,16 +489,25 @@ __global__ __launch_bounds__(64) void interp_wave_kernel(const InterpParams p) {
             o_trip = base + (int64_t)wp + 1 - p.wbase - p.tile_exact_before[trip];
         }
         uint32_t run = 0;
-        bool unsorted = false;
+        // 32-bit forms of rows_flags<true> (every row lies in [s0, s0 + 2^31); interp_count_kernel has checked the order):
+        // window id from one multiply-high, "exact head" as an integer comparison
+        const uint32_t s0lo = (uint32_t)p.s0, i32 = (uint32_t)p.interval;
+        uint32_t rb_prev = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int64_t i = base + 128 * k + 2 * lane;
-            long long tl = __shfl_up((long long)tb[k], 1);
-            if (lane == 0) tl = k == 0 ? (long long)t_before : (long long)lane_value(tb[k > 0 ? k - 1 : 0], 63);
-            const uint64_t tt[kIR] = {ta[k], tb[k]};
-            const RowsR f = rows_flags<true>(tt, (int64_t)tl, i, p.n, p.s0, p.interval, p.magic, m32, -1, p.has_left != 0, &unsorted);
-            const uint32_t e0 = i < p.n ? 1u : 0u, e1 = i + 1 < p.n ? 1u : 0u;
-            const uint32_t sy0 = (uint32_t)f.synth[0], sy1 = (uint32_t)f.synth[1];
+            const uint32_t ra = (uint32_t)ta[k] - s0lo, rb = (uint32_t)tb[k] - s0lo;
+            uint32_t rl = __shfl_up(rb, 1);
+            if (lane == 0) rl = k == 0 ? (uint32_t)t_before - s0lo : (uint32_t)__builtin_amdgcn_readlane((int)rb_prev, 63);
+            rb_prev = rb;
+            const bool in0 = i < p.n, in1 = i + 1 < p.n;
+            const bool first = i == 0 && !p.has_left;  // the frame's first row has no left neighbour
+            const uint32_t wl = mdiv32(rl, m32), wa = mdiv32(ra, m32), wb = mdiv32(rb, m32);
+            const bool head0 = in0 && (first || wa != wl), head1 = in1 && wb != wa;
+            const bool exact0 = head0 && ra == wa * i32, exact1 = head1 && rb == wb * i32;
+            const uint32_t sy0 = head0 ? ((first ? 0u : wa - wl - 1u) + (exact0 ? 0u : 1u)) : 0u;
+            const uint32_t sy1 = head1 ? (wb - wa - 1u + (exact1 ? 0u : 1u)) : 0u;
+            const uint32_t e0 = in0 ? 1u : 0u, e1 = in1 ? 1u : 0u;
             const uint32_t mine = e0 + e1 + sy0 + sy1;
             uint32_t inc = mine;
             for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(inc, o); if (lane >= o) inc += y; }
@@ -507,12 +516,11 @@ __global__ __launch_bounds__(64) void interp_wave_kernel(const InterpParams p) {
             o += sy0; L.orel[k][0][lane] = o; o += e0;
             o += sy1; L.orel[k][1][lane] = o;
             L.synth[k][0][lane] = sy0; L.synth[k][1][lane] = sy1;
-            L.k0[k][0][lane] = (uint32_t)(f.exact[0] ? f.wid[0] - 1 : f.wid[0]);
-            L.k0[k][1][lane] = (uint32_t)(f.exact[1] ? f.wid[1] - 1 : f.wid[1]);
+            L.k0[k][0][lane] = exact0 ? wa - 1u : wa;
+            L.k0[k][1][lane] = exact1 ? wb - 1u : wb;
             if (lane == 0) { L.o0[k] = run; L.tot[k] = tot; }
             run += tot;
         }
-        (void)unsorted;  // (interp_count_kernel has already checked the order)
     }
     wave_lds_order();
 
