@@ -601,3 +601,19 @@ def test_mode_whole_frame():
         want = orc.aggregate_whole(ocols, 0, aggs)
         for k, g, w in zip(_names(aggs), got, want):
             compare("whole %s n=%d" % (k, n), g, w, exact=k != "Sum", rtol=1e-11)
+
+
+def test_mode_only_call_declines_what_the_device_path_declines():
+    """a call made of Mode reducers alone never reaches the tile kernels: the same contract errors must come from its own pass"""
+    ts = np.array([1, 2, 5, 4, 9, 12], dtype=np.int64)
+    v = np.array([1.0, 1.0, 2.0, 2.0, 2.0, 3.0])
+    with pytest.raises(capi.BowGpuError) as e:
+        capi.rolling_aggregate([capi.Column(ts), capi.Column(v)], 0, 4, [("Mode", 0), ("Mode", 1)])
+    assert "TS_UNSORTED" in str(e.value)
+    bm = np.packbits(np.array([1, 1, 0, 1, 1, 1], dtype=bool), bitorder="little")
+    with pytest.raises(capi.BowGpuError) as e:
+        capi.rolling_aggregate([capi.Column(np.sort(ts), bm, capi.INT64, 0, 6, -1), capi.Column(v)], 0, 4, [("Mode", 0), ("Mode", 1)])
+    assert "TS_NULLS" in str(e.value)
+    with pytest.raises(capi.BowGpuError) as e:   # aggregation.go:163-166: the interval column must be kept
+        capi.rolling_aggregate([capi.Column(np.sort(ts)), capi.Column(v)], 0, 4, [("Mode", 1)])
+    assert "KEEP_INTERVAL" in str(e.value)
