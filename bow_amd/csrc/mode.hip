@@ -17,6 +17,8 @@
 // HBM-bound / latency-bound integer work: no MFMA anywhere.
 #include <hipcub/hipcub.hpp>
 
+#include <vector>
+
 #include "agg_device.h"
 #include "bitmap_device.h"
 
@@ -305,10 +307,10 @@ int launch_mode(Ctx *c, const int64_t *ts, const int64_t *first_idx, int64_t n, 
         BG_TRY(db.alloc((size_t)hcount[1] * 24));
         hipLaunchKernelGGL(mode_fetch_bounds_kernel, dim3(64), dim3(256), 0, c->stream, P, (int64_t)hcount[1], reinterpret_cast<int64_t *>(db.p));
         BG_HIP(hipGetLastError());
-        std::string hb((size_t)hcount[1] * 24, '\0');
-        BG_HIP(hipMemcpyAsync(&hb[0], db.p, hb.size(), hipMemcpyDeviceToHost, c->stream));
+        std::vector<int64_t> hb((size_t)hcount[1] * 3);   // (window, first row, end row) of every queued long window
+        BG_HIP(hipMemcpyAsync(hb.data(), db.p, hb.size() * 8, hipMemcpyDeviceToHost, c->stream));
         BG_HIP(hipStreamSynchronize(c->stream));
-        const int64_t *bounds = reinterpret_cast<const int64_t *>(hb.data());
+        const int64_t *bounds = hb.data();
         for (uint32_t q = 0; q < hcount[1]; q++) BG_TRY(mode_long_window(c, P, bounds[3 * q], bounds[3 * q + 1], bounds[3 * q + 2]));
     }
     BG_HIP(hipStreamSynchronize(c->stream));
