@@ -55,6 +55,10 @@ class _Interp(C.Structure):
 
 
 def build(force=False):
+    # BOW_ORACLE_SANITIZED=1 (tests/test_oracle_sanitized.py): the AddressSanitizer + UBSan build of the same source
+    if os.environ.get("BOW_ORACLE_SANITIZED") == "1":
+        subprocess.check_call(["make", "-C", _HERE, "-s", "libbow_oracle_asan.so"])
+        return os.path.join(_HERE, "libbow_oracle_asan.so")
     so = os.path.join(_HERE, "libbow_oracle.so")
     src = os.path.join(_HERE, "bow_oracle.c")
     hdr = os.path.join(_HERE, "bow_oracle.h")
