@@ -1278,6 +1278,52 @@ int bowgpu_shard_aggregate(const bowgpu_col *cols, int32_t ncols, int32_t ts_col
     return 0;
 }
 
+int bowgpu_shard_carry_only(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval, const bowgpu_options *opts,
+                            int64_t global_s0, int32_t holds_global_row0, const bowgpu_agg *aggs, int32_t naggs,
+                            bowgpu_shard_carry *carry) {
+    if (!cols || ncols <= 0 || !carry) return fail(BOWGPU_ERR_ARG, "null argument");
+    if (ts_col < 0 || ts_col >= ncols) return fail(BOWGPU_ERR_BAD_COL, "no interval column with index %d", ts_col);
+    bowgpu_options o = {0, 0, 0};
+    if (opts) o = *opts;
+    int inclusive = 0, nic = -1;
+    BG_TRY(validate_aggs(cols, ncols, ts_col, aggs, naggs, &inclusive, &nic));
+    if (inclusive) return fail(BOWGPU_ERR_UNSUPPORTED, "bowgpu_shard_carry_only: inclusive windows take their carry from bowgpu_shard_aggregate");
+    if (naggs > BOWGPU_CARRY_MAX_AGGS) return fail(BOWGPU_ERR_UNSUPPORTED, "sharded aggregate: too many aggregations");
+    for (int i = 0; i < naggs; i++)
+        if (aggs[i].kind == BOWGPU_AGG_MODE) return fail(BOWGPU_ERR_UNSUPPORTED, "sharded aggregate: Mode is not a mergeable reducer");
+    for (int i = 0; i < ncols; i++)
+        if (cols[i].residency != BOWGPU_DEVICE) return fail(BOWGPU_ERR_UNSUPPORTED, "sharded aggregate: columns must be device-resident");
+    Ctx *c;
+    BG_TRY(ctx_get(&c));
+    Plan plan;
+    int64_t wf, wl;
+    BG_TRY(shard_plan(c, &cols[ts_col], interval, o.offset, global_s0, &plan, &wf, &wl));
+    memset(carry, 0, sizeof *carry);
+    carry->first_window_id = wf;
+    carry->last_window_id = wl;
+    carry->first_ts = plan.first_ts;
+    carry->last_ts = plan.last_ts;
+    carry->nrows = cols[ts_col].length;
+    carry->naggs = naggs;
+    if (plan.W <= 0) return 0;
+    // the descriptor block of the shard's call, with output columns nobody writes (range_state mode 0 only reads rows)
+    std::vector<bowgpu_out> no_outs(naggs);
+    void *dummy;
+    BG_TRY(ctx_pool(c, kPoolShard, 16384, &dummy));
+    for (int i = 0; i < naggs; i++) {
+        memset(&no_outs[i], 0, sizeof(bowgpu_out));
+        no_outs[i].values = dummy; no_outs[i].validity = reinterpret_cast<uint8_t *>(dummy);
+        no_outs[i].length = 0; no_outs[i].residency = BOWGPU_DEVICE;
+    }
+    AggJob job;
+    BG_TRY(job_build(c, cols, ncols, ts_col, plan, 0, aggs, naggs, no_outs.data(), wf, 0, holds_global_row0 != 0, &job));
+    bowgpu_carry_state *dst = reinterpret_cast<bowgpu_carry_state *>(dummy);
+    BG_TRY(launch_range_state(c, job.P, 0, (uint64_t)wl, nullptr, dst, nullptr));
+    BG_HIP(hipMemcpyAsync(carry->last, dst, sizeof(bowgpu_carry_state) * naggs, hipMemcpyDeviceToHost, c->stream));
+    BG_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 int bowgpu_shard_fix_first(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval,
                            const bowgpu_options *opts, int64_t global_s0, int64_t lead, const bowgpu_agg *aggs,
                            int32_t naggs, bowgpu_out *outs, int64_t first_window_id, const bowgpu_carry_state *seeds,

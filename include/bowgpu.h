@@ -372,6 +372,14 @@ int bowgpu_shard_aggregate(const bowgpu_col *cols, int32_t ncols, int32_t ts_col
                            bowgpu_shard_carry *carry,
                            const bowgpu_next_row *next_row /* nullable */, int32_t finish_last);
 
+/* The carry bowgpu_shard_aggregate would export, WITHOUT reducing the shard: only the rows of the shard's last window are read.
+ * Lets a caller put the carry exchange in flight before the shard's main pass (the exchange is latency, the pass is milliseconds).
+ * For calls without inclusive reducers (with them the last window's state depends on the neighbour's first row: use the carry
+ * bowgpu_shard_aggregate returns). */
+int bowgpu_shard_carry_only(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval,
+                            const bowgpu_options *opts, int64_t global_s0, int32_t holds_global_row0,
+                            const bowgpu_agg *aggs, int32_t naggs, bowgpu_shard_carry *carry);
+
 /* This shard's first row in the layout bowgpu_shard_aggregate / _fix_first of the LEFT neighbour expect. */
 int bowgpu_shard_first_row(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, const bowgpu_agg *aggs, int32_t naggs,
                            bowgpu_next_row *out);

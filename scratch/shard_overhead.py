@@ -27,3 +27,4 @@ print("  local_info            %.3f ms" % timeit(sess.local_info))
 print("  phase1 (aggregate)    %.3f ms" % timeit(lambda: sess.phase1(s0, info)))
 c = sess.phase1(s0, info)
 print("  phase2                %.3f ms" % timeit(lambda: sess.phase2([c])))
+print("  shard_carry_only      %.3f ms" % timeit(lambda: p.shard_carry_only(s0, True)))

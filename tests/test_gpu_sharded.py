@@ -197,3 +197,35 @@ def test_sharded_interpolate_equals_whole(kind):
             assert np.array_equal(gm, wm), (mode, c, np.flatnonzero(gm != wm)[:10])
             wv = want[c].values[:want[c].length].view(np.uint64)
             assert np.array_equal(gv[gm], wv[wm]), (mode, c, np.flatnonzero(gv[gm] != wv[wm])[:10])
+
+
+def test_carry_only_equals_the_carry_of_the_pass():
+    """bowgpu_shard_carry_only (what the bench's ranks exchange while their main pass runs) against the carry that
+    bowgpu_shard_aggregate returns, over random splits - empty shards, one-row shards, last windows of thousands of rows,
+    rows below s0 on the first shard"""
+    rng = np.random.default_rng(77)
+    for case in range(40):
+        n = int(rng.integers(1, 30_000))
+        ts = (np.cumsum(rng.integers(0, 4, n)) - int(rng.choice([0, 5000]))).astype(np.int64)
+        vals = np.round(rng.standard_normal(n) * 100, 1)
+        valid = rng.random(n) > rng.choice([0.0, 0.3])
+        interval = int(rng.choice([3, 10, 1000, 20_000]))
+        offset = int(rng.integers(-interval, interval + 1))
+        K = int(rng.integers(2, 6))
+        cuts = np.sort(rng.integers(0, n + 1, K - 1))
+        bounds = list(zip([0] + list(cuts), list(cuts) + [n]))
+        first_nonempty = next(a for a, b in bounds if b > a)
+        s0 = sharded.first_window_start(int(ts[first_nonempty]), interval, offset)
+        aggs = TW_AGGS[:3] + AGGS[1:5] if case % 2 else AGGS
+        aggs = [a for a in aggs if a[0] not in ("IntegralTrapezoid", "WeightedAverageLinear")]
+        for r, (a, b) in enumerate(bounds):
+            if b == a:
+                continue
+            cols = [capi.Column(ts[a:b].copy(), None, capi.INT64).to_device(),
+                    capi.Column(vals[a:b].copy(), np.packbits(valid[a:b], bitorder="little"), capi.FLOAT64, 0, b - a, -1).to_device()]
+            prov = sharded.GpuProvider(cols, 0, interval, aggs, offset=offset)
+            assert not prov.has_inclusive
+            prov.first_last_nrows()
+            early = prov.shard_carry_only(s0, a == 0)
+            full = prov.shard_aggregate(s0, a == 0, 0)
+            assert early == full, (case, r, n, interval, offset)
