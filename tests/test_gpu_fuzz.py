@@ -87,6 +87,8 @@ def run_paths(ccols, ocols, interval, aggs, offset, inclusive, label):
 def test_fuzz_aggregate(seed):
     rng = np.random.default_rng(1000 + seed)
     sizes = [0, 1, 2, 63, 64, 65, 511, 512, 513, 639, 640, 641, 1023, 1025, 2047, 2049, 5000, 40_000]
+    if os.environ.get("BOW_FUZZ_BIG") == "1":   # soak runs: frames of millions of rows (thousands of tiles per call)
+        sizes += [300_000, 1_000_000, 3_000_000]
     for case in range(45):
         n = int(sizes[int(rng.integers(0, len(sizes)))]) if rng.random() < 0.8 else int(rng.integers(0, 3000))
         ts = rand_ts(rng, n)
