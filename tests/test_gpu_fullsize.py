@@ -180,3 +180,25 @@ def test_headline_1e9_every_window_properties_and_sharded():
         assert np.array_equal(g_mean.view(np.uint64), w_mean[fs:fs + nwin].view(np.uint64)), r
         covered += nwin
     assert covered == len(w_ts)
+
+
+def test_fills_and_is_col_sorted_at_full_size():
+    """the four fills and IsColSorted on configs[2]'s columns (irregular int64 ts, 30 % nulls) at 1e8 rows (2e7 on small hosts),
+    every row against the oracle"""
+    n = N8 if BIG_HOST else 20_000_000
+    ts, val = capi.gen_sparse(0, n, seed=9)
+    ts_o, val_o, bm_o = orc.gen_sparse(0, n, seed=9)
+    oval, ots = orc.Column(val_o, bm_o, orc.FLOAT64), orc.Column(ts_o, None, orc.INT64)
+    for method in ("Previous", "Next", "Mean"):
+        got, gu = capi.fill(val, method, out_residency=capi.DEVICE)
+        want, wu = orc.fill(oval, method)
+        assert gu == wu
+        cmp_out("full-size Fill%s" % method, got, want)
+        del got, want
+    got, gu = capi.fill_linear([ts, val], 0, 1, out_residency=capi.DEVICE)
+    want, wu = orc.fill_linear([ots, oval], 0, 1)
+    assert gu == wu
+    cmp_out("full-size FillLinear", got, want)
+    assert capi.is_col_sorted(ts) and orc.is_col_sorted(ots)
+    # a filled column has no nulls left (ts is sorted, the first and the last value of gen_sparse columns may be null)
+    assert got.null_count == want.length - int(want.valid_mask().sum())
