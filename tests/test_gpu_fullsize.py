@@ -202,3 +202,20 @@ def test_fills_and_is_col_sorted_at_full_size():
     assert capi.is_col_sorted(ts) and orc.is_col_sorted(ots)
     # a filled column has no nulls left (ts is sorted, the first and the last value of gen_sparse columns may be null)
     assert got.null_count == want.length - int(want.valid_mask().sum())
+
+
+def test_mode_at_scale():
+    """aggregation.Mode on 2e7 rows of configs[2]'s generator (ten distinct values, 30 % nulls: ties in nearly every window):
+    10-row windows through the lane-per-window class, 1000-row windows through the workgroup class, every window against the oracle"""
+    n = 20_000_000
+    ts, val = capi.gen_sparse(0, n, seed=3)
+    ts_o, val_o, bm_o = orc.gen_sparse(0, n, seed=3)
+    ocols = [orc.Column(ts_o, None, orc.INT64), orc.Column(val_o, bm_o, orc.FLOAT64)]
+    for interval, rows in ((100, 20_000_000), (10_000, 2_000_000)):   # (the oracle's Mode is quadratic in a window's rows)
+        cc = [capi.Column(ts.values, None, capi.INT64, 0, rows, 0), capi.Column(val.values, val.validity, capi.FLOAT64, 0, rows, -1)]
+        oc = [orc.Column(ts_o, None, orc.INT64, length=rows), orc.Column(val_o, bm_o, orc.FLOAT64, length=rows)]
+        aggs = [("WindowStart", 0), ("Mode", 1), ("Count", 1)]
+        got, info = capi.rolling_aggregate(cc, 0, interval, aggs, offset=3, out_residency=capi.DEVICE)
+        want, _ = orc.aggregate(oc, 0, interval, aggs, offset=3)
+        for (k, _), g, w in zip(aggs, got, want):
+            compare("Mode at scale I=%d %s" % (interval, k), g, w)
