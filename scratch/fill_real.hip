@@ -9,6 +9,7 @@ namespace bowgpu {
 void set_error(const char *, ...) {}
 int fail(int code, const char *fmt, ...) { va_list ap; va_start(ap, fmt); vprintf(fmt, ap); va_end(ap); printf("\n"); return code; }
 int hip_fail(hipError_t e, const char *what) { printf("%s: %s\n", what, hipGetErrorString(e)); return -100; }
+int ctx_pool(Ctx *, int, size_t bytes, void **dptr) { return hipMalloc(dptr, bytes) == hipSuccess ? 0 : -100; }  // (leaks: a harness)
 }
 using namespace bowgpu;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
