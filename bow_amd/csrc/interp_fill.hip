@@ -39,31 +39,70 @@ __global__ __launch_bounds__(256) void nbr_block_kernel(const uint32_t *vbits, i
     if (lane == 0) { last_in[g] = hi; first_in[g] = lo; }
 }
 
-// exclusive running max of last_in (-> prev_before) and exclusive reverse running min of first_in (-> next_after):
-// one workgroup, each thread owns a contiguous run of blocks
-__global__ __launch_bounds__(1024) void nbr_scan_kernel(const int64_t *last_in, const int64_t *first_in, int64_t nblocks,
-                                                        int64_t *prev_before, int64_t *next_after) {
-    __shared__ int64_t s_hi[1024], s_lo[1024];
-    const int t = threadIdx.x;
-    const int64_t per = (nblocks + 1023) / 1024;
-    const int64_t a = t * per, b = a + per < nblocks ? a + per : nblocks;
-    int64_t hi = -1, lo = INT64_MAX;
-    for (int64_t g = a; g < b; g++) { if (last_in[g] > hi) hi = last_in[g]; if (first_in[g] < lo) lo = first_in[g]; }
-    s_hi[t] = hi; s_lo[t] = lo;
-    __syncthreads();
-    // inclusive running max (forward) / running min (backward) over the 1024 thread totals, ten doubling steps
-    for (int o = 1; o < 1024; o <<= 1) {
-        const int64_t h = t >= o ? s_hi[t - o] : -1, l = t + o < 1024 ? s_lo[t + o] : INT64_MAX;
-        __syncthreads();
-        if (h > s_hi[t]) s_hi[t] = h;
-        if (l < s_lo[t]) s_lo[t] = l;
-        __syncthreads();
+// exclusive running max of last_in (-> prev_before) and exclusive reverse running min of first_in (-> next_after), in tiles of
+// 1024 blocks: nbr_tile_kernel reduces every tile to (max, min); nbr_scan_kernel folds the tiles before / after its own into a
+// carry and scans its tile with shuffles (coalesced reads and writes; the first version - one workgroup, every thread walking a
+// contiguous run of entries - spent 80 us in dependent strided loads)
+__device__ __forceinline__ void block_max_min(long long &hi, long long &lo, int64_t *s_hi, int64_t *s_lo) {  // 1024 threads; result in s_hi[0], s_lo[0]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int o = 32; o > 0; o >>= 1) {
+        const long long y = __shfl_down(hi, o), z = __shfl_down(lo, o);
+        if (y > hi) hi = y;
+        if (z < lo) lo = z;
     }
-    const int64_t before = t > 0 ? s_hi[t - 1] : -1, after = t < 1023 ? s_lo[t + 1] : INT64_MAX;  // exclusive
-    int64_t run = before;
-    for (int64_t g = a; g < b; g++) { prev_before[g] = run; if (last_in[g] > run) run = last_in[g]; }
-    run = after;
-    for (int64_t g = b - 1; g >= a; g--) { next_after[g] = run == INT64_MAX ? -1 : run; if (first_in[g] < run) run = first_in[g]; }
+    if (lane == 0) { s_hi[wv] = hi; s_lo[wv] = lo; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long h = s_hi[0], l = s_lo[0];
+        for (int w = 1; w < 16; w++) { if (s_hi[w] > h) h = s_hi[w]; if (s_lo[w] < l) l = s_lo[w]; }
+        s_hi[0] = h; s_lo[0] = l;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void nbr_tile_kernel(const int64_t *last_in, const int64_t *first_in, int64_t nblocks, int64_t *tile_hi,
+                                                        int64_t *tile_lo) {
+    __shared__ int64_t s_hi[16], s_lo[16];
+    const int64_t g = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    long long hi = g < nblocks ? last_in[g] : -1, lo = g < nblocks ? first_in[g] : INT64_MAX;
+    block_max_min(hi, lo, s_hi, s_lo);
+    if (threadIdx.x == 0) { tile_hi[blockIdx.x] = s_hi[0]; tile_lo[blockIdx.x] = s_lo[0]; }
+}
+
+__global__ __launch_bounds__(1024) void nbr_scan_kernel(const int64_t *last_in, const int64_t *first_in, int64_t nblocks, const int64_t *tile_hi,
+                                                        const int64_t *tile_lo, int64_t ntiles, int64_t *prev_before, int64_t *next_after) {
+    __shared__ int64_t s_hi[16], s_lo[16], s_wh[16], s_wl[16];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    // carries: everything in the tiles before / after this one
+    long long ch = -1, cl = INT64_MAX;
+    for (int64_t j = t; j < ntiles; j += 1024) {
+        if (j < (int64_t)blockIdx.x && tile_hi[j] > ch) ch = tile_hi[j];
+        if (j > (int64_t)blockIdx.x && tile_lo[j] < cl) cl = tile_lo[j];
+    }
+    block_max_min(ch, cl, s_hi, s_lo);
+    const long long carry_hi = s_hi[0], carry_lo = s_lo[0];
+    __syncthreads();
+    // the tile: inclusive scans inside each wavefront, the 16 wavefront totals through LDS
+    const int64_t g = (int64_t)blockIdx.x * 1024 + t;
+    long long ih = g < nblocks ? last_in[g] : -1, il = g < nblocks ? first_in[g] : INT64_MAX;
+    for (int o = 1; o < 64; o <<= 1) {
+        const long long y = __shfl_up(ih, o), z = __shfl_down(il, o);
+        if (lane >= o && y > ih) ih = y;
+        if (lane + o < 64 && z < il) il = z;
+    }
+    if (lane == 63) s_wh[wv] = ih;
+    if (lane == 0) s_wl[wv] = il;
+    __syncthreads();
+    long long before = __shfl_up(ih, 1), after = __shfl_down(il, 1);
+    if (lane == 0) before = -1;
+    if (lane == 63) after = INT64_MAX;
+    for (int w = 0; w < 16; w++) {
+        if (w < wv && s_wh[w] > before) before = s_wh[w];
+        if (w > wv && s_wl[w] < after) after = s_wl[w];
+    }
+    if (carry_hi > before) before = carry_hi;
+    if (carry_lo < after) after = carry_lo;
+    if (g < nblocks) { prev_before[g] = before; next_after[g] = after == INT64_MAX ? -1 : after; }
 }
 
 
@@ -722,7 +761,7 @@ int launch_first_last_valid(Ctx *c, const uint32_t *vbits, int64_t vbit0, int64_
 
 size_t nbr_index_bytes(int64_t n, int64_t vbit0) {
     const int64_t nblocks = (vbit0 + (n > 0 ? n : 1) - 1) / kNbrBlockBits - vbit0 / kNbrBlockBits + 1;
-    return (size_t)nblocks * 8 * 4;
+    return (size_t)nblocks * 8 * 4 + (size_t)((nblocks + 1023) / 1024) * 8 * 2;  // four per-block tables + two per-tile ones
 }
 
 int nbr_index_build(Ctx *c, const uint32_t *vbits, int64_t vbit0, int64_t n, void *work, NbrIndex *out) {
@@ -731,9 +770,13 @@ int nbr_index_build(Ctx *c, const uint32_t *vbits, int64_t vbit0, int64_t n, voi
     const int64_t nblocks = (vbit0 + n - 1) / kNbrBlockBits - out->g0 + 1;
     int64_t *w = reinterpret_cast<int64_t *>(work);
     int64_t *last_in = w, *first_in = w + nblocks, *prev_before = w + 2 * nblocks, *next_after = w + 3 * nblocks;
+    const int64_t ntiles = (nblocks + 1023) / 1024;
+    int64_t *tile_hi = w + 4 * nblocks, *tile_lo = tile_hi + ntiles;
     hipLaunchKernelGGL(nbr_block_kernel, dim3((unsigned)((nblocks + 3) / 4)), dim3(256), 0, c->stream, vbits, vbit0, n, out->g0, nblocks,
                        last_in, first_in);
-    hipLaunchKernelGGL(nbr_scan_kernel, dim3(1), dim3(1024), 0, c->stream, last_in, first_in, nblocks, prev_before, next_after);
+    hipLaunchKernelGGL(nbr_tile_kernel, dim3((unsigned)ntiles), dim3(1024), 0, c->stream, last_in, first_in, nblocks, tile_hi, tile_lo);
+    hipLaunchKernelGGL(nbr_scan_kernel, dim3((unsigned)ntiles), dim3(1024), 0, c->stream, last_in, first_in, nblocks, tile_hi, tile_lo, ntiles,
+                       prev_before, next_after);
     BG_HIP(hipGetLastError());
     out->prev_before = prev_before; out->next_after = next_after;
     return 0;
