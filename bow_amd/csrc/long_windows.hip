@@ -249,13 +249,116 @@ __global__ __launch_bounds__(256) void long_partial_kernel(const AggParams p, co
     }
 }
 
-// one workgroup (one wave) per long window: merge its chunk partials in order, write the outputs, then the empty
-// windows that follow it
+// One LANE per long window: the usual long window has a handful of chunk partials and no run of empty windows behind it, and
+// finishing it (rebuild the reference's running state from the order-free partial, evaluate the reducers, write the slot) is
+// work for one lane - 64 windows per wavefront instead of one workgroup each.  Windows with more partials or a longer run of
+// empty windows are left to long_final_block_kernel (lane_finishes is the split).
+constexpr int kLaneParts = 8, kLaneGap = 8;
+__device__ __forceinline__ bool lane_finishes(const LongEntry &le, int64_t nparts) {
+    return nparts <= kLaneParts && (int64_t)(le.next_wid - le.wid) - 1 <= kLaneGap;
+}
+
 __global__ __launch_bounds__(256) void long_final_kernel(const AggParams p, const int64_t n_long, const LongEntry *entries,
-                                                         const int64_t *offsets, const Part *partials) {
+                                                         const int64_t *offsets, const Part *partials, int32_t *leftover,
+                                                         unsigned long long *n_leftover) {
+    const int lane = threadIdx.x & 63;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool have = e < n_long;
+    LongEntry le;
+    le.wid = 0; le.r0 = 0; le.r1 = 0; le.next_wid = 1; le.incl_row = 0; le.dead = 1;
+    int64_t w0 = 0, w1 = 0;
+    if (have) { le = entries[e]; w0 = offsets[e]; w1 = offsets[e + 1]; }
+    const int64_t my_gap = have ? (int64_t)(le.next_wid - le.wid) - 1 : 0;
+    const bool simple = have && lane_finishes(le, w1 - w0);
+    if (have && !simple) leftover[atomicAdd(n_leftover, 1ull)] = (int32_t)e;  // (rare) for long_final_block_kernel
+    (void)lane;
+
+    for (int slot = -1; slot < p.ncols; slot++) {
+        const unsigned my_mask = p.pass_mask[slot + 1];
+        if (my_mask == 0) continue;
+        const ColDesc *cd = slot >= 0 ? &p.cols[slot] : nullptr;
+        const int col_type = cd ? cd->type : BOWGPU_INT64;
+        const bool need_vals = cd && (p.pass_flags[slot + 1] & kPassNeedVals);
+        const uint64_t *vp = cd ? reinterpret_cast<const uint64_t *>(cd->values) : nullptr;
+
+        // the outputs of window `w` (an entry) from its merged partial
+        auto finish = [&](const LongEntry &w, const Part &acc) {
+            const int64_t win_start = p.s0 + (int64_t)(w.wid * (uint64_t)p.interval);
+            const int64_t oslot = (int64_t)(w.wid - (uint64_t)p.wid_base);
+            const int64_t len = w.dead ? 0 : w.r1 - w.r0;
+            if ((uint64_t)oslot >= (uint64_t)p.W) return;
+            // rebuild the reference's running state from the order-free partial
+            Stats st;
+            stats_init(st);
+            st.sum = acc.sum; st.count = acc.count; st.has_value = acc.first_idx >= 0;
+            if (st.has_value) {
+                st.first_bits = vp[acc.first_idx]; st.last_bits = vp[acc.last_idx];
+                const double f = bits_to_f64(st.first_bits, col_type);
+                // minmax.go:16-28: seeded by the first valid value; a NaN seed is never replaced
+                st.vmin = (f != f) ? f : (acc.min_idx >= 0 ? acc.vmin : f);
+                st.vmax = (f != f) ? f : (acc.max_idx >= 0 ? acc.vmax : f);
+                st.has_point = 1; st.pt = (double)p.ts[acc.last_idx]; st.pv = bits_to_f64(st.last_bits, col_type);
+                st.integ_trap = acc.trap; st.integ_step = acc.step; st.has_pair = acc.count >= 2;
+            }
+            // the state including the inclusive row, for the reducers that want it (aggregation.go:207-211)
+            Stats st_incl = st;
+            if (w.incl_row && need_vals && col_valid(*cd, w.r1)) {
+                const uint64_t raw = vp[w.r1];
+                const double x = bits_to_f64(raw, col_type);
+                stats_value<false>(st_incl, x, raw);
+                stats_point(st_incl, (double)p.ts[w.r1], x);
+            }
+            for (unsigned m = my_mask; m; m &= m - 1) {
+                const AggDesc &a = p.aggs[__ffs(m) - 1];
+                const bool inc = a.kind == BOWGPU_AGG_INTEGRAL_TRAPEZOID || a.kind == BOWGPU_AGG_WAVG_LINEAR;
+                Val v = finish_val(reduce_val(a.kind, inc ? st_incl : st, inc ? len + w.incl_row : len, win_start, p.interval,
+                                              col_type == BOWGPU_INT64), a);
+                reinterpret_cast<uint64_t *>(a.out_values)[oslot] = v.bits;
+                if (a.out_valid) {
+                    if (v.valid) atomicOr(&a.out_valid[oslot >> 5], 1u << (oslot & 31));
+                    else if (p.bits_preset) atomicAnd(&a.out_valid[oslot >> 5], ~(1u << (oslot & 31)));
+                }
+            }
+        };
+        // the empty windows gk = first, first + step, ... <= gap behind window `w`
+        auto empties = [&](const LongEntry &w, int64_t gap, int64_t first, int64_t step) {
+            const int64_t win_start = p.s0 + (int64_t)(w.wid * (uint64_t)p.interval);
+            const int64_t oslot = (int64_t)(w.wid - (uint64_t)p.wid_base);
+            Stats em;
+            stats_init(em);
+            for (int64_t gk = first; gk <= gap; gk += step) {
+                const int64_t gs = oslot + gk;
+                if (gs < 0 || gs >= p.W) break;
+                const int64_t gstart = win_start + gk * p.interval;
+                for (unsigned m = my_mask; m; m &= m - 1) {
+                    const AggDesc &a = p.aggs[__ffs(m) - 1];
+                    Val v = finish_val(reduce_val(a.kind, em, 0, gstart, p.interval, col_type == BOWGPU_INT64), a);
+                    reinterpret_cast<uint64_t *>(a.out_values)[gs] = v.bits;
+                    if (p.bits_preset && a.out_valid && !v.valid) atomicAnd(&a.out_valid[gs >> 5], ~(1u << (gs & 31)));
+                }
+            }
+        };
+
+        if (simple) {
+            Part acc;
+            part_init(acc);
+            if (need_vals)
+                for (int64_t w = w0; w < w1; w++) part_merge(acc, partials[w * p.ncols + slot]);  // (at most kLaneParts, in order)
+            finish(le, acc);
+            empties(le, my_gap, 1, 1);
+        }
+    }
+}
+
+// The windows long_final_kernel leaves (many chunk partials, or a long run of empty windows behind them): one workgroup per
+// window merges its chunk partials in a fixed shape, writes the outputs, then the empty windows that follow it
+__global__ __launch_bounds__(256) void long_final_block_kernel(const AggParams p, const LongEntry *entries, const int64_t *offsets,
+                                                               const Part *partials, const int32_t *leftover,
+                                                               const unsigned long long *n_leftover) {
     __shared__ Part red[4];
-    const int64_t e = blockIdx.x;
-    if (e >= n_long) return;
+    const int64_t nleft = (int64_t)*n_leftover;  // (usually 0: the launch then costs a few microseconds)
+    for (int64_t i = blockIdx.x; i < nleft; i += gridDim.x) {
+    const int64_t e = leftover[i];
     const LongEntry le = entries[e];
     const int lane = threadIdx.x;
     const int64_t win_start = p.s0 + (int64_t)(le.wid * (uint64_t)p.interval);
@@ -333,6 +436,8 @@ __global__ __launch_bounds__(256) void long_final_kernel(const AggParams p, cons
             }
         }
     }
+    __syncthreads();  // (red[] is reused by the next entry)
+    }
 }
 
 size_t long_entry_size() { return sizeof(LongEntry); }
@@ -359,8 +464,13 @@ int launch_long_windows_v2(Ctx *c, const AggParams &p, const LongListStarts *sta
     hipLaunchKernelGGL(long_map_kernel, dim3((unsigned)((n_long + 3) / 4)), dim3(256), 0, c->stream, n_long, offsets, work_entry);
     hipLaunchKernelGGL(long_partial_kernel, dim3((unsigned)((max_work + 3) / 4)), dim3(256), 0, c->stream, p, n_long,
                        reinterpret_cast<const LongEntry *>(entries), offsets, work_entry, reinterpret_cast<Part *>(partials));
-    hipLaunchKernelGGL(long_final_kernel, dim3((unsigned)n_long), dim3(256), 0, c->stream, p, n_long,
-                       reinterpret_cast<const LongEntry *>(entries), offsets, reinterpret_cast<const Part *>(partials));
+    // the chunk -> window map has served long_partial_kernel: its buffer now lists the windows left to the workgroup kernel
+    unsigned long long *n_leftover = reinterpret_cast<unsigned long long *>(d_total);
+    BG_HIP(hipMemsetAsync(n_leftover, 0, 8, c->stream));
+    hipLaunchKernelGGL(long_final_kernel, dim3((unsigned)((n_long + 255) / 256)), dim3(256), 0, c->stream, p, n_long,
+                       reinterpret_cast<const LongEntry *>(entries), offsets, reinterpret_cast<const Part *>(partials), work_entry, n_leftover);
+    hipLaunchKernelGGL(long_final_block_kernel, dim3((unsigned)(n_long < 2048 ? n_long : 2048)), dim3(256), 0, c->stream, p,
+                       reinterpret_cast<const LongEntry *>(entries), offsets, reinterpret_cast<const Part *>(partials), work_entry, n_leftover);
     BG_HIP(hipGetLastError());
     return 0;
 }
