@@ -617,3 +617,25 @@ def test_mode_only_call_declines_what_the_device_path_declines():
     with pytest.raises(capi.BowGpuError) as e:   # aggregation.go:163-166: the interval column must be kept
         capi.rolling_aggregate([capi.Column(np.sort(ts)), capi.Column(v)], 0, 4, [("Mode", 1)])
     assert "KEEP_INTERVAL" in str(e.value)
+
+
+def test_long_window_final_split():
+    """long windows are finished by one lane when they have at most 8 chunk partials (4096 rows each) and at most 8 empty windows
+    behind them, else by a workgroup: both sides of both limits, with nulls, for every reducer"""
+    rng = np.random.default_rng(21)
+    I = 1_000_000
+    lens = [32768, 32769, 4096, 4097, 20_000, 70_000, 8 * 4096 - 1, 9 * 4096]
+    gaps = [0, 8, 9, 1, 40, 0, 8, 9]
+    ts_parts, t0 = [], 0
+    for ln, gap in zip(lens, gaps):
+        ts_parts.append(t0 + np.sort(rng.integers(0, I, ln)))
+        t0 += (gap + 1) * I
+    ts = np.concatenate(ts_parts).astype(np.int64)
+    n = len(ts)
+    vals = np.round(rng.standard_normal(n) * 100, 2)
+    valid = rng.random(n) > 0.2
+    aggs = [("WindowStart", 0), ("Sum", 1), ("ArithmeticMean", 1), ("Min", 1), ("Max", 1), ("Count", 1), ("First", 1), ("Last", 1),
+            ("NumRows", 1), ("IntegralStep", 1), ("WeightedAverageLinear", 1)]
+    outs, exp, info = run_both(ts, [(vals, valid)], I, aggs)
+    assert info.long_windows >= len(lens)
+    assert outs[0].length == sum(g + 1 for g in gaps[:-1]) + 1
