@@ -9,8 +9,11 @@
 // Mode is not a streaming reducer (no constant-size state), so it does not ride in the tile kernels; it runs over the
 // window row ranges (first row of every window: interp_fill.hip window_first_rows_kernel) in three size classes:
 //   <= 32 rows     mode_small_kernel : one lane per window, validity as a 32-bit mask, O(n^2) compares from L1/L2
-//   <= kModeMid    mode_mid_kernel   : one workgroup per window, valid values compacted in row order into LDS,
-//                                      nb(i) by a broadcast scan of LDS, (count, first row) reduced across the workgroup
+//   <= kModeMid    mode_mid_kernel   : one workgroup per window.  Up to kModeHash rows: an LDS hash table counts the keys, and
+//                                      the answer is the smallest LAST row among the keys with the largest count (the first
+//                                      row at which a count reaches M is the last row of a key that ends at M) - linear in
+//                                      the rows.  Above that: valid values compacted in row order into LDS, nb(i) by a
+//                                      broadcast scan of LDS, (count, first row) reduced across the workgroup
 //   longer         mode_long_*       : valid rows selected, keyed (canonical bits; NaNs get unique keys), radix-sorted
 //                                      stably with their row number (hipCUB), run lengths by binary search from each run head,
 //                                      (length, row of the run's M-th element) reduced with a 64-bit atomic max
@@ -28,6 +31,8 @@ namespace {
 
 constexpr int kModeSmall = 32;
 constexpr int kModeMid = 7680;  // 60 KB of LDS values
+constexpr int kModeHash = 2560;  // windows up to this many rows: an LDS hash table of kHashSlots (key, count) slots instead of the O(n^2) scan
+constexpr int kHashSlots = 4096;
 
 struct ModeParams {
     const uint64_t *values;
@@ -112,6 +117,89 @@ __global__ __launch_bounds__(256) void mode_mid_kernel(ModeParams p) {
     const int n = (int)(b - a);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool is_int = p.is_int != 0;
+    if (n <= kModeHash) {
+        // Order-free form of the map walk: with M = the largest count of a (non-NaN) key, the first row at which some count
+        // reaches M is the LAST row of a key whose final count is M - the smallest such last row.  So: count every key in an
+        // LDS hash table (phase A), flag the slots whose count is M, let every row of a flagged key raise its slot's "last row"
+        // (phase B), take the smallest of those (phase C).  M <= 1 (all values distinct, or only NaNs): the first valid row.
+        constexpr uint64_t kEmpty = ~0ull;        // a NaN pattern for Float64 keys; Int64 -1 is counted apart ("spec")
+        constexpr uint32_t kFlag = 0x80000000u;
+        uint64_t *keys = sv;
+        uint32_t *cnt = reinterpret_cast<uint32_t *>(sv + kHashSlots);
+        int lg = 8;                                  // table size: the power of two >= 2 n, 256 .. kHashSlots (n <= kModeHash fits: load <= 0.63)
+        while ((1 << lg) < 2 * n && (1 << lg) < kHashSlots) lg++;
+        const int S = 1 << lg;
+        __shared__ uint32_t s_first, s_M, s_spec, s_spec_last, s_best;
+        for (int i = tid; i < S; i += 256) { keys[i] = kEmpty; cnt[i] = 0; }
+        if (tid == 0) { s_first = 0xFFFFFFFFu; s_M = 0; s_spec = 0; s_spec_last = 0; s_best = 0xFFFFFFFFu; }
+        __syncthreads();
+        auto key_of = [&](uint64_t v, bool *skip) -> uint64_t {
+            *skip = false;
+            if (!is_int) {
+                const double x = __longlong_as_double((long long)v);
+                if (x != x) { *skip = true; return 0; }   // every NaN is a key of its own: count 1
+                if (x == 0.0) return 0ull;                 // -0 == +0
+            }
+            return v;
+        };
+        auto slot_of = [&](uint64_t key, bool claim) -> int {
+            int h = (int)((key * 0x9E3779B97F4A7C15ull) >> (64 - lg));
+            for (;;) {
+                unsigned long long cur = keys[h];
+                if (cur == key) return h;
+                if (cur == kEmpty) {
+                    if (!claim) return -1;
+                    cur = atomicCAS(reinterpret_cast<unsigned long long *>(&keys[h]), (unsigned long long)kEmpty, (unsigned long long)key);
+                    if (cur == kEmpty || cur == key) return h;
+                }
+                h = (h + 1) & (S - 1);
+            }
+        };
+        for (int r = tid; r < n; r += 256) {   // phase A
+            if (!row_valid(p, a + r)) continue;
+            atomicMin(&s_first, (uint32_t)r);
+            bool skip;
+            const uint64_t key = key_of(p.values[a + r], &skip);
+            if (skip) continue;
+            if (key == kEmpty) atomicAdd(&s_spec, 1u);
+            else atomicAdd(&cnt[slot_of(key, true)], 1u);
+        }
+        __syncthreads();
+        uint32_t mx = 0;
+        for (int i = tid; i < S; i += 256) mx = cnt[i] > mx ? cnt[i] : mx;
+        if (mx) atomicMax(&s_M, mx);
+        if (tid == 0 && s_spec) atomicMax(&s_M, s_spec);
+        __syncthreads();
+        const uint32_t M = s_M;
+        if (M <= 1) {
+            if (tid == 0) {
+                if (s_first != 0xFFFFFFFFu) store_result(p, k, p.values[a + s_first]);
+                else p.out_values[k] = 0ull;
+            }
+            return;
+        }
+        for (int i = tid; i < S; i += 256) cnt[i] = cnt[i] == M ? kFlag : 0u;
+        const bool spec_flag = s_spec == M;
+        __syncthreads();
+        for (int r = tid; r < n; r += 256) {   // phase B
+            if (!row_valid(p, a + r)) continue;
+            bool skip;
+            const uint64_t key = key_of(p.values[a + r], &skip);
+            if (skip) continue;
+            if (key == kEmpty) { if (spec_flag) atomicMax(&s_spec_last, (uint32_t)r); continue; }
+            const int h = slot_of(key, false);
+            if (cnt[h] & kFlag) atomicMax(&cnt[h], kFlag | (uint32_t)r);
+        }
+        __syncthreads();
+        uint32_t best = 0xFFFFFFFFu;   // phase C
+        for (int i = tid; i < S; i += 256)
+            if (cnt[i] & kFlag) { const uint32_t last = cnt[i] & ~kFlag; best = last < best ? last : best; }
+        if (best != 0xFFFFFFFFu) atomicMin(&s_best, best);
+        if (tid == 0 && spec_flag) atomicMin(&s_best, s_spec_last);
+        __syncthreads();
+        if (tid == 0) store_result(p, k, p.values[a + s_best]);
+        return;
+    }
     // valid values, compacted in row order
     int m = 0;
     for (int c0 = 0; c0 < n; c0 += 256) {

@@ -639,3 +639,29 @@ def test_long_window_final_split():
     outs, exp, info = run_both(ts, [(vals, valid)], I, aggs)
     assert info.long_windows >= len(lens)
     assert outs[0].length == sum(g + 1 for g in gaps[:-1]) + 1
+
+
+@pytest.mark.parametrize("kind", ["int", "float"])
+def test_mode_size_class_boundaries(kind):
+    """windows of exactly 32 / 33 rows (lane | workgroup), 2048 / 2560 / 2561 rows (hash table at its fullest | the scan form),
+    7680 / 7681 rows (scan | radix sort): mostly distinct values (a full table, long probe chains), a few planted repeats,
+    Int64 -1 (the table's empty marker, counted apart) and NaNs"""
+    rng = np.random.default_rng(31 + (kind == "int"))
+    lens = [32, 33, 2048, 2049, 2560, 2561, 7680, 7681, 100, 2300]
+    I = 100_000
+    ts = np.concatenate([k * I + np.sort(rng.choice(I, ln, replace=False)) for k, ln in enumerate(lens)]).astype(np.int64)
+    n = len(ts)
+    if kind == "int":
+        vals = rng.integers(-10 ** 9, 10 ** 9, n).astype(np.int64)
+        vals[rng.random(n) < 0.02] = -1
+    else:
+        vals = rng.standard_normal(n) * 1e6
+        vals[rng.random(n) < 0.02] = np.nan
+        vals[rng.random(n) < 0.01] = -0.0
+        vals[rng.random(n) < 0.01] = 0.0
+    for _ in range(40):   # planted repeats, some of them late in their window
+        i = int(rng.integers(0, n - 50))
+        vals[i + int(rng.integers(1, 50))] = vals[i]
+    valid = rng.random(n) > 0.1
+    outs, exp, info = run_both(ts, [(vals, valid), (vals, None)], I, [("WindowStart", 0), ("Mode", 1), ("Mode", 2), ("Count", 1)])
+    assert outs[0].length == len(lens)
