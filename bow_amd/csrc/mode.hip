@@ -8,7 +8,8 @@
 //
 // Mode is not a streaming reducer (no constant-size state), so it does not ride in the tile kernels; it runs over the
 // window row ranges (first row of every window: interp_fill.hip window_first_rows_kernel) in three size classes:
-//   <= 32 rows     mode_small_kernel : one lane per window, validity as a 32-bit mask, O(n^2) compares from L1/L2
+//   <= 32 rows     mode_small_kernel : one lane per window, validity as a 32-bit mask, the window copied to the lane's LDS
+//                                      column, O(n^2) compares out of LDS
 //   <= kModeMid    mode_mid_kernel   : one workgroup per window.  Up to kModeHash rows: an LDS hash table counts the keys, and
 //                                      the answer is the smallest LAST row among the keys with the largest count (the first
 //                                      row at which a count reaches M is the last row of a key that ends at M) - linear in
@@ -71,8 +72,12 @@ __device__ __forceinline__ void store_result(const ModeParams &p, int64_t k, uin
     atomicOr(&p.out_valid[k >> 5], 1u << (k & 31));
 }
 
-__global__ __launch_bounds__(256) void mode_small_kernel(ModeParams p) {
-    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+constexpr int kSmallThreads = 128;
+__global__ __launch_bounds__(kSmallThreads) void mode_small_kernel(ModeParams p) {
+    // a lane's window goes to its own LDS column first (sw[row][thread]: conflict-free): the O(n^2) compares then read LDS -
+    // the same reads from global memory touch a different cache line per lane, 64 lines per wavefront instruction
+    __shared__ uint64_t sw[kModeSmall * kSmallThreads];
+    const int64_t k = (int64_t)blockIdx.x * kSmallThreads + threadIdx.x;
     bool have = false;
     uint64_t res = 0;
     if (k < p.W) {
@@ -84,14 +89,18 @@ __global__ __launch_bounds__(256) void mode_small_kernel(ModeParams p) {
             else p.long_queue[atomicAdd(&p.counters[1], 1u)] = k;
         } else if (n > 0) {
             uint32_t mask = 0;
-            for (int i = 0; i < (int)n; i++) mask |= row_valid(p, a + i) ? (1u << i) : 0u;
+            uint64_t *mine = sw + threadIdx.x;
+            for (int i = 0; i < (int)n; i++) {
+                mask |= row_valid(p, a + i) ? (1u << i) : 0u;
+                mine[i * kSmallThreads] = p.values[a + i];
+            }
             int best = 0;
             const bool is_int = p.is_int != 0;
             for (int i = 0; i < (int)n; i++) {
                 if (!((mask >> i) & 1u)) continue;
-                const uint64_t v = p.values[a + i];
+                const uint64_t v = mine[i * kSmallThreads];
                 int nb = 0;
-                for (int j = 0; j < i; j++) nb += (((mask >> j) & 1u) && mode_eq(p.values[a + j], v, is_int)) ? 1 : 0;
+                for (int j = 0; j < i; j++) nb += (((mask >> j) & 1u) && mode_eq(mine[j * kSmallThreads], v, is_int)) ? 1 : 0;
                 nb += 1;  // this row (a NaN: its own fresh key)
                 if (nb > best) { best = nb; res = v; }
             }
@@ -379,7 +388,7 @@ int launch_mode(Ctx *c, const int64_t *ts, const int64_t *first_idx, int64_t n, 
     P.mid_queue = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(dq.p) + 256);
     P.long_queue = P.mid_queue + qcap;
     BG_HIP(hipMemsetAsync(P.counters, 0, 256, c->stream));
-    hipLaunchKernelGGL(mode_small_kernel, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, c->stream, P);
+    hipLaunchKernelGGL(mode_small_kernel, dim3((unsigned)((W + kSmallThreads - 1) / kSmallThreads)), dim3(kSmallThreads), 0, c->stream, P);
     BG_HIP(hipGetLastError());
     uint32_t hcount[2] = {0, 0};
     BG_HIP(hipMemcpyAsync(hcount, P.counters, 8, hipMemcpyDeviceToHost, c->stream));
