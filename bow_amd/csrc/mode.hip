@@ -10,6 +10,7 @@
 // window row ranges (first row of every window: interp_fill.hip window_first_rows_kernel) in three size classes:
 //   <= 32 rows     mode_small_kernel : one lane per window, validity as a 32-bit mask, the window copied to the lane's LDS
 //                                      column, O(n^2) compares out of LDS
+//   <= kModeWave   mode_wave_kernel  : one wavefront per window: a 512-slot LDS hash table of (key, count), no barrier
 //   <= kModeMid    mode_mid_kernel   : one workgroup per window.  Up to kModeHash rows: an LDS hash table counts the keys, and
 //                                      the answer is the smallest LAST row among the keys with the largest count (the first
 //                                      row at which a count reaches M is the last row of a key that ends at M) - linear in
@@ -32,6 +33,7 @@ namespace {
 
 constexpr int kModeSmall = 32;
 constexpr int kModeMid = 7680;  // 60 KB of LDS values
+constexpr int kModeWave = 256;   // up to this many rows: one WAVEFRONT per window (a 512-slot table in its LDS slice, no barrier)
 constexpr int kModeHash = 2560;  // windows up to this many rows: an LDS hash table of kHashSlots (key, count) slots instead of the O(n^2) scan
 constexpr int kHashSlots = 4096;
 
@@ -47,8 +49,8 @@ struct ModeParams {
     double fac[BOWGPU_MAX_FACTORS];
     uint64_t *out_values;
     uint32_t *out_valid;
-    uint32_t *counters;  // [0] = mid-size windows queued, [1] = long windows queued
-    int64_t *mid_queue, *long_queue;
+    uint32_t *counters;  // [0] = mid-size windows queued, [1] = long windows queued, [2] = windows for one wavefront each
+    int64_t *mid_queue, *long_queue, *wave_queue;
 };
 
 __device__ __forceinline__ bool mode_eq(uint64_t a, uint64_t b, bool is_int) {
@@ -78,15 +80,16 @@ __global__ __launch_bounds__(kSmallThreads) void mode_small_kernel(ModeParams p)
     // the same reads from global memory touch a different cache line per lane, 64 lines per wavefront instruction
     __shared__ uint64_t sw[kModeSmall * kSmallThreads];
     const int64_t k = (int64_t)blockIdx.x * kSmallThreads + threadIdx.x;
-    bool have = false;
+    bool have = false, to_mid = false, to_long = false, to_wave = false;
     uint64_t res = 0;
     if (k < p.W) {
         int64_t a, b;
         window_rows(p, k, &a, &b);
         const int64_t n = b - a;
         if (n > kModeSmall) {
-            if (n <= kModeMid) p.mid_queue[atomicAdd(&p.counters[0], 1u)] = k;
-            else p.long_queue[atomicAdd(&p.counters[1], 1u)] = k;
+            to_wave = n <= kModeWave;
+            to_mid = !to_wave && n <= kModeMid;
+            to_long = n > kModeMid;
         } else if (n > 0) {
             uint32_t mask = 0;
             uint64_t *mine = sw + threadIdx.x;
@@ -106,14 +109,145 @@ __global__ __launch_bounds__(kSmallThreads) void mode_small_kernel(ModeParams p)
             }
             have = best > 0;
         }
-        if (n <= kModeSmall) p.out_values[k] = have ? apply_factors(res, p.is_int != 0, p.nfac, p.fac) : 0ull;  // nil slots hold 0 (bowbuffer.go:22-40)
+        if (!to_mid && !to_long && !to_wave) p.out_values[k] = have ? apply_factors(res, p.is_int != 0, p.nfac, p.fac) : 0ull;  // nil slots hold 0 (bowbuffer.go:22-40)
+    }
+    const int lane = threadIdx.x & 63;
+    // queue pushes, one atomic per wavefront and queue: atomics on a single address are serialised (~10 ns each: 2e6 windows of
+    // 50 rows pushed one by one cost 19 ms)
+    {
+        const uint64_t below = (1ull << lane) - 1ull;
+        const uint64_t bm = __ballot(to_mid), bl = __ballot(to_long), bw = __ballot(to_wave);
+        if (bw) {
+            uint32_t base = 0;
+            if (lane == __ffsll((long long)bw) - 1) base = atomicAdd(&p.counters[2], (uint32_t)__popcll(bw));
+            base = (uint32_t)__shfl((int)base, __ffsll((long long)bw) - 1);
+            if (to_wave) p.wave_queue[base + (uint32_t)__popcll(bw & below)] = k;
+        }
+        if (bm) {
+            uint32_t base = 0;
+            if (lane == __ffsll((long long)bm) - 1) base = atomicAdd(&p.counters[0], (uint32_t)__popcll(bm));
+            base = (uint32_t)__shfl((int)base, __ffsll((long long)bm) - 1);
+            if (to_mid) p.mid_queue[base + (uint32_t)__popcll(bm & below)] = k;
+        }
+        if (bl) {
+            uint32_t base = 0;
+            if (lane == __ffsll((long long)bl) - 1) base = atomicAdd(&p.counters[1], (uint32_t)__popcll(bl));
+            base = (uint32_t)__shfl((int)base, __ffsll((long long)bl) - 1);
+            if (to_long) p.long_queue[base + (uint32_t)__popcll(bl & below)] = k;
+        }
     }
     // validity words of this wavefront's 64 windows (queued windows set their bit later, atomically)
     const uint64_t m = __ballot(have);
-    const int lane = threadIdx.x & 63;
     const int64_t k0 = k - lane;
     if (lane == 0 && k0 < p.W) p.out_valid[k0 >> 5] = (uint32_t)m;
     if (lane == 32 && k0 + 32 < p.W) p.out_valid[(k0 >> 5) + 1] = (uint32_t)(m >> 32);
+}
+
+// Windows of 33 .. kModeWave rows: one wavefront per window, four per workgroup, no barrier.  The same order-free form as the
+// hash path of mode_mid_kernel (count per key; the smallest LAST row among the keys with the largest count) with a 512-slot
+// table in the wavefront's own LDS slice and the scalars reduced by shuffles.  (One workgroup per such window - 60 KB of LDS,
+// six barriers - ran 2e6 windows of 50 rows in 19 ms.)
+constexpr int kWaveSlots = 512;
+__global__ __launch_bounds__(256) void mode_wave_kernel(ModeParams p, const int64_t nq) {
+    __shared__ uint64_t keys_all[4][kWaveSlots];
+    __shared__ uint32_t cnt_all[4][kWaveSlots];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t q = (int64_t)blockIdx.x * 4 + wv;
+    if (q >= nq) return;
+    uint64_t *keys = keys_all[wv];
+    uint32_t *cnt = cnt_all[wv];
+    const int64_t k = p.wave_queue[q];
+    int64_t a, b;
+    window_rows(p, k, &a, &b);
+    const int n = (int)(b - a);   // 33 .. kModeWave
+    const bool is_int = p.is_int != 0;
+    constexpr uint64_t kEmpty = ~0ull;
+    constexpr uint32_t kFlag = 0x80000000u;
+    auto wave_sync = []() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    for (int i = lane; i < kWaveSlots; i += 64) { keys[i] = kEmpty; cnt[i] = 0; }
+    wave_sync();
+    // the lane's rows: lane, lane + 64, ... (at most four)
+    uint64_t key[4];
+    bool use[4];
+    uint32_t first = 0xFFFFFFFFu, spec = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int r = lane + 64 * j;
+        use[j] = false; key[j] = 0;
+        if (r < n && row_valid(p, a + r)) {
+            first = first < (uint32_t)r ? first : (uint32_t)r;
+            uint64_t v = p.values[a + r];
+            bool skip = false;
+            if (!is_int) {
+                const double x = __longlong_as_double((long long)v);
+                if (x != x) skip = true;          // every NaN is a key of its own: count 1
+                else if (x == 0.0) v = 0ull;      // -0 == +0
+            }
+            if (!skip) {
+                if (v == kEmpty) spec++;          // Int64 -1 is the table's empty marker: counted apart
+                else { use[j] = true; key[j] = v; }
+            }
+        }
+    }
+    auto slot_of = [&](uint64_t kk, bool claim) -> int {
+        int h = (int)((kk * 0x9E3779B97F4A7C15ull) >> 55);
+        for (;;) {
+            unsigned long long cur = keys[h];
+            if (cur == kk) return h;
+            if (cur == kEmpty) {
+                if (!claim) return -1;
+                cur = atomicCAS(reinterpret_cast<unsigned long long *>(&keys[h]), (unsigned long long)kEmpty, (unsigned long long)kk);
+                if (cur == kEmpty || cur == kk) return h;
+            }
+            h = (h + 1) & (kWaveSlots - 1);
+        }
+    };
+    int slot[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        if (use[j]) { slot[j] = slot_of(key[j], true); atomicAdd(&cnt[slot[j]], 1u); }
+    wave_sync();
+    auto wave_max = [&](uint32_t x) { for (int o = 32; o > 0; o >>= 1) { const uint32_t y = __shfl_xor((int)x, o); x = y > x ? y : x; } return x; };
+    auto wave_min = [&](uint32_t x) { for (int o = 32; o > 0; o >>= 1) { const uint32_t y = __shfl_xor((int)x, o); x = y < x ? y : x; } return x; };
+    auto wave_sum = [&](uint32_t x) { for (int o = 32; o > 0; o >>= 1) x += (uint32_t)__shfl_xor((int)x, o); return x; };
+    uint32_t mx = 0;
+    for (int i = lane; i < kWaveSlots; i += 64) mx = cnt[i] > mx ? cnt[i] : mx;
+    const uint32_t spec_total = wave_sum(spec);
+    uint32_t M = wave_max(mx);
+    M = spec_total > M ? spec_total : M;
+    first = wave_min(first);
+    if (M <= 1) {   // all values distinct, or only NaNs: the first valid row
+        if (lane == 0) {
+            if (first != 0xFFFFFFFFu) store_result(p, k, p.values[a + first]);
+            else p.out_values[k] = 0ull;
+        }
+        return;
+    }
+    wave_sync();
+    for (int i = lane; i < kWaveSlots; i += 64) cnt[i] = cnt[i] == M ? kFlag : 0u;
+    wave_sync();
+    uint32_t spec_last = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t r = (uint32_t)(lane + 64 * j);
+        if (use[j]) { if (cnt[slot[j]] & kFlag) atomicMax(&cnt[slot[j]], kFlag | r); }
+        else if (spec_total == M && (int)r < n && is_int && row_valid(p, a + r) && p.values[a + r] == kEmpty) spec_last = r;  // (rows ascend with j)
+    }
+    wave_sync();
+    uint32_t best = 0xFFFFFFFFu;
+    for (int i = lane; i < kWaveSlots; i += 64)
+        if (cnt[i] & kFlag) { const uint32_t last = cnt[i] & ~kFlag; best = last < best ? last : best; }
+    best = wave_min(best);
+    if (spec_total == M) {
+        const uint32_t sl = wave_max(spec_last);
+        best = sl < best ? sl : best;
+    }
+    if (lane == 0) store_result(p, k, p.values[a + best]);
 }
 
 __global__ __launch_bounds__(256) void mode_mid_kernel(ModeParams p) {
@@ -383,18 +517,23 @@ int launch_mode(Ctx *c, const int64_t *ts, const int64_t *first_idx, int64_t n, 
     // queues: a queued window has > kModeSmall rows
     const int64_t qcap = n / (kModeSmall + 1) + 2;
     DevBuf dq;
-    BG_TRY(dq.alloc(256 + (size_t)qcap * 16));
+    BG_TRY(dq.alloc(256 + (size_t)qcap * 24));
     P.counters = reinterpret_cast<uint32_t *>(dq.p);
     P.mid_queue = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(dq.p) + 256);
     P.long_queue = P.mid_queue + qcap;
+    P.wave_queue = P.long_queue + qcap;
     BG_HIP(hipMemsetAsync(P.counters, 0, 256, c->stream));
     hipLaunchKernelGGL(mode_small_kernel, dim3((unsigned)((W + kSmallThreads - 1) / kSmallThreads)), dim3(kSmallThreads), 0, c->stream, P);
     BG_HIP(hipGetLastError());
-    uint32_t hcount[2] = {0, 0};
-    BG_HIP(hipMemcpyAsync(hcount, P.counters, 8, hipMemcpyDeviceToHost, c->stream));
+    uint32_t hcount[3] = {0, 0, 0};
+    BG_HIP(hipMemcpyAsync(hcount, P.counters, 12, hipMemcpyDeviceToHost, c->stream));
     BG_HIP(hipStreamSynchronize(c->stream));
-    *n_mid = hcount[0];
+    *n_mid = (int64_t)hcount[0] + hcount[2];
     *n_long = hcount[1];
+    if (hcount[2] > 0) {
+        hipLaunchKernelGGL(mode_wave_kernel, dim3((hcount[2] + 3) / 4), dim3(256), 0, c->stream, P, (int64_t)hcount[2]);
+        BG_HIP(hipGetLastError());
+    }
     if (hcount[0] > 0) {
         hipLaunchKernelGGL(mode_mid_kernel, dim3(hcount[0]), dim3(256), 0, c->stream, P);
         BG_HIP(hipGetLastError());

@@ -643,11 +643,11 @@ def test_long_window_final_split():
 
 @pytest.mark.parametrize("kind", ["int", "float"])
 def test_mode_size_class_boundaries(kind):
-    """windows of exactly 32 / 33 rows (lane | workgroup), 2048 / 2560 / 2561 rows (hash table at its fullest | the scan form),
+    """windows of exactly 32 / 33 rows (lane | wavefront), 256 / 257 rows (wavefront | workgroup), 2048 / 2560 / 2561 rows (hash table at its fullest | the scan form),
     7680 / 7681 rows (scan | radix sort): mostly distinct values (a full table, long probe chains), a few planted repeats,
     Int64 -1 (the table's empty marker, counted apart) and NaNs"""
     rng = np.random.default_rng(31 + (kind == "int"))
-    lens = [32, 33, 2048, 2049, 2560, 2561, 7680, 7681, 100, 2300]
+    lens = [32, 33, 2048, 2049, 2560, 2561, 7680, 7681, 100, 2300, 64, 65, 255, 256, 257, 129]
     I = 100_000
     ts = np.concatenate([k * I + np.sort(rng.choice(I, ln, replace=False)) for k, ln in enumerate(lens)]).astype(np.int64)
     n = len(ts)
