@@ -1,4 +1,4 @@
-"""aggregation.Mode: wall time per call (device-resident columns and outputs), 1e8 rows, the three window-size classes of mode.hip."""
+"""aggregation.Mode: wall time per call (device-resident columns and outputs), 1e8 rows, the window-size classes of mode.hip."""
 import sys, time
 sys.path.insert(0, '.')
 import numpy as np
@@ -20,6 +20,8 @@ W0 = ("WindowStart", 0)
 run("Mean alone (for scale), 10 rows / window", 100, [W0, ("ArithmeticMean", 1)])
 run("Mode, 10 rows / window (lane per window)", 100, [W0, ("Mode", 1)])
 run("Mode, 25 rows / window (lane per window)", 250, [W0, ("Mode", 1)])
+run("Mode, 50 rows / window (wavefront per window)", 500, [W0, ("Mode", 1)])
+run("Mode, 200 rows / window (wavefront per window)", 2_000, [W0, ("Mode", 1)])
 run("Mode, 1000 rows / window (workgroup per window)", 10_000, [W0, ("Mode", 1)])
 run("Mode, 7000 rows / window (workgroup per window)", 70_000, [W0, ("Mode", 1)])
 run("Mode, 1e6 rows / window (sort path)", 10_000_000, [W0, ("Mode", 1)], reps=1)
