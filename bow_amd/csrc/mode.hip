@@ -7,15 +7,14 @@
 // Int64 compares bits, Float64 compares numerically (-0 == +0; the value returned is the row's own).
 //
 // Mode is not a streaming reducer (no constant-size state), so it does not ride in the tile kernels; it runs over the
-// window row ranges (first row of every window: interp_fill.hip window_first_rows_kernel) in three size classes:
+// window row ranges (first row of every window: interp_fill.hip window_first_rows_kernel) in size classes:
 //   <= 32 rows     mode_small_kernel : one lane per window, validity as a 32-bit mask, the window copied to the lane's LDS
 //                                      column, O(n^2) compares out of LDS
 //   <= kModeWave   mode_wave_kernel  : one wavefront per window: a 512-slot LDS hash table of (key, count), no barrier
-//   <= kModeMid    mode_mid_kernel   : one workgroup per window.  Up to kModeHash rows: an LDS hash table counts the keys, and
-//                                      the answer is the smallest LAST row among the keys with the largest count (the first
-//                                      row at which a count reaches M is the last row of a key that ends at M) - linear in
-//                                      the rows.  Above that: valid values compacted in row order into LDS, nb(i) by a
-//                                      broadcast scan of LDS, (count, first row) reduced across the workgroup
+//   <= kModeHash   mode_mid_kernel   : one workgroup per window: an LDS hash table counts the keys, and the answer is the
+//                                      smallest LAST row among the keys with the largest count (the first row at which a count
+//                                      reaches M is the last row of a key that ends at M) - linear in the rows
+//   <= kModeMid    mode_big_kernel   : the same with 16384 slots that hold the claiming ROW instead of the key (128 KB of LDS)
 //   longer         mode_long_*       : valid rows selected, keyed (canonical bits; NaNs get unique keys), radix-sorted
 //                                      stably with their row number (hipCUB), run lengths by binary search from each run head,
 //                                      (length, row of the run's M-th element) reduced with a 64-bit atomic max
@@ -32,7 +31,7 @@ namespace bowgpu {
 namespace {
 
 constexpr int kModeSmall = 32;
-constexpr int kModeMid = 7680;  // 60 KB of LDS values
+constexpr int kModeMid = 7680;  // the largest window a workgroup takes (mode_big_kernel's table at load 0.47)
 constexpr int kModeWave = 256;   // up to this many rows: one WAVEFRONT per window (a 512-slot table in its LDS slice, no barrier)
 constexpr int kModeHash = 2560;  // windows up to this many rows: an LDS hash table of kHashSlots (key, count) slots instead of the O(n^2) scan
 constexpr int kHashSlots = 4096;
@@ -251,16 +250,15 @@ __global__ __launch_bounds__(256) void mode_wave_kernel(ModeParams p, const int6
 }
 
 __global__ __launch_bounds__(256) void mode_mid_kernel(ModeParams p) {
-    __shared__ uint64_t sv[kModeMid];
-    __shared__ uint32_t wtot[4];
-    __shared__ unsigned long long sbest[4];
+    __shared__ uint64_t sv[kHashSlots + kHashSlots / 2];   // keys, then the 32-bit counts
     const int64_t k = p.mid_queue[blockIdx.x];
     int64_t a, b;
     window_rows(p, k, &a, &b);
     const int n = (int)(b - a);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
     const bool is_int = p.is_int != 0;
-    if (n <= kModeHash) {
+    if (n > kModeHash) return;   // mode_big_kernel's
+    {
         // Order-free form of the map walk: with M = the largest count of a (non-NaN) key, the first row at which some count
         // reaches M is the LAST row of a key whose final count is M - the smallest such last row.  So: count every key in an
         // LDS hash table (phase A), flag the slots whose count is M, let every row of a flagged key raise its slot's "last row"
@@ -341,43 +339,81 @@ __global__ __launch_bounds__(256) void mode_mid_kernel(ModeParams p) {
         if (tid == 0 && spec_flag) atomicMin(&s_best, s_spec_last);
         __syncthreads();
         if (tid == 0) store_result(p, k, p.values[a + s_best]);
+    }
+}
+
+// Windows of kModeHash + 1 .. kModeMid rows (the other entries of the same queue): the same counting with a table of 16384 slots
+// that hold the ROW that claimed them instead of the key (4 + 4 bytes per slot: 128 KB of the CU's 160 KB LDS; keys are compared
+// through the claiming row's value), so no key needs an "empty" marker.  One workgroup per CU, ~20 us per window - the O(n^2)
+// scan it replaces took 2.5 ms.
+constexpr int kBigSlots = 16384;
+__global__ __launch_bounds__(256) void mode_big_kernel(ModeParams p) {
+    __shared__ uint32_t owner[kBigSlots];
+    __shared__ uint32_t cnt[kBigSlots];
+    __shared__ uint32_t s_first, s_M, s_best;
+    const int64_t k = p.mid_queue[blockIdx.x];
+    int64_t a, b;
+    window_rows(p, k, &a, &b);
+    const int n = (int)(b - a);
+    if (n <= kModeHash) return;   // mode_mid_kernel's
+    const int tid = threadIdx.x;
+    const bool is_int = p.is_int != 0;
+    constexpr uint32_t kNone = 0xFFFFFFFFu, kFlag = 0x80000000u;
+    for (int i = tid; i < kBigSlots; i += 256) { owner[i] = kNone; cnt[i] = 0; }
+    if (tid == 0) { s_first = kNone; s_M = 0; s_best = kNone; }
+    __syncthreads();
+    // slot of the key of row r (value v, not a NaN); claim: take an empty slot for it
+    auto slot_of = [&](uint32_t r, uint64_t v, bool claim) -> int {
+        uint64_t key = v;
+        if (!is_int && __longlong_as_double((long long)v) == 0.0) key = 0ull;   // -0 and +0 hash alike
+        int h = (int)((key * 0x9E3779B97F4A7C15ull) >> 50);
+        for (;;) {
+            uint32_t o = owner[h];
+            if (o == kNone) {
+                if (!claim) return -1;
+                o = atomicCAS(&owner[h], kNone, r);
+                if (o == kNone) return h;
+            }
+            if (mode_eq(p.values[a + o], v, is_int)) return h;
+            h = (h + 1) & (kBigSlots - 1);
+        }
+    };
+    for (int r = tid; r < n; r += 256) {   // phase A: counts
+        if (!row_valid(p, a + r)) continue;
+        atomicMin(&s_first, (uint32_t)r);
+        const uint64_t v = p.values[a + r];
+        if (!is_int) { const double x = __longlong_as_double((long long)v); if (x != x) continue; }   // a NaN: a key of its own, count 1
+        atomicAdd(&cnt[slot_of((uint32_t)r, v, true)], 1u);
+    }
+    __syncthreads();
+    uint32_t mx = 0;
+    for (int i = tid; i < kBigSlots; i += 256) mx = cnt[i] > mx ? cnt[i] : mx;
+    if (mx) atomicMax(&s_M, mx);
+    __syncthreads();
+    const uint32_t M = s_M;
+    if (M <= 1) {
+        if (tid == 0) {
+            if (s_first != kNone) store_result(p, k, p.values[a + s_first]);
+            else p.out_values[k] = 0ull;
+        }
         return;
     }
-    // valid values, compacted in row order
-    int m = 0;
-    for (int c0 = 0; c0 < n; c0 += 256) {
-        const int r = c0 + tid;
-        const bool ok = r < n && row_valid(p, a + r);
-        const uint64_t v = ok ? p.values[a + r] : 0ull;
-        const uint64_t bal = __ballot(ok);
-        if (lane == 0) wtot[wave] = (uint32_t)__popcll(bal);
-        __syncthreads();
-        int off = m;
-        for (int w = 0; w < wave; w++) off += (int)wtot[w];
-        if (ok) sv[off + __popcll(bal & ((1ull << lane) - 1ull))] = v;
-        m += (int)(wtot[0] + wtot[1] + wtot[2] + wtot[3]);
-        __syncthreads();
-    }
-    // (count, earliest row): counts first, then the smaller row wins
-    unsigned long long best = 0;
-    for (int i = tid; i < m; i += 256) {
-        const uint64_t v = sv[i];
-        uint32_t nb = 1;
-        for (int j = 0; j < i; j++) nb += mode_eq(sv[j], v, is_int) ? 1u : 0u;
-        const unsigned long long cand = ((unsigned long long)nb << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)i);
-        best = cand > best ? cand : best;
-    }
-    for (int d = 32; d >= 1; d >>= 1) {
-        const unsigned long long o = __shfl_down(best, d, 64);
-        best = o > best ? o : best;
-    }
-    if (lane == 0) sbest[wave] = best;
+    for (int i = tid; i < kBigSlots; i += 256) cnt[i] = cnt[i] == M ? kFlag : 0u;
     __syncthreads();
-    if (tid == 0) {
-        for (int w = 1; w < 4; w++) best = sbest[w] > best ? sbest[w] : best;
-        if (m > 0) store_result(p, k, sv[0xFFFFFFFFu - (uint32_t)best]);
-        else p.out_values[k] = 0ull;
+    for (int r = tid; r < n; r += 256) {   // phase B: the last row of every key that reached M
+        if (!row_valid(p, a + r)) continue;
+        const uint64_t v = p.values[a + r];
+        if (!is_int) { const double x = __longlong_as_double((long long)v); if (x != x) continue; }
+        const int h = slot_of((uint32_t)r, v, false);
+        if (cnt[h] & kFlag) atomicMax(&cnt[h], kFlag | (uint32_t)r);
     }
+    __syncthreads();
+    uint32_t best = kNone;   // phase C: the smallest of those
+    for (int i = tid; i < kBigSlots; i += 256)
+        if (cnt[i] & kFlag) { const uint32_t last = cnt[i] & ~kFlag; best = last < best ? last : best; }
+    if (best != kNone) atomicMin(&s_best, best);
+    __syncthreads();
+    if (tid == 0) store_result(p, k, p.values[a + s_best]);
 }
 
 // ---- long windows: sort path -----------------------------------------------------------------------------------------
@@ -536,6 +572,7 @@ int launch_mode(Ctx *c, const int64_t *ts, const int64_t *first_idx, int64_t n, 
     }
     if (hcount[0] > 0) {
         hipLaunchKernelGGL(mode_mid_kernel, dim3(hcount[0]), dim3(256), 0, c->stream, P);
+        hipLaunchKernelGGL(mode_big_kernel, dim3(hcount[0]), dim3(256), 0, c->stream, P);   // (each takes its share of the queue)
         BG_HIP(hipGetLastError());
     }
     if (hcount[1] > 0) {
