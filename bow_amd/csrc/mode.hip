@@ -15,6 +15,7 @@
 //                                      smallest LAST row among the keys with the largest count (the first row at which a count
 //                                      reaches M is the last row of a key that ends at M) - linear in the rows
 //   <= kModeMid    mode_big_kernel   : the same with 16384 slots that hold the claiming ROW instead of the key (128 KB of LDS)
+//   <= kModeGlobal mode_global_kernel: the same table in global memory, 2^lg >= 2 n slots per window, one workgroup per window
 //   longer         mode_long_*       : valid rows selected, keyed (canonical bits; NaNs get unique keys), radix-sorted
 //                                      stably with their row number (hipCUB), run lengths by binary search from each run head,
 //                                      (length, row of the run's M-th element) reduced with a 64-bit atomic max
@@ -33,6 +34,7 @@ namespace {
 constexpr int kModeSmall = 32;
 constexpr int kModeMid = 7680;  // the largest window a workgroup takes (mode_big_kernel's table at load 0.47)
 constexpr int kModeWave = 256;   // up to this many rows: one WAVEFRONT per window (a 512-slot table in its LDS slice, no barrier)
+constexpr int kModeGlobal = 2000000;  // up to this many rows: a hash table in global memory, one workgroup per window; beyond: radix sort
 constexpr int kModeHash = 2560;  // windows up to this many rows: an LDS hash table of kHashSlots (key, count) slots instead of the O(n^2) scan
 constexpr int kHashSlots = 4096;
 
@@ -347,26 +349,22 @@ __global__ __launch_bounds__(256) void mode_mid_kernel(ModeParams p) {
 // through the claiming row's value), so no key needs an "empty" marker.  One workgroup per CU, ~20 us per window - the O(n^2)
 // scan it replaces took 2.5 ms.
 constexpr int kBigSlots = 16384;
-__global__ __launch_bounds__(256) void mode_big_kernel(ModeParams p) {
-    __shared__ uint32_t owner[kBigSlots];
-    __shared__ uint32_t cnt[kBigSlots];
-    __shared__ uint32_t s_first, s_M, s_best;
-    const int64_t k = p.mid_queue[blockIdx.x];
-    int64_t a, b;
-    window_rows(p, k, &a, &b);
-    const int n = (int)(b - a);
-    if (n <= kModeHash) return;   // mode_mid_kernel's
-    const int tid = threadIdx.x;
-    const bool is_int = p.is_int != 0;
+
+// The counting itself, for a table of 2^lg slots (owner[] = kNone, cnt[] = 0 on entry) that may live in LDS or in global
+// memory; s3 = three words of LDS.  Called by all 256 threads of the workgroup.
+__device__ __forceinline__ void mode_owner_table(const ModeParams &p, const int64_t k, const int64_t a, const int n, uint32_t *owner,
+                                                 uint32_t *cnt, const int lg, uint32_t *s3) {
     constexpr uint32_t kNone = 0xFFFFFFFFu, kFlag = 0x80000000u;
-    for (int i = tid; i < kBigSlots; i += 256) { owner[i] = kNone; cnt[i] = 0; }
+    uint32_t &s_first = s3[0], &s_M = s3[1], &s_best = s3[2];
+    const int tid = threadIdx.x, S = 1 << lg;
+    const bool is_int = p.is_int != 0;
     if (tid == 0) { s_first = kNone; s_M = 0; s_best = kNone; }
     __syncthreads();
     // slot of the key of row r (value v, not a NaN); claim: take an empty slot for it
     auto slot_of = [&](uint32_t r, uint64_t v, bool claim) -> int {
         uint64_t key = v;
         if (!is_int && __longlong_as_double((long long)v) == 0.0) key = 0ull;   // -0 and +0 hash alike
-        int h = (int)((key * 0x9E3779B97F4A7C15ull) >> 50);
+        int h = (int)((key * 0x9E3779B97F4A7C15ull) >> (64 - lg));
         for (;;) {
             uint32_t o = owner[h];
             if (o == kNone) {
@@ -375,7 +373,7 @@ __global__ __launch_bounds__(256) void mode_big_kernel(ModeParams p) {
                 if (o == kNone) return h;
             }
             if (mode_eq(p.values[a + o], v, is_int)) return h;
-            h = (h + 1) & (kBigSlots - 1);
+            h = (h + 1) & (S - 1);
         }
     };
     for (int r = tid; r < n; r += 256) {   // phase A: counts
@@ -387,7 +385,7 @@ __global__ __launch_bounds__(256) void mode_big_kernel(ModeParams p) {
     }
     __syncthreads();
     uint32_t mx = 0;
-    for (int i = tid; i < kBigSlots; i += 256) mx = cnt[i] > mx ? cnt[i] : mx;
+    for (int i = tid; i < S; i += 256) mx = cnt[i] > mx ? cnt[i] : mx;
     if (mx) atomicMax(&s_M, mx);
     __syncthreads();
     const uint32_t M = s_M;
@@ -398,7 +396,7 @@ __global__ __launch_bounds__(256) void mode_big_kernel(ModeParams p) {
         }
         return;
     }
-    for (int i = tid; i < kBigSlots; i += 256) cnt[i] = cnt[i] == M ? kFlag : 0u;
+    for (int i = tid; i < S; i += 256) cnt[i] = cnt[i] == M ? kFlag : 0u;
     __syncthreads();
     for (int r = tid; r < n; r += 256) {   // phase B: the last row of every key that reached M
         if (!row_valid(p, a + r)) continue;
@@ -409,11 +407,34 @@ __global__ __launch_bounds__(256) void mode_big_kernel(ModeParams p) {
     }
     __syncthreads();
     uint32_t best = kNone;   // phase C: the smallest of those
-    for (int i = tid; i < kBigSlots; i += 256)
+    for (int i = tid; i < S; i += 256)
         if (cnt[i] & kFlag) { const uint32_t last = cnt[i] & ~kFlag; best = last < best ? last : best; }
     if (best != kNone) atomicMin(&s_best, best);
     __syncthreads();
     if (tid == 0) store_result(p, k, p.values[a + s_best]);
+}
+
+__global__ __launch_bounds__(256) void mode_big_kernel(ModeParams p) {
+    __shared__ uint32_t owner[kBigSlots];
+    __shared__ uint32_t cnt[kBigSlots];
+    __shared__ uint32_t s3[3];
+    const int64_t k = p.mid_queue[blockIdx.x];
+    int64_t a, b;
+    window_rows(p, k, &a, &b);
+    const int n = (int)(b - a);
+    if (n <= kModeHash) return;   // mode_mid_kernel's
+    for (int i = threadIdx.x; i < kBigSlots; i += 256) { owner[i] = 0xFFFFFFFFu; cnt[i] = 0; }
+    mode_owner_table(p, k, a, n, owner, cnt, 14, s3);
+}
+
+// Windows of kModeMid + 1 .. kModeGlobal rows: the same table in global memory (2^lg >= 2 n slots per window, carved out of
+// one allocation by the host, which knows these windows' bounds), one workgroup per window.  Without it every such window went
+// through the radix-sort path below, one after the other from the host: 1e4 windows of 1e4 rows took seconds.
+struct ModeTable { int64_t k, a, n, off; int32_t lg, _pad; };
+__global__ __launch_bounds__(256) void mode_global_kernel(ModeParams p, const ModeTable *tables, uint32_t *owner_all, uint32_t *cnt_all) {
+    __shared__ uint32_t s3[3];
+    const ModeTable t = tables[blockIdx.x];
+    mode_owner_table(p, t.k, t.a, (int)t.n, owner_all + t.off, cnt_all + t.off, t.lg, s3);
 }
 
 // ---- long windows: sort path -----------------------------------------------------------------------------------------
@@ -584,7 +605,35 @@ int launch_mode(Ctx *c, const int64_t *ts, const int64_t *first_idx, int64_t n, 
         BG_HIP(hipMemcpyAsync(hb.data(), db.p, hb.size() * 8, hipMemcpyDeviceToHost, c->stream));
         BG_HIP(hipStreamSynchronize(c->stream));
         const int64_t *bounds = hb.data();
-        for (uint32_t q = 0; q < hcount[1]; q++) BG_TRY(mode_long_window(c, P, bounds[3 * q], bounds[3 * q + 1], bounds[3 * q + 2]));
+        // windows up to kModeGlobal rows: one launch, tables of 2^lg >= 2 n slots each out of one allocation
+        std::vector<ModeTable> tabs;
+        int64_t slots = 0;
+        for (uint32_t q = 0; q < hcount[1]; q++) {
+            const int64_t wn = bounds[3 * q + 2] - bounds[3 * q + 1];
+            if (wn > kModeGlobal) continue;
+            ModeTable t;
+            t.k = bounds[3 * q]; t.a = bounds[3 * q + 1]; t.n = wn; t.off = slots; t._pad = 0;
+            t.lg = 14;
+            while ((1ll << t.lg) < 2 * wn) t.lg++;
+            slots += 1ll << t.lg;
+            tabs.push_back(t);
+        }
+        if (!tabs.empty()) {
+            DevBuf d_tabs, d_owner, d_cnt;
+            BG_TRY(d_tabs.alloc(tabs.size() * sizeof(ModeTable)));
+            BG_TRY(d_owner.alloc((size_t)slots * 4));
+            BG_TRY(d_cnt.alloc((size_t)slots * 4));
+            BG_HIP(hipMemcpyAsync(d_tabs.p, tabs.data(), tabs.size() * sizeof(ModeTable), hipMemcpyHostToDevice, c->stream));
+            BG_HIP(hipMemsetAsync(d_owner.p, 0xFF, (size_t)slots * 4, c->stream));
+            BG_HIP(hipMemsetAsync(d_cnt.p, 0, (size_t)slots * 4, c->stream));
+            hipLaunchKernelGGL(mode_global_kernel, dim3((unsigned)tabs.size()), dim3(256), 0, c->stream, P,
+                               reinterpret_cast<const ModeTable *>(d_tabs.p), reinterpret_cast<uint32_t *>(d_owner.p),
+                               reinterpret_cast<uint32_t *>(d_cnt.p));
+            BG_HIP(hipGetLastError());
+            BG_HIP(hipStreamSynchronize(c->stream));   // (tabs and the DevBufs go out of scope)
+        }
+        for (uint32_t q = 0; q < hcount[1]; q++)
+            if (bounds[3 * q + 2] - bounds[3 * q + 1] > kModeGlobal) BG_TRY(mode_long_window(c, P, bounds[3 * q], bounds[3 * q + 1], bounds[3 * q + 2]));
     }
     BG_HIP(hipStreamSynchronize(c->stream));
     return 0;

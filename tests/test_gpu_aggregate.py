@@ -665,3 +665,29 @@ def test_mode_size_class_boundaries(kind):
     valid = rng.random(n) > 0.1
     outs, exp, info = run_both(ts, [(vals, valid), (vals, None)], I, [("WindowStart", 0), ("Mode", 1), ("Mode", 2), ("Count", 1)])
     assert outs[0].length == len(lens)
+
+
+def test_mode_windows_beyond_the_global_table():
+    """windows of more than 2e6 rows take the radix-sort path; the oracle's Mode is quadratic, so the expectation is numpy's:
+    among the values with the largest count, the one whose LAST occurrence comes first (= the row at which a count first reaches
+    the maximum); a smaller window beside them goes through the global-memory table"""
+    rng = np.random.default_rng(12)
+    n1, n2 = 2_300_000, 900_000
+    ts = np.concatenate([np.sort(rng.integers(0, 10 ** 9, n1)), 10 ** 9 + np.sort(rng.integers(0, 10 ** 9, n2))]).astype(np.int64)
+    n = n1 + n2
+    vals = rng.integers(0, 200_000, n).astype(np.float64) / 4      # ~11 occurrences per value: many ties for the maximum
+    vals[rng.random(n) < 0.01] = np.nan
+    valid = rng.random(n) > 0.2
+    cols = [capi.Column(ts, None, capi.INT64), capi.Column(vals, np.packbits(valid, bitorder="little"), capi.FLOAT64, 0, n, -1)]
+    outs, info = capi.rolling_aggregate(cols, 0, 10 ** 9, [("WindowStart", 0), ("Mode", 1)])
+    assert outs[1].length == 2 and outs[1].null_count == 0
+    got = outs[1].host_arrays()[0]
+    for w, (lo, hi) in enumerate([(0, n1), (n1, n)]):
+        v, ok = vals[lo:hi], valid[lo:hi] & ~np.isnan(vals[lo:hi])
+        rows = np.flatnonzero(ok)
+        uniq, inv, counts = np.unique(v[rows], return_inverse=True, return_counts=True)
+        last = np.zeros(len(uniq), dtype=np.int64)
+        np.maximum.at(last, inv, rows)
+        cand = np.flatnonzero(counts == counts.max())
+        want = uniq[cand[np.argmin(last[cand])]]
+        assert got[w] == want, (w, got[w], want, counts.max())
