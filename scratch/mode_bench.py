@@ -24,5 +24,6 @@ run("Mode, 50 rows / window (wavefront per window)", 500, [W0, ("Mode", 1)])
 run("Mode, 200 rows / window (wavefront per window)", 2_000, [W0, ("Mode", 1)])
 run("Mode, 1000 rows / window (workgroup per window)", 10_000, [W0, ("Mode", 1)])
 run("Mode, 7000 rows / window (workgroup per window)", 70_000, [W0, ("Mode", 1)])
-run("Mode, 1e6 rows / window (sort path)", 10_000_000, [W0, ("Mode", 1)], reps=1)
+run("Mode, 10 000 rows / window (global-memory tables)", 100_000, [W0, ("Mode", 1)])
+run("Mode, 1e6 rows / window (global-memory tables)", 10_000_000, [W0, ("Mode", 1)], reps=1)
 run("Mode, one window of 1e8 rows (sort path)", 2_000_000_000, [W0, ("Mode", 1)], reps=1)
