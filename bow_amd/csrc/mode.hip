@@ -51,7 +51,7 @@ struct ModeParams {
     uint64_t *out_values;
     uint32_t *out_valid;
     uint32_t *counters;  // [0] = mid-size windows queued, [1] = long windows queued, [2] = windows for one wavefront each
-    int64_t *mid_queue, *long_queue, *wave_queue;
+    int64_t *mid_queue, *long_queue, *wave_queue, *big_queue;  // counters[3] = windows for mode_big_kernel
 };
 
 __device__ __forceinline__ bool mode_eq(uint64_t a, uint64_t b, bool is_int) {
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(kSmallThreads) void mode_small_kernel(ModeParams p)
     // the same reads from global memory touch a different cache line per lane, 64 lines per wavefront instruction
     __shared__ uint64_t sw[kModeSmall * kSmallThreads];
     const int64_t k = (int64_t)blockIdx.x * kSmallThreads + threadIdx.x;
-    bool have = false, to_mid = false, to_long = false, to_wave = false;
+    bool have = false, to_mid = false, to_long = false, to_wave = false, to_big = false;
     uint64_t res = 0;
     if (k < p.W) {
         int64_t a, b;
@@ -89,7 +89,8 @@ __global__ __launch_bounds__(kSmallThreads) void mode_small_kernel(ModeParams p)
         const int64_t n = b - a;
         if (n > kModeSmall) {
             to_wave = n <= kModeWave;
-            to_mid = !to_wave && n <= kModeMid;
+            to_mid = !to_wave && n <= kModeHash;
+            to_big = n > kModeHash && n <= kModeMid;
             to_long = n > kModeMid;
         } else if (n > 0) {
             uint32_t mask = 0;
@@ -110,14 +111,20 @@ __global__ __launch_bounds__(kSmallThreads) void mode_small_kernel(ModeParams p)
             }
             have = best > 0;
         }
-        if (!to_mid && !to_long && !to_wave) p.out_values[k] = have ? apply_factors(res, p.is_int != 0, p.nfac, p.fac) : 0ull;  // nil slots hold 0 (bowbuffer.go:22-40)
+        if (!to_mid && !to_long && !to_wave && !to_big) p.out_values[k] = have ? apply_factors(res, p.is_int != 0, p.nfac, p.fac) : 0ull;  // nil slots hold 0 (bowbuffer.go:22-40)
     }
     const int lane = threadIdx.x & 63;
     // queue pushes, one atomic per wavefront and queue: atomics on a single address are serialised (~10 ns each: 2e6 windows of
     // 50 rows pushed one by one cost 19 ms)
     {
         const uint64_t below = (1ull << lane) - 1ull;
-        const uint64_t bm = __ballot(to_mid), bl = __ballot(to_long), bw = __ballot(to_wave);
+        const uint64_t bm = __ballot(to_mid), bl = __ballot(to_long), bw = __ballot(to_wave), bb = __ballot(to_big);
+        if (bb) {
+            uint32_t base = 0;
+            if (lane == __ffsll((long long)bb) - 1) base = atomicAdd(&p.counters[3], (uint32_t)__popcll(bb));
+            base = (uint32_t)__shfl((int)base, __ffsll((long long)bb) - 1);
+            if (to_big) p.big_queue[base + (uint32_t)__popcll(bb & below)] = k;
+        }
         if (bw) {
             uint32_t base = 0;
             if (lane == __ffsll((long long)bw) - 1) base = atomicAdd(&p.counters[2], (uint32_t)__popcll(bw));
@@ -259,7 +266,6 @@ __global__ __launch_bounds__(256) void mode_mid_kernel(ModeParams p) {
     const int n = (int)(b - a);
     const int tid = threadIdx.x;
     const bool is_int = p.is_int != 0;
-    if (n > kModeHash) return;   // mode_big_kernel's
     {
         // Order-free form of the map walk: with M = the largest count of a (non-NaN) key, the first row at which some count
         // reaches M is the LAST row of a key whose final count is M - the smallest such last row.  So: count every key in an
@@ -344,7 +350,7 @@ __global__ __launch_bounds__(256) void mode_mid_kernel(ModeParams p) {
     }
 }
 
-// Windows of kModeHash + 1 .. kModeMid rows (the other entries of the same queue): the same counting with a table of 16384 slots
+// Windows of kModeHash + 1 .. kModeMid rows (a queue of their own): the same counting with a table of 16384 slots
 // that hold the ROW that claimed them instead of the key (4 + 4 bytes per slot: 128 KB of the CU's 160 KB LDS; keys are compared
 // through the claiming row's value), so no key needs an "empty" marker.  One workgroup per CU, ~20 us per window - the O(n^2)
 // scan it replaces took 2.5 ms.
@@ -418,11 +424,10 @@ __global__ __launch_bounds__(256) void mode_big_kernel(ModeParams p) {
     __shared__ uint32_t owner[kBigSlots];
     __shared__ uint32_t cnt[kBigSlots];
     __shared__ uint32_t s3[3];
-    const int64_t k = p.mid_queue[blockIdx.x];
+    const int64_t k = p.big_queue[blockIdx.x];
     int64_t a, b;
     window_rows(p, k, &a, &b);
     const int n = (int)(b - a);
-    if (n <= kModeHash) return;   // mode_mid_kernel's
     for (int i = threadIdx.x; i < kBigSlots; i += 256) { owner[i] = 0xFFFFFFFFu; cnt[i] = 0; }
     mode_owner_table(p, k, a, n, owner, cnt, 14, s3);
 }
@@ -574,18 +579,19 @@ int launch_mode(Ctx *c, const int64_t *ts, const int64_t *first_idx, int64_t n, 
     // queues: a queued window has > kModeSmall rows
     const int64_t qcap = n / (kModeSmall + 1) + 2;
     DevBuf dq;
-    BG_TRY(dq.alloc(256 + (size_t)qcap * 24));
+    BG_TRY(dq.alloc(256 + (size_t)qcap * 32));
     P.counters = reinterpret_cast<uint32_t *>(dq.p);
     P.mid_queue = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(dq.p) + 256);
     P.long_queue = P.mid_queue + qcap;
     P.wave_queue = P.long_queue + qcap;
+    P.big_queue = P.wave_queue + qcap;
     BG_HIP(hipMemsetAsync(P.counters, 0, 256, c->stream));
     hipLaunchKernelGGL(mode_small_kernel, dim3((unsigned)((W + kSmallThreads - 1) / kSmallThreads)), dim3(kSmallThreads), 0, c->stream, P);
     BG_HIP(hipGetLastError());
-    uint32_t hcount[3] = {0, 0, 0};
-    BG_HIP(hipMemcpyAsync(hcount, P.counters, 12, hipMemcpyDeviceToHost, c->stream));
+    uint32_t hcount[4] = {0, 0, 0, 0};
+    BG_HIP(hipMemcpyAsync(hcount, P.counters, 16, hipMemcpyDeviceToHost, c->stream));
     BG_HIP(hipStreamSynchronize(c->stream));
-    *n_mid = (int64_t)hcount[0] + hcount[2];
+    *n_mid = (int64_t)hcount[0] + hcount[2] + hcount[3];
     *n_long = hcount[1];
     if (hcount[2] > 0) {
         hipLaunchKernelGGL(mode_wave_kernel, dim3((hcount[2] + 3) / 4), dim3(256), 0, c->stream, P, (int64_t)hcount[2]);
@@ -593,7 +599,10 @@ int launch_mode(Ctx *c, const int64_t *ts, const int64_t *first_idx, int64_t n, 
     }
     if (hcount[0] > 0) {
         hipLaunchKernelGGL(mode_mid_kernel, dim3(hcount[0]), dim3(256), 0, c->stream, P);
-        hipLaunchKernelGGL(mode_big_kernel, dim3(hcount[0]), dim3(256), 0, c->stream, P);   // (each takes its share of the queue)
+        BG_HIP(hipGetLastError());
+    }
+    if (hcount[3] > 0) {
+        hipLaunchKernelGGL(mode_big_kernel, dim3(hcount[3]), dim3(256), 0, c->stream, P);
         BG_HIP(hipGetLastError());
     }
     if (hcount[1] > 0) {
