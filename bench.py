@@ -108,15 +108,85 @@ def measured_traffic(rows, kernel=None):
     return (2.0 * sum(f) / len(f) + sum(w) / len(w)) * 1024.0
 
 
+def _count(s):
+    """row counts as the shell writes them: 100000000, 1e8, 2.5e7"""
+    return int(float(s))
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv, env=None, script=None, timeout=None):
+    """`bench.py --gpus N` started WITHOUT a launcher (no WORLD_SIZE in the environment): this process becomes the launcher.
+    It starts one fresh child per rank (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set as
+    torch.distributed.run would) and never touches the GPU itself - nothing here imports torch.  Rank 0's stdout is the
+    only thing forwarded to stdout (the one JSON line); the other ranks' stdout goes to stderr.  A rank that dies takes
+    the others with it and the exit code is non-zero."""
+    import subprocess
+    import threading
+    base = dict(os.environ if env is None else env)
+    base.setdefault("MASTER_ADDR", "127.0.0.1")
+    base.setdefault("MASTER_PORT", str(free_port()))
+    base["WORLD_SIZE"] = str(n)
+    base["LOCAL_WORLD_SIZE"] = str(n)
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    script = script or os.path.abspath(__file__)
+    procs = []
+    for r in range(n):
+        e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=e,
+                                      stdout=subprocess.PIPE, stderr=None, text=True))
+
+    def pump(p, r):
+        for line in p.stdout:
+            (sys.stdout if r == 0 else sys.stderr).write(line)
+            (sys.stdout if r == 0 else sys.stderr).flush()
+
+    threads = [threading.Thread(target=pump, args=(p, r), daemon=True) for r, p in enumerate(procs)]
+    for t in threads:
+        t.start()
+    rc = 0
+    t_end = None if timeout is None else time.monotonic() + timeout
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                sys.stderr.write("bench.py: rank %d exited with code %d; stopping the other ranks\n" % (r, code))
+                for q in live:
+                    procs[q].terminate()   # exactly the PIDs started above
+        if t_end is not None and time.monotonic() > t_end and live:
+            sys.stderr.write("bench.py: ranks %s still running after %.0f s; stopping them\n" % (sorted(live), timeout))
+            for q in live:
+                procs[q].kill()
+            rc = rc or 124
+        time.sleep(0.05)
+    for t in threads:
+        t.join(timeout=5)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rows", type=int, default=1_000_000_000, help="rows per GPU")
-    ap.add_argument("--cpu-sample", type=int, default=100_000_000)
+    ap.add_argument("--rows", type=_count, default=1_000_000_000, help="rows per GPU")
+    ap.add_argument("--cpu-sample", type=_count, default=100_000_000)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher around us: be the launcher (before anything touches the GPU in this process)
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -130,6 +200,9 @@ def main():
     # BOW_BENCH_SINGLE_DEVICE=1 + BOW_BENCH_BACKEND=gloo: exercise the N>1 code path on a 1-GPU box (testing aid)
     if os.environ.get("BOW_BENCH_SINGLE_DEVICE") == "1":
         local_rank = 0
+    elif torch.cuda.device_count() <= local_rank:
+        raise SystemExit("bench.py: rank %d needs GPU %d, this box has %d (BOW_BENCH_SINGLE_DEVICE=1 BOW_BENCH_BACKEND=gloo puts "
+                         "every rank on GPU 0 to exercise the N>1 path on a 1-GPU box)" % (rank, local_rank, torch.cuda.device_count()))
     backend = os.environ.get("BOW_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     capi.set_device(local_rank)
