@@ -8,8 +8,10 @@ rows through the C ABI (bitmap init + bucketing/reduction kernel + status readba
   python bench.py [--gpus N] [--steps K] [--warmup W] [--rows R]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1: rows are range-partitioned (rank r owns rows [r*R, (r+1)*R): weak scaling); the only
-exchange is the boundary-window carry (one fixed-size record per rank, all_gather over RCCL).
+N > 1: rows are range-partitioned (rank r owns rows [r*R, (r+1)*R): weak scaling); the only exchange of a step is ONE
+all_gather of a fixed-size record per rank (first / last timestamp + the running state of the rank's last window) over RCCL;
+the ownership rules live behind the C ABI (bowgpu_shard_begin / _plan / _finish).  Without a launcher (no WORLD_SIZE in the
+environment) `--gpus N` starts its own N rank processes.
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -242,6 +244,8 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    if world > 1:
+        runner.gather.ms, runner.gather.calls = 0.0, 0
     t0 = time.perf_counter()
     kernel_ms = []
     for _ in range(args.steps):
@@ -284,6 +288,10 @@ def main():
             "device": capi.device_name(),
         }
         line["roofline"]["traffic"] = measured_traffic(rows, kernel_name)
+        if world > 1:
+            # host wall time per step inside THE exchange of the call (upload + all_gather of one 2424-byte record per rank + download)
+            line["exchange_ms"] = runner.gather.ms / args.steps
+            line["exchanges_per_step"] = runner.gather.calls / args.steps
         if world == 1:
             # the achievable line: a trivial streaming sum over the same two columns, measured in this run
             try:

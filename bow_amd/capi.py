@@ -101,6 +101,20 @@ class ShardCarry(C.Structure):
                 ("last", CarryState * CARRY_MAX_AGGS)]
 
 
+class ShardRecord(C.Structure):
+    """bowgpu_shard_record: what one rank contributes to the exchange of a sharded Aggregate"""
+    _fields_ = [("nrows", C.c_int64), ("first_ts", C.c_int64), ("last_ts", C.c_int64), ("carry_from_ts", C.c_int64),
+                ("naggs", C.c_int32), ("flags", C.c_int32), ("first_row", NextRow), ("last", CarryState * CARRY_MAX_AGGS)]
+
+
+class ShardDecision(C.Structure):
+    """bowgpu_shard_decision: what bowgpu_shard_plan settles for one rank"""
+    _fields_ = [("s0", C.c_int64), ("num_windows", C.c_int64), ("first_window_id", C.c_int64), ("last_window_id", C.c_int64),
+                ("lead_empty_windows", C.c_int64), ("first_slot_window_id", C.c_int64), ("windows_local", C.c_int64),
+                ("windows_owned", C.c_int64), ("holds_global_row0", C.c_int32), ("drops_last", C.c_int32),
+                ("seed_first_rank", C.c_int32), ("next_rank", C.c_int32), ("finish_last", C.c_int32), ("retry_with_s0", C.c_int32)]
+
+
 # every symbol include/bowgpu.h declares (checked by tests/test_abi_symbols.py)
 SYMBOLS = [
     "bowgpu_abi_version", "bowgpu_last_error", "bowgpu_device_count", "bowgpu_set_device", "bowgpu_device_name",
@@ -110,7 +124,8 @@ SYMBOLS = [
     "bowgpu_rolling_aggregate", "bowgpu_window_bounds", "bowgpu_aggregate_whole",
     "bowgpu_rolling_interpolate_count", "bowgpu_rolling_interpolate_fill", "bowgpu_shard_interp_points",
     "bowgpu_shard_interpolate_count", "bowgpu_shard_interpolate_fill", "bowgpu_fill_linear", "bowgpu_fill",
-    "bowgpu_is_col_sorted", "bowgpu_shard_span", "bowgpu_shard_aggregate", "bowgpu_shard_carry_only", "bowgpu_shard_first_row", "bowgpu_shard_fix_first", "bowgpu_carry_merge", "bowgpu_gen_dense",
+    "bowgpu_is_col_sorted", "bowgpu_shard_span", "bowgpu_shard_aggregate", "bowgpu_shard_carry_only", "bowgpu_shard_first_row", "bowgpu_shard_fix_first", "bowgpu_carry_merge",
+    "bowgpu_shard_begin", "bowgpu_shard_plan", "bowgpu_shard_finish", "bowgpu_gen_dense",
     "bowgpu_gen_sparse", "bowgpu_stream_read_ceiling", "bowgpu_checksum64", "bowgpu_parquet_open", "bowgpu_parquet_close",
     "bowgpu_parquet_info", "bowgpu_parquet_column", "bowgpu_parquet_read_column",
 ]

@@ -78,6 +78,7 @@ int ctx_scratch(Ctx *c, size_t bytes, void **dptr) {
 }
 
 int ctx_pinned(Ctx *c, size_t bytes, void **hptr) {
+    if (bytes < 16384) bytes = 16384;  // one block for every small user (status words, null counts, seeds): it never moves under them
     if (c->h_pinned_bytes < bytes) {
         if (c->h_pinned) (void)hipHostFree(c->h_pinned);
         c->h_pinned = nullptr;
@@ -326,6 +327,14 @@ static int enforce_interval_and_offset(int64_t interval, int64_t offset, int64_t
     return 0;
 }
 
+// s0 of newIntervalRolling (rolling.go:95-99) from the first timestamp: Go's (first/interval)*interval + offset with
+// truncating division and wrapping int64 arithmetic
+static int64_t first_window_start(int64_t first, int64_t interval, int64_t offset_norm) {
+    int64_t s0 = (int64_t)((uint64_t)((first / interval) * interval) + (uint64_t)offset_norm);
+    if (s0 > first) s0 = (int64_t)((uint64_t)s0 - (uint64_t)interval);
+    return s0;
+}
+
 int plan_make(Ctx *c, const bowgpu_col *ts, int64_t interval, int64_t raw_offset, Plan *p) {
     // reference rolling/rolling.go:69-112 and :143-154
     if (ts->type != BOWGPU_INT64)
@@ -362,9 +371,7 @@ int plan_make(Ctx *c, const bowgpu_col *ts, int64_t interval, int64_t raw_offset
         BG_TRY(fetch_i64(c, ts, 0, &first));
     }
     p->first_ts = first;
-    // Go: (first/interval)*interval + offset with wrapping int64 arithmetic
-    int64_t s0 = (int64_t)((uint64_t)((first / interval) * interval) + (uint64_t)p->offset);
-    if (s0 > first) s0 = (int64_t)((uint64_t)s0 - (uint64_t)interval);
+    const int64_t s0 = first_window_start(first, interval, p->offset);
     p->s0 = s0;
     if (ts->validity) {
         // countWindows: last VALID ts scanning backwards (GetPrevInt64, bowgetters.go:189-199)
@@ -1448,6 +1455,224 @@ int bowgpu_shard_first_row(const bowgpu_col *cols, int32_t ncols, int32_t ts_col
     BG_HIP(hipStreamSynchronize(c->stream));
     out->ts = (int64_t)tsb;
     out->present = 1;
+    return 0;
+}
+
+// ---- the shard protocol: begin -> one exchange -> finish --------------------------------------------------------------
+
+// largest point of the window grid {offset + k * interval} that is <= t; false when it is not an int64
+static bool grid_floor(int64_t t, int64_t interval, int64_t offset_norm, int64_t *out) {
+    const __int128 d = (__int128)t - offset_norm;
+    const __int128 k = d >= 0 ? d / interval : -((-d + interval - 1) / interval);
+    const __int128 b = k * interval + offset_norm;
+    if (b < (__int128)INT64_MIN || b > (__int128)INT64_MAX) return false;
+    *out = (int64_t)b;
+    return true;
+}
+
+static int shard_cols_check(const bowgpu_col *cols, int32_t ncols, const bowgpu_agg *aggs, int32_t naggs) {
+    for (int i = 0; i < naggs; i++)
+        if (aggs[i].kind == BOWGPU_AGG_MODE) return fail(BOWGPU_ERR_UNSUPPORTED, "sharded aggregate: Mode is not a mergeable reducer");
+    for (int i = 0; i < ncols; i++)
+        if (cols[i].residency != BOWGPU_DEVICE) return fail(BOWGPU_ERR_UNSUPPORTED, "sharded aggregate: columns must be device-resident");
+    if (naggs > BOWGPU_CARRY_MAX_AGGS) return fail(BOWGPU_ERR_UNSUPPORTED, "sharded aggregate: too many aggregations");
+    return 0;
+}
+
+int bowgpu_shard_begin(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval, const bowgpu_options *opts,
+                       const bowgpu_agg *aggs, int32_t naggs, const int64_t *global_s0, bowgpu_shard_record *rec) {
+    if (!cols || ncols <= 0 || !rec || !aggs) return fail(BOWGPU_ERR_ARG, "null argument");
+    if (ts_col < 0 || ts_col >= ncols) return fail(BOWGPU_ERR_BAD_COL, "no interval column with index %d", ts_col);
+    bowgpu_options o = {0, 0, 0};
+    if (opts) o = *opts;
+    int inclusive = o.inclusive ? 1 : 0, nic = -1;
+    BG_TRY(validate_aggs(cols, ncols, ts_col, aggs, naggs, &inclusive, &nic));
+    BG_TRY(shard_cols_check(cols, ncols, aggs, naggs));
+    memset(rec, 0, sizeof *rec);
+    rec->naggs = naggs;
+    rec->flags = global_s0 ? 1 : 0;
+    rec->nrows = cols[ts_col].length;
+    Ctx *c;
+    BG_TRY(ctx_get(&c));
+    Plan plan;
+    BG_TRY(plan_make(c, &cols[ts_col], interval, o.offset, &plan));  // type / interval / first-ts checks; first and last ts
+    if (rec->nrows == 0) return 0;
+    rec->first_ts = plan.first_ts;
+    rec->last_ts = plan.last_ts;
+    // the window grid is {offset + k * interval} whatever the frame's first row is (rolling.go:95-99): the window holding this
+    // rank's last row starts on it.  Ids here are relative to `base`, a grid point at or below the rank's first row.
+    int64_t base;
+    if (global_s0) base = *global_s0;
+    else if (!grid_floor(plan.first_ts, interval, plan.offset, &base))
+        return fail(BOWGPU_ERR_UNSUPPORTED, "interval column reaches below the int64 window grid");
+    plan.s0 = base;
+    const int64_t wl = plan.last_ts < base ? 0 : (int64_t)(((uint64_t)plan.last_ts - (uint64_t)base) / (uint64_t)interval);
+    // (window 0 of the real grid also takes the rows below s0: range_state_kernel starts at row 0 for it)
+    rec->carry_from_ts = wl == 0 ? INT64_MIN : (int64_t)((uint64_t)base + (uint64_t)wl * (uint64_t)interval);
+    if (inclusive)
+        BG_TRY(bowgpu_shard_first_row(cols, ncols, ts_col, aggs, naggs, &rec->first_row));
+    std::vector<bowgpu_out> no_outs(naggs);
+    void *dummy;
+    BG_TRY(ctx_pool(c, kPoolShard, 16384, &dummy));
+    for (int i = 0; i < naggs; i++) {
+        memset(&no_outs[i], 0, sizeof(bowgpu_out));
+        no_outs[i].values = dummy; no_outs[i].validity = reinterpret_cast<uint8_t *>(dummy);
+        no_outs[i].length = 0; no_outs[i].residency = BOWGPU_DEVICE;
+    }
+    AggJob job;
+    BG_TRY(job_build(c, cols, ncols, ts_col, plan, 0, aggs, naggs, no_outs.data(), wl, 0, false, &job));
+    bowgpu_carry_state *dst = reinterpret_cast<bowgpu_carry_state *>(dummy);
+    BG_TRY(launch_range_state(c, job.P, 0, (uint64_t)wl, nullptr, dst, nullptr));
+    BG_HIP(hipMemcpyAsync(rec->last, dst, sizeof(bowgpu_carry_state) * naggs, hipMemcpyDeviceToHost, c->stream));
+    BG_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int bowgpu_shard_plan(const bowgpu_shard_record *recs, int32_t world, int32_t rank, int64_t interval, int64_t raw_offset,
+                      bowgpu_shard_decision *d) {
+    if (!recs || !d || world <= 0 || rank < 0 || rank >= world) return fail(BOWGPU_ERR_ARG, "bad shard plan arguments");
+    int64_t off;
+    BG_TRY(enforce_interval_and_offset(interval, raw_offset, &off));
+    memset(d, 0, sizeof *d);
+    d->first_window_id = d->last_window_id = d->first_slot_window_id = -1;
+    d->seed_first_rank = d->next_rank = -1;
+    int g0 = -1, gl = -1;
+    for (int q = 0; q < world; q++) {
+        if (recs[q].nrows < 0) return fail(BOWGPU_ERR_ARG, "rank %d: negative row count", q);
+        if (recs[q].nrows == 0) continue;
+        if (recs[q].last_ts < recs[q].first_ts) return fail(BOWGPU_ERR_TS_UNSORTED, "interval column is not ascending on rank %d", q);
+        if (gl >= 0 && recs[gl].last_ts > recs[q].first_ts)
+            return fail(BOWGPU_ERR_TS_UNSORTED, "interval column is not ascending across ranks %d and %d", gl, q);
+        if (g0 < 0) g0 = q;
+        gl = q;
+    }
+    if (g0 < 0) return 0;  // no rows anywhere: no windows (rolling.go:143-146)
+    const int64_t s0 = first_window_start(recs[g0].first_ts, interval, off);
+    d->s0 = s0;
+    d->holds_global_row0 = rank == g0;
+    const int64_t last = recs[gl].last_ts;
+    if (s0 > last) return 0;   // countWindows: s0 beyond the last row (only rows below s0) => no windows (rolling.go:150-152)
+    if (last > 0 && s0 < 0 && (uint64_t)last - (uint64_t)s0 > (uint64_t)INT64_MAX)
+        return fail(BOWGPU_ERR_UNSUPPORTED, "interval column spans more than 2^63: int64 overflow in the reference's countWindows");
+    d->num_windows = (int64_t)(((uint64_t)last - (uint64_t)s0) / (uint64_t)interval) + 1;
+    // first / last window of a rank; rows below s0 (Go's truncating division on negative timestamps) ride in window 0
+    auto wid_of = [&](int64_t t) -> int64_t { return t < s0 ? 0 : (int64_t)(((uint64_t)t - (uint64_t)s0) / (uint64_t)interval); };
+    auto wf = [&](int q) { return recs[q].nrows == 0 ? (int64_t)-1 : wid_of(recs[q].first_ts); };
+    auto wl = [&](int q) { return recs[q].nrows == 0 ? (int64_t)-1 : wid_of(recs[q].last_ts); };
+    auto left_of = [&](int q) { int r = q - 1; while (r >= 0 && recs[r].nrows == 0) r--; return r; };
+    auto right_of = [&](int q) { int r = q + 1; while (r < world && recs[r].nrows == 0) r++; return r < world ? r : -1; };
+    // window 0 with rows below s0 split over ranks: the first-attempt states were cut on the local grid
+    if (s0 > recs[g0].first_ts)
+        for (int q = 0; q < world; q++) {
+            if (recs[q].nrows == 0 || (recs[q].flags & 1)) continue;
+            const int r = right_of(q);
+            if (wl(q) == 0 && r >= 0 && wf(r) == 0 && recs[q].carry_from_ts > recs[q].first_ts) d->retry_with_s0 = 1;
+        }
+    if (recs[rank].nrows == 0) return 0;
+    const int64_t f = wf(rank), l = wl(rank);
+    d->first_window_id = f;
+    d->last_window_id = l;
+    const int lq = left_of(rank), rq = right_of(rank);
+    d->next_rank = rq;
+    // empty windows between the left neighbour's last window and this rank's first one are this rank's to output; with nothing
+    // to the left there are none (global row 0 lies in window 0)
+    d->lead_empty_windows = lq < 0 ? 0 : std::max<int64_t>(0, f - wl(lq) - 1);
+    // ranks (ascending) holding earlier rows of this rank's FIRST window
+    int sf = -1;
+    for (int q = lq; q >= 0 && wl(q) == f; q = left_of(q)) {
+        sf = q;
+        if (wf(q) != f) break;   // q only contributes its tail
+    }
+    d->seed_first_rank = sf;
+    d->drops_last = rq >= 0 && wf(rq) == l;
+    d->first_slot_window_id = f - d->lead_empty_windows;
+    d->windows_local = l - f + 1 + d->lead_empty_windows;
+    d->windows_owned = d->windows_local - (d->drops_last ? 1 : 0);
+    d->finish_last = !d->drops_last && !(f == l && sf >= 0);
+    return 0;
+}
+
+int bowgpu_shard_finish(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval, const bowgpu_options *opts,
+                        const bowgpu_agg *aggs, int32_t naggs, bowgpu_out *outs, const bowgpu_shard_record *recs, int32_t world,
+                        int32_t rank, bowgpu_shard_decision *decision, bowgpu_agg_info *info) {
+    if (!cols || ncols <= 0 || !outs || !recs || !aggs) return fail(BOWGPU_ERR_ARG, "null argument");
+    if (ts_col < 0 || ts_col >= ncols) return fail(BOWGPU_ERR_BAD_COL, "no interval column with index %d", ts_col);
+    bowgpu_options o = {0, 0, 0};
+    if (opts) o = *opts;
+    int inclusive = o.inclusive ? 1 : 0, nic = -1;
+    BG_TRY(validate_aggs(cols, ncols, ts_col, aggs, naggs, &inclusive, &nic));
+    BG_TRY(shard_check(cols, ncols, aggs, naggs, outs, &o));
+    bowgpu_shard_decision d;
+    BG_TRY(bowgpu_shard_plan(recs, world, rank, interval, o.offset, &d));
+    if (decision) *decision = d;
+    if (info) {
+        memset(info, 0, sizeof *info);
+        info->s0 = d.s0; info->num_windows = d.num_windows; info->new_interval_col = nic; info->inclusive = inclusive;
+    }
+    if (d.retry_with_s0) return BOWGPU_SHARD_RETRY;
+    const bowgpu_shard_record &me = recs[rank];
+    if (me.nrows != cols[ts_col].length) return fail(BOWGPU_ERR_ARG, "record of rank %d says %lld rows, the interval column has %lld", rank,
+                                                     (long long)me.nrows, (long long)cols[ts_col].length);
+    if (cols[ts_col].type != BOWGPU_INT64) return fail(BOWGPU_ERR_TS_TYPE, "impossible to create a new intervalRolling on column of type float64");
+    Ctx *c;
+    BG_TRY(ctx_get(&c));
+    // the rank's plan from its own record: no round trip to the device for first / last ts
+    Plan plan;
+    plan.interval = interval;
+    BG_TRY(enforce_interval_and_offset(interval, o.offset, &plan.offset));
+    plan.magic = magic_make((uint64_t)interval);
+    plan.s0 = d.s0;
+    plan.first_ts = me.first_ts;
+    plan.last_ts = me.last_ts;
+    const int64_t wf = d.first_window_id, wl = d.last_window_id, lead = d.lead_empty_windows;
+    plan.W = wf < 0 ? 0 : wl - wf + 1;
+    const int64_t Wtot = plan.W + lead;
+    AggJob job;
+    const bool pre_rows_here = me.nrows > 0 && me.first_ts < d.s0;   // rows below s0 ride in window 0 (rolling.go:194-196)
+    BG_TRY(job_build(c, cols, ncols, ts_col, plan, inclusive, aggs, naggs, outs, wf < 0 ? 0 : wf - lead, Wtot, pre_rows_here, &job));
+    int64_t n_long = 0;
+    double ms = 0;
+    BG_TRY(job_run(c, &job, aggs, naggs, &n_long, &ms, false, &plan));
+    if (lead > 0) BG_TRY(launch_fill_empty(c, job.P, 0, lead));
+    if (plan.W > 0) {
+        void *pool;
+        BG_TRY(ctx_pool(c, kPoolShard, 16384, &pool));
+        bowgpu_carry_state *dseed = reinterpret_cast<bowgpu_carry_state *>(pool);
+        bowgpu_next_row *dnext = nullptr;
+        const bowgpu_next_row *next_row = d.next_rank >= 0 ? &recs[d.next_rank].first_row : nullptr;
+        if (inclusive && next_row && next_row->present) {
+            dnext = reinterpret_cast<bowgpu_next_row *>(reinterpret_cast<char *>(pool) + 8192);
+            BG_HIP(hipMemcpyAsync(dnext, next_row, sizeof *next_row, hipMemcpyHostToDevice, c->stream));
+        }
+        // the rank owns its last window and only now knows the row that may close it (rolling.go:201-209)
+        if (dnext && d.finish_last) BG_TRY(launch_range_state(c, job.P, 2, (uint64_t)wl, nullptr, nullptr, dnext));
+        if (d.seed_first_rank >= 0) {
+            // running state of this rank's first window over the rows the ranks to the left hold: one rank's state as is,
+            // several merged in rank order (empty ranks in between hold zero states: identity)
+            bowgpu_carry_state seeds[BOWGPU_CARRY_MAX_AGGS];
+            for (int a = 0; a < naggs; a++) {
+                seeds[a] = recs[d.seed_first_rank].last[a];
+                for (int q = d.seed_first_rank + 1; q < rank; q++) {
+                    if (recs[q].nrows == 0) continue;
+                    bowgpu_carry_state m;
+                    BG_TRY(bowgpu_carry_merge(&seeds[a], &recs[q].last[a], &m));
+                    seeds[a] = m;
+                }
+            }
+            // (the records were built by the caller's all_gather: pageable memory, so stage through the pinned block)
+            bowgpu_carry_state *hseed;
+            static_assert(4096 + sizeof seeds <= 16384, "pinned block");
+            BG_TRY(ctx_pinned(c, 16384, reinterpret_cast<void **>(&hseed)));
+            hseed = reinterpret_cast<bowgpu_carry_state *>(reinterpret_cast<char *>(hseed) + 4096);
+            memcpy(hseed, seeds, sizeof(bowgpu_carry_state) * naggs);
+            BG_HIP(hipMemcpyAsync(dseed, hseed, sizeof(bowgpu_carry_state) * naggs, hipMemcpyHostToDevice, c->stream));
+            // the window may also be the rank's last one: then the next rank's first row can be its inclusive row
+            const bool also_last = wf == wl && !d.drops_last;
+            BG_TRY(launch_range_state(c, job.P, 1, (uint64_t)wf, dseed, nullptr, also_last ? dnext : nullptr));
+        }
+    }
+    BG_TRY(job_finish(c, &job, aggs, naggs));
+    if (info) { info->long_windows = n_long; info->kernel_ms = ms; }
     return 0;
 }
 

@@ -54,7 +54,9 @@ __global__ __launch_bounds__(256) void range_state_kernel(const AggParams p, con
             if (p.ts[mid] >= lim) hi = mid; else lo = mid + 1;
         }
         const int64_t b = ovf ? p.n : lo;
-        s_r0 = mode != 1 ? b : 0;
+        // window 0 also holds the rows below s0 (Go's truncating division puts s0 above a negative first timestamp:
+        // rolling.go:96-99, :194-196), so its state starts at row 0
+        s_r0 = mode != 1 ? (wid == 0 ? 0 : b) : 0;
         s_r1 = mode != 1 ? p.n : b;
     }
     __syncthreads();

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define BOWGPU_ABI_VERSION 2
+#define BOWGPU_ABI_VERSION 3
 
 /* bow.Type (reference bowtypes.go:17-32) */
 enum {
@@ -401,6 +401,62 @@ int bowgpu_shard_fix_first(const bowgpu_col *cols, int32_t ncols, int32_t ts_col
  * only used when one window spans three or more ranks. */
 int bowgpu_carry_merge(const bowgpu_carry_state *left, const bowgpu_carry_state *right,
                        bowgpu_carry_state *out);
+
+/* ---- the shard protocol behind the ABI: begin -> ONE exchange -> finish ------------------------------------------
+ * What a host (the cgo shim inside reference rolling/aggregation.go:123-145, or bow_amd/sharded.py here) does per
+ * Rolling.Aggregate over R ranks:
+ *     bowgpu_shard_begin(my columns)            -> my record             (fixed size)
+ *     all_gather of the records as bytes        (RCCL over xGMI / any transport: the ONLY exchange of the call)
+ *     bowgpu_shard_finish(my columns, records)  -> my output slots + which global windows they are
+ * All ownership rules (which rank outputs a window that straddles a boundary, who emits the empty windows between two
+ * shards, whose running state seeds whose first window, who needs whose first row for an inclusive window) are decided
+ * inside the library from the gathered records; every rank derives the same decisions from the same bytes. */
+typedef struct bowgpu_shard_record {
+    int64_t nrows, first_ts, last_ts;      /* of this rank's interval column (0 rows: the rest is zero) */
+    int64_t carry_from_ts;                 /* the running states below cover this rank's rows with ts >= carry_from_ts:
+                                              the start, on the offset-aligned window grid, of the window holding last_ts
+                                              (INT64_MIN: all of the rank's rows) */
+    int32_t naggs;
+    int32_t flags;                         /* bit 0: built with the global first window start known (second attempt) */
+    bowgpu_next_row first_row;             /* this rank's first row (filled when some reducer needs inclusive windows) */
+    bowgpu_carry_state last[BOWGPU_CARRY_MAX_AGGS];  /* per aggregator: running state of the rank's LAST window over its rows */
+} bowgpu_shard_record;
+
+/* What bowgpu_shard_plan decides for one rank. */
+typedef struct bowgpu_shard_decision {
+    int64_t s0;                     /* global first window start (rolling.go:95-99 on the first row of the first non-empty rank) */
+    int64_t num_windows;            /* global W (rolling.go:143-154) */
+    int64_t first_window_id;        /* global id of the first / last window with a row on this rank; -1: no rows */
+    int64_t last_window_id;
+    int64_t lead_empty_windows;     /* empty windows in front of first_window_id that this rank outputs too */
+    int64_t first_slot_window_id;   /* global window id of output slot 0 (= first_window_id - lead_empty_windows); -1: none */
+    int64_t windows_local;          /* output slots this rank writes */
+    int64_t windows_owned;          /* ... of which it owns the first windows_owned (a last window that continues on a rank
+                                       to the right belongs to that rank) */
+    int32_t holds_global_row0;
+    int32_t drops_last;
+    int32_t seed_first_rank;        /* ranks seed_first_rank .. rank-1 hold earlier rows of this rank's first window; -1: none */
+    int32_t next_rank;              /* next rank to the right that holds rows; -1: none */
+    int32_t finish_last;            /* this rank folds next_rank's first row into its last window during the pass */
+    int32_t retry_with_s0;          /* 1: the records cannot settle window 0 (rows below s0, rolling.go:96-99 with negative
+                                       timestamps, split across ranks): run bowgpu_shard_begin again with &s0 and exchange again */
+} bowgpu_shard_decision;
+
+#define BOWGPU_SHARD_RETRY 1   /* bowgpu_shard_finish: nothing was computed; see retry_with_s0 */
+
+/* global_s0: NULL on the first attempt. */
+int bowgpu_shard_begin(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval,
+                       const bowgpu_options *opts, const bowgpu_agg *aggs, int32_t naggs,
+                       const int64_t *global_s0, bowgpu_shard_record *record);
+/* Pure host arithmetic on the gathered records (no device, no column data): usable from any process. */
+int bowgpu_shard_plan(const bowgpu_shard_record *records, int32_t world, int32_t rank, int64_t interval,
+                      int64_t raw_offset, bowgpu_shard_decision *out);
+/* The rank's pass + stitch.  outs: device-resident, capacity >= (last_ts - first_ts) / interval + 2 + lead (or simply
+ * global W).  Returns 0, BOWGPU_SHARD_RETRY, or a negative error. */
+int bowgpu_shard_finish(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval,
+                        const bowgpu_options *opts, const bowgpu_agg *aggs, int32_t naggs, bowgpu_out *outs,
+                        const bowgpu_shard_record *records, int32_t world, int32_t rank,
+                        bowgpu_shard_decision *decision /* nullable */, bowgpu_agg_info *info /* nullable */);
 
 /* ---- synthetic inputs generated in HBM -------------------------------- */
 

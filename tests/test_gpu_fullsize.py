@@ -161,16 +161,11 @@ def test_headline_1e9_every_window_properties_and_sharded():
     w_ts, w_mean = whole[0].host_arrays()[0], whole[1].host_arrays()[0]
     del ts, val, got, whole
     world, R = 8, N9 // 8
-    provs, sess = [], []
+    provs = []
     for r in range(world):
         cols = list(capi.gen_dense(r * R, R, seed=42))
-        p = sharded.GpuProvider(cols, 0, 10, aggs[:2], offset=3)
-        provs.append(p)
-        sess.append(sharded.ShardSession(p, r, world, 10))
-    s0 = provs[0].plan_s0()
-    infos = [s.local_info() for s in sess]
-    carries = [s.phase1(s0, infos) for s in sess]
-    owned = [s.phase2(carries) for s in sess]
+        provs.append(sharded.GpuProvider(cols, 0, 10, aggs[:2], offset=3))
+    owned = [(d.first_slot_window_id, d.windows_owned) for d in sharded.run_local(provs)]
     assert capi.last_kernel_name() == "rolling_simple_kernel"
     covered = 0
     for r, (fs, nwin) in enumerate(owned):

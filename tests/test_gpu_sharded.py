@@ -1,6 +1,6 @@
 """Row-range sharding on ONE GPU: K simulated ranks each hold a row range in HBM and
-run the real protocol of bow_amd/sharded.py (ShardSession: plan exchange -> phase 1 -> carry exchange
--> phase 2) with the HIP provider; the stitched windows must equal the oracle on the whole frame."""
+run the real protocol behind the C ABI (bowgpu_shard_begin -> the gathered records -> bowgpu_shard_finish; bow_amd/sharded.py
+is the transport) with the HIP provider; the stitched windows must equal the oracle on the whole frame."""
 import numpy as np
 import pytest
 
@@ -23,25 +23,15 @@ def run_sharded(ts, vals, valid, bounds, interval, offset=0, aggs=None):
     """bounds: row boundaries [0, b1, ..., n] of the simulated ranks"""
     AGGS = aggs if aggs is not None else globals()["AGGS"]
     world = len(bounds) - 1
-    provs, sess = [], []
+    provs = []
     for r in range(world):
         a, b = bounds[r], bounds[r + 1]
         bm = None if valid is None else np.packbits(valid[a:b], bitorder="little")
         cols = [capi.Column(ts[a:b].copy(), None, capi.INT64).to_device(),
                 capi.Column(vals[a:b].copy(), bm, capi.FLOAT64 if vals.dtype == np.float64 else capi.INT64, 0, b - a, -1).to_device()]
-        p = sharded.GpuProvider(cols, 0, interval, AGGS, offset=offset)
-        provs.append(p)
-        sess.append(sharded.ShardSession(p, r, world, interval))
-    info = [s.local_info() for s in sess]
-    # s0 as sharded_aggregate derives it: from the first timestamp of the first rank that holds rows
-    s0 = 0
-    for b in info:
-        f, _, nr = np.frombuffer(b[:24], dtype=np.int64)
-        if nr > 0:
-            s0 = sharded.first_window_start(int(f), interval, offset)
-            break
-    carries = [s.phase1(s0, info) for s in sess]
-    owned = [s.phase2(carries) for s in sess]
+        provs.append(sharded.GpuProvider(cols, 0, interval, AGGS, offset=offset))
+    decisions = sharded.run_local(provs)
+    owned = [(d.first_slot_window_id, d.windows_owned) for d in decisions]
     # assemble the global result from what each rank owns
     W = max(fs + n for fs, n in owned if fs >= 0)
     res = []
@@ -59,7 +49,7 @@ def run_sharded(ts, vals, valid, bounds, interval, offset=0, aggs=None):
             seen[fs:fs + n] += 1
         assert (seen == 1).all(), (k, np.flatnonzero(seen != 1)[:10])
         res.append((vals_g, valid_g, provs[0].outs[i].type))
-    return res, sess[0].plan
+    return res, sharded.ShardPlan(decisions=decisions)
 
 
 @pytest.mark.parametrize("mode", ["dense", "irregular", "gappy"])
@@ -224,8 +214,13 @@ def test_carry_only_equals_the_carry_of_the_pass():
             cols = [capi.Column(ts[a:b].copy(), None, capi.INT64).to_device(),
                     capi.Column(vals[a:b].copy(), np.packbits(valid[a:b], bitorder="little"), capi.FLOAT64, 0, b - a, -1).to_device()]
             prov = sharded.GpuProvider(cols, 0, interval, aggs, offset=offset)
-            assert not prov.has_inclusive
             prov.first_last_nrows()
             early = prov.shard_carry_only(s0, a == 0)
             full = prov.shard_aggregate(s0, a == 0, 0)
             assert early == full, (case, r, n, interval, offset)
+            # ... and the states bowgpu_shard_begin puts in the rank's record (computed on the offset-aligned grid, before any
+            # rank knows s0) are those same states whenever the record covers the rank's whole last window
+            rec = capi.ShardRecord.from_buffer_copy(prov.begin())
+            car = capi.ShardCarry.from_buffer_copy(full)
+            if s0 <= int(ts[a]):
+                assert bytes(rec.last) == bytes(car.last), (case, r, n, interval, offset)

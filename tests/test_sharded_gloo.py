@@ -1,7 +1,8 @@
 """The multi-rank protocol of bow_amd/sharded.py under torch.distributed (gloo, world_size 2 and 3)
 on CPU.  Compute is replaced by a numpy provider that follows the same provider interface as the
 HIP one (the HIP provider itself is covered by tests/test_gpu_sharded.py); what is tested here is
-the exchange: s0 broadcast, plan all_gather, carry all_gather, ownership of straddling windows."""
+the exchange (ONE all_gather of fixed-size records per call) and the ownership decisions bowgpu_shard_plan takes from the
+gathered records - pure host arithmetic inside libbowgpu.so, so it runs here without a GPU."""
 import ctypes as C
 import os
 import socket
@@ -17,19 +18,12 @@ AGGS = [("WindowStart", 0), ("Sum", 1), ("ArithmeticMean", 1), ("Min", 1), ("Max
 
 
 class NumpyProvider:
-    """Reference-order reducers over this rank's rows with numpy / python floats (test double)."""
+    """Reference-order reducers over this rank's rows with numpy / python floats (test double for GpuProvider: same
+    begin / finish interface, every ownership decision taken from bowgpu_shard_plan)."""
 
-    def __init__(self, ts, vals, interval):
-        self.ts, self.vals, self.interval = ts, vals, interval
+    def __init__(self, ts, vals, interval, offset=0):
+        self.ts, self.vals, self.interval, self.offset = ts, vals, interval, offset
         self.out = None
-
-    def first_last_nrows(self):
-        n = len(self.ts)
-        return (int(self.ts[0]), int(self.ts[-1]), n) if n else (0, 0, 0)
-
-    def plan_s0(self):
-        from oracle import pyoracle as orc
-        return orc.plan_windows(orc.Column(self.ts, None, orc.INT64), self.interval, 0)[0]
 
     def _state(self, rows, seed=None):
         st = dict(sum=0.0, vmin=0.0, vmax=0.0, count=0, nrows=0, has=0) if seed is None else dict(seed)
@@ -46,18 +40,14 @@ class NumpyProvider:
             st["nrows"] += 1
         return st
 
-    def _pack(self, st):
-        from bow_amd import capi
-        arr = (capi.CarryState * capi.CARRY_MAX_AGGS)()
-        for i in range(len(AGGS)):
-            arr[i].sum, arr[i].vmin, arr[i].vmax = st["sum"], st["vmin"], st["vmax"]
-            arr[i].nn_min, arr[i].nn_max, arr[i].has_nn = st["vmin"], st["vmax"], st["has"]
-            arr[i].count, arr[i].nrows, arr[i].has_value = st["count"], st["nrows"], st["has"]
-        return bytes(arr)
+    @staticmethod
+    def _fill(cs, st):
+        cs.sum, cs.vmin, cs.vmax = st["sum"], st["vmin"], st["vmax"]
+        cs.nn_min, cs.nn_max, cs.has_nn = st["vmin"], st["vmax"], st["has"]
+        cs.count, cs.nrows, cs.has_value = st["count"], st["nrows"], st["has"]
 
-    def _unpack(self, b):
-        from bow_amd import capi
-        a = (capi.CarryState * capi.CARRY_MAX_AGGS).from_buffer_copy(b)[0]
+    @staticmethod
+    def _unpack(a):
         return dict(sum=a.sum, vmin=a.vmin, vmax=a.vmax, count=a.count, nrows=a.nrows, has=a.has_value)
 
     def _emit(self, slot, wid, st):
@@ -66,47 +56,57 @@ class NumpyProvider:
                           (st["sum"] / st["count"]) if st["count"] else None,
                           st["vmin"] if st["has"] else None, st["vmax"] if st["has"] else None, st["count"]]
 
-    def shard_aggregate(self, s0, holds_row0, lead):
+    def begin(self, global_s0=None):
         from bow_amd import capi
-        self.s0 = s0
-        I = self.interval
-        carry = capi.ShardCarry()
+        rec = capi.ShardRecord()
         n = len(self.ts)
+        rec.nrows, rec.naggs = n, len(AGGS)
         if n == 0:
-            carry.first_window_id = carry.last_window_id = -1
-            self.out = []
-            return bytes(carry)
+            return bytes(rec)
+        I = self.interval
+        rec.first_ts, rec.last_ts = int(self.ts[0]), int(self.ts[-1])
+        off = self.offset % I                      # (non-negative offsets in these tests)
+        start = (rec.last_ts - off) // I * I + off   # the window grid does not depend on the frame's first row
+        rec.carry_from_ts = start
+        st = self._state(self.vals[self.ts >= start])
+        for i in range(len(AGGS)):
+            self._fill(rec.last[i], st)
+        return bytes(rec)
+
+    def finish(self, records, rank):
+        from bow_amd import capi, sharded
+        d = sharded.plan(records, rank, self.interval, self.offset)
+        assert not d.retry_with_s0
+        self.s0 = s0 = d.s0
+        I = self.interval
+        self.out = []
+        if d.first_window_id < 0:
+            return 0, d
         wid = (self.ts - s0) // I
-        wf, wl = int(wid[0]), int(wid[-1])
-        self.wf = wf
-        self.out = [None] * (wl - wf + 1 + lead)
+        wf, wl, lead = d.first_window_id, d.last_window_id, d.lead_empty_windows
+        assert (wf, wl) == (int(wid[0]), int(wid[-1]))
+        self.out = [None] * d.windows_local
         empty = dict(sum=0.0, vmin=0.0, vmax=0.0, count=0, nrows=0, has=0)
         for k in range(wf - lead, wl + 1):
             rows = self.vals[wid == k]
             self._emit(k - (wf - lead), k, self._state(rows) if len(rows) else empty)
-        carry.first_window_id, carry.last_window_id = wf, wl
-        carry.first_ts, carry.last_ts, carry.nrows, carry.naggs = int(self.ts[0]), int(self.ts[-1]), n, len(AGGS)
-        last = (capi.CarryState * capi.CARRY_MAX_AGGS).from_buffer_copy(self._pack(self._state(self.vals[wid == wl])))
-        for i in range(capi.CARRY_MAX_AGGS):
-            carry.last[i] = last[i]
-        return bytes(carry)
+        if d.seed_first_rank >= 0:
+            recs = [capi.ShardRecord.from_buffer_copy(b) for b in records]
+            seed = self._unpack(recs[d.seed_first_rank].last[0])
+            for q in range(d.seed_first_rank + 1, rank):
+                if recs[q].nrows:
+                    seed = self._merge(seed, self._unpack(recs[q].last[0]))
+            self._emit(lead, wf, self._state(self.vals[wid == wf], seed))
+        return 0, d
 
-    def fix_first(self, s0, lead, first_window_id, seed_bytes):
-        wid = (self.ts - s0) // self.interval
-        st = self._state(self.vals[wid == first_window_id], self._unpack(seed_bytes))
-        self._emit(lead, first_window_id, st)
-        return self._pack(st)
-
-    def merge(self, a, b):
-        x, y = self._unpack(a), self._unpack(b)
+    @staticmethod
+    def _merge(x, y):
         if not y["has"]:
-            x["nrows"] += y["nrows"]
-            return self._pack(x)
+            return dict(x, nrows=x["nrows"] + y["nrows"])
         if not x["has"]:
-            y["nrows"] += x["nrows"]
-            return self._pack(y)
-        return self._pack(dict(sum=x["sum"] + y["sum"], vmin=min(x["vmin"], y["vmin"]), vmax=max(x["vmax"], y["vmax"]),
-                               count=x["count"] + y["count"], nrows=x["nrows"] + y["nrows"], has=1))
+            return dict(y, nrows=x["nrows"] + y["nrows"])
+        return dict(sum=x["sum"] + y["sum"], vmin=min(x["vmin"], y["vmin"]), vmax=max(x["vmax"], y["vmax"]),
+                    count=x["count"] + y["count"], nrows=x["nrows"] + y["nrows"], has=1)
 
 
 def _worker(rank, world, port, bounds, interval, q):
@@ -120,8 +120,10 @@ def _worker(rank, world, port, bounds, interval, q):
         ts, vals = _data()
         a, b = bounds[rank], bounds[rank + 1]
         prov = NumpyProvider(ts[a:b], vals[a:b], interval)
-        first_slot, owned, plan = sharded.sharded_aggregate(prov, dist, torch, rank, world, interval)
-        q.put((rank, first_slot, owned, prov.out[:max(owned, 0)]))
+        gather = sharded.Gather(dist, torch, world, "cpu")
+        d = sharded.sharded_aggregate(prov, gather, rank, world)
+        assert gather.calls == 1          # ONE exchange per call
+        q.put((rank, d.first_slot_window_id, d.windows_owned, prov.out[:max(d.windows_owned, 0)]))
     finally:
         dist.destroy_process_group()
 
@@ -179,3 +181,100 @@ def test_protocol_under_gloo(world, bounds, interval):
                 assert abs(g - e) <= 1e-11 * max(1.0, abs(e)), (k, AGGS[i], g, e)
             else:
                 assert g == e, (k, AGGS[i], g, e)
+
+
+def _records(spans, interval, offset=0):
+    """records as bowgpu_shard_begin would fill them, from (first_ts, last_ts, nrows) per rank"""
+    from bow_amd import capi
+    out = []
+    for f, l, n in spans:
+        r = capi.ShardRecord()
+        r.nrows = n
+        if n:
+            r.first_ts, r.last_ts = f, l
+            off = offset % interval
+            r.carry_from_ts = (l - off) // interval * interval + off
+        out.append(bytes(r))
+    return out
+
+
+def test_c_plan_equals_the_python_plan():
+    """bowgpu_shard_plan (C, behind the ABI) against the round-1 Python rules on random shard layouts: empty ranks, one-row
+    ranks, several ranks inside one window, gaps of many empty windows between ranks, offsets."""
+    from bow_amd import sharded
+    from legacy_shard_plan import ShardPlan as OldPlan
+    rng = np.random.default_rng(2024)
+    cases = 0
+    for _ in range(3000):
+        world = int(rng.integers(1, 9))
+        interval = int(rng.choice([1, 3, 7, 10, 100, 1000]))
+        offset = int(rng.integers(0, 3 * interval))
+        t = int(rng.integers(0, 5000))
+        spans = []
+        for _r in range(world):
+            kind = rng.integers(0, 6)
+            if kind == 0:
+                spans.append((0, 0, 0))
+                continue
+            t += int(rng.choice([0, 1, 2, interval, 5 * interval + 3, 1]))
+            f = t
+            n = 1 if kind == 1 else int(rng.integers(1, 50))
+            t += 0 if n == 1 else int(rng.integers(0, 4 * interval + 1))
+            spans.append((f, t, n))
+        recs = _records(spans, interval, offset)
+        new = sharded.ShardPlan(recs, interval, offset)
+        first = next((f for f, _l, n in spans if n), None)
+        if first is None:
+            assert all(w == -1 for w in new.wf)
+            continue
+        s0 = sharded.first_window_start(first, interval, offset)
+        assert new.s0 == s0
+        old = OldPlan(s0, interval, [s[0] for s in spans], [s[1] for s in spans], [s[2] for s in spans])
+        assert new.wf == old.wf and new.wl == old.wl, (spans, interval, offset)
+        for r in range(world):
+            assert new.lead_empty(r) == old.lead_empty(r), (r, spans, interval, offset)
+            assert new.seed_ranks(r) == old.seed_ranks(r), (r, spans, interval, offset)
+            assert new.drops_last(r) == old.drops_last(r), (r, spans, interval, offset)
+            d = new.decisions[r]
+            if old.wf[r] >= 0:
+                W_local = old.wl[r] - old.wf[r] + 1 + old.lead_empty(r)
+                assert d.windows_local == W_local and d.windows_owned == W_local - (1 if old.drops_last(r) else 0)
+                assert d.first_slot_window_id == old.wf[r] - old.lead_empty(r)
+                assert d.next_rank == old.right_nonempty(r)
+            assert not d.retry_with_s0
+        # every window of the frame is owned exactly once
+        W = new.decisions[0].num_windows
+        seen = np.zeros(W, dtype=int)
+        for d in new.decisions:
+            if d.first_slot_window_id >= 0:
+                seen[d.first_slot_window_id:d.first_slot_window_id + d.windows_owned] += 1
+        assert (seen == 1).all(), (spans, interval, offset)
+        cases += 1
+    assert cases > 2000
+
+
+def test_c_plan_rejects_ranks_out_of_order_and_handles_rows_below_s0():
+    from bow_amd import capi, sharded
+    recs = _records([(0, 50, 10), (40, 90, 10)], 10)
+    with pytest.raises(capi.BowGpuError) as e:
+        sharded.plan(recs, 0, 10)
+    assert e.value.code == -14      # BOWGPU_ERR_TS_UNSORTED
+    # Go's truncating division: first ts -7, interval 5, offset 4 -> s0 = -6 ABOVE the first row; rows below s0 ride in
+    # window 0 (rolling.go:96-99, :194-196).  Rank 0 holds rows in grid cells -1 and 0, rank 1 continues window 0: the
+    # first-attempt state of rank 0 (cut on the grid: rows >= -6 only) cannot seed it -> every rank is told to retry with s0
+    recs = _records([(-7, -3, 4), (-2, 20, 9)], 5, 4)
+    for r in range(2):
+        d = sharded.plan(recs, r, 5, 4)
+        assert d.s0 == -6 and d.retry_with_s0 == 1
+    assert sharded.first_window_start(-7, 5, 4) == -6
+    # second attempt: flags bit 0 set, the state covers all rows of window 0
+    fixed = []
+    for b in recs:
+        r = capi.ShardRecord.from_buffer_copy(b)
+        r.flags = 1
+        r.carry_from_ts = -(1 << 63) if r.last_ts < -6 + 5 else r.carry_from_ts
+        fixed.append(bytes(r))
+    d1 = sharded.plan(fixed, 1, 5, 4)
+    assert d1.retry_with_s0 == 0 and d1.first_window_id == 0 and d1.seed_first_rank == 0
+    d0 = sharded.plan(fixed, 0, 5, 4)
+    assert d0.first_window_id == 0 and d0.last_window_id == 0 and d0.drops_last == 1 and d0.windows_owned == 0
