@@ -30,6 +30,12 @@ bows = {
         "value": [10.0, N, N, N, 10.0, 10.0, 20.0, 10.0, 20.0],
         "value_type": "float64",
     },
+    # rolling/aggregation/mode_test.go:11-31 (local to TestMode)
+    "modeFloatBow": {
+        "time": [10, 11, 20, 21, 22, 30, 31, 32, 50, 51],
+        "value": [10.0, 10.0, 42.0, 42.0, 10.0, N, N, 10.0, N, N],
+        "value_type": "float64",
+    },
     # core_test.go:54-70
     "sparseBoolBow": {
         "time": [10, 11, 20, 40, 41, 50, 51, 61, 69],
@@ -77,6 +83,10 @@ reducers = [
     red("Last", "empty", "emptyBow", [], "firstlast_test.go:87-97"),
     red("Last", "sparse float", "sparseFloatBow", [10.0, N, N, 10.0, 20.0, 20.0], "firstlast_test.go:99-116"),
     red("Last", "sparse bool", "sparseBoolBow", [True, N, N, False, False, False], "firstlast_test.go:118-135", out_type="bool"),
+    # mode_test.go (Mode itself is outside the hot-path scope - SURVEY.md Appendix C - but its vectors pin the oracle's restatement)
+    red("Mode", "empty", "emptyBow", [], "mode_test.go:33-44"),
+    dict(red("Mode", "mode float", "modeFloatBow", [10.0, 42.0, 10.0, N, N], "mode_test.go:11-31,45-62"), expect_time=[10, 20, 30, 40, 50]),
+    red("Mode", "sparse bool", "sparseBoolBow", [True, N, N, False, True, True], "mode_test.go:63-81", out_type="bool"),
     # integral_test.go
     red("IntegralStep", "empty", "emptyBow", [], "integral_test.go:13-24"),
     red("IntegralStep", "sparse float", "sparseFloatBow",

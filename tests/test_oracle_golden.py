@@ -184,3 +184,18 @@ def test_factor(golden):
     cols = [orc.Column.from_list([0], orc.INT64), orc.Column.from_list([11.0], orc.FLOAT64)]
     outs, _ = orc.aggregate(cols, 0, 10, [("WindowStart", 0), ("Last", 1, [0.1])])
     assert outs[1].to_list() == [1.1]
+
+
+def test_fixture_file_is_exactly_what_the_committed_script_writes():
+    """tests/golden/reference_vectors.json must be reproducible: it equals, value for value, what
+    tests/golden/transcribe_reference_vectors.py (the hand transcription, with its file:line citations) writes."""
+    import importlib.util
+    import json
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("transcribe_reference_vectors", os.path.join(here, "transcribe_reference_vectors.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    with open(os.path.join(here, "reference_vectors.json")) as f:
+        committed = json.load(f)
+    assert json.loads(json.dumps(mod.out)) == committed
