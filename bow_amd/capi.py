@@ -118,7 +118,7 @@ class ShardDecision(C.Structure):
 # every symbol include/bowgpu.h declares (checked by tests/test_abi_symbols.py)
 SYMBOLS = [
     "bowgpu_abi_version", "bowgpu_last_error", "bowgpu_device_count", "bowgpu_set_device", "bowgpu_device_name",
-    "bowgpu_set_stream", "bowgpu_synchronize", "bowgpu_last_kernel_ms", "bowgpu_last_kernel_name", "bowgpu_malloc", "bowgpu_free", "bowgpu_memcpy_h2d",
+    "bowgpu_set_stream", "bowgpu_synchronize", "bowgpu_trim", "bowgpu_mem_info", "bowgpu_last_kernel_ms", "bowgpu_last_kernel_name", "bowgpu_malloc", "bowgpu_free", "bowgpu_memcpy_h2d",
     "bowgpu_memcpy_d2h", "bowgpu_memset", "bowgpu_timer_create", "bowgpu_timer_start", "bowgpu_timer_stop",
     "bowgpu_timer_elapsed_ms", "bowgpu_timer_destroy", "bowgpu_enforce_interval_and_offset", "bowgpu_plan_windows",
     "bowgpu_rolling_aggregate", "bowgpu_window_bounds", "bowgpu_aggregate_whole",
@@ -145,6 +145,18 @@ def lib():
         L.bowgpu_last_kernel_name.restype = C.c_char_p
         _lib = L
     return _lib
+
+
+def mem_info():
+    f, t = C.c_int64(0), C.c_int64(0)
+    check(lib().bowgpu_mem_info(C.byref(f), C.byref(t)))
+    return f.value, t.value
+
+
+def trim(all_threads=True):
+    n = C.c_int64(0)
+    check(lib().bowgpu_trim(1 if all_threads else 0, C.byref(n)))
+    return n.value
 
 
 def check(rc):

@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -41,9 +42,37 @@ int hip_fail(hipError_t e, const char *what) {
 }
 
 // ---------------------------------------------------------------- context
-static thread_local Ctx g_ctx;
+// All device state is per calling thread (cgo calls arrive on arbitrary OS threads).  A thread that exits gives its state
+// back: stream, events, pools, pinned block and its cache of scratch blocks - unless the process itself is exiting (the HIP
+// runtime may already be going down then; the sentinel below is constructed after the runtime's own statics, so it is
+// destroyed before them).
+static bool g_process_exiting = false;
+namespace {
+struct ExitSentinel { ~ExitSentinel() { g_process_exiting = true; } };
+void ctx_release(Ctx *c) {
+    if (!c->inited) return;
+    (void)hipSetDevice(c->device);
+    if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+    if (c->d_scratch) (void)hipFree(c->d_scratch);
+    if (c->d_params) (void)hipFree(c->d_params);
+    for (int i = 0; i < Ctx::kPoolSlots; i++) if (c->pool[i]) (void)hipFree(c->pool[i]);
+    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    *c = Ctx();
+}
+struct CtxHolder {
+    Ctx c;
+    ~CtxHolder() { if (!g_process_exiting) ctx_release(&c); }
+};
+}  // namespace
+static thread_local CtxHolder g_ctx_holder;
+#define g_ctx (g_ctx_holder.c)
 
 int ctx_get(Ctx **out) {
+    static ExitSentinel sentinel;   // (constructed on the first call of any thread)
+    (void)sentinel;
     Ctx *c = &g_ctx;
     if (!c->inited) {
         int n = 0;
@@ -110,43 +139,66 @@ int ctx_pool(Ctx *c, int slot, size_t bytes, void **dptr) {
 }
 
 // ---------------------------------------------------------------- per-thread cache of device scratch blocks
+// Each thread keeps the blocks its calls freed (steady-state calls issue no hipMalloc / hipFree).  The caches are registered
+// process-wide so that memory one thread hoards does not starve another: a failed allocation trims EVERY thread's cache before
+// it gives up, bowgpu_trim() does the same on request, and a thread that exits frees its own.
 namespace {
+struct BufCache;
+std::mutex g_caches_mu;
+std::vector<BufCache *> g_caches;   // guarded by g_caches_mu
 struct BufCache {
     struct E { void *p; size_t cap; };
+    std::mutex mu;                  // the owner works under it; another thread takes it only to trim
     std::vector<E> v;
     size_t total = 0;
-    void drop_all() {
-        for (const E &e : v) (void)hipFree(e.p);
+    BufCache() { std::lock_guard<std::mutex> g(g_caches_mu); g_caches.push_back(this); }
+    size_t drop_all_locked() {
+        size_t freed = 0;
+        for (const E &e : v) { (void)hipFree(e.p); freed += e.cap; }
         v.clear();
         total = 0;
+        return freed;
     }
-    ~BufCache() { /* process exit: the runtime may already be gone; leave the blocks to it */ }
+    size_t drop_all() { std::lock_guard<std::mutex> g(mu); return drop_all_locked(); }
+    ~BufCache() {
+        { std::lock_guard<std::mutex> g(g_caches_mu); g_caches.erase(std::remove(g_caches.begin(), g_caches.end(), this), g_caches.end()); }
+        if (!g_process_exiting) drop_all();   // (process exit: the runtime may already be gone; leave the blocks to it)
+    }
 };
 thread_local BufCache g_bufs;
 constexpr size_t kCacheEntries = 24;
-constexpr size_t kCacheBytes = (size_t)48 << 30;
+constexpr size_t kCacheBytes = (size_t)24 << 30;   // per thread
+size_t trim_all_threads() {
+    std::lock_guard<std::mutex> g(g_caches_mu);
+    size_t freed = 0;
+    for (BufCache *c : g_caches) freed += c->drop_all();
+    return freed;
+}
 }  // namespace
 
 void devbuf_cache_drop() { g_bufs.drop_all(); }
 
 int devbuf_acquire(size_t n, void **p, size_t *cap) {
-    // smallest cached block that holds n without wasting more than half of itself (or 1 MiB)
-    int best = -1;
-    for (size_t i = 0; i < g_bufs.v.size(); i++) {
-        const size_t c = g_bufs.v[i].cap;
-        if (c >= n && (c <= 2 * n || c <= n + (1u << 20)) && (best < 0 || c < g_bufs.v[best].cap)) best = (int)i;
-    }
-    if (best >= 0) {
-        *p = g_bufs.v[best].p;
-        *cap = g_bufs.v[best].cap;
-        g_bufs.total -= *cap;
-        g_bufs.v.erase(g_bufs.v.begin() + best);
-        return 0;
+    {
+        std::lock_guard<std::mutex> g(g_bufs.mu);
+        // smallest cached block that holds n without wasting more than half of itself (or 1 MiB)
+        int best = -1;
+        for (size_t i = 0; i < g_bufs.v.size(); i++) {
+            const size_t c = g_bufs.v[i].cap;
+            if (c >= n && (c <= 2 * n || c <= n + (1u << 20)) && (best < 0 || c < g_bufs.v[best].cap)) best = (int)i;
+        }
+        if (best >= 0) {
+            *p = g_bufs.v[best].p;
+            *cap = g_bufs.v[best].cap;
+            g_bufs.total -= *cap;
+            g_bufs.v.erase(g_bufs.v.begin() + best);
+            return 0;
+        }
     }
     hipError_t e = hipMalloc(p, n);
-    if (e == hipErrorOutOfMemory && !g_bufs.v.empty()) {  // give the cached blocks back and try once more
-        g_bufs.drop_all();
-        e = hipMalloc(p, n);
+    if (e == hipErrorOutOfMemory) {  // give every thread's cached blocks back and try once more
+        (void)hipGetLastError();
+        if (trim_all_threads() > 0) e = hipMalloc(p, n);
     }
     if (e != hipSuccess) return hip_fail(e, "hipMalloc");
     *cap = n;
@@ -154,6 +206,7 @@ int devbuf_acquire(size_t n, void **p, size_t *cap) {
 }
 
 void devbuf_release(void *p, size_t cap) {
+    std::lock_guard<std::mutex> g(g_bufs.mu);
     g_bufs.v.push_back({p, cap});
     g_bufs.total += cap;
     while (g_bufs.v.size() > kCacheEntries || g_bufs.total > kCacheBytes) {  // evict the largest
@@ -1020,18 +1073,31 @@ int bowgpu_set_device(int device) {
         // drop per-device state of the old device
         (void)hipSetDevice(c->device);
         devbuf_cache_drop();
-        if (c->d_scratch) (void)hipFree(c->d_scratch);
-        if (c->d_params) (void)hipFree(c->d_params);
-        for (int i = 0; i < Ctx::kPoolSlots; i++) if (c->pool[i]) (void)hipFree(c->pool[i]);
-        if (c->h_pinned) (void)hipHostFree(c->h_pinned);
-        if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
-        if (c->ev0) (void)hipEventDestroy(c->ev0);
-        if (c->ev1) (void)hipEventDestroy(c->ev1);
-        *c = Ctx();
+        ctx_release(c);
     }
     c->device = device;
     Ctx *cc;
     return ctx_get(&cc);
+}
+
+int bowgpu_trim(int32_t all_threads, int64_t *bytes_freed) {
+    // cached scratch blocks back to the device: the calling thread's, or every thread's (an idle service about to hand the GPU
+    // to someone else; a host that saw BOWGPU_ERR_OOM from another library)
+    Ctx *c;
+    BG_TRY(ctx_get(&c));
+    const size_t freed = all_threads ? trim_all_threads() : g_bufs.drop_all();
+    if (bytes_freed) *bytes_freed = (int64_t)freed;
+    return 0;
+}
+
+int bowgpu_mem_info(int64_t *free_bytes, int64_t *total_bytes) {
+    Ctx *c;
+    BG_TRY(ctx_get(&c));
+    size_t f = 0, t = 0;
+    BG_HIP(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = (int64_t)f;
+    if (total_bytes) *total_bytes = (int64_t)t;
+    return 0;
 }
 
 int bowgpu_device_name(char *buf, int cap) {

@@ -17,6 +17,8 @@
 #include <string>
 #include <vector>
 
+#include <exception>
+
 #include "common.h"
 
 namespace bowgpu {
@@ -41,6 +43,7 @@ struct TReader {
     const uint8_t *b;
     size_t n, p = 0;
     bool ok = true;
+    int depth = 0;   // nesting of skip() / skip_struct(): a corrupt footer must not overflow the stack
     uint8_t byte() { if (p >= n) { ok = false; return 0; } return b[p++]; }
     uint64_t varint() {
         uint64_t r = 0;
@@ -57,12 +60,18 @@ struct TReader {
     int64_t zigzag() { const uint64_t v = varint(); return (int64_t)(v >> 1) ^ -(int64_t)(v & 1); }
     std::string binary() {
         const uint64_t len = varint();
-        if (!ok || p + len > n) { ok = false; return std::string(); }
+        if (!ok || len > n - p) { ok = false; return std::string(); }   // (p <= n always; no wrap for a 64-bit len)
         std::string s(reinterpret_cast<const char *>(b + p), (size_t)len);
         p += (size_t)len;
         return s;
     }
     void skip(int type) {
+        if (!ok) return;
+        if (++depth > 64) { ok = false; --depth; return; }
+        skip1(type);
+        --depth;
+    }
+    void skip1(int type) {
         switch (type) {
         case 1: case 2: break;                         // bool in the field header
         case 3: byte(); break;
@@ -73,10 +82,16 @@ struct TReader {
             const uint8_t h = byte();
             uint64_t cnt = h >> 4;
             if (cnt == 15) cnt = varint();
+            if (cnt > n - p) { ok = false; break; }   // every element takes at least one byte
             for (uint64_t i = 0; i < cnt && ok; i++) { if ((h & 15) <= 2) byte(); else skip(h & 15); }  // (list<bool>: one byte each)
             break;
         }
-        case 11: { const uint64_t cnt = varint(); if (cnt) { const uint8_t kv = byte(); for (uint64_t i = 0; i < cnt && ok; i++) { skip(kv >> 4); skip(kv & 15); } } break; }
+        case 11: {
+            const uint64_t cnt = varint();
+            if (cnt > n - p) { ok = false; break; }   // (bool keys / values take no bytes: the count itself is bounded by the input)
+            if (cnt) { const uint8_t kv = byte(); for (uint64_t i = 0; i < cnt && ok; i++) { skip(kv >> 4); skip(kv & 15); } }
+            break;
+        }
         case 12: skip_struct(); break;
         default: ok = false;
         }
@@ -90,7 +105,7 @@ struct TReader {
         *fid = delta ? (int16_t)(*fid + delta) : (int16_t)zigzag();
         return ok;
     }
-    void skip_struct() { int16_t fid = 0; int t; while (field(&fid, &t)) skip(t); }
+    void skip_struct() { int16_t fid = 0; int t; while (ok && field(&fid, &t)) skip(t); }
     // list header: element type and count
     uint64_t list(int *etype) { const uint8_t h = byte(); uint64_t cnt = h >> 4; if (cnt == 15) cnt = varint(); *etype = h & 15; return cnt; }
 };
@@ -256,13 +271,24 @@ using namespace bowgpu;
 
 extern "C" {
 
+// (no C++ exception may cross the C ABI: a corrupt footer can still make a container throw length_error / bad_alloc)
+static int parquet_open_impl(const char *path, bowgpu_parquet **handle);
+static int parquet_read_column_impl(bowgpu_parquet *handle, int32_t i, bowgpu_out *out);
+
 int bowgpu_parquet_open(const char *path, bowgpu_parquet **handle) {
     if (!path || !handle) return fail(BOWGPU_ERR_ARG, "null argument");
+    try { return parquet_open_impl(path, handle); }
+    catch (const std::exception &e) { *handle = nullptr; return fail(BOWGPU_ERR_ARG, "parquet: malformed file '%s' (%s)", path, e.what()); }
+    catch (...) { *handle = nullptr; return fail(BOWGPU_ERR_ARG, "parquet: malformed file '%s'", path); }
+}
+
+static int parquet_open_impl(const char *path, bowgpu_parquet **handle) {
     *handle = nullptr;
-    ParquetFile *pf = new ParquetFile();
+    struct Guard { ParquetFile *p; ~Guard() { delete p; } } guard{new ParquetFile()};
+    ParquetFile *pf = guard.p;
     pf->path = path;
     pf->fd = open(path, O_RDONLY);
-    if (pf->fd < 0) { delete pf; return fail(BOWGPU_ERR_ARG, "parquet: cannot open '%s'", path); }
+    if (pf->fd < 0) return fail(BOWGPU_ERR_ARG, "parquet: cannot open '%s'", path);
     struct stat st;
     int rc = 0;
     if (fstat(pf->fd, &st) != 0 || st.st_size < 12) rc = fail(BOWGPU_ERR_ARG, "parquet: '%s' is too short", path);
@@ -282,7 +308,8 @@ int bowgpu_parquet_open(const char *path, bowgpu_parquet **handle) {
     if (!rc)
         for (const PqRowGroup &g : pf->groups)
             if (g.cols.size() != pf->cols.size()) { rc = fail(BOWGPU_ERR_UNSUPPORTED, "parquet: nested schema in '%s' is outside the loader", path); break; }
-    if (rc) { delete pf; return rc; }
+    if (rc) return rc;
+    guard.p = nullptr;
     *handle = reinterpret_cast<bowgpu_parquet *>(pf);
     return 0;
 }
@@ -312,6 +339,12 @@ int bowgpu_parquet_column(const bowgpu_parquet *handle, int32_t i, char *name, i
 }
 
 int bowgpu_parquet_read_column(bowgpu_parquet *handle, int32_t i, bowgpu_out *out) {
+    try { return parquet_read_column_impl(handle, i, out); }
+    catch (const std::exception &e) { return fail(BOWGPU_ERR_ARG, "parquet: malformed file (%s)", e.what()); }
+    catch (...) { return fail(BOWGPU_ERR_ARG, "parquet: malformed file"); }
+}
+
+static int parquet_read_column_impl(bowgpu_parquet *handle, int32_t i, bowgpu_out *out) {
     ParquetFile *pf = reinterpret_cast<ParquetFile *>(handle);
     if (!pf || !out) return fail(BOWGPU_ERR_ARG, "null argument");
     if (i < 0 || i >= (int32_t)pf->cols.size()) return fail(BOWGPU_ERR_BAD_COL, "parquet: no column with index %d", i);
@@ -355,7 +388,13 @@ int bowgpu_parquet_read_column(bowgpu_parquet *handle, int32_t i, bowgpu_out *ou
             if (!parse_page_header(chunk + p, chunk_len - p, &h)) return fail(BOWGPU_ERR_ARG, "parquet: malformed page header in column '%s'", sc.name.c_str());
             p += h.hdr_len;
             if (h.comp_size < 0 || p + (size_t)h.comp_size > chunk_len) return fail(BOWGPU_ERR_ARG, "parquet: page of column '%s' runs past its chunk", sc.name.c_str());
-            if (h.raw_size < 0 || h.num_values < 0 || (int64_t)h.raw_size > (int64_t)16 * h.num_values + (1 << 20))
+            // plausibility of the sizes a page header claims.  A DATA page holds at most 8 value bytes + level bits per value; a
+            // DICTIONARY page carries its count in its own header field (DataPageHeader.num_values stays 0 there), is PLAIN 8-byte
+            // values, and may well exceed 1 MiB (parquet-cpp only falls back to PLAIN once the dictionary has grown past its limit)
+            const bool dict_hdr = h.type == 2;
+            if (h.raw_size < 0 || h.num_values < 0 ||
+                (!dict_hdr && (int64_t)h.raw_size > (int64_t)16 * h.num_values + (1 << 20)) ||
+                (dict_hdr && (h.dict_values < 0 || (int64_t)h.dict_values > (int64_t)1 << 27 || (int64_t)h.raw_size != (int64_t)8 * h.dict_values)))
                 return fail(BOWGPU_ERR_ARG, "parquet: implausible page header in column '%s'", sc.name.c_str());
             if (h.type == 2) {  // the chunk's dictionary: PLAIN values, decompressed like a page
                 if ((h.dict_encoding != 0 && h.dict_encoding != 2) || dict_off >= 0 || (int64_t)h.raw_size != (int64_t)h.dict_values * 8)

@@ -146,6 +146,12 @@ int bowgpu_device_name(char *buf, int cap);
  * thread; NULL restores the library's own stream. */
 int bowgpu_set_stream(void *hip_stream);
 int bowgpu_synchronize(void);
+/* Device state is per calling thread (stream, pools, a cache of freed scratch blocks: at most 24 blocks / 24 GB per thread);
+ * a thread that exits releases its own.  bowgpu_trim frees cached scratch blocks now: the calling thread's (all_threads = 0)
+ * or every thread's.  A failed allocation inside the library trims every thread's cache itself before reporting BOWGPU_ERR_OOM. */
+int bowgpu_trim(int32_t all_threads, int64_t *bytes_freed /* nullable */);
+/* free / total HBM of the calling thread's device (hipMemGetInfo): lets a host size its shards (288 GB per MI355X) */
+int bowgpu_mem_info(int64_t *free_bytes, int64_t *total_bytes);
 /* device time (HIP events on the stream) of the tile kernel of this thread's last aggregate call */
 int bowgpu_last_kernel_ms(double *ms);
 /* ... and which tile kernel that was ("rolling_simple_kernel", "rolling_wave_kernel", "rolling_agg_kernel"; "" before any call) */

@@ -75,3 +75,51 @@ def test_concurrent_calls_from_many_threads():
         th.join(timeout=500)
     assert not any(th.is_alive() for th in threads), "a worker hangs"
     assert not errors, errors[:3]
+
+
+def test_a_thread_that_exits_gives_its_device_memory_back():
+    """Per-thread state (stream, pools, pinned block, the cache of freed scratch blocks) must not outlive its thread: a cgo host
+    whose calls hop OS threads would otherwise multiply the footprint by the number of threads it ever used."""
+    n = 20_000_000
+    ts = np.arange(n, dtype=np.int64)
+    vals = np.ones(n)
+    capi.rolling_aggregate([capi.Column(ts[:1000], None, capi.INT64), capi.Column(vals[:1000], None, capi.FLOAT64)], 0, 10, AGGS[:3])
+    capi.trim(True)
+    free0, total = capi.mem_info()
+    seen = {}
+
+    def work():
+        # host-resident columns: the call stages 2 x 160 MB through this thread's scratch cache
+        capi.rolling_aggregate([capi.Column(ts, None, capi.INT64), capi.Column(vals, None, capi.FLOAT64)], 0, 10, AGGS[:3])
+        seen["during"] = capi.mem_info()[0]
+
+    th = threading.Thread(target=work)
+    th.start()
+    th.join()
+    free1, _ = capi.mem_info()
+    assert free0 - seen["during"] > 200 << 20          # the worker did cache its staging blocks while it lived ...
+    assert free0 - free1 < 64 << 20, (free0, free1)    # ... and they are gone with it
+
+
+def test_trim_frees_every_threads_cache():
+    n = 10_000_000
+    ts = np.arange(n, dtype=np.int64)
+    vals = np.ones(n)
+    capi.trim(True)
+    free0, _ = capi.mem_info()
+    hold, done = threading.Event(), threading.Event()
+
+    def work():
+        capi.rolling_aggregate([capi.Column(ts, None, capi.INT64), capi.Column(vals, None, capi.FLOAT64)], 0, 10, AGGS[:3])
+        done.set()
+        hold.wait(60)      # stay alive, cache populated
+
+    th = threading.Thread(target=work)
+    th.start()
+    assert done.wait(120)
+    assert free0 - capi.mem_info()[0] > 100 << 20
+    freed = capi.trim(True)             # from THIS thread: trims the worker's cache too
+    assert freed > 100 << 20
+    assert free0 - capi.mem_info()[0] < 64 << 20
+    hold.set()
+    th.join()

@@ -208,3 +208,58 @@ def test_config0_parquet_to_rolling_mean_without_leaving_the_device():
         want, _ = orc.aggregate(ocols, 0, interval, aggs, offset=offset)
         for (k, _), g, w in zip(aggs, got, want):
             compare("config0 %s I=%d" % (k, interval), g, w)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("compression", ["snappy", "none"])
+def test_dictionary_pages_larger_than_one_mebibyte(tmp_path, compression):
+    """High-cardinality but repeating INT64 / DOUBLE columns written with pyarrow defaults carry a dictionary page slightly over
+    1 MiB (parquet-cpp falls back to PLAIN only after a batch pushed the dictionary past that size): ~140k distinct 8-byte values."""
+    rng = np.random.default_rng(17)
+    n = 600_000
+    keys = rng.integers(0, 140_000, n)
+    pool_i = rng.integers(-1 << 62, 1 << 62, 140_000)
+    pool_f = rng.standard_normal(140_000) * 1e6
+    mask = rng.random(n) < 0.1
+    table = pa.table({"i": pa.array(pool_i[keys], mask=mask), "f": pa.array(pool_f[keys]), "k": pa.array(keys.astype(np.int64))})
+    path = str(tmp_path / "bigdict.parquet")
+    pq.write_table(table, path, compression=compression, use_dictionary=True)
+    md = pq.ParquetFile(path).metadata
+    enc = {md.row_group(0).column(j).path_in_schema: md.row_group(0).column(j) for j in range(3)}
+    assert any(c.dictionary_page_offset is not None and c.total_uncompressed_size > (1 << 20) for c in enc.values())
+    assert check_file(path, table) == 3
+
+
+def _footer_file(tmp_path, name, footer):
+    """PAR1 | footer | len | PAR1 : enough of a file for bowgpu_parquet_open to reach the Thrift parser"""
+    p = tmp_path / name
+    p.write_bytes(b"PAR1" + footer + len(footer).to_bytes(4, "little") + b"PAR1")
+    return str(p)
+
+
+def test_hostile_thrift_footers_fail_cleanly(tmp_path):
+    """bowgpu_parquet_open is host-only: footers built to wrap a length, blow the stack or spin must come back as an error
+    code - no exception across the C ABI, no crash, no seconds-long loop."""
+    import time
+    hostile = {
+        # field 1 (i32 version) then field 2..: a binary (type 8) whose varint length is 2^64 - 1
+        "huge_binary": bytes([0x15, 0x02, 0x18]) + b"\xff" * 9 + b"\x01",
+        # a list (type 9) of lists of lists ... 200 deep, each with one element
+        "deep_lists": bytes([0x19]) + bytes([0x19]) * 200 + b"\x00",
+        # nested structs 100 000 deep: field id delta 1, type 12
+        "deep_structs": bytes([0x1c]) * 100_000,
+        # a map (type 11) with 2^62 bool -> bool entries (no bytes per entry)
+        "huge_map": bytes([0x1b]) + b"\xff" * 8 + b"\x3f" + bytes([0x11]),
+        # a list with a 2^60 element count of i32
+        "huge_list": bytes([0x19, 0xf5]) + b"\xff" * 8 + b"\x0f",
+    }
+    for name, footer in hostile.items():
+        path = _footer_file(tmp_path, name + ".parquet", footer)
+        t0 = time.perf_counter()
+        with pytest.raises(capi.BowGpuError):
+            capi.ParquetFile(path)
+        assert time.perf_counter() - t0 < 2.0, name
+    # and the real files still open
+    f = capi.ParquetFile(REF_FILES[0])
+    assert f.num_rows == 100
+    f.close()
