@@ -193,6 +193,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # the ONE JSON line is the only thing this process may write to stdout: native libraries (gloo's "[Gloo] Rank 0 is connected
+    # ..." goes to fd 1) write into stderr from here on, the line itself goes to the saved descriptor
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     import torch
     from bow_amd import capi
@@ -299,6 +304,14 @@ def main():
                 line["roofline"]["stream_read_ceiling"] = {"value": ceil, "unit": "GB/s", "frac_of_ceiling": achieved / ceil}
             except Exception as e:
                 line["roofline"]["stream_read_ceiling"] = {"error": repr(e)}
+            # ... and for this TRAFFIC MIX: the same reads plus the same output bytes (two 8-byte slots per window) written in the
+            # same pattern by a kernel that does no work (HBM writes are not free next to the reads: bus turnarounds)
+            try:
+                rw, rw_ms = capi.stream_rw_ceiling(cols[0].values, cols[1].values, rows * 8, outs[0].values, outs[1].values, interval)
+                line["roofline"]["stream_rw_ceiling"] = {"value": rw, "unit": "GB/s", "ms": rw_ms, "frac_of_ceiling": achieved / rw,
+                                                         "what": "trivial kernel, same bytes read (16 B/row) and written (2 x 8 B/window), same store pattern"}
+            except Exception as e:
+                line["roofline"]["stream_rw_ceiling"] = {"error": repr(e)}
         if not args.no_cpu and world == 1:
             try:
                 line["cpu_baseline"] = cpu_baseline(capi, min(args.cpu_sample, rows))
@@ -314,7 +327,8 @@ def main():
                 line["cpu_baseline_all_cores"] = cpu_baseline_parallel(capi, min(args.cpu_sample, rows))
             except Exception as e:
                 line["cpu_baseline_all_cores"] = {"error": repr(e)}
-        print(json.dumps(line))
+        json_out.write(json.dumps(line) + "\n")
+        json_out.flush()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -101,6 +101,12 @@ class ShardCarry(C.Structure):
                 ("last", CarryState * CARRY_MAX_AGGS)]
 
 
+class Plan(C.Structure):
+    """bowgpu_plan: what newIntervalRolling computes once per Rolling"""
+    _fields_ = [("s0", C.c_int64), ("num_windows", C.c_int64), ("first_ts", C.c_int64), ("last_ts", C.c_int64),
+                ("interval", C.c_int64), ("offset", C.c_int64), ("nrows", C.c_int64)]
+
+
 class ShardRecord(C.Structure):
     """bowgpu_shard_record: what one rank contributes to the exchange of a sharded Aggregate"""
     _fields_ = [("nrows", C.c_int64), ("first_ts", C.c_int64), ("last_ts", C.c_int64), ("carry_from_ts", C.c_int64),
@@ -121,12 +127,12 @@ SYMBOLS = [
     "bowgpu_set_stream", "bowgpu_synchronize", "bowgpu_trim", "bowgpu_mem_info", "bowgpu_last_kernel_ms", "bowgpu_last_kernel_name", "bowgpu_malloc", "bowgpu_free", "bowgpu_memcpy_h2d",
     "bowgpu_memcpy_d2h", "bowgpu_memset", "bowgpu_timer_create", "bowgpu_timer_start", "bowgpu_timer_stop",
     "bowgpu_timer_elapsed_ms", "bowgpu_timer_destroy", "bowgpu_enforce_interval_and_offset", "bowgpu_plan_windows",
-    "bowgpu_rolling_aggregate", "bowgpu_window_bounds", "bowgpu_aggregate_whole",
+    "bowgpu_rolling_aggregate", "bowgpu_plan_windows_ex", "bowgpu_rolling_aggregate_planned", "bowgpu_window_bounds", "bowgpu_aggregate_whole",
     "bowgpu_rolling_interpolate_count", "bowgpu_rolling_interpolate_fill", "bowgpu_shard_interp_points",
     "bowgpu_shard_interpolate_count", "bowgpu_shard_interpolate_fill", "bowgpu_fill_linear", "bowgpu_fill",
     "bowgpu_is_col_sorted", "bowgpu_shard_span", "bowgpu_shard_aggregate", "bowgpu_shard_carry_only", "bowgpu_shard_first_row", "bowgpu_shard_fix_first", "bowgpu_carry_merge",
     "bowgpu_shard_begin", "bowgpu_shard_plan", "bowgpu_shard_finish", "bowgpu_gen_dense",
-    "bowgpu_gen_sparse", "bowgpu_stream_read_ceiling", "bowgpu_checksum64", "bowgpu_parquet_open", "bowgpu_parquet_close",
+    "bowgpu_gen_sparse", "bowgpu_stream_read_ceiling", "bowgpu_stream_rw_ceiling", "bowgpu_checksum64", "bowgpu_parquet_open", "bowgpu_parquet_close",
     "bowgpu_parquet_info", "bowgpu_parquet_column", "bowgpu_parquet_read_column",
 ]
 
@@ -376,18 +382,31 @@ def plan_windows(ts, interval, offset=0):
     return s0.value, W.value
 
 
-def rolling_aggregate(cols, ts_col, interval, aggs, offset=0, inclusive=False, out_residency=HOST, outs=None):
-    """Returns (list[OutColumn], AggInfo).  aggs: [(kind, col[, factors])]."""
+def plan_windows_ex(ts, interval, offset=0):
+    """bowgpu_plan_windows_ex -> Plan (what newIntervalRolling keeps in the Rolling: one round trip to the device, once)"""
+    p = Plan()
+    c = ts.c()
+    check(lib().bowgpu_plan_windows_ex(C.byref(c), C.c_int64(interval), C.c_int64(offset), C.byref(p)))
+    return p
+
+
+def rolling_aggregate(cols, ts_col, interval, aggs, offset=0, inclusive=False, out_residency=HOST, outs=None, plan=None):
+    """Returns (list[OutColumn], AggInfo).  aggs: [(kind, col[, factors])].  plan: a Plan from plan_windows_ex on this
+    interval column (the call then skips its own round trip for the first / last timestamp)."""
     if outs is None:
-        s0, W = plan_windows(cols[ts_col], interval, offset)
+        W = plan.num_windows if plan is not None else plan_windows(cols[ts_col], interval, offset)[1]
         outs = [OutColumn(W, out_residency) for _ in aggs]
     oarr = (Out * max(len(aggs), 1))()
     for i, o in enumerate(outs):
         oarr[i] = o.c()
     opts = Options(offset, int(bool(inclusive)), 0)
     info = AggInfo()
-    check(lib().bowgpu_rolling_aggregate(_cols(cols), len(cols), ts_col, C.c_int64(interval), C.byref(opts),
-                                         _aggs(aggs), len(aggs), oarr, C.byref(info)))
+    if plan is not None:
+        check(lib().bowgpu_rolling_aggregate_planned(_cols(cols), len(cols), ts_col, C.byref(plan), C.byref(opts),
+                                                     _aggs(aggs), len(aggs), oarr, C.byref(info)))
+    else:
+        check(lib().bowgpu_rolling_aggregate(_cols(cols), len(cols), ts_col, C.c_int64(interval), C.byref(opts),
+                                             _aggs(aggs), len(aggs), oarr, C.byref(info)))
     for i, o in enumerate(outs):
         o.absorb(oarr[i])
     return outs, info
@@ -537,6 +556,15 @@ def stream_read_ceiling(buf_a, buf_b, bytes_each):
     g = C.c_double(0)
     check(lib().bowgpu_stream_read_ceiling(C.c_void_p(buf_a.ptr), C.c_void_p(buf_b.ptr), C.c_int64(bytes_each), C.byref(g)))
     return g.value
+
+
+def stream_rw_ceiling(buf_a, buf_b, bytes_each, out_a, out_b, rows_per_slot):
+    """(read GB/s, ms) of a trivial kernel with the benched kernel's traffic mix: two input streams read, two output streams of
+    one 8-byte slot per rows_per_slot rows written (the achievable line for reads AND writes together)"""
+    g, ms = C.c_double(0), C.c_double(0)
+    check(lib().bowgpu_stream_rw_ceiling(C.c_void_p(buf_a.ptr), C.c_void_p(buf_b.ptr), C.c_int64(bytes_each), C.c_void_p(out_a.ptr),
+                                         C.c_void_p(out_b.ptr), C.c_int64(rows_per_slot), C.byref(g), C.byref(ms)))
+    return g.value, ms.value
 
 
 class ParquetFile:

@@ -127,6 +127,7 @@ int ctx_params(Ctx *c, void **dptr) {
 
 int ctx_pool(Ctx *c, int slot, size_t bytes, void **dptr) {
     if (slot < 0 || slot >= Ctx::kPoolSlots) return fail(BOWGPU_ERR_ARG, "bad pool slot");
+    c->pool_gen[slot]++;
     if (c->pool_bytes[slot] < bytes) {
         if (c->pool[slot]) (void)hipFree(c->pool[slot]);
         c->pool[slot] = nullptr;
@@ -354,7 +355,7 @@ int devout_prepare(Ctx *c, bowgpu_out *out, int64_t slots, DevOut *d, int pool_s
     return 0;
 }
 
-int devout_finish(Ctx *c, DevOut *d, int64_t slots, int32_t type, int64_t null_count) {
+int devout_finish(Ctx *c, DevOut *d, int64_t slots, int32_t type, int64_t null_count, bool copy_bitmap) {
     bowgpu_out *out = d->user;
     out->length = slots;
     out->type = type;
@@ -362,7 +363,7 @@ int devout_finish(Ctx *c, DevOut *d, int64_t slots, int32_t type, int64_t null_c
     if (slots == 0) return 0;
     const size_t vb = (size_t)((slots + 7) >> 3);
     if (out->residency == BOWGPU_DEVICE) {
-        BG_HIP(hipMemcpyAsync(out->validity, d->validity, vb, hipMemcpyDeviceToDevice, c->stream));
+        if (copy_bitmap) BG_HIP(hipMemcpyAsync(out->validity, d->validity, vb, hipMemcpyDeviceToDevice, c->stream));
     } else {
         BG_HIP(hipMemcpyAsync(out->values, d->values, (size_t)slots * 8, hipMemcpyDeviceToHost, c->stream));
         BG_HIP(hipMemcpyAsync(out->validity, d->validity, vb, hipMemcpyDeviceToHost, c->stream));
@@ -511,6 +512,7 @@ struct AggJob {
     int64_t W = 0;
     size_t scratch_bytes = 0;
     int inclusive = 0;
+    bool counts_used = false;   // the valid counters hold a previous count (they accumulate): zero them before counting again
 };
 
 static int job_build(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t ts_col, const Plan &plan, int inclusive,
@@ -650,23 +652,50 @@ static int job_build(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t ts_c
     return 0;
 }
 
-// null counts of the nullable outputs + copy-back, enqueued only (no sync)
-static int job_enqueue_tail(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, uint64_t **hcnt_out) {
+// status words and valid counts live side by side in the device scratch block and come back in ONE copy
+constexpr size_t kCountsOffset = 1024;                       // bytes: counts[kMaxAggs] behind the status words
+constexpr size_t kReadbackBytes = kCountsOffset + 8 * kMaxAggs;
+static_assert(kStatusWords * 4 <= kCountsOffset, "status words overlap the counters");
+
+static void job_bitmaps(AggJob *job, const bowgpu_agg *aggs, int32_t naggs, bool all_ones, BitmapBatch *b) {
+    memset(b, 0, sizeof *b);
+    b->n = naggs;
+    b->status_words = kStatusWords;
+    b->nbits = job->W > 0 ? job->W : 0;
+    b->status = job->P.status;
+    b->counts = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(job->P.status) + kCountsOffset);
+    for (int i = 0; i < naggs; i++) {
+        b->work[i] = reinterpret_cast<uint32_t *>(job->douts[i].validity);
+        const bowgpu_out *u = job->douts[i].user;
+        b->user[i] = (u && u->residency == BOWGPU_DEVICE) ? u->validity : nullptr;
+        // never-nil reducers: all-ones bitmap; nullable ones start all-null (bowbuffer.go:25) - except under the simple kernels,
+        // where every bitmap starts as ones and only the bits of nil results are cleared
+        b->ones[i] = all_ones || kind_never_nil(aggs[i].kind);
+        b->count[i] = !kind_never_nil(aggs[i].kind);
+    }
+}
+
+// valid counts of the nullable outputs + bitmaps into the caller's buffers (one launch) + copy-back of host-resident outputs,
+// enqueued only (no sync); the counts come back with the status words (job_readback)
+static int job_enqueue_tail(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs) {
     const int64_t W = job->W;
-    void *d;
-    BG_TRY(ctx_scratch(c, job->scratch_bytes, &d));
-    uint64_t *dcnt = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(d) + 1024);
-    uint64_t *hcnt;
-    BG_TRY(ctx_pinned(c, 4096, reinterpret_cast<void **>(&hcnt)));
-    hcnt += 64;  // behind the status words, which share the pinned block
-    *hcnt_out = hcnt;
-    if (W > 0)
-        for (int i = 0; i < naggs; i++) {
-            if (kind_never_nil(aggs[i].kind)) continue;
-            BG_TRY(launch_popcount(c, reinterpret_cast<const uint32_t *>(job->douts[i].validity), 0, W, dcnt + i));
-            BG_HIP(hipMemcpyAsync(hcnt + i, dcnt + i, 8, hipMemcpyDeviceToHost, c->stream));
-        }
-    for (int i = 0; i < naggs; i++) BG_TRY(devout_finish(c, &job->douts[i], W, job->P.aggs[i].out_type, 0));
+    if (W > 0) {
+        BitmapBatch b;
+        job_bitmaps(job, aggs, naggs, false, &b);
+        if (job->counts_used) BG_HIP(hipMemsetAsync(b.counts, 0, 8 * kMaxAggs, c->stream));
+        BG_TRY(launch_finish_bitmaps(c, b));
+        job->counts_used = true;
+    }
+    for (int i = 0; i < naggs; i++) BG_TRY(devout_finish(c, &job->douts[i], W, job->P.aggs[i].out_type, 0, false));
+    return 0;
+}
+
+static int job_readback(Ctx *c, AggJob *job, uint32_t **hstat, uint64_t **hcnt) {
+    char *hp;
+    BG_TRY(ctx_pinned(c, 16384, reinterpret_cast<void **>(&hp)));
+    BG_HIP(hipMemcpyAsync(hp, job->P.status, kReadbackBytes, hipMemcpyDeviceToHost, c->stream));
+    *hstat = reinterpret_cast<uint32_t *>(hp);
+    *hcnt = reinterpret_cast<uint64_t *>(hp + kCountsOffset);
     return 0;
 }
 
@@ -708,8 +737,7 @@ static int job_launch_tiles(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t
     AggParams &P = job->P;
     const int64_t W = job->W;
     *used_simple = false;
-    BG_HIP(hipMemsetAsync(P.status, 0, kStatusWords * 4, c->stream));
-    if (W <= 0) return 0;
+    if (W <= 0) { BG_HIP(hipMemsetAsync(P.status, 0, kReadbackBytes, c->stream)); return 0; }
     // The lean kernels cover exclusive windows without time-weighted reducers and without rows below s0; everything
     // else (and BOWGPU_FORCE_GENERAL=1, used by the tests to cover all of them) takes the general kernel.
     bool lean = !job->inclusive && !P.pre_rows;
@@ -725,13 +753,11 @@ static int job_launch_tiles(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t
                     simple_applies(job, aggs, naggs, *plan, true, &need, &is_int, &has_nulls, &wide);
     simple = simple || tw;
     P.bits_preset = simple ? 1 : 0;
-    for (int i = 0; i < naggs; i++) {
-        const size_t vb = (size_t)((W + 7) >> 3);
-        // never-nil reducers: all-ones bitmap (tail bits cleared); nullable ones start all-null (bowbuffer.go:25) - except
-        // under the simple kernel, where every bitmap starts as ones and only empty windows are cleared
-        const bool ones = simple || kind_never_nil(aggs[i].kind);
-        BG_HIP(hipMemsetAsync(job->douts[i].validity, ones ? 0xFF : 0x00, ((vb + 3) & ~(size_t)3), c->stream));
-        if (ones) BG_TRY(launch_fix_tail_bits(c, job->douts[i].validity, W));
+    {
+        BitmapBatch b;
+        job_bitmaps(job, aggs, naggs, simple, &b);
+        BG_TRY(launch_preset_bitmaps(c, b));   // + status words and counters to zero
+        job->counts_used = false;
     }
     // kernel_ms brackets the dominant kernel only, on the stream it runs on
     BG_HIP(hipEventRecord(c->ev0, c->stream));
@@ -834,13 +860,11 @@ static int job_run(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, i
     // column + every window as an entry of the multi-workgroup reduction.  (BOWGPU_NO_LONG_ONLY=1: test switch.)
     const char *nlo = getenv("BOWGPU_NO_LONG_ONLY");
     if (allow_long_only && plan && W > 0 && P.wid_base == 0 && P.n / W >= kLongOnlyAvgRows && !(nlo && nlo[0] == '1')) {
-        BG_HIP(hipMemsetAsync(P.status, 0, kStatusWords * 4, c->stream));
         P.bits_preset = 0;
-        for (int i = 0; i < naggs; i++) {
-            const size_t vb = (size_t)((W + 7) >> 3);
-            const bool ones = kind_never_nil(aggs[i].kind);
-            BG_HIP(hipMemsetAsync(job->douts[i].validity, ones ? 0xFF : 0x00, ((vb + 3) & ~(size_t)3), c->stream));
-            if (ones) BG_TRY(launch_fix_tail_bits(c, job->douts[i].validity, W));
+        {
+            BitmapBatch b;
+            job_bitmaps(job, aggs, naggs, false, &b);
+            BG_TRY(launch_preset_bitmaps(c, b));
         }
         BG_HIP(hipEventRecord(c->ev0, c->stream));
         int64_t n_all = 0;
@@ -848,10 +872,9 @@ static int job_run(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, i
         BG_HIP(hipEventRecord(c->ev1, c->stream));
         c->last_kernel_name = "long_partial_kernel";
         uint32_t *hs;
-        BG_TRY(ctx_pinned(c, 4096, reinterpret_cast<void **>(&hs)));
-        BG_HIP(hipMemcpyAsync(hs, P.status, kStatusWords * 4, hipMemcpyDeviceToHost, c->stream));
         uint64_t *hc = nullptr;
-        if (finish) BG_TRY(job_enqueue_tail(c, job, aggs, naggs, &hc));
+        if (finish) BG_TRY(job_enqueue_tail(c, job, aggs, naggs));
+        BG_TRY(job_readback(c, job, &hs, &hc));
         BG_HIP(hipStreamSynchronize(c->stream));
         if (hs[0]) return fail(BOWGPU_ERR_TS_UNSORTED, "interval column is not ascending: outside the device path");
         if (finish)
@@ -868,26 +891,26 @@ static int job_run(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, i
     // status -> host (pinned).  Optimistically enqueue the tail (null counts, copy-back) behind the tile kernel so
     // the common case needs ONE synchronisation; if windows were queued for the cooperative path, run it and redo the tail.
     uint32_t *hstat;
-    BG_TRY(ctx_pinned(c, 4096, reinterpret_cast<void **>(&hstat)));
-    BG_HIP(hipMemcpyAsync(hstat, P.status, kStatusWords * 4, hipMemcpyDeviceToHost, c->stream));
     uint64_t *hcnt = nullptr;
-    if (finish) BG_TRY(job_enqueue_tail(c, job, aggs, naggs, &hcnt));
+    if (finish) BG_TRY(job_enqueue_tail(c, job, aggs, naggs));
+    BG_TRY(job_readback(c, job, &hstat, &hcnt));
     BG_HIP(hipStreamSynchronize(c->stream));
     if (hstat[0]) return fail(BOWGPU_ERR_TS_UNSORTED, "interval column is not ascending: outside the device path");
     if (used_simple && hstat[4]) {
         // some tile needs window ids the simple kernel cannot encode: redo the call with the general lean kernel
         BG_TRY(job_launch_tiles(c, job, aggs, naggs, plan, false, &used_simple));
-        BG_HIP(hipMemcpyAsync(hstat, P.status, kStatusWords * 4, hipMemcpyDeviceToHost, c->stream));
-        if (finish) BG_TRY(job_enqueue_tail(c, job, aggs, naggs, &hcnt));
+        if (finish) BG_TRY(job_enqueue_tail(c, job, aggs, naggs));
+        BG_TRY(job_readback(c, job, &hstat, &hcnt));
         BG_HIP(hipStreamSynchronize(c->stream));
         if (hstat[0]) return fail(BOWGPU_ERR_TS_UNSORTED, "interval column is not ascending: outside the device path");
     }
     if (hstat[2]) return fail(BOWGPU_ERR_HIP, "internal: long-window list overflow");
     int64_t n_long = 0;
-    BG_TRY(run_long_windows(c, P, hstat, &n_long));
-    if (n_long > 0) {
-        if (finish) {
-            BG_TRY(job_enqueue_tail(c, job, aggs, naggs, &hcnt));
+    {
+        BG_TRY(run_long_windows(c, P, hstat, &n_long));
+        if (n_long > 0 && finish) {
+            BG_TRY(job_enqueue_tail(c, job, aggs, naggs));
+            BG_TRY(job_readback(c, job, &hstat, &hcnt));
             BG_HIP(hipStreamSynchronize(c->stream));
         }
     }
@@ -905,8 +928,10 @@ static int job_run(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, i
 }
 
 static int job_finish(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs) {
+    uint32_t *hstat;
     uint64_t *hcnt = nullptr;
-    BG_TRY(job_enqueue_tail(c, job, aggs, naggs, &hcnt));
+    BG_TRY(job_enqueue_tail(c, job, aggs, naggs));
+    BG_TRY(job_readback(c, job, &hstat, &hcnt));
     BG_HIP(hipStreamSynchronize(c->stream));
     for (int i = 0; i < naggs; i++)
         job->douts[i].user->null_count = (job->W > 0 && !kind_never_nil(aggs[i].kind)) ? job->W - (int64_t)hcnt[i] : 0;
@@ -1236,17 +1261,9 @@ int bowgpu_plan_windows(const bowgpu_col *ts, int64_t interval, int64_t offset, 
     return 0;
 }
 
-int bowgpu_rolling_aggregate(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval,
-                             const bowgpu_options *opts, const bowgpu_agg *aggs, int32_t naggs,
-                             bowgpu_out *outs, bowgpu_agg_info *info) {
-    if (!cols || ncols <= 0) return fail(BOWGPU_ERR_ARG, "no columns");
-    if (ts_col < 0 || ts_col >= ncols) return fail(BOWGPU_ERR_BAD_COL, "no interval column with index %d", ts_col);
-    bowgpu_options o = {0, 0, 0};
-    if (opts) o = *opts;
-    // reference order: the Rolling exists first (newIntervalRolling errors), then Aggregate validates
-    Plan plan;
-    BG_TRY(plan_make(nullptr, &cols[ts_col], interval, o.offset, &plan));
-    int inclusive = o.inclusive ? 1 : 0, nic = -1;
+static int aggregate_with_plan(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, const Plan &plan, int opt_inclusive,
+                               const bowgpu_agg *aggs, int32_t naggs, bowgpu_out *outs, bowgpu_agg_info *info) {
+    int inclusive = opt_inclusive ? 1 : 0, nic = -1;
     BG_TRY(validate_aggs(cols, ncols, ts_col, aggs, naggs, &inclusive, &nic));
     if (!outs) return fail(BOWGPU_ERR_ARG, "no output columns");
     Ctx *c;
@@ -1263,6 +1280,45 @@ int bowgpu_rolling_aggregate(const bowgpu_col *cols, int32_t ncols, int32_t ts_c
         info->kernel_ms = ms;
     }
     return 0;
+}
+
+int bowgpu_rolling_aggregate(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval,
+                             const bowgpu_options *opts, const bowgpu_agg *aggs, int32_t naggs,
+                             bowgpu_out *outs, bowgpu_agg_info *info) {
+    if (!cols || ncols <= 0) return fail(BOWGPU_ERR_ARG, "no columns");
+    if (ts_col < 0 || ts_col >= ncols) return fail(BOWGPU_ERR_BAD_COL, "no interval column with index %d", ts_col);
+    bowgpu_options o = {0, 0, 0};
+    if (opts) o = *opts;
+    // reference order: the Rolling exists first (newIntervalRolling errors), then Aggregate validates
+    Plan plan;
+    BG_TRY(plan_make(nullptr, &cols[ts_col], interval, o.offset, &plan));
+    return aggregate_with_plan(cols, ncols, ts_col, plan, o.inclusive, aggs, naggs, outs, info);
+}
+
+int bowgpu_plan_windows_ex(const bowgpu_col *ts, int64_t interval, int64_t offset, bowgpu_plan *out) {
+    if (!ts || !out) return fail(BOWGPU_ERR_ARG, "null argument");
+    Plan p;
+    BG_TRY(plan_make(nullptr, ts, interval, offset, &p));
+    out->s0 = p.s0; out->num_windows = p.W; out->first_ts = p.first_ts; out->last_ts = p.last_ts;
+    out->interval = p.interval; out->offset = p.offset; out->nrows = ts->length;
+    return 0;
+}
+
+int bowgpu_rolling_aggregate_planned(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, const bowgpu_plan *pl,
+                                     const bowgpu_options *opts, const bowgpu_agg *aggs, int32_t naggs,
+                                     bowgpu_out *outs, bowgpu_agg_info *info) {
+    if (!cols || ncols <= 0 || !pl) return fail(BOWGPU_ERR_ARG, "null argument");
+    if (ts_col < 0 || ts_col >= ncols) return fail(BOWGPU_ERR_BAD_COL, "no interval column with index %d", ts_col);
+    const bowgpu_col *ts = &cols[ts_col];
+    if (ts->type != BOWGPU_INT64) return fail(BOWGPU_ERR_TS_TYPE, "impossible to create a new intervalRolling on column of type float64");
+    if (pl->interval <= 0) return fail(BOWGPU_ERR_INTERVAL, "strictly positive interval required");
+    if (pl->nrows != ts->length || pl->offset < 0 || pl->offset >= pl->interval || pl->num_windows < 0)
+        return fail(BOWGPU_ERR_ARG, "the plan was not made for this interval column");
+    Plan plan;
+    plan.interval = pl->interval; plan.offset = pl->offset; plan.s0 = pl->s0; plan.W = pl->num_windows;
+    plan.first_ts = pl->first_ts; plan.last_ts = pl->last_ts;
+    plan.magic = magic_make((uint64_t)pl->interval);
+    return aggregate_with_plan(cols, ncols, ts_col, plan, opts ? opts->inclusive : 0, aggs, naggs, outs, info);
 }
 
 // ---- entry points implemented in extras.cpp: window_bounds, aggregate_whole, interpolate,
@@ -1772,6 +1828,27 @@ int bowgpu_stream_read_ceiling(const void *dev_a, const void *dev_b, int64_t byt
         if (gbs > best) best = gbs;
     }
     *gb_per_s = best;
+    return 0;
+}
+
+int bowgpu_stream_rw_ceiling(const void *dev_a, const void *dev_b, int64_t bytes_each, void *out_a, void *out_b, int64_t rows_per_slot,
+                             double *read_gb_per_s, double *ms_out) {
+    if (!dev_a || !dev_b || !out_a || !out_b || !read_gb_per_s || bytes_each < (1 << 20) || rows_per_slot <= 0)
+        return fail(BOWGPU_ERR_ARG, "two device input buffers of at least 1 MiB each and two output buffers are needed");
+    if ((reinterpret_cast<uintptr_t>(dev_a) | reinterpret_cast<uintptr_t>(dev_b)) & 15) return fail(BOWGPU_ERR_ARG, "buffers must be 16-byte aligned");
+    Ctx *c;
+    BG_TRY(ctx_get(&c));
+    const int64_t rows = bytes_each / 4096 * 512;
+    const int64_t nslots = (rows + rows_per_slot - 1) / rows_per_slot;
+    double best = 0.0, best_ms = 0.0;
+    for (int nt = 0; nt < 2; nt++) {
+        float ms = 0;
+        BG_TRY(stream_rw_run(c, dev_a, dev_b, bytes_each, out_a, out_b, rows_per_slot, nslots, nt != 0, 5, &ms));
+        const double gbs = 2.0 * (double)rows * 8.0 / (ms * 1e-3) / 1e9;
+        if (gbs > best) { best = gbs; best_ms = ms; }
+    }
+    *read_gb_per_s = best;
+    if (ms_out) *ms_out = best_ms;
     return 0;
 }
 

@@ -47,6 +47,20 @@ struct Ctx {
     static constexpr int kPoolSlots = 40;   // 0..15 output validity working copies, kPoolInterp.. Interpolate / fill scratch, last: long windows
     void *pool[kPoolSlots] = {};
     size_t pool_bytes[kPoolSlots] = {};
+    uint64_t pool_gen[kPoolSlots] = {};     // bumped on every ctx_pool() of the slot: lets a cached result notice that its block was handed out again
+    // what bowgpu_rolling_interpolate_count leaves for the _fill call that follows it on the same (unchanged) columns: the
+    // per-trip prefix of exact window heads, so that the interval column is not scanned a second time (extras.cpp)
+    struct InterpCache {
+        bool valid = false;
+        const void *ts_values = nullptr;
+        int64_t ts_offset = 0, n = 0, interval = 0, raw_offset = 0;
+        bool sharded = false;
+        int64_t global_s0 = 0, left_ts = 0;
+        int has_left = 0;
+        uint64_t gen = 0;                   // pool_gen of the prefix block when it was written
+        int64_t s0 = 0, W = 0, first_ts = 0, last_ts = 0, offset_norm = 0, kq = -1, drop = 0, M = 0, wbase = 0;
+        int kq_empty = 0;
+    } interp_cache;
     void *d_params = nullptr;      // 4 KB device block holding the kernels' descriptor struct
 };
 int ctx_get(Ctx **out);                       // initialises HIP on first use; fails loudly without a GPU
@@ -106,7 +120,7 @@ struct DevOut {
     bowgpu_out *user = nullptr;
 };
 int devout_prepare(Ctx *c, bowgpu_out *out, int64_t slots, DevOut *d, int pool_slot = -1);
-int devout_finish(Ctx *c, DevOut *d, int64_t slots, int32_t type, int64_t null_count);
+int devout_finish(Ctx *c, DevOut *d, int64_t slots, int32_t type, int64_t null_count, bool copy_bitmap = true);
 
 // ---------------------------------------------------------------- division by the interval
 // Granlund–Montgomery round-up method (N = 64): exact floor(n / d) for every 0 <= n < 2^64.
@@ -225,10 +239,25 @@ constexpr int kStatusWords = kLongCountWord + kLongLists;
 struct LongListStarts { int64_t start[kLongLists + 1]; };  // prefix sums of the sub-list counts (host side)
 size_t long_entry_size();
 size_t long_part_size();
+int stream_rw_run(Ctx *c, const void *a, const void *b, int64_t bytes_each, void *o0, void *o1, int64_t rows_per_slot, int64_t nslots, bool nt,
+                  int reps, float *ms);
 int stream_sum_run(Ctx *c, const void *a, const void *b, int64_t bytes_each, int mode, int blocks_per_cu, int reps, uint64_t *d_out, float *ms);
 int launch_long_windows_v2(Ctx *c, const AggParams &p, const LongListStarts *starts, void *entries, int32_t *nchunks, int64_t *offsets,
                            int64_t *block_sums, int64_t *d_total, int32_t *work_entry, void *partials, int64_t max_work);
 int launch_fix_tail_bits(Ctx *c, uint8_t *bitmap, int64_t nbits);
+// every output bitmap of one call in one launch (rolling_agg.hip)
+struct BitmapBatch {
+    int32_t n, status_words;
+    int64_t nbits;                 // W
+    uint32_t *work[kMaxAggs];      // word-aligned working copies the kernels update
+    uint8_t *user[kMaxAggs];       // finish: the caller's device buffer of ceil(W/8) bytes (nullptr: host-resident output, copied separately)
+    int32_t ones[kMaxAggs];        // preset: start all-valid (else all-null)
+    int32_t count[kMaxAggs];       // finish: count the valid bits into counts[a]
+    uint32_t *status;              // preset zeroes status[0 .. status_words) and counts[0 .. kMaxAggs)
+    unsigned long long *counts;
+};
+int launch_preset_bitmaps(Ctx *c, const BitmapBatch &b);
+int launch_finish_bitmaps(Ctx *c, const BitmapBatch &b);
 int launch_popcount(Ctx *c, const uint32_t *words, int64_t bit0, int64_t nbits, uint64_t *d_count);
 
 // mode.hip: one aggregation.Mode output over the windows whose first rows are first_idx[0 .. W]
@@ -261,6 +290,7 @@ constexpr int kNbrBlockBits = 4096;
 constexpr int kPoolMode = 17;    // aggregation.Mode: its output's validity working copy
 constexpr int kPoolColOrder = 18; // IsColSorted: one (first valid, last valid) record per 512-row trip
 constexpr int kPoolShard = 19;   // shard stitch: seed / merged states and the next shard's first row
+constexpr int kPoolGaps = 32;    // window_first_rows: queued runs of empty windows
 constexpr int kPoolInterp = 20;  // context pool slots 20..30: tile counts, their scan, scan sums, one neighbour index per column
 struct NbrIndex {
     const int64_t *prev_before;  // [nblocks] last valid row in any earlier block, -1 if none
@@ -297,6 +327,8 @@ struct InterpParams {
     int32_t has_left, _pad3;           // sharded Interpolate: rows exist on shards to the left, the last of them at left_ts;
     int64_t left_ts, wbase;            // the windows up to theirs (wbase = its id + 1) are not this shard's to account for
     int32_t ncols, ts_col;
+    int32_t allow_wave2;               // the whole-trip wave kernel may take the call (0: the call is being redone after its run list overflowed)
+    int32_t kq_empty;                  // window kq has no row of its own (pass 1's finding)
     InterpCol cols[kMaxCols];
 };
 int64_t interp_tiles(int64_t n);

@@ -143,14 +143,42 @@ struct InterpJob {
     int64_t kq = -1;  // window whose start is -1 (InterpParams::kq)
     int64_t drop = 0; // leading rows that belong to no window (InterpParams::drop)
     int64_t M = 0;    // output rows - input rows
+    int kq_empty = 0; // window kq has no row of its own
     int has_left = 0; // sharded Interpolate: rows exist to the left, the last of them at left_ts, in window wbase - 1
     int64_t left_ts = 0, wbase = 0;
 };
 
 // pass 1 of interpolate.hip: exact heads per tile, their exclusive scan, M = synthetic rows
 // shard: global_s0 + edge of a row-range shard (nullptr: the whole frame)
+static bool interp_cache_hit(Ctx *c, const bowgpu_col *ts, int64_t interval, int64_t raw_offset, const int64_t *global_s0,
+                             const bowgpu_interp_edge *edge) {
+    const Ctx::InterpCache &k = c->interp_cache;
+    if (!k.valid || ts->residency != BOWGPU_DEVICE) return false;   // (a host column is staged into a fresh device copy per call)
+    if (k.ts_values != ts->values || k.ts_offset != ts->offset || k.n != ts->length || k.interval != interval || k.raw_offset != raw_offset) return false;
+    if (k.sharded != (global_s0 != nullptr)) return false;
+    if (global_s0 && (k.global_s0 != *global_s0 || k.has_left != ((edge && edge->has_left) ? 1 : 0) || (k.has_left && k.left_ts != edge->left_last_ts))) return false;
+    return k.gen == c->pool_gen[kPoolInterp + 1] && c->pool[kPoolInterp + 1] != nullptr;
+}
+
 static int interp_prepare(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval,
-                          const bowgpu_options *o, InterpJob *job, const int64_t *global_s0 = nullptr, const bowgpu_interp_edge *edge = nullptr) {
+                          const bowgpu_options *o, InterpJob *job, const int64_t *global_s0 = nullptr, const bowgpu_interp_edge *edge = nullptr,
+                          bool use_cache = false) {
+    // The _fill call right after _count on the same device-resident, unchanged interval column (Bows are immutable in the
+    // reference; include/bowgpu.h states the contract): pass 1's prefix is still in the context pool
+    if (use_cache && interp_cache_hit(c, &cols[ts_col], interval, o->offset, global_s0, edge)) {
+        const Ctx::InterpCache &k = c->interp_cache;
+        for (int i = 0; i < ncols; i++)
+            if (cols[i].length != k.n) return fail(BOWGPU_ERR_ARG, "column %d has a different length", i);
+        job->plan.interval = interval; job->plan.offset = k.offset_norm; job->plan.s0 = k.s0; job->plan.W = k.W;
+        job->plan.first_ts = k.first_ts; job->plan.last_ts = k.last_ts; job->plan.magic = magic_make((uint64_t)interval);
+        job->kq = k.kq; job->drop = k.drop; job->M = k.M; job->wbase = k.wbase; job->has_left = k.has_left; job->left_ts = k.left_ts;
+        job->kq_empty = k.kq_empty;
+        job->tile_before = c->pool[kPoolInterp + 1];
+        BG_TRY(ts_device(c, &cols[ts_col], &job->dts));
+        c->interp_cache.valid = false;   // one use: the outputs of this fill may be what the next call reads
+        return 0;
+    }
+    c->interp_cache.valid = false;
     BG_TRY(plan_make(c, &cols[ts_col], interval, o->offset, &job->plan));
     if (global_s0) {
         // a shard: windows are counted from the frame's s0; the shard accounts for the windows after its left neighbours' last one
@@ -203,7 +231,19 @@ static int interp_prepare(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t
     BG_HIP(hipStreamSynchronize(c->stream));
     if (hstat[0]) return fail(BOWGPU_ERR_TS_UNSORTED, "interval column is not ascending: outside the device path");
     job->drop = (int64_t)(((uint64_t)hstat[3] << 32) | hstat[2]);
+    job->kq_empty = hstat[1] ? 1 : 0;
     job->M = W - total - ((job->kq >= 0 && hstat[1]) ? 1 : 0) - job->drop;  // rows added (synthetic) minus rows dropped
+    {
+        Ctx::InterpCache &k = c->interp_cache;
+        const bowgpu_col *tsc = &cols[ts_col];
+        k.ts_values = tsc->values; k.ts_offset = tsc->offset; k.n = n; k.interval = interval; k.raw_offset = o->offset;
+        k.sharded = global_s0 != nullptr; k.global_s0 = global_s0 ? *global_s0 : 0;
+        k.has_left = job->has_left; k.left_ts = job->left_ts;
+        k.gen = c->pool_gen[kPoolInterp + 1];
+        k.s0 = pl.s0; k.W = pl.W; k.first_ts = pl.first_ts; k.last_ts = pl.last_ts; k.offset_norm = pl.offset;
+        k.kq = job->kq; k.drop = job->drop; k.M = job->M; k.wbase = job->wbase; k.kq_empty = job->kq_empty;
+        k.valid = tsc->residency == BOWGPU_DEVICE;
+    }
     return 0;
 }
 
@@ -235,18 +275,21 @@ static int interp_fill_impl(const bowgpu_col *cols, int32_t ncols, int32_t ts_co
     if (edge && ncols > kMaxCols) return fail(BOWGPU_ERR_UNSUPPORTED, "sharded Interpolate: at most %d columns (bowgpu_interp_edge)", kMaxCols);
     bowgpu_options o = {0, 0, 0};
     if (opts) o = *opts;
-    Plan probe;
-    BG_TRY(plan_make(nullptr, &cols[ts_col], interval, o.offset, &probe));
+    Ctx *c = nullptr;
+    const bool cached = cols[ts_col].length > 0 && ctx_get(&c) == 0 && interp_cache_hit(c, &cols[ts_col], interval, o.offset, global_s0, edge);
+    if (!cached) {   // (the _count call that filled the cache ran these checks on the same arguments)
+        Plan probe;
+        BG_TRY(plan_make(nullptr, &cols[ts_col], interval, o.offset, &probe));
+    }
     BG_TRY(interp_validate(cols, ncols, ts_col, &o, interps, ninterps));
     const int64_t n = cols[ts_col].length;
     if (n == 0) {
         for (int i = 0; i < ninterps; i++) { outs[i].length = 0; outs[i].null_count = 0; outs[i].type = cols[i].type; }
         return 0;
     }
-    Ctx *c;
     BG_TRY(ctx_get(&c));
     InterpJob job;
-    BG_TRY(interp_prepare(c, cols, ncols, ts_col, interval, &o, &job, global_s0, edge));
+    BG_TRY(interp_prepare(c, cols, ncols, ts_col, interval, &o, &job, global_s0, edge, true));
     const int64_t n_out = n + job.M;
     if (n_out == 0) {
         for (int i = 0; i < ninterps; i++) { outs[i].length = 0; outs[i].null_count = 0; outs[i].type = cols[i].type; }
@@ -261,8 +304,9 @@ static int interp_fill_impl(const bowgpu_col *cols, int32_t ncols, int32_t ts_co
     P.ts = reinterpret_cast<const int64_t *>(job.dts.values);
     P.n = n; P.s0 = job.plan.s0; P.interval = job.plan.interval; P.W = job.plan.W; P.magic = job.plan.magic;
     P.tile_exact_before = reinterpret_cast<const int64_t *>(job.tile_before);
-    P.status = reinterpret_cast<uint32_t *>(dscr);  // (status[1] still holds pass 1's answer about window kq)
+    P.status = reinterpret_cast<uint32_t *>(dscr);
     P.kq = job.kq;
+    P.kq_empty = job.kq_empty;
     P.drop = job.drop;
     P.has_left = job.has_left; P.left_ts = job.left_ts; P.wbase = job.wbase;
     P.fast32 = interp_fast32(job.plan, job.kq) ? 1 : 0;
@@ -273,42 +317,57 @@ static int interp_fill_impl(const bowgpu_col *cols, int32_t ncols, int32_t ts_co
         if (i == ts_col) { dc.values = job.dts.values; dc.length = n; dc.type = BOWGPU_INT64; }
         else BG_TRY(devcol_prepare(c, &cols[i], &dc, true, true));
         BG_TRY(devout_prepare(c, &outs[i], n_out, &douts[i], i < 16 ? i : -1));  // validity working copy from the context pool
-        BG_HIP(hipMemsetAsync(douts[i].validity, 0, (size_t)(((n_out + 7) >> 3) + 3) & ~(size_t)3, c->stream));
     }
-    // the output positions depend on the interval column alone, so the columns go through the tile kernel kMaxCols at a time
-    // (a Bow of any width: interpolation.go:98-161 loops over the interpolators)
-    for (int b0 = 0; b0 < ncols; b0 += kMaxCols) {
-        const int nb = ncols - b0 < kMaxCols ? ncols - b0 : kMaxCols;
-        P.ncols = nb;
-        for (int j = 0; j < nb; j++) {
-            const int i = b0 + j;
-            const DevCol &dc = job.dcols[i];
-            InterpCol &ic = P.cols[j];
-            memset(&ic, 0, sizeof ic);
-            ic.values = reinterpret_cast<const uint64_t *>(dc.values);
-            ic.vbits = dc.vbits; ic.vbit0 = dc.vbit0; ic.type = cols[i].type; ic.kind = interps[i].kind;
-            ic.const_value = interps[i].const_value;
-            ic.has_prev = interps[i].has_prev_row; ic.prev_t_valid = interps[i].prev_t_valid; ic.prev_v_valid = interps[i].prev_v_valid;
-            ic.prev_t = interps[i].prev_t; ic.prev_v = interps[i].prev_v; ic.prev_v_i64 = interps[i].prev_v_i64;
-            ic.out_values = reinterpret_cast<uint64_t *>(douts[i].values);
-            ic.out_valid_words = reinterpret_cast<uint32_t *>(douts[i].validity);
-            if (edge && edge->next_valid[i]) { ic.next_valid = 1; ic.next_t = edge->next_t[i]; ic.next_v = edge->next_v[i]; }
-            if (dc.vbits && (ic.kind == BOWGPU_INTERP_LINEAR || ic.kind == BOWGPU_INTERP_STEP_PREVIOUS)) {
-                void *ix;
-                BG_TRY(ctx_pool(c, kPoolInterp + 3 + j, nbr_index_bytes(n, dc.vbit0), &ix));  // (reused by the next batch: stream order)
-                BG_TRY(nbr_index_build(c, dc.vbits, dc.vbit0, n, ix, &ic.nbr));
-            }
-        }
-        BG_TRY(launch_interp_tiles(c, P));
-    }
-    uint64_t *dcnt = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(dscr) + 1024);
     std::vector<uint64_t> hcnt(ninterps, 0);
-    for (int i = 0; i < ninterps; i++) {
-        BG_TRY(launch_popcount(c, reinterpret_cast<const uint32_t *>(douts[i].validity), 0, n_out, dcnt + i));
-        BG_HIP(hipMemcpyAsync(&hcnt[i], dcnt + i, 8, hipMemcpyDeviceToHost, c->stream));
-    }
-    BG_HIP(hipStreamSynchronize(c->stream));
-    for (int i = 0; i < ninterps; i++) BG_TRY(devout_finish(c, &douts[i], n_out, cols[i].type, n_out - (int64_t)hcnt[i]));
+    uint32_t hstat[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long *dcnt = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(dscr) + 1024);
+    // The output positions depend on the interval column alone, so the columns go through the kernel kMaxCols at a time (a Bow
+    // of any width: interpolation.go:98-161 loops over the interpolators).  Per batch: ONE launch zeroes the batch's bitmaps (and,
+    // first batch, the status words), the kernel, ONE launch counts the valid bits and copies the bitmaps into the caller's buffers.
+    auto run_all = [&](int allow_wave2) -> int {
+        P.allow_wave2 = allow_wave2;
+        for (int b0 = 0; b0 < ncols; b0 += kMaxCols) {
+            const int nb = ncols - b0 < kMaxCols ? ncols - b0 : kMaxCols;
+            P.ncols = nb;
+            BitmapBatch bb;
+            memset(&bb, 0, sizeof bb);
+            bb.n = nb; bb.nbits = n_out; bb.status = P.status; bb.counts = dcnt; bb.status_words = b0 == 0 ? 16 : 0;
+            for (int j = 0; j < nb; j++) {
+                const int i = b0 + j;
+                const DevCol &dc = job.dcols[i];
+                InterpCol &ic = P.cols[j];
+                memset(&ic, 0, sizeof ic);
+                ic.values = reinterpret_cast<const uint64_t *>(dc.values);
+                ic.vbits = dc.vbits; ic.vbit0 = dc.vbit0; ic.type = cols[i].type; ic.kind = interps[i].kind;
+                ic.const_value = interps[i].const_value;
+                ic.has_prev = interps[i].has_prev_row; ic.prev_t_valid = interps[i].prev_t_valid; ic.prev_v_valid = interps[i].prev_v_valid;
+                ic.prev_t = interps[i].prev_t; ic.prev_v = interps[i].prev_v; ic.prev_v_i64 = interps[i].prev_v_i64;
+                ic.out_values = reinterpret_cast<uint64_t *>(douts[i].values);
+                ic.out_valid_words = reinterpret_cast<uint32_t *>(douts[i].validity);
+                if (edge && edge->next_valid[i]) { ic.next_valid = 1; ic.next_t = edge->next_t[i]; ic.next_v = edge->next_v[i]; }
+                if (dc.vbits && (ic.kind == BOWGPU_INTERP_LINEAR || ic.kind == BOWGPU_INTERP_STEP_PREVIOUS)) {
+                    void *ix;
+                    BG_TRY(ctx_pool(c, kPoolInterp + 3 + j, nbr_index_bytes(n, dc.vbit0), &ix));  // (reused by the next batch: stream order)
+                    BG_TRY(nbr_index_build(c, dc.vbits, dc.vbit0, n, ix, &ic.nbr));
+                }
+                bb.work[j] = reinterpret_cast<uint32_t *>(douts[i].validity);
+                bb.user[j] = outs[i].residency == BOWGPU_DEVICE ? outs[i].validity : nullptr;
+                bb.ones[j] = 0;
+                bb.count[j] = 1;
+            }
+            BG_TRY(launch_preset_bitmaps(c, bb));
+            BG_TRY(launch_interp_tiles(c, P));
+            BG_TRY(launch_finish_bitmaps(c, bb));
+            BG_HIP(hipMemcpyAsync(&hcnt[b0], dcnt, 8 * (size_t)nb, hipMemcpyDeviceToHost, c->stream));
+        }
+        BG_HIP(hipMemcpyAsync(hstat, P.status, sizeof hstat, hipMemcpyDeviceToHost, c->stream));
+        BG_HIP(hipStreamSynchronize(c->stream));
+        return 0;
+    };
+    BG_TRY(run_all(1));
+    if (hstat[5]) BG_TRY(run_all(0));   // some trip has more runs of synthetic rows than interp_wave2_kernel lists: the first wave kernel takes the call
+    if (hstat[0]) return fail(BOWGPU_ERR_TS_UNSORTED, "interval column is not ascending: outside the device path");
+    for (int i = 0; i < ninterps; i++) BG_TRY(devout_finish(c, &douts[i], n_out, cols[i].type, n_out - (int64_t)hcnt[i], false));
     BG_HIP(hipStreamSynchronize(c->stream));
     return 0;
 }

@@ -145,8 +145,65 @@ int stream_sum_run(Ctx *c, const void *a, const void *b, int64_t bytes_each, int
     return 0;
 }
 
-namespace {
-}  // namespace
+// The achievable line for the benched TRAFFIC MIX, not just its reads: a trivial kernel (one xor per loaded word) that reads two
+// streams of 8 bytes per row and writes two streams of 8 bytes per `rows_per_slot` rows in the tile kernels' store pattern (one
+// wavefront per 512 rows, consecutive lanes -> consecutive 8-byte slots, piece ends unaligned).  kNt: non-temporal loads.
+template <bool kNt>
+__global__ __launch_bounds__(64) void stream_rw_kernel(const ulonglong2 *__restrict__ a, const ulonglong2 *__restrict__ b, uint64_t *__restrict__ o0,
+                                                       uint64_t *__restrict__ o1, const int64_t ntiles, const int64_t tiles_per_xcd,
+                                                       const int64_t rows_per_slot, const int64_t nslots) {
+    typedef unsigned long long v2 __attribute__((ext_vector_type(2)));
+    const int64_t w = blockIdx.x;
+    const int64_t tile = (w & 7) * tiles_per_xcd + (w >> 3);
+    if (tile >= ntiles) return;
+    const int lane = threadIdx.x;
+    const ulonglong2 *pa = a + tile * 256 + lane, *pb = b + tile * 256 + lane;
+    unsigned long long x = 0, y = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (kNt) {
+            const v2 u = __builtin_nontemporal_load(reinterpret_cast<const v2 *>(pa + 64 * j));
+            const v2 v = __builtin_nontemporal_load(reinterpret_cast<const v2 *>(pb + 64 * j));
+            x ^= u.x ^ u.y; y ^= v.x ^ v.y;
+        } else {
+            const ulonglong2 u = pa[64 * j], v = pb[64 * j];
+            x ^= u.x ^ u.y; y ^= v.x ^ v.y;
+        }
+    }
+    asm volatile("" :: "v"(x), "v"(y));   // every lane's loads stay alive, also in lanes that store nothing
+    const int64_t base = tile * 512;
+    const int64_t s0 = (base + rows_per_slot - 1) / rows_per_slot, s1 = (base + 512 + rows_per_slot - 1) / rows_per_slot;
+    for (int64_t s = s0 + lane; s < s1 && s < nslots; s += 64) { o0[s] = x; o1[s] = y; }
+}
+
+// average duration (ms) of `reps` launches reading 2 x bytes_each and writing 2 x nslots x 8 bytes
+int stream_rw_run(Ctx *c, const void *a, const void *b, int64_t bytes_each, void *o0, void *o1, int64_t rows_per_slot, int64_t nslots, bool nt,
+                  int reps, float *ms) {
+    const int64_t ntiles = bytes_each / 4096;
+    const int64_t per_xcd = (ntiles + 7) / 8;
+    hipEvent_t e0, e1;
+    BG_HIP(hipEventCreate(&e0));
+    BG_HIP(hipEventCreate(&e1));
+    auto launch = [&]() {
+        if (nt) hipLaunchKernelGGL(stream_rw_kernel<true>, dim3((unsigned)(per_xcd * 8)), dim3(64), 0, c->stream, reinterpret_cast<const ulonglong2 *>(a),
+                                   reinterpret_cast<const ulonglong2 *>(b), reinterpret_cast<uint64_t *>(o0), reinterpret_cast<uint64_t *>(o1), ntiles,
+                                   per_xcd, rows_per_slot, nslots);
+        else hipLaunchKernelGGL(stream_rw_kernel<false>, dim3((unsigned)(per_xcd * 8)), dim3(64), 0, c->stream, reinterpret_cast<const ulonglong2 *>(a),
+                                reinterpret_cast<const ulonglong2 *>(b), reinterpret_cast<uint64_t *>(o0), reinterpret_cast<uint64_t *>(o1), ntiles,
+                                per_xcd, rows_per_slot, nslots);
+    };
+    launch();  // warm-up
+    BG_HIP(hipEventRecord(e0, c->stream));
+    for (int r = 0; r < reps; r++) launch();
+    BG_HIP(hipEventRecord(e1, c->stream));
+    BG_HIP(hipEventSynchronize(e1));
+    BG_HIP(hipGetLastError());
+    BG_HIP(hipEventElapsedTime(ms, e0, e1));
+    *ms /= reps;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return 0;
+}
 
 int launch_gen_dense(Ctx *c, int64_t row0, int64_t n, uint64_t seed, int64_t *ts, double *val) {
     if (n <= 0) return 0;

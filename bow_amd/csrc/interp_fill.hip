@@ -108,9 +108,15 @@ __global__ __launch_bounds__(1024) void nbr_scan_kernel(const int64_t *last_in, 
 
 // ------------------------------------------------------------------ Interpolate
 // first row of every window: first_idx[k] = lower_bound(ts, s_k) for k in [0, W], first_idx[W] = n
+// The row that opens window w also names the first row of every EMPTY window before it.  Short runs of empties are written by
+// that row's thread; a long run (two rows 1e9 apart with interval 10 leave 1e8 empty windows: one lane storing them one by one
+// took seconds) is queued and filled by the whole grid in window_gaps_kernel.
+constexpr int kGapInline = 64;       // empties a thread writes itself
+constexpr int kGapListCap = 4096;    // queued runs; beyond that the thread falls back to writing them itself
+struct GapRun { int64_t k0, k1, row; };   // first_idx[k0 .. k1) = row
 __global__ __launch_bounds__(256) void window_first_rows_kernel(const int64_t *ts, int64_t n, int64_t s0, int64_t interval,
                                                                 MagicDiv magic, int64_t W, int64_t *first_idx,
-                                                                uint32_t *status) {
+                                                                uint32_t *status, GapRun *gaps, uint32_t *gap_count) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += stride) {
         if (i == n) {  // windows after the last row's window do not exist (W = wid(last)+1); terminator
@@ -128,7 +134,22 @@ __global__ __launch_bounds__(256) void window_first_rows_kernel(const int64_t *t
             if (tp > t) atomicOr(&status[0], 1u);
             wp = tp < s0 ? 0 : magic_div((uint64_t)tp - (uint64_t)s0, magic);
         }
-        for (uint64_t k = wp + 1; k <= w && (int64_t)k < W; k++) first_idx[k] = i;  // k's first row (and every empty window before it)
+        uint64_t k_end = w + 1;   // k's first row (and every empty window before it): windows wp + 1 .. w
+        if ((int64_t)k_end > W) k_end = (uint64_t)W;
+        if (w >= wp && k_end > wp + 1 && k_end - (wp + 1) > (uint64_t)kGapInline) {
+            const uint32_t slot = atomicAdd(gap_count, 1u);
+            if (slot < (uint32_t)kGapListCap) { gaps[slot] = GapRun{(int64_t)(wp + 1), (int64_t)k_end, i}; continue; }
+        }
+        for (uint64_t k = wp + 1; k < k_end; k++) first_idx[k] = i;
+    }
+}
+__global__ __launch_bounds__(256) void window_gaps_kernel(const GapRun *gaps, const uint32_t *gap_count, int64_t *first_idx) {
+    uint32_t ng = *gap_count;
+    if (ng > (uint32_t)kGapListCap) ng = kGapListCap;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (uint32_t g = 0; g < ng; g++) {
+        const GapRun r = gaps[g];
+        for (int64_t k = r.k0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < r.k1; k += stride) first_idx[k] = r.row;
     }
 }
 
@@ -688,8 +709,17 @@ static inline unsigned grid_for(int64_t n, int per_block = 256, int64_t cap = 25
 }
 
 int launch_window_first_rows(Ctx *c, const int64_t *ts, int64_t n, const Plan &plan, int64_t *first_idx, uint32_t *status) {
+    void *w;
+    BG_TRY(ctx_pool(c, kPoolGaps, 256 + sizeof(GapRun) * kGapListCap, &w));
+    uint32_t *gap_count = reinterpret_cast<uint32_t *>(w);
+    GapRun *gaps = reinterpret_cast<GapRun *>(reinterpret_cast<char *>(w) + 256);
+    BG_HIP(hipMemsetAsync(gap_count, 0, 4, c->stream));
     hipLaunchKernelGGL(window_first_rows_kernel, dim3(grid_for(n + 1)), dim3(256), 0, c->stream, ts, n, plan.s0, plan.interval,
-                       plan.magic, plan.W, first_idx, status);
+                       plan.magic, plan.W, first_idx, status, gaps, gap_count);
+    // long runs of empty windows: the whole grid fills them (a few blocks when there are none: it reads the count and leaves)
+    const int64_t spare = plan.W - n;   // an upper bound of the empties
+    const unsigned gblocks = spare > (int64_t)kGapInline ? (unsigned)std::min<int64_t>(2048, (spare + 255) / 256) : 1u;
+    hipLaunchKernelGGL(window_gaps_kernel, dim3(gblocks), dim3(256), 0, c->stream, gaps, gap_count, first_idx);
     BG_HIP(hipGetLastError());
     return 0;
 }

@@ -219,7 +219,7 @@ __global__ __launch_bounds__(kIThreads) void interp_tile_kernel(const InterpPara
     const int64_t r0 = (int64_t)blockIdx.x * kITile;
     const int64_t i = r0 + kIR * (int64_t)tid;
     for (int w = tid; w < kMaxCols * kISpanWords; w += kIThreads) (&lbits[0][0])[w] = 0;
-    const int64_t kq = (!kFast && p.kq >= 0 && p.status[1]) ? p.kq : -1;  // see rows_flags
+    const int64_t kq = (!kFast && p.kq >= 0 && p.kq_empty) ? p.kq : -1;  // see rows_flags
     const Magic32 m32 = {p.m32, p.sh1_32, p.sh2_32};
     if (tid == 0) s_nlong = 0;
 
@@ -636,6 +636,253 @@ __global__ __launch_bounds__(64) void interp_wave_kernel(const InterpParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// interp_wave2_kernel: the trip (512 rows, one wavefront, no barrier) handled AS A WHOLE per column instead of chunk by chunk.
+// interp_wave_kernel issues ~2200 vector instructions per trip - four wave scans through the LDS crossbar, per-chunk neighbour
+// searches with ~13 of 64 lanes at work, a staging flush per chunk - and is bound by instruction issue (1.47 ms per 1e8 rows for
+// 3.35 GB of traffic).  Here:
+//   phase 1  flags and output positions of all 512 rows stay in REGISTERS (lane l = rows 2l, 2l+1 of each 128-row chunk); the
+//            four scans are DPP scans (six v_add_dpp each, no LDS); every run of synthetic rows (a window start that is not a
+//            row, plus the empty windows before it) becomes one entry of a list in LDS: (row, count, output position);
+//   phase 2  per column: the rows go to their output positions in the LDS stage; ONE lane per run computes its synthetic rows
+//            (~50 of 64 lanes busy on the configs[2] shape): the nearest valid rows around the run's row come from the column's
+//            validity words of the trip (LDS, count-leading / trailing-zeros), their values and timestamps from global memory
+//            (lines the trip has just loaded: L1 / L2 hits); the stage then leaves as contiguous stores, output validity = the
+//            ballot of the staged flags streamed through the scalar bit accumulator.
+// A trip with more runs than the list holds (windows of < 2 rows, nearly all without a row on their start) raises status[5]
+// and the host redoes the call with interp_wave_kernel; a trip with more outputs than the stage holds (long runs of empty
+// windows) writes directly.
+constexpr int kW2Stage = 768;   // outputs staged per trip and column (512 rows + up to 256 synthetic rows)
+constexpr int kW2Runs = 256;    // runs of synthetic rows per trip
+
+struct Wave2Lds {
+    uint64_t val[kW2Stage];
+    uint8_t flag[kW2Stage];
+    uint32_t run_a[kW2Runs];    // local row | count << 9 (count saturates at 2^23 - 1: longer runs take their count from run_n)
+    uint32_t run_o[kW2Runs];    // output position (relative to the trip's first) of the row the run sits in front of
+    uint32_t vw[18];            // validity bits of the column's rows of this trip: row r = bit r (word r >> 5)
+};
+
+// inclusive wave scan of one unsigned per lane: Hillis-Steele inside the 16-lane rows (row_shr 1, 2, 4, 8), then the row totals
+// across (row_bcast 15 into rows 1 and 3, row_bcast 31 into rows 2 and 3): six DPP moves + adds, no LDS
+__device__ __forceinline__ uint32_t wave_scan_u32(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);
+    return x;
+}
+
+__global__ __launch_bounds__(64) void interp_wave2_kernel(const InterpParams p) {
+    __shared__ Wave2Lds L;
+    const int lane = threadIdx.x;
+    const int64_t trip = blockIdx.x;
+    const int64_t base = trip * 512;
+    if (base >= p.n) return;
+    const int64_t left_trip = p.n - base;
+    const bool full = left_trip >= 512;
+    const int nloc = full ? 512 : (int)left_trip;
+    const Magic32 m32 = {p.m32, p.sh1_32, p.sh2_32};
+    const uint32_t s0lo = (uint32_t)p.s0, i32 = (uint32_t)p.interval;
+    const int sh2l = (2 * lane) & 63;
+    const uint64_t *tsu = reinterpret_cast<const uint64_t *>(p.ts);
+
+    auto load2 = [&](const uint64_t *col, int k, uint64_t *a, uint64_t *b) {
+        const int r = 128 * k + 2 * lane;
+        const uint64_t *src = col + base;
+        if (full && (reinterpret_cast<uintptr_t>(col) & 15) == 0) { const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(src + r); *a = v.x; *b = v.y; }
+        else { *a = r < left_trip ? src[r] : 0; *b = r + 1 < left_trip ? src[r + 1] : 0; }
+    };
+
+    // ---- phase 1: output positions (relative to o_trip) and synthetic-row counts of the lane's eight rows, the run list
+    int64_t o_trip = 0, t_before = p.left_ts;
+    uint32_t or0[4], or1[4];
+    uint32_t tot = 0;
+    int nrun = 0;
+    {
+        uint64_t ta[4], tb[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) load2(tsu, k, &ta[k], &tb[k]);
+        if (base > 0) {
+            t_before = p.ts[base - 1];
+            const uint32_t wp = mdiv32((uint32_t)((uint64_t)t_before - (uint64_t)p.s0), m32);
+            o_trip = base + (int64_t)wp + 1 - p.wbase - p.tile_exact_before[trip];
+        }
+        uint32_t rb_prev = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int64_t i = base + 128 * k + 2 * lane;
+            const uint32_t ra = (uint32_t)ta[k] - s0lo, rb = (uint32_t)tb[k] - s0lo;
+            uint32_t rl = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rb, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+            if (lane == 0) rl = k == 0 ? (uint32_t)t_before - s0lo : (uint32_t)__builtin_amdgcn_readlane((int)rb_prev, 63);
+            rb_prev = rb;
+            const bool in0 = i < p.n, in1 = i + 1 < p.n;
+            const bool first = i == 0 && !p.has_left;  // the frame's first row has no left neighbour
+            const uint32_t wl = mdiv32(rl, m32), wa = mdiv32(ra, m32), wb = mdiv32(rb, m32);
+            const bool head0 = in0 && (first || wa != wl), head1 = in1 && wb != wa;
+            const bool exact0 = head0 && ra == wa * i32, exact1 = head1 && rb == wb * i32;
+            const uint32_t sy0 = head0 ? ((first ? 0u : wa - wl - 1u) + (exact0 ? 0u : 1u)) : 0u;
+            const uint32_t sy1 = head1 ? (wb - wa - 1u + (exact1 ? 0u : 1u)) : 0u;
+            const uint32_t e0 = in0 ? 1u : 0u, e1 = in1 ? 1u : 0u;
+            const uint32_t mine = e0 + e1 + sy0 + sy1;
+            const uint32_t inc = wave_scan_u32(mine);
+            uint32_t o = tot + inc - mine;
+            o += sy0; or0[k] = o; o += e0;
+            o += sy1; or1[k] = o;
+            tot += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+            // the runs of this chunk, in row order
+            const bool ha = sy0 > 0, hb = sy1 > 0;
+            const unsigned long long ma = __ballot(ha), mb = __ballot(hb);
+            if (ma | mb) {
+                int pos = nrun;
+                pos += __builtin_amdgcn_mbcnt_hi((unsigned)(ma >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ma, 0));
+                pos += __builtin_amdgcn_mbcnt_hi((unsigned)(mb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb, 0));
+                const uint32_t la = (uint32_t)(128 * k + 2 * lane);
+                if (ha && pos < kW2Runs) { L.run_a[pos] = la | ((sy0 < 0x7FFFFFu ? sy0 : 0x7FFFFFu) << 9); L.run_o[pos] = or0[k]; }
+                pos += ha ? 1 : 0;
+                if (hb && pos < kW2Runs) { L.run_a[pos] = (la + 1u) | ((sy1 < 0x7FFFFFu ? sy1 : 0x7FFFFFu) << 9); L.run_o[pos] = or1[k]; }
+                nrun += __popcll(ma) + __popcll(mb);
+            }
+        }
+    }
+    if (nrun > kW2Runs) {   // outside this kernel's list: the host redoes the call with interp_wave_kernel
+        if (lane == 0) atomicOr(&p.status[5], 1u);
+        return;
+    }
+    const bool staged = tot <= (uint32_t)kW2Stage;
+    wave_lds_order();
+
+    // ---- phase 2: one column at a time
+    uint64_t na[4], nb[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) load2(p.cols[0].values, k, &na[k], &nb[k]);
+#pragma unroll 1
+    for (int c = 0; c < p.ncols; c++) {
+        const InterpCol &ic = p.cols[c];
+        const bool want_p = ic.kind == BOWGPU_INTERP_LINEAR || ic.kind == BOWGPU_INTERP_STEP_PREVIOUS, want_n = ic.kind == BOWGPU_INTERP_LINEAR;
+        uint64_t a[4], b[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { a[k] = na[k]; b[k] = nb[k]; }
+        if (c + 1 < p.ncols) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) load2(p.cols[c + 1].values, k, &na[k], &nb[k]);
+        }
+        uint64_t *out = ic.out_values + o_trip;
+        auto put = [&](uint32_t pos, uint64_t bits, int valid) {
+            if (staged) { L.val[pos] = bits; L.flag[pos] = (uint8_t)valid; }
+            else {
+                out[pos] = bits;
+                if (valid) atomicOr(&ic.out_valid_words[(o_trip + pos) >> 5], 1u << ((o_trip + pos) & 31));
+            }
+        };
+        // the rows to their places; the column's validity bits of the trip to LDS (four words per chunk, lanes 0..3)
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int r = 128 * k + 2 * lane;
+            uint64_t w0 = ~0ull, w1 = ~0ull;
+            if (128 * k < nloc) load_bits128<false>(ic.vbits, ic.vbit0, base + 128 * k, p.n, &w0, &w1);
+            else { w0 = 0; w1 = 0; }
+            const int fl = (int)(((lane < 32 ? w0 : w1) >> sh2l) & 3ull);
+            if (lane < 4) L.vw[4 * k + lane] = (uint32_t)((lane < 2 ? w0 : w1) >> (32 * (lane & 1)));
+            if (r < nloc) put(or0[k], a[k], fl & 1);
+            if (r + 1 < nloc) put(or1[k], b[k], (fl >> 1) & 1);
+        }
+        // the last valid point before the trip (Linear / StepPrevious; the same for every run that finds none inside the trip)
+        NbPoint carry; carry.has = 0; carry.t = 0; carry.bits = 0;
+        if (want_p && base > 0 && nrun > 0) {
+            const int64_t pi = prev_valid_ix(ic.vbits, ic.vbit0, p.n, base - 1, ic.nbr);
+            if (pi >= 0) { carry.has = 1; carry.t = p.ts[pi]; carry.bits = ic.values[pi]; }
+        }
+        wave_lds_order();
+        // ---- one lane per run of synthetic rows
+#pragma unroll 1
+        for (int q0 = 0; q0 < nrun; q0 += 64) {
+            const int q = q0 + lane;
+            const bool act = q < nrun;
+            const uint32_t e = act ? L.run_a[q] : 0u;
+            const uint32_t orow = act ? L.run_o[q] : 0u;
+            const int al = (int)(e & 511u);
+            uint32_t cnt = e >> 9;
+            const int64_t ar = base + al;
+            const uint64_t tsa = act ? tsu[ar] : 0ull;
+            const uint32_t rel = (uint32_t)tsa - s0lo;
+            const uint32_t w = mdiv32(rel, m32);
+            const uint32_t kk0 = rel == w * i32 ? w - 1u : w;   // the window of the run's first synthetic row (next to the row)
+            if (cnt == 0x7FFFFFu) {  // a saturated count: recompute it from the row before (the windows between the two rows)
+                const uint32_t wl = mdiv32((uint32_t)(ar > 0 ? tsu[ar - 1] : (uint64_t)p.left_ts) - s0lo, m32);
+                cnt = w - wl - 1u + (rel == w * i32 ? 0u : 1u);
+            }
+            NbPoint qp = carry, qn; qn.has = 0; qn.t = 0; qn.bits = 0;
+            if (act && want_p) {   // nearest valid row before row al
+                int r = al - 1;
+                while (r >= 0) {
+                    const int sh = r & 31;
+                    uint32_t x = L.vw[r >> 5];
+                    x = sh == 31 ? x : (x & ((2u << sh) - 1u));
+                    if (x) { r = (r & ~31) + 31 - __clz((int)x); break; }
+                    r = (r & ~31) - 1;
+                }
+                if (r >= 0) { qp.has = 1; qp.bits = ic.values[base + r]; qp.t = (int64_t)tsu[base + r]; }
+            }
+            if (act && want_n) {   // nearest valid row from row al on
+                int r = al;
+                bool found = false;
+                while (r < nloc) {
+                    const uint32_t x = L.vw[r >> 5] & (~0u << (r & 31));
+                    if (x) { r = (r & ~31) + __ffs((int)x) - 1; found = r < nloc; break; }
+                    r = (r | 31) + 1;
+                }
+                int64_t ni = found ? base + r : -1;
+                if (!found && base + nloc < p.n) ni = next_valid_ix(ic.vbits, ic.vbit0, p.n, base + nloc, ic.nbr);  // beyond the trip (rare)
+                if (ni >= 0) { qn.has = 1; qn.bits = ic.values[ni]; qn.t = (int64_t)tsu[ni]; }
+            }
+            const bool is_long = act && cnt > (uint32_t)kSmallRun;
+            if (act && !is_long) {
+                for (uint32_t j = 0; j < cnt; j++) {
+                    const int64_t sk = p.s0 + (int64_t)((uint64_t)(kk0 - j) * (uint64_t)p.interval);
+                    uint64_t bits; int valid;
+                    synth_value_pt(ic, sk, qp, qn, &bits, &valid);
+                    put(orow - 1 - j, bits, valid);
+                }
+            }
+            uint64_t lm = __ballot(is_long);  // long runs of empty windows: the whole wavefront, one run at a time
+            while (lm) {
+                const int src = __ffsll((long long)lm) - 1;
+                lm &= lm - 1;
+                const uint32_t rcnt = (uint32_t)__builtin_amdgcn_readlane((int)cnt, src);
+                const uint32_t rk0 = (uint32_t)__builtin_amdgcn_readlane((int)kk0, src);
+                const uint32_t ro = (uint32_t)__builtin_amdgcn_readlane((int)orow, src);
+                NbPoint rp, rn;
+                rp.has = __builtin_amdgcn_readlane(qp.has, src); rp.bits = lane_value(qp.bits, src); rp.t = (int64_t)lane_value((uint64_t)qp.t, src);
+                rn.has = __builtin_amdgcn_readlane(qn.has, src); rn.bits = lane_value(qn.bits, src); rn.t = (int64_t)lane_value((uint64_t)qn.t, src);
+                for (uint32_t j = (uint32_t)lane; j < rcnt; j += 64) {
+                    const int64_t sk = p.s0 + (int64_t)((uint64_t)(rk0 - j) * (uint64_t)p.interval);
+                    uint64_t bits; int valid;
+                    synth_value_pt(ic, sk, rp, rn, &bits, &valid);
+                    put(ro - 1 - j, bits, valid);
+                }
+            }
+        }
+        // ---- the stage leaves: contiguous stores, validity words from the ballots of the flags
+        if (staged) {
+            wave_lds_order();
+            BitStream bs;
+            bs.start(ic.out_valid_words, o_trip);
+            for (uint32_t g = 0; g < tot; g += 64) {
+                const uint32_t j = g + (uint32_t)lane;
+                int fv = 0;
+                if (j < tot) { out[j] = L.val[j]; fv = L.flag[j]; }
+                const uint64_t bb = __ballot(fv != 0);
+                bs.append(bb, (int)(tot - g < 64u ? tot - g : 64u), lane);
+            }
+            bs.finish(lane);
+            wave_lds_order();
+        }
+    }
+}
+
 // The two corner cases of the reference's window walk that are not statements about single rows:
 //   status[1] = 1 when window kq (the one that starts at -1, if any) has no row of its own;
 //   status[2..3] = number of leading rows below s0 when window 0 has no row of its own: Go's truncating division can put
@@ -706,8 +953,12 @@ int launch_interp_tiles(Ctx *c, const InterpParams &p) {
     // the usual shape takes the barrier-free wave kernel (BOWGPU_INTERP_TILE=1: test switch that keeps it on the tile kernel)
     const char *force_tile = getenv("BOWGPU_INTERP_TILE");
     static_assert(kITile == 512, "interp_wave_kernel's trips are the count kernel's tiles");
-    if (p.fast32 && p.drop == 0 && p.kq < 0 && !(force_tile && force_tile[0] == '1'))
-        hipLaunchKernelGGL(interp_wave_kernel, dim3((unsigned)ntiles), dim3(64), 0, c->stream, p);
+    // BOWGPU_INTERP_WAVE1=1: the first wave kernel (also what a call is redone with when a trip overflows the second one's run list)
+    const char *wave1 = getenv("BOWGPU_INTERP_WAVE1");
+    if (p.fast32 && p.drop == 0 && p.kq < 0 && !(force_tile && force_tile[0] == '1')) {
+        if (p.allow_wave2 && !(wave1 && wave1[0] == '1')) hipLaunchKernelGGL(interp_wave2_kernel, dim3((unsigned)ntiles), dim3(64), 0, c->stream, p);
+        else hipLaunchKernelGGL(interp_wave_kernel, dim3((unsigned)ntiles), dim3(64), 0, c->stream, p);
+    }
     else if (p.fast32) hipLaunchKernelGGL(interp_tile_kernel<true>, dim3((unsigned)ntiles), dim3(kIThreads), 0, c->stream, p);
     else hipLaunchKernelGGL(interp_tile_kernel<false>, dim3((unsigned)ntiles), dim3(kIThreads), 0, c->stream, p);
     BG_HIP(hipGetLastError());

@@ -447,6 +447,67 @@ int launch_rolling_aggregate(Ctx *c, const AggParams &p) {
     return 0;
 }
 
+// ---- the output bitmaps of one call, all in ONE launch each way (per-output memset + tail fix + popcount + copy-back used to be
+// eleven stream operations around a kernel of a few microseconds: DESIGN.md section 6)
+// preset: working bitmaps to all-ones / all-zeros with the padding bits of the last byte clear (bowbuffer.go:25), status words and
+// the valid counters to zero.  finish: valid bits counted (nullable outputs) and the bitmap's ceil(W/8) bytes copied into the
+// caller's device buffer (any alignment; the working copy is word-aligned because the kernels update validity as 32-bit words).
+__global__ __launch_bounds__(256) void preset_bitmaps_kernel(const BitmapBatch b) {
+    const int a = blockIdx.y;
+    if (a == 0 && blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < b.status_words; i += blockDim.x) b.status[i] = 0u;
+        if (threadIdx.x < kMaxAggs) b.counts[threadIdx.x] = 0ull;
+    }
+    if (a >= b.n) return;
+    const int64_t nwords = (b.nbits + 31) >> 5;
+    const uint32_t fill = b.ones[a] ? 0xFFFFFFFFu : 0u;
+    uint32_t *w = b.work[a];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t x = fill;
+        if (i == nwords - 1 && (b.nbits & 31)) x &= (1u << (b.nbits & 31)) - 1u;
+        w[i] = x;
+    }
+}
+__global__ __launch_bounds__(256) void finish_bitmaps_kernel(const BitmapBatch b) {
+    const int a = blockIdx.y;
+    if (a >= b.n) return;
+    const int64_t nwords = (b.nbits + 31) >> 5, nbytes = (b.nbits + 7) >> 3;
+    const uint32_t *w = b.work[a];
+    uint8_t *u = b.user[a];
+    const bool aligned = (reinterpret_cast<uintptr_t>(u) & 3) == 0;
+    unsigned long long acc = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t x = w[i];
+        if (i == nwords - 1 && (b.nbits & 31)) x &= (1u << (b.nbits & 31)) - 1u;
+        if (b.count[a]) acc += __popc(x);
+        if (u) {
+            if (aligned && 4 * i + 4 <= nbytes) reinterpret_cast<uint32_t *>(u)[i] = x;
+            else for (int k = 0; k < 4 && 4 * i + k < nbytes; k++) u[4 * i + k] = (uint8_t)(x >> (8 * k));
+        }
+    }
+    if (b.count[a]) {
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+        if ((threadIdx.x & 63) == 0 && acc) atomicAdd(&b.counts[a], acc);
+    }
+}
+
+static unsigned bitmap_grid(int64_t nbits) {
+    const int64_t nwords = (nbits + 31) >> 5;
+    int64_t g = (nwords + 255) / 256;
+    return (unsigned)(g < 1 ? 1 : g > 512 ? 512 : g);
+}
+int launch_preset_bitmaps(Ctx *c, const BitmapBatch &b) {
+    hipLaunchKernelGGL(preset_bitmaps_kernel, dim3(bitmap_grid(b.nbits), b.n > 0 ? b.n : 1), dim3(256), 0, c->stream, b);
+    BG_HIP(hipGetLastError());
+    return 0;
+}
+int launch_finish_bitmaps(Ctx *c, const BitmapBatch &b) {
+    if (b.n <= 0 || b.nbits <= 0) return 0;
+    hipLaunchKernelGGL(finish_bitmaps_kernel, dim3(bitmap_grid(b.nbits), b.n), dim3(256), 0, c->stream, b);
+    BG_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_fix_tail_bits(Ctx *c, uint8_t *bitmap, int64_t nbits) {
     if ((nbits & 7) == 0) return 0;
     hipLaunchKernelGGL(fix_tail_bits_kernel, dim3(1), dim3(64), 0, c->stream, bitmap, nbits);

@@ -181,6 +181,18 @@ int bowgpu_enforce_interval_and_offset(int64_t interval, int64_t offset, int64_t
 int bowgpu_plan_windows(const bowgpu_col *ts, int64_t interval, int64_t offset, int64_t *s0,
                         int64_t *num_windows);
 
+/* The same plan as one record, for hosts that keep it: the reference computes it ONCE, in the constructor
+ * (newIntervalRolling, rolling/rolling.go:69-112, stores the first window start and numWindows in the intervalRolling), and
+ * every later Aggregate / Interpolate on that Rolling uses it.  first_ts / last_ts are the two scalars the plan was made from.
+ * With device-resident columns the plan costs one round trip to the GPU; bowgpu_rolling_aggregate_planned skips it. */
+typedef struct bowgpu_plan {
+    int64_t s0, num_windows;
+    int64_t first_ts, last_ts;
+    int64_t interval, offset;      /* offset: normalised (enforceIntervalAndOffset) */
+    int64_t nrows;                 /* of the interval column the plan was made for */
+} bowgpu_plan;
+int bowgpu_plan_windows_ex(const bowgpu_col *ts, int64_t interval, int64_t offset, bowgpu_plan *plan);
+
 /* Rolling.Aggregate — reference rolling/aggregation.go:123-238 (indexedAggregations,
  * validateAggregation, aggregateWindows) fused with the reducers of rolling/aggregation/.
  * One pass over the interval column buckets rows into windows; every aggregator of every
@@ -195,6 +207,12 @@ int bowgpu_rolling_aggregate(const bowgpu_col *cols, int32_t ncols, int32_t ts_c
                              int64_t interval, const bowgpu_options *opts,
                              const bowgpu_agg *aggs, int32_t naggs, bowgpu_out *outs,
                              bowgpu_agg_info *info);
+
+/* ... with the plan the host already holds (bowgpu_plan_windows_ex on THIS interval column; a plan whose nrows differs from the
+ * column's length is rejected).  opts->offset is ignored in favour of the plan's. */
+int bowgpu_rolling_aggregate_planned(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, const bowgpu_plan *plan,
+                                     const bowgpu_options *opts, const bowgpu_agg *aggs, int32_t naggs,
+                                     bowgpu_out *outs, bowgpu_agg_info *info);
 
 /* intervalRolling.Next for every window at once — reference rolling/rolling.go:177-239.
  * For window k: first_index[k] = Window.FirstIndex, [slice_begin[k], slice_end[k]) = the rows
@@ -475,6 +493,12 @@ int bowgpu_gen_sparse(int64_t row0, int64_t n, uint64_t seed, int64_t *ts_dev, d
 /* The "achievable" line next to the 8 TB/s peak: best rate (GB/s) of a trivial streaming sum over two device
  * buffers of bytes_each bytes (16-byte aligned), tried in a few launch shapes.  Measurement aid for bench.py. */
 int bowgpu_stream_read_ceiling(const void *dev_a, const void *dev_b, int64_t bytes_each, double *gb_per_s);
+/* The achievable line for the benched traffic MIX: the same two 8-byte-per-row input streams read by a trivial kernel that also
+ * writes two output streams of 8 bytes per `rows_per_slot` rows (out_a / out_b: device buffers of ceil(rows / rows_per_slot)
+ * 8-byte slots) in the tile kernels' store pattern.  Best of plain / non-temporal loads; the rate counts the bytes READ, like
+ * roofline.achieved does.  Measurement aid for bench.py ("stream_rw_ceiling"). */
+int bowgpu_stream_rw_ceiling(const void *dev_a, const void *dev_b, int64_t bytes_each, void *out_a, void *out_b,
+                             int64_t rows_per_slot, double *read_gb_per_s, double *ms /* nullable */);
 /* order-independent 64-bit checksum of a device buffer of n 8-byte words (xor / sum of mix) */
 int bowgpu_checksum64(const void *dev, int64_t n_words, uint64_t *xor_out, uint64_t *sum_out);
 

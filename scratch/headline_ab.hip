@@ -220,7 +220,11 @@ __global__ __launch_bounds__(64 * WPB, TILE <= 640 ? (TILE == 512 ? 6 : (TILE < 
         }
         if (!OST) {
             if (store) {
-                if (NTS == 3) { if ((mean_bits ^ ws_bits) == 0x0123456789abcdefull) atomicOr(&p.status[7], 1u); }
+                if (NTS == 4) {
+                    __hip_atomic_store(&p.out_ws[wid], ws_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&p.out_mean[wid], mean_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else if (NTS == 5) { p.out_mean[wid] = mean_bits; if (ws_bits == 0x0123456789abcdefull) p.out_ws[wid] = ws_bits; }
+                else if (NTS == 3) { if ((mean_bits ^ ws_bits) == 0x0123456789abcdefull) atomicOr(&p.status[7], 1u); }
                 else if (NTS == 2) { p.out_ws[wid & 255u] = ws_bits; p.out_mean[wid & 255u] = mean_bits; }   // diagnostic: no HBM write traffic
                 else if (NTS) { __builtin_nontemporal_store(ws_bits, &p.out_ws[wid]); __builtin_nontemporal_store(mean_bits, &p.out_mean[wid]); }
                 else { p.out_ws[wid] = ws_bits; p.out_mean[wid] = mean_bits; }
@@ -300,6 +304,7 @@ __global__ __launch_bounds__(64 * WPB) void rw_ceiling_kernel(const uint64_t *__
 #pragma unroll
         for (int j = 0; j < 8; j++) { x ^= sh[j * 64 + lane]; y ^= sh[512 + j * 64 + lane]; }
     }
+    asm volatile("" :: "v"(x), "v"(y));   // every lane's loads stay (a lane that does not store would otherwise lose them)
     // 512 rows -> 51.2 slots of each output: lanes 0..50 store (the dense shape's store pattern, 8 B per lane)
     int64_t slot0 = (base + 9) / 10;
     int64_t slot1 = (base + 512 + 9) / 10;
@@ -595,6 +600,19 @@ static void launch_stream(const P &p, hipStream_t st) {
     hipLaunchKernelGGL((stream_kernel<HOT, OSTG, NTL, DEFER>), dim3((unsigned)(per_xcd * 8)), dim3(64), 0, st, p, nr, per_xcd, KT);
 }
 
+__global__ __launch_bounds__(256) void ws_fill_kernel(uint64_t *out, int64_t W, int64_t s0, int64_t interval) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 2;
+    for (int64_t k = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2; k < W; k += stride) {
+        const uint64_t a = (uint64_t)(s0 + k * interval), b = (uint64_t)(s0 + (k + 1) * interval);
+        if (k + 1 < W) *reinterpret_cast<ulonglong2 *>(&out[k]) = make_ulonglong2(a, b); else out[k] = a;
+    }
+}
+static void launch_ws_fill(const P &p, hipStream_t st) {
+    hipLaunchKernelGGL(ws_fill_kernel, dim3(2048), dim3(256), 0, st, p.out_ws, p.W, p.s0, p.interval);
+}
+template <int TILE, int NT, int ALIGN>
+static void launch_tile_split(const P &p, hipStream_t st);
+
 __global__ void gen_kernel(int64_t n, int64_t *ts, double *val) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -627,6 +645,11 @@ static void launch_tile(const P &p, hipStream_t st) {
     const int64_t waves = per_xcd * 8;
     hipLaunchKernelGGL((tile_kernel<TILE, VDMA, ABL, OST, NT, WPB, ALIGN, NTS>), dim3((unsigned)((waves + WPB - 1) / WPB)), dim3(64 * WPB), 0, st, p, ntiles, per_xcd);
 }
+template <int TILE, int NT, int ALIGN>
+static void launch_tile_split(const P &p, hipStream_t st) {   // the window starts by a fill kernel, the means by the tile kernel
+    launch_ws_fill(p, st);
+    launch_tile<TILE, 0, 4, 0, NT, 1, ALIGN, 5>(p, st);
+}
 template <int MODE, int NT, int WPB, int ST = 0>
 static void launch_rw(const P &p, hipStream_t st) {
     const int64_t ntiles = p.n / 512;
@@ -658,22 +681,26 @@ int main(int argc, char **argv) {
 #define V(name, fn, out) vs.push_back(Variant{name, fn, out, {}})
     V("t512_reg_full", (launch_tile<512, 0, 4, 0, 0, 1>), true);
     V("t512_reg_al16_nti", (launch_tile<512, 0, 4, 0, 2, 1, 16>), true);
+    V("t512_reg_al16_nti_nts", (launch_tile<512, 0, 4, 0, 2, 1, 16, 1>), true);
+    V("t512_reg_nti_nts", (launch_tile<512, 0, 4, 0, 2, 1, 0, 1>), true);
+    V("t512_reg_sc1", (launch_tile<512, 0, 4, 0, 0, 1, 0, 4>), true);
+    V("t512_reg_nti_sc1", (launch_tile<512, 0, 4, 0, 2, 1, 0, 4>), true);
+    V("t1024_reg_al16_nti", (launch_tile<1024, 0, 4, 0, 2, 1, 16>), true);
+    V("t1024_reg_al16_nti_nts", (launch_tile<1024, 0, 4, 0, 2, 1, 16, 1>), true);
+    V("t1024_dma_al16_nti_nts", (launch_tile<1024, 1, 4, 0, 2, 1, 16, 1>), true);
+    V("t512_meanonly", (launch_tile<512, 0, 4, 0, 0, 1, 0, 5>), false);
+    V("t512_meanonly_nti", (launch_tile<512, 0, 4, 0, 2, 1, 0, 5>), false);
+    V("ws_fill", launch_ws_fill, false);
+    V("t512_split", (launch_tile_split<512, 0, 0>), true);
+    V("t512_split_nti_al16", (launch_tile_split<512, 2, 16>), true);
+    V("t1024_split_nti_al16", (launch_tile_split<1024, 2, 16>), true);
     V("t512_reg_hotst", (launch_tile<512, 0, 4, 0, 0, 1, 0, 2>), false);
-    V("s_kt4", (launch_stream<4, 0, 0, 0>), true);
-    V("s_kt16", (launch_stream<16, 0, 0, 0>), true);
-    V("s_kt2_defer", (launch_stream<2, 0, 0, 0, 1>), true);
-    V("s_kt4_defer", (launch_stream<4, 0, 0, 0, 1>), true);
-    V("s_kt8_defer", (launch_stream<8, 0, 0, 0, 1>), true);
-    V("s_kt16_defer", (launch_stream<16, 0, 0, 0, 1>), true);
-    V("s_kt32_defer", (launch_stream<32, 0, 0, 0, 1>), true);
-    V("s_kt16_defer_nt", (launch_stream<16, 0, 0, 1, 1>), true);
-    V("s_kt16_hot", (launch_stream<16, 1, 0, 0>), false);
-    V("s_kt16_hot_defer", (launch_stream<16, 1, 0, 0, 1>), false);
     V("rw_reg_st0", (launch_rw<0, 0, 1, 0>), false);
-    V("rw_reg_st7_lds", (launch_rw<0, 0, 1, 7>), false);
-    V("rw_reg_st9_lds_al16", (launch_rw<0, 0, 1, 9>), false);
+    V("rw_regnt_st0", (launch_rw<0, 1, 1, 0>), false);
     V("rw_reg_st2_al16", (launch_rw<0, 0, 1, 2>), false);
+    V("rw_reg_st7_lds", (launch_rw<0, 0, 1, 7>), false);
     V("rw_reg_st4_none", (launch_rw<0, 0, 1, 4>), false);
+    V("rw_regnt_st4_none", (launch_rw<0, 1, 1, 4>), false);
     if (only) {   // comma-separated substrings
         std::vector<std::string> pats;
         std::string o(only);

@@ -1,3 +1,5 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-scratch/ab_pmc2.sh r2f 1e9 "t512_reg_full,t512_reg_hotst,t512_reg_al16_nti,rw_reg_st0,rw_reg_st2_al16,rw_reg_st7_lds,rw_reg_st4_none" 2>&1 | tail -80
+mkdir -p gpurun_out/r2g
+timeout 600 scratch/bin/headline_ab 1e9 9 > gpurun_out/r2g/ab_1e9.txt 2>&1
+cat gpurun_out/r2g/ab_1e9.txt

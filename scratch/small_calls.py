@@ -17,3 +17,10 @@ for n in (10, 1000, 100_000, 1_000_000):
         for _ in range(reps): capi.rolling_aggregate(cols, 0, 10, aggs, outs=outs)
         dt = (time.perf_counter() - t0) / reps
         print("n=%-8d %-26s %.1f us per call" % (n, label, dt * 1e6))
+        # with the plan the host keeps from the constructor (newIntervalRolling computes it once): no round trip for first / last ts
+        plan = capi.plan_windows_ex(cols[0], 10, 0)
+        for _ in range(5): capi.rolling_aggregate(cols, 0, 10, aggs, outs=outs, plan=plan)
+        t0 = time.perf_counter()
+        for _ in range(reps): capi.rolling_aggregate(cols, 0, 10, aggs, outs=outs, plan=plan)
+        dt = (time.perf_counter() - t0) / reps
+        print("n=%-8d %-26s %.1f us per call (planned)" % (n, label, dt * 1e6))

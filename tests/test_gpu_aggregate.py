@@ -691,3 +691,71 @@ def test_mode_windows_beyond_the_global_table():
         cand = np.flatnonzero(counts == counts.max())
         want = uniq[cand[np.argmin(last[cand])]]
         assert got[w] == want, (w, got[w], want, counts.max())
+
+
+def test_planned_call_equals_the_plain_call():
+    """bowgpu_rolling_aggregate_planned: the plan the host keeps from the constructor (newIntervalRolling computes it once,
+    rolling.go:69-112) gives the same outputs as the call that makes its own plan; a plan made for another column is rejected."""
+    rng = np.random.default_rng(11)
+    n = 50_000
+    ts = np.cumsum(rng.integers(0, 6, n)).astype(np.int64) - 300
+    vals = rng.standard_normal(n)
+    valid = rng.random(n) > 0.2
+    cols = [capi.Column(ts, None, capi.INT64).to_device(),
+            capi.Column(vals, np.packbits(valid, bitorder="little"), capi.FLOAT64, 0, n, -1).to_device()]
+    aggs = [("WindowStart", 0), ("ArithmeticMean", 1), ("Min", 1), ("Count", 1), ("WeightedAverageLinear", 1)]
+    for interval, offset in ((7, 0), (100, -13), (5000, 4999)):
+        plain, info0 = capi.rolling_aggregate(cols, 0, interval, aggs, offset=offset, out_residency=capi.DEVICE)
+        plan = capi.plan_windows_ex(cols[0], interval, offset)
+        assert (plan.s0, plan.num_windows) == (info0.s0, info0.num_windows) and plan.nrows == n
+        planned, info1 = capi.rolling_aggregate(cols, 0, interval, aggs, offset=offset, out_residency=capi.DEVICE, plan=plan)
+        assert (info1.s0, info1.num_windows, info1.inclusive) == (info0.s0, info0.num_windows, info0.inclusive)
+        for a, b in zip(plain, planned):
+            assert a.length == b.length and a.null_count == b.null_count and a.type == b.type
+            assert np.array_equal(a.host_arrays()[0].view(np.uint64), b.host_arrays()[0].view(np.uint64))
+            assert np.array_equal(a.host_arrays()[1], b.host_arrays()[1])
+    short = [capi.Column(ts[:100], None, capi.INT64).to_device(), capi.Column(vals[:100], None, capi.FLOAT64).to_device()]
+    with pytest.raises(capi.BowGpuError) as e:
+        capi.rolling_aggregate(short, 0, 7, aggs, plan=plan, outs=[capi.OutColumn(plan.num_windows, capi.DEVICE) for _ in aggs])
+    assert e.value.code == -10
+
+
+def test_device_output_bitmaps_of_any_alignment_and_length():
+    """the caller's device validity buffer holds exactly ceil(W/8) bytes at any address: the fused finish kernel must write those
+    bytes and not one more (a guard byte behind the buffer stays intact), clear the padding bits, and count the nulls"""
+    rng = np.random.default_rng(5)
+    for W_target in (1, 7, 8, 9, 31, 32, 33, 63, 64, 65, 1000, 4097):
+        n = W_target * 3
+        ts = np.arange(n, dtype=np.int64)
+        vals = rng.standard_normal(n)
+        valid = rng.random(n) > 0.6
+        bm = np.packbits(valid, bitorder="little")
+        cols = [capi.Column(ts, None, capi.INT64).to_device(), capi.Column(vals, bm, capi.FLOAT64, 0, n, -1).to_device()]
+        aggs = [("WindowStart", 0), ("ArithmeticMean", 1), ("Sum", 1)]
+        want, _ = orc.aggregate([orc.Column(ts, None, orc.INT64), orc.Column(vals, bm, orc.FLOAT64)], 0, 3, aggs)
+        W = want[0].length
+        assert W == W_target
+        nb = (W + 7) // 8
+        for shift in (0, 1, 2, 3):
+            outs = [capi.OutColumn(W, capi.DEVICE) for _ in aggs]
+            raw = []
+            for o in outs:   # validity inside a bigger buffer: [shift guard bytes][ceil(W/8) bytes][guard bytes]
+                big = capi.DeviceBuffer(nb + 16)
+                capi.check(capi.lib().bowgpu_memset(capi.C.c_void_p(big.ptr), 0x5A, capi.C.c_int64(nb + 16)))
+                raw.append(big)
+            oarr = (capi.Out * len(aggs))()
+            for i, o in enumerate(outs):
+                oarr[i] = o.c()
+                oarr[i].validity = raw[i].ptr + shift
+            info = capi.AggInfo()
+            opts = capi.Options(0, 0, 0)
+            capi.check(capi.lib().bowgpu_rolling_aggregate(capi._cols(cols), 2, 0, capi.C.c_int64(3), capi.C.byref(opts), capi._aggs(aggs),
+                                                           len(aggs), oarr, capi.C.byref(info)))
+            capi.synchronize()
+            for i, w in enumerate(want):
+                host = raw[i].to_numpy(np.uint8, nb + 16)
+                assert (host[:shift] == 0x5A).all() and (host[shift + nb:] == 0x5A).all(), (W, shift, i)
+                got_bits = np.unpackbits(host[shift:shift + nb], bitorder="little")
+                assert np.array_equal(got_bits[:W].astype(bool), w.valid_mask()), (W, shift, i)
+                assert not got_bits[W:].any(), (W, shift, i)     # padding bits clear (bowbuffer.go:25)
+                assert oarr[i].null_count == W - int(w.valid_mask().sum()), (W, shift, i)

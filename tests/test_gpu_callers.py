@@ -431,3 +431,24 @@ def test_whole_random_vs_oracle():
             assert gl[0] == wl[0], k
         else:
             assert abs(gl[0] - wl[0]) <= 1e-10 * max(1.0, abs(wl[0])), (k, gl[0], wl[0])
+
+
+def test_window_bounds_across_a_gap_of_millions_of_empty_windows():
+    """Two bursts of rows 3e8 apart with interval 10: 3e7 empty windows between them all take the second burst's first row as
+    their FirstIndex.  One lane used to store them one by one (seconds); the grid fills long runs now."""
+    import time
+    a = np.arange(0, 1000, dtype=np.int64)
+    gap = 300_000_000
+    ts = np.concatenate([a, a + gap, a + 2 * gap + 5])
+    col = capi.Column(ts, None, capi.INT64).to_device()
+    capi.window_bounds(capi.Column(ts[:100], None, capi.INT64), 10)   # warm the context
+    t0 = time.perf_counter()
+    s0, W, first, lo, hi, inc = capi.window_bounds(col, 10)
+    dt = time.perf_counter() - t0
+    assert W == (2 * gap + 5 + 999) // 10 + 1 and s0 == 0
+    k = np.arange(W, dtype=np.int64)
+    want = np.searchsorted(ts, k * 10, side="left")        # FirstIndex = first row at or after the window start
+    assert np.array_equal(first, want)
+    empty = hi == lo
+    assert empty.sum() == W - len(np.unique(ts // 10)) and np.array_equal(lo[~empty], want[~empty])
+    assert dt < 5.0, dt     # (dominated by copying 4 x 8 x 6e7 bytes back to the host)

@@ -20,7 +20,28 @@ N8 = 100_000_000
 N9 = 1_000_000_000
 # the MI355X boxes have hundreds of host cores' worth of RAM: the oracle then checks EVERY output slot even at 1e8 / 1e9 rows
 # (it runs ~250 M rows/s per reducer there); on a small host the same tests fall back to sampled row ranges
-BIG_HOST = psutil.virtual_memory().total > 200e9
+HOST_RAM = psutil.virtual_memory().total
+BIG_HOST = HOST_RAM > 200e9
+# which branch ran is part of the evidence: it goes to the test log (pytest -rA / -s shows it; captured output is kept on failure)
+# and to gpurun_out/fullsize_mode.txt on the GPU box
+_MODE = "host RAM %.0f GB -> full-size outputs are checked on %s" % (HOST_RAM / 1e9, "EVERY slot against the oracle" if BIG_HOST else
+                                                                     "SAMPLED row ranges (small host)")
+print("[test_gpu_fullsize] " + _MODE)
+try:
+    os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"), exist_ok=True)
+    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "fullsize_mode.txt"), "w") as _f:
+        _f.write(_MODE + "\n")
+except OSError:
+    pass
+
+
+def test_headline_check_is_not_sampled_on_a_big_host():
+    """a >= 200 GB host must take the every-slot branch of the headline check (the sampled fallback exists for small dev boxes only)"""
+    import warnings
+    if HOST_RAM >= 200e9:
+        assert BIG_HOST
+    else:
+        warnings.warn("small host (%.0f GB RAM): the 1e8 / 1e9-row outputs are checked on sampled row ranges only" % (HOST_RAM / 1e9))
 
 
 def _paths():

@@ -2,7 +2,7 @@
 counts around the tile sizes, timestamp patterns (dense, irregular, duplicates, gaps, negative / rows below s0), intervals
 and raw offsets, Arrow offsets into longer buffers, null densities from 0 to 100 %, NaN / +-0 / Inf values, mixed column
 types, random reducer lists with Factor chains, inclusive windows, host / device residency - each case through every tile
-kernel that covers it (BOW_FUZZ_SEEDS=N runs N seeds instead of 8).  Bit-exact except Sum / Mean / integrals of windows on the long-window path (1e-11 relative)."""
+kernel that covers it (BOW_FUZZ_SEEDS=N runs N seeds instead of 64).  Bit-exact except Sum / Mean / integrals of windows on the long-window path (1e-11 relative)."""
 import os
 
 import numpy as np
@@ -83,7 +83,7 @@ def run_paths(ccols, ocols, interval, aggs, offset, inclusive, label):
             compare("%s %s path=%s" % (label, a[0], path), g, w, exact=exact, rtol=1e-11)
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("BOW_FUZZ_SEEDS", "8"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BOW_FUZZ_SEEDS", "64"))))
 def test_fuzz_aggregate(seed):
     rng = np.random.default_rng(1000 + seed)
     sizes = [0, 1, 2, 63, 64, 65, 511, 512, 513, 639, 640, 641, 1023, 1025, 2047, 2049, 5000, 40_000]
@@ -141,7 +141,7 @@ def test_fuzz_aggregate(seed):
         run_paths(ccols, ocols, interval, aggs, offset, inclusive_call, label)
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("BOW_FUZZ_SEEDS", "8")) // 2))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BOW_FUZZ_SEEDS", "64")) // 2))
 def test_fuzz_interpolate_and_fills(seed):
     rng = np.random.default_rng(2000 + seed)
     for case in range(40):
@@ -185,7 +185,7 @@ def test_fuzz_interpolate_and_fills(seed):
             assert np.array_equal(se, [w_["slice_end"] for w_ in wins]), label
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("BOW_FUZZ_SEEDS", "8")) // 2))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BOW_FUZZ_SEEDS", "64")) // 2))
 def test_fuzz_sharded(seed):
     """random row-range splits (empty shards, one-row shards, shards smaller than a window) through the real protocol of
     bow_amd/sharded.py on simulated ranks; the stitched result must equal the oracle on the whole frame"""
@@ -231,7 +231,7 @@ def test_fuzz_sharded(seed):
                 assert np.array_equal(gv[gm], wv[wm]), (label, k)
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("BOW_FUZZ_SEEDS", "8")) // 2))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BOW_FUZZ_SEEDS", "64")) // 2))
 def test_fuzz_sharded_interpolate(seed):
     """Rolling.Interpolate over random row-range splits (empty shards, one-row shards): concatenated shard outputs == the oracle on
     the whole frame"""
