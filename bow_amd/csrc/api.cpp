@@ -1852,6 +1852,17 @@ int bowgpu_stream_rw_ceiling(const void *dev_a, const void *dev_b, int64_t bytes
     return 0;
 }
 
+// diagnostic builds only (in-kernel stamps): words [first, first + n) of the calling thread's device status block
+int bowgpu_debug_status(int32_t first, int32_t n, uint32_t *out, int32_t zero_after) {
+    Ctx *c;
+    BG_TRY(ctx_get(&c));
+    if (!out || first < 0 || n <= 0 || (size_t)(first + n) * 4 > 8192 || !c->d_scratch) return fail(BOWGPU_ERR_ARG, "bad status range");
+    BG_HIP(hipMemcpyAsync(out, reinterpret_cast<uint32_t *>(c->d_scratch) + first, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    BG_HIP(hipStreamSynchronize(c->stream));
+    if (zero_after) BG_HIP(hipMemsetAsync(reinterpret_cast<uint32_t *>(c->d_scratch) + first, 0, (size_t)n * 4, c->stream));
+    return 0;
+}
+
 int bowgpu_checksum64(const void *dev, int64_t n_words, uint64_t *xor_out, uint64_t *sum_out) {
     Ctx *c;
     BG_TRY(ctx_get(&c));

@@ -59,7 +59,7 @@ struct Ctx {
         int has_left = 0;
         uint64_t gen = 0;                   // pool_gen of the prefix block when it was written
         int64_t s0 = 0, W = 0, first_ts = 0, last_ts = 0, offset_norm = 0, kq = -1, drop = 0, M = 0, wbase = 0;
-        int kq_empty = 0;
+        int kq_empty = 0, inclusive = 0, e0 = 0;
     } interp_cache;
     void *d_params = nullptr;      // 4 KB device block holding the kernels' descriptor struct
 };
@@ -329,6 +329,7 @@ struct InterpParams {
     int32_t ncols, ts_col;
     int32_t allow_wave2;               // the whole-trip wave kernel may take the call (0: the call is being redone after its run list overflowed)
     int32_t kq_empty;                  // window kq has no row of its own (pass 1's finding)
+    int32_t inclusive, e0;             // Options.Inclusive (interp_wave2_kernel<true> only); e0: row 0 sits exactly on the first window's start
     InterpCol cols[kMaxCols];
 };
 int64_t interp_tiles(int64_t n);

@@ -131,7 +131,6 @@ static int interp_validate(const bowgpu_col *cols, int32_t ncols, int32_t ts_col
         const int t = cols[i].type;
         if (t != BOWGPU_INT64 && t != BOWGPU_FLOAT64) return fail(BOWGPU_ERR_UNSUPPORTED, "column type %s is outside the device path", type_name(t));
     }
-    if (o->inclusive) return fail(BOWGPU_ERR_UNSUPPORTED, "Interpolate on inclusive windows duplicates rows in the reference; not on the device path");
     return 0;
 }
 
@@ -144,18 +143,19 @@ struct InterpJob {
     int64_t drop = 0; // leading rows that belong to no window (InterpParams::drop)
     int64_t M = 0;    // output rows - input rows
     int kq_empty = 0; // window kq has no row of its own
+    int e0 = 0;       // inclusive windows: row 0 sits exactly on the first window's start
     int has_left = 0; // sharded Interpolate: rows exist to the left, the last of them at left_ts, in window wbase - 1
     int64_t left_ts = 0, wbase = 0;
 };
 
 // pass 1 of interpolate.hip: exact heads per tile, their exclusive scan, M = synthetic rows
 // shard: global_s0 + edge of a row-range shard (nullptr: the whole frame)
-static bool interp_cache_hit(Ctx *c, const bowgpu_col *ts, int64_t interval, int64_t raw_offset, const int64_t *global_s0,
+static bool interp_cache_hit(Ctx *c, const bowgpu_col *ts, int64_t interval, int64_t raw_offset, int inclusive, const int64_t *global_s0,
                              const bowgpu_interp_edge *edge) {
     const Ctx::InterpCache &k = c->interp_cache;
     if (!k.valid || ts->residency != BOWGPU_DEVICE) return false;   // (a host column is staged into a fresh device copy per call)
     if (k.ts_values != ts->values || k.ts_offset != ts->offset || k.n != ts->length || k.interval != interval || k.raw_offset != raw_offset) return false;
-    if (k.sharded != (global_s0 != nullptr)) return false;
+    if (k.sharded != (global_s0 != nullptr) || k.inclusive != (inclusive ? 1 : 0)) return false;
     if (global_s0 && (k.global_s0 != *global_s0 || k.has_left != ((edge && edge->has_left) ? 1 : 0) || (k.has_left && k.left_ts != edge->left_last_ts))) return false;
     return k.gen == c->pool_gen[kPoolInterp + 1] && c->pool[kPoolInterp + 1] != nullptr;
 }
@@ -165,14 +165,14 @@ static int interp_prepare(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t
                           bool use_cache = false) {
     // The _fill call right after _count on the same device-resident, unchanged interval column (Bows are immutable in the
     // reference; include/bowgpu.h states the contract): pass 1's prefix is still in the context pool
-    if (use_cache && interp_cache_hit(c, &cols[ts_col], interval, o->offset, global_s0, edge)) {
+    if (use_cache && interp_cache_hit(c, &cols[ts_col], interval, o->offset, o->inclusive, global_s0, edge)) {
         const Ctx::InterpCache &k = c->interp_cache;
         for (int i = 0; i < ncols; i++)
             if (cols[i].length != k.n) return fail(BOWGPU_ERR_ARG, "column %d has a different length", i);
         job->plan.interval = interval; job->plan.offset = k.offset_norm; job->plan.s0 = k.s0; job->plan.W = k.W;
         job->plan.first_ts = k.first_ts; job->plan.last_ts = k.last_ts; job->plan.magic = magic_make((uint64_t)interval);
         job->kq = k.kq; job->drop = k.drop; job->M = k.M; job->wbase = k.wbase; job->has_left = k.has_left; job->left_ts = k.left_ts;
-        job->kq_empty = k.kq_empty;
+        job->kq_empty = k.kq_empty; job->e0 = k.e0;
         job->tile_before = c->pool[kPoolInterp + 1];
         BG_TRY(ts_device(c, &cols[ts_col], &job->dts));
         c->interp_cache.valid = false;   // one use: the outputs of this fill may be what the next call reads
@@ -211,7 +211,7 @@ static int interp_prepare(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t
         const int64_t k = (int64_t)((uint64_t)(-1 - pl.s0) / (uint64_t)pl.interval);
         if (k < W) job->kq = k;
     }
-    const int64_t ntiles = interp_tiles(n);
+    const int64_t ntiles = 2 * interp_tiles(n);   // exact heads are counted per 256 rows: two entries per tile of the count kernel
     BG_TRY(ctx_pool(c, kPoolInterp + 0, (size_t)ntiles * 4 + 16, &job->tile_exact));
     BG_TRY(ctx_pool(c, kPoolInterp + 1, (size_t)(ntiles + 1) * 8, &job->tile_before));
     BG_TRY(ctx_pool(c, kPoolInterp + 2, (size_t)((ntiles + 2047) / 2048 + 1) * 8, &job->block_sums));
@@ -232,6 +232,17 @@ static int interp_prepare(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t
     if (hstat[0]) return fail(BOWGPU_ERR_TS_UNSORTED, "interval column is not ascending: outside the device path");
     job->drop = (int64_t)(((uint64_t)hstat[3] << 32) | hstat[2]);
     job->kq_empty = hstat[1] ? 1 : 0;
+    if (o->inclusive) {
+        // Inclusive windows (rolling.go:201-209 + interpolation.go:98-116): a row on a window's end is also the last row of that
+        // window's bow, so it appears twice in the concatenation - every window then contributes exactly one row in front of
+        // its first row (a synthetic row, or that copy), except window 0 when row 0 sits on its start: n + W - e0 rows.  The
+        // whole-trip wave kernel takes them; its preconditions (interp_fast32, no dropped rows, no -1 sentinel window) bound the shape.
+        if (global_s0) return fail(BOWGPU_ERR_UNSUPPORTED, "sharded Interpolate on inclusive windows is outside the device path");
+        if (!interp_fast32(pl, job->kq) || job->drop != 0)
+            return fail(BOWGPU_ERR_UNSUPPORTED, "Interpolate on inclusive windows: rows outside [s0, s0 + 2^31) or below s0 are outside the device path");
+        job->e0 = pl.first_ts == pl.s0 ? 1 : 0;
+        job->M = W - job->e0;
+    } else
     job->M = W - total - ((job->kq >= 0 && hstat[1]) ? 1 : 0) - job->drop;  // rows added (synthetic) minus rows dropped
     {
         Ctx::InterpCache &k = c->interp_cache;
@@ -242,6 +253,7 @@ static int interp_prepare(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t
         k.gen = c->pool_gen[kPoolInterp + 1];
         k.s0 = pl.s0; k.W = pl.W; k.first_ts = pl.first_ts; k.last_ts = pl.last_ts; k.offset_norm = pl.offset;
         k.kq = job->kq; k.drop = job->drop; k.M = job->M; k.wbase = job->wbase; k.kq_empty = job->kq_empty;
+        k.inclusive = o->inclusive ? 1 : 0; k.e0 = job->e0;
         k.valid = tsc->residency == BOWGPU_DEVICE;
     }
     return 0;
@@ -276,7 +288,7 @@ static int interp_fill_impl(const bowgpu_col *cols, int32_t ncols, int32_t ts_co
     bowgpu_options o = {0, 0, 0};
     if (opts) o = *opts;
     Ctx *c = nullptr;
-    const bool cached = cols[ts_col].length > 0 && ctx_get(&c) == 0 && interp_cache_hit(c, &cols[ts_col], interval, o.offset, global_s0, edge);
+    const bool cached = cols[ts_col].length > 0 && ctx_get(&c) == 0 && interp_cache_hit(c, &cols[ts_col], interval, o.offset, o.inclusive, global_s0, edge);
     if (!cached) {   // (the _count call that filled the cache ran these checks on the same arguments)
         Plan probe;
         BG_TRY(plan_make(nullptr, &cols[ts_col], interval, o.offset, &probe));
@@ -307,6 +319,7 @@ static int interp_fill_impl(const bowgpu_col *cols, int32_t ncols, int32_t ts_co
     P.status = reinterpret_cast<uint32_t *>(dscr);
     P.kq = job.kq;
     P.kq_empty = job.kq_empty;
+    P.inclusive = o.inclusive ? 1 : 0; P.e0 = job.e0;
     P.drop = job.drop;
     P.has_left = job.has_left; P.left_ts = job.left_ts; P.wbase = job.wbase;
     P.fast32 = interp_fast32(job.plan, job.kq) ? 1 : 0;
@@ -365,6 +378,8 @@ static int interp_fill_impl(const bowgpu_col *cols, int32_t ncols, int32_t ts_co
         return 0;
     };
     BG_TRY(run_all(1));
+    if (hstat[5] && o.inclusive)
+        return fail(BOWGPU_ERR_UNSUPPORTED, "Interpolate on inclusive windows: windows shorter than two rows on average are outside the device path");
     if (hstat[5]) BG_TRY(run_all(0));   // some trip has more runs of synthetic rows than interp_wave2_kernel lists: the first wave kernel takes the call
     if (hstat[0]) return fail(BOWGPU_ERR_TS_UNSORTED, "interval column is not ascending: outside the device path");
     for (int i = 0; i < ninterps; i++) BG_TRY(devout_finish(c, &douts[i], n_out, cols[i].type, n_out - (int64_t)hcnt[i], false));

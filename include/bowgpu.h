@@ -499,6 +499,9 @@ int bowgpu_stream_read_ceiling(const void *dev_a, const void *dev_b, int64_t byt
  * roofline.achieved does.  Measurement aid for bench.py ("stream_rw_ceiling"). */
 int bowgpu_stream_rw_ceiling(const void *dev_a, const void *dev_b, int64_t bytes_each, void *out_a, void *out_b,
                              int64_t rows_per_slot, double *read_gb_per_s, double *ms /* nullable */);
+/* Diagnostic builds only (kernels compiled with in-kernel stamps): words [first, first + n) of the calling thread's device
+ * status block; zero_after clears them.  The product build never writes those words. */
+int bowgpu_debug_status(int32_t first, int32_t n, uint32_t *out, int32_t zero_after);
 /* order-independent 64-bit checksum of a device buffer of n 8-byte words (xor / sum of mix) */
 int bowgpu_checksum64(const void *dev, int64_t n_words, uint64_t *xor_out, uint64_t *sum_out);
 

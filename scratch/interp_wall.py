@@ -1,0 +1,40 @@
+"""Interpolate(WindowStart, Linear) on the configs[2] shape (1e8 rows, 30 % nulls, interval 100): wall time of the _count call, of the
+_fill call that follows it (outputs allocated once, outside the timing), and of both; BOWGPU_INTERP_WAVE1=1 / BOWGPU_INTERP_TILE=1
+switch to the older kernels for an A/B in one process."""
+import os, sys, time
+sys.path.insert(0, '.')
+import ctypes as C
+from bow_amd import capi
+n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 100_000_000
+ts, val = capi.gen_sparse(0, n, seed=42)
+cols = [ts, val]
+ip = [{"kind": "WindowStart", "col": 0}, {"kind": "Linear", "col": 1}]
+carr, iarr = capi._cols(cols), capi._interps(ip)
+opts = capi.Options(0, 0, 0)
+L = capi.lib()
+def count():
+    m = C.c_int64(0)
+    capi.check(L.bowgpu_rolling_interpolate_count(carr, 2, 0, C.c_int64(100), C.byref(opts), iarr, 2, C.byref(m)))
+    return m.value
+n_out = count()
+outs = [capi.OutColumn(n_out, capi.DEVICE) for _ in ip]
+oarr = (capi.Out * 2)()
+def fill():
+    for i, o in enumerate(outs):
+        oarr[i] = o.c()
+    capi.check(L.bowgpu_rolling_interpolate_fill(carr, 2, 0, C.c_int64(100), C.byref(opts), iarr, 2, oarr))
+def timeit(fn, reps=10):
+    fn(); capi.synchronize()
+    t = []
+    for _ in range(reps):
+        t0 = time.perf_counter(); fn(); capi.synchronize(); t.append((time.perf_counter() - t0) * 1e3)
+    t.sort()
+    return t[len(t) // 2]
+for label, env in (("wave2 (default)", {}), ("wave1", {"BOWGPU_INTERP_WAVE1": "1"}), ("tile", {"BOWGPU_INTERP_TILE": "1"})):
+    for k in ("BOWGPU_INTERP_WAVE1", "BOWGPU_INTERP_TILE"):
+        os.environ[k] = env.get(k, "0")
+    both = timeit(lambda: (count(), fill()))
+    c_ms = timeit(count)
+    f_alone = timeit(fill)              # no _count in front: the fill call makes its own pass 1
+    print("%-32s %d -> %d rows: count %.3f ms, count+fill %.3f ms (%.1f G rows/s), fill without a preceding count %.3f ms" %
+          (label, n, n_out, c_ms, both, n / both / 1e6, f_alone))

@@ -1,21 +1,31 @@
 #!/bin/bash
-# usage: scratch/pmc_any.sh <tag> <kernel substring> <python script...> : FETCH_SIZE / WRITE_SIZE / busy counters of one kernel
+# usage: scratch/pmc_any.sh <tag> <kernel substring> <python script...> : HBM traffic / SQ busy-wait / LDS counters of one kernel, separate passes
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 TAG=$1; KSUB=$2; shift; shift
 OUT=gpurun_out/pmc_$TAG
 rm -rf $OUT && mkdir -p $OUT
 i=0
-for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum TCC_EA_WRREQ_sum TCC_EA_WRREQ_64B_sum"; do
+for C in "FETCH_SIZE" "WRITE_SIZE" \
+         "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
+         "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_ANY SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA" \
+         "SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_SMEM SQ_INST_LEVEL_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_FLAT SQ_INSTS_BRANCH SQ_IFETCH" \
+         "TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE"; do
   i=$((i+1))
   timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/p$i -- python3 "$@" > $OUT/p$i.log 2>&1
 done
-python3 - <<PY
+python3 - <<PY | tee $OUT/summary.txt
 import csv, glob, collections
 acc = collections.defaultdict(list)
+dur = []
 for f in glob.glob("$OUT/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         if "$KSUB" in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+for f in glob.glob("$OUT/p1/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "$KSUB" in r["Kernel_Name"]:
+            dur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+print("kernel %s: n=%d median %.4f ms" % ("$KSUB", len(dur), sorted(dur)[len(dur) // 2] if dur else 0))
 for k, v in sorted(acc.items()):
     print("%-26s n=%d avg=%.5g" % (k, len(v), sum(v) / len(v)))
 PY

@@ -29,27 +29,31 @@ def _interps(spec):
 
 
 def both_interp_kernels(fn):
-    """runs fn() under both Interpolate tile kernels (the barrier-free wave kernel takes the usual shapes; BOWGPU_INTERP_TILE=1
-    keeps them on the workgroup kernel that serves the rest), checks that they agree bit for bit, returns the first result"""
+    """runs fn() under all three Interpolate kernels - the whole-trip wave kernel (default for the usual shapes), the first wave
+    kernel (BOWGPU_INTERP_WAVE1=1) and the workgroup kernel that serves the rest (BOWGPU_INTERP_TILE=1) - checks that they agree
+    bit for bit, returns the first result"""
     import os
     res = []
-    for flag in ("0", "1"):
-        os.environ["BOWGPU_INTERP_TILE"] = flag
+    for env in ({}, {"BOWGPU_INTERP_WAVE1": "1"}, {"BOWGPU_INTERP_TILE": "1"}):
+        for k in ("BOWGPU_INTERP_WAVE1", "BOWGPU_INTERP_TILE"):
+            os.environ[k] = env.get(k, "0")
         try:
             res.append(fn())
         finally:
+            os.environ["BOWGPU_INTERP_WAVE1"] = "0"
             os.environ["BOWGPU_INTERP_TILE"] = "0"
-    a, b = res
-    if isinstance(a, list) and a and isinstance(a[0], list):   # one list of columns per shard
-        a_cols, b_cols = [c for sh in a for c in sh], [c for sh in b for c in sh]
-    else:
-        a_cols, b_cols = list(a), list(b)
-    assert len(a_cols) == len(b_cols)
-    for x, y in zip(a_cols, b_cols):
-        assert x.length == y.length and x.null_count == y.null_count
-        xv, xb = x.host_arrays()
-        yv, yb = y.host_arrays()
-        assert np.array_equal(xv.view(np.uint64), yv.view(np.uint64)) and np.array_equal(xb, yb)
+    a = res[0]
+    for b in res[1:]:
+        if isinstance(a, list) and a and isinstance(a[0], list):   # one list of columns per shard
+            a_cols, b_cols = [c for sh in a for c in sh], [c for sh in b for c in sh]
+        else:
+            a_cols, b_cols = list(a), list(b)
+        assert len(a_cols) == len(b_cols)
+        for x, y in zip(a_cols, b_cols):
+            assert x.length == y.length and x.null_count == y.null_count
+            xv, xb = x.host_arrays()
+            yv, yb = y.host_arrays()
+            assert np.array_equal(xv.view(np.uint64), yv.view(np.uint64)) and np.array_equal(xb, yb)
     return a
 
 
@@ -452,3 +456,35 @@ def test_window_bounds_across_a_gap_of_millions_of_empty_windows():
     empty = hi == lo
     assert empty.sum() == W - len(np.unique(ts // 10)) and np.array_equal(lo[~empty], want[~empty])
     assert dt < 5.0, dt     # (dominated by copying 4 x 8 x 6e7 bytes back to the host)
+
+
+@pytest.mark.parametrize("vtype", ["f64", "i64"])
+def test_interpolate_on_inclusive_windows(vtype):
+    """Options.Inclusive + Interpolate: the reference concatenates the window bows, and an inclusive window's bow also holds the
+    row that sits exactly on its end (rolling.go:201-209, interpolation.go:98-116) - that row appears twice.  Against the
+    oracle's literal window walk: dense rows on the grid (every window start is a row), irregular rows, runs of empty windows."""
+    rng = np.random.default_rng(21)
+    typ = capi.FLOAT64 if vtype == "f64" else capi.INT64
+    cases = []
+    for n, interval, offset in [(1, 5, 0), (2, 5, 0), (40, 3, 1), (5000, 10, 0), (60_000, 100, 7), (30_000, 4, 0)]:
+        cases.append((np.cumsum(rng.integers(1, 9, n)).astype(np.int64) + 3, interval, offset))
+    cases.append((np.arange(0, 50_000, 5, dtype=np.int64), 10, 0))              # every other row sits on a window start
+    cases.append((np.arange(0, 20_000, dtype=np.int64) * 10, 10, 0))            # every row does
+    step = rng.integers(1, 4, 20_000)
+    step[rng.random(20_000) < 0.004] = rng.integers(500, 20_000)
+    cases.append((np.cumsum(step).astype(np.int64), 10, 3))                     # long runs of empty windows
+    cases.append((np.repeat(np.arange(0, 3000, dtype=np.int64) * 7, 3), 7, 0))  # duplicated timestamps on window starts: only the first is the inclusive row
+    for ts, interval, offset in cases:
+        n = len(ts)
+        vals = np.round(rng.standard_normal(n) * 100, 2) if vtype == "f64" else rng.integers(-1000, 1000, n).astype(np.int64)
+        valid = rng.random(n) >= 0.3
+        bm = np.packbits(valid, bitorder="little")
+        for kind in ["Linear", "StepPrevious", "None"]:
+            ip = [{"kind": "WindowStart", "col": 0}, {"kind": kind, "col": 1}]
+            got = capi.rolling_interpolate([capi.Column(ts).to_device(), capi.Column(vals, bm, typ, 0, n, -1).to_device()], 0, interval, ip,
+                                           offset=offset, inclusive=True)
+            want = orc.interpolate([orc.Column(ts, None, orc.INT64), orc.Column(vals, bm, typ)], 0, interval, ip, offset=offset, inclusive=True)
+            cmp_out("inclusive ts %s n=%d I=%d" % (kind, n, interval), got[0], want[0])
+            cmp_out("inclusive val %s n=%d I=%d" % (kind, n, interval), got[1], want[1])
+            plain = orc.interpolate([orc.Column(ts, None, orc.INT64), orc.Column(vals, bm, typ)], 0, interval, ip, offset=offset)
+            assert want[0].length >= plain[0].length
