@@ -801,7 +801,12 @@ static int job_launch_tiles(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t
         S.status = P.status; S.long_list = P.long_list; S.long_cap = P.long_cap;
         S.inclusive = job->inclusive ? 1 : 0;
         if (tw) {
-            BG_TRY(launch_rolling_tw(c, S, is_int, has_nulls, wide));
+            // 32-bit staged timestamps: exact when float64(s0 of slot 0) + float64(offset) needs no rounding, i.e. every |ts| < 2^53
+            // (BOWGPU_TW_F64=1: test / A-B switch that keeps the float64 form)
+            const int64_t lim53 = 1ll << 53;
+            const char *f64 = getenv("BOWGPU_TW_F64");
+            const bool ts32 = !wide && plan->first_ts > -lim53 && plan->last_ts < lim53 && S.s0 > -lim53 && !(f64 && f64[0] == '1');
+            BG_TRY(launch_rolling_tw(c, S, is_int, has_nulls, wide, ts32));
             c->last_kernel_name = "rolling_tw_kernel";
         } else {
             BG_TRY(launch_rolling_simple(c, S, need, is_int, has_nulls, wide));

@@ -8,6 +8,8 @@
 // successor starts exactly at its end also folds that first row of the successor in for the reducers that declared
 // NeedInclusiveWindow, while the others see the window without it (Window.UnsetInclusive, window.go:23-31).
 // What this kernel does not take goes to rolling_agg.hip (rows below s0, mixed column types, 64-bit window ids).
+#include <type_traits>
+
 #include "agg_device.h"
 
 namespace bowgpu {
@@ -24,9 +26,14 @@ constexpr uint32_t kSatT = 0xFFFFu;
 // send the call to the general kernel.  A wave's LDS: 11.8 KB => 13 resident waves per CU.
 constexpr int kSegCapT = 400;
 
+// kTs32: the timestamps are staged as 32-bit offsets from the tile's base window start instead of float64 values (half the LDS:
+// 9.4 KB per wavefront => 17 resident per CU instead of 13; the kernel's rate follows its occupancy).  float64(ts) is then rebuilt
+// as float64(base) + float64(offset), which is exact - and so equal to the reference's single conversion (integral.go:17) - when
+// every |ts| of the call is below 2^53 (the host checks; nanosecond epochs take the float64 form).
+template <bool kTs32>
 struct TwShared {
     uint64_t val[kRowsT];
-    double tsf[kRowsT];          // float64(ts) of every row of the tile (integral.go:17)
+    typename std::conditional<kTs32, uint32_t, double>::type tsf[kRowsT];   // float64(ts) of every row of the tile (integral.go:17), or its 32-bit offset
     uint32_t vbits[kRowsT / 32 + 2];  // validity words of the value column for this tile (kNulls only)
     uint32_t seg[kSegCapT + 2];  // heads in row order: local row | on-window-start flag << 15 | (wid - wid of the tile's first row) << 16
 };
@@ -38,6 +45,14 @@ __device__ __forceinline__ uint32_t mdiv32(uint32_t n, uint32_t m, uint32_t sh1,
 __device__ __forceinline__ uint32_t left32(uint32_t x, uint32_t lane0) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)lane0, (int)x, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
 }
+// non-temporal 16-byte loads / 8-byte stores: see rolling_simple.hip (rows 128..511 of a tile are read by this wavefront only;
+// outputs are never read back)
+typedef unsigned long long u64x2_tw __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ ulonglong2 load16_nt(const ulonglong2 *q) {
+    const u64x2_tw v = __builtin_nontemporal_load(reinterpret_cast<const u64x2_tw *>(q));
+    return make_ulonglong2(v.x, v.y);
+}
+__device__ __forceinline__ void store8_nt(uint64_t *p, uint64_t v) { __builtin_nontemporal_store(v, p); }
 __device__ __forceinline__ void lds_order() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     asm volatile("" ::: "memory");
@@ -48,10 +63,11 @@ __device__ __forceinline__ void lds_order() {
 
 // kInt: Int64 value columns; kNulls: some column has nulls
 // kWide: see rolling_simple.hip (window ids relative to the tile's first window: rows may span more than 2^32 from slot 0)
-template <bool kInt, bool kNulls, bool kWide>
+template <bool kInt, bool kNulls, bool kWide, bool kTs32>
 __global__ __launch_bounds__(kWave, 3) void rolling_tw_kernel(const SimpleParams p, const int64_t ntiles, const int64_t tiles_per_xcd) {
+    static_assert(!(kWide && kTs32), "the wide form keeps float64 timestamps");
     constexpr bool kMulti = true;  // one pass per value column, always in loop form
-    __shared__ TwShared sh;
+    __shared__ TwShared<kTs32> sh;
     const int64_t b = blockIdx.x;
     const int64_t tile = (b & 7) * tiles_per_xcd + (b >> 3);  // XCD-contiguous tile runs (look-ahead rows hit the same L2)
     if (tile >= ntiles) return;
@@ -68,7 +84,10 @@ __global__ __launch_bounds__(kWave, 3) void rolling_tw_kernel(const SimpleParams
         if (interior) {
             const ulonglong2 *q = reinterpret_cast<const ulonglong2 *>(src + base) + lane;
 #pragma unroll
-            for (int j = 0; j < kChunksT; j++) { const ulonglong2 x = q[j * 64]; a[j] = x.x; bb[j] = x.y; }
+            for (int j = 0; j < kChunksT; j++) {
+                const ulonglong2 x = (j > 0 && j < kChunksT - 1) ? load16_nt(q + j * 64) : q[j * 64];
+                a[j] = x.x; bb[j] = x.y;
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < kChunksT; j++) load_pair(src, base + j * 128 + 2 * lane, n, true, a[j], bb[j]);
@@ -136,8 +155,8 @@ __global__ __launch_bounds__(kWave, 3) void rolling_tw_kernel(const SimpleParams
         left_w = (uint32_t)__builtin_amdgcn_readlane((int)wb, 63);
         left_ts = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(tb[j] >> 32), 63) << 32) |
                             (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)tb[j], 63));
-        sh.tsf[l] = (double)tsa;
-        sh.tsf[l + 1] = (double)tsb;
+        if (kTs32) { sh.tsf[l] = ra; sh.tsf[l + 1] = rb; }
+        else { sh.tsf[l] = (double)tsa; sh.tsf[l + 1] = (double)tsb; }
     }
     if (__ballot(unsorted)) {  // the call fails with BOWGPU_ERR_TS_UNSORTED
         if (lane == 0) atomicOr(&p.status[0], 1u);
@@ -150,6 +169,15 @@ __global__ __launch_bounds__(kWave, 3) void rolling_tw_kernel(const SimpleParams
     }
 
     const bool reaches_end = base + kRowsT >= n;
+    // which running statistics the outputs of this call read (wave-uniform: the walk skips the others' arithmetic; a call with
+    // WeightedAverageStep alone then does two float64 operations per row instead of seven)
+    bool need_step = false, need_trap = false, need_mm = false;
+    for (int a = 0; a < p.naggs; a++) {
+        const int k = p.kind[a];
+        need_step |= k == BOWGPU_AGG_INTEGRAL_STEP || k == BOWGPU_AGG_WAVG_STEP;
+        need_trap |= k == BOWGPU_AGG_INTEGRAL_TRAPEZOID || k == BOWGPU_AGG_WAVG_LINEAR;
+        need_mm |= k == BOWGPU_AGG_MIN || k == BOWGPU_AGG_MAX;
+    }
     // windows of the call, as an id relative to w0 (the last tile's successor id when the data ends in it)
     const uint64_t Wrel = (uint64_t)p.W - w0;
     const uint32_t W32 = Wrel > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)Wrel;
@@ -205,22 +233,35 @@ __global__ __launch_bounds__(kWave, 3) void rolling_tw_kernel(const SimpleParams
         uint64_t first_raw = 0, last_raw = 0;
         int count = 0;
         double pt = 0.0, pv = 0.0, integ_step = 0.0, integ_trap = 0.0;
-        for (int r = r0; r < r1; r++) {
-            if (kNulls && !((sh.vbits[r >> 5] >> (r & 31)) & 1u)) continue;
-            const uint64_t raw = sh.val[r];
+        const double ws0_d = (double)ws0;
+        auto ts_at = [&](int r) -> double { return kTs32 ? ws0_d + (double)(uint32_t)sh.tsf[r] : (double)sh.tsf[r]; };
+        auto step = [&](uint64_t raw, double t) {   // one valid row, in row order
             const double x = cint ? (double)(int64_t)raw : __longlong_as_double((long long)raw);
-            const double t = sh.tsf[r];
             sum += x;
             if (count == 0) { mn = x; mx = x; first_raw = raw; }
             else {
-                if (x < mn) mn = x;
-                if (x > mx) mx = x;
-                integ_trap += (pv + x) / 2 * (t - pt);
-                integ_step += pv * (t - pt);
+                if (need_mm) { if (x < mn) mn = x; if (x > mx) mx = x; }
+                const double dt = t - pt;
+                if (need_trap) integ_trap += (pv + x) / 2 * dt;
+                if (need_step) integ_step += pv * dt;
             }
             pt = t; pv = x;
             last_raw = raw;
             count++;
+        };
+        if (!kNulls) {
+            int r = r0;
+            for (; r + 4 <= r1; r += 4) {   // four rows' LDS reads in flight; the arithmetic stays in row order
+                const uint64_t q0 = sh.val[r], q1 = sh.val[r + 1], q2 = sh.val[r + 2], q3 = sh.val[r + 3];
+                const double t0 = ts_at(r), t1 = ts_at(r + 1), t2 = ts_at(r + 2), t3 = ts_at(r + 3);
+                step(q0, t0); step(q1, t1); step(q2, t2); step(q3, t3);
+            }
+            for (; r < r1; r++) step(sh.val[r], ts_at(r));
+        } else {
+            for (int r = r0; r < r1; r++) {
+                if (!((sh.vbits[r >> 5] >> (r & 31)) & 1u)) continue;
+                step(sh.val[r], ts_at(r));
+            }
         }
         // the same state with the inclusive row folded in (only the trapezoid integral and its point count are read)
         double integ_trap_incl = integ_trap;
@@ -228,7 +269,7 @@ __global__ __launch_bounds__(kWave, 3) void rolling_tw_kernel(const SimpleParams
         if (incl_row && (!kNulls || ((sh.vbits[r1 >> 5] >> (r1 & 31)) & 1u))) {
             const uint64_t raw = sh.val[r1];
             const double x = cint ? (double)(int64_t)raw : __longlong_as_double((long long)raw);
-            if (count > 0) integ_trap_incl += (pv + x) / 2 * (sh.tsf[r1] - pt);
+            if (count > 0) integ_trap_incl += (pv + x) / 2 * (ts_at(r1) - pt);
             count_incl++;
         }
         const int nrows = r1 - r0;
@@ -280,7 +321,7 @@ __global__ __launch_bounds__(kWave, 3) void rolling_tw_kernel(const SimpleParams
                 bits = 0;
                 atomicAnd(&p.out_valid[a][slot >> 5], ~(1u << (slot & 31)));
             }
-            p.out_values[a][slot] = bits;
+            store8_nt(&p.out_values[a][slot], bits);
             // the empty windows right after this one (rare): values of an empty slice + cleared validity bits
             // (A.9 "Empty slice": WindowStart s_k ; Sum 0.0 ; Count 0 ; NumRows 0.0 ; the rest nil)
             for (uint32_t g = 1; g <= gap; g++) {
@@ -299,17 +340,18 @@ __global__ __launch_bounds__(kWave, 3) void rolling_tw_kernel(const SimpleParams
     }  // columns
 }
 
-int launch_rolling_tw(Ctx *c, const SimpleParams &p, bool is_int, bool has_nulls, bool wide) {
+int launch_rolling_tw(Ctx *c, const SimpleParams &p, bool is_int, bool has_nulls, bool wide, bool ts32) {
     if (p.n <= 0) return 0;
     const int64_t ntiles = (p.n + kTileT - 1) / kTileT;
     const int64_t per_xcd = (ntiles + 7) / 8;
     const int64_t grid = per_xcd * 8;
     if (grid > 0x7FFFFFFFll) return fail(BOWGPU_ERR_UNSUPPORTED, "too many rows for one launch: %lld", (long long)p.n);
     const dim3 g((unsigned)grid), blk(kWave);
-#define BG_TW(I, U)                                                                                             \
-    do {                                                                                                        \
-        if (wide) hipLaunchKernelGGL((rolling_tw_kernel<I, U, true>), g, blk, 0, c->stream, p, ntiles, per_xcd);  \
-        else hipLaunchKernelGGL((rolling_tw_kernel<I, U, false>), g, blk, 0, c->stream, p, ntiles, per_xcd);      \
+#define BG_TW(I, U)                                                                                                      \
+    do {                                                                                                                 \
+        if (wide) hipLaunchKernelGGL((rolling_tw_kernel<I, U, true, false>), g, blk, 0, c->stream, p, ntiles, per_xcd);    \
+        else if (ts32) hipLaunchKernelGGL((rolling_tw_kernel<I, U, false, true>), g, blk, 0, c->stream, p, ntiles, per_xcd); \
+        else hipLaunchKernelGGL((rolling_tw_kernel<I, U, false, false>), g, blk, 0, c->stream, p, ntiles, per_xcd);       \
     } while (0)
     if (is_int) { if (has_nulls) BG_TW(true, true); else BG_TW(true, false); }
     else { if (has_nulls) BG_TW(false, true); else BG_TW(false, false); }

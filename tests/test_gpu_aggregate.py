@@ -759,3 +759,33 @@ def test_device_output_bitmaps_of_any_alignment_and_length():
                 assert np.array_equal(got_bits[:W].astype(bool), w.valid_mask()), (W, shift, i)
                 assert not got_bits[W:].any(), (W, shift, i)     # padding bits clear (bowbuffer.go:25)
                 assert oarr[i].null_count == W - int(w.valid_mask().sum()), (W, shift, i)
+
+
+def test_time_weighted_kernel_timestamp_forms_agree():
+    """rolling_tw_kernel stages the interval column either as float64(ts) or - when every |ts| < 2^53, where it is exact - as
+    32-bit offsets rebuilt to float64 in the walk (BOWGPU_TW_F64=1 keeps the float64 form): bit-identical outputs, both equal to
+    the oracle; timestamps at and beyond 2^53 must take the float64 form by themselves."""
+    rng = np.random.default_rng(53)
+    aggs = [("WindowStart", 0), ("IntegralStep", 1), ("IntegralTrapezoid", 1), ("WeightedAverageStep", 1), ("WeightedAverageLinear", 1),
+            ("ArithmeticMean", 1), ("Min", 1)]
+    for shift in (0, -10**6, (1 << 53) - 5000, (1 << 60)):
+        n = 30_000
+        ts = (np.cumsum(rng.integers(0, 5, n)).astype(np.int64) + shift)
+        vals = np.round(rng.standard_normal(n) * 10, 3)
+        valid = rng.random(n) > 0.25
+        bm = np.packbits(valid, bitorder="little")
+        cols = [capi.Column(ts, None, capi.INT64).to_device(), capi.Column(vals, bm, capi.FLOAT64, 0, n, -1).to_device()]
+        want, _ = orc.aggregate([orc.Column(ts, None, orc.INT64), orc.Column(vals, bm, orc.FLOAT64)], 0, 7, aggs, offset=2)
+        res = []
+        for flag in ("0", "1"):
+            os.environ["BOWGPU_TW_F64"] = flag
+            try:
+                got, info = capi.rolling_aggregate(cols, 0, 7, aggs, offset=2, out_residency=capi.DEVICE)
+            finally:
+                os.environ["BOWGPU_TW_F64"] = "0"
+            assert capi.last_kernel_name() == "rolling_tw_kernel"
+            for (k, _), g, w in zip(aggs, got, want):
+                compare("tw forms shift=%d %s" % (shift, k), g, w)
+            res.append([g.host_arrays() for g in got])
+        for (va, ba), (vb, bb) in zip(*res):
+            assert np.array_equal(va.view(np.uint64), vb.view(np.uint64)) and np.array_equal(ba, bb)
