@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BOWGPU_LIB") or os.path.join(_HERE, "libbowgpu.so")
 
 FLOAT64, INT64, BOOLEAN, STRING = 1, 2, 3, 4
-HOST, DEVICE = 0, 1
+HOST, DEVICE, HOST_PINNED = 0, 1, 2
 TYPE_NAMES = {"float64": FLOAT64, "int64": INT64, "bool": BOOLEAN, "utf8": STRING}
 
 AGG = {
@@ -124,7 +124,7 @@ class ShardDecision(C.Structure):
 # every symbol include/bowgpu.h declares (checked by tests/test_abi_symbols.py)
 SYMBOLS = [
     "bowgpu_abi_version", "bowgpu_last_error", "bowgpu_device_count", "bowgpu_set_device", "bowgpu_device_name",
-    "bowgpu_set_stream", "bowgpu_synchronize", "bowgpu_trim", "bowgpu_mem_info", "bowgpu_last_kernel_ms", "bowgpu_last_kernel_name", "bowgpu_malloc", "bowgpu_free", "bowgpu_memcpy_h2d",
+    "bowgpu_set_stream", "bowgpu_synchronize", "bowgpu_trim", "bowgpu_mem_info", "bowgpu_host_register", "bowgpu_host_unregister", "bowgpu_last_kernel_ms", "bowgpu_last_kernel_name", "bowgpu_malloc", "bowgpu_free", "bowgpu_memcpy_h2d",
     "bowgpu_memcpy_d2h", "bowgpu_memset", "bowgpu_timer_create", "bowgpu_timer_start", "bowgpu_timer_stop",
     "bowgpu_timer_elapsed_ms", "bowgpu_timer_destroy", "bowgpu_enforce_interval_and_offset", "bowgpu_plan_windows",
     "bowgpu_rolling_aggregate", "bowgpu_plan_windows_ex", "bowgpu_rolling_aggregate_planned", "bowgpu_window_bounds", "bowgpu_aggregate_whole",
@@ -151,6 +151,26 @@ def lib():
         L.bowgpu_last_kernel_name.restype = C.c_char_p
         _lib = L
     return _lib
+
+
+def page_aligned(count, dtype, fill=None):
+    """a numpy array on pages of its own (registered buffers should not share pages with anything else)"""
+    nbytes = max(count, 1) * np.dtype(dtype).itemsize
+    raw = np.empty(((nbytes + 4095) // 4096 + 1) * 4096, dtype=np.uint8)
+    off = (-raw.ctypes.data) % 4096
+    arr = raw[off:off + nbytes].view(dtype)
+    if fill is not None:
+        arr[:] = fill
+    return arr
+
+
+def host_register(arr):
+    """page-lock + map a numpy array for the device (columns over it may then be passed with residency HOST_PINNED)"""
+    check(lib().bowgpu_host_register(arr.ctypes.data_as(C.c_void_p), C.c_int64(arr.nbytes)))
+
+
+def host_unregister(arr):
+    check(lib().bowgpu_host_unregister(arr.ctypes.data_as(C.c_void_p)))
 
 
 def mem_info():
@@ -241,6 +261,26 @@ class Column:
         vals = np.array([x if x is not None else 0 for x in data], dtype=dt)
         return cls(vals, validity, typ, 0, n, int(n - valid.sum()))
 
+    def pin(self):
+        """register the numpy buffers (bowgpu_host_register) and pass the column as HOST_PINNED from now on"""
+        assert self.residency != DEVICE
+        if self.residency == HOST:
+            if self.values.size:
+                host_register(self.values)
+            if self.validity is not None and self.validity.size:
+                host_register(self.validity)
+            self.residency = HOST_PINNED
+        return self
+
+    def unpin(self):
+        if self.residency == HOST_PINNED:
+            if self.values.size:
+                host_unregister(self.values)
+            if self.validity is not None and self.validity.size:
+                host_unregister(self.validity)
+            self.residency = HOST
+        return self
+
     def to_device(self):
         if self.residency == DEVICE:
             return self
@@ -269,9 +309,15 @@ class OutColumn:
         self.slots = slots
         self.residency = residency
         nb = (slots + 7) // 8
-        if residency == HOST:
-            self.values = np.full(max(slots, 1), 0x5A5A5A5A5A5A5A5A, dtype=np.uint64)  # poisoned
-            self.validity = np.full(max(nb, 1), 0xA5, dtype=np.uint8)
+        if residency != DEVICE:
+            if residency == HOST_PINNED:
+                self.values = page_aligned(slots, np.uint64, 0x5A5A5A5A5A5A5A5A)
+                self.validity = page_aligned(nb, np.uint8, 0xA5)
+                host_register(self.values)
+                host_register(self.validity)
+            else:
+                self.values = np.full(max(slots, 1), 0x5A5A5A5A5A5A5A5A, dtype=np.uint64)  # poisoned
+                self.validity = np.full(max(nb, 1), 0xA5, dtype=np.uint8)
         else:
             self.values = DeviceBuffer(max(slots, 1) * 8)
             self.validity = DeviceBuffer(max(nb, 1))
@@ -281,7 +327,7 @@ class OutColumn:
 
     def c(self):
         o = Out()
-        if self.residency == HOST:
+        if self.residency != DEVICE:
             o.values, o.validity = self.values.ctypes.data, self.validity.ctypes.data
         else:
             o.values, o.validity = self.values.ptr, self.validity.ptr
@@ -294,7 +340,7 @@ class OutColumn:
     def host_arrays(self):
         n = self.length
         nb = (n + 7) // 8
-        if self.residency == HOST:
+        if self.residency != DEVICE:
             vals, bm = self.values[:n], self.validity[:nb]
         else:
             vals, bm = self.values.to_numpy(np.uint64, n), self.validity.to_numpy(np.uint8, nb)

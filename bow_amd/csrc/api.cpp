@@ -281,6 +281,12 @@ int count_nulls_device(Ctx *c, DevCol *dc) {
     return 0;
 }
 
+// BOWGPU_PINNED_STAGE=1 (A/B switch): pinned input columns are staged through HBM by DMA like pageable ones instead of being read in place
+static bool pinned_as_host() {
+    const char *e = getenv("BOWGPU_PINNED_STAGE");
+    return e && e[0] == '1';
+}
+
 int devcol_prepare(Ctx *c, const bowgpu_col *col, DevCol *out, bool need_values, bool need_validity) {
     if (col->length < 0 || col->offset < 0) return fail(BOWGPU_ERR_ARG, "negative column length/offset");
     if (col->length > 0 && !col->values) return fail(BOWGPU_ERR_ARG, "column has no values buffer");
@@ -299,7 +305,27 @@ int devcol_prepare(Ctx *c, const bowgpu_col *col, DevCol *out, bool need_values,
             out->vbit0 = (int64_t)(a & 3) * 8 + col->offset;
             out->vwords = (out->vbit0 + n + 31) >> 5;
         }
-    } else if (col->residency == BOWGPU_HOST) {
+    } else if (col->residency == BOWGPU_HOST_PINNED && !pinned_as_host()) {
+        // zero-copy: the kernels read the registered host buffers where they lie (coalesced 16-byte loads over PCIe)
+        if (reinterpret_cast<uintptr_t>(col->values) & 7) return fail(BOWGPU_ERR_ARG, "values buffer must be 8-byte aligned");
+        void *dv = nullptr;
+        if (hipHostGetDevicePointer(&dv, const_cast<void *>(col->values), 0) != hipSuccess || !dv) {
+            (void)hipGetLastError();
+            return fail(BOWGPU_ERR_ARG, "BOWGPU_HOST_PINNED: the values buffer is not registered (bowgpu_host_register)");
+        }
+        out->values = reinterpret_cast<const char *>(dv) + 8 * col->offset;
+        if (has_bitmap) {
+            void *db = nullptr;
+            if (hipHostGetDevicePointer(&db, const_cast<uint8_t *>(col->validity), 0) != hipSuccess || !db) {
+                (void)hipGetLastError();
+                return fail(BOWGPU_ERR_ARG, "BOWGPU_HOST_PINNED: the validity buffer is not registered (bowgpu_host_register)");
+            }
+            const uintptr_t a = reinterpret_cast<uintptr_t>(db);
+            out->vbits = reinterpret_cast<const uint32_t *>(a & ~(uintptr_t)3);
+            out->vbit0 = (int64_t)(a & 3) * 8 + col->offset;
+            out->vwords = (out->vbit0 + n + 31) >> 5;
+        }
+    } else if (col->residency == BOWGPU_HOST || col->residency == BOWGPU_HOST_PINNED) {
         if (need_values) {
             BG_TRY(out->own_values.alloc((size_t)n * 8 + 16));
             BG_HIP(hipMemcpyAsync(out->own_values.p, reinterpret_cast<const char *>(col->values) + 8 * col->offset,
@@ -1117,6 +1143,55 @@ int bowgpu_trim(int32_t all_threads, int64_t *bytes_freed) {
     BG_TRY(ctx_get(&c));
     const size_t freed = all_threads ? trim_all_threads() : g_bufs.drop_all();
     if (bytes_freed) *bytes_freed = (int64_t)freed;
+    return 0;
+}
+
+// Registration is page-granular: the range is widened to whole pages (pinning a neighbour's bytes in the same page is harmless),
+// and pages some earlier registration already covers - two small Arrow buffers from one allocator arena often share a page - are
+// skipped one by one.
+static bool host_range_mapped(const void *p) {
+    void *d = nullptr;
+    const bool ok = hipHostGetDevicePointer(&d, const_cast<void *>(p), 0) == hipSuccess && d;
+    if (!ok) (void)hipGetLastError();
+    return ok;
+}
+
+int bowgpu_host_register(void *ptr, int64_t bytes) {
+    if (!ptr || bytes <= 0) return fail(BOWGPU_ERR_ARG, "null buffer / non-positive size");
+    Ctx *c;
+    BG_TRY(ctx_get(&c));
+    const uintptr_t page = 4096;
+    const uintptr_t lo = reinterpret_cast<uintptr_t>(ptr) & ~(page - 1);
+    const uintptr_t hi = (reinterpret_cast<uintptr_t>(ptr) + (uintptr_t)bytes + page - 1) & ~(page - 1);
+    hipError_t e = hipHostRegister(reinterpret_cast<void *>(lo), hi - lo, hipHostRegisterMapped | hipHostRegisterPortable);
+    if (e == hipSuccess) return 0;
+    (void)hipGetLastError();
+    if (e != hipErrorHostMemoryAlreadyRegistered) return hip_fail(e, "hipHostRegister");
+    // part of the range is registered already: the rest, page by page (bounded: this is the small-buffer case)
+    if ((hi - lo) / page > 4096) {
+        if (host_range_mapped(reinterpret_cast<void *>(lo)) && host_range_mapped(reinterpret_cast<void *>(hi - 1))) return 0;
+        return fail(BOWGPU_ERR_ARG, "bowgpu_host_register: the range overlaps an earlier registration only partly");
+    }
+    for (uintptr_t a = lo; a < hi; a += page) {
+        if (host_range_mapped(reinterpret_cast<void *>(a))) continue;
+        e = hipHostRegister(reinterpret_cast<void *>(a), page, hipHostRegisterMapped | hipHostRegisterPortable);
+        if (e != hipSuccess && e != hipErrorHostMemoryAlreadyRegistered) return hip_fail(e, "hipHostRegister");
+        (void)hipGetLastError();
+    }
+    return 0;
+}
+
+int bowgpu_host_unregister(void *ptr) {
+    if (!ptr) return fail(BOWGPU_ERR_ARG, "null buffer");
+    Ctx *c;
+    BG_TRY(ctx_get(&c));
+    BG_HIP(hipStreamSynchronize(c->stream));   // nothing of this thread is still reading it
+    const uintptr_t lo = reinterpret_cast<uintptr_t>(ptr) & ~(uintptr_t)4095;
+    const hipError_t e = hipHostUnregister(reinterpret_cast<void *>(lo));
+    if (e != hipSuccess) {   // (a page that an earlier, still live registration covers stays with its owner)
+        (void)hipGetLastError();
+        if (e != hipErrorHostMemoryNotRegistered && e != hipErrorInvalidValue) return hip_fail(e, "hipHostUnregister");
+    }
     return 0;
 }
 

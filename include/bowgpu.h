@@ -37,8 +37,11 @@ enum {
 
 /* where a buffer lives */
 enum {
-    BOWGPU_HOST = 0,   /* ordinary host memory (Go heap / malloc): staged through HBM by the call */
-    BOWGPU_DEVICE = 1  /* HBM of the current device (bowgpu_malloc or any hipMalloc'd pointer) */
+    BOWGPU_HOST = 0,   /* ordinary (pageable) host memory - Go heap / malloc: staged through HBM by the call */
+    BOWGPU_DEVICE = 1, /* HBM of the current device (bowgpu_malloc or any hipMalloc'd pointer) */
+    BOWGPU_HOST_PINNED = 2  /* host memory page-locked and mapped for the device with bowgpu_host_register (or hipHostMalloc /
+                               hipHostRegister): INPUT columns are read by the kernels where they lie - zero-copy over PCIe, no staging
+                               copy, no HBM footprint; OUTPUT columns are produced in HBM and leave by one asynchronous DMA each */
 };
 
 /* error codes; the Go shim maps them back to the reference's error strings */
@@ -163,6 +166,13 @@ int bowgpu_free(void *ptr);
 int bowgpu_memcpy_h2d(void *dst, const void *src, int64_t bytes);
 int bowgpu_memcpy_d2h(void *dst, const void *src, int64_t bytes);
 int bowgpu_memset(void *dst, int value, int64_t bytes);
+
+/* Page-lock `bytes` of host memory at `ptr` and map them for the device, so that columns inside the range may be passed with
+ * residency BOWGPU_HOST_PINNED (reference bowseries.go:59-83 hands Go-heap slices: a cgo shim registers the Arrow buffers of a Bow
+ * it keeps using - Bows are immutable - once, e.g. from a finalizer-paired constructor).  Registration costs about a millisecond
+ * per 4 MB (every page is touched and locked): do it per buffer, not per call.  The range must stay valid until unregistered. */
+int bowgpu_host_register(void *ptr, int64_t bytes);
+int bowgpu_host_unregister(void *ptr);
 
 /* ---- stream timers (HIP events on the stream the kernels are launched on) --------- */
 int bowgpu_timer_create(void **timer);

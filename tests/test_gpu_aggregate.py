@@ -789,3 +789,54 @@ def test_time_weighted_kernel_timestamp_forms_agree():
             res.append([g.host_arrays() for g in got])
         for (va, ba), (vb, bb) in zip(*res):
             assert np.array_equal(va.view(np.uint64), vb.view(np.uint64)) and np.array_equal(ba, bb)
+
+
+def test_pinned_zero_copy_residency_equals_the_other_residencies():
+    """BOWGPU_HOST_PINNED: registered host buffers are read in place by the kernels (zero-copy) and outputs leave by DMA into
+    registered buffers; the same call with pageable / device-resident columns, and with BOWGPU_PINNED_STAGE=1, gives the same bits.
+    Arrow offsets and nulls included; an unregistered buffer passed as pinned is an error, not a fault."""
+    rng = np.random.default_rng(8)
+    n = 300_000
+    ts_full = np.cumsum(rng.integers(0, 4, n + 100)).astype(np.int64)
+    v_full = rng.standard_normal(n + 100)
+    m_full = rng.random(n + 100) > 0.3
+    bm_full = np.packbits(m_full, bitorder="little")
+    aggs = [("WindowStart", 0), ("ArithmeticMean", 1), ("Min", 1), ("Count", 1), ("WeightedAverageStep", 1)]
+    for off in (0, 37):
+        def cols():
+            return [capi.Column(ts_full, None, capi.INT64, off, n, 0), capi.Column(v_full, bm_full, capi.FLOAT64, off, n, -1)]
+        want, _ = orc.aggregate([orc.Column(ts_full[off:off + n], None, orc.INT64),
+                                 orc.Column(v_full[off:off + n], np.packbits(m_full[off:off + n], bitorder="little"), orc.FLOAT64)], 0, 10, aggs)
+        host, _ = capi.rolling_aggregate(cols(), 0, 10, aggs)
+        pinned_cols = [c.pin() for c in cols()]
+        try:
+            W = want[0].length
+            outs = [capi.OutColumn(W, capi.HOST_PINNED) for _ in aggs]
+            pinned, _ = capi.rolling_aggregate(pinned_cols, 0, 10, aggs, outs=outs)
+            os.environ["BOWGPU_PINNED_STAGE"] = "1"
+            try:
+                staged, _ = capi.rolling_aggregate(pinned_cols, 0, 10, aggs)
+            finally:
+                os.environ["BOWGPU_PINNED_STAGE"] = "0"
+            for (k, _), w, a, b, c_ in zip(aggs, want, host, pinned, staged):
+                compare("pinned off=%d %s" % (off, k), b, w)
+                for x in (a, c_):
+                    assert np.array_equal(x.host_arrays()[0].view(np.uint64), b.host_arrays()[0].view(np.uint64))
+                    assert np.array_equal(x.host_arrays()[1], b.host_arrays()[1])
+            # Interpolate and a fill through the same residency
+            ip = [{"kind": "WindowStart", "col": 0}, {"kind": "Linear", "col": 1}]
+            gi = capi.rolling_interpolate(pinned_cols, 0, 10, ip)
+            wi = orc.interpolate([orc.Column(ts_full[off:off + n], None, orc.INT64),
+                                  orc.Column(v_full[off:off + n], np.packbits(m_full[off:off + n], bitorder="little"), orc.FLOAT64)], 0, 10, ip)
+            from test_gpu_callers import cmp_out
+            cmp_out("pinned interpolate ts", gi[0], wi[0])
+            cmp_out("pinned interpolate val", gi[1], wi[1])
+        finally:
+            for c_ in pinned_cols:
+                c_.unpin()
+    bogus = [capi.Column(ts_full[:1000].copy(), None, capi.INT64), capi.Column(v_full[:1000].copy(), None, capi.FLOAT64)]
+    for c_ in bogus:
+        c_.residency = capi.HOST_PINNED     # never registered
+    with pytest.raises(capi.BowGpuError) as e:
+        capi.rolling_aggregate(bogus, 0, 10, aggs[:2])
+    assert e.value.code == -10
