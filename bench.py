@@ -89,10 +89,21 @@ def cpu_baseline_parallel(capi, rows_sample):
                       "thread pool, %.1f s" % (reps, rows_sample, len(ranges), dt)}
 
 
+def kernel_source_sha():
+    """hash of the sources the benched kernel is compiled from: ties a committed counter file to the code that is running"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("rolling_simple.hip", "agg_device.h", "common.h"):
+        with open(os.path.join(ROOT, "bow_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def measured_traffic(rows, kernel=None):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r*_pmc_hbm_traffic_bench_1e9.csv: FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, in KB), when they were
-    collected for this row count; None otherwise (PMC cannot be collected from inside the timed run)."""
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r*_pmc_hbm_traffic_bench_1e9.csv:
+    FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, in KB) - only when they were collected for this row count, for this kernel and from the
+    sources this tree holds (each row carries the full kernel signature and a hash of the kernel's sources); None otherwise (PMC
+    cannot be collected from inside the timed run)."""
     import csv
     import glob
     if rows != 1_000_000_000:
@@ -100,10 +111,13 @@ def measured_traffic(rows, kernel=None):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic_bench_1e9.csv")))
     if not files:
         return None
+    sha = kernel_source_sha()
     f, w = [], []
     for r in csv.DictReader(open(files[-1])):
-        if kernel and r["kernel"] != kernel:
-            continue  # counters of another kernel (an older build): not this run's traffic
+        if r.get("source_sha") != sha:
+            continue  # counters of another build of the kernel: not this run's traffic
+        if kernel and kernel not in r["kernel"]:
+            continue
         (f if r["counter"] == "FETCH_SIZE" else w).append(float(r["value_KB"]))
     if not f or not w:
         return None

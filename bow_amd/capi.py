@@ -325,6 +325,17 @@ class OutColumn:
         self.null_count = -1
         self.length = slots
 
+    def __del__(self):
+        # a registered buffer must be unregistered before its pages go back to the allocator (a later mapping at the same address
+        # would otherwise look registered and is not)
+        if getattr(self, "residency", None) == HOST_PINNED and _lib is not None:
+            try:
+                host_unregister(self.values)
+                host_unregister(self.validity)
+            except Exception:
+                pass
+            self.residency = HOST
+
     def c(self):
         o = Out()
         if self.residency != DEVICE:

@@ -57,6 +57,7 @@ void ctx_release(Ctx *c) {
     if (c->d_params) (void)hipFree(c->d_params);
     for (int i = 0; i < Ctx::kPoolSlots; i++) if (c->pool[i]) (void)hipFree(c->pool[i]);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    if (c->h_bounce) (void)hipHostFree(c->h_bounce);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -328,8 +329,7 @@ int devcol_prepare(Ctx *c, const bowgpu_col *col, DevCol *out, bool need_values,
     } else if (col->residency == BOWGPU_HOST || col->residency == BOWGPU_HOST_PINNED) {
         if (need_values) {
             BG_TRY(out->own_values.alloc((size_t)n * 8 + 16));
-            BG_HIP(hipMemcpyAsync(out->own_values.p, reinterpret_cast<const char *>(col->values) + 8 * col->offset,
-                                  (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+            BG_TRY(copy_h2d(c, out->own_values.p, reinterpret_cast<const char *>(col->values) + 8 * col->offset, (size_t)n * 8));
             out->values = out->own_values.p;
         }
         if (has_bitmap && need_validity) {
@@ -337,7 +337,7 @@ int devcol_prepare(Ctx *c, const bowgpu_col *col, DevCol *out, bool need_values,
             const size_t nb = (size_t)(b1 - b0);
             BG_TRY(out->own_validity.alloc(((nb + 3) & ~(size_t)3) + 8));
             BG_HIP(hipMemsetAsync(out->own_validity.p, 0, out->own_validity.bytes, c->stream));
-            BG_HIP(hipMemcpyAsync(out->own_validity.p, col->validity + b0, nb, hipMemcpyHostToDevice, c->stream));
+            BG_TRY(copy_h2d(c, out->own_validity.p, col->validity + b0, nb));
             out->vbits = reinterpret_cast<const uint32_t *>(out->own_validity.p);
             out->vbit0 = col->offset & 7;
             out->vwords = (out->vbit0 + n + 31) >> 5;
@@ -381,6 +381,44 @@ int devout_prepare(Ctx *c, bowgpu_out *out, int64_t slots, DevOut *d, int pool_s
     return 0;
 }
 
+// Device <-> host copies of caller buffers.  hipMemcpyAsync refuses (invalid argument) a host range that lies only PARTLY inside some
+// registered range - e.g. a small malloc'ed buffer sharing a page with a buffer somebody registered.  Such a copy goes through the
+// context's own pinned block instead, in pieces.
+int copy_d2h(Ctx *c, void *dst, const void *src, size_t bytes) {
+    if (bytes == 0) return 0;
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) return 0;
+    (void)hipGetLastError();
+    if (e != hipErrorInvalidValue) return hip_fail(e, "hipMemcpyAsync (device to host)");
+    constexpr size_t kPiece = 1 << 20;
+    if (!c->h_bounce) BG_HIP(hipHostMalloc(&c->h_bounce, kPiece, hipHostMallocDefault));   // (its own block: ctx_pinned's must not move)
+    char *hp = reinterpret_cast<char *>(c->h_bounce);
+    for (size_t o = 0; o < bytes; o += kPiece) {
+        const size_t m = bytes - o < kPiece ? bytes - o : kPiece;
+        BG_HIP(hipMemcpyAsync(hp, reinterpret_cast<const char *>(src) + o, m, hipMemcpyDeviceToHost, c->stream));
+        BG_HIP(hipStreamSynchronize(c->stream));
+        memcpy(reinterpret_cast<char *>(dst) + o, hp, m);
+    }
+    return 0;
+}
+int copy_h2d(Ctx *c, void *dst, const void *src, size_t bytes) {
+    if (bytes == 0) return 0;
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) return 0;
+    (void)hipGetLastError();
+    if (e != hipErrorInvalidValue) return hip_fail(e, "hipMemcpyAsync (host to device)");
+    constexpr size_t kPiece = 1 << 20;
+    if (!c->h_bounce) BG_HIP(hipHostMalloc(&c->h_bounce, kPiece, hipHostMallocDefault));   // (its own block: ctx_pinned's must not move)
+    char *hp = reinterpret_cast<char *>(c->h_bounce);
+    for (size_t o = 0; o < bytes; o += kPiece) {
+        const size_t m = bytes - o < kPiece ? bytes - o : kPiece;
+        memcpy(hp, reinterpret_cast<const char *>(src) + o, m);
+        BG_HIP(hipMemcpyAsync(reinterpret_cast<char *>(dst) + o, hp, m, hipMemcpyHostToDevice, c->stream));
+        BG_HIP(hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
 int devout_finish(Ctx *c, DevOut *d, int64_t slots, int32_t type, int64_t null_count, bool copy_bitmap) {
     bowgpu_out *out = d->user;
     out->length = slots;
@@ -391,8 +429,8 @@ int devout_finish(Ctx *c, DevOut *d, int64_t slots, int32_t type, int64_t null_c
     if (out->residency == BOWGPU_DEVICE) {
         if (copy_bitmap) BG_HIP(hipMemcpyAsync(out->validity, d->validity, vb, hipMemcpyDeviceToDevice, c->stream));
     } else {
-        BG_HIP(hipMemcpyAsync(out->values, d->values, (size_t)slots * 8, hipMemcpyDeviceToHost, c->stream));
-        BG_HIP(hipMemcpyAsync(out->validity, d->validity, vb, hipMemcpyDeviceToHost, c->stream));
+        BG_TRY(copy_d2h(c, out->values, d->values, (size_t)slots * 8));
+        BG_TRY(copy_d2h(c, out->validity, d->validity, vb));
     }
     return 0;
 }
@@ -731,19 +769,19 @@ static int job_readback(Ctx *c, AggJob *job, uint32_t **hstat, uint64_t **hcnt) 
 static bool simple_applies(const AggJob *job, const bowgpu_agg *aggs, int32_t naggs, const Plan &plan, bool time_weighted, int *need,
                            bool *is_int, bool *has_nulls, bool *wide) {
     const AggParams &P = job->P;
-    if ((job->inclusive && !time_weighted) || P.pre_rows || !P.fits32 || naggs > kSimpleMaxAggs) return false;
+    if ((job->inclusive && !time_weighted) || !P.fits32 || naggs > kSimpleMaxAggs) return false;
     if (P.W <= 0) return false;
-    // output slot 0 starts at s0 + wid_base * interval (wid_base != 0: a shard; it never lies above the shard's first row)
+    // output slot 0 starts at s0 + wid_base * interval (wid_base != 0: a shard; it never lies above the shard's first row).  Rows
+    // below it exist only as the frame's rows below s0 (P.pre_rows: they ride in window 0; the kernels force their ids)
     const int64_t slot0_start = P.s0 + (int64_t)((uint64_t)P.wid_base * (uint64_t)P.interval);
-    if (plan.first_ts < slot0_start) return false;
+    if (plan.first_ts < slot0_start && !(P.pre_rows && P.wid_base == 0)) return false;
     // rows within 2^32 of slot 0: global 32-bit window ids; else (nanosecond timestamps) ids relative to each tile's first window
     *wide = (uint64_t)plan.last_ts - (uint64_t)slot0_start >= 0xFFFFFFF0ull || P.W >= 0xFFFFFFF0ll;
-    if (reinterpret_cast<uintptr_t>(P.ts) & 15) return false;
+    // (columns that start on an 8-byte but not a 16-byte boundary - Arrow slices with odd offsets - stay here: 8-byte loads)
     *need = 0;
     *is_int = true;  // (reducers over the interval column itself)
     *has_nulls = false;
     for (int s = 0; s < P.ncols; s++) {
-        if (reinterpret_cast<uintptr_t>(P.cols[s].values) & 15) return false;
         *has_nulls = *has_nulls || P.cols[s].vbits != nullptr;
         *is_int = P.cols[0].type == BOWGPU_INT64;
     }
@@ -766,7 +804,7 @@ static int job_launch_tiles(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t
     if (W <= 0) { BG_HIP(hipMemsetAsync(P.status, 0, kReadbackBytes, c->stream)); return 0; }
     // The lean kernels cover exclusive windows without time-weighted reducers and without rows below s0; everything
     // else (and BOWGPU_FORCE_GENERAL=1, used by the tests to cover all of them) takes the general kernel.
-    bool lean = !job->inclusive && !P.pre_rows;
+    bool lean = !job->inclusive;   // (rows below s0 - P.pre_rows - are taken by the wave-tile kernels; the lean wave kernel declines them below)
     for (int i = 0; i < naggs; i++)
         if (aggs[i].kind >= BOWGPU_AGG_INTEGRAL_STEP && aggs[i].kind <= BOWGPU_AGG_WAVG_LINEAR) lean = false;
     const char *force = getenv("BOWGPU_FORCE_GENERAL");
@@ -826,12 +864,16 @@ static int job_launch_tiles(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t
         }
         S.status = P.status; S.long_list = P.long_list; S.long_cap = P.long_cap;
         S.inclusive = job->inclusive ? 1 : 0;
+        S.pre_rows = P.pre_rows;
+        S.unaligned_mask = (reinterpret_cast<uintptr_t>(P.ts) & 15) ? 0x80000000u : 0u;
+        for (int s = 0; s < S.ncols; s++)
+            if (reinterpret_cast<uintptr_t>(S.values[s]) & 15) S.unaligned_mask |= 1u << s;
         if (tw) {
             // 32-bit staged timestamps: exact when float64(s0 of slot 0) + float64(offset) needs no rounding, i.e. every |ts| < 2^53
             // (BOWGPU_TW_F64=1: test / A-B switch that keeps the float64 form)
             const int64_t lim53 = 1ll << 53;
             const char *f64 = getenv("BOWGPU_TW_F64");
-            const bool ts32 = !wide && plan->first_ts > -lim53 && plan->last_ts < lim53 && S.s0 > -lim53 && !(f64 && f64[0] == '1');
+            const bool ts32 = !wide && !P.pre_rows && plan->first_ts > -lim53 && plan->last_ts < lim53 && S.s0 > -lim53 && !(f64 && f64[0] == '1');
             BG_TRY(launch_rolling_tw(c, S, is_int, has_nulls, wide, ts32));
             c->last_kernel_name = "rolling_tw_kernel";
         } else {
@@ -839,7 +881,7 @@ static int job_launch_tiles(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t
             c->last_kernel_name = "rolling_simple_kernel";
         }
         *used_simple = true;
-    } else if (lean) {
+    } else if (lean && !P.pre_rows) {
         BG_TRY(launch_rolling_fast(c, P));
         c->last_kernel_name = "rolling_wave_kernel";
     } else {
@@ -1146,9 +1188,8 @@ int bowgpu_trim(int32_t all_threads, int64_t *bytes_freed) {
     return 0;
 }
 
-// Registration is page-granular: the range is widened to whole pages (pinning a neighbour's bytes in the same page is harmless),
-// and pages some earlier registration already covers - two small Arrow buffers from one allocator arena often share a page - are
-// skipped one by one.
+// The range is registered as given.  A range that an earlier registration already covers is fine; one it covers only partly is
+// refused (two small buffers inside one page can do that: register the enclosing allocation instead).
 static bool host_range_mapped(const void *p) {
     void *d = nullptr;
     const bool ok = hipHostGetDevicePointer(&d, const_cast<void *>(p), 0) == hipSuccess && d;
@@ -1160,25 +1201,14 @@ int bowgpu_host_register(void *ptr, int64_t bytes) {
     if (!ptr || bytes <= 0) return fail(BOWGPU_ERR_ARG, "null buffer / non-positive size");
     Ctx *c;
     BG_TRY(ctx_get(&c));
-    const uintptr_t page = 4096;
-    const uintptr_t lo = reinterpret_cast<uintptr_t>(ptr) & ~(page - 1);
-    const uintptr_t hi = (reinterpret_cast<uintptr_t>(ptr) + (uintptr_t)bytes + page - 1) & ~(page - 1);
-    hipError_t e = hipHostRegister(reinterpret_cast<void *>(lo), hi - lo, hipHostRegisterMapped | hipHostRegisterPortable);
+    const hipError_t e = hipHostRegister(ptr, (size_t)bytes, hipHostRegisterMapped | hipHostRegisterPortable);
     if (e == hipSuccess) return 0;
     (void)hipGetLastError();
-    if (e != hipErrorHostMemoryAlreadyRegistered) return hip_fail(e, "hipHostRegister");
-    // part of the range is registered already: the rest, page by page (bounded: this is the small-buffer case)
-    if ((hi - lo) / page > 4096) {
-        if (host_range_mapped(reinterpret_cast<void *>(lo)) && host_range_mapped(reinterpret_cast<void *>(hi - 1))) return 0;
+    if (e == hipErrorHostMemoryAlreadyRegistered) {
+        if (host_range_mapped(ptr) && host_range_mapped(reinterpret_cast<char *>(ptr) + bytes - 1)) return 0;
         return fail(BOWGPU_ERR_ARG, "bowgpu_host_register: the range overlaps an earlier registration only partly");
     }
-    for (uintptr_t a = lo; a < hi; a += page) {
-        if (host_range_mapped(reinterpret_cast<void *>(a))) continue;
-        e = hipHostRegister(reinterpret_cast<void *>(a), page, hipHostRegisterMapped | hipHostRegisterPortable);
-        if (e != hipSuccess && e != hipErrorHostMemoryAlreadyRegistered) return hip_fail(e, "hipHostRegister");
-        (void)hipGetLastError();
-    }
-    return 0;
+    return hip_fail(e, "hipHostRegister");
 }
 
 int bowgpu_host_unregister(void *ptr) {
@@ -1186,9 +1216,8 @@ int bowgpu_host_unregister(void *ptr) {
     Ctx *c;
     BG_TRY(ctx_get(&c));
     BG_HIP(hipStreamSynchronize(c->stream));   // nothing of this thread is still reading it
-    const uintptr_t lo = reinterpret_cast<uintptr_t>(ptr) & ~(uintptr_t)4095;
-    const hipError_t e = hipHostUnregister(reinterpret_cast<void *>(lo));
-    if (e != hipSuccess) {   // (a page that an earlier, still live registration covers stays with its owner)
+    const hipError_t e = hipHostUnregister(ptr);
+    if (e != hipSuccess) {   // (a range that an earlier, still live registration covers stays with its owner)
         (void)hipGetLastError();
         if (e != hipErrorHostMemoryNotRegistered && e != hipErrorInvalidValue) return hip_fail(e, "hipHostUnregister");
     }

@@ -39,6 +39,7 @@ struct Ctx {
     size_t d_scratch_bytes = 0;
     void *h_pinned = nullptr;
     size_t h_pinned_bytes = 0;
+    void *h_bounce = nullptr;   // 1 MB, copy_d2h/copy_h2d's fallback
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double last_kernel_ms = 0.0;
     const char *last_kernel_name = "";  // the tile kernel last_kernel_ms brackets
@@ -119,6 +120,8 @@ struct DevOut {
     DevBuf own_values, own_validity;
     bowgpu_out *user = nullptr;
 };
+int copy_d2h(Ctx *c, void *dst, const void *src, size_t bytes);   // caller buffers: fall back to a bounce through the pinned block
+int copy_h2d(Ctx *c, void *dst, const void *src, size_t bytes);
 int devout_prepare(Ctx *c, bowgpu_out *out, int64_t slots, DevOut *d, int pool_slot = -1);
 int devout_finish(Ctx *c, DevOut *d, int64_t slots, int32_t type, int64_t null_count, bool copy_bitmap = true);
 
@@ -212,6 +215,8 @@ struct SimpleParams {
     int32_t naggs;
     int32_t ncols;                         // value columns (>= 1; reducers over the interval column use it as a column)
     int32_t inclusive;                     // rolling_tw.hip: windows are built inclusive (some reducer needs it)
+    int32_t pre_rows;                      // s0 lies above the first timestamp: the rows below it ride in window 0
+    uint32_t unaligned_mask;               // bit c: value column c starts on an 8-byte, not a 16-byte boundary; bit 31: the interval column
     const void *values[kMaxCols];
     const uint32_t *vbits[kMaxCols];       // nullptr: this column has no nulls
     int64_t vbit0[kMaxCols], vwords[kMaxCols];

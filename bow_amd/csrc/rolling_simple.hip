@@ -83,31 +83,41 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
     // ---- loads: ts, then the first value column right behind it
     uint64_t ta[kChunksS], tb[kChunksS], va[kChunksS], vb[kChunksS];
     const uint64_t *__restrict__ ts = reinterpret_cast<const uint64_t *>(p.ts);
-    auto load_col = [&](const uint64_t *__restrict__ src, uint64_t (&a)[kChunksS], uint64_t (&bb)[kChunksS]) {
-        if (interior) {
+    // a column whose first row is only 8-byte aligned (an Arrow slice with an odd offset) is read with two 8-byte loads per lane and
+    // chunk instead of one 16-byte load: slower through the L1, but the call stays on this kernel
+    auto load_col = [&](const uint64_t *__restrict__ src, uint64_t (&a)[kChunksS], uint64_t (&bb)[kChunksS], bool aligned) {
+        if (interior && aligned) {
             const ulonglong2 *q = reinterpret_cast<const ulonglong2 *>(src + base) + lane;
 #pragma unroll
             for (int j = 0; j < kChunksS; j++) {
                 const ulonglong2 x = (j > 0 && j < kChunksS - 1) ? load16_nt(q + j * 64) : q[j * 64];
                 a[j] = x.x; bb[j] = x.y;
             }
+        } else if (interior) {
+            const uint64_t *q = src + base + 2 * lane;
+#pragma unroll
+            for (int j = 0; j < kChunksS; j++) { a[j] = q[j * 128]; bb[j] = q[j * 128 + 1]; }
         } else {
 #pragma unroll
-            for (int j = 0; j < kChunksS; j++) load_pair(src, base + j * 128 + 2 * lane, n, true, a[j], bb[j]);
+            for (int j = 0; j < kChunksS; j++) load_pair(src, base + j * 128 + 2 * lane, n, aligned, a[j], bb[j]);
         }
     };
-    load_col(ts, ta, tb);
-    load_col(reinterpret_cast<const uint64_t *>(p.values[0]), va, vb);
+    load_col(ts, ta, tb, !(p.unaligned_mask >> 31));
+    load_col(reinterpret_cast<const uint64_t *>(p.values[0]), va, vb, !(p.unaligned_mask & 1u));
     // the row left of the tile (scalar load): first head flag + order check
     const int64_t left0 = base > 0 ? p.ts[base - 1] : INT64_MIN;
     // ids are 32-bit and relative to window w0, which starts at ws0: slot 0 of the call, or (kWide) the tile's first window
     uint64_t w0 = 0;
     int64_t ws0 = p.s0;
     bool unsorted = false, sat = false;  // rows out of order ; ids the 16-bit local fields / 32-bit arithmetic cannot hold
+    const int64_t ts_first = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ta[0] >> 32)) << 32) |
+                                       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ta[0]));
+    // p.pre_rows: Go's truncating division put s0 above a negative first timestamp (rolling.go:96-99); the rows below s0 ride in
+    // window 0 (rolling.go:194-196).  They are the frame's first rows, fewer than one interval's worth of time: ids below are
+    // forced to 0 for them (wave-uniform test per tile: only tiles that start below s0 pay for the per-row comparison)
+    const bool pre = p.pre_rows && ts_first < p.s0;
     if (kWide) {
-        const int64_t ts_first = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ta[0] >> 32)) << 32) |
-                                           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ta[0]));
-        w0 = magic_div((uint64_t)ts_first - (uint64_t)p.s0, p.magic);
+        w0 = pre ? 0ull : magic_div((uint64_t)ts_first - (uint64_t)p.s0, p.magic);
         ws0 = p.s0 + (int64_t)(w0 * (uint64_t)p.interval);
         const int64_t ts_last = p.ts[base + nloc - 1];
         // ids come from (ts - ws0) >> k with k = trailing zero bits of the interval (floor(a / b) == floor((a >> k) / (b >> k)) when
@@ -120,8 +130,8 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
     };
 
     // ---- window ids (32-bit), head flags, compaction with a running scalar count
-    const uint32_t w_first = kWide ? 0u : mdiv32((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ta[0]) - s0_lo, p.m32, p.sh1, p.sh2);
-    uint32_t left_w = (base > 0 && (!kWide || left0 >= ws0)) ? mdiv32(rel32(left0), p.m32, p.sh1, p.sh2) : 0xFFFFFFFEu;
+    const uint32_t w_first = (kWide || pre) ? 0u : mdiv32((uint32_t)ts_first - s0_lo, p.m32, p.sh1, p.sh2);
+    uint32_t left_w = base == 0 ? 0xFFFFFFFEu : (pre && left0 < ws0) ? 0u : (kWide && left0 < ws0) ? 0xFFFFFFFEu : mdiv32(rel32(left0), p.m32, p.sh1, p.sh2);
     int64_t left_ts = left0;
     int nseg_total = 0, nseg_owned = 0;
 #pragma unroll
@@ -134,8 +144,9 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
         const int64_t prev_ts = (int64_t)(((uint64_t)phi << 32) | plo);
         unsorted |= (pa && prev_ts > tsa) || (pb && tsa > tsb);
         const uint32_t ra = rel32(tsa), rb = rel32(tsb);
-        const uint32_t wa = mdiv32(ra, p.m32, p.sh1, p.sh2);
-        const uint32_t wb = mdiv32(rb, p.m32, p.sh1, p.sh2);
+        uint32_t wa = mdiv32(ra, p.m32, p.sh1, p.sh2);
+        uint32_t wb = mdiv32(rb, p.m32, p.sh1, p.sh2);
+        if (pre) { if (tsa < ws0) wa = 0u; if (tsb < ws0) wb = 0u; }
         const uint32_t wprev = left32(wb, left_w);
         const bool ha = pa && (wa != wprev);
         const bool hb = pb && (wb != wa);
@@ -210,7 +221,7 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
 #pragma unroll
             for (int j = 0; j < kChunksS; j++)
                 *reinterpret_cast<ulonglong2 *>(&sh.val[j * 128 + 2 * lane]) = make_ulonglong2(va[j], vb[j]);
-            if (c + 1 < ncols) load_col(reinterpret_cast<const uint64_t *>(p.values[c + 1]), va, vb);
+            if (c + 1 < ncols) load_col(reinterpret_cast<const uint64_t *>(p.values[c + 1]), va, vb, !((p.unaligned_mask >> (c + 1)) & 1u));
         }
         if (kNulls && lane < kRowsS / 32) {  // 32 validity bits per lane, any bit offset (Arrow slices)
             uint32_t word = 0xFFFFFFFFu;
@@ -245,11 +256,14 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
             }
             continue;
         }
+        // window 0 made only of rows below s0 is an EMPTY slice in the reference (rolling.go:194-196: lastRowIndex stays -1)
+        const bool dead = pre && tile == 0 && q == 0 && p.ts[base + r1 - 1] < p.s0;
         // ---- the walk: rows r0 .. r1-1 in order (sum.go:16-22, arithmeticmean.go:17-24, minmax.go:16-28, count.go:12-18)
         double sum = 0.0, mn = 0.0, mx = 0.0;
         uint64_t first_raw = 0, last_raw = 0;
         int count;
-        if (!kNulls) {
+        if (dead) count = 0;
+        else if (!kNulls) {
             first_raw = sh.val[r0];
             mn = cint ? (double)(int64_t)first_raw : __longlong_as_double((long long)first_raw);
             mx = mn;
@@ -282,8 +296,8 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
                 count++;
             }
         }
-        const int nrows = r1 - r0;
-        const bool has_value = count > 0;  // (always true without nulls)
+        const int nrows = dead ? 0 : r1 - r0;
+        const bool has_value = count > 0;  // (always true without nulls, but for the dead window 0)
         const int64_t win_start = ws0 + (int64_t)((uint64_t)wid * (uint64_t)(uint32_t)p.interval);
         const int64_t slot = (int64_t)(w0 + wid);  // output slot
         if (wid >= W32) continue;  // (only on corrupt input)
@@ -310,7 +324,7 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
             const bool int_result = k == BOWGPU_AGG_WINDOW_START || k == BOWGPU_AGG_COUNT || (cint && (k == BOWGPU_AGG_FIRST || k == BOWGPU_AGG_LAST));
             const int nf = p.nfac[a];
             if (nf) bits = apply_factors(bits, int_result, nf, p.fac[a]);
-            if (kNulls && nil) {  // a window whose values are all null (rare): nil => slot 0, bit cleared
+            if ((kNulls || pre) && nil) {  // a window whose values are all null (rare) / the dead window 0: nil => slot 0, bit cleared
                 bits = 0;
                 atomicAnd(&p.out_valid[a][slot >> 5], ~(1u << (slot & 31)));
             }
