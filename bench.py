@@ -223,6 +223,8 @@ def main():
     ap.add_argument("--rows", type=_count, default=1_000_000_000, help="rows per GPU")
     ap.add_argument("--cpu-sample", type=_count, default=100_000_000)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-pinned", action="store_true",
+                    help="skip the host_pinned aside (profiling: it launches the same kernel over PCIe, which would pollute per-kernel averages)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -351,7 +353,7 @@ def main():
                                                          "what": "trivial kernel, same bytes read (16 B/row) and written (2 x 8 B/window), same store pattern"}
             except Exception as e:
                 line["roofline"]["stream_rw_ceiling"] = {"error": repr(e)}
-        if world == 1:
+        if world == 1 and not args.no_pinned:
             # PCIe-inclusive aside (never `value`): the same call on HOST-resident columns of a 1e8-row sample - registered buffers
             # read in place by the kernels (BOWGPU_HOST_PINNED, zero-copy), outputs by DMA into registered buffers
             try:

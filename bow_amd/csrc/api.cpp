@@ -7,6 +7,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <mutex>
@@ -57,7 +60,7 @@ void ctx_release(Ctx *c) {
     if (c->d_params) (void)hipFree(c->d_params);
     for (int i = 0; i < Ctx::kPoolSlots; i++) if (c->pool[i]) (void)hipFree(c->pool[i]);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
-    if (c->h_bounce) (void)hipHostFree(c->h_bounce);
+    if (c->h_bounce) { (void)hipHostFree(c->h_bounce); (void)hipEventDestroy(c->bounce_ev[0]); (void)hipEventDestroy(c->bounce_ev[1]); }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -71,9 +74,27 @@ struct CtxHolder {
 static thread_local CtxHolder g_ctx_holder;
 #define g_ctx (g_ctx_holder.c)
 
+// BOWGPU_ABORT_TRACE=1 (diagnostic): the C stack of whoever calls abort() - the HIP runtime does so on a queue error, with no
+// message when stderr is not a terminal - before the process dies
+static void abort_trace(int) {
+    void *frames[64];
+    const int n = backtrace(frames, 64);
+    static const char msg[] = "bowgpu: SIGABRT, C stack:\n";
+    (void)!write(2, msg, sizeof msg - 1);
+    backtrace_symbols_fd(frames, n, 2);
+    signal(SIGABRT, SIG_DFL);
+    raise(SIGABRT);
+}
+
 int ctx_get(Ctx **out) {
     static ExitSentinel sentinel;   // (constructed on the first call of any thread)
     (void)sentinel;
+    static const bool traced = [] {
+        const char *t = getenv("BOWGPU_ABORT_TRACE");
+        if (t && t[0] == '1') signal(SIGABRT, abort_trace);
+        return true;
+    }();
+    (void)traced;
     Ctx *c = &g_ctx;
     if (!c->inited) {
         int n = 0;
@@ -329,7 +350,8 @@ int devcol_prepare(Ctx *c, const bowgpu_col *col, DevCol *out, bool need_values,
     } else if (col->residency == BOWGPU_HOST || col->residency == BOWGPU_HOST_PINNED) {
         if (need_values) {
             BG_TRY(out->own_values.alloc((size_t)n * 8 + 16));
-            BG_TRY(copy_h2d(c, out->own_values.p, reinterpret_cast<const char *>(col->values) + 8 * col->offset, (size_t)n * 8));
+            BG_TRY(copy_h2d(c, out->own_values.p, reinterpret_cast<const char *>(col->values) + 8 * col->offset, (size_t)n * 8,
+                            col->residency == BOWGPU_HOST_PINNED));
             out->values = out->own_values.p;
         }
         if (has_bitmap && need_validity) {
@@ -337,7 +359,7 @@ int devcol_prepare(Ctx *c, const bowgpu_col *col, DevCol *out, bool need_values,
             const size_t nb = (size_t)(b1 - b0);
             BG_TRY(out->own_validity.alloc(((nb + 3) & ~(size_t)3) + 8));
             BG_HIP(hipMemsetAsync(out->own_validity.p, 0, out->own_validity.bytes, c->stream));
-            BG_TRY(copy_h2d(c, out->own_validity.p, col->validity + b0, nb));
+            BG_TRY(copy_h2d(c, out->own_validity.p, col->validity + b0, nb, col->residency == BOWGPU_HOST_PINNED));
             out->vbits = reinterpret_cast<const uint32_t *>(out->own_validity.p);
             out->vbit0 = col->offset & 7;
             out->vwords = (out->vbit0 + n + 31) >> 5;
@@ -381,40 +403,71 @@ int devout_prepare(Ctx *c, bowgpu_out *out, int64_t slots, DevOut *d, int pool_s
     return 0;
 }
 
-// Device <-> host copies of caller buffers.  hipMemcpyAsync refuses (invalid argument) a host range that lies only PARTLY inside some
-// registered range - e.g. a small malloc'ed buffer sharing a page with a buffer somebody registered.  Such a copy goes through the
-// context's own pinned block instead, in pieces.
-int copy_d2h(Ctx *c, void *dst, const void *src, size_t bytes) {
+// Device <-> host copies of PAGEABLE caller buffers go through the context's own pinned staging (two kBouncePiece halves: the
+// DMA of one overlaps the CPU copy of the other) and never hand the caller's pointer to the HIP runtime.  The runtime would pin
+// the caller's pages itself (a userptr mapping, kept in a cache), and that goes wrong in ways the library cannot see: it refuses
+// a range that lies only partly inside a registered one (a small malloc'ed buffer sharing a page with a buffer somebody
+// registered), and on this pool GPU writes through such mappings were seen to die with "write access to a read-only page" on
+// fresh machines.  Small copies (the runtime stages those itself) and BOWGPU_RUNTIME_PINS=1 (A/B switch) keep the direct form.
+constexpr size_t kBouncePiece = 4u << 20;
+constexpr size_t kBounceDirect = 16384;
+static bool runtime_pins() {
+    static const bool on = [] { const char *e = getenv("BOWGPU_RUNTIME_PINS"); return e && e[0] == '1'; }();
+    return on;
+}
+static int bounce_get(Ctx *c, char **half0, char **half1) {
+    if (!c->h_bounce) {
+        BG_HIP(hipHostMalloc(&c->h_bounce, 2 * kBouncePiece, hipHostMallocDefault));   // (its own block: ctx_pinned's must not move)
+        BG_HIP(hipEventCreateWithFlags(&c->bounce_ev[0], hipEventDisableTiming));
+        BG_HIP(hipEventCreateWithFlags(&c->bounce_ev[1], hipEventDisableTiming));
+    }
+    *half0 = reinterpret_cast<char *>(c->h_bounce);
+    *half1 = *half0 + kBouncePiece;
+    return 0;
+}
+int copy_d2h(Ctx *c, void *dst, const void *src, size_t bytes, bool registered) {
     if (bytes == 0) return 0;
-    hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) return 0;
-    (void)hipGetLastError();
-    if (e != hipErrorInvalidValue) return hip_fail(e, "hipMemcpyAsync (device to host)");
-    constexpr size_t kPiece = 1 << 20;
-    if (!c->h_bounce) BG_HIP(hipHostMalloc(&c->h_bounce, kPiece, hipHostMallocDefault));   // (its own block: ctx_pinned's must not move)
-    char *hp = reinterpret_cast<char *>(c->h_bounce);
-    for (size_t o = 0; o < bytes; o += kPiece) {
-        const size_t m = bytes - o < kPiece ? bytes - o : kPiece;
-        BG_HIP(hipMemcpyAsync(hp, reinterpret_cast<const char *>(src) + o, m, hipMemcpyDeviceToHost, c->stream));
-        BG_HIP(hipStreamSynchronize(c->stream));
-        memcpy(reinterpret_cast<char *>(dst) + o, hp, m);
+    if (bytes <= kBounceDirect || registered || runtime_pins()) {
+        const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) return 0;
+        (void)hipGetLastError();
+        if (e != hipErrorInvalidValue) return hip_fail(e, "hipMemcpyAsync (device to host)");
+    }
+    char *h[2];
+    BG_TRY(bounce_get(c, &h[0], &h[1]));
+    const size_t pieces = (bytes + kBouncePiece - 1) / kBouncePiece;
+    auto len = [&](size_t k) { return k + 1 < pieces ? kBouncePiece : bytes - k * kBouncePiece; };
+    for (size_t k = 0; k <= pieces; k++) {
+        if (k < pieces) {   // piece k on its way into half k & 1 ...  (stream order keeps it behind an earlier upload out of that half)
+            c->bounce_busy[k & 1] = false;
+            BG_HIP(hipMemcpyAsync(h[k & 1], reinterpret_cast<const char *>(src) + k * kBouncePiece, len(k), hipMemcpyDeviceToHost, c->stream));
+            BG_HIP(hipEventRecord(c->bounce_ev[k & 1], c->stream));
+        }
+        if (k > 0) {        // ... while piece k - 1 leaves the other half
+            BG_HIP(hipEventSynchronize(c->bounce_ev[(k - 1) & 1]));
+            memcpy(reinterpret_cast<char *>(dst) + (k - 1) * kBouncePiece, h[(k - 1) & 1], len(k - 1));
+        }
     }
     return 0;
 }
-int copy_h2d(Ctx *c, void *dst, const void *src, size_t bytes) {
+int copy_h2d(Ctx *c, void *dst, const void *src, size_t bytes, bool registered) {
     if (bytes == 0) return 0;
-    hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) return 0;
-    (void)hipGetLastError();
-    if (e != hipErrorInvalidValue) return hip_fail(e, "hipMemcpyAsync (host to device)");
-    constexpr size_t kPiece = 1 << 20;
-    if (!c->h_bounce) BG_HIP(hipHostMalloc(&c->h_bounce, kPiece, hipHostMallocDefault));   // (its own block: ctx_pinned's must not move)
-    char *hp = reinterpret_cast<char *>(c->h_bounce);
-    for (size_t o = 0; o < bytes; o += kPiece) {
-        const size_t m = bytes - o < kPiece ? bytes - o : kPiece;
-        memcpy(hp, reinterpret_cast<const char *>(src) + o, m);
-        BG_HIP(hipMemcpyAsync(reinterpret_cast<char *>(dst) + o, hp, m, hipMemcpyHostToDevice, c->stream));
-        BG_HIP(hipStreamSynchronize(c->stream));
+    if (bytes <= kBounceDirect || registered || runtime_pins()) {
+        const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) return 0;
+        (void)hipGetLastError();
+        if (e != hipErrorInvalidValue) return hip_fail(e, "hipMemcpyAsync (host to device)");
+    }
+    char *h[2];
+    BG_TRY(bounce_get(c, &h[0], &h[1]));
+    const size_t pieces = (bytes + kBouncePiece - 1) / kBouncePiece;
+    for (size_t k = 0; k < pieces; k++) {
+        const size_t m = k + 1 < pieces ? kBouncePiece : bytes - k * kBouncePiece;
+        if (c->bounce_busy[k & 1]) BG_HIP(hipEventSynchronize(c->bounce_ev[k & 1]));   // the DMA that last read this half is done
+        memcpy(h[k & 1], reinterpret_cast<const char *>(src) + k * kBouncePiece, m);
+        BG_HIP(hipMemcpyAsync(reinterpret_cast<char *>(dst) + k * kBouncePiece, h[k & 1], m, hipMemcpyHostToDevice, c->stream));
+        BG_HIP(hipEventRecord(c->bounce_ev[k & 1], c->stream));
+        c->bounce_busy[k & 1] = true;
     }
     return 0;
 }
@@ -429,8 +482,9 @@ int devout_finish(Ctx *c, DevOut *d, int64_t slots, int32_t type, int64_t null_c
     if (out->residency == BOWGPU_DEVICE) {
         if (copy_bitmap) BG_HIP(hipMemcpyAsync(out->validity, d->validity, vb, hipMemcpyDeviceToDevice, c->stream));
     } else {
-        BG_TRY(copy_d2h(c, out->values, d->values, (size_t)slots * 8));
-        BG_TRY(copy_d2h(c, out->validity, d->validity, vb));
+        // (registered buffers take the DMA directly; pageable ones go through the staging halves)
+        BG_TRY(copy_d2h(c, out->values, d->values, (size_t)slots * 8, out->residency == BOWGPU_HOST_PINNED));
+        BG_TRY(copy_d2h(c, out->validity, d->validity, vb, out->residency == BOWGPU_HOST_PINNED));
     }
     return 0;
 }
@@ -693,6 +747,7 @@ static int job_build(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t ts_c
         if (k == BOWGPU_AGG_MIN || k == BOWGPU_AGG_MAX) fl |= kPassMinMax;
         if (k == BOWGPU_AGG_FIRST || k == BOWGPU_AGG_LAST) fl |= kPassFirstLast;
         if (d.out_valid) fl |= kPassNullable;
+        if (k >= BOWGPU_AGG_INTEGRAL_STEP && k <= BOWGPU_AGG_WAVG_LINEAR && d.slot >= 0) P.cols[d.slot].need_ts = 1;
         P.pass_flags[idx] |= fl;
         if (d.slot < P.first_pass_slot) P.first_pass_slot = d.slot;
         if (kind_reads_values(k) && d.slot > P.last_val_slot) P.last_val_slot = d.slot;
@@ -885,6 +940,12 @@ static int job_launch_tiles(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t
         BG_TRY(launch_rolling_fast(c, P));
         c->last_kernel_name = "rolling_wave_kernel";
     } else {
+        static const bool trace = [] { const char *t = getenv("BOWGPU_TRACE_ROUTE"); return t && t[0] == '1'; }();
+        if (trace && !(force && force[0] == '1'))
+            fprintf(stderr, "bowgpu route: general kernel (n=%lld W=%lld interval=%lld inclusive=%d naggs=%d pre_rows=%lld wid_base=%lld "
+                            "fits32=%d allow_simple=%d plan=%d first_ts=%lld s0=%lld)\n", (long long)P.n, (long long)P.W,
+                    (long long)P.interval, (int)job->inclusive, naggs, (long long)P.pre_rows, (long long)P.wid_base, (int)P.fits32,
+                    (int)allow_simple, plan ? 1 : 0, plan ? (long long)plan->first_ts : 0ll, (long long)P.s0);
         BG_TRY(launch_rolling_aggregate(c, P));
         c->last_kernel_name = "rolling_agg_kernel";
     }
@@ -940,8 +1001,15 @@ static int job_run(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, i
             BG_TRY(launch_preset_bitmaps(c, b));
         }
         BG_HIP(hipEventRecord(c->ev0, c->stream));
-        int64_t n_all = 0;
-        BG_TRY(run_long_windows(c, P, nullptr, &n_all));
+        int64_t n_all = W;
+        const char *cls = getenv("BOWGPU_LONG_CLASSIC");   // test / A-B switch: the bisection + per-window chunks form
+        if ((cls && cls[0] == '1') || P.n / W >= kLongClassicAvgRows || W >= (1ll << 32)) {
+            BG_TRY(run_long_windows(c, P, nullptr, &n_all));
+        } else {
+            void *w;
+            BG_TRY(ctx_pool(c, Ctx::kPoolSlots - 1, long_stream_workspace(P.n, P.W, P.ncols), &w));
+            BG_TRY(launch_long_stream(c, P, w));
+        }
         BG_HIP(hipEventRecord(c->ev1, c->stream));
         c->last_kernel_name = "long_partial_kernel";
         uint32_t *hs;
@@ -1290,7 +1358,7 @@ int bowgpu_memcpy_h2d(void *dst, const void *src, int64_t bytes) {
     Ctx *c;
     BG_TRY(ctx_get(&c));
     if (bytes > 0) {
-        BG_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
+        BG_TRY(copy_h2d(c, dst, src, (size_t)bytes));
         BG_HIP(hipStreamSynchronize(c->stream));
     }
     return 0;
@@ -1300,7 +1368,7 @@ int bowgpu_memcpy_d2h(void *dst, const void *src, int64_t bytes) {
     Ctx *c;
     BG_TRY(ctx_get(&c));
     if (bytes > 0) {
-        BG_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
+        BG_TRY(copy_d2h(c, dst, src, (size_t)bytes));
         BG_HIP(hipStreamSynchronize(c->stream));
     }
     return 0;
@@ -1966,7 +2034,7 @@ int bowgpu_debug_status(int32_t first, int32_t n, uint32_t *out, int32_t zero_af
     Ctx *c;
     BG_TRY(ctx_get(&c));
     if (!out || first < 0 || n <= 0 || (size_t)(first + n) * 4 > 8192 || !c->d_scratch) return fail(BOWGPU_ERR_ARG, "bad status range");
-    BG_HIP(hipMemcpyAsync(out, reinterpret_cast<uint32_t *>(c->d_scratch) + first, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    BG_TRY(copy_d2h(c, out, reinterpret_cast<uint32_t *>(c->d_scratch) + first, (size_t)n * 4));
     BG_HIP(hipStreamSynchronize(c->stream));
     if (zero_after) BG_HIP(hipMemsetAsync(reinterpret_cast<uint32_t *>(c->d_scratch) + first, 0, (size_t)n * 4, c->stream));
     return 0;

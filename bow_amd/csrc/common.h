@@ -39,7 +39,9 @@ struct Ctx {
     size_t d_scratch_bytes = 0;
     void *h_pinned = nullptr;
     size_t h_pinned_bytes = 0;
-    void *h_bounce = nullptr;   // 1 MB, copy_d2h/copy_h2d's fallback
+    void *h_bounce = nullptr;   // two halves of pinned staging for copies of pageable caller buffers (copy_d2h / copy_h2d)
+    hipEvent_t bounce_ev[2] = {nullptr, nullptr};
+    bool bounce_busy[2] = {false, false};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double last_kernel_ms = 0.0;
     const char *last_kernel_name = "";  // the tile kernel last_kernel_ms brackets
@@ -120,8 +122,9 @@ struct DevOut {
     DevBuf own_values, own_validity;
     bowgpu_out *user = nullptr;
 };
-int copy_d2h(Ctx *c, void *dst, const void *src, size_t bytes);   // caller buffers: fall back to a bounce through the pinned block
-int copy_h2d(Ctx *c, void *dst, const void *src, size_t bytes);
+// copies of caller buffers: pageable ones through the context's pinned staging, registered ones (BOWGPU_HOST_PINNED) directly
+int copy_d2h(Ctx *c, void *dst, const void *src, size_t bytes, bool registered = false);
+int copy_h2d(Ctx *c, void *dst, const void *src, size_t bytes, bool registered = false);
 int devout_prepare(Ctx *c, bowgpu_out *out, int64_t slots, DevOut *d, int pool_slot = -1);
 int devout_finish(Ctx *c, DevOut *d, int64_t slots, int32_t type, int64_t null_count, bool copy_bitmap = true);
 
@@ -237,7 +240,9 @@ int launch_rolling_tw(Ctx *c, const SimpleParams &p, bool is_int, bool has_nulls
 int launch_rolling_aggregate(Ctx *c, const AggParams &p);   // general kernel (rolling_agg.hip)
 int launch_rolling_fast(Ctx *c, const AggParams &p);        // lean kernel for exclusive windows without time-weighted reducers (rolling_fast.hip)
 constexpr int kLongChunkRows = 4096;
-constexpr int64_t kLongOnlyAvgRows = 512;   // windows averaging at least this many rows skip the tile kernels (api.cpp job_run)
+constexpr int kLongStreamRows = 512;  // chunk of the streaming form of the long-window reduction (long_windows.hip)
+constexpr int64_t kLongOnlyAvgRows = 128;   // windows averaging at least this many rows skip the tile kernels (api.cpp job_run)
+constexpr int64_t kLongClassicAvgRows = 32768;   // ... and from here on the handful of giant windows go by bisection + per-window chunks
 constexpr int kLongLists = 64;      // sub-lists of the long-window queue (agg_device.h push_long_window)
 constexpr int kLongCountWord = 16;  // status[kLongCountWord + s] = entries in sub-list s
 constexpr int kStatusWords = kLongCountWord + kLongLists;
@@ -249,6 +254,8 @@ int stream_rw_run(Ctx *c, const void *a, const void *b, int64_t bytes_each, void
 int stream_sum_run(Ctx *c, const void *a, const void *b, int64_t bytes_each, int mode, int blocks_per_cu, int reps, uint64_t *d_out, float *ms);
 int launch_long_windows_v2(Ctx *c, const AggParams &p, const LongListStarts *starts, void *entries, int32_t *nchunks, int64_t *offsets,
                            int64_t *block_sums, int64_t *d_total, int32_t *work_entry, void *partials, int64_t max_work);
+size_t long_stream_workspace(int64_t n, int64_t W, int ncols);
+int launch_long_stream(Ctx *c, const AggParams &p, void *workspace);   // every window of the call, one read of the rows
 int launch_fix_tail_bits(Ctx *c, uint8_t *bitmap, int64_t nbits);
 // every output bitmap of one call in one launch (rolling_agg.hip)
 struct BitmapBatch {

@@ -20,7 +20,8 @@ struct ByteOut {
 
 int copy_or_alias(Ctx *c, void *user, int residency, const void *dev, size_t nbytes) {
     if (nbytes == 0 || !user) return 0;
-    BG_HIP(hipMemcpyAsync(user, dev, nbytes, residency == BOWGPU_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+    if (residency == BOWGPU_DEVICE) BG_HIP(hipMemcpyAsync(user, dev, nbytes, hipMemcpyDeviceToDevice, c->stream));
+    else BG_TRY(copy_d2h(c, user, dev, nbytes, residency == BOWGPU_HOST_PINNED));
     return 0;
 }
 
@@ -80,10 +81,10 @@ int bowgpu_window_bounds(const bowgpu_col *ts, int64_t interval, const bowgpu_op
     uint32_t hstat[4] = {0, 0, 0, 0};
     BG_HIP(hipMemcpyAsync(hstat, status, 16, hipMemcpyDeviceToHost, c->stream));
     if (!dev) {
-        if (first_index) BG_HIP(hipMemcpyAsync(first_index, pfi, (size_t)W * 8, hipMemcpyDeviceToHost, c->stream));
-        if (slice_begin) BG_HIP(hipMemcpyAsync(slice_begin, psb, (size_t)W * 8, hipMemcpyDeviceToHost, c->stream));
-        if (slice_end) BG_HIP(hipMemcpyAsync(slice_end, pse, (size_t)W * 8, hipMemcpyDeviceToHost, c->stream));
-        if (is_inclusive) BG_HIP(hipMemcpyAsync(is_inclusive, pin, (size_t)W, hipMemcpyDeviceToHost, c->stream));
+        if (first_index) BG_TRY(copy_d2h(c, first_index, pfi, (size_t)W * 8));
+        if (slice_begin) BG_TRY(copy_d2h(c, slice_begin, psb, (size_t)W * 8));
+        if (slice_end) BG_TRY(copy_d2h(c, slice_end, pse, (size_t)W * 8));
+        if (is_inclusive) BG_TRY(copy_d2h(c, is_inclusive, pin, (size_t)W));
     }
     BG_HIP(hipStreamSynchronize(c->stream));
     if (hstat[0]) return fail(BOWGPU_ERR_TS_UNSORTED, "interval column is not ascending: outside the device path");

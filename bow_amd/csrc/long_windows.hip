@@ -21,6 +21,7 @@ namespace bowgpu {
 namespace {
 
 constexpr int kChunkRows = kLongChunkRows;
+constexpr int kStreamRows = kLongStreamRows;   // the streaming form's chunk (one wavefront)
 
 struct LongEntry {
     uint64_t wid;
@@ -105,6 +106,117 @@ __device__ __forceinline__ void block_reduce(Part &acc, Part *red /* [4], LDS */
     }
 }
 
+// partial `i` of an array of Part, or - lite - of {sum, count} pairs (what Sum / Mean / Count need: the streaming form's
+// storage when no reducer of the call wants more)
+struct PartLite { double sum; int64_t count; };
+__device__ __forceinline__ Part part_at(const Part *base, int64_t i, int lite) {
+    if (!lite) return base[i];
+    const PartLite l = reinterpret_cast<const PartLite *>(base)[i];
+    Part q;
+    part_init(q);
+    q.sum = l.sum; q.count = l.count;
+    return q;
+}
+
+// window id of a row's timestamp (rows below s0 ride in window 0: SURVEY A.5)
+__device__ __forceinline__ uint64_t row_wid(const AggParams &p, int64_t t) {
+    return (p.pre_rows && t < p.s0) ? 0ull : magic_div((uint64_t)t - (uint64_t)p.s0, p.magic);
+}
+
+// wid, r0 and r1 known: what follows the window (rolling.go:197-209) - the next non-empty window, whether the row at r1 sits
+// exactly on the window's end (an inclusive window takes it), whether window 0 is made of rows below s0 only
+__device__ __forceinline__ void entry_close(const AggParams &p, LongEntry &le) {
+    uint64_t next_wid = (uint64_t)(p.wid_base + p.W);
+    bool at_start = false;
+    if (le.r1 < p.n) {
+        const int64_t t = p.ts[le.r1];
+        next_wid = magic_div((uint64_t)t - (uint64_t)p.s0, p.magic);
+        at_start = (t == p.s0 + (int64_t)(next_wid * (uint64_t)p.interval));
+    }
+    le.next_wid = next_wid;
+    le.incl_row = (p.inclusive && le.r1 < p.n && at_start && next_wid == le.wid + 1) ? 1 : 0;
+    le.dead = (p.pre_rows && le.r0 == 0 && !(p.ts[le.r1 - 1] >= p.s0 || le.incl_row)) ? 1 : 0;
+}
+
+// first row >= lo whose timestamp reaches the end of window `wid` (p.n when none), by bisection in global memory
+__device__ __forceinline__ int64_t window_end_row(const AggParams &p, uint64_t wid, int64_t lo) {
+    const int64_t win_start = p.s0 + (int64_t)(wid * (uint64_t)p.interval);
+    const int64_t lim = win_start + p.interval;
+    if (lim < win_start) return p.n;  // int64 overflow: no row can reach it
+    int64_t hi = p.n;
+    while (lo < hi) {
+        const int64_t mid = lo + ((hi - lo) >> 1);
+        if (p.ts[mid] >= lim) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
+// The outputs of one column pass (slot; -1: the reducers that need no column) for window `w`, from its merged order-free partial
+__device__ __forceinline__ void emit_window(const AggParams &p, int slot, const LongEntry &w, const Part &acc) {
+    const unsigned my_mask = p.pass_mask[slot + 1];
+    const ColDesc *cd = slot >= 0 ? &p.cols[slot] : nullptr;
+    const int col_type = cd ? cd->type : BOWGPU_INT64;
+    const bool need_vals = cd && (p.pass_flags[slot + 1] & kPassNeedVals);
+    const uint64_t *vp = cd ? reinterpret_cast<const uint64_t *>(cd->values) : nullptr;
+    const int64_t win_start = p.s0 + (int64_t)(w.wid * (uint64_t)p.interval);
+    const int64_t oslot = (int64_t)(w.wid - (uint64_t)p.wid_base);
+    const int64_t len = w.dead ? 0 : w.r1 - w.r0;
+    if ((uint64_t)oslot >= (uint64_t)p.W) return;
+    // rebuild the reference's running state from the order-free partial
+    Stats st;
+    stats_init(st);
+    st.sum = acc.sum; st.count = acc.count; st.has_value = acc.first_idx >= 0;
+    if (st.has_value) {
+        st.first_bits = vp[acc.first_idx]; st.last_bits = vp[acc.last_idx];
+        const double f = bits_to_f64(st.first_bits, col_type);
+        // minmax.go:16-28: seeded by the first valid value; a NaN seed is never replaced
+        st.vmin = (f != f) ? f : (acc.min_idx >= 0 ? acc.vmin : f);
+        st.vmax = (f != f) ? f : (acc.max_idx >= 0 ? acc.vmax : f);
+        st.has_point = 1; st.pt = (double)p.ts[acc.last_idx]; st.pv = bits_to_f64(st.last_bits, col_type);
+        st.integ_trap = acc.trap; st.integ_step = acc.step; st.has_pair = acc.count >= 2;
+    }
+    // the state including the inclusive row, for the reducers that want it (aggregation.go:207-211)
+    Stats st_incl = st;
+    if (w.incl_row && need_vals && col_valid(*cd, w.r1)) {
+        const uint64_t raw = vp[w.r1];
+        const double x = bits_to_f64(raw, col_type);
+        stats_value<false>(st_incl, x, raw);
+        stats_point(st_incl, (double)p.ts[w.r1], x);
+    }
+    for (unsigned m = my_mask; m; m &= m - 1) {
+        const AggDesc &a = p.aggs[__ffs(m) - 1];
+        const bool inc = a.kind == BOWGPU_AGG_INTEGRAL_TRAPEZOID || a.kind == BOWGPU_AGG_WAVG_LINEAR;
+        Val v = finish_val(reduce_val(a.kind, inc ? st_incl : st, inc ? len + w.incl_row : len, win_start, p.interval,
+                                      col_type == BOWGPU_INT64), a);
+        reinterpret_cast<uint64_t *>(a.out_values)[oslot] = v.bits;
+        if (a.out_valid) {
+            if (v.valid) atomicOr(&a.out_valid[oslot >> 5], 1u << (oslot & 31));
+            else if (p.bits_preset) atomicAnd(&a.out_valid[oslot >> 5], ~(1u << (oslot & 31)));
+        }
+    }
+}
+
+// the empty windows gk = first, first + step, ... <= gap behind window `w`, same pass
+__device__ __forceinline__ void emit_empties(const AggParams &p, int slot, const LongEntry &w, int64_t gap, int64_t first, int64_t step) {
+    const unsigned my_mask = p.pass_mask[slot + 1];
+    const int col_type = slot >= 0 ? p.cols[slot].type : BOWGPU_INT64;
+    const int64_t win_start = p.s0 + (int64_t)(w.wid * (uint64_t)p.interval);
+    const int64_t oslot = (int64_t)(w.wid - (uint64_t)p.wid_base);
+    Stats em;
+    stats_init(em);
+    for (int64_t gk = first; gk <= gap; gk += step) {
+        const int64_t gs = oslot + gk;
+        if (gs < 0 || gs >= p.W) break;
+        const int64_t gstart = win_start + gk * p.interval;
+        for (unsigned m = my_mask; m; m &= m - 1) {
+            const AggDesc &a = p.aggs[__ffs(m) - 1];
+            Val v = finish_val(reduce_val(a.kind, em, 0, gstart, p.interval, col_type == BOWGPU_INT64), a);
+            reinterpret_cast<uint64_t *>(a.out_values)[gs] = v.bits;
+            if (p.bits_preset && a.out_valid && !v.valid) atomicAnd(&a.out_valid[gs >> 5], ~(1u << (gs & 31)));
+        }
+    }
+}
+
 }  // namespace
 
 __global__ __launch_bounds__(256) void long_bounds_kernel(const AggParams p, const LongListStarts starts, LongEntry *entries,
@@ -126,17 +238,9 @@ __global__ __launch_bounds__(256) void long_bounds_kernel(const AggParams p, con
         if (p.ts[mid] >= lim) hi = mid; else lo = mid + 1;
     }
     const int64_t r1 = ovf ? p.n : lo;
-    uint64_t next_wid = (uint64_t)(p.wid_base + p.W);
-    bool at_start = false;
-    if (r1 < p.n) {
-        const int64_t t = p.ts[r1];
-        next_wid = magic_div((uint64_t)t - (uint64_t)p.s0, p.magic);
-        at_start = (t == p.s0 + (int64_t)(next_wid * (uint64_t)p.interval));
-    }
     LongEntry le;
-    le.wid = wid; le.r0 = r0; le.r1 = r1; le.next_wid = next_wid;
-    le.incl_row = (p.inclusive && r1 < p.n && at_start && next_wid == wid + 1) ? 1 : 0;
-    le.dead = (p.pre_rows && r0 == 0 && !(p.ts[r1 - 1] >= p.s0 || le.incl_row)) ? 1 : 0;
+    le.wid = wid; le.r0 = r0; le.r1 = r1;
+    entry_close(p, le);
     entries[e] = le;
     nchunks[e] = (int32_t)((r1 - r0 + kChunkRows - 1) / kChunkRows);
 }
@@ -281,162 +385,477 @@ __global__ __launch_bounds__(256) void long_final_kernel(const AggParams p, cons
         const bool need_vals = cd && (p.pass_flags[slot + 1] & kPassNeedVals);
         const uint64_t *vp = cd ? reinterpret_cast<const uint64_t *>(cd->values) : nullptr;
 
-        // the outputs of window `w` (an entry) from its merged partial
-        auto finish = [&](const LongEntry &w, const Part &acc) {
-            const int64_t win_start = p.s0 + (int64_t)(w.wid * (uint64_t)p.interval);
-            const int64_t oslot = (int64_t)(w.wid - (uint64_t)p.wid_base);
-            const int64_t len = w.dead ? 0 : w.r1 - w.r0;
-            if ((uint64_t)oslot >= (uint64_t)p.W) return;
-            // rebuild the reference's running state from the order-free partial
-            Stats st;
-            stats_init(st);
-            st.sum = acc.sum; st.count = acc.count; st.has_value = acc.first_idx >= 0;
-            if (st.has_value) {
-                st.first_bits = vp[acc.first_idx]; st.last_bits = vp[acc.last_idx];
-                const double f = bits_to_f64(st.first_bits, col_type);
-                // minmax.go:16-28: seeded by the first valid value; a NaN seed is never replaced
-                st.vmin = (f != f) ? f : (acc.min_idx >= 0 ? acc.vmin : f);
-                st.vmax = (f != f) ? f : (acc.max_idx >= 0 ? acc.vmax : f);
-                st.has_point = 1; st.pt = (double)p.ts[acc.last_idx]; st.pv = bits_to_f64(st.last_bits, col_type);
-                st.integ_trap = acc.trap; st.integ_step = acc.step; st.has_pair = acc.count >= 2;
-            }
-            // the state including the inclusive row, for the reducers that want it (aggregation.go:207-211)
-            Stats st_incl = st;
-            if (w.incl_row && need_vals && col_valid(*cd, w.r1)) {
-                const uint64_t raw = vp[w.r1];
-                const double x = bits_to_f64(raw, col_type);
-                stats_value<false>(st_incl, x, raw);
-                stats_point(st_incl, (double)p.ts[w.r1], x);
-            }
-            for (unsigned m = my_mask; m; m &= m - 1) {
-                const AggDesc &a = p.aggs[__ffs(m) - 1];
-                const bool inc = a.kind == BOWGPU_AGG_INTEGRAL_TRAPEZOID || a.kind == BOWGPU_AGG_WAVG_LINEAR;
-                Val v = finish_val(reduce_val(a.kind, inc ? st_incl : st, inc ? len + w.incl_row : len, win_start, p.interval,
-                                              col_type == BOWGPU_INT64), a);
-                reinterpret_cast<uint64_t *>(a.out_values)[oslot] = v.bits;
-                if (a.out_valid) {
-                    if (v.valid) atomicOr(&a.out_valid[oslot >> 5], 1u << (oslot & 31));
-                    else if (p.bits_preset) atomicAnd(&a.out_valid[oslot >> 5], ~(1u << (oslot & 31)));
-                }
-            }
-        };
-        // the empty windows gk = first, first + step, ... <= gap behind window `w`
-        auto empties = [&](const LongEntry &w, int64_t gap, int64_t first, int64_t step) {
-            const int64_t win_start = p.s0 + (int64_t)(w.wid * (uint64_t)p.interval);
-            const int64_t oslot = (int64_t)(w.wid - (uint64_t)p.wid_base);
-            Stats em;
-            stats_init(em);
-            for (int64_t gk = first; gk <= gap; gk += step) {
-                const int64_t gs = oslot + gk;
-                if (gs < 0 || gs >= p.W) break;
-                const int64_t gstart = win_start + gk * p.interval;
-                for (unsigned m = my_mask; m; m &= m - 1) {
-                    const AggDesc &a = p.aggs[__ffs(m) - 1];
-                    Val v = finish_val(reduce_val(a.kind, em, 0, gstart, p.interval, col_type == BOWGPU_INT64), a);
-                    reinterpret_cast<uint64_t *>(a.out_values)[gs] = v.bits;
-                    if (p.bits_preset && a.out_valid && !v.valid) atomicAnd(&a.out_valid[gs >> 5], ~(1u << (gs & 31)));
-                }
-            }
-        };
-
         if (simple) {
             Part acc;
             part_init(acc);
             if (need_vals)
                 for (int64_t w = w0; w < w1; w++) part_merge(acc, partials[w * p.ncols + slot]);  // (at most kLaneParts, in order)
-            finish(le, acc);
-            empties(le, my_gap, 1, 1);
+            emit_window(p, slot, le, acc);
+            emit_empties(p, slot, le, my_gap, 1, 1);
         }
     }
 }
 
-// The windows long_final_kernel leaves (many chunk partials, or a long run of empty windows behind them): one workgroup per
-// window merges its chunk partials in a fixed shape, writes the outputs, then the empty windows that follow it
-__global__ __launch_bounds__(256) void long_final_block_kernel(const AggParams p, const LongEntry *entries, const int64_t *offsets,
-                                                               const Part *partials, const int32_t *leftover,
-                                                               const unsigned long long *n_leftover) {
+// The windows the lane-per-window kernels leave (many chunk partials, or a long run of empty windows behind them): one workgroup
+// per window merges its chunk partials in a fixed shape, writes the outputs, then the empty windows that follow it.
+// leftover: indices into entries / off0 / off1 (nullptr: the lists are compact, entry i).  stream_chunks > 0: the entries come
+// from stream_final_kernel - windows that ran past its look-ahead; their end is found here by bisection, their partials are
+// [off0, 2 * (chunk of the end) + 1) of the chunk grid, and the empty windows are not theirs to write.
+__global__ __launch_bounds__(256) void long_final_block_kernel(const AggParams p, const LongEntry *entries, const int64_t *off0,
+                                                               const int64_t *off1, const Part *partials, const int32_t *leftover,
+                                                               const unsigned long long *n_leftover, const int64_t stream_chunks, const int lite) {
     __shared__ Part red[4];
+    __shared__ LongEntry s_le;
+    __shared__ int64_t s_w1;
     const int64_t nleft = (int64_t)*n_leftover;  // (usually 0: the launch then costs a few microseconds)
     for (int64_t i = blockIdx.x; i < nleft; i += gridDim.x) {
-    const int64_t e = leftover[i];
-    const LongEntry le = entries[e];
-    const int lane = threadIdx.x;
-    const int64_t win_start = p.s0 + (int64_t)(le.wid * (uint64_t)p.interval);
-    const int64_t oslot = (int64_t)(le.wid - (uint64_t)p.wid_base);
-    const int64_t len = le.dead ? 0 : le.r1 - le.r0;
-
-    for (int slot = -1; slot < p.ncols; slot++) {
-        const unsigned my_mask = p.pass_mask[slot + 1];
-        if (my_mask == 0) continue;
-        const ColDesc *cd = slot >= 0 ? &p.cols[slot] : nullptr;
-        const int col_type = cd ? cd->type : BOWGPU_INT64;
-        Part acc;
-        part_init(acc);
-        if (cd && (p.pass_flags[slot + 1] & kPassNeedVals)) {
-            const int64_t w0 = offsets[e], w1 = offsets[e + 1];
-            if (w1 - w0 == 1) {  // the common medium-sized window: nothing to merge
-                if (lane == 0) acc = partials[w0 * p.ncols + slot];
-            } else {
-                for (int64_t w = w0 + lane; w < w1; w += 256) part_merge(acc, partials[w * p.ncols + slot]);
-                block_reduce(acc, red, lane);
-                __syncthreads();
+        const int64_t e = leftover ? leftover[i] : i;
+        const int lane = threadIdx.x;
+        if (lane == 0) {
+            LongEntry le = entries[e];
+            int64_t w1 = off1[e];
+            if (stream_chunks > 0) {
+                le.r1 = window_end_row(p, le.wid, le.r0 + 1);
+                entry_close(p, le);
+                le.next_wid = le.wid + 1;
+                w1 = 2 * (le.r1 / kStreamRows) + 1;
+                if (w1 > 2 * stream_chunks) w1 = 2 * stream_chunks;
             }
+            s_le = le;
+            s_w1 = w1;
         }
-        if (lane == 0 && (uint64_t)oslot < (uint64_t)p.W) {
-            // rebuild the reference's running state from the order-free partial
-            const uint64_t *vp = cd ? reinterpret_cast<const uint64_t *>(cd->values) : nullptr;
-            Stats st;
-            stats_init(st);
-            auto fill = [&](Stats &s, const Part &a) {
-                s.sum = a.sum; s.count = a.count; s.has_value = a.first_idx >= 0;
-                if (s.has_value) {
-                    s.first_bits = vp[a.first_idx]; s.last_bits = vp[a.last_idx];
-                    const double f = bits_to_f64(s.first_bits, col_type);
-                    // minmax.go:16-28: seeded by the first valid value; a NaN seed is never replaced
-                    s.vmin = (f != f) ? f : (a.min_idx >= 0 ? a.vmin : f);
-                    s.vmax = (f != f) ? f : (a.max_idx >= 0 ? a.vmax : f);
-                    s.has_point = 1; s.pt = (double)p.ts[a.last_idx]; s.pv = bits_to_f64(s.last_bits, col_type);
-                    s.integ_trap = a.trap; s.integ_step = a.step; s.has_pair = a.count >= 2;
-                }
-            };
-            fill(st, acc);
-            // the state including the inclusive row, for the reducers that want it (aggregation.go:207-211)
-            Stats st_incl = st;
-            if (le.incl_row && cd && (p.pass_flags[slot + 1] & kPassNeedVals) && col_valid(*cd, le.r1)) {
-                const uint64_t raw = vp[le.r1];
-                const double x = bits_to_f64(raw, col_type);
-                stats_value<false>(st_incl, x, raw);
-                stats_point(st_incl, (double)p.ts[le.r1], x);
-            }
-            for (unsigned m = my_mask; m; m &= m - 1) {
-                const AggDesc &a = p.aggs[__ffs(m) - 1];
-                const bool inc = a.kind == BOWGPU_AGG_INTEGRAL_TRAPEZOID || a.kind == BOWGPU_AGG_WAVG_LINEAR;
-                Val v = finish_val(reduce_val(a.kind, inc ? st_incl : st, inc ? len + le.incl_row : len, win_start, p.interval,
-                                              col_type == BOWGPU_INT64), a);
-                reinterpret_cast<uint64_t *>(a.out_values)[oslot] = v.bits;
-                if (a.out_valid) {
-                    if (v.valid) atomicOr(&a.out_valid[oslot >> 5], 1u << (oslot & 31));
-                    else if (p.bits_preset) atomicAnd(&a.out_valid[oslot >> 5], ~(1u << (oslot & 31)));
-                }
-            }
-        }
-        // empty windows after this one
+        __syncthreads();
+        const LongEntry le = s_le;
+        const int64_t w0 = off0[e], w1 = s_w1;
         const int64_t gap = (int64_t)(le.next_wid - le.wid) - 1;
-        Stats em;
-        stats_init(em);
-        for (int64_t gk = 1 + lane; gk <= gap; gk += 256) {
-            const int64_t gs = oslot + gk;
-            if (gs < 0 || gs >= p.W) break;
-            const int64_t gstart = win_start + gk * p.interval;
-            for (unsigned m = my_mask; m; m &= m - 1) {
-                const AggDesc &a = p.aggs[__ffs(m) - 1];
-                Val v = finish_val(reduce_val(a.kind, em, 0, gstart, p.interval, col_type == BOWGPU_INT64), a);
-                reinterpret_cast<uint64_t *>(a.out_values)[gs] = v.bits;
-                if (p.bits_preset && a.out_valid && !v.valid) atomicAnd(&a.out_valid[gs >> 5], ~(1u << (gs & 31)));
+        for (int slot = -1; slot < p.ncols; slot++) {
+            if (p.pass_mask[slot + 1] == 0) continue;
+            Part acc;
+            part_init(acc);
+            if (slot >= 0 && (p.pass_flags[slot + 1] & kPassNeedVals)) {
+                if (w1 - w0 == 1) {  // the common medium-sized window: nothing to merge
+                    if (lane == 0) acc = part_at(partials, w0 * p.ncols + slot, lite);
+                } else {
+                    for (int64_t w = w0 + lane; w < w1; w += 256) part_merge(acc, part_at(partials, w * p.ncols + slot, lite));
+                    block_reduce(acc, red, lane);
+                    __syncthreads();
+                }
+            }
+            if (lane == 0) emit_window(p, slot, le, acc);
+            emit_empties(p, slot, le, gap, 1 + lane, 256);
+        }
+        __syncthreads();  // (red[], s_le are reused by the next entry)
+    }
+}
+
+// ---------------------------------------------------------------- the streaming form (every window of the call, one read of the rows)
+//
+// When the windows of a call average a hundred rows or more, the lane-per-window tile kernels would queue most of them for the
+// pipeline above, which then reads the rows a second time.  Instead: ONE pass over the rows on a fixed grid of kStreamRows-row
+// chunks, one wavefront per chunk (long_stream_kernel).  The wave stages its timestamps in LDS (checking their order on the
+// way), cuts the chunk into its windows' segments by a wave-wide search for each window's end, and reduces every segment (lanes
+// stride its rows, then a butterfly) into an order-free partial:
+//   - a window that starts and ends inside the chunk: its partial goes to wparts[window], its rows to recs[window];
+//   - the rows of a window that began in an earlier chunk go to the chunk's HEAD partial, the rows of one that runs on into the
+//     next chunk to its TAIL partial: parts[2 g] / parts[2 g + 1] (identity partials when unused), so that the partials of a window
+//     that spans chunks g .. k are the consecutive range [2 g + 1, 2 k + 1); recs[window] names the chunk it starts in.
+// stream_final_kernel then finishes the windows, one LANE per window of the call: empty ones (no record), the ones inside a
+// chunk, and the ones over a few chunks (it walks the heads that follow); windows over many chunks go to
+// long_final_block_kernel.  Same order-free reducers and the same tolerance as above; every row is read once.
+struct ChunkMeta {
+    int32_t head_rows;    // leading rows that belong to the window of the row before the chunk (the whole chunk: it runs through)
+};
+struct WinRec {
+    int64_t r0;           // first row of the window; < 0: the window has no rows
+    int32_t rows;         // its rows when it lies inside one chunk; -1: it runs on into the chunks after `chunk`
+    int32_t chunk;
+};
+
+constexpr int kStreamScan = 64;   // chunks a lane of stream_final_kernel looks ahead for the end of its window
+
+__device__ __forceinline__ uint32_t magic_div32(uint32_t n, uint32_t m, uint32_t sh1, uint32_t sh2) {
+    const uint32_t t = __umulhi(m, n);
+    return (t + ((n - t) >> sh1)) >> sh2;
+}
+
+typedef unsigned long long u64x2s_t __attribute__((ext_vector_type(2)));
+// rows i0, i0 + 1 of the chunk (i0 even) as one 16-byte streaming load when the column allows it
+__device__ __forceinline__ void stream_load_pair(const uint64_t *base, int i0, int rows, bool vec, uint64_t &x, uint64_t &y) {
+    if (vec && i0 + 1 < rows) {
+        const u64x2s_t q = __builtin_nontemporal_load(reinterpret_cast<const u64x2s_t *>(base + i0));
+        x = q.x; y = q.y;
+    } else {
+        x = i0 < rows ? __builtin_nontemporal_load(base + i0) : 0;
+        y = i0 + 1 < rows ? __builtin_nontemporal_load(base + i0 + 1) : 0;
+    }
+}
+
+// ---- one DPP move of a 32-bit / 64-bit lane value; lanes without a source receive 0
+template <int kCtrl, int kRowMask, bool kBound>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t x) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, kCtrl, kRowMask, 0xf, kBound);
+}
+template <int kCtrl, int kRowMask, bool kBound>
+__device__ __forceinline__ double dpp_f64(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), kCtrl, kRowMask, 0xf, kBound);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), kCtrl, kRowMask, 0xf, kBound);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double x, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+}
+
+// The order-free partial of a run of rows as the segmented scan carries it: row indices are 1 + the row's index in the chunk
+// (0: none), so that the zero a DPP move hands to a lane without a source is the identity.
+template <int kNeed>
+struct SegVal {
+    double sum;
+    uint32_t cnt;
+    uint32_t first, last;       // kNeed != 0
+    double vmin, vmax;          // kNeed & 1
+    uint32_t imin, imax;
+    double trap, step;          // kNeed & 4
+};
+template <int kNeed>
+__device__ __forceinline__ SegVal<kNeed> seg_identity() {
+    SegVal<kNeed> v;
+    v.sum = 0.0; v.cnt = 0; v.first = 0; v.last = 0; v.vmin = 0.0; v.vmax = 0.0; v.imin = 0; v.imax = 0; v.trap = 0.0; v.step = 0.0;
+    return v;
+}
+// a (earlier rows) followed by b (later rows)
+template <int kNeed>
+__device__ __forceinline__ SegVal<kNeed> seg_join(const SegVal<kNeed> &a, const SegVal<kNeed> &b) {
+    SegVal<kNeed> r = b;
+    r.sum = a.sum + b.sum;
+    r.cnt = a.cnt + b.cnt;
+    if (kNeed != 0) { r.first = a.first ? a.first : b.first; r.last = b.last ? b.last : a.last; }
+    if (kNeed & 1) {   // ties keep the smaller row index: a's
+        if (a.imin && (!b.imin || a.vmin <= b.vmin)) { r.vmin = a.vmin; r.imin = a.imin; }
+        if (a.imax && (!b.imax || a.vmax >= b.vmax)) { r.vmax = a.vmax; r.imax = a.imax; }
+    }
+    if (kNeed & 4) { r.trap = a.trap + b.trap; r.step = a.step + b.step; }
+    return r;
+}
+template <int kNeed, int kCtrl, int kRowMask, bool kBound>
+__device__ __forceinline__ SegVal<kNeed> seg_dpp(const SegVal<kNeed> &v) {
+    SegVal<kNeed> r = seg_identity<kNeed>();
+    r.sum = dpp_f64<kCtrl, kRowMask, kBound>(v.sum);
+    r.cnt = dpp_u32<kCtrl, kRowMask, kBound>(v.cnt);
+    if (kNeed != 0) { r.first = dpp_u32<kCtrl, kRowMask, kBound>(v.first); r.last = dpp_u32<kCtrl, kRowMask, kBound>(v.last); }
+    if (kNeed & 1) {
+        r.vmin = dpp_f64<kCtrl, kRowMask, kBound>(v.vmin); r.vmax = dpp_f64<kCtrl, kRowMask, kBound>(v.vmax);
+        r.imin = dpp_u32<kCtrl, kRowMask, kBound>(v.imin); r.imax = dpp_u32<kCtrl, kRowMask, kBound>(v.imax);
+    }
+    if (kNeed & 4) { r.trap = dpp_f64<kCtrl, kRowMask, kBound>(v.trap); r.step = dpp_f64<kCtrl, kRowMask, kBound>(v.step); }
+    return r;
+}
+template <int kNeed>
+__device__ __forceinline__ SegVal<kNeed> seg_readlane(const SegVal<kNeed> &v, int l) {
+    SegVal<kNeed> r = seg_identity<kNeed>();
+    r.sum = readlane_f64(v.sum, l);
+    r.cnt = (uint32_t)__builtin_amdgcn_readlane((int)v.cnt, l);
+    if (kNeed != 0) { r.first = (uint32_t)__builtin_amdgcn_readlane((int)v.first, l); r.last = (uint32_t)__builtin_amdgcn_readlane((int)v.last, l); }
+    if (kNeed & 1) {
+        r.vmin = readlane_f64(v.vmin, l); r.vmax = readlane_f64(v.vmax, l);
+        r.imin = (uint32_t)__builtin_amdgcn_readlane((int)v.imin, l); r.imax = (uint32_t)__builtin_amdgcn_readlane((int)v.imax, l);
+    }
+    if (kNeed & 4) { r.trap = readlane_f64(v.trap, l); r.step = readlane_f64(v.step, l); }
+    return r;
+}
+// one step of the segmented inclusive scan: lanes whose run has not met a boundary yet take the incoming prefix
+template <int kNeed, int kCtrl, int kRowMask, bool kBound>
+__device__ __forceinline__ void seg_step(SegVal<kNeed> &v, uint32_t &f) {
+    const SegVal<kNeed> in = seg_dpp<kNeed, kCtrl, kRowMask, kBound>(v);
+    const uint32_t fin = dpp_u32<kCtrl, kRowMask, kBound>(f);
+    if (!f) v = seg_join<kNeed>(in, v);
+    f |= fin;
+}
+// partial -> storage slot i: a Part, or (kNeed == 0) a PartLite
+template <int kNeed>
+__device__ __forceinline__ void seg_store(Part *base, int64_t i, const SegVal<kNeed> &v, int64_t c0) {
+    if (kNeed == 0) {
+        PartLite l;
+        l.sum = v.sum; l.count = (int64_t)v.cnt;
+        reinterpret_cast<PartLite *>(base)[i] = l;
+    } else {
+        Part q;
+        part_init(q);
+        q.sum = v.sum; q.count = (int64_t)v.cnt;
+        q.first_idx = v.first ? c0 + v.first - 1 : -1; q.last_idx = v.last ? c0 + v.last - 1 : -1;
+        if (kNeed & 1) {
+            q.vmin = v.vmin; q.vmax = v.vmax;
+            q.min_idx = v.imin ? c0 + v.imin - 1 : -1; q.max_idx = v.imax ? c0 + v.imax - 1 : -1;
+        }
+        if (kNeed & 4) { q.trap = v.trap; q.step = v.step; }
+        base[i] = q;
+    }
+}
+
+// kNeed: 1 extrema, 2 first / last, 4 time-weighted terms (any of them: the row indices are tracked); 0: {sum, count} storage.
+// One wavefront per chunk; lane l holds rows 128 j + 2 l, + 1 of the chunk for trip j (16-byte loads), nothing goes through
+// LDS.  Per trip: the rows' window ids (relative to the chunk's first window: 32-bit arithmetic when the chunk allows it), a
+// boundary flag per row (its id differs from the row before), then a SEGMENTED inclusive scan of the rows' partials over the 64
+// lanes (DPP: row_shr 1 / 2 / 4 / 8, row_bcast 15 / 31) with the running partial carried from trip to trip in scalar
+// registers.  Every boundary row closes the window of the row before it: the lane that holds the boundary writes that
+// window's partial and record.
+template <int kNeed>
+__global__ __launch_bounds__(256) void long_stream_kernel(const AggParams p, const int64_t nchunks, ChunkMeta *meta, Part *parts,
+                                                          WinRec *recs, Part *wparts) {
+    typedef SegVal<kNeed> SV;
+    constexpr bool kMinMax = (kNeed & 1) != 0, kTw = (kNeed & 4) != 0, kIdx = kNeed != 0;
+    constexpr int kTrips = kStreamRows / 128;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t g = (int64_t)blockIdx.x * 4 + wv;
+    if (g >= nchunks) return;
+    const int64_t c0 = g * kStreamRows;
+    const int rows = (int)(p.n - c0 < kStreamRows ? p.n - c0 : kStreamRows);
+    const bool has_prev = c0 > 0, has_next = c0 + rows < p.n;
+    const uint64_t *tsp = reinterpret_cast<const uint64_t *>(p.ts);
+    const bool tvec = (reinterpret_cast<uintptr_t>(p.ts) & 15) == 0;
+    int slot0 = -1;   // the first column pass that reads values: its loads travel with the timestamps'
+    for (int sl = p.ncols - 1; sl >= 0; sl--)
+        if (p.pass_mask[sl + 1] && (p.pass_flags[sl + 1] & kPassNeedVals)) slot0 = sl;
+
+    uint64_t tx[kTrips], ty[kTrips], vx[kTrips], vy[kTrips];
+#pragma unroll
+    for (int j = 0; j < kTrips; j++) stream_load_pair(tsp + c0, j * 128 + 2 * lane, rows, tvec, tx[j], ty[j]);
+    if (slot0 >= 0) {
+        const uint64_t *vp = reinterpret_cast<const uint64_t *>(p.cols[slot0].values);
+        const bool vvec = (reinterpret_cast<uintptr_t>(vp) & 15) == 0;
+#pragma unroll
+        for (int j = 0; j < kTrips; j++) stream_load_pair(vp + c0, j * 128 + 2 * lane, rows, vvec, vx[j], vy[j]);
+    }
+    // (uniform: scalar loads) the rows around the chunk and its first / last row
+    const int64_t ts_prev = p.ts[has_prev ? c0 - 1 : c0], ts_next = p.ts[has_next ? c0 + rows : c0 + rows - 1];
+    const int64_t ts_first = p.ts[c0], ts_last = p.ts[c0 + rows - 1];
+    const uint64_t wid0 = row_wid(p, ts_first);
+    const int64_t start0 = p.s0 + (int64_t)(wid0 * (uint64_t)p.interval);
+    const bool fast32 = p.fits32 && ts_last >= ts_first && (uint64_t)ts_last - (uint64_t)start0 < 0xFFFFFFFFull;
+    const uint32_t rel_last = (uint32_t)(row_wid(p, ts_last) - wid0);
+    const bool prev_same = has_prev && (ts_prev >= start0 || wid0 == 0);      // (rows are ascending; rows below s0 ride in window 0)
+    bool next_same = false;
+    {
+        const uint64_t wl = wid0 + rel_last;
+        const int64_t ws = p.s0 + (int64_t)(wl * (uint64_t)p.interval), lim = ws + p.interval;
+        next_same = has_next && (lim < ws || ts_next < lim);
+    }
+    auto rel_of = [&](int64_t t) -> uint32_t {
+        if (fast32) return t < start0 ? 0u : magic_div32((uint32_t)((uint64_t)t - (uint64_t)start0), p.m32, p.sh1_32, p.sh2_32);
+        return (uint32_t)(row_wid(p, t) - wid0);
+    };
+
+    // ---- window ids, boundary flags, order check, the start row of the run each row belongs to (1 + row; 0: before the chunk)
+    uint32_t relx[kTrips], rely[kTrips], pst[kTrips], fmask = 0;
+    int head_rows = 0;     // (one lane) the boundary that closes the window running in from the chunks before
+    uint32_t carry_rel = 0, carry_st = 0;
+    {
+        bool bad = false;
+        int64_t carry_ts = ts_prev;
+#pragma unroll
+        for (int j = 0; j < kTrips; j++) {
+            const int i0 = j * 128 + 2 * lane;
+            const bool inx = i0 < rows, iny = i0 + 1 < rows;
+            const int64_t x = (int64_t)tx[j], y = (int64_t)ty[j];
+            const int64_t py = (int64_t)((uint64_t)(uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)carry_ts, (int)(uint32_t)(uint64_t)y, 0x138, 0xf, 0xf, false) |
+                                         (uint64_t)(uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)((uint64_t)carry_ts >> 32), (int)(uint32_t)((uint64_t)y >> 32), 0x138, 0xf, 0xf, false) << 32);
+            bad |= (inx && py > x) || (iny && x > y);
+            carry_ts = (int64_t)((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)y, 63) |
+                                 (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)y >> 32), 63) << 32);
+            const uint32_t rx = inx ? rel_of(x) : rel_last, ry = iny ? rel_of(y) : rel_last;
+            relx[j] = rx; rely[j] = ry;
+            const uint32_t prel = (uint32_t)__builtin_amdgcn_update_dpp((int)carry_rel, (int)ry, 0x138, 0xf, 0xf, false);
+            const bool fx = inx && ((j == 0 && lane == 0) ? !prev_same : prel != rx);
+            const bool fy = iny && ry != rx;
+            fmask |= (fx ? 1u : 0u) << (2 * j) | (fy ? 2u : 0u) << (2 * j);
+            carry_rel = (uint32_t)__builtin_amdgcn_readlane((int)ry, 63);
+            // start of the run in front of row x: the latest boundary among the rows before it (plain max-scan + carry)
+            uint32_t m = fy ? (uint32_t)(i0 + 2) : (fx ? (uint32_t)(i0 + 1) : 0u);
+            auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+            m = mx(m, dpp_u32<0x111, 0xf, true>(m)); m = mx(m, dpp_u32<0x112, 0xf, true>(m));
+            m = mx(m, dpp_u32<0x114, 0xf, true>(m)); m = mx(m, dpp_u32<0x118, 0xf, true>(m));
+            m = mx(m, dpp_u32<0x142, 0xa, false>(m)); m = mx(m, dpp_u32<0x143, 0xc, false>(m));
+            const uint32_t mprev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x138, 0xf, 0xf, false);
+            pst[j] = mx(carry_st, mprev);
+            carry_st = mx(carry_st, (uint32_t)__builtin_amdgcn_readlane((int)m, 63));
+            // the records of the windows these boundaries close
+            const uint32_t row_x = (uint32_t)i0, row_y = (uint32_t)(i0 + 1);
+            if (fx && row_x > 0) {
+                if (pst[j] == 0) head_rows = (int)row_x;
+                else {
+                    const int64_t oslot = (int64_t)(wid0 + prel - (uint64_t)p.wid_base);
+                    if ((uint64_t)oslot < (uint64_t)p.W) { WinRec r; r.r0 = c0 + pst[j] - 1; r.rows = (int32_t)(row_x - (pst[j] - 1)); r.chunk = (int32_t)g; recs[oslot] = r; }
+                }
+            }
+            if (fy) {
+                const uint32_t st = fx ? row_x + 1 : pst[j];
+                if (st == 0) head_rows = (int)row_y;
+                else {
+                    const int64_t oslot = (int64_t)(wid0 + rx - (uint64_t)p.wid_base);
+                    if ((uint64_t)oslot < (uint64_t)p.W) { WinRec r; r.r0 = c0 + st - 1; r.rows = (int32_t)(row_y - (st - 1)); r.chunk = (int32_t)g; recs[oslot] = r; }
+                }
+            }
+        }
+        if (lane == 0) bad |= ts_last > ts_next;
+        if (__ballot(bad) && lane == 0) atomicOr(&p.status[0], 1u);
+    }
+    // the run that reaches the end of the chunk: through (no boundary at all), a whole window, or one that runs on
+    const bool through = carry_st == 0;
+    const bool tail_open = !through && next_same;
+    const int64_t tail_slot = (int64_t)(wid0 + rel_last - (uint64_t)p.wid_base);
+    const unsigned long long hm = __ballot(head_rows != 0);
+    const int hr = through ? rows : (hm ? __shfl(head_rows, __ffsll((long long)hm) - 1) : 0);
+    if (lane == 0) {
+        meta[g].head_rows = hr;
+        if (!through && (uint64_t)tail_slot < (uint64_t)p.W) {
+            WinRec r;
+            r.r0 = c0 + carry_st - 1; r.rows = tail_open ? -1 : (int32_t)(rows - (int)(carry_st - 1)); r.chunk = (int32_t)g;
+            recs[tail_slot] = r;
+        }
+    }
+
+    // ---- per column pass: the rows' partials, the segmented scan, the partials of the closed windows
+    for (int slot = 0; slot < p.ncols; slot++) {
+        if (p.pass_mask[slot + 1] == 0 || !(p.pass_flags[slot + 1] & kPassNeedVals)) continue;
+        const ColDesc &cd = p.cols[slot];
+        const uint64_t *vp = reinterpret_cast<const uint64_t *>(cd.values);
+        const bool need_ts = kTw && cd.need_ts;
+        if (slot != slot0) {
+            const bool vvec = (reinterpret_cast<uintptr_t>(vp) & 15) == 0;
+#pragma unroll
+            for (int j = 0; j < kTrips; j++) stream_load_pair(vp + c0, j * 128 + 2 * lane, rows, vvec, vx[j], vy[j]);
+        }
+        SV carry = seg_identity<kNeed>();   // (uniform) the run that reaches into the current trip
+        bool head_done = false;
+#pragma unroll
+        for (int j = 0; j < kTrips; j++) {
+            const int i0 = j * 128 + 2 * lane;
+            const bool fx = (fmask >> (2 * j)) & 1u, fy = (fmask >> (2 * j)) & 2u;
+            auto elem = [&](int i, uint64_t raw, int64_t t, uint32_t rel) -> SV {
+                SV e = seg_identity<kNeed>();
+                if (i >= rows || !col_valid(cd, c0 + i)) return e;
+                const double x = bits_to_f64(raw, cd.type);
+                e.sum = x; e.cnt = 1;
+                if (kIdx) { e.first = (uint32_t)(i + 1); e.last = (uint32_t)(i + 1); }
+                if (kMinMax && x == x) { e.vmin = x; e.vmax = x; e.imin = (uint32_t)(i + 1); e.imax = (uint32_t)(i + 1); }
+                if (need_ts) {   // the term of the pair (this point, next both-valid point inside the window)
+                    const int64_t rn = col_next_valid(cd, c0 + i + 1, p.n);
+                    if (rn >= 0) {
+                        const uint64_t wid = wid0 + rel;
+                        const int64_t ws = p.s0 + (int64_t)(wid * (uint64_t)p.interval), lim = ws + p.interval;
+                        const int64_t tn = p.ts[rn];
+                        if (lim < ws || tn < lim) {
+                            const double t0 = (double)t, t1 = (double)tn;
+                            const double x1 = bits_to_f64(vp[rn], cd.type);
+                            e.trap = (x + x1) / 2 * (t1 - t0);   // integral.go:24
+                            e.step = x * (t1 - t0);              // integral.go:55
+                        }
+                    }
+                }
+                return e;
+            };
+            const SV ex = elem(i0, vx[j], (int64_t)tx[j], relx[j]), ey = elem(i0 + 1, vy[j], (int64_t)ty[j], rely[j]);
+            // the lane's run since its last boundary, scanned over the lanes
+            SV v = fy ? ey : seg_join<kNeed>(ex, ey);
+            uint32_t f = (fx || fy) ? 1u : 0u;
+            seg_step<kNeed, 0x111, 0xf, true>(v, f);
+            seg_step<kNeed, 0x112, 0xf, true>(v, f);
+            seg_step<kNeed, 0x114, 0xf, true>(v, f);
+            seg_step<kNeed, 0x118, 0xf, true>(v, f);
+            seg_step<kNeed, 0x142, 0xa, false>(v, f);
+            seg_step<kNeed, 0x143, 0xc, false>(v, f);
+            // exclusive: what lies in front of row x in its run (lane 0: the carry)
+            SV before = seg_dpp<kNeed, 0x138, 0xf, false>(v);
+            const uint32_t fbefore = dpp_u32<0x138, 0xf, false>(f);
+            if (!fbefore) before = seg_join<kNeed>(carry, before);
+            const SV upto_x = fx ? ex : seg_join<kNeed>(before, ex);
+            // closed windows
+            // (the id of the row before row x: a DPP move, so outside the divergent code below)
+            const uint32_t prel0 = j > 0 ? (uint32_t)__builtin_amdgcn_readlane((int)rely[j > 0 ? j - 1 : 0], 63) : 0u;
+            const uint32_t prel = (uint32_t)__builtin_amdgcn_update_dpp((int)prel0, (int)rely[j], 0x138, 0xf, 0xf, false);
+            if (fx && i0 > 0) {
+                if (pst[j] == 0) { seg_store<kNeed>(parts, (2 * g) * p.ncols + slot, before, c0); }
+                else {
+                    const int64_t oslot = (int64_t)(wid0 + prel - (uint64_t)p.wid_base);
+                    if ((uint64_t)oslot < (uint64_t)p.W) seg_store<kNeed>(wparts, oslot * p.ncols + slot, before, c0);
+                }
+            }
+            if (fy) {
+                const uint32_t st = fx ? (uint32_t)(i0 + 1) : pst[j];
+                if (st == 0) { seg_store<kNeed>(parts, (2 * g) * p.ncols + slot, upto_x, c0); }
+                else {
+                    const int64_t oslot = (int64_t)(wid0 + relx[j] - (uint64_t)p.wid_base);
+                    if ((uint64_t)oslot < (uint64_t)p.W) seg_store<kNeed>(wparts, oslot * p.ncols + slot, upto_x, c0);
+                }
+            }
+            // the run that leaves the trip
+            const SV last = seg_readlane<kNeed>(v, 63);
+            const uint32_t flast = (uint32_t)__builtin_amdgcn_readlane((int)f, 63);
+            carry = flast ? last : seg_join<kNeed>(carry, last);
+        }
+        (void)head_done;
+        if (lane == 0) {
+            const SV id = seg_identity<kNeed>();
+            if (through) {
+                seg_store<kNeed>(parts, (2 * g) * p.ncols + slot, carry, c0);
+                seg_store<kNeed>(parts, (2 * g + 1) * p.ncols + slot, id, c0);
+            } else {
+                if (hr == 0) seg_store<kNeed>(parts, (2 * g) * p.ncols + slot, id, c0);
+                if (tail_open) seg_store<kNeed>(parts, (2 * g + 1) * p.ncols + slot, carry, c0);
+                else {
+                    seg_store<kNeed>(parts, (2 * g + 1) * p.ncols + slot, id, c0);
+                    if ((uint64_t)tail_slot < (uint64_t)p.W) seg_store<kNeed>(wparts, tail_slot * p.ncols + slot, carry, c0);
+                }
             }
         }
     }
-    __syncthreads();  // (red[] is reused by the next entry)
+}
+
+// One lane per window of the call: the empty ones (no record), the ones inside one chunk (their partial is ready), and the ones
+// over a few chunks (walk the heads that follow the chunk they start in, merge the range of partials).  Windows that run
+// further than kStreamScan chunks are queued for long_final_block_kernel: entries / off0 / off1 [i], i < *n_leftover.
+__global__ __launch_bounds__(256) void stream_final_kernel(const AggParams p, const int64_t nchunks, const ChunkMeta *meta,
+                                                           const Part *parts, const WinRec *recs, const Part *wparts,
+                                                           LongEntry *entries, int64_t *off0, int64_t *off1,
+                                                           unsigned long long *n_leftover, const int lite) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= p.W) return;
+    const WinRec rec = recs[k];
+    LongEntry le;
+    le.wid = (uint64_t)(p.wid_base + k); le.r0 = rec.r0; le.r1 = -1; le.next_wid = le.wid + 1; le.incl_row = 0; le.dead = 0;
+    if (rec.r0 < 0) {   // no rows: the reducers' values for an empty window (window k itself: "0 windows behind it")
+        for (int slot = -1; slot < p.ncols; slot++)
+            if (p.pass_mask[slot + 1]) emit_empties(p, slot, le, 0, 0, 1);
+        return;
+    }
+    const int64_t g = rec.chunk;
+    int64_t w0 = 2 * g + 1, w1 = w0;
+    if (rec.rows >= 0) {
+        le.r1 = rec.r0 + rec.rows;
+    } else {
+        for (int64_t c = g + 1; c <= g + kStreamScan; c++) {
+            if (c >= nchunks) { le.r1 = p.n; w1 = 2 * nchunks; break; }
+            const int64_t rows_c = p.n - c * kStreamRows < kStreamRows ? p.n - c * kStreamRows : kStreamRows;
+            const int64_t hr = meta[c].head_rows;
+            if (hr < rows_c) { le.r1 = c * kStreamRows + hr; w1 = 2 * c + 1; break; }
+        }
+        if (le.r1 < 0) {
+            const unsigned long long i = atomicAdd(n_leftover, 1ull);
+            entries[i] = le;
+            off0[i] = w0;
+            off1[i] = w1;
+            return;
+        }
+    }
+    if (p.inclusive || p.pre_rows) entry_close(p, le);   // (the row behind the window / rows below s0 matter only then)
+    for (int slot = -1; slot < p.ncols; slot++) {
+        if (p.pass_mask[slot + 1] == 0) continue;
+        Part acc;
+        part_init(acc);
+        if (slot >= 0 && (p.pass_flags[slot + 1] & kPassNeedVals)) {
+            if (rec.rows >= 0) acc = part_at(wparts, k * p.ncols + slot, lite);
+            else for (int64_t w = w0; w < w1; w++) part_merge(acc, part_at(parts, w * p.ncols + slot, lite));
+        }
+        emit_window(p, slot, le, acc);
     }
 }
 
@@ -470,7 +889,50 @@ int launch_long_windows_v2(Ctx *c, const AggParams &p, const LongListStarts *sta
     hipLaunchKernelGGL(long_final_kernel, dim3((unsigned)((n_long + 255) / 256)), dim3(256), 0, c->stream, p, n_long,
                        reinterpret_cast<const LongEntry *>(entries), offsets, reinterpret_cast<const Part *>(partials), work_entry, n_leftover);
     hipLaunchKernelGGL(long_final_block_kernel, dim3((unsigned)(n_long < 2048 ? n_long : 2048)), dim3(256), 0, c->stream, p,
-                       reinterpret_cast<const LongEntry *>(entries), offsets, reinterpret_cast<const Part *>(partials), work_entry, n_leftover);
+                       reinterpret_cast<const LongEntry *>(entries), offsets, offsets + 1, reinterpret_cast<const Part *>(partials),
+                       (const int32_t *)work_entry, n_leftover, (int64_t)0, 0);
+    BG_HIP(hipGetLastError());
+    return 0;
+}
+
+// The streaming form: every window of the call in one read of the rows.  Workspace (bytes): long_stream_workspace(n, W, ncols).
+static size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+size_t long_stream_workspace(int64_t n, int64_t W, int ncols) {
+    const size_t nch = (size_t)((n + kStreamRows - 1) / kStreamRows), nc = (size_t)(ncols > 0 ? ncols : 1), w = (size_t)(W > 0 ? W : 1);
+    return up256(nch * sizeof(ChunkMeta)) + up256(nch * 2 * nc * sizeof(Part)) + up256(w * sizeof(WinRec)) + up256(w * nc * sizeof(Part)) +
+           up256(nch * sizeof(LongEntry)) + 2 * up256(nch * 8) + 256;
+}
+
+int launch_long_stream(Ctx *c, const AggParams &p, void *workspace) {
+    if (p.n <= 0 || p.W <= 0) return 0;
+    const size_t nch = (size_t)((p.n + kStreamRows - 1) / kStreamRows), nc = (size_t)(p.ncols > 0 ? p.ncols : 1), w = (size_t)p.W;
+    char *q = reinterpret_cast<char *>(workspace);
+    ChunkMeta *meta = reinterpret_cast<ChunkMeta *>(q); q += up256(nch * sizeof(ChunkMeta));
+    Part *parts = reinterpret_cast<Part *>(q); q += up256(nch * 2 * nc * sizeof(Part));
+    WinRec *recs = reinterpret_cast<WinRec *>(q); q += up256(w * sizeof(WinRec));
+    Part *wparts = reinterpret_cast<Part *>(q); q += up256(w * nc * sizeof(Part));
+    LongEntry *entries = reinterpret_cast<LongEntry *>(q); q += up256(nch * sizeof(LongEntry));
+    int64_t *off0 = reinterpret_cast<int64_t *>(q); q += up256(nch * 8);
+    int64_t *off1 = reinterpret_cast<int64_t *>(q); q += up256(nch * 8);
+    unsigned long long *n_leftover = reinterpret_cast<unsigned long long *>(q);
+    BG_HIP(hipMemsetAsync(n_leftover, 0, 8, c->stream));
+    BG_HIP(hipMemsetAsync(recs, 0xFF, w * sizeof(WinRec), c->stream));   // r0 = -1: no rows
+    int need = 0;
+    for (int sl = 0; sl < p.ncols; sl++) {
+        if (p.pass_flags[sl + 1] & kPassMinMax) need |= 1;
+        if (p.pass_flags[sl + 1] & kPassFirstLast) need |= 2;
+        if (p.cols[sl].need_ts) need |= 4;
+    }
+    const dim3 grid((unsigned)((nch + 3) / 4)), block(256);
+    const int64_t nchunks = (int64_t)nch;
+    if (need == 0) hipLaunchKernelGGL(long_stream_kernel<0>, grid, block, 0, c->stream, p, nchunks, meta, parts, recs, wparts);
+    else if (!(need & 4) && !(need & 1)) hipLaunchKernelGGL(long_stream_kernel<2>, grid, block, 0, c->stream, p, nchunks, meta, parts, recs, wparts);
+    else if (!(need & 4)) hipLaunchKernelGGL(long_stream_kernel<3>, grid, block, 0, c->stream, p, nchunks, meta, parts, recs, wparts);
+    else hipLaunchKernelGGL(long_stream_kernel<7>, grid, block, 0, c->stream, p, nchunks, meta, parts, recs, wparts);
+    hipLaunchKernelGGL(stream_final_kernel, dim3((unsigned)((p.W + 255) / 256)), dim3(256), 0, c->stream, p, nchunks, meta, parts, recs, wparts,
+                       entries, off0, off1, n_leftover, need == 0 ? 1 : 0);
+    hipLaunchKernelGGL(long_final_block_kernel, dim3((unsigned)(nch < 2048 ? nch : 2048)), dim3(256), 0, c->stream, p, entries, off0, off1,
+                       parts, (const int32_t *)nullptr, n_leftover, nchunks, need == 0 ? 1 : 0);
     BG_HIP(hipGetLastError());
     return 0;
 }

@@ -464,7 +464,7 @@ static int parquet_read_column_impl(bowgpu_parquet *handle, int32_t i, bowgpu_ou
     BG_TRY(ctx_pool(c, kPoolInterp + 1, pages.size() * sizeof(PqPage) + 32, &d_pages));
     if (any_comp) BG_TRY(ctx_pool(c, kPoolInterp + 2, (size_t)raw_total + 32, &d_raw));
     for (const Span &sp : spans)
-        BG_HIP(hipMemcpyAsync(reinterpret_cast<char *>(d_bytes) + sp.dev_off, pf->map + sp.file_off, (size_t)sp.len, hipMemcpyHostToDevice, c->stream));
+        BG_TRY(copy_h2d(c, reinterpret_cast<char *>(d_bytes) + sp.dev_off, pf->map + sp.file_off, (size_t)sp.len));
     BG_HIP(hipMemcpyAsync(d_pages, pages.data(), pages.size() * sizeof(PqPage), hipMemcpyHostToDevice, c->stream));
     void *dscr;
     BG_TRY(ctx_scratch(c, 8192, &dscr));

@@ -7,6 +7,7 @@ sys.path.insert(0, ROOT)
 from bench import kernel_source_sha   # hash of the sources the benched kernel is compiled from
 
 sha = kernel_source_sha()
+BENCH_GRID = 100_000_000   # work-items of the benched launch (1e9 rows = 1 953 125 tiles x 64 lanes); smaller launches of the same kernel are other legs
 
 # 1. kernel stats
 rows = []
@@ -25,8 +26,8 @@ with open("%s/%s_pmc_hbm_traffic_bench_1e9.csv" % (out, tag), "w", newline="") a
     for sub in ("fetch", "write"):
         for f in glob.glob(out + "/" + sub + "/**/*counter_collection.csv", recursive=True):
             for r in csv.DictReader(open(f)):
-                if "rolling" not in r["Kernel_Name"]:
-                    continue
+                if "rolling" not in r["Kernel_Name"] or int(r["Grid_Size"]) < BENCH_GRID:
+                    continue     # (the bench line's host_pinned leg runs the same kernel over 1e8 rows: not the benched launch)
                 w.writerow([r["Kernel_Name"], r["Counter_Name"], r["Counter_Value"], r["Dispatch_Id"], sha])
 
 # 3. the SQ / L2 / L1 counter table of the benched kernel (averages over its dispatches)
@@ -36,13 +37,13 @@ name = None
 for sub in ("sq1", "sq2", "tcc", "tcp", "fetch", "write"):
     for f in glob.glob(out + "/" + sub + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if "rolling_simple_kernel" in r["Kernel_Name"]:
+            if "rolling_simple_kernel" in r["Kernel_Name"] and int(r["Grid_Size"]) >= BENCH_GRID:
                 name = r["Kernel_Name"]
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 dur = []
 for f in glob.glob(out + "/stats/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "rolling_simple_kernel" in r["Kernel_Name"]:
+        if "rolling_simple_kernel" in r["Kernel_Name"] and int(r["Grid_Size_X"]) >= BENCH_GRID:
             dur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
 with open("%s/%s_pmc_counters_bench_1e9.txt" % (out, tag), "w") as fh:
     fh.write("kernel: %s\nsource_sha: %s\n" % (name, sha))

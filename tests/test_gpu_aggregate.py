@@ -82,9 +82,9 @@ def run_both(ts, cols_np, interval, aggs, offset=0, inclusive=False, device=Fals
     first = None
     # three HIP code paths over the same inputs: simple kernel where it applies (else lean), lean kernel, general kernel
     # (the lean / general runs also switch the long-only shortcut off, so windows of thousands of rows take both long paths)
-    for label, env in (("auto", {}), ("lean", {"BOWGPU_NO_SIMPLE": "1", "BOWGPU_NO_LONG_ONLY": "1"}),
+    for label, env in (("auto", {}), ("classic-long", {"BOWGPU_LONG_CLASSIC": "1"}), ("lean", {"BOWGPU_NO_SIMPLE": "1", "BOWGPU_NO_LONG_ONLY": "1"}),
                        ("general", {"BOWGPU_FORCE_GENERAL": "1", "BOWGPU_NO_LONG_ONLY": "1"})):
-        for k in ("BOWGPU_NO_SIMPLE", "BOWGPU_FORCE_GENERAL", "BOWGPU_NO_LONG_ONLY"):
+        for k in ("BOWGPU_NO_SIMPLE", "BOWGPU_FORCE_GENERAL", "BOWGPU_NO_LONG_ONLY", "BOWGPU_LONG_CLASSIC"):
             os.environ[k] = env.get(k, "0")
         try:
             outs, info = capi.rolling_aggregate(ccols, 0, interval, aggs, offset=offset, inclusive=inclusive,
@@ -93,6 +93,7 @@ def run_both(ts, cols_np, interval, aggs, offset=0, inclusive=False, device=Fals
             os.environ["BOWGPU_NO_SIMPLE"] = "0"
             os.environ["BOWGPU_FORCE_GENERAL"] = "0"
             os.environ["BOWGPU_NO_LONG_ONLY"] = "0"
+            os.environ["BOWGPU_LONG_CLASSIC"] = "0"
         assert info.new_interval_col == nic
         for k, g, w in zip(_names(aggs), outs, exp):
             exact = info.long_windows == 0 or k not in ORDER_SENSITIVE
