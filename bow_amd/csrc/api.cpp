@@ -941,7 +941,8 @@ static int job_launch_tiles(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t
         c->last_kernel_name = "rolling_wave_kernel";
     } else {
         static const bool trace = [] { const char *t = getenv("BOWGPU_TRACE_ROUTE"); return t && t[0] == '1'; }();
-        if (trace && !(force && force[0] == '1'))
+        const char *nos = getenv("BOWGPU_NO_SIMPLE");
+        if (trace && !(force && force[0] == '1') && !(nos && nos[0] == '1') && allow_simple)
             fprintf(stderr, "bowgpu route: general kernel (n=%lld W=%lld interval=%lld inclusive=%d naggs=%d pre_rows=%lld wid_base=%lld "
                             "fits32=%d allow_simple=%d plan=%d first_ts=%lld s0=%lld)\n", (long long)P.n, (long long)P.W,
                     (long long)P.interval, (int)job->inclusive, naggs, (long long)P.pre_rows, (long long)P.wid_base, (int)P.fits32,

@@ -134,8 +134,11 @@ typedef struct bowgpu_agg_info {
     int64_t num_windows;        /* W (rolling.go:143-154) */
     int32_t new_interval_col;   /* index of the LAST aggregator reading the interval column (aggregation.go:152-161) */
     int32_t inclusive;          /* effective Options.Inclusive after validateAggregation (aggregation.go:183-185) */
-    int64_t long_windows;       /* windows reduced by the cooperative (non-sequential-order) path: Sum/Mean/Integral
-                                   of those are within 1e-12 relative, everything else is bit-exact */
+    int64_t long_windows;       /* windows reduced in an ORDER-FREE form instead of the reference's left-to-right walk: windows longer
+                                   than a tile's look-ahead (128 rows), and every window of a call whose windows average >= 128
+                                   rows.  THE STATED TOLERANCE: Sum / ArithmeticMean / Integral* / WeightedAverage* of those windows
+                                   are within 1e-12 relative of the reference (fixed, deterministic summation tree); every other
+                                   reducer, and every window when this is 0, is bit-exact */
     double kernel_ms;           /* device time of the kernels of this call (HIP events on the library stream) */
 } bowgpu_agg_info;
 
