@@ -1006,13 +1006,14 @@ static int job_run(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, i
         const char *cls = getenv("BOWGPU_LONG_CLASSIC");   // test / A-B switch: the bisection + per-window chunks form
         if ((cls && cls[0] == '1') || P.n / W >= kLongClassicAvgRows || W >= (1ll << 32)) {
             BG_TRY(run_long_windows(c, P, nullptr, &n_all));
+            c->last_kernel_name = "long_partial_kernel";
         } else {
             void *w;
             BG_TRY(ctx_pool(c, Ctx::kPoolSlots - 1, long_stream_workspace(P.n, P.W, P.ncols), &w));
             BG_TRY(launch_long_stream(c, P, w));
+            c->last_kernel_name = "long_stream_kernel";
         }
         BG_HIP(hipEventRecord(c->ev1, c->stream));
-        c->last_kernel_name = "long_partial_kernel";
         uint32_t *hs;
         uint64_t *hc = nullptr;
         if (finish) BG_TRY(job_enqueue_tail(c, job, aggs, naggs));

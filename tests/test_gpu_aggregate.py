@@ -398,6 +398,41 @@ def test_long_windows_mixed_shapes(inclusive):
         assert info.long_windows >= 5
 
 
+def test_streaming_form_chunk_edges():
+    """The one-read streaming form (windows averaging >= 128 rows) on shapes built around its 512-row chunks: window boundaries exactly
+    on chunk edges and one row off them, windows of exactly one chunk / several chunks / more chunks than a lane of the finish kernel
+    looks ahead, a partial last chunk of 1 .. 511 rows, empty windows between long ones, an all-null window, Int64 values,
+    time-weighted reducers and inclusive windows, rows below s0 in a long window 0 - against the oracle and against the
+    bisection form (`classic-long` in run_both)."""
+    rng = np.random.default_rng(512)
+    base_aggs = [(k, 0 if k == "WindowStart" else 1) for k in ALL_AGGS]
+    tw = [("WindowStart", 0)] + [(k, 1) for k in TIME_AGGS] + [("Sum", 2), ("Max", 2)]
+    for n in (512 * 9, 512 * 9 + 1, 512 * 9 - 1, 512 * 40 + 255, 513, 511 * 3):
+        for first in (0, 1, 511, -700):
+            ts = np.arange(n, dtype=np.int64) + first
+            f, fv = make_vals(rng, n, "f64", 0.2)
+            i, iv = make_vals(rng, n, "i64", 0.1)
+            fv[512:1024] = False                         # one chunk with no valid value at all
+            for interval in (512, 256, 1024, 1536, 130, 700):
+                if n // interval < 1 or n / max(1, (n // interval + 2)) < 128:
+                    continue
+                for offset in (0, 1, interval - 1):
+                    outs, exp, info = run_both(ts, [(f, fv), (i, iv)], interval, base_aggs + [("Sum", 2), ("Min", 2)], offset=offset)
+                    assert info.long_windows == info.num_windows > 0, (n, first, interval, offset)
+                run_both(ts, [(f, fv), (i, iv)], interval, tw, offset=3, inclusive=True)
+    # windows over more chunks than a lane of stream_final_kernel walks (64) next to short ones, and runs of empty windows
+    pieces, t = [], 0
+    for rows in (40_000, 3, 600, 70_000, 1, 513, 33_000):
+        pieces.append(t + np.sort(rng.integers(0, 1000, rows)))
+        t += 1000 * int(rng.integers(1, 6))
+    ts = np.concatenate(pieces).astype(np.int64)
+    f, fv = make_vals(rng, len(ts), "f64", 0.3)
+    outs, exp, info = run_both(ts, [(f, fv)], 1000, base_aggs + [(k, 1) for k in TIME_AGGS])
+    assert info.long_windows == info.num_windows
+    capi.rolling_aggregate([capi.Column(ts), capi.Column(f, np.packbits(fv, bitorder="little"), capi.FLOAT64, 0, len(ts), -1)], 0, 1000, base_aggs)
+    assert capi.last_kernel_name() == "long_stream_kernel"
+
+
 def test_nanosecond_timestamps_beyond_2_53():
     # nanosecond timestamps far above 2^53, where float64(ts) is lossy - and that lossy value is what the time-weighted
     # reducers read (integral.go:17,:49) - positive and negative; 1 s windows (tile kernels) and 1 day windows (long-window path).
