@@ -22,20 +22,26 @@ constexpr int kHaloT = 128;
 constexpr int kRowsT = kTileT + kHaloT;
 constexpr int kChunksT = kRowsT / 128;
 constexpr uint32_t kSatT = 0xFFFFu;
-// At most kSegCapT windows may start inside one tile (+ look-ahead); denser tiles (windows of < 1.6 rows on average)
-// send the call to the general kernel.  A wave's LDS: 11.8 KB => 13 resident waves per CU.
-constexpr int kSegCapT = 400;
+// At most kSegCap windows may start inside one tile (+ look-ahead); denser tiles send the call to the general kernel.
+// The kernel's rate follows its OCCUPANCY (same wave lifetime as rolling_simple.hip, fewer resident wavefronts: measured), and the
+// occupancy follows the LDS per wavefront, so the segment list is sized to the byte:
+//   float64 timestamps (kTs32 = false): 5120 + 5120 + 88 + 4 * 274 = 11424 B  => 14 wavefronts per CU;   272 heads = windows of >= 2.4 rows
+//   32-bit offsets     (kTs32 = true) : 5120 + 2560 (+ 88 with nulls) + 2 * cap <= 8192 B => 20 wavefronts per CU; the list holds 16-bit
+//   entries (row | on-window-start flag << 15; the window id of a head is recomputed from its staged offset): 240 heads (200 with
+//   nulls) = windows of >= 2.7 (3.2) rows on average
+template <bool kTs32, bool kNulls>
+struct TwCap { static constexpr int value = kTs32 ? (kNulls ? 200 : 240) : 272; };
 
-// kTs32: the timestamps are staged as 32-bit offsets from the tile's base window start instead of float64 values (half the LDS:
-// 9.4 KB per wavefront => 17 resident per CU instead of 13; the kernel's rate follows its occupancy).  float64(ts) is then rebuilt
-// as float64(base) + float64(offset), which is exact - and so equal to the reference's single conversion (integral.go:17) - when
-// every |ts| of the call is below 2^53 (the host checks; nanosecond epochs take the float64 form).
-template <bool kTs32>
+// kTs32: the timestamps are staged as 32-bit offsets from the tile's base window start instead of float64 values.  float64(ts) is
+// then rebuilt as float64(base) + float64(offset), which is exact - and so equal to the reference's single conversion
+// (integral.go:17) - when every |ts| of the call is below 2^53 (the host checks; nanosecond epochs take the float64 form).
+template <bool kTs32, bool kNulls>
 struct TwShared {
     uint64_t val[kRowsT];
     typename std::conditional<kTs32, uint32_t, double>::type tsf[kRowsT];   // float64(ts) of every row of the tile (integral.go:17), or its 32-bit offset
-    uint32_t vbits[kRowsT / 32 + 2];  // validity words of the value column for this tile (kNulls only)
-    uint32_t seg[kSegCapT + 2];  // heads in row order: local row | on-window-start flag << 15 | (wid - wid of the tile's first row) << 16
+    uint32_t vbits[kNulls ? kRowsT / 32 + 2 : 1];  // validity words of the value column for this tile (kNulls only)
+    // heads in row order: local row | on-window-start flag << 15 (| (wid - wid of the tile's first row) << 16 in the 32-bit form)
+    typename std::conditional<kTs32, uint16_t, uint32_t>::type seg[TwCap<kTs32, kNulls>::value + 2];
 };
 
 __device__ __forceinline__ uint32_t mdiv32(uint32_t n, uint32_t m, uint32_t sh1, uint32_t sh2) {
@@ -67,7 +73,8 @@ template <bool kInt, bool kNulls, bool kWide, bool kTs32>
 __global__ __launch_bounds__(kWave, 3) void rolling_tw_kernel(const SimpleParams p, const int64_t ntiles, const int64_t tiles_per_xcd) {
     static_assert(!(kWide && kTs32), "the wide form keeps float64 timestamps");
     constexpr bool kMulti = true;  // one pass per value column, always in loop form
-    __shared__ TwShared<kTs32> sh;
+    __shared__ TwShared<kTs32, kNulls> sh;
+    constexpr int kSegCapT = TwCap<kTs32, kNulls>::value;
     const int64_t b = blockIdx.x;
     const int64_t tile = (b & 7) * tiles_per_xcd + (b >> 3);  // XCD-contiguous tile runs (look-ahead rows hit the same L2)
     if (tile >= ntiles) return;
@@ -148,7 +155,7 @@ __global__ __launch_bounds__(kWave, 3) void rolling_tw_kernel(const SimpleParams
         const bool ha = pa && (wa != wprev);
         const bool hb = pb && (wb != wa);
         const uint32_t la = wa - w_first, lb = wb - w_first;
-        sat |= (ha && la >= kSatT) || (hb && lb >= kSatT);
+        if (!kTs32) sat |= (ha && la >= kSatT) || (hb && lb >= kSatT);   // (the 16-bit id field of the 32-bit list entries)
         const unsigned long long ma = __ballot(ha), mb = __ballot(hb);
         int pos = nseg_total;
         pos += __builtin_amdgcn_mbcnt_hi((unsigned)(ma >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ma, 0));
@@ -156,17 +163,20 @@ __global__ __launch_bounds__(kWave, 3) void rolling_tw_kernel(const SimpleParams
         // bit 15: the row sits exactly on its window's start (what makes it the inclusive row of the window before)
         const uint32_t ik = (uint32_t)((uint64_t)p.interval >> (kWide ? p.shift_k : 0));
         const uint64_t lowmask = kWide ? ((1ull << p.shift_k) - 1ull) : 0ull;
-        const uint32_t sa = (ra == wa * ik && (((uint64_t)tsa - (uint64_t)ws0) & lowmask) == 0) ? 0x8000u : 0u;
-        const uint32_t sb = (rb == wb * ik && (((uint64_t)tsb - (uint64_t)ws0) & lowmask) == 0) ? 0x8000u : 0u;
-        if (ha && pos < kSegCapT) sh.seg[pos] = (uint32_t)l | sa | (la << 16);
+        uint32_t sa = 0u, sb = 0u;
+        if (p.inclusive) {   // (uniform: only inclusive calls look at the flag)
+            sa = (ra == wa * ik && (((uint64_t)tsa - (uint64_t)ws0) & lowmask) == 0) ? 0x8000u : 0u;
+            sb = (rb == wb * ik && (((uint64_t)tsb - (uint64_t)ws0) & lowmask) == 0) ? 0x8000u : 0u;
+        }
+        if (ha && pos < kSegCapT) sh.seg[pos] = kTs32 ? ((uint32_t)l | sa) : ((uint32_t)l | sa | (la << 16));
         pos += ha ? 1 : 0;
-        if (hb && pos < kSegCapT) sh.seg[pos] = (uint32_t)(l + 1) | sb | (lb << 16);
+        if (hb && pos < kSegCapT) sh.seg[pos] = kTs32 ? ((uint32_t)(l + 1) | sb) : ((uint32_t)(l + 1) | sb | (lb << 16));
         nseg_total += __popcll(ma) + __popcll(mb);
         if (j == kChunksT - 2) nseg_owned = nseg_total;
         left_w = (uint32_t)__builtin_amdgcn_readlane((int)wb, 63);
         left_ts = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(tb[j] >> 32), 63) << 32) |
                             (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)tb[j], 63));
-        if (kTs32) { sh.tsf[l] = ra; sh.tsf[l + 1] = rb; }
+        if (kTs32) *reinterpret_cast<uint2 *>(&sh.tsf[l]) = make_uint2(ra, rb);   // (l is even: one 8-byte LDS write)
         else { sh.tsf[l] = (double)tsa; sh.tsf[l + 1] = (double)tsb; }
     }
     if (__ballot(unsorted)) {  // the call fails with BOWGPU_ERR_TS_UNSORTED
@@ -220,12 +230,13 @@ __global__ __launch_bounds__(kWave, 3) void rolling_tw_kernel(const SimpleParams
     for (int q = lane; q < nseg_owned; q += kWave) {
         const uint32_t e0 = sh.seg[q], e1 = sh.seg[q + 1];
         const int r0 = (int)(e0 & 0x7FFFu);
-        const uint32_t wid = w_first + (e0 >> 16);
+        // (kTs32: the id of a head row from its staged offset - the same division the flag pass did)
+        const uint32_t wid = kTs32 ? mdiv32((uint32_t)sh.tsf[r0], p.m32, p.sh1, p.sh2) : w_first + (e0 >> 16);
         int r1;
         uint32_t next_wid;
         if (q + 1 < nseg_total) {
             r1 = (int)(e1 & 0x7FFFu);
-            next_wid = w_first + (e1 >> 16);
+            next_wid = kTs32 ? mdiv32((uint32_t)sh.tsf[r1], p.m32, p.sh1, p.sh2) : w_first + (e1 >> 16);
         } else if (reaches_end) {
             r1 = nloc;
             next_wid = W32;
@@ -247,7 +258,10 @@ __global__ __launch_bounds__(kWave, 3) void rolling_tw_kernel(const SimpleParams
         int count = 0;
         double pt = 0.0, pv = 0.0, integ_step = 0.0, integ_trap = 0.0;
         const double ws0_d = (double)ws0;
-        auto ts_at = [&](int r) -> double { return kTs32 ? ws0_d + (double)(uint32_t)sh.tsf[r] : (double)sh.tsf[r]; };
+        // kTs32: the walk runs on times RELATIVE to ws0 (one conversion per row): every |ts| is below 2^53, so ws0 + offset is exact
+        // and differences of two such times equal the differences of their offsets bit for bit; the absolute time of the last
+        // point is rebuilt once, after the walk
+        auto ts_at = [&](int r) -> double { return kTs32 ? (double)(uint32_t)sh.tsf[r] : (double)sh.tsf[r]; };
         auto step = [&](uint64_t raw, double t) {   // one valid row, in row order
             const double x = cint ? (double)(int64_t)raw : __longlong_as_double((long long)raw);
             sum += x;
@@ -286,6 +300,7 @@ __global__ __launch_bounds__(kWave, 3) void rolling_tw_kernel(const SimpleParams
             if (count > 0) integ_trap_incl += (pv + x) / 2 * (ts_at(r1) - pt);
             count_incl++;
         }
+        if (kTs32) pt = ws0_d + pt;   // (absolute again: integral.go:66 reads float64(last_value) - t of the last point)
         const int nrows = dead ? 0 : r1 - r0;
         const bool has_value = count > 0;
         const int64_t win_start = ws0 + (int64_t)((uint64_t)wid * (uint64_t)(uint32_t)p.interval);
