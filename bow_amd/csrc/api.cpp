@@ -994,7 +994,22 @@ static int job_run(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, i
     // for long_windows.hip by a tile kernel that reads every row just to find that out.  Skip it: order check of the interval
     // column + every window as an entry of the multi-workgroup reduction.  (BOWGPU_NO_LONG_ONLY=1: test switch.)
     const char *nlo = getenv("BOWGPU_NO_LONG_ONLY");
-    if (allow_long_only && plan && W > 0 && P.wid_base == 0 && P.n / W >= kLongOnlyAvgRows && !(nlo && nlo[0] == '1')) {
+    const char *cls = getenv("BOWGPU_LONG_CLASSIC");      // test / A-B switches: only the bisection + per-window chunks form ...
+    const char *sall = getenv("BOWGPU_LONG_STREAM_ALL");  // ... / the streaming form for every reducer set
+    // Which form?  The streaming segmented-scan form (one read, from 128 rows per window on average) when the reducers need only
+    // {sum, count} partials - Sum / ArithmeticMean / Count / WindowStart / NumRows: 0.27 - 0.33 ms per 1e8 rows.  Its instantiations
+    // that also scan extrema, first / last rows or the time-weighted terms are correct but slower than the bisection form today
+    // (1e8 rows, 1000-row windows: Min/Max 0.68 vs 0.46 ms, time-weighted 1.8 vs 0.72 ms), so those sets keep the bisection form,
+    // from 512 rows per window on, as do calls of a handful of giant windows.
+    bool lite_set = true;
+    for (int sl = 0; sl < P.ncols; sl++)
+        if ((P.pass_flags[sl + 1] & (kPassMinMax | kPassFirstLast)) || P.cols[sl].need_ts) lite_set = false;
+    const int64_t avg_rows = W > 0 ? P.n / W : 0;
+    const bool classic_only = cls && cls[0] == '1';
+    const bool stream_ok = !classic_only && (lite_set || (sall && sall[0] == '1')) && avg_rows >= kLongOnlyAvgRows &&
+                           avg_rows < kLongClassicAvgRows && W < (1ll << 32);
+    const bool classic_ok = avg_rows >= kLongBisectAvgRows;
+    if (allow_long_only && plan && W > 0 && P.wid_base == 0 && (stream_ok || classic_ok) && !(nlo && nlo[0] == '1')) {
         P.bits_preset = 0;
         {
             BitmapBatch b;
@@ -1003,8 +1018,7 @@ static int job_run(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, i
         }
         BG_HIP(hipEventRecord(c->ev0, c->stream));
         int64_t n_all = W;
-        const char *cls = getenv("BOWGPU_LONG_CLASSIC");   // test / A-B switch: the bisection + per-window chunks form
-        if ((cls && cls[0] == '1') || P.n / W >= kLongClassicAvgRows || W >= (1ll << 32)) {
+        if (!stream_ok) {
             BG_TRY(run_long_windows(c, P, nullptr, &n_all));
             c->last_kernel_name = "long_partial_kernel";
         } else {

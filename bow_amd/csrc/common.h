@@ -241,7 +241,8 @@ int launch_rolling_aggregate(Ctx *c, const AggParams &p);   // general kernel (r
 int launch_rolling_fast(Ctx *c, const AggParams &p);        // lean kernel for exclusive windows without time-weighted reducers (rolling_fast.hip)
 constexpr int kLongChunkRows = 4096;
 constexpr int kLongStreamRows = 512;  // chunk of the streaming form of the long-window reduction (long_windows.hip)
-constexpr int64_t kLongOnlyAvgRows = 128;   // windows averaging at least this many rows skip the tile kernels (api.cpp job_run)
+constexpr int64_t kLongOnlyAvgRows = 128;   // windows averaging at least this many rows skip the tile kernels: streaming form (api.cpp job_run)
+constexpr int64_t kLongBisectAvgRows = 512; // ... bisection form, for the reducer sets the streaming form is not the faster one for
 constexpr int64_t kLongClassicAvgRows = 32768;   // ... and from here on the handful of giant windows go by bisection + per-window chunks
 constexpr int kLongLists = 64;      // sub-lists of the long-window queue (agg_device.h push_long_window)
 constexpr int kLongCountWord = 16;  // status[kLongCountWord + s] = entries in sub-list s

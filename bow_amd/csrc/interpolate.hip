@@ -670,7 +670,7 @@ template <int kRows, int kRuns>
 struct Wave2Lds {
     static constexpr int kStage = kRows + kRows / 2;   // outputs staged per trip and column (the rows + up to half as many synthetic rows)
     alignas(16) uint64_t val[kStage + 2];  // staged outputs; index = position + parity, so that pairs (2i, 2i + 1) are 16-byte aligned in the output too
-    uint64_t rowts[kRows];       // the trip's timestamps by row
+    uint32_t rowrel[kRows];      // the trip's timestamps by row, as ts - s0 (this kernel's shapes keep every row within 2^32 of s0)
     uint16_t pos[kRows];         // row -> position (staged trips)
     uint32_t obits[(kStage + 32) / 32 + 2];   // output validity bits; bit index = (o_trip & 31) + position: words line up with the bitmap's
     uint32_t run_a[kRuns];       // local row | count << 9 (count saturates at 2^23 - 1: such a run recomputes it)
@@ -804,7 +804,7 @@ __global__ __launch_bounds__(64, kCh == 2 ? 4 : 3) void interp_wave2_kernel(cons
             o += sy0; or0[k] = o; o += e0;
             o += sy1; or1[k] = o;
             tot += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-            *reinterpret_cast<ulonglong2 *>(&L.rowts[128 * k + 2 * lane]) = make_ulonglong2(ta[k], tb[k]);
+            *reinterpret_cast<uint2 *>(&L.rowrel[128 * k + 2 * lane]) = make_uint2(ra, rb);
             *reinterpret_cast<uint32_t *>(&L.pos[128 * k + 2 * lane]) = (or0[k] & 0xFFFFu) | (or1[k] << 16);
             // the runs of this chunk, in row order
             const bool ha = sy0 > 0, hb = sy1 > 0;
@@ -910,13 +910,13 @@ __global__ __launch_bounds__(64, kCh == 2 ? 4 : 3) void interp_wave2_kernel(cons
             const uint32_t orow = act ? L.run_o[q] : 0u;
             const int al = (int)(e & 511u);
             uint32_t cnt = e >> 9;
-            const uint32_t rel = (uint32_t)L.rowts[al] - s0lo;
+            const uint32_t rel = L.rowrel[al];
             const uint32_t w = mdiv32(rel, m32);
             const bool exact = rel == w * i32;
             const uint32_t jd = (kIncl && exact && cnt > 0) ? 1u : 0u;   // the run's first row is the copy of row al, not a synthetic row
             const uint32_t kfirst = exact ? w - 1u : w;                 // the window of the run's first SYNTHETIC row
             if (cnt == 0x7FFFFFu) {  // a saturated count: recompute it from the row before (the windows between the two rows)
-                const uint32_t wl = mdiv32((uint32_t)(al > 0 ? L.rowts[al - 1] : (uint64_t)t_before) - s0lo, m32);
+                const uint32_t wl = mdiv32(al > 0 ? L.rowrel[al - 1] : (uint32_t)t_before - s0lo, m32);
                 cnt = w - wl - 1u + (exact ? (kIncl ? 1u : 0u) : 1u);
             }
             NbPoint qp = carry, qn; qn.has = 0; qn.t = 0; qn.bits = 0;
@@ -929,7 +929,7 @@ __global__ __launch_bounds__(64, kCh == 2 ? 4 : 3) void interp_wave2_kernel(cons
                     if (x) { r = (r & ~31) + 31 - __clz((int)x); break; }
                     r = (r & ~31) - 1;
                 }
-                if (r >= 0) { qp.has = 1; qp.bits = row_bits(r); qp.t = (int64_t)L.rowts[r]; }
+                if (r >= 0) { qp.has = 1; qp.bits = row_bits(r); qp.t = p.s0 + (int64_t)(uint64_t)L.rowrel[r]; }
             }
             if (act && want_n) {   // nearest valid row from row al on
                 int r = al;
@@ -939,7 +939,7 @@ __global__ __launch_bounds__(64, kCh == 2 ? 4 : 3) void interp_wave2_kernel(cons
                     if (x) { r = (r & ~31) + __ffs((int)x) - 1; found = r < nloc; break; }
                     r = (r | 31) + 1;
                 }
-                if (found) { qn.has = 1; qn.bits = row_bits(r); qn.t = (int64_t)L.rowts[r]; }
+                if (found) { qn.has = 1; qn.bits = row_bits(r); qn.t = p.s0 + (int64_t)(uint64_t)L.rowrel[r]; }
                 else if (base + nloc < p.n) {   // beyond the trip (rare): bitmap + index
                     const int64_t ni = next_valid_ix(ic.vbits, ic.vbit0, p.n, base + nloc, ic.nbr);
                     if (ni >= 0) { qn.has = 1; qn.bits = ic.values[ni]; qn.t = (int64_t)tsu[ni]; }

@@ -1,0 +1,24 @@
+"""Long windows (interval 1000, 1e8 rows) with reducer sets that select the different instantiations of long_stream_kernel."""
+import sys, time
+sys.path.insert(0, '.')
+from bow_amd import capi
+n = 100_000_000
+ts, val = capi.gen_dense(0, n, seed=42)
+tss, vals = capi.gen_sparse(0, n, seed=3)
+sets = {"Mean": [("WindowStart", 0), ("ArithmeticMean", 1)],
+        "First+Last": [("WindowStart", 0), ("First", 1), ("Last", 1)],
+        "Sum+Mean+Min+Max": [("WindowStart", 0), ("Sum", 1), ("ArithmeticMean", 1), ("Min", 1), ("Max", 1)],
+        "WeightedAverageStep": [("WindowStart", 0), ("WeightedAverageStep", 1)],
+        "all four time-weighted": [("WindowStart", 0), ("IntegralStep", 1), ("IntegralTrapezoid", 1), ("WeightedAverageStep", 1), ("WeightedAverageLinear", 1)]}
+for label, cols, interval in (("dense", [ts, val], 1000), ("30% nulls", [tss, vals], 10000)):
+    for name, aggs in sets.items():
+        s0, W = capi.plan_windows(cols[0], interval, 0)
+        outs = [capi.OutColumn(W, capi.DEVICE) for _ in aggs]
+        capi.rolling_aggregate(cols, 0, interval, aggs, outs=outs); capi.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            _, info = capi.rolling_aggregate(cols, 0, interval, aggs, outs=outs)
+        capi.synchronize()
+        dt = (time.perf_counter() - t0) / 3
+        print("%-10s %-26s W=%-7d %s  bracket %.3f ms  wall %.3f ms  %.1f Grows/s  %.1f%% of 8 TB/s" %
+              (label, name, W, capi.last_kernel_name(), info.kernel_ms, dt * 1e3, n / dt / 1e9, n * 16 / (info.kernel_ms * 1e-3) / 8e12 * 100))

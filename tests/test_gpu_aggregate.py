@@ -82,9 +82,10 @@ def run_both(ts, cols_np, interval, aggs, offset=0, inclusive=False, device=Fals
     first = None
     # three HIP code paths over the same inputs: simple kernel where it applies (else lean), lean kernel, general kernel
     # (the lean / general runs also switch the long-only shortcut off, so windows of thousands of rows take both long paths)
-    for label, env in (("auto", {}), ("classic-long", {"BOWGPU_LONG_CLASSIC": "1"}), ("lean", {"BOWGPU_NO_SIMPLE": "1", "BOWGPU_NO_LONG_ONLY": "1"}),
+    for label, env in (("auto", {}), ("classic-long", {"BOWGPU_LONG_CLASSIC": "1"}), ("stream-all", {"BOWGPU_LONG_STREAM_ALL": "1"}),
+                       ("lean", {"BOWGPU_NO_SIMPLE": "1", "BOWGPU_NO_LONG_ONLY": "1"}),
                        ("general", {"BOWGPU_FORCE_GENERAL": "1", "BOWGPU_NO_LONG_ONLY": "1"})):
-        for k in ("BOWGPU_NO_SIMPLE", "BOWGPU_FORCE_GENERAL", "BOWGPU_NO_LONG_ONLY", "BOWGPU_LONG_CLASSIC"):
+        for k in ("BOWGPU_NO_SIMPLE", "BOWGPU_FORCE_GENERAL", "BOWGPU_NO_LONG_ONLY", "BOWGPU_LONG_CLASSIC", "BOWGPU_LONG_STREAM_ALL"):
             os.environ[k] = env.get(k, "0")
         try:
             outs, info = capi.rolling_aggregate(ccols, 0, interval, aggs, offset=offset, inclusive=inclusive,
@@ -94,6 +95,7 @@ def run_both(ts, cols_np, interval, aggs, offset=0, inclusive=False, device=Fals
             os.environ["BOWGPU_FORCE_GENERAL"] = "0"
             os.environ["BOWGPU_NO_LONG_ONLY"] = "0"
             os.environ["BOWGPU_LONG_CLASSIC"] = "0"
+            os.environ["BOWGPU_LONG_STREAM_ALL"] = "0"
         assert info.new_interval_col == nic
         for k, g, w in zip(_names(aggs), outs, exp):
             exact = info.long_windows == 0 or k not in ORDER_SENSITIVE
@@ -417,7 +419,9 @@ def test_streaming_form_chunk_edges():
                 if n // interval < 1 or n / max(1, (n // interval + 2)) < 128:
                     continue
                 for offset in (0, 1, interval - 1):
-                    outs, exp, info = run_both(ts, [(f, fv), (i, iv)], interval, base_aggs + [("Sum", 2), ("Min", 2)], offset=offset)
+                    run_both(ts, [(f, fv), (i, iv)], interval, base_aggs + [("Sum", 2), ("Min", 2)], offset=offset)
+                    # ({sum, count} reducer sets take the streaming form on their own)
+                    outs, exp, info = run_both(ts, [(f, fv), (i, iv)], interval, [("WindowStart", 0), ("Sum", 1), ("ArithmeticMean", 2), ("Count", 1)], offset=offset)
                     assert info.long_windows == info.num_windows > 0, (n, first, interval, offset)
                 run_both(ts, [(f, fv), (i, iv)], interval, tw, offset=3, inclusive=True)
     # windows over more chunks than a lane of stream_final_kernel walks (64) next to short ones, and runs of empty windows
@@ -429,8 +433,11 @@ def test_streaming_form_chunk_edges():
     f, fv = make_vals(rng, len(ts), "f64", 0.3)
     outs, exp, info = run_both(ts, [(f, fv)], 1000, base_aggs + [(k, 1) for k in TIME_AGGS])
     assert info.long_windows == info.num_windows
-    capi.rolling_aggregate([capi.Column(ts), capi.Column(f, np.packbits(fv, bitorder="little"), capi.FLOAT64, 0, len(ts), -1)], 0, 1000, base_aggs)
+    cols = [capi.Column(ts), capi.Column(f, np.packbits(fv, bitorder="little"), capi.FLOAT64, 0, len(ts), -1)]
+    capi.rolling_aggregate(cols, 0, 1000, [("WindowStart", 0), ("ArithmeticMean", 1), ("Sum", 1), ("Count", 1)])
     assert capi.last_kernel_name() == "long_stream_kernel"
+    capi.rolling_aggregate(cols, 0, 1000, base_aggs)       # extrema / first / last: the bisection form is the faster one today
+    assert capi.last_kernel_name() == "long_partial_kernel"
 
 
 def test_nanosecond_timestamps_beyond_2_53():

@@ -47,9 +47,10 @@ def test_headline_check_is_not_sampled_on_a_big_host():
 def _paths():
     """the three tile kernels over the same call (auto = simple kernel where it applies)"""
     # (the lean / general runs also switch the long-only shortcut off, so windows of thousands of rows take both long paths)
-    for label, env in (("auto", {}), ("classic-long", {"BOWGPU_LONG_CLASSIC": "1"}), ("lean", {"BOWGPU_NO_SIMPLE": "1", "BOWGPU_NO_LONG_ONLY": "1"}),
+    for label, env in (("auto", {}), ("classic-long", {"BOWGPU_LONG_CLASSIC": "1"}), ("stream-all", {"BOWGPU_LONG_STREAM_ALL": "1"}),
+                       ("lean", {"BOWGPU_NO_SIMPLE": "1", "BOWGPU_NO_LONG_ONLY": "1"}),
                        ("general", {"BOWGPU_FORCE_GENERAL": "1", "BOWGPU_NO_LONG_ONLY": "1"})):
-        for k in ("BOWGPU_NO_SIMPLE", "BOWGPU_FORCE_GENERAL", "BOWGPU_NO_LONG_ONLY", "BOWGPU_LONG_CLASSIC"):
+        for k in ("BOWGPU_NO_SIMPLE", "BOWGPU_FORCE_GENERAL", "BOWGPU_NO_LONG_ONLY", "BOWGPU_LONG_CLASSIC", "BOWGPU_LONG_STREAM_ALL"):
             os.environ[k] = env.get(k, "0")
         try:
             yield label
@@ -58,6 +59,7 @@ def _paths():
             os.environ["BOWGPU_FORCE_GENERAL"] = "0"
             os.environ["BOWGPU_NO_LONG_ONLY"] = "0"
             os.environ["BOWGPU_LONG_CLASSIC"] = "0"
+            os.environ["BOWGPU_LONG_STREAM_ALL"] = "0"
 
 
 def test_config1_dense_1e8_sum_mean_min_max():
