@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <execinfo.h>
 #include <signal.h>
 #include <unistd.h>
@@ -985,6 +986,10 @@ static int run_long_windows(Ctx *c, const AggParams &P, const uint32_t *hstat, i
     return launch_long_windows_v2(c, P, hstat ? &starts : nullptr, entries, nchunks, offsets, sums, total, work_entry, q, max_work);
 }
 
+// BOWGPU_CALL_PROFILE=1 (diagnostic): where a call's wall time goes on the host - until the synchronisation, inside it, after it
+static thread_local double g_prof_sync_begin = 0, g_prof_sync_end = 0;
+static double now_us() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e6 + t.tv_nsec * 1e-3; }
+
 static int job_run(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, int64_t *long_windows, double *kernel_ms,
                    bool finish, const Plan *plan = nullptr, bool allow_long_only = false) {
     AggParams &P = job->P;
@@ -1051,7 +1056,9 @@ static int job_run(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, i
     uint64_t *hcnt = nullptr;
     if (finish) BG_TRY(job_enqueue_tail(c, job, aggs, naggs));
     BG_TRY(job_readback(c, job, &hstat, &hcnt));
+    g_prof_sync_begin = now_us();
     BG_HIP(hipStreamSynchronize(c->stream));
+    g_prof_sync_end = now_us();
     if (hstat[0]) return fail(BOWGPU_ERR_TS_UNSORTED, "interval column is not ascending: outside the device path");
     if (used_simple && hstat[4]) {
         // some tile needs window ids the simple kernel cannot encode: redo the call with the general lean kernel
@@ -1463,7 +1470,19 @@ static int aggregate_with_plan(const bowgpu_col *cols, int32_t ncols, int32_t ts
     BG_TRY(ctx_get(&c));
     int64_t n_long = 0;
     double ms = 0;
+    static const bool prof = [] { const char *e = getenv("BOWGPU_CALL_PROFILE"); return e && e[0] == '1'; }();
+    const double t_in = prof ? now_us() : 0;
     BG_TRY(run_aggregate(c, cols, ncols, ts_col, plan, inclusive, aggs, naggs, outs, 0, plan.W, &n_long, &ms));
+    if (prof) {
+        static thread_local double acc[3] = {0, 0, 0};
+        static thread_local int calls = 0;
+        const double t_out = now_us();
+        acc[0] += g_prof_sync_begin - t_in; acc[1] += g_prof_sync_end - g_prof_sync_begin; acc[2] += t_out - g_prof_sync_end;
+        if (++calls == 200) {
+            fprintf(stderr, "bowgpu call profile (200 calls): enqueue %.1f us, synchronise %.1f us, after %.1f us\n", acc[0] / 200, acc[1] / 200, acc[2] / 200);
+            acc[0] = acc[1] = acc[2] = 0; calls = 0;
+        }
+    }
     if (info) {
         info->s0 = plan.s0;
         info->num_windows = plan.W;
