@@ -827,6 +827,7 @@ static bool simple_applies(const AggJob *job, const bowgpu_agg *aggs, int32_t na
     const AggParams &P = job->P;
     if ((job->inclusive && !time_weighted) || !P.fits32 || naggs > kSimpleMaxAggs) return false;
     if (P.W <= 0) return false;
+
     // output slot 0 starts at s0 + wid_base * interval (wid_base != 0: a shard; it never lies above the shard's first row).  Rows
     // below it exist only as the frame's rows below s0 (P.pre_rows: they ride in window 0; the kernels force their ids)
     const int64_t slot0_start = P.s0 + (int64_t)((uint64_t)P.wid_base * (uint64_t)P.interval);
@@ -933,7 +934,11 @@ static int job_launch_tiles(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t
             BG_TRY(launch_rolling_tw(c, S, is_int, has_nulls, wide, ts32));
             c->last_kernel_name = "rolling_tw_kernel";
         } else {
-            BG_TRY(launch_rolling_simple(c, S, need, is_int, has_nulls, wide));
+            // (the head list of a tile comes in two sizes - rolling_simple.hip SimpleCap: the small one buys four more resident
+            // wavefronts per CU and serves calls whose windows average >= 3 rows; BOWGPU_SIMPLE_DENSE=1/0 forces either, for tests)
+            const char *fd = getenv("BOWGPU_SIMPLE_DENSE");
+            const bool dense = fd && (fd[0] == '0' || fd[0] == '1') ? fd[0] == '1' : P.n / P.W < 3;
+            BG_TRY(launch_rolling_simple(c, S, need, is_int, has_nulls, wide, dense));
             c->last_kernel_name = "rolling_simple_kernel";
         }
         *used_simple = true;

@@ -26,15 +26,21 @@ constexpr int kHaloS = 128;
 constexpr int kRowsS = kTileS + kHaloS;
 constexpr int kChunksS = kRowsS / 128;
 constexpr uint32_t kSatS = 0xFFFFu;
-// At most kSegCapS windows may start inside one tile (+ look-ahead); denser tiles (windows of < 1.6 rows on average)
-// send the call to the general lean kernel.  The cap keeps a wave's LDS at 6.6 KB => 24 resident waves per CU.
-constexpr int kSegCapS = 400;
+// At most SimpleCap windows may start inside one tile (+ look-ahead); denser tiles send the call to the general lean kernel.
+// The kernel's rate follows its OCCUPANCY and the occupancy follows the LDS per wavefront, which is allocated in 1 KB steps
+// (same-session A/B at 1e9 rows, three repeats: 6816 B and 6656 B 3.24 ms - 22 wavefronts per CU; 6144 B 3.10 ms - 26).  So the
+// head list comes in two sizes, chosen by the host from the plan (n / W):
+//   kDense = false: 254 heads (232 with nulls), LDS exactly 6144 B - calls whose windows average >= 3 rows
+//   kDense = true : 400 heads (378 with nulls), LDS 6.7 KB          - the rest: windows of 1.6 .. 3 rows, and frames with many
+//                   empty windows (n / W says nothing about their non-empty ones); the round-1 layout
+template <bool kNulls, bool kDense> struct SimpleCap { static constexpr int value = kDense ? (kNulls ? 378 : 400) : (kNulls ? 232 : 254); };
 constexpr int kAlignS = 16;   // output slots per 128-byte line: the granule of the slot-aligned hand-over between tiles
 
+template <bool kNulls, bool kDense>
 struct SimpleShared {
     uint64_t val[kRowsS];
-    uint32_t vbits[kRowsS / 32 + 2];  // validity words of the value column for this tile (kNulls only)
-    uint32_t seg[kSegCapS + 2];  // heads in row order: local row | (wid - wid of the tile's first row) << 16
+    uint32_t vbits[kNulls ? kRowsS / 32 + 2 : 1];  // validity words of the value column for this tile (kNulls only)
+    uint32_t seg[SimpleCap<kNulls, kDense>::value + (kNulls ? 2 : 1)];  // heads in row order: local row | (wid - wid of the tile's first row) << 16
 };
 
 __device__ __forceinline__ uint32_t mdiv32(uint32_t n, uint32_t m, uint32_t sh1, uint32_t sh2) {
@@ -67,10 +73,11 @@ __device__ __forceinline__ void lds_order() {
 // kMulti: more than one value column (the single-column shape keeps its straight-line form)
 // kWide: the rows of the call span 2^32 or more from slot 0 (nanosecond timestamps): window ids are taken relative to the
 // tile's first window (one exact 64-bit division on the scalar unit per tile), which only needs each TILE's rows within 2^32
-template <int kNeed, bool kInt, bool kNulls, bool kMulti, bool kWide>
+template <int kNeed, bool kInt, bool kNulls, bool kMulti, bool kWide, bool kDense>
 __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimpleParams p, const int64_t ntiles,
                                                                   const int64_t tiles_per_xcd) {
-    __shared__ SimpleShared sh;
+    __shared__ SimpleShared<kNulls, kDense> sh;
+    constexpr int kSegCapS = SimpleCap<kNulls, kDense>::value;
     const int64_t b = blockIdx.x;
     const int64_t tile = (b & 7) * tiles_per_xcd + (b >> 3);  // XCD-contiguous tile runs (look-ahead rows hit the same L2)
     if (tile >= ntiles) return;
@@ -102,8 +109,12 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
             for (int j = 0; j < kChunksS; j++) load_pair(src, base + j * 128 + 2 * lane, n, aligned, a[j], bb[j]);
         }
     };
+    // some tile has already found that the call needs the other kernel (head list overflow): the host will redo it, stop early
+    // (the flag's load goes out in front of the columns' and is looked at when they are)
+    const uint32_t redo_seen = __hip_atomic_load(&p.status[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (device scope: another XCD's L2 may hold the stale 0)
     load_col(ts, ta, tb, !(p.unaligned_mask >> 31));
     load_col(reinterpret_cast<const uint64_t *>(p.values[0]), va, vb, !(p.unaligned_mask & 1u));
+    if (redo_seen) return;
     // the row left of the tile (scalar load): first head flag + order check
     const int64_t left0 = base > 0 ? p.ts[base - 1] : INT64_MIN;
     // ids are 32-bit and relative to window w0, which starts at ws0: slot 0 of the call, or (kWide) the tile's first window
@@ -173,7 +184,8 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
     }
     if (nseg_total > kSegCapS) sat = true;
     if (__ballot(sat)) {  // a tile the 16-bit local ids / the segment list cannot describe: the host redoes the call with the general lean kernel
-        if (lane == 0) atomicOr(&p.status[4], 1u);
+        // (one atomic per call, not one per tile: 2e5 atomics on one address took 2 ms)
+        if (lane == 0 && !__hip_atomic_load(&p.status[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(&p.status[4], 1u);
         return;
     }
 
@@ -347,7 +359,7 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
     }  // columns
 }
 
-int launch_rolling_simple(Ctx *c, const SimpleParams &p, int need, bool is_int, bool has_nulls, bool wide) {
+int launch_rolling_simple(Ctx *c, const SimpleParams &p, int need, bool is_int, bool has_nulls, bool wide, bool dense) {
     if (p.n <= 0) return 0;
     const int64_t ntiles = (p.n + kTileS - 1) / kTileS;
     const int64_t per_xcd = (ntiles + 7) / 8;
@@ -356,8 +368,10 @@ int launch_rolling_simple(Ctx *c, const SimpleParams &p, int need, bool is_int, 
     const dim3 g((unsigned)grid), blk(kWave);
 #define BG_LAUNCH2(N, I, U, M)                                                                                               \
     do {                                                                                                                     \
-        if (wide) hipLaunchKernelGGL((rolling_simple_kernel<N, I, U, M, true>), g, blk, 0, c->stream, p, ntiles, per_xcd);   \
-        else hipLaunchKernelGGL((rolling_simple_kernel<N, I, U, M, false>), g, blk, 0, c->stream, p, ntiles, per_xcd);       \
+        if (wide && dense) hipLaunchKernelGGL((rolling_simple_kernel<N, I, U, M, true, true>), g, blk, 0, c->stream, p, ntiles, per_xcd);    \
+        else if (wide) hipLaunchKernelGGL((rolling_simple_kernel<N, I, U, M, true, false>), g, blk, 0, c->stream, p, ntiles, per_xcd);       \
+        else if (dense) hipLaunchKernelGGL((rolling_simple_kernel<N, I, U, M, false, true>), g, blk, 0, c->stream, p, ntiles, per_xcd);      \
+        else hipLaunchKernelGGL((rolling_simple_kernel<N, I, U, M, false, false>), g, blk, 0, c->stream, p, ntiles, per_xcd);                \
     } while (0)
 #define BG_LAUNCH(N, I, U)                                                \
     do {                                                                  \

@@ -106,8 +106,12 @@ __global__ __launch_bounds__(kWave, 3) void rolling_tw_kernel(const SimpleParams
             for (int j = 0; j < kChunksT; j++) load_pair(src, base + j * 128 + 2 * lane, n, aligned, a[j], bb[j]);
         }
     };
+    // some tile has already found that the call needs the other kernel (head list overflow): the host will redo it, stop early
+    // (the flag's load goes out in front of the columns' and is looked at when they are)
+    const uint32_t redo_seen = __hip_atomic_load(&p.status[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (device scope: another XCD's L2 may hold the stale 0)
     load_col(ts, ta, tb, !(p.unaligned_mask >> 31));
     load_col(reinterpret_cast<const uint64_t *>(p.values[0]), va, vb, !(p.unaligned_mask & 1u));
+    if (redo_seen) return;
     // the row left of the tile (scalar load): first head flag + order check
     const int64_t left0 = base > 0 ? p.ts[base - 1] : INT64_MIN;
     // ids are 32-bit and relative to window w0, which starts at ws0: slot 0 of the call, or (kWide) the tile's first window
@@ -185,7 +189,8 @@ __global__ __launch_bounds__(kWave, 3) void rolling_tw_kernel(const SimpleParams
     }
     if (nseg_total > kSegCapT) sat = true;
     if (__ballot(sat)) {  // a tile the 16-bit local ids / the segment list cannot describe: the host redoes the call with the general lean kernel
-        if (lane == 0) atomicOr(&p.status[4], 1u);
+        // (one atomic per call, not one per tile: 2e5 atomics on one address took 2 ms)
+        if (lane == 0 && !__hip_atomic_load(&p.status[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(&p.status[4], 1u);
         return;
     }
 

@@ -83,10 +83,14 @@ def run_both(ts, cols_np, interval, aggs, offset=0, inclusive=False, device=Fals
     # three HIP code paths over the same inputs: simple kernel where it applies (else lean), lean kernel, general kernel
     # (the lean / general runs also switch the long-only shortcut off, so windows of thousands of rows take both long paths)
     for label, env in (("auto", {}), ("classic-long", {"BOWGPU_LONG_CLASSIC": "1"}), ("stream-all", {"BOWGPU_LONG_STREAM_ALL": "1"}),
+                       ("small-list", {"BOWGPU_SIMPLE_DENSE": "0"}), ("large-list", {"BOWGPU_SIMPLE_DENSE": "1"}),
                        ("lean", {"BOWGPU_NO_SIMPLE": "1", "BOWGPU_NO_LONG_ONLY": "1"}),
                        ("general", {"BOWGPU_FORCE_GENERAL": "1", "BOWGPU_NO_LONG_ONLY": "1"})):
         for k in ("BOWGPU_NO_SIMPLE", "BOWGPU_FORCE_GENERAL", "BOWGPU_NO_LONG_ONLY", "BOWGPU_LONG_CLASSIC", "BOWGPU_LONG_STREAM_ALL"):
             os.environ[k] = env.get(k, "0")
+        os.environ.pop("BOWGPU_SIMPLE_DENSE", None)      # (the simple kernel's two head-list sizes: by the plan unless forced)
+        if "BOWGPU_SIMPLE_DENSE" in env:
+            os.environ["BOWGPU_SIMPLE_DENSE"] = env["BOWGPU_SIMPLE_DENSE"]
         try:
             outs, info = capi.rolling_aggregate(ccols, 0, interval, aggs, offset=offset, inclusive=inclusive,
                                                 out_residency=capi.DEVICE if device else capi.HOST)
@@ -96,6 +100,7 @@ def run_both(ts, cols_np, interval, aggs, offset=0, inclusive=False, device=Fals
             os.environ["BOWGPU_NO_LONG_ONLY"] = "0"
             os.environ["BOWGPU_LONG_CLASSIC"] = "0"
             os.environ["BOWGPU_LONG_STREAM_ALL"] = "0"
+            os.environ.pop("BOWGPU_SIMPLE_DENSE", None)
         assert info.new_interval_col == nic
         for k, g, w in zip(_names(aggs), outs, exp):
             exact = info.long_windows == 0 or k not in ORDER_SENSITIVE
@@ -284,10 +289,13 @@ def test_sixteen_outputs_in_one_call():
                                                                            "Sum", "ArithmeticMean", "Min", "Max", "Count", "First", "Last"])]
     assert len(aggs) == 16
     run_both(ts, cols, 25, aggs, offset=4)
+    run_both(ts, cols, 60, aggs, offset=4)
     cc = [capi.Column(ts)] + [capi.Column(v, None if m is None else np.packbits(m, bitorder="little"),
                                           capi.INT64 if v.dtype == np.int64 else capi.FLOAT64, 0, n, -1) for v, m in cols]
     capi.rolling_aggregate(cc, 0, 25, aggs, offset=4)
     assert capi.last_kernel_name() == "rolling_simple_kernel"
+    capi.rolling_aggregate(cc, 0, 12, aggs, offset=4)     # 1.2 rows per window: more heads than even the large list holds => redone by the wave kernel
+    assert capi.last_kernel_name() == "rolling_wave_kernel"
 
 
 def test_more_outputs_and_columns_than_one_launch_takes():

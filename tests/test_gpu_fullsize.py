@@ -48,10 +48,14 @@ def _paths():
     """the three tile kernels over the same call (auto = simple kernel where it applies)"""
     # (the lean / general runs also switch the long-only shortcut off, so windows of thousands of rows take both long paths)
     for label, env in (("auto", {}), ("classic-long", {"BOWGPU_LONG_CLASSIC": "1"}), ("stream-all", {"BOWGPU_LONG_STREAM_ALL": "1"}),
+                       ("small-list", {"BOWGPU_SIMPLE_DENSE": "0"}), ("large-list", {"BOWGPU_SIMPLE_DENSE": "1"}),
                        ("lean", {"BOWGPU_NO_SIMPLE": "1", "BOWGPU_NO_LONG_ONLY": "1"}),
                        ("general", {"BOWGPU_FORCE_GENERAL": "1", "BOWGPU_NO_LONG_ONLY": "1"})):
         for k in ("BOWGPU_NO_SIMPLE", "BOWGPU_FORCE_GENERAL", "BOWGPU_NO_LONG_ONLY", "BOWGPU_LONG_CLASSIC", "BOWGPU_LONG_STREAM_ALL"):
             os.environ[k] = env.get(k, "0")
+        os.environ.pop("BOWGPU_SIMPLE_DENSE", None)      # (the simple kernel's two head-list sizes: by the plan unless forced)
+        if "BOWGPU_SIMPLE_DENSE" in env:
+            os.environ["BOWGPU_SIMPLE_DENSE"] = env["BOWGPU_SIMPLE_DENSE"]
         try:
             yield label
         finally:
@@ -60,6 +64,7 @@ def _paths():
             os.environ["BOWGPU_NO_LONG_ONLY"] = "0"
             os.environ["BOWGPU_LONG_CLASSIC"] = "0"
             os.environ["BOWGPU_LONG_STREAM_ALL"] = "0"
+            os.environ.pop("BOWGPU_SIMPLE_DENSE", None)
 
 
 def test_config1_dense_1e8_sum_mean_min_max():

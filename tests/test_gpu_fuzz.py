@@ -68,10 +68,14 @@ def rand_col(rng, n, pad):
 def run_paths(ccols, ocols, interval, aggs, offset, inclusive, label):
     exp, nic = orc.aggregate(ocols, 0, interval, aggs, offset=offset, inclusive=inclusive)
     for path, env in (("auto", {}), ("classic-long", {"BOWGPU_LONG_CLASSIC": "1"}), ("stream-all", {"BOWGPU_LONG_STREAM_ALL": "1"}),
+                       ("small-list", {"BOWGPU_SIMPLE_DENSE": "0"}), ("large-list", {"BOWGPU_SIMPLE_DENSE": "1"}),
                        ("lean", {"BOWGPU_NO_SIMPLE": "1", "BOWGPU_NO_LONG_ONLY": "1"}),
                       ("general", {"BOWGPU_FORCE_GENERAL": "1", "BOWGPU_NO_LONG_ONLY": "1"})):
         for k in ("BOWGPU_NO_SIMPLE", "BOWGPU_FORCE_GENERAL", "BOWGPU_NO_LONG_ONLY", "BOWGPU_LONG_CLASSIC", "BOWGPU_LONG_STREAM_ALL"):
             os.environ[k] = env.get(k, "0")
+        os.environ.pop("BOWGPU_SIMPLE_DENSE", None)      # (the simple kernel's two head-list sizes: by the plan unless forced)
+        if "BOWGPU_SIMPLE_DENSE" in env:
+            os.environ["BOWGPU_SIMPLE_DENSE"] = env["BOWGPU_SIMPLE_DENSE"]
         try:
             outs, info = capi.rolling_aggregate(ccols, 0, interval, aggs, offset=offset, inclusive=inclusive)
         finally:
@@ -80,6 +84,7 @@ def run_paths(ccols, ocols, interval, aggs, offset, inclusive, label):
             os.environ["BOWGPU_NO_LONG_ONLY"] = "0"
             os.environ["BOWGPU_LONG_CLASSIC"] = "0"
             os.environ["BOWGPU_LONG_STREAM_ALL"] = "0"
+            os.environ.pop("BOWGPU_SIMPLE_DENSE", None)
         assert info.new_interval_col == nic, label
         for a, g, w in zip(aggs, outs, exp):
             exact = info.long_windows == 0 or a[0] not in ORDER_SENSITIVE
