@@ -842,6 +842,25 @@ def test_time_weighted_kernel_timestamp_forms_agree():
             assert np.array_equal(va.view(np.uint64), vb.view(np.uint64)) and np.array_equal(ba, bb)
 
 
+def test_time_weighted_kernel_window_ids_far_apart_inside_one_tile():
+    """Gaps of millions of empty windows between neighbouring rows: the time-weighted kernel's 16-bit head entries carry no window
+    id (it is recomputed from the staged 32-bit offset), so ids more than 65535 apart inside one tile stay on that kernel; the
+    simple kernel's 32-bit entries hold 16 bits of id and hand such a tile to the wave kernel (status flag + redo)."""
+    rng = np.random.default_rng(65536)
+    n = 40_000
+    step = rng.integers(1, 6, n)
+    step[rng.random(n) < 0.0008] = rng.integers(2_000_000, 9_000_000)
+    ts = np.cumsum(step).astype(np.int64) + 11
+    vals, valid = make_vals(rng, n, "f64", 0.2)
+    tw = [("WindowStart", 0)] + [(k, 1) for k in TIME_AGGS] + [("Count", 1)]
+    for inclusive in (False, True):
+        run_both(ts, [(vals, valid)], 25, tw, offset=2, inclusive=inclusive)
+    cols = [capi.Column(ts), capi.Column(vals, np.packbits(valid, bitorder="little"), capi.FLOAT64, 0, n, -1)]
+    capi.rolling_aggregate(cols, 0, 25, tw, offset=2)
+    assert capi.last_kernel_name() == "rolling_tw_kernel"
+    run_both(ts, [(vals, valid)], 25, [(k, 0 if k == "WindowStart" else 1) for k in ALL_AGGS], offset=2)
+
+
 def test_pinned_zero_copy_residency_equals_the_other_residencies():
     """BOWGPU_HOST_PINNED: registered host buffers are read in place by the kernels (zero-copy) and outputs leave by DMA into
     registered buffers; the same call with pageable / device-resident columns, and with BOWGPU_PINNED_STAGE=1, gives the same bits.
