@@ -729,7 +729,7 @@ __global__ __launch_bounds__(64, kCh == 2 ? 4 : 3) void interp_wave2_kernel(cons
     auto load2 = [&](const uint64_t *col, int k, uint64_t *a, uint64_t *b) {
         const int r = 128 * k + 2 * lane;
         const uint64_t *src = col + base;
-        if (full && (reinterpret_cast<uintptr_t>(col) & 15) == 0) { const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(src + r); *a = v.x; *b = v.y; }
+        if (full && (reinterpret_cast<uintptr_t>(col) & 15) == 0) { typedef unsigned long long u64x2i_t __attribute__((ext_vector_type(2))); const u64x2i_t v = __builtin_nontemporal_load(reinterpret_cast<const u64x2i_t *>(src + r)); *a = v.x; *b = v.y; }   // (streamed once)
         else { *a = r < left_trip ? src[r] : 0; *b = r + 1 < left_trip ? src[r + 1] : 0; }
     };
 
@@ -994,7 +994,7 @@ __global__ __launch_bounds__(64, kCh == 2 ? 4 : 3) void interp_wave2_kernel(cons
             for (uint32_t i = (uint32_t)lane; 2 * i < nelem; i += 64) {
                 const ulonglong2 x = *reinterpret_cast<const ulonglong2 *>(&L.val[2 * i]);
                 const bool lo_ok = 2 * i >= par, hi_ok = 2 * i + 1 < nelem;
-                if (lo_ok && hi_ok) out2[i] = x;
+                if (lo_ok && hi_ok) { typedef unsigned long long u64x2o_t __attribute__((ext_vector_type(2))); u64x2o_t q; q.x = x.x; q.y = x.y; __builtin_nontemporal_store(q, reinterpret_cast<u64x2o_t *>(out2 + i)); }   // (never read back)
                 else if (lo_ok) out[2 * i - par] = x.x;
                 else if (hi_ok) out[2 * i + 1 - par] = x.y;
             }
