@@ -1,5 +1,5 @@
 """Long windows (interval 1000, 1e8 rows) with reducer sets that select the different instantiations of long_stream_kernel."""
-import sys, time
+import gc, sys, time
 sys.path.insert(0, '.')
 from bow_amd import capi
 n = 100_000_000
@@ -14,11 +14,13 @@ for label, cols, interval in (("dense", [ts, val], 1000), ("30% nulls", [tss, va
     for name, aggs in sets.items():
         s0, W = capi.plan_windows(cols[0], interval, 0)
         outs = [capi.OutColumn(W, capi.DEVICE) for _ in aggs]
-        capi.rolling_aggregate(cols, 0, interval, aggs, outs=outs); capi.synchronize()
+        for _ in range(2):
+            capi.rolling_aggregate(cols, 0, interval, aggs, outs=outs)
+        gc.collect(); capi.synchronize()     # (earlier output buffers are freed outside the timed calls)
         t0 = time.perf_counter()
-        for _ in range(3):
+        for _ in range(5):
             _, info = capi.rolling_aggregate(cols, 0, interval, aggs, outs=outs)
         capi.synchronize()
-        dt = (time.perf_counter() - t0) / 3
+        dt = (time.perf_counter() - t0) / 5
         print("%-10s %-26s W=%-7d %s  bracket %.3f ms  wall %.3f ms  %.1f Grows/s  %.1f%% of 8 TB/s" %
               (label, name, W, capi.last_kernel_name(), info.kernel_ms, dt * 1e3, n / dt / 1e9, n * 16 / (info.kernel_ms * 1e-3) / 8e12 * 100))

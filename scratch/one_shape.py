@@ -17,6 +17,7 @@ interval, aggs = {"longw200": (200, [("WindowStart", 0), ("ArithmeticMean", 1)])
                   "longw1000_5": (1000, [("WindowStart", 0), ("Sum", 1), ("ArithmeticMean", 1), ("Min", 1), ("Max", 1)]),
                   "mean": (10, [("WindowStart", 0), ("ArithmeticMean", 1)]),
                   "mean2": (2, [("WindowStart", 0), ("ArithmeticMean", 1)]),
+                  "mean100": (100, [("WindowStart", 0), ("ArithmeticMean", 1)]),
                   "mean3": (3, [("WindowStart", 0), ("ArithmeticMean", 1)]),
                   "tw_was": (10, [("WindowStart", 0), ("WeightedAverageStep", 1)]),
                   "tw_3int": (10, [("WindowStart", 0), ("IntegralStep", 1), ("IntegralTrapezoid", 1), ("ArithmeticMean", 1)])}[name]

@@ -1,6 +1,7 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rm -rf gpurun_out/r2x; timeout -s KILL 120 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r2x -- python3 scratch/one_shape.py mean2 > /dev/null 2>&1
+timeout -s KILL 100 python3 scratch/one_shape.py mean100 | tail -1
+rm -rf gpurun_out/r2x; timeout -s KILL 120 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r2x -- python3 scratch/one_shape.py mean100 > /dev/null 2>&1
 python3 - <<'PY'
 import csv,glob
 for f in glob.glob("gpurun_out/r2x/**/*kernel_stats.csv", recursive=True):
