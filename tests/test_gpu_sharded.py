@@ -33,7 +33,7 @@ def run_sharded(ts, vals, valid, bounds, interval, offset=0, aggs=None):
     decisions = sharded.run_local(provs)
     owned = [(d.first_slot_window_id, d.windows_owned) for d in decisions]
     # assemble the global result from what each rank owns
-    W = max(fs + n for fs, n in owned if fs >= 0)
+    W = max((fs + n for fs, n in owned if fs >= 0), default=0)   # (0: every row lies below the first window start - the reference builds no window)
     res = []
     for i, (k, _) in enumerate(AGGS):
         vals_g = np.zeros(W, dtype=np.uint64)
