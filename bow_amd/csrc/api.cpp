@@ -439,7 +439,9 @@ int copy_d2h(Ctx *c, void *dst, const void *src, size_t bytes, bool registered) 
     const size_t pieces = (bytes + kBouncePiece - 1) / kBouncePiece;
     auto len = [&](size_t k) { return k + 1 < pieces ? kBouncePiece : bytes - k * kBouncePiece; };
     for (size_t k = 0; k <= pieces; k++) {
-        if (k < pieces) {   // piece k on its way into half k & 1 ...  (stream order keeps it behind an earlier upload out of that half)
+        if (k < pieces) {   // piece k on its way into half k & 1 ...  (behind an earlier upload out of that half: stream order would do, but
+                            // the caller may have switched streams since - bowgpu_set_stream - so wait for the upload's event)
+            if (c->bounce_busy[k & 1]) BG_HIP(hipEventSynchronize(c->bounce_ev[k & 1]));
             c->bounce_busy[k & 1] = false;
             BG_HIP(hipMemcpyAsync(h[k & 1], reinterpret_cast<const char *>(src) + k * kBouncePiece, len(k), hipMemcpyDeviceToHost, c->stream));
             BG_HIP(hipEventRecord(c->bounce_ev[k & 1], c->stream));
