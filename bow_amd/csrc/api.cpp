@@ -13,7 +13,10 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "common.h"
@@ -426,6 +429,73 @@ static int bounce_get(Ctx *c, char **half0, char **half1) {
     *half1 = *half0 + kBouncePiece;
     return 0;
 }
+// The CPU side of the staging: one core copies at ~12 GB/s, the link takes 55.  Pieces of a megabyte or more are split over a small
+// process-wide pool of helper threads (they only ever call memcpy; created on first use, BOWGPU_COPY_THREADS = 0 .. 8, default 3;
+// the pool object is never destroyed, so no thread can wake up into a torn-down condition variable at exit).
+namespace {
+struct CopyPool {
+    struct Job { char *d; const char *s; size_t n; std::atomic<int> *left; };
+    std::mutex m;
+    std::condition_variable work, done;
+    std::vector<Job> q;
+    int nthreads = 0;
+    void run() {
+        for (;;) {
+            Job j;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                work.wait(lk, [&] { return !q.empty(); });
+                j = q.back();
+                q.pop_back();
+            }
+            memcpy(j.d, j.s, j.n);
+            if (j.left->fetch_sub(1) == 1) {
+                std::lock_guard<std::mutex> lk(m);
+                done.notify_all();
+            }
+        }
+    }
+};
+CopyPool *copy_pool() {
+    static CopyPool *pool = [] {
+        CopyPool *p = new CopyPool();   // (leaked on purpose)
+        const char *e = getenv("BOWGPU_COPY_THREADS");
+        int n = e ? atoi(e) : 3;
+        if (n < 0) n = 0;
+        if (n > 8) n = 8;
+        for (int i = 0; i < n; i++) {
+            try { std::thread([p] { p->run(); }).detach(); p->nthreads++; } catch (...) { break; }
+        }
+        return p;
+    }();
+    return pool;
+}
+void staged_memcpy(void *dst, const void *src, size_t n) {
+    constexpr size_t kMinPart = 256u << 10;
+    CopyPool *p = n >= 4 * kMinPart ? copy_pool() : nullptr;
+    if (!p || p->nthreads == 0) { memcpy(dst, src, n); return; }
+    const int parts = p->nthreads + 1;
+    const size_t part = ((n / parts) + 63) & ~(size_t)63;
+    std::atomic<int> left(0);
+    char *d = reinterpret_cast<char *>(dst);
+    const char *s = reinterpret_cast<const char *>(src);
+    size_t off = part;   // [0, part) is the caller's own share
+    {
+        std::lock_guard<std::mutex> lk(p->m);
+        for (int i = 1; i < parts && off < n; i++, off += part) {
+            const size_t len = off + part < n && i + 1 < parts ? part : n - off;
+            left.fetch_add(1);
+            p->q.push_back({d + off, s + off, len, &left});
+            if (len == n - off) { off = n; break; }
+        }
+    }
+    p->work.notify_all();
+    memcpy(d, s, part < n ? part : n);
+    std::unique_lock<std::mutex> lk(p->m);
+    p->done.wait(lk, [&] { return left.load() == 0; });
+}
+}  // namespace
+
 int copy_d2h(Ctx *c, void *dst, const void *src, size_t bytes, bool registered) {
     if (bytes == 0) return 0;
     if (bytes <= kBounceDirect || registered || runtime_pins()) {
@@ -448,7 +518,7 @@ int copy_d2h(Ctx *c, void *dst, const void *src, size_t bytes, bool registered) 
         }
         if (k > 0) {        // ... while piece k - 1 leaves the other half
             BG_HIP(hipEventSynchronize(c->bounce_ev[(k - 1) & 1]));
-            memcpy(reinterpret_cast<char *>(dst) + (k - 1) * kBouncePiece, h[(k - 1) & 1], len(k - 1));
+            staged_memcpy(reinterpret_cast<char *>(dst) + (k - 1) * kBouncePiece, h[(k - 1) & 1], len(k - 1));
         }
     }
     return 0;
@@ -467,7 +537,7 @@ int copy_h2d(Ctx *c, void *dst, const void *src, size_t bytes, bool registered) 
     for (size_t k = 0; k < pieces; k++) {
         const size_t m = k + 1 < pieces ? kBouncePiece : bytes - k * kBouncePiece;
         if (c->bounce_busy[k & 1]) BG_HIP(hipEventSynchronize(c->bounce_ev[k & 1]));   // the DMA that last read this half is done
-        memcpy(h[k & 1], reinterpret_cast<const char *>(src) + k * kBouncePiece, m);
+        staged_memcpy(h[k & 1], reinterpret_cast<const char *>(src) + k * kBouncePiece, m);
         BG_HIP(hipMemcpyAsync(reinterpret_cast<char *>(dst) + k * kBouncePiece, h[k & 1], m, hipMemcpyHostToDevice, c->stream));
         BG_HIP(hipEventRecord(c->bounce_ev[k & 1], c->stream));
         c->bounce_busy[k & 1] = true;

@@ -842,6 +842,30 @@ def test_time_weighted_kernel_timestamp_forms_agree():
             assert np.array_equal(va.view(np.uint64), vb.view(np.uint64)) and np.array_equal(ba, bb)
 
 
+def test_pageable_columns_through_the_staging_halves_and_helper_threads():
+    """Host (pageable) columns and outputs big enough for several 4 MB staging pieces, each split over the copy helpers, at odd
+    sizes and Arrow offsets; the same call with device-resident columns gives the same bits."""
+    rng = np.random.default_rng(4 << 20)
+    n = 3_000_017
+    ts_full = np.cumsum(rng.integers(1, 4, n + 9)).astype(np.int64)
+    v_full = rng.standard_normal(n + 9)
+    m_full = rng.random(n + 9) > 0.2
+    bm_full = np.packbits(m_full, bitorder="little")
+    aggs = [("WindowStart", 0), ("Sum", 1), ("ArithmeticMean", 1), ("Min", 1), ("Count", 1)]
+    for off in (0, 5):
+        host = [capi.Column(ts_full, None, capi.INT64, off, n, 0), capi.Column(v_full, bm_full, capi.FLOAT64, off, n, -1)]
+        dev = [capi.Column(ts_full[off:off + n].copy(), None, capi.INT64).to_device(),
+               capi.Column(v_full[off:off + n].copy(), np.packbits(m_full[off:off + n], bitorder="little"), capi.FLOAT64, 0, n, -1).to_device()]
+        a, _ = capi.rolling_aggregate(host, 0, 3, aggs)                               # ~2e6 windows: 16 MB per output back through the halves
+        b, _ = capi.rolling_aggregate(dev, 0, 3, aggs, out_residency=capi.DEVICE)
+        want, _ = orc.aggregate([orc.Column(ts_full[off:off + n], None, orc.INT64),
+                                 orc.Column(v_full[off:off + n], np.packbits(m_full[off:off + n], bitorder="little"), orc.FLOAT64)], 0, 3, aggs)
+        for (k, _), x, y, w in zip(aggs, a, b, want):
+            compare("pageable off=%d %s" % (off, k), x, w)
+            assert np.array_equal(x.host_arrays()[0].view(np.uint64), y.host_arrays()[0].view(np.uint64))
+            assert np.array_equal(x.host_arrays()[1], y.host_arrays()[1])
+
+
 def test_time_weighted_kernel_window_ids_far_apart_inside_one_tile():
     """Gaps of millions of empty windows between neighbouring rows: the time-weighted kernel's 16-bit head entries carry no window
     id (it is recomputed from the staged 32-bit offset), so ids more than 65535 apart inside one tile stay on that kernel; the
