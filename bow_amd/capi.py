@@ -132,7 +132,7 @@ SYMBOLS = [
     "bowgpu_shard_interpolate_count", "bowgpu_shard_interpolate_fill", "bowgpu_fill_linear", "bowgpu_fill",
     "bowgpu_is_col_sorted", "bowgpu_shard_span", "bowgpu_shard_aggregate", "bowgpu_shard_carry_only", "bowgpu_shard_first_row", "bowgpu_shard_fix_first", "bowgpu_carry_merge",
     "bowgpu_shard_begin", "bowgpu_shard_plan", "bowgpu_shard_finish", "bowgpu_gen_dense",
-    "bowgpu_gen_sparse", "bowgpu_stream_read_ceiling", "bowgpu_stream_rw_ceiling", "bowgpu_debug_status", "bowgpu_checksum64", "bowgpu_parquet_open", "bowgpu_parquet_close",
+    "bowgpu_gen_sparse", "bowgpu_stream_read_ceiling", "bowgpu_stream_rw_ceiling", "bowgpu_debug_status", "bowgpu_debug_host_copy", "bowgpu_checksum64", "bowgpu_parquet_open", "bowgpu_parquet_close",
     "bowgpu_parquet_info", "bowgpu_parquet_column", "bowgpu_parquet_read_column",
 ]
 

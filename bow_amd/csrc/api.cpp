@@ -2142,6 +2142,12 @@ int bowgpu_stream_rw_ceiling(const void *dev_a, const void *dev_b, int64_t bytes
 }
 
 // diagnostic builds only (in-kernel stamps): words [first, first + n) of the calling thread's device status block
+int bowgpu_debug_host_copy(void *dst, const void *src, int64_t bytes) {
+    if (bytes < 0 || (bytes > 0 && (!dst || !src))) return fail(BOWGPU_ERR_ARG, "null buffer / negative size");
+    if (bytes > 0) staged_memcpy(dst, src, (size_t)bytes);
+    return 0;
+}
+
 int bowgpu_debug_status(int32_t first, int32_t n, uint32_t *out, int32_t zero_after) {
     Ctx *c;
     BG_TRY(ctx_get(&c));

@@ -515,6 +515,9 @@ int bowgpu_stream_rw_ceiling(const void *dev_a, const void *dev_b, int64_t bytes
 /* Diagnostic builds only (kernels compiled with in-kernel stamps): words [first, first + n) of the calling thread's device
  * status block; zero_after clears them.  The product build never writes those words. */
 int bowgpu_debug_status(int32_t first, int32_t n, uint32_t *out, int32_t zero_after);
+/* The CPU side of the staging of pageable buffers on its own (no device involved): a memcpy split over the library's helper threads
+ * (BOWGPU_COPY_THREADS).  For the sanitizer run of the host code and for measuring the host's copy rate. */
+int bowgpu_debug_host_copy(void *dst, const void *src, int64_t bytes);
 /* order-independent 64-bit checksum of a device buffer of n 8-byte words (xor / sum of mix) */
 int bowgpu_checksum64(const void *dev, int64_t n_words, uint64_t *xor_out, uint64_t *sum_out);
 

@@ -50,6 +50,19 @@ for interval, off in [(5, 8), (5, -2), (5, 5), (7, -(1 << 62)), (1, 1 << 62)]:
     capi.check(L.bowgpu_enforce_interval_and_offset(C.c_int64(interval), C.c_int64(off), C.byref(out)))
     assert 0 <= out.value < interval
 
+# ---- the CPU side of the pageable staging: a memcpy split over the helper threads, odd sizes and alignments, from two threads at once
+import threading
+def copies(seed):
+    r = np.random.default_rng(seed)
+    for n in [0, 1, 63, 4096, (1 << 20) - 1, (1 << 20) + 7, (4 << 20), (4 << 20) + 12345, 9_999_999]:
+        a = r.integers(0, 256, n + 16, dtype=np.uint8)
+        b = np.zeros(n + 16, dtype=np.uint8)
+        off = int(r.integers(0, 16))
+        capi.check(L.bowgpu_debug_host_copy(C.c_void_p(b.ctypes.data + off), C.c_void_p(a.ctypes.data + off), C.c_int64(n)))
+        assert np.array_equal(b[off:off + n], a[off:off + n]) and not b[:off].any() and not b[off + n:].any(), n
+th = [threading.Thread(target=copies, args=(s,)) for s in (1, 2)]
+[t.start() for t in th]; [t.join() for t in th]
+
 # ---- validation that runs before any device is touched (aggregation.go:147-188, interpolation.go:40-96)
 ts = capi.Column(np.arange(10, dtype=np.int64))
 val = capi.Column(np.arange(10, dtype=np.float64))
