@@ -441,6 +441,9 @@ def test_streaming_form_chunk_edges():
     f, fv = make_vals(rng, len(ts), "f64", 0.3)
     outs, exp, info = run_both(ts, [(f, fv)], 1000, base_aggs + [(k, 1) for k in TIME_AGGS])
     assert info.long_windows == info.num_windows
+    # reducers that read no value column at all (no column pass: only the windows' records)
+    outs, exp, info = run_both(ts, [(f, fv)], 1000, [("WindowStart", 0), ("NumRows", 1), ("NumRows", 0)])
+    assert info.long_windows == info.num_windows
     cols = [capi.Column(ts), capi.Column(f, np.packbits(fv, bitorder="little"), capi.FLOAT64, 0, len(ts), -1)]
     capi.rolling_aggregate(cols, 0, 1000, [("WindowStart", 0), ("ArithmeticMean", 1), ("Sum", 1), ("Count", 1)])
     assert capi.last_kernel_name() == "long_stream_kernel"
