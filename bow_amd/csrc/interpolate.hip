@@ -991,8 +991,19 @@ __global__ __launch_bounds__(64, kCh == 2 ? 4 : 3) void interp_wave2_kernel(cons
             wave_lds_order();
             const uint32_t nelem = par + tot;            // stage elements [par, par + tot) are real
             ulonglong2 *out2 = reinterpret_cast<ulonglong2 *>(out - par);
-            for (uint32_t i = (uint32_t)lane; 2 * i < nelem; i += 64) {
-                const ulonglong2 x = *reinterpret_cast<const ulonglong2 *>(&L.val[2 * i]);
+            // (all LDS reads of the stage first, then the stores: a rolled loop pays the LDS latency once per trip of 64 pairs)
+            constexpr int kFlushTrips = (kStage / 2 + 1 + 63) / 64;
+            ulonglong2 fx[kFlushTrips];
+#pragma unroll
+            for (int k = 0; k < kFlushTrips; k++) {
+                const uint32_t i = (uint32_t)lane + 64u * (uint32_t)k;
+                fx[k] = 2 * i < nelem ? *reinterpret_cast<const ulonglong2 *>(&L.val[2 * i]) : make_ulonglong2(0, 0);
+            }
+#pragma unroll
+            for (int k = 0; k < kFlushTrips; k++) {
+                const uint32_t i = (uint32_t)lane + 64u * (uint32_t)k;
+                if (2 * i >= nelem) continue;
+                const ulonglong2 x = fx[k];
                 const bool lo_ok = 2 * i >= par, hi_ok = 2 * i + 1 < nelem;
                 if (lo_ok && hi_ok) { typedef unsigned long long u64x2o_t __attribute__((ext_vector_type(2))); u64x2o_t q; q.x = x.x; q.y = x.y; __builtin_nontemporal_store(q, reinterpret_cast<u64x2o_t *>(out2 + i)); }   // (never read back)
                 else if (lo_ok) out[2 * i - par] = x.x;
