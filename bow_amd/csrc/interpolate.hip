@@ -750,8 +750,8 @@ __global__ __launch_bounds__(64, kCh == 2 ? 4 : 3) void interp_wave2_kernel(cons
     // per column: the bitmap words around the trip's rows (4 B per lane) and the kW2Back rows in front of the trip (8 lanes x 16 B)
     // go straight into LDS (global_load_lds: no registers held while they are in flight); words / rows that do not exist read as 0
     static_assert(kW2Back == 16, "two rows per lane, eight lanes");
-    for (int i = lane; i < kMaxCols * (kRows / 32 + 4); i += 64) (&L.raw[0][0])[i] = 0u;
-    for (int i = lane; i < kMaxCols * kW2Back; i += 64) (&L.prev[0][0])[i] = 0ull;
+    for (int i = lane; i < p.ncols * (kRows / 32 + 4); i += 64) (&L.raw[0][0])[i] = 0u;      // (the columns of this call only)
+    for (int i = lane; i < p.ncols * kW2Back; i += 64) (&L.prev[0][0])[i] = 0ull;
     if (lane < kW2Back) L.prets[lane] = 0ull;
     wave_lds_order();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the zeroes are in place before any of the loads below can land on them
