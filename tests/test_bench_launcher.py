@@ -79,3 +79,33 @@ def test_bench_two_ranks_on_one_gpu():
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak"
     assert rec["config"]["parallelism"] == "rows range-partitioned x2"
     assert rec["value"] > 0 and "exchange_ms" in rec
+
+
+@pytest.mark.gpu
+def test_bench_line_contract_single_gpu():
+    """`python bench.py` at N = 1 (a reduced row count, everything else as the default run): ONE JSON line on stdout with the keys of
+    the bench contract - the metric of BASELINE.json, the roofline object (live kernel time on the library's stream, the in-run
+    ceilings) and the cpu_baseline object - and values that hang together."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rows", "2e7", "--steps", "4", "--warmup", "1",
+                        "--cpu-sample", "2e6"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert rec["metric"] == "rows/sec rolling-mean on 1B-row float64" and rec["metric"] in base["metric"]
+    assert rec["unit"] == "rows/s" and rec["n_gpus"] == 1 and rec["steps"] == 4 and rec["warmup"] == 1
+    assert rec["higher_is_better"] is True and rec["scaling"] == "weak" and rec["vs_baseline"] is None
+    assert rec["dtype"] == "f64" and rec["data"] == "synthetic" and "workload" in rec["config"] and "model" not in rec["config"]
+    assert abs(rec["value"] - 2e7 / (rec["ms_per_step"] * 1e-3)) / rec["value"] < 1e-6
+    roof = rec["roofline"]
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    assert abs(roof["achieved"] - 2e7 * 16 / (roof["kernel_ms"] * 1e-3) / 1e9) / roof["achieved"] < 1e-6
+    assert roof["kernel"] == "rolling_simple_kernel" and 0 < roof["kernel_ms"] <= rec["ms_per_step"]
+    assert roof["traffic"] is None          # (PMC traffic is committed for the 1e9-row launch only)
+    assert roof["stream_read_ceiling"]["value"] > 0 and roof["stream_rw_ceiling"]["value"] > 0
+    cpu = rec["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["cores"] == 1 and cpu["unit"] == "rows/s" and cpu["value"] > 0 and cpu["sample"]
+    assert rec["host_pinned"]["value"] > 0 and rec["host_pinned"]["pageable_rows_per_s"] > 0
