@@ -134,6 +134,7 @@ SYMBOLS = [
     "bowgpu_shard_begin", "bowgpu_shard_plan", "bowgpu_shard_finish", "bowgpu_gen_dense",
     "bowgpu_gen_sparse", "bowgpu_stream_read_ceiling", "bowgpu_stream_rw_ceiling", "bowgpu_debug_status", "bowgpu_debug_host_copy", "bowgpu_checksum64", "bowgpu_parquet_open", "bowgpu_parquet_close",
     "bowgpu_parquet_info", "bowgpu_parquet_column", "bowgpu_parquet_read_column",
+    "bowgpu_debug_set_route", "bowgpu_debug_get_route", "bowgpu_checksum64_at",
 ]
 
 _lib = None
@@ -190,6 +191,52 @@ def check(rc):
         raise BowGpuError(rc, lib().bowgpu_last_error().decode("utf-8", "replace"))
 
 
+# ------------------------------------------------------------------ test / A-B routing (bowgpu_debug_set_route: per calling thread)
+ROUTE_NO_SIMPLE, ROUTE_FORCE_GENERAL, ROUTE_NO_LONG_ONLY, ROUTE_LONG_CLASSIC, ROUTE_LONG_STREAM_ALL = 1, 2, 4, 8, 16
+ROUTE_SIMPLE_SMALL_LIST, ROUTE_SIMPLE_LARGE_LIST, ROUTE_TW_F64, ROUTE_INTERP_WAVE1, ROUTE_INTERP_TILE = 32, 64, 128, 256, 512
+ROUTE_PINNED_STAGE, ROUTE_STRICT_ORDER = 1024, 2048
+
+
+def set_route(mask):
+    check(lib().bowgpu_debug_set_route(C.c_uint32(mask)))
+
+
+def get_route():
+    m = C.c_uint32(0)
+    check(lib().bowgpu_debug_get_route(C.byref(m)))
+    return m.value
+
+
+class route:
+    """with capi.route(mask): ...  - the calling thread's calls take the kernels `mask` selects; the previous mask comes back after"""
+
+    def __init__(self, mask):
+        self.mask = mask
+
+    def __enter__(self):
+        self.prev = get_route()
+        set_route(self.mask)
+        return self
+
+    def __exit__(self, *exc):
+        set_route(self.prev)
+        return False
+
+
+# every kernel / form a Rolling.Aggregate call can be pushed through (the tests run each case through all of them)
+AGG_ROUTES = (("auto", 0), ("classic-long", ROUTE_LONG_CLASSIC), ("stream-all", ROUTE_LONG_STREAM_ALL),
+              ("small-list", ROUTE_SIMPLE_SMALL_LIST), ("large-list", ROUTE_SIMPLE_LARGE_LIST),
+              ("lean", ROUTE_NO_SIMPLE | ROUTE_NO_LONG_ONLY), ("general", ROUTE_FORCE_GENERAL | ROUTE_NO_LONG_ONLY))
+INTERP_ROUTES = (("wave2", 0), ("wave1", ROUTE_INTERP_WAVE1), ("tile", ROUTE_INTERP_TILE))
+
+
+def agg_routes():
+    """yields a label per route with that route in force for the calling thread"""
+    for label, mask in AGG_ROUTES:
+        with route(mask):
+            yield label
+
+
 # ------------------------------------------------------------------ device buffers
 class DeviceBuffer:
     """A hipMalloc'd buffer owned by Python."""
@@ -208,10 +255,11 @@ class DeviceBuffer:
             check(lib().bowgpu_memcpy_h2d(C.c_void_p(b.ptr), arr.ctypes.data_as(C.c_void_p), C.c_int64(arr.nbytes)))
         return b
 
-    def to_numpy(self, dtype, count):
+    def to_numpy(self, dtype, count, first=0):
+        """`count` elements of `dtype` starting at element `first`"""
         out = np.empty(count, dtype=dtype)
         if out.nbytes:
-            check(lib().bowgpu_memcpy_d2h(out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr), C.c_int64(out.nbytes)))
+            check(lib().bowgpu_memcpy_d2h(out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr + first * out.itemsize), C.c_int64(out.nbytes)))
         return out
 
     def free(self):
@@ -656,9 +704,10 @@ class ParquetFile:
         self.close()
 
 
-def checksum64(devbuf, n_words):
+def checksum64(devbuf, n_words, index_base=0, word_offset=0):
+    """(xor, sum) of n_words 8-byte words starting word_offset words into devbuf, hashed as words index_base.. of a larger array"""
     x, s = C.c_uint64(0), C.c_uint64(0)
-    check(lib().bowgpu_checksum64(C.c_void_p(devbuf.ptr), C.c_int64(n_words), C.byref(x), C.byref(s)))
+    check(lib().bowgpu_checksum64_at(C.c_void_p(devbuf.ptr + 8 * word_offset), C.c_int64(n_words), C.c_int64(index_base), C.byref(x), C.byref(s)))
     return x.value, s.value
 
 

@@ -48,6 +48,18 @@ int hip_fail(hipError_t e, const char *what) {
     return BOWGPU_ERR_HIP;
 }
 
+// ---------------------------------------------------------------- test / A-B routing
+// Which kernel serves a call is decided from the call's shape alone.  The tests (and A/B measurements) need to push one call
+// through every kernel that can take it: bowgpu_debug_set_route() sets a PER-THREAD mask of BOWGPU_ROUTE_* bits.  Nothing on the
+// call path reads the environment; BOWGPU_ROUTE=<mask> is read ONCE per process as the initial mask of every thread (so that a
+// profiler run of an unmodified script can pick a kernel).
+static uint32_t route_env_default() {
+    static const uint32_t v = [] { const char *e = getenv("BOWGPU_ROUTE"); return e ? (uint32_t)strtoul(e, nullptr, 0) : 0u; }();
+    return v;
+}
+static thread_local uint32_t g_route = route_env_default();
+uint32_t route_mask() { return g_route; }
+
 // ---------------------------------------------------------------- context
 // All device state is per calling thread (cgo calls arrive on arbitrary OS threads).  A thread that exits gives its state
 // back: stream, events, pools, pinned block and its cache of scratch blocks - unless the process itself is exiting (the HIP
@@ -307,11 +319,8 @@ int count_nulls_device(Ctx *c, DevCol *dc) {
     return 0;
 }
 
-// BOWGPU_PINNED_STAGE=1 (A/B switch): pinned input columns are staged through HBM by DMA like pageable ones instead of being read in place
-static bool pinned_as_host() {
-    const char *e = getenv("BOWGPU_PINNED_STAGE");
-    return e && e[0] == '1';
-}
+// BOWGPU_ROUTE_PINNED_STAGE (A/B switch): pinned input columns are staged through HBM by DMA like pageable ones instead of being read in place
+static bool pinned_as_host() { return (route_mask() & BOWGPU_ROUTE_PINNED_STAGE) != 0; }
 
 int devcol_prepare(Ctx *c, const bowgpu_col *col, DevCol *out, bool need_values, bool need_validity) {
     if (col->length < 0 || col->offset < 0) return fail(BOWGPU_ERR_ARG, "negative column length/offset");
@@ -920,29 +929,32 @@ static bool simple_applies(const AggJob *job, const bowgpu_agg *aggs, int32_t na
         if (k == BOWGPU_AGG_MIN || k == BOWGPU_AGG_MAX) *need |= 1;
         if (k == BOWGPU_AGG_FIRST || k == BOWGPU_AGG_LAST) *need |= 2;
     }
-    const char *off = getenv("BOWGPU_NO_SIMPLE");
-    if (off && off[0] == '1') return false;
+    if (route_mask() & BOWGPU_ROUTE_NO_SIMPLE) return false;
     return true;
 }
 
 static int job_launch_tiles(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, const Plan *plan, bool allow_simple,
-                            bool *used_simple) {
+                            bool *used_simple, bool force_large_list = false, bool *used_small_list = nullptr) {
     AggParams &P = job->P;
     const int64_t W = job->W;
     *used_simple = false;
+    bool small_dummy = false;
+    if (!used_small_list) used_small_list = &small_dummy;
+    *used_small_list = false;
     if (W <= 0) { BG_HIP(hipMemsetAsync(P.status, 0, kReadbackBytes, c->stream)); return 0; }
     // The lean kernels cover exclusive windows without time-weighted reducers and without rows below s0; everything
-    // else (and BOWGPU_FORCE_GENERAL=1, used by the tests to cover all of them) takes the general kernel.
+    // else (and BOWGPU_ROUTE_FORCE_GENERAL, used by the tests to cover all of them) takes the general kernel.
     bool lean = !job->inclusive;   // (rows below s0 - P.pre_rows - are taken by the wave-tile kernels; the lean wave kernel declines them below)
     for (int i = 0; i < naggs; i++)
         if (aggs[i].kind >= BOWGPU_AGG_INTEGRAL_STEP && aggs[i].kind <= BOWGPU_AGG_WAVG_LINEAR) lean = false;
-    const char *force = getenv("BOWGPU_FORCE_GENERAL");
-    if (force && force[0] == '1') lean = false;
+    const uint32_t route = route_mask();
+    const bool force = (route & BOWGPU_ROUTE_FORCE_GENERAL) != 0;
+    if (force) lean = false;
     int need = 0;
     bool is_int = false, has_nulls = false, wide = false;
     bool simple = lean && allow_simple && plan && simple_applies(job, aggs, naggs, *plan, false, &need, &is_int, &has_nulls, &wide);
     // time-weighted reducers / inclusive windows: the same wave-tile structure with ts staged as float64 (rolling_tw.hip)
-    const bool tw = !lean && !(force && force[0] == '1') && allow_simple && plan &&
+    const bool tw = !lean && !force && allow_simple && plan &&
                     simple_applies(job, aggs, naggs, *plan, true, &need, &is_int, &has_nulls, &wide);
     simple = simple || tw;
     P.bits_preset = simple ? 1 : 0;
@@ -999,17 +1011,17 @@ static int job_launch_tiles(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t
             if (reinterpret_cast<uintptr_t>(S.values[s]) & 15) S.unaligned_mask |= 1u << s;
         if (tw) {
             // 32-bit staged timestamps: exact when float64(s0 of slot 0) + float64(offset) needs no rounding, i.e. every |ts| < 2^53
-            // (BOWGPU_TW_F64=1: test / A-B switch that keeps the float64 form)
+            // (BOWGPU_ROUTE_TW_F64: test / A-B switch that keeps the float64 form)
             const int64_t lim53 = 1ll << 53;
-            const char *f64 = getenv("BOWGPU_TW_F64");
-            const bool ts32 = !wide && !P.pre_rows && plan->first_ts > -lim53 && plan->last_ts < lim53 && S.s0 > -lim53 && !(f64 && f64[0] == '1');
+            const bool ts32 = !wide && !P.pre_rows && plan->first_ts > -lim53 && plan->last_ts < lim53 && S.s0 > -lim53 && !(route & BOWGPU_ROUTE_TW_F64);
             BG_TRY(launch_rolling_tw(c, S, is_int, has_nulls, wide, ts32));
             c->last_kernel_name = "rolling_tw_kernel";
         } else {
             // (the head list of a tile comes in two sizes - rolling_simple.hip SimpleCap: the small one buys four more resident
-            // wavefronts per CU and serves calls whose windows average >= 3 rows; BOWGPU_SIMPLE_DENSE=1/0 forces either, for tests)
-            const char *fd = getenv("BOWGPU_SIMPLE_DENSE");
-            const bool dense = fd && (fd[0] == '0' || fd[0] == '1') ? fd[0] == '1' : P.n / P.W < 3;
+            // wavefronts per CU and serves calls whose windows average >= 3 rows; BOWGPU_ROUTE_SIMPLE_LARGE_LIST / _SMALL_LIST force
+            // either, for tests; a call whose tiles overflow the small list is redone with the large one - job_run)
+            const bool dense = force_large_list || ((route & BOWGPU_ROUTE_SIMPLE_LARGE_LIST) ? true : (route & BOWGPU_ROUTE_SIMPLE_SMALL_LIST) ? false : P.n / P.W < 3);
+            *used_small_list = !dense;
             BG_TRY(launch_rolling_simple(c, S, need, is_int, has_nulls, wide, dense));
             c->last_kernel_name = "rolling_simple_kernel";
         }
@@ -1019,8 +1031,7 @@ static int job_launch_tiles(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t
         c->last_kernel_name = "rolling_wave_kernel";
     } else {
         static const bool trace = [] { const char *t = getenv("BOWGPU_TRACE_ROUTE"); return t && t[0] == '1'; }();
-        const char *nos = getenv("BOWGPU_NO_SIMPLE");
-        if (trace && !(force && force[0] == '1') && !(nos && nos[0] == '1') && allow_simple)
+        if (trace && !force && !(route & BOWGPU_ROUTE_NO_SIMPLE) && allow_simple)
             fprintf(stderr, "bowgpu route: general kernel (n=%lld W=%lld interval=%lld inclusive=%d naggs=%d pre_rows=%lld wid_base=%lld "
                             "fits32=%d allow_simple=%d plan=%d first_ts=%lld s0=%lld)\n", (long long)P.n, (long long)P.W,
                     (long long)P.interval, (int)job->inclusive, naggs, (long long)P.pre_rows, (long long)P.wid_base, (int)P.fits32,
@@ -1074,10 +1085,11 @@ static int job_run(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, i
     bool used_simple = false;
     // Long-only pipeline: when the windows of an unsharded call average thousands of rows, nearly all of them would be queued
     // for long_windows.hip by a tile kernel that reads every row just to find that out.  Skip it: order check of the interval
-    // column + every window as an entry of the multi-workgroup reduction.  (BOWGPU_NO_LONG_ONLY=1: test switch.)
-    const char *nlo = getenv("BOWGPU_NO_LONG_ONLY");
-    const char *cls = getenv("BOWGPU_LONG_CLASSIC");      // test / A-B switches: only the bisection + per-window chunks form ...
-    const char *sall = getenv("BOWGPU_LONG_STREAM_ALL");  // ... / the streaming form for every reducer set
+    // column + every window as an entry of the multi-workgroup reduction.  (BOWGPU_ROUTE_NO_LONG_ONLY: test switch.)
+    const uint32_t route = route_mask();
+    const bool nlo = (route & BOWGPU_ROUTE_NO_LONG_ONLY) != 0;
+    const bool cls = (route & BOWGPU_ROUTE_LONG_CLASSIC) != 0;      // test / A-B switches: only the bisection + per-window chunks form ...
+    const bool sall = (route & BOWGPU_ROUTE_LONG_STREAM_ALL) != 0;  // ... / the streaming form for every reducer set
     // Which form?  The streaming segmented-scan form (one read, from 128 rows per window on average) when the reducers need only
     // {sum, count} partials - Sum / ArithmeticMean / Count / WindowStart / NumRows: 0.27 - 0.33 ms per 1e8 rows.  Its instantiations
     // that also scan extrema, first / last rows or the time-weighted terms are correct but slower than the bisection form today
@@ -1087,11 +1099,11 @@ static int job_run(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, i
     for (int sl = 0; sl < P.ncols; sl++)
         if ((P.pass_flags[sl + 1] & (kPassMinMax | kPassFirstLast)) || P.cols[sl].need_ts) lite_set = false;
     const int64_t avg_rows = W > 0 ? P.n / W : 0;
-    const bool classic_only = cls && cls[0] == '1';
-    const bool stream_ok = !classic_only && (lite_set || (sall && sall[0] == '1')) && avg_rows >= kLongOnlyAvgRows &&
+    const bool classic_only = cls;
+    const bool stream_ok = !classic_only && (lite_set || sall) && avg_rows >= kLongOnlyAvgRows &&
                            avg_rows < kLongClassicAvgRows && W < (1ll << 32);
     const bool classic_ok = avg_rows >= kLongBisectAvgRows;
-    if (allow_long_only && plan && W > 0 && P.wid_base == 0 && (stream_ok || classic_ok) && !(nlo && nlo[0] == '1')) {
+    if (allow_long_only && plan && W > 0 && P.wid_base == 0 && (stream_ok || classic_ok) && !nlo) {
         P.bits_preset = 0;
         {
             BitmapBatch b;
@@ -1126,7 +1138,8 @@ static int job_run(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, i
         if (kernel_ms) *kernel_ms = ms;
         return 0;
     }
-    BG_TRY(job_launch_tiles(c, job, aggs, naggs, plan, true, &used_simple));
+    bool used_small_list = false;
+    BG_TRY(job_launch_tiles(c, job, aggs, naggs, plan, true, &used_simple, false, &used_small_list));
     // status -> host (pinned).  Optimistically enqueue the tail (null counts, copy-back) behind the tile kernel so
     // the common case needs ONE synchronisation; if windows were queued for the cooperative path, run it and redo the tail.
     uint32_t *hstat;
@@ -1137,6 +1150,15 @@ static int job_run(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, i
     BG_HIP(hipStreamSynchronize(c->stream));
     g_prof_sync_end = now_us();
     if (hstat[0]) return fail(BOWGPU_ERR_TS_UNSORTED, "interval column is not ascending: outside the device path");
+    if (used_simple && hstat[4] && used_small_list) {
+        // clumpy data: a high average of rows per window, but some tile holds more window heads than the small list takes - the
+        // same kernel with its large list (400 heads per 640 rows) before anything slower is tried
+        BG_TRY(job_launch_tiles(c, job, aggs, naggs, plan, true, &used_simple, true, &used_small_list));
+        if (finish) BG_TRY(job_enqueue_tail(c, job, aggs, naggs));
+        BG_TRY(job_readback(c, job, &hstat, &hcnt));
+        BG_HIP(hipStreamSynchronize(c->stream));
+        if (hstat[0]) return fail(BOWGPU_ERR_TS_UNSORTED, "interval column is not ascending: outside the device path");
+    }
     if (used_simple && hstat[4]) {
         // some tile needs window ids the simple kernel cannot encode: redo the call with the general lean kernel
         BG_TRY(job_launch_tiles(c, job, aggs, naggs, plan, false, &used_simple));
@@ -1322,6 +1344,17 @@ using namespace bowgpu;
 extern "C" {
 
 int bowgpu_abi_version(void) { return BOWGPU_ABI_VERSION; }
+
+int bowgpu_debug_set_route(uint32_t mask) {
+    if (mask & ~(uint32_t)BOWGPU_ROUTE__ALL) return fail(BOWGPU_ERR_ARG, "unknown route bits 0x%x", mask & ~(uint32_t)BOWGPU_ROUTE__ALL);
+    g_route = mask;
+    return 0;
+}
+int bowgpu_debug_get_route(uint32_t *mask) {
+    if (!mask) return fail(BOWGPU_ERR_ARG, "null argument");
+    *mask = g_route;
+    return 0;
+}
 
 const char *bowgpu_last_error(void) { return g_err; }
 
@@ -2159,12 +2192,16 @@ int bowgpu_debug_status(int32_t first, int32_t n, uint32_t *out, int32_t zero_af
 }
 
 int bowgpu_checksum64(const void *dev, int64_t n_words, uint64_t *xor_out, uint64_t *sum_out) {
+    return bowgpu_checksum64_at(dev, n_words, 0, xor_out, sum_out);
+}
+
+int bowgpu_checksum64_at(const void *dev, int64_t n_words, int64_t index_base, uint64_t *xor_out, uint64_t *sum_out) {
     Ctx *c;
     BG_TRY(ctx_get(&c));
     void *d;
     BG_TRY(ctx_scratch(c, 4096, &d));
     uint64_t *dout = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(d) + 3072);
-    BG_TRY(launch_checksum64(c, dev, n_words, dout));
+    BG_TRY(launch_checksum64(c, dev, n_words, dout, (uint64_t)index_base));
     uint64_t h[2] = {0, 0};
     BG_HIP(hipMemcpyAsync(h, dout, 16, hipMemcpyDeviceToHost, c->stream));
     BG_HIP(hipStreamSynchronize(c->stream));

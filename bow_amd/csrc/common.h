@@ -28,6 +28,9 @@ int hip_fail(hipError_t e, const char *what);
         if (_rc != 0) return _rc; \
     } while (0)
 
+// test / A-B routing of the calling thread (BOWGPU_ROUTE_* bits; bowgpu_debug_set_route): never the environment
+uint32_t route_mask();
+
 // ---------------------------------------------------------------- per-thread context
 struct Ctx {
     int device = 0;
@@ -388,6 +391,6 @@ struct WholeFinalH {
 // generate.hip
 int launch_gen_dense(Ctx *c, int64_t row0, int64_t n, uint64_t seed, int64_t *ts, double *val);
 int launch_gen_sparse(Ctx *c, int64_t row0, int64_t n, uint64_t seed, int64_t *ts, double *val, uint8_t *validity);
-int launch_checksum64(Ctx *c, const void *dev, int64_t n, uint64_t *d_out2);
+int launch_checksum64(Ctx *c, const void *dev, int64_t n, uint64_t *d_out2, uint64_t index_base = 0);
 
 }  // namespace bowgpu

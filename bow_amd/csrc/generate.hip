@@ -64,12 +64,12 @@ __global__ __launch_bounds__(256) void gen_sparse_kernel(int64_t row0, int64_t n
     }
 }
 
-__global__ __launch_bounds__(256) void checksum64_kernel(const uint64_t *__restrict__ p, int64_t n,
+__global__ __launch_bounds__(256) void checksum64_kernel(const uint64_t *__restrict__ p, int64_t n, uint64_t index_base,
                                                          unsigned long long *out) {
     unsigned long long x = 0, s = 0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint64_t h = mix64(0x5bd1e995u, p[i] ^ ((uint64_t)i * 0x9E3779B97F4A7C15ull));
+        const uint64_t h = mix64(0x5bd1e995u, p[i] ^ ((index_base + (uint64_t)i) * 0x9E3779B97F4A7C15ull));
         x ^= h;
         s += h;
     }
@@ -224,13 +224,13 @@ int launch_gen_sparse(Ctx *c, int64_t row0, int64_t n, uint64_t seed, int64_t *t
     return 0;
 }
 
-int launch_checksum64(Ctx *c, const void *dev, int64_t n, uint64_t *d_out2) {
+int launch_checksum64(Ctx *c, const void *dev, int64_t n, uint64_t *d_out2, uint64_t index_base) {
     BG_HIP(hipMemsetAsync(d_out2, 0, 16, c->stream));
     if (n <= 0) return 0;
     int64_t grid = (n + 255) / 256;
     if (grid > 256 * 16) grid = 256 * 16;
     hipLaunchKernelGGL(checksum64_kernel, dim3((unsigned)grid), dim3(256), 0, c->stream,
-                       reinterpret_cast<const uint64_t *>(dev), n, reinterpret_cast<unsigned long long *>(d_out2));
+                       reinterpret_cast<const uint64_t *>(dev), n, index_base, reinterpret_cast<unsigned long long *>(d_out2));
     BG_HIP(hipGetLastError());
     return 0;
 }

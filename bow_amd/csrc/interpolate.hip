@@ -1095,16 +1095,16 @@ void interp_magic32(int64_t interval, uint32_t *m, uint32_t *sh1, uint32_t *sh2)
 int launch_interp_tiles(Ctx *c, const InterpParams &p) {
     const int64_t ntiles = (p.n + kITile - 1) / kITile;
     if (ntiles <= 0) return 0;
-    // the usual shape takes the barrier-free wave kernel (BOWGPU_INTERP_TILE=1: test switch that keeps it on the tile kernel)
-    const char *force_tile = getenv("BOWGPU_INTERP_TILE");
+    // the usual shape takes the barrier-free wave kernel (BOWGPU_ROUTE_INTERP_TILE: test switch that keeps it on the tile kernel)
+    const bool force_tile = (route_mask() & BOWGPU_ROUTE_INTERP_TILE) != 0;
     static_assert(kITile == 512, "interp_wave_kernel's trips are the count kernel's tiles");
-    // BOWGPU_INTERP_WAVE1=1: the first wave kernel (also what a call is redone with when a trip overflows the second one's run list)
-    const char *wave1 = getenv("BOWGPU_INTERP_WAVE1");
-    if (p.fast32 && p.drop == 0 && p.kq < 0 && (p.inclusive || !(force_tile && force_tile[0] == '1'))) {
+    // BOWGPU_ROUTE_INTERP_WAVE1: the first wave kernel (also what a call is redone with when a trip overflows the second one's run list)
+    const bool wave1 = (route_mask() & BOWGPU_ROUTE_INTERP_WAVE1) != 0;
+    if (p.fast32 && p.drop == 0 && p.kq < 0 && (p.inclusive || !force_tile)) {
         // (trips of 256 rows - twice the wavefronts, 8 KB of LDS each, 16 resident per CU instead of 10 - were measured: 1.72 ms against
         // 1.43 ms; a wavefront's life is ~40 k cycles either way, three quarters of it waiting on its own dependent LDS round trips)
         if (p.inclusive) hipLaunchKernelGGL((interp_wave2_kernel<true, 4>), dim3((unsigned)ntiles), dim3(64), 0, c->stream, p);   // (the only kernel that takes inclusive windows)
-        else if (p.allow_wave2 && !(wave1 && wave1[0] == '1')) hipLaunchKernelGGL((interp_wave2_kernel<false, 4>), dim3((unsigned)ntiles), dim3(64), 0, c->stream, p);
+        else if (p.allow_wave2 && !wave1) hipLaunchKernelGGL((interp_wave2_kernel<false, 4>), dim3((unsigned)ntiles), dim3(64), 0, c->stream, p);
         else hipLaunchKernelGGL(interp_wave_kernel, dim3((unsigned)ntiles), dim3(64), 0, c->stream, p);
     }
     else if (p.fast32) hipLaunchKernelGGL(interp_tile_kernel<true>, dim3((unsigned)ntiles), dim3(kIThreads), 0, c->stream, p);

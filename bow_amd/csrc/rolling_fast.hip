@@ -471,21 +471,11 @@ int launch_rolling_fast(Ctx *c, const AggParams &p) {
     if (p.n <= 0) return 0;
     const int64_t ntiles = (p.n + kTileW - 1) / kTileW;
     const int64_t per_xcd = (ntiles + 7) / 8;
-    // The persistent variant (each wave prefetches its next tile) measured SLOWER than one tile per wave on MI355X
-    // (4.24 vs 3.78 ms at 1e9 rows: fewer resident waves at 127 VGPRs); kept behind BOWGPU_FAST_PERSIST=1 for experiments.
-    int persist = 0;
-    if (const char *e = getenv("BOWGPU_FAST_PERSIST")) persist = atoi(e);
-    if (persist && ntiles >= 256 * 16 * 4) {
-        // 16 resident waves per CU, each walking its tiles with the next one prefetched
-        int waves = 16;
-        if (const char *e = getenv("BOWGPU_FAST_WAVES")) waves = atoi(e);
-        const int64_t grid = 256 * (int64_t)waves;
-        hipLaunchKernelGGL(rolling_wave_kernel<true>, dim3((unsigned)grid), dim3(kWave), 0, c->stream, p, ntiles, per_xcd);
-    } else {
-        const int64_t grid = per_xcd * 8;
-        if (grid > 0x7FFFFFFFll) return fail(BOWGPU_ERR_UNSUPPORTED, "too many rows for one launch: %lld", (long long)p.n);
-        hipLaunchKernelGGL(rolling_wave_kernel<false>, dim3((unsigned)grid), dim3(kWave), 0, c->stream, p, ntiles, per_xcd);
-    }
+    // (a persistent variant - each wave prefetching its next tile - measured SLOWER on MI355X: 4.24 vs 3.78 ms at 1e9 rows, fewer
+    // resident waves at 127 VGPRs; the kPersist form of the kernel is kept in the source for that record, never launched)
+    const int64_t grid = per_xcd * 8;
+    if (grid > 0x7FFFFFFFll) return fail(BOWGPU_ERR_UNSUPPORTED, "too many rows for one launch: %lld", (long long)p.n);
+    hipLaunchKernelGGL(rolling_wave_kernel<false>, dim3((unsigned)grid), dim3(kWave), 0, c->stream, p, ntiles, per_xcd);
     BG_HIP(hipGetLastError());
     return 0;
 }

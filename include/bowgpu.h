@@ -73,7 +73,7 @@ typedef struct bowgpu_col {
     int64_t length;           /* Data.Len() */
     int64_t null_count;       /* Data.NullN(); -1 = unknown (the library counts) */
     int32_t type;             /* BOWGPU_FLOAT64 | BOWGPU_INT64 */
-    int32_t residency;        /* BOWGPU_HOST | BOWGPU_DEVICE */
+    int32_t residency;        /* BOWGPU_HOST | BOWGPU_DEVICE | BOWGPU_HOST_PINNED */
 } bowgpu_col;
 
 /* Output column: caller-owned storage for `length` slots — what bow.NewBuffer(W, typ)
@@ -512,6 +512,28 @@ int bowgpu_stream_read_ceiling(const void *dev_a, const void *dev_b, int64_t byt
  * roofline.achieved does.  Measurement aid for bench.py ("stream_rw_ceiling"). */
 int bowgpu_stream_rw_ceiling(const void *dev_a, const void *dev_b, int64_t bytes_each, void *out_a, void *out_b,
                              int64_t rows_per_slot, double *read_gb_per_s, double *ms /* nullable */);
+/* Test / A-B routing.  Which kernel serves a call follows from the call's shape alone; the parity tests push one call through
+ * every kernel that can take it by setting these bits for the CALLING THREAD (0 = product routing).  The library never reads the
+ * environment on the call path; BOWGPU_ROUTE=<mask> is read once per process as every thread's initial mask (profiling an
+ * unmodified script).  All routes give the same results where several apply. */
+enum {
+    BOWGPU_ROUTE_NO_SIMPLE = 1,          /* wave-tile kernels (rolling_simple / rolling_tw) off: rolling_wave_kernel / the general kernel */
+    BOWGPU_ROUTE_FORCE_GENERAL = 2,      /* everything through rolling_agg_kernel */
+    BOWGPU_ROUTE_NO_LONG_ONLY = 4,       /* long windows through the tile kernels' queue instead of the long-only forms */
+    BOWGPU_ROUTE_LONG_CLASSIC = 8,       /* long-only calls: bisection form only */
+    BOWGPU_ROUTE_LONG_STREAM_ALL = 16,   /* long-only calls: streaming form for every reducer set */
+    BOWGPU_ROUTE_SIMPLE_SMALL_LIST = 32, /* rolling_simple_kernel: the 254-head list whatever the plan says */
+    BOWGPU_ROUTE_SIMPLE_LARGE_LIST = 64, /* ... the 400-head list */
+    BOWGPU_ROUTE_TW_F64 = 128,           /* rolling_tw_kernel: float64 timestamps in LDS even where 32-bit offsets are exact */
+    BOWGPU_ROUTE_INTERP_WAVE1 = 256,     /* Interpolate: interp_wave_kernel */
+    BOWGPU_ROUTE_INTERP_TILE = 512,      /* Interpolate: interp_tile_kernel */
+    BOWGPU_ROUTE_PINNED_STAGE = 1024,    /* BOWGPU_HOST_PINNED inputs staged through HBM instead of read in place */
+    BOWGPU_ROUTE_STRICT_ORDER = 2048,    /* same as bowgpu_options.strict_order for every call of the thread */
+    BOWGPU_ROUTE__ALL = 4095
+};
+int bowgpu_debug_set_route(uint32_t mask);
+int bowgpu_debug_get_route(uint32_t *mask);
+
 /* Diagnostic builds only (kernels compiled with in-kernel stamps): words [first, first + n) of the calling thread's device
  * status block; zero_after clears them.  The product build never writes those words. */
 int bowgpu_debug_status(int32_t first, int32_t n, uint32_t *out, int32_t zero_after);
@@ -520,6 +542,10 @@ int bowgpu_debug_status(int32_t first, int32_t n, uint32_t *out, int32_t zero_af
 int bowgpu_debug_host_copy(void *dst, const void *src, int64_t bytes);
 /* order-independent 64-bit checksum of a device buffer of n 8-byte words (xor / sum of mix) */
 int bowgpu_checksum64(const void *dev, int64_t n_words, uint64_t *xor_out, uint64_t *sum_out);
+/* ... of words that are words [index_base, index_base + n_words) of a larger array: the checksums of the pieces of an array
+ * combine (xor with xor, sum with sum, mod 2^64) into the checksum of the whole - sharded outputs against the unsharded ones
+ * without bringing either to the host */
+int bowgpu_checksum64_at(const void *dev, int64_t n_words, int64_t index_base, uint64_t *xor_out, uint64_t *sum_out);
 
 #ifdef __cplusplus
 }

@@ -1,6 +1,6 @@
 """PCIe-inclusive rates: the same Rolling.Aggregate call with host-resident columns, as a cgo caller holding Arrow buffers would make it -
 pageable memory (Go heap / malloc: staged through HBM by the runtime's pageable copy), registered memory read in place by the kernels
-(BOWGPU_HOST_PINNED: zero-copy), registered memory staged by DMA (BOWGPU_PINNED_STAGE=1).  Reported in DESIGN.md section 6 and as
+(BOWGPU_HOST_PINNED: zero-copy), registered memory staged by DMA (ROUTE_PINNED_STAGE).  Reported in DESIGN.md section 6 and as
 bench.py's `host_pinned` key; never bench.py's `value`."""
 import os, sys, time
 sys.path.insert(0, '.')
@@ -30,9 +30,9 @@ outs = [capi.OutColumn(W, capi.HOST_PINNED) for _ in aggs]
 print("registering 2 x %.1f GB + outputs: %.1f ms" % (8 * n / 1e9, (time.perf_counter() - t0) * 1e3))
 info = run("registered columns read in place (zero-copy), registered outputs", cols, outs)
 want = [o.host_arrays()[0].copy() for o in outs]
-os.environ["BOWGPU_PINNED_STAGE"] = "1"
-run("registered columns staged by DMA (BOWGPU_PINNED_STAGE=1), registered outputs", cols, outs)
-os.environ["BOWGPU_PINNED_STAGE"] = "0"
+capi.set_route(capi.ROUTE_PINNED_STAGE)
+run("registered columns staged by DMA (ROUTE_PINNED_STAGE), registered outputs", cols, outs)
+capi.set_route(0)
 for w, o in zip(want, outs):
     assert np.array_equal(w.view(np.uint64), o.host_arrays()[0].view(np.uint64))
 dev = [c.to_device() for c in [capi.Column(ts), capi.Column(val)]]

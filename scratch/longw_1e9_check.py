@@ -9,7 +9,7 @@ aggs = [("WindowStart", 0), ("Sum", 1), ("ArithmeticMean", 1), ("Count", 1)]
 for interval in (200, 1000, 7777):
     res = {}
     for mode in ("stream", "classic"):
-        os.environ["BOWGPU_LONG_CLASSIC"] = "1" if mode == "classic" else "0"
+        capi.set_route(capi.ROUTE_LONG_CLASSIC if mode == "classic" else 0)
         outs, info = capi.rolling_aggregate([ts, val], 0, interval, aggs, out_residency=capi.DEVICE)
         capi.synchronize()
         t0 = time.perf_counter()
@@ -27,4 +27,4 @@ for interval in (200, 1000, 7777):
             err = np.max(np.abs(x - y) / np.maximum(np.abs(y), 1e-300))
             assert err <= 1e-12, (k, err)
     print("  stream == classic (exact reducers bit for bit, Sum / Mean within 1e-12)")
-os.environ["BOWGPU_LONG_CLASSIC"] = "0"
+capi.set_route(0)

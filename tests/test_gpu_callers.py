@@ -30,18 +30,12 @@ def _interps(spec):
 
 def both_interp_kernels(fn):
     """runs fn() under all three Interpolate kernels - the whole-trip wave kernel (default for the usual shapes), the first wave
-    kernel (BOWGPU_INTERP_WAVE1=1) and the workgroup kernel that serves the rest (BOWGPU_INTERP_TILE=1) - checks that they agree
+    kernel (capi.ROUTE_INTERP_WAVE1) and the workgroup kernel that serves the rest (capi.ROUTE_INTERP_TILE) - checks that they agree
     bit for bit, returns the first result"""
-    import os
     res = []
-    for env in ({}, {"BOWGPU_INTERP_WAVE1": "1"}, {"BOWGPU_INTERP_TILE": "1"}):
-        for k in ("BOWGPU_INTERP_WAVE1", "BOWGPU_INTERP_TILE"):
-            os.environ[k] = env.get(k, "0")
-        try:
+    for _label, mask in capi.INTERP_ROUTES:
+        with capi.route(mask):
             res.append(fn())
-        finally:
-            os.environ["BOWGPU_INTERP_WAVE1"] = "0"
-            os.environ["BOWGPU_INTERP_TILE"] = "0"
     a = res[0]
     for b in res[1:]:
         if isinstance(a, list) and a and isinstance(a[0], list):   # one list of columns per shard

@@ -3,7 +3,7 @@ the HIP path through the C ABI, inputs generated in HBM by the counter-based gen
 in oracle/bow_oracle.c).  Where the oracle finishes in seconds the whole output is compared with it bit for bit;
 beyond that, size-independent properties: conservation of rows / counts, the arithmetic progression of window
 starts, idempotence of Interpolate, sharded == whole, and oracle comparisons on random row ranges."""
-import os
+import ctypes as C
 
 import numpy as np
 import psutil
@@ -18,53 +18,23 @@ pytestmark = pytest.mark.gpu
 
 N8 = 100_000_000
 N9 = 1_000_000_000
-# the MI355X boxes have hundreds of host cores' worth of RAM: the oracle then checks EVERY output slot even at 1e8 / 1e9 rows
-# (it runs ~250 M rows/s per reducer there); on a small host the same tests fall back to sampled row ranges
+# The MI355X boxes have hundreds of GB of host RAM: there the oracle checks EVERY output slot even at 1e8 / 1e9 rows (it runs
+# ~250 M rows/s per reducer).  Those checks are tests OF THEIR OWN that SKIP on a small host - so a run that reports
+# "N passed, 0 skipped" has made them, and a run on a small dev box says which ones it did not make.  The sampled / property
+# checks next to them run everywhere.
 HOST_RAM = psutil.virtual_memory().total
 BIG_HOST = HOST_RAM > 200e9
-# which branch ran is part of the evidence: it goes to the test log (pytest -rA / -s shows it; captured output is kept on failure)
-# and to gpurun_out/fullsize_mode.txt on the GPU box
-_MODE = "host RAM %.0f GB -> full-size outputs are checked on %s" % (HOST_RAM / 1e9, "EVERY slot against the oracle" if BIG_HOST else
-                                                                     "SAMPLED row ranges (small host)")
-print("[test_gpu_fullsize] " + _MODE)
-try:
-    os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"), exist_ok=True)
-    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "fullsize_mode.txt"), "w") as _f:
-        _f.write(_MODE + "\n")
-except OSError:
-    pass
+needs_big_host = pytest.mark.skipif(not BIG_HOST, reason="host has %.0f GB RAM (< 200 GB): the every-slot oracle check at this size "
+                                                         "is not run here" % (HOST_RAM / 1e9))
 
 
-def test_headline_check_is_not_sampled_on_a_big_host():
-    """a >= 200 GB host must take the every-slot branch of the headline check (the sampled fallback exists for small dev boxes only)"""
-    import warnings
-    if HOST_RAM >= 200e9:
-        assert BIG_HOST
-    else:
-        warnings.warn("small host (%.0f GB RAM): the 1e8 / 1e9-row outputs are checked on sampled row ranges only" % (HOST_RAM / 1e9))
+def _gpu_free_gb():
+    return capi.mem_info()[0] / 1e9
 
 
 def _paths():
-    """the three tile kernels over the same call (auto = simple kernel where it applies)"""
-    # (the lean / general runs also switch the long-only shortcut off, so windows of thousands of rows take both long paths)
-    for label, env in (("auto", {}), ("classic-long", {"BOWGPU_LONG_CLASSIC": "1"}), ("stream-all", {"BOWGPU_LONG_STREAM_ALL": "1"}),
-                       ("small-list", {"BOWGPU_SIMPLE_DENSE": "0"}), ("large-list", {"BOWGPU_SIMPLE_DENSE": "1"}),
-                       ("lean", {"BOWGPU_NO_SIMPLE": "1", "BOWGPU_NO_LONG_ONLY": "1"}),
-                       ("general", {"BOWGPU_FORCE_GENERAL": "1", "BOWGPU_NO_LONG_ONLY": "1"})):
-        for k in ("BOWGPU_NO_SIMPLE", "BOWGPU_FORCE_GENERAL", "BOWGPU_NO_LONG_ONLY", "BOWGPU_LONG_CLASSIC", "BOWGPU_LONG_STREAM_ALL"):
-            os.environ[k] = env.get(k, "0")
-        os.environ.pop("BOWGPU_SIMPLE_DENSE", None)      # (the simple kernel's two head-list sizes: by the plan unless forced)
-        if "BOWGPU_SIMPLE_DENSE" in env:
-            os.environ["BOWGPU_SIMPLE_DENSE"] = env["BOWGPU_SIMPLE_DENSE"]
-        try:
-            yield label
-        finally:
-            os.environ["BOWGPU_NO_SIMPLE"] = "0"
-            os.environ["BOWGPU_FORCE_GENERAL"] = "0"
-            os.environ["BOWGPU_NO_LONG_ONLY"] = "0"
-            os.environ["BOWGPU_LONG_CLASSIC"] = "0"
-            os.environ["BOWGPU_LONG_STREAM_ALL"] = "0"
-            os.environ.pop("BOWGPU_SIMPLE_DENSE", None)
+    """every kernel / form over the same call (auto = simple kernel where it applies)"""
+    return capi.agg_routes()
 
 
 def test_config1_dense_1e8_sum_mean_min_max():
@@ -97,12 +67,9 @@ def test_config3_eight_columns_1e8():
             compare("config3 col %d %s" % (c, k), got[i], w)
 
 
-def test_config2_sparse_nulls_linear_fill_then_mean():
-    """configs[2]: irregular int64 ts, 30 % nulls, Linear fill (Rolling.Interpolate) then the rolling mean.
-    2e7 rows against the oracle in full; 1e8 rows through properties."""
+def _config2_every_row(n):
     ip = [{"kind": "WindowStart", "col": 0}, {"kind": "Linear", "col": 1}]
     aggs = [("WindowStart", 0), ("ArithmeticMean", 1), ("Count", 1), ("Min", 1)]
-    n = N8 if BIG_HOST else 20_000_000
     ts, val = capi.gen_sparse(0, n, seed=5)
     ts_o, val_o, bm_o = orc.gen_sparse(0, n, seed=5)
     ocols = [orc.Column(ts_o, None, orc.INT64), orc.Column(val_o, bm_o, orc.FLOAT64)]
@@ -119,9 +86,24 @@ def test_config2_sparse_nulls_linear_fill_then_mean():
         exp, _ = orc.aggregate([want[0], want[1]], 0, 100, aggs, offset=offset)
         for (k, _), g, w in zip(aggs, got, exp):
             compare("config2 %s off=%d" % (k, offset), g, w)
-    del ts, val, filled, cols2, got
 
-    # ---- full size: properties
+
+def test_config2_sparse_nulls_linear_fill_then_mean_2e7_every_row():
+    """configs[2]: irregular int64 ts, 30 % nulls, Linear fill (Rolling.Interpolate) then the rolling mean - 2e7 rows, every
+    output row and window against the oracle (any host)"""
+    _config2_every_row(20_000_000)
+
+
+@needs_big_host
+def test_config2_sparse_nulls_linear_fill_then_mean_1e8_every_row():
+    """configs[2] at its full 1e8 rows, every output row and window against the oracle"""
+    _config2_every_row(N8)
+
+
+def test_config2_full_size_properties():
+    """configs[2] at 1e8 rows through size-independent properties: sortedness, same windows before and after, idempotence,
+    conservation of rows and valid values"""
+    ip = [{"kind": "WindowStart", "col": 0}, {"kind": "Linear", "col": 1}]
     ts, val = capi.gen_sparse(0, N8, seed=5)
     s0, W = capi.plan_windows(ts, 100, 7)
     filled = capi.rolling_interpolate([ts, val], 0, 100, ip, offset=7, out_residency=capi.DEVICE)
@@ -152,10 +134,14 @@ def test_config2_sparse_nulls_linear_fill_then_mean():
     assert np.array_equal(before[0].host_arrays()[0], after[0].host_arrays()[0])
 
 
-def test_headline_1e9_every_window_properties_and_sharded():
-    """the benched configuration (1e9 rows, interval 10, WindowStart + ArithmeticMean and friends)"""
+HEAD_AGGS = [("WindowStart", 0), ("ArithmeticMean", 1), ("Count", 1), ("Sum", 1), ("NumRows", 1)]
+
+
+def test_headline_1e9_properties_sampled_oracle_and_sharded():
+    """the benched configuration (1e9 rows, interval 10, WindowStart + ArithmeticMean and friends): properties of every window,
+    eight 2e6-row ranges against the oracle bit for bit, and 8 row-range shards == the one call"""
     ts, val = capi.gen_dense(0, N9, seed=42)
-    aggs = [("WindowStart", 0), ("ArithmeticMean", 1), ("Count", 1), ("Sum", 1), ("NumRows", 1)]
+    aggs = HEAD_AGGS
     got, info = capi.rolling_aggregate([ts, val], 0, 10, aggs, out_residency=capi.DEVICE)
     assert capi.last_kernel_name() == "rolling_simple_kernel" and info.long_windows == 0
     W = N9 // 10
@@ -169,12 +155,6 @@ def test_headline_1e9_every_window_properties_and_sharded():
     mean, sm = got[1].host_arrays()[0], got[3].host_arrays()[0]
     assert np.array_equal(mean, sm / 10.0)  # the same left-to-right sum feeds both (arithmeticmean.go:17-28)
     assert 0.0 <= mean.min() and mean.max() < 1.0
-    if BIG_HOST:  # every window of the benched call against the oracle, bit for bit
-        ts_o, val_o = orc.gen_dense(0, N9, seed=42)
-        want, _ = orc.aggregate([orc.Column(ts_o, None, orc.INT64), orc.Column(val_o, None, orc.FLOAT64)], 0, 10, aggs[:2])
-        assert np.array_equal(ws, want[0].values[:W])
-        assert np.array_equal(mean.view(np.uint64), want[1].values[:W].view(np.uint64))
-        del ts_o, val_o, want
     # random row ranges against the oracle, bit for bit
     rng = np.random.default_rng(1)
     for a in [0, N9 - 2_000_000] + [int(x) * 10 for x in rng.integers(0, (N9 - 2_000_000) // 10, 6)]:
@@ -206,10 +186,231 @@ def test_headline_1e9_every_window_properties_and_sharded():
     assert covered == len(w_ts)
 
 
-def test_fills_and_is_col_sorted_at_full_size():
-    """the four fills and IsColSorted on configs[2]'s columns (irregular int64 ts, 30 % nulls) at 1e8 rows (2e7 on small hosts),
-    every row against the oracle"""
-    n = N8 if BIG_HOST else 20_000_000
+@needs_big_host
+def test_headline_1e9_every_window_against_the_oracle():
+    """every one of the 1e8 windows of the benched call against the oracle, bit for bit (needs ~40 GB of host RAM for the oracle's
+    copy of the columns: skipped, visibly, on a small host)"""
+    ts, val = capi.gen_dense(0, N9, seed=42)
+    got, info = capi.rolling_aggregate([ts, val], 0, 10, HEAD_AGGS[:2], out_residency=capi.DEVICE)
+    assert capi.last_kernel_name() == "rolling_simple_kernel" and info.long_windows == 0
+    W = N9 // 10
+    ts_o, val_o = orc.gen_dense(0, N9, seed=42)
+    want, _ = orc.aggregate([orc.Column(ts_o, None, orc.INT64), orc.Column(val_o, None, orc.FLOAT64)], 0, 10, HEAD_AGGS[:2])
+    assert got[0].length == W and want[0].length == W
+    assert np.array_equal(got[0].host_arrays()[0], want[0].values[:W])
+    assert np.array_equal(got[1].host_arrays()[0].view(np.uint64), want[1].values[:W].view(np.uint64))
+    assert got[1].null_count == 0
+
+
+def _oracle_windows(a, rows, interval, offset, aggs, s0_global):
+    """the oracle over dense rows [a, a + rows): (global id of its first window, its outputs).  The window grid is the frame's
+    (offset-aligned) as long as a >= 0; the first and the last window of the range may be cut and are for the caller to skip."""
+    ts_o, val_o = orc.gen_dense(a, rows, seed=42)
+    want, _ = orc.aggregate([orc.Column(ts_o, None, orc.INT64), orc.Column(val_o, None, orc.FLOAT64)], 0, interval, aggs, offset=offset)
+    s0_local = sharded.first_window_start(a, interval, offset)
+    assert (s0_local - s0_global) % interval == 0
+    return (s0_local - s0_global) // interval, want
+
+
+@pytest.mark.timeout(1800)
+def test_config4_eight_shards_of_1e9_rows_and_one_call_past_2_32_rows():
+    """configs[4] at its size on ONE GPU: 8e9 dense rows resident in HBM (128 GB) as 8 row-range shards of 1e9 rows through the
+    shard protocol (begin -> records -> finish), interval 10 with offset 3 so that a window straddles every shard boundary -
+    and the SAME 8e9 rows as one unsharded call (row indices, output slots and window ids past 2^32; the kWide form of the
+    tile kernel at frame scale).  Sharded == unsharded on every window by a checksum of checksums computed on the device;
+    ownership is contiguous; WindowStart is the arithmetic progression; Count is 10 but for the first and the last window;
+    2e6-row ranges on both sides of every shard boundary, around row 2^32 and at both ends against the oracle, bit for bit."""
+    if _gpu_free_gb() < 200:
+        pytest.skip("needs 200 GB of free HBM (an MI355X has 288 GB), found %.0f GB" % _gpu_free_gb())
+    world, R = 8, N9
+    N = world * R
+    interval, offset = 10, 3
+    vals = capi.DeviceBuffer(N * 8)
+    tsb = capi.DeviceBuffer(N * 8)
+    capi.check(capi.lib().bowgpu_gen_dense(C.c_int64(0), C.c_int64(N), C.c_uint64(42), C.c_void_p(tsb.ptr), C.c_void_p(vals.ptr)))
+    ts = capi.Column(tsb, None, capi.INT64, 0, N, 0)
+    val = capi.Column(vals, None, capi.FLOAT64, 0, N, 0)
+    s0, W = capi.plan_windows(ts, interval, offset)
+    assert s0 == -7 and W == (N - 1 + 7) // 10 + 1
+
+    # ---- the unsharded call: 8e9 rows, 8e8 + 1 windows
+    aggs = [("WindowStart", 0), ("ArithmeticMean", 1), ("Count", 1), ("Min", 1), ("Last", 1)]
+    whole, info = capi.rolling_aggregate([ts, val], 0, interval, aggs, offset=offset, out_residency=capi.DEVICE)
+    assert capi.last_kernel_name() == "rolling_simple_kernel" and info.long_windows == 0 and info.num_windows == W
+    assert [g.length for g in whole] == [W] * 5 and [g.null_count for g in whole] == [0] * 5
+    CH = 100_000_000
+    for k0 in range(0, W, CH):     # WindowStart progression and Count, every window, 1e8 at a time
+        m = min(CH, W - k0)
+        ws = whole[0].values.to_numpy(np.int64, m, first=k0)
+        assert ws[0] == s0 + interval * k0 and (np.diff(ws) == interval).all(), k0
+        cnt = whole[2].values.to_numpy(np.int64, m, first=k0)
+        lo, hi = (1 if k0 == 0 else 0), (m - 1 if k0 + m == W else m)
+        assert (cnt[lo:hi] == 10).all(), k0
+        if k0 == 0:
+            assert cnt[0] == 3          # rows 0, 1, 2 in [-7, 3)
+        if k0 + m == W:
+            assert cnt[-1] == 7         # rows N-7 .. N-1 in [N-7, N+3)
+        del ws, cnt
+
+    def check_range(a, rows, what):
+        g0, want = _oracle_windows(a, rows, interval, offset, aggs, s0)
+        nw = want[0].length
+        lo, hi = (0 if a == 0 else 1), (nw if a + rows == N else nw - 1)   # (a range cut out of the frame: its edge windows are partial)
+        for (k, _), g, w in zip(aggs, whole, want):
+            gv = g.values.to_numpy(np.uint64, hi - lo, first=g0 + lo)
+            assert np.array_equal(gv, w.values[:nw].view(np.uint64)[lo:hi]), (what, k, a)
+        return g0 + lo, g0 + hi, [w.values[:nw].view(np.uint64)[lo:hi] for w in want[:2]]
+
+    half = 1_000_000
+    ranges = [(0, 2 * half, "front"), (N - 2 * half, 2 * half, "back"), ((1 << 32) - half, 2 * half, "row 2^32")]
+    ranges += [(r * R - half, 2 * half, "boundary %d" % r) for r in range(1, world)]
+    oracle_at = {what: check_range(a, rows, what) for a, rows, what in ranges}
+    cks_whole = [capi.checksum64(whole[i].values, W) for i in (0, 1)]
+
+    # ---- the same rows as 8 shards of 1e9 through the shard protocol
+    provs = []
+    for r in range(world):
+        cols = [capi.Column(tsb, None, capi.INT64, r * R, R, 0), capi.Column(vals, None, capi.FLOAT64, r * R, R, 0)]
+        provs.append(sharded.GpuProvider(cols, 0, interval, aggs[:2], offset=offset))
+    decisions = sharded.run_local(provs)
+    assert capi.last_kernel_name() == "rolling_simple_kernel"
+    covered = 0
+    cx = [[0, 0], [0, 0]]
+    for r, d in enumerate(decisions):
+        fs, nwin = d.first_slot_window_id, d.windows_owned
+        assert d.s0 == s0 and d.num_windows == W
+        assert fs == covered, (r, fs, covered)            # each rank owns the next contiguous run of windows
+        assert d.drops_last == (1 if r + 1 < world else 0)   # offset 3: every boundary window straddles and goes to the right rank
+        assert (d.seed_first_rank >= 0) == (r > 0)
+        for i in (0, 1):
+            x, sm = capi.checksum64(provs[r].outs[i].values, nwin, index_base=fs)
+            cx[i][0] ^= x
+            cx[i][1] = (cx[i][1] + sm) & 0xFFFFFFFFFFFFFFFF
+        covered += nwin
+    assert covered == W
+    # checksum of checksums: the owned slots of the 8 ranks, hashed at their global positions, are the unsharded outputs
+    for i, k in ((0, "WindowStart"), (1, "ArithmeticMean")):
+        assert tuple(cx[i]) == cks_whole[i], k
+    # ... and the windows on both sides of every boundary, straight from the owning rank's buffer, against the oracle
+    for r in range(1, world):
+        lo, hi, want2 = oracle_at["boundary %d" % r]
+        for q in (r - 1, r):
+            fs, nwin = decisions[q].first_slot_window_id, decisions[q].windows_owned
+            a, b = max(lo, fs), min(hi, fs + nwin)
+            assert a < b
+            for i in (0, 1):
+                gv = provs[q].outs[i].values.to_numpy(np.uint64, b - a, first=a - fs)
+                assert np.array_equal(gv, want2[i][a - lo:b - lo]), (r, q, i)
+        assert decisions[r - 1].first_slot_window_id + decisions[r - 1].windows_owned == decisions[r].first_slot_window_id
+    del provs, whole
+
+    # ---- window ids past 2^30: interval 7 over the same rows (1.14e9 windows), WindowStart + Count
+    s7, W7 = capi.plan_windows(ts, 7, 0)
+    assert s7 == 0 and W7 == (N - 1) // 7 + 1 and W7 > (1 << 30)
+    got7, info7 = capi.rolling_aggregate([ts, val], 0, 7, [("WindowStart", 0), ("Count", 1), ("Max", 1)], out_residency=capi.DEVICE)
+    assert info7.long_windows == 0 and [g.null_count for g in got7] == [0, 0, 0]
+    for k0 in list(range(0, W7, 4 * CH))[:2] + [W7 - CH]:
+        m = min(CH, W7 - k0)
+        ws = got7[0].values.to_numpy(np.int64, m, first=k0)
+        assert ws[0] == 7 * k0 and (np.diff(ws) == 7).all(), k0
+        cnt = got7[1].values.to_numpy(np.int64, m, first=k0)
+        assert (cnt[:m - 1] == 7).all() and cnt[-1] == (7 if k0 + m < W7 else N - 7 * (W7 - 1)), k0
+    a = (1 << 32) - 700_000
+    ts_o, val_o = orc.gen_dense(a, 1_400_000, seed=42)
+    want, _ = orc.aggregate([orc.Column(ts_o, None, orc.INT64), orc.Column(val_o, None, orc.FLOAT64)], 0, 7,
+                            [("WindowStart", 0), ("Count", 1), ("Max", 1)])
+    g0 = sharded.first_window_start(a, 7, 0) // 7
+    nw = want[0].length
+    for g, w in zip(got7, want):
+        assert np.array_equal(g.values.to_numpy(np.uint64, nw - 2, first=g0 + 1), w.values[:nw].view(np.uint64)[1:nw - 1])
+
+
+@pytest.mark.timeout(1800)
+def test_interpolate_and_fill_past_2_32_rows():
+    """Rolling.Interpolate (count + fill) and FillPrevious on 4.4e9 sparse rows (irregular int64 ts, 30 % nulls; 70 GB of columns):
+    input rows, output positions and timestamps past 2^32.  Properties on the whole result, ranges around output position 2^32
+    and at both ends against the oracle."""
+    if _gpu_free_gb() < 200:
+        pytest.skip("needs 200 GB of free HBM (an MI355X has 288 GB), found %.0f GB" % _gpu_free_gb())
+    n = 4_400_000_000
+    ts, val = capi.gen_sparse(0, n, seed=11)
+    ip = [{"kind": "WindowStart", "col": 0}, {"kind": "Linear", "col": 1}]
+    s0, W = capi.plan_windows(ts, 100, 7)
+    filled = capi.rolling_interpolate([ts, val], 0, 100, ip, offset=7, out_residency=capi.DEVICE)
+    m = filled[0].length
+    assert n <= m <= n + W and m > (1 << 32)
+    f_ts = capi.Column(filled[0].values, None, capi.INT64, 0, m, 0)
+    f_val = capi.Column(filled[1].values, filled[1].validity, capi.FLOAT64, 0, m, -1)
+    assert filled[0].null_count == 0
+    assert capi.is_col_sorted(f_ts)
+    assert capi.plan_windows(f_ts, 100, 7) == (s0, W)
+    # conservation through two reducers over input and output: rows and valid values per window
+    aggs2 = [("WindowStart", 0), ("NumRows", 1), ("Count", 1)]
+    before, _ = capi.rolling_aggregate([ts, val], 0, 100, aggs2, offset=7, out_residency=capi.DEVICE)
+    after, _ = capi.rolling_aggregate([f_ts, f_val], 0, 100, aggs2, offset=7, out_residency=capi.DEVICE)
+    assert capi.checksum64(before[0].values, W) == capi.checksum64(after[0].values, W)
+    added_total = 0
+    CH = 11_000_000
+    for k0 in (0, W // 2 - CH // 2, W - CH):
+        nb = before[1].values.to_numpy(np.float64, CH, first=k0)
+        na = after[1].values.to_numpy(np.float64, CH, first=k0)
+        added = na - nb
+        assert ((added == 0) | (added == 1)).all(), k0
+        # a window gains a row exactly when it has rows and its first row is not on its start: afterwards every non-empty window has one there
+        cb = before[2].values.to_numpy(np.int64, CH, first=k0)
+        ca = after[2].values.to_numpy(np.int64, CH, first=k0)
+        assert ((ca - cb) >= 0).all() and ((ca - cb) <= added).all(), k0
+        added_total += int(added.sum())
+    assert added_total > 0
+    del before, after
+
+    def check_at(a, rows, what):
+        """input rows [a, a + rows): the oracle's Interpolate of that range against the device's output rows for it"""
+        ts_o, val_o, bm_o = orc.gen_sparse(a, rows, seed=11)
+        want = orc.interpolate([orc.Column(ts_o, None, orc.INT64), orc.Column(val_o, bm_o, orc.FLOAT64)], 0, 100, ip, offset=7)
+        wt = want[0].values[:want[0].length]
+        # where the range's rows lie in the device output: timestamps are strictly increasing (10 i + U{0..9}), so search for them
+        est = int(a * (m / n))
+        lo = max(0, est - 3_000_000)
+        cnt = min(m - lo, 6_000_000 + want[0].length)
+        gt = filled[0].values.to_numpy(np.int64, cnt, first=lo)
+        # (a range cut out of the frame lacks the neighbours beyond its edges - Linear needs both - and its first window is cut)
+        skip = 0 if a == 0 else 2000
+        k = want[0].length - skip - (0 if a + rows == n else 2000)
+        p0 = int(np.searchsorted(gt, wt[skip]))
+        assert gt[p0] == wt[skip], what
+        assert np.array_equal(gt[p0:p0 + k], wt[skip:skip + k]), what
+        gv = filled[1].values.to_numpy(np.uint64, k, first=lo + p0)
+        b0 = (lo + p0) // 8
+        gb = np.unpackbits(filled[1].validity.to_numpy(np.uint8, min((k + 7) // 8 + 1, (m + 7) // 8 - b0), first=b0), bitorder="little")
+        gb = gb[(lo + p0) % 8:(lo + p0) % 8 + k].astype(bool)
+        wm = want[1].valid_mask()[skip:skip + k]
+        assert np.array_equal(gb, wm), what
+        wv = want[1].values[:want[1].length].view(np.uint64)[skip:skip + k]
+        assert np.array_equal(gv[wm], wv[wm]), what
+        return lo + p0
+
+    check_at(0, 2_000_000, "front")
+    check_at(n - 2_000_000, 2_000_000, "back")
+    pos = check_at((int((1 << 32) * (n / m)) - 1_000_000) // 8 * 8, 2_000_000, "output position 2^32")
+    assert pos < (1 << 32) < pos + 2_000_000
+    check_at((1 << 32) - 1_000_000, 2_000_000, "input row 2^32")
+    del filled, f_ts, f_val
+
+    # FillPrevious of the value column: every row from the first valid one on is valid afterwards
+    got, unchanged = capi.fill(val, "Previous", out_residency=capi.DEVICE)
+    assert not unchanged and got.length == n
+    head_valid = np.unpackbits(val.validity.to_numpy(np.uint8, 16), bitorder="little").astype(bool)
+    assert got.null_count == int(np.argmax(head_valid))      # the leading nulls stay null (bowfill.go:162-253)
+    for a in (0, (1 << 32) - 1_000_000, n - 2_000_000):
+        ts_o, val_o, bm_o = orc.gen_sparse(a, 2_000_000, seed=11)
+        want, _ = orc.fill(orc.Column(val_o, bm_o, orc.FLOAT64), "Previous")
+        first_valid = int(np.argmax(want.valid_mask()))      # (rows before the range's first valid value need the row before the range)
+        gv = got.values.to_numpy(np.uint64, 2_000_000 - first_valid, first=a + first_valid)
+        assert np.array_equal(gv, want.values[:want.length].view(np.uint64)[first_valid:]), a
+
+
+def _fills_every_row(n):
     ts, val = capi.gen_sparse(0, n, seed=9)
     ts_o, val_o, bm_o = orc.gen_sparse(0, n, seed=9)
     oval, ots = orc.Column(val_o, bm_o, orc.FLOAT64), orc.Column(ts_o, None, orc.INT64)
@@ -226,6 +427,17 @@ def test_fills_and_is_col_sorted_at_full_size():
     assert capi.is_col_sorted(ts) and orc.is_col_sorted(ots)
     # a filled column has no nulls left (ts is sorted, the first and the last value of gen_sparse columns may be null)
     assert got.null_count == want.length - int(want.valid_mask().sum())
+
+
+def test_fills_and_is_col_sorted_2e7_every_row():
+    """the four fills and IsColSorted on configs[2]'s columns (irregular int64 ts, 30 % nulls), 2e7 rows, every row against the oracle"""
+    _fills_every_row(20_000_000)
+
+
+@needs_big_host
+def test_fills_and_is_col_sorted_1e8_every_row():
+    """... at configs[2]'s full 1e8 rows"""
+    _fills_every_row(N8)
 
 
 def test_mode_at_scale():

@@ -2,7 +2,8 @@
 counts around the tile sizes, timestamp patterns (dense, irregular, duplicates, gaps, negative / rows below s0), intervals
 and raw offsets, Arrow offsets into longer buffers, null densities from 0 to 100 %, NaN / +-0 / Inf values, mixed column
 types, random reducer lists with Factor chains, inclusive windows, host / device residency - each case through every tile
-kernel that covers it (BOW_FUZZ_SEEDS=N runs N seeds instead of 64).  Bit-exact except Sum / Mean / integrals of windows on the long-window path (1e-11 relative)."""
+kernel that covers it (BOW_FUZZ_SEEDS=N runs N seeds instead of 64).  Bit-exact except Sum / Mean / integrals of windows on an
+order-free path, which must lie within the stated bound (tests/tolerance.py)."""
 import os
 
 import numpy as np
@@ -11,6 +12,7 @@ import pytest
 from bow_amd import capi
 from oracle import pyoracle as orc
 from test_gpu_aggregate import ALL_AGGS, TIME_AGGS, ORDER_SENSITIVE, compare
+from tolerance import assert_within, order_free_bounds
 from test_gpu_callers import both_interp_kernels
 from test_gpu_callers import cmp_out
 
@@ -67,28 +69,15 @@ def rand_col(rng, n, pad):
 
 def run_paths(ccols, ocols, interval, aggs, offset, inclusive, label):
     exp, nic = orc.aggregate(ocols, 0, interval, aggs, offset=offset, inclusive=inclusive)
-    for path, env in (("auto", {}), ("classic-long", {"BOWGPU_LONG_CLASSIC": "1"}), ("stream-all", {"BOWGPU_LONG_STREAM_ALL": "1"}),
-                       ("small-list", {"BOWGPU_SIMPLE_DENSE": "0"}), ("large-list", {"BOWGPU_SIMPLE_DENSE": "1"}),
-                       ("lean", {"BOWGPU_NO_SIMPLE": "1", "BOWGPU_NO_LONG_ONLY": "1"}),
-                      ("general", {"BOWGPU_FORCE_GENERAL": "1", "BOWGPU_NO_LONG_ONLY": "1"})):
-        for k in ("BOWGPU_NO_SIMPLE", "BOWGPU_FORCE_GENERAL", "BOWGPU_NO_LONG_ONLY", "BOWGPU_LONG_CLASSIC", "BOWGPU_LONG_STREAM_ALL"):
-            os.environ[k] = env.get(k, "0")
-        os.environ.pop("BOWGPU_SIMPLE_DENSE", None)      # (the simple kernel's two head-list sizes: by the plan unless forced)
-        if "BOWGPU_SIMPLE_DENSE" in env:
-            os.environ["BOWGPU_SIMPLE_DENSE"] = env["BOWGPU_SIMPLE_DENSE"]
-        try:
-            outs, info = capi.rolling_aggregate(ccols, 0, interval, aggs, offset=offset, inclusive=inclusive)
-        finally:
-            os.environ["BOWGPU_NO_SIMPLE"] = "0"
-            os.environ["BOWGPU_FORCE_GENERAL"] = "0"
-            os.environ["BOWGPU_NO_LONG_ONLY"] = "0"
-            os.environ["BOWGPU_LONG_CLASSIC"] = "0"
-            os.environ["BOWGPU_LONG_STREAM_ALL"] = "0"
-            os.environ.pop("BOWGPU_SIMPLE_DENSE", None)
+    bounds = None
+    for path in capi.agg_routes():
+        outs, info = capi.rolling_aggregate(ccols, 0, interval, aggs, offset=offset, inclusive=inclusive)
         assert info.new_interval_col == nic, label
-        for a, g, w in zip(aggs, outs, exp):
+        if info.long_windows and bounds is None:
+            bounds = order_free_bounds(ocols, 0, interval, aggs, offset=offset, inclusive=inclusive, ref=exp)
+        for i, (a, g, w) in enumerate(zip(aggs, outs, exp)):
             exact = info.long_windows == 0 or a[0] not in ORDER_SENSITIVE
-            compare("%s %s path=%s" % (label, a[0], path), g, w, exact=exact, rtol=1e-11)
+            compare("%s %s path=%s" % (label, a[0], path), g, w, exact=exact, bound=None if exact else bounds[i])
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("BOW_FUZZ_SEEDS", "64"))))
@@ -227,14 +216,15 @@ def test_fuzz_sharded(seed):
         # (frames with rows below s0 - Go's truncating division on a negative first timestamp - are included: the shard
         # protocol settles them with its second exchange)
         res, plan = run_sharded(ts, vals, valid, bounds, interval, offset=offset, aggs=AGGS)
-        for (k, _), (gv, gm, typ), w in zip(AGGS, res, exp):
+        tol = order_free_bounds([orc.Column(ts, None, orc.INT64), orc.Column(vals, bm, orc.FLOAT64)], 0, interval, AGGS, offset=offset,
+                                inclusive=tw, ref=exp)
+        for i, ((k, _), (gv, gm, typ), w) in enumerate(zip(AGGS, res, exp)):
             assert len(gv) == w.length, (label, k, len(gv), w.length)
             wm = w.valid_mask()
             assert np.array_equal(gm, wm), (label, k)
             wv = w.values[:w.length].view(np.uint64)
             if k in ORDER:
-                g, e = gv.view(np.float64)[gm], wv.view(np.float64)[wm]
-                assert np.allclose(g, e, rtol=1e-10, atol=1e-9 if tw else 0), (label, k)
+                assert_within((label, k), gv.view(np.float64)[gm], wv.view(np.float64)[wm], tol[i][wm])
             else:
                 assert np.array_equal(gv[gm], wv[wm]), (label, k)
 
