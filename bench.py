@@ -9,10 +9,15 @@ rows through the C ABI (bitmap init + bucketing/reduction kernel + status readba
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 N > 1: rows are range-partitioned (rank r owns rows [r*R, (r+1)*R): weak scaling); the only exchange of a step is ONE
-all_gather of a fixed-size record per rank (first / last timestamp + the running state of the rank's last window) over RCCL;
-the ownership rules live behind the C ABI (bowgpu_shard_begin / _plan / _finish).  Without a launcher (no WORLD_SIZE in the
-environment) `--gpus N` starts its own N rank processes.
-Rank 0 prints ONE JSON line.
+all_gather of a fixed-size record per rank (first / last timestamp + the running state of the rank's last window) over RCCL,
+started BEFORE the rank's pass is enqueued and collected after (bowgpu_shard_begin / _pass_begin / _finish: the exchange is off
+the critical path; `exchange_ms` = one exchange alone, `exchange_hidden_ms` = what the overlap saves per step against the serial
+order, both measured after the timed region); the ownership rules live behind the C ABI.  Without a launcher (no WORLD_SIZE in
+the environment) `--gpus N` starts its own N rank processes.  A preflight (device count, one exchange under a watchdog) turns a
+rendezvous that cannot complete into a non-zero exit with a message instead of a hang.
+Rank 0 prints ONE JSON line; it carries `parity_check`: the outputs of the timed call compared, outside the timed region, with
+the oracle on the first and the last 2e6 rows of rank 0's rows bit for bit, plus the WindowStart progression of every window -
+a mismatch is a non-zero exit.
 """
 import argparse
 import json
@@ -166,6 +171,71 @@ def host_pinned_rate(capi, dev_cols, sample, aggs):
             c.unpin()
 
 
+def parity_check(capi, outs, rows, row0, interval, offset, owned, first_slot, s0):
+    """The outputs the timed steps produced (rank 0's), checked OUTSIDE the timed region: WindowStart of every owned window is the
+    arithmetic progression; the windows of the first and of the last 2e6 rows against the oracle (the checker), bit for bit.
+    Returns the `parity_check` object of the JSON line; ok == False makes the run fail."""
+    import numpy as np
+    from oracle import pyoracle as orc
+    from bow_amd.sharded import first_window_start
+    aggs = [("WindowStart", 0), ("ArithmeticMean", 1)]
+    res = {"ok": True, "windows_total": int(owned), "checked_against_oracle": 0, "progression_checked": 0}
+    try:
+        CH = 50_000_000
+        for k0 in range(0, owned, CH):
+            m = min(CH, owned - k0)
+            ws = outs[0].values.to_numpy(np.int64, m, first=k0)
+            if ws[0] != s0 + interval * (first_slot + k0) or not (np.diff(ws) == interval).all():
+                raise AssertionError("WindowStart is not the arithmetic progression in slots [%d, %d)" % (k0, k0 + m))
+            res["progression_checked"] += int(m)
+        span = min(2_000_000, rows)
+        for a in sorted({row0, row0 + rows - span}):
+            ts_o, val_o = orc.gen_dense(a, span, seed=42)
+            want, _ = orc.aggregate([orc.Column(ts_o, None, orc.INT64), orc.Column(val_o, None, orc.FLOAT64)], 0, interval, aggs, offset=offset)
+            g0 = (first_window_start(a, interval, offset) - s0) // interval - first_slot   # output slot of the range's first window
+            nw = want[0].length
+            lo = 0 if a == row0 and row0 == 0 else 1                 # (a range cut out of the frame: its first window lacks rows)
+            hi = nw if (a + span == row0 + rows and g0 + nw <= owned and offset == 0) else nw - 1
+            lo, hi = max(lo, -g0), min(hi, owned - g0)
+            for i in (0, 1):
+                gv = outs[i].values.to_numpy(np.uint64, hi - lo, first=g0 + lo)
+                if not np.array_equal(gv, want[i].values[:nw].view(np.uint64)[lo:hi]):
+                    raise AssertionError("output %d differs from the oracle on rows [%d, %d)" % (i, a, a + span))
+            res["checked_against_oracle"] += int(hi - lo)
+        x, s = capi.checksum64(outs[1].values, owned)
+        res["mean_checksum64"] = "%016x%016x" % (x, s)
+        res["what"] = ("outputs of the timed steps, after the timed region: WindowStart progression over every owned window; windows "
+                       "of the first and the last %d rows of rank 0 against oracle/bow_oracle.c, bit for bit" % span)
+    except AssertionError as e:
+        res["ok"] = False
+        res["error"] = str(e)
+    return res
+
+
+def preflight(dist, torch, world, rank, backend, seconds=120):
+    """N > 1, before anything is timed: every rank must see its device, and ONE exchange of the record-sized buffer must complete.
+    A rendezvous that cannot (a rank on the wrong device, a transport that never connects) ends the run with a message and a
+    non-zero exit code instead of hanging until the driver's limit."""
+    import threading
+    from bow_amd import sharded
+    done = threading.Event()
+
+    def watchdog():
+        if not done.wait(seconds):
+            sys.stderr.write("bench.py: rank %d: the preflight exchange (%s, world %d) did not complete within %d s - "
+                             "giving up\n" % (rank, backend, world, seconds))
+            sys.stderr.flush()
+            os._exit(3)
+
+    threading.Thread(target=watchdog, daemon=True).start()
+    device = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else "cpu"
+    g = sharded.Gather(dist, torch, world, device, nbytes=64)
+    got = g(bytes([rank % 251]) * 64)
+    done.set()
+    if [b[0] for b in got] != [r % 251 for r in range(world)]:
+        raise SystemExit("bench.py: rank %d: the preflight all_gather returned the wrong bytes" % rank)
+
+
 def _count(s):
     """row counts as the shell writes them: 100000000, 1e8, 2.5e7"""
     return int(float(s))
@@ -240,6 +310,7 @@ def main():
     ap.add_argument("--rows", type=_count, default=1_000_000_000, help="rows per GPU")
     ap.add_argument("--cpu-sample", type=_count, default=100_000_000)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the parity_check of the timed outputs against the oracle")
     ap.add_argument("--no-pinned", action="store_true",
                     help="skip the host_pinned aside (profiling: it launches the same kernel over PCIe, which would pollute per-kernel averages)")
     args = ap.parse_args()
@@ -275,10 +346,12 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import datetime
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=300))
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=datetime.timedelta(seconds=300))
+        preflight(dist, torch, world, rank, backend)
 
     rows = args.rows
     aggs = [("WindowStart", 0), ("ArithmeticMean", 1)]
@@ -308,7 +381,7 @@ def main():
         step()
     barrier()
     if world > 1:
-        runner.gather.ms, runner.gather.calls = 0.0, 0
+        runner.gather.ms, runner.gather.wait_ms, runner.gather.calls = 0.0, 0.0, 0
     t0 = time.perf_counter()
     kernel_ms = []
     for _ in range(args.steps):
@@ -320,6 +393,41 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    exch = None
+    if world > 1:
+        # after the timed region: the same steps in the SERIAL order (begin -> exchange -> pass) and the exchange alone
+        g = runner.gather
+        exch = {"window_ms": g.ms / max(g.calls, 1), "host_wait_ms": g.wait_ms / max(g.calls, 1), "per_step": g.calls / args.steps}
+        ks = max(3, min(args.steps, 10))
+        runner.step(overlap=False)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(ks):
+            runner.step(overlap=False)
+        barrier()
+        ts_ = torch.tensor([(time.perf_counter() - t1) / ks], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(ts_, op=dist.ReduceOp.MAX)
+        exch["serial_ms_per_step"] = float(ts_.item()) * 1e3
+        rec = runner.provider.begin()
+        g(rec)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(20):
+            g(rec)
+        te = torch.tensor([(time.perf_counter() - t1) / 20], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        exch["alone_ms"] = float(te.item()) * 1e3
+        runner.step()          # (leave the outputs of an ordinary step behind for the parity check)
+        barrier()
+
+    parity = None
+    if rank == 0 and not args.no_parity:
+        # BEFORE the probes below (the read + write probe stores into the output buffers)
+        if world == 1:
+            parity = parity_check(capi, outs, rows, 0, INTERVAL, 0, W, 0, s0)
+        else:
+            d = runner.decision
+            parity = parity_check(capi, runner.provider.outs, rows, 0, INTERVAL, OFFSET_MULTI, d.windows_owned, d.first_slot_window_id, d.s0)
 
     if rank == 0:
         total_rows = rows * world * args.steps
@@ -349,12 +457,20 @@ def main():
                          "kernel": kernel_name, "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": rows * BYTES_PER_ROW},
             "device": capi.device_name(),
+            "parity_check": parity,
         }
         line["roofline"]["traffic"] = measured_traffic(rows, kernel_name)
         if world > 1:
-            # host wall time per step inside THE exchange of the call (upload + all_gather of one 2424-byte record per rank + download)
-            line["exchange_ms"] = runner.gather.ms / args.steps
-            line["exchanges_per_step"] = runner.gather.calls / args.steps
+            # THE exchange of a step (upload + all_gather of one 2424-byte record per rank + download, pinned buffers allocated once):
+            # alone it takes exchange_ms; in the timed steps it is in flight while the pass runs, and the step is exchange_hidden_ms
+            # shorter than the same step in the serial order
+            line["exchange_ms"] = exch["alone_ms"]
+            line["exchange_hidden_ms"] = max(0.0, exch["serial_ms_per_step"] - dt / args.steps * 1e3)
+            line["exchange"] = {"alone_ms": exch["alone_ms"], "serial_ms_per_step": exch["serial_ms_per_step"],
+                                "overlapped_ms_per_step": dt / args.steps * 1e3, "host_wait_ms_per_step": exch["host_wait_ms"],
+                                "window_ms_per_step": exch["window_ms"], "exchanges_per_step": exch["per_step"],
+                                "record_bytes": runner.gather.n, "buffers": "pinned host + device, allocated once"}
+            line["exchanges_per_step"] = exch["per_step"]
         if world == 1:
             # the achievable line: a trivial streaming sum over the same two columns, measured in this run
             try:
@@ -365,11 +481,13 @@ def main():
             # ... and for this TRAFFIC MIX: the same reads plus the same output bytes (two 8-byte slots per window) written in the
             # same pattern by a kernel that does no work (HBM writes are not free next to the reads: bus turnarounds)
             try:
-                rw, rw_ms = capi.stream_rw_ceiling(cols[0].values, cols[1].values, rows * 8, outs[0].values, outs[1].values, interval)
-                line["roofline"]["stream_rw_ceiling"] = {"value": rw, "unit": "GB/s", "ms": rw_ms, "frac_of_ceiling": achieved / rw,
-                                                         "what": "trivial kernel, same bytes read (16 B/row) and written (2 x 8 B/window), same store pattern"}
+                rw, rw_ms = capi.stream_rw_probe(cols[0].values, cols[1].values, rows * 8, outs[0].values, outs[1].values, interval)
+                line["roofline"]["stream_rw_probe"] = {"value": rw, "unit": "GB/s", "ms": rw_ms, "product_over_probe": achieved / rw,
+                                                       "what": "trivial kernel, same bytes read (16 B/row) and written (2 x 8 B/window), same store "
+                                                               "pattern, no arithmetic: ONE launch shape, a probe of what the writes cost beside "
+                                                               "the reads - not a bound (the product kernel is usually a little faster)"}
             except Exception as e:
-                line["roofline"]["stream_rw_ceiling"] = {"error": repr(e)}
+                line["roofline"]["stream_rw_probe"] = {"error": repr(e)}
         if world == 1 and not args.no_pinned:
             # PCIe-inclusive aside (never `value`): the same call on HOST-resident columns of a 1e8-row sample - registered buffers
             # read in place by the kernels (BOWGPU_HOST_PINNED, zero-copy), outputs by DMA into registered buffers
@@ -394,6 +512,11 @@ def main():
                 line["cpu_baseline_all_cores"] = {"error": repr(e)}
         json_out.write(json.dumps(line) + "\n")
         json_out.flush()
+        if parity is not None and not parity["ok"]:
+            sys.stderr.write("bench.py: PARITY CHECK FAILED: %s\n" % parity.get("error"))
+            if dist is not None:
+                dist.destroy_process_group()
+            raise SystemExit(4)
     if dist is not None:
         dist.destroy_process_group()
 

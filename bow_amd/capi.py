@@ -131,8 +131,8 @@ SYMBOLS = [
     "bowgpu_rolling_interpolate_count", "bowgpu_rolling_interpolate_fill", "bowgpu_shard_interp_points",
     "bowgpu_shard_interpolate_count", "bowgpu_shard_interpolate_fill", "bowgpu_fill_linear", "bowgpu_fill",
     "bowgpu_is_col_sorted", "bowgpu_shard_span", "bowgpu_shard_aggregate", "bowgpu_shard_carry_only", "bowgpu_shard_first_row", "bowgpu_shard_fix_first", "bowgpu_carry_merge",
-    "bowgpu_shard_begin", "bowgpu_shard_plan", "bowgpu_shard_finish", "bowgpu_gen_dense",
-    "bowgpu_gen_sparse", "bowgpu_stream_read_ceiling", "bowgpu_stream_rw_ceiling", "bowgpu_debug_status", "bowgpu_debug_host_copy", "bowgpu_checksum64", "bowgpu_parquet_open", "bowgpu_parquet_close",
+    "bowgpu_shard_begin", "bowgpu_shard_pass_begin", "bowgpu_shard_plan", "bowgpu_shard_finish", "bowgpu_gen_dense",
+    "bowgpu_gen_sparse", "bowgpu_stream_read_ceiling", "bowgpu_stream_rw_probe", "bowgpu_debug_status", "bowgpu_debug_host_copy", "bowgpu_checksum64", "bowgpu_parquet_open", "bowgpu_parquet_close",
     "bowgpu_parquet_info", "bowgpu_parquet_column", "bowgpu_parquet_read_column",
     "bowgpu_debug_set_route", "bowgpu_debug_get_route", "bowgpu_checksum64_at",
 ]
@@ -663,11 +663,11 @@ def stream_read_ceiling(buf_a, buf_b, bytes_each):
     return g.value
 
 
-def stream_rw_ceiling(buf_a, buf_b, bytes_each, out_a, out_b, rows_per_slot):
+def stream_rw_probe(buf_a, buf_b, bytes_each, out_a, out_b, rows_per_slot):
     """(read GB/s, ms) of a trivial kernel with the benched kernel's traffic mix: two input streams read, two output streams of
     one 8-byte slot per rows_per_slot rows written (the achievable line for reads AND writes together)"""
     g, ms = C.c_double(0), C.c_double(0)
-    check(lib().bowgpu_stream_rw_ceiling(C.c_void_p(buf_a.ptr), C.c_void_p(buf_b.ptr), C.c_int64(bytes_each), C.c_void_p(out_a.ptr),
+    check(lib().bowgpu_stream_rw_probe(C.c_void_p(buf_a.ptr), C.c_void_p(buf_b.ptr), C.c_int64(bytes_each), C.c_void_p(out_a.ptr),
                                          C.c_void_p(out_b.ptr), C.c_int64(rows_per_slot), C.byref(g), C.byref(ms)))
     return g.value, ms.value
 

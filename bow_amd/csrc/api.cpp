@@ -715,9 +715,12 @@ struct AggJob {
     bool counts_used = false;   // the valid counters hold a previous count (they accumulate): zero them before counting again
 };
 
+static void pending_drop(Ctx *c);   // a pass put in flight by bowgpu_shard_pass_begin and not collected: settled before the scratch is reused
+
 static int job_build(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t ts_col, const Plan &plan, int inclusive,
                      const bowgpu_agg *aggs, int32_t naggs, bowgpu_out *outs, int64_t wid_base, int64_t W,
                      bool holds_row0, AggJob *job) {
+    pending_drop(c);
     const bowgpu_col *tsc = &cols[ts_col];
     const int64_t n = tsc->length;
     for (int i = 0; i < ncols; i++)
@@ -1078,11 +1081,19 @@ static int run_long_windows(Ctx *c, const AggParams &P, const uint32_t *hstat, i
 static thread_local double g_prof_sync_begin = 0, g_prof_sync_end = 0;
 static double now_us() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e6 + t.tv_nsec * 1e-3; }
 
+struct PassState {
+    bool used_simple = false, used_small_list = false;
+    uint32_t *hstat = nullptr;
+    uint64_t *hcnt = nullptr;
+};
+static int job_pass_enqueue(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, const Plan *plan, bool finish, PassState *ps);
+static int job_pass_complete(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, const Plan *plan, bool finish, PassState *ps,
+                             int64_t *long_windows, double *kernel_ms);
+
 static int job_run(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, int64_t *long_windows, double *kernel_ms,
                    bool finish, const Plan *plan = nullptr, bool allow_long_only = false) {
     AggParams &P = job->P;
     const int64_t W = job->W;
-    bool used_simple = false;
     // Long-only pipeline: when the windows of an unsharded call average thousands of rows, nearly all of them would be queued
     // for long_windows.hip by a tile kernel that reads every row just to find that out.  Skip it: order check of the interval
     // column + every window as an entry of the multi-workgroup reduction.  (BOWGPU_ROUTE_NO_LONG_ONLY: test switch.)
@@ -1138,14 +1149,29 @@ static int job_run(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, i
         if (kernel_ms) *kernel_ms = ms;
         return 0;
     }
-    bool used_small_list = false;
-    BG_TRY(job_launch_tiles(c, job, aggs, naggs, plan, true, &used_simple, false, &used_small_list));
+    PassState ps;
+    BG_TRY(job_pass_enqueue(c, job, aggs, naggs, plan, finish, &ps));
+    return job_pass_complete(c, job, aggs, naggs, plan, finish, &ps, long_windows, kernel_ms);
+}
+
+// the tile pass of a call, enqueued only: bitmap preset, tile kernel, (tail), read-back of the status words - no synchronisation
+static int job_pass_enqueue(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, const Plan *plan, bool finish, PassState *ps) {
+    BG_TRY(job_launch_tiles(c, job, aggs, naggs, plan, true, &ps->used_simple, false, &ps->used_small_list));
     // status -> host (pinned).  Optimistically enqueue the tail (null counts, copy-back) behind the tile kernel so
     // the common case needs ONE synchronisation; if windows were queued for the cooperative path, run it and redo the tail.
-    uint32_t *hstat;
-    uint64_t *hcnt = nullptr;
     if (finish) BG_TRY(job_enqueue_tail(c, job, aggs, naggs));
-    BG_TRY(job_readback(c, job, &hstat, &hcnt));
+    BG_TRY(job_readback(c, job, &ps->hstat, &ps->hcnt));
+    return 0;
+}
+
+// ... and its completion: the one synchronisation, the redo of a call the wave-tile kernels could not describe, the queued long windows
+static int job_pass_complete(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, const Plan *plan, bool finish, PassState *ps,
+                             int64_t *long_windows, double *kernel_ms) {
+    AggParams &P = job->P;
+    const int64_t W = job->W;
+    bool used_simple = ps->used_simple, used_small_list = ps->used_small_list;
+    uint32_t *hstat = ps->hstat;
+    uint64_t *hcnt = ps->hcnt;
     g_prof_sync_begin = now_us();
     BG_HIP(hipStreamSynchronize(c->stream));
     g_prof_sync_end = now_us();
@@ -1334,6 +1360,25 @@ static int run_aggregate(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t 
     }
     if (n_mode > 0) return run_modes(c, cols, ncols, ts_col, plan, aggs, naggs, outs, inclusive, long_windows);
     return 0;
+}
+
+// ---- the pass of a sharded call put in flight BEFORE the exchange (bowgpu_shard_pass_begin): one per thread
+struct PendingPass {
+    AggJob job;
+    Plan plan;
+    PassState ps;
+    std::vector<bowgpu_agg> aggs;
+    std::vector<const void *> col_values, out_values;
+    int64_t n = 0, interval = 0, raw_offset = 0, base = 0;
+    int32_t ts_col = 0, inclusive = 0;
+};
+static thread_local PendingPass *g_pending = nullptr;   // (plain pointer: no destructor order to worry about at thread exit)
+
+static void pending_drop(Ctx *c) {
+    if (!g_pending) return;
+    if (c && c->inited) (void)hipStreamSynchronize(c->stream);   // its kernels are done with the scratch blocks before anyone reuses them
+    delete g_pending;
+    g_pending = nullptr;
 }
 
 }  // namespace bowgpu
@@ -1721,7 +1766,7 @@ int bowgpu_shard_aggregate(const bowgpu_col *cols, int32_t ncols, int32_t ts_col
             dnext = reinterpret_cast<bowgpu_next_row *>(reinterpret_cast<char *>(pool) + 8192);
             BG_HIP(hipMemcpyAsync(dnext, next_row, sizeof *next_row, hipMemcpyHostToDevice, c->stream));
         }
-        BG_TRY(launch_range_state(c, job.P, finish ? 2 : 0, (uint64_t)wl, nullptr, dst, dnext));
+        BG_TRY(launch_range_state(c, job.P, finish ? 2 : 0, (uint64_t)wl, nullptr, dst, dnext, 0));
         BG_HIP(hipMemcpyAsync(carry->last, dst, sizeof(bowgpu_carry_state) * naggs, hipMemcpyDeviceToHost, c->stream));
         BG_HIP(hipStreamSynchronize(c->stream));
     }
@@ -1972,6 +2017,53 @@ int bowgpu_shard_begin(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, in
     return 0;
 }
 
+// The rank's pass put in flight BEFORE the exchange, from its own record alone: output slot 0 = the window of the rank's first
+// row on the offset-aligned grid, i.e. what bowgpu_shard_finish will decide whenever no empty windows lie in front of the rank
+// (lead_empty_windows == 0) and no row lies below the frame's first window start.  Enqueued only - the call returns while the
+// kernel runs - and collected by the bowgpu_shard_finish that follows on this thread; if the gathered records decide otherwise
+// (a gap to the left neighbour, the negative-timestamp corner) finish discards it and runs the pass the serial way.
+int bowgpu_shard_pass_begin(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval, const bowgpu_options *opts,
+                            const bowgpu_agg *aggs, int32_t naggs, bowgpu_out *outs, const bowgpu_shard_record *me) {
+    if (!cols || ncols <= 0 || !outs || !me || !aggs) return fail(BOWGPU_ERR_ARG, "null argument");
+    if (ts_col < 0 || ts_col >= ncols) return fail(BOWGPU_ERR_BAD_COL, "no interval column with index %d", ts_col);
+    bowgpu_options o = {0, 0, 0};
+    if (opts) o = *opts;
+    int inclusive = o.inclusive ? 1 : 0, nic = -1;
+    BG_TRY(validate_aggs(cols, ncols, ts_col, aggs, naggs, &inclusive, &nic));
+    BG_TRY(shard_check(cols, ncols, aggs, naggs, outs, &o));
+    if (cols[ts_col].type != BOWGPU_INT64) return fail(BOWGPU_ERR_TS_TYPE, "impossible to create a new intervalRolling on column of type float64");
+    if (me->nrows != cols[ts_col].length) return fail(BOWGPU_ERR_ARG, "the record says %lld rows, the interval column has %lld",
+                                                      (long long)me->nrows, (long long)cols[ts_col].length);
+    Ctx *c;
+    BG_TRY(ctx_get(&c));
+    pending_drop(c);
+    // declined (not an error): nothing to reduce, or timestamps below zero, where the frame's first window start may lie ABOVE
+    // a rank's rows (rolling.go:96-99) - that needs the records
+    if (me->nrows == 0 || me->first_ts < 0 || me->last_ts < me->first_ts) return BOWGPU_SHARD_PASS_DECLINED;
+    PendingPass *pp = new PendingPass();
+    Plan &plan = pp->plan;
+    plan.interval = interval;
+    int rc = enforce_interval_and_offset(interval, o.offset, &plan.offset);
+    int64_t base = 0;
+    if (rc == 0 && !grid_floor(me->first_ts, interval, plan.offset, &base)) rc = BOWGPU_SHARD_PASS_DECLINED;
+    if (rc != 0) { delete pp; return rc; }
+    plan.magic = magic_make((uint64_t)interval);
+    plan.s0 = base;                       // local numbering: slot k = window [base + k * interval, ...)
+    plan.first_ts = me->first_ts;
+    plan.last_ts = me->last_ts;
+    plan.W = (int64_t)(((uint64_t)me->last_ts - (uint64_t)base) / (uint64_t)interval) + 1;
+    pp->base = base;
+    pp->n = me->nrows; pp->interval = interval; pp->raw_offset = o.offset; pp->ts_col = ts_col; pp->inclusive = inclusive;
+    pp->aggs.assign(aggs, aggs + naggs);
+    for (int i = 0; i < ncols; i++) pp->col_values.push_back(reinterpret_cast<const char *>(cols[i].values) + 8 * cols[i].offset);
+    for (int i = 0; i < naggs; i++) pp->out_values.push_back(outs[i].values);
+    rc = job_build(c, cols, ncols, ts_col, plan, inclusive, aggs, naggs, outs, 0, plan.W, false, &pp->job);
+    if (rc == 0) rc = job_pass_enqueue(c, &pp->job, aggs, naggs, &plan, false, &pp->ps);
+    if (rc != 0) { (void)hipStreamSynchronize(c->stream); delete pp; return rc; }
+    g_pending = pp;
+    return 0;
+}
+
 int bowgpu_shard_plan(const bowgpu_shard_record *recs, int32_t world, int32_t rank, int64_t interval, int64_t raw_offset,
                       bowgpu_shard_decision *d) {
     if (!recs || !d || world <= 0 || rank < 0 || rank >= world) return fail(BOWGPU_ERR_ARG, "bad shard plan arguments");
@@ -2053,7 +2145,11 @@ int bowgpu_shard_finish(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, i
         memset(info, 0, sizeof *info);
         info->s0 = d.s0; info->num_windows = d.num_windows; info->new_interval_col = nic; info->inclusive = inclusive;
     }
-    if (d.retry_with_s0) return BOWGPU_SHARD_RETRY;
+    if (d.retry_with_s0) {
+        Ctx *cc;
+        if (g_pending && ctx_get(&cc) == 0) pending_drop(cc);
+        return BOWGPU_SHARD_RETRY;
+    }
     const bowgpu_shard_record &me = recs[rank];
     if (me.nrows != cols[ts_col].length) return fail(BOWGPU_ERR_ARG, "record of rank %d says %lld rows, the interval column has %lld", rank,
                                                      (long long)me.nrows, (long long)cols[ts_col].length);
@@ -2073,10 +2169,38 @@ int bowgpu_shard_finish(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, i
     const int64_t Wtot = plan.W + lead;
     AggJob job;
     const bool pre_rows_here = me.nrows > 0 && me.first_ts < d.s0;   // rows below s0 ride in window 0 (rolling.go:194-196)
-    BG_TRY(job_build(c, cols, ncols, ts_col, plan, inclusive, aggs, naggs, outs, wf < 0 ? 0 : wf - lead, Wtot, pre_rows_here, &job));
     int64_t n_long = 0;
     double ms = 0;
-    BG_TRY(job_run(c, &job, aggs, naggs, &n_long, &ms, false, &plan));
+    // the pass bowgpu_shard_pass_begin put in flight before the exchange, if the records decide what it assumed
+    bool collected = false;
+    if (g_pending) {
+        PendingPass *pp = g_pending;
+        bool same = pp->n == me.nrows && pp->interval == interval && pp->raw_offset == o.offset && pp->ts_col == ts_col &&
+                    pp->inclusive == inclusive && (int32_t)pp->aggs.size() == naggs && (int32_t)pp->col_values.size() == ncols &&
+                    memcmp(pp->aggs.data(), aggs, sizeof(bowgpu_agg) * (size_t)naggs) == 0;
+        for (int i = 0; same && i < ncols; i++) same = pp->col_values[i] == reinterpret_cast<const char *>(cols[i].values) + 8 * cols[i].offset;
+        for (int i = 0; same && i < naggs; i++) same = pp->out_values[i] == outs[i].values;
+        const bool holds = same && wf >= 0 && lead == 0 && !pre_rows_here && pp->plan.W == plan.W &&
+                           pp->base == (int64_t)((uint64_t)d.s0 + (uint64_t)wf * (uint64_t)interval);
+        if (holds) {
+            g_pending = nullptr;
+            job = std::move(pp->job);
+            const int rc = job_pass_complete(c, &job, aggs, naggs, &pp->plan, false, &pp->ps, &n_long, &ms);
+            delete pp;
+            if (rc != 0) return rc;
+            // from the pass's local numbering (slot 0 starts at base) to the frame's: the stitch below speaks global window ids
+            job.P.s0 = d.s0;
+            job.P.wid_base = wf;
+            for (int i = 0; i < naggs; i++) job.douts[i].user = &outs[i];   // (the descriptor array of THIS call receives length / null_count)
+            collected = true;
+        } else {
+            pending_drop(c);
+        }
+    }
+    if (!collected) {
+        BG_TRY(job_build(c, cols, ncols, ts_col, plan, inclusive, aggs, naggs, outs, wf < 0 ? 0 : wf - lead, Wtot, pre_rows_here, &job));
+        BG_TRY(job_run(c, &job, aggs, naggs, &n_long, &ms, false, &plan));
+    }
     if (lead > 0) BG_TRY(launch_fill_empty(c, job.P, 0, lead));
     if (plan.W > 0) {
         void *pool;
@@ -2089,11 +2213,15 @@ int bowgpu_shard_finish(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, i
             BG_HIP(hipMemcpyAsync(dnext, next_row, sizeof *next_row, hipMemcpyHostToDevice, c->stream));
         }
         // the rank owns its last window and only now knows the row that may close it (rolling.go:201-209)
-        if (dnext && d.finish_last) BG_TRY(launch_range_state(c, job.P, 2, (uint64_t)wl, nullptr, nullptr, dnext));
+        if (dnext && d.finish_last) BG_TRY(launch_range_state(c, job.P, 2, (uint64_t)wl, nullptr, nullptr, dnext, 0));
         if (d.seed_first_rank >= 0) {
             // running state of this rank's first window over the rows the ranks to the left hold: one rank's state as is,
             // several merged in rank order (empty ranks in between hold zero states: identity)
             bowgpu_carry_state seeds[BOWGPU_CARRY_MAX_AGGS];
+            // (window 0 stitched across shards is an empty slice unless one of its rows reaches s0: range_state_kernel's rule)
+            int seed_alive = 0;
+            for (int q = d.seed_first_rank; q < rank; q++)
+                if (recs[q].nrows > 0 && recs[q].last_ts >= d.s0) seed_alive = 1;
             for (int a = 0; a < naggs; a++) {
                 seeds[a] = recs[d.seed_first_rank].last[a];
                 for (int q = d.seed_first_rank + 1; q < rank; q++) {
@@ -2112,7 +2240,7 @@ int bowgpu_shard_finish(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, i
             BG_HIP(hipMemcpyAsync(dseed, hseed, sizeof(bowgpu_carry_state) * naggs, hipMemcpyHostToDevice, c->stream));
             // the window may also be the rank's last one: then the next rank's first row can be its inclusive row
             const bool also_last = wf == wl && !d.drops_last;
-            BG_TRY(launch_range_state(c, job.P, 1, (uint64_t)wf, dseed, nullptr, also_last ? dnext : nullptr));
+            BG_TRY(launch_range_state(c, job.P, 1, (uint64_t)wf, dseed, nullptr, also_last ? dnext : nullptr, seed_alive));
         }
     }
     BG_TRY(job_finish(c, &job, aggs, naggs));
@@ -2153,7 +2281,7 @@ int bowgpu_stream_read_ceiling(const void *dev_a, const void *dev_b, int64_t byt
     return 0;
 }
 
-int bowgpu_stream_rw_ceiling(const void *dev_a, const void *dev_b, int64_t bytes_each, void *out_a, void *out_b, int64_t rows_per_slot,
+int bowgpu_stream_rw_probe(const void *dev_a, const void *dev_b, int64_t bytes_each, void *out_a, void *out_b, int64_t rows_per_slot,
                              double *read_gb_per_s, double *ms_out) {
     if (!dev_a || !dev_b || !out_a || !out_b || !read_gb_per_s || bytes_each < (1 << 20) || rows_per_slot <= 0)
         return fail(BOWGPU_ERR_ARG, "two device input buffers of at least 1 MiB each and two output buffers are needed");

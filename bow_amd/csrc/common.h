@@ -284,7 +284,7 @@ int launch_mode(Ctx *c, const int64_t *ts, const int64_t *first_idx, int64_t n, 
 
 // shard.hip
 int launch_range_state(Ctx *c, const AggParams &p, int mode, uint64_t wid, const bowgpu_carry_state *d_seeds,
-                       bowgpu_carry_state *d_states_out, const bowgpu_next_row *d_next = nullptr);
+                       bowgpu_carry_state *d_states_out, const bowgpu_next_row *d_next = nullptr, int seed_alive = 1);
 
 int launch_fill_empty(Ctx *c, const AggParams &p, int64_t slot0, int64_t slot1);
 

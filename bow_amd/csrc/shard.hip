@@ -38,9 +38,12 @@ constexpr int kSeqLimit = 8192;  // longer ranges are merged from 256 contiguous
 //         whether the next shard's first row is that window's inclusive row
 // next: the first row of the next non-empty shard to the right (nullable).  The window's inclusive row (rolling.go:201-209) is
 // the local row right after its rows when that row sits exactly on the window's end, else `next` when ITS timestamp does.
+// seed_alive: some row behind the seeds has ts >= s0.  Window 0 also spans the rows BELOW s0 (negative timestamps), but it is an
+// empty slice unless one of its rows reaches s0 or it takes an inclusive row (rolling.go:194-228: lastRowIndex stays -1) - the
+// "dead window 0" rule of the tile kernels, here for the window as stitched across shards.
 __global__ __launch_bounds__(256) void range_state_kernel(const AggParams p, const int mode, const uint64_t wid,
                                                           const bowgpu_carry_state *seeds,
-                                                          bowgpu_carry_state *states_out, const bowgpu_next_row *next) {
+                                                          bowgpu_carry_state *states_out, const bowgpu_next_row *next, const int seed_alive) {
     __shared__ Stats part[256];
     __shared__ int64_t s_r0, s_r1;
     const int tid = threadIdx.x;
@@ -117,9 +120,13 @@ __global__ __launch_bounds__(256) void range_state_kernel(const AggParams p, con
             }
         }
         if (tid == 0) {
-            const int64_t nrows = seed_rows + len;
+            int64_t nrows = seed_rows + len;
             if (states_out) stats_to_carry(acc, nrows, states_out[a]);
             if (mode != 0 && (uint64_t)oslot < (uint64_t)p.W) {
+                if (wid == 0 && !incl_src && !seed_alive && !(len > 0 && p.ts[r1 - 1] >= p.s0)) {   // dead window 0: an empty slice
+                    stats_init(acc);
+                    nrows = 0;
+                }
                 int64_t nrows_seen = nrows;
                 if (incl_src && kind_needs_inclusive(ad.kind)) {  // the reducers that declared NeedInclusiveWindow see one more row
                     nrows_seen = nrows + 1;
@@ -182,8 +189,8 @@ int launch_fill_empty(Ctx *c, const AggParams &p, int64_t slot0, int64_t slot1) 
 }
 
 int launch_range_state(Ctx *c, const AggParams &p, int mode, uint64_t wid, const bowgpu_carry_state *d_seeds,
-                       bowgpu_carry_state *d_states_out, const bowgpu_next_row *d_next) {
-    hipLaunchKernelGGL(range_state_kernel, dim3(1), dim3(256), 0, c->stream, p, mode, wid, d_seeds, d_states_out, d_next);
+                       bowgpu_carry_state *d_states_out, const bowgpu_next_row *d_next, int seed_alive) {
+    hipLaunchKernelGGL(range_state_kernel, dim3(1), dim3(256), 0, c->stream, p, mode, wid, d_seeds, d_states_out, d_next, seed_alive);
     BG_HIP(hipGetLastError());
     return 0;
 }

@@ -5,8 +5,10 @@ reduces its own rows with no data-path collective.  The protocol lives BEHIND th
 protocol"); what is left here is the transport:
 
     record  = bowgpu_shard_begin(my columns)                    one small kernel, one read-back        (~2.8 KB)
-    records = all_gather(record)                                 THE exchange of the call (RCCL over xGMI / gloo in tests)
-    bowgpu_shard_finish(my columns, records) -> my output slots  the pass + the boundary-window stitch
+    all_gather(record) STARTS                                    THE exchange of the call (RCCL over xGMI / gloo in tests)
+    bowgpu_shard_pass_begin(my columns, record)                  the pass over my rows, enqueued: it runs while the records travel
+    records = the all_gather's result
+    bowgpu_shard_finish(my columns, records) -> my output slots  collects the pass + the boundary-window stitch
 
 Every rank derives the same ownership decisions from the same gathered bytes (bowgpu_shard_plan: which rank outputs a
 window that straddles a boundary, who emits the empty windows between two shards, whose running state seeds whose first
@@ -81,41 +83,92 @@ class ShardPlan:
 
 
 class Gather:
-    """all_gather of one fixed-size record per rank, as bytes: one upload, one collective into ONE tensor, one download.
-    The collective form is chosen once, from the backend, so every rank always issues the same collective and a failure
-    surfaces as an error instead of a hang."""
+    """all_gather of one fixed-size record per rank, as bytes.  Buffers are allocated ONCE: a page-locked host pair and (nccl) a
+    device pair, so a step hands the HIP runtime no pageable memory (runtime-pinned pageable pages faulted on
+    fresh machines) and allocates nothing.  start() puts the exchange in flight on a stream of its own - upload, collective,
+    download - and returns; wait() blocks the HOST until the bytes are there.  In between the caller enqueues the rank's pass on
+    the library's stream (bowgpu_shard_pass_begin), which is how the exchange leaves the critical path.  The collective form is
+    chosen once, from the backend, so every rank always issues the same collective and a failure surfaces as an error instead
+    of a hang."""
 
-    def __init__(self, dist, torch, world, device):
+    def __init__(self, dist, torch, world, device, nbytes=None):
+        from . import capi
         self.dist, self.torch, self.world, self.device = dist, torch, world, device
+        self.n = nbytes if nbytes is not None else C.sizeof(capi.ShardRecord)
+        self.on_gpu = world > 1 and str(device).startswith("cuda")
         self.single = world > 1 and dist.get_backend() == "nccl"   # all_gather_into_tensor: RCCL; gloo takes the list form
-        self.ms = 0.0     # wall time spent in exchanges (reported by bench.py as exchange_ms)
+        self.ms = 0.0          # host wall time start() -> wait() returned, summed (bench.py: the window the exchange had)
+        self.wait_ms = 0.0     # ... of which the host spent blocked inside wait()
         self.calls = 0
+        self._work = None
+        if world == 1:
+            return
+        pin = bool(self.on_gpu)
+        self.h_send = torch.empty(self.n, dtype=torch.uint8, pin_memory=pin)
+        self.h_recv = torch.empty(world * self.n, dtype=torch.uint8, pin_memory=pin)
+        self.h_send_np, self.h_recv_np = self.h_send.numpy(), self.h_recv.numpy()
+        if self.on_gpu:
+            self.d_send = torch.empty(self.n, dtype=torch.uint8, device=device)
+            self.d_recv = torch.empty(world * self.n, dtype=torch.uint8, device=device)
+            self.stream = torch.cuda.Stream(device=device)
+        if not self.single:
+            src = self.d_recv if self.on_gpu else self.h_recv
+            self.recv_views = [src[r * self.n:(r + 1) * self.n] for r in range(world)]
+
+    def start(self, payload):
+        if self.world == 1:
+            self._payload = bytes(payload)
+            return
+        assert self._work is None, "one exchange at a time"
+        assert len(payload) == self.n
+        torch, dist = self.torch, self.dist
+        self._t0 = time.perf_counter()
+        self.h_send_np[:] = np.frombuffer(payload, dtype=np.uint8)
+        if self.on_gpu:
+            with torch.cuda.stream(self.stream):
+                self.d_send.copy_(self.h_send, non_blocking=True)
+                if self.single:
+                    self._work = dist.all_gather_into_tensor(self.d_recv, self.d_send, async_op=True)
+                else:
+                    self._work = dist.all_gather(self.recv_views, self.d_send, async_op=True)
+        else:
+            self._work = dist.all_gather(self.recv_views, self.h_send, async_op=True)
+
+    def wait(self):
+        if self.world == 1:
+            return [self._payload]
+        torch = self.torch
+        t1 = time.perf_counter()
+        if self.on_gpu:
+            with torch.cuda.stream(self.stream):
+                self._work.wait()                     # (stream-side for nccl: the download below queues behind the collective)
+                self.h_recv.copy_(self.d_recv, non_blocking=True)
+            self.stream.synchronize()
+        else:
+            self._work.wait()
+        self._work = None
+        host = self.h_recv_np.tobytes()
+        t2 = time.perf_counter()
+        self.ms += (t2 - self._t0) * 1e3
+        self.wait_ms += (t2 - t1) * 1e3
+        self.calls += 1
+        return [host[r * self.n:(r + 1) * self.n] for r in range(self.world)]
 
     def __call__(self, payload):
-        if self.world == 1:
-            return [bytes(payload)]
-        torch, dist = self.torch, self.dist
-        t0 = time.perf_counter()
-        t = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(self.device)
-        n = t.numel()
-        if self.single:
-            out = torch.empty(self.world * n, dtype=torch.uint8, device=self.device)
-            dist.all_gather_into_tensor(out, t)
-        else:
-            outs = [torch.empty_like(t) for _ in range(self.world)]
-            dist.all_gather(outs, t)
-            out = torch.cat(outs)
-        host = out.cpu().numpy().tobytes()
-        self.ms += (time.perf_counter() - t0) * 1e3
-        self.calls += 1
-        return [host[r * n:(r + 1) * n] for r in range(self.world)]
+        self.start(payload)
+        return self.wait()
 
 
-def sharded_aggregate(provider, gather, rank, world):
+def sharded_aggregate(provider, gather, rank, world, overlap=True):
     """begin -> exchange -> finish (-> once more in the rows-below-s0 corner).  Returns the rank's capi.ShardDecision:
     output slot k of the provider is global window first_slot_window_id + k, the first windows_owned of them are this rank's.
-    provider:  begin(global_s0=None) -> record bytes ;  finish(records) -> (rc, decision)"""
-    recs = gather(provider.begin())
+    provider:  begin(global_s0=None) -> record bytes ;  finish(records, rank) -> (rc, decision) ;  optionally
+    pass_begin(record) - puts the rank's pass in flight while the records travel (overlap=False: the serial order, for A/B)."""
+    rec = provider.begin()
+    gather.start(rec)
+    if overlap and hasattr(provider, "pass_begin"):
+        provider.pass_begin(rec)
+    recs = gather.wait()
     rc, d = provider.finish(recs, rank)
     if rc == RETRY:
         recs = gather(provider.begin(d.s0))
@@ -125,11 +178,16 @@ def sharded_aggregate(provider, gather, rank, world):
     return d
 
 
-def run_local(providers):
+def run_local(providers, overlap=True):
     """The protocol over ranks that live in ONE process (tests: K simulated ranks on one GPU; the all_gather is a list).
-    Returns every rank's decision."""
+    Returns every rank's decision.  overlap: each rank's pass is put in flight from its own record (bowgpu_shard_pass_begin)
+    before its finish - one thread holds one pass in flight, so begin-pass and finish alternate rank by rank here."""
     recs = [p.begin() for p in providers]
-    res = [p.finish(recs, r) for r, p in enumerate(providers)]
+    res = []
+    for r, p in enumerate(providers):
+        if overlap and hasattr(p, "pass_begin"):
+            p.pass_begin(recs[r])
+        res.append(p.finish(recs, r))
     if any(rc == RETRY for rc, _ in res):
         assert all(rc == RETRY for rc, _ in res), "every rank must take the same decision from the same records"
         s0 = res[0][1].s0
@@ -163,6 +221,21 @@ class GpuProvider:
                                                  C.byref(self._opts), self._aarr, len(self.aggs), s0, C.byref(rec)))
         self._f, self._l = rec.first_ts, rec.last_ts
         return bytes(rec)
+
+    def pass_begin(self, record):
+        """the pass over this rank's rows, enqueued from its own record (the exchange travels meanwhile); finish() collects it.
+        Returns True when something was put in flight."""
+        capi = self.capi
+        rec = capi.ShardRecord.from_buffer_copy(bytes(record))
+        cap = self.capacity or 0
+        if rec.nrows > 0 and rec.last_ts >= rec.first_ts:
+            cap = max(cap, (rec.last_ts - rec.first_ts) // self.interval + 3)
+        self._pass_oarr = self._ensure_outs(max(cap, 1))
+        rc = capi.lib().bowgpu_shard_pass_begin(self._carr, len(self.cols), self.ts_col, C.c_int64(self.interval), C.byref(self._opts),
+                                                self._aarr, len(self.aggs), self._pass_oarr, C.byref(rec))
+        if rc < 0:
+            capi.check(rc)
+        return rc == 0
 
     def finish(self, records, rank):
         capi = self.capi
@@ -243,7 +316,8 @@ class ShardedRolling:
         device = torch.device("cuda", torch.cuda.current_device()) if (world > 1 and exchange_device == "cuda") else "cpu"
         self.gather = Gather(dist, torch, world, device)
 
-    def step(self):
-        d = sharded_aggregate(self.provider, self.gather, self.rank, self.world)
+    def step(self, overlap=True):
+        d = sharded_aggregate(self.provider, self.gather, self.rank, self.world, overlap=overlap)
+        self.decision = d
         self.first_slot, self.owned = d.first_slot_window_id, d.windows_owned
         return self.provider.info

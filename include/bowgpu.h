@@ -480,11 +480,23 @@ typedef struct bowgpu_shard_decision {
 } bowgpu_shard_decision;
 
 #define BOWGPU_SHARD_RETRY 1   /* bowgpu_shard_finish: nothing was computed; see retry_with_s0 */
+#define BOWGPU_SHARD_PASS_DECLINED 1   /* bowgpu_shard_pass_begin: nothing was enqueued (not an error); bowgpu_shard_finish runs the pass */
 
 /* global_s0: NULL on the first attempt. */
 int bowgpu_shard_begin(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval,
                        const bowgpu_options *opts, const bowgpu_agg *aggs, int32_t naggs,
                        const int64_t *global_s0, bowgpu_shard_record *record);
+/* The exchange off the critical path (comms row): between bowgpu_shard_begin and bowgpu_shard_finish a host may call
+ *     bowgpu_shard_pass_begin(my columns, my outputs, my record)
+ * which ENQUEUES the rank's pass over its rows and returns at once - the all_gather of the records then travels while the kernel
+ * runs.  The pass assumes what is true of every rank but the odd one: no empty windows between its left neighbour's rows and its
+ * own, no row below the frame's first window start.  bowgpu_shard_finish on the same thread collects it when the gathered records
+ * agree (same columns, outputs, options, aggregators) and discards it otherwise; results are the same bytes either way.  At most
+ * one pass per thread is in flight; no other bowgpu call of this thread may come between the two except bowgpu_shard_plan.
+ * Returns 0, BOWGPU_SHARD_PASS_DECLINED (empty shard, negative timestamps: nothing enqueued), or a negative error. */
+int bowgpu_shard_pass_begin(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval,
+                            const bowgpu_options *opts, const bowgpu_agg *aggs, int32_t naggs, bowgpu_out *outs,
+                            const bowgpu_shard_record *my_record);
 /* Pure host arithmetic on the gathered records (no device, no column data): usable from any process. */
 int bowgpu_shard_plan(const bowgpu_shard_record *records, int32_t world, int32_t rank, int64_t interval,
                       int64_t raw_offset, bowgpu_shard_decision *out);
@@ -509,8 +521,8 @@ int bowgpu_stream_read_ceiling(const void *dev_a, const void *dev_b, int64_t byt
 /* The achievable line for the benched traffic MIX: the same two 8-byte-per-row input streams read by a trivial kernel that also
  * writes two output streams of 8 bytes per `rows_per_slot` rows (out_a / out_b: device buffers of ceil(rows / rows_per_slot)
  * 8-byte slots) in the tile kernels' store pattern.  Best of plain / non-temporal loads; the rate counts the bytes READ, like
- * roofline.achieved does.  Measurement aid for bench.py ("stream_rw_ceiling"). */
-int bowgpu_stream_rw_ceiling(const void *dev_a, const void *dev_b, int64_t bytes_each, void *out_a, void *out_b,
+ * roofline.achieved does.  Measurement aid for bench.py ("stream_rw_probe"). */
+int bowgpu_stream_rw_probe(const void *dev_a, const void *dev_b, int64_t bytes_each, void *out_a, void *out_b,
                              int64_t rows_per_slot, double *read_gb_per_s, double *ms /* nullable */);
 /* Test / A-B routing.  Which kernel serves a call follows from the call's shape alone; the parity tests push one call through
  * every kernel that can take it by setting these bits for the CALLING THREAD (0 = product routing).  The library never reads the

@@ -78,7 +78,9 @@ def test_bench_two_ranks_on_one_gpu():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak"
     assert rec["config"]["parallelism"] == "rows range-partitioned x2"
-    assert rec["value"] > 0 and "exchange_ms" in rec
+    assert rec["value"] > 0 and rec["exchange_ms"] > 0 and rec["exchange_hidden_ms"] >= 0
+    assert rec["exchange"]["exchanges_per_step"] == 1 and rec["exchange"]["record_bytes"] > 2000
+    assert rec["parity_check"]["ok"] is True and rec["parity_check"]["checked_against_oracle"] > 100_000
 
 
 @pytest.mark.gpu
@@ -105,7 +107,9 @@ def test_bench_line_contract_single_gpu():
     assert abs(roof["achieved"] - 2e7 * 16 / (roof["kernel_ms"] * 1e-3) / 1e9) / roof["achieved"] < 1e-6
     assert roof["kernel"] == "rolling_simple_kernel" and 0 < roof["kernel_ms"] <= rec["ms_per_step"]
     assert roof["traffic"] is None          # (PMC traffic is committed for the 1e9-row launch only)
-    assert roof["stream_read_ceiling"]["value"] > 0 and roof["stream_rw_ceiling"]["value"] > 0
+    assert roof["stream_read_ceiling"]["value"] > 0 and roof["stream_rw_probe"]["value"] > 0
     cpu = rec["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] == 1 and cpu["unit"] == "rows/s" and cpu["value"] > 0 and cpu["sample"]
     assert rec["host_pinned"]["value"] > 0 and rec["host_pinned"]["pageable_rows_per_s"] > 0
+    par = rec["parity_check"]
+    assert par["ok"] is True and par["progression_checked"] == 2_000_000 and par["checked_against_oracle"] >= 2_000_000 // 10 * 2 - 2

@@ -190,6 +190,43 @@ def test_sharded_interpolate_equals_whole(kind):
             assert np.array_equal(gv[gm], wv[wm]), (mode, c, np.flatnonzero(gv[gm] != wv[wm])[:10])
 
 
+@pytest.mark.parametrize("tw", [False, True])
+def test_sharded_window_0_of_rows_below_s0_only(tw):
+    """negative timestamps: Go's truncating division puts s0 above the first rows (rolling.go:96-99), window 0 spans them and is an
+    EMPTY slice unless one of its rows reaches s0 or it takes an inclusive row (rolling.go:194-228).  Frames whose window 0 holds
+    ONLY rows below s0, split across ranks in every way, with plain and time-weighted (inclusive) reducers: the window stitched
+    from the shards' running states must come out empty, as in the unsharded call and the oracle."""
+    aggs = TW_AGGS if tw else AGGS
+    frames = [
+        # ([-15, -12] with interval 10: s0 = -10 + 0 ... offset below picks s0 = -11) then a far row: window 0 = rows below s0 only
+        (np.array([-15, -12, 100, 101, 130], dtype=np.int64), 10, 9),
+        (np.array([-15, -14, -13, -12, 100], dtype=np.int64), 10, 9),
+        (np.array([-15, -12, -11, 100], dtype=np.int64), 10, 9),          # ... and one where a row DOES reach s0 = -11
+        (np.array([-15, -12, -1, 100], dtype=np.int64), 10, 9),           # a row exactly on window 0's end (-1): its inclusive row
+        (np.array([-25, -23, -22, 17, 40], dtype=np.int64), 20, 19),
+    ]
+    rng = np.random.default_rng(5)
+    for ts, interval, offset in frames:
+        n = len(ts)
+        vals = np.round(rng.standard_normal(n) * 10, 2)
+        valid = np.ones(n, bool)
+        bm = np.packbits(valid, bitorder="little")
+        ocols = [orc.Column(ts, None, orc.INT64), orc.Column(vals, bm, orc.FLOAT64)]
+        s0, W = orc.plan_windows(ocols[0], interval, offset)
+        assert s0 > ts[0]                                   # the corner this test is about
+        exp, _ = orc.aggregate(ocols, 0, interval, aggs, offset=offset, inclusive=tw)
+        whole, _ = capi.rolling_aggregate([capi.Column(ts), capi.Column(vals, bm, capi.FLOAT64, 0, n, -1)], 0, interval, aggs, offset=offset)
+        for cut in [[0, k, n] for k in range(1, n)] + [[0, 1, 2, n], [0, 2, 2, 3, n], [0, 1, 2, 3, n]]:
+            res, plan = run_sharded(ts, vals, valid, cut, interval, offset=offset, aggs=aggs)
+            for (k, _), (gv, gm, typ), w, wh in zip(aggs, res, exp, whole):
+                label = (list(ts), cut, k)
+                assert len(gv) == w.length == wh.length, label
+                wm = w.valid_mask()
+                assert np.array_equal(gm, wm), label
+                wv = w.values[:w.length].view(np.uint64)
+                assert np.array_equal(gv[gm], wv[wm]), label
+
+
 def test_carry_only_equals_the_carry_of_the_pass():
     """bowgpu_shard_carry_only (what the bench's ranks exchange while their main pass runs) against the carry that
     bowgpu_shard_aggregate returns, over random splits - empty shards, one-row shards, last windows of thousands of rows,

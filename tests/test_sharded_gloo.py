@@ -24,6 +24,23 @@ class NumpyProvider:
     def __init__(self, ts, vals, interval, offset=0):
         self.ts, self.vals, self.interval, self.offset = ts, vals, interval, offset
         self.out = None
+        self.events = []
+        self._early = None
+
+    def pass_begin(self, record):
+        """the rank's own windows from its own record alone, BEFORE the gathered records exist (what bowgpu_shard_pass_begin
+        enqueues on the device): local numbering, slot 0 = the window of the first row on the offset-aligned grid"""
+        from bow_amd import capi
+        self.events.append("pass_begin")
+        rec = capi.ShardRecord.from_buffer_copy(bytes(record))
+        if rec.nrows == 0 or rec.first_ts < 0:
+            return False
+        I, off = self.interval, self.offset % self.interval
+        base = (rec.first_ts - off) // I * I + off
+        lw = (self.ts - base) // I
+        empty = dict(sum=0.0, vmin=0.0, vmax=0.0, count=0, nrows=0, has=0)
+        self._early = (base, [self._state(self.vals[lw == k]) if (lw == k).any() else empty for k in range(int(lw[-1]) + 1)])
+        return True
 
     def _state(self, rows, seed=None):
         st = dict(sum=0.0, vmin=0.0, vmax=0.0, count=0, nrows=0, has=0) if seed is None else dict(seed)
@@ -58,6 +75,7 @@ class NumpyProvider:
 
     def begin(self, global_s0=None):
         from bow_amd import capi
+        self.events.append("begin")
         rec = capi.ShardRecord()
         n = len(self.ts)
         rec.nrows, rec.naggs = n, len(AGGS)
@@ -75,6 +93,8 @@ class NumpyProvider:
 
     def finish(self, records, rank):
         from bow_amd import capi, sharded
+        self.events.append("finish")
+        self.collected = False
         d = sharded.plan(records, rank, self.interval, self.offset)
         assert not d.retry_with_s0
         self.s0 = s0 = d.s0
@@ -87,9 +107,18 @@ class NumpyProvider:
         assert (wf, wl) == (int(wid[0]), int(wid[-1]))
         self.out = [None] * d.windows_local
         empty = dict(sum=0.0, vmin=0.0, vmax=0.0, count=0, nrows=0, has=0)
-        for k in range(wf - lead, wl + 1):
-            rows = self.vals[wid == k]
-            self._emit(k - (wf - lead), k, self._state(rows) if len(rows) else empty)
+        early, self._early = self._early, None
+        if early is not None and lead == 0 and early[0] == s0 + wf * I:
+            # the pass that ran while the records travelled assumed exactly this (no gap to the left neighbour): collect it
+            assert len(early[1]) == wl - wf + 1
+            for k, st in enumerate(early[1]):
+                self._emit(k, wf + k, st)
+            self.collected = True
+        else:
+            self.collected = False
+            for k in range(wf - lead, wl + 1):
+                rows = self.vals[wid == k]
+                self._emit(k - (wf - lead), k, self._state(rows) if len(rows) else empty)
         if d.seed_first_rank >= 0:
             recs = [capi.ShardRecord.from_buffer_copy(b) for b in records]
             seed = self._unpack(recs[d.seed_first_rank].last[0])
@@ -121,8 +150,18 @@ def _worker(rank, world, port, bounds, interval, q):
         a, b = bounds[rank], bounds[rank + 1]
         prov = NumpyProvider(ts[a:b], vals[a:b], interval)
         gather = sharded.Gather(dist, torch, world, "cpu")
-        d = sharded.sharded_aggregate(prov, gather, rank, world)
+        d = sharded.sharded_aggregate(prov, gather, rank, world)        # the overlapped order: the pass starts before the records are in
         assert gather.calls == 1          # ONE exchange per call
+        assert prov.events == ["begin", "pass_begin", "finish"]
+        overlapped, was_collected = [list(r) if r is not None else None for r in prov.out], prov.collected
+        # ... and the serial order (begin -> exchange -> finish) gives the same bytes, decision for decision
+        prov.events = []
+        d2 = sharded.sharded_aggregate(prov, gather, rank, world, overlap=False)
+        assert gather.calls == 2 and prov.events == ["begin", "finish"] and not prov.collected
+        assert bytes(d2) == bytes(d)
+        assert [repr(r) for r in prov.out] == [repr(r) for r in overlapped]
+        # a rank with rows and no gap in front of it must have USED its early pass
+        assert was_collected == (b > a and d.lead_empty_windows == 0)
         q.put((rank, d.first_slot_window_id, d.windows_owned, prov.out[:max(d.windows_owned, 0)]))
     finally:
         dist.destroy_process_group()

@@ -29,8 +29,10 @@ _MAG_KIND = {"Sum": "Sum", "ArithmeticMean": "Sum", "IntegralStep": "IntegralSte
 
 
 def abs_columns(ocols, ts_col):
+    """the frame with every value column replaced by its absolute values; the interval column stays (it defines the windows) and
+    its absolute values - reducers may read the interval column itself - come as one more column at index len(ocols)"""
     out = []
-    for i, c in enumerate(ocols):
+    for i, c in enumerate(list(ocols) + [ocols[ts_col]]):
         if i == ts_col:
             out.append(c)
             continue
@@ -48,15 +50,16 @@ def order_free_bounds(ocols, ts_col, interval, aggs, offset=0, inclusive=False, 
     if any(k in ("IntegralTrapezoid", "WeightedAverageLinear") for k in kinds):
         inclusive = True                                  # aggregation.go:183-185
     acols = abs_columns(ocols, ts_col)
+    src = lambda col: len(ocols) if col == ts_col else col    # noqa: E731  (where a column's absolute values are)
     mag_aggs, where = [("WindowStart", ts_col)], {}
-    for k, col in {(_MAG_KIND[a[0]], a[1]) for a in aggs if a[0] in ORDER_SENSITIVE}:
+    for k, col in sorted({(_MAG_KIND[a[0]], a[1]) for a in aggs if a[0] in ORDER_SENSITIVE}):
         where[(k, col)] = len(mag_aggs)
-        mag_aggs.append((k, col))
-    for col in {a[1] for a in aggs if a[0] in ORDER_SENSITIVE}:
+        mag_aggs.append((k, src(col)))
+    for col in sorted({a[1] for a in aggs if a[0] in ORDER_SENSITIVE}):
         where[("Count", col)] = len(mag_aggs)
-        mag_aggs.append(("Count", col))
+        mag_aggs.append(("Count", src(col)))
         where[("NumRows", col)] = len(mag_aggs)
-        mag_aggs.append(("NumRows", col))
+        mag_aggs.append(("NumRows", src(col)))
     mags, _ = orc.aggregate(acols, ts_col, interval, mag_aggs, offset=offset, inclusive=inclusive)
     out = []
     for i, a in enumerate(aggs):
