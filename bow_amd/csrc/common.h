@@ -307,6 +307,7 @@ constexpr int kPoolMode = 17;    // aggregation.Mode: its output's validity work
 constexpr int kPoolColOrder = 18; // IsColSorted: one (first valid, last valid) record per 512-row trip
 constexpr int kPoolShard = 19;   // shard stitch: seed / merged states and the next shard's first row
 constexpr int kPoolGaps = 32;    // window_first_rows: queued runs of empty windows
+constexpr int kPoolInterpEdge = 31;   // Interpolate: the trips' edge words (interp_wave3_kernel)
 constexpr int kPoolInterp = 20;  // context pool slots 20..30: tile counts, their scan, scan sums, one neighbour index per column
 struct NbrIndex {
     const int64_t *prev_before;  // [nblocks] last valid row in any earlier block, -1 if none
@@ -345,7 +346,8 @@ struct InterpParams {
     int32_t ncols, ts_col;
     int32_t allow_wave2;               // the whole-trip wave kernel may take the call (0: the call is being redone after its run list overflowed)
     int32_t kq_empty;                  // window kq has no row of its own (pass 1's finding)
-    int32_t inclusive, e0;             // Options.Inclusive (interp_wave2_kernel<true> only); e0: row 0 sits exactly on the first window's start
+    int32_t inclusive, e0;             // Options.Inclusive (interp_wave2 / wave3 kernels only); e0: row 0 sits exactly on the first window's start
+    uint64_t *edge_words;              // interp_wave3_kernel: [ncols][trips of 512 rows] - a trip's bits of the bitmap word it shares with the trip before it
     InterpCol cols[kMaxCols];
 };
 int64_t interp_tiles(int64_t n);

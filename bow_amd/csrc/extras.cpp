@@ -326,6 +326,11 @@ static int interp_fill_impl(const bowgpu_col *cols, int32_t ncols, int32_t ts_co
     P.fast32 = interp_fast32(job.plan, job.kq) ? 1 : 0;
     if (P.fast32) interp_magic32(job.plan.interval, &P.m32, &P.sh1_32, &P.sh2_32);
     P.ts_col = ts_col;
+    {   // one word per 512-row trip and column of a launch (at most kMaxCols columns per launch)
+        void *ew;
+        BG_TRY(ctx_pool(c, kPoolInterpEdge, (size_t)((n + 511) / 512) * kMaxCols * 8 + 64, &ew));
+        P.edge_words = reinterpret_cast<uint64_t *>(ew);
+    }
     for (int i = 0; i < ncols; i++) {
         DevCol &dc = job.dcols[i];
         if (i == ts_col) { dc.values = job.dts.values; dc.length = n; dc.type = BOWGPU_INT64; }
@@ -379,9 +384,11 @@ static int interp_fill_impl(const bowgpu_col *cols, int32_t ncols, int32_t ts_co
         return 0;
     };
     BG_TRY(run_all(1));
+    // some trip has more runs of synthetic rows than the default kernel lists: interp_wave_kernel (inclusive windows: interp_wave2_kernel,
+    // whose list holds a run per row) takes the call
+    if (hstat[5]) BG_TRY(run_all(0));
     if (hstat[5] && o.inclusive)
         return fail(BOWGPU_ERR_UNSUPPORTED, "Interpolate on inclusive windows: windows shorter than two rows on average are outside the device path");
-    if (hstat[5]) BG_TRY(run_all(0));   // some trip has more runs of synthetic rows than interp_wave2_kernel lists: the first wave kernel takes the call
     if (hstat[0]) return fail(BOWGPU_ERR_TS_UNSORTED, "interval column is not ascending: outside the device path");
     for (int i = 0; i < ninterps; i++) BG_TRY(devout_finish(c, &douts[i], n_out, cols[i].type, n_out - (int64_t)hcnt[i], false));
     BG_HIP(hipStreamSynchronize(c->stream));

@@ -15,6 +15,8 @@
 // Algorithmic traffic: 8 B (ts, twice) + 8 B per column read, 8 B per column written, per row.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "bitmap_device.h"
 
 namespace bowgpu {
@@ -876,7 +878,11 @@ __global__ __launch_bounds__(64, kCh == 2 ? 4 : 3) void interp_wave2_kernel(cons
                 carry.has = 1; carry.bits = L.prev[c][src]; carry.t = (int64_t)L.prets[src];
             } else if (base > kW2Back) {
                 const int64_t pi = prev_valid_ix(ic.vbits, ic.vbit0, p.n, base - kW2Back - 1, ic.nbr);
-                if (pi >= 0) { carry.has = 1; carry.t = p.ts[pi]; carry.bits = ic.values[pi]; }
+                if (pi >= 0) {
+                    uint64_t xb = ic.values[pi], xt = (uint64_t)p.ts[pi];
+                    asm volatile("" : "+v"(xb), "+v"(xt));   // (see below: no load left pending at the join)
+                    carry.has = 1; carry.t = (int64_t)xt; carry.bits = xb;
+                }
             }
         }
         wave_lds_order();
@@ -942,7 +948,13 @@ __global__ __launch_bounds__(64, kCh == 2 ? 4 : 3) void interp_wave2_kernel(cons
                 if (found) { qn.has = 1; qn.bits = row_bits(r); qn.t = p.s0 + (int64_t)(uint64_t)L.rowrel[r]; }
                 else if (base + nloc < p.n) {   // beyond the trip (rare): bitmap + index
                     const int64_t ni = next_valid_ix(ic.vbits, ic.vbit0, p.n, base + nloc, ic.nbr);
-                    if (ni >= 0) { qn.has = 1; qn.bits = ic.values[ni]; qn.t = (int64_t)tsu[ni]; }
+                    if (ni >= 0) {
+                        uint64_t xb = ic.values[ni], xt = tsu[ni];
+                        // (waited for inside the rare branch: pending at the join, these two loads make the compiler put a wait for ALL
+                        // outstanding loads and stores in front of every later write to their registers - the flush's LDS reads among them)
+                        asm volatile("" : "+v"(xb), "+v"(xt));
+                        qn.has = 1; qn.bits = xb; qn.t = (int64_t)xt;
+                    }
                 }
             }
             uint64_t dup_bits = 0;
@@ -1028,6 +1040,440 @@ __global__ __launch_bounds__(64, kCh == 2 ? 4 : 3) void interp_wave2_kernel(cons
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// interp_wave3_kernel (round 3): interp_wave2_kernel's pass rebuilt for OCCUPANCY.  wave2 holds 13 KB of LDS and 158 VGPRs per
+// wavefront - 11 resident per CU - and its rate followed that (counters: 9.5 wavefronts per CU, 68 % of a wave's life spent waiting,
+// LDS bank-conflict cycles 2.5x the LDS issue cycles: 64 lanes OR-ing their validity bits into two or three words).  Same trips
+// (512 rows, one wavefront, no barrier, all of a trip's loads up front), but everything that does not have to be in LDS is not:
+//   * the column's validity words of the trip come through the constant address space (load_bits128: scalar loads), as do the
+//     128 rows in front of the trip, among which the last valid point before it nearly always lies (two scalar loads fetch it) -
+//     no per-column bitmap and "previous rows" arrays, no LDS-DMA round;
+//   * timestamps stay in REGISTERS as 32-bit offsets from s0; a run of synthetic rows gets its neighbours' timestamps with
+//     ds_bpermute (the LDS crossbar, no LDS memory) and their values from the stage through a row -> position table;
+//   * outputs are staged in LDS in output order, ALIGNED to the output bitmap's words (stage slot = position + (o_trip & 31)),
+//     with one validity BYTE per staged output; the flush reads 16 bytes per lane for the values and, in a second lane mapping
+//     (lane l = slot 64 r + l), the flags whose ballots ARE the bitmap words - no LDS atomics, no bit interleaving;
+//   * 16-byte non-temporal stores onto 16-byte aligned addresses, whole validity words (atomic OR only for the two words a trip
+//     may share with its neighbours).
+// LDS 9.5 KB per wavefront (10 KB allocated: 16 per CU), <= 128 VGPRs.  Two designs that lost on the way (same data, 1e8 rows):
+// 256-row trips at 20 wavefronts per CU, 1.74 ms against wave2's 1.26 - twice the per-trip instructions per row, the scalar unit
+// saturated (5.1e8 scalar instructions per launch against 1.5e8); neighbour points gathered from global memory instead of
+// LDS / registers, 1.95 ms - gfx950 counts loads and stores in ONE counter, so waiting for a gather waited for every store of the
+// previous column's flush.  Trips whose outputs exceed the stage (long runs of empty windows) write directly; more runs than the
+// list holds (windows of < 4 rows on average) raise status[5] and the host redoes the call with interp_wave_kernel /
+// interp_wave2_kernel.  Results are bit-identical to the other Interpolate kernels (the tests run all of them).
+constexpr int kT3Rows = 512;                  // rows per trip: 4 chunks of 128, lane l = rows 2l, 2l + 1 of each
+constexpr int kT3Ch = kT3Rows / 128;
+constexpr int kT3Stage = kT3Rows + kT3Rows / 2;   // outputs staged per trip and column (the rows + up to half as many synthetic rows)
+constexpr int kT3Slots = kT3Stage + 32;       // ... + the bit offset of the trip's first output inside its bitmap word
+
+template <int kRuns>
+struct Wave3Lds {
+    alignas(16) uint64_t val[kT3Slots];       // staged outputs
+    alignas(8) uint8_t fl[kT3Slots + 8];      // their validity, one byte each
+    uint32_t run_a[kRuns];                    // local row | copy flag << 9 | count << 10 (count saturates: such a trip is redone elsewhere)
+    uint32_t run_k[kRuns];                    // window of the run's first synthetic row
+    uint16_t run_o[kRuns];                    // output position (relative to the trip's first) of the row the run sits in front of
+    uint16_t pos[kT3Rows];                    // row -> output position: a run's neighbour rows are read back from the stage
+    uint64_t vw[2 * kT3Ch];                   // the current column's validity bits of the trip's rows: row r = bit r & 63 of word r >> 6
+};
+
+template <bool kIncl>
+__global__ __launch_bounds__(64, 4) void interp_wave3_kernel(const InterpParams p, const int64_t ntrips, const int64_t trips_per_xcd) {
+    constexpr int kRuns = kIncl ? kT3Rows : kT3Rows / 4;
+    __shared__ Wave3Lds<kRuns> L;
+    const int lane = threadIdx.x;
+#ifdef BOWGPU_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last) :: "memory");
+#endif
+    const int64_t b = blockIdx.x;
+    const int64_t trip = (b & 7) * trips_per_xcd + (b >> 3);   // XCD-contiguous runs of trips: the rows around a trip's ends are in that XCD's L2
+    if (trip >= ntrips) return;
+    const int64_t base = trip * kT3Rows;
+    const int64_t left_trip = p.n - base;
+    const bool full = left_trip >= kT3Rows;
+    const int nloc = full ? kT3Rows : (int)left_trip;
+    const Magic32 m32 = {p.m32, p.sh1_32, p.sh2_32};
+    const uint32_t s0lo = (uint32_t)p.s0, i32 = (uint32_t)p.interval;
+    const uint64_t *tsu = reinterpret_cast<const uint64_t *>(p.ts);
+    typedef const uint64_t __attribute__((address_space(4))) *const_u64;   // inputs nobody writes during the kernel: scalar loads
+
+    auto load2 = [&](const uint64_t *col, int k, uint64_t *a, uint64_t *bb) {
+        const int r = 128 * k + 2 * lane;
+        const uint64_t *src = col + base;
+        if (full && (reinterpret_cast<uintptr_t>(col) & 15) == 0) {
+            typedef unsigned long long u64x2i_t __attribute__((ext_vector_type(2)));
+            const u64x2i_t v = __builtin_nontemporal_load(reinterpret_cast<const u64x2i_t *>(src + r));   // (streamed once)
+            *a = v.x; *bb = v.y;
+        } else { *a = r < left_trip ? src[r] : 0; *bb = r + 1 < left_trip ? src[r + 1] : 0; }
+    };
+
+    // ---- round 1: the trip's timestamps and the values of its first column that is not the interval column itself
+    uint64_t ta[kT3Ch], tb[kT3Ch], na[kT3Ch], nb[kT3Ch];
+#pragma unroll
+    for (int k = 0; k < kT3Ch; k++) load2(tsu, k, &ta[k], &tb[k]);
+    const bool col0_is_ts = p.cols[0].values == tsu;
+    const int first_loaded = col0_is_ts ? 1 : 0;     // the column na / nb hold when the column loop starts
+    if (first_loaded < p.ncols) {
+#pragma unroll
+        for (int k = 0; k < kT3Ch; k++) load2(p.cols[first_loaded].values, k, &na[k], &nb[k]);
+    }
+    int64_t o_trip = 0, t_before = p.left_ts;
+    if (base > 0) {
+        t_before = (int64_t)((const_u64)(uintptr_t)tsu)[base - 1];
+        const uint32_t wp = mdiv32((uint32_t)((uint64_t)t_before - (uint64_t)p.s0), m32);
+        // inclusive windows: one extra row in front of every window's first row (synthetic or the copy), but none for an exact row 0
+        // (tile_exact_before holds one entry per 256 rows)
+        o_trip = kIncl ? base + (int64_t)wp + 1 - p.wbase - p.e0 : base + (int64_t)wp + 1 - p.wbase - p.tile_exact_before[trip * (kT3Rows / 256)];
+    }
+    const uint32_t sh_o = (uint32_t)(o_trip & 31);   // stage slot of the trip's first output = its bit inside its bitmap word
+    if (lane < p.ncols) p.edge_words[(int64_t)lane * ntrips + trip] = 0ull;   // (no entry unless a staged flush below leaves one)
+
+    // ---- phase 1: output positions (relative to o_trip) of the lane's rows, the run list; the timestamps stay as 32-bit offsets
+    uint32_t rr0[kT3Ch], rr1[kT3Ch];
+    uint32_t tot = 0;
+    int nrun = 0;
+    bool toolong = false;
+    {
+        uint32_t rb_prev = 0;
+#pragma unroll
+        for (int k = 0; k < kT3Ch; k++) {
+            const int64_t i = base + 128 * k + 2 * lane;
+            const uint32_t ra = (uint32_t)ta[k] - s0lo, rb = (uint32_t)tb[k] - s0lo;
+            rr0[k] = ra; rr1[k] = rb;
+            uint32_t rl = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rb, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+            if (lane == 0) rl = k == 0 ? (uint32_t)t_before - s0lo : (uint32_t)__builtin_amdgcn_readlane((int)rb_prev, 63);
+            rb_prev = rb;
+            const bool in0 = i < p.n, in1 = i + 1 < p.n;
+            const bool first = i == 0 && !p.has_left;  // the frame's first row has no left neighbour
+            const uint32_t wl = mdiv32(rl, m32), wa = mdiv32(ra, m32), wb = mdiv32(rb, m32);
+            const bool head0 = in0 && (first || wa != wl), head1 = in1 && wb != wa;
+            const bool exact0 = head0 && ra == wa * i32, exact1 = head1 && rb == wb * i32;
+            // rows in front of a head: the empty windows before it + a synthetic row for its own window - or, when the row sits on
+            // its window's start, nothing (exclusive windows) / the copy of itself that closes the window before (inclusive ones)
+            const uint32_t sy0 = head0 ? ((first ? 0u : wa - wl - 1u) + (exact0 ? ((kIncl && !first) ? 1u : 0u) : 1u)) : 0u;
+            const uint32_t sy1 = head1 ? (wb - wa - 1u + (exact1 ? (kIncl ? 1u : 0u) : 1u)) : 0u;
+            const uint32_t e0 = in0 ? 1u : 0u, e1 = in1 ? 1u : 0u;
+            const uint32_t mine = e0 + e1 + sy0 + sy1;
+            const uint32_t inc = wave_scan_u32(mine);
+            uint32_t o = tot + inc - mine;
+            o += sy0; const uint32_t o0 = o; o += e0;
+            o += sy1; const uint32_t o1 = o;
+            tot += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+            *reinterpret_cast<uint32_t *>(&L.pos[128 * k + 2 * lane]) = (o0 < 0xFFFFu ? o0 : 0xFFFFu) | ((o1 < 0xFFFFu ? o1 : 0xFFFFu) << 16);
+            // the runs of this chunk, in row order
+            const bool ha = sy0 > 0, hb = sy1 > 0;
+            const unsigned long long ma = __ballot(ha), mb = __ballot(hb);
+            toolong |= sy0 >= 0x3FFFFFu || sy1 >= 0x3FFFFFu;
+            if (ma | mb) {
+                int pos = nrun;
+                pos += __builtin_amdgcn_mbcnt_hi((unsigned)(ma >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ma, 0));
+                pos += __builtin_amdgcn_mbcnt_hi((unsigned)(mb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb, 0));
+                const uint32_t la = (uint32_t)(128 * k + 2 * lane);
+                // (the run's first row is the copy of its row, not a synthetic row, when the windows are inclusive and the row sits on its window's start)
+                if (ha && pos < kRuns) {
+                    L.run_a[pos] = la | ((kIncl && exact0) ? 0x200u : 0u) | (sy0 << 10);
+                    L.run_k[pos] = exact0 ? wa - 1u : wa;
+                    L.run_o[pos] = (uint16_t)(o0 < 0xFFFFu ? o0 : 0xFFFFu);
+                }
+                pos += ha ? 1 : 0;
+                if (hb && pos < kRuns) {
+                    L.run_a[pos] = (la + 1u) | ((kIncl && exact1) ? 0x200u : 0u) | (sy1 << 10);
+                    L.run_k[pos] = exact1 ? wb - 1u : wb;
+                    L.run_o[pos] = (uint16_t)(o1 < 0xFFFFu ? o1 : 0xFFFFu);
+                }
+                nrun += __popcll(ma) + __popcll(mb);
+            }
+        }
+    }
+    // outside this kernel's list, or positions its 16-bit tables cannot hold (a trip with 65 535 or more synthetic rows): the host
+    // redoes the call with another kernel
+    if (nrun > kRuns || tot >= 0xFFFFu || __ballot(toolong)) {
+        if (lane == 0) atomicOr(&p.status[5], 1u);
+        return;
+    }
+    const bool staged = tot <= (uint32_t)kT3Stage;
+    // the timestamp offset of row r of the trip (r differs per lane): out of the registers of the lane that holds it
+    auto rel_of = [&](int r) -> uint32_t {
+        const int src = ((r & 127) >> 1) << 2;
+        uint32_t x = 0;
+#pragma unroll
+        for (int k = 0; k < kT3Ch; k++) {
+            const uint32_t y0 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)rr0[k]);
+            const uint32_t y1 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)rr1[k]);
+            if ((r >> 7) == k) x = (r & 1) ? y1 : y0;
+        }
+        return x;
+    };
+    W2_STAMP(0);   // round 1 (timestamps) + phase 1
+
+    // ---- phase 2: one column at a time (the next column's values in flight meanwhile)
+#pragma unroll 1
+    for (int c = 0; c < p.ncols; c++) {
+        const InterpCol &ic = p.cols[c];
+        const bool want_p = ic.kind == BOWGPU_INTERP_LINEAR || ic.kind == BOWGPU_INTERP_STEP_PREVIOUS, want_n = ic.kind == BOWGPU_INTERP_LINEAR;
+        uint64_t a[kT3Ch], bq[kT3Ch];
+        if (c == 0 && col0_is_ts) {   // the interval column's own values: s0 + offset (the loaded registers were given up after phase 1)
+#pragma unroll
+            for (int k = 0; k < kT3Ch; k++) { a[k] = (uint64_t)p.s0 + (uint64_t)rr0[k]; bq[k] = (uint64_t)p.s0 + (uint64_t)rr1[k]; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < kT3Ch; k++) { a[k] = na[k]; bq[k] = nb[k]; }
+            if (c + 1 < p.ncols) {
+#pragma unroll
+                for (int k = 0; k < kT3Ch; k++) load2(p.cols[c + 1].values, k, &na[k], &nb[k]);
+            }
+        }
+        // the column's validity bits of the trip's rows: scalar 64-bit words
+        uint64_t vs[2 * kT3Ch];
+#pragma unroll
+        for (int k = 0; k < kT3Ch; k++) {
+            vs[2 * k] = 0; vs[2 * k + 1] = 0;
+            if (full) load_bits128<true>(ic.vbits, ic.vbit0, base + 128 * k, p.n, &vs[2 * k], &vs[2 * k + 1]);
+            else if (left_trip > 128 * k) load_bits128<false>(ic.vbits, ic.vbit0, base + 128 * k, p.n, &vs[2 * k], &vs[2 * k + 1]);
+        }
+        // the last valid point before the trip: among the 64 rows in front of it; further back only after a run of 64 nulls -
+        // then through the bitmap and the neighbour index
+        NbPoint carry; carry.has = 0; carry.t = 0; carry.bits = 0;
+        if (want_p && base > 0 && nrun > 0) {
+            uint64_t back = ~0ull, unused;
+            if (ic.vbits) load_bits128<true>(ic.vbits, ic.vbit0, base - 128, p.n, &unused, &back);   // (base is a multiple of 512: the 128 rows exist)
+            int64_t pi = -1;
+            if (back) pi = base - 1 - __clzll((long long)back);
+            else if (base > 64) pi = prev_valid_ix(ic.vbits, ic.vbit0, p.n, base - 65, ic.nbr);
+            if (pi >= 0) {
+                carry.has = 1;
+                carry.t = (int64_t)((const_u64)(uintptr_t)tsu)[pi];
+                carry.bits = ((const_u64)(uintptr_t)ic.values)[pi];
+            }
+        }
+        uint64_t *out = ic.out_values + o_trip;
+        // (the body twice, with `staged` a compile-time constant: the staged form then holds no global store inside a loop - LLVM
+        // drains the memory counter in front of a loop that stores and uses registers loaded outside it, which on gfx950, where
+        // stores and loads share the counter, is a wait for every store of the previous column's flush)
+        auto column_body = [&](auto staged_tag) {
+        constexpr bool staged = decltype(staged_tag)::value;
+        if (staged) {
+#pragma unroll
+            for (int i = 0; i < ((kT3Slots + 8) / 8 + 63) / 64; i++)
+                if (lane + 64 * i < (kT3Slots + 8) / 8) *reinterpret_cast<uint64_t *>(&L.fl[8 * (lane + 64 * i)]) = 0ull;
+        }
+        if (lane < 2 * kT3Ch) {
+            uint64_t x = 0;
+#pragma unroll
+            for (int w = 0; w < 2 * kT3Ch; w++) if (lane == w) x = vs[w];
+            L.vw[lane] = x;
+        }
+        wave_lds_order();
+        auto put = [&](uint32_t pos, uint64_t bits, int valid) {
+            if (staged) {
+                L.val[sh_o + pos] = bits;
+                L.fl[sh_o + pos] = (uint8_t)valid;
+            } else {
+                out[pos] = bits;
+                if (valid) {
+                    // (bits of the word shared with the trip before go to this trip's edge entry, like the staged form's: that trip may
+                    // store the word plainly)
+                    if (sh_o + pos < 32u && sh_o != 0u)
+                        atomicOr(reinterpret_cast<unsigned long long *>(&p.edge_words[(int64_t)c * ntrips + trip]),
+                                 (unsigned long long)(uint32_t)(o_trip >> 5) | ((unsigned long long)(1u << (sh_o + pos)) << 32));
+                    else atomicOr(&ic.out_valid_words[(o_trip + pos) >> 5], 1u << ((o_trip + pos) & 31));
+                }
+            }
+        };
+        // the rows to their places
+#pragma unroll
+        for (int k = 0; k < kT3Ch; k++) {
+            const int r = 128 * k + 2 * lane;
+            const uint32_t pp = *reinterpret_cast<const uint32_t *>(&L.pos[r]);
+            const int fl = (int)(((lane < 32 ? vs[2 * k] : vs[2 * k + 1]) >> ((2 * lane) & 63)) & 3ull);
+            if (r < nloc) put(pp & 0xFFFFu, a[k], fl & 1);
+            if (r + 1 < nloc) put(pp >> 16, bq[k], (fl >> 1) & 1);
+        }
+        wave_lds_order();
+        W2_STAMP(1);   // column head: values arrive, validity words, carry, rows staged
+        // the nearest valid rows around row al inside the trip (-1: none), from the column's validity words
+        auto nearest = [&](int al, int *rp, int *rn) {
+            *rp = -1; *rn = -1;
+            if (want_p) {
+                int r = al - 1;
+                while (r >= 0) {
+                    const int sh = r & 63;
+                    uint64_t x = L.vw[r >> 6];
+                    x = sh == 63 ? x : (x & ((2ull << sh) - 1ull));
+                    if (x) { r = (r & ~63) + 63 - __clzll((long long)x); break; }
+                    r = (r & ~63) - 1;
+                }
+                *rp = r;
+            }
+            if (want_n) {
+                int r = al;
+                bool found = false;
+                while (r < nloc) {
+                    const uint64_t x = L.vw[r >> 6] & (~0ull << (r & 63));
+                    if (x) { r = (r & ~63) + __ffsll((long long)x) - 1; found = r < nloc; break; }
+                    r = (r | 63) + 1;
+                }
+                *rn = found ? r : -1;
+            }
+        };
+        // their (timestamp, value): the timestamps out of the registers of the lanes that hold them, the values from the stage
+        // through the row -> position table (no global load in the run pass: on gfx950 a wait for a load is also a wait for every
+        // store issued before it, i.e. for the previous column's flush); the point after the trip (rare) through the bitmap + index
+        auto row_bits = [&](int r) -> uint64_t { return staged ? L.val[sh_o + (uint32_t)L.pos[r]] : ic.values[base + r]; };
+        auto points = [&](int rp, int rn, NbPoint *qp, NbPoint *qn) {
+            *qp = carry; qn->has = 0; qn->t = 0; qn->bits = 0;
+            const uint32_t tp = want_p ? rel_of(rp < 0 ? 0 : rp) : 0u, tn = want_n ? rel_of(rn < 0 ? 0 : rn) : 0u;   // (bpermute: every lane takes part)
+            if (rp >= 0) { qp->has = 1; qp->t = p.s0 + (int64_t)(uint64_t)tp; qp->bits = row_bits(rp); }
+            if (rn >= 0) { qn->has = 1; qn->t = p.s0 + (int64_t)(uint64_t)tn; qn->bits = row_bits(rn); }
+            else if (want_n && base + nloc < p.n) {
+                const int64_t ni = next_valid_ix(ic.vbits, ic.vbit0, p.n, base + nloc, ic.nbr);
+                if (ni >= 0) {
+                    uint64_t xb = ic.values[ni], xt = tsu[ni];
+                    // (the two loads are waited for HERE, inside the rare branch: left pending at the join, the compiler puts a wait for
+                    // every outstanding load AND store in front of each later write to their registers - the flush's LDS reads among them)
+                    asm volatile("" : "+v"(xb), "+v"(xt));
+                    qn->has = 1; qn->bits = xb; qn->t = (int64_t)xt;
+                }
+            }
+        };
+        // ---- one lane per run (runs of up to kSmallRun rows; the long runs of empty windows follow, one at a time)
+        bool any_long = false;
+#pragma unroll 1
+        for (int q0 = 0; q0 < nrun; q0 += 64) {
+            const int q = q0 + lane;
+            const bool act = q < nrun;
+            const uint32_t e = act ? L.run_a[q] : 0u;
+            const uint32_t cnt = e >> 10;
+            const bool mine = act && cnt <= (uint32_t)kSmallRun;
+            any_long |= __ballot(act && !mine) != 0ull;
+            const uint32_t orow = act ? (uint32_t)L.run_o[q] : 0u;
+            const uint32_t kfirst = act ? L.run_k[q] : 0u;
+            const int al = (int)(e & 511u);
+            const uint32_t jd = (kIncl && (e & 0x200u) && cnt > 0) ? 1u : 0u;   // the run's first row is the copy of row al
+            int rp = -1, rn = -1;
+            if (mine) nearest(al, &rp, &rn);
+            NbPoint qp, qn;
+            points(rp, rn, &qp, &qn);
+            if (mine) {
+                for (uint32_t j = 0; j < cnt; j++) {
+                    uint64_t bits; int valid;
+                    if (kIncl && j < jd) { bits = row_bits(al); valid = (int)((L.vw[al >> 6] >> (al & 63)) & 1ull); }
+                    else {
+                        const int64_t sk = p.s0 + (int64_t)((uint64_t)(kfirst - (j - jd)) * (uint64_t)p.interval);
+                        synth_value_pt(ic, sk, qp, qn, &bits, &valid);
+                    }
+                    put(orow - 1 - j, bits, valid);
+                }
+            }
+        }
+        if (any_long) {   // long runs of empty windows: the whole wavefront on one run at a time, everything about the run wave-uniform
+#pragma unroll 1
+            for (int q = 0; q < nrun; q++) {
+                const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.run_a[q]);
+                const uint32_t cnt = e >> 10;
+                if (cnt <= (uint32_t)kSmallRun) continue;
+                const uint32_t orow = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)L.run_o[q]);
+                const uint32_t kfirst = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.run_k[q]);
+                const int al = (int)(e & 511u);
+                const uint32_t jd = (kIncl && (e & 0x200u)) ? 1u : 0u;
+                int rp, rn;
+                nearest(al, &rp, &rn);
+                NbPoint qp, qn;
+                points(rp, rn, &qp, &qn);
+                for (uint32_t j = (uint32_t)lane; j < cnt; j += 64) {
+                    uint64_t bits; int valid;
+                    if (kIncl && j < jd) { bits = row_bits(al); valid = (int)((L.vw[al >> 6] >> (al & 63)) & 1ull); }
+                    else {
+                        const int64_t sk = p.s0 + (int64_t)((uint64_t)(kfirst - (j - jd)) * (uint64_t)p.interval);
+                        synth_value_pt(ic, sk, qp, qn, &bits, &valid);
+                    }
+                    put(orow - 1 - j, bits, valid);
+                }
+            }
+        }
+        W2_STAMP(2);   // run pass
+        // ---- the stage leaves: stage slot e <-> output position (o_trip - sh_o) + e, a multiple of 32 at e = 0, so every pair
+        // (2i, 2i + 1) is 16-byte aligned in the output and every 64 slots are two whole words of the output bitmap
+        if (staged) {
+            wave_lds_order();
+            const uint32_t e_lo = sh_o, e_hi = sh_o + tot;   // real slots
+            uint64_t *outA = out - sh_o;
+            uint32_t *wdst = ic.out_valid_words + ((o_trip - (int64_t)sh_o) >> 5);
+            constexpr int kFlush = (kT3Slots + 127) / 128;
+            // (every LDS read unconditional, at a clamped address: a conditional read would first zero its destination registers with
+            // vector moves, and the compiler puts a wait for ALL outstanding stores in front of a vector write to registers an earlier
+            // store took its data from - measured: the flush then waited for the previous batch's stores, 55 % of a wave's life)
+#pragma unroll 1
+            for (int k2 = 0; k2 < kFlush; k2 += 2) {   // two rounds of 128 slots at a time: the LDS reads of both, then the stores
+                if (128u * (uint32_t)k2 >= e_hi) break;   // (wave-uniform)
+                ulonglong2 fx[2];
+                uint32_t ff[4];
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const uint32_t e0 = 128u * (uint32_t)(k2 + u) + 2u * (uint32_t)lane;
+                    fx[u] = *reinterpret_cast<const ulonglong2 *>(&L.val[e0 < (uint32_t)(kT3Slots - 2) ? e0 : (uint32_t)(kT3Slots - 2)]);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {   // the flags in bitmap order: lane l = slot 64 (2 k2 + u) + l
+                    const uint32_t e = 64u * (uint32_t)(2 * k2 + u) + (uint32_t)lane;
+                    ff[u] = (uint32_t)L.fl[e < (uint32_t)(kT3Slots + 7) ? e : (uint32_t)(kT3Slots + 7)];   // (slots outside [e_lo, e_hi) hold 0: zeroed per column)
+                }
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const uint32_t e0 = 128u * (uint32_t)(k2 + u) + 2u * (uint32_t)lane;
+                    const bool lo_ok = e0 - e_lo < tot, hi_ok = e0 + 1u - e_lo < tot;   // (unsigned: also false below e_lo)
+                    const ulonglong2 x = fx[u];
+                    if (lo_ok && hi_ok) { typedef unsigned long long u64x2o_t __attribute__((ext_vector_type(2))); u64x2o_t v; v.x = x.x; v.y = x.y; __builtin_nontemporal_store(v, reinterpret_cast<u64x2o_t *>(outA + e0)); }   // (never read back)
+                    else if (lo_ok) outA[e0] = x.x;
+                    else if (hi_ok) outA[e0 + 1] = x.y;
+                }
+                {
+                // eight bitmap words: ballot u = slots 64 (2 k2 + u) .. + 63
+                const uint64_t m0 = __ballot(ff[0] != 0u), m1 = __ballot(ff[1] != 0u), m2 = __ballot(ff[2] != 0u), m3 = __ballot(ff[3] != 0u);
+                if (lane < 8) {
+                    const uint64_t mm = (lane >> 1) == 0 ? m0 : (lane >> 1) == 1 ? m1 : (lane >> 1) == 2 ? m2 : m3;
+                    const uint32_t x32 = (lane & 1) ? (uint32_t)(mm >> 32) : (uint32_t)mm;
+                    const uint32_t wi = 8u * (uint32_t)(k2 >> 1) + (uint32_t)lane;      // word of the stage
+                    const uint32_t first_bit = 32u * wi;
+                    if (first_bit < e_hi && first_bit + 32u > e_lo) {
+                        // A trip's first word may also hold the last bits of the trip before it.  NO atomic: an agent-scope atomic OR is
+                        // executed beyond the XCD's L2, and the two per trip and column this kernel (like interp_wave2_kernel) used to
+                        // issue cost 0.7 of its 1.5 ms (same data, the stores left plain: 0.87 ms for the call against 1.57).  Instead the
+                        // trip BEFORE stores that word plainly - its own bits, zeroes above them - and this trip's bits of it go to a
+                        // list (one entry per trip and column) that interp_edge_fix_kernel ORs in afterwards.
+                        if (first_bit < e_lo) p.edge_words[(int64_t)c * ntrips + trip] = (uint64_t)(uint32_t)((o_trip - (int64_t)sh_o) >> 5) | ((uint64_t)x32 << 32);
+                        else wdst[wi] = x32;
+                    }
+                }
+                }
+            }
+            wave_lds_order();
+        }
+        };   // column_body
+        if (staged) column_body(std::true_type{});
+        else column_body(std::false_type{});
+        W2_STAMP(3);   // flush
+    }
+#ifdef BOWGPU_STAMPS
+    if (lane == 0) {
+        for (int i = 0; i < 5; i++) atomicAdd(reinterpret_cast<unsigned long long *>(p.status + 32) + i, st_acc[i]);
+        atomicAdd(reinterpret_cast<unsigned long long *>(p.status + 32) + 7, 1ull);
+    }
+#endif
+}
+
+// the bits the trips of interp_wave3_kernel left for the words they share with the trip before them (one entry per trip and column:
+// word index | bits << 32; 0: nothing).  Two entries never name the same word: a trip in the middle of the frame holds 512 rows.
+__global__ __launch_bounds__(256) void interp_edge_fix_kernel(const InterpParams p, const int64_t ntrips) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ntrips * p.ncols) return;
+    const uint64_t e = p.edge_words[i];
+    const uint32_t bits = (uint32_t)(e >> 32);
+    if (bits) p.cols[i / ntrips].out_valid_words[(uint32_t)e] |= bits;
+}
+
 // The two corner cases of the reference's window walk that are not statements about single rows:
 //   status[1] = 1 when window kq (the one that starts at -1, if any) has no row of its own;
 //   status[2..3] = number of leading rows below s0 when window 0 has no row of its own: Go's truncating division can put
@@ -1095,15 +1541,25 @@ void interp_magic32(int64_t interval, uint32_t *m, uint32_t *sh1, uint32_t *sh2)
 int launch_interp_tiles(Ctx *c, const InterpParams &p) {
     const int64_t ntiles = (p.n + kITile - 1) / kITile;
     if (ntiles <= 0) return 0;
-    // the usual shape takes the barrier-free wave kernel (BOWGPU_ROUTE_INTERP_TILE: test switch that keeps it on the tile kernel)
-    const bool force_tile = (route_mask() & BOWGPU_ROUTE_INTERP_TILE) != 0;
+    // the usual shape takes the barrier-free wave kernels (BOWGPU_ROUTE_INTERP_TILE: test switch that keeps it on the tile kernel)
+    const uint32_t route = route_mask();
+    const bool force_tile = (route & BOWGPU_ROUTE_INTERP_TILE) != 0;
     static_assert(kITile == 512, "interp_wave_kernel's trips are the count kernel's tiles");
-    // BOWGPU_ROUTE_INTERP_WAVE1: the first wave kernel (also what a call is redone with when a trip overflows the second one's run list)
-    const bool wave1 = (route_mask() & BOWGPU_ROUTE_INTERP_WAVE1) != 0;
+    static_assert(kT3Rows == 512, "interp_wave3_kernel's trips are the count kernel's tiles");
+    // BOWGPU_ROUTE_INTERP_WAVE1 / _WAVE2: the round-1 / round-2 wave kernels (wave1 is also what a call is redone with when a trip
+    // overflows the run list of the others)
+    const bool wave1 = (route & BOWGPU_ROUTE_INTERP_WAVE1) != 0, wave2 = (route & BOWGPU_ROUTE_INTERP_WAVE2) != 0;
     if (p.fast32 && p.drop == 0 && p.kq < 0 && (p.inclusive || !force_tile)) {
-        // (trips of 256 rows - twice the wavefronts, 8 KB of LDS each, 16 resident per CU instead of 10 - were measured: 1.72 ms against
-        // 1.43 ms; a wavefront's life is ~40 k cycles either way, three quarters of it waiting on its own dependent LDS round trips)
-        if (p.inclusive) hipLaunchKernelGGL((interp_wave2_kernel<true, 4>), dim3((unsigned)ntiles), dim3(64), 0, c->stream, p);   // (the only kernel that takes inclusive windows)
+        const bool lean = p.allow_wave2 && !wave1 && !wave2;
+        if (lean || (p.inclusive && !wave2)) {
+            const int64_t ntrips = (p.n + kT3Rows - 1) / kT3Rows, per_xcd = (ntrips + 7) / 8;
+            if (per_xcd * 8 > 0x7FFFFFFFll) return fail(BOWGPU_ERR_UNSUPPORTED, "too many rows for one launch: %lld", (long long)p.n);
+            if (!p.edge_words) return fail(BOWGPU_ERR_ARG, "internal: interp_wave3_kernel needs its edge list");
+            if (p.inclusive) hipLaunchKernelGGL((interp_wave3_kernel<true>), dim3((unsigned)(per_xcd * 8)), dim3(64), 0, c->stream, p, ntrips, per_xcd);
+            else hipLaunchKernelGGL((interp_wave3_kernel<false>), dim3((unsigned)(per_xcd * 8)), dim3(64), 0, c->stream, p, ntrips, per_xcd);
+            hipLaunchKernelGGL(interp_edge_fix_kernel, dim3((unsigned)((ntrips * p.ncols + 255) / 256)), dim3(256), 0, c->stream, p, ntrips);
+        }
+        else if (p.inclusive) hipLaunchKernelGGL((interp_wave2_kernel<true, 4>), dim3((unsigned)ntiles), dim3(64), 0, c->stream, p);   // (wave2 and wave3 take inclusive windows)
         else if (p.allow_wave2 && !wave1) hipLaunchKernelGGL((interp_wave2_kernel<false, 4>), dim3((unsigned)ntiles), dim3(64), 0, c->stream, p);
         else hipLaunchKernelGGL(interp_wave_kernel, dim3((unsigned)ntiles), dim3(64), 0, c->stream, p);
     }

@@ -537,11 +537,12 @@ enum {
     BOWGPU_ROUTE_SIMPLE_SMALL_LIST = 32, /* rolling_simple_kernel: the 254-head list whatever the plan says */
     BOWGPU_ROUTE_SIMPLE_LARGE_LIST = 64, /* ... the 400-head list */
     BOWGPU_ROUTE_TW_F64 = 128,           /* rolling_tw_kernel: float64 timestamps in LDS even where 32-bit offsets are exact */
-    BOWGPU_ROUTE_INTERP_WAVE1 = 256,     /* Interpolate: interp_wave_kernel */
+    BOWGPU_ROUTE_INTERP_WAVE1 = 256,     /* Interpolate: interp_wave_kernel (default: interp_wave3_kernel) */
     BOWGPU_ROUTE_INTERP_TILE = 512,      /* Interpolate: interp_tile_kernel */
     BOWGPU_ROUTE_PINNED_STAGE = 1024,    /* BOWGPU_HOST_PINNED inputs staged through HBM instead of read in place */
     BOWGPU_ROUTE_STRICT_ORDER = 2048,    /* same as bowgpu_options.strict_order for every call of the thread */
-    BOWGPU_ROUTE__ALL = 4095
+    BOWGPU_ROUTE_INTERP_WAVE2 = 4096,    /* Interpolate: interp_wave2_kernel (the round-2 default) */
+    BOWGPU_ROUTE__ALL = 8191
 };
 int bowgpu_debug_set_route(uint32_t mask);
 int bowgpu_debug_get_route(uint32_t *mask);

@@ -30,7 +30,7 @@ def timeit(fn, reps=10):
         t0 = time.perf_counter(); fn(); capi.synchronize(); t.append((time.perf_counter() - t0) * 1e3)
     t.sort()
     return t[len(t) // 2]
-for label, mask in (("wave2 (default)", 0), ("wave1", capi.ROUTE_INTERP_WAVE1), ("tile", capi.ROUTE_INTERP_TILE)):
+for label, mask in (("wave3 (default)", 0), ("wave2", capi.ROUTE_INTERP_WAVE2), ("wave1", capi.ROUTE_INTERP_WAVE1), ("tile", capi.ROUTE_INTERP_TILE)):
     capi.set_route(mask)
     both = timeit(lambda: (count(), fill()))
     c_ms = timeit(count)
