@@ -10,6 +10,8 @@
 // What this kernel does not take goes to rolling_agg.hip (rows below s0, mixed column types, 64-bit window ids).
 #include <type_traits>
 
+#include <stddef.h>
+
 #include "agg_device.h"
 
 namespace bowgpu {
@@ -106,12 +108,26 @@ __global__ __launch_bounds__(kWave, 3) void rolling_tw_kernel(const SimpleParams
             for (int j = 0; j < kChunksT; j++) load_pair(src, base + j * 128 + 2 * lane, n, aligned, a[j], bb[j]);
         }
     };
-    // some tile has already found that the call needs the other kernel (head list overflow): the host will redo it, stop early
-    // (the flag's load goes out in front of the columns' and is looked at when they are)
-    const uint32_t redo_seen = __hip_atomic_load(&p.status[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (device scope: another XCD's L2 may hold the stale 0)
-    load_col(ts, ta, tb, !(p.unaligned_mask >> 31));
-    load_col(reinterpret_cast<const uint64_t *>(p.values[0]), va, vb, !(p.unaligned_mask & 1u));
-    if (redo_seen) return;
+    // The usual tile - interior, both columns 16-byte aligned - issues its ten loads back to back in ONE block, and nothing in
+    // front of them (rolling_simple.hip: two load_col() calls put a wait for all outstanding loads between the columns, and the
+    // status word that used to be looked at here cost every tile a memory round trip before its real loads)
+    if (interior && !(p.unaligned_mask & 0x80000001u)) {
+        const ulonglong2 *qt = reinterpret_cast<const ulonglong2 *>(ts + base) + lane;
+        const ulonglong2 *qv = reinterpret_cast<const ulonglong2 *>(reinterpret_cast<const uint64_t *>(p.values[0]) + base) + lane;
+#pragma unroll
+        for (int j = 0; j < kChunksT; j++) {
+            const ulonglong2 x = (j > 0 && j < kChunksT - 1) ? load16_nt(qt + j * 64) : qt[j * 64];
+            ta[j] = x.x; tb[j] = x.y;
+        }
+#pragma unroll
+        for (int j = 0; j < kChunksT; j++) {
+            const ulonglong2 x = (j > 0 && j < kChunksT - 1) ? load16_nt(qv + j * 64) : qv[j * 64];
+            va[j] = x.x; vb[j] = x.y;
+        }
+    } else {
+        load_col(ts, ta, tb, !(p.unaligned_mask >> 31));
+        load_col(reinterpret_cast<const uint64_t *>(p.values[0]), va, vb, !(p.unaligned_mask & 1u));
+    }
     // the row left of the tile (scalar load): first head flag + order check
     const int64_t left0 = base > 0 ? p.ts[base - 1] : INT64_MIN;
     // ids are 32-bit and relative to window w0, which starts at ws0: slot 0 of the call, or (kWide) the tile's first window
@@ -313,10 +329,15 @@ __global__ __launch_bounds__(kWave, 3) void rolling_tw_kernel(const SimpleParams
         if (wid >= W32) continue;  // (only on corrupt input)
         const uint32_t gap = next_wid - wid - 1;
         // ---- outputs of this column: lane q -> slot wid
-#pragma unroll
-        for (int a = 0; a < kSimpleMaxAggs; a++) {
-            if (a >= p.naggs) break;
+        // (the output's pointer through a SCALAR load from the kernel-argument segment, the index made wave-uniform explicitly:
+        // rolling_simple.hip - a vector load of it made every output wait for the previous output's store)
+#pragma unroll 1
+        for (int a_ = 0; a_ < p.naggs; a_++) {
+            const int a = __builtin_amdgcn_readfirstlane(a_);
             if (kMulti && p.col[a] != c) continue;
+            typedef const uint64_t __attribute__((address_space(4))) *karg_u64;
+            typedef uint64_t __attribute__((address_space(1))) *global_u64;
+            const global_u64 out_a = (global_u64)((karg_u64)__builtin_amdgcn_kernarg_segment_ptr())[offsetof(SimpleParams, out_values) / 8 + a];
             uint64_t bits;
             bool nil = false;
             const int k = p.kind[a];
@@ -355,7 +376,7 @@ __global__ __launch_bounds__(kWave, 3) void rolling_tw_kernel(const SimpleParams
                 bits = 0;
                 atomicAnd(&p.out_valid[a][slot >> 5], ~(1u << (slot & 31)));
             }
-            store8_nt(&p.out_values[a][slot], bits);
+            __builtin_nontemporal_store(bits, &out_a[slot]);
             // the empty windows right after this one (rare): values of an empty slice + cleared validity bits
             // (A.9 "Empty slice": WindowStart s_k ; Sum 0.0 ; Count 0 ; NumRows 0.0 ; the rest nil)
             for (uint32_t g = 1; g <= gap; g++) {
@@ -366,7 +387,7 @@ __global__ __launch_bounds__(kWave, 3) void rolling_tw_kernel(const SimpleParams
                 // (Sum / NumRows of an empty slice are +0.0 and Count is 0: a negative factor still turns the floats into -0.0)
                 if (nf && (k == BOWGPU_AGG_WINDOW_START || k == BOWGPU_AGG_SUM || k == BOWGPU_AGG_NUM_ROWS || k == BOWGPU_AGG_COUNT))
                     gbits = apply_factors(gbits, int_result, nf, p.fac[a]);
-                p.out_values[a][gw] = gbits;
+                out_a[gw] = gbits;
                 if (p.out_valid[a]) atomicAnd(&p.out_valid[a][gw >> 5], ~(1u << (gw & 31)));
             }
         }
