@@ -60,6 +60,10 @@ static uint32_t route_env_default() {
 static thread_local uint32_t g_route = route_env_default();
 uint32_t route_mask() { return g_route; }
 
+static std::atomic<uint64_t> g_write_epoch{1};
+uint64_t device_write_epoch() { return g_write_epoch.load(std::memory_order_relaxed); }
+void device_write_epoch_bump() { g_write_epoch.fetch_add(1, std::memory_order_relaxed); }
+
 // ---------------------------------------------------------------- context
 // All device state is per calling thread (cgo calls arrive on arbitrary OS threads).  A thread that exits gives its state
 // back: stream, events, pools, pinned block and its cache of scratch blocks - unless the process itself is exiting (the HIP
@@ -713,7 +717,9 @@ struct AggJob {
     size_t scratch_bytes = 0;
     int inclusive = 0;
     bool counts_used = false;   // the valid counters hold a previous count (they accumulate): zero them before counting again
+    bool check_plan = false;    // the plan came from the caller (bowgpu_rolling_aggregate_planned): the pass checks it against the column
 };
+static thread_local bool g_plan_from_caller = false;   // set around run_aggregate by the planned entry point
 
 static void pending_drop(Ctx *c);   // a pass put in flight by bowgpu_shard_pass_begin and not collected: settled before the scratch is reused
 
@@ -740,6 +746,7 @@ static int job_build(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t ts_c
     job->douts.resize(naggs);
     job->W = W;
     job->inclusive = inclusive;
+    job->check_plan = g_plan_from_caller;
     std::vector<DevCol> &dcols = job->dcols;
     std::vector<int> slot_of(ncols, -1);
     AggParams &P = job->P;
@@ -966,6 +973,7 @@ static int job_launch_tiles(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t
         job_bitmaps(job, aggs, naggs, simple, &b);
         BG_TRY(launch_preset_bitmaps(c, b));   // + status words and counters to zero
         job->counts_used = false;
+        if (job->check_plan && plan) BG_TRY(launch_plan_check(c, P.ts, P.n, plan->first_ts, plan->last_ts, P.status));
     }
     // kernel_ms brackets the dominant kernel only, on the stream it runs on
     BG_HIP(hipEventRecord(c->ev0, c->stream));
@@ -1120,6 +1128,7 @@ static int job_run(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, i
             BitmapBatch b;
             job_bitmaps(job, aggs, naggs, false, &b);
             BG_TRY(launch_preset_bitmaps(c, b));
+            if (job->check_plan) BG_TRY(launch_plan_check(c, P.ts, P.n, plan->first_ts, plan->last_ts, P.status));
         }
         BG_HIP(hipEventRecord(c->ev0, c->stream));
         int64_t n_all = W;
@@ -1138,6 +1147,7 @@ static int job_run(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, i
         if (finish) BG_TRY(job_enqueue_tail(c, job, aggs, naggs));
         BG_TRY(job_readback(c, job, &hs, &hc));
         BG_HIP(hipStreamSynchronize(c->stream));
+        if (hs[6]) return fail(BOWGPU_ERR_ARG, "the plan was not made for this interval column (its first / last timestamp differ)");
         if (hs[0]) return fail(BOWGPU_ERR_TS_UNSORTED, "interval column is not ascending: outside the device path");
         if (finish)
             for (int i = 0; i < naggs; i++)
@@ -1175,6 +1185,7 @@ static int job_pass_complete(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_
     g_prof_sync_begin = now_us();
     BG_HIP(hipStreamSynchronize(c->stream));
     g_prof_sync_end = now_us();
+    if (hstat[6]) return fail(BOWGPU_ERR_ARG, "the plan was not made for this interval column (its first / last timestamp differ)");
     if (hstat[0]) return fail(BOWGPU_ERR_TS_UNSORTED, "interval column is not ascending: outside the device path");
     if (used_simple && hstat[4] && used_small_list) {
         // clumpy data: a high average of rows per window, but some tile holds more window heads than the small list takes - the
@@ -1528,6 +1539,7 @@ int bowgpu_malloc(void **ptr, int64_t bytes) {
 int bowgpu_free(void *ptr) {
     Ctx *c;
     BG_TRY(ctx_get(&c));
+    device_write_epoch_bump();   // (the address may come back from the allocator holding other data)
     if (ptr) BG_HIP(hipFree(ptr));
     return 0;
 }
@@ -1536,6 +1548,7 @@ int bowgpu_memcpy_h2d(void *dst, const void *src, int64_t bytes) {
     Ctx *c;
     BG_TRY(ctx_get(&c));
     if (bytes > 0) {
+        device_write_epoch_bump();
         BG_TRY(copy_h2d(c, dst, src, (size_t)bytes));
         BG_HIP(hipStreamSynchronize(c->stream));
     }
@@ -1555,7 +1568,7 @@ int bowgpu_memcpy_d2h(void *dst, const void *src, int64_t bytes) {
 int bowgpu_memset(void *dst, int value, int64_t bytes) {
     Ctx *c;
     BG_TRY(ctx_get(&c));
-    if (bytes > 0) BG_HIP(hipMemsetAsync(dst, value, (size_t)bytes, c->stream));
+    if (bytes > 0) { device_write_epoch_bump(); BG_HIP(hipMemsetAsync(dst, value, (size_t)bytes, c->stream)); }
     return 0;
 }
 
@@ -1681,11 +1694,23 @@ int bowgpu_rolling_aggregate_planned(const bowgpu_col *cols, int32_t ncols, int3
     if (pl->interval <= 0) return fail(BOWGPU_ERR_INTERVAL, "strictly positive interval required");
     if (pl->nrows != ts->length || pl->offset < 0 || pl->offset >= pl->interval || pl->num_windows < 0)
         return fail(BOWGPU_ERR_ARG, "the plan was not made for this interval column");
+    // the plan against itself (host arithmetic) ... and against the column: the pass compares the two timestamps it was made from with
+    // the column's first and last row (one tiny launch in front of the tile kernel, no round trip) - a plan made for another
+    // column of the same length, or for this buffer before it was refilled, is BOWGPU_ERR_ARG instead of silently wrong routes
+    if (ts->length > 0) {
+        const int64_t s0 = first_window_start(pl->first_ts, pl->interval, pl->offset);
+        const int64_t W = s0 > pl->last_ts ? 0 : (int64_t)(((uint64_t)pl->last_ts - (uint64_t)s0) / (uint64_t)pl->interval) + 1;
+        if (pl->last_ts < pl->first_ts || s0 != pl->s0 || W != pl->num_windows)
+            return fail(BOWGPU_ERR_ARG, "the plan is not consistent (s0 / num_windows do not follow from its first / last timestamp)");
+    }
     Plan plan;
     plan.interval = pl->interval; plan.offset = pl->offset; plan.s0 = pl->s0; plan.W = pl->num_windows;
     plan.first_ts = pl->first_ts; plan.last_ts = pl->last_ts;
     plan.magic = magic_make((uint64_t)pl->interval);
-    return aggregate_with_plan(cols, ncols, ts_col, plan, opts ? opts->inclusive : 0, aggs, naggs, outs, info);
+    g_plan_from_caller = ts->length > 0;
+    const int rc = aggregate_with_plan(cols, ncols, ts_col, plan, opts ? opts->inclusive : 0, aggs, naggs, outs, info);
+    g_plan_from_caller = false;
+    return rc;
 }
 
 // ---- entry points implemented in extras.cpp: window_bounds, aggregate_whole, interpolate,
@@ -2251,6 +2276,7 @@ int bowgpu_shard_finish(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, i
 int bowgpu_gen_dense(int64_t row0, int64_t n, uint64_t seed, int64_t *ts_dev, double *val_dev) {
     Ctx *c;
     BG_TRY(ctx_get(&c));
+    device_write_epoch_bump();
     return launch_gen_dense(c, row0, n, seed, ts_dev, val_dev);
 }
 
@@ -2258,6 +2284,7 @@ int bowgpu_gen_sparse(int64_t row0, int64_t n, uint64_t seed, int64_t *ts_dev, d
     Ctx *c;
     BG_TRY(ctx_get(&c));
     if (row0 & 7) return fail(BOWGPU_ERR_ARG, "row0 must be a multiple of 8");
+    device_write_epoch_bump();
     return launch_gen_sparse(c, row0, n, seed, ts_dev, val_dev, validity_dev);
 }
 

@@ -28,6 +28,11 @@ int hip_fail(hipError_t e, const char *what);
         if (_rc != 0) return _rc; \
     } while (0)
 
+// Counts the calls that write to or free device memory THROUGH THE LIBRARY, in any thread (bowgpu_free, bowgpu_memcpy_h2d, bowgpu_memset,
+// the generators): results cached from a caller's device buffer (the Interpolate count -> fill prefix) are dropped when it moves.
+uint64_t device_write_epoch();
+void device_write_epoch_bump();
+
 // test / A-B routing of the calling thread (BOWGPU_ROUTE_* bits; bowgpu_debug_set_route): never the environment
 uint32_t route_mask();
 
@@ -64,6 +69,7 @@ struct Ctx {
         int64_t global_s0 = 0, left_ts = 0;
         int has_left = 0;
         uint64_t gen = 0;                   // pool_gen of the prefix block when it was written
+        uint64_t epoch = 0;                 // device_write_epoch() when it was written: any write / free through the library since then drops it
         int64_t s0 = 0, W = 0, first_ts = 0, last_ts = 0, offset_norm = 0, kq = -1, drop = 0, M = 0, wbase = 0;
         int kq_empty = 0, inclusive = 0, e0 = 0;
     } interp_cache;
@@ -274,6 +280,7 @@ struct BitmapBatch {
 };
 int launch_preset_bitmaps(Ctx *c, const BitmapBatch &b);
 int launch_finish_bitmaps(Ctx *c, const BitmapBatch &b);
+int launch_plan_check(Ctx *c, const int64_t *ts, int64_t n, int64_t first_ts, int64_t last_ts, uint32_t *status);   // status[6] = 1: not this column's plan
 int launch_popcount(Ctx *c, const uint32_t *words, int64_t bit0, int64_t nbits, uint64_t *d_count);
 
 // mode.hip: one aggregation.Mode output over the windows whose first rows are first_idx[0 .. W]
@@ -347,6 +354,7 @@ struct InterpParams {
     int32_t allow_wave2;               // the whole-trip wave kernel may take the call (0: the call is being redone after its run list overflowed)
     int32_t kq_empty;                  // window kq has no row of its own (pass 1's finding)
     int32_t inclusive, e0;             // Options.Inclusive (interp_wave2 / wave3 kernels only); e0: row 0 sits exactly on the first window's start
+    int64_t n_out;                     // rows the call is to produce (n + what the count pass found): interp_wave3_kernel's last trip checks that it ends there
     uint64_t *edge_words;              // interp_wave3_kernel: [ncols][trips of 512 rows] - a trip's bits of the bitmap word it shares with the trip before it
     InterpCol cols[kMaxCols];
 };

@@ -158,6 +158,7 @@ static bool interp_cache_hit(Ctx *c, const bowgpu_col *ts, int64_t interval, int
     if (k.ts_values != ts->values || k.ts_offset != ts->offset || k.n != ts->length || k.interval != interval || k.raw_offset != raw_offset) return false;
     if (k.sharded != (global_s0 != nullptr) || k.inclusive != (inclusive ? 1 : 0)) return false;
     if (global_s0 && (k.global_s0 != *global_s0 || k.has_left != ((edge && edge->has_left) ? 1 : 0) || (k.has_left && k.left_ts != edge->left_last_ts))) return false;
+    if (k.epoch != device_write_epoch()) return false;   // something was written to / freed from device memory through the library since the count
     return k.gen == c->pool_gen[kPoolInterp + 1] && c->pool[kPoolInterp + 1] != nullptr;
 }
 
@@ -165,7 +166,9 @@ static int interp_prepare(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t
                           const bowgpu_options *o, InterpJob *job, const int64_t *global_s0 = nullptr, const bowgpu_interp_edge *edge = nullptr,
                           bool use_cache = false) {
     // The _fill call right after _count on the same device-resident, unchanged interval column (Bows are immutable in the
-    // reference; include/bowgpu.h states the contract): pass 1's prefix is still in the context pool
+    // reference; include/bowgpu.h, "Rolling.Interpolate", states the contract): pass 1's prefix is still in the context pool.  A
+    // write or free THROUGH the library in between drops it (device_write_epoch); the fill kernel checks the output count it
+    // arrives at against the cached one and the call fails with BOWGPU_ERR_ARG when they differ (status[6])
     if (use_cache && interp_cache_hit(c, &cols[ts_col], interval, o->offset, o->inclusive, global_s0, edge)) {
         const Ctx::InterpCache &k = c->interp_cache;
         for (int i = 0; i < ncols; i++)
@@ -252,6 +255,7 @@ static int interp_prepare(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t
         k.sharded = global_s0 != nullptr; k.global_s0 = global_s0 ? *global_s0 : 0;
         k.has_left = job->has_left; k.left_ts = job->left_ts;
         k.gen = c->pool_gen[kPoolInterp + 1];
+        k.epoch = device_write_epoch();
         k.s0 = pl.s0; k.W = pl.W; k.first_ts = pl.first_ts; k.last_ts = pl.last_ts; k.offset_norm = pl.offset;
         k.kq = job->kq; k.drop = job->drop; k.M = job->M; k.wbase = job->wbase; k.kq_empty = job->kq_empty;
         k.inclusive = o->inclusive ? 1 : 0; k.e0 = job->e0;
@@ -326,6 +330,7 @@ static int interp_fill_impl(const bowgpu_col *cols, int32_t ncols, int32_t ts_co
     P.fast32 = interp_fast32(job.plan, job.kq) ? 1 : 0;
     if (P.fast32) interp_magic32(job.plan.interval, &P.m32, &P.sh1_32, &P.sh2_32);
     P.ts_col = ts_col;
+    P.n_out = n_out;
     {   // one word per 512-row trip and column of a launch (at most kMaxCols columns per launch)
         void *ew;
         BG_TRY(ctx_pool(c, kPoolInterpEdge, (size_t)((n + 511) / 512) * kMaxCols * 8 + 64, &ew));
@@ -390,6 +395,8 @@ static int interp_fill_impl(const bowgpu_col *cols, int32_t ncols, int32_t ts_co
     if (hstat[5] && o.inclusive)
         return fail(BOWGPU_ERR_UNSUPPORTED, "Interpolate on inclusive windows: windows shorter than two rows on average are outside the device path");
     if (hstat[0]) return fail(BOWGPU_ERR_TS_UNSORTED, "interval column is not ascending: outside the device path");
+    if (hstat[6]) return fail(BOWGPU_ERR_ARG, "Interpolate: the rows produced do not add up to the count - the interval column changed between "
+                                              "bowgpu_rolling_interpolate_count and _fill (include/bowgpu.h: the contract between the two calls)");
     for (int i = 0; i < ninterps; i++) BG_TRY(devout_finish(c, &douts[i], n_out, cols[i].type, n_out - (int64_t)hcnt[i], false));
     BG_HIP(hipStreamSynchronize(c->stream));
     return 0;

@@ -516,6 +516,15 @@ int launch_preset_bitmaps(Ctx *c, const BitmapBatch &b) {
     BG_HIP(hipGetLastError());
     return 0;
 }
+// a caller-supplied plan (bowgpu_rolling_aggregate_planned) against the column it is used on: the two scalars it was made from
+__global__ void plan_check_kernel(const int64_t *ts, int64_t n, int64_t first_ts, int64_t last_ts, uint32_t *status) {
+    if (threadIdx.x == 0 && blockIdx.x == 0 && n > 0 && (ts[0] != first_ts || ts[n - 1] != last_ts)) status[6] = 1u;
+}
+int launch_plan_check(Ctx *c, const int64_t *ts, int64_t n, int64_t first_ts, int64_t last_ts, uint32_t *status) {
+    hipLaunchKernelGGL(plan_check_kernel, dim3(1), dim3(64), 0, c->stream, ts, n, first_ts, last_ts, status);
+    BG_HIP(hipGetLastError());
+    return 0;
+}
 int launch_finish_bitmaps(Ctx *c, const BitmapBatch &b) {
     if (b.n <= 0 || b.nbits <= 0) return 0;
     hipLaunchKernelGGL(finish_bitmaps_kernel, dim3(bitmap_grid(b.nbits), b.n), dim3(256), 0, c->stream, b);

@@ -266,7 +266,14 @@ typedef struct bowgpu_interp {
 
 /* Rolling.Interpolate — reference rolling/interpolation.go:30-161.  Two calls: _count gives
  * the number of output rows (N + windows missing their start), _fill writes them.
- * interps must list the Bow's columns in order (bowappend.go:11-13 needs equal schemas). */
+ * interps must list the Bow's columns in order (bowappend.go:11-13 needs equal schemas).
+ * CONTRACT between the two calls: a _fill that directly follows the _count of the same DEVICE-resident interval column (same
+ * pointer, offset, length, interval, options, calling thread) reuses what the count pass learnt about it and does not scan it
+ * again - the column must not be modified or freed in between (Bows are immutable in the reference; a cgo shim makes the two
+ * calls back to back inside Rolling.Interpolate).  Writes and frees made THROUGH this library (bowgpu_free, bowgpu_memcpy_h2d,
+ * bowgpu_memset, the generators) drop the reuse by themselves; a buffer rewritten by the caller's own kernels is the caller's to
+ * keep unchanged.  As a last line the fill compares the number of rows it produces with the count: a mismatch is
+ * BOWGPU_ERR_ARG and the outputs are to be discarded. */
 int bowgpu_rolling_interpolate_count(const bowgpu_col *cols, int32_t ncols, int32_t ts_col,
                                      int64_t interval, const bowgpu_options *opts,
                                      const bowgpu_interp *interps, int32_t ninterps,

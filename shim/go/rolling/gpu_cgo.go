@@ -1,0 +1,261 @@
+//go:build bowgpu
+
+package rolling
+
+/*
+#cgo CFLAGS: -I${SRCDIR}/../third_party/bowgpu/include
+#cgo LDFLAGS: -L${SRCDIR}/../third_party/bowgpu/lib -lbowgpu -Wl,-rpath,${SRCDIR}/../third_party/bowgpu/lib
+#include <stdlib.h>
+#include "bowgpu.h"
+*/
+import "C"
+
+import (
+	"errors"
+	"fmt"
+	"runtime"
+	"unsafe"
+
+	"github.com/apache/arrow/go/v8/arrow/bitutil"
+	"github.com/metronlab/bow"
+)
+
+var errDeclined = errors.New("bowgpu: input outside the device path") // the caller continues on the reference's own Go path
+
+// colDesc exposes one Arrow array exactly as bow holds it (bowseries.go:59-83, bow.go:183-186).
+func colDesc(b bow.Bow, i int, pin *runtime.Pinner) C.bowgpu_col {
+	d := (*b.ArrowRecord()).Column(i).Data()
+	var c C.bowgpu_col
+	if vals := d.Buffers()[1].Bytes(); len(vals) > 0 {
+		pin.Pin(&vals[0])
+		c.values = unsafe.Pointer(&vals[0])
+	}
+	if vb := d.Buffers()[0]; vb != nil && vb.Len() > 0 {
+		v := vb.Bytes()
+		pin.Pin(&v[0])
+		c.validity = (*C.uint8_t)(unsafe.Pointer(&v[0]))
+	}
+	c.offset, c.length, c.null_count = C.int64_t(d.Offset()), C.int64_t(d.Len()), C.int64_t(d.NullN())
+	c._type = C.int32_t(b.ColumnType(i)) // bow.Float64 = 1, bow.Int64 = 2 (bowtypes.go:21-23)
+	c.residency = C.BOWGPU_HOST          // C.BOWGPU_HOST_PINNED for a Bow registered with RegisterForGPU
+	return c
+}
+
+func gpuErr(rc C.int, intervalCol string) error {
+	switch rc {
+	case C.BOWGPU_ERR_KEEP_INTERVAL: // aggregation.go:163-166
+		return fmt.Errorf("must keep interval column '%s'", intervalCol)
+	case C.BOWGPU_ERR_TS_NULLS, C.BOWGPU_ERR_TS_UNSORTED, C.BOWGPU_ERR_UNSUPPORTED, C.BOWGPU_ERR_NO_DEVICE:
+		return errDeclined
+	default:
+		return errors.New(C.GoString(C.bowgpu_last_error())) // the reference's own text (rolling.go:71,92,116)
+	}
+}
+
+func b2i(b bool) C.int32_t {
+	if b {
+		return 1
+	}
+	return 0
+}
+
+// newOuts allocates what bow.NewBuffer(n, typ) would (bowbuffer.go:22-40): n 8-byte slots + ceil(n/8) validity bytes per output.
+func newOuts(k, n int, pin *runtime.Pinner) ([]C.bowgpu_out, [][]int64, [][]byte) {
+	outs, data, valid := make([]C.bowgpu_out, k), make([][]int64, k), make([][]byte, k)
+	for i := range outs {
+		data[i], valid[i] = make([]int64, n+1), make([]byte, bitutil.CeilByte(n)/8+1)
+		pin.Pin(&data[i][0])
+		pin.Pin(&valid[i][0])
+		outs[i].values, outs[i].validity = unsafe.Pointer(&data[i][0]), (*C.uint8_t)(unsafe.Pointer(&valid[i][0]))
+		outs[i].length, outs[i].residency = C.int64_t(n), C.BOWGPU_HOST
+	}
+	return outs, data, valid
+}
+
+func seriesOf(name string, out C.bowgpu_out, data []int64, valid []byte, n int) bow.Series {
+	vb := valid[:bitutil.CeilByte(n)/8] // a []byte validity is taken as is (bowseries.go:211-215)
+	if bow.Type(out._type) == bow.Int64 {
+		return bow.NewSeries(name, bow.Int64, data[:n], vb)
+	}
+	return bow.NewSeries(name, bow.Float64, unsafe.Slice((*float64)(unsafe.Pointer(&data[0])), n), vb)
+}
+
+type gpuFactor interface{ GPUFactor() (float64, bool) } // transformation.Factor (rolling/transformation/gpu_factor.go)
+
+// exportFactors: aggregation.go:216-221 applies a.Transformations() to every window's result; Factor chains are passed on instead.
+func exportFactors(a ColAggregation, dst *C.bowgpu_agg) bool {
+	ts := a.Transformations()
+	if len(ts) > C.BOWGPU_MAX_FACTORS {
+		return false
+	}
+	for i, t := range ts {
+		f, ok := interface{}(t).(gpuFactor)
+		if !ok {
+			return false // a user closure
+		}
+		n, _ := f.GPUFactor()
+		dst.factors[i] = C.double(n)
+	}
+	dst.n_factors = C.int32_t(len(ts))
+	return true
+}
+
+func (r *intervalRolling) describe(aggrs []ColAggregation, pin *runtime.Pinner) ([]C.bowgpu_col, []C.bowgpu_agg, C.bowgpu_options, error) {
+	cols := make([]C.bowgpu_col, r.bow.NumCols())
+	for i := range cols {
+		cols[i] = colDesc(r.bow, i, pin)
+	}
+	cAggs := make([]C.bowgpu_agg, len(aggrs))
+	for i, a := range aggrs {
+		k, ok := a.(gpuKinded)
+		if !ok || k.GPUKind() < 0 || !exportFactors(a, &cAggs[i]) {
+			return nil, nil, C.bowgpu_options{}, errDeclined
+		}
+		cAggs[i].kind, cAggs[i].col = C.int32_t(k.GPUKind()), C.int32_t(a.InputIndex())
+	}
+	opts := C.bowgpu_options{offset: C.int64_t(r.options.Offset), inclusive: b2i(r.options.Inclusive)}
+	return cols, cAggs, opts, nil
+}
+
+// aggregateWindowsGPU is called first thing in (*intervalRolling).aggregateWindows (aggregation.go:190); errDeclined falls through
+// to the Go loop.  r.gpuPlan is the C.bowgpu_plan newIntervalRolling keeps (bowgpu_plan_windows_ex, once per Rolling).
+func (r *intervalRolling) aggregateWindowsGPU(aggrs []ColAggregation) (bow.Bow, error) {
+	var pin runtime.Pinner // Go >= 1.21; with go1.18 copy the slices into C.malloc'd memory instead
+	defer pin.Unpin()
+	cols, cAggs, opts, err := r.describe(aggrs, &pin)
+	if err != nil {
+		return nil, err
+	}
+	W := r.numWindows // rolling.go:102
+	outs, data, valid := newOuts(len(aggrs), W, &pin)
+	var info C.bowgpu_agg_info
+	rc := C.bowgpu_rolling_aggregate_planned(&cols[0], C.int32_t(len(cols)), C.int32_t(r.intervalColIndex), &r.gpuPlan, &opts,
+		&cAggs[0], C.int32_t(len(cAggs)), &outs[0], &info)
+	if rc != 0 {
+		return nil, gpuErr(rc, r.bow.ColumnName(r.intervalColIndex))
+	}
+	series := make([]bow.Series, len(aggrs))
+	for i, a := range aggrs {
+		name := a.OutputName() // aggregation.go:230-234
+		if name == "" {
+			name = r.bow.ColumnName(a.InputIndex())
+		}
+		series[i] = seriesOf(name, outs[i], data[i], valid[i], W)
+	}
+	r.options.Inclusive = info.inclusive != 0 // aggregation.go:139: the flag persists into the returned Rolling
+	return bow.NewBow(series...)              // aggregation.go:237
+}
+
+// keepPlan: the tail of newIntervalRolling (rolling.go:102-111).
+func (r *intervalRolling) keepPlan(pin *runtime.Pinner) error {
+	ts := colDesc(r.bow, r.intervalColIndex, pin)
+	if rc := C.bowgpu_plan_windows_ex(&ts, C.int64_t(r.interval), C.int64_t(r.options.Offset), &r.gpuPlan); rc != 0 {
+		return gpuErr(rc, r.bow.ColumnName(r.intervalColIndex))
+	}
+	r.numWindows = int(r.gpuPlan.num_windows)
+	return nil
+}
+
+// interpolateWindowsGPU is called from (*intervalRolling).Interpolate after validateInterpolation (interpolation.go:40-55).
+func (r *intervalRolling) interpolateWindowsGPU(interps []ColInterpolation) (bow.Bow, error) {
+	var pin runtime.Pinner
+	defer pin.Unpin()
+	cols := make([]C.bowgpu_col, r.bow.NumCols())
+	for i := range cols {
+		cols[i] = colDesc(r.bow, i, &pin)
+	}
+	cI := make([]C.bowgpu_interp, len(interps))
+	for i, ip := range interps {
+		k, ok := ip.(gpuKinded)
+		if !ok || k.GPUKind() < 0 {
+			return nil, errDeclined
+		}
+		cI[i].kind, cI[i].col = C.int32_t(k.GPUKind()), C.int32_t(ip.colIndex)
+		if pr := r.options.PrevRow; pr != nil { // linear.go:14-18, stepprevious.go:13-15 read the LAST row of PrevRow
+			last := pr.NumRows() - 1
+			t, tok := pr.GetFloat64(r.intervalColIndex, last)
+			v, vok := pr.GetFloat64(ip.colIndex, last)
+			cI[i].has_prev_row, cI[i].prev_t, cI[i].prev_v = 1, C.double(t), C.double(v)
+			cI[i].prev_t_valid, cI[i].prev_v_valid = b2i(tok), b2i(vok)
+			if iv, ok := pr.GetValue(ip.colIndex, last).(int64); ok {
+				cI[i].prev_v_i64 = C.int64_t(iv)
+			}
+		}
+	}
+	opts := C.bowgpu_options{offset: C.int64_t(r.options.Offset), inclusive: b2i(r.options.Inclusive)}
+	var nOut C.int64_t
+	if rc := C.bowgpu_rolling_interpolate_count(&cols[0], C.int32_t(len(cols)), C.int32_t(r.intervalColIndex), C.int64_t(r.interval),
+		&opts, &cI[0], C.int32_t(len(cI)), &nOut); rc != 0 {
+		return nil, gpuErr(rc, r.bow.ColumnName(r.intervalColIndex))
+	}
+	n := int(nOut)
+	outs, data, valid := newOuts(len(interps), n, &pin)
+	// (back to back with the count on the same columns: include/bowgpu.h, the contract between the two calls)
+	if rc := C.bowgpu_rolling_interpolate_fill(&cols[0], C.int32_t(len(cols)), C.int32_t(r.intervalColIndex), C.int64_t(r.interval),
+		&opts, &cI[0], C.int32_t(len(cI)), &outs[0]); rc != 0 {
+		return nil, gpuErr(rc, r.bow.ColumnName(r.intervalColIndex))
+	}
+	series := make([]bow.Series, len(interps))
+	for i := range interps { // names / types of the input columns (interpolation.go:149-155)
+		series[i] = seriesOf(r.bow.ColumnName(i), outs[i], data[i], valid[i], n)
+	}
+	return bow.NewBow(series...)
+}
+
+// RegisterForGPU: a Bow the application keeps using (Bows are immutable) registers its Arrow buffers once; the kernels then read
+// them where they lie (zero-copy over PCIe) and colDesc passes C.BOWGPU_HOST_PINNED.
+func RegisterForGPU(b bow.Bow) (release func()) {
+	rec := *b.ArrowRecord()
+	var ptrs []unsafe.Pointer
+	for i := 0; i < int(rec.NumCols()); i++ {
+		for _, buf := range rec.Column(i).Data().Buffers() {
+			if buf != nil && buf.Len() > 0 {
+				p := unsafe.Pointer(&buf.Bytes()[0])
+				if C.bowgpu_host_register(p, C.int64_t(buf.Len())) == 0 {
+					ptrs = append(ptrs, p)
+				}
+			}
+		}
+	}
+	return func() {
+		for _, p := range ptrs {
+			C.bowgpu_host_unregister(p)
+		}
+	}
+}
+
+// aggregateShardGPU: one rank of a row-range sharded Aggregate (one goroutine / process per GPU; columns and outputs device
+// resident).  start / wait are the host's transport: an RCCL / MPI all_gather of one record per rank, begun before the rank's pass
+// is enqueued and collected after it - the exchange is off the critical path (include/bowgpu.h, bowgpu_shard_pass_begin).
+func (r *intervalRolling) aggregateShardGPU(rank, world int, start func([]byte), wait func() [][]byte, cols []C.bowgpu_col,
+	cAggs []C.bowgpu_agg, outs []C.bowgpu_out, opts C.bowgpu_options) (C.bowgpu_shard_decision, error) {
+	nc, na, ts, iv := C.int32_t(len(cols)), C.int32_t(len(cAggs)), C.int32_t(r.intervalColIndex), C.int64_t(r.interval)
+	var rec C.bowgpu_shard_record
+	var d C.bowgpu_shard_decision
+	var s0 *C.int64_t // nil on the first attempt
+	for attempt := 0; attempt < 2; attempt++ {
+		if rc := C.bowgpu_shard_begin(&cols[0], nc, ts, iv, &opts, &cAggs[0], na, s0, &rec); rc != 0 {
+			return d, gpuErr(rc, r.bow.ColumnName(r.intervalColIndex))
+		}
+		start(C.GoBytes(unsafe.Pointer(&rec), C.sizeof_bowgpu_shard_record)) // THE exchange of the call, in flight ...
+		if rc := C.bowgpu_shard_pass_begin(&cols[0], nc, ts, iv, &opts, &cAggs[0], na, &outs[0], &rec); rc < 0 {
+			return d, gpuErr(rc, r.bow.ColumnName(r.intervalColIndex)) // (BOWGPU_SHARD_PASS_DECLINED = 1 is not an error)
+		}
+		all := wait() // ... while the pass runs
+		recs := make([]C.bowgpu_shard_record, world)
+		for q := range recs {
+			copy(unsafe.Slice((*byte)(unsafe.Pointer(&recs[q])), C.sizeof_bowgpu_shard_record), all[q])
+		}
+		rc := C.bowgpu_shard_finish(&cols[0], nc, ts, iv, &opts, &cAggs[0], na, &outs[0], &recs[0], C.int32_t(world), C.int32_t(rank), &d, nil)
+		if rc == C.BOWGPU_SHARD_RETRY { // rows below the first window start split across ranks (negative timestamps): once more, s0 known
+			s0 = &d.s0
+			continue
+		}
+		if rc != 0 {
+			return d, gpuErr(rc, r.bow.ColumnName(r.intervalColIndex))
+		}
+		// output slots [0, d.windows_owned) are global windows d.first_slot_window_id ...: concatenated in rank order = the unsharded result
+		return d, nil
+	}
+	return d, errors.New("bowgpu: the shard protocol did not settle after the second exchange")
+}

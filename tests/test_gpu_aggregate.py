@@ -783,6 +783,23 @@ def test_planned_call_equals_the_plain_call():
     with pytest.raises(capi.BowGpuError) as e:
         capi.rolling_aggregate(short, 0, 7, aggs, plan=plan, outs=[capi.OutColumn(plan.num_windows, capi.DEVICE) for _ in aggs])
     assert e.value.code == -10
+    # a plan made for ANOTHER column of the same length (other first / last timestamp): caught by the pass itself, for every kernel
+    # a planned call can take (tile kernels, long-only forms) - BOWGPU_ERR_ARG instead of wrong routes and silently dropped windows
+    other = [capi.Column(ts + 1000, None, capi.INT64).to_device(), cols[1]]
+    for interval in (7, 1000, 50_000):
+        plan = capi.plan_windows_ex(cols[0], interval, 0)
+        for label in capi.agg_routes():
+            with pytest.raises(capi.BowGpuError) as e:
+                capi.rolling_aggregate(other, 0, interval, aggs[:4], plan=plan, outs=[capi.OutColumn(plan.num_windows + 8, capi.DEVICE) for _ in aggs[:4]])
+            assert e.value.code == -10 and "plan" in e.value.message, (interval, label)
+            good, _ = capi.rolling_aggregate(cols, 0, interval, aggs[:4], plan=plan, out_residency=capi.DEVICE)   # (and the thread goes on working)
+            assert good[0].length == plan.num_windows
+    # ... and a plan that contradicts itself, on the host
+    bad = capi.plan_windows_ex(cols[0], 7, 0)
+    bad.num_windows += 1
+    with pytest.raises(capi.BowGpuError) as e:
+        capi.rolling_aggregate(cols, 0, 7, aggs, plan=bad, outs=[capi.OutColumn(bad.num_windows, capi.DEVICE) for _ in aggs])
+    assert e.value.code == -10 and "consistent" in e.value.message
 
 
 def test_device_output_bitmaps_of_any_alignment_and_length():

@@ -482,3 +482,67 @@ def test_interpolate_on_inclusive_windows(vtype):
             cmp_out("inclusive val %s n=%d I=%d" % (kind, n, interval), got[1], want[1])
             plain = orc.interpolate([orc.Column(ts, None, orc.INT64), orc.Column(vals, bm, typ)], 0, interval, ip, offset=offset)
             assert want[0].length >= plain[0].length
+
+
+def test_interpolate_count_to_fill_reuse_is_dropped_when_the_column_changes():
+    """include/bowgpu.h, "CONTRACT between the two calls": a _fill that follows the _count of the same device-resident interval
+    column reuses the count pass.  Writes and frees made through the library in between drop the reuse (the fill then scans the new
+    data); a buffer rewritten behind the library's back is caught by the fill's own row count where the counts differ."""
+    import ctypes as C
+    rng = np.random.default_rng(12)
+    n = 40_000
+    ip = [{"kind": "WindowStart", "col": 0}, {"kind": "Linear", "col": 1}]
+    L = capi.lib()
+
+    def frame(seed, step):
+        r = np.random.default_rng(seed)
+        ts = np.cumsum(r.integers(1, step, n)).astype(np.int64)
+        v = np.round(r.standard_normal(n), 3)
+        m = r.random(n) > 0.3
+        return ts, v, np.packbits(m, bitorder="little")
+
+    ts_a, v_a, bm_a = frame(1, 9)
+    ts_b, v_b, bm_b = frame(2, 25)       # other timestamps: another number of synthetic rows
+    cols = [capi.Column(ts_a, None, capi.INT64).to_device(), capi.Column(v_a, bm_a, capi.FLOAT64, 0, n, -1).to_device()]
+    carr, iarr = capi._cols(cols), capi._interps(ip)
+    opts = capi.Options(0, 0, 0)
+
+    def count():
+        m = C.c_int64(0)
+        capi.check(L.bowgpu_rolling_interpolate_count(carr, 2, 0, C.c_int64(10), C.byref(opts), iarr, 2, C.byref(m)))
+        return m.value
+
+    def fill(slots):
+        outs = [capi.OutColumn(slots, capi.DEVICE) for _ in ip]
+        oarr = (capi.Out * 2)()
+        for i, o in enumerate(outs):
+            oarr[i] = o.c()
+        rc = L.bowgpu_rolling_interpolate_fill(carr, 2, 0, C.c_int64(10), C.byref(opts), iarr, 2, oarr)
+        for i, o in enumerate(outs):
+            o.absorb(oarr[i])
+        return rc, outs
+
+    want_a = orc.interpolate([orc.Column(ts_a, None, orc.INT64), orc.Column(v_a, bm_a, orc.FLOAT64)], 0, 10, ip)
+    want_b = orc.interpolate([orc.Column(ts_b, None, orc.INT64), orc.Column(v_b, bm_b, orc.FLOAT64)], 0, 10, ip)
+    assert want_a[0].length != want_b[0].length
+    m_a = count()
+    assert m_a == want_a[0].length
+    rc, outs = fill(m_a)                                           # the ordinary pair of calls
+    assert rc == 0
+    cmp_out("reuse a ts", outs[0], want_a[0]); cmp_out("reuse a val", outs[1], want_a[1])
+    # 1. the interval column rewritten THROUGH the library between the two calls: the fill scans the new column
+    assert count() == m_a
+    capi.check(L.bowgpu_memcpy_h2d(C.c_void_p(cols[0].values.ptr), ts_b.ctypes.data_as(C.c_void_p), C.c_int64(ts_b.nbytes)))
+    rc, outs = fill(max(m_a, want_b[0].length) + 8)
+    assert rc == 0 and outs[0].length == orc.interpolate([orc.Column(ts_b, None, orc.INT64), orc.Column(v_a, bm_a, orc.FLOAT64)], 0, 10, ip)[0].length
+    # 2. ... behind the library's back (a raw hipMemcpy): the fill's own row count does not add up -> BOWGPU_ERR_ARG
+    hip = C.CDLL("libamdhip64.so")
+    assert count() == outs[0].length
+    assert hip.hipMemcpy(C.c_void_p(cols[0].values.ptr), ts_a.ctypes.data_as(C.c_void_p), C.c_size_t(ts_a.nbytes), 1) == 0
+    rc, _ = fill(max(m_a, want_b[0].length) + 8)
+    assert rc == -10 and b"changed between" in L.bowgpu_last_error()
+    # ... and the thread goes on working: the same pair of calls on the column as it is now
+    assert count() == m_a
+    rc, outs = fill(m_a)
+    assert rc == 0
+    cmp_out("after the tampering, ts", outs[0], want_a[0]); cmp_out("after the tampering, val", outs[1], want_a[1])
