@@ -1307,6 +1307,98 @@ static int run_modes(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t ts_c
     return 0;
 }
 
+static int run_aggregate(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t ts_col, const Plan &plan,
+                         int inclusive, const bowgpu_agg *aggs, int32_t naggs, bowgpu_out *outs,
+                         int64_t wid_base, int64_t W, int64_t *long_windows, double *kernel_ms);
+
+// An interval column WITH NULLS (ts_nulls.hip has the semantics: rolling.go:177-239 skips such rows, :143-154 counts windows from the
+// last valid timestamp, :162-173 ends the iteration at once when the physically last timestamp is null).  The call is rewritten
+// onto a dense interval column - nulls forward-filled - with every value column's validity ANDed with the rows that belong to a
+// window (and, for the time-weighted reducers, with the interval column's own validity), and then takes the ordinary path.
+// Exclusive windows of an unsharded call; NumRows (it counts rows, valid or not) and Mode are declined.
+static int run_aggregate_null_ts(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t ts_col, const Plan &plan, int inclusive,
+                                 const bowgpu_agg *aggs, int32_t naggs, bowgpu_out *outs, DevCol &dts, int64_t *long_windows, double *kernel_ms) {
+    const bowgpu_col *tsc = &cols[ts_col];
+    const int64_t n = tsc->length, W = plan.W;
+    if (inclusive) return fail(BOWGPU_ERR_TS_NULLS, "interval column has %lld nulls and the windows are inclusive: outside the device path", (long long)dts.null_count);
+    for (int i = 0; i < naggs; i++)
+        if (aggs[i].kind == BOWGPU_AGG_NUM_ROWS || aggs[i].kind == BOWGPU_AGG_MODE)
+            return fail(BOWGPU_ERR_TS_NULLS, "interval column has %lld nulls: NumRows / Mode over it are outside the device path", (long long)dts.null_count);
+    for (int i = 0; i < ncols; i++)
+        if (cols[i].length != n) return fail(BOWGPU_ERR_ARG, "column %d has %lld rows, interval column has %lld", i, (long long)cols[i].length, (long long)n);
+    if (long_windows) *long_windows = 0;
+    if (kernel_ms) *kernel_ms = 0;
+    int last_valid = 1;
+    BG_TRY(fetch_valid(c, tsc, n - 1, &last_valid));
+    if (!last_valid || W == 0) {
+        // HasNext (rolling.go:162-173) is false from the start when the physically last timestamp is null: no window is ever
+        // produced and every slot of the numWindows-long output buffers stays nil (bowbuffer.go:22-40: zero data, all-null bitmap)
+        for (int i = 0; i < naggs; i++) {
+            DevOut d;
+            BG_TRY(devout_prepare(c, &outs[i], W, &d, i));
+            int t = kind_type(aggs[i].kind);
+            if (t == BOWGPU_INPUT_DEPENDENT) t = cols[aggs[i].col].type;
+            if (t == BOWGPU_ITERATOR_DEPENDENT) t = tsc->type;
+            if (W > 0) {
+                BG_HIP(hipMemsetAsync(d.values, 0, (size_t)W * 8, c->stream));
+                BG_HIP(hipMemsetAsync(d.validity, 0, (size_t)((W + 7) >> 3), c->stream));
+            }
+            BG_TRY(devout_finish(c, &d, W, t, W));
+            BG_HIP(hipStreamSynchronize(c->stream));
+        }
+        return 0;
+    }
+    // the interval column forward-filled + which rows belong to a window
+    DevBuf ixbuf, ts_eff, keep, dropped;
+    NbrIndex ix;
+    BG_TRY(ixbuf.alloc(nbr_index_bytes(n, dts.vbit0)));
+    BG_TRY(nbr_index_build(c, dts.vbits, dts.vbit0, n, ixbuf.p, &ix));
+    BG_TRY(ts_eff.alloc((size_t)n * 8 + 16));
+    const size_t bm_bytes = (size_t)((n + 63) >> 6) * 8 + 8;
+    BG_TRY(keep.alloc(bm_bytes));
+    BG_TRY(dropped.alloc(8));
+    BG_TRY(launch_ts_nullfill(c, reinterpret_cast<const int64_t *>(dts.values), dts.vbits, dts.vbit0, n, ix, plan.s0, plan.magic,
+                              reinterpret_cast<int64_t *>(ts_eff.p), reinterpret_cast<uint64_t *>(keep.p), reinterpret_cast<unsigned long long *>(dropped.p)));
+    // one rewritten column per (input column, plain | time-weighted) that some reducer reads
+    std::vector<bowgpu_col> cols2(cols, cols + ncols);
+    std::vector<bowgpu_agg> aggs2(aggs, aggs + naggs);
+    std::vector<DevCol> dcs(ncols);
+    std::vector<DevBuf> bitmaps;
+    bitmaps.reserve(2 * (size_t)ncols);
+    std::vector<int> plain_of(ncols, -1), tw_of(ncols, -1);
+    {
+        bowgpu_col &t = cols2[ts_col];
+        t.values = ts_eff.p; t.validity = nullptr; t.offset = 0; t.length = n; t.null_count = 0; t.type = BOWGPU_INT64; t.residency = BOWGPU_DEVICE;
+    }
+    for (int i = 0; i < naggs; i++) {
+        if (!kind_reads_values(aggs[i].kind)) continue;
+        const int col = aggs[i].col;
+        const bool tw = aggs[i].kind >= BOWGPU_AGG_INTEGRAL_STEP && aggs[i].kind <= BOWGPU_AGG_WAVG_LINEAR;
+        int &slot = tw ? tw_of[col] : plain_of[col];
+        if (slot < 0) {
+            const uint32_t *vbits; int64_t vbit0; const void *values;
+            if (col == ts_col) { values = dts.values; vbits = dts.vbits; vbit0 = dts.vbit0; }
+            else {
+                DevCol &dc = dcs[col];
+                if (dc.values == nullptr) BG_TRY(devcol_prepare(c, &cols[col], &dc, true, true));
+                values = dc.values; vbits = dc.vbits; vbit0 = dc.vbit0;
+            }
+            bitmaps.emplace_back();
+            DevBuf &bm = bitmaps.back();
+            BG_TRY(bm.alloc(bm_bytes));
+            if (tw) BG_TRY(launch_and_bits(c, vbits, vbit0, dts.vbits, dts.vbit0, n, reinterpret_cast<uint64_t *>(bm.p)));
+            else BG_TRY(launch_and_bits(c, vbits, vbit0, reinterpret_cast<const uint32_t *>(keep.p), 0, n, reinterpret_cast<uint64_t *>(bm.p)));
+            bowgpu_col nc;
+            nc.values = values; nc.validity = reinterpret_cast<const uint8_t *>(bm.p); nc.offset = 0; nc.length = n; nc.null_count = -1;
+            nc.type = cols[col].type; nc.residency = BOWGPU_DEVICE;
+            slot = (int)cols2.size();
+            cols2.push_back(nc);
+        }
+        aggs2[i].col = slot;
+    }
+    return run_aggregate(c, cols2.data(), (int32_t)cols2.size(), ts_col, plan, 0, aggs2.data(), naggs, outs, 0, W, long_windows, kernel_ms);
+}
+
 // An unsharded Aggregate call: the streaming reducers in batches that one launch of the tile kernels takes (at most kMaxAggs
 // outputs over at most kMaxCols column passes - the reference has no such limits, aggregation.go:190-238 simply loops), then the
 // Mode outputs.
@@ -1316,6 +1408,11 @@ static int run_aggregate(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t 
     int n_mode = 0;
     for (int i = 0; i < naggs; i++) n_mode += aggs[i].kind == BOWGPU_AGG_MODE;
     if (n_mode > 0 && (wid_base != 0 || W != plan.W)) return fail(BOWGPU_ERR_UNSUPPORTED, "Mode runs on unsharded calls only");
+    if (wid_base == 0 && W == plan.W && cols[ts_col].validity && cols[ts_col].null_count != 0 && cols[ts_col].length > 0) {
+        DevCol dts;   // (values + validity on the device; counts the nulls when the caller did not)
+        BG_TRY(devcol_prepare(c, &cols[ts_col], &dts, true, true));
+        if (dts.null_count > 0) return run_aggregate_null_ts(c, cols, ncols, ts_col, plan, inclusive, aggs, naggs, outs, dts, long_windows, kernel_ms);
+    }
     if (long_windows) *long_windows = 0;
     if (kernel_ms) *kernel_ms = 0;
     // greedy batches in output order; the column-pass count follows job_build's rule (a pass serves at most 4 nullable reducers)

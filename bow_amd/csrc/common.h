@@ -289,6 +289,11 @@ int launch_mode(Ctx *c, const int64_t *ts, const int64_t *first_idx, int64_t n, 
                 const uint32_t *vbits, int64_t vbit0, int is_int, const bowgpu_agg *agg, void *out_values, uint32_t *out_valid,
                 int64_t *n_mid, int64_t *n_long);
 
+// ts_nulls.hip: an interval column with nulls rewritten for the tile kernels (forward-filled timestamps, the rows that belong to a window)
+int launch_ts_nullfill(Ctx *c, const int64_t *ts, const uint32_t *tbits, int64_t tbit0, int64_t n, const struct NbrIndex &ix, int64_t s0,
+                       const MagicDiv &magic, int64_t *ts_eff, uint64_t *keep, unsigned long long *d_dropped);
+int launch_and_bits(Ctx *c, const uint32_t *a, int64_t abit0, const uint32_t *b, int64_t bbit0, int64_t n, uint64_t *out);
+
 // shard.hip
 int launch_range_state(Ctx *c, const AggParams &p, int mode, uint64_t wid, const bowgpu_carry_state *d_seeds,
                        bowgpu_carry_state *d_states_out, const bowgpu_next_row *d_next = nullptr, int seed_alive = 1);

@@ -147,6 +147,7 @@ struct InterpJob {
     int e0 = 0;       // inclusive windows: row 0 sits exactly on the first window's start
     int has_left = 0; // sharded Interpolate: rows exist to the left, the last of them at left_ts, in window wbase - 1
     int64_t left_ts = 0, wbase = 0;
+    bool from_cache = false;   // pass 1 was not run by this call: its results are the preceding _count's
 };
 
 // pass 1 of interpolate.hip: exact heads per tile, their exclusive scan, M = synthetic rows
@@ -178,6 +179,7 @@ static int interp_prepare(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t
         job->kq = k.kq; job->drop = k.drop; job->M = k.M; job->wbase = k.wbase; job->has_left = k.has_left; job->left_ts = k.left_ts;
         job->kq_empty = k.kq_empty; job->e0 = k.e0;
         job->tile_before = c->pool[kPoolInterp + 1];
+        job->from_cache = true;
         BG_TRY(ts_device(c, &cols[ts_col], &job->dts));
         c->interp_cache.valid = false;   // one use: the outputs of this fill may be what the next call reads
         return 0;
@@ -389,14 +391,25 @@ static int interp_fill_impl(const bowgpu_col *cols, int32_t ncols, int32_t ts_co
         return 0;
     };
     BG_TRY(run_all(1));
+    // (a reused count whose column has changed since: interp_wave3_kernel stored nothing for the trips that did not fit and said
+    // so; the kernels a redo would use do not check, so the error comes first)
+    if (hstat[6]) return fail(BOWGPU_ERR_ARG, "Interpolate: the rows produced do not add up to the count - the interval column changed between "
+                                              "bowgpu_rolling_interpolate_count and _fill (include/bowgpu.h: the contract between the two calls)");
+    if (hstat[5] && job.from_cache) {
+        // the redo runs kernels that trust pass 1 blindly: make pass 1 this call's own before handing it to them
+        InterpJob fresh;
+        BG_TRY(interp_prepare(c, cols, ncols, ts_col, interval, &o, &fresh, global_s0, edge, false));
+        if (n + fresh.M != n_out) return fail(BOWGPU_ERR_ARG, "Interpolate: the interval column changed between bowgpu_rolling_interpolate_count and _fill");
+        P.tile_exact_before = reinterpret_cast<const int64_t *>(fresh.tile_before);
+        P.kq = fresh.kq; P.kq_empty = fresh.kq_empty; P.drop = fresh.drop; P.e0 = fresh.e0;
+        P.s0 = fresh.plan.s0; P.W = fresh.plan.W;
+    }
     // some trip has more runs of synthetic rows than the default kernel lists: interp_wave_kernel (inclusive windows: interp_wave2_kernel,
     // whose list holds a run per row) takes the call
     if (hstat[5]) BG_TRY(run_all(0));
     if (hstat[5] && o.inclusive)
         return fail(BOWGPU_ERR_UNSUPPORTED, "Interpolate on inclusive windows: windows shorter than two rows on average are outside the device path");
     if (hstat[0]) return fail(BOWGPU_ERR_TS_UNSORTED, "interval column is not ascending: outside the device path");
-    if (hstat[6]) return fail(BOWGPU_ERR_ARG, "Interpolate: the rows produced do not add up to the count - the interval column changed between "
-                                              "bowgpu_rolling_interpolate_count and _fill (include/bowgpu.h: the contract between the two calls)");
     for (int i = 0; i < ninterps; i++) BG_TRY(devout_finish(c, &douts[i], n_out, cols[i].type, n_out - (int64_t)hcnt[i], false));
     BG_HIP(hipStreamSynchronize(c->stream));
     return 0;

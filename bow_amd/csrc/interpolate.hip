@@ -1194,8 +1194,13 @@ __global__ __launch_bounds__(64, 4) void interp_wave3_kernel(const InterpParams 
         return;
     }
     const bool staged = tot <= (uint32_t)kT3Stage;
-    // the last trip ends where the count pass said the outputs end - or the interval column is not the one that was counted
-    if (trip == ntrips - 1 && lane == 0 && o_trip + (int64_t)tot != p.n_out) atomicOr(&p.status[6], 1u);
+    // The last trip ends where the count pass said the outputs end, and every trip lies inside the outputs - or the interval
+    // column is not the one that was counted (a _fill that reuses its _count's prefix: include/bowgpu.h, the contract between the
+    // two calls).  Such a trip stores NOTHING: a stale prefix must not become a write outside the caller's buffers.
+    if (o_trip < 0 || o_trip + (int64_t)tot > p.n_out || (trip == ntrips - 1 && o_trip + (int64_t)tot != p.n_out)) {
+        if (lane == 0) atomicOr(&p.status[6], 1u);
+        return;
+    }
     // the timestamp offset of row r of the trip (r differs per lane): out of the registers of the lane that holds it
     auto rel_of = [&](int r) -> uint32_t {
         const int src = ((r & 127) >> 1) << 2;

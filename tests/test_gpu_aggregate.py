@@ -490,16 +490,20 @@ def test_nanosecond_timestamps_beyond_2_53():
     assert capi.last_kernel_name() == "rolling_tw_kernel"
 
 
-def test_declines_unsorted_and_null_timestamps():
+def test_declines_unsorted_timestamps_and_what_null_timestamps_cannot_have():
     ts = np.array([1, 5, 3, 9, 12, 20], dtype=np.int64)
     v = np.arange(6, dtype=np.float64)
     with pytest.raises(capi.BowGpuError) as e:
         capi.rolling_aggregate([capi.Column(ts), capi.Column(v)], 0, 4, [("WindowStart", 0), ("Sum", 1)])
     assert e.value.code == -14
+    # null timestamps: served on the device for exclusive windows (test_null_timestamps_*), declined - BOWGPU_ERR_TS_NULLS - for
+    # inclusive windows, NumRows and Mode
     tsn = capi.Column.from_list([1, None, 3, 9], "int64")
-    with pytest.raises(capi.BowGpuError) as e:
-        capi.rolling_aggregate([tsn, capi.Column(v[:4])], 0, 4, [("WindowStart", 0), ("Sum", 1)])
-    assert e.value.code == -13
+    for aggs, incl in (([("WindowStart", 0), ("IntegralTrapezoid", 1)], False), ([("WindowStart", 0), ("Sum", 1)], True),
+                       ([("WindowStart", 0), ("NumRows", 1)], False), ([("WindowStart", 0), ("Mode", 1)], False)):
+        with pytest.raises(capi.BowGpuError) as e:
+            capi.rolling_aggregate([tsn, capi.Column(v[:4])], 0, 4, aggs, inclusive=incl)
+        assert e.value.code == -13, aggs
     with pytest.raises(capi.BowGpuError) as e:  # first ts null is the reference's own ctor error (rolling.go:89-93)
         capi.rolling_aggregate([capi.Column.from_list([None, 2, 3, 9], "int64"), capi.Column(v[:4])], 0, 4,
                                [("WindowStart", 0), ("Sum", 1)])
@@ -666,6 +670,93 @@ def test_mode_whole_frame():
         for k, g, w in zip(_names(aggs), got, want):
             # (whole-frame Sum: one window over all rows, reduced as a tree - tests/tolerance.py)
             compare("whole %s n=%d" % (k, n), g, w, exact=k != "Sum", bound=[2.0 * (n + 2) * 2.0 ** -53 * float(np.abs(vals[valid]).sum())])
+
+
+def _null_ts_frame(rng, n, null_frac, mode="irregular", vnull=0.2):
+    ts = make_ts(rng, n, mode)
+    tvalid = rng.random(n) >= null_frac
+    tvalid[0] = True                       # (the constructor needs a first timestamp: rolling.go:89-93)
+    tvalid[-1] = True                      # (a null LAST timestamp ends the iteration before it starts: its own test)
+    vals = np.round(rng.standard_normal(n) * 100, 3)
+    vvalid = rng.random(n) >= vnull
+    return ts, tvalid, vals, vvalid
+
+
+NULL_TS_AGGS = [("WindowStart", 0), ("Sum", 1), ("ArithmeticMean", 1), ("Min", 1), ("Max", 1), ("Count", 1), ("First", 1), ("Last", 1),
+                ("IntegralStep", 1), ("WeightedAverageStep", 1), ("Sum", 0), ("Count", 0), ("Last", 0), ("WeightedAverageStep", 0)]
+
+
+def _run_null_ts(ts, tvalid, vals, vvalid, interval, offset=0, aggs=NULL_TS_AGGS, device=False):
+    n = len(ts)
+    tbm = np.packbits(tvalid, bitorder="little")
+    vbm = None if vvalid is None else np.packbits(vvalid, bitorder="little")
+    ccols = [capi.Column(ts, tbm, capi.INT64, 0, n, -1), capi.Column(vals, vbm, capi.FLOAT64, 0, n, -1)]
+    if device:
+        ccols = [c.to_device() for c in ccols]
+    ocols = [orc.Column(ts, tbm, orc.INT64), orc.Column(vals, vbm, orc.FLOAT64)]
+    want, nic = orc.aggregate(ocols, 0, interval, aggs, offset=offset)
+    bounds = None
+    for label in capi.agg_routes():
+        got, info = capi.rolling_aggregate(ccols, 0, interval, aggs, offset=offset, out_residency=capi.DEVICE if device else capi.HOST)
+        assert info.new_interval_col == nic
+        if info.long_windows and bounds is None:
+            # (the bound's magnitudes: the oracle over |x| on the SAME frame, null timestamps included)
+            bounds = order_free_bounds(ocols, 0, interval, aggs, offset=offset, ref=want)
+        for i, ((k, _c), g, w) in enumerate(zip(aggs, got, want)):
+            exact = info.long_windows == 0 or k not in ORDER_SENSITIVE
+            compare("null ts %s col %d path=%s n=%d I=%d" % (k, _c, label, n, interval), g, w, exact=exact, bound=None if exact else bounds[i])
+    return want
+
+
+@pytest.mark.parametrize("null_frac", [0.02, 0.3, 0.9])
+def test_null_timestamps_against_the_oracle(null_frac):
+    """rolling.go:190-193 skips a row whose interval value is null; it stays inside its window's slice when taken rows surround it
+    (its value columns are reduced) and belongs to no window behind the window's last taken row.  The device path (ts_nulls.hip)
+    against the oracle's literal walk: every exclusive-window reducer incl. the step integrals and reducers over the interval
+    column itself, every kernel route, windows shorter and longer than the null runs."""
+    rng = np.random.default_rng(int(null_frac * 100))
+    for n, interval, offset, mode in [(1, 10, 0, "dense"), (2, 3, 1, "dense"), (700, 5, 2, "dups"), (3000, 10, 0, "irregular"),
+                                      (5000, 64, 7, "gappy"), (40_000, 25, -3, "irregular"), (40_000, 4000, 11, "dense"),
+                                      (6000, 10, 3, "negative")]:
+        ts, tvalid, vals, vvalid = _null_ts_frame(rng, n, null_frac, mode)
+        _run_null_ts(ts, tvalid, vals, vvalid, interval, offset, device=(n % 2 == 0))
+
+
+def test_null_timestamps_runs_at_window_edges_and_the_null_last_row():
+    ts = np.array([10, 11, 12, 13, 20, 21, 22, 30, 31, 45, 46], dtype=np.int64)
+    vals = np.arange(1.0, 12.0)
+    allv = np.ones(len(ts), bool)
+    for nulls in ([1], [3], [4], [3, 4], [2, 3, 4, 5], [1, 2, 3, 4, 5, 6, 7, 8, 9], [7, 8], [9]):
+        tvalid = allv.copy()
+        tvalid[nulls] = False
+        want = _run_null_ts(ts, tvalid, vals, None, 10)
+        _run_null_ts(ts, tvalid, vals, None, 10, offset=5)
+    # window [10, 20) with its rows 12, 13 null: they trail the window's last taken row -> in no slice: Count 2, not 4
+    tvalid = allv.copy(); tvalid[[2, 3]] = False
+    want = _run_null_ts(ts, tvalid, vals, None, 10)
+    assert want[5].to_list()[0] == 2 and want[1].to_list()[0] == 1.0 + 2.0
+    # ... but null rows BETWEEN taken rows are reduced: rows 11, 12 null, 13 valid -> Count 4
+    tvalid = allv.copy(); tvalid[[1, 2]] = False
+    want = _run_null_ts(ts, tvalid, vals, None, 10)
+    assert want[5].to_list()[0] == 4 and want[10].to_list()[0] == 10.0 + 13.0   # (Sum over the interval column itself skips them)
+    # the physically last timestamp null: HasNext is false from the start (rolling.go:162-173) - numWindows slots, all nil
+    tvalid = allv.copy(); tvalid[-1] = False
+    want = _run_null_ts(ts, tvalid, vals, None, 10)
+    assert want[0].length == 4 and all(x is None for w in want for x in w.to_list())   # (windows 10, 20, 30, 40: the last valid ts is 45)
+    tvalid[-3:] = False
+    want = _run_null_ts(ts, tvalid, vals, None, 10)
+    assert want[0].length == 3 and all(x is None for w in want for x in w.to_list())
+
+
+def test_null_timestamps_large_frame_on_the_device():
+    """2e6 rows, 5 % null timestamps, device-resident: the rewritten call takes the ordinary tile kernel"""
+    rng = np.random.default_rng(99)
+    n = 2_000_000
+    ts, tvalid, vals, vvalid = _null_ts_frame(rng, n, 0.05, "irregular", vnull=0.1)
+    _run_null_ts(ts, tvalid, vals, vvalid, 20, 3, aggs=NULL_TS_AGGS[:10], device=True)
+    with capi.route(0):
+        pass
+    assert capi.last_kernel_name() == "rolling_agg_kernel"   # (agg_routes ends with the general kernel)
 
 
 def test_mode_only_call_declines_what_the_device_path_declines():

@@ -1,0 +1,84 @@
+"""The device path for an interval column with nulls (bow_amd/csrc/ts_nulls.hip) rewrites the call onto a dense interval column:
+timestamps forward-filled, value validity ANDed with "the row belongs to a window" (and with the interval column's validity for the
+time-weighted reducers).  CPU check of that REWRITE RULE against the oracle's literal window walk (rolling.go:177-239 restated in
+oracle/bow_oracle.c): the oracle on the rewritten, dense frame must equal the oracle on the original frame with its null
+timestamps - for every reducer the device path serves.  (The GPU tests compare the kernels with the oracle directly.)"""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as orc
+
+PLAIN = ["Sum", "ArithmeticMean", "Min", "Max", "Count", "First", "Last"]
+TW = ["IntegralStep", "WeightedAverageStep"]
+
+
+def go_div(a, b):
+    q = abs(a) // b
+    return -q if a < 0 else q
+
+
+def rewrite(ts, tvalid, s0, interval):
+    """ts_eff, keep - what ts_nullfill_kernel computes"""
+    n = len(ts)
+    idx = np.arange(n)
+    prev = np.maximum.accumulate(np.where(tvalid, idx, -1))
+    nxt = np.minimum.accumulate(np.where(tvalid, idx, n)[::-1])[::-1]
+    ts_eff = ts[np.maximum(prev, 0)].copy()
+    wid = lambda t: np.where(t < s0, 0, (t - s0) // interval)      # rows below s0 ride in window 0
+    keep = tvalid.copy()
+    nul = ~tvalid
+    ok = nul & (prev >= 0) & (nxt < n)
+    keep[ok] = wid(ts[prev[ok]]) == wid(ts[np.minimum(nxt[ok], n - 1)])
+    return ts_eff, keep
+
+
+@pytest.mark.parametrize("null_frac", [0.03, 0.3, 0.8])
+def test_the_rewritten_dense_frame_gives_the_oracles_answer(null_frac):
+    rng = np.random.default_rng(int(null_frac * 1000))
+    for case in range(60):
+        n = int(rng.integers(1, 400))
+        ts = np.cumsum(rng.integers(0, 7, n)).astype(np.int64) + int(rng.integers(-60, 60))
+        tvalid = rng.random(n) >= null_frac
+        tvalid[0] = tvalid[-1] = True
+        vals = np.round(rng.standard_normal(n) * 10, 2)
+        vvalid = rng.random(n) >= 0.25
+        interval = int(rng.choice([1, 2, 5, 10, 40, 1000]))
+        offset = int(rng.integers(-interval, 2 * interval))
+        tbm, vbm = np.packbits(tvalid, bitorder="little"), np.packbits(vvalid, bitorder="little")
+        ocols = [orc.Column(ts, tbm, orc.INT64), orc.Column(vals, vbm, orc.FLOAT64)]
+        try:
+            s0, W = orc.plan_windows(ocols[0], interval, offset)
+        except orc.OracleError:
+            continue
+        aggs = [("WindowStart", 0)] + [(k, 1) for k in PLAIN + TW] + [("Sum", 0), ("Last", 0), ("IntegralStep", 0)]
+        want, _ = orc.aggregate(ocols, 0, interval, aggs, offset=offset)
+        ts_eff, keep = rewrite(ts, tvalid, s0, interval)
+        assert (np.diff(ts_eff) >= 0).all()
+        # columns of the rewritten call: [ts_eff, val & keep, val & tsvalid, ts & tsvalid(& keep), ts & tsvalid]
+        dense = [orc.Column(ts_eff, None, orc.INT64),
+                 orc.Column(vals, np.packbits(vvalid & keep, bitorder="little"), orc.FLOAT64),
+                 orc.Column(vals, np.packbits(vvalid & tvalid, bitorder="little"), orc.FLOAT64),
+                 orc.Column(ts, np.packbits(tvalid & keep, bitorder="little"), orc.INT64),
+                 orc.Column(ts, np.packbits(tvalid, bitorder="little"), orc.INT64)]
+        aggs2 = [("WindowStart", 0)] + [(k, 1) for k in PLAIN] + [(k, 2) for k in TW] + [("Sum", 3), ("Last", 3), ("IntegralStep", 4)]
+        got, _ = orc.aggregate(dense, 0, interval, aggs2, offset=offset)
+        label = (case, n, interval, offset)
+        for (k, _c), g, w in zip(aggs, got, want):
+            assert g.length == w.length == W, (label, k)
+            gm, wm = g.valid_mask(), w.valid_mask()
+            assert np.array_equal(gm, wm), (label, k, list(ts), list(tvalid.astype(int)))
+            gv, wv = g.values[:W].view(np.uint64), w.values[:W].view(np.uint64)
+            assert np.array_equal(gv[gm], wv[wm]), (label, k)
+
+
+def test_a_null_last_timestamp_produces_no_window_at_all():
+    ts = np.array([10, 11, 20, 21, 30], dtype=np.int64)
+    vals = np.arange(5.0)
+    for tail in (1, 2):
+        tvalid = np.ones(5, bool)
+        tvalid[-tail:] = False
+        cols = [orc.Column(ts, np.packbits(tvalid, bitorder="little"), orc.INT64), orc.Column(vals, None, orc.FLOAT64)]
+        s0, W = orc.plan_windows(cols[0], 10, 0)
+        assert (s0, W) == (10, 2)             # countWindows measures from the last VALID timestamp (rolling.go:143-154)
+        out, _ = orc.aggregate(cols, 0, 10, [("WindowStart", 0), ("Sum", 1), ("Count", 1)])
+        assert all(o.length == W and not o.valid_mask().any() for o in out)   # ... and HasNext (:162-173) never lets a window start
