@@ -971,9 +971,9 @@ static int job_launch_tiles(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t
     {
         BitmapBatch b;
         job_bitmaps(job, aggs, naggs, simple, &b);
-        BG_TRY(launch_preset_bitmaps(c, b));   // + status words and counters to zero
+        if (job->check_plan && plan) { b.check_ts = P.ts; b.check_n = P.n; b.check_first = plan->first_ts; b.check_last = plan->last_ts; }
+        BG_TRY(launch_preset_bitmaps(c, b));   // + status words and counters to zero (+ the check of a caller-supplied plan)
         job->counts_used = false;
-        if (job->check_plan && plan) BG_TRY(launch_plan_check(c, P.ts, P.n, plan->first_ts, plan->last_ts, P.status));
     }
     // kernel_ms brackets the dominant kernel only, on the stream it runs on
     BG_HIP(hipEventRecord(c->ev0, c->stream));
@@ -1127,8 +1127,8 @@ static int job_run(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, i
         {
             BitmapBatch b;
             job_bitmaps(job, aggs, naggs, false, &b);
+            if (job->check_plan) { b.check_ts = P.ts; b.check_n = P.n; b.check_first = plan->first_ts; b.check_last = plan->last_ts; }
             BG_TRY(launch_preset_bitmaps(c, b));
-            if (job->check_plan) BG_TRY(launch_plan_check(c, P.ts, P.n, plan->first_ts, plan->last_ts, P.status));
         }
         BG_HIP(hipEventRecord(c->ev0, c->stream));
         int64_t n_all = W;

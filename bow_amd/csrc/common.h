@@ -277,10 +277,11 @@ struct BitmapBatch {
     int32_t count[kMaxAggs];       // finish: count the valid bits into counts[a]
     uint32_t *status;              // preset zeroes status[0 .. status_words) and counts[0 .. kMaxAggs)
     unsigned long long *counts;
+    const int64_t *check_ts;       // preset: a caller-supplied plan is checked against this interval column (nullptr: no check);
+    int64_t check_n, check_first, check_last;   // status[6] = 1 when its first / last row are not the plan's two timestamps
 };
 int launch_preset_bitmaps(Ctx *c, const BitmapBatch &b);
 int launch_finish_bitmaps(Ctx *c, const BitmapBatch &b);
-int launch_plan_check(Ctx *c, const int64_t *ts, int64_t n, int64_t first_ts, int64_t last_ts, uint32_t *status);   // status[6] = 1: not this column's plan
 int launch_popcount(Ctx *c, const uint32_t *words, int64_t bit0, int64_t nbits, uint64_t *d_count);
 
 // mode.hip: one aggregation.Mode output over the windows whose first rows are first_idx[0 .. W]
@@ -353,7 +354,7 @@ struct InterpParams {
     int64_t drop;                      // leading rows that belong to no window (interp_quirk_kernel), normally 0
     uint32_t m32, sh1_32, sh2_32;      // 32-bit magic of the interval (fast32 only)
     int32_t fast32;                    // interp_fast32(plan, kq): 32-bit window ids, integer exact-head test
-    int32_t has_left, _pad3;           // sharded Interpolate: rows exist on shards to the left, the last of them at left_ts;
+    int32_t has_left, wide32;          // wide32: interp_wide32() - interp_wave3_kernel's trip-relative form applies (fast32 implies it); sharded Interpolate: rows exist on shards to the left, the last of them at left_ts;
     int64_t left_ts, wbase;            // the windows up to theirs (wbase = its id + 1) are not this shard's to account for
     int32_t ncols, ts_col;
     int32_t allow_wave2;               // the whole-trip wave kernel may take the call (0: the call is being redone after its run list overflowed)
@@ -365,6 +366,7 @@ struct InterpParams {
 };
 int64_t interp_tiles(int64_t n);
 bool interp_fast32(const Plan &plan, int64_t kq);
+bool interp_wide32(const Plan &plan, int64_t kq);   // ... without the bound on the frame's span: 32-bit arithmetic relative to each trip
 void interp_magic32(int64_t interval, uint32_t *m, uint32_t *sh1, uint32_t *sh2);
 int launch_interp_count(Ctx *c, const int64_t *ts, int64_t n, const Plan &plan, int64_t kq, int has_left, int64_t left_ts,
                         int32_t *tile_exact, uint32_t *status);

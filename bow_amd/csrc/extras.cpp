@@ -330,7 +330,8 @@ static int interp_fill_impl(const bowgpu_col *cols, int32_t ncols, int32_t ts_co
     P.drop = job.drop;
     P.has_left = job.has_left; P.left_ts = job.left_ts; P.wbase = job.wbase;
     P.fast32 = interp_fast32(job.plan, job.kq) ? 1 : 0;
-    if (P.fast32) interp_magic32(job.plan.interval, &P.m32, &P.sh1_32, &P.sh2_32);
+    P.wide32 = interp_wide32(job.plan, job.kq) ? 1 : 0;
+    if (P.fast32 || P.wide32) interp_magic32(job.plan.interval, &P.m32, &P.sh1_32, &P.sh2_32);
     P.ts_col = ts_col;
     P.n_out = n_out;
     {   // one word per 512-row trip and column of a launch (at most kMaxCols columns per launch)

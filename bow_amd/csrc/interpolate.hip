@@ -1095,7 +1095,7 @@ __global__ __launch_bounds__(64, 4) void interp_wave3_kernel(const InterpParams 
     const bool full = left_trip >= kT3Rows;
     const int nloc = full ? kT3Rows : (int)left_trip;
     const Magic32 m32 = {p.m32, p.sh1_32, p.sh2_32};
-    const uint32_t s0lo = (uint32_t)p.s0, i32 = (uint32_t)p.interval;
+    const uint32_t i32 = (uint32_t)p.interval;
     const uint64_t *tsu = reinterpret_cast<const uint64_t *>(p.ts);
     typedef const uint64_t __attribute__((address_space(4))) *const_u64;   // inputs nobody writes during the kernel: scalar loads
 
@@ -1119,13 +1119,25 @@ __global__ __launch_bounds__(64, 4) void interp_wave3_kernel(const InterpParams 
 #pragma unroll
         for (int k = 0; k < kT3Ch; k++) load2(p.cols[first_loaded].values, k, &na[k], &nb[k]);
     }
+    // Window ids and timestamps are 32-bit and RELATIVE TO THE TRIP: w0 = the window of its first row (one exact 64-bit division on
+    // the scalar unit), ws0 = that window's start.  Only the trip's own span has to fit 32 bits - millisecond timestamps over months,
+    // microseconds over hours per 512 rows - not the frame's (round 2's wave kernels needed every row within 2^31 of s0 and sent
+    // everything else to the workgroup kernel at half the rate).  A trip that does not fit raises status[5] (redo elsewhere).
+    const int64_t ts_first = (int64_t)((const_u64)(uintptr_t)tsu)[base], ts_lastrow = (int64_t)((const_u64)(uintptr_t)tsu)[base + nloc - 1];
+    const uint64_t w0 = magic_div((uint64_t)ts_first - (uint64_t)p.s0, p.magic);      // (every row lies at or above s0: the host checked the first)
+    const int64_t ws0 = p.s0 + (int64_t)(w0 * (uint64_t)p.interval);
+    const uint32_t s0lo = (uint32_t)ws0;
+    bool toolong = ts_lastrow < ts_first || (uint64_t)ts_lastrow - (uint64_t)ws0 >= 0x7FFFFFFFull;
     int64_t o_trip = 0, t_before = p.left_ts;
-    if (base > 0) {
-        t_before = (int64_t)((const_u64)(uintptr_t)tsu)[base - 1];
-        const uint32_t wp = mdiv32((uint32_t)((uint64_t)t_before - (uint64_t)p.s0), m32);
+    uint64_t gap0 = 0;   // windows between the row before the trip and the trip's first row (0: the same window)
+    if (base > 0 || p.has_left) {
+        if (base > 0) t_before = (int64_t)((const_u64)(uintptr_t)tsu)[base - 1];
+        const uint64_t wp = magic_div((uint64_t)t_before - (uint64_t)p.s0, p.magic);
+        gap0 = w0 - wp;
+        toolong |= t_before > ts_first || gap0 >= 0x3FFFFFull;
         // inclusive windows: one extra row in front of every window's first row (synthetic or the copy), but none for an exact row 0
         // (tile_exact_before holds one entry per 256 rows)
-        o_trip = kIncl ? base + (int64_t)wp + 1 - p.wbase - p.e0 : base + (int64_t)wp + 1 - p.wbase - p.tile_exact_before[trip * (kT3Rows / 256)];
+        if (base > 0) o_trip = kIncl ? base + (int64_t)wp + 1 - p.wbase - p.e0 : base + (int64_t)wp + 1 - p.wbase - p.tile_exact_before[trip * (kT3Rows / 256)];
     }
     const uint32_t sh_o = (uint32_t)(o_trip & 31);   // stage slot of the trip's first output = its bit inside its bitmap word
     if (lane < p.ncols) p.edge_words[(int64_t)lane * ntrips + trip] = 0ull;   // (no entry unless a staged flush below leaves one)
@@ -1134,7 +1146,6 @@ __global__ __launch_bounds__(64, 4) void interp_wave3_kernel(const InterpParams 
     uint32_t rr0[kT3Ch], rr1[kT3Ch];
     uint32_t tot = 0;
     int nrun = 0;
-    bool toolong = false;
     {
         uint32_t rb_prev = 0;
 #pragma unroll
@@ -1143,11 +1154,15 @@ __global__ __launch_bounds__(64, 4) void interp_wave3_kernel(const InterpParams 
             const uint32_t ra = (uint32_t)ta[k] - s0lo, rb = (uint32_t)tb[k] - s0lo;
             rr0[k] = ra; rr1[k] = rb;
             uint32_t rl = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rb, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-            if (lane == 0) rl = k == 0 ? (uint32_t)t_before - s0lo : (uint32_t)__builtin_amdgcn_readlane((int)rb_prev, 63);
+            if (lane == 0) rl = k == 0 ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)rb_prev, 63);
             rb_prev = rb;
             const bool in0 = i < p.n, in1 = i + 1 < p.n;
             const bool first = i == 0 && !p.has_left;  // the frame's first row has no left neighbour
-            const uint32_t wl = mdiv32(rl, m32), wa = mdiv32(ra, m32), wb = mdiv32(rb, m32);
+            uint32_t wl = mdiv32(rl, m32);
+            const uint32_t wa = mdiv32(ra, m32), wb = mdiv32(rb, m32);
+            // (the trip's first row: its window is local id 0 by construction, the row before it lies gap0 windows further back - ids
+            // are unsigned and wrap, the differences below come out right)
+            if (k == 0 && lane == 0) wl = 0u - (uint32_t)gap0;
             const bool head0 = in0 && (first || wa != wl), head1 = in1 && wb != wa;
             const bool exact0 = head0 && ra == wa * i32, exact1 = head1 && rb == wb * i32;
             // rows in front of a head: the empty windows before it + a synthetic row for its own window - or, when the row sits on
@@ -1223,7 +1238,7 @@ __global__ __launch_bounds__(64, 4) void interp_wave3_kernel(const InterpParams 
         uint64_t a[kT3Ch], bq[kT3Ch];
         if (c == 0 && col0_is_ts) {   // the interval column's own values: s0 + offset (the loaded registers were given up after phase 1)
 #pragma unroll
-            for (int k = 0; k < kT3Ch; k++) { a[k] = (uint64_t)p.s0 + (uint64_t)rr0[k]; bq[k] = (uint64_t)p.s0 + (uint64_t)rr1[k]; }
+            for (int k = 0; k < kT3Ch; k++) { a[k] = (uint64_t)ws0 + (uint64_t)rr0[k]; bq[k] = (uint64_t)ws0 + (uint64_t)rr1[k]; }
         } else {
 #pragma unroll
             for (int k = 0; k < kT3Ch; k++) { a[k] = na[k]; bq[k] = nb[k]; }
@@ -1332,8 +1347,8 @@ __global__ __launch_bounds__(64, 4) void interp_wave3_kernel(const InterpParams 
         auto points = [&](int rp, int rn, NbPoint *qp, NbPoint *qn) {
             *qp = carry; qn->has = 0; qn->t = 0; qn->bits = 0;
             const uint32_t tp = want_p ? rel_of(rp < 0 ? 0 : rp) : 0u, tn = want_n ? rel_of(rn < 0 ? 0 : rn) : 0u;   // (bpermute: every lane takes part)
-            if (rp >= 0) { qp->has = 1; qp->t = p.s0 + (int64_t)(uint64_t)tp; qp->bits = row_bits(rp); }
-            if (rn >= 0) { qn->has = 1; qn->t = p.s0 + (int64_t)(uint64_t)tn; qn->bits = row_bits(rn); }
+            if (rp >= 0) { qp->has = 1; qp->t = ws0 + (int64_t)(uint64_t)tp; qp->bits = row_bits(rp); }
+            if (rn >= 0) { qn->has = 1; qn->t = ws0 + (int64_t)(uint64_t)tn; qn->bits = row_bits(rn); }
             else if (want_n && base + nloc < p.n) {
                 const int64_t ni = next_valid_ix(ic.vbits, ic.vbit0, p.n, base + nloc, ic.nbr);
                 if (ni >= 0) {
@@ -1368,7 +1383,7 @@ __global__ __launch_bounds__(64, 4) void interp_wave3_kernel(const InterpParams 
                     uint64_t bits; int valid;
                     if (kIncl && j < jd) { bits = row_bits(al); valid = (int)((L.vw[al >> 6] >> (al & 63)) & 1ull); }
                     else {
-                        const int64_t sk = p.s0 + (int64_t)((uint64_t)(kfirst - (j - jd)) * (uint64_t)p.interval);
+                        const int64_t sk = ws0 + (int64_t)(int32_t)(kfirst - (j - jd)) * p.interval;   // (local ids: -1 is the window before the trip's first)
                         synth_value_pt(ic, sk, qp, qn, &bits, &valid);
                     }
                     put(orow - 1 - j, bits, valid);
@@ -1393,7 +1408,7 @@ __global__ __launch_bounds__(64, 4) void interp_wave3_kernel(const InterpParams 
                     uint64_t bits; int valid;
                     if (kIncl && j < jd) { bits = row_bits(al); valid = (int)((L.vw[al >> 6] >> (al & 63)) & 1ull); }
                     else {
-                        const int64_t sk = p.s0 + (int64_t)((uint64_t)(kfirst - (j - jd)) * (uint64_t)p.interval);
+                        const int64_t sk = ws0 + (int64_t)(int32_t)(kfirst - (j - jd)) * p.interval;   // (local ids: -1 is the window before the trip's first)
                         synth_value_pt(ic, sk, qp, qn, &bits, &valid);
                     }
                     put(orow - 1 - j, bits, valid);
@@ -1523,6 +1538,12 @@ bool interp_fast32(const Plan &plan, int64_t kq) {
            plan.first_ts > -lim53 && plan.last_ts < lim53;
 }
 
+// interp_wave3_kernel's shapes: as above, but only each 512-row TRIP has to span less than 2^31 (checked by the kernel itself)
+bool interp_wide32(const Plan &plan, int64_t kq) {
+    const int64_t lim53 = 1ll << 53;
+    return kq < 0 && plan.first_ts >= plan.s0 && plan.interval < (1ll << 31) && plan.first_ts > -lim53 && plan.last_ts < lim53 && plan.last_ts >= plan.first_ts;
+}
+
 int launch_interp_count(Ctx *c, const int64_t *ts, int64_t n, const Plan &plan, int64_t kq, int has_left, int64_t left_ts,
                         int32_t *tile_exact, uint32_t *status) {
     const int64_t ntiles = (n + kITile - 1) / kITile;
@@ -1556,20 +1577,22 @@ int launch_interp_tiles(Ctx *c, const InterpParams &p) {
     // BOWGPU_ROUTE_INTERP_WAVE1 / _WAVE2: the round-1 / round-2 wave kernels (wave1 is also what a call is redone with when a trip
     // overflows the run list of the others)
     const bool wave1 = (route & BOWGPU_ROUTE_INTERP_WAVE1) != 0, wave2 = (route & BOWGPU_ROUTE_INTERP_WAVE2) != 0;
-    if (p.fast32 && p.drop == 0 && p.kq < 0 && (p.inclusive || !force_tile)) {
-        const bool lean = p.allow_wave2 && !wave1 && !wave2;
-        if (lean || (p.inclusive && !wave2)) {
-            const int64_t ntrips = (p.n + kT3Rows - 1) / kT3Rows, per_xcd = (ntrips + 7) / 8;
-            if (per_xcd * 8 > 0x7FFFFFFFll) return fail(BOWGPU_ERR_UNSUPPORTED, "too many rows for one launch: %lld", (long long)p.n);
-            if (!p.edge_words) return fail(BOWGPU_ERR_ARG, "internal: interp_wave3_kernel needs its edge list");
-            if (p.inclusive) hipLaunchKernelGGL((interp_wave3_kernel<true>), dim3((unsigned)(per_xcd * 8)), dim3(64), 0, c->stream, p, ntrips, per_xcd);
-            else hipLaunchKernelGGL((interp_wave3_kernel<false>), dim3((unsigned)(per_xcd * 8)), dim3(64), 0, c->stream, p, ntrips, per_xcd);
-            hipLaunchKernelGGL(interp_edge_fix_kernel, dim3((unsigned)((ntrips * p.ncols + 255) / 256)), dim3(256), 0, c->stream, p, ntrips);
-        }
-        else if (p.inclusive) hipLaunchKernelGGL((interp_wave2_kernel<true, 4>), dim3((unsigned)ntiles), dim3(64), 0, c->stream, p);   // (wave2 and wave3 take inclusive windows)
-        else if (p.allow_wave2 && !wave1) hipLaunchKernelGGL((interp_wave2_kernel<false, 4>), dim3((unsigned)ntiles), dim3(64), 0, c->stream, p);
-        else hipLaunchKernelGGL(interp_wave_kernel, dim3((unsigned)ntiles), dim3(64), 0, c->stream, p);
+    const bool shape_ok = p.drop == 0 && p.kq < 0;
+    // interp_wave3_kernel: the product's choice for every shape it can take (its trip-relative form only needs each TRIP within 2^31:
+    // wide32); not on a redo (a trip overflowed its lists: allow_wave2 == 0), not when a test asks for another kernel.  Inclusive
+    // windows are served by wave3 and wave2 only, whatever the test switches say.
+    const bool want3 = p.allow_wave2 && !wave2 && (p.inclusive || (!wave1 && !force_tile));
+    if (shape_ok && (p.fast32 || p.wide32) && want3) {
+        const int64_t ntrips = (p.n + kT3Rows - 1) / kT3Rows, per_xcd = (ntrips + 7) / 8;
+        if (per_xcd * 8 > 0x7FFFFFFFll) return fail(BOWGPU_ERR_UNSUPPORTED, "too many rows for one launch: %lld", (long long)p.n);
+        if (!p.edge_words) return fail(BOWGPU_ERR_ARG, "internal: interp_wave3_kernel needs its edge list");
+        if (p.inclusive) hipLaunchKernelGGL((interp_wave3_kernel<true>), dim3((unsigned)(per_xcd * 8)), dim3(64), 0, c->stream, p, ntrips, per_xcd);
+        else hipLaunchKernelGGL((interp_wave3_kernel<false>), dim3((unsigned)(per_xcd * 8)), dim3(64), 0, c->stream, p, ntrips, per_xcd);
+        hipLaunchKernelGGL(interp_edge_fix_kernel, dim3((unsigned)((ntrips * p.ncols + 255) / 256)), dim3(256), 0, c->stream, p, ntrips);
     }
+    else if (shape_ok && p.fast32 && p.inclusive) hipLaunchKernelGGL((interp_wave2_kernel<true, 4>), dim3((unsigned)ntiles), dim3(64), 0, c->stream, p);
+    else if (shape_ok && p.fast32 && !force_tile && p.allow_wave2 && !wave1) hipLaunchKernelGGL((interp_wave2_kernel<false, 4>), dim3((unsigned)ntiles), dim3(64), 0, c->stream, p);
+    else if (shape_ok && p.fast32 && !force_tile) hipLaunchKernelGGL(interp_wave_kernel, dim3((unsigned)ntiles), dim3(64), 0, c->stream, p);
     else if (p.fast32) hipLaunchKernelGGL(interp_tile_kernel<true>, dim3((unsigned)ntiles), dim3(kIThreads), 0, c->stream, p);
     else hipLaunchKernelGGL(interp_tile_kernel<false>, dim3((unsigned)ntiles), dim3(kIThreads), 0, c->stream, p);
     BG_HIP(hipGetLastError());

@@ -455,7 +455,10 @@ int launch_rolling_aggregate(Ctx *c, const AggParams &p) {
 __global__ __launch_bounds__(256) void preset_bitmaps_kernel(const BitmapBatch b) {
     const int a = blockIdx.y;
     if (a == 0 && blockIdx.x == 0) {
-        for (int i = threadIdx.x; i < b.status_words; i += blockDim.x) b.status[i] = 0u;
+        // (status[6], thread 6: a caller-supplied plan - bowgpu_rolling_aggregate_planned - against the column it is used on: the two
+        // timestamps it was made from are the column's first and last row, or the call fails instead of taking wrong routes)
+        for (int i = threadIdx.x; i < b.status_words; i += blockDim.x)
+            b.status[i] = (i == 6 && b.check_ts && b.check_n > 0 && (b.check_ts[0] != b.check_first || b.check_ts[b.check_n - 1] != b.check_last)) ? 1u : 0u;
         if (threadIdx.x < kMaxAggs) b.counts[threadIdx.x] = 0ull;
     }
     if (a >= b.n) return;
@@ -513,15 +516,6 @@ static unsigned bitmap_grid(int64_t nbits) {
 }
 int launch_preset_bitmaps(Ctx *c, const BitmapBatch &b) {
     hipLaunchKernelGGL(preset_bitmaps_kernel, dim3(bitmap_grid(b.nbits), b.n > 0 ? b.n : 1), dim3(256), 0, c->stream, b);
-    BG_HIP(hipGetLastError());
-    return 0;
-}
-// a caller-supplied plan (bowgpu_rolling_aggregate_planned) against the column it is used on: the two scalars it was made from
-__global__ void plan_check_kernel(const int64_t *ts, int64_t n, int64_t first_ts, int64_t last_ts, uint32_t *status) {
-    if (threadIdx.x == 0 && blockIdx.x == 0 && n > 0 && (ts[0] != first_ts || ts[n - 1] != last_ts)) status[6] = 1u;
-}
-int launch_plan_check(Ctx *c, const int64_t *ts, int64_t n, int64_t first_ts, int64_t last_ts, uint32_t *status) {
-    hipLaunchKernelGGL(plan_check_kernel, dim3(1), dim3(64), 0, c->stream, ts, n, first_ts, last_ts, status);
     BG_HIP(hipGetLastError());
     return 0;
 }

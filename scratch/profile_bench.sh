@@ -6,7 +6,7 @@
 #   4. --kernel-trace --pmc <SQ counters> (two passes) + the L2 <-> fabric counters
 # then scratch/profile_collect.py boils them down to the files committed under profiles/ (kernel signature + a hash of the kernel's
 # sources in every row, so that bench.py only quotes traffic that belongs to the code it runs).
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/prof
 rm -rf $OUT && mkdir -p $OUT

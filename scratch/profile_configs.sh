@@ -2,7 +2,7 @@
 # rocprofv3 kernel stats of the secondary configurations (BASELINE.json configs 1-3, time-weighted reducers, Interpolate / fills,
 # long windows, small calls, host-resident columns) -> gpurun_out/prof_cfg/<TAG>_kernel_stats_<name>.csv + <TAG>_stdout_<name>.txt,
 # which are copied to profiles/ as they are.  Usage: profile_configs.sh r02 [names...]
-TAG=${1:-r02}; shift
+TAG=${1:-r03}; shift
 NAMES=${@:-configs general_bench interp_bench interp_wall longw longw_kinds small_calls host_resident}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/prof_cfg

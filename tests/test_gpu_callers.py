@@ -108,6 +108,35 @@ def test_interpolate_random_vs_oracle(vtype):
                 cmp_out("val %s n=%d prev=%s" % (kind, n, prev is not None), got[1], want[1])
 
 
+@pytest.mark.parametrize("base_ts", [0, 1_700_000_000_000, -(1 << 40), (1 << 52)])
+def test_interpolate_frames_spanning_more_than_2_31(base_ts):
+    """millisecond / microsecond timestamps: the frame spans far more than 2^31 from its first window start (round 2's wave kernels
+    declined that: every row had to lie within 2^31 of s0).  interp_wave3_kernel's arithmetic is relative to each 512-row trip;
+    a single trip that spans more (a gap of 3e9 inside it) is redone by the workgroup kernel.  All kernels bit for bit + the oracle."""
+    rng = np.random.default_rng(17)
+    n = 40_000
+    step = rng.integers(1, 200_000, n)
+    for with_jump in (False, True):
+        st = step.copy()
+        if with_jump:
+            st[n // 2] = 3_000_000_000
+        ts = np.cumsum(st).astype(np.int64) + base_ts
+        assert int(ts[-1]) - int(ts[0]) > (1 << 32)
+        vals = np.round(rng.standard_normal(n) * 100, 2)
+        valid = rng.random(n) >= 0.3
+        bm = np.packbits(valid, bitorder="little")
+        for interval, offset in ((60_000, 0), (1_000_000, 7), (10_000_000, -3)):
+            if with_jump and interval < 1_000_000:
+                continue       # (millions of empty windows behind the jump: covered by the empty-window-runs test at a friendlier size)
+            for kind in ("Linear", "StepPrevious"):
+                ip = [{"kind": "WindowStart", "col": 0}, {"kind": kind, "col": 1}]
+                got = both_interp_kernels(lambda: capi.rolling_interpolate([capi.Column(ts), capi.Column(vals, bm, capi.FLOAT64, 0, n, -1)], 0,
+                                                                           interval, ip, offset=offset))
+                want = orc.interpolate([orc.Column(ts, None, orc.INT64), orc.Column(vals, bm, orc.FLOAT64)], 0, interval, ip, offset=offset)
+                cmp_out("wide ts %s I=%d jump=%s" % (kind, interval, with_jump), got[0], want[0])
+                cmp_out("wide val %s I=%d jump=%s" % (kind, interval, with_jump), got[1], want[1])
+
+
 def test_interpolate_empty_window_runs_and_the_minus_one_sentinel():
     # (1) long runs of empty windows (thousands of synthetic rows in front of one row, more than a tile stages in LDS);
     # (2) the reference's sentinel: an EMPTY window whose start is -1 gets no synthetic row, because "no first value" is
