@@ -1109,17 +1109,18 @@ static int job_run(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, i
     const bool nlo = (route & BOWGPU_ROUTE_NO_LONG_ONLY) != 0;
     const bool cls = (route & BOWGPU_ROUTE_LONG_CLASSIC) != 0;      // test / A-B switches: only the bisection + per-window chunks form ...
     const bool sall = (route & BOWGPU_ROUTE_LONG_STREAM_ALL) != 0;  // ... / the streaming form for every reducer set
-    // Which form?  The streaming segmented-scan form (one read, from 128 rows per window on average) when the reducers need only
-    // {sum, count} partials - Sum / ArithmeticMean / Count / WindowStart / NumRows: 0.27 - 0.33 ms per 1e8 rows.  Its instantiations
-    // that also scan extrema, first / last rows or the time-weighted terms are correct but slower than the bisection form today
-    // (1e8 rows, 1000-row windows: Min/Max 0.68 vs 0.46 ms, time-weighted 1.8 vs 0.72 ms), so those sets keep the bisection form,
-    // from 512 rows per window on, as do calls of a handful of giant windows.
+    // Which form?  The streaming form - one read of the rows, long_windows.hip long_short_kernel / long_stream_kernel - for every
+    // reducer set: from 128 rows per window on average when the reducers need only {sum, count} partials (Sum / ArithmeticMean /
+    // Count / WindowStart / NumRows), from 256 when they also need extrema, first / last rows or the time-weighted terms (below
+    // that its chunks hold several boundaries each and the tile kernels win: 1e8 rows, 128-row windows, Min + Max 0.84 against
+    // 0.47 ms).  1e8 rows, 1000-row windows: 0.29 - 0.40 ms against 0.44 - 0.72 ms for the bisection form, which keeps the calls of
+    // a handful of giant windows (from 32768 rows per window: the streaming form's final merge walks a window's chunks serially).
     bool lite_set = true;
     for (int sl = 0; sl < P.ncols; sl++)
         if ((P.pass_flags[sl + 1] & (kPassMinMax | kPassFirstLast)) || P.cols[sl].need_ts) lite_set = false;
     const int64_t avg_rows = W > 0 ? P.n / W : 0;
     const bool classic_only = cls;
-    const bool stream_ok = !classic_only && (lite_set || sall) && avg_rows >= kLongOnlyAvgRows &&
+    const bool stream_ok = !classic_only && avg_rows >= ((lite_set || sall) ? kLongOnlyAvgRows : kLongStreamAnyAvgRows) &&
                            avg_rows < kLongClassicAvgRows && W < (1ll << 32);
     const bool classic_ok = avg_rows >= kLongBisectAvgRows;
     if (allow_long_only && plan && W > 0 && P.wid_base == 0 && (stream_ok || classic_ok) && !nlo) {

@@ -457,8 +457,11 @@ def test_streaming_form_chunk_edges():
     cols = [capi.Column(ts), capi.Column(f, np.packbits(fv, bitorder="little"), capi.FLOAT64, 0, len(ts), -1)]
     capi.rolling_aggregate(cols, 0, 1000, [("WindowStart", 0), ("ArithmeticMean", 1), ("Sum", 1), ("Count", 1)])
     assert capi.last_kernel_name() == "long_stream_kernel"
-    capi.rolling_aggregate(cols, 0, 1000, base_aggs)       # extrema / first / last: the bisection form is the faster one today
-    assert capi.last_kernel_name() == "long_partial_kernel"
+    capi.rolling_aggregate(cols, 0, 1000, base_aggs)       # extrema / first / last / time-weighted terms: the streaming form too
+    assert capi.last_kernel_name() == "long_stream_kernel"
+    with capi.route(capi.ROUTE_LONG_CLASSIC):               # (the bisection form stays reachable)
+        capi.rolling_aggregate(cols, 0, 1000, base_aggs)
+        assert capi.last_kernel_name() == "long_partial_kernel"
 
 
 def test_nanosecond_timestamps_beyond_2_53():
