@@ -253,7 +253,7 @@ constexpr int kLongStreamRows = 512;  // chunk of the streaming form of the long
 constexpr int64_t kLongOnlyAvgRows = 128;   // windows averaging at least this many rows skip the tile kernels: streaming form (api.cpp job_run)
 constexpr int64_t kLongStreamAnyAvgRows = 256;   // ... from here on for every reducer set (extrema, first / last, time-weighted terms)
 constexpr int64_t kLongBisectAvgRows = 512; // ... bisection form where the streaming form does not apply (BOWGPU_ROUTE_LONG_CLASSIC; W >= 2^32)
-constexpr int64_t kLongClassicAvgRows = 32768;   // ... and from here on the handful of giant windows go by bisection + per-window chunks
+constexpr int64_t kLongClassicAvgRows = 1ll << 22;   // ... and from here on the handful of giant windows go by bisection + per-window chunks
 constexpr int kLongLists = 64;      // sub-lists of the long-window queue (agg_device.h push_long_window)
 constexpr int kLongCountWord = 16;  // status[kLongCountWord + s] = entries in sub-list s
 constexpr int kStatusWords = kLongCountWord + kLongLists;

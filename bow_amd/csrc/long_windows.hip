@@ -1487,7 +1487,15 @@ __global__ __launch_bounds__(256) void stream_final_kernel(const AggParams p, co
     if (rec.rows >= 0) {
         le.r1 = rec.r0 + rec.rows;
     } else {
-        for (int64_t c = g + 1; c <= g + kStreamScan; c++) {
+        // the window ends where the next window that has rows starts (rows are ascending, the windows partition them) ...
+        for (int64_t kk = k + 1; kk <= k + 8; kk++) {
+            if (kk >= p.W) { le.r1 = p.n; break; }
+            const int64_t rs = recs[kk].r0;
+            if (rs >= 0) { le.r1 = rs; break; }
+        }
+        if (le.r1 >= 0) w1 = 2 * ((le.r1 - 1) / kStreamRows) + 1;    // (its last row's chunk: the head partial of that chunk is its last partial)
+        // ... or, behind a run of empty windows, where the first chunk head ends that does not cover its chunk
+        else for (int64_t c = g + 1; c <= g + kStreamScan; c++) {
             if (c >= nchunks) { le.r1 = p.n; w1 = 2 * nchunks; break; }
             const int64_t rows_c = p.n - c * kStreamRows < kStreamRows ? p.n - c * kStreamRows : kStreamRows;
             const int64_t hr = meta[c].head_rows;
@@ -1511,6 +1519,68 @@ __global__ __launch_bounds__(256) void stream_final_kernel(const AggParams p, co
             else for (int64_t w = w0; w < w1; w++) part_merge(acc, part_at(parts, w * p.ncols + slot, lite));
         }
         emit_window(p, slot, le, acc);
+    }
+}
+
+// The same for windows of many chunks: kT (64 / 256) threads per window - the next window that has rows is looked for 64 records
+// at a time, the window's partials are merged kT at a time, then over the lanes (and the workgroup's four wavefronts).
+template <int kT>
+__global__ __launch_bounds__(256) void stream_final_wide_kernel(const AggParams p, const int64_t nchunks, const ChunkMeta *meta, const Part *parts,
+                                                                const WinRec *recs, const Part *wparts, const int lite) {
+    __shared__ Part red[4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int t = kT == 64 ? lane : tid;
+    const int64_t k = kT == 64 ? (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(tid >> 6) : (int64_t)blockIdx.x;
+    if (k >= p.W) return;
+    const WinRec rec = recs[k];
+    LongEntry le;
+    le.wid = (uint64_t)(p.wid_base + k); le.r0 = rec.r0; le.r1 = -1; le.next_wid = le.wid + 1; le.incl_row = 0; le.dead = 0;
+    if (rec.r0 < 0) {
+        if (t == 0)
+            for (int slot = -1; slot < p.ncols; slot++)
+                if (p.pass_mask[slot + 1]) emit_empties(p, slot, le, 0, 0, 1);
+        return;
+    }
+    const int64_t w0 = 2 * (int64_t)rec.chunk + 1;
+    int64_t w1 = w0;
+    if (rec.rows >= 0) le.r1 = rec.r0 + rec.rows;
+    else {
+        for (int64_t kb = k + 1; le.r1 < 0; kb += 64) {
+            const int64_t kk = kb + lane;
+            const int64_t rs = kk < p.W ? recs[kk].r0 : p.n;       // (behind the call's last window: the end of the rows)
+            const uint64_t m = __ballot(rs >= 0);
+            if (m) {
+                const int l = __ffsll((long long)m) - 1;
+                le.r1 = (int64_t)((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)rs, l) |
+                                  (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)rs >> 32), l) << 32);
+            }
+        }
+        w1 = 2 * ((le.r1 - 1) / kStreamRows) + 1;
+    }
+    if (p.inclusive || p.pre_rows) entry_close(p, le);
+    for (int slot = -1; slot < p.ncols; slot++) {
+        if (p.pass_mask[slot + 1] == 0) continue;
+        Part acc;
+        part_init(acc);
+        if (slot >= 0 && (p.pass_flags[slot + 1] & kPassNeedVals)) {
+            if (rec.rows >= 0) {
+                if (t == 0) acc = part_at(wparts, k * p.ncols + slot, lite);
+            } else {
+                for (int64_t w = w0 + t; w < w1; w += kT) part_merge(acc, part_at(parts, w * p.ncols + slot, lite));
+                if (kT == 256) block_reduce(acc, red, tid);
+                else
+                    for (int o = 32; o > 0; o >>= 1) {
+                        Part other;
+                        other.sum = __shfl_down(acc.sum, o); other.trap = __shfl_down(acc.trap, o); other.step = __shfl_down(acc.step, o);
+                        other.vmin = __shfl_down(acc.vmin, o); other.vmax = __shfl_down(acc.vmax, o);
+                        other.count = __shfl_down((long long)acc.count, o);
+                        other.min_idx = __shfl_down((long long)acc.min_idx, o); other.max_idx = __shfl_down((long long)acc.max_idx, o);
+                        other.first_idx = __shfl_down((long long)acc.first_idx, o); other.last_idx = __shfl_down((long long)acc.last_idx, o);
+                        if (lane + o < 64) part_merge(acc, other);
+                    }
+            }
+        }
+        if (t == 0) emit_window(p, slot, le, acc);
     }
 }
 
@@ -1600,10 +1670,20 @@ int launch_long_stream(Ctx *c, const AggParams &p, void *workspace) {
     else if (!(need & 1)) BG_LONG_STREAM(6);
     else BG_LONG_STREAM(7);
 #undef BG_LONG_STREAM
-    hipLaunchKernelGGL(stream_final_kernel, dim3((unsigned)((p.W + 255) / 256)), dim3(256), 0, c->stream, p, nchunks, meta, parts, recs, wparts,
-                       entries, off0, off1, n_leftover, need == 0 ? 1 : 0);
-    hipLaunchKernelGGL(long_final_block_kernel, dim3((unsigned)(nch < 2048 ? nch : 2048)), dim3(256), 0, c->stream, p, entries, off0, off1,
-                       parts, (const int32_t *)nullptr, n_leftover, nchunks, need == 0 ? 1 : 0);
+    // the windows' partials merged and the reducers finished: a lane per window while windows span a few chunks, a wavefront / a
+    // workgroup per window beyond that
+    const int64_t avg_rows = p.n / p.W;
+    if (avg_rows < 8 * kStreamRows) {
+        hipLaunchKernelGGL(stream_final_kernel, dim3((unsigned)((p.W + 255) / 256)), dim3(256), 0, c->stream, p, nchunks, meta, parts, recs, wparts,
+                           entries, off0, off1, n_leftover, need == 0 ? 1 : 0);
+        hipLaunchKernelGGL(long_final_block_kernel, dim3((unsigned)(nch < 2048 ? nch : 2048)), dim3(256), 0, c->stream, p, entries, off0, off1,
+                           parts, (const int32_t *)nullptr, n_leftover, nchunks, need == 0 ? 1 : 0);
+    } else if (avg_rows < 128 * kStreamRows)
+        hipLaunchKernelGGL(stream_final_wide_kernel<64>, dim3((unsigned)((p.W + 3) / 4)), dim3(256), 0, c->stream, p, nchunks, meta, parts, recs,
+                           wparts, need == 0 ? 1 : 0);
+    else
+        hipLaunchKernelGGL(stream_final_wide_kernel<256>, dim3((unsigned)p.W), dim3(256), 0, c->stream, p, nchunks, meta, parts, recs, wparts,
+                           need == 0 ? 1 : 0);
     BG_HIP(hipGetLastError());
     return 0;
 }
