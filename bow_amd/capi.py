@@ -56,7 +56,7 @@ class Agg(C.Structure):
 
 
 class Options(C.Structure):
-    _fields_ = [("offset", C.c_int64), ("inclusive", C.c_int32), ("_pad", C.c_int32)]
+    _fields_ = [("offset", C.c_int64), ("inclusive", C.c_int32), ("strict_order", C.c_int32)]
 
 
 class AggInfo(C.Structure):
@@ -495,16 +495,17 @@ def plan_windows_ex(ts, interval, offset=0):
     return p
 
 
-def rolling_aggregate(cols, ts_col, interval, aggs, offset=0, inclusive=False, out_residency=HOST, outs=None, plan=None):
+def rolling_aggregate(cols, ts_col, interval, aggs, offset=0, inclusive=False, out_residency=HOST, outs=None, plan=None, strict_order=False):
     """Returns (list[OutColumn], AggInfo).  aggs: [(kind, col[, factors])].  plan: a Plan from plan_windows_ex on this
-    interval column (the call then skips its own round trip for the first / last timestamp)."""
+    interval column (the call then skips its own round trip for the first / last timestamp).  strict_order: every window in the
+    reference's row order or BOWGPU_ERR_UNSUPPORTED (bowgpu_options.strict_order)."""
     if outs is None:
         W = plan.num_windows if plan is not None else plan_windows(cols[ts_col], interval, offset)[1]
         outs = [OutColumn(W, out_residency) for _ in aggs]
     oarr = (Out * max(len(aggs), 1))()
     for i, o in enumerate(outs):
         oarr[i] = o.c()
-    opts = Options(offset, int(bool(inclusive)), 0)
+    opts = Options(offset, int(bool(inclusive)), int(bool(strict_order)))
     info = AggInfo()
     if plan is not None:
         check(lib().bowgpu_rolling_aggregate_planned(_cols(cols), len(cols), ts_col, C.byref(plan), C.byref(opts),

@@ -720,6 +720,7 @@ struct AggJob {
     bool check_plan = false;    // the plan came from the caller (bowgpu_rolling_aggregate_planned): the pass checks it against the column
 };
 static thread_local bool g_plan_from_caller = false;   // set around run_aggregate by the planned entry point
+static thread_local bool g_strict_order = false;   // bowgpu_options.strict_order of the call in progress (or BOWGPU_ROUTE_STRICT_ORDER)
 
 static void pending_drop(Ctx *c);   // a pass put in flight by bowgpu_shard_pass_begin and not collected: settled before the scratch is reused
 
@@ -1106,7 +1107,7 @@ static int job_run(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, i
     // for long_windows.hip by a tile kernel that reads every row just to find that out.  Skip it: order check of the interval
     // column + every window as an entry of the multi-workgroup reduction.  (BOWGPU_ROUTE_NO_LONG_ONLY: test switch.)
     const uint32_t route = route_mask();
-    const bool nlo = (route & BOWGPU_ROUTE_NO_LONG_ONLY) != 0;
+    const bool nlo = (route & BOWGPU_ROUTE_NO_LONG_ONLY) != 0 || g_strict_order;
     const bool cls = (route & BOWGPU_ROUTE_LONG_CLASSIC) != 0;      // test / A-B switches: only the bisection + per-window chunks form ...
     const bool sall = (route & BOWGPU_ROUTE_LONG_STREAM_ALL) != 0;  // ... / the streaming form for every reducer set
     // Which form?  The streaming form - one read of the rows, long_windows.hip long_short_kernel / long_stream_kernel - for every
@@ -1208,6 +1209,13 @@ static int job_pass_complete(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_
     if (hstat[2]) return fail(BOWGPU_ERR_HIP, "internal: long-window list overflow");
     int64_t n_long = 0;
     {
+        if (g_strict_order) {
+            int64_t queued = 0;
+            for (int s = 0; s < kLongLists; s++) queued += hstat[kLongCountWord + s];
+            if (queued > 0)
+                return fail(BOWGPU_ERR_UNSUPPORTED, "strict_order: %lld window(s) are longer than a tile's look-ahead (128 rows) and would be reduced order-free",
+                            (long long)queued);
+        }
         BG_TRY(run_long_windows(c, P, hstat, &n_long));
         if (n_long > 0 && finish) {
             BG_TRY(job_enqueue_tail(c, job, aggs, naggs));
@@ -1770,7 +1778,10 @@ int bowgpu_rolling_aggregate(const bowgpu_col *cols, int32_t ncols, int32_t ts_c
     // reference order: the Rolling exists first (newIntervalRolling errors), then Aggregate validates
     Plan plan;
     BG_TRY(plan_make(nullptr, &cols[ts_col], interval, o.offset, &plan));
-    return aggregate_with_plan(cols, ncols, ts_col, plan, o.inclusive, aggs, naggs, outs, info);
+    g_strict_order = o.strict_order != 0 || (route_mask() & BOWGPU_ROUTE_STRICT_ORDER) != 0;
+    const int rc = aggregate_with_plan(cols, ncols, ts_col, plan, o.inclusive, aggs, naggs, outs, info);
+    g_strict_order = false;
+    return rc;
 }
 
 int bowgpu_plan_windows_ex(const bowgpu_col *ts, int64_t interval, int64_t offset, bowgpu_plan *out) {
@@ -1806,8 +1817,10 @@ int bowgpu_rolling_aggregate_planned(const bowgpu_col *cols, int32_t ncols, int3
     plan.first_ts = pl->first_ts; plan.last_ts = pl->last_ts;
     plan.magic = magic_make((uint64_t)pl->interval);
     g_plan_from_caller = ts->length > 0;
+    g_strict_order = (opts && opts->strict_order != 0) || (route_mask() & BOWGPU_ROUTE_STRICT_ORDER) != 0;
     const int rc = aggregate_with_plan(cols, ncols, ts_col, plan, opts ? opts->inclusive : 0, aggs, naggs, outs, info);
     g_plan_from_caller = false;
+    g_strict_order = false;
     return rc;
 }
 
@@ -1819,7 +1832,7 @@ int bowgpu_rolling_aggregate_planned(const bowgpu_col *cols, int32_t ncols, int3
 
 static int shard_check(const bowgpu_col *cols, int32_t ncols, const bowgpu_agg *aggs, int32_t naggs, bowgpu_out *outs,
                        const bowgpu_options *o) {
-    (void)o;
+    if (o && o->strict_order) return fail(BOWGPU_ERR_UNSUPPORTED, "sharded aggregate: strict_order is not offered (carries and long windows merge order-free)");
     for (int i = 0; i < naggs; i++) {
         // a window cut by a shard boundary needs all its rows in one place: Mode has no constant-size partial state
         if (aggs[i].kind == BOWGPU_AGG_MODE) return fail(BOWGPU_ERR_UNSUPPORTED, "sharded aggregate: Mode is not a mergeable reducer");

@@ -125,7 +125,11 @@ typedef struct bowgpu_agg {
 typedef struct bowgpu_options {
     int64_t offset;
     int32_t inclusive;
-    int32_t _pad;
+    int32_t strict_order;       /* not in the reference.  != 0: every window is reduced in the reference's left-to-right row order or the
+                                   call is declined - no order-free form (bowgpu_agg_info.long_windows is 0 on success).  Windows that
+                                   a tile cannot hold (longer than its 128-row look-ahead) make the call BOWGPU_ERR_UNSUPPORTED instead
+                                   of being summed as a tree; honoured by bowgpu_rolling_aggregate[_planned], declined (same code) by
+                                   the bowgpu_shard_* protocol.  0: see bowgpu_agg_info.long_windows for the bound that applies */
 } bowgpu_options;
 
 /* Diagnostics of one aggregate call */
@@ -135,10 +139,16 @@ typedef struct bowgpu_agg_info {
     int32_t new_interval_col;   /* index of the LAST aggregator reading the interval column (aggregation.go:152-161) */
     int32_t inclusive;          /* effective Options.Inclusive after validateAggregation (aggregation.go:183-185) */
     int64_t long_windows;       /* windows reduced in an ORDER-FREE form instead of the reference's left-to-right walk: windows longer
-                                   than a tile's look-ahead (128 rows), and every window of a call whose windows average >= 128
-                                   rows.  THE STATED TOLERANCE: Sum / ArithmeticMean / Integral* / WeightedAverage* of those windows
-                                   are within 1e-12 relative of the reference (fixed, deterministic summation tree); every other
-                                   reducer, and every window when this is 0, is bit-exact */
+                                   than a tile's look-ahead (128 rows), and every window of a call whose windows average >= 128 rows
+                                   ({sum, count} reducer sets; >= 256 rows for the others).  THE STATED TOLERANCE, for the float sums
+                                   of those windows (u = 2^-53, n = the window's rows, x = its valid values, T = its time-weighted
+                                   terms):   |Sum - ref| <= 2 (n + 2) u SUM|x_i|;   ArithmeticMean: that / count + 2 u |ref|;
+                                   Integral*: 4 (n + 2) u SUM|T_i| (a Factor scales it);   WeightedAverage*: that / (t_last - t_first)
+                                   + 2 u |ref|.  A bound on SUM|x|, not on |ref|: a window whose values cancel may differ from the
+                                   reference in every digit of a result near zero (tests/tolerance.py states and asserts it, a
+                                   cancelling window included).  The summation tree is fixed: equal inputs give equal bits.  Every
+                                   other reducer, and every window when this is 0, is bit-exact.  bowgpu_options.strict_order
+                                   declines instead */
     double kernel_ms;           /* device time of the kernels of this call (HIP events on the library stream) */
 } bowgpu_agg_info;
 

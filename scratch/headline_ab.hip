@@ -339,11 +339,11 @@ __global__ __launch_bounds__(64 * WPB) void rw_ceiling_kernel(const uint64_t *__
 // sum / count go on in row order in the next iteration: bit-exact however long the window is).  The window open at the end
 // of the range is finished by its owner reading on in 128-row steps.
 // HOT: stores go to a 4 KB region (no HBM write traffic; diagnostic).  OSTG: results staged in LDS, flushed as aligned 16-B stores.
-template <int HOT, int OSTG, int NTL, int DEFER = 0>
+template <int HOT, int OSTG, int NTL, int DEFER = 0, int STG = 256>     // STG: staged results per output (power of two ring); flushed in bursts of STG / 2
 __global__ __launch_bounds__(64) void stream_kernel(const P p, const int64_t nranges, const int64_t ranges_per_xcd, const int KT) {
     constexpr int TILE = 512, CH = 4;
     constexpr int SEGCAP = 512;
-    constexpr int STG = 256;                 // staged results per output (power of two ring)
+    constexpr int FL = STG / 2;
     __shared__ uint64_t s_val[TILE];
     __shared__ uint32_t s_seg[SEGCAP + 2];
     __shared__ uint64_t s_out[OSTG ? 2 * STG : 2];
@@ -403,20 +403,26 @@ __global__ __launch_bounds__(64) void stream_kernel(const P p, const int64_t nra
     auto flush = [&](bool all) {   // staged ring -> global, 16 B per lane on even slots; keeps a tail < 2 * 64 unless `all`
         if (!OSTG) return;
         lds_order();
-        while (stg_n >= 128 || (all && stg_n > 0)) {
-            int take = stg_n >= 128 ? 128 : stg_n;
+        while (stg_n >= FL || (all && stg_n > 0)) {
+            int take = stg_n >= FL ? FL : stg_n;
             const int odd = (int)(stg_w0 & 1u);
             if (odd) {
                 if (lane == 0) store_pair(stg_w0, s_out[stg_w0 & (STG - 1)], s_out[STG + (stg_w0 & (STG - 1))]);
                 stg_w0++; stg_n--; take--;
                 if (take == 0) continue;
             }
-            const int npair = take >> 1;   // <= 64
-            if (lane < npair) {
-                const uint32_t w = stg_w0 + 2 * lane;
+            const int npair = take >> 1;   // <= FL / 2
+            // one output column after the other: each a contiguous burst of up to FL * 8 bytes
+            for (int q = lane; q < npair; q += 64) {
+                const uint32_t w = stg_w0 + 2 * q;
                 const uint32_t i0 = w & (STG - 1), i1 = (w + 1) & (STG - 1);
                 const uint32_t o = HOT ? (w & 255u) : w;
                 *reinterpret_cast<ulonglong2 *>(&p.out_ws[o]) = make_ulonglong2(s_out[i0], s_out[i1]);
+            }
+            for (int q = lane; q < npair; q += 64) {
+                const uint32_t w = stg_w0 + 2 * q;
+                const uint32_t i0 = w & (STG - 1), i1 = (w + 1) & (STG - 1);
+                const uint32_t o = HOT ? (w & 255u) : w;
                 *reinterpret_cast<ulonglong2 *>(&p.out_mean[o]) = make_ulonglong2(s_out[STG + i0], s_out[STG + i1]);
             }
             stg_w0 += 2 * npair; stg_n -= 2 * npair;
@@ -509,7 +515,7 @@ __global__ __launch_bounds__(64) void stream_kernel(const P p, const int64_t nra
                         if (stg_n == 0) stg_w0 = wq;
                         if (closes) { s_out[wid & (STG - 1)] = ws_bits; s_out[STG + (wid & (STG - 1))] = mean_bits; }
                         stg_n += __popcll(cm);
-                        if (stg_n >= 128) flush(false);
+                        if (stg_n >= FL) flush(false);
                     } else {
                         flush(true);
                         if (closes) store_pair(wid, ws_bits, mean_bits);
@@ -592,12 +598,94 @@ __global__ __launch_bounds__(64) void stream_kernel(const P p, const int64_t nra
     if (bad && lane == 0) atomicOr(&p.status[0], 1u);
 }
 
-template <int KT, int HOT, int OSTG, int NTL, int DEFER = 0>
+template <int KT, int HOT, int OSTG, int NTL, int DEFER = 0, int STG = 256>
 static void launch_stream(const P &p, hipStream_t st) {
     const int64_t rows = (int64_t)KT * 512;
     const int64_t nr = (p.n + rows - 1) / rows;
     const int64_t per_xcd = (nr + 7) / 8;
-    hipLaunchKernelGGL((stream_kernel<HOT, OSTG, NTL, DEFER>), dim3((unsigned)(per_xcd * 8)), dim3(64), 0, st, p, nr, per_xcd, KT);
+    hipLaunchKernelGGL((stream_kernel<HOT, OSTG, NTL, DEFER, STG>), dim3((unsigned)(per_xcd * 8)), dim3(64), 0, st, p, nr, per_xcd, KT);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The probe with TEMPORALLY CLUSTERED writes: one wavefront walks KT consecutive 512-row tiles (the next tile's loads in flight
+// while the current one is folded), stages the dense shape's outputs (51.2 slots per tile and column) in an LDS ring and flushes
+// FL slots per column at a time - FL * 8 contiguous bytes, 16 B per lane, one column after the other.  No arithmetic but the xor:
+// what the write pattern alone is worth.
+template <int NT, int FL>
+__global__ __launch_bounds__(64) void rw_burst_kernel(const uint64_t *__restrict__ a, const uint64_t *__restrict__ b, uint64_t *__restrict__ o0,
+                                                      uint64_t *__restrict__ o1, const int64_t n, const int64_t nranges, const int64_t ranges_per_xcd, const int KT) {
+    constexpr int STG = 2 * FL;
+    __shared__ uint64_t ring[2][STG];
+    const int64_t bb = blockIdx.x;
+    const int64_t rg = (bb & 7) * ranges_per_xcd + (bb >> 3);
+    if (rg >= nranges) return;
+    const int lane = threadIdx.x;
+    const int64_t rbase = rg * (int64_t)KT * 512;
+    const int nit = (int)((((rbase + (int64_t)KT * 512 < n ? rbase + (int64_t)KT * 512 : n) - rbase) / 512));
+    ulonglong2 A0[4], B0[4], A1[4], B1[4];
+    auto load_set = [&](int it, ulonglong2 (&A)[4], ulonglong2 (&B)[4]) {
+        const ulonglong2 *pa = reinterpret_cast<const ulonglong2 *>(a + rbase + (int64_t)it * 512) + lane, *pb = reinterpret_cast<const ulonglong2 *>(b + rbase + (int64_t)it * 512) + lane;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { A[j] = NT ? nt_load(pa + 64 * j) : pa[64 * j]; B[j] = NT ? nt_load(pb + 64 * j) : pb[64 * j]; }
+    };
+    int64_t stg_w0 = (rbase + 9) / 10;
+    int stg_n = 0;
+    auto flush = [&](bool all) {
+        lds_order();
+        while (stg_n >= FL || (all && stg_n > 0)) {
+            int take = stg_n >= FL ? FL : stg_n;
+            if (stg_w0 & 1) {
+                if (lane == 0) { o0[stg_w0] = ring[0][stg_w0 & (STG - 1)]; o1[stg_w0] = ring[1][stg_w0 & (STG - 1)]; }
+                stg_w0++; stg_n--; take--;
+                if (take == 0) continue;
+            }
+            const int npair = take >> 1;
+            for (int q = lane; q < npair; q += 64) {
+                const int64_t w = stg_w0 + 2 * q;
+                *reinterpret_cast<ulonglong2 *>(&o0[w]) = make_ulonglong2(ring[0][w & (STG - 1)], ring[0][(w + 1) & (STG - 1)]);
+            }
+            for (int q = lane; q < npair; q += 64) {
+                const int64_t w = stg_w0 + 2 * q;
+                *reinterpret_cast<ulonglong2 *>(&o1[w]) = make_ulonglong2(ring[1][w & (STG - 1)], ring[1][(w + 1) & (STG - 1)]);
+            }
+            stg_w0 += 2 * npair; stg_n -= 2 * npair;
+            if ((take & 1) && all) {
+                if (lane == 0) { o0[stg_w0] = ring[0][stg_w0 & (STG - 1)]; o1[stg_w0] = ring[1][stg_w0 & (STG - 1)]; }
+                stg_w0++; stg_n--;
+            } else if (take & 1) break;
+        }
+        lds_order();
+    };
+    auto process = [&](int it, ulonglong2 (&A)[4], ulonglong2 (&B)[4]) {
+        const uint64_t x = A[0].x ^ A[0].y ^ A[1].x ^ A[1].y ^ A[2].x ^ A[2].y ^ A[3].x ^ A[3].y;
+        const uint64_t y = B[0].x ^ B[0].y ^ B[1].x ^ B[1].y ^ B[2].x ^ B[2].y ^ B[3].x ^ B[3].y;
+        const int64_t base = rbase + (int64_t)it * 512;
+        const int64_t slot0 = (base + 9) / 10, slot1 = (base + 512 + 9) / 10;
+        if (slot0 + lane < slot1) { ring[0][(slot0 + lane) & (STG - 1)] = x; ring[1][(slot0 + lane) & (STG - 1)] = y; }
+        stg_n += (int)(slot1 - slot0);
+        if (stg_n >= FL) flush(false);
+    };
+    int it = 0;
+    if (nit > 0) {
+        load_set(0, A0, B0);
+        while (true) {
+            if (it + 1 < nit) load_set(it + 1, A1, B1);
+            process(it, A0, B0);
+            if (++it >= nit) break;
+            if (it + 1 < nit) load_set(it + 1, A0, B0);
+            process(it, A1, B1);
+            if (++it >= nit) break;
+        }
+    }
+    flush(true);
+}
+template <int KT, int NT, int FL>
+static void launch_rw_burst(const P &p, hipStream_t st) {
+    const int64_t rows = (int64_t)KT * 512;
+    const int64_t nr = (p.n + rows - 1) / rows;
+    const int64_t per_xcd = (nr + 7) / 8;
+    hipLaunchKernelGGL((rw_burst_kernel<NT, FL>), dim3((unsigned)(per_xcd * 8)), dim3(64), 0, st, reinterpret_cast<const uint64_t *>(p.ts), p.val, p.out_ws,
+                       p.out_mean, p.n, nr, per_xcd, KT);
 }
 
 __global__ __launch_bounds__(256) void ws_fill_kernel(uint64_t *out, int64_t W, int64_t s0, int64_t interval) {
@@ -701,6 +789,15 @@ int main(int argc, char **argv) {
     V("rw_reg_st7_lds", (launch_rw<0, 0, 1, 7>), false);
     V("rw_reg_st4_none", (launch_rw<0, 0, 1, 4>), false);
     V("rw_regnt_st4_none", (launch_rw<0, 1, 1, 4>), false);
+    // round 3: temporally clustered writes (K consecutive tiles per wavefront, bursts of FL slots = FL * 8 bytes per output column)
+    V("burst_rw_k8_1k", (launch_rw_burst<8, 1, 128>), false);
+    V("burst_rw_k8_2k", (launch_rw_burst<8, 1, 256>), false);
+    V("burst_rw_k16_4k", (launch_rw_burst<16, 1, 512>), false);
+    V("burst_rw_k32_8k", (launch_rw_burst<32, 1, 1024>), false);
+    V("burst_stream_k4_1k", (launch_stream<4, 0, 1, 1, 0, 256>), true);
+    V("burst_stream_k8_2k", (launch_stream<8, 0, 1, 1, 0, 512>), true);
+    V("burst_stream_k16_4k", (launch_stream<16, 0, 1, 1, 0, 1024>), true);
+    V("burst_stream_k16_direct", (launch_stream<16, 0, 0, 1, 0, 256>), true);
     if (only) {   // comma-separated substrings
         std::vector<std::string> pats;
         std::string o(only);

@@ -1053,3 +1053,55 @@ def test_pinned_zero_copy_residency_equals_the_other_residencies():
     with pytest.raises(capi.BowGpuError) as e:
         capi.rolling_aggregate(bogus, 0, 10, aggs[:2])
     assert e.value.code == -10
+
+
+def test_strict_order_and_the_pinned_form_thresholds():
+    """bowgpu_options.strict_order: every window in the reference's row order (bit-exact, long_windows == 0) or the call is declined.
+    And the window lengths at which a call changes form (common.h kLongOnlyAvgRows = 128 for {sum, count} reducer sets,
+    kLongStreamAnyAvgRows = 256 for the others) - a change of these is a change of which calls are bit-exact."""
+    rng = np.random.default_rng(77)
+    n = 128 * 2400          # (whole windows of 128 and of 256 rows: the averages are the window lengths)
+    ts = np.arange(n, dtype=np.int64)
+    f = rng.standard_normal(n)
+    cols = [capi.Column(ts, None, capi.INT64), capi.Column(f, None, capi.FLOAT64)]
+    ocols = [orc.Column(ts, None, orc.INT64), orc.Column(f, None, orc.FLOAT64)]
+    lite = [("WindowStart", 0), ("Sum", 1), ("ArithmeticMean", 1)]
+    more = [("WindowStart", 0), ("Sum", 1), ("Min", 1), ("WeightedAverageStep", 1)]
+    # which form runs where
+    for aggs, interval, kernel in ((lite, 127, "rolling_simple_kernel"), (lite, 128, "long_stream_kernel"), (more, 255, None),
+                                   (more, 256, "long_stream_kernel"), (more, 1000, "long_stream_kernel")):
+        outs, info = capi.rolling_aggregate(cols, 0, interval, aggs)
+        name = capi.last_kernel_name()
+        if kernel is None:
+            assert not name.startswith("long_stream"), (interval, name)
+        else:
+            assert name == kernel, (interval, name)
+        assert (info.long_windows == info.num_windows) == name.startswith("long_"), (interval, name, info.long_windows)
+    # strict order: short windows are exact either way ...
+    for interval in (10, 100):
+        exp, _ = orc.aggregate(ocols, 0, interval, more)
+        outs, info = capi.rolling_aggregate(cols, 0, interval, more, strict_order=True)
+        assert info.long_windows == 0
+        for k, g, w in zip(_names(more), outs, exp):
+            compare("strict %s I=%d" % (k, interval), g, w, exact=True)
+    # ... and windows no tile can hold are declined, whatever the reducer set, planned or not, per call or per thread
+    for aggs in (lite, more):
+        for interval in (1000, 100_000):
+            with pytest.raises(capi.BowGpuError) as e:
+                capi.rolling_aggregate(cols, 0, interval, aggs, strict_order=True)
+            assert e.value.code == -9 and "strict_order" in e.value.message, (interval, e.value.message)
+        # (128-row windows: the streaming form by default for the {sum, count} set, but a tile still holds them - in row order)
+        exp, _ = orc.aggregate(ocols, 0, 128, aggs)
+        outs, info = capi.rolling_aggregate(cols, 0, 128, aggs, strict_order=True)
+        assert info.long_windows == 0 and not capi.last_kernel_name().startswith("long_")
+        for k, g, w in zip(_names(aggs), outs, exp):
+            compare("strict %s I=128" % k, g, w, exact=True)
+    plan = capi.plan_windows_ex(cols[0], 1000, 0)
+    with pytest.raises(capi.BowGpuError) as e:
+        capi.rolling_aggregate(cols, 0, 1000, lite, plan=plan, strict_order=True)
+    assert e.value.code == -9
+    with capi.route(capi.ROUTE_STRICT_ORDER):
+        with pytest.raises(capi.BowGpuError):
+            capi.rolling_aggregate(cols, 0, 1000, lite)
+    outs, info = capi.rolling_aggregate(cols, 0, 1000, lite)       # (the flag does not stick to the thread)
+    assert info.long_windows == info.num_windows
