@@ -1177,28 +1177,28 @@ __global__ __launch_bounds__(256, 4) void long_short_kernel(const AggParams p, c
 #pragma unroll
         for (int j = 0; j < kTrips; j++) stream_load_pair(vp + c0, j * 128 + 2 * lane, rows, vvec, vx[j], vy[j]);
     }
-    // the validity words of a column's rows, in row order (bit k of W[q]: row 64 q + k of the chunk; rows behind the column's end: 0), and
-    // of the 128 rows behind the chunk - scalar loads, issued with the column's value loads
+    // the validity words of a column's rows, in row order (bit k of W[q]: row 64 q + k of the chunk), and of the 128 rows behind the
+    // chunk - ten scalar loads through the constant address space, issued with the column's value loads.  Only whole 64-bit words
+    // inside the column: a bitmap at an odd bit offset and the column's last chunks go the general way.
     uint64_t W[2 * kTrips], Wn[2];
-    auto load_validity = [&](const ColDesc &cd) {
+    auto load_validity = [&](const ColDesc &cd) -> bool {
+        if (!cd.vbits) {
+#pragma unroll
+            for (int i = 0; i < 2 * kTrips; i++) W[i] = ~0ull;
+            Wn[0] = ~0ull; Wn[1] = ~0ull;
+            return true;
+        }
         const int64_t bit = cd.vbit0 + c0;
-        if (cd.vbits && !(bit & 63) && c0 + kStreamRows + 128 <= p.n) {     // whole 64-bit words, all of them inside the column: ten loads, nothing else
-            typedef const uint64_t __attribute__((address_space(4))) *const_words64;
-            const_words64 q = (const_words64)(uintptr_t)cd.vbits + (bit >> 6);
+        if (bit & 63) return false;
+        typedef const uint64_t __attribute__((address_space(4))) *const_words64;
+        const_words64 q = (const_words64)(uintptr_t)cd.vbits + (bit >> 6);
 #pragma unroll
-            for (int i = 0; i < 2 * kTrips; i++) W[i] = q[i];
-            Wn[0] = q[2 * kTrips]; Wn[1] = q[2 * kTrips + 1];
-            return;
-        }
-#pragma unroll
-        for (int j = 0; j < kTrips; j++) {
-            W[2 * j] = 0; W[2 * j + 1] = 0;
-            if (j * 128 < rows) load_bits128<false>(cd.vbits, cd.vbit0, c0 + j * 128, p.n, &W[2 * j], &W[2 * j + 1]);
-        }
-        Wn[0] = 0; Wn[1] = 0;
-        if (has_next) load_bits128<false>(cd.vbits, cd.vbit0, c0 + rows, p.n, &Wn[0], &Wn[1]);
+        for (int i = 0; i < 2 * kTrips; i++) W[i] = q[i];
+        Wn[0] = q[2 * kTrips]; Wn[1] = q[2 * kTrips + 1];
+        return true;
     };
-    if (!kDense && slot0 >= 0) load_validity(p.cols[slot0]);
+    bool words_ok = true;
+    if (!kDense && slot0 >= 0) words_ok = load_validity(p.cols[slot0]);
     // (uniform: scalar loads) the rows around the chunk and its first / last row
     const int64_t ts_prev = p.ts[has_prev ? c0 - 1 : c0], ts_next = p.ts[has_next ? c0 + rows : c0 + rows - 1];
     const int64_t ts_first = p.ts[c0], ts_last = p.ts[c0 + rows - 1];
@@ -1209,7 +1209,7 @@ __global__ __launch_bounds__(256, 4) void long_short_kernel(const AggParams p, c
     // float64(t1) - float64(t0) of two timestamps below 2^53 that are less than 2^32 apart is exactly their 32-bit difference: the
     // time-weighted terms are computed that way here, chunks outside these limits go the general way
     const bool small_t = ts_first > -(1ll << 53) && ts_next < (1ll << 53) && ts_next >= ts_first && (uint64_t)ts_next - (uint64_t)ts_first < 0xFFFFFFFFull;
-    if (rel_last > 1 || (kDense && rows != kStreamRows) || (kTw && !small_t)) {   // (also: a chunk whose last timestamp lies below its first - the general form raises the order flag)
+    if (rel_last > 1 || (kDense && rows != kStreamRows) || (kTw && !small_t) || (!kDense && (!words_ok || c0 + kStreamRows + 128 > p.n))) {   // (also: a chunk whose last timestamp lies below its first - the general form raises the order flag)
         if (lane == 0) todo[g] = 1;
         return;
     }
@@ -1273,7 +1273,10 @@ __global__ __launch_bounds__(256, 4) void long_short_kernel(const AggParams p, c
             const bool vvec = (reinterpret_cast<uintptr_t>(vp) & 15) == 0;
 #pragma unroll
             for (int j = 0; j < kTrips; j++) stream_load_pair(vp + c0, j * 128 + 2 * lane, rows, vvec, vx[j], vy[j]);
-            if (!kDense) load_validity(cd);
+            if (!kDense && !load_validity(cd)) {
+                if (lane == 0) todo[g] = 1;
+                return;
+            }
         }
         double xv[kTrips], yv[kTrips];
         if (cd.type == BOWGPU_FLOAT64) {      // (a branch, not a select: Int64 columns convert per element - bowgetters.go:224-229 - and only they pay for it)
@@ -1359,10 +1362,13 @@ __global__ __launch_bounds__(256, 4) void long_short_kernel(const AggParams p, c
                 cnt_b = tot - cnt_a;
             }
             // the points are the rows with a value.  For each trip, the first point BEHIND it (uniform; times: low words, see small_t):
-            // found back to front
-            uint32_t cn_t[kTrips], cn_rel[kTrips];
+            // found back to front.  Which pairs (point, next point) straddle a window boundary is a statement about at most two ROWS of the
+            // chunk: the last valid row in front of the boundary, and the chunk's last valid row when the point behind the chunk lies in
+            // another window - their terms are dropped (z0 / z1), no window bits per row.
+            uint32_t cn_t[kTrips];
             double cn_v[kTrips];
             bool cn_has[kTrips];
+            int z0 = -1, z1 = -1;
             if (need_ts) {
                 uint32_t c_t = 0, c_rel = 0;
                 double c_v = 0.0;
@@ -1377,22 +1383,28 @@ __global__ __launch_bounds__(256, 4) void long_short_kernel(const AggParams p, c
                             if (lane == 0) todo[g] = 1;
                             return;
                         }
-                        const uint64_t wn = row_wid(p, tn) - wid0;   // (only "the row's window or not" is read; far-away rows saturate)
+                        const uint64_t wn = row_wid(p, tn) - wid0;   // (only "the last row's window or not" is read; far-away rows saturate)
                         c_rel = wn > 0xFFFFFFFEull ? 0xFFFFFFFFu : (uint32_t)wn;
                         c_t = (uint32_t)(uint64_t)tn; c_v = bits_to_f64(vp[rn], cd.type); c_has = true;
                     }
                 }
+                if (split && cnt_a > 0) z0 = last_a;
+                if (cnt_a + cnt_b > 0) {
+                    const int last_all = cnt_b > 0 ? last_b : last_a;
+                    const uint32_t rel_all = (split && last_all >= rb) ? 1u : 0u;
+                    if (!(c_has && c_rel == rel_all)) z1 = last_all;
+                }
 #pragma unroll
                 for (int jj = 0; jj < kTrips; jj++) {
                     const int j = kTrips - 1 - jj;
-                    cn_t[j] = c_t; cn_v[j] = c_v; cn_rel[j] = c_rel; cn_has[j] = c_has;
+                    cn_t[j] = c_t; cn_v[j] = c_v; cn_has[j] = c_has;
                     if (W[2 * j] | W[2 * j + 1]) {
                         const int r0 = W[2 * j] ? __ffsll((long long)W[2 * j]) - 1 : 64 + __ffsll((long long)W[2 * j + 1]) - 1;   // the trip's first valid row
                         const int l0 = r0 >> 1;
                         const bool is_x = !(r0 & 1);
                         c_t = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(is_x ? tx[j] : ty[j]), l0);
                         c_v = readlane_f64(is_x ? xv[j] : yv[j], l0);
-                        c_rel = (split && j * 128 + r0 >= rb) ? 1u : 0u; c_has = true;
+                        c_has = true;
                     }
                 }
             }
@@ -1403,29 +1415,31 @@ __global__ __launch_bounds__(256, 4) void long_short_kernel(const AggParams p, c
                 const bool okx = (vmask >> (2 * j)) & 1u, oky = (vmask >> (2 * j)) & 2u;
                 double trx = 0.0, try_ = 0.0, stx = 0.0, sty = 0.0;
                 if (need_ts) {
-                    const uint32_t rlx = (split && i0 >= rb) ? 1u : 0u, rly = (split && i0 + 1 >= rb) ? 1u : 0u;
                     const uint32_t xt = (uint32_t)tx[j], yt = (uint32_t)ty[j];
                     // the lane's own first point, the lanes that have one, the first of them above this lane
-                    const uint32_t o_t = okx ? xt : yt, o_rel = okx ? rlx : rly;
+                    const uint32_t o_t = okx ? xt : yt;
                     const double o_v = okx ? xv[j] : yv[j];
                     const uint64_t hasm = __ballot(okx || oky);
                     const uint64_t above = (hasm >> lane) >> 1;
                     const int src = (lane + 1 + (above ? __ffsll((long long)above) - 1 : 0)) << 2;
-                    uint32_t a_t = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)o_t), a_rel = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)o_rel);
+                    uint32_t a_t = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)o_t);
                     double a_v = __hiloint2double(__builtin_amdgcn_ds_bpermute(src, __double2hiint(o_v)), __builtin_amdgcn_ds_bpermute(src, __double2loint(o_v)));
                     bool a_has = true;
-                    if (!above) { a_t = cn_t[j]; a_v = cn_v[j]; a_rel = cn_rel[j]; a_has = cn_has[j]; }
-                    if (oky && a_has && a_rel == rly) {
+                    if (!above) { a_t = cn_t[j]; a_v = cn_v[j]; a_has = cn_has[j]; }
+                    if (oky && a_has) {
                         const double dy = (double)(a_t - yt);
                         try_ = (yv[j] + a_v) / 2 * dy; sty = yv[j] * dy;   // integral.go:24 / :55
                     }
-                    if (okx) {
-                        const uint32_t b_t = oky ? yt : a_t, b_rel = oky ? rly : a_rel;
+                    if (okx && (oky || a_has)) {
+                        const uint32_t b_t = oky ? yt : a_t;
                         const double b_v = oky ? yv[j] : a_v;
-                        if ((oky || a_has) && b_rel == rlx) {
-                            const double dx = (double)(b_t - xt);
-                            trx = (xv[j] + b_v) / 2 * dx; stx = xv[j] * dx;
-                        }
+                        const double dx = (double)(b_t - xt);
+                        trx = (xv[j] + b_v) / 2 * dx; stx = xv[j] * dx;
+                    }
+                    if ((z0 >> 7) == j || (z1 >> 7) == j) {      // (uniform)
+                        const bool zx = i0 == z0 || i0 == z1, zy = i0 + 1 == z0 || i0 + 1 == z1;
+                        if (zx) { trx = 0.0; stx = 0.0; }
+                        if (zy) { try_ = 0.0; sty = 0.0; }
                     }
                 }
                 // (a row without a value: its terms are zero already, its value counts as 0)
