@@ -654,13 +654,22 @@ __device__ __forceinline__ void seg_store(Part *base, int64_t i, const SegVal<kN
 // ---- one lane's partial of a segment, for the chunks with at most one boundary (long_stream_kernel's short path)
 __device__ __forceinline__ double asm_min_f64(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ double asm_max_f64(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-template <int kNeed>
+template <int kNeed, bool kTrack>
 struct LaneAcc {
     double s, tr, st, mn, mx;    // extrema: seeded with +inf / -inf and replaced on < / > only, so a NaN never enters and equal values
     uint32_t imn, imx;           // keep the earliest row; nothing below +inf found: index 0, emit_window falls back to the window's first value
+    uint32_t vc, vf, vl;         // kTrack (nullable columns): the lane's valid rows of the segment - how many, the first and the last (1 + row)
     __device__ __forceinline__ void init() {
         s = 0.0; tr = 0.0; st = 0.0; imn = 0; imx = 0;
         mn = __longlong_as_double(0x7ff0000000000000ll); mx = __longlong_as_double((long long)0xfff0000000000000ull);
+        vc = 0; vf = 0xFFFFFFFFu; vl = 0;
+    }
+    __device__ __forceinline__ void track(bool c, uint32_t idx1) {
+        if (kTrack) {
+            vc += c ? 1u : 0u;
+            const uint32_t lo = c ? idx1 : 0xFFFFFFFFu, hi = c ? idx1 : 0u;
+            vf = lo < vf ? lo : vf; vl = hi > vl ? hi : vl;
+        }
     }
     __device__ __forceinline__ void add(double x, double trv, double stv, uint32_t idx1) {
         s += x;
@@ -678,6 +687,7 @@ struct LaneAcc {
             if (c && x > mx) { mx = x; imx = idx1; }
         }
         if (kNeed & 4) { tr += trv; st += stv; }
+        track(c, idx1);
     }
     __device__ __forceinline__ void add_if(bool c, double x, double trv, double stv, uint32_t idx1) {
         s += c ? x : 0.0;
@@ -686,15 +696,32 @@ struct LaneAcc {
             if (c && x > mx) { mx = x; imx = idx1; }
         }
         if (kNeed & 4) { tr += c ? trv : 0.0; st += c ? stv : 0.0; }
+        track(c, idx1);
     }
 };
-// the lanes' partials joined: the segment's partial, uniform.  Extrema: the extreme over the wavefront, then the earliest row among the
-// lanes that hold it - a lane holds the earliest of its own rows, lanes of one 128-row trip are in row order, trips are tried in order.
-template <int kNeed>
-__device__ __forceinline__ SegVal<kNeed> lane_acc_finish(const LaneAcc<kNeed> &a, uint32_t cnt, int first, int last) {
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+    v += dpp_u32<0x111, 0xf, true>(v); v += dpp_u32<0x112, 0xf, true>(v); v += dpp_u32<0x114, 0xf, true>(v);
+    v += dpp_u32<0x118, 0xf, true>(v); v += dpp_u32<0x142, 0xa, false>(v); v += dpp_u32<0x143, 0xc, false>(v);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+    v = mx(v, dpp_keep_u32<0x111, 0xf>(v)); v = mx(v, dpp_keep_u32<0x112, 0xf>(v)); v = mx(v, dpp_keep_u32<0x114, 0xf>(v));
+    v = mx(v, dpp_keep_u32<0x118, 0xf>(v)); v = mx(v, dpp_keep_u32<0x142, 0xa>(v)); v = mx(v, dpp_keep_u32<0x143, 0xc>(v));
+    return v;
+}
+// the lanes' partials joined: the segment's partial, uniform.  kTrack: count / first / last valid row from the lanes' own (cnt / first /
+// last are ignored); else they are the caller's closed forms (rows, 0-based).  Extrema: the extreme over the wavefront, then the
+// earliest row among the lanes that hold it - a lane holds the earliest of its own rows, lanes of one 128-row trip are in row
+// order, trips are tried in order.
+template <int kNeed, bool kTrack>
+__device__ __forceinline__ SegVal<kNeed> lane_acc_finish(const LaneAcc<kNeed, kTrack> &a, uint32_t cnt, int first, int last) {
     SegVal<kNeed> t = seg_identity<kNeed>();
+    if (kTrack) cnt = readlane_u32(wave_sum_u32(a.vc), 63);
     if (cnt == 0) return t;
-    t.cnt = cnt; t.first = (uint32_t)(first + 1); t.last = (uint32_t)(last + 1);
+    t.cnt = cnt;
+    if (kTrack) { t.first = readlane_u32(wave_min_u32(a.vf), 63); t.last = readlane_u32(wave_max_u32(a.vl), 63); }
+    else { t.first = (uint32_t)(first + 1); t.last = (uint32_t)(last + 1); }
     t.sum = readlane_f64(wave_sum_f64(a.s), 63);
     if (kNeed & 4) { t.trap = readlane_f64(wave_sum_f64(a.tr), 63); t.step = readlane_f64(wave_sum_f64(a.st), 63); }
     if (kNeed & 1) {
@@ -1135,28 +1162,31 @@ __global__ __launch_bounds__(256) void long_stream_kernel(const AggParams p, con
     }
 }
 
-// ---- Chunks with AT MOST ONE window boundary behind their first row - with windows longer than the chunk, all of them; the others
-// are flagged (todo[g] = 1) for long_stream_kernel.  (A list with one atomic counter instead of the flags: 2.8 ms per 1e8 rows when
-// every chunk is appended - 2e5 atomics on one address.)  Same outputs as stream_chunk
-// (meta, recs, parts, wparts), but nothing is computed per row that a uniform value can say:
-//   - no window ids: the one boundary is the first row at or above the second window's start (one 64-bit compare per row, and
-//     only in the chunks that have a boundary); no segmented scan: segment A in front of the boundary, segment B behind it, range
-//     tests only in the 128-row trip that holds the boundary;
-//   - count / first / last row: closed forms for a dense column, population count / lowest / highest bit of the rows' ballots
-//     for a nullable one (scalar work);
+// ---- Chunks with AT MOST ONE window boundary PER 128-ROW TRIP (and at most four in all) - every chunk once windows are longer
+// than the chunk, nearly every chunk from 256-row windows on; the others are flagged (todo[g] = 1) for long_stream_kernel.  (A
+// list with one atomic counter instead of the flags: 2.8 ms per 1e8 rows when every chunk is appended - 2e5 atomics on one
+// address.)  Same outputs as long_stream_kernel (meta, recs, parts, wparts), but nothing is computed per row that a uniform value
+// can say:
+//   - no window ids: boundary k is the first row at or above the k-th window start behind the chunk's first window (one 64-bit
+//     compare per row and boundary, none in a chunk without boundaries); no segmented scan: ONE running partial, closed by a plain
+//     reduction at every boundary and at the chunk's end, range tests only in the trips that hold a boundary;
+//   - count / first / last row of a segment: closed forms for a dense column; for a nullable one the lanes count their valid rows
+//     and keep their first / last, three 32-bit reductions at the segment's end (the validity WORDS come by scalar loads; doing
+//     the counts on them in scalar code cost more scalar instructions than the scalar unit had left);
 //   - sum and the time-weighted terms: local additions + six DPP steps per field; extrema: see lane_acc_finish;
 //   - the next point of a row (time-weighted terms): the same lane / the next lane (one DPP move) for a dense column, the lane
-//     that holds it (ballot, lowest set bit above the lane, five ds_bpermute) for a nullable one - no bitmap walk, no gathers.
-// 1e8 rows, 1000-row windows, dense: 540 / 510 vector instructions per 512-row chunk (extrema / time-weighted) against 930 / 1370
-// for the segment loop of long_stream_kernel and ~2000 for a segmented scan of all ten fields; a nullable column: 890 (and as many
+//     that holds it (ballot, lowest set bit above the lane, ds_bpermute) for a nullable one - no bitmap walk, no gathers.
+// 1e8 rows, 1000-row windows, dense: ~440 vector instructions per 512-row chunk against 930 / 1370 (extrema / time-weighted) for the
+// segment loop of long_stream_kernel and ~2000 for a segmented scan of all ten fields; a nullable column: 700 - 800 (and as many
 // scalar ones - the bitmap words, the counts).  kDense: no column of the pass has a validity bitmap (the launcher's choice; one
 // kernel with both paths needs 190 - 240 registers, the two apart 97 - 128).
 template <int kNeed, bool kDense>
 __global__ __launch_bounds__(256, 4) void long_short_kernel(const AggParams p, const int64_t nchunks, ChunkMeta *meta, Part *parts, WinRec *recs,
-                                                         Part *wparts, uint8_t *todo) {
+                                                            Part *wparts, uint8_t *todo) {
     typedef SegVal<kNeed> SV;
     constexpr bool kTw = (kNeed & 4) != 0;
     constexpr int kTrips = kStreamRows / 128;
+    constexpr int kMaxB = 4;                 // boundaries per chunk (one per trip)
     const int lane = threadIdx.x & 63;
     const int64_t g = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (g >= nchunks) return;
@@ -1205,15 +1235,12 @@ __global__ __launch_bounds__(256, 4) void long_short_kernel(const AggParams p, c
     const uint64_t wid0 = row_wid(p, ts_first);
     const int64_t start0 = p.s0 + (int64_t)(wid0 * (uint64_t)p.interval);
     const uint32_t rel_last = (uint32_t)(row_wid(p, ts_last) - wid0);
-    // (kDense: no column of the pass has a validity bitmap - the launcher's choice - and the one chunk that is not full goes the general way too)
     // float64(t1) - float64(t0) of two timestamps below 2^53 that are less than 2^32 apart is exactly their 32-bit difference: the
     // time-weighted terms are computed that way here, chunks outside these limits go the general way
     const bool small_t = ts_first > -(1ll << 53) && ts_next < (1ll << 53) && ts_next >= ts_first && (uint64_t)ts_next - (uint64_t)ts_first < 0xFFFFFFFFull;
-    if (rel_last > 1 || (kDense && rows != kStreamRows) || (kTw && !small_t) || (!kDense && (!words_ok || c0 + kStreamRows + 128 > p.n))) {   // (also: a chunk whose last timestamp lies below its first - the general form raises the order flag)
-        if (lane == 0) todo[g] = 1;
-        return;
-    }
-    if (lane == 0) todo[g] = 0;
+    // (kDense: no column of the pass has a validity bitmap - the launcher's choice - and the one chunk that is not full goes the general way too)
+    bool general = rel_last > (uint32_t)kMaxB || (kDense && rows != kStreamRows) || (kTw && !small_t) ||
+                   (!kDense && (!words_ok || c0 + kStreamRows + 128 > p.n));   // (rel_last: also a chunk whose last timestamp lies below its first)
     const bool prev_same = has_prev && (ts_prev >= start0 || wid0 == 0);      // (rows are ascending; rows below s0 ride in window 0)
     bool next_same = false;
     {
@@ -1221,12 +1248,18 @@ __global__ __launch_bounds__(256, 4) void long_short_kernel(const AggParams p, c
         const int64_t ws = p.s0 + (int64_t)(wl * (uint64_t)p.interval), lim = ws + p.interval;
         next_same = has_next && (lim < ws || ts_next < lim);
     }
-    // ---- order check, the boundary row (0: none)
-    int rb = 0;
-    {
+    // ---- order check; boundary k = the first row at or above window start k behind the chunk's first window (k <= rel_last: such a row
+    // exists, and start0 + k * interval <= ts_last cannot wrap); per trip: the boundary row it holds (-1: none) and the window,
+    // relative to the chunk's first, that starts there (windows without rows in between: several k share a row, the last one counts)
+    int tb_row[kTrips], tb_rel[kTrips];
+#pragma unroll
+    for (int j = 0; j < kTrips; j++) { tb_row[j] = -1; tb_rel[j] = 0; }
+    if (!general) {
         bool bad = false;
+        int rbk[kMaxB];
+#pragma unroll
+        for (int k = 0; k < kMaxB; k++) rbk[k] = 0;
         int64_t carry_ts = ts_prev;
-        const int64_t lim = start0 + p.interval;  // (read when rel_last == 1: a row at or above it exists, the sum cannot wrap)
 #pragma unroll
         for (int j = 0; j < kTrips; j++) {
             const int i0 = j * 128 + 2 * lane;
@@ -1237,32 +1270,66 @@ __global__ __launch_bounds__(256, 4) void long_short_kernel(const AggParams p, c
             bad |= (inx && py > x) || (iny && x > y);
             carry_ts = (int64_t)((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)y, 63) |
                                  (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)y >> 32), 63) << 32);
-            if (rel_last == 1 && rb == 0) {
-                const uint64_t ax = __ballot(inx && x >= lim), ay = __ballot(iny && y >= lim);
-                if (ax | ay) {
-                    const int lx = ax ? __ffsll((long long)ax) - 1 : 64, ly = ay ? __ffsll((long long)ay) - 1 : 64;
-                    rb = j * 128 + (lx <= ly ? 2 * lx : 2 * ly + 1);
+#pragma unroll
+            for (int k = 0; k < kMaxB; k++) {
+                if ((uint32_t)k < rel_last && rbk[k] == 0) {
+                    const int64_t lim = start0 + (int64_t)(k + 1) * p.interval;
+                    const uint64_t ax = __ballot(inx && x >= lim), ay = __ballot(iny && y >= lim);
+                    if (ax | ay) {
+                        const int lx = ax ? __ffsll((long long)ax) - 1 : 64, ly = ay ? __ffsll((long long)ay) - 1 : 64;
+                        rbk[k] = j * 128 + (lx <= ly ? 2 * lx : 2 * ly + 1);
+                    }
                 }
             }
         }
         if (lane == 0) bad |= ts_last > ts_next;
         if (__ballot(bad) && lane == 0) atomicOr(&p.status[0], 1u);
+#pragma unroll
+        for (int k = 0; k < kMaxB; k++) {
+            if ((uint32_t)k >= rel_last) continue;
+            const int r = rbk[k];
+#pragma unroll
+            for (int j = 0; j < kTrips; j++)
+                if ((r >> 7) == j) {
+                    if (tb_row[j] >= 0 && tb_row[j] != r) general = true;     // two boundaries in one trip
+                    tb_row[j] = r; tb_rel[j] = k + 1;
+                }
+        }
     }
-    const bool split = rb > 0, b0 = !prev_same;      // (b0: a boundary at the chunk's first row)
-    const bool through = !split && !b0;
+    if (general) {
+        if (lane == 0) todo[g] = 1;
+        return;
+    }
+    if (lane == 0) todo[g] = 0;
+    const bool b0 = !prev_same;      // a boundary at the chunk's first row: its first segment is a window of its own, not a head
+    int nb = 0, first_rb = 0, last_rb = 0;
+#pragma unroll
+    for (int j = 0; j < kTrips; j++)
+        if (tb_row[j] >= 0) { if (nb == 0) first_rb = tb_row[j]; last_rb = tb_row[j]; nb++; }
+    const bool through = nb == 0 && !b0;
     const bool tail_open = !through && next_same;
-    const int64_t slot_a = (int64_t)(wid0 - (uint64_t)p.wid_base), tail_slot = (int64_t)(wid0 + rel_last - (uint64_t)p.wid_base);
-    const int hr = through ? rows : ((split && !b0) ? rb : 0);
+    const int64_t tail_slot = (int64_t)(wid0 + rel_last - (uint64_t)p.wid_base);
+    const int hr = through ? rows : ((nb > 0 && !b0) ? first_rb : 0);
     if (lane == 0) {
         meta[g].head_rows = hr;
-        if (split && b0 && (uint64_t)slot_a < (uint64_t)p.W) { WinRec r; r.r0 = c0; r.rows = rb; r.chunk = (int32_t)g; recs[slot_a] = r; }
+        int seg_start = 0;
+        uint32_t seg_rel = 0;
+        bool first_seg = true;
+#pragma unroll
+        for (int j = 0; j < kTrips; j++) {
+            if (tb_row[j] < 0) continue;
+            if (!(first_seg && !b0)) {
+                const int64_t sl = (int64_t)(wid0 + seg_rel - (uint64_t)p.wid_base);
+                if ((uint64_t)sl < (uint64_t)p.W) { WinRec r; r.r0 = c0 + seg_start; r.rows = tb_row[j] - seg_start; r.chunk = (int32_t)g; recs[sl] = r; }
+            }
+            seg_start = tb_row[j]; seg_rel = (uint32_t)tb_rel[j]; first_seg = false;
+        }
         if (!through && (uint64_t)tail_slot < (uint64_t)p.W) {
             WinRec r;
-            r.r0 = c0 + rb; r.rows = tail_open ? -1 : (int32_t)(rows - rb); r.chunk = (int32_t)g;
+            r.r0 = c0 + last_rb; r.rows = tail_open ? -1 : (int32_t)(rows - last_rb); r.chunk = (int32_t)g;
             recs[tail_slot] = r;
         }
     }
-    const int jb = rb >> 7, r7 = rb & 127;          // the trip that holds the boundary, the boundary's row inside it
 
     for (int slot = 0; slot < p.ncols; slot++) {
         if (p.pass_mask[slot + 1] == 0 || !(p.pass_flags[slot + 1] & kPassNeedVals)) continue;
@@ -1287,20 +1354,79 @@ __global__ __launch_bounds__(256, 4) void long_short_kernel(const AggParams p, c
             for (int j = 0; j < kTrips; j++) { xv[j] = (double)(int64_t)vx[j]; yv[j] = (double)(int64_t)vy[j]; }
             __builtin_amdgcn_sched_barrier(0);
         }
-        // the rows' partials: segment A in front of the boundary (split chunks only), segment B behind it
-        LaneAcc<kNeed> A, B;
-        A.init(); B.init();
-        uint32_t cnt_a = 0, cnt_b = 0;
-        int first_a = 0, last_a = 0, first_b = 0, last_b = 0;
-        if (kDense) {
-            // every row is a value (and a point: its next point is row y of the lane for row x, row x of the next lane for row y; lane 63:
-            // the first row of the next trip / the row behind the chunk)
-            cnt_a = (uint32_t)rb; last_a = rb - 1; cnt_b = (uint32_t)(rows - rb); first_b = rb; last_b = rows - 1;
-            const int rq = rb - 1, jq = rq >> 7, lq = (rq & 127) >> 1;     // the row in front of the boundary: its pair straddles two windows
+        // the lane's rows of trip j (nullable column): bits 0 / 1 = row x / row y has a value
+        uint32_t vmask = 0;
+        if (!kDense) {
 #pragma unroll
-            for (int j = 0; j < kTrips; j++) {
-                double trx = 0.0, try_ = 0.0, stx = 0.0, sty = 0.0;
+            for (int j = 0; j < kTrips; j++) vmask |= (uint32_t)(((lane < 32 ? W[2 * j] : W[2 * j + 1]) >> ((2 * lane) & 63)) & 3ull) << (2 * j);
+        }
+        // (nullable, time-weighted) the points are the rows with a value.  For each trip, the first point BEHIND it (uniform; times: low
+        // words, see small_t), found back to front; and the segment it belongs to (the tail segment = nb, another window = none)
+        uint32_t cn_t[kTrips], cn_seg[kTrips];
+        double cn_v[kTrips];
+        if (!kDense && need_ts) {
+            uint32_t c_t = 0, c_seg = 0xFFu;
+            double c_v = 0.0;
+            if (has_next) {
+                // (nearly always among the 128 rows behind the chunk: their words are here already)
+                int64_t rn = Wn[0] ? c0 + rows + __ffsll((long long)Wn[0]) - 1 : (Wn[1] ? c0 + rows + 64 + __ffsll((long long)Wn[1]) - 1 : -2);
+                if (rn == -2) rn = col_next_valid(cd, c0 + rows, p.n);
+                if (rn >= 0) {
+                    const int64_t tn = p.ts[rn];
+                    if (!(tn < (1ll << 53) && tn >= ts_first && (uint64_t)tn - (uint64_t)ts_first < 0xFFFFFFFFull)) {   // (see small_t)
+                        if (lane == 0) todo[g] = 1;
+                        return;
+                    }
+                    if (row_wid(p, tn) - wid0 == (uint64_t)rel_last) c_seg = (uint32_t)nb;
+                    c_t = (uint32_t)(uint64_t)tn; c_v = bits_to_f64(vp[rn], cd.type);
+                }
+            }
+            uint32_t seg_of_trip_end = (uint32_t)nb;     // the segment of the rows behind trip j's boundary, back to front
+#pragma unroll
+            for (int jj = 0; jj < kTrips; jj++) {
+                const int j = kTrips - 1 - jj;
+                cn_t[j] = c_t; cn_v[j] = c_v; cn_seg[j] = c_seg;
+                if (W[2 * j] | W[2 * j + 1]) {
+                    const int r0 = W[2 * j] ? __ffsll((long long)W[2 * j]) - 1 : 64 + __ffsll((long long)W[2 * j + 1]) - 1;   // the trip's first valid row
+                    const int l0 = r0 >> 1;
+                    const bool is_x = !(r0 & 1);
+                    c_t = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(is_x ? tx[j] : ty[j]), l0);
+                    c_v = readlane_f64(is_x ? xv[j] : yv[j], l0);
+                    c_seg = (tb_row[j] >= 0 && j * 128 + r0 < tb_row[j]) ? seg_of_trip_end - 1u : seg_of_trip_end;
+                }
+                if (tb_row[j] >= 0) seg_of_trip_end--;
+            }
+        }
+        // ---- the running partial over the trips, closed at every boundary
+        LaneAcc<kNeed, !kDense> cur;        // (a nullable column: the lanes count their valid rows and keep the first / last themselves)
+        cur.init();
+        int seg_start = 0;
+        uint32_t seg_rel = 0, seg_ix = 0;        // the open segment: its first row, its window relative to the chunk's first, its number
+        bool first_seg = true;
+        auto close = [&](int rb) {                 // the open segment ends in front of row rb (a boundary): its partial goes out
+            const SV tot = lane_acc_finish<kNeed, !kDense>(cur, (uint32_t)(rb - seg_start), seg_start, rb - 1);
+            if (lane == 63) {
+                if (first_seg && prev_same) seg_store<kNeed>(parts, (2 * g) * p.ncols + slot, tot, c0);      // the partial of the window that runs in
+                else {
+                    const int64_t sl = (int64_t)(wid0 + seg_rel - (uint64_t)p.wid_base);
+                    if ((uint64_t)sl < (uint64_t)p.W) seg_store<kNeed>(wparts, sl * p.ncols + slot, tot, c0);
+                }
+            }
+            cur.init();
+            first_seg = false;
+        };
+#pragma unroll
+        for (int j = 0; j < kTrips; j++) {
+            const int i0 = j * 128 + 2 * lane;
+            const uint32_t ix = (uint32_t)(i0 + 1);
+            const int rbj = tb_row[j];                                  // (uniform) the boundary of this trip, -1: none
+            const bool ax = rbj < 0 || i0 < rbj, ay = rbj < 0 || i0 + 1 < rbj;   // row in front of it
+            double trx = 0.0, try_ = 0.0, stx = 0.0, sty = 0.0;
+            bool okx = true, oky = true;
+            if (kDense) {
                 if (need_ts) {
+                    // every row is a point: the next point of row x is row y of the lane, of row y row x of the next lane (lane 63: the first
+                    // row of the next trip / the row behind the chunk)
                     uint32_t n_t;
                     double n_v;
                     if (j + 1 < kTrips) {
@@ -1317,153 +1443,63 @@ __global__ __launch_bounds__(256, 4) void long_short_kernel(const AggParams p, c
                     const double dx = (double)((uint32_t)ty[j] - (uint32_t)tx[j]), dy = (double)(a_t - (uint32_t)ty[j]);
                     trx = (xv[j] + yv[j]) / 2 * dx; stx = xv[j] * dx;      // integral.go:24 / :55
                     try_ = (yv[j] + a_v) / 2 * dy; sty = yv[j] * dy;
-                    // the pairs that straddle a window boundary contribute nothing
+                    // the pairs that straddle a window boundary contribute nothing: the chunk's last row unless its window runs on, and the
+                    // row in front of this trip's / the next trip's boundary
                     if (j == kTrips - 1 && !(has_next && next_same) && lane == 63) { try_ = 0.0; sty = 0.0; }
-                    if (split && j == jq && lane == lq) {
-                        if (rq & 1) { try_ = 0.0; sty = 0.0; } else { trx = 0.0; stx = 0.0; }
+                    const int rq0 = rbj - 1, rq1 = (j + 1 < kTrips ? tb_row[j + 1 < kTrips ? j + 1 : j] : -1) - 1;
+                    if (rbj > 0 && (rq0 >> 7) == j) {
+                        if (i0 == rq0) { trx = 0.0; stx = 0.0; }
+                        if (i0 + 1 == rq0) { try_ = 0.0; sty = 0.0; }
                     }
+                    if (rq1 >= 0 && (rq1 >> 7) == j && i0 + 1 == rq1) { try_ = 0.0; sty = 0.0; }     // (that boundary is the next trip's first row)
                 }
-                const uint32_t ix = (uint32_t)(j * 128 + 2 * lane + 1);
-                if (!split || j > jb) { B.add(xv[j], trx, stx, ix); B.add(yv[j], try_, sty, ix + 1); }
-                else if (j < jb) { A.add(xv[j], trx, stx, ix); A.add(yv[j], try_, sty, ix + 1); }
-                else {
-                    const bool ax = 2 * lane < r7, ay = 2 * lane + 1 < r7;
-                    A.add_if(ax, xv[j], trx, stx, ix); B.add_if(!ax, xv[j], trx, stx, ix);
-                    A.add_if(ay, yv[j], try_, sty, ix + 1); B.add_if(!ay, yv[j], try_, sty, ix + 1);
-                }
-                __builtin_amdgcn_sched_barrier(0);     // (one trip after the other: interleaved, the four trips' temporaries cost ~100 registers)
-            }
-        } else {
-            // the lane's rows of trip j: bits 0 / 1 = row x / row y has a value
-            uint32_t vmask = 0;
-#pragma unroll
-            for (int j = 0; j < kTrips; j++) vmask |= (uint32_t)(((lane < 32 ? W[2 * j] : W[2 * j + 1]) >> ((2 * lane) & 63)) & 3ull) << (2 * j);
-            // count / first / last valid row of the two segments: scalar work on the words (qb: the word that holds the boundary, mb: its
-            // rows in front of the boundary; no boundary: both 0, every word belongs to B)
-            {
-                const int qb = rb >> 6;
-                const uint64_t mb = (1ull << (rb & 63)) - 1ull;
-                uint32_t tot = 0;
-                bool any_a = false, any_b = false;
-#pragma unroll
-                for (int q = 0; q < 2 * kTrips; q++) {
-                    const uint64_t wa = q < qb ? W[q] : (q == qb ? W[q] & mb : 0ull), wb = W[q] ^ wa;
-                    tot += (uint32_t)__popcll(W[q]);
-                    if (wa) {
-                        cnt_a += (uint32_t)__popcll(wa);
-                        if (!any_a) first_a = 64 * q + __ffsll((long long)wa) - 1;
-                        last_a = 64 * q + 63 - __clzll((long long)wa); any_a = true;
-                    }
-                    if (wb) {
-                        if (!any_b) first_b = 64 * q + __ffsll((long long)wb) - 1;
-                        last_b = 64 * q + 63 - __clzll((long long)wb); any_b = true;
-                    }
-                }
-                cnt_b = tot - cnt_a;
-            }
-            // the points are the rows with a value.  For each trip, the first point BEHIND it (uniform; times: low words, see small_t):
-            // found back to front.  Which pairs (point, next point) straddle a window boundary is a statement about at most two ROWS of the
-            // chunk: the last valid row in front of the boundary, and the chunk's last valid row when the point behind the chunk lies in
-            // another window - their terms are dropped (z0 / z1), no window bits per row.
-            uint32_t cn_t[kTrips];
-            double cn_v[kTrips];
-            bool cn_has[kTrips];
-            int z0 = -1, z1 = -1;
-            if (need_ts) {
-                uint32_t c_t = 0, c_rel = 0;
-                double c_v = 0.0;
-                bool c_has = false;
-                if (has_next) {
-                    // (nearly always among the 128 rows behind the chunk: their words are here already)
-                    int64_t rn = Wn[0] ? c0 + rows + __ffsll((long long)Wn[0]) - 1 : (Wn[1] ? c0 + rows + 64 + __ffsll((long long)Wn[1]) - 1 : -2);
-                    if (rn == -2) rn = col_next_valid(cd, c0 + rows, p.n);
-                    if (rn >= 0) {
-                        const int64_t tn = p.ts[rn];
-                        if (!(tn < (1ll << 53) && tn >= ts_first && (uint64_t)tn - (uint64_t)ts_first < 0xFFFFFFFFull)) {   // (see small_t)
-                            if (lane == 0) todo[g] = 1;
-                            return;
-                        }
-                        const uint64_t wn = row_wid(p, tn) - wid0;   // (only "the last row's window or not" is read; far-away rows saturate)
-                        c_rel = wn > 0xFFFFFFFEull ? 0xFFFFFFFFu : (uint32_t)wn;
-                        c_t = (uint32_t)(uint64_t)tn; c_v = bits_to_f64(vp[rn], cd.type); c_has = true;
-                    }
-                }
-                if (split && cnt_a > 0) z0 = last_a;
-                if (cnt_a + cnt_b > 0) {
-                    const int last_all = cnt_b > 0 ? last_b : last_a;
-                    const uint32_t rel_all = (split && last_all >= rb) ? 1u : 0u;
-                    if (!(c_has && c_rel == rel_all)) z1 = last_all;
-                }
-#pragma unroll
-                for (int jj = 0; jj < kTrips; jj++) {
-                    const int j = kTrips - 1 - jj;
-                    cn_t[j] = c_t; cn_v[j] = c_v; cn_has[j] = c_has;
-                    if (W[2 * j] | W[2 * j + 1]) {
-                        const int r0 = W[2 * j] ? __ffsll((long long)W[2 * j]) - 1 : 64 + __ffsll((long long)W[2 * j + 1]) - 1;   // the trip's first valid row
-                        const int l0 = r0 >> 1;
-                        const bool is_x = !(r0 & 1);
-                        c_t = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(is_x ? tx[j] : ty[j]), l0);
-                        c_v = readlane_f64(is_x ? xv[j] : yv[j], l0);
-                        c_has = true;
-                    }
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < kTrips; j++) {
-                const int i0 = j * 128 + 2 * lane;
-                const uint32_t ix = (uint32_t)(i0 + 1);
-                const bool okx = (vmask >> (2 * j)) & 1u, oky = (vmask >> (2 * j)) & 2u;
-                double trx = 0.0, try_ = 0.0, stx = 0.0, sty = 0.0;
+            } else {
+                okx = (vmask >> (2 * j)) & 1u; oky = (vmask >> (2 * j)) & 2u;
                 if (need_ts) {
+                    // the segment of the rows behind this trip's boundary = the number of boundaries up to and including this trip
+                    uint32_t seg_hi = seg_ix + (rbj >= 0 ? 1u : 0u);
+                    const uint32_t sgx = ax ? seg_ix : seg_hi, sgy = ay ? seg_ix : seg_hi;
                     const uint32_t xt = (uint32_t)tx[j], yt = (uint32_t)ty[j];
                     // the lane's own first point, the lanes that have one, the first of them above this lane
-                    const uint32_t o_t = okx ? xt : yt;
+                    const uint32_t o_t = okx ? xt : yt, o_seg = okx ? sgx : sgy;
                     const double o_v = okx ? xv[j] : yv[j];
                     const uint64_t hasm = __ballot(okx || oky);
                     const uint64_t above = (hasm >> lane) >> 1;
                     const int src = (lane + 1 + (above ? __ffsll((long long)above) - 1 : 0)) << 2;
-                    uint32_t a_t = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)o_t);
+                    uint32_t a_t = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)o_t), a_seg = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)o_seg);
                     double a_v = __hiloint2double(__builtin_amdgcn_ds_bpermute(src, __double2hiint(o_v)), __builtin_amdgcn_ds_bpermute(src, __double2loint(o_v)));
-                    bool a_has = true;
-                    if (!above) { a_t = cn_t[j]; a_v = cn_v[j]; a_has = cn_has[j]; }
-                    if (oky && a_has) {
+                    if (!above) { a_t = cn_t[j]; a_v = cn_v[j]; a_seg = cn_seg[j]; }
+                    if (oky && a_seg == sgy) {
                         const double dy = (double)(a_t - yt);
                         try_ = (yv[j] + a_v) / 2 * dy; sty = yv[j] * dy;   // integral.go:24 / :55
                     }
-                    if (okx && (oky || a_has)) {
-                        const uint32_t b_t = oky ? yt : a_t;
+                    if (okx) {
+                        const uint32_t b_t = oky ? yt : a_t, b_seg = oky ? sgy : a_seg;
                         const double b_v = oky ? yv[j] : a_v;
-                        const double dx = (double)(b_t - xt);
-                        trx = (xv[j] + b_v) / 2 * dx; stx = xv[j] * dx;
-                    }
-                    if ((z0 >> 7) == j || (z1 >> 7) == j) {      // (uniform)
-                        const bool zx = i0 == z0 || i0 == z1, zy = i0 + 1 == z0 || i0 + 1 == z1;
-                        if (zx) { trx = 0.0; stx = 0.0; }
-                        if (zy) { try_ = 0.0; sty = 0.0; }
+                        if (b_seg == sgx) {
+                            const double dx = (double)(b_t - xt);
+                            trx = (xv[j] + b_v) / 2 * dx; stx = xv[j] * dx;
+                        }
                     }
                 }
-                // (a row without a value: its terms are zero already, its value counts as 0)
-                const double xs = okx ? xv[j] : 0.0, ys = oky ? yv[j] : 0.0;
-                if (!split || j > jb) { B.add_v(okx, xs, xv[j], trx, stx, ix); B.add_v(oky, ys, yv[j], try_, sty, ix + 1); }
-                else if (j < jb) { A.add_v(okx, xs, xv[j], trx, stx, ix); A.add_v(oky, ys, yv[j], try_, sty, ix + 1); }
-                else {
-                    const bool ax = 2 * lane < r7, ay = 2 * lane + 1 < r7;
-                    A.add_if(okx && ax, xv[j], trx, stx, ix); A.add_if(oky && ay, yv[j], try_, sty, ix + 1);
-                    B.add_if(okx && !ax, xv[j], trx, stx, ix); B.add_if(oky && !ay, yv[j], try_, sty, ix + 1);
+            }
+            if (rbj < 0) {
+                if (kDense) { cur.add(xv[j], trx, stx, ix); cur.add(yv[j], try_, sty, ix + 1); }
+                else {       // (a row without a value: its terms are zero already, its value counts as 0)
+                    cur.add_v(okx, okx ? xv[j] : 0.0, xv[j], trx, stx, ix); cur.add_v(oky, oky ? yv[j] : 0.0, yv[j], try_, sty, ix + 1);
                 }
-                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                cur.add_if(okx && ax, xv[j], trx, stx, ix); cur.add_if(oky && ay, yv[j], try_, sty, ix + 1);
+                close(rbj);
+                cur.add_if(okx && !ax, xv[j], trx, stx, ix); cur.add_if(oky && !ay, yv[j], try_, sty, ix + 1);
+                seg_start = rbj; seg_rel = (uint32_t)tb_rel[j]; seg_ix++;
             }
+            __builtin_amdgcn_sched_barrier(0);     // (one trip after the other: interleaved, the four trips' temporaries cost ~100 registers)
         }
-        const SV id = seg_identity<kNeed>();
-        const SV tail = lane_acc_finish<kNeed>(B, cnt_b, first_b, last_b);
-        if (split) {
-            const SV head = lane_acc_finish<kNeed>(A, cnt_a, first_a, last_a);
-            if (lane == 63) {
-                if (prev_same) seg_store<kNeed>(parts, (2 * g) * p.ncols + slot, head, c0);      // the partial of the window that runs in
-                else if ((uint64_t)slot_a < (uint64_t)p.W) seg_store<kNeed>(wparts, slot_a * p.ncols + slot, head, c0);
-            }
-        }
+        // the segment that reaches the chunk's end
+        const SV tail = lane_acc_finish<kNeed, !kDense>(cur, (uint32_t)(rows - seg_start), seg_start, rows - 1);
         if (lane == 63) {
+            const SV id = seg_identity<kNeed>();
             if (through) {
                 seg_store<kNeed>(parts, (2 * g) * p.ncols + slot, tail, c0);
                 seg_store<kNeed>(parts, (2 * g + 1) * p.ncols + slot, id, c0);
@@ -1666,9 +1702,9 @@ int launch_long_stream(Ctx *c, const AggParams &p, void *workspace) {
     }
     const dim3 grid((unsigned)((nch + 3) / 4)), block(256);
     const int64_t nchunks = (int64_t)nch;
-    // Windows of at least a chunk's rows on average: nearly every chunk holds at most one boundary - long_short_kernel, then the general
-    // form for the chunks it flagged.  Shorter windows: the general form for every chunk.
-    const bool short_first = p.n / p.W >= kStreamRows;
+    // Windows of at least half a chunk's rows on average: nearly every 128-row trip holds at most one boundary - long_short_kernel, then
+    // the general form for the chunks it flagged.  Shorter windows: the general form for every chunk.
+    const bool short_first = p.n / p.W >= kStreamRows / 2;
     const dim3 fgrid((unsigned)((nch + 255) / 256));      // a wavefront per 64 chunk flags
     uint8_t *todo = reinterpret_cast<uint8_t *>(entries);   // (entries is written by stream_final_kernel, behind these launches: borrowed)
 #define BG_LONG_STREAM(K)                                                                                                              \
