@@ -11,7 +11,7 @@ TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 DST=gpurun_out/profiles_$TAG
 rm -rf $DST && mkdir -p $DST
-git rev-parse HEAD > $DST/${TAG}_commit.txt 2>/dev/null || echo "(snapshot without .git)" > $DST/${TAG}_commit.txt
+(git rev-parse HEAD 2>/dev/null || cat scratch/HEAD_COMMIT 2>/dev/null || echo "(snapshot without .git)") > $DST/${TAG}_commit.txt
 bash scratch/profile_bench.sh $TAG > $DST/profile_bench.log 2>&1
 cp gpurun_out/prof/${TAG}_* $DST/ 2>/dev/null
 cp gpurun_out/prof/bench.json $DST/${TAG}_bench_1e9.json 2>/dev/null
