@@ -154,7 +154,9 @@ __device__ __forceinline__ int64_t window_end_row(const AggParams &p, uint64_t w
 }
 
 // The outputs of one column pass (slot; -1: the reducers that need no column) for window `w`, from its merged order-free partial
-__device__ __forceinline__ void emit_window(const AggParams &p, int slot, const LongEntry &w, const Part &acc) {
+// (valid_out != nullptr: the validity bitmaps are not touched; bit i of *valid_out is set when the output of aggregation i is valid -
+// the caller assembles whole bitmap words from its lanes)
+__device__ __forceinline__ void emit_window(const AggParams &p, int slot, const LongEntry &w, const Part &acc, uint32_t *valid_out = nullptr) {
     const unsigned my_mask = p.pass_mask[slot + 1];
     const ColDesc *cd = slot >= 0 ? &p.cols[slot] : nullptr;
     const int col_type = cd ? cd->type : BOWGPU_INT64;
@@ -191,7 +193,8 @@ __device__ __forceinline__ void emit_window(const AggParams &p, int slot, const 
         Val v = finish_val(reduce_val(a.kind, inc ? st_incl : st, inc ? len + w.incl_row : len, win_start, p.interval,
                                       col_type == BOWGPU_INT64), a);
         reinterpret_cast<uint64_t *>(a.out_values)[oslot] = v.bits;
-        if (a.out_valid) {
+        if (valid_out) { if (v.valid) *valid_out |= 1u << (__ffs(m) - 1); }
+        else if (a.out_valid) {
             if (v.valid) atomicOr(&a.out_valid[oslot >> 5], 1u << (oslot & 31));
             else if (p.bits_preset) atomicAnd(&a.out_valid[oslot >> 5], ~(1u << (oslot & 31)));
         }
@@ -1522,53 +1525,91 @@ __global__ __launch_bounds__(256) void stream_final_kernel(const AggParams p, co
                                                            const Part *parts, const WinRec *recs, const Part *wparts,
                                                            LongEntry *entries, int64_t *off0, int64_t *off1,
                                                            unsigned long long *n_leftover, const int lite) {
+    // A lane's life here is a chain of dependent loads (record -> partials -> the first / last value of the window): what can be
+    // loaded early is (the next two records with the lane's own; up to four partials at once), and the validity bits do not go
+    // through atomics - lane k is window k, so the ballots of a wavefront ARE two words of every output's bitmap.
+    const int lane = threadIdx.x & 63;
     const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (k >= p.W) return;
-    const WinRec rec = recs[k];
-    LongEntry le;
-    le.wid = (uint64_t)(p.wid_base + k); le.r0 = rec.r0; le.r1 = -1; le.next_wid = le.wid + 1; le.incl_row = 0; le.dead = 0;
-    if (rec.r0 < 0) {   // no rows: the reducers' values for an empty window (window k itself: "0 windows behind it")
-        for (int slot = -1; slot < p.ncols; slot++)
-            if (p.pass_mask[slot + 1]) emit_empties(p, slot, le, 0, 0, 1);
-        return;
+    const bool in = k < p.W;
+    const bool defer_bits = !p.bits_preset;      // (bitmaps preset to all-null: whole words can be stored)
+    uint32_t vbits = 0;                          // bit i: the output of aggregation i is valid for this lane's window
+    if (in) {
+        const WinRec rec = recs[k];
+        const int64_t rn1 = k + 1 < p.W ? recs[k + 1].r0 : p.n, rn2 = k + 2 < p.W ? recs[k + 2].r0 : p.n;   // (behind the last window: the end of the rows)
+        LongEntry le;
+        le.wid = (uint64_t)(p.wid_base + k); le.r0 = rec.r0; le.r1 = -1; le.next_wid = le.wid + 1; le.incl_row = 0; le.dead = 0;
+        bool done = false;
+        if (rec.r0 < 0) {   // no rows: the reducers' values for an empty window (window k itself: "0 windows behind it")
+            for (int slot = -1; slot < p.ncols; slot++)
+                if (p.pass_mask[slot + 1]) emit_empties(p, slot, le, 0, 0, 1);
+            done = true;
+        }
+        const int64_t g = rec.chunk;
+        int64_t w0 = 2 * g + 1, w1 = w0;
+        if (!done) {
+            if (rec.rows >= 0) le.r1 = rec.r0 + rec.rows;
+            else {
+                // the window ends where the next window that has rows starts (rows are ascending, the windows partition them) ...
+                if (rn1 >= 0) le.r1 = rn1;
+                else if (rn2 >= 0) le.r1 = rn2;
+                else
+                    for (int64_t kk = k + 3; kk <= k + 8; kk++) {
+                        if (kk >= p.W) { le.r1 = p.n; break; }
+                        const int64_t rs = recs[kk].r0;
+                        if (rs >= 0) { le.r1 = rs; break; }
+                    }
+                if (le.r1 >= 0) w1 = 2 * ((le.r1 - 1) / kStreamRows) + 1;    // (its last row's chunk: the head partial of that chunk is its last partial)
+                // ... or, behind a run of empty windows, where the first chunk head ends that does not cover its chunk
+                else for (int64_t c = g + 1; c <= g + kStreamScan; c++) {
+                    if (c >= nchunks) { le.r1 = p.n; w1 = 2 * nchunks; break; }
+                    const int64_t rows_c = p.n - c * kStreamRows < kStreamRows ? p.n - c * kStreamRows : kStreamRows;
+                    const int64_t hr = meta[c].head_rows;
+                    if (hr < rows_c) { le.r1 = c * kStreamRows + hr; w1 = 2 * c + 1; break; }
+                }
+                if (le.r1 < 0) {       // (long_final_block_kernel finishes it, validity bits included: this lane's stay 0 here)
+                    const unsigned long long i = atomicAdd(n_leftover, 1ull);
+                    entries[i] = le;
+                    off0[i] = w0;
+                    off1[i] = w1;
+                    done = true;
+                }
+            }
+        }
+        if (!done) {
+            if (p.inclusive || p.pre_rows) entry_close(p, le);   // (the row behind the window / rows below s0 matter only then)
+            for (int slot = -1; slot < p.ncols; slot++) {
+                if (p.pass_mask[slot + 1] == 0) continue;
+                Part acc;
+                part_init(acc);
+                if (slot >= 0 && (p.pass_flags[slot + 1] & kPassNeedVals)) {
+                    if (rec.rows >= 0) acc = part_at(wparts, k * p.ncols + slot, lite);
+                    else {
+                        // four partials at a time (a 1000-row window has three to five): their loads go out together
+                        for (int64_t w = w0; w < w1; w += 4) {
+                            const int64_t wl = w1 - 1;
+                            const Part q0 = part_at(parts, w * p.ncols + slot, lite), q1 = part_at(parts, (w + 1 < wl ? w + 1 : wl) * p.ncols + slot, lite),
+                                       q2 = part_at(parts, (w + 2 < wl ? w + 2 : wl) * p.ncols + slot, lite), q3 = part_at(parts, (w + 3 < wl ? w + 3 : wl) * p.ncols + slot, lite);
+                            part_merge(acc, q0);
+                            if (w + 1 < w1) part_merge(acc, q1);
+                            if (w + 2 < w1) part_merge(acc, q2);
+                            if (w + 3 < w1) part_merge(acc, q3);
+                        }
+                    }
+                }
+                emit_window(p, slot, le, acc, defer_bits ? &vbits : nullptr);
+            }
+        }
     }
-    const int64_t g = rec.chunk;
-    int64_t w0 = 2 * g + 1, w1 = w0;
-    if (rec.rows >= 0) {
-        le.r1 = rec.r0 + rec.rows;
-    } else {
-        // the window ends where the next window that has rows starts (rows are ascending, the windows partition them) ...
-        for (int64_t kk = k + 1; kk <= k + 8; kk++) {
-            if (kk >= p.W) { le.r1 = p.n; break; }
-            const int64_t rs = recs[kk].r0;
-            if (rs >= 0) { le.r1 = rs; break; }
+    if (defer_bits) {
+        // (every lane of the wavefront arrives here: windows 64 w .. 64 w + 63 = bitmap words 2 w, 2 w + 1 of every output)
+        const int64_t k0 = k - lane;
+        for (int a = 0; a < p.naggs; a++) {
+            uint32_t *bits = p.aggs[a].out_valid;
+            const uint64_t m = __ballot((vbits >> a) & 1u);
+            if (!bits) continue;
+            if (lane == 0 && k0 < p.W) bits[k0 >> 5] = (uint32_t)m;
+            if (lane == 32 && k0 + 32 < p.W) bits[(k0 + 32) >> 5] = (uint32_t)(m >> 32);
         }
-        if (le.r1 >= 0) w1 = 2 * ((le.r1 - 1) / kStreamRows) + 1;    // (its last row's chunk: the head partial of that chunk is its last partial)
-        // ... or, behind a run of empty windows, where the first chunk head ends that does not cover its chunk
-        else for (int64_t c = g + 1; c <= g + kStreamScan; c++) {
-            if (c >= nchunks) { le.r1 = p.n; w1 = 2 * nchunks; break; }
-            const int64_t rows_c = p.n - c * kStreamRows < kStreamRows ? p.n - c * kStreamRows : kStreamRows;
-            const int64_t hr = meta[c].head_rows;
-            if (hr < rows_c) { le.r1 = c * kStreamRows + hr; w1 = 2 * c + 1; break; }
-        }
-        if (le.r1 < 0) {
-            const unsigned long long i = atomicAdd(n_leftover, 1ull);
-            entries[i] = le;
-            off0[i] = w0;
-            off1[i] = w1;
-            return;
-        }
-    }
-    if (p.inclusive || p.pre_rows) entry_close(p, le);   // (the row behind the window / rows below s0 matter only then)
-    for (int slot = -1; slot < p.ncols; slot++) {
-        if (p.pass_mask[slot + 1] == 0) continue;
-        Part acc;
-        part_init(acc);
-        if (slot >= 0 && (p.pass_flags[slot + 1] & kPassNeedVals)) {
-            if (rec.rows >= 0) acc = part_at(wparts, k * p.ncols + slot, lite);
-            else for (int64_t w = w0; w < w1; w++) part_merge(acc, part_at(parts, w * p.ncols + slot, lite));
-        }
-        emit_window(p, slot, le, acc);
     }
 }
 
@@ -1723,7 +1764,11 @@ int launch_long_stream(Ctx *c, const AggParams &p, void *workspace) {
     // the windows' partials merged and the reducers finished: a lane per window while windows span a few chunks, a wavefront / a
     // workgroup per window beyond that
     const int64_t avg_rows = p.n / p.W;
-    if (avg_rows < 8 * kStreamRows) {
+#ifndef BOWGPU_WIDE_FINAL_ROWS
+#define BOWGPU_WIDE_FINAL_ROWS (8 * kStreamRows)
+#endif
+    constexpr int64_t kStreamWideFinalRows = BOWGPU_WIDE_FINAL_ROWS;
+    if (avg_rows < kStreamWideFinalRows) {
         hipLaunchKernelGGL(stream_final_kernel, dim3((unsigned)((p.W + 255) / 256)), dim3(256), 0, c->stream, p, nchunks, meta, parts, recs, wparts,
                            entries, off0, off1, n_leftover, need == 0 ? 1 : 0);
         hipLaunchKernelGGL(long_final_block_kernel, dim3((unsigned)(nch < 2048 ? nch : 2048)), dim3(256), 0, c->stream, p, entries, off0, off1,
