@@ -1111,11 +1111,10 @@ static int job_run(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, i
     const bool cls = (route & BOWGPU_ROUTE_LONG_CLASSIC) != 0;      // test / A-B switches: only the bisection + per-window chunks form ...
     const bool sall = (route & BOWGPU_ROUTE_LONG_STREAM_ALL) != 0;  // ... / the streaming form for every reducer set
     // Which form?  The streaming form - one read of the rows, long_windows.hip long_short_kernel / long_stream_kernel - for every
-    // reducer set: from 128 rows per window on average when the reducers need only {sum, count} partials (Sum / ArithmeticMean /
-    // Count / WindowStart / NumRows), from 256 when they also need extrema, first / last rows or the time-weighted terms (below
-    // that its chunks hold several boundaries each and the tile kernels win: 1e8 rows, 128-row windows, Min + Max 0.84 against
-    // 0.47 ms).  1e8 rows, 1000-row windows: 0.29 - 0.40 ms against 0.44 - 0.72 ms for the bisection form, which keeps the calls of
-    // a handful of giant windows (from 32768 rows per window: the streaming form's final merge walks a window's chunks serially).
+    // reducer set from 128 rows per window on average (1e8 rows: 1000-row windows 0.26 - 0.33 ms against 0.44 - 0.72 ms for the
+    // bisection form; 128 .. 256-row windows 0.35 - 0.55 ms dense, 0.40 - 0.76 ms on irregular data with nulls, against 0.35 - 1.0 /
+    // 0.7 - 1.8 ms for the tile kernels, whose lane-per-window walk idles most lanes at that length); the bisection form keeps the
+    // calls of a handful of giant windows (from 4M rows per window: the streaming form's final merge is one workgroup per window).
     bool lite_set = true;
     for (int sl = 0; sl < P.ncols; sl++)
         if ((P.pass_flags[sl + 1] & (kPassMinMax | kPassFirstLast)) || P.cols[sl].need_ts) lite_set = false;

@@ -251,7 +251,7 @@ int launch_rolling_fast(Ctx *c, const AggParams &p);        // lean kernel for e
 constexpr int kLongChunkRows = 4096;
 constexpr int kLongStreamRows = 512;  // chunk of the streaming form of the long-window reduction (long_windows.hip)
 constexpr int64_t kLongOnlyAvgRows = 128;   // windows averaging at least this many rows skip the tile kernels: streaming form (api.cpp job_run)
-constexpr int64_t kLongStreamAnyAvgRows = 256;   // ... from here on for every reducer set (extrema, first / last, time-weighted terms)
+constexpr int64_t kLongStreamAnyAvgRows = 128;   // ... the same for the reducer sets with extrema, first / last or time-weighted terms (256 until long_short_kernel took a boundary per 128-row trip)
 constexpr int64_t kLongBisectAvgRows = 512; // ... bisection form where the streaming form does not apply (BOWGPU_ROUTE_LONG_CLASSIC; W >= 2^32)
 constexpr int64_t kLongClassicAvgRows = 1ll << 22;   // ... and from here on the handful of giant windows go by bisection + per-window chunks
 constexpr int kLongLists = 64;      // sub-lists of the long-window queue (agg_device.h push_long_window)

@@ -1743,9 +1743,10 @@ int launch_long_stream(Ctx *c, const AggParams &p, void *workspace) {
     }
     const dim3 grid((unsigned)((nch + 3) / 4)), block(256);
     const int64_t nchunks = (int64_t)nch;
-    // Windows of at least half a chunk's rows on average: nearly every 128-row trip holds at most one boundary - long_short_kernel, then
-    // the general form for the chunks it flagged.  Shorter windows: the general form for every chunk.
-    const bool short_first = p.n / p.W >= kStreamRows / 2;
+    // Windows of at least a trip's rows (128) on average - every call that gets here: long_short_kernel first, then the general form
+    // for the chunks it flagged (two boundaries inside one 128-row trip, ...).  Measured down to 128-row windows on regular and on
+    // irregular data (1e8 rows, Min + Max: 0.55 / 0.62 ms against 0.72 / 0.74 for the general form alone; scratch/longw_sweep.py).
+    const bool short_first = p.n / p.W >= 128;
     const dim3 fgrid((unsigned)((nch + 255) / 256));      // a wavefront per 64 chunk flags
     uint8_t *todo = reinterpret_cast<uint8_t *>(entries);   // (entries is written by stream_final_kernel, behind these launches: borrowed)
 #define BG_LONG_STREAM(K)                                                                                                              \

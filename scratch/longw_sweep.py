@@ -1,6 +1,6 @@
 """Which form for which window length: 1e8 rows, window lengths 64 .. 1e6 rows, three reducer sets, the routes of api.cpp job_run
 (auto / streaming for every set / bisection form / tile kernels + cooperative path).  Prints bracket / wall per call in ms (the bracket of the tile route covers the tile kernel only)."""
-import gc, sys, time
+import gc, os, sys, time
 sys.path.insert(0, '.')
 from bow_amd import capi
 n = 100_000_000
@@ -14,7 +14,7 @@ only = sys.argv[1:] or ["dense", "sparse"]
 for label, cols, scale in (("dense", dense, 1), ("sparse", sparse, 10)):
     if label not in only:
         continue
-    for rows_per_window in (64, 128, 256, 512, 1000, 4000, 32768, 262144, 1_000_000):
+    for rows_per_window in [int(x) for x in os.environ.get("SWEEP_ROWS", "64,128,256,512,1000,4000,32768,262144,1000000").split(",")]:
         interval = rows_per_window * scale
         for name, aggs in sets.items():
             s0, W = capi.plan_windows(cols[0], interval, 0)
