@@ -578,7 +578,7 @@ def shard_interp_points(cols, ts_col):
     return bytes(pts)
 
 
-def shard_interpolate(cols, ts_col, interval, interps, global_s0, rank, all_points, offset=0, out_residency=HOST):
+def shard_interpolate(cols, ts_col, interval, interps, global_s0, rank, all_points, offset=0, out_residency=HOST, inclusive=False):
     """Rolling.Interpolate of one row-range shard.  all_points: every rank's shard_interp_points bytes, in rank order.  The
     shards' outputs concatenated in rank order equal the unsharded result."""
     pts = [InterpPoints.from_buffer_copy(b) for b in all_points]
@@ -596,7 +596,7 @@ def shard_interpolate(cols, ts_col, interval, interps, global_s0, rank, all_poin
             if pts[q].nrows > 0 and pts[q].first_valid[i]:
                 edge.next_valid[i], edge.next_t[i], edge.next_v[i] = 1, pts[q].first_t[i], pts[q].first_v[i]
                 break
-    opts = Options(offset, 0, 0)
+    opts = Options(offset, int(bool(inclusive)), 0)
     carr, iarr = _cols(cols), _interps(ips)
     n_out = C.c_int64(0)
     check(lib().bowgpu_shard_interpolate_count(carr, len(cols), ts_col, C.c_int64(interval), C.byref(opts), C.c_int64(global_s0),

@@ -243,10 +243,12 @@ static int interp_prepare(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t
         // window's bow, so it appears twice in the concatenation - every window then contributes exactly one row in front of
         // its first row (a synthetic row, or that copy), except window 0 when row 0 sits on its start: n + W - e0 rows.  The
         // whole-trip wave kernel takes them; its preconditions (interp_fast32, no dropped rows, no -1 sentinel window) bound the shape.
-        if (global_s0) return fail(BOWGPU_ERR_UNSUPPORTED, "sharded Interpolate on inclusive windows is outside the device path");
-        if (!interp_fast32(pl, job->kq) || job->drop != 0)
-            return fail(BOWGPU_ERR_UNSUPPORTED, "Interpolate on inclusive windows: rows outside [s0, s0 + 2^31) or below s0 are outside the device path");
-        job->e0 = pl.first_ts == pl.s0 ? 1 : 0;
+        // A shard (global_s0): the same statement over the windows the shard accounts for (those behind its left neighbours' last
+        // one) - the copy of a row that sits on its window's start travels with the row itself, and only the FRAME's first row can
+        // be the exact row 0 that gets nothing in front.
+        if (!(interp_fast32(pl, job->kq) || interp_wide32(pl, job->kq)) || job->drop != 0)
+            return fail(BOWGPU_ERR_UNSUPPORTED, "Interpolate on inclusive windows: rows below s0, intervals of 2^31 and more or timestamps beyond 2^53 are outside the device path");
+        job->e0 = (!job->has_left && pl.first_ts == pl.s0) ? 1 : 0;
         job->M = W - job->e0;
     } else
     job->M = W - total - ((job->kq >= 0 && hstat[1]) ? 1 : 0) - job->drop;  // rows added (synthetic) minus rows dropped
