@@ -1259,9 +1259,7 @@ __global__ __launch_bounds__(256, 4) void long_short_kernel(const AggParams p, c
     for (int j = 0; j < kTrips; j++) { tb_row[j] = -1; tb_rel[j] = 0; }
     if (!general) {
         bool bad = false;
-        int rbk[kMaxB];
-#pragma unroll
-        for (int k = 0; k < kMaxB; k++) rbk[k] = 0;
+        uint32_t kfound = 0;                 // boundaries 1 .. kfound are placed (rows ascend: boundary k + 1 never lies in front of boundary k)
         int64_t carry_ts = ts_prev;
 #pragma unroll
         for (int j = 0; j < kTrips; j++) {
@@ -1273,31 +1271,24 @@ __global__ __launch_bounds__(256, 4) void long_short_kernel(const AggParams p, c
             bad |= (inx && py > x) || (iny && x > y);
             carry_ts = (int64_t)((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)y, 63) |
                                  (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)y >> 32), 63) << 32);
+            // the boundaries that fall into this trip, in order (a trip with none - every trip of a chunk without boundaries - costs one
+            // scalar compare)
 #pragma unroll
-            for (int k = 0; k < kMaxB; k++) {
-                if ((uint32_t)k < rel_last && rbk[k] == 0) {
-                    const int64_t lim = start0 + (int64_t)(k + 1) * p.interval;
-                    const uint64_t ax = __ballot(inx && x >= lim), ay = __ballot(iny && y >= lim);
-                    if (ax | ay) {
-                        const int lx = ax ? __ffsll((long long)ax) - 1 : 64, ly = ay ? __ffsll((long long)ay) - 1 : 64;
-                        rbk[k] = j * 128 + (lx <= ly ? 2 * lx : 2 * ly + 1);
-                    }
-                }
+            for (int it = 0; it < kMaxB; it++) {
+                if (kfound >= rel_last) break;
+                const int64_t lim = start0 + (int64_t)(kfound + 1) * p.interval;
+                const uint64_t ax = __ballot(inx && x >= lim), ay = __ballot(iny && y >= lim);
+                if (!(ax | ay)) break;
+                const int lx = ax ? __ffsll((long long)ax) - 1 : 64, ly = ay ? __ffsll((long long)ay) - 1 : 64;
+                const int r = j * 128 + (lx <= ly ? 2 * lx : 2 * ly + 1);
+                if (tb_row[j] >= 0 && tb_row[j] != r) general = true;     // two boundaries in one trip
+                tb_row[j] = r; tb_rel[j] = (int)(kfound + 1);
+                kfound++;
             }
         }
         if (lane == 0) bad |= ts_last > ts_next;
         if (__ballot(bad) && lane == 0) atomicOr(&p.status[0], 1u);
-#pragma unroll
-        for (int k = 0; k < kMaxB; k++) {
-            if ((uint32_t)k >= rel_last) continue;
-            const int r = rbk[k];
-#pragma unroll
-            for (int j = 0; j < kTrips; j++)
-                if ((r >> 7) == j) {
-                    if (tb_row[j] >= 0 && tb_row[j] != r) general = true;     // two boundaries in one trip
-                    tb_row[j] = r; tb_rel[j] = k + 1;
-                }
-        }
+        if (kfound != rel_last) general = true;     // (rows out of order: the general form raises the flag)
     }
     if (general) {
         if (lane == 0) todo[g] = 1;
