@@ -167,13 +167,22 @@ __global__ __launch_bounds__(256) void scan_block_sums_kernel(const int32_t *in,
     __syncthreads();
     if (threadIdx.x == 0) block_sums[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
-__global__ void scan_sums_kernel(int64_t *block_sums, int64_t nblocks, int64_t *total) {
-    // single thread: nblocks = W/2048 (<= ~50 k for W = 1e8)
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        int64_t run = 0;
-        for (int64_t i = 0; i < nblocks; i++) { const int64_t v = block_sums[i]; block_sums[i] = run; run += v; }
-        *total = run;
+__global__ __launch_bounds__(64) void scan_sums_kernel(int64_t *block_sums, int64_t nblocks, int64_t *total) {
+    // ONE wavefront: every lane sums its contiguous share of the block sums, the 64 shares are scanned over the lanes, then every lane
+    // writes the exclusive prefixes of its share (one thread walking all of them took 22 us for 200 sums: a chain of dependent
+    // loads and stores; nblocks = n / 2048 <= ~50 k for n = 1e8)
+    const int lane = threadIdx.x;
+    const int64_t per = (nblocks + 63) / 64, a = lane * per, b = a + per < nblocks ? a + per : nblocks;
+    long long mine = 0;
+    for (int64_t i = a; i < b; i++) mine += block_sums[i];
+    long long incl = mine;
+    for (int o = 1; o < 64; o <<= 1) {
+        const long long up = __shfl_up(incl, o);
+        if (lane >= o) incl += up;
     }
+    long long run = incl - mine;
+    for (int64_t i = a; i < b; i++) { const int64_t v = block_sums[i]; block_sums[i] = run; run += v; }
+    if (lane == 63) *total = incl;
 }
 __global__ __launch_bounds__(256) void scan_apply_kernel(const int32_t *in, int64_t n, const int64_t *block_sums, int64_t *out) {
     __shared__ long long sh[256];
