@@ -299,7 +299,9 @@ int bowgpu_rolling_interpolate_fill(const bowgpu_col *cols, int32_t ncols, int32
  * since the last row on the shards to its left (has_left / left_last_ts).  A Linear / StepPrevious interpolator whose nearest
  * valid point lies on another shard gets it from the caller: the point to the LEFT through bowgpu_interp.prev_* (the reference's
  * own Options.PrevRow mechanism), the point to the RIGHT through next_*.  Shards concatenated in rank order = the unsharded
- * result.  Frames with rows below the first window start or negative window starts are outside the sharded path. */
+ * result, for exclusive and for inclusive windows (opts->inclusive: a row on its window's start is preceded by the copy of itself
+ * that closes the window before - the copy travels with its row).  Frames with rows below the first window start or negative
+ * window starts are outside the sharded path. */
 typedef struct bowgpu_interp_edge {
     int32_t has_left;         /* a shard to the left holds rows */
     int32_t _pad;
