@@ -574,10 +574,18 @@ static int fill_finish(Ctx *c, FillParams &P, int64_t n, const DevCol &dfill, De
     // copy of devout_prepare (((ceil(n/8)+3)&~3)+4 bytes) always holds
     P.out_valid_words = reinterpret_cast<uint32_t *>(dout->validity);
     P.valid_count = reinterpret_cast<unsigned long long *>(dcnt);
+    BG_HIP(hipEventRecord(c->ev0, c->stream));
     BG_TRY(fill_run(c, P));
+    BG_HIP(hipEventRecord(c->ev1, c->stream));
     uint64_t hcnt = 0;
     BG_HIP(hipMemcpyAsync(&hcnt, dcnt, 8, hipMemcpyDeviceToHost, c->stream));
     BG_HIP(hipStreamSynchronize(c->stream));
+    {   // (bowgpu_last_kernel_ms / _name: the fill kernel of this call)
+        float ms = 0;
+        BG_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        c->last_kernel_ms = ms;
+        c->last_kernel_name = "fill_kernel";
+    }
     BG_TRY(devout_finish(c, dout, n, type, n - (int64_t)hcnt));
     BG_HIP(hipStreamSynchronize(c->stream));
     return 0;
