@@ -32,6 +32,10 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 BYTES_PER_ROW = 16.0   # algorithmic read bytes/row: 8 (ts) + 8 (value); null_count == 0 => no bitmap
 INTERVAL = 10
+HEADLINE_ROWS = 1_000_000_000
+# checksum64 (xor, sum) of the 1e8 means of the benched call at its full size: the value test_gpu_fullsize.py's
+# test_headline_1e9_every_window_against_the_oracle obtains from outputs it has just compared with the oracle on EVERY window
+HEADLINE_MEAN_CHECKSUM64 = "bed3073b06e80b6f8a90ff85ba2864c7"
 # N > 1: same interval (same per-row work as N = 1), but Options.Offset = 3 so that every shard boundary
 # (a multiple of 10 rows) falls INSIDE a window and the boundary-window stitch really runs
 OFFSET_MULTI = 3
@@ -175,12 +179,12 @@ def parity_check(capi, outs, rows, row0, interval, offset, owned, first_slot, s0
     """The outputs the timed steps produced (rank 0's), checked OUTSIDE the timed region: WindowStart of every owned window is the
     arithmetic progression; the windows of the first and of the last 2e6 rows against the oracle (the checker), bit for bit.
     Returns the `parity_check` object of the JSON line; ok == False makes the run fail."""
-    import numpy as np
-    from oracle import pyoracle as orc
-    from bow_amd.sharded import first_window_start
     aggs = [("WindowStart", 0), ("ArithmeticMean", 1)]
     res = {"ok": True, "windows_total": int(owned), "checked_against_oracle": 0, "progression_checked": 0}
     try:
+        import numpy as np
+        from oracle import pyoracle as orc   # (raises when oracle/libbow_oracle.so has not been built: reported below, the line is still printed)
+        from bow_amd.sharded import first_window_start
         CH = 50_000_000
         for k0 in range(0, owned, CH):
             m = min(CH, owned - k0)
@@ -206,9 +210,17 @@ def parity_check(capi, outs, rows, row0, interval, offset, owned, first_slot, s0
         res["mean_checksum64"] = "%016x%016x" % (x, s)
         res["what"] = ("outputs of the timed steps, after the timed region: WindowStart progression over every owned window; windows "
                        "of the first and the last %d rows of rank 0 against oracle/bow_oracle.c, bit for bit" % span)
-    except AssertionError as e:
+        # the benched configuration at its full size: every one of its 1e8 means is validated against the oracle by
+        # tests/test_gpu_fullsize.py::test_headline_1e9_every_window_against_the_oracle, which pins this checksum of them
+        if (rows, row0, interval, offset, first_slot) == (HEADLINE_ROWS, 0, INTERVAL, 0, 0) and owned == HEADLINE_ROWS // INTERVAL:
+            res["mean_checksum64_expected"] = HEADLINE_MEAN_CHECKSUM64
+            if res["mean_checksum64"] != HEADLINE_MEAN_CHECKSUM64:
+                raise AssertionError("checksum of the %d means is %s, the oracle-validated value is %s" %
+                                     (owned, res["mean_checksum64"], HEADLINE_MEAN_CHECKSUM64))
+            res["what"] += "; checksum of all %d means equal to the value pinned by the every-window oracle test" % owned
+    except Exception as e:   # (anything: a missing oracle library, a failed copy - the JSON line is still written, the run exits non-zero)
         res["ok"] = False
-        res["error"] = str(e)
+        res["error"] = "%s: %s" % (type(e).__name__, e)
     return res
 
 

@@ -25,6 +25,7 @@ INTERP = {"WindowStart": 0, "Linear": 1, "StepPrevious": 2, "None": 3, "Const": 
 
 MAX_FACTORS = 4
 CARRY_MAX_AGGS = 16
+ABI_VERSION = 4   # include/bowgpu.h BOWGPU_ABI_VERSION (asserted when the library is loaded)
 
 ERR_NAMES = {
     -1: "INTERVAL", -2: "TS_TYPE", -3: "FIRST_TS_NULL", -4: "NO_AGG", -5: "KEEP_INTERVAL", -6: "BAD_COL",
@@ -150,6 +151,9 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.bowgpu_last_error.restype = C.c_char_p
         L.bowgpu_last_kernel_name.restype = C.c_char_p
+        got = L.bowgpu_abi_version()
+        if got != ABI_VERSION:   # struct layouts / option meanings of include/bowgpu.h this binding was written against
+            raise OSError("%s has BOWGPU_ABI_VERSION %d, this binding expects %d: rebuild (make -C bow_amd/csrc)" % (LIB_PATH, got, ABI_VERSION))
         _lib = L
     return _lib
 

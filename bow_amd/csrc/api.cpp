@@ -106,6 +106,15 @@ static void abort_trace(int) {
     raise(SIGABRT);
 }
 
+// bowgpu_shard_pass_begin leaves a pass in flight on the thread's stream ("PendingPass" below): its kernels use the context's
+// scratch, pools and pinned read-back block.  Its two owners (bowgpu_shard_pass_begin, bowgpu_shard_finish) mark themselves; EVERY
+// other entry point that takes the context settles and drops the pass first, so nothing reuses that memory under running kernels
+// (the header states the rule; this enforces it).  A thread that exits with a pass in flight: PendingHolder's destructor.
+static thread_local bool g_pending_owner = false;
+struct PendingOwnerScope { bool was; PendingOwnerScope() : was(g_pending_owner) { g_pending_owner = true; } ~PendingOwnerScope() { g_pending_owner = was; } };
+static void pending_drop(Ctx *c);
+static bool pending_exists();
+
 int ctx_get(Ctx **out) {
     static ExitSentinel sentinel;   // (constructed on the first call of any thread)
     (void)sentinel;
@@ -132,6 +141,7 @@ int ctx_get(Ctx **out) {
     } else {
         BG_HIP(hipSetDevice(c->device));  // cgo calls may hop OS threads: no thread-affine HIP state assumed
     }
+    if (!g_pending_owner && pending_exists()) pending_drop(c);
     *out = c;
     return 0;
 }
@@ -1488,13 +1498,28 @@ struct PendingPass {
     int64_t n = 0, interval = 0, raw_offset = 0, base = 0;
     int32_t ts_col = 0, inclusive = 0;
 };
-static thread_local PendingPass *g_pending = nullptr;   // (plain pointer: no destructor order to worry about at thread exit)
+// (declared after g_bufs and g_ctx_holder: thread-local objects of one translation unit are destroyed in reverse declaration order, so
+// at thread exit this runs while the thread's block cache and context are still alive; at process exit the pass is left to the runtime)
+struct PendingHolder {
+    PendingPass *p = nullptr;
+    ~PendingHolder();
+};
+static thread_local PendingHolder g_pending_holder;
+#define g_pending (g_pending_holder.p)
 
+static bool pending_exists() { return g_pending != nullptr; }
 static void pending_drop(Ctx *c) {
     if (!g_pending) return;
     if (c && c->inited) (void)hipStreamSynchronize(c->stream);   // its kernels are done with the scratch blocks before anyone reuses them
     delete g_pending;
     g_pending = nullptr;
+}
+PendingHolder::~PendingHolder() {
+    if (!p || g_process_exiting) return;
+    Ctx *c = &g_ctx;
+    if (c->inited) { (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream); }
+    delete p;
+    p = nullptr;
 }
 
 }  // namespace bowgpu
@@ -1750,7 +1775,10 @@ static int aggregate_with_plan(const bowgpu_col *cols, int32_t ncols, int32_t ts
         static thread_local double acc[3] = {0, 0, 0};
         static thread_local int calls = 0;
         const double t_out = now_us();
-        acc[0] += g_prof_sync_begin - t_in; acc[1] += g_prof_sync_end - g_prof_sync_begin; acc[2] += t_out - g_prof_sync_end;
+        // (a route with no single synchronisation point of its own - the long-window forms - leaves the stamps of an EARLIER call behind:
+        // such a call is booked whole under "enqueue" instead of producing negative parts)
+        if (g_prof_sync_begin >= t_in) { acc[0] += g_prof_sync_begin - t_in; acc[1] += g_prof_sync_end - g_prof_sync_begin; acc[2] += t_out - g_prof_sync_end; }
+        else acc[0] += t_out - t_in;
         if (++calls == 200) {
             fprintf(stderr, "bowgpu call profile (200 calls): enqueue %.1f us, synchronise %.1f us, after %.1f us\n", acc[0] / 200, acc[1] / 200, acc[2] / 200);
             acc[0] = acc[1] = acc[2] = 0; calls = 0;
@@ -1831,7 +1859,7 @@ int bowgpu_rolling_aggregate_planned(const bowgpu_col *cols, int32_t ncols, int3
 
 static int shard_check(const bowgpu_col *cols, int32_t ncols, const bowgpu_agg *aggs, int32_t naggs, bowgpu_out *outs,
                        const bowgpu_options *o) {
-    if (o && o->strict_order) return fail(BOWGPU_ERR_UNSUPPORTED, "sharded aggregate: strict_order is not offered (carries and long windows merge order-free)");
+    if ((o && o->strict_order) || (route_mask() & BOWGPU_ROUTE_STRICT_ORDER)) return fail(BOWGPU_ERR_UNSUPPORTED, "sharded aggregate: strict_order is not offered (carries and long windows merge order-free)");
     for (int i = 0; i < naggs; i++) {
         // a window cut by a shard boundary needs all its rows in one place: Mode has no constant-size partial state
         if (aggs[i].kind == BOWGPU_AGG_MODE) return fail(BOWGPU_ERR_UNSUPPORTED, "sharded aggregate: Mode is not a mergeable reducer");
@@ -2169,6 +2197,7 @@ int bowgpu_shard_pass_begin(const bowgpu_col *cols, int32_t ncols, int32_t ts_co
     if (cols[ts_col].type != BOWGPU_INT64) return fail(BOWGPU_ERR_TS_TYPE, "impossible to create a new intervalRolling on column of type float64");
     if (me->nrows != cols[ts_col].length) return fail(BOWGPU_ERR_ARG, "the record says %lld rows, the interval column has %lld",
                                                       (long long)me->nrows, (long long)cols[ts_col].length);
+    PendingOwnerScope owner;
     Ctx *c;
     BG_TRY(ctx_get(&c));
     pending_drop(c);
@@ -2268,6 +2297,7 @@ int bowgpu_shard_finish(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, i
                         int32_t rank, bowgpu_shard_decision *decision, bowgpu_agg_info *info) {
     if (!cols || ncols <= 0 || !outs || !recs || !aggs) return fail(BOWGPU_ERR_ARG, "null argument");
     if (ts_col < 0 || ts_col >= ncols) return fail(BOWGPU_ERR_BAD_COL, "no interval column with index %d", ts_col);
+    PendingOwnerScope owner;   // (the pass in flight is this call's to collect or drop)
     bowgpu_options o = {0, 0, 0};
     if (opts) o = *opts;
     int inclusive = o.inclusive ? 1 : 0, nic = -1;

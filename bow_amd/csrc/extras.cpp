@@ -409,6 +409,11 @@ static int interp_fill_impl(const bowgpu_col *cols, int32_t ncols, int32_t ts_co
     }
     // some trip has more runs of synthetic rows than the default kernel lists: interp_wave_kernel (inclusive windows: interp_wave2_kernel,
     // whose list holds a run per row) takes the call
+    // (inclusive windows: the redo runs interp_wave2_kernel<true>, which needs the whole frame within 2^31 of s0 - fast32.  A frame
+    // that only interp_wave3_kernel's trip-relative form can take has no second kernel: decline instead of producing exclusive rows)
+    if (hstat[5] && o.inclusive && !P.fast32)
+        return fail(BOWGPU_ERR_UNSUPPORTED, "Interpolate on inclusive windows: a 512-row trip that spans 2^31 or more, or holds more runs of "
+                                            "added rows than the kernel lists, on a frame wider than 2^31 is outside the device path");
     if (hstat[5]) BG_TRY(run_all(0));
     if (hstat[5] && o.inclusive)
         return fail(BOWGPU_ERR_UNSUPPORTED, "Interpolate on inclusive windows: windows shorter than two rows on average are outside the device path");

@@ -1590,6 +1590,8 @@ int launch_interp_tiles(Ctx *c, const InterpParams &p) {
         else hipLaunchKernelGGL((interp_wave3_kernel<false>), dim3((unsigned)(per_xcd * 8)), dim3(64), 0, c->stream, p, ntrips, per_xcd);
         hipLaunchKernelGGL(interp_edge_fix_kernel, dim3((unsigned)((ntrips * p.ncols + 255) / 256)), dim3(256), 0, c->stream, p, ntrips);
     }
+    else if (p.inclusive && !(shape_ok && p.fast32))   // no other kernel builds inclusive windows: never fall through to an exclusive one
+        return fail(BOWGPU_ERR_UNSUPPORTED, "Interpolate on inclusive windows: this shape is outside the device path");
     else if (shape_ok && p.fast32 && p.inclusive) hipLaunchKernelGGL((interp_wave2_kernel<true, 4>), dim3((unsigned)ntiles), dim3(64), 0, c->stream, p);
     else if (shape_ok && p.fast32 && !force_tile && p.allow_wave2 && !wave1) hipLaunchKernelGGL((interp_wave2_kernel<false, 4>), dim3((unsigned)ntiles), dim3(64), 0, c->stream, p);
     else if (shape_ok && p.fast32 && !force_tile) hipLaunchKernelGGL(interp_wave_kernel, dim3((unsigned)ntiles), dim3(64), 0, c->stream, p);

@@ -22,7 +22,10 @@
 extern "C" {
 #endif
 
-#define BOWGPU_ABI_VERSION 3
+/* 4 (round 4): bowgpu_options' former padding word is `strict_order` (a caller that left it uninitialised now has calls declined),
+ * bowgpu_stream_rw_ceiling became bowgpu_stream_rw_probe, the BOWGPU_ROUTE_* bits moved.  A binding checks bowgpu_abi_version()
+ * against the value it was written for when it loads the library (bow_amd/capi.py lib(); shim/go/rolling/gpu_cgo.go init()). */
+#define BOWGPU_ABI_VERSION 4
 
 /* bow.Type (reference bowtypes.go:17-32) */
 enum {

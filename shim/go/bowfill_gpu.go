@@ -1,4 +1,4 @@
-//go:build bowgpu
+//go:build bowgpu && go1.21
 
 package bow
 

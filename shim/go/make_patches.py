@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Generates shim/go/patches/*.patch - the edits a maintainer applies to the reference's OWN files - and
+tests/golden/go_type_shapes.json - the struct fields / method sets of the reference types the shim touches.
+
+Run in the build container, where the reference tree is at /root/reference (it never travels: the GPU box sees only the
+committed patches and the JSON).  Each patch is a unified diff with two lines of context; nothing else of the reference is stored.
+tests/test_go_shim.py re-runs this script when the reference is present and requires the committed files to be reproduced
+byte for byte, then applies the patches to a scratch copy with `patch --dry-run`.
+
+    python3 shim/go/make_patches.py [--check]
+"""
+import difflib
+import json
+import os
+import re
+import sys
+
+REF = os.environ.get("BOW_REFERENCE", "/root/reference")
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+
+AGG_TAGS = {"WindowStart": "GPUKindWindowStart", "Sum": "GPUKindSum", "ArithmeticMean": "GPUKindArithmeticMean", "Min": "GPUKindMin",
+            "Max": "GPUKindMax", "Count": "GPUKindCount", "First": "GPUKindFirst", "Last": "GPUKindLast",
+            "IntegralStep": "GPUKindIntegralStep", "IntegralTrapezoid": "GPUKindIntegralTrapezoid",
+            "WeightedAverageStep": "GPUKindWeightedAvgStep", "WeightedAverageLinear": "GPUKindWeightedAvgLinear", "Mode": "GPUKindMode"}
+INTERP_TAGS = {"WindowStart": "GPUInterpWindowStart", "Linear": "GPUInterpLinear", "StepPrevious": "GPUInterpStepPrevious",
+               "None": "GPUInterpNone"}
+
+
+def sub_once(src, old, new, path):
+    assert src.count(old) == 1, (path, old, src.count(old))
+    return src.replace(old, new)
+
+
+def edit_aggregation_go(src, path):
+    src = sub_once(src, "\toutputName string\n\ttyp        bow.Type\n}",
+                   "\toutputName string\n\ttyp        bow.Type\n\n"
+                   "\tgpuKind int32 // bowgpu: 0 = no tag (a user closure), else BOWGPU_AGG_* + 1 (gpu_kinds.go); a field, so copies keep it\n}", path)
+    src = sub_once(src, "func (r *intervalRolling) aggregateWindows(aggrs []ColAggregation) (bow.Bow, error) {\n",
+                   "func (r *intervalRolling) aggregateWindows(aggrs []ColAggregation) (bow.Bow, error) {\n"
+                   "\tif b, err := r.aggregateWindowsGPU(aggrs); err != errDeclined { // bowgpu: gpu_cgo.go / gpu_off.go\n"
+                   "\t\treturn b, err\n\t}\n\n", path)
+    return src
+
+
+def edit_interpolation_go(src, path):
+    src = sub_once(src, "\tcolIndex int\n}", "\tcolIndex int\n\n"
+                   "\tgpuKind int32 // bowgpu: 0 = no tag, else BOWGPU_INTERP_* + 1 (gpu_kinds.go)\n}", path)
+    src = sub_once(src, "func (r *intervalRolling) interpolateWindows(interps []ColInterpolation) (bow.Bow, error) {\n",
+                   "func (r *intervalRolling) interpolateWindows(interps []ColInterpolation) (bow.Bow, error) {\n"
+                   "\tif b, err := r.interpolateWindowsGPU(interps); err != errDeclined { // bowgpu: gpu_cgo.go / gpu_off.go\n"
+                   "\t\treturn b, err\n\t}\n\n", path)
+    return src
+
+
+def edit_constructors(src, path, ctor, tags, ret):
+    """every `func Name(col string) rolling.<ret> { ... rolling.<ctor>(... ) }`: the call becomes <ctor>GPU(..., rolling.<tag>)"""
+    out, pos, done = [], 0, []
+    for m in re.finditer(r"^func (\w+)\(\w+ string\) rolling\.%s \{\n" % ret, src, flags=re.M):
+        name = m.group(1)
+        if name not in tags:
+            continue
+        end = src.index("\n}\n", m.end()) + 3          # the function's closing brace (gofmt: column 0)
+        body = src[m.start():end]
+        body = sub_once(body, "rolling.%s(" % ctor, "rolling.%sGPU(" % ctor, path)
+        lines = body.rstrip("\n").split("\n")
+        assert lines[-1] == "}" and lines[-2].rstrip().endswith(")"), (path, name, lines[-2:])
+        call_end = lines[-2]
+        if call_end.strip() == ")":                       # `\t\t},\n\t)` form (linear.go)
+            assert lines[-3].rstrip().endswith(","), (path, name)
+            lines.insert(-2, lines[-3][:len(lines[-3]) - len(lines[-3].lstrip())] + "rolling.%s," % tags[name])
+        else:                                             # `\t\t})` form
+            lines[-2] = call_end.rstrip()[:-1] + ", rolling.%s)" % tags[name]
+        out.append(src[pos:m.start()])
+        out.append("\n".join(lines) + "\n")
+        pos = end
+        done.append(name)
+    out.append(src[pos:])
+    assert done, path
+    return "".join(out), done
+
+
+def diff(rel, old, new):
+    d = difflib.unified_diff(old.splitlines(True), new.splitlines(True), "a/" + rel, "b/" + rel, n=2)
+    return "".join(d)
+
+
+def go_shapes():
+    """struct fields and method names of the reference types the shim reads or extends"""
+    shapes = {}
+
+    def struct_fields(path, name):
+        src = open(os.path.join(REF, path)).read()
+        m = re.search(r"^type %s struct \{\n(.*?)^\}" % name, src, flags=re.M | re.S)
+        fields = []
+        for line in m.group(1).split("\n"):
+            line = re.sub(r"//.*", "", line).strip()
+            if line:
+                fields.append(line.split()[0])
+        return fields
+
+    def iface_methods(path, name):
+        src = open(os.path.join(REF, path)).read()
+        m = re.search(r"^type %s interface \{\n(.*?)^\}" % name, src, flags=re.M | re.S)
+        return sorted(set(re.findall(r"^\t(\w+)\(", m.group(1), flags=re.M)))
+
+    def methods_of(paths, recv):
+        names = set()
+        for p in paths:
+            names |= set(re.findall(r"^func \(\w+ \*?%s\) (\w+)\(" % recv, open(os.path.join(REF, p)).read(), flags=re.M))
+        return sorted(names)
+
+    def funcs(path):
+        return sorted(set(re.findall(r"^func (\w+)\(", open(os.path.join(REF, path)).read(), flags=re.M)))
+
+    shapes["rolling.colAggregation"] = {"kind": "struct", "file": "rolling/aggregation.go", "fields": struct_fields("rolling/aggregation.go", "colAggregation"),
+                                        "methods": methods_of(["rolling/aggregation.go"], "colAggregation")}
+    shapes["rolling.ColAggregation"] = {"kind": "interface", "file": "rolling/aggregation.go", "methods": iface_methods("rolling/aggregation.go", "ColAggregation")}
+    shapes["rolling.ColInterpolation"] = {"kind": "struct", "file": "rolling/interpolation.go", "fields": struct_fields("rolling/interpolation.go", "ColInterpolation"),
+                                          "methods": methods_of(["rolling/interpolation.go"], "ColInterpolation")}
+    shapes["rolling.intervalRolling"] = {"kind": "struct", "file": "rolling/rolling.go", "fields": struct_fields("rolling/rolling.go", "intervalRolling"),
+                                         "methods": methods_of(["rolling/rolling.go", "rolling/aggregation.go", "rolling/interpolation.go"], "intervalRolling")}
+    shapes["rolling.Options"] = {"kind": "struct", "file": "rolling/rolling.go", "fields": struct_fields("rolling/rolling.go", "Options")}
+    shapes["bow.Bow"] = {"kind": "interface", "file": "bow.go", "methods": iface_methods("bow.go", "Bow")}
+    shapes["transformation"] = {"kind": "package", "file": "rolling/transformation/factor.go", "funcs": funcs("rolling/transformation/factor.go"),
+                                "Func": re.search(r"^type Func (.*)$", open(os.path.join(REF, "rolling/transformation/factor.go")).read(), flags=re.M).group(1)}
+    shapes["rolling.funcs"] = {"kind": "package", "funcs": sorted(set(funcs("rolling/aggregation.go") + funcs("rolling/interpolation.go") + funcs("rolling/rolling.go")))}
+    shapes["bow.funcs"] = {"kind": "package", "funcs": sorted(set(funcs("bow.go") + funcs("bowseries.go") + funcs("bowbuffer.go")))}
+    shapes["go.mod"] = {"go": re.search(r"^go (\S+)$", open(os.path.join(REF, "go.mod")).read(), flags=re.M).group(1)}
+    return shapes
+
+
+def generate():
+    files = {}
+    p1 = ""
+    for rel, fn in (("rolling/aggregation.go", edit_aggregation_go), ("rolling/interpolation.go", edit_interpolation_go)):
+        old = open(os.path.join(REF, rel)).read()
+        p1 += diff(rel, old, fn(old, rel))
+    files["patches/0001-rolling-gpu-kind-fields-and-hooks.patch"] = p1
+    p2, tagged = "", []
+    for rel in sorted(os.listdir(os.path.join(REF, "rolling", "aggregation"))):
+        if rel.endswith("_test.go") or not rel.endswith(".go") or rel == "whole.go":
+            continue
+        rel = "rolling/aggregation/" + rel
+        old = open(os.path.join(REF, rel)).read()
+        new, done = edit_constructors(old, rel, "NewColAggregation", AGG_TAGS, "ColAggregation")
+        tagged += done
+        p2 += diff(rel, old, new)
+    assert sorted(tagged) == sorted(AGG_TAGS), sorted(set(AGG_TAGS) - set(tagged))
+    files["patches/0002-aggregation-constructors-carry-their-kind.patch"] = p2
+    p3, tagged = "", []
+    for rel in sorted(os.listdir(os.path.join(REF, "rolling", "interpolation"))):
+        if rel.endswith("_test.go") or not rel.endswith(".go"):
+            continue
+        rel = "rolling/interpolation/" + rel
+        old = open(os.path.join(REF, rel)).read()
+        new, done = edit_constructors(old, rel, "NewColInterpolation", INTERP_TAGS, "ColInterpolation")
+        tagged += done
+        p3 += diff(rel, old, new)
+    assert sorted(tagged) == sorted(INTERP_TAGS)
+    files["patches/0003-interpolation-constructors-carry-their-kind.patch"] = p3
+    return files, json.dumps(go_shapes(), indent=1, sort_keys=True) + "\n"
+
+
+def main():
+    files, shapes = generate()
+    targets = {os.path.join(HERE, k): v for k, v in files.items()}
+    targets[os.path.join(ROOT, "tests", "golden", "go_type_shapes.json")] = shapes
+    if "--check" in sys.argv:
+        bad = [p for p, v in targets.items() if not os.path.exists(p) or open(p).read() != v]
+        if bad:
+            sys.exit("stale: %s (run shim/go/make_patches.py)" % ", ".join(os.path.relpath(b, ROOT) for b in bad))
+        return
+    for p, v in targets.items():
+        os.makedirs(os.path.dirname(p), exist_ok=True)
+        open(p, "w").write(v)
+        print("wrote", os.path.relpath(p, ROOT), len(v), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,4 +1,7 @@
-//go:build bowgpu
+//go:build bowgpu && go1.21
+
+// (go1.21: runtime.Pinner.  The reference's go.mod says `go 1.18` - a LANGUAGE version, which does not limit the standard library of
+// the toolchain that builds it; with an older toolchain this file drops out and gpu_off.go keeps every call on the Go path.)
 
 package rolling
 
@@ -18,7 +21,17 @@ import (
 
 	"github.com/apache/arrow/go/v8/arrow/bitutil"
 	"github.com/metronlab/bow"
+	"github.com/metronlab/bow/rolling/transformation"
 )
+
+// the struct layouts and option meanings this file was written against (include/bowgpu.h BOWGPU_ABI_VERSION)
+const bowgpuABI = 4
+
+func init() {
+	if v := int(C.bowgpu_abi_version()); v != bowgpuABI {
+		panic(fmt.Sprintf("libbowgpu.so has ABI version %d, the binding was written for %d", v, bowgpuABI))
+	}
+}
 
 var errDeclined = errors.New("bowgpu: input outside the device path") // the caller continues on the reference's own Go path
 
@@ -80,20 +93,19 @@ func seriesOf(name string, out C.bowgpu_out, data []int64, valid []byte, n int) 
 	return bow.NewSeries(name, bow.Float64, unsafe.Slice((*float64)(unsafe.Pointer(&data[0])), n), vb)
 }
 
-type gpuFactor interface{ GPUFactor() (float64, bool) } // transformation.Factor (rolling/transformation/gpu_factor.go)
-
-// exportFactors: aggregation.go:216-221 applies a.Transformations() to every window's result; Factor chains are passed on instead.
+// exportFactors: aggregation.go:216-221 applies a.Transformations() to every window's result; a chain made of transformation.Factor
+// closures only (recognised and read back by transformation.FactorOf, rolling/transformation/gpu_factor.go) is passed on instead;
+// any other transformation.Func is a user closure and keeps the aggregator on the Go path.
 func exportFactors(a ColAggregation, dst *C.bowgpu_agg) bool {
 	ts := a.Transformations()
 	if len(ts) > C.BOWGPU_MAX_FACTORS {
 		return false
 	}
 	for i, t := range ts {
-		f, ok := interface{}(t).(gpuFactor)
+		n, ok := transformation.FactorOf(t)
 		if !ok {
-			return false // a user closure
+			return false
 		}
-		n, _ := f.GPUFactor()
 		dst.factors[i] = C.double(n)
 	}
 	dst.n_factors = C.int32_t(len(ts))
@@ -107,20 +119,24 @@ func (r *intervalRolling) describe(aggrs []ColAggregation, pin *runtime.Pinner) 
 	}
 	cAggs := make([]C.bowgpu_agg, len(aggrs))
 	for i, a := range aggrs {
-		k, ok := a.(gpuKinded)
-		if !ok || k.GPUKind() < 0 || !exportFactors(a, &cAggs[i]) {
+		k := gpuKindOfAggregation(a) // the colAggregation's own field: RenameOutput / SetTransformations copies keep it (gpu_kinds.go)
+		if k < 0 || !exportFactors(a, &cAggs[i]) {
 			return nil, nil, C.bowgpu_options{}, errDeclined
 		}
-		cAggs[i].kind, cAggs[i].col = C.int32_t(k.GPUKind()), C.int32_t(a.InputIndex())
+		cAggs[i].kind, cAggs[i].col = C.int32_t(k), C.int32_t(a.InputIndex())
 	}
 	opts := C.bowgpu_options{offset: C.int64_t(r.options.Offset), inclusive: b2i(r.options.Inclusive)}
 	return cols, cAggs, opts, nil
 }
 
-// aggregateWindowsGPU is called first thing in (*intervalRolling).aggregateWindows (aggregation.go:190); errDeclined falls through
-// to the Go loop.  r.gpuPlan is the C.bowgpu_plan newIntervalRolling keeps (bowgpu_plan_windows_ex, once per Rolling).
+// aggregateWindowsGPU is called first thing in (*intervalRolling).aggregateWindows (aggregation.go:190, patches/0001); errDeclined
+// falls through to the Go loop.  The reference's loop starts wherever the iterator stands (`for rCopy.HasNext()`, aggregation.go:200):
+// a Rolling the caller has already stepped with Next() aggregates only its remaining windows - that stays on the Go path.
 func (r *intervalRolling) aggregateWindowsGPU(aggrs []ColAggregation) (bow.Bow, error) {
-	var pin runtime.Pinner // Go >= 1.21; with go1.18 copy the slices into C.malloc'd memory instead
+	if r.currWindowIndex != 0 || r.currRowIndex != 0 || r.numWindows == 0 {
+		return nil, errDeclined
+	}
+	var pin runtime.Pinner
 	defer pin.Unpin()
 	cols, cAggs, opts, err := r.describe(aggrs, &pin)
 	if err != nil {
@@ -129,10 +145,15 @@ func (r *intervalRolling) aggregateWindowsGPU(aggrs []ColAggregation) (bow.Bow, 
 	W := r.numWindows // rolling.go:102
 	outs, data, valid := newOuts(len(aggrs), W, &pin)
 	var info C.bowgpu_agg_info
-	rc := C.bowgpu_rolling_aggregate_planned(&cols[0], C.int32_t(len(cols)), C.int32_t(r.intervalColIndex), &r.gpuPlan, &opts,
+	// (host-resident columns: the library's own plan is O(1) host arithmetic on the first / last timestamp.  A Bow whose buffers live
+	// in HBM would keep the C.bowgpu_plan of bowgpu_plan_windows_ex in the intervalRolling and call bowgpu_rolling_aggregate_planned.)
+	rc := C.bowgpu_rolling_aggregate(&cols[0], C.int32_t(len(cols)), C.int32_t(r.intervalColIndex), C.int64_t(r.interval), &opts,
 		&cAggs[0], C.int32_t(len(cAggs)), &outs[0], &info)
 	if rc != 0 {
 		return nil, gpuErr(rc, r.bow.ColumnName(r.intervalColIndex))
+	}
+	if int(info.num_windows) != W || int64(info.s0) != r.currWindowFirstValue { // the library's plan IS newIntervalRolling's (rolling.go:95-102)
+		return nil, errDeclined
 	}
 	series := make([]bow.Series, len(aggrs))
 	for i, a := range aggrs {
@@ -142,22 +163,15 @@ func (r *intervalRolling) aggregateWindowsGPU(aggrs []ColAggregation) (bow.Bow, 
 		}
 		series[i] = seriesOf(name, outs[i], data[i], valid[i], W)
 	}
-	r.options.Inclusive = info.inclusive != 0 // aggregation.go:139: the flag persists into the returned Rolling
-	return bow.NewBow(series...)              // aggregation.go:237
+	return bow.NewBow(series...) // aggregation.go:237
 }
 
-// keepPlan: the tail of newIntervalRolling (rolling.go:102-111).
-func (r *intervalRolling) keepPlan(pin *runtime.Pinner) error {
-	ts := colDesc(r.bow, r.intervalColIndex, pin)
-	if rc := C.bowgpu_plan_windows_ex(&ts, C.int64_t(r.interval), C.int64_t(r.options.Offset), &r.gpuPlan); rc != 0 {
-		return gpuErr(rc, r.bow.ColumnName(r.intervalColIndex))
-	}
-	r.numWindows = int(r.gpuPlan.num_windows)
-	return nil
-}
-
-// interpolateWindowsGPU is called from (*intervalRolling).Interpolate after validateInterpolation (interpolation.go:40-55).
+// interpolateWindowsGPU is called first thing in (*intervalRolling).interpolateWindows (interpolation.go:98, patches/0001), i.e. after
+// validateInterpolation has filled every interps[i].colIndex (interpolation.go:40-48, :75-78).
 func (r *intervalRolling) interpolateWindowsGPU(interps []ColInterpolation) (bow.Bow, error) {
+	if r.currWindowIndex != 0 || r.currRowIndex != 0 || r.numWindows == 0 {
+		return nil, errDeclined
+	}
 	var pin runtime.Pinner
 	defer pin.Unpin()
 	cols := make([]C.bowgpu_col, r.bow.NumCols())
@@ -166,11 +180,11 @@ func (r *intervalRolling) interpolateWindowsGPU(interps []ColInterpolation) (bow
 	}
 	cI := make([]C.bowgpu_interp, len(interps))
 	for i, ip := range interps {
-		k, ok := ip.(gpuKinded)
-		if !ok || k.GPUKind() < 0 {
+		k := ip.gpuKind - 1 // ColInterpolation is a struct (interpolation.go:10-16): the tag is its own field (patches/0001, gpu_kinds.go)
+		if k < 0 {
 			return nil, errDeclined
 		}
-		cI[i].kind, cI[i].col = C.int32_t(k.GPUKind()), C.int32_t(ip.colIndex)
+		cI[i].kind, cI[i].col = C.int32_t(k), C.int32_t(ip.colIndex)
 		if pr := r.options.PrevRow; pr != nil { // linear.go:14-18, stepprevious.go:13-15 read the LAST row of PrevRow
 			last := pr.NumRows() - 1
 			t, tok := pr.GetFloat64(r.intervalColIndex, last)

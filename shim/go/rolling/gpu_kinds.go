@@ -28,30 +28,33 @@ const (
 	GPUInterpNone         int32 = 3
 )
 
-// gpuKinded is implemented by the aggregators / interpolators the built-in constructors return.
-type gpuKinded interface{ GPUKind() int32 }
+// The tag lives IN the reference's own types (patches/0001: a `gpuKind int32` field in colAggregation, rolling/aggregation.go:41-51,
+// and in the ColInterpolation struct, rolling/interpolation.go:10-16), stored as kind + 1 so that the zero value means "no tag".
+// A field - not a wrapper type - because RenameOutput and SetTransformations return `aCopy := *a` (aggregation.go:82-86, :104-108):
+// the copy keeps every field, so aggregation.ArithmeticMean("v").RenameOutput("m").SetTransformations(transformation.Factor(2))
+// still carries GPUKindArithmeticMean when it reaches describe() in gpu_cgo.go.
 
-type kindedAggregation struct {
-	ColAggregation
-	kind int32
-}
-
-func (k kindedAggregation) GPUKind() int32 { return k.kind }
-
-// NewColAggregationGPU is NewColAggregation (rolling/aggregation.go:53) plus the tag; fn stays the reference's closure and is
-// what runs whenever the device path declines.
+// NewColAggregationGPU is NewColAggregation (rolling/aggregation.go:53-61) for the built-in constructors of rolling/aggregation;
+// fn stays the reference's closure and is what runs whenever the device path declines.
 func NewColAggregationGPU(inputName string, needInclusiveWindow bool, typ bow.Type, fn ColAggregationFunc, kind int32) ColAggregation {
-	return kindedAggregation{NewColAggregation(inputName, needInclusiveWindow, typ, fn), kind}
+	a := NewColAggregation(inputName, needInclusiveWindow, typ, fn).(*colAggregation)
+	a.gpuKind = kind + 1
+	return a
 }
 
-type kindedInterpolation struct {
-	ColInterpolation
-	kind int32
+// gpuKindOfAggregation: the tag of a built-in aggregator, GPUKindNone for anything else (a user's own ColAggregation implementation,
+// a closure handed to NewColAggregation).
+func gpuKindOfAggregation(a ColAggregation) int32 {
+	if ca, ok := a.(*colAggregation); ok {
+		return ca.gpuKind - 1
+	}
+	return GPUKindNone
 }
 
-func (k kindedInterpolation) GPUKind() int32 { return k.kind }
-
-// NewColInterpolationGPU is NewColInterpolation (rolling/interpolation.go:22-28) plus the tag.
-func NewColInterpolationGPU(inputName string, inputTypes []bow.Type, fn ColInterpolationFunc, kind int32) ColInterpolation {
-	return kindedInterpolation{NewColInterpolation(inputName, inputTypes, fn), kind}
+// NewColInterpolationGPU is NewColInterpolation (rolling/interpolation.go:22-28) plus the tag; ColInterpolation is a struct passed
+// by value, so the field travels with every copy (Interpolate(interps ...ColInterpolation), validateInterpolation(&interps[i], i)).
+func NewColInterpolationGPU(colName string, inputTypes []bow.Type, fn ColInterpolationFunc, kind int32) ColInterpolation {
+	ip := NewColInterpolation(colName, inputTypes, fn)
+	ip.gpuKind = kind + 1
+	return ip
 }

@@ -24,7 +24,7 @@ def test_every_declared_symbol_is_exported():
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, missing
     assert sorted(capi.SYMBOLS) == names
-    assert L.bowgpu_abi_version() == 3
+    assert L.bowgpu_abi_version() == capi.ABI_VERSION == int(re.search(r'#define BOWGPU_ABI_VERSION (\d+)', open(os.path.join(ROOT, 'include', 'bowgpu.h')).read()).group(1))
 
 
 def test_plan_on_host_buffers(golden):

@@ -6,6 +6,8 @@ import glob
 import os
 import re
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HDR = open(os.path.join(ROOT, "include", "bowgpu.h")).read()
 GO = {f: open(f).read() for f in glob.glob(os.path.join(ROOT, "shim", "go", "**", "*.go"), recursive=True)}
@@ -41,8 +43,9 @@ def _prototypes():
 
 def test_shim_files_exist_and_are_go_shaped():
     names = {os.path.relpath(f, os.path.join(ROOT, "shim", "go")) for f in GO}
-    assert {"bowfill_gpu.go", "rolling/gpu_cgo.go", "rolling/gpu_kinds.go", "rolling/aggregation/gpu_kinds.go",
-            "rolling/interpolation/gpu_kinds.go", "rolling/transformation/gpu_factor.go"} <= names
+    assert {"bowfill_gpu.go", "rolling/gpu_cgo.go", "rolling/gpu_off.go", "rolling/gpu_kinds.go", "rolling/transformation/gpu_factor.go"} <= names
+    # (round 3 shipped two comment-only files for the constructors: they are real diffs now, shim/go/patches/0002, 0003)
+    assert not {"rolling/aggregation/gpu_kinds.go", "rolling/interpolation/gpu_kinds.go"} & names
     for f, src in GO.items():
         assert re.search(r"^package \w+$", src, flags=re.M), f
         code = re.sub(r"//.*", "", src)
@@ -67,7 +70,7 @@ def test_every_c_name_the_shim_uses_is_in_the_header():
     assert used_fn and used_fn <= set(protos), used_fn - set(protos)
     assert used_const <= set(enums), used_const - set(enums)
     # the entry points of the hot path are bound
-    assert {"bowgpu_rolling_aggregate_planned", "bowgpu_plan_windows_ex", "bowgpu_rolling_interpolate_count", "bowgpu_rolling_interpolate_fill",
+    assert {"bowgpu_rolling_aggregate", "bowgpu_abi_version", "bowgpu_rolling_interpolate_count", "bowgpu_rolling_interpolate_fill",
             "bowgpu_fill_linear", "bowgpu_fill", "bowgpu_is_col_sorted", "bowgpu_shard_begin", "bowgpu_shard_pass_begin", "bowgpu_shard_finish",
             "bowgpu_host_register", "bowgpu_last_error"} <= used_fn
 
@@ -107,3 +110,118 @@ def test_kind_tags_equal_the_header_enums():
     assert got["GPUKindNone"] == -1
     # bow.Type values the shim passes through as bowgpu_col.type (bowtypes.go:21-23)
     assert enums["BOWGPU_FLOAT64"] == 1 and enums["BOWGPU_INT64"] == 2
+
+
+# ---------------------------------------------------------------- the shim against the REFERENCE's types
+# tests/golden/go_type_shapes.json: struct fields / method sets of the reference types the shim reads or extends, extracted from
+# /root/reference by shim/go/make_patches.py in the build container (the reference itself never travels to the GPU box).
+import json
+import shutil
+import subprocess
+import sys
+
+SHAPES = json.load(open(os.path.join(ROOT, "tests", "golden", "go_type_shapes.json")))
+PATCH_DIR = os.path.join(ROOT, "shim", "go", "patches")
+PATCHES = {f: open(os.path.join(PATCH_DIR, f)).read() for f in sorted(os.listdir(PATCH_DIR)) if f.endswith(".patch")}
+REF = os.environ.get("BOW_REFERENCE", "/root/reference")
+
+
+def _go(rel):
+    return re.sub(r"//.*", "", GO[os.path.join(ROOT, "shim", "go", *rel.split("/"))])
+
+
+def _added_by_patches(rel):
+    """lines the patches add to one reference file"""
+    out, cur = [], None
+    for text in PATCHES.values():
+        for line in text.split("\n"):
+            if line.startswith("+++ b/"):
+                cur = line[6:]
+            elif cur == rel and line.startswith("+") and not line.startswith("+++"):
+                out.append(line[1:])
+    return "\n".join(out)
+
+
+def test_the_tag_is_a_field_of_the_reference_types_not_a_wrapper():
+    """ColInterpolation is a struct (no type assertion on it, no embedding wrapper returned as one), and a
+    wrapper around the ColAggregation interface loses its tag in RenameOutput / SetTransformations, which copy the inner struct."""
+    assert SHAPES["rolling.ColInterpolation"]["kind"] == "struct" and SHAPES["rolling.ColAggregation"]["kind"] == "interface"
+    assert {"RenameOutput", "SetTransformations"} <= set(SHAPES["rolling.colAggregation"]["methods"])   # the copying methods live on the struct
+    every = "\n".join(_go(os.path.relpath(f, os.path.join(ROOT, "shim", "go"))) for f in GO)
+    assert "kindedAggregation" not in every and "kindedInterpolation" not in every and "gpuKinded" not in every
+    assert not re.search(r"\bip\.\(", every)                      # no type assertion on a ColInterpolation value
+    # the field is added to BOTH structs by patch 0001, and only there
+    assert re.search(r"^\tgpuKind int32", _added_by_patches("rolling/aggregation.go"), flags=re.M)
+    assert re.search(r"^\tgpuKind int32", _added_by_patches("rolling/interpolation.go"), flags=re.M)
+    assert "gpuKind" not in SHAPES["rolling.colAggregation"]["fields"] + SHAPES["rolling.ColInterpolation"]["fields"]
+    kinds = _go("rolling/gpu_kinds.go")
+    assert re.search(r"NewColAggregation\(inputName, needInclusiveWindow, typ, fn\)\.\(\*colAggregation\)", kinds)   # the concrete type NewColAggregation returns
+    assert "a.gpuKind = kind + 1" in kinds and "ip.gpuKind = kind + 1" in kinds
+    # runtime.Pinner needs Go 1.21: stated as a build constraint, with a fallback file for everything else
+    assert "//go:build bowgpu && go1.21" in GO[os.path.join(ROOT, "shim", "go", "rolling", "gpu_cgo.go")]
+    assert "//go:build !(bowgpu && go1.21)" in GO[os.path.join(ROOT, "shim", "go", "rolling", "gpu_off.go")]
+    assert SHAPES["go.mod"]["go"] == "1.18"
+
+
+def test_every_identifier_the_shim_uses_on_a_reference_type_exists_there():
+    cgo, kinds, off = _go("rolling/gpu_cgo.go"), _go("rolling/gpu_kinds.go"), _go("rolling/gpu_off.go")
+    R = SHAPES["rolling.intervalRolling"]
+    shim_methods = set(re.findall(r"^func \(r \*intervalRolling\) (\w+)\(", cgo, flags=re.M))
+    assert shim_methods - set(R["methods"]) == shim_methods        # the shim adds methods, it does not redefine the reference's
+    assert set(re.findall(r"^func \(r \*intervalRolling\) (\w+)\(", off, flags=re.M)) == {"aggregateWindowsGPU", "interpolateWindowsGPU"} <= shim_methods
+    for name in set(re.findall(r"\br\.(\w+)", cgo)):
+        assert name in R["fields"] or name in R["methods"] or name in shim_methods, ("intervalRolling", name)
+    for name in set(re.findall(r"\br\.options\.(\w+)", cgo)):
+        assert name in SHAPES["rolling.Options"]["fields"], ("Options", name)
+    bow_methods = set(SHAPES["bow.Bow"]["methods"])
+    for name in set(re.findall(r"\b(?:r\.bow|pr|b)\.(\w+)\(", cgo)):
+        assert name in bow_methods, ("bow.Bow", name)
+    for name in set(re.findall(r"\bbow\.(New\w+)\(", cgo)):
+        assert name in SHAPES["bow.funcs"]["funcs"], ("package bow", name)
+    agg_methods = set(SHAPES["rolling.ColAggregation"]["methods"])
+    for name in set(re.findall(r"\ba\.(\w+)\(", cgo)):
+        assert name in agg_methods, ("ColAggregation", name)
+    for name in set(re.findall(r"\bip\.(\w+)", cgo + kinds)):
+        assert name in SHAPES["rolling.ColInterpolation"]["fields"] + ["gpuKind"], ("ColInterpolation", name)
+    for name in set(re.findall(r"\b(?:ca|a)\.(\w+)\b(?!\()", kinds)):
+        assert name in SHAPES["rolling.colAggregation"]["fields"] + ["gpuKind"], ("colAggregation", name)
+    for name in ("NewColAggregation", "NewColInterpolation"):
+        assert name in SHAPES["rolling.funcs"]["funcs"]
+    # transformation.Func is a func type: a Factor is recognised by its code pointer, not by an interface it cannot implement
+    assert SHAPES["transformation"]["Func"].startswith("func(interface{})") and "Factor" in SHAPES["transformation"]["funcs"]
+    fac = _go("rolling/transformation/gpu_factor.go")
+    assert "func FactorOf(f Func) (n float64, ok bool)" in fac and "reflect.ValueOf(Factor(1)).Pointer()" in fac
+    assert "transformation.FactorOf(t)" in cgo and "gpuKindOfAggregation(a)" in cgo
+    # the hooks call what both build variants define, and compare with the sentinel both define
+    hooks = _added_by_patches("rolling/aggregation.go") + _added_by_patches("rolling/interpolation.go")
+    assert "r.aggregateWindowsGPU(aggrs); err != errDeclined" in hooks and "r.interpolateWindowsGPU(interps); err != errDeclined" in hooks
+    assert "var errDeclined" in cgo and "var errDeclined" in off
+
+
+def test_every_builtin_constructor_is_tagged_by_the_patches():
+    kinds = _go("rolling/gpu_kinds.go")
+    tags = set(re.findall(r"\b(GPU(?:Kind|Interp)\w+)\s+int32", kinds)) - {"GPUKindNone"}
+    used = set(re.findall(r"rolling\.(GPU(?:Kind|Interp)\w+)", "\n".join(PATCHES.values())))
+    assert used == tags, (tags - used, used - tags)
+    for text in (PATCHES["0002-aggregation-constructors-carry-their-kind.patch"], PATCHES["0003-interpolation-constructors-carry-their-kind.patch"]):
+        minus = [l for l in text.split("\n") if l.startswith("-") and not l.startswith("---")]
+        plus = [l for l in text.split("\n") if l.startswith("+") and not l.startswith("+++")]
+        assert all("rolling.NewCol" in l or l.strip("-\t ") in ("})", ")") for l in minus), minus
+        assert all("GPU" in l for l in plus), plus              # nothing but the constructor name and the tag changes: the closures are untouched
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="the reference tree is only present in the build container")
+def test_patches_are_reproduced_from_the_reference_and_apply_cleanly(tmp_path):
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "shim", "go", "make_patches.py"), "--check"])
+    touched = sorted({l[6:] for t in PATCHES.values() for l in t.split("\n") if l.startswith("+++ b/")})
+    for rel in touched:
+        os.makedirs(os.path.dirname(tmp_path / rel), exist_ok=True)
+        shutil.copy(os.path.join(REF, rel), tmp_path / rel)
+    for name in PATCHES:
+        subprocess.check_call(["patch", "-p1", "-s", "-i", os.path.join(PATCH_DIR, name)], cwd=tmp_path)
+    agg = open(tmp_path / "rolling/aggregation.go").read()
+    assert agg.count("gpuKind int32") == 1 and "aCopy := *a" in agg                       # the copy keeps the new field
+    assert "rolling.NewColAggregationGPU(col, false, bow.Float64," in open(tmp_path / "rolling/aggregation/arithmeticmean.go").read()
+    for rel in touched:
+        code = re.sub(r"//.*", "", open(tmp_path / rel).read())
+        assert code.count("{") == code.count("}") and code.count("(") == code.count(")"), rel

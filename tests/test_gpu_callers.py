@@ -135,6 +135,20 @@ def test_interpolate_frames_spanning_more_than_2_31(base_ts):
                 want = orc.interpolate([orc.Column(ts, None, orc.INT64), orc.Column(vals, bm, orc.FLOAT64)], 0, interval, ip, offset=offset)
                 cmp_out("wide ts %s I=%d jump=%s" % (kind, interval, with_jump), got[0], want[0])
                 cmp_out("wide val %s I=%d jump=%s" % (kind, interval, with_jump), got[1], want[1])
+                # INCLUSIVE windows on the same frames: only interp_wave3_kernel's trip-relative form takes a frame wider than 2^31.
+                # Without the jump it equals the oracle; with it (one trip spans 3e9) there is no second kernel for inclusive
+                # windows: the call must be declined, never answered with the exclusive layout
+                cols = [capi.Column(ts), capi.Column(vals, bm, capi.FLOAT64, 0, n, -1)]
+                if with_jump:
+                    with pytest.raises(capi.BowGpuError) as ei:
+                        capi.rolling_interpolate(cols, 0, interval, ip, offset=offset, inclusive=True)
+                    assert ei.value.code == -9   # BOWGPU_ERR_UNSUPPORTED
+                else:
+                    goti = capi.rolling_interpolate(cols, 0, interval, ip, offset=offset, inclusive=True)
+                    wanti = orc.interpolate([orc.Column(ts, None, orc.INT64), orc.Column(vals, bm, orc.FLOAT64)], 0, interval, ip,
+                                            offset=offset, inclusive=True)
+                    cmp_out("wide inclusive ts %s I=%d" % (kind, interval), goti[0], wanti[0])
+                    cmp_out("wide inclusive val %s I=%d" % (kind, interval), goti[1], wanti[1])
 
 
 def test_interpolate_empty_window_runs_and_the_minus_one_sentinel():
