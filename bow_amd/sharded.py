@@ -91,17 +91,20 @@ class Gather:
     chosen once, from the backend, so every rank always issues the same collective and a failure surfaces as an error instead
     of a hang."""
 
-    def __init__(self, dist, torch, world, device, nbytes=None):
+    def __init__(self, dist, torch, world, device, nbytes=None, force_collective=False):
         from . import capi
         self.dist, self.torch, self.world, self.device = dist, torch, world, device
         self.n = nbytes if nbytes is not None else C.sizeof(capi.ShardRecord)
-        self.on_gpu = world > 1 and str(device).startswith("cuda")
-        self.single = world > 1 and dist.get_backend() == "nccl"   # all_gather_into_tensor: RCCL; gloo takes the list form
+        # force_collective: run the real exchange even at world 1 (no shortcut) - how the RCCL transport is exercised on a 1-GPU box
+        # (tests/test_gpu_rccl_world1.py): pinned pair, side stream, all_gather_into_tensor(async_op=True), stream-side wait, D2H
+        self.collective = world > 1 or bool(force_collective)
+        self.on_gpu = self.collective and str(device).startswith("cuda")
+        self.single = self.collective and dist.get_backend() == "nccl"   # all_gather_into_tensor: RCCL; gloo takes the list form
         self.ms = 0.0          # host wall time start() -> wait() returned, summed (bench.py: the window the exchange had)
         self.wait_ms = 0.0     # ... of which the host spent blocked inside wait()
         self.calls = 0
         self._work = None
-        if world == 1:
+        if not self.collective:
             return
         pin = bool(self.on_gpu)
         self.h_send = torch.empty(self.n, dtype=torch.uint8, pin_memory=pin)
@@ -116,7 +119,7 @@ class Gather:
             self.recv_views = [src[r * self.n:(r + 1) * self.n] for r in range(world)]
 
     def start(self, payload):
-        if self.world == 1:
+        if not self.collective:
             self._payload = bytes(payload)
             return
         assert self._work is None, "one exchange at a time"
@@ -135,7 +138,7 @@ class Gather:
             self._work = dist.all_gather(self.recv_views, self.h_send, async_op=True)
 
     def wait(self):
-        if self.world == 1:
+        if not self.collective:
             return [self._payload]
         torch = self.torch
         t1 = time.perf_counter()
@@ -306,15 +309,15 @@ class GpuProvider:
 class ShardedRolling:
     """bench.py's multi-GPU step: dense synthetic rows generated in this rank's HBM."""
 
-    def __init__(self, rank, world, rows, interval, aggs, dist, torch, seed=42, offset=0, exchange_device="cuda"):
+    def __init__(self, rank, world, rows, interval, aggs, dist, torch, seed=42, offset=0, exchange_device="cuda", force_collective=False):
         from . import capi
         self.rank, self.world, self.interval, self.aggs = rank, world, interval, aggs
         ts, val = capi.gen_dense(rank * rows, rows, seed=seed)
         self.cols = [ts, val]
         cap = rows // interval + 3
         self.provider = GpuProvider(self.cols, 0, interval, aggs, offset=offset, out_capacity=cap)
-        device = torch.device("cuda", torch.cuda.current_device()) if (world > 1 and exchange_device == "cuda") else "cpu"
-        self.gather = Gather(dist, torch, world, device)
+        device = torch.device("cuda", torch.cuda.current_device()) if ((world > 1 or force_collective) and exchange_device == "cuda") else "cpu"
+        self.gather = Gather(dist, torch, world, device, force_collective=force_collective)
 
     def step(self, overlap=True):
         d = sharded_aggregate(self.provider, self.gather, self.rank, self.world, overlap=overlap)

@@ -317,3 +317,34 @@ def test_c_plan_rejects_ranks_out_of_order_and_handles_rows_below_s0():
     assert d1.retry_with_s0 == 0 and d1.first_window_id == 0 and d1.seed_first_rank == 0
     d0 = sharded.plan(fixed, 0, 5, 4)
     assert d0.first_window_id == 0 and d0.last_window_id == 0 and d0.drops_last == 1 and d0.windows_owned == 0
+
+
+def test_forced_collective_at_world_1_under_gloo():
+    """Gather(force_collective=True) at world 1 issues the real exchange instead of returning the payload (the switch the GPU suite
+    uses to run RCCL on a 1-GPU box, tests/test_gpu_rccl_world1.py); here over gloo on the CPU, list form, and then one whole
+    protocol step through it: same decisions and bytes as the shortcut."""
+    import torch
+    import torch.distributed as dist
+    from bow_amd import sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        plain = sharded.Gather(dist, torch, 1, "cpu")
+        forced = sharded.Gather(dist, torch, 1, "cpu", force_collective=True)
+        assert not plain.collective and forced.collective and not forced.on_gpu and not forced.single
+        payload = bytes(range(256)) * 9 + bytes(forced.n - 2304)
+        payload = payload[:forced.n]
+        forced.start(payload)
+        assert forced._work is not None                       # a collective is in flight
+        assert forced.wait() == [payload] == plain(payload)
+        assert forced.calls == 1 and plain.calls == 0         # (the shortcut does not count as an exchange)
+        ts, vals = _data()
+        outs = []
+        for g in (plain, forced):
+            prov = NumpyProvider(ts, vals, 7)
+            d = sharded.sharded_aggregate(prov, g, 0, 1)
+            outs.append((bytes(d), [repr(r) for r in prov.out]))
+        assert outs[0] == outs[1]
+    finally:
+        dist.destroy_process_group()
