@@ -203,6 +203,86 @@ __device__ __forceinline__ bool kind_is_integral(int kind) {
 }
 
 
+// ---------------------------------------------------------------- the walk of the wave-tile kernels (rolling_simple.hip, rolling_tw.hip)
+// A tile's values are staged in LDS as float64 with the NULL rows already replaced (see rolling_simple.hip "one pass per value
+// column"), so the walk of one lane over one window is branch-free: one LDS read and one addition per row.
+
+// v_min_f64 / v_max_f64 without the canonicalising copies LLVM puts in front of llvm.minnum / maxnum (IEEE mode: a signalling NaN
+// would have to be quieted first).  What the instruction does with the inputs minmax.go never meets in this order - a NaN seed, a
+// signalling NaN, zeros of both signs - is settled after the walk (walk_values), so the raw instruction is enough.
+__device__ __forceinline__ double vmin64(double a, double b) { double d; asm("v_min_f64 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ double vmax64(double a, double b) { double d; asm("v_max_f64 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+constexpr uint64_t kNullAsNaN = 0x7FF8000000000000ull;   // what a null row holds in LDS while extrema are walked (x < mn and x > mx are false for it)
+
+// valid rows of the window [r0, r1) of a tile whose validity words (32 rows each, tile-relative) are vbits[]: how many, the first,
+// the last (count.go:12-18, firstlast.go:11-35, the seed of minmax.go:16-21); fv = lv = -1 when there is none
+__device__ __forceinline__ void window_valid_rows(const uint32_t *vbits, int r0, int r1, int &count, int &fv, int &lv) {
+    count = 0; fv = -1; lv = -1;
+    const int wl = (r1 - 1) >> 5;
+    for (int w = r0 >> 5; w <= wl; w++) {
+        uint32_t m = vbits[w];
+        if (w == (r0 >> 5)) m &= 0xFFFFFFFFu << (r0 & 31);
+        if (w == wl) m &= 0xFFFFFFFFu >> (31 - ((r1 - 1) & 31));
+        count += __popc(m);
+        if (m) {
+            if (fv < 0) fv = w * 32 + __ffs((int)m) - 1;
+            lv = w * 32 + 31 - __clz((int)m);
+        }
+    }
+}
+
+// rows fv .. lv of the staged column in order (sum.go:16-22, arithmeticmean.go:17-24, minmax.go:16-28): four LDS reads in flight, the
+// additions in row order.  Extrema: v_min_f64 / v_max_f64 from the seed (row fv) on.  The instruction differs from
+// `if x < mn { mn = x }` in three cases only - the seed is a NaN (minmax.go keeps it: no value compares below a NaN; the instruction
+// drops it), a signalling NaN among the values (the instruction returns it quieted), and a result of zero (+0 and -0 are equal for
+// minmax.go, so the EARLIEST zero stays; the instruction orders them) - and in those the window is walked again with the
+// comparison itself.  Null rows hold +0.0 when sums are walked and a quiet NaN when extrema are.
+__device__ __forceinline__ void walk_values(const uint64_t *val, int fv, int lv, bool do_sum, bool do_mm, double &sum, double &mn, double &mx) {
+    const double seed = __longlong_as_double((long long)val[fv]);
+    sum = 0.0; mn = seed; mx = seed;
+    if (!(do_sum || do_mm)) return;
+    int r = fv;
+    const int rend = lv + 1;
+    for (; r + 4 <= rend; r += 4) {
+        const double x0 = __longlong_as_double((long long)val[r]), x1 = __longlong_as_double((long long)val[r + 1]);
+        const double x2 = __longlong_as_double((long long)val[r + 2]), x3 = __longlong_as_double((long long)val[r + 3]);
+        if (do_sum) { sum += x0; sum += x1; sum += x2; sum += x3; }
+        if (do_mm) {
+            mn = vmin64(vmin64(vmin64(vmin64(mn, x0), x1), x2), x3);
+            mx = vmax64(vmax64(vmax64(vmax64(mx, x0), x1), x2), x3);
+        }
+    }
+    for (; r < rend; r++) {
+        const double x = __longlong_as_double((long long)val[r]);
+        if (do_sum) sum += x;
+        if (do_mm) { mn = vmin64(mn, x); mx = vmax64(mx, x); }
+    }
+    if (do_mm) {
+        if (seed != seed) { mn = seed; mx = seed; }
+        else if (mn == 0.0 || mx == 0.0 || mn != mn || mx != mx) {
+            mn = seed; mx = seed;
+            for (int rr = fv + 1; rr < rend; rr++) {
+                const double x = __longlong_as_double((long long)val[rr]);
+                if (x < mn) mn = x;
+                if (x > mx) mx = x;
+            }
+        }
+    }
+}
+
+// rows a .. b-1 of a staged array of terms added in order onto +0.0 (the integrals: integral.go:22-31, :48-62)
+__device__ __forceinline__ double walk_terms(const uint64_t *t, int a, int b) {
+    double acc = 0.0;
+    int r = a;
+    for (; r + 4 <= b; r += 4) {
+        const double x0 = __longlong_as_double((long long)t[r]), x1 = __longlong_as_double((long long)t[r + 1]);
+        const double x2 = __longlong_as_double((long long)t[r + 2]), x3 = __longlong_as_double((long long)t[r + 3]);
+        acc += x0; acc += x1; acc += x2; acc += x3;
+    }
+    for (; r < b; r++) acc += __longlong_as_double((long long)t[r]);
+    return acc;
+}
+
 // ---------------------------------------------------------------- the queue of long windows
 // A tile queues at most one window (the one still open at the end of its look-ahead).  kLongLists sub-lists with their
 // own counters (status[16 + s]) keep the appends off a single contended address: 1e5 appends to ONE counter cost ~1 ms.

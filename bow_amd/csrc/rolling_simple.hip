@@ -196,7 +196,7 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
         left_ts = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(tb[j] >> 32), 63) << 32) |
                             (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)tb[j], 63));
         // single column: its values go to LDS now (their registers die here)
-        if (!kMulti) *reinterpret_cast<ulonglong2 *>(&sh.val[l]) = make_ulonglong2(va[j], vb[j]);
+        if (!kMulti && !kNulls && !kInt) *reinterpret_cast<ulonglong2 *>(&sh.val[l]) = make_ulonglong2(va[j], vb[j]);
     }
     if (__ballot(unsorted)) {  // the call fails with BOWGPU_ERR_TS_UNSORTED
         if (lane == 0) atomicOr(&p.status[0], 1u);
@@ -244,30 +244,80 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
     // windows of the call, as an id relative to w0 (the last tile's successor id when the data ends in it)
     const uint64_t Wrel = (uint64_t)p.W - w0;
     const uint32_t W32 = Wrel > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)Wrel;
-    // ---- one pass per value column: stage its values in LDS (the next column's loads go out first), walk, store
+    // which running sums the outputs read (wave-uniform): a call without Sum / ArithmeticMean skips the additions, and a nullable
+    // column then stages its nulls as NaN straight away (see below)
+    bool need_sum = false;
+    for (int a = 0; a < p.naggs; a++) need_sum |= p.kind[a] == BOWGPU_AGG_SUM || p.kind[a] == BOWGPU_AGG_MEAN;
+    // validity words of one column's 640 rows, 32 per lane (lanes 0..19), any bit offset (Arrow slices); issued WITH the column's
+    // value loads so that they share one memory round trip
+    auto load_vword = [&](int c) -> uint32_t {
+        uint32_t word = 0xFFFFFFFFu;
+        if (lane < kRowsS / 32 && p.vbits[c] != nullptr) {
+            const int64_t bit = p.vbit0[c] + base + 32 * (int64_t)lane;
+            const int64_t wi = bit >> 5;
+            const int shb = (int)(bit & 31);
+            const uint32_t lo = wi < p.vwords[c] ? p.vbits[c][wi] : 0u;
+            const uint32_t hi = (shb != 0 && wi + 1 < p.vwords[c]) ? p.vbits[c][wi + 1] : 0u;
+            word = shb ? ((lo >> shb) | (hi << (32 - shb))) : lo;
+        }
+        return word;
+    };
+    uint32_t vword = kNulls ? load_vword(0) : 0u;
+    // ---- one pass per value column: stage its values in LDS (the next column's loads go out first), walk, store.
+    // What is staged is what the walk adds, so the walk itself is branch-free (round 4; the per-row validity test, type switch and
+    // first-value test of the round-1 walk cost 14 instructions per row on a chain only 512 / w lanes deep):
+    //   * Int64 columns are converted to float64 here, ten rows per lane in parallel, not one per step of the walk;
+    //   * a NULL row holds +0.0 while sums are walked - exact: sum.go:16 starts at +0.0 and x + (+0.0) == x bit for bit for every
+    //     x but -0.0, which a sum that started at +0.0 can never be - and a quiet NaN while extrema are walked (x < mn, x > mx are
+    //     false for it: minmax.go:22-27 would have skipped the row);
+    //   * count / first / last valid row of a window come from its validity words (popcount, count-leading / trailing-zeros).
     const int ncols = kMulti ? p.ncols : 1;
     for (int c = 0; c < ncols; c++) {
         const bool cint = kMulti ? (p.col_is_int[c] != 0) : kInt;  // mixed column types: per pass (uniform)
-        if (kMulti) {
+        constexpr bool kStageHere = kMulti || kNulls || kInt;
+        if (kStageHere) {
             lds_order();  // the previous pass is done with sh.val / sh.vbits
-#pragma unroll
-            for (int j = 0; j < kChunksS; j++)
-                *reinterpret_cast<ulonglong2 *>(&sh.val[j * 128 + 2 * lane]) = make_ulonglong2(va[j], vb[j]);
-            if (c + 1 < ncols) load_col(reinterpret_cast<const uint64_t *>(p.values[c + 1]), va, vb, !((p.unaligned_mask >> (c + 1)) & 1u));
-        }
-        if (kNulls && lane < kRowsS / 32) {  // 32 validity bits per lane, any bit offset (Arrow slices)
-            uint32_t word = 0xFFFFFFFFu;
-            if (p.vbits[c] != nullptr) {
-                const int64_t bit = p.vbit0[c] + base + 32 * (int64_t)lane;
-                const int64_t wi = bit >> 5;
-                const int shb = (int)(bit & 31);
-                const uint32_t lo = wi < p.vwords[c] ? p.vbits[c][wi] : 0u;
-                const uint32_t hi = (shb != 0 && wi + 1 < p.vwords[c]) ? p.vbits[c][wi + 1] : 0u;
-                word = shb ? ((lo >> shb) | (hi << (32 - shb))) : lo;
+            if (kNulls) {
+                if (lane < kRowsS / 32) sh.vbits[lane] = vword;
+                lds_order();
             }
-            sh.vbits[lane] = word;
+            const uint64_t fill = need_sum ? 0ull : kNullAsNaN;
+#pragma unroll
+            for (int j = 0; j < kChunksS; j++) {
+                uint64_t xa = va[j], xb = vb[j];
+                if (cint) {
+                    xa = (uint64_t)__double_as_longlong((double)(int64_t)xa);
+                    xb = (uint64_t)__double_as_longlong((double)(int64_t)xb);
+                }
+                if (kNulls) {
+                    const uint32_t two = sh.vbits[j * 4 + (lane >> 4)] >> ((2 * lane) & 31);
+                    if (!(two & 1u)) xa = fill;
+                    if (!(two & 2u)) xb = fill;
+                }
+                *reinterpret_cast<ulonglong2 *>(&sh.val[j * 128 + 2 * lane]) = make_ulonglong2(xa, xb);
+            }
+            if (kMulti && c + 1 < ncols) {
+                load_col(reinterpret_cast<const uint64_t *>(p.values[c + 1]), va, vb, !((p.unaligned_mask >> (c + 1)) & 1u));
+                if (kNulls) vword = load_vword(c + 1);
+            }
         }
         lds_order();
+        // a nullable column whose outputs want sums AND extrema is walked twice: phase 1 with +0.0 in the null rows (everything but
+        // Min / Max), then the null rows are overwritten with NaN and phase 2 walks the extrema.  Every other shape: phase 0, one walk.
+        const bool two_phase = kNulls && (kNeed & 1) && need_sum;
+        for (int phase = two_phase ? 1 : 0; phase <= (two_phase ? 2 : 0); phase++) {
+            if (phase == 2) {
+                lds_order();
+#pragma unroll
+                for (int j = 0; j < kChunksS; j++) {
+                    const uint32_t two = sh.vbits[j * 4 + (lane >> 4)] >> ((2 * lane) & 31);
+                    if (!(two & 1u)) sh.val[j * 128 + 2 * lane] = kNullAsNaN;
+                    if (!(two & 2u)) sh.val[j * 128 + 2 * lane + 1] = kNullAsNaN;
+                }
+                lds_order();
+            }
+            const bool do_sum = need_sum && phase != 2;
+            const bool do_mm = (kNeed & 1) && phase != 1;
 
     for (int q = q_start + lane; q < q_end; q += kWave) {
         const uint32_t e0 = sh.seg[q], e1 = sh.seg[q + 1];
@@ -283,49 +333,29 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
             next_wid = W32;
         } else {
             // rows run past the look-ahead: hand the window (all its columns) to the cooperative path
-            if (c == 0) {
+            if (c == 0 && phase != 2) {
                 push_long_window(p.status, p.long_list, p.long_cap, tile, (uint64_t)p.wid_base + w0 + wid, base + r0);
             }
             continue;
         }
         // window 0 made only of rows below s0 is an EMPTY slice in the reference (rolling.go:194-196: lastRowIndex stays -1)
         const bool dead = pre && tile == 0 && q == 0 && p.ts[base + r1 - 1] < p.s0;
-        // ---- the walk: rows r0 .. r1-1 in order (sum.go:16-22, arithmeticmean.go:17-24, minmax.go:16-28, count.go:12-18)
+        // ---- valid rows of the window: how many, the first, the last; then the walk (agg_device.h)
+        int count = r1 - r0, fv = r0, lv = r1 - 1;
+        if (kNulls) window_valid_rows(sh.vbits, r0, r1, count, fv, lv);
+        if (dead) count = 0;
         double sum = 0.0, mn = 0.0, mx = 0.0;
         uint64_t first_raw = 0, last_raw = 0;
-        int count;
-        if (dead) count = 0;
-        else if (!kNulls) {
-            first_raw = sh.val[r0];
-            mn = cint ? (double)(int64_t)first_raw : __longlong_as_double((long long)first_raw);
-            mx = mn;
-            auto step = [&](uint64_t raw) {
-                const double x = cint ? (double)(int64_t)raw : __longlong_as_double((long long)raw);
-                sum += x;
-                if (kNeed & 1) {
-                    if (x < mn) mn = x;
-                    if (x > mx) mx = x;
+        if (count > 0) {
+            first_raw = sh.val[fv];
+            walk_values(sh.val, fv, lv, do_sum, do_mm, sum, mn, mx);
+            if (kNeed & 2) {
+                last_raw = sh.val[lv];
+                if (cint) {   // the staged values are float64(v): First / Last return the Int64 itself (firstlast.go:17, :32)
+                    const uint64_t *__restrict__ src = reinterpret_cast<const uint64_t *>(p.values[c]);
+                    first_raw = src[base + fv];
+                    last_raw = src[base + lv];
                 }
-            };
-            int r = r0;
-            for (; r + 4 <= r1; r += 4) {  // four LDS reads in flight; the additions stay in row order
-                const uint64_t q0 = sh.val[r], q1 = sh.val[r + 1], q2 = sh.val[r + 2], q3 = sh.val[r + 3];
-                step(q0); step(q1); step(q2); step(q3);
-            }
-            for (; r < r1; r++) step(sh.val[r]);
-            count = r1 - r0;
-            if (kNeed & 2) last_raw = sh.val[r1 - 1];
-        } else {
-            count = 0;
-            for (int r = r0; r < r1; r++) {
-                if (!((sh.vbits[r >> 5] >> (r & 31)) & 1u)) continue;
-                const uint64_t raw = sh.val[r];
-                const double x = cint ? (double)(int64_t)raw : __longlong_as_double((long long)raw);
-                sum += x;
-                if (count == 0) { mn = x; mx = x; first_raw = raw; }
-                else if (kNeed & 1) { if (x < mn) mn = x; if (x > mx) mx = x; }
-                last_raw = raw;
-                count++;
             }
         }
         const int nrows = dead ? 0 : r1 - r0;
@@ -343,13 +373,14 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
         for (int a_ = 0; a_ < p.naggs; a_++) {
             const int a = __builtin_amdgcn_readfirstlane(a_);
             if (kMulti && p.col[a] != c) continue;
+            const int k = p.kind[a];
+            if (phase != 0 && (phase == 2) != (k == BOWGPU_AGG_MIN || k == BOWGPU_AGG_MAX)) continue;   // two walks: each output once
             // (p is the kernel's first argument: its bytes start the kernel-argument segment, which is constant address space)
             typedef const uint64_t __attribute__((address_space(4))) *karg_u64;
             typedef uint64_t __attribute__((address_space(1))) *global_u64;   // (a pointer read as an integer has lost its address space: say it)
             const global_u64 out_a = (global_u64)((karg_u64)__builtin_amdgcn_kernarg_segment_ptr())[offsetof(SimpleParams, out_values) / 8 + a];
             uint64_t bits;
             bool nil = false;
-            const int k = p.kind[a];
             switch (k) {
             case BOWGPU_AGG_WINDOW_START: bits = (uint64_t)win_start; break;
             case BOWGPU_AGG_SUM: bits = (uint64_t)__double_as_longlong(sum); break;
@@ -384,6 +415,7 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
             }
         }
     }
+        }  // phases
     }  // columns
 }
 

@@ -21,8 +21,8 @@
 // The previous valid point of a row: the row before it (a DPP move) in a column without nulls; with nulls the nearest set bit
 // below it in the tile's validity words (count-leading-zeros), its value and time gathered from LDS.
 // One LDS array serves every phase of a column in turn - the staged values (Sum / Mean / Min / Max / First / Last: the walk of
-// rolling_simple.hip), then the step terms, then the trapezoid terms, written in place - next to the rows' times, which every term
-// pass reads: nothing of a tile stays in registers between the phases.
+// rolling_simple.hip), then the step terms, then the trapezoid terms, written in place from registers - so the wavefront's LDS is
+// 6 KB for columns without nulls (round 3: 8 - 11.4 KB).
 // What this kernel does not take goes to rolling_agg.hip (64-bit window ids, tiles denser than the head list).
 #include <type_traits>
 
@@ -41,22 +41,23 @@ constexpr int kRowsT = kTileT + kHaloT;
 constexpr int kChunksT = kRowsT / 128;
 constexpr uint32_t kSatT = 0xFFFFu;
 // At most TwCap windows may start inside one tile (+ look-ahead); denser tiles send the call to the general kernel.  Sized so that the
-// wavefront's LDS ends on a 1 KB allocation step: 9 KB with 32-bit times (370 heads; 350 with nulls), 11 KB with 64-bit times (230)
+// wavefront's LDS ends on a 1 KB allocation step: 6 KB (columns without nulls: 250 heads = windows of >= 2.6 rows), 9 KB (nulls,
+// 32-bit times: 356 heads), 11 KB (nulls, 64-bit times: 230 heads)
 template <bool kNulls, bool kTs32>
-struct TwCap { static constexpr int value = kTs32 ? (kNulls ? 350 : 370) : 230; };
+struct TwCap { static constexpr int value = !kNulls ? 250 : (kTs32 ? 356 : 230); };
 
 // kTs32: float64(ts) is rebuilt as float64(s0 of slot 0) + float64(offset), which is exact - and so equal to the reference's single
 // conversion (integral.go:17) - when every |ts| of the call is below 2^53 (the host checks; nanosecond epochs take the 64-bit form).
 template <bool kNulls, bool kTs32>
 struct TwShared {
     uint64_t val[kRowsT];                          // the column's staged values; then its step terms; then its trapezoid terms
-    // the time of every row, where the term pass reads a row's own and its previous point's: a 32-bit offset from slot 0 (kTs32) or the int64 itself
-    typename std::conditional<kTs32, uint32_t, int64_t>::type tsx[kRowsT];
-    uint32_t vbits[kNulls ? kRowsT / 32 + 2 : 2];  // validity words of the value column for this tile
+    // nullable columns: where a row's previous valid point is gathered from - its time as a 32-bit offset from slot 0 (kTs32) or as the int64 itself
+    typename std::conditional<kTs32, uint32_t, int64_t>::type tsx[kNulls ? kRowsT : 1];
+    uint32_t vbits[kNulls ? kRowsT / 32 + 2 : 1];  // validity words of the value column for this tile
     uint32_t seg[TwCap<kNulls, kTs32>::value + 2]; // heads in row order: local row | on-window-start flag << 15 | (wid - wid of the tile's first row) << 16
 };
-static_assert(sizeof(TwShared<false, true>) <= 9216 && sizeof(TwShared<true, true>) <= 9216, "LDS of the 32-bit forms: 9 KB");
-static_assert(sizeof(TwShared<false, false>) <= 11264 && sizeof(TwShared<true, false>) <= 11264, "LDS of the 64-bit forms: 11 KB");
+static_assert(sizeof(TwShared<false, true>) <= 6144 && sizeof(TwShared<false, false>) <= 6144, "LDS of the dense forms: 6 KB");
+static_assert(sizeof(TwShared<true, true>) <= 9216 && sizeof(TwShared<true, false>) <= 11264, "LDS of the nullable forms: 9 / 11 KB");
 
 __device__ __forceinline__ uint32_t mdiv32(uint32_t n, uint32_t m, uint32_t sh1, uint32_t sh2) {
     const uint32_t t = __umulhi(m, n);
@@ -93,9 +94,8 @@ __device__ __forceinline__ void lds_order() {
 
 // kNulls: some column has nulls; kWide: see rolling_simple.hip (window ids relative to the tile's first window: rows may span more
 // than 2^32 from slot 0); kTs32: times as 32-bit offsets from slot 0 (above)
-// kBoth: the call has step AND trapezoid integrals: the terms of the second kind wait in registers while the first kind is walked
-template <bool kNulls, bool kWide, bool kTs32, bool kBoth>
-__global__ __launch_bounds__(kWave, 4) void rolling_tw_kernel(const SimpleParams p, const int64_t ntiles, const int64_t tiles_per_xcd) {
+template <bool kNulls, bool kWide, bool kTs32>
+__global__ __launch_bounds__(kWave, 2) void rolling_tw_kernel(const SimpleParams p, const int64_t ntiles, const int64_t tiles_per_xcd) {
     static_assert(!(kWide && kTs32), "the wide form keeps 64-bit timestamps");
     __shared__ TwShared<kNulls, kTs32> sh;
     constexpr int kSegCapT = TwCap<kNulls, kTs32>::value;
@@ -194,7 +194,10 @@ __global__ __launch_bounds__(kWave, 4) void rolling_tw_kernel(const SimpleParams
     const uint32_t left_w0 = base == 0 ? 0xFFFFFFFEu : (pre && left0 < ws0) ? 0u : (kWide && left0 < ws0) ? 0xFFFFFFFEu : mdiv32(rel32(left0), p.m32, p.sh1, p.sh2);
     uint32_t left_w = left_w0;
     int64_t left_ts = left0;
-    typedef typename std::conditional<kTs32, uint32_t, uint64_t>::type tkey_t;   // a row's time as the term pass reads it back from LDS
+    // what the term pass keeps of a row's timestamp: its 32-bit offset from slot 0 (kTs32), else the int64 itself - float64(ts) and the
+    // window id are both recomputed from it (keeping them for ten rows per lane cost more registers than the kernel had)
+    typedef typename std::conditional<kTs32, uint32_t, uint64_t>::type tkey_t;
+    tkey_t tka[kChunksT], tkb[kChunksT];
     int nseg_total = 0, nseg_owned = 0;
 #pragma unroll
     for (int j = 0; j < kChunksT; j++) {
@@ -209,6 +212,7 @@ __global__ __launch_bounds__(kWave, 4) void rolling_tw_kernel(const SimpleParams
         uint32_t wa = mdiv32(ra, p.m32, p.sh1, p.sh2);
         uint32_t wb = mdiv32(rb, p.m32, p.sh1, p.sh2);
         if (pre) { if (tsa < ws0) wa = 0u; if (tsb < ws0) wb = 0u; }
+        if (kTs32) { tka[j] = (tkey_t)ra; tkb[j] = (tkey_t)rb; } else { tka[j] = (tkey_t)ta[j]; tkb[j] = (tkey_t)tb[j]; }
         const uint32_t wprev = left32(wb, left_w);
         const bool ha = pa && (wa != wprev);
         const bool hb = pb && (wb != wa);
@@ -234,9 +238,10 @@ __global__ __launch_bounds__(kWave, 4) void rolling_tw_kernel(const SimpleParams
         left_w = (uint32_t)__builtin_amdgcn_readlane((int)wb, 63);
         left_ts = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(tb[j] >> 32), 63) << 32) |
                             (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)tb[j], 63));
-        // the rows' times, for the term passes (float64(ts) and the window id are both recomputed from them there)
-        if (kTs32) *reinterpret_cast<uint2 *>(&sh.tsx[l]) = make_uint2(ra, rb);   // (l is even: one 8-byte LDS write)
-        else *reinterpret_cast<ulonglong2 *>(&sh.tsx[l]) = make_ulonglong2(ta[j], tb[j]);
+        if (kNulls) {   // where the term pass gathers the time of a row's previous valid point from
+            if (kTs32) *reinterpret_cast<uint2 *>(&sh.tsx[l]) = make_uint2(ra, rb);   // (l is even: one 8-byte LDS write)
+            else *reinterpret_cast<ulonglong2 *>(&sh.tsx[l]) = make_ulonglong2(ta[j], tb[j]);
+        }
     }
     if (__ballot(unsorted)) {  // the call fails with BOWGPU_ERR_TS_UNSORTED
         if (lane == 0) atomicOr(&p.status[0], 1u);
@@ -276,6 +281,7 @@ __global__ __launch_bounds__(kWave, 4) void rolling_tw_kernel(const SimpleParams
     const int ncols = p.ncols;
     for (int c = 0; c < ncols; c++) {
         const bool cint = p.col_is_int[c] != 0;  // mixed column types: per pass (uniform)
+        const bool col_tw = (need_step || need_trap);   // (a column none of whose outputs integrates still computes nothing it does not need: the phases below skip by kind)
         // ---- stage the values (converted to float64, nulls replaced: rolling_simple.hip) - the gather source of the term pass for a
         // nullable column, and what the value reducers walk
         lds_order();  // the previous pass is done with sh.val / sh.vbits
@@ -283,78 +289,67 @@ __global__ __launch_bounds__(kWave, 4) void rolling_tw_kernel(const SimpleParams
             if (lane < kRowsT / 32) sh.vbits[lane] = vword;
             lds_order();
         }
-        // ---- stage the column: float64(v) (Int64 columns are converted here: bowgetters.go:224-229), null rows replaced as in
-        // rolling_simple.hip.  It is what the value reducers walk and what the term pass reads.
+        // Int64 columns: converted to float64 once, in place (bowgetters.go:224-229 converts per element; First / Last, which return the
+        // Int64 itself, go back to the column for it)
+        if (cint) {
+#pragma unroll
+            for (int j = 0; j < kChunksT; j++) {
+                va[j] = (uint64_t)__double_as_longlong((double)(int64_t)va[j]);
+                vb[j] = (uint64_t)__double_as_longlong((double)(int64_t)vb[j]);
+            }
+        }
+        auto conv = [&](uint64_t x) -> double { return __longlong_as_double((long long)x); };
+        uint32_t okbits = 0;   // bit 2j: row a of chunk j is a valid point, bit 2j+1: row b
         {
             const uint64_t fill = need_sum ? 0ull : kNullAsNaN;
 #pragma unroll
             for (int j = 0; j < kChunksT; j++) {
+                uint32_t two = 3u;
+                if (kNulls) two = (sh.vbits[j * 4 + (lane >> 4)] >> ((2 * lane) & 31)) & 3u;
                 const int l = j * 128 + 2 * lane;
-                uint64_t ra_ = va[j], rb_ = vb[j];
-                if (cint) {
-                    ra_ = (uint64_t)__double_as_longlong((double)(int64_t)ra_);
-                    rb_ = (uint64_t)__double_as_longlong((double)(int64_t)rb_);
+                if (l >= nloc) two = 0u; else if (l + 1 >= nloc) two &= 1u;
+                okbits |= two << (2 * j);
+                if (kNulls || need_vals) {
+                    uint64_t ra_ = (uint64_t)__double_as_longlong(conv(va[j])), rb_ = (uint64_t)__double_as_longlong(conv(vb[j]));
+                    if (kNulls) { if (!(two & 1u)) ra_ = fill; if (!(two & 2u)) rb_ = fill; }
+                    *reinterpret_cast<ulonglong2 *>(&sh.val[l]) = make_ulonglong2(ra_, rb_);
                 }
-                if (kNulls) {
-                    const uint32_t two = sh.vbits[j * 4 + (lane >> 4)] >> ((2 * lane) & 31);
-                    if (!(two & 1u)) ra_ = fill;
-                    if (!(two & 2u)) rb_ = fill;
-                }
-                *reinterpret_cast<ulonglong2 *>(&sh.val[l]) = make_ulonglong2(ra_, rb_);
             }
         }
-        // the next column's loads go out now: its registers are free (this column lives in LDS)
-        if (c + 1 < ncols) {
-            load_col(reinterpret_cast<const uint64_t *>(p.values[c + 1]), va, vb, !((p.unaligned_mask >> (c + 1)) & 1u));
-            if (kNulls) vword = load_vword(c + 1);
-        }
         lds_order();
-        // ---- the term pass: the terms of this lane's ten rows from the staged values and times.  `first` (step terms when the call
-        // has them, else trapezoid terms) replaces the staged values in LDS - chunk by chunk for a column without nulls (a row's
-        // previous point is the previous row: read before the chunk is written, the row in front of the NEXT chunk saved first);
-        // after the whole pass for a nullable column (previous points are gathered from anywhere below).  kBoth: the trapezoid terms
-        // wait in registers until the step terms have been walked.
-        double keep_a[kBoth ? kChunksT : 1], keep_b[kBoth ? kChunksT : 1];               // the second kind (kBoth)
-        double first_a[kNulls ? kChunksT : 1], first_b[kNulls ? kChunksT : 1];           // the first kind of a nullable column, until the pass is over
-        auto term_pass = [&]() __attribute__((always_inline)) {
-            const bool first_is_step = need_step;
-            double carry_x = 0.0;                   // staged value of row 128 j - 1, read before chunk j - 1 was overwritten
-            uint32_t carry_w = left_w0;             // ... its window id
+        // ---- the terms of this lane's ten rows.  A column without nulls: computed in the phase that walks them, straight into LDS
+        // (nothing is gathered: the previous point is the previous row).  With nulls: both kinds now, into registers, while sh.val still
+        // holds the values the previous points are gathered from; they replace the staged values phase by phase.
+        double st_a[kNulls ? kChunksT : 1], st_b[kNulls ? kChunksT : 1], tr_a[kNulls ? kChunksT : 1], tr_b[kNulls ? kChunksT : 1];
+        auto term_pass = [&](bool want_step, bool want_trap, bool to_lds_step) __attribute__((always_inline)) {
+            double carry_x = 0.0, carry_t = 0.0;    // row 128 j - 1: the previous chunk's last row (lane 63, row b)
+            uint32_t carry_w = left_w0;
 #pragma unroll
             for (int j = 0; j < kChunksT; j++) {
                 const int l = j * 128 + 2 * lane;
-                const ulonglong2 xv = *reinterpret_cast<const ulonglong2 *>(&sh.val[l]);
-                const double xa = __longlong_as_double((long long)xv.x), xb = __longlong_as_double((long long)xv.y);
-                tkey_t ka, kb;
-                if (kTs32) { const uint2 k2 = *reinterpret_cast<const uint2 *>(&sh.tsx[l]); ka = (tkey_t)k2.x; kb = (tkey_t)k2.y; }
-                else { const ulonglong2 k2 = *reinterpret_cast<const ulonglong2 *>(&sh.tsx[l]); ka = (tkey_t)k2.x; kb = (tkey_t)k2.y; }
-                const double ta_d = time_d(ka), tb_d = time_d(kb);
-                const uint32_t wa = wid_k(ka), wb = wid_k(kb);
+                const double ta_d = time_d(tka[j]), tb_d = time_d(tkb[j]);
+                const uint32_t wa = wid_k(tka[j]), wb = wid_k(tkb[j]);
+                const double xa = conv(va[j]), xb = conv(vb[j]);
                 const uint32_t wprev = left32(wb, carry_w);
                 const bool ha = l < nloc && wa != wprev, hb = l + 1 < nloc && wb != wa;
                 double sa = 0.0, sb = 0.0, qa = 0.0, qb = 0.0;
                 if (!kNulls) {
-                    // previous point of row a: the row before it; of row b: row a
-                    const int lp = l > 0 ? l - 1 : 0;
-                    const double xp = (lane == 0 && j > 0) ? carry_x : __longlong_as_double((long long)sh.val[lp]);
-                    const double tp = time_d((tkey_t)sh.tsx[lp]);
+                    // previous point of row a: row b of the lane to the left; of row b: row a
+                    const double xp = left64(xb, carry_x), tp = left64(tb_d, carry_t);
                     const double dta = ta_d - tp, dtb = tb_d - ta_d;
-                    if (need_step) {
+                    if (want_step) {
                         sa = ha ? xp * (last_value_d(wprev) - abs_d(tp)) : xp * dta;
                         sb = hb ? xa * (last_value_d(wa) - abs_d(ta_d)) : xa * dtb;
                     }
-                    if (need_trap) {
+                    if (want_trap) {
                         qa = (xp + xa) / 2 * dta;
                         qb = (xa + xb) / 2 * dtb;
                     }
-                    if (j + 1 < kChunksT) carry_x = __longlong_as_double((long long)sh.val[j * 128 + 127]);
-                    lds_order();   // every lane has read this chunk's values
-                    const double oa = first_is_step ? sa : qa, ob = first_is_step ? sb : qb;
+                    carry_x = lane63(xb); carry_t = lane63(tb_d);
+                    const double oa = to_lds_step ? sa : qa, ob = to_lds_step ? sb : qb;
                     *reinterpret_cast<ulonglong2 *>(&sh.val[l]) = make_ulonglong2((uint64_t)__double_as_longlong(oa), (uint64_t)__double_as_longlong(ob));
                 } else {
-                    uint32_t two = (sh.vbits[j * 4 + (lane >> 4)] >> ((2 * lane) & 31)) & 3u;
-                    if (l >= nloc) two = 0u; else if (l + 1 >= nloc) two &= 1u;
-                    const bool a_ok = two & 1u, b_ok = two & 2u;
+                    const bool a_ok = (okbits >> (2 * j)) & 1u, b_ok = (okbits >> (2 * j + 1)) & 1u;
                     // previous valid point of row a: the nearest set bit below it in the tile's validity words
                     int wi = l >> 5;
                     uint32_t m = sh.vbits[wi] & ((1u << (l & 31)) - 1u);
@@ -373,33 +368,31 @@ __global__ __launch_bounds__(kWave, 4) void rolling_tw_kernel(const SimpleParams
                     const double xp2 = a_ok ? xa : xp, tp2 = a_ok ? ta_d : tp;
                     const uint32_t wp2 = a_ok ? wa : wp;
                     const bool has_p2 = a_ok || has_p;
-                    if (need_step) {
+                    if (want_step) {
                         if (ha) sa = has_p ? xp * (last_value_d(wp) - abs_d(tp)) : 0.0;
                         else if (a_ok && has_p && wp == wa) sa = xp * (ta_d - tp);
                         if (hb) sb = has_p2 ? xp2 * (last_value_d(wp2) - abs_d(tp2)) : 0.0;
                         else if (b_ok && has_p2 && wp2 == wb) sb = xp2 * (tb_d - tp2);
                     }
-                    if (need_trap) {
+                    if (want_trap) {
                         if (a_ok && has_p && (ha || wp == wa)) qa = (xp + xa) / 2 * (ta_d - tp);
                         if (b_ok && has_p2 && (hb || wp2 == wb)) qb = (xp2 + xb) / 2 * (tb_d - tp2);
                     }
-                    first_a[kNulls ? j : 0] = first_is_step ? sa : qa;
-                    first_b[kNulls ? j : 0] = first_is_step ? sb : qb;
+                    st_a[kNulls ? j : 0] = sa; st_b[kNulls ? j : 0] = sb; tr_a[kNulls ? j : 0] = qa; tr_b[kNulls ? j : 0] = qb;
                 }
-                if (kBoth) { keep_a[kBoth ? j : 0] = qa; keep_b[kBoth ? j : 0] = qb; }
                 carry_w = (uint32_t)__builtin_amdgcn_readlane((int)wb, 63);
-                // (one chunk at a time: left to itself the scheduler interleaves the five unrolled chunks to hide latencies, which costs
-                // more registers than the kernel has)
+                // (one chunk at a time: left to itself the scheduler interleaves the five unrolled chunks to hide latencies and the
+                // kernel needs 160 registers instead of 100)
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (kNulls) {
-                lds_order();   // every gather of the pass is done
-#pragma unroll
-                for (int j = 0; j < kChunksT; j++)
-                    *reinterpret_cast<ulonglong2 *>(&sh.val[j * 128 + 2 * lane]) = make_ulonglong2(
-                        (uint64_t)__double_as_longlong(first_a[kNulls ? j : 0]), (uint64_t)__double_as_longlong(first_b[kNulls ? j : 0]));
-            }
         };
+        if (kNulls && col_tw) term_pass(need_step, need_trap, false);
+        // the next column's loads go out now when its registers are free (a nullable column lives in LDS and in the term registers; a
+        // column without nulls computes its terms from va / vb in the phases below, so its successor is loaded behind them)
+        if (kNulls && c + 1 < ncols) {
+            load_col(reinterpret_cast<const uint64_t *>(p.values[c + 1]), va, vb, !((p.unaligned_mask >> (c + 1)) & 1u));
+            if (kNulls) vword = load_vword(c + 1);
+        }
         // ---- phases, each one walk over what sh.val holds:
         //   0 / 1 / 2  the staged values (rolling_simple.hip: 1 + 2 when a nullable column feeds sums AND extrema), every output that
         //              is not an integral; 3  the step terms; 4  the trapezoid terms
@@ -415,20 +408,21 @@ __global__ __launch_bounds__(kWave, 4) void rolling_tw_kernel(const SimpleParams
 #pragma unroll
                 for (int j = 0; j < kChunksT; j++) {
                     const int l = j * 128 + 2 * lane;
-                    const uint32_t two = sh.vbits[j * 4 + (lane >> 4)] >> ((2 * lane) & 31);
-                    if (!(two & 1u)) sh.val[l] = kNullAsNaN;
-                    if (!(two & 2u)) sh.val[l + 1] = kNullAsNaN;
+                    if (!((okbits >> (2 * j)) & 1u)) sh.val[l] = kNullAsNaN;
+                    if (!((okbits >> (2 * j + 1)) & 1u)) sh.val[l + 1] = kNullAsNaN;
                 }
                 lds_order();
             }
             if (phase >= 3) {
-                lds_order();   // the walks of the phase before are done with sh.val
-                if (phase == 3 || !need_step) term_pass();
-                else if (kBoth) {
+                lds_order();
+                if (!kNulls) term_pass(phase == 3, phase == 4, phase == 3);
+                else {
 #pragma unroll
-                    for (int j = 0; j < kChunksT; j++)
-                        *reinterpret_cast<ulonglong2 *>(&sh.val[j * 128 + 2 * lane]) = make_ulonglong2(
-                            (uint64_t)__double_as_longlong(keep_a[kBoth ? j : 0]), (uint64_t)__double_as_longlong(keep_b[kBoth ? j : 0]));
+                    for (int j = 0; j < kChunksT; j++) {
+                        const double a_ = phase == 3 ? st_a[kNulls ? j : 0] : tr_a[kNulls ? j : 0], b_ = phase == 3 ? st_b[kNulls ? j : 0] : tr_b[kNulls ? j : 0];
+                        *reinterpret_cast<ulonglong2 *>(&sh.val[j * 128 + 2 * lane]) =
+                            make_ulonglong2((uint64_t)__double_as_longlong(a_), (uint64_t)__double_as_longlong(b_));
+                    }
                 }
                 lds_order();
             }
@@ -593,22 +587,14 @@ int launch_rolling_tw(Ctx *c, const SimpleParams &p, bool is_int, bool has_nulls
     const int64_t grid = per_xcd * 8;
     if (grid > 0x7FFFFFFFll) return fail(BOWGPU_ERR_UNSUPPORTED, "too many rows for one launch: %lld", (long long)p.n);
     const dim3 g((unsigned)grid), blk(kWave);
-    bool step = false, trap = false;
-    for (int a = 0; a < p.naggs; a++) {
-        step |= p.kind[a] == BOWGPU_AGG_INTEGRAL_STEP || p.kind[a] == BOWGPU_AGG_WAVG_STEP;
-        trap |= p.kind[a] == BOWGPU_AGG_INTEGRAL_TRAPEZOID || p.kind[a] == BOWGPU_AGG_WAVG_LINEAR;
-    }
-    const bool both = step && trap;
-#define BG_TW2(U, B)                                                                                                        \
-    do {                                                                                                                    \
-        if (wide) hipLaunchKernelGGL((rolling_tw_kernel<U, true, false, B>), g, blk, 0, c->stream, p, ntiles, per_xcd);      \
-        else if (ts32) hipLaunchKernelGGL((rolling_tw_kernel<U, false, true, B>), g, blk, 0, c->stream, p, ntiles, per_xcd); \
-        else hipLaunchKernelGGL((rolling_tw_kernel<U, false, false, B>), g, blk, 0, c->stream, p, ntiles, per_xcd);         \
+#define BG_TW(U)                                                                                                         \
+    do {                                                                                                                 \
+        if (wide) hipLaunchKernelGGL((rolling_tw_kernel<U, true, false>), g, blk, 0, c->stream, p, ntiles, per_xcd);      \
+        else if (ts32) hipLaunchKernelGGL((rolling_tw_kernel<U, false, true>), g, blk, 0, c->stream, p, ntiles, per_xcd); \
+        else hipLaunchKernelGGL((rolling_tw_kernel<U, false, false>), g, blk, 0, c->stream, p, ntiles, per_xcd);         \
     } while (0)
-#define BG_TW(U) do { if (both) BG_TW2(U, true); else BG_TW2(U, false); } while (0)
     if (has_nulls) BG_TW(true); else BG_TW(false);
 #undef BG_TW
-#undef BG_TW2
     BG_HIP(hipGetLastError());
     return 0;
 }

@@ -139,7 +139,8 @@ def test_interpolate_frames_spanning_more_than_2_31(base_ts):
                 # Without the jump it equals the oracle; with it (one trip spans 3e9) there is no second kernel for inclusive
                 # windows: the call must be declined, never answered with the exclusive layout
                 cols = [capi.Column(ts), capi.Column(vals, bm, capi.FLOAT64, 0, n, -1)]
-                if with_jump:
+                below_s0 = capi.plan_windows(cols[0], interval, offset)[0] > int(ts[0])   # negative timestamps: Go's truncating division
+                if with_jump or below_s0:                                                 # (rows below s0 + inclusive windows: declined as before)
                     with pytest.raises(capi.BowGpuError) as ei:
                         capi.rolling_interpolate(cols, 0, interval, ip, offset=offset, inclusive=True)
                     assert ei.value.code == -9   # BOWGPU_ERR_UNSUPPORTED
