@@ -14,9 +14,9 @@
 //   * a row that is not its window's first valid point holds its term against the previous valid point of the SAME window;
 //   * a row that is the first valid point of its window holds +0.0 (adding +0.0 to a sum that started at +0.0 changes no bit);
 //   * the slot of a window's FIRST ROW (a head: valid or not, its own term is never added) holds what CLOSES the window before
-//     it: for the step integral v0 * (float64(LastValue) - t0) of that window's last valid point (integral.go:49-55), for the
-//     trapezoid the term that joins that point to the head row - added only when the head row is the inclusive row of the window
-//     before (rolling.go:201-209);
+//     it: for the step integral the value v0 of that window's last valid point - its lane adds v0 * (float64(LastValue) - t0)
+//     (integral.go:49-55) - and for the trapezoid the term that joins that point to the head row, added only when the head row is
+//     the inclusive row of the window before (rolling.go:201-209);
 //   * null rows hold +0.0.
 // The previous valid point of a row: the row before it (a DPP move) in a column without nulls; with nulls the nearest set bit
 // below it in the tile's validity words (count-leading-zeros), its value and time gathered from LDS.
@@ -39,11 +39,13 @@ constexpr int kTileT = 512;
 constexpr int kHaloT = 128;
 constexpr int kRowsT = kTileT + kHaloT;
 constexpr int kChunksT = kRowsT / 128;
-constexpr uint32_t kSatT = 0xFFFFu;
-// At most TwCap windows may start inside one tile (+ look-ahead); denser tiles send the call to the general kernel.  Sized so that the
-// wavefront's LDS ends on a 1 KB allocation step: 9 KB with 32-bit times (370 heads; 350 with nulls), 11 KB with 64-bit times (230)
+// At most TwCap windows may start inside one tile (+ look-ahead); denser tiles send the call to the general kernel.  The head list holds
+// 16-bit entries (row | on-window-start flag << 15; the window id of a head is recomputed from its staged time, so ids of any
+// distance inside one tile stay on this kernel).  The kernel's rate follows its occupancy and that follows the LDS per wavefront
+// (1 KB steps), so the list is sized to the byte: 32-bit times 8 KB (20 wavefronts per CU): 240 heads = windows of >= 2.7 rows, 208
+// with nulls; 64-bit times 11 KB (14 per CU): 464 heads
 template <bool kNulls, bool kTs32>
-struct TwCap { static constexpr int value = kTs32 ? (kNulls ? 350 : 370) : 230; };
+struct TwCap { static constexpr int value = kTs32 ? (kNulls ? 208 : 240) : 464; };
 
 // kTs32: float64(ts) is rebuilt as float64(s0 of slot 0) + float64(offset), which is exact - and so equal to the reference's single
 // conversion (integral.go:17) - when every |ts| of the call is below 2^53 (the host checks; nanosecond epochs take the 64-bit form).
@@ -53,9 +55,9 @@ struct TwShared {
     // the time of every row, where the term pass reads a row's own and its previous point's: a 32-bit offset from slot 0 (kTs32) or the int64 itself
     typename std::conditional<kTs32, uint32_t, int64_t>::type tsx[kRowsT];
     uint32_t vbits[kNulls ? kRowsT / 32 + 2 : 2];  // validity words of the value column for this tile
-    uint32_t seg[TwCap<kNulls, kTs32>::value + 2]; // heads in row order: local row | on-window-start flag << 15 | (wid - wid of the tile's first row) << 16
+    uint16_t seg[TwCap<kNulls, kTs32>::value + 2]; // heads in row order: local row | on-window-start flag << 15
 };
-static_assert(sizeof(TwShared<false, true>) <= 9216 && sizeof(TwShared<true, true>) <= 9216, "LDS of the 32-bit forms: 9 KB");
+static_assert(sizeof(TwShared<false, true>) <= 8192 && sizeof(TwShared<true, true>) <= 8192, "LDS of the 32-bit forms: 8 KB");
 static_assert(sizeof(TwShared<false, false>) <= 11264 && sizeof(TwShared<true, false>) <= 11264, "LDS of the 64-bit forms: 11 KB");
 
 __device__ __forceinline__ uint32_t mdiv32(uint32_t n, uint32_t m, uint32_t sh1, uint32_t sh2) {
@@ -190,11 +192,11 @@ __global__ __launch_bounds__(kWave, 4) void rolling_tw_kernel(const SimpleParams
     auto wid_of = [&](int64_t t) -> uint32_t { return (pre && t < ws0) ? 0u : mdiv32(rel32(t), p.m32, p.sh1, p.sh2); };
 
     // ---- window ids (32-bit), head flags, compaction with a running scalar count
-    const uint32_t w_first = (kWide || pre) ? 0u : mdiv32((uint32_t)ts_first - s0_lo, p.m32, p.sh1, p.sh2);
     const uint32_t left_w0 = base == 0 ? 0xFFFFFFFEu : (pre && left0 < ws0) ? 0u : (kWide && left0 < ws0) ? 0xFFFFFFFEu : mdiv32(rel32(left0), p.m32, p.sh1, p.sh2);
     uint32_t left_w = left_w0;
     int64_t left_ts = left0;
     typedef typename std::conditional<kTs32, uint32_t, uint64_t>::type tkey_t;   // a row's time as the term pass reads it back from LDS
+    uint32_t hmask = 0;   // bit 2j: row a of chunk j starts a window, bit 2j + 1: row b
     int nseg_total = 0, nseg_owned = 0;
 #pragma unroll
     for (int j = 0; j < kChunksT; j++) {
@@ -212,8 +214,7 @@ __global__ __launch_bounds__(kWave, 4) void rolling_tw_kernel(const SimpleParams
         const uint32_t wprev = left32(wb, left_w);
         const bool ha = pa && (wa != wprev);
         const bool hb = pb && (wb != wa);
-        const uint32_t la = wa - w_first, lb = wb - w_first;
-        sat |= (ha && la >= kSatT) || (hb && lb >= kSatT);
+        hmask |= (ha ? 1u : 0u) << (2 * j) | (hb ? 2u : 0u) << (2 * j);
         const unsigned long long ma = __ballot(ha), mb = __ballot(hb);
         int pos = nseg_total;
         pos += __builtin_amdgcn_mbcnt_hi((unsigned)(ma >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ma, 0));
@@ -226,9 +227,9 @@ __global__ __launch_bounds__(kWave, 4) void rolling_tw_kernel(const SimpleParams
             sa = (ra == wa * ik && (((uint64_t)tsa - (uint64_t)ws0) & lowmask) == 0) ? 0x8000u : 0u;
             sb = (rb == wb * ik && (((uint64_t)tsb - (uint64_t)ws0) & lowmask) == 0) ? 0x8000u : 0u;
         }
-        if (ha && pos < kSegCapT) sh.seg[pos] = (uint32_t)l | sa | (la << 16);
+        if (ha && pos < kSegCapT) sh.seg[pos] = (uint16_t)((uint32_t)l | sa);
         pos += ha ? 1 : 0;
-        if (hb && pos < kSegCapT) sh.seg[pos] = (uint32_t)(l + 1) | sb | (lb << 16);
+        if (hb && pos < kSegCapT) sh.seg[pos] = (uint16_t)((uint32_t)(l + 1) | sb);
         nseg_total += __popcll(ma) + __popcll(mb);
         if (j == kChunksT - 2) nseg_owned = nseg_total;
         left_w = (uint32_t)__builtin_amdgcn_readlane((int)wb, 63);
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(kWave, 4) void rolling_tw_kernel(const SimpleParams
         return;
     }
     if (nseg_total > kSegCapT) sat = true;
-    if (__ballot(sat)) {  // a tile the 16-bit local ids / the segment list cannot describe: the host redoes the call with the general kernel
+    if (__ballot(sat)) {  // a tile the segment list / the 32-bit arithmetic cannot describe: the host redoes the call with the general kernel
         // (one atomic per call, not one per tile: 2e5 atomics on one address took 2 ms)
         if (lane == 0 && !__hip_atomic_load(&p.status[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(&p.status[4], 1u);
         return;
@@ -319,7 +320,6 @@ __global__ __launch_bounds__(kWave, 4) void rolling_tw_kernel(const SimpleParams
         auto term_pass = [&]() __attribute__((always_inline)) {
             const bool first_is_step = need_step;
             double carry_x = 0.0;                   // staged value of row 128 j - 1, read before chunk j - 1 was overwritten
-            uint32_t carry_w = left_w0;             // ... its window id
 #pragma unroll
             for (int j = 0; j < kChunksT; j++) {
                 const int l = j * 128 + 2 * lane;
@@ -328,20 +328,22 @@ __global__ __launch_bounds__(kWave, 4) void rolling_tw_kernel(const SimpleParams
                 tkey_t ka, kb;
                 if (kTs32) { const uint2 k2 = *reinterpret_cast<const uint2 *>(&sh.tsx[l]); ka = (tkey_t)k2.x; kb = (tkey_t)k2.y; }
                 else { const ulonglong2 k2 = *reinterpret_cast<const ulonglong2 *>(&sh.tsx[l]); ka = (tkey_t)k2.x; kb = (tkey_t)k2.y; }
-                const double ta_d = time_d(ka), tb_d = time_d(kb);
-                const uint32_t wa = wid_k(ka), wb = wid_k(kb);
-                const uint32_t wprev = left32(wb, carry_w);
-                const bool ha = l < nloc && wa != wprev, hb = l + 1 < nloc && wb != wa;
+                // float64(t1) - float64(t0) (integral.go:28, :54): with 32-bit offsets the difference of the offsets, converted - exact, and
+                // equal to the difference of the two float64 times, which are exact themselves (every |ts| < 2^53)
+                auto dt_of = [&](tkey_t k1, tkey_t k0) -> double {
+                    return kTs32 ? (double)(uint32_t)((uint32_t)k1 - (uint32_t)k0) : time_d(k1) - time_d(k0);
+                };
+                const bool ha = (hmask >> (2 * j)) & 1u, hb = (hmask >> (2 * j + 1)) & 1u;
                 double sa = 0.0, sb = 0.0, qa = 0.0, qb = 0.0;
                 if (!kNulls) {
-                    // previous point of row a: the row before it; of row b: row a
+                    // previous point of row a: the row before it; of row b: row a.  A head's slot: the value of the point before it (step:
+                    // what the window's lane multiplies by the time left in the window before; trapezoid: the joining term)
                     const int lp = l > 0 ? l - 1 : 0;
                     const double xp = (lane == 0 && j > 0) ? carry_x : __longlong_as_double((long long)sh.val[lp]);
-                    const double tp = time_d((tkey_t)sh.tsx[lp]);
-                    const double dta = ta_d - tp, dtb = tb_d - ta_d;
+                    const double dta = dt_of(ka, (tkey_t)sh.tsx[lp]), dtb = dt_of(kb, ka);
                     if (need_step) {
-                        sa = ha ? xp * (last_value_d(wprev) - abs_d(tp)) : xp * dta;
-                        sb = hb ? xa * (last_value_d(wa) - abs_d(ta_d)) : xa * dtb;
+                        sa = ha ? xp : xp * dta;
+                        sb = hb ? xa : xa * dtb;
                     }
                     if (need_trap) {
                         qa = (xp + xa) / 2 * dta;
@@ -360,34 +362,33 @@ __global__ __launch_bounds__(kWave, 4) void rolling_tw_kernel(const SimpleParams
                     uint32_t m = sh.vbits[wi] & ((1u << (l & 31)) - 1u);
                     while (m == 0u && wi > 0) { wi--; m = sh.vbits[wi]; }
                     const int pr = m ? wi * 32 + 31 - __clz((int)m) : -1;
-                    double xp = 0.0, tp = 0.0;
-                    uint32_t wp = 0xFFFFFFFDu;
-                    if (pr >= 0) {
-                        xp = __longlong_as_double((long long)sh.val[pr]);
-                        const tkey_t kp = (tkey_t)sh.tsx[pr];
-                        tp = time_d(kp);
-                        wp = wid_k(kp);
-                    }
                     const bool has_p = pr >= 0;
+                    const int prc = has_p ? pr : 0;
+                    const double xp = __longlong_as_double((long long)sh.val[prc]);
+                    const tkey_t kp = (tkey_t)sh.tsx[prc];
+                    // the same window?  (a head's previous point never is; a row that follows a head in its lane pair may not be either)
+                    const uint32_t wa = wid_k(ka), wb = wid_k(kb), wp = wid_k(kp);
+                    const bool same_a = has_p && !ha && wp == wa;
                     // ... of row b: row a when that is a valid point
-                    const double xp2 = a_ok ? xa : xp, tp2 = a_ok ? ta_d : tp;
-                    const uint32_t wp2 = a_ok ? wa : wp;
+                    const double xp2 = a_ok ? xa : xp;
+                    const tkey_t kp2 = a_ok ? ka : kp;
                     const bool has_p2 = a_ok || has_p;
+                    const bool same_b = has_p2 && !hb && (a_ok ? wa : wp) == wb;
+                    const double dta = dt_of(ka, kp), dtb = dt_of(kb, kp2);
                     if (need_step) {
-                        if (ha) sa = has_p ? xp * (last_value_d(wp) - abs_d(tp)) : 0.0;
-                        else if (a_ok && has_p && wp == wa) sa = xp * (ta_d - tp);
-                        if (hb) sb = has_p2 ? xp2 * (last_value_d(wp2) - abs_d(tp2)) : 0.0;
-                        else if (b_ok && has_p2 && wp2 == wb) sb = xp2 * (tb_d - tp2);
+                        if (ha) sa = xp;                       // (read only when the window before has a valid point: then it is that point)
+                        else if (a_ok && same_a) sa = xp * dta;
+                        if (hb) sb = xp2;
+                        else if (b_ok && same_b) sb = xp2 * dtb;
                     }
                     if (need_trap) {
-                        if (a_ok && has_p && (ha || wp == wa)) qa = (xp + xa) / 2 * (ta_d - tp);
-                        if (b_ok && has_p2 && (hb || wp2 == wb)) qb = (xp2 + xb) / 2 * (tb_d - tp2);
+                        if (a_ok && has_p && (ha || same_a)) qa = (xp + xa) / 2 * dta;
+                        if (b_ok && has_p2 && (hb || same_b)) qb = (xp2 + xb) / 2 * dtb;
                     }
                     first_a[kNulls ? j : 0] = first_is_step ? sa : qa;
                     first_b[kNulls ? j : 0] = first_is_step ? sb : qb;
                 }
                 if (kBoth) { keep_a[kBoth ? j : 0] = qa; keep_b[kBoth ? j : 0] = qb; }
-                carry_w = (uint32_t)__builtin_amdgcn_readlane((int)wb, 63);
                 // (one chunk at a time: left to itself the scheduler interleaves the five unrolled chunks to hide latencies, which costs
                 // more registers than the kernel has)
                 __builtin_amdgcn_sched_barrier(0);
@@ -439,12 +440,12 @@ __global__ __launch_bounds__(kWave, 4) void rolling_tw_kernel(const SimpleParams
     for (int q = lane; q < nseg_owned; q += kWave) {
         const uint32_t e0 = sh.seg[q], e1 = sh.seg[q + 1];
         const int r0 = (int)(e0 & 0x7FFFu);
-        const uint32_t wid = w_first + (e0 >> 16);
+        const uint32_t wid = wid_k((tkey_t)sh.tsx[r0]);   // (the id of a head row from its staged time: the division the flag pass did)
         int r1;
         uint32_t next_wid;
         if (q + 1 < nseg_total) {
             r1 = (int)(e1 & 0x7FFFu);
-            next_wid = w_first + (e1 >> 16);
+            next_wid = wid_k((tkey_t)sh.tsx[r1]);
         } else if (reaches_end) {
             r1 = nloc;
             next_wid = W32;
@@ -486,14 +487,13 @@ __global__ __launch_bounds__(kWave, 4) void rolling_tw_kernel(const SimpleParams
             integ = walk_terms(sh.val, fv + 1, lv + 1);
             if (phase == 3) {
                 // + v0 * (float64(LastValue) - t0) of the last valid point (integral.go:49-55): staged in the next window's head slot
-                double closing;
-                if (next_staged) closing = __longlong_as_double((long long)sh.val[r1]);
-                else {   // the data ends inside this window (one window per call): from the columns themselves
+                double pv;
+                if (next_staged) pv = __longlong_as_double((long long)sh.val[r1]);   // the next window's head slot: the value of the point before it
+                else {   // the data ends inside this window (one window per call): from the column itself
                     const uint64_t raw = reinterpret_cast<const uint64_t *>(p.values[c])[base + lv];
-                    const double pv = cint ? (double)(int64_t)raw : __longlong_as_double((long long)raw);
-                    closing = pv * (last_value_d(wid) - (double)p.ts[base + lv]);
+                    pv = cint ? (double)(int64_t)raw : __longlong_as_double((long long)raw);
                 }
-                integ = integ + closing;
+                integ = integ + pv * (last_value_d(wid) - abs_d(time_d((tkey_t)sh.tsx[lv])));
             } else {
                 // the inclusive row (the successor's first row, when it sits on this window's end and is a valid point) joins in
                 int cnt = count;
