@@ -1025,6 +1025,14 @@ static int job_launch_tiles(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t
             S.out_values[i] = reinterpret_cast<uint64_t *>(P.aggs[i].out_values);
             S.out_valid[i] = P.aggs[i].out_valid;
         }
+        for (int i = 0; i < naggs; i++) {
+            const int k = aggs[i].kind;
+            if (k == BOWGPU_AGG_INTEGRAL_STEP || k == BOWGPU_AGG_WAVG_STEP) S.need |= kNeedStep;
+            if (k == BOWGPU_AGG_INTEGRAL_TRAPEZOID || k == BOWGPU_AGG_WAVG_LINEAR) S.need |= kNeedTrap;
+            if (k == BOWGPU_AGG_MIN || k == BOWGPU_AGG_MAX) S.need |= kNeedMinMax;
+            if (k == BOWGPU_AGG_SUM || k == BOWGPU_AGG_MEAN) S.need |= kNeedSum;
+            if (k == BOWGPU_AGG_FIRST || k == BOWGPU_AGG_LAST) S.need |= kNeedFirstLast;
+        }
         S.status = P.status; S.long_list = P.long_list; S.long_cap = P.long_cap;
         S.inclusive = job->inclusive ? 1 : 0;
         S.pre_rows = P.pre_rows;

@@ -216,13 +216,15 @@ struct AggParams {
 };
 
 constexpr int kSimpleMaxAggs = 16;
+enum : uint32_t { kNeedStep = 1, kNeedTrap = 2, kNeedMinMax = 4, kNeedSum = 8, kNeedFirstLast = 16 };
 // descriptor of rolling_simple.hip's kernel: value columns of one type, factor-free outputs, 32-bit window ids
 struct SimpleParams {
     const int64_t *ts;
     int64_t n, s0, interval, W;            // s0 = start of output slot 0 (a shard: global s0 + wid_base * interval)
     int64_t wid_base;                      // global id of output slot 0 (only for the long-window queue)
     MagicDiv magic;                        // 64-bit magic of the interval: the per-tile base window of the kWide variants
-    int32_t shift_k, _pad4;                // kWide: trailing zero bits of the interval; m32 / sh1 / sh2 then divide by interval >> shift_k
+    int32_t shift_k;                       // kWide: trailing zero bits of the interval; m32 / sh1 / sh2 then divide by interval >> shift_k
+    uint32_t need;                         // kNeed* bits: which running statistics the outputs of the call read (set by the host: one scalar test per use in the kernels)
     uint32_t m32, sh1, sh2;
     int32_t naggs;
     int32_t ncols;                         // value columns (>= 1; reducers over the interval column use it as a column)

@@ -246,8 +246,7 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
     const uint32_t W32 = Wrel > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)Wrel;
     // which running sums the outputs read (wave-uniform): a call without Sum / ArithmeticMean skips the additions, and a nullable
     // column then stages its nulls as NaN straight away (see below)
-    bool need_sum = false;
-    for (int a = 0; a < p.naggs; a++) need_sum |= p.kind[a] == BOWGPU_AGG_SUM || p.kind[a] == BOWGPU_AGG_MEAN;
+    const bool need_sum = p.need & kNeedSum;
     // validity words of one column's 640 rows, 32 per lane (lanes 0..19), any bit offset (Arrow slices); issued WITH the column's
     // value loads so that they share one memory round trip
     auto load_vword = [&](int c) -> uint32_t {
@@ -304,7 +303,8 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
         lds_order();
         // a nullable column whose outputs want sums AND extrema is walked twice: phase 1 with +0.0 in the null rows (everything but
         // Min / Max), then the null rows are overwritten with NaN and phase 2 walks the extrema.  Every other shape: phase 0, one walk.
-        const bool two_phase = kNulls && (kNeed & 1) && need_sum;
+        const bool two_phase = kNulls && (kNeed & 1) && need_sum && nseg_total <= kTwoWalksMaxHeads;
+        const bool pred_walk = kNulls && (kNeed & 1) && need_sum && !two_phase;   // one walk, extrema under the validity bit
         for (int phase = two_phase ? 1 : 0; phase <= (two_phase ? 2 : 0); phase++) {
             if (phase == 2) {
                 lds_order();
@@ -348,7 +348,8 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
         uint64_t first_raw = 0, last_raw = 0;
         if (count > 0) {
             first_raw = sh.val[fv];
-            walk_values(sh.val, fv, lv, do_sum, do_mm, sum, mn, mx);
+            if (kNulls && pred_walk) walk_values_pred(sh.val, sh.vbits, fv, lv, sum, mn, mx);
+            else walk_values(sh.val, fv, lv, do_sum, do_mm, sum, mn, mx);
             if (kNeed & 2) {
                 last_raw = sh.val[lv];
                 if (cint) {   // the staged values are float64(v): First / Last return the Int64 itself (firstlast.go:17, :32)

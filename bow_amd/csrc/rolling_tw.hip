@@ -197,6 +197,17 @@ __global__ __launch_bounds__(kWave, 4) void rolling_tw_kernel(const SimpleParams
     int64_t left_ts = left0;
     typedef typename std::conditional<kTs32, uint32_t, uint64_t>::type tkey_t;   // a row's time as the term pass reads it back from LDS
     uint32_t hmask = 0;   // bit 2j: row a of chunk j starts a window, bit 2j + 1: row b
+    // which running statistics the outputs of this call read (set by the host, wave-uniform): only those are staged, computed and walked
+    const bool need_step = p.need & kNeedStep, need_trap = p.need & kNeedTrap, need_mm = p.need & kNeedMinMax, need_sum = p.need & kNeedSum,
+               need_fl = p.need & kNeedFirstLast;
+    const bool need_vals = need_mm || need_sum || need_fl;
+    // The usual call - integrals only (next to WindowStart / Count / NumRows), first column without nulls: the terms of column 0 are
+    // computed right here in the flag pass, where a row's timestamp, value, head flag and left neighbour are all in registers, and go
+    // straight to LDS: no staging, no term pass, no value phase.
+    const bool early_terms = !kNulls && !need_vals;
+    double keep_a[kBoth ? kChunksT : 1], keep_b[kBoth ? kChunksT : 1];   // kBoth: the trapezoid terms wait here while the step terms are walked
+    double early_carry_x = 0.0;
+    const bool cint0 = p.col_is_int[0] != 0;
     int nseg_total = 0, nseg_owned = 0;
 #pragma unroll
     for (int j = 0; j < kChunksT; j++) {
@@ -238,6 +249,21 @@ __global__ __launch_bounds__(kWave, 4) void rolling_tw_kernel(const SimpleParams
         // the rows' times, for the term passes (float64(ts) and the window id are both recomputed from them there)
         if (kTs32) *reinterpret_cast<uint2 *>(&sh.tsx[l]) = make_uint2(ra, rb);   // (l is even: one 8-byte LDS write)
         else *reinterpret_cast<ulonglong2 *>(&sh.tsx[l]) = make_ulonglong2(ta[j], tb[j]);
+        if (early_terms) {   // (see the term pass below for what a slot holds)
+            const double xa = cint0 ? (double)(int64_t)va[j] : __longlong_as_double((long long)va[j]);
+            const double xb = cint0 ? (double)(int64_t)vb[j] : __longlong_as_double((long long)vb[j]);
+            const double xp = left64(xb, early_carry_x);
+            early_carry_x = lane63(xb);
+            // float64(t1) - float64(t0): the 32-bit difference converted (exact: both times are, and they are less than 2^32 apart), else as written
+            const double dta = kTs32 ? (double)(uint32_t)((uint32_t)tsa - (uint32_t)prev_ts) : (double)tsa - (double)prev_ts;
+            const double dtb = kTs32 ? (double)(uint32_t)((uint32_t)tsb - (uint32_t)tsa) : (double)tsb - (double)tsa;
+            double s1 = 0.0, s2 = 0.0, q1 = 0.0, q2 = 0.0;
+            if (need_step) { s1 = ha ? xp : xp * dta; s2 = hb ? xa : xa * dtb; }
+            if (need_trap) { q1 = (xp + xa) / 2 * dta; q2 = (xa + xb) / 2 * dtb; }
+            const double oa = need_step ? s1 : q1, ob = need_step ? s2 : q2;
+            *reinterpret_cast<ulonglong2 *>(&sh.val[l]) = make_ulonglong2((uint64_t)__double_as_longlong(oa), (uint64_t)__double_as_longlong(ob));
+            if (kBoth) { keep_a[kBoth ? j : 0] = q1; keep_b[kBoth ? j : 0] = q2; }
+        }
     }
     if (__ballot(unsorted)) {  // the call fails with BOWGPU_ERR_TS_UNSORTED
         if (lane == 0) atomicOr(&p.status[0], 1u);
@@ -251,17 +277,6 @@ __global__ __launch_bounds__(kWave, 4) void rolling_tw_kernel(const SimpleParams
     }
 
     const bool reaches_end = base + kRowsT >= n;
-    // which running statistics the outputs of this call read (wave-uniform): only those are staged, computed and walked
-    bool need_step = false, need_trap = false, need_mm = false, need_sum = false, need_fl = false;
-    for (int a = 0; a < p.naggs; a++) {
-        const int k = p.kind[a];
-        need_step |= k == BOWGPU_AGG_INTEGRAL_STEP || k == BOWGPU_AGG_WAVG_STEP;
-        need_trap |= k == BOWGPU_AGG_INTEGRAL_TRAPEZOID || k == BOWGPU_AGG_WAVG_LINEAR;
-        need_mm |= k == BOWGPU_AGG_MIN || k == BOWGPU_AGG_MAX;
-        need_sum |= k == BOWGPU_AGG_SUM || k == BOWGPU_AGG_MEAN;
-        need_fl |= k == BOWGPU_AGG_FIRST || k == BOWGPU_AGG_LAST;
-    }
-    const bool need_vals = need_mm || need_sum || need_fl;
     // windows of the call, as an id relative to w0 (the last tile's successor id when the data ends in it)
     const uint64_t Wrel = (uint64_t)p.W - w0;
     const uint32_t W32 = Wrel > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)Wrel;
@@ -280,13 +295,14 @@ __global__ __launch_bounds__(kWave, 4) void rolling_tw_kernel(const SimpleParams
         // ---- stage the values (converted to float64, nulls replaced: rolling_simple.hip) - the gather source of the term pass for a
         // nullable column, and what the value reducers walk
         lds_order();  // the previous pass is done with sh.val / sh.vbits
+        const bool early = early_terms && c == 0;   // its first kind of terms is in sh.val already (flag pass)
         if (kNulls) {
             if (lane < kRowsT / 32) sh.vbits[lane] = vword;
             lds_order();
         }
         // ---- stage the column: float64(v) (Int64 columns are converted here: bowgetters.go:224-229), null rows replaced as in
         // rolling_simple.hip.  It is what the value reducers walk and what the term pass reads.
-        {
+        if (!early) {
             const uint64_t fill = need_sum ? 0ull : kNullAsNaN;
 #pragma unroll
             for (int j = 0; j < kChunksT; j++) {
@@ -315,11 +331,16 @@ __global__ __launch_bounds__(kWave, 4) void rolling_tw_kernel(const SimpleParams
         // previous point is the previous row: read before the chunk is written, the row in front of the NEXT chunk saved first);
         // after the whole pass for a nullable column (previous points are gathered from anywhere below).  kBoth: the trapezoid terms
         // wait in registers until the step terms have been walked.
-        double keep_a[kBoth ? kChunksT : 1], keep_b[kBoth ? kChunksT : 1];               // the second kind (kBoth)
         double first_a[kNulls ? kChunksT : 1], first_b[kNulls ? kChunksT : 1];           // the first kind of a nullable column, until the pass is over
         auto term_pass = [&]() __attribute__((always_inline)) {
             const bool first_is_step = need_step;
             double carry_x = 0.0;                   // staged value of row 128 j - 1, read before chunk j - 1 was overwritten
+            // (the head flags and the tile's row count do not change from column to column and phase to phase: left visible, the compiler
+            // hoists the twenty lane masks derived from them to the top of the kernel and spills them - 60 scalar registers, a
+            // v_readlane per use)
+            uint32_t hm = hmask;
+            int nl = nloc;
+            asm volatile("" : "+v"(hm), "+s"(nl));
 #pragma unroll
             for (int j = 0; j < kChunksT; j++) {
                 const int l = j * 128 + 2 * lane;
@@ -333,7 +354,7 @@ __global__ __launch_bounds__(kWave, 4) void rolling_tw_kernel(const SimpleParams
                 auto dt_of = [&](tkey_t k1, tkey_t k0) -> double {
                     return kTs32 ? (double)(uint32_t)((uint32_t)k1 - (uint32_t)k0) : time_d(k1) - time_d(k0);
                 };
-                const bool ha = (hmask >> (2 * j)) & 1u, hb = (hmask >> (2 * j + 1)) & 1u;
+                const bool ha = (hm >> (2 * j)) & 1u, hb = (hm >> (2 * j + 1)) & 1u;
                 double sa = 0.0, sb = 0.0, qa = 0.0, qb = 0.0;
                 if (!kNulls) {
                     // previous point of row a: the row before it; of row b: row a.  A head's slot: the value of the point before it (step:
@@ -355,7 +376,7 @@ __global__ __launch_bounds__(kWave, 4) void rolling_tw_kernel(const SimpleParams
                     *reinterpret_cast<ulonglong2 *>(&sh.val[l]) = make_ulonglong2((uint64_t)__double_as_longlong(oa), (uint64_t)__double_as_longlong(ob));
                 } else {
                     uint32_t two = (sh.vbits[j * 4 + (lane >> 4)] >> ((2 * lane) & 31)) & 3u;
-                    if (l >= nloc) two = 0u; else if (l + 1 >= nloc) two &= 1u;
+                    if (l >= nl) two = 0u; else if (l + 1 >= nl) two &= 1u;
                     const bool a_ok = two & 1u, b_ok = two & 2u;
                     // previous valid point of row a: the nearest set bit below it in the tile's validity words
                     int wi = l >> 5;
@@ -404,11 +425,12 @@ __global__ __launch_bounds__(kWave, 4) void rolling_tw_kernel(const SimpleParams
         // ---- phases, each one walk over what sh.val holds:
         //   0 / 1 / 2  the staged values (rolling_simple.hip: 1 + 2 when a nullable column feeds sums AND extrema), every output that
         //              is not an integral; 3  the step terms; 4  the trapezoid terms
-        const bool two_phase = kNulls && need_mm && need_sum;
+        const bool two_phase = kNulls && need_mm && need_sum && nseg_total <= kTwoWalksMaxHeads;
+        const bool pred_walk = kNulls && need_mm && need_sum && !two_phase;   // one walk, extrema under the validity bit (agg_device.h)
         for (int phase = two_phase ? 1 : 0; phase <= 4; phase++) {
             if (phase == 1 && !two_phase) continue;
             if (phase == 2 && !two_phase) continue;
-            if (phase == 0 && two_phase) continue;
+            if (phase == 0 && (two_phase || (!need_vals && (need_step || need_trap)))) continue;   // (no value reducer: the first integral phase also writes WindowStart / Count / NumRows)
             if (phase == 3 && !need_step) continue;
             if (phase == 4 && !need_trap) continue;
             if (phase == 2) {
@@ -424,7 +446,7 @@ __global__ __launch_bounds__(kWave, 4) void rolling_tw_kernel(const SimpleParams
             }
             if (phase >= 3) {
                 lds_order();   // the walks of the phase before are done with sh.val
-                if (phase == 3 || !need_step) term_pass();
+                if (phase == 3 || !need_step) { if (!early) term_pass(); }
                 else if (kBoth) {
 #pragma unroll
                     for (int j = 0; j < kChunksT; j++)
@@ -435,7 +457,8 @@ __global__ __launch_bounds__(kWave, 4) void rolling_tw_kernel(const SimpleParams
             }
             const bool do_sum = need_sum && phase <= 1;
             const bool do_mm = need_mm && (phase == 0 || phase == 2);
-            const bool first_phase = phase == (two_phase ? 1 : 0);
+            const int phase1 = two_phase ? 1 : (need_vals || !(need_step || need_trap)) ? 0 : need_step ? 3 : 4;   // the first phase that runs
+            const bool first_phase = phase == phase1;
 
     for (int q = lane; q < nseg_owned; q += kWave) {
         const uint32_t e0 = sh.seg[q], e1 = sh.seg[q + 1];
@@ -471,7 +494,8 @@ __global__ __launch_bounds__(kWave, 4) void rolling_tw_kernel(const SimpleParams
         if (phase <= 2) {
             if (has_value && need_vals) {
                 first_raw = sh.val[fv];
-                walk_values(sh.val, fv, lv, do_sum, do_mm, sum, mn, mx);
+                if (kNulls && pred_walk) walk_values_pred(sh.val, sh.vbits, fv, lv, sum, mn, mx);
+                else walk_values(sh.val, fv, lv, do_sum, do_mm, sum, mn, mx);
                 if (need_fl) {
                     last_raw = sh.val[lv];
                     if (cint) {   // the staged values are float64(v): First / Last return the Int64 itself (firstlast.go:17, :32)
@@ -523,7 +547,7 @@ __global__ __launch_bounds__(kWave, 4) void rolling_tw_kernel(const SimpleParams
             const bool k_trap = k == BOWGPU_AGG_INTEGRAL_TRAPEZOID || k == BOWGPU_AGG_WAVG_LINEAR;
             const bool k_mm = k == BOWGPU_AGG_MIN || k == BOWGPU_AGG_MAX;
             // each output in exactly one phase
-            const int home = k_step ? 3 : k_trap ? 4 : (two_phase ? (k_mm ? 2 : 1) : 0);
+            const int home = k_step ? 3 : k_trap ? 4 : (two_phase ? (k_mm ? 2 : 1) : phase1);
             if (home != phase) continue;
             typedef const uint64_t __attribute__((address_space(4))) *karg_u64;
             typedef uint64_t __attribute__((address_space(1))) *global_u64;
@@ -593,12 +617,7 @@ int launch_rolling_tw(Ctx *c, const SimpleParams &p, bool is_int, bool has_nulls
     const int64_t grid = per_xcd * 8;
     if (grid > 0x7FFFFFFFll) return fail(BOWGPU_ERR_UNSUPPORTED, "too many rows for one launch: %lld", (long long)p.n);
     const dim3 g((unsigned)grid), blk(kWave);
-    bool step = false, trap = false;
-    for (int a = 0; a < p.naggs; a++) {
-        step |= p.kind[a] == BOWGPU_AGG_INTEGRAL_STEP || p.kind[a] == BOWGPU_AGG_WAVG_STEP;
-        trap |= p.kind[a] == BOWGPU_AGG_INTEGRAL_TRAPEZOID || p.kind[a] == BOWGPU_AGG_WAVG_LINEAR;
-    }
-    const bool both = step && trap;
+    const bool both = (p.need & kNeedStep) && (p.need & kNeedTrap);
 #define BG_TW2(U, B)                                                                                                        \
     do {                                                                                                                    \
         if (wide) hipLaunchKernelGGL((rolling_tw_kernel<U, true, false, B>), g, blk, 0, c->stream, p, ntiles, per_xcd);      \
