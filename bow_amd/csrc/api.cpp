@@ -1032,6 +1032,11 @@ static int job_launch_tiles(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t
             if (k == BOWGPU_AGG_MIN || k == BOWGPU_AGG_MAX) S.need |= kNeedMinMax;
             if (k == BOWGPU_AGG_SUM || k == BOWGPU_AGG_MEAN) S.need |= kNeedSum;
             if (k == BOWGPU_AGG_FIRST || k == BOWGPU_AGG_LAST) S.need |= kNeedFirstLast;
+            const int cls = (k == BOWGPU_AGG_MIN || k == BOWGPU_AGG_MAX) ? 1 : (k == BOWGPU_AGG_INTEGRAL_STEP || k == BOWGPU_AGG_WAVG_STEP) ? 2
+                            : (k == BOWGPU_AGG_INTEGRAL_TRAPEZOID || k == BOWGPU_AGG_WAVG_LINEAR) ? 3
+                            : (k == BOWGPU_AGG_SUM || k == BOWGPU_AGG_MEAN || k == BOWGPU_AGG_FIRST || k == BOWGPU_AGG_LAST) ? 0 : 4;
+            S.kind_mask[cls] |= 1u << i;
+            S.col_mask[S.col[i]] |= 1u << i;
         }
         S.status = P.status; S.long_list = P.long_list; S.long_cap = P.long_cap;
         S.inclusive = job->inclusive ? 1 : 0;
@@ -1136,9 +1141,17 @@ static int job_run(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, i
     bool lite_set = true;
     for (int sl = 0; sl < P.ncols; sl++)
         if ((P.pass_flags[sl + 1] & (kPassMinMax | kPassFirstLast)) || P.cols[sl].need_ts) lite_set = false;
+    // (round 4: the tile kernels' walks are branch-free - at 128 rows per window they beat the streaming form for every set but the
+    // {sum, count} ones and the calls with both kinds of integral, scratch/midw_sweep.py; from 129 on some window of the call no longer
+    // fits a tile's look-ahead and the cooperative path would have to run as well: the streaming form takes over)
+    bool step_k = false, trap_k = false;
+    for (int i = 0; i < naggs; i++) {
+        step_k |= aggs[i].kind == BOWGPU_AGG_INTEGRAL_STEP || aggs[i].kind == BOWGPU_AGG_WAVG_STEP;
+        trap_k |= aggs[i].kind == BOWGPU_AGG_INTEGRAL_TRAPEZOID || aggs[i].kind == BOWGPU_AGG_WAVG_LINEAR;
+    }
     const int64_t avg_rows = W > 0 ? P.n / W : 0;
     const bool classic_only = cls;
-    const bool stream_ok = !classic_only && avg_rows >= ((lite_set || sall) ? kLongOnlyAvgRows : kLongStreamAnyAvgRows) &&
+    const bool stream_ok = !classic_only && avg_rows >= ((lite_set || sall || (step_k && trap_k)) ? kLongOnlyAvgRows : kLongStreamAnyAvgRows) &&
                            avg_rows < kLongClassicAvgRows && W < (1ll << 32);
     const bool classic_ok = avg_rows >= kLongBisectAvgRows;
     if (allow_long_only && plan && W > 0 && P.wid_base == 0 && (stream_ok || classic_ok) && !nlo) {

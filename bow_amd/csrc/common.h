@@ -224,6 +224,8 @@ struct SimpleParams {
     int64_t wid_base;                      // global id of output slot 0 (only for the long-window queue)
     MagicDiv magic;                        // 64-bit magic of the interval: the per-tile base window of the kWide variants
     int32_t shift_k;                       // kWide: trailing zero bits of the interval; m32 / sh1 / sh2 then divide by interval >> shift_k
+    uint32_t kind_mask[5];                 // outputs by class (bit a = output a): 0 Sum / Mean / First / Last, 1 Min / Max, 2 step integrals, 3 trapezoid integrals, 4 WindowStart / Count / NumRows
+    uint32_t col_mask[kMaxCols];           // outputs of value column c
     uint32_t need;                         // kNeed* bits: which running statistics the outputs of the call read (set by the host: one scalar test per use in the kernels)
     uint32_t m32, sh1, sh2;
     int32_t naggs;
@@ -253,7 +255,7 @@ int launch_rolling_fast(Ctx *c, const AggParams &p);        // lean kernel for e
 constexpr int kLongChunkRows = 4096;
 constexpr int kLongStreamRows = 512;  // chunk of the streaming form of the long-window reduction (long_windows.hip)
 constexpr int64_t kLongOnlyAvgRows = 128;   // windows averaging at least this many rows skip the tile kernels: streaming form (api.cpp job_run)
-constexpr int64_t kLongStreamAnyAvgRows = 128;   // ... the same for the reducer sets with extrema, first / last or time-weighted terms (256 until long_short_kernel took a boundary per 128-row trip)
+constexpr int64_t kLongStreamAnyAvgRows = 129;   // ... the same for the reducer sets with extrema, first / last or ONE kind of time-weighted term (256 until long_short_kernel took a boundary per 128-row trip; 128 until the tile kernels' walks became branch-free: windows of exactly 128 rows fit a tile's look-ahead and the tile kernels win there)
 constexpr int64_t kLongBisectAvgRows = 512; // ... bisection form where the streaming form does not apply (BOWGPU_ROUTE_LONG_CLASSIC; W >= 2^32)
 constexpr int64_t kLongClassicAvgRows = 1ll << 22;   // ... and from here on the handful of giant windows go by bisection + per-window chunks
 constexpr int kLongLists = 64;      // sub-lists of the long-window queue (agg_device.h push_long_window)

@@ -288,6 +288,27 @@ __global__ __launch_bounds__(kWave, 4) void rolling_tw_kernel(const SimpleParams
     auto wid_k = [&](tkey_t k) -> uint32_t { return kTs32 ? mdiv32((uint32_t)k, p.m32, p.sh1, p.sh2) : wid_of((int64_t)k); };
     auto abs_d = [&](double t) -> double { return kTs32 ? ws0_d + t : t; };
 
+    // ---- the geometry of a window: its rows [r0, r1), its id and its successor's.  It depends on neither the column nor the phase, so
+    // this lane's first window (q = lane: every window of the tile unless more than 64 start in it) is worked out once, here
+    auto geometry = [&](int q, int &r0, int &r1, uint32_t &wid, uint32_t &next_wid, uint32_t &e1) -> int {   // 0: a window; 1: it runs past the look-ahead
+        const uint32_t e0 = sh.seg[q];
+        e1 = sh.seg[q + 1];
+        r0 = (int)(e0 & 0x7FFFu);
+        wid = wid_k((tkey_t)sh.tsx[r0]);   // (the id of a head row from its staged time: the division the flag pass did)
+        if (q + 1 < nseg_total) {
+            r1 = (int)(e1 & 0x7FFFu);
+            next_wid = wid_k((tkey_t)sh.tsx[r1]);
+            return 0;
+        }
+        r1 = nloc;
+        next_wid = W32;
+        return reaches_end ? 0 : 1;
+    };
+    lds_order();   // the head list and the staged times are complete
+    int g_r0 = 0, g_r1 = 0, g_state = 2;
+    uint32_t g_wid = 0, g_next = 0, g_e1 = 0;
+    if (lane < nseg_owned) g_state = geometry(lane, g_r0, g_r1, g_wid, g_next, g_e1);
+
     // ---- one pass per value column
     const int ncols = p.ncols;
     for (int c = 0; c < ncols; c++) {
@@ -457,22 +478,24 @@ __global__ __launch_bounds__(kWave, 4) void rolling_tw_kernel(const SimpleParams
             }
             const bool do_sum = need_sum && phase <= 1;
             const bool do_mm = need_mm && (phase == 0 || phase == 2);
+            // the outputs of this phase: every output in exactly one
+            uint32_t out_mask;
+            {
+                const uint32_t others = p.kind_mask[4];
+                const int ph1 = two_phase ? 1 : (need_vals || !(need_step || need_trap)) ? 0 : need_step ? 3 : 4;   // the first phase that runs
+                out_mask = phase == 0 ? (p.kind_mask[0] | p.kind_mask[1]) : phase == 1 ? p.kind_mask[0] : phase == 2 ? p.kind_mask[1]
+                           : phase == 3 ? p.kind_mask[2] : p.kind_mask[3];
+                if (phase == ph1) out_mask |= others;
+                out_mask &= p.col_mask[c];
+            }
             const int phase1 = two_phase ? 1 : (need_vals || !(need_step || need_trap)) ? 0 : need_step ? 3 : 4;   // the first phase that runs
             const bool first_phase = phase == phase1;
 
     for (int q = lane; q < nseg_owned; q += kWave) {
-        const uint32_t e0 = sh.seg[q], e1 = sh.seg[q + 1];
-        const int r0 = (int)(e0 & 0x7FFFu);
-        const uint32_t wid = wid_k((tkey_t)sh.tsx[r0]);   // (the id of a head row from its staged time: the division the flag pass did)
-        int r1;
-        uint32_t next_wid;
-        if (q + 1 < nseg_total) {
-            r1 = (int)(e1 & 0x7FFFu);
-            next_wid = wid_k((tkey_t)sh.tsx[r1]);
-        } else if (reaches_end) {
-            r1 = nloc;
-            next_wid = W32;
-        } else {
+        int r0 = g_r0, r1 = g_r1, state = g_state;
+        uint32_t wid = g_wid, next_wid = g_next, e1 = g_e1;
+        if (q != lane) state = geometry(q, r0, r1, wid, next_wid, e1);
+        if (state != 0) {
             // rows run past the look-ahead: hand the window (all its columns) to the cooperative path
             if (c == 0 && first_phase) {
                 push_long_window(p.status, p.long_list, p.long_cap, tile, (uint64_t)p.wid_base + w0 + wid, base + r0);
@@ -538,17 +561,11 @@ __global__ __launch_bounds__(kWave, 4) void rolling_tw_kernel(const SimpleParams
         // ---- outputs of this column and phase: lane q -> slot wid
         // (the output's pointer through a SCALAR load from the kernel-argument segment, the index made wave-uniform explicitly:
         // rolling_simple.hip - a vector load of it made every output wait for the previous output's store)
+        // (the outputs of this column and phase as a bit mask from the host: no iteration, no descriptor load for the others)
 #pragma unroll 1
-        for (int a_ = 0; a_ < p.naggs; a_++) {
-            const int a = __builtin_amdgcn_readfirstlane(a_);
-            if (p.col[a] != c) continue;
+        for (uint32_t am = out_mask; am; am &= am - 1u) {
+            const int a = __builtin_amdgcn_readfirstlane(__builtin_ctz(am));
             const int k = p.kind[a];
-            const bool k_step = k == BOWGPU_AGG_INTEGRAL_STEP || k == BOWGPU_AGG_WAVG_STEP;
-            const bool k_trap = k == BOWGPU_AGG_INTEGRAL_TRAPEZOID || k == BOWGPU_AGG_WAVG_LINEAR;
-            const bool k_mm = k == BOWGPU_AGG_MIN || k == BOWGPU_AGG_MAX;
-            // each output in exactly one phase
-            const int home = k_step ? 3 : k_trap ? 4 : (two_phase ? (k_mm ? 2 : 1) : phase1);
-            if (home != phase) continue;
             typedef const uint64_t __attribute__((address_space(4))) *karg_u64;
             typedef uint64_t __attribute__((address_space(1))) *global_u64;
             const global_u64 out_a = (global_u64)((karg_u64)__builtin_amdgcn_kernarg_segment_ptr())[offsetof(SimpleParams, out_values) / 8 + a];

@@ -2,7 +2,7 @@
 (irregular timestamps, 30 % nulls), default route - plus, from 96 rows on, the streaming form and the tile kernels forced, to show
 where the threshold belongs.  Prints the bracket of all kernels of a call in ms, the fraction of 8 TB/s that is (algorithmic read
 bytes: 16 B per row, + 1/8 B per row for a nullable column) and the kernel that ran."""
-import gc, os, sys
+import gc, os, sys, time
 sys.path.insert(0, '.')
 from bow_amd import capi
 n = int(float(os.environ.get("SWEEP_N", "1e8")))
@@ -37,13 +37,17 @@ for label, cols, scale, bpr in (("dense", dense, 1, 16.0), ("sparse", sparse, 10
                         for _ in range(2):
                             capi.rolling_aggregate(list(cols), 0, interval, aggs, outs=outs)
                         ms = []
+                        capi.synchronize()
+                        t0 = time.perf_counter()
                         for _ in range(5):
                             _, info = capi.rolling_aggregate(list(cols), 0, interval, aggs, outs=outs)
                             ms.append(info.kernel_ms)
+                        capi.synchronize()
+                        wall = (time.perf_counter() - t0) / 5 * 1e3
                         k = sorted(ms)[2]
                         frac = n * bpr / (k * 1e-3) / 8e12
                         kn = capi.last_kernel_name().replace("_kernel", "").replace("rolling_", "r_").replace("long_", "l_")
-                        line += "  %s %.3f ms %.2f (%s, long %d)" % (rname, k, frac, kn, info.long_windows)
+                        line += "  %s %.3f ms %.2f (%s, long %d, wall %.3f)" % (rname, k, frac, kn, info.long_windows, wall)
                         if rname == "auto":
                             worst[(label, name)] = min(worst.get((label, name), 9.0), frac)
                     except Exception as e:

@@ -1057,8 +1057,8 @@ def test_pinned_zero_copy_residency_equals_the_other_residencies():
 
 def test_strict_order_and_the_pinned_form_thresholds():
     """bowgpu_options.strict_order: every window in the reference's row order (bit-exact, long_windows == 0) or the call is declined.
-    And the window length at which a call changes form (common.h kLongOnlyAvgRows = kLongStreamAnyAvgRows = 128 rows on average) -
-    a change of it is a change of which calls are bit-exact."""
+    And the window length at which a call changes form (common.h: kLongOnlyAvgRows = 128 rows on average for the {sum, count} sets and
+    the calls with both kinds of integral, kLongStreamAnyAvgRows = 129 for the rest) - a change of it is a change of which calls are bit-exact."""
     rng = np.random.default_rng(77)
     n = 128 * 2400          # (whole windows of 128 and of 256 rows: the averages are the window lengths)
     ts = np.arange(n, dtype=np.int64)
@@ -1068,8 +1068,10 @@ def test_strict_order_and_the_pinned_form_thresholds():
     lite = [("WindowStart", 0), ("Sum", 1), ("ArithmeticMean", 1)]
     more = [("WindowStart", 0), ("Sum", 1), ("Min", 1), ("WeightedAverageStep", 1)]
     # which form runs where
+    both = [("WindowStart", 0), ("IntegralStep", 1), ("WeightedAverageLinear", 1)]
     for aggs, interval, kernel in ((lite, 127, "rolling_simple_kernel"), (lite, 128, "long_stream_kernel"), (more, 127, None),
-                                   (more, 128, "long_stream_kernel"), (more, 256, "long_stream_kernel"), (more, 1000, "long_stream_kernel")):
+                                   (more, 128, "rolling_tw_kernel"), (more, 130, "long_stream_kernel"), (more, 256, "long_stream_kernel"),
+                                   (more, 1000, "long_stream_kernel"), (both, 127, "rolling_tw_kernel"), (both, 128, "long_stream_kernel")):
         outs, info = capi.rolling_aggregate(cols, 0, interval, aggs)
         name = capi.last_kernel_name()
         if kernel is None:
