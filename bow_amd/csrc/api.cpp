@@ -1080,7 +1080,7 @@ static int job_launch_tiles(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t
 
 // Windows longer than a tile's look-ahead: workspace from the context pool, then long_windows.hip
 // hstat == nullptr: the long-only pipeline (every window of the call)
-static int run_long_windows(Ctx *c, const AggParams &P, const uint32_t *hstat, int64_t *n_long_out) {
+static int run_long_windows(Ctx *c, const AggParams &P, const uint32_t *hstat, int64_t *n_long_out, bool strict = false) {
     LongListStarts starts;
     starts.start[0] = 0;
     if (hstat)
@@ -1106,7 +1106,7 @@ static int run_long_windows(Ctx *c, const AggParams &P, const uint32_t *hstat, i
     int64_t *sums = reinterpret_cast<int64_t *>(q); q += b_sums;
     int64_t *total = reinterpret_cast<int64_t *>(q); q += 256;
     int32_t *work_entry = reinterpret_cast<int32_t *>(q); q += b_map;
-    return launch_long_windows_v2(c, P, hstat ? &starts : nullptr, entries, nchunks, offsets, sums, total, work_entry, q, max_work);
+    return launch_long_windows_v2(c, P, hstat ? &starts : nullptr, entries, nchunks, offsets, sums, total, work_entry, q, max_work, strict);
 }
 
 // BOWGPU_CALL_PROFILE=1 (diagnostic): where a call's wall time goes on the host - until the synchronisation, inside it, after it
@@ -1154,7 +1154,10 @@ static int job_run(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, i
     const bool stream_ok = !classic_only && avg_rows >= ((lite_set || sall || (step_k && trap_k)) ? kLongOnlyAvgRows : kLongStreamAnyAvgRows) &&
                            avg_rows < kLongClassicAvgRows && W < (1ll << 32);
     const bool classic_ok = avg_rows >= kLongBisectAvgRows;
-    if (allow_long_only && plan && W > 0 && P.wid_base == 0 && (stream_ok || classic_ok) && !nlo) {
+    // bowgpu_options.strict_order on a call of long windows: every window by one lane in row order (long_windows.hip
+    // long_strict_kernel) instead of a tile kernel that reads every row only to queue nearly every window
+    const bool strict_long = g_strict_order && avg_rows >= kLongStreamAnyAvgRows && !(route & BOWGPU_ROUTE_NO_LONG_ONLY);
+    if (allow_long_only && plan && W > 0 && P.wid_base == 0 && (((stream_ok || classic_ok) && !nlo) || strict_long)) {
         P.bits_preset = 0;
         {
             BitmapBatch b;
@@ -1164,7 +1167,11 @@ static int job_run(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, i
         }
         BG_HIP(hipEventRecord(c->ev0, c->stream));
         int64_t n_all = W;
-        if (!stream_ok) {
+        if (strict_long) {
+            BG_TRY(run_long_windows(c, P, nullptr, &n_all, true));
+            n_all = 0;   // (bowgpu_agg_info.long_windows counts the windows reduced order-free: none)
+            c->last_kernel_name = "long_strict_kernel";
+        } else if (!stream_ok) {
             BG_TRY(run_long_windows(c, P, nullptr, &n_all));
             c->last_kernel_name = "long_partial_kernel";
         } else {
@@ -1181,6 +1188,7 @@ static int job_run(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, i
         BG_HIP(hipStreamSynchronize(c->stream));
         if (hs[6]) return fail(BOWGPU_ERR_ARG, "the plan was not made for this interval column (its first / last timestamp differ)");
         if (hs[0]) return fail(BOWGPU_ERR_TS_UNSORTED, "interval column is not ascending: outside the device path");
+        if (hs[7]) return fail(BOWGPU_ERR_UNSUPPORTED, "strict_order: some window holds more than 2^20 rows (one lane walks a window in row order: beyond that the call is declined)");
         if (finish)
             for (int i = 0; i < naggs; i++)
                 job->douts[i].user->null_count = !kind_never_nil(aggs[i].kind) ? W - (int64_t)hc[i] : 0;
@@ -1239,19 +1247,16 @@ static int job_pass_complete(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_
     if (hstat[2]) return fail(BOWGPU_ERR_HIP, "internal: long-window list overflow");
     int64_t n_long = 0;
     {
-        if (g_strict_order) {
-            int64_t queued = 0;
-            for (int s = 0; s < kLongLists; s++) queued += hstat[kLongCountWord + s];
-            if (queued > 0)
-                return fail(BOWGPU_ERR_UNSUPPORTED, "strict_order: %lld window(s) are longer than a tile's look-ahead (128 rows) and would be reduced order-free",
-                            (long long)queued);
-        }
-        BG_TRY(run_long_windows(c, P, hstat, &n_long));
-        if (n_long > 0 && finish) {
-            BG_TRY(job_enqueue_tail(c, job, aggs, naggs));
+        // (strict_order: the windows a tile could not hold are walked in row order by one lane each - long_strict_kernel - instead of
+        // being reduced as a tree; a window beyond 2^20 rows declines the call)
+        BG_TRY(run_long_windows(c, P, hstat, &n_long, g_strict_order));
+        if (n_long > 0 && (finish || g_strict_order)) {
+            if (finish) BG_TRY(job_enqueue_tail(c, job, aggs, naggs));
             BG_TRY(job_readback(c, job, &hstat, &hcnt));
             BG_HIP(hipStreamSynchronize(c->stream));
+            if (hstat[7]) return fail(BOWGPU_ERR_UNSUPPORTED, "strict_order: some window holds more than 2^20 rows (one lane walks a window in row order: beyond that the call is declined)");
         }
+        if (g_strict_order) n_long = 0;   // (none of them was reduced order-free)
     }
     if (finish)
         for (int i = 0; i < naggs; i++)

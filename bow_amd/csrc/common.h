@@ -268,7 +268,7 @@ int stream_rw_run(Ctx *c, const void *a, const void *b, int64_t bytes_each, void
                   int reps, float *ms);
 int stream_sum_run(Ctx *c, const void *a, const void *b, int64_t bytes_each, int mode, int blocks_per_cu, int reps, uint64_t *d_out, float *ms);
 int launch_long_windows_v2(Ctx *c, const AggParams &p, const LongListStarts *starts, void *entries, int32_t *nchunks, int64_t *offsets,
-                           int64_t *block_sums, int64_t *d_total, int32_t *work_entry, void *partials, int64_t max_work);
+                           int64_t *block_sums, int64_t *d_total, int32_t *work_entry, void *partials, int64_t max_work, bool strict = false);
 size_t long_stream_workspace(int64_t n, int64_t W, int ncols);
 int launch_long_stream(Ctx *c, const AggParams &p, void *workspace);   // every window of the call, one read of the rows
 int launch_fix_tail_bits(Ctx *c, uint8_t *bitmap, int64_t nbits);

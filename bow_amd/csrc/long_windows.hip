@@ -153,6 +153,8 @@ __device__ __forceinline__ int64_t window_end_row(const AggParams &p, uint64_t w
     return lo;
 }
 
+__device__ __forceinline__ void emit_stats(const AggParams &p, int slot, const LongEntry &w, const Stats &st, uint32_t *valid_out);
+
 // The outputs of one column pass (slot; -1: the reducers that need no column) for window `w`, from its merged order-free partial
 // (valid_out != nullptr: the validity bitmaps are not touched; bit i of *valid_out is set when the output of aggregation i is valid -
 // the caller assembles whole bitmap words from its lanes)
@@ -179,6 +181,21 @@ __device__ __forceinline__ void emit_window(const AggParams &p, int slot, const 
         st.has_point = 1; st.pt = (double)p.ts[acc.last_idx]; st.pv = bits_to_f64(st.last_bits, col_type);
         st.integ_trap = acc.trap; st.integ_step = acc.step; st.has_pair = acc.count >= 2;
     }
+    emit_stats(p, slot, w, st, valid_out);
+}
+
+// ... from the reference's running state itself (emit_window rebuilds it from an order-free partial; long_strict_kernel arrives
+// with the state of a walk in row order)
+__device__ __forceinline__ void emit_stats(const AggParams &p, int slot, const LongEntry &w, const Stats &st, uint32_t *valid_out) {
+    const unsigned my_mask = p.pass_mask[slot + 1];
+    const ColDesc *cd = slot >= 0 ? &p.cols[slot] : nullptr;
+    const int col_type = cd ? cd->type : BOWGPU_INT64;
+    const bool need_vals = cd && (p.pass_flags[slot + 1] & kPassNeedVals);
+    const uint64_t *vp = cd ? reinterpret_cast<const uint64_t *>(cd->values) : nullptr;
+    const int64_t win_start = p.s0 + (int64_t)(w.wid * (uint64_t)p.interval);
+    const int64_t oslot = (int64_t)(w.wid - (uint64_t)p.wid_base);
+    const int64_t len = w.dead ? 0 : w.r1 - w.r0;
+    if ((uint64_t)oslot >= (uint64_t)p.W) return;
     // the state including the inclusive row, for the reducers that want it (aggregation.go:207-211)
     Stats st_incl = st;
     if (w.incl_row && need_vals && col_valid(*cd, w.r1)) {
@@ -283,6 +300,48 @@ __global__ __launch_bounds__(256) void ts_sorted_kernel(const int64_t *__restric
         bad |= l > a || a > b;
     }
     if (bad) atomicOr(&status[0], 1u);
+}
+
+// bowgpu_options.strict_order for the windows no tile holds: one LANE per window walks its rows in the reference's order - every
+// reducer through the same running state the reference keeps (sum.go:16-22, minmax.go:16-28, integral.go:14-31, :46-62), so Sum /
+// Mean / Integral* / WeightedAverage* come out bit for bit - and writes its outputs and the empty windows behind it.  Neighbouring
+// lanes read neighbouring windows: a load touches 64 cache lines, but the next fifteen rows of each lane come out of the same lines
+// (L1 / L2), so the rows are still fetched from HBM once.  Four rows of a lane are loaded before the first is consumed.  Windows
+// longer than kStrictMaxRows are not walked (status[7]: the call is declined) - a single lane would take milliseconds per window.
+constexpr int64_t kStrictMaxRows = 1ll << 20;
+__global__ __launch_bounds__(256) void long_strict_kernel(const AggParams p, const int64_t n_long, const LongEntry *entries, const int fill_gaps) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n_long) return;
+    const LongEntry le = entries[e];
+    if (le.r1 - le.r0 > kStrictMaxRows) {
+        if (!__hip_atomic_load(&p.status[7], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(&p.status[7], 1u);
+        return;
+    }
+    const int64_t gap = fill_gaps ? (int64_t)(le.next_wid - le.wid) - 1 : 0;
+    for (int slot = -1; slot < p.ncols; slot++) {
+        if (p.pass_mask[slot + 1] == 0) continue;
+        Stats st;
+        stats_init(st);
+        bool need_ts = false;
+        if (slot >= 0 && slot_needs(p, slot, &need_ts) && !le.dead) {
+            const ColDesc &cd = p.cols[slot];
+            const uint64_t *vp = reinterpret_cast<const uint64_t *>(cd.values);
+            auto one = [&](int64_t r, uint64_t raw) {
+                if (!col_valid(cd, r)) return;
+                const double x = bits_to_f64(raw, cd.type);
+                stats_value<false>(st, x, raw);
+                if (need_ts) stats_point(st, (double)p.ts[r], x);
+            };
+            int64_t r = le.r0;
+            for (; r + 4 <= le.r1; r += 4) {
+                const uint64_t q0 = vp[r], q1 = vp[r + 1], q2 = vp[r + 2], q3 = vp[r + 3];
+                one(r, q0); one(r + 1, q1); one(r + 2, q2); one(r + 3, q3);
+            }
+            for (; r < le.r1; r++) one(r, vp[r]);
+        }
+        emit_stats(p, slot, le, st, nullptr);
+        if (gap > 0) emit_empties(p, slot, le, gap, 1, 1);
+    }
 }
 
 // chunk -> window map: work_entry[w] = e for the chunks [offsets[e], offsets[e+1]) of queued window e
@@ -1672,7 +1731,7 @@ size_t long_part_size() { return sizeof(Part); }
 // starts == nullptr: every window of the call is an entry (long-only pipeline), preceded by the order check of the interval column
 int launch_long_windows_v2(Ctx *c, const AggParams &p, const LongListStarts *starts, void *entries, int32_t *nchunks,
                            int64_t *offsets, int64_t *block_sums, int64_t *d_total, int32_t *work_entry, void *partials,
-                           int64_t max_work) {
+                           int64_t max_work, bool strict) {
     const int64_t n_long = starts ? starts->start[kLongLists] : p.W;
     if (n_long <= 0) return 0;
     if (starts) {
@@ -1685,6 +1744,12 @@ int launch_long_windows_v2(Ctx *c, const AggParams &p, const LongListStarts *sta
         hipLaunchKernelGGL(ts_sorted_kernel, dim3((unsigned)g), dim3(256), 0, c->stream, p.ts, p.n, p.status);
         hipLaunchKernelGGL(long_bounds_all_kernel, dim3((unsigned)((n_long + 255) / 256)), dim3(256), 0, c->stream, p,
                            reinterpret_cast<LongEntry *>(entries), nchunks);
+    }
+    if (strict) {   // every window in row order, one lane each (queued windows: + the empty windows behind them)
+        hipLaunchKernelGGL(long_strict_kernel, dim3((unsigned)((n_long + 255) / 256)), dim3(256), 0, c->stream, p, n_long,
+                           reinterpret_cast<const LongEntry *>(entries), starts ? 1 : 0);
+        BG_HIP(hipGetLastError());
+        return 0;
     }
     BG_TRY(launch_exclusive_scan(c, nchunks, n_long, offsets, block_sums, d_total));
     hipLaunchKernelGGL(long_map_kernel, dim3((unsigned)((n_long + 3) / 4)), dim3(256), 0, c->stream, n_long, offsets, work_entry);

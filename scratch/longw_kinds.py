@@ -1,7 +1,9 @@
-"""Long windows (interval 1000, 1e8 rows) with reducer sets that select the different instantiations of long_stream_kernel."""
+"""Long windows (interval 1000, 1e8 rows) with reducer sets that select the different instantiations of long_stream_kernel.
+`strict` as an argument: the same calls with bowgpu_options.strict_order (every window walked in row order: long_strict_kernel)."""
 import gc, sys, time
 sys.path.insert(0, '.')
 from bow_amd import capi
+strict = "strict" in sys.argv[1:]
 n = 100_000_000
 ts, val = capi.gen_dense(0, n, seed=42)
 tss, vals = capi.gen_sparse(0, n, seed=3)
@@ -15,12 +17,12 @@ for label, cols, interval in (("dense", [ts, val], 1000), ("30% nulls", [tss, va
         s0, W = capi.plan_windows(cols[0], interval, 0)
         outs = [capi.OutColumn(W, capi.DEVICE) for _ in aggs]
         for _ in range(2):
-            capi.rolling_aggregate(cols, 0, interval, aggs, outs=outs)
+            capi.rolling_aggregate(cols, 0, interval, aggs, outs=outs, strict_order=strict)
         gc.collect(); capi.synchronize()     # (earlier output buffers are freed outside the timed calls)
         t0 = time.perf_counter()
         ms = []
         for _ in range(7):
-            _, info = capi.rolling_aggregate(cols, 0, interval, aggs, outs=outs)
+            _, info = capi.rolling_aggregate(cols, 0, interval, aggs, outs=outs, strict_order=strict)
             ms.append(info.kernel_ms)
         capi.synchronize()
         dt = (time.perf_counter() - t0) / 7

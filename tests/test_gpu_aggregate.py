@@ -1086,12 +1086,16 @@ def test_strict_order_and_the_pinned_form_thresholds():
         assert info.long_windows == 0
         for k, g, w in zip(_names(more), outs, exp):
             compare("strict %s I=%d" % (k, interval), g, w, exact=True)
-    # ... and windows no tile can hold are declined, whatever the reducer set, planned or not, per call or per thread
-    for aggs in (lite, more):
-        for interval in (1000, 100_000):
-            with pytest.raises(capi.BowGpuError) as e:
-                capi.rolling_aggregate(cols, 0, interval, aggs, strict_order=True)
-            assert e.value.code == -9 and "strict_order" in e.value.message, (interval, e.value.message)
+    # ... and windows no tile can hold are walked in row order by one lane each (round 4: long_strict_kernel; round 3 declined them):
+    # bit for bit, whatever the reducer set, planned or not, per call or per thread, inclusive or not
+    every = [(k, 0 if k == "WindowStart" else 1) for k in ALL_AGGS]
+    for aggs in (lite, more, every):
+        for interval in (130, 1000, 100_000):
+            exp, _ = orc.aggregate(ocols, 0, interval, aggs)
+            outs, info = capi.rolling_aggregate(cols, 0, interval, aggs, strict_order=True)
+            assert info.long_windows == 0 and capi.last_kernel_name() == "long_strict_kernel", (interval, capi.last_kernel_name())
+            for k, g, w in zip(_names(aggs), outs, exp):
+                compare("strict %s I=%d" % (k, interval), g, w, exact=True)
         # (128-row windows: the streaming form by default for the {sum, count} set, but a tile still holds them - in row order)
         exp, _ = orc.aggregate(ocols, 0, 128, aggs)
         outs, info = capi.rolling_aggregate(cols, 0, 128, aggs, strict_order=True)
@@ -1099,11 +1103,53 @@ def test_strict_order_and_the_pinned_form_thresholds():
         for k, g, w in zip(_names(aggs), outs, exp):
             compare("strict %s I=128" % k, g, w, exact=True)
     plan = capi.plan_windows_ex(cols[0], 1000, 0)
-    with pytest.raises(capi.BowGpuError) as e:
-        capi.rolling_aggregate(cols, 0, 1000, lite, plan=plan, strict_order=True)
-    assert e.value.code == -9
+    exp, _ = orc.aggregate(ocols, 0, 1000, lite)
+    outs, info = capi.rolling_aggregate(cols, 0, 1000, lite, plan=plan, strict_order=True)
     with capi.route(capi.ROUTE_STRICT_ORDER):
-        with pytest.raises(capi.BowGpuError):
-            capi.rolling_aggregate(cols, 0, 1000, lite)
+        outs2, info2 = capi.rolling_aggregate(cols, 0, 1000, lite)
+    for k, g, g2, w in zip(_names(lite), outs, outs2, exp):
+        compare("strict planned %s" % k, g, w, exact=True)
+        compare("strict by route %s" % k, g2, w, exact=True)
+    assert info.long_windows == 0 and info2.long_windows == 0
     outs, info = capi.rolling_aggregate(cols, 0, 1000, lite)       # (the flag does not stick to the thread)
     assert info.long_windows == info.num_windows
+
+
+def test_strict_order_mixed_lengths_nulls_and_the_stated_limit():
+    """strict_order on irregular data: mostly short windows with a few that outgrow a tile (the tile kernel queues them, one lane each
+    walks them in row order), nullable and Int64 columns, inclusive windows, rows below s0; and the stated limit - a window of more
+    than 2^20 rows declines the call (BOWGPU_ERR_UNSUPPORTED), it is never reduced as a tree behind the caller's back."""
+    rng = np.random.default_rng(2024)
+    n = 400_000
+    step = rng.integers(1, 5, n)
+    step[rng.random(n) < 0.002] = 4000            # a gap now and then: empty windows behind a window
+    ts = np.cumsum(step).astype(np.int64) - 3000  # (negative timestamps: rows below s0 ride in window 0)
+    burst = rng.random(n) < 0.0005
+    for i in np.flatnonzero(burst)[:40]:          # bursts of rows with one timestamp: windows of hundreds / thousands of rows
+        ts[i:i + int(rng.integers(200, 3000))] = ts[i]
+    ts = np.sort(ts)
+    f, fm = make_vals(rng, n, "f64", 0.3)
+    g, gm = make_vals(rng, n, "i64", 0.1)
+    aggs = [(k, 0 if k == "WindowStart" else 1) for k in ALL_AGGS + TIME_AGGS] + [("Sum", 2), ("ArithmeticMean", 2), ("First", 2), ("WeightedAverageLinear", 2)]
+    for interval, offset in ((50, 0), (300, 7)):
+        for inclusive in (False, True):
+            cols = [capi.Column(ts), capi.Column(f, np.packbits(fm, bitorder="little"), capi.FLOAT64, 0, n, -1),
+                    capi.Column(g, np.packbits(gm, bitorder="little"), capi.INT64, 0, n, -1)]
+            ocols = [orc.Column(ts, None, orc.INT64), orc.Column(f, np.packbits(fm, bitorder="little"), orc.FLOAT64),
+                     orc.Column(g, np.packbits(gm, bitorder="little"), orc.INT64)]
+            exp, _ = orc.aggregate(ocols, 0, interval, aggs, offset=offset, inclusive=inclusive)
+            outs, info = capi.rolling_aggregate(cols, 0, interval, aggs, offset=offset, inclusive=inclusive, strict_order=True)
+            assert info.long_windows == 0
+            for k, got, want in zip(_names(aggs), outs, exp):
+                compare("strict mixed %s I=%d incl=%s" % (k, interval, inclusive), got, want, exact=True)
+    # the limit
+    m = (1 << 20) + 5000
+    bigv = rng.standard_normal(m)
+    big = [capi.Column(np.arange(m, dtype=np.int64)), capi.Column(bigv, None, capi.FLOAT64)]
+    with pytest.raises(capi.BowGpuError) as e:
+        capi.rolling_aggregate(big, 0, 1 << 21, [("WindowStart", 0), ("Sum", 1)], strict_order=True)
+    assert e.value.code == -9 and "2^20" in e.value.message
+    outs, info = capi.rolling_aggregate(big, 0, 1 << 19, [("WindowStart", 0), ("Sum", 1)], strict_order=True)   # (half a million rows per window: served)
+    exp, _ = orc.aggregate([orc.Column(np.arange(m, dtype=np.int64), None, orc.INT64), orc.Column(bigv, None, orc.FLOAT64)], 0, 1 << 19,
+                           [("WindowStart", 0), ("Sum", 1)])
+    compare("strict 2^19-row windows Sum", outs[1], exp[1], exact=True)
