@@ -326,18 +326,39 @@ __global__ __launch_bounds__(256) void long_strict_kernel(const AggParams p, con
         if (slot >= 0 && slot_needs(p, slot, &need_ts) && !le.dead) {
             const ColDesc &cd = p.cols[slot];
             const uint64_t *vp = reinterpret_cast<const uint64_t *>(cd.values);
-            auto one = [&](int64_t r, uint64_t raw) {
-                if (!col_valid(cd, r)) return;
+            const uint64_t *tp = reinterpret_cast<const uint64_t *>(p.ts);
+            auto one = [&](bool ok, uint64_t raw, uint64_t traw) {
+                if (!ok) return;
                 const double x = bits_to_f64(raw, cd.type);
                 stats_value<false>(st, x, raw);
-                if (need_ts) stats_point(st, (double)p.ts[r], x);
+                if (need_ts) stats_point(st, (double)(int64_t)traw, x);
             };
+            // eight rows of the lane are loaded (values, timestamps when an integral wants them, the validity bits as one or two words)
+            // before the first is consumed: the chain of additions is the only thing that has to wait
             int64_t r = le.r0;
-            for (; r + 4 <= le.r1; r += 4) {
-                const uint64_t q0 = vp[r], q1 = vp[r + 1], q2 = vp[r + 2], q3 = vp[r + 3];
-                one(r, q0); one(r + 1, q1); one(r + 2, q2); one(r + 3, q3);
+            for (; r + 8 <= le.r1; r += 8) {
+                uint64_t q[8], t[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) q[i] = vp[r + i];
+                if (need_ts) {
+#pragma unroll
+                    for (int i = 0; i < 8; i++) t[i] = tp[r + i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; i++) t[i] = 0;
+                }
+                uint32_t bits = 0xFFu;
+                if (cd.vbits) {
+                    const int64_t bit = cd.vbit0 + r;
+                    const uint32_t lo = cd.vbits[bit >> 5];
+                    const int sh = (int)(bit & 31);
+                    bits = lo >> sh;
+                    if (sh > 24) bits |= cd.vbits[(bit >> 5) + 1] << (32 - sh);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; i++) one((bits >> i) & 1u, q[i], t[i]);
             }
-            for (; r < le.r1; r++) one(r, vp[r]);
+            for (; r < le.r1; r++) one(col_valid(cd, r), vp[r], need_ts ? tp[r] : 0ull);
         }
         emit_stats(p, slot, le, st, nullptr);
         if (gap > 0) emit_empties(p, slot, le, gap, 1, 1);
