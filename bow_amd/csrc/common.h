@@ -8,6 +8,7 @@
 #include <string>
 
 #include "../../include/bowgpu.h"
+#include "debug_routes.h"
 
 namespace bowgpu {
 

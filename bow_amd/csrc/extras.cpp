@@ -407,16 +407,13 @@ static int interp_fill_impl(const bowgpu_col *cols, int32_t ncols, int32_t ts_co
         P.kq = fresh.kq; P.kq_empty = fresh.kq_empty; P.drop = fresh.drop; P.e0 = fresh.e0;
         P.s0 = fresh.plan.s0; P.W = fresh.plan.W;
     }
-    // some trip has more runs of synthetic rows than the default kernel lists: interp_wave_kernel (inclusive windows: interp_wave2_kernel,
-    // whose list holds a run per row) takes the call
-    // (inclusive windows: the redo runs interp_wave2_kernel<true>, which needs the whole frame within 2^31 of s0 - fast32.  A frame
-    // that only interp_wave3_kernel's trip-relative form can take has no second kernel: decline instead of producing exclusive rows)
-    if (hstat[5] && o.inclusive && !P.fast32)
-        return fail(BOWGPU_ERR_UNSUPPORTED, "Interpolate on inclusive windows: a 512-row trip that spans 2^31 or more, or holds more runs of "
-                                            "added rows than the kernel lists, on a frame wider than 2^31 is outside the device path");
-    if (hstat[5]) BG_TRY(run_all(0));
+    // some trip has more runs of synthetic rows than interp_wave3_kernel lists, spans 2^31 or more, or holds a gap of millions of empty
+    // windows: the workgroup kernel takes the call.  It builds exclusive windows only: an inclusive call is declined instead of being
+    // answered with the exclusive layout.
     if (hstat[5] && o.inclusive)
-        return fail(BOWGPU_ERR_UNSUPPORTED, "Interpolate on inclusive windows: windows shorter than two rows on average are outside the device path");
+        return fail(BOWGPU_ERR_UNSUPPORTED, "Interpolate on inclusive windows: a 512-row trip that spans 2^31 or more, or holds a gap of "
+                                            "millions of empty windows, is outside the device path");
+    if (hstat[5]) BG_TRY(run_all(0));
     if (hstat[0]) return fail(BOWGPU_ERR_TS_UNSORTED, "interval column is not ascending: outside the device path");
     for (int i = 0; i < ninterps; i++) BG_TRY(devout_finish(c, &douts[i], n_out, cols[i].type, n_out - (int64_t)hcnt[i], false));
     BG_HIP(hipStreamSynchronize(c->stream));

@@ -371,317 +371,14 @@ __global__ __launch_bounds__(kIThreads) void interp_tile_kernel(const InterpPara
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// interp_wave_kernel: the same pass for the usual shape (fast32: every row in [s0, s0 + 2^31), no dropped rows, no -1 sentinel
-// window) with ONE WAVEFRONT per 512 rows and no barrier.  interp_tile_kernel is bound by waiting (six workgroup barriers per
-// tile; every synthetic row walks bitmap -> neighbour index -> value through dependent global loads).  Here:
-//   phase 1  flags and output positions of the trip's four 128-row chunks (lane l = rows 2l, 2l+1): a wave scan per chunk and a
-//            running scalar total; per-lane results parked in the wavefront's LDS slice;
-//   phase 2  column by column, chunk by chunk (rolled loops: one copy of the code, few registers): the column's validity as
-//            two 64-bit words (scalar loads) split into even-row / odd-row lane masks; the neighbours of a window start from
-//            those masks (count-leading / trailing-zeros) with values and timestamps by shuffle, the previous chunk's last
-//            valid point carried in scalar registers, the bitmap + index consulted once per trip (before its first row) and
-//            by the rare lane whose next valid row lies beyond its chunk; outputs staged in LDS in output order and written
-//            as contiguous stores; output validity = the ballot of the staged flags, streamed through a scalar bit
-//            accumulator into whole words (atomic only where a word is shared with another trip).
-constexpr int kWStage = 256;  // outputs of one chunk staged in LDS (128 rows + up to 128 synthetic rows; more: written directly)
-
-struct WaveLds {
-    uint64_t val[kWStage];
-    uint8_t flag[kWStage];
-    uint32_t synth[4][2][64], k0[4][2][64], orel[4][2][64];  // [chunk][row of the lane][lane]
-    uint32_t o0[4], tot[4];
-};
-
+// (rounds 1 - 2 had two more kernels here, interp_wave_kernel and interp_wave2_kernel: interp_wave3_kernel below replaced both, 1.6 - 2.9x
+// faster; they are gone from the library since round 4.  interp_tile_kernel above stays as the kernel for the shapes wave3 does not
+// take - 64-bit window ids, dropped rows, the -1 sentinel window, a trip whose lists overflow - and as the second opinion of the tests.)
 __device__ __forceinline__ void wave_lds_order() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     asm volatile("" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-
-// output validity bits of one column, appended in output order; whole words leave with plain stores, a word that another trip
-// (or a directly written chunk) may also touch with an atomic OR.  All state is wave-uniform.
-struct BitStream {
-    uint32_t *words;
-    uint64_t acc;      // pending bits (fewer than 32 between appends)
-    int nacc;
-    int64_t wpos;      // word index of acc's bit 0
-    bool shared;       // the next word to leave may hold bits of somebody else
-    __device__ __forceinline__ void start(uint32_t *w, int64_t bitpos) { words = w; acc = 0; nacc = (int)(bitpos & 31); wpos = bitpos >> 5; shared = true; }
-    __device__ __forceinline__ void append(uint64_t b, int r, int lane) {  // r <= 64 bits of b
-        uint64_t lo = acc | (b << nacc), hi = nacc ? (b >> (64 - nacc)) : 0ull;
-        int total = nacc + r;
-        while (total >= 32) {
-            const uint32_t w = (uint32_t)lo;
-            if (lane == 0) { if (shared) { if (w) atomicOr(&words[wpos], w); } else words[wpos] = w; }
-            shared = false;
-            lo = (lo >> 32) | (hi << 32); hi >>= 32;
-            total -= 32; wpos++;
-        }
-        acc = lo; nacc = total;
-    }
-    __device__ __forceinline__ void finish(int lane) {
-        if (nacc > 0 && lane == 0 && (uint32_t)acc) atomicOr(&words[wpos], (uint32_t)acc);
-        acc = 0; nacc = 0;
-    }
-};
-
-__global__ __launch_bounds__(64) void interp_wave_kernel(const InterpParams p) {
-    __shared__ WaveLds L;
-    const int lane = threadIdx.x;
-    const int64_t trip = blockIdx.x;
-    const int64_t base = trip * 512;
-    if (base >= p.n) return;
-    const int64_t left_trip = p.n - base;
-    const bool full = left_trip >= 512;
-    const Magic32 m32 = {p.m32, p.sh1_32, p.sh2_32};
-    const uint64_t lt = (1ull << lane) - 1ull, gt = lane == 63 ? 0ull : (~0ull << (lane + 1));
-    const int sh2l = (2 * lane) & 63;
-
-    // a pair of one column's rows of chunk k (16-B load when the trip is whole and the column aligned)
-    auto load2 = [&](const uint64_t *col, int k, uint64_t *a, uint64_t *b) {
-        const int r = 128 * k + 2 * lane;
-        const uint64_t *src = col + base;
-        if (full && (reinterpret_cast<uintptr_t>(col) & 15) == 0) { const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(src + r); *a = v.x; *b = v.y; }
-        else { *a = r < left_trip ? src[r] : 0; *b = r + 1 < left_trip ? src[r + 1] : 0; }
-    };
-
-    // ---- phase 1: where the trip's outputs start; flags and output positions (relative to o_trip) of every row
-    int64_t o_trip = 0, t_before = p.left_ts;
-    {
-        uint64_t ta[4], tb[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) load2(reinterpret_cast<const uint64_t *>(p.ts), k, &ta[k], &tb[k]);
-        if (base > 0) {
-            t_before = p.ts[base - 1];
-            const uint32_t wp = mdiv32((uint32_t)((uint64_t)t_before - (uint64_t)p.s0), m32);
-            o_trip = base + (int64_t)wp + 1 - p.wbase - p.tile_exact_before[2 * trip];   // (one entry per 256 rows)
-        }
-        uint32_t run = 0;
-        // 32-bit forms of rows_flags<true> (every row lies in [s0, s0 + 2^31); interp_count_kernel has checked the order):
-        // window id from one multiply-high, "exact head" as an integer comparison
-        const uint32_t s0lo = (uint32_t)p.s0, i32 = (uint32_t)p.interval;
-        uint32_t rb_prev = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int64_t i = base + 128 * k + 2 * lane;
-            const uint32_t ra = (uint32_t)ta[k] - s0lo, rb = (uint32_t)tb[k] - s0lo;
-            uint32_t rl = __shfl_up(rb, 1);
-            if (lane == 0) rl = k == 0 ? (uint32_t)t_before - s0lo : (uint32_t)__builtin_amdgcn_readlane((int)rb_prev, 63);
-            rb_prev = rb;
-            const bool in0 = i < p.n, in1 = i + 1 < p.n;
-            const bool first = i == 0 && !p.has_left;  // the frame's first row has no left neighbour
-            const uint32_t wl = mdiv32(rl, m32), wa = mdiv32(ra, m32), wb = mdiv32(rb, m32);
-            const bool head0 = in0 && (first || wa != wl), head1 = in1 && wb != wa;
-            const bool exact0 = head0 && ra == wa * i32, exact1 = head1 && rb == wb * i32;
-            const uint32_t sy0 = head0 ? ((first ? 0u : wa - wl - 1u) + (exact0 ? 0u : 1u)) : 0u;
-            const uint32_t sy1 = head1 ? (wb - wa - 1u + (exact1 ? 0u : 1u)) : 0u;
-            const uint32_t e0 = in0 ? 1u : 0u, e1 = in1 ? 1u : 0u;
-            const uint32_t mine = e0 + e1 + sy0 + sy1;
-            uint32_t inc = mine;
-            for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(inc, o); if (lane >= o) inc += y; }
-            const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-            uint32_t o = run + inc - mine;
-            o += sy0; L.orel[k][0][lane] = o; o += e0;
-            o += sy1; L.orel[k][1][lane] = o;
-            L.synth[k][0][lane] = sy0; L.synth[k][1][lane] = sy1;
-            L.k0[k][0][lane] = exact0 ? wa - 1u : wa;
-            L.k0[k][1][lane] = exact1 ? wb - 1u : wb;
-            if (lane == 0) { L.o0[k] = run; L.tot[k] = tot; }
-            run += tot;
-        }
-    }
-    wave_lds_order();
-
-    // ---- phase 2: one column at a time, one chunk at a time
-#pragma unroll 1
-    for (int c = 0; c < p.ncols; c++) {
-        const InterpCol &ic = p.cols[c];
-        const bool want_p = ic.kind == BOWGPU_INTERP_LINEAR || ic.kind == BOWGPU_INTERP_STEP_PREVIOUS, want_n = ic.kind == BOWGPU_INTERP_LINEAR;
-        const uint64_t *tsu = reinterpret_cast<const uint64_t *>(p.ts);
-        NbPoint carry; carry.has = 0; carry.t = 0; carry.bits = 0;  // the last valid point before the current chunk (wave-uniform)
-        if (want_p && base > 0) {
-            const int64_t pi = prev_valid_ix(ic.vbits, ic.vbit0, p.n, base - 1, ic.nbr);
-            if (pi >= 0) { carry.has = 1; carry.t = p.ts[pi]; carry.bits = ic.values[pi]; }
-        }
-        BitStream bs;
-        bs.start(ic.out_valid_words, o_trip);
-        // (the next chunk's rows are requested before this chunk is worked on)
-        uint64_t na, nb, nta = 0, ntb = 0;
-        load2(ic.values, 0, &na, &nb);
-        if (want_n) load2(tsu, 0, &nta, &ntb);
-#pragma unroll 1
-        for (int k = 0; k < 4; k++) {
-            const int64_t cb = base + 128 * k;
-            if (cb >= p.n) break;
-            const uint64_t a = na, b = nb, ta = nta, tb = ntb;
-            if (k + 1 < 4 && cb + 128 < p.n) {
-                load2(ic.values, k + 1, &na, &nb);
-                if (want_n) load2(tsu, k + 1, &nta, &ntb);
-            }
-            uint64_t w0, w1;
-            load_bits128<false>(ic.vbits, ic.vbit0, cb, p.n, &w0, &w1);
-            const int fl = (int)(((lane < 32 ? w0 : w1) >> sh2l) & 3ull);
-            const uint32_t tot = L.tot[k], o0 = L.o0[k];
-            const uint32_t sy0 = L.synth[k][0][lane], sy1 = L.synth[k][1][lane];
-            const uint32_t or0 = L.orel[k][0][lane] - o0, or1 = L.orel[k][1][lane] - o0;   // relative to the chunk's first output
-            const bool staged = tot <= (uint32_t)kWStage;
-            uint64_t *out = ic.out_values + o_trip + o0;
-            const int64_t obit0 = o_trip + o0;
-            auto put = [&](uint32_t pos, uint64_t bits, int valid) {
-                if (staged) { L.val[pos] = bits; L.flag[pos] = (uint8_t)valid; }
-                else {
-                    out[pos] = bits;
-                    if (valid) atomicOr(&ic.out_valid_words[(obit0 + pos) >> 5], 1u << ((obit0 + pos) & 31));
-                }
-            };
-            const int64_t i = cb + 2 * lane;
-            if (i < p.n) put(or0, a, fl & 1);
-            if (i + 1 < p.n) put(or1, b, (fl >> 1) & 1);
-            uint64_t me = 0, mo = 0;
-            if (want_p) { me = __ballot(fl & 1); mo = __ballot(fl & 2); }
-            if (__ballot(sy0 > 0 || sy1 > 0)) {
-                // pp = the valid point before the lane's even row, np = the valid point from its odd row on
-                NbPoint pp = carry, np; np.has = 0; np.t = 0; np.bits = 0;
-                if (want_p) {
-                    const uint64_t xe = me & lt, xo = mo & lt;
-                    const int le = xe ? 63 - __clzll((long long)xe) : -1, lo = xo ? 63 - __clzll((long long)xo) : -1;
-                    const bool odd = lo >= le, found = (xe | xo) != 0;
-                    const int sl = found ? (odd ? lo : le) : lane;
-                    const uint64_t x0 = __shfl((unsigned long long)a, sl), x1 = __shfl((unsigned long long)b, sl);
-                    if (found) { pp.has = 1; pp.bits = odd ? x1 : x0; }
-                    if (want_n) {
-                        const uint64_t y0 = __shfl((unsigned long long)ta, sl), y1 = __shfl((unsigned long long)tb, sl);
-                        if (found) pp.t = (int64_t)(odd ? y1 : y0);
-                    }
-                }
-                if (want_n) {
-                    const uint64_t xe = me & gt, xo = mo & gt;
-                    const int fe = xe ? __ffsll((long long)xe) - 1 : 64, fo = xo ? __ffsll((long long)xo) - 1 : 64;
-                    const bool even = fe <= fo, found = (xe | xo) != 0;
-                    const int sl = found ? (even ? fe : fo) : lane;
-                    const uint64_t x0 = __shfl((unsigned long long)a, sl), x1 = __shfl((unsigned long long)b, sl);
-                    const uint64_t y0 = __shfl((unsigned long long)ta, sl), y1 = __shfl((unsigned long long)tb, sl);
-                    if (found) { np.has = 1; np.bits = even ? x0 : x1; np.t = (int64_t)(even ? y0 : y1); }
-                }
-                // a lane's first synthetic run sits before its even row when that row starts a window, else before its odd row;
-                // both rows starting windows (one-row windows) takes a second turn
-#pragma unroll 1
-                for (int turn = 0; turn < 2; turn++) {
-                    const bool odd_row = turn == 1 || sy0 == 0;
-                    const bool active = turn == 0 ? (sy0 > 0 || sy1 > 0) : (sy0 > 0 && sy1 > 0);
-                    if (!__ballot(active)) break;
-                    const uint32_t cnt = active ? (odd_row ? sy1 : sy0) : 0u;
-                    const uint32_t kk0 = odd_row ? L.k0[k][1][lane] : L.k0[k][0][lane];
-                    const uint32_t orow = odd_row ? or1 : or0;
-                    // neighbours of that row: before it / from it on
-                    NbPoint qp = pp, qn = np;
-                    if (odd_row) { if (fl & 1) { qp.has = 1; qp.bits = a; qp.t = (int64_t)ta; } }
-                    if (fl & 2) { qn.has = 1; qn.bits = b; qn.t = (int64_t)tb; }
-                    if (!odd_row && (fl & 1)) { qn.has = 1; qn.bits = a; qn.t = (int64_t)ta; }
-                    if (want_n && cnt > 0 && !qn.has) {  // no valid row from here to the end of the chunk: bitmap + index (rare)
-                        const int64_t ni = next_valid_ix(ic.vbits, ic.vbit0, p.n, cb + 128, ic.nbr);
-                        if (ni >= 0) { qn.has = 1; qn.t = p.ts[ni]; qn.bits = ic.values[ni]; }
-                    }
-                    const bool is_long = cnt > (uint32_t)kSmallRun;
-                    if (cnt > 0 && !is_long) {
-                        for (uint32_t j = 0; j < cnt; j++) {
-                            const int64_t sk = p.s0 + (int64_t)((uint64_t)(kk0 - j) * (uint64_t)p.interval);
-                            uint64_t bits; int valid;
-                            synth_value_pt(ic, sk, qp, qn, &bits, &valid);
-                            put(orow - 1 - j, bits, valid);
-                        }
-                    }
-                    uint64_t lm = __ballot(is_long);  // long runs of empty windows: the whole wavefront, one run at a time
-                    while (lm) {
-                        const int src = __ffsll((long long)lm) - 1;
-                        lm &= lm - 1;
-                        const uint32_t rcnt = (uint32_t)__builtin_amdgcn_readlane((int)cnt, src);
-                        const uint32_t rk0 = (uint32_t)__builtin_amdgcn_readlane((int)kk0, src);
-                        const uint32_t ro = (uint32_t)__builtin_amdgcn_readlane((int)orow, src);
-                        NbPoint rp, rn;
-                        rp.has = __builtin_amdgcn_readlane(qp.has, src); rp.bits = lane_value(qp.bits, src); rp.t = (int64_t)lane_value((uint64_t)qp.t, src);
-                        rn.has = __builtin_amdgcn_readlane(qn.has, src); rn.bits = lane_value(qn.bits, src); rn.t = (int64_t)lane_value((uint64_t)qn.t, src);
-                        for (uint32_t j = (uint32_t)lane; j < rcnt; j += 64) {
-                            const int64_t sk = p.s0 + (int64_t)((uint64_t)(rk0 - j) * (uint64_t)p.interval);
-                            uint64_t bits; int valid;
-                            synth_value_pt(ic, sk, rp, rn, &bits, &valid);
-                            put(ro - 1 - j, bits, valid);
-                        }
-                    }
-                }
-            }
-            if (staged) {
-                wave_lds_order();
-                for (uint32_t g = 0; g < tot; g += 64) {
-                    const uint32_t j = g + (uint32_t)lane;
-                    int fv = 0;
-                    if (j < tot) { out[j] = L.val[j]; fv = L.flag[j]; }
-                    const uint64_t bb = __ballot(fv != 0);
-                    bs.append(bb, (int)(tot - g < 64u ? tot - g : 64u), lane);
-                }
-                wave_lds_order();
-            } else {  // written directly (values + atomic bits): restart the bit stream behind this chunk
-                bs.finish(lane);
-                bs.start(ic.out_valid_words, obit0 + (int64_t)tot);
-            }
-            if (want_p && (me | mo)) {  // the chunk's last valid point, for the chunks after it
-                const int le = me ? 63 - __clzll((long long)me) : -1, lo = mo ? 63 - __clzll((long long)mo) : -1;
-                const bool odd = lo >= le;
-                const int sl = odd ? lo : le;
-                carry.has = 1;
-                carry.bits = odd ? lane_value(b, sl) : lane_value(a, sl);
-                if (want_n) carry.t = (int64_t)(odd ? lane_value(tb, sl) : lane_value(ta, sl));
-            }
-        }
-        bs.finish(lane);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------
-// interp_wave2_kernel: a trip (kCh chunks of 128 rows, one wavefront, no barrier) handled AS A WHOLE per column instead of chunk by
-// chunk, with ONE round of global loads in front of everything.  interp_wave_kernel spends a wavefront's life waiting: four wave
-// scans through the LDS crossbar, then per column and chunk a chain of dependent global loads (the column's bitmap -> the
-// neighbour index -> the neighbours' values and timestamps) with ~13 of 64 lanes at work.  Here:
-//   round 1  all loads a trip needs are issued together: its timestamps, the first column's values, and - per column, straight
-//            into LDS (global_load_lds) - the bitmap words around its rows and the kW2Back rows in front of it, where the last
-//            valid point before the trip nearly always lies (the only thing a trip needs from rows outside it);
-//   phase 1  flags and output positions of the rows stay in REGISTERS (lane l = rows 2l, 2l+1 of each 128-row chunk); the scans
-//            are DPP scans (six v_add_dpp each, no LDS); timestamps and output positions by ROW go to LDS; every run of synthetic
-//            rows (a window start that is not a row, plus the empty windows before it) becomes one entry of a list:
-//            (row, count, output position);
-//   phase 2  per column (the next column's values already in flight): the rows go to their output positions in the LDS stage;
-//            ONE lane per run computes its synthetic rows (most of the 64 lanes busy on the configs[2] shape): the nearest valid
-//            rows around the run's row from the column's validity words of the trip (LDS, count-leading / trailing-zeros), their
-//            values out of the stage (through the row -> position table) and their timestamps out of LDS - no global load;
-//            the stage then leaves as 16-byte stores onto 16-byte aligned addresses, the validity bits - assembled in an LDS bit
-//            array whose words line up with the bitmap's - as whole words.
-//            (Storing rows and synthetic rows straight to their positions instead of staging them was measured: the holes a
-//            wavefront leaves and fills a moment later cost 1.5x the write traffic plus read-modify-write fills, 1.86 ms vs 1.43.)
-// INCLUSIVE windows (Options.Inclusive; rolling.go:201-209): a window's bow also holds the first row of the next window when that
-// row sits exactly on the window's end, and Interpolate concatenates the window bows (interpolation.go:98-116) - such a row
-// appears twice, once as the last row of window k and once as the first row of window k + 1.  In row terms: every exact head
-// of a window k + 1 >= 1 is preceded by a copy of itself, so every window contributes exactly one row in front of its first row
-// (a synthetic row or that copy), and the output position of row i is simply i + wid(i) + 1 - [row 0 is an exact head].
-// A trip with more runs than the list holds (windows of < 2 rows, nearly all without a row on their start) raises status[5]
-// and the host redoes the call with interp_wave_kernel; a trip with more outputs than the stage holds (long runs of empty
-// windows) writes directly.
-constexpr int kW2Back = 16;     // rows in front of a trip loaded with it (for the last valid point before the trip)
-
-template <int kRows, int kRuns>
-struct Wave2Lds {
-    static constexpr int kStage = kRows + kRows / 2;   // outputs staged per trip and column (the rows + up to half as many synthetic rows)
-    alignas(16) uint64_t val[kStage + 2];  // staged outputs; index = position + parity, so that pairs (2i, 2i + 1) are 16-byte aligned in the output too
-    uint32_t rowrel[kRows];      // the trip's timestamps by row, as ts - s0 (this kernel's shapes keep every row within 2^32 of s0)
-    uint16_t pos[kRows];         // row -> position (staged trips)
-    uint32_t obits[(kStage + 32) / 32 + 2];   // output validity bits; bit index = (o_trip & 31) + position: words line up with the bitmap's
-    uint32_t run_a[kRuns];       // local row | count << 9 (count saturates at 2^23 - 1: such a run recomputes it)
-    uint32_t run_o[kRuns];       // output position (relative to the trip's first) of the row the run sits in front of
-    uint32_t raw[kMaxCols][kRows / 32 + 4];  // per column: the bitmap words around the trip's rows as they lie in memory ([0] = the word before the first row's)
-    uint32_t vw[kRows / 32 + 2]; // the current column's, shifted into place: row r = bit r (word r >> 5)
-    alignas(16) uint64_t prev[kMaxCols][kW2Back];   // per column: the values of the kW2Back rows in front of the trip
-    alignas(16) uint64_t prets[kW2Back];            // ... and their timestamps
-};
 
 // inclusive wave scan of one unsigned per lane: Hillis-Steele inside the 16-lane rows (row_shr 1, 2, 4, 8), then the row totals
 // across (row_bcast 15 into rows 1 and 3, row_bcast 31 into rows 2 and 3): six DPP moves + adds, no LDS
@@ -704,342 +401,6 @@ __device__ __forceinline__ uint32_t wave_scan_u32(uint32_t x) {
 #define W2_STAMP(i) do { } while (0)
 #endif
 
-// kCh: 128-row chunks per trip (4: the count kernel's tile)
-template <bool kIncl, int kCh>
-__global__ __launch_bounds__(64, kCh == 2 ? 4 : 3) void interp_wave2_kernel(const InterpParams p) {
-    constexpr int kRows = 128 * kCh;
-    constexpr int kRuns = kIncl ? kRows : kRows / 2;
-    typedef Wave2Lds<kRows, kRuns> Lds;
-    constexpr int kStage = Lds::kStage;
-    constexpr int kRawWords = kRows / 32 + 2;   // the word before the first row's + the words of the rows + one more for the shift
-    __shared__ Lds L;
-    const int lane = threadIdx.x;
-#ifdef BOWGPU_STAMPS
-    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last) :: "memory");
-#endif
-    const int64_t trip = blockIdx.x;
-    const int64_t base = trip * kRows;
-    if (base >= p.n) return;
-    const int64_t left_trip = p.n - base;
-    const bool full = left_trip >= kRows;
-    const int nloc = full ? kRows : (int)left_trip;
-    const Magic32 m32 = {p.m32, p.sh1_32, p.sh2_32};
-    const uint32_t s0lo = (uint32_t)p.s0, i32 = (uint32_t)p.interval;
-    const uint64_t *tsu = reinterpret_cast<const uint64_t *>(p.ts);
-
-    auto load2 = [&](const uint64_t *col, int k, uint64_t *a, uint64_t *b) {
-        const int r = 128 * k + 2 * lane;
-        const uint64_t *src = col + base;
-        if (full && (reinterpret_cast<uintptr_t>(col) & 15) == 0) { typedef unsigned long long u64x2i_t __attribute__((ext_vector_type(2))); const u64x2i_t v = __builtin_nontemporal_load(reinterpret_cast<const u64x2i_t *>(src + r)); *a = v.x; *b = v.y; }   // (streamed once)
-        else { *a = r < left_trip ? src[r] : 0; *b = r + 1 < left_trip ? src[r + 1] : 0; }
-    };
-
-    // ---- round 1: everything the trip reads from global memory, issued together
-    uint64_t ta[kCh], tb[kCh], na[kCh], nb[kCh];
-#pragma unroll
-    for (int k = 0; k < kCh; k++) load2(tsu, k, &ta[k], &tb[k]);
-#pragma unroll
-    for (int k = 0; k < kCh; k++) load2(p.cols[0].values, k, &na[k], &nb[k]);
-    int64_t o_trip = 0, t_before = p.left_ts;
-    if (base > 0) {
-        t_before = p.ts[base - 1];
-        const uint32_t wp = mdiv32((uint32_t)((uint64_t)t_before - (uint64_t)p.s0), m32);
-        // inclusive windows: one extra row in front of every window's first row (synthetic or the copy), but none for an exact row 0
-        // (tile_exact_before holds one entry per 256 rows)
-        o_trip = kIncl ? base + (int64_t)wp + 1 - p.wbase - p.e0 : base + (int64_t)wp + 1 - p.wbase - p.tile_exact_before[trip * (kRows / 256)];
-    }
-    // per column: the bitmap words around the trip's rows (4 B per lane) and the kW2Back rows in front of the trip (8 lanes x 16 B)
-    // go straight into LDS (global_load_lds: no registers held while they are in flight); words / rows that do not exist read as 0
-    static_assert(kW2Back == 16, "two rows per lane, eight lanes");
-    for (int i = lane; i < p.ncols * (kRows / 32 + 4); i += 64) (&L.raw[0][0])[i] = 0u;      // (the columns of this call only)
-    for (int i = lane; i < p.ncols * kW2Back; i += 64) (&L.prev[0][0])[i] = 0ull;
-    if (lane < kW2Back) L.prets[lane] = 0ull;
-    wave_lds_order();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the zeroes are in place before any of the loads below can land on them
-    if (base > 0 && lane < kW2Back / 2)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(tsu + base - kW2Back + 2 * lane),
-                                         (__attribute__((address_space(3))) void *)(&L.prets[0]), 16, 0, 0);
-#pragma unroll
-    for (int c = 0; c < kMaxCols; c++) {
-        if (c < p.ncols) {
-            const InterpCol &ic = p.cols[c];
-            if (ic.vbits) {
-                const int64_t wi = ((ic.vbit0 + base) >> 5) - 1 + lane, wlast = (ic.vbit0 + p.n - 1) >> 5;
-                if (lane < kRawWords && wi >= 0 && wi <= wlast)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ic.vbits + wi),
-                                                     (__attribute__((address_space(3))) void *)(&L.raw[c][0]), 4, 0, 0);
-            }
-            if (base > 0 && lane < kW2Back / 2 && (ic.kind == BOWGPU_INTERP_LINEAR || ic.kind == BOWGPU_INTERP_STEP_PREVIOUS))
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ic.values + base - kW2Back + 2 * lane),
-                                                 (__attribute__((address_space(3))) void *)(&L.prev[c][0]), 16, 0, 0);
-        }
-    }
-    W2_STAMP(0);   // issue of round 1
-
-    // ---- phase 1: output positions (relative to o_trip) and synthetic-row counts of the lane's rows, the run list
-    uint32_t or0[kCh], or1[kCh];
-    uint32_t tot = 0;
-    int nrun = 0;
-    {
-        uint32_t rb_prev = 0;
-#pragma unroll
-        for (int k = 0; k < kCh; k++) {
-            const int64_t i = base + 128 * k + 2 * lane;
-            const uint32_t ra = (uint32_t)ta[k] - s0lo, rb = (uint32_t)tb[k] - s0lo;
-            uint32_t rl = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rb, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-            if (lane == 0) rl = k == 0 ? (uint32_t)t_before - s0lo : (uint32_t)__builtin_amdgcn_readlane((int)rb_prev, 63);
-            rb_prev = rb;
-            const bool in0 = i < p.n, in1 = i + 1 < p.n;
-            const bool first = i == 0 && !p.has_left;  // the frame's first row has no left neighbour
-            const uint32_t wl = mdiv32(rl, m32), wa = mdiv32(ra, m32), wb = mdiv32(rb, m32);
-            const bool head0 = in0 && (first || wa != wl), head1 = in1 && wb != wa;
-            const bool exact0 = head0 && ra == wa * i32, exact1 = head1 && rb == wb * i32;
-            // rows in front of a head: the empty windows before it + a synthetic row for its own window - or, when the row sits on
-            // its window's start, nothing (exclusive windows) / the copy of itself that closes the window before (inclusive ones)
-            const uint32_t sy0 = head0 ? ((first ? 0u : wa - wl - 1u) + (exact0 ? ((kIncl && !first) ? 1u : 0u) : 1u)) : 0u;
-            const uint32_t sy1 = head1 ? (wb - wa - 1u + (exact1 ? (kIncl ? 1u : 0u) : 1u)) : 0u;
-            const uint32_t e0 = in0 ? 1u : 0u, e1 = in1 ? 1u : 0u;
-            const uint32_t mine = e0 + e1 + sy0 + sy1;
-            const uint32_t inc = wave_scan_u32(mine);
-            uint32_t o = tot + inc - mine;
-            o += sy0; or0[k] = o; o += e0;
-            o += sy1; or1[k] = o;
-            tot += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-            *reinterpret_cast<uint2 *>(&L.rowrel[128 * k + 2 * lane]) = make_uint2(ra, rb);
-            *reinterpret_cast<uint32_t *>(&L.pos[128 * k + 2 * lane]) = (or0[k] & 0xFFFFu) | (or1[k] << 16);
-            // the runs of this chunk, in row order
-            const bool ha = sy0 > 0, hb = sy1 > 0;
-            const unsigned long long ma = __ballot(ha), mb = __ballot(hb);
-            if (ma | mb) {
-                int pos = nrun;
-                pos += __builtin_amdgcn_mbcnt_hi((unsigned)(ma >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ma, 0));
-                pos += __builtin_amdgcn_mbcnt_hi((unsigned)(mb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb, 0));
-                const uint32_t la = (uint32_t)(128 * k + 2 * lane);
-                if (ha && pos < kRuns) { L.run_a[pos] = la | ((sy0 < 0x7FFFFFu ? sy0 : 0x7FFFFFu) << 9); L.run_o[pos] = or0[k]; }
-                pos += ha ? 1 : 0;
-                if (hb && pos < kRuns) { L.run_a[pos] = (la + 1u) | ((sy1 < 0x7FFFFFu ? sy1 : 0x7FFFFFu) << 9); L.run_o[pos] = or1[k]; }
-                nrun += __popcll(ma) + __popcll(mb);
-            }
-        }
-    }
-    if (nrun > kRuns) {   // outside this kernel's list: the host redoes the call with interp_wave_kernel
-        if (lane == 0) atomicOr(&p.status[5], 1u);
-        return;
-    }
-    const bool staged = tot <= (uint32_t)kStage;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the direct-to-LDS loads of round 1 have landed (everything else of it was consumed above)
-    wave_lds_order();
-    W2_STAMP(1);   // wait for round 1 + phase 1
-
-    // ---- phase 2: one column at a time
-    const uint32_t sh_o = (uint32_t)(o_trip & 31);   // bit of the trip's first output inside its bitmap word
-#pragma unroll 1
-    for (int c = 0; c < p.ncols; c++) {
-        const InterpCol &ic = p.cols[c];
-        const bool want_p = ic.kind == BOWGPU_INTERP_LINEAR || ic.kind == BOWGPU_INTERP_STEP_PREVIOUS, want_n = ic.kind == BOWGPU_INTERP_LINEAR;
-        uint64_t a[kCh], b[kCh];
-#pragma unroll
-        for (int k = 0; k < kCh; k++) { a[k] = na[k]; b[k] = nb[k]; }
-        if (c + 1 < p.ncols) {
-#pragma unroll
-            for (int k = 0; k < kCh; k++) load2(p.cols[c + 1].values, k, &na[k], &nb[k]);
-        }
-        uint64_t *out = ic.out_values + o_trip;
-        const uint32_t par = (uint32_t)((reinterpret_cast<uintptr_t>(out) >> 3) & 1);   // the trip's first output is the odd half of a 16-byte pair
-        // the column's validity bits of the trip's rows, shifted into place (row r = bit r)
-        if (lane < (kStage + 32) / 32 + 2) L.obits[lane] = 0u;
-        const int sb = (int)((ic.vbit0 + base) & 31);
-        if (lane < kRows / 32) {
-            uint32_t x = 0xFFFFFFFFu;
-            if (ic.vbits) {
-                const uint32_t lo = L.raw[c][lane + 1], hi = L.raw[c][lane + 2];
-                x = sb ? (lo >> sb) | (hi << (32 - sb)) : lo;
-            }
-            const int left = nloc - 32 * lane;   // rows of the trip from this word on
-            if (left < 32) x = left <= 0 ? 0u : (x & ((1u << left) - 1u));
-            L.vw[lane] = x;
-        }
-        // the last valid point before the trip: among the kW2Back rows in front of it (their bits lie in raw[c][0..1]); further
-        // back only after a run of kW2Back nulls - then through the bitmap and the neighbour index
-        NbPoint carry; carry.has = 0; carry.t = 0; carry.bits = 0;
-        if (want_p && base > 0 && nrun > 0) {
-            bool v = false;
-            if (lane < kW2Back) {
-                v = true;
-                if (ic.vbits) {
-                    const int bp = 32 + sb - kW2Back + lane;       // bit index counted from raw[c][0]'s bit 0 (sb < 32, kW2Back <= 32)
-                    v = (L.raw[c][bp >> 5] >> (bp & 31)) & 1u;
-                }
-            }
-            const uint64_t m = __ballot(v);
-            if (m) {
-                const int src = 63 - __clzll((long long)m);
-                carry.has = 1; carry.bits = L.prev[c][src]; carry.t = (int64_t)L.prets[src];
-            } else if (base > kW2Back) {
-                const int64_t pi = prev_valid_ix(ic.vbits, ic.vbit0, p.n, base - kW2Back - 1, ic.nbr);
-                if (pi >= 0) {
-                    uint64_t xb = ic.values[pi], xt = (uint64_t)p.ts[pi];
-                    asm volatile("" : "+v"(xb), "+v"(xt));   // (see below: no load left pending at the join)
-                    carry.has = 1; carry.t = (int64_t)xt; carry.bits = xb;
-                }
-            }
-        }
-        wave_lds_order();
-        auto put = [&](uint32_t pos, uint64_t bits, int valid) {
-            if (staged) {
-                L.val[pos + par] = bits;
-                if (valid) atomicOr(&L.obits[(sh_o + pos) >> 5], 1u << ((sh_o + pos) & 31));
-            } else {
-                out[pos] = bits;
-                if (valid) atomicOr(&ic.out_valid_words[(o_trip + pos) >> 5], 1u << ((o_trip + pos) & 31));
-            }
-        };
-        // the rows to their places
-#pragma unroll
-        for (int k = 0; k < kCh; k++) {
-            const int r = 128 * k + 2 * lane;
-            const int fl = (int)((L.vw[4 * k + (lane >> 4)] >> ((2 * lane) & 31)) & 3u);
-            if (r < nloc) put(or0[k], a[k], fl & 1);
-            if (r + 1 < nloc) put(or1[k], b[k], (fl >> 1) & 1);
-        }
-        wave_lds_order();
-        W2_STAMP(2);   // column head: validity words, carry, rows staged
-        // a row of the trip as a neighbour point / as the copy that closes the window before (staged trips read the stage)
-        auto row_bits = [&](int r) -> uint64_t { return staged ? L.val[L.pos[r] + par] : ic.values[base + r]; };
-        // ---- one lane per run
-#pragma unroll 1
-        for (int q0 = 0; q0 < nrun; q0 += 64) {
-            const int q = q0 + lane;
-            const bool act = q < nrun;
-            const uint32_t e = act ? L.run_a[q] : 0u;
-            const uint32_t orow = act ? L.run_o[q] : 0u;
-            const int al = (int)(e & 511u);
-            uint32_t cnt = e >> 9;
-            const uint32_t rel = L.rowrel[al];
-            const uint32_t w = mdiv32(rel, m32);
-            const bool exact = rel == w * i32;
-            const uint32_t jd = (kIncl && exact && cnt > 0) ? 1u : 0u;   // the run's first row is the copy of row al, not a synthetic row
-            const uint32_t kfirst = exact ? w - 1u : w;                 // the window of the run's first SYNTHETIC row
-            if (cnt == 0x7FFFFFu) {  // a saturated count: recompute it from the row before (the windows between the two rows)
-                const uint32_t wl = mdiv32(al > 0 ? L.rowrel[al - 1] : (uint32_t)t_before - s0lo, m32);
-                cnt = w - wl - 1u + (exact ? (kIncl ? 1u : 0u) : 1u);
-            }
-            NbPoint qp = carry, qn; qn.has = 0; qn.t = 0; qn.bits = 0;
-            if (act && want_p) {   // nearest valid row before row al
-                int r = al - 1;
-                while (r >= 0) {
-                    const int sh = r & 31;
-                    uint32_t x = L.vw[r >> 5];
-                    x = sh == 31 ? x : (x & ((2u << sh) - 1u));
-                    if (x) { r = (r & ~31) + 31 - __clz((int)x); break; }
-                    r = (r & ~31) - 1;
-                }
-                if (r >= 0) { qp.has = 1; qp.bits = row_bits(r); qp.t = p.s0 + (int64_t)(uint64_t)L.rowrel[r]; }
-            }
-            if (act && want_n) {   // nearest valid row from row al on
-                int r = al;
-                bool found = false;
-                while (r < nloc) {
-                    const uint32_t x = L.vw[r >> 5] & (~0u << (r & 31));
-                    if (x) { r = (r & ~31) + __ffs((int)x) - 1; found = r < nloc; break; }
-                    r = (r | 31) + 1;
-                }
-                if (found) { qn.has = 1; qn.bits = row_bits(r); qn.t = p.s0 + (int64_t)(uint64_t)L.rowrel[r]; }
-                else if (base + nloc < p.n) {   // beyond the trip (rare): bitmap + index
-                    const int64_t ni = next_valid_ix(ic.vbits, ic.vbit0, p.n, base + nloc, ic.nbr);
-                    if (ni >= 0) {
-                        uint64_t xb = ic.values[ni], xt = tsu[ni];
-                        // (waited for inside the rare branch: pending at the join, these two loads make the compiler put a wait for ALL
-                        // outstanding loads and stores in front of every later write to their registers - the flush's LDS reads among them)
-                        asm volatile("" : "+v"(xb), "+v"(xt));
-                        qn.has = 1; qn.bits = xb; qn.t = (int64_t)xt;
-                    }
-                }
-            }
-            uint64_t dup_bits = 0;
-            int dup_valid = 0;
-            if (kIncl && act && jd) { dup_bits = row_bits(al); dup_valid = (int)((L.vw[al >> 5] >> (al & 31)) & 1u); }
-            const bool is_long = act && cnt > (uint32_t)kSmallRun;
-            if (act && !is_long) {
-                for (uint32_t j = 0; j < cnt; j++) {
-                    uint64_t bits; int valid;
-                    if (kIncl && j < jd) { bits = dup_bits; valid = dup_valid; }
-                    else {
-                        const int64_t sk = p.s0 + (int64_t)((uint64_t)(kfirst - (j - jd)) * (uint64_t)p.interval);
-                        synth_value_pt(ic, sk, qp, qn, &bits, &valid);
-                    }
-                    put(orow - 1 - j, bits, valid);
-                }
-            }
-            uint64_t lm = __ballot(is_long);  // long runs of empty windows: the whole wavefront, one run at a time
-            while (lm) {
-                const int src = __ffsll((long long)lm) - 1;
-                lm &= lm - 1;
-                const uint32_t rcnt = (uint32_t)__builtin_amdgcn_readlane((int)cnt, src);
-                const uint32_t rk0 = (uint32_t)__builtin_amdgcn_readlane((int)kfirst, src);
-                const uint32_t rjd = (uint32_t)__builtin_amdgcn_readlane((int)jd, src);
-                const uint32_t ro = (uint32_t)__builtin_amdgcn_readlane((int)orow, src);
-                const uint64_t rdb = lane_value(dup_bits, src);
-                const int rdv = __builtin_amdgcn_readlane(dup_valid, src);
-                NbPoint rp, rn;
-                rp.has = __builtin_amdgcn_readlane(qp.has, src); rp.bits = lane_value(qp.bits, src); rp.t = (int64_t)lane_value((uint64_t)qp.t, src);
-                rn.has = __builtin_amdgcn_readlane(qn.has, src); rn.bits = lane_value(qn.bits, src); rn.t = (int64_t)lane_value((uint64_t)qn.t, src);
-                for (uint32_t j = (uint32_t)lane; j < rcnt; j += 64) {
-                    uint64_t bits; int valid;
-                    if (kIncl && j < rjd) { bits = rdb; valid = rdv; }
-                    else {
-                        const int64_t sk = p.s0 + (int64_t)((uint64_t)(rk0 - (j - rjd)) * (uint64_t)p.interval);
-                        synth_value_pt(ic, sk, rp, rn, &bits, &valid);
-                    }
-                    put(ro - 1 - j, bits, valid);
-                }
-            }
-        }
-        W2_STAMP(3);   // run pass
-        // ---- the stage leaves: 16 bytes per lane onto 16-byte aligned addresses (single 8-byte stores at the two ends), the
-        // validity words as they are (the first and the last one may be shared with the neighbouring trips: atomic OR)
-        if (staged) {
-            wave_lds_order();
-            const uint32_t nelem = par + tot;            // stage elements [par, par + tot) are real
-            ulonglong2 *out2 = reinterpret_cast<ulonglong2 *>(out - par);
-            // (all LDS reads of the stage first, then the stores: a rolled loop pays the LDS latency once per trip of 64 pairs)
-            constexpr int kFlushTrips = (kStage / 2 + 1 + 63) / 64;
-            ulonglong2 fx[kFlushTrips];
-#pragma unroll
-            for (int k = 0; k < kFlushTrips; k++) {
-                const uint32_t i = (uint32_t)lane + 64u * (uint32_t)k;
-                fx[k] = 2 * i < nelem ? *reinterpret_cast<const ulonglong2 *>(&L.val[2 * i]) : make_ulonglong2(0, 0);
-            }
-#pragma unroll
-            for (int k = 0; k < kFlushTrips; k++) {
-                const uint32_t i = (uint32_t)lane + 64u * (uint32_t)k;
-                if (2 * i >= nelem) continue;
-                const ulonglong2 x = fx[k];
-                const bool lo_ok = 2 * i >= par, hi_ok = 2 * i + 1 < nelem;
-                if (lo_ok && hi_ok) { typedef unsigned long long u64x2o_t __attribute__((ext_vector_type(2))); u64x2o_t q; q.x = x.x; q.y = x.y; __builtin_nontemporal_store(q, reinterpret_cast<u64x2o_t *>(out2 + i)); }   // (never read back)
-                else if (lo_ok) out[2 * i - par] = x.x;
-                else if (hi_ok) out[2 * i + 1 - par] = x.y;
-            }
-            const uint32_t nw = (sh_o + tot + 31) >> 5;
-            uint32_t *wdst = ic.out_valid_words + (o_trip >> 5);
-            for (uint32_t wi = (uint32_t)lane; wi < nw; wi += 64) {
-                const uint32_t x = L.obits[wi];
-                if (wi == 0 || wi == nw - 1) { if (x) atomicOr(&wdst[wi], x); }
-                else wdst[wi] = x;
-            }
-            wave_lds_order();
-        }
-        W2_STAMP(4);   // flush
-    }
-#ifdef BOWGPU_STAMPS
-    if (lane == 0) {
-        for (int i = 0; i < 5; i++) atomicAdd(reinterpret_cast<unsigned long long *>(p.status + 32) + i, st_acc[i]);
-        atomicAdd(reinterpret_cast<unsigned long long *>(p.status + 32) + 7, 1ull);
-    }
-#endif
-}
-
 // ---------------------------------------------------------------------------------------------------------------------------
 // interp_wave3_kernel (round 3): interp_wave2_kernel's pass rebuilt for OCCUPANCY.  wave2 holds 13 KB of LDS and 158 VGPRs per
 // wavefront - 11 resident per CU - and its rate followed that (counters: 9.5 wavefronts per CU, 68 % of a wave's life spent waiting,
@@ -1060,8 +421,8 @@ __global__ __launch_bounds__(64, kCh == 2 ? 4 : 3) void interp_wave2_kernel(cons
 // saturated (5.1e8 scalar instructions per launch against 1.5e8); neighbour points gathered from global memory instead of
 // LDS / registers, 1.95 ms - gfx950 counts loads and stores in ONE counter, so waiting for a gather waited for every store of the
 // previous column's flush.  Trips whose outputs exceed the stage (long runs of empty windows) write directly; more runs than the
-// list holds (windows of < 4 rows on average) raise status[5] and the host redoes the call with interp_wave_kernel /
-// interp_wave2_kernel.  Results are bit-identical to the other Interpolate kernels (the tests run all of them).
+// list holds (windows of < 4 rows on average) raise status[5] and the host redoes the call with interp_tile_kernel.  Results are
+// bit-identical to that kernel's (the tests run both).
 constexpr int kT3Rows = 512;                  // rows per trip: 4 chunks of 128, lane l = rows 2l, 2l + 1 of each
 constexpr int kT3Ch = kT3Rows / 128;
 constexpr int kT3Stage = kT3Rows + kT3Rows / 2;   // outputs staged per trip and column (the rows + up to half as many synthetic rows)
@@ -1569,20 +930,15 @@ void interp_magic32(int64_t interval, uint32_t *m, uint32_t *sh1, uint32_t *sh2)
 int launch_interp_tiles(Ctx *c, const InterpParams &p) {
     const int64_t ntiles = (p.n + kITile - 1) / kITile;
     if (ntiles <= 0) return 0;
-    // the usual shape takes the barrier-free wave kernels (BOWGPU_ROUTE_INTERP_TILE: test switch that keeps it on the tile kernel)
+    // interp_wave3_kernel for every shape it can take (its trip-relative form only needs each TRIP within 2^31: wide32); the workgroup
+    // kernel for the rest - 64-bit window ids, dropped rows, the -1 sentinel window - and for the redo of a call one of whose trips
+    // overflowed wave3's lists (allow_wave2 == 0).  BOWGPU_ROUTE_INTERP_TILE: the test switch that runs an exclusive call through the
+    // workgroup kernel (the second opinion of the tests).  Inclusive windows are built by wave3 alone.
     const uint32_t route = route_mask();
-    const bool force_tile = (route & BOWGPU_ROUTE_INTERP_TILE) != 0;
-    static_assert(kITile == 512, "interp_wave_kernel's trips are the count kernel's tiles");
-    static_assert(kT3Rows == 512, "interp_wave3_kernel's trips are the count kernel's tiles");
-    // BOWGPU_ROUTE_INTERP_WAVE1 / _WAVE2: the round-1 / round-2 wave kernels (wave1 is also what a call is redone with when a trip
-    // overflows the run list of the others)
-    const bool wave1 = (route & BOWGPU_ROUTE_INTERP_WAVE1) != 0, wave2 = (route & BOWGPU_ROUTE_INTERP_WAVE2) != 0;
+    const bool force_tile = (route & BOWGPU_ROUTE_INTERP_TILE) != 0 && !p.inclusive;
+    static_assert(kT3Rows == kITile, "interp_wave3_kernel's trips are the count kernel's tiles");
     const bool shape_ok = p.drop == 0 && p.kq < 0;
-    // interp_wave3_kernel: the product's choice for every shape it can take (its trip-relative form only needs each TRIP within 2^31:
-    // wide32); not on a redo (a trip overflowed its lists: allow_wave2 == 0), not when a test asks for another kernel.  Inclusive
-    // windows are served by wave3 and wave2 only, whatever the test switches say.
-    const bool want3 = p.allow_wave2 && !wave2 && (p.inclusive || (!wave1 && !force_tile));
-    if (shape_ok && (p.fast32 || p.wide32) && want3) {
+    if (shape_ok && (p.fast32 || p.wide32) && p.allow_wave2 && !force_tile) {
         const int64_t ntrips = (p.n + kT3Rows - 1) / kT3Rows, per_xcd = (ntrips + 7) / 8;
         if (per_xcd * 8 > 0x7FFFFFFFll) return fail(BOWGPU_ERR_UNSUPPORTED, "too many rows for one launch: %lld", (long long)p.n);
         if (!p.edge_words) return fail(BOWGPU_ERR_ARG, "internal: interp_wave3_kernel needs its edge list");
@@ -1590,11 +946,8 @@ int launch_interp_tiles(Ctx *c, const InterpParams &p) {
         else hipLaunchKernelGGL((interp_wave3_kernel<false>), dim3((unsigned)(per_xcd * 8)), dim3(64), 0, c->stream, p, ntrips, per_xcd);
         hipLaunchKernelGGL(interp_edge_fix_kernel, dim3((unsigned)((ntrips * p.ncols + 255) / 256)), dim3(256), 0, c->stream, p, ntrips);
     }
-    else if (p.inclusive && !(shape_ok && p.fast32))   // no other kernel builds inclusive windows: never fall through to an exclusive one
+    else if (p.inclusive)   // no other kernel builds inclusive windows: never fall through to an exclusive one
         return fail(BOWGPU_ERR_UNSUPPORTED, "Interpolate on inclusive windows: this shape is outside the device path");
-    else if (shape_ok && p.fast32 && p.inclusive) hipLaunchKernelGGL((interp_wave2_kernel<true, 4>), dim3((unsigned)ntiles), dim3(64), 0, c->stream, p);
-    else if (shape_ok && p.fast32 && !force_tile && p.allow_wave2 && !wave1) hipLaunchKernelGGL((interp_wave2_kernel<false, 4>), dim3((unsigned)ntiles), dim3(64), 0, c->stream, p);
-    else if (shape_ok && p.fast32 && !force_tile) hipLaunchKernelGGL(interp_wave_kernel, dim3((unsigned)ntiles), dim3(64), 0, c->stream, p);
     else if (p.fast32) hipLaunchKernelGGL(interp_tile_kernel<true>, dim3((unsigned)ntiles), dim3(kIThreads), 0, c->stream, p);
     else hipLaunchKernelGGL(interp_tile_kernel<false>, dim3((unsigned)ntiles), dim3(kIThreads), 0, c->stream, p);
     BG_HIP(hipGetLastError());

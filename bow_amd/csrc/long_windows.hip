@@ -159,14 +159,10 @@ __device__ __forceinline__ void emit_stats(const AggParams &p, int slot, const L
 // (valid_out != nullptr: the validity bitmaps are not touched; bit i of *valid_out is set when the output of aggregation i is valid -
 // the caller assembles whole bitmap words from its lanes)
 __device__ __forceinline__ void emit_window(const AggParams &p, int slot, const LongEntry &w, const Part &acc, uint32_t *valid_out = nullptr) {
-    const unsigned my_mask = p.pass_mask[slot + 1];
     const ColDesc *cd = slot >= 0 ? &p.cols[slot] : nullptr;
     const int col_type = cd ? cd->type : BOWGPU_INT64;
-    const bool need_vals = cd && (p.pass_flags[slot + 1] & kPassNeedVals);
     const uint64_t *vp = cd ? reinterpret_cast<const uint64_t *>(cd->values) : nullptr;
-    const int64_t win_start = p.s0 + (int64_t)(w.wid * (uint64_t)p.interval);
     const int64_t oslot = (int64_t)(w.wid - (uint64_t)p.wid_base);
-    const int64_t len = w.dead ? 0 : w.r1 - w.r0;
     if ((uint64_t)oslot >= (uint64_t)p.W) return;
     // rebuild the reference's running state from the order-free partial
     Stats st;

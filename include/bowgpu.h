@@ -547,25 +547,15 @@ int bowgpu_stream_read_ceiling(const void *dev_a, const void *dev_b, int64_t byt
  * roofline.achieved does.  Measurement aid for bench.py ("stream_rw_probe"). */
 int bowgpu_stream_rw_probe(const void *dev_a, const void *dev_b, int64_t bytes_each, void *out_a, void *out_b,
                              int64_t rows_per_slot, double *read_gb_per_s, double *ms /* nullable */);
-/* Test / A-B routing.  Which kernel serves a call follows from the call's shape alone; the parity tests push one call through
- * every kernel that can take it by setting these bits for the CALLING THREAD (0 = product routing).  The library never reads the
- * environment on the call path; BOWGPU_ROUTE=<mask> is read once per process as every thread's initial mask (profiling an
- * unmodified script).  All routes give the same results where several apply. */
+/* Per-thread route mask.  Which kernel serves a call follows from the call's shape alone; two bits are a caller's business:
+ *   BOWGPU_ROUTE_STRICT_ORDER  bowgpu_options.strict_order for every call of the thread
+ *   BOWGPU_ROUTE_PINNED_STAGE  BOWGPU_HOST_PINNED inputs staged through HBM instead of read in place over the host link
+ * The remaining bits (bow_amd/csrc/debug_routes.h, not part of the ABI) let the parity tests push one call through every kernel
+ * that can take it; all routes give the same results where several apply.  The library never reads the environment on the call
+ * path; BOWGPU_ROUTE=<mask> is read once per process as every thread's initial mask (profiling an unmodified script). */
 enum {
-    BOWGPU_ROUTE_NO_SIMPLE = 1,          /* wave-tile kernels (rolling_simple / rolling_tw) off: rolling_wave_kernel / the general kernel */
-    BOWGPU_ROUTE_FORCE_GENERAL = 2,      /* everything through rolling_agg_kernel */
-    BOWGPU_ROUTE_NO_LONG_ONLY = 4,       /* long windows through the tile kernels' queue instead of the long-only forms */
-    BOWGPU_ROUTE_LONG_CLASSIC = 8,       /* long-only calls: bisection form only */
-    BOWGPU_ROUTE_LONG_STREAM_ALL = 16,   /* long-only calls: streaming form for every reducer set */
-    BOWGPU_ROUTE_SIMPLE_SMALL_LIST = 32, /* rolling_simple_kernel: the 254-head list whatever the plan says */
-    BOWGPU_ROUTE_SIMPLE_LARGE_LIST = 64, /* ... the 400-head list */
-    BOWGPU_ROUTE_TW_F64 = 128,           /* rolling_tw_kernel: float64 timestamps in LDS even where 32-bit offsets are exact */
-    BOWGPU_ROUTE_INTERP_WAVE1 = 256,     /* Interpolate: interp_wave_kernel (default: interp_wave3_kernel) */
-    BOWGPU_ROUTE_INTERP_TILE = 512,      /* Interpolate: interp_tile_kernel */
-    BOWGPU_ROUTE_PINNED_STAGE = 1024,    /* BOWGPU_HOST_PINNED inputs staged through HBM instead of read in place */
-    BOWGPU_ROUTE_STRICT_ORDER = 2048,    /* same as bowgpu_options.strict_order for every call of the thread */
-    BOWGPU_ROUTE_INTERP_WAVE2 = 4096,    /* Interpolate: interp_wave2_kernel (the round-2 default) */
-    BOWGPU_ROUTE__ALL = 8191
+    BOWGPU_ROUTE_PINNED_STAGE = 1024,
+    BOWGPU_ROUTE_STRICT_ORDER = 2048
 };
 int bowgpu_debug_set_route(uint32_t mask);
 int bowgpu_debug_get_route(uint32_t *mask);

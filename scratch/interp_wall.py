@@ -1,5 +1,5 @@
 """Interpolate(WindowStart, Linear) on the configs[2] shape (1e8 rows, 30 % nulls, interval 100): wall time of the _count call, of the
-_fill call that follows it (outputs allocated once, outside the timing), and of both; capi.ROUTE_INTERP_WAVE1 / ROUTE_INTERP_TILE
+_fill call that follows it (outputs allocated once, outside the timing), and of both; capi.ROUTE_INTERP_TILE
 switch to the older kernels for an A/B in one process."""
 import os, sys, time
 sys.path.insert(0, '.')
@@ -30,7 +30,7 @@ def timeit(fn, reps=10):
         t0 = time.perf_counter(); fn(); capi.synchronize(); t.append((time.perf_counter() - t0) * 1e3)
     t.sort()
     return t[len(t) // 2]
-for label, mask in (("wave3 (default)", 0), ("wave2", capi.ROUTE_INTERP_WAVE2), ("wave1", capi.ROUTE_INTERP_WAVE1), ("tile", capi.ROUTE_INTERP_TILE)):
+for label, mask in (("wave3 (default)", 0), ("tile", capi.ROUTE_INTERP_TILE)):
     capi.set_route(mask)
     both = timeit(lambda: (count(), fill()))
     c_ms = timeit(count)

@@ -64,3 +64,19 @@ def test_no_cpu_fallback_without_gpu():
     with pytest.raises(capi.BowGpuError) as e:
         capi.rolling_aggregate([ts, val], 0, 10, [("WindowStart", 0), ("Sum", 1)])
     assert e.value.code == -11
+
+
+def test_route_bits_of_the_binding_equal_the_headers():
+    """two public bits in include/bowgpu.h, the test / A-B bits in bow_amd/csrc/debug_routes.h (not part of the ABI): capi.py holds copies"""
+    pub = open(os.path.join(ROOT, "include", "bowgpu.h")).read()
+    prv = open(os.path.join(ROOT, "bow_amd", "csrc", "debug_routes.h")).read()
+    bits = {}
+    for src in (pub, prv):
+        for name, val in re.findall(r"\b(BOWGPU_ROUTE_\w+) = (\d+)", src):
+            bits[name] = int(val)
+    assert set(re.findall(r"\b(BOWGPU_ROUTE_\w+) =", pub)) == {"BOWGPU_ROUTE_PINNED_STAGE", "BOWGPU_ROUTE_STRICT_ORDER"}
+    for name, val in bits.items():
+        if name == "BOWGPU_ROUTE__ALL":
+            continue
+        assert getattr(capi, name[len("BOWGPU_"):]) == val, name
+    assert bits["BOWGPU_ROUTE__ALL"] == sum(v for k, v in bits.items() if k != "BOWGPU_ROUTE__ALL")

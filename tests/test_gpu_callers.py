@@ -29,9 +29,9 @@ def _interps(spec):
 
 
 def both_interp_kernels(fn):
-    """runs fn() under all three Interpolate kernels - the whole-trip wave kernel (default for the usual shapes), the first wave
-    kernel (capi.ROUTE_INTERP_WAVE1) and the workgroup kernel that serves the rest (capi.ROUTE_INTERP_TILE) - checks that they agree
-    bit for bit, returns the first result"""
+    """runs fn() under both Interpolate kernels - interp_wave3_kernel (the product's, for the usual shapes) and the workgroup kernel that
+    serves the rest (capi.ROUTE_INTERP_TILE: the one kept second implementation) - checks that they agree bit for bit, returns the
+    first result"""
     res = []
     for _label, mask in capi.INTERP_ROUTES:
         with capi.route(mask):
