@@ -575,6 +575,24 @@ def rolling_interpolate(cols, ts_col, interval, interps, offset=0, inclusive=Fal
     return outs
 
 
+def rolling_interpolate_onepass(cols, ts_col, interval, interps, offset=0, inclusive=False, out_residency=HOST, capacity=None, outs=None):
+    """Rolling.Interpolate as ONE call: bowgpu_rolling_interpolate_fill without a preceding _count.  The output buffers are sized by
+    the caller (default: rows + windows, the most any call adds); the call sets their length."""
+    opts = Options(offset, int(bool(inclusive)), 0)
+    if capacity is None:
+        capacity = cols[ts_col].length + (plan_windows(cols[ts_col], interval, offset)[1] if cols[ts_col].length else 0)
+    carr, iarr = _cols(cols), _interps(interps)
+    if outs is None:
+        outs = [OutColumn(capacity, out_residency) for _ in interps]
+    oarr = (Out * max(len(interps), 1))()
+    for i, o in enumerate(outs):
+        oarr[i] = o.c()
+    check(lib().bowgpu_rolling_interpolate_fill(carr, len(cols), ts_col, C.c_int64(interval), C.byref(opts), iarr, len(interps), oarr))
+    for i, o in enumerate(outs):
+        o.absorb(oarr[i])
+    return outs
+
+
 def shard_interp_points(cols, ts_col):
     """this shard's first / last valid point per column (bytes of bowgpu_interp_points: travels through an all_gather)"""
     pts = InterpPoints()

@@ -268,6 +268,33 @@ static int interp_prepare(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t
     return 0;
 }
 
+// Rolling.Interpolate as ONE pass over the rows (a _fill that does not follow its _count): no count pass - the order of the interval
+// column is checked by the fill kernel itself and, for exclusive windows, the exact heads of the earlier trips reach a trip by
+// decoupled look-back (interpolate.hip trip_lookback); inclusive windows need no such count at all (n_out = n + W - e0).  Taken for
+// the shapes interp_wave3_kernel serves on its own: the whole frame (no shard), no -1 sentinel window, no rows below s0.
+// *applies = false: the two-pass path (interp_prepare) takes the call.
+static int interp_onepass_prepare(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval, const bowgpu_options *o,
+                                  InterpJob *job, bool *applies) {
+    *applies = false;
+    if (route_mask() & BOWGPU_ROUTE_INTERP_TILE) return 0;
+    const int64_t n = cols[ts_col].length;
+    if (n <= 0) return 0;
+    for (int i = 0; i < ncols; i++)
+        if (cols[i].length != n) return fail(BOWGPU_ERR_ARG, "column %d has a different length", i);
+    BG_TRY(plan_make(c, &cols[ts_col], interval, o->offset, &job->plan));
+    const Plan &pl = job->plan;
+    if (pl.W <= 0 || pl.first_ts < pl.s0 || pl.s0 <= -1) return 0;   // (s0 <= -1: a window may start at -1 - the reference's sentinel)
+    if (!(interp_fast32(pl, -1) || interp_wide32(pl, -1))) return 0;
+    BG_TRY(ts_contract(c, &cols[ts_col]));
+    BG_TRY(ts_device(c, &cols[ts_col], &job->dts));
+    job->kq = -1; job->drop = 0; job->kq_empty = 0; job->has_left = 0; job->wbase = 0;
+    job->e0 = (o->inclusive && pl.first_ts == pl.s0) ? 1 : 0;
+    job->M = o->inclusive ? pl.W - job->e0 : 0;   // (exclusive windows: known when the kernel has run)
+    c->interp_cache.valid = false;
+    *applies = true;
+    return 0;
+}
+
 static int interp_count_impl(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval, const bowgpu_options *opts,
                              const bowgpu_interp *interps, int32_t ninterps, int64_t *n_out, const int64_t *global_s0,
                              const bowgpu_interp_edge *edge) {
@@ -310,8 +337,17 @@ static int interp_fill_impl(const bowgpu_col *cols, int32_t ncols, int32_t ts_co
     }
     BG_TRY(ctx_get(&c));
     InterpJob job;
-    BG_TRY(interp_prepare(c, cols, ncols, ts_col, interval, &o, &job, global_s0, edge, true));
-    const int64_t n_out = n + job.M;
+    bool onepass = false;
+    if (!cached && !global_s0 && !edge) BG_TRY(interp_onepass_prepare(c, cols, ncols, ts_col, interval, &o, &job, &onepass));
+    if (!onepass) BG_TRY(interp_prepare(c, cols, ncols, ts_col, interval, &o, &job, global_s0, edge, true));
+    const bool look = onepass && !o.inclusive;   // exclusive windows in one pass: the row count comes out of the kernel
+    int64_t n_out = n + job.M;
+    if (look) {   // ... and until then the caller's buffers bound what it may write (bowgpu_out.length in: capacity)
+        n_out = outs[0].length;
+        for (int i = 1; i < ninterps; i++) n_out = outs[i].length < n_out ? outs[i].length : n_out;
+        if (n_out < n) return fail(BOWGPU_ERR_ARG, "output column has %lld slots, at least %lld needed", (long long)n_out, (long long)n);
+        if (n_out > n + job.plan.W) n_out = n + job.plan.W;   // (no call adds more than one row per window)
+    }
     if (n_out == 0) {
         for (int i = 0; i < ninterps; i++) { outs[i].length = 0; outs[i].null_count = 0; outs[i].type = cols[i].type; }
         return 0;
@@ -336,6 +372,14 @@ static int interp_fill_impl(const bowgpu_col *cols, int32_t ncols, int32_t ts_co
     if (P.fast32 || P.wide32) interp_magic32(job.plan.interval, &P.m32, &P.sh1_32, &P.sh2_32);
     P.ts_col = ts_col;
     P.n_out = n_out;
+    if (look) {
+        void *st;
+        const int64_t ntrips = (n + 511) / 512;
+        BG_TRY(ctx_pool(c, kPoolInterp + 0, (size_t)ntrips * 8 + 64, &st));
+        BG_HIP(hipMemsetAsync(st, 0, (size_t)ntrips * 8, c->stream));
+        P.look_state = reinterpret_cast<uint64_t *>(st);
+        P.total_out = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(dscr) + 512);
+    }
     {   // one word per 512-row trip and column of a launch (at most kMaxCols columns per launch)
         void *ew;
         BG_TRY(ctx_pool(c, kPoolInterpEdge, (size_t)((n + 511) / 512) * kMaxCols * 8 + 64, &ew));
@@ -349,6 +393,7 @@ static int interp_fill_impl(const bowgpu_col *cols, int32_t ncols, int32_t ts_co
     }
     std::vector<uint64_t> hcnt(ninterps, 0);
     uint32_t hstat[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int64_t look_total = 0;
     unsigned long long *dcnt = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(dscr) + 1024);
     // The output positions depend on the interval column alone, so the columns go through the kernel kMaxCols at a time (a Bow
     // of any width: interpolation.go:98-161 loops over the interpolators).  Per batch: ONE launch zeroes the batch's bitmaps (and,
@@ -390,18 +435,32 @@ static int interp_fill_impl(const bowgpu_col *cols, int32_t ncols, int32_t ts_co
             BG_HIP(hipMemcpyAsync(&hcnt[b0], dcnt, 8 * (size_t)nb, hipMemcpyDeviceToHost, c->stream));
         }
         BG_HIP(hipMemcpyAsync(hstat, P.status, sizeof hstat, hipMemcpyDeviceToHost, c->stream));
+        if (P.look_state) BG_HIP(hipMemcpyAsync(&look_total, P.total_out, 8, hipMemcpyDeviceToHost, c->stream));
         BG_HIP(hipStreamSynchronize(c->stream));
         return 0;
     };
     BG_TRY(run_all(1));
+    if (look && !hstat[0] && !hstat[5]) {
+        // the rows the call produced; a trip that would have passed the end of the caller's buffers stored nothing and said so
+        if (hstat[6] || look_total > n_out)
+            return fail(BOWGPU_ERR_ARG, "output column has %lld slots, %lld needed (bowgpu_rolling_interpolate_count gives the number)",
+                        (long long)n_out, (long long)look_total);
+        n_out = look_total;
+        hstat[6] = 0;
+    }
     // (a reused count whose column has changed since: interp_wave3_kernel stored nothing for the trips that did not fit and said
     // so; the kernels a redo would use do not check, so the error comes first)
     if (hstat[6]) return fail(BOWGPU_ERR_ARG, "Interpolate: the rows produced do not add up to the count - the interval column changed between "
                                               "bowgpu_rolling_interpolate_count and _fill (include/bowgpu.h: the contract between the two calls)");
-    if (hstat[5] && job.from_cache) {
-        // the redo runs kernels that trust pass 1 blindly: make pass 1 this call's own before handing it to them
+    if (hstat[5] && (job.from_cache || onepass)) {
+        // the redo runs a kernel that trusts pass 1 blindly (and needs one): make pass 1 this call's own before handing it over
         InterpJob fresh;
         BG_TRY(interp_prepare(c, cols, ncols, ts_col, interval, &o, &fresh, global_s0, edge, false));
+        if (look) {
+            if (n + fresh.M > n_out) return fail(BOWGPU_ERR_ARG, "output column has %lld slots, %lld needed", (long long)n_out, (long long)(n + fresh.M));
+            n_out = n + fresh.M;
+            P.n_out = n_out; P.look_state = nullptr;
+        }
         if (n + fresh.M != n_out) return fail(BOWGPU_ERR_ARG, "Interpolate: the interval column changed between bowgpu_rolling_interpolate_count and _fill");
         P.tile_exact_before = reinterpret_cast<const int64_t *>(fresh.tile_before);
         P.kq = fresh.kq; P.kq_empty = fresh.kq_empty; P.drop = fresh.drop; P.e0 = fresh.e0;

@@ -108,6 +108,50 @@ def test_interpolate_random_vs_oracle(vtype):
                 cmp_out("val %s n=%d prev=%s" % (kind, n, prev is not None), got[1], want[1])
 
 
+@pytest.mark.parametrize("vtype", ["f64", "i64"])
+def test_interpolate_in_one_pass_without_a_count(vtype):
+    """bowgpu_rolling_interpolate_fill on its own (round 4): no count pass - the fill kernel checks the order of the interval column
+    itself and, for exclusive windows, a trip learns the exact heads of the trips before it by decoupled look-back; the caller sizes the
+    buffers (rows + windows at most), the call sets their length.  Equal to the oracle and to count + fill, bit for bit; a buffer that
+    is too small is an error that names the size, never a write past its end; an unsorted column is declined."""
+    rng = np.random.default_rng(2604)
+    typ = capi.FLOAT64 if vtype == "f64" else capi.INT64
+    shapes = [(1, 5, 0), (700, 3, 1), (5000, 10, 0), (60_000, 100, 7), (60_000, 7, 0), (300_000, 4, 0), (300_000, 1000, 13)]
+    for n, interval, offset in shapes:
+        ts = np.cumsum(rng.integers(0, 20, n)).astype(np.int64) + 500
+        if n > 1000:
+            ts[n // 2:] += 1_000_000          # a long run of empty windows in the middle
+            ts[n // 3: n // 3 + 2000] = ts[n // 3] - (ts[n // 3] % interval) + offset % interval   # rows sitting exactly on a window start, duplicated
+            ts = np.sort(ts)
+        vals = np.round(rng.standard_normal(n) * 100, 2) if vtype == "f64" else rng.integers(-1000, 1000, n).astype(np.int64)
+        bm = np.packbits(rng.random(n) >= 0.3, bitorder="little")
+        for kind in ("Linear", "StepPrevious"):
+            ip = [{"kind": "WindowStart", "col": 0}, {"kind": kind, "col": 1}]
+            for inclusive in (False, True):
+                cols = [capi.Column(ts), capi.Column(vals, bm, typ, 0, n, -1)]
+                want = orc.interpolate([orc.Column(ts, None, orc.INT64), orc.Column(vals, bm, typ)], 0, interval, ip, offset=offset, inclusive=inclusive)
+                for res in (capi.HOST, capi.DEVICE):
+                    got = capi.rolling_interpolate_onepass(cols, 0, interval, ip, offset=offset, inclusive=inclusive, out_residency=res)
+                    cmp_out("one pass ts %s n=%d I=%d incl=%s" % (kind, n, interval, inclusive), got[0], want[0])
+                    cmp_out("one pass val %s n=%d I=%d incl=%s" % (kind, n, interval, inclusive), got[1], want[1])
+                # buffers of exactly the right size, and one slot short
+                exact = capi.rolling_interpolate_onepass(cols, 0, interval, ip, offset=offset, inclusive=inclusive, capacity=want[0].length)
+                cmp_out("one pass exact capacity", exact[1], want[1])
+                if want[0].length > n:
+                    with pytest.raises(capi.BowGpuError) as e:
+                        capi.rolling_interpolate_onepass(cols, 0, interval, ip, offset=offset, inclusive=inclusive, capacity=want[0].length - 1)
+                    assert e.value.code == -10 and str(want[0].length) in e.value.message, e.value.message
+    # not ascending: declined by the fill kernel's own check (there is no count pass to notice)
+    ts = np.arange(100_000, dtype=np.int64) * 3
+    ts[77_777] = 5
+    vals = rng.standard_normal(100_000)
+    for inclusive in (False, True):
+        with pytest.raises(capi.BowGpuError) as e:
+            capi.rolling_interpolate_onepass([capi.Column(ts), capi.Column(vals, None, capi.FLOAT64)], 0, 10,
+                                             [{"kind": "WindowStart", "col": 0}, {"kind": "Linear", "col": 1}], inclusive=inclusive)
+        assert e.value.code == -14
+
+
 @pytest.mark.parametrize("base_ts", [0, 1_700_000_000_000, -(1 << 40), (1 << 52)])
 def test_interpolate_frames_spanning_more_than_2_31(base_ts):
     """millisecond / microsecond timestamps: the frame spans far more than 2^31 from its first window start (round 2's wave kernels
