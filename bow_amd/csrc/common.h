@@ -368,11 +368,6 @@ struct InterpParams {
     int32_t inclusive, e0;             // Options.Inclusive (interp_wave2 / wave3 kernels only); e0: row 0 sits exactly on the first window's start
     int64_t n_out;                     // rows the call is to produce (n + what the count pass found): interp_wave3_kernel's last trip checks that it ends there
     uint64_t *edge_words;              // interp_wave3_kernel: [ncols][trips of 512 rows] - a trip's bits of the bitmap word it shares with the trip before it
-    // One-pass Interpolate (no count pass: bowgpu_rolling_interpolate_fill on its own): one word per trip of interp_wave3_kernel's decoupled
-    // look-back - flag << 62 (1: this trip's exact heads, 2: those of every trip up to and including it) | count - zeroed by the host;
-    // nullptr: tile_exact_before holds the prefix.  total_out[0] = rows the call produced (written by the last trip).
-    uint64_t *look_state;
-    int64_t *total_out;
     InterpCol cols[kMaxCols];
 };
 int64_t interp_tiles(int64_t n);

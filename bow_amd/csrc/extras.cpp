@@ -268,15 +268,17 @@ static int interp_prepare(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t
     return 0;
 }
 
-// Rolling.Interpolate as ONE pass over the rows (a _fill that does not follow its _count): no count pass - the order of the interval
-// column is checked by the fill kernel itself and, for exclusive windows, the exact heads of the earlier trips reach a trip by
-// decoupled look-back (interpolate.hip trip_lookback); inclusive windows need no such count at all (n_out = n + W - e0).  Taken for
-// the shapes interp_wave3_kernel serves on its own: the whole frame (no shard), no -1 sentinel window, no rows below s0.
-// *applies = false: the two-pass path (interp_prepare) takes the call.
+// Rolling.Interpolate on INCLUSIVE windows as ONE pass over the rows (a _fill that does not follow its _count): every window then
+// contributes exactly one row in front of its first - n_out = n + W - e0, and a trip's output position depends on nothing a count
+// pass would tell - so there is no count pass; the fill kernel checks the order of the interval column itself.  (Exclusive windows
+// need the number of rows sitting exactly on a window start before each trip.  A decoupled look-back inside the fill kernel was
+// built and measured in round 4: 1.67 ms against 1.12 ms for count pass + fill at 1e8 rows - an uncached word per trip each way
+// costs more than the 0.16 ms count pass it replaces; not kept.)  Taken for the shapes interp_wave3_kernel serves on its own: the
+// whole frame (no shard), no -1 sentinel window, no rows below s0.  *applies = false: the two-pass path (interp_prepare).
 static int interp_onepass_prepare(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval, const bowgpu_options *o,
                                   InterpJob *job, bool *applies) {
     *applies = false;
-    if (route_mask() & BOWGPU_ROUTE_INTERP_TILE) return 0;
+    if (!o->inclusive) return 0;
     const int64_t n = cols[ts_col].length;
     if (n <= 0) return 0;
     for (int i = 0; i < ncols; i++)
@@ -289,7 +291,7 @@ static int interp_onepass_prepare(Ctx *c, const bowgpu_col *cols, int32_t ncols,
     BG_TRY(ts_device(c, &cols[ts_col], &job->dts));
     job->kq = -1; job->drop = 0; job->kq_empty = 0; job->has_left = 0; job->wbase = 0;
     job->e0 = (o->inclusive && pl.first_ts == pl.s0) ? 1 : 0;
-    job->M = o->inclusive ? pl.W - job->e0 : 0;   // (exclusive windows: known when the kernel has run)
+    job->M = pl.W - job->e0;
     c->interp_cache.valid = false;
     *applies = true;
     return 0;
@@ -340,14 +342,7 @@ static int interp_fill_impl(const bowgpu_col *cols, int32_t ncols, int32_t ts_co
     bool onepass = false;
     if (!cached && !global_s0 && !edge) BG_TRY(interp_onepass_prepare(c, cols, ncols, ts_col, interval, &o, &job, &onepass));
     if (!onepass) BG_TRY(interp_prepare(c, cols, ncols, ts_col, interval, &o, &job, global_s0, edge, true));
-    const bool look = onepass && !o.inclusive;   // exclusive windows in one pass: the row count comes out of the kernel
-    int64_t n_out = n + job.M;
-    if (look) {   // ... and until then the caller's buffers bound what it may write (bowgpu_out.length in: capacity)
-        n_out = outs[0].length;
-        for (int i = 1; i < ninterps; i++) n_out = outs[i].length < n_out ? outs[i].length : n_out;
-        if (n_out < n) return fail(BOWGPU_ERR_ARG, "output column has %lld slots, at least %lld needed", (long long)n_out, (long long)n);
-        if (n_out > n + job.plan.W) n_out = n + job.plan.W;   // (no call adds more than one row per window)
-    }
+    const int64_t n_out = n + job.M;
     if (n_out == 0) {
         for (int i = 0; i < ninterps; i++) { outs[i].length = 0; outs[i].null_count = 0; outs[i].type = cols[i].type; }
         return 0;
@@ -372,19 +367,6 @@ static int interp_fill_impl(const bowgpu_col *cols, int32_t ncols, int32_t ts_co
     if (P.fast32 || P.wide32) interp_magic32(job.plan.interval, &P.m32, &P.sh1_32, &P.sh2_32);
     P.ts_col = ts_col;
     P.n_out = n_out;
-    if (look) {
-        void *st;
-        const int64_t ntrips = (n + 511) / 512;
-        BG_TRY(ctx_pool(c, kPoolInterp + 0, (size_t)ntrips * 8 + 64, &st));
-        BG_HIP(hipMemsetAsync(st, 0, (size_t)ntrips * 8, c->stream));
-        P.look_state = reinterpret_cast<uint64_t *>(st);
-        P.total_out = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(dscr) + 512);
-    }
-    {   // one word per 512-row trip and column of a launch (at most kMaxCols columns per launch)
-        void *ew;
-        BG_TRY(ctx_pool(c, kPoolInterpEdge, (size_t)((n + 511) / 512) * kMaxCols * 8 + 64, &ew));
-        P.edge_words = reinterpret_cast<uint64_t *>(ew);
-    }
     for (int i = 0; i < ncols; i++) {
         DevCol &dc = job.dcols[i];
         if (i == ts_col) { dc.values = job.dts.values; dc.length = n; dc.type = BOWGPU_INT64; }
@@ -393,7 +375,6 @@ static int interp_fill_impl(const bowgpu_col *cols, int32_t ncols, int32_t ts_co
     }
     std::vector<uint64_t> hcnt(ninterps, 0);
     uint32_t hstat[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int64_t look_total = 0;
     unsigned long long *dcnt = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(dscr) + 1024);
     // The output positions depend on the interval column alone, so the columns go through the kernel kMaxCols at a time (a Bow
     // of any width: interpolation.go:98-161 loops over the interpolators).  Per batch: ONE launch zeroes the batch's bitmaps (and,
@@ -435,19 +416,10 @@ static int interp_fill_impl(const bowgpu_col *cols, int32_t ncols, int32_t ts_co
             BG_HIP(hipMemcpyAsync(&hcnt[b0], dcnt, 8 * (size_t)nb, hipMemcpyDeviceToHost, c->stream));
         }
         BG_HIP(hipMemcpyAsync(hstat, P.status, sizeof hstat, hipMemcpyDeviceToHost, c->stream));
-        if (P.look_state) BG_HIP(hipMemcpyAsync(&look_total, P.total_out, 8, hipMemcpyDeviceToHost, c->stream));
         BG_HIP(hipStreamSynchronize(c->stream));
         return 0;
     };
     BG_TRY(run_all(1));
-    if (look && !hstat[0] && !hstat[5]) {
-        // the rows the call produced; a trip that would have passed the end of the caller's buffers stored nothing and said so
-        if (hstat[6] || look_total > n_out)
-            return fail(BOWGPU_ERR_ARG, "output column has %lld slots, %lld needed (bowgpu_rolling_interpolate_count gives the number)",
-                        (long long)n_out, (long long)look_total);
-        n_out = look_total;
-        hstat[6] = 0;
-    }
     // (a reused count whose column has changed since: interp_wave3_kernel stored nothing for the trips that did not fit and said
     // so; the kernels a redo would use do not check, so the error comes first)
     if (hstat[6]) return fail(BOWGPU_ERR_ARG, "Interpolate: the rows produced do not add up to the count - the interval column changed between "
@@ -456,11 +428,6 @@ static int interp_fill_impl(const bowgpu_col *cols, int32_t ncols, int32_t ts_co
         // the redo runs a kernel that trusts pass 1 blindly (and needs one): make pass 1 this call's own before handing it over
         InterpJob fresh;
         BG_TRY(interp_prepare(c, cols, ncols, ts_col, interval, &o, &fresh, global_s0, edge, false));
-        if (look) {
-            if (n + fresh.M > n_out) return fail(BOWGPU_ERR_ARG, "output column has %lld slots, %lld needed", (long long)n_out, (long long)(n + fresh.M));
-            n_out = n + fresh.M;
-            P.n_out = n_out; P.look_state = nullptr;
-        }
         if (n + fresh.M != n_out) return fail(BOWGPU_ERR_ARG, "Interpolate: the interval column changed between bowgpu_rolling_interpolate_count and _fill");
         P.tile_exact_before = reinterpret_cast<const int64_t *>(fresh.tile_before);
         P.kq = fresh.kq; P.kq_empty = fresh.kq_empty; P.drop = fresh.drop; P.e0 = fresh.e0;

@@ -428,38 +428,6 @@ constexpr int kT3Ch = kT3Rows / 128;
 constexpr int kT3Stage = kT3Rows + kT3Rows / 2;   // outputs staged per trip and column (the rows + up to half as many synthetic rows)
 constexpr int kT3Slots = kT3Stage + 32;       // ... + the bit offset of the trip's first output inside its bitmap word
 
-// Decoupled look-back over the trips of interp_wave3_kernel<.., kLook = true> (one-pass Interpolate): the output position of a trip
-// needs the number of rows that sit exactly on a window start ("exact heads") in all rows before it - the one thing about earlier
-// trips it cannot compute itself.  Trips are numbered by workgroup id there (dispatch order: the smallest unfinished trip is always
-// running, so nobody waits for a trip that has not started), each publishes its own count as soon as its timestamps are in, then
-// sums its predecessors' 64 at a time until it meets one that already knows its inclusive prefix, and publishes its own.
-__device__ __forceinline__ int64_t trip_lookback(uint64_t *state, int64_t trip, uint32_t own, int lane) {
-    constexpr uint64_t kVal = (1ull << 62) - 1ull;
-    if (trip == 0) {
-        if (lane == 0) __hip_atomic_store(&state[0], (2ull << 62) | (uint64_t)own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return 0;
-    }
-    if (lane == 0) __hip_atomic_store(&state[trip], (1ull << 62) | (uint64_t)own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    uint64_t excl = 0;
-    int64_t idx = trip - 1;
-    for (;;) {
-        const int64_t j = idx - lane;
-        const uint64_t st = j >= 0 ? __hip_atomic_load(&state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2ull << 62);   // (nothing lies before trip 0)
-        const uint32_t flag = (uint32_t)(st >> 62);
-        const unsigned long long m2 = __ballot(flag == 2u), m0 = __ballot(flag == 0u);
-        const int first2 = m2 ? __builtin_ctzll(m2) : 64;
-        const unsigned long long need = first2 < 63 ? ((2ull << first2) - 1ull) : ~0ull;   // lanes 0 .. first2: the predecessors to add up
-        if (m0 & need) { __builtin_amdgcn_s_sleep(1); continue; }   // one of them has not published yet
-        uint64_t v = lane <= first2 ? (st & kVal) : 0ull;
-        for (int o = 32; o > 0; o >>= 1) v += (uint64_t)__shfl_xor((unsigned long long)v, o);
-        excl += v;
-        if (first2 < 64) break;
-        idx -= 64;
-    }
-    if (lane == 0) __hip_atomic_store(&state[trip], (2ull << 62) | ((excl + (uint64_t)own) & kVal), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return (int64_t)excl;
-}
-
 template <int kRuns>
 struct Wave3Lds {
     alignas(16) uint64_t val[kT3Slots];       // staged outputs
@@ -471,10 +439,8 @@ struct Wave3Lds {
     uint64_t vw[2 * kT3Ch];                   // the current column's validity bits of the trip's rows: row r = bit r & 63 of word r >> 6
 };
 
-// kLook: exclusive windows without a count pass - the exact heads of the earlier trips by look-back (trip_lookback above)
-template <bool kIncl, bool kLook>
+template <bool kIncl>
 __global__ __launch_bounds__(64, 4) void interp_wave3_kernel(const InterpParams p, const int64_t ntrips, const int64_t trips_per_xcd) {
-    static_assert(!(kIncl && kLook), "inclusive windows need no count of exact heads at all");
     constexpr int kRuns = kIncl ? kT3Rows : kT3Rows / 4;
     __shared__ Wave3Lds<kRuns> L;
     const int lane = threadIdx.x;
@@ -483,8 +449,7 @@ __global__ __launch_bounds__(64, 4) void interp_wave3_kernel(const InterpParams 
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last) :: "memory");
 #endif
     const int64_t b = blockIdx.x;
-    // XCD-contiguous runs of trips: the rows around a trip's ends are in that XCD's L2 (kLook: dispatch order instead - see trip_lookback)
-    const int64_t trip = kLook ? b : (b & 7) * trips_per_xcd + (b >> 3);
+    const int64_t trip = (b & 7) * trips_per_xcd + (b >> 3);   // XCD-contiguous runs of trips: the rows around a trip's ends are in that XCD's L2
     if (trip >= ntrips) return;
     const int64_t base = trip * kT3Rows;
     const int64_t left_trip = p.n - base;
@@ -532,17 +497,16 @@ __global__ __launch_bounds__(64, 4) void interp_wave3_kernel(const InterpParams 
         gap0 = w0 - wp;
         toolong |= t_before > ts_first || gap0 >= 0x3FFFFFull;
         // inclusive windows: one extra row in front of every window's first row (synthetic or the copy), but none for an exact row 0
-        // (tile_exact_before holds one entry per 256 rows; kLook: the exact heads before the trip are subtracted after phase 1)
-        if (base > 0) o_trip = kIncl ? base + (int64_t)wp + 1 - p.wbase - p.e0
-                               : base + (int64_t)wp + 1 - p.wbase - (kLook ? 0 : p.tile_exact_before[trip * (kT3Rows / 256)]);
+        // (tile_exact_before holds one entry per 256 rows)
+        if (base > 0) o_trip = kIncl ? base + (int64_t)wp + 1 - p.wbase - p.e0 : base + (int64_t)wp + 1 - p.wbase - p.tile_exact_before[trip * (kT3Rows / 256)];
     }
     if (lane < p.ncols) p.edge_words[(int64_t)lane * ntrips + trip] = 0ull;   // (no entry unless a staged flush below leaves one)
 
     // ---- phase 1: output positions (relative to o_trip) of the lane's rows, the run list; the timestamps stay as 32-bit offsets
     uint32_t rr0[kT3Ch], rr1[kT3Ch];
-    uint32_t tot = 0, nexact = 0;
+    uint32_t tot = 0;
     int nrun = 0;
-    bool unsorted = false;   // (the count pass checks the order too; a fill on its own has only this check)
+    bool unsorted = false;   // (the count pass checks the order too; an inclusive fill on its own - no count pass - has only this check)
     {
         uint32_t rb_prev = 0;
         uint64_t tb_prev = (uint64_t)t_before;
@@ -570,7 +534,6 @@ __global__ __launch_bounds__(64, 4) void interp_wave3_kernel(const InterpParams 
             if (k == 0 && lane == 0) wl = 0u - (uint32_t)gap0;
             const bool head0 = in0 && (first || wa != wl), head1 = in1 && wb != wa;
             const bool exact0 = head0 && ra == wa * i32, exact1 = head1 && rb == wb * i32;
-            if (kLook) nexact += (uint32_t)(__popcll(__ballot(exact0)) + __popcll(__ballot(exact1)));
             // rows in front of a head: the empty windows before it + a synthetic row for its own window - or, when the row sits on
             // its window's start, nothing (exclusive windows) / the copy of itself that closes the window before (inclusive ones)
             const uint32_t sy0 = head0 ? ((first ? 0u : wa - wl - 1u) + (exact0 ? ((kIncl && !first) ? 1u : 0u) : 1u)) : 0u;
@@ -608,12 +571,6 @@ __global__ __launch_bounds__(64, 4) void interp_wave3_kernel(const InterpParams 
             }
         }
     }
-    // (kLook: before anything can end this trip - every trip publishes, or its successors would wait for ever)
-    if (kLook) {
-        const int64_t before = trip_lookback(p.look_state, trip, nexact, lane);
-        if (base > 0) o_trip -= before;
-        if (trip == ntrips - 1 && lane == 0) p.total_out[0] = o_trip + (int64_t)tot;
-    }
     const uint32_t sh_o = (uint32_t)(o_trip & 31);   // stage slot of the trip's first output = its bit inside its bitmap word
     if (__ballot(unsorted)) {   // the call fails with BOWGPU_ERR_TS_UNSORTED
         if (lane == 0 && !__hip_atomic_load(&p.status[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(&p.status[0], 1u);
@@ -629,8 +586,7 @@ __global__ __launch_bounds__(64, 4) void interp_wave3_kernel(const InterpParams 
     // The last trip ends where the count pass said the outputs end, and every trip lies inside the outputs - or the interval
     // column is not the one that was counted (a _fill that reuses its _count's prefix: include/bowgpu.h, the contract between the
     // two calls).  Such a trip stores NOTHING: a stale prefix must not become a write outside the caller's buffers.
-    // (kLook: n_out is the capacity of the caller's buffers; a trip beyond it stores nothing either and the call reports how many rows it needs)
-    if (o_trip < 0 || o_trip + (int64_t)tot > p.n_out || (!kLook && trip == ntrips - 1 && o_trip + (int64_t)tot != p.n_out)) {
+    if (o_trip < 0 || o_trip + (int64_t)tot > p.n_out || (trip == ntrips - 1 && o_trip + (int64_t)tot != p.n_out)) {
         if (lane == 0 && !__hip_atomic_load(&p.status[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(&p.status[6], 1u);
         return;
     }
@@ -999,9 +955,8 @@ int launch_interp_tiles(Ctx *c, const InterpParams &p) {
         const int64_t ntrips = (p.n + kT3Rows - 1) / kT3Rows, per_xcd = (ntrips + 7) / 8;
         if (per_xcd * 8 > 0x7FFFFFFFll) return fail(BOWGPU_ERR_UNSUPPORTED, "too many rows for one launch: %lld", (long long)p.n);
         if (!p.edge_words) return fail(BOWGPU_ERR_ARG, "internal: interp_wave3_kernel needs its edge list");
-        if (p.inclusive) hipLaunchKernelGGL((interp_wave3_kernel<true, false>), dim3((unsigned)(per_xcd * 8)), dim3(64), 0, c->stream, p, ntrips, per_xcd);
-        else if (p.look_state) hipLaunchKernelGGL((interp_wave3_kernel<false, true>), dim3((unsigned)ntrips), dim3(64), 0, c->stream, p, ntrips, per_xcd);
-        else hipLaunchKernelGGL((interp_wave3_kernel<false, false>), dim3((unsigned)(per_xcd * 8)), dim3(64), 0, c->stream, p, ntrips, per_xcd);
+        if (p.inclusive) hipLaunchKernelGGL((interp_wave3_kernel<true>), dim3((unsigned)(per_xcd * 8)), dim3(64), 0, c->stream, p, ntrips, per_xcd);
+        else hipLaunchKernelGGL((interp_wave3_kernel<false>), dim3((unsigned)(per_xcd * 8)), dim3(64), 0, c->stream, p, ntrips, per_xcd);
         hipLaunchKernelGGL(interp_edge_fix_kernel, dim3((unsigned)((ntrips * p.ncols + 255) / 256)), dim3(256), 0, c->stream, p, ntrips);
     }
     else if (p.inclusive)   // no other kernel builds inclusive windows: never fall through to an exclusive one

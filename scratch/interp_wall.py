@@ -34,6 +34,6 @@ for label, mask in (("wave3 (default)", 0), ("tile", capi.ROUTE_INTERP_TILE)):
     capi.set_route(mask)
     both = timeit(lambda: (count(), fill()))
     c_ms = timeit(count)
-    f_alone = timeit(fill)              # no _count in front: one pass over the rows (look-back inside the fill kernel); the tile route makes its own count pass
-    print("%-32s %d -> %d rows: count %.3f ms, count+fill %.3f ms (%.1f G rows/s), ONE PASS (fill on its own, no count pass) %.3f ms" %
+    f_alone = timeit(fill)              # no _count in front: the fill call makes its own pass 1
+    print("%-32s %d -> %d rows: count %.3f ms, count+fill %.3f ms (%.1f G rows/s), fill on its own (its own count pass inside) %.3f ms" %
           (label, n, n_out, c_ms, both, n / both / 1e6, f_alone))

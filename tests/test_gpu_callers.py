@@ -110,17 +110,18 @@ def test_interpolate_random_vs_oracle(vtype):
 
 @pytest.mark.parametrize("vtype", ["f64", "i64"])
 def test_interpolate_in_one_pass_without_a_count(vtype):
-    """bowgpu_rolling_interpolate_fill on its own (round 4): no count pass - the fill kernel checks the order of the interval column
-    itself and, for exclusive windows, a trip learns the exact heads of the trips before it by decoupled look-back; the caller sizes the
-    buffers (rows + windows at most), the call sets their length.  Equal to the oracle and to count + fill, bit for bit; a buffer that
-    is too small is an error that names the size, never a write past its end; an unsorted column is declined."""
+    """bowgpu_rolling_interpolate_fill on its own, without a preceding _count: the caller sizes the buffers (rows + windows at most), the
+    call sets their length.  Inclusive windows take ONE pass over the rows (n_out = n + W - e0 needs no count; the fill kernel checks
+    the order of the interval column itself); exclusive windows make their own count pass first (a look-back inside the fill kernel
+    was measured slower: extras.cpp).  Equal to the oracle bit for bit; a buffer that is too small is an error that names the
+    size, never a write past its end; an unsorted column is declined."""
     rng = np.random.default_rng(2604)
     typ = capi.FLOAT64 if vtype == "f64" else capi.INT64
     shapes = [(1, 5, 0), (700, 3, 1), (5000, 10, 0), (60_000, 100, 7), (60_000, 7, 0), (300_000, 4, 0), (300_000, 1000, 13)]
     for n, interval, offset in shapes:
         ts = np.cumsum(rng.integers(0, 20, n)).astype(np.int64) + 500
         if n > 1000:
-            ts[n // 2:] += 1_000_000          # a long run of empty windows in the middle
+            ts[n // 2:] += 20_000 * interval  # a long run of empty windows in the middle
             ts[n // 3: n // 3 + 2000] = ts[n // 3] - (ts[n // 3] % interval) + offset % interval   # rows sitting exactly on a window start, duplicated
             ts = np.sort(ts)
         vals = np.round(rng.standard_normal(n) * 100, 2) if vtype == "f64" else rng.integers(-1000, 1000, n).astype(np.int64)
