@@ -367,6 +367,11 @@ static int interp_fill_impl(const bowgpu_col *cols, int32_t ncols, int32_t ts_co
     if (P.fast32 || P.wide32) interp_magic32(job.plan.interval, &P.m32, &P.sh1_32, &P.sh2_32);
     P.ts_col = ts_col;
     P.n_out = n_out;
+    {   // one word per 512-row trip and column of a launch (at most kMaxCols columns per launch)
+        void *ew;
+        BG_TRY(ctx_pool(c, kPoolInterpEdge, (size_t)((n + 511) / 512) * kMaxCols * 8 + 64, &ew));
+        P.edge_words = reinterpret_cast<uint64_t *>(ew);
+    }
     for (int i = 0; i < ncols; i++) {
         DevCol &dc = job.dcols[i];
         if (i == ts_col) { dc.values = job.dts.values; dc.length = n; dc.type = BOWGPU_INT64; }
