@@ -275,6 +275,7 @@ __device__ __forceinline__ void walk_values(const uint64_t *val, int fv, int lv,
 // instead - sums, then extrema over NaN-filled nulls with walk_values - which costs a second pass over the windows but 5 instead of
 // 11 instructions per row.
 constexpr int kTwoWalksMaxHeads = 24;   // (640 rows / 24: windows of ~27 rows and more)
+constexpr int kWalkAllMaxHeads = 48;    // rolling_tw.hip: tiles with more heads (windows of < ~13 rows) walk every reducer in one pass
 __device__ __forceinline__ void walk_values_pred(const uint64_t *val, const uint32_t *vbits, int fv, int lv, double &sum, double &mn, double &mx) {
     const double seed = __longlong_as_double((long long)val[fv]);
     sum = 0.0; mn = seed; mx = seed;

@@ -97,7 +97,7 @@ __device__ __forceinline__ void lds_order() {
 // than 2^32 from slot 0); kTs32: times as 32-bit offsets from slot 0 (above)
 // kBoth: the call has step AND trapezoid integrals: the terms of the second kind wait in registers while the first kind is walked
 template <bool kNulls, bool kWide, bool kTs32, bool kBoth>
-__global__ __launch_bounds__(kWave, 4) void rolling_tw_kernel(const SimpleParams p, const int64_t ntiles, const int64_t tiles_per_xcd) {
+__global__ __launch_bounds__(kWave, (!kNulls && kTs32) ? 5 : 4) void rolling_tw_kernel(const SimpleParams p, const int64_t ntiles, const int64_t tiles_per_xcd) {
     static_assert(!(kWide && kTs32), "the wide form keeps 64-bit timestamps");
     __shared__ TwShared<kNulls, kTs32> sh;
     constexpr int kSegCapT = TwCap<kNulls, kTs32>::value;
@@ -446,12 +446,18 @@ __global__ __launch_bounds__(kWave, 4) void rolling_tw_kernel(const SimpleParams
         // ---- phases, each one walk over what sh.val holds:
         //   0 / 1 / 2  the staged values (rolling_simple.hip: 1 + 2 when a nullable column feeds sums AND extrema), every output that
         //              is not an integral; 3  the step terms; 4  the trapezoid terms
-        const bool two_phase = kNulls && need_mm && need_sum && nseg_total <= kTwoWalksMaxHeads;
+        // A tile of many SHORT windows (more than kWalkAllMaxHeads heads in its 640 rows: windows of fewer than ~13 rows) whose column
+        // needs more than one walk - values next to integrals, both kinds of integral, or nulls (the term pass gathers) - is served
+        // by ONE walk that does everything per row (walk_all below: the round-1 walk).  At that length the chain is short and a phase
+        // per kind costs more than it saves: 10-row windows, IntegralStep + IntegralTrapezoid + Mean 0.56 ms per 1e8 rows in phases
+        // against 0.37 in one walk; from ~16 rows on the phases win and keep winning (64-row windows with nulls: 0.59 against 1.04 ms).
+        const bool walk_all = !early && nseg_total > kWalkAllMaxHeads && (need_step || need_trap);
+        const bool two_phase = !walk_all && kNulls && need_mm && need_sum && nseg_total <= kTwoWalksMaxHeads;
         const bool pred_walk = kNulls && need_mm && need_sum && !two_phase;   // one walk, extrema under the validity bit (agg_device.h)
-        for (int phase = two_phase ? 1 : 0; phase <= 4; phase++) {
+        for (int phase = two_phase ? 1 : 0; phase <= (walk_all ? 0 : 4); phase++) {
             if (phase == 1 && !two_phase) continue;
             if (phase == 2 && !two_phase) continue;
-            if (phase == 0 && (two_phase || (!need_vals && (need_step || need_trap)))) continue;   // (no value reducer: the first integral phase also writes WindowStart / Count / NumRows)
+            if (phase == 0 && !walk_all && (two_phase || (!need_vals && (need_step || need_trap)))) continue;   // (no value reducer: the first integral phase also writes WindowStart / Count / NumRows)
             if (phase == 3 && !need_step) continue;
             if (phase == 4 && !need_trap) continue;
             if (phase == 2) {
@@ -486,6 +492,7 @@ __global__ __launch_bounds__(kWave, 4) void rolling_tw_kernel(const SimpleParams
                 out_mask = phase == 0 ? (p.kind_mask[0] | p.kind_mask[1]) : phase == 1 ? p.kind_mask[0] : phase == 2 ? p.kind_mask[1]
                            : phase == 3 ? p.kind_mask[2] : p.kind_mask[3];
                 if (phase == ph1) out_mask |= others;
+                if (walk_all) out_mask = p.kind_mask[0] | p.kind_mask[1] | p.kind_mask[2] | p.kind_mask[3] | others;
                 out_mask &= p.col_mask[c];
             }
             const int phase1 = two_phase ? 1 : (need_vals || !(need_step || need_trap)) ? 0 : need_step ? 3 : 4;   // the first phase that runs
@@ -511,10 +518,46 @@ __global__ __launch_bounds__(kWave, 4) void rolling_tw_kernel(const SimpleParams
         if (kNulls) window_valid_rows(sh.vbits, r0, r1, count, fv, lv);
         if (dead) count = 0;
         const bool has_value = count > 0;
-        double sum = 0.0, mn = 0.0, mx = 0.0, integ = 0.0;
+        double sum = 0.0, mn = 0.0, mx = 0.0, integ = 0.0, integ_t = 0.0;
         uint64_t first_raw = 0, last_raw = 0;
         bool trap_nil = true;
-        if (phase <= 2) {
+        if (walk_all) {
+            // every reducer of the column in one walk over the window's valid rows, in row order (sum.go:16-22, minmax.go:16-28,
+            // integral.go:14-31 / :46-62), then the inclusive row for the trapezoid
+            if (has_value) {
+                first_raw = sh.val[fv];
+                double pt = 0.0, pv = 0.0, step = 0.0, trap = 0.0;
+                int cnt = 0;
+                for (int r = fv; r <= lv; r++) {
+                    if (kNulls && !((sh.vbits[r >> 5] >> (r & 31)) & 1u)) continue;
+                    const uint64_t raw = sh.val[r];
+                    const double x = __longlong_as_double((long long)raw), t = time_d((tkey_t)sh.tsx[r]);
+                    sum += x;
+                    if (cnt == 0) { mn = x; mx = x; }
+                    else {
+                        if (need_mm) { if (x < mn) mn = x; if (x > mx) mx = x; }
+                        const double dt = t - pt;
+                        if (need_trap) trap += (pv + x) / 2 * dt;
+                        if (need_step) step += pv * dt;
+                    }
+                    pt = t; pv = x; last_raw = raw;
+                    cnt++;
+                }
+                integ = step + pv * (last_value_d(wid) - abs_d(pt));
+                integ_t = trap;
+                if (incl_row && (!kNulls || ((sh.vbits[r1 >> 5] >> (r1 & 31)) & 1u))) {
+                    const double x = __longlong_as_double((long long)sh.val[r1]);
+                    integ_t = trap + (pv + x) / 2 * (time_d((tkey_t)sh.tsx[r1]) - pt);
+                    cnt++;
+                }
+                trap_nil = cnt < 2;
+                if (need_fl && cint) {
+                    const uint64_t *__restrict__ src = reinterpret_cast<const uint64_t *>(p.values[c]);
+                    first_raw = src[base + fv];
+                    last_raw = src[base + lv];
+                }
+            }
+        } else if (phase <= 2) {
             if (has_value && need_vals) {
                 first_raw = sh.val[fv];
                 if (kNulls && pred_walk) walk_values_pred(sh.val, sh.vbits, fv, lv, sum, mn, mx);
@@ -549,6 +592,7 @@ __global__ __launch_bounds__(kWave, 4) void rolling_tw_kernel(const SimpleParams
                     cnt++;
                 }
                 trap_nil = cnt < 2;
+                integ_t = integ;
             }
         } else if (phase == 4) {
             trap_nil = true;   // (no point of its own: at most the inclusive row - fewer than two points, integral.go:33-35)
@@ -590,7 +634,7 @@ __global__ __launch_bounds__(kWave, 4) void rolling_tw_kernel(const SimpleParams
             }
             case BOWGPU_AGG_INTEGRAL_TRAPEZOID:                                             // integral.go:11-37 (inclusive window)
             case BOWGPU_AGG_WAVG_LINEAR: {                                                  // weightedmean.go:25-33
-                double r = integ;
+                double r = integ_t;
                 if (k == BOWGPU_AGG_WAVG_LINEAR) r = r / (double)((win_start + p.interval) - win_start);
                 bits = (uint64_t)__double_as_longlong(r);
                 nil = trap_nil;
