@@ -44,6 +44,8 @@ constexpr int kChunksT = kRowsT / 128;
 // distance inside one tile stay on this kernel).  The kernel's rate follows its occupancy and that follows the LDS per wavefront
 // (1 KB steps), so the list is sized to the byte: 32-bit times 8 KB (20 wavefronts per CU): 240 heads = windows of >= 2.7 rows, 208
 // with nulls; 64-bit times 11 KB (14 per CU): 464 heads
+constexpr int64_t kShortAvgRows = 14;   // calls whose windows average fewer rows: rolling_tw_kernel<.., kShort = true>
+
 template <bool kNulls, bool kTs32>
 struct TwCap { static constexpr int value = kTs32 ? (kNulls ? 208 : 240) : 464; };
 
@@ -96,8 +98,10 @@ __device__ __forceinline__ void lds_order() {
 // kNulls: some column has nulls; kWide: see rolling_simple.hip (window ids relative to the tile's first window: rows may span more
 // than 2^32 from slot 0); kTs32: times as 32-bit offsets from slot 0 (above)
 // kBoth: the call has step AND trapezoid integrals: the terms of the second kind wait in registers while the first kind is walked
-template <bool kNulls, bool kWide, bool kTs32, bool kBoth>
-__global__ __launch_bounds__(kWave, (!kNulls && kTs32) ? 5 : 4) void rolling_tw_kernel(const SimpleParams p, const int64_t ntiles, const int64_t tiles_per_xcd) {
+// kShort: a call whose windows average fewer than kShortAvgRows rows - every tile takes the one-walk form (walk_all below), and the
+// term machinery is not even compiled in: its registers cost a wavefront per SIMD, which at that window length is what sets the rate
+template <bool kNulls, bool kWide, bool kTs32, bool kBoth, bool kShort>
+__global__ __launch_bounds__(kWave, (kShort || (!kNulls && kTs32 && !kBoth)) ? 5 : 4) void rolling_tw_kernel(const SimpleParams p, const int64_t ntiles, const int64_t tiles_per_xcd) {
     static_assert(!(kWide && kTs32), "the wide form keeps 64-bit timestamps");
     __shared__ TwShared<kNulls, kTs32> sh;
     constexpr int kSegCapT = TwCap<kNulls, kTs32>::value;
@@ -204,8 +208,9 @@ __global__ __launch_bounds__(kWave, (!kNulls && kTs32) ? 5 : 4) void rolling_tw_
     // The usual call - integrals only (next to WindowStart / Count / NumRows), first column without nulls: the terms of column 0 are
     // computed right here in the flag pass, where a row's timestamp, value, head flag and left neighbour are all in registers, and go
     // straight to LDS: no staging, no term pass, no value phase.
-    const bool early_terms = !kNulls && !need_vals;
-    double keep_a[kBoth ? kChunksT : 1], keep_b[kBoth ? kChunksT : 1];   // kBoth: the trapezoid terms wait here while the step terms are walked
+    const bool early_terms = !kShort && !kNulls && !need_vals;
+    constexpr bool kKeep = kBoth && !kShort;
+    double keep_a[kKeep ? kChunksT : 1], keep_b[kKeep ? kChunksT : 1];   // kBoth: the trapezoid terms wait here while the step terms are walked
     double early_carry_x = 0.0;
     const bool cint0 = p.col_is_int[0] != 0;
     int nseg_total = 0, nseg_owned = 0;
@@ -262,7 +267,7 @@ __global__ __launch_bounds__(kWave, (!kNulls && kTs32) ? 5 : 4) void rolling_tw_
             if (need_trap) { q1 = (xp + xa) / 2 * dta; q2 = (xa + xb) / 2 * dtb; }
             const double oa = need_step ? s1 : q1, ob = need_step ? s2 : q2;
             *reinterpret_cast<ulonglong2 *>(&sh.val[l]) = make_ulonglong2((uint64_t)__double_as_longlong(oa), (uint64_t)__double_as_longlong(ob));
-            if (kBoth) { keep_a[kBoth ? j : 0] = q1; keep_b[kBoth ? j : 0] = q2; }
+            if (kKeep) { keep_a[kKeep ? j : 0] = q1; keep_b[kKeep ? j : 0] = q2; }
         }
     }
     if (__ballot(unsorted)) {  // the call fails with BOWGPU_ERR_TS_UNSORTED
@@ -352,8 +357,11 @@ __global__ __launch_bounds__(kWave, (!kNulls && kTs32) ? 5 : 4) void rolling_tw_
         // previous point is the previous row: read before the chunk is written, the row in front of the NEXT chunk saved first);
         // after the whole pass for a nullable column (previous points are gathered from anywhere below).  kBoth: the trapezoid terms
         // wait in registers until the step terms have been walked.
-        double first_a[kNulls ? kChunksT : 1], first_b[kNulls ? kChunksT : 1];           // the first kind of a nullable column, until the pass is over
+        constexpr bool kFirst = kNulls && !kShort;
+        double first_a[kFirst ? kChunksT : 1], first_b[kFirst ? kChunksT : 1];           // the first kind of a nullable column, until the pass is over
         auto term_pass = [&]() __attribute__((always_inline)) {
+            if constexpr (kShort) return;
+            else {
             const bool first_is_step = need_step;
             double carry_x = 0.0;                   // staged value of row 128 j - 1, read before chunk j - 1 was overwritten
             // (the head flags and the tile's row count do not change from column to column and phase to phase: left visible, the compiler
@@ -427,10 +435,10 @@ __global__ __launch_bounds__(kWave, (!kNulls && kTs32) ? 5 : 4) void rolling_tw_
                         if (a_ok && has_p && (ha || same_a)) qa = (xp + xa) / 2 * dta;
                         if (b_ok && has_p2 && (hb || same_b)) qb = (xp2 + xb) / 2 * dtb;
                     }
-                    first_a[kNulls ? j : 0] = first_is_step ? sa : qa;
-                    first_b[kNulls ? j : 0] = first_is_step ? sb : qb;
+                    first_a[kFirst ? j : 0] = first_is_step ? sa : qa;
+                    first_b[kFirst ? j : 0] = first_is_step ? sb : qb;
                 }
-                if (kBoth) { keep_a[kBoth ? j : 0] = qa; keep_b[kBoth ? j : 0] = qb; }
+                if (kKeep) { keep_a[kKeep ? j : 0] = qa; keep_b[kKeep ? j : 0] = qb; }
                 // (one chunk at a time: left to itself the scheduler interleaves the five unrolled chunks to hide latencies, which costs
                 // more registers than the kernel has)
                 __builtin_amdgcn_sched_barrier(0);
@@ -440,7 +448,8 @@ __global__ __launch_bounds__(kWave, (!kNulls && kTs32) ? 5 : 4) void rolling_tw_
 #pragma unroll
                 for (int j = 0; j < kChunksT; j++)
                     *reinterpret_cast<ulonglong2 *>(&sh.val[j * 128 + 2 * lane]) = make_ulonglong2(
-                        (uint64_t)__double_as_longlong(first_a[kNulls ? j : 0]), (uint64_t)__double_as_longlong(first_b[kNulls ? j : 0]));
+                        (uint64_t)__double_as_longlong(first_a[kFirst ? j : 0]), (uint64_t)__double_as_longlong(first_b[kFirst ? j : 0]));
+            }
             }
         };
         // ---- phases, each one walk over what sh.val holds:
@@ -451,7 +460,7 @@ __global__ __launch_bounds__(kWave, (!kNulls && kTs32) ? 5 : 4) void rolling_tw_
         // by ONE walk that does everything per row (walk_all below: the round-1 walk).  At that length the chain is short and a phase
         // per kind costs more than it saves: 10-row windows, IntegralStep + IntegralTrapezoid + Mean 0.56 ms per 1e8 rows in phases
         // against 0.37 in one walk; from ~16 rows on the phases win and keep winning (64-row windows with nulls: 0.59 against 1.04 ms).
-        const bool walk_all = !early && nseg_total > kWalkAllMaxHeads && (need_step || need_trap);
+        const bool walk_all = kShort || (!early && nseg_total > kWalkAllMaxHeads && (need_step || need_trap));
         const bool two_phase = !walk_all && kNulls && need_mm && need_sum && nseg_total <= kTwoWalksMaxHeads;
         const bool pred_walk = kNulls && need_mm && need_sum && !two_phase;   // one walk, extrema under the validity bit (agg_device.h)
         for (int phase = two_phase ? 1 : 0; phase <= (walk_all ? 0 : 4); phase++) {
@@ -474,11 +483,11 @@ __global__ __launch_bounds__(kWave, (!kNulls && kTs32) ? 5 : 4) void rolling_tw_
             if (phase >= 3) {
                 lds_order();   // the walks of the phase before are done with sh.val
                 if (phase == 3 || !need_step) { if (!early) term_pass(); }
-                else if (kBoth) {
+                else if (kKeep) {
 #pragma unroll
                     for (int j = 0; j < kChunksT; j++)
                         *reinterpret_cast<ulonglong2 *>(&sh.val[j * 128 + 2 * lane]) = make_ulonglong2(
-                            (uint64_t)__double_as_longlong(keep_a[kBoth ? j : 0]), (uint64_t)__double_as_longlong(keep_b[kBoth ? j : 0]));
+                            (uint64_t)__double_as_longlong(keep_a[kKeep ? j : 0]), (uint64_t)__double_as_longlong(keep_b[kKeep ? j : 0]));
                 }
                 lds_order();
             }
@@ -679,14 +688,17 @@ int launch_rolling_tw(Ctx *c, const SimpleParams &p, bool is_int, bool has_nulls
     if (grid > 0x7FFFFFFFll) return fail(BOWGPU_ERR_UNSUPPORTED, "too many rows for one launch: %lld", (long long)p.n);
     const dim3 g((unsigned)grid), blk(kWave);
     const bool both = (p.need & kNeedStep) && (p.need & kNeedTrap);
-#define BG_TW2(U, B)                                                                                                        \
-    do {                                                                                                                    \
-        if (wide) hipLaunchKernelGGL((rolling_tw_kernel<U, true, false, B>), g, blk, 0, c->stream, p, ntiles, per_xcd);      \
-        else if (ts32) hipLaunchKernelGGL((rolling_tw_kernel<U, false, true, B>), g, blk, 0, c->stream, p, ntiles, per_xcd); \
-        else hipLaunchKernelGGL((rolling_tw_kernel<U, false, false, B>), g, blk, 0, c->stream, p, ntiles, per_xcd);         \
+    const bool shrt = p.W > 0 && p.n / p.W < kShortAvgRows;
+#define BG_TW3(U, B, S)                                                                                                        \
+    do {                                                                                                                       \
+        if (wide) hipLaunchKernelGGL((rolling_tw_kernel<U, true, false, B, S>), g, blk, 0, c->stream, p, ntiles, per_xcd);      \
+        else if (ts32) hipLaunchKernelGGL((rolling_tw_kernel<U, false, true, B, S>), g, blk, 0, c->stream, p, ntiles, per_xcd); \
+        else hipLaunchKernelGGL((rolling_tw_kernel<U, false, false, B, S>), g, blk, 0, c->stream, p, ntiles, per_xcd);         \
     } while (0)
+#define BG_TW2(U, B) do { if (shrt) BG_TW3(U, false, true); else BG_TW3(U, B, false); } while (0)
 #define BG_TW(U) do { if (both) BG_TW2(U, true); else BG_TW2(U, false); } while (0)
     if (has_nulls) BG_TW(true); else BG_TW(false);
+#undef BG_TW3
 #undef BG_TW
 #undef BG_TW2
     BG_HIP(hipGetLastError());
