@@ -497,14 +497,14 @@ __global__ __launch_bounds__(kWave, (kShort || (!kNulls && kTs32 && !kBoth)) ? 5
             uint32_t out_mask;
             {
                 const uint32_t others = p.kind_mask[4];
-                const int ph1 = two_phase ? 1 : (need_vals || !(need_step || need_trap)) ? 0 : need_step ? 3 : 4;   // the first phase that runs
+                const int ph1 = walk_all ? 0 : two_phase ? 1 : (need_vals || !(need_step || need_trap)) ? 0 : need_step ? 3 : 4;   // the first phase that runs
                 out_mask = phase == 0 ? (p.kind_mask[0] | p.kind_mask[1]) : phase == 1 ? p.kind_mask[0] : phase == 2 ? p.kind_mask[1]
                            : phase == 3 ? p.kind_mask[2] : p.kind_mask[3];
                 if (phase == ph1) out_mask |= others;
                 if (walk_all) out_mask = p.kind_mask[0] | p.kind_mask[1] | p.kind_mask[2] | p.kind_mask[3] | others;
                 out_mask &= p.col_mask[c];
             }
-            const int phase1 = two_phase ? 1 : (need_vals || !(need_step || need_trap)) ? 0 : need_step ? 3 : 4;   // the first phase that runs
+            const int phase1 = walk_all ? 0 : two_phase ? 1 : (need_vals || !(need_step || need_trap)) ? 0 : need_step ? 3 : 4;   // the first phase that runs
             const bool first_phase = phase == phase1;
 
     for (int q = lane; q < nseg_owned; q += kWave) {
@@ -688,7 +688,10 @@ int launch_rolling_tw(Ctx *c, const SimpleParams &p, bool is_int, bool has_nulls
     if (grid > 0x7FFFFFFFll) return fail(BOWGPU_ERR_UNSUPPORTED, "too many rows for one launch: %lld", (long long)p.n);
     const dim3 g((unsigned)grid), blk(kWave);
     const bool both = (p.need & kNeedStep) && (p.need & kNeedTrap);
-    const bool shrt = p.W > 0 && p.n / p.W < kShortAvgRows;
+    // the one-walk instantiation up to the window length where the phases take over (scratch/midw_sweep.py, 1e8 rows): a single kind of
+    // integral on a column without nulls 14 rows, with nulls or next to value reducers 20, both kinds 64 (44 with nulls)
+    const int64_t short_rows = both ? (has_nulls ? 44 : 64) : (has_nulls || (p.need & (kNeedSum | kNeedMinMax | kNeedFirstLast))) ? 20 : kShortAvgRows;
+    const bool shrt = p.W > 0 && p.n / p.W < short_rows;
 #define BG_TW3(U, B, S)                                                                                                        \
     do {                                                                                                                       \
         if (wide) hipLaunchKernelGGL((rolling_tw_kernel<U, true, false, B, S>), g, blk, 0, c->stream, p, ntiles, per_xcd);      \
