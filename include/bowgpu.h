@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-/* 4 (round 4): bowgpu_options' former padding word is `strict_order` (a caller that left it uninitialised now has calls declined),
+/* 4 (round 4): bowgpu_options' former padding word is `strict_order` (a caller that left it uninitialised now gets the row-order forms),
  * bowgpu_stream_rw_ceiling became bowgpu_stream_rw_probe, the BOWGPU_ROUTE_* bits moved.  A binding checks bowgpu_abi_version()
  * against the value it was written for when it loads the library (bow_amd/capi.py lib(); shim/go/rolling/gpu_cgo.go init()). */
 #define BOWGPU_ABI_VERSION 4
@@ -129,11 +129,14 @@ typedef struct bowgpu_agg {
 typedef struct bowgpu_options {
     int64_t offset;
     int32_t inclusive;
-    int32_t strict_order;       /* not in the reference.  != 0: every window is reduced in the reference's left-to-right row order or the
-                                   call is declined - no order-free form (bowgpu_agg_info.long_windows is 0 on success).  Windows that
-                                   a tile cannot hold (longer than its 128-row look-ahead) make the call BOWGPU_ERR_UNSUPPORTED instead
-                                   of being summed as a tree; honoured by bowgpu_rolling_aggregate[_planned], declined (same code) by
-                                   the bowgpu_shard_* protocol.  0: see bowgpu_agg_info.long_windows for the bound that applies */
+    int32_t strict_order;       /* not in the reference.  != 0: every window is reduced in the reference's left-to-right row order - no
+                                   order-free form, Sum / ArithmeticMean / Integral* / WeightedAverage* bit for bit, and
+                                   bowgpu_agg_info.long_windows is 0 on success.  Windows that a tile cannot hold (longer than its
+                                   128-row look-ahead) are walked by one lane each (round 4; round 3 declined them): 0.25 - 0.48 of
+                                   the HBM peak at 1000-row windows.  A window of more than 2^20 rows makes the call
+                                   BOWGPU_ERR_UNSUPPORTED (one lane per window: beyond that it would take milliseconds each).
+                                   Honoured by bowgpu_rolling_aggregate[_planned]; declined (BOWGPU_ERR_UNSUPPORTED) by the
+                                   bowgpu_shard_* protocol.  0: see bowgpu_agg_info.long_windows for the bound that applies */
 } bowgpu_options;
 
 /* Diagnostics of one aggregate call */
@@ -143,7 +146,7 @@ typedef struct bowgpu_agg_info {
     int32_t new_interval_col;   /* index of the LAST aggregator reading the interval column (aggregation.go:152-161) */
     int32_t inclusive;          /* effective Options.Inclusive after validateAggregation (aggregation.go:183-185) */
     int64_t long_windows;       /* windows reduced in an ORDER-FREE form instead of the reference's left-to-right walk: windows longer
-                                   than a tile's look-ahead (128 rows), and every window of a call whose windows average >= 128 rows.  THE STATED TOLERANCE, for the float sums
+                                   than a tile's look-ahead (128 rows), and every window of a call whose windows average >= 129 rows (128 for {sum, count} sets and calls with both kinds of integral).  THE STATED TOLERANCE, for the float sums
                                    of those windows (u = 2^-53, n = the window's rows, x = its valid values, T = its time-weighted
                                    terms):   |Sum - ref| <= 2 (n + 2) u SUM|x_i|;   ArithmeticMean: that / count + 2 u |ref|;
                                    Integral*: 4 (n + 2) u SUM|T_i| (a Factor scales it);   WeightedAverage*: that / (t_last - t_first)
@@ -151,7 +154,7 @@ typedef struct bowgpu_agg_info {
                                    reference in every digit of a result near zero (tests/tolerance.py states and asserts it, a
                                    cancelling window included).  The summation tree is fixed: equal inputs give equal bits.  Every
                                    other reducer, and every window when this is 0, is bit-exact.  bowgpu_options.strict_order
-                                   declines instead */
+                                   walks those windows in row order instead */
     double kernel_ms;           /* device time of the kernels of this call (HIP events on the library stream) */
 } bowgpu_agg_info;
 
@@ -287,7 +290,10 @@ typedef struct bowgpu_interp {
  * calls back to back inside Rolling.Interpolate).  Writes and frees made THROUGH this library (bowgpu_free, bowgpu_memcpy_h2d,
  * bowgpu_memset, the generators) drop the reuse by themselves; a buffer rewritten by the caller's own kernels is the caller's to
  * keep unchanged.  As a last line the fill compares the number of rows it produces with the count: a mismatch is
- * BOWGPU_ERR_ARG and the outputs are to be discarded. */
+ * BOWGPU_ERR_ARG and the outputs are to be discarded.
+ * _fill does not NEED a preceding _count: called on its own it sizes the outputs itself against bowgpu_out.length (in: capacity;
+ * rows + windows always suffice; too small is BOWGPU_ERR_ARG naming the size).  Inclusive windows then take one pass over the rows
+ * (n_out = n + W - [row 0 on its window's start] needs no count); exclusive windows make their own count pass first. */
 int bowgpu_rolling_interpolate_count(const bowgpu_col *cols, int32_t ncols, int32_t ts_col,
                                      int64_t interval, const bowgpu_options *opts,
                                      const bowgpu_interp *interps, int32_t ninterps,
