@@ -51,16 +51,23 @@ struct TwCap { static constexpr int value = kTs32 ? (kNulls ? 208 : 240) : 464; 
 
 // kTs32: float64(ts) is rebuilt as float64(s0 of slot 0) + float64(offset), which is exact - and so equal to the reference's single
 // conversion (integral.go:17) - when every |ts| of the call is below 2^53 (the host checks; nanosecond epochs take the 64-bit form).
-template <bool kNulls, bool kTs32>
+// kLean: the commonest call - ONE value column without nulls, integrals only - keeps nothing but the term array and the head list in
+// LDS (6 KB: 26 wavefronts per CU, the simple kernel's occupancy): no staged times - a head entry carries its window id (32-bit
+// entries: row | on-window-start flag << 10 | (wid - wid of the tile's first row) << 11; ids more than 2^21 apart inside one tile
+// send the call to the general kernel) and the slot of a head holds the closing PRODUCT v0 * (float64(LastValue) - t0) of the window
+// before it, computed by the head's lane in the flag pass, where both are in registers.
+template <bool kNulls, bool kTs32, bool kLean>
 struct TwShared {
     uint64_t val[kRowsT];                          // the column's staged values; then its step terms; then its trapezoid terms
     // the time of every row, where the term pass reads a row's own and its previous point's: a 32-bit offset from slot 0 (kTs32) or the int64 itself
-    typename std::conditional<kTs32, uint32_t, int64_t>::type tsx[kRowsT];
+    typename std::conditional<kTs32, uint32_t, int64_t>::type tsx[kLean ? 1 : kRowsT];
     uint32_t vbits[kNulls ? kRowsT / 32 + 2 : 2];  // validity words of the value column for this tile
-    uint16_t seg[TwCap<kNulls, kTs32>::value + 2]; // heads in row order: local row | on-window-start flag << 15
+    // heads in row order: local row | on-window-start flag << 15 (kLean: see above)
+    typename std::conditional<kLean, uint32_t, uint16_t>::type seg[(kLean ? 248 : TwCap<kNulls, kTs32>::value) + 2];
 };
-static_assert(sizeof(TwShared<false, true>) <= 8192 && sizeof(TwShared<true, true>) <= 8192, "LDS of the 32-bit forms: 8 KB");
-static_assert(sizeof(TwShared<false, false>) <= 11264 && sizeof(TwShared<true, false>) <= 11264, "LDS of the 64-bit forms: 11 KB");
+static_assert(sizeof(TwShared<false, true, false>) <= 8192 && sizeof(TwShared<true, true, false>) <= 8192, "LDS of the 32-bit forms: 8 KB");
+static_assert(sizeof(TwShared<false, false, false>) <= 11264 && sizeof(TwShared<true, false, false>) <= 11264, "LDS of the 64-bit forms: 11 KB");
+static_assert(sizeof(TwShared<false, true, true>) <= 6144 && sizeof(TwShared<false, false, true>) <= 6144, "LDS of the lean forms: 6 KB");
 
 __device__ __forceinline__ uint32_t mdiv32(uint32_t n, uint32_t m, uint32_t sh1, uint32_t sh2) {
     const uint32_t t = __umulhi(m, n);
@@ -100,11 +107,13 @@ __device__ __forceinline__ void lds_order() {
 // kBoth: the call has step AND trapezoid integrals: the terms of the second kind wait in registers while the first kind is walked
 // kShort: a call whose windows average fewer than kShortAvgRows rows - every tile takes the one-walk form (walk_all below), and the
 // term machinery is not even compiled in: its registers cost a wavefront per SIMD, which at that window length is what sets the rate
-template <bool kNulls, bool kWide, bool kTs32, bool kBoth, bool kShort>
-__global__ __launch_bounds__(kWave, (kShort || (!kNulls && kTs32 && !kBoth)) ? 5 : 4) void rolling_tw_kernel(const SimpleParams p, const int64_t ntiles, const int64_t tiles_per_xcd) {
+template <bool kNulls, bool kWide, bool kTs32, bool kBoth, bool kShort, bool kLean>
+__global__ __launch_bounds__(kWave, (kShort || kLean || (!kNulls && kTs32 && !kBoth)) ? 5 : 4) void rolling_tw_kernel(const SimpleParams p, const int64_t ntiles, const int64_t tiles_per_xcd) {
     static_assert(!(kWide && kTs32), "the wide form keeps 64-bit timestamps");
-    __shared__ TwShared<kNulls, kTs32> sh;
-    constexpr int kSegCapT = TwCap<kNulls, kTs32>::value;
+    static_assert(!kLean || (!kNulls && !kShort), "the lean form: one column without nulls, integrals only, terms from the flag pass");
+    __shared__ TwShared<kNulls, kTs32, kLean> sh;
+    constexpr int kSegCapT = kLean ? 248 : TwCap<kNulls, kTs32>::value;
+    constexpr uint32_t kRowMask = kLean ? 0x3FFu : 0x7FFFu, kStartBit = kLean ? 0x400u : 0x8000u;
     const int64_t b = blockIdx.x;
     const int64_t tile = (b & 7) * tiles_per_xcd + (b >> 3);  // XCD-contiguous tile runs (look-ahead rows hit the same L2)
     if (tile >= ntiles) return;
@@ -196,6 +205,7 @@ __global__ __launch_bounds__(kWave, (kShort || (!kNulls && kTs32 && !kBoth)) ? 5
     auto wid_of = [&](int64_t t) -> uint32_t { return (pre && t < ws0) ? 0u : mdiv32(rel32(t), p.m32, p.sh1, p.sh2); };
 
     // ---- window ids (32-bit), head flags, compaction with a running scalar count
+    const uint32_t w_first = (kWide || pre) ? 0u : mdiv32((uint32_t)ts_first - s0_lo, p.m32, p.sh1, p.sh2);   // (kLean: head entries hold ids relative to it)
     const uint32_t left_w0 = base == 0 ? 0xFFFFFFFEu : (pre && left0 < ws0) ? 0u : (kWide && left0 < ws0) ? 0xFFFFFFFEu : mdiv32(rel32(left0), p.m32, p.sh1, p.sh2);
     uint32_t left_w = left_w0;
     int64_t left_ts = left0;
@@ -209,6 +219,10 @@ __global__ __launch_bounds__(kWave, (kShort || (!kNulls && kTs32 && !kBoth)) ? 5
     // computed right here in the flag pass, where a row's timestamp, value, head flag and left neighbour are all in registers, and go
     // straight to LDS: no staging, no term pass, no value phase.
     const bool early_terms = !kShort && !kNulls && !need_vals;
+    if (kLean && (p.ncols != 1 || need_vals)) {   // (the host launches the lean form for such calls only)
+        if (lane == 0) atomicOr(&p.status[4], 1u);
+        return;
+    }
     constexpr bool kKeep = kBoth && !kShort;
     double keep_a[kKeep ? kChunksT : 1], keep_b[kKeep ? kChunksT : 1];   // kBoth: the trapezoid terms wait here while the step terms are walked
     double early_carry_x = 0.0;
@@ -240,20 +254,30 @@ __global__ __launch_bounds__(kWave, (kShort || (!kNulls && kTs32 && !kBoth)) ? 5
         const uint64_t lowmask = kWide ? ((1ull << p.shift_k) - 1ull) : 0ull;
         uint32_t sa = 0u, sb = 0u;
         if (p.inclusive) {   // (uniform: only inclusive calls look at the flag)
-            sa = (ra == wa * ik && (((uint64_t)tsa - (uint64_t)ws0) & lowmask) == 0) ? 0x8000u : 0u;
-            sb = (rb == wb * ik && (((uint64_t)tsb - (uint64_t)ws0) & lowmask) == 0) ? 0x8000u : 0u;
+            sa = (ra == wa * ik && (((uint64_t)tsa - (uint64_t)ws0) & lowmask) == 0) ? kStartBit : 0u;
+            sb = (rb == wb * ik && (((uint64_t)tsb - (uint64_t)ws0) & lowmask) == 0) ? kStartBit : 0u;
         }
-        if (ha && pos < kSegCapT) sh.seg[pos] = (uint16_t)((uint32_t)l | sa);
-        pos += ha ? 1 : 0;
-        if (hb && pos < kSegCapT) sh.seg[pos] = (uint16_t)((uint32_t)(l + 1) | sb);
+        if (kLean) {
+            const uint32_t la = wa - w_first, lb = wb - w_first;
+            sat |= (ha && la >= (1u << 21)) || (hb && lb >= (1u << 21));
+            if (ha && pos < kSegCapT) sh.seg[pos] = (uint32_t)l | sa | (la << 11);
+            pos += ha ? 1 : 0;
+            if (hb && pos < kSegCapT) sh.seg[pos] = (uint32_t)(l + 1) | sb | (lb << 11);
+        } else {
+            if (ha && pos < kSegCapT) sh.seg[pos] = (uint16_t)((uint32_t)l | sa);
+            pos += ha ? 1 : 0;
+            if (hb && pos < kSegCapT) sh.seg[pos] = (uint16_t)((uint32_t)(l + 1) | sb);
+        }
         nseg_total += __popcll(ma) + __popcll(mb);
         if (j == kChunksT - 2) nseg_owned = nseg_total;
         left_w = (uint32_t)__builtin_amdgcn_readlane((int)wb, 63);
         left_ts = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(tb[j] >> 32), 63) << 32) |
                             (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)tb[j], 63));
         // the rows' times, for the term passes (float64(ts) and the window id are both recomputed from them there)
-        if (kTs32) *reinterpret_cast<uint2 *>(&sh.tsx[l]) = make_uint2(ra, rb);   // (l is even: one 8-byte LDS write)
-        else *reinterpret_cast<ulonglong2 *>(&sh.tsx[l]) = make_ulonglong2(ta[j], tb[j]);
+        if (!kLean) {
+            if (kTs32) *reinterpret_cast<uint2 *>(&sh.tsx[l]) = make_uint2(ra, rb);   // (l is even: one 8-byte LDS write)
+            else *reinterpret_cast<ulonglong2 *>(&sh.tsx[l]) = make_ulonglong2(ta[j], tb[j]);
+        }
         if (early_terms) {   // (see the term pass below for what a slot holds)
             const double xa = cint0 ? (double)(int64_t)va[j] : __longlong_as_double((long long)va[j]);
             const double xb = cint0 ? (double)(int64_t)vb[j] : __longlong_as_double((long long)vb[j]);
@@ -263,7 +287,18 @@ __global__ __launch_bounds__(kWave, (kShort || (!kNulls && kTs32 && !kBoth)) ? 5
             const double dta = kTs32 ? (double)(uint32_t)((uint32_t)tsa - (uint32_t)prev_ts) : (double)tsa - (double)prev_ts;
             const double dtb = kTs32 ? (double)(uint32_t)((uint32_t)tsb - (uint32_t)tsa) : (double)tsb - (double)tsa;
             double s1 = 0.0, s2 = 0.0, q1 = 0.0, q2 = 0.0;
-            if (need_step) { s1 = ha ? xp : xp * dta; s2 = hb ? xa : xa * dtb; }
+            if (need_step) {
+                if (kLean) {
+                    // a head's slot: v0 * (float64(LastValue) - t0) of the window before (integral.go:49-55).  32-bit times: the
+                    // difference as an integer, converted - it is below the interval, and equal to the difference of the two
+                    // float64 values, which are exact themselves (every |ts| < 2^53); else the two conversions as written
+                    const double ca = kTs32 ? (double)(uint32_t)((wprev + 1u) * (uint32_t)p.interval - ((uint32_t)prev_ts - s0_lo))
+                                            : (double)(ws0 + (int64_t)(((uint64_t)wprev + 1ull) * (uint64_t)(uint32_t)p.interval)) - (double)prev_ts;
+                    const double cb = kTs32 ? (double)(uint32_t)((wa + 1u) * (uint32_t)p.interval - ra)
+                                            : (double)(ws0 + (int64_t)(((uint64_t)wa + 1ull) * (uint64_t)(uint32_t)p.interval)) - (double)tsa;
+                    s1 = ha ? xp * ca : xp * dta; s2 = hb ? xa * cb : xa * dtb;
+                } else { s1 = ha ? xp : xp * dta; s2 = hb ? xa : xa * dtb; }
+            }
             if (need_trap) { q1 = (xp + xa) / 2 * dta; q2 = (xa + xb) / 2 * dtb; }
             const double oa = need_step ? s1 : q1, ob = need_step ? s2 : q2;
             *reinterpret_cast<ulonglong2 *>(&sh.val[l]) = make_ulonglong2((uint64_t)__double_as_longlong(oa), (uint64_t)__double_as_longlong(ob));
@@ -298,11 +333,12 @@ __global__ __launch_bounds__(kWave, (kShort || (!kNulls && kTs32 && !kBoth)) ? 5
     auto geometry = [&](int q, int &r0, int &r1, uint32_t &wid, uint32_t &next_wid, uint32_t &e1) -> int {   // 0: a window; 1: it runs past the look-ahead
         const uint32_t e0 = sh.seg[q];
         e1 = sh.seg[q + 1];
-        r0 = (int)(e0 & 0x7FFFu);
-        wid = wid_k((tkey_t)sh.tsx[r0]);   // (the id of a head row from its staged time: the division the flag pass did)
+        r0 = (int)(e0 & kRowMask);
+        // (the id of a head row from its staged time - the division the flag pass did - or, kLean, out of its entry)
+        if (kLean) wid = w_first + (e0 >> 11); else wid = wid_k((tkey_t)sh.tsx[r0]);
         if (q + 1 < nseg_total) {
-            r1 = (int)(e1 & 0x7FFFu);
-            next_wid = wid_k((tkey_t)sh.tsx[r1]);
+            r1 = (int)(e1 & kRowMask);
+            if (kLean) next_wid = w_first + (e1 >> 11); else next_wid = wid_k((tkey_t)sh.tsx[r1]);
             return 0;
         }
         r1 = nloc;
@@ -520,7 +556,7 @@ __global__ __launch_bounds__(kWave, (kShort || (!kNulls && kTs32 && !kBoth)) ? 5
         }
         const bool next_staged = q + 1 < nseg_total;   // row r1 is a head of this tile: its slot holds what closes this window
         // does the successor's first row sit exactly on this window's end?  (rolling.go:201-209; only looked at for inclusive calls)
-        const bool incl_row = p.inclusive && next_staged && next_wid == wid + 1 && (e1 & 0x8000u);
+        const bool incl_row = p.inclusive && next_staged && next_wid == wid + 1 && (e1 & kStartBit);
         // window 0 made only of rows below s0 is an EMPTY slice in the reference (rolling.go:194-196: lastRowIndex stays -1)
         const bool dead = pre && tile == 0 && q == 0 && !(p.ts[base + r1 - 1] >= p.s0 || incl_row);
         int count = r1 - r0, fv = r0, lv = r1 - 1;
@@ -586,13 +622,17 @@ __global__ __launch_bounds__(kWave, (kShort || (!kNulls && kTs32 && !kBoth)) ? 5
             integ = walk_terms(sh.val, fv + 1, lv + 1);
             if (phase == 3) {
                 // + v0 * (float64(LastValue) - t0) of the last valid point (integral.go:49-55): staged in the next window's head slot
-                double pv;
-                if (next_staged) pv = __longlong_as_double((long long)sh.val[r1]);   // the next window's head slot: the value of the point before it
-                else {   // the data ends inside this window (one window per call): from the column itself
-                    const uint64_t raw = reinterpret_cast<const uint64_t *>(p.values[c])[base + lv];
-                    pv = cint ? (double)(int64_t)raw : __longlong_as_double((long long)raw);
+                if (kLean && next_staged) integ = integ + __longlong_as_double((long long)sh.val[r1]);   // the next window's head slot: the closing product
+                else {
+                    double pv, tlast;
+                    if (next_staged) pv = __longlong_as_double((long long)sh.val[r1]);   // the next window's head slot: the value of the point before it
+                    else {   // the data ends inside this window (one window per call): from the column itself
+                        const uint64_t raw = reinterpret_cast<const uint64_t *>(p.values[c])[base + lv];
+                        pv = cint ? (double)(int64_t)raw : __longlong_as_double((long long)raw);
+                    }
+                    if (kLean) tlast = (double)p.ts[base + lv]; else tlast = abs_d(time_d((tkey_t)sh.tsx[lv]));
+                    integ = integ + pv * (last_value_d(wid) - tlast);
                 }
-                integ = integ + pv * (last_value_d(wid) - abs_d(time_d((tkey_t)sh.tsx[lv])));
             } else {
                 // the inclusive row (the successor's first row, when it sits on this window's end and is a valid point) joins in
                 int cnt = count;
@@ -692,15 +732,20 @@ int launch_rolling_tw(Ctx *c, const SimpleParams &p, bool is_int, bool has_nulls
     // integral on a column without nulls 14 rows, with nulls or next to value reducers 20, both kinds 64 (44 with nulls)
     const int64_t short_rows = both ? (has_nulls ? 44 : 64) : (has_nulls || (p.need & (kNeedSum | kNeedMinMax | kNeedFirstLast))) ? 20 : kShortAvgRows;
     const bool shrt = p.W > 0 && p.n / p.W < short_rows;
-#define BG_TW3(U, B, S)                                                                                                        \
-    do {                                                                                                                       \
-        if (wide) hipLaunchKernelGGL((rolling_tw_kernel<U, true, false, B, S>), g, blk, 0, c->stream, p, ntiles, per_xcd);      \
-        else if (ts32) hipLaunchKernelGGL((rolling_tw_kernel<U, false, true, B, S>), g, blk, 0, c->stream, p, ntiles, per_xcd); \
-        else hipLaunchKernelGGL((rolling_tw_kernel<U, false, false, B, S>), g, blk, 0, c->stream, p, ntiles, per_xcd);         \
+    // the lean form: one value column without nulls, integrals only, whatever the window length
+    const bool lean = !has_nulls && p.ncols == 1 && !(p.need & (kNeedSum | kNeedMinMax | kNeedFirstLast));
+#define BG_TW4(U, B, S, L)                                                                                                       \
+    do {                                                                                                                          \
+        if (wide) hipLaunchKernelGGL((rolling_tw_kernel<U, true, false, B, S, L>), g, blk, 0, c->stream, p, ntiles, per_xcd);      \
+        else if (ts32) hipLaunchKernelGGL((rolling_tw_kernel<U, false, true, B, S, L>), g, blk, 0, c->stream, p, ntiles, per_xcd); \
+        else hipLaunchKernelGGL((rolling_tw_kernel<U, false, false, B, S, L>), g, blk, 0, c->stream, p, ntiles, per_xcd);         \
     } while (0)
+#define BG_TW3(U, B, S) BG_TW4(U, B, S, false)
 #define BG_TW2(U, B) do { if (shrt) BG_TW3(U, false, true); else BG_TW3(U, B, false); } while (0)
 #define BG_TW(U) do { if (both) BG_TW2(U, true); else BG_TW2(U, false); } while (0)
-    if (has_nulls) BG_TW(true); else BG_TW(false);
+    if (lean) { if (both) BG_TW4(false, true, false, true); else BG_TW4(false, false, false, true); }
+    else if (has_nulls) BG_TW(true); else BG_TW(false);
+#undef BG_TW4
 #undef BG_TW3
 #undef BG_TW
 #undef BG_TW2
