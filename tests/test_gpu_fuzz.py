@@ -78,6 +78,16 @@ def run_paths(ccols, ocols, interval, aggs, offset, inclusive, label):
         for i, (a, g, w) in enumerate(zip(aggs, outs, exp)):
             exact = info.long_windows == 0 or a[0] not in ORDER_SENSITIVE
             compare("%s %s path=%s" % (label, a[0], path), g, w, exact=exact, bound=None if exact else bounds[i])
+    # bowgpu_options.strict_order: every window in row order - every reducer bit for bit, whatever the window lengths (round 4:
+    # long windows by one lane each); declined only when a window holds more than 2^20 rows
+    try:
+        outs, info = capi.rolling_aggregate(ccols, 0, interval, aggs, offset=offset, inclusive=inclusive, strict_order=True)
+    except capi.BowGpuError as e:
+        assert e.code == -9 and "2^20" in e.message, (label, e.message)
+        return
+    assert info.long_windows == 0, label
+    for a, g, w in zip(aggs, outs, exp):
+        compare("%s %s strict" % (label, a[0]), g, w, exact=True)
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("BOW_FUZZ_SEEDS", "64"))))
