@@ -1,13 +1,13 @@
 #!/bin/bash
 # Every profiles/<tag>_* file of a round from ONE script at ONE commit (run on the GPU box through gpurun):
-#   scratch/profile_all.sh r03     -> gpurun_out/profiles_r03/  (copy its files to profiles/ as they are)
+#   scratch/profile_all.sh r04     -> gpurun_out/profiles_r04/  (copy its files to profiles/ as they are)
 # 1. scratch/profile_bench.sh   : the bench line un-profiled, rocprofv3 --kernel-trace --stats, the FETCH_SIZE / WRITE_SIZE passes and
-#                                 the SQ / L2 counter passes of the benched kernel (traffic rows carry the kernel signature + source hash)
-# 2. scratch/profile_configs.sh : the secondary shapes, each un-profiled (stdout) and under --kernel-trace --stats
-# 3. scratch/pmc_sq.sh          : counter passes of the Interpolate fill kernel, the time-weighted tile kernel and the long-window
-#                                 streaming kernel (1000-row windows: dense / 30 % nulls, extrema / time-weighted; FETCH_SIZE included)
-# (--pmc passes never carry another trace domain; every profiled process is python3 itself: no env / shell hop after `--`)
-TAG=${1:-r03}
+#                                 one SQ counter pass of the benched kernel (traffic rows carry the kernel signature + source hash)
+# 2. the secondary shapes, un-profiled stdout tables (the scripts print kernel brackets from HIP events and wall times)
+# 3. scratch/pmc_quick.sh       : one counter pass (instruction mix, LDS) per mid-window shape
+# (--pmc passes never carry another trace domain; every profiled process is python3 itself: no env / shell hop after `--`.  Every
+# rocprofv3 pass runs under a hard limit: the profiler now and then hangs at process exit on this pool.)
+TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 DST=gpurun_out/profiles_$TAG
 rm -rf $DST && mkdir -p $DST
@@ -15,15 +15,15 @@ rm -rf $DST && mkdir -p $DST
 bash scratch/profile_bench.sh $TAG > $DST/profile_bench.log 2>&1
 cp gpurun_out/prof/${TAG}_* $DST/ 2>/dev/null
 cp gpurun_out/prof/bench.json $DST/${TAG}_bench_1e9.json 2>/dev/null
-bash scratch/profile_configs.sh $TAG configs general_bench interp_wall fill_wall longw longw_kinds longw_sweep small_calls host_resident > $DST/profile_configs.log 2>&1
-cp gpurun_out/prof_cfg/${TAG}_* $DST/ 2>/dev/null
-bash scratch/pmc_sq.sh w3 interp_wave3 scratch/interp_pmc.py > /dev/null 2>&1
-cp gpurun_out/pmc_w3/summary.txt $DST/${TAG}_pmc_interp_wave3_1e8.txt 2>/dev/null
-bash scratch/pmc_sq.sh tw rolling_tw scratch/one_shape.py tw_was > /dev/null 2>&1
-cp gpurun_out/pmc_tw/summary.txt $DST/${TAG}_pmc_tw_was_1e8.txt 2>/dev/null
-for V in "minmax dense" "tw dense" "minmax sparse" "tw sparse"; do
+for name in configs general_bench interp_wall fill_wall longw_kinds midw_sweep small_calls host_resident; do
+  PROF=0; [ "$name" = small_calls ] && PROF=1
+  BOWGPU_CALL_PROFILE=$PROF timeout -s KILL 600 python3 scratch/$name.py 2>&1 | grep -v "^[WE]2026" > $DST/${TAG}_stdout_${name}.txt
+done
+timeout -s KILL 300 python3 scratch/longw_kinds.py strict 2>&1 | grep -v "^[WE]2026" > $DST/${TAG}_stdout_longw_kinds_strict.txt
+timeout -s KILL 600 python3 scratch/longw_sweep.py 2>&1 | grep -v "^[WE]2026" > $DST/${TAG}_stdout_longw_sweep.txt
+: > $DST/${TAG}_pmc_mid_windows.txt
+for V in "WAvgStep 64 dense rolling_tw" "TW4 64 dense rolling_tw" "WAvgStep 64 sparse rolling_tw" "Mean 64 dense rolling_simple" "SumMinMax 64 sparse rolling_simple" "MinMax 64 sparse rolling_simple"; do
   set -- $V
-  bash scratch/pmc_sq.sh lw_$1_$2 long_short scratch/longw_one.py $1 $2 > /dev/null 2>&1
-  cp gpurun_out/pmc_lw_$1_$2/summary.txt $DST/${TAG}_pmc_long_short_$1_$2_1e8.txt 2>/dev/null
+  bash scratch/pmc_quick.sh $1_$2_$3 $4 scratch/one_shape.py gen $1 $2 $3 | tail -1 >> $DST/${TAG}_pmc_mid_windows.txt
 done
 ls -la $DST

@@ -3,7 +3,7 @@
 #   1. the bench line itself (un-profiled)                          -> gpurun_out/prof/bench.json
 #   2. --kernel-trace --stats                                       -> gpurun_out/prof/stats
 #   3. --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, as MI355X_MICROARCH.md prescribes)
-#   4. --kernel-trace --pmc <SQ counters> (two passes) + the L2 <-> fabric counters
+#   4. --kernel-trace --pmc <SQ counters> (one pass: waves, cycles, instruction mix)
 # then scratch/profile_collect.py boils them down to the files committed under profiles/ (kernel signature + a hash of the kernel's
 # sources in every row, so that bench.py only quotes traffic that belongs to the code it runs).
 TAG=${1:-r03}
@@ -11,11 +11,8 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/prof
 rm -rf $OUT && mkdir -p $OUT
 timeout -s KILL 400 python3 bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
-timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu --no-pinned > $OUT/stats.log 2>&1
-timeout -s KILL 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-pinned > $OUT/fetch.log 2>&1
-timeout -s KILL 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-pinned > $OUT/write.log 2>&1
-timeout -s KILL 400 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $OUT/sq1 -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-pinned > $OUT/sq1.log 2>&1
-timeout -s KILL 400 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_LEVEL_VMEM SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/sq2 -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-pinned > $OUT/sq2.log 2>&1
-timeout -s KILL 400 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum --output-format csv -d $OUT/tcc -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-pinned > $OUT/tcc.log 2>&1
-timeout -s KILL 400 rocprofv3 --kernel-trace --pmc TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_LATENCY_sum TCP_TCC_WRITE_REQ_sum GRBM_GUI_ACTIVE --output-format csv -d $OUT/tcp -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-pinned > $OUT/tcp.log 2>&1
+timeout -s KILL 150 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu --no-pinned > $OUT/stats.log 2>&1
+timeout -s KILL 150 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-pinned > $OUT/fetch.log 2>&1
+timeout -s KILL 150 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-pinned > $OUT/write.log 2>&1
+timeout -s KILL 150 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $OUT/sq1 -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-pinned > $OUT/sq1.log 2>&1
 python3 scratch/profile_collect.py $OUT $TAG
