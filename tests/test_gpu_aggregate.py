@@ -1153,3 +1153,41 @@ def test_strict_order_mixed_lengths_nulls_and_the_stated_limit():
     exp, _ = orc.aggregate([orc.Column(np.arange(m, dtype=np.int64), None, orc.INT64), orc.Column(bigv, None, orc.FLOAT64)], 0, 1 << 19,
                            [("WindowStart", 0), ("Sum", 1)])
     compare("strict 2^19-row windows Sum", outs[1], exp[1], exact=True)
+
+
+@pytest.mark.parametrize("data", ["regular", "irregular", "ns"])
+def test_time_weighted_kernel_forms_by_shape(data):
+    """rolling_tw_kernel's instantiations, each reached on purpose (round 4; DESIGN.md "The walks"): the lean form (one column without
+    nulls, integrals only), the one-walk form of short windows, the term phases (nulls: previous points gathered; values next to
+    integrals; both kinds of integral with the second kind waiting in registers), several columns incl. an Int64 one - at window lengths
+    either side of every threshold (14 / 20 / 44 / 64 rows per window, 48 heads per tile), exclusive and inclusive, 32-bit and 64-bit
+    times.  Every window fits a tile here, so every reducer is bit-exact."""
+    rng = np.random.default_rng({"regular": 1, "irregular": 2, "ns": 3}[data])
+    n = 60_000
+    if data == "regular":
+        ts = np.arange(n, dtype=np.int64) * 3 + 17
+        unit = 3
+    elif data == "irregular":
+        ts = np.cumsum(rng.integers(1, 6, n)).astype(np.int64) - 500
+        unit = 3
+    else:   # nanosecond epochs at ~10 Hz: beyond 2^53 and far wider than 2^32 (64-bit times, per-tile window ids)
+        ts = (1_700_000_000_000_000_000 + np.cumsum(rng.integers(90_000_000, 110_000_000, n))).astype(np.int64)
+        unit = 100_000_000
+    f, fm = make_vals(rng, n, "f64", 0.3)
+    g, gm = make_vals(rng, n, "i64", 0.2)
+    dense = (f, None)
+    one_kind = [("WindowStart", 0), ("WeightedAverageStep", 1)]
+    one_trap = [("WindowStart", 0), ("WeightedAverageLinear", 1), ("Count", 1)]
+    both = [("WindowStart", 0), ("IntegralStep", 1), ("IntegralTrapezoid", 1), ("WeightedAverageStep", 1), ("WeightedAverageLinear", 1)]
+    mixed = [("WindowStart", 0), ("IntegralStep", 1), ("ArithmeticMean", 1), ("Min", 1), ("Last", 1)]
+    mixed_both = [("WindowStart", 0), ("IntegralTrapezoid", 1), ("WeightedAverageStep", 1), ("Sum", 1), ("Max", 1), ("First", 1)]
+    multi = [("WindowStart", 0), ("WeightedAverageStep", 1), ("IntegralTrapezoid", 2), ("Sum", 2), ("WeightedAverageLinear", 3), ("First", 3)]
+    for rows_per_window in (5, 13, 16, 19, 22, 40, 48, 60, 70, 110):
+        interval = rows_per_window * unit
+        for inclusive in (False, True):
+            for cols, sets in (([dense], (one_kind, one_trap, both, mixed, mixed_both)),          # lean / one-walk / phases without nulls
+                               ([(f, fm)], (one_kind, both, mixed, mixed_both)),                      # gathers
+                               ([dense, (f, fm), (g, gm)], (multi,))):                                # several columns, an Int64 one
+                for aggs in sets:
+                    outs, exp, info = run_both(ts, cols, interval, aggs, offset=int(rng.integers(0, interval)), inclusive=inclusive)
+                    assert info.long_windows == 0
