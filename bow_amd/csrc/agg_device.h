@@ -231,38 +231,51 @@ __device__ __forceinline__ void window_valid_rows(const uint32_t *vbits, int r0,
     }
 }
 
+// Where row r of a tile lives in the staged array.  kSwz: two pad slots per 32 rows.  One lane walks one window, so the lanes of a
+// wavefront read rows that lie one window length apart - and REGULAR windows of 16 / 32 / 64 / 128 rows put every lane on the same
+// LDS bank (a stride of 256 B and its multiples): at 64 rows per window the bank-conflict cycles were 60 % of a wavefront's life
+// (SQ_LDS_BANK_CONFLICT; Mean 0.67 of the HBM peak at 64 rows per window, 0.79 at 100).  With the pads a stride of 32 k rows becomes 34 k
+// slots: 64-row windows land 8 banks apart.  A group of four rows that starts on a multiple of four never straddles a pad, so the
+// walk reads its groups as before after at most three single steps; pairs (2 i, 2 i + 1) stay 16-byte aligned for the staging stores.
+template <bool kSwz> __device__ __forceinline__ int swz(int r) { return kSwz ? r + 2 * (r >> 5) : r; }
+constexpr int swz_slots(int rows) { return rows + 2 * (rows / 32); }
+
 // rows fv .. lv of the staged column in order (sum.go:16-22, arithmeticmean.go:17-24, minmax.go:16-28): four LDS reads in flight, the
 // additions in row order.  Extrema: v_min_f64 / v_max_f64 from the seed (row fv) on.  The instruction differs from
 // `if x < mn { mn = x }` in three cases only - the seed is a NaN (minmax.go keeps it: no value compares below a NaN; the instruction
 // drops it), a signalling NaN among the values (the instruction returns it quieted), and a result of zero (+0 and -0 are equal for
 // minmax.go, so the EARLIEST zero stays; the instruction orders them) - and in those the window is walked again with the
 // comparison itself.  Null rows hold +0.0 when sums are walked and a quiet NaN when extrema are.
+template <bool kSwz>
 __device__ __forceinline__ void walk_values(const uint64_t *val, int fv, int lv, bool do_sum, bool do_mm, double &sum, double &mn, double &mx) {
-    const double seed = __longlong_as_double((long long)val[fv]);
+    const double seed = __longlong_as_double((long long)val[swz<kSwz>(fv)]);
     sum = 0.0; mn = seed; mx = seed;
     if (!(do_sum || do_mm)) return;
     int r = fv;
     const int rend = lv + 1;
+    auto one = [&](int rr) {
+        const double x = __longlong_as_double((long long)val[swz<kSwz>(rr)]);
+        if (do_sum) sum += x;
+        if (do_mm) { mn = vmin64(mn, x); mx = vmax64(mx, x); }
+    };
+    if (kSwz) for (; r < rend && (r & 3); r++) one(r);
     for (; r + 4 <= rend; r += 4) {
-        const double x0 = __longlong_as_double((long long)val[r]), x1 = __longlong_as_double((long long)val[r + 1]);
-        const double x2 = __longlong_as_double((long long)val[r + 2]), x3 = __longlong_as_double((long long)val[r + 3]);
+        const uint64_t *g = val + swz<kSwz>(r);
+        const double x0 = __longlong_as_double((long long)g[0]), x1 = __longlong_as_double((long long)g[1]);
+        const double x2 = __longlong_as_double((long long)g[2]), x3 = __longlong_as_double((long long)g[3]);
         if (do_sum) { sum += x0; sum += x1; sum += x2; sum += x3; }
         if (do_mm) {
             mn = vmin64(vmin64(vmin64(vmin64(mn, x0), x1), x2), x3);
             mx = vmax64(vmax64(vmax64(vmax64(mx, x0), x1), x2), x3);
         }
     }
-    for (; r < rend; r++) {
-        const double x = __longlong_as_double((long long)val[r]);
-        if (do_sum) sum += x;
-        if (do_mm) { mn = vmin64(mn, x); mx = vmax64(mx, x); }
-    }
+    for (; r < rend; r++) one(r);
     if (do_mm) {
         if (seed != seed) { mn = seed; mx = seed; }
         else if (mn == 0.0 || mx == 0.0 || mn != mn || mx != mx) {
             mn = seed; mx = seed;
             for (int rr = fv + 1; rr < rend; rr++) {
-                const double x = __longlong_as_double((long long)val[rr]);
+                const double x = __longlong_as_double((long long)val[swz<kSwz>(rr)]);
                 if (x < mn) mn = x;
                 if (x > mx) mx = x;
             }
@@ -276,11 +289,12 @@ __device__ __forceinline__ void walk_values(const uint64_t *val, int fv, int lv,
 // 11 instructions per row.
 constexpr int kTwoWalksMaxHeads = 24;   // (640 rows / 24: windows of ~27 rows and more)
 constexpr int kWalkAllMaxHeads = 48;    // rolling_tw.hip: tiles with more heads (windows of < ~13 rows) walk every reducer in one pass
+template <bool kSwz>
 __device__ __forceinline__ void walk_values_pred(const uint64_t *val, const uint32_t *vbits, int fv, int lv, double &sum, double &mn, double &mx) {
-    const double seed = __longlong_as_double((long long)val[fv]);
+    const double seed = __longlong_as_double((long long)val[swz<kSwz>(fv)]);
     sum = 0.0; mn = seed; mx = seed;
     for (int r = fv; r <= lv; r++) {
-        const double x = __longlong_as_double((long long)val[r]);
+        const double x = __longlong_as_double((long long)val[swz<kSwz>(r)]);
         sum += x;
         if ((vbits[r >> 5] >> (r & 31)) & 1u) {
             if (x < mn) mn = x;
@@ -290,15 +304,18 @@ __device__ __forceinline__ void walk_values_pred(const uint64_t *val, const uint
 }
 
 // rows a .. b-1 of a staged array of terms added in order onto +0.0 (the integrals: integral.go:22-31, :48-62)
+template <bool kSwz>
 __device__ __forceinline__ double walk_terms(const uint64_t *t, int a, int b) {
     double acc = 0.0;
     int r = a;
+    if (kSwz) for (; r < b && (r & 3); r++) acc += __longlong_as_double((long long)t[swz<kSwz>(r)]);
     for (; r + 4 <= b; r += 4) {
-        const double x0 = __longlong_as_double((long long)t[r]), x1 = __longlong_as_double((long long)t[r + 1]);
-        const double x2 = __longlong_as_double((long long)t[r + 2]), x3 = __longlong_as_double((long long)t[r + 3]);
+        const uint64_t *g = t + swz<kSwz>(r);
+        const double x0 = __longlong_as_double((long long)g[0]), x1 = __longlong_as_double((long long)g[1]);
+        const double x2 = __longlong_as_double((long long)g[2]), x3 = __longlong_as_double((long long)g[3]);
         acc += x0; acc += x1; acc += x2; acc += x3;
     }
-    for (; r < b; r++) acc += __longlong_as_double((long long)t[r]);
+    for (; r < b; r++) acc += __longlong_as_double((long long)t[swz<kSwz>(r)]);
     return acc;
 }
 

@@ -1053,9 +1053,9 @@ static int job_launch_tiles(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t
             c->last_kernel_name = "rolling_tw_kernel";
         } else {
             // (the head list of a tile comes in two sizes - rolling_simple.hip SimpleCap: the small one buys four more resident
-            // wavefronts per CU and serves calls whose windows average >= 3 rows; BOWGPU_ROUTE_SIMPLE_LARGE_LIST / _SMALL_LIST force
+            // wavefronts per CU and serves calls whose windows average >= 5 rows; BOWGPU_ROUTE_SIMPLE_LARGE_LIST / _SMALL_LIST force
             // either, for tests; a call whose tiles overflow the small list is redone with the large one - job_run)
-            const bool dense = force_large_list || ((route & BOWGPU_ROUTE_SIMPLE_LARGE_LIST) ? true : (route & BOWGPU_ROUTE_SIMPLE_SMALL_LIST) ? false : P.n / P.W < 3);
+            const bool dense = force_large_list || ((route & BOWGPU_ROUTE_SIMPLE_LARGE_LIST) ? true : (route & BOWGPU_ROUTE_SIMPLE_SMALL_LIST) ? false : P.n / P.W < 5);
             *used_small_list = !dense;
             BG_TRY(launch_rolling_simple(c, S, need, is_int, has_nulls, wide, dense));
             c->last_kernel_name = "rolling_simple_kernel";

@@ -32,15 +32,16 @@ constexpr uint32_t kSatS = 0xFFFFu;
 // The kernel's rate follows its OCCUPANCY and the occupancy follows the LDS per wavefront, which is allocated in 1 KB steps
 // (same-session A/B at 1e9 rows, three repeats: 6816 B and 6656 B 3.24 ms - 22 wavefronts per CU; 6144 B 3.10 ms - 26).  So the
 // head list comes in two sizes, chosen by the host from the plan (n / W):
-//   kDense = false: 254 heads (232 with nulls), LDS exactly 6144 B - calls whose windows average >= 3 rows
-//   kDense = true : 400 heads (378 with nulls), LDS 6.7 KB          - the rest: windows of 1.6 .. 3 rows, and frames with many
+//   kDense = false: 174 heads (152 with nulls), LDS exactly 6144 B - calls whose windows average >= 5 rows
+//   kDense = true : 400 heads (378 with nulls), LDS 6.9 KB          - the rest: windows of 1.6 .. 5 rows, and frames with many
 //                   empty windows (n / W says nothing about their non-empty ones); the round-1 layout
-template <bool kNulls, bool kDense> struct SimpleCap { static constexpr int value = kDense ? (kNulls ? 378 : 400) : (kNulls ? 232 : 254); };
+template <bool kNulls, bool kDense> struct SimpleCap { static constexpr int value = kDense ? (kNulls ? 378 : 400) : (kNulls ? 152 : 174); };
+constexpr bool kSwzS = true;   // the staged column carries two pad slots per 32 rows (agg_device.h swz): regular windows of 16 k rows off one bank
 constexpr int kAlignS = 16;   // output slots per 128-byte line: the granule of the slot-aligned hand-over between tiles
 
 template <bool kNulls, bool kDense>
 struct SimpleShared {
-    uint64_t val[kRowsS];
+    uint64_t val[swz_slots(kRowsS)];
     uint32_t vbits[kNulls ? kRowsS / 32 + 2 : 1];  // validity words of the value column for this tile (kNulls only)
     uint32_t seg[SimpleCap<kNulls, kDense>::value + (kNulls ? 2 : 1)];  // heads in row order: local row | (wid - wid of the tile's first row) << 16
 };
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
         left_ts = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(tb[j] >> 32), 63) << 32) |
                             (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)tb[j], 63));
         // single column: its values go to LDS now (their registers die here)
-        if (!kMulti && !kNulls && !kInt) *reinterpret_cast<ulonglong2 *>(&sh.val[l]) = make_ulonglong2(va[j], vb[j]);
+        if (!kMulti && !kNulls && !kInt) *reinterpret_cast<ulonglong2 *>(&sh.val[swz<kSwzS>(l)]) = make_ulonglong2(va[j], vb[j]);
     }
     if (__ballot(unsorted)) {  // the call fails with BOWGPU_ERR_TS_UNSORTED
         if (lane == 0) atomicOr(&p.status[0], 1u);
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
                     if (!(two & 1u)) xa = fill;
                     if (!(two & 2u)) xb = fill;
                 }
-                *reinterpret_cast<ulonglong2 *>(&sh.val[j * 128 + 2 * lane]) = make_ulonglong2(xa, xb);
+                *reinterpret_cast<ulonglong2 *>(&sh.val[swz<kSwzS>(j * 128 + 2 * lane)]) = make_ulonglong2(xa, xb);
             }
             if (kMulti && c + 1 < ncols) {
                 load_col(reinterpret_cast<const uint64_t *>(p.values[c + 1]), va, vb, !((p.unaligned_mask >> (c + 1)) & 1u));
@@ -311,8 +312,8 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
 #pragma unroll
                 for (int j = 0; j < kChunksS; j++) {
                     const uint32_t two = sh.vbits[j * 4 + (lane >> 4)] >> ((2 * lane) & 31);
-                    if (!(two & 1u)) sh.val[j * 128 + 2 * lane] = kNullAsNaN;
-                    if (!(two & 2u)) sh.val[j * 128 + 2 * lane + 1] = kNullAsNaN;
+                    if (!(two & 1u)) sh.val[swz<kSwzS>(j * 128 + 2 * lane)] = kNullAsNaN;
+                    if (!(two & 2u)) sh.val[swz<kSwzS>(j * 128 + 2 * lane) + 1] = kNullAsNaN;
                 }
                 lds_order();
             }
@@ -347,11 +348,11 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
         double sum = 0.0, mn = 0.0, mx = 0.0;
         uint64_t first_raw = 0, last_raw = 0;
         if (count > 0) {
-            first_raw = sh.val[fv];
-            if (kNulls && pred_walk) walk_values_pred(sh.val, sh.vbits, fv, lv, sum, mn, mx);
-            else walk_values(sh.val, fv, lv, do_sum, do_mm, sum, mn, mx);
+            first_raw = sh.val[swz<kSwzS>(fv)];
+            if (kNulls && pred_walk) walk_values_pred<kSwzS>(sh.val, sh.vbits, fv, lv, sum, mn, mx);
+            else walk_values<kSwzS>(sh.val, fv, lv, do_sum, do_mm, sum, mn, mx);
             if (kNeed & 2) {
-                last_raw = sh.val[lv];
+                last_raw = sh.val[swz<kSwzS>(lv)];
                 if (cint) {   // the staged values are float64(v): First / Last return the Int64 itself (firstlast.go:17, :32)
                     const uint64_t *__restrict__ src = reinterpret_cast<const uint64_t *>(p.values[c]);
                     first_raw = src[base + fv];

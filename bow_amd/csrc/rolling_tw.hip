@@ -46,6 +46,7 @@ constexpr int kChunksT = kRowsT / 128;
 // with nulls; 64-bit times 11 KB (14 per CU): 464 heads
 constexpr int64_t kShortAvgRows = 14;   // calls whose windows average fewer rows: rolling_tw_kernel<.., kShort = true>
 
+constexpr int kLeanCap = 170;           // heads of the lean form (6 KB with the padded term array): windows of >= 3.8 rows; the host sends averages below 5 to the other forms
 template <bool kNulls, bool kTs32>
 struct TwCap { static constexpr int value = kTs32 ? (kNulls ? 208 : 240) : 464; };
 
@@ -58,12 +59,12 @@ struct TwCap { static constexpr int value = kTs32 ? (kNulls ? 208 : 240) : 464; 
 // before it, computed by the head's lane in the flag pass, where both are in registers.
 template <bool kNulls, bool kTs32, bool kLean>
 struct TwShared {
-    uint64_t val[kRowsT];                          // the column's staged values; then its step terms; then its trapezoid terms
+    uint64_t val[kLean ? swz_slots(kRowsT) : kRowsT];   // the column's staged values; then its step terms; then its trapezoid terms (kLean: padded - agg_device.h swz)
     // the time of every row, where the term pass reads a row's own and its previous point's: a 32-bit offset from slot 0 (kTs32) or the int64 itself
     typename std::conditional<kTs32, uint32_t, int64_t>::type tsx[kLean ? 1 : kRowsT];
     uint32_t vbits[kNulls ? kRowsT / 32 + 2 : 2];  // validity words of the value column for this tile
     // heads in row order: local row | on-window-start flag << 15 (kLean: see above)
-    typename std::conditional<kLean, uint32_t, uint16_t>::type seg[(kLean ? 248 : TwCap<kNulls, kTs32>::value) + 2];
+    typename std::conditional<kLean, uint32_t, uint16_t>::type seg[(kLean ? kLeanCap : TwCap<kNulls, kTs32>::value) + 2];
 };
 static_assert(sizeof(TwShared<false, true, false>) <= 8192 && sizeof(TwShared<true, true, false>) <= 8192, "LDS of the 32-bit forms: 8 KB");
 static_assert(sizeof(TwShared<false, false, false>) <= 11264 && sizeof(TwShared<true, false, false>) <= 11264, "LDS of the 64-bit forms: 11 KB");
@@ -112,7 +113,11 @@ __global__ __launch_bounds__(kWave, (kShort || kLean || (!kNulls && kTs32 && !kB
     static_assert(!(kWide && kTs32), "the wide form keeps 64-bit timestamps");
     static_assert(!kLean || (!kNulls && !kShort), "the lean form: one column without nulls, integrals only, terms from the flag pass");
     __shared__ TwShared<kNulls, kTs32, kLean> sh;
-    constexpr int kSegCapT = kLean ? 248 : TwCap<kNulls, kTs32>::value;
+    constexpr int kSegCapT = kLean ? kLeanCap : TwCap<kNulls, kTs32>::value;
+    // the padded layout of the term array (agg_device.h swz) where two walks per tile make LDS the busiest unit: both kinds of integral in the
+    // lean form.  (One kind: the three single steps in front of a window's first aligned group cost more than the bank conflicts did - same-box
+    // A/B at 1e8 rows, 16 .. 96 rows per window: +2 .. 4 % kernel time with the pads.)
+    constexpr bool kSwzT = kLean && kBoth;
     constexpr uint32_t kRowMask = kLean ? 0x3FFu : 0x7FFFu, kStartBit = kLean ? 0x400u : 0x8000u;
     const int64_t b = blockIdx.x;
     const int64_t tile = (b & 7) * tiles_per_xcd + (b >> 3);  // XCD-contiguous tile runs (look-ahead rows hit the same L2)
@@ -301,7 +306,7 @@ __global__ __launch_bounds__(kWave, (kShort || kLean || (!kNulls && kTs32 && !kB
             }
             if (need_trap) { q1 = (xp + xa) / 2 * dta; q2 = (xa + xb) / 2 * dtb; }
             const double oa = need_step ? s1 : q1, ob = need_step ? s2 : q2;
-            *reinterpret_cast<ulonglong2 *>(&sh.val[l]) = make_ulonglong2((uint64_t)__double_as_longlong(oa), (uint64_t)__double_as_longlong(ob));
+            *reinterpret_cast<ulonglong2 *>(&sh.val[swz<kSwzT>(l)]) = make_ulonglong2((uint64_t)__double_as_longlong(oa), (uint64_t)__double_as_longlong(ob));
             if (kKeep) { keep_a[kKeep ? j : 0] = q1; keep_b[kKeep ? j : 0] = q2; }
         }
     }
@@ -379,7 +384,7 @@ __global__ __launch_bounds__(kWave, (kShort || kLean || (!kNulls && kTs32 && !kB
                     if (!(two & 1u)) ra_ = fill;
                     if (!(two & 2u)) rb_ = fill;
                 }
-                *reinterpret_cast<ulonglong2 *>(&sh.val[l]) = make_ulonglong2(ra_, rb_);
+                *reinterpret_cast<ulonglong2 *>(&sh.val[swz<kSwzT>(l)]) = make_ulonglong2(ra_, rb_);
             }
         }
         // the next column's loads go out now: its registers are free (this column lives in LDS)
@@ -409,7 +414,7 @@ __global__ __launch_bounds__(kWave, (kShort || kLean || (!kNulls && kTs32 && !kB
 #pragma unroll
             for (int j = 0; j < kChunksT; j++) {
                 const int l = j * 128 + 2 * lane;
-                const ulonglong2 xv = *reinterpret_cast<const ulonglong2 *>(&sh.val[l]);
+                const ulonglong2 xv = *reinterpret_cast<const ulonglong2 *>(&sh.val[swz<kSwzT>(l)]);
                 const double xa = __longlong_as_double((long long)xv.x), xb = __longlong_as_double((long long)xv.y);
                 tkey_t ka, kb;
                 if (kTs32) { const uint2 k2 = *reinterpret_cast<const uint2 *>(&sh.tsx[l]); ka = (tkey_t)k2.x; kb = (tkey_t)k2.y; }
@@ -425,7 +430,7 @@ __global__ __launch_bounds__(kWave, (kShort || kLean || (!kNulls && kTs32 && !kB
                     // previous point of row a: the row before it; of row b: row a.  A head's slot: the value of the point before it (step:
                     // what the window's lane multiplies by the time left in the window before; trapezoid: the joining term)
                     const int lp = l > 0 ? l - 1 : 0;
-                    const double xp = (lane == 0 && j > 0) ? carry_x : __longlong_as_double((long long)sh.val[lp]);
+                    const double xp = (lane == 0 && j > 0) ? carry_x : __longlong_as_double((long long)sh.val[swz<kSwzT>(lp)]);
                     const double dta = dt_of(ka, (tkey_t)sh.tsx[lp]), dtb = dt_of(kb, ka);
                     if (need_step) {
                         sa = ha ? xp : xp * dta;
@@ -435,10 +440,10 @@ __global__ __launch_bounds__(kWave, (kShort || kLean || (!kNulls && kTs32 && !kB
                         qa = (xp + xa) / 2 * dta;
                         qb = (xa + xb) / 2 * dtb;
                     }
-                    if (j + 1 < kChunksT) carry_x = __longlong_as_double((long long)sh.val[j * 128 + 127]);
+                    if (j + 1 < kChunksT) carry_x = __longlong_as_double((long long)sh.val[swz<kSwzT>(j * 128 + 127)]);
                     lds_order();   // every lane has read this chunk's values
                     const double oa = first_is_step ? sa : qa, ob = first_is_step ? sb : qb;
-                    *reinterpret_cast<ulonglong2 *>(&sh.val[l]) = make_ulonglong2((uint64_t)__double_as_longlong(oa), (uint64_t)__double_as_longlong(ob));
+                    *reinterpret_cast<ulonglong2 *>(&sh.val[swz<kSwzT>(l)]) = make_ulonglong2((uint64_t)__double_as_longlong(oa), (uint64_t)__double_as_longlong(ob));
                 } else {
                     uint32_t two = (sh.vbits[j * 4 + (lane >> 4)] >> ((2 * lane) & 31)) & 3u;
                     if (l >= nl) two = 0u; else if (l + 1 >= nl) two &= 1u;
@@ -450,7 +455,7 @@ __global__ __launch_bounds__(kWave, (kShort || kLean || (!kNulls && kTs32 && !kB
                     const int pr = m ? wi * 32 + 31 - __clz((int)m) : -1;
                     const bool has_p = pr >= 0;
                     const int prc = has_p ? pr : 0;
-                    const double xp = __longlong_as_double((long long)sh.val[prc]);
+                    const double xp = __longlong_as_double((long long)sh.val[swz<kSwzT>(prc)]);
                     const tkey_t kp = (tkey_t)sh.tsx[prc];
                     // the same window?  (a head's previous point never is; a row that follows a head in its lane pair may not be either)
                     const uint32_t wa = wid_k(ka), wb = wid_k(kb), wp = wid_k(kp);
@@ -483,7 +488,7 @@ __global__ __launch_bounds__(kWave, (kShort || kLean || (!kNulls && kTs32 && !kB
                 lds_order();   // every gather of the pass is done
 #pragma unroll
                 for (int j = 0; j < kChunksT; j++)
-                    *reinterpret_cast<ulonglong2 *>(&sh.val[j * 128 + 2 * lane]) = make_ulonglong2(
+                    *reinterpret_cast<ulonglong2 *>(&sh.val[swz<kSwzT>(j * 128 + 2 * lane)]) = make_ulonglong2(
                         (uint64_t)__double_as_longlong(first_a[kFirst ? j : 0]), (uint64_t)__double_as_longlong(first_b[kFirst ? j : 0]));
             }
             }
@@ -511,8 +516,8 @@ __global__ __launch_bounds__(kWave, (kShort || kLean || (!kNulls && kTs32 && !kB
                 for (int j = 0; j < kChunksT; j++) {
                     const int l = j * 128 + 2 * lane;
                     const uint32_t two = sh.vbits[j * 4 + (lane >> 4)] >> ((2 * lane) & 31);
-                    if (!(two & 1u)) sh.val[l] = kNullAsNaN;
-                    if (!(two & 2u)) sh.val[l + 1] = kNullAsNaN;
+                    if (!(two & 1u)) sh.val[swz<kSwzT>(l)] = kNullAsNaN;
+                    if (!(two & 2u)) sh.val[swz<kSwzT>(l + 1)] = kNullAsNaN;
                 }
                 lds_order();
             }
@@ -522,7 +527,7 @@ __global__ __launch_bounds__(kWave, (kShort || kLean || (!kNulls && kTs32 && !kB
                 else if (kKeep) {
 #pragma unroll
                     for (int j = 0; j < kChunksT; j++)
-                        *reinterpret_cast<ulonglong2 *>(&sh.val[j * 128 + 2 * lane]) = make_ulonglong2(
+                        *reinterpret_cast<ulonglong2 *>(&sh.val[swz<kSwzT>(j * 128 + 2 * lane)]) = make_ulonglong2(
                             (uint64_t)__double_as_longlong(keep_a[kKeep ? j : 0]), (uint64_t)__double_as_longlong(keep_b[kKeep ? j : 0]));
                 }
                 lds_order();
@@ -570,12 +575,12 @@ __global__ __launch_bounds__(kWave, (kShort || kLean || (!kNulls && kTs32 && !kB
             // every reducer of the column in one walk over the window's valid rows, in row order (sum.go:16-22, minmax.go:16-28,
             // integral.go:14-31 / :46-62), then the inclusive row for the trapezoid
             if (has_value) {
-                first_raw = sh.val[fv];
+                first_raw = sh.val[swz<kSwzT>(fv)];
                 double pt = 0.0, pv = 0.0, step = 0.0, trap = 0.0;
                 int cnt = 0;
                 for (int r = fv; r <= lv; r++) {
                     if (kNulls && !((sh.vbits[r >> 5] >> (r & 31)) & 1u)) continue;
-                    const uint64_t raw = sh.val[r];
+                    const uint64_t raw = sh.val[swz<kSwzT>(r)];
                     const double x = __longlong_as_double((long long)raw), t = time_d((tkey_t)sh.tsx[r]);
                     sum += x;
                     if (cnt == 0) { mn = x; mx = x; }
@@ -591,7 +596,7 @@ __global__ __launch_bounds__(kWave, (kShort || kLean || (!kNulls && kTs32 && !kB
                 integ = step + pv * (last_value_d(wid) - abs_d(pt));
                 integ_t = trap;
                 if (incl_row && (!kNulls || ((sh.vbits[r1 >> 5] >> (r1 & 31)) & 1u))) {
-                    const double x = __longlong_as_double((long long)sh.val[r1]);
+                    const double x = __longlong_as_double((long long)sh.val[swz<kSwzT>(r1)]);
                     integ_t = trap + (pv + x) / 2 * (time_d((tkey_t)sh.tsx[r1]) - pt);
                     cnt++;
                 }
@@ -604,11 +609,11 @@ __global__ __launch_bounds__(kWave, (kShort || kLean || (!kNulls && kTs32 && !kB
             }
         } else if (phase <= 2) {
             if (has_value && need_vals) {
-                first_raw = sh.val[fv];
-                if (kNulls && pred_walk) walk_values_pred(sh.val, sh.vbits, fv, lv, sum, mn, mx);
-                else walk_values(sh.val, fv, lv, do_sum, do_mm, sum, mn, mx);
+                first_raw = sh.val[swz<kSwzT>(fv)];
+                if (kNulls && pred_walk) walk_values_pred<kSwzT>(sh.val, sh.vbits, fv, lv, sum, mn, mx);
+                else walk_values<kSwzT>(sh.val, fv, lv, do_sum, do_mm, sum, mn, mx);
                 if (need_fl) {
-                    last_raw = sh.val[lv];
+                    last_raw = sh.val[swz<kSwzT>(lv)];
                     if (cint) {   // the staged values are float64(v): First / Last return the Int64 itself (firstlast.go:17, :32)
                         const uint64_t *__restrict__ src = reinterpret_cast<const uint64_t *>(p.values[c]);
                         first_raw = src[base + fv];
@@ -619,13 +624,13 @@ __global__ __launch_bounds__(kWave, (kShort || kLean || (!kNulls && kTs32 && !kB
         } else if (has_value) {
             // the terms of the window's points after its first (the first point's own slot holds +0.0, or - when it is the window's
             // first row - what closes the window before), in row order
-            integ = walk_terms(sh.val, fv + 1, lv + 1);
+            integ = walk_terms<kSwzT>(sh.val, fv + 1, lv + 1);
             if (phase == 3) {
                 // + v0 * (float64(LastValue) - t0) of the last valid point (integral.go:49-55): staged in the next window's head slot
-                if (kLean && next_staged) integ = integ + __longlong_as_double((long long)sh.val[r1]);   // the next window's head slot: the closing product
+                if (kLean && next_staged) integ = integ + __longlong_as_double((long long)sh.val[swz<kSwzT>(r1)]);   // the next window's head slot: the closing product
                 else {
                     double pv, tlast;
-                    if (next_staged) pv = __longlong_as_double((long long)sh.val[r1]);   // the next window's head slot: the value of the point before it
+                    if (next_staged) pv = __longlong_as_double((long long)sh.val[swz<kSwzT>(r1)]);   // the next window's head slot: the value of the point before it
                     else {   // the data ends inside this window (one window per call): from the column itself
                         const uint64_t raw = reinterpret_cast<const uint64_t *>(p.values[c])[base + lv];
                         pv = cint ? (double)(int64_t)raw : __longlong_as_double((long long)raw);
@@ -637,7 +642,7 @@ __global__ __launch_bounds__(kWave, (kShort || kLean || (!kNulls && kTs32 && !kB
                 // the inclusive row (the successor's first row, when it sits on this window's end and is a valid point) joins in
                 int cnt = count;
                 if (incl_row && (!kNulls || ((sh.vbits[r1 >> 5] >> (r1 & 31)) & 1u))) {
-                    integ += __longlong_as_double((long long)sh.val[r1]);
+                    integ += __longlong_as_double((long long)sh.val[swz<kSwzT>(r1)]);
                     cnt++;
                 }
                 trap_nil = cnt < 2;
@@ -728,12 +733,13 @@ int launch_rolling_tw(Ctx *c, const SimpleParams &p, bool is_int, bool has_nulls
     if (grid > 0x7FFFFFFFll) return fail(BOWGPU_ERR_UNSUPPORTED, "too many rows for one launch: %lld", (long long)p.n);
     const dim3 g((unsigned)grid), blk(kWave);
     const bool both = (p.need & kNeedStep) && (p.need & kNeedTrap);
+    // the lean form: one value column without nulls, integrals only, windows of 5 rows and more on average (its head list: kLeanCap)
+    const bool lean = !has_nulls && p.ncols == 1 && !(p.need & (kNeedSum | kNeedMinMax | kNeedFirstLast)) && p.W > 0 && p.n / p.W >= 5;
     // the one-walk instantiation up to the window length where the phases take over (scratch/midw_sweep.py, 1e8 rows): a single kind of
-    // integral on a column without nulls 14 rows, with nulls or next to value reducers 20, both kinds 64 (44 with nulls)
-    const int64_t short_rows = both ? (has_nulls ? 44 : 64) : (has_nulls || (p.need & (kNeedSum | kNeedMinMax | kNeedFirstLast))) ? 20 : kShortAvgRows;
+    // integral on a column without nulls 14 rows, with nulls or next to value reducers 20; both kinds 12 where the lean form takes
+    // over (its padded term array: 0.385 against 0.413 ms at 12 rows per window, 0.436 against 0.562 at 48), else 64 (44 with nulls)
+    const int64_t short_rows = both ? (has_nulls ? 44 : lean ? 12 : 64) : (has_nulls || (p.need & (kNeedSum | kNeedMinMax | kNeedFirstLast))) ? 20 : kShortAvgRows;
     const bool shrt = p.W > 0 && p.n / p.W < short_rows;
-    // the lean form: one value column without nulls, integrals only, whatever the window length
-    const bool lean = !has_nulls && p.ncols == 1 && !(p.need & (kNeedSum | kNeedMinMax | kNeedFirstLast));
 #define BG_TW4(U, B, S, L)                                                                                                       \
     do {                                                                                                                          \
         if (wide) hipLaunchKernelGGL((rolling_tw_kernel<U, true, false, B, S, L>), g, blk, 0, c->stream, p, ntiles, per_xcd);      \
