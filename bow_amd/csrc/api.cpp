@@ -1360,16 +1360,17 @@ static int run_aggregate(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t 
 // An interval column WITH NULLS (ts_nulls.hip has the semantics: rolling.go:177-239 skips such rows, :143-154 counts windows from the
 // last valid timestamp, :162-173 ends the iteration at once when the physically last timestamp is null).  The call is rewritten
 // onto a dense interval column - nulls forward-filled - with every value column's validity ANDed with the rows that belong to a
-// window (and, for the time-weighted reducers, with the interval column's own validity), and then takes the ordinary path.
-// Exclusive windows of an unsharded call; NumRows (it counts rows, valid or not) and Mode are declined.
+// window (and, for the time-weighted reducers, with the interval column's own validity), and then takes the ordinary path into
+// device temporaries; NumRows is counted as Count over the rows that belong to a window; after an inclusive iteration the windows
+// behind a row on a window start with a null timestamp right behind it get the outputs of IntegralTrapezoid / WeightedAverageLinear
+// from ts_quirk_fix_kernel.  Unsharded calls; Mode is declined.
 static int run_aggregate_null_ts(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t ts_col, const Plan &plan, int inclusive,
                                  const bowgpu_agg *aggs, int32_t naggs, bowgpu_out *outs, DevCol &dts, int64_t *long_windows, double *kernel_ms) {
     const bowgpu_col *tsc = &cols[ts_col];
     const int64_t n = tsc->length, W = plan.W;
-    if (inclusive) return fail(BOWGPU_ERR_TS_NULLS, "interval column has %lld nulls and the windows are inclusive: outside the device path", (long long)dts.null_count);
     for (int i = 0; i < naggs; i++)
-        if (aggs[i].kind == BOWGPU_AGG_NUM_ROWS || aggs[i].kind == BOWGPU_AGG_MODE)
-            return fail(BOWGPU_ERR_TS_NULLS, "interval column has %lld nulls: NumRows / Mode over it are outside the device path", (long long)dts.null_count);
+        if (aggs[i].kind == BOWGPU_AGG_MODE)
+            return fail(BOWGPU_ERR_TS_NULLS, "interval column has %lld nulls: Mode over it is outside the device path", (long long)dts.null_count);
     for (int i = 0; i < ncols; i++)
         if (cols[i].length != n) return fail(BOWGPU_ERR_ARG, "column %d has %lld rows, interval column has %lld", i, (long long)cols[i].length, (long long)n);
     if (long_windows) *long_windows = 0;
@@ -1394,46 +1395,75 @@ static int run_aggregate_null_ts(Ctx *c, const bowgpu_col *cols, int32_t ncols, 
         }
         return 0;
     }
-    // the interval column forward-filled + which rows belong to a window
-    DevBuf ixbuf, ts_eff, keep, dropped;
+    // the interval column forward-filled + which rows belong to a window (+ inclusive: its validity without the rows ts_nulls.hip describes)
+    DevBuf ixbuf, ts_eff, keep, plain_ts, dropped;
     NbrIndex ix;
     BG_TRY(ixbuf.alloc(nbr_index_bytes(n, dts.vbit0)));
     BG_TRY(nbr_index_build(c, dts.vbits, dts.vbit0, n, ixbuf.p, &ix));
     BG_TRY(ts_eff.alloc((size_t)n * 8 + 16));
     const size_t bm_bytes = (size_t)((n + 63) >> 6) * 8 + 8;
     BG_TRY(keep.alloc(bm_bytes));
-    BG_TRY(dropped.alloc(8));
-    BG_TRY(launch_ts_nullfill(c, reinterpret_cast<const int64_t *>(dts.values), dts.vbits, dts.vbit0, n, ix, plan.s0, plan.magic,
-                              reinterpret_cast<int64_t *>(ts_eff.p), reinterpret_cast<uint64_t *>(keep.p), reinterpret_cast<unsigned long long *>(dropped.p)));
-    // one rewritten column per (input column, plain | time-weighted) that some reducer reads
+    if (inclusive) BG_TRY(plain_ts.alloc(bm_bytes));
+    BG_TRY(dropped.alloc(16));
+    BG_TRY(launch_ts_nullfill(c, reinterpret_cast<const int64_t *>(dts.values), dts.vbits, dts.vbit0, n, ix, plan.s0, plan.interval, plan.magic, inclusive,
+                              reinterpret_cast<int64_t *>(ts_eff.p), reinterpret_cast<uint64_t *>(keep.p), reinterpret_cast<uint64_t *>(plain_ts.p),
+                              reinterpret_cast<unsigned long long *>(dropped.p)));
+    // one rewritten column per (input column, class of reducer) that some reducer reads:
+    //   plain       value validity AND keep
+    //   step        IntegralStep / WeightedAverageStep: their points are the rows with timestamp AND value (bowgetters.go:299-311); they read
+    //               windows through UnsetInclusive, so after an inclusive iteration the rows ts_nulls.hip describes are not among them
+    //   linear      IntegralTrapezoid / WeightedAverageLinear: value validity AND the interval column's
+    //   rows        NumRows: Count over keep itself
+    enum { kPlain = 0, kStep = 1, kLinear = 2, kClasses = 3 };
     std::vector<bowgpu_col> cols2(cols, cols + ncols);
     std::vector<bowgpu_agg> aggs2(aggs, aggs + naggs);
     std::vector<DevCol> dcs(ncols);
     std::vector<DevBuf> bitmaps;
-    bitmaps.reserve(2 * (size_t)ncols);
-    std::vector<int> plain_of(ncols, -1), tw_of(ncols, -1);
+    bitmaps.reserve(kClasses * (size_t)ncols + 1);
+    std::vector<int> slot_of(kClasses * (size_t)ncols, -1);
+    int rows_slot = -1;
     {
         bowgpu_col &t = cols2[ts_col];
         t.values = ts_eff.p; t.validity = nullptr; t.offset = 0; t.length = n; t.null_count = 0; t.type = BOWGPU_INT64; t.residency = BOWGPU_DEVICE;
     }
+    auto device_col = [&](int col, const void **values, const uint32_t **vbits, int64_t *vbit0) -> int {
+        if (col == ts_col) { *values = dts.values; *vbits = dts.vbits; *vbit0 = dts.vbit0; return 0; }
+        DevCol &dc = dcs[col];
+        if (dc.values == nullptr) BG_TRY(devcol_prepare(c, &cols[col], &dc, true, true));
+        *values = dc.values; *vbits = dc.vbits; *vbit0 = dc.vbit0;
+        return 0;
+    };
+    bool any_linear = false;
     for (int i = 0; i < naggs; i++) {
-        if (!kind_reads_values(aggs[i].kind)) continue;
+        const int kind = aggs[i].kind;
+        if (kind == BOWGPU_AGG_NUM_ROWS) {
+            if (rows_slot < 0) {
+                bowgpu_col nc;
+                nc.values = ts_eff.p; nc.validity = reinterpret_cast<const uint8_t *>(keep.p); nc.offset = 0; nc.length = n; nc.null_count = -1;
+                nc.type = BOWGPU_INT64; nc.residency = BOWGPU_DEVICE;
+                rows_slot = (int)cols2.size();
+                cols2.push_back(nc);
+            }
+            aggs2[i].kind = BOWGPU_AGG_COUNT;
+            aggs2[i].col = rows_slot;
+            continue;
+        }
+        if (!kind_reads_values(kind)) continue;
         const int col = aggs[i].col;
-        const bool tw = aggs[i].kind >= BOWGPU_AGG_INTEGRAL_STEP && aggs[i].kind <= BOWGPU_AGG_WAVG_LINEAR;
-        int &slot = tw ? tw_of[col] : plain_of[col];
+        const bool linear = kind_needs_inclusive(kind);
+        const bool tw = kind >= BOWGPU_AGG_INTEGRAL_STEP && kind <= BOWGPU_AGG_WAVG_LINEAR;
+        const int cls = linear ? kLinear : tw ? kStep : kPlain;
+        any_linear |= linear;
+        int &slot = slot_of[(size_t)cls * ncols + col];
         if (slot < 0) {
             const uint32_t *vbits; int64_t vbit0; const void *values;
-            if (col == ts_col) { values = dts.values; vbits = dts.vbits; vbit0 = dts.vbit0; }
-            else {
-                DevCol &dc = dcs[col];
-                if (dc.values == nullptr) BG_TRY(devcol_prepare(c, &cols[col], &dc, true, true));
-                values = dc.values; vbits = dc.vbits; vbit0 = dc.vbit0;
-            }
+            BG_TRY(device_col(col, &values, &vbits, &vbit0));
             bitmaps.emplace_back();
             DevBuf &bm = bitmaps.back();
             BG_TRY(bm.alloc(bm_bytes));
-            if (tw) BG_TRY(launch_and_bits(c, vbits, vbit0, dts.vbits, dts.vbit0, n, reinterpret_cast<uint64_t *>(bm.p)));
-            else BG_TRY(launch_and_bits(c, vbits, vbit0, reinterpret_cast<const uint32_t *>(keep.p), 0, n, reinterpret_cast<uint64_t *>(bm.p)));
+            if (cls == kPlain) BG_TRY(launch_and_bits(c, vbits, vbit0, reinterpret_cast<const uint32_t *>(keep.p), 0, n, reinterpret_cast<uint64_t *>(bm.p)));
+            else if (cls == kStep && inclusive) BG_TRY(launch_and_bits(c, vbits, vbit0, reinterpret_cast<const uint32_t *>(plain_ts.p), 0, n, reinterpret_cast<uint64_t *>(bm.p)));
+            else BG_TRY(launch_and_bits(c, vbits, vbit0, dts.vbits, dts.vbit0, n, reinterpret_cast<uint64_t *>(bm.p)));
             bowgpu_col nc;
             nc.values = values; nc.validity = reinterpret_cast<const uint8_t *>(bm.p); nc.offset = 0; nc.length = n; nc.null_count = -1;
             nc.type = cols[col].type; nc.residency = BOWGPU_DEVICE;
@@ -1442,7 +1472,67 @@ static int run_aggregate_null_ts(Ctx *c, const bowgpu_col *cols, int32_t ncols, 
         }
         aggs2[i].col = slot;
     }
-    return run_aggregate(c, cols2.data(), (int32_t)cols2.size(), ts_col, plan, 0, aggs2.data(), naggs, outs, 0, W, long_windows, kernel_ms);
+    // the ordinary path, into device temporaries
+    const size_t vb = (size_t)((W + 7) >> 3);
+    std::vector<DevBuf> tvals(naggs), tbits(naggs);
+    std::vector<bowgpu_out> touts(naggs);
+    for (int i = 0; i < naggs; i++) {
+        BG_TRY(tvals[i].alloc((size_t)W * 8 + 8));
+        BG_TRY(tbits[i].alloc(((vb + 3) & ~(size_t)3) + 8));
+        bowgpu_out &t = touts[i];
+        t.values = tvals[i].p; t.validity = reinterpret_cast<uint8_t *>(tbits[i].p); t.length = W; t.null_count = 0; t.type = 0; t.residency = BOWGPU_DEVICE;
+    }
+    BG_TRY(run_aggregate(c, cols2.data(), (int32_t)cols2.size(), ts_col, plan, inclusive, aggs2.data(), naggs, touts.data(), 0, W, long_windows, kernel_ms));
+    for (int i = 0; i < naggs; i++)
+        if (aggs[i].kind == BOWGPU_AGG_NUM_ROWS) {
+            BG_TRY(launch_count_to_f64(c, reinterpret_cast<uint64_t *>(tvals[i].p), W));
+            touts[i].type = BOWGPU_FLOAT64;
+        }
+    if (inclusive && any_linear) {
+        unsigned long long *d_fixed = reinterpret_cast<unsigned long long *>(dropped.p) + 1;
+        BG_HIP(hipMemsetAsync(d_fixed, 0, 8, c->stream));
+        std::vector<int> fixed;
+        QuirkFix fx;
+        fx.naggs = 0; fx._pad = 0;
+        auto flush = [&]() -> int {
+            if (fx.naggs) BG_TRY(launch_ts_quirk_fix(c, reinterpret_cast<const int64_t *>(dts.values), dts.vbits, dts.vbit0, n, ix, plan.s0, plan.interval, plan.magic,
+                                                    W, fx, d_fixed));
+            fx.naggs = 0;
+            return 0;
+        };
+        for (int i = 0; i < naggs; i++) {
+            if (!kind_needs_inclusive(aggs[i].kind)) continue;
+            QuirkFixAgg &fa = fx.a[fx.naggs++];
+            BG_TRY(device_col(aggs[i].col, &fa.values, &fa.vbits, &fa.vbit0));
+            fa.out_values = reinterpret_cast<uint64_t *>(tvals[i].p); fa.out_valid = reinterpret_cast<uint32_t *>(tbits[i].p);
+            fa.type = cols[aggs[i].col].type; fa.kind = aggs[i].kind; fa.n_factors = aggs[i].n_factors; fa._pad = 0;
+            for (int f = 0; f < BOWGPU_MAX_FACTORS; f++) fa.factors[f] = aggs[i].factors[f];
+            fixed.push_back(i);
+            if (fx.naggs == 8) BG_TRY(flush());
+        }
+        BG_TRY(flush());
+        // their null counts again
+        void *dscr;
+        BG_TRY(ctx_scratch(c, 8192, &dscr));
+        uint64_t *dcnt = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(dscr) + 1024);
+        for (int i : fixed) {
+            uint64_t hcnt = 0;
+            BG_TRY(launch_popcount(c, reinterpret_cast<const uint32_t *>(tbits[i].p), 0, W, dcnt));
+            BG_HIP(hipMemcpyAsync(&hcnt, dcnt, 8, hipMemcpyDeviceToHost, c->stream));
+            BG_HIP(hipStreamSynchronize(c->stream));
+            touts[i].null_count = W - (int64_t)hcnt;
+        }
+    }
+    // ... and on to the caller's columns
+    for (int i = 0; i < naggs; i++) {
+        DevOut d;
+        BG_TRY(devout_prepare(c, &outs[i], W, &d, i));
+        BG_HIP(hipMemcpyAsync(d.values, tvals[i].p, (size_t)W * 8, hipMemcpyDeviceToDevice, c->stream));
+        BG_HIP(hipMemcpyAsync(d.validity, tbits[i].p, vb, hipMemcpyDeviceToDevice, c->stream));
+        BG_TRY(devout_finish(c, &d, W, touts[i].type, touts[i].null_count, true));
+        BG_HIP(hipStreamSynchronize(c->stream));
+    }
+    return 0;
 }
 
 // An unsharded Aggregate call: the streaming reducers in batches that one launch of the tile kernels takes (at most kMaxAggs

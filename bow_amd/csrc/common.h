@@ -297,8 +297,21 @@ int launch_mode(Ctx *c, const int64_t *ts, const int64_t *first_idx, int64_t n, 
                 int64_t *n_mid, int64_t *n_long);
 
 // ts_nulls.hip: an interval column with nulls rewritten for the tile kernels (forward-filled timestamps, the rows that belong to a window)
-int launch_ts_nullfill(Ctx *c, const int64_t *ts, const uint32_t *tbits, int64_t tbit0, int64_t n, const struct NbrIndex &ix, int64_t s0,
-                       const MagicDiv &magic, int64_t *ts_eff, uint64_t *keep, unsigned long long *d_dropped);
+// (inclusive: the keep rule of inclusive windows; plain - inclusive only - receives the interval column's validity without the rows
+// that sit on a window start with a null timestamp right behind them: ts_nulls.hip)
+int launch_ts_nullfill(Ctx *c, const int64_t *ts, const uint32_t *tbits, int64_t tbit0, int64_t n, const struct NbrIndex &ix, int64_t s0, int64_t interval,
+                       const MagicDiv &magic, int inclusive, int64_t *ts_eff, uint64_t *keep, uint64_t *plain, unsigned long long *d_dropped);
+// the outputs of IntegralTrapezoid / WeightedAverageLinear for the windows behind such rows, recomputed by a walk in the reference's order
+struct QuirkFixAgg {
+    const void *values; const uint32_t *vbits; int64_t vbit0;     // the reducer's input column (its own validity)
+    uint64_t *out_values; uint32_t *out_valid;                    // its output: 8-byte slots, validity words (bit 0 = window 0)
+    int32_t type, kind, n_factors, _pad;
+    double factors[BOWGPU_MAX_FACTORS];
+};
+struct QuirkFix { int32_t naggs, _pad; QuirkFixAgg a[8]; };
+int launch_ts_quirk_fix(Ctx *c, const int64_t *ts, const uint32_t *tbits, int64_t tbit0, int64_t n, const struct NbrIndex &ix, int64_t s0, int64_t interval,
+                        const MagicDiv &magic, int64_t W, const QuirkFix &fx, unsigned long long *d_fixed);
+int launch_count_to_f64(Ctx *c, uint64_t *v, int64_t n);
 int launch_and_bits(Ctx *c, const uint32_t *a, int64_t abit0, const uint32_t *b, int64_t bbit0, int64_t n, uint64_t *out);
 
 // shard.hip

@@ -1,4 +1,4 @@
-// ts_nulls.hip — the device path for an interval column WITH NULLS (Rolling.Aggregate, exclusive windows).
+// ts_nulls.hip — the device path for an interval column WITH NULLS (Rolling.Aggregate; exclusive and inclusive windows).
 //
 // The reference's window walk (rolling/rolling.go:177-239) skips a row whose interval value is null (:190-193): the row neither
 // ends a window nor extends it, but the window's slice is [first row, last taken row + 1) (:224-228), so a null row that lies
@@ -15,9 +15,10 @@
 // with every value column's validity ANDed with `keep` (a row outside every slice is never read) and, for the time-weighted
 // reducers - their points are the rows where timestamp AND value are valid (bowgetters.go:299-311 GetNextFloat64s) - with the
 // interval column's own validity too.  Cost: one more pass over the interval column (8 B read + 8 B written per row) and n / 8 bytes
-// per bitmap; the reference's Go loop runs at ~1e7 rows/s.  The only reducer this cannot serve is NumRows (the test closure of
-// aggregation_test.go:28-31 counts rows, valid or not): such a call is declined.
+// per bitmap; the reference's Go loop runs at ~1e7 rows/s.  NumRows (the test closure of aggregation_test.go:28-31 counts the rows of
+// the slice, valid or not) is Count over the keep bits.
 #include "bitmap_device.h"
+#include "agg_device.h"
 
 namespace bowgpu {
 
@@ -27,30 +28,122 @@ __device__ __forceinline__ uint64_t wid_of(int64_t t, int64_t s0, const MagicDiv
     return t < s0 ? 0ull : magic_div((uint64_t)t - (uint64_t)s0, magic);   // rows below s0 ride in window 0 (rolling.go:194-196)
 }
 
-// one lane per row, 64 rows per wavefront: the keep bits of a wavefront's rows are one 64-bit word of the bitmap (bit 0 = row 0)
+// INCLUSIVE iteration (Options.Inclusive, or a reducer of the call asks for it - IntegralTrapezoid / WeightedAverageLinear,
+// aggregation.go:183-185 - and then for every reducer of the call: the others see each window through UnsetInclusive, window.go:23-31).
+// A window w also takes the first valid row whose timestamp equals its end E (rolling.go:201-209), so
+//   - the null rows between its last row below E and that row lie inside its slice:   keep |= ts[q] == start(wid(ts[p]) + 1)
+//   - the next window starts at `rowIndex - 1` (:214-218), the row in front of the one that ended the scan.  That is the inclusive row
+//     itself - unless null rows follow it: then it is the LAST of those null rows, and the next window, w + 1, begins there WITHOUT the
+//     row that sits on its start.  Such a row i ("a row on a window start, the first with that timestamp, not in window 0,
+//     with a null timestamp right behind it") belongs to window w only, and there only as the inclusive row; the null rows behind it
+//     belong to no slice, except the last one, which opens the slice of w + 1 when w + 1 takes a row at all.
+// In the rewritten call: such a row is invisible (validity 0) to every reducer that reads windows through UnsetInclusive - they see it
+// neither in w (the inclusive row is dropped) nor in w + 1 - which is every reducer but the two that need inclusive windows; for
+// those two the row must stay the end point of w, so the tile kernels compute w + 1 WITH it, and ts_quirk_fix_kernel below recomputes
+// their outputs for those windows afterwards, walking the rows the way the reference does.
+__device__ __forceinline__ bool on_later_start(int64_t t, int64_t s0, int64_t interval, const MagicDiv &magic) {
+    if (t < s0) return false;
+    const uint64_t d = (uint64_t)t - (uint64_t)s0, q = magic_div(d, magic);
+    return q >= 1 && q * (uint64_t)interval == d;
+}
+// row i (timestamp valid) is such a row
+__device__ __forceinline__ bool quirk_row(const int64_t *__restrict__ ts, const uint32_t *__restrict__ tbits, int64_t tbit0, int64_t n, const NbrIndex &ix,
+                                          int64_t s0, int64_t interval, const MagicDiv &magic, int64_t i) {
+    if (i + 1 >= n || bit_at(tbits, tbit0, i + 1)) return false;
+    const int64_t t = ts[i];
+    if (!on_later_start(t, s0, interval, magic)) return false;
+    const int64_t pp = prev_valid_ix(tbits, tbit0, n, i - 1, ix);
+    return pp < 0 || ts[pp] < t;
+}
+
+// one lane per row, 64 rows per wavefront: the keep bits of a wavefront's rows are one 64-bit word of the bitmap (bit 0 = row 0).
+// plain (inclusive only, else nullptr): the interval column's validity without the rows described above.
 __global__ __launch_bounds__(256) void ts_nullfill_kernel(const int64_t *__restrict__ ts, const uint32_t *__restrict__ tbits, const int64_t tbit0,
-                                                          const int64_t n, const NbrIndex ix, const int64_t s0, const MagicDiv magic,
-                                                          int64_t *__restrict__ ts_eff, uint64_t *__restrict__ keep, unsigned long long *n_dropped) {
+                                                          const int64_t n, const NbrIndex ix, const int64_t s0, const int64_t interval, const MagicDiv magic,
+                                                          const int inclusive, int64_t *__restrict__ ts_eff, uint64_t *__restrict__ keep,
+                                                          uint64_t *__restrict__ plain, unsigned long long *n_dropped) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool k = false, dropped = false;
+    bool k = false, dropped = false, quirk = false, tv = false;
     if (i < n) {
         if (bit_at(tbits, tbit0, i)) {
             ts_eff[i] = ts[i];
-            k = true;
+            tv = true;
+            quirk = inclusive && quirk_row(ts, tbits, tbit0, n, ix, s0, interval, magic, i);
+            k = !quirk;
         } else {
             const int64_t p = prev_valid_ix(tbits, tbit0, n, i - 1, ix);   // (row 0 is valid: the constructor checked it, rolling.go:89-93)
             const int64_t q = next_valid_ix(tbits, tbit0, n, i + 1, ix);
             const int64_t tp = p >= 0 ? ts[p] : s0;
             ts_eff[i] = tp;
-            k = p >= 0 && q >= 0 && wid_of(tp, s0, magic) == wid_of(ts[q], s0, magic);
+            if (p >= 0 && q >= 0) {
+                const int64_t tq = ts[q];
+                const uint64_t wp = wid_of(tp, s0, magic);
+                k = wp == wid_of(tq, s0, magic);
+                if (inclusive) {
+                    k = k || (tq >= s0 && (uint64_t)tq - (uint64_t)s0 == (wp + 1) * (uint64_t)interval);
+                    if (quirk_row(ts, tbits, tbit0, n, ix, s0, interval, magic, p)) k = k && i == q - 1;
+                }
+            }
             dropped = !k;
         }
     }
-    const unsigned long long m = __ballot(k), d = __ballot(dropped);
+    const unsigned long long m = __ballot(k), d = __ballot(dropped || quirk), pm = __ballot(tv && !quirk);
     if ((threadIdx.x & 63) == 0) {
-        if (i < n) keep[i >> 6] = m;
+        if (i < n) { keep[i >> 6] = m; if (plain) plain[i >> 6] = pm; }
         if (d) atomicAdd(n_dropped, (unsigned long long)__popcll(d));
     }
+}
+
+// The two reducers that need inclusive windows, for the windows described above: thread i finds out whether row i is such a row; if
+// so it walks the window that starts at ts[i] as rolling.go:188-212 does from the row in front of the next valid timestamp - rows below
+// the window's end, then the first row on it - and integral.go:14-31 over the points among them (timestamp and value valid:
+// bowgetters.go:299-311), and overwrites the window's slot in the outputs of those reducers.
+__global__ __launch_bounds__(256) void ts_quirk_fix_kernel(const int64_t *__restrict__ ts, const uint32_t *__restrict__ tbits, const int64_t tbit0,
+                                                           const int64_t n, const NbrIndex ix, const int64_t s0, const int64_t interval, const MagicDiv magic,
+                                                           const int64_t W, const QuirkFix fx, unsigned long long *n_fixed) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !bit_at(tbits, tbit0, i)) return;
+    if (!quirk_row(ts, tbits, tbit0, n, ix, s0, interval, magic, i)) return;
+    const int64_t start = ts[i];
+    const uint64_t slot = magic_div((uint64_t)start - (uint64_t)s0, magic);
+    if (slot >= (uint64_t)W) return;
+    const int64_t end = (int64_t)((uint64_t)start + (uint64_t)interval);
+    const bool open_end = end < start;                 // (the end wraps: no timestamp reaches it)
+    const int64_t b = next_valid_ix(tbits, tbit0, n, i + 1, ix);
+    atomicAdd(n_fixed, 1ull);
+    for (int a = 0; a < fx.naggs; a++) {
+        const QuirkFixAgg &fa = fx.a[a];
+        double sum = 0.0, t0 = 0.0, v0 = 0.0;
+        bool have = false, ok = false, took_end = false;
+        for (int64_t r = b; r >= 0 && r < n; r++) {
+            if (!bit_at(tbits, tbit0, r)) continue;
+            const int64_t t = ts[r];
+            if (!open_end) {
+                if (t > end) break;
+                if (t == end) { if (took_end) break; took_end = true; }
+            }
+            if (!bit_at(fa.vbits, fa.vbit0, r)) continue;
+            const uint64_t raw = reinterpret_cast<const uint64_t *>(fa.values)[r];
+            const double v1 = fa.type == BOWGPU_INT64 ? (double)(int64_t)raw : __longlong_as_double((long long)raw), t1 = (double)t;
+            if (have) { sum += (v0 + v1) / 2 * (t1 - t0); ok = true; }     // integral.go:24
+            t0 = t1; v0 = v1; have = true;
+        }
+        uint64_t bits = 0;
+        if (ok) {
+            if (fa.kind == BOWGPU_AGG_WAVG_LINEAR) sum = sum / (double)interval;    // weightedmean.go:29-33: LastValue - FirstValue
+            bits = apply_factors((uint64_t)__double_as_longlong(sum), false, fa.n_factors, fa.factors);
+        }
+        fa.out_values[slot] = bits;
+        if (ok) atomicOr(&fa.out_valid[slot >> 5], 1u << (slot & 31));
+        else atomicAnd(&fa.out_valid[slot >> 5], ~(1u << (slot & 31)));
+    }
+}
+
+// NumRows of a call over an interval column with nulls is counted as Count over the keep bits (Int64): float64(count) in place
+// (aggregation_test.go:28-31 returns float64(w.Bow.NumRows()))
+__global__ __launch_bounds__(256) void count_to_f64_kernel(uint64_t *__restrict__ v, const int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = (uint64_t)__double_as_longlong((double)(int64_t)v[i]);
 }
 
 // out (bit 0 = row 0, whole 64-bit words) = a AND b; a / b: Arrow bitmaps at any bit offset, nullptr = all ones
@@ -75,12 +168,28 @@ __global__ __launch_bounds__(256) void and_bits_kernel(const uint32_t *__restric
 
 }  // namespace
 
-int launch_ts_nullfill(Ctx *c, const int64_t *ts, const uint32_t *tbits, int64_t tbit0, int64_t n, const NbrIndex &ix, int64_t s0,
-                       const MagicDiv &magic, int64_t *ts_eff, uint64_t *keep, unsigned long long *d_dropped) {
+int launch_ts_nullfill(Ctx *c, const int64_t *ts, const uint32_t *tbits, int64_t tbit0, int64_t n, const NbrIndex &ix, int64_t s0, int64_t interval,
+                       const MagicDiv &magic, int inclusive, int64_t *ts_eff, uint64_t *keep, uint64_t *plain, unsigned long long *d_dropped) {
     if (n <= 0) return 0;
     BG_HIP(hipMemsetAsync(d_dropped, 0, 8, c->stream));
-    hipLaunchKernelGGL(ts_nullfill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, ts, tbits, tbit0, n, ix, s0, magic, ts_eff, keep,
-                       d_dropped);
+    hipLaunchKernelGGL(ts_nullfill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, ts, tbits, tbit0, n, ix, s0, interval, magic, inclusive,
+                       ts_eff, keep, plain, d_dropped);
+    BG_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_ts_quirk_fix(Ctx *c, const int64_t *ts, const uint32_t *tbits, int64_t tbit0, int64_t n, const NbrIndex &ix, int64_t s0, int64_t interval,
+                        const MagicDiv &magic, int64_t W, const QuirkFix &fx, unsigned long long *d_fixed) {
+    if (n <= 0 || fx.naggs == 0) return 0;
+    hipLaunchKernelGGL(ts_quirk_fix_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, ts, tbits, tbit0, n, ix, s0, interval, magic, W, fx,
+                       d_fixed);
+    BG_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_count_to_f64(Ctx *c, uint64_t *v, int64_t n) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(count_to_f64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, v, n);
     BG_HIP(hipGetLastError());
     return 0;
 }

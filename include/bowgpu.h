@@ -62,8 +62,8 @@ enum {
     BOWGPU_ERR_ARG = -10,
     BOWGPU_ERR_NO_DEVICE = -11,      /* no HIP device / runtime: the product path has no CPU fallback */
     BOWGPU_ERR_HIP = -12,            /* a HIP call failed; message has the hipError string */
-    BOWGPU_ERR_TS_NULLS = -13,       /* interval column has nulls AND the call has inclusive windows, NumRows, Mode or is sharded: the
-                                        device path declines (caller keeps the reference path); exclusive windows are served */
+    BOWGPU_ERR_TS_NULLS = -13,       /* interval column has nulls AND the call has Mode, is sharded or is Rolling.Interpolate / Fill: the
+                                        device path declines (caller keeps the reference path); Aggregate is served otherwise */
     BOWGPU_ERR_TS_UNSORTED = -14,    /* interval column not ascending: device path declines */
     BOWGPU_ERR_OOM = -15
 };
@@ -232,7 +232,8 @@ int bowgpu_plan_windows_ex(const bowgpu_col *ts, int64_t interval, int64_t offse
  * Device-path contract: interval column Int64, its valid values ascending (else BOWGPU_ERR_TS_UNSORTED: the caller keeps the
  * reference's own path); value columns Float64 or Int64.  Nulls in the interval column (rolling.go:190-193: such a row neither
  * ends nor extends a window, yet lies inside its window's slice when rows of the same window surround it) are served for
- * exclusive windows; with inclusive windows, NumRows or Mode the call is BOWGPU_ERR_TS_NULLS. */
+ * exclusive and inclusive iterations alike (incl. rolling.go:214-218's `rowIndex - 1` when a null follows an inclusive row);
+ * with Mode the call is BOWGPU_ERR_TS_NULLS. */
 int bowgpu_rolling_aggregate(const bowgpu_col *cols, int32_t ncols, int32_t ts_col,
                              int64_t interval, const bowgpu_options *opts,
                              const bowgpu_agg *aggs, int32_t naggs, bowgpu_out *outs,

@@ -499,14 +499,12 @@ def test_declines_unsorted_timestamps_and_what_null_timestamps_cannot_have():
     with pytest.raises(capi.BowGpuError) as e:
         capi.rolling_aggregate([capi.Column(ts), capi.Column(v)], 0, 4, [("WindowStart", 0), ("Sum", 1)])
     assert e.value.code == -14
-    # null timestamps: served on the device for exclusive windows (test_null_timestamps_*), declined - BOWGPU_ERR_TS_NULLS - for
-    # inclusive windows, NumRows and Mode
+    # null timestamps: served on the device (test_null_timestamps_*: exclusive and inclusive windows, NumRows), declined -
+    # BOWGPU_ERR_TS_NULLS - for Mode
     tsn = capi.Column.from_list([1, None, 3, 9], "int64")
-    for aggs, incl in (([("WindowStart", 0), ("IntegralTrapezoid", 1)], False), ([("WindowStart", 0), ("Sum", 1)], True),
-                       ([("WindowStart", 0), ("NumRows", 1)], False), ([("WindowStart", 0), ("Mode", 1)], False)):
-        with pytest.raises(capi.BowGpuError) as e:
-            capi.rolling_aggregate([tsn, capi.Column(v[:4])], 0, 4, aggs, inclusive=incl)
-        assert e.value.code == -13, aggs
+    with pytest.raises(capi.BowGpuError) as e:
+        capi.rolling_aggregate([tsn, capi.Column(v[:4])], 0, 4, [("WindowStart", 0), ("Mode", 1)])
+    assert e.value.code == -13
     with pytest.raises(capi.BowGpuError) as e:  # first ts null is the reference's own ctor error (rolling.go:89-93)
         capi.rolling_aggregate([capi.Column.from_list([None, 2, 3, 9], "int64"), capi.Column(v[:4])], 0, 4,
                                [("WindowStart", 0), ("Sum", 1)])
@@ -689,7 +687,26 @@ NULL_TS_AGGS = [("WindowStart", 0), ("Sum", 1), ("ArithmeticMean", 1), ("Min", 1
                 ("IntegralStep", 1), ("WeightedAverageStep", 1), ("Sum", 0), ("Count", 0), ("Last", 0), ("WeightedAverageStep", 0)]
 
 
-def _run_null_ts(ts, tvalid, vals, vvalid, interval, offset=0, aggs=NULL_TS_AGGS, device=False):
+# ... and what an INCLUSIVE iteration adds (Options.Inclusive, or one of the two reducers that ask for it - aggregation.go:183-185):
+# the two themselves, NumRows, a Factor on one of them
+NULL_TS_AGGS_INCL = NULL_TS_AGGS + [("NumRows", 1), ("IntegralTrapezoid", 1), ("WeightedAverageLinear", 1), ("IntegralTrapezoid", 0),
+                                    ("WeightedAverageLinear", 1, [2.5])]
+
+
+def _rows_on_a_start_with_a_null_behind(ts, tvalid, s0, interval):
+    """the rows ts_nulls.hip singles out after an inclusive iteration: on a window start (not window 0's), the first with that
+    timestamp, the next row's timestamp null (the next window begins at `rowIndex - 1`, rolling.go:214-218)"""
+    n = len(ts)
+    idx = np.arange(n)
+    prev = np.maximum.accumulate(np.where(tvalid, idx, -1))
+    hit = np.zeros(n, bool)
+    hit[:-1] = tvalid[:-1] & ~tvalid[1:] & (ts[:-1] >= s0 + interval) & ((ts[:-1] - s0) % interval == 0)
+    pp = np.concatenate(([-1], prev[:-1]))
+    hit &= (pp < 0) | (ts[np.maximum(pp, 0)] < ts)
+    return int(hit.sum())
+
+
+def _run_null_ts(ts, tvalid, vals, vvalid, interval, offset=0, aggs=NULL_TS_AGGS, device=False, inclusive=False):
     n = len(ts)
     tbm = np.packbits(tvalid, bitorder="little")
     vbm = None if vvalid is None else np.packbits(vvalid, bitorder="little")
@@ -697,17 +714,20 @@ def _run_null_ts(ts, tvalid, vals, vvalid, interval, offset=0, aggs=NULL_TS_AGGS
     if device:
         ccols = [c.to_device() for c in ccols]
     ocols = [orc.Column(ts, tbm, orc.INT64), orc.Column(vals, vbm, orc.FLOAT64)]
-    want, nic = orc.aggregate(ocols, 0, interval, aggs, offset=offset)
+    want, nic = orc.aggregate(ocols, 0, interval, aggs, offset=offset, inclusive=inclusive)
     bounds = None
     for label in capi.agg_routes():
-        got, info = capi.rolling_aggregate(ccols, 0, interval, aggs, offset=offset, out_residency=capi.DEVICE if device else capi.HOST)
+        got, info = capi.rolling_aggregate(ccols, 0, interval, aggs, offset=offset, inclusive=inclusive,
+                                           out_residency=capi.DEVICE if device else capi.HOST)
         assert info.new_interval_col == nic
         if info.long_windows and bounds is None:
             # (the bound's magnitudes: the oracle over |x| on the SAME frame, null timestamps included)
-            bounds = order_free_bounds(ocols, 0, interval, aggs, offset=offset, ref=want)
-        for i, ((k, _c), g, w) in enumerate(zip(aggs, got, want)):
+            bounds = order_free_bounds(ocols, 0, interval, aggs, offset=offset, ref=want, inclusive=inclusive)
+        for i, (a, g, w) in enumerate(zip(aggs, got, want)):
+            k, _c = a[0], a[1]
             exact = info.long_windows == 0 or k not in ORDER_SENSITIVE
-            compare("null ts %s col %d path=%s n=%d I=%d" % (k, _c, label, n, interval), g, w, exact=exact, bound=None if exact else bounds[i])
+            compare("null ts %s col %d path=%s n=%d I=%d incl=%d" % (k, _c, label, n, interval, inclusive), g, w, exact=exact,
+                    bound=None if exact else bounds[i])
     return want
 
 
@@ -723,6 +743,43 @@ def test_null_timestamps_against_the_oracle(null_frac):
                                       (6000, 10, 3, "negative")]:
         ts, tvalid, vals, vvalid = _null_ts_frame(rng, n, null_frac, mode)
         _run_null_ts(ts, tvalid, vals, vvalid, interval, offset, device=(n % 2 == 0))
+
+
+@pytest.mark.parametrize("null_frac", [0.02, 0.3, 0.9])
+def test_null_timestamps_inclusive_windows_against_the_oracle(null_frac):
+    """An inclusive iteration over an interval column with nulls (rolling.go:201-218): the window also takes the first row ON its
+    end, the null rows in front of that row lie inside its slice, and the next window starts at `rowIndex - 1` - the inclusive row
+    itself, or, when null rows follow it, the last of THEM: that window then begins without the row on its start.
+    Every reducer incl. NumRows and the two that ask for inclusive windows, Options.Inclusive set or only implied, every route;
+    frames where rows sit on window starts all the time (dense / dups timestamps, small intervals) so the A.5 case is common."""
+    rng = np.random.default_rng(1000 + int(null_frac * 100))
+    seen = 0
+    for n, interval, offset, mode in [(1, 10, 0, "dense"), (2, 3, 1, "dense"), (700, 5, 2, "dups"), (3000, 10, 0, "irregular"),
+                                      (5000, 64, 7, "gappy"), (40_000, 25, -3, "irregular"), (40_000, 4000, 11, "dense"),
+                                      (6000, 10, 3, "negative"), (5000, 1, 0, "dups"), (20_000, 4, 1, "dense")]:
+        ts, tvalid, vals, vvalid = _null_ts_frame(rng, n, null_frac, mode)
+        s0, _W = orc.plan_windows(orc.Column(ts, np.packbits(tvalid, bitorder="little"), orc.INT64), interval, offset)
+        seen += _rows_on_a_start_with_a_null_behind(ts, tvalid, s0, interval)
+        _run_null_ts(ts, tvalid, vals, vvalid, interval, offset, aggs=NULL_TS_AGGS_INCL, device=(n % 2 == 0), inclusive=(n % 3 == 0))
+        # Options.Inclusive alone, no reducer that asks for it: everything is read through UnsetInclusive, but the slices are the inclusive iteration's
+        _run_null_ts(ts, tvalid, vals, vvalid, interval, offset, aggs=NULL_TS_AGGS + [("NumRows", 0)], device=(n % 2 == 1), inclusive=True)
+    assert seen > 50
+
+
+def test_null_timestamps_numrows_counts_the_rows_of_the_slice():
+    ts = np.array([10, 11, 12, 13, 20, 21, 22, 30, 31, 45, 46], dtype=np.int64)
+    vals = np.arange(1.0, 12.0)
+    tvalid = np.ones(len(ts), bool)
+    tvalid[[1, 2]] = False      # between taken rows of window [10, 20): inside the slice
+    tvalid[[5, 6]] = False      # behind the last taken row of [20, 30): in no slice
+    want = _run_null_ts(ts, tvalid, vals, None, 10, aggs=[("WindowStart", 0), ("NumRows", 1), ("Count", 1)])
+    assert want[1].to_list() == [4.0, 1.0, 2.0, 2.0] and want[2].to_list() == [4, 1, 2, 2]
+    # the A.5 case by hand: 20 sits on a start, a null behind it -> [20, 30) begins at the null row in front of 21, without row 20
+    tvalid = np.ones(len(ts), bool)
+    tvalid[5] = False
+    ts2 = ts.copy(); ts2[5] = 20; ts2[6] = 21
+    want = _run_null_ts(ts2, tvalid, vals, None, 10, aggs=[("WindowStart", 0), ("NumRows", 1), ("First", 1), ("IntegralTrapezoid", 1)])
+    assert want[1].to_list()[1] == 2.0 and want[2].to_list()[1] == 6.0
 
 
 def test_null_timestamps_runs_at_window_edges_and_the_null_last_row():

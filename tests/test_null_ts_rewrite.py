@@ -10,6 +10,7 @@ from oracle import pyoracle as orc
 
 PLAIN = ["Sum", "ArithmeticMean", "Min", "Max", "Count", "First", "Last"]
 TW = ["IntegralStep", "WeightedAverageStep"]
+LINEAR = ["IntegralTrapezoid", "WeightedAverageLinear"]   # the two reducers that ask for inclusive windows (aggregation.go:183-185)
 
 
 def go_div(a, b):
@@ -82,3 +83,91 @@ def test_a_null_last_timestamp_produces_no_window_at_all():
         assert (s0, W) == (10, 2)             # countWindows measures from the last VALID timestamp (rolling.go:143-154)
         out, _ = orc.aggregate(cols, 0, 10, [("WindowStart", 0), ("Sum", 1), ("Count", 1)])
         assert all(o.length == W and not o.valid_mask().any() for o in out)   # ... and HasNext (:162-173) never lets a window start
+
+
+def rewrite_inclusive(ts, tvalid, s0, interval):
+    """ts_eff, keep, quirk - what ts_nullfill_kernel computes for an INCLUSIVE iteration (rolling.go:201-218).  quirk: a row on a window
+    start (not window 0's), the first with that timestamp, with a null timestamp right behind it - the next window starts at
+    `rowIndex - 1`, the last of the null rows, without this row."""
+    n = len(ts)
+    idx = np.arange(n)
+    prev = np.maximum.accumulate(np.where(tvalid, idx, -1))
+    nxt = np.minimum.accumulate(np.where(tvalid, idx, n)[::-1])[::-1]
+    ts_eff = ts[np.maximum(prev, 0)].copy()
+    wid = lambda t: 0 if t < s0 else (t - s0) // interval      # noqa: E731
+    quirk = np.zeros(n, bool)
+    for i in range(n - 1):
+        if not tvalid[i] or tvalid[i + 1]:
+            continue
+        t = ts[i]
+        if t < s0 + interval or (t - s0) % interval:
+            continue
+        p = prev[i - 1] if i > 0 else -1
+        if p >= 0 and ts[p] == t:
+            continue
+        quirk[i] = True
+    keep = tvalid & ~quirk
+    for j in range(n):
+        if tvalid[j]:
+            continue
+        p, q = prev[j], nxt[j]
+        if p < 0 or q >= n:
+            continue
+        tp, tq = ts[p], ts[q]
+        k = wid(tp) == wid(tq) or tq == s0 + (wid(tp) + 1) * interval      # ... or q is the row ON the end of p's window
+        if quirk[p]:
+            k = k and j == q - 1                                             # only the last null row opens the next window's slice
+        keep[j] = k
+    return ts_eff, keep, quirk
+
+
+def test_the_inclusive_rewrite_gives_the_oracles_answer():
+    """every reducer that reads windows through UnsetInclusive (window.go:23-31) - incl. NumRows as Count over the keep bits - is
+    exact on the rewritten frame everywhere; the two that need inclusive windows are exact except in the windows BEHIND a quirk row,
+    which the device path recomputes by a walk (ts_quirk_fix_kernel; the GPU tests compare those with the oracle)"""
+    rng = np.random.default_rng(7)
+    with_quirks = 0
+    for case in range(700):
+        null_frac = rng.choice([0.03, 0.3, 0.6])
+        n = int(rng.integers(1, 120))
+        ts = np.cumsum(rng.integers(0, 7, n)).astype(np.int64) + int(rng.integers(-60, 60))
+        tvalid = rng.random(n) >= null_frac
+        tvalid[0] = tvalid[-1] = True
+        vals = np.round(rng.standard_normal(n) * 10, 2)
+        vvalid = rng.random(n) >= 0.25
+        interval = int(rng.choice([1, 2, 5, 10, 40]))
+        offset = int(rng.integers(-interval, 2 * interval))
+        ocols = [orc.Column(ts, np.packbits(tvalid, bitorder="little"), orc.INT64), orc.Column(vals, np.packbits(vvalid, bitorder="little"), orc.FLOAT64)]
+        try:
+            s0, W = orc.plan_windows(ocols[0], interval, offset)
+        except orc.OracleError:
+            continue
+        aggs = [("WindowStart", 0), ("NumRows", 1)] + [(k, 1) for k in PLAIN + TW + LINEAR] + [("Sum", 0), ("Last", 0), ("IntegralStep", 0)]
+        want, _ = orc.aggregate(ocols, 0, interval, aggs, offset=offset, inclusive=bool(case & 1))   # (LINEAR implies it anyway)
+        ts_eff, keep, quirk = rewrite_inclusive(ts, tvalid, s0, interval)
+        with_quirks += bool(quirk.any())
+        behind = {int((ts[i] - s0) // interval) for i in np.nonzero(quirk)[0]}
+        pack = lambda m: np.packbits(m, bitorder="little")      # noqa: E731
+        dense = [orc.Column(ts_eff, None, orc.INT64),
+                 orc.Column(vals, pack(vvalid & keep), orc.FLOAT64),                 # 1 plain
+                 orc.Column(vals, pack(vvalid & tvalid & ~quirk), orc.FLOAT64),      # 2 step integrals
+                 orc.Column(ts, pack(tvalid & keep), orc.INT64),                     # 3 plain, the interval column itself
+                 orc.Column(ts, pack(tvalid & ~quirk), orc.INT64),                   # 4 step, the interval column itself
+                 orc.Column(vals, pack(keep), orc.FLOAT64),                          # 5 NumRows
+                 orc.Column(vals, pack(vvalid & tvalid), orc.FLOAT64)]               # 6 the two inclusive reducers
+        aggs2 = ([("WindowStart", 0), ("Count", 5)] + [(k, 1) for k in PLAIN] + [(k, 2) for k in TW] + [(k, 6) for k in LINEAR] +
+                 [("Sum", 3), ("Last", 3), ("IntegralStep", 4)])
+        got, _ = orc.aggregate(dense, 0, interval, aggs2, offset=offset, inclusive=True)
+        for (k, _c), g, w in zip(aggs, got, want):
+            gm, wm = g.valid_mask().copy(), w.valid_mask().copy()
+            gv, wv = g.values[:W].copy(), w.values[:W].copy()
+            if k == "NumRows":
+                gv = gv.view(np.int64).astype(np.float64)
+            if k in LINEAR:
+                for f in behind:
+                    if f < W:
+                        gm[f] = wm[f] = False
+            label = (case, k, list(ts), list(tvalid.astype(int)), interval, offset)
+            assert np.array_equal(gm, wm), label
+            assert np.array_equal(gv.view(np.uint64)[gm], wv.view(np.uint64)[wm]), label
+    assert with_quirks > 100
