@@ -305,7 +305,7 @@ static int fetch_i64(Ctx *c, const bowgpu_col *col, int64_t row, int64_t *out) {
     return 0;
 }
 
-static int fetch_valid(Ctx *c, const bowgpu_col *col, int64_t row, int *valid) {
+int fetch_valid(Ctx *c, const bowgpu_col *col, int64_t row, int *valid) {
     if (!col->validity) { *valid = 1; return 0; }
     const int64_t bit = col->offset + row;
     uint8_t byte = 0;

@@ -312,6 +312,21 @@ struct QuirkFix { int32_t naggs, _pad; QuirkFixAgg a[8]; };
 int launch_ts_quirk_fix(Ctx *c, const int64_t *ts, const uint32_t *tbits, int64_t tbit0, int64_t n, const struct NbrIndex &ix, int64_t s0, int64_t interval,
                         const MagicDiv &magic, int64_t W, const QuirkFix &fx, unsigned long long *d_fixed);
 int launch_count_to_f64(Ctx *c, uint64_t *v, int64_t n);
+int fetch_valid(Ctx *c, const bowgpu_col *col, int64_t row, int *valid);   // (api.cpp) validity bit of one row of a column, wherever it lives
+// Rolling.Interpolate over an interval column with nulls: the kept rows compacted (ts_nulls.hip)
+constexpr int kMaxCompactCols = 16;
+struct CompactCols {
+    int32_t ncols, ts_col;
+    const uint64_t *values[kMaxCompactCols]; const uint32_t *vbits[kMaxCompactCols]; int64_t vbit0[kMaxCompactCols];   // the call's columns
+    uint64_t *out_values[kMaxCompactCols];      // their kept rows
+    uint64_t *lookup_bits[kMaxCompactCols];     // validity of the compacted call's columns (nullptr: the interval column - dense)
+    uint64_t *patch_values[kMaxCompactCols]; uint32_t *patch_valid[kMaxCompactCols];   // the outputs interp_patch_kernel corrects
+};
+int launch_keep_counts(Ctx *c, const uint64_t *keep, int64_t nw, int32_t *counts);
+int launch_compact_rows(Ctx *c, const uint64_t *keep, const int64_t *base, int64_t n, const int64_t *ts_eff, const uint32_t *tbits, int64_t tbit0,
+                        const CompactCols &cc, int64_t *marker, uint32_t *flags);
+int launch_pack_flags(Ctx *c, const uint32_t *flags, int64_t m, const CompactCols &cc, uint64_t *marker_bits);
+int launch_interp_patch(Ctx *c, const int64_t *marker_out, const uint32_t *marker_valid, int64_t m_out, const uint32_t *flags, const CompactCols &cc);
 int launch_and_bits(Ctx *c, const uint32_t *a, int64_t abit0, const uint32_t *b, int64_t bbit0, int64_t n, uint64_t *out);
 
 // shard.hip

@@ -451,13 +451,153 @@ static int interp_fill_impl(const bowgpu_col *cols, int32_t ncols, int32_t ts_co
     return 0;
 }
 
+// Rolling.Interpolate over an interval column WITH NULLS, exclusive iteration (ts_nulls.hip has the semantics and the kernels): the
+// call is made on the kept rows - those inside some window's slice - compacted into device temporaries, plus a marker column that
+// tells afterwards which output rows are copies of null-timestamp rows; those get their null timestamp and their values' own
+// validity back.  outs == nullptr: the row count only.  *applies = false: the interval column has no nulls.
+static int interp_null_ts(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval, const bowgpu_options *opts,
+                          const bowgpu_interp *interps, int32_t ninterps, int64_t *n_out, bowgpu_out *outs, bool *applies) {
+    *applies = false;
+    if (!cols || ncols <= 0 || ts_col < 0 || ts_col >= ncols) return 0;       // (the ordinary path reports these)
+    const bowgpu_col *tsc = &cols[ts_col];
+    if (!tsc->validity || tsc->null_count == 0 || tsc->length == 0) return 0;
+    bowgpu_options o = {0, 0, 0};
+    if (opts) o = *opts;
+    Plan plan;
+    BG_TRY(plan_make(nullptr, tsc, interval, o.offset, &plan));                // ctor errors first (rolling.go:69-112)
+    BG_TRY(interp_validate(cols, ncols, ts_col, &o, interps, ninterps));
+    Ctx *c;
+    BG_TRY(ctx_get(&c));
+    DevCol dts;
+    BG_TRY(devcol_prepare(c, tsc, &dts, true, true));
+    if (dts.null_count <= 0) return 0;
+    *applies = true;
+    const int64_t n = tsc->length;
+    if (o.inclusive) return fail(BOWGPU_ERR_TS_NULLS, "interval column has %lld nulls and the windows are inclusive: Interpolate is outside the device path", (long long)dts.null_count);
+    if (ncols > kMaxCompactCols) return fail(BOWGPU_ERR_UNSUPPORTED, "Interpolate over an interval column with nulls: at most %d columns", kMaxCompactCols);
+    for (int i = 0; i < ncols; i++)
+        if (cols[i].length != n) return fail(BOWGPU_ERR_ARG, "column %d has a different length", i);
+    auto nothing = [&]() -> int {
+        if (n_out) *n_out = 0;
+        if (outs) for (int i = 0; i < ninterps; i++) { outs[i].length = 0; outs[i].null_count = 0; outs[i].type = cols[i].type; }
+        return 0;
+    };
+    int last_valid = 1;
+    BG_TRY(fetch_valid(c, tsc, n - 1, &last_valid));
+    if (!last_valid || plan.W == 0) return nothing();      // HasNext (rolling.go:162-173) is false from the start: no window, no rows
+    // the rows that belong to a window, compacted
+    DevBuf ixbuf, ts_eff, keep, dropped, counts, base, sums, flags, marker, marker_bits;
+    NbrIndex ix;
+    BG_TRY(ixbuf.alloc(nbr_index_bytes(n, dts.vbit0)));
+    BG_TRY(nbr_index_build(c, dts.vbits, dts.vbit0, n, ixbuf.p, &ix));
+    BG_TRY(ts_eff.alloc((size_t)n * 8 + 16));
+    const int64_t nw = (n + 63) >> 6;
+    BG_TRY(keep.alloc((size_t)nw * 8 + 8));
+    BG_TRY(dropped.alloc(16));
+    BG_TRY(launch_ts_nullfill(c, reinterpret_cast<const int64_t *>(dts.values), dts.vbits, dts.vbit0, n, ix, plan.s0, plan.interval, plan.magic, 0,
+                              reinterpret_cast<int64_t *>(ts_eff.p), reinterpret_cast<uint64_t *>(keep.p), nullptr, reinterpret_cast<unsigned long long *>(dropped.p)));
+    BG_TRY(counts.alloc((size_t)nw * 4 + 16));
+    BG_TRY(base.alloc((size_t)(nw + 1) * 8 + 16));
+    BG_TRY(sums.alloc((size_t)((nw + 2047) / 2048 + 2) * 8));
+    BG_TRY(launch_keep_counts(c, reinterpret_cast<const uint64_t *>(keep.p), nw, reinterpret_cast<int32_t *>(counts.p)));
+    int64_t *d_total = reinterpret_cast<int64_t *>(dropped.p) + 1;
+    BG_TRY(launch_exclusive_scan(c, reinterpret_cast<const int32_t *>(counts.p), nw, reinterpret_cast<int64_t *>(base.p), reinterpret_cast<int64_t *>(sums.p), d_total));
+    int64_t m = 0;
+    BG_HIP(hipMemcpyAsync(&m, d_total, 8, hipMemcpyDeviceToHost, c->stream));
+    BG_HIP(hipStreamSynchronize(c->stream));
+    if (m <= 0) return nothing();
+    const size_t mbm = (size_t)((m + 63) >> 6) * 8 + 8;
+    std::vector<DevCol> dcs(ncols);
+    std::vector<DevBuf> cvals(ncols), cbits(ncols);
+    CompactCols cc;
+    memset(&cc, 0, sizeof cc);
+    cc.ncols = ncols; cc.ts_col = ts_col;
+    for (int i = 0; i < ncols; i++) {
+        BG_TRY(cvals[i].alloc((size_t)m * 8 + 16));
+        cc.out_values[i] = reinterpret_cast<uint64_t *>(cvals[i].p);
+        if (i == ts_col) continue;
+        BG_TRY(devcol_prepare(c, &cols[i], &dcs[i], true, true));
+        cc.values[i] = reinterpret_cast<const uint64_t *>(dcs[i].values); cc.vbits[i] = dcs[i].vbits; cc.vbit0[i] = dcs[i].vbit0;
+        BG_TRY(cbits[i].alloc(mbm));
+        cc.lookup_bits[i] = reinterpret_cast<uint64_t *>(cbits[i].p);
+    }
+    BG_TRY(flags.alloc((size_t)m * 4 + 16));
+    BG_TRY(marker.alloc((size_t)m * 8 + 16));
+    BG_TRY(marker_bits.alloc(mbm));
+    BG_TRY(launch_compact_rows(c, reinterpret_cast<const uint64_t *>(keep.p), reinterpret_cast<const int64_t *>(base.p), n, reinterpret_cast<const int64_t *>(ts_eff.p),
+                               dts.vbits, dts.vbit0, cc, reinterpret_cast<int64_t *>(marker.p), reinterpret_cast<uint32_t *>(flags.p)));
+    BG_TRY(launch_pack_flags(c, reinterpret_cast<const uint32_t *>(flags.p), m, cc, reinterpret_cast<uint64_t *>(marker_bits.p)));
+    device_write_epoch_bump();      // (temporaries may sit where an earlier call's columns sat: no count -> fill reuse across this point)
+    // the compacted call: the Bow's columns + the marker under interpolation.None
+    std::vector<bowgpu_col> cols2(ncols + 1);
+    std::vector<bowgpu_interp> interps2(interps, interps + ninterps);
+    for (int i = 0; i <= ncols; i++) {
+        bowgpu_col &t = cols2[i];
+        memset(&t, 0, sizeof t);
+        t.offset = 0; t.length = m; t.residency = BOWGPU_DEVICE;
+        if (i == ncols) { t.values = marker.p; t.validity = reinterpret_cast<const uint8_t *>(marker_bits.p); t.type = BOWGPU_INT64; t.null_count = -1; }
+        else if (i == ts_col) { t.values = cvals[i].p; t.validity = nullptr; t.type = BOWGPU_INT64; t.null_count = 0; }
+        else { t.values = cvals[i].p; t.validity = reinterpret_cast<const uint8_t *>(cbits[i].p); t.type = cols[i].type; t.null_count = -1; }
+    }
+    {
+        bowgpu_interp mk;
+        memset(&mk, 0, sizeof mk);
+        mk.kind = BOWGPU_INTERP_NONE; mk.col = ncols;
+        interps2.push_back(mk);
+    }
+    int64_t m_out = 0;
+    BG_TRY(interp_count_impl(cols2.data(), ncols + 1, ts_col, interval, &o, interps2.data(), ninterps + 1, &m_out, nullptr, nullptr));
+    if (n_out) *n_out = m_out;
+    if (!outs) { c->interp_cache.valid = false; return 0; }
+    if (m_out == 0) return nothing();
+    const size_t vb = (size_t)((m_out + 7) >> 3);
+    std::vector<DevBuf> tvals(ncols + 1), tbits(ncols + 1);
+    std::vector<bowgpu_out> touts(ncols + 1);
+    for (int i = 0; i <= ncols; i++) {
+        BG_TRY(tvals[i].alloc((size_t)m_out * 8 + 16));
+        BG_TRY(tbits[i].alloc(((vb + 3) & ~(size_t)3) + 8));
+        BG_HIP(hipMemsetAsync(tbits[i].p, 0, ((vb + 3) & ~(size_t)3) + 8, c->stream));
+        bowgpu_out &t = touts[i];
+        t.values = tvals[i].p; t.validity = reinterpret_cast<uint8_t *>(tbits[i].p); t.length = m_out; t.null_count = 0; t.type = 0; t.residency = BOWGPU_DEVICE;
+        if (i < ncols) { cc.patch_values[i] = reinterpret_cast<uint64_t *>(tvals[i].p); cc.patch_valid[i] = reinterpret_cast<uint32_t *>(tbits[i].p); }
+    }
+    BG_TRY(interp_fill_impl(cols2.data(), ncols + 1, ts_col, interval, &o, interps2.data(), ninterps + 1, touts.data(), nullptr, nullptr));
+    c->interp_cache.valid = false;
+    if (touts[0].length != m_out) return fail(BOWGPU_ERR_ARG, "internal: Interpolate over an interval column with nulls produced %lld rows, counted %lld", (long long)touts[0].length, (long long)m_out);
+    BG_TRY(launch_interp_patch(c, reinterpret_cast<const int64_t *>(tvals[ncols].p), reinterpret_cast<const uint32_t *>(tbits[ncols].p), m_out,
+                               reinterpret_cast<const uint32_t *>(flags.p), cc));
+    void *dscr;
+    BG_TRY(ctx_scratch(c, 8192, &dscr));
+    uint64_t *dcnt = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(dscr) + 1024);
+    for (int i = 0; i < ncols; i++) {
+        uint64_t hcnt = 0;
+        BG_TRY(launch_popcount(c, reinterpret_cast<const uint32_t *>(tbits[i].p), 0, m_out, dcnt));
+        BG_HIP(hipMemcpyAsync(&hcnt, dcnt, 8, hipMemcpyDeviceToHost, c->stream));
+        BG_HIP(hipStreamSynchronize(c->stream));
+        DevOut d;
+        BG_TRY(devout_prepare(c, &outs[i], m_out, &d, i < 16 ? i : -1));
+        BG_HIP(hipMemcpyAsync(d.values, tvals[i].p, (size_t)m_out * 8, hipMemcpyDeviceToDevice, c->stream));
+        BG_HIP(hipMemcpyAsync(d.validity, tbits[i].p, vb, hipMemcpyDeviceToDevice, c->stream));
+        BG_TRY(devout_finish(c, &d, m_out, cols[i].type, m_out - (int64_t)hcnt, true));
+        BG_HIP(hipStreamSynchronize(c->stream));
+    }
+    device_write_epoch_bump();
+    return 0;
+}
+
 int bowgpu_rolling_interpolate_count(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval,
                                      const bowgpu_options *opts, const bowgpu_interp *interps, int32_t ninterps, int64_t *n_out) {
+    bool null_ts = false;
+    if (n_out) BG_TRY(interp_null_ts(cols, ncols, ts_col, interval, opts, interps, ninterps, n_out, nullptr, &null_ts));
+    if (null_ts) return 0;
     return interp_count_impl(cols, ncols, ts_col, interval, opts, interps, ninterps, n_out, nullptr, nullptr);
 }
 
 int bowgpu_rolling_interpolate_fill(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval,
                                     const bowgpu_options *opts, const bowgpu_interp *interps, int32_t ninterps, bowgpu_out *outs) {
+    bool null_ts = false;
+    if (outs) BG_TRY(interp_null_ts(cols, ncols, ts_col, interval, opts, interps, ninterps, nullptr, outs, &null_ts));
+    if (null_ts) return 0;
     return interp_fill_impl(cols, ncols, ts_col, interval, opts, interps, ninterps, outs, nullptr, nullptr);
 }
 

@@ -166,6 +166,65 @@ __global__ __launch_bounds__(256) void and_bits_kernel(const uint32_t *__restric
     out[w] = x;
 }
 
+// ---- Rolling.Interpolate over an interval column with nulls (exclusive iteration).  Its output is the slices themselves
+// (interpolation.go:98-161): rows in no slice vanish, null-timestamp rows inside a slice are copied as they are, and the
+// interpolators look for neighbours among the rows where timestamp AND value are valid (linear.go:20-31, stepprevious.go:19).  So
+// the call is made on the KEPT rows - compacted, timestamps forward-filled, every column's validity ANDed with the interval column's
+// - plus one more Int64 column under interpolation.None whose only valid rows are the null-timestamp ones, holding their row
+// number: wherever that column comes out valid, the output row is a copy of such a row, and interp_patch_kernel gives it its
+// null timestamp and the values' own validity back.
+__global__ __launch_bounds__(256) void keep_counts_kernel(const uint64_t *__restrict__ keep, const int64_t nw, int32_t *__restrict__ counts) {
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w < nw) counts[w] = __popcll(keep[w]);
+}
+
+// flags[dst]: bit 0 = the row's timestamp is valid, bit 1 + c = column c has a value in it (the interval column: its timestamp)
+__global__ __launch_bounds__(256) void compact_rows_kernel(const uint64_t *__restrict__ keep, const int64_t *__restrict__ base, const int64_t n,
+                                                           const int64_t *__restrict__ ts_eff, const uint32_t *__restrict__ tbits, const int64_t tbit0,
+                                                           const CompactCols cc, int64_t *__restrict__ marker, uint32_t *__restrict__ flags) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t kw = keep[i >> 6];
+    const int lane = (int)(i & 63);
+    if (!((kw >> lane) & 1ull)) return;
+    const int64_t dst = base[i >> 6] + __popcll(kw & ((1ull << lane) - 1ull));
+    const bool tv = bit_at(tbits, tbit0, i);
+    uint32_t f = tv ? 1u : 0u;
+    for (int c = 0; c < cc.ncols; c++) {
+        if (c == cc.ts_col) { cc.out_values[c][dst] = (uint64_t)ts_eff[i]; if (tv) f |= 2u << c; }
+        else { cc.out_values[c][dst] = cc.values[c][i]; if (bit_at(cc.vbits[c], cc.vbit0[c], i)) f |= 2u << c; }
+    }
+    flags[dst] = f;
+    marker[dst] = dst;
+}
+
+// the bitmaps of the compacted call, 64 rows per wavefront: lookup[c] = value AND timestamp valid; marker_bits = timestamp null
+__global__ __launch_bounds__(256) void pack_flags_kernel(const uint32_t *__restrict__ flags, const int64_t m, const CompactCols cc, uint64_t *__restrict__ marker_bits) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t f = i < m ? flags[i] : 1u;
+    const bool lane0 = (threadIdx.x & 63) == 0 && i < m;
+    for (int c = 0; c < cc.ncols; c++) {
+        const unsigned long long b = __ballot((f & 1u) && ((f >> (1 + c)) & 1u));
+        if (lane0 && cc.lookup_bits[c]) cc.lookup_bits[c][i >> 6] = b;
+    }
+    const unsigned long long mb = __ballot(!(f & 1u));
+    if (lane0) marker_bits[i >> 6] = mb;
+}
+
+__global__ __launch_bounds__(256) void interp_patch_kernel(const int64_t *__restrict__ marker_out, const uint32_t *__restrict__ marker_valid, const int64_t m_out,
+                                                           const uint32_t *__restrict__ flags, const CompactCols cc) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m_out || !((marker_valid[j >> 5] >> (j & 31)) & 1u)) return;
+    const int64_t r = marker_out[j];
+    const uint32_t f = flags[r];
+    for (int c = 0; c < cc.ncols; c++) {
+        if ((f >> (1 + c)) & 1u) {
+            cc.patch_values[c][j] = cc.out_values[c][r];
+            atomicOr(&cc.patch_valid[c][j >> 5], 1u << (j & 31));
+        } else atomicAnd(&cc.patch_valid[c][j >> 5], ~(1u << (j & 31)));
+    }
+}
+
 }  // namespace
 
 int launch_ts_nullfill(Ctx *c, const int64_t *ts, const uint32_t *tbits, int64_t tbit0, int64_t n, const NbrIndex &ix, int64_t s0, int64_t interval,
@@ -202,4 +261,34 @@ int launch_and_bits(Ctx *c, const uint32_t *a, int64_t abit0, const uint32_t *b,
     return 0;
 }
 
+int launch_keep_counts(Ctx *c, const uint64_t *keep, int64_t nw, int32_t *counts) {
+    if (nw <= 0) return 0;
+    hipLaunchKernelGGL(keep_counts_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, c->stream, keep, nw, counts);
+    BG_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_compact_rows(Ctx *c, const uint64_t *keep, const int64_t *base, int64_t n, const int64_t *ts_eff, const uint32_t *tbits, int64_t tbit0,
+                        const CompactCols &cc, int64_t *marker, uint32_t *flags) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(compact_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, keep, base, n, ts_eff, tbits, tbit0, cc, marker, flags);
+    BG_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_pack_flags(Ctx *c, const uint32_t *flags, int64_t m, const CompactCols &cc, uint64_t *marker_bits) {
+    if (m <= 0) return 0;
+    hipLaunchKernelGGL(pack_flags_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, flags, m, cc, marker_bits);
+    BG_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_interp_patch(Ctx *c, const int64_t *marker_out, const uint32_t *marker_valid, int64_t m_out, const uint32_t *flags, const CompactCols &cc) {
+    if (m_out <= 0) return 0;
+    hipLaunchKernelGGL(interp_patch_kernel, dim3((unsigned)((m_out + 255) / 256)), dim3(256), 0, c->stream, marker_out, marker_valid, m_out, flags, cc);
+    BG_HIP(hipGetLastError());
+    return 0;
+}
+
 }  // namespace bowgpu
+

@@ -635,3 +635,62 @@ def test_interpolate_count_to_fill_reuse_is_dropped_when_the_column_changes():
     rc, outs = fill(m_a)
     assert rc == 0
     cmp_out("after the tampering, ts", outs[0], want_a[0]); cmp_out("after the tampering, val", outs[1], want_a[1])
+
+
+@pytest.mark.parametrize("null_frac", [0.02, 0.3, 0.8])
+def test_interpolate_over_an_interval_column_with_nulls(null_frac):
+    """Rolling.Interpolate when the interval column has nulls (exclusive iteration; ts_nulls.hip): the output is the slices themselves -
+    rows that belong to no window vanish (rolling.go:190-193, :224-228), null-timestamp rows inside a slice are copied with their
+    null timestamp and their values' own validity, the interpolators look for neighbours among the rows whose timestamp AND value are
+    valid (linear.go:20-31, stepprevious.go:19).  Every interpolator, a PrevRow, two value columns, both kernels, against the oracle."""
+    rng = np.random.default_rng(int(null_frac * 100) + 7)
+    for n, interval, offset, mode in [(1, 10, 0, "dense"), (2, 3, 1, "dense"), (700, 5, 2, "dups"), (3000, 10, 0, "irregular"),
+                                      (5000, 64, 7, "gappy"), (40_000, 25, -3, "irregular"), (40_000, 4000, 11, "dense"), (6000, 10, 3, "negative"),
+                                      (9000, 1, 0, "dups")]:
+        if mode == "dense":
+            ts = np.arange(n, dtype=np.int64) + int(rng.integers(-50, 50))
+        elif mode == "dups":
+            ts = np.cumsum(rng.integers(0, 3, n)).astype(np.int64) - 77
+        elif mode == "gappy":
+            step = rng.integers(1, 5, n)
+            step[rng.random(n) < 0.01] = rng.integers(100, 5000)
+            ts = np.cumsum(step).astype(np.int64) - 12345
+        elif mode == "negative":
+            ts = np.cumsum(rng.integers(1, 7, n)).astype(np.int64) - 3 * n
+        else:
+            ts = np.cumsum(rng.integers(1, 20, n)).astype(np.int64) + int(rng.integers(-1000, 1000))
+        tvalid = rng.random(n) >= null_frac
+        tvalid[0] = tvalid[-1] = True
+        vals = np.round(rng.standard_normal(n) * 100, 2)
+        ivals = rng.integers(-1000, 1000, n).astype(np.int64)
+        v1, v2 = rng.random(n) >= 0.3, rng.random(n) >= 0.1
+        tbm, b1, b2 = (np.packbits(x, bitorder="little") for x in (tvalid, v1, v2))
+        for kinds in (("Linear", "StepPrevious"), ("StepPrevious", "None"), ("None", "Linear")):
+            for prev in (None, (float(ts[0] - 3), True, 42.5, True, 42)):
+                ip = [{"kind": "WindowStart", "col": 0}, {"kind": kinds[0], "col": 1}, {"kind": kinds[1], "col": 2}]
+                if prev is not None:
+                    ip[1]["prev"] = prev
+                    ip[2]["prev"] = prev
+                ccols = [capi.Column(ts, tbm, capi.INT64, 0, n, -1), capi.Column(vals, b1, capi.FLOAT64, 0, n, -1), capi.Column(ivals, b2, capi.INT64, 0, n, -1)]
+                if n % 2 == 0:
+                    ccols = [c.to_device() for c in ccols]
+                got = both_interp_kernels(lambda: capi.rolling_interpolate(ccols, 0, interval, ip, offset=offset))
+                want = orc.interpolate([orc.Column(ts, tbm, orc.INT64), orc.Column(vals, b1, orc.FLOAT64), orc.Column(ivals, b2, orc.INT64)], 0, interval, ip,
+                                       offset=offset)
+                label = "n=%d I=%d %s %s prev=%s nulls=%.2f" % (n, interval, mode, kinds, prev is not None, null_frac)
+                for k in range(3):
+                    cmp_out("col %d %s" % (k, label), got[k], want[k])
+    # the physically last timestamp null: HasNext is false from the start (rolling.go:162-173) - no window, no rows
+    ts = np.array([10, 11, 20, 21, 30], dtype=np.int64)
+    tvalid = np.array([1, 1, 0, 1, 0], bool)
+    cols = [capi.Column(ts, np.packbits(tvalid, bitorder="little"), capi.INT64, 0, 5, -1), capi.Column(np.arange(5.0))]
+    ip = [{"kind": "WindowStart", "col": 0}, {"kind": "Linear", "col": 1}]
+    want = orc.interpolate([orc.Column(ts, np.packbits(tvalid, bitorder="little"), orc.INT64), orc.Column(np.arange(5.0), None, orc.FLOAT64)], 0, 10, ip)
+    got = capi.rolling_interpolate(cols, 0, 10, ip)
+    assert got[0].length == want[0].length == 0
+    # inclusive windows over an interval column with nulls stay outside the device path
+    tvalid = np.array([1, 1, 0, 1, 1], bool)
+    cols = [capi.Column(ts, np.packbits(tvalid, bitorder="little"), capi.INT64, 0, 5, -1), capi.Column(np.arange(5.0))]
+    with pytest.raises(capi.BowGpuError) as e:
+        capi.rolling_interpolate(cols, 0, 10, ip, inclusive=True)
+    assert e.value.code == -13

@@ -171,3 +171,53 @@ def test_the_inclusive_rewrite_gives_the_oracles_answer():
             assert np.array_equal(gm, wm), label
             assert np.array_equal(gv.view(np.uint64)[gm], wv.view(np.uint64)[wm]), label
     assert with_quirks > 100
+
+
+def test_interpolate_on_the_kept_rows_plus_a_marker_column_gives_the_oracles_answer():
+    """Rolling.Interpolate over an interval column with nulls (exclusive iteration) as extras.cpp interp_null_ts makes it: the kept
+    rows compacted (timestamps forward-filled, value validity ANDed with the interval column's), one more Int64 column under
+    interpolation.None that is valid exactly in the null-timestamp rows and holds their row number; in the output, wherever that
+    column is valid the row is a copy of such a row: its timestamp becomes null, its value gets its own validity back."""
+    rng = np.random.default_rng(11)
+    pack = lambda m: np.packbits(m, bitorder="little")      # noqa: E731
+    for case in range(600):
+        null_frac = rng.choice([0.03, 0.3, 0.6])
+        n = int(rng.integers(1, 100))
+        ts = np.cumsum(rng.integers(0, 7, n)).astype(np.int64) + int(rng.integers(-60, 60))
+        tvalid = rng.random(n) >= null_frac
+        tvalid[0] = tvalid[-1] = True
+        vals = np.round(rng.standard_normal(n) * 10, 2)
+        vvalid = rng.random(n) >= 0.25
+        interval = int(rng.choice([1, 2, 5, 10, 40]))
+        offset = int(rng.integers(-interval, 2 * interval))
+        ocols = [orc.Column(ts, pack(tvalid), orc.INT64), orc.Column(vals, pack(vvalid), orc.FLOAT64)]
+        try:
+            s0, _W = orc.plan_windows(ocols[0], interval, offset)
+        except orc.OracleError:
+            continue
+        kind = ["Linear", "StepPrevious", "None"][case % 3]
+        ip = [{"kind": "WindowStart", "col": 0}, {"kind": kind, "col": 1}]
+        if case % 2:
+            ip[1]["prev"] = (float(ts[0] - 3), True, 42.5, True, 42)
+        want = orc.interpolate(ocols, 0, interval, ip, offset=offset)
+        ts_eff, keep = rewrite(ts, tvalid, s0, interval)
+        k = np.nonzero(keep)[0]
+        cts, cv, ctv, cvv = ts_eff[k], vals[k], tvalid[k], vvalid[k]
+        dense = [orc.Column(cts, None, orc.INT64), orc.Column(cv, pack(cvv & ctv), orc.FLOAT64),
+                 orc.Column(np.arange(len(k), dtype=np.int64), pack(~ctv), orc.INT64)]
+        got = orc.interpolate(dense, 0, interval, ip + [{"kind": "None", "col": 2}], offset=offset)
+        m_out = got[0].length
+        gts_m, gv_m = got[0].valid_mask().copy(), got[1].valid_mask().copy()
+        gv = got[1].values[:m_out].copy()
+        for j in np.nonzero(got[2].valid_mask())[0]:
+            r = got[2].values[j]
+            gts_m[j] = False
+            gv_m[j] = cvv[r]
+            if cvv[r]:
+                gv[j] = cv[r]
+        label = (case, list(ts), list(tvalid.astype(int)), list(vvalid.astype(int)), interval, offset, kind)
+        assert m_out == want[0].length, label
+        wm0, wm1 = want[0].valid_mask(), want[1].valid_mask()
+        assert np.array_equal(gts_m, wm0) and np.array_equal(gv_m, wm1), label
+        assert np.array_equal(got[0].values[:m_out].view(np.uint64)[gts_m], want[0].values[:m_out].view(np.uint64)[wm0]), label
+        assert np.array_equal(gv.view(np.uint64)[gv_m], want[1].values[:m_out].view(np.uint64)[wm1]), label
