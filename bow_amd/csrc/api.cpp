@@ -1138,12 +1138,10 @@ static int job_run(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, i
     // bisection form; 128 .. 256-row windows 0.35 - 0.55 ms dense, 0.40 - 0.76 ms on irregular data with nulls, against 0.35 - 1.0 /
     // 0.7 - 1.8 ms for the tile kernels, whose lane-per-window walk idles most lanes at that length); the bisection form keeps the
     // calls of a handful of giant windows (from 4M rows per window: the streaming form's final merge is one workgroup per window).
-    bool lite_set = true;
-    for (int sl = 0; sl < P.ncols; sl++)
-        if ((P.pass_flags[sl + 1] & (kPassMinMax | kPassFirstLast)) || P.cols[sl].need_ts) lite_set = false;
-    // (round 4: the tile kernels' walks are branch-free - at 128 rows per window they beat the streaming form for every set but the
-    // {sum, count} ones and the calls with both kinds of integral, scratch/midw_sweep.py; from 129 on some window of the call no longer
-    // fits a tile's look-ahead and the cooperative path would have to run as well: the streaming form takes over)
+    // (round 4: the tile kernels' walks are branch-free and their staged columns padded against LDS bank conflicts - at 128 rows per
+    // window they beat the streaming form for every set but the calls with both kinds of integral (Mean: 0.283 against 0.319 ms dense,
+    // 0.327 against 0.341 with nulls), scratch/midw_sweep.py; from 129 on some window of the call no longer fits a tile's look-ahead and
+    // the cooperative path would have to run as well: the streaming form takes over)
     bool step_k = false, trap_k = false;
     for (int i = 0; i < naggs; i++) {
         step_k |= aggs[i].kind == BOWGPU_AGG_INTEGRAL_STEP || aggs[i].kind == BOWGPU_AGG_WAVG_STEP;
@@ -1151,7 +1149,7 @@ static int job_run(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, i
     }
     const int64_t avg_rows = W > 0 ? P.n / W : 0;
     const bool classic_only = cls;
-    const bool stream_ok = !classic_only && avg_rows >= ((lite_set || sall || (step_k && trap_k)) ? kLongOnlyAvgRows : kLongStreamAnyAvgRows) &&
+    const bool stream_ok = !classic_only && avg_rows >= ((sall || (step_k && trap_k)) ? kLongOnlyAvgRows : kLongStreamAnyAvgRows) &&
                            avg_rows < kLongClassicAvgRows && W < (1ll << 32);
     const bool classic_ok = avg_rows >= kLongBisectAvgRows;
     // bowgpu_options.strict_order on a call of long windows: every window by one lane in row order (long_windows.hip

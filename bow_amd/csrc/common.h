@@ -255,8 +255,8 @@ int launch_rolling_aggregate(Ctx *c, const AggParams &p);   // general kernel (r
 int launch_rolling_fast(Ctx *c, const AggParams &p);        // lean kernel for exclusive windows without time-weighted reducers (rolling_fast.hip)
 constexpr int kLongChunkRows = 4096;
 constexpr int kLongStreamRows = 512;  // chunk of the streaming form of the long-window reduction (long_windows.hip)
-constexpr int64_t kLongOnlyAvgRows = 128;   // windows averaging at least this many rows skip the tile kernels: streaming form (api.cpp job_run)
-constexpr int64_t kLongStreamAnyAvgRows = 129;   // ... the same for the reducer sets with extrema, first / last or ONE kind of time-weighted term (256 until long_short_kernel took a boundary per 128-row trip; 128 until the tile kernels' walks became branch-free: windows of exactly 128 rows fit a tile's look-ahead and the tile kernels win there)
+constexpr int64_t kLongOnlyAvgRows = 128;   // calls with BOTH kinds of integral whose windows average at least this many rows skip the tile kernels: streaming form (api.cpp job_run)
+constexpr int64_t kLongStreamAnyAvgRows = 129;   // ... the same for every other reducer set (256 until long_short_kernel took a boundary per 128-row trip; 128 until the tile kernels' walks became branch-free: windows of exactly 128 rows fit a tile's look-ahead and the tile kernels win there)
 constexpr int64_t kLongBisectAvgRows = 512; // ... bisection form where the streaming form does not apply (BOWGPU_ROUTE_LONG_CLASSIC; W >= 2^32)
 constexpr int64_t kLongClassicAvgRows = 1ll << 22;   // ... and from here on the handful of giant windows go by bisection + per-window chunks
 constexpr int kLongLists = 64;      // sub-lists of the long-window queue (agg_device.h push_long_window)

@@ -147,7 +147,7 @@ typedef struct bowgpu_agg_info {
     int32_t new_interval_col;   /* index of the LAST aggregator reading the interval column (aggregation.go:152-161) */
     int32_t inclusive;          /* effective Options.Inclusive after validateAggregation (aggregation.go:183-185) */
     int64_t long_windows;       /* windows reduced in an ORDER-FREE form instead of the reference's left-to-right walk: windows longer
-                                   than a tile's look-ahead (128 rows), and every window of a call whose windows average >= 129 rows (128 for {sum, count} sets and calls with both kinds of integral).  THE STATED TOLERANCE, for the float sums
+                                   than a tile's look-ahead (128 rows), and every window of a call whose windows average >= 129 rows (128 for calls with both kinds of integral).  THE STATED TOLERANCE, for the float sums
                                    of those windows (u = 2^-53, n = the window's rows, x = its valid values, T = its time-weighted
                                    terms):   |Sum - ref| <= 2 (n + 2) u SUM|x_i|;   ArithmeticMean: that / count + 2 u |ref|;
                                    Integral*: 4 (n + 2) u SUM|T_i| (a Factor scales it);   WeightedAverage*: that / (t_last - t_first)

@@ -419,7 +419,7 @@ def test_long_windows_mixed_shapes(inclusive):
 
 
 def test_streaming_form_chunk_edges():
-    """The one-read streaming form (windows averaging >= 128 rows) on shapes built around its 512-row chunks: window boundaries exactly
+    """The one-read streaming form (windows averaging >= 129 rows) on shapes built around its 512-row chunks: window boundaries exactly
     on chunk edges and one row off them, windows of exactly one chunk / several chunks / more chunks than a lane of the finish kernel
     looks ahead, a partial last chunk of 1 .. 511 rows, empty windows between long ones, an all-null window, Int64 values,
     time-weighted reducers and inclusive windows, rows below s0 in a long window 0 - against the oracle and against the
@@ -433,8 +433,8 @@ def test_streaming_form_chunk_edges():
             f, fv = make_vals(rng, n, "f64", 0.2)
             i, iv = make_vals(rng, n, "i64", 0.1)
             fv[512:1024] = False                         # one chunk with no valid value at all
-            for interval in (512, 256, 1024, 1536, 130, 700):
-                if n // interval < 1 or n / max(1, (n // interval + 2)) < 128:
+            for interval in (512, 256, 1024, 1536, 135, 700):
+                if n // interval < 1 or n / max(1, (n // interval + 2)) < 129:      # (kLongStreamAnyAvgRows)
                     continue
                 for offset in (0, 1, interval - 1):
                     run_both(ts, [(f, fv), (i, iv)], interval, base_aggs + [("Sum", 2), ("Min", 2)], offset=offset)
@@ -1114,8 +1114,8 @@ def test_pinned_zero_copy_residency_equals_the_other_residencies():
 
 def test_strict_order_and_the_pinned_form_thresholds():
     """bowgpu_options.strict_order: every window in the reference's row order (bit-exact, long_windows == 0) or the call is declined.
-    And the window length at which a call changes form (common.h: kLongOnlyAvgRows = 128 rows on average for the {sum, count} sets and
-    the calls with both kinds of integral, kLongStreamAnyAvgRows = 129 for the rest) - a change of it is a change of which calls are bit-exact."""
+    And the window length at which a call changes form (common.h: kLongOnlyAvgRows = 128 rows on average for the calls with both kinds
+    of integral, kLongStreamAnyAvgRows = 129 for the rest) - a change of it is a change of which calls are bit-exact."""
     rng = np.random.default_rng(77)
     n = 128 * 2400          # (whole windows of 128 and of 256 rows: the averages are the window lengths)
     ts = np.arange(n, dtype=np.int64)
@@ -1126,7 +1126,7 @@ def test_strict_order_and_the_pinned_form_thresholds():
     more = [("WindowStart", 0), ("Sum", 1), ("Min", 1), ("WeightedAverageStep", 1)]
     # which form runs where
     both = [("WindowStart", 0), ("IntegralStep", 1), ("WeightedAverageLinear", 1)]
-    for aggs, interval, kernel in ((lite, 127, "rolling_simple_kernel"), (lite, 128, "long_stream_kernel"), (more, 127, None),
+    for aggs, interval, kernel in ((lite, 127, "rolling_simple_kernel"), (lite, 128, "rolling_simple_kernel"), (lite, 130, "long_stream_kernel"), (more, 127, None),
                                    (more, 128, "rolling_tw_kernel"), (more, 130, "long_stream_kernel"), (more, 256, "long_stream_kernel"),
                                    (more, 1000, "long_stream_kernel"), (both, 127, "rolling_tw_kernel"), (both, 128, "long_stream_kernel")):
         outs, info = capi.rolling_aggregate(cols, 0, interval, aggs)
@@ -1153,7 +1153,7 @@ def test_strict_order_and_the_pinned_form_thresholds():
             assert info.long_windows == 0 and capi.last_kernel_name() == "long_strict_kernel", (interval, capi.last_kernel_name())
             for k, g, w in zip(_names(aggs), outs, exp):
                 compare("strict %s I=%d" % (k, interval), g, w, exact=True)
-        # (128-row windows: the streaming form by default for the {sum, count} set, but a tile still holds them - in row order)
+        # (128-row windows: a tile still holds them - in row order)
         exp, _ = orc.aggregate(ocols, 0, 128, aggs)
         outs, info = capi.rolling_aggregate(cols, 0, 128, aggs, strict_order=True)
         assert info.long_windows == 0 and not capi.last_kernel_name().startswith("long_")
