@@ -17,7 +17,10 @@ cp gpurun_out/prof/${TAG}_* $DST/ 2>/dev/null
 cp gpurun_out/prof/bench.json $DST/${TAG}_bench_1e9.json 2>/dev/null
 for name in configs general_bench interp_wall fill_wall longw_kinds midw_sweep small_calls host_resident; do
   PROF=0; [ "$name" = small_calls ] && PROF=1
-  BOWGPU_CALL_PROFILE=$PROF timeout -s KILL 600 python3 scratch/$name.py 2>&1 | grep -v "^[WE]2026" > $DST/${TAG}_stdout_${name}.txt
+  BOWGPU_CALL_PROFILE=$PROF timeout -s KILL 600 python3 scratch/$name.py 2> $DST/${TAG}_stderr_${name}.tmp | grep -v "^[WE]2026" > $DST/${TAG}_stdout_${name}.txt
+  # (the call profiler's lines - stderr - go to their own file, not into the table)
+  grep "^bowgpu call profile" $DST/${TAG}_stderr_${name}.tmp > $DST/${TAG}_stderr_${name}_call_profile.txt; [ -s $DST/${TAG}_stderr_${name}_call_profile.txt ] || rm -f $DST/${TAG}_stderr_${name}_call_profile.txt
+  rm -f $DST/${TAG}_stderr_${name}.tmp
 done
 timeout -s KILL 300 python3 scratch/longw_kinds.py strict 2>&1 | grep -v "^[WE]2026" > $DST/${TAG}_stdout_longw_kinds_strict.txt
 timeout -s KILL 600 python3 scratch/longw_sweep.py 2>&1 | grep -v "^[WE]2026" > $DST/${TAG}_stdout_longw_sweep.txt
