@@ -766,6 +766,17 @@ def test_null_timestamps_inclusive_windows_against_the_oracle(null_frac):
     assert seen > 50
 
 
+def test_null_timestamps_inclusive_large_frame_on_the_device():
+    """3e6 rows, 4 % null timestamps, dense timestamps and an interval of 8: every eighth row sits on a window start and one in 25 of those
+    has a null behind it - thousands of windows recomputed by ts_quirk_fix_kernel, the rest by the ordinary tile kernel"""
+    rng = np.random.default_rng(4)
+    n = 3_000_000
+    ts, tvalid, vals, vvalid = _null_ts_frame(rng, n, 0.04, "dense", vnull=0.1)
+    s0, _W = orc.plan_windows(orc.Column(ts, np.packbits(tvalid, bitorder="little"), orc.INT64), 8, 3)
+    assert _rows_on_a_start_with_a_null_behind(ts, tvalid, s0, 8) > 5000
+    _run_null_ts(ts, tvalid, vals, vvalid, 8, 3, aggs=NULL_TS_AGGS_INCL, device=True)
+
+
 def test_null_timestamps_numrows_counts_the_rows_of_the_slice():
     ts = np.array([10, 11, 12, 13, 20, 21, 22, 30, 31, 45, 46], dtype=np.int64)
     vals = np.arange(1.0, 12.0)

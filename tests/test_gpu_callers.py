@@ -646,7 +646,7 @@ def test_interpolate_over_an_interval_column_with_nulls(null_frac):
     rng = np.random.default_rng(int(null_frac * 100) + 7)
     for n, interval, offset, mode in [(1, 10, 0, "dense"), (2, 3, 1, "dense"), (700, 5, 2, "dups"), (3000, 10, 0, "irregular"),
                                       (5000, 64, 7, "gappy"), (40_000, 25, -3, "irregular"), (40_000, 4000, 11, "dense"), (6000, 10, 3, "negative"),
-                                      (9000, 1, 0, "dups")]:
+                                      (9000, 1, 0, "dups")] + ([(3_000_000, 50, 7, "irregular")] if null_frac == 0.3 else []):
         if mode == "dense":
             ts = np.arange(n, dtype=np.int64) + int(rng.integers(-50, 50))
         elif mode == "dups":
