@@ -350,7 +350,7 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
         if (count > 0) {
             first_raw = sh.val[swz<kSwzS>(fv)];
             if (kNulls && pred_walk) walk_values_pred<kSwzS>(sh.val, sh.vbits, fv, lv, sum, mn, mx);
-            else walk_values<kSwzS>(sh.val, fv, lv, do_sum, do_mm, sum, mn, mx);
+            else walk_values<kSwzS, !kMulti>(sh.val, fv, lv, do_sum, do_mm, sum, mn, mx);
             if (kNeed & 2) {
                 last_raw = sh.val[swz<kSwzS>(lv)];
                 if (cint) {   // the staged values are float64(v): First / Last return the Int64 itself (firstlast.go:17, :32)

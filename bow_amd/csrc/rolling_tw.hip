@@ -611,7 +611,7 @@ __global__ __launch_bounds__(kWave, (kShort || kLean || (!kNulls && kTs32 && !kB
             if (has_value && need_vals) {
                 first_raw = sh.val[swz<kSwzT>(fv)];
                 if (kNulls && pred_walk) walk_values_pred<kSwzT>(sh.val, sh.vbits, fv, lv, sum, mn, mx);
-                else walk_values<kSwzT>(sh.val, fv, lv, do_sum, do_mm, sum, mn, mx);
+                else walk_values<kSwzT, kLean || kShort>(sh.val, fv, lv, do_sum, do_mm, sum, mn, mx);
                 if (need_fl) {
                     last_raw = sh.val[swz<kSwzT>(lv)];
                     if (cint) {   // the staged values are float64(v): First / Last return the Int64 itself (firstlast.go:17, :32)
@@ -624,7 +624,7 @@ __global__ __launch_bounds__(kWave, (kShort || kLean || (!kNulls && kTs32 && !kB
         } else if (has_value) {
             // the terms of the window's points after its first (the first point's own slot holds +0.0, or - when it is the window's
             // first row - what closes the window before), in row order
-            integ = walk_terms<kSwzT>(sh.val, fv + 1, lv + 1);
+            integ = walk_terms<kSwzT, kLean || (!kNulls && kTs32 && !kBoth)>(sh.val, fv + 1, lv + 1);
             if (phase == 3) {
                 // + v0 * (float64(LastValue) - t0) of the last valid point (integral.go:49-55): staged in the next window's head slot
                 if (kLean && next_staged) integ = integ + __longlong_as_double((long long)sh.val[swz<kSwzT>(r1)]);   // the next window's head slot: the closing product
