@@ -395,11 +395,9 @@ __global__ __launch_bounds__(kWave, (kShort || kLean || (!kNulls && kTs32 && !kB
         lds_order();
         // ---- the term pass: the terms of this lane's ten rows from the staged values and times.  `first` (step terms when the call
         // has them, else trapezoid terms) replaces the staged values in LDS - chunk by chunk for a column without nulls (a row's
-        // previous point is the previous row: read before the chunk is written, the row in front of the NEXT chunk saved first);
-        // after the whole pass for a nullable column (previous points are gathered from anywhere below).  kBoth: the trapezoid terms
-        // wait in registers until the step terms have been walked.
-        constexpr bool kFirst = kNulls && !kShort;
-        double first_a[kFirst ? kChunksT : 1], first_b[kFirst ? kChunksT : 1];           // the first kind of a nullable column, until the pass is over
+        // previous point is the previous row: read before the chunk is written, the row in front of the NEXT chunk saved first), and
+        // for a nullable column too, whose chunks are taken from the last to the first (previous points are gathered from below).
+        // kBoth: the trapezoid terms wait in registers until the step terms have been walked.
         auto term_pass = [&]() __attribute__((always_inline)) {
             if constexpr (kShort) return;
             else {
@@ -411,8 +409,14 @@ __global__ __launch_bounds__(kWave, (kShort || kLean || (!kNulls && kTs32 && !kB
             uint32_t hm = hmask;
             int nl = nloc;
             asm volatile("" : "+v"(hm), "+s"(nl));
+            // (a nullable column: chunks from the LAST to the first.  The previous points of a chunk's rows lie in the chunk itself or below
+            // it, so once every lane has gathered for chunk j nothing will read the staged values of chunk j again - the chunks still to
+            // come are below it - and its terms go into LDS right away, as for a column without nulls.  In forward order the terms of
+            // all five chunks had to wait in registers for the end of the pass: 20 of them, which put the instantiation with both
+            // kinds of integral 26 registers over its 128 - spilled inside this loop: 0.82 ms for ANY call through it, 0.55 without)
 #pragma unroll
-            for (int j = 0; j < kChunksT; j++) {
+            for (int jj = 0; jj < kChunksT; jj++) {
+                const int j = kNulls ? kChunksT - 1 - jj : jj;
                 const int l = j * 128 + 2 * lane;
                 const ulonglong2 xv = *reinterpret_cast<const ulonglong2 *>(&sh.val[swz<kSwzT>(l)]);
                 const double xa = __longlong_as_double((long long)xv.x), xb = __longlong_as_double((long long)xv.y);
@@ -476,20 +480,14 @@ __global__ __launch_bounds__(kWave, (kShort || kLean || (!kNulls && kTs32 && !kB
                         if (a_ok && has_p && (ha || same_a)) qa = (xp + xa) / 2 * dta;
                         if (b_ok && has_p2 && (hb || same_b)) qb = (xp2 + xb) / 2 * dtb;
                     }
-                    first_a[kFirst ? j : 0] = first_is_step ? sa : qa;
-                    first_b[kFirst ? j : 0] = first_is_step ? sb : qb;
+                    lds_order();   // every lane has gathered for this chunk
+                    const double oa = first_is_step ? sa : qa, ob = first_is_step ? sb : qb;
+                    *reinterpret_cast<ulonglong2 *>(&sh.val[swz<kSwzT>(l)]) = make_ulonglong2((uint64_t)__double_as_longlong(oa), (uint64_t)__double_as_longlong(ob));
                 }
                 if (kKeep) { keep_a[kKeep ? j : 0] = qa; keep_b[kKeep ? j : 0] = qb; }
                 // (one chunk at a time: left to itself the scheduler interleaves the five unrolled chunks to hide latencies, which costs
                 // more registers than the kernel has)
                 __builtin_amdgcn_sched_barrier(0);
-            }
-            if (kNulls) {
-                lds_order();   // every gather of the pass is done
-#pragma unroll
-                for (int j = 0; j < kChunksT; j++)
-                    *reinterpret_cast<ulonglong2 *>(&sh.val[swz<kSwzT>(j * 128 + 2 * lane)]) = make_ulonglong2(
-                        (uint64_t)__double_as_longlong(first_a[kFirst ? j : 0]), (uint64_t)__double_as_longlong(first_b[kFirst ? j : 0]));
             }
             }
         };
