@@ -735,8 +735,9 @@ int launch_rolling_tw(Ctx *c, const SimpleParams &p, bool is_int, bool has_nulls
     const bool lean = !has_nulls && p.ncols == 1 && !(p.need & (kNeedSum | kNeedMinMax | kNeedFirstLast)) && p.W > 0 && p.n / p.W >= 5;
     // the one-walk instantiation up to the window length where the phases take over (scratch/midw_sweep.py, 1e8 rows): a single kind of
     // integral on a column without nulls 14 rows, with nulls or next to value reducers 20; both kinds 12 where the lean form takes
-    // over (its padded term array: 0.385 against 0.413 ms at 12 rows per window, 0.436 against 0.562 at 48), else 64 (44 with nulls)
-    const int64_t short_rows = both ? (has_nulls ? 44 : lean ? 12 : 64) : (has_nulls || (p.need & (kNeedSum | kNeedMinMax | kNeedFirstLast))) ? 20 : kShortAvgRows;
+    // over (its padded term array: 0.385 against 0.413 ms at 12 rows per window, 0.436 against 0.562 at 48), else 64 (38 with nulls:
+    // 0.642 against 0.698 ms at 32 rows per window, 0.710 against 0.685 at 40)
+    const int64_t short_rows = both ? (has_nulls ? 38 : lean ? 12 : 64) : (has_nulls || (p.need & (kNeedSum | kNeedMinMax | kNeedFirstLast))) ? 20 : kShortAvgRows;
     const bool shrt = p.W > 0 && p.n / p.W < short_rows;
 #define BG_TW4(U, B, S, L)                                                                                                       \
     do {                                                                                                                          \
