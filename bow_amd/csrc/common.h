@@ -296,6 +296,12 @@ int launch_mode(Ctx *c, const int64_t *ts, const int64_t *first_idx, int64_t n, 
                 const uint32_t *vbits, int64_t vbit0, int is_int, const bowgpu_agg *agg, void *out_values, uint32_t *out_valid,
                 int64_t *n_mid, int64_t *n_long);
 
+// neighbour index of a validity bitmap (interp_fill.hip nbr_index_build)
+struct NbrIndex {
+    const int64_t *prev_before;  // [nblocks] last valid row in any earlier block, -1 if none
+    const int64_t *next_after;   // [nblocks] first valid row in any later block, -1 if none
+    int64_t g0;                  // absolute block number of the column's first bit
+};
 // ts_nulls.hip: an interval column with nulls rewritten for the tile kernels (forward-filled timestamps, the rows that belong to a window)
 // (inclusive: the keep rule of inclusive windows; plain - inclusive only - receives the interval column's validity without the rows
 // that sit on a window start with a null timestamp right behind them: ts_nulls.hip)
@@ -321,12 +327,24 @@ struct CompactCols {
     uint64_t *out_values[kMaxCompactCols];      // their kept rows
     uint64_t *lookup_bits[kMaxCompactCols];     // validity of the compacted call's columns (nullptr: the interval column - dense)
     uint64_t *patch_values[kMaxCompactCols]; uint32_t *patch_valid[kMaxCompactCols];   // the outputs interp_patch_kernel corrects
+    uint64_t *ts_bits;                          // inclusive iteration: which compacted rows have a timestamp (nullptr: not wanted)
+};
+// the interpolators of the call + the both-valid bitmaps of the compacted columns with their neighbour indices: what interp_patch_kernel
+// needs to make the synthetic row of a window that begins behind null rows (inclusive iteration)
+struct PatchInterps {
+    int64_t m;
+    const uint64_t *both_bits[kMaxCompactCols];
+    NbrIndex nbr[kMaxCompactCols];
+    int32_t type[kMaxCompactCols], kind[kMaxCompactCols], has_prev[kMaxCompactCols], prev_t_valid[kMaxCompactCols], prev_v_valid[kMaxCompactCols];
+    double const_value[kMaxCompactCols], prev_t[kMaxCompactCols], prev_v[kMaxCompactCols];
+    int64_t prev_v_i64[kMaxCompactCols];
 };
 int launch_keep_counts(Ctx *c, const uint64_t *keep, int64_t nw, int32_t *counts);
 int launch_compact_rows(Ctx *c, const uint64_t *keep, const int64_t *base, int64_t n, const int64_t *ts_eff, const uint32_t *tbits, int64_t tbit0,
-                        const CompactCols &cc, int64_t *marker, uint32_t *flags);
+                        const uint64_t *plain, const CompactCols &cc, int64_t *marker, uint32_t *flags);
 int launch_pack_flags(Ctx *c, const uint32_t *flags, int64_t m, const CompactCols &cc, uint64_t *marker_bits);
-int launch_interp_patch(Ctx *c, const int64_t *marker_out, const uint32_t *marker_valid, int64_t m_out, const uint32_t *flags, const CompactCols &cc);
+int launch_interp_patch(Ctx *c, const int64_t *marker_out, const uint32_t *marker_valid, int64_t m_out, const uint32_t *flags, const CompactCols &cc,
+                        const PatchInterps &px);
 int launch_and_bits(Ctx *c, const uint32_t *a, int64_t abit0, const uint32_t *b, int64_t bbit0, int64_t n, uint64_t *out);
 
 // shard.hip
@@ -356,11 +374,6 @@ constexpr int kPoolShard = 19;   // shard stitch: seed / merged states and the n
 constexpr int kPoolGaps = 32;    // window_first_rows: queued runs of empty windows
 constexpr int kPoolInterpEdge = 31;   // Interpolate: the trips' edge words (interp_wave3_kernel)
 constexpr int kPoolInterp = 20;  // context pool slots 20..30: tile counts, their scan, scan sums, one neighbour index per column
-struct NbrIndex {
-    const int64_t *prev_before;  // [nblocks] last valid row in any earlier block, -1 if none
-    const int64_t *next_after;   // [nblocks] first valid row in any later block, -1 if none
-    int64_t g0;                  // absolute block number of the column's first bit
-};
 // kernel parameter blocks of interp_fill.hip (filled by extras.cpp, passed by value)
 struct InterpCol {
     const uint64_t *values;

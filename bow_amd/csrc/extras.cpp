@@ -451,10 +451,12 @@ static int interp_fill_impl(const bowgpu_col *cols, int32_t ncols, int32_t ts_co
     return 0;
 }
 
-// Rolling.Interpolate over an interval column WITH NULLS, exclusive iteration (ts_nulls.hip has the semantics and the kernels): the
+// Rolling.Interpolate over an interval column WITH NULLS (ts_nulls.hip has the semantics and the kernels): the
 // call is made on the kept rows - those inside some window's slice - compacted into device temporaries, plus a marker column that
 // tells afterwards which output rows are copies of null-timestamp rows; those get their null timestamp and their values' own
-// validity back.  outs == nullptr: the row count only.  *applies = false: the interval column has no nulls.
+// validity back; after an inclusive iteration the second copy of a row on a window start with null timestamps behind it becomes the
+// synthetic start row of the window that begins behind it.  outs == nullptr: the row count only.  *applies = false: the interval
+// column has no nulls.
 static int interp_null_ts(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval, const bowgpu_options *opts,
                           const bowgpu_interp *interps, int32_t ninterps, int64_t *n_out, bowgpu_out *outs, bool *applies) {
     *applies = false;
@@ -473,7 +475,6 @@ static int interp_null_ts(const bowgpu_col *cols, int32_t ncols, int32_t ts_col,
     if (dts.null_count <= 0) return 0;
     *applies = true;
     const int64_t n = tsc->length;
-    if (o.inclusive) return fail(BOWGPU_ERR_TS_NULLS, "interval column has %lld nulls and the windows are inclusive: Interpolate is outside the device path", (long long)dts.null_count);
     if (ncols > kMaxCompactCols) return fail(BOWGPU_ERR_UNSUPPORTED, "Interpolate over an interval column with nulls: at most %d columns", kMaxCompactCols);
     for (int i = 0; i < ncols; i++)
         if (cols[i].length != n) return fail(BOWGPU_ERR_ARG, "column %d has a different length", i);
@@ -486,21 +487,35 @@ static int interp_null_ts(const bowgpu_col *cols, int32_t ncols, int32_t ts_col,
     BG_TRY(fetch_valid(c, tsc, n - 1, &last_valid));
     if (!last_valid || plan.W == 0) return nothing();      // HasNext (rolling.go:162-173) is false from the start: no window, no rows
     // the rows that belong to a window, compacted
-    DevBuf ixbuf, ts_eff, keep, dropped, counts, base, sums, flags, marker, marker_bits;
+    const int incl = o.inclusive ? 1 : 0;
+    DevBuf ixbuf, ts_eff, keep, plain_ts, dropped, counts, base, sums, flags, marker, marker_bits, ts_bits;
     NbrIndex ix;
     BG_TRY(ixbuf.alloc(nbr_index_bytes(n, dts.vbit0)));
     BG_TRY(nbr_index_build(c, dts.vbits, dts.vbit0, n, ixbuf.p, &ix));
     BG_TRY(ts_eff.alloc((size_t)n * 8 + 16));
     const int64_t nw = (n + 63) >> 6;
     BG_TRY(keep.alloc((size_t)nw * 8 + 8));
-    BG_TRY(dropped.alloc(16));
-    BG_TRY(launch_ts_nullfill(c, reinterpret_cast<const int64_t *>(dts.values), dts.vbits, dts.vbit0, n, ix, plan.s0, plan.interval, plan.magic, 0,
-                              reinterpret_cast<int64_t *>(ts_eff.p), reinterpret_cast<uint64_t *>(keep.p), nullptr, reinterpret_cast<unsigned long long *>(dropped.p)));
+    BG_TRY(dropped.alloc(32));
+    BG_HIP(hipMemsetAsync(dropped.p, 0, 32, c->stream));
+    if (incl) BG_TRY(plain_ts.alloc((size_t)nw * 8 + 8));
+    // (inclusive iteration: mode 2 - the rows on a window start with a null timestamp behind them stay, ts_nulls.hip; slot 1 of `dropped`
+    // counts the two shapes of them this path cannot express)
+    BG_TRY(launch_ts_nullfill(c, reinterpret_cast<const int64_t *>(dts.values), dts.vbits, dts.vbit0, n, ix, plan.s0, plan.interval, plan.magic, incl ? 2 : 0,
+                              reinterpret_cast<int64_t *>(ts_eff.p), reinterpret_cast<uint64_t *>(keep.p), reinterpret_cast<uint64_t *>(plain_ts.p),
+                              reinterpret_cast<unsigned long long *>(dropped.p)));
+    if (incl) {
+        unsigned long long h_out = 0;
+        BG_HIP(hipMemcpyAsync(&h_out, reinterpret_cast<unsigned long long *>(dropped.p) + 1, 8, hipMemcpyDeviceToHost, c->stream));
+        BG_HIP(hipStreamSynchronize(c->stream));
+        if (h_out)
+            return fail(BOWGPU_ERR_TS_NULLS, "inclusive Interpolate over an interval column with nulls: %llu row(s) on a window start with null timestamps behind them are "
+                        "followed by an equal timestamp or sit on -1: outside the device path", h_out);
+    }
     BG_TRY(counts.alloc((size_t)nw * 4 + 16));
     BG_TRY(base.alloc((size_t)(nw + 1) * 8 + 16));
     BG_TRY(sums.alloc((size_t)((nw + 2047) / 2048 + 2) * 8));
     BG_TRY(launch_keep_counts(c, reinterpret_cast<const uint64_t *>(keep.p), nw, reinterpret_cast<int32_t *>(counts.p)));
-    int64_t *d_total = reinterpret_cast<int64_t *>(dropped.p) + 1;
+    int64_t *d_total = reinterpret_cast<int64_t *>(dropped.p) + 2;
     BG_TRY(launch_exclusive_scan(c, reinterpret_cast<const int32_t *>(counts.p), nw, reinterpret_cast<int64_t *>(base.p), reinterpret_cast<int64_t *>(sums.p), d_total));
     int64_t m = 0;
     BG_HIP(hipMemcpyAsync(&m, d_total, 8, hipMemcpyDeviceToHost, c->stream));
@@ -524,8 +539,10 @@ static int interp_null_ts(const bowgpu_col *cols, int32_t ncols, int32_t ts_col,
     BG_TRY(flags.alloc((size_t)m * 4 + 16));
     BG_TRY(marker.alloc((size_t)m * 8 + 16));
     BG_TRY(marker_bits.alloc(mbm));
+    if (incl) { BG_TRY(ts_bits.alloc(mbm)); cc.ts_bits = reinterpret_cast<uint64_t *>(ts_bits.p); }
     BG_TRY(launch_compact_rows(c, reinterpret_cast<const uint64_t *>(keep.p), reinterpret_cast<const int64_t *>(base.p), n, reinterpret_cast<const int64_t *>(ts_eff.p),
-                               dts.vbits, dts.vbit0, cc, reinterpret_cast<int64_t *>(marker.p), reinterpret_cast<uint32_t *>(flags.p)));
+                               dts.vbits, dts.vbit0, reinterpret_cast<const uint64_t *>(plain_ts.p), cc, reinterpret_cast<int64_t *>(marker.p),
+                               reinterpret_cast<uint32_t *>(flags.p)));
     BG_TRY(launch_pack_flags(c, reinterpret_cast<const uint32_t *>(flags.p), m, cc, reinterpret_cast<uint64_t *>(marker_bits.p)));
     device_write_epoch_bump();      // (temporaries may sit where an earlier call's columns sat: no count -> fill reuse across this point)
     // the compacted call: the Bow's columns + the marker under interpolation.None
@@ -564,8 +581,23 @@ static int interp_null_ts(const bowgpu_col *cols, int32_t ncols, int32_t ts_col,
     BG_TRY(interp_fill_impl(cols2.data(), ncols + 1, ts_col, interval, &o, interps2.data(), ninterps + 1, touts.data(), nullptr, nullptr));
     c->interp_cache.valid = false;
     if (touts[0].length != m_out) return fail(BOWGPU_ERR_ARG, "internal: Interpolate over an interval column with nulls produced %lld rows, counted %lld", (long long)touts[0].length, (long long)m_out);
+    PatchInterps px;
+    memset(&px, 0, sizeof px);
+    px.m = m;
+    std::vector<DevBuf> nbrbufs(ncols);
+    if (incl) {
+        for (int i = 0; i < ncols; i++) {
+            px.both_bits[i] = i == ts_col ? reinterpret_cast<const uint64_t *>(ts_bits.p) : reinterpret_cast<const uint64_t *>(cbits[i].p);
+            BG_TRY(nbrbufs[i].alloc(nbr_index_bytes(m, 0)));
+            BG_TRY(nbr_index_build(c, reinterpret_cast<const uint32_t *>(px.both_bits[i]), 0, m, nbrbufs[i].p, &px.nbr[i]));
+            px.type[i] = cols[i].type; px.kind[i] = interps[i].kind; px.const_value[i] = interps[i].const_value;
+            px.has_prev[i] = interps[i].has_prev_row; px.prev_t_valid[i] = interps[i].prev_t_valid; px.prev_v_valid[i] = interps[i].prev_v_valid;
+            px.prev_t[i] = interps[i].prev_t; px.prev_v[i] = interps[i].prev_v; px.prev_v_i64[i] = interps[i].prev_v_i64;
+        }
+    }
     BG_TRY(launch_interp_patch(c, reinterpret_cast<const int64_t *>(tvals[ncols].p), reinterpret_cast<const uint32_t *>(tbits[ncols].p), m_out,
-                               reinterpret_cast<const uint32_t *>(flags.p), cc));
+                               reinterpret_cast<const uint32_t *>(flags.p), cc, px));
+    BG_HIP(hipStreamSynchronize(c->stream));       // (nbrbufs are released at the end of this scope)
     void *dscr;
     BG_TRY(ctx_scratch(c, 8192, &dscr));
     uint64_t *dcnt = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(dscr) + 1024);

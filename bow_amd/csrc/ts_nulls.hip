@@ -19,6 +19,7 @@
 // the slice, valid or not) is Count over the keep bits.
 #include "bitmap_device.h"
 #include "agg_device.h"
+#include "interp_device.h"
 
 namespace bowgpu {
 
@@ -69,7 +70,14 @@ __global__ __launch_bounds__(256) void ts_nullfill_kernel(const int64_t *__restr
             ts_eff[i] = ts[i];
             tv = true;
             quirk = inclusive && quirk_row(ts, tbits, tbit0, n, ix, s0, interval, magic, i);
-            k = !quirk;
+            k = !quirk || inclusive == 2;     // (Interpolate keeps such a row: it is the last row of its window's slice)
+            if (quirk && inclusive == 2) {
+                // two shapes the compacted call cannot express (interp_null_ts declines them): the next valid timestamp EQUALS this row's - the
+                // next window then has its start and adds no row, an ordinary call would copy this row a second time - and a row on -1,
+                // the value interpolateWindow uses for "no first value" (interpolation.go:119-127)
+                const int64_t b = next_valid_ix(tbits, tbit0, n, i + 1, ix);
+                if (ts[i] == -1 || (b >= 0 && ts[b] == ts[i])) atomicAdd(n_dropped + 1, 1ull);
+            }
         } else {
             const int64_t p = prev_valid_ix(tbits, tbit0, n, i - 1, ix);   // (row 0 is valid: the constructor checked it, rolling.go:89-93)
             const int64_t q = next_valid_ix(tbits, tbit0, n, i + 1, ix);
@@ -87,7 +95,7 @@ __global__ __launch_bounds__(256) void ts_nullfill_kernel(const int64_t *__restr
             dropped = !k;
         }
     }
-    const unsigned long long m = __ballot(k), d = __ballot(dropped || quirk), pm = __ballot(tv && !quirk);
+    const unsigned long long m = __ballot(k), d = __ballot(dropped || (quirk && inclusive != 2)), pm = __ballot(tv && !quirk);
     if ((threadIdx.x & 63) == 0) {
         if (i < n) { keep[i >> 6] = m; if (plain) plain[i >> 6] = pm; }
         if (d) atomicAdd(n_dropped, (unsigned long long)__popcll(d));
@@ -178,10 +186,12 @@ __global__ __launch_bounds__(256) void keep_counts_kernel(const uint64_t *__rest
     if (w < nw) counts[w] = __popcll(keep[w]);
 }
 
-// flags[dst]: bit 0 = the row's timestamp is valid, bit 1 + c = column c has a value in it (the interval column: its timestamp)
+constexpr uint32_t kFlagQuirk = 1u << 31;
+// flags[dst]: bit 0 = the row's timestamp is valid, bit 1 + c = column c has a value in it (the interval column: its timestamp), bit 31: kFlagQuirk
 __global__ __launch_bounds__(256) void compact_rows_kernel(const uint64_t *__restrict__ keep, const int64_t *__restrict__ base, const int64_t n,
                                                            const int64_t *__restrict__ ts_eff, const uint32_t *__restrict__ tbits, const int64_t tbit0,
-                                                           const CompactCols cc, int64_t *__restrict__ marker, uint32_t *__restrict__ flags) {
+                                                           const uint64_t *__restrict__ plain, const CompactCols cc, int64_t *__restrict__ marker,
+                                                           uint32_t *__restrict__ flags) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint64_t kw = keep[i >> 6];
@@ -194,6 +204,7 @@ __global__ __launch_bounds__(256) void compact_rows_kernel(const uint64_t *__res
         if (c == cc.ts_col) { cc.out_values[c][dst] = (uint64_t)ts_eff[i]; if (tv) f |= 2u << c; }
         else { cc.out_values[c][dst] = cc.values[c][i]; if (bit_at(cc.vbits[c], cc.vbit0[c], i)) f |= 2u << c; }
     }
+    if (plain && tv && !((plain[i >> 6] >> lane) & 1ull)) f |= kFlagQuirk;     // (inclusive iteration: ts_nulls.hip's "row on a window start ...")
     flags[dst] = f;
     marker[dst] = dst;
 }
@@ -204,19 +215,46 @@ __global__ __launch_bounds__(256) void pack_flags_kernel(const uint32_t *__restr
     const uint32_t f = i < m ? flags[i] : 1u;
     const bool lane0 = (threadIdx.x & 63) == 0 && i < m;
     for (int c = 0; c < cc.ncols; c++) {
-        const unsigned long long b = __ballot((f & 1u) && ((f >> (1 + c)) & 1u));
+        const unsigned long long b = __ballot(i < m && (f & 1u) && ((f >> (1 + c)) & 1u));
         if (lane0 && cc.lookup_bits[c]) cc.lookup_bits[c][i >> 6] = b;
+        if (lane0 && c == cc.ts_col && cc.ts_bits) cc.ts_bits[i >> 6] = b;     // (the patch pass looks neighbours of the interval column up too)
     }
-    const unsigned long long mb = __ballot(!(f & 1u));
+    const unsigned long long mb = __ballot(!(f & 1u) || (f & kFlagQuirk));
     if (lane0) marker_bits[i >> 6] = mb;
 }
 
 __global__ __launch_bounds__(256) void interp_patch_kernel(const int64_t *__restrict__ marker_out, const uint32_t *__restrict__ marker_valid, const int64_t m_out,
-                                                           const uint32_t *__restrict__ flags, const CompactCols cc) {
+                                                           const uint32_t *__restrict__ flags, const CompactCols cc, const PatchInterps px) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m_out || !((marker_valid[j >> 5] >> (j & 31)) & 1u)) return;
     const int64_t r = marker_out[j];
     const uint32_t f = flags[r];
+    if (f & 1u) {
+        // a row with a timestamp under the marker: a row on a window start with a null timestamp behind it (inclusive iteration).  Its
+        // FIRST copy closes the window it ends; the copy right behind it stands where the next window - which begins at the last of
+        // those null rows, without this row - gets its synthetic start row (interpolation.go:137-160): the interpolators' values at the
+        // window's start, neighbours looked up among the rows with timestamp AND value from this row down / from the row behind it up
+        if (!(f & kFlagQuirk) || j == 0 || !((marker_valid[(j - 1) >> 5] >> ((j - 1) & 31)) & 1u) || marker_out[j - 1] != r) return;
+        const int64_t sk = (int64_t)cc.out_values[cc.ts_col][r];
+        for (int c = 0; c < cc.ncols; c++) {
+            InterpCol ic;
+            ic.type = px.type[c]; ic.kind = px.kind[c]; ic.const_value = px.const_value[c];
+            ic.has_prev = px.has_prev[c]; ic.prev_t_valid = px.prev_t_valid[c]; ic.prev_v_valid = px.prev_v_valid[c];
+            ic.prev_t = px.prev_t[c]; ic.prev_v = px.prev_v[c]; ic.prev_v_i64 = px.prev_v_i64[c];
+            ic.next_valid = 0; ic.next_t = 0; ic.next_v = 0;
+            const uint32_t *lb = reinterpret_cast<const uint32_t *>(px.both_bits[c]);
+            const int64_t pi = prev_valid_ix(lb, 0, px.m, r, px.nbr[c]), ni = next_valid_ix(lb, 0, px.m, r + 1, px.nbr[c]);
+            NbPoint pp, np;
+            pp.has = pi >= 0; pp.t = pi >= 0 ? (int64_t)cc.out_values[cc.ts_col][pi] : 0; pp.bits = pi >= 0 ? cc.out_values[c][pi] : 0;
+            np.has = ni >= 0; np.t = ni >= 0 ? (int64_t)cc.out_values[cc.ts_col][ni] : 0; np.bits = ni >= 0 ? cc.out_values[c][ni] : 0;
+            uint64_t bits; int valid;
+            synth_value_pt(ic, sk, pp, np, &bits, &valid);
+            cc.patch_values[c][j] = bits;
+            if (valid) atomicOr(&cc.patch_valid[c][j >> 5], 1u << (j & 31));
+            else atomicAnd(&cc.patch_valid[c][j >> 5], ~(1u << (j & 31)));
+        }
+        return;
+    }
     for (int c = 0; c < cc.ncols; c++) {
         if ((f >> (1 + c)) & 1u) {
             cc.patch_values[c][j] = cc.out_values[c][r];
@@ -269,9 +307,9 @@ int launch_keep_counts(Ctx *c, const uint64_t *keep, int64_t nw, int32_t *counts
 }
 
 int launch_compact_rows(Ctx *c, const uint64_t *keep, const int64_t *base, int64_t n, const int64_t *ts_eff, const uint32_t *tbits, int64_t tbit0,
-                        const CompactCols &cc, int64_t *marker, uint32_t *flags) {
+                        const uint64_t *plain, const CompactCols &cc, int64_t *marker, uint32_t *flags) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(compact_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, keep, base, n, ts_eff, tbits, tbit0, cc, marker, flags);
+    hipLaunchKernelGGL(compact_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, keep, base, n, ts_eff, tbits, tbit0, plain, cc, marker, flags);
     BG_HIP(hipGetLastError());
     return 0;
 }
@@ -283,9 +321,10 @@ int launch_pack_flags(Ctx *c, const uint32_t *flags, int64_t m, const CompactCol
     return 0;
 }
 
-int launch_interp_patch(Ctx *c, const int64_t *marker_out, const uint32_t *marker_valid, int64_t m_out, const uint32_t *flags, const CompactCols &cc) {
+int launch_interp_patch(Ctx *c, const int64_t *marker_out, const uint32_t *marker_valid, int64_t m_out, const uint32_t *flags, const CompactCols &cc,
+                        const PatchInterps &px) {
     if (m_out <= 0) return 0;
-    hipLaunchKernelGGL(interp_patch_kernel, dim3((unsigned)((m_out + 255) / 256)), dim3(256), 0, c->stream, marker_out, marker_valid, m_out, flags, cc);
+    hipLaunchKernelGGL(interp_patch_kernel, dim3((unsigned)((m_out + 255) / 256)), dim3(256), 0, c->stream, marker_out, marker_valid, m_out, flags, cc, px);
     BG_HIP(hipGetLastError());
     return 0;
 }

@@ -62,9 +62,10 @@ enum {
     BOWGPU_ERR_ARG = -10,
     BOWGPU_ERR_NO_DEVICE = -11,      /* no HIP device / runtime: the product path has no CPU fallback */
     BOWGPU_ERR_HIP = -12,            /* a HIP call failed; message has the hipError string */
-    BOWGPU_ERR_TS_NULLS = -13,       /* interval column has nulls AND the call has Mode, is sharded, or is Rolling.Interpolate on inclusive
-                                        windows: the device path declines (caller keeps the reference path); Aggregate and Interpolate
-                                        are served otherwise */
+    BOWGPU_ERR_TS_NULLS = -13,       /* interval column has nulls AND the call has Mode or is sharded (or, Rolling.Interpolate on inclusive
+                                        windows: a row on a window start has null timestamps behind it and then an EQUAL timestamp, or sits on
+                                        -1): the device path declines (caller keeps the reference path); Aggregate and Interpolate are served
+                                        otherwise */
     BOWGPU_ERR_TS_UNSORTED = -14,    /* interval column not ascending: device path declines */
     BOWGPU_ERR_OOM = -15
 };
@@ -295,8 +296,9 @@ typedef struct bowgpu_interp {
  * BOWGPU_ERR_ARG and the outputs are to be discarded.
  * _fill does not NEED a preceding _count: called on its own it sizes the outputs itself against bowgpu_out.length (in: capacity;
  * rows + windows always suffice; too small is BOWGPU_ERR_ARG naming the size).  Inclusive windows then take one pass over the rows
- * (n_out = n + W - [row 0 on its window's start] needs no count); exclusive windows make their own count pass first.  * An interval column WITH NULLS (exclusive windows): the output is the windows' slices - rows that belong to no window vanish
- * (rolling.go:190-193, :224-228), null-timestamp rows inside a slice are copied as they are; inclusive windows: BOWGPU_ERR_TS_NULLS.
+ * (n_out = n + W - [row 0 on its window's start] needs no count); exclusive windows make their own count pass first.  * An interval column WITH NULLS: the output is the windows' slices - rows that belong to no window vanish (rolling.go:190-193,
+ * :224-228), null-timestamp rows inside a slice are copied as they are; inclusive windows too (incl. rolling.go:214-218's
+ * `rowIndex - 1` after a null), except for two shapes that are BOWGPU_ERR_TS_NULLS (see the error code).
  */
 int bowgpu_rolling_interpolate_count(const bowgpu_col *cols, int32_t ncols, int32_t ts_col,
                                      int64_t interval, const bowgpu_options *opts,

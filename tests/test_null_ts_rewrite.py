@@ -221,3 +221,110 @@ def test_interpolate_on_the_kept_rows_plus_a_marker_column_gives_the_oracles_ans
         assert np.array_equal(gts_m, wm0) and np.array_equal(gv_m, wm1), label
         assert np.array_equal(got[0].values[:m_out].view(np.uint64)[gts_m], want[0].values[:m_out].view(np.uint64)[wm0]), label
         assert np.array_equal(gv.view(np.uint64)[gv_m], want[1].values[:m_out].view(np.uint64)[wm1]), label
+
+
+def _synth(kind, sk, pp, np_, prevrow):
+    # pp / np_: (t, v) or None ; float64 column
+    if kind == "None": return None
+    if kind == "StepPrevious":
+        if pp is not None: return pp[1]
+        if prevrow is not None and prevrow[3]: return prevrow[2]
+        return None
+    if kind == "Linear":
+        if pp is not None: t0, v0 = float(pp[0]), pp[1]
+        elif prevrow is not None and prevrow[1] and prevrow[3]: t0, v0 = prevrow[0], prevrow[2]
+        else: return None
+        if np_ is None: return None
+        t2, v2 = float(np_[0]), np_[1]
+        with np.errstate(all='ignore'):
+            coef = (np.float64(sk) - np.float64(t0)) / (np.float64(t2) - np.float64(t0))
+            return float((np.float64(v2) - np.float64(v0)) * coef + np.float64(v0))
+
+
+def test_inclusive_interpolate_on_the_kept_rows_gives_the_oracles_answer():
+    """Rolling.Interpolate over an interval column with nulls after an INCLUSIVE iteration, as extras.cpp interp_null_ts makes it: the
+    kept rows - the inclusive keep rule, the rows on a window start with a null timestamp behind them included - compacted, the
+    marker column valid in the null-timestamp rows AND in those rows; the ordinary inclusive call then copies such a row twice (the
+    end of its window, the start of the next); the second copy stands where the reference has the next window's synthetic start row
+    (that window begins at the last null row, without the row on its start: rolling.go:214-218) and is replaced by the
+    interpolators' values there.  Two shapes are declined: an equal timestamp right behind the null rows (the next window then has
+    its start and adds no row), and such a row on -1 (interpolation.go:119-127's "no first value")."""
+    pack = lambda m: np.packbits(m, bitorder="little")      # noqa: E731
+    synth = _synth
+    nq = 0
+    rng = np.random.default_rng(21)
+    for case in range(600):
+        null_frac = rng.choice([0.03, 0.3, 0.6])
+        n = int(rng.integers(1, 100))
+        ts = np.cumsum(rng.integers(0, 7, n)).astype(np.int64) + int(rng.integers(-60, 60))
+        tvalid = rng.random(n) >= null_frac
+        tvalid[0] = tvalid[-1] = True
+        vals = np.round(rng.standard_normal(n) * 10, 2)
+        vvalid = rng.random(n) >= 0.25
+        interval = int(rng.choice([1, 2, 5, 10, 40]))
+        offset = int(rng.integers(-interval, 2 * interval))
+        ocols = [orc.Column(ts, pack(tvalid), orc.INT64), orc.Column(vals, pack(vvalid), orc.FLOAT64)]
+        try:
+            s0, W = orc.plan_windows(ocols[0], interval, offset)
+        except orc.OracleError:
+            continue
+        kind = ["Linear", "StepPrevious", "None"][case % 3]
+        ip = [{"kind": "WindowStart", "col": 0}, {"kind": kind, "col": 1}]
+        prevrow = None
+        if case % 2:
+            prevrow = (float(ts[0] - 3), True, 42.5, True, 42)
+            ip[1]["prev"] = prevrow
+        want = orc.interpolate(ocols, 0, interval, ip, offset=offset, inclusive=True)
+        ts_eff, keep, quirk = rewrite_inclusive(ts, tvalid, s0, interval)
+        keep = keep & ~quirk
+        nq += int(quirk.any())
+        outside = False                      # the two shapes interp_null_ts declines (ts_nulls.hip ts_nullfill_kernel, mode 2)
+        for i in np.nonzero(quirk)[0]:
+            b = i + 1
+            while b < n and not tvalid[b]:
+                b += 1
+            if (b < n and ts[b] == ts[i]) or ts[i] == -1:
+                outside = True
+        if outside:
+            continue
+        k = np.nonzero(keep | quirk)[0]
+        cts, cv, ctv, cvv, cq = ts_eff[k], vals[k], tvalid[k], vvalid[k], quirk[k]
+        m = len(k)
+        marker = np.arange(m, dtype=np.int64)
+        dense = [orc.Column(cts, None, orc.INT64), orc.Column(cv, pack(cvv & ctv), orc.FLOAT64), orc.Column(marker, pack(~ctv | cq), orc.INT64)]
+        got = orc.interpolate(dense, 0, interval, ip + [{"kind": "None", "col": 2}], offset=offset, inclusive=True)
+        mo = got[0].length
+        gts_m, gv_m = got[0].valid_mask().copy(), got[1].valid_mask().copy()
+        gts, gv = got[0].values[:mo].copy(), got[1].values[:mo].copy()
+        mm = got[2].valid_mask(); mv = got[2].values[:mo]
+        both = tvalid & vvalid
+        for j in np.nonzero(mm)[0]:
+            r = mv[j]
+            if not ctv[r]:      # copy of a null-timestamp row
+                gts_m[j] = False
+                gv_m[j] = cvv[r]
+                if cvv[r]: gv[j] = cv[r]
+            elif cq[r] and j > 0 and mm[j - 1] and mv[j - 1] == r:   # the second copy of a quirk row: the next window's synthetic start row
+                i = k[r]                      # original row
+                sk = ts[i]
+                pi = i
+                while pi >= 0 and not both[pi]: pi -= 1
+                b = i + 1
+                while b < n and not tvalid[b]: b += 1
+                ni = b
+                while ni < n and not both[ni]: ni += 1
+                pp = (ts[pi], vals[pi]) if pi >= 0 else None
+                nn = (ts[ni], vals[ni]) if ni < n else None
+                x = synth(kind, sk, pp, nn, prevrow)
+                gts[j] = sk; gts_m[j] = True
+                if x is None: gv_m[j] = False
+                else: gv_m[j] = True; gv[j] = x
+        info = (case, [int(x) for x in ts], list(tvalid.astype(int)), list(vvalid.astype(int)), interval, offset, kind)
+        assert mo == want[0].length, (mo, want[0].length, info)
+        wm0, wm1 = want[0].valid_mask(), want[1].valid_mask()
+        assert np.array_equal(gts_m, wm0), info
+        assert np.array_equal(gv_m, wm1), (np.nonzero(gv_m != wm1)[0], info)
+        assert np.array_equal(gts.view(np.uint64)[gts_m], want[0].values[:mo].view(np.uint64)[wm0]), info
+        assert np.array_equal(gv.view(np.uint64)[gv_m], want[1].values[:mo].view(np.uint64)[wm1]), info
+
+    assert nq > 100
