@@ -791,6 +791,14 @@ def test_null_timestamps_numrows_counts_the_rows_of_the_slice():
     ts2 = ts.copy(); ts2[5] = 20; ts2[6] = 21
     want = _run_null_ts(ts2, tvalid, vals, None, 10, aggs=[("WindowStart", 0), ("NumRows", 1), ("First", 1), ("IntegralTrapezoid", 1)])
     assert want[1].to_list()[1] == 2.0 and want[2].to_list()[1] == 6.0
+    # a planned call (bowgpu_plan_windows_ex + bowgpu_rolling_aggregate_planned) over the same frame takes the same path
+    tbm = np.packbits(tvalid, bitorder="little")
+    ccols = [capi.Column(ts2, tbm, capi.INT64, 0, len(ts2), -1).to_device(), capi.Column(vals).to_device()]
+    plan = capi.plan_windows_ex(ccols[0], 10, 0)
+    aggs = [("WindowStart", 0), ("NumRows", 1), ("First", 1), ("IntegralTrapezoid", 1)]
+    got, _info = capi.rolling_aggregate(ccols, 0, 10, aggs, plan=plan)
+    for (k, _c), g, w in zip(aggs, got, want):
+        compare("planned null ts %s" % k, g, w)
 
 
 def test_null_timestamps_runs_at_window_edges_and_the_null_last_row():
