@@ -98,35 +98,44 @@ def cpu_baseline_parallel(capi, rows_sample):
                       "thread pool, %.1f s" % (reps, rows_sample, len(ranges), dt)}
 
 
-def kernel_source_sha():
-    """hash of the sources the benched kernel is compiled from: ties a committed counter file to the code that is running"""
-    import hashlib
-    h = hashlib.sha256()
-    for f in ("rolling_simple.hip", "agg_device.h", "common.h"):
-        with open(os.path.join(ROOT, "bow_amd", "csrc", f), "rb") as fh:
-            h.update(fh.read())
-    return h.hexdigest()[:16]
+# the instantiation the benched call runs (one Float64 column without nulls, 10-row windows: the unpadded small-list form);
+# tests/test_gpu_fullsize.py asserts it on the GPU, tests/test_profiles_fresh.py that the committed counters are its
+BENCH_KERNEL_INSTANCE = "rolling_simple_kernel<0, false, false, false, false, false, false>"
 
 
-def measured_traffic(rows, kernel=None):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r*_pmc_hbm_traffic_bench_1e9.csv:
-    FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, in KB) - only when they were collected for this row count, for this kernel and from the
-    sources this tree holds (each row carries the full kernel signature and a hash of the kernel's sources); None otherwise (PMC
-    cannot be collected from inside the timed run)."""
-    import csv
+def kernel_sha(instance):
+    """identity of one rolling_simple_kernel instantiation as the build left it next to the library (bow_amd/csrc/kernel_sha.py:
+    sha256 over the kernel's machine code + descriptor): ties a committed counter file to the code that is running.  Round 4 hashed
+    three source files; an edit to common.h that changed nothing the kernel is compiled from made the evidence look stale and the
+    driver's line lost its counter traffic."""
+    try:
+        with open(os.path.join(ROOT, "bow_amd", "libbowgpu.kernel_sha.json")) as fh:
+            return json.load(fh)["kernels"].get(instance, {}).get("sha")
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+def newest_traffic_file():
     import glob
-    if rows != 1_000_000_000:
+    import re
+    files = glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic_bench_1e9.csv"))
+    return max(files, key=lambda f: int(re.search(r"r(\d+)_pmc", os.path.basename(f)).group(1))) if files else None
+
+
+def measured_traffic(rows, instance=None):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r*_pmc_hbm_traffic_bench_1e9.csv:
+    FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, in KB) - only when they were collected for this row count, for the instantiation that ran
+    and from the machine code this library holds (each row carries the full kernel signature and the kernel's sha); None otherwise
+    (PMC cannot be collected from inside the timed run)."""
+    import csv
+    f_ = newest_traffic_file()
+    sha = kernel_sha(instance) if instance else None
+    if rows != HEADLINE_ROWS or not f_ or not sha:
         return None
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic_bench_1e9.csv")))
-    if not files:
-        return None
-    sha = kernel_source_sha()
     f, w = [], []
-    for r in csv.DictReader(open(files[-1])):
-        if r.get("source_sha") != sha:
-            continue  # counters of another build of the kernel: not this run's traffic
-        if kernel and kernel not in r["kernel"]:
-            continue
+    for r in csv.DictReader(open(f_)):
+        if r.get("kernel_sha") != sha or instance not in r["kernel"]:
+            continue  # counters of another build of the kernel / of another instantiation: not this run's traffic
         (f if r["counter"] == "FETCH_SIZE" else w).append(float(r["value_KB"]))
     if not f or not w:
         return None
@@ -446,6 +455,7 @@ def main():
         value = total_rows / dt
         k_ms = sum(kernel_ms) / len(kernel_ms)
         kernel_name = capi.last_kernel_name()
+        kernel_instance = capi.last_kernel_instance()
         achieved = rows * BYTES_PER_ROW / (k_ms * 1e-3) / 1e9
         line = {
             "metric": "rows/sec rolling-mean on 1B-row float64",
@@ -466,12 +476,14 @@ def main():
                        "rows_per_gpu": rows, "windows_per_gpu": rows // interval, "parallelism": "rows range-partitioned x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": kernel_name, "kernel_ms": k_ms,
+                         "kernel": kernel_name, "kernel_instance": kernel_instance, "kernel_sha": kernel_sha(kernel_instance), "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": rows * BYTES_PER_ROW},
             "device": capi.device_name(),
             "parity_check": parity,
         }
-        line["roofline"]["traffic"] = measured_traffic(rows, kernel_name)
+        line["roofline"]["traffic"] = measured_traffic(rows, kernel_instance)
+        if line["roofline"]["traffic"] is not None:
+            line["roofline"]["traffic_source"] = "profiles/" + os.path.basename(newest_traffic_file()) + " (2 x FETCH_SIZE + WRITE_SIZE, same kernel_sha)"
         if world > 1:
             # THE exchange of a step (upload + all_gather of one 2424-byte record per rank + download, pinned buffers allocated once):
             # alone it takes exchange_ms; in the timed steps it is in flight while the pass runs, and the step is exchange_hidden_ms

@@ -213,6 +213,11 @@ __device__ __forceinline__ bool kind_is_integral(int kind) {
 __device__ __forceinline__ double vmin64(double a, double b) { double d; asm("v_min_f64 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 __device__ __forceinline__ double vmax64(double a, double b) { double d; asm("v_max_f64 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 constexpr uint64_t kNullAsNaN = 0x7FF8000000000000ull;   // what a null row holds in LDS while extrema are walked (x < mn and x > mx are false for it)
+// a signalling NaN (v_cmp_class_f64, class bit 0).  The kernels run in IEEE mode: v_min_f64 / v_max_f64 return a signalling operand
+// QUIETED, and the next step then drops that quiet NaN for the row after it - the running extremum is lost ([5, sNaN, 7]: 7, where
+// minmax.go:22-27 keeps 5).  So the staging pass looks for one (one compare per row, all lanes busy) and a tile that holds one walks
+// its extrema with the comparison itself (walk_values' `exact_mm`).
+__device__ __forceinline__ bool is_snan(uint64_t bits) { return __builtin_amdgcn_class(__longlong_as_double((long long)bits), 1); }
 
 // valid rows of the window [r0, r1) of a tile whose validity words (32 rows each, tile-relative) are vbits[]: how many, the first,
 // the last (count.go:12-18, firstlast.go:11-35, the seed of minmax.go:16-21); fv = lv = -1 when there is none
@@ -280,11 +285,12 @@ __device__ __forceinline__ void walk_rows(const uint64_t *val, int r, const int 
 // rows fv .. lv of the staged column (sum.go:16-22, arithmeticmean.go:17-24, minmax.go:16-28).  Extrema: v_min_f64 / v_max_f64 from the
 // seed (row fv) on.  The instruction differs from
 // `if x < mn { mn = x }` in three cases only - the seed is a NaN (minmax.go keeps it: no value compares below a NaN; the instruction
-// drops it), a signalling NaN among the values (the instruction returns it quieted), and a result of zero (+0 and -0 are equal for
-// minmax.go, so the EARLIEST zero stays; the instruction orders them) - and in those the window is walked again with the
-// comparison itself.  Null rows hold +0.0 when sums are walked and a quiet NaN when extrema are.
+// drops it), a signalling NaN among the values (the instruction returns it quieted and the step after it then drops the running
+// extremum: the RESULT does not show it, so the staging pass reports it - `exact_mm`, see is_snan), and a result of zero (+0 and -0
+// are equal for minmax.go, so the EARLIEST zero stays; the instruction orders them) - and in those the window is walked again with
+// the comparison itself.  Null rows hold +0.0 when sums are walked and a quiet NaN when extrema are.
 template <bool kSwz, bool kEight>
-__device__ __forceinline__ void walk_values(const uint64_t *val, int fv, int lv, bool do_sum, bool do_mm, double &sum, double &mn, double &mx) {
+__device__ __forceinline__ void walk_values(const uint64_t *val, int fv, int lv, bool do_sum, bool do_mm, bool exact_mm, double &sum, double &mn, double &mx) {
     const double seed = __longlong_as_double((long long)val[swz<kSwz>(fv)]);
     sum = 0.0; mn = seed; mx = seed;
     const int rend = lv + 1;
@@ -315,7 +321,7 @@ __device__ __forceinline__ void walk_values(const uint64_t *val, int fv, int lv,
     }
     if (do_mm) {
         if (seed != seed) { mn = seed; mx = seed; }
-        else if (mn == 0.0 || mx == 0.0 || mn != mn || mx != mx) {
+        else if (exact_mm || mn == 0.0 || mx == 0.0 || mn != mn || mx != mx) {
             mn = seed; mx = seed;
             for (int rr = fv + 1; rr < rend; rr++) {
                 const double x = __longlong_as_double((long long)val[swz<kSwz>(rr)]);

@@ -1055,10 +1055,11 @@ static int job_launch_tiles(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t
             // (the head list of a tile comes in two sizes - rolling_simple.hip SimpleCap: the small one buys four more resident
             // wavefronts per CU and serves calls whose windows average >= 5 rows; BOWGPU_ROUTE_SIMPLE_LARGE_LIST / _SMALL_LIST force
             // either, for tests; a call whose tiles overflow the small list is redone with the large one - job_run)
-            const bool dense = force_large_list || ((route & BOWGPU_ROUTE_SIMPLE_LARGE_LIST) ? true : (route & BOWGPU_ROUTE_SIMPLE_SMALL_LIST) ? false : P.n / P.W < 5);
+            // (the unpadded instantiation's small list holds 254 heads: windows of 3 rows and more, as before the pads)
+            const int64_t small_list_rows = rolling_simple_plain(S, is_int, has_nulls) ? 3 : 5;
+            const bool dense = force_large_list || ((route & BOWGPU_ROUTE_SIMPLE_LARGE_LIST) ? true : (route & BOWGPU_ROUTE_SIMPLE_SMALL_LIST) ? false : P.n / P.W < small_list_rows);
             *used_small_list = !dense;
-            BG_TRY(launch_rolling_simple(c, S, need, is_int, has_nulls, wide, dense));
-            c->last_kernel_name = "rolling_simple_kernel";
+            BG_TRY(launch_rolling_simple(c, S, need, is_int, has_nulls, wide, dense));   // (sets c->last_kernel_name: the instantiation)
         }
         *used_simple = true;
     } else if (lean && !P.pre_rows) {

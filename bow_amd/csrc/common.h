@@ -249,6 +249,7 @@ struct SimpleParams {
     int64_t long_cap;
 };
 int launch_rolling_simple(Ctx *c, const SimpleParams &p, int need, bool is_int, bool has_nulls, bool wide, bool dense);   // dense: the larger head list (windows of < 3 rows)
+bool rolling_simple_plain(const SimpleParams &p, bool is_int, bool has_nulls);   // the call takes the unpadded instantiation (short windows over one Float64 column without nulls): its small list holds 254 heads
 int launch_rolling_tw(Ctx *c, const SimpleParams &p, bool is_int, bool has_nulls, bool wide, bool ts32);  // time-weighted reducers / inclusive windows (rolling_tw.hip)
 
 int launch_rolling_aggregate(Ctx *c, const AggParams &p);   // general kernel (rolling_agg.hip)

@@ -11,6 +11,7 @@ enum {
     BOWGPU_ROUTE_SIMPLE_SMALL_LIST = 32, // rolling_simple_kernel: the 254-head list whatever the plan says
     BOWGPU_ROUTE_SIMPLE_LARGE_LIST = 64, // ... the 400-head list
     BOWGPU_ROUTE_TW_F64 = 128,           // rolling_tw_kernel: 64-bit timestamps in LDS even where 32-bit offsets are exact
+    BOWGPU_ROUTE_SIMPLE_PADDED = 256,    // rolling_simple_kernel: the padded staging also for the calls that would take the unpadded instantiation (short windows, one Float64 column without nulls)
     BOWGPU_ROUTE_INTERP_TILE = 512,      // Interpolate (exclusive windows): interp_tile_kernel instead of interp_wave3_kernel
-    BOWGPU_ROUTE__ALL = 3839             // every defined bit, the two public ones (1024, 2048) included
+    BOWGPU_ROUTE__ALL = 4095             // every defined bit, the two public ones (1024, 2048) included
 };

@@ -425,6 +425,10 @@ static int interp_fill_impl(const bowgpu_col *cols, int32_t ncols, int32_t ts_co
         return 0;
     };
     BG_TRY(run_all(1));
+    // An interval column out of order comes FIRST: a one-pass call derives its row count from the first and the last timestamp alone,
+    // so on an unsorted column most trips also fail the "fits the counted range" test below - and the documented answer for such a
+    // column is the decline (BOWGPU_ERR_TS_UNSORTED: the caller keeps the reference's own path), not an argument error.
+    if (hstat[0]) return fail(BOWGPU_ERR_TS_UNSORTED, "interval column is not ascending: outside the device path");
     // (a reused count whose column has changed since: interp_wave3_kernel stored nothing for the trips that did not fit and said
     // so; the kernels a redo would use do not check, so the error comes first)
     if (hstat[6]) return fail(BOWGPU_ERR_ARG, "Interpolate: the rows produced do not add up to the count - the interval column changed between "

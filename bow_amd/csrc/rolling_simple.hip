@@ -35,16 +35,25 @@ constexpr uint32_t kSatS = 0xFFFFu;
 //   kDense = false: 174 heads (152 with nulls), LDS exactly 6144 B - calls whose windows average >= 5 rows
 //   kDense = true : 400 heads (378 with nulls), LDS 6.9 KB          - the rest: windows of 1.6 .. 5 rows, and frames with many
 //                   empty windows (n / W says nothing about their non-empty ones); the round-1 layout
-template <bool kNulls, bool kDense> struct SimpleCap { static constexpr int value = kDense ? (kNulls ? 378 : 400) : (kNulls ? 152 : 174); };
-constexpr bool kSwzS = true;   // the staged column carries two pad slots per 32 rows (agg_device.h swz): regular windows of 16 k rows off one bank
+// kPad: the staged column carries two pad slots per 32 rows (agg_device.h swz): regular windows of 16 k rows off one LDS bank.  Calls of
+// SHORT windows (at most kPlainMaxAvgRows rows on average) over one Float64 column without nulls - the benched shape - take the
+// instantiation WITHOUT the pads: lanes that walk windows a few rows apart never met on a bank, and the pads cost them 45 vector
+// instructions per tile (432 -> 477: the address arithmetic of swz() and the single steps in front of a walk's first aligned group)
+// plus 80 of the head list's entries (254 heads in 6144 B without the pads).
+constexpr int64_t kPlainMaxAvgRows = 16;
+template <bool kNulls, bool kDense, bool kPad> struct SimpleCap {
+    static constexpr int value = kDense ? (kNulls ? 378 : 400) : kPad ? (kNulls ? 152 : 174) : 254;
+};
 constexpr int kAlignS = 16;   // output slots per 128-byte line: the granule of the slot-aligned hand-over between tiles
 
-template <bool kNulls, bool kDense>
+template <bool kNulls, bool kDense, bool kPad>
 struct SimpleShared {
-    uint64_t val[swz_slots(kRowsS)];
+    uint64_t val[kPad ? swz_slots(kRowsS) : kRowsS];
     uint32_t vbits[kNulls ? kRowsS / 32 + 2 : 1];  // validity words of the value column for this tile (kNulls only)
-    uint32_t seg[SimpleCap<kNulls, kDense>::value + (kNulls ? 2 : 1)];  // heads in row order: local row | (wid - wid of the tile's first row) << 16
+    uint32_t seg[SimpleCap<kNulls, kDense, kPad>::value + (kNulls ? 2 : 1)];  // heads in row order: local row | (wid - wid of the tile's first row) << 16
 };
+static_assert(sizeof(SimpleShared<false, false, true>) <= 6144 && sizeof(SimpleShared<true, false, true>) <= 6144 &&
+              sizeof(SimpleShared<false, false, false>) <= 6144, "LDS of the small-list forms: 6 KB (26 wavefronts per CU)");
 
 __device__ __forceinline__ uint32_t mdiv32(uint32_t n, uint32_t m, uint32_t sh1, uint32_t sh2) {
     const uint32_t t = __umulhi(m, n);
@@ -76,11 +85,13 @@ __device__ __forceinline__ void lds_order() {
 // kMulti: more than one value column (the single-column shape keeps its straight-line form)
 // kWide: the rows of the call span 2^32 or more from slot 0 (nanosecond timestamps): window ids are taken relative to the
 // tile's first window (one exact 64-bit division on the scalar unit per tile), which only needs each TILE's rows within 2^32
-template <int kNeed, bool kInt, bool kNulls, bool kMulti, bool kWide, bool kDense>
+template <int kNeed, bool kInt, bool kNulls, bool kMulti, bool kWide, bool kDense, bool kPad>
 __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimpleParams p, const int64_t ntiles,
                                                                   const int64_t tiles_per_xcd) {
-    __shared__ SimpleShared<kNulls, kDense> sh;
-    constexpr int kSegCapS = SimpleCap<kNulls, kDense>::value;
+    static_assert(kPad || (!kInt && !kNulls && !kMulti), "the unpadded form: one Float64 column without nulls");
+    __shared__ SimpleShared<kNulls, kDense, kPad> sh;
+    constexpr int kSegCapS = SimpleCap<kNulls, kDense, kPad>::value;
+    constexpr bool kSwzS = kPad;
     const int64_t b = blockIdx.x;
     const int64_t tile = (b & 7) * tiles_per_xcd + (b >> 3);  // XCD-contiguous tile runs (look-ahead rows hit the same L2)
     if (tile >= ntiles) return;
@@ -166,6 +177,7 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
     uint32_t left_w = base == 0 ? 0xFFFFFFFEu : (pre && left0 < ws0) ? 0u : (kWide && left0 < ws0) ? 0xFFFFFFFEu : mdiv32(rel32(left0), p.m32, p.sh1, p.sh2);
     int64_t left_ts = left0;
     int nseg_total = 0, nseg_owned = 0;
+    bool snan = false;   // (kNeed & 1) a signalling NaN among this lane's staged values: the tile's extrema are walked by comparison (agg_device.h is_snan)
 #pragma unroll
     for (int j = 0; j < kChunksS; j++) {
         const int l = j * 128 + 2 * lane;
@@ -197,7 +209,10 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
         left_ts = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(tb[j] >> 32), 63) << 32) |
                             (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)tb[j], 63));
         // single column: its values go to LDS now (their registers die here)
-        if (!kMulti && !kNulls && !kInt) *reinterpret_cast<ulonglong2 *>(&sh.val[swz<kSwzS>(l)]) = make_ulonglong2(va[j], vb[j]);
+        if (!kMulti && !kNulls && !kInt) {
+            *reinterpret_cast<ulonglong2 *>(&sh.val[swz<kSwzS>(l)]) = make_ulonglong2(va[j], vb[j]);
+            if (kNeed & 1) snan = snan || is_snan(va[j]) || is_snan(vb[j]);
+        }
     }
     if (__ballot(unsorted)) {  // the call fails with BOWGPU_ERR_TS_UNSORTED
         if (lane == 0) atomicOr(&p.status[0], 1u);
@@ -282,6 +297,7 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
                 lds_order();
             }
             const uint64_t fill = need_sum ? 0ull : kNullAsNaN;
+            snan = false;
 #pragma unroll
             for (int j = 0; j < kChunksS; j++) {
                 uint64_t xa = va[j], xb = vb[j];
@@ -294,6 +310,7 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
                     if (!(two & 1u)) xa = fill;
                     if (!(two & 2u)) xb = fill;
                 }
+                if ((kNeed & 1) && !cint) snan = snan || is_snan(xa) || is_snan(xb);   // (what is staged: a null row's own bits are gone)
                 *reinterpret_cast<ulonglong2 *>(&sh.val[swz<kSwzS>(j * 128 + 2 * lane)]) = make_ulonglong2(xa, xb);
             }
             if (kMulti && c + 1 < ncols) {
@@ -302,6 +319,7 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
             }
         }
         lds_order();
+        const bool exact_mm = (kNeed & 1) && __ballot(snan) != 0ull;
         // a nullable column whose outputs want sums AND extrema is walked twice: phase 1 with +0.0 in the null rows (everything but
         // Min / Max), then the null rows are overwritten with NaN and phase 2 walks the extrema.  Every other shape: phase 0, one walk.
         const bool two_phase = kNulls && (kNeed & 1) && need_sum && nseg_total <= kTwoWalksMaxHeads;
@@ -350,7 +368,7 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
         if (count > 0) {
             first_raw = sh.val[swz<kSwzS>(fv)];
             if (kNulls && pred_walk) walk_values_pred<kSwzS>(sh.val, sh.vbits, fv, lv, sum, mn, mx);
-            else walk_values<kSwzS, !kMulti>(sh.val, fv, lv, do_sum, do_mm, sum, mn, mx);
+            else walk_values<kSwzS, !kMulti>(sh.val, fv, lv, do_sum, do_mm, exact_mm, sum, mn, mx);
             if (kNeed & 2) {
                 last_raw = sh.val[swz<kSwzS>(lv)];
                 if (cint) {   // the staged values are float64(v): First / Last return the Int64 itself (firstlast.go:17, :32)
@@ -421,6 +439,10 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
     }  // columns
 }
 
+bool rolling_simple_plain(const SimpleParams &p, bool is_int, bool has_nulls) {
+    return p.ncols <= 1 && !is_int && !has_nulls && p.W > 0 && p.n / p.W <= kPlainMaxAvgRows && !(route_mask() & BOWGPU_ROUTE_SIMPLE_PADDED);
+}
+
 int launch_rolling_simple(Ctx *c, const SimpleParams &p, int need, bool is_int, bool has_nulls, bool wide, bool dense) {
     if (p.n <= 0) return 0;
     const int64_t ntiles = (p.n + kTileS - 1) / kTileS;
@@ -428,26 +450,37 @@ int launch_rolling_simple(Ctx *c, const SimpleParams &p, int need, bool is_int, 
     const int64_t grid = per_xcd * 8;
     if (grid > 0x7FFFFFFFll) return fail(BOWGPU_ERR_UNSUPPORTED, "too many rows for one launch: %lld", (long long)p.n);
     const dim3 g((unsigned)grid), blk(kWave);
-#define BG_LAUNCH2(N, I, U, M)                                                                                               \
-    do {                                                                                                                     \
-        if (wide && dense) hipLaunchKernelGGL((rolling_simple_kernel<N, I, U, M, true, true>), g, blk, 0, c->stream, p, ntiles, per_xcd);    \
-        else if (wide) hipLaunchKernelGGL((rolling_simple_kernel<N, I, U, M, true, false>), g, blk, 0, c->stream, p, ntiles, per_xcd);       \
-        else if (dense) hipLaunchKernelGGL((rolling_simple_kernel<N, I, U, M, false, true>), g, blk, 0, c->stream, p, ntiles, per_xcd);      \
-        else hipLaunchKernelGGL((rolling_simple_kernel<N, I, U, M, false, false>), g, blk, 0, c->stream, p, ntiles, per_xcd);                \
+    const bool plain = rolling_simple_plain(p, is_int, has_nulls);
+    // (the instantiation's name as rocprofv3 prints it: bowgpu_last_kernel_name() - what ties a committed counter file to this launch)
+#define BG_GO(N, I, U, M, WD, D, PD)                                                                                          \
+    do {                                                                                                                      \
+        hipLaunchKernelGGL((rolling_simple_kernel<N, I, U, M, WD, D, PD>), g, blk, 0, c->stream, p, ntiles, per_xcd);          \
+        c->last_kernel_name = "rolling_simple_kernel<" #N ", " #I ", " #U ", " #M ", " #WD ", " #D ", " #PD ">";               \
+    } while (0)
+#define BG_LAUNCH3(N, I, U, M, PD)                                       \
+    do {                                                                 \
+        if (wide && dense) BG_GO(N, I, U, M, true, true, PD);            \
+        else if (wide) BG_GO(N, I, U, M, true, false, PD);               \
+        else if (dense) BG_GO(N, I, U, M, false, true, PD);              \
+        else BG_GO(N, I, U, M, false, false, PD);                        \
     } while (0)
 #define BG_LAUNCH(N, I, U)                                                \
     do {                                                                  \
-        if (p.ncols > 1) BG_LAUNCH2(N, I, U, true);                       \
-        else BG_LAUNCH2(N, I, U, false);                                  \
+        if (p.ncols > 1) BG_LAUNCH3(N, I, U, true, true);                 \
+        else BG_LAUNCH3(N, I, U, false, true);                            \
     } while (0)
 #define BG_NEED(I, U)                                                                                   \
     switch (need) { case 0: BG_LAUNCH(0, I, U); break; case 1: BG_LAUNCH(1, I, U); break;              \
                     case 2: BG_LAUNCH(2, I, U); break; default: BG_LAUNCH(3, I, U); break; }
-    if (is_int) { if (has_nulls) { BG_NEED(true, true) } else { BG_NEED(true, false) } }
+    if (plain) {
+        switch (need) { case 0: BG_LAUNCH3(0, false, false, false, false); break; case 1: BG_LAUNCH3(1, false, false, false, false); break;
+                        case 2: BG_LAUNCH3(2, false, false, false, false); break; default: BG_LAUNCH3(3, false, false, false, false); break; }
+    } else if (is_int) { if (has_nulls) { BG_NEED(true, true) } else { BG_NEED(true, false) } }
     else { if (has_nulls) { BG_NEED(false, true) } else { BG_NEED(false, false) } }
 #undef BG_NEED
 #undef BG_LAUNCH
-#undef BG_LAUNCH2
+#undef BG_LAUNCH3
+#undef BG_GO
     BG_HIP(hipGetLastError());
     return 0;
 }

@@ -369,6 +369,7 @@ __global__ __launch_bounds__(kWave, (kShort || kLean || (!kNulls && kTs32 && !kB
         }
         // ---- stage the column: float64(v) (Int64 columns are converted here: bowgetters.go:224-229), null rows replaced as in
         // rolling_simple.hip.  It is what the value reducers walk and what the term pass reads.
+        bool snan = false;   // a signalling NaN among the staged values: the tile's extrema are walked by comparison (agg_device.h is_snan)
         if (!early) {
             const uint64_t fill = need_sum ? 0ull : kNullAsNaN;
 #pragma unroll
@@ -384,9 +385,11 @@ __global__ __launch_bounds__(kWave, (kShort || kLean || (!kNulls && kTs32 && !kB
                     if (!(two & 1u)) ra_ = fill;
                     if (!(two & 2u)) rb_ = fill;
                 }
+                if (need_mm && !cint) snan = snan || is_snan(ra_) || is_snan(rb_);
                 *reinterpret_cast<ulonglong2 *>(&sh.val[swz<kSwzT>(l)]) = make_ulonglong2(ra_, rb_);
             }
         }
+        const bool exact_mm = need_mm && __ballot(snan) != 0ull;
         // the next column's loads go out now: its registers are free (this column lives in LDS)
         if (c + 1 < ncols) {
             load_col(reinterpret_cast<const uint64_t *>(p.values[c + 1]), va, vb, !((p.unaligned_mask >> (c + 1)) & 1u));
@@ -609,7 +612,7 @@ __global__ __launch_bounds__(kWave, (kShort || kLean || (!kNulls && kTs32 && !kB
             if (has_value && need_vals) {
                 first_raw = sh.val[swz<kSwzT>(fv)];
                 if (kNulls && pred_walk) walk_values_pred<kSwzT>(sh.val, sh.vbits, fv, lv, sum, mn, mx);
-                else walk_values<kSwzT, kLean || kShort>(sh.val, fv, lv, do_sum, do_mm, sum, mn, mx);
+                else walk_values<kSwzT, kLean || kShort>(sh.val, fv, lv, do_sum, do_mm, exact_mm, sum, mn, mx);
                 if (need_fl) {
                     last_raw = sh.val[swz<kSwzT>(lv)];
                     if (cint) {   // the staged values are float64(v): First / Last return the Int64 itself (firstlast.go:17, :32)

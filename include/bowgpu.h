@@ -178,7 +178,11 @@ int bowgpu_trim(int32_t all_threads, int64_t *bytes_freed /* nullable */);
 int bowgpu_mem_info(int64_t *free_bytes, int64_t *total_bytes);
 /* device time (HIP events on the stream) of the tile kernel of this thread's last aggregate call */
 int bowgpu_last_kernel_ms(double *ms);
-/* ... and which tile kernel that was ("rolling_simple_kernel", "rolling_wave_kernel", "rolling_agg_kernel"; "" before any call) */
+/* ... and which tile kernel that was ("rolling_tw_kernel", "rolling_wave_kernel", "rolling_agg_kernel", "long_stream_kernel", ...; "" before
+ * any call).  rolling_simple_kernel comes with its template arguments, spelled as rocprofv3 prints them
+ * ("rolling_simple_kernel<0, false, false, false, false, false, false>"): the text up to '<' is the kernel, the whole string the
+ * instantiation that ran - what bench.py matches against the committed counter files (profiles/) and the per-kernel code hashes
+ * the build leaves next to the library (libbowgpu.kernel_sha.json) */
 const char *bowgpu_last_kernel_name(void);
 
 /* ---- HBM buffers (so callers can keep columns resident between calls) ------------- */

@@ -4,9 +4,16 @@ import csv, glob, hashlib, os, sys
 out, tag = sys.argv[1], sys.argv[2]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from bench import kernel_source_sha   # hash of the sources the benched kernel is compiled from
+from bench import kernel_sha, BENCH_KERNEL_INSTANCE   # identity of the machine code of each rolling_simple_kernel instantiation (bow_amd/libbowgpu.kernel_sha.json)
 
-sha = kernel_source_sha()
+
+def instance_of(kernel_name):
+    """void bowgpu::rolling_simple_kernel<0, false, ...>(bowgpu::SimpleParams, long, long) -> rolling_simple_kernel<0, false, ...>"""
+    s = kernel_name.replace("void ", "").replace("bowgpu::", "")
+    return s[:s.index(">") + 1] if ">" in s else s.split("(")[0]
+
+
+sha = kernel_sha(BENCH_KERNEL_INSTANCE)
 BENCH_GRID = 100_000_000   # work-items of the benched launch (1e9 rows = 1 953 125 tiles x 64 lanes); smaller launches of the same kernel are other legs
 
 # 1. kernel stats
@@ -22,13 +29,13 @@ with open("%s/%s_kernel_stats_bench_1e9.csv" % (out, tag), "w", newline="") as f
 # 2. HBM traffic counters of the rolling kernels: full kernel signature + source hash per row
 with open("%s/%s_pmc_hbm_traffic_bench_1e9.csv" % (out, tag), "w", newline="") as fh:
     w = csv.writer(fh)
-    w.writerow(["kernel", "counter", "value_KB", "dispatch_id", "source_sha"])
+    w.writerow(["kernel", "counter", "value_KB", "dispatch_id", "kernel_sha"])
     for sub in ("fetch", "write"):
         for f in glob.glob(out + "/" + sub + "/**/*counter_collection.csv", recursive=True):
             for r in csv.DictReader(open(f)):
                 if "rolling" not in r["Kernel_Name"] or int(r["Grid_Size"]) < BENCH_GRID:
                     continue     # (the bench line's host_pinned leg runs the same kernel over 1e8 rows: not the benched launch)
-                w.writerow([r["Kernel_Name"], r["Counter_Name"], r["Counter_Value"], r["Dispatch_Id"], sha])
+                w.writerow([r["Kernel_Name"], r["Counter_Name"], r["Counter_Value"], r["Dispatch_Id"], kernel_sha(instance_of(r["Kernel_Name"]))])
 
 # 3. the SQ / L2 / L1 counter table of the benched kernel (averages over its dispatches)
 import collections
@@ -46,7 +53,7 @@ for f in glob.glob(out + "/stats/**/*kernel_trace.csv", recursive=True):
         if "rolling_simple_kernel" in r["Kernel_Name"] and int(r["Grid_Size_X"]) >= BENCH_GRID:
             dur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
 with open("%s/%s_pmc_counters_bench_1e9.txt" % (out, tag), "w") as fh:
-    fh.write("kernel: %s\nsource_sha: %s\n" % (name, sha))
+    fh.write("kernel: %s\nkernel_sha: %s\n" % (name, kernel_sha(instance_of(name)) if name else sha))
     if dur:
         dur.sort()
         fh.write("kernel-trace duration: n=%d min %.4f ms median %.4f ms max %.4f ms\n" % (len(dur), dur[0], dur[len(dur) // 2], dur[-1]))

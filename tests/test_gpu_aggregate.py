@@ -322,6 +322,45 @@ def test_nan_inf_signed_zero_semantics():
     assert not np.signbit(outs[1].host_arrays()[0][0])
 
 
+@pytest.mark.parametrize("rows_per_window", [10, 40, 100])
+def test_signalling_nan_inside_a_window_does_not_lose_the_running_extremum(rows_per_window):
+    """minmax.go:22-27 compares: a NaN of either kind in mid-window is skipped.  v_min_f64 / v_max_f64 (IEEE mode) return a
+    SIGNALLING operand quieted and the step after it drops that quiet NaN for the next row - [5, sNaN, 7] would give Min 7.  A
+    tile that stages one walks its extrema by comparison (agg_device.h is_snan): the simple kernel (extrema alone, next to sums),
+    the time-weighted kernel (extrema next to an integral), a nullable column in both of its forms (two walks in tiles of few
+    windows, one predicated walk in tiles of many) and an Int64 neighbour column that cannot hold one."""
+    rng = np.random.default_rng(9 + rows_per_window)
+    n = 40_000
+    ts = np.arange(n, dtype=np.int64)
+    v = rng.normal(size=n)
+    SNAN = np.array([0x7FF0000000000001, 0xFFF4000000000123], dtype=np.uint64).view(np.float64)
+    # never a window's first or last valid row: rows 3 and 6 of every third window; the row before holds the window's extremum
+    w0 = np.arange(0, n - rows_per_window, 3 * rows_per_window)
+    v[w0 + 2] = 1e6
+    v[w0 + 5] = -1e6
+    v[w0 + 3] = SNAN[0]
+    v[w0 + 6] = SNAN[1]
+    valid = rng.random(n) > 0.3
+    valid[w0[:, None] + np.arange(8)[None, :]] = True
+    vi = rng.integers(-1000, 1000, n).astype(np.int64)
+    for cols, aggs in [
+        ([(v, None)], [("WindowStart", 0), ("Min", 1), ("Max", 1)]),
+        ([(v, None)], [("WindowStart", 0), ("Min", 1), ("Max", 1), ("Sum", 1), ("First", 1), ("Last", 1)]),
+        ([(v, valid)], [("WindowStart", 0), ("Min", 1), ("Max", 1)]),
+        ([(v, valid)], [("WindowStart", 0), ("Min", 1), ("Max", 1), ("ArithmeticMean", 1)]),
+        ([(v, None), (vi, None)], [("WindowStart", 0), ("Max", 1), ("Min", 2), ("Min", 1)]),
+        ([(v, None)], [("WindowStart", 0), ("Min", 1), ("Max", 1), ("IntegralStep", 1)]),
+        ([(v, valid)], [("WindowStart", 0), ("Min", 1), ("Max", 1), ("WeightedAverageLinear", 1), ("Sum", 1)]),
+    ]:
+        outs, exp, info = run_both(ts, cols, rows_per_window, aggs)
+        assert info.long_windows == 0
+        k = _names(aggs)
+        gmin, gmax = outs[k.index("Min")], outs[k.index("Max")]
+        if cols[0][1] is None and len(cols) == 1:   # (the planted extremes are what comes out: the sNaN behind them changed nothing)
+            slot = w0 // rows_per_window
+            assert (gmax.host_arrays()[0][slot] == 1e6).all() and (gmin.host_arrays()[0][slot] == -1e6).all()
+
+
 def test_device_resident_columns_and_arrow_offsets():
     rng = np.random.default_rng(21)
     n, off = 70_000, 13  # a sliced Arrow array: offset 13 into shared buffers (bow.go:279-283)

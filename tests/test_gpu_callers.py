@@ -151,6 +151,17 @@ def test_interpolate_in_one_pass_without_a_count(vtype):
             capi.rolling_interpolate_onepass([capi.Column(ts), capi.Column(vals, None, capi.FLOAT64)], 0, 10,
                                              [{"kind": "WindowStart", "col": 0}, {"kind": "Linear", "col": 1}], inclusive=inclusive)
         assert e.value.code == -14
+    # ... and with the disorder at the END of the column: the one-pass row count comes from the first and the last timestamp alone, so
+    # it is tiny here and nearly every trip also fails the "fits the counted range" check - the answer is still the decline (-14: the
+    # caller keeps the reference's path), not the argument error of a column that changed between _count and _fill (-10)
+    for tail in (1, 700):
+        ts = np.arange(100_000, dtype=np.int64) * 3 + 100
+        ts[-tail:] = 105
+        for inclusive in (False, True):
+            with pytest.raises(capi.BowGpuError) as e:
+                capi.rolling_interpolate_onepass([capi.Column(ts), capi.Column(vals, None, capi.FLOAT64)], 0, 10,
+                                                 [{"kind": "WindowStart", "col": 0}, {"kind": "Linear", "col": 1}], inclusive=inclusive)
+            assert e.value.code == -14, (tail, inclusive, e.value.code, e.value.message)
 
 
 @pytest.mark.parametrize("base_ts", [0, 1_700_000_000_000, -(1 << 40), (1 << 52)])

@@ -1,0 +1,63 @@
+"""The counter evidence under profiles/ must belong to the code this tree builds.
+
+bench.py quotes `roofline.traffic` from the newest profiles/r*_pmc_hbm_traffic_bench_1e9.csv, and only when the rows carry the
+identity (sha over the machine code: bow_amd/csrc/kernel_sha.py) of the kernel instantiation that ran.  In round 4 the last
+product commit of the round changed the hash after the counters had been collected, nothing failed, and the driver's bench line
+went out with "traffic": null.  This test fails instead: a change to the benched kernel (rolling_simple.hip, agg_device.h, anything
+that alters its instructions) makes the CPU suite red until scratch/profile_bench.sh has been re-run on a GPU box and its
+summaries committed (profiles/README.md)."""
+import csv
+import json
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "bow_amd", "csrc")
+
+
+def _tree_sha():
+    # (compiles rolling_simple.hip for gfx950 when its object is missing or older than its sources: ~30 s, nothing when current)
+    subprocess.check_call(["make", "-s", "-C", CSRC, "../libbowgpu.kernel_sha.json"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    import bench
+    sha = bench.kernel_sha(bench.BENCH_KERNEL_INSTANCE)
+    assert sha, "bow_amd/libbowgpu.kernel_sha.json does not list %s" % bench.BENCH_KERNEL_INSTANCE
+    return bench, sha
+
+
+def test_the_committed_counter_traffic_belongs_to_the_kernel_this_tree_builds():
+    bench, sha = _tree_sha()
+    f = bench.newest_traffic_file()
+    assert f, "no profiles/r*_pmc_hbm_traffic_bench_1e9.csv"
+    rows = [r for r in csv.DictReader(open(f)) if bench.BENCH_KERNEL_INSTANCE in r["kernel"]]
+    assert rows, "%s holds no row of %s: re-run scratch/profile_bench.sh" % (os.path.basename(f), bench.BENCH_KERNEL_INSTANCE)
+    stale = sorted({r.get("kernel_sha") for r in rows} - {sha})
+    assert not stale, ("%s was collected from another build of the benched kernel (kernel_sha %s, this tree builds %s): re-run "
+                       "scratch/profile_bench.sh on a GPU box and commit its summaries" % (os.path.basename(f), stale, sha))
+    assert {r["counter"] for r in rows} >= {"FETCH_SIZE", "WRITE_SIZE"}
+    t = bench.measured_traffic(bench.HEADLINE_ROWS, bench.BENCH_KERNEL_INSTANCE)
+    # 16.0 GB read + 1.6 GB written algorithmic; wasted re-reads would show as traffic well above that
+    assert t is not None and 17.0e9 <= t <= 19.5e9, t
+    # the kernel-stats summary and the counter table of the same collection sit next to it
+    tag = os.path.basename(f).split("_")[0]
+    for name in ("%s_kernel_stats_bench_1e9.csv", "%s_pmc_counters_bench_1e9.txt", "%s_bench_1e9.json"):
+        assert os.path.exists(os.path.join(ROOT, "profiles", name % tag)), name % tag
+    assert "kernel_sha: %s" % sha in open(os.path.join(ROOT, "profiles", "%s_pmc_counters_bench_1e9.txt" % tag)).read()
+    line = json.load(open(os.path.join(ROOT, "profiles", "%s_bench_1e9.json" % tag)))
+    assert line["roofline"]["kernel_instance"] == bench.BENCH_KERNEL_INSTANCE and line["roofline"]["kernel_sha"] == sha
+    assert line["roofline"]["traffic"] is not None
+
+
+def test_the_identity_ignores_what_the_kernel_is_not_compiled_from(tmp_path):
+    """the hash covers the kernel's machine code + descriptor: every instantiation is listed, two different instantiations differ, and the
+    descriptor's entry offset (which moves when ANOTHER kernel of the object changes size) is left out"""
+    bench, sha = _tree_sha()
+    doc = json.load(open(os.path.join(ROOT, "bow_amd", "libbowgpu.kernel_sha.json")))
+    ks = doc["kernels"]
+    assert len(ks) >= 64 and all(k.startswith("rolling_simple_kernel<") for k in ks)
+    padded = bench.BENCH_KERNEL_INSTANCE.replace("false>", "true>")
+    assert padded in ks and ks[padded]["sha"] != sha
+    import sys
+    sys.path.insert(0, CSRC)
+    import kernel_sha
+    again = kernel_sha.kernel_identities(os.path.join(CSRC, "build", "rolling_simple.o"), "rolling_simple_kernel")
+    assert again[bench.BENCH_KERNEL_INSTANCE]["sha"] == sha
