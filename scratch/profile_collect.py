@@ -75,6 +75,6 @@ with open("%s/%s_pmc_counters_bench_1e9.txt" % (out, tag), "w") as fh:
     if "TCP_TCC_READ_REQ_LATENCY_sum" in av:
         fh.write("L1 -> L2 read latency %.0f cycles, write (to acknowledgement) %.0f cycles\n" %
                  (av["TCP_TCC_READ_REQ_LATENCY_sum"] / av["TCP_TCC_READ_REQ_sum"], av["TCP_TCC_WRITE_REQ_LATENCY_sum"] / max(av["TCP_TCC_WRITE_REQ_sum"], 1)))
-for f in sorted(glob.glob(out + "/%s_*" % tag)) + [out + "/bench.json"]:
+for f in sorted(glob.glob(out + "/%s_*" % tag)):
     print("==", f)
     print(open(f).read()[:3500])

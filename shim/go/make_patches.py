@@ -53,6 +53,56 @@ def edit_interpolation_go(src, path):
     return src
 
 
+def edit_bowfill_go(src, path):
+    # FillLinear: behind ALL of its argument checks (bowfill.go:15-55), in front of the loop
+    src = sub_once(src, "\tif b.Column(toFillColIndex).NullN() == 0 {\n\t\treturn b, nil\n\t}\n\tbuf := b.NewBufferFromCol(toFillColIndex)\n",
+                   "\tif b.Column(toFillColIndex).NullN() == 0 {\n\t\treturn b, nil\n\t}\n"
+                   "\tif filled, err := b.fillLinearGPU(refColIndex, toFillColIndex); err != errGPUDeclined { // bowgpu: bowfill_gpu.go / bowfill_gpu_off.go\n"
+                   "\t\treturn filled, err\n\t}\n"
+                   "\tbuf := b.NewBufferFromCol(toFillColIndex)\n", path)
+    # FillMean: first thing in the per-column goroutine
+    src = sub_once(src, "\t\t\tdefer wg.Done()\n\n\t\t\tbuf := b.NewBufferFromCol(colIndex)\n\t\t\tfor rowIndex := 0; rowIndex < b.NumRows(); rowIndex++ {\n",
+                   "\t\t\tdefer wg.Done()\n\n"
+                   "\t\t\tif s, ok := b.fillGPU(colIndex, \"Mean\"); ok { // bowgpu\n"
+                   "\t\t\t\tfilledSeries[colIndex] = s\n\t\t\t\treturn\n\t\t\t}\n"
+                   "\t\t\tbuf := b.NewBufferFromCol(colIndex)\n\t\t\tfor rowIndex := 0; rowIndex < b.NumRows(); rowIndex++ {\n", path)
+    # fill (FillPrevious / FillNext): the same
+    src = sub_once(src, "\t\t\tdefer wg.Done()\n\n\t\t\tdata := b.Column(colIndex).Data()\n",
+                   "\t\t\tdefer wg.Done()\n\n"
+                   "\t\t\tif s, ok := b.fillGPU(colIndex, method); ok { // bowgpu\n"
+                   "\t\t\t\tfilledSeries[colIndex] = s\n\t\t\t\treturn\n\t\t\t}\n"
+                   "\t\t\tdata := b.Column(colIndex).Data()\n", path)
+    return src
+
+
+def edit_bowassertion_go(src, path):
+    src = sub_once(src, "\tif b.IsColEmpty(colIndex) {\n\t\treturn false\n\t}\n",
+                   "\tif b.IsColEmpty(colIndex) {\n\t\treturn false\n\t}\n"
+                   "\tif sorted, err := b.isColSortedGPU(colIndex); err != errGPUDeclined { // bowgpu: bowfill_gpu.go / bowfill_gpu_off.go\n"
+                   "\t\treturn sorted\n\t}\n", path)
+    return src
+
+
+def edit_whole_go(src, path):
+    src = sub_once(src, "\tintervalColIndex, err := b.ColumnIndex(intervalColName)\n\tif err != nil {\n\t\treturn nil, err\n\t}\n",
+                   "\tintervalColIndex, err := b.ColumnIndex(intervalColName)\n\tif err != nil {\n\t\treturn nil, err\n\t}\n"
+                   "\tif res, err := aggregateWholeGPU(b, intervalColIndex, aggrs); err != rolling.ErrGPUDeclined { // bowgpu: whole_gpu.go\n"
+                   "\t\treturn res, err\n\t}\n", path)
+    return src
+
+
+def error_strings():
+    """the texts of the reference's errors that the shim words itself (the rest come through bowgpu_last_error, which api.cpp words)"""
+    out = {}
+    src = open(os.path.join(REF, "bowfill.go")).read()
+    m = re.search(r'fmt\.Errorf\("(refColIndex \'%d\' is empty or not sorted)",', src)
+    out["bowfill.go FillLinear not sorted"] = m.group(1)
+    src = open(os.path.join(REF, "rolling", "aggregation.go")).read()
+    m = re.search(r'"(must keep interval column \'%s\')"', src)
+    out["rolling/aggregation.go keep interval"] = m.group(1)
+    return out
+
+
 def edit_constructors(src, path, ctor, tags, ret):
     """every `func Name(col string) rolling.<ret> { ... rolling.<ctor>(... ) }`: the call becomes <ctor>GPU(..., rolling.<tag>)"""
     out, pos, done = [], 0, []
@@ -125,7 +175,10 @@ def go_shapes():
     shapes["transformation"] = {"kind": "package", "file": "rolling/transformation/factor.go", "funcs": funcs("rolling/transformation/factor.go"),
                                 "Func": re.search(r"^type Func (.*)$", open(os.path.join(REF, "rolling/transformation/factor.go")).read(), flags=re.M).group(1)}
     shapes["rolling.funcs"] = {"kind": "package", "funcs": sorted(set(funcs("rolling/aggregation.go") + funcs("rolling/interpolation.go") + funcs("rolling/rolling.go")))}
-    shapes["bow.funcs"] = {"kind": "package", "funcs": sorted(set(funcs("bow.go") + funcs("bowseries.go") + funcs("bowbuffer.go")))}
+    shapes["bow.funcs"] = {"kind": "package", "funcs": sorted(set(funcs("bow.go") + funcs("bowseries.go") + funcs("bowbuffer.go") + funcs("bowmetadata.go")))}
+    shapes["bow.bow"] = {"kind": "struct", "file": "bow.go", "fields": struct_fields("bow.go", "bow"),
+                         "methods": methods_of([f for f in sorted(os.listdir(REF)) if f.endswith(".go") and not f.endswith("_test.go")], "bow")}
+    shapes["error_strings"] = error_strings()
     shapes["go.mod"] = {"go": re.search(r"^go (\S+)$", open(os.path.join(REF, "go.mod")).read(), flags=re.M).group(1)}
     return shapes
 
@@ -159,6 +212,13 @@ def generate():
         p3 += diff(rel, old, new)
     assert sorted(tagged) == sorted(INTERP_TAGS)
     files["patches/0003-interpolation-constructors-carry-their-kind.patch"] = p3
+    p4 = ""
+    for rel, fn in (("bowassertion.go", edit_bowassertion_go), ("bowfill.go", edit_bowfill_go)):
+        old = open(os.path.join(REF, rel)).read()
+        p4 += diff(rel, old, fn(old, rel))
+    files["patches/0004-fill-and-is-col-sorted-hooks.patch"] = p4
+    old = open(os.path.join(REF, "rolling/aggregation/whole.go")).read()
+    files["patches/0005-whole-frame-aggregate-hook.patch"] = diff("rolling/aggregation/whole.go", old, edit_whole_go(old, "rolling/aggregation/whole.go"))
     return files, json.dumps(go_shapes(), indent=1, sort_keys=True) + "\n"
 
 

@@ -35,6 +35,9 @@ func init() {
 
 var errDeclined = errors.New("bowgpu: input outside the device path") // the caller continues on the reference's own Go path
 
+// ErrGPUDeclined is errDeclined for the hook in package rolling/aggregation (whole_gpu.go, patches/0005).
+var ErrGPUDeclined = errDeclined
+
 // colDesc exposes one Arrow array exactly as bow holds it (bowseries.go:59-83, bow.go:183-186).
 func colDesc(b bow.Bow, i int, pin *runtime.Pinner) C.bowgpu_col {
 	d := (*b.ArrowRecord()).Column(i).Data()
@@ -50,7 +53,8 @@ func colDesc(b bow.Bow, i int, pin *runtime.Pinner) C.bowgpu_col {
 	}
 	c.offset, c.length, c.null_count = C.int64_t(d.Offset()), C.int64_t(d.Len()), C.int64_t(d.NullN())
 	c._type = C.int32_t(b.ColumnType(i)) // bow.Float64 = 1, bow.Int64 = 2 (bowtypes.go:21-23)
-	c.residency = C.BOWGPU_HOST          // C.BOWGPU_HOST_PINNED for a Bow registered with RegisterForGPU
+	// C.BOWGPU_HOST, or C.BOWGPU_HOST_PINNED when the Bow's buffers were registered (bow.RegisterForGPU): read in place, zero-copy
+	c.residency = C.int32_t(bow.GPUResidency(c.values, unsafe.Pointer(c.validity)))
 	return c
 }
 
@@ -217,25 +221,45 @@ func (r *intervalRolling) interpolateWindowsGPU(interps []ColInterpolation) (bow
 }
 
 // RegisterForGPU: a Bow the application keeps using (Bows are immutable) registers its Arrow buffers once; the kernels then read
-// them where they lie (zero-copy over PCIe) and colDesc passes C.BOWGPU_HOST_PINNED.
-func RegisterForGPU(b bow.Bow) (release func()) {
-	rec := *b.ArrowRecord()
-	var ptrs []unsafe.Pointer
-	for i := 0; i < int(rec.NumCols()); i++ {
-		for _, buf := range rec.Column(i).Data().Buffers() {
-			if buf != nil && buf.Len() > 0 {
-				p := unsafe.Pointer(&buf.Bytes()[0])
-				if C.bowgpu_host_register(p, C.int64_t(buf.Len())) == 0 {
-					ptrs = append(ptrs, p)
-				}
-			}
-		}
+// them where they lie (zero-copy over PCIe): colDesc finds the buffers in bow's registry and passes C.BOWGPU_HOST_PINNED.
+func RegisterForGPU(b bow.Bow) (release func()) { return bow.RegisterForGPU(b) }
+
+// AggregateWholeGPU is aggregation.Aggregate (rolling/aggregation/whole.go:12-93) for aggregators that all carry a kind tag, called
+// from the hook patches/0005 puts in front of whole.go's loop (whole_gpu.go has validated the names and set the input indices).
+// ONE window over the whole frame, always inclusive, FirstValue / LastValue through a float64 round trip and -1 when the interval
+// column has no valid value (whole.go:54-62), IteratorDependent resolved to the INPUT column's type (:44-46): all behind
+// bowgpu_aggregate_whole.  Anything the library answers with an error is declined, so that the reference's loop words the error.
+func AggregateWholeGPU(b bow.Bow, intervalColIndex int, aggrs []ColAggregation) (bow.Bow, error) {
+	if b.NumRows() < bow.GPUMinRows {
+		return nil, errDeclined
 	}
-	return func() {
-		for _, p := range ptrs {
-			C.bowgpu_host_unregister(p)
-		}
+	var pin runtime.Pinner
+	defer pin.Unpin()
+	cols := make([]C.bowgpu_col, b.NumCols())
+	for i := range cols {
+		cols[i] = colDesc(b, i, &pin)
 	}
+	cAggs := make([]C.bowgpu_agg, len(aggrs))
+	for i, a := range aggrs {
+		k := gpuKindOfAggregation(a)
+		if k < 0 || !exportFactors(a, &cAggs[i]) {
+			return nil, errDeclined
+		}
+		cAggs[i].kind, cAggs[i].col = C.int32_t(k), C.int32_t(a.InputIndex())
+	}
+	outs, data, valid := newOuts(len(aggrs), 1, &pin)
+	if rc := C.bowgpu_aggregate_whole(&cols[0], C.int32_t(len(cols)), C.int32_t(intervalColIndex), &cAggs[0], C.int32_t(len(cAggs)), &outs[0]); rc != 0 {
+		return nil, errDeclined
+	}
+	series := make([]bow.Series, len(aggrs))
+	for i, a := range aggrs {
+		name := a.OutputName() // whole.go:39-42
+		if name == "" {
+			name = b.ColumnName(a.InputIndex())
+		}
+		series[i] = seriesOf(name, outs[i], data[i], valid[i], int(outs[i].length))
+	}
+	return bow.NewBow(series...) // whole.go:92
 }
 
 // aggregateShardGPU: one rank of a row-range sharded Aggregate (one goroutine / process per GPU; columns and outputs device

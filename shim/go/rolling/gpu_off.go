@@ -19,3 +19,12 @@ func (r *intervalRolling) aggregateWindowsGPU(aggrs []ColAggregation) (bow.Bow, 
 func (r *intervalRolling) interpolateWindowsGPU(interps []ColInterpolation) (bow.Bow, error) {
 	return nil, errDeclined
 }
+
+// ErrGPUDeclined / AggregateWholeGPU: what the hook of rolling/aggregation/whole.go (patches/0005, whole_gpu.go) compares with and calls.
+var ErrGPUDeclined = errDeclined
+
+func AggregateWholeGPU(b bow.Bow, intervalColIndex int, aggrs []ColAggregation) (bow.Bow, error) {
+	return nil, errDeclined
+}
+
+func RegisterForGPU(b bow.Bow) (release func()) { return bow.RegisterForGPU(b) }

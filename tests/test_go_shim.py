@@ -43,7 +43,8 @@ def _prototypes():
 
 def test_shim_files_exist_and_are_go_shaped():
     names = {os.path.relpath(f, os.path.join(ROOT, "shim", "go")) for f in GO}
-    assert {"bowfill_gpu.go", "rolling/gpu_cgo.go", "rolling/gpu_off.go", "rolling/gpu_kinds.go", "rolling/transformation/gpu_factor.go"} <= names
+    assert {"bowfill_gpu.go", "bowfill_gpu_off.go", "rolling/gpu_cgo.go", "rolling/gpu_off.go", "rolling/gpu_kinds.go", "rolling/transformation/gpu_factor.go",
+            "rolling/aggregation/whole_gpu.go"} <= names
     # (round 3 shipped two comment-only files for the constructors: they are real diffs now, shim/go/patches/0002, 0003)
     assert not {"rolling/aggregation/gpu_kinds.go", "rolling/interpolation/gpu_kinds.go"} & names
     for f, src in GO.items():
@@ -72,7 +73,7 @@ def test_every_c_name_the_shim_uses_is_in_the_header():
     # the entry points of the hot path are bound
     assert {"bowgpu_rolling_aggregate", "bowgpu_abi_version", "bowgpu_rolling_interpolate_count", "bowgpu_rolling_interpolate_fill",
             "bowgpu_fill_linear", "bowgpu_fill", "bowgpu_is_col_sorted", "bowgpu_shard_begin", "bowgpu_shard_pass_begin", "bowgpu_shard_finish",
-            "bowgpu_host_register", "bowgpu_last_error"} <= used_fn
+            "bowgpu_host_register", "bowgpu_host_unregister", "bowgpu_last_error", "bowgpu_aggregate_whole"} <= used_fn
 
 
 def test_call_sites_pass_as_many_arguments_as_the_prototypes_take():
@@ -225,3 +226,89 @@ def test_patches_are_reproduced_from_the_reference_and_apply_cleanly(tmp_path):
     for rel in touched:
         code = re.sub(r"//.*", "", open(tmp_path / rel).read())
         assert code.count("{") == code.count("}") and code.count("(") == code.count(")"), rel
+
+
+# ---------------------------------------------------------------- round 5: no dead binding, the reference's error texts
+def _patched_and_shim_sources():
+    """every line the patches ADD to the reference plus every shim file: the code that exists only because of the shim"""
+    added = "\n".join(l[1:] for t in PATCHES.values() for l in t.split("\n") if l.startswith("+") and not l.startswith("+++"))
+    return added, {os.path.relpath(f, os.path.join(ROOT, "shim", "go")): re.sub(r"//.*", "", src) for f, src in GO.items()}
+
+
+def test_every_gpu_function_the_shim_defines_has_a_caller():
+    """fillLinearGPU / fillGPU / isColSortedGPU were defined and nothing called them - no patch touched bowfill.go or
+    bowassertion.go - and aggregation.Aggregate had no binding at all.  Every `...GPU` function or method a shim file defines must be
+    called from a line some patch adds to the reference or from another shim file; the exported entry points of the application
+    (RegisterForGPU, the shard protocol's aggregateShardGPU - driven by the application's own transport) are the stated exceptions."""
+    added, files = _patched_and_shim_sources()
+    defined = {}
+    for rel, code in files.items():
+        for m in re.finditer(r"^func (?:\(\w+ \*?\w+\) )?(\w*GPU\w*)\(", code, flags=re.M):
+            defined.setdefault(m.group(1), set()).add(rel)
+    assert {"fillLinearGPU", "fillGPU", "isColSortedGPU", "aggregateWholeGPU", "AggregateWholeGPU", "aggregateWindowsGPU", "interpolateWindowsGPU",
+            "NewColAggregationGPU", "NewColInterpolationGPU"} <= set(defined)
+    entry_points = {"RegisterForGPU", "aggregateShardGPU", "GPUResidency"}
+    for name, where in defined.items():
+        calls = len(re.findall(r"(?<!func )(?<!\) )\b%s\(" % name, added))
+        for rel, code in files.items():
+            body = re.sub(r"^func (?:\(\w+ \*?\w+\) )?%s\(" % name, "", code, flags=re.M)    # its own definition is not a call
+            calls += len(re.findall(r"\b%s\(" % name, body))
+        assert calls > 0 or name in entry_points, "%s (defined in %s) has no caller in the patched tree" % (name, sorted(where))
+    # the hooks sit in the functions VERDICT names, behind the reference's own argument checks
+    fill = _added_by_patches("bowfill.go")
+    assert "b.fillLinearGPU(refColIndex, toFillColIndex); err != errGPUDeclined" in fill and fill.count("b.fillGPU(colIndex, ") == 2
+    assert 'b.fillGPU(colIndex, "Mean")' in fill and "b.fillGPU(colIndex, method)" in fill
+    assert "b.isColSortedGPU(colIndex); err != errGPUDeclined" in _added_by_patches("bowassertion.go")
+    assert "aggregateWholeGPU(b, intervalColIndex, aggrs); err != rolling.ErrGPUDeclined" in _added_by_patches("rolling/aggregation/whole.go")
+    # both build variants define what the hooks call and compare with
+    on, off = files["bowfill_gpu.go"], files["bowfill_gpu_off.go"]
+    for sym in ("var errGPUDeclined", "func (b *bow) fillLinearGPU(refCol, toFillCol int) (Bow, error)", "func (b *bow) fillGPU(colIndex int, method string) (Series, bool)",
+                "func (b *bow) isColSortedGPU(colIndex int) (bool, error)", "func RegisterForGPU(b Bow) (release func())",
+                "func GPUResidency(values, validity unsafe.Pointer) int32"):
+        assert sym in on and sym in off, sym
+    assert "//go:build bowgpu && go1.21" in GO[os.path.join(ROOT, "shim", "go", "bowfill_gpu.go")]
+    assert "//go:build !(bowgpu && go1.21)" in GO[os.path.join(ROOT, "shim", "go", "bowfill_gpu_off.go")]
+    ron, roff = files["rolling/gpu_cgo.go"], files["rolling/gpu_off.go"]
+    for sym in ("var ErrGPUDeclined = errDeclined", "func AggregateWholeGPU(b bow.Bow, intervalColIndex int, aggrs []ColAggregation) (bow.Bow, error)",
+                "func RegisterForGPU(b bow.Bow) (release func())"):
+        assert sym in ron and sym in roff, sym
+
+
+def test_the_error_texts_the_shim_words_are_the_references():
+    """bowfill.go:40-41 says "refColIndex '%d' is empty or not sorted"; round 4's binding said "bow.FillLinear: column '%s' is ..."."""
+    texts = SHAPES["error_strings"]
+    fill = GO[os.path.join(ROOT, "shim", "go", "bowfill_gpu.go")]
+    cgo = GO[os.path.join(ROOT, "shim", "go", "rolling", "gpu_cgo.go")]
+    want = texts["bowfill.go FillLinear not sorted"]
+    assert want == "refColIndex '%d' is empty or not sorted"
+    assert 'fmt.Errorf("%s", refCol)' % want in fill
+    assert 'fmt.Errorf("%s", intervalCol)' % texts["rolling/aggregation.go keep interval"] in cgo
+    # every other fmt.Errorf / errors.New text in the bow-package binding is the decline sentinel's own
+    worded = set(re.findall(r'(?:fmt\.Errorf|errors\.New)\("([^"]*)"', re.sub(r"//.*", "", fill)))
+    assert worded == {want, "bowgpu: input outside the device path"}, worded
+
+
+def test_registered_buffers_reach_the_library_as_pinned_residency():
+    """RegisterForGPU existed but colDesc always passed BOWGPU_HOST - the zero-copy residency was unreachable from Go"""
+    fill, cgo = _go("bowfill_gpu.go"), _go("rolling/gpu_cgo.go")
+    assert "gpuRegistered.Store(p, buf.Len())" in fill and "C.bowgpu_host_register(p, C.int64_t(buf.Len()))" in fill
+    assert "return int32(C.BOWGPU_HOST_PINNED)" in fill
+    assert "c.residency = C.int32_t(GPUResidency(c.values, unsafe.Pointer(c.validity)))" in fill
+    assert "c.residency = C.int32_t(bow.GPUResidency(c.values, unsafe.Pointer(c.validity)))" in cgo
+    assert "c.residency = C.BOWGPU_HOST" not in cgo and "c.residency = C.BOWGPU_HOST" not in fill.replace("C.BOWGPU_HOST_PINNED", "")
+
+
+def test_the_bow_package_binding_uses_only_what_the_reference_defines():
+    code = _go("bowfill_gpu.go")
+    B = SHAPES["bow.bow"]
+    assert B["fields"] == ["arrow.Record"]
+    record_methods = {"ColumnName", "Column", "Schema", "NumCols", "NumRows"}     # arrow.Record, through the embedded field
+    for name in set(re.findall(r"\bb\.(\w+)\(", code)):
+        assert name in B["methods"] or name in record_methods or name.endswith("GPU"), ("bow", name)
+    for name in set(re.findall(r"(?<![.\w])(New\w+)\(", code)):
+        assert name in SHAPES["bow.funcs"]["funcs"], ("package bow", name)
+    whole = _go("rolling/aggregation/whole_gpu.go")
+    for name in set(re.findall(r"\baggr\.(\w+)\(", whole)):
+        assert name in SHAPES["rolling.ColAggregation"]["methods"], ("ColAggregation", name)
+    for name in set(re.findall(r"\bb\.(\w+)\(", whole)):
+        assert name in SHAPES["bow.Bow"]["methods"], ("bow.Bow", name)
