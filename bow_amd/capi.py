@@ -25,7 +25,7 @@ INTERP = {"WindowStart": 0, "Linear": 1, "StepPrevious": 2, "None": 3, "Const": 
 
 MAX_FACTORS = 4
 CARRY_MAX_AGGS = 16
-ABI_VERSION = 4   # include/bowgpu.h BOWGPU_ABI_VERSION (asserted when the library is loaded)
+ABI_VERSION = 5   # include/bowgpu.h BOWGPU_ABI_VERSION (asserted when the library is loaded)
 
 ERR_NAMES = {
     -1: "INTERVAL", -2: "TS_TYPE", -3: "FIRST_TS_NULL", -4: "NO_AGG", -5: "KEEP_INTERVAL", -6: "BAD_COL",
@@ -124,7 +124,7 @@ class ShardDecision(C.Structure):
 
 # every symbol include/bowgpu.h declares (checked by tests/test_abi_symbols.py)
 SYMBOLS = [
-    "bowgpu_abi_version", "bowgpu_last_error", "bowgpu_device_count", "bowgpu_set_device", "bowgpu_device_name",
+    "bowgpu_abi_version", "bowgpu_rolling_interpolate_aggregate", "bowgpu_last_error", "bowgpu_device_count", "bowgpu_set_device", "bowgpu_device_name",
     "bowgpu_set_stream", "bowgpu_synchronize", "bowgpu_trim", "bowgpu_mem_info", "bowgpu_host_register", "bowgpu_host_unregister", "bowgpu_last_kernel_ms", "bowgpu_last_kernel_name", "bowgpu_malloc", "bowgpu_free", "bowgpu_memcpy_h2d",
     "bowgpu_memcpy_d2h", "bowgpu_memset", "bowgpu_timer_create", "bowgpu_timer_start", "bowgpu_timer_stop",
     "bowgpu_timer_elapsed_ms", "bowgpu_timer_destroy", "bowgpu_enforce_interval_and_offset", "bowgpu_plan_windows",
@@ -198,7 +198,7 @@ def check(rc):
 # ------------------------------------------------------------------ test / A-B routing (bowgpu_debug_set_route: per calling thread)
 ROUTE_NO_SIMPLE, ROUTE_FORCE_GENERAL, ROUTE_NO_LONG_ONLY, ROUTE_LONG_CLASSIC, ROUTE_LONG_STREAM_ALL = 1, 2, 4, 8, 16
 ROUTE_SIMPLE_SMALL_LIST, ROUTE_SIMPLE_LARGE_LIST, ROUTE_TW_F64, ROUTE_SIMPLE_PADDED, ROUTE_INTERP_TILE = 32, 64, 128, 256, 512
-ROUTE_PINNED_STAGE, ROUTE_STRICT_ORDER = 1024, 2048
+ROUTE_PINNED_STAGE, ROUTE_STRICT_ORDER, ROUTE_NO_FUSED = 1024, 2048, 4096
 
 
 def set_route(mask):
@@ -562,6 +562,25 @@ def _interps(interps):
             arr[i].prev_v, arr[i].prev_v_valid = prev[2], int(prev[3])
             arr[i].prev_v_i64 = prev[4] if len(prev) > 4 else 0
     return arr
+
+
+def rolling_interpolate_aggregate(cols, ts_col, interval, interps, aggs, offset=0, inclusive=False, out_residency=HOST, outs=None):
+    """r.Interpolate(interps...).Aggregate(aggs...) without the interpolated frame (bowgpu_rolling_interpolate_aggregate): returns
+    (list[OutColumn], AggInfo) as rolling_aggregate does.  The window grid of the interpolated frame is the input's, so the outputs hold
+    plan_windows(...)[1] slots."""
+    if outs is None:
+        W = plan_windows(cols[ts_col], interval, offset)[1]
+        outs = [OutColumn(W, out_residency) for _ in aggs]
+    oarr = (Out * max(len(aggs), 1))()
+    for i, o in enumerate(outs):
+        oarr[i] = o.c()
+    opts = Options(offset, int(bool(inclusive)), 0)
+    info = AggInfo()
+    check(lib().bowgpu_rolling_interpolate_aggregate(_cols(cols), len(cols), ts_col, C.c_int64(interval), C.byref(opts),
+                                                     _interps(interps), len(interps), _aggs(aggs), len(aggs), oarr, C.byref(info)))
+    for i, o in enumerate(outs):
+        o.absorb(oarr[i])
+    return outs, info
 
 
 def rolling_interpolate(cols, ts_col, interval, interps, offset=0, inclusive=False, out_residency=HOST):

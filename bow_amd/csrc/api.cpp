@@ -954,6 +954,66 @@ static bool simple_applies(const AggJob *job, const bowgpu_agg *aggs, int32_t na
     return true;
 }
 
+// the descriptor of the wave-tile kernels (rolling_simple.hip, rolling_tw.hip, rolling_fused.hip) from a built job
+static void simple_params_build(const AggJob *job, const bowgpu_agg *aggs, int32_t naggs, bool wide, SimpleParams *out) {
+    const AggParams &P = job->P;
+    SimpleParams &S = *out;
+    memset(&S, 0, sizeof S);
+    S.ts = P.ts;
+    S.n = P.n; S.interval = P.interval; S.W = P.W;
+    S.wid_base = P.wid_base;
+    S.magic = P.magic;
+    S.s0 = P.s0 + (int64_t)((uint64_t)P.wid_base * (uint64_t)P.interval);
+    S.m32 = P.m32; S.sh1 = P.sh1_32; S.sh2 = P.sh2_32;
+    S.shift_k = 0;
+    if (wide) {  // ids from (ts - tile base) >> k divided by interval >> k, k = trailing zero bits of the interval
+        int k = 0;
+        while (k < 31 && !(((uint64_t)P.interval >> k) & 1ull)) k++;
+        S.shift_k = k;
+        const uint64_t d = (uint64_t)P.interval >> k;
+        int l = 0;
+        while (l < 32 && (1ull << l) < d) l++;
+        S.m32 = (uint32_t)((((1ull << l) - d) << 32) / d) + 1;
+        S.sh1 = l < 1 ? (uint32_t)l : 1u;
+        S.sh2 = l > 1 ? (uint32_t)(l - 1) : 0u;
+    }
+    S.naggs = naggs;
+    S.ncols = P.ncols > 0 ? P.ncols : 1;
+    S.values[0] = P.ts;  // only WindowStart / NumRows: any column serves as "the" column
+    for (int s = 0; s < P.ncols; s++) {
+        S.values[s] = P.cols[s].values;
+        S.vbits[s] = P.cols[s].vbits; S.vbit0[s] = P.cols[s].vbit0; S.vwords[s] = P.cols[s].vwords;
+        S.col_is_int[s] = P.cols[s].type == BOWGPU_INT64;
+    }
+    for (int i = 0; i < naggs; i++) {
+        S.kind[i] = aggs[i].kind;
+        S.nfac[i] = aggs[i].n_factors;
+        for (int f = 0; f < aggs[i].n_factors && f < BOWGPU_MAX_FACTORS; f++) S.fac[i][f] = aggs[i].factors[f];
+        S.col[i] = P.aggs[i].slot < 0 ? 0 : P.aggs[i].slot;
+        S.out_values[i] = reinterpret_cast<uint64_t *>(P.aggs[i].out_values);
+        S.out_valid[i] = P.aggs[i].out_valid;
+    }
+    for (int i = 0; i < naggs; i++) {
+        const int k = aggs[i].kind;
+        if (k == BOWGPU_AGG_INTEGRAL_STEP || k == BOWGPU_AGG_WAVG_STEP) S.need |= kNeedStep;
+        if (k == BOWGPU_AGG_INTEGRAL_TRAPEZOID || k == BOWGPU_AGG_WAVG_LINEAR) S.need |= kNeedTrap;
+        if (k == BOWGPU_AGG_MIN || k == BOWGPU_AGG_MAX) S.need |= kNeedMinMax;
+        if (k == BOWGPU_AGG_SUM || k == BOWGPU_AGG_MEAN) S.need |= kNeedSum;
+        if (k == BOWGPU_AGG_FIRST || k == BOWGPU_AGG_LAST) S.need |= kNeedFirstLast;
+        const int cls = (k == BOWGPU_AGG_MIN || k == BOWGPU_AGG_MAX) ? 1 : (k == BOWGPU_AGG_INTEGRAL_STEP || k == BOWGPU_AGG_WAVG_STEP) ? 2
+                        : (k == BOWGPU_AGG_INTEGRAL_TRAPEZOID || k == BOWGPU_AGG_WAVG_LINEAR) ? 3
+                        : (k == BOWGPU_AGG_SUM || k == BOWGPU_AGG_MEAN || k == BOWGPU_AGG_FIRST || k == BOWGPU_AGG_LAST) ? 0 : 4;
+        S.kind_mask[cls] |= 1u << i;
+        S.col_mask[S.col[i]] |= 1u << i;
+    }
+    S.status = P.status; S.long_list = P.long_list; S.long_cap = P.long_cap;
+    S.inclusive = job->inclusive ? 1 : 0;
+    S.pre_rows = P.pre_rows;
+    S.unaligned_mask = (reinterpret_cast<uintptr_t>(P.ts) & 15) ? 0x80000000u : 0u;
+    for (int s = 0; s < S.ncols; s++)
+        if (reinterpret_cast<uintptr_t>(S.values[s]) & 15) S.unaligned_mask |= 1u << s;
+}
+
 static int job_launch_tiles(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, const Plan *plan, bool allow_simple,
                             bool *used_simple, bool force_large_list = false, bool *used_small_list = nullptr) {
     AggParams &P = job->P;
@@ -990,60 +1050,7 @@ static int job_launch_tiles(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t
     BG_HIP(hipEventRecord(c->ev0, c->stream));
     if (simple) {
         SimpleParams S;
-        memset(&S, 0, sizeof S);
-        S.ts = P.ts;
-        S.n = P.n; S.interval = P.interval; S.W = P.W;
-        S.wid_base = P.wid_base;
-        S.magic = P.magic;
-        S.s0 = P.s0 + (int64_t)((uint64_t)P.wid_base * (uint64_t)P.interval);
-        S.m32 = P.m32; S.sh1 = P.sh1_32; S.sh2 = P.sh2_32;
-        S.shift_k = 0;
-        if (wide) {  // ids from (ts - tile base) >> k divided by interval >> k, k = trailing zero bits of the interval
-            int k = 0;
-            while (k < 31 && !(((uint64_t)P.interval >> k) & 1ull)) k++;
-            S.shift_k = k;
-            const uint64_t d = (uint64_t)P.interval >> k;
-            int l = 0;
-            while (l < 32 && (1ull << l) < d) l++;
-            S.m32 = (uint32_t)((((1ull << l) - d) << 32) / d) + 1;
-            S.sh1 = l < 1 ? (uint32_t)l : 1u;
-            S.sh2 = l > 1 ? (uint32_t)(l - 1) : 0u;
-        }
-        S.naggs = naggs;
-        S.ncols = P.ncols > 0 ? P.ncols : 1;
-        S.values[0] = P.ts;  // only WindowStart / NumRows: any column serves as "the" column
-        for (int s = 0; s < P.ncols; s++) {
-            S.values[s] = P.cols[s].values;
-            S.vbits[s] = P.cols[s].vbits; S.vbit0[s] = P.cols[s].vbit0; S.vwords[s] = P.cols[s].vwords;
-            S.col_is_int[s] = P.cols[s].type == BOWGPU_INT64;
-        }
-        for (int i = 0; i < naggs; i++) {
-            S.kind[i] = aggs[i].kind;
-            S.nfac[i] = aggs[i].n_factors;
-            for (int f = 0; f < aggs[i].n_factors && f < BOWGPU_MAX_FACTORS; f++) S.fac[i][f] = aggs[i].factors[f];
-            S.col[i] = P.aggs[i].slot < 0 ? 0 : P.aggs[i].slot;
-            S.out_values[i] = reinterpret_cast<uint64_t *>(P.aggs[i].out_values);
-            S.out_valid[i] = P.aggs[i].out_valid;
-        }
-        for (int i = 0; i < naggs; i++) {
-            const int k = aggs[i].kind;
-            if (k == BOWGPU_AGG_INTEGRAL_STEP || k == BOWGPU_AGG_WAVG_STEP) S.need |= kNeedStep;
-            if (k == BOWGPU_AGG_INTEGRAL_TRAPEZOID || k == BOWGPU_AGG_WAVG_LINEAR) S.need |= kNeedTrap;
-            if (k == BOWGPU_AGG_MIN || k == BOWGPU_AGG_MAX) S.need |= kNeedMinMax;
-            if (k == BOWGPU_AGG_SUM || k == BOWGPU_AGG_MEAN) S.need |= kNeedSum;
-            if (k == BOWGPU_AGG_FIRST || k == BOWGPU_AGG_LAST) S.need |= kNeedFirstLast;
-            const int cls = (k == BOWGPU_AGG_MIN || k == BOWGPU_AGG_MAX) ? 1 : (k == BOWGPU_AGG_INTEGRAL_STEP || k == BOWGPU_AGG_WAVG_STEP) ? 2
-                            : (k == BOWGPU_AGG_INTEGRAL_TRAPEZOID || k == BOWGPU_AGG_WAVG_LINEAR) ? 3
-                            : (k == BOWGPU_AGG_SUM || k == BOWGPU_AGG_MEAN || k == BOWGPU_AGG_FIRST || k == BOWGPU_AGG_LAST) ? 0 : 4;
-            S.kind_mask[cls] |= 1u << i;
-            S.col_mask[S.col[i]] |= 1u << i;
-        }
-        S.status = P.status; S.long_list = P.long_list; S.long_cap = P.long_cap;
-        S.inclusive = job->inclusive ? 1 : 0;
-        S.pre_rows = P.pre_rows;
-        S.unaligned_mask = (reinterpret_cast<uintptr_t>(P.ts) & 15) ? 0x80000000u : 0u;
-        for (int s = 0; s < S.ncols; s++)
-            if (reinterpret_cast<uintptr_t>(S.values[s]) & 15) S.unaligned_mask |= 1u << s;
+        simple_params_build(job, aggs, naggs, wide, &S);
         if (tw) {
             // 32-bit staged timestamps: exact when float64(s0 of slot 0) + float64(offset) needs no rounding, i.e. every |ts| < 2^53
             // (BOWGPU_ROUTE_TW_F64: test / A-B switch that keeps the float64 form)
@@ -1605,6 +1612,86 @@ static int run_aggregate(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t 
     return 0;
 }
 
+// ---- Rolling.Interpolate(...).Aggregate(...) in ONE pass over the rows (rolling_fused.hip), where the shape allows it.
+// *done = false: the call is outside the fused kernel's domain (or some tile of it was - the kernel said so): the caller makes the two
+// calls through device temporaries instead (bowgpu_rolling_interpolate_aggregate).  The domain: exclusive windows, the reducers of
+// rolling_simple.hip, an interval column without nulls interpolated by WindowStart, value columns under Linear / StepPrevious / None /
+// WindowStart, a frame that starts at or above 0 and spans less than 2^32 from its first window, windows of 4 .. 128 rows on average.
+static int fused_try(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t ts_col, const Plan &plan, const bowgpu_options &o, int inclusive,
+                     const bowgpu_interp *interps, const bowgpu_agg *aggs, int32_t naggs, bowgpu_out *outs, double *kernel_ms, bool *done) {
+    *done = false;
+    const bowgpu_col *tsc = &cols[ts_col];
+    const int64_t n = tsc->length, W = plan.W;
+    if (route_mask() & (BOWGPU_ROUTE_NO_FUSED | BOWGPU_ROUTE_NO_SIMPLE | BOWGPU_ROUTE_FORCE_GENERAL)) return 0;
+    if (n <= 0 || W <= 0 || inclusive || o.inclusive || naggs > kSimpleMaxAggs) return 0;
+    if (tsc->validity && tsc->null_count != 0) return 0;                      // (an interval column with nulls: extras.cpp interp_null_ts)
+    const int64_t lim53 = 1ll << 53;
+    if (plan.first_ts < plan.s0 || plan.s0 < 0 || plan.last_ts >= lim53) return 0;   // rows below s0, the -1 sentinel window, float64(ts) inexact
+    if (((uint64_t)plan.interval >> 32) != 0 || (uint64_t)plan.last_ts - (uint64_t)plan.s0 >= 0xFFFFFFF0ull || W >= 0xFFFFFFF0ll) return 0;
+    if (n / W < 4 || n / W > 128) return 0;
+    for (int i = 0; i < ncols; i++) {
+        const int k = interps[i].kind;
+        if (k != BOWGPU_INTERP_WINDOW_START && k != BOWGPU_INTERP_LINEAR && k != BOWGPU_INTERP_STEP_PREVIOUS && k != BOWGPU_INTERP_NONE) return 0;
+    }
+    if (interps[ts_col].kind != BOWGPU_INTERP_WINDOW_START) return 0;           // anything else does not keep the window grid
+    {
+        std::vector<int> nullable(ncols, 0);
+        int distinct = 0;
+        for (int i = 0; i < naggs; i++) {
+            const int k = aggs[i].kind;
+            if ((k >= BOWGPU_AGG_INTEGRAL_STEP && k <= BOWGPU_AGG_WAVG_LINEAR) || k == BOWGPU_AGG_MODE) return 0;
+            if (!kind_reads_values(k)) continue;
+            if (nullable[aggs[i].col] == 0) distinct++;
+            nullable[aggs[i].col]++;                                           // (an upper bound of job_build's count per pass)
+            if (nullable[aggs[i].col] > 4) return 0;
+        }
+        if (distinct > kMaxCols) return 0;
+    }
+    AggJob job;
+    BG_TRY(job_build(c, cols, ncols, ts_col, plan, 0, aggs, naggs, outs, 0, W, true, &job));
+    AggParams &P = job.P;
+    int need = 0;
+    bool is_int = false, has_nulls = false, wide = false;
+    if (P.pre_rows || !simple_applies(&job, aggs, naggs, plan, false, &need, &is_int, &has_nulls, &wide) || wide) return 0;
+    P.bits_preset = 1;
+    {
+        BitmapBatch b;
+        job_bitmaps(&job, aggs, naggs, true, &b);
+        BG_TRY(launch_preset_bitmaps(c, b));
+        job.counts_used = false;
+    }
+    FusedParams F;
+    memset(&F, 0, sizeof F);
+    simple_params_build(&job, aggs, naggs, false, &F.s);
+    for (int s = 0; s < kMaxCols; s++) { F.cols[s].kind = BOWGPU_INTERP_NONE; F.cols[s].type = BOWGPU_INT64; }
+    for (int i = 0; i < naggs; i++) {
+        if (!kind_reads_values(aggs[i].kind) || P.aggs[i].slot < 0) continue;
+        const bowgpu_interp &ip = interps[aggs[i].col];
+        FusedCol &fc = F.cols[P.aggs[i].slot];
+        fc.type = cols[aggs[i].col].type; fc.kind = ip.kind;
+        fc.has_prev = ip.has_prev_row; fc.prev_t_valid = ip.prev_t_valid; fc.prev_v_valid = ip.prev_v_valid;
+        fc.const_value = ip.const_value; fc.prev_t = ip.prev_t; fc.prev_v = ip.prev_v; fc.prev_v_i64 = ip.prev_v_i64;
+    }
+    BG_HIP(hipEventRecord(c->ev0, c->stream));
+    BG_TRY(launch_rolling_fused(c, F, need, has_nulls));
+    BG_HIP(hipEventRecord(c->ev1, c->stream));
+    uint32_t *hstat;
+    uint64_t *hcnt = nullptr;
+    BG_TRY(job_enqueue_tail(c, &job, aggs, naggs));
+    BG_TRY(job_readback(c, &job, &hstat, &hcnt));
+    BG_HIP(hipStreamSynchronize(c->stream));
+    if (hstat[0]) return fail(BOWGPU_ERR_TS_UNSORTED, "interval column is not ascending: outside the device path");
+    if (hstat[4] || hstat[5]) return 0;   // a tile the fused kernel cannot describe (too many heads, a long window, a far neighbour point)
+    for (int i = 0; i < naggs; i++)
+        job.douts[i].user->null_count = !kind_never_nil(aggs[i].kind) ? W - (int64_t)hcnt[i] : 0;
+    float ms = 0;
+    BG_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    c->last_kernel_ms = ms;
+    if (kernel_ms) *kernel_ms = ms;
+    *done = true;
+    return 0;
+}
+
 // ---- the pass of a sharded call put in flight BEFORE the exchange (bowgpu_shard_pass_begin): one per thread
 struct PendingPass {
     AggJob job;
@@ -1925,6 +2012,62 @@ int bowgpu_rolling_aggregate(const bowgpu_col *cols, int32_t ncols, int32_t ts_c
     g_strict_order = o.strict_order != 0 || (route_mask() & BOWGPU_ROUTE_STRICT_ORDER) != 0;
     const int rc = aggregate_with_plan(cols, ncols, ts_col, plan, o.inclusive, aggs, naggs, outs, info);
     g_strict_order = false;
+    return rc;
+}
+
+/* Rolling.Interpolate(interps...) followed by Rolling.Aggregate(aggs...) on the Rolling it returns (reference
+ * rolling/interpolation.go:30-69, rolling/aggregation.go:123-145), without handing the interpolated frame back: one pass over the
+ * rows where the shape allows it (rolling_fused.hip), else the two calls through device temporaries - the same bits either way. */
+int bowgpu_rolling_interpolate_aggregate(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval, const bowgpu_options *opts,
+                                         const bowgpu_interp *interps, int32_t ninterps, const bowgpu_agg *aggs, int32_t naggs,
+                                         bowgpu_out *outs, bowgpu_agg_info *info) {
+    if (!cols || ncols <= 0) return fail(BOWGPU_ERR_ARG, "no columns");
+    if (ts_col < 0 || ts_col >= ncols) return fail(BOWGPU_ERR_BAD_COL, "no interval column with index %d", ts_col);
+    if (!interps) return fail(BOWGPU_ERR_ARG, "null argument");
+    bowgpu_options o = {0, 0, 0};
+    if (opts) o = *opts;
+    // the reference's order: the Rolling exists first (newIntervalRolling), Interpolate validates its interpolators, then Aggregate
+    // validates its aggregators against the interpolated Bow - which has the input's columns and types (interpolation.go:139-155)
+    Plan plan;
+    BG_TRY(plan_make(nullptr, &cols[ts_col], interval, o.offset, &plan));
+    BG_TRY(interp_validate(cols, ncols, ts_col, &o, interps, ninterps));
+    int inclusive = o.inclusive ? 1 : 0, nic = -1;
+    BG_TRY(validate_aggs(cols, ncols, ts_col, aggs, naggs, &inclusive, &nic));
+    if (!outs) return fail(BOWGPU_ERR_ARG, "no output columns");
+    Ctx *c;
+    BG_TRY(ctx_get(&c));
+    bool done = false;
+    double ms = 0;
+    BG_TRY(fused_try(c, cols, ncols, ts_col, plan, o, inclusive, interps, aggs, naggs, outs, &ms, &done));
+    if (done) {
+        if (info) {
+            info->s0 = plan.s0; info->num_windows = plan.W; info->new_interval_col = nic; info->inclusive = inclusive;
+            info->long_windows = 0; info->kernel_ms = ms;
+        }
+        return 0;
+    }
+    // the two calls.  The interpolated frame lives in device temporaries and is aggregated where it lies.
+    int64_t n_out = 0;
+    BG_TRY(bowgpu_rolling_interpolate_count(cols, ncols, ts_col, interval, &o, interps, ninterps, &n_out));
+    std::vector<DevBuf> vals(ncols), bits(ncols);
+    std::vector<bowgpu_out> mid(ncols);
+    std::vector<bowgpu_col> icols(ncols);
+    for (int i = 0; i < ncols; i++) {
+        BG_TRY(vals[i].alloc((size_t)n_out * 8 + 16));
+        BG_TRY(bits[i].alloc((size_t)((n_out + 7) >> 3) + 16));
+        memset(&mid[i], 0, sizeof mid[i]);
+        mid[i].values = vals[i].p; mid[i].validity = reinterpret_cast<uint8_t *>(bits[i].p);
+        mid[i].length = n_out; mid[i].residency = BOWGPU_DEVICE;
+    }
+    if (n_out > 0) BG_TRY(bowgpu_rolling_interpolate_fill(cols, ncols, ts_col, interval, &o, interps, ninterps, mid.data()));
+    for (int i = 0; i < ncols; i++) {
+        memset(&icols[i], 0, sizeof icols[i]);
+        icols[i].values = mid[i].values; icols[i].validity = mid[i].validity;
+        icols[i].offset = 0; icols[i].length = n_out; icols[i].null_count = n_out > 0 ? mid[i].null_count : 0;
+        icols[i].type = cols[i].type; icols[i].residency = BOWGPU_DEVICE;
+    }
+    const int rc = bowgpu_rolling_aggregate(icols.data(), ncols, ts_col, interval, &o, aggs, naggs, outs, info);
+    // (the temporaries go back to the block cache: every entry point above has synchronised the stream)
     return rc;
 }
 

@@ -252,6 +252,22 @@ int launch_rolling_simple(Ctx *c, const SimpleParams &p, int need, bool is_int, 
 bool rolling_simple_plain(const SimpleParams &p, bool is_int, bool has_nulls);   // the call takes the unpadded instantiation (short windows over one Float64 column without nulls): its small list holds 254 heads
 int launch_rolling_tw(Ctx *c, const SimpleParams &p, bool is_int, bool has_nulls, bool wide, bool ts32);  // time-weighted reducers / inclusive windows (rolling_tw.hip)
 
+// rolling_fused.hip: Interpolate -> Aggregate in one pass.  Per value column pass: the column's interpolator (what interp_device.h
+// synth_value_pt reads of an InterpCol, same field names)
+struct FusedCol {
+    int32_t type, kind;            // BOWGPU_FLOAT64 / BOWGPU_INT64 ; BOWGPU_INTERP_*
+    int32_t has_prev, prev_t_valid, prev_v_valid, next_valid;   // Options.PrevRow (linear.go:14-18, stepprevious.go:13-15); next_valid: always 0 here
+    double const_value, prev_t, prev_v, next_t, next_v;
+    int64_t prev_v_i64;
+};
+struct FusedParams {
+    SimpleParams s;                // FIRST: the kernel reads the output pointers through the kernel-argument segment at SimpleParams' offsets
+    FusedCol cols[kMaxCols];       // by column pass (SimpleParams::values[c])
+};
+int launch_rolling_fused(Ctx *c, const FusedParams &fp, int need, bool has_nulls);
+// Interpolate + validateInterpolation (extras.cpp; reference rolling/interpolation.go:30-96)
+int interp_validate(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, const bowgpu_options *o, const bowgpu_interp *interps, int32_t ninterps);
+
 int launch_rolling_aggregate(Ctx *c, const AggParams &p);   // general kernel (rolling_agg.hip)
 int launch_rolling_fast(Ctx *c, const AggParams &p);        // lean kernel for exclusive windows without time-weighted reducers (rolling_fast.hip)
 constexpr int kLongChunkRows = 4096;

@@ -107,8 +107,8 @@ static const char *type_name(int t) {
     return t == BOWGPU_FLOAT64 ? "float64" : t == BOWGPU_INT64 ? "int64" : t == BOWGPU_BOOLEAN ? "bool" : t == BOWGPU_STRING ? "utf8" : "undefined";
 }
 
-static int interp_validate(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, const bowgpu_options *o,
-                           const bowgpu_interp *interps, int32_t ninterps) {
+extern "C++" int bowgpu::interp_validate(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, const bowgpu_options *o,
+                    const bowgpu_interp *interps, int32_t ninterps) {
     // Interpolate + validateInterpolation: reference rolling/interpolation.go:30-96
     if (ninterps <= 0) return fail(BOWGPU_ERR_ARG, "at least one column interpolation is required");
     int nic = -1;

@@ -10,7 +10,9 @@ struct NbPoint { int64_t t; uint64_t bits; int has; };
 // the value an interpolator gives the synthetic row of a window starting at sk whose FirstIndex is row a
 // (interpolation/windowstart.go:10-12, linear.go:12-37, stepprevious.go:11-24, none.go); pp / np = the valid row before a /
 // the valid row from a on, found once per run of synthetic rows (ts has no nulls: both-valid == value valid)
-__device__ __forceinline__ void synth_value_pt(const InterpCol &ic, int64_t sk, const NbPoint &pp, const NbPoint &np, uint64_t *bits_out,
+// (IC: InterpCol, or rolling_fused.hip's FusedCol - the same fields)
+template <class IC>
+__device__ __forceinline__ void synth_value_pt(const IC &ic, int64_t sk, const NbPoint &pp, const NbPoint &np, uint64_t *bits_out,
                                                int *valid_out) {
     const bool is_int = ic.type == BOWGPU_INT64;
     uint64_t bits = 0;

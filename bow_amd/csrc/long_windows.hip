@@ -461,10 +461,7 @@ __global__ __launch_bounds__(256) void long_final_kernel(const AggParams p, cons
     for (int slot = -1; slot < p.ncols; slot++) {
         const unsigned my_mask = p.pass_mask[slot + 1];
         if (my_mask == 0) continue;
-        const ColDesc *cd = slot >= 0 ? &p.cols[slot] : nullptr;
-        const int col_type = cd ? cd->type : BOWGPU_INT64;
-        const bool need_vals = cd && (p.pass_flags[slot + 1] & kPassNeedVals);
-        const uint64_t *vp = cd ? reinterpret_cast<const uint64_t *>(cd->values) : nullptr;
+        const bool need_vals = slot >= 0 && (p.pass_flags[slot + 1] & kPassNeedVals);
 
         if (simple) {
             Part acc;

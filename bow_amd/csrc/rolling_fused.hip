@@ -1,0 +1,512 @@
+// rolling_fused.hip — Rolling.Interpolate followed by Rolling.Aggregate as ONE pass over the rows, without materialising the
+// interpolated frame:  r.Interpolate(interps...).Aggregate(aggrs...)  (reference rolling/interpolation.go:30-69 returns a Rolling
+// over the interpolated Bow with the same interval and options; rolling/aggregation.go:123-145 consumes it).
+//
+// For an ascending, non-null interval column and exclusive windows the interpolated frame has the SAME window grid as the original
+// (its first row sits on s_0 - the synthetic row of window 0 or an original row that starts it - and its last row is the original's)
+// and window k of it holds
+//     [ one synthetic row at s_k, unless the window's first row sits exactly on s_k - empty windows included
+//       (interpolation.go:98-161: firstColValue != window.FirstValue) ]  +  the window's original rows.
+// The synthetic row's value in column c is what the column's interpolator gives for the window (linear.go:8-38: the expression
+// ((v2 - v0) * ((s_k - t0) / (t2 - t0))) + v0 on the nearest both-valid rows before / from the window's FirstIndex; stepprevious.go,
+// windowstart.go, none.go), stored in the column's type (interpolation.go:149-150: an Int64 column truncates), and the reducers
+// then see it as the window's FIRST row: Sum = ((0 + x_s) + x_1) + ..., Min / Max seeded by it, First = it, Count / NumRows + 1.
+// So the tile kernel of rolling_simple.hip - one wavefront per tile of 512 + 128 rows, one lane walks one window in row order -
+// only needs each window's synthetic value fed to the same left-to-right walk: bit-identical to the two-call path by construction.
+//
+// What it does NOT take raises a status flag and the host makes the two calls instead (api.cpp fused_run -> the generic path):
+// windows that run past a tile's look-ahead, tiles denser than the head list, a run of more than 2048 null rows between a window
+// and its neighbour point (the two-call path has the neighbour index for those).  Inclusive windows, time-weighted reducers, wide
+// frames, rows below s0 and interval columns with nulls never get here (the host declines them up front).
+#include <stddef.h>
+
+#include "interp_device.h"
+
+namespace bowgpu {
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kTileF = 512;
+constexpr int kHaloF = 128;
+constexpr int kRowsF = kTileF + kHaloF;
+constexpr int kChunksF = kRowsF / 128;
+constexpr int kCapF = 150;          // heads per tile (+ look-ahead): windows of 4.3 rows and more on average; LDS exactly 6 KB
+constexpr uint32_t kSatF = 0xFFFFu;
+constexpr int kAlignF = 16;
+constexpr uint32_t kRowMaskF = 0x3FFu, kExactBitF = 0x8000u;   // a head entry: local row | its row sits exactly on the window start << 15 | (wid - wid of the tile's first row) << 16
+constexpr int kWalkWordsF = 64;     // a neighbour point outside the tile: at most this many validity words are searched (2048 rows)
+
+struct FusedShared {
+    uint64_t val[swz_slots(kRowsF)];   // the staged column (agg_device.h swz: padded against bank conflicts)
+    uint32_t vbits[kRowsF / 32 + 2];   // validity words of the value column for this tile
+    uint32_t seg[kCapF + 2];
+};
+static_assert(sizeof(FusedShared) <= 6144, "LDS of the fused kernel: 6 KB (26 wavefronts per CU)");
+
+__device__ __forceinline__ uint32_t mdiv32(uint32_t n, uint32_t m, uint32_t sh1, uint32_t sh2) {
+    const uint32_t t = __umulhi(m, n);
+    return (t + ((n - t) >> sh1)) >> sh2;
+}
+__device__ __forceinline__ uint32_t left32(uint32_t x, uint32_t lane0) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)lane0, (int)x, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+typedef unsigned long long u64x2_f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ ulonglong2 load16_nt(const ulonglong2 *q) {
+    const u64x2_f v = __builtin_nontemporal_load(reinterpret_cast<const u64x2_f *>(q));
+    return make_ulonglong2(v.x, v.y);
+}
+__device__ __forceinline__ void lds_order() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// nearest valid row at or before `row` / at or after it, looking at no more than kWalkWordsF words; -1: none (the column's first /
+// last row was reached); *gave_up: the words ran out first
+__device__ inline int64_t prev_valid_bounded(const uint32_t *bits, int64_t bit0, int64_t row, bool *gave_up) {
+    if (row < 0) return -1;
+    int64_t b = bit0 + row;
+    for (int k = 0; k < kWalkWordsF && b >= bit0; k++) {
+        const int64_t w = b >> 5;
+        const int sh = (int)(b & 31);
+        uint32_t x = bits[w];
+        x = sh == 31 ? x : (x & ((2u << sh) - 1u));
+        if (w == (bit0 >> 5)) x &= ~0u << (bit0 & 31);
+        if (x) return (w << 5) + (31 - __clz((int)x)) - bit0;
+        b = (w << 5) - 1;
+    }
+    if (b >= bit0) *gave_up = true;
+    return -1;
+}
+__device__ inline int64_t next_valid_bounded(const uint32_t *bits, int64_t bit0, int64_t n, int64_t row, bool *gave_up) {
+    if (row >= n) return -1;
+    int64_t b = bit0 + row;
+    const int64_t bend = bit0 + n;
+    for (int k = 0; k < kWalkWordsF && b < bend; k++) {
+        const int64_t w = b >> 5;
+        const uint32_t x = bits[w] & (~0u << (b & 31));
+        if (x) {
+            const int64_t r = (w << 5) + (__ffs((int)x) - 1) - bit0;
+            return r < n ? r : -1;
+        }
+        b = (w + 1) << 5;
+    }
+    if (b < bend) *gave_up = true;
+    return -1;
+}
+
+// rows fv .. lv of the staged column behind an optional synthetic first row of value xs (seeded), in row order: sum.go:16-22,
+// arithmeticmean.go:17-24, minmax.go:16-28 over [x_s, x_fv, ..., x_lv].  The same loops and the same settling of v_min_f64 / v_max_f64
+// as agg_device.h walk_values; the seed is the synthetic value when there is one, else the first valid row.
+template <bool kSwz, bool kEight>
+__device__ __forceinline__ void walk_seeded(const uint64_t *val, int fv, int lv, bool do_sum, bool do_mm, bool exact_mm, bool seeded, double xs,
+                                            double &sum, double &mn, double &mx) {
+    const double seed = seeded ? xs : __longlong_as_double((long long)val[swz<kSwz>(fv)]);
+    sum = seeded ? 0.0 + xs : 0.0;
+    mn = seed; mx = seed;
+    const int rend = lv + 1;
+    if (fv < rend) {
+        if (do_sum && do_mm) walk_rows<kSwz, kEight, true, true>(val, fv, rend, sum, mn, mx);
+        else if (do_mm) walk_rows<kSwz, kEight, false, true>(val, fv, rend, sum, mn, mx);
+        else if (do_sum) walk_rows<kSwz, kEight, true, false>(val, fv, rend, sum, mn, mx);
+    }
+    if (do_mm) {
+        if (seed != seed) { mn = seed; mx = seed; }
+        else if (exact_mm || mn == 0.0 || mx == 0.0 || mn != mn || mx != mx) {
+            mn = seed; mx = seed;
+            for (int rr = fv; rr < rend; rr++) {
+                const double x = __longlong_as_double((long long)val[swz<kSwz>(rr)]);
+                if (x < mn) mn = x;
+                if (x > mx) mx = x;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// kNeed: bit0 min/max wanted, bit1 first/last wanted; kNulls: some value column has nulls; kMulti: more than one value column
+template <int kNeed, bool kNulls, bool kMulti>
+__global__ __launch_bounds__(kWave, kMulti ? 5 : 6) void rolling_fused_kernel(const FusedParams fp, const int64_t ntiles, const int64_t tiles_per_xcd) {
+    __shared__ FusedShared sh;
+    constexpr bool kSwzF = true;
+    const SimpleParams &p = fp.s;
+    const int64_t b = blockIdx.x;
+    const int64_t tile = (b & 7) * tiles_per_xcd + (b >> 3);  // XCD-contiguous tile runs (look-ahead rows hit the same L2)
+    if (tile >= ntiles) return;
+    const int lane = threadIdx.x;
+    const int64_t base = tile * kTileF;
+    const int64_t n = p.n;
+    const bool interior = base + kRowsF <= n;
+    const int nloc = interior ? kRowsF : (int)(n - base);
+
+    // ---- loads: ts, then the first value column right behind it (rolling_simple.hip: one block of loads for the usual tile)
+    uint64_t ta[kChunksF], tb[kChunksF], va[kChunksF], vb[kChunksF];
+    const uint64_t *__restrict__ ts = reinterpret_cast<const uint64_t *>(p.ts);
+    auto load_col = [&](const uint64_t *__restrict__ src, uint64_t (&a)[kChunksF], uint64_t (&bb)[kChunksF], bool aligned) {
+        if (interior && aligned) {
+            const ulonglong2 *q = reinterpret_cast<const ulonglong2 *>(src + base) + lane;
+#pragma unroll
+            for (int j = 0; j < kChunksF; j++) {
+                const ulonglong2 x = (j > 0 && j < kChunksF - 1) ? load16_nt(q + j * 64) : q[j * 64];
+                a[j] = x.x; bb[j] = x.y;
+            }
+        } else if (interior) {
+            const uint64_t *q = src + base + 2 * lane;
+#pragma unroll
+            for (int j = 0; j < kChunksF; j++) { a[j] = q[j * 128]; bb[j] = q[j * 128 + 1]; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < kChunksF; j++) load_pair(src, base + j * 128 + 2 * lane, n, aligned, a[j], bb[j]);
+        }
+    };
+    if (interior && !(p.unaligned_mask & 0x80000001u)) {
+        const ulonglong2 *qt = reinterpret_cast<const ulonglong2 *>(ts + base) + lane;
+        const ulonglong2 *qv = reinterpret_cast<const ulonglong2 *>(reinterpret_cast<const uint64_t *>(p.values[0]) + base) + lane;
+#pragma unroll
+        for (int j = 0; j < kChunksF; j++) {
+            const ulonglong2 x = (j > 0 && j < kChunksF - 1) ? load16_nt(qt + j * 64) : qt[j * 64];
+            ta[j] = x.x; tb[j] = x.y;
+        }
+#pragma unroll
+        for (int j = 0; j < kChunksF; j++) {
+            const ulonglong2 x = (j > 0 && j < kChunksF - 1) ? load16_nt(qv + j * 64) : qv[j * 64];
+            va[j] = x.x; vb[j] = x.y;
+        }
+    } else {
+        load_col(ts, ta, tb, !(p.unaligned_mask >> 31));
+        load_col(reinterpret_cast<const uint64_t *>(p.values[0]), va, vb, !(p.unaligned_mask & 1u));
+    }
+    auto load_vword = [&](int c) -> uint32_t {
+        uint32_t word = 0xFFFFFFFFu;
+        if (lane < kRowsF / 32 && p.vbits[c] != nullptr) {
+            const int64_t bit = p.vbit0[c] + base + 32 * (int64_t)lane;
+            const int64_t wi = bit >> 5;
+            const int shb = (int)(bit & 31);
+            const uint32_t lo = wi < p.vwords[c] ? p.vbits[c][wi] : 0u;
+            const uint32_t hi = (shb != 0 && wi + 1 < p.vwords[c]) ? p.vbits[c][wi + 1] : 0u;
+            word = shb ? ((lo >> shb) | (hi << (32 - shb))) : lo;
+        }
+        return word;
+    };
+    uint32_t vword = kNulls ? load_vword(0) : 0u;
+    const int64_t left0 = base > 0 ? p.ts[base - 1] : INT64_MIN;
+    const int64_t ws0 = p.s0;
+    bool unsorted = false, sat = false;
+    const int64_t ts_first = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ta[0] >> 32)) << 32) |
+                                       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ta[0]));
+    const uint32_t s0_lo = (uint32_t)ws0;
+    const uint32_t ik = (uint32_t)p.interval;
+
+    // ---- window ids (32-bit, global: the host sends frames whose rows lie within 2^32 of s0), head flags with their
+    // "sits exactly on the window start" bit, compaction with a running scalar count
+    const uint32_t w_first = mdiv32((uint32_t)ts_first - s0_lo, p.m32, p.sh1, p.sh2);
+    uint32_t left_w = base == 0 ? 0xFFFFFFFEu : mdiv32((uint32_t)left0 - s0_lo, p.m32, p.sh1, p.sh2);
+    int64_t left_ts = left0;
+    int nseg_total = 0, nseg_owned = 0;
+#pragma unroll
+    for (int j = 0; j < kChunksF; j++) {
+        const int l = j * 128 + 2 * lane;
+        const bool pa = l < nloc, pb = l + 1 < nloc;
+        const int64_t tsa = (int64_t)ta[j], tsb = (int64_t)tb[j];
+        const uint32_t plo = left32((uint32_t)tb[j], (uint32_t)left_ts);
+        const uint32_t phi = left32((uint32_t)(tb[j] >> 32), (uint32_t)((uint64_t)left_ts >> 32));
+        const int64_t prev_ts = (int64_t)(((uint64_t)phi << 32) | plo);
+        unsorted |= (pa && prev_ts > tsa) || (pb && tsa > tsb);
+        const uint32_t ra = (uint32_t)tsa - s0_lo, rb = (uint32_t)tsb - s0_lo;
+        const uint32_t wa = mdiv32(ra, p.m32, p.sh1, p.sh2);
+        const uint32_t wb = mdiv32(rb, p.m32, p.sh1, p.sh2);
+        const uint32_t wprev = left32(wb, left_w);
+        const bool ha = pa && (wa != wprev);
+        const bool hb = pb && (wb != wa);
+        const uint32_t la = wa - w_first, lb = wb - w_first;
+        sat |= (ha && la >= kSatF) || (hb && lb >= kSatF);
+        const unsigned long long ma = __ballot(ha), mb = __ballot(hb);
+        int pos = nseg_total;
+        pos += __builtin_amdgcn_mbcnt_hi((unsigned)(ma >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ma, 0));
+        pos += __builtin_amdgcn_mbcnt_hi((unsigned)(mb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb, 0));
+        if (ha && pos < kCapF) sh.seg[pos] = (uint32_t)l | (ra == wa * ik ? kExactBitF : 0u) | (la << 16);
+        pos += ha ? 1 : 0;
+        if (hb && pos < kCapF) sh.seg[pos] = (uint32_t)(l + 1) | (rb == wb * ik ? kExactBitF : 0u) | (lb << 16);
+        nseg_total += __popcll(ma) + __popcll(mb);
+        if (j == kChunksF - 2) nseg_owned = nseg_total;
+        left_w = (uint32_t)__builtin_amdgcn_readlane((int)wb, 63);
+        left_ts = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(tb[j] >> 32), 63) << 32) |
+                            (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)tb[j], 63));
+    }
+    if (__ballot(unsorted)) {  // the call fails with BOWGPU_ERR_TS_UNSORTED
+        if (lane == 0) atomicOr(&p.status[0], 1u);
+        return;
+    }
+    if (nseg_total > kCapF) sat = true;
+    if (__ballot(sat)) {  // a tile this kernel cannot describe: the host makes the two calls instead
+        if (lane == 0 && !__hip_atomic_load(&p.status[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(&p.status[4], 1u);
+        return;
+    }
+
+    const bool reaches_end = base + kRowsF >= n;
+    // ---- which windows this wavefront outputs: those that start in its 512 rows, with the slot-aligned hand-over of rolling_simple.hip
+    int q_start = 0, q_end = nseg_owned;
+    {
+        lds_order();
+        auto handover = [&](int qf, int qlim) -> int {
+            if (qf >= qlim) return qf;
+            const uint32_t gf = w_first + (sh.seg[qf] >> 16);
+            const uint32_t A = (gf + (kAlignF - 1)) & ~(uint32_t)(kAlignF - 1);
+            if (A == gf) return qf;
+            const int qi = qf + lane;
+            const bool below = lane < kAlignF && qi < qlim && (w_first + (sh.seg[qi < qlim ? qi : qf] >> 16)) < A;
+            const int nb = __popcll(__ballot(below));
+            return qf + nb < qlim ? qf + nb : qf;
+        };
+        int n128 = 0;
+        {
+            const int qa = lane, qb = lane + 64, qc = lane + 128;
+            const bool a = qa < nseg_total && (int)(sh.seg[qa < nseg_total ? qa : 0] & kRowMaskF) < 128;
+            const bool bq = qb < nseg_total && (int)(sh.seg[qb < nseg_total ? qb : 0] & kRowMaskF) < 128;
+            const bool cq = qc < nseg_total && (int)(sh.seg[qc < nseg_total ? qc : 0] & kRowMaskF) < 128;
+            n128 = __popcll(__ballot(a)) + __popcll(__ballot(bq)) + __popcll(__ballot(cq));
+        }
+        if (tile > 0) q_start = handover(0, n128);
+        q_end = handover(nseg_owned, nseg_total);
+    }
+    const uint32_t W32 = (uint64_t)p.W > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)p.W;
+    const bool need_sum = p.need & kNeedSum;
+    bool gave_up = false;   // a neighbour point further away than the bounded search looks: the host makes the two calls instead
+
+    // ---- one pass per value column: stage (rolling_simple.hip: float64(v), nulls replaced), synthetic values, walk, store
+    const int ncols = kMulti ? p.ncols : 1;
+    for (int c = 0; c < ncols; c++) {
+        const bool cint = p.col_is_int[c] != 0;
+        const FusedCol fc = fp.cols[c];
+        const uint64_t *__restrict__ src = reinterpret_cast<const uint64_t *>(p.values[c]);
+        const uint32_t *cbits = p.vbits[c];
+        lds_order();  // the previous pass is done with sh.val / sh.vbits
+        if (kNulls) {
+            if (lane < kRowsF / 32) sh.vbits[lane] = vword;
+            lds_order();
+        }
+        bool snan = false;
+        {
+            const uint64_t fill = need_sum ? 0ull : kNullAsNaN;
+#pragma unroll
+            for (int j = 0; j < kChunksF; j++) {
+                uint64_t xa = va[j], xb = vb[j];
+                if (cint) {
+                    xa = (uint64_t)__double_as_longlong((double)(int64_t)xa);
+                    xb = (uint64_t)__double_as_longlong((double)(int64_t)xb);
+                }
+                if (kNulls) {
+                    const uint32_t two = sh.vbits[j * 4 + (lane >> 4)] >> ((2 * lane) & 31);
+                    if (!(two & 1u)) xa = fill;
+                    if (!(two & 2u)) xb = fill;
+                }
+                if ((kNeed & 1) && !cint) snan = snan || is_snan(xa) || is_snan(xb);
+                *reinterpret_cast<ulonglong2 *>(&sh.val[swz<kSwzF>(j * 128 + 2 * lane)]) = make_ulonglong2(xa, xb);
+            }
+            if (kMulti && c + 1 < ncols) {
+                load_col(reinterpret_cast<const uint64_t *>(p.values[c + 1]), va, vb, !((p.unaligned_mask >> (c + 1)) & 1u));
+                if (kNulls) vword = load_vword(c + 1);
+            }
+        }
+        lds_order();
+        const bool exact_mm = (kNeed & 1) && __ballot(snan) != 0ull;
+
+        // the two neighbour points of a window whose FirstIndex is local row a (0 <= a <= nloc): the nearest valid row of the column
+        // before it and from it on (linear.go:20-31, stepprevious.go:19; the interval column has no nulls: both-valid == value valid).
+        // Inside the tile: the tile's validity words; outside: a bounded walk over the column's bitmap.
+        auto neighbours = [&](int a, NbPoint &pp, NbPoint &np) {
+            pp.has = 0; pp.t = 0; pp.bits = 0; np.has = 0; np.t = 0; np.bits = 0;
+            const bool want_prev = fc.kind == BOWGPU_INTERP_LINEAR || fc.kind == BOWGPU_INTERP_STEP_PREVIOUS;
+            const bool want_next = fc.kind == BOWGPU_INTERP_LINEAR;
+            int64_t prow = -1, nrow = -1;
+            if (want_prev) {
+                if (!kNulls || cbits == nullptr) prow = base + a - 1;   // (-1 in front of the frame's first row)
+                else {
+                    int pr = -1;
+                    if (a > 0) {
+                        int wi = (a - 1) >> 5;
+                        uint32_t m = sh.vbits[wi] & (0xFFFFFFFFu >> (31 - ((a - 1) & 31)));
+                        while (m == 0u && wi > 0) { wi--; m = sh.vbits[wi]; }
+                        if (m) pr = wi * 32 + 31 - __clz((int)m);
+                    }
+                    prow = pr >= 0 ? base + pr : prev_valid_bounded(cbits, p.vbit0[c], base - 1, &gave_up);
+                }
+            }
+            if (want_next) {
+                if (!kNulls || cbits == nullptr) nrow = base + a < n ? base + a : -1;
+                else {
+                    int nr = -1;
+                    if (a < nloc) {
+                        const int wl = (nloc - 1) >> 5;
+                        int wi = a >> 5;
+                        uint32_t m = sh.vbits[wi] & (0xFFFFFFFFu << (a & 31));
+                        while (m == 0u && wi < wl) { wi++; m = sh.vbits[wi]; }
+                        if (m) { nr = wi * 32 + __ffs((int)m) - 1; if (nr >= nloc) nr = -1; }
+                    }
+                    nrow = nr >= 0 ? base + nr : next_valid_bounded(cbits, p.vbit0[c], n, base + nloc, &gave_up);
+                }
+            }
+            if (prow >= 0) { pp.has = 1; pp.t = p.ts[prow]; pp.bits = src[prow]; }
+            if (nrow >= 0) { np.has = 1; np.t = p.ts[nrow]; np.bits = src[nrow]; }
+        };
+
+        // a nullable column whose outputs want sums AND extrema is walked twice (rolling_simple.hip): phase 1 with +0.0 in the null rows,
+        // then the null rows are overwritten with NaN and phase 2 walks the extrema.  Every other shape: phase 0, one walk.
+        const bool two_phase = kNulls && (kNeed & 1) && need_sum;
+        for (int phase = two_phase ? 1 : 0; phase <= (two_phase ? 2 : 0); phase++) {
+            if (phase == 2) {
+                lds_order();
+#pragma unroll
+                for (int j = 0; j < kChunksF; j++) {
+                    const uint32_t two = sh.vbits[j * 4 + (lane >> 4)] >> ((2 * lane) & 31);
+                    if (!(two & 1u)) sh.val[swz<kSwzF>(j * 128 + 2 * lane)] = kNullAsNaN;
+                    if (!(two & 2u)) sh.val[swz<kSwzF>(j * 128 + 2 * lane) + 1] = kNullAsNaN;
+                }
+                lds_order();
+            }
+            const bool do_sum = need_sum && phase != 2;
+            const bool do_mm = (kNeed & 1) && phase != 1;
+
+    for (int q = q_start + lane; q < q_end; q += kWave) {
+        const uint32_t e0 = sh.seg[q], e1 = sh.seg[q + 1];
+        const int r0 = (int)(e0 & kRowMaskF);
+        const bool exact = (e0 & kExactBitF) != 0;
+        const uint32_t wid = w_first + (e0 >> 16);
+        int r1;
+        uint32_t next_wid;
+        if (q + 1 < nseg_total) {
+            r1 = (int)(e1 & kRowMaskF);
+            next_wid = w_first + (e1 >> 16);
+        } else if (reaches_end) {
+            r1 = nloc;
+            next_wid = W32;
+        } else {
+            gave_up = true;   // rows run past the look-ahead: the two-call path has the long-window forms
+            continue;
+        }
+        if (wid >= W32) continue;  // (only on corrupt input)
+        const int64_t win_start = ws0 + (int64_t)((uint64_t)wid * (uint64_t)ik);
+        // ---- the synthetic row in front of the window's rows (interpolation.go:118-160), as the reducers of this column see it
+        uint64_t sbits = 0;
+        int sv = 0;
+        if (!exact) {
+            NbPoint pp, np;
+            neighbours(r0, pp, np);
+            synth_value_pt(fc, win_start, pp, np, &sbits, &sv);
+        }
+        const double xs = cint ? (double)(int64_t)sbits : __longlong_as_double((long long)sbits);   // bowgetters.go:224-229
+        // ---- valid rows of the window: how many, the first, the last; then the walk behind the synthetic row
+        int count = r1 - r0, fv = r0, lv = r1 - 1;
+        if (kNulls) window_valid_rows(sh.vbits, r0, r1, count, fv, lv);
+        const bool own = count > 0;      // the window has a valid row of its own
+        if (!own) { fv = r0; lv = r0 - 1; }
+        count += sv;
+        const bool has_value = count > 0;
+        double sum = 0.0, mn = 0.0, mx = 0.0;
+        uint64_t first_raw = 0, last_raw = 0;
+        if (has_value) {
+            walk_seeded<kSwzF, !kMulti>(sh.val, fv, lv, do_sum, do_mm, exact_mm, sv != 0, xs, sum, mn, mx);
+            if (kNeed & 2) {
+                if (own) {
+                    first_raw = sh.val[swz<kSwzF>(fv)];
+                    last_raw = sh.val[swz<kSwzF>(lv)];
+                    if (cint) { first_raw = src[base + fv]; last_raw = src[base + lv]; }   // First / Last return the Int64 itself (firstlast.go:17, :32)
+                }
+                if (sv) { first_raw = sbits; if (!own) last_raw = sbits; }
+            }
+        }
+        const int nrows = (r1 - r0) + (exact ? 0 : 1);
+        const int64_t slot = (int64_t)wid;
+        const uint32_t gap = next_wid - wid - 1;
+        // the empty windows right after this one hold ONE row each, their synthetic row: every one of them has FirstIndex r1 (the next
+        // window's first row: rolling.go:224-231 leaves currRowIndex there), so one pair of neighbour points serves the whole run
+        NbPoint gp, gn;
+        if (gap) neighbours(r1, gp, gn);
+#pragma unroll 1
+        for (int a_ = 0; a_ < p.naggs; a_++) {
+            const int a = __builtin_amdgcn_readfirstlane(a_);
+            if (kMulti && p.col[a] != c) continue;
+            const int k = p.kind[a];
+            if (phase != 0 && (phase == 2) != (k == BOWGPU_AGG_MIN || k == BOWGPU_AGG_MAX)) continue;   // two walks: each output once
+            typedef const uint64_t __attribute__((address_space(4))) *karg_u64;
+            typedef uint64_t __attribute__((address_space(1))) *global_u64;
+            const global_u64 out_a = (global_u64)((karg_u64)__builtin_amdgcn_kernarg_segment_ptr())[offsetof(SimpleParams, out_values) / 8 + a];
+            uint64_t bits;
+            bool nil = false;
+            switch (k) {
+            case BOWGPU_AGG_WINDOW_START: bits = (uint64_t)win_start; break;
+            case BOWGPU_AGG_SUM: bits = (uint64_t)__double_as_longlong(sum); break;
+            case BOWGPU_AGG_MEAN: bits = (uint64_t)__double_as_longlong(sum / (double)(int64_t)count); nil = !has_value; break;
+            case BOWGPU_AGG_MIN: bits = (uint64_t)__double_as_longlong(mn); nil = !has_value; break;
+            case BOWGPU_AGG_MAX: bits = (uint64_t)__double_as_longlong(mx); nil = !has_value; break;
+            case BOWGPU_AGG_COUNT: bits = (uint64_t)(int64_t)count; break;
+            case BOWGPU_AGG_FIRST: bits = first_raw; nil = !has_value; break;
+            case BOWGPU_AGG_LAST: bits = last_raw; nil = !has_value; break;
+            default: bits = (uint64_t)__double_as_longlong((double)nrows); break;  // NumRows
+            }
+            const bool int_result = k == BOWGPU_AGG_WINDOW_START || k == BOWGPU_AGG_COUNT || (cint && (k == BOWGPU_AGG_FIRST || k == BOWGPU_AGG_LAST));
+            const int nf = p.nfac[a];
+            if (nf) bits = apply_factors(bits, int_result, nf, p.fac[a]);
+            if (nil) {
+                bits = 0;
+                atomicAnd(&p.out_valid[a][slot >> 5], ~(1u << (slot & 31)));
+            }
+            __builtin_nontemporal_store(bits, &out_a[slot]);
+            for (uint32_t g = 1; g <= gap; g++) {
+                if (wid + g >= W32) break;
+                const int64_t gw = slot + g;
+                const int64_t gstart = win_start + (int64_t)((uint64_t)g * (uint64_t)ik);
+                uint64_t gs = 0;
+                int gv = 0;
+                synth_value_pt(fc, gstart, gp, gn, &gs, &gv);
+                const double gx = cint ? (double)(int64_t)gs : __longlong_as_double((long long)gs);
+                uint64_t gbits;
+                bool gnil = false;
+                switch (k) {
+                case BOWGPU_AGG_WINDOW_START: gbits = (uint64_t)gstart; break;
+                case BOWGPU_AGG_SUM: gbits = (uint64_t)__double_as_longlong(gv ? 0.0 + gx : 0.0); break;
+                case BOWGPU_AGG_MEAN: gbits = (uint64_t)__double_as_longlong((0.0 + gx) / 1.0); gnil = !gv; break;
+                case BOWGPU_AGG_MIN: case BOWGPU_AGG_MAX: gbits = (uint64_t)__double_as_longlong(gx); gnil = !gv; break;
+                case BOWGPU_AGG_COUNT: gbits = (uint64_t)(int64_t)gv; break;
+                case BOWGPU_AGG_FIRST: case BOWGPU_AGG_LAST: gbits = gs; gnil = !gv; break;
+                default: gbits = (uint64_t)__double_as_longlong(1.0); break;  // NumRows: the synthetic row
+                }
+                if (nf) gbits = apply_factors(gbits, int_result, nf, p.fac[a]);
+                if (gnil) {
+                    gbits = 0;
+                    atomicAnd(&p.out_valid[a][gw >> 5], ~(1u << (gw & 31)));
+                }
+                out_a[gw] = gbits;
+            }
+        }
+    }
+        }  // phases
+    }  // columns
+    if (__ballot(gave_up)) {
+        if (lane == 0 && !__hip_atomic_load(&p.status[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(&p.status[5], 1u);
+    }
+}
+
+int launch_rolling_fused(Ctx *c, const FusedParams &fp, int need, bool has_nulls) {
+    const SimpleParams &p = fp.s;
+    if (p.n <= 0) return 0;
+    const int64_t ntiles = (p.n + kTileF - 1) / kTileF;
+    const int64_t per_xcd = (ntiles + 7) / 8;
+    const int64_t grid = per_xcd * 8;
+    if (grid > 0x7FFFFFFFll) return fail(BOWGPU_ERR_UNSUPPORTED, "too many rows for one launch: %lld", (long long)p.n);
+    const dim3 g((unsigned)grid), blk(kWave);
+#define BG_FGO(N, U, M) hipLaunchKernelGGL((rolling_fused_kernel<N, U, M>), g, blk, 0, c->stream, fp, ntiles, per_xcd)
+#define BG_FM(N, U) do { if (p.ncols > 1) BG_FGO(N, U, true); else BG_FGO(N, U, false); } while (0)
+#define BG_FN(U) switch (need) { case 0: BG_FM(0, U); break; case 1: BG_FM(1, U); break; case 2: BG_FM(2, U); break; default: BG_FM(3, U); break; }
+    if (has_nulls) { BG_FN(true) } else { BG_FN(false) }
+#undef BG_FN
+#undef BG_FM
+#undef BG_FGO
+    BG_HIP(hipGetLastError());
+    c->last_kernel_name = "rolling_fused_kernel";
+    return 0;
+}
+
+}  // namespace bowgpu

@@ -25,7 +25,9 @@ extern "C" {
 /* 4 (round 4): bowgpu_options' former padding word is `strict_order` (a caller that left it uninitialised now gets the row-order forms),
  * bowgpu_stream_rw_ceiling became bowgpu_stream_rw_probe, the BOWGPU_ROUTE_* bits moved.  A binding checks bowgpu_abi_version()
  * against the value it was written for when it loads the library (bow_amd/capi.py lib(); shim/go/rolling/gpu_cgo.go init()). */
-#define BOWGPU_ABI_VERSION 4
+/* 5 (round 5): bowgpu_rolling_interpolate_aggregate added; bowgpu_last_kernel_name() spells rolling_simple_kernel with its template
+ * arguments; bowgpu_agg_info gained nothing (same layout). */
+#define BOWGPU_ABI_VERSION 5
 
 /* bow.Type (reference bowtypes.go:17-32) */
 enum {
@@ -342,6 +344,28 @@ int bowgpu_shard_interpolate_count(const bowgpu_col *cols, int32_t ncols, int32_
 int bowgpu_shard_interpolate_fill(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval,
                                   const bowgpu_options *opts, int64_t global_s0, const bowgpu_interp *interps, int32_t ninterps,
                                   const bowgpu_interp_edge *edge, bowgpu_out *outs);
+
+/* ---- Rolling.Interpolate(...).Aggregate(...) without the interpolated frame ---------- */
+
+/* r.Interpolate(interps...).Aggregate(aggs...) - reference rolling/interpolation.go:30-69 (returns a Rolling over the interpolated
+ * Bow with the same interval and options) + rolling/aggregation.go:123-145 (consumes it) - when the caller wants only the aggregated
+ * Bow: the interpolated frame (rows + one synthetic row per window that does not start on its first row, interpolation.go:98-161) is
+ * never handed back and, where the shape allows it, never written.  interps: one per column of the Bow, in column order (as for
+ * bowgpu_rolling_interpolate_*); aggs[i].col indexes those same columns - the interpolated Bow has the input's columns and types
+ * (interpolation.go:139-155).  outs / info: as bowgpu_rolling_aggregate on the Rolling Interpolate returns.
+ *   ONE pass over the rows (rolling_fused.hip: a window's synthetic value - linear.go:34-35's expression on the nearest both-valid
+ * rows either side of the window's FirstIndex - is fed as the window's first row to the same left-to-right walk) for: exclusive
+ * windows; WindowStart / Sum / ArithmeticMean / Min / Max / Count / First / Last / NumRows; an interval column without nulls under
+ * interpolation.WindowStart; value columns under Linear / StepPrevious / None (/ WindowStart); a frame that starts at or above 0 and
+ * spans less than 2^32 from its first window start; windows of 4 .. 128 rows on average, none longer than 128 rows.
+ *   Everything else (and any call some tile of which the fused kernel cannot describe): bowgpu_rolling_interpolate_count + _fill into
+ * device temporaries, then bowgpu_rolling_aggregate on them - what the two calls give, bit for bit, including their declines
+ * (BOWGPU_ERR_TS_UNSORTED, ...).  Errors: newIntervalRolling's first, then Interpolate's (BOWGPU_ERR_TYPE "accepts types ...",
+ * BOWGPU_ERR_KEEP_INTERVAL), then Aggregate's.  Both forms are bit-identical to the two calls made one after the other
+ * (tests/test_gpu_fused.py: every window against oracle interpolate -> aggregate, and against the two-call path). */
+int bowgpu_rolling_interpolate_aggregate(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval,
+                                         const bowgpu_options *opts, const bowgpu_interp *interps, int32_t ninterps,
+                                         const bowgpu_agg *aggs, int32_t naggs, bowgpu_out *outs, bowgpu_agg_info *info);
 
 /* ---- Bow.FillLinear / IsColSorted -------------------------------------------------- */
 

@@ -25,7 +25,7 @@ import (
 )
 
 // the struct layouts and option meanings this file was written against (include/bowgpu.h BOWGPU_ABI_VERSION)
-const bowgpuABI = 4
+const bowgpuABI = 5
 
 func init() {
 	if v := int(C.bowgpu_abi_version()); v != bowgpuABI {

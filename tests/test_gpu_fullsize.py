@@ -86,6 +86,13 @@ def _config2_every_row(n):
         exp, _ = orc.aggregate([want[0], want[1]], 0, 100, aggs, offset=offset)
         for (k, _), g, w in zip(aggs, got, exp):
             compare("config2 %s off=%d" % (k, offset), g, w)
+        # ... and the same pipeline as ONE call, the interpolated frame never written (rolling_fused.hip): every window, bit for bit
+        del filled, cols2, got
+        fused, _ = capi.rolling_interpolate_aggregate([ts, val], 0, 100, ip, aggs, offset=offset, out_residency=capi.DEVICE)
+        assert capi.last_kernel_name() == "rolling_fused_kernel"
+        for (k, _), g, w in zip(aggs, fused, exp):
+            compare("config2 as one call %s off=%d" % (k, offset), g, w)
+        del fused
 
 
 def test_config2_sparse_nulls_linear_fill_then_mean_2e7_every_row():
