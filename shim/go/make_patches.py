@@ -53,6 +53,15 @@ def edit_interpolation_go(src, path):
     return src
 
 
+def edit_interpolation_go_lazy(src, path):
+    # Interpolate: once the interpolators are validated and the interval column is known to be kept, in front of interpolateWindows
+    src = sub_once(src, "\tb, err := rCopy.interpolateWindows(interps)\n",
+                   "\tif lazy := rCopy.lazyInterpolationGPU(interps, newIntervalCol); lazy != nil { // bowgpu: gpu_lazy.go, gpu_cgo.go / gpu_off.go\n"
+                   "\t\treturn lazy\n\t}\n\n"
+                   "\tb, err := rCopy.interpolateWindows(interps)\n", path)
+    return src
+
+
 def edit_bowfill_go(src, path):
     # FillLinear: behind ALL of its argument checks (bowfill.go:15-55), in front of the loop
     src = sub_once(src, "\tif b.Column(toFillColIndex).NullN() == 0 {\n\t\treturn b, nil\n\t}\n\tbuf := b.NewBufferFromCol(toFillColIndex)\n",
@@ -170,6 +179,7 @@ def go_shapes():
                                           "methods": methods_of(["rolling/interpolation.go"], "ColInterpolation")}
     shapes["rolling.intervalRolling"] = {"kind": "struct", "file": "rolling/rolling.go", "fields": struct_fields("rolling/rolling.go", "intervalRolling"),
                                          "methods": methods_of(["rolling/rolling.go", "rolling/aggregation.go", "rolling/interpolation.go"], "intervalRolling")}
+    shapes["rolling.Rolling"] = {"kind": "interface", "file": "rolling/rolling.go", "methods": iface_methods("rolling/rolling.go", "Rolling")}
     shapes["rolling.Options"] = {"kind": "struct", "file": "rolling/rolling.go", "fields": struct_fields("rolling/rolling.go", "Options")}
     shapes["bow.Bow"] = {"kind": "interface", "file": "bow.go", "methods": iface_methods("bow.go", "Bow")}
     shapes["transformation"] = {"kind": "package", "file": "rolling/transformation/factor.go", "funcs": funcs("rolling/transformation/factor.go"),
@@ -219,6 +229,9 @@ def generate():
     files["patches/0004-fill-and-is-col-sorted-hooks.patch"] = p4
     old = open(os.path.join(REF, "rolling/aggregation/whole.go")).read()
     files["patches/0005-whole-frame-aggregate-hook.patch"] = diff("rolling/aggregation/whole.go", old, edit_whole_go(old, "rolling/aggregation/whole.go"))
+    # 0006 comes on top of 0001 (both edit rolling/interpolation.go): the diff is taken against the file as 0001 leaves it
+    base = edit_interpolation_go(open(os.path.join(REF, "rolling/interpolation.go")).read(), "rolling/interpolation.go")
+    files["patches/0006-interpolate-returns-a-lazy-rolling.patch"] = diff("rolling/interpolation.go", base, edit_interpolation_go_lazy(base, "rolling/interpolation.go"))
     return files, json.dumps(go_shapes(), indent=1, sort_keys=True) + "\n"
 
 

@@ -182,23 +182,9 @@ func (r *intervalRolling) interpolateWindowsGPU(interps []ColInterpolation) (bow
 	for i := range cols {
 		cols[i] = colDesc(r.bow, i, &pin)
 	}
-	cI := make([]C.bowgpu_interp, len(interps))
-	for i, ip := range interps {
-		k := ip.gpuKind - 1 // ColInterpolation is a struct (interpolation.go:10-16): the tag is its own field (patches/0001, gpu_kinds.go)
-		if k < 0 {
-			return nil, errDeclined
-		}
-		cI[i].kind, cI[i].col = C.int32_t(k), C.int32_t(ip.colIndex)
-		if pr := r.options.PrevRow; pr != nil { // linear.go:14-18, stepprevious.go:13-15 read the LAST row of PrevRow
-			last := pr.NumRows() - 1
-			t, tok := pr.GetFloat64(r.intervalColIndex, last)
-			v, vok := pr.GetFloat64(ip.colIndex, last)
-			cI[i].has_prev_row, cI[i].prev_t, cI[i].prev_v = 1, C.double(t), C.double(v)
-			cI[i].prev_t_valid, cI[i].prev_v_valid = b2i(tok), b2i(vok)
-			if iv, ok := pr.GetValue(ip.colIndex, last).(int64); ok {
-				cI[i].prev_v_i64 = C.int64_t(iv)
-			}
-		}
+	cI, ok := r.interpDesc(interps)
+	if !ok {
+		return nil, errDeclined
 	}
 	opts := C.bowgpu_options{offset: C.int64_t(r.options.Offset), inclusive: b2i(r.options.Inclusive)}
 	var nOut C.int64_t
@@ -218,6 +204,101 @@ func (r *intervalRolling) interpolateWindowsGPU(interps []ColInterpolation) (bow
 		series[i] = seriesOf(r.bow.ColumnName(i), outs[i], data[i], valid[i], n)
 	}
 	return bow.NewBow(series...)
+}
+
+// interpDesc: the interpolators as the library takes them (the tag is ColInterpolation's own field: patches/0001, gpu_kinds.go), with
+// Options.PrevRow's last row (linear.go:14-18, stepprevious.go:13-15).  ok == false: some interpolator is a user closure.
+func (r *intervalRolling) interpDesc(interps []ColInterpolation) ([]C.bowgpu_interp, bool) {
+	cI := make([]C.bowgpu_interp, len(interps))
+	for i, ip := range interps {
+		k := ip.gpuKind - 1
+		if k < 0 {
+			return nil, false
+		}
+		cI[i].kind, cI[i].col = C.int32_t(k), C.int32_t(ip.colIndex)
+		if pr := r.options.PrevRow; pr != nil {
+			last := pr.NumRows() - 1
+			t, tok := pr.GetFloat64(r.intervalColIndex, last)
+			v, vok := pr.GetFloat64(ip.colIndex, last)
+			cI[i].has_prev_row, cI[i].prev_t, cI[i].prev_v = 1, C.double(t), C.double(v)
+			cI[i].prev_t_valid, cI[i].prev_v_valid = b2i(tok), b2i(vok)
+			if iv, ok := pr.GetValue(ip.colIndex, last).(int64); ok {
+				cI[i].prev_v_i64 = C.int64_t(iv)
+			}
+		}
+	}
+	return cI, true
+}
+
+// lazyInterpolationGPU is called by Interpolate once its interpolators are validated (patches/0006, interpolation.go:56): a non-nil
+// result is the Rolling Interpolate returns - gpu_lazy.go.  nil (a user closure among the interpolators, a Rolling already stepped with
+// Next(), a Bow without windows) = the reference's Interpolate as it stands.
+func (r *intervalRolling) lazyInterpolationGPU(interps []ColInterpolation, newIntervalCol int) Rolling {
+	if r.currWindowIndex != 0 || r.currRowIndex != 0 || r.numWindows == 0 {
+		return nil
+	}
+	for _, ip := range interps {
+		if ip.gpuKind == 0 {
+			return nil
+		}
+	}
+	return &lazyInterpolation{base: *r, interps: append([]ColInterpolation(nil), interps...), newIntervalCol: newIntervalCol}
+}
+
+// interpolateAggregateGPU is Interpolate(interps...).Aggregate(aggrs...) as ONE call to the library.  It mirrors Aggregate
+// (aggregation.go:123-145) on the interpolated Rolling, whose Bow has the input's columns and types (interpolation.go:139-155 - the
+// library takes one interpolator per column, in order, so the names resolve to the same indices): indexedAggregations on a copy, the
+// call, newIntervalRolling on the result with the options indexedAggregations left (Inclusive).  nil = anything that is not a plain
+// success: the caller then makes the reference's own two steps, which word every error.
+func (r *intervalRolling) interpolateAggregateGPU(interps []ColInterpolation, aggrs []ColAggregation) Rolling {
+	if len(interps) != r.bow.NumCols() {
+		return nil
+	}
+	for i, ip := range interps {
+		if ip.colIndex != i {
+			return nil
+		}
+	}
+	rCopy := *r
+	newIntervalCol, aggrs, err := rCopy.indexedAggregations(aggrs)
+	if err != nil {
+		return nil
+	}
+	var pin runtime.Pinner
+	defer pin.Unpin()
+	cols, cAggs, opts, err := rCopy.describe(aggrs, &pin)
+	if err != nil {
+		return nil
+	}
+	cI, ok := r.interpDesc(interps)
+	if !ok {
+		return nil
+	}
+	W := r.numWindows // the interpolated frame keeps the window grid (its first row sits on the first window's start); the library checks the capacity
+	outs, data, valid := newOuts(len(aggrs), W, &pin)
+	var info C.bowgpu_agg_info
+	if rc := C.bowgpu_rolling_interpolate_aggregate(&cols[0], C.int32_t(len(cols)), C.int32_t(r.intervalColIndex), C.int64_t(r.interval), &opts,
+		&cI[0], C.int32_t(len(cI)), &cAggs[0], C.int32_t(len(cAggs)), &outs[0], &info); rc != 0 {
+		return nil
+	}
+	n := int(info.num_windows)
+	series := make([]bow.Series, len(aggrs))
+	for i, a := range aggrs {
+		name := a.OutputName() // aggregation.go:230-234
+		if name == "" {
+			name = r.bow.ColumnName(a.InputIndex())
+		}
+		series[i] = seriesOf(name, outs[i], data[i], valid[i], n)
+	}
+	b, err := bow.NewBow(series...)
+	if err != nil {
+		return nil
+	}
+	newR, err := newIntervalRolling(b, newIntervalCol, rCopy.interval, rCopy.options) // aggregation.go:139
+	if err != nil {
+		return rCopy.setError(fmt.Errorf("newIntervalRolling: %w", err))
+	}
+	return newR
 }
 
 // RegisterForGPU: a Bow the application keeps using (Bows are immutable) registers its Arrow buffers once; the kernels then read

@@ -28,3 +28,13 @@ func AggregateWholeGPU(b bow.Bow, intervalColIndex int, aggrs []ColAggregation) 
 }
 
 func RegisterForGPU(b bow.Bow) (release func()) { return bow.RegisterForGPU(b) }
+
+// lazyInterpolationGPU: nil = Interpolate runs as the reference wrote it (patches/0006); interpolateAggregateGPU is only reached
+// through a lazyInterpolation, which this build never makes.
+func (r *intervalRolling) lazyInterpolationGPU(interps []ColInterpolation, newIntervalCol int) Rolling {
+	return nil
+}
+
+func (r *intervalRolling) interpolateAggregateGPU(interps []ColInterpolation, aggrs []ColAggregation) Rolling {
+	return nil
+}

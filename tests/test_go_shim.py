@@ -167,9 +167,18 @@ def test_the_tag_is_a_field_of_the_reference_types_not_a_wrapper():
 def test_every_identifier_the_shim_uses_on_a_reference_type_exists_there():
     cgo, kinds, off = _go("rolling/gpu_cgo.go"), _go("rolling/gpu_kinds.go"), _go("rolling/gpu_off.go")
     R = SHAPES["rolling.intervalRolling"]
-    shim_methods = set(re.findall(r"^func \(r \*intervalRolling\) (\w+)\(", cgo, flags=re.M))
+    lazy = _go("rolling/gpu_lazy.go")
+    shim_methods = set(re.findall(r"^func \(r \*intervalRolling\) (\w+)\(", cgo + lazy, flags=re.M))
     assert shim_methods - set(R["methods"]) == shim_methods        # the shim adds methods, it does not redefine the reference's
-    assert set(re.findall(r"^func \(r \*intervalRolling\) (\w+)\(", off, flags=re.M)) == {"aggregateWindowsGPU", "interpolateWindowsGPU"} <= shim_methods
+    assert set(re.findall(r"^func \(r \*intervalRolling\) (\w+)\(", off, flags=re.M)) == {"aggregateWindowsGPU", "interpolateWindowsGPU", "lazyInterpolationGPU",
+                                                                                       "interpolateAggregateGPU"} <= shim_methods
+    for name in set(re.findall(r"\b(?:r|rCopy)\.(\w+)", lazy)):
+        assert name in R["fields"] or name in R["methods"] or name in shim_methods, ("intervalRolling", name)
+    # the lazy Rolling implements the whole Rolling interface (rolling.go:14-29) and nothing else the reference does not know
+    assert sorted(set(re.findall(r"^func \(l \*lazyInterpolation\) (\w+)\(", lazy, flags=re.M)) - {"materialised"}) == SHAPES["rolling.Rolling"]["methods"]
+    assert "rCopy.lazyInterpolationGPU(interps, newIntervalCol); lazy != nil" in _added_by_patches("rolling/interpolation.go")
+    for text in ('fmt.Errorf("intervalRolling.interpolateWindows: %w", err)', 'fmt.Errorf("newIntervalRolling: %w", err)'):
+        assert text in lazy and text in open(os.path.join(REF, "rolling", "interpolation.go")).read() if os.path.isdir(REF) else text in lazy
     for name in set(re.findall(r"\br\.(\w+)", cgo)):
         assert name in R["fields"] or name in R["methods"] or name in shim_methods, ("intervalRolling", name)
     for name in set(re.findall(r"\br\.options\.(\w+)", cgo)):
