@@ -1626,7 +1626,9 @@ static int fused_try(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t ts_c
     if (n <= 0 || W <= 0 || inclusive || o.inclusive || naggs > kSimpleMaxAggs) return 0;
     if (tsc->validity && tsc->null_count != 0) return 0;                      // (an interval column with nulls: extras.cpp interp_null_ts)
     const int64_t lim53 = 1ll << 53;
-    if (plan.first_ts < plan.s0 || plan.s0 < 0 || plan.last_ts >= lim53) return 0;   // rows below s0, the -1 sentinel window, float64(ts) inexact
+    if (plan.first_ts < plan.s0 || plan.last_ts >= lim53 || plan.s0 <= -lim53) return 0;   // rows below s0; float64(ts) inexact
+    // a window that starts at -1, the reference's "no first value" sentinel (interpolation.go:99-105): such a window never gets a synthetic row
+    if (plan.s0 <= -1 && (uint64_t)(-1 - plan.s0) % (uint64_t)plan.interval == 0 && (int64_t)((uint64_t)(-1 - plan.s0) / (uint64_t)plan.interval) < W) return 0;
     if (((uint64_t)plan.interval >> 32) != 0 || (uint64_t)plan.last_ts - (uint64_t)plan.s0 >= 0xFFFFFFF0ull || W >= 0xFFFFFFF0ll) return 0;
     if (n / W < 4 || n / W > 128) return 0;
     for (int i = 0; i < ncols; i++) {
@@ -1641,9 +1643,8 @@ static int fused_try(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t ts_c
             const int k = aggs[i].kind;
             if ((k >= BOWGPU_AGG_INTEGRAL_STEP && k <= BOWGPU_AGG_WAVG_LINEAR) || k == BOWGPU_AGG_MODE) return 0;
             if (!kind_reads_values(k)) continue;
-            if (nullable[aggs[i].col] == 0) distinct++;
-            nullable[aggs[i].col]++;                                           // (an upper bound of job_build's count per pass)
-            if (nullable[aggs[i].col] > 4) return 0;
+            if (nullable[aggs[i].col] % 4 == 0) distinct++;                    // (job_build opens another pass of the column behind every fourth
+            nullable[aggs[i].col]++;                                           //  reducer that may yield nil: an upper bound of its count)
         }
         if (distinct > kMaxCols) return 0;
     }

@@ -31,18 +31,26 @@ constexpr int kTileF = 512;
 constexpr int kHaloF = 128;
 constexpr int kRowsF = kTileF + kHaloF;
 constexpr int kChunksF = kRowsF / 128;
-constexpr int kCapF = 150;          // heads per tile (+ look-ahead): windows of 4.3 rows and more on average; LDS exactly 6 KB
-constexpr uint32_t kSatF = 0xFFFFu;
+constexpr int kCapF = 208;          // heads per tile (+ look-ahead): windows of 3.1 rows and more on average; LDS exactly 8 KB
 constexpr int kAlignF = 16;
-constexpr uint32_t kRowMaskF = 0x3FFu, kExactBitF = 0x8000u;   // a head entry: local row | its row sits exactly on the window start << 15 | (wid - wid of the tile's first row) << 16
+#ifndef BOWGPU_FUSED_NT
+#define BOWGPU_FUSED_NT 1
+#endif
+constexpr bool kNtF = BOWGPU_FUSED_NT != 0;   // non-temporal loads of a tile's interior chunks (rolling_simple.hip); A/B: -DBOWGPU_FUSED_NT=0
 constexpr int kWalkWordsF = 64;     // a neighbour point outside the tile: at most this many validity words are searched (2048 rows)
 
+// The rows' times stay in LDS as 32-bit offsets from the first window start: a synthetic row needs the times of its two neighbour
+// points (linear.go:34), rows a lane other than the window's holds.  (Fetched from the column instead - two 8-byte gathers per window
+// after the tile's own loads - the kernel read 2.19 GB for 1.61 GB of rows at 1e8 rows and took 0.43 ms; profiles/r05_stdout_fused_ab.txt.)
+// A head entry is the head's local row alone: its window id and whether it sits exactly on the window's start are recomputed from
+// its staged time.  8 KB per wavefront: 20 per CU.
 struct FusedShared {
-    uint64_t val[swz_slots(kRowsF)];   // the staged column (agg_device.h swz: padded against bank conflicts)
+    uint64_t val[kRowsF];              // the staged column (not padded: the windows of a frame that wants interpolating are irregular)
+    uint32_t tsx[kRowsF];              // ts - s0 of every row of the tile
     uint32_t vbits[kRowsF / 32 + 2];   // validity words of the value column for this tile
-    uint32_t seg[kCapF + 2];
+    uint16_t seg[kCapF + 2];           // heads in row order: local row
 };
-static_assert(sizeof(FusedShared) <= 6144, "LDS of the fused kernel: 6 KB (26 wavefronts per CU)");
+static_assert(sizeof(FusedShared) <= 8192, "LDS of the fused kernel: 8 KB (20 wavefronts per CU)");
 
 __device__ __forceinline__ uint32_t mdiv32(uint32_t n, uint32_t m, uint32_t sh1, uint32_t sh2) {
     const uint32_t t = __umulhi(m, n);
@@ -130,7 +138,7 @@ __device__ __forceinline__ void walk_seeded(const uint64_t *val, int fv, int lv,
 template <int kNeed, bool kNulls, bool kMulti>
 __global__ __launch_bounds__(kWave, kMulti ? 5 : 6) void rolling_fused_kernel(const FusedParams fp, const int64_t ntiles, const int64_t tiles_per_xcd) {
     __shared__ FusedShared sh;
-    constexpr bool kSwzF = true;
+    constexpr bool kSwzF = false;
     const SimpleParams &p = fp.s;
     const int64_t b = blockIdx.x;
     const int64_t tile = (b & 7) * tiles_per_xcd + (b >> 3);  // XCD-contiguous tile runs (look-ahead rows hit the same L2)
@@ -149,7 +157,7 @@ __global__ __launch_bounds__(kWave, kMulti ? 5 : 6) void rolling_fused_kernel(co
             const ulonglong2 *q = reinterpret_cast<const ulonglong2 *>(src + base) + lane;
 #pragma unroll
             for (int j = 0; j < kChunksF; j++) {
-                const ulonglong2 x = (j > 0 && j < kChunksF - 1) ? load16_nt(q + j * 64) : q[j * 64];
+                const ulonglong2 x = (kNtF && j > 0 && j < kChunksF - 1) ? load16_nt(q + j * 64) : q[j * 64];
                 a[j] = x.x; bb[j] = x.y;
             }
         } else if (interior) {
@@ -166,12 +174,12 @@ __global__ __launch_bounds__(kWave, kMulti ? 5 : 6) void rolling_fused_kernel(co
         const ulonglong2 *qv = reinterpret_cast<const ulonglong2 *>(reinterpret_cast<const uint64_t *>(p.values[0]) + base) + lane;
 #pragma unroll
         for (int j = 0; j < kChunksF; j++) {
-            const ulonglong2 x = (j > 0 && j < kChunksF - 1) ? load16_nt(qt + j * 64) : qt[j * 64];
+            const ulonglong2 x = (kNtF && j > 0 && j < kChunksF - 1) ? load16_nt(qt + j * 64) : qt[j * 64];
             ta[j] = x.x; tb[j] = x.y;
         }
 #pragma unroll
         for (int j = 0; j < kChunksF; j++) {
-            const ulonglong2 x = (j > 0 && j < kChunksF - 1) ? load16_nt(qv + j * 64) : qv[j * 64];
+            const ulonglong2 x = (kNtF && j > 0 && j < kChunksF - 1) ? load16_nt(qv + j * 64) : qv[j * 64];
             va[j] = x.x; vb[j] = x.y;
         }
     } else {
@@ -194,14 +202,11 @@ __global__ __launch_bounds__(kWave, kMulti ? 5 : 6) void rolling_fused_kernel(co
     const int64_t left0 = base > 0 ? p.ts[base - 1] : INT64_MIN;
     const int64_t ws0 = p.s0;
     bool unsorted = false, sat = false;
-    const int64_t ts_first = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ta[0] >> 32)) << 32) |
-                                       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ta[0]));
     const uint32_t s0_lo = (uint32_t)ws0;
     const uint32_t ik = (uint32_t)p.interval;
 
-    // ---- window ids (32-bit, global: the host sends frames whose rows lie within 2^32 of s0), head flags with their
-    // "sits exactly on the window start" bit, compaction with a running scalar count
-    const uint32_t w_first = mdiv32((uint32_t)ts_first - s0_lo, p.m32, p.sh1, p.sh2);
+    // ---- window ids (32-bit, global: the host sends frames whose rows lie within 2^32 of s0), head flags, compaction with a running
+    // scalar count; every row's time goes to LDS as its offset from s0
     uint32_t left_w = base == 0 ? 0xFFFFFFFEu : mdiv32((uint32_t)left0 - s0_lo, p.m32, p.sh1, p.sh2);
     int64_t left_ts = left0;
     int nseg_total = 0, nseg_owned = 0;
@@ -220,15 +225,14 @@ __global__ __launch_bounds__(kWave, kMulti ? 5 : 6) void rolling_fused_kernel(co
         const uint32_t wprev = left32(wb, left_w);
         const bool ha = pa && (wa != wprev);
         const bool hb = pb && (wb != wa);
-        const uint32_t la = wa - w_first, lb = wb - w_first;
-        sat |= (ha && la >= kSatF) || (hb && lb >= kSatF);
         const unsigned long long ma = __ballot(ha), mb = __ballot(hb);
         int pos = nseg_total;
         pos += __builtin_amdgcn_mbcnt_hi((unsigned)(ma >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ma, 0));
         pos += __builtin_amdgcn_mbcnt_hi((unsigned)(mb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb, 0));
-        if (ha && pos < kCapF) sh.seg[pos] = (uint32_t)l | (ra == wa * ik ? kExactBitF : 0u) | (la << 16);
+        if (ha && pos < kCapF) sh.seg[pos] = (uint16_t)l;
         pos += ha ? 1 : 0;
-        if (hb && pos < kCapF) sh.seg[pos] = (uint32_t)(l + 1) | (rb == wb * ik ? kExactBitF : 0u) | (lb << 16);
+        if (hb && pos < kCapF) sh.seg[pos] = (uint16_t)(l + 1);
+        *reinterpret_cast<uint2 *>(&sh.tsx[l]) = make_uint2(ra, rb);   // (l is even: one 8-byte LDS write)
         nseg_total += __popcll(ma) + __popcll(mb);
         if (j == kChunksF - 2) nseg_owned = nseg_total;
         left_w = (uint32_t)__builtin_amdgcn_readlane((int)wb, 63);
@@ -250,23 +254,23 @@ __global__ __launch_bounds__(kWave, kMulti ? 5 : 6) void rolling_fused_kernel(co
     int q_start = 0, q_end = nseg_owned;
     {
         lds_order();
+        auto wid_at = [&](int q) -> uint32_t { return mdiv32(sh.tsx[sh.seg[q]], p.m32, p.sh1, p.sh2); };
         auto handover = [&](int qf, int qlim) -> int {
             if (qf >= qlim) return qf;
-            const uint32_t gf = w_first + (sh.seg[qf] >> 16);
+            const uint32_t gf = wid_at(qf);
             const uint32_t A = (gf + (kAlignF - 1)) & ~(uint32_t)(kAlignF - 1);
             if (A == gf) return qf;
             const int qi = qf + lane;
-            const bool below = lane < kAlignF && qi < qlim && (w_first + (sh.seg[qi < qlim ? qi : qf] >> 16)) < A;
+            const bool below = lane < kAlignF && qi < qlim && wid_at(qi < qlim ? qi : qf) < A;
             const int nb = __popcll(__ballot(below));
             return qf + nb < qlim ? qf + nb : qf;
         };
-        int n128 = 0;
+        int n128 = 0;   // heads inside this tile's first 128 rows (at most 128 of them: two list entries per lane)
         {
-            const int qa = lane, qb = lane + 64, qc = lane + 128;
-            const bool a = qa < nseg_total && (int)(sh.seg[qa < nseg_total ? qa : 0] & kRowMaskF) < 128;
-            const bool bq = qb < nseg_total && (int)(sh.seg[qb < nseg_total ? qb : 0] & kRowMaskF) < 128;
-            const bool cq = qc < nseg_total && (int)(sh.seg[qc < nseg_total ? qc : 0] & kRowMaskF) < 128;
-            n128 = __popcll(__ballot(a)) + __popcll(__ballot(bq)) + __popcll(__ballot(cq));
+            const int qa = lane, qb = lane + 64;
+            const bool a = qa < nseg_total && (int)sh.seg[qa < nseg_total ? qa : 0] < 128;
+            const bool bq = qb < nseg_total && (int)sh.seg[qb < nseg_total ? qb : 0] < 128;
+            n128 = __popcll(__ballot(a)) + __popcll(__ballot(bq));
         }
         if (tile > 0) q_start = handover(0, n128);
         q_end = handover(nseg_owned, nseg_total);
@@ -348,8 +352,19 @@ __global__ __launch_bounds__(kWave, kMulti ? 5 : 6) void rolling_fused_kernel(co
                     nrow = nr >= 0 ? base + nr : next_valid_bounded(cbits, p.vbit0[c], n, base + nloc, &gave_up);
                 }
             }
-            if (prow >= 0) { pp.has = 1; pp.t = p.ts[prow]; pp.bits = src[prow]; }
-            if (nrow >= 0) { np.has = 1; np.t = p.ts[nrow]; np.bits = src[nrow]; }
+            // the points themselves: time and (Float64) value out of the staged tile when the row lies in it; an Int64 column hands its own
+            // bits on (linear.go reads float64(v), StepPrevious copies the Int64: synth_value_pt converts)
+            auto point = [&](int64_t row, NbPoint &q) {
+                if (row < 0) return;
+                q.has = 1;
+                const int64_t loc = row - base;
+                const bool in_tile = loc >= 0 && loc < nloc;
+                q.t = in_tile ? ws0 + (int64_t)(uint64_t)sh.tsx[in_tile ? (int)loc : 0] : p.ts[row];
+                if (!cint && in_tile) q.bits = sh.val[swz<kSwzF>((int)loc)];
+                else q.bits = src[row];
+            };
+            point(prow, pp);
+            point(nrow, np);
         };
 
         // a nullable column whose outputs want sums AND extrema is walked twice (rolling_simple.hip): phase 1 with +0.0 in the null rows,
@@ -370,15 +385,15 @@ __global__ __launch_bounds__(kWave, kMulti ? 5 : 6) void rolling_fused_kernel(co
             const bool do_mm = (kNeed & 1) && phase != 1;
 
     for (int q = q_start + lane; q < q_end; q += kWave) {
-        const uint32_t e0 = sh.seg[q], e1 = sh.seg[q + 1];
-        const int r0 = (int)(e0 & kRowMaskF);
-        const bool exact = (e0 & kExactBitF) != 0;
-        const uint32_t wid = w_first + (e0 >> 16);
+        const int r0 = (int)sh.seg[q];
+        const uint32_t t0x = sh.tsx[r0];
+        const uint32_t wid = mdiv32(t0x, p.m32, p.sh1, p.sh2);
+        const bool exact = t0x == wid * ik;     // the window's first row sits on its start: no synthetic row (interpolation.go:108-116)
         int r1;
         uint32_t next_wid;
         if (q + 1 < nseg_total) {
-            r1 = (int)(e1 & kRowMaskF);
-            next_wid = w_first + (e1 >> 16);
+            r1 = (int)sh.seg[q + 1];
+            next_wid = mdiv32(sh.tsx[r1], p.m32, p.sh1, p.sh2);
         } else if (reaches_end) {
             r1 = nloc;
             next_wid = W32;

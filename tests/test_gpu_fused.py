@@ -128,15 +128,15 @@ def test_fused_declines_what_it_cannot_describe_and_the_answer_stays_the_same():
     ip = [{"kind": "WindowStart", "col": 0}, {"kind": "Linear", "col": 1}]
     aggs = [("WindowStart", 0), ("ArithmeticMean", 1), ("Min", 1), ("Count", 1)]
     # a run of 5000 nulls: a neighbour point further away than the bounded search looks
-    ts = np.arange(n, dtype=np.int64) * 3
+    ts = np.arange(n, dtype=np.int64) * 3 + 1     # (no row sits on a window start: every window gets a synthetic row)
     v, valid = _vals(rng, n, "f64", 0.2)
     valid[40_000:45_000] = False
     run_fused(ts, [(v, valid)], 60, ip, aggs, expect="two-call")
     valid[40_000:45_000] = True
     run_fused(ts, [(v, valid)], 60, ip, aggs, expect="fused")
-    # one window of 300 rows among windows of 20
+    # one window of 700 rows among windows of 20 (longer than any tile holds; a window of up to 128 rows always fits one)
     ts2 = ts.copy()
-    ts2[50_000:50_300] = ts2[50_000]
+    ts2[50_000:50_700] = ts2[50_000]
     run_fused(np.sort(ts2), [(v, valid)], 60, ip, aggs, expect="two-call")
     # a stretch of windows of one row each: more heads than a tile's list holds
     ts3 = ts.copy()
