@@ -564,7 +564,7 @@ def _interps(interps):
     return arr
 
 
-def rolling_interpolate_aggregate(cols, ts_col, interval, interps, aggs, offset=0, inclusive=False, out_residency=HOST, outs=None):
+def rolling_interpolate_aggregate(cols, ts_col, interval, interps, aggs, offset=0, inclusive=False, out_residency=HOST, outs=None, strict_order=False):
     """r.Interpolate(interps...).Aggregate(aggs...) without the interpolated frame (bowgpu_rolling_interpolate_aggregate): returns
     (list[OutColumn], AggInfo) as rolling_aggregate does.  The window grid of the interpolated frame is the input's, so the outputs hold
     plan_windows(...)[1] slots."""
@@ -574,7 +574,7 @@ def rolling_interpolate_aggregate(cols, ts_col, interval, interps, aggs, offset=
     oarr = (Out * max(len(aggs), 1))()
     for i, o in enumerate(outs):
         oarr[i] = o.c()
-    opts = Options(offset, int(bool(inclusive)), 0)
+    opts = Options(offset, int(bool(inclusive)), int(bool(strict_order)))
     info = AggInfo()
     check(lib().bowgpu_rolling_interpolate_aggregate(_cols(cols), len(cols), ts_col, C.c_int64(interval), C.byref(opts),
                                                      _interps(interps), len(interps), _aggs(aggs), len(aggs), oarr, C.byref(info)))

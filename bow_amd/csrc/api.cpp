@@ -736,7 +736,7 @@ static void pending_drop(Ctx *c);   // a pass put in flight by bowgpu_shard_pass
 
 static int job_build(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t ts_col, const Plan &plan, int inclusive,
                      const bowgpu_agg *aggs, int32_t naggs, bowgpu_out *outs, int64_t wid_base, int64_t W,
-                     bool holds_row0, AggJob *job) {
+                     bool holds_row0, AggJob *job, int nullable_per_pass = 4) {
     pending_drop(c);
     const bowgpu_col *tsc = &cols[ts_col];
     const int64_t n = tsc->length;
@@ -797,7 +797,7 @@ static int job_build(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t ts_c
         const int col = aggs[i].col;
         int s = slot_of[col];
         const bool nullable = !kind_never_nil(aggs[i].kind);
-        if (s >= 0 && nullable && nullable_in_slot[s] >= 4) s = -1;  // at most 4 nullable reducers per pass: open another slot
+        if (s >= 0 && nullable && nullable_in_slot[s] >= nullable_per_pass) s = -1;  // at most 4 nullable reducers per pass of the general kernel: open another slot (rolling_fused.hip has no such limit)
         if (s < 0) {
             if (P.ncols >= kMaxCols) return fail(BOWGPU_ERR_UNSUPPORTED, "at most %d value columns per call", kMaxCols);
             s = P.ncols++;
@@ -1637,19 +1637,17 @@ static int fused_try(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t ts_c
     }
     if (interps[ts_col].kind != BOWGPU_INTERP_WINDOW_START) return 0;           // anything else does not keep the window grid
     {
-        std::vector<int> nullable(ncols, 0);
+        std::vector<int> used(ncols, 0);
         int distinct = 0;
         for (int i = 0; i < naggs; i++) {
             const int k = aggs[i].kind;
             if ((k >= BOWGPU_AGG_INTEGRAL_STEP && k <= BOWGPU_AGG_WAVG_LINEAR) || k == BOWGPU_AGG_MODE) return 0;
-            if (!kind_reads_values(k)) continue;
-            if (nullable[aggs[i].col] % 4 == 0) distinct++;                    // (job_build opens another pass of the column behind every fourth
-            nullable[aggs[i].col]++;                                           //  reducer that may yield nil: an upper bound of its count)
+            if (kind_reads_values(k) && !used[aggs[i].col]++) distinct++;
         }
         if (distinct > kMaxCols) return 0;
     }
     AggJob job;
-    BG_TRY(job_build(c, cols, ncols, ts_col, plan, 0, aggs, naggs, outs, 0, W, true, &job));
+    BG_TRY(job_build(c, cols, ncols, ts_col, plan, 0, aggs, naggs, outs, 0, W, true, &job, kMaxAggs));   // (one pass per column whatever its reducers)
     AggParams &P = job.P;
     int need = 0;
     bool is_int = false, has_nulls = false, wide = false;

@@ -132,6 +132,23 @@ __device__ __forceinline__ void walk_seeded(const uint64_t *val, int fv, int lv,
     }
 }
 
+// ... and for a nullable column staged with +0.0 in its null rows whose outputs want sums AND extrema, in a tile of many short windows:
+// one walk, the extrema under the row's validity bit (agg_device.h walk_values_pred; minmax.go:16-28 as written, so a NaN seed stays)
+template <bool kSwz>
+__device__ __forceinline__ void walk_pred_seeded(const uint64_t *val, const uint32_t *vbits, int fv, int lv, bool seeded, double xs, double &sum, double &mn, double &mx) {
+    const double seed = seeded ? xs : __longlong_as_double((long long)val[swz<kSwz>(fv)]);
+    sum = seeded ? 0.0 + xs : 0.0;
+    mn = seed; mx = seed;
+    for (int r = fv; r <= lv; r++) {
+        const double x = __longlong_as_double((long long)val[swz<kSwz>(r)]);
+        sum += x;
+        if ((vbits[r >> 5] >> (r & 31)) & 1u) {
+            if (x < mn) mn = x;
+            if (x > mx) mx = x;
+        }
+    }
+}
+
 }  // namespace
 
 // kNeed: bit0 min/max wanted, bit1 first/last wanted; kNulls: some value column has nulls; kMulti: more than one value column
@@ -367,9 +384,11 @@ __global__ __launch_bounds__(kWave, kMulti ? 5 : 6) void rolling_fused_kernel(co
             point(nrow, np);
         };
 
-        // a nullable column whose outputs want sums AND extrema is walked twice (rolling_simple.hip): phase 1 with +0.0 in the null rows,
-        // then the null rows are overwritten with NaN and phase 2 walks the extrema.  Every other shape: phase 0, one walk.
-        const bool two_phase = kNulls && (kNeed & 1) && need_sum;
+        // a nullable column whose outputs want sums AND extrema is walked twice in tiles of few long windows (rolling_simple.hip): phase 1
+        // with +0.0 in the null rows, then the null rows are overwritten with NaN and phase 2 walks the extrema; in tiles of many short
+        // windows once, the extrema under the validity bit.  Every other shape: phase 0, one walk.
+        const bool two_phase = kNulls && (kNeed & 1) && need_sum && nseg_total <= kTwoWalksMaxHeads;
+        const bool pred_walk = kNulls && (kNeed & 1) && need_sum && !two_phase;   // one walk, extrema under the validity bit
         for (int phase = two_phase ? 1 : 0; phase <= (two_phase ? 2 : 0); phase++) {
             if (phase == 2) {
                 lds_order();
@@ -422,7 +441,8 @@ __global__ __launch_bounds__(kWave, kMulti ? 5 : 6) void rolling_fused_kernel(co
         double sum = 0.0, mn = 0.0, mx = 0.0;
         uint64_t first_raw = 0, last_raw = 0;
         if (has_value) {
-            walk_seeded<kSwzF, !kMulti>(sh.val, fv, lv, do_sum, do_mm, exact_mm, sv != 0, xs, sum, mn, mx);
+            if (kNulls && pred_walk) walk_pred_seeded<kSwzF>(sh.val, sh.vbits, fv, lv, sv != 0, xs, sum, mn, mx);
+            else walk_seeded<kSwzF, !kMulti>(sh.val, fv, lv, do_sum, do_mm, exact_mm, sv != 0, xs, sum, mn, mx);
             if (kNeed & 2) {
                 if (own) {
                     first_raw = sh.val[swz<kSwzF>(fv)];

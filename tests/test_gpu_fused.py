@@ -24,8 +24,10 @@ def _cols(ts, cols_np):
     return ccols, ocols
 
 
-def run_fused(ts, cols_np, interval, interps, aggs, offset=0, inclusive=False, device=False, expect=None):
-    """expect: "fused" / "two-call" - which form the plain call must have taken (None: either)"""
+def run_fused(ts, cols_np, interval, interps, aggs, offset=0, inclusive=False, device=False, expect=None, strict_order=False):
+    """expect: "fused" / "two-call" - which form the plain call must have taken (None: either).  strict_order: for frames with a window
+    longer than a tile holds - the two-call form then walks it in row order too (bowgpu_options.strict_order), so every comparison stays
+    bit for bit (without it such a window's float sums carry the stated order-free tolerance: bowgpu_agg_info.long_windows)"""
     ccols, ocols = _cols(ts, cols_np)
     if device:
         ccols = [c.to_device() for c in ccols]
@@ -35,16 +37,18 @@ def run_fused(ts, cols_np, interval, interps, aggs, offset=0, inclusive=False, d
     label = "n=%d I=%d off=%d %s" % (len(ts), interval, offset, [a[0] for a in aggs])
     # 1. the one call
     capi.rolling_aggregate(ccols[:1], 0, interval, [("WindowStart", 0)], offset=offset)   # (something else as the thread's last kernel)
-    got, info = capi.rolling_interpolate_aggregate(ccols, 0, interval, interps, aggs, offset=offset, inclusive=inclusive, out_residency=res)
+    got, info = capi.rolling_interpolate_aggregate(ccols, 0, interval, interps, aggs, offset=offset, inclusive=inclusive, out_residency=res,
+                                                   strict_order=strict_order)
     took = "fused" if capi.last_kernel_name() == "rolling_fused_kernel" else "two-call"
     if expect is not None:
         assert took == expect, (label, took)
-    assert info.new_interval_col == nic and info.num_windows == want[0].length
+    assert info.new_interval_col == nic and info.num_windows == want[0].length and info.long_windows == 0
     for (k, _c, *_f), g, w in zip(aggs, got, want):
         compare("one call (%s) %s %s" % (took, k, label), g, w)
     # 2. the same entry point, two calls through device temporaries
     with capi.route(capi.ROUTE_NO_FUSED):
-        got2, _ = capi.rolling_interpolate_aggregate(ccols, 0, interval, interps, aggs, offset=offset, inclusive=inclusive, out_residency=res)
+        got2, _ = capi.rolling_interpolate_aggregate(ccols, 0, interval, interps, aggs, offset=offset, inclusive=inclusive, out_residency=res,
+                                                     strict_order=strict_order)
         assert capi.last_kernel_name() != "rolling_fused_kernel"
     for (k, _c, *_f), g, w in zip(aggs, got2, want):
         compare("two calls behind the entry point %s %s" % (k, label), g, w)
@@ -52,7 +56,7 @@ def run_fused(ts, cols_np, interval, interps, aggs, offset=0, inclusive=False, d
     filled = capi.rolling_interpolate(ccols, 0, interval, interps, offset=offset, inclusive=inclusive, out_residency=capi.DEVICE)
     fcols = [capi.Column(f.values, f.validity, f.type, 0, f.length, -1) for f in filled]   # (device buffers of the first call's outputs)
     if fcols[0].length > 0:
-        got3, _ = capi.rolling_aggregate(fcols, 0, interval, aggs, offset=offset, inclusive=inclusive, out_residency=res)
+        got3, _ = capi.rolling_aggregate(fcols, 0, interval, aggs, offset=offset, inclusive=inclusive, out_residency=res, strict_order=strict_order)
         for (k, _c, *_f), g, w in zip(aggs, got3, want):
             compare("Interpolate then Aggregate %s %s" % (k, label), g, w)
     return got, want, took
@@ -137,7 +141,7 @@ def test_fused_declines_what_it_cannot_describe_and_the_answer_stays_the_same():
     # one window of 700 rows among windows of 20 (longer than any tile holds; a window of up to 128 rows always fits one)
     ts2 = ts.copy()
     ts2[50_000:50_700] = ts2[50_000]
-    run_fused(np.sort(ts2), [(v, valid)], 60, ip, aggs, expect="two-call")
+    run_fused(np.sort(ts2), [(v, valid)], 60, ip, aggs, expect="two-call", strict_order=True)
     # a stretch of windows of one row each: more heads than a tile's list holds
     ts3 = ts.copy()
     ts3[60_000:] += np.arange(n - 60_000) * 1000
@@ -146,7 +150,24 @@ def test_fused_declines_what_it_cannot_describe_and_the_answer_stays_the_same():
     run_fused(ts, [(v, valid)], 60, ip, [("WindowStart", 0), ("WeightedAverageStep", 1)], expect="two-call")
     run_fused(ts, [(v, valid)], 60, ip, [("WindowStart", 0), ("IntegralTrapezoid", 1), ("ArithmeticMean", 1)], expect="two-call")
     run_fused(ts, [(v, valid)], 60, ip, aggs, inclusive=True, expect="two-call")
-    run_fused(ts - 777, [(v, valid)], 60, ip, aggs, expect="two-call")
+    # negative timestamps: fine as such (the first window start lies below the first row) ...
+    run_fused(ts - 777, [(v, valid)], 60, ip, aggs, expect="fused")
+    # ... but not with a window that starts at -1, the reference's "no first value" sentinel (interpolation.go:99-105: that window never
+    # gets a synthetic row)
+    run_fused(ts - 62, [(v, valid)], 60, ip, aggs, offset=59, expect="two-call")     # (windows start at -61, -1, 59, ...)
+    # rows below the first window start (Go's truncating division: rolling.go:96-99): the synthetic row of window 0 lands IN FRONT of
+    # them (interpolation.go:160), so the interpolated interval column is not ascending - the Aggregate step declines it, in one call as
+    # in two (the caller keeps the reference's own path for such a frame)
+    ccols, _o = _cols(ts - 51, [(v, valid)])
+    for mask in (0, capi.ROUTE_NO_FUSED):
+        with capi.route(mask), pytest.raises(capi.BowGpuError) as e:
+            capi.rolling_interpolate_aggregate(ccols, 0, 60, ip, aggs, offset=50)
+        assert e.value.code == -14
+    filled = capi.rolling_interpolate(ccols, 0, 60, ip, offset=50)
+    assert filled[0].to_list()[:2] == [-10, -50]
+    with pytest.raises(capi.BowGpuError) as e:
+        capi.rolling_aggregate([capi.Column(f.host_arrays()[0], f.host_arrays()[1], f.type, 0, f.length, -1) for f in filled], 0, 60, aggs, offset=50)
+    assert e.value.code == -14
     run_fused(ts, [(v, valid)], 60, [{"kind": "WindowStart", "col": 0}, {"kind": "Const", "col": 1, "const": 9.9}], aggs, expect="two-call")
     # nanosecond epochs: wider than 2^32 from the first window
     run_fused(ts * 1_000_000 + 1_700_000_000_000_000_000, [(v, valid)], 60_000_000, ip, aggs, expect="two-call")
