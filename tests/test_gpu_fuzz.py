@@ -193,6 +193,68 @@ def test_fuzz_interpolate_and_fills(seed):
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("BOW_FUZZ_SEEDS", "64")) // 2))
+def test_fuzz_interpolate_then_aggregate_as_one_call(seed):
+    """bowgpu_rolling_interpolate_aggregate against oracle interpolate -> oracle aggregate: frames inside the fused kernel's domain
+    (windows of a few to ~100 rows, ascending timestamps, any null density, one or two value columns of either type, PrevRow, Factor
+    chains) and frames anywhere in the C ABI's (which take the two-call form); every case also through the two-call form of the
+    same entry point (capi.ROUTE_NO_FUSED).  A frame whose interpolated interval column comes out unsorted (rows below the first
+    window start) must be declined by both forms alike."""
+    rng = np.random.default_rng(7000 + seed)
+    fused = 0
+    for case in range(24):
+        in_domain = rng.random() < 0.7
+        if in_domain:
+            n = int(rng.integers(600, 4000))
+            ts = np.cumsum(rng.integers(0, int(rng.integers(2, 30)), n)).astype(np.int64) + int(rng.integers(-3000, 3000))
+            if rng.random() < 0.3:
+                ts[n // 2:] += int(rng.integers(1000, 200_000))     # a run of empty windows
+            span = max(int(ts[-1] - ts[0]), 1)
+            interval = max(1, int(span / (n / float(rng.integers(5, 90)))))
+        else:
+            n = int(rng.integers(1, 500))
+            ts = rand_ts(rng, n)
+            interval = int([1, 2, 5, 10, 64, 100, 1000][int(rng.integers(0, 7))])
+        offset = int(rng.integers(-2 * interval, 2 * interval + 1))
+        ncol = 1 + int(rng.random() < 0.4)
+        ccols, ocols = [capi.Column(ts, None, capi.INT64)], [orc.Column(ts, None, orc.INT64)]
+        ip = [{"kind": "WindowStart", "col": 0}]
+        for j in range(ncol):
+            v, bm, typ, off = rand_col(rng, n, 0)
+            if bm is not None and n > 600 and not np.unpackbits(bm, bitorder="little")[:n].any():
+                bm = None      # (an all-null column of thousands of rows: the oracle's neighbour walks are quadratic)
+            ccols.append(capi.Column(v, bm, typ, 0, n, -1 if bm is not None else 0))
+            ocols.append(orc.Column(v, bm, typ, offset=0, length=n))
+            ip.append({"kind": ["Linear", "StepPrevious", "None"][int(rng.integers(0, 3))], "col": 1 + j})
+            if rng.random() < 0.3:
+                ip[-1]["prev"] = (float(ts[0] - 3), True, 42.5, True, 42)
+        kinds = list(rng.choice(ALL_AGGS[1:], size=int(rng.integers(1, 7))))
+        aggs = [("WindowStart", 0)] + [(str(k), int(rng.integers(0 if k in ("Count", "NumRows") else 1, ncol + 1))) for k in kinds]
+        if rng.random() < 0.3:
+            i = int(rng.integers(1, len(aggs)))
+            aggs[i] = aggs[i] + ([float(rng.choice([2.0, -1.0, 0.5, 1e3]))],)
+        label = "seed=%d case=%d n=%d I=%d off=%d %s %s" % (seed, case, n, interval, offset, [a[0] for a in aggs], [i_["kind"] for i_ in ip])
+        res = {}
+        for form, mask in (("one call", 0), ("two-call form", capi.ROUTE_NO_FUSED)):
+            with capi.route(mask):
+                try:
+                    res[form] = capi.rolling_interpolate_aggregate(ccols, 0, interval, ip, aggs, offset=offset, strict_order=True)
+                    if mask == 0:
+                        fused += capi.last_kernel_name() == "rolling_fused_kernel"
+                except capi.BowGpuError as e:
+                    res[form] = e.code
+        if isinstance(res["one call"], int) or isinstance(res["two-call form"], int):
+            assert res["one call"] == res["two-call form"] == -14, (label, res)   # the interpolated interval column is not ascending
+            continue
+        mid = orc.interpolate(ocols, 0, interval, ip, offset=offset)
+        want, nic = orc.aggregate(mid, 0, interval, aggs, offset=offset)
+        for form, (outs, info) in res.items():
+            assert info.new_interval_col == nic and info.long_windows == 0, label
+            for a, g, w in zip(aggs, outs, want):
+                compare("%s %s %s" % (label, form, a[0]), g, w)
+    assert fused >= 8, fused       # (most frames of the first kind take the fused kernel)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BOW_FUZZ_SEEDS", "64")) // 2))
 def test_fuzz_sharded(seed):
     """random row-range splits (empty shards, one-row shards, shards smaller than a window) through the real protocol of
     bow_amd/sharded.py on simulated ranks; the stitched result must equal the oracle on the whole frame"""
