@@ -504,10 +504,21 @@ class Rolling {
     std::vector<uint8_t> isIncl;
     int64_t s0 = 0;
 
-    std::pair<int, Error> NumWindows() const { return {numWindows, err}; }
-    std::pair<BowPtr, Error> Bow() const { return {bow, err}; }
+    // A Rolling that Interpolate returned and whose interpolated Bow nobody has asked for yet (the Go shim: rolling/gpu_lazy.go,
+    // patches/0006).  Aggregate on it is ONE call to the library (bowgpu_rolling_interpolate_aggregate); every other use first makes
+    // the Rolling the reference's Interpolate returns (interpolation.go:57-68) and then IS that Rolling.
+    struct Lazy {
+        std::shared_ptr<const Rolling> base;   // the Rolling Interpolate was called on
+        std::vector<ColInterpolation> interps; // validated: every colIndex is set
+        int newIntervalCol = -1;
+    };
+    std::shared_ptr<Lazy> lazy;
+
+    std::pair<int, Error> NumWindows() const { materialise(); return {numWindows, err}; }
+    std::pair<BowPtr, Error> Bow() const { materialise(); return {bow, err}; }
 
     Error loadBounds() {
+        materialise();
         if (boundsReady) return Error();
         firstIndex.assign((size_t)numWindows + 1, 0);
         sliceBegin = firstIndex; sliceEnd = firstIndex;
@@ -545,6 +556,17 @@ class Rolling {
     RollingPtr Interpolate(std::vector<ColInterpolation> interps) const;
 
   private:
+    RollingPtr interpolated(const std::vector<ColInterpolation> &interps, int newIntervalCol) const;   // the tail of Interpolate (interpolation.go:57-68)
+    RollingPtr interpolateAggregateGPU(const std::vector<ColAggregation> &aggrs) const;                // nullptr: make the two steps
+    std::vector<bowgpu_interp> describeInterps(const std::vector<ColInterpolation> &interps, bool *all_builtin) const;
+    void materialise() const {
+        if (!lazy) return;
+        Rolling *self = const_cast<Rolling *>(this);
+        std::shared_ptr<Lazy> l = self->lazy;
+        self->lazy = nullptr;
+        RollingPtr real = l->base->interpolated(l->interps, l->newIntervalCol);
+        *self = *real;
+    }
     RollingPtr withError(const Error &e) const {
         auto r = std::make_shared<Rolling>(*this);
         r->err = e;
@@ -582,6 +604,10 @@ inline std::pair<RollingPtr, Error> IntervalRolling(BowPtr b, const std::string 
 
 // ----------------------------------------------------------------------------- Aggregate
 inline RollingPtr Rolling::Aggregate(const std::vector<ColAggregation> &aggrs) const {
+    if (lazy) {   // r.Interpolate(...).Aggregate(...): both steps in one call to the library when it takes them
+        if (RollingPtr r = interpolateAggregateGPU(aggrs)) return r;
+        materialise();
+    }
     if (err) return std::make_shared<Rolling>(*this);  // aggregation.go:124-126
     // indexedAggregations + validateAggregation: aggregation.go:147-188
     auto fail = [&](const std::string &prefix, const Error &e) { return withError(Wrap(prefix, e)); };
@@ -722,6 +748,7 @@ inline RollingPtr Rolling::Aggregate(const std::vector<ColAggregation> &aggrs) c
 
 // ----------------------------------------------------------------------------- Interpolate
 inline RollingPtr Rolling::Interpolate(std::vector<ColInterpolation> interps) const {
+    materialise();
     if (err) return std::make_shared<Rolling>(*this);  // interpolation.go:31-33
     if (interps.empty()) return withError(Errorf("at least one column interpolation is required"));
     int newIntervalCol = -1;
@@ -743,10 +770,26 @@ inline RollingPtr Rolling::Interpolate(std::vector<ColInterpolation> interps) co
     }
     if (newIntervalCol == -1) return withError(Errorf("must keep interval column '" + bow->ColumnName(intervalColIndex) + "'"));
 
+    // every interpolator a built-in, a Rolling nobody has stepped, a Bow with windows: the interpolated Bow is made when first asked for
+    bool all_builtin = true;
+    for (const auto &ip : interps) all_builtin = all_builtin && ip.gpuKind >= 0;
+    if (all_builtin && currWindowIndex == 0 && numWindows > 0) {
+        materialise();
+        auto r = std::make_shared<Rolling>(*this);
+        r->lazy = std::make_shared<Lazy>();
+        r->lazy->base = std::make_shared<const Rolling>(*this);
+        r->lazy->interps = interps;
+        r->lazy->newIntervalCol = newIntervalCol;
+        return r;
+    }
+    return interpolated(interps, newIntervalCol);
+}
+
+inline std::vector<bowgpu_interp> Rolling::describeInterps(const std::vector<ColInterpolation> &interps, bool *all_builtin) const {
     std::vector<bowgpu_interp> gi;
+    *all_builtin = true;
     for (const auto &ip : interps) {
-        if (ip.gpuKind < 0)
-            return withError(Wrap("intervalRolling.interpolateWindows", Errorf("custom ColInterpolation closures are outside the device path")));
+        if (ip.gpuKind < 0) { *all_builtin = false; return gi; }
         bowgpu_interp g;
         memset(&g, 0, sizeof g);
         g.kind = ip.gpuKind; g.col = ip.colIndex; g.const_value = ip.constValue;
@@ -759,6 +802,15 @@ inline RollingPtr Rolling::Interpolate(std::vector<ColInterpolation> interps) co
         }
         gi.push_back(g);
     }
+    return gi;
+}
+
+// interpolateWindows + newIntervalRolling on the result: interpolation.go:57-68, :98-161
+inline RollingPtr Rolling::interpolated(const std::vector<ColInterpolation> &interps, int newIntervalCol) const {
+    bool all_builtin = true;
+    std::vector<bowgpu_interp> gi = describeInterps(interps, &all_builtin);
+    if (!all_builtin)
+        return withError(Wrap("intervalRolling.interpolateWindows", Errorf("custom ColInterpolation closures are outside the device path")));
     std::vector<bowgpu_col> cols;
     for (int i = 0; i < bow->NumCols(); i++) cols.push_back(bow->ArrowCol(i));
     bowgpu_options o = {options.Offset, options.Inclusive ? 1 : 0, 0};
@@ -779,6 +831,62 @@ inline RollingPtr Rolling::Interpolate(std::vector<ColInterpolation> interps) co
     if (e) return withError(Wrap("intervalRolling.interpolateWindows", e));
     auto [newR, e2] = newIntervalRolling(b, newIntervalCol, interval, options);  // interpolation.go:63
     if (e2) return withError(Wrap("newIntervalRolling", e2));
+    return newR;
+}
+
+// Interpolate(...).Aggregate(...) as one call (Go shim: interpolateAggregateGPU in rolling/gpu_cgo.go).  Mirrors Aggregate
+// (aggregation.go:123-145) on the interpolated Rolling, whose Bow has the input's columns and types: indexedAggregations, the call,
+// newIntervalRolling on the result.  nullptr = anything that is not a plain success: the caller makes the reference's two steps, which
+// word every error.
+inline RollingPtr Rolling::interpolateAggregateGPU(const std::vector<ColAggregation> &aggrs) const {
+    const Rolling &b0 = *lazy->base;
+    const std::vector<ColInterpolation> &interps = lazy->interps;
+    if ((int)interps.size() != b0.bow->NumCols() || aggrs.empty()) return nullptr;
+    for (size_t i = 0; i < interps.size(); i++)
+        if (interps[i].colIndex != (int)i) return nullptr;
+    Options opts = b0.options;
+    int newIntervalCol = -1;
+    std::vector<bowgpu_agg> ga;
+    for (size_t i = 0; i < aggrs.size(); i++) {
+        if (aggrs[i].InputName().empty()) return nullptr;
+        auto [readIndex, e] = b0.bow->ColumnIndex(aggrs[i].InputName());
+        if (e) return nullptr;
+        aggrs[i].SetInputIndex(readIndex);
+        if (aggrs[i].NeedInclusiveWindow()) opts.Inclusive = true;
+        if (readIndex == b0.intervalColIndex) newIntervalCol = (int)i;
+        if (aggrs[i].GPUKind() < 0 || aggrs[i].Transformations().size() > BOWGPU_MAX_FACTORS) return nullptr;
+        bowgpu_agg g;
+        memset(&g, 0, sizeof g);
+        g.kind = aggrs[i].GPUKind(); g.col = readIndex;
+        for (const auto &t : aggrs[i].Transformations()) {
+            if (!t.is_factor) return nullptr;
+            g.factors[g.n_factors++] = t.factor;
+        }
+        ga.push_back(g);
+    }
+    if (newIntervalCol == -1) return nullptr;
+    bool all_builtin = true;
+    std::vector<bowgpu_interp> gi = b0.describeInterps(interps, &all_builtin);
+    if (!all_builtin) return nullptr;
+    std::vector<bowgpu_col> cols;
+    for (int i = 0; i < b0.bow->NumCols(); i++) cols.push_back(b0.bow->ArrowCol(i));
+    std::vector<detail::OutStore> stores(ga.size());
+    std::vector<bowgpu_out> outs;
+    for (auto &s : stores) outs.push_back(s.Make(b0.numWindows));   // the interpolated frame keeps the window grid; the library checks the capacity
+    bowgpu_options o = {opts.Offset, opts.Inclusive ? 1 : 0, 0};
+    bowgpu_agg_info info;
+    if (bowgpu_rolling_interpolate_aggregate(cols.data(), b0.bow->NumCols(), b0.intervalColIndex, b0.interval, &o, gi.data(), (int32_t)gi.size(),
+                                             ga.data(), (int32_t)ga.size(), outs.data(), &info) != 0)
+        return nullptr;
+    std::vector<Series> series;
+    for (size_t i = 0; i < ga.size(); i++) {
+        const std::string name = aggrs[i].OutputName().empty() ? b0.bow->ColumnName(aggrs[i].InputIndex()) : aggrs[i].OutputName();   // aggregation.go:230-234
+        series.push_back(stores[i].ToSeries(name, outs[i]));
+    }
+    auto [b, e] = NewBow(std::move(series));
+    if (e) return nullptr;
+    auto [newR, e2] = newIntervalRolling(b, newIntervalCol, b0.interval, opts);  // aggregation.go:139
+    if (e2) return b0.withError(Wrap("newIntervalRolling", e2));
     return newR;
 }
 

@@ -303,6 +303,32 @@ static void TestInterpolate() {
       auto [f, e] = r->Interpolate({ip::WindowStart(timeCol), ip::Linear(valueCol)})->Aggregate({ag::WindowStart(timeCol), ag::ArithmeticMean(valueCol)})->Bow();
       CHECK(!e);
       expectEqual(f, rows({{I(10), F(10.)}, {I(12), F(12.)}, {I(14), F(14.5)}, {I(16), F(16.5)}})); }
+    TEST("Interpolate then Aggregate: the lazy Rolling (one library call) equals the two steps");
+    { // 6000 irregular rows, a third of the values null: inside the fused kernel's domain (bowgpu_rolling_interpolate_aggregate)
+      std::vector<Value> t, v;
+      uint64_t x = 88172645463325252ull;
+      int64_t ts = 1000;
+      for (int i = 0; i < 6000; i++) {
+          x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+          ts += (int64_t)(x % 19);
+          t.push_back(I(ts));
+          if ((x >> 20) % 3 == 0) v.push_back(N); else v.push_back(F((double)((x >> 8) % 100000) / 7.0));
+      }
+      auto big = tv(t, v);
+      for (int64_t off : {0, 7}) {
+          auto [r, e0] = rl::IntervalRolling(big, timeCol, 100, {off, false, nullptr}); CHECK(!e0);
+          std::vector<rl::ColAggregation> aggs = {ag::WindowStart(timeCol), ag::ArithmeticMean(valueCol).RenameOutput("mean"), ag::Min(valueCol).RenameOutput("min"),
+                                                  ag::Count(valueCol).RenameOutput("n"), ag::First(valueCol).RenameOutput("first").SetTransformations({tr::Factor(0.5)})};
+          auto lazyR = r->Interpolate({ip::WindowStart(timeCol), ip::Linear(valueCol)});
+          CHECK(lazyR->lazy != nullptr);
+          auto [one, e1] = lazyR->Aggregate(aggs)->Bow(); CHECK(!e1);
+          CHECK_EQ_STR(std::string(bowgpu_last_kernel_name()), "rolling_fused_kernel");
+          auto eagerR = r->Interpolate({ip::WindowStart(timeCol), ip::Linear(valueCol)});
+          auto [mid, e2] = eagerR->Bow(); CHECK(!e2); CHECK(eagerR->lazy == nullptr && mid->NumRows() > 6000);   // asking for the Bow made it
+          auto [two, e3] = eagerR->Aggregate(aggs)->Bow(); CHECK(!e3);
+          expectEqual(one, two);
+      }
+    }
 }
 
 // ---- bowfill_test.go:11-26, :156-203, :332-380, :533-546
