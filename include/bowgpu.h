@@ -67,7 +67,8 @@ enum {
     BOWGPU_ERR_TS_NULLS = -13,       /* interval column has nulls AND the call has Mode or is sharded (or, Rolling.Interpolate on inclusive
                                         windows: a row on a window start has null timestamps behind it and then an EQUAL timestamp, or sits on
                                         -1): the device path declines (caller keeps the reference path); Aggregate and Interpolate are served
-                                        otherwise */
+                                        otherwise.  (Rolling.Interpolate over an interval column with nulls takes at most 16 columns per
+                                        call: more is BOWGPU_ERR_UNSUPPORTED.) */
     BOWGPU_ERR_TS_UNSORTED = -14,    /* interval column not ascending: device path declines */
     BOWGPU_ERR_OOM = -15
 };
@@ -158,7 +159,14 @@ typedef struct bowgpu_agg_info {
                                    reference in every digit of a result near zero (tests/tolerance.py states and asserts it, a
                                    cancelling window included).  The summation tree is fixed: equal inputs give equal bits.  Every
                                    other reducer, and every window when this is 0, is bit-exact.  bowgpu_options.strict_order
-                                   walks those windows in row order instead */
+                                   walks those windows in row order instead.
+                                   WHAT "BIT-EXACT" EXCLUDES, everywhere in this header: the sign and payload of a NaN that the
+                                   arithmetic itself GENERATES (inf - inf, 0 * inf, 0 / 0 in a Sum, a mean, an integral, an
+                                   interpolated value).  gfx950 produces the positive default NaN 0x7FF8000000000000 where x86 - the
+                                   reference's Go on amd64 - produces the negative "real indefinite" 0xFFF8000000000000; Go prints
+                                   both as NaN and no operation on this path tells them apart.  A NaN that comes FROM THE INPUT keeps
+                                   its bits (payload and sign) through First / Last / Min / Max / fills / interpolation copies, and a
+                                   NaN operand propagates through an addition as on x86 (quieted, payload kept). */
     double kernel_ms;           /* device time of the kernels of this call (HIP events on the library stream) */
 } bowgpu_agg_info;
 
@@ -241,7 +249,10 @@ int bowgpu_plan_windows_ex(const bowgpu_col *ts, int64_t interval, int64_t offse
  * reference's own path); value columns Float64 or Int64.  Nulls in the interval column (rolling.go:190-193: such a row neither
  * ends nor extends a window, yet lies inside its window's slice when rows of the same window surround it) are served for
  * exclusive and inclusive iterations alike (incl. rolling.go:214-218's `rowIndex - 1` when a null follows an inclusive row);
- * with Mode the call is BOWGPU_ERR_TS_NULLS. */
+ * with Mode the call is BOWGPU_ERR_TS_NULLS.  Cost of such a call: one extra pass over the interval column (16 bytes per row) that
+ * writes a forward-filled copy of it (8 bytes per row) and n / 8 bytes per rewritten validity class (up to three per value column on
+ * an inclusive iteration); every output goes through a device temporary (W * 8 bytes each) before it reaches the caller's buffer;
+ * NumRows is counted as Count over the rows that belong to a window and converted to float64 in a pass of its own. */
 int bowgpu_rolling_aggregate(const bowgpu_col *cols, int32_t ncols, int32_t ts_col,
                              int64_t interval, const bowgpu_options *opts,
                              const bowgpu_agg *aggs, int32_t naggs, bowgpu_out *outs,
@@ -302,9 +313,12 @@ typedef struct bowgpu_interp {
  * BOWGPU_ERR_ARG and the outputs are to be discarded.
  * _fill does not NEED a preceding _count: called on its own it sizes the outputs itself against bowgpu_out.length (in: capacity;
  * rows + windows always suffice; too small is BOWGPU_ERR_ARG naming the size).  Inclusive windows then take one pass over the rows
- * (n_out = n + W - [row 0 on its window's start] needs no count); exclusive windows make their own count pass first.  * An interval column WITH NULLS: the output is the windows' slices - rows that belong to no window vanish (rolling.go:190-193,
+ * (n_out = n + W - [row 0 on its window's start] needs no count); exclusive windows make their own count pass first.
+ * An interval column WITH NULLS: the output is the windows' slices - rows that belong to no window vanish (rolling.go:190-193,
  * :224-228), null-timestamp rows inside a slice are copied as they are; inclusive windows too (incl. rolling.go:214-218's
- * `rowIndex - 1` after a null), except for two shapes that are BOWGPU_ERR_TS_NULLS (see the error code).
+ * `rowIndex - 1` after a null), except for two shapes that are BOWGPU_ERR_TS_NULLS (see the error code).  At most 16 columns per
+ * call (BOWGPU_ERR_UNSUPPORTED beyond).  Cost: the call is made on the KEPT rows, compacted into device temporaries (8 bytes per row
+ * and column + n / 8 bytes per bitmap), and _count and _fill each run that compaction - well over twice an ordinary call.
  */
 int bowgpu_rolling_interpolate_count(const bowgpu_col *cols, int32_t ncols, int32_t ts_col,
                                      int64_t interval, const bowgpu_options *opts,
