@@ -82,6 +82,44 @@ __device__ __forceinline__ int64_t next_valid_ix(const uint32_t *bits, int64_t b
     return ix.next_after[g - ix.g0];
 }
 
+// ... and WITHOUT an index: at most kNbrNearWords words are looked at (2048 rows); *far is set when they ran out before a valid row
+// or the column's first / last row was found - the caller then raises a status word and the host repeats the call with the index
+// built (three small launches that the usual column - no run of thousands of nulls next to a window start - never needs).
+constexpr int kNbrNearWords = 64;
+__device__ inline int64_t prev_valid_near(const uint32_t *bits, int64_t bit0, int64_t n, int64_t row, bool *far) {
+    if (row < 0 || row >= n) return -1;
+    if (!bits) return row;
+    int64_t b = bit0 + row;
+    for (int k = 0; k < kNbrNearWords && b >= bit0; k++) {
+        const int64_t w = b >> 5;
+        const int sh = (int)(b & 31);
+        uint32_t x = bits[w];
+        x = sh == 31 ? x : (x & ((2u << sh) - 1u));
+        if (w == (bit0 >> 5)) x &= ~0u << (bit0 & 31);
+        if (x) return (w << 5) + (31 - __clz((int)x)) - bit0;
+        b = (w << 5) - 1;
+    }
+    if (b >= bit0) *far = true;
+    return -1;
+}
+__device__ inline int64_t next_valid_near(const uint32_t *bits, int64_t bit0, int64_t n, int64_t row, bool *far) {
+    if (row < 0 || row >= n) return -1;
+    if (!bits) return row;
+    int64_t b = bit0 + row;
+    const int64_t bend = bit0 + n;
+    for (int k = 0; k < kNbrNearWords && b < bend; k++) {
+        const int64_t w = b >> 5;
+        const uint32_t x = bits[w] & (~0u << (b & 31));
+        if (x) {
+            const int64_t r = (w << 5) + (__ffs((int)x) - 1) - bit0;
+            return r < n ? r : -1;
+        }
+        b = (w + 1) << 5;
+    }
+    if (b < bend) *far = true;
+    return -1;
+}
+
 // ---------------------------------------------------------------- wave-uniform bitmap access (fills, IsColSorted, Interpolate)
 // 128 validity bits of rows [row0, row0 + 128) in row order (w0 = rows 0..63); rows at or beyond n read as 0 (kFull: the
 // caller knows row0 + 128 <= n).  Every lane passes the same arguments and the bitmap is an input nobody writes during the

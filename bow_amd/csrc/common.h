@@ -435,6 +435,7 @@ void interp_magic32(int64_t interval, uint32_t *m, uint32_t *sh1, uint32_t *sh2)
 int launch_interp_count(Ctx *c, const int64_t *ts, int64_t n, const Plan &plan, int64_t kq, int has_left, int64_t left_ts,
                         int32_t *tile_exact, uint32_t *status);
 int launch_interp_tiles(Ctx *c, const InterpParams &p);
+bool interp_takes_wave3(const InterpParams &p);   // (with p.allow_wave2 set) - that kernel needs no neighbour index on its first attempt
 enum { kFillLinear = -1 };  // FillParams::method; >= 0: BOWGPU_FILL_PREVIOUS / NEXT / MEAN
 struct FillParams {
     const uint64_t *ref_values; const uint32_t *ref_vbits; int64_t ref_vbit0; int32_t ref_type;  // FillLinear only

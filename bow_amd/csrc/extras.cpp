@@ -384,7 +384,10 @@ static int interp_fill_impl(const bowgpu_col *cols, int32_t ncols, int32_t ts_co
     // The output positions depend on the interval column alone, so the columns go through the kernel kMaxCols at a time (a Bow
     // of any width: interpolation.go:98-161 loops over the interpolators).  Per batch: ONE launch zeroes the batch's bitmaps (and,
     // first batch, the status words), the kernel, ONE launch counts the valid bits and copies the bitmaps into the caller's buffers.
-    auto run_all = [&](int allow_wave2) -> int {
+    // (with_index: the neighbour index of each nullable column under Linear / StepPrevious - three small launches per column.
+    // interp_wave3_kernel finds a synthetic row's neighbour points by a bounded walk and says so when one lies further away
+    // (status[7]): the index is built for the workgroup kernel and for that repeat only.)
+    auto run_all = [&](int allow_wave2, bool with_index) -> int {
         P.allow_wave2 = allow_wave2;
         for (int b0 = 0; b0 < ncols; b0 += kMaxCols) {
             const int nb = ncols - b0 < kMaxCols ? ncols - b0 : kMaxCols;
@@ -405,7 +408,7 @@ static int interp_fill_impl(const bowgpu_col *cols, int32_t ncols, int32_t ts_co
                 ic.out_values = reinterpret_cast<uint64_t *>(douts[i].values);
                 ic.out_valid_words = reinterpret_cast<uint32_t *>(douts[i].validity);
                 if (edge && edge->next_valid[i]) { ic.next_valid = 1; ic.next_t = edge->next_t[i]; ic.next_v = edge->next_v[i]; }
-                if (dc.vbits && (ic.kind == BOWGPU_INTERP_LINEAR || ic.kind == BOWGPU_INTERP_STEP_PREVIOUS)) {
+                if (with_index && dc.vbits && (ic.kind == BOWGPU_INTERP_LINEAR || ic.kind == BOWGPU_INTERP_STEP_PREVIOUS)) {
                     void *ix;
                     BG_TRY(ctx_pool(c, kPoolInterp + 3 + j, nbr_index_bytes(n, dc.vbit0), &ix));  // (reused by the next batch: stream order)
                     BG_TRY(nbr_index_build(c, dc.vbits, dc.vbit0, n, ix, &ic.nbr));
@@ -424,7 +427,10 @@ static int interp_fill_impl(const bowgpu_col *cols, int32_t ncols, int32_t ts_co
         BG_HIP(hipStreamSynchronize(c->stream));
         return 0;
     };
-    BG_TRY(run_all(1));
+    P.allow_wave2 = 1;
+    const bool first_with_index = !interp_takes_wave3(P);
+    BG_TRY(run_all(1, first_with_index));
+    if (hstat[7] && !first_with_index && !hstat[0] && !hstat[6]) BG_TRY(run_all(1, true));   // a run of thousands of nulls next to a window start
     // An interval column out of order comes FIRST: a one-pass call derives its row count from the first and the last timestamp alone,
     // so on an unsorted column most trips also fail the "fits the counted range" test below - and the documented answer for such a
     // column is the decline (BOWGPU_ERR_TS_UNSORTED: the caller keeps the reference's own path), not an argument error.
@@ -448,7 +454,7 @@ static int interp_fill_impl(const bowgpu_col *cols, int32_t ncols, int32_t ts_co
     if (hstat[5] && o.inclusive)
         return fail(BOWGPU_ERR_UNSUPPORTED, "Interpolate on inclusive windows: a 512-row trip that spans 2^31 or more, or holds a gap of "
                                             "millions of empty windows, is outside the device path");
-    if (hstat[5]) BG_TRY(run_all(0));
+    if (hstat[5]) BG_TRY(run_all(0, true));
     if (hstat[0]) return fail(BOWGPU_ERR_TS_UNSORTED, "interval column is not ascending: outside the device path");
     for (int i = 0; i < ninterps; i++) BG_TRY(devout_finish(c, &douts[i], n_out, cols[i].type, n_out - (int64_t)hcnt[i], false));
     BG_HIP(hipStreamSynchronize(c->stream));

@@ -556,6 +556,7 @@ __global__ __launch_bounds__(64, 4) void interp_wave3_kernel(const InterpParams 
         return x;
     };
     W2_STAMP(0);   // round 1 (timestamps) + phase 1
+    bool far = false;   // a neighbour point further away than the index-free walk looks: the host repeats the call with the index (status[7])
 
     // ---- phase 2: one column at a time (the next column's values in flight meanwhile)
 #pragma unroll 1
@@ -590,7 +591,7 @@ __global__ __launch_bounds__(64, 4) void interp_wave3_kernel(const InterpParams 
             if (ic.vbits) load_bits128<true>(ic.vbits, ic.vbit0, base - 128, p.n, &unused, &back);   // (base is a multiple of 512: the 128 rows exist)
             int64_t pi = -1;
             if (back) pi = base - 1 - __clzll((long long)back);
-            else if (base > 64) pi = prev_valid_ix(ic.vbits, ic.vbit0, p.n, base - 65, ic.nbr);
+            else if (base > 64) pi = ic.nbr.prev_before ? prev_valid_ix(ic.vbits, ic.vbit0, p.n, base - 65, ic.nbr) : prev_valid_near(ic.vbits, ic.vbit0, p.n, base - 65, &far);
             if (pi >= 0) {
                 carry.has = 1;
                 carry.t = (int64_t)((const_u64)(uintptr_t)tsu)[pi];
@@ -677,7 +678,7 @@ __global__ __launch_bounds__(64, 4) void interp_wave3_kernel(const InterpParams 
             if (rp >= 0) { qp->has = 1; qp->t = ws0 + (int64_t)(uint64_t)tp; qp->bits = row_bits(rp); }
             if (rn >= 0) { qn->has = 1; qn->t = ws0 + (int64_t)(uint64_t)tn; qn->bits = row_bits(rn); }
             else if (want_n && base + nloc < p.n) {
-                const int64_t ni = next_valid_ix(ic.vbits, ic.vbit0, p.n, base + nloc, ic.nbr);
+                const int64_t ni = ic.nbr.next_after ? next_valid_ix(ic.vbits, ic.vbit0, p.n, base + nloc, ic.nbr) : next_valid_near(ic.vbits, ic.vbit0, p.n, base + nloc, &far);
                 if (ni >= 0) {
                     uint64_t xb = ic.values[ni], xt = tsu[ni];
                     // (the two loads are waited for HERE, inside the rare branch: left pending at the join, the compiler puts a wait for
@@ -805,6 +806,9 @@ __global__ __launch_bounds__(64, 4) void interp_wave3_kernel(const InterpParams 
         else column_body(std::false_type{});
         W2_STAMP(3);   // flush
     }
+    if (__ballot(far)) {
+        if (lane == 0 && !__hip_atomic_load(&p.status[7], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(&p.status[7], 1u);
+    }
 #ifdef BOWGPU_STAMPS
     if (lane == 0) {
         for (int i = 0; i < 5; i++) atomicAdd(reinterpret_cast<unsigned long long *>(p.status + 32) + i, st_acc[i]);
@@ -893,6 +897,13 @@ void interp_magic32(int64_t interval, uint32_t *m, uint32_t *sh1, uint32_t *sh2)
     *m = x.m; *sh1 = x.sh1; *sh2 = x.sh2;
 }
 
+// does interp_wave3_kernel take this call?  (It looks a synthetic row's neighbour points up without the neighbour index - a bounded
+// walk, status[7] when it does not reach - so the host builds the index only for the workgroup kernel and for a repeat.)
+bool interp_takes_wave3(const InterpParams &p) {
+    const bool force_tile = (route_mask() & BOWGPU_ROUTE_INTERP_TILE) != 0 && !p.inclusive;
+    return p.drop == 0 && p.kq < 0 && (p.fast32 || p.wide32) && p.allow_wave2 && !force_tile;
+}
+
 int launch_interp_tiles(Ctx *c, const InterpParams &p) {
     const int64_t ntiles = (p.n + kITile - 1) / kITile;
     if (ntiles <= 0) return 0;
@@ -900,11 +911,8 @@ int launch_interp_tiles(Ctx *c, const InterpParams &p) {
     // kernel for the rest - 64-bit window ids, dropped rows, the -1 sentinel window - and for the redo of a call one of whose trips
     // overflowed wave3's lists (allow_wave2 == 0).  BOWGPU_ROUTE_INTERP_TILE: the test switch that runs an exclusive call through the
     // workgroup kernel (the second opinion of the tests).  Inclusive windows are built by wave3 alone.
-    const uint32_t route = route_mask();
-    const bool force_tile = (route & BOWGPU_ROUTE_INTERP_TILE) != 0 && !p.inclusive;
     static_assert(kT3Rows == kITile, "interp_wave3_kernel's trips are the count kernel's tiles");
-    const bool shape_ok = p.drop == 0 && p.kq < 0;
-    if (shape_ok && (p.fast32 || p.wide32) && p.allow_wave2 && !force_tile) {
+    if (interp_takes_wave3(p)) {
         const int64_t ntrips = (p.n + kT3Rows - 1) / kT3Rows, per_xcd = (ntrips + 7) / 8;
         if (per_xcd * 8 > 0x7FFFFFFFll) return fail(BOWGPU_ERR_UNSUPPORTED, "too many rows for one launch: %lld", (long long)p.n);
         if (!p.edge_words) return fail(BOWGPU_ERR_ARG, "internal: interp_wave3_kernel needs its edge list");

@@ -483,7 +483,21 @@ __global__ __launch_bounds__(256) void finish_bitmaps_kernel(const BitmapBatch b
     // flight: 1e8 bits took 38 us), the words behind the last full group and the partial last word one by one below
     const bool vec = (reinterpret_cast<uintptr_t>(w) & 15) == 0 && (!u || (reinterpret_cast<uintptr_t>(u) & 15) == 0);
     const int64_t nvec = vec ? ((b.nbits >> 5) >> 2) : 0;   // groups of four FULL words
-    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < nvec; g += (int64_t)gridDim.x * blockDim.x) {
+    // (four independent 16-byte loads in flight per thread: one per trip left this kernel latency-bound - 35 us for two bitmaps of 1.09e8
+    // bits, 1.5 TB/s; the Interpolate call and every Aggregate call end with it)
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; g + 3 * stride < nvec; g += 4 * stride) {
+        const uint4 *q = reinterpret_cast<const uint4 *>(w) + g;
+        const uint4 x0 = q[0], x1 = q[stride], x2 = q[2 * stride], x3 = q[3 * stride];
+        if (b.count[a]) acc += __popc(x0.x) + __popc(x0.y) + __popc(x0.z) + __popc(x0.w) + __popc(x1.x) + __popc(x1.y) + __popc(x1.z) + __popc(x1.w) +
+                               __popc(x2.x) + __popc(x2.y) + __popc(x2.z) + __popc(x2.w) + __popc(x3.x) + __popc(x3.y) + __popc(x3.z) + __popc(x3.w);
+        if (u) {
+            uint4 *d = reinterpret_cast<uint4 *>(u) + g;
+            d[0] = x0; d[stride] = x1; d[2 * stride] = x2; d[3 * stride] = x3;
+        }
+    }
+    for (; g < nvec; g += stride) {
         const uint4 x = reinterpret_cast<const uint4 *>(w)[g];
         if (b.count[a]) acc += __popc(x.x) + __popc(x.y) + __popc(x.z) + __popc(x.w);
         if (u) reinterpret_cast<uint4 *>(u)[g] = x;

@@ -20,6 +20,7 @@
 // frames, rows below s0 and interval columns with nulls never get here (the host declines them up front).
 #include <stddef.h>
 
+#include "bitmap_device.h"
 #include "interp_device.h"
 
 namespace bowgpu {
@@ -37,7 +38,6 @@ constexpr int kAlignF = 16;
 #define BOWGPU_FUSED_NT 1
 #endif
 constexpr bool kNtF = BOWGPU_FUSED_NT != 0;   // non-temporal loads of a tile's interior chunks (rolling_simple.hip); A/B: -DBOWGPU_FUSED_NT=0
-constexpr int kWalkWordsF = 64;     // a neighbour point outside the tile: at most this many validity words are searched (2048 rows)
 
 // The rows' times stay in LDS as 32-bit offsets from the first window start: a synthetic row needs the times of its two neighbour
 // points (linear.go:34), rows a lane other than the window's holds.  (Fetched from the column instead - two 8-byte gathers per window
@@ -68,40 +68,6 @@ __device__ __forceinline__ void lds_order() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     asm volatile("" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// nearest valid row at or before `row` / at or after it, looking at no more than kWalkWordsF words; -1: none (the column's first /
-// last row was reached); *gave_up: the words ran out first
-__device__ inline int64_t prev_valid_bounded(const uint32_t *bits, int64_t bit0, int64_t row, bool *gave_up) {
-    if (row < 0) return -1;
-    int64_t b = bit0 + row;
-    for (int k = 0; k < kWalkWordsF && b >= bit0; k++) {
-        const int64_t w = b >> 5;
-        const int sh = (int)(b & 31);
-        uint32_t x = bits[w];
-        x = sh == 31 ? x : (x & ((2u << sh) - 1u));
-        if (w == (bit0 >> 5)) x &= ~0u << (bit0 & 31);
-        if (x) return (w << 5) + (31 - __clz((int)x)) - bit0;
-        b = (w << 5) - 1;
-    }
-    if (b >= bit0) *gave_up = true;
-    return -1;
-}
-__device__ inline int64_t next_valid_bounded(const uint32_t *bits, int64_t bit0, int64_t n, int64_t row, bool *gave_up) {
-    if (row >= n) return -1;
-    int64_t b = bit0 + row;
-    const int64_t bend = bit0 + n;
-    for (int k = 0; k < kWalkWordsF && b < bend; k++) {
-        const int64_t w = b >> 5;
-        const uint32_t x = bits[w] & (~0u << (b & 31));
-        if (x) {
-            const int64_t r = (w << 5) + (__ffs((int)x) - 1) - bit0;
-            return r < n ? r : -1;
-        }
-        b = (w + 1) << 5;
-    }
-    if (b < bend) *gave_up = true;
-    return -1;
 }
 
 // rows fv .. lv of the staged column behind an optional synthetic first row of value xs (seeded), in row order: sum.go:16-22,
@@ -352,7 +318,7 @@ __global__ __launch_bounds__(kWave, kMulti ? 5 : 6) void rolling_fused_kernel(co
                         while (m == 0u && wi > 0) { wi--; m = sh.vbits[wi]; }
                         if (m) pr = wi * 32 + 31 - __clz((int)m);
                     }
-                    prow = pr >= 0 ? base + pr : prev_valid_bounded(cbits, p.vbit0[c], base - 1, &gave_up);
+                    prow = pr >= 0 ? base + pr : prev_valid_near(cbits, p.vbit0[c], n, base - 1, &gave_up);
                 }
             }
             if (want_next) {
@@ -366,7 +332,7 @@ __global__ __launch_bounds__(kWave, kMulti ? 5 : 6) void rolling_fused_kernel(co
                         while (m == 0u && wi < wl) { wi++; m = sh.vbits[wi]; }
                         if (m) { nr = wi * 32 + __ffs((int)m) - 1; if (nr >= nloc) nr = -1; }
                     }
-                    nrow = nr >= 0 ? base + nr : next_valid_bounded(cbits, p.vbit0[c], n, base + nloc, &gave_up);
+                    nrow = nr >= 0 ? base + nr : next_valid_near(cbits, p.vbit0[c], n, base + nloc, &gave_up);
                 }
             }
             // the points themselves: time and (Float64) value out of the staged tile when the row lies in it; an Int64 column hands its own

@@ -20,6 +20,8 @@ run("cfg1 dense Sum/Mean/Min/Max (+WindowStart), interval 10", [ts, val], 10,
 run("cfg1 dense WindowStart+Mean, interval 10", [ts, val], 10, [("WindowStart", 0), ("ArithmeticMean", 1)], 16)
 run("cfg1 dense WindowStart+Mean, interval 1000 (long windows)", [ts, val], 1000, [("WindowStart", 0), ("ArithmeticMean", 1)], 16)
 ts2, val2 = capi.gen_sparse(0, n, seed=42)
+# (the column's null count as a Bow knows it - Data().NullN(), what the cgo shim passes; -1 makes every call count the bits first)
+val2 = capi.Column(val2.values, val2.validity, capi.FLOAT64, 0, n, n - capi.aggregate_whole([ts2, val2], 0, [("Count", 1)])[0].to_list()[0])
 run("cfg2 sparse 30% nulls WindowStart+Mean, interval 100", [ts2, val2], 100, [("WindowStart", 0), ("ArithmeticMean", 1)], 16.125)
 ip = [{"kind": "WindowStart", "col": 0}, {"kind": "Linear", "col": 1}]
 filled = capi.rolling_interpolate([ts2, val2], 0, 100, ip, out_residency=capi.DEVICE)

@@ -7,6 +7,8 @@ import ctypes as C
 from bow_amd import capi
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 100_000_000
 ts, val = capi.gen_sparse(0, n, seed=42)
+# the column's null count as a Bow knows it (Data().NullN(): what the cgo shim passes; -1 makes every call count the bits first)
+val = capi.Column(val.values, val.validity, capi.FLOAT64, 0, n, n - capi.aggregate_whole([ts, val], 0, [("Count", 1)])[0].to_list()[0])
 cols = [ts, val]
 ip = [{"kind": "WindowStart", "col": 0}, {"kind": "Linear", "col": 1}]
 carr, iarr = capi._cols(cols), capi._interps(ip)
