@@ -198,7 +198,7 @@ def check(rc):
 # ------------------------------------------------------------------ test / A-B routing (bowgpu_debug_set_route: per calling thread)
 ROUTE_NO_SIMPLE, ROUTE_FORCE_GENERAL, ROUTE_NO_LONG_ONLY, ROUTE_LONG_CLASSIC, ROUTE_LONG_STREAM_ALL = 1, 2, 4, 8, 16
 ROUTE_SIMPLE_SMALL_LIST, ROUTE_SIMPLE_LARGE_LIST, ROUTE_TW_F64, ROUTE_SIMPLE_PADDED, ROUTE_INTERP_TILE = 32, 64, 128, 256, 512
-ROUTE_PINNED_STAGE, ROUTE_STRICT_ORDER, ROUTE_NO_FUSED = 1024, 2048, 4096
+ROUTE_PINNED_STAGE, ROUTE_STRICT_ORDER, ROUTE_NO_FUSED, ROUTE_TW_ROWS = 1024, 2048, 4096, 8192
 
 
 def set_route(mask):
@@ -229,7 +229,7 @@ class route:
 
 # every kernel / form a Rolling.Aggregate call can be pushed through (the tests run each case through all of them)
 AGG_ROUTES = (("auto", 0), ("classic-long", ROUTE_LONG_CLASSIC), ("stream-all", ROUTE_LONG_STREAM_ALL),
-              ("small-list", ROUTE_SIMPLE_SMALL_LIST), ("large-list", ROUTE_SIMPLE_LARGE_LIST), ("padded", ROUTE_SIMPLE_PADDED),
+              ("small-list", ROUTE_SIMPLE_SMALL_LIST), ("large-list", ROUTE_SIMPLE_LARGE_LIST), ("padded", ROUTE_SIMPLE_PADDED), ("tw-rows", ROUTE_TW_ROWS),
               ("lean", ROUTE_NO_SIMPLE | ROUTE_NO_LONG_ONLY), ("general", ROUTE_FORCE_GENERAL | ROUTE_NO_LONG_ONLY))
 INTERP_ROUTES = (("wave3", 0), ("tile", ROUTE_INTERP_TILE))   # the product kernel and the one kept second implementation
 

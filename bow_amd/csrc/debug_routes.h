@@ -14,5 +14,6 @@ enum {
     BOWGPU_ROUTE_SIMPLE_PADDED = 256,    // rolling_simple_kernel: the padded staging also for the calls that would take the unpadded instantiation (short windows, one Float64 column without nulls)
     BOWGPU_ROUTE_INTERP_TILE = 512,      // Interpolate (exclusive windows): interp_tile_kernel instead of interp_wave3_kernel
     BOWGPU_ROUTE_NO_FUSED = 4096,        // bowgpu_rolling_interpolate_aggregate: the two calls through device temporaries even where rolling_fused_kernel applies
-    BOWGPU_ROUTE__ALL = 8191             // every defined bit, the two public ones (1024, 2048) included
+    BOWGPU_ROUTE_TW_ROWS = 8192,         // time-weighted reducers on a nullable column: rolling_tw_kernel's row-space form even where rolling_twc_kernel (valid points compacted) applies
+    BOWGPU_ROUTE__ALL = 16383            // every defined bit, the two public ones (1024, 2048) included
 };

@@ -1194,6 +1194,17 @@ def test_strict_order_and_the_pinned_form_thresholds():
         else:
             assert name == kernel, (interval, name)
         assert (info.long_windows == info.num_windows) == name.startswith("long_"), (interval, name, info.long_windows)
+    # ... with a nullable column the valid points are compacted first (rolling_twc.hip), from 12 rows per window on and up to 128 for both
+    # kinds of integral too
+    fv = rng.random(n) > 0.3
+    ncols = [capi.Column(ts, None, capi.INT64), capi.Column(f, np.packbits(fv, bitorder="little"), capi.FLOAT64, 0, n, -1)]
+    for aggs, interval, kernel in ((more, 10, "rolling_tw_kernel"), (more, 12, "rolling_twc_kernel"), (more, 128, "rolling_twc_kernel"), (more, 130, "long_stream_kernel"),
+                                   (both, 128, "rolling_twc_kernel"), (both, 129, "long_stream_kernel"), (lite, 64, "rolling_simple_kernel")):
+        capi.rolling_aggregate(ncols, 0, interval, aggs)
+        assert capi.last_kernel_name() == kernel, (interval, capi.last_kernel_name())
+    with capi.route(capi.ROUTE_TW_ROWS):
+        capi.rolling_aggregate(ncols, 0, 64, more)
+        assert capi.last_kernel_name() == "rolling_tw_kernel"
     # strict order: short windows are exact either way ...
     for interval in (10, 100):
         exp, _ = orc.aggregate(ocols, 0, interval, more)
