@@ -1199,7 +1199,7 @@ def test_strict_order_and_the_pinned_form_thresholds():
     fv = rng.random(n) > 0.3
     ncols = [capi.Column(ts, None, capi.INT64), capi.Column(f, np.packbits(fv, bitorder="little"), capi.FLOAT64, 0, n, -1)]
     for aggs, interval, kernel in ((more, 10, "rolling_tw_kernel"), (more, 12, "rolling_twc_kernel"), (more, 128, "rolling_twc_kernel"), (more, 130, "long_stream_kernel"),
-                                   (both, 128, "rolling_twc_kernel"), (both, 129, "long_stream_kernel"), (lite, 64, "rolling_simple_kernel")):
+                                   (both, 128, "rolling_twc_kernel"), (both, 130, "long_stream_kernel"), (lite, 64, "rolling_simple_kernel")):
         capi.rolling_aggregate(ncols, 0, interval, aggs)
         assert capi.last_kernel_name() == kernel, (interval, capi.last_kernel_name())
     with capi.route(capi.ROUTE_TW_ROWS):
