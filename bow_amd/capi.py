@@ -125,7 +125,7 @@ class ShardDecision(C.Structure):
 # every symbol include/bowgpu.h declares (checked by tests/test_abi_symbols.py)
 SYMBOLS = [
     "bowgpu_abi_version", "bowgpu_rolling_interpolate_aggregate", "bowgpu_last_error", "bowgpu_device_count", "bowgpu_set_device", "bowgpu_device_name",
-    "bowgpu_set_stream", "bowgpu_synchronize", "bowgpu_trim", "bowgpu_mem_info", "bowgpu_host_register", "bowgpu_host_unregister", "bowgpu_last_kernel_ms", "bowgpu_last_kernel_name", "bowgpu_malloc", "bowgpu_free", "bowgpu_memcpy_h2d",
+    "bowgpu_set_stream", "bowgpu_synchronize", "bowgpu_trim", "bowgpu_mem_info", "bowgpu_host_register", "bowgpu_host_unregister", "bowgpu_last_kernel_ms", "bowgpu_last_call_slow_rows", "bowgpu_last_kernel_name", "bowgpu_malloc", "bowgpu_free", "bowgpu_memcpy_h2d",
     "bowgpu_memcpy_d2h", "bowgpu_memset", "bowgpu_timer_create", "bowgpu_timer_start", "bowgpu_timer_stop",
     "bowgpu_timer_elapsed_ms", "bowgpu_timer_destroy", "bowgpu_enforce_interval_and_offset", "bowgpu_plan_windows",
     "bowgpu_rolling_aggregate", "bowgpu_plan_windows_ex", "bowgpu_rolling_aggregate_planned", "bowgpu_window_bounds", "bowgpu_aggregate_whole",
@@ -476,6 +476,13 @@ def last_kernel_name():
 def last_kernel_instance():
     """... with them, where the library reports them (rolling_simple_kernel): the instantiation that ran, as rocprofv3 spells it"""
     return lib().bowgpu_last_kernel_name().decode()
+
+
+def last_call_slow_rows():
+    """rows of the thread's last Aggregate / Interpolate call served by rolling_agg_kernel / interp_tile_kernel (0: the fast kernels took it)"""
+    r = C.c_int64(0)
+    check(lib().bowgpu_last_call_slow_rows(C.byref(r)))
+    return r.value
 
 
 def last_kernel_ms():

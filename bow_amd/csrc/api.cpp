@@ -1067,6 +1067,16 @@ static int job_launch_tiles(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t
                 BG_TRY(launch_rolling_tw(c, S, is_int, has_nulls, wide, ts32));
                 c->last_kernel_name = "rolling_tw_kernel";
             }
+        } else if ([&] {
+                       static const int exp_mode = [] { const char *e = getenv("BOWGPU_EXP_TWC_VALUES"); return e ? atoi(e) : 0; }();   // A/B only
+                       const int64_t lim53 = 1ll << 53;
+                       const bool ts32 = !wide && !P.pre_rows && plan->first_ts > -lim53 && plan->last_ts < lim53 && S.s0 > -lim53;
+                       const bool both = (S.need & kNeedSum) && (S.need & kNeedMinMax);
+                       return exp_mode && has_nulls && ts32 && !force_large_list && P.n / P.W >= kCompactMinAvgRows && (exp_mode == 2 || both);
+                   }()) {
+            BG_TRY(launch_rolling_twc(c, S));
+            *used_small_list = true;
+            c->last_kernel_name = "rolling_twc_kernel";
         } else {
             // (the head list of a tile comes in two sizes - rolling_simple.hip SimpleCap: the small one buys four more resident
             // wavefronts per CU and serves calls whose windows average >= 5 rows; BOWGPU_ROUTE_SIMPLE_LARGE_LIST / _SMALL_LIST force
@@ -1090,6 +1100,7 @@ static int job_launch_tiles(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t
                     (int)allow_simple, plan ? 1 : 0, plan ? (long long)plan->first_ts : 0ll, (long long)P.s0);
         BG_TRY(launch_rolling_aggregate(c, P));
         c->last_kernel_name = "rolling_agg_kernel";
+        c->last_slow_rows += P.n;   // (the general kernel: 0.32 of the HBM peak where the wave-tile kernels reach 0.6 - 0.7)
     }
     BG_HIP(hipEventRecord(c->ev1, c->stream));
     return 0;
@@ -1866,6 +1877,14 @@ const char *bowgpu_last_kernel_name(void) {
     return c->last_kernel_name;
 }
 
+int bowgpu_last_call_slow_rows(int64_t *rows) {
+    if (!rows) return fail(BOWGPU_ERR_ARG, "null argument");
+    Ctx *c;
+    BG_TRY(ctx_get(&c));
+    *rows = c->last_slow_rows;
+    return 0;
+}
+
 int bowgpu_last_kernel_ms(double *ms) {
     Ctx *c;
     BG_TRY(ctx_get(&c));
@@ -1982,6 +2001,7 @@ static int aggregate_with_plan(const bowgpu_col *cols, int32_t ncols, int32_t ts
     if (!outs) return fail(BOWGPU_ERR_ARG, "no output columns");
     Ctx *c;
     BG_TRY(ctx_get(&c));
+    c->last_slow_rows = 0;
     int64_t n_long = 0;
     double ms = 0;
     static const bool prof = [] { const char *e = getenv("BOWGPU_CALL_PROFILE"); return e && e[0] == '1'; }();

@@ -54,6 +54,7 @@ struct Ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double last_kernel_ms = 0.0;
     const char *last_kernel_name = "";  // the tile kernel last_kernel_ms brackets
+    int64_t last_slow_rows = 0;         // rows of the last Aggregate / Interpolate call served by a kernel kept for the shapes the fast ones decline (bowgpu_last_call_slow_rows)
     // grow-only pool of temporaries reused across calls (word-aligned validity working copies, ...):
     // hipMalloc / hipFree per call cost more than the kernels' fixed overhead
     static constexpr int kPoolSlots = 40;   // 0..15 output validity working copies, kPoolInterp.. Interpolate / fill scratch, last: long windows

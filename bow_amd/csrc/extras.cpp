@@ -338,6 +338,7 @@ static int interp_fill_impl(const bowgpu_col *cols, int32_t ncols, int32_t ts_co
         return 0;
     }
     BG_TRY(ctx_get(&c));
+    c->last_slow_rows = 0;
     InterpJob job;
     bool onepass = false;
     if (!cached && !global_s0 && !edge) BG_TRY(interp_onepass_prepare(c, cols, ncols, ts_col, interval, &o, &job, &onepass));
@@ -420,6 +421,7 @@ static int interp_fill_impl(const bowgpu_col *cols, int32_t ncols, int32_t ts_co
             }
             BG_TRY(launch_preset_bitmaps(c, bb));
             BG_TRY(launch_interp_tiles(c, P));
+            if (!interp_takes_wave3(P) && b0 == 0) c->last_slow_rows += n;   // (interp_tile_kernel: 2.2 ms per 1e8 rows where interp_wave3_kernel takes 1.15)
             BG_TRY(launch_finish_bitmaps(c, bb));
             BG_HIP(hipMemcpyAsync(&hcnt[b0], dcnt, 8 * (size_t)nb, hipMemcpyDeviceToHost, c->stream));
         }

@@ -188,6 +188,13 @@ int bowgpu_trim(int32_t all_threads, int64_t *bytes_freed /* nullable */);
 int bowgpu_mem_info(int64_t *free_bytes, int64_t *total_bytes);
 /* device time (HIP events on the stream) of the tile kernel of this thread's last aggregate call */
 int bowgpu_last_kernel_ms(double *ms);
+/* Rows of this thread's last Rolling.Aggregate / Rolling.Interpolate (_fill) call that were served by one of the two kernels the
+ * library keeps for the shapes its fast kernels decline - rolling_agg_kernel (window ids beyond 32 bits inside one tile, tiles denser
+ * than a head list, intervals >= 2^32 with time-weighted reducers: about 0.3 of the HBM peak where the wave-tile kernels reach
+ * 0.6 - 0.7) and interp_tile_kernel (64-bit window ids, dropped rows, the -1 sentinel window, a trip whose lists overflow: half the
+ * rate of interp_wave3_kernel).  0 for the usual call; the results are the same bits either way.  A caller that finds this non-zero on
+ * its hot path is on a route 2 - 3x slower than the figures the documentation quotes. */
+int bowgpu_last_call_slow_rows(int64_t *rows);
 /* ... and which tile kernel that was ("rolling_tw_kernel", "rolling_wave_kernel", "rolling_agg_kernel", "long_stream_kernel", ...; "" before
  * any call).  rolling_simple_kernel comes with its template arguments, spelled as rocprofv3 prints them
  * ("rolling_simple_kernel<0, false, false, false, false, false, false>"): the text up to '<' is the kernel, the whole string the

@@ -628,6 +628,33 @@ def test_simple_kernel_redo_when_ids_overflow():
     run_both(ts, [(vals, None)], 2, [("WindowStart", 0), ("ArithmeticMean", 1), ("Count", 1)])
 
 
+def test_slow_route_counter_tells_a_caller_when_a_fallback_kernel_served_the_call():
+    """bowgpu_last_call_slow_rows: 0 for the usual call; the call's rows when rolling_agg_kernel (here forced; in the product: the redo of
+    a tile no wave-tile kernel can describe, intervals >= 2^32 with time-weighted reducers) or interp_tile_kernel served it"""
+    n = 50_000
+    ts = np.arange(n, dtype=np.int64) * 3
+    v = np.arange(n, dtype=np.float64)
+    cols = [capi.Column(ts), capi.Column(v, None, capi.FLOAT64)]
+    aggs = [("WindowStart", 0), ("ArithmeticMean", 1)]
+    capi.rolling_aggregate(cols, 0, 30, aggs)
+    assert capi.last_call_slow_rows() == 0 and capi.last_kernel_name() == "rolling_simple_kernel"
+    with capi.route(capi.ROUTE_FORCE_GENERAL | capi.ROUTE_NO_LONG_ONLY):
+        capi.rolling_aggregate(cols, 0, 30, aggs)
+        assert capi.last_call_slow_rows() == n and capi.last_kernel_name() == "rolling_agg_kernel"
+    # the product's own way there: window ids 2^16 apart inside one tile (the simple kernel flags the call, the wave kernel redoes it - fast)
+    ts2 = np.concatenate([np.arange(0, 300), np.arange(300, 600) * 1_000_000]).astype(np.int64)
+    capi.rolling_aggregate([capi.Column(ts2), capi.Column(v[:600].copy(), None, capi.FLOAT64)], 0, 2, aggs)
+    assert capi.last_call_slow_rows() == 0
+    ip = [{"kind": "WindowStart", "col": 0}, {"kind": "Linear", "col": 1}]
+    capi.rolling_interpolate(cols, 0, 30, ip)
+    assert capi.last_call_slow_rows() == 0
+    with capi.route(capi.ROUTE_INTERP_TILE):
+        capi.rolling_interpolate(cols, 0, 30, ip)
+        assert capi.last_call_slow_rows() == n
+    capi.rolling_aggregate(cols, 0, 30, aggs)
+    assert capi.last_call_slow_rows() == 0
+
+
 # ------------------------------------------------------------------ aggregation.Mode (mode.go:8-32)
 def _mode_values(rng, n, kind):
     if kind == "int":
