@@ -1060,7 +1060,7 @@ static int job_launch_tiles(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t
             // the list raises status[4] and the call is redone here with force_large_list (job_pass_complete), i.e. by rolling_tw.hip
             const bool compact = has_nulls && ts32 && !force_large_list && !(route & BOWGPU_ROUTE_TW_ROWS) && P.n / P.W >= kCompactMinAvgRows;
             if (compact) {
-                BG_TRY(launch_rolling_twc(c, S));
+                BG_TRY(launch_rolling_twc(c, S, P.n / P.W > 128));   // (windows of 129 .. kCompactLongMaxAvgRows rows on average: 256 rows of look-ahead)
                 *used_small_list = true;
                 c->last_kernel_name = "rolling_twc_kernel";
             } else {
@@ -1068,11 +1068,14 @@ static int job_launch_tiles(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t
                 c->last_kernel_name = "rolling_tw_kernel";
             }
         } else if ([&] {
-                       static const int exp_mode = [] { const char *e = getenv("BOWGPU_EXP_TWC_VALUES"); return e ? atoi(e) : 0; }();   // A/B only
+                       // a nullable column whose outputs want sums AND extrema, windows of kCompactValuesMinAvgRows rows and more: the compacting
+                       // form walks the valid points once where rolling_simple.hip walks the rows twice (or once under the validity bit) - 1e8
+                       // rows, 30 % nulls, Sum + Min + Max: 0.412 against 0.440 ms at 64 rows per window, 0.451 against 0.558 at 128; below
+                       // that length, and for every other value set, rolling_simple.hip stays ahead (profiles/r05_stdout_twc_values_ab.txt)
                        const int64_t lim53 = 1ll << 53;
                        const bool ts32 = !wide && !P.pre_rows && plan->first_ts > -lim53 && plan->last_ts < lim53 && S.s0 > -lim53;
-                       const bool both = (S.need & kNeedSum) && (S.need & kNeedMinMax);
-                       return exp_mode && has_nulls && ts32 && !force_large_list && P.n / P.W >= kCompactMinAvgRows && (exp_mode == 2 || both);
+                       const bool sums_and_extrema = (S.need & kNeedSum) && (S.need & kNeedMinMax);
+                       return has_nulls && ts32 && sums_and_extrema && !force_large_list && !(route & BOWGPU_ROUTE_TW_ROWS) && P.n / P.W >= kCompactValuesMinAvgRows;
                    }()) {
             BG_TRY(launch_rolling_twc(c, S));
             *used_small_list = true;
@@ -1181,7 +1184,16 @@ static int job_run(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, i
     // rows per window for both kinds of integral too: 0.53 against 0.72 ms per 1e8 rows)
     bool any_nulls = false;
     for (int s = 0; s < P.ncols; s++) any_nulls = any_nulls || P.cols[s].vbits != nullptr;
-    const bool stream_ok = !classic_only && avg_rows >= ((sall || (step_k && trap_k && !any_nulls)) ? kLongOnlyAvgRows : kLongStreamAnyAvgRows) &&
+    // ... and with 256 rows of look-ahead the same kernel keeps the calls of 129 .. kCompactLongMaxAvgRows rows per window that have a
+    // time-weighted reducer on a nullable column (the streaming form's slowest shape: 0.32 of the peak at 192 rows per window)
+    const int64_t lim53 = 1ll << 53;
+    const bool compact_long = !sall && !cls && any_nulls && (step_k || trap_k) && plan && avg_rows > 128 &&
+                              avg_rows <= ((step_k && trap_k) ? kCompactLongBothMaxAvgRows : kCompactLongMaxAvgRows) && P.fits32 &&
+                              !P.pre_rows && plan->first_ts > -lim53 && plan->last_ts < lim53 &&
+                              (uint64_t)plan->last_ts - (uint64_t)P.s0 < 0xFFFFFFF0ull && W < 0xFFFFFFF0ll && naggs <= kSimpleMaxAggs &&
+                              !(route & (BOWGPU_ROUTE_TW_ROWS | BOWGPU_ROUTE_TW_F64 | BOWGPU_ROUTE_NO_SIMPLE | BOWGPU_ROUTE_FORCE_GENERAL)) && !g_strict_order;
+    const bool stream_ok = !classic_only && !compact_long &&
+                           avg_rows >= ((sall || (step_k && trap_k && !any_nulls)) ? kLongOnlyAvgRows : kLongStreamAnyAvgRows) &&
                            avg_rows < kLongClassicAvgRows && W < (1ll << 32);
     const bool classic_ok = avg_rows >= kLongBisectAvgRows;
     // bowgpu_options.strict_order on a call of long windows: every window by one lane in row order (long_windows.hip

@@ -30,21 +30,23 @@ namespace {
 
 constexpr int kWave = 64;
 constexpr int kTileC = 512;
-constexpr int kHaloC = 128;
-constexpr int kRowsC = kTileC + kHaloC;
-constexpr int kChunksC = kRowsC / 128;
-constexpr int kWordsC = kRowsC / 32;
-constexpr int kCapC = 92;           // heads per tile (+ look-ahead): windows of 7 rows and more on average; LDS exactly 8 KB
 constexpr uint32_t kRowMaskC = 0x3FFu, kStartBitC = 0x400u;   // a head entry: local row | sits on its window's start << 10 | (wid - wid of the tile's first row) << 11
 
+// kHalo: the look-ahead behind a tile's 512 rows.  128 rows: windows of up to 128 rows always lie inside one tile, 8 KB of LDS (20
+// wavefronts per CU), 92 heads (windows of 7 rows and more on average).  256 rows: the form for calls whose windows average 129 .. 224
+// rows, which no 128-row look-ahead holds and the streaming form serves at 0.32 of the peak when the column has nulls: 10 KB (16 per CU).
+template <int kHalo> struct TwcCap { static constexpr int value = kHalo == 128 ? 92 : 200; };
+template <int kHalo>
 struct TwcShared {
-    uint64_t val[kRowsC];            // the column's valid values, compacted; then its step terms; then its trapezoid terms
-    uint32_t ctx[kRowsC];            // their times: 32-bit offsets from the start of slot 0
-    uint32_t vbits[kWordsC + 2];     // validity words of the value column for this tile (rows beyond the tile's last row: 0)
-    uint16_t wpre[kWordsC + 2];      // valid rows in front of each word; [kWordsC] = all of the tile's
-    uint32_t seg[kCapC + 2];         // heads in row order
+    static constexpr int kRows = kTileC + kHalo, kWords = kRows / 32;
+    uint64_t val[kRows];            // the column's valid values, compacted; then its step terms; then its trapezoid terms
+    uint32_t ctx[kRows];            // their times: 32-bit offsets from the start of slot 0
+    uint32_t vbits[kWords + 2];     // validity words of the value column for this tile (rows beyond the tile's last row: 0)
+    uint16_t wpre[kWords + 2];      // valid rows in front of each word; [kWords] = all of the tile's
+    uint32_t seg[TwcCap<kHalo>::value + 2];   // heads in row order
 };
-static_assert(sizeof(TwcShared) <= 8192, "LDS of the compacting form: 8 KB (20 wavefronts per CU)");
+static_assert(sizeof(TwcShared<128>) <= 8192, "LDS of the compacting form: 8 KB (20 wavefronts per CU)");
+static_assert(sizeof(TwcShared<256>) <= 10240, "LDS of the compacting form with the long look-ahead: 10 KB (16 wavefronts per CU)");
 
 __device__ __forceinline__ uint32_t mdiv32(uint32_t n, uint32_t m, uint32_t sh1, uint32_t sh2) {
     const uint32_t t = __umulhi(m, n);
@@ -80,9 +82,10 @@ __device__ __forceinline__ uint32_t wave_scan_u32(uint32_t x) {
 // kMulti: more than one value column.  The single-column form compacts its column right in the flag pass, where a row's time and
 // value are in registers anyway - nothing of the tile then lives in registers behind it (no times kept for later columns, no next
 // column in flight): 96 instead of 134 registers, a fifth more wavefronts per CU.
-template <bool kBoth, bool kMulti>
-__global__ __launch_bounds__(kWave, kMulti ? 4 : 5) void rolling_twc_kernel(const SimpleParams p, const int64_t ntiles, const int64_t tiles_per_xcd) {
-    __shared__ TwcShared sh;
+template <bool kBoth, bool kMulti, int kHalo>
+__global__ __launch_bounds__(kWave, (kMulti || kHalo != 128) ? 4 : 5) void rolling_twc_kernel(const SimpleParams p, const int64_t ntiles, const int64_t tiles_per_xcd) {
+    constexpr int kRowsC = kTileC + kHalo, kChunksC = kRowsC / 128, kWordsC = kRowsC / 32, kCapC = TwcCap<kHalo>::value;
+    __shared__ TwcShared<kHalo> sh;
     const int64_t b = blockIdx.x;
     const int64_t tile = (b & 7) * tiles_per_xcd + (b >> 3);  // XCD-contiguous tile runs (look-ahead rows hit the same L2)
     if (tile >= ntiles) return;
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(kWave, kMulti ? 4 : 5) void rolling_twc_kernel(cons
             const ulonglong2 *q = reinterpret_cast<const ulonglong2 *>(src + base) + lane;
 #pragma unroll
             for (int j = 0; j < kChunksC; j++) {
-                const ulonglong2 x = (j > 0 && j < kChunksC - 1) ? load16_nt(q + j * 64) : q[j * 64];
+                const ulonglong2 x = (j >= kHalo / 128 && j < kTileC / 128) ? load16_nt(q + j * 64) : q[j * 64];
                 a[j] = x.x; bb[j] = x.y;
             }
         } else if (interior) {
@@ -134,12 +137,12 @@ __global__ __launch_bounds__(kWave, kMulti ? 4 : 5) void rolling_twc_kernel(cons
         const ulonglong2 *qv = reinterpret_cast<const ulonglong2 *>(reinterpret_cast<const uint64_t *>(p.values[0]) + base) + lane;
 #pragma unroll
         for (int j = 0; j < kChunksC; j++) {
-            const ulonglong2 x = (j > 0 && j < kChunksC - 1) ? load16_nt(qt + j * 64) : qt[j * 64];
+            const ulonglong2 x = (j >= kHalo / 128 && j < kTileC / 128) ? load16_nt(qt + j * 64) : qt[j * 64];
             ta[j] = x.x; tb[j] = x.y;
         }
 #pragma unroll
         for (int j = 0; j < kChunksC; j++) {
-            const ulonglong2 x = (j > 0 && j < kChunksC - 1) ? load16_nt(qv + j * 64) : qv[j * 64];
+            const ulonglong2 x = (j >= kHalo / 128 && j < kTileC / 128) ? load16_nt(qv + j * 64) : qv[j * 64];
             va[j] = x.x; vb[j] = x.y;
         }
     } else {
@@ -221,7 +224,7 @@ __global__ __launch_bounds__(kWave, kMulti ? 4 : 5) void rolling_twc_kernel(cons
         pos += ha ? 1 : 0;
         if (hb && pos < kCapC) sh.seg[pos] = (uint32_t)(l + 1) | sb | (lb << 11);
         nseg_total += __popcll(ma) + __popcll(mb);
-        if (j == kChunksC - 2) nseg_owned = nseg_total;
+        if (j == kTileC / 128 - 1) nseg_owned = nseg_total;   // (the heads inside the tile's own 512 rows)
         left_w = (uint32_t)__builtin_amdgcn_readlane((int)wb, 63);
         left_ts = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(tb[j] >> 32), 63) << 32) |
                             (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)tb[j], 63));
@@ -483,7 +486,7 @@ __global__ __launch_bounds__(kWave, kMulti ? 4 : 5) void rolling_twc_kernel(cons
     }  // columns
 }
 
-int launch_rolling_twc(Ctx *c, const SimpleParams &p) {
+int launch_rolling_twc(Ctx *c, const SimpleParams &p, bool long_halo) {
     if (p.n <= 0) return 0;
     const int64_t ntiles = (p.n + kTileC - 1) / kTileC;
     const int64_t per_xcd = (ntiles + 7) / 8;
@@ -491,13 +494,14 @@ int launch_rolling_twc(Ctx *c, const SimpleParams &p) {
     if (grid > 0x7FFFFFFFll) return fail(BOWGPU_ERR_UNSUPPORTED, "too many rows for one launch: %lld", (long long)p.n);
     const dim3 g((unsigned)grid), blk(kWave);
     const bool both = (p.need & kNeedStep) && (p.need & kNeedTrap);
-    if (p.ncols > 1) {
-        if (both) hipLaunchKernelGGL((rolling_twc_kernel<true, true>), g, blk, 0, c->stream, p, ntiles, per_xcd);
-        else hipLaunchKernelGGL((rolling_twc_kernel<false, true>), g, blk, 0, c->stream, p, ntiles, per_xcd);
-    } else {
-        if (both) hipLaunchKernelGGL((rolling_twc_kernel<true, false>), g, blk, 0, c->stream, p, ntiles, per_xcd);
-        else hipLaunchKernelGGL((rolling_twc_kernel<false, false>), g, blk, 0, c->stream, p, ntiles, per_xcd);
-    }
+#define BG_TWC(B, M)                                                                                                         \
+    do {                                                                                                                      \
+        if (long_halo) hipLaunchKernelGGL((rolling_twc_kernel<B, M, 256>), g, blk, 0, c->stream, p, ntiles, per_xcd);           \
+        else hipLaunchKernelGGL((rolling_twc_kernel<B, M, 128>), g, blk, 0, c->stream, p, ntiles, per_xcd);                    \
+    } while (0)
+    if (p.ncols > 1) { if (both) BG_TWC(true, true); else BG_TWC(false, true); }
+    else { if (both) BG_TWC(true, false); else BG_TWC(false, false); }
+#undef BG_TWC
     BG_HIP(hipGetLastError());
     return 0;
 }

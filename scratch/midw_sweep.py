@@ -28,6 +28,8 @@ for label, cols, scale, bpr in (("dense", dense, 1, 16.0), ("sparse", sparse, 10
             s0, W = capi.plan_windows(cols[0], interval, 0)
             outs = [capi.OutColumn(W, capi.DEVICE) for _ in aggs]
             routes = [("auto", 0)]
+            if label == "sparse" and os.environ.get("SWEEP_ROUTES", "1") == "1":
+                routes += [("row-space", capi.ROUTE_TW_ROWS)]   # round 5: without rolling_twc_kernel (the forms of round 4: rolling_tw / rolling_simple / streaming)
             if rpw >= 96 and os.environ.get("SWEEP_ROUTES", "1") == "1":
                 routes += [("stream", capi.ROUTE_LONG_STREAM_ALL), ("tiles", capi.ROUTE_NO_LONG_ONLY)]
             line = "%-6s %4d rows/window %-9s" % (label, rpw, name)
