@@ -628,6 +628,38 @@ def test_simple_kernel_redo_when_ids_overflow():
     run_both(ts, [(vals, None)], 2, [("WindowStart", 0), ("ArithmeticMean", 1), ("Count", 1)])
 
 
+@pytest.mark.parametrize("rows_per_window", [14, 40, 100, 128, 150, 200, 250])
+def test_compacting_kernel_for_nullable_columns_under_time_weighted_reducers(rows_per_window):
+    """rolling_twc_kernel (round 5): a nullable column's valid points are compacted in LDS, the integrals' terms come from the dense
+    neighbour logic, one lane adds a window's terms in row order - bit for bit the oracle, like the row-space form of rolling_tw.hip it
+    replaces (run_both pushes every case through both: capi.ROUTE_TW_ROWS).  Window lengths either side of the two look-aheads (128 /
+    256 rows), one and both kinds of integral, value reducers next to them, Int64 and multi-column calls, inclusive windows by option
+    and by reducer, Factor chains, null densities from a few to nearly all, tiles with an all-null stretch."""
+    rng = np.random.default_rng(500 + rows_per_window)
+    n = 260_000
+    ts = np.cumsum(rng.integers(1, 20, n)).astype(np.int64) + 777
+    interval = 10 * rows_per_window
+    for null_frac in (0.3, 0.02, 0.93):
+        f, fm = make_vals(rng, n, "f64", null_frac)
+        g, gm = make_vals(rng, n, "i64", 0.5)
+        fm[100_000:103_000] = False       # a stretch without a valid point: windows with no point, tiles with none
+        sets = [[("WindowStart", 0), ("WeightedAverageStep", 1)],
+                [("WindowStart", 0)] + [(k, 1) for k in TIME_AGGS],
+                [("WindowStart", 0), ("IntegralTrapezoid", 1), ("ArithmeticMean", 1), ("Min", 1), ("Last", 1), ("Count", 1), ("NumRows", 1)],
+                [("WindowStart", 0), ("IntegralStep", 2, [0.1]), ("WeightedAverageLinear", 1, [2.0, -1.0]), ("First", 2), ("Max", 2), ("Sum", 1)],
+                [("WindowStart", 0), ("Sum", 1), ("Min", 1), ("Max", 1)]]
+        for aggs in sets:
+            for inclusive in (False, True):
+                outs, exp, info = run_both(ts, [(f, fm), (g, gm)], interval, aggs, offset=7, inclusive=inclusive)
+                assert info.long_windows == 0 or rows_per_window >= 100   # (irregular rows: a few windows outgrow the look-ahead and take the cooperative path)
+    # a frame that is mostly long windows with a stretch of one-row windows: more heads than the compacting kernel's list holds in
+    # some tiles - the call is redone by the row-space form (and by the forms behind it); the answer is the same
+    ts2 = ts.copy()
+    ts2[50_000:50_400] = ts2[50_000] + np.arange(400) * interval
+    ts2[50_400:] += 400 * interval
+    run_both(ts2, [(f, fm)], interval, [("WindowStart", 0), ("WeightedAverageStep", 1), ("IntegralTrapezoid", 1)])
+
+
 def test_slow_route_counter_tells_a_caller_when_a_fallback_kernel_served_the_call():
     """bowgpu_last_call_slow_rows: 0 for the usual call; the call's rows when rolling_agg_kernel (here forced; in the product: the redo of
     a tile no wave-tile kernel can describe, intervals >= 2^32 with time-weighted reducers) or interp_tile_kernel served it"""
