@@ -730,6 +730,25 @@ struct AggJob {
     bool check_plan = false;    // the plan came from the caller (bowgpu_rolling_aggregate_planned): the pass checks it against the column
 };
 static thread_local bool g_plan_from_caller = false;   // set around run_aggregate by the planned entry point
+// Up to which window length (rows on average) a call on a NULLABLE column stays on rolling_twc_kernel with its 256 rows of look-ahead
+// instead of taking the streaming form (0: it does not) - from the 1e8-row sweeps of profiles/r05_stdout_midw_sweep.txt, 30 % nulls, kernel
+// ms compacting / streaming at 144 and 192 rows per window: one kind of integral 0.45 / 0.70 and 0.47 / 0.64, First + Last 0.38 / 0.46 and
+// 0.37 / 0.43 (both up to 255 rows); Min + Max 0.47 / 0.61 and 0.49 / 0.52, both kinds of integral 0.63 / 0.73 and 0.69 / 0.65 (up to 176);
+// sums and counts alone: the streaming form (0.41 / 0.37).  Columns without nulls: the streaming form throughout (it has its dense
+// instantiations; the compacting kernel is 10 - 40 % behind there).
+static int64_t compact_long_max_rows(const bowgpu_agg *aggs, int32_t naggs) {
+    bool step = false, trap = false, mm = false, fl = false;
+    for (int i = 0; i < naggs; i++) {
+        const int k = aggs[i].kind;
+        step |= k == BOWGPU_AGG_INTEGRAL_STEP || k == BOWGPU_AGG_WAVG_STEP;
+        trap |= k == BOWGPU_AGG_INTEGRAL_TRAPEZOID || k == BOWGPU_AGG_WAVG_LINEAR;
+        mm |= k == BOWGPU_AGG_MIN || k == BOWGPU_AGG_MAX;
+        fl |= k == BOWGPU_AGG_FIRST || k == BOWGPU_AGG_LAST;
+    }
+    if ((step && trap) || mm) return kCompactLongBothMaxAvgRows;
+    if (step || trap || fl) return kCompactLongMaxAvgRows;
+    return 0;
+}
 static thread_local bool g_strict_order = false;   // bowgpu_options.strict_order of the call in progress (or BOWGPU_ROUTE_STRICT_ORDER)
 
 static void pending_drop(Ctx *c);   // a pass put in flight by bowgpu_shard_pass_begin and not collected: settled before the scratch is reused
@@ -1075,9 +1094,11 @@ static int job_launch_tiles(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t
                        const int64_t lim53 = 1ll << 53;
                        const bool ts32 = !wide && !P.pre_rows && plan->first_ts > -lim53 && plan->last_ts < lim53 && S.s0 > -lim53;
                        const bool sums_and_extrema = (S.need & kNeedSum) && (S.need & kNeedMinMax);
+                       // (beyond 128 rows per window the call is here only because job_run kept it off the streaming form: compact_long_max_rows)
+                       if (has_nulls && ts32 && !force_large_list && !(route & BOWGPU_ROUTE_TW_ROWS) && P.n / P.W > 128 && P.n / P.W <= compact_long_max_rows(aggs, naggs)) return true;
                        return has_nulls && ts32 && sums_and_extrema && !force_large_list && !(route & BOWGPU_ROUTE_TW_ROWS) && P.n / P.W >= kCompactValuesMinAvgRows;
                    }()) {
-            BG_TRY(launch_rolling_twc(c, S));
+            BG_TRY(launch_rolling_twc(c, S, P.n / P.W > 128));
             *used_small_list = true;
             c->last_kernel_name = "rolling_twc_kernel";
         } else {
@@ -1184,11 +1205,10 @@ static int job_run(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, i
     // rows per window for both kinds of integral too: 0.53 against 0.72 ms per 1e8 rows)
     bool any_nulls = false;
     for (int s = 0; s < P.ncols; s++) any_nulls = any_nulls || P.cols[s].vbits != nullptr;
-    // ... and with 256 rows of look-ahead the same kernel keeps the calls of 129 .. kCompactLongMaxAvgRows rows per window that have a
-    // time-weighted reducer on a nullable column (the streaming form's slowest shape: 0.32 of the peak at 192 rows per window)
+    // ... and with 256 rows of look-ahead the same kernel keeps the calls of 129 .. 176 / 255 rows per window on a nullable column whose
+    // reducer set the streaming form serves worst (compact_long_max_rows)
     const int64_t lim53 = 1ll << 53;
-    const bool compact_long = !sall && !cls && any_nulls && (step_k || trap_k) && plan && avg_rows > 128 &&
-                              avg_rows <= ((step_k && trap_k) ? kCompactLongBothMaxAvgRows : kCompactLongMaxAvgRows) && P.fits32 &&
+    const bool compact_long = !sall && !cls && any_nulls && plan && avg_rows > 128 && avg_rows <= compact_long_max_rows(aggs, naggs) && P.fits32 &&
                               !P.pre_rows && plan->first_ts > -lim53 && plan->last_ts < lim53 &&
                               (uint64_t)plan->last_ts - (uint64_t)P.s0 < 0xFFFFFFF0ull && W < 0xFFFFFFF0ll && naggs <= kSimpleMaxAggs &&
                               !(route & (BOWGPU_ROUTE_TW_ROWS | BOWGPU_ROUTE_TW_F64 | BOWGPU_ROUTE_NO_SIMPLE | BOWGPU_ROUTE_FORCE_GENERAL)) && !g_strict_order;

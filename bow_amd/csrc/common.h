@@ -270,8 +270,8 @@ int launch_rolling_fused(Ctx *c, const FusedParams &fp, int need, bool has_nulls
 int interp_validate(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, const bowgpu_options *o, const bowgpu_interp *interps, int32_t ninterps);
 
 int launch_rolling_twc(Ctx *c, const SimpleParams &p, bool long_halo = false);   // (long_halo: 256 rows of look-ahead) nullable columns under time-weighted reducers, 32-bit times: the valid points compacted first (rolling_twc.hip)
-constexpr int64_t kCompactLongMaxAvgRows = 255;             // ... and, with 256 rows of look-ahead, up to this many (beyond: the streaming form) - one kind of integral: 0.45 - 0.49 against 0.54 - 0.70 ms
-constexpr int64_t kCompactLongBothMaxAvgRows = 176;         //     both kinds: two walks of ~130 points by a handful of lanes - the streaming form is ahead from 192 rows on (0.65 against 0.69 ms)
+constexpr int64_t kCompactLongMaxAvgRows = 255;             // ... and, with 256 rows of look-ahead, up to this many (beyond: the streaming form) - one kind of integral, First / Last
+constexpr int64_t kCompactLongBothMaxAvgRows = 176;         //     both kinds of integral, Min / Max: the streaming form is ahead from 192 rows on (api.cpp compact_long_max_rows)
 constexpr int64_t kCompactValuesMinAvgRows = 48;            // value reducers alone: only sums AND extrema on a nullable column, from this window length on
 constexpr int64_t kCompactMinAvgRows = 12;                  // ... for calls whose windows average at least this many rows (its head list: 92 per 640 rows)
 int launch_rolling_aggregate(Ctx *c, const AggParams &p);   // general kernel (rolling_agg.hip)

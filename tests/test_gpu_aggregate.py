@@ -1261,7 +1261,8 @@ def test_strict_order_and_the_pinned_form_thresholds():
     for aggs, interval, kernel in ((more, 10, "rolling_tw_kernel"), (more, 12, "rolling_twc_kernel"), (more, 128, "rolling_twc_kernel"), (more, 130, "rolling_twc_kernel"),
                                    (more, 250, "rolling_twc_kernel"), (more, 260, "long_stream_kernel"), (both, 128, "rolling_twc_kernel"), (both, 170, "rolling_twc_kernel"),
                                    (both, 180, "long_stream_kernel"), (lite, 64, "rolling_simple_kernel"), (summ, 40, "rolling_simple_kernel"), (summ, 50, "rolling_twc_kernel"),
-                                   (summ, 128, "rolling_twc_kernel"), (summ, 130, "long_stream_kernel")):
+                                   (summ, 128, "rolling_twc_kernel"), (summ, 170, "rolling_twc_kernel"), (summ, 180, "long_stream_kernel"),
+                                   ([("WindowStart", 0), ("First", 1), ("Last", 1)], 250, "rolling_twc_kernel"), (lite, 130, "long_stream_kernel")):
         capi.rolling_aggregate(ncols, 0, interval, aggs)
         assert capi.last_kernel_name() == kernel, (interval, capi.last_kernel_name())
     with capi.route(capi.ROUTE_TW_ROWS):
