@@ -1259,7 +1259,8 @@ def test_strict_order_and_the_pinned_form_thresholds():
     ncols = [capi.Column(ts, None, capi.INT64), capi.Column(f, np.packbits(fv, bitorder="little"), capi.FLOAT64, 0, n, -1)]
     summ = [("WindowStart", 0), ("Sum", 1), ("Min", 1), ("Max", 1)]
     for aggs, interval, kernel in ((more, 10, "rolling_tw_kernel"), (more, 12, "rolling_twc_kernel"), (more, 128, "rolling_twc_kernel"), (more, 130, "rolling_twc_kernel"),
-                                   (more, 250, "rolling_twc_kernel"), (more, 260, "long_stream_kernel"), (both, 128, "rolling_twc_kernel"), (both, 170, "rolling_twc_kernel"),
+                                   (more, 170, "rolling_twc_kernel"), (more, 180, "long_stream_kernel"), ([("WindowStart", 0), ("WeightedAverageStep", 1)], 250, "rolling_twc_kernel"),
+                                   ([("WindowStart", 0), ("WeightedAverageStep", 1)], 260, "long_stream_kernel"), (both, 128, "rolling_twc_kernel"), (both, 170, "rolling_twc_kernel"),
                                    (both, 180, "long_stream_kernel"), (lite, 64, "rolling_simple_kernel"), (summ, 40, "rolling_simple_kernel"), (summ, 50, "rolling_twc_kernel"),
                                    (summ, 128, "rolling_twc_kernel"), (summ, 170, "rolling_twc_kernel"), (summ, 180, "long_stream_kernel"),
                                    ([("WindowStart", 0), ("First", 1), ("Last", 1)], 250, "rolling_twc_kernel"), (lite, 130, "long_stream_kernel")):
