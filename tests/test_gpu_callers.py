@@ -164,6 +164,32 @@ def test_interpolate_in_one_pass_without_a_count(vtype):
             assert e.value.code == -14, (tail, inclusive, e.value.code, e.value.message)
 
 
+def test_interpolate_neighbour_points_thousands_of_null_rows_away():
+    """interp_wave3_kernel looks a synthetic row's neighbour points up without the neighbour index (round 5: a walk over at most 64
+    validity words; the index cost three launches per column and call); a point further away raises status[7] and the call is repeated
+    with the index built.  Runs of 2500 .. 3000 nulls in front of, behind and across window starts (the ORACLE, like the reference's
+    GetPrevFloat64s walks, is quadratic in the run length: sizes stay small), both interpolators that look for neighbours, both kernels."""
+    rng = np.random.default_rng(41)
+    n = 60_000
+    ts = np.arange(n, dtype=np.int64) * 3 + 1        # (no row on a window start: every window gets a synthetic row)
+    vals = np.round(rng.standard_normal(n) * 100, 2)
+    valid = rng.random(n) >= 0.2
+    for a, b in ((10_000, 13_000), (30_000, 32_500), (45_000, 45_700), (n - 2_600, n)):
+        valid[a:b] = False
+    valid[:2_500] = False                             # ... and no previous point at all for the first windows
+    bm = np.packbits(valid, bitorder="little")
+    for kind in ("Linear", "StepPrevious"):
+        ip = [{"kind": "WindowStart", "col": 0}, {"kind": kind, "col": 1}]
+        for interval, offset in ((60, 0), (3000, 7)):
+            got = both_interp_kernels(lambda: capi.rolling_interpolate([capi.Column(ts), capi.Column(vals, bm, capi.FLOAT64, 0, n, -1)], 0, interval, ip, offset=offset))
+            want = orc.interpolate([orc.Column(ts, None, orc.INT64), orc.Column(vals, bm, orc.FLOAT64)], 0, interval, ip, offset=offset)
+            cmp_out("far neighbours ts %s I=%d" % (kind, interval), got[0], want[0])
+            cmp_out("far neighbours val %s I=%d" % (kind, interval), got[1], want[1])
+            one = capi.rolling_interpolate_onepass([capi.Column(ts), capi.Column(vals, bm, capi.FLOAT64, 0, n, -1)], 0, interval, ip, offset=offset, inclusive=True)
+            want_i = orc.interpolate([orc.Column(ts, None, orc.INT64), orc.Column(vals, bm, orc.FLOAT64)], 0, interval, ip, offset=offset, inclusive=True)
+            cmp_out("far neighbours, inclusive one pass %s I=%d" % (kind, interval), one[1], want_i[1])
+
+
 @pytest.mark.parametrize("base_ts", [0, 1_700_000_000_000, -(1 << 40), (1 << 52)])
 def test_interpolate_frames_spanning_more_than_2_31(base_ts):
     """millisecond / microsecond timestamps: the frame spans far more than 2^31 from its first window start (round 2's wave kernels
