@@ -1333,12 +1333,13 @@ static int job_pass_complete(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_
     return 0;
 }
 
-static int job_finish(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs) {
+static int job_finish(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, uint32_t *strict_limit_hit = nullptr) {
     uint32_t *hstat;
     uint64_t *hcnt = nullptr;
     BG_TRY(job_enqueue_tail(c, job, aggs, naggs));
     BG_TRY(job_readback(c, job, &hstat, &hcnt));
     BG_HIP(hipStreamSynchronize(c->stream));
+    if (strict_limit_hit) *strict_limit_hit = hstat[7];
     for (int i = 0; i < naggs; i++)
         job->douts[i].user->null_count = (job->W > 0 && !kind_never_nil(aggs[i].kind)) ? job->W - (int64_t)hcnt[i] : 0;
     return 0;
@@ -2181,9 +2182,15 @@ int bowgpu_rolling_aggregate_planned(const bowgpu_col *cols, int32_t ncols, int3
 
 // ---- row-range sharding -------------------------------------------------------------------
 
+static bool strict_wanted(const bowgpu_options *o) { return (o && o->strict_order) || (route_mask() & BOWGPU_ROUTE_STRICT_ORDER); }
+struct StrictScope { bool was; explicit StrictScope(bool on) : was(g_strict_order) { g_strict_order = on; } ~StrictScope() { g_strict_order = was; } };
+// allow_strict: the record protocol (bowgpu_shard_begin / _pass_begin / _finish) serves bowgpu_options.strict_order since round 5 - a
+// rank's own windows by the unsharded forms, a window shared by TWO ranks by the right rank's re-walk of its rows seeded with the left
+// rank's running state (row order across the boundary); a window spread over three or more ranks merges partial sums and is declined
+// by _finish.  The building blocks of round 1 (bowgpu_shard_aggregate, _carry_only) still decline it.
 static int shard_check(const bowgpu_col *cols, int32_t ncols, const bowgpu_agg *aggs, int32_t naggs, bowgpu_out *outs,
-                       const bowgpu_options *o) {
-    if ((o && o->strict_order) || (route_mask() & BOWGPU_ROUTE_STRICT_ORDER)) return fail(BOWGPU_ERR_UNSUPPORTED, "sharded aggregate: strict_order is not offered (carries and long windows merge order-free)");
+                       const bowgpu_options *o, bool allow_strict = false) {
+    if (!allow_strict && strict_wanted(o)) return fail(BOWGPU_ERR_UNSUPPORTED, "sharded aggregate: strict_order is offered by the record protocol only (bowgpu_shard_begin / _pass_begin / _finish)");
     for (int i = 0; i < naggs; i++) {
         // a window cut by a shard boundary needs all its rows in one place: Mode has no constant-size partial state
         if (aggs[i].kind == BOWGPU_AGG_MODE) return fail(BOWGPU_ERR_UNSUPPORTED, "sharded aggregate: Mode is not a mergeable reducer");
@@ -2498,9 +2505,14 @@ int bowgpu_shard_begin(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, in
     AggJob job;
     BG_TRY(job_build(c, cols, ncols, ts_col, plan, 0, aggs, naggs, no_outs.data(), wl, 0, false, &job));
     bowgpu_carry_state *dst = reinterpret_cast<bowgpu_carry_state *>(dummy);
-    BG_TRY(launch_range_state(c, job.P, 0, (uint64_t)wl, nullptr, dst, nullptr));
+    const bool strict = strict_wanted(&o);
+    uint32_t far = 0;
+    if (strict) BG_HIP(hipMemsetAsync(job.P.status + 7, 0, 4, c->stream));
+    BG_TRY(launch_range_state(c, job.P, 0, (uint64_t)wl, nullptr, dst, nullptr, 1, strict ? 1 : 0));
     BG_HIP(hipMemcpyAsync(rec->last, dst, sizeof(bowgpu_carry_state) * naggs, hipMemcpyDeviceToHost, c->stream));
+    if (strict) BG_HIP(hipMemcpyAsync(&far, job.P.status + 7, 4, hipMemcpyDeviceToHost, c->stream));
     BG_HIP(hipStreamSynchronize(c->stream));
+    if (far) return fail(BOWGPU_ERR_UNSUPPORTED, "strict_order: the shard's last window holds more than 2^20 rows (one lane walks a window in row order: beyond that the call is declined)");
     return 0;
 }
 
@@ -2517,10 +2529,11 @@ int bowgpu_shard_pass_begin(const bowgpu_col *cols, int32_t ncols, int32_t ts_co
     if (opts) o = *opts;
     int inclusive = o.inclusive ? 1 : 0, nic = -1;
     BG_TRY(validate_aggs(cols, ncols, ts_col, aggs, naggs, &inclusive, &nic));
-    BG_TRY(shard_check(cols, ncols, aggs, naggs, outs, &o));
+    BG_TRY(shard_check(cols, ncols, aggs, naggs, outs, &o, true));
     if (cols[ts_col].type != BOWGPU_INT64) return fail(BOWGPU_ERR_TS_TYPE, "impossible to create a new intervalRolling on column of type float64");
     if (me->nrows != cols[ts_col].length) return fail(BOWGPU_ERR_ARG, "the record says %lld rows, the interval column has %lld",
                                                       (long long)me->nrows, (long long)cols[ts_col].length);
+    StrictScope strict_scope(strict_wanted(&o));
     PendingOwnerScope owner;
     Ctx *c;
     BG_TRY(ctx_get(&c));
@@ -2626,7 +2639,9 @@ int bowgpu_shard_finish(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, i
     if (opts) o = *opts;
     int inclusive = o.inclusive ? 1 : 0, nic = -1;
     BG_TRY(validate_aggs(cols, ncols, ts_col, aggs, naggs, &inclusive, &nic));
-    BG_TRY(shard_check(cols, ncols, aggs, naggs, outs, &o));
+    BG_TRY(shard_check(cols, ncols, aggs, naggs, outs, &o, true));
+    const bool strict = strict_wanted(&o);
+    StrictScope strict_scope(strict);
     bowgpu_shard_decision d;
     BG_TRY(bowgpu_shard_plan(recs, world, rank, interval, o.offset, &d));
     if (decision) *decision = d;
@@ -2702,7 +2717,7 @@ int bowgpu_shard_finish(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, i
             BG_HIP(hipMemcpyAsync(dnext, next_row, sizeof *next_row, hipMemcpyHostToDevice, c->stream));
         }
         // the rank owns its last window and only now knows the row that may close it (rolling.go:201-209)
-        if (dnext && d.finish_last) BG_TRY(launch_range_state(c, job.P, 2, (uint64_t)wl, nullptr, nullptr, dnext, 0));
+        if (dnext && d.finish_last) BG_TRY(launch_range_state(c, job.P, 2, (uint64_t)wl, nullptr, nullptr, dnext, 0, strict ? 1 : 0));
         if (d.seed_first_rank >= 0) {
             // running state of this rank's first window over the rows the ranks to the left hold: one rank's state as is,
             // several merged in rank order (empty ranks in between hold zero states: identity)
@@ -2711,6 +2726,11 @@ int bowgpu_shard_finish(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, i
             int seed_alive = 0;
             for (int q = d.seed_first_rank; q < rank; q++)
                 if (recs[q].nrows > 0 && recs[q].last_ts >= d.s0) seed_alive = 1;
+            if (strict) {   // (a window spread over three or more ranks merges the middle ranks' partial sums: not row order)
+                int with_rows = 0;
+                for (int q = d.seed_first_rank; q < rank; q++) with_rows += recs[q].nrows > 0;
+                if (with_rows > 1) return fail(BOWGPU_ERR_UNSUPPORTED, "strict_order: a window is spread over three or more shards (its middle shards contribute partial sums)");
+            }
             for (int a = 0; a < naggs; a++) {
                 seeds[a] = recs[d.seed_first_rank].last[a];
                 for (int q = d.seed_first_rank + 1; q < rank; q++) {
@@ -2729,10 +2749,12 @@ int bowgpu_shard_finish(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, i
             BG_HIP(hipMemcpyAsync(dseed, hseed, sizeof(bowgpu_carry_state) * naggs, hipMemcpyHostToDevice, c->stream));
             // the window may also be the rank's last one: then the next rank's first row can be its inclusive row
             const bool also_last = wf == wl && !d.drops_last;
-            BG_TRY(launch_range_state(c, job.P, 1, (uint64_t)wf, dseed, nullptr, also_last ? dnext : nullptr, seed_alive));
+            BG_TRY(launch_range_state(c, job.P, 1, (uint64_t)wf, dseed, nullptr, also_last ? dnext : nullptr, seed_alive, strict ? 1 : 0));
         }
     }
-    BG_TRY(job_finish(c, &job, aggs, naggs));
+    uint32_t too_long = 0;
+    BG_TRY(job_finish(c, &job, aggs, naggs, strict ? &too_long : nullptr));
+    if (too_long) return fail(BOWGPU_ERR_UNSUPPORTED, "strict_order: some window holds more than 2^20 rows (one lane walks a window in row order: beyond that the call is declined)");
     if (info) { info->long_windows = n_long; info->kernel_ms = ms; }
     return 0;
 }

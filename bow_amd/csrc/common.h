@@ -372,7 +372,7 @@ int launch_and_bits(Ctx *c, const uint32_t *a, int64_t abit0, const uint32_t *b,
 
 // shard.hip
 int launch_range_state(Ctx *c, const AggParams &p, int mode, uint64_t wid, const bowgpu_carry_state *d_seeds,
-                       bowgpu_carry_state *d_states_out, const bowgpu_next_row *d_next = nullptr, int seed_alive = 1);
+                       bowgpu_carry_state *d_states_out, const bowgpu_next_row *d_next = nullptr, int seed_alive = 1, int strict = 0);
 
 int launch_fill_empty(Ctx *c, const AggParams &p, int64_t slot0, int64_t slot1);
 

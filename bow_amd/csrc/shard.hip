@@ -41,9 +41,13 @@ constexpr int kSeqLimit = 8192;  // longer ranges are merged from 256 contiguous
 // seed_alive: some row behind the seeds has ts >= s0.  Window 0 also spans the rows BELOW s0 (negative timestamps), but it is an
 // empty slice unless one of its rows reaches s0 or it takes an inclusive row (rolling.go:194-228: lastRowIndex stays -1) - the
 // "dead window 0" rule of the tile kernels, here for the window as stitched across shards.
+// strict: bowgpu_options.strict_order - the rows are walked by ONE lane in row order whatever their number (the 256 contiguous partials
+// of a long range change the order of a Sum's additions); a range of more than 2^20 rows raises status[7] and is left alone (the
+// stated limit of strict_order: api.cpp turns it into BOWGPU_ERR_UNSUPPORTED)
 __global__ __launch_bounds__(256) void range_state_kernel(const AggParams p, const int mode, const uint64_t wid,
                                                           const bowgpu_carry_state *seeds,
-                                                          bowgpu_carry_state *states_out, const bowgpu_next_row *next, const int seed_alive) {
+                                                          bowgpu_carry_state *states_out, const bowgpu_next_row *next, const int seed_alive,
+                                                          const int strict) {
     __shared__ Stats part[256];
     __shared__ int64_t s_r0, s_r1;
     const int tid = threadIdx.x;
@@ -65,6 +69,10 @@ __global__ __launch_bounds__(256) void range_state_kernel(const AggParams p, con
     __syncthreads();
     const int64_t r0 = s_r0, r1 = s_r1;
     const int64_t len = r1 - r0;
+    if (strict && len > (1ll << 20)) {
+        if (tid == 0) atomicOr(&p.status[7], 1u);
+        return;
+    }
     const int64_t win_start = p.s0 + (int64_t)(wid * (uint64_t)p.interval);
     const int64_t win_end = win_start + p.interval;
     const int64_t oslot = (int64_t)(wid - (uint64_t)p.wid_base);
@@ -92,7 +100,7 @@ __global__ __launch_bounds__(256) void range_state_kernel(const AggParams p, con
                 const int64_t bit = cd->vbit0 + r;
                 return (cd->vbits[bit >> 5] >> (bit & 31)) & 1u;
             };
-            if (len <= kSeqLimit) {
+            if (len <= kSeqLimit || strict) {
                 if (tid == 0)
                     for (int64_t r = r0; r < r1; r++)
                         if (valid_at(r)) {
@@ -189,8 +197,8 @@ int launch_fill_empty(Ctx *c, const AggParams &p, int64_t slot0, int64_t slot1) 
 }
 
 int launch_range_state(Ctx *c, const AggParams &p, int mode, uint64_t wid, const bowgpu_carry_state *d_seeds,
-                       bowgpu_carry_state *d_states_out, const bowgpu_next_row *d_next, int seed_alive) {
-    hipLaunchKernelGGL(range_state_kernel, dim3(1), dim3(256), 0, c->stream, p, mode, wid, d_seeds, d_states_out, d_next, seed_alive);
+                       bowgpu_carry_state *d_states_out, const bowgpu_next_row *d_next, int seed_alive, int strict) {
+    hipLaunchKernelGGL(range_state_kernel, dim3(1), dim3(256), 0, c->stream, p, mode, wid, d_seeds, d_states_out, d_next, seed_alive, strict);
     BG_HIP(hipGetLastError());
     return 0;
 }

@@ -203,7 +203,7 @@ def run_local(providers, overlap=True):
 class GpuProvider:
     """The product provider: HIP kernels through the C ABI (device-resident columns and outputs)."""
 
-    def __init__(self, cols, ts_col, interval, aggs, offset=0, out_capacity=None):
+    def __init__(self, cols, ts_col, interval, aggs, offset=0, out_capacity=None, strict_order=False):
         from . import capi
         self.capi = capi
         self.cols, self.ts_col, self.interval, self.aggs, self.offset = cols, ts_col, interval, aggs, offset
@@ -212,7 +212,7 @@ class GpuProvider:
         self.outs = None
         self._carr = capi._cols(cols)
         self._aarr = capi._aggs(aggs)
-        self._opts = capi.Options(offset, 0, 0)
+        self._opts = capi.Options(offset, 0, int(bool(strict_order)))   # (strict_order: every window in the reference's row order, also across a shard boundary)
         self.info = capi.AggInfo()
 
     # ---- the protocol

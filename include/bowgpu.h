@@ -140,8 +140,12 @@ typedef struct bowgpu_options {
                                    128-row look-ahead) are walked by one lane each (round 4; round 3 declined them): 0.25 - 0.48 of
                                    the HBM peak at 1000-row windows.  A window of more than 2^20 rows makes the call
                                    BOWGPU_ERR_UNSUPPORTED (one lane per window: beyond that it would take milliseconds each).
-                                   Honoured by bowgpu_rolling_aggregate[_planned]; declined (BOWGPU_ERR_UNSUPPORTED) by the
-                                   bowgpu_shard_* protocol.  0: see bowgpu_agg_info.long_windows for the bound that applies */
+                                   Honoured by bowgpu_rolling_aggregate[_planned], by bowgpu_rolling_interpolate_aggregate and (round 5) by
+                                   the shard record protocol - bowgpu_shard_begin / _pass_begin / _finish: a window shared by TWO ranks
+                                   is re-walked by the right rank seeded with the left rank's running state, i.e. in row order across
+                                   the boundary; a window spread over three or more ranks, or a boundary window of more than 2^20
+                                   rows, is BOWGPU_ERR_UNSUPPORTED.  The round-1 building blocks (bowgpu_shard_aggregate,
+                                   _carry_only) decline it.  0: see bowgpu_agg_info.long_windows for the bound that applies */
 } bowgpu_options;
 
 /* Diagnostics of one aggregate call */

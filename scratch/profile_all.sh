@@ -25,8 +25,17 @@ done
 timeout -s KILL 300 python3 scratch/longw_kinds.py strict 2>&1 | grep -v "^[WE]2026" > $DST/${TAG}_stdout_longw_kinds_strict.txt
 timeout -s KILL 600 python3 scratch/longw_sweep.py 2>&1 | grep -v "^[WE]2026" > $DST/${TAG}_stdout_longw_sweep.txt
 : > $DST/${TAG}_pmc_mid_windows.txt
-for V in "WAvgStep 64 dense rolling_tw" "TW4 64 dense rolling_tw" "WAvgStep 64 sparse rolling_tw" "Mean 64 dense rolling_simple" "SumMinMax 64 sparse rolling_simple" "MinMax 64 sparse rolling_simple"; do
+for V in "WAvgStep 64 dense rolling_tw" "TW4 64 dense rolling_tw" "WAvgStep 64 sparse rolling_twc" "TW4 64 sparse rolling_twc" "TW4 96 sparse rolling_twc" "WAvgStep 192 sparse rolling_twc" "Mean 64 dense rolling_simple" "SumMinMax 64 sparse rolling_twc" "MinMax 64 sparse rolling_simple"; do
   set -- $V
   bash scratch/pmc_quick.sh $1_$2_$3 $4 scratch/one_shape.py gen $1 $2 $3 | tail -1 >> $DST/${TAG}_pmc_mid_windows.txt
 done
+# 4. the streaming form's slowest instantiation next to its dense twin: which unit is busy (a counter-backed floor)
+: > $DST/${TAG}_pmc_long_short_tw.txt
+for V in "WeightedAverageStep sparse" "WeightedAverageStep dense" "Mean sparse"; do
+  set -- $V
+  echo "== $1 $2, 1000 rows per window" >> $DST/${TAG}_pmc_long_short_tw.txt
+  bash scratch/pmc_sq.sh lstw_$1_$2 long_short scratch/longw_pmc.py $1 $2 | grep -v "^pass" >> $DST/${TAG}_pmc_long_short_tw.txt
+done
+# 5. the configs[2] pipeline as one call against the two calls; the fused kernel's traffic
+timeout -s KILL 300 python3 scratch/cfg2_fused.py 2>&1 | grep -v "^[WE]2026" > $DST/${TAG}_stdout_cfg2_fused.txt
 ls -la $DST

@@ -20,7 +20,7 @@ TW_AGGS = [("WindowStart", 0), ("IntegralStep", 1), ("WeightedAverageStep", 1), 
            ("ArithmeticMean", 1), ("Count", 1), ("Last", 1), ("NumRows", 1)]
 
 
-def run_sharded(ts, vals, valid, bounds, interval, offset=0, aggs=None):
+def run_sharded(ts, vals, valid, bounds, interval, offset=0, aggs=None, strict_order=False):
     """bounds: row boundaries [0, b1, ..., n] of the simulated ranks"""
     AGGS = aggs if aggs is not None else globals()["AGGS"]
     world = len(bounds) - 1
@@ -30,7 +30,7 @@ def run_sharded(ts, vals, valid, bounds, interval, offset=0, aggs=None):
         bm = None if valid is None else np.packbits(valid[a:b], bitorder="little")
         cols = [capi.Column(ts[a:b].copy(), None, capi.INT64).to_device(),
                 capi.Column(vals[a:b].copy(), bm, capi.FLOAT64 if vals.dtype == np.float64 else capi.INT64, 0, b - a, -1).to_device()]
-        provs.append(sharded.GpuProvider(cols, 0, interval, AGGS, offset=offset))
+        provs.append(sharded.GpuProvider(cols, 0, interval, AGGS, offset=offset, strict_order=strict_order))
     decisions = sharded.run_local(provs)
     owned = [(d.first_slot_window_id, d.windows_owned) for d in decisions]
     # assemble the global result from what each rank owns
@@ -86,6 +86,34 @@ def test_sharded_equals_whole(mode):
             else:
                 bad = np.flatnonzero(gv[gm] != wv[wm])
                 assert bad.size == 0, (mode, interval, k, bad[:5])
+
+
+def test_sharded_strict_order_is_row_order_across_a_shard_boundary():
+    """bowgpu_options.strict_order on a sharded call (round 5; declined before): a rank's own windows by the unsharded forms (long ones
+    walked by one lane each), a window shared by two ranks by the right rank's re-walk seeded with the left rank's running state -
+    every reducer bit for bit, windows of 10 .. 3000 rows, nulls, offsets that put a window across every boundary; a window spread
+    over three ranks is declined (its middle rank would contribute a partial sum)."""
+    rng = np.random.default_rng(5)
+    n = 60_000
+    ts = np.cumsum(rng.integers(1, 4, n)).astype(np.int64)
+    vals = rng.standard_normal(n) * 1e6
+    valid = rng.random(n) >= 0.25
+    bm = np.packbits(valid, bitorder="little")
+    aggs = AGGS + [("IntegralStep", 1), ("WeightedAverageLinear", 1)]
+    for interval, offset, bounds in [(20, 3, [0, 15_000, 30_001, 44_444, n]), (400, 7, [0, 20_000, 40_000, n]), (6_000, 1, [0, 19_999, 41_000, n])]:
+        res, plan = run_sharded(ts, vals, valid, bounds, interval, offset=offset, aggs=aggs, strict_order=True)
+        exp, _ = orc.aggregate([orc.Column(ts, None, orc.INT64), orc.Column(vals, bm, orc.FLOAT64)], 0, interval, aggs, offset=offset)
+        for (k, _), (gv, gm, typ), w in zip(aggs, res, exp):
+            wm = w.valid_mask()
+            assert len(gv) == w.length and np.array_equal(gm, wm), (interval, k)
+            wv = w.values[:w.length].view(np.uint64)
+            diff = gv[gm] != wv[wm]
+            if diff.any():   # (generated NaNs carry the hardware's default payload: test_gpu_aggregate.compare)
+                diff &= ~(np.isnan(gv.view(np.float64)[gm]) & np.isnan(wv.view(np.float64)[wm]))
+            assert not diff.any(), (interval, k, np.flatnonzero(diff)[:5])
+    with pytest.raises(capi.BowGpuError) as e:      # ranks of 100 rows, windows of ~1000: every window is spread over many ranks
+        run_sharded(ts[:2000], vals[:2000], valid[:2000], list(range(0, 2001, 100)), 2000, aggs=AGGS, strict_order=True)
+    assert e.value.code == -9 and "three or more shards" in e.value.message
 
 
 def test_sharded_gaps_between_shards():
