@@ -2191,13 +2191,15 @@ struct StrictScope { bool was; explicit StrictScope(bool on) : was(g_strict_orde
 static int shard_check(const bowgpu_col *cols, int32_t ncols, const bowgpu_agg *aggs, int32_t naggs, bowgpu_out *outs,
                        const bowgpu_options *o, bool allow_strict = false) {
     if (!allow_strict && strict_wanted(o)) return fail(BOWGPU_ERR_UNSUPPORTED, "sharded aggregate: strict_order is offered by the record protocol only (bowgpu_shard_begin / _pass_begin / _finish)");
+    // (allow_strict: the record protocol.  It also takes HOST-resident columns and outputs since round 5 - staged through HBM per call the way
+    // the unsharded entry points stage them: the pass put in flight by _pass_begin keeps its staged copies until _finish collects it)
     for (int i = 0; i < naggs; i++) {
         // a window cut by a shard boundary needs all its rows in one place: Mode has no constant-size partial state
         if (aggs[i].kind == BOWGPU_AGG_MODE) return fail(BOWGPU_ERR_UNSUPPORTED, "sharded aggregate: Mode is not a mergeable reducer");
-        if (outs[i].residency != BOWGPU_DEVICE) return fail(BOWGPU_ERR_UNSUPPORTED, "sharded aggregate: outputs must be device-resident");
+        if (!allow_strict && outs[i].residency != BOWGPU_DEVICE) return fail(BOWGPU_ERR_UNSUPPORTED, "sharded aggregate: outputs must be device-resident");
     }
     for (int i = 0; i < ncols; i++)
-        if (cols[i].residency != BOWGPU_DEVICE) return fail(BOWGPU_ERR_UNSUPPORTED, "sharded aggregate: columns must be device-resident");
+        if (!allow_strict && cols[i].residency != BOWGPU_DEVICE) return fail(BOWGPU_ERR_UNSUPPORTED, "sharded aggregate: columns must be device-resident");
     if (naggs > BOWGPU_CARRY_MAX_AGGS) return fail(BOWGPU_ERR_UNSUPPORTED, "sharded aggregate: too many aggregations");
     return 0;
 }
@@ -2417,7 +2419,11 @@ int bowgpu_shard_first_row(const bowgpu_col *cols, int32_t ncols, int32_t ts_col
     Ctx *c;
     BG_TRY(ctx_get(&c));
     auto fetch = [&](const bowgpu_col &col, uint64_t *bits, int32_t *valid) -> int {
-        if (col.residency != BOWGPU_DEVICE) return fail(BOWGPU_ERR_UNSUPPORTED, "sharded aggregate: columns must be device-resident");
+        if (col.residency != BOWGPU_DEVICE) {   // host memory (pageable or registered): read where it lies
+            memcpy(bits, reinterpret_cast<const char *>(col.values) + 8 * col.offset, 8);
+            *valid = (col.validity && col.null_count != 0) ? ((col.validity[col.offset >> 3] >> (col.offset & 7)) & 1) : 1;
+            return 0;
+        }
         BG_HIP(hipMemcpyAsync(bits, reinterpret_cast<const char *>(col.values) + 8 * col.offset, 8, hipMemcpyDeviceToHost, c->stream));
         *valid = 1;
         if (col.validity && col.null_count != 0) {
@@ -2454,10 +2460,9 @@ static bool grid_floor(int64_t t, int64_t interval, int64_t offset_norm, int64_t
 }
 
 static int shard_cols_check(const bowgpu_col *cols, int32_t ncols, const bowgpu_agg *aggs, int32_t naggs) {
+    (void)cols; (void)ncols;   // (any residency: bowgpu_shard_begin stages host-resident columns like every other entry point)
     for (int i = 0; i < naggs; i++)
         if (aggs[i].kind == BOWGPU_AGG_MODE) return fail(BOWGPU_ERR_UNSUPPORTED, "sharded aggregate: Mode is not a mergeable reducer");
-    for (int i = 0; i < ncols; i++)
-        if (cols[i].residency != BOWGPU_DEVICE) return fail(BOWGPU_ERR_UNSUPPORTED, "sharded aggregate: columns must be device-resident");
     if (naggs > BOWGPU_CARRY_MAX_AGGS) return fail(BOWGPU_ERR_UNSUPPORTED, "sharded aggregate: too many aggregations");
     return 0;
 }

@@ -201,10 +201,12 @@ def run_local(providers, overlap=True):
 
 
 class GpuProvider:
-    """The product provider: HIP kernels through the C ABI (device-resident columns and outputs)."""
+    """The product provider: HIP kernels through the C ABI (columns of any residency; outputs device-resident unless out_residency
+    says otherwise - host-resident shards are staged through HBM per call, see include/bowgpu.h at bowgpu_shard_pass_begin)."""
 
-    def __init__(self, cols, ts_col, interval, aggs, offset=0, out_capacity=None, strict_order=False):
+    def __init__(self, cols, ts_col, interval, aggs, offset=0, out_capacity=None, strict_order=False, out_residency=None):
         from . import capi
+        self.out_residency = capi.DEVICE if out_residency is None else out_residency
         self.capi = capi
         self.cols, self.ts_col, self.interval, self.aggs, self.offset = cols, ts_col, interval, aggs, offset
         self.n = cols[ts_col].length
@@ -261,7 +263,7 @@ class GpuProvider:
         capi = self.capi
         if self.outs is None or self.outs[0].slots < need:
             cap = max(need, self.capacity or 0)
-            self.outs = [capi.OutColumn(cap, capi.DEVICE) for _ in self.aggs]
+            self.outs = [capi.OutColumn(cap, self.out_residency) for _ in self.aggs]
         oarr = (capi.Out * len(self.aggs))()
         for i, o in enumerate(self.outs):
             oarr[i] = o.c()

@@ -570,7 +570,11 @@ typedef struct bowgpu_shard_decision {
 #define BOWGPU_SHARD_RETRY 1   /* bowgpu_shard_finish: nothing was computed; see retry_with_s0 */
 #define BOWGPU_SHARD_PASS_DECLINED 1   /* bowgpu_shard_pass_begin: nothing was enqueued (not an error); bowgpu_shard_finish runs the pass */
 
-/* global_s0: NULL on the first attempt. */
+/* Columns and outputs of the three calls below: any residency since ABI 5.  Host-resident ones are staged through HBM per call
+ * the way bowgpu_rolling_aggregate stages them (so begin + pass_begin move each column over PCIe twice, once for the record and
+ * once for the pass; a pass put in flight keeps its staged copies until bowgpu_shard_finish collects it).  The one-call-per-phase
+ * building blocks above (bowgpu_shard_aggregate, _fix_first, _shard_span) keep taking device memory only.
+ * global_s0: NULL on the first attempt. */
 int bowgpu_shard_begin(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval,
                        const bowgpu_options *opts, const bowgpu_agg *aggs, int32_t naggs,
                        const int64_t *global_s0, bowgpu_shard_record *record);
@@ -588,7 +592,7 @@ int bowgpu_shard_pass_begin(const bowgpu_col *cols, int32_t ncols, int32_t ts_co
 /* Pure host arithmetic on the gathered records (no device, no column data): usable from any process. */
 int bowgpu_shard_plan(const bowgpu_shard_record *records, int32_t world, int32_t rank, int64_t interval,
                       int64_t raw_offset, bowgpu_shard_decision *out);
-/* The rank's pass + stitch.  outs: device-resident, capacity >= (last_ts - first_ts) / interval + 2 + lead (or simply
+/* The rank's pass + stitch.  outs: any residency (the ones given to bowgpu_shard_pass_begin), capacity >= (last_ts - first_ts) / interval + 2 + lead (or simply
  * global W).  Returns 0, BOWGPU_SHARD_RETRY, or a negative error. */
 int bowgpu_shard_finish(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval,
                         const bowgpu_options *opts, const bowgpu_agg *aggs, int32_t naggs, bowgpu_out *outs,

@@ -20,17 +20,18 @@ TW_AGGS = [("WindowStart", 0), ("IntegralStep", 1), ("WeightedAverageStep", 1), 
            ("ArithmeticMean", 1), ("Count", 1), ("Last", 1), ("NumRows", 1)]
 
 
-def run_sharded(ts, vals, valid, bounds, interval, offset=0, aggs=None, strict_order=False):
-    """bounds: row boundaries [0, b1, ..., n] of the simulated ranks"""
+def run_sharded(ts, vals, valid, bounds, interval, offset=0, aggs=None, strict_order=False, host=False):
+    """bounds: row boundaries [0, b1, ..., n] of the simulated ranks; host: the shards' columns and outputs live in host memory"""
     AGGS = aggs if aggs is not None else globals()["AGGS"]
     world = len(bounds) - 1
     provs = []
     for r in range(world):
         a, b = bounds[r], bounds[r + 1]
         bm = None if valid is None else np.packbits(valid[a:b], bitorder="little")
-        cols = [capi.Column(ts[a:b].copy(), None, capi.INT64).to_device(),
-                capi.Column(vals[a:b].copy(), bm, capi.FLOAT64 if vals.dtype == np.float64 else capi.INT64, 0, b - a, -1).to_device()]
-        provs.append(sharded.GpuProvider(cols, 0, interval, AGGS, offset=offset, strict_order=strict_order))
+        cols = [capi.Column(ts[a:b].copy(), None, capi.INT64), capi.Column(vals[a:b].copy(), bm, capi.FLOAT64 if vals.dtype == np.float64 else capi.INT64, 0, b - a, -1)]
+        if not host:
+            cols = [c_.to_device() for c_ in cols]
+        provs.append(sharded.GpuProvider(cols, 0, interval, AGGS, offset=offset, strict_order=strict_order, out_residency=capi.HOST if host else None))
     decisions = sharded.run_local(provs)
     owned = [(d.first_slot_window_id, d.windows_owned) for d in decisions]
     # assemble the global result from what each rank owns
@@ -114,6 +115,23 @@ def test_sharded_strict_order_is_row_order_across_a_shard_boundary():
     with pytest.raises(capi.BowGpuError) as e:      # ranks of 100 rows, windows of ~1000: every window is spread over many ranks
         run_sharded(ts[:2000], vals[:2000], valid[:2000], list(range(0, 2001, 100)), 2000, aggs=AGGS, strict_order=True)
     assert e.value.code == -9 and "three or more shards" in e.value.message
+
+
+def test_sharded_host_resident_columns_and_outputs():
+    """the record protocol on shards whose columns AND outputs live in host memory (round 5; declined before): staged through HBM per
+    call like the unsharded entry points, the pass put in flight by bowgpu_shard_pass_begin keeps its staged copies until
+    bowgpu_shard_finish collects it.  Same bits as the device-resident run, inclusive windows and the exchange of first rows included."""
+    rng = np.random.default_rng(8)
+    n = 30_000
+    ts = np.cumsum(rng.integers(1, 9, n)).astype(np.int64)
+    vals = rng.standard_normal(n)
+    valid = rng.random(n) >= 0.3
+    for aggs in (AGGS, TW_AGGS):
+        for interval, bounds in ((13, [0, 7_000, 7_001, 20_000, n]), (500, [0, 10_000, 10_000, n])):
+            dev, _ = run_sharded(ts, vals, valid, bounds, interval, offset=5, aggs=aggs)
+            hst, _ = run_sharded(ts, vals, valid, bounds, interval, offset=5, aggs=aggs, host=True)
+            for (k, _c), (gv, gm, t1), (hv, hm, t2) in zip(aggs, dev, hst):
+                assert t1 == t2 and np.array_equal(gm, hm) and np.array_equal(gv, hv), (k, interval)
 
 
 def test_sharded_gaps_between_shards():
