@@ -4,6 +4,7 @@ This module is NOT a CPU implementation of anything: every function forwards to 
 library.  If the library is missing or no GPU is present the call raises (BowGpuError /
 OSError); there is no fallback.
 """
+import contextlib
 import ctypes as C
 import os
 
@@ -198,7 +199,7 @@ def check(rc):
 # ------------------------------------------------------------------ test / A-B routing (bowgpu_debug_set_route: per calling thread)
 ROUTE_NO_SIMPLE, ROUTE_FORCE_GENERAL, ROUTE_NO_LONG_ONLY, ROUTE_LONG_CLASSIC, ROUTE_LONG_STREAM_ALL = 1, 2, 4, 8, 16
 ROUTE_SIMPLE_SMALL_LIST, ROUTE_SIMPLE_LARGE_LIST, ROUTE_TW_F64, ROUTE_SIMPLE_PADDED, ROUTE_INTERP_TILE = 32, 64, 128, 256, 512
-ROUTE_PINNED_STAGE, ROUTE_STRICT_ORDER, ROUTE_NO_FUSED, ROUTE_TW_ROWS = 1024, 2048, 4096, 8192
+ROUTE_PINNED_STAGE, ROUTE_STRICT_ORDER, ROUTE_NO_FUSED, ROUTE_TW_ROWS, ROUTE_INTERP_COPIES = 1024, 2048, 4096, 8192, 16384
 
 
 def set_route(mask):
@@ -590,13 +591,32 @@ def rolling_interpolate_aggregate(cols, ts_col, interval, interps, aggs, offset=
     return outs, info
 
 
-def rolling_interpolate(cols, ts_col, interval, interps, offset=0, inclusive=False, out_residency=HOST):
+_interp_out_override = None
+
+
+@contextlib.contextmanager
+def interp_outputs(residency, padded):
+    """tests: every rolling_interpolate() inside allocates its outputs with this residency / capacity rule, whatever it asks for"""
+    global _interp_out_override
+    old, _interp_out_override = _interp_out_override, (residency, padded)
+    try:
+        yield
+    finally:
+        _interp_out_override = old
+
+
+def rolling_interpolate(cols, ts_col, interval, interps, offset=0, inclusive=False, out_residency=HOST, padded=True):
+    """count -> allocate -> fill.  padded: the outputs' capacity is the row count rounded up to 512 rows, i.e. bitmaps of whole
+    64-byte blocks like the Arrow allocator's (memory.NewGoAllocator pads to 64 bytes) - device-resident bitmaps that reach the end of
+    their last 32-bit word are written in place (include/bowgpu.h at bowgpu_rolling_interpolate_fill); False: exactly the rows."""
+    if _interp_out_override is not None:
+        out_residency, padded = _interp_out_override
     opts = Options(offset, int(bool(inclusive)), 0)
     n_out = C.c_int64(0)
     carr, iarr = _cols(cols), _interps(interps)
     check(lib().bowgpu_rolling_interpolate_count(carr, len(cols), ts_col, C.c_int64(interval), C.byref(opts),
                                                  iarr, len(interps), C.byref(n_out)))
-    outs = [OutColumn(n_out.value, out_residency) for _ in interps]
+    outs = [OutColumn((n_out.value + 511) // 512 * 512 if padded else n_out.value, out_residency) for _ in interps]
     oarr = (Out * max(len(interps), 1))()
     for i, o in enumerate(outs):
         oarr[i] = o.c()

@@ -625,8 +625,7 @@ int plan_make(Ctx *c, const bowgpu_col *ts, int64_t interval, int64_t raw_offset
             int64_t *hp;
             BG_TRY(ctx_pinned(c, 4096, reinterpret_cast<void **>(&hp)));
             hp += 256;  // bytes 2048.. of the pinned block
-            BG_HIP(hipMemcpyAsync(hp, base, 8, hipMemcpyDeviceToHost, c->stream));
-            BG_HIP(hipMemcpyAsync(hp + 1, base + (n - 1), 8, hipMemcpyDeviceToHost, c->stream));
+            BG_TRY(launch_fetch_two(c, base, 0, n - 1, hp));   // (the kernel stores into the registered block)
             BG_HIP(hipStreamSynchronize(c->stream));
             first = hp[0]; last = hp[1];
         } else {

@@ -70,7 +70,7 @@ struct Ctx {
         bool sharded = false;
         int64_t global_s0 = 0, left_ts = 0;
         int has_left = 0;
-        uint64_t gen = 0;                   // pool_gen of the prefix block when it was written
+        uint64_t gen = 0, gen0 = 0;         // pool_gen of the two prefix blocks when they were written
         uint64_t epoch = 0;                 // device_write_epoch() when it was written: any write / free through the library since then drops it
         int64_t s0 = 0, W = 0, first_ts = 0, last_ts = 0, offset_norm = 0, kq = -1, drop = 0, M = 0, wbase = 0;
         int kq_empty = 0, inclusive = 0, e0 = 0;
@@ -312,6 +312,7 @@ struct BitmapBatch {
 int launch_preset_bitmaps(Ctx *c, const BitmapBatch &b);
 int launch_finish_bitmaps(Ctx *c, const BitmapBatch &b);
 int launch_popcount(Ctx *c, const uint32_t *words, int64_t bit0, int64_t nbits, uint64_t *d_count);
+int launch_fetch_two(Ctx *c, const int64_t *col, int64_t i0, int64_t i1, int64_t *host_out);   // host_out: registered host memory
 
 // mode.hip: one aggregation.Mode output over the windows whose first rows are first_idx[0 .. W]
 int launch_mode(Ctx *c, const int64_t *ts, const int64_t *first_idx, int64_t n, int64_t s0, int64_t interval, int64_t W, int pre_rows,
@@ -418,7 +419,8 @@ struct InterpParams {
     const int64_t *ts;
     int64_t n, s0, interval, W;
     MagicDiv magic;
-    const int64_t *tile_exact_before;  // per tile of interpolate.hip: exact heads in all earlier tiles
+    const int32_t *tile_local;         // pass 1 of interpolate.hip: per 256 rows, the exact heads in the earlier rows of the same super-tile
+    const int64_t *super_before;       // ... and per super-tile of kInterpSuperRows rows, the exact heads in all earlier super-tiles
     uint32_t *status;                  // [0] |= 1: interval column not ascending; [1]: window kq has no row of its own
     int64_t kq;                        // index of the window that starts at -1 (the reference's "no first value" sentinel), else -1
     int64_t drop;                      // leading rows that belong to no window (interp_quirk_kernel), normally 0
@@ -432,14 +434,23 @@ struct InterpParams {
     int32_t inclusive, e0;             // Options.Inclusive (interp_wave2 / wave3 kernels only); e0: row 0 sits exactly on the first window's start
     int64_t n_out;                     // rows the call is to produce (n + what the count pass found): interp_wave3_kernel's last trip checks that it ends there
     uint64_t *edge_words;              // interp_wave3_kernel: [ncols][trips of 512 rows] - a trip's bits of the bitmap word it shares with the trip before it
+    uint32_t *trip_valid;              // interp_wave3_kernel: [ncols][trips] valid outputs per trip (nullptr: not kept - a pass over the bitmaps counts them)
+    unsigned long long *valid_counts;  // ... summed by interp_edge_fix_kernel into [ncols][kInterpEdgeBlocks] partial counts
+    uint32_t *host_status;             // in place: registered host memory that interp_edge_fix_kernel copies the 16 status words into (valid_counts then lies there too)
+    int32_t in_place, _pad_ip;         // out_valid_words ARE the caller's bitmaps and nobody zeroed them: every word of [0, n_out) gets stored
     InterpCol cols[kMaxCols];
 };
 int64_t interp_tiles(int64_t n);
 bool interp_fast32(const Plan &plan, int64_t kq);
 bool interp_wide32(const Plan &plan, int64_t kq);   // ... without the bound on the frame's span: 32-bit arithmetic relative to each trip
 void interp_magic32(int64_t interval, uint32_t *m, uint32_t *sh1, uint32_t *sh2);
+constexpr int kInterpSuperRows = 8192;
+constexpr int kInterpEdgeBlocks = 128;   // interp_edge_fix_kernel: workgroups (= partial valid-output counts) per column
+int64_t interp_supers(int64_t n);
+// pass 1: tile_local [ceil(n/256)] + super_sum [supers] (scratch) + super_before [supers + 1] + *d_total; two launches
 int launch_interp_count(Ctx *c, const int64_t *ts, int64_t n, const Plan &plan, int64_t kq, int has_left, int64_t left_ts,
-                        int32_t *tile_exact, uint32_t *status);
+                        int32_t *tile_local, int32_t *super_sum, int64_t *super_before, int64_t *d_total, uint32_t *status,
+                        int64_t *host_back /* registered host memory: [0] total, [1], [2] the four status words */);
 int launch_interp_tiles(Ctx *c, const InterpParams &p);
 bool interp_takes_wave3(const InterpParams &p);   // (with p.allow_wave2 set) - that kernel needs no neighbour index on its first attempt
 enum { kFillLinear = -1 };  // FillParams::method; >= 0: BOWGPU_FILL_PREVIOUS / NEXT / MEAN

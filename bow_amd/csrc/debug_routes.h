@@ -15,5 +15,6 @@ enum {
     BOWGPU_ROUTE_INTERP_TILE = 512,      // Interpolate (exclusive windows): interp_tile_kernel instead of interp_wave3_kernel
     BOWGPU_ROUTE_NO_FUSED = 4096,        // bowgpu_rolling_interpolate_aggregate: the two calls through device temporaries even where rolling_fused_kernel applies
     BOWGPU_ROUTE_TW_ROWS = 8192,         // time-weighted reducers on a nullable column: rolling_tw_kernel's row-space form even where rolling_twc_kernel (valid points compacted) applies
-    BOWGPU_ROUTE__ALL = 16383            // every defined bit, the two public ones (1024, 2048) included
+    BOWGPU_ROUTE_INTERP_COPIES = 16384,  // Interpolate: output bitmaps through the zeroed working copies + the counting pass even where interp_wave3_kernel could write them in place
+    BOWGPU_ROUTE__ALL = 32767            // every defined bit, the two public ones (1024, 2048) included
 };

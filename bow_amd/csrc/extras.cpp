@@ -139,7 +139,7 @@ struct InterpJob {
     Plan plan;
     DevCol dts;
     std::vector<DevCol> dcols;
-    void *tile_exact = nullptr, *tile_before = nullptr, *block_sums = nullptr;  // context pool (no hipMalloc / hipFree per call)
+    void *tile_local = nullptr, *super_before = nullptr, *super_sum = nullptr;  // context pool (no hipMalloc / hipFree per call)
     int64_t kq = -1;  // window whose start is -1 (InterpParams::kq)
     int64_t drop = 0; // leading rows that belong to no window (InterpParams::drop)
     int64_t M = 0;    // output rows - input rows
@@ -160,12 +160,12 @@ static bool interp_cache_hit(Ctx *c, const bowgpu_col *ts, int64_t interval, int
     if (k.sharded != (global_s0 != nullptr) || k.inclusive != (inclusive ? 1 : 0)) return false;
     if (global_s0 && (k.global_s0 != *global_s0 || k.has_left != ((edge && edge->has_left) ? 1 : 0) || (k.has_left && k.left_ts != edge->left_last_ts))) return false;
     if (k.epoch != device_write_epoch()) return false;   // something was written to / freed from device memory through the library since the count
-    return k.gen == c->pool_gen[kPoolInterp + 1] && c->pool[kPoolInterp + 1] != nullptr;
+    return k.gen == c->pool_gen[kPoolInterp + 1] && c->pool[kPoolInterp + 1] != nullptr && k.gen0 == c->pool_gen[kPoolInterp + 0] && c->pool[kPoolInterp + 0] != nullptr;
 }
 
 static int interp_prepare(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval,
                           const bowgpu_options *o, InterpJob *job, const int64_t *global_s0 = nullptr, const bowgpu_interp_edge *edge = nullptr,
-                          bool use_cache = false) {
+                          bool use_cache = false, const Plan *probe = nullptr) {
     // The _fill call right after _count on the same device-resident, unchanged interval column (Bows are immutable in the
     // reference; include/bowgpu.h, "Rolling.Interpolate", states the contract): pass 1's prefix is still in the context pool.  A
     // write or free THROUGH the library in between drops it (device_write_epoch); the fill kernel checks the output count it
@@ -178,14 +178,16 @@ static int interp_prepare(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t
         job->plan.first_ts = k.first_ts; job->plan.last_ts = k.last_ts; job->plan.magic = magic_make((uint64_t)interval);
         job->kq = k.kq; job->drop = k.drop; job->M = k.M; job->wbase = k.wbase; job->has_left = k.has_left; job->left_ts = k.left_ts;
         job->kq_empty = k.kq_empty; job->e0 = k.e0;
-        job->tile_before = c->pool[kPoolInterp + 1];
+        job->tile_local = c->pool[kPoolInterp + 0];
+        job->super_before = c->pool[kPoolInterp + 1];
         job->from_cache = true;
         BG_TRY(ts_device(c, &cols[ts_col], &job->dts));
         c->interp_cache.valid = false;   // one use: the outputs of this fill may be what the next call reads
         return 0;
     }
     c->interp_cache.valid = false;
-    BG_TRY(plan_make(c, &cols[ts_col], interval, o->offset, &job->plan));
+    if (probe) job->plan = *probe;   // (the caller's constructor checks already fetched the column's first and last timestamp: one round trip, not two)
+    else BG_TRY(plan_make(c, &cols[ts_col], interval, o->offset, &job->plan));
     if (global_s0) {
         // a shard: windows are counted from the frame's s0; the shard accounts for the windows after its left neighbours' last one
         Plan &pl = job->plan;
@@ -218,23 +220,24 @@ static int interp_prepare(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t
         if (k < W) job->kq = k;
     }
     const int64_t ntiles = 2 * interp_tiles(n);   // exact heads are counted per 256 rows: two entries per tile of the count kernel
-    BG_TRY(ctx_pool(c, kPoolInterp + 0, (size_t)ntiles * 4 + 16, &job->tile_exact));
-    BG_TRY(ctx_pool(c, kPoolInterp + 1, (size_t)(ntiles + 1) * 8, &job->tile_before));
-    BG_TRY(ctx_pool(c, kPoolInterp + 2, (size_t)((ntiles + 2047) / 2048 + 1) * 8, &job->block_sums));
+    const int64_t nsuper = interp_supers(n);
+    BG_TRY(ctx_pool(c, kPoolInterp + 0, (size_t)ntiles * 4 + 16, &job->tile_local));
+    BG_TRY(ctx_pool(c, kPoolInterp + 1, (size_t)(nsuper + 1) * 8, &job->super_before));
+    BG_TRY(ctx_pool(c, kPoolInterp + 2, (size_t)nsuper * 4 + 16, &job->super_sum));
     void *dscr;
     BG_TRY(ctx_scratch(c, 8192, &dscr));
     uint32_t *status = reinterpret_cast<uint32_t *>(dscr);
-    int64_t *d_total = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(dscr) + 512);
     BG_HIP(hipMemsetAsync(status, 0, 64, c->stream));
     const int64_t *ts = reinterpret_cast<const int64_t *>(job->dts.values);
-    BG_TRY(launch_interp_count(c, ts, n, pl, job->kq, job->has_left, job->left_ts, reinterpret_cast<int32_t *>(job->tile_exact), status));
-    BG_TRY(launch_exclusive_scan(c, reinterpret_cast<const int32_t *>(job->tile_exact), ntiles, reinterpret_cast<int64_t *>(job->tile_before),
-                                 reinterpret_cast<int64_t *>(job->block_sums), d_total));
-    uint32_t hstat[4];
-    int64_t total = 0;
-    BG_HIP(hipMemcpyAsync(hstat, status, 16, hipMemcpyDeviceToHost, c->stream));
-    BG_HIP(hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, c->stream));
+    int64_t *d_total = reinterpret_cast<int64_t *>(status + 4);
+    int64_t *hback;   // the pass' findings arrive in the registered block by the scan kernel's own stores
+    BG_TRY(ctx_pinned(c, 16384, reinterpret_cast<void **>(&hback)));
+    hback += 384;     // bytes 3072.. of it
+    BG_TRY(launch_interp_count(c, ts, n, pl, job->kq, job->has_left, job->left_ts, reinterpret_cast<int32_t *>(job->tile_local),
+                               reinterpret_cast<int32_t *>(job->super_sum), reinterpret_cast<int64_t *>(job->super_before), d_total, status, hback));
     BG_HIP(hipStreamSynchronize(c->stream));
+    const uint32_t hstat[4] = {(uint32_t)(uint64_t)hback[1], (uint32_t)((uint64_t)hback[1] >> 32), (uint32_t)(uint64_t)hback[2], (uint32_t)((uint64_t)hback[2] >> 32)};
+    const int64_t total = hback[0];
     if (hstat[0]) return fail(BOWGPU_ERR_TS_UNSORTED, "interval column is not ascending: outside the device path");
     job->drop = (int64_t)(((uint64_t)hstat[3] << 32) | hstat[2]);
     job->kq_empty = hstat[1] ? 1 : 0;
@@ -259,6 +262,7 @@ static int interp_prepare(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t
         k.sharded = global_s0 != nullptr; k.global_s0 = global_s0 ? *global_s0 : 0;
         k.has_left = job->has_left; k.left_ts = job->left_ts;
         k.gen = c->pool_gen[kPoolInterp + 1];
+        k.gen0 = c->pool_gen[kPoolInterp + 0];
         k.epoch = device_write_epoch();
         k.s0 = pl.s0; k.W = pl.W; k.first_ts = pl.first_ts; k.last_ts = pl.last_ts; k.offset_norm = pl.offset;
         k.kq = job->kq; k.drop = job->drop; k.M = job->M; k.wbase = job->wbase; k.kq_empty = job->kq_empty;
@@ -276,14 +280,15 @@ static int interp_prepare(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t
 // costs more than the 0.16 ms count pass it replaces; not kept.)  Taken for the shapes interp_wave3_kernel serves on its own: the
 // whole frame (no shard), no -1 sentinel window, no rows below s0.  *applies = false: the two-pass path (interp_prepare).
 static int interp_onepass_prepare(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval, const bowgpu_options *o,
-                                  InterpJob *job, bool *applies) {
+                                  InterpJob *job, bool *applies, const Plan *probe = nullptr) {
     *applies = false;
     if (!o->inclusive) return 0;
     const int64_t n = cols[ts_col].length;
     if (n <= 0) return 0;
     for (int i = 0; i < ncols; i++)
         if (cols[i].length != n) return fail(BOWGPU_ERR_ARG, "column %d has a different length", i);
-    BG_TRY(plan_make(c, &cols[ts_col], interval, o->offset, &job->plan));
+    if (probe) job->plan = *probe;
+    else BG_TRY(plan_make(c, &cols[ts_col], interval, o->offset, &job->plan));
     const Plan &pl = job->plan;
     if (pl.W <= 0 || pl.first_ts < pl.s0 || pl.s0 <= -1) return 0;   // (s0 <= -1: a window may start at -1 - the reference's sentinel)
     if (!(interp_fast32(pl, -1) || interp_wide32(pl, -1))) return 0;
@@ -312,7 +317,7 @@ static int interp_count_impl(const bowgpu_col *cols, int32_t ncols, int32_t ts_c
     Ctx *c;
     BG_TRY(ctx_get(&c));
     InterpJob job;
-    BG_TRY(interp_prepare(c, cols, ncols, ts_col, interval, &o, &job, global_s0, edge));
+    BG_TRY(interp_prepare(c, cols, ncols, ts_col, interval, &o, &job, global_s0, edge, false, &probe));
     *n_out = cols[ts_col].length + job.M;
     return 0;
 }
@@ -327,10 +332,8 @@ static int interp_fill_impl(const bowgpu_col *cols, int32_t ncols, int32_t ts_co
     if (opts) o = *opts;
     Ctx *c = nullptr;
     const bool cached = cols[ts_col].length > 0 && ctx_get(&c) == 0 && interp_cache_hit(c, &cols[ts_col], interval, o.offset, o.inclusive, global_s0, edge);
-    if (!cached) {   // (the _count call that filled the cache ran these checks on the same arguments)
-        Plan probe;
-        BG_TRY(plan_make(nullptr, &cols[ts_col], interval, o.offset, &probe));
-    }
+    Plan probe;
+    if (!cached) BG_TRY(plan_make(nullptr, &cols[ts_col], interval, o.offset, &probe));   // (the _count call that filled the cache ran these checks on the same arguments)
     BG_TRY(interp_validate(cols, ncols, ts_col, &o, interps, ninterps));
     const int64_t n = cols[ts_col].length;
     if (n == 0) {
@@ -341,8 +344,8 @@ static int interp_fill_impl(const bowgpu_col *cols, int32_t ncols, int32_t ts_co
     c->last_slow_rows = 0;
     InterpJob job;
     bool onepass = false;
-    if (!cached && !global_s0 && !edge) BG_TRY(interp_onepass_prepare(c, cols, ncols, ts_col, interval, &o, &job, &onepass));
-    if (!onepass) BG_TRY(interp_prepare(c, cols, ncols, ts_col, interval, &o, &job, global_s0, edge, true));
+    if (!cached && !global_s0 && !edge) BG_TRY(interp_onepass_prepare(c, cols, ncols, ts_col, interval, &o, &job, &onepass, &probe));
+    if (!onepass) BG_TRY(interp_prepare(c, cols, ncols, ts_col, interval, &o, &job, global_s0, edge, true, cached ? nullptr : &probe));
     const int64_t n_out = n + job.M;
     if (n_out == 0) {
         for (int i = 0; i < ninterps; i++) { outs[i].length = 0; outs[i].null_count = 0; outs[i].type = cols[i].type; }
@@ -356,7 +359,8 @@ static int interp_fill_impl(const bowgpu_col *cols, int32_t ncols, int32_t ts_co
     BG_TRY(ctx_scratch(c, 8192, &dscr));
     P.ts = reinterpret_cast<const int64_t *>(job.dts.values);
     P.n = n; P.s0 = job.plan.s0; P.interval = job.plan.interval; P.W = job.plan.W; P.magic = job.plan.magic;
-    P.tile_exact_before = reinterpret_cast<const int64_t *>(job.tile_before);
+    P.tile_local = reinterpret_cast<const int32_t *>(job.tile_local);
+    P.super_before = reinterpret_cast<const int64_t *>(job.super_before);
     P.status = reinterpret_cast<uint32_t *>(dscr);
     P.kq = job.kq;
     P.kq_empty = job.kq_empty;
@@ -368,30 +372,52 @@ static int interp_fill_impl(const bowgpu_col *cols, int32_t ncols, int32_t ts_co
     if (P.fast32 || P.wide32) interp_magic32(job.plan.interval, &P.m32, &P.sh1_32, &P.sh2_32);
     P.ts_col = ts_col;
     P.n_out = n_out;
-    {   // one word per 512-row trip and column of a launch (at most kMaxCols columns per launch)
+    const int64_t ntrips512 = (n + 511) / 512;
+    {   // one word per 512-row trip and column of a launch (at most kMaxCols columns per launch), and one valid-output count
         void *ew;
-        BG_TRY(ctx_pool(c, kPoolInterpEdge, (size_t)((n + 511) / 512) * kMaxCols * 8 + 64, &ew));
+        BG_TRY(ctx_pool(c, kPoolInterpEdge, (size_t)ntrips512 * kMaxCols * 12 + 64, &ew));
         P.edge_words = reinterpret_cast<uint64_t *>(ew);
     }
+    uint32_t *trip_valid = reinterpret_cast<uint32_t *>(P.edge_words + ntrips512 * kMaxCols);
+    // Device-resident outputs whose bitmaps can take whole 32-bit words - a 4-byte aligned pointer and a capacity that reaches the end
+    // of the word holding row n_out - 1 - are WRITTEN IN PLACE by interp_wave3_kernel, which stores every word of [0, n_out) itself
+    // and counts the valid outputs per trip: no launch that zeroes the bitmaps in front of it and no pass over them behind it (round 4:
+    // preset + finish, 41 us of 1.0 ms at 1e8 rows).  Anything else - a host-resident output, an odd pointer, a capacity of exactly
+    // n_out rows that ends mid-word, the workgroup kernel - keeps the working copies from the context pool and those two launches.
+    bool can_place = true;
     for (int i = 0; i < ncols; i++) {
         DevCol &dc = job.dcols[i];
         if (i == ts_col) { dc.values = job.dts.values; dc.length = n; dc.type = BOWGPU_INT64; }
         else BG_TRY(devcol_prepare(c, &cols[i], &dc, true, true));
         BG_TRY(devout_prepare(c, &outs[i], n_out, &douts[i], i < 16 ? i : -1));  // validity working copy from the context pool
+        can_place = can_place && outs[i].residency == BOWGPU_DEVICE && (reinterpret_cast<uintptr_t>(outs[i].validity) & 3) == 0 &&
+                    ((outs[i].length + 7) >> 3) >= 4 * ((n_out + 31) >> 5);
     }
     std::vector<uint64_t> hcnt(ninterps, 0);
     uint32_t hstat[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long *dcnt = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(dscr) + 1024);
     // The output positions depend on the interval column alone, so the columns go through the kernel kMaxCols at a time (a Bow
-    // of any width: interpolation.go:98-161 loops over the interpolators).  Per batch: ONE launch zeroes the batch's bitmaps (and,
-    // first batch, the status words), the kernel, ONE launch counts the valid bits and copies the bitmaps into the caller's buffers.
+    // of any width: interpolation.go:98-161 loops over the interpolators).  Per batch, in place: the kernel + the edge fix (which
+    // also sums the counts); through working copies: ONE launch zeroes the batch's bitmaps (and, first batch, the status words), the
+    // kernel(s), ONE launch counts the valid bits and copies the bitmaps into the caller's buffers.
     // (with_index: the neighbour index of each nullable column under Linear / StepPrevious - three small launches per column.
     // interp_wave3_kernel finds a synthetic row's neighbour points by a bounded walk and says so when one lies further away
     // (status[7]): the index is built for the workgroup kernel and for that repeat only.)
     auto run_all = [&](int allow_wave2, bool with_index) -> int {
         P.allow_wave2 = allow_wave2;
+        const bool place = can_place && interp_takes_wave3(P) && !(route_mask() & BOWGPU_ROUTE_INTERP_COPIES);
+        P.in_place = place ? 1 : 0;
+        P.trip_valid = place ? trip_valid : nullptr;
+        char *hp;
+        BG_TRY(ctx_pinned(c, 16384, reinterpret_cast<void **>(&hp)));
+        // (in place: kInterpEdgeBlocks partial counts per column of the batch, every one of them stored - by interp_edge_fix_kernel, straight
+        // into the host's registered block, the status words in front of them: no copy command behind the launches)
+        P.valid_counts = place ? reinterpret_cast<unsigned long long *>(hp + 1024) : dcnt;
+        P.host_status = place ? reinterpret_cast<uint32_t *>(hp) : nullptr;
+        static_assert(1024 + 8 * (size_t)kMaxCols * kInterpEdgeBlocks <= 16384, "the registered block holds the status words and the partial counts");
         for (int b0 = 0; b0 < ncols; b0 += kMaxCols) {
             const int nb = ncols - b0 < kMaxCols ? ncols - b0 : kMaxCols;
+            const bool last_batch = b0 + nb == ncols;
             P.ncols = nb;
             BitmapBatch bb;
             memset(&bb, 0, sizeof bb);
@@ -407,7 +433,7 @@ static int interp_fill_impl(const bowgpu_col *cols, int32_t ncols, int32_t ts_co
                 ic.has_prev = interps[i].has_prev_row; ic.prev_t_valid = interps[i].prev_t_valid; ic.prev_v_valid = interps[i].prev_v_valid;
                 ic.prev_t = interps[i].prev_t; ic.prev_v = interps[i].prev_v; ic.prev_v_i64 = interps[i].prev_v_i64;
                 ic.out_values = reinterpret_cast<uint64_t *>(douts[i].values);
-                ic.out_valid_words = reinterpret_cast<uint32_t *>(douts[i].validity);
+                ic.out_valid_words = reinterpret_cast<uint32_t *>(place ? outs[i].validity : douts[i].validity);
                 if (edge && edge->next_valid[i]) { ic.next_valid = 1; ic.next_t = edge->next_t[i]; ic.next_v = edge->next_v[i]; }
                 if (with_index && dc.vbits && (ic.kind == BOWGPU_INTERP_LINEAR || ic.kind == BOWGPU_INTERP_STEP_PREVIOUS)) {
                     void *ix;
@@ -419,14 +445,26 @@ static int interp_fill_impl(const bowgpu_col *cols, int32_t ncols, int32_t ts_co
                 bb.ones[j] = 0;
                 bb.count[j] = 1;
             }
-            BG_TRY(launch_preset_bitmaps(c, bb));
+            if (place) { if (b0 == 0) BG_HIP(hipMemsetAsync(P.status, 0, 64, c->stream)); }   // (the status words; the partial counts are all stored)
+            else BG_TRY(launch_preset_bitmaps(c, bb));
             BG_TRY(launch_interp_tiles(c, P));
             if (!interp_takes_wave3(P) && b0 == 0) c->last_slow_rows += n;   // (interp_tile_kernel: 2.2 ms per 1e8 rows where interp_wave3_kernel takes 1.15)
-            BG_TRY(launch_finish_bitmaps(c, bb));
-            BG_HIP(hipMemcpyAsync(&hcnt[b0], dcnt, 8 * (size_t)nb, hipMemcpyDeviceToHost, c->stream));
+            if (!place) BG_TRY(launch_finish_bitmaps(c, bb));
+            // the batch's counts - and, behind the last batch, the status words in front of them: one copy
+            if (!place) {
+                if (last_batch) BG_HIP(hipMemcpyAsync(hp, P.status, 1024 + 8 * (size_t)nb, hipMemcpyDeviceToHost, c->stream));
+                else BG_HIP(hipMemcpyAsync(hp + 1024, dcnt, 8 * (size_t)nb, hipMemcpyDeviceToHost, c->stream));
+            }
+            BG_HIP(hipStreamSynchronize(c->stream));   // (per batch: the pinned block is read before the next batch's copy lands in it)
+            const unsigned long long *hc = reinterpret_cast<const unsigned long long *>(hp + 1024);
+            for (int j = 0; j < nb; j++) {
+                unsigned long long v = 0;
+                if (place) for (int k = 0; k < kInterpEdgeBlocks; k++) v += hc[j * kInterpEdgeBlocks + k];
+                else v = hc[j];
+                hcnt[b0 + j] = v;
+            }
+            if (last_batch) memcpy(hstat, hp, sizeof hstat);
         }
-        BG_HIP(hipMemcpyAsync(hstat, P.status, sizeof hstat, hipMemcpyDeviceToHost, c->stream));
-        BG_HIP(hipStreamSynchronize(c->stream));
         return 0;
     };
     P.allow_wave2 = 1;
@@ -446,7 +484,8 @@ static int interp_fill_impl(const bowgpu_col *cols, int32_t ncols, int32_t ts_co
         InterpJob fresh;
         BG_TRY(interp_prepare(c, cols, ncols, ts_col, interval, &o, &fresh, global_s0, edge, false));
         if (n + fresh.M != n_out) return fail(BOWGPU_ERR_ARG, "Interpolate: the interval column changed between bowgpu_rolling_interpolate_count and _fill");
-        P.tile_exact_before = reinterpret_cast<const int64_t *>(fresh.tile_before);
+        P.tile_local = reinterpret_cast<const int32_t *>(fresh.tile_local);
+        P.super_before = reinterpret_cast<const int64_t *>(fresh.super_before);
         P.kq = fresh.kq; P.kq_empty = fresh.kq_empty; P.drop = fresh.drop; P.e0 = fresh.e0;
         P.s0 = fresh.plan.s0; P.W = fresh.plan.W;
     }

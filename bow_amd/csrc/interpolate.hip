@@ -27,7 +27,7 @@ namespace {
 constexpr int kIR = 2;              // consecutive rows per thread (one 16-B load per lane and column)
 constexpr int kITile = 512;         // rows per workgroup (1 wavefront x 128 rows: 3.6 ms per call, 4 x 128: 2.75, 8 x 128: 2.75)
 constexpr int kIThreads = 256;
-constexpr int kCountThreads = 256;  // interp_count_kernel: four tiles (wavefronts) per workgroup
+constexpr int kCountThreads = 1024; // interp_count_kernel: sixteen tiles (wavefronts) per workgroup = one super-tile of kInterpSuperRows rows
 constexpr int kIStage = 1024;       // outputs of one column staged in LDS per tile (rows + synthetic rows)
 constexpr int kISpanWords = 128;    // output validity bits staged in LDS per column: 4096 bits (rows + synthetic rows of a tile)
 constexpr int kLongRuns = 32;       // long runs of empty windows a tile shares among its threads (more: their owners write them)
@@ -118,6 +118,11 @@ __device__ __forceinline__ RowsR rows_flags(const uint64_t (&t)[kIR], int64_t t_
 }
 
 // timestamp left of a thread's first row: the neighbouring lane's last row, LDS across waves, global across tiles
+// exact heads in front of 256-row entry e (pass 1's two-level prefix)
+__device__ __forceinline__ int64_t interp_exact_before(const InterpParams &p, int64_t e) {
+    return p.super_before[e / (kInterpSuperRows / 256)] + (int64_t)p.tile_local[e];
+}
+
 __device__ __forceinline__ int64_t left_ts(const uint64_t (&t)[kIR], const int64_t *ts, int64_t i, int64_t n, long long *wave_last, int tid,
                                            int64_t shard_left_ts) {
     const int lane = tid & 63, wv = tid >> 6;
@@ -129,36 +134,108 @@ __device__ __forceinline__ int64_t left_ts(const uint64_t (&t)[kIR], const int64
     return (int64_t)l;
 }
 
-// exact heads per tile of kITile rows.  One wavefront per tile, no barrier: lane l holds rows 2l, 2l+1 of each of the tile's four
-// 128-row chunks (16-B loads, all in flight at once); the timestamp left of a lane's rows comes from its neighbour lane, from
-// the previous chunk's last lane, or (first chunk) from the row before the tile; the count is two ballots per chunk.
+// exact heads per 256 rows, as an exclusive prefix WITHIN the super-tile of kSuperRows rows that holds them (tile_local), and per
+// super-tile (super_sum; interp_super_scan_kernel turns those into the prefix over the super-tiles - two launches for pass 1
+// where round 4 had four, and 1.5 MB of prefix written where the three-kernel scan wrote and re-read 3 + 1.5).  A workgroup per
+// super-tile, one wavefront per tile of kITile rows: lane l holds rows 2l, 2l+1 of each of the tile's four 128-row chunks (16-B
+// loads, all in flight at once); the timestamp left of a lane's rows comes from its neighbour lane, from the previous chunk's last
+// lane, or (first chunk) from the row before the tile; the count is two ballots per chunk; ONE barrier, behind the loads.
 template <bool kFast>
 __global__ __launch_bounds__(kCountThreads) void interp_count_kernel(const int64_t *ts, int64_t n, int64_t s0, int64_t interval,
                                                                  MagicDiv magic, Magic32 m32, int has_left, int64_t shard_left_ts,
-                                                                 int32_t *tile_exact, uint32_t *status) {
+                                                                 int32_t *tile_local, int32_t *super_sum, uint32_t *status) {
+    __shared__ int32_t sh[2 * (kCountThreads / 64)];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t tile = (int64_t)blockIdx.x * (kCountThreads / 64) + wv;
     const int64_t base = tile * kITile;
-    if (base >= n) return;
-    const bool vec = (reinterpret_cast<uintptr_t>(ts) & 15) == 0;
-    uint64_t t[kITile / 128][kIR];
+    int cnt[2] = {0, 0};   // per 256 rows
+    if (base < n) {
+        const bool vec = (reinterpret_cast<uintptr_t>(ts) & 15) == 0;
+        uint64_t t[kITile / 128][kIR];
 #pragma unroll
-    for (int k = 0; k < kITile / 128; k++) loadR(reinterpret_cast<const uint64_t *>(ts), base + 128 * k + kIR * lane, n, vec, t[k]);
-    int64_t t_before = base > 0 ? ts[base - 1] : shard_left_ts;
-    bool unsorted = false;
-    int cnt[2] = {0, 0};   // per 256 rows: interp_wave2_kernel's short trips start in the middle of a tile
+        for (int k = 0; k < kITile / 128; k++) loadR(reinterpret_cast<const uint64_t *>(ts), base + 128 * k + kIR * lane, n, vec, t[k]);
+        int64_t t_before = base > 0 ? ts[base - 1] : shard_left_ts;
+        bool unsorted = false;
 #pragma unroll
-    for (int k = 0; k < kITile / 128; k++) {
-        const int64_t i = base + 128 * k + kIR * lane;
-        long long tl = __shfl_up((long long)t[k][kIR - 1], 1);
-        if (lane == 0) tl = (long long)t_before;
-        const RowsR f = rows_flags<kFast>(t[k], (int64_t)tl, i, n, s0, interval, magic, m32, -1, has_left != 0, &unsorted);
-        cnt[k >> 1] += __popcll(__ballot(f.exact[0])) + __popcll(__ballot(f.exact[1]));
-        t_before = (int64_t)lane_value(t[k][kIR - 1], 63);
+        for (int k = 0; k < kITile / 128; k++) {
+            const int64_t i = base + 128 * k + kIR * lane;
+            long long tl = __shfl_up((long long)t[k][kIR - 1], 1);
+            if (lane == 0) tl = (long long)t_before;
+            const RowsR f = rows_flags<kFast>(t[k], (int64_t)tl, i, n, s0, interval, magic, m32, -1, has_left != 0, &unsorted);
+            cnt[k >> 1] += __popcll(__ballot(f.exact[0])) + __popcll(__ballot(f.exact[1]));
+            t_before = (int64_t)lane_value(t[k][kIR - 1], 63);
+        }
+        if (__ballot(unsorted) && lane == 0) atomicOr(&status[0], 1u);
     }
-    if (__ballot(unsorted) && lane == 0) atomicOr(&status[0], 1u);
-    if (lane == 0) { tile_exact[2 * tile] = cnt[0]; tile_exact[2 * tile + 1] = cnt[1]; }
+    if (lane == 0) { sh[2 * wv] = cnt[0]; sh[2 * wv + 1] = cnt[1]; }
+    __syncthreads();
+    if (wv == 0) {
+        constexpr int kE = 2 * (kCountThreads / 64);   // entries of a super-tile (<= 64)
+        const int32_t mine = lane < kE ? sh[lane] : 0;
+        int32_t incl = mine;
+#pragma unroll
+        for (int o = 1; o < kE; o <<= 1) {
+            const int32_t up = __shfl_up(incl, o);
+            if (lane >= o) incl += up;
+        }
+        const int64_t e = (int64_t)blockIdx.x * kE + lane;
+        if (lane < kE && e * 256 < n) tile_local[e] = incl - mine;
+        if (lane == kE - 1) super_sum[blockIdx.x] = incl;
+    }
+}
+
+// exclusive prefix of the super-tile sums (one workgroup: n / 8192 sums - 12 k for 1e8 rows), the total behind them.  A thread takes
+// 4 kQ consecutive sums: 16-byte loads, all in flight at once (kQ = 4 serves 1.3e8 rows, 16 serves 5e8; the loop form beyond)
+template <int kQ>
+__global__ __launch_bounds__(1024) void interp_super_scan_kernel(const int32_t *super_sum, int64_t nsuper, int64_t *super_before, int64_t *total,
+                                                                 const uint32_t *status, int64_t *host_back) {
+    __shared__ long long sh[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    long long mine = 0;
+    int32_t x[kQ > 0 ? 4 * kQ : 1];
+    int64_t a, b;
+    if (kQ > 0) {
+        a = (int64_t)tid * 4 * kQ; b = a + 4 * kQ < nsuper ? a + 4 * kQ : nsuper;
+#pragma unroll
+        for (int q = 0; q < kQ; q++) {
+            const int64_t i = a + 4 * q;
+            int4 v = make_int4(0, 0, 0, 0);
+            if (i + 4 <= nsuper) v = *reinterpret_cast<const int4 *>(super_sum + i);   // (the pool block is 256-byte aligned)
+            else { if (i < nsuper) v.x = super_sum[i]; if (i + 1 < nsuper) v.y = super_sum[i + 1]; if (i + 2 < nsuper) v.z = super_sum[i + 2]; }
+            x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 4 * kQ; j++) mine += x[j];
+    } else {
+        const int64_t per = (nsuper + 1023) / 1024;
+        a = (int64_t)tid * per; b = a + per < nsuper ? a + per : nsuper;
+        for (int64_t i = a; i < b; i++) mine += super_sum[i];
+    }
+    long long incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const long long up = __shfl_up(incl, o);
+        if (lane >= o) incl += up;
+    }
+    if (lane == 63) sh[wv] = incl;
+    __syncthreads();
+    long long before = 0;
+    for (int w = 0; w < wv; w++) before += sh[w];
+    long long run = before + incl - mine;
+    if (kQ > 0) {
+#pragma unroll
+        for (int j = 0; j < 4 * kQ; j++) { if (a + j < nsuper) super_before[a + j] = run; run += x[j]; }
+    } else {
+        for (int64_t i = a; i < b; i++) { super_before[i] = run; run += super_sum[i]; }
+    }
+    if (tid == 1023) { super_before[nsuper] = before + incl; *total = before + incl; }
+    // pass 1's findings straight into the host's registered block (the stores go over the link; no copy command behind the launch):
+    // [0] the total, [1] status words 0 | 1 << 32, [2] status words 2 | 3 << 32 - written by the count kernel in front of this one
+    if (host_back) {
+        if (tid == 1023) host_back[0] = before + incl;
+        if (tid < 2) host_back[1 + tid] = (int64_t)((uint64_t)status[2 * tid] | ((uint64_t)status[2 * tid + 1] << 32));
+    }
 }
 
 template <bool kFast>
@@ -191,7 +268,7 @@ __global__ __launch_bounds__(kIThreads) void interp_tile_kernel(const InterpPara
         const uint64_t wp = kFast ? (uint64_t)mdiv32((uint32_t)((uint64_t)tp - (uint64_t)p.s0), m32)
                                   : (tp < p.s0 ? 0 : magic_div((uint64_t)tp - (uint64_t)p.s0, p.magic));
         // (a shard with rows to its left only accounts for the windows after their last one: wbase = that window + 1)
-        o_base = (r0 - (p.drop < r0 ? p.drop : r0)) + (int64_t)wp + 1 - p.wbase - p.tile_exact_before[2 * (int64_t)blockIdx.x];   // (one entry per 256 rows)
+        o_base = (r0 - (p.drop < r0 ? p.drop : r0)) + (int64_t)wp + 1 - p.wbase - interp_exact_before(p, 2 * (int64_t)blockIdx.x);   // (one entry per 256 rows)
         if (kq >= 0 && (uint64_t)kq <= wp) o_base -= 1;
     }
     const int64_t lbase = o_base & ~(int64_t)31;  // LDS bit 0
@@ -451,7 +528,7 @@ __global__ __launch_bounds__(64, 4) void interp_wave3_kernel(const InterpParams 
         toolong |= t_before > ts_first || gap0 >= 0x3FFFFFull;
         // inclusive windows: one extra row in front of every window's first row (synthetic or the copy), but none for an exact row 0
         // (tile_exact_before holds one entry per 256 rows)
-        if (base > 0) o_trip = kIncl ? base + (int64_t)wp + 1 - p.wbase - p.e0 : base + (int64_t)wp + 1 - p.wbase - p.tile_exact_before[trip * (kT3Rows / 256)];
+        if (base > 0) o_trip = kIncl ? base + (int64_t)wp + 1 - p.wbase - p.e0 : base + (int64_t)wp + 1 - p.wbase - interp_exact_before(p, trip * (kT3Rows / 256));
     }
     if (lane < p.ncols) p.edge_words[(int64_t)lane * ntrips + trip] = 0ull;   // (no entry unless a staged flush below leaves one)
 
@@ -461,30 +538,31 @@ __global__ __launch_bounds__(64, 4) void interp_wave3_kernel(const InterpParams 
     int nrun = 0;
     bool unsorted = false;   // (the count pass checks the order too; an inclusive fill on its own - no count pass - has only this check)
     {
-        uint32_t rb_prev = 0;
+        uint32_t wb_prev = 0;
         uint64_t tb_prev = (uint64_t)t_before;
 #pragma unroll
         for (int k = 0; k < kT3Ch; k++) {
             const int64_t i = base + 128 * k + 2 * lane;
             const uint32_t ra = (uint32_t)ta[k] - s0lo, rb = (uint32_t)tb[k] - s0lo;
             rr0[k] = ra; rr1[k] = rb;
-            uint32_t rl = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rb, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-            if (lane == 0) rl = k == 0 ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)rb_prev, 63);
-            rb_prev = rb;
             const bool in0 = i < p.n, in1 = i + 1 < p.n;
             const bool first = i == 0 && !p.has_left;  // the frame's first row has no left neighbour
-            {
+            if (kIncl) {
+                // (exclusive windows: every fill follows a count pass - its own or the _count call's, whose reuse is guarded by the
+                // row-count check below - and interp_count_kernel checks the order; 14 vector instructions per chunk not spent twice)
                 const uint32_t plo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)tb[k], 0x138, 0xf, 0xf, false);
                 const uint32_t phi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(tb[k] >> 32), 0x138, 0xf, 0xf, false);
                 const int64_t tl = lane == 0 ? (int64_t)tb_prev : (int64_t)(((uint64_t)phi << 32) | plo);
                 unsorted |= (in0 && !first && tl > (int64_t)ta[k]) || (in1 && (int64_t)ta[k] > (int64_t)tb[k]);
                 tb_prev = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(tb[k] >> 32), 63) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)tb[k], 63);
             }
-            uint32_t wl = mdiv32(rl, m32);
             const uint32_t wa = mdiv32(ra, m32), wb = mdiv32(rb, m32);
-            // (the trip's first row: its window is local id 0 by construction, the row before it lies gap0 windows further back - ids
-            // are unsigned and wrap, the differences below come out right)
-            if (k == 0 && lane == 0) wl = 0u - (uint32_t)gap0;
+            // the left neighbour's window: the lane below computed it as its wb (a DPP move, not a third division); lane 0 takes the
+            // previous chunk's last - or, the trip's first row: its window is local id 0 by construction, the row before it lies gap0
+            // windows further back (ids are unsigned and wrap, the differences below come out right)
+            uint32_t wl = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wb, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+            if (lane == 0) wl = k == 0 ? 0u - (uint32_t)gap0 : (uint32_t)__builtin_amdgcn_readlane((int)wb_prev, 63);
+            wb_prev = wb;
             const bool head0 = in0 && (first || wa != wl), head1 = in1 && wb != wa;
             const bool exact0 = head0 && ra == wa * i32, exact1 = head1 && rb == wb * i32;
             // rows in front of a head: the empty windows before it + a synthetic row for its own window - or, when the row sits on
@@ -602,12 +680,19 @@ __global__ __launch_bounds__(64, 4) void interp_wave3_kernel(const InterpParams 
         // (the body twice, with `staged` a compile-time constant: the staged form then holds no global store inside a loop - LLVM
         // drains the memory counter in front of a loop that stores and uses registers loaded outside it, which on gfx950, where
         // stores and loads share the counter, is a wait for every store of the previous column's flush)
+        uint32_t nvalid = 0;   // valid outputs of this trip and column: staged - wave-uniform, off the flush's ballots; else per lane
         auto column_body = [&](auto staged_tag) {
         constexpr bool staged = decltype(staged_tag)::value;
         if (staged) {
 #pragma unroll
             for (int i = 0; i < ((kT3Slots + 8) / 8 + 63) / 64; i++)
                 if (lane + 64 * i < (kT3Slots + 8) / 8) *reinterpret_cast<uint64_t *>(&L.fl[8 * (lane + 64 * i)]) = 0ull;
+        } else if (p.in_place) {
+            // nobody zeroed the caller's bitmap: the words this trip owns (all it touches but a first one shared with the trip before,
+            // which that trip stores) start as 0 - agent-scope stores, like the ORs that follow them
+            const int64_t wl = (o_trip + (int64_t)tot - 1) >> 5;
+            for (int64_t w = ((o_trip + 31) >> 5) + lane; w <= wl; w += 64) __hip_atomic_store(&ic.out_valid_words[w], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         }
         if (lane < 2 * kT3Ch) {
             uint64_t x = 0;
@@ -623,6 +708,7 @@ __global__ __launch_bounds__(64, 4) void interp_wave3_kernel(const InterpParams 
             } else {
                 out[pos] = bits;
                 if (valid) {
+                    nvalid++;
                     // (bits of the word shared with the trip before go to this trip's edge entry, like the staged form's: that trip may
                     // store the word plainly)
                     if (sh_o + pos < 32u && sh_o != 0u)
@@ -711,7 +797,10 @@ __global__ __launch_bounds__(64, 4) void interp_wave3_kernel(const InterpParams 
                     uint64_t bits; int valid;
                     if (kIncl && j < jd) { bits = row_bits(al); valid = (int)((L.vw[al >> 6] >> (al & 63)) & 1ull); }
                     else {
-                        const int64_t sk = ws0 + (int64_t)(int32_t)(kfirst - (j - jd)) * p.interval;   // (local ids: -1 is the window before the trip's first)
+                        // (local ids: -1 is the window before the trip's first; the offset of a window start inside the trip fits 32 bits
+                        // like every row's - one 32-bit multiplication)
+                        const int32_t soff = (int32_t)((kfirst - (j - jd)) * i32);
+                        const int64_t sk = ws0 + (int64_t)soff;
                         synth_value_pt(ic, sk, qp, qn, &bits, &valid);
                     }
                     put(orow - 1 - j, bits, valid);
@@ -736,7 +825,8 @@ __global__ __launch_bounds__(64, 4) void interp_wave3_kernel(const InterpParams 
                     uint64_t bits; int valid;
                     if (kIncl && j < jd) { bits = row_bits(al); valid = (int)((L.vw[al >> 6] >> (al & 63)) & 1ull); }
                     else {
-                        const int64_t sk = ws0 + (int64_t)(int32_t)(kfirst - (j - jd)) * p.interval;   // (local ids: -1 is the window before the trip's first)
+                        const int32_t soff = (int32_t)((kfirst - (j - jd)) * i32);
+                        const int64_t sk = ws0 + (int64_t)soff;
                         synth_value_pt(ic, sk, qp, qn, &bits, &valid);
                     }
                     put(orow - 1 - j, bits, valid);
@@ -782,6 +872,7 @@ __global__ __launch_bounds__(64, 4) void interp_wave3_kernel(const InterpParams 
                 {
                 // eight bitmap words: ballot u = slots 64 (2 k2 + u) .. + 63
                 const uint64_t m0 = __ballot(ff[0] != 0u), m1 = __ballot(ff[1] != 0u), m2 = __ballot(ff[2] != 0u), m3 = __ballot(ff[3] != 0u);
+                nvalid += (uint32_t)(__popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3));   // (slots outside the trip's hold 0)
                 if (lane < 8) {
                     const uint64_t mm = (lane >> 1) == 0 ? m0 : (lane >> 1) == 1 ? m1 : (lane >> 1) == 2 ? m2 : m3;
                     const uint32_t x32 = (lane & 1) ? (uint32_t)(mm >> 32) : (uint32_t)mm;
@@ -803,7 +894,12 @@ __global__ __launch_bounds__(64, 4) void interp_wave3_kernel(const InterpParams 
         }
         };   // column_body
         if (staged) column_body(std::true_type{});
-        else column_body(std::false_type{});
+        else {
+            column_body(std::false_type{});
+            for (int o = 32; o > 0; o >>= 1) nvalid += __shfl_down(nvalid, o);
+        }
+        // the column's null count without a pass over its bitmap: one partial per trip, summed by interp_edge_fix_kernel
+        if (p.trip_valid && lane == 0) p.trip_valid[(int64_t)c * ntrips + trip] = nvalid;
         W2_STAMP(3);   // flush
     }
     if (__ballot(far)) {
@@ -819,12 +915,26 @@ __global__ __launch_bounds__(64, 4) void interp_wave3_kernel(const InterpParams 
 
 // the bits the trips of interp_wave3_kernel left for the words they share with the trip before them (one entry per trip and column:
 // word index | bits << 32; 0: nothing).  Two entries never name the same word: a trip in the middle of the frame holds 512 rows.
+// Also the trips' valid-output counts when the kernel kept them, as kEdgeBlocks partial sums per column (plain stores - the host adds
+// them up: 1564 agent-scope adds to two addresses cost 16 us here); blockIdx.y = column, grid-stride over the trips.
 __global__ __launch_bounds__(256) void interp_edge_fix_kernel(const InterpParams p, const int64_t ntrips) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= ntrips * p.ncols) return;
-    const uint64_t e = p.edge_words[i];
-    const uint32_t bits = (uint32_t)(e >> 32);
-    if (bits) p.cols[i / ntrips].out_valid_words[(uint32_t)e] |= bits;
+    __shared__ unsigned long long sh[4];
+    const int c = blockIdx.y;
+    unsigned long long v = 0;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < ntrips; t += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t e = p.edge_words[(int64_t)c * ntrips + t];
+        const uint32_t bits = (uint32_t)(e >> 32);
+        if (bits) p.cols[c].out_valid_words[(uint32_t)e] |= bits;
+        if (p.trip_valid) v += p.trip_valid[(int64_t)c * ntrips + t];
+    }
+    if (!p.trip_valid) return;
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    // (the partial counts and the status words - interp_wave3_kernel's, the launch in front of this one - go straight into the host's
+    // registered block: no copy command behind the launch)
+    if (threadIdx.x == 0) p.valid_counts[c * kInterpEdgeBlocks + blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+    if (blockIdx.x == 0 && c == 0 && threadIdx.x < 16 && p.host_status) p.host_status[threadIdx.x] = p.status[threadIdx.x];
 }
 
 // The two corner cases of the reference's window walk that are not statements about single rows:
@@ -876,21 +986,26 @@ bool interp_wide32(const Plan &plan, int64_t kq) {
 }
 
 int launch_interp_count(Ctx *c, const int64_t *ts, int64_t n, const Plan &plan, int64_t kq, int has_left, int64_t left_ts,
-                        int32_t *tile_exact, uint32_t *status) {
-    const int64_t ntiles = (n + kITile - 1) / kITile;
-    if (ntiles <= 0) return 0;
+                        int32_t *tile_local, int32_t *super_sum, int64_t *super_before, int64_t *d_total, uint32_t *status, int64_t *host_back) {
+    static_assert(kCountThreads / 64 * kITile == kInterpSuperRows, "a workgroup of the count kernel is one super-tile");
+    const int64_t nsuper = interp_supers(n);
+    if (nsuper <= 0) return 0;
     if (kq >= 0 || plan.first_ts < plan.s0)
         hipLaunchKernelGGL(interp_quirk_kernel, dim3(1), dim3(64), 0, c->stream, ts, n, plan.s0, plan.interval, kq, status);
     if (interp_fast32(plan, kq))
-        hipLaunchKernelGGL(interp_count_kernel<true>, dim3((unsigned)((ntiles + 3) / 4)), dim3(kCountThreads), 0, c->stream, ts, n, plan.s0, plan.interval,
-                           plan.magic, magic32_make(plan.interval), has_left, left_ts, tile_exact, status);
+        hipLaunchKernelGGL(interp_count_kernel<true>, dim3((unsigned)nsuper), dim3(kCountThreads), 0, c->stream, ts, n, plan.s0, plan.interval,
+                           plan.magic, magic32_make(plan.interval), has_left, left_ts, tile_local, super_sum, status);
     else
-        hipLaunchKernelGGL(interp_count_kernel<false>, dim3((unsigned)((ntiles + 3) / 4)), dim3(kCountThreads), 0, c->stream, ts, n, plan.s0, plan.interval,
-                           plan.magic, Magic32{0, 0, 0}, has_left, left_ts, tile_exact, status);
+        hipLaunchKernelGGL(interp_count_kernel<false>, dim3((unsigned)nsuper), dim3(kCountThreads), 0, c->stream, ts, n, plan.s0, plan.interval,
+                           plan.magic, Magic32{0, 0, 0}, has_left, left_ts, tile_local, super_sum, status);
+    if (nsuper <= 1024 * 16) hipLaunchKernelGGL(interp_super_scan_kernel<4>, dim3(1), dim3(1024), 0, c->stream, super_sum, nsuper, super_before, d_total, status, host_back);
+    else if (nsuper <= 1024 * 64) hipLaunchKernelGGL(interp_super_scan_kernel<16>, dim3(1), dim3(1024), 0, c->stream, super_sum, nsuper, super_before, d_total, status, host_back);
+    else hipLaunchKernelGGL(interp_super_scan_kernel<0>, dim3(1), dim3(1024), 0, c->stream, super_sum, nsuper, super_before, d_total, status, host_back);
     BG_HIP(hipGetLastError());
     return 0;
 }
 
+int64_t interp_supers(int64_t n) { return (n + kInterpSuperRows - 1) / kInterpSuperRows; }
 int64_t interp_tiles(int64_t n) { return (n + kITile - 1) / kITile; }
 void interp_magic32(int64_t interval, uint32_t *m, uint32_t *sh1, uint32_t *sh2) {
     const Magic32 x = magic32_make(interval);
@@ -918,7 +1033,8 @@ int launch_interp_tiles(Ctx *c, const InterpParams &p) {
         if (!p.edge_words) return fail(BOWGPU_ERR_ARG, "internal: interp_wave3_kernel needs its edge list");
         if (p.inclusive) hipLaunchKernelGGL((interp_wave3_kernel<true>), dim3((unsigned)(per_xcd * 8)), dim3(64), 0, c->stream, p, ntrips, per_xcd);
         else hipLaunchKernelGGL((interp_wave3_kernel<false>), dim3((unsigned)(per_xcd * 8)), dim3(64), 0, c->stream, p, ntrips, per_xcd);
-        hipLaunchKernelGGL(interp_edge_fix_kernel, dim3((unsigned)((ntrips * p.ncols + 255) / 256)), dim3(256), 0, c->stream, p, ntrips);
+        // (kInterpEdgeBlocks workgroups per column whatever the size: the host reads that many partial counts)
+        hipLaunchKernelGGL(interp_edge_fix_kernel, dim3(kInterpEdgeBlocks, (unsigned)p.ncols), dim3(256), 0, c->stream, p, ntrips);
     }
     else if (p.inclusive)   // no other kernel builds inclusive windows: never fall through to an exclusive one
         return fail(BOWGPU_ERR_UNSUPPORTED, "Interpolate on inclusive windows: this shape is outside the device path");

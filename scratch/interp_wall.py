@@ -19,7 +19,10 @@ def count():
     capi.check(L.bowgpu_rolling_interpolate_count(carr, 2, 0, C.c_int64(100), C.byref(opts), iarr, 2, C.byref(m)))
     return m.value
 n_out = count()
-outs = [capi.OutColumn(n_out, capi.DEVICE) for _ in ip]
+# (capacity: the rows rounded up to 512, i.e. bitmaps of whole 64-byte blocks as the Arrow allocator hands out - a bitmap that reaches the
+# end of its last 32-bit word is written in place; "exact" as the first argument after the row count: exactly n_out rows of capacity)
+exact = len(sys.argv) > 2 and sys.argv[2] == "exact"
+outs = [capi.OutColumn(n_out if exact else (n_out + 511) // 512 * 512, capi.DEVICE) for _ in ip]
 oarr = (capi.Out * 2)()
 def fill():
     for i, o in enumerate(outs):
@@ -32,7 +35,10 @@ def timeit(fn, reps=10):
         t0 = time.perf_counter(); fn(); capi.synchronize(); t.append((time.perf_counter() - t0) * 1e3)
     t.sort()
     return t[len(t) // 2]
-for label, mask in (("wave3 (default)", 0), ("tile", capi.ROUTE_INTERP_TILE)):
+for _ in range(20):   # (the first dozen launches of a process run 5 % slower than the rest: clocks, page mappings)
+    count(); fill()
+capi.synchronize()
+for label, mask in (("wave3 (default)", 0), ("wave3, bitmap copies", capi.ROUTE_INTERP_COPIES), ("tile", capi.ROUTE_INTERP_TILE)):
     capi.set_route(mask)
     both = timeit(lambda: (count(), fill()))
     c_ms = timeit(count)

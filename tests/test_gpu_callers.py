@@ -36,6 +36,12 @@ def both_interp_kernels(fn):
     for _label, mask in capi.INTERP_ROUTES:
         with capi.route(mask):
             res.append(fn())
+    # ... and under the product kernel with device-resident outputs: bitmaps that reach the end of their last word are written in place
+    # (no zeroing launch in front, the null counts summed from per-trip partials), a capacity of exactly the rows goes through the
+    # working copies unless it happens to end on a word
+    for padded in (True, False):
+        with capi.interp_outputs(capi.DEVICE, padded):
+            res.append(fn())
     a = res[0]
     for b in res[1:]:
         if isinstance(a, list) and a and isinstance(a[0], list):   # one list of columns per shard
