@@ -469,21 +469,19 @@ struct Wave3Lds {
     uint64_t vw[2 * kT3Ch];                   // the current column's validity bits of the trip's rows: row r = bit r & 63 of word r >> 6
 };
 
-template <bool kIncl>
-__global__ __launch_bounds__(64, 4) void interp_wave3_kernel(const InterpParams p, const int64_t ntrips, const int64_t trips_per_xcd) {
-    constexpr int kRuns = kIncl ? kT3Rows : kT3Rows / 4;
-    __shared__ Wave3Lds<kRuns> L;
+// One trip.  kFull: all of its 512 rows exist - every trip but the frame's last; kFull and (below) `staged` are compile-time constants
+// of the column loop so that what LLVM hoists out of that loop is what the USUAL trip needs: with the partial trip's masks and the
+// unstaged form's addresses in the same loop it hoisted - and spilled, one v_writelane each - 233 scalars per wavefront, 114 without.
+template <bool kIncl, bool kFull, int kRuns>
+__device__ __forceinline__ void wave3_trip(const InterpParams &p, const int64_t ntrips, const int64_t trip, Wave3Lds<kRuns> &L) {
     const int lane = threadIdx.x;
 #ifdef BOWGPU_STAMPS
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last) :: "memory");
 #endif
-    const int64_t b = blockIdx.x;
-    const int64_t trip = (b & 7) * trips_per_xcd + (b >> 3);   // XCD-contiguous runs of trips: the rows around a trip's ends are in that XCD's L2
-    if (trip >= ntrips) return;
     const int64_t base = trip * kT3Rows;
     const int64_t left_trip = p.n - base;
-    const bool full = left_trip >= kT3Rows;
+    constexpr bool full = kFull;
     const int nloc = full ? kT3Rows : (int)left_trip;
     const Magic32 m32 = {p.m32, p.sh1_32, p.sh2_32};
     const uint32_t i32 = (uint32_t)p.interval;
@@ -613,7 +611,7 @@ __global__ __launch_bounds__(64, 4) void interp_wave3_kernel(const InterpParams 
         if (lane == 0) atomicOr(&p.status[5], 1u);
         return;
     }
-    const bool staged = tot <= (uint32_t)kT3Stage;
+    const bool staged_rt = tot <= (uint32_t)kT3Stage;
     // The last trip ends where the count pass said the outputs end, and every trip lies inside the outputs - or the interval
     // column is not the one that was counted (a _fill that reuses its _count's prefix: include/bowgpu.h, the contract between the
     // two calls).  Such a trip stores NOTHING: a stale prefix must not become a write outside the caller's buffers.
@@ -637,6 +635,11 @@ __global__ __launch_bounds__(64, 4) void interp_wave3_kernel(const InterpParams 
     bool far = false;   // a neighbour point further away than the index-free walk looks: the host repeats the call with the index (status[7])
 
     // ---- phase 2: one column at a time (the next column's values in flight meanwhile)
+    // (the loop twice, with `staged` a compile-time constant: the staged form then holds no global store inside a loop - LLVM
+    // drains the memory counter in front of a loop that stores and uses registers loaded outside it, which on gfx950, where
+    // stores and loads share the counter, is a wait for every store of the previous column's flush)
+    auto column_loop = [&](auto staged_tag) {
+    constexpr bool staged = decltype(staged_tag)::value;
 #pragma unroll 1
     for (int c = 0; c < p.ncols; c++) {
         const InterpCol &ic = p.cols[c];
@@ -677,12 +680,7 @@ __global__ __launch_bounds__(64, 4) void interp_wave3_kernel(const InterpParams 
             }
         }
         uint64_t *out = ic.out_values + o_trip;
-        // (the body twice, with `staged` a compile-time constant: the staged form then holds no global store inside a loop - LLVM
-        // drains the memory counter in front of a loop that stores and uses registers loaded outside it, which on gfx950, where
-        // stores and loads share the counter, is a wait for every store of the previous column's flush)
         uint32_t nvalid = 0;   // valid outputs of this trip and column: staged - wave-uniform, off the flush's ballots; else per lane
-        auto column_body = [&](auto staged_tag) {
-        constexpr bool staged = decltype(staged_tag)::value;
         if (staged) {
 #pragma unroll
             for (int i = 0; i < ((kT3Slots + 8) / 8 + 63) / 64; i++)
@@ -892,16 +890,14 @@ __global__ __launch_bounds__(64, 4) void interp_wave3_kernel(const InterpParams 
             }
             wave_lds_order();
         }
-        };   // column_body
-        if (staged) column_body(std::true_type{});
-        else {
-            column_body(std::false_type{});
-            for (int o = 32; o > 0; o >>= 1) nvalid += __shfl_down(nvalid, o);
-        }
+        if (!staged) { for (int o = 32; o > 0; o >>= 1) nvalid += __shfl_down(nvalid, o); }
         // the column's null count without a pass over its bitmap: one partial per trip, summed by interp_edge_fix_kernel
         if (p.trip_valid && lane == 0) p.trip_valid[(int64_t)c * ntrips + trip] = nvalid;
         W2_STAMP(3);   // flush
     }
+    };   // column_loop
+    if (staged_rt) column_loop(std::true_type{});
+    else column_loop(std::false_type{});
     if (__ballot(far)) {
         if (lane == 0 && !__hip_atomic_load(&p.status[7], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(&p.status[7], 1u);
     }
@@ -911,6 +907,17 @@ __global__ __launch_bounds__(64, 4) void interp_wave3_kernel(const InterpParams 
         atomicAdd(reinterpret_cast<unsigned long long *>(p.status + 32) + 7, 1ull);
     }
 #endif
+}
+
+template <bool kIncl>
+__global__ __launch_bounds__(64, 4) void interp_wave3_kernel(const InterpParams p, const int64_t ntrips, const int64_t trips_per_xcd) {
+    constexpr int kRuns = kIncl ? kT3Rows : kT3Rows / 4;
+    __shared__ Wave3Lds<kRuns> L;
+    const int64_t b = blockIdx.x;
+    const int64_t trip = (b & 7) * trips_per_xcd + (b >> 3);   // XCD-contiguous runs of trips: the rows around a trip's ends are in that XCD's L2
+    if (trip >= ntrips) return;
+    if (p.n - trip * kT3Rows >= kT3Rows) wave3_trip<kIncl, true, kRuns>(p, ntrips, trip, L);
+    else wave3_trip<kIncl, false, kRuns>(p, ntrips, trip, L);
 }
 
 // the bits the trips of interp_wave3_kernel left for the words they share with the trip before them (one entry per trip and column:
