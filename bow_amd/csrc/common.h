@@ -437,7 +437,7 @@ struct InterpParams {
     uint32_t *trip_valid;              // interp_wave3_kernel: [ncols][trips] valid outputs per trip (nullptr: not kept - a pass over the bitmaps counts them)
     unsigned long long *valid_counts;  // ... summed by interp_edge_fix_kernel into [ncols][kInterpEdgeBlocks] partial counts
     uint32_t *host_status;             // in place: registered host memory that interp_edge_fix_kernel copies the 16 status words into (valid_counts then lies there too)
-    int32_t in_place, _pad_ip;         // out_valid_words ARE the caller's bitmaps and nobody zeroed them: every word of [0, n_out) gets stored
+    int32_t in_place, aligned16;       // aligned16: ts and every input column's values are 16-byte aligned (interp_wave3_kernel's vector loads unconditional); out_valid_words ARE the caller's bitmaps and nobody zeroed them: every word of [0, n_out) gets stored
     InterpCol cols[kMaxCols];
 };
 int64_t interp_tiles(int64_t n);

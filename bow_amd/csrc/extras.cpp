@@ -447,6 +447,8 @@ static int interp_fill_impl(const bowgpu_col *cols, int32_t ncols, int32_t ts_co
             }
             if (place) { if (b0 == 0) BG_HIP(hipMemsetAsync(P.status, 0, 64, c->stream)); }   // (the status words; the partial counts are all stored)
             else BG_TRY(launch_preset_bitmaps(c, bb));
+            P.aligned16 = (reinterpret_cast<uintptr_t>(P.ts) & 15) == 0 ? 1 : 0;
+            for (int j = 0; j < nb; j++) if (reinterpret_cast<uintptr_t>(P.cols[j].values) & 15) P.aligned16 = 0;
             BG_TRY(launch_interp_tiles(c, P));
             if (!interp_takes_wave3(P) && b0 == 0) c->last_slow_rows += n;   // (interp_tile_kernel: 2.2 ms per 1e8 rows where interp_wave3_kernel takes 1.15)
             if (!place) BG_TRY(launch_finish_bitmaps(c, bb));

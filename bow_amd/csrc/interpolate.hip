@@ -469,7 +469,8 @@ struct Wave3Lds {
     uint64_t vw[2 * kT3Ch];                   // the current column's validity bits of the trip's rows: row r = bit r & 63 of word r >> 6
 };
 
-// One trip.  kFull: all of its 512 rows exist - every trip but the frame's last; kFull and (below) `staged` are compile-time constants
+// One trip.  kFull: all of its 512 rows exist - every trip but the frame's last - and every input column is 16-byte aligned (the
+// usual call: Arrow buffers are; a slice at an odd row offset is not); kFull and (below) `staged` are compile-time constants
 // of the column loop so that what LLVM hoists out of that loop is what the USUAL trip needs: with the partial trip's masks and the
 // unstaged form's addresses in the same loop it hoisted - and spilled, one v_writelane each - 233 scalars per wavefront, 114 without.
 template <bool kIncl, bool kFull, int kRuns>
@@ -481,7 +482,7 @@ __device__ __forceinline__ void wave3_trip(const InterpParams &p, const int64_t 
 #endif
     const int64_t base = trip * kT3Rows;
     const int64_t left_trip = p.n - base;
-    constexpr bool full = kFull;
+    const bool full = kFull || left_trip >= kT3Rows;   // (kFull = false also takes the full trips of a call with a column off 16-byte alignment)
     const int nloc = full ? kT3Rows : (int)left_trip;
     const Magic32 m32 = {p.m32, p.sh1_32, p.sh2_32};
     const uint32_t i32 = (uint32_t)p.interval;
@@ -491,7 +492,7 @@ __device__ __forceinline__ void wave3_trip(const InterpParams &p, const int64_t 
     auto load2 = [&](const uint64_t *col, int k, uint64_t *a, uint64_t *bb) {
         const int r = 128 * k + 2 * lane;
         const uint64_t *src = col + base;
-        if (full && (reinterpret_cast<uintptr_t>(col) & 15) == 0) {
+        if (full && (kFull || (reinterpret_cast<uintptr_t>(col) & 15) == 0)) {   // (kFull: the host found every column 16-byte aligned)
             typedef unsigned long long u64x2i_t __attribute__((ext_vector_type(2)));
             const u64x2i_t v = __builtin_nontemporal_load(reinterpret_cast<const u64x2i_t *>(src + r));   // (streamed once)
             *a = v.x; *bb = v.y;
@@ -638,10 +639,17 @@ __device__ __forceinline__ void wave3_trip(const InterpParams &p, const int64_t 
     // (the loop twice, with `staged` a compile-time constant: the staged form then holds no global store inside a loop - LLVM
     // drains the memory counter in front of a loop that stores and uses registers loaded outside it, which on gfx950, where
     // stores and loads share the counter, is a wait for every store of the previous column's flush)
+    const int lane0 = lane;
     auto column_loop = [&](auto staged_tag) {
     constexpr bool staged = decltype(staged_tag)::value;
 #pragma unroll 1
     for (int c = 0; c < p.ncols; c++) {
+        // (the lane number, opaque per column: LLVM otherwise computes every lane predicate of the body - lane == w, lane < 8, ... , a
+        // v_cmp each - in front of the loop and, out of scalar registers, parks each in two lanes of a vector register: two
+        // v_writelane there, two v_readlane per use here, for what one v_cmp recomputes)
+        int lane_v = lane0;
+        asm volatile("" : "+v"(lane_v));
+        const int lane = lane_v;
         const InterpCol &ic = p.cols[c];
         const bool want_p = ic.kind == BOWGPU_INTERP_LINEAR || ic.kind == BOWGPU_INTERP_STEP_PREVIOUS, want_n = ic.kind == BOWGPU_INTERP_LINEAR;
         uint64_t a[kT3Ch], bq[kT3Ch];
@@ -916,7 +924,7 @@ __global__ __launch_bounds__(64, 4) void interp_wave3_kernel(const InterpParams 
     const int64_t b = blockIdx.x;
     const int64_t trip = (b & 7) * trips_per_xcd + (b >> 3);   // XCD-contiguous runs of trips: the rows around a trip's ends are in that XCD's L2
     if (trip >= ntrips) return;
-    if (p.n - trip * kT3Rows >= kT3Rows) wave3_trip<kIncl, true, kRuns>(p, ntrips, trip, L);
+    if (p.aligned16 && p.n - trip * kT3Rows >= kT3Rows) wave3_trip<kIncl, true, kRuns>(p, ntrips, trip, L);
     else wave3_trip<kIncl, false, kRuns>(p, ntrips, trip, L);
 }
 
