@@ -1368,6 +1368,9 @@ __global__ __launch_bounds__(256, 4) void long_short_kernel(const AggParams p, c
         return;
     }
     if (lane == 0) todo[g] = 0;
+    // (a chunk that stays here is full - kDense: rows != kStreamRows went the general way, else c0 + kStreamRows + 128 <= n: said to
+    // the compiler, the row-bound predicates of everything below fold away)
+    if (rows != kStreamRows) __builtin_unreachable();
     const bool b0 = !prev_same;      // a boundary at the chunk's first row: its first segment is a window of its own, not a head
     int nb = 0, first_rb = 0, last_rb = 0;
 #pragma unroll
