@@ -726,6 +726,7 @@ struct AggJob {
     size_t scratch_bytes = 0;
     int inclusive = 0;
     bool counts_used = false;   // the valid counters hold a previous count (they accumulate): zero them before counting again
+    bool tail_wrote_host = false;   // the finish launch stores the status words and the counts into the registered host block itself
     bool check_plan = false;    // the plan came from the caller (bowgpu_rolling_aggregate_planned): the pass checks it against the column
 };
 static thread_local bool g_plan_from_caller = false;   // set around run_aggregate by the planned entry point
@@ -922,7 +923,12 @@ static int job_enqueue_tail(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t
     if (W > 0) {
         BitmapBatch b;
         job_bitmaps(job, aggs, naggs, false, &b);
-        if (job->counts_used) BG_HIP(hipMemsetAsync(b.counts, 0, 8 * kMaxAggs, c->stream));
+        if (W <= kFinishHostBits) {
+            // a small call is a chain of dependent launches and little else: its last launch hands the status words and the counts to
+            // the host itself instead of a copy command doing so behind it
+            BG_TRY(ctx_pinned(c, 16384, reinterpret_cast<void **>(&b.host_block)));
+            job->tail_wrote_host = true;
+        } else if (job->counts_used) BG_HIP(hipMemsetAsync(b.counts, 0, 8 * kMaxAggs, c->stream));
         BG_TRY(launch_finish_bitmaps(c, b));
         job->counts_used = true;
     }
@@ -933,7 +939,8 @@ static int job_enqueue_tail(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t
 static int job_readback(Ctx *c, AggJob *job, uint32_t **hstat, uint64_t **hcnt) {
     char *hp;
     BG_TRY(ctx_pinned(c, 16384, reinterpret_cast<void **>(&hp)));
-    BG_HIP(hipMemcpyAsync(hp, job->P.status, kReadbackBytes, hipMemcpyDeviceToHost, c->stream));
+    if (job->tail_wrote_host) job->tail_wrote_host = false;   // (finish_bitmaps_kernel is storing both there)
+    else BG_HIP(hipMemcpyAsync(hp, job->P.status, kReadbackBytes, hipMemcpyDeviceToHost, c->stream));
     *hstat = reinterpret_cast<uint32_t *>(hp);
     *hcnt = reinterpret_cast<uint64_t *>(hp + kCountsOffset);
     return 0;

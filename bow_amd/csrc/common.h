@@ -306,9 +306,12 @@ struct BitmapBatch {
     int32_t count[kMaxAggs];       // finish: count the valid bits into counts[a]
     uint32_t *status;              // preset zeroes status[0 .. status_words) and counts[0 .. kMaxAggs)
     unsigned long long *counts;
+    char *host_block;              // finish, one workgroup per bitmap (nbits <= kFinishHostBits): registered host memory that receives the status
+                                   // words [0, status_words) and, at byte 1024 + 8 a, bitmap a's count - by the kernel's own stores
     const int64_t *check_ts;       // preset: a caller-supplied plan is checked against this interval column (nullptr: no check);
     int64_t check_n, check_first, check_last;   // status[6] = 1 when its first / last row are not the plan's two timestamps
 };
+constexpr int64_t kFinishHostBits = 262144;   // up to here ONE workgroup finishes a bitmap (32 KB: a microsecond) and can hand its count to the host itself
 int launch_preset_bitmaps(Ctx *c, const BitmapBatch &b);
 int launch_finish_bitmaps(Ctx *c, const BitmapBatch &b);
 int launch_popcount(Ctx *c, const uint32_t *words, int64_t bit0, int64_t nbits, uint64_t *d_count);

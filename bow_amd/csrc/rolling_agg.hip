@@ -518,9 +518,13 @@ __global__ __launch_bounds__(256) void finish_bitmaps_kernel(const BitmapBatch b
         __syncthreads();
         if (threadIdx.x == 0) {
             const unsigned long long t = wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
-            if (t) atomicAdd(&b.counts[a], t);
+            if (b.host_block) reinterpret_cast<unsigned long long *>(b.host_block + 1024)[a] = t;   // (the only workgroup of this bitmap)
+            else if (t) atomicAdd(&b.counts[a], t);
         }
-    }
+    } else if (b.host_block && threadIdx.x == 0) reinterpret_cast<unsigned long long *>(b.host_block + 1024)[a] = 0;
+    // the status words of the launches in front of this one, straight into the host's block: no copy command behind the call's last launch
+    if (b.host_block && a == 0 && blockIdx.x == 0)
+        for (int t = threadIdx.x; t < b.status_words; t += blockDim.x) reinterpret_cast<uint32_t *>(b.host_block)[t] = b.status[t];
 }
 
 static unsigned bitmap_grid(int64_t nbits) {
@@ -535,7 +539,7 @@ int launch_preset_bitmaps(Ctx *c, const BitmapBatch &b) {
 }
 int launch_finish_bitmaps(Ctx *c, const BitmapBatch &b) {
     if (b.n <= 0 || b.nbits <= 0) return 0;
-    hipLaunchKernelGGL(finish_bitmaps_kernel, dim3(bitmap_grid(b.nbits), b.n), dim3(256), 0, c->stream, b);
+    hipLaunchKernelGGL(finish_bitmaps_kernel, dim3(b.host_block ? 1u : bitmap_grid(b.nbits), b.n), dim3(256), 0, c->stream, b);
     BG_HIP(hipGetLastError());
     return 0;
 }
