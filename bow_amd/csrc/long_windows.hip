@@ -1401,8 +1401,15 @@ __global__ __launch_bounds__(256, 4) void long_short_kernel(const AggParams p, c
         }
     }
 
+    const int lane0 = lane;
     for (int slot = 0; slot < p.ncols; slot++) {
         if (p.pass_mask[slot + 1] == 0 || !(p.pass_flags[slot + 1] & kPassNeedVals)) continue;
+        // (the lane number, opaque per column pass: LLVM otherwise computes every lane predicate of the body - "row in front of this trip's
+        // boundary", lane == 63, ... - in front of the loop and parks each, out of scalar registers, in two lanes of a vector register:
+        // ~100 v_writelane there and as many v_readlane here for what one v_cmp each recomputes; interp_wave3_kernel has the same)
+        int lane_v = lane0;
+        asm volatile("" : "+v"(lane_v));
+        const int lane = lane_v;
         const ColDesc &cd = p.cols[slot];
         const uint64_t *vp = reinterpret_cast<const uint64_t *>(cd.values);
         const bool need_ts = kTw && cd.need_ts;
