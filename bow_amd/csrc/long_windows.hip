@@ -1402,6 +1402,7 @@ __global__ __launch_bounds__(256, 4) void long_short_kernel(const AggParams p, c
     }
 
     const int lane0 = lane;
+    const int64_t g0 = g;
     for (int slot = 0; slot < p.ncols; slot++) {
         if (p.pass_mask[slot + 1] == 0 || !(p.pass_flags[slot + 1] & kPassNeedVals)) continue;
         // (the lane number, opaque per column pass: LLVM otherwise computes every lane predicate of the body - "row in front of this trip's
@@ -1410,6 +1411,13 @@ __global__ __launch_bounds__(256, 4) void long_short_kernel(const AggParams p, c
         int lane_v = lane0;
         asm volatile("" : "+v"(lane_v));
         const int lane = lane_v;
+        // (the same for the chunk number and the trips' boundary rows: what hangs on them - the partials' addresses, "this trip has a
+        // boundary" - is scalar arithmetic the loop can afford; hoisted, it is forty more scalars to park)
+        int64_t g_v = g0;
+        asm volatile("" : "+s"(g_v));
+        const int64_t g = g_v;
+#pragma unroll
+        for (int j = 0; j < kTrips; j++) asm volatile("" : "+s"(tb_row[j]));
         const ColDesc &cd = p.cols[slot];
         const uint64_t *vp = reinterpret_cast<const uint64_t *>(cd.values);
         const bool need_ts = kTw && cd.need_ts;
