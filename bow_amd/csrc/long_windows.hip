@@ -838,6 +838,7 @@ __global__ __launch_bounds__(256) void long_stream_kernel(const AggParams p, con
     constexpr bool kMinMax = (kNeed & 1) != 0, kTw = (kNeed & 4) != 0, kIdx = kNeed != 0;
     constexpr int kTrips = kStreamRows / 128;
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane_outer = lane;
     const int64_t wave = (int64_t)blockIdx.x * 4 + wv;
     const int64_t g_base = kFlagged ? wave * 64 : wave;
     uint64_t todo = kFlagged ? __ballot(g_base + lane < nchunks && only[g_base + lane] != 0) : (wave < nchunks ? 1ull : 0ull);
@@ -974,6 +975,9 @@ __global__ __launch_bounds__(256) void long_stream_kernel(const AggParams p, con
         const double kNaN = __longlong_as_double(0x7ff8000000000000ll);
         for (int slot = 0; slot < p.ncols; slot++) {
             if (p.pass_mask[slot + 1] == 0 || !(p.pass_flags[slot + 1] & kPassNeedVals)) continue;
+            int lane_v = lane_outer;   // (opaque per column pass: see long_short_kernel)
+            asm volatile("" : "+v"(lane_v));
+            const int lane = lane_v;
             const ColDesc &cd = p.cols[slot];
             const uint64_t *vp = reinterpret_cast<const uint64_t *>(cd.values);
             const bool need_ts = kTw && cd.need_ts;
@@ -1143,6 +1147,9 @@ __global__ __launch_bounds__(256) void long_stream_kernel(const AggParams p, con
     // ---- per column pass: the rows' partials, the segmented scan, the partials of the closed windows
     for (int slot = 0; slot < p.ncols; slot++) {
         if (p.pass_mask[slot + 1] == 0 || !(p.pass_flags[slot + 1] & kPassNeedVals)) continue;
+        int lane_v = lane_outer;   // (opaque per column pass: see long_short_kernel)
+        asm volatile("" : "+v"(lane_v));
+        const int lane = lane_v;
         const ColDesc &cd = p.cols[slot];
         const uint64_t *vp = reinterpret_cast<const uint64_t *>(cd.values);
         const bool need_ts = kTw && cd.need_ts;
