@@ -280,6 +280,47 @@ def test_interpolate_empty_window_runs_and_the_minus_one_sentinel():
     check(np.array([-3, -2, 0, 8, 9], dtype=np.int64), 5, 4)
 
 
+@pytest.mark.parametrize("inclusive", [False, True])
+def test_interpolate_trips_with_more_outputs_than_the_stage_holds(inclusive):
+    """512-row trips that produce more than 768 rows with few enough runs for interp_wave3_kernel's list: its UNSTAGED form - outputs
+    stored from the lanes, validity bits ORed into the bitmap.  With the bitmaps written in place (device-resident outputs whose
+    capacity reaches the end of the last word; round 5) nobody zeroes them beforehand: such a trip zeroes the words it owns itself.
+    Every variant of both_interp_kernels - working copies, in place, the workgroup kernel for exclusive windows - gives the
+    oracle's rows, and so does a second call into the SAME dirty output buffers."""
+    rng = np.random.default_rng(77)
+    interval, rows_per_window, nwin = 100, 8, 2_500
+    starts = np.cumsum(rng.integers(6, 16, nwin)) * interval              # 5 .. 14 empty windows in front of every window with rows
+    offs = np.sort(rng.integers(1, interval, (nwin, rows_per_window)), axis=1)
+    ts = (starts[:, None] + offs).reshape(-1).astype(np.int64)
+    assert np.all(np.diff(ts) >= 0)
+    n = len(ts)
+    vals = np.round(rng.standard_normal(n) * 10, 1)
+    valid = rng.random(n) >= 0.3
+    bm = np.packbits(valid, bitorder="little")
+    ip = [{"kind": "WindowStart", "col": 0}, {"kind": "Linear", "col": 1}]
+    want = orc.interpolate([orc.Column(ts, None, orc.INT64), orc.Column(vals, bm, orc.FLOAT64)], 0, interval, ip, inclusive=inclusive)
+    assert want[0].length > 2 * n      # ~1.3 synthetic rows per row: ~1200 outputs per trip
+    cols = [capi.Column(ts), capi.Column(vals, bm, capi.FLOAT64, 0, n, -1)]
+    if inclusive:
+        res = []
+        for resid, padded in ((capi.HOST, True), (capi.DEVICE, True), (capi.DEVICE, False)):
+            with capi.interp_outputs(resid, padded):
+                res.append(capi.rolling_interpolate(cols, 0, interval, ip, inclusive=True))
+    else:
+        res = [both_interp_kernels(lambda: capi.rolling_interpolate(cols, 0, interval, ip))]
+    for got in res:
+        for c in range(2):
+            cmp_out("col %d" % c, got[c], want[c])
+    # the same output buffers again, full of the first call's bits
+    dcols = [c_.to_device() for c_ in cols]
+    outs = None
+    for _ in range(2):
+        outs = capi.rolling_interpolate_onepass(dcols, 0, interval, ip, inclusive=inclusive, out_residency=capi.DEVICE,
+                                                capacity=(want[0].length + 511) // 512 * 512, outs=outs)
+        for c in range(2):
+            cmp_out("again, col %d" % c, outs[c], want[c])
+
+
 def test_interpolate_a_wide_bow():
     """a Bow of 21 columns (the tile kernel takes 8 per launch; interpolation.go:98-161 loops over any number)"""
     rng = np.random.default_rng(23)
