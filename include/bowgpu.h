@@ -325,6 +325,12 @@ typedef struct bowgpu_interp {
  * _fill does not NEED a preceding _count: called on its own it sizes the outputs itself against bowgpu_out.length (in: capacity;
  * rows + windows always suffice; too small is BOWGPU_ERR_ARG naming the size).  Inclusive windows then take one pass over the rows
  * (n_out = n + W - [row 0 on its window's start] needs no count); exclusive windows make their own count pass first.
+ * DEVICE-resident outputs are written in place - no working copy of their bitmaps, no launch that zeroes or counts them - when each
+ * validity pointer is 4-byte aligned and the capacity (bowgpu_out.length on entry) reaches the end of the 32-bit word that holds row
+ * n_out - 1, i.e. ceil(length / 8) >= 4 * ceil(n_out / 32): allocate a multiple of 32 rows (Arrow's allocators pad to 64 bytes, 512
+ * rows).  Outputs that do not qualify cost one more small launch and a copy of the bitmaps (0.03 ms per 1e8 rows), nothing else.
+ * Input columns whose value pointers are not all 16-byte aligned (a slice at an odd row offset) take 8-byte loads in the kernel's
+ * general instantiation.
  * An interval column WITH NULLS: the output is the windows' slices - rows that belong to no window vanish (rolling.go:190-193,
  * :224-228), null-timestamp rows inside a slice are copied as they are; inclusive windows too (incl. rolling.go:214-218's
  * `rowIndex - 1` after a null), except for two shapes that are BOWGPU_ERR_TS_NULLS (see the error code).  At most 16 columns per
