@@ -782,8 +782,13 @@ __device__ __forceinline__ void wave3_trip(const InterpParams &p, const int64_t 
         };
         // ---- one lane per run (runs of up to kSmallRun rows; the long runs of empty windows follow, one at a time)
         bool any_long = false;
+#ifdef BOWGPU_X_SKIP_RUNS   // (diagnostic build only, like BOWGPU_STAMPS: the kernel WITHOUT its run pass - wrong outputs, same bytes moved; the
+        const int nrun_x = 0;   //  difference to the product build is what the pass costs: scratch/build_variant.sh xruns interpolate.hip -DBOWGPU_X_SKIP_RUNS)
+#else
+        const int nrun_x = nrun;
+#endif
 #pragma unroll 1
-        for (int q0 = 0; q0 < nrun; q0 += 64) {
+        for (int q0 = 0; q0 < nrun_x; q0 += 64) {
             const int q = q0 + lane;
             const bool act = q < nrun;
             const uint32_t e = act ? L.run_a[q] : 0u;

@@ -38,7 +38,9 @@ def timeit(fn, reps=10):
 for _ in range(20):   # (the first dozen launches of a process run 5 % slower than the rest: clocks, page mappings)
     count(); fill()
 capi.synchronize()
-for label, mask in (("wave3 (default)", 0), ("wave3, bitmap copies", capi.ROUTE_INTERP_COPIES), ("tile", capi.ROUTE_INTERP_TILE)):
+# ("one" as the second argument: the default route only - what a profiler pass wants)
+only_default = len(sys.argv) > 2 and sys.argv[2] == "one"
+for label, mask in (("wave3 (default)", 0), ("wave3, bitmap copies", capi.ROUTE_INTERP_COPIES), ("tile", capi.ROUTE_INTERP_TILE))[:1 if only_default else 3]:
     capi.set_route(mask)
     both = timeit(lambda: (count(), fill()))
     c_ms = timeit(count)

@@ -36,6 +36,17 @@ for V in "WeightedAverageStep sparse" "WeightedAverageStep dense" "Mean sparse";
   echo "== $1 $2, 1000 rows per window" >> $DST/${TAG}_pmc_long_short_tw.txt
   bash scratch/pmc_sq.sh lstw_$1_$2 long_short scratch/longw_pmc.py $1 $2 | grep -v "^pass" >> $DST/${TAG}_pmc_long_short_tw.txt
 done
+# 4b. Interpolate: the launches of a call (at most 5) and the fill kernel's counters
+timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/iw_$TAG -o iw -- python3 scratch/interp_wall.py 1e8 one > /dev/null 2>&1
+cp $(find gpurun_out/iw_$TAG -name "*kernel_stats.csv" | head -1) $DST/${TAG}_kernel_stats_interp_wall.csv 2>/dev/null
+bash scratch/pmc_sq.sh iw3_$TAG interp_wave3 scratch/interp_wall.py 1e8 one | grep -v "^pass" > $DST/${TAG}_pmc_interp_wave3_1e8.txt
+# 4c. ... and the same call through the diagnostic build without the kernel's run pass (built beforehand, travels with the snapshot:
+#     scratch/build_variant.sh xruns interpolate.hip -DBOWGPU_X_SKIP_RUNS): what the pass costs = how far the kernel is from its traffic
+if [ -f bow_amd/libbowgpu_xruns.so ]; then
+  (echo "== product build"; timeout -s KILL 200 python3 scratch/interp_wall.py 1e8 one 2>&1 | grep -v "^[WE]2026"
+   echo "== diagnostic build, no run pass (outputs wrong, same bytes moved)"; BOWGPU_LIB=bow_amd/libbowgpu_xruns.so timeout -s KILL 200 python3 scratch/interp_wall.py 1e8 one 2>&1 | grep -v "^[WE]2026") > $DST/${TAG}_stdout_interp_skip_runs.txt
+fi
+[ -f bow_amd/libbowgpu_stamps.so ] && BOWGPU_LIB=bow_amd/libbowgpu_stamps.so timeout -s KILL 200 python3 scratch/interp_stamps.py 2>&1 | grep -v "^[WE]2026" > $DST/${TAG}_stdout_interp_stamps.txt
 # 5. the configs[2] pipeline as one call against the two calls; the fused kernel's traffic
 timeout -s KILL 300 python3 scratch/cfg2_fused.py 2>&1 | grep -v "^[WE]2026" > $DST/${TAG}_stdout_cfg2_fused.txt
 ls -la $DST
