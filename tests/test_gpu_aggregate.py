@@ -361,6 +361,38 @@ def test_signalling_nan_inside_a_window_does_not_lose_the_running_extremum(rows_
             assert (gmax.host_arrays()[0][slot] == 1e6).all() and (gmin.host_arrays()[0][slot] == -1e6).all()
 
 
+@pytest.mark.parametrize("rows_per_window", [300, 1000, 6000])
+def test_signalling_nan_inside_a_long_window(rows_per_window):
+    """... and the same through the long-window forms (streaming, bisection, the tile kernels' queue): Min / Max are exact reducers
+    there too - the extremum in front of an sNaN and the one behind it, with and without nulls, an sNaN as a window's very first value
+    (minmax.go keeps a NaN seed: the result is that NaN, bit for bit)."""
+    rng = np.random.default_rng(19 + rows_per_window)
+    n = 60 * rows_per_window + 77
+    ts = np.arange(n, dtype=np.int64)
+    v = rng.normal(size=n)
+    SNAN = np.array([0x7FF0000000000001, 0xFFF4000000000123], dtype=np.uint64).view(np.float64)
+    w0 = np.arange(0, n - rows_per_window, 3 * rows_per_window)
+    for d in (2, rows_per_window // 2, rows_per_window - 9):      # near the window's start, in its middle (another lane / trip), near its end
+        v[w0 + d] = 1e6
+        v[w0 + d + 3] = -1e6
+        v[w0 + d + 1] = SNAN[0]
+        v[w0 + d + 4] = SNAN[1]
+    v[w0[::4] + rows_per_window] = SNAN[0]                      # a seed: the first row of the window behind every fourth planted one
+    valid = rng.random(n) > 0.3
+    valid[w0[:, None] + np.arange(8)[None, :]] = True
+    for cols, aggs in [
+        ([(v, None)], [("WindowStart", 0), ("Min", 1), ("Max", 1)]),
+        ([(v, None)], [("WindowStart", 0), ("Min", 1), ("Max", 1), ("Sum", 1), ("First", 1), ("Last", 1)]),
+        ([(v, valid)], [("WindowStart", 0), ("Min", 1), ("Max", 1)]),
+        ([(v, valid)], [("WindowStart", 0), ("Min", 1), ("Max", 1), ("WeightedAverageStep", 1)]),
+    ]:
+        outs, exp, info = run_both(ts, cols, rows_per_window, aggs)
+        k = _names(aggs)
+        if cols[0][1] is None:
+            slot = w0 // rows_per_window
+            assert (outs[k.index("Max")].host_arrays()[0][slot] == 1e6).all() and (outs[k.index("Min")].host_arrays()[0][slot] == -1e6).all()
+
+
 def test_device_resident_columns_and_arrow_offsets():
     rng = np.random.default_rng(21)
     n, off = 70_000, 13  # a sliced Arrow array: offset 13 into shared buffers (bow.go:279-283)
