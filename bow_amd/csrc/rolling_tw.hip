@@ -108,8 +108,12 @@ __device__ __forceinline__ void lds_order() {
 // kBoth: the call has step AND trapezoid integrals: the terms of the second kind wait in registers while the first kind is walked
 // kShort: a call whose windows average fewer than kShortAvgRows rows - every tile takes the one-walk form (walk_all below), and the
 // term machinery is not even compiled in: its registers cost a wavefront per SIMD, which at that window length is what sets the rate
-template <bool kNulls, bool kWide, bool kTs32, bool kBoth, bool kShort, bool kLean>
-__global__ __launch_bounds__(kWave, (kShort || kLean || (!kNulls && kTs32 && !kBoth)) ? 5 : 4) void rolling_tw_kernel(const SimpleParams p, const int64_t ntiles, const int64_t tiles_per_xcd) {
+// kMulti: more than one value column - a real loop over the column passes.  One column (kMulti = false): straight-line code, and
+// what LLVM would compute in front of that loop and park, out of scalar registers, in vector lanes is computed where it is used
+// (round 5, found on interp_wave3_kernel: 75 - 90 parked scalars per wavefront here, 31 - 45 without the loop, 20 - 30 fewer vector
+// registers).
+template <bool kNulls, bool kWide, bool kTs32, bool kBoth, bool kShort, bool kLean, bool kMulti>
+__global__ __launch_bounds__(kWave, (kShort || kLean || (!kNulls && kTs32 && (!kBoth || !kMulti))) ? 5 : 4) void rolling_tw_kernel(const SimpleParams p, const int64_t ntiles, const int64_t tiles_per_xcd) {
     static_assert(!(kWide && kTs32), "the wide form keeps 64-bit timestamps");
     static_assert(!kLean || (!kNulls && !kShort), "the lean form: one column without nulls, integrals only, terms from the flag pass");
     __shared__ TwShared<kNulls, kTs32, kLean> sh;
@@ -356,7 +360,7 @@ __global__ __launch_bounds__(kWave, (kShort || kLean || (!kNulls && kTs32 && !kB
     if (lane < nseg_owned) g_state = geometry(lane, g_r0, g_r1, g_wid, g_next, g_e1);
 
     // ---- one pass per value column
-    const int ncols = p.ncols;
+    const int ncols = kMulti ? p.ncols : 1;
     for (int c = 0; c < ncols; c++) {
         const bool cint = p.col_is_int[c] != 0;  // mixed column types: per pass (uniform)
         // ---- stage the values (converted to float64, nulls replaced: rolling_simple.hip) - the gather source of the term pass for a
@@ -742,11 +746,18 @@ int launch_rolling_tw(Ctx *c, const SimpleParams &p, bool is_int, bool has_nulls
     // 0.642 against 0.698 ms at 32 rows per window, 0.710 against 0.685 at 40)
     const int64_t short_rows = both ? (has_nulls ? 38 : lean ? 12 : 64) : (has_nulls || (p.need & (kNeedSum | kNeedMinMax | kNeedFirstLast))) ? 20 : kShortAvgRows;
     const bool shrt = p.W > 0 && p.n / p.W < short_rows;
+    const bool multi = p.ncols > 1;
 #define BG_TW4(U, B, S, L)                                                                                                       \
     do {                                                                                                                          \
-        if (wide) hipLaunchKernelGGL((rolling_tw_kernel<U, true, false, B, S, L>), g, blk, 0, c->stream, p, ntiles, per_xcd);      \
-        else if (ts32) hipLaunchKernelGGL((rolling_tw_kernel<U, false, true, B, S, L>), g, blk, 0, c->stream, p, ntiles, per_xcd); \
-        else hipLaunchKernelGGL((rolling_tw_kernel<U, false, false, B, S, L>), g, blk, 0, c->stream, p, ntiles, per_xcd);         \
+        if (multi) {                                                                                                                      \
+            if (wide) hipLaunchKernelGGL((rolling_tw_kernel<U, true, false, B, S, L, true>), g, blk, 0, c->stream, p, ntiles, per_xcd);      \
+            else if (ts32) hipLaunchKernelGGL((rolling_tw_kernel<U, false, true, B, S, L, true>), g, blk, 0, c->stream, p, ntiles, per_xcd); \
+            else hipLaunchKernelGGL((rolling_tw_kernel<U, false, false, B, S, L, true>), g, blk, 0, c->stream, p, ntiles, per_xcd);         \
+        } else {                                                                                                                          \
+            if (wide) hipLaunchKernelGGL((rolling_tw_kernel<U, true, false, B, S, L, false>), g, blk, 0, c->stream, p, ntiles, per_xcd);      \
+            else if (ts32) hipLaunchKernelGGL((rolling_tw_kernel<U, false, true, B, S, L, false>), g, blk, 0, c->stream, p, ntiles, per_xcd); \
+            else hipLaunchKernelGGL((rolling_tw_kernel<U, false, false, B, S, L, false>), g, blk, 0, c->stream, p, ntiles, per_xcd);         \
+        }                                                                                                                                 \
     } while (0)
 #define BG_TW3(U, B, S) BG_TW4(U, B, S, false)
 #define BG_TW2(U, B) do { if (shrt) BG_TW3(U, false, true); else BG_TW3(U, B, false); } while (0)
