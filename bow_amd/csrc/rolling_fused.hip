@@ -119,7 +119,7 @@ __device__ __forceinline__ void walk_pred_seeded(const uint64_t *val, const uint
 
 // kNeed: bit0 min/max wanted, bit1 first/last wanted; kNulls: some value column has nulls; kMulti: more than one value column
 template <int kNeed, bool kNulls, bool kMulti>
-__global__ __launch_bounds__(kWave, kMulti ? 5 : 6) void rolling_fused_kernel(const FusedParams fp, const int64_t ntiles, const int64_t tiles_per_xcd) {
+__global__ __launch_bounds__(kWave, kMulti ? 4 : 6) void rolling_fused_kernel(const FusedParams fp, const int64_t ntiles, const int64_t tiles_per_xcd) {
     __shared__ FusedShared sh;
     constexpr bool kSwzF = false;
     const SimpleParams &p = fp.s;
