@@ -83,7 +83,7 @@ __device__ __forceinline__ uint32_t wave_scan_u32(uint32_t x) {
 // value are in registers anyway - nothing of the tile then lives in registers behind it (no times kept for later columns, no next
 // column in flight): 96 instead of 134 registers, a fifth more wavefronts per CU.
 template <bool kBoth, bool kMulti, int kHalo>
-__global__ __launch_bounds__(kWave, (kMulti || kHalo != 128) ? 4 : 5) void rolling_twc_kernel(const SimpleParams p, const int64_t ntiles, const int64_t tiles_per_xcd) {
+__global__ __launch_bounds__(kWave, (kMulti && kBoth) ? 3 : (kMulti || kHalo != 128) ? 4 : 5) void rolling_twc_kernel(const SimpleParams p, const int64_t ntiles, const int64_t tiles_per_xcd) {
     constexpr int kRowsC = kTileC + kHalo, kChunksC = kRowsC / 128, kWordsC = kRowsC / 32, kCapC = TwcCap<kHalo>::value;
     __shared__ TwcShared<kHalo> sh;
     const int64_t b = blockIdx.x;
