@@ -185,18 +185,18 @@ __global__ __launch_bounds__(kCountThreads) void interp_count_kernel(const int64
     }
 }
 
-// exclusive prefix of the super-tile sums (one workgroup: n / 8192 sums - 12 k for 1e8 rows), the total behind them.  A thread takes
-// 4 kQ consecutive sums: 16-byte loads, all in flight at once (kQ = 4 serves 1.3e8 rows, 16 serves 5e8; the loop form beyond)
-template <int kQ>
+// exclusive prefix of the super-tile sums (one workgroup: n / 8192 sums - 12 k for 1e8 rows), the total behind them.  In passes of
+// 16384 sums: a thread takes 16 consecutive ones (four 16-byte loads, all in flight at once), the workgroup scans the threads'
+// totals, a running carry joins the passes (1e8 rows: one pass, 9 us; 1e9 rows: eight).
 __global__ __launch_bounds__(1024) void interp_super_scan_kernel(const int32_t *super_sum, int64_t nsuper, int64_t *super_before, int64_t *total,
                                                                  const uint32_t *status, int64_t *host_back) {
+    constexpr int kQ = 4;
     __shared__ long long sh[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    long long mine = 0;
-    int32_t x[kQ > 0 ? 4 * kQ : 1];
-    int64_t a, b;
-    if (kQ > 0) {
-        a = (int64_t)tid * 4 * kQ; b = a + 4 * kQ < nsuper ? a + 4 * kQ : nsuper;
+    long long carry = 0;
+    for (int64_t pass0 = 0; pass0 < nsuper; pass0 += 1024 * 4 * kQ) {
+        const int64_t a = pass0 + (int64_t)tid * 4 * kQ;
+        int32_t x[4 * kQ];
 #pragma unroll
         for (int q = 0; q < kQ; q++) {
             const int64_t i = a + 4 * q;
@@ -205,35 +205,30 @@ __global__ __launch_bounds__(1024) void interp_super_scan_kernel(const int32_t *
             else { if (i < nsuper) v.x = super_sum[i]; if (i + 1 < nsuper) v.y = super_sum[i + 1]; if (i + 2 < nsuper) v.z = super_sum[i + 2]; }
             x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
         }
+        long long mine = 0;
 #pragma unroll
         for (int j = 0; j < 4 * kQ; j++) mine += x[j];
-    } else {
-        const int64_t per = (nsuper + 1023) / 1024;
-        a = (int64_t)tid * per; b = a + per < nsuper ? a + per : nsuper;
-        for (int64_t i = a; i < b; i++) mine += super_sum[i];
-    }
-    long long incl = mine;
+        long long incl = mine;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const long long up = __shfl_up(incl, o);
-        if (lane >= o) incl += up;
-    }
-    if (lane == 63) sh[wv] = incl;
-    __syncthreads();
-    long long before = 0;
-    for (int w = 0; w < wv; w++) before += sh[w];
-    long long run = before + incl - mine;
-    if (kQ > 0) {
+        for (int o = 1; o < 64; o <<= 1) {
+            const long long up = __shfl_up(incl, o);
+            if (lane >= o) incl += up;
+        }
+        __syncthreads();   // (the previous pass is done with sh)
+        if (lane == 63) sh[wv] = incl;
+        __syncthreads();
+        long long before = carry, all = 0;
+        for (int w = 0; w < 16; w++) { if (w < wv) before += sh[w]; all += sh[w]; }
+        long long run = before + incl - mine;
 #pragma unroll
         for (int j = 0; j < 4 * kQ; j++) { if (a + j < nsuper) super_before[a + j] = run; run += x[j]; }
-    } else {
-        for (int64_t i = a; i < b; i++) { super_before[i] = run; run += super_sum[i]; }
+        carry += all;
     }
-    if (tid == 1023) { super_before[nsuper] = before + incl; *total = before + incl; }
+    if (tid == 1023) { super_before[nsuper] = carry; *total = carry; }
     // pass 1's findings straight into the host's registered block (the stores go over the link; no copy command behind the launch):
     // [0] the total, [1] status words 0 | 1 << 32, [2] status words 2 | 3 << 32 - written by the count kernel in front of this one
     if (host_back) {
-        if (tid == 1023) host_back[0] = before + incl;
+        if (tid == 1023) host_back[0] = carry;
         if (tid < 2) host_back[1 + tid] = (int64_t)((uint64_t)status[2 * tid] | ((uint64_t)status[2 * tid + 1] << 32));
     }
 }
@@ -1018,9 +1013,7 @@ int launch_interp_count(Ctx *c, const int64_t *ts, int64_t n, const Plan &plan, 
     else
         hipLaunchKernelGGL(interp_count_kernel<false>, dim3((unsigned)nsuper), dim3(kCountThreads), 0, c->stream, ts, n, plan.s0, plan.interval,
                            plan.magic, Magic32{0, 0, 0}, has_left, left_ts, tile_local, super_sum, status);
-    if (nsuper <= 1024 * 16) hipLaunchKernelGGL(interp_super_scan_kernel<4>, dim3(1), dim3(1024), 0, c->stream, super_sum, nsuper, super_before, d_total, status, host_back);
-    else if (nsuper <= 1024 * 64) hipLaunchKernelGGL(interp_super_scan_kernel<16>, dim3(1), dim3(1024), 0, c->stream, super_sum, nsuper, super_before, d_total, status, host_back);
-    else hipLaunchKernelGGL(interp_super_scan_kernel<0>, dim3(1), dim3(1024), 0, c->stream, super_sum, nsuper, super_before, d_total, status, host_back);
+    hipLaunchKernelGGL(interp_super_scan_kernel, dim3(1), dim3(1024), 0, c->stream, super_sum, nsuper, super_before, d_total, status, host_back);
     BG_HIP(hipGetLastError());
     return 0;
 }
