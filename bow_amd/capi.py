@@ -686,8 +686,10 @@ def shard_interpolate(cols, ts_col, interval, interps, global_s0, rank, all_poin
     return outs
 
 
-def fill_linear(cols, ref_col, fill_col, out_residency=HOST):
-    out = OutColumn(cols[fill_col].length, out_residency)
+def fill_linear(cols, ref_col, fill_col, out_residency=HOST, capacity=None):
+    """capacity: rows the output buffers can hold (default: exactly the column's) - a device-resident bitmap that reaches the end of its
+    last 64-bit word and is 8-byte aligned is written in place (bow_amd/csrc/extras.cpp fill_finish)"""
+    out = OutColumn(cols[fill_col].length if capacity is None else capacity, out_residency)
     o = out.c()
     unchanged = C.c_int32(0)
     check(lib().bowgpu_fill_linear(_cols(cols), len(cols), ref_col, fill_col, C.byref(o), C.byref(unchanged)))
@@ -698,9 +700,9 @@ def fill_linear(cols, ref_col, fill_col, out_residency=HOST):
 FILL = {"Previous": 0, "Next": 1, "Mean": 2}
 
 
-def fill(col, method, out_residency=HOST):
-    """Bow.FillPrevious / FillNext / FillMean of one column -> (OutColumn, unchanged)"""
-    out = OutColumn(col.length, out_residency)
+def fill(col, method, out_residency=HOST, capacity=None):
+    """Bow.FillPrevious / FillNext / FillMean of one column -> (OutColumn, unchanged); capacity: see fill_linear"""
+    out = OutColumn(col.length if capacity is None else capacity, out_residency)
     o = out.c()
     c = col.c()
     unchanged = C.c_int32(0)

@@ -465,7 +465,9 @@ struct FillParams {
     uint64_t *out_values;
     uint32_t *out_valid_words;   // 8-byte aligned, a multiple of 64 bits long
     unsigned long long *valid_count;  // += valid output rows
-    NbrIndex nbr;                // of the fill column's bitmap
+    NbrIndex nbr;                // of the fill column's bitmap; prev_before == nullptr: not built - the kernel then looks at most 2048
+                                 // rows beyond a trip's ends and raises *far_flag when that does not reach (the host repeats the call with the index)
+    uint32_t *far_flag;
 };
 // builds the index of (vbits, vbit0, n) into `work` (nbr_index_bytes(n, vbit0) bytes of device memory)
 int launch_first_last_valid(Ctx *c, const uint32_t *vbits, int64_t vbit0, int64_t n, int64_t *d_rows);

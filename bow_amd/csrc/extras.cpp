@@ -817,35 +817,49 @@ int bowgpu_fill_linear(const bowgpu_col *cols, int32_t ncols, int32_t ref_col, i
     return fill_finish(c, P, n, dfill, &dout, ft);
 }
 
-// shared tail of the fill entry points: neighbour index of the fill column, the kernel, validity bytes -> bits, copy-back
+// shared tail of the fill entry points: the kernel, the count of valid outputs, copy-back.
+// The neighbour index of the fill column's bitmap (three small launches, ~25 us at 1e8 rows) is built only for a REPEAT: the kernel
+// finds the valid row beyond a trip's ends by a bounded walk (2048 rows) and says so when a run of nulls is longer - the usual column
+// never needs the index (Interpolate does the same since round 5).  A device-resident output bitmap that can take the kernel's whole
+// 64-bit words - 8-byte aligned, capacity to the end of the word holding row n - 1 - is written in place: no copy behind the kernel.
 static int fill_finish(Ctx *c, FillParams &P, int64_t n, const DevCol &dfill, DevOut *dout, int type) {
-    void *ix;
-    BG_TRY(ctx_pool(c, kPoolInterp + 3, nbr_index_bytes(n, dfill.vbit0), &ix));
-    BG_TRY(nbr_index_build(c, dfill.vbits, dfill.vbit0, n, ix, &P.nbr));
     void *dscr;
     BG_TRY(ctx_scratch(c, 8192, &dscr));
-    uint64_t *dcnt = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(dscr) + 1024);
-    BG_HIP(hipMemsetAsync(dcnt, 0, 8, c->stream));
+    uint64_t *dcnt = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(dscr) + 8);
     P.n = n;
     P.out_values = reinterpret_cast<uint64_t *>(dout->values);
     // the kernel stores one whole 64-bit validity word per wavefront trip: ceil(n/64)*8 bytes, which the word-aligned working
     // copy of devout_prepare (((ceil(n/8)+3)&~3)+4 bytes) always holds
-    P.out_valid_words = reinterpret_cast<uint32_t *>(dout->validity);
+    const bowgpu_out *u = dout->user;
+    const bool place = n > 0 && u->residency == BOWGPU_DEVICE && (reinterpret_cast<uintptr_t>(u->validity) & 7) == 0 &&
+                       ((u->length + 7) >> 3) >= 8 * ((n + 63) >> 6);   // (u->length: still the capacity the caller handed in)
+    P.out_valid_words = reinterpret_cast<uint32_t *>(place ? u->validity : dout->validity);
     P.valid_count = reinterpret_cast<unsigned long long *>(dcnt);
-    BG_HIP(hipEventRecord(c->ev0, c->stream));
-    BG_TRY(fill_run(c, P));
-    BG_HIP(hipEventRecord(c->ev1, c->stream));
-    uint64_t hcnt = 0;
-    BG_HIP(hipMemcpyAsync(&hcnt, dcnt, 8, hipMemcpyDeviceToHost, c->stream));
-    BG_HIP(hipStreamSynchronize(c->stream));
+    P.far_flag = reinterpret_cast<uint32_t *>(dscr);
+    memset(&P.nbr, 0, sizeof P.nbr);
+    struct { uint32_t far, pad; uint64_t cnt; } back = {0, 0, 0};
+    for (int attempt = 0; attempt < 2; attempt++) {
+        if (attempt == 1) {
+            void *ix;
+            BG_TRY(ctx_pool(c, kPoolInterp + 3, nbr_index_bytes(n, dfill.vbit0), &ix));
+            BG_TRY(nbr_index_build(c, dfill.vbits, dfill.vbit0, n, ix, &P.nbr));
+        }
+        BG_HIP(hipMemsetAsync(dscr, 0, 16, c->stream));
+        BG_HIP(hipEventRecord(c->ev0, c->stream));
+        BG_TRY(fill_run(c, P));
+        BG_HIP(hipEventRecord(c->ev1, c->stream));
+        BG_HIP(hipMemcpyAsync(&back, dscr, 16, hipMemcpyDeviceToHost, c->stream));
+        BG_HIP(hipStreamSynchronize(c->stream));
+        if (!back.far) break;
+    }
     {   // (bowgpu_last_kernel_ms / _name: the fill kernel of this call)
         float ms = 0;
         BG_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
         c->last_kernel_ms = ms;
         c->last_kernel_name = "fill_kernel";
     }
-    BG_TRY(devout_finish(c, dout, n, type, n - (int64_t)hcnt));
-    BG_HIP(hipStreamSynchronize(c->stream));
+    BG_TRY(devout_finish(c, dout, n, type, n - (int64_t)back.cnt, !place));
+    if (!place) BG_HIP(hipStreamSynchronize(c->stream));
     return 0;
 }
 

@@ -319,7 +319,9 @@ __device__ __forceinline__ void fill_trip(const FillParams &p, const int64_t bas
         if (want_prev) {
             FillNb cur; cur.row = -1; cur.bits = 0; cur.ref = 0;
             if (!(me[0] & 1ull)) {  // the trip starts with a null: what lies before it
-                cur.row = prev_valid_ix(p.fill_vbits, p.fill_vbit0, p.n, base - 1, p.nbr);
+                bool far = false;
+                cur.row = p.nbr.prev_before ? prev_valid_ix(p.fill_vbits, p.fill_vbit0, p.n, base - 1, p.nbr) : prev_valid_near(p.fill_vbits, p.fill_vbit0, p.n, base - 1, &far);
+                if (far && lane == 0 && !__hip_atomic_load(p.far_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(p.far_flag, 1u);
                 if (cur.row >= 0) { cur.bits = p.fill_values[cur.row]; if (linear) cur.ref = p.ref_values[cur.row]; }
             }
 #pragma unroll
@@ -343,7 +345,9 @@ __device__ __forceinline__ void fill_trip(const FillParams &p, const int64_t bas
 #pragma unroll
             for (int k = 0; k < kC; k++) if (k == kl) mlast = (rl & 1) ? mo[k] : me[k];
             if (!((mlast >> (rl >> 1)) & 1ull)) {  // the trip ends with a null: what lies after it
-                cur.row = next_valid_ix(p.fill_vbits, p.fill_vbit0, p.n, base + kTrip, p.nbr);
+                bool far = false;
+                cur.row = p.nbr.next_after ? next_valid_ix(p.fill_vbits, p.fill_vbit0, p.n, base + kTrip, p.nbr) : next_valid_near(p.fill_vbits, p.fill_vbit0, p.n, base + kTrip, &far);
+                if (far && lane == 0 && !__hip_atomic_load(p.far_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(p.far_flag, 1u);
                 if (cur.row >= 0) { cur.bits = p.fill_values[cur.row]; if (linear) cur.ref = p.ref_values[cur.row]; }
             }
 #pragma unroll

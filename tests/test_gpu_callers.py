@@ -422,8 +422,13 @@ def test_fill_linear_random_vs_oracle(ftype, desc):
     fill_valid[:3] = False  # leading nulls have no previous value
     rb, fb = np.packbits(ref_valid, bitorder="little"), np.packbits(fill_valid, bitorder="little")
     ftyp = capi.FLOAT64 if ftype == "f64" else capi.INT64
-    got, unchanged = capi.fill_linear([capi.Column(ref, rb, capi.FLOAT64, 0, n, -1), capi.Column(fill, fb, ftyp, 0, n, -1)], 0, 1)
     want, wu = orc.fill_linear([orc.Column(ref, rb, orc.FLOAT64), orc.Column(fill, fb, ftyp)], 0, 1)
+    for resid, cap in ((capi.DEVICE, None), (capi.DEVICE, (n + 511) // 512 * 512)):   # (device-resident outputs: exact capacity, padded = bitmap in place)
+        got, unchanged = capi.fill_linear([capi.Column(ref, rb, capi.FLOAT64, 0, n, -1), capi.Column(fill, fb, ftyp, 0, n, -1)], 0, 1,
+                                          out_residency=resid, capacity=cap)
+        assert unchanged == wu
+        cmp_out("FillLinear, device-resident output", got, want)
+    got, unchanged = capi.fill_linear([capi.Column(ref, rb, capi.FLOAT64, 0, n, -1), capi.Column(fill, fb, ftyp, 0, n, -1)], 0, 1)
     assert unchanged == wu
     cmp_out("fill", got, want)
     # no nulls => the reference returns the receiver
@@ -455,10 +460,13 @@ def test_fill_random_vs_oracle(ftype, method):
         valid = rng.random(tot) >= null_frac
         bm = np.packbits(valid, bitorder="little")
         typ = capi.FLOAT64 if ftype == "f64" else capi.INT64
-        got, gu = capi.fill(capi.Column(vals, bm, typ, off, n, -1), method)
         want, wu = orc.fill(orc.Column(vals, bm, typ, offset=off, length=n), method)
-        assert gu == wu
-        cmp_out("%s n=%d off=%d" % (method, n, off), got, want)
+        # host-resident output; device-resident with a capacity of exactly the rows (bitmap through the working copy unless it ends on a
+        # 64-bit word) and padded to 512 rows (the Arrow allocators' 64 bytes: bitmap written in place, round 5)
+        for resid, cap in ((capi.HOST, None), (capi.DEVICE, None), (capi.DEVICE, (n + 511) // 512 * 512)):
+            got, gu = capi.fill(capi.Column(vals, bm, typ, off, n, -1), method, out_residency=resid, capacity=cap)
+            assert gu == wu
+            cmp_out("%s n=%d off=%d" % (method, n, off), got, want)
 
 
 def test_fill_long_null_runs_use_the_block_index():
@@ -481,12 +489,14 @@ def test_fill_long_null_runs_use_the_block_index():
         both = (prev >= 0) & (nxt < m)
         exp["Mean"] = (np.where(both, (v[np.maximum(prev, 0)] + v[np.minimum(nxt, m - 1)]) / 2, 0.0), both)
         for method in ("Previous", "Next", "Mean"):
-            got, _ = capi.fill(capi.Column(vals, bm, capi.FLOAT64, off, m, -1), method, out_residency=capi.DEVICE)
-            gv, gm = got.host_arrays()[0], got.valid_mask()
-            wv, wm = exp[method]
-            assert np.array_equal(gm, wm), (method, off)
-            assert np.array_equal(gv[gm], wv[wm]), (method, off)
-            assert got.null_count == int((~wm).sum())
+            # (the kernel's bounded walk does not reach across these runs: the call is repeated with the neighbour index built - round 5)
+            for cap in (None, (m + 511) // 512 * 512):
+                got, _ = capi.fill(capi.Column(vals, bm, capi.FLOAT64, off, m, -1), method, out_residency=capi.DEVICE, capacity=cap)
+                gv, gm = got.host_arrays()[0], got.valid_mask()
+                wv, wm = exp[method]
+                assert np.array_equal(gm, wm), (method, off)
+                assert np.array_equal(gv[gm], wv[wm]), (method, off)
+                assert got.null_count == int((~wm).sum())
     # FillLinear through the same index: ref = row number => linear in the row between the two valid neighbours
     ref = np.arange(n, dtype=np.int64)
     got, _ = capi.fill_linear([capi.Column(ref), capi.Column(vals, bm, capi.FLOAT64, 0, n, -1)], 0, 1)
