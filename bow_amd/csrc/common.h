@@ -399,6 +399,7 @@ constexpr int kPoolMode = 17;    // aggregation.Mode: its output's validity work
 constexpr int kPoolColOrder = 18; // IsColSorted: one (first valid, last valid) record per 512-row trip
 constexpr int kPoolShard = 19;   // shard stitch: seed / merged states and the next shard's first row
 constexpr int kPoolGaps = 32;    // window_first_rows: queued runs of empty windows
+constexpr int kPoolWhole = 32;        // bowgpu_aggregate_whole: partial states, the reducers' values and validity bytes
 constexpr int kPoolInterpEdge = 31;   // Interpolate: the trips' edge words (interp_wave3_kernel)
 constexpr int kPoolInterp = 20;  // context pool slots 20..30: tile counts, their scan, scan sums, one neighbour index per column
 // kernel parameter blocks of interp_fill.hip (filled by extras.cpp, passed by value)

@@ -918,19 +918,29 @@ int bowgpu_aggregate_whole(const bowgpu_col *cols, int32_t ncols, int32_t ts_col
     BG_TRY(ts_device(c, &cols[ts_col], &dts));
     // FirstValue / LastValue: int64(float64(first / last valid ts)) (whole.go:54-71)
     int64_t tfirst = 0, tlast = 0;
-    BG_HIP(hipMemcpyAsync(&tfirst, dts.values, 8, hipMemcpyDeviceToHost, c->stream));
-    BG_HIP(hipMemcpyAsync(&tlast, reinterpret_cast<const char *>(dts.values) + 8 * (n - 1), 8, hipMemcpyDeviceToHost, c->stream));
-    BG_HIP(hipStreamSynchronize(c->stream));
+    {
+        int64_t *hp;   // (one small kernel that stores both into the registered block: api.cpp plan_make does the same)
+        BG_TRY(ctx_pinned(c, 4096, reinterpret_cast<void **>(&hp)));
+        hp += 256;
+        BG_TRY(launch_fetch_two(c, reinterpret_cast<const int64_t *>(dts.values), 0, n - 1, hp));
+        BG_HIP(hipStreamSynchronize(c->stream));
+        tfirst = hp[0]; tlast = hp[1];
+    }
     auto go_i64 = [](double x) -> int64_t { return (!(x >= -9223372036854775808.0 && x < 9223372036854775808.0)) ? INT64_MIN : (int64_t)x; };
     const int64_t first_value = go_i64((double)tfirst), last_value = go_i64((double)tlast);
 
     int64_t nblocks = (n + 65535) / 65536;
     if (nblocks > 2048) nblocks = 2048;
     const int64_t chunk = (n + nblocks - 1) / nblocks;
-    DevBuf partials, onev, oneb;
-    BG_TRY(partials.alloc((size_t)(nblocks + 1) * stats_size()));  // + the merged state of the column (whole_run)
-    BG_TRY(onev.alloc(8 * (size_t)naggs));
-    BG_TRY(oneb.alloc(64 + (size_t)naggs));
+    // (one block of the context pool - no hipMalloc / hipFree per call: the partial states + the merged state of the column
+    // (whole_run), one value and one validity byte per reducer)
+    struct Part { void *p; } partials, onev, oneb;
+    {
+        const size_t pb = ((size_t)(nblocks + 1) * stats_size() + 255) & ~(size_t)255, vb = (8 * (size_t)naggs + 255) & ~(size_t)255;
+        void *blk;
+        BG_TRY(ctx_pool(c, kPoolWhole, pb + vb + 64 + (size_t)naggs, &blk));
+        partials.p = blk; onev.p = reinterpret_cast<char *>(blk) + pb; oneb.p = reinterpret_cast<char *>(blk) + pb + vb;
+    }
     std::vector<DevCol> dcols(ncols);
     std::vector<char> done(naggs, 0);
     // Mode (mode.go:8-32) over the one window [0, n): mode.hip, not the streaming partial states
@@ -992,16 +1002,24 @@ int bowgpu_aggregate_whole(const bowgpu_col *cols, int32_t ncols, int32_t ts_col
     BG_HIP(hipMemcpyAsync(hv.data(), onev.p, 8 * (size_t)naggs, hipMemcpyDeviceToHost, c->stream));
     BG_HIP(hipMemcpyAsync(hb.data(), oneb.p, (size_t)naggs, hipMemcpyDeviceToHost, c->stream));
     BG_HIP(hipStreamSynchronize(c->stream));
+    bool any_device = false;
+    std::vector<uint8_t> vbs(naggs);
     for (int i = 0; i < naggs; i++) {
         if (outs[i].length < 1 || !outs[i].values || !outs[i].validity) return fail(BOWGPU_ERR_ARG, "output column %d needs one slot", i);
-        const uint8_t vb = hb[i] ? 1 : 0;
-        BG_HIP(hipMemcpyAsync(outs[i].values, &hv[i], 8, outs[i].residency == BOWGPU_DEVICE ? hipMemcpyHostToDevice : hipMemcpyHostToHost, c->stream));
-        BG_HIP(hipMemcpyAsync(outs[i].validity, &vb, 1, outs[i].residency == BOWGPU_DEVICE ? hipMemcpyHostToDevice : hipMemcpyHostToHost, c->stream));
-        BG_HIP(hipStreamSynchronize(c->stream));
+        vbs[i] = hb[i] ? 1 : 0;
+        if (outs[i].residency == BOWGPU_DEVICE) {   // (one synchronisation behind all of them; host-resident slots are plain stores)
+            BG_HIP(hipMemcpyAsync(outs[i].values, &hv[i], 8, hipMemcpyHostToDevice, c->stream));
+            BG_HIP(hipMemcpyAsync(outs[i].validity, &vbs[i], 1, hipMemcpyHostToDevice, c->stream));
+            any_device = true;
+        } else {
+            memcpy(outs[i].values, &hv[i], 8);
+            *outs[i].validity = vbs[i];
+        }
         outs[i].length = 1;
-        outs[i].null_count = vb ? 0 : 1;
+        outs[i].null_count = vbs[i] ? 0 : 1;
         outs[i].type = out_type_of(i);
     }
+    if (any_device) BG_HIP(hipStreamSynchronize(c->stream));
     return 0;
 }
 

@@ -642,6 +642,131 @@ __global__ __launch_bounds__(256) void whole_partial_kernel(const WholeParams p)
     }
 }
 
+// Level 1 for the VALUE reducers (Count / Sum / Mean / Min / Max / First / Last; no time-weighted one on the column), round 5: nothing
+// is merged across lanes per step.  The kernel above spends ~600 of its ~850 instructions per 512-row step on the six-round shuffle tree
+// over the 14-field state (0.56 ms per 1e8 rows, 0.18 of peak); none of these reducers needs the adjacency that tree preserves - what
+// depends on ROW ORDER is positional and reduces by row index:
+//   Sum, Count       per lane over all its steps, added up at the end (whole-frame sums never were in row order: 1e-12 rel, see above)
+//   First / Last     the lane's lowest / highest valid row and its bits; the lowest / highest index wins
+//   Min / Max        minmax.go:16-28 over the concatenation = the first valid value if that is a NaN (a NaN seed sticks), else the
+//                    extremum of the non-NaN values, the EARLIEST of equal ones (+0 / -0): (value, row) pairs, ties to the lower row
+// A step's validity bits are one byte load per lane, not a load per row.  The wavefront's
+// result is written as the same Stats record, for the same contiguous quarter of the workgroup's rows: the merge levels do not change.
+template <bool kNulls>
+__global__ __launch_bounds__(256) void whole_value_kernel(const WholeParams p) {
+    __shared__ Stats part[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t lo = (int64_t)blockIdx.x * p.chunk;
+    int64_t hi = lo + p.chunk;
+    if (hi > p.n) hi = p.n;
+    const int64_t steps = hi > lo ? (hi - lo + 511) / 512 : 0;
+    const int64_t s_per = (steps + 3) / 4;
+    const int64_t q_lo = lo + (int64_t)wv * s_per * 512;
+    int64_t q_hi = q_lo + s_per * 512;
+    if (q_hi > hi) q_hi = hi;
+    const bool vec = (reinterpret_cast<uintptr_t>(p.values) & 15) == 0;
+    double sum = 0.0, mn = 0.0, mx = 0.0;
+    long long count = 0, mn_row = -1, mx_row = -1, first_row = -1, last_row = -1;
+    uint64_t first_bits = 0, last_bits = 0;
+    // Lane l holds rows 2l, 2l + 1 of each of the step's four 128-row chunks: every load instruction reads 1 KB of consecutive bytes
+    // (eight consecutive rows per lane - the kernel above - make an instruction touch 32 cache lines for 16 bytes each, four times
+    // over: 0.234 ms per 1e8 rows at four times the L2 traffic).  Rows still ascend within a lane.  The next step's loads are in flight
+    // while this step's rows are consumed.
+    // The step's 512 validity bits are 64 (65 at an odd bit offset) consecutive bytes: lane l loads byte l - one coalesced load per
+    // step - and a lane's two bits of a chunk come out of the lane that holds them (ds_bpermute: the crossbar, no LDS memory).  (The
+    // chunks' bits as wave-uniform scalar words, as the rolling kernels read them, cost this lean kernel 0.28 ms per 1e8 rows where
+    // this costs 0.2: four dependent trips to the scalar cache per step and nothing else to do meanwhile.)
+    const uint8_t *vbytes = reinterpret_cast<const uint8_t *>(p.vbits);
+    const int64_t last_byte = kNulls ? (p.vbit0 + p.n - 1) >> 3 : 0;
+    auto fetch = [&](int64_t base, uint64_t (&v)[8], uint32_t &vb, uint32_t &vb64) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) load_pair(p.values, base + 128 * k + 2 * lane, q_hi, vec && (base & 1) == 0, v[2 * k], v[2 * k + 1]);
+        vb = 0; vb64 = 0;
+        if (kNulls) {
+            const int64_t b0 = (p.vbit0 + base) >> 3;
+            if (b0 + lane <= last_byte) vb = vbytes[b0 + lane];
+            if (b0 + 64 <= last_byte) vb64 = vbytes[b0 + 64];
+        }
+    };
+    uint64_t vn[8];
+    uint32_t vbn = 0, vb64n = 0;
+    if (q_lo < q_hi) fetch(q_lo, vn, vbn, vb64n);
+    for (int64_t base = q_lo; base < q_hi; base += 512) {
+        uint64_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = vn[k];
+        uint32_t m = 0xFFu;
+        if (kNulls) {
+            // 16 bits from byte j on: the lane's own byte and its upper neighbour's (lane 63: the 65th byte)
+            uint32_t up = (uint32_t)__shfl_down((int)vbn, 1);
+            if (lane == 63) up = vb64n;
+            const uint32_t pair = vbn | (up << 8);
+            const uint32_t s_off = (uint32_t)((p.vbit0 + base) & 7);
+            m = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t bitpos = s_off + 128u * k + 2u * (uint32_t)lane;   // < 519
+                const uint32_t j = bitpos >> 3;
+                uint32_t w = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((j < 64u ? j : 63u) << 2), (int)pair);
+                if (j >= 64u) w = vb64n;                                           // (the 65th byte is in every lane)
+                m |= ((w >> (bitpos & 7u)) & 3u) << (2 * k);
+            }
+        }
+        if (base + 512 < q_hi) fetch(base + 512, vn, vbn, vb64n);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            // (selects, not branches: 30 % nulls would split every row's step in two.  A row without a value adds +0.0 - exact: the sum
+            // starts at +0.0 and x + (+0.0) == x for every x a sum that started there can be)
+            const int64_t r = base + 128 * (k >> 1) + 2 * lane + (k & 1);
+            const bool ok = r < q_hi && ((m >> k) & 1u);
+            const double x = bits_to_f64(v[k], p.type);
+            sum += ok ? x : 0.0;
+            count += ok ? 1 : 0;
+            const bool fst = ok && first_row < 0;
+            first_row = fst ? r : first_row; first_bits = fst ? v[k] : first_bits;
+            last_row = ok ? r : last_row; last_bits = ok ? v[k] : last_bits;
+            // (rows come in ascending order within the lane: strict comparisons keep the earliest of equal values; a NaN never enters)
+            const bool lo_ = ok && x == x && (mn_row < 0 || x < mn), hi_ = ok && x == x && (mx_row < 0 || x > mx);
+            mn = lo_ ? x : mn; mn_row = lo_ ? r : mn_row;
+            mx = hi_ ? x : mx; mx_row = hi_ ? r : mx_row;
+        }
+    }
+    // ---- across the lanes, once per wavefront: by value, ties to the lower row; by row index
+    for (int o = 32; o > 0; o >>= 1) {
+        sum += __shfl_down(sum, o);
+        count += __shfl_down(count, o);
+        const double omn = __shfl_down(mn, o), omx = __shfl_down(mx, o);
+        const long long omn_row = __shfl_down(mn_row, o), omx_row = __shfl_down(mx_row, o);
+        if (omn_row >= 0 && (mn_row < 0 || omn < mn || (omn == mn && omn_row < mn_row))) { mn = omn; mn_row = omn_row; }
+        if (omx_row >= 0 && (mx_row < 0 || omx > mx || (omx == mx && omx_row < mx_row))) { mx = omx; mx_row = omx_row; }
+        const long long ofr = __shfl_down(first_row, o), olr = __shfl_down(last_row, o);
+        const unsigned long long ofb = __shfl_down((unsigned long long)first_bits, o), olb = __shfl_down((unsigned long long)last_bits, o);
+        if (ofr >= 0 && (first_row < 0 || ofr < first_row)) { first_row = ofr; first_bits = ofb; }
+        if (olr > last_row) { last_row = olr; last_bits = olb; }
+    }
+    if (lane == 0) {
+        Stats st;
+        stats_init(st);
+        if (count > 0) {
+            st.sum = sum; st.count = count; st.has_value = 1;
+            st.first_bits = first_bits; st.last_bits = last_bits;
+            const double f = bits_to_f64(first_bits, p.type);
+            st.has_nn = mn_row >= 0 ? 1 : 0;
+            st.nn_min = mn; st.nn_max = mx;
+            // (stats_value's seed rule on this range: a NaN first value sticks, else the non-NaN extrema - f itself is one of them)
+            st.vmin = (f != f || !st.has_nn) ? f : mn;
+            st.vmax = (f != f || !st.has_nn) ? f : mx;
+        }
+        part[wv] = st;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        Stats acc = part[0];
+        stats_merge(acc, part[1]); stats_merge(acc, part[2]); stats_merge(acc, part[3]);
+        p.partials[blockIdx.x] = acc;
+    }
+}
+
 // Level 2: the workgroup partials of one column -> one state, in order: thread t merges a contiguous run of them, then the
 // same order-preserving tree across lanes and the four wavefronts.  merged[0] receives the result.
 __global__ __launch_bounds__(256) void whole_merge_kernel(const Stats *partials, int64_t nblocks, Stats *merged) {
@@ -850,7 +975,9 @@ int fill_run(Ctx *c, const FillParams &p) {
 // partial states of the column's row chunks, then their ordered merge into partials[nblocks] (one extra slot)
 int whole_run(Ctx *c, const void *params_blob, int64_t nblocks) {
     const WholeParams &p = *reinterpret_cast<const WholeParams *>(params_blob);
-    hipLaunchKernelGGL(whole_partial_kernel, dim3((unsigned)nblocks), dim3(256), 0, c->stream, p);
+    if (p.need_ts) hipLaunchKernelGGL(whole_partial_kernel, dim3((unsigned)nblocks), dim3(256), 0, c->stream, p);
+    else if (p.vbits) hipLaunchKernelGGL(whole_value_kernel<true>, dim3((unsigned)nblocks), dim3(256), 0, c->stream, p);
+    else hipLaunchKernelGGL(whole_value_kernel<false>, dim3((unsigned)nblocks), dim3(256), 0, c->stream, p);
     hipLaunchKernelGGL(whole_merge_kernel, dim3(1), dim3(256), 0, c->stream, p.partials, nblocks, p.partials + nblocks);
     BG_HIP(hipGetLastError());
     return 0;
