@@ -614,6 +614,57 @@ def test_whole_random_vs_oracle():
             assert abs(gl[0] - wl[0]) <= 1e-10 * max(1.0, abs(wl[0])), (k, gl[0], wl[0])
 
 
+@pytest.mark.parametrize("vtype", ["f64", "i64"])
+def test_whole_value_reducers_by_row_index(vtype):
+    """aggregation.Aggregate with value reducers only takes whole_value_kernel (round 5): per-lane (value, row) pairs reduced by row
+    index once per wavefront.  What depends on position - First / Last, the NaN seed of Min / Max, the EARLIEST of equal extremes
+    (+0.0 / -0.0) - must come out as whole.go / minmax.go give it: sizes around the 512-row step and the workgroup chunk, Arrow slices
+    at odd offsets (bitmap bit offsets 0 .. 7), NaN / signalling NaN / zeros of both signs planted first, last and in between."""
+    rng = np.random.default_rng(5)
+    kinds = ["Min", "Max", "First", "Last", "Count", "Sum", "ArithmeticMean"]
+    aggs = [(k, 1) for k in kinds]
+    for n in (1, 2, 7, 511, 512, 513, 4097, 70_001, 300_123):
+        for off in (0, 1, 3, 5):
+            for plant in ("none", "zeros", "nan-first", "nan-mid", "all-null", "no-bitmap"):
+                tot = n + off + 5
+                ts = np.arange(tot, dtype=np.int64)
+                if vtype == "f64":
+                    vals = np.round(rng.standard_normal(tot) * 100, 1)
+                    if plant == "zeros":
+                        vals[rng.random(tot) < 0.5] = 0.0
+                        vals[rng.random(tot) < 0.3] = -0.0
+                        vals = np.where(np.abs(vals) > 0, np.abs(vals), vals)       # zeros of both signs are the minimum
+                    if plant == "nan-first":
+                        vals[off] = np.array([0x7FF0000000000001], dtype=np.uint64).view(np.float64)[0]   # a signalling NaN seed
+                    if plant == "nan-mid" and n > 2:
+                        vals[off + 1 + rng.integers(0, n - 1, max(1, n // 50))] = np.nan
+                else:
+                    vals = rng.integers(-1000, 1000, tot).astype(np.int64)
+                    if plant == "zeros":
+                        vals[rng.random(tot) < 0.6] = 0
+                valid = rng.random(tot) >= 0.3
+                if plant == "nan-first":
+                    valid[off] = True
+                if plant == "all-null":
+                    valid[:] = False
+                bm = None if plant == "no-bitmap" else np.packbits(valid, bitorder="little")
+                typ = capi.FLOAT64 if vtype == "f64" else capi.INT64
+                got = capi.aggregate_whole([capi.Column(ts, None, capi.INT64, off, n, 0), capi.Column(vals, bm, typ, off, n, -1 if bm is not None else 0)], 0, aggs)
+                want = orc.aggregate_whole([orc.Column(ts, None, orc.INT64, offset=off, length=n), orc.Column(vals, bm, typ, offset=off, length=n)], 0, aggs)
+                for k, g, w in zip(kinds, got, want):
+                    label = (k, n, off, plant)
+                    w_null = w.to_list()[0] is None
+                    assert g.length == w.length == 1 and g.null_count == (1 if w_null else 0), label
+                    if w_null:
+                        continue
+                    gb, wb = g.host_arrays()[0].view(np.uint64)[0], w.values[:1].view(np.uint64)[0]
+                    if k in ("Sum", "ArithmeticMean"):
+                        gv, wv = g.host_arrays()[0].view(np.float64)[0], w.values[:1].view(np.float64)[0]
+                        assert (np.isnan(gv) and np.isnan(wv)) or abs(gv - wv) <= 1e-10 * max(1.0, abs(wv)), label
+                    else:
+                        assert gb == wb, (label, hex(gb), hex(wb))
+
+
 def test_window_bounds_across_a_gap_of_millions_of_empty_windows():
     """Two bursts of rows 3e8 apart with interval 10: 3e7 empty windows between them all take the second burst's first row as
     their FirstIndex.  One lane used to store them one by one (seconds); the grid fills long runs now."""
