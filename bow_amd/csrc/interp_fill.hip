@@ -652,7 +652,13 @@ __global__ __launch_bounds__(256) void whole_partial_kernel(const WholeParams p)
 //                    extremum of the non-NaN values, the EARLIEST of equal ones (+0 / -0): (value, row) pairs, ties to the lower row
 // A step's validity bits are one byte load per lane, not a load per row.  The wavefront's
 // result is written as the same Stats record, for the same contiguous quarter of the workgroup's rows: the merge levels do not change.
-template <bool kNulls>
+// kTs: a time-weighted reducer wants the column's integrals too (integral.go:14-31, :46-62 over the whole frame): every valid point's
+// terms with its NEXT valid point.  Inside a 128-row chunk that point is the lane's own second row or the first point of the next lane
+// that has one (ballot, lowest set bit above the lane, four ds_bpermute - long_short_kernel's neighbour search); a chunk's first
+// point closes the pair with the last point so far (uniform: carried from chunk to chunk, step to step); the terms are summed per
+// lane, their order is free like the sums' (1e-12 rel).  The range's first and last point go into the Stats record: stats_merge
+// stitches the ranges.
+template <bool kNulls, bool kTs>
 __global__ __launch_bounds__(256) void whole_value_kernel(const WholeParams p) {
     __shared__ Stats part[4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -668,6 +674,10 @@ __global__ __launch_bounds__(256) void whole_value_kernel(const WholeParams p) {
     double sum = 0.0, mn = 0.0, mx = 0.0;
     long long count = 0, mn_row = -1, mx_row = -1, first_row = -1, last_row = -1;
     uint64_t first_bits = 0, last_bits = 0;
+    double trap = 0.0, step = 0.0;                            // kTs: this lane's share of the terms
+    double c_t = 0.0, c_v = 0.0, f_t = 0.0, f_v = 0.0;        // (uniform) the last point so far; the range's first point
+    bool c_has = false, any_pair = false;
+    const bool tvec = kTs && (reinterpret_cast<uintptr_t>(p.ts) & 15) == 0;
     // Lane l holds rows 2l, 2l + 1 of each of the step's four 128-row chunks: every load instruction reads 1 KB of consecutive bytes
     // (eight consecutive rows per lane - the kernel above - make an instruction touch 32 cache lines for 16 bytes each, four times
     // over: 0.234 ms per 1e8 rows at four times the L2 traffic).  Rows still ascend within a lane.  The next step's loads are in flight
@@ -678,9 +688,13 @@ __global__ __launch_bounds__(256) void whole_value_kernel(const WholeParams p) {
     // this costs 0.2: four dependent trips to the scalar cache per step and nothing else to do meanwhile.)
     const uint8_t *vbytes = reinterpret_cast<const uint8_t *>(p.vbits);
     const int64_t last_byte = kNulls ? (p.vbit0 + p.n - 1) >> 3 : 0;
-    auto fetch = [&](int64_t base, uint64_t (&v)[8], uint32_t &vb, uint32_t &vb64) {
+    auto fetch = [&](int64_t base, uint64_t (&v)[8], uint64_t (&t)[8], uint32_t &vb, uint32_t &vb64) {
 #pragma unroll
         for (int k = 0; k < 4; k++) load_pair(p.values, base + 128 * k + 2 * lane, q_hi, vec && (base & 1) == 0, v[2 * k], v[2 * k + 1]);
+        if (kTs) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) load_pair(reinterpret_cast<const uint64_t *>(p.ts), base + 128 * k + 2 * lane, q_hi, tvec && (base & 1) == 0, t[2 * k], t[2 * k + 1]);
+        }
         vb = 0; vb64 = 0;
         if (kNulls) {
             const int64_t b0 = (p.vbit0 + base) >> 3;
@@ -688,13 +702,13 @@ __global__ __launch_bounds__(256) void whole_value_kernel(const WholeParams p) {
             if (b0 + 64 <= last_byte) vb64 = vbytes[b0 + 64];
         }
     };
-    uint64_t vn[8];
+    uint64_t vn[8], tn[8];
     uint32_t vbn = 0, vb64n = 0;
-    if (q_lo < q_hi) fetch(q_lo, vn, vbn, vb64n);
+    if (q_lo < q_hi) fetch(q_lo, vn, tn, vbn, vb64n);
     for (int64_t base = q_lo; base < q_hi; base += 512) {
-        uint64_t v[8];
+        uint64_t v[8], tt[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) v[k] = vn[k];
+        for (int k = 0; k < 8; k++) { v[k] = vn[k]; if (kTs) tt[k] = tn[k]; }
         uint32_t m = 0xFFu;
         if (kNulls) {
             // 16 bits from byte j on: the lane's own byte and its upper neighbour's (lane 63: the 65th byte)
@@ -712,7 +726,39 @@ __global__ __launch_bounds__(256) void whole_value_kernel(const WholeParams p) {
                 m |= ((w >> (bitpos & 7u)) & 3u) << (2 * k);
             }
         }
-        if (base + 512 < q_hi) fetch(base + 512, vn, vbn, vb64n);
+        if (base + 512 < q_hi) fetch(base + 512, vn, tn, vbn, vb64n);
+        if (kTs) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int64_t rx = base + 128 * k + 2 * lane;
+                const bool okx = rx < q_hi && ((m >> (2 * k)) & 1u), oky = rx + 1 < q_hi && ((m >> (2 * k + 1)) & 1u);
+                const uint64_t hasm = __ballot(okx || oky);
+                if (!hasm) continue;                                   // (uniform)
+                const double xt = (double)(int64_t)tt[2 * k], yt = (double)(int64_t)tt[2 * k + 1];   // whole.go / integral.go: float64(ts)
+                const double xv = bits_to_f64(v[2 * k], p.type), yv = bits_to_f64(v[2 * k + 1], p.type);
+                const double o_t = okx ? xt : yt, o_v = okx ? xv : yv;      // the lane's first point
+                const double l_t = oky ? yt : xt, l_v = oky ? yv : xv;      // ... and its last
+                // the first point of the next lane that has one
+                const uint64_t above = (hasm >> lane) >> 1;
+                const int src = (lane + 1 + (above ? __ffsll((long long)above) - 1 : 0)) << 2;
+                const double a_t = __hiloint2double(__builtin_amdgcn_ds_bpermute(src, __double2hiint(o_t)), __builtin_amdgcn_ds_bpermute(src, __double2loint(o_t)));
+                const double a_v = __hiloint2double(__builtin_amdgcn_ds_bpermute(src, __double2hiint(o_v)), __builtin_amdgcn_ds_bpermute(src, __double2loint(o_v)));
+                if (okx && oky) { trap += (xv + yv) / 2 * (yt - xt); step += xv * (yt - xt); }
+                if ((okx || oky) && above) { trap += (l_v + a_v) / 2 * (a_t - l_t); step += l_v * (a_t - l_t); }
+                // (uniform) the chunk's first point closes the pair with the last point so far; its last point is the new one
+                const int lf = __ffsll((long long)hasm) - 1, ll = 63 - __clzll((long long)hasm);
+                const double q_t = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(o_t), lf), __builtin_amdgcn_readlane(__double2loint(o_t), lf));
+                const double q_v = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(o_v), lf), __builtin_amdgcn_readlane(__double2loint(o_v), lf));
+                if (c_has) {
+                    if (lane == 0) { trap += (c_v + q_v) / 2 * (q_t - c_t); step += c_v * (q_t - c_t); }
+                    any_pair = true;
+                } else { f_t = q_t; f_v = q_v; }
+                any_pair = any_pair || (hasm & (hasm - 1)) != 0 || __ballot(okx && oky) != 0;
+                c_t = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(l_t), ll), __builtin_amdgcn_readlane(__double2loint(l_t), ll));
+                c_v = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(l_v), ll), __builtin_amdgcn_readlane(__double2loint(l_v), ll));
+                c_has = true;
+            }
+        }
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             // (selects, not branches: 30 % nulls would split every row's step in two.  A row without a value adds +0.0 - exact: the sum
@@ -743,10 +789,16 @@ __global__ __launch_bounds__(256) void whole_value_kernel(const WholeParams p) {
         const unsigned long long ofb = __shfl_down((unsigned long long)first_bits, o), olb = __shfl_down((unsigned long long)last_bits, o);
         if (ofr >= 0 && (first_row < 0 || ofr < first_row)) { first_row = ofr; first_bits = ofb; }
         if (olr > last_row) { last_row = olr; last_bits = olb; }
+        if (kTs) { trap += __shfl_down(trap, o); step += __shfl_down(step, o); }
     }
     if (lane == 0) {
         Stats st;
         stats_init(st);
+        if (kTs && c_has) {
+            st.has_point = 1; st.has_pair = any_pair ? 1 : 0;
+            st.first_pt = f_t; st.first_pv = f_v; st.pt = c_t; st.pv = c_v;
+            st.integ_trap = trap; st.integ_step = step;
+        }
         if (count > 0) {
             st.sum = sum; st.count = count; st.has_value = 1;
             st.first_bits = first_bits; st.last_bits = last_bits;
@@ -975,9 +1027,13 @@ int fill_run(Ctx *c, const FillParams &p) {
 // partial states of the column's row chunks, then their ordered merge into partials[nblocks] (one extra slot)
 int whole_run(Ctx *c, const void *params_blob, int64_t nblocks) {
     const WholeParams &p = *reinterpret_cast<const WholeParams *>(params_blob);
-    if (p.need_ts) hipLaunchKernelGGL(whole_partial_kernel, dim3((unsigned)nblocks), dim3(256), 0, c->stream, p);
-    else if (p.vbits) hipLaunchKernelGGL(whole_value_kernel<true>, dim3((unsigned)nblocks), dim3(256), 0, c->stream, p);
-    else hipLaunchKernelGGL(whole_value_kernel<false>, dim3((unsigned)nblocks), dim3(256), 0, c->stream, p);
+    // (whole_partial_kernel - the shuffle-tree form of rounds 1 - 4 - stays as the second implementation: BOWGPU_ROUTE_FORCE_GENERAL)
+    if (route_mask() & BOWGPU_ROUTE_FORCE_GENERAL) hipLaunchKernelGGL(whole_partial_kernel, dim3((unsigned)nblocks), dim3(256), 0, c->stream, p);
+    else if (p.need_ts) {
+        if (p.vbits) hipLaunchKernelGGL((whole_value_kernel<true, true>), dim3((unsigned)nblocks), dim3(256), 0, c->stream, p);
+        else hipLaunchKernelGGL((whole_value_kernel<false, true>), dim3((unsigned)nblocks), dim3(256), 0, c->stream, p);
+    } else if (p.vbits) hipLaunchKernelGGL((whole_value_kernel<true, false>), dim3((unsigned)nblocks), dim3(256), 0, c->stream, p);
+    else hipLaunchKernelGGL((whole_value_kernel<false, false>), dim3((unsigned)nblocks), dim3(256), 0, c->stream, p);
     hipLaunchKernelGGL(whole_merge_kernel, dim3(1), dim3(256), 0, c->stream, p.partials, nblocks, p.partials + nblocks);
     BG_HIP(hipGetLastError());
     return 0;

@@ -603,15 +603,48 @@ def test_whole_random_vs_oracle():
     kinds = ["WindowStart", "Sum", "ArithmeticMean", "Min", "Max", "Count", "First", "Last", "IntegralStep",
              "IntegralTrapezoid", "WeightedAverageStep", "WeightedAverageLinear"]
     aggs = [(k, 0 if k == "WindowStart" else 1) for k in kinds]
-    got = capi.aggregate_whole([capi.Column(ts), capi.Column(vals, bm, capi.FLOAT64, 0, n, -1)], 0, aggs)
     want = orc.aggregate_whole([orc.Column(ts, None, orc.INT64), orc.Column(vals, bm, orc.FLOAT64)], 0, aggs)
-    for k, g, w in zip(kinds, got, want):
-        gl, wl = g.to_list(), w.to_list()
-        assert len(gl) == len(wl) == 1 and (gl[0] is None) == (wl[0] is None), k
-        if k in ("WindowStart", "Min", "Max", "Count", "First", "Last"):
-            assert gl[0] == wl[0], k
-        else:
-            assert abs(gl[0] - wl[0]) <= 1e-10 * max(1.0, abs(wl[0])), (k, gl[0], wl[0])
+    # (round 5: whole_value_kernel<.., kTs> - terms with the next valid point found across lanes, chunks and steps; the shuffle-tree
+    # kernel of rounds 1 - 4 stays behind ROUTE_FORCE_GENERAL as the second implementation)
+    for mask in (0, capi.ROUTE_FORCE_GENERAL):
+        with capi.route(mask):
+            got = capi.aggregate_whole([capi.Column(ts), capi.Column(vals, bm, capi.FLOAT64, 0, n, -1)], 0, aggs)
+        for k, g, w in zip(kinds, got, want):
+            gl, wl = g.to_list(), w.to_list()
+            assert len(gl) == len(wl) == 1 and (gl[0] is None) == (wl[0] is None), k
+            if k in ("WindowStart", "Min", "Max", "Count", "First", "Last"):
+                assert gl[0] == wl[0], k
+            else:
+                assert abs(gl[0] - wl[0]) <= 1e-10 * max(1.0, abs(wl[0])), (k, gl[0], wl[0])
+
+
+def test_whole_time_weighted_sparse_points():
+    """the integrals over the whole frame when valid points are rare and clustered: chunks, steps and whole wavefront ranges without
+    a point, one point in the frame (no pair: nil), two points 100 000 rows apart, points only at the ends, Int64 values, slices"""
+    rng = np.random.default_rng(77)
+    kinds = ["IntegralStep", "IntegralTrapezoid", "WeightedAverageStep", "WeightedAverageLinear", "Count", "Last"]
+    aggs = [(k, 1) for k in kinds]
+    # (sizes of a few wavefront ranges, not more: the oracle - like the reference - walks to the next valid point from every row)
+    for n, pts in ((5, [2]), (9_000, [2_000, 7_000]), (10_001, [0, 10_000]), (7_000, list(range(0, 7_000, 111))),
+                   (9_457, sorted(rng.choice(9_457, 40, replace=False).tolist())), (4_000, []), (600, [0, 1, 2, 597, 598, 599])):
+        for off in (0, 3):
+            for typ_name in ("f64", "i64"):
+                tot = n + off
+                ts = np.cumsum(rng.integers(1, 50, tot)).astype(np.int64)
+                vals = np.round(rng.standard_normal(tot) * 10, 1) if typ_name == "f64" else rng.integers(-100, 100, tot).astype(np.int64)
+                valid = np.zeros(tot, dtype=bool)
+                valid[[off + q for q in pts]] = True
+                bm = np.packbits(valid, bitorder="little")
+                typ = capi.FLOAT64 if typ_name == "f64" else capi.INT64
+                want = orc.aggregate_whole([orc.Column(ts, None, orc.INT64, offset=off, length=n), orc.Column(vals, bm, typ, offset=off, length=n)], 0, aggs)
+                for mask in (0, capi.ROUTE_FORCE_GENERAL):
+                    with capi.route(mask):
+                        got = capi.aggregate_whole([capi.Column(ts, None, capi.INT64, off, n, 0), capi.Column(vals, bm, typ, off, n, -1)], 0, aggs)
+                    for k, g, w in zip(kinds, got, want):
+                        gl, wl = g.to_list(), w.to_list()
+                        assert (gl[0] is None) == (wl[0] is None), (k, n, off, typ_name, mask, gl, wl)
+                        if gl[0] is not None:
+                            assert abs(gl[0] - wl[0]) <= 1e-10 * max(1.0, abs(wl[0])), (k, n, off, typ_name, mask, gl[0], wl[0])
 
 
 @pytest.mark.parametrize("vtype", ["f64", "i64"])
