@@ -692,6 +692,28 @@ def test_compacting_kernel_for_nullable_columns_under_time_weighted_reducers(row
     run_both(ts2, [(f, fm)], interval, [("WindowStart", 0), ("WeightedAverageStep", 1), ("IntegralTrapezoid", 1)])
 
 
+@pytest.mark.parametrize("W", [262_143, 262_144, 262_145, 300_001])
+def test_null_counts_around_the_size_where_the_finish_launch_reports_to_the_host_itself(W):
+    """up to 262 144 windows (common.h kFinishHostBits) ONE workgroup per output finishes the bitmap and stores the status words and
+    the valid counts straight into the host's registered block (round 5: no copy command behind a small call); above it the counts are
+    summed with atomics and copied.  Both sides of the boundary: outputs, null counts, and the unsorted-column status through that path."""
+    rng = np.random.default_rng(W)
+    n = W * 2 - 1                                    # two rows per window, the last window one
+    ts = np.arange(n, dtype=np.int64)
+    v, valid = make_vals(rng, n, "f64", 0.6)         # ~16 % of the windows hold no value: Mean / Min nil there
+    aggs = [("WindowStart", 0), ("ArithmeticMean", 1), ("Min", 1), ("Count", 1), ("Last", 1)]
+    for device in (False, True):
+        outs, exp, info = run_both(ts, [(v, valid)], 2, aggs, device=device)
+        assert outs[0].length == W
+        for g, w in zip(outs, exp):
+            assert g.null_count == w.length - int(w.valid_mask().sum())
+    bad = ts.copy()
+    bad[n // 2] = 0
+    with pytest.raises(capi.BowGpuError) as e:
+        capi.rolling_aggregate([capi.Column(bad), capi.Column(v, np.packbits(valid, bitorder="little"), capi.FLOAT64, 0, n, -1)], 0, 2, aggs)
+    assert e.value.code == -14
+
+
 def test_slow_route_counter_tells_a_caller_when_a_fallback_kernel_served_the_call():
     """bowgpu_last_call_slow_rows: 0 for the usual call; the call's rows when rolling_agg_kernel (here forced; in the product: the redo of
     a tile no wave-tile kernel can describe, intervals >= 2^32 with time-weighted reducers) or interp_tile_kernel served it"""
