@@ -931,7 +931,9 @@ int bowgpu_aggregate_whole(const bowgpu_col *cols, int32_t ncols, int32_t ts_col
 
     int64_t nblocks = (n + 65535) / 65536;
     if (nblocks > 2048) nblocks = 2048;
-    const int64_t chunk = (n + nblocks - 1) / nblocks;
+    // (a multiple of the kernels' 512-row step: every workgroup's rows then start on a 16-byte boundary of the columns and on a byte of
+    // the bitmap's rows; the workgroups this leaves without rows write the identity state)
+    const int64_t chunk = ((n + nblocks - 1) / nblocks + 511) & ~(int64_t)511;
     // (one block of the context pool - no hipMalloc / hipFree per call: the partial states + the merged state of the column
     // (whole_run), one value and one validity byte per reducer)
     struct Part { void *p; } partials, onev, oneb;
