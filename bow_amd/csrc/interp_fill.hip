@@ -931,7 +931,7 @@ int launch_col_order(Ctx *c, const uint64_t *values, const uint32_t *vbits, int6
     void *w;
     BG_TRY(ctx_pool(c, kPoolColOrder, (size_t)(ntrips + ntrips / 128 + 8) * sizeof(TripEdge), &w));  // every level of the join
     TripEdge *edges = reinterpret_cast<TripEdge *>(w);
-    const dim3 grid(grid_for(ntrips, 4, 1024)), block(256);
+    const dim3 grid(grid_for(ntrips, 4, 4096)), block(256);   // (1024 workgroups left 16 wavefronts per CU waiting out one load each: 0.25 ms per 1e8 rows)
     const bool is_int = type == BOWGPU_INT64;
     if (is_int) hipLaunchKernelGGL(col_order_kernel<true>, grid, block, 0, c->stream, values, vbits, vbit0, n, edges, d_flags);
     else hipLaunchKernelGGL(col_order_kernel<false>, grid, block, 0, c->stream, values, vbits, vbit0, n, edges, d_flags);
