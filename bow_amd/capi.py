@@ -131,7 +131,7 @@ SYMBOLS = [
     "bowgpu_timer_elapsed_ms", "bowgpu_timer_destroy", "bowgpu_enforce_interval_and_offset", "bowgpu_plan_windows",
     "bowgpu_rolling_aggregate", "bowgpu_plan_windows_ex", "bowgpu_rolling_aggregate_planned", "bowgpu_window_bounds", "bowgpu_aggregate_whole",
     "bowgpu_rolling_interpolate_count", "bowgpu_rolling_interpolate_fill", "bowgpu_shard_interp_points",
-    "bowgpu_shard_interpolate_count", "bowgpu_shard_interpolate_fill", "bowgpu_fill_linear", "bowgpu_fill",
+    "bowgpu_shard_interpolate_count", "bowgpu_shard_interpolate_fill", "bowgpu_fill_linear", "bowgpu_fill_linear_sorted", "bowgpu_fill",
     "bowgpu_is_col_sorted", "bowgpu_shard_span", "bowgpu_shard_aggregate", "bowgpu_shard_carry_only", "bowgpu_shard_first_row", "bowgpu_shard_fix_first", "bowgpu_carry_merge",
     "bowgpu_shard_begin", "bowgpu_shard_pass_begin", "bowgpu_shard_plan", "bowgpu_shard_finish", "bowgpu_gen_dense",
     "bowgpu_gen_sparse", "bowgpu_stream_read_ceiling", "bowgpu_stream_rw_probe", "bowgpu_debug_status", "bowgpu_debug_host_copy", "bowgpu_checksum64", "bowgpu_parquet_open", "bowgpu_parquet_close",
@@ -686,13 +686,14 @@ def shard_interpolate(cols, ts_col, interval, interps, global_s0, rank, all_poin
     return outs
 
 
-def fill_linear(cols, ref_col, fill_col, out_residency=HOST, capacity=None):
+def fill_linear(cols, ref_col, fill_col, out_residency=HOST, capacity=None, ref_checked=False):
     """capacity: rows the output buffers can hold (default: exactly the column's) - a device-resident bitmap that reaches the end of its
     last 64-bit word and is 8-byte aligned is written in place (bow_amd/csrc/extras.cpp fill_finish)"""
     out = OutColumn(cols[fill_col].length if capacity is None else capacity, out_residency)
     o = out.c()
     unchanged = C.c_int32(0)
-    check(lib().bowgpu_fill_linear(_cols(cols), len(cols), ref_col, fill_col, C.byref(o), C.byref(unchanged)))
+    fn = lib().bowgpu_fill_linear_sorted if ref_checked else lib().bowgpu_fill_linear   # (ref_checked: the caller ran bowfill.go:35-42 itself)
+    check(fn(_cols(cols), len(cols), ref_col, fill_col, C.byref(o), C.byref(unchanged)))
     out.absorb(o)
     return out, bool(unchanged.value)
 

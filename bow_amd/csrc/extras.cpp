@@ -778,7 +778,16 @@ int bowgpu_is_col_sorted(const bowgpu_col *col, int32_t *sorted) {
 
 static int fill_finish(Ctx *c, FillParams &P, int64_t n, const DevCol &dfill, DevOut *dout, int type);
 
+static int fill_linear_impl(const bowgpu_col *cols, int32_t ncols, int32_t ref_col, int32_t fill_col, bowgpu_out *out, int32_t *unchanged,
+                            bool ref_checked);
 int bowgpu_fill_linear(const bowgpu_col *cols, int32_t ncols, int32_t ref_col, int32_t fill_col, bowgpu_out *out, int32_t *unchanged) {
+    return fill_linear_impl(cols, ncols, ref_col, fill_col, out, unchanged, false);
+}
+int bowgpu_fill_linear_sorted(const bowgpu_col *cols, int32_t ncols, int32_t ref_col, int32_t fill_col, bowgpu_out *out, int32_t *unchanged) {
+    return fill_linear_impl(cols, ncols, ref_col, fill_col, out, unchanged, true);
+}
+static int fill_linear_impl(const bowgpu_col *cols, int32_t ncols, int32_t ref_col, int32_t fill_col, bowgpu_out *out, int32_t *unchanged,
+                            bool ref_checked) {
     // reference bowfill.go:14-103
     if (!cols || !out || !unchanged) return fail(BOWGPU_ERR_ARG, "null argument");
     if (ref_col < 0 || ref_col > ncols - 1) return fail(BOWGPU_ERR_BAD_COL, "refColIndex is out of range");
@@ -800,8 +809,10 @@ int bowgpu_fill_linear(const bowgpu_col *cols, int32_t ncols, int32_t ref_col, i
     BG_TRY(devcol_prepare(c, &cols[fill_col], &dfill, true, true));
     DevOut dout;
     BG_TRY(devout_prepare(c, out, n, &dout, 0));
-    uint32_t f = 0;
-    if (n > 0) BG_TRY(col_order_flags(c, dref, rt, &f));
+    // (ref_checked: the caller's own bowfill.go:35-42 - the ref column holds a value and IsColSorted - has run; the pass over the ref
+    // column that establishes both, a quarter of the call at 1e8 rows, is not made a second time)
+    uint32_t f = ref_checked ? 4u : 0u;
+    if (n > 0 && !ref_checked) BG_TRY(col_order_flags(c, dref, rt, &f));
     const bool ref_empty = !(f & 4);                                  // IsColEmpty: bowassertion.go:84-86
     const bool ref_sorted = (f & 4) && !((f & 1) && (f & 2));
     if (!ref_empty && !ref_sorted) return fail(BOWGPU_ERR_NOT_SORTED, "refColIndex '%d' is empty or not sorted", ref_col);

@@ -405,6 +405,12 @@ int bowgpu_rolling_interpolate_aggregate(const bowgpu_col *cols, int32_t ncols, 
  * (bowfill.go:35-37, :53-55). */
 int bowgpu_fill_linear(const bowgpu_col *cols, int32_t ncols, int32_t ref_col, int32_t fill_col,
                        bowgpu_out *out, int32_t *unchanged);
+/* The same for a caller whose own checks have run - reference bowfill.go:35-42: the ref column holds a value and IsColSorted says
+ * yes (the cgo shim's hook sits behind them; its IsColSorted is bowgpu_is_col_sorted): the pass over the ref column that establishes
+ * both (a quarter of the call at 1e8 rows) is not made a second time.  On a ref column that is NOT sorted the filled values are
+ * whatever linear.go's expression gives between the neighbours found - no error, no out-of-bounds access. */
+int bowgpu_fill_linear_sorted(const bowgpu_col *cols, int32_t ncols, int32_t ref_col, int32_t fill_col,
+                              bowgpu_out *out, int32_t *unchanged);
 
 /* Bow.FillPrevious / Bow.FillNext (LOCF / NOCB) — reference bowfill.go:162-253 — and Bow.FillMean — reference
  * bowfill.go:105-160 — of ONE Int64 / Float64 column (the reference loops over the selected columns, one goroutine each;

@@ -25,3 +25,9 @@ def fl():
 w = med(fl)
 print("%-40s wall %.3f ms per call  %6.1f G rows/s  %.2f of 8 TB/s on %.2f GB moved (kernel %s %.3f ms)" %
       ("FillLinear, 30 % nulls, ref = ts", w, n / w / 1e6, 2.4125 / w / 8, 2.4125, capi.last_kernel_name(), capi.last_kernel_ms()))
+def fls():
+    o = out.c(); u = C.c_int32(0)
+    capi.check(capi.lib().bowgpu_fill_linear_sorted(carr, 2, 0, 1, C.byref(o), C.byref(u)))
+w = med(fls)
+print("%-40s wall %.3f ms per call  %6.1f G rows/s  %.2f of 8 TB/s on %.2f GB moved (kernel %s %.3f ms)" %
+      ("... the ref column checked by the caller", w, n / w / 1e6, 2.4125 / w / 8, 2.4125, capi.last_kernel_name(), capi.last_kernel_ms()))

@@ -15,7 +15,7 @@ rm -rf $DST && mkdir -p $DST
 bash scratch/profile_bench.sh $TAG > $DST/profile_bench.log 2>&1
 cp gpurun_out/prof/${TAG}_* $DST/ 2>/dev/null
 cp gpurun_out/prof/bench.json $DST/${TAG}_bench_1e9.json 2>/dev/null
-for name in configs general_bench interp_wall fill_wall whole_wall longw_kinds midw_sweep small_calls host_resident; do
+for name in configs general_bench interp_wall fill_wall whole_wall callers_wall longw_kinds midw_sweep small_calls host_resident; do
   PROF=0; [ "$name" = small_calls ] && PROF=1
   BOWGPU_CALL_PROFILE=$PROF timeout -s KILL 600 python3 scratch/$name.py 2> $DST/${TAG}_stderr_${name}.tmp | grep -v "^[WE]2026" > $DST/${TAG}_stdout_${name}.txt
   # (the call profiler's lines - stderr - go to their own file, not into the table)

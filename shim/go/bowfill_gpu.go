@@ -130,9 +130,11 @@ func (b *bow) fillLinearGPU(refCol, toFillCol int) (Bow, error) {
 	cols := []C.bowgpu_col{gpuColDesc(b, refCol, &pin), gpuColDesc(b, toFillCol, &pin)}
 	out, data, valid := gpuOut(b.NumRows(), &pin)
 	var unchanged C.int32_t
-	switch rc := C.bowgpu_fill_linear(&cols[0], 2, 0, 1, &out, &unchanged); rc {
+	// (_sorted: FillLinear's own checks - bowfill.go:35-42, IsColEmpty and IsColSorted of the ref column, the latter through
+	// isColSortedGPU - have run by the time the hook is reached: the library does not scan the ref column for them again)
+	switch rc := C.bowgpu_fill_linear_sorted(&cols[0], 2, 0, 1, &out, &unchanged); rc {
 	case 0:
-	case C.BOWGPU_ERR_NOT_SORTED: // bowfill.go:39-42 (IsColSorted has said otherwise by now: kept for a column that changed in between)
+	case C.BOWGPU_ERR_NOT_SORTED: // (bowgpu_fill_linear's answer - bowfill.go:39-42 in the reference's words - for a binding that calls the checking form)
 		return nil, fmt.Errorf("refColIndex '%d' is empty or not sorted", refCol)
 	default:
 		return nil, errGPUDeclined

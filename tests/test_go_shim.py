@@ -72,7 +72,7 @@ def test_every_c_name_the_shim_uses_is_in_the_header():
     assert used_const <= set(enums), used_const - set(enums)
     # the entry points of the hot path are bound
     assert {"bowgpu_rolling_aggregate", "bowgpu_abi_version", "bowgpu_rolling_interpolate_count", "bowgpu_rolling_interpolate_fill",
-            "bowgpu_fill_linear", "bowgpu_fill", "bowgpu_is_col_sorted", "bowgpu_shard_begin", "bowgpu_shard_pass_begin", "bowgpu_shard_finish",
+            "bowgpu_fill_linear_sorted", "bowgpu_fill", "bowgpu_is_col_sorted", "bowgpu_shard_begin", "bowgpu_shard_pass_begin", "bowgpu_shard_finish",
             "bowgpu_host_register", "bowgpu_host_unregister", "bowgpu_last_error", "bowgpu_aggregate_whole"} <= used_fn
 
 

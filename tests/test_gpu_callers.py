@@ -431,6 +431,10 @@ def test_fill_linear_random_vs_oracle(ftype, desc):
     got, unchanged = capi.fill_linear([capi.Column(ref, rb, capi.FLOAT64, 0, n, -1), capi.Column(fill, fb, ftyp, 0, n, -1)], 0, 1)
     assert unchanged == wu
     cmp_out("fill", got, want)
+    # bowgpu_fill_linear_sorted: the caller's own bowfill.go:35-42 has run (the cgo hook's position) - same result, no second order check
+    got, unchanged = capi.fill_linear([capi.Column(ref, rb, capi.FLOAT64, 0, n, -1), capi.Column(fill, fb, ftyp, 0, n, -1)], 0, 1, ref_checked=True)
+    assert unchanged == wu
+    cmp_out("fill, ref checked by the caller", got, want)
     # no nulls => the reference returns the receiver
     got, unchanged = capi.fill_linear([capi.Column(ref, rb, capi.FLOAT64, 0, n, -1), capi.Column(fill, None, ftyp)], 0, 1)
     assert unchanged and got.null_count == 0
