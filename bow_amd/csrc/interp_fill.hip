@@ -659,7 +659,7 @@ __global__ __launch_bounds__(256) void whole_partial_kernel(const WholeParams p)
 // lane, their order is free like the sums' (1e-12 rel).  The range's first and last point go into the Stats record: stats_merge
 // stitches the ranges.
 template <bool kNulls, bool kTs>
-__global__ __launch_bounds__(256) void whole_value_kernel(const WholeParams p) {
+__global__ __launch_bounds__(256, 4) void whole_value_kernel(const WholeParams p) {
     __shared__ Stats part[4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t lo = (int64_t)blockIdx.x * p.chunk;
@@ -702,11 +702,14 @@ __global__ __launch_bounds__(256) void whole_value_kernel(const WholeParams p) {
             if (b0 + 64 <= last_byte) vb64 = vbytes[b0 + 64];
         }
     };
+    // (kTs: no loads ahead - two more columns' worth of registers in flight cost the time-weighted form a third of its wavefronts)
+    constexpr bool kAhead = !kTs;
     uint64_t vn[8], tn[8];
     uint32_t vbn = 0, vb64n = 0;
-    if (q_lo < q_hi) fetch(q_lo, vn, tn, vbn, vb64n);
+    if (kAhead && q_lo < q_hi) fetch(q_lo, vn, tn, vbn, vb64n);
     for (int64_t base = q_lo; base < q_hi; base += 512) {
         uint64_t v[8], tt[8];
+        if (!kAhead) fetch(base, vn, tn, vbn, vb64n);
 #pragma unroll
         for (int k = 0; k < 8; k++) { v[k] = vn[k]; if (kTs) tt[k] = tn[k]; }
         uint32_t m = 0xFFu;
@@ -726,7 +729,7 @@ __global__ __launch_bounds__(256) void whole_value_kernel(const WholeParams p) {
                 m |= ((w >> (bitpos & 7u)) & 3u) << (2 * k);
             }
         }
-        if (base + 512 < q_hi) fetch(base + 512, vn, tn, vbn, vb64n);
+        if (kAhead && base + 512 < q_hi) fetch(base + 512, vn, tn, vbn, vb64n);
         if (kTs) {
 #pragma unroll
             for (int k = 0; k < 4; k++) {
