@@ -658,8 +658,10 @@ __global__ __launch_bounds__(256) void whole_partial_kernel(const WholeParams p)
 // point closes the pair with the last point so far (uniform: carried from chunk to chunk, step to step); the terms are summed per
 // lane, their order is free like the sums' (1e-12 rel).  The range's first and last point go into the Stats record: stats_merge
 // stitches the ranges.
+// (launch bounds: four wavefronts per SIMD - the time-weighted form then fits 128 vector registers with three of them parked in scratch;
+// with nulls as well it would park seventeen and ran 0.46 ms on one box, 0.58 on the next: three wavefronts, 141 registers, none parked)
 template <bool kNulls, bool kTs>
-__global__ __launch_bounds__(256, 4) void whole_value_kernel(const WholeParams p) {
+__global__ __launch_bounds__(256, (kNulls && kTs) ? 3 : 4) void whole_value_kernel(const WholeParams p) {
     __shared__ Stats part[4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t lo = (int64_t)blockIdx.x * p.chunk;
