@@ -61,3 +61,18 @@ def test_the_identity_ignores_what_the_kernel_is_not_compiled_from(tmp_path):
     import kernel_sha
     again = kernel_sha.kernel_identities(os.path.join(CSRC, "build", "rolling_simple.o"), "rolling_simple_kernel")
     assert again[bench.BENCH_KERNEL_INSTANCE]["sha"] == sha
+
+
+def test_every_profile_file_of_the_round_is_described_and_every_described_file_exists():
+    """profiles/README.md, round-5 section: the files it names are there, and no r05_* file sits in profiles/ without a line about it"""
+    import re
+    readme = open(os.path.join(ROOT, "profiles", "README.md")).read()
+    sec = readme[readme.index("## Round 5"):readme.index("## Round 4")]
+    named = set(re.findall(r"`(r05_[A-Za-z0-9_.]+)`", sec))
+    present = {f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.startswith("r05_")}
+    assert named <= present, sorted(named - present)
+    assert present <= named, sorted(present - named)
+    # the design document does not quote round-5 evidence that is not there either
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    quoted = set(re.findall(r"`(?:profiles/)?(r05_[A-Za-z0-9_.]+\.(?:txt|csv|json))`", design))
+    assert quoted <= present, sorted(quoted - present)
