@@ -173,7 +173,29 @@ def host_pinned_rate(capi, dev_cols, sample, aggs):
             dt = time.perf_counter() - t0
             best = dt if best is None or dt < best else best
         moved = sample * BYTES_PER_ROW + 2 * 8.125 * W
-        return {"value": sample / best, "unit": "rows/s", "ms_per_call": best * 1e3, "rows": sample, "pcie_gb_per_s": moved / best / 1e9,
+        # ... and the SAME call with the library's multi-device fan-out on (bowgpu_set_devices: one call, row ranges over the listed
+        # devices, each reading its range in place over its own host link).  On a one-GPU box the device is listed twice: the path
+        # runs (two ranks, records in host memory, stitched outputs) but there is only one link to share.
+        multi = None
+        try:
+            ndev = capi.device_count()
+            ids = list(range(ndev)) if ndev > 1 else [0, 0]
+            with capi.devices(ids):
+                bm = None
+                for _ in range(4):
+                    t0 = time.perf_counter()
+                    capi.rolling_aggregate(cols, 0, INTERVAL, aggs, outs=outs)
+                    dt = time.perf_counter() - t0
+                    bm = dt if bm is None or dt < bm else bm
+                ranks = capi.last_call_ranks()
+            multi = {"value": sample / bm, "unit": "rows/s", "ms_per_call": bm * 1e3, "rows": sample, "devices": ids, "ranks": ranks,
+                     "pcie_gb_per_s": moved / bm / 1e9,
+                     "what": "the same registered columns through ONE bowgpu_rolling_aggregate call with bowgpu_set_devices(%s) in force: "
+                             "row ranges on one library thread per listed device, boundary windows stitched in row order, outputs placed "
+                             "in the caller's buffers (bit-identical to the one-device call: tests/test_gpu_multi.py)" % ids}
+        except Exception as e:
+            multi = {"error": repr(e)}
+        return {"multi": multi, "value": sample / best, "unit": "rows/s", "ms_per_call": best * 1e3, "rows": sample, "pcie_gb_per_s": moved / best / 1e9,
                 "pageable_rows_per_s": (sample / pageable) if pageable else None,
                 "pageable_pcie_gb_per_s": (moved / pageable / 1e9) if pageable else None,
                 "what": "PCIe-inclusive: registered host columns read in place by the kernels (zero-copy) + outputs by DMA to registered "
@@ -517,6 +539,7 @@ def main():
             # read in place by the kernels (BOWGPU_HOST_PINNED, zero-copy), outputs by DMA into registered buffers
             try:
                 line["host_pinned"] = host_pinned_rate(capi, cols, min(rows, 100_000_000), aggs)
+                line["host_pinned_multi"] = line["host_pinned"].pop("multi", None)
             except Exception as e:
                 line["host_pinned"] = {"error": repr(e)}
         if not args.no_cpu and world == 1:

@@ -26,7 +26,7 @@ INTERP = {"WindowStart": 0, "Linear": 1, "StepPrevious": 2, "None": 3, "Const": 
 
 MAX_FACTORS = 4
 CARRY_MAX_AGGS = 16
-ABI_VERSION = 5   # include/bowgpu.h BOWGPU_ABI_VERSION (asserted when the library is loaded)
+ABI_VERSION = 6   # include/bowgpu.h BOWGPU_ABI_VERSION (asserted when the library is loaded)
 
 ERR_NAMES = {
     -1: "INTERVAL", -2: "TS_TYPE", -3: "FIRST_TS_NULL", -4: "NO_AGG", -5: "KEEP_INTERVAL", -6: "BAD_COL",
@@ -137,6 +137,7 @@ SYMBOLS = [
     "bowgpu_gen_sparse", "bowgpu_stream_read_ceiling", "bowgpu_stream_rw_probe", "bowgpu_debug_status", "bowgpu_debug_host_copy", "bowgpu_checksum64", "bowgpu_parquet_open", "bowgpu_parquet_close",
     "bowgpu_parquet_info", "bowgpu_parquet_column", "bowgpu_parquet_read_column",
     "bowgpu_debug_set_route", "bowgpu_debug_get_route", "bowgpu_checksum64_at",
+    "bowgpu_set_devices", "bowgpu_get_devices", "bowgpu_set_fanout_min_rows", "bowgpu_last_call_ranks",
 ]
 
 _lib = None
@@ -179,6 +180,45 @@ def host_unregister(arr):
     check(lib().bowgpu_host_unregister(arr.ctypes.data_as(C.c_void_p)))
 
 
+def set_devices(ids, min_rows=None):
+    """bowgpu_set_devices: Rolling.Aggregate calls are cut into row ranges over these devices from now on (process-wide; [] = off)"""
+    ids = list(ids)
+    arr = (C.c_int * max(len(ids), 1))(*ids)
+    check(lib().bowgpu_set_devices(arr, len(ids)))
+    if min_rows is not None:
+        check(lib().bowgpu_set_fanout_min_rows(C.c_int64(min_rows)))
+
+
+def get_devices():
+    n = C.c_int(0)
+    arr = (C.c_int * 64)()
+    check(lib().bowgpu_get_devices(arr, 64, C.byref(n)))
+    return [arr[i] for i in range(n.value)]
+
+
+def last_call_ranks():
+    """row ranges that served this thread's last Rolling.Aggregate call (1: the one-device path)"""
+    n = C.c_int(0)
+    check(lib().bowgpu_last_call_ranks(C.byref(n)))
+    return n.value
+
+
+class devices:
+    """with capi.devices([0, 0, 0, 0], min_rows=1000): ...  - the fan-out in force inside the block, the previous setting after"""
+
+    def __init__(self, ids, min_rows=None):
+        self.ids, self.min_rows = list(ids), min_rows
+
+    def __enter__(self):
+        self.prev = get_devices()
+        set_devices(self.ids, self.min_rows)
+        return self
+
+    def __exit__(self, *exc):
+        set_devices(self.prev, (1 << 20) if self.min_rows is not None else None)
+        return False
+
+
 def mem_info():
     f, t = C.c_int64(0), C.c_int64(0)
     check(lib().bowgpu_mem_info(C.byref(f), C.byref(t)))
@@ -200,6 +240,7 @@ def check(rc):
 ROUTE_NO_SIMPLE, ROUTE_FORCE_GENERAL, ROUTE_NO_LONG_ONLY, ROUTE_LONG_CLASSIC, ROUTE_LONG_STREAM_ALL = 1, 2, 4, 8, 16
 ROUTE_SIMPLE_SMALL_LIST, ROUTE_SIMPLE_LARGE_LIST, ROUTE_TW_F64, ROUTE_SIMPLE_PADDED, ROUTE_INTERP_TILE = 32, 64, 128, 256, 512
 ROUTE_PINNED_STAGE, ROUTE_STRICT_ORDER, ROUTE_NO_FUSED, ROUTE_TW_ROWS, ROUTE_INTERP_COPIES = 1024, 2048, 4096, 8192, 16384
+ROUTE_QUEUE_HOST, ROUTE_QUEUE_DEVICE = 32768, 65536
 
 
 def set_route(mask):
@@ -231,7 +272,8 @@ class route:
 # every kernel / form a Rolling.Aggregate call can be pushed through (the tests run each case through all of them)
 AGG_ROUTES = (("auto", 0), ("classic-long", ROUTE_LONG_CLASSIC), ("stream-all", ROUTE_LONG_STREAM_ALL),
               ("small-list", ROUTE_SIMPLE_SMALL_LIST), ("large-list", ROUTE_SIMPLE_LARGE_LIST), ("padded", ROUTE_SIMPLE_PADDED), ("tw-rows", ROUTE_TW_ROWS),
-              ("lean", ROUTE_NO_SIMPLE | ROUTE_NO_LONG_ONLY), ("general", ROUTE_FORCE_GENERAL | ROUTE_NO_LONG_ONLY))
+              ("lean", ROUTE_NO_SIMPLE | ROUTE_NO_LONG_ONLY), ("general", ROUTE_FORCE_GENERAL | ROUTE_NO_LONG_ONLY),
+              ("queue-device", ROUTE_NO_LONG_ONLY | ROUTE_QUEUE_DEVICE), ("queue-host", ROUTE_NO_LONG_ONLY | ROUTE_QUEUE_HOST))
 INTERP_ROUTES = (("wave3", 0), ("tile", ROUTE_INTERP_TILE))   # the product kernel and the one kept second implementation
 
 

@@ -146,6 +146,8 @@ int ctx_get(Ctx **out) {
     return 0;
 }
 
+int current_device_of_thread() { return g_ctx.device; }
+
 int ctx_scratch(Ctx *c, size_t bytes, void **dptr) {
     if (c->d_scratch_bytes < bytes) {
         if (c->d_scratch) (void)hipFree(c->d_scratch);
@@ -1096,7 +1098,8 @@ static int job_launch_tiles(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t
                        // a nullable column whose outputs want sums AND extrema, windows of kCompactValuesMinAvgRows rows and more: the compacting
                        // form walks the valid points once where rolling_simple.hip walks the rows twice (or once under the validity bit) - 1e8
                        // rows, 30 % nulls, Sum + Min + Max: 0.412 against 0.440 ms at 64 rows per window, 0.451 against 0.558 at 128; below
-                       // that length, and for every other value set, rolling_simple.hip stays ahead (profiles/r05_stdout_twc_values_ab.txt)
+                       // that length, and for every other value set, rolling_simple.hip stays ahead (the A/B of round 5, timing only; the sweep that shows the routed
+                       // kernels side by side is profiles/r05_stdout_midw_sweep.txt)
                        const int64_t lim53 = 1ll << 53;
                        const bool ts32 = !wide && !P.pre_rows && plan->first_ts > -lim53 && plan->last_ts < lim53 && S.s0 > -lim53;
                        const bool sums_and_extrema = (S.need & kNeedSum) && (S.need & kNeedMinMax);
@@ -1137,6 +1140,33 @@ static int job_launch_tiles(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t
 }
 
 // Windows longer than a tile's look-ahead: workspace from the context pool, then long_windows.hip
+struct LongWork {
+    void *entries; int32_t *nchunks; int64_t *offsets, *sums, *total; int32_t *work_entry; void *parts;
+    int64_t max_work;
+};
+static int long_workspace(Ctx *c, const AggParams &P, int64_t n_entries, LongWork *w) {
+    const int64_t max_work = n_entries + (P.n + kLongChunkRows - 1) / kLongChunkRows;
+    const int64_t scan_blocks = (n_entries + 2047) / 2048;
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t b_entries = up((size_t)n_entries * long_entry_size());
+    const size_t b_nchunks = up((size_t)n_entries * 4);
+    const size_t b_offsets = up((size_t)(n_entries + 1) * 8);
+    const size_t b_sums = up((size_t)(scan_blocks + 1) * 8);
+    const size_t b_parts = up((size_t)max_work * (size_t)(P.ncols > 0 ? P.ncols : 1) * long_part_size());
+    const size_t b_map = up((size_t)max_work * 4);
+    void *blk;
+    BG_TRY(ctx_pool(c, Ctx::kPoolSlots - 1, b_entries + b_nchunks + b_offsets + b_sums + 256 + b_map + b_parts, &blk));
+    char *q = reinterpret_cast<char *>(blk);
+    w->entries = q; q += b_entries;
+    w->nchunks = reinterpret_cast<int32_t *>(q); q += b_nchunks;
+    w->offsets = reinterpret_cast<int64_t *>(q); q += b_offsets;
+    w->sums = reinterpret_cast<int64_t *>(q); q += b_sums;
+    w->total = reinterpret_cast<int64_t *>(q); q += 256;
+    w->work_entry = reinterpret_cast<int32_t *>(q); q += b_map;
+    w->parts = q;
+    w->max_work = max_work;
+    return 0;
+}
 // hstat == nullptr: the long-only pipeline (every window of the call)
 static int run_long_windows(Ctx *c, const AggParams &P, const uint32_t *hstat, int64_t *n_long_out, bool strict = false) {
     LongListStarts starts;
@@ -1146,25 +1176,9 @@ static int run_long_windows(Ctx *c, const AggParams &P, const uint32_t *hstat, i
     const int64_t n_long = hstat ? starts.start[kLongLists] : P.W;
     *n_long_out = n_long;
     if (n_long == 0) return 0;
-    const int64_t max_work = n_long + (P.n + kLongChunkRows - 1) / kLongChunkRows;
-    const int64_t scan_blocks = (n_long + 2047) / 2048;
-    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t b_entries = up((size_t)n_long * long_entry_size());
-    const size_t b_nchunks = up((size_t)n_long * 4);
-    const size_t b_offsets = up((size_t)(n_long + 1) * 8);
-    const size_t b_sums = up((size_t)(scan_blocks + 1) * 8);
-    const size_t b_parts = up((size_t)max_work * (size_t)(P.ncols > 0 ? P.ncols : 1) * long_part_size());
-    void *w;
-    const size_t b_map = up((size_t)max_work * 4);
-    BG_TRY(ctx_pool(c, Ctx::kPoolSlots - 1, b_entries + b_nchunks + b_offsets + b_sums + 256 + b_map + b_parts, &w));
-    char *q = reinterpret_cast<char *>(w);
-    void *entries = q; q += b_entries;
-    int32_t *nchunks = reinterpret_cast<int32_t *>(q); q += b_nchunks;
-    int64_t *offsets = reinterpret_cast<int64_t *>(q); q += b_offsets;
-    int64_t *sums = reinterpret_cast<int64_t *>(q); q += b_sums;
-    int64_t *total = reinterpret_cast<int64_t *>(q); q += 256;
-    int32_t *work_entry = reinterpret_cast<int32_t *>(q); q += b_map;
-    return launch_long_windows_v2(c, P, hstat ? &starts : nullptr, entries, nchunks, offsets, sums, total, work_entry, q, max_work, strict);
+    LongWork w;
+    BG_TRY(long_workspace(c, P, n_long, &w));
+    return launch_long_windows_v2(c, P, hstat ? &starts : nullptr, w.entries, w.nchunks, w.offsets, w.sums, w.total, w.work_entry, w.parts, w.max_work, strict);
 }
 
 // BOWGPU_CALL_PROFILE=1 (diagnostic): where a call's wall time goes on the host - until the synchronisation, inside it, after it
@@ -1175,7 +1189,21 @@ struct PassState {
     bool used_simple = false, used_small_list = false;
     uint32_t *hstat = nullptr;
     uint64_t *hcnt = nullptr;
+    bool queue = false;     // long_queue_kernel rides behind the tile kernel: the queued windows are served without the host in between
+    LongWork qw{};          // ... its workspace (sized for the queue's capacity)
 };
+// From how many rows per window (on average) on a tile pass is followed by long_queue_kernel unconditionally: below, windows longer than a
+// tile's look-ahead are the exception and a call pays nothing for them until one shows up (the host then reads the counts and launches the
+// machinery: rounds 1 - 5); from here on they are expected, and the launch (a few microseconds when the queue is empty) replaces a host
+// round trip and eight launches
+constexpr int64_t kQueueMinAvgRows = 64;
+static int job_queue_enqueue(Ctx *c, AggJob *job, PassState *ps) {
+    if (!ps->queue) return 0;
+    const AggParams &P = job->P;
+    BG_TRY(launch_long_queue(c, P, P.long_cap * kLongLists, ps->qw.entries, ps->qw.nchunks, g_strict_order ? ((int64_t)1 << 20) : kQueueWalkMaxRows, g_strict_order));
+    BG_HIP(hipEventRecord(c->ev1, c->stream));   // (the bracket of kernel_ms: tile kernel + queue)
+    return 0;
+}
 static int job_pass_enqueue(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, const Plan *plan, bool finish, PassState *ps);
 static int job_pass_complete(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, const Plan *plan, bool finish, PassState *ps,
                              int64_t *long_windows, double *kernel_ms);
@@ -1274,7 +1302,14 @@ static int job_run(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, i
 
 // the tile pass of a call, enqueued only: bitmap preset, tile kernel, (tail), read-back of the status words - no synchronisation
 static int job_pass_enqueue(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, const Plan *plan, bool finish, PassState *ps) {
+    {
+        const uint32_t route = route_mask();
+        const int64_t avg_rows = job->W > 0 ? job->P.n / job->W : 0;
+        ps->queue = job->W > 0 && !(route & BOWGPU_ROUTE_QUEUE_HOST) && (avg_rows >= kQueueMinAvgRows || (route & BOWGPU_ROUTE_QUEUE_DEVICE));
+        if (ps->queue) BG_TRY(long_workspace(c, job->P, job->P.long_cap * kLongLists, &ps->qw));
+    }
     BG_TRY(job_launch_tiles(c, job, aggs, naggs, plan, true, &ps->used_simple, false, &ps->used_small_list));
+    BG_TRY(job_queue_enqueue(c, job, ps));
     // status -> host (pinned).  Optimistically enqueue the tail (null counts, copy-back) behind the tile kernel so
     // the common case needs ONE synchronisation; if windows were queued for the cooperative path, run it and redo the tail.
     if (finish) BG_TRY(job_enqueue_tail(c, job, aggs, naggs));
@@ -1299,6 +1334,7 @@ static int job_pass_complete(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_
         // clumpy data: a high average of rows per window, but some tile holds more window heads than the small list takes - the
         // same kernel with its large list (400 heads per 640 rows) before anything slower is tried
         BG_TRY(job_launch_tiles(c, job, aggs, naggs, plan, true, &used_simple, true, &used_small_list));
+        BG_TRY(job_queue_enqueue(c, job, ps));
         if (finish) BG_TRY(job_enqueue_tail(c, job, aggs, naggs));
         BG_TRY(job_readback(c, job, &hstat, &hcnt));
         BG_HIP(hipStreamSynchronize(c->stream));
@@ -1307,6 +1343,7 @@ static int job_pass_complete(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_
     if (used_simple && hstat[4]) {
         // some tile needs window ids the simple kernel cannot encode: redo the call with the general lean kernel
         BG_TRY(job_launch_tiles(c, job, aggs, naggs, plan, false, &used_simple));
+        BG_TRY(job_queue_enqueue(c, job, ps));
         if (finish) BG_TRY(job_enqueue_tail(c, job, aggs, naggs));
         BG_TRY(job_readback(c, job, &hstat, &hcnt));
         BG_HIP(hipStreamSynchronize(c->stream));
@@ -1314,7 +1351,22 @@ static int job_pass_complete(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_
     }
     if (hstat[2]) return fail(BOWGPU_ERR_HIP, "internal: long-window list overflow");
     int64_t n_long = 0;
-    {
+    if (ps->queue) {
+        // long_queue_kernel has walked the queued windows of up to kQueueWalkMaxRows rows in row order (exact) behind the tile kernel; the
+        // longer ones are listed for the chunked order-free machinery - usually none, and the call is done with its one synchronisation
+        if (hstat[7]) return fail(BOWGPU_ERR_UNSUPPORTED, "strict_order: some window holds more than 2^20 rows (one lane walks a window in row order: beyond that the call is declined)");
+        const int64_t n_big = (int64_t)hstat[kQueueBigWord];
+        if (n_big > 0) {
+            const LongWork &w = ps->qw;
+            BG_TRY(launch_long_windows_v2(c, P, nullptr, w.entries, w.nchunks, w.offsets, w.sums, w.total, w.work_entry, w.parts, w.max_work, false, n_big));
+            if (finish) {
+                BG_TRY(job_enqueue_tail(c, job, aggs, naggs));
+                BG_TRY(job_readback(c, job, &hstat, &hcnt));
+                BG_HIP(hipStreamSynchronize(c->stream));
+            }
+        }
+        n_long = n_big;
+    } else {
         // (strict_order: the windows a tile could not hold are walked in row order by one lane each - long_strict_kernel - instead of
         // being reduced as a tree; a window beyond 2^20 rows declines the call)
         BG_TRY(run_long_windows(c, P, hstat, &n_long, g_strict_order));
@@ -2038,6 +2090,11 @@ static int aggregate_with_plan(const bowgpu_col *cols, int32_t ncols, int32_t ts
     int inclusive = opt_inclusive ? 1 : 0, nic = -1;
     BG_TRY(validate_aggs(cols, ncols, ts_col, aggs, naggs, &inclusive, &nic));
     if (!outs) return fail(BOWGPU_ERR_ARG, "no output columns");
+    {   // bowgpu_set_devices: the call cut into row ranges over the listed devices (multi.cpp); not taken -> the one-device path below
+        bool fanned = false;
+        BG_TRY(multi_aggregate(cols, ncols, ts_col, plan, opt_inclusive, g_strict_order, aggs, naggs, outs, info, &fanned));
+        if (fanned) return 0;
+    }
     Ctx *c;
     BG_TRY(ctx_get(&c));
     c->last_slow_rows = 0;
@@ -2107,6 +2164,7 @@ int bowgpu_rolling_interpolate_aggregate(const bowgpu_col *cols, int32_t ncols, 
     if (!outs) return fail(BOWGPU_ERR_ARG, "no output columns");
     Ctx *c;
     BG_TRY(ctx_get(&c));
+    c->last_slow_rows = 0;   // (bowgpu_last_call_slow_rows speaks of THIS call; the two-call form below resets it again in its own entry points)
     bool done = false;
     double ms = 0;
     BG_TRY(fused_try(c, cols, ncols, ts_col, plan, o, inclusive, interps, aggs, naggs, outs, &ms, &done));
@@ -2549,6 +2607,7 @@ int bowgpu_shard_pass_begin(const bowgpu_col *cols, int32_t ncols, int32_t ts_co
     Ctx *c;
     BG_TRY(ctx_get(&c));
     pending_drop(c);
+    c->last_slow_rows = 0;
     // declined (not an error): nothing to reduce, or timestamps below zero, where the frame's first window start may lie ABOVE
     // a rank's rows (rolling.go:96-99) - that needs the records
     if (me->nrows == 0 || me->first_ts < 0 || me->last_ts < me->first_ts) return BOWGPU_SHARD_PASS_DECLINED;
@@ -2671,6 +2730,7 @@ int bowgpu_shard_finish(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, i
     if (cols[ts_col].type != BOWGPU_INT64) return fail(BOWGPU_ERR_TS_TYPE, "impossible to create a new intervalRolling on column of type float64");
     Ctx *c;
     BG_TRY(ctx_get(&c));
+    if (!g_pending) c->last_slow_rows = 0;   // (a pass in flight has booked its rows already: bowgpu_shard_pass_begin reset the counter)
     // the rank's plan from its own record: no round trip to the device for first / last ts
     Plan plan;
     plan.interval = interval;

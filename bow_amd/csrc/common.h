@@ -162,6 +162,10 @@ int kind_type(int kind);
 bool kind_never_nil(int kind);
 bool kind_reads_values(int kind);
 
+// multi.cpp: one Rolling.Aggregate over the devices of bowgpu_set_devices (*done = false: not a call for it, nothing was touched)
+int multi_aggregate(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, const Plan &plan, int opt_inclusive, bool strict,
+                    const bowgpu_agg *aggs, int32_t naggs, bowgpu_out *outs, bowgpu_agg_info *info, bool *done);
+
 // ---------------------------------------------------------------- kernels (rolling_agg.hip)
 constexpr int kMaxCols = 8;    // value columns reduced per launch
 constexpr int kMaxAggs = 16;   // output columns per launch
@@ -292,7 +296,13 @@ int stream_rw_run(Ctx *c, const void *a, const void *b, int64_t bytes_each, void
                   int reps, float *ms);
 int stream_sum_run(Ctx *c, const void *a, const void *b, int64_t bytes_each, int mode, int blocks_per_cu, int reps, uint64_t *d_out, float *ms);
 int launch_long_windows_v2(Ctx *c, const AggParams &p, const LongListStarts *starts, void *entries, int32_t *nchunks, int64_t *offsets,
-                           int64_t *block_sums, int64_t *d_total, int32_t *work_entry, void *partials, int64_t max_work, bool strict = false);
+                           int64_t *block_sums, int64_t *d_total, int32_t *work_entry, void *partials, int64_t max_work, bool strict = false,
+                           int64_t n_given = 0);
+// the queued windows of a tile pass without the host in between: grid from the queue's capacity, counts read on the device; short windows
+// walked in row order, the others listed in big_entries / big_nchunks (status[kQueueBigWord] of them) for launch_long_windows_v2(n_given)
+int launch_long_queue(Ctx *c, const AggParams &p, int64_t capacity, void *big_entries, int32_t *big_nchunks, int64_t walk_max_rows, bool strict);
+constexpr int kQueueBigWord = 8;          // status word: windows long_queue_kernel left to the chunked machinery
+constexpr int64_t kQueueWalkMaxRows = 1024;   // ... those longer than this
 size_t long_stream_workspace(int64_t n, int64_t W, int ncols);
 int launch_long_stream(Ctx *c, const AggParams &p, void *workspace);   // every window of the call, one read of the rows
 int launch_fix_tail_bits(Ctx *c, uint8_t *bitmap, int64_t nbits);
@@ -399,9 +409,13 @@ constexpr int kPoolMode = 17;    // aggregation.Mode: its output's validity work
 constexpr int kPoolColOrder = 18; // IsColSorted: one (first valid, last valid) record per 512-row trip
 constexpr int kPoolShard = 19;   // shard stitch: seed / merged states and the next shard's first row
 constexpr int kPoolGaps = 32;    // window_first_rows: queued runs of empty windows
-constexpr int kPoolWhole = 32;        // bowgpu_aggregate_whole: partial states, the reducers' values and validity bytes
+constexpr int kPoolWhole = 33;        // bowgpu_aggregate_whole: partial states, the reducers' values and validity bytes
 constexpr int kPoolInterpEdge = 31;   // Interpolate: the trips' edge words (interp_wave3_kernel)
 constexpr int kPoolInterp = 20;  // context pool slots 20..30: tile counts, their scan, scan sums, one neighbour index per column
+// every user its own slot: 0..15 the outputs' validity working copies, 17..19, 20..30 (kPoolInterp + 0..10), 31, 32, 33, kPoolSlots - 1 the long windows
+static_assert(kPoolMode != kPoolColOrder && kPoolColOrder != kPoolShard && kPoolMode != kPoolShard && kPoolMode > 15 && kPoolShard < kPoolInterp &&
+              kPoolInterp + 10 < kPoolInterpEdge && kPoolInterpEdge < kPoolGaps && kPoolGaps < kPoolWhole && kPoolWhole < Ctx::kPoolSlots - 1,
+              "context pool slots must be distinct");
 // kernel parameter blocks of interp_fill.hip (filled by extras.cpp, passed by value)
 struct InterpCol {
     const uint64_t *values;

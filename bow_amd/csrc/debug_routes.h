@@ -16,5 +16,7 @@ enum {
     BOWGPU_ROUTE_NO_FUSED = 4096,        // bowgpu_rolling_interpolate_aggregate: the two calls through device temporaries even where rolling_fused_kernel applies
     BOWGPU_ROUTE_TW_ROWS = 8192,         // time-weighted reducers on a nullable column: rolling_tw_kernel's row-space form even where rolling_twc_kernel (valid points compacted) applies
     BOWGPU_ROUTE_INTERP_COPIES = 16384,  // Interpolate: output bitmaps through the zeroed working copies + the counting pass even where interp_wave3_kernel could write them in place
-    BOWGPU_ROUTE__ALL = 32767            // every defined bit, the two public ones (1024, 2048) included
+    BOWGPU_ROUTE_QUEUE_HOST = 32768,     // windows a tile pass queues: the host reads the counts and launches the long-window machinery (rounds 1 - 5) even where long_queue_kernel would be enqueued behind the tile kernel
+    BOWGPU_ROUTE_QUEUE_DEVICE = 65536,   // ... long_queue_kernel behind every tile pass, whatever the call's average window length
+    BOWGPU_ROUTE__ALL = 131071           // every defined bit, the two public ones (1024, 2048) included
 };

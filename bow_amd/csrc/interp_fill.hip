@@ -537,6 +537,54 @@ __global__ __launch_bounds__(256) void col_order_kernel(const uint64_t *values, 
     }
 }
 
+// The same for a column WITHOUT nulls (bowassertion.go:15-81 then compares every row with the row before it): no masks, no carries through
+// runs of nulls, no per-trip records and no join launches - a row's left neighbour is the lane to the left (DPP wave_shr:1), lane 0's is
+// lane 63 of the 128-row group before, and the first row of a trip reads the row in front of the trip from memory (one scalar load per
+// 512 rows).  One launch for the whole column: what remains is four 16-byte loads and eight compares per lane and trip.
+template <bool kInt>
+__global__ __launch_bounds__(256) void col_order_dense_kernel(const uint64_t *values, int64_t n, uint32_t *flags) {
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t wave = (int64_t)blockIdx.x * 4 + wv, nwaves = (int64_t)gridDim.x * 4;
+    const bool vec = (reinterpret_cast<uintptr_t>(values) & 15) == 0;
+    uint32_t f = 0;
+    for (int64_t trip = wave; trip * 512 < n; trip += nwaves) {
+        const int64_t base = trip * 512;
+        const int64_t left_trip = n - base;
+        const bool full = left_trip >= 512;
+        const uint64_t *src = values + base;
+        uint64_t a[4], b[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int r = 128 * k + 2 * lane;
+            if (full && vec) { const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(src + r); a[k] = v.x; b[k] = v.y; }
+            else { a[k] = r < left_trip ? src[r] : 0; b[k] = r + 1 < left_trip ? src[r + 1] : 0; }
+        }
+        uint64_t carry = base > 0 ? src[-1] : 0;   // (uniform address: the row in front of the trip)
+        bool has_carry = base > 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int r = 128 * k + 2 * lane;
+            const uint32_t llo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b[k], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+            const uint32_t lhi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b[k] >> 32), 0x138, 0xf, 0xf, false);
+            const uint64_t left = lane == 0 ? carry : ((uint64_t)lhi << 32) | llo;
+            if ((lane > 0 || has_carry) && r < left_trip) f |= order_cmp<kInt>(left, a[k]);
+            if (r + 1 < left_trip) f |= order_cmp<kInt>(a[k], b[k]);
+            carry = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b[k], 63) |
+                    (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b[k] >> 32), 63) << 32;
+            has_carry = true;
+        }
+    }
+    __shared__ uint32_t block_flags[4];
+    const uint32_t F = (__ballot(f & 1) ? 1u : 0u) | (__ballot(f & 2) ? 2u : 0u);
+    if (lane == 0) block_flags[wv] = F;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t B = block_flags[0] | block_flags[1] | block_flags[2] | block_flags[3] | (blockIdx.x == 0 && n > 0 ? 4u : 0u);
+        if (B) atomicOr(flags, B);
+    }
+}
+
 // pairs whose rows lie in different trips: 256 consecutive records per workgroup, joined in order by one thread out of LDS;
 // the workgroup's own (first valid, last valid) record goes to the next level (the host repeats until one record is left)
 template <bool kInt>
@@ -933,11 +981,18 @@ int launch_col_order(Ctx *c, const uint64_t *values, const uint32_t *vbits, int6
     BG_HIP(hipMemsetAsync(d_flags, 0, 4, c->stream));
     if (n == 0) return 0;
     const int64_t ntrips = (n + 511) / 512;
-    void *w;
-    BG_TRY(ctx_pool(c, kPoolColOrder, (size_t)(ntrips + ntrips / 128 + 8) * sizeof(TripEdge), &w));  // every level of the join
-    TripEdge *edges = reinterpret_cast<TripEdge *>(w);
     const dim3 grid(grid_for(ntrips, 4, 4096)), block(256);   // (1024 workgroups left 16 wavefronts per CU waiting out one load each: 0.25 ms per 1e8 rows)
     const bool is_int = type == BOWGPU_INT64;
+    void *w;
+    if (vbits || (route_mask() & BOWGPU_ROUTE_FORCE_GENERAL)) BG_TRY(ctx_pool(c, kPoolColOrder, (size_t)(ntrips + ntrips / 128 + 8) * sizeof(TripEdge), &w));  // every level of the join
+    else w = nullptr;
+    TripEdge *edges = reinterpret_cast<TripEdge *>(w);
+    if (!vbits && !(route_mask() & BOWGPU_ROUTE_FORCE_GENERAL)) {   // no nulls: one launch, no per-trip records to join (BOWGPU_ROUTE_FORCE_GENERAL: the tests' switch to the general form)
+        if (is_int) hipLaunchKernelGGL(col_order_dense_kernel<true>, grid, block, 0, c->stream, values, n, d_flags);
+        else hipLaunchKernelGGL(col_order_dense_kernel<false>, grid, block, 0, c->stream, values, n, d_flags);
+        BG_HIP(hipGetLastError());
+        return 0;
+    }
     if (is_int) hipLaunchKernelGGL(col_order_kernel<true>, grid, block, 0, c->stream, values, vbits, vbit0, n, edges, d_flags);
     else hipLaunchKernelGGL(col_order_kernel<false>, grid, block, 0, c->stream, values, vbits, vbit0, n, edges, d_flags);
     int64_t n_in = ntrips;

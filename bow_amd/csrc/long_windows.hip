@@ -305,14 +305,8 @@ __global__ __launch_bounds__(256) void ts_sorted_kernel(const int64_t *__restric
 // (L1 / L2), so the rows are still fetched from HBM once.  Four rows of a lane are loaded before the first is consumed.  Windows
 // longer than kStrictMaxRows are not walked (status[7]: the call is declined) - a single lane would take milliseconds per window.
 constexpr int64_t kStrictMaxRows = 1ll << 20;
-__global__ __launch_bounds__(256) void long_strict_kernel(const AggParams p, const int64_t n_long, const LongEntry *entries, const int fill_gaps) {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= n_long) return;
-    const LongEntry le = entries[e];
-    if (le.r1 - le.r0 > kStrictMaxRows) {
-        if (!__hip_atomic_load(&p.status[7], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(&p.status[7], 1u);
-        return;
-    }
+// one lane, one window: the walk in row order, the window's outputs, the empty windows behind it (fill_gaps)
+__device__ __forceinline__ void walk_entry(const AggParams &p, const LongEntry &le, const int fill_gaps) {
     const int64_t gap = fill_gaps ? (int64_t)(le.next_wid - le.wid) - 1 : 0;
     for (int slot = -1; slot < p.ncols; slot++) {
         if (p.pass_mask[slot + 1] == 0) continue;
@@ -358,6 +352,79 @@ __global__ __launch_bounds__(256) void long_strict_kernel(const AggParams p, con
         }
         emit_stats(p, slot, le, st, nullptr);
         if (gap > 0) emit_empties(p, slot, le, gap, 1, 1);
+    }
+}
+
+__global__ __launch_bounds__(256) void long_strict_kernel(const AggParams p, const int64_t n_long, const LongEntry *entries, const int fill_gaps) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n_long) return;
+    const LongEntry le = entries[e];
+    if (le.r1 - le.r0 > kStrictMaxRows) {
+        if (!__hip_atomic_load(&p.status[7], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(&p.status[7], 1u);
+        return;
+    }
+    walk_entry(p, le, fill_gaps);
+}
+
+// The queued windows of a tile pass served WITHOUT the host in between (reference rolling/aggregation.go:190-238 is one loop): launched
+// behind the tile kernel with a grid sized from the queue's CAPACITY; how many windows were queued is read here, from the sub-lists'
+// counters in the status block.  One lane per queued window: its end row (galloping from its first row - these windows are a few
+// hundred rows long, not the log2(n) probes of a bisection over the frame), then by its LENGTH either the walk in row order right
+// here (exact, like long_strict_kernel: up to walk_max_rows rows) or an entry of the compact list `big` for the chunked order-free
+// machinery, which the host runs only when status[kQueueBigWord] comes back non-zero.  strict != 0: nothing goes to the list - a window
+// beyond walk_max_rows raises status[7] (the call is declined).
+__global__ __launch_bounds__(256) void long_queue_kernel(const AggParams p, LongEntry *big, int32_t *big_nchunks, const int64_t walk_max_rows,
+                                                         const int strict) {
+    __shared__ int64_t s_start[kLongLists + 1];
+    if (threadIdx.x < 64) {   // prefix sums of the 64 sub-list counters (every workgroup: 64 loads, one wave scan)
+        const uint32_t cnt = p.status[kLongCountWord + threadIdx.x];
+        uint32_t incl = cnt;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o);
+            if ((int)threadIdx.x >= o) incl += up;
+        }
+        s_start[threadIdx.x + 1] = (int64_t)incl;
+        if (threadIdx.x == 0) s_start[0] = 0;
+    }
+    __syncthreads();
+    const int64_t n_long = s_start[kLongLists];
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n_long) return;
+    int sub = 0;
+    while (s_start[sub + 1] <= e) sub++;
+    const int64_t *item = p.long_list + 2 * (sub * p.long_cap + (e - s_start[sub]));
+    LongEntry le;
+    le.wid = (uint64_t)item[0];
+    le.r0 = item[1];
+    const int64_t win_start = p.s0 + (int64_t)(le.wid * (uint64_t)p.interval);
+    const int64_t lim = win_start + p.interval;
+    int64_t r1 = p.n;
+    if (lim >= win_start) {   // (else int64 overflow: no row can reach the window's end)
+        // gallop: the first probe at the look-ahead the window outgrew, doubling until a row beyond the window is found
+        int64_t lo = le.r0 + 1, step = 128, hi = p.n;
+        for (;;) {
+            const int64_t probe = le.r0 + step;
+            if (probe >= p.n) break;
+            if (p.ts[probe] >= lim) { hi = probe; break; }
+            lo = probe + 1;
+            step <<= 1;
+        }
+        while (lo < hi) {
+            const int64_t mid = lo + ((hi - lo) >> 1);
+            if (p.ts[mid] >= lim) hi = mid; else lo = mid + 1;
+        }
+        r1 = lo;
+    }
+    le.r1 = r1;
+    entry_close(p, le);
+    if (le.r1 - le.r0 <= walk_max_rows) {
+        walk_entry(p, le, 1);
+    } else if (strict) {
+        if (!__hip_atomic_load(&p.status[7], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(&p.status[7], 1u);
+    } else {
+        const uint32_t at = atomicAdd(&p.status[kQueueBigWord], 1u);
+        big[at] = le;
+        big_nchunks[at] = (int32_t)((le.r1 - le.r0 + kChunkRows - 1) / kChunkRows);
     }
 }
 
@@ -1768,12 +1835,22 @@ size_t long_entry_size() { return sizeof(LongEntry); }
 size_t long_part_size() { return sizeof(Part); }
 
 // starts == nullptr: every window of the call is an entry (long-only pipeline), preceded by the order check of the interval column
+int launch_long_queue(Ctx *c, const AggParams &p, int64_t capacity, void *big_entries, int32_t *big_nchunks, int64_t walk_max_rows, bool strict) {
+    if (capacity <= 0) return 0;
+    hipLaunchKernelGGL(long_queue_kernel, dim3((unsigned)((capacity + 255) / 256)), dim3(256), 0, c->stream, p,
+                       reinterpret_cast<LongEntry *>(big_entries), big_nchunks, walk_max_rows, strict ? 1 : 0);
+    BG_HIP(hipGetLastError());
+    return 0;
+}
+
+// n_given > 0: entries / nchunks [0, n_given) are already there (long_queue_kernel's compact list of the windows it did not walk)
 int launch_long_windows_v2(Ctx *c, const AggParams &p, const LongListStarts *starts, void *entries, int32_t *nchunks,
                            int64_t *offsets, int64_t *block_sums, int64_t *d_total, int32_t *work_entry, void *partials,
-                           int64_t max_work, bool strict) {
-    const int64_t n_long = starts ? starts->start[kLongLists] : p.W;
+                           int64_t max_work, bool strict, int64_t n_given) {
+    const int64_t n_long = n_given > 0 ? n_given : starts ? starts->start[kLongLists] : p.W;
     if (n_long <= 0) return 0;
-    if (starts) {
+    if (n_given > 0) {
+    } else if (starts) {
         hipLaunchKernelGGL(long_bounds_kernel, dim3((unsigned)((n_long + 255) / 256)), dim3(256), 0, c->stream, p, *starts,
                            reinterpret_cast<LongEntry *>(entries), nchunks);
     } else {

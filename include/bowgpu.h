@@ -27,7 +27,9 @@ extern "C" {
  * against the value it was written for when it loads the library (bow_amd/capi.py lib(); shim/go/rolling/gpu_cgo.go init()). */
 /* 5 (round 5): bowgpu_rolling_interpolate_aggregate added; bowgpu_last_kernel_name() spells rolling_simple_kernel with its template
  * arguments; bowgpu_agg_info gained nothing (same layout). */
-#define BOWGPU_ABI_VERSION 5
+/* 6 (round 6): bowgpu_set_devices / bowgpu_get_devices / bowgpu_set_fanout_min_rows added (one call over several devices); no struct
+ * changed. */
+#define BOWGPU_ABI_VERSION 6
 
 /* bow.Type (reference bowtypes.go:17-32) */
 enum {
@@ -180,6 +182,26 @@ const char *bowgpu_last_error(void);
 int bowgpu_device_count(int *count);
 int bowgpu_set_device(int device);          /* per calling thread; default device 0 */
 int bowgpu_device_name(char *buf, int cap);
+/* ONE call, N devices (reference rolling/aggregation.go:123-145 - the user makes one Aggregate call).  Process-wide:
+ * after bowgpu_set_devices(ids, n >= 2) every bowgpu_rolling_aggregate / _planned / _interpolate_aggregate call of any thread whose interval
+ * column holds at least 2 x min_rows rows is cut into up to n row ranges (multiples of 4096 rows; never fewer than min_rows rows each), one per
+ * listed device, and runs as the shard record protocol below (bowgpu_shard_begin -> records -> bowgpu_shard_finish, the carry-in stitch in
+ * row order) on one persistent library thread per list entry.  The records are exchanged in host memory - one process holds them all: no
+ * collective, no transport.  Each rank puts the windows it owns at their places in the caller's buffers, so the outputs, null counts and
+ * bowgpu_agg_info are what the one-device call gives, bit for bit (info.kernel_ms: the slowest rank's; info.long_windows: the ranks' sum).
+ *   Served: HOST columns (each rank stages its own rows once, over its own device's host link) and HOST_PINNED columns (each device reads
+ * its range in place) with host-resident outputs, on any list of devices; DEVICE-resident columns or outputs only when every listed device is
+ * the calling thread's device (the same id may be listed several times - which is also how a one-GPU box exercises the path).  Calls the
+ * record protocol declines - aggregation.Mode, more than 16 aggregators, an interval column with nulls, strict_order with a window over
+ * three ranks - and calls with too few rows take the one-device path of the calling thread as before; so does everything else in this
+ * header.  Fanned-out calls are serialised process-wide (the devices are busy with one anyway).
+ *   n <= 1 (or ids == NULL, n == 0) switches the fan-out off.  min_rows: default 2^20 (bowgpu_set_fanout_min_rows). */
+int bowgpu_set_devices(const int *ids, int n);
+int bowgpu_get_devices(int *ids, int cap, int *n);   /* the list in force (n = 0: off); ids may be NULL */
+int bowgpu_set_fanout_min_rows(int64_t rows);
+/* row ranges (= library threads, = entries of the device list) that served the calling thread's last bowgpu_rolling_aggregate / _planned /
+ * _interpolate_aggregate call; 1: the one-device path */
+int bowgpu_last_call_ranks(int *ranks);
 /* Use an externally owned hipStream_t (e.g. torch's current stream) for all work of this
  * thread; NULL restores the library's own stream. */
 int bowgpu_set_stream(void *hip_stream);

@@ -25,12 +25,42 @@ import (
 )
 
 // the struct layouts and option meanings this file was written against (include/bowgpu.h BOWGPU_ABI_VERSION)
-const bowgpuABI = 5
+const bowgpuABI = 6
 
 func init() {
 	if v := int(C.bowgpu_abi_version()); v != bowgpuABI {
 		panic(fmt.Sprintf("libbowgpu.so has ABI version %d, the binding was written for %d", v, bowgpuABI))
 	}
+	// every GPU of the node behind the ONE r.Aggregate(...) call (aggregation.go:123-145): the library cuts the rows of a call into
+	// one range per listed device and stitches the windows that straddle a cut in row order (include/bowgpu.h, bowgpu_set_devices) -
+	// aggregateWindowsGPU below does not change.  No GPU / one GPU: nothing to set, the calls stay on device 0.
+	var n C.int
+	if C.bowgpu_device_count(&n) == 0 && n > 1 {
+		ids := make([]int, int(n))
+		for i := range ids {
+			ids[i] = i
+		}
+		_ = SetGPUDevices(ids)
+	}
+}
+
+// SetGPUDevices names the devices one Aggregate call is spread over (process-wide; nil or one id: one device, as before round 6).
+// init() lists every device of the node; an application that shares the node narrows the list here.
+func SetGPUDevices(ids []int) error {
+	if len(ids) == 0 {
+		if rc := C.bowgpu_set_devices(nil, 0); rc != 0 {
+			return errors.New(C.GoString(C.bowgpu_last_error()))
+		}
+		return nil
+	}
+	c := make([]C.int, len(ids))
+	for i, id := range ids {
+		c[i] = C.int(id)
+	}
+	if rc := C.bowgpu_set_devices(&c[0], C.int(len(c))); rc != 0 {
+		return errors.New(C.GoString(C.bowgpu_last_error()))
+	}
+	return nil
 }
 
 var errDeclined = errors.New("bowgpu: input outside the device path") // the caller continues on the reference's own Go path
@@ -341,40 +371,4 @@ func AggregateWholeGPU(b bow.Bow, intervalColIndex int, aggrs []ColAggregation) 
 		series[i] = seriesOf(name, outs[i], data[i], valid[i], int(outs[i].length))
 	}
 	return bow.NewBow(series...) // whole.go:92
-}
-
-// aggregateShardGPU: one rank of a row-range sharded Aggregate (one goroutine / process per GPU; columns and outputs device
-// resident).  start / wait are the host's transport: an RCCL / MPI all_gather of one record per rank, begun before the rank's pass
-// is enqueued and collected after it - the exchange is off the critical path (include/bowgpu.h, bowgpu_shard_pass_begin).
-func (r *intervalRolling) aggregateShardGPU(rank, world int, start func([]byte), wait func() [][]byte, cols []C.bowgpu_col,
-	cAggs []C.bowgpu_agg, outs []C.bowgpu_out, opts C.bowgpu_options) (C.bowgpu_shard_decision, error) {
-	nc, na, ts, iv := C.int32_t(len(cols)), C.int32_t(len(cAggs)), C.int32_t(r.intervalColIndex), C.int64_t(r.interval)
-	var rec C.bowgpu_shard_record
-	var d C.bowgpu_shard_decision
-	var s0 *C.int64_t // nil on the first attempt
-	for attempt := 0; attempt < 2; attempt++ {
-		if rc := C.bowgpu_shard_begin(&cols[0], nc, ts, iv, &opts, &cAggs[0], na, s0, &rec); rc != 0 {
-			return d, gpuErr(rc, r.bow.ColumnName(r.intervalColIndex))
-		}
-		start(C.GoBytes(unsafe.Pointer(&rec), C.sizeof_bowgpu_shard_record)) // THE exchange of the call, in flight ...
-		if rc := C.bowgpu_shard_pass_begin(&cols[0], nc, ts, iv, &opts, &cAggs[0], na, &outs[0], &rec); rc < 0 {
-			return d, gpuErr(rc, r.bow.ColumnName(r.intervalColIndex)) // (BOWGPU_SHARD_PASS_DECLINED = 1 is not an error)
-		}
-		all := wait() // ... while the pass runs
-		recs := make([]C.bowgpu_shard_record, world)
-		for q := range recs {
-			copy(unsafe.Slice((*byte)(unsafe.Pointer(&recs[q])), C.sizeof_bowgpu_shard_record), all[q])
-		}
-		rc := C.bowgpu_shard_finish(&cols[0], nc, ts, iv, &opts, &cAggs[0], na, &outs[0], &recs[0], C.int32_t(world), C.int32_t(rank), &d, nil)
-		if rc == C.BOWGPU_SHARD_RETRY { // rows below the first window start split across ranks (negative timestamps): once more, s0 known
-			s0 = &d.s0
-			continue
-		}
-		if rc != 0 {
-			return d, gpuErr(rc, r.bow.ColumnName(r.intervalColIndex))
-		}
-		// output slots [0, d.windows_owned) are global windows d.first_slot_window_id ...: concatenated in rank order = the unsharded result
-		return d, nil
-	}
-	return d, errors.New("bowgpu: the shard protocol did not settle after the second exchange")
 }

@@ -2,6 +2,8 @@ package rolling
 
 import (
 	"fmt"
+	"sync"
+	"sync/atomic"
 
 	"github.com/metronlab/bow"
 )
@@ -17,7 +19,9 @@ type lazyInterpolation struct {
 	base           intervalRolling    // the Rolling Interpolate was called on (Interpolate works on a copy: interpolation.go:35)
 	interps        []ColInterpolation // validated: every colIndex is set (interpolation.go:40-48)
 	newIntervalCol int
-	real           Rolling // what the reference's Interpolate returns, once something has asked for it
+	once           sync.Once
+	real           Rolling // what the reference's Interpolate returns, once something has asked for it (written once, under `once`)
+	made           uint32 // 1 once real is set (sync/atomic: this file builds with every toolchain the reference does)
 }
 
 // interpolated is the tail of (*intervalRolling).Interpolate (interpolation.go:57-68) with the reference's error texts.
@@ -37,17 +41,20 @@ func (r *intervalRolling) interpolated(interps []ColInterpolation, newIntervalCo
 	return newR
 }
 
+// materialised: the reference's Interpolate returned an *intervalRolling whose Aggregate / Bow / NumWindows only read or copy it, so one
+// Rolling could be shared by goroutines; the lazy one keeps that - the interpolation is made once, whoever asks first.
 func (l *lazyInterpolation) materialised() Rolling {
-	if l.real == nil {
+	l.once.Do(func() {
 		l.real = l.base.interpolated(l.interps, l.newIntervalCol)
-	}
+		atomic.StoreUint32(&l.made, 1)
+	})
 	return l.real
 }
 
 // Aggregate: both steps in one call to the library when nothing has asked for the interpolated Bow yet; nil from
 // interpolateAggregateGPU (gpu_cgo.go / gpu_off.go) = the reference's own two steps.
 func (l *lazyInterpolation) Aggregate(aggrs ...ColAggregation) Rolling {
-	if l.real == nil {
+	if atomic.LoadUint32(&l.made) == 0 {
 		if r := l.base.interpolateAggregateGPU(l.interps, aggrs); r != nil {
 			return r
 		}

@@ -29,6 +29,9 @@ func AggregateWholeGPU(b bow.Bow, intervalColIndex int, aggrs []ColAggregation) 
 
 func RegisterForGPU(b bow.Bow) (release func()) { return bow.RegisterForGPU(b) }
 
+// SetGPUDevices: there is no device path in this build; the list is accepted and ignored.
+func SetGPUDevices(ids []int) error { return nil }
+
 // lazyInterpolationGPU: nil = Interpolate runs as the reference wrote it (patches/0006); interpolateAggregateGPU is only reached
 // through a lazyInterpolation, which this build never makes.
 func (r *intervalRolling) lazyInterpolationGPU(interps []ColInterpolation, newIntervalCol int) Rolling {

@@ -72,7 +72,7 @@ def test_every_c_name_the_shim_uses_is_in_the_header():
     assert used_const <= set(enums), used_const - set(enums)
     # the entry points of the hot path are bound
     assert {"bowgpu_rolling_aggregate", "bowgpu_abi_version", "bowgpu_rolling_interpolate_count", "bowgpu_rolling_interpolate_fill",
-            "bowgpu_fill_linear_sorted", "bowgpu_fill", "bowgpu_is_col_sorted", "bowgpu_shard_begin", "bowgpu_shard_pass_begin", "bowgpu_shard_finish",
+            "bowgpu_fill_linear_sorted", "bowgpu_fill", "bowgpu_is_col_sorted", "bowgpu_set_devices", "bowgpu_device_count",
             "bowgpu_host_register", "bowgpu_host_unregister", "bowgpu_last_error", "bowgpu_aggregate_whole"} <= used_fn
 
 
@@ -247,8 +247,10 @@ def _patched_and_shim_sources():
 def test_every_gpu_function_the_shim_defines_has_a_caller():
     """fillLinearGPU / fillGPU / isColSortedGPU were defined and nothing called them - no patch touched bowfill.go or
     bowassertion.go - and aggregation.Aggregate had no binding at all.  Every `...GPU` function or method a shim file defines must be
-    called from a line some patch adds to the reference or from another shim file; the exported entry points of the application
-    (RegisterForGPU, the shard protocol's aggregateShardGPU - driven by the application's own transport) are the stated exceptions."""
+    called from a line some patch adds to the reference or from another shim file; the one stated exception is the application's own
+    entry point RegisterForGPU.  (Round 6: aggregateShardGPU - a rank of the shard protocol for an application-side transport, never
+    called - is gone: the library spreads ONE Aggregate call over the devices itself, bowgpu_set_devices, which init() switches on
+    through SetGPUDevices.)"""
     added, files = _patched_and_shim_sources()
     defined = {}
     for rel, code in files.items():
@@ -256,7 +258,10 @@ def test_every_gpu_function_the_shim_defines_has_a_caller():
             defined.setdefault(m.group(1), set()).add(rel)
     assert {"fillLinearGPU", "fillGPU", "isColSortedGPU", "aggregateWholeGPU", "AggregateWholeGPU", "aggregateWindowsGPU", "interpolateWindowsGPU",
             "NewColAggregationGPU", "NewColInterpolationGPU"} <= set(defined)
-    entry_points = {"RegisterForGPU", "aggregateShardGPU", "GPUResidency"}
+    entry_points = {"RegisterForGPU"}
+    assert "aggregateShardGPU" not in defined and "SetGPUDevices" in defined
+    cgo = files["rolling/gpu_cgo.go"]
+    assert "C.bowgpu_set_devices(&c[0], C.int(len(c)))" in cgo and "_ = SetGPUDevices(ids)" in cgo[cgo.index("func init()"):cgo.index("func SetGPUDevices")]
     for name, where in defined.items():
         calls = len(re.findall(r"(?<!func )(?<!\) )\b%s\(" % name, added))
         for rel, code in files.items():
@@ -279,7 +284,7 @@ def test_every_gpu_function_the_shim_defines_has_a_caller():
     assert "//go:build !(bowgpu && go1.21)" in GO[os.path.join(ROOT, "shim", "go", "bowfill_gpu_off.go")]
     ron, roff = files["rolling/gpu_cgo.go"], files["rolling/gpu_off.go"]
     for sym in ("var ErrGPUDeclined = errDeclined", "func AggregateWholeGPU(b bow.Bow, intervalColIndex int, aggrs []ColAggregation) (bow.Bow, error)",
-                "func RegisterForGPU(b bow.Bow) (release func())"):
+                "func RegisterForGPU(b bow.Bow) (release func())", "func SetGPUDevices(ids []int) error"):
         assert sym in ron and sym in roff, sym
 
 

@@ -558,6 +558,42 @@ def test_is_col_sorted_across_trips():
         assert got == want, (case, n, as_int, pad)
 
 
+def test_is_col_sorted_without_nulls_every_neighbour_pair():
+    """col_order_dense_kernel (round 6: a column without nulls in ONE launch - a row's left neighbour is the lane to the left, lane 63 of the
+    group before, or the row in front of the trip): one pair out of order at every position that changes who the neighbour is (lane 0 / 63,
+    128-row groups, 512-row trips, the ragged last trip), ascending and descending, both types, odd Arrow offsets (8-byte loads), NaN
+    (compares false both ways: bowassertion.go:64-74) - against the oracle and against the general kernel (BOWGPU_ROUTE_FORCE_GENERAL)"""
+    rng = np.random.default_rng(23)
+    for n in (1, 2, 3, 127, 128, 129, 511, 512, 513, 640, 1024, 1537, 70_001):
+        spots = sorted({p for p in (1, 2, 63, 64, 65, 126, 127, 128, 129, 255, 256, 383, 384, 510, 511, 512, 513, 1023, 1024, 1025, n - 2, n - 1,
+                                    int(rng.integers(1, max(n, 2)))) if 1 <= p < n})
+        for as_int in (True, False):
+            for desc in (False, True):
+                for pad in (0, 1):
+                    base = np.cumsum(rng.integers(0, 3, n)).astype(np.int64)
+                    if desc:
+                        base = base[::-1].copy()
+                    for spot in [None] + spots:
+                        vals = base.copy()
+                        if spot is not None:
+                            vals[spot:] += -10_000 if not desc else 10_000
+                        buf = np.concatenate([np.full(pad, 7, np.int64), vals, np.zeros(3, np.int64)])
+                        data = buf if as_int else buf.astype(np.float64)
+                        if not as_int and spot is None and n > 4:
+                            data[pad + n // 2] = np.nan
+                        typ = capi.INT64 if as_int else capi.FLOAT64
+                        col = capi.Column(data, None, typ, pad, n, 0)
+                        want = orc.is_col_sorted(orc.Column(data, None, typ, offset=pad, length=n))
+                        got = capi.is_col_sorted(col)
+                        with capi.route(capi.ROUTE_FORCE_GENERAL):
+                            general = capi.is_col_sorted(col)
+                        assert got == want == general, (n, as_int, desc, pad, spot, got, want, general)
+    dcol = capi.Column(np.arange(3_000_000, dtype=np.int64), None, capi.INT64).to_device()
+    assert capi.is_col_sorted(dcol)
+    z = np.zeros(1000, np.float64)
+    assert capi.is_col_sorted(capi.Column(z, None, capi.FLOAT64)) == orc.is_col_sorted(orc.Column(z, None, capi.FLOAT64))   # all equal
+
+
 # ------------------------------------------------------------------ window bounds (the iterator)
 def test_golden_window_bounds(golden):
     for v in golden["iterate"]:

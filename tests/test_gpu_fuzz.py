@@ -90,8 +90,9 @@ def run_paths(ccols, ocols, interval, aggs, offset, inclusive, label):
         compare("%s %s strict" % (label, a[0]), g, w, exact=True)
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("BOW_FUZZ_SEEDS", "64"))))
-def test_fuzz_aggregate(seed):
+def aggregate_cases(seed):
+    """the seeded cases of test_fuzz_aggregate: (ccols, ocols, n, interval, aggs, offset, inclusive_call, label) - also what
+    tests/test_gpu_multi.py pushes through the multi-device fan-out"""
     rng = np.random.default_rng(1000 + seed)
     sizes = [0, 1, 2, 63, 64, 65, 511, 512, 513, 639, 640, 641, 1023, 1025, 2047, 2049, 5000, 40_000]
     if os.environ.get("BOW_FUZZ_BIG") == "1":   # soak runs: frames of millions of rows (thousands of tiles per call)
@@ -141,6 +142,12 @@ def test_fuzz_aggregate(seed):
             aggs.append(("IntegralTrapezoid", 1))
         inclusive_call = any(a[0] in ("IntegralTrapezoid", "WeightedAverageLinear") for a in aggs)
         label = "seed=%d case=%d n=%d I=%d off=%d pad=%d" % (seed, case, n, interval, offset, pad)
+        yield ccols, ocols, n, interval, aggs, offset, inclusive_call, label
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BOW_FUZZ_SEEDS", "64"))))
+def test_fuzz_aggregate(seed):
+    for ccols, ocols, n, interval, aggs, offset, inclusive_call, label in aggregate_cases(seed):
         if n == 0:
             outs, info = capi.rolling_aggregate(ccols, 0, interval, aggs, offset=offset)
             assert all(o.length == 0 for o in outs), label
