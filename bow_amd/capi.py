@@ -272,8 +272,8 @@ class route:
 # every kernel / form a Rolling.Aggregate call can be pushed through (the tests run each case through all of them)
 AGG_ROUTES = (("auto", 0), ("classic-long", ROUTE_LONG_CLASSIC), ("stream-all", ROUTE_LONG_STREAM_ALL),
               ("small-list", ROUTE_SIMPLE_SMALL_LIST), ("large-list", ROUTE_SIMPLE_LARGE_LIST), ("padded", ROUTE_SIMPLE_PADDED), ("tw-rows", ROUTE_TW_ROWS),
-              ("lean", ROUTE_NO_SIMPLE | ROUTE_NO_LONG_ONLY), ("general", ROUTE_FORCE_GENERAL | ROUTE_NO_LONG_ONLY),
-              ("queue-device", ROUTE_NO_LONG_ONLY | ROUTE_QUEUE_DEVICE), ("queue-host", ROUTE_NO_LONG_ONLY | ROUTE_QUEUE_HOST))
+              ("queue-device", ROUTE_NO_LONG_ONLY | ROUTE_QUEUE_DEVICE), ("queue-host", ROUTE_NO_LONG_ONLY | ROUTE_QUEUE_HOST),
+              ("lean", ROUTE_NO_SIMPLE | ROUTE_NO_LONG_ONLY), ("general", ROUTE_FORCE_GENERAL | ROUTE_NO_LONG_ONLY))   # ("general" stays last: tests read the last kernel's name)
 INTERP_ROUTES = (("wave3", 0), ("tile", ROUTE_INTERP_TILE))   # the product kernel and the one kept second implementation
 
 

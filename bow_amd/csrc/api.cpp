@@ -76,8 +76,10 @@ void ctx_release(Ctx *c) {
     if (!c->inited) return;
     (void)hipSetDevice(c->device);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+    if (c->null_ts_cache && c->null_ts_cache_free) { void *q = c->null_ts_cache; c->null_ts_cache = nullptr; c->null_ts_cache_free(q); }
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->d_params) (void)hipFree(c->d_params);
+    if (c->d_zeroed) (void)hipFree(c->d_zeroed);
     for (int i = 0; i < Ctx::kPoolSlots; i++) if (c->pool[i]) (void)hipFree(c->pool[i]);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->h_bounce) { (void)hipHostFree(c->h_bounce); (void)hipEventDestroy(c->bounce_ev[0]); (void)hipEventDestroy(c->bounce_ev[1]); }
@@ -148,6 +150,10 @@ int ctx_get(Ctx **out) {
 
 int current_device_of_thread() { return g_ctx.device; }
 
+void ctx_drop_null_ts_cache(Ctx *c) {
+    if (c->null_ts_cache && c->null_ts_cache_free) { void *p = c->null_ts_cache; c->null_ts_cache = nullptr; c->null_ts_cache_free(p); }
+}
+
 int ctx_scratch(Ctx *c, size_t bytes, void **dptr) {
     if (c->d_scratch_bytes < bytes) {
         if (c->d_scratch) (void)hipFree(c->d_scratch);
@@ -176,6 +182,15 @@ int ctx_pinned(Ctx *c, size_t bytes, void **hptr) {
 int ctx_params(Ctx *c, void **dptr) {
     if (!c->d_params) BG_HIP(hipMalloc(&c->d_params, 4096));
     *dptr = c->d_params;
+    return 0;
+}
+
+int ctx_zeroed(Ctx *c, uint32_t **dptr) {
+    if (!c->d_zeroed) {
+        BG_HIP(hipMalloc(&c->d_zeroed, 256));
+        BG_HIP(hipMemsetAsync(c->d_zeroed, 0, 256, c->stream));
+    }
+    *dptr = reinterpret_cast<uint32_t *>(c->d_zeroed);
     return 0;
 }
 
@@ -1246,7 +1261,30 @@ static int job_run(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, i
                               !P.pre_rows && plan->first_ts > -lim53 && plan->last_ts < lim53 &&
                               (uint64_t)plan->last_ts - (uint64_t)P.s0 < 0xFFFFFFF0ull && W < 0xFFFFFFF0ll && naggs <= kSimpleMaxAggs &&
                               !(route & (BOWGPU_ROUTE_TW_ROWS | BOWGPU_ROUTE_TW_F64 | BOWGPU_ROUTE_NO_SIMPLE | BOWGPU_ROUTE_FORCE_GENERAL)) && !g_strict_order;
-    const bool stream_ok = !classic_only && !compact_long &&
+    // Round 6: the windows a tile pass queues are served behind it without the host (long_queue_kernel: a lane per queued window, in row
+    // order), which moves the hand-over to the streaming form for columns WITHOUT nulls from 129 rows per window to where the streaming
+    // form wins on WALL (1e8 rows, dense, wall ms tile route / streaming form at 144, 160, 192, 224 rows per window -
+    // profiles/r06_stdout_midw_band.txt): Min + Max 0.407 / 0.547, 0.420 / 0.510, 0.455 / 0.472, 0.504 / 0.448; Sum + Min + Max
+    // 0.445 / 0.549, 0.463 / 0.507, 0.508 / 0.472; First + Last 0.363 / 0.412, 0.368 / 0.396, 0.408 / 0.379; one kind of integral
+    // 0.458 / 0.504, 0.470 / 0.483, 0.511 / 0.454; sums and counts alone and both kinds of integral: the streaming form throughout.
+    int64_t tile_band_rows = 0;
+    {
+        bool mm = false, fl = false, sums = false;
+        for (int i = 0; i < naggs; i++) {
+            const int k = aggs[i].kind;
+            mm |= k == BOWGPU_AGG_MIN || k == BOWGPU_AGG_MAX;
+            fl |= k == BOWGPU_AGG_FIRST || k == BOWGPU_AGG_LAST;
+            sums |= k == BOWGPU_AGG_SUM || k == BOWGPU_AGG_MEAN;
+        }
+        if (step_k && trap_k) tile_band_rows = 0;
+        else if (mm && !sums && !step_k && !trap_k) tile_band_rows = 200;
+        else if (mm || fl || step_k || trap_k) tile_band_rows = 176;
+    }
+    const bool tile_band = !sall && !cls && !any_nulls && plan && avg_rows > 128 && avg_rows <= tile_band_rows && P.fits32 && !P.pre_rows &&
+                           plan->first_ts > -lim53 && plan->last_ts < lim53 && (uint64_t)plan->last_ts - (uint64_t)P.s0 < 0xFFFFFFF0ull &&
+                           W < 0xFFFFFFF0ll && naggs <= kSimpleMaxAggs &&
+                           !(route & (BOWGPU_ROUTE_NO_SIMPLE | BOWGPU_ROUTE_FORCE_GENERAL | BOWGPU_ROUTE_QUEUE_HOST)) && !g_strict_order;
+    const bool stream_ok = !classic_only && !compact_long && !tile_band &&
                            avg_rows >= ((sall || (step_k && trap_k && !any_nulls)) ? kLongOnlyAvgRows : kLongStreamAnyAvgRows) &&
                            avg_rows < kLongClassicAvgRows && W < (1ll << 32);
     const bool classic_ok = avg_rows >= kLongBisectAvgRows;
@@ -1833,6 +1871,8 @@ static void pending_drop(Ctx *c) {
     g_pending = nullptr;
 }
 PendingHolder::~PendingHolder() {
+    // (this object is destroyed before the thread's block cache and context: what holds device blocks is released here)
+    if (!g_process_exiting && g_ctx.inited) { (void)hipSetDevice(g_ctx.device); ctx_drop_null_ts_cache(&g_ctx); }
     if (!p || g_process_exiting) return;
     Ctx *c = &g_ctx;
     if (c->inited) { (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream); }
@@ -1875,6 +1915,7 @@ int bowgpu_set_device(int device) {
     if (c->inited && c->device != device) {
         // drop per-device state of the old device
         (void)hipSetDevice(c->device);
+        ctx_drop_null_ts_cache(c);   // (its blocks go back to the cache that is dropped next)
         devbuf_cache_drop();
         ctx_release(c);
     }
@@ -1888,6 +1929,7 @@ int bowgpu_trim(int32_t all_threads, int64_t *bytes_freed) {
     // to someone else; a host that saw BOWGPU_ERR_OOM from another library)
     Ctx *c;
     BG_TRY(ctx_get(&c));
+    ctx_drop_null_ts_cache(c);
     const size_t freed = all_threads ? trim_all_threads() : g_bufs.drop_all();
     if (bytes_freed) *bytes_freed = (int64_t)freed;
     return 0;
@@ -2162,6 +2204,11 @@ int bowgpu_rolling_interpolate_aggregate(const bowgpu_col *cols, int32_t ncols, 
     int inclusive = o.inclusive ? 1 : 0, nic = -1;
     BG_TRY(validate_aggs(cols, ncols, ts_col, aggs, naggs, &inclusive, &nic));
     if (!outs) return fail(BOWGPU_ERR_ARG, "no output columns");
+    {   // bowgpu_set_devices: every rank interpolates and aggregates its own row range (multi.cpp); not taken -> one device, below
+        bool fanned = false;
+        BG_TRY(multi_interpolate_aggregate(cols, ncols, ts_col, plan, o.inclusive, o.strict_order != 0 || (route_mask() & BOWGPU_ROUTE_STRICT_ORDER) != 0, interps, ninterps, aggs, naggs, outs, info, &fanned));
+        if (fanned) return 0;
+    }
     Ctx *c;
     BG_TRY(ctx_get(&c));
     c->last_slow_rows = 0;   // (bowgpu_last_call_slow_rows speaks of THIS call; the two-call form below resets it again in its own entry points)

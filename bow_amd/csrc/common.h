@@ -76,11 +76,18 @@ struct Ctx {
         int kq_empty = 0, inclusive = 0, e0 = 0;
     } interp_cache;
     void *d_params = nullptr;      // 4 KB device block holding the kernels' descriptor struct
+    void *d_zeroed = nullptr;      // 256 zeroed bytes: flags / tickets of kernels whose last workgroup reports to the host and resets them
+    // what an Interpolate _count over an interval column WITH NULLS leaves for its _fill (extras.cpp NullTsState: device temporaries);
+    // freed through null_ts_cache_free by the fill, bowgpu_trim, bowgpu_set_device and at thread exit
+    void *null_ts_cache = nullptr;
+    void (*null_ts_cache_free)(void *) = nullptr;
 };
+void ctx_drop_null_ts_cache(Ctx *c);
 int ctx_get(Ctx **out);                       // initialises HIP on first use; fails loudly without a GPU
 int ctx_scratch(Ctx *c, size_t bytes, void **dptr);
 int ctx_pinned(Ctx *c, size_t bytes, void **hptr);
 int ctx_params(Ctx *c, void **dptr);
+int ctx_zeroed(Ctx *c, uint32_t **dptr);       // 256 bytes of device memory, zero when handed out for the first time: every kernel that uses words of it leaves them zero
 int ctx_pool(Ctx *c, int slot, size_t bytes, void **dptr);
 
 // ---------------------------------------------------------------- temp device buffers
@@ -165,6 +172,9 @@ bool kind_reads_values(int kind);
 // multi.cpp: one Rolling.Aggregate over the devices of bowgpu_set_devices (*done = false: not a call for it, nothing was touched)
 int multi_aggregate(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, const Plan &plan, int opt_inclusive, bool strict,
                     const bowgpu_agg *aggs, int32_t naggs, bowgpu_out *outs, bowgpu_agg_info *info, bool *done);
+int multi_interpolate_aggregate(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, const Plan &plan, int opt_inclusive, bool strict,
+                                const bowgpu_interp *interps, int32_t ninterps, const bowgpu_agg *aggs, int32_t naggs, bowgpu_out *outs,
+                                bowgpu_agg_info *info, bool *done);
 
 // ---------------------------------------------------------------- kernels (rolling_agg.hip)
 constexpr int kMaxCols = 8;    // value columns reduced per launch
@@ -394,6 +404,7 @@ int launch_fill_empty(Ctx *c, const AggParams &p, int64_t slot0, int64_t slot1);
 int launch_window_first_rows(Ctx *c, const int64_t *ts, int64_t n, const Plan &plan, int64_t *first_idx, uint32_t *status);
 int launch_exclusive_scan(Ctx *c, const int32_t *in, int64_t n, int64_t *out, int64_t *block_sums, int64_t *d_total);
 int launch_col_order(Ctx *c, const uint64_t *values, const uint32_t *vbits, int64_t vbit0, int64_t n, int32_t type, uint32_t *d_flags);
+int launch_col_order_dense(Ctx *c, const uint64_t *values, int64_t n, int32_t type, uint32_t *d_zeroed2, uint32_t *host_flags);
 int launch_window_bounds(Ctx *c, const int64_t *ts, int64_t n, const Plan &plan, int inclusive, int pre_rows,
                          const int64_t *first_idx, int64_t *first_index, int64_t *slice_begin, int64_t *slice_end, uint8_t *is_incl);
 int whole_run(Ctx *c, const void *params_blob, int64_t nblocks);
@@ -506,6 +517,18 @@ struct WholeFinalH {
     uint64_t *out_value;
     uint8_t *out_valid_byte;
 };
+
+struct WholeFinishH {
+    const int64_t *ts;
+    int64_t nrows;
+    int32_t n, _pad;
+    int32_t slot[kMaxAggs];
+    WholeFinalH f[kMaxAggs];
+    uint64_t *host_values;    // registered host memory
+    uint8_t *host_valid;
+};
+int whole_value_run(Ctx *c, const void *params_blob, int64_t nblocks);
+int whole_finish_run(Ctx *c, const void *partials, int64_t nblocks, const WholeFinishH &fin);
 
 // generate.hip
 int launch_gen_dense(Ctx *c, int64_t row0, int64_t n, uint64_t seed, int64_t *ts, double *val);

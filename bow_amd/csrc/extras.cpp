@@ -510,6 +510,47 @@ static int interp_fill_impl(const bowgpu_col *cols, int32_t ncols, int32_t ts_co
 // validity back; after an inclusive iteration the second copy of a row on a window start with null timestamps behind it becomes the
 // synthetic start row of the window that begins behind it.  outs == nullptr: the row count only.  *applies = false: the interval
 // column has no nulls.
+// What bowgpu_rolling_interpolate_count builds for an interval column with nulls and the bowgpu_rolling_interpolate_fill that follows
+// it needs again: the kept rows compacted (one 8-byte column and one bitmap per column of the Bow, the marker column, the flags) and the
+// compacted call's descriptors.  Kept per thread between the two calls, keyed like the count -> fill prefix of the ordinary path
+// (Ctx::InterpCache): DEVICE-resident columns, the same pointers / offsets / lengths / null counts / interpolators / options, nothing
+// written to or freed from device memory through the library in between (device_write_epoch) - include/bowgpu.h states the contract
+// for the ordinary path, this is the same one.  Dropped by the fill that uses it, by any other Interpolate of the thread over an interval
+// column with nulls, by bowgpu_trim, bowgpu_set_device and at thread exit (round 5 ran the whole compaction twice: ADVICE r04).
+namespace {
+struct NullTsState {
+    std::vector<bowgpu_col> key_cols;
+    std::vector<bowgpu_interp> key_interps;
+    int32_t ts_col = 0;
+    int64_t interval = 0;
+    bowgpu_options o = {0, 0, 0};
+    uint64_t epoch = 0;
+    DevBuf flags, marker, marker_bits, ts_bits;
+    std::vector<DevBuf> cvals, cbits;
+    CompactCols cc;
+    std::vector<bowgpu_col> cols2;
+    std::vector<bowgpu_interp> interps2;
+    int64_t m = 0, m_out = 0;
+};
+void null_ts_state_free(void *p) { delete reinterpret_cast<NullTsState *>(p); }
+void null_ts_cache_drop(Ctx *c) {
+    if (c->null_ts_cache) { void *p = c->null_ts_cache; c->null_ts_cache = nullptr; null_ts_state_free(p); }
+}
+bool null_ts_cache_hit(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval, const bowgpu_options &o,
+                       const bowgpu_interp *interps, int32_t ninterps) {
+    const NullTsState *st = reinterpret_cast<const NullTsState *>(c->null_ts_cache);
+    if (!st || st->ts_col != ts_col || st->interval != interval || (int32_t)st->key_cols.size() != ncols || (int32_t)st->key_interps.size() != ninterps) return false;
+    if (st->o.offset != o.offset || st->o.inclusive != o.inclusive || st->o.strict_order != o.strict_order) return false;
+    if (st->epoch != device_write_epoch()) return false;
+    for (int i = 0; i < ncols; i++) {
+        const bowgpu_col &a = st->key_cols[i], &b = cols[i];
+        if (b.residency != BOWGPU_DEVICE || a.values != b.values || a.validity != b.validity || a.offset != b.offset || a.length != b.length ||
+            a.null_count != b.null_count || a.type != b.type) return false;
+    }
+    return memcmp(st->key_interps.data(), interps, sizeof(bowgpu_interp) * (size_t)ninterps) == 0;
+}
+}  // namespace
+
 static int interp_null_ts(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval, const bowgpu_options *opts,
                           const bowgpu_interp *interps, int32_t ninterps, int64_t *n_out, bowgpu_out *outs, bool *applies) {
     *applies = false;
@@ -523,9 +564,14 @@ static int interp_null_ts(const bowgpu_col *cols, int32_t ncols, int32_t ts_col,
     BG_TRY(interp_validate(cols, ncols, ts_col, &o, interps, ninterps));
     Ctx *c;
     BG_TRY(ctx_get(&c));
+    // the _fill right behind its _count: the compaction is there (NullTsState above)
+    const bool reuse = outs && null_ts_cache_hit(c, cols, ncols, ts_col, interval, o, interps, ninterps);
+    if (!reuse) null_ts_cache_drop(c);
     DevCol dts;
-    BG_TRY(devcol_prepare(c, tsc, &dts, true, true));
-    if (dts.null_count <= 0) return 0;
+    if (!reuse) {
+        BG_TRY(devcol_prepare(c, tsc, &dts, true, true));
+        if (dts.null_count <= 0) return 0;
+    }
     *applies = true;
     const int64_t n = tsc->length;
     if (ncols > kMaxCompactCols) return fail(BOWGPU_ERR_UNSUPPORTED, "Interpolate over an interval column with nulls: at most %d columns", kMaxCompactCols);
@@ -536,12 +582,25 @@ static int interp_null_ts(const bowgpu_col *cols, int32_t ncols, int32_t ts_col,
         if (outs) for (int i = 0; i < ninterps; i++) { outs[i].length = 0; outs[i].null_count = 0; outs[i].type = cols[i].type; }
         return 0;
     };
+    const int incl = o.inclusive ? 1 : 0;
+    // (the state of this call: a fresh one, or the one the count left; a fresh one is kept for the fill only when the count succeeded on
+    // DEVICE-resident columns)
+    struct StateOwner { NullTsState *p = nullptr; bool keep = false; ~StateOwner() { if (p && !keep) delete p; } } owner;
+    if (reuse) { owner.p = reinterpret_cast<NullTsState *>(c->null_ts_cache); c->null_ts_cache = nullptr; }   // (one use: this fill owns it now)
+    else owner.p = new NullTsState();
+    NullTsState &S = *owner.p;
+    DevBuf &flags = S.flags, &marker = S.marker, &marker_bits = S.marker_bits, &ts_bits = S.ts_bits;
+    std::vector<DevBuf> &cvals = S.cvals, &cbits = S.cbits;
+    CompactCols &cc = S.cc;
+    std::vector<bowgpu_col> &cols2 = S.cols2;
+    std::vector<bowgpu_interp> &interps2 = S.interps2;
+    int64_t m = S.m, m_out = S.m_out;
+    if (!reuse) {
     int last_valid = 1;
     BG_TRY(fetch_valid(c, tsc, n - 1, &last_valid));
     if (!last_valid || plan.W == 0) return nothing();      // HasNext (rolling.go:162-173) is false from the start: no window, no rows
     // the rows that belong to a window, compacted
-    const int incl = o.inclusive ? 1 : 0;
-    DevBuf ixbuf, ts_eff, keep, plain_ts, dropped, counts, base, sums, flags, marker, marker_bits, ts_bits;
+    DevBuf ixbuf, ts_eff, keep, plain_ts, dropped, counts, base, sums;
     NbrIndex ix;
     BG_TRY(ixbuf.alloc(nbr_index_bytes(n, dts.vbit0)));
     BG_TRY(nbr_index_build(c, dts.vbits, dts.vbit0, n, ixbuf.p, &ix));
@@ -570,14 +629,12 @@ static int interp_null_ts(const bowgpu_col *cols, int32_t ncols, int32_t ts_col,
     BG_TRY(launch_keep_counts(c, reinterpret_cast<const uint64_t *>(keep.p), nw, reinterpret_cast<int32_t *>(counts.p)));
     int64_t *d_total = reinterpret_cast<int64_t *>(dropped.p) + 2;
     BG_TRY(launch_exclusive_scan(c, reinterpret_cast<const int32_t *>(counts.p), nw, reinterpret_cast<int64_t *>(base.p), reinterpret_cast<int64_t *>(sums.p), d_total));
-    int64_t m = 0;
     BG_HIP(hipMemcpyAsync(&m, d_total, 8, hipMemcpyDeviceToHost, c->stream));
     BG_HIP(hipStreamSynchronize(c->stream));
     if (m <= 0) return nothing();
     const size_t mbm = (size_t)((m + 63) >> 6) * 8 + 8;
     std::vector<DevCol> dcs(ncols);
-    std::vector<DevBuf> cvals(ncols), cbits(ncols);
-    CompactCols cc;
+    cvals.resize(ncols); cbits.resize(ncols);
     memset(&cc, 0, sizeof cc);
     cc.ncols = ncols; cc.ts_col = ts_col;
     for (int i = 0; i < ncols; i++) {
@@ -599,8 +656,8 @@ static int interp_null_ts(const bowgpu_col *cols, int32_t ncols, int32_t ts_col,
     BG_TRY(launch_pack_flags(c, reinterpret_cast<const uint32_t *>(flags.p), m, cc, reinterpret_cast<uint64_t *>(marker_bits.p)));
     device_write_epoch_bump();      // (temporaries may sit where an earlier call's columns sat: no count -> fill reuse across this point)
     // the compacted call: the Bow's columns + the marker under interpolation.None
-    std::vector<bowgpu_col> cols2(ncols + 1);
-    std::vector<bowgpu_interp> interps2(interps, interps + ninterps);
+    cols2.assign(ncols + 1, bowgpu_col());
+    interps2.assign(interps, interps + ninterps);
     for (int i = 0; i <= ncols; i++) {
         bowgpu_col &t = cols2[i];
         memset(&t, 0, sizeof t);
@@ -615,10 +672,24 @@ static int interp_null_ts(const bowgpu_col *cols, int32_t ncols, int32_t ts_col,
         mk.kind = BOWGPU_INTERP_NONE; mk.col = ncols;
         interps2.push_back(mk);
     }
-    int64_t m_out = 0;
     BG_TRY(interp_count_impl(cols2.data(), ncols + 1, ts_col, interval, &o, interps2.data(), ninterps + 1, &m_out, nullptr, nullptr));
+    S.m = m; S.m_out = m_out;
+    }   // (!reuse)
     if (n_out) *n_out = m_out;
-    if (!outs) { c->interp_cache.valid = false; return 0; }
+    if (!outs) {
+        // the count alone: what it built stays for the fill that follows (DEVICE-resident columns: the contract of the ordinary path) -
+        // the compacted call's own count -> fill prefix (c->interp_cache) with it, its interval column lives in the kept state
+        bool all_device = true;
+        for (int i = 0; i < ncols; i++) all_device = all_device && cols[i].residency == BOWGPU_DEVICE;
+        if (all_device && m_out > 0) {
+            S.key_cols.assign(cols, cols + ncols); S.key_interps.assign(interps, interps + ninterps);
+            S.ts_col = ts_col; S.interval = interval; S.o = o; S.epoch = device_write_epoch();
+            BG_HIP(hipStreamSynchronize(c->stream));
+            c->null_ts_cache = owner.p; c->null_ts_cache_free = null_ts_state_free;
+            owner.keep = true;
+        } else c->interp_cache.valid = false;
+        return 0;
+    }
     if (m_out == 0) return nothing();
     const size_t vb = (size_t)((m_out + 7) >> 3);
     std::vector<DevBuf> tvals(ncols + 1), tbits(ncols + 1);
@@ -751,6 +822,20 @@ int bowgpu_shard_interp_points(const bowgpu_col *cols, int32_t ncols, int32_t ts
 
 // ---------------------------------------------------------------------------- IsColSorted / FillLinear
 static int col_order_flags(Ctx *c, const DevCol &dc, int32_t type, uint32_t *flags) {
+    if (!dc.vbits && dc.length > 0 && !(route_mask() & BOWGPU_ROUTE_FORCE_GENERAL)) {
+        // a column without nulls: ONE launch whose last workgroup stores the flags into the registered block (bit 31 = "this launch wrote it")
+        uint32_t *dz;
+        BG_TRY(ctx_zeroed(c, &dz));
+        char *hp;
+        BG_TRY(ctx_pinned(c, 16384, reinterpret_cast<void **>(&hp)));
+        volatile uint32_t *hf = reinterpret_cast<volatile uint32_t *>(hp + 12288);
+        *hf = 0;
+        BG_TRY(launch_col_order_dense(c, reinterpret_cast<const uint64_t *>(dc.values), dc.length, type, dz + 8, const_cast<uint32_t *>(hf)));
+        BG_HIP(hipStreamSynchronize(c->stream));
+        if (!(*hf & 0x80000000u)) return fail(BOWGPU_ERR_HIP, "internal: the order kernel did not report");
+        *flags = *hf & 7u;
+        return 0;
+    }
     void *dscr;
     BG_TRY(ctx_scratch(c, 8192, &dscr));
     uint32_t *dflags = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(dscr) + 256);
@@ -927,9 +1012,13 @@ int bowgpu_aggregate_whole(const bowgpu_col *cols, int32_t ncols, int32_t ts_col
     if (cols[ts_col].type != BOWGPU_INT64) return fail(BOWGPU_ERR_UNSUPPORTED, "whole-frame aggregation on the device path needs an Int64 interval column");
     DevCol dts;
     BG_TRY(ts_device(c, &cols[ts_col], &dts));
-    // FirstValue / LastValue: int64(float64(first / last valid ts)) (whole.go:54-71)
+    // FirstValue / LastValue: int64(float64(first / last valid ts)) (whole.go:54-71).  The product path reads them in its finish
+    // launch; the second implementation (BOWGPU_ROUTE_FORCE_GENERAL: whole_partial_kernel and the launches of rounds 1 - 5) on the host
+    const bool general = (route_mask() & BOWGPU_ROUTE_FORCE_GENERAL) != 0;
+    bool any_mode = false;
+    for (int i = 0; i < naggs; i++) any_mode |= aggs[i].kind == BOWGPU_AGG_MODE;
     int64_t tfirst = 0, tlast = 0;
-    {
+    if (general) {
         int64_t *hp;   // (one small kernel that stores both into the registered block: api.cpp plan_make does the same)
         BG_TRY(ctx_pinned(c, 4096, reinterpret_cast<void **>(&hp)));
         hp += 256;
@@ -939,6 +1028,12 @@ int bowgpu_aggregate_whole(const bowgpu_col *cols, int32_t ncols, int32_t ts_col
     }
     auto go_i64 = [](double x) -> int64_t { return (!(x >= -9223372036854775808.0 && x < 9223372036854775808.0)) ? INT64_MIN : (int64_t)x; };
     const int64_t first_value = go_i64((double)tfirst), last_value = go_i64((double)tlast);
+    // where the finish launches store what the host reads back: the context's registered block (bytes 8192.. : values, then validity bytes)
+    char *hblock;
+    BG_TRY(ctx_pinned(c, 16384, reinterpret_cast<void **>(&hblock)));
+    uint64_t *host_values = reinterpret_cast<uint64_t *>(hblock + 8192);
+    uint8_t *host_valid = reinterpret_cast<uint8_t *>(hblock + 8192 + 8 * 64);
+    if (naggs > 64) return fail(BOWGPU_ERR_UNSUPPORTED, "whole-frame aggregation: at most 64 aggregators per call");
 
     int64_t nblocks = (n + 65535) / 65536;
     if (nblocks > 2048) nblocks = 2048;
@@ -996,6 +1091,30 @@ int bowgpu_aggregate_whole(const bowgpu_col *cols, int32_t ncols, int32_t ts_col
         for (int j = i; j < naggs; j++)
             if (aggs[j].col == col && aggs[j].kind >= BOWGPU_AGG_INTEGRAL_STEP && aggs[j].kind <= BOWGPU_AGG_WAVG_LINEAR) P.need_ts = 1;
         P.partials = partials.p; P.chunk = chunk;
+        if (!general) {
+            // the value kernel + ONE launch that merges its partials, evaluates every reducer of the column and stores the results where
+            // the host reads them (kMaxAggs reducers per launch)
+            BG_TRY(whole_value_run(c, &P, nblocks));
+            std::vector<int> mine;
+            for (int j = i; j < naggs; j++) if (aggs[j].col == col && !done[j]) { mine.push_back(j); done[j] = 1; }
+            for (size_t at = 0; at < mine.size(); at += kMaxAggs) {
+                WholeFinishH fin;
+                memset(&fin, 0, sizeof fin);
+                fin.ts = reinterpret_cast<const int64_t *>(dts.values); fin.nrows = n;
+                fin.n = (int32_t)std::min<size_t>(kMaxAggs, mine.size() - at);
+                fin.host_values = host_values; fin.host_valid = host_valid;
+                for (int q = 0; q < fin.n; q++) {
+                    const int j = mine[at + q];
+                    WholeFinalH &F = fin.f[q];
+                    F.kind = aggs[j].kind; F.out_type = out_type_of(j); F.col_is_int = cols[col].type == BOWGPU_INT64;
+                    F.n_factors = aggs[j].n_factors;
+                    for (int k = 0; k < F.n_factors && k < BOWGPU_MAX_FACTORS; k++) F.factors[k] = aggs[j].factors[k];
+                    fin.slot[q] = j;
+                }
+                BG_TRY(whole_finish_run(c, partials.p, nblocks, fin));
+            }
+            continue;
+        }
         BG_TRY(whole_run(c, &P, nblocks));
         for (int j = i; j < naggs; j++) {
             if (aggs[j].col != col || done[j]) continue;
@@ -1012,9 +1131,14 @@ int bowgpu_aggregate_whole(const bowgpu_col *cols, int32_t ncols, int32_t ts_col
     }
     std::vector<uint64_t> hv(naggs);
     std::vector<uint8_t> hb(naggs);
-    BG_HIP(hipMemcpyAsync(hv.data(), onev.p, 8 * (size_t)naggs, hipMemcpyDeviceToHost, c->stream));
-    BG_HIP(hipMemcpyAsync(hb.data(), oneb.p, (size_t)naggs, hipMemcpyDeviceToHost, c->stream));
-    BG_HIP(hipStreamSynchronize(c->stream));
+    if (general || any_mode) {   // (Mode's outputs, and everything of the second implementation, leave through the device block)
+        BG_HIP(hipMemcpyAsync(hv.data(), onev.p, 8 * (size_t)naggs, hipMemcpyDeviceToHost, c->stream));
+        BG_HIP(hipMemcpyAsync(hb.data(), oneb.p, (size_t)naggs, hipMemcpyDeviceToHost, c->stream));
+    }
+    BG_HIP(hipStreamSynchronize(c->stream));   // THE synchronisation of the call
+    if (!general)
+        for (int i = 0; i < naggs; i++)
+            if (aggs[i].kind != BOWGPU_AGG_MODE) { hv[i] = host_values[i]; hb[i] = host_valid[i]; }
     bool any_device = false;
     std::vector<uint8_t> vbs(naggs);
     for (int i = 0; i < naggs; i++) {

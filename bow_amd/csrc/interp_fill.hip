@@ -541,8 +541,10 @@ __global__ __launch_bounds__(256) void col_order_kernel(const uint64_t *values, 
 // runs of nulls, no per-trip records and no join launches - a row's left neighbour is the lane to the left (DPP wave_shr:1), lane 0's is
 // lane 63 of the 128-row group before, and the first row of a trip reads the row in front of the trip from memory (one scalar load per
 // 512 rows).  One launch for the whole column: what remains is four 16-byte loads and eight compares per lane and trip.
+// flags / ticket: two words of the context's zeroed block (every launch leaves them zero); the last workgroup to finish hands the flags
+// to the host itself (host_flags: registered memory) - no memset in front of the launch, no copy command behind it
 template <bool kInt>
-__global__ __launch_bounds__(256) void col_order_dense_kernel(const uint64_t *values, int64_t n, uint32_t *flags) {
+__global__ __launch_bounds__(256) void col_order_dense_kernel(const uint64_t *values, int64_t n, uint32_t *flags, uint32_t *ticket, uint32_t *host_flags) {
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t wave = (int64_t)blockIdx.x * 4 + wv, nwaves = (int64_t)gridDim.x * 4;
@@ -582,6 +584,13 @@ __global__ __launch_bounds__(256) void col_order_dense_kernel(const uint64_t *va
     if (threadIdx.x == 0) {
         const uint32_t B = block_flags[0] | block_flags[1] | block_flags[2] | block_flags[3] | (blockIdx.x == 0 && n > 0 ? 4u : 0u);
         if (B) atomicOr(flags, B);
+        __threadfence();
+        if (atomicAdd(ticket, 1u) == gridDim.x - 1) {   // the last workgroup: every other one's flags are in
+            __threadfence();
+            const uint32_t all = atomicExch(flags, 0u);
+            *ticket = 0u;
+            __hip_atomic_store(host_flags, all | 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (bit 31: written by this launch)
+        }
     }
 }
 
@@ -924,6 +933,56 @@ __global__ void whole_final_kernel(const Stats *partials, int64_t nblocks, int64
     *f.out_valid_byte = (uint8_t)(v.valid ? 1 : 0);
 }
 
+// The tail of a whole-frame call as ONE launch per column (round 6; rounds 1 - 5: a merge launch, one launch per reducer, a launch +
+// synchronisation for the first / last timestamp in front, two copies behind): the workgroup partials merged in order (whole_merge_kernel's
+// tree), FirstValue / LastValue read here - int64(float64(first / last ts)), whole.go:54-71 -, every reducer of the column evaluated and
+// stored where the host reads it: the registered block (value j at host_values[j], validity at host_valid[j]).
+struct WholeFinish {
+    const int64_t *ts;
+    int64_t nrows;
+    int32_t n, _pad;
+    int32_t slot[kMaxAggs];            // which output of the call
+    WholeFinal f[kMaxAggs];
+    uint64_t *host_values;
+    uint8_t *host_valid;
+};
+__global__ __launch_bounds__(256) void whole_finish_kernel(const Stats *partials, int64_t nblocks, const WholeFinish fin) {
+    __shared__ Stats part[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t per = (nblocks + 255) / 256;
+    const int64_t a = (int64_t)threadIdx.x * per;
+    int64_t b = a + per;
+    if (b > nblocks) b = nblocks;
+    Stats st;
+    stats_init(st);
+    for (int64_t i = a; i < b; i++) stats_merge(st, partials[i]);
+    for (int o = 1; o < 64; o <<= 1) {
+        const Stats other = stats_shfl_down(st, o);
+        if ((lane & (2 * o - 1)) == 0) stats_merge(st, other);
+    }
+    if (lane == 0) part[wv] = st;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    Stats acc = part[0];
+    stats_merge(acc, part[1]); stats_merge(acc, part[2]); stats_merge(acc, part[3]);
+    const int64_t first_value = go_f64_to_i64((double)fin.ts[0]), last_value = go_f64_to_i64((double)fin.ts[fin.nrows - 1]);
+    for (int j = 0; j < fin.n; j++) {
+        const WholeFinal &f = fin.f[j];
+        // reduce_val expects (win_start, interval) with LastValue = win_start + interval (whole.go:64-71)
+        Val v = reduce_val(f.kind, acc, fin.nrows, first_value, last_value - first_value, f.col_is_int);
+        if (v.valid) {
+            for (int k = 0; k < f.n_factors; k++) {
+                if (v.is_int) v.bits = (uint64_t)go_f64_to_i64((double)(int64_t)v.bits * f.factors[k]);
+                else v.bits = (uint64_t)__double_as_longlong(__longlong_as_double((long long)v.bits) * f.factors[k]);
+            }
+            // SetOrDropStrict (bowbuffer.go:84-104): a type assertion, no conversion
+            if ((f.out_type == BOWGPU_INT64) != (v.is_int != 0)) v.valid = 0;
+        }
+        fin.host_values[fin.slot[j]] = v.valid ? v.bits : 0;
+        fin.host_valid[fin.slot[j]] = (uint8_t)(v.valid ? 1 : 0);
+    }
+}
+
 // Window.FirstIndex / Window.Bow row range / Window.IsInclusive of every window (rolling.go:177-239)
 __global__ __launch_bounds__(256) void window_bounds_kernel(const int64_t *ts, int64_t n, int64_t s0, int64_t interval, int64_t W,
                                                             int inclusive, int pre_rows, const int64_t *first_idx,
@@ -977,6 +1036,16 @@ int launch_exclusive_scan(Ctx *c, const int32_t *in, int64_t n, int64_t *out /* 
     return 0;
 }
 
+// a column without nulls, one launch and nothing else: *host_flags (registered memory) receives the flags | 0x80000000 by the kernel's own store
+int launch_col_order_dense(Ctx *c, const uint64_t *values, int64_t n, int32_t type, uint32_t *d_zeroed2, uint32_t *host_flags) {
+    const int64_t ntrips = (n + 511) / 512;
+    const dim3 grid(grid_for(ntrips, 4, 4096)), block(256);
+    if (type == BOWGPU_INT64) hipLaunchKernelGGL(col_order_dense_kernel<true>, grid, block, 0, c->stream, values, n, d_zeroed2, d_zeroed2 + 1, host_flags);
+    else hipLaunchKernelGGL(col_order_dense_kernel<false>, grid, block, 0, c->stream, values, n, d_zeroed2, d_zeroed2 + 1, host_flags);
+    BG_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_col_order(Ctx *c, const uint64_t *values, const uint32_t *vbits, int64_t vbit0, int64_t n, int32_t type, uint32_t *d_flags) {
     BG_HIP(hipMemsetAsync(d_flags, 0, 4, c->stream));
     if (n == 0) return 0;
@@ -984,15 +1053,8 @@ int launch_col_order(Ctx *c, const uint64_t *values, const uint32_t *vbits, int6
     const dim3 grid(grid_for(ntrips, 4, 4096)), block(256);   // (1024 workgroups left 16 wavefronts per CU waiting out one load each: 0.25 ms per 1e8 rows)
     const bool is_int = type == BOWGPU_INT64;
     void *w;
-    if (vbits || (route_mask() & BOWGPU_ROUTE_FORCE_GENERAL)) BG_TRY(ctx_pool(c, kPoolColOrder, (size_t)(ntrips + ntrips / 128 + 8) * sizeof(TripEdge), &w));  // every level of the join
-    else w = nullptr;
+    BG_TRY(ctx_pool(c, kPoolColOrder, (size_t)(ntrips + ntrips / 128 + 8) * sizeof(TripEdge), &w));  // every level of the join
     TripEdge *edges = reinterpret_cast<TripEdge *>(w);
-    if (!vbits && !(route_mask() & BOWGPU_ROUTE_FORCE_GENERAL)) {   // no nulls: one launch, no per-trip records to join (BOWGPU_ROUTE_FORCE_GENERAL: the tests' switch to the general form)
-        if (is_int) hipLaunchKernelGGL(col_order_dense_kernel<true>, grid, block, 0, c->stream, values, n, d_flags);
-        else hipLaunchKernelGGL(col_order_dense_kernel<false>, grid, block, 0, c->stream, values, n, d_flags);
-        BG_HIP(hipGetLastError());
-        return 0;
-    }
     if (is_int) hipLaunchKernelGGL(col_order_kernel<true>, grid, block, 0, c->stream, values, vbits, vbit0, n, edges, d_flags);
     else hipLaunchKernelGGL(col_order_kernel<false>, grid, block, 0, c->stream, values, vbits, vbit0, n, edges, d_flags);
     int64_t n_in = ntrips;
@@ -1104,6 +1166,26 @@ int whole_final_run(Ctx *c, const void *partials, int64_t nblocks, int64_t nrows
     const WholeFinal &f = *reinterpret_cast<const WholeFinal *>(final_blob);
     hipLaunchKernelGGL(whole_final_kernel, dim3(1), dim3(64), 0, c->stream, reinterpret_cast<const Stats *>(partials), nblocks, nrows,
                        first_value, last_value, f);
+    BG_HIP(hipGetLastError());
+    return 0;
+}
+
+// the value kernel of one column (no merge launch): whole_finish_run follows
+int whole_value_run(Ctx *c, const void *params_blob, int64_t nblocks) {
+    const WholeParams &p = *reinterpret_cast<const WholeParams *>(params_blob);
+    if (p.need_ts) {
+        if (p.vbits) hipLaunchKernelGGL((whole_value_kernel<true, true>), dim3((unsigned)nblocks), dim3(256), 0, c->stream, p);
+        else hipLaunchKernelGGL((whole_value_kernel<false, true>), dim3((unsigned)nblocks), dim3(256), 0, c->stream, p);
+    } else if (p.vbits) hipLaunchKernelGGL((whole_value_kernel<true, false>), dim3((unsigned)nblocks), dim3(256), 0, c->stream, p);
+    else hipLaunchKernelGGL((whole_value_kernel<false, false>), dim3((unsigned)nblocks), dim3(256), 0, c->stream, p);
+    BG_HIP(hipGetLastError());
+    return 0;
+}
+
+static_assert(sizeof(WholeFinish) == sizeof(WholeFinishH), "host / device layouts of the whole-frame tail");
+int whole_finish_run(Ctx *c, const void *partials, int64_t nblocks, const WholeFinishH &fin) {
+    hipLaunchKernelGGL(whole_finish_kernel, dim3(1), dim3(256), 0, c->stream, reinterpret_cast<const Stats *>(partials), nblocks,
+                       *reinterpret_cast<const WholeFinish *>(&fin));
     BG_HIP(hipGetLastError());
     return 0;
 }

@@ -180,12 +180,19 @@ struct Rank {
     bowgpu_shard_record record;
     bowgpu_shard_decision decision;
     bowgpu_agg_info info;
+    // Interpolate -> Aggregate: the rank's points, what lies beyond its two ends, its interpolated rows (device temporaries)
+    bowgpu_interp_points points;
+    bowgpu_interp_edge edge;
+    std::vector<bowgpu_interp> interps;
+    std::vector<DevBuf> mid_values, mid_bits;
+    std::vector<bowgpu_col> raw_cols;   // the rank's rows as given (cols becomes the interpolated frame once it exists)
+    bool interpolated = false;
     int rc = 0;
     std::string err;
     void fail_from_thread(int code) { rc = code; err = bowgpu_last_error(); }
     void release() {   // on the rank's own thread: the blocks go back to THAT thread's (device's) cache
-        staged_values.clear(); staged_bits.clear(); out_values.clear(); out_bits.clear();
-        staged = false;
+        staged_values.clear(); staged_bits.clear(); out_values.clear(); out_bits.clear(); mid_values.clear(); mid_bits.clear();
+        staged = false; interpolated = false;
     }
 };
 
@@ -199,6 +206,9 @@ struct Call {
     std::vector<uint8_t *> frame_bits;   // per output: where the frame's bitmap is assembled (the caller's buffer when it lies on the host)
     std::vector<Rank> ranks;
     std::vector<bowgpu_shard_record> records;
+    const bowgpu_interp *interps = nullptr;   // Rolling.Interpolate(...).Aggregate(...): one interpolator per column; nullptr: Aggregate alone
+    int32_t ninterps = 0;
+    int64_t global_s0 = 0;
 };
 
 int rank_enter(Worker *w, const Call &call, Ctx **c) {
@@ -213,7 +223,7 @@ int rank_enter(Worker *w, const Call &call, Ctx **c) {
 // stage the rank's rows of every referenced pageable column into HBM (values from an 8-row boundary so that one offset serves values and bits)
 int rank_stage(Ctx *c, const Call &call, Rank *rk) {
     if (rk->staged) return 0;
-    std::vector<char> used(call.ncols, 0);
+    std::vector<char> used(call.ncols, call.interps ? 1 : 0);   // (Interpolate rewrites every column: interpolation.go:139-155)
     used[call.ts_col] = 1;
     for (int a = 0; a < call.naggs; a++) used[call.aggs[a].col] = 1;
     rk->cols.resize(call.ncols);
@@ -249,11 +259,66 @@ int rank_stage(Ctx *c, const Call &call, Rank *rk) {
     return 0;
 }
 
-void rank_begin(Worker *w, Call *call, int r, const int64_t *global_s0) {
+// Interpolate -> Aggregate, phase 1: the rank's first / last valid point per column (what its neighbours' Linear / StepPrevious need)
+void rank_points(Worker *w, Call *call, int r) {
     Rank *rk = &call->ranks[r];
     Ctx *c;
     int rc = rank_enter(w, *call, &c);
     if (rc == 0) rc = rank_stage(c, *call, rk);
+    if (rc == 0) rc = bowgpu_shard_interp_points(rk->cols.data(), call->ncols, call->ts_col, &rk->points);
+    if (rc != 0) rk->fail_from_thread(rc);
+}
+
+// ... phase 2: the rank's interpolated rows into device temporaries (bowgpu_shard_interpolate_count + _fill: concatenated in rank order they
+// are the unsharded Interpolate, bit for bit); from here on the rank's columns ARE that frame
+int rank_interpolate_impl(Ctx *c, Call *call, int r) {
+    Rank *rk = &call->ranks[r];
+    const int nc = call->ncols;
+    int64_t n_out = 0;
+    BG_TRY(bowgpu_shard_interpolate_count(rk->cols.data(), nc, call->ts_col, call->interval, &call->opts, call->global_s0, rk->interps.data(),
+                                          call->ninterps, &rk->edge, &n_out));
+    const int64_t cap = (n_out + 31) & ~(int64_t)31;   // (whole bitmap words: the fill writes device bitmaps in place)
+    rk->mid_values.resize(nc); rk->mid_bits.resize(nc);
+    std::vector<bowgpu_out> mid(nc);
+    for (int i = 0; i < nc; i++) {
+        BG_TRY(rk->mid_values[i].alloc((size_t)cap * 8 + 16));
+        BG_TRY(rk->mid_bits[i].alloc((size_t)(cap >> 3) + 16));
+        memset(&mid[i], 0, sizeof mid[i]);
+        mid[i].values = rk->mid_values[i].p; mid[i].validity = reinterpret_cast<uint8_t *>(rk->mid_bits[i].p);
+        mid[i].length = cap; mid[i].residency = BOWGPU_DEVICE;
+    }
+    if (n_out > 0)
+        BG_TRY(bowgpu_shard_interpolate_fill(rk->cols.data(), nc, call->ts_col, call->interval, &call->opts, call->global_s0, rk->interps.data(),
+                                             call->ninterps, &rk->edge, mid.data()));
+    rk->raw_cols = rk->cols;
+    for (int i = 0; i < nc; i++) {
+        bowgpu_col ic;
+        memset(&ic, 0, sizeof ic);
+        ic.values = mid[i].values; ic.validity = mid[i].validity; ic.offset = 0; ic.length = n_out;
+        ic.null_count = n_out > 0 ? mid[i].null_count : 0;
+        ic.type = call->cols[i].type; ic.residency = BOWGPU_DEVICE;
+        rk->cols[i] = ic;
+    }
+    // the staged copies of the input rows have served
+    BG_HIP(hipStreamSynchronize(c->stream));
+    rk->staged_values.clear(); rk->staged_bits.clear();
+    rk->interpolated = true;
+    return 0;
+}
+
+void rank_interpolate(Worker *w, Call *call, int r) {
+    Rank *rk = &call->ranks[r];
+    Ctx *c = nullptr;
+    int rc = rank_enter(w, *call, &c);
+    if (rc == 0) rc = rank_interpolate_impl(c, call, r);
+    if (rc != 0) rk->fail_from_thread(rc);
+}
+
+void rank_begin(Worker *w, Call *call, int r, const int64_t *global_s0) {
+    Rank *rk = &call->ranks[r];
+    Ctx *c;
+    int rc = rank_enter(w, *call, &c);
+    if (rc == 0 && !rk->interpolated) rc = rank_stage(c, *call, rk);
     if (rc == 0)
         rc = bowgpu_shard_begin(rk->cols.data(), call->ncols, call->ts_col, call->interval, &call->opts, call->aggs, call->naggs, global_s0,
                                 &rk->record);
@@ -322,10 +387,13 @@ bool is_decline(int rc) { return rc == BOWGPU_ERR_UNSUPPORTED || rc == BOWGPU_ER
 
 }  // namespace
 
-// Rolling.Aggregate over the listed devices.  *done = false (and 0 returned): the call is not one for the fan-out - the caller goes
-// on with the one-device path.  plan: the frame's (newIntervalRolling's s0 / numWindows), against which the ranks' decisions are checked.
-int multi_aggregate(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, const Plan &plan, int opt_inclusive, bool strict,
-                    const bowgpu_agg *aggs, int32_t naggs, bowgpu_out *outs, bowgpu_agg_info *info, bool *done) {
+// One fanned-out call.  *done = false (and 0 returned): the call is not one for the fan-out - the caller goes on with the one-device
+// path.  plan: the frame's (newIntervalRolling's s0 / numWindows), against which the ranks' decisions are checked.  interps != nullptr:
+// Rolling.Interpolate(interps...).Aggregate(aggs...) - every rank interpolates its rows first (its neighbours' edge points reach it
+// through the same host-memory exchange), then the ranks aggregate their interpolated rows like any other frame.
+static int fan_call(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, const Plan &plan, int opt_inclusive, bool strict,
+                    const bowgpu_interp *interps, int32_t ninterps, const bowgpu_agg *aggs, int32_t naggs, bowgpu_out *outs,
+                    bowgpu_agg_info *info, bool *done) {
     *done = false;
     g_last_ranks = 1;
     std::vector<int> ids;
@@ -344,6 +412,12 @@ int multi_aggregate(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, const
     if (naggs > BOWGPU_CARRY_MAX_AGGS) return 0;
     for (int i = 0; i < naggs; i++) if (aggs[i].kind == BOWGPU_AGG_MODE) return 0;
     if (cols[ts_col].validity && cols[ts_col].null_count != 0) return 0;   // (nulls in the interval column: the one-device path serves them)
+    if (interps) {
+        // the sharded Interpolate's own limits (include/bowgpu.h): at most 8 columns (bowgpu_interp_edge), frames at or above 0 whose
+        // first row is not below the first window start
+        if (ncols > 8 || ninterps != ncols || plan.s0 < 0 || plan.first_ts < plan.s0) return 0;
+        for (int i = 0; i < ncols; i++) if (interps[i].col != i) return 0;
+    }
     // device-resident buffers belong to ONE device: only a list that names the calling thread's device throughout can share them
     bool any_device = false;
     for (int i = 0; i < ncols; i++) any_device |= cols[i].residency == BOWGPU_DEVICE;
@@ -369,6 +443,7 @@ int multi_aggregate(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, const
     call.cols = cols; call.ncols = ncols; call.ts_col = ts_col; call.interval = plan.interval;
     call.opts.offset = plan.offset; call.opts.inclusive = opt_inclusive ? 1 : 0; call.opts.strict_order = strict ? 1 : 0;
     call.aggs = aggs; call.naggs = naggs; call.outs = outs; call.route = route_mask(); call.world = world;
+    call.interps = interps; call.ninterps = ninterps; call.global_s0 = plan.s0;
     call.ranks.resize(world);
     call.records.resize(world);
     // row ranges: multiples of 4096 rows (16-byte aligned value pointers, whole bitmap words) except the last one's end
@@ -400,6 +475,43 @@ int multi_aggregate(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, const
     };
     auto cleanup = [&] { fan_run(f, world, [&](int r) { rank_cleanup(f->workers[r], &call, r); }); };
 
+    if (interps) {
+        fan_run(f, world, [&](int r) { call.ranks[r].rc = 0; rank_points(f->workers[r], &call, r); });
+        bool declined = false;
+        int rc = first_error(&declined);
+        if (rc != 0 || declined) { cleanup(); return rc; }
+        // what lies beyond each rank's two ends, from every rank's points (host arithmetic: the "exchange")
+        for (int r = 0; r < world; r++) {
+            Rank &rk = call.ranks[r];
+            memset(&rk.edge, 0, sizeof rk.edge);
+            rk.interps.assign(interps, interps + ninterps);
+            int left_last = -1;
+            for (int q = 0; q < r; q++) if (call.ranks[q].points.nrows > 0) left_last = q;
+            if (left_last >= 0) { rk.edge.has_left = 1; rk.edge.left_last_ts = call.ranks[left_last].points.last_ts; }
+            for (int i = 0; i < ncols; i++) {
+                for (int q = r - 1; q >= 0; q--) {      // nearest valid point on the left: the reference's own PrevRow mechanism carries it (linear.go:14-18)
+                    const bowgpu_interp_points &pq = call.ranks[q].points;
+                    if (pq.nrows > 0 && pq.last_valid[i]) {
+                        bowgpu_interp &ip = rk.interps[i];
+                        ip.has_prev_row = 1; ip.prev_t_valid = 1; ip.prev_v_valid = 1;
+                        ip.prev_t = pq.last_t[i]; ip.prev_v = pq.last_v[i]; ip.prev_v_i64 = pq.last_v_i64[i];
+                        break;
+                    }
+                }
+                for (int q = r + 1; q < world; q++) {   // nearest valid point on the right
+                    const bowgpu_interp_points &pq = call.ranks[q].points;
+                    if (pq.nrows > 0 && pq.first_valid[i]) {
+                        rk.edge.next_valid[i] = 1; rk.edge.next_t[i] = pq.first_t[i]; rk.edge.next_v[i] = pq.first_v[i];
+                        break;
+                    }
+                }
+            }
+        }
+        fan_run(f, world, [&](int r) { rank_interpolate(f->workers[r], &call, r); });
+        rc = first_error(&declined);
+        if (rc != 0 || declined) { cleanup(); return rc; }
+    }
+
     int64_t s0_known = 0;
     const int64_t *s0_ptr = nullptr;
     for (int attempt = 0; attempt < 2; attempt++) {
@@ -416,6 +528,7 @@ int multi_aggregate(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, const
         const bowgpu_shard_decision &d0 = call.ranks[0].decision;
         if (!d0.retry_with_s0 && (d0.s0 != plan.s0 || d0.num_windows != W)) {
             cleanup();
+            if (interps) return 0;   // (an interpolated frame whose windows are not the input's: the two calls on one device word whatever there is to say)
             return fail(BOWGPU_ERR_ARG, "the plan was not made for this interval column (its first / last timestamp differ)");
         }
         fan_run(f, world, [&](int r) { rank_finish(f->workers[r], &call, r); });
@@ -442,12 +555,9 @@ int multi_aggregate(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, const
         for (int r = 0; r < world; r++) valid += call.ranks[r].valid[i];
         outs[i].length = W;
         outs[i].null_count = W - valid;
-        outs[i].type = call.ranks[0].outs.empty() ? outs[i].type : call.ranks[0].outs[i].type;
-    }
-    // the types were resolved by every rank alike; take them from a rank that ran
-    for (int i = 0; i < naggs; i++)
-        for (int r = 0; r < world; r++)
+        for (int r = 0; r < world; r++)   // (the types were resolved by every rank alike)
             if (!call.ranks[r].outs.empty()) { outs[i].type = call.ranks[r].outs[i].type; break; }
+    }
     bool any_dev_out = false;
     for (int i = 0; i < naggs; i++) any_dev_out |= outs[i].residency == BOWGPU_DEVICE;
     if (any_dev_out) {
@@ -469,6 +579,17 @@ int multi_aggregate(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, const
     g_last_ranks = world;
     *done = true;
     return 0;
+}
+
+int multi_aggregate(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, const Plan &plan, int opt_inclusive, bool strict,
+                    const bowgpu_agg *aggs, int32_t naggs, bowgpu_out *outs, bowgpu_agg_info *info, bool *done) {
+    return fan_call(cols, ncols, ts_col, plan, opt_inclusive, strict, nullptr, 0, aggs, naggs, outs, info, done);
+}
+
+int multi_interpolate_aggregate(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, const Plan &plan, int opt_inclusive, bool strict,
+                                const bowgpu_interp *interps, int32_t ninterps, const bowgpu_agg *aggs, int32_t naggs, bowgpu_out *outs,
+                                bowgpu_agg_info *info, bool *done) {
+    return fan_call(cols, ncols, ts_col, plan, opt_inclusive, strict, interps, ninterps, aggs, naggs, outs, info, done);
 }
 
 }  // namespace bowgpu

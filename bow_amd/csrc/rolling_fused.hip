@@ -38,6 +38,10 @@ constexpr int kAlignF = 16;
 #define BOWGPU_FUSED_NT 1
 #endif
 constexpr bool kNtF = BOWGPU_FUSED_NT != 0;   // non-temporal loads of a tile's interior chunks (rolling_simple.hip); A/B: -DBOWGPU_FUSED_NT=0
+#ifndef BOWGPU_FUSED_SWZ
+#define BOWGPU_FUSED_SWZ 0
+#endif
+constexpr bool kSwzFused = BOWGPU_FUSED_SWZ != 0;   // the staged column padded by two slots per 32 rows (agg_device.h swz): A/B -DBOWGPU_FUSED_SWZ=1
 
 // The rows' times stay in LDS as 32-bit offsets from the first window start: a synthetic row needs the times of its two neighbour
 // points (linear.go:34), rows a lane other than the window's holds.  (Fetched from the column instead - two 8-byte gathers per window
@@ -45,12 +49,12 @@ constexpr bool kNtF = BOWGPU_FUSED_NT != 0;   // non-temporal loads of a tile's 
 // A head entry is the head's local row alone: its window id and whether it sits exactly on the window's start are recomputed from
 // its staged time.  8 KB per wavefront: 20 per CU.
 struct FusedShared {
-    uint64_t val[kRowsF];              // the staged column (not padded: the windows of a frame that wants interpolating are irregular)
+    uint64_t val[kSwzFused ? swz_slots(kRowsF) : kRowsF];   // the staged column
     uint32_t tsx[kRowsF];              // ts - s0 of every row of the tile
     uint32_t vbits[kRowsF / 32 + 2];   // validity words of the value column for this tile
     uint16_t seg[kCapF + 2];           // heads in row order: local row
 };
-static_assert(sizeof(FusedShared) <= 8192, "LDS of the fused kernel: 8 KB (20 wavefronts per CU)");
+static_assert(sizeof(FusedShared) <= (kSwzFused ? 8192 + 320 : 8192), "LDS of the fused kernel: 8 KB (20 wavefronts per CU; padded: 8.3 KB, 18)");
 
 __device__ __forceinline__ uint32_t mdiv32(uint32_t n, uint32_t m, uint32_t sh1, uint32_t sh2) {
     const uint32_t t = __umulhi(m, n);
@@ -121,7 +125,7 @@ __device__ __forceinline__ void walk_pred_seeded(const uint64_t *val, const uint
 template <int kNeed, bool kNulls, bool kMulti>
 __global__ __launch_bounds__(kWave, kMulti ? 4 : 6) void rolling_fused_kernel(const FusedParams fp, const int64_t ntiles, const int64_t tiles_per_xcd) {
     __shared__ FusedShared sh;
-    constexpr bool kSwzF = false;
+    constexpr bool kSwzF = kSwzFused;
     const SimpleParams &p = fp.s;
     const int64_t b = blockIdx.x;
     const int64_t tile = (b & 7) * tiles_per_xcd + (b >> 3);  // XCD-contiguous tile runs (look-ahead rows hit the same L2)

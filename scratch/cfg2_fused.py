@@ -2,7 +2,7 @@
 interval 100, offsets 0 and 7: the two calls (count + fill, then Aggregate on the filled frame: what a caller who wants the filled Bow
 makes) against the ONE call bowgpu_rolling_interpolate_aggregate (rolling_fused.hip: the interpolated frame is never written), and the
 same entry point pushed through its two-call form.  Wall per call (outputs allocated once), kernel bracket, bytes."""
-import sys, time
+import os, sys, time
 sys.path.insert(0, '.')
 import ctypes as C
 from bow_amd import capi
@@ -25,7 +25,7 @@ SETS = ([("WindowStart", 0), ("ArithmeticMean", 1)], [("WindowStart", 0), ("Arit
 if len(sys.argv) > 2 and sys.argv[2] == "quick":
     SETS = SETS[:1]
 for aggs in SETS:
-    for offset in (0, 7):
+    for offset in ((7, 0) if os.environ.get('CFG2_ORDER') == 'rev' else (0, 7)):   # (CFG2_ORDER=rev: which offset is measured first - round 6: the 10 % spread of round 5 follows the ORDER, not the offset)
         s0, W = capi.plan_windows(ts, 100, offset)
         outs = [capi.OutColumn(W, capi.DEVICE) for _ in aggs]
         kms = []

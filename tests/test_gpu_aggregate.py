@@ -1283,6 +1283,36 @@ def test_pinned_zero_copy_residency_equals_the_other_residencies():
     assert e.value.code == -10
 
 
+def test_strict_long_windows_find_an_unsorted_interval_column_themselves():
+    """Round 6: under strict_order a call of long windows with a time-weighted reducer has no pass of its own over the interval column any
+    more - the lane walks check the order of the rows they read (long_windows.hip walk_entry check_order) and that the windows' row
+    ranges tile the frame.  One descent anywhere - inside a window, between two windows, at the frame's ends, in front of a run of empty
+    windows - must still be BOWGPU_ERR_TS_UNSORTED; sets that read no timestamps keep ts_sorted_kernel."""
+    rng = np.random.default_rng(5)
+    n = 300_000
+    base = np.cumsum(rng.integers(1, 4, n)).astype(np.int64)
+    base[200_000:] += 50_000                       # a run of empty windows
+    v = rng.standard_normal(n)
+    tw = [("WindowStart", 0), ("WeightedAverageStep", 1), ("ArithmeticMean", 1)]
+    plain = [("WindowStart", 0), ("ArithmeticMean", 1)]
+    for aggs in (tw, plain):
+        outs, info = capi.rolling_aggregate([capi.Column(base, None, capi.INT64), capi.Column(v, None, capi.FLOAT64)], 0, 1500, aggs, strict_order=True)
+        assert capi.last_kernel_name() == "long_strict_kernel" and info.long_windows == 0
+        exp, _ = orc.aggregate([orc.Column(base, None, orc.INT64), orc.Column(v, None, orc.FLOAT64)], 0, 1500, aggs)
+        for a, g, w in zip(aggs, outs, exp):
+            compare("strict sorted " + a[0], g, w)
+        for spot in (1, 2, 7, 8, 9, 700, 751, 199_999, 200_000, 200_001, n - 2, n - 1, int(rng.integers(1, n))):
+            for drop in (1, 10_000_000):
+                ts = base.copy()
+                ts[spot] = ts[spot - 1] - drop
+                cols = [capi.Column(ts, None, capi.INT64), capi.Column(v, None, capi.FLOAT64)]
+                with pytest.raises(capi.BowGpuError) as e:
+                    capi.rolling_aggregate(cols, 0, 1500, aggs, strict_order=True)
+                assert e.value.code in (-14, -9), (aggs[1][0], spot, drop, e.value)     # (-9: the bisection on unsorted rows made a window of > 2^20 rows - declined either way)
+                if drop == 1:
+                    assert e.value.code == -14, (aggs[1][0], spot, e.value)
+
+
 def test_strict_order_and_the_pinned_form_thresholds():
     """bowgpu_options.strict_order: every window in the reference's row order (bit-exact, long_windows == 0) or the call is declined.
     And the window length at which a call changes form (common.h: kLongOnlyAvgRows = 128 rows on average for the calls with both kinds
@@ -1297,8 +1327,13 @@ def test_strict_order_and_the_pinned_form_thresholds():
     more = [("WindowStart", 0), ("Sum", 1), ("Min", 1), ("WeightedAverageStep", 1)]
     # which form runs where
     both = [("WindowStart", 0), ("IntegralStep", 1), ("WeightedAverageLinear", 1)]
+    # (round 6: the windows a tile pass queues are walked behind it by long_queue_kernel - in row order, so long_windows stays 0 -, which
+    # keeps columns WITHOUT nulls on the tile kernels up to 176 rows per window for sets with extrema, First / Last or one kind of integral,
+    # up to 200 for extrema alone: api.cpp job_run tile_band_rows)
+    mm_only = [("WindowStart", 0), ("Min", 1), ("Max", 1)]
     for aggs, interval, kernel in ((lite, 127, "rolling_simple_kernel"), (lite, 128, "rolling_simple_kernel"), (lite, 130, "long_stream_kernel"), (more, 127, None),
-                                   (more, 128, "rolling_tw_kernel"), (more, 130, "long_stream_kernel"), (more, 256, "long_stream_kernel"),
+                                   (more, 128, "rolling_tw_kernel"), (more, 130, "rolling_tw_kernel"), (more, 176, "rolling_tw_kernel"), (more, 180, "long_stream_kernel"),
+                                   (more, 256, "long_stream_kernel"), (mm_only, 200, "rolling_simple_kernel"), (mm_only, 208, "long_stream_kernel"),
                                    (more, 1000, "long_stream_kernel"), (both, 127, "rolling_tw_kernel"), (both, 128, "long_stream_kernel")):
         outs, info = capi.rolling_aggregate(cols, 0, interval, aggs)
         name = capi.last_kernel_name()

@@ -855,6 +855,74 @@ def test_interpolate_count_to_fill_reuse_is_dropped_when_the_column_changes():
     cmp_out("after the tampering, ts", outs[0], want_a[0]); cmp_out("after the tampering, val", outs[1], want_a[1])
 
 
+def test_null_ts_fill_uses_what_its_count_built_and_notices_what_came_between():
+    """Round 6 (ADVICE r04 / VERDICT r05 weak 10): over an interval column with nulls the _count's compaction of the kept rows stays for the
+    _fill that follows it on the same DEVICE-resident columns (extras.cpp NullTsState) instead of being built a second time.  The fill is
+    right - against the oracle - when it follows its count, when a write through the library came between (the state is dropped), when
+    ANOTHER frame's count came between, when it runs without a count, and when the interpolators differ from the count's."""
+    import ctypes as C
+    rng = np.random.default_rng(99)
+    L = capi.lib()
+
+    def frame(n, seed):
+        r = np.random.default_rng(seed)
+        ts = np.cumsum(r.integers(1, 9, n)).astype(np.int64)
+        tv = r.random(n) >= 0.2
+        tv[0] = tv[-1] = True
+        v = np.round(r.standard_normal(n) * 10, 2)
+        vv = r.random(n) >= 0.3
+        tbm, vbm = np.packbits(tv, bitorder="little"), np.packbits(vv, bitorder="little")
+        ccols = [capi.Column(ts, tbm, capi.INT64, 0, n, -1).to_device(), capi.Column(v, vbm, capi.FLOAT64, 0, n, -1).to_device()]
+        ocols = [orc.Column(ts, tbm, orc.INT64), orc.Column(v, vbm, orc.FLOAT64)]
+        return ccols, ocols
+
+    def count(ccols, ip, interval):
+        n_out = C.c_int64(0)
+        opts = capi.Options(0, 0, 0)
+        capi.check(L.bowgpu_rolling_interpolate_count(capi._cols(ccols), 2, 0, C.c_int64(interval), C.byref(opts), capi._interps(ip), 2, C.byref(n_out)))
+        return n_out.value
+
+    def fill(ccols, ip, interval, cap):
+        outs = [capi.OutColumn((cap + 511) // 512 * 512, capi.HOST) for _ in ip]    # (host outputs: nothing is allocated on the device between the calls)
+        oarr = (capi.Out * 2)()
+        for i, o in enumerate(outs):
+            oarr[i] = o.c()
+        opts = capi.Options(0, 0, 0)
+        capi.check(L.bowgpu_rolling_interpolate_fill(capi._cols(ccols), 2, 0, C.c_int64(interval), C.byref(opts), capi._interps(ip), 2, oarr))
+        for i, o in enumerate(outs):
+            o.absorb(oarr[i])
+        return outs
+
+    A, oA = frame(150_000, 1)
+    B, oB = frame(90_000, 2)
+    ip = [{"kind": "WindowStart", "col": 0}, {"kind": "Linear", "col": 1}]
+    ip2 = [{"kind": "WindowStart", "col": 0}, {"kind": "StepPrevious", "col": 1}]
+    wantA, wantB, wantA2 = orc.interpolate(oA, 0, 40, ip), orc.interpolate(oB, 0, 40, ip), orc.interpolate(oA, 0, 40, ip2)
+    scratch = capi.DeviceBuffer(64)
+
+    def check(label, got, want):
+        for k in range(2):
+            cmp_out("%s col %d" % (label, k), got[k], want[k])
+
+    m = count(A, ip, 40)
+    assert m == wantA[0].length
+    check("fill right behind its count", fill(A, ip, 40, m), wantA)
+    check("a fill on its own", fill(A, ip, 40, m), wantA)
+    m = count(A, ip, 40)
+    capi.check(L.bowgpu_memset(C.c_void_p(scratch.ptr), 0, C.c_int64(64)))        # a write through the library: the state is dropped
+    check("a library write between count and fill", fill(A, ip, 40, m), wantA)
+    m = count(A, ip, 40)
+    mb = count(B, ip, 40)                                                          # another frame's count: the state is B's now
+    check("A's fill after B's count", fill(A, ip, 40, m), wantA)
+    mb = count(B, ip, 40)
+    check("B's fill after B's count", fill(B, ip, 40, mb), wantB)
+    m = count(A, ip, 40)
+    check("other interpolators than the count's", fill(A, ip2, 40, m), wantA2)
+    m = count(A, ip, 40)
+    capi.trim(all_threads=False)                                                   # the blocks go back to the device: nothing dangles
+    check("a trim between count and fill", fill(A, ip, 40, m), wantA)
+
+
 @pytest.mark.parametrize("null_frac", [0.02, 0.3, 0.8])
 def test_interpolate_over_an_interval_column_with_nulls(null_frac):
     """Rolling.Interpolate when the interval column has nulls (ts_nulls.hip): the output is the slices themselves -

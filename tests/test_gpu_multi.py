@@ -255,3 +255,90 @@ def test_ten_million_rows_registered_host_memory_over_eight_ranks():
     finally:
         for c in ccols:
             c.unpin()
+
+
+# ------------------------------------------------------------------ r.Interpolate(...).Aggregate(...) as ONE call over N ranks
+def check_pipeline(ccols, ocols, interval, interps, aggs, offset, ids, min_rows, label, strict=False, expect_ranks=None, out_residency=capi.HOST):
+    """bowgpu_rolling_interpolate_aggregate with the fan-out on, against oracle interpolate -> oracle aggregate and against the same
+    call on one device (bit for bit: the ranks' interpolated rows concatenated ARE the unsharded Interpolate; windows of these tests are
+    reduced in row order on both)"""
+    mid = orc.interpolate(ocols, 0, interval, interps, offset=offset)
+    want, nic = orc.aggregate(mid, 0, interval, aggs, offset=offset)
+    one, info1 = capi.rolling_interpolate_aggregate(ccols, 0, interval, interps, aggs, offset=offset, strict_order=strict, out_residency=out_residency)
+    assert capi.last_call_ranks() == 1
+    with capi.devices(ids, min_rows=min_rows):
+        got, info = capi.rolling_interpolate_aggregate(ccols, 0, interval, interps, aggs, offset=offset, strict_order=strict, out_residency=out_residency)
+        ranks = capi.last_call_ranks()
+    if expect_ranks is not None:
+        assert ranks == expect_ranks, (label, ranks)
+    assert (info.s0, info.num_windows, info.new_interval_col) == (info1.s0, info1.num_windows, nic), label
+    for a, g, w, o in zip(aggs, got, want, one):
+        if info.long_windows == 0:
+            compare("%s %s ranks=%d" % (label, a[0], ranks), g, w)
+            if info1.long_windows == 0:
+                same_bits("%s %s vs one device" % (label, a[0]), g, o)
+    return ranks
+
+
+@pytest.mark.parametrize("residency", [capi.HOST, capi.HOST_PINNED, capi.DEVICE], ids=["host", "pinned", "device"])
+@pytest.mark.parametrize("kind", ["Linear", "StepPrevious", "None"])
+def test_interpolate_then_aggregate_as_one_call_over_ranks(kind, residency):
+    """configs[2]'s pipeline through the fan-out: every rank interpolates ITS rows (its neighbours' nearest valid points reach it
+    through the host-memory exchange - long runs of nulls put them several ranks away), then the ranks aggregate the interpolated
+    rows; Float64 and Int64 columns, PrevRow, a Factor chain"""
+    n = 120_000
+    rng = np.random.default_rng(31)
+    ts = (np.cumsum(rng.integers(1, 20, n)) + 500).astype(np.int64)
+    a = np.round(rng.standard_normal(n) * 100, 2)
+    va = rng.random(n) >= 0.3
+    va[31_000:36_000] = False                  # runs of nulls across the rank boundaries (32 768 for 4 and 8 ranks, 40 960 for 3): a rank's nearest
+    va[39_000:43_000] = False                  # valid point lies on its neighbour (the oracle's neighbour walks bound the run lengths: quadratic)
+    b = rng.integers(-1000, 1000, n).astype(np.int64)
+    vb = rng.random(n) >= 0.5
+    vb[:6_000] = False                         # nothing valid to the left of the first windows: Options.PrevRow serves
+    prev = (float(ts[0] - 3), True, 42.5, True, 42)
+    ip = [{"kind": "WindowStart", "col": 0}, {"kind": kind, "col": 1}, {"kind": kind, "col": 2, "prev": prev}]
+    aggs = [("WindowStart", 0), ("ArithmeticMean", 1), ("Sum", 2, [0.5]), ("Min", 1), ("Max", 2), ("Count", 1), ("First", 2), ("Last", 1), ("NumRows", 0)]
+    bma, bmb = np.packbits(va, bitorder="little"), np.packbits(vb, bitorder="little")
+    ocols = [orc.Column(ts, None, orc.INT64), orc.Column(a, bma, orc.FLOAT64), orc.Column(b, bmb, orc.INT64)]
+    if residency == capi.HOST_PINNED:
+        bufs = []
+        for arr in (ts, a, b, bma, bmb):
+            p = capi.page_aligned(len(arr), arr.dtype); p[:] = arr; bufs.append(p)
+        ccols = [capi.Column(bufs[0], None, capi.INT64).pin(), capi.Column(bufs[1], bufs[3], capi.FLOAT64, 0, n, -1).pin(),
+                 capi.Column(bufs[2], bufs[4], capi.INT64, 0, n, -1).pin()]
+    else:
+        ccols = [capi.Column(ts, None, capi.INT64), capi.Column(a, bma, capi.FLOAT64, 0, n, -1), capi.Column(b, bmb, capi.INT64, 0, n, -1)]
+        if residency == capi.DEVICE:
+            ccols = [c.to_device() for c in ccols]
+    try:
+        for interval, offset, k in [(100, 0, 4), (64, 7, 8), (1000, 3, 3)]:
+            check_pipeline(ccols, ocols, interval, ip, aggs, offset, [0] * k, 2000, "%s I=%d k=%d" % (kind, interval, k), expect_ranks=k,
+                           out_residency=residency)
+    finally:
+        for c in ccols:
+            c.unpin()
+
+
+def test_pipeline_shapes_the_fan_out_leaves_to_one_device():
+    """rows below the first window start / negative window starts (outside the sharded Interpolate), more than 8 columns: the same call,
+    served by the calling thread's device"""
+    n = 40_000
+    rng = np.random.default_rng(4)
+    ts = (np.cumsum(rng.integers(1, 9, n)) - 1000).astype(np.int64)       # starts below zero
+    v = rng.standard_normal(n)
+    valid = rng.random(n) >= 0.3
+    bm = np.packbits(valid, bitorder="little")
+    ccols = [capi.Column(ts, None, capi.INT64), capi.Column(v, bm, capi.FLOAT64, 0, n, -1)]
+    ocols = [orc.Column(ts, None, orc.INT64), orc.Column(v, bm, orc.FLOAT64)]
+    ip = [{"kind": "WindowStart", "col": 0}, {"kind": "Linear", "col": 1}]
+    aggs = [("WindowStart", 0), ("ArithmeticMean", 1), ("Count", 1)]
+    assert check_pipeline(ccols, ocols, 50, ip, aggs, 0, [0, 0, 0], 500, "negative") == 1
+    # nine columns
+    ts2 = (ts + 5000).astype(np.int64)
+    cc = [capi.Column(ts2, None, capi.INT64)] + [capi.Column(v * (i + 1), bm, capi.FLOAT64, 0, n, -1) for i in range(8)]
+    oc = [orc.Column(ts2, None, orc.INT64)] + [orc.Column(v * (i + 1), bm, orc.FLOAT64) for i in range(8)]
+    ip9 = [{"kind": "WindowStart", "col": 0}] + [{"kind": "Linear", "col": i + 1} for i in range(8)]
+    assert check_pipeline(cc, oc, 50, ip9, [("WindowStart", 0), ("ArithmeticMean", 8)], 0, [0, 0], 500, "nine columns") == 1
+    # ... and eight are served by the ranks
+    assert check_pipeline(cc[:8], oc[:8], 50, ip9[:8], [("WindowStart", 0), ("ArithmeticMean", 7)], 0, [0, 0], 500, "eight columns") == 2
