@@ -404,7 +404,6 @@ int launch_fill_empty(Ctx *c, const AggParams &p, int64_t slot0, int64_t slot1);
 int launch_window_first_rows(Ctx *c, const int64_t *ts, int64_t n, const Plan &plan, int64_t *first_idx, uint32_t *status);
 int launch_exclusive_scan(Ctx *c, const int32_t *in, int64_t n, int64_t *out, int64_t *block_sums, int64_t *d_total);
 int launch_col_order(Ctx *c, const uint64_t *values, const uint32_t *vbits, int64_t vbit0, int64_t n, int32_t type, uint32_t *d_flags);
-int launch_col_order_dense(Ctx *c, const uint64_t *values, int64_t n, int32_t type, uint32_t *d_zeroed2, uint32_t *host_flags);
 int launch_window_bounds(Ctx *c, const int64_t *ts, int64_t n, const Plan &plan, int inclusive, int pre_rows,
                          const int64_t *first_idx, int64_t *first_index, int64_t *slice_begin, int64_t *slice_end, uint8_t *is_incl);
 int whole_run(Ctx *c, const void *params_blob, int64_t nblocks);

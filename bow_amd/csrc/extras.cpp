@@ -4,6 +4,7 @@
 // orchestrates the HIP kernels of interp_fill.hip; no column data is reduced on the CPU.
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "common.h"
@@ -741,10 +742,59 @@ static int interp_null_ts(const bowgpu_col *cols, int32_t ncols, int32_t ts_col,
     return 0;
 }
 
+// ... for Bows wider than the compaction's 16 columns (round 6; BOWGPU_ERR_UNSUPPORTED before): the value columns in groups of 15, each
+// group with the interval column in front as a frame of its own.  A column's output depends on the interval column and on itself only
+// (the interpolators look at one column each: interpolation.go:139-155), so the groups' outputs side by side are the call's; the row count
+// comes from the first group, the interval column's output is written by every group (the same bytes).  Errors are the whole frame's:
+// it is validated before anything runs.
+static int interp_null_ts_any(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval, const bowgpu_options *opts,
+                              const bowgpu_interp *interps, int32_t ninterps, int64_t *n_out, bowgpu_out *outs, bool *applies) {
+    *applies = false;
+    if (!cols || ncols <= kMaxCompactCols || ts_col < 0 || ts_col >= ncols || !interps || ninterps != ncols)
+        return interp_null_ts(cols, ncols, ts_col, interval, opts, interps, ninterps, n_out, outs, applies);
+    const bowgpu_col *tsc = &cols[ts_col];
+    if (!tsc->validity || tsc->null_count == 0 || tsc->length == 0) return 0;
+    bowgpu_options o = {0, 0, 0};
+    if (opts) o = *opts;
+    Plan plan;
+    BG_TRY(plan_make(nullptr, tsc, interval, o.offset, &plan));
+    BG_TRY(interp_validate(cols, ncols, ts_col, &o, interps, ninterps));
+    for (int i = 0; i < ncols; i++) if (interps[i].col != i) return interp_null_ts(cols, ncols, ts_col, interval, opts, interps, ninterps, n_out, outs, applies);
+    std::vector<int> values;
+    for (int i = 0; i < ncols; i++) if (i != ts_col) values.push_back(i);
+    bool first = true;
+    for (size_t at = 0; at < values.size(); at += kMaxCompactCols - 1) {
+        const size_t m = std::min<size_t>(kMaxCompactCols - 1, values.size() - at);
+        std::vector<bowgpu_col> sc(m + 1);
+        std::vector<bowgpu_interp> si(m + 1);
+        std::vector<bowgpu_out> so(m + 1);
+        sc[0] = cols[ts_col]; si[0] = interps[ts_col]; si[0].col = 0;
+        if (outs) so[0] = outs[ts_col];
+        for (size_t k = 0; k < m; k++) {
+            sc[k + 1] = cols[values[at + k]];
+            si[k + 1] = interps[values[at + k]]; si[k + 1].col = (int32_t)k + 1;
+            if (outs) so[k + 1] = outs[values[at + k]];
+        }
+        bool ap = false;
+        int64_t cnt = 0;
+        BG_TRY(interp_null_ts(sc.data(), (int32_t)m + 1, 0, interval, opts, si.data(), (int32_t)m + 1, (n_out && first) ? &cnt : nullptr, outs ? so.data() : nullptr, &ap));
+        if (!ap) return 0;   // (the interval column turned out to have no nulls: the ordinary path takes the call)
+        *applies = true;
+        if (n_out && first) *n_out = cnt;
+        if (outs) {
+            outs[ts_col] = so[0];
+            for (size_t k = 0; k < m; k++) outs[values[at + k]] = so[k + 1];
+        }
+        first = false;
+        if (!outs) break;   // (the count: one group tells it)
+    }
+    return 0;
+}
+
 int bowgpu_rolling_interpolate_count(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval,
                                      const bowgpu_options *opts, const bowgpu_interp *interps, int32_t ninterps, int64_t *n_out) {
     bool null_ts = false;
-    if (n_out) BG_TRY(interp_null_ts(cols, ncols, ts_col, interval, opts, interps, ninterps, n_out, nullptr, &null_ts));
+    if (n_out) BG_TRY(interp_null_ts_any(cols, ncols, ts_col, interval, opts, interps, ninterps, n_out, nullptr, &null_ts));
     if (null_ts) return 0;
     return interp_count_impl(cols, ncols, ts_col, interval, opts, interps, ninterps, n_out, nullptr, nullptr);
 }
@@ -752,7 +802,7 @@ int bowgpu_rolling_interpolate_count(const bowgpu_col *cols, int32_t ncols, int3
 int bowgpu_rolling_interpolate_fill(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, int64_t interval,
                                     const bowgpu_options *opts, const bowgpu_interp *interps, int32_t ninterps, bowgpu_out *outs) {
     bool null_ts = false;
-    if (outs) BG_TRY(interp_null_ts(cols, ncols, ts_col, interval, opts, interps, ninterps, nullptr, outs, &null_ts));
+    if (outs) BG_TRY(interp_null_ts_any(cols, ncols, ts_col, interval, opts, interps, ninterps, nullptr, outs, &null_ts));
     if (null_ts) return 0;
     return interp_fill_impl(cols, ncols, ts_col, interval, opts, interps, ninterps, outs, nullptr, nullptr);
 }
@@ -822,20 +872,6 @@ int bowgpu_shard_interp_points(const bowgpu_col *cols, int32_t ncols, int32_t ts
 
 // ---------------------------------------------------------------------------- IsColSorted / FillLinear
 static int col_order_flags(Ctx *c, const DevCol &dc, int32_t type, uint32_t *flags) {
-    if (!dc.vbits && dc.length > 0 && !(route_mask() & BOWGPU_ROUTE_FORCE_GENERAL)) {
-        // a column without nulls: ONE launch whose last workgroup stores the flags into the registered block (bit 31 = "this launch wrote it")
-        uint32_t *dz;
-        BG_TRY(ctx_zeroed(c, &dz));
-        char *hp;
-        BG_TRY(ctx_pinned(c, 16384, reinterpret_cast<void **>(&hp)));
-        volatile uint32_t *hf = reinterpret_cast<volatile uint32_t *>(hp + 12288);
-        *hf = 0;
-        BG_TRY(launch_col_order_dense(c, reinterpret_cast<const uint64_t *>(dc.values), dc.length, type, dz + 8, const_cast<uint32_t *>(hf)));
-        BG_HIP(hipStreamSynchronize(c->stream));
-        if (!(*hf & 0x80000000u)) return fail(BOWGPU_ERR_HIP, "internal: the order kernel did not report");
-        *flags = *hf & 7u;
-        return 0;
-    }
     void *dscr;
     BG_TRY(ctx_scratch(c, 8192, &dscr));
     uint32_t *dflags = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(dscr) + 256);

@@ -342,7 +342,10 @@ __device__ __forceinline__ void walk_entry(const AggParams &p, const LongEntry &
             // 16-byte loads from an even row on (a lane's eight rows are one 64-byte line of each column: four load instructions per
             // column instead of eight - neighbouring lanes read lines far apart, so what a load instruction costs is its count of lines:
             // 1000-row windows, WeightedAverageStep, 0.706 -> 0.602 ms per 1e8 rows.  A second batch of eight rows in flight behind the
-            // first - tried in round 6 - made it 0.652: the walk is bound by line requests, not by their latency)
+            // first - tried in round 6 - made it 0.652.  Also tried and not kept: the wavefront fetching its 64 windows' lines TOGETHER - four
+            // neighbouring lanes per line, every line asked for once, 16 lines per load instruction - and handing each window's lane its
+            // eight rows through LDS: every test green, 0.470 -> 0.757 ms for the same call, Mean 0.43 -> 0.61 (the load, the LDS round trip
+            // and the chain of additions then run strictly one after the other in a kernel that has one or two wavefronts per SIMD))
             const bool vec = ((reinterpret_cast<uintptr_t>(vp) | (need_ts ? reinterpret_cast<uintptr_t>(tp) : 0)) & 15) == 0;
             if (vec && (r & 1) && r < le.r1) { one(col_valid(cd, r), vp[r], need_ts ? tp[r] : 0ull); r++; }
             for (; r + 8 <= le.r1; r += 8) {

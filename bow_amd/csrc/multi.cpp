@@ -429,6 +429,11 @@ static int fan_call(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, const
     if (any_device) {
         const int mine = current_device_of_thread();
         for (int id : ids) if (id != mine) return 0;
+        // the ranks work on streams of their own: what the calling thread's stream (bowgpu_set_stream: possibly the application's) still
+        // has in flight on these buffers is done first
+        Ctx *c;
+        BG_TRY(ctx_get(&c));
+        BG_HIP(hipStreamSynchronize(c->stream));
     }
     Fanout *f;
     {

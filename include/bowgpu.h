@@ -69,8 +69,7 @@ enum {
     BOWGPU_ERR_TS_NULLS = -13,       /* interval column has nulls AND the call has Mode or is sharded (or, Rolling.Interpolate on inclusive
                                         windows: a row on a window start has null timestamps behind it and then an EQUAL timestamp, or sits on
                                         -1): the device path declines (caller keeps the reference path); Aggregate and Interpolate are served
-                                        otherwise.  (Rolling.Interpolate over an interval column with nulls takes at most 16 columns per
-                                        call: more is BOWGPU_ERR_UNSUPPORTED.) */
+                                        otherwise. */
     BOWGPU_ERR_TS_UNSORTED = -14,    /* interval column not ascending: device path declines */
     BOWGPU_ERR_OOM = -15
 };
@@ -355,9 +354,10 @@ typedef struct bowgpu_interp {
  * general instantiation.
  * An interval column WITH NULLS: the output is the windows' slices - rows that belong to no window vanish (rolling.go:190-193,
  * :224-228), null-timestamp rows inside a slice are copied as they are; inclusive windows too (incl. rolling.go:214-218's
- * `rowIndex - 1` after a null), except for two shapes that are BOWGPU_ERR_TS_NULLS (see the error code).  At most 16 columns per
- * call (BOWGPU_ERR_UNSUPPORTED beyond).  Cost: the call is made on the KEPT rows, compacted into device temporaries (8 bytes per row
- * and column + n / 8 bytes per bitmap), and _count and _fill each run that compaction - well over twice an ordinary call.
+ * `rowIndex - 1` after a null), except for two shapes that are BOWGPU_ERR_TS_NULLS (see the error code).  Any number
+ * of columns (round 6: beyond 16 the value columns go in groups of 15, each with the interval column).  Cost: the call is made on the
+ * KEPT rows, compacted into device temporaries (8 bytes per row and column + n / 8 bytes per bitmap); a _fill that follows its _count on
+ * the same DEVICE-resident columns (the contract above) uses what the count built, any other _fill builds it itself.
  */
 int bowgpu_rolling_interpolate_count(const bowgpu_col *cols, int32_t ncols, int32_t ts_col,
                                      int64_t interval, const bowgpu_options *opts,

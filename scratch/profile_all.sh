@@ -49,4 +49,35 @@ fi
 [ -f bow_amd/libbowgpu_stamps.so ] && BOWGPU_LIB=bow_amd/libbowgpu_stamps.so timeout -s KILL 200 python3 scratch/interp_stamps.py 2>&1 | grep -v "^[WE]2026" > $DST/${TAG}_stdout_interp_stamps.txt
 # 5. the configs[2] pipeline as one call against the two calls; the fused kernel's traffic
 timeout -s KILL 300 python3 scratch/cfg2_fused.py 2>&1 | grep -v "^[WE]2026" > $DST/${TAG}_stdout_cfg2_fused.txt
+# 6. round 6: counters of the kernels README quotes a figure for and that had no counter file: the fused kernel at both
+#    offsets next to the plain sparse Mean, the strict lane walks, the queue walk behind a tile pass, the streaming form in the band, the callers
+: > $DST/${TAG}_pmc_rolling_fused.txt
+for V in "0 2" "7 2" "0 7" "7 7"; do
+  set -- $V
+  echo "== Interpolate -> Aggregate, offset $1, $2 reducers (configs[2]: 1e8 irregular rows, 30 % nulls, interval 100)" >> $DST/${TAG}_pmc_rolling_fused.txt
+  bash scratch/pmc_sq.sh fused_$1_$2 rolling_fused scratch/fused_one.py 1e8 $1 $2 | grep -v "^pass" >> $DST/${TAG}_pmc_rolling_fused.txt
+done
+echo "== the same rows through bowgpu_rolling_aggregate (no interpolation): rolling_simple_kernel, Mean, offset 0" >> $DST/${TAG}_pmc_rolling_fused.txt
+bash scratch/pmc_sq.sh fused_plain rolling_simple scratch/fused_one.py 1e8 0 2 plain | grep -v "^pass" >> $DST/${TAG}_pmc_rolling_fused.txt
+: > $DST/${TAG}_pmc_long_strict.txt
+for V in "mean dense" "tw dense" "tw sparse" "tw4 dense"; do
+  set -- $V
+  echo "== strict_order, 1000-row windows, $1 $2" >> $DST/${TAG}_pmc_long_strict.txt
+  bash scratch/pmc_sq.sh strict_$1_$2 long_strict scratch/longw_one.py $1 $2 strict | grep -v "^pass" >> $DST/${TAG}_pmc_long_strict.txt
+done
+: > $DST/${TAG}_pmc_band.txt
+for V in "MinMax 160 dense long_queue" "MinMax 160 dense rolling_simple" "MinMax 224 dense long_short" "SumMinMax 224 dense long_short" "MinMax 224 dense stream_final"; do
+  set -- $V
+  echo "== $1, $2 rows per window, $3: $4" >> $DST/${TAG}_pmc_band.txt
+  bash scratch/pmc_sq.sh band_$1_$2_$4 $4 scratch/one_shape.py gen $1 $2 $3 | grep -v "^pass" >> $DST/${TAG}_pmc_band.txt
+done
+: > $DST/${TAG}_pmc_callers.txt
+for K in whole_value whole_finish col_order_dense "col_order_kernel" fill_kernel; do
+  echo "== $K (scratch/callers_one.py: 1e8 rows)" >> $DST/${TAG}_pmc_callers.txt
+  bash scratch/pmc_sq.sh callers_$K $K scratch/callers_one.py | grep -v "^pass" >> $DST/${TAG}_pmc_callers.txt
+done
+# 7. round 6: one call over the device list (the same device listed N times on a one-GPU box): wall by residency and rank count
+timeout -s KILL 600 python3 scratch/multi_wall.py 2>&1 | grep -v "^[WE]2026" > $DST/${TAG}_stdout_multi_wall.txt
+CFG2_ORDER=rev timeout -s KILL 300 python3 scratch/cfg2_fused.py 1e8 quick 2>&1 | grep -v "^[WE]2026" > $DST/${TAG}_stdout_cfg2_fused_rev.txt
+SWEEP_ROWS=96,128,144,160,192,224,256,320 SWEEP_HOSTQ=1 timeout -s KILL 900 python3 scratch/midw_sweep.py 2>&1 | grep -v "^[WE]2026" > $DST/${TAG}_stdout_midw_band.txt
 ls -la $DST

