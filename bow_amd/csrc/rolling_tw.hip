@@ -121,7 +121,10 @@ __global__ __launch_bounds__(kWave, (kShort || kLean || (!kNulls && kTs32 && (!k
     // the padded layout of the term array (agg_device.h swz) where two walks per tile make LDS the busiest unit: both kinds of integral in the
     // lean form.  (One kind: the three single steps in front of a window's first aligned group cost more than the bank conflicts did - same-box
     // A/B at 1e8 rows, 16 .. 96 rows per window: +2 .. 4 % kernel time with the pads.)
-    constexpr bool kSwzT = kLean && kBoth;
+#ifndef BOWGPU_TW_LEAN_PAD
+#define BOWGPU_TW_LEAN_PAD 0   // A/B build (scratch/build_variant.sh twpad rolling_tw.hip -DBOWGPU_TW_LEAN_PAD=1): the pads for ONE kind of integral too - profiles/r06_stdout_tw_lean_pad_ab.txt
+#endif
+    constexpr bool kSwzT = kLean && (kBoth || BOWGPU_TW_LEAN_PAD != 0);
     constexpr uint32_t kRowMask = kLean ? 0x3FFu : 0x7FFFu, kStartBit = kLean ? 0x400u : 0x8000u;
     const int64_t b = blockIdx.x;
     const int64_t tile = (b & 7) * tiles_per_xcd + (b >> 3);  // XCD-contiguous tile runs (look-ahead rows hit the same L2)

@@ -76,6 +76,17 @@ for K in whole_value whole_finish col_order_dense "col_order_kernel" fill_kernel
   echo "== $K (scratch/callers_one.py: 1e8 rows)" >> $DST/${TAG}_pmc_callers.txt
   bash scratch/pmc_sq.sh callers_$K $K scratch/callers_one.py | grep -v "^pass" >> $DST/${TAG}_pmc_callers.txt
 done
+# 6b. VERDICT r05 item 4a: the lean dense form of rolling_tw_kernel with the padded term layout for ONE kind of integral as well (A/B build,
+#     travels with the snapshot: scratch/build_variant.sh twpad rolling_tw.hip -DBOWGPU_TW_LEAN_PAD=1)
+if [ -f bow_amd/libbowgpu_twpad.so ]; then
+  (echo "== product build (pads only where both kinds of integral are walked)"
+   SWEEP_ROWS=16,32,64,96,128 SWEEP_ROUTES=0 timeout -s KILL 300 python3 scratch/midw_sweep.py dense WAvgStep 2>&1 | grep -v "^[WE]2026"
+   echo "== -DBOWGPU_TW_LEAN_PAD=1 (pads for one kind too)"
+   BOWGPU_LIB=$GRAFT_REPO_ROOT/bow_amd/libbowgpu_twpad.so SWEEP_ROWS=16,32,64,96,128 SWEEP_ROUTES=0 timeout -s KILL 300 python3 scratch/midw_sweep.py dense WAvgStep 2>&1 | grep -v "^[WE]2026"
+   echo "== counters, 64 rows per window: product, then padded"
+   bash scratch/pmc_quick.sh WAvgStep_64_dense_product rolling_tw scratch/one_shape.py gen WAvgStep 64 dense | tail -1
+   BOWGPU_LIB=$GRAFT_REPO_ROOT/bow_amd/libbowgpu_twpad.so bash scratch/pmc_quick.sh WAvgStep_64_dense_padded rolling_tw scratch/one_shape.py gen WAvgStep 64 dense | tail -1) > $DST/${TAG}_stdout_tw_lean_pad_ab.txt
+fi
 # 7. round 6: one call over the device list (the same device listed N times on a one-GPU box): wall by residency and rank count
 timeout -s KILL 600 python3 scratch/multi_wall.py 2>&1 | grep -v "^[WE]2026" > $DST/${TAG}_stdout_multi_wall.txt
 CFG2_ORDER=rev timeout -s KILL 300 python3 scratch/cfg2_fused.py 1e8 quick 2>&1 | grep -v "^[WE]2026" > $DST/${TAG}_stdout_cfg2_fused_rev.txt

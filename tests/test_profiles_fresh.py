@@ -63,16 +63,60 @@ def test_the_identity_ignores_what_the_kernel_is_not_compiled_from(tmp_path):
     assert again[bench.BENCH_KERNEL_INSTANCE]["sha"] == sha
 
 
+ROUND = "r06"
+
+
 def test_every_profile_file_of_the_round_is_described_and_every_described_file_exists():
-    """profiles/README.md, round-5 section: the files it names are there, and no r05_* file sits in profiles/ without a line about it"""
+    """profiles/README.md, the section of the current round: the files it names are there, and no file of the round sits in profiles/ without
+    a line about it.  The same for what DESIGN.md, README.md, the sources under bow_amd/csrc and include/bowgpu.h quote from ANY round
+    (a routing rule in api.cpp cited an A/B file that had never been committed, and nothing noticed)."""
     import re
     readme = open(os.path.join(ROOT, "profiles", "README.md")).read()
-    sec = readme[readme.index("## Round 5"):readme.index("## Round 4")]
-    named = set(re.findall(r"`(r05_[A-Za-z0-9_.]+)`", sec))
-    present = {f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.startswith("r05_")}
+    sec = readme[readme.index("## Round 6"):readme.index("## Round 5")]
+    named = set(re.findall(r"`(%s_[A-Za-z0-9_.]+)`" % ROUND, sec))
+    present_all = set(os.listdir(os.path.join(ROOT, "profiles")))
+    present = {f for f in present_all if f.startswith(ROUND + "_")}
     assert named <= present, sorted(named - present)
     assert present <= named, sorted(present - named)
-    # the design document does not quote round-5 evidence that is not there either
-    design = open(os.path.join(ROOT, "DESIGN.md")).read()
-    quoted = set(re.findall(r"`(?:profiles/)?(r05_[A-Za-z0-9_.]+\.(?:txt|csv|json))`", design))
-    assert quoted <= present, sorted(quoted - present)
+    pat = re.compile(r"(?:profiles/)?(r0[1-9]_[A-Za-z0-9_]+\.(?:txt|csv|json))")
+    docs = [os.path.join(ROOT, "DESIGN.md"), os.path.join(ROOT, "README.md"), os.path.join(ROOT, "HISTORY.md"), os.path.join(ROOT, "include", "bowgpu.h")]
+    docs += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".cpp", ".hip", ".h"))]
+    for path in docs:
+        if not os.path.exists(path):
+            continue
+        quoted = set(pat.findall(open(path).read()))
+        missing = sorted(q for q in quoted if q not in present_all)
+        assert not missing, "%s quotes evidence that is not under profiles/: %s" % (os.path.relpath(path, ROOT), missing)
+
+
+# which device sources a counter file of the round speaks about (host code - api.cpp, extras.cpp, multi.cpp - routes calls; it does not change
+# what a kernel's counters say)
+COUNTER_FILES = {
+    "r06_pmc_rolling_fused.txt": ["rolling_fused.hip", "rolling_simple.hip", "agg_device.h", "interp_device.h", "bitmap_device.h"],
+    "r06_pmc_long_strict.txt": ["long_windows.hip", "agg_device.h"],
+    "r06_pmc_band.txt": ["long_windows.hip", "rolling_simple.hip", "agg_device.h"],
+    "r06_pmc_callers.txt": ["interp_fill.hip", "agg_device.h", "bitmap_device.h"],
+    "r06_pmc_mid_windows.txt": ["rolling_tw.hip", "rolling_twc.hip", "rolling_simple.hip", "agg_device.h"],
+    "r06_pmc_interp_wave3_1e8.txt": ["interpolate.hip", "interp_device.h", "agg_device.h"],
+    "r06_pmc_long_short_tw.txt": ["long_windows.hip", "agg_device.h"],
+}
+
+
+def test_the_rounds_counter_files_belong_to_the_kernels_this_tree_builds():
+    """the sha rule of the benched instantiation extended to the round's other counter files.  They were collected from
+    ONE snapshot (profiles/r06_commit.txt); a device source one of them speaks about changed since then means it describes other code -
+    the CPU suite is red until scratch/profile_all.sh has been re-run on a GPU box and its files committed.  (Without a git history - the
+    GPU box gets a snapshot - there is nothing to compare with.)"""
+    for f in COUNTER_FILES:
+        assert os.path.exists(os.path.join(ROOT, "profiles", f)), f
+    if not os.path.isdir(os.path.join(ROOT, ".git")):
+        return
+    commit = open(os.path.join(ROOT, "profiles", "%s_commit.txt" % ROUND)).read().split()[0]
+    rc = subprocess.run(["git", "cat-file", "-e", commit + "^{commit}"], cwd=ROOT)
+    assert rc.returncode == 0, "profiles/%s_commit.txt names %s, which this history does not hold" % (ROUND, commit)
+    changed = subprocess.check_output(["git", "diff", "--name-only", commit, "HEAD", "--", "bow_amd/csrc"], cwd=ROOT).decode().split()
+    changed += subprocess.check_output(["git", "diff", "--name-only", "HEAD", "--", "bow_amd/csrc"], cwd=ROOT).decode().split()   # (working-tree edits count too)
+    changed = {os.path.basename(f) for f in changed}
+    stale = {f: sorted(changed & set(srcs)) for f, srcs in COUNTER_FILES.items() if changed & set(srcs)}
+    assert not stale, ("device sources changed since the round's counter files were collected at %s: %s - re-run scratch/profile_all.sh %s on a "
+                       "GPU box and commit its files" % (commit[:10], stale, ROUND))
