@@ -72,6 +72,28 @@ __device__ __forceinline__ ulonglong2 load16_nt(const ulonglong2 *q) {
     return make_ulonglong2(v.x, v.y);
 }
 __device__ __forceinline__ void store8_nt(uint64_t *p, uint64_t v) { __builtin_nontemporal_store(v, p); }
+// the double that the lane kCtrl names holds (row_shr:N inside a row of 16 lanes); a lane without such a neighbour keeps its own
+template <int kCtrl>
+__device__ __forceinline__ double row_dpp64(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(x), __double2loint(x), kCtrl, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(x), __double2hiint(x), kCtrl, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// Tiles of FEW windows (at most kCoopMaxHeads heads in the tile's 640 rows: windows of ~92 rows and more; ~128 when the window's lane walks
+// its rows for a sum anyway - the extrema then ride along at 2 instructions per row): the extrema of the tile's windows
+// are found by ALL 64 lanes - 16 lanes per window, four windows per pass, each lane over a contiguous piece of its window - instead of
+// by one lane per window (minmax.go:16-28 walks left to right; 192-row windows left 61 lanes idle for 192 steps).  Extrema are order-free
+// apart from two rules of the reference's loop, both kept: a NaN first value stays (the window's lane applies it), and among values that
+// compare equal - -0.0 and +0.0 - the EARLIER row stays: pieces are contiguous and ascend with the lane, a lane steps through its piece
+// in row order with `<` / `>`, and the combine takes the LATER lane's value only when it is strictly better.
+// Same-box A/B at 1e8 rows (profiles/r06_stdout_coop_extrema_ab.txt; kernel ms with / without, dense): Min + Max 96 rows 0.299 / 0.306, 128 rows
+// 0.285 / 0.330, 160 rows 0.340 / 0.392, 192 rows 0.359 / 0.428; with nulls 128 rows 0.321 / 0.386; Sum + Min + Max 144 rows 0.398 / 0.416 - but
+// 64 rows 0.338 / 0.305 and 96 rows 0.361 / 0.331 with twelve heads allowed, hence the two limits.
+#ifndef BOWGPU_COOP_MAX_HEADS
+#define BOWGPU_COOP_MAX_HEADS 7   // (A/B: scratch/build_variant.sh nocoop rolling_simple.hip -DBOWGPU_COOP_MAX_HEADS=0)
+#endif
+constexpr int kCoopMaxHeads = BOWGPU_COOP_MAX_HEADS;
+constexpr int kCoopMaxHeadsSum = BOWGPU_COOP_MAX_HEADS < 5 ? BOWGPU_COOP_MAX_HEADS : 5;
 __device__ __forceinline__ void lds_order() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     asm volatile("" ::: "memory");
@@ -338,6 +360,44 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
             const bool do_sum = need_sum && phase != 2;
             const bool do_mm = (kNeed & 1) && phase != 1;
 
+            // ---- the extrema of a tile of few windows, by all lanes (see kCoopMaxHeads)
+            double coop_mn = 0.0, coop_mx = 0.0;
+            const int nw_own = q_end - q_start;
+            const bool coop = (kNeed & 1) && do_mm && !pred_walk && nw_own > 0 && nseg_total <= (do_sum ? kCoopMaxHeadsSum : kCoopMaxHeads);
+            if ((kNeed & 1) && coop) {
+                const int sub = lane & 15, grp = lane >> 4;
+#pragma unroll 1
+                for (int j0 = 0; j0 < nw_own; j0 += 4) {
+                    const int wq = q_start + j0 + grp;
+                    int a0 = 0, a1 = 0;
+                    if (j0 + grp < nw_own) {
+                        a0 = (int)(sh.seg[wq] & 0xFFFFu);
+                        a1 = wq + 1 < nseg_total ? (int)(sh.seg[wq + 1] & 0xFFFFu) : (reaches_end ? nloc : a0);   // (a window that runs past the look-ahead is queued: nothing to do here)
+                    }
+                    const int per = (a1 - a0 + 15) >> 4;
+                    int r = a0 + sub * per;
+                    const int rend = r + per < a1 ? r + per : a1;
+                    double mnl = __longlong_as_double(0x7FF0000000000000ll), mxl = __longlong_as_double((long long)0xFFF0000000000000ull);
+                    for (; r < rend; r++) {
+                        const double x = __longlong_as_double((long long)sh.val[swz<kSwzS>(r)]);
+                        if (x < mnl) mnl = x;
+                        if (x > mxl) mxl = x;
+                    }
+                    // ordered inclusive scan over the row's 16 lanes: what the earlier lanes hold stays unless this lane's is strictly better
+#define BG_COOP_STEP(CTRL, DIST)                                            \
+                    {                                                        \
+                        const double en = row_dpp64<CTRL>(mnl), ex = row_dpp64<CTRL>(mxl);  \
+                        if (sub >= DIST) { if (!(mnl < en)) mnl = en; if (!(mxl > ex)) mxl = ex; } \
+                    }
+                    BG_COOP_STEP(0x111, 1) BG_COOP_STEP(0x112, 2) BG_COOP_STEP(0x114, 4) BG_COOP_STEP(0x118, 8)
+#undef BG_COOP_STEP
+                    // lane 15 of row i holds window j0 + i's extrema: hand them to the window's own lane (lane j0 + i of this pass)
+                    const int src = (16 * (lane - j0) + 15) & 63;
+                    const double gmn = __shfl(mnl, src), gmx = __shfl(mxl, src);
+                    if (lane >= j0 && lane < j0 + 4 && lane < nw_own) { coop_mn = gmn; coop_mx = gmx; }
+                }
+            }
+
     for (int q = q_start + lane; q < q_end; q += kWave) {
         const uint32_t e0 = sh.seg[q], e1 = sh.seg[q + 1];
         const int r0 = (int)(e0 & 0xFFFFu);
@@ -368,6 +428,13 @@ __global__ __launch_bounds__(kWave, 6) void rolling_simple_kernel(const SimplePa
         if (count > 0) {
             first_raw = sh.val[swz<kSwzS>(fv)];
             if (kNulls && pred_walk) walk_values_pred<kSwzS>(sh.val, sh.vbits, fv, lv, sum, mn, mx);
+            else if ((kNeed & 1) && coop) {
+                // the window's extrema were found by all lanes above; what is left to the window's lane: the sum (in row order) and the
+                // reference's seed rule - a NaN first value is never replaced (minmax.go:16-28)
+                if (do_sum) walk_values<kSwzS, !kMulti>(sh.val, fv, lv, true, false, false, sum, mn, mx);
+                const double seed = __longlong_as_double((long long)first_raw);
+                if (seed != seed) { mn = seed; mx = seed; } else { mn = coop_mn; mx = coop_mx; }
+            }
             else walk_values<kSwzS, !kMulti>(sh.val, fv, lv, do_sum, do_mm, exact_mm, sum, mn, mx);
             if (kNeed & 2) {
                 last_raw = sh.val[swz<kSwzS>(lv)];

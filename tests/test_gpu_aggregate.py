@@ -1283,6 +1283,44 @@ def test_pinned_zero_copy_residency_equals_the_other_residencies():
     assert e.value.code == -10
 
 
+@pytest.mark.parametrize("vkind,null_frac", [("f64", 0.0), ("f64", 0.3), ("f64", 0.95), ("i64", 0.0), ("i64", 0.4)])
+def test_extrema_of_tiles_with_few_windows_by_all_lanes(vkind, null_frac):
+    """Round 6: in a tile of few windows (rolling_simple.hip kCoopMaxHeads: windows of ~92 rows and more, ~128 next to sums) the extrema are found by all 64
+    lanes - 16 per window over contiguous pieces - instead of by one lane per window.  minmax.go:16-28's two order-dependent rules must
+    survive: a NaN FIRST value stays whatever follows; among values that compare equal (-0.0 / +0.0) the earlier row stays.  Windows of
+    40 .. 600 rows (below / above the switch, longer than the look-ahead: queued), regular and irregular, columns full of NaN / +-0 /
+    +-Inf and ties, nulls up to 95 %, Min / Max alone and next to sums and First / Last - every output bit for bit, every route."""
+    rng = np.random.default_rng(int(null_frac * 100) + (7 if vkind == "f64" else 13))
+    n = 120_000
+    for mode, interval in [("dense", 40), ("dense", 53), ("dense", 64), ("dense", 100), ("dense", 128), ("dense", 160), ("dense", 250), ("dense", 600),
+                           ("irregular", 600), ("irregular", 1500), ("gappy", 300), ("dups", 90)]:
+        ts = make_ts(rng, n, mode)
+        if vkind == "f64":
+            v = rng.standard_normal(n) * 10.0 ** rng.integers(-2, 3, n)
+            sp = rng.random(n)
+            v[sp < 0.08] = np.nan
+            v[(sp >= 0.08) & (sp < 0.16)] = 0.0
+            v[(sp >= 0.16) & (sp < 0.24)] = -0.0
+            v[(sp >= 0.24) & (sp < 0.27)] = np.inf
+            v[(sp >= 0.27) & (sp < 0.30)] = -np.inf
+            v[(sp >= 0.30) & (sp < 0.45)] = np.round(v[(sp >= 0.30) & (sp < 0.45)])     # ties
+            if interval >= 100:      # whole windows of zeros of both signs, of NaN, of one infinity
+                v[5_000:5_400] = np.where(rng.random(400) < 0.5, 0.0, -0.0)
+                v[9_000:9_400] = np.nan
+                v[12_000:12_400] = np.inf
+        else:
+            v = rng.integers(-5, 6, n).astype(np.int64)
+        valid = None if null_frac == 0 else rng.random(n) >= null_frac
+        for aggs in ([("WindowStart", 0), ("Min", 1), ("Max", 1)],
+                     [("WindowStart", 0), ("Sum", 1), ("Min", 1), ("Max", 1), ("Count", 1)],
+                     [("Max", 1), ("First", 1), ("WindowStart", 0), ("Last", 1), ("Min", 1, [-2.0]), ("ArithmeticMean", 1)]):
+            outs, exp, info = run_both(ts, [(v, valid)], interval, aggs, offset=int(rng.integers(0, interval)))
+            for (k, *_), g, w in zip(aggs, outs, exp):
+                exact = info.long_windows == 0 or k not in ORDER_SENSITIVE
+                if exact:
+                    compare("few windows per tile %s I=%d %s nulls=%.2f %s" % (mode, interval, vkind, null_frac, k), g, w)
+
+
 def test_strict_long_windows_find_an_unsorted_interval_column_themselves():
     """Round 6: under strict_order a call of long windows with a time-weighted reducer has no pass of its own over the interval column any
     more - the lane walks check the order of the rows they read (long_windows.hip walk_entry check_order) and that the windows' row
@@ -1331,11 +1369,11 @@ def test_strict_order_and_the_pinned_form_thresholds():
     both = [("WindowStart", 0), ("IntegralStep", 1), ("WeightedAverageLinear", 1)]
     # (round 6: the windows a tile pass queues are walked behind it by long_queue_kernel - in row order, so long_windows stays 0 -, which
     # keeps columns WITHOUT nulls on the tile kernels up to 176 rows per window for sets with extrema, First / Last or one kind of integral,
-    # up to 200 for extrema alone: api.cpp job_run tile_band_rows)
+    # up to 240 for extrema alone: api.cpp job_run tile_band_rows)
     mm_only = [("WindowStart", 0), ("Min", 1), ("Max", 1)]
     for aggs, interval, kernel in ((lite, 127, "rolling_simple_kernel"), (lite, 128, "rolling_simple_kernel"), (lite, 130, "long_stream_kernel"), (more, 127, None),
                                    (more, 128, "rolling_tw_kernel"), (more, 130, "rolling_tw_kernel"), (more, 176, "rolling_tw_kernel"), (more, 180, "long_stream_kernel"),
-                                   (more, 256, "long_stream_kernel"), (mm_only, 200, "rolling_simple_kernel"), (mm_only, 208, "long_stream_kernel"),
+                                   (more, 256, "long_stream_kernel"), (mm_only, 240, "rolling_simple_kernel"), (mm_only, 250, "long_stream_kernel"),
                                    (more, 1000, "long_stream_kernel"), (both, 127, "rolling_tw_kernel"), (both, 128, "long_stream_kernel")):
         outs, info = capi.rolling_aggregate(cols, 0, interval, aggs)
         name = capi.last_kernel_name()
