@@ -1264,7 +1264,7 @@ static int job_run(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, i
     // Round 6: the windows a tile pass queues are served behind it without the host (long_queue_kernel: a lane per queued window, in row
     // order), which moves the hand-over to the streaming form for columns WITHOUT nulls from 129 rows per window to where the streaming
     // form wins on WALL (1e8 rows, dense, wall ms tile route / streaming form at 144, 160, 192, 224 rows per window -
-    // profiles/r06_stdout_midw_band.txt): Min + Max 0.407 / 0.547, 0.420 / 0.510, 0.455 / 0.472, 0.504 / 0.448; Sum + Min + Max
+    // profiles/r06_stdout_midw_band_first.txt): Min + Max 0.407 / 0.547, 0.420 / 0.510, 0.455 / 0.472, 0.504 / 0.448; Sum + Min + Max
     // 0.445 / 0.549, 0.463 / 0.507, 0.508 / 0.472; First + Last 0.363 / 0.412, 0.368 / 0.396, 0.408 / 0.379; one kind of integral
     // 0.458 / 0.504, 0.470 / 0.483, 0.511 / 0.454; sums and counts alone and both kinds of integral: the streaming form throughout.
     int64_t tile_band_rows = 0;

@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 TAG=$1; KSUB=$2; shift; shift
 OUT=gpurun_out/pmcq_$TAG
 rm -rf $OUT && mkdir -p $OUT
-timeout -s KILL 100 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS --output-format csv -d $OUT/p -- python3 "$@" > $OUT/p.log 2>&1
+timeout -s KILL ${PMC_LIMIT:-100} rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS --output-format csv -d $OUT/p -- python3 "$@" > $OUT/p.log 2>&1
 python3 - <<PY | tee $OUT/summary.txt
 import csv, glob, collections
 acc = collections.defaultdict(list)

@@ -10,7 +10,7 @@ for C in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_
          "SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_SMEM SQ_INST_LEVEL_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_FLAT SQ_INSTS_BRANCH SQ_IFETCH" \
          "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  timeout -s KILL 150 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/p$i -- python3 "$@" > $OUT/p$i.log 2>&1 || echo "pass $i: rc=$?"
+  timeout -s KILL ${PMC_LIMIT:-150} rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/p$i -- python3 "$@" > $OUT/p$i.log 2>&1 || echo "pass $i: rc=$?"
 done
 python3 - <<PY | tee $OUT/summary.txt
 import csv, glob, collections
