@@ -1277,7 +1277,7 @@ static int job_run(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, i
             sums |= k == BOWGPU_AGG_SUM || k == BOWGPU_AGG_MEAN;
         }
         if (step_k && trap_k) tile_band_rows = 0;
-        else if (mm && !sums && !step_k && !trap_k) tile_band_rows = 240;   // (200 before the tile kernel found the extrema of long windows with all its lanes: rolling_simple.hip kCoopMaxHeads)
+        else if (mm && !sums && !step_k && !trap_k) tile_band_rows = 200;   // (240 was tried once the tile kernel found the extrema of long windows with all its lanes: at 224 rows the queue walk costs more than that saves - 0.498 against 0.453 ms wall, profiles/r06_stdout_midw_band.txt)
         else if (mm || fl || step_k || trap_k) tile_band_rows = 176;
     }
     const bool tile_band = !sall && !cls && !any_nulls && plan && avg_rows > 128 && avg_rows <= tile_band_rows && P.fits32 && !P.pre_rows &&

@@ -1369,11 +1369,11 @@ def test_strict_order_and_the_pinned_form_thresholds():
     both = [("WindowStart", 0), ("IntegralStep", 1), ("WeightedAverageLinear", 1)]
     # (round 6: the windows a tile pass queues are walked behind it by long_queue_kernel - in row order, so long_windows stays 0 -, which
     # keeps columns WITHOUT nulls on the tile kernels up to 176 rows per window for sets with extrema, First / Last or one kind of integral,
-    # up to 240 for extrema alone: api.cpp job_run tile_band_rows)
+    # up to 200 for extrema alone: api.cpp job_run tile_band_rows)
     mm_only = [("WindowStart", 0), ("Min", 1), ("Max", 1)]
     for aggs, interval, kernel in ((lite, 127, "rolling_simple_kernel"), (lite, 128, "rolling_simple_kernel"), (lite, 130, "long_stream_kernel"), (more, 127, None),
                                    (more, 128, "rolling_tw_kernel"), (more, 130, "rolling_tw_kernel"), (more, 176, "rolling_tw_kernel"), (more, 180, "long_stream_kernel"),
-                                   (more, 256, "long_stream_kernel"), (mm_only, 240, "rolling_simple_kernel"), (mm_only, 250, "long_stream_kernel"),
+                                   (more, 256, "long_stream_kernel"), (mm_only, 200, "rolling_simple_kernel"), (mm_only, 208, "long_stream_kernel"),
                                    (more, 1000, "long_stream_kernel"), (both, 127, "rolling_tw_kernel"), (both, 128, "long_stream_kernel")):
         outs, info = capi.rolling_aggregate(cols, 0, interval, aggs)
         name = capi.last_kernel_name()
