@@ -745,6 +745,7 @@ struct AggJob {
     bool counts_used = false;   // the valid counters hold a previous count (they accumulate): zero them before counting again
     bool tail_wrote_host = false;   // the finish launch stores the status words and the counts into the registered host block itself
     bool check_plan = false;    // the plan came from the caller (bowgpu_rolling_aggregate_planned): the pass checks it against the column
+    bool band_rows = false;     // job_run: a nullable column under extrema / First + Last alone, 129 .. 200 rows per window - rolling_simple.hip + the queue launch, not rolling_twc.hip
 };
 static thread_local bool g_plan_from_caller = false;   // set around run_aggregate by the planned entry point
 // Up to which window length (rows on average) a call on a NULLABLE column stays on rolling_twc_kernel with its 256 rows of look-ahead
@@ -1119,6 +1120,7 @@ static int job_launch_tiles(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t
                        const bool ts32 = !wide && !P.pre_rows && plan->first_ts > -lim53 && plan->last_ts < lim53 && S.s0 > -lim53;
                        const bool sums_and_extrema = (S.need & kNeedSum) && (S.need & kNeedMinMax);
                        // (beyond 128 rows per window the call is here only because job_run kept it off the streaming form: compact_long_max_rows)
+                       if (job->band_rows) return false;   // (job_run: extrema / First + Last alone on a nullable column in the 129 .. 200 band - this kernel + the queue launch)
                        if (has_nulls && ts32 && !force_large_list && !(route & BOWGPU_ROUTE_TW_ROWS) && P.n / P.W > 128 && P.n / P.W <= compact_long_max_rows(aggs, naggs)) return true;
                        return has_nulls && ts32 && sums_and_extrema && !force_large_list && !(route & BOWGPU_ROUTE_TW_ROWS) && P.n / P.W >= kCompactValuesMinAvgRows;
                    }()) {
@@ -1257,17 +1259,18 @@ static int job_run(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, i
     // ... and with 256 rows of look-ahead the same kernel keeps the calls of 129 .. 176 / 255 rows per window on a nullable column whose
     // reducer set the streaming form serves worst (compact_long_max_rows)
     const int64_t lim53 = 1ll << 53;
-    const bool compact_long = !sall && !cls && any_nulls && plan && avg_rows > 128 && avg_rows <= compact_long_max_rows(aggs, naggs) && P.fits32 &&
-                              !P.pre_rows && plan->first_ts > -lim53 && plan->last_ts < lim53 &&
-                              (uint64_t)plan->last_ts - (uint64_t)P.s0 < 0xFFFFFFF0ull && W < 0xFFFFFFF0ll && naggs <= kSimpleMaxAggs &&
-                              !(route & (BOWGPU_ROUTE_TW_ROWS | BOWGPU_ROUTE_TW_F64 | BOWGPU_ROUTE_NO_SIMPLE | BOWGPU_ROUTE_FORCE_GENERAL)) && !g_strict_order;
     // Round 6: the windows a tile pass queues are served behind it without the host (long_queue_kernel: a lane per queued window, in row
     // order), which moves the hand-over to the streaming form for columns WITHOUT nulls from 129 rows per window to where the streaming
     // form wins on WALL (1e8 rows, dense, wall ms tile route / streaming form at 144, 160, 192, 224 rows per window -
     // profiles/r06_stdout_midw_band_first.txt): Min + Max 0.407 / 0.547, 0.420 / 0.510, 0.455 / 0.472, 0.504 / 0.448; Sum + Min + Max
     // 0.445 / 0.549, 0.463 / 0.507, 0.508 / 0.472; First + Last 0.363 / 0.412, 0.368 / 0.396, 0.408 / 0.379; one kind of integral
     // 0.458 / 0.504, 0.470 / 0.483, 0.511 / 0.454; sums and counts alone and both kinds of integral: the streaming form throughout.
+    // ... and for NULLABLE columns when the set has neither sums nor integrals (the null rows are staged as NaN and never win; no second walk):
+    // 1e8 rows, 30 % nulls, wall ms rolling_simple.hip + queue / what round 5 routed (rolling_twc.hip, from 192 rows the streaming form) at 144,
+    // 160, 192 rows per window: Min + Max 0.448 / 0.575, 0.454 / 0.581, 0.468 / 0.568 (224 rows: 0.562 / 0.543); First + Last 0.419 / 0.466,
+    // 0.422 / 0.466, 0.450 / 0.460; Sum + Min + Max gains nothing (0.594 / 0.608) and keeps round 5's rule (profiles/r06_stdout_nullable_band_ab.txt)
     int64_t tile_band_rows = 0;
+    bool no_sum_set = false;
     {
         bool mm = false, fl = false, sums = false;
         for (int i = 0; i < naggs; i++) {
@@ -1276,14 +1279,20 @@ static int job_run(Ctx *c, AggJob *job, const bowgpu_agg *aggs, int32_t naggs, i
             fl |= k == BOWGPU_AGG_FIRST || k == BOWGPU_AGG_LAST;
             sums |= k == BOWGPU_AGG_SUM || k == BOWGPU_AGG_MEAN;
         }
+        no_sum_set = (mm || fl) && !sums && !step_k && !trap_k;
         if (step_k && trap_k) tile_band_rows = 0;
         else if (mm && !sums && !step_k && !trap_k) tile_band_rows = 200;   // (240 was tried once the tile kernel found the extrema of long windows with all its lanes: at 224 rows the queue walk costs more than that saves - 0.498 against 0.453 ms wall, profiles/r06_stdout_midw_band.txt)
         else if (mm || fl || step_k || trap_k) tile_band_rows = 176;
     }
-    const bool tile_band = !sall && !cls && !any_nulls && plan && avg_rows > 128 && avg_rows <= tile_band_rows && P.fits32 && !P.pre_rows &&
+    const bool tile_band = !sall && !cls && (!any_nulls || (no_sum_set && !(route & BOWGPU_ROUTE_TW_ROWS))) && plan && avg_rows > 128 && avg_rows <= tile_band_rows && P.fits32 && !P.pre_rows &&
                            plan->first_ts > -lim53 && plan->last_ts < lim53 && (uint64_t)plan->last_ts - (uint64_t)P.s0 < 0xFFFFFFF0ull &&
                            W < 0xFFFFFFF0ll && naggs <= kSimpleMaxAggs &&
                            !(route & (BOWGPU_ROUTE_NO_SIMPLE | BOWGPU_ROUTE_FORCE_GENERAL | BOWGPU_ROUTE_QUEUE_HOST)) && !g_strict_order;
+    const bool compact_long = !sall && !cls && !tile_band && any_nulls && plan && avg_rows > 128 && avg_rows <= compact_long_max_rows(aggs, naggs) && P.fits32 &&
+                              !P.pre_rows && plan->first_ts > -lim53 && plan->last_ts < lim53 &&
+                              (uint64_t)plan->last_ts - (uint64_t)P.s0 < 0xFFFFFFF0ull && W < 0xFFFFFFF0ll && naggs <= kSimpleMaxAggs &&
+                              !(route & (BOWGPU_ROUTE_TW_ROWS | BOWGPU_ROUTE_TW_F64 | BOWGPU_ROUTE_NO_SIMPLE | BOWGPU_ROUTE_FORCE_GENERAL)) && !g_strict_order;
+    job->band_rows = tile_band && any_nulls;
     const bool stream_ok = !classic_only && !compact_long && !tile_band &&
                            avg_rows >= ((sall || (step_k && trap_k && !any_nulls)) ? kLongOnlyAvgRows : kLongStreamAnyAvgRows) &&
                            avg_rows < kLongClassicAvgRows && W < (1ll << 32);

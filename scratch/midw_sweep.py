@@ -32,6 +32,8 @@ for label, cols, scale, bpr in (("dense", dense, 1, 16.0), ("sparse", sparse, 10
                 routes += [("row-space", capi.ROUTE_TW_ROWS)]   # round 5: without rolling_twc_kernel (the forms of round 4: rolling_tw / rolling_simple / streaming)
             if rpw >= 96 and os.environ.get("SWEEP_ROUTES", "1") == "1":
                 routes += [("stream", capi.ROUTE_LONG_STREAM_ALL), ("tiles", capi.ROUTE_NO_LONG_ONLY)]
+                if label == "sparse" and os.environ.get("SWEEP_TILES_ROWS") == "1":   # round 6: the tile route WITHOUT rolling_twc_kernel (rolling_simple / rolling_tw + the queue launch) on nullable columns
+                    routes += [("tiles-rows", capi.ROUTE_NO_LONG_ONLY | capi.ROUTE_TW_ROWS)]
                 if os.environ.get("SWEEP_HOSTQ") == "1":   # round 6 A/B: the tile route with the queued windows through the host (rounds 1 - 5) instead of long_queue_kernel
                     routes += [("tiles-hostq", capi.ROUTE_NO_LONG_ONLY | capi.ROUTE_QUEUE_HOST)]
             line = "%-6s %4d rows/window %-9s" % (label, rpw, name)

@@ -1392,7 +1392,12 @@ def test_strict_order_and_the_pinned_form_thresholds():
                                    ([("WindowStart", 0), ("WeightedAverageStep", 1)], 260, "long_stream_kernel"), (both, 128, "rolling_twc_kernel"), (both, 170, "rolling_twc_kernel"),
                                    (both, 180, "long_stream_kernel"), (lite, 64, "rolling_simple_kernel"), (summ, 40, "rolling_simple_kernel"), (summ, 50, "rolling_twc_kernel"),
                                    (summ, 128, "rolling_twc_kernel"), (summ, 170, "rolling_twc_kernel"), (summ, 180, "long_stream_kernel"),
-                                   ([("WindowStart", 0), ("First", 1), ("Last", 1)], 250, "rolling_twc_kernel"), (lite, 130, "long_stream_kernel")):
+                                   ([("WindowStart", 0), ("First", 1), ("Last", 1)], 250, "rolling_twc_kernel"), (lite, 130, "long_stream_kernel"),
+                                   # round 6: extrema / First + Last ALONE on a nullable column stay on rolling_simple.hip (+ the queue launch) through the band
+                                   (mm_only, 150, "rolling_simple_kernel"), (mm_only, 200, "rolling_simple_kernel"), (mm_only, 208, "long_stream_kernel"),
+                                   ([("WindowStart", 0), ("First", 1), ("Last", 1)], 150, "rolling_simple_kernel"),
+                                   ([("WindowStart", 0), ("First", 1), ("Last", 1)], 180, "rolling_twc_kernel"),
+                                   ([("WindowStart", 0), ("Min", 1), ("Last", 1)], 170, "rolling_simple_kernel")):
         capi.rolling_aggregate(ncols, 0, interval, aggs)
         assert capi.last_kernel_name() == kernel, (interval, capi.last_kernel_name())
     with capi.route(capi.ROUTE_TW_ROWS):

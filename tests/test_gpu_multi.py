@@ -23,7 +23,13 @@ def same_bits(label, a, b):
     av, ab = a.host_arrays()
     bv, bb = b.host_arrays()
     assert np.array_equal(ab, bb), (label, "validity")
-    assert np.array_equal(av.view(np.uint64), bv.view(np.uint64)), (label, np.flatnonzero(av.view(np.uint64) != bv.view(np.uint64))[:10])
+    diff = av.view(np.uint64) != bv.view(np.uint64)
+    if diff.any() and a.type == capi.FLOAT64:
+        # what "bit-exact" excludes everywhere (include/bowgpu.h): sign and payload of a NaN the arithmetic GENERATES or passes on through an
+        # addition - two NaN operands keep the FIRST one's bits, and a window stitched across two ranks adds its halves in another operand
+        # order than the one-lane walk does (found by the 200-seed soak: IntegralStep over a column of NaN / Inf, 0x7FF8... against 0xFFF8...)
+        diff &= ~(np.isnan(av.view(np.float64)) & np.isnan(bv.view(np.float64)))
+    assert not diff.any(), (label, np.flatnonzero(diff)[:10])
 
 
 def check_case(ccols, ocols, interval, aggs, offset, inclusive, label, ids, min_rows, strict=False, out_residency=capi.HOST, expect_ranks=None):
