@@ -739,6 +739,15 @@ def test_slow_route_counter_tells_a_caller_when_a_fallback_kernel_served_the_cal
         assert capi.last_call_slow_rows() == n
     capi.rolling_aggregate(cols, 0, 30, aggs)
     assert capi.last_call_slow_rows() == 0
+    # ... and the fused Interpolate -> Aggregate call speaks of ITSELF (it used to leave the previous call's figure standing)
+    with capi.route(capi.ROUTE_FORCE_GENERAL | capi.ROUTE_NO_LONG_ONLY):
+        capi.rolling_aggregate(cols, 0, 30, aggs)
+        assert capi.last_call_slow_rows() == n
+    big = 200_000
+    tsb = np.cumsum(np.random.default_rng(3).integers(1, 9, big)).astype(np.int64)
+    colsb = [capi.Column(tsb), capi.Column(np.arange(big, dtype=np.float64), None, capi.FLOAT64)]
+    capi.rolling_interpolate_aggregate(colsb, 0, 100, ip, aggs)
+    assert capi.last_kernel_name() == "rolling_fused_kernel" and capi.last_call_slow_rows() == 0
 
 
 # ------------------------------------------------------------------ aggregation.Mode (mode.go:8-32)
