@@ -137,7 +137,7 @@ SYMBOLS = [
     "bowgpu_gen_sparse", "bowgpu_stream_read_ceiling", "bowgpu_stream_rw_probe", "bowgpu_debug_status", "bowgpu_debug_host_copy", "bowgpu_checksum64", "bowgpu_parquet_open", "bowgpu_parquet_close",
     "bowgpu_parquet_info", "bowgpu_parquet_column", "bowgpu_parquet_read_column",
     "bowgpu_debug_set_route", "bowgpu_debug_get_route", "bowgpu_checksum64_at",
-    "bowgpu_set_devices", "bowgpu_get_devices", "bowgpu_set_fanout_min_rows", "bowgpu_last_call_ranks",
+    "bowgpu_set_devices", "bowgpu_get_devices", "bowgpu_set_fanout_min_rows", "bowgpu_last_call_ranks", "bowgpu_fanout_counts",
 ]
 
 _lib = None
@@ -194,6 +194,13 @@ def get_devices():
     arr = (C.c_int * 64)()
     check(lib().bowgpu_get_devices(arr, 64, C.byref(n)))
     return [arr[i] for i in range(n.value)]
+
+
+def fanout_counts():
+    """(calls that arrived with a device list in force, calls that ran as row ranges), process-wide"""
+    a, b = C.c_int64(0), C.c_int64(0)
+    check(lib().bowgpu_fanout_counts(C.byref(a), C.byref(b)))
+    return a.value, b.value
 
 
 def last_call_ranks():

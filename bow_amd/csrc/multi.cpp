@@ -15,9 +15,11 @@
 // thread's device (how a one-GPU box exercises the path: the same id listed N times).  Everything the record protocol declines
 // (Mode, more than 16 aggregators, interval columns with nulls, strict_order windows over three ranks) is served by the one-device
 // path as before.  No CPU implementation of anything here: the ranks run the HIP kernels.
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -53,11 +55,37 @@ struct Fanout {
     int pending = 0;
 };
 
+std::atomic<int64_t> g_calls_listed{0}, g_calls_served{0};   // bowgpu_fanout_counts
 thread_local int g_last_ranks = 1;            // ranks that served the calling thread's last Rolling.Aggregate (bowgpu_last_call_ranks)
 std::mutex g_cfg_mu;
 std::vector<int> g_ids;                      // guarded by g_cfg_mu
 int64_t g_min_rows = (int64_t)1 << 20;       // rows per rank below which a call is not cut further
 Fanout *g_fan = nullptr;                     // never destroyed (a worker may sit in its condition variable at process exit)
+
+// BOWGPU_DEVICES="0,1,2,3" / BOWGPU_FANOUT_MIN_ROWS=<rows>, read ONCE per process (like BOWGPU_ROUTE): the initial device list of a process
+// that never calls bowgpu_set_devices - how an unmodified program (the C++ mirror's replay of the reference's test tables,
+// tests/test_gpu_host_mirror.py) runs through the fan-out.  Nothing on the call path reads the environment.
+std::once_flag g_env_once;
+void env_defaults() {
+    std::call_once(g_env_once, [] {
+        const char *d = getenv("BOWGPU_DEVICES");
+        const char *m = getenv("BOWGPU_FANOUT_MIN_ROWS");
+        std::lock_guard<std::mutex> g(g_cfg_mu);
+        if (d && *d && g_ids.empty()) {
+            std::vector<int> ids;
+            for (const char *q = d; *q;) {
+                char *end = nullptr;
+                const long v = strtol(q, &end, 10);
+                if (end == q) break;
+                if (v >= 0 && v < 1024) ids.push_back((int)v);
+                q = *end == ',' ? end + 1 : end;
+                if (*end != ',' ) break;
+            }
+            if (ids.size() >= 2 && ids.size() <= 64) g_ids = ids;
+        }
+        if (m && *m) { const long long v = strtoll(m, nullptr, 10); if (v >= 1) g_min_rows = v; }
+    });
+}
 
 void worker_main(Worker *w) {
     for (;;) {
@@ -396,6 +424,7 @@ static int fan_call(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, const
                     bowgpu_agg_info *info, bool *done) {
     *done = false;
     g_last_ranks = 1;
+    env_defaults();
     std::vector<int> ids;
     int64_t min_rows;
     {
@@ -403,6 +432,7 @@ static int fan_call(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, const
         ids = g_ids;
         min_rows = g_min_rows;
     }
+    if (ids.size() >= 2) g_calls_listed.fetch_add(1, std::memory_order_relaxed);
     if (ids.size() < 2) return 0;
     const int64_t n = cols[ts_col].length;
     const int64_t W = plan.W;
@@ -582,6 +612,7 @@ static int fan_call(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, const
         }
     }
     g_last_ranks = world;
+    g_calls_served.fetch_add(1, std::memory_order_relaxed);
     *done = true;
     return 0;
 }
@@ -605,6 +636,7 @@ extern "C" {
 
 int bowgpu_set_devices(const int *ids, int n) {
     if (n < 0 || (n > 0 && !ids)) return fail(BOWGPU_ERR_ARG, "bowgpu_set_devices: bad arguments");
+    env_defaults();   // (so that a later first call does not overwrite what this call sets)
     if (n > 64) return fail(BOWGPU_ERR_ARG, "bowgpu_set_devices: at most 64 ranks");
     int count = 0;
     if (n > 0) {
@@ -620,6 +652,7 @@ int bowgpu_set_devices(const int *ids, int n) {
 
 int bowgpu_get_devices(int *ids, int cap, int *n) {
     if (!n) return fail(BOWGPU_ERR_ARG, "null argument");
+    env_defaults();
     std::lock_guard<std::mutex> g(g_cfg_mu);
     *n = (int)g_ids.size();
     for (int i = 0; ids && i < cap && i < (int)g_ids.size(); i++) ids[i] = g_ids[i];
@@ -632,8 +665,16 @@ int bowgpu_last_call_ranks(int *ranks) {
     return 0;
 }
 
+int bowgpu_fanout_counts(int64_t *calls, int64_t *served) {
+    if (!calls || !served) return fail(BOWGPU_ERR_ARG, "null argument");
+    *calls = g_calls_listed.load(std::memory_order_relaxed);
+    *served = g_calls_served.load(std::memory_order_relaxed);
+    return 0;
+}
+
 int bowgpu_set_fanout_min_rows(int64_t rows) {
     if (rows < 1) return fail(BOWGPU_ERR_ARG, "bowgpu_set_fanout_min_rows: at least one row per rank");
+    env_defaults();
     std::lock_guard<std::mutex> g(g_cfg_mu);
     g_min_rows = rows;
     return 0;

@@ -194,13 +194,18 @@ int bowgpu_device_name(char *buf, int cap);
  * record protocol declines - aggregation.Mode, more than 16 aggregators, an interval column with nulls, strict_order with a window over
  * three ranks - and calls with too few rows take the one-device path of the calling thread as before; so does everything else in this
  * header.  Fanned-out calls are serialised process-wide (the devices are busy with one anyway).
- *   n <= 1 (or ids == NULL, n == 0) switches the fan-out off.  min_rows: default 2^20 (bowgpu_set_fanout_min_rows). */
+ *   n <= 1 (or ids == NULL, n == 0) switches the fan-out off.  min_rows: default 2^20 (bowgpu_set_fanout_min_rows).  A process that never
+ * calls bowgpu_set_devices starts with the list BOWGPU_DEVICES="0,1,..." names (and BOWGPU_FANOUT_MIN_ROWS), read once - for running an
+ * unmodified program through the fan-out; nothing on the call path reads the environment. */
 int bowgpu_set_devices(const int *ids, int n);
 int bowgpu_get_devices(int *ids, int cap, int *n);   /* the list in force (n = 0: off); ids may be NULL */
 int bowgpu_set_fanout_min_rows(int64_t rows);
 /* row ranges (= library threads, = entries of the device list) that served the calling thread's last bowgpu_rolling_aggregate / _planned /
  * _interpolate_aggregate call; 1: the one-device path */
 int bowgpu_last_call_ranks(int *ranks);
+/* process-wide since load: Rolling.Aggregate calls that arrived while a list of two or more devices was in force, and how many of them ran as
+ * row ranges (the rest: what the fan-out declines, served by the one-device path) */
+int bowgpu_fanout_counts(int64_t *calls, int64_t *served);
 /* Use an externally owned hipStream_t (e.g. torch's current stream) for all work of this
  * thread; NULL restores the library's own stream. */
 int bowgpu_set_stream(void *hip_stream);
