@@ -1833,6 +1833,7 @@ static int fused_try(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t ts_c
         fc.has_prev = ip.has_prev_row; fc.prev_t_valid = ip.prev_t_valid; fc.prev_v_valid = ip.prev_v_valid;
         fc.const_value = ip.const_value; fc.prev_t = ip.prev_t; fc.prev_v = ip.prev_v; fc.prev_v_i64 = ip.prev_v_i64;
     }
+    F.inv_interval = (1.0 / (double)plan.interval) * (1.0 + 0x1.0p-40);
     BG_HIP(hipEventRecord(c->ev0, c->stream));
     BG_TRY(launch_rolling_fused(c, F, need, has_nulls));
     BG_HIP(hipEventRecord(c->ev1, c->stream));

@@ -278,6 +278,7 @@ struct FusedCol {
 struct FusedParams {
     SimpleParams s;                // FIRST: the kernel reads the output pointers through the kernel-argument segment at SimpleParams' offsets
     FusedCol cols[kMaxCols];       // by column pass (SimpleParams::values[c])
+    double inv_interval;           // (1 / interval) * (1 + 2^-40): floor(x * inv_interval) == x / interval for every x < 2^32 (rolling_fused.hip fdiv32)
 };
 int launch_rolling_fused(Ctx *c, const FusedParams &fp, int need, bool has_nulls);
 // Interpolate + validateInterpolation (extras.cpp; reference rolling/interpolation.go:30-96)

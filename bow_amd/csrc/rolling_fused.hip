@@ -20,6 +20,8 @@
 // frames, rows below s0 and interval columns with nulls never get here (the host declines them up front).
 #include <stddef.h>
 
+#include <type_traits>
+
 #include "bitmap_device.h"
 #include "interp_device.h"
 
@@ -41,6 +43,10 @@ constexpr bool kNtF = BOWGPU_FUSED_NT != 0;   // non-temporal loads of a tile's 
 #ifndef BOWGPU_FUSED_SWZ
 #define BOWGPU_FUSED_SWZ 0
 #endif
+#ifndef BOWGPU_FUSED_T32
+#define BOWGPU_FUSED_T32 1
+#endif
+constexpr bool kT32Fused = BOWGPU_FUSED_T32 != 0;   // Linear between two rows of the frame on 32-bit time differences (the q-loop); A/B: -DBOWGPU_FUSED_T32=0
 constexpr bool kSwzFused = BOWGPU_FUSED_SWZ != 0;   // the staged column padded by two slots per 32 rows (agg_device.h swz): A/B -DBOWGPU_FUSED_SWZ=1
 
 // The rows' times stay in LDS as 32-bit offsets from the first window start: a synthetic row needs the times of its two neighbour
@@ -56,10 +62,27 @@ struct FusedShared {
 };
 static_assert(sizeof(FusedShared) <= (kSwzFused ? 8192 + 320 : 8192), "LDS of the fused kernel: 8 KB (20 wavefronts per CU; padded: 8.3 KB, 18)");
 
+// (the high half as the instruction itself: __umulhi reaches the backend as a 64-bit product of two zero-extended values, and with the
+// magic number's extension hoisted into another block every division carried a v_mad_u64_u32 with a ZERO multiplicand - a quarter-rate
+// instruction per division, 16 per tile; round 6, read off the ISA)
+__device__ __forceinline__ uint32_t mulhi32(uint32_t m, uint32_t n) {
+    uint32_t t;
+    asm("v_mul_hi_u32 %0, %1, %2" : "=v"(t) : "s"(m), "v"(n));
+    return t;
+}
 __device__ __forceinline__ uint32_t mdiv32(uint32_t n, uint32_t m, uint32_t sh1, uint32_t sh2) {
-    const uint32_t t = __umulhi(m, n);
+    const uint32_t t = mulhi32(m, n);
     return (t + ((n - t) >> sh1)) >> sh2;
 }
+#ifndef BOWGPU_FUSED_FDIV
+#define BOWGPU_FUSED_FDIV 1
+#endif
+// n / interval through float64: n < 2^32 is exact as a double, inv = (1 / interval)(1 + d) with d = 2^-40 (+- 2^-52: the host's two
+// roundings), the product rounds by at most 2^-53 relative.  With q = n / interval: the computed value is q (1 + d)(1 + e) - never below q
+// (d > 2^-52), and below floor(q) + 1 because the distance of q to the next integer is at least 1 / interval while the excess is
+// q (d + e) < 2^32 / interval * 2^-39: the truncating conversion gives floor(q).  Three full-rate instructions where the magic-number
+// form takes a quarter-rate multiplication and four more (A/B: -DBOWGPU_FUSED_FDIV=0; every n x interval pair of tests/test_gpu_fused.py's sweep)
+__device__ __forceinline__ uint32_t fdiv32(uint32_t n, double inv) { return (uint32_t)((double)n * inv); }
 __device__ __forceinline__ uint32_t left32(uint32_t x, uint32_t lane0) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)lane0, (int)x, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
 }
@@ -191,24 +214,33 @@ __global__ __launch_bounds__(kWave, kMulti ? 4 : 6) void rolling_fused_kernel(co
     bool unsorted = false, sat = false;
     const uint32_t s0_lo = (uint32_t)ws0;
     const uint32_t ik = (uint32_t)p.interval;
+    const double inv_ik = fp.inv_interval;
+    auto wdiv = [&](uint32_t x) -> uint32_t { return BOWGPU_FUSED_FDIV ? fdiv32(x, inv_ik) : mdiv32(x, p.m32, p.sh1, p.sh2); };
 
     // ---- window ids (32-bit, global: the host sends frames whose rows lie within 2^32 of s0), head flags, compaction with a running
     // scalar count; every row's time goes to LDS as its offset from s0
-    uint32_t left_w = base == 0 ? 0xFFFFFFFEu : mdiv32((uint32_t)left0 - s0_lo, p.m32, p.sh1, p.sh2);
+    uint32_t left_w = base == 0 ? 0xFFFFFFFEu : wdiv((uint32_t)left0 - s0_lo);
     int64_t left_ts = left0;
     int nseg_total = 0, nseg_owned = 0;
+#ifndef BOWGPU_FUSED_INTERIOR
+#define BOWGPU_FUSED_INTERIOR 1
+#endif
+    // (an interior tile holds all its 640 rows: told to the compiler, the per-row "is there such a row" tests and the divergent regions
+    // they guard leave the usual tile's flag pass; A/B: -DBOWGPU_FUSED_INTERIOR=0)
+    auto flag_pass = [&](auto full_tag) __attribute__((always_inline)) {
+    constexpr bool kFull = decltype(full_tag)::value;
 #pragma unroll
     for (int j = 0; j < kChunksF; j++) {
         const int l = j * 128 + 2 * lane;
-        const bool pa = l < nloc, pb = l + 1 < nloc;
+        const bool pa = kFull || l < nloc, pb = kFull || l + 1 < nloc;
         const int64_t tsa = (int64_t)ta[j], tsb = (int64_t)tb[j];
         const uint32_t plo = left32((uint32_t)tb[j], (uint32_t)left_ts);
         const uint32_t phi = left32((uint32_t)(tb[j] >> 32), (uint32_t)((uint64_t)left_ts >> 32));
         const int64_t prev_ts = (int64_t)(((uint64_t)phi << 32) | plo);
         unsorted |= (pa && prev_ts > tsa) || (pb && tsa > tsb);
         const uint32_t ra = (uint32_t)tsa - s0_lo, rb = (uint32_t)tsb - s0_lo;
-        const uint32_t wa = mdiv32(ra, p.m32, p.sh1, p.sh2);
-        const uint32_t wb = mdiv32(rb, p.m32, p.sh1, p.sh2);
+        const uint32_t wa = wdiv(ra);
+        const uint32_t wb = wdiv(rb);
         const uint32_t wprev = left32(wb, left_w);
         const bool ha = pa && (wa != wprev);
         const bool hb = pb && (wb != wa);
@@ -226,6 +258,9 @@ __global__ __launch_bounds__(kWave, kMulti ? 4 : 6) void rolling_fused_kernel(co
         left_ts = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(tb[j] >> 32), 63) << 32) |
                             (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)tb[j], 63));
     }
+    };
+    if (BOWGPU_FUSED_INTERIOR && interior) flag_pass(std::true_type{});
+    else flag_pass(std::false_type{});
     if (__ballot(unsorted)) {  // the call fails with BOWGPU_ERR_TS_UNSORTED
         if (lane == 0) atomicOr(&p.status[0], 1u);
         return;
@@ -241,7 +276,7 @@ __global__ __launch_bounds__(kWave, kMulti ? 4 : 6) void rolling_fused_kernel(co
     int q_start = 0, q_end = nseg_owned;
     {
         lds_order();
-        auto wid_at = [&](int q) -> uint32_t { return mdiv32(sh.tsx[sh.seg[q]], p.m32, p.sh1, p.sh2); };
+        auto wid_at = [&](int q) -> uint32_t { return wdiv(sh.tsx[sh.seg[q]]); };
         auto handover = [&](int qf, int qlim) -> int {
             if (qf >= qlim) return qf;
             const uint32_t gf = wid_at(qf);
@@ -281,13 +316,19 @@ __global__ __launch_bounds__(kWave, kMulti ? 4 : 6) void rolling_fused_kernel(co
         bool snan = false;
         {
             const uint64_t fill = need_sum ? 0ull : kNullAsNaN;
+            if (cint) {
+                // a BRANCH (the column's type is uniform): as a select the compiler converted every row of every Float64 column too -
+                // eight float64 instructions and four selects per chunk, 60 vector instructions per tile for nothing (round 6, the ISA)
+                asm volatile("");
+#pragma unroll
+                for (int j = 0; j < kChunksF; j++) {
+                    va[j] = (uint64_t)__double_as_longlong((double)(int64_t)va[j]);
+                    vb[j] = (uint64_t)__double_as_longlong((double)(int64_t)vb[j]);
+                }
+            }
 #pragma unroll
             for (int j = 0; j < kChunksF; j++) {
                 uint64_t xa = va[j], xb = vb[j];
-                if (cint) {
-                    xa = (uint64_t)__double_as_longlong((double)(int64_t)xa);
-                    xb = (uint64_t)__double_as_longlong((double)(int64_t)xb);
-                }
                 if (kNulls) {
                     const uint32_t two = sh.vbits[j * 4 + (lane >> 4)] >> ((2 * lane) & 31);
                     if (!(two & 1u)) xa = fill;
@@ -341,18 +382,22 @@ __global__ __launch_bounds__(kWave, kMulti ? 4 : 6) void rolling_fused_kernel(co
             }
             // the points themselves: time and (Float64) value out of the staged tile when the row lies in it; an Int64 column hands its own
             // bits on (linear.go reads float64(v), StepPrevious copies the Int64: synth_value_pt converts)
+            // (q.t: the row's time as its 32-bit offset from the first window start - every row of the frame lies within 2^32 of it, the
+            // host's precondition; abs_points() below makes them the timestamps synth_value_pt reads)
             auto point = [&](int64_t row, NbPoint &q) {
                 if (row < 0) return;
                 q.has = 1;
                 const int64_t loc = row - base;
                 const bool in_tile = loc >= 0 && loc < nloc;
-                q.t = in_tile ? ws0 + (int64_t)(uint64_t)sh.tsx[in_tile ? (int)loc : 0] : p.ts[row];
+                q.t = (int64_t)(uint64_t)(in_tile ? sh.tsx[in_tile ? (int)loc : 0] : (uint32_t)((uint64_t)p.ts[row] - (uint64_t)ws0));
                 if (!cint && in_tile) q.bits = sh.val[swz<kSwzF>((int)loc)];
                 else q.bits = src[row];
             };
             point(prow, pp);
             point(nrow, np);
         };
+
+        auto abs_points = [&](NbPoint &pp, NbPoint &np) { pp.t += ws0; np.t += ws0; };
 
         // a nullable column whose outputs want sums AND extrema is walked twice in tiles of few long windows (rolling_simple.hip): phase 1
         // with +0.0 in the null rows, then the null rows are overwritten with NaN and phase 2 walks the extrema; in tiles of many short
@@ -376,13 +421,13 @@ __global__ __launch_bounds__(kWave, kMulti ? 4 : 6) void rolling_fused_kernel(co
     for (int q = q_start + lane; q < q_end; q += kWave) {
         const int r0 = (int)sh.seg[q];
         const uint32_t t0x = sh.tsx[r0];
-        const uint32_t wid = mdiv32(t0x, p.m32, p.sh1, p.sh2);
+        const uint32_t wid = wdiv(t0x);
         const bool exact = t0x == wid * ik;     // the window's first row sits on its start: no synthetic row (interpolation.go:108-116)
         int r1;
         uint32_t next_wid;
         if (q + 1 < nseg_total) {
             r1 = (int)sh.seg[q + 1];
-            next_wid = mdiv32(sh.tsx[r1], p.m32, p.sh1, p.sh2);
+            next_wid = wdiv(sh.tsx[r1]);
         } else if (reaches_end) {
             r1 = nloc;
             next_wid = W32;
@@ -398,9 +443,24 @@ __global__ __launch_bounds__(kWave, kMulti ? 4 : 6) void rolling_fused_kernel(co
         if (!exact) {
             NbPoint pp, np;
             neighbours(r0, pp, np);
-            synth_value_pt(fc, win_start, pp, np, &sbits, &sv);
+            if (kT32Fused && fc.kind == BOWGPU_INTERP_LINEAR && pp.has && np.has) {
+                // linear.go:34 between two rows of the frame: float64(s) - float64(t0) and float64(t2) - float64(t0) are differences of
+                // exact values (every |time| < 2^53, the host's precondition) that are integers below 2^32 themselves (t0 < s <= t2: the
+                // point before the window's first row lies in an earlier window, the point from it on in this one or later), so each
+                // equals its 32-bit integer difference, converted: two subtractions and two conversions instead of three 64-bit
+                // conversions with their range checks (synth_value_pt; bit-identical - tests/test_gpu_fused.py, the fuzz)
+                const double a = (double)(uint32_t)(wid * ik - (uint32_t)pp.t), b = (double)(uint32_t)((uint32_t)np.t - (uint32_t)pp.t);
+                const double v0 = bits_to_f64(pp.bits, fc.type), v2 = bits_to_f64(np.bits, fc.type);
+                const double r = ((v2 - v0) * (a / b)) + v0;
+                sbits = fc.type == BOWGPU_INT64 ? (uint64_t)go_f64_to_i64(r) : (uint64_t)__double_as_longlong(r);
+                sv = 1;
+            } else {
+                abs_points(pp, np);
+                synth_value_pt(fc, win_start, pp, np, &sbits, &sv);
+            }
         }
-        const double xs = cint ? (double)(int64_t)sbits : __longlong_as_double((long long)sbits);   // bowgetters.go:224-229
+        double xs = __longlong_as_double((long long)sbits);
+        if (cint) { asm volatile(""); xs = (double)(int64_t)sbits; }   // bowgetters.go:224-229 (a branch: see the staging loop)
         // ---- valid rows of the window: how many, the first, the last; then the walk behind the synthetic row
         int count = r1 - r0, fv = r0, lv = r1 - 1;
         if (kNulls) window_valid_rows(sh.vbits, r0, r1, count, fv, lv);
@@ -425,18 +485,14 @@ __global__ __launch_bounds__(kWave, kMulti ? 4 : 6) void rolling_fused_kernel(co
         const int nrows = (r1 - r0) + (exact ? 0 : 1);
         const int64_t slot = (int64_t)wid;
         const uint32_t gap = next_wid - wid - 1;
-        // the empty windows right after this one hold ONE row each, their synthetic row: every one of them has FirstIndex r1 (the next
-        // window's first row: rolling.go:224-231 leaves currRowIndex there), so one pair of neighbour points serves the whole run
-        NbPoint gp, gn;
-        if (gap) neighbours(r1, gp, gn);
+        typedef const uint64_t __attribute__((address_space(4))) *karg_u64;
+        typedef uint64_t __attribute__((address_space(1))) *global_u64;
 #pragma unroll 1
         for (int a_ = 0; a_ < p.naggs; a_++) {
             const int a = __builtin_amdgcn_readfirstlane(a_);
             if (kMulti && p.col[a] != c) continue;
             const int k = p.kind[a];
             if (phase != 0 && (phase == 2) != (k == BOWGPU_AGG_MIN || k == BOWGPU_AGG_MAX)) continue;   // two walks: each output once
-            typedef const uint64_t __attribute__((address_space(4))) *karg_u64;
-            typedef uint64_t __attribute__((address_space(1))) *global_u64;
             const global_u64 out_a = (global_u64)((karg_u64)__builtin_amdgcn_kernarg_segment_ptr())[offsetof(SimpleParams, out_values) / 8 + a];
             uint64_t bits;
             bool nil = false;
@@ -459,6 +515,26 @@ __global__ __launch_bounds__(kWave, kMulti ? 4 : 6) void rolling_fused_kernel(co
                 atomicAnd(&p.out_valid[a][slot >> 5], ~(1u << (slot & 31)));
             }
             __builtin_nontemporal_store(bits, &out_a[slot]);
+        }
+        // the empty windows right after this one hold ONE row each, their synthetic row: every one of them has FirstIndex r1 (the next
+        // window's first row: rolling.go:224-231 leaves currRowIndex there), so one pair of neighbour points serves the whole run.
+        // Its own loop over the outputs, behind a branch: inside the loop above, what the run needs that does not depend on the output
+        // (the neighbour points' times and values as float64, their differences) was computed in front of that loop for EVERY window,
+        // gap or not - 45 vector instructions per pass over the heads (round 6, the ISA); frames without empty windows now skip all of it.
+        if (gap == 0) continue;
+        asm volatile("");
+        NbPoint gp, gn;
+        neighbours(r1, gp, gn);
+        abs_points(gp, gn);
+#pragma unroll 1
+        for (int a_ = 0; a_ < p.naggs; a_++) {
+            const int a = __builtin_amdgcn_readfirstlane(a_);
+            if (kMulti && p.col[a] != c) continue;
+            const int k = p.kind[a];
+            if (phase != 0 && (phase == 2) != (k == BOWGPU_AGG_MIN || k == BOWGPU_AGG_MAX)) continue;
+            const global_u64 out_a = (global_u64)((karg_u64)__builtin_amdgcn_kernarg_segment_ptr())[offsetof(SimpleParams, out_values) / 8 + a];
+            const bool int_result = k == BOWGPU_AGG_WINDOW_START || k == BOWGPU_AGG_COUNT || (cint && (k == BOWGPU_AGG_FIRST || k == BOWGPU_AGG_LAST));
+            const int nf = p.nfac[a];
             for (uint32_t g = 1; g <= gap; g++) {
                 if (wid + g >= W32) break;
                 const int64_t gw = slot + g;

@@ -104,19 +104,29 @@ COUNTER_FILES = {
 
 def test_the_rounds_counter_files_belong_to_the_kernels_this_tree_builds():
     """the sha rule of the benched instantiation extended to the round's other counter files.  They were collected from
-    ONE snapshot (profiles/r06_commit.txt); a device source one of them speaks about changed since then means it describes other code -
-    the CPU suite is red until scratch/profile_all.sh has been re-run on a GPU box and its files committed.  (Without a git history - the
+    ONE snapshot (profiles/r06_commit.txt, first line; a file collected again later has its own line there); a device source one of them
+    speaks about changed since ITS commit means it describes other code - the CPU suite is red until it has been collected again on a GPU
+    box and committed.  (Without a git history - the
     GPU box gets a snapshot - there is nothing to compare with.)"""
     for f in COUNTER_FILES:
         assert os.path.exists(os.path.join(ROOT, "profiles", f)), f
     if not os.path.isdir(os.path.join(ROOT, ".git")):
         return
-    commit = open(os.path.join(ROOT, "profiles", "%s_commit.txt" % ROUND)).read().split()[0]
-    rc = subprocess.run(["git", "cat-file", "-e", commit + "^{commit}"], cwd=ROOT)
-    assert rc.returncode == 0, "profiles/%s_commit.txt names %s, which this history does not hold" % (ROUND, commit)
-    changed = subprocess.check_output(["git", "diff", "--name-only", commit, "HEAD", "--", "bow_amd/csrc"], cwd=ROOT).decode().split()
-    changed += subprocess.check_output(["git", "diff", "--name-only", "HEAD", "--", "bow_amd/csrc"], cwd=ROOT).decode().split()   # (working-tree edits count too)
-    changed = {os.path.basename(f) for f in changed}
-    stale = {f: sorted(changed & set(srcs)) for f, srcs in COUNTER_FILES.items() if changed & set(srcs)}
-    assert not stale, ("device sources changed since the round's counter files were collected at %s: %s - re-run scratch/profile_all.sh %s on a "
-                       "GPU box and commit its files" % (commit[:10], stale, ROUND))
+    # profiles/r06_commit.txt: the snapshot the round's collection ran on; further lines "<file> <commit>" name the files collected again later
+    lines = [l.split() for l in open(os.path.join(ROOT, "profiles", "%s_commit.txt" % ROUND)).read().splitlines() if l.strip() and not l.startswith("#")]
+    default, later = lines[0][0], {l[0]: l[1] for l in lines[1:]}
+    assert set(later) <= set(COUNTER_FILES), sorted(set(later) - set(COUNTER_FILES))
+    dirty = subprocess.check_output(["git", "diff", "--name-only", "HEAD", "--", "bow_amd/csrc"], cwd=ROOT).decode().split()   # (working-tree edits count too)
+    changed_since = {}
+    for commit in {default, *later.values()}:
+        rc = subprocess.run(["git", "cat-file", "-e", commit + "^{commit}"], cwd=ROOT)
+        assert rc.returncode == 0, "profiles/%s_commit.txt names %s, which this history does not hold" % (ROUND, commit)
+        names = subprocess.check_output(["git", "diff", "--name-only", commit, "HEAD", "--", "bow_amd/csrc"], cwd=ROOT).decode().split()
+        changed_since[commit] = {os.path.basename(f) for f in names + dirty}
+    stale = {}
+    for f, srcs in COUNTER_FILES.items():
+        hit = changed_since[later.get(f, default)] & set(srcs)
+        if hit:
+            stale[f] = (later.get(f, default)[:10], sorted(hit))
+    assert not stale, ("device sources changed since these counter files were collected (file: (commit, sources)): %s - collect them again on a GPU box "
+                       "(scratch/profile_all.sh %s, scratch/refresh_fused.sh) and name the commit in profiles/%s_commit.txt" % (stale, ROUND, ROUND))
