@@ -194,7 +194,12 @@ static int interp_prepare(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t
         Plan &pl = job->plan;
         pl.s0 = *global_s0;
         if (cols[ts_col].length > 0) {
-            if (pl.first_ts < pl.s0) return fail(BOWGPU_ERR_UNSUPPORTED, "sharded interpolate: rows below the first window start are outside the sharded path");
+            // rows below the first window start (Go's truncating division on a negative first timestamp: rolling.go:96-99) ride in window 0
+            // or belong to no window at all - which of the two depends on the first row AT OR ABOVE s0 (interp_quirk_kernel).  They are the
+            // frame's first rows: the frame's first shard serves them as the unsharded call does when that row is its own; the corner that
+            // is left - a first shard of nothing but such rows, fewer than one interval's worth of time - is declined.
+            if (pl.first_ts < pl.s0 && ((edge && edge->has_left) || pl.last_ts < pl.s0))
+                return fail(BOWGPU_ERR_UNSUPPORTED, "sharded interpolate: a shard of nothing but rows below the first window start is outside the sharded path");
             const int64_t wl = (int64_t)(((uint64_t)pl.last_ts - (uint64_t)pl.s0) / (uint64_t)interval);
             job->has_left = edge && edge->has_left ? 1 : 0;
             if (job->has_left) {
@@ -203,7 +208,6 @@ static int interp_prepare(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t
                 job->wbase = (int64_t)(((uint64_t)edge->left_last_ts - (uint64_t)pl.s0) / (uint64_t)interval) + 1;
             }
             pl.W = wl + 1 - job->wbase;  // windows this shard accounts for
-            if (pl.s0 <= -1) return fail(BOWGPU_ERR_UNSUPPORTED, "sharded interpolate: negative window starts are outside the sharded path");
         }
     }
     const int64_t n = cols[ts_col].length, W = job->plan.W;
@@ -217,8 +221,11 @@ static int interp_prepare(Ctx *c, const bowgpu_col *cols, int32_t ncols, int32_t
     const Plan &pl = job->plan;
     job->kq = -1;
     if (pl.s0 <= -1 && (uint64_t)(-1 - pl.s0) % (uint64_t)pl.interval == 0) {
+        // (a shard accounts for windows wbase .. wbase + W - 1 of the frame; the one that starts at -1 concerns the shard that accounts for it:
+        // its rows, if it has any, can only be that shard's own - the left neighbours end in an earlier window, and when this shard ends
+        // in a later one nothing of the window lies to its right)
         const int64_t k = (int64_t)((uint64_t)(-1 - pl.s0) / (uint64_t)pl.interval);
-        if (k < W) job->kq = k;
+        if (k >= job->wbase && k - job->wbase < W) job->kq = k;
     }
     const int64_t ntiles = 2 * interp_tiles(n);   // exact heads are counted per 256 rows: two entries per tile of the count kernel
     const int64_t nsuper = interp_supers(n);

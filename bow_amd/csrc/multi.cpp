@@ -443,9 +443,10 @@ static int fan_call(const bowgpu_col *cols, int32_t ncols, int32_t ts_col, const
     for (int i = 0; i < naggs; i++) if (aggs[i].kind == BOWGPU_AGG_MODE) return 0;
     if (cols[ts_col].validity && cols[ts_col].null_count != 0) return 0;   // (nulls in the interval column: the one-device path serves them)
     if (interps) {
-        // the sharded Interpolate's own limits (include/bowgpu.h): at most 8 columns (bowgpu_interp_edge), frames at or above 0 whose
-        // first row is not below the first window start
-        if (ncols > 8 || ninterps != ncols || plan.s0 < 0 || plan.first_ts < plan.s0) return 0;
+        // the sharded Interpolate's own limit (include/bowgpu.h): at most 8 columns (bowgpu_interp_edge).  Rows below the first window start
+        // (a negative first timestamp under Go's truncating division) make the interpolated frame start with its synthetic row at s0 and go
+        // on BELOW it: what Aggregate then does with that frame is the one-device path's business
+        if (ncols > 8 || ninterps != ncols || plan.first_ts < plan.s0) return 0;
         for (int i = 0; i < ncols; i++) if (interps[i].col != i) return 0;
     }
     // device-resident buffers belong to ONE device: only a list that names the calling thread's device throughout can share them

@@ -379,8 +379,10 @@ int bowgpu_rolling_interpolate_fill(const bowgpu_col *cols, int32_t ncols, int32
  * valid point lies on another shard gets it from the caller: the point to the LEFT through bowgpu_interp.prev_* (the reference's
  * own Options.PrevRow mechanism), the point to the RIGHT through next_*.  Shards concatenated in rank order = the unsharded
  * result, for exclusive and for inclusive windows (opts->inclusive: a row on its window's start is preceded by the copy of itself
- * that closes the window before - the copy travels with its row).  Frames with rows below the first window start or negative
- * window starts are outside the sharded path. */
+ * that closes the window before - the copy travels with its row).  Negative timestamps: negative window starts are served (the
+ * window that starts at -1, the reference's "no first value" sentinel, by the shard that accounts for it); rows below the first
+ * window start (rolling.go:96-99) by the frame's first shard when the first row at or above s0 is its own - a first shard of nothing
+ * but such rows is declined (BOWGPU_ERR_UNSUPPORTED). */
 typedef struct bowgpu_interp_edge {
     int32_t has_left;         /* a shard to the left holds rows */
     int32_t _pad;

@@ -327,8 +327,9 @@ def test_interpolate_then_aggregate_as_one_call_over_ranks(kind, residency):
 
 
 def test_pipeline_shapes_the_fan_out_leaves_to_one_device():
-    """rows below the first window start / negative window starts (outside the sharded Interpolate), more than 8 columns: the same call,
-    served by the calling thread's device"""
+    """rows below the first window start (the interpolated frame then starts with its synthetic row at s0 and goes on below it), more than 8
+    columns: the same call, served by the calling thread's device.  Negative window starts - the window that starts at -1 among them - are
+    served by the ranks since round 6."""
     n = 40_000
     rng = np.random.default_rng(4)
     ts = (np.cumsum(rng.integers(1, 9, n)) - 1000).astype(np.int64)       # starts below zero
@@ -339,7 +340,33 @@ def test_pipeline_shapes_the_fan_out_leaves_to_one_device():
     ocols = [orc.Column(ts, None, orc.INT64), orc.Column(v, bm, orc.FLOAT64)]
     ip = [{"kind": "WindowStart", "col": 0}, {"kind": "Linear", "col": 1}]
     aggs = [("WindowStart", 0), ("ArithmeticMean", 1), ("Count", 1)]
-    assert check_pipeline(ccols, ocols, 50, ip, aggs, 0, [0, 0, 0], 500, "negative") == 1
+    assert check_pipeline(ccols, ocols, 50, ip, aggs, 0, [0, 0, 0], 500, "negative starts") == 3
+    tsm = (ts - ts[0] - 951).astype(np.int64)                                # first row ON the first window start -951 = -1 - 19 * 50 (offset 49)
+    c1 = [capi.Column(tsm, None, capi.INT64), ccols[1]]
+    o1 = [orc.Column(tsm, None, orc.INT64), ocols[1]]
+    assert orc.plan_windows(o1[0], 50, 49)[0] == tsm[0] == -951
+    assert check_pipeline(c1, o1, 50, ip, aggs, 49, [0, 0, 0, 0], 500, "a window that starts at -1") == 4
+    keep = (tsm < -1) | (tsm >= 49)                                          # ... and the same with that window empty: no synthetic row for it
+    c2 = [capi.Column(tsm[keep].copy(), None, capi.INT64), capi.Column(v[keep].copy(), np.packbits(valid[keep], bitorder="little"), capi.FLOAT64, 0, int(keep.sum()), -1)]
+    o2 = [orc.Column(tsm[keep].copy(), None, orc.INT64), orc.Column(v[keep].copy(), np.packbits(valid[keep], bitorder="little"), orc.FLOAT64)]
+    assert check_pipeline(c2, o2, 50, ip, aggs, 49, [0, 0, 0], 500, "the window that starts at -1, empty") == 3
+    ts3 = np.concatenate([np.array([-15, -12], dtype=np.int64), ts + 1100])  # Go's truncating division: s0 = -11 above the first two rows
+    v3, valid3 = np.concatenate([[1.5, 2.5], v]), np.concatenate([[True, True], valid])
+    bm3 = np.packbits(valid3, bitorder="little")
+    c3 = [capi.Column(ts3, None, capi.INT64), capi.Column(v3, bm3, capi.FLOAT64, 0, n + 2, -1)]
+    o3 = [orc.Column(ts3, None, orc.INT64), orc.Column(v3, bm3, orc.FLOAT64)]
+    assert orc.plan_windows(o3[0], 10, 9)[0] > ts3[0]
+    # (the pipeline is declined - one device interpolates - and the Aggregate over the interpolated frame, an ordinary frame in that device's
+    # memory, is what the three ranks of THIS list serve: a list of one device throughout shares device-resident buffers)
+    assert check_pipeline(c3, o3, 10, ip, aggs, 9, [0, 0, 0], 500, "rows below s0 that belong to no window") == 3
+    # ... and rows below s0 that ride in window 0 (a row at or above s0 inside its first interval): the interpolated frame starts with its
+    # synthetic row at s0 and goes on BELOW it - Aggregate refuses it as not ascending, with the device list in force exactly as without
+    assert orc.plan_windows(ocols[0], 50, 49)[0] > ts[0]
+    for ids in ([0], [0, 0, 0]):
+        with capi.devices(ids, min_rows=500):
+            with pytest.raises(capi.BowGpuError) as e:
+                capi.rolling_interpolate_aggregate(ccols, 0, 50, ip, aggs, offset=49)
+            assert e.value.code == -14 and capi.last_call_ranks() == 1
     # nine columns
     ts2 = (ts + 5000).astype(np.int64)
     cc = [capi.Column(ts2, None, capi.INT64)] + [capi.Column(v * (i + 1), bm, capi.FLOAT64, 0, n, -1) for i in range(8)]

@@ -239,6 +239,63 @@ def test_sharded_interpolate_equals_whole(kind):
                 assert np.array_equal(gv[gm], wv[wm]), (mode, inclusive, c, np.flatnonzero(gv[gm] != wv[wm])[:10])
 
 
+def test_sharded_interpolate_negative_timestamps():
+    """the sharded Interpolate on frames that start below 0 - negative window starts, the window that
+    starts at -1 (the reference's "no first value" sentinel, interpolation.go:99-119: it never gets a synthetic row) with and without a row
+    of its own and on either side of a shard boundary, and rows below the first window start (Go's truncating division, rolling.go:96-99)
+    on the frame's first shard.  Shards concatenated = the oracle's unsharded frame, bit for bit, through both kernels."""
+    rng = np.random.default_rng(23)
+    ip = [{"kind": "WindowStart", "col": 0}, {"kind": "Linear", "col": 1}, {"kind": "StepPrevious", "col": 2}]
+    cases = []
+    for interval, offset, t0, n, sentinel in [(100, 0, -5_017, 4_000, None), (100, 99, -5_017, 4_000, "empty"), (100, 99, -5_017, 4_000, "row"),
+                                              (10, 9, -2_003, 3_000, "empty"), (7, 0, -777, 2_500, None), (50, 49, -1_051, 2_000, "row")]:
+        ts = t0 + np.cumsum(rng.integers(1, 9, n)).astype(np.int64)
+        if sentinel == "empty":
+            ts = ts[(ts < -1) | (ts >= -1 + interval)]        # the window [-1, -1 + interval) has no row
+        elif sentinel == "row":
+            assert ((ts >= -1) & (ts < -1 + interval)).any()
+        cases.append((ts, interval, offset))
+    # rows below s0 that ride in window 0 (a row at or above s0 inside its first interval) and rows that belong to no window (none there)
+    cases.append((np.concatenate([np.array([-15, -12, -11, -9], dtype=np.int64), np.cumsum(rng.integers(1, 9, 1500)).astype(np.int64)]), 10, 9))
+    cases.append((np.concatenate([np.array([-15, -12], dtype=np.int64), 100 + np.cumsum(rng.integers(1, 9, 1500)).astype(np.int64)]), 10, 9))
+    served = 0
+    for ts, interval, offset in cases:
+        n = len(ts)
+        v1 = np.round(rng.standard_normal(n) * 100, 2)
+        v2 = rng.integers(-1000, 1000, n).astype(np.int64)
+        m1, m2 = rng.random(n) >= 0.3, rng.random(n) >= 0.3
+        b1, b2 = np.packbits(m1, bitorder="little"), np.packbits(m2, bitorder="little")
+        want = orc.interpolate([orc.Column(ts, None, orc.INT64), orc.Column(v1, b1, orc.FLOAT64), orc.Column(v2, b2, orc.INT64)], 0, interval, ip, offset=offset)
+        s0 = sharded.first_window_start(int(ts[0]), interval, offset)
+        zero = int(np.searchsorted(ts, -1))                    # the first row at or above -1: a boundary right there, and one inside the window
+        for bounds in ([0, n // 3, 2 * n // 3, n], [0, max(zero, 1), min(zero + 2, n - 1), n], [0, 5, n], [0, max(zero - 3, 1), n]):
+            bounds = sorted(set(bounds))
+            shards = []
+            for r in range(len(bounds) - 1):
+                a, b = bounds[r], bounds[r + 1]
+                shards.append([capi.Column(ts[a:b].copy(), None, capi.INT64).to_device(),
+                               capi.Column(v1[a:b].copy(), np.packbits(m1[a:b], bitorder="little"), capi.FLOAT64, 0, b - a, -1).to_device(),
+                               capi.Column(v2[a:b].copy(), np.packbits(m2[a:b], bitorder="little"), capi.INT64, 0, b - a, -1).to_device()])
+            points = [capi.shard_interp_points(cols, 0) for cols in shards]
+            try:
+                outs = both_interp_kernels(lambda: [capi.shard_interpolate(cols, 0, interval, ip, s0, r, points, offset=offset) for r, cols in enumerate(shards)])
+            except capi.BowGpuError as e:
+                # the one corner that stays declined: a first shard of nothing but rows below the first window start
+                assert e.code == -9 and ts[0] < s0 and ts[bounds[1] - 1] < s0, (list(ts[:6]), interval, offset, bounds, str(e))
+                continue
+            served += 1
+            for c in range(3):
+                gv = np.concatenate([o[c].host_arrays()[0].view(np.uint64) for o in outs])
+                gm = np.concatenate([o[c].valid_mask() for o in outs])
+                wm = want[c].valid_mask()
+                label = (list(ts[:4]), interval, offset, bounds, c)
+                assert len(gv) == want[c].length, label + (len(gv), want[c].length)
+                assert np.array_equal(gm, wm), label + (np.flatnonzero(gm != wm)[:10],)
+                wv = want[c].values[:want[c].length].view(np.uint64)
+                assert np.array_equal(gv[gm], wv[wm]), label + (np.flatnonzero(gv[gm] != wv[wm])[:10],)
+    assert served >= 4 * len(cases) - 4, served
+
+
 @pytest.mark.parametrize("tw", [False, True])
 def test_sharded_window_0_of_rows_below_s0_only(tw):
     """negative timestamps: Go's truncating division puts s0 above the first rows (rolling.go:96-99), window 0 spans them and is an
