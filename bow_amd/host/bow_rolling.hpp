@@ -602,6 +602,14 @@ inline std::pair<RollingPtr, Error> IntervalRolling(BowPtr b, const std::string 
     return newIntervalRolling(b, colIndex, interval, options);
 }
 
+// SetGPUDevices: the devices ONE Aggregate / Interpolate(...).Aggregate(...) call is spread over (process-wide; none or one id: one device) -
+// the C++ twin of shim/go/rolling/gpu_cgo.go's SetGPUDevices (bowgpu_set_devices; a Go application gets the node's devices from the shim's
+// init(), a C++ one calls this once).  Nothing else changes: r->Aggregate(...) is the same call with the same result.
+inline Error SetGPUDevices(const std::vector<int> &ids) {
+    if (bowgpu_set_devices(ids.empty() ? nullptr : ids.data(), (int)ids.size())) return Error(bowgpu_last_error());
+    return Error();
+}
+
 // ----------------------------------------------------------------------------- Aggregate
 inline RollingPtr Rolling::Aggregate(const std::vector<ColAggregation> &aggrs) const {
     if (lazy) {   // r.Interpolate(...).Aggregate(...): both steps in one call to the library when it takes them

@@ -446,6 +446,39 @@ static void TestBenchShape() {
     CHECK(ok);
 }
 
+// rl::SetGPUDevices: the bench-shaped call spread over this box's device listed three times - the same Bow, bit for bit - and the list off again
+static void TestSetGPUDevices() {
+    TEST("SetGPUDevices");
+    const int n = 300000;
+    std::vector<int64_t> t(n);
+    std::vector<Value> v(n);
+    uint64_t x = 99;
+    int64_t ts = 0;
+    for (int i = 0; i < n; i++) {
+        x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+        ts += 1 + (int64_t)(x % 7);
+        t[i] = ts;
+        if ((x >> 20) % 4 == 0) v[i] = N; else v[i] = F((double)((x >> 8) % 100000) / 7.0);
+    }
+    std::vector<Value> tc(n);
+    for (int i = 0; i < n; i++) tc[i] = I(t[i]);
+    auto b = tv(tc, v);
+    std::vector<rl::ColAggregation> aggs = {ag::WindowStart(timeCol), ag::ArithmeticMean(valueCol).RenameOutput("mean"), ag::Min(valueCol).RenameOutput("min"),
+                                            ag::Count(valueCol).RenameOutput("n"), ag::Last(valueCol).RenameOutput("last")};
+    auto [r, e0] = rl::IntervalRolling(b, timeCol, 50, {3, false, nullptr}); CHECK(!e0);
+    auto [one, e1] = r->Aggregate(aggs)->Bow(); CHECK(!e1);
+    int ranks = 0; bowgpu_last_call_ranks(&ranks); CHECK(ranks == 1 || getenv("BOWGPU_DEVICES") != nullptr);
+    std::vector<int> before(64); int nb = 0; bowgpu_get_devices(before.data(), 64, &nb); before.resize(nb);
+    CHECK(!rl::SetGPUDevices({0, 0, 0}));
+    bowgpu_set_fanout_min_rows(50000);
+    auto [many, e2] = r->Aggregate(aggs)->Bow(); CHECK(!e2);
+    bowgpu_last_call_ranks(&ranks); CHECK(ranks == 3);
+    expectEqual(one, many);
+    CHECK((bool)rl::SetGPUDevices({0, 99}));   // no such device: the list stays as it was
+    CHECK(!rl::SetGPUDevices(before));
+    bowgpu_set_fanout_min_rows(getenv("BOWGPU_FANOUT_MIN_ROWS") ? atoll(getenv("BOWGPU_FANOUT_MIN_ROWS")) : (1ll << 20));
+}
+
 int main(int argc, char **argv) {
     int ndev = 0;
     if (bowgpu_device_count(&ndev) != 0 || ndev == 0) {
@@ -464,6 +497,7 @@ int main(int argc, char **argv) {
     TestFillLinear();
     TestParquet(argc > 1 ? argv[1] : "tests/golden");
     TestBenchShape();
+    TestSetGPUDevices();
     printf("%d checks, %d failures\n", g_checks, g_fail);
     int64_t listed = 0, served = 0;
     bowgpu_fanout_counts(&listed, &served);
