@@ -79,7 +79,6 @@ void ctx_release(Ctx *c) {
     if (c->null_ts_cache && c->null_ts_cache_free) { void *q = c->null_ts_cache; c->null_ts_cache = nullptr; c->null_ts_cache_free(q); }
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->d_params) (void)hipFree(c->d_params);
-    if (c->d_zeroed) (void)hipFree(c->d_zeroed);
     for (int i = 0; i < Ctx::kPoolSlots; i++) if (c->pool[i]) (void)hipFree(c->pool[i]);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->h_bounce) { (void)hipHostFree(c->h_bounce); (void)hipEventDestroy(c->bounce_ev[0]); (void)hipEventDestroy(c->bounce_ev[1]); }
@@ -182,15 +181,6 @@ int ctx_pinned(Ctx *c, size_t bytes, void **hptr) {
 int ctx_params(Ctx *c, void **dptr) {
     if (!c->d_params) BG_HIP(hipMalloc(&c->d_params, 4096));
     *dptr = c->d_params;
-    return 0;
-}
-
-int ctx_zeroed(Ctx *c, uint32_t **dptr) {
-    if (!c->d_zeroed) {
-        BG_HIP(hipMalloc(&c->d_zeroed, 256));
-        BG_HIP(hipMemsetAsync(c->d_zeroed, 0, 256, c->stream));
-    }
-    *dptr = reinterpret_cast<uint32_t *>(c->d_zeroed);
     return 0;
 }
 

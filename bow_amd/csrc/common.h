@@ -76,7 +76,6 @@ struct Ctx {
         int kq_empty = 0, inclusive = 0, e0 = 0;
     } interp_cache;
     void *d_params = nullptr;      // 4 KB device block holding the kernels' descriptor struct
-    void *d_zeroed = nullptr;      // 256 zeroed bytes: flags / tickets of kernels whose last workgroup reports to the host and resets them
     // what an Interpolate _count over an interval column WITH NULLS leaves for its _fill (extras.cpp NullTsState: device temporaries);
     // freed through null_ts_cache_free by the fill, bowgpu_trim, bowgpu_set_device and at thread exit
     void *null_ts_cache = nullptr;
@@ -87,7 +86,6 @@ int ctx_get(Ctx **out);                       // initialises HIP on first use; f
 int ctx_scratch(Ctx *c, size_t bytes, void **dptr);
 int ctx_pinned(Ctx *c, size_t bytes, void **hptr);
 int ctx_params(Ctx *c, void **dptr);
-int ctx_zeroed(Ctx *c, uint32_t **dptr);       // 256 bytes of device memory, zero when handed out for the first time: every kernel that uses words of it leaves them zero
 int ctx_pool(Ctx *c, int slot, size_t bytes, void **dptr);
 
 // ---------------------------------------------------------------- temp device buffers
